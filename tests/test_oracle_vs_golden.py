@@ -1,0 +1,123 @@
+"""Pins oracle/vdjx_oracle.c (the CPU restatement) against dumps of the compiled reference.
+
+The reference ships no tests or golden vectors for this path, so the vectors in
+tests/golden/ were produced by running the reference's own functions (oracle/_ref/vdjer_ref, built
+from /root/reference by oracle/Makefile) on seeded inputs; tests/golden/make_golden.py is the script.
+Everything here is bit-exact (integer / byte / index work).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import golden_util as G
+
+
+def test_murmur_and_seq_to_int_known_answers():
+    # known answers quoted in SURVEY §8c plus the generated table
+    assert oracle.murmur64a(b"ACGTACGTACGTACGTACGTACGTACGTACGTACG") == 5958308921596863335
+    assert oracle.seq_to_int("ACTTCTGGGGCCAGGG") == 631241279
+    for s, h, code in G.rows("hash.tsv.gz"):
+        assert oracle.murmur64a(s.encode()) == int(h), s
+        if len(s) >= 16:
+            assert oracle.seq_to_int(s) == int(code)
+
+
+@pytest.mark.parametrize("case,tag", [("noisy", "noisy_k35"), ("noisy", "noisy_k25"), ("noisy", "noisy_mq230"),
+                                      ("noisy", "noisy_mq20"), ("pre", "pre_k35")])
+def test_kmer_table_prune_graph(case, tag):
+    c = G.Case(case)
+    info = G.manifest()[case][tag]
+    p = G.flags_to_params(info["flags"])
+    t = oracle.KmerTable(c.pool, p["k"])
+    assert t.size() == info["pre"]
+    if tag == "pre_k35":
+        # full pre-prune table: count, multi flag, first read and the (bug-compatible) quality sums
+        first, count, multi, qs = t.export(with_qs=True)
+        mine = {}
+        for i in range(len(first)):
+            km = oracle.inst_kmer(c.pool, int(first[i]), p["k"])
+            rd = oracle.inst_kmer(c.pool, int(first[i]) & ~63, c.pool.rl)
+            mine[km] = (int(count[i]), int(multi[i]), rd, bytes(qs[i, :p["k"]]).hex())
+        ref = {r[0]: (int(r[1]), int(r[2]), r[3], r[4]) for r in G.rows("pre_k35.pre.tsv.gz")}
+        assert mine == ref
+    assert t.prune(p["mf"], p["mq"]) == info["survivors"]
+    first, count, _, _ = t.export()
+    mine = {oracle.inst_kmer(c.pool, int(f), p["k"]): int(n) for f, n in zip(first, count)}
+    ref = {r[0]: int(r[1]) for r in G.rows(f"{tag}.survivors.tsv.gz")}
+    assert mine == ref
+
+    g = oracle.Graph(t, c.v_codes, c.j_codes)
+    nodes = G.rows(f"{tag}.nodes.tsv.gz")
+    assert g.n == len(nodes) == info["nodes"]
+    for i, r in enumerate(nodes):
+        assert int(r[0]) == i + 1
+        assert oracle.inst_kmer(c.pool, int(g.first[i]), p["k"]) == r[1]
+        assert int(g.freq[i]) == int(r[2])
+        assert (int(g.has_v[i]), int(g.has_j[i])) == (int(r[3]), int(r[4]))
+        to = [int(x) for x in r[5].split(",") if x]
+        fr = [int(x) for x in r[6].split(",") if x]
+        assert list(g.to_ids[i, :g.to_deg[i]]) == to
+        assert list(g.from_ids[i, :g.from_deg[i]]) == fr
+
+
+@pytest.mark.parametrize("tag", ["k35_t30", "k35_t25", "k35_t34", "k25_t20"])
+def test_root_scorer(tag):
+    c = G.Case("noisy")
+    info = G.manifest()["score"][tag]
+    s = oracle.RootScorer([c.v_region], 15)
+    rows = G.rows(f"score_{tag}.tsv.gz")
+    assert len(rows) == info["n"]
+    got = [s.score(r[0], info["thr"]) for r in rows]
+    assert got == [int(r[1]) for r in rows]
+    assert sum(got) == info["ones"]
+
+
+def parse_map(name):
+    out = []
+    for l in G.text(name).splitlines():
+        f = l.split("\t")
+        if f[0] == "W":
+            out.append({"valid": int(f[2]), "n": int(f[3]), "pairs": [], "starts": []})
+        elif f[0] == "P":
+            out[-1]["pairs"].append((f[1], int(f[2]), int(f[3]), int(f[4]), int(f[5]), int(f[6])))
+        elif f[0] == "S":
+            out[-1]["starts"] = [tuple(int(x) for x in e.split(",")) for e in f[1].split(";") if e] if len(f) > 1 else []
+    return out
+
+
+@pytest.mark.parametrize("tag", ["ins175", "ins150_rf2", "ins200_ms20"])
+def test_quick_map_and_coverage(tag):
+    c = G.Case("map")
+    info = G.manifest()["map"][tag]
+    p = dict(rs=35, ms=48, rf=1)
+    it = iter(info["flags"])
+    for f in it:
+        p[f.lstrip("-")] = int(next(it))
+    ix = oracle.ReadIndex(c.pool)
+    wins = G.text("map_windows.txt.gz").split()
+    ref = parse_map(f"map_{tag}.txt.gz")
+    assert len(wins) == len(ref)
+    for w, r in zip(wins, ref):
+        pairs, starts = ix.quick_map(w)
+        assert len(pairs) == r["n"]
+        mine = [(f"r{q['pair_id']}", int(q["pos1"]), int(q["pos2"]), int(q["insert"]), int(q["rc1"]), int(q["rc2"])) for q in pairs]
+        assert mine == r["pairs"]
+        assert [tuple(x) for x in starts.tolist()] == r["starts"]
+        v = ix.coverage_is_valid(starts, len(w), info["ins"], rs=p["rs"], ms=p["ms"], floor=p["rf"])
+        assert v == r["valid"]
+
+
+@pytest.mark.parametrize("tag", ["e2e_tiled", "e2e_mixed"])
+def test_sam_text_of_final_contigs(tag):
+    """a-10: re-map every contig of the reference's FASTA and reproduce its SAM byte for byte."""
+    c = G.Case(tag)
+    ix = oracle.ReadIndex(c.pool)
+    fa = G.text(f"{tag}.contigs.fa.gz").splitlines()
+    out = ["@HD\tVN:1.4\tSO:unsorted\n"]
+    for i in range(0, len(fa), 2):
+        out.append(f"@SQ\tSN:{fa[i][1:]}\tLN:{len(fa[i + 1])}\n")
+    for i in range(0, len(fa), 2):
+        pairs, _ = ix.quick_map(fa[i + 1])
+        for q in pairs:
+            out.append(ix.sam_pair(fa[i][1:], f"r{q['pair_id']}", q))
+    assert "".join(out) == G.text(f"{tag}.sam.gz")

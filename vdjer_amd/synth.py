@@ -1,0 +1,318 @@
+"""Synthetic IgH repertoire / read-pool / ref-dir generator.
+
+The reference ships no runnable inputs (demo BAM is a missing blob, the reference index bundle is a
+download), so every workload this repo measures or tests is generated here from a fixed seed.
+
+Conventions reproduced from the reference:
+  * pool record  = '0' + rl bases + rl Phred+33 chars, two records per read (as-is, then
+    reverse-complement with reversed qualities)           -- bam_read.c:206-244 (add_to_buffer)
+  * per-record read info {pair id, read_num, is_rc}        -- quick_map3.c:126-149 (add_read_info)
+  * ref-dir files v_index / j_index / ig_vdj.fa / v_region.fa -- params.c:37-51
+  * anchor code: 16 bases, A=0 T=1 C=2 G=3, first base most significant -- seq_to_kmer.c:6-46
+
+Transcript design (so that the reference's window finder, vj_filter.c:127-309, accepts a clone):
+  V(300) = 99 random non-stop codons + TGT;   V anchor = V[277:293]  (Cys codon 4 nt after it)
+  CDR3   = TGT + 3*U[8,20] core + TGG         (length multiple of 3 in [30,66])
+  J tail = TGG + 119 random non-stop codons;  J anchor = J[8:24]     (5 nt after the Trp codon)
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_STOPS = {"TAG", "TAA", "TGA"}
+_CODONS = [a + b + c for a in "ACGT" for b in "ACGT" for c in "ACGT"]
+_NONSTOP = [c for c in _CODONS if c not in _STOPS]
+_IDX = {c: i for i, c in enumerate("ACGT")}
+
+
+def seq_to_int(s: str) -> int:
+    """16-mer -> 32-bit anchor code (seq_to_kmer.c:32-46; A0 T1 C2 G3)."""
+    val = 0
+    code = {"A": 0, "T": 1, "C": 2, "G": 3}
+    for ch in s[:16]:
+        val = (val << 2) | code[ch]
+    return val
+
+
+def revcomp(s: str) -> str:
+    return s[::-1].translate(str.maketrans("ACGTN", "TGCAN"))
+
+
+def _rand_codons(rng: np.random.Generator, n: int) -> str:
+    idx = rng.integers(0, len(_NONSTOP), size=n)
+    return "".join(_NONSTOP[i] for i in idx)
+
+
+@dataclass
+class Repertoire:
+    v_germ: list
+    j_germ: list
+    clones: list            # transcript strings
+    clone_v: list
+    clone_j: list
+    weights: np.ndarray     # Zipf abundance, sums to 1
+    seed: int
+    # derived
+    v_anchors: list = field(default_factory=list)
+    j_anchors: list = field(default_factory=list)
+
+    @property
+    def v_region(self) -> str:
+        return "".join(self.v_germ)
+
+    def windows(self, window_span: int = 486, j_extension: int = 162) -> list:
+        """The 486-nt candidate window the reference derives for each clone (vj_filter.c:265-276)."""
+        out = []
+        for t, cdr3 in zip(self.clones, self.cdr3s()):
+            c = t.find(cdr3)
+            start = c - (window_span - (len(cdr3) + j_extension))
+            out.append(t[start:start + window_span] if start >= 0 and len(t) - start > window_span else None)
+        return out
+
+    def cdr3s(self) -> list:
+        out = []
+        for t in self.clones:
+            c = 297
+            w = t.find("TGG", c + 3)
+            # the designed Trp codon is the in-frame one that starts the J tail
+            while (w - c) % 3 != 0 or t[w + 8:w + 24] not in self.j_anchors:
+                w = t.find("TGG", w + 1)
+            out.append(t[c:w + 3])
+        return out
+
+
+def make_repertoire(n_clones: int, seed: int = 20261002, n_v: int = 60, n_j: int = 6,
+                    zipf_s: float = 1.1, j_codons: int = 119) -> Repertoire:
+    rng = np.random.default_rng(seed)
+    v_germ = [_rand_codons(rng, 99) + "TGT" for _ in range(n_v)]
+    j_germ = ["TGG" + _rand_codons(rng, j_codons) for _ in range(n_j)]
+    clones, cv, cj = [], [], []
+    for _ in range(n_clones):
+        g = int(rng.integers(0, n_v))
+        h = int(rng.integers(0, n_j))
+        v = list(v_germ[g])
+        for _m in range(int(rng.integers(0, 7))):
+            # somatic point mutation outside the anchor (277..292) and the Cys codon, never making a stop
+            for _try in range(20):
+                pos = int(rng.integers(0, 270))
+                nb = "ACGT"[int(rng.integers(0, 4))]
+                if nb == v[pos]:
+                    continue
+                c0 = pos - pos % 3
+                cod = v[c0:c0 + 3]
+                cod[pos % 3] = nb
+                if "".join(cod) in _STOPS:
+                    continue
+                v[pos] = nb
+                break
+        core = _rand_codons(rng, int(rng.integers(8, 21)))
+        clones.append("".join(v) + core + j_germ[h])
+        cv.append(g)
+        cj.append(h)
+    ranks = np.arange(1, n_clones + 1, dtype=np.float64)
+    w = 1.0 / ranks ** zipf_s
+    w /= w.sum()
+    rep = Repertoire(v_germ, j_germ, clones, cv, cj, w, seed)
+    rep.v_anchors = [v[277:293] for v in v_germ]
+    rep.j_anchors = [j[8:24] for j in j_germ]
+    return rep
+
+
+def write_ref_dir(rep: Repertoire, path: str) -> str:
+    """Synthetic --ref-dir (params.c:43-50): v_index, j_index, ig_vdj.fa, v_region.fa."""
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "v_region.fa"), "w") as f:
+        f.write(">v_region\n" + rep.v_region + "\n")
+    with open(os.path.join(path, "ig_vdj.fa"), "w") as f:
+        for i, v in enumerate(rep.v_germ):
+            f.write(f">V{i}\n{v}\n")
+        for i, j in enumerate(rep.j_germ):
+            f.write(f">J{i}\n{j}\n")
+    with open(os.path.join(path, "v_index"), "w") as f:
+        for a in sorted(set(rep.v_anchors)):
+            f.write(f"{seq_to_int(a)}\t0\n")
+    with open(os.path.join(path, "j_index"), "w") as f:
+        for a in sorted(set(rep.j_anchors)):
+            f.write(f"{seq_to_int(a)}\t0\n")
+    return path
+
+
+@dataclass
+class ReadPool:
+    """Pools in the reference's a-0 layout plus the per-record read info the quick_map index needs."""
+    rl: int
+    primary: np.ndarray       # uint8 [Rp, 2*rl+1]
+    secondary: np.ndarray     # uint8 [Rs, 2*rl+1]
+    # per-record info, primary records first then secondary (== scan order of build_pre_graph)
+    pair_id: np.ndarray       # uint32 [R]
+    read_num: np.ndarray      # uint8  [R]   1|2
+    is_rc: np.ndarray         # uint8  [R]
+    reg_rank: np.ndarray      # uint32 [R]   registration order (add_read_info call order)
+    n_pairs: int
+
+    @property
+    def n_records(self) -> int:
+        return self.primary.shape[0] + self.secondary.shape[0]
+
+    def names(self):
+        return [f"r{i}" for i in range(self.n_pairs)]
+
+    def write_reads_file(self, path: str) -> None:
+        """Text reads file for oracle/_ref/vdjer_ref (one read per line, registration order)."""
+        rl = self.rl
+        allrec = np.concatenate([self.primary, self.secondary], axis=0)
+        npri = self.primary.shape[0]
+        order = np.argsort(self.reg_rank, kind="stable")
+        with open(path, "w") as f:
+            for r in order:
+                if self.reg_rank[r] % 2:      # the rc record of a read: derived by the harness
+                    continue
+                rec = allrec[r]
+                seq = rec[1:1 + rl].tobytes().decode()
+                qual = rec[1 + rl:1 + 2 * rl].tobytes().decode()
+                f.write(f"{'P' if r < npri else 'S'} r{self.pair_id[r]} {self.read_num[r]} {self.is_rc[r]} {seq} {qual}\n")
+
+
+_COMP = np.array([3, 2, 1, 0], dtype=np.uint8)   # over ACGT indices
+_QUAL_CHARS = np.frombuffer(bytes([40 + 33, 30 + 33, 12 + 33]), dtype=np.uint8)
+
+
+def _qualities(rng, shape):
+    u = rng.random(shape, dtype=np.float32)
+    q = np.zeros(shape, dtype=np.uint8)
+    q[u >= 0.85] = 1
+    q[u >= 0.95] = 2
+    return _QUAL_CHARS[q]
+
+
+def make_reads(rep: Repertoire, n_pairs: int, noise_frac: float = 0.3, rl: int = 50, seed: int | None = None,
+               ins_mean: float = 175.0, ins_sd: float = 10.0, ins_lo: int = 120, ins_hi: int = 240,
+               err: float = 0.002, n_rate: float = 0.001, swap: float = 0.5,
+               clean: bool = False, chunk: int = 1 << 20) -> ReadPool:
+    """Generate n_pairs paired reads.  Clone pairs go to the primary pool, noise pairs to the secondary
+    pool (the reference routes reads with a V/D/J 15-mer to primary and other unmapped reads to
+    secondary, bam_read.c:355-380).  clean=True: no errors / Ns / low qualities (tiny goldens)."""
+    rng = np.random.default_rng(rep.seed + 7919 if seed is None else seed)
+    C = len(rep.clones)
+    lens = np.array([len(t) for t in rep.clones], dtype=np.int64)
+    lmax = int(lens.max())
+    T = np.zeros((C, lmax), dtype=np.uint8)
+    for i, t in enumerate(rep.clones):
+        T[i, :len(t)] = np.array([_IDX[c] for c in t], dtype=np.uint8)
+    Tflat = T.reshape(-1)
+    cdf = np.cumsum(rep.weights)
+    cdf[-1] = 1.0
+
+    rec_len = 2 * rl + 1
+    is_noise_all = rng.random(n_pairs) < noise_frac
+    n_noise = int(is_noise_all.sum())
+    n_clone = n_pairs - n_noise
+    primary = np.empty((4 * n_clone, rec_len), dtype=np.uint8)
+    secondary = np.empty((4 * n_noise, rec_len), dtype=np.uint8)
+    ar = np.arange(rl, dtype=np.int64)
+
+    pcur = scur = 0
+    for c0 in range(0, n_pairs, chunk):
+        c1 = min(n_pairs, c0 + chunk)
+        m = c1 - c0
+        noise = is_noise_all[c0:c1]
+        # --- bases (ACGT indices) for both mates, forward orientation of the fragment
+        r1 = rng.integers(0, 4, size=(m, rl), dtype=np.uint8)
+        r2 = rng.integers(0, 4, size=(m, rl), dtype=np.uint8)
+        ci = np.flatnonzero(~noise)
+        if ci.size:
+            clone = np.searchsorted(cdf, rng.random(ci.size), side="right").astype(np.int64)
+            clone = np.minimum(clone, C - 1)
+            ins = np.clip(np.rint(rng.normal(ins_mean, ins_sd, ci.size)), ins_lo, ins_hi).astype(np.int64)
+            ins = np.minimum(ins, lens[clone])
+            start = (rng.random(ci.size) * (lens[clone] - ins + 1)).astype(np.int64)
+            base = clone * lmax + start
+            f1 = Tflat[base[:, None] + ar[None, :]]
+            f2 = Tflat[(base + ins - rl)[:, None] + ar[None, :]]
+            r1[ci] = f1
+            r2[ci] = _COMP[f2[:, ::-1]]
+            sw = ci[rng.random(ci.size) < swap]
+            tmp = r1[sw].copy()
+            r1[sw] = r2[sw]
+            r2[sw] = tmp
+            if not clean and err > 0:
+                for r in (r1, r2):
+                    e = rng.random((ci.size, rl), dtype=np.float32) < err
+                    sub = rng.integers(1, 4, size=(ci.size, rl), dtype=np.uint8)
+                    blk = r[ci]
+                    blk[e] = (blk[e] + sub[e]) & 3
+                    r[ci] = blk
+        a1 = ACGT[r1]
+        a2 = ACGT[r2]
+        if clean:
+            q1 = np.full((m, rl), 40 + 33, dtype=np.uint8)
+            q2 = np.full((m, rl), 40 + 33, dtype=np.uint8)
+        else:
+            q1 = _qualities(rng, (m, rl))
+            q2 = _qualities(rng, (m, rl))
+            if n_rate > 0:
+                a1[rng.random((m, rl), dtype=np.float32) < n_rate] = ord("N")
+                a2[rng.random((m, rl), dtype=np.float32) < n_rate] = ord("N")
+        # --- 4 records per pair: R1, rc(R1), R2, rc(R2)
+        recs = np.empty((m, 4, rec_len), dtype=np.uint8)
+        recs[:, :, 0] = ord("0")
+        comp_ascii = np.arange(256, dtype=np.uint8)
+        for a, b in (("A", "T"), ("T", "A"), ("C", "G"), ("G", "C")):
+            comp_ascii[ord(a)] = ord(b)
+        recs[:, 0, 1:1 + rl] = a1
+        recs[:, 0, 1 + rl:] = q1
+        recs[:, 1, 1:1 + rl] = comp_ascii[a1[:, ::-1]]
+        recs[:, 1, 1 + rl:] = q1[:, ::-1]
+        recs[:, 2, 1:1 + rl] = a2
+        recs[:, 2, 1 + rl:] = q2
+        recs[:, 3, 1:1 + rl] = comp_ascii[a2[:, ::-1]]
+        recs[:, 3, 1 + rl:] = q2[:, ::-1]
+        pc = recs[~noise].reshape(-1, rec_len)
+        sc = recs[noise].reshape(-1, rec_len)
+        primary[pcur:pcur + pc.shape[0]] = pc
+        secondary[scur:scur + sc.shape[0]] = sc
+        pcur += pc.shape[0]
+        scur += sc.shape[0]
+
+    # --- per-record info in scan order (primary records then secondary)
+    pair_idx = np.arange(n_pairs, dtype=np.uint32)
+    pid_p = np.repeat(pair_idx[~is_noise_all], 4)
+    pid_s = np.repeat(pair_idx[is_noise_all], 4)
+    pair_id = np.concatenate([pid_p, pid_s])
+    R = pair_id.shape[0]
+    within = np.tile(np.arange(4, dtype=np.uint32), R // 4)
+    read_num = (1 + within // 2).astype(np.uint8)
+    is_rc = (within & 1).astype(np.uint8)            # unmapped BAM reads: as-is record is_rc=0, rc record 1
+    reg_rank = (pair_id.astype(np.uint64) * 4 + within).astype(np.uint32)
+    return ReadPool(rl, primary, secondary, pair_id, read_num, is_rc, reg_rank, n_pairs)
+
+
+def tile_reads(rep: Repertoire, clone_ids, ins: int = 175, copies: int = 3, rl: int = 50, step: int = 1) -> ReadPool:
+    """Deterministic dense tiling (every start, fixed insert, `copies` copies, quality 'I'):
+    the SURVEY §8c recipe that makes a clone pass the coverage validator."""
+    p_recs = []
+    pid = []
+    n = 0
+    comp = str.maketrans("ACGT", "TGCA")
+    for c in clone_ids:
+        t = rep.clones[c]
+        for s in range(0, len(t) - ins + 1, step):
+            a = t[s:s + rl]
+            b = t[s + ins - rl:s + ins][::-1].translate(comp)
+            for _ in range(copies):
+                q = "I" * rl
+                for seq in (a, a[::-1].translate(comp), b, b[::-1].translate(comp)):
+                    p_recs.append(("0" + seq + q).encode())
+                    pid.append(n)
+                n += 1
+    primary = np.frombuffer(b"".join(p_recs), dtype=np.uint8).reshape(-1, 2 * rl + 1).copy()
+    secondary = np.zeros((0, 2 * rl + 1), dtype=np.uint8)
+    pair_id = np.array(pid, dtype=np.uint32)
+    R = pair_id.shape[0]
+    within = np.tile(np.arange(4, dtype=np.uint32), R // 4)
+    return ReadPool(rl, primary, secondary, pair_id, (1 + within // 2).astype(np.uint8), (within & 1).astype(np.uint8),
+                    (pair_id * 4 + within).astype(np.uint32), n)
