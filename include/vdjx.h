@@ -1,0 +1,147 @@
+/*
+ * include/vdjx.h -- C ABI of libvdjx.so, the MI355X (gfx950) implementation of V'DJer's hot path.
+ *
+ * The reference (mozack/vdjer) has no plugin/FFI layer: it is one C++ program whose hot path is a
+ * set of internal call sites.  Each entry point below replaces one of those call
+ * sites; the "replaces:" lines cite the reference interface under /root/reference/src/main/c
+ * (A2 = assembler2_vdj.c).  INTEGRATION.md shows the binding a maintainer adds on the reference side.
+ *
+ * Conventions: plain C types only; every call returns 0 on success or a negative VDJX_E* code with a
+ * message available from vdjx_last_error(); nothing ever calls exit().  One host thread drives one
+ * context; calls are synchronous (internally they run on the context's HIP stream).  Host pointers
+ * unless a parameter is named d_* (device pointer, same device as the context).
+ */
+#ifndef VDJX_H
+#define VDJX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDJX_OK 0
+#define VDJX_EINVAL (-1)   /* bad argument */
+#define VDJX_EHIP (-2)     /* HIP runtime error */
+#define VDJX_ELIMIT (-3)   /* input exceeds a documented limit (rl <= 64, k <= 50, records*offsets < 2^31) */
+#define VDJX_ESTATE (-4)   /* call order violated (e.g. scorer used before its index was loaded) */
+
+#define VDJX_MAX_READ_LEN 64
+#define VDJX_MAX_KMER 50    /* A2:70 MAX_KMER_LEN */
+
+typedef struct vdjx_ctx vdjx_ctx;
+typedef struct vdjx_pool vdjx_pool;
+typedef struct vdjx_graph vdjx_graph;
+
+const char* vdjx_last_error(void);
+const char* vdjx_version(void);
+
+/* One context per GPU (one process per GPU in multi-GPU runs). */
+int vdjx_init(int device, vdjx_ctx** out);
+void vdjx_shutdown(vdjx_ctx* ctx);
+/* blocks until all work queued on the context's stream is done */
+int vdjx_sync(vdjx_ctx* ctx);
+
+/* ---- a-0: read pool -------------------------------------------------------------------------
+ * replaces: the two NUL-terminated ASCII pools handed to assemble() (A2:1350-1358, 1545-1554),
+ * produced by add_to_buffer (bam_read.c:206-244): records of 2*rl+1 bytes, '0' + rl bases + rl
+ * Phred+33 characters, primary pool scanned before secondary (A2:1388-1390).
+ * Packs the pool on the device (2-bit bases A0 T1 C2 G3 as seq_to_kmer.c:6-29, N mask, Phred<20
+ * mask, quality bytes).  Bases other than ACGT are treated as 'N'.  The caller keeps the ASCII. */
+int vdjx_pool_load(vdjx_ctx* ctx, const uint8_t* primary, size_t n_primary,
+                   const uint8_t* secondary, size_t n_secondary, int rl, vdjx_pool** out);
+/* same, ASCII pools already resident in device memory (16-byte aligned) */
+int vdjx_pool_load_device(vdjx_ctx* ctx, const uint8_t* d_primary, size_t n_primary,
+                          const uint8_t* d_secondary, size_t n_secondary, int rl, vdjx_pool** out);
+size_t vdjx_pool_records(const vdjx_pool* pool);
+void vdjx_pool_free(vdjx_pool* pool);
+
+/* ---- a-6: V/J anchor sets ---------------------------------------------------------------------
+ * replaces: vjf_init -> load_kmers (vj_filter.c:56-68, 311-340): the codes whose distance column
+ * passed --am.  Kept as two 2^32-bit bitmaps in HBM; code 0 is never a member (vj_filter.c:317-318). */
+int vdjx_anchor_sets_load(vdjx_ctx* ctx, const uint32_t* v_codes, size_t nv, const uint32_t* j_codes, size_t nj);
+/* replaces: seq_to_int + matches_vmer/matches_jmer over every offset of a contig
+ * (vj_filter.c:221-238): out_v/out_j[i] for i in [0, len-16) */
+int vdjx_anchor_probe(vdjx_ctx* ctx, const char* contig, int len, uint8_t* out_v, uint8_t* out_j);
+
+/* ---- a-1, a-2, a-3: k-mer table, prune, graph build --------------------------------------------
+ * replaces: build_pre_graph x2 + prune_pre_graph + build_graph2 x2 (A2:1388-1408; bodies
+ * A2:240-259, 322-367, 454-484, 267-320, 190-237).  The result is everything the host-side
+ * traversal needs without re-scanning the pool: nodes in creation order with their ordered edge
+ * lists. */
+int vdjx_kmer_build(vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, vdjx_graph** out);
+size_t vdjx_graph_nodes(const vdjx_graph* g);
+/* distinct gated k-mers before the prune ("Pre Num nodes", A2:407) */
+size_t vdjx_graph_pre_nodes(const vdjx_graph* g);
+/* Node i (0-based; reference node id = i+1, A2:188,200), in creation order:
+ *   first_inst  record*64+offset of the first (ungated) occurrence, records counted over primary then secondary
+ *   gated_count frequency of the pre_node (A2:130,345-347), saturated at 32765
+ *   freq        node frequency (A2:119,261-265), saturated at 32765
+ *   has_v/has_j A2:288-303
+ *   to_deg/from_deg <= 4; to_ids/from_ids [n][4] 1-based node ids in list order (head of the
+ *   reference's prepend list first, A2:223-237)
+ *   kmers       n*k ASCII characters (may be NULL)                                              */
+int vdjx_graph_export(const vdjx_graph* g, uint64_t* first_inst, uint32_t* gated_count, uint32_t* freq,
+                      uint8_t* has_v, uint8_t* has_j, uint8_t* to_deg, uint32_t* to_ids,
+                      uint8_t* from_deg, uint32_t* from_ids, char* kmers);
+void vdjx_graph_free(vdjx_graph* g);
+
+/* ---- a-7: root (V-region homology) scorer ------------------------------------------------------
+ * replaces: score_seq_init(k, 1000, v_region.fa) (seq_score.c:50-70) and score_seq(kmer, thr)
+ * (seq_score.c:118-158) as called per root by worker_thread (A2:1103).
+ * lines: the non-header lines of v_region.fa, newline stripped; each must be longer than 2k.     */
+int vdjx_vregion_load(vdjx_ctx* ctx, const char* const* lines, size_t n_lines, int vk);
+/* kmers: n*k ASCII; out[i] = 0|1 */
+int vdjx_root_score(vdjx_ctx* ctx, const char* kmers, size_t n, int k, int threshold, uint8_t* out);
+
+/* ---- a-8, a-9, a-10: read->contig mapper, coverage validator, SAM placements --------------------
+ * replaces: add_read_info (quick_map3.c:126-149) for the index; quick_map_process_contig +
+ * coverage_is_valid as called per candidate window by output_contig (A2:841-847; quick_map3.c:188-266,
+ * coverage.c:10-130); quick_map_process_contig_file -> output_mapping for the final contigs
+ * (quick_map3.c:152-181, 311-340).
+ * Per pool record (scan order): pair id (identity of the read name), read_num 1|2, is_rc, and the
+ * registration rank (order of the add_read_info calls).                                           */
+int vdjx_read_index_build(vdjx_ctx* ctx, const vdjx_pool* pool, const uint32_t* pair_id,
+                          const uint8_t* read_num, const uint8_t* is_rc, const uint32_t* reg_rank, uint32_t n_pairs);
+
+typedef struct {
+	int eval_start;    /* --e0 */
+	int eval_stop;     /* --e1 */
+	int read_span;     /* --rs */
+	int mate_span;     /* --ms */
+	int insert_low;    /* --ins */
+	int insert_high;   /* --ins */
+	int floor;         /* --rf; 0 disables the coverage check (A2:846) */
+} vdjx_cov_params;
+
+/* windows: n strings of `len` chars, stride `len`.  out_valid[i] = coverage_is_valid(...),
+ * out_npairs[i] = mapped pairs. */
+int vdjx_window_score(vdjx_ctx* ctx, const char* windows, size_t n, int len, const vdjx_cov_params* p,
+                      uint8_t* out_valid, uint32_t* out_npairs);
+
+typedef struct {
+	uint32_t pair_id;
+	uint32_t rec1, rec2;       /* pool record (scan order) that matched for read 1 / read 2 */
+	int16_t pos1, pos2, insert;
+	uint8_t rc1, rc2;
+} vdjx_pair;
+
+/* Mapped pairs of each contig in the reference's output order.  Two-call protocol: first call with
+ * pairs == NULL fills offsets[n+1]; second call with pairs sized offsets[n]. */
+int vdjx_map_emit(vdjx_ctx* ctx, const char* contigs, size_t n, int len, uint64_t* offsets, vdjx_pair* pairs);
+
+/* ---- profiling hooks (HIP events on the context's stream) ---------------------------------------*/
+int vdjx_profile_enable(vdjx_ctx* ctx, int on);
+int vdjx_profile_reset(vdjx_ctx* ctx);
+/* number of distinct kernel names recorded since the last reset */
+int vdjx_profile_count(vdjx_ctx* ctx);
+/* idx-th entry: kernel name, summed milliseconds, launch count */
+int vdjx_profile_get(vdjx_ctx* ctx, int idx, const char** name, double* total_ms, uint64_t* launches);
+
+/* ---- multi-GPU (hash-prefix sharding) -- declared in round 1, see DESIGN.md §7 ------ */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

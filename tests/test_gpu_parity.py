@@ -1,0 +1,248 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (libvdjx.so via ctypes), against
+  (1) the golden dumps of the compiled reference in tests/golden/ and
+  (2) the CPU oracle (oracle/vdjx_oracle.c) on seeded inputs.
+Everything is integer / byte / index work: comparisons are bit-exact.
+"""
+import numpy as np
+import pytest
+
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vdjer_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def assert_graph_equals_oracle(hg, og, pool, k):
+    from oracle import oracle
+    assert hg.n == og.n
+    np.testing.assert_array_equal(hg.first_inst, og.first)
+    np.testing.assert_array_equal(hg.freq, og.freq)
+    np.testing.assert_array_equal(hg.has_v, og.has_v)
+    np.testing.assert_array_equal(hg.has_j, og.has_j)
+    np.testing.assert_array_equal(hg.to_deg, og.to_deg)
+    np.testing.assert_array_equal(hg.from_deg, og.from_deg)
+    np.testing.assert_array_equal(hg.to_ids, og.to_ids)
+    np.testing.assert_array_equal(hg.from_ids, og.from_ids)
+    for i in range(0, hg.n, max(1, hg.n // 200)):
+        assert hg.kmer(i) == oracle.inst_kmer(pool, int(og.first[i]), k)
+
+
+def run_both(ctx, case_pool, v_codes, j_codes, k, mf, mq):
+    from oracle import oracle
+    t = oracle.KmerTable(case_pool, k)
+    pre = t.size()
+    t.prune(mf, mq)
+    first, count, _, _ = t.export()
+    og = oracle.Graph(t, v_codes, j_codes)
+    ctx.anchor_sets_load(v_codes, j_codes)
+    p = ctx.pool_load(case_pool.primary, case_pool.secondary, case_pool.rl)
+    hg = ctx.kmer_build(p, k, mf, mq)
+    p.free()
+    assert hg.pre_nodes == pre
+    assert_graph_equals_oracle(hg, og, case_pool, k)
+    # gated count per surviving k-mer (pre_node.frequency)
+    o_cnt = {oracle.inst_kmer(case_pool, int(f), k): int(n) for f, n in zip(first, count)}
+    h_cnt = {hg.kmer(i): int(hg.gated_count[i]) for i in range(hg.n)}
+    assert o_cnt == h_cnt
+    return hg
+
+
+@pytest.mark.parametrize("case,tag", [("noisy", "noisy_k35"), ("noisy", "noisy_k25"), ("noisy", "noisy_mq230"),
+                                      ("noisy", "noisy_mq20"), ("pre", "pre_k35")])
+def test_kmer_build_vs_reference_dump(ctx, case, tag):
+    c = G.Case(case)
+    info = G.manifest()[case][tag]
+    p = G.flags_to_params(info["flags"])
+    hg = run_both(ctx, c.pool, c.v_codes, c.j_codes, p["k"], p["mf"], p["mq"])
+    assert hg.pre_nodes == info["pre"]
+    nodes = G.rows(f"{tag}.nodes.tsv.gz")
+    assert hg.n == len(nodes) == info["nodes"]
+    for i, r in enumerate(nodes):
+        assert hg.kmer(i) == r[1]
+        assert int(hg.freq[i]) == int(r[2])
+        assert (int(hg.has_v[i]), int(hg.has_j[i])) == (int(r[3]), int(r[4]))
+        assert list(hg.to_ids[i, :hg.to_deg[i]]) == [int(x) for x in r[5].split(",") if x]
+        assert list(hg.from_ids[i, :hg.from_deg[i]]) == [int(x) for x in r[6].split(",") if x]
+    surv = {r[0]: int(r[1]) for r in G.rows(f"{tag}.survivors.tsv.gz")}
+    assert {hg.kmer(i): int(hg.gated_count[i]) for i in range(hg.n)} == surv
+
+
+@pytest.mark.parametrize("k,mf,mq,n_pairs,seed", [(35, 3, 90, 40000, 1), (25, 2, 60, 20000, 2), (35, 2, 254, 8000, 3),
+                                                   (16, 3, 90, 3000, 4), (12, 2, 40, 1500, 5), (48, 2, 60, 6000, 6),
+                                                   (50, 2, 60, 6000, 7), (31, 1, 100, 5000, 8)])
+def test_kmer_build_vs_oracle_seeded(ctx, k, mf, mq, n_pairs, seed):
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(12, seed=100 + seed)
+    pool = synth.make_reads(rep, n_pairs, noise_frac=0.3, seed=seed, err=0.004, n_rate=0.002)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    run_both(ctx, pool, vc, jc, k, mf, mq)
+
+
+def test_kmer_build_edge_cases(ctx):
+    from vdjer_amd import synth, api
+    rep = synth.make_repertoire(2, seed=77)
+    vc = np.array([synth.seq_to_int(a) for a in rep.v_anchors], dtype=np.uint32)
+    jc = np.array([synth.seq_to_int(a) for a in rep.j_anchors], dtype=np.uint32)
+    # empty pools
+    empty = synth.ReadPool(50, np.zeros((0, 101), np.uint8), np.zeros((0, 101), np.uint8), np.zeros(0, np.uint32),
+                           np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(0, np.uint32), 0)
+    ctx.anchor_sets_load(vc, jc)
+    p = ctx.pool_load(empty.primary, empty.secondary, 50)
+    g = ctx.kmer_build(p, 35, 3, 90)
+    assert g.n == 0 and g.pre_nodes == 0
+    p.free()
+    # secondary-only / primary-only, k == rl (one k-mer per record), all-N and all-low-quality reads
+    pool = synth.make_reads(rep, 1200, noise_frac=0.5, seed=9)
+    pool.primary[::7, 1:51] = ord("N")
+    pool.secondary[::5, 51:101] = ord("#")
+    for k, mf, mq in ((50, 2, 60), (35, 3, 90)):
+        run_both(ctx, pool, vc, jc, k, mf, mq)
+    only_sec = synth.ReadPool(50, np.zeros((0, 101), np.uint8), np.concatenate([pool.primary, pool.secondary]), pool.pair_id,
+                              pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+    run_both(ctx, only_sec, vc, jc, 35, 3, 90)
+    # a malformed record must fail loudly, not be skipped
+    bad = pool.primary.copy()
+    bad[3, 0] = ord("x")
+    with pytest.raises(api.VdjxError):
+        ctx.pool_load(bad, pool.secondary, 50)
+    with pytest.raises(api.VdjxError):
+        ctx.pool_load(np.full((2, 131), ord("0"), np.uint8), np.zeros((0, 131), np.uint8), 65)   # rl > 64
+
+
+def test_hot_kmer_skew(ctx):
+    """One clone at extreme depth: a handful of k-mers with tens of thousands of instances in one bucket."""
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(1, seed=5)
+    pool = synth.make_reads(rep, 60000, noise_frac=0.02, seed=11)
+    vc = np.array([synth.seq_to_int(a) for a in rep.v_anchors], dtype=np.uint32)
+    jc = np.array([synth.seq_to_int(a) for a in rep.j_anchors], dtype=np.uint32)
+    hg = run_both(ctx, pool, vc, jc, 35, 3, 90)
+    assert int(hg.freq.max()) > 1000
+
+
+@pytest.mark.parametrize("tag", ["k35_t30", "k35_t25", "k35_t34", "k25_t20"])
+def test_root_score_vs_reference_dump(ctx, tag):
+    c = G.Case("noisy")
+    info = G.manifest()["score"][tag]
+    ctx.vregion_load([c.v_region], 15)
+    rows = G.rows(f"score_{tag}.tsv.gz")
+    got = ctx.root_score([r[0] for r in rows], info["k"], info["thr"])
+    assert got.tolist() == [int(r[1]) for r in rows]
+
+
+def test_root_score_vs_oracle_multiline(ctx):
+    from oracle import oracle
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(5, seed=300)
+    lines = [rep.v_region[:6000], rep.v_region[6000:6100], rep.v_region[9000:]]
+    s = oracle.RootScorer(lines, 15)
+    ctx.vregion_load(lines, 15)
+    rng = np.random.default_rng(4)
+    qs = []
+    for _ in range(300):
+        src = rep.v_region if rng.random() < 0.7 else "".join("ACGT"[i] for i in rng.integers(0, 4, 400))
+        st = int(rng.integers(0, len(src) - 35))
+        q = list(src[st:st + 35])
+        for _m in range(int(rng.integers(0, 9))):
+            q[int(rng.integers(0, 35))] = "ACGT"[int(rng.integers(0, 4))]
+        qs.append("".join(q))
+    for thr in (30, 22, 35, 0):
+        got = ctx.root_score(qs, 35, thr)
+        assert got.tolist() == [s.score(q, thr) for q in qs]
+
+
+def test_anchor_probe(ctx):
+    from vdjer_amd import synth
+    c = G.Case("noisy")
+    ctx.anchor_sets_load(c.v_codes, c.j_codes)
+    vs, js = set(c.v_codes.tolist()), set(c.j_codes.tolist())
+    for t in c.clones:
+        ov, oj = ctx.anchor_probe(t)
+        exp_v = [int(synth.seq_to_int(t[i:i + 16]) in vs) for i in range(len(t) - 16)]
+        exp_j = [int(synth.seq_to_int(t[i:i + 16]) in js) for i in range(len(t) - 16)]
+        assert ov.tolist() == exp_v and oj.tolist() == exp_j
+        assert sum(exp_v) >= 1 and sum(exp_j) >= 1
+
+
+def _load_index(ctx, pool):
+    p = ctx.pool_load(pool.primary, pool.secondary, pool.rl)
+    ctx.read_index_build(p, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+    return p
+
+
+@pytest.mark.parametrize("tag", ["ins175", "ins150_rf2", "ins200_ms20"])
+def test_window_score_and_map_vs_reference_dump(ctx, tag):
+    from tests.test_oracle_vs_golden import parse_map
+    c = G.Case("map")
+    info = G.manifest()["map"][tag]
+    prm = dict(rs=35, ms=48, rf=1)
+    it = iter(info["flags"])
+    for f in it:
+        prm[f.lstrip("-")] = int(next(it))
+    p = _load_index(ctx, c.pool)
+    wins = G.text("map_windows.txt.gz").split()
+    ref = parse_map(f"map_{tag}.txt.gz")
+    by_len = {}
+    for i, w in enumerate(wins):
+        by_len.setdefault(len(w), []).append(i)
+    for ln, idxs in by_len.items():
+        ws = [wins[i] for i in idxs]
+        valid, npairs = ctx.window_score(ws, info["ins"], rs=prm["rs"], ms=prm["ms"], floor=prm["rf"])
+        assert npairs.tolist() == [ref[i]["n"] for i in idxs]
+        assert valid.tolist() == [ref[i]["valid"] for i in idxs]
+        offs, pairs = ctx.map_emit(ws)
+        for j, i in enumerate(idxs):
+            mine = [(f"r{q['pair_id']}", int(q["pos1"]), int(q["pos2"]), int(q["insert"]), int(q["rc1"]), int(q["rc2"]))
+                    for q in pairs[int(offs[j]):int(offs[j + 1])]]
+            assert mine == ref[i]["pairs"]
+    p.free()
+
+
+@pytest.mark.parametrize("tag", ["e2e_tiled", "e2e_mixed", "e2e_k25"])
+def test_sam_of_reference_contigs(ctx, tag):
+    """a-10: map the reference's own final contigs and reproduce its SAM body byte for byte."""
+    from vdjer_amd import api
+    c = G.Case(tag)
+    p = _load_index(ctx, c.pool)
+    fa = G.text(f"{tag}.contigs.fa.gz").splitlines()
+    ids = [fa[i][1:] for i in range(0, len(fa), 2)]
+    seqs = [fa[i + 1] for i in range(0, len(fa), 2)]
+    offs, pairs = ctx.map_emit(seqs)
+    body = api.sam_text((c.pool.primary, c.pool.secondary), c.pool.names(), ids, offs, pairs, c.pool.rl)
+    head = "@HD\tVN:1.4\tSO:unsorted\n" + "".join(f"@SQ\tSN:{i}\tLN:{len(s)}\n" for i, s in zip(ids, seqs))
+    assert head + body == G.text(f"{tag}.sam.gz")
+    p.free()
+
+
+def test_window_score_vs_oracle_seeded(ctx):
+    """Deeper pool, every clone window plus shifted/mutated ones, three parameter sets."""
+    from oracle import oracle
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(8, seed=900)
+    pool = synth.make_reads(rep, 30000, noise_frac=0.1, seed=12)
+    ix = oracle.ReadIndex(pool)
+    p = _load_index(ctx, pool)
+    wins = []
+    for w in rep.windows():
+        if w is None:
+            continue
+        wins += [w, w[::-1], synth.revcomp(w)]
+    for t in rep.clones:
+        for s in (0, 7, 40, 100):
+            wins.append(t[s:s + 486])
+    for ins, rs, ms, fl in ((175, 35, 48, 1), (160, 30, 60, 2), (175, 35, 48, 0), (230, 35, 48, 1)):
+        valid, npairs = ctx.window_score(wins, ins, rs=rs, ms=ms, floor=fl)
+        for i, w in enumerate(wins):
+            pairs, starts = ix.quick_map(w)
+            assert int(npairs[i]) == len(pairs)
+            exp = 1 if fl == 0 else ix.coverage_is_valid(starts, len(w), ins, rs=rs, ms=ms, floor=fl)
+            assert int(valid[i]) == exp, (i, ins, rs, ms, fl)
+    p.free()

@@ -1,0 +1,92 @@
+"""ctypes loader of vdjer_amd/libvdjx.so (the HIP hot path).  There is no CPU fallback: if the library is
+missing or cannot be loaded this raises, loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvdjx.so")
+_lib = None
+
+# every symbol include/vdjx.h declares
+SYMBOLS = [
+    "vdjx_last_error", "vdjx_version", "vdjx_init", "vdjx_shutdown", "vdjx_sync",
+    "vdjx_pool_load", "vdjx_pool_load_device", "vdjx_pool_records", "vdjx_pool_free",
+    "vdjx_anchor_sets_load", "vdjx_anchor_probe",
+    "vdjx_kmer_build", "vdjx_graph_nodes", "vdjx_graph_pre_nodes", "vdjx_graph_export", "vdjx_graph_free",
+    "vdjx_vregion_load", "vdjx_root_score",
+    "vdjx_read_index_build", "vdjx_window_score", "vdjx_map_emit",
+    "vdjx_profile_enable", "vdjx_profile_reset", "vdjx_profile_count", "vdjx_profile_get",
+]
+
+
+class VdjxError(RuntimeError):
+    pass
+
+
+class CovParams(C.Structure):
+    _fields_ = [("eval_start", C.c_int), ("eval_stop", C.c_int), ("read_span", C.c_int), ("mate_span", C.c_int),
+                ("insert_low", C.c_int), ("insert_high", C.c_int), ("floor", C.c_int)]
+
+
+class Pair(C.Structure):
+    _fields_ = [("pair_id", C.c_uint32), ("rec1", C.c_uint32), ("rec2", C.c_uint32),
+                ("pos1", C.c_int16), ("pos2", C.c_int16), ("insert", C.c_int16),
+                ("rc1", C.c_uint8), ("rc2", C.c_uint8)]
+
+
+def build() -> str:
+    """Compile libvdjx.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VdjxError(f"{LIB_PATH} is missing: build it with `make -C vdjer_amd/csrc` "
+                        "(there is no CPU fallback for the hot path)")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i32, u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
+    L.vdjx_last_error.restype = C.c_char_p
+    L.vdjx_version.restype = C.c_char_p
+    L.vdjx_init.argtypes = [i32, C.POINTER(vp)]
+    L.vdjx_shutdown.argtypes = [vp]
+    L.vdjx_shutdown.restype = None
+    L.vdjx_sync.argtypes = [vp]
+    L.vdjx_pool_load.argtypes = [vp, vp, sz, vp, sz, i32, C.POINTER(vp)]
+    L.vdjx_pool_load_device.argtypes = [vp, vp, sz, vp, sz, i32, C.POINTER(vp)]
+    L.vdjx_pool_records.argtypes = [vp]
+    L.vdjx_pool_records.restype = sz
+    L.vdjx_pool_free.argtypes = [vp]
+    L.vdjx_pool_free.restype = None
+    L.vdjx_anchor_sets_load.argtypes = [vp, vp, sz, vp, sz]
+    L.vdjx_anchor_probe.argtypes = [vp, C.c_char_p, i32, vp, vp]
+    L.vdjx_kmer_build.argtypes = [vp, vp, i32, i32, i32, C.POINTER(vp)]
+    L.vdjx_graph_nodes.argtypes = [vp]
+    L.vdjx_graph_nodes.restype = sz
+    L.vdjx_graph_pre_nodes.argtypes = [vp]
+    L.vdjx_graph_pre_nodes.restype = sz
+    L.vdjx_graph_export.argtypes = [vp] + [vp] * 10
+    L.vdjx_graph_free.argtypes = [vp]
+    L.vdjx_graph_free.restype = None
+    L.vdjx_vregion_load.argtypes = [vp, C.POINTER(C.c_char_p), sz, i32]
+    L.vdjx_root_score.argtypes = [vp, C.c_char_p, sz, i32, i32, vp]
+    L.vdjx_read_index_build.argtypes = [vp, vp, vp, vp, vp, vp, u32]
+    L.vdjx_window_score.argtypes = [vp, C.c_char_p, sz, i32, C.POINTER(CovParams), vp, vp]
+    L.vdjx_map_emit.argtypes = [vp, C.c_char_p, sz, i32, vp, vp]
+    L.vdjx_profile_enable.argtypes = [vp, i32]
+    L.vdjx_profile_reset.argtypes = [vp]
+    L.vdjx_profile_count.argtypes = [vp]
+    L.vdjx_profile_get.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise VdjxError(f"{what or 'vdjx'} failed ({rc}): {lib().vdjx_last_error().decode(errors='replace')}")

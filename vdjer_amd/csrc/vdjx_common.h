@@ -1,0 +1,141 @@
+// vdjx_common.h -- shared host/device definitions of libvdjx (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/vdjx.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef unsigned __int128 u128;
+
+#define VDJX_WAVE 64
+
+// ----------------------------------------------------------------------------------------------
+// error plumbing
+// ----------------------------------------------------------------------------------------------
+void vdjx_set_error(const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                                            \
+	do {                                                                                         \
+		hipError_t e_ = (expr);                                                                  \
+		if (e_ != hipSuccess) {                                                                  \
+			vdjx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+			return VDJX_EHIP;                                                                    \
+		}                                                                                        \
+	} while (0)
+
+// ----------------------------------------------------------------------------------------------
+// host-side objects behind the opaque handles
+// ----------------------------------------------------------------------------------------------
+struct vdjx_prof_entry {
+	double ms = 0;
+	uint64_t launches = 0;
+};
+
+struct vdjx_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool profiling = false;
+	std::vector<std::string> prof_names;                 // insertion order
+	std::map<std::string, vdjx_prof_entry> prof;
+	struct pending_ev { std::string name; hipEvent_t a, b; };
+	std::vector<pending_ev> prof_pending;
+	// a-6 anchor bitmaps (2^32 bits each)
+	u32* d_vbits = nullptr;
+	u32* d_jbits = nullptr;
+	bool anchors_loaded = false;
+	// a-7 V-region index
+	char* d_vtext = nullptr;          // all lines concatenated
+	u32* d_line_off = nullptr;        // [n_lines+1]
+	u32* d_seed_code = nullptr;       // sorted vk-mer codes
+	u32* d_seed_pos = nullptr;        // position within its line
+	size_t n_lines = 0, n_seeds = 0;
+	int vk = 0;
+	std::vector<u32> h_line_off;
+	// a-8 read index
+	const vdjx_pool* ri_pool = nullptr;
+	u32* d_ri_slots = nullptr;        // hash slot -> class id + 1
+	u32 ri_nslots = 0;
+	u32* d_ri_rep = nullptr;          // class -> representative record
+	u32* d_ri_start = nullptr;        // class -> CSR start [ncls+1]
+	u32* d_ri_recs = nullptr;         // CSR: records in registration order
+	u32* d_pair_id = nullptr;
+	uint8_t* d_read_num = nullptr;
+	uint8_t* d_is_rc = nullptr;
+	u32* d_pair_r2 = nullptr;         // pair -> as-is record of read 2 (or ~0u)
+	u32 n_pairs = 0, n_classes = 0;
+};
+
+struct vdjx_pool {
+	vdjx_ctx* ctx = nullptr;
+	size_t n_primary = 0, n_records = 0;
+	int rl = 0;
+	int qstride = 0;
+	u64* d_bases = nullptr;      // [R][2]  (hi, lo) of the 2*rl-bit read, first base most significant
+	u64* d_nmask = nullptr;      // [R] bit i = base i is not ACGT
+	u64* d_lowq = nullptr;       // [R] bit i = (uint8)(q-33) < 20
+	uint8_t* d_quals = nullptr;  // [R][qstride] Phred+33 characters
+};
+
+struct vdjx_graph {
+	int k = 0;
+	size_t n = 0, pre_nodes = 0;
+	std::vector<uint64_t> first_inst;
+	std::vector<uint32_t> gated_count, freq;
+	std::vector<uint8_t> has_v, has_j, to_deg, from_deg;
+	std::vector<uint32_t> to_ids, from_ids;
+	std::vector<u64> key_lo, key_hi;
+};
+
+// profiling: bracket a launch with events on the context's stream
+struct vdjx_prof_scope {
+	vdjx_ctx* c;
+	const char* name;
+	hipEvent_t a = nullptr, b = nullptr;
+	vdjx_prof_scope(vdjx_ctx* ctx, const char* nm);
+	~vdjx_prof_scope();
+};
+void vdjx_prof_collect(vdjx_ctx* ctx);
+
+// ----------------------------------------------------------------------------------------------
+// device helpers
+// ----------------------------------------------------------------------------------------------
+__host__ __device__ inline u64 vdjx_mix(u64 lo, u64 hi) {
+	u64 x = lo ^ (hi * 0x9E3779B97F4A7C15ull) ^ 0x2545F4914F6CDD1Dull;
+	x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+	x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+	x ^= x >> 32;
+	return x;
+}
+
+// k-mer at offset o of a packed read (first base most significant), as a 2k-bit integer
+__host__ __device__ inline void vdjx_kmer_at(u64 bhi, u64 blo, int rl, int k, int o, u64& khi, u64& klo) {
+	u128 b = ((u128) bhi << 64) | blo;
+	int sh = 2 * (rl - k - o);
+	u128 v = b >> sh;
+	if (k < 64) v &= (((u128) 1) << (2 * k)) - 1;
+	khi = (u64) (v >> 64);
+	klo = (u64) v;
+}
+
+__device__ inline u32 vdjx_wave_inc(u32* ctr, bool pred) {
+	// wave-aggregated counter increment (LDS or global); returns this lane's slot, undefined if !pred
+	u64 m = __ballot(pred);
+	u32 res = 0;
+	if (pred) {
+		int lane = __lane_id();
+		u32 rank = __popcll(m & ((1ull << lane) - 1ull));
+		int leader = __ffsll((long long) m) - 1;
+		u32 base = 0;
+		if (lane == leader) base = atomicAdd(ctr, (u32) __popcll(m));
+		base = __shfl(base, leader);
+		res = base + rank;
+	}
+	return res;
+}

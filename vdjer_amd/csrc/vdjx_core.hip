@@ -1,0 +1,258 @@
+// vdjx_core.hip -- context, error, profiling and pool-packing (K1) parts of libvdjx.
+#include "vdjx_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+// ----------------------------------------------------------------------------------------------
+// errors
+// ----------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void vdjx_set_error(const char* fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+}
+
+extern "C" const char* vdjx_last_error(void) { return g_err; }
+extern "C" const char* vdjx_version(void) { return "vdjx 0.1 (gfx950)"; }
+
+// ----------------------------------------------------------------------------------------------
+// context
+// ----------------------------------------------------------------------------------------------
+extern "C" int vdjx_init(int device, vdjx_ctx** out) {
+	if (!out) { vdjx_set_error("vdjx_init: out is NULL"); return VDJX_EINVAL; }
+	*out = nullptr;
+	int n = 0;
+	HIP_TRY(hipGetDeviceCount(&n));
+	if (device < 0 || device >= n) { vdjx_set_error("vdjx_init: device %d of %d", device, n); return VDJX_EINVAL; }
+	HIP_TRY(hipSetDevice(device));
+	vdjx_ctx* c = new vdjx_ctx();
+	c->device = device;
+	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+	if (e != hipSuccess) { delete c; vdjx_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return VDJX_EHIP; }
+	*out = c;
+	return VDJX_OK;
+}
+
+static void free_dev(void* p) { if (p) (void) hipFree(p); }
+
+extern "C" void vdjx_shutdown(vdjx_ctx* c) {
+	if (!c) return;
+	(void) hipSetDevice(c->device);
+	(void) hipStreamSynchronize(c->stream);
+	free_dev(c->d_vbits); free_dev(c->d_jbits);
+	free_dev(c->d_vtext); free_dev(c->d_line_off); free_dev(c->d_seed_code); free_dev(c->d_seed_pos);
+	free_dev(c->d_ri_slots); free_dev(c->d_ri_rep); free_dev(c->d_ri_start); free_dev(c->d_ri_recs);
+	free_dev(c->d_pair_id); free_dev(c->d_read_num); free_dev(c->d_is_rc); free_dev(c->d_pair_r2);
+	for (auto& p : c->prof_pending) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
+	(void) hipStreamDestroy(c->stream);
+	delete c;
+}
+
+extern "C" int vdjx_sync(vdjx_ctx* c) {
+	if (!c) { vdjx_set_error("vdjx_sync: ctx is NULL"); return VDJX_EINVAL; }
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return VDJX_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// profiling
+// ----------------------------------------------------------------------------------------------
+vdjx_prof_scope::vdjx_prof_scope(vdjx_ctx* ctx, const char* nm) : c(ctx), name(nm) {
+	if (!c->profiling) return;
+	if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+	(void) hipEventRecord(a, c->stream);
+}
+
+vdjx_prof_scope::~vdjx_prof_scope() {
+	if (!c->profiling || !a) return;
+	(void) hipEventRecord(b, c->stream);
+	c->prof_pending.push_back({name, a, b});
+}
+
+void vdjx_prof_collect(vdjx_ctx* c) {
+	for (auto& p : c->prof_pending) {
+		float ms = 0;
+		if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+			if (!c->prof.count(p.name)) c->prof_names.push_back(p.name);
+			auto& e = c->prof[p.name];
+			e.ms += ms;
+			e.launches++;
+		}
+		(void) hipEventDestroy(p.a);
+		(void) hipEventDestroy(p.b);
+	}
+	c->prof_pending.clear();
+}
+
+extern "C" int vdjx_profile_enable(vdjx_ctx* c, int on) {
+	if (!c) return VDJX_EINVAL;
+	vdjx_prof_collect(c);
+	c->profiling = on != 0;
+	return VDJX_OK;
+}
+
+extern "C" int vdjx_profile_reset(vdjx_ctx* c) {
+	if (!c) return VDJX_EINVAL;
+	vdjx_prof_collect(c);
+	c->prof.clear();
+	c->prof_names.clear();
+	return VDJX_OK;
+}
+
+extern "C" int vdjx_profile_count(vdjx_ctx* c) {
+	if (!c) return VDJX_EINVAL;
+	vdjx_prof_collect(c);
+	return (int) c->prof_names.size();
+}
+
+extern "C" int vdjx_profile_get(vdjx_ctx* c, int idx, const char** name, double* total_ms, uint64_t* launches) {
+	if (!c || idx < 0 || idx >= (int) c->prof_names.size()) { vdjx_set_error("vdjx_profile_get: bad index"); return VDJX_EINVAL; }
+	const std::string& nm = c->prof_names[idx];
+	if (name) *name = nm.c_str();
+	if (total_ms) *total_ms = c->prof[nm].ms;
+	if (launches) *launches = c->prof[nm].launches;
+	return VDJX_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// K1 pool_pack: ASCII records -> 2-bit bases + masks + quality bytes
+//   replaces the record parsing of A2:380-394 (layout written by bam_read.c:206-244)
+//   One 256-thread workgroup stages 256 records (<= 33 KB) through LDS with 16-byte coalesced
+//   loads; thread t then packs record t.  HBM-bound: reads 2*rl+1 B, writes 32 B + qstride per record.
+// ----------------------------------------------------------------------------------------------
+#define PACK_RECS 256
+
+__global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restrict__ ascii, size_t n_rec, int rl, size_t rec0,
+                                                         u64* __restrict__ bases, u64* __restrict__ nmask,
+                                                         u64* __restrict__ lowq, uint8_t* __restrict__ quals, int qstride,
+                                                         u32* __restrict__ bad_strand) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const int reclen = 2 * rl + 1;
+	const size_t first = (size_t) blockIdx.x * PACK_RECS;
+	const size_t nhere = n_rec - first < PACK_RECS ? n_rec - first : PACK_RECS;
+	const size_t bytes = nhere * (size_t) reclen;
+	const uint8_t* src = ascii + first * (size_t) reclen;       // 16-byte aligned: 256*reclen is a multiple of 16
+	const size_t nvec = bytes / 16;
+	for (size_t v = threadIdx.x; v < nvec; v += PACK_RECS)
+		((uint4*) lds)[v] = ((const uint4*) src)[v];
+	for (size_t b = nvec * 16 + threadIdx.x; b < bytes; b += PACK_RECS) lds[b] = src[b];
+	__syncthreads();
+	if (threadIdx.x >= nhere) return;
+	const uint8_t* r = lds + (size_t) threadIdx.x * reclen;
+	if (r[0] != '0') atomicAdd(bad_strand, 1u);   // A2:383-391; the reference only ever writes '0' (bam_read.c:219,231)
+	u128 b = 0;
+	u64 nm = 0, lq = 0;
+	for (int i = 0; i < rl; i++) {
+		uint8_t ch = r[1 + i];
+		u32 code;
+		switch (ch) {                       // seq_to_kmer.c:6-29: A0 T1 C2 G3
+		case 'A': code = 0; break;
+		case 'T': code = 1; break;
+		case 'C': code = 2; break;
+		case 'G': code = 3; break;
+		default: code = 0; nm |= 1ull << i; break;
+		}
+		b = (b << 2) | code;
+		uint8_t q = (uint8_t) (r[1 + rl + i] - 33);             // phred33(), A2:150-152
+		if (q < 20) lq |= 1ull << i;                             // MIN_BASE_QUALITY, A2:76,252
+	}
+	const size_t g = rec0 + first + threadIdx.x;
+	bases[2 * g] = (u64) (b >> 64);
+	bases[2 * g + 1] = (u64) b;
+	nmask[g] = nm;
+	lowq[g] = lq;
+	uint8_t* qd = quals + g * (size_t) qstride;
+	for (int i = 0; i < rl; i++) qd[i] = r[1 + rl + i];
+	for (int i = rl; i < qstride; i++) qd[i] = 33;
+}
+
+static int pool_pack_device(vdjx_ctx* c, const uint8_t* d_primary, size_t n_primary,
+                            const uint8_t* d_secondary, size_t n_secondary, int rl, vdjx_pool** out) {
+	*out = nullptr;
+	if (rl < 1 || rl > VDJX_MAX_READ_LEN) { vdjx_set_error("read length %d outside [1,%d]", rl, VDJX_MAX_READ_LEN); return VDJX_ELIMIT; }
+	size_t R = n_primary + n_secondary;
+	if (R >= (1ull << 31)) { vdjx_set_error("too many records for one GPU: %zu", R); return VDJX_ELIMIT; }
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_pool* p = new vdjx_pool();
+	p->ctx = c; p->n_primary = n_primary; p->n_records = R; p->rl = rl;
+	p->qstride = (rl + 15) / 16 * 16;
+	size_t Ra = R ? R : 1;
+	u32* d_bad = nullptr;
+	hipError_t e;
+	if ((e = hipMalloc(&p->d_bases, Ra * 16)) != hipSuccess || (e = hipMalloc(&p->d_nmask, Ra * 8)) != hipSuccess ||
+	    (e = hipMalloc(&p->d_lowq, Ra * 8)) != hipSuccess || (e = hipMalloc(&p->d_quals, Ra * (size_t) p->qstride)) != hipSuccess ||
+	    (e = hipMalloc(&d_bad, 4)) != hipSuccess) {
+		vdjx_set_error("pool alloc: %s", hipGetErrorString(e));
+		vdjx_pool_free(p);
+		return VDJX_EHIP;
+	}
+	(void) hipMemsetAsync(d_bad, 0, 4, c->stream);
+	size_t lds = (size_t) PACK_RECS * (2 * rl + 1) + 16;
+	{
+		vdjx_prof_scope ps(c, "k_pool_pack");
+		if (n_primary)
+			hipLaunchKernelGGL(k_pool_pack, dim3((unsigned) ((n_primary + PACK_RECS - 1) / PACK_RECS)), dim3(PACK_RECS), lds, c->stream,
+			                   d_primary, n_primary, rl, (size_t) 0, p->d_bases, p->d_nmask, p->d_lowq, p->d_quals, p->qstride, d_bad);
+		if (n_secondary)
+			hipLaunchKernelGGL(k_pool_pack, dim3((unsigned) ((n_secondary + PACK_RECS - 1) / PACK_RECS)), dim3(PACK_RECS), lds, c->stream,
+			                   d_secondary, n_secondary, rl, n_primary, p->d_bases, p->d_nmask, p->d_lowq, p->d_quals, p->qstride, d_bad);
+	}
+	u32 bad = 0;
+	e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e == hipSuccess) e = hipGetLastError();
+	(void) hipFree(d_bad);
+	if (e != hipSuccess) { vdjx_set_error("pool pack: %s", hipGetErrorString(e)); vdjx_pool_free(p); return VDJX_EHIP; }
+	if (bad) {
+		// build_pre_graph prints "Initial char in input invalid" and exits (A2:383-391); we return an error
+		vdjx_set_error("pool: %u records do not start with the '0' strand byte", bad);
+		vdjx_pool_free(p);
+		return VDJX_EINVAL;
+	}
+	*out = p;
+	return VDJX_OK;
+}
+
+extern "C" int vdjx_pool_load_device(vdjx_ctx* c, const uint8_t* d_primary, size_t n_primary,
+                                     const uint8_t* d_secondary, size_t n_secondary, int rl, vdjx_pool** out) {
+	if (!c || !out) { vdjx_set_error("vdjx_pool_load_device: NULL argument"); return VDJX_EINVAL; }
+	if ((n_primary && !d_primary) || (n_secondary && !d_secondary)) { vdjx_set_error("vdjx_pool_load_device: NULL pool"); return VDJX_EINVAL; }
+	if (((uintptr_t) d_primary & 15) || ((uintptr_t) d_secondary & 15)) { vdjx_set_error("device pools must be 16-byte aligned"); return VDJX_EINVAL; }
+	return pool_pack_device(c, d_primary, n_primary, d_secondary, n_secondary, rl, out);
+}
+
+extern "C" int vdjx_pool_load(vdjx_ctx* c, const uint8_t* primary, size_t n_primary,
+                              const uint8_t* secondary, size_t n_secondary, int rl, vdjx_pool** out) {
+	if (!c || !out) { vdjx_set_error("vdjx_pool_load: NULL argument"); return VDJX_EINVAL; }
+	if ((n_primary && !primary) || (n_secondary && !secondary)) { vdjx_set_error("vdjx_pool_load: NULL pool"); return VDJX_EINVAL; }
+	if (rl < 1 || rl > VDJX_MAX_READ_LEN) { vdjx_set_error("read length %d outside [1,%d]", rl, VDJX_MAX_READ_LEN); return VDJX_ELIMIT; }
+	HIP_TRY(hipSetDevice(c->device));
+	size_t reclen = 2 * (size_t) rl + 1;
+	uint8_t *dp = nullptr, *ds = nullptr;
+	if (n_primary) {
+		HIP_TRY(hipMalloc(&dp, n_primary * reclen + 16));
+		HIP_TRY(hipMemcpyAsync(dp, primary, n_primary * reclen, hipMemcpyHostToDevice, c->stream));
+	}
+	if (n_secondary) {
+		HIP_TRY(hipMalloc(&ds, n_secondary * reclen + 16));
+		HIP_TRY(hipMemcpyAsync(ds, secondary, n_secondary * reclen, hipMemcpyHostToDevice, c->stream));
+	}
+	int rc = pool_pack_device(c, dp, n_primary, ds, n_secondary, rl, out);
+	free_dev(dp);
+	free_dev(ds);
+	return rc;
+}
+
+extern "C" size_t vdjx_pool_records(const vdjx_pool* p) { return p ? p->n_records : 0; }
+
+extern "C" void vdjx_pool_free(vdjx_pool* p) {
+	if (!p) return;
+	(void) hipSetDevice(p->ctx->device);
+	free_dev(p->d_bases); free_dev(p->d_nmask); free_dev(p->d_lowq); free_dev(p->d_quals);
+	delete p;
+}

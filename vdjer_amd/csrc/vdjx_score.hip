@@ -1,0 +1,753 @@
+// vdjx_score.hip -- the batched scorers (SURVEY §8a rows a-7 ... a-10).
+//
+//   K7  k_seed_count / k_root_dp      root (V-region homology) scorer         seq_score.c:92-156
+//   K8  k_ri_insert + host CSR        read index                              quick_map3.c:126-149
+//       k_window_score                read->window mapper + coverage test     quick_map3.c:188-266, coverage.c:10-130
+//   K10 k_map_emit                    mapped pairs of final contigs in order  quick_map3.c:152-181, 311-340
+//
+// None of this is a dense contraction: the DP is a max-plus recurrence on int8 cells, the mapper is
+// exact-match hashing, the validator is counting.  They run on the VALU/LDS; MFMA does not apply.
+#include "vdjx_common.h"
+
+#include <algorithm>
+#include <numeric>
+#include <string.h>
+
+#define NONE32 0xFFFFFFFFu
+
+namespace {
+struct DevBuf {
+	std::vector<void*> ptrs;
+	~DevBuf() { for (void* p : ptrs) if (p) (void) hipFree(p); }
+	template <typename T> hipError_t alloc(T** out, size_t n) {
+		void* p = nullptr;
+		hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
+		if (e == hipSuccess) ptrs.push_back(p);
+		*out = (T*) p;
+		return e;
+	}
+};
+
+template <typename T> void free_set(T*& p) { if (p) (void) hipFree(p); p = nullptr; }
+}  // namespace
+
+// ==============================================================================================
+// a-7 root scorer
+// ==============================================================================================
+__host__ __device__ inline int base_code(char ch) {
+	switch (ch) {
+	case 'A': return 0;
+	case 'T': return 1;
+	case 'C': return 2;
+	case 'G': return 3;
+	default: return -1;
+	}
+}
+
+extern "C" int vdjx_vregion_load(vdjx_ctx* c, const char* const* lines, size_t n_lines, int vk) {
+	if (!c || (n_lines && !lines)) { vdjx_set_error("vdjx_vregion_load: NULL argument"); return VDJX_EINVAL; }
+	if (vk < 2 || vk > 16) { vdjx_set_error("vregion k-mer size %d outside [2,16]", vk); return VDJX_ELIMIT; }
+	HIP_TRY(hipSetDevice(c->device));
+	free_set(c->d_vtext); free_set(c->d_line_off); free_set(c->d_seed_code); free_set(c->d_seed_pos);
+	std::vector<u32> off(n_lines + 1, 0);
+	std::string text;
+	for (size_t i = 0; i < n_lines; i++) {
+		text += lines[i];
+		off[i + 1] = (u32) text.size();
+	}
+	// seq_score.c:36-48: every vk-mer start i < len - vk of every line, keyed by content; all lines share the map
+	std::vector<std::pair<u32, u32>> seeds;
+	for (size_t li = 0; li < n_lines; li++) {
+		const char* s = text.data() + off[li];
+		long len = (long) (off[li + 1] - off[li]);
+		for (long i = 0; i < len - vk; i++) {
+			u32 code = 0;
+			bool ok = true;
+			for (int j = 0; j < vk; j++) {
+				int b = base_code(s[i + j]);
+				if (b < 0) { ok = false; break; }
+				code = (code << 2) | (u32) b;
+			}
+			if (ok) seeds.push_back({code, (u32) i});
+		}
+	}
+	std::sort(seeds.begin(), seeds.end());
+	seeds.erase(std::unique(seeds.begin(), seeds.end()), seeds.end());
+	std::vector<u32> sc(seeds.size()), sp(seeds.size());
+	for (size_t i = 0; i < seeds.size(); i++) { sc[i] = seeds[i].first; sp[i] = seeds[i].second; }
+	HIP_TRY(hipMalloc(&c->d_vtext, text.size() + 16));
+	HIP_TRY(hipMalloc(&c->d_line_off, off.size() * 4));
+	HIP_TRY(hipMalloc(&c->d_seed_code, sc.size() * 4 + 4));
+	HIP_TRY(hipMalloc(&c->d_seed_pos, sp.size() * 4 + 4));
+	HIP_TRY(hipMemcpy(c->d_vtext, text.data(), text.size(), hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(c->d_line_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+	if (!sc.empty()) {
+		HIP_TRY(hipMemcpy(c->d_seed_code, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(c->d_seed_pos, sp.data(), sp.size() * 4, hipMemcpyHostToDevice));
+	}
+	c->n_lines = n_lines;
+	c->n_seeds = sc.size();
+	c->vk = vk;
+	c->h_line_off = off;
+	return VDJX_OK;
+}
+
+__device__ inline u32 lower_bound_u32(const u32* __restrict__ a, u32 n, u32 key) {
+	u32 lo = 0, hi = n;
+	while (lo < hi) {
+		u32 mid = (lo + hi) >> 1;
+		if (a[mid] < key) lo = mid + 1; else hi = mid;
+	}
+	return lo;
+}
+
+// per (root, seed offset): the range of index hits (seq_score.c:124-131)
+__global__ void k_seed_count(const char* __restrict__ kmers, u32 n, int k, int vk, const u32* __restrict__ seed_code, u32 n_seeds,
+                             u32* __restrict__ hit_lo, u32* __restrict__ hit_cnt) {
+	const u32 stop = (u32) (k - vk);
+	u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= n * stop) return;
+	const u32 root = w / stop, i = w - root * stop;
+	const char* s = kmers + (size_t) root * k + i;
+	u32 code = 0;
+	bool ok = true;
+	for (int j = 0; j < vk; j++) {
+		int b = base_code(s[j]);
+		if (b < 0) ok = false;
+		code = (code << 2) | (u32) (b & 3);
+	}
+	u32 lo = 0, cnt = 0;
+	if (ok) {
+		lo = lower_bound_u32(seed_code, n_seeds, code);
+		u32 hi = lo;
+		while (hi < n_seeds && seed_code[hi] == code) hi++;
+		cnt = hi - lo;
+	}
+	hit_lo[w] = lo;
+	hit_cnt[w] = cnt;
+}
+
+// one thread per (root, seed offset, hit): for every line run the (k+1) x (2k+1) DP (seq_score.c:76-116) on
+// root x line[start, start+2k), start as seq_score.c:139-146.  int8 cells, match +1 / mismatch 0 / gap -1,
+// first row and column 0; out[root] = 1 as soon as any cell >= threshold.
+#define DP_THREADS 128
+__global__ __launch_bounds__(DP_THREADS) void k_root_dp(const char* __restrict__ kmers, int k, int threshold,
+                                                        const u32* __restrict__ hit_lo, const u32* __restrict__ hit_pre,
+                                                        u32 n_groups, u32 stop, u32 total, const u32* __restrict__ seed_pos,
+                                                        const char* __restrict__ vtext, const u32* __restrict__ line_off, u32 n_lines,
+                                                        uint8_t* __restrict__ out) {
+	__shared__ signed char col[(VDJX_MAX_KMER + 1) * DP_THREADS];
+	__shared__ char qs[VDJX_MAX_KMER * DP_THREADS];
+	const u32 tid = threadIdx.x;
+	const u32 w = blockIdx.x * DP_THREADS + tid;
+	if (w >= total) return;
+	// group = (root, seed offset) holding work item w: last group with hit_pre[g] <= w
+	u32 lo = 0, hi = n_groups;
+	while (hi - lo > 1) {
+		u32 mid = (lo + hi) >> 1;
+		if (hit_pre[mid] <= w) lo = mid; else hi = mid;
+	}
+	const u32 g = lo;
+	const u32 root = g / stop;
+	if (out[root]) return;
+	const int pos = (int) seed_pos[hit_lo[g] + (w - hit_pre[g])];
+	for (int r = 0; r < k; r++) qs[r * DP_THREADS + tid] = kmers[(size_t) root * k + r];
+	for (u32 li = 0; li < n_lines; li++) {
+		const int len = (int) (line_off[li + 1] - line_off[li]);
+		int start = pos - k;
+		if (start < 0) start = 0;
+		if (start >= len - 2 * k) start = len - 2 * k - 1;
+		const char* ref = vtext + line_off[li] + start;
+		for (int r = 0; r <= k; r++) col[r * DP_THREADS + tid] = 0;
+		for (int cidx = 1; cidx <= 2 * k; cidx++) {
+			const char rc = ref[cidx - 1];
+			int diag = 0, up = 0;
+			for (int r = 1; r <= k; r++) {
+				const int left = col[r * DP_THREADS + tid];
+				int v = left - 1;
+				v = v > up - 1 ? v : up - 1;
+				const int d = diag + (qs[(r - 1) * DP_THREADS + tid] == rc ? 1 : 0);
+				v = v > d ? v : d;
+				diag = left;
+				up = v;
+				col[r * DP_THREADS + tid] = (signed char) v;
+				if (v >= threshold) { out[root] = 1; return; }
+			}
+		}
+	}
+}
+
+extern "C" int vdjx_root_score(vdjx_ctx* c, const char* kmers, size_t n, int k, int threshold, uint8_t* out) {
+	if (!c || (n && (!kmers || !out))) { vdjx_set_error("vdjx_root_score: NULL argument"); return VDJX_EINVAL; }
+	if (!c->d_vtext) { vdjx_set_error("vdjx_root_score: call vdjx_vregion_load first"); return VDJX_ESTATE; }
+	if (k < 1 || k > VDJX_MAX_KMER) { vdjx_set_error("k=%d outside [1,%d]", k, VDJX_MAX_KMER); return VDJX_ELIMIT; }
+	if (n == 0) return VDJX_OK;
+	for (size_t li = 0; li < c->n_lines; li++) {
+		if ((long) (c->h_line_off[li + 1] - c->h_line_off[li]) <= 2L * k) {
+			vdjx_set_error("v_region line %zu is not longer than 2k=%d (the reference reads out of bounds there)", li, 2 * k);
+			return VDJX_EINVAL;
+		}
+	}
+	memset(out, 0, n);
+	const int stop = k - c->vk;
+	if (stop <= 0 || c->n_seeds == 0) return VDJX_OK;          // no seed can hit: score_seq returns 0
+	if (n * (size_t) stop >= (1ull << 31)) { vdjx_set_error("too many roots in one call"); return VDJX_ELIMIT; }
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t st = c->stream;
+	DevBuf db;
+	char* d_k;
+	u32 *d_lo, *d_cnt, *d_pre;
+	uint8_t* d_out;
+	const u32 ng = (u32) (n * stop);
+	HIP_TRY(db.alloc(&d_k, n * k));
+	HIP_TRY(db.alloc(&d_lo, ng));
+	HIP_TRY(db.alloc(&d_cnt, ng));
+	HIP_TRY(db.alloc(&d_pre, ng + 1));
+	HIP_TRY(db.alloc(&d_out, n));
+	HIP_TRY(hipMemcpyAsync(d_k, kmers, n * k, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemsetAsync(d_out, 0, n, st));
+	{
+		vdjx_prof_scope ps(c, "k_seed_count");
+		hipLaunchKernelGGL(k_seed_count, dim3((ng + 255) / 256), dim3(256), 0, st, d_k, (u32) n, k, c->vk, c->d_seed_code, (u32) c->n_seeds, d_lo, d_cnt);
+	}
+	std::vector<u32> cnt(ng), pre(ng + 1);
+	HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt, (size_t) ng * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	u64 run = 0;
+	for (u32 i = 0; i < ng; i++) { pre[i] = (u32) run; run += cnt[i]; }
+	pre[ng] = (u32) run;
+	if (run >= (1ull << 31)) { vdjx_set_error("too many seed hits in one call (%llu)", (unsigned long long) run); return VDJX_ELIMIT; }
+	if (threshold <= 0) {
+		// cells of row/column 0 are 0 and are tested too (seq_score.c:103-112): any seed hit accepts
+		for (size_t r = 0; r < n; r++) out[r] = pre[(r + 1) * stop] > pre[r * stop];
+		return VDJX_OK;
+	}
+	if (run) {
+		HIP_TRY(hipMemcpyAsync(d_pre, pre.data(), (size_t) (ng + 1) * 4, hipMemcpyHostToDevice, st));
+		vdjx_prof_scope ps(c, "k_root_dp");
+		hipLaunchKernelGGL(k_root_dp, dim3((unsigned) ((run + DP_THREADS - 1) / DP_THREADS)), dim3(DP_THREADS), 0, st, d_k, k, threshold,
+		                   d_lo, d_pre, ng, (u32) stop, (u32) run, c->d_seed_pos, c->d_vtext, c->d_line_off, (u32) c->n_lines, d_out);
+	}
+	HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	return VDJX_OK;
+}
+
+// ==============================================================================================
+// a-8 read index
+// ==============================================================================================
+// Exact-match index: read sequence -> records.  Device part: open-addressing table whose slots name
+// a representative record (the key bytes live in the immutable packed pool, so claiming a slot is
+// one 32-bit CAS).  Records holding an 'N' are left out: contigs are ACGT-only and can never match them.
+__global__ void k_ri_insert(const u64* __restrict__ bases, const u64* __restrict__ nmask, u32 R,
+                            u32* __restrict__ slots, u32 mask, u32* __restrict__ rec_slot) {
+	u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= R) return;
+	if (nmask[r]) { rec_slot[r] = NONE32; return; }
+	const ulonglong2 b = ((const ulonglong2*) bases)[r];
+	u32 slot = (u32) (vdjx_mix(b.y, b.x) >> 17) & mask;
+	for (;;) {
+		u32 cur = slots[slot];
+		if (cur == 0) {
+			cur = atomicCAS(&slots[slot], 0u, r + 1);
+			if (cur == 0) break;
+		}
+		const ulonglong2 o = ((const ulonglong2*) bases)[cur - 1];
+		if (o.x == b.x && o.y == b.y) break;
+		slot = (slot + 1) & mask;
+	}
+	rec_slot[r] = slot;
+}
+
+extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const uint32_t* pair_id,
+                                     const uint8_t* read_num, const uint8_t* is_rc, const uint32_t* reg_rank, uint32_t n_pairs) {
+	if (!c || !pool || !pair_id || !read_num || !is_rc || !reg_rank) { vdjx_set_error("vdjx_read_index_build: NULL argument"); return VDJX_EINVAL; }
+	if (pool->ctx != c) { vdjx_set_error("vdjx_read_index_build: pool belongs to another context"); return VDJX_EINVAL; }
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t st = c->stream;
+	const u32 R = (u32) pool->n_records;
+	free_set(c->d_ri_slots); free_set(c->d_ri_rep); free_set(c->d_ri_start); free_set(c->d_ri_recs);
+	free_set(c->d_pair_id); free_set(c->d_read_num); free_set(c->d_is_rc); free_set(c->d_pair_r2);
+	c->ri_pool = nullptr;
+	for (u32 r = 0; r < R; r++) {
+		if (pair_id[r] >= n_pairs) { vdjx_set_error("pair_id[%u]=%u >= n_pairs=%u", r, pair_id[r], n_pairs); return VDJX_EINVAL; }
+	}
+	u32 mask = 1023;
+	while ((size_t) mask + 1 < (size_t) R * 2) mask = mask * 2 + 1;
+	DevBuf db;
+	u32* d_rec_slot;
+	HIP_TRY(hipMalloc(&c->d_ri_slots, ((size_t) mask + 1) * 4));
+	HIP_TRY(db.alloc(&d_rec_slot, R));
+	HIP_TRY(hipMemsetAsync(c->d_ri_slots, 0, ((size_t) mask + 1) * 4, st));
+	if (R) {
+		vdjx_prof_scope ps(c, "k_ri_insert");
+		hipLaunchKernelGGL(k_ri_insert, dim3((R + 255) / 256), dim3(256), 0, st, pool->d_bases, pool->d_nmask, R, c->d_ri_slots, mask, d_rec_slot);
+	}
+	std::vector<u32> rec_slot(R);
+	HIP_TRY(hipMemcpyAsync(rec_slot.data(), d_rec_slot, (size_t) R * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	// host: classes in first-registration order, members in registration order (add_read_info, quick_map3.c:126-149)
+	std::vector<u32> order(R);
+	std::iota(order.begin(), order.end(), 0u);
+	std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return reg_rank[a] < reg_rank[b]; });
+	std::vector<u32> slot_cls((size_t) mask + 1, NONE32), cls_cnt, rep;
+	std::vector<u32> rec_cls(R, NONE32);
+	for (u32 i = 0; i < R; i++) {
+		const u32 r = order[i];
+		const u32 s = rec_slot[r];
+		if (s == NONE32) continue;
+		if (slot_cls[s] == NONE32) { slot_cls[s] = (u32) cls_cnt.size(); cls_cnt.push_back(0); rep.push_back(r); }
+		rec_cls[r] = slot_cls[s];
+		cls_cnt[slot_cls[s]]++;
+	}
+	const u32 ncls = (u32) cls_cnt.size();
+	std::vector<u32> start(ncls + 1, 0), recs;
+	for (u32 i = 0; i < ncls; i++) start[i + 1] = start[i] + cls_cnt[i];
+	recs.resize(start[ncls] ? start[ncls] : 1);
+	std::vector<u32> fill(start.begin(), start.end() - 1);
+	for (u32 i = 0; i < R; i++) {
+		const u32 r = order[i];
+		if (rec_cls[r] != NONE32) recs[fill[rec_cls[r]]++] = r;
+	}
+	// slot -> class id + 1
+	std::vector<u32> slots((size_t) mask + 1, 0);
+	for (size_t s = 0; s <= mask; s++) if (slot_cls[s] != NONE32) slots[s] = slot_cls[s] + 1;
+	// read-2 records of every pair in registration order (at most two: as-is and reverse complement, bam_read.c:206-244)
+	std::vector<u32> pr2((size_t) n_pairs * 2 + 2, NONE32);
+	for (u32 i = 0; i < R; i++) {
+		const u32 r = order[i];
+		if (read_num[r] == 1) continue;
+		const u32 p = pair_id[r];
+		if (pr2[2 * (size_t) p] == NONE32) pr2[2 * (size_t) p] = r;
+		else if (pr2[2 * (size_t) p + 1] == NONE32) pr2[2 * (size_t) p + 1] = r;
+		else { vdjx_set_error("pair %u has more than two read-2 records (read names must be unique per pair)", p); return VDJX_EINVAL; }
+	}
+	HIP_TRY(hipMalloc(&c->d_ri_rep, ((size_t) ncls + 1) * 4));
+	HIP_TRY(hipMalloc(&c->d_ri_start, ((size_t) ncls + 1) * 4));
+	HIP_TRY(hipMalloc(&c->d_ri_recs, recs.size() * 4));
+	HIP_TRY(hipMalloc(&c->d_pair_id, ((size_t) R + 1) * 4));
+	HIP_TRY(hipMalloc(&c->d_read_num, (size_t) R + 1));
+	HIP_TRY(hipMalloc(&c->d_is_rc, (size_t) R + 1));
+	HIP_TRY(hipMalloc(&c->d_pair_r2, pr2.size() * 4));
+	HIP_TRY(hipMemcpy(c->d_ri_slots, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
+	if (ncls) HIP_TRY(hipMemcpy(c->d_ri_rep, rep.data(), (size_t) ncls * 4, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(c->d_ri_start, start.data(), start.size() * 4, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(c->d_ri_recs, recs.data(), recs.size() * 4, hipMemcpyHostToDevice));
+	if (R) {
+		HIP_TRY(hipMemcpy(c->d_pair_id, pair_id, (size_t) R * 4, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(c->d_read_num, read_num, R, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(c->d_is_rc, is_rc, R, hipMemcpyHostToDevice));
+	}
+	HIP_TRY(hipMemcpy(c->d_pair_r2, pr2.data(), pr2.size() * 4, hipMemcpyHostToDevice));
+	c->ri_nslots = mask + 1;
+	c->n_pairs = n_pairs;
+	c->n_classes = ncls;
+	c->ri_pool = pool;
+	return VDJX_OK;
+}
+
+// ==============================================================================================
+// a-8/a-9/a-10 mapper core shared by k_window_score and k_map_emit
+// ==============================================================================================
+#define MAP_THREADS 512
+#define MAP_MAXOFF 1024          // window/contig length - rl  <= MAP_MAXOFF
+#define WT_SLOTS 2048            // LDS table: distinct rl-mers of the window -> last offset
+
+struct ReadIndexDev {
+	const u64* bases; const u64* nmask;
+	const u32* slots; u32 mask;
+	const u32* rep; const u32* start; const u32* recs;
+	const u32* pair_id; const uint8_t* read_num; const uint8_t* is_rc; const u32* pair_r2;
+	int rl;
+};
+
+struct MapLds {
+	u64 sub_hi[MAP_MAXOFF], sub_lo[MAP_MAXOFF];     // packed rl-mer at every offset
+	u32 cls[MAP_MAXOFF];                            // read class at the offset or NONE32
+	u32 hpre[MAP_MAXOFF + 1];                       // prefix of class sizes (hits enumerate in reference order)
+	u32 wt_rep[WT_SLOTS];                           // offset+1 of a representative
+	u32 wt_last[WT_SLOTS];                          // last offset with that rl-mer
+	u32 scan[MAP_THREADS];
+};
+
+// pack + classify every offset o in [0, len-rl) (quick_map3.c:200: the last offset is never looked at),
+// build the rl-mer -> last offset table, prefix the class sizes.  Returns the hit count H (all lanes).
+__device__ inline u32 map_prepare(MapLds& L, const ReadIndexDev& ix, const char* __restrict__ w, int len) {
+	const int rl = ix.rl;
+	const int noff = len - rl;
+	const u32 tid = threadIdx.x;
+	for (u32 i = tid; i < WT_SLOTS; i += MAP_THREADS) { L.wt_rep[i] = 0; L.wt_last[i] = 0; }
+	for (int o = tid; o < noff; o += MAP_THREADS) {
+		u128 b = 0;
+		bool ok = true;
+		for (int j = 0; j < rl; j++) {
+			int cde = base_code(w[o + j]);
+			if (cde < 0) ok = false;
+			b = (b << 2) | (u32) (cde & 3);
+		}
+		const u64 hi = (u64) (b >> 64), lo = (u64) b;
+		L.sub_hi[o] = hi; L.sub_lo[o] = lo;
+		u32 cls = NONE32;
+		if (ok) {
+			u32 slot = (u32) (vdjx_mix(lo, hi) >> 17) & ix.mask;
+			for (;;) {
+				const u32 v = ix.slots[slot];
+				if (!v) break;
+				const u32 rr = ix.rep[v - 1];
+				const ulonglong2 k = ((const ulonglong2*) ix.bases)[rr];
+				if (k.x == hi && k.y == lo) { cls = v - 1; break; }
+				slot = (slot + 1) & ix.mask;
+			}
+		} else {
+			L.sub_hi[o] = ~0ull;                    // can never equal a read (2*rl <= 128 bits, reads have no N here)
+		}
+		L.cls[o] = cls;
+		L.hpre[o] = cls != NONE32 ? ix.start[cls + 1] - ix.start[cls] : 0u;     // class size, prefixed below
+	}
+	__syncthreads();
+	// rl-mer -> last offset (needed for "read2[id] = m_info": the last writer wins, quick_map3.c:214)
+	for (int o = tid; o < noff; o += MAP_THREADS) {
+		const u64 hi = L.sub_hi[o], lo = L.sub_lo[o];
+		if (hi == ~0ull) continue;
+		u32 slot = (u32) vdjx_mix(lo, hi) & (WT_SLOTS - 1);
+		for (;;) {
+			u32 cur = L.wt_rep[slot];
+			if (cur == 0) {
+				cur = atomicCAS(&L.wt_rep[slot], 0u, (u32) o + 1);
+				if (cur == 0) cur = (u32) o + 1;
+			}
+			if (L.sub_hi[cur - 1] == hi && L.sub_lo[cur - 1] == lo) { atomicMax(&L.wt_last[slot], (u32) o + 1); break; }
+			slot = (slot + 1) & (WT_SLOTS - 1);
+		}
+	}
+	// class sizes -> exclusive prefix (serial over <= 1024 offsets by one wave is plenty)
+	__syncthreads();
+	if (tid == 0) {
+		u32 run = 0;
+		for (int o = 0; o < noff; o++) {
+			const u32 sz = L.hpre[o];
+			L.hpre[o] = run;
+			run += sz;
+		}
+		L.hpre[noff] = run;
+	}
+	__syncthreads();
+	return L.hpre[noff];
+}
+
+// last offset+1 at which the read `rec` occurs in the window, or 0
+__device__ inline u32 map_last_occurrence(const MapLds& L, const ReadIndexDev& ix, u32 rec) {
+	if (ix.nmask[rec]) return 0;
+	const ulonglong2 k = ((const ulonglong2*) ix.bases)[rec];
+	u32 slot = (u32) vdjx_mix(k.y, k.x) & (WT_SLOTS - 1);
+	for (;;) {
+		const u32 cur = L.wt_rep[slot];
+		if (cur == 0) return 0;
+		if (L.sub_hi[cur - 1] == k.x && L.sub_lo[cur - 1] == k.y) return L.wt_last[slot];
+		slot = (slot + 1) & (WT_SLOTS - 1);
+	}
+}
+
+struct Hit {
+	bool pair;          // a mapped pair (quick_map3.c:223-245)
+	u32 pair_id, rec1, rec2;
+	int pos1, pos2, insert;
+	uint8_t rc1, rc2;
+};
+
+// hit h (reference order: offset-major, registration order inside a class) -> mapped pair or not
+__device__ inline Hit map_eval_hit(const MapLds& L, const ReadIndexDev& ix, int noff, u32 h) {
+	Hit r;
+	r.pair = false;
+	// offset holding hit h: last o with hpre[o] <= h
+	int lo = 0, hi = noff;
+	while (hi - lo > 1) {
+		int mid = (lo + hi) >> 1;
+		if (L.hpre[mid] <= h) lo = mid; else hi = mid;
+	}
+	const int o = lo;
+	const u32 cl = L.cls[o];
+	const u32 rec = ix.recs[ix.start[cl] + (h - L.hpre[o])];
+	if (ix.read_num[rec] != 1) return r;            // read-2 instances only feed the read2 map
+	const u32 p = ix.pair_id[rec];
+	// read2[id]: among the pair's read-2 records the one written last = largest offset, then latest registration
+	const u32 ra = ix.pair_r2[2 * (size_t) p], rb = ix.pair_r2[2 * (size_t) p + 1];
+	u32 best = 0, brec = NONE32;
+	if (ra != NONE32) { u32 l = map_last_occurrence(L, ix, ra); if (l) { best = l; brec = ra; } }
+	if (rb != NONE32) { u32 l = map_last_occurrence(L, ix, rb); if (l && l >= best) { best = l; brec = rb; } }
+	if (brec == NONE32) return r;
+	const uint8_t rc1 = ix.is_rc[rec], rc2 = ix.is_rc[brec];
+	if (rc1 == rc2) return r;                       // quick_map3.c:227
+	const int pos1 = o + 1, pos2 = (int) best;
+	const int d = pos1 - pos2;
+	const int insert = (int) (short) ((d < 0 ? -d : d) + ix.rl);
+	if (insert < 50 || insert > 400) return r;      // MIN_INSERT / MAX_INSERT, quick_map3.c:23-24
+	r.pair = true;
+	r.pair_id = p; r.rec1 = rec; r.rec2 = brec;
+	r.pos1 = pos1; r.pos2 = pos2; r.insert = insert; r.rc1 = rc1; r.rc2 = rc2;
+	return r;
+}
+
+// ----------------------------------------------------------------------------------------------
+// K8+K9: one workgroup per window.  Scratch per workgroup: (len+1)^2 u32 "C[f][s]" = number of
+// start entries (first=f, second=s); turned into a summed-area table so that the mate-coverage test
+// of coverage.c:10-61 (recomputed from scratch per position there) becomes box sums.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MAP_THREADS) void k_window_score(ReadIndexDev ix, const char* __restrict__ windows, u32 n, int len,
+                                                              vdjx_cov_params cp, u32* __restrict__ scratch_all,
+                                                              uint8_t* __restrict__ out_valid, u32* __restrict__ out_npairs) {
+	__shared__ MapLds L;
+	__shared__ u32 hf[MAP_MAXOFF + 64 + 2];         // histogram of firsts -> inclusive prefix "cum"
+	__shared__ u32 s_np, s_bad;
+	const u32 tid = threadIdx.x;
+	const int rl = ix.rl;
+	const int noff = len - rl;
+	const int D = len + 1;                          // positions 1..len-rl used; table indexed [0..len]
+	u32* C = scratch_all + (size_t) blockIdx.x * (size_t) D * D;
+	for (u32 wi = blockIdx.x; wi < n; wi += gridDim.x) {
+		const char* w = windows + (size_t) wi * len;
+		const u32 H = map_prepare(L, ix, w, len);
+		for (u32 i = tid; i < (u32) (D * D); i += MAP_THREADS) C[i] = 0;
+		for (u32 i = tid; i < (u32) D + 1; i += MAP_THREADS) hf[i] = 0;
+		if (tid == 0) { s_np = 0; s_bad = 0; }
+		__syncthreads();
+		for (u32 h = tid; h < H; h += MAP_THREADS) {
+			Hit r = map_eval_hit(L, ix, noff, h);
+			if (!r.pair) continue;
+			atomicAdd(&s_np, 1u);
+			// start_positions gets (pos1,pos2) and (pos2,pos1) (quick_map3.c:241-242)
+			atomicAdd(&C[r.pos1 * D + r.pos2], 1u);
+			atomicAdd(&C[r.pos2 * D + r.pos1], 1u);
+			atomicAdd(&hf[r.pos1], 1u);
+			atomicAdd(&hf[r.pos2], 1u);
+		}
+		__threadfence();
+		__syncthreads();
+		const u32 npairs = s_np;
+		uint8_t valid = 1;
+		if (cp.floor != 0) {
+			// ---- summed-area table: rows then columns
+			for (u32 f = tid; f < (u32) D; f += MAP_THREADS) {
+				u32 run = 0;
+				for (int s = 0; s < D; s++) { run += C[f * D + s]; C[f * D + s] = run; }
+			}
+			__threadfence();
+			__syncthreads();
+			for (u32 s = tid; s < (u32) D; s += MAP_THREADS) {
+				u32 run = 0;
+				for (int f = 0; f < D; f++) { run += C[f * D + s]; C[f * D + s] = run; }
+			}
+			// ---- cum[p] = number of entries with first <= p
+			if (tid == 0) {
+				u32 run = 0;
+				for (int p = 0; p < D; p++) { run += hf[p]; hf[p] = run; }
+			}
+			__threadfence();
+			__syncthreads();
+			const int n_ent = (int) hf[D - 1];
+			const int e0 = cp.eval_start, e1 = cp.eval_stop, fl = cp.floor;
+			const int gap = rl - cp.read_span;
+			// ---- rule 1 (coverage.c:76-121) from the cumulative histogram; see DESIGN.md "coverage restated"
+			if (tid == 0) {
+				bool ok = true;
+				auto cum = [&](int p) -> int { return p < 0 ? 0 : (p >= D ? n_ent : (int) hf[p]); };
+				auto value_at = [&](int idx) -> int {       // idx-th smallest first (0-based)
+					int lo2 = 0, hi2 = D - 1;               // smallest p with cum[p] > idx
+					while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (cum(mid) > idx) hi2 = mid; else lo2 = mid + 1; }
+					return lo2;
+				};
+				const int vmax = e1 - cp.read_span + 1;
+				bool first_seen = false;
+				for (int v = e0 > 1 ? e0 : 1; v <= vmax && v < D && ok; v++) {
+					if (cum(v) == cum(v - 1)) continue;
+					const int i0 = cum(v - 1);
+					if (i0 < fl) { ok = false; break; }
+					if (!first_seen) { first_seen = true; if (v > e0 + gap) { ok = false; break; } }
+					if (cum(v - gap - 1) > i0 - fl) { ok = false; break; }
+				}
+				int i_fin = cum(vmax);
+				if (i_fin >= n_ent) i_fin = n_ent - 1;
+				if (ok && n_ent > 0) {
+					const int v_fin = value_at(i_fin);
+					if (i_fin > fl && value_at(i_fin - fl) < v_fin - gap) ok = false;
+					if (!(i_fin > 0 && v_fin > e1 - rl)) ok = false;
+				} else {
+					ok = false;
+				}
+				if (!ok) s_bad = 1;
+			}
+			__syncthreads();
+			// ---- rule 2 (coverage.c:10-61): for every evaluated pos, every j in [mate_low, mate_high) needs
+			// floor mates covering it among the entries starting in [pos-rl+1, pos]
+			if (!s_bad) {
+				const int clo = cp.insert_low - rl - cp.mate_span / 2;
+				const int chi = cp.insert_high - rl + cp.mate_span / 2;
+				const int span = chi - clo + 2;          // upper bound of j values per pos
+				const int npos = e1 - e0;
+				for (int idx = tid; idx < npos * (span > 0 ? span : 0); idx += MAP_THREADS) {
+					const int pos = e0 + idx / span;
+					const int jj = idx % span;
+					if (pos >= e1) continue;
+					if (pos != e0 && (pos - 1 + clo) >= e1) continue;   // loop condition uses the previous mate_low
+					int ml = pos + clo, mh = pos + chi;
+					if (mh > e1) mh = e1 + 1;
+					const int j = ml + jj;
+					if (j >= mh) continue;
+					if (j < 0 || j > len + 1023) { s_bad = 1; continue; }
+					// entries with first in [pos-rl+1, pos] and second in [j-rl+1, j]
+					int f1 = pos, f0 = pos - rl;                 // box (f0, f1]
+					int s1 = j, s0 = j - rl;
+					if (f1 > D - 1) f1 = D - 1;
+					if (s1 > D - 1) s1 = D - 1;
+					if (f0 < 0) f0 = 0;
+					if (s0 < 0) s0 = 0;
+					int cov = 0;
+					if (f1 > f0 && s1 > s0) {
+						// entries have first, second >= 1, so row/column 0 of the table are empty
+						cov = (int) (C[f1 * D + s1] - C[f0 * D + s1] - C[f1 * D + s0] + C[f0 * D + s0]);
+					}
+					if (cov < fl) s_bad = 1;
+				}
+			}
+			__syncthreads();
+			valid = s_bad ? 0 : 1;
+		}
+		if (tid == 0) { out_valid[wi] = valid; out_npairs[wi] = npairs; }
+		__syncthreads();
+	}
+}
+
+// ----------------------------------------------------------------------------------------------
+// K10: mapped pairs of a contig in the reference's order.  mode 0: count only; mode 1: write.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MAP_THREADS) void k_map_emit(ReadIndexDev ix, const char* __restrict__ contigs, u32 n, int len,
+                                                          int mode, u64* __restrict__ counts, const u64* __restrict__ offsets,
+                                                          vdjx_pair* __restrict__ pairs) {
+	__shared__ MapLds L;
+	__shared__ u32 s_base;
+	const u32 tid = threadIdx.x;
+	const int noff = len - ix.rl;
+	for (u32 ci = blockIdx.x; ci < n; ci += gridDim.x) {
+		const char* w = contigs + (size_t) ci * len;
+		const u32 H = map_prepare(L, ix, w, len);
+		if (tid == 0) s_base = 0;
+		__syncthreads();
+		for (u32 h0 = 0; h0 < H; h0 += MAP_THREADS) {
+			const u32 h = h0 + tid;
+			Hit r;
+			r.pair = false;
+			if (h < H) r = map_eval_hit(L, ix, noff, h);
+			// ordered compaction: inclusive scan of the flags
+			L.scan[tid] = r.pair ? 1u : 0u;
+			__syncthreads();
+			for (u32 d = 1; d < MAP_THREADS; d <<= 1) {
+				u32 v = tid >= d ? L.scan[tid - d] : 0;
+				__syncthreads();
+				L.scan[tid] += v;
+				__syncthreads();
+			}
+			const u32 base = s_base;
+			if (r.pair && mode == 1) {
+				vdjx_pair* o = pairs + offsets[ci] + base + L.scan[tid] - 1;
+				o->pair_id = r.pair_id; o->rec1 = r.rec1; o->rec2 = r.rec2;
+				o->pos1 = (int16_t) r.pos1; o->pos2 = (int16_t) r.pos2; o->insert = (int16_t) r.insert;
+				o->rc1 = r.rc1; o->rc2 = r.rc2;
+			}
+			__syncthreads();
+			if (tid == MAP_THREADS - 1) s_base = base + L.scan[tid];
+			__syncthreads();
+		}
+		if (tid == 0 && mode == 0) counts[ci] = s_base;
+		__syncthreads();
+	}
+}
+
+static int make_index_view(vdjx_ctx* c, ReadIndexDev* ix, int len, const char* who) {
+	if (!c->ri_pool) { vdjx_set_error("%s: call vdjx_read_index_build first", who); return VDJX_ESTATE; }
+	const vdjx_pool* p = c->ri_pool;
+	if (len <= p->rl) { vdjx_set_error("%s: len=%d must exceed the read length %d", who, len, p->rl); return VDJX_EINVAL; }
+	if (len - p->rl > MAP_MAXOFF) { vdjx_set_error("%s: len=%d too long (max %d)", who, len, MAP_MAXOFF + p->rl); return VDJX_ELIMIT; }
+	ix->bases = p->d_bases; ix->nmask = p->d_nmask;
+	ix->slots = c->d_ri_slots; ix->mask = c->ri_nslots - 1;
+	ix->rep = c->d_ri_rep; ix->start = c->d_ri_start; ix->recs = c->d_ri_recs;
+	ix->pair_id = c->d_pair_id; ix->read_num = c->d_read_num; ix->is_rc = c->d_is_rc; ix->pair_r2 = c->d_pair_r2;
+	ix->rl = p->rl;
+	return VDJX_OK;
+}
+
+extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int len, const vdjx_cov_params* p,
+                                 uint8_t* out_valid, uint32_t* out_npairs) {
+	if (!c || !p || (n && (!windows || !out_valid || !out_npairs))) { vdjx_set_error("vdjx_window_score: NULL argument"); return VDJX_EINVAL; }
+	if (n == 0) return VDJX_OK;
+	ReadIndexDev ix;
+	int rc = make_index_view(c, &ix, len, "vdjx_window_score");
+	if (rc) return rc;
+	if (p->eval_start < 1 || p->eval_stop <= p->eval_start) { vdjx_set_error("vdjx_window_score: bad eval range"); return VDJX_EINVAL; }
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t st = c->stream;
+	DevBuf db;
+	const u32 grid = (u32) std::min<size_t>(n, 512);
+	const size_t D = (size_t) len + 1;
+	char* d_w;
+	u32 *d_scratch, *d_np;
+	uint8_t* d_valid;
+	HIP_TRY(db.alloc(&d_w, n * len));
+	HIP_TRY(db.alloc(&d_scratch, (size_t) grid * D * D));
+	HIP_TRY(db.alloc(&d_np, n));
+	HIP_TRY(db.alloc(&d_valid, n));
+	HIP_TRY(hipMemcpyAsync(d_w, windows, n * len, hipMemcpyHostToDevice, st));
+	{
+		vdjx_prof_scope ps(c, "k_window_score");
+		hipLaunchKernelGGL(k_window_score, dim3(grid), dim3(MAP_THREADS), 0, st, ix, d_w, (u32) n, len, *p, d_scratch, d_valid, d_np);
+	}
+	HIP_TRY(hipMemcpyAsync(out_valid, d_valid, n, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	return VDJX_OK;
+}
+
+extern "C" int vdjx_map_emit(vdjx_ctx* c, const char* contigs, size_t n, int len, uint64_t* offsets, vdjx_pair* pairs) {
+	if (!c || !offsets || (n && !contigs)) { vdjx_set_error("vdjx_map_emit: NULL argument"); return VDJX_EINVAL; }
+	if (n == 0) { offsets[0] = 0; return VDJX_OK; }
+	ReadIndexDev ix;
+	int rc = make_index_view(c, &ix, len, "vdjx_map_emit");
+	if (rc) return rc;
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t st = c->stream;
+	DevBuf db;
+	const u32 grid = (u32) std::min<size_t>(n, 1024);
+	char* d_c;
+	u64 *d_counts, *d_off;
+	HIP_TRY(db.alloc(&d_c, n * len));
+	HIP_TRY(db.alloc(&d_counts, n));
+	HIP_TRY(db.alloc(&d_off, n + 1));
+	HIP_TRY(hipMemcpyAsync(d_c, contigs, n * len, hipMemcpyHostToDevice, st));
+	if (!pairs) {
+		{
+			vdjx_prof_scope ps(c, "k_map_emit_count");
+			hipLaunchKernelGGL(k_map_emit, dim3(grid), dim3(MAP_THREADS), 0, st, ix, d_c, (u32) n, len, 0, d_counts, (const u64*) nullptr, (vdjx_pair*) nullptr);
+		}
+		std::vector<u64> cnt(n);
+		HIP_TRY(hipMemcpyAsync(cnt.data(), d_counts, n * 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(hipGetLastError());
+		offsets[0] = 0;
+		for (size_t i = 0; i < n; i++) offsets[i + 1] = offsets[i] + cnt[i];
+		return VDJX_OK;
+	}
+	vdjx_pair* d_pairs;
+	const u64 total = offsets[n];
+	HIP_TRY(db.alloc(&d_pairs, (size_t) total));
+	HIP_TRY(hipMemcpyAsync(d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
+	{
+		vdjx_prof_scope ps(c, "k_map_emit");
+		hipLaunchKernelGGL(k_map_emit, dim3(grid), dim3(MAP_THREADS), 0, st, ix, d_c, (u32) n, len, 1, d_counts, (const u64*) d_off, d_pairs);
+	}
+	if (total) HIP_TRY(hipMemcpyAsync(pairs, d_pairs, (size_t) total * sizeof(vdjx_pair), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	return VDJX_OK;
+}
