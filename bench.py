@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- M paired-reads/s through the hot path (k-mer build + contig scoring), IgH, 50 bp PE.
+
+One "step" = one pass of the hot path over one batch of synthetic reads already resident in HBM as the
+reference's ASCII pool records:
+    pool_pack -> k-mer table + prune + graph (a-1..a-3, a-5/a-6) -> root scorer over every root of that
+    graph (a-7) -> window mapper + coverage test over the repertoire's candidate windows (a-8, a-9)
+    -> mapped-pair emission for the accepted contigs (a-10)
+Workload = BASELINE.json configs[1]: 1 M synthetic pairs (2,000 clones, Zipf 1.1, 30 % noise,
+k=35 mf=3 mq=90, --ins 175) per GPU.  With N GPUs every rank holds its own 1 M-pair shard of an N M-pair pool
+and the k-mer instances are exchanged by hash prefix (vdjer_amd/shard.py): weak scaling.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel of the step (HIP events on the
+library's stream) against HBM peak; `cpu_baseline` times the CPU oracle (a C port of the reference's
+algorithm, oracle/vdjx_oracle.c, -O2, 1 thread) on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes_per_pair(k: int, rl: int = 50) -> dict:
+    """SURVEY §8d.  P = 4*(rl-k+1) instances per pair; per kernel:
+    scatter: packed input once (126 B) + one 16-B key per instance written;   aggregate: every key read once;
+    graph pass: packed input once more + one 16-B probe per instance."""
+    P = 4 * (rl - k + 1)
+    inp = 2 * ((rl + 3) // 4 + rl)
+    return {"P": P, "input": inp, "total": inp + 32 * P + inp + 16 * P,
+            "k_pool_pack": 4 * (2 * rl + 1), "k_kmer_hist": inp, "k_kmer_scatter": inp + 16 * P,
+            "k_bucket_aggregate": 16 * P, "k_bucket_finalize": 16 * P, "k_graph_edges": inp + 16 * P}
+
+
+def make_workload(n_pairs: int, n_clones: int, seed: int, rank: int):
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(n_clones, seed=seed)
+    pool = synth.make_reads(rep, n_pairs, noise_frac=0.3, seed=seed + 7919 + 104729 * rank)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    wins = [w for w in rep.windows() if w]
+    return rep, pool, vc, jc, wins
+
+
+def cpu_baseline(rep, vc, jc, wins, n_sample: int, k: int, mf: int, mq: int, ins: int, seed: int) -> dict:
+    """The same step on the CPU oracle (test infrastructure used here only as the timed baseline)."""
+    from oracle import oracle
+    from vdjer_amd import synth
+    pool = synth.make_reads(rep, n_sample, noise_frac=0.3, seed=seed + 13)
+    t0 = time.perf_counter()
+    tb = oracle.KmerTable(pool, k)
+    tb.prune(mf, mq)
+    g = oracle.Graph(tb, vc, jc)
+    t1 = time.perf_counter()
+    sc = oracle.RootScorer([rep.v_region], 15)
+    roots = [oracle.inst_kmer(pool, int(g.first[i]), k) for i in np.flatnonzero(g.from_deg == 0)]
+    n_ok = sum(sc.score(r, 30) for r in roots)
+    t2 = time.perf_counter()
+    ix = oracle.ReadIndex(pool)
+    t3 = time.perf_counter()           # index build is part of extraction in the reference: not timed
+    nvalid = 0
+    contigs = []
+    for w in wins:
+        pairs, starts = ix.quick_map(w)
+        if ix.coverage_is_valid(starts, len(w), ins):
+            nvalid += 1
+            contigs.append(w[51:411])
+    for c in contigs:
+        ix.quick_map(c)
+    t4 = time.perf_counter()
+    secs = (t1 - t0) + (t2 - t1) + (t4 - t3)
+    return {"value": n_sample / secs / 1e6, "unit": "M paired-reads/s", "cores": 1, "kind": "port",
+            "sample": f"{n_sample} pairs of the same generator: kmer+prune+graph {t1 - t0:.2f}s, {len(roots)} roots "
+                      f"({n_ok} accepted) {t2 - t1:.2f}s, {len(wins)} windows ({nvalid} valid) + SAM mapping {t4 - t3:.2f}s; "
+                      "oracle/vdjx_oracle.c -O2, 1 thread (the reference's k-mer build is single-threaded, A2:1388-1408)",
+            "seconds": secs}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=1_000_000, help="pairs per GPU")
+    ap.add_argument("--clones", type=int, default=2000)
+    ap.add_argument("--k", type=int, default=35)
+    ap.add_argument("--mf", type=int, default=3)
+    ap.add_argument("--mq", type=int, default=90)
+    ap.add_argument("--mrs", type=int, default=30)
+    ap.add_argument("--ins", type=int, default=175)
+    ap.add_argument("--seed", type=int, default=20261002)
+    ap.add_argument("--cpu-sample", type=int, default=500_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--parity-sample", type=int, default=20000, help="records of the 1 %% parity gate (SURVEY §8d)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vdjer_amd import api
+
+    rep, pool, vc, jc, wins = make_workload(args.pairs, args.clones, args.seed, rank)
+    rl = pool.rl
+    ctx = api.Context(local_rank)
+    ctx.anchor_sets_load(vc, jc)
+    ctx.vregion_load([rep.v_region], 15)
+    d_pri = torch.from_numpy(pool.primary).to(dev)
+    d_sec = torch.from_numpy(pool.secondary).to(dev)
+    torch.cuda.synchronize()
+
+    if world > 1:
+        from vdjer_amd import shard
+        engine = shard.ShardedHotPath(ctx, dist, dev)
+    else:
+        engine = None
+
+    state = {}
+    # the read index belongs to extraction in the reference (add_read_info is called from extract, bam_read.c:228,243):
+    # built once, outside the timed region, over a pool handle that stays alive
+    p_index = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
+    ctx.read_index_build(p_index, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+
+    def step(first: bool = False):
+        p = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
+        if engine is None:
+            g = ctx.kmer_build(p, args.k, args.mf, args.mq)
+        else:
+            g = engine.kmer_build(p, args.k, args.mf, args.mq)
+        roots = g.kmers[g.from_deg == 0]
+        ok = ctx.root_score(roots, args.k, args.mrs) if roots.shape[0] else np.zeros(0, np.uint8)
+        valid, npairs = ctx.window_score(wins, args.ins)
+        contigs = [w[51:411] for w, v in zip(wins, valid) if v]
+        offs, pairs = ctx.map_emit(contigs)
+        state.update(nodes=g.n, pre=g.pre_nodes, roots=int(roots.shape[0]), roots_ok=int(ok.sum()), windows=len(wins),
+                     valid=int(valid.sum()), mapped=int(pairs.shape[0]), graph=g)
+        p.free()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(first=(i == 0))
+    ctx.profile(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- parity gate inside the benchmark: a record sample re-checked against the oracle
+    parity = None
+    if rank == 0 and args.parity_sample > 0 and world == 1:
+        from oracle import oracle
+        from vdjer_amd import synth
+        n_s = min(args.parity_sample, args.pairs)
+        sp = synth.make_reads(rep, n_s, noise_frac=0.3, seed=args.seed + 99)
+        pp = ctx.pool_load(sp.primary, sp.secondary, rl)
+        hg = ctx.kmer_build(pp, args.k, args.mf, args.mq)
+        pp.free()
+        tb = oracle.KmerTable(sp, args.k)
+        tb.prune(args.mf, args.mq)
+        og = oracle.Graph(tb, vc, jc)
+        parity = bool(hg.n == og.n and np.array_equal(hg.first_inst, og.first) and np.array_equal(hg.freq, og.freq)
+                      and np.array_equal(hg.to_ids, og.to_ids) and np.array_equal(hg.from_ids, og.from_ids))
+        if not parity:
+            raise SystemExit("parity gate failed: HIP k-mer build differs from the oracle")
+
+    if rank != 0:
+        return
+    ms_step = dt / args.steps * 1e3
+    total_pairs = args.pairs * world
+    value = total_pairs * args.steps / dt / 1e6
+    ab = algorithmic_bytes_per_pair(args.k, rl)
+    # dominant kernel of the step by summed device time
+    dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else (None, (0.0, 0))
+    roof = None
+    if dom[0]:
+        avg_ms = dom[1][0] / max(1, dom[1][1])
+        launches_per_step = dom[1][1] / args.steps
+        per_pair = ab.get(dom[0], ab["total"])
+        bytes_per_launch = per_pair * args.pairs / max(1.0, launches_per_step)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "algorithmic_bytes_per_pair": per_pair,
+                "hot_path_frac": round(ab["total"] * args.pairs / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    cpu = None
+    if not args.no_cpu and world == 1:
+        cpu = cpu_baseline(rep, vc, jc, wins, min(args.cpu_sample, args.pairs), args.k, args.mf, args.mq, args.ins, args.seed)
+    out = {
+        "metric": "M paired-reads/sec (k-mer build + contig score), IgH 50bp PE", "value": round(value, 4),
+        "unit": "M paired-reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8/u64 (2-bit packed bases, integer counts)", "data": "synthetic",
+        "config": {"workload": f"synthetic {args.pairs} 50bp PE pairs per GPU, IGH, k={args.k} mf={args.mf} mq={args.mq} "
+                               f"ins={args.ins} (BASELINE.json configs[1]; SURVEY §8d C2)",
+                   "pairs_per_gpu": args.pairs, "clones": args.clones, "noise": 0.3, "parallelism": f"hash-prefix x{world}"},
+        "roofline": roof, "cpu_baseline": cpu,
+        "kernels_ms_per_step": {k_: round(v[0] / args.steps, 4) for k_, v in prof.items()},
+        "counts": {k_: v for k_, v in state.items() if k_ != "graph"}, "parity_gate": parity,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
