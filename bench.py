@@ -142,17 +142,29 @@ def main():
     p_index = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
     ctx.read_index_build(p_index, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
 
+    wall = {}
+
+    def lap(name, t):
+        wall[name] = wall.get(name, 0.0) + (time.perf_counter() - t)
+        return time.perf_counter()
+
     def step(first: bool = False):
+        t = time.perf_counter()
         p = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
+        t = lap("pool_pack", t)
         if engine is None:
             g = ctx.kmer_build(p, args.k, args.mf, args.mq)
         else:
             g = engine.kmer_build(p, args.k, args.mf, args.mq)
+        t = lap("kmer_build", t)
         roots = g.kmers[g.from_deg == 0]
         ok = ctx.root_score(roots, args.k, args.mrs) if roots.shape[0] else np.zeros(0, np.uint8)
+        t = lap("root_score", t)
         valid, npairs = ctx.window_score(wins, args.ins)
+        t = lap("window_score", t)
         contigs = [w[51:411] for w, v in zip(wins, valid) if v]
         offs, pairs = ctx.map_emit(contigs)
+        t = lap("map_emit", t)
         state.update(nodes=g.n, pre=g.pre_nodes, roots=int(roots.shape[0]), roots_ok=int(ok.sum()), windows=len(wins),
                      valid=int(valid.sum()), mapped=int(pairs.shape[0]), graph=g)
         p.free()
@@ -167,6 +179,7 @@ def main():
         step(first=(i == 0))
     ctx.profile(True)
     ctx.profile_reset()
+    wall.clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -230,6 +243,7 @@ def main():
                    "pairs_per_gpu": args.pairs, "clones": args.clones, "noise": 0.3, "parallelism": f"hash-prefix x{world}"},
         "roofline": roof, "cpu_baseline": cpu,
         "kernels_ms_per_step": {k_: round(v[0] / args.steps, 4) for k_, v in prof.items()},
+        "wall_ms_per_step": {k_: round(v / args.steps * 1e3, 3) for k_, v in wall.items()},
         "counts": {k_: v for k_, v in state.items() if k_ != "graph"}, "parity_gate": parity,
     }
     print(json.dumps(out))

@@ -491,25 +491,42 @@ __device__ inline Hit map_eval_hit(const MapLds& L, const ReadIndexDev& ix, int 
 }
 
 // ----------------------------------------------------------------------------------------------
-// K8+K9: one workgroup per window.  Scratch per workgroup: (len+1)^2 u32 "C[f][s]" = number of
-// start entries (first=f, second=s); turned into a summed-area table so that the mate-coverage test
-// of coverage.c:10-61 (recomputed from scratch per position there) becomes box sums.
+// K8+K9: one workgroup per window.
+//
+// coverage.c restated for counting hardware.  The start list holds (pos1,pos2) and
+// (pos2,pos1) per mapped pair (quick_map3.c:241-242).
+//  rule 1 (coverage.c:76-121) only looks at the sorted `first` values: it is evaluated from their
+//    cumulative histogram.
+//  rule 2 (coverage.c:10-61) rebuilds, for every position pos, a coverage array from the entries whose
+//    first lies in (pos-rl, pos] and tests every j = pos+delta, delta in [clo, chi).  For a fixed delta
+//    an entry (f, s) is counted at pos iff both f and s-delta lie in (pos-rl, pos], i.e. for pos in
+//    [max(f, s-delta), min(f, s-delta)+rl): one +1/-1 pair in a difference array over pos.  The kernel
+//    keeps DB difference arrays (one per delta of the current batch) in LDS, re-enumerates the hits for
+//    every batch, prefixes, and tests.  O(entries * 2rl + positions * deltas) LDS operations per window
+//    instead of the reference's O(positions * entries-in-50bp * rl).
 // ----------------------------------------------------------------------------------------------
+#define COV_WORDS 8192
 __global__ __launch_bounds__(MAP_THREADS) void k_window_score(ReadIndexDev ix, const char* __restrict__ windows, u32 n, int len,
-                                                              vdjx_cov_params cp, u32* __restrict__ scratch_all,
-                                                              uint8_t* __restrict__ out_valid, u32* __restrict__ out_npairs) {
+                                                              vdjx_cov_params cp, uint8_t* __restrict__ out_valid,
+                                                              u32* __restrict__ out_npairs) {
 	__shared__ MapLds L;
 	__shared__ u32 hf[MAP_MAXOFF + 64 + 2];         // histogram of firsts -> inclusive prefix "cum"
+	__shared__ int diff[COV_WORDS];
 	__shared__ u32 s_np, s_bad;
 	const u32 tid = threadIdx.x;
 	const int rl = ix.rl;
 	const int noff = len - rl;
-	const int D = len + 1;                          // positions 1..len-rl used; table indexed [0..len]
-	u32* C = scratch_all + (size_t) blockIdx.x * (size_t) D * D;
+	const int D = len + 1;
+	const int e0 = cp.eval_start, e1 = cp.eval_stop, fl = cp.floor;
+	const int gap = rl - cp.read_span;
+	const int clo = cp.insert_low - rl - cp.mate_span / 2;
+	const int chi = cp.insert_high - rl + cp.mate_span / 2;
+	const int npos = e1 - e0;                        // positions e0 .. e1-1
+	const int stride = npos + 1;
+	const int DB = COV_WORDS / stride;               // deltas per batch (host guarantees >= 1)
 	for (u32 wi = blockIdx.x; wi < n; wi += gridDim.x) {
 		const char* w = windows + (size_t) wi * len;
 		const u32 H = map_prepare(L, ix, w, len);
-		for (u32 i = tid; i < (u32) (D * D); i += MAP_THREADS) C[i] = 0;
 		for (u32 i = tid; i < (u32) D + 1; i += MAP_THREADS) hf[i] = 0;
 		if (tid == 0) { s_np = 0; s_bad = 0; }
 		__syncthreads();
@@ -517,44 +534,22 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_score(ReadIndexDev ix, c
 			Hit r = map_eval_hit(L, ix, noff, h);
 			if (!r.pair) continue;
 			atomicAdd(&s_np, 1u);
-			// start_positions gets (pos1,pos2) and (pos2,pos1) (quick_map3.c:241-242)
-			atomicAdd(&C[r.pos1 * D + r.pos2], 1u);
-			atomicAdd(&C[r.pos2 * D + r.pos1], 1u);
 			atomicAdd(&hf[r.pos1], 1u);
 			atomicAdd(&hf[r.pos2], 1u);
 		}
-		__threadfence();
 		__syncthreads();
 		const u32 npairs = s_np;
 		uint8_t valid = 1;
-		if (cp.floor != 0) {
-			// ---- summed-area table: rows then columns
-			for (u32 f = tid; f < (u32) D; f += MAP_THREADS) {
-				u32 run = 0;
-				for (int s = 0; s < D; s++) { run += C[f * D + s]; C[f * D + s] = run; }
-			}
-			__threadfence();
-			__syncthreads();
-			for (u32 s = tid; s < (u32) D; s += MAP_THREADS) {
-				u32 run = 0;
-				for (int f = 0; f < D; f++) { run += C[f * D + s]; C[f * D + s] = run; }
-			}
-			// ---- cum[p] = number of entries with first <= p
+		if (fl != 0) {
+			// ---- rule 1
 			if (tid == 0) {
 				u32 run = 0;
 				for (int p = 0; p < D; p++) { run += hf[p]; hf[p] = run; }
-			}
-			__threadfence();
-			__syncthreads();
-			const int n_ent = (int) hf[D - 1];
-			const int e0 = cp.eval_start, e1 = cp.eval_stop, fl = cp.floor;
-			const int gap = rl - cp.read_span;
-			// ---- rule 1 (coverage.c:76-121) from the cumulative histogram; see DESIGN.md "coverage restated"
-			if (tid == 0) {
+				const int n_ent = (int) hf[D - 1];
 				bool ok = true;
 				auto cum = [&](int p) -> int { return p < 0 ? 0 : (p >= D ? n_ent : (int) hf[p]); };
-				auto value_at = [&](int idx) -> int {       // idx-th smallest first (0-based)
-					int lo2 = 0, hi2 = D - 1;               // smallest p with cum[p] > idx
+				auto value_at = [&](int idx) -> int {       // idx-th smallest first (0-based): smallest p with cum[p] > idx
+					int lo2 = 0, hi2 = D - 1;
 					while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (cum(mid) > idx) hi2 = mid; else lo2 = mid + 1; }
 					return lo2;
 				};
@@ -562,54 +557,69 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_score(ReadIndexDev ix, c
 				bool first_seen = false;
 				for (int v = e0 > 1 ? e0 : 1; v <= vmax && v < D && ok; v++) {
 					if (cum(v) == cum(v - 1)) continue;
-					const int i0 = cum(v - 1);
-					if (i0 < fl) { ok = false; break; }
-					if (!first_seen) { first_seen = true; if (v > e0 + gap) { ok = false; break; } }
-					if (cum(v - gap - 1) > i0 - fl) { ok = false; break; }
+					const int i0 = cum(v - 1);                            // smallest index holding value v
+					if (i0 < fl) { ok = false; break; }                   // coverage.c:80-84
+					if (!first_seen) { first_seen = true; if (v > e0 + gap) { ok = false; break; } }   // :86-93
+					if (cum(v - gap - 1) > i0 - fl) { ok = false; break; }                              // :96-100
 				}
 				int i_fin = cum(vmax);
-				if (i_fin >= n_ent) i_fin = n_ent - 1;
+				if (i_fin >= n_ent) i_fin = n_ent - 1;                    // :106-108
 				if (ok && n_ent > 0) {
 					const int v_fin = value_at(i_fin);
-					if (i_fin > fl && value_at(i_fin - fl) < v_fin - gap) ok = false;
-					if (!(i_fin > 0 && v_fin > e1 - rl)) ok = false;
+					if (i_fin > fl && value_at(i_fin - fl) < v_fin - gap) ok = false;   // :111-113
+					if (!(i_fin > 0 && v_fin > e1 - rl)) ok = false;                   // :116-120
 				} else {
 					ok = false;
 				}
 				if (!ok) s_bad = 1;
 			}
 			__syncthreads();
-			// ---- rule 2 (coverage.c:10-61): for every evaluated pos, every j in [mate_low, mate_high) needs
-			// floor mates covering it among the entries starting in [pos-rl+1, pos]
-			if (!s_bad) {
-				const int clo = cp.insert_low - rl - cp.mate_span / 2;
-				const int chi = cp.insert_high - rl + cp.mate_span / 2;
-				const int span = chi - clo + 2;          // upper bound of j values per pos
-				const int npos = e1 - e0;
-				for (int idx = tid; idx < npos * (span > 0 ? span : 0); idx += MAP_THREADS) {
-					const int pos = e0 + idx / span;
-					const int jj = idx % span;
-					if (pos >= e1) continue;
-					if (pos != e0 && (pos - 1 + clo) >= e1) continue;   // loop condition uses the previous mate_low
-					int ml = pos + clo, mh = pos + chi;
-					if (mh > e1) mh = e1 + 1;
-					const int j = ml + jj;
-					if (j >= mh) continue;
-					if (j < 0 || j > len + 1023) { s_bad = 1; continue; }
-					// entries with first in [pos-rl+1, pos] and second in [j-rl+1, j]
-					int f1 = pos, f0 = pos - rl;                 // box (f0, f1]
-					int s1 = j, s0 = j - rl;
-					if (f1 > D - 1) f1 = D - 1;
-					if (s1 > D - 1) s1 = D - 1;
-					if (f0 < 0) f0 = 0;
-					if (s0 < 0) s0 = 0;
-					int cov = 0;
-					if (f1 > f0 && s1 > s0) {
-						// entries have first, second >= 1, so row/column 0 of the table are empty
-						cov = (int) (C[f1 * D + s1] - C[f0 * D + s1] - C[f1 * D + s0] + C[f0 * D + s0]);
+			// ---- rule 2
+			for (int d0 = clo; d0 < chi && !s_bad; d0 += DB) {
+				const int nd = chi - d0 < DB ? chi - d0 : DB;
+				for (int i = tid; i < nd * stride; i += MAP_THREADS) diff[i] = 0;
+				__syncthreads();
+				for (u32 h = tid; h < H; h += MAP_THREADS) {
+					Hit r = map_eval_hit(L, ix, noff, h);
+					if (!r.pair) continue;
+					for (int e = 0; e < 2; e++) {
+						const int f = e ? r.pos2 : r.pos1, sx = e ? r.pos1 : r.pos2;
+						// deltas of this batch with |f - (sx - delta)| < rl
+						int dlo = sx - f - rl + 1, dhi = sx - f + rl - 1;
+						if (dlo < d0) dlo = d0;
+						if (dhi > d0 + nd - 1) dhi = d0 + nd - 1;
+						for (int dl = dlo; dl <= dhi; dl++) {
+							const int v = sx - dl;
+							int lo = f > v ? f : v;                       // first pos that sees both
+							int hi = (f < v ? f : v) + rl;                // one past the last
+							if (lo < e0) lo = e0;
+							if (hi > e1) hi = e1;
+							if (lo < hi) {
+								atomicAdd(&diff[(dl - d0) * stride + (lo - e0)], 1);
+								atomicAdd(&diff[(dl - d0) * stride + (hi - e0)], -1);
+							}
+						}
 					}
-					if (cov < fl) s_bad = 1;
 				}
+				__syncthreads();
+				if ((int) tid < nd) {
+					int run = 0;
+					int* row = diff + tid * stride;
+					for (int p = 0; p < npos; p++) { run += row[p]; row[p] = run; }
+				}
+				__syncthreads();
+				for (int i = tid; i < nd * npos; i += MAP_THREADS) {
+					const int dl = d0 + i / npos;
+					const int pos = e0 + i % npos;
+					if (pos != e0 && (pos - 1 + clo) >= e1) continue;     // the loop tests the previous mate_low (coverage.c:25)
+					int mh = pos + chi;
+					if (mh > e1) mh = e1 + 1;                             // coverage.c:36-38
+					const int j = pos + dl;
+					if (j >= mh) continue;
+					if (j < 0 || j > len + 1023) { s_bad = 1; continue; }  // outside the reference's array: undefined there
+					if (diff[(dl - d0) * stride + (pos - e0)] < fl) s_bad = 1;
+				}
+				__syncthreads();
 			}
 			__syncthreads();
 			valid = s_bad ? 0 : 1;
@@ -688,19 +698,18 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t st = c->stream;
 	DevBuf db;
-	const u32 grid = (u32) std::min<size_t>(n, 512);
-	const size_t D = (size_t) len + 1;
+	const u32 grid = (u32) std::min<size_t>(n, 2048);
 	char* d_w;
-	u32 *d_scratch, *d_np;
+	u32* d_np;
 	uint8_t* d_valid;
+	if (p->eval_stop - p->eval_start + 1 > COV_WORDS) { vdjx_set_error("vdjx_window_score: eval range too long"); return VDJX_ELIMIT; }
 	HIP_TRY(db.alloc(&d_w, n * len));
-	HIP_TRY(db.alloc(&d_scratch, (size_t) grid * D * D));
 	HIP_TRY(db.alloc(&d_np, n));
 	HIP_TRY(db.alloc(&d_valid, n));
 	HIP_TRY(hipMemcpyAsync(d_w, windows, n * len, hipMemcpyHostToDevice, st));
 	{
 		vdjx_prof_scope ps(c, "k_window_score");
-		hipLaunchKernelGGL(k_window_score, dim3(grid), dim3(MAP_THREADS), 0, st, ix, d_w, (u32) n, len, *p, d_scratch, d_valid, d_np);
+		hipLaunchKernelGGL(k_window_score, dim3(grid), dim3(MAP_THREADS), 0, st, ix, d_w, (u32) n, len, *p, d_valid, d_np);
 	}
 	HIP_TRY(hipMemcpyAsync(out_valid, d_valid, n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
