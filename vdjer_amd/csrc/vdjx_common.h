@@ -38,8 +38,21 @@ struct vdjx_prof_entry {
 	uint64_t launches = 0;
 };
 
+// Grow-only device workspace: one bump allocator per context, reset at the end of every API call.
+// hipMalloc/hipFree cost milliseconds each and hipFree synchronises the device; the hot path allocates ~25
+// buffers per call, so they come out of this arena instead.
+struct vdjx_arena {
+	struct chunk { char* p; size_t cap; };
+	std::vector<chunk> chunks;
+	size_t used = 0;                 // bytes used in the last chunk
+	void* alloc(size_t bytes);       // 256-byte aligned; nullptr (and the error set) on failure
+	void reset();                    // forget all allocations; coalesces multiple chunks into one
+	void release();
+};
+
 struct vdjx_ctx {
 	int device = 0;
+	vdjx_arena arena;
 	hipStream_t stream = nullptr;
 	bool profiling = false;
 	std::vector<std::string> prof_names;                 // insertion order
@@ -68,7 +81,13 @@ struct vdjx_ctx {
 	u32* d_pair_id = nullptr;
 	uint8_t* d_read_num = nullptr;
 	uint8_t* d_is_rc = nullptr;
-	u32* d_pair_r2 = nullptr;         // pair -> as-is record of read 2 (or ~0u)
+	u32* d_pair_r2 = nullptr;         // pair -> its two read-2 records in registration order (or ~0u)
+	uint4* d_rec_info = nullptr;      // record -> {pair id, class of read-2 record A, class of B, flags}
+	// cached result of the last vdjx_map_emit count call (the write call of the two-call protocol reuses it)
+	uint64_t me_key = 0;
+	void* me_pairs = nullptr;         // vdjx_pair[me_cap], per-contig regions at me_hoff
+	size_t me_cap = 0;
+	std::vector<u64> me_hoff, me_cnt;
 	u32 n_pairs = 0, n_classes = 0;
 };
 
@@ -91,6 +110,17 @@ struct vdjx_graph {
 	std::vector<uint8_t> has_v, has_j, to_deg, from_deg;
 	std::vector<uint32_t> to_ids, from_ids;
 	std::vector<u64> key_lo, key_hi;
+};
+
+// scoped workspace allocations out of the context's arena
+struct vdjx_work {
+	vdjx_ctx* c;
+	explicit vdjx_work(vdjx_ctx* ctx) : c(ctx) {}
+	~vdjx_work() { c->arena.reset(); }
+	template <typename T> hipError_t alloc(T** out, size_t n) {
+		*out = (T*) c->arena.alloc((n ? n : 1) * sizeof(T));
+		return *out ? hipSuccess : hipErrorOutOfMemory;
+	}
 };
 
 // profiling: bracket a launch with events on the context's stream

@@ -48,9 +48,43 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	free_dev(c->d_vtext); free_dev(c->d_line_off); free_dev(c->d_seed_code); free_dev(c->d_seed_pos);
 	free_dev(c->d_ri_slots); free_dev(c->d_ri_rep); free_dev(c->d_ri_start); free_dev(c->d_ri_recs);
 	free_dev(c->d_pair_id); free_dev(c->d_read_num); free_dev(c->d_is_rc); free_dev(c->d_pair_r2);
+	free_dev(c->d_rec_info); free_dev(c->me_pairs);
+	c->arena.release();
 	for (auto& p : c->prof_pending) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
 	(void) hipStreamDestroy(c->stream);
 	delete c;
+}
+
+void* vdjx_arena::alloc(size_t bytes) {
+	bytes = (bytes + 255) & ~(size_t) 255;
+	if (chunks.empty() || used + bytes > chunks.back().cap) {
+		size_t cap = bytes > ((size_t) 64 << 20) ? bytes : ((size_t) 64 << 20);
+		char* p = nullptr;
+		hipError_t e = hipMalloc(&p, cap);
+		if (e != hipSuccess) { vdjx_set_error("workspace alloc of %zu bytes: %s", cap, hipGetErrorString(e)); return nullptr; }
+		chunks.push_back({p, cap});
+		used = 0;
+	}
+	void* r = chunks.back().p + used;
+	used += bytes;
+	return r;
+}
+
+void vdjx_arena::reset() {
+	if (chunks.size() > 1) {
+		size_t total = 0;
+		for (auto& ch : chunks) { total += ch.cap; (void) hipFree(ch.p); }
+		chunks.clear();
+		char* p = nullptr;
+		if (hipMalloc(&p, total) == hipSuccess) chunks.push_back({p, total});
+	}
+	used = 0;
+}
+
+void vdjx_arena::release() {
+	for (auto& ch : chunks) (void) hipFree(ch.p);
+	chunks.clear();
+	used = 0;
 }
 
 extern "C" int vdjx_sync(vdjx_ctx* c) {

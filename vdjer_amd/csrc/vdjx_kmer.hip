@@ -470,18 +470,6 @@ __global__ void k_node_flags(const u64* __restrict__ s_lo, const u64* __restrict
 // ----------------------------------------------------------------------------------------------
 namespace {
 
-struct DevBuf {
-	std::vector<void*> ptrs;
-	~DevBuf() { for (void* p : ptrs) if (p) (void) hipFree(p); }
-	template <typename T> hipError_t alloc(T** out, size_t n) {
-		void* p = nullptr;
-		hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
-		if (e == hipSuccess) ptrs.push_back(p);
-		*out = (T*) p;
-		return e;
-	}
-};
-
 template <typename THI>
 int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, vdjx_graph* g) {
 	const int rl = pool->rl;
@@ -489,7 +477,7 @@ int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, v
 	const size_t R = pool->n_records;
 	const size_t NI = R * (size_t) P;
 	hipStream_t st = c->stream;
-	DevBuf db;
+	vdjx_work db(c);
 
 	// ---- partition geometry: ~2048 instances per bucket, at most 2^15 buckets (128 KB LDS histogram)
 	u32 nb_bits = 8;
@@ -573,10 +561,9 @@ int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, v
 	u64 *s_lo = nullptr, *s_hi = nullptr;
 	u32 *s_gcnt = nullptr, *s_gfirst = nullptr, *s_ucnt = nullptr, *s_ufirst = nullptr;
 	for (int attempt = 0; attempt < 2; attempt++) {
-		DevBuf tmp;
-		HIP_TRY(tmp.alloc(&s_lo, cap)); HIP_TRY(tmp.alloc(&s_hi, cap));
-		HIP_TRY(tmp.alloc(&s_gcnt, cap)); HIP_TRY(tmp.alloc(&s_gfirst, cap));
-		HIP_TRY(tmp.alloc(&s_ucnt, cap)); HIP_TRY(tmp.alloc(&s_ufirst, cap));
+		HIP_TRY(db.alloc(&s_lo, cap)); HIP_TRY(db.alloc(&s_hi, cap));
+		HIP_TRY(db.alloc(&s_gcnt, cap)); HIP_TRY(db.alloc(&s_gfirst, cap));
+		HIP_TRY(db.alloc(&s_ucnt, cap)); HIP_TRY(db.alloc(&s_ufirst, cap));
 		HIP_TRY(hipMemsetAsync(n_surv, 0, 4, st));
 		SurvOut so{s_lo, s_hi, s_gcnt, s_gfirst, s_ucnt, s_ufirst, n_surv, cap};
 		{
@@ -588,11 +575,7 @@ int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, v
 		HIP_TRY(hipMemcpyAsync(&ns, n_surv, 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
 		HIP_TRY(hipGetLastError());
-		if (ns <= cap) {
-			for (void* p : tmp.ptrs) db.ptrs.push_back(p);
-			tmp.ptrs.clear();
-			break;
-		}
+		if (ns <= cap) break;
 		cap = ns;
 		if (attempt == 1) { vdjx_set_error("survivor capacity logic failed"); return VDJX_EHIP; }
 	}

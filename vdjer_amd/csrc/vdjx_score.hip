@@ -16,18 +16,6 @@
 #define NONE32 0xFFFFFFFFu
 
 namespace {
-struct DevBuf {
-	std::vector<void*> ptrs;
-	~DevBuf() { for (void* p : ptrs) if (p) (void) hipFree(p); }
-	template <typename T> hipError_t alloc(T** out, size_t n) {
-		void* p = nullptr;
-		hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
-		if (e == hipSuccess) ptrs.push_back(p);
-		*out = (T*) p;
-		return e;
-	}
-};
-
 template <typename T> void free_set(T*& p) { if (p) (void) hipFree(p); p = nullptr; }
 }  // namespace
 
@@ -194,7 +182,7 @@ extern "C" int vdjx_root_score(vdjx_ctx* c, const char* kmers, size_t n, int k, 
 	if (n * (size_t) stop >= (1ull << 31)) { vdjx_set_error("too many roots in one call"); return VDJX_ELIMIT; }
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t st = c->stream;
-	DevBuf db;
+	vdjx_work db(c);
 	char* d_k;
 	u32 *d_lo, *d_cnt, *d_pre;
 	uint8_t* d_out;
@@ -260,6 +248,11 @@ __global__ void k_ri_insert(const u64* __restrict__ bases, const u64* __restrict
 	rec_slot[r] = slot;
 }
 
+#define RI_R1 1u        // rec_info.w: the record is a read-1 instance
+#define RI_RC 2u        //             its is_rc flag
+#define RI_RCA 4u       //             is_rc of the pair's read-2 record A (registered first)
+#define RI_RCB 8u       //             is_rc of the pair's read-2 record B (registered last)
+
 extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const uint32_t* pair_id,
                                      const uint8_t* read_num, const uint8_t* is_rc, const uint32_t* reg_rank, uint32_t n_pairs) {
 	if (!c || !pool || !pair_id || !read_num || !is_rc || !reg_rank) { vdjx_set_error("vdjx_read_index_build: NULL argument"); return VDJX_EINVAL; }
@@ -268,14 +261,15 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 	hipStream_t st = c->stream;
 	const u32 R = (u32) pool->n_records;
 	free_set(c->d_ri_slots); free_set(c->d_ri_rep); free_set(c->d_ri_start); free_set(c->d_ri_recs);
-	free_set(c->d_pair_id); free_set(c->d_read_num); free_set(c->d_is_rc); free_set(c->d_pair_r2);
+	free_set(c->d_pair_id); free_set(c->d_read_num); free_set(c->d_is_rc); free_set(c->d_pair_r2); free_set(c->d_rec_info);
 	c->ri_pool = nullptr;
+	c->me_key = 0;
 	for (u32 r = 0; r < R; r++) {
 		if (pair_id[r] >= n_pairs) { vdjx_set_error("pair_id[%u]=%u >= n_pairs=%u", r, pair_id[r], n_pairs); return VDJX_EINVAL; }
 	}
 	u32 mask = 1023;
 	while ((size_t) mask + 1 < (size_t) R * 2) mask = mask * 2 + 1;
-	DevBuf db;
+	vdjx_work db(c);
 	u32* d_rec_slot;
 	HIP_TRY(hipMalloc(&c->d_ri_slots, ((size_t) mask + 1) * 4));
 	HIP_TRY(db.alloc(&d_rec_slot, R));
@@ -311,7 +305,6 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 		const u32 r = order[i];
 		if (rec_cls[r] != NONE32) recs[fill[rec_cls[r]]++] = r;
 	}
-	// slot -> class id + 1
 	std::vector<u32> slots((size_t) mask + 1, 0);
 	for (size_t s = 0; s <= mask; s++) if (slot_cls[s] != NONE32) slots[s] = slot_cls[s] + 1;
 	// read-2 records of every pair in registration order (at most two: as-is and reverse complement, bam_read.c:206-244)
@@ -324,6 +317,19 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 		else if (pr2[2 * (size_t) p + 1] == NONE32) pr2[2 * (size_t) p + 1] = r;
 		else { vdjx_set_error("pair %u has more than two read-2 records (read names must be unique per pair)", p); return VDJX_EINVAL; }
 	}
+	// per record: everything a hit needs in one 16-byte load
+	std::vector<uint4> info(R ? R : 1);
+	for (u32 r = 0; r < R; r++) {
+		const u32 p = pair_id[r];
+		const u32 ra = pr2[2 * (size_t) p], rb = pr2[2 * (size_t) p + 1];
+		uint4 v;
+		v.x = p;
+		v.y = ra != NONE32 ? rec_cls[ra] : NONE32;
+		v.z = rb != NONE32 ? rec_cls[rb] : NONE32;
+		v.w = (read_num[r] == 1 ? RI_R1 : 0u) | (is_rc[r] ? RI_RC : 0u) | (ra != NONE32 && is_rc[ra] ? RI_RCA : 0u) |
+		      (rb != NONE32 && is_rc[rb] ? RI_RCB : 0u);
+		info[r] = v;
+	}
 	HIP_TRY(hipMalloc(&c->d_ri_rep, ((size_t) ncls + 1) * 4));
 	HIP_TRY(hipMalloc(&c->d_ri_start, ((size_t) ncls + 1) * 4));
 	HIP_TRY(hipMalloc(&c->d_ri_recs, recs.size() * 4));
@@ -331,6 +337,7 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 	HIP_TRY(hipMalloc(&c->d_read_num, (size_t) R + 1));
 	HIP_TRY(hipMalloc(&c->d_is_rc, (size_t) R + 1));
 	HIP_TRY(hipMalloc(&c->d_pair_r2, pr2.size() * 4));
+	HIP_TRY(hipMalloc(&c->d_rec_info, info.size() * sizeof(uint4)));
 	HIP_TRY(hipMemcpy(c->d_ri_slots, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
 	if (ncls) HIP_TRY(hipMemcpy(c->d_ri_rep, rep.data(), (size_t) ncls * 4, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(c->d_ri_start, start.data(), start.size() * 4, hipMemcpyHostToDevice));
@@ -339,6 +346,7 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 		HIP_TRY(hipMemcpy(c->d_pair_id, pair_id, (size_t) R * 4, hipMemcpyHostToDevice));
 		HIP_TRY(hipMemcpy(c->d_read_num, read_num, R, hipMemcpyHostToDevice));
 		HIP_TRY(hipMemcpy(c->d_is_rc, is_rc, R, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(c->d_rec_info, info.data(), (size_t) R * sizeof(uint4), hipMemcpyHostToDevice));
 	}
 	HIP_TRY(hipMemcpy(c->d_pair_r2, pr2.data(), pr2.size() * 4, hipMemcpyHostToDevice));
 	c->ri_nslots = mask + 1;
@@ -349,36 +357,37 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 }
 
 // ==============================================================================================
-// a-8/a-9/a-10 mapper core shared by k_window_score and k_map_emit
+// a-8/a-9/a-10 mapper core shared by k_window_hits, k_window_score and k_map_emit
 // ==============================================================================================
 #define MAP_THREADS 512
 #define MAP_MAXOFF 1024          // window/contig length - rl  <= MAP_MAXOFF
-#define WT_SLOTS 2048            // LDS table: distinct rl-mers of the window -> last offset
+#define WT_SLOTS 2048            // LDS table: read class -> last offset of the window where it occurs
 
 struct ReadIndexDev {
-	const u64* bases; const u64* nmask;
+	const u64* bases;
 	const u32* slots; u32 mask;
 	const u32* rep; const u32* start; const u32* recs;
-	const u32* pair_id; const uint8_t* read_num; const uint8_t* is_rc; const u32* pair_r2;
+	const uint4* rec_info; const u32* pair_r2;
 	int rl;
 };
 
 struct MapLds {
-	u64 sub_hi[MAP_MAXOFF], sub_lo[MAP_MAXOFF];     // packed rl-mer at every offset
 	u32 cls[MAP_MAXOFF];                            // read class at the offset or NONE32
+	u32 cstart[MAP_MAXOFF];                         // CSR start of that class
 	u32 hpre[MAP_MAXOFF + 1];                       // prefix of class sizes (hits enumerate in reference order)
-	u32 wt_rep[WT_SLOTS];                           // offset+1 of a representative
-	u32 wt_last[WT_SLOTS];                          // last offset with that rl-mer
+	u32 wt_key[WT_SLOTS];                           // class id + 1
+	u32 wt_last[WT_SLOTS];                          // last offset + 1 with that class
 	u32 scan[MAP_THREADS];
 };
 
-// pack + classify every offset o in [0, len-rl) (quick_map3.c:200: the last offset is never looked at),
-// build the rl-mer -> last offset table, prefix the class sizes.  Returns the hit count H (all lanes).
+// classify every offset o in [0, len-rl) (quick_map3.c:200: the last offset is never looked at), build the
+// class -> last offset table, prefix the class sizes.  Returns the hit count H (uniform).
 __device__ inline u32 map_prepare(MapLds& L, const ReadIndexDev& ix, const char* __restrict__ w, int len) {
 	const int rl = ix.rl;
 	const int noff = len - rl;
 	const u32 tid = threadIdx.x;
-	for (u32 i = tid; i < WT_SLOTS; i += MAP_THREADS) { L.wt_rep[i] = 0; L.wt_last[i] = 0; }
+	for (u32 i = tid; i < WT_SLOTS; i += MAP_THREADS) { L.wt_key[i] = 0; L.wt_last[i] = 0; }
+	__syncthreads();
 	for (int o = tid; o < noff; o += MAP_THREADS) {
 		u128 b = 0;
 		bool ok = true;
@@ -388,8 +397,7 @@ __device__ inline u32 map_prepare(MapLds& L, const ReadIndexDev& ix, const char*
 			b = (b << 2) | (u32) (cde & 3);
 		}
 		const u64 hi = (u64) (b >> 64), lo = (u64) b;
-		L.sub_hi[o] = hi; L.sub_lo[o] = lo;
-		u32 cls = NONE32;
+		u32 cls = NONE32, cs = 0, sz = 0;
 		if (ok) {
 			u32 slot = (u32) (vdjx_mix(lo, hi) >> 17) & ix.mask;
 			for (;;) {
@@ -400,59 +408,63 @@ __device__ inline u32 map_prepare(MapLds& L, const ReadIndexDev& ix, const char*
 				if (k.x == hi && k.y == lo) { cls = v - 1; break; }
 				slot = (slot + 1) & ix.mask;
 			}
-		} else {
-			L.sub_hi[o] = ~0ull;                    // can never equal a read (2*rl <= 128 bits, reads have no N here)
+		}
+		if (cls != NONE32) {
+			cs = ix.start[cls];
+			sz = ix.start[cls + 1] - cs;
+			// class -> last offset ("read2[id] = m_info": the last writer wins, quick_map3.c:214)
+			u32 slot = (cls * 2654435761u) & (WT_SLOTS - 1);
+			for (;;) {
+				u32 cur = L.wt_key[slot];
+				if (cur == 0) {
+					cur = atomicCAS(&L.wt_key[slot], 0u, cls + 1);
+					if (cur == 0) cur = cls + 1;
+				}
+				if (cur == cls + 1) { atomicMax(&L.wt_last[slot], (u32) o + 1); break; }
+				slot = (slot + 1) & (WT_SLOTS - 1);
+			}
 		}
 		L.cls[o] = cls;
-		L.hpre[o] = cls != NONE32 ? ix.start[cls + 1] - ix.start[cls] : 0u;     // class size, prefixed below
+		L.cstart[o] = cs;
+		L.hpre[o] = sz;
 	}
 	__syncthreads();
-	// rl-mer -> last offset (needed for "read2[id] = m_info": the last writer wins, quick_map3.c:214)
-	for (int o = tid; o < noff; o += MAP_THREADS) {
-		const u64 hi = L.sub_hi[o], lo = L.sub_lo[o];
-		if (hi == ~0ull) continue;
-		u32 slot = (u32) vdjx_mix(lo, hi) & (WT_SLOTS - 1);
-		for (;;) {
-			u32 cur = L.wt_rep[slot];
-			if (cur == 0) {
-				cur = atomicCAS(&L.wt_rep[slot], 0u, (u32) o + 1);
-				if (cur == 0) cur = (u32) o + 1;
-			}
-			if (L.sub_hi[cur - 1] == hi && L.sub_lo[cur - 1] == lo) { atomicMax(&L.wt_last[slot], (u32) o + 1); break; }
-			slot = (slot + 1) & (WT_SLOTS - 1);
+	// exclusive prefix of the class sizes: wave 0, 16 consecutive offsets per lane
+	if (tid < 64) {
+		const int per = (noff + 63) / 64;
+		const int a = (int) tid * per;
+		const int b2 = a + per < noff ? a + per : noff;
+		u32 sum = 0;
+		for (int o = a; o < b2; o++) sum += L.hpre[o];
+		u32 incl = sum;
+		for (int d = 1; d < 64; d <<= 1) {
+			u32 v = __shfl_up(incl, d);
+			if ((int) tid >= d) incl += v;
 		}
-	}
-	// class sizes -> exclusive prefix (serial over <= 1024 offsets by one wave is plenty)
-	__syncthreads();
-	if (tid == 0) {
-		u32 run = 0;
-		for (int o = 0; o < noff; o++) {
-			const u32 sz = L.hpre[o];
-			L.hpre[o] = run;
-			run += sz;
-		}
-		L.hpre[noff] = run;
+		u32 run = incl - sum;
+		for (int o = a; o < b2; o++) { const u32 sz = L.hpre[o]; L.hpre[o] = run; run += sz; }
+		if (tid == 63) L.hpre[noff] = incl;
 	}
 	__syncthreads();
 	return L.hpre[noff];
 }
 
-// last offset+1 at which the read `rec` occurs in the window, or 0
-__device__ inline u32 map_last_occurrence(const MapLds& L, const ReadIndexDev& ix, u32 rec) {
-	if (ix.nmask[rec]) return 0;
-	const ulonglong2 k = ((const ulonglong2*) ix.bases)[rec];
-	u32 slot = (u32) vdjx_mix(k.y, k.x) & (WT_SLOTS - 1);
+// last offset+1 at which a read of class `cls` occurs in the window, or 0
+__device__ inline u32 map_last_occurrence(const MapLds& L, u32 cls) {
+	if (cls == NONE32) return 0;
+	u32 slot = (cls * 2654435761u) & (WT_SLOTS - 1);
 	for (;;) {
-		const u32 cur = L.wt_rep[slot];
+		const u32 cur = L.wt_key[slot];
 		if (cur == 0) return 0;
-		if (L.sub_hi[cur - 1] == k.x && L.sub_lo[cur - 1] == k.y) return L.wt_last[slot];
+		if (cur == cls + 1) return L.wt_last[slot];
 		slot = (slot + 1) & (WT_SLOTS - 1);
 	}
 }
 
 struct Hit {
 	bool pair;          // a mapped pair (quick_map3.c:223-245)
-	u32 pair_id, rec1, rec2;
+	u32 pair_id, rec1;
+	int which;          // 0: read-2 record A won, 1: B
 	int pos1, pos2, insert;
 	uint8_t rc1, rc2;
 };
@@ -461,37 +473,46 @@ struct Hit {
 __device__ inline Hit map_eval_hit(const MapLds& L, const ReadIndexDev& ix, int noff, u32 h) {
 	Hit r;
 	r.pair = false;
-	// offset holding hit h: last o with hpre[o] <= h
-	int lo = 0, hi = noff;
+	int lo = 0, hi = noff;                          // offset holding hit h: last o with hpre[o] <= h
 	while (hi - lo > 1) {
 		int mid = (lo + hi) >> 1;
 		if (L.hpre[mid] <= h) lo = mid; else hi = mid;
 	}
 	const int o = lo;
-	const u32 cl = L.cls[o];
-	const u32 rec = ix.recs[ix.start[cl] + (h - L.hpre[o])];
-	if (ix.read_num[rec] != 1) return r;            // read-2 instances only feed the read2 map
-	const u32 p = ix.pair_id[rec];
+	const u32 rec = ix.recs[L.cstart[o] + (h - L.hpre[o])];
+	const uint4 info = ix.rec_info[rec];
+	if (!(info.w & RI_R1)) return r;                // read-2 instances only feed the read2 map
 	// read2[id]: among the pair's read-2 records the one written last = largest offset, then latest registration
-	const u32 ra = ix.pair_r2[2 * (size_t) p], rb = ix.pair_r2[2 * (size_t) p + 1];
-	u32 best = 0, brec = NONE32;
-	if (ra != NONE32) { u32 l = map_last_occurrence(L, ix, ra); if (l) { best = l; brec = ra; } }
-	if (rb != NONE32) { u32 l = map_last_occurrence(L, ix, rb); if (l && l >= best) { best = l; brec = rb; } }
-	if (brec == NONE32) return r;
-	const uint8_t rc1 = ix.is_rc[rec], rc2 = ix.is_rc[brec];
+	const u32 la = map_last_occurrence(L, info.y), lb = map_last_occurrence(L, info.z);
+	if (!la && !lb) return r;
+	const int which = (lb && lb >= la) ? 1 : 0;
+	const u32 best = which ? lb : la;
+	const uint8_t rc1 = (info.w & RI_RC) ? 1 : 0;
+	const uint8_t rc2 = (info.w & (which ? RI_RCB : RI_RCA)) ? 1 : 0;
 	if (rc1 == rc2) return r;                       // quick_map3.c:227
 	const int pos1 = o + 1, pos2 = (int) best;
 	const int d = pos1 - pos2;
 	const int insert = (int) (short) ((d < 0 ? -d : d) + ix.rl);
 	if (insert < 50 || insert > 400) return r;      // MIN_INSERT / MAX_INSERT, quick_map3.c:23-24
 	r.pair = true;
-	r.pair_id = p; r.rec1 = rec; r.rec2 = brec;
+	r.pair_id = info.x; r.rec1 = rec; r.which = which;
 	r.pos1 = pos1; r.pos2 = pos2; r.insert = insert; r.rc1 = rc1; r.rc2 = rc2;
 	return r;
 }
 
+// hits per window/contig: sizes the pair scratch and orders the work largest-first
+__global__ __launch_bounds__(MAP_THREADS) void k_window_hits(ReadIndexDev ix, const char* __restrict__ windows, u32 n, int len,
+                                                             u32* __restrict__ out_hits) {
+	__shared__ MapLds L;
+	for (u32 wi = blockIdx.x; wi < n; wi += gridDim.x) {
+		const u32 H = map_prepare(L, ix, windows + (size_t) wi * len, len);
+		if (threadIdx.x == 0) out_hits[wi] = H;
+		__syncthreads();
+	}
+}
+
 // ----------------------------------------------------------------------------------------------
-// K8+K9: one workgroup per window.
+// K8+K9: one workgroup per window (largest first).
 //
 // coverage.c restated for counting hardware.  The start list holds (pos1,pos2) and
 // (pos2,pos1) per mapped pair (quick_map3.c:241-242).
@@ -501,14 +522,14 @@ __device__ inline Hit map_eval_hit(const MapLds& L, const ReadIndexDev& ix, int 
 //    first lies in (pos-rl, pos] and tests every j = pos+delta, delta in [clo, chi).  For a fixed delta
 //    an entry (f, s) is counted at pos iff both f and s-delta lie in (pos-rl, pos], i.e. for pos in
 //    [max(f, s-delta), min(f, s-delta)+rl): one +1/-1 pair in a difference array over pos.  The kernel
-//    keeps DB difference arrays (one per delta of the current batch) in LDS, re-enumerates the hits for
-//    every batch, prefixes, and tests.  O(entries * 2rl + positions * deltas) LDS operations per window
-//    instead of the reference's O(positions * entries-in-50bp * rl).
+//    keeps DB difference arrays (one per delta of the current batch) in LDS, replays the window's mapped
+//    pairs (stored once in a scratch list) for every batch, prefixes, and tests.
 // ----------------------------------------------------------------------------------------------
 #define COV_WORDS 8192
 __global__ __launch_bounds__(MAP_THREADS) void k_window_score(ReadIndexDev ix, const char* __restrict__ windows, u32 n, int len,
-                                                              vdjx_cov_params cp, uint8_t* __restrict__ out_valid,
-                                                              u32* __restrict__ out_npairs) {
+                                                              vdjx_cov_params cp, const u32* __restrict__ order,
+                                                              const u64* __restrict__ pair_off, u32* __restrict__ pair_buf,
+                                                              uint8_t* __restrict__ out_valid, u32* __restrict__ out_npairs) {
 	__shared__ MapLds L;
 	__shared__ u32 hf[MAP_MAXOFF + 64 + 2];         // histogram of firsts -> inclusive prefix "cum"
 	__shared__ int diff[COV_WORDS];
@@ -524,19 +545,27 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_score(ReadIndexDev ix, c
 	const int npos = e1 - e0;                        // positions e0 .. e1-1
 	const int stride = npos + 1;
 	const int DB = COV_WORDS / stride;               // deltas per batch (host guarantees >= 1)
-	for (u32 wi = blockIdx.x; wi < n; wi += gridDim.x) {
+	for (u32 bi = blockIdx.x; bi < n; bi += gridDim.x) {
+		const u32 wi = order[bi];
 		const char* w = windows + (size_t) wi * len;
+		u32* pairs = pair_buf + pair_off[wi];
 		const u32 H = map_prepare(L, ix, w, len);
 		for (u32 i = tid; i < (u32) D + 1; i += MAP_THREADS) hf[i] = 0;
 		if (tid == 0) { s_np = 0; s_bad = 0; }
 		__syncthreads();
-		for (u32 h = tid; h < H; h += MAP_THREADS) {
-			Hit r = map_eval_hit(L, ix, noff, h);
-			if (!r.pair) continue;
-			atomicAdd(&s_np, 1u);
-			atomicAdd(&hf[r.pos1], 1u);
-			atomicAdd(&hf[r.pos2], 1u);
+		for (u32 h0 = 0; h0 < H; h0 += MAP_THREADS) {
+			const u32 h = h0 + tid;
+			Hit r;
+			r.pair = false;
+			if (h < H) r = map_eval_hit(L, ix, noff, h);
+			const u32 slot = vdjx_wave_inc(&s_np, r.pair);
+			if (r.pair) {
+				pairs[slot] = ((u32) r.pos1 << 16) | (u32) r.pos2;
+				atomicAdd(&hf[r.pos1], 1u);
+				atomicAdd(&hf[r.pos2], 1u);
+			}
 		}
+		__threadfence_block();
 		__syncthreads();
 		const u32 npairs = s_np;
 		uint8_t valid = 1;
@@ -579,25 +608,23 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_score(ReadIndexDev ix, c
 				const int nd = chi - d0 < DB ? chi - d0 : DB;
 				for (int i = tid; i < nd * stride; i += MAP_THREADS) diff[i] = 0;
 				__syncthreads();
-				for (u32 h = tid; h < H; h += MAP_THREADS) {
-					Hit r = map_eval_hit(L, ix, noff, h);
-					if (!r.pair) continue;
-					for (int e = 0; e < 2; e++) {
-						const int f = e ? r.pos2 : r.pos1, sx = e ? r.pos1 : r.pos2;
-						// deltas of this batch with |f - (sx - delta)| < rl
-						int dlo = sx - f - rl + 1, dhi = sx - f + rl - 1;
-						if (dlo < d0) dlo = d0;
-						if (dhi > d0 + nd - 1) dhi = d0 + nd - 1;
-						for (int dl = dlo; dl <= dhi; dl++) {
-							const int v = sx - dl;
-							int lo = f > v ? f : v;                       // first pos that sees both
-							int hi = (f < v ? f : v) + rl;                // one past the last
-							if (lo < e0) lo = e0;
-							if (hi > e1) hi = e1;
-							if (lo < hi) {
-								atomicAdd(&diff[(dl - d0) * stride + (lo - e0)], 1);
-								atomicAdd(&diff[(dl - d0) * stride + (hi - e0)], -1);
-							}
+				for (u32 q = tid; q < 2 * npairs; q += MAP_THREADS) {
+					const u32 pr = pairs[q >> 1];
+					const int p1 = (int) (pr >> 16), p2 = (int) (pr & 0xFFFFu);
+					const int f = (q & 1) ? p2 : p1, sx = (q & 1) ? p1 : p2;
+					// deltas of this batch with |f - (sx - delta)| < rl
+					int dlo = sx - f - rl + 1, dhi = sx - f + rl - 1;
+					if (dlo < d0) dlo = d0;
+					if (dhi > d0 + nd - 1) dhi = d0 + nd - 1;
+					for (int dl = dlo; dl <= dhi; dl++) {
+						const int v = sx - dl;
+						int lo = f > v ? f : v;                           // first pos that sees both
+						int hi = (f < v ? f : v) + rl;                    // one past the last
+						if (lo < e0) lo = e0;
+						if (hi > e1) hi = e1;
+						if (lo < hi) {
+							atomicAdd(&diff[(dl - d0) * stride + (lo - e0)], 1);
+							atomicAdd(&diff[(dl - d0) * stride + (hi - e0)], -1);
 						}
 					}
 				}
@@ -630,17 +657,19 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_score(ReadIndexDev ix, c
 }
 
 // ----------------------------------------------------------------------------------------------
-// K10: mapped pairs of a contig in the reference's order.  mode 0: count only; mode 1: write.
+// K10: mapped pairs of a contig in the reference's order, written to a per-contig region of `pairs`
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(MAP_THREADS) void k_map_emit(ReadIndexDev ix, const char* __restrict__ contigs, u32 n, int len,
-                                                          int mode, u64* __restrict__ counts, const u64* __restrict__ offsets,
-                                                          vdjx_pair* __restrict__ pairs) {
+                                                          const u32* __restrict__ order, const u64* __restrict__ region_off,
+                                                          vdjx_pair* __restrict__ pairs, u64* __restrict__ counts) {
 	__shared__ MapLds L;
 	__shared__ u32 s_base;
 	const u32 tid = threadIdx.x;
 	const int noff = len - ix.rl;
-	for (u32 ci = blockIdx.x; ci < n; ci += gridDim.x) {
+	for (u32 bi = blockIdx.x; bi < n; bi += gridDim.x) {
+		const u32 ci = order[bi];
 		const char* w = contigs + (size_t) ci * len;
+		vdjx_pair* out = pairs + region_off[ci];
 		const u32 H = map_prepare(L, ix, w, len);
 		if (tid == 0) s_base = 0;
 		__syncthreads();
@@ -649,29 +678,43 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_emit(ReadIndexDev ix, const
 			Hit r;
 			r.pair = false;
 			if (h < H) r = map_eval_hit(L, ix, noff, h);
-			// ordered compaction: inclusive scan of the flags
-			L.scan[tid] = r.pair ? 1u : 0u;
+			// ordered compaction: inclusive scan of the flags (wave ballots + one LDS word per wave)
+			const u64 m = __ballot(r.pair);
+			const u32 lane = tid & 63, wv = tid >> 6;
+			const u32 before = __popcll(m & ((1ull << lane) - 1ull));
+			if (lane == 0) L.scan[wv] = (u32) __popcll(m);
 			__syncthreads();
-			for (u32 d = 1; d < MAP_THREADS; d <<= 1) {
-				u32 v = tid >= d ? L.scan[tid - d] : 0;
-				__syncthreads();
-				L.scan[tid] += v;
-				__syncthreads();
+			u32 wbase = 0, total = 0;
+			for (u32 i = 0; i < MAP_THREADS / 64; i++) {
+				const u32 v = L.scan[i];
+				if (i < wv) wbase += v;
+				total += v;
 			}
 			const u32 base = s_base;
-			if (r.pair && mode == 1) {
-				vdjx_pair* o = pairs + offsets[ci] + base + L.scan[tid] - 1;
-				o->pair_id = r.pair_id; o->rec1 = r.rec1; o->rec2 = r.rec2;
+			if (r.pair) {
+				vdjx_pair* o = out + base + wbase + before;
+				o->pair_id = r.pair_id; o->rec1 = r.rec1; o->rec2 = ix.pair_r2[2 * (size_t) r.pair_id + r.which];
 				o->pos1 = (int16_t) r.pos1; o->pos2 = (int16_t) r.pos2; o->insert = (int16_t) r.insert;
 				o->rc1 = r.rc1; o->rc2 = r.rc2;
 			}
 			__syncthreads();
-			if (tid == MAP_THREADS - 1) s_base = base + L.scan[tid];
+			if (tid == 0) s_base = base + total;
 			__syncthreads();
 		}
-		if (tid == 0 && mode == 0) counts[ci] = s_base;
+		if (tid == 0) counts[ci] = s_base;
 		__syncthreads();
 	}
+}
+
+// gather the per-contig regions into the dense caller layout
+__global__ void k_gather_pairs(const vdjx_pair* __restrict__ src, const u64* __restrict__ region_off, const u64* __restrict__ dst_off,
+                               u32 n, vdjx_pair* __restrict__ dst) {
+	const u32 ci = blockIdx.x;
+	if (ci >= n) return;
+	const u64 cnt = dst_off[ci + 1] - dst_off[ci];
+	const uint32_t* s = (const uint32_t*) (src + region_off[ci]);
+	uint32_t* d = (uint32_t*) (dst + dst_off[ci]);
+	for (u64 i = threadIdx.x; i < cnt * (sizeof(vdjx_pair) / 4); i += blockDim.x) d[i] = s[i];
 }
 
 static int make_index_view(vdjx_ctx* c, ReadIndexDev* ix, int len, const char* who) {
@@ -679,11 +722,37 @@ static int make_index_view(vdjx_ctx* c, ReadIndexDev* ix, int len, const char* w
 	const vdjx_pool* p = c->ri_pool;
 	if (len <= p->rl) { vdjx_set_error("%s: len=%d must exceed the read length %d", who, len, p->rl); return VDJX_EINVAL; }
 	if (len - p->rl > MAP_MAXOFF) { vdjx_set_error("%s: len=%d too long (max %d)", who, len, MAP_MAXOFF + p->rl); return VDJX_ELIMIT; }
-	ix->bases = p->d_bases; ix->nmask = p->d_nmask;
+	ix->bases = p->d_bases;
 	ix->slots = c->d_ri_slots; ix->mask = c->ri_nslots - 1;
 	ix->rep = c->d_ri_rep; ix->start = c->d_ri_start; ix->recs = c->d_ri_recs;
-	ix->pair_id = c->d_pair_id; ix->read_num = c->d_read_num; ix->is_rc = c->d_is_rc; ix->pair_r2 = c->d_pair_r2;
+	ix->rec_info = c->d_rec_info; ix->pair_r2 = c->d_pair_r2;
 	ix->rl = p->rl;
+	return VDJX_OK;
+}
+
+// hits per string, exclusive offsets, and the largest-first processing order
+static int plan_windows(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, const char* d_w, size_t n, int len,
+                        std::vector<u64>& off, u32** d_order, u64** d_off) {
+	hipStream_t st = c->stream;
+	u32* d_hits;
+	HIP_TRY(db.alloc(&d_hits, n));
+	{
+		vdjx_prof_scope ps(c, "k_window_hits");
+		hipLaunchKernelGGL(k_window_hits, dim3((u32) std::min<size_t>(n, 4096)), dim3(MAP_THREADS), 0, st, ix, d_w, (u32) n, len, d_hits);
+	}
+	std::vector<u32> hits(n), order(n);
+	HIP_TRY(hipMemcpyAsync(hits.data(), d_hits, n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	off.assign(n + 1, 0);
+	for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + hits[i];
+	std::iota(order.begin(), order.end(), 0u);
+	std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return hits[a] > hits[b]; });
+	HIP_TRY(db.alloc(d_order, n));
+	HIP_TRY(db.alloc(d_off, n + 1));
+	HIP_TRY(hipMemcpyAsync(*d_order, order.data(), n * 4, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(*d_off, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));       // `order`/`off` staging buffers die with this frame
 	return VDJX_OK;
 }
 
@@ -695,21 +764,26 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	int rc = make_index_view(c, &ix, len, "vdjx_window_score");
 	if (rc) return rc;
 	if (p->eval_start < 1 || p->eval_stop <= p->eval_start) { vdjx_set_error("vdjx_window_score: bad eval range"); return VDJX_EINVAL; }
+	if (p->eval_stop - p->eval_start + 1 > COV_WORDS) { vdjx_set_error("vdjx_window_score: eval range too long"); return VDJX_ELIMIT; }
+	if (n >= (1ull << 31)) { vdjx_set_error("vdjx_window_score: too many windows"); return VDJX_ELIMIT; }
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t st = c->stream;
-	DevBuf db;
-	const u32 grid = (u32) std::min<size_t>(n, 2048);
+	vdjx_work db(c);
 	char* d_w;
-	u32* d_np;
+	u32 *d_np, *d_order, *d_pairbuf;
+	u64* d_off;
 	uint8_t* d_valid;
-	if (p->eval_stop - p->eval_start + 1 > COV_WORDS) { vdjx_set_error("vdjx_window_score: eval range too long"); return VDJX_ELIMIT; }
 	HIP_TRY(db.alloc(&d_w, n * len));
 	HIP_TRY(db.alloc(&d_np, n));
 	HIP_TRY(db.alloc(&d_valid, n));
 	HIP_TRY(hipMemcpyAsync(d_w, windows, n * len, hipMemcpyHostToDevice, st));
+	std::vector<u64> off;
+	rc = plan_windows(c, db, ix, d_w, n, len, off, &d_order, &d_off);
+	if (rc) return rc;
+	HIP_TRY(db.alloc(&d_pairbuf, (size_t) off[n]));
 	{
 		vdjx_prof_scope ps(c, "k_window_score");
-		hipLaunchKernelGGL(k_window_score, dim3(grid), dim3(MAP_THREADS), 0, st, ix, d_w, (u32) n, len, *p, d_valid, d_np);
+		hipLaunchKernelGGL(k_window_score, dim3((u32) n), dim3(MAP_THREADS), 0, st, ix, d_w, (u32) n, len, *p, d_order, d_off, d_pairbuf, d_valid, d_np);
 	}
 	HIP_TRY(hipMemcpyAsync(out_valid, d_valid, n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
@@ -718,45 +792,73 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	return VDJX_OK;
 }
 
+static uint64_t fnv1a(const char* p, size_t n, uint64_t h) {
+	for (size_t i = 0; i < n; i++) { h ^= (unsigned char) p[i]; h *= 0x100000001b3ull; }
+	return h;
+}
+
 extern "C" int vdjx_map_emit(vdjx_ctx* c, const char* contigs, size_t n, int len, uint64_t* offsets, vdjx_pair* pairs) {
 	if (!c || !offsets || (n && !contigs)) { vdjx_set_error("vdjx_map_emit: NULL argument"); return VDJX_EINVAL; }
 	if (n == 0) { offsets[0] = 0; return VDJX_OK; }
+	if (n >= (1ull << 31)) { vdjx_set_error("vdjx_map_emit: too many contigs"); return VDJX_ELIMIT; }
 	ReadIndexDev ix;
 	int rc = make_index_view(c, &ix, len, "vdjx_map_emit");
 	if (rc) return rc;
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t st = c->stream;
-	DevBuf db;
-	const u32 grid = (u32) std::min<size_t>(n, 1024);
-	char* d_c;
-	u64 *d_counts, *d_off;
-	HIP_TRY(db.alloc(&d_c, n * len));
-	HIP_TRY(db.alloc(&d_counts, n));
-	HIP_TRY(db.alloc(&d_off, n + 1));
-	HIP_TRY(hipMemcpyAsync(d_c, contigs, n * len, hipMemcpyHostToDevice, st));
-	if (!pairs) {
-		{
-			vdjx_prof_scope ps(c, "k_map_emit_count");
-			hipLaunchKernelGGL(k_map_emit, dim3(grid), dim3(MAP_THREADS), 0, st, ix, d_c, (u32) n, len, 0, d_counts, (const u64*) nullptr, (vdjx_pair*) nullptr);
+	vdjx_work db(c);
+	// the mapping runs once: the counting call keeps its pairs on the device for the writing call
+	uint64_t key = fnv1a(contigs, n * (size_t) len, 0xcbf29ce484222325ull ^ (uint64_t) n * 1315423911ull ^ (uint64_t) len);
+	if (!key) key = 1;
+	if (c->me_key != key || c->me_cnt.size() != n) {
+		c->me_key = 0;
+		char* d_c;
+		u32* d_order;
+		u64 *d_off, *d_counts;
+		HIP_TRY(db.alloc(&d_c, n * len));
+		HIP_TRY(db.alloc(&d_counts, n));
+		HIP_TRY(hipMemcpyAsync(d_c, contigs, n * len, hipMemcpyHostToDevice, st));
+		std::vector<u64> off;
+		rc = plan_windows(c, db, ix, d_c, n, len, off, &d_order, &d_off);
+		if (rc) return rc;
+		if (off[n] > c->me_cap) {
+			free_set(c->me_pairs);
+			c->me_cap = 0;
+			HIP_TRY(hipMalloc(&c->me_pairs, (size_t) off[n] * sizeof(vdjx_pair)));
+			c->me_cap = (size_t) off[n];
 		}
-		std::vector<u64> cnt(n);
-		HIP_TRY(hipMemcpyAsync(cnt.data(), d_counts, n * 8, hipMemcpyDeviceToHost, st));
+		{
+			vdjx_prof_scope ps(c, "k_map_emit");
+			hipLaunchKernelGGL(k_map_emit, dim3((u32) n), dim3(MAP_THREADS), 0, st, ix, d_c, (u32) n, len, d_order, d_off,
+			                   (vdjx_pair*) c->me_pairs, d_counts);
+		}
+		c->me_cnt.resize(n);
+		HIP_TRY(hipMemcpyAsync(c->me_cnt.data(), d_counts, n * 8, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
 		HIP_TRY(hipGetLastError());
-		offsets[0] = 0;
-		for (size_t i = 0; i < n; i++) offsets[i + 1] = offsets[i] + cnt[i];
-		return VDJX_OK;
+		c->me_hoff = off;
+		c->me_key = key;
 	}
-	vdjx_pair* d_pairs;
+	offsets[0] = 0;
+	for (size_t i = 0; i < n; i++) offsets[i + 1] = offsets[i] + c->me_cnt[i];
+	if (!pairs) return VDJX_OK;
 	const u64 total = offsets[n];
-	HIP_TRY(db.alloc(&d_pairs, (size_t) total));
-	HIP_TRY(hipMemcpyAsync(d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
-	{
-		vdjx_prof_scope ps(c, "k_map_emit");
-		hipLaunchKernelGGL(k_map_emit, dim3(grid), dim3(MAP_THREADS), 0, st, ix, d_c, (u32) n, len, 1, d_counts, (const u64*) d_off, d_pairs);
+	if (total) {
+		vdjx_pair* d_dense;
+		u64 *d_roff, *d_doff;
+		HIP_TRY(db.alloc(&d_dense, (size_t) total));
+		HIP_TRY(db.alloc(&d_roff, n + 1));
+		HIP_TRY(db.alloc(&d_doff, n + 1));
+		HIP_TRY(hipMemcpyAsync(d_roff, c->me_hoff.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(d_doff, offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
+		{
+			vdjx_prof_scope ps(c, "k_gather_pairs");
+			hipLaunchKernelGGL(k_gather_pairs, dim3((u32) n), dim3(256), 0, st, (const vdjx_pair*) c->me_pairs, d_roff, d_doff, (u32) n, d_dense);
+		}
+		HIP_TRY(hipMemcpyAsync(pairs, d_dense, (size_t) total * sizeof(vdjx_pair), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(hipGetLastError());
 	}
-	if (total) HIP_TRY(hipMemcpyAsync(pairs, d_pairs, (size_t) total * sizeof(vdjx_pair), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	HIP_TRY(hipGetLastError());
+	c->me_key = 0;           // one counting call serves one writing call
 	return VDJX_OK;
 }
