@@ -110,6 +110,7 @@ struct vdjx_graph {
 	std::vector<uint8_t> has_v, has_j, to_deg, from_deg;
 	std::vector<uint32_t> to_ids, from_ids;
 	std::vector<u64> key_lo, key_hi;
+	std::vector<char> kmers;         // n*k ASCII
 };
 
 // scoped workspace allocations out of the context's arena

@@ -465,6 +465,115 @@ __global__ void k_node_flags(const u64* __restrict__ s_lo, const u64* __restrict
 	has_j[i] = code ? (jbits[code >> 5] >> (code & 31)) & 1u : 0;
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// K6: node numbering and list building on the device.
+// Node ids are creation order (new_node, A2:188-204) = rank of the node's first ungated instance.
+// First instances are distinct integers below R*P, so the rank comes from a bitmap over the instance
+// space and a popcount prefix (no sort).  toNodes/fromNodes are prepend-on-first-sight lists
+// (link_nodes, A2:223-237) of at most 4 entries: a 4-element sort by first sight, newest first.
+// ----------------------------------------------------------------------------------------------
+__global__ void k_mark_first(const u32* __restrict__ ufirst, u32 n, u32* __restrict__ bits) {
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) atomicOr(&bits[ufirst[i] >> 5], 1u << (ufirst[i] & 31));
+}
+
+#define POPC_WORDS 4096u
+__global__ __launch_bounds__(256) void k_popc_blocks(const u32* __restrict__ bits, u32 nwords, u32* __restrict__ word_pre,
+                                                     u32* __restrict__ block_sum) {
+	__shared__ u32 part[256];
+	const u32 w0 = blockIdx.x * POPC_WORDS + threadIdx.x * 16;
+	u32 loc[16];
+	u32 s = 0;
+	for (int i = 0; i < 16; i++) {
+		const u32 w = w0 + i;
+		loc[i] = s;
+		s += w < nwords ? __popc(bits[w]) : 0;
+	}
+	part[threadIdx.x] = s;
+	__syncthreads();
+	for (u32 d = 1; d < 256; d <<= 1) {
+		u32 v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+		__syncthreads();
+		part[threadIdx.x] += v;
+		__syncthreads();
+	}
+	const u32 excl = part[threadIdx.x] - s;
+	for (int i = 0; i < 16; i++) if (w0 + i < nwords) word_pre[w0 + i] = excl + loc[i];
+	if (threadIdx.x == 255) block_sum[blockIdx.x] = part[255];
+}
+
+struct NodeOut {
+	u64* first_inst; u32* gcnt; u32* freq; uint8_t* hv; uint8_t* hj; u64* klo; u64* khi; char* kmers;
+	uint8_t* to_deg; u32* to_ids; uint8_t* from_deg; u32* from_ids;
+};
+
+__global__ void k_node_rank(const u32* __restrict__ ufirst, u32 n, const u32* __restrict__ bits, const u32* __restrict__ word_pre,
+                            const u32* __restrict__ block_pre, u32* __restrict__ rank) {
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const u32 f = ufirst[i], w = f >> 5;
+	rank[i] = block_pre[w / POPC_WORDS] + word_pre[w] + __popc(bits[w] & ((1u << (f & 31)) - 1u));
+}
+
+// in-edges: (u -> v) lands in slot (v, first base of u); a k-mer has at most 4 predecessors
+__global__ void k_in_edges(const u32* __restrict__ edge_first, const u32* __restrict__ edge_to, const u64* __restrict__ s_lo,
+                           const u64* __restrict__ s_hi, u32 n, int k, u32* __restrict__ in_first, u32* __restrict__ in_from) {
+	u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n * 4u) return;
+	const u32 ef = edge_first[e];
+	if (ef == NONE32) return;
+	const u32 u = e >> 2, v = edge_to[e];
+	const u128 key = ((u128) s_hi[u] << 64) | s_lo[u];
+	const u32 a = (u32) (key >> (2 * (k - 1))) & 3u;
+	in_first[v * 4 + a] = ef;
+	in_from[v * 4 + a] = u;
+}
+
+__device__ inline void sort4_desc(u32 (&f)[4], u32 (&id)[4]) {
+	// entries with f == NONE32 are absent: give them the smallest key
+#define CSWAP(a, b) { const bool sw = key[a] < key[b]; if (sw) { u64 t = key[a]; key[a] = key[b]; key[b] = t; } }
+	u64 key[4];
+	for (int i = 0; i < 4; i++) key[i] = f[i] == NONE32 ? 0ull : (((u64) f[i] + 1) << 32) | id[i];
+	CSWAP(0, 1) CSWAP(2, 3) CSWAP(0, 2) CSWAP(1, 3) CSWAP(1, 2)
+	for (int i = 0; i < 4; i++) { f[i] = key[i] ? (u32) (key[i] >> 32) - 1 : NONE32; id[i] = (u32) key[i]; }
+#undef CSWAP
+}
+
+__global__ void k_node_emit(const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, const u32* __restrict__ s_gcnt,
+                            const u32* __restrict__ s_ucnt, const u32* __restrict__ s_ufirst, const uint8_t* __restrict__ hv,
+                            const uint8_t* __restrict__ hj, const u32* __restrict__ rank, const u32* __restrict__ edge_first,
+                            const u32* __restrict__ edge_to, const u32* __restrict__ in_first, const u32* __restrict__ in_from,
+                            u32 n, int k, int P, NodeOut o) {
+	u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n) return;
+	const u32 r = rank[s];
+	const u32 inst = s_ufirst[s];
+	o.first_inst[r] = (u64) (inst / (u32) P) * 64 + (inst % (u32) P);
+	o.gcnt[r] = s_gcnt[s];
+	o.freq[r] = s_ucnt[s];
+	o.hv[r] = hv[s];
+	o.hj[r] = hj[s];
+	o.klo[r] = s_lo[s];
+	o.khi[r] = s_hi[s];
+	const u128 key = ((u128) s_hi[s] << 64) | s_lo[s];
+	for (int j = 0; j < k; j++) {
+		const u32 b = (u32) (key >> (2 * (k - 1 - j))) & 3u;
+		o.kmers[(size_t) r * k + j] = b == 0 ? 'A' : (b == 1 ? 'T' : (b == 2 ? 'C' : 'G'));
+	}
+	u32 f[4], id[4];
+	for (int e = 0; e < 4; e++) { f[e] = edge_first[s * 4 + e]; id[e] = f[e] != NONE32 ? rank[edge_to[s * 4 + e]] + 1 : 0; }
+	sort4_desc(f, id);
+	u32 deg = 0;
+	for (int e = 0; e < 4; e++) { o.to_ids[(size_t) r * 4 + e] = f[e] != NONE32 ? id[e] : 0; deg += f[e] != NONE32; }
+	o.to_deg[r] = (uint8_t) deg;
+	for (int e = 0; e < 4; e++) { f[e] = in_first[s * 4 + e]; id[e] = f[e] != NONE32 ? rank[in_from[s * 4 + e]] + 1 : 0; }
+	sort4_desc(f, id);
+	deg = 0;
+	for (int e = 0; e < 4; e++) { o.from_ids[(size_t) r * 4 + e] = f[e] != NONE32 ? id[e] : 0; deg += f[e] != NONE32; }
+	o.from_deg[r] = (uint8_t) deg;
+}
+
 // ----------------------------------------------------------------------------------------------
 // host driver
 // ----------------------------------------------------------------------------------------------
@@ -616,53 +725,55 @@ int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, v
 		hipLaunchKernelGGL(k_node_flags, dim3((ns + 255) / 256), dim3(256), 0, st, s_lo, s_hi, ns, k, c->d_vbits, c->d_jbits, d_hv, d_hj);
 	}
 
-	// ---- to the host: nodes sorted by first (ungated) sight == creation order of new_node (A2:188-204)
-	std::vector<u64> lo(ns), hi(ns);
-	std::vector<u32> gcnt(ns), gfirst(ns), ucnt(ns), ufirst(ns), ef((size_t) ns * 4), et((size_t) ns * 4);
-	std::vector<uint8_t> hv(ns), hj(ns);
-	HIP_TRY(hipMemcpyAsync(lo.data(), s_lo, (size_t) ns * 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(hi.data(), s_hi, (size_t) ns * 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(gcnt.data(), s_gcnt, (size_t) ns * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(gfirst.data(), s_gfirst, (size_t) ns * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(ucnt.data(), s_ucnt, (size_t) ns * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(ufirst.data(), s_ufirst, (size_t) ns * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(ef.data(), edge_first, (size_t) ns * 16, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(et.data(), edge_to, (size_t) ns * 16, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(hv.data(), d_hv, ns, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(hj.data(), d_hj, ns, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	HIP_TRY(hipGetLastError());
-
-	std::vector<u32> order(ns), rank(ns);
-	std::iota(order.begin(), order.end(), 0u);
-	std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return ufirst[a] < ufirst[b]; });
-	for (u32 i = 0; i < ns; i++) rank[order[i]] = i;
-
+	// ---- node ids, ordered lists, k-mer text: all on the device (K6), the host only copies
+	const u32 nwords = (u32) ((NI + 31) / 32);
+	const u32 npb = (nwords + POPC_WORDS - 1) / POPC_WORDS;
+	u32 *bits, *word_pre, *block_sum, *block_pre, *rank, *in_first, *in_from;
+	HIP_TRY(db.alloc(&bits, nwords));
+	HIP_TRY(db.alloc(&word_pre, nwords));
+	HIP_TRY(db.alloc(&block_sum, npb));
+	HIP_TRY(db.alloc(&block_pre, npb + 1));
+	HIP_TRY(db.alloc(&rank, ns));
+	HIP_TRY(db.alloc(&in_first, (size_t) ns * 4));
+	HIP_TRY(db.alloc(&in_from, (size_t) ns * 4));
+	NodeOut no;
+	HIP_TRY(db.alloc(&no.first_inst, ns)); HIP_TRY(db.alloc(&no.gcnt, ns)); HIP_TRY(db.alloc(&no.freq, ns));
+	HIP_TRY(db.alloc(&no.hv, ns)); HIP_TRY(db.alloc(&no.hj, ns)); HIP_TRY(db.alloc(&no.klo, ns)); HIP_TRY(db.alloc(&no.khi, ns));
+	HIP_TRY(db.alloc(&no.kmers, (size_t) ns * k));
+	HIP_TRY(db.alloc(&no.to_deg, ns)); HIP_TRY(db.alloc(&no.to_ids, (size_t) ns * 4));
+	HIP_TRY(db.alloc(&no.from_deg, ns)); HIP_TRY(db.alloc(&no.from_ids, (size_t) ns * 4));
+	HIP_TRY(hipMemsetAsync(bits, 0, (size_t) nwords * 4, st));
+	HIP_TRY(hipMemsetAsync(in_first, 0xFF, (size_t) ns * 16, st));
+	{
+		vdjx_prof_scope ps(c, "k_node_order");
+		hipLaunchKernelGGL(k_mark_first, dim3((ns + 255) / 256), dim3(256), 0, st, s_ufirst, ns, bits);
+		hipLaunchKernelGGL(k_popc_blocks, dim3(npb), dim3(256), 0, st, bits, nwords, word_pre, block_sum);
+		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, block_sum, npb, block_pre);
+		hipLaunchKernelGGL(k_node_rank, dim3((ns + 255) / 256), dim3(256), 0, st, s_ufirst, ns, bits, word_pre, block_pre, rank);
+		hipLaunchKernelGGL(k_in_edges, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, edge_first, edge_to, s_lo, s_hi, ns, k, in_first, in_from);
+		hipLaunchKernelGGL(k_node_emit, dim3((ns + 255) / 256), dim3(256), 0, st, s_lo, s_hi, s_gcnt, s_ucnt, s_ufirst, d_hv, d_hj, rank,
+		                   edge_first, edge_to, in_first, in_from, ns, k, P, no);
+	}
 	g->first_inst.resize(ns); g->gated_count.resize(ns); g->freq.resize(ns);
 	g->has_v.resize(ns); g->has_j.resize(ns);
-	g->to_deg.assign(ns, 0); g->from_deg.assign(ns, 0);
-	g->to_ids.assign((size_t) ns * 4, 0); g->from_ids.assign((size_t) ns * 4, 0);
+	g->to_deg.resize(ns); g->from_deg.resize(ns);
+	g->to_ids.resize((size_t) ns * 4); g->from_ids.resize((size_t) ns * 4);
 	g->key_lo.resize(ns); g->key_hi.resize(ns);
-	struct Edge { u32 first, from, to; };
-	std::vector<Edge> edges;
-	edges.reserve((size_t) ns * 2);
-	for (u32 i = 0; i < ns; i++) {
-		const u32 s = order[i];
-		const u32 inst = ufirst[s];
-		g->first_inst[i] = (uint64_t) (inst / (u32) P) * 64 + (inst % (u32) P);
-		g->gated_count[i] = gcnt[s];
-		g->freq[i] = ucnt[s];
-		g->has_v[i] = hv[s]; g->has_j[i] = hj[s];
-		g->key_lo[i] = lo[s]; g->key_hi[i] = hi[s];
-		for (int e = 0; e < 4; e++)
-			if (ef[(size_t) s * 4 + e] != NONE32) edges.push_back({ef[(size_t) s * 4 + e], i, rank[et[(size_t) s * 4 + e]]});
-	}
-	// prepend-on-first-sight lists (A2:223-237): the most recently first-seen edge is the list head
-	std::sort(edges.begin(), edges.end(), [](const Edge& a, const Edge& b) { return a.first > b.first; });
-	for (const Edge& e : edges) {
-		if (g->to_deg[e.from] < 4) g->to_ids[(size_t) e.from * 4 + g->to_deg[e.from]++] = e.to + 1;
-		if (g->from_deg[e.to] < 4) g->from_ids[(size_t) e.to * 4 + g->from_deg[e.to]++] = e.from + 1;
-	}
+	g->kmers.resize((size_t) ns * k);
+	HIP_TRY(hipMemcpyAsync(g->first_inst.data(), no.first_inst, (size_t) ns * 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(g->gated_count.data(), no.gcnt, (size_t) ns * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(g->freq.data(), no.freq, (size_t) ns * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(g->has_v.data(), no.hv, ns, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(g->has_j.data(), no.hj, ns, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(g->key_lo.data(), no.klo, (size_t) ns * 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(g->key_hi.data(), no.khi, (size_t) ns * 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(g->kmers.data(), no.kmers, (size_t) ns * k, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(g->to_deg.data(), no.to_deg, ns, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(g->to_ids.data(), no.to_ids, (size_t) ns * 16, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(g->from_deg.data(), no.from_deg, ns, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(g->from_ids.data(), no.from_ids, (size_t) ns * 16, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
 	return VDJX_OK;
 }
 
@@ -701,13 +812,7 @@ extern "C" int vdjx_graph_export(const vdjx_graph* g, uint64_t* first_inst, uint
 	if (from_deg) memcpy(from_deg, g->from_deg.data(), n);
 	if (to_ids) memcpy(to_ids, g->to_ids.data(), n * 16);
 	if (from_ids) memcpy(from_ids, g->from_ids.data(), n * 16);
-	if (kmers) {
-		static const char L[4] = {'A', 'T', 'C', 'G'};
-		for (size_t i = 0; i < n; i++) {
-			u128 key = ((u128) g->key_hi[i] << 64) | g->key_lo[i];
-			for (int j = 0; j < g->k; j++) kmers[i * g->k + j] = L[(unsigned) (key >> (2 * (g->k - 1 - j))) & 3u];
-		}
-	}
+	if (kmers) memcpy(kmers, g->kmers.data(), n * (size_t) g->k);
 	return VDJX_OK;
 }
 
