@@ -138,9 +138,43 @@ def main():
 
     state = {}
     # the read index belongs to extraction in the reference (add_read_info is called from extract, bam_read.c:228,243):
-    # built once, outside the timed region, over a pool handle that stays alive
-    p_index = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
-    ctx.read_index_build(p_index, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+    # built once, outside the timed region, over a pool handle that stays alive.  With several GPUs every rank
+    # holds the index of the WHOLE pool (replicate the index, shard the windows: no communication).
+    if world == 1:
+        p_index = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
+        ctx.read_index_build(p_index, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+    else:
+        mine = torch.cat([d_pri, d_sec], dim=0)
+        R_loc = mine.shape[0]
+        allrec = torch.empty((world * R_loc, mine.shape[1]), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(allrec, mine)
+
+        def gather_np(a, scale):
+            x = torch.from_numpy(a.astype(np.int64) + rank * scale).to(dev)
+            out = torch.empty(world * x.shape[0], dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(out, x)
+            return out.cpu().numpy()
+        g_pair = gather_np(pool.pair_id, args.pairs).astype(np.uint32)
+        g_rank = gather_np(pool.reg_rank, 4 * args.pairs).astype(np.uint32)
+        g_rnum = gather_np(pool.read_num, 0).astype(np.uint8)
+        g_rc = gather_np(pool.is_rc, 0).astype(np.uint8)
+        torch.cuda.synchronize()
+        p_index = ctx.pool_load_device(0, 0, allrec.data_ptr(), allrec.shape[0], rl)
+        ctx.read_index_build(p_index, g_pair, g_rnum, g_rc, g_rank, args.pairs * world)
+        del allrec, mine
+    my_wins = wins[rank::world]
+
+    def gather_bytes(a):
+        """all_gather of a small uint8 vector whose length differs per rank"""
+        n = torch.tensor([a.shape[0]], dtype=torch.int64, device=dev)
+        ns = [torch.empty_like(n) for _ in range(world)]
+        dist.all_gather(ns, n)
+        mx = max(int(x.item()) for x in ns)
+        pad = torch.zeros(max(mx, 1), dtype=torch.uint8, device=dev)
+        pad[:a.shape[0]] = torch.from_numpy(a).to(dev)
+        outs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(outs, pad)
+        return [o[:int(x.item())].cpu().numpy() for o, x in zip(outs, ns)]
 
     wall = {}
 
@@ -158,15 +192,20 @@ def main():
             g = engine.kmer_build(p, args.k, args.mf, args.mq)
         t = lap("kmer_build", t)
         roots = g.kmers[g.from_deg == 0]
-        ok = ctx.root_score(roots, args.k, args.mrs) if roots.shape[0] else np.zeros(0, np.uint8)
+        my_roots = roots[rank::world]
+        ok = ctx.root_score(my_roots, args.k, args.mrs) if my_roots.shape[0] else np.zeros(0, np.uint8)
         t = lap("root_score", t)
-        valid, npairs = ctx.window_score(wins, args.ins)
+        valid, npairs = ctx.window_score(my_wins, args.ins)
         t = lap("window_score", t)
-        contigs = [w[51:411] for w, v in zip(wins, valid) if v]
+        contigs = [w[51:411] for w, v in zip(my_wins, valid) if v]
         offs, pairs = ctx.map_emit(contigs)
         t = lap("map_emit", t)
+        if world > 1:      # every rank learns every verdict (a few KB)
+            ok = np.concatenate(gather_bytes(ok))
+            valid = np.concatenate(gather_bytes(valid))
+            t = lap("gather_results", t)
         state.update(nodes=g.n, pre=g.pre_nodes, roots=int(roots.shape[0]), roots_ok=int(ok.sum()), windows=len(wins),
-                     valid=int(valid.sum()), mapped=int(pairs.shape[0]), graph=g)
+                     valid=int(valid.sum()), mapped_this_rank=int(pairs.shape[0]), graph=g)
         p.free()
 
     def barrier():

@@ -139,7 +139,40 @@ int vdjx_profile_count(vdjx_ctx* ctx);
 /* idx-th entry: kernel name, summed milliseconds, launch count */
 int vdjx_profile_get(vdjx_ctx* ctx, int idx, const char** name, double* total_ms, uint64_t* launches);
 
-/* ---- multi-GPU (hash-prefix sharding) -- declared in round 1, see DESIGN.md §7 ------ */
+/* ---- multi-GPU k-mer build: hash-prefix sharding with one exchange step ------------------
+ * The reference has no counterpart (its only parallelism is pthreads over roots, A2:1287-1348); these
+ * phases split vdjx_kmer_build so that the caller can move the bytes between ranks (one process per GPU;
+ * vdjer_amd/shard.py does it with torch.distributed over RCCL).  Record numbering is rank-major with a
+ * common stride: rank r's records are [r*rec_stride, r*rec_stride + R_r).  nranks is a power of two; the
+ * owner of a k-mer is given by the top log2(nranks) bits of its hash.  All pointers are device pointers
+ * owned by the caller and must stay valid until vdjx_shard_free.  Call order:
+ *   begin -> pool_export -> [all_gather] -> set_pool -> partition_count -> [all_to_all counts]
+ *   -> partition_fill -> [all_to_all tuples] -> reduce -> survivors -> [all_gather] -> edges
+ *   -> [all_reduce MIN] -> finish -> free                                                          */
+typedef struct vdjx_shard vdjx_shard;
+int vdjx_shard_begin(vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, int rank, int nranks,
+                     uint64_t rec_stride, vdjx_shard** out);
+void vdjx_shard_free(vdjx_shard* s);
+int vdjx_shard_qstride(const vdjx_shard* s);       /* quality bytes per record in the packed pool */
+int vdjx_shard_key_hi_bytes(const vdjx_shard* s);  /* 4 (k <= 47) or 8: width of the key_hi tuple column */
+/* local packed pool -> caller buffers: R x 16 B bases, R x 8 B N mask, R x qstride B qualities */
+int vdjx_shard_pool_export(vdjx_shard* s, void* d_bases, void* d_nmask, void* d_quals);
+/* the replicated pool: nranks*rec_stride records each */
+int vdjx_shard_set_pool(vdjx_shard* s, const void* d_bases_all, const void* d_nmask_all, const void* d_quals_all);
+/* send_counts[nranks]: k-mer instances this rank sends to every owner */
+int vdjx_shard_partition_count(vdjx_shard* s, uint64_t* send_counts);
+/* tuple columns (u64 key_lo, u32|u64 key_hi, u32 instance|gated bit), owner-contiguous, sum(send_counts) entries */
+int vdjx_shard_partition_fill(vdjx_shard* s, void* d_lo, void* d_hi, void* d_inst);
+/* owner side: the received tuples -> this rank's survivors (a-1/a-2 for the k-mers it owns) */
+int vdjx_shard_reduce(vdjx_shard* s, const void* d_lo, const void* d_hi, const void* d_inst, uint64_t n_recv,
+                      uint64_t* n_survivors, uint64_t* n_distinct);
+/* n_survivors records of 32 B: {u64 key_lo, u64 key_hi, u32 gated count, u32 gated first, u32 count, u32 first} */
+int vdjx_shard_survivors(vdjx_shard* s, void* d_out);
+/* all ranks' survivors (rank order) -> local edge pass into d_edge_first/d_edge_to [ns_total*4] u32
+ * (0xFFFFFFFF = no edge); the caller MIN-reduces both arrays over ranks (unsigned order) */
+int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t ns_total, void* d_edge_first, void* d_edge_to);
+/* reduced edge arrays -> the graph, identical on every rank */
+int vdjx_shard_finish(vdjx_shard* s, const void* d_edge_first, const void* d_edge_to, uint64_t pre_nodes_total, vdjx_graph** out);
 
 #ifdef __cplusplus
 }

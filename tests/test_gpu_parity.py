@@ -246,3 +246,54 @@ def test_window_score_vs_oracle_seeded(ctx):
             exp = 1 if fl == 0 else ix.coverage_is_valid(starts, len(w), ins, rs=rs, ms=ms, floor=fl)
             assert int(valid[i]) == exp, (i, ins, rs, ms, fl)
     p.free()
+
+
+@pytest.mark.parametrize("world,k,mf,mq", [(2, 35, 3, 90), (4, 25, 2, 60), (2, 48, 2, 60)])
+def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq):
+    """The real multi-rank driver + the HIP phase engine with `world` ranks on this one GPU (ranks are threads,
+    collectives are tensor copies: tests/fake_dist.py).  Result == single-GPU build of the union pool == oracle."""
+    import threading
+    import torch
+    from tests.fake_dist import ThreadDist
+    from vdjer_amd import api, shard, synth
+    rep = synth.make_repertoire(6, seed=41)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    pools = [synth.make_reads(rep, 6000, noise_frac=0.3, seed=500 + r, err=0.004, n_rate=0.002) for r in range(world)]
+    cat = np.concatenate([np.concatenate([p.primary, p.secondary]) for p in pools])
+    R = cat.shape[0]
+    union = synth.ReadPool(50, cat, np.zeros((0, 101), np.uint8), np.zeros(R, np.uint32), np.zeros(R, np.uint8),
+                           np.zeros(R, np.uint8), np.arange(R, dtype=np.uint32), 0)
+    ref = run_both(ctx, union, vc, jc, k, mf, mq)           # single-GPU == oracle, and the reference result
+    dist = ThreadDist(world)
+    out, errs = [None] * world, []
+
+    def work(r):
+        try:
+            dist.set_rank(r)
+            c = api.Context(0)
+            c.anchor_sets_load(vc, jc)
+            p = c.pool_load(pools[r].primary, pools[r].secondary, 50)
+            drv = shard.ShardedHotPath(c, dist, torch.device("cuda", 0))
+            out[r] = drv.kmer_build(p, k, mf, mq)
+            p.free()
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            dist.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for g in out:
+        assert g.n == ref.n and g.pre_nodes == ref.pre_nodes
+        np.testing.assert_array_equal(g.first_inst, ref.first_inst)
+        np.testing.assert_array_equal(g.freq, ref.freq)
+        np.testing.assert_array_equal(g.gated_count, ref.gated_count)
+        np.testing.assert_array_equal(g.has_v, ref.has_v)
+        np.testing.assert_array_equal(g.to_ids, ref.to_ids)
+        np.testing.assert_array_equal(g.from_ids, ref.from_ids)
+        np.testing.assert_array_equal(g.kmers, ref.kmers)

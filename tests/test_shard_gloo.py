@@ -1,0 +1,87 @@
+"""world_size-2 `gloo` run (CPU) of the multi-rank driver vdjer_amd/shard.py: the all_gather / all-to-all /
+all_reduce choreography, split arithmetic and record numbering, with the pure-Python phase engine of
+tests/shard_ref_engine.py standing in for the GPU engine.  The sharded result must equal the oracle's
+single-process result on the rank-major concatenation of the shards."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(rank, n_pairs=90, seed=5):
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(2, seed=seed)
+    pool = synth.make_reads(rep, n_pairs, noise_frac=0.2, seed=100 + rank, err=0.01, n_rate=0.004)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    return rep, pool, vc, jc
+
+
+def _worker(rank, world, port, k, mf, mq, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from tests.shard_ref_engine import RefShardEngine
+    from vdjer_amd import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rep, pool, vc, jc = _make(rank)
+        drv = shard.ShardedHotPath(None, dist, torch.device("cpu"), engine=RefShardEngine(vc, jc))
+        g = drv.kmer_build(pool, k, mf, mq)
+        q.put((rank, g.n, g.pre_nodes, g.first_inst.tolist(), g.freq.tolist(), g.gated_count.tolist(), g.has_v.tolist(),
+               g.has_j.tolist(), g.to_ids.tolist(), g.from_ids.tolist(), drv.bytes_exchanged))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,mf,mq", [(35, 2, 60), (25, 2, 40)])
+def test_sharded_driver_world2_gloo(k, mf, mq):
+    import torch.multiprocessing as mp
+    from oracle import oracle
+    from vdjer_amd import synth
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, k, mf, mq, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the union pool in rank-major scan order
+    pools = [_make(r)[1] for r in range(world)]
+    rep, _, vc, jc = _make(0)
+    cat = np.concatenate([np.concatenate([p.primary, p.secondary]) for p in pools])
+    union = synth.ReadPool(50, cat, np.zeros((0, 101), np.uint8), np.zeros(cat.shape[0], np.uint32), np.zeros(cat.shape[0], np.uint8),
+                           np.zeros(cat.shape[0], np.uint8), np.arange(cat.shape[0], dtype=np.uint32), 0)
+    t = oracle.KmerTable(union, k)
+    pre = t.size()
+    t.prune(mf, mq)
+    first, count, _, _ = t.export()
+    og = oracle.Graph(t, vc, jc)
+    assert og.n > 20
+    for r in res:                          # identical on every rank
+        assert r[1] == og.n and r[2] == pre
+        assert r[3] == og.first.tolist()
+        assert r[4] == og.freq.tolist()
+        assert r[6] == og.has_v.tolist() and r[7] == og.has_j.tolist()
+        assert r[8] == og.to_ids.tolist() and r[9] == og.from_ids.tolist()
+        assert r[10] > 0
+    gc = {int(f): int(c) for f, c in zip(first, count)}
+    assert sorted(res[0][5]) == sorted(gc.values())

@@ -19,6 +19,9 @@ SYMBOLS = [
     "vdjx_vregion_load", "vdjx_root_score",
     "vdjx_read_index_build", "vdjx_window_score", "vdjx_map_emit",
     "vdjx_profile_enable", "vdjx_profile_reset", "vdjx_profile_count", "vdjx_profile_get",
+    "vdjx_shard_begin", "vdjx_shard_free", "vdjx_shard_qstride", "vdjx_shard_key_hi_bytes", "vdjx_shard_pool_export",
+    "vdjx_shard_set_pool", "vdjx_shard_partition_count", "vdjx_shard_partition_fill", "vdjx_shard_reduce",
+    "vdjx_shard_survivors", "vdjx_shard_edges", "vdjx_shard_finish",
 ]
 
 

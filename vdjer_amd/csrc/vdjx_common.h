@@ -50,9 +50,13 @@ struct vdjx_arena {
 	void release();
 };
 
+struct vdjx_shard;
+
 struct vdjx_ctx {
 	int device = 0;
 	vdjx_arena arena;
+	vdjx_arena shard_arena;            // lives across the phases of one sharded build
+	vdjx_shard* live_shard = nullptr;
 	hipStream_t stream = nullptr;
 	bool profiling = false;
 	std::vector<std::string> prof_names;                 // insertion order

@@ -50,6 +50,7 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	free_dev(c->d_pair_id); free_dev(c->d_read_num); free_dev(c->d_is_rc); free_dev(c->d_pair_r2);
 	free_dev(c->d_rec_info); free_dev(c->me_pairs);
 	c->arena.release();
+	c->shard_arena.release();
 	for (auto& p : c->prof_pending) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
 	(void) hipStreamDestroy(c->stream);
 	delete c;

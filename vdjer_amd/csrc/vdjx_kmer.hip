@@ -56,7 +56,7 @@ __device__ inline RecView load_rec(const u64* __restrict__ bases, const u64* __r
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HIST_THREADS) void k_kmer_hist(const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                             size_t R, int rl, int k, u32 nb_bits, size_t rpb,
-                                                            u32* __restrict__ block_hist) {
+                                                            u32* __restrict__ block_hist) {   // bucket sizes do not depend on the record numbering
 	extern __shared__ u32 hist[];
 	const u32 NB = 1u << nb_bits;
 	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) hist[i] = 0;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(const u32* __restrict__ bu
 // ----------------------------------------------------------------------------------------------
 template <typename THI>
 __global__ __launch_bounds__(HIST_THREADS) void k_kmer_scatter(const u64* __restrict__ bases, const u64* __restrict__ nmask,
-                                                               const u64* __restrict__ lowq, size_t R, int rl, int k, u32 nb_bits,
+                                                               const u64* __restrict__ lowq, size_t R, u32 rec_base, int rl, int k, u32 nb_bits,
                                                                size_t rpb, const u32* __restrict__ block_hist,
                                                                const u32* __restrict__ bucket_start, u64* __restrict__ t_lo,
                                                                THI* __restrict__ t_hi, u32* __restrict__ t_inst) {
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(HIST_THREADS) void k_kmer_scatter(const u64* __rest
 			u32 gated = ((v.lq >> o) & km) ? 0u : 0x80000000u;   // all k Phred >= 20 (A2:252)
 			t_lo[pos] = klo;
 			t_hi[pos] = (THI) khi;
-			t_inst[pos] = gated | (u32) (r * (size_t) P + (size_t) o);
+			t_inst[pos] = gated | (u32) ((rec_base + r) * (size_t) P + (size_t) o);
 		}
 	}
 }
@@ -429,7 +429,7 @@ __device__ inline int surv_lookup(const u32* __restrict__ table, u32 mask, const
 
 // add_to_graph's edge bookkeeping (A2:311-318, link_nodes A2:223-237): an edge prev->curr exists when two
 // adjacent offsets of one record both survive; list order is by first sight, so keep the minimum instance.
-__global__ void k_graph_edges(const u64* __restrict__ bases, const u64* __restrict__ nmask, size_t R, int rl, int k,
+__global__ void k_graph_edges(const u64* __restrict__ bases, const u64* __restrict__ nmask, size_t R, u32 rec_base, int rl, int k,
                               const u32* __restrict__ table, u32 mask, const u64* __restrict__ s_lo, const u64* __restrict__ s_hi,
                               u32* __restrict__ edge_first, u32* __restrict__ edge_to) {
 	size_t r = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -445,7 +445,7 @@ __global__ void k_graph_edges(const u64* __restrict__ bases, const u64* __restri
 		int s = surv_lookup(table, mask, s_lo, s_hi, klo, khi);
 		if (s >= 0 && prev >= 0) {
 			const u32 e = (u32) prev * 4u + (u32) (klo & 3ull);
-			atomicMin(&edge_first[e], (u32) (r * (size_t) P + (size_t) o));
+			atomicMin(&edge_first[e], (u32) ((rec_base + r) * (size_t) P + (size_t) o));
 			edge_to[e] = (u32) s;
 		}
 		prev = s;
@@ -465,6 +465,68 @@ __global__ void k_node_flags(const u64* __restrict__ s_lo, const u64* __restrict
 	has_j[i] = code ? (jbits[code >> 5] >> (code & 31)) & 1u : 0;
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// multi-GPU: the owner of a hash prefix re-buckets the tuples it received from every rank
+// ----------------------------------------------------------------------------------------------
+template <typename THI>
+__global__ __launch_bounds__(HIST_THREADS) void k_tuple_hist(const u64* __restrict__ lo, const THI* __restrict__ hi, size_t n,
+                                                             u32 shift, u32 local_mask, size_t tpb, u32* __restrict__ block_hist) {
+	extern __shared__ u32 hist[];
+	const u32 NBL = local_mask + 1;
+	for (u32 i = threadIdx.x; i < NBL; i += HIST_THREADS) hist[i] = 0;
+	__syncthreads();
+	const size_t t0 = (size_t) blockIdx.x * tpb;
+	const size_t t1 = t0 + tpb < n ? t0 + tpb : n;
+	for (size_t t = t0 + threadIdx.x; t < t1; t += HIST_THREADS) {
+		const u64 h = vdjx_mix(lo[t], (u64) hi[t]);
+		atomicAdd(&hist[(u32) (h >> shift) & local_mask], 1u);
+	}
+	__syncthreads();
+	for (u32 i = threadIdx.x; i < NBL; i += HIST_THREADS) block_hist[(size_t) blockIdx.x * NBL + i] = hist[i];
+}
+
+template <typename THI>
+__global__ __launch_bounds__(HIST_THREADS) void k_tuple_scatter(const u64* __restrict__ lo, const THI* __restrict__ hi,
+                                                                const u32* __restrict__ inst, size_t n, u32 shift, u32 local_mask,
+                                                                size_t tpb, const u32* __restrict__ block_hist,
+                                                                const u32* __restrict__ bucket_start, u64* __restrict__ t_lo,
+                                                                THI* __restrict__ t_hi, u32* __restrict__ t_inst) {
+	extern __shared__ u32 cursor[];
+	const u32 NBL = local_mask + 1;
+	for (u32 i = threadIdx.x; i < NBL; i += HIST_THREADS) cursor[i] = bucket_start[i] + block_hist[(size_t) blockIdx.x * NBL + i];
+	__syncthreads();
+	const size_t t0 = (size_t) blockIdx.x * tpb;
+	const size_t t1 = t0 + tpb < n ? t0 + tpb : n;
+	for (size_t t = t0 + threadIdx.x; t < t1; t += HIST_THREADS) {
+		const u64 l = lo[t];
+		const THI hh = hi[t];
+		const u64 h = vdjx_mix(l, (u64) hh);
+		const u32 pos = atomicAdd(&cursor[(u32) (h >> shift) & local_mask], 1u);
+		t_lo[pos] = l;
+		t_hi[pos] = hh;
+		t_inst[pos] = inst[t];
+	}
+}
+
+struct SurvRec { u64 lo, hi; u32 gcnt, gfirst, ucnt, ufirst; };   // 32 bytes: what owners exchange
+
+__global__ void k_surv_pack(const u64* __restrict__ lo, const u64* __restrict__ hi, const u32* __restrict__ gcnt,
+                            const u32* __restrict__ gfirst, const u32* __restrict__ ucnt, const u32* __restrict__ ufirst, u32 n,
+                            SurvRec* __restrict__ out) {
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	SurvRec r{lo[i], hi[i], gcnt[i], gfirst[i], ucnt[i], ufirst[i]};
+	out[i] = r;
+}
+
+__global__ void k_surv_unpack(const SurvRec* __restrict__ in, u32 n, u64* __restrict__ lo, u64* __restrict__ hi, u32* __restrict__ gcnt,
+                              u32* __restrict__ gfirst, u32* __restrict__ ucnt, u32* __restrict__ ufirst) {
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const SurvRec r = in[i];
+	lo[i] = r.lo; hi[i] = r.hi; gcnt[i] = r.gcnt; gfirst[i] = r.gfirst; ucnt[i] = r.ucnt; ufirst[i] = r.ufirst;
+}
 
 // ----------------------------------------------------------------------------------------------
 // K6: node numbering and list building on the device.
@@ -575,78 +637,138 @@ __global__ void k_node_emit(const u64* __restrict__ s_lo, const u64* __restrict_
 }
 
 // ----------------------------------------------------------------------------------------------
-// host driver
+// host driver: the build as stages, shared by the single-GPU call and the sharded (multi-GPU) phases
 // ----------------------------------------------------------------------------------------------
 namespace {
 
-template <typename THI>
-int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, vdjx_graph* g) {
-	const int rl = pool->rl;
-	const int P = rl - k + 1;
-	const size_t R = pool->n_records;
-	const size_t NI = R * (size_t) P;
-	hipStream_t st = c->stream;
-	vdjx_work db(c);
+// allocations that outlive one API call (the sharded phases): the context's second arena
+struct PersistAlloc {
+	vdjx_ctx* c;
+	explicit PersistAlloc(vdjx_ctx* ctx) : c(ctx) {}
+	template <typename T> hipError_t alloc(T** out, size_t n) {
+		*out = (T*) c->shard_arena.alloc((n ? n : 1) * sizeof(T));
+		return *out ? hipSuccess : hipErrorOutOfMemory;
+	}
+};
 
-	// ---- partition geometry: ~2048 instances per bucket, at most 2^15 buckets (128 KB LDS histogram)
+template <typename THI> struct Tuples {
+	u64* lo = nullptr; THI* hi = nullptr; u32* inst = nullptr;
+	u32* bucket_start = nullptr;      // [NB+1]
+	u32 NB = 0, N = 0;
+};
+
+struct PoolView { const u64* bases; const u64* nmask; const uint8_t* quals; int qstride; };
+
+struct Survivors {
+	u64 *lo = nullptr, *hi = nullptr;
+	u32 *gcnt = nullptr, *gfirst = nullptr, *ucnt = nullptr, *ufirst = nullptr;
+	u32 n = 0;
+	u64 ndist = 0;
+};
+
+struct Edges { u32* first = nullptr; u32* to = nullptr; };
+
+u32 choose_nb_bits(size_t NI) {
+	// ~2048 instances per bucket, at most 2^15 buckets (128 KB LDS histogram)
 	u32 nb_bits = 8;
 	while (nb_bits < 15 && ((size_t) 2048 << nb_bits) < NI) nb_bits++;
-	const u32 NB = 1u << nb_bits;
-	u32 nblk = (u32) std::min<size_t>(512, (R + 4095) / 4096);
-	if (nblk == 0) nblk = 1;
-	const size_t rpb = (R + nblk - 1) / nblk;
+	return nb_bits;
+}
 
-	u32 *block_hist, *bucket_cnt, *bucket_start, *bucket_ncand, *bucket_nct, *g_err, *n_surv;
-	u64* g_distinct;
-	HIP_TRY(db.alloc(&block_hist, (size_t) nblk * NB));
-	HIP_TRY(db.alloc(&bucket_cnt, NB));
-	HIP_TRY(db.alloc(&bucket_start, NB + 1));
-	HIP_TRY(db.alloc(&bucket_ncand, NB));
-	HIP_TRY(db.alloc(&bucket_nct, NB));
-	HIP_TRY(db.alloc(&g_err, 1));
-	HIP_TRY(db.alloc(&n_surv, 1));
-	HIP_TRY(db.alloc(&g_distinct, 1));
-	HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
-	HIP_TRY(hipMemsetAsync(n_surv, 0, 4, st));
-	HIP_TRY(hipMemsetAsync(g_distinct, 0, 8, st));
+struct PartPlan { u32 nb_bits, NB, nblk; size_t rpb; u32* block_hist; u32* bucket_cnt; u32* bucket_start; };
 
-	const size_t lds_hist = (size_t) NB * 4;
+// K2a + K2b over the records of `pool`: bucket sizes and per-workgroup offsets
+template <typename A>
+int stage_partition_count(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, u32 nb_bits, PartPlan* pp, u32* N_out) {
+	hipStream_t st = c->stream;
+	const size_t R = pool->n_records;
+	pp->nb_bits = nb_bits;
+	pp->NB = 1u << nb_bits;
+	pp->nblk = (u32) std::min<size_t>(512, (R + 4095) / 4096);
+	if (pp->nblk == 0) pp->nblk = 1;
+	pp->rpb = (R + pp->nblk - 1) / pp->nblk;
+	HIP_TRY(db.alloc(&pp->block_hist, (size_t) pp->nblk * pp->NB));
+	HIP_TRY(db.alloc(&pp->bucket_cnt, pp->NB));
+	HIP_TRY(db.alloc(&pp->bucket_start, pp->NB + 1));
+	const size_t lds_hist = (size_t) pp->NB * 4;
 	HIP_TRY(hipFuncSetAttribute((const void*) k_kmer_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_hist));
-	HIP_TRY(hipFuncSetAttribute((const void*) k_kmer_scatter<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_hist));
 	{
 		vdjx_prof_scope ps(c, "k_kmer_hist");
-		hipLaunchKernelGGL(k_kmer_hist, dim3(nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, R, rl, k, nb_bits, rpb, block_hist);
+		hipLaunchKernelGGL(k_kmer_hist, dim3(pp->nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, R, pool->rl, k,
+		                   nb_bits, pp->rpb, pp->block_hist);
 	}
 	{
 		vdjx_prof_scope ps(c, "k_hist_scan");
-		hipLaunchKernelGGL(k_hist_colscan, dim3((NB + 255) / 256), dim3(256), 0, st, block_hist, nblk, NB, bucket_cnt);
-		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, bucket_cnt, NB, bucket_start);
+		hipLaunchKernelGGL(k_hist_colscan, dim3((pp->NB + 255) / 256), dim3(256), 0, st, pp->block_hist, pp->nblk, pp->NB, pp->bucket_cnt);
+		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, pp->bucket_cnt, pp->NB, pp->bucket_start);
 	}
-	u32 N = 0;
-	HIP_TRY(hipMemcpyAsync(&N, bucket_start + NB, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(N_out, pp->bucket_start + pp->NB, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	return VDJX_OK;
+}
 
-	// ---- tuples + in-place candidate arrays (bucket b owns [bucket_start[b], bucket_start[b+1]) of each)
-	u64 *t_lo, *c_lo;
-	THI *t_hi, *c_hi;
-	u32 *t_inst, *c_cnt, *c_first, *ct_lcid, *ct_inst;
-	HIP_TRY(db.alloc(&t_lo, N));
-	HIP_TRY(db.alloc(&t_hi, N));
-	HIP_TRY(db.alloc(&t_inst, N));
-	HIP_TRY(db.alloc(&c_lo, N));
-	HIP_TRY(db.alloc(&c_hi, N));
-	HIP_TRY(db.alloc(&c_cnt, N));
-	HIP_TRY(db.alloc(&c_first, N));
-	HIP_TRY(db.alloc(&ct_lcid, N));
-	HIP_TRY(db.alloc(&ct_inst, N));
+// K2c into caller-chosen arrays
+template <typename THI>
+int stage_partition_fill(vdjx_ctx* c, const vdjx_pool* pool, u32 rec_base, int k, const PartPlan& pp, u64* t_lo, THI* t_hi, u32* t_inst) {
+	const size_t lds_hist = (size_t) pp.NB * 4;
+	HIP_TRY(hipFuncSetAttribute((const void*) k_kmer_scatter<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_hist));
+	vdjx_prof_scope ps(c, "k_kmer_scatter");
+	hipLaunchKernelGGL(k_kmer_scatter<THI>, dim3(pp.nblk), dim3(HIST_THREADS), lds_hist, c->stream, pool->d_bases, pool->d_nmask, pool->d_lowq,
+	                   pool->n_records, rec_base, pool->rl, k, pp.nb_bits, pp.rpb, pp.block_hist, pp.bucket_start, t_lo, t_hi, t_inst);
+	return VDJX_OK;
+}
+
+// owner side: bucket the received tuples by the hash bits below the owner bits
+template <typename THI, typename A>
+int stage_repartition(vdjx_ctx* c, A& db, const u64* r_lo, const THI* r_hi, const u32* r_inst, size_t n, u32 owner_bits,
+                      Tuples<THI>* out) {
+	hipStream_t st = c->stream;
+	const u32 lb = choose_nb_bits(n);
+	const u32 shift = 64 - owner_bits - lb;
+	const u32 NBL = 1u << lb;
+	u32 nblk = (u32) std::min<size_t>(512, (n + 65535) / 65536);
+	if (nblk == 0) nblk = 1;
+	const size_t tpb = (n + nblk - 1) / nblk;
+	u32 *block_hist, *bucket_cnt;
+	HIP_TRY(db.alloc(&block_hist, (size_t) nblk * NBL));
+	HIP_TRY(db.alloc(&bucket_cnt, NBL));
+	HIP_TRY(db.alloc(&out->bucket_start, NBL + 1));
+	HIP_TRY(db.alloc(&out->lo, n));
+	HIP_TRY(db.alloc(&out->hi, n));
+	HIP_TRY(db.alloc(&out->inst, n));
+	const size_t lds = (size_t) NBL * 4;
+	HIP_TRY(hipFuncSetAttribute((const void*) k_tuple_hist<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_tuple_scatter<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 	{
-		vdjx_prof_scope ps(c, "k_kmer_scatter");
-		hipLaunchKernelGGL(k_kmer_scatter<THI>, dim3(nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, pool->d_lowq,
-		                   R, rl, k, nb_bits, rpb, block_hist, bucket_start, t_lo, t_hi, t_inst);
+		vdjx_prof_scope ps(c, "k_tuple_repartition");
+		hipLaunchKernelGGL(k_tuple_hist<THI>, dim3(nblk), dim3(HIST_THREADS), lds, st, r_lo, r_hi, n, shift, NBL - 1, tpb, block_hist);
+		hipLaunchKernelGGL(k_hist_colscan, dim3((NBL + 255) / 256), dim3(256), 0, st, block_hist, nblk, NBL, bucket_cnt);
+		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, bucket_cnt, NBL, out->bucket_start);
+		hipLaunchKernelGGL(k_tuple_scatter<THI>, dim3(nblk), dim3(HIST_THREADS), lds, st, r_lo, r_hi, r_inst, n, shift, NBL - 1, tpb,
+		                   block_hist, out->bucket_start, out->lo, out->hi, out->inst);
 	}
+	out->NB = NBL;
+	out->N = (u32) n;
+	return VDJX_OK;
+}
 
-	// ---- prune thresholds.  mq is clamped as A2:1514-1516; a sum >= 214 reads as 255 (A2:356-360), so the test
+// K3a + K3b
+template <typename THI, typename A>
+int stage_reduce(vdjx_ctx* c, A& db, const Tuples<THI>& t, const PoolView& pv, int k, int P, int mf, int mq, Survivors* sv) {
+	hipStream_t st = c->stream;
+	const u32 NB = t.NB, N = t.N;
+	u64 *c_lo, *g_distinct;
+	THI* c_hi;
+	u32 *c_cnt, *c_first, *ct_lcid, *ct_inst, *bucket_ncand, *bucket_nct, *g_err, *n_surv;
+	HIP_TRY(db.alloc(&c_lo, N)); HIP_TRY(db.alloc(&c_hi, N)); HIP_TRY(db.alloc(&c_cnt, N)); HIP_TRY(db.alloc(&c_first, N));
+	HIP_TRY(db.alloc(&ct_lcid, N)); HIP_TRY(db.alloc(&ct_inst, N));
+	HIP_TRY(db.alloc(&bucket_ncand, NB)); HIP_TRY(db.alloc(&bucket_nct, NB));
+	HIP_TRY(db.alloc(&g_err, 1)); HIP_TRY(db.alloc(&n_surv, 1)); HIP_TRY(db.alloc(&g_distinct, 1));
+	HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
+	HIP_TRY(hipMemsetAsync(g_distinct, 0, 8, st));
+
+	// prune thresholds.  mq is clamped as A2:1514-1516; a sum >= 214 reads as 255 (A2:356-360), so the test
 	// "S_j >= mq" is "true sum >= min(mq, 214)".  Every gated instance other than the first adds >= 20
 	// (MIN_BASE_QUALITY) to every S_j, so a key with count >= TLOW = 1 + ceil(mqq/20) passes the quality test
 	// whatever its qualities are: only keys with count < TLOW need their sums computed.
@@ -660,26 +782,22 @@ int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, v
 	HIP_TRY(hipFuncSetAttribute((const void*) k_bucket_aggregate<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_agg));
 	{
 		vdjx_prof_scope ps(c, "k_bucket_aggregate");
-		hipLaunchKernelGGL(k_bucket_aggregate<THI>, dim3(NB), dim3(K3_THREADS), lds_agg, st, t_lo, t_hi, t_inst, bucket_start, cmin,
+		hipLaunchKernelGGL(k_bucket_aggregate<THI>, dim3(NB), dim3(K3_THREADS), lds_agg, st, t.lo, t.hi, t.inst, t.bucket_start, cmin,
 		                   c_lo, c_hi, c_cnt, c_first, ct_lcid, ct_inst, bucket_ncand, bucket_nct, g_distinct, g_err);
 	}
-
 	// survivors: capacity grows on demand (rerun of the cheap finalize pass)
 	u32 cap = (u32) std::min<size_t>((size_t) N / 2 + 1024, (size_t) 1 << 22);
 	u32 ns = 0;
-	u64 *s_lo = nullptr, *s_hi = nullptr;
-	u32 *s_gcnt = nullptr, *s_gfirst = nullptr, *s_ucnt = nullptr, *s_ufirst = nullptr;
 	for (int attempt = 0; attempt < 2; attempt++) {
-		HIP_TRY(db.alloc(&s_lo, cap)); HIP_TRY(db.alloc(&s_hi, cap));
-		HIP_TRY(db.alloc(&s_gcnt, cap)); HIP_TRY(db.alloc(&s_gfirst, cap));
-		HIP_TRY(db.alloc(&s_ucnt, cap)); HIP_TRY(db.alloc(&s_ufirst, cap));
+		HIP_TRY(db.alloc(&sv->lo, cap)); HIP_TRY(db.alloc(&sv->hi, cap));
+		HIP_TRY(db.alloc(&sv->gcnt, cap)); HIP_TRY(db.alloc(&sv->gfirst, cap));
+		HIP_TRY(db.alloc(&sv->ucnt, cap)); HIP_TRY(db.alloc(&sv->ufirst, cap));
 		HIP_TRY(hipMemsetAsync(n_surv, 0, 4, st));
-		SurvOut so{s_lo, s_hi, s_gcnt, s_gfirst, s_ucnt, s_ufirst, n_surv, cap};
+		SurvOut so{sv->lo, sv->hi, sv->gcnt, sv->gfirst, sv->ucnt, sv->ufirst, n_surv, cap};
 		{
 			vdjx_prof_scope ps(c, "k_bucket_finalize");
-			hipLaunchKernelGGL(k_bucket_finalize<THI>, dim3(NB), dim3(K3B_THREADS), 0, st, bucket_start, bucket_ncand, bucket_nct,
-			                   c_lo, c_hi, c_cnt, c_first, ct_lcid, ct_inst, pool->d_bases, pool->d_nmask, pool->d_quals, pool->qstride,
-			                   k, P, mfu, mqq, tlow, so);
+			hipLaunchKernelGGL(k_bucket_finalize<THI>, dim3(NB), dim3(K3B_THREADS), 0, st, t.bucket_start, bucket_ncand, bucket_nct,
+			                   c_lo, c_hi, c_cnt, c_first, ct_lcid, ct_inst, pv.bases, pv.nmask, pv.quals, pv.qstride, k, P, mfu, mqq, tlow, so);
 		}
 		HIP_TRY(hipMemcpyAsync(&ns, n_surv, 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
@@ -689,43 +807,52 @@ int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, v
 		if (attempt == 1) { vdjx_set_error("survivor capacity logic failed"); return VDJX_EHIP; }
 	}
 	u32 err = 0;
-	u64 ndist = 0;
 	HIP_TRY(hipMemcpy(&err, g_err, 4, hipMemcpyDeviceToHost));
-	HIP_TRY(hipMemcpy(&ndist, g_distinct, 8, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(&sv->ndist, g_distinct, 8, hipMemcpyDeviceToHost));
 	if (err) { vdjx_set_error("k_bucket_aggregate: %u buckets could not be split to fit LDS", err); return VDJX_EHIP; }
-	g->pre_nodes = (size_t) ndist;
-	g->n = ns;
-	g->k = k;
-	if (ns == 0) return VDJX_OK;
+	sv->n = ns;
+	return VDJX_OK;
+}
 
-	// ---- graph pass: survivor table, edges, flags
+// K5 over the records of `pool` (numbered from rec_base); edge arrays are caller-provided [ns*4]
+template <typename A>
+int stage_edges(vdjx_ctx* c, A& db, const vdjx_pool* pool, u32 rec_base, int k, const Survivors& sv, u32* edge_first, u32* edge_to) {
+	hipStream_t st = c->stream;
+	const u32 ns = sv.n;
 	u32 tmask = 1023;
 	while ((size_t) tmask + 1 < (size_t) ns * 2) tmask = tmask * 2 + 1;
-	u32 *table, *edge_first, *edge_to;
-	uint8_t *d_hv, *d_hj;
+	u32* table;
 	HIP_TRY(db.alloc(&table, (size_t) tmask + 1));
-	HIP_TRY(db.alloc(&edge_first, (size_t) ns * 4));
-	HIP_TRY(db.alloc(&edge_to, (size_t) ns * 4));
-	HIP_TRY(db.alloc(&d_hv, ns));
-	HIP_TRY(db.alloc(&d_hj, ns));
 	HIP_TRY(hipMemsetAsync(table, 0, ((size_t) tmask + 1) * 4, st));
 	HIP_TRY(hipMemsetAsync(edge_first, 0xFF, (size_t) ns * 16, st));
 	HIP_TRY(hipMemsetAsync(edge_to, 0xFF, (size_t) ns * 16, st));
 	{
 		vdjx_prof_scope ps(c, "k_surv_table");
-		hipLaunchKernelGGL(k_surv_table, dim3((ns + 255) / 256), dim3(256), 0, st, s_lo, s_hi, ns, table, tmask);
+		hipLaunchKernelGGL(k_surv_table, dim3((ns + 255) / 256), dim3(256), 0, st, sv.lo, sv.hi, ns, table, tmask);
 	}
-	{
+	if (pool->n_records) {
 		vdjx_prof_scope ps(c, "k_graph_edges");
-		hipLaunchKernelGGL(k_graph_edges, dim3((unsigned) ((R + 255) / 256)), dim3(256), 0, st, pool->d_bases, pool->d_nmask, R, rl, k,
-		                   table, tmask, s_lo, s_hi, edge_first, edge_to);
+		hipLaunchKernelGGL(k_graph_edges, dim3((unsigned) ((pool->n_records + 255) / 256)), dim3(256), 0, st, pool->d_bases, pool->d_nmask,
+		                   pool->n_records, rec_base, pool->rl, k, table, tmask, sv.lo, sv.hi, edge_first, edge_to);
 	}
+	return VDJX_OK;
+}
+
+// K6: flags, node ids, ordered lists, k-mer text; the host only copies
+template <typename A>
+int stage_finish(vdjx_ctx* c, A& db, const Survivors& sv, const u32* edge_first, const u32* edge_to, size_t NI, int k, int P, vdjx_graph* g) {
+	hipStream_t st = c->stream;
+	const u32 ns = sv.n;
+	g->n = ns;
+	g->k = k;
+	if (ns == 0) return VDJX_OK;
+	uint8_t *d_hv, *d_hj;
+	HIP_TRY(db.alloc(&d_hv, ns));
+	HIP_TRY(db.alloc(&d_hj, ns));
 	{
 		vdjx_prof_scope ps(c, "k_node_flags");
-		hipLaunchKernelGGL(k_node_flags, dim3((ns + 255) / 256), dim3(256), 0, st, s_lo, s_hi, ns, k, c->d_vbits, c->d_jbits, d_hv, d_hj);
+		hipLaunchKernelGGL(k_node_flags, dim3((ns + 255) / 256), dim3(256), 0, st, sv.lo, sv.hi, ns, k, c->d_vbits, c->d_jbits, d_hv, d_hj);
 	}
-
-	// ---- node ids, ordered lists, k-mer text: all on the device (K6), the host only copies
 	const u32 nwords = (u32) ((NI + 31) / 32);
 	const u32 npb = (nwords + POPC_WORDS - 1) / POPC_WORDS;
 	u32 *bits, *word_pre, *block_sum, *block_pre, *rank, *in_first, *in_from;
@@ -746,12 +873,12 @@ int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, v
 	HIP_TRY(hipMemsetAsync(in_first, 0xFF, (size_t) ns * 16, st));
 	{
 		vdjx_prof_scope ps(c, "k_node_order");
-		hipLaunchKernelGGL(k_mark_first, dim3((ns + 255) / 256), dim3(256), 0, st, s_ufirst, ns, bits);
+		hipLaunchKernelGGL(k_mark_first, dim3((ns + 255) / 256), dim3(256), 0, st, sv.ufirst, ns, bits);
 		hipLaunchKernelGGL(k_popc_blocks, dim3(npb), dim3(256), 0, st, bits, nwords, word_pre, block_sum);
 		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, block_sum, npb, block_pre);
-		hipLaunchKernelGGL(k_node_rank, dim3((ns + 255) / 256), dim3(256), 0, st, s_ufirst, ns, bits, word_pre, block_pre, rank);
-		hipLaunchKernelGGL(k_in_edges, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, edge_first, edge_to, s_lo, s_hi, ns, k, in_first, in_from);
-		hipLaunchKernelGGL(k_node_emit, dim3((ns + 255) / 256), dim3(256), 0, st, s_lo, s_hi, s_gcnt, s_ucnt, s_ufirst, d_hv, d_hj, rank,
+		hipLaunchKernelGGL(k_node_rank, dim3((ns + 255) / 256), dim3(256), 0, st, sv.ufirst, ns, bits, word_pre, block_pre, rank);
+		hipLaunchKernelGGL(k_in_edges, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, edge_first, edge_to, sv.lo, sv.hi, ns, k, in_first, in_from);
+		hipLaunchKernelGGL(k_node_emit, dim3((ns + 255) / 256), dim3(256), 0, st, sv.lo, sv.hi, sv.gcnt, sv.ucnt, sv.ufirst, d_hv, d_hj, rank,
 		                   edge_first, edge_to, in_first, in_from, ns, k, P, no);
 	}
 	g->first_inst.resize(ns); g->gated_count.resize(ns); g->freq.resize(ns);
@@ -777,7 +904,38 @@ int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, v
 	return VDJX_OK;
 }
 
+template <typename THI>
+int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, vdjx_graph* g) {
+	const int P = pool->rl - k + 1;
+	const size_t NI = pool->n_records * (size_t) P;
+	vdjx_work db(c);
+	PartPlan pp;
+	Tuples<THI> t;
+	int rc = stage_partition_count(c, db, pool, k, choose_nb_bits(NI), &pp, &t.N);
+	if (rc) return rc;
+	HIP_TRY(db.alloc(&t.lo, t.N)); HIP_TRY(db.alloc(&t.hi, t.N)); HIP_TRY(db.alloc(&t.inst, t.N));
+	t.bucket_start = pp.bucket_start;
+	t.NB = pp.NB;
+	rc = stage_partition_fill<THI>(c, pool, 0, k, pp, t.lo, t.hi, t.inst);
+	if (rc) return rc;
+	PoolView pv{pool->d_bases, pool->d_nmask, pool->d_quals, pool->qstride};
+	Survivors sv;
+	rc = stage_reduce<THI>(c, db, t, pv, k, P, mf, mq, &sv);
+	if (rc) return rc;
+	g->pre_nodes = (size_t) sv.ndist;
+	Edges e;
+	if (sv.n) {
+		HIP_TRY(db.alloc(&e.first, (size_t) sv.n * 4));
+		HIP_TRY(db.alloc(&e.to, (size_t) sv.n * 4));
+		rc = stage_edges(c, db, pool, 0, k, sv, e.first, e.to);
+		if (rc) return rc;
+	}
+	return stage_finish(c, db, sv, e.first, e.to, NI, k, P, g);
+}
+
 }  // namespace
+
+static bool key_hi_is_u32(int k) { return 2 * k - 64 <= 30; }
 
 extern "C" int vdjx_kmer_build(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, vdjx_graph** out) {
 	if (!c || !pool || !out) { vdjx_set_error("vdjx_kmer_build: NULL argument"); return VDJX_EINVAL; }
@@ -789,8 +947,191 @@ extern "C" int vdjx_kmer_build(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf
 	if (k > 16 && !c->anchors_loaded) { vdjx_set_error("vdjx_kmer_build: call vdjx_anchor_sets_load first (k > 16)"); return VDJX_ESTATE; }
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_graph* g = new vdjx_graph();
-	int rc = (2 * k - 64 <= 30) ? kmer_build_impl<u32>(c, pool, k, mf, mq, g) : kmer_build_impl<u64>(c, pool, k, mf, mq, g);
+	int rc = key_hi_is_u32(k) ? kmer_build_impl<u32>(c, pool, k, mf, mq, g) : kmer_build_impl<u64>(c, pool, k, mf, mq, g);
 	if (rc != VDJX_OK) { delete g; return rc; }
+	*out = g;
+	return VDJX_OK;
+}
+
+// ==============================================================================================
+// Sharded build: one process per GPU; the caller moves the bytes between ranks
+// (torch.distributed over RCCL in vdjer_amd/shard.py).  Record numbering: rank r's records are
+// [r*rec_stride, r*rec_stride + R_r); k-mer ownership = top log2(nranks) bits of the bucket index.
+// ==============================================================================================
+struct vdjx_shard {
+	vdjx_ctx* c = nullptr;
+	const vdjx_pool* pool = nullptr;
+	int k = 0, mf = 0, mq = 0, rank = 0, nranks = 1;
+	u32 rec_stride = 0, nb_bits = 0, owner_bits = 0;
+	bool hi64 = false;
+	PartPlan pp{};
+	u32 N_local = 0;
+	PoolView gpool{nullptr, nullptr, nullptr, 0};
+	Survivors local_sv, all_sv;
+	int phase = 0;
+};
+
+extern "C" int vdjx_shard_begin(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, int rank, int nranks,
+                                uint64_t rec_stride, vdjx_shard** out) {
+	if (!c || !pool || !out) { vdjx_set_error("vdjx_shard_begin: NULL argument"); return VDJX_EINVAL; }
+	*out = nullptr;
+	if (c->live_shard) { vdjx_set_error("vdjx_shard_begin: a sharded build is already in flight on this context"); return VDJX_ESTATE; }
+	if (nranks < 1 || (nranks & (nranks - 1)) || nranks > 256 || rank < 0 || rank >= nranks) { vdjx_set_error("nranks must be a power of two, 0 <= rank < nranks"); return VDJX_EINVAL; }
+	if (k < 1 || k > VDJX_MAX_KMER || k > pool->rl) { vdjx_set_error("k=%d outside [1,min(%d,rl=%d)]", k, VDJX_MAX_KMER, pool->rl); return VDJX_ELIMIT; }
+	if (rec_stride < pool->n_records) { vdjx_set_error("rec_stride %llu < local records %zu", (unsigned long long) rec_stride, pool->n_records); return VDJX_EINVAL; }
+	const size_t NI = (size_t) rec_stride * nranks * (size_t) (pool->rl - k + 1);
+	if (NI >= (1ull << 31)) { vdjx_set_error("global records*offsets = %zu >= 2^31", NI); return VDJX_ELIMIT; }
+	if (k > 16 && !c->anchors_loaded) { vdjx_set_error("vdjx_shard_begin: call vdjx_anchor_sets_load first (k > 16)"); return VDJX_ESTATE; }
+	vdjx_shard* s = new vdjx_shard();
+	s->c = c; s->pool = pool; s->k = k; s->mf = mf; s->mq = mq; s->rank = rank; s->nranks = nranks;
+	s->rec_stride = (u32) rec_stride;
+	s->hi64 = !key_hi_is_u32(k);
+	// sender side: a coarse partition (long, coalesced runs); the owner re-buckets what it receives for LDS
+	while ((1 << s->owner_bits) < nranks) s->owner_bits++;
+	s->nb_bits = s->owner_bits + 4 > 8 ? s->owner_bits + 4 : 8;
+	c->live_shard = s;
+	*out = s;
+	return VDJX_OK;
+}
+
+extern "C" void vdjx_shard_free(vdjx_shard* s) {
+	if (!s) return;
+	(void) hipSetDevice(s->c->device);
+	(void) hipStreamSynchronize(s->c->stream);
+	s->c->shard_arena.reset();
+	s->c->live_shard = nullptr;
+	delete s;
+}
+
+extern "C" int vdjx_shard_qstride(const vdjx_shard* s) { return s ? s->pool->qstride : 0; }
+extern "C" int vdjx_shard_key_hi_bytes(const vdjx_shard* s) { return s ? (s->hi64 ? 8 : 4) : 0; }
+
+// copy the local packed pool (bases 16 B, N mask 8 B, qualities qstride B per record) into caller buffers
+extern "C" int vdjx_shard_pool_export(vdjx_shard* s, void* d_bases, void* d_nmask, void* d_quals) {
+	if (!s || !d_bases || !d_nmask || !d_quals) { vdjx_set_error("vdjx_shard_pool_export: NULL argument"); return VDJX_EINVAL; }
+	const vdjx_pool* p = s->pool;
+	hipStream_t st = s->c->stream;
+	HIP_TRY(hipSetDevice(s->c->device));
+	HIP_TRY(hipMemcpyAsync(d_bases, p->d_bases, p->n_records * 16, hipMemcpyDeviceToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d_nmask, p->d_nmask, p->n_records * 8, hipMemcpyDeviceToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d_quals, p->d_quals, p->n_records * (size_t) p->qstride, hipMemcpyDeviceToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	return VDJX_OK;
+}
+
+// the replicated pool: arrays of nranks*rec_stride records (rank-major), caller-owned for the shard's lifetime
+extern "C" int vdjx_shard_set_pool(vdjx_shard* s, const void* d_bases_all, const void* d_nmask_all, const void* d_quals_all) {
+	if (!s || !d_bases_all || !d_nmask_all || !d_quals_all) { vdjx_set_error("vdjx_shard_set_pool: NULL argument"); return VDJX_EINVAL; }
+	s->gpool = PoolView{(const u64*) d_bases_all, (const u64*) d_nmask_all, (const uint8_t*) d_quals_all, s->pool->qstride};
+	return VDJX_OK;
+}
+
+// tuples this rank will send to every owner
+extern "C" int vdjx_shard_partition_count(vdjx_shard* s, uint64_t* send_counts) {
+	if (!s || !send_counts) { vdjx_set_error("vdjx_shard_partition_count: NULL argument"); return VDJX_EINVAL; }
+	vdjx_ctx* c = s->c;
+	HIP_TRY(hipSetDevice(c->device));
+	PersistAlloc db(c);
+	int rc = stage_partition_count(c, db, s->pool, s->k, s->nb_bits, &s->pp, &s->N_local);
+	if (rc) return rc;
+	std::vector<u32> starts((size_t) s->pp.NB + 1);
+	HIP_TRY(hipMemcpy(starts.data(), s->pp.bucket_start, starts.size() * 4, hipMemcpyDeviceToHost));
+	const u32 per = s->pp.NB >> s->owner_bits;
+	for (int g = 0; g < s->nranks; g++) send_counts[g] = starts[(size_t) (g + 1) * per] - starts[(size_t) g * per];
+	s->phase = 1;
+	return VDJX_OK;
+}
+
+// write the tuples, owner-contiguous, into caller buffers of sum(send_counts) entries
+extern "C" int vdjx_shard_partition_fill(vdjx_shard* s, void* d_lo, void* d_hi, void* d_inst) {
+	if (!s || s->phase < 1) { vdjx_set_error("vdjx_shard_partition_fill: call vdjx_shard_partition_count first"); return VDJX_ESTATE; }
+	if (s->N_local && (!d_lo || !d_hi || !d_inst)) { vdjx_set_error("vdjx_shard_partition_fill: NULL buffer"); return VDJX_EINVAL; }
+	vdjx_ctx* c = s->c;
+	HIP_TRY(hipSetDevice(c->device));
+	const u32 rec_base = s->rec_stride * (u32) s->rank;
+	int rc = s->hi64 ? stage_partition_fill<u64>(c, s->pool, rec_base, s->k, s->pp, (u64*) d_lo, (u64*) d_hi, (u32*) d_inst)
+	                 : stage_partition_fill<u32>(c, s->pool, rec_base, s->k, s->pp, (u64*) d_lo, (u32*) d_hi, (u32*) d_inst);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipGetLastError());
+	s->phase = 2;
+	return VDJX_OK;
+}
+
+template <typename THI>
+static int shard_reduce_impl(vdjx_shard* s, const void* d_lo, const void* d_hi, const void* d_inst, uint64_t n_recv) {
+	vdjx_ctx* c = s->c;
+	PersistAlloc db(c);
+	Tuples<THI> t;
+	int rc = stage_repartition<THI>(c, db, (const u64*) d_lo, (const THI*) d_hi, (const u32*) d_inst, (size_t) n_recv, s->owner_bits, &t);
+	if (rc) return rc;
+	return stage_reduce<THI>(c, db, t, s->gpool, s->k, s->pool->rl - s->k + 1, s->mf, s->mq, &s->local_sv);
+}
+
+// owner side: received tuples -> this rank's survivors
+extern "C" int vdjx_shard_reduce(vdjx_shard* s, const void* d_lo, const void* d_hi, const void* d_inst, uint64_t n_recv,
+                                 uint64_t* n_survivors, uint64_t* n_distinct) {
+	if (!s || !n_survivors || !n_distinct) { vdjx_set_error("vdjx_shard_reduce: NULL argument"); return VDJX_EINVAL; }
+	if (!s->gpool.bases) { vdjx_set_error("vdjx_shard_reduce: call vdjx_shard_set_pool first"); return VDJX_ESTATE; }
+	if (n_recv >= (1ull << 31)) { vdjx_set_error("vdjx_shard_reduce: too many tuples"); return VDJX_ELIMIT; }
+	HIP_TRY(hipSetDevice(s->c->device));
+	int rc = s->hi64 ? shard_reduce_impl<u64>(s, d_lo, d_hi, d_inst, n_recv) : shard_reduce_impl<u32>(s, d_lo, d_hi, d_inst, n_recv);
+	if (rc) return rc;
+	*n_survivors = s->local_sv.n;
+	*n_distinct = s->local_sv.ndist;
+	s->phase = 3;
+	return VDJX_OK;
+}
+
+// this rank's survivors as 32-byte records {key_lo, key_hi, gated count, gated first, count, first}
+extern "C" int vdjx_shard_survivors(vdjx_shard* s, void* d_out) {
+	if (!s || s->phase < 3) { vdjx_set_error("vdjx_shard_survivors: call vdjx_shard_reduce first"); return VDJX_ESTATE; }
+	const Survivors& v = s->local_sv;
+	if (!v.n) return VDJX_OK;
+	if (!d_out) { vdjx_set_error("vdjx_shard_survivors: NULL buffer"); return VDJX_EINVAL; }
+	HIP_TRY(hipSetDevice(s->c->device));
+	hipLaunchKernelGGL(k_surv_pack, dim3((v.n + 255) / 256), dim3(256), 0, s->c->stream, v.lo, v.hi, v.gcnt, v.gfirst, v.ucnt, v.ufirst, v.n, (SurvRec*) d_out);
+	HIP_TRY(hipStreamSynchronize(s->c->stream));
+	HIP_TRY(hipGetLastError());
+	return VDJX_OK;
+}
+
+// every rank: all survivors (rank order) + local edge pass into caller arrays [ns_total*4] (to be MIN-reduced over ranks)
+extern "C" int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t ns_total, void* d_edge_first, void* d_edge_to) {
+	if (!s || s->phase < 3) { vdjx_set_error("vdjx_shard_edges: call vdjx_shard_reduce first"); return VDJX_ESTATE; }
+	if (ns_total >= (1ull << 30)) { vdjx_set_error("vdjx_shard_edges: too many survivors"); return VDJX_ELIMIT; }
+	vdjx_ctx* c = s->c;
+	HIP_TRY(hipSetDevice(c->device));
+	PersistAlloc db(c);
+	Survivors& a = s->all_sv;
+	a.n = (u32) ns_total;
+	s->phase = 4;
+	if (!ns_total) return VDJX_OK;
+	if (!d_surv_all || !d_edge_first || !d_edge_to) { vdjx_set_error("vdjx_shard_edges: NULL buffer"); return VDJX_EINVAL; }
+	HIP_TRY(db.alloc(&a.lo, a.n)); HIP_TRY(db.alloc(&a.hi, a.n)); HIP_TRY(db.alloc(&a.gcnt, a.n));
+	HIP_TRY(db.alloc(&a.gfirst, a.n)); HIP_TRY(db.alloc(&a.ucnt, a.n)); HIP_TRY(db.alloc(&a.ufirst, a.n));
+	hipLaunchKernelGGL(k_surv_unpack, dim3((a.n + 255) / 256), dim3(256), 0, c->stream, (const SurvRec*) d_surv_all, a.n, a.lo, a.hi, a.gcnt,
+	                   a.gfirst, a.ucnt, a.ufirst);
+	int rc = stage_edges(c, db, s->pool, s->rec_stride * (u32) s->rank, s->k, a, (u32*) d_edge_first, (u32*) d_edge_to);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipGetLastError());
+	return VDJX_OK;
+}
+
+// every rank: reduced edge arrays -> the graph (identical on all ranks)
+extern "C" int vdjx_shard_finish(vdjx_shard* s, const void* d_edge_first, const void* d_edge_to, uint64_t pre_nodes_total, vdjx_graph** out) {
+	if (!s || !out || s->phase < 4) { vdjx_set_error("vdjx_shard_finish: call vdjx_shard_edges first"); return VDJX_ESTATE; }
+	*out = nullptr;
+	vdjx_ctx* c = s->c;
+	HIP_TRY(hipSetDevice(c->device));
+	PersistAlloc db(c);
+	const int P = s->pool->rl - s->k + 1;
+	const size_t NI = (size_t) s->rec_stride * s->nranks * (size_t) P;
+	vdjx_graph* g = new vdjx_graph();
+	g->pre_nodes = (size_t) pre_nodes_total;
+	int rc = stage_finish(c, db, s->all_sv, (const u32*) d_edge_first, (const u32*) d_edge_to, NI, s->k, P, g);
+	if (rc) { delete g; return rc; }
 	*out = g;
 	return VDJX_OK;
 }
