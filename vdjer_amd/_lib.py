@@ -50,6 +50,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; whichever HIP runtime is loaded first serves the whole process.  When torch
+    # is used in the same process (bench.py, shard.py) it must come first so that device pointers are shared.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional for the single-GPU C ABI
+        pass
     if not os.path.exists(LIB_PATH):
         raise VdjxError(f"{LIB_PATH} is missing: build it with `make -C vdjer_amd/csrc` "
                         "(there is no CPU fallback for the hot path)")
