@@ -113,11 +113,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # dry run of the N>1 path on a box with one GPU: VDJX_BENCH_ONE_DEVICE=1 puts every rank on device 0 and moves
+    # the bytes with gloo (RCCL refuses two ranks on one device).  Never used for reported numbers.
+    one_device = os.environ.get("VDJX_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from vdjer_amd import api
 
@@ -133,8 +141,9 @@ def main():
     if world > 1:
         from vdjer_amd import shard
         engine = shard.ShardedHotPath(ctx, dist, dev)
+        cm = engine.comm
     else:
-        engine = None
+        engine = cm = None
 
     state = {}
     # the read index belongs to extraction in the reference (add_read_info is called from extract, bam_read.c:228,243):
@@ -145,15 +154,11 @@ def main():
         ctx.read_index_build(p_index, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
     else:
         mine = torch.cat([d_pri, d_sec], dim=0)
-        R_loc = mine.shape[0]
-        allrec = torch.empty((world * R_loc, mine.shape[1]), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(allrec, mine)
+        allrec = cm.all_gather_cat(mine)
 
         def gather_np(a, scale):
             x = torch.from_numpy(a.astype(np.int64) + rank * scale).to(dev)
-            out = torch.empty(world * x.shape[0], dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(out, x)
-            return out.cpu().numpy()
+            return cm.all_gather_cat(x).cpu().numpy()
         g_pair = gather_np(pool.pair_id, args.pairs).astype(np.uint32)
         g_rank = gather_np(pool.reg_rank, 4 * args.pairs).astype(np.uint32)
         g_rnum = gather_np(pool.read_num, 0).astype(np.uint8)
@@ -166,15 +171,10 @@ def main():
 
     def gather_bytes(a):
         """all_gather of a small uint8 vector whose length differs per rank"""
-        n = torch.tensor([a.shape[0]], dtype=torch.int64, device=dev)
-        ns = [torch.empty_like(n) for _ in range(world)]
-        dist.all_gather(ns, n)
-        mx = max(int(x.item()) for x in ns)
-        pad = torch.zeros(max(mx, 1), dtype=torch.uint8, device=dev)
-        pad[:a.shape[0]] = torch.from_numpy(a).to(dev)
-        outs = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(outs, pad)
-        return [o[:int(x.item())].cpu().numpy() for o, x in zip(outs, ns)]
+        ns = cm.all_gather_cat(torch.tensor([a.shape[0]], dtype=torch.int64, device=dev)).cpu().numpy()
+        full = cm.all_gather_var(torch.from_numpy(np.ascontiguousarray(a)).to(dev), [int(x) for x in ns]).cpu().numpy()
+        offs = np.concatenate([[0], np.cumsum(ns)])
+        return [full[offs[i]:offs[i + 1]] for i in range(world)]
 
     wall = {}
 
@@ -229,7 +229,7 @@ def main():
     ctx.profile(False)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        cm.all_reduce(tt, dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     # ---- parity gate inside the benchmark: a record sample re-checked against the oracle
@@ -282,6 +282,7 @@ def main():
                    "pairs_per_gpu": args.pairs, "clones": args.clones, "noise": 0.3, "parallelism": f"hash-prefix x{world}"},
         "roofline": roof, "cpu_baseline": cpu,
         "kernels_ms_per_step": {k_: round(v[0] / args.steps, 4) for k_, v in prof.items()},
+        "exchange_bytes_per_step_rank0": (engine.bytes_exchanged // (args.steps + args.warmup)) if engine else 0,
         "wall_ms_per_step": {k_: round(v / args.steps * 1e3, 3) for k_, v in wall.items()},
         "counts": {k_: v for k_, v in state.items() if k_ != "graph"}, "parity_gate": parity,
     }

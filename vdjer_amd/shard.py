@@ -145,53 +145,103 @@ class HipShardEngine:
         self._gpool = self._recv = self._surv_all = None
 
 
+class Comm:
+    """The four collectives the sharded path needs, on RCCL ("nccl") natively and on "gloo" through host copies
+    (gloo has no all_to_all_single / all_gather_into_tensor; used by the CPU tests and single-device dry runs)."""
+
+    def __init__(self, dist, device):
+        import torch
+        self.t, self.dist, self.dev = torch, dist, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        backend = dist.get_backend() if hasattr(dist, "get_backend") else "native"
+        self.native = backend != "gloo"
+        self.on_gpu = device.type == "cuda"
+        self.bytes = 0
+
+    def sync(self):
+        if self.on_gpu:
+            self.t.cuda.synchronize(self.dev)
+
+    def _host(self, x):
+        return x if self.native else x.cpu()
+
+    def all_reduce(self, x, op):
+        if self.native:
+            self.dist.all_reduce(x, op=op)
+        else:
+            h = x.cpu()
+            self.dist.all_reduce(h, op=op)
+            x.copy_(h)
+        return x
+
+    def all_gather_cat(self, x):
+        """equal shapes on every rank -> concatenation along dim 0 (rank order)"""
+        t = self.t
+        self.bytes += x.numel() * x.element_size() * self.world
+        if self.native:
+            out = t.empty((self.world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            self.dist.all_gather_into_tensor(out, x.contiguous())
+            return out
+        h = x.cpu().contiguous()
+        outs = [t.empty_like(h) for _ in range(self.world)]
+        self.dist.all_gather(outs, h)
+        return t.cat(outs, dim=0).to(x.device)
+
+    def all_gather_var(self, x, counts):
+        """first dimension differs per rank (counts known everywhere)"""
+        t = self.t
+        mx = int(max(counts)) if len(counts) else 0
+        pad = t.zeros((max(mx, 1),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        if x.shape[0]:
+            pad[:x.shape[0]] = x
+        full = self.all_gather_cat(pad)
+        if not sum(counts):
+            return x[:0]
+        return t.cat([full[i * pad.shape[0]:i * pad.shape[0] + int(c)] for i, c in enumerate(counts)], dim=0)
+
+    def all_to_all_v(self, send, in_splits, recv, out_splits):
+        self.bytes += send.numel() * send.element_size()
+        if self.native:
+            self.dist.all_to_all_single(recv, send, out_splits, in_splits)
+            return
+        hs = send.cpu()
+        hr = self.t.empty(recv.shape, dtype=recv.dtype)
+        ins, outs = list(hs.split(in_splits)), list(hr.split(out_splits))
+        reqs = []
+        for peer in range(self.world):
+            if peer == self.rank:
+                outs[peer].copy_(ins[peer])
+            else:
+                reqs.append(self.dist.isend(ins[peer].contiguous(), peer))
+                reqs.append(self.dist.irecv(outs[peer], peer))
+        for r in reqs:
+            r.wait()
+        recv.copy_(hr)
+
+
 class ShardedHotPath:
     """Drives one sharded k-mer build over a torch.distributed process group."""
 
     def __init__(self, ctx, dist, device, engine=None):
         import torch
         self.torch, self.dist, self.dev = torch, dist, device
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.comm = Comm(dist, device)
+        self.rank, self.world = self.comm.rank, self.comm.world
         if self.world & (self.world - 1):
             raise ValueError("the number of ranks must be a power of two (ownership = hash-prefix bits)")
         self.engine = engine if engine is not None else HipShardEngine(ctx, device)
-        self.on_gpu = device.type == "cuda"
         self.stride = None
-        self.bytes_exchanged = 0
 
-    def _sync(self):
-        if self.on_gpu:
-            self.torch.cuda.synchronize(self.dev)
-
-    def _p2p(self, outs, ins):
-        dist = self.dist
-        reqs = []
-        for peer in range(self.world):
-            if peer == self.rank:
-                outs[peer].copy_(ins[peer])
-            else:
-                reqs.append(dist.isend(ins[peer].contiguous(), peer))
-                reqs.append(dist.irecv(outs[peer], peer))
-        for r in reqs:
-            r.wait()
-
-    def _all_gather_var(self, x, counts):
-        """all_gather of tensors whose first dimension differs per rank (counts known everywhere)."""
-        t, dist = self.torch, self.dist
-        mx = int(max(counts)) if len(counts) else 0
-        pad = t.zeros((max(mx, 1),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        if x.shape[0]:
-            pad[:x.shape[0]] = x
-        outs = [t.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(outs, pad)
-        return t.cat([o[:int(c)] for o, c in zip(outs, counts)], dim=0) if sum(counts) else x[:0]
+    @property
+    def bytes_exchanged(self):
+        return self.comm.bytes
 
     def kmer_build(self, pool, k: int = 35, mf: int = 3, mq: int = 90):
-        t, dist, eng = self.torch, self.dist, self.engine
+        t, dist, eng, cm = self.torch, self.dist, self.engine, self.comm
         G, r = self.world, self.rank
         if self.stride is None:
             s = t.tensor([pool.n_records], dtype=t.int64, device=self.dev)
-            dist.all_reduce(s, op=dist.ReduceOp.MAX)
+            cm.all_reduce(s, dist.ReduceOp.MAX)
             self.stride = int(s.item())
         stride = self.stride
         eng.begin(pool, k, mf, mq, r, G, stride)
@@ -201,52 +251,39 @@ class ShardedHotPath:
             for x in eng.pool_export():
                 pad = t.zeros((stride,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
                 pad[:x.shape[0]] = x
-                full = t.empty((G * stride,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-                dist.all_gather_into_tensor(full, pad) if self.on_gpu else dist.all_gather(list(full.split(stride)), pad)
-                glob.append(full)
-                self.bytes_exchanged += full.numel() * full.element_size()
-            self._sync()
+                glob.append(cm.all_gather_cat(pad))
+            cm.sync()
             eng.set_pool(glob)
-            # 2./3. partition by owner, exchange
+            # 2./3. partition by owner, then the exchange step: counts, then the tuple columns
             send_counts = eng.partition_count()
             sc = t.tensor(send_counts, dtype=t.int64, device=self.dev)
             rc = t.empty_like(sc)
-            if self.on_gpu:
-                dist.all_to_all_single(rc, sc)
-            else:
-                self._p2p(list(rc.split(1)), list(sc.split(1)))
-            self._sync()
+            cm.all_to_all_v(sc, [1] * G, rc, [1] * G)
+            cm.sync()
             recv_counts = rc.cpu().numpy()
             send = eng.partition_fill(int(send_counts.sum()))
             recv = eng.recv_like(int(recv_counts.sum()))
             ins, outs = [int(v) for v in send_counts], [int(v) for v in recv_counts]
             for s_, r_ in zip(send, recv):
-                if self.on_gpu:
-                    dist.all_to_all_single(r_, s_, outs, ins)
-                else:
-                    self._p2p(list(r_.split(outs)), list(s_.split(ins)))
-                self.bytes_exchanged += s_.numel() * s_.element_size()
-            self._sync()
+                cm.all_to_all_v(s_, ins, r_, outs)
+            cm.sync()
             del send
             # 4. owners reduce and prune
             ns, ndist = eng.reduce(recv)
-            meta = t.tensor([ns, ndist], dtype=t.int64, device=self.dev)
-            metas = [t.empty_like(meta) for _ in range(G)]
-            dist.all_gather(metas, meta)
-            self._sync()
-            ns_all = [int(m[0].item()) for m in metas]
-            pre_total = sum(int(m[1].item()) for m in metas)
+            meta = cm.all_gather_cat(t.tensor([[ns, ndist]], dtype=t.int64, device=self.dev)).cpu().numpy()
+            ns_all = [int(v) for v in meta[:, 0]]
+            pre_total = int(meta[:, 1].sum())
             # 5. survivors everywhere, local edges, MIN over ranks
-            surv_all = self._all_gather_var(eng.survivors(ns), ns_all)
-            self._sync()
+            surv_all = cm.all_gather_var(eng.survivors(ns), ns_all)
+            cm.sync()
             ef, et = eng.edges(surv_all)
             if ef.numel():
                 flip = -2 ** 31       # unsigned order on int32 tensors: flip the sign bit around the MIN
                 for x in (ef, et):
                     x.bitwise_xor_(flip)
-                    dist.all_reduce(x, op=dist.ReduceOp.MIN)
+                    cm.all_reduce(x, dist.ReduceOp.MIN)
                     x.bitwise_xor_(flip)
-            self._sync()
+            cm.sync()
             # 6. node numbering + list order
             return eng.finish(ef, et, pre_total)
         finally:
