@@ -10,7 +10,8 @@
 //   K2a k_kmer_hist        per-workgroup LDS histogram of bucket sizes over a slice of the pool
 //   K2b k_hist_colscan /   exclusive offsets per (workgroup, bucket)  -> deterministic placement,
 //       k_bucket_scan      no global atomics
-//   K2c k_kmer_scatter     LDS cursors, tuples {key_lo, key_hi, inst|gated} written bucket-contiguous
+//   K2c k_part_records /   LDS-staged counting sort per round: tuples {key_lo, key_hi, inst|gated} written as
+//       k_part_tuples      coalesced bucket runs (256 coarse buckets, then 128 fine ones inside each)
 //   K3a k_bucket_aggregate LDS open-addressing table per bucket: gated count + first instance per
 //                          distinct k-mer; keys with count >= max(mf,2) become candidates, their
 //                          tuples are compacted in place (noise singletons die here)
@@ -24,12 +25,12 @@
 #include <string.h>
 
 #define HIST_THREADS 1024
-#define K3_THREADS 1024
-#define K3_SLOTS 4096u              // LDS table slots per sub-pass
-#define K3_SUB_TUPLES 3072u         // tuples per sub-pass the table is sized for
-#define K3B_THREADS 512
-#define K3B_CH 2048u                // candidates per chunk
-#define K3B_A 256u                  // quality-sum rows per round
+#define K3_THREADS 512
+#define K3_SLOTS 2048u              // LDS table slots per sub-pass (56 KB with u32 key_hi: 2 workgroups per CU)
+#define K3_SUB_TUPLES 3072u         // tuples per sub-pass before the first split (an overflow splits further)
+#define K3B_THREADS 256
+#define K3B_CH 1024u                // candidates per chunk
+#define K3B_A 128u                  // quality-sum rows per round
 #define K3B_KW 25u                  // u32 words per row (2 x u16 sums each), k <= 50
 #define NONE32 0xFFFFFFFFu
 #define INST_MASK 0x7FFFFFFFu
@@ -117,37 +118,159 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(const u32* __restrict__ bu
 }
 
 // ----------------------------------------------------------------------------------------------
-// K2c
+// K2c: LDS-staged partition (software write combining).
+// A direct scatter into 2^15 buckets writes 4-16 B at a time to tens of millions of open write fronts;
+// rocprofv3 WRITE_SIZE showed 5.7x the algorithmic bytes reaching HBM (profiles/r01b_traffic.json).
+// Instead a workgroup stages PART_ROUND tuples per round in LDS, counting-sorts them by bucket there and
+// writes every bucket's run with consecutive lanes on consecutive addresses.  <= 1024 buckets per pass keep
+// the runs long; 2^15 buckets are reached in two passes (256 coarse x 128 fine), the second pass working
+// one coarse bucket (a few MB, cache resident) at a time.  Placement inside a bucket is arbitrary
+// (per-round global cursor bump): every per-k-mer reduction downstream is order-free.
 // ----------------------------------------------------------------------------------------------
-template <typename THI>
-__global__ __launch_bounds__(HIST_THREADS) void k_kmer_scatter(const u64* __restrict__ bases, const u64* __restrict__ nmask,
-                                                               const u64* __restrict__ lowq, size_t R, u32 rec_base, int rl, int k, u32 nb_bits,
-                                                               size_t rpb, const u32* __restrict__ block_hist,
-                                                               const u32* __restrict__ bucket_start, u64* __restrict__ t_lo,
-                                                               THI* __restrict__ t_hi, u32* __restrict__ t_inst) {
-	extern __shared__ u32 cursor[];
-	const u32 NB = 1u << nb_bits;
-	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) cursor[i] = bucket_start[i] + block_hist[(size_t) blockIdx.x * NB + i];
+#define PART_THREADS 512
+#define PART_LDS_BYTES 131072
+#define PART_MAXB 1024
+
+template <typename THI> struct Tup { u64 lo; THI hi; u32 inst; };
+
+// exclusive scan of cnt[0..n) (n <= 1024) into base[0..n], base[n] = total; all PART_THREADS threads call it
+__device__ inline void part_scan(const u32* cnt, u32* base, u32* tmp, u32 n) {
+	const u32 t = threadIdx.x;
+	const u32 a = 2 * t < n ? cnt[2 * t] : 0, b = 2 * t + 1 < n ? cnt[2 * t + 1] : 0;
+	tmp[t] = a + b;
 	__syncthreads();
+	for (u32 d = 1; d < PART_THREADS; d <<= 1) {
+		u32 v = t >= d ? tmp[t - d] : 0;
+		__syncthreads();
+		tmp[t] += v;
+		__syncthreads();
+	}
+	const u32 excl = tmp[t] - (a + b);
+	if (2 * t < n) base[2 * t] = excl;
+	if (2 * t + 1 < n) base[2 * t + 1] = excl + a;
+	if (t == PART_THREADS - 1) base[n] = tmp[t];
+	__syncthreads();
+}
+
+// records -> tuples, one pass over `nbk` buckets selected by (hash >> shift) & (nbk-1)
+template <typename THI>
+__global__ __launch_bounds__(PART_THREADS) void k_part_records(const u64* __restrict__ bases, const u64* __restrict__ nmask,
+                                                               const u64* __restrict__ lowq, size_t R, u32 rec_base, int rl, int k,
+                                                               u32 shift, u32 nbk, size_t rpb, u32* __restrict__ gcur,
+                                                               u64* __restrict__ o_lo, THI* __restrict__ o_hi, u32* __restrict__ o_inst) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	Tup<THI>* stage = (Tup<THI>*) smem;
+	__shared__ u32 cnt[PART_MAXB], base[PART_MAXB + 1], cur[PART_MAXB], gbase[PART_MAXB], tmp[PART_THREADS];
+	const u32 ROUND = PART_LDS_BYTES / sizeof(Tup<THI>);
+	const int P = rl - k + 1;
+	const u32 RR = ROUND / (u32) P;                                  // records per round
+	const u64 km = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+	const u32 mask = nbk - 1;
 	const size_t r0 = (size_t) blockIdx.x * rpb;
 	const size_t r1 = r0 + rpb < R ? r0 + rpb : R;
-	const int P = rl - k + 1;
-	const u64 km = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
-	for (size_t r = r0 + threadIdx.x; r < r1; r += HIST_THREADS) {
-		RecView v = load_rec(bases, nmask, lowq, r);
-		for (int o = 0; o < P; o++) {
-			if ((v.nm >> o) & km) continue;
-			u64 khi, klo;
-			vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
-			u64 h = vdjx_mix(klo, khi);
-			u32 pos = atomicAdd(&cursor[(u32) (h >> (64 - nb_bits))], 1u);
-			u32 gated = ((v.lq >> o) & km) ? 0u : 0x80000000u;   // all k Phred >= 20 (A2:252)
-			t_lo[pos] = klo;
-			t_hi[pos] = (THI) khi;
-			t_inst[pos] = gated | (u32) ((rec_base + r) * (size_t) P + (size_t) o);
+	for (size_t rs = r0; rs < r1; rs += RR) {
+		const size_t re = rs + RR < r1 ? rs + RR : r1;
+		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) cnt[i] = 0;
+		__syncthreads();
+		for (size_t r = rs + threadIdx.x; r < re; r += PART_THREADS) {
+			RecView v = load_rec(bases, nmask, nullptr, r);
+			for (int o = 0; o < P; o++) {
+				if ((v.nm >> o) & km) continue;
+				u64 khi, klo;
+				vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
+				atomicAdd(&cnt[(u32) (vdjx_mix(klo, khi) >> shift) & mask], 1u);
+			}
 		}
+		__syncthreads();
+		part_scan(cnt, base, tmp, nbk);
+		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) {
+			cur[i] = base[i];
+			gbase[i] = cnt[i] ? atomicAdd(&gcur[i], cnt[i]) : 0u;
+		}
+		__syncthreads();
+		for (size_t r = rs + threadIdx.x; r < re; r += PART_THREADS) {
+			RecView v = load_rec(bases, nmask, lowq, r);
+			for (int o = 0; o < P; o++) {
+				if ((v.nm >> o) & km) continue;
+				u64 khi, klo;
+				vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
+				const u32 b = (u32) (vdjx_mix(klo, khi) >> shift) & mask;
+				const u32 pos = atomicAdd(&cur[b], 1u);
+				const u32 gated = ((v.lq >> o) & km) ? 0u : 0x80000000u;       // all k Phred >= 20 (A2:252)
+				Tup<THI> t;
+				t.lo = klo; t.hi = (THI) khi; t.inst = gated | (u32) ((rec_base + r) * (size_t) P + (size_t) o);
+				stage[pos] = t;
+			}
+		}
+		__syncthreads();
+		const u32 n = base[nbk];
+		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
+			const Tup<THI> t = stage[i];
+			const u32 b = (u32) (vdjx_mix(t.lo, (u64) t.hi) >> shift) & mask;
+			const u32 g = gbase[b] + (i - base[b]);
+			o_lo[g] = t.lo; o_hi[g] = t.hi; o_inst[g] = t.inst;
+		}
+		__syncthreads();
 	}
 }
+
+// tuples -> tuples: segment s of the input ([seg_start[s << seg_shift], seg_start[(s+1) << seg_shift])) is split over
+// `slices` workgroups; bucket = (s << sub_bits) | ((hash >> shift) & (2^sub_bits - 1)); gcur indexed by bucket
+template <typename THI>
+__global__ __launch_bounds__(PART_THREADS) void k_part_tuples(const u64* __restrict__ i_lo, const THI* __restrict__ i_hi,
+                                                              const u32* __restrict__ i_inst, const u32* __restrict__ seg_start,
+                                                              u32 seg_shift, u32 slices, u32 shift, u32 sub_bits,
+                                                              u32* __restrict__ gcur, u64* __restrict__ o_lo, THI* __restrict__ o_hi,
+                                                              u32* __restrict__ o_inst) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	Tup<THI>* stage = (Tup<THI>*) smem;
+	__shared__ u32 cnt[PART_MAXB], base[PART_MAXB + 1], cur[PART_MAXB], gbase[PART_MAXB], tmp[PART_THREADS];
+	const u32 ROUND = PART_LDS_BYTES / sizeof(Tup<THI>);
+	const u32 seg = blockIdx.x / slices, sl = blockIdx.x % slices;
+	const u32 nbk = 1u << sub_bits, mask = nbk - 1;
+	const size_t s0 = seg_start[(size_t) seg << seg_shift], s1 = seg_start[((size_t) seg + 1) << seg_shift];
+	const size_t len = s1 - s0;
+	const size_t per = (len + slices - 1) / slices;
+	const size_t t0 = s0 + (size_t) sl * per;
+	const size_t t1 = t0 + per < s1 ? t0 + per : s1;
+	u32* gc = gcur + ((size_t) seg << sub_bits);
+	for (size_t ts = t0; ts < t1; ts += ROUND) {
+		const size_t te = ts + ROUND < t1 ? ts + ROUND : t1;
+		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) cnt[i] = 0;
+		__syncthreads();
+		for (size_t t = ts + threadIdx.x; t < te; t += PART_THREADS)
+			atomicAdd(&cnt[(u32) (vdjx_mix(i_lo[t], (u64) i_hi[t]) >> shift) & mask], 1u);
+		__syncthreads();
+		part_scan(cnt, base, tmp, nbk);
+		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) {
+			cur[i] = base[i];
+			gbase[i] = cnt[i] ? atomicAdd(&gc[i], cnt[i]) : 0u;
+		}
+		__syncthreads();
+		for (size_t t = ts + threadIdx.x; t < te; t += PART_THREADS) {
+			Tup<THI> x;
+			x.lo = i_lo[t]; x.hi = i_hi[t]; x.inst = i_inst[t];
+			const u32 b = (u32) (vdjx_mix(x.lo, (u64) x.hi) >> shift) & mask;
+			stage[atomicAdd(&cur[b], 1u)] = x;
+		}
+		__syncthreads();
+		const u32 n = base[nbk];
+		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
+			const Tup<THI> x = stage[i];
+			const u32 b = (u32) (vdjx_mix(x.lo, (u64) x.hi) >> shift) & mask;
+			const u32 g = gbase[b] + (i - base[b]);
+			o_lo[g] = x.lo; o_hi[g] = x.hi; o_inst[g] = x.inst;
+		}
+		__syncthreads();
+	}
+}
+
+// cursors of a partition pass: cur[i] = bucket_start[i << sh]
+__global__ void k_init_cursors(const u32* __restrict__ bucket_start, u32 n, u32 sh, u32* __restrict__ cur) {
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) cur[i] = bucket_start[(size_t) i << sh];
+}
+
 
 // ----------------------------------------------------------------------------------------------
 // K3a: LDS hash aggregation per bucket
@@ -445,8 +568,12 @@ __global__ void k_graph_edges(const u64* __restrict__ bases, const u64* __restri
 		int s = surv_lookup(table, mask, s_lo, s_hi, klo, khi);
 		if (s >= 0 && prev >= 0) {
 			const u32 e = (u32) prev * 4u + (u32) (klo & 3ull);
-			atomicMin(&edge_first[e], (u32) ((rec_base + r) * (size_t) P + (size_t) o));
-			edge_to[e] = (u32) s;
+			const u32 inst = (u32) ((rec_base + r) * (size_t) P + (size_t) o);
+			// first sights only ever decrease: a (possibly stale) plain read that is already smaller needs no atomic
+			if (edge_first[e] > inst) {
+				atomicMin(&edge_first[e], inst);
+				edge_to[e] = (u32) s;
+			}
 		}
 		prev = s;
 	}
@@ -484,29 +611,6 @@ __global__ __launch_bounds__(HIST_THREADS) void k_tuple_hist(const u64* __restri
 	}
 	__syncthreads();
 	for (u32 i = threadIdx.x; i < NBL; i += HIST_THREADS) block_hist[(size_t) blockIdx.x * NBL + i] = hist[i];
-}
-
-template <typename THI>
-__global__ __launch_bounds__(HIST_THREADS) void k_tuple_scatter(const u64* __restrict__ lo, const THI* __restrict__ hi,
-                                                                const u32* __restrict__ inst, size_t n, u32 shift, u32 local_mask,
-                                                                size_t tpb, const u32* __restrict__ block_hist,
-                                                                const u32* __restrict__ bucket_start, u64* __restrict__ t_lo,
-                                                                THI* __restrict__ t_hi, u32* __restrict__ t_inst) {
-	extern __shared__ u32 cursor[];
-	const u32 NBL = local_mask + 1;
-	for (u32 i = threadIdx.x; i < NBL; i += HIST_THREADS) cursor[i] = bucket_start[i] + block_hist[(size_t) blockIdx.x * NBL + i];
-	__syncthreads();
-	const size_t t0 = (size_t) blockIdx.x * tpb;
-	const size_t t1 = t0 + tpb < n ? t0 + tpb : n;
-	for (size_t t = t0 + threadIdx.x; t < t1; t += HIST_THREADS) {
-		const u64 l = lo[t];
-		const THI hh = hi[t];
-		const u64 h = vdjx_mix(l, (u64) hh);
-		const u32 pos = atomicAdd(&cursor[(u32) (h >> shift) & local_mask], 1u);
-		t_lo[pos] = l;
-		t_hi[pos] = hh;
-		t_inst[pos] = inst[t];
-	}
 }
 
 struct SurvRec { u64 lo, hi; u32 gcnt, gfirst, ucnt, ufirst; };   // 32 bytes: what owners exchange
@@ -708,45 +812,102 @@ int stage_partition_count(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, u32 
 	return VDJX_OK;
 }
 
-// K2c into caller-chosen arrays
-template <typename THI>
-int stage_partition_fill(vdjx_ctx* c, const vdjx_pool* pool, u32 rec_base, int k, const PartPlan& pp, u64* t_lo, THI* t_hi, u32* t_inst) {
-	const size_t lds_hist = (size_t) pp.NB * 4;
-	HIP_TRY(hipFuncSetAttribute((const void*) k_kmer_scatter<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_hist));
-	vdjx_prof_scope ps(c, "k_kmer_scatter");
-	hipLaunchKernelGGL(k_kmer_scatter<THI>, dim3(pp.nblk), dim3(HIST_THREADS), lds_hist, c->stream, pool->d_bases, pool->d_nmask, pool->d_lowq,
-	                   pool->n_records, rec_base, pool->rl, k, pp.nb_bits, pp.rpb, pp.block_hist, pp.bucket_start, t_lo, t_hi, t_inst);
+// one- or two-pass LDS-staged partition of a tuple source into 2^nb_bits buckets whose starts are known
+// (bucket_start[NB+1]); `tmp_*` are scratch arrays of N tuples (two-pass only)
+struct PartGeom { u32 nb_bits, cbits, fbits; };
+inline PartGeom part_geom(u32 nb_bits) {
+	PartGeom g{nb_bits, nb_bits, 0};
+	if (nb_bits > 10) { g.cbits = 8; g.fbits = nb_bits - 8; }
+	return g;
+}
+
+// K2c from the records of `pool` into caller-chosen arrays (bucket starts from stage_partition_count)
+template <typename THI, typename A>
+int stage_partition_fill(vdjx_ctx* c, A& db, const vdjx_pool* pool, u32 rec_base, int k, const PartPlan& pp, u32 N,
+                         u64* t_lo, THI* t_hi, u32* t_inst) {
+	hipStream_t st = c->stream;
+	const PartGeom g = part_geom(pp.nb_bits);
+	const size_t R = pool->n_records;
+	const u32 NBc = 1u << g.cbits;
+	u32* gcur;
+	HIP_TRY(db.alloc(&gcur, NBc));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_part_records<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_part_tuples<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
+	u32 nblk = (u32) std::min<size_t>(1024, (R + 2047) / 2048);
+	if (nblk == 0) nblk = 1;
+	const size_t rpb = (R + nblk - 1) / nblk;
+	u64* l1_lo = t_lo; THI* l1_hi = t_hi; u32* l1_inst = t_inst;
+	if (g.fbits) {
+		HIP_TRY(db.alloc(&l1_lo, N)); HIP_TRY(db.alloc(&l1_hi, N)); HIP_TRY(db.alloc(&l1_inst, N));
+	}
+	{
+		vdjx_prof_scope ps(c, "k_part_records");
+		hipLaunchKernelGGL(k_init_cursors, dim3((NBc + 255) / 256), dim3(256), 0, st, pp.bucket_start, NBc, g.fbits, gcur);
+		hipLaunchKernelGGL(k_part_records<THI>, dim3(nblk), dim3(PART_THREADS), PART_LDS_BYTES, st, pool->d_bases, pool->d_nmask,
+		                   pool->d_lowq, R, rec_base, pool->rl, k, 64 - g.cbits, NBc, rpb, gcur, l1_lo, l1_hi, l1_inst);
+	}
+	if (g.fbits) {
+		u32* gcur2;
+		HIP_TRY(db.alloc(&gcur2, pp.NB));
+		const u32 slices = 4;
+		vdjx_prof_scope ps(c, "k_part_tuples");
+		hipLaunchKernelGGL(k_init_cursors, dim3((pp.NB + 255) / 256), dim3(256), 0, st, pp.bucket_start, pp.NB, 0u, gcur2);
+		hipLaunchKernelGGL(k_part_tuples<THI>, dim3(NBc * slices), dim3(PART_THREADS), PART_LDS_BYTES, st, l1_lo, l1_hi, l1_inst,
+		                   pp.bucket_start, g.fbits, slices, 64 - pp.nb_bits, g.fbits, gcur2, t_lo, t_hi, t_inst);
+	}
 	return VDJX_OK;
 }
 
-// owner side: bucket the received tuples by the hash bits below the owner bits
+// owner side: bucket the received tuples by the hash bits below the owner bits (same LDS-staged passes)
 template <typename THI, typename A>
 int stage_repartition(vdjx_ctx* c, A& db, const u64* r_lo, const THI* r_hi, const u32* r_inst, size_t n, u32 owner_bits,
                       Tuples<THI>* out) {
 	hipStream_t st = c->stream;
 	const u32 lb = choose_nb_bits(n);
-	const u32 shift = 64 - owner_bits - lb;
+	const PartGeom g = part_geom(lb);
 	const u32 NBL = 1u << lb;
 	u32 nblk = (u32) std::min<size_t>(512, (n + 65535) / 65536);
 	if (nblk == 0) nblk = 1;
 	const size_t tpb = (n + nblk - 1) / nblk;
-	u32 *block_hist, *bucket_cnt;
+	u32 *block_hist, *bucket_cnt, *gcur, *whole;
 	HIP_TRY(db.alloc(&block_hist, (size_t) nblk * NBL));
 	HIP_TRY(db.alloc(&bucket_cnt, NBL));
 	HIP_TRY(db.alloc(&out->bucket_start, NBL + 1));
 	HIP_TRY(db.alloc(&out->lo, n));
 	HIP_TRY(db.alloc(&out->hi, n));
 	HIP_TRY(db.alloc(&out->inst, n));
+	HIP_TRY(db.alloc(&gcur, NBL));
+	HIP_TRY(db.alloc(&whole, 2));
 	const size_t lds = (size_t) NBL * 4;
 	HIP_TRY(hipFuncSetAttribute((const void*) k_tuple_hist<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-	HIP_TRY(hipFuncSetAttribute((const void*) k_tuple_scatter<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_part_tuples<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
+	const u32 seg[2] = {0u, (u32) n};
+	HIP_TRY(hipMemcpyAsync(whole, seg, 8, hipMemcpyHostToDevice, st));
 	{
-		vdjx_prof_scope ps(c, "k_tuple_repartition");
-		hipLaunchKernelGGL(k_tuple_hist<THI>, dim3(nblk), dim3(HIST_THREADS), lds, st, r_lo, r_hi, n, shift, NBL - 1, tpb, block_hist);
+		vdjx_prof_scope ps(c, "k_tuple_hist");
+		hipLaunchKernelGGL(k_tuple_hist<THI>, dim3(nblk), dim3(HIST_THREADS), lds, st, r_lo, r_hi, n, 64 - owner_bits - lb, NBL - 1, tpb, block_hist);
 		hipLaunchKernelGGL(k_hist_colscan, dim3((NBL + 255) / 256), dim3(256), 0, st, block_hist, nblk, NBL, bucket_cnt);
 		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, bucket_cnt, NBL, out->bucket_start);
-		hipLaunchKernelGGL(k_tuple_scatter<THI>, dim3(nblk), dim3(HIST_THREADS), lds, st, r_lo, r_hi, r_inst, n, shift, NBL - 1, tpb,
-		                   block_hist, out->bucket_start, out->lo, out->hi, out->inst);
+	}
+	u64* l1_lo = out->lo; THI* l1_hi = out->hi; u32* l1_inst = out->inst;
+	if (g.fbits) {
+		HIP_TRY(db.alloc(&l1_lo, n)); HIP_TRY(db.alloc(&l1_hi, n)); HIP_TRY(db.alloc(&l1_inst, n));
+	}
+	{
+		vdjx_prof_scope ps(c, "k_part_tuples");
+		const u32 NBc = 1u << g.cbits;
+		const u32 sl1 = (u32) std::min<size_t>(1024, (n + 65535) / 65536) ? (u32) std::min<size_t>(1024, (n + 65535) / 65536) : 1u;
+		// pass 1: the whole input is one segment; cursors = starts of the coarse buckets
+		hipLaunchKernelGGL(k_init_cursors, dim3((NBc + 255) / 256), dim3(256), 0, st, out->bucket_start, NBc, g.fbits, gcur);
+		hipLaunchKernelGGL(k_part_tuples<THI>, dim3(sl1), dim3(PART_THREADS), PART_LDS_BYTES, st, r_lo, r_hi, r_inst, whole, 0u, sl1,
+		                   64 - owner_bits - g.cbits, g.cbits, gcur, l1_lo, l1_hi, l1_inst);
+		if (g.fbits) {
+			u32* gcur2;
+			HIP_TRY(db.alloc(&gcur2, NBL));
+			hipLaunchKernelGGL(k_init_cursors, dim3((NBL + 255) / 256), dim3(256), 0, st, out->bucket_start, NBL, 0u, gcur2);
+			hipLaunchKernelGGL(k_part_tuples<THI>, dim3(NBc * 4), dim3(PART_THREADS), PART_LDS_BYTES, st, l1_lo, l1_hi, l1_inst,
+			                   out->bucket_start, g.fbits, 4u, 64 - owner_bits - lb, g.fbits, gcur2, out->lo, out->hi, out->inst);
+		}
 	}
 	out->NB = NBL;
 	out->N = (u32) n;
@@ -916,7 +1077,7 @@ int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, v
 	HIP_TRY(db.alloc(&t.lo, t.N)); HIP_TRY(db.alloc(&t.hi, t.N)); HIP_TRY(db.alloc(&t.inst, t.N));
 	t.bucket_start = pp.bucket_start;
 	t.NB = pp.NB;
-	rc = stage_partition_fill<THI>(c, pool, 0, k, pp, t.lo, t.hi, t.inst);
+	rc = stage_partition_fill<THI>(c, db, pool, 0, k, pp, t.N, t.lo, t.hi, t.inst);
 	if (rc) return rc;
 	PoolView pv{pool->d_bases, pool->d_nmask, pool->d_quals, pool->qstride};
 	Survivors sv;
@@ -1049,8 +1210,9 @@ extern "C" int vdjx_shard_partition_fill(vdjx_shard* s, void* d_lo, void* d_hi, 
 	vdjx_ctx* c = s->c;
 	HIP_TRY(hipSetDevice(c->device));
 	const u32 rec_base = s->rec_stride * (u32) s->rank;
-	int rc = s->hi64 ? stage_partition_fill<u64>(c, s->pool, rec_base, s->k, s->pp, (u64*) d_lo, (u64*) d_hi, (u32*) d_inst)
-	                 : stage_partition_fill<u32>(c, s->pool, rec_base, s->k, s->pp, (u64*) d_lo, (u32*) d_hi, (u32*) d_inst);
+	PersistAlloc db(c);
+	int rc = s->hi64 ? stage_partition_fill<u64>(c, db, s->pool, rec_base, s->k, s->pp, s->N_local, (u64*) d_lo, (u64*) d_hi, (u32*) d_inst)
+	                 : stage_partition_fill<u32>(c, db, s->pool, rec_base, s->k, s->pp, s->N_local, (u64*) d_lo, (u32*) d_hi, (u32*) d_inst);
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	HIP_TRY(hipGetLastError());

@@ -337,7 +337,9 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 	HIP_TRY(hipMalloc(&c->d_read_num, (size_t) R + 1));
 	HIP_TRY(hipMalloc(&c->d_is_rc, (size_t) R + 1));
 	HIP_TRY(hipMalloc(&c->d_pair_r2, pr2.size() * 4));
-	HIP_TRY(hipMalloc(&c->d_rec_info, info.size() * sizeof(uint4)));
+	std::vector<uint4> csr_info(recs.size());
+	for (size_t i = 0; i < (size_t) start[ncls]; i++) csr_info[i] = info[recs[i]];
+	HIP_TRY(hipMalloc(&c->d_rec_info, csr_info.size() * sizeof(uint4)));
 	HIP_TRY(hipMemcpy(c->d_ri_slots, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
 	if (ncls) HIP_TRY(hipMemcpy(c->d_ri_rep, rep.data(), (size_t) ncls * 4, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(c->d_ri_start, start.data(), start.size() * 4, hipMemcpyHostToDevice));
@@ -346,8 +348,8 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 		HIP_TRY(hipMemcpy(c->d_pair_id, pair_id, (size_t) R * 4, hipMemcpyHostToDevice));
 		HIP_TRY(hipMemcpy(c->d_read_num, read_num, R, hipMemcpyHostToDevice));
 		HIP_TRY(hipMemcpy(c->d_is_rc, is_rc, R, hipMemcpyHostToDevice));
-		HIP_TRY(hipMemcpy(c->d_rec_info, info.data(), (size_t) R * sizeof(uint4), hipMemcpyHostToDevice));
 	}
+	HIP_TRY(hipMemcpy(c->d_rec_info, csr_info.data(), csr_info.size() * sizeof(uint4), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(c->d_pair_r2, pr2.data(), pr2.size() * 4, hipMemcpyHostToDevice));
 	c->ri_nslots = mask + 1;
 	c->n_pairs = n_pairs;
@@ -367,7 +369,7 @@ struct ReadIndexDev {
 	const u64* bases;
 	const u32* slots; u32 mask;
 	const u32* rep; const u32* start; const u32* recs;
-	const uint4* rec_info; const u32* pair_r2;
+	const uint4* csr_info; const u32* pair_r2;    // csr_info[i] = record info of recs[i]: one coalesced 16-byte load per hit
 	int rl;
 };
 
@@ -479,8 +481,8 @@ __device__ inline Hit map_eval_hit(const MapLds& L, const ReadIndexDev& ix, int 
 		if (L.hpre[mid] <= h) lo = mid; else hi = mid;
 	}
 	const int o = lo;
-	const u32 rec = ix.recs[L.cstart[o] + (h - L.hpre[o])];
-	const uint4 info = ix.rec_info[rec];
+	const u32 ci = L.cstart[o] + (h - L.hpre[o]);
+	const uint4 info = ix.csr_info[ci];
 	if (!(info.w & RI_R1)) return r;                // read-2 instances only feed the read2 map
 	// read2[id]: among the pair's read-2 records the one written last = largest offset, then latest registration
 	const u32 la = map_last_occurrence(L, info.y), lb = map_last_occurrence(L, info.z);
@@ -495,7 +497,7 @@ __device__ inline Hit map_eval_hit(const MapLds& L, const ReadIndexDev& ix, int 
 	const int insert = (int) (short) ((d < 0 ? -d : d) + ix.rl);
 	if (insert < 50 || insert > 400) return r;      // MIN_INSERT / MAX_INSERT, quick_map3.c:23-24
 	r.pair = true;
-	r.pair_id = info.x; r.rec1 = rec; r.which = which;
+	r.pair_id = info.x; r.rec1 = ix.recs[ci]; r.which = which;
 	r.pos1 = pos1; r.pos2 = pos2; r.insert = insert; r.rc1 = rc1; r.rc2 = rc2;
 	return r;
 }
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_score(ReadIndexDev ix, c
 	__shared__ MapLds L;
 	__shared__ u32 hf[MAP_MAXOFF + 64 + 2];         // histogram of firsts -> inclusive prefix "cum"
 	__shared__ int diff[COV_WORDS];
-	__shared__ u32 s_np, s_bad;
+	__shared__ u32 s_np, s_bad, s_ok;
 	const u32 tid = threadIdx.x;
 	const int rl = ix.rl;
 	const int noff = len - rl;
@@ -603,49 +605,62 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_score(ReadIndexDev ix, c
 				if (!ok) s_bad = 1;
 			}
 			__syncthreads();
-			// ---- rule 2
+			// ---- rule 2.  Coverage only grows with more entries, so the pair list is replayed in doubling chunks and
+			// a batch of deltas is done as soon as every tested (pos, delta) already reaches the floor.
 			for (int d0 = clo; d0 < chi && !s_bad; d0 += DB) {
 				const int nd = chi - d0 < DB ? chi - d0 : DB;
 				for (int i = tid; i < nd * stride; i += MAP_THREADS) diff[i] = 0;
 				__syncthreads();
-				for (u32 q = tid; q < 2 * npairs; q += MAP_THREADS) {
-					const u32 pr = pairs[q >> 1];
-					const int p1 = (int) (pr >> 16), p2 = (int) (pr & 0xFFFFu);
-					const int f = (q & 1) ? p2 : p1, sx = (q & 1) ? p1 : p2;
-					// deltas of this batch with |f - (sx - delta)| < rl
-					int dlo = sx - f - rl + 1, dhi = sx - f + rl - 1;
-					if (dlo < d0) dlo = d0;
-					if (dhi > d0 + nd - 1) dhi = d0 + nd - 1;
-					for (int dl = dlo; dl <= dhi; dl++) {
-						const int v = sx - dl;
-						int lo = f > v ? f : v;                           // first pos that sees both
-						int hi = (f < v ? f : v) + rl;                    // one past the last
-						if (lo < e0) lo = e0;
-						if (hi > e1) hi = e1;
-						if (lo < hi) {
-							atomicAdd(&diff[(dl - d0) * stride + (lo - e0)], 1);
-							atomicAdd(&diff[(dl - d0) * stride + (hi - e0)], -1);
+				u32 done = 0, chunk = 4096;
+				for (;;) {
+					const u32 end = done + chunk < 2 * npairs ? done + chunk : 2 * npairs;
+					for (u32 q = done + tid; q < end; q += MAP_THREADS) {
+						const u32 pr = pairs[q >> 1];
+						const int p1 = (int) (pr >> 16), p2 = (int) (pr & 0xFFFFu);
+						const int f = (q & 1) ? p2 : p1, sx = (q & 1) ? p1 : p2;
+						// deltas of this batch with |f - (sx - delta)| < rl
+						int dlo = sx - f - rl + 1, dhi = sx - f + rl - 1;
+						if (dlo < d0) dlo = d0;
+						if (dhi > d0 + nd - 1) dhi = d0 + nd - 1;
+						for (int dl = dlo; dl <= dhi; dl++) {
+							const int v = sx - dl;
+							int lo = f > v ? f : v;                       // first pos that sees both
+							int hi = (f < v ? f : v) + rl;                // one past the last
+							if (lo < e0) lo = e0;
+							if (hi > e1) hi = e1;
+							if (lo < hi) {
+								atomicAdd(&diff[(dl - d0) * stride + (lo - e0)], 1);
+								atomicAdd(&diff[(dl - d0) * stride + (hi - e0)], -1);
+							}
 						}
 					}
+					if (tid == 0) s_ok = 1;
+					__syncthreads();
+					if ((int) tid < nd) {
+						const int dl = d0 + (int) tid;
+						const int* row = diff + tid * stride;
+						int run = 0;
+						bool ok = true;
+						for (int p = 0; p < npos; p++) {
+							run += row[p];
+							const int pos = e0 + p;
+							if (pos != e0 && (pos - 1 + clo) >= e1) break;       // the loop tests the previous mate_low (coverage.c:25)
+							int mh = pos + chi;
+							if (mh > e1) mh = e1 + 1;                             // coverage.c:36-38
+							const int j = pos + dl;
+							if (j >= mh) continue;
+							if (j < 0 || j > len + 1023) { s_bad = 1; break; }    // outside the reference's array: undefined there
+							if (run < fl) ok = false;
+						}
+						if (!ok) s_ok = 0;
+					}
+					__syncthreads();
+					done = end;
+					if (s_ok || s_bad || done >= 2 * npairs) break;
+					chunk *= 2;
+					__syncthreads();
 				}
-				__syncthreads();
-				if ((int) tid < nd) {
-					int run = 0;
-					int* row = diff + tid * stride;
-					for (int p = 0; p < npos; p++) { run += row[p]; row[p] = run; }
-				}
-				__syncthreads();
-				for (int i = tid; i < nd * npos; i += MAP_THREADS) {
-					const int dl = d0 + i / npos;
-					const int pos = e0 + i % npos;
-					if (pos != e0 && (pos - 1 + clo) >= e1) continue;     // the loop tests the previous mate_low (coverage.c:25)
-					int mh = pos + chi;
-					if (mh > e1) mh = e1 + 1;                             // coverage.c:36-38
-					const int j = pos + dl;
-					if (j >= mh) continue;
-					if (j < 0 || j > len + 1023) { s_bad = 1; continue; }  // outside the reference's array: undefined there
-					if (diff[(dl - d0) * stride + (pos - e0)] < fl) s_bad = 1;
-				}
+				if (!s_ok) s_bad = 1;          // every entry counted and some (pos, delta) is still short
 				__syncthreads();
 			}
 			__syncthreads();
@@ -725,7 +740,7 @@ static int make_index_view(vdjx_ctx* c, ReadIndexDev* ix, int len, const char* w
 	ix->bases = p->d_bases;
 	ix->slots = c->d_ri_slots; ix->mask = c->ri_nslots - 1;
 	ix->rep = c->d_ri_rep; ix->start = c->d_ri_start; ix->recs = c->d_ri_recs;
-	ix->rec_info = c->d_rec_info; ix->pair_r2 = c->d_pair_r2;
+	ix->csr_info = c->d_rec_info; ix->pair_r2 = c->d_pair_r2;
 	ix->rl = p->rl;
 	return VDJX_OK;
 }
