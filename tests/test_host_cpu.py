@@ -1,0 +1,128 @@
+"""CPU tests of the serial host stage (vdjer_amd/csrc/host: sparsehash-order emulation, condensation, contig
+enumeration, window discovery, acceptance, overlap removal, FASTA/SAM/dot text) against dumps of the compiled
+reference.  The scorers behind the stage are the CPU oracle here (the GPU tests run the same stage behind libvdjx)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import golden_util as G
+from vdjer_amd import api, host
+
+
+def test_dense_table_iteration_order_vs_sparsehash():
+    """insert / erase / resize(0) sequences on dense_hash_map<const char*, ..., contig_hash> (360-char keys)"""
+    L = host.lib()
+    t = host.SphTable()
+    L.sph_init(C.byref(t), 360, 0)
+    keep = []
+    got = []
+    for op in G.text("order_ops.txt.gz").splitlines():
+        if op[0] == "I":
+            kb = C.create_string_buffer(op[2:].encode())
+            keep.append(kb)
+            L.sph_map_put(C.byref(t), C.cast(kb, C.c_char_p), None, None)
+        elif op[0] == "E":
+            L.sph_erase(C.byref(t), op[2:].encode())
+        elif op[0] == "R":
+            L.sph_resize0(C.byref(t))
+        elif op[0] == "D":
+            got.append(f"D\t{L.sph_size(C.byref(t))}\t{t.nbuckets}")
+            b = L.sph_next(C.byref(t), 0)
+            while b < t.nbuckets:
+                got.append(t.b[b].key.decode())
+                b = L.sph_next(C.byref(t), b + 1)
+    assert got == G.text("order_out.txt.gz").splitlines()
+    assert L.sph_murmur64a(b"ACGTACGTACGTACGTACGTACGTACGTACGTACG", 35, 97) == 5958308921596863335
+
+
+def _golden_graph(tag, k):
+    rows = G.rows(f"{tag}.nodes.tsv.gz")
+    n = len(rows)
+    g = api.Graph(k, n, 0, np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint8),
+                  np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros((n, 4), np.uint32), np.zeros(n, np.uint8),
+                  np.zeros((n, 4), np.uint32), np.zeros((n, k), np.uint8))
+    for i, r in enumerate(rows):
+        g.kmers[i] = np.frombuffer(r[1].encode(), np.uint8)
+        g.freq[i], g.has_v[i], g.has_j[i] = int(r[2]), int(r[3]), int(r[4])
+        to = [int(x) for x in r[5].split(",") if x]
+        fr = [int(x) for x in r[6].split(",") if x]
+        g.to_deg[i], g.from_deg[i] = len(to), len(fr)
+        g.to_ids[i, :len(to)] = to
+        g.from_ids[i, :len(fr)] = fr
+    return g
+
+
+@pytest.mark.parametrize("tag,k", [("noisy_k35", 35), ("noisy_k25", 25), ("noisy_mq230", 35), ("pre_k35", 35)])
+def test_nodes_table_order(tag, k):
+    g = _golden_graph(tag, k)
+    assert host.node_order(g).tolist() == [int(r[0]) for r in G.rows(f"{tag}.node_order.tsv.gz")]
+
+
+def test_window_discovery_vs_reference():
+    z = np.load(os.path.join(G.GOLD, "vjf_codes.npz"))
+    p = host.make_params("IGH", ins=175)
+    contigs = G.text("vjf_contigs.txt.gz").split()
+    exp, cur = [], None
+    for l in G.text("vjf_out.txt.gz").splitlines():
+        f = l.split("\t")
+        if f[0] == "C":
+            cur = []
+            exp.append(cur)
+        else:
+            cur.append((f[0], f[1]))
+    assert len(exp) == len(contigs)
+    for c, e in zip(contigs, exp):
+        assert host.vjf_search(p, c, z["v_codes"], z["j_codes"]) == e
+    assert sum(len(e) for e in exp) >= 5
+
+
+def _oracle_hooks(pool, v_region, p):
+    sc = oracle.RootScorer([v_region], p.vregion_kmer_size)
+    ix = oracle.ReadIndex(pool)
+
+    def root_score(km, k, thr):
+        return [sc.score(km[i].tobytes().decode(), thr) for i in range(km.shape[0])]
+
+    def window_score(wins):
+        out = []
+        for w in wins:
+            pairs, starts = ix.quick_map(w)
+            out.append(1 if p.read_filter_floor == 0 else ix.coverage_is_valid(
+                starts, len(w), p.insert_len, e0=p.eval_start, e1=p.eval_stop, rs=p.filter_read_span, ms=p.filter_mate_span,
+                floor=p.read_filter_floor))
+        return out
+
+    def sam_body(ids, contigs):
+        txt = []
+        for cid, c in zip(ids, contigs):
+            pairs, _ = ix.quick_map(c)
+            for q in pairs:
+                txt.append(ix.sam_pair(cid, f"r{q['pair_id']}", q))
+        return "".join(txt)
+
+    return root_score, window_score, sam_body
+
+
+@pytest.mark.parametrize("tag", ["e2e_tiled", "e2e_mixed", "e2e_k25"])
+def test_host_stage_end_to_end_vs_reference(tag, tmp_path):
+    """graph (from the oracle) -> host stage -> vdj_contigs.fa, SAM and vdjer.dot byte-identical to the reference's"""
+    c = G.Case(tag)
+    info = G.manifest()["e2e"][tag]
+    fl = G.flags_to_params(info["flags"])
+    p = host.make_params("IGH", ins=175, k=fl["k"], mf=fl["mf"], mq=fl["mq"], mcs=fl["mcs"], mrs=fl["mrs"], rl=c.pool.rl)
+    t = oracle.KmerTable(c.pool, fl["k"])
+    t.prune(fl["mf"], fl["mq"])
+    og = oracle.Graph(t, c.v_codes, c.j_codes)
+    g = api.Graph(fl["k"], og.n, 0, og.first, np.zeros(og.n, np.uint32), og.freq, og.has_v, og.has_j, og.to_deg, og.to_ids,
+                  og.from_deg, og.from_ids,
+                  np.frombuffer("".join(oracle.inst_kmer(c.pool, int(f), fl["k"]) for f in og.first).encode(), np.uint8).reshape(og.n, fl["k"]))
+    fa, dot, sam = tmp_path / "c.fa", tmp_path / "g.dot", tmp_path / "o.sam"
+    st = host.assemble(p, g, *_oracle_hooks(c.pool, c.v_region, p), c.v_codes, c.j_codes, str(fa), str(dot), str(sam))
+    assert st["n_roots"] == info["roots"]
+    assert fa.read_text() == G.text(f"{tag}.contigs.fa.gz")
+    assert dot.read_text() == G.text(f"{tag}.dot.gz")
+    assert sam.read_text() == G.text(f"{tag}.sam.gz")
+    assert st["n_contigs_out"] == info["contigs"]

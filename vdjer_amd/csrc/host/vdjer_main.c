@@ -1,0 +1,374 @@
+/*
+ * vdjer_main.c -- the `vdjer` command line (params.c:74-101, 214-298) over libvdjx (GPU hot path) and
+ * vdjh (serial host stage).  Plain C; talks to the GPU only through the C ABI of include/vdjx.h.
+ *
+ *   vdjer --in <reads> --chain IGH|IGK|IGL --ref-dir <dir> --ins <n> [--t --k --mf --mq --mcs --am --miw --maw
+ *         --jc --ws -jext --rf --vk --mrs --rs --ms --e0 --e1 --wo --vf --jf --rms]
+ * writes ./vdj_contigs.fa and ./vdjer.dot, SAM on stdout, log on stderr; exit 0 on success.
+ *
+ * --in: BAM extraction (bam_read.c, htslib) is the next row of the scope table and is not part of
+ * this build; --in takes the extracted read pool as text, one read per line in extraction order:
+ *     <pool:P|S> <name> <read_num:1|2> <is_rev:0|1> <SEQ> <QUAL>
+ * from which the pool records (as-is + reverse complement, bam_read.c:206-244) are rebuilt.
+ */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+
+#include "../../../include/vdjx.h"
+#include "sph.h"
+#include "vdjh.h"
+
+typedef struct {
+	vdjh_params hp;
+	const char* in;
+	char v_anchors[4096], j_anchors[4096], source_sim_file[4096];
+	int anchor_mismatches, threads;
+	int have_chain, have_ref;
+} cli;
+
+static void usage(void) {
+	fprintf(stderr, "vdjer \n\t--in <extracted reads (text; see vdjer_main.c)>\n\t--chain <IGH|IGK|IGL>\n\t--ref-dir </path/to/vdjer/ref/dir>\n"
+	                "\t--mf <min node frequency (default: 3)>\n\t--mq <min base quality (default: 90)>\n\t--mcs <min contig score (default: -5)\n"
+	                "\t--t <threads (default: 1)\n\t--am <anchor mismatches (default: 4)\n\t--miw/--maw <min/max window between conserved amino acids>\n"
+	                "\t--jc <conserved J amino acid (W|F)\n\t--ws <window span (default: 486)\n\t--jext <J extension (default: 162)\n"
+	                "\t--ins <expected / median insert length>\n\t--rf <read filter floor (default: 1)\n\t--k <kmer size (default: 35)>\n"
+	                "\t--vk <vregion kmer size (default: 15)>\n\t--mrs <min source node homology score (default: 30)\n"
+	                "\t--rs <read span distance (default: 35)>\n\t--ms <mate span distance (default: 48)>\n"
+	                "\t--e0/--e1 <start/stop position for contig filtering (default: 52/411)>\n\t--wo <window overlap check size>\n");
+}
+
+static int file_exists(const char* f) { struct stat b; return stat(f, &b) == 0; }
+
+/* params.c:214-298: positional "--flag value" pairs; unknown flags only warn */
+static int parse(int argc, char** argv, cli* c) {
+	memset(c, 0, sizeof *c);
+	vdjh_default_params(&c->hp);
+	c->anchor_mismatches = 4;
+	c->threads = 1;
+	for (int i = 1; i < argc; i += 2) {
+		const char* a = argv[i];
+		if (!strcmp(a, "--help")) { usage(); exit(0); }
+		if (i + 1 >= argc) { fprintf(stderr, "Missing value for param: %s\n", a); usage(); return -1; }
+		const char* v = argv[i + 1];
+		if (!strcmp(a, "--in")) c->in = v;
+		else if (!strcmp(a, "--chain")) { if (vdjh_set_chain(&c->hp, v)) { fprintf(stderr, "%s\n", vdjh_last_error()); return -1; } c->have_chain = 1; }
+		else if (!strcmp(a, "--ref-dir")) {
+			snprintf(c->v_anchors, sizeof c->v_anchors, "%s/v_index", v);
+			snprintf(c->j_anchors, sizeof c->j_anchors, "%s/j_index", v);
+			snprintf(c->source_sim_file, sizeof c->source_sim_file, "%s/v_region.fa", v);
+			c->have_ref = 1;
+		}
+		else if (!strcmp(a, "--mf")) c->hp.min_node_freq = atoi(v);
+		else if (!strcmp(a, "--mq")) c->hp.min_base_quality = atoi(v);
+		else if (!strcmp(a, "--mcs")) c->hp.min_contig_score = (float) atof(v);
+		else if (!strcmp(a, "--t")) c->threads = atoi(v);
+		else if (!strcmp(a, "--vf")) snprintf(c->v_anchors, sizeof c->v_anchors, "%s", v);
+		else if (!strcmp(a, "--jf")) snprintf(c->j_anchors, sizeof c->j_anchors, "%s", v);
+		else if (!strcmp(a, "--am")) c->anchor_mismatches = atoi(v);
+		else if (!strcmp(a, "--miw")) c->hp.vj_min_win = atoi(v);
+		else if (!strcmp(a, "--maw")) c->hp.vj_max_win = atoi(v);
+		else if (!strcmp(a, "--jc")) c->hp.j_conserved = v[0];
+		else if (!strcmp(a, "--ws")) c->hp.window_span = atoi(v);
+		else if (!strcmp(a, "-jext")) c->hp.j_extension = atoi(v);        /* sic: params.c:262 */
+		else if (!strcmp(a, "--vdjf") || !strcmp(a, "--vr") || !strcmp(a, "--cr")) { /* extraction-only settings */ }
+		else if (!strcmp(a, "--ins")) c->hp.insert_len = atoi(v);
+		else if (!strcmp(a, "--rf")) c->hp.read_filter_floor = atoi(v);
+		else if (!strcmp(a, "--k")) c->hp.k = atoi(v);
+		else if (!strcmp(a, "--rms")) snprintf(c->source_sim_file, sizeof c->source_sim_file, "%s", v);
+		else if (!strcmp(a, "--vk")) c->hp.vregion_kmer_size = atoi(v);
+		else if (!strcmp(a, "--mrs")) c->hp.min_source_homology_score = atoi(v);
+		else if (!strcmp(a, "--rs")) c->hp.filter_read_span = atoi(v);
+		else if (!strcmp(a, "--ms")) c->hp.filter_mate_span = atoi(v);
+		else if (!strcmp(a, "--e0")) c->hp.eval_start = atoi(v);
+		else if (!strcmp(a, "--e1")) c->hp.eval_stop = atoi(v);
+		else if (!strcmp(a, "--wo")) c->hp.window_overlap_check_size = atoi(v);
+		else fprintf(stderr, "Invalid param: %s\n", a);
+	}
+	int ok = 1;       /* validate_params, params.c:143-212 */
+	if (!c->in) { fprintf(stderr, "Input must be specified\n"); ok = 0; }
+	else if (!file_exists(c->in)) { fprintf(stderr, "Could not find input file: %s\n", c->in); ok = 0; }
+	if (!c->v_anchors[0]) { fprintf(stderr, "V anchor file must be specified\n"); ok = 0; }
+	else if (!file_exists(c->v_anchors)) { fprintf(stderr, "Could not locate v_index file: %s\n", c->v_anchors); ok = 0; }
+	if (!c->j_anchors[0]) { fprintf(stderr, "J anchor file must be specified\n"); ok = 0; }
+	else if (!file_exists(c->j_anchors)) { fprintf(stderr, "Could not locate j_index file: %s\n", c->j_anchors); ok = 0; }
+	if (!c->source_sim_file[0]) { fprintf(stderr, "source_sim_file file must be specified\n"); ok = 0; }
+	if (c->hp.j_conserved != 'W' && c->hp.j_conserved != 'F') { fprintf(stderr, "Conserved J AA must be W or F: %c\n", c->hp.j_conserved); ok = 0; }
+	if (c->hp.insert_len <= 0) { fprintf(stderr, "insert_len must be specified and > 0\n"); ok = 0; }
+	if (!ok) { usage(); return -1; }
+	if (c->hp.min_base_quality >= 255) c->hp.min_base_quality = 254;      /* A2:1514-1516 */
+	return 0;
+}
+
+static time_t t_start, t_prev;
+static void status(const char* desc) {         /* status.c:22-32 without the /proc dumps */
+	time_t now = time(NULL);
+	fprintf(stderr, "ELAPSED_SECS\t%s\t%ld\t%ld\n", desc, (long) (now - t_start), (long) (now - t_prev));
+	t_prev = now;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* inputs                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+	int rl;
+	uint8_t *primary, *secondary;
+	size_t n_primary, n_secondary;
+	uint32_t *pair_id, *reg_rank;       /* scan order: primary records then secondary */
+	uint8_t *read_num, *is_rc;
+	char** names;
+	uint32_t n_pairs;
+} reads_t;
+
+static char comp(char c) { switch (c) { case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C'; default: return c; } }
+
+static int load_reads(const char* path, reads_t* r) {
+	FILE* fp = fopen(path, "r");
+	if (!fp) { fprintf(stderr, "cannot open %s\n", path); return -1; }
+	unsigned char magic[4] = {0};
+	if (fread(magic, 1, 4, fp) == 4 && ((magic[0] == 0x1f && magic[1] == 0x8b) || !memcmp(magic, "BAM\1", 4))) {
+		fprintf(stderr, "%s looks like a BAM/BGZF file: BAM extraction is not part of this build (SURVEY 8f-2); "
+		                "pass the extracted reads as text (see vdjer_main.c)\n", path);
+		fclose(fp);
+		return -1;
+	}
+	rewind(fp);
+	char pool[8], name[512];
+	static char seq[1024], qual[1024];
+	int rn, rev;
+	size_t np = 0, ns = 0;
+	int rl = -1;
+	while (fscanf(fp, "%7s %511s %d %d %1023s %1023s", pool, name, &rn, &rev, seq, qual) == 6) {   /* get_read_length: the maximum */
+		int l = (int) strlen(seq);
+		if (l > rl) rl = l;
+		if (pool[0] == 'P') np++; else ns++;
+	}
+	if (rl <= 0) { fprintf(stderr, "Error retrieving read length from: %s\n", path); fclose(fp); return -1; }
+	rewind(fp);
+	memset(r, 0, sizeof *r);
+	r->rl = rl;
+	const size_t rec = 2 * (size_t) rl + 1;
+	r->n_primary = 2 * np;
+	r->n_secondary = 2 * ns;
+	const size_t R = r->n_primary + r->n_secondary;
+	r->primary = (uint8_t*) calloc(r->n_primary * rec + 1, 1);
+	r->secondary = (uint8_t*) calloc(r->n_secondary * rec + 1, 1);
+	r->pair_id = (uint32_t*) calloc(R + 1, 4);
+	r->reg_rank = (uint32_t*) calloc(R + 1, 4);
+	r->read_num = (uint8_t*) calloc(R + 1, 1);
+	r->is_rc = (uint8_t*) calloc(R + 1, 1);
+	r->names = (char**) calloc(np + ns + 1, sizeof(char*));
+	sph_table ids;                       /* read name -> pair id */
+	sph_init(&ids, 0, 0);
+	size_t ip = 0, is = 0;
+	uint32_t reg = 0;
+	while (fscanf(fp, "%7s %511s %d %d %1023s %1023s", pool, name, &rn, &rev, seq, qual) == 6) {
+		if ((int) strlen(seq) != rl || (int) strlen(qual) != rl) { fprintf(stderr, "read %s: length != %d\n", name, rl); fclose(fp); return -1; }
+		size_t b = sph_find(&ids, name);
+		uint32_t pid;
+		if (b == (size_t) -1) {
+			pid = r->n_pairs++;
+			r->names[pid] = strdup(name);
+			sph_map_put(&ids, r->names[pid], (void*) (uintptr_t) (pid + 1), NULL);
+		} else {
+			pid = (uint32_t) (uintptr_t) ids.b[b].val - 1;
+		}
+		const int isp = pool[0] == 'P';
+		uint8_t* base = isp ? r->primary + ip * rec : r->secondary + is * rec;
+		const size_t g = isp ? ip : r->n_primary + is;
+		base[0] = '0';
+		memcpy(base + 1, seq, (size_t) rl);
+		memcpy(base + 1 + rl, qual, (size_t) rl);
+		base[rec] = '0';
+		for (int i = 0; i < rl; i++) {
+			base[rec + 1 + i] = (uint8_t) comp(seq[rl - 1 - i]);
+			base[rec + 1 + rl + i] = (uint8_t) qual[rl - 1 - i];
+		}
+		for (int j = 0; j < 2; j++) {
+			r->pair_id[g + j] = pid;
+			r->read_num[g + j] = (uint8_t) rn;
+			r->is_rc[g + j] = (uint8_t) (j ? !rev : (rev != 0));     /* add_read_info(..., bam_is_rev) then (!bam_is_rev) */
+			r->reg_rank[g + j] = reg++;
+		}
+		if (isp) ip += 2; else is += 2;
+	}
+	fclose(fp);
+	sph_free(&ids);
+	return 0;
+}
+
+/* load_kmers, vj_filter.c:56-68 */
+static int load_codes(const char* path, int max_dist, uint32_t** out, size_t* n) {
+	FILE* in = fopen(path, "r");
+	if (!in) { fprintf(stderr, "cannot open %s\n", path); return -1; }
+	size_t cap = 1024, cnt = 0;
+	uint32_t* v = (uint32_t*) malloc(cap * 4);
+	unsigned long kmer;
+	int freq;
+	while (fscanf(in, "%lu\t%d\n", &kmer, &freq) == 2) {
+		if (freq <= max_dist) {
+			if (cnt == cap) { cap *= 2; v = (uint32_t*) realloc(v, cap * 4); }
+			v[cnt++] = (uint32_t) kmer;
+		}
+	}
+	fclose(in);
+	*out = v;
+	*n = cnt;
+	return 0;
+}
+
+static int cmp_u32(const void* a, const void* b) { uint32_t x = *(const uint32_t*) a, y = *(const uint32_t*) b; return x < y ? -1 : x > y; }
+
+/* score_seq_init's reader (seq_score.c:50-70): fgets chunks of 999,999 chars, header lines skipped */
+static int load_vregion(const char* path, char*** lines, size_t* n) {
+	FILE* fp = fopen(path, "r");
+	if (!fp) { fprintf(stderr, "cannot open %s\n", path); return -1; }
+	char* buf = (char*) malloc(1000000);
+	size_t cap = 4, cnt = 0;
+	char** v = (char**) malloc(cap * sizeof(char*));
+	while (fgets(buf, 1000000, fp) != NULL) {
+		if (buf[0] == '>') continue;
+		size_t l = strlen(buf);
+		if (l) buf[l - 1] = '\0';                        /* "Get rid of newline" */
+		if (cnt == cap) { cap *= 2; v = (char**) realloc(v, cap * sizeof(char*)); }
+		v[cnt++] = strdup(buf);
+	}
+	fclose(fp);
+	free(buf);
+	*lines = v;
+	*n = cnt;
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* hooks onto libvdjx                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { vdjx_ctx* gx; const reads_t* r; const vdjh_params* p; } hook_ud;
+
+static int h_root_score(void* ud, const char* kmers, size_t n, int k, int thr, uint8_t* out) {
+	hook_ud* u = (hook_ud*) ud;
+	int rc = vdjx_root_score(u->gx, kmers, n, k, thr, out);
+	if (rc) fprintf(stderr, "vdjx_root_score: %s\n", vdjx_last_error());
+	return rc;
+}
+
+static int h_window_score(void* ud, const char* windows, size_t n, int len, uint8_t* valid) {
+	hook_ud* u = (hook_ud*) ud;
+	const vdjh_params* p = u->p;
+	vdjx_cov_params cp = {p->eval_start, p->eval_stop, p->filter_read_span, p->filter_mate_span, p->insert_len, p->insert_len, p->read_filter_floor};
+	uint32_t* np = (uint32_t*) malloc((n + 1) * 4);
+	int rc = vdjx_window_score(u->gx, windows, n, len, &cp, valid, np);
+	if (rc) fprintf(stderr, "vdjx_window_score: %s\n", vdjx_last_error());
+	free(np);
+	return rc;
+}
+
+static const uint8_t* rec_ptr(const reads_t* r, uint32_t rec) {
+	const size_t sz = 2 * (size_t) r->rl + 1;
+	return rec < r->n_primary ? r->primary + rec * sz : r->secondary + (rec - r->n_primary) * sz;
+}
+
+/* output_mapping, quick_map3.c:152-181 */
+static int h_sam_body(void* ud, const char* const* ids, const char* contigs, size_t n, int len, FILE* out) {
+	hook_ud* u = (hook_ud*) ud;
+	const reads_t* r = u->r;
+	uint64_t* offs = (uint64_t*) calloc(n + 1, 8);
+	int rc = vdjx_map_emit(u->gx, contigs, n, len, offs, NULL);
+	vdjx_pair* pairs = NULL;
+	if (!rc) {
+		pairs = (vdjx_pair*) malloc((offs[n] + 1) * sizeof(vdjx_pair));
+		rc = vdjx_map_emit(u->gx, contigs, n, len, offs, pairs);
+	}
+	if (rc) { fprintf(stderr, "vdjx_map_emit: %s\n", vdjx_last_error()); free(offs); free(pairs); return rc; }
+	const int rl = r->rl;
+	for (size_t c = 0; c < n; c++) {
+		char cid[256];
+		strncpy(cid, ids[c], 255);
+		cid[255] = 0;
+		for (uint64_t i = offs[c]; i < offs[c + 1]; i++) {
+			const vdjx_pair* q = &pairs[i];
+			const char* name = r->names[q->pair_id];
+			if (name[0] == '@') name++;
+			const int flag1 = 0x1 | 0x2 | (q->rc1 ? 0x10 : 0x20) | 0x40;
+			const int flag2 = 0x1 | 0x2 | (q->rc2 ? 0x10 : 0x20) | 0x80;
+			const uint8_t* r1 = rec_ptr(r, q->rec1);
+			const uint8_t* r2 = rec_ptr(r, q->rec2);
+			fprintf(out, "%s\t%d\t%s\t%d\t255\t%dM\t=\t%d\t%d\t%.*s\t%.*s\n", name, flag1, cid, (int) q->pos1, rl, (int) q->pos2, (int) q->insert,
+			        rl, (const char*) r1 + 1, rl, (const char*) r1 + 1 + rl);
+			fprintf(out, "%s\t%d\t%s\t%d\t255\t%dM\t=\t%d\t%d\t%.*s\t%.*s\n", name, flag2, cid, (int) q->pos2, rl, (int) q->pos1, (int) q->insert,
+			        rl, (const char*) r2 + 1, rl, (const char*) r2 + 1 + rl);
+		}
+	}
+	free(offs);
+	free(pairs);
+	return 0;
+}
+
+#define VX(call) do { if ((call) != 0) { fprintf(stderr, "%s: %s\n", #call, vdjx_last_error()); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+	t_start = t_prev = time(NULL);
+	status("START");
+	cli c;
+	if (parse(argc, argv, &c)) return 255;                  /* the reference exits with -1 */
+	reads_t rd;
+	if (load_reads(c.in, &rd)) return 255;
+	c.hp.read_length = rd.rl;
+	fprintf(stderr, "read length:\t%d\n", rd.rl);
+
+	uint32_t *vc = NULL, *jc = NULL;
+	size_t nv = 0, nj = 0;
+	if (load_codes(c.v_anchors, c.anchor_mismatches, &vc, &nv) || load_codes(c.j_anchors, c.anchor_mismatches, &jc, &nj)) return 255;
+	qsort(vc, nv, 4, cmp_u32);
+	qsort(jc, nj, 4, cmp_u32);
+	char** vlines = NULL;
+	size_t nvl = 0;
+	if (load_vregion(c.source_sim_file, &vlines, &nvl)) return 255;
+
+	vdjx_ctx* gx = NULL;
+	VX(vdjx_init(0, &gx));
+	VX(vdjx_anchor_sets_load(gx, vc, nv, jc, nj));
+	VX(vdjx_vregion_load(gx, (const char* const*) vlines, nvl, c.hp.vregion_kmer_size));
+	status("POST_VJF_INIT");
+
+	vdjx_pool* px = NULL;
+	VX(vdjx_pool_load(gx, rd.primary, rd.n_primary, rd.secondary, rd.n_secondary, rd.rl, &px));
+	VX(vdjx_read_index_build(gx, px, rd.pair_id, rd.read_num, rd.is_rc, rd.reg_rank, rd.n_pairs));
+	status("POST_READ_EXTRACT");
+
+	fprintf(stderr, "Assembling...\n");
+	vdjx_graph* gg = NULL;
+	VX(vdjx_kmer_build(gx, px, c.hp.k, c.hp.min_node_freq, c.hp.min_base_quality, &gg));
+	const size_t n = vdjx_graph_nodes(gg);
+	fprintf(stderr, "Pre Num nodes: %zu\npre nodes after pruning: %zu\nNum nodes: %zu\n", vdjx_graph_pre_nodes(gg), n, n);
+	status("POST_BUILD_GRAPH2");
+	vdjh_graph hg;
+	memset(&hg, 0, sizeof hg);
+	hg.n = n;
+	hg.k = c.hp.k;
+	char* kmers = (char*) malloc(n * (size_t) c.hp.k + 1);
+	uint32_t* freq = (uint32_t*) malloc((n + 1) * 4);
+	uint8_t *hv = (uint8_t*) malloc(n + 1), *hj = (uint8_t*) malloc(n + 1), *td = (uint8_t*) malloc(n + 1), *fd = (uint8_t*) malloc(n + 1);
+	uint32_t *ti = (uint32_t*) malloc((n + 1) * 16), *fi = (uint32_t*) malloc((n + 1) * 16);
+	VX(vdjx_graph_export(gg, NULL, NULL, freq, hv, hj, td, ti, fd, fi, kmers));
+	hg.kmers = kmers; hg.freq = freq; hg.has_v = hv; hg.has_j = hj; hg.to_deg = td; hg.to_ids = ti; hg.from_deg = fd; hg.from_ids = fi;
+
+	hook_ud ud = {gx, &rd, &c.hp};
+	vdjh_hooks hk = {&ud, h_root_score, h_window_score, h_sam_body, vc, nv, jc, nj};
+	vdjh_stats st;
+	if (vdjh_assemble(&c.hp, &hg, &hk, "vdj_contigs.fa", "vdjer.dot", stdout, &st)) {
+		fprintf(stderr, "%s\n", vdjh_last_error());
+		return 1;
+	}
+	fprintf(stderr, "num root nodes: %zu\nProcessed roots: %zu\ncontig_candidates: %zu\nwindows scored: %zu valid: %zu\ncontigs: %zu\n",
+	        st.n_roots, st.n_roots_accepted, st.n_contig_candidates, st.n_windows_scored, st.n_windows_valid, st.n_contigs_out);
+	status("FINIS");
+	fflush(stdout);
+	vdjx_graph_free(gg);
+	vdjx_pool_free(px);
+	vdjx_shutdown(gx);
+	return 0;
+}

@@ -2,7 +2,7 @@
 //
 //   K7  k_seed_count / k_root_dp      root (V-region homology) scorer         seq_score.c:92-156
 //   K8  k_ri_insert + host CSR        read index                              quick_map3.c:126-149
-//       k_window_score                read->window mapper + coverage test     quick_map3.c:188-266, coverage.c:10-130
+//       k_window_pairs / k_window_cover  read->window mapper + coverage test  quick_map3.c:188-266, coverage.c:10-130
 //   K10 k_map_emit                    mapped pairs of final contigs in order  quick_map3.c:152-181, 311-340
 //
 // None of this is a dense contraction: the DP is a max-plus recurrence on int8 cells, the mapper is
@@ -359,7 +359,7 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 }
 
 // ==============================================================================================
-// a-8/a-9/a-10 mapper core shared by k_window_hits, k_window_score and k_map_emit
+// a-8/a-9/a-10 mapper core shared by k_window_hits, k_window_pairs and k_map_emit
 // ==============================================================================================
 #define MAP_THREADS 512
 #define MAP_MAXOFF 1024          // window/contig length - rl  <= MAP_MAXOFF
@@ -528,17 +528,38 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_hits(ReadIndexDev ix, co
 //    pairs (stored once in a scratch list) for every batch, prefixes, and tests.
 // ----------------------------------------------------------------------------------------------
 #define COV_WORDS 8192
-__global__ __launch_bounds__(MAP_THREADS) void k_window_score(ReadIndexDev ix, const char* __restrict__ windows, u32 n, int len,
-                                                              vdjx_cov_params cp, const u32* __restrict__ order,
+#define HIT_CHUNK 8192u          // hits per workgroup of k_window_pairs: deep windows are spread over many CUs
+
+// K8: mapped pairs of a slice of a window's hits, appended (any order) to the window's pair list
+__global__ __launch_bounds__(MAP_THREADS) void k_window_pairs(ReadIndexDev ix, const char* __restrict__ windows, int len,
+                                                              const uint4* __restrict__ work /* {window, h0, h1, -} */,
                                                               const u64* __restrict__ pair_off, u32* __restrict__ pair_buf,
-                                                              uint8_t* __restrict__ out_valid, u32* __restrict__ out_npairs) {
+                                                              u32* __restrict__ pair_cnt) {
 	__shared__ MapLds L;
+	const uint4 wk = work[blockIdx.x];
+	const u32 wi = wk.x;
+	const int noff = len - ix.rl;
+	const u32 H = map_prepare(L, ix, windows + (size_t) wi * len, len);
+	const u32 h1 = wk.z < H ? wk.z : H;
+	u32* pairs = pair_buf + pair_off[wi];
+	for (u32 h0 = wk.y; h0 < h1; h0 += MAP_THREADS) {
+		const u32 h = h0 + threadIdx.x;
+		Hit r;
+		r.pair = false;
+		if (h < h1) r = map_eval_hit(L, ix, noff, h);
+		const u32 slot = vdjx_wave_inc(&pair_cnt[wi], r.pair);
+		if (r.pair) pairs[slot] = ((u32) r.pos1 << 16) | (u32) r.pos2;
+	}
+}
+
+// K9: coverage verdict of a window from its pair list
+__global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, vdjx_cov_params cp, const u32* __restrict__ order,
+                                                              const u64* __restrict__ pair_off, const u32* __restrict__ pair_buf,
+                                                              const u32* __restrict__ pair_cnt, uint8_t* __restrict__ out_valid) {
 	__shared__ u32 hf[MAP_MAXOFF + 64 + 2];         // histogram of firsts -> inclusive prefix "cum"
 	__shared__ int diff[COV_WORDS];
-	__shared__ u32 s_np, s_bad, s_ok;
+	__shared__ u32 s_bad, s_ok;
 	const u32 tid = threadIdx.x;
-	const int rl = ix.rl;
-	const int noff = len - rl;
 	const int D = len + 1;
 	const int e0 = cp.eval_start, e1 = cp.eval_stop, fl = cp.floor;
 	const int gap = rl - cp.read_span;
@@ -547,128 +568,112 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_score(ReadIndexDev ix, c
 	const int npos = e1 - e0;                        // positions e0 .. e1-1
 	const int stride = npos + 1;
 	const int DB = COV_WORDS / stride;               // deltas per batch (host guarantees >= 1)
-	for (u32 bi = blockIdx.x; bi < n; bi += gridDim.x) {
-		const u32 wi = order[bi];
-		const char* w = windows + (size_t) wi * len;
-		u32* pairs = pair_buf + pair_off[wi];
-		const u32 H = map_prepare(L, ix, w, len);
-		for (u32 i = tid; i < (u32) D + 1; i += MAP_THREADS) hf[i] = 0;
-		if (tid == 0) { s_np = 0; s_bad = 0; }
-		__syncthreads();
-		for (u32 h0 = 0; h0 < H; h0 += MAP_THREADS) {
-			const u32 h = h0 + tid;
-			Hit r;
-			r.pair = false;
-			if (h < H) r = map_eval_hit(L, ix, noff, h);
-			const u32 slot = vdjx_wave_inc(&s_np, r.pair);
-			if (r.pair) {
-				pairs[slot] = ((u32) r.pos1 << 16) | (u32) r.pos2;
-				atomicAdd(&hf[r.pos1], 1u);
-				atomicAdd(&hf[r.pos2], 1u);
-			}
+	const u32 wi = order[blockIdx.x];
+	const u32* pairs = pair_buf + pair_off[wi];
+	const u32 npairs = pair_cnt[wi];
+	if (fl == 0) { if (tid == 0) out_valid[wi] = 1; return; }
+	for (u32 i = tid; i < (u32) D + 1; i += MAP_THREADS) hf[i] = 0;
+	if (tid == 0) { s_bad = 0; s_ok = 0; }
+	__syncthreads();
+	for (u32 q = tid; q < npairs; q += MAP_THREADS) {
+		const u32 pr = pairs[q];
+		atomicAdd(&hf[pr >> 16], 1u);
+		atomicAdd(&hf[pr & 0xFFFFu], 1u);
+	}
+	__syncthreads();
+	// ---- rule 1
+	if (tid == 0) {
+		u32 run = 0;
+		for (int p = 0; p < D; p++) { run += hf[p]; hf[p] = run; }
+		const int n_ent = (int) hf[D - 1];
+		bool ok = true;
+		auto cum = [&](int p) -> int { return p < 0 ? 0 : (p >= D ? n_ent : (int) hf[p]); };
+		auto value_at = [&](int idx) -> int {       // idx-th smallest first (0-based): smallest p with cum[p] > idx
+			int lo2 = 0, hi2 = D - 1;
+			while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (cum(mid) > idx) hi2 = mid; else lo2 = mid + 1; }
+			return lo2;
+		};
+		const int vmax = e1 - cp.read_span + 1;
+		bool first_seen = false;
+		for (int v = e0 > 1 ? e0 : 1; v <= vmax && v < D && ok; v++) {
+			if (cum(v) == cum(v - 1)) continue;
+			const int i0 = cum(v - 1);                            // smallest index holding value v
+			if (i0 < fl) { ok = false; break; }                   // coverage.c:80-84
+			if (!first_seen) { first_seen = true; if (v > e0 + gap) { ok = false; break; } }   // :86-93
+			if (cum(v - gap - 1) > i0 - fl) { ok = false; break; }                              // :96-100
 		}
-		__threadfence_block();
+		int i_fin = cum(vmax);
+		if (i_fin >= n_ent) i_fin = n_ent - 1;                    // :106-108
+		if (ok && n_ent > 0) {
+			const int v_fin = value_at(i_fin);
+			if (i_fin > fl && value_at(i_fin - fl) < v_fin - gap) ok = false;   // :111-113
+			if (!(i_fin > 0 && v_fin > e1 - rl)) ok = false;                   // :116-120
+		} else {
+			ok = false;
+		}
+		if (!ok) s_bad = 1;
+	}
+	__syncthreads();
+	// ---- rule 2.  Coverage only grows with more entries, so the pair list is replayed in doubling chunks and
+	// a batch of deltas is done as soon as every tested (pos, delta) already reaches the floor.
+	for (int d0 = clo; d0 < chi && !s_bad; d0 += DB) {
+		const int nd = chi - d0 < DB ? chi - d0 : DB;
+		for (int i = tid; i < nd * stride; i += MAP_THREADS) diff[i] = 0;
 		__syncthreads();
-		const u32 npairs = s_np;
-		uint8_t valid = 1;
-		if (fl != 0) {
-			// ---- rule 1
-			if (tid == 0) {
-				u32 run = 0;
-				for (int p = 0; p < D; p++) { run += hf[p]; hf[p] = run; }
-				const int n_ent = (int) hf[D - 1];
+		u32 done = 0, chunk = 4096;
+		for (;;) {
+			const u32 end = done + chunk < 2 * npairs ? done + chunk : 2 * npairs;
+			for (u32 q = done + tid; q < end; q += MAP_THREADS) {
+				const u32 pr = pairs[q >> 1];
+				const int p1 = (int) (pr >> 16), p2 = (int) (pr & 0xFFFFu);
+				const int f = (q & 1) ? p2 : p1, sx = (q & 1) ? p1 : p2;
+				// deltas of this batch with |f - (sx - delta)| < rl
+				int dlo = sx - f - rl + 1, dhi = sx - f + rl - 1;
+				if (dlo < d0) dlo = d0;
+				if (dhi > d0 + nd - 1) dhi = d0 + nd - 1;
+				for (int dl = dlo; dl <= dhi; dl++) {
+					const int v = sx - dl;
+					int lo = f > v ? f : v;                       // first pos that sees both
+					int hi = (f < v ? f : v) + rl;                // one past the last
+					if (lo < e0) lo = e0;
+					if (hi > e1) hi = e1;
+					if (lo < hi) {
+						atomicAdd(&diff[(dl - d0) * stride + (lo - e0)], 1);
+						atomicAdd(&diff[(dl - d0) * stride + (hi - e0)], -1);
+					}
+				}
+			}
+			if (tid == 0) s_ok = 1;
+			__syncthreads();
+			if ((int) tid < nd) {
+				const int dl = d0 + (int) tid;
+				const int* row = diff + tid * stride;
+				int run = 0;
 				bool ok = true;
-				auto cum = [&](int p) -> int { return p < 0 ? 0 : (p >= D ? n_ent : (int) hf[p]); };
-				auto value_at = [&](int idx) -> int {       // idx-th smallest first (0-based): smallest p with cum[p] > idx
-					int lo2 = 0, hi2 = D - 1;
-					while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (cum(mid) > idx) hi2 = mid; else lo2 = mid + 1; }
-					return lo2;
-				};
-				const int vmax = e1 - cp.read_span + 1;
-				bool first_seen = false;
-				for (int v = e0 > 1 ? e0 : 1; v <= vmax && v < D && ok; v++) {
-					if (cum(v) == cum(v - 1)) continue;
-					const int i0 = cum(v - 1);                            // smallest index holding value v
-					if (i0 < fl) { ok = false; break; }                   // coverage.c:80-84
-					if (!first_seen) { first_seen = true; if (v > e0 + gap) { ok = false; break; } }   // :86-93
-					if (cum(v - gap - 1) > i0 - fl) { ok = false; break; }                              // :96-100
+				for (int p = 0; p < npos; p++) {
+					run += row[p];
+					const int pos = e0 + p;
+					if (pos != e0 && (pos - 1 + clo) >= e1) break;       // the loop tests the previous mate_low (coverage.c:25)
+					int mh = pos + chi;
+					if (mh > e1) mh = e1 + 1;                             // coverage.c:36-38
+					const int j = pos + dl;
+					if (j >= mh) continue;
+					if (j < 0 || j > len + 1023) { s_bad = 1; break; }    // outside the reference's array: undefined there
+					if (run < fl) ok = false;
 				}
-				int i_fin = cum(vmax);
-				if (i_fin >= n_ent) i_fin = n_ent - 1;                    // :106-108
-				if (ok && n_ent > 0) {
-					const int v_fin = value_at(i_fin);
-					if (i_fin > fl && value_at(i_fin - fl) < v_fin - gap) ok = false;   // :111-113
-					if (!(i_fin > 0 && v_fin > e1 - rl)) ok = false;                   // :116-120
-				} else {
-					ok = false;
-				}
-				if (!ok) s_bad = 1;
+				if (!ok) s_ok = 0;
 			}
 			__syncthreads();
-			// ---- rule 2.  Coverage only grows with more entries, so the pair list is replayed in doubling chunks and
-			// a batch of deltas is done as soon as every tested (pos, delta) already reaches the floor.
-			for (int d0 = clo; d0 < chi && !s_bad; d0 += DB) {
-				const int nd = chi - d0 < DB ? chi - d0 : DB;
-				for (int i = tid; i < nd * stride; i += MAP_THREADS) diff[i] = 0;
-				__syncthreads();
-				u32 done = 0, chunk = 4096;
-				for (;;) {
-					const u32 end = done + chunk < 2 * npairs ? done + chunk : 2 * npairs;
-					for (u32 q = done + tid; q < end; q += MAP_THREADS) {
-						const u32 pr = pairs[q >> 1];
-						const int p1 = (int) (pr >> 16), p2 = (int) (pr & 0xFFFFu);
-						const int f = (q & 1) ? p2 : p1, sx = (q & 1) ? p1 : p2;
-						// deltas of this batch with |f - (sx - delta)| < rl
-						int dlo = sx - f - rl + 1, dhi = sx - f + rl - 1;
-						if (dlo < d0) dlo = d0;
-						if (dhi > d0 + nd - 1) dhi = d0 + nd - 1;
-						for (int dl = dlo; dl <= dhi; dl++) {
-							const int v = sx - dl;
-							int lo = f > v ? f : v;                       // first pos that sees both
-							int hi = (f < v ? f : v) + rl;                // one past the last
-							if (lo < e0) lo = e0;
-							if (hi > e1) hi = e1;
-							if (lo < hi) {
-								atomicAdd(&diff[(dl - d0) * stride + (lo - e0)], 1);
-								atomicAdd(&diff[(dl - d0) * stride + (hi - e0)], -1);
-							}
-						}
-					}
-					if (tid == 0) s_ok = 1;
-					__syncthreads();
-					if ((int) tid < nd) {
-						const int dl = d0 + (int) tid;
-						const int* row = diff + tid * stride;
-						int run = 0;
-						bool ok = true;
-						for (int p = 0; p < npos; p++) {
-							run += row[p];
-							const int pos = e0 + p;
-							if (pos != e0 && (pos - 1 + clo) >= e1) break;       // the loop tests the previous mate_low (coverage.c:25)
-							int mh = pos + chi;
-							if (mh > e1) mh = e1 + 1;                             // coverage.c:36-38
-							const int j = pos + dl;
-							if (j >= mh) continue;
-							if (j < 0 || j > len + 1023) { s_bad = 1; break; }    // outside the reference's array: undefined there
-							if (run < fl) ok = false;
-						}
-						if (!ok) s_ok = 0;
-					}
-					__syncthreads();
-					done = end;
-					if (s_ok || s_bad || done >= 2 * npairs) break;
-					chunk *= 2;
-					__syncthreads();
-				}
-				if (!s_ok) s_bad = 1;          // every entry counted and some (pos, delta) is still short
-				__syncthreads();
-			}
+			done = end;
+			if (s_ok || s_bad || done >= 2 * npairs) break;
+			chunk *= 2;
 			__syncthreads();
-			valid = s_bad ? 0 : 1;
 		}
-		if (tid == 0) { out_valid[wi] = valid; out_npairs[wi] = npairs; }
+		if (!s_ok) s_bad = 1;          // every entry counted and some (pos, delta) is still short
 		__syncthreads();
 	}
+	__syncthreads();
+	if (tid == 0) out_valid[wi] = s_bad ? 0 : 1;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -796,9 +801,31 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	rc = plan_windows(c, db, ix, d_w, n, len, off, &d_order, &d_off);
 	if (rc) return rc;
 	HIP_TRY(db.alloc(&d_pairbuf, (size_t) off[n]));
+	// work list: deep windows are cut into slices of HIT_CHUNK hits (largest windows first)
+	std::vector<uint4> work;
 	{
-		vdjx_prof_scope ps(c, "k_window_score");
-		hipLaunchKernelGGL(k_window_score, dim3((u32) n), dim3(MAP_THREADS), 0, st, ix, d_w, (u32) n, len, *p, d_order, d_off, d_pairbuf, d_valid, d_np);
+		std::vector<u32> ord(n);
+		std::iota(ord.begin(), ord.end(), 0u);
+		std::stable_sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+		for (u32 wi : ord) {
+			const u32 H = (u32) (off[wi + 1] - off[wi]);
+			for (u32 h0 = 0; h0 < H || h0 == 0; h0 += HIT_CHUNK) {
+				work.push_back(make_uint4(wi, h0, std::min(H, h0 + HIT_CHUNK), 0));
+				if (H == 0) break;
+			}
+		}
+	}
+	uint4* d_work;
+	HIP_TRY(db.alloc(&d_work, work.size()));
+	HIP_TRY(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(uint4), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemsetAsync(d_np, 0, n * 4, st));
+	{
+		vdjx_prof_scope ps(c, "k_window_pairs");
+		hipLaunchKernelGGL(k_window_pairs, dim3((u32) work.size()), dim3(MAP_THREADS), 0, st, ix, d_w, len, d_work, d_off, d_pairbuf, d_np);
+	}
+	{
+		vdjx_prof_scope ps(c, "k_window_cover");
+		hipLaunchKernelGGL(k_window_cover, dim3((u32) n), dim3(MAP_THREADS), 0, st, len, ix.rl, *p, d_order, d_off, d_pairbuf, d_np, d_valid);
 	}
 	HIP_TRY(hipMemcpyAsync(out_valid, d_valid, n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
