@@ -59,6 +59,8 @@ class Pool:
         if self.h:
             _lib.lib().vdjx_pool_free(self.h)
             self.h = None
+            if self in getattr(self.ctx, "_pools", []):
+                self.ctx._pools.remove(self)
 
     def __del__(self):
         try:
@@ -74,8 +76,12 @@ class Context:
         check(self.L.vdjx_init(device, C.byref(h)), "vdjx_init")
         self.h = h
         self.device = device
+        self._pools = []
 
     def close(self):
+        for p in list(getattr(self, "_pools", [])):
+            p.free()
+        self._pools = []
         if getattr(self, "h", None):
             self.L.vdjx_shutdown(self.h)
             self.h = None
@@ -95,14 +101,18 @@ class Context:
         sec = _c(secondary, np.uint8).reshape(-1, 2 * rl + 1)
         h = C.c_void_p()
         check(self.L.vdjx_pool_load(self.h, _p(pri), pri.shape[0], _p(sec), sec.shape[0], rl, C.byref(h)), "vdjx_pool_load")
-        return Pool(self, h, rl, pri.shape[0] + sec.shape[0])
+        p = Pool(self, h, rl, pri.shape[0] + sec.shape[0])
+        self._pools.append(p)
+        return p
 
     def pool_load_device(self, d_primary: int, n_primary: int, d_secondary: int, n_secondary: int, rl: int) -> Pool:
         """ASCII pools already resident in device memory (raw device pointers, 16-byte aligned)."""
         h = C.c_void_p()
         check(self.L.vdjx_pool_load_device(self.h, C.c_void_p(d_primary), n_primary, C.c_void_p(d_secondary), n_secondary,
                                            rl, C.byref(h)), "vdjx_pool_load_device")
-        return Pool(self, h, rl, n_primary + n_secondary)
+        p = Pool(self, h, rl, n_primary + n_secondary)
+        self._pools.append(p)
+        return p
 
     # ---- a-6
     def anchor_sets_load(self, v_codes, j_codes) -> None:

@@ -60,6 +60,7 @@ static int load_set(vdjx_ctx* c, const u32* codes, size_t n, u32** d_bits) {
 extern "C" int vdjx_anchor_sets_load(vdjx_ctx* c, const uint32_t* v_codes, size_t nv, const uint32_t* j_codes, size_t nj) {
 	if (!c || (nv && !v_codes) || (nj && !j_codes)) { vdjx_set_error("vdjx_anchor_sets_load: NULL argument"); return VDJX_EINVAL; }
 	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
 	int rc = load_set(c, v_codes, nv, &c->d_vbits);
 	if (rc) return rc;
 	rc = load_set(c, j_codes, nj, &c->d_jbits);
@@ -75,6 +76,7 @@ extern "C" int vdjx_anchor_probe(vdjx_ctx* c, const char* contig, int len, uint8
 	int n = len - 16;
 	if (n <= 0) return VDJX_OK;
 	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
 	char* d_c = nullptr;
 	uint8_t* d_o = nullptr;
 	u32* d_bad = nullptr;

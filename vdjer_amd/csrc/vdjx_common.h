@@ -20,6 +20,8 @@ typedef unsigned __int128 u128;
 // error plumbing
 // ----------------------------------------------------------------------------------------------
 void vdjx_set_error(const char* fmt, ...);
+// drop a stale error left in the runtime's per-thread slot by an earlier, unrelated call
+inline void vdjx_clear_errors() { (void) hipGetLastError(); }
 
 #define HIP_TRY(expr)                                                                            \
 	do {                                                                                         \
@@ -97,6 +99,7 @@ struct vdjx_ctx {
 
 struct vdjx_pool {
 	vdjx_ctx* ctx = nullptr;
+	int device = 0;              // copy: a pool may be freed after its context
 	size_t n_primary = 0, n_records = 0;
 	int rl = 0;
 	int qstride = 0;

@@ -214,7 +214,8 @@ static int pool_pack_device(vdjx_ctx* c, const uint8_t* d_primary, size_t n_prim
 	if (R >= (1ull << 31)) { vdjx_set_error("too many records for one GPU: %zu", R); return VDJX_ELIMIT; }
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_pool* p = new vdjx_pool();
-	p->ctx = c; p->n_primary = n_primary; p->n_records = R; p->rl = rl;
+	p->ctx = c; p->device = c->device; p->n_primary = n_primary; p->n_records = R; p->rl = rl;
+	vdjx_clear_errors();
 	p->qstride = (rl + 15) / 16 * 16;
 	size_t Ra = R ? R : 1;
 	u32* d_bad = nullptr;
@@ -287,7 +288,7 @@ extern "C" size_t vdjx_pool_records(const vdjx_pool* p) { return p ? p->n_record
 
 extern "C" void vdjx_pool_free(vdjx_pool* p) {
 	if (!p) return;
-	(void) hipSetDevice(p->ctx->device);
+	(void) hipSetDevice(p->device);
 	free_dev(p->d_bases); free_dev(p->d_nmask); free_dev(p->d_lowq); free_dev(p->d_quals);
 	delete p;
 }

@@ -1107,6 +1107,7 @@ extern "C" int vdjx_kmer_build(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf
 	if (NI >= (1ull << 31)) { vdjx_set_error("records*offsets = %zu >= 2^31: shard the pool over more GPUs", NI); return VDJX_ELIMIT; }
 	if (k > 16 && !c->anchors_loaded) { vdjx_set_error("vdjx_kmer_build: call vdjx_anchor_sets_load first (k > 16)"); return VDJX_ESTATE; }
 	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
 	vdjx_graph* g = new vdjx_graph();
 	int rc = key_hi_is_u32(k) ? kmer_build_impl<u32>(c, pool, k, mf, mq, g) : kmer_build_impl<u64>(c, pool, k, mf, mq, g);
 	if (rc != VDJX_OK) { delete g; return rc; }
@@ -1173,6 +1174,7 @@ extern "C" int vdjx_shard_pool_export(vdjx_shard* s, void* d_bases, void* d_nmas
 	const vdjx_pool* p = s->pool;
 	hipStream_t st = s->c->stream;
 	HIP_TRY(hipSetDevice(s->c->device));
+	vdjx_clear_errors();
 	HIP_TRY(hipMemcpyAsync(d_bases, p->d_bases, p->n_records * 16, hipMemcpyDeviceToDevice, st));
 	HIP_TRY(hipMemcpyAsync(d_nmask, p->d_nmask, p->n_records * 8, hipMemcpyDeviceToDevice, st));
 	HIP_TRY(hipMemcpyAsync(d_quals, p->d_quals, p->n_records * (size_t) p->qstride, hipMemcpyDeviceToDevice, st));
@@ -1192,6 +1194,7 @@ extern "C" int vdjx_shard_partition_count(vdjx_shard* s, uint64_t* send_counts) 
 	if (!s || !send_counts) { vdjx_set_error("vdjx_shard_partition_count: NULL argument"); return VDJX_EINVAL; }
 	vdjx_ctx* c = s->c;
 	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
 	PersistAlloc db(c);
 	int rc = stage_partition_count(c, db, s->pool, s->k, s->nb_bits, &s->pp, &s->N_local);
 	if (rc) return rc;
@@ -1209,6 +1212,7 @@ extern "C" int vdjx_shard_partition_fill(vdjx_shard* s, void* d_lo, void* d_hi, 
 	if (s->N_local && (!d_lo || !d_hi || !d_inst)) { vdjx_set_error("vdjx_shard_partition_fill: NULL buffer"); return VDJX_EINVAL; }
 	vdjx_ctx* c = s->c;
 	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
 	const u32 rec_base = s->rec_stride * (u32) s->rank;
 	PersistAlloc db(c);
 	int rc = s->hi64 ? stage_partition_fill<u64>(c, db, s->pool, rec_base, s->k, s->pp, s->N_local, (u64*) d_lo, (u64*) d_hi, (u32*) d_inst)
@@ -1237,6 +1241,7 @@ extern "C" int vdjx_shard_reduce(vdjx_shard* s, const void* d_lo, const void* d_
 	if (!s->gpool.bases) { vdjx_set_error("vdjx_shard_reduce: call vdjx_shard_set_pool first"); return VDJX_ESTATE; }
 	if (n_recv >= (1ull << 31)) { vdjx_set_error("vdjx_shard_reduce: too many tuples"); return VDJX_ELIMIT; }
 	HIP_TRY(hipSetDevice(s->c->device));
+	vdjx_clear_errors();
 	int rc = s->hi64 ? shard_reduce_impl<u64>(s, d_lo, d_hi, d_inst, n_recv) : shard_reduce_impl<u32>(s, d_lo, d_hi, d_inst, n_recv);
 	if (rc) return rc;
 	*n_survivors = s->local_sv.n;
@@ -1252,6 +1257,7 @@ extern "C" int vdjx_shard_survivors(vdjx_shard* s, void* d_out) {
 	if (!v.n) return VDJX_OK;
 	if (!d_out) { vdjx_set_error("vdjx_shard_survivors: NULL buffer"); return VDJX_EINVAL; }
 	HIP_TRY(hipSetDevice(s->c->device));
+	vdjx_clear_errors();
 	hipLaunchKernelGGL(k_surv_pack, dim3((v.n + 255) / 256), dim3(256), 0, s->c->stream, v.lo, v.hi, v.gcnt, v.gfirst, v.ucnt, v.ufirst, v.n, (SurvRec*) d_out);
 	HIP_TRY(hipStreamSynchronize(s->c->stream));
 	HIP_TRY(hipGetLastError());
@@ -1264,6 +1270,7 @@ extern "C" int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t 
 	if (ns_total >= (1ull << 30)) { vdjx_set_error("vdjx_shard_edges: too many survivors"); return VDJX_ELIMIT; }
 	vdjx_ctx* c = s->c;
 	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
 	PersistAlloc db(c);
 	Survivors& a = s->all_sv;
 	a.n = (u32) ns_total;
@@ -1287,6 +1294,7 @@ extern "C" int vdjx_shard_finish(vdjx_shard* s, const void* d_edge_first, const 
 	*out = nullptr;
 	vdjx_ctx* c = s->c;
 	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
 	PersistAlloc db(c);
 	const int P = s->pool->rl - s->k + 1;
 	const size_t NI = (size_t) s->rec_stride * s->nranks * (size_t) P;

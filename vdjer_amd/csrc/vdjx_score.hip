@@ -36,6 +36,7 @@ extern "C" int vdjx_vregion_load(vdjx_ctx* c, const char* const* lines, size_t n
 	if (!c || (n_lines && !lines)) { vdjx_set_error("vdjx_vregion_load: NULL argument"); return VDJX_EINVAL; }
 	if (vk < 2 || vk > 16) { vdjx_set_error("vregion k-mer size %d outside [2,16]", vk); return VDJX_ELIMIT; }
 	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
 	free_set(c->d_vtext); free_set(c->d_line_off); free_set(c->d_seed_code); free_set(c->d_seed_pos);
 	std::vector<u32> off(n_lines + 1, 0);
 	std::string text;
@@ -181,6 +182,7 @@ extern "C" int vdjx_root_score(vdjx_ctx* c, const char* kmers, size_t n, int k, 
 	if (stop <= 0 || c->n_seeds == 0) return VDJX_OK;          // no seed can hit: score_seq returns 0
 	if (n * (size_t) stop >= (1ull << 31)) { vdjx_set_error("too many roots in one call"); return VDJX_ELIMIT; }
 	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
 	hipStream_t st = c->stream;
 	vdjx_work db(c);
 	char* d_k;
@@ -258,6 +260,7 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 	if (!c || !pool || !pair_id || !read_num || !is_rc || !reg_rank) { vdjx_set_error("vdjx_read_index_build: NULL argument"); return VDJX_EINVAL; }
 	if (pool->ctx != c) { vdjx_set_error("vdjx_read_index_build: pool belongs to another context"); return VDJX_EINVAL; }
 	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
 	hipStream_t st = c->stream;
 	const u32 R = (u32) pool->n_records;
 	free_set(c->d_ri_slots); free_set(c->d_ri_rep); free_set(c->d_ri_start); free_set(c->d_ri_recs);
@@ -787,6 +790,7 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	if (p->eval_stop - p->eval_start + 1 > COV_WORDS) { vdjx_set_error("vdjx_window_score: eval range too long"); return VDJX_ELIMIT; }
 	if (n >= (1ull << 31)) { vdjx_set_error("vdjx_window_score: too many windows"); return VDJX_ELIMIT; }
 	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
 	hipStream_t st = c->stream;
 	vdjx_work db(c);
 	char* d_w;
@@ -847,6 +851,7 @@ extern "C" int vdjx_map_emit(vdjx_ctx* c, const char* contigs, size_t n, int len
 	int rc = make_index_view(c, &ix, len, "vdjx_map_emit");
 	if (rc) return rc;
 	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
 	hipStream_t st = c->stream;
 	vdjx_work db(c);
 	// the mapping runs once: the counting call keeps its pairs on the device for the writing call
