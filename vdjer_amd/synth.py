@@ -162,7 +162,7 @@ class ReadPool:
         return [f"r{i}" for i in range(self.n_pairs)]
 
     def write_reads_file(self, path: str) -> None:
-        """Text reads file for oracle/_ref/vdjer_ref (one read per line, registration order)."""
+        """Extracted-reads text file (one read per line, registration order): the --in format of vdjer_amd/vdjer."""
         rl = self.rl
         allrec = np.concatenate([self.primary, self.secondary], axis=0)
         npri = self.primary.shape[0]
