@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--seed", type=int, default=20261002)
     ap.add_argument("--cpu-sample", type=int, default=500_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--windows", choices=["traversal", "generator"], default="traversal",
+                    help="scorer inputs: the candidate windows/contigs the host traversal derives from the graph (default), "
+                         "or one window per clone straight from the generator")
     ap.add_argument("--parity-sample", type=int, default=20000, help="records of the 1 %% parity gate (SURVEY §8d)")
     args = ap.parse_args()
 
@@ -167,7 +170,36 @@ def main():
         p_index = ctx.pool_load_device(0, 0, allrec.data_ptr(), allrec.shape[0], rl)
         ctx.read_index_build(p_index, g_pair, g_rnum, g_rc, g_rank, args.pairs * world)
         del allrec, mine
+    scorer_src = "one window per clone from the generator"
+    if args.windows == "traversal":
+        # the windows the reference would hand to quick_map/coverage for THIS pool: run the serial host stage once,
+        # outside the timed region, and keep what it asked the scorers (identical on every rank)
+        import tempfile
+        from vdjer_amd import host
+        p0 = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
+        g0 = engine.kmer_build(p0, args.k, args.mf, args.mq) if engine else ctx.kmer_build(p0, args.k, args.mf, args.mq)
+        p0.free()
+        prm = host.make_params("IGH", ins=args.ins, k=args.k, mf=args.mf, mq=args.mq, mrs=args.mrs, rl=rl)
+        rs_fn, ws_fn, _ = host.gpu_hooks(ctx, None, None, prm)
+        asked = []
+
+        def ws_capture(w):
+            asked.extend(w)
+            return ws_fn(w)
+        with tempfile.TemporaryDirectory() as td:
+            t_tr = time.perf_counter()
+            st_tr = host.assemble(prm, g0, rs_fn, ws_capture, None, vc, jc, os.path.join(td, "c.fa"), None, None)
+            t_tr = time.perf_counter() - t_tr
+            fa = open(os.path.join(td, "c.fa")).read().split("\n")
+        wins = asked
+        contigs_fixed = [fa[i] for i in range(1, len(fa), 2)]
+        scorer_src = (f"host traversal of this pool's graph ({t_tr:.1f}s serial, untimed): {st_tr['n_contig_candidates']} contig candidates "
+                      f"-> {len(wins)} distinct windows, {len(contigs_fixed)} final contigs")
+        del g0
+    else:
+        contigs_fixed = None
     my_wins = wins[rank::world]
+    my_contigs = contigs_fixed[rank::world] if contigs_fixed is not None else None
 
     def gather_bytes(a):
         """all_gather of a small uint8 vector whose length differs per rank"""
@@ -197,7 +229,7 @@ def main():
         t = lap("root_score", t)
         valid, npairs = ctx.window_score(my_wins, args.ins)
         t = lap("window_score", t)
-        contigs = [w[51:411] for w, v in zip(my_wins, valid) if v]
+        contigs = my_contigs if my_contigs is not None else [w[51:411] for w, v in zip(my_wins, valid) if v]
         offs, pairs = ctx.map_emit(contigs)
         t = lap("map_emit", t)
         if world > 1:      # every rank learns every verdict (a few KB)
@@ -205,7 +237,8 @@ def main():
             valid = np.concatenate(gather_bytes(valid))
             t = lap("gather_results", t)
         state.update(nodes=g.n, pre=g.pre_nodes, roots=int(roots.shape[0]), roots_ok=int(ok.sum()), windows=len(wins),
-                     valid=int(valid.sum()), mapped_this_rank=int(pairs.shape[0]), graph=g)
+                     valid=int(valid.sum()), contigs=len(contigs) if world == 1 else None, mapped_this_rank=int(pairs.shape[0]),
+                     window_pairs_this_rank=int(npairs.sum()), graph=g)
         p.free()
 
     def barrier():
@@ -279,7 +312,8 @@ def main():
         "dtype": "u8/u64 (2-bit packed bases, integer counts)", "data": "synthetic",
         "config": {"workload": f"synthetic {args.pairs} 50bp PE pairs per GPU, IGH, k={args.k} mf={args.mf} mq={args.mq} "
                                f"ins={args.ins} (BASELINE.json configs[1]; SURVEY §8d C2)",
-                   "pairs_per_gpu": args.pairs, "clones": args.clones, "noise": 0.3, "parallelism": f"hash-prefix x{world}"},
+                   "pairs_per_gpu": args.pairs, "clones": args.clones, "noise": 0.3, "parallelism": f"hash-prefix x{world}",
+                   "scorer_inputs": scorer_src},
         "roofline": roof, "cpu_baseline": cpu,
         "kernels_ms_per_step": {k_: round(v[0] / args.steps, 4) for k_, v in prof.items()},
         "exchange_bytes_per_step_rank0": (engine.bytes_exchanged // (args.steps + args.warmup)) if engine else 0,
