@@ -37,8 +37,19 @@ def algorithmic_bytes_per_pair(k: int, rl: int = 50) -> dict:
     P = 4 * (rl - k + 1)
     inp = 2 * ((rl + 3) // 4 + rl)
     return {"P": P, "input": inp, "total": inp + 32 * P + inp + 16 * P,
-            "k_pool_pack": 4 * (2 * rl + 1), "k_kmer_hist": inp, "k_kmer_scatter": inp + 16 * P,
+            "k_pool_pack": 4 * (2 * rl + 1), "k_kmer_hist": inp, "k_part_records": inp + 16 * P, "k_part_tuples": 32 * P,
             "k_bucket_aggregate": 16 * P, "k_bucket_finalize": 16 * P, "k_graph_edges": inp + 16 * P}
+
+
+def scorer_bytes(stats: dict, n_windows: int, n_contigs: int, k: int, rl: int = 50, wlen: int = 486, clen: int = 360) -> dict:
+    """SURVEY §8d, scorers (not proportional to pairs): per window (len-rl) probes x 32 B + 8 B per matched read
+    instance; 8 B per emitted start entry; per contig (len-rl) probes x 32 B + 8 B per instance + one 20-B pair
+    record out; per (root, seed hit) k + 2k bytes."""
+    return {"k_window_hits": n_windows * (wlen - rl) * 32,
+            "k_window_pairs": n_windows * (wlen - rl) * 32 + 8 * stats.get("window_hits", 0),
+            "k_window_cover": 8 * 2 * stats.get("window_pairs", 0),
+            "k_map_emit": n_contigs * (clen - rl) * 32 + 8 * stats.get("map_hits", 0),
+            "k_root_dp": 3 * k * stats.get("root_dp_items", 0)}
 
 
 def make_workload(n_pairs: int, n_clones: int, seed: int, rank: int):
@@ -238,7 +249,7 @@ def main():
             t = lap("gather_results", t)
         state.update(nodes=g.n, pre=g.pre_nodes, roots=int(roots.shape[0]), roots_ok=int(ok.sum()), windows=len(wins),
                      valid=int(valid.sum()), contigs=len(contigs) if world == 1 else None, mapped_this_rank=int(pairs.shape[0]),
-                     window_pairs_this_rank=int(npairs.sum()), graph=g)
+                     window_pairs_this_rank=int(npairs.sum()), n_contigs_rank=len(contigs), graph=g)
         p.free()
 
     def barrier():
@@ -260,6 +271,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = ctx.profile_get()
     ctx.profile(False)
+    stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_pairs", "window_work_items", "map_hits", "root_dp_items")}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         cm.all_reduce(tt, dist.ReduceOp.MAX)
@@ -295,12 +307,24 @@ def main():
     if dom[0]:
         avg_ms = dom[1][0] / max(1, dom[1][1])
         launches_per_step = dom[1][1] / args.steps
-        per_pair = ab.get(dom[0], ab["total"])
-        bytes_per_launch = per_pair * args.pairs / max(1.0, launches_per_step)
+        sb = scorer_bytes(stats, len(my_wins), state.get("n_contigs_rank", 0), args.k, rl)
+        if dom[0] in sb:
+            bytes_per_launch = sb[dom[0]] / max(1.0, launches_per_step)
+            per_pair = None
+        else:
+            per_pair = ab.get(dom[0], ab["total"])
+            bytes_per_launch = per_pair * args.pairs / max(1.0, launches_per_step)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tf):     # PMC pass of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), see profiles/README.md
+            tk = json.load(open(tf)).get("kernels", {})
+            for name, v in tk.items():
+                if name.split("<")[0] == dom[0]:
+                    traffic = v["hbm_bytes"]
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                "algorithmic_bytes_per_pair": per_pair,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
+                "algorithmic_bytes_per_launch": int(bytes_per_launch), "algorithmic_bytes_per_pair": per_pair,
                 "hot_path_frac": round(ab["total"] * args.pairs / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
     cpu = None
     if not args.no_cpu and world == 1:
@@ -318,7 +342,7 @@ def main():
         "kernels_ms_per_step": {k_: round(v[0] / args.steps, 4) for k_, v in prof.items()},
         "exchange_bytes_per_step_rank0": (engine.bytes_exchanged // (args.steps + args.warmup)) if engine else 0,
         "wall_ms_per_step": {k_: round(v / args.steps * 1e3, 3) for k_, v in wall.items()},
-        "counts": {k_: v for k_, v in state.items() if k_ != "graph"}, "parity_gate": parity,
+        "counts": {k_: v for k_, v in state.items() if k_ != "graph"}, "scorer_stats": stats, "parity_gate": parity,
     }
     print(json.dumps(out))
 

@@ -131,6 +131,11 @@ typedef struct {
  * pairs == NULL fills offsets[n+1]; second call with pairs sized offsets[n]. */
 int vdjx_map_emit(vdjx_ctx* ctx, const char* contigs, size_t n, int len, uint64_t* offsets, vdjx_pair* pairs);
 
+/* counters of the most recent scorer calls, by name: "window_hits" (read instances matched by the last
+ * vdjx_window_score call, summed over windows), "window_hits_max", "window_pairs", "window_work_items",
+ * "map_hits", "root_dp_items".  Unknown names return 0.  Used by bench.py to price the scorers' algorithmic bytes. */
+uint64_t vdjx_stat(vdjx_ctx* ctx, const char* name);
+
 /* ---- profiling hooks (HIP events on the context's stream) ---------------------------------------*/
 int vdjx_profile_enable(vdjx_ctx* ctx, int on);
 int vdjx_profile_reset(vdjx_ctx* ctx);

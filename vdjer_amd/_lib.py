@@ -18,7 +18,7 @@ SYMBOLS = [
     "vdjx_kmer_build", "vdjx_graph_nodes", "vdjx_graph_pre_nodes", "vdjx_graph_export", "vdjx_graph_free",
     "vdjx_vregion_load", "vdjx_root_score",
     "vdjx_read_index_build", "vdjx_window_score", "vdjx_map_emit",
-    "vdjx_profile_enable", "vdjx_profile_reset", "vdjx_profile_count", "vdjx_profile_get",
+    "vdjx_stat", "vdjx_profile_enable", "vdjx_profile_reset", "vdjx_profile_count", "vdjx_profile_get",
     "vdjx_shard_begin", "vdjx_shard_free", "vdjx_shard_qstride", "vdjx_shard_key_hi_bytes", "vdjx_shard_pool_export",
     "vdjx_shard_set_pool", "vdjx_shard_partition_count", "vdjx_shard_partition_fill", "vdjx_shard_reduce",
     "vdjx_shard_survivors", "vdjx_shard_edges", "vdjx_shard_finish",
@@ -88,6 +88,8 @@ def lib():
     L.vdjx_read_index_build.argtypes = [vp, vp, vp, vp, vp, vp, u32]
     L.vdjx_window_score.argtypes = [vp, C.c_char_p, sz, i32, C.POINTER(CovParams), vp, vp]
     L.vdjx_map_emit.argtypes = [vp, C.c_char_p, sz, i32, vp, vp]
+    L.vdjx_stat.argtypes = [vp, C.c_char_p]
+    L.vdjx_stat.restype = C.c_uint64
     L.vdjx_profile_enable.argtypes = [vp, i32]
     L.vdjx_profile_reset.argtypes = [vp]
     L.vdjx_profile_count.argtypes = [vp]

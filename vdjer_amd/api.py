@@ -196,6 +196,9 @@ class Context:
         check(self.L.vdjx_map_emit(self.h, raw, n, ln, _p(offs), _p(pairs)), "vdjx_map_emit")
         return offs, pairs
 
+    def stat(self, name: str) -> int:
+        return int(self.L.vdjx_stat(self.h, name.encode()))
+
     # ---- profiling
     def profile(self, on: bool = True):
         check(self.L.vdjx_profile_enable(self.h, 1 if on else 0))

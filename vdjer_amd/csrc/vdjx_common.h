@@ -83,6 +83,7 @@ struct vdjx_ctx {
 	u32 ri_nslots = 0;
 	u32* d_ri_rep = nullptr;          // class -> representative record
 	u32* d_ri_start = nullptr;        // class -> CSR start [ncls+1]
+	u32* d_ri_cnt1 = nullptr;         // class -> number of read-1 members (stored first)
 	u32* d_ri_recs = nullptr;         // CSR: records in registration order
 	u32* d_pair_id = nullptr;
 	uint8_t* d_read_num = nullptr;
@@ -95,6 +96,7 @@ struct vdjx_ctx {
 	size_t me_cap = 0;
 	std::vector<u64> me_hoff, me_cnt;
 	u32 n_pairs = 0, n_classes = 0;
+	std::map<std::string, uint64_t> stats;
 };
 
 struct vdjx_pool {

@@ -48,7 +48,7 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	free_dev(c->d_vtext); free_dev(c->d_line_off); free_dev(c->d_seed_code); free_dev(c->d_seed_pos);
 	free_dev(c->d_ri_slots); free_dev(c->d_ri_rep); free_dev(c->d_ri_start); free_dev(c->d_ri_recs);
 	free_dev(c->d_pair_id); free_dev(c->d_read_num); free_dev(c->d_is_rc); free_dev(c->d_pair_r2);
-	free_dev(c->d_rec_info); free_dev(c->me_pairs);
+	free_dev(c->d_rec_info); free_dev(c->me_pairs); free_dev(c->d_ri_cnt1);
 	c->arena.release();
 	c->shard_arena.release();
 	for (auto& p : c->prof_pending) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
@@ -122,6 +122,12 @@ void vdjx_prof_collect(vdjx_ctx* c) {
 		(void) hipEventDestroy(p.b);
 	}
 	c->prof_pending.clear();
+}
+
+extern "C" uint64_t vdjx_stat(vdjx_ctx* c, const char* name) {
+	if (!c || !name) return 0;
+	auto it = c->stats.find(name);
+	return it == c->stats.end() ? 0 : it->second;
 }
 
 extern "C" int vdjx_profile_enable(vdjx_ctx* c, int on) {

@@ -207,6 +207,7 @@ extern "C" int vdjx_root_score(vdjx_ctx* c, const char* kmers, size_t n, int k, 
 	for (u32 i = 0; i < ng; i++) { pre[i] = (u32) run; run += cnt[i]; }
 	pre[ng] = (u32) run;
 	if (run >= (1ull << 31)) { vdjx_set_error("too many seed hits in one call (%llu)", (unsigned long long) run); return VDJX_ELIMIT; }
+	c->stats["root_dp_items"] = run;
 	if (threshold <= 0) {
 		// cells of row/column 0 are 0 and are tested too (seq_score.c:103-112): any seed hit accepts
 		for (size_t r = 0; r < n; r++) out[r] = pre[(r + 1) * stop] > pre[r * stop];
@@ -303,10 +304,17 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 	std::vector<u32> start(ncls + 1, 0), recs;
 	for (u32 i = 0; i < ncls; i++) start[i + 1] = start[i] + cls_cnt[i];
 	recs.resize(start[ncls] ? start[ncls] : 1);
-	std::vector<u32> fill(start.begin(), start.end() - 1);
+	// members of a class: read-1 instances first, each group in registration order.  Only read-1 instances are
+	// enumerated as hits (quick_map3.c:211-215: read-2 instances only feed the read2 map, which the class -> last
+	// offset table replaces), so a class's hit count is its read-1 count.
+	std::vector<u32> cnt1(ncls + 1, 0);
+	for (u32 r = 0; r < R; r++) if (rec_cls[r] != NONE32 && read_num[r] == 1) cnt1[rec_cls[r]]++;
+	std::vector<u32> fill1(start.begin(), start.end() - 1), fill2(ncls);
+	for (u32 i = 0; i < ncls; i++) fill2[i] = start[i] + cnt1[i];
 	for (u32 i = 0; i < R; i++) {
 		const u32 r = order[i];
-		if (rec_cls[r] != NONE32) recs[fill[rec_cls[r]]++] = r;
+		if (rec_cls[r] == NONE32) continue;
+		if (read_num[r] == 1) recs[fill1[rec_cls[r]]++] = r; else recs[fill2[rec_cls[r]]++] = r;
 	}
 	std::vector<u32> slots((size_t) mask + 1, 0);
 	for (size_t s = 0; s <= mask; s++) if (slot_cls[s] != NONE32) slots[s] = slot_cls[s] + 1;
@@ -333,6 +341,9 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 		      (rb != NONE32 && is_rc[rb] ? RI_RCB : 0u);
 		info[r] = v;
 	}
+	free_set(c->d_ri_cnt1);
+	HIP_TRY(hipMalloc(&c->d_ri_cnt1, ((size_t) ncls + 1) * 4));
+	HIP_TRY(hipMemcpy(c->d_ri_cnt1, cnt1.data(), ((size_t) ncls + 1) * 4, hipMemcpyHostToDevice));
 	HIP_TRY(hipMalloc(&c->d_ri_rep, ((size_t) ncls + 1) * 4));
 	HIP_TRY(hipMalloc(&c->d_ri_start, ((size_t) ncls + 1) * 4));
 	HIP_TRY(hipMalloc(&c->d_ri_recs, recs.size() * 4));
@@ -371,7 +382,7 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 struct ReadIndexDev {
 	const u64* bases;
 	const u32* slots; u32 mask;
-	const u32* rep; const u32* start; const u32* recs;
+	const u32* rep; const u32* start; const u32* cnt1; const u32* recs;
 	const uint4* csr_info; const u32* pair_r2;    // csr_info[i] = record info of recs[i]: one coalesced 16-byte load per hit
 	int rl;
 };
@@ -416,7 +427,7 @@ __device__ inline u32 map_prepare(MapLds& L, const ReadIndexDev& ix, const char*
 		}
 		if (cls != NONE32) {
 			cs = ix.start[cls];
-			sz = ix.start[cls + 1] - cs;
+			sz = ix.cnt1[cls];                      // read-1 members come first
 			// class -> last offset ("read2[id] = m_info": the last writer wins, quick_map3.c:214)
 			u32 slot = (cls * 2654435761u) & (WT_SLOTS - 1);
 			for (;;) {
@@ -562,6 +573,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 	__shared__ u32 hf[MAP_MAXOFF + 64 + 2];         // histogram of firsts -> inclusive prefix "cum"
 	__shared__ int diff[COV_WORDS];
 	__shared__ u32 s_bad, s_ok;
+	__shared__ int s_firstv;
 	const u32 tid = threadIdx.x;
 	const int D = len + 1;
 	const int e0 = cp.eval_start, e1 = cp.eval_stop, fl = cp.floor;
@@ -575,46 +587,84 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 	const u32* pairs = pair_buf + pair_off[wi];
 	const u32 npairs = pair_cnt[wi];
 	if (fl == 0) { if (tid == 0) out_valid[wi] = 1; return; }
+	// histogram of the start entries' first values: one private copy per wave in `diff` (deep windows put
+	// hundreds of thousands of increments on a few hundred positions), then summed into hf
+	const u32 wv = tid >> 6, NW = MAP_THREADS / 64;
+	u32* hp = (u32*) diff;
+	const bool priv = (u32) (D + 1) * NW <= COV_WORDS;
 	for (u32 i = tid; i < (u32) D + 1; i += MAP_THREADS) hf[i] = 0;
+	if (priv) for (u32 i = tid; i < (u32) (D + 1) * NW; i += MAP_THREADS) hp[i] = 0;
 	if (tid == 0) { s_bad = 0; s_ok = 0; }
 	__syncthreads();
+	u32* myh = priv ? hp + wv * (u32) (D + 1) : hf;
 	for (u32 q = tid; q < npairs; q += MAP_THREADS) {
 		const u32 pr = pairs[q];
-		atomicAdd(&hf[pr >> 16], 1u);
-		atomicAdd(&hf[pr & 0xFFFFu], 1u);
+		atomicAdd(&myh[pr >> 16], 1u);
+		atomicAdd(&myh[pr & 0xFFFFu], 1u);
 	}
 	__syncthreads();
-	// ---- rule 1
-	if (tid == 0) {
-		u32 run = 0;
-		for (int p = 0; p < D; p++) { run += hf[p]; hf[p] = run; }
+	if (priv) {
+		for (u32 i = tid; i < (u32) D + 1; i += MAP_THREADS) {
+			u32 sum = 0;
+			for (u32 w2 = 0; w2 < NW; w2++) sum += hp[w2 * (u32) (D + 1) + i];
+			hf[i] = sum;
+		}
+		__syncthreads();
+	}
+	// ---- rule 1 (coverage.c:76-121) from the cumulative histogram cum[p] = #entries with first <= p.
+	// Wave 0 prefixes; then every candidate value v is tested by its own thread (any failure invalidates, so the
+	// reference's first-failure order does not matter); thread 0 does the two end-of-list checks.
+	if (tid < 64) {
+		const int per = (D + 63) / 64;
+		const int a0 = (int) tid * per;
+		const int b0 = a0 + per < D ? a0 + per : D;
+		u32 sum = 0;
+		for (int q = a0; q < b0; q++) sum += hf[q];
+		u32 incl = sum;
+		for (int d = 1; d < 64; d <<= 1) {
+			u32 v = __shfl_up(incl, d);
+			if ((int) tid >= d) incl += v;
+		}
+		u32 run = incl - sum;
+		for (int q = a0; q < b0; q++) { run += hf[q]; hf[q] = run; }
+	}
+	if (tid == 0) s_firstv = 0x7FFFFFFF;
+	__syncthreads();
+	{
 		const int n_ent = (int) hf[D - 1];
-		bool ok = true;
-		auto cum = [&](int p) -> int { return p < 0 ? 0 : (p >= D ? n_ent : (int) hf[p]); };
-		auto value_at = [&](int idx) -> int {       // idx-th smallest first (0-based): smallest p with cum[p] > idx
-			int lo2 = 0, hi2 = D - 1;
-			while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (cum(mid) > idx) hi2 = mid; else lo2 = mid + 1; }
-			return lo2;
-		};
 		const int vmax = e1 - cp.read_span + 1;
-		bool first_seen = false;
-		for (int v = e0 > 1 ? e0 : 1; v <= vmax && v < D && ok; v++) {
-			if (cum(v) == cum(v - 1)) continue;
-			const int i0 = cum(v - 1);                            // smallest index holding value v
-			if (i0 < fl) { ok = false; break; }                   // coverage.c:80-84
-			if (!first_seen) { first_seen = true; if (v > e0 + gap) { ok = false; break; } }   // :86-93
-			if (cum(v - gap - 1) > i0 - fl) { ok = false; break; }                              // :96-100
+		const int vlo = e0 > 1 ? e0 : 1;
+		for (int v = vlo + (int) tid; v <= vmax && v < D; v += MAP_THREADS) {
+			const int cv = (int) hf[v], cv1 = (int) hf[v - 1];
+			if (cv == cv1) continue;
+			atomicMin(&s_firstv, v);
+			const int i0 = cv1;                                   // smallest index holding value v
+			if (i0 < fl) s_bad = 1;                               // coverage.c:80-84
+			const int pg = v - gap - 1;
+			const int cg = pg < 0 ? 0 : (pg >= D ? n_ent : (int) hf[pg]);
+			if (cg > i0 - fl) s_bad = 1;                          // :96-100
 		}
-		int i_fin = cum(vmax);
-		if (i_fin >= n_ent) i_fin = n_ent - 1;                    // :106-108
-		if (ok && n_ent > 0) {
-			const int v_fin = value_at(i_fin);
-			if (i_fin > fl && value_at(i_fin - fl) < v_fin - gap) ok = false;   // :111-113
-			if (!(i_fin > 0 && v_fin > e1 - rl)) ok = false;                   // :116-120
-		} else {
-			ok = false;
+		__syncthreads();
+		if (tid == 0) {
+			bool ok = true;
+			auto cum = [&](int p) -> int { return p < 0 ? 0 : (p >= D ? n_ent : (int) hf[p]); };
+			auto value_at = [&](int idx) -> int {       // idx-th smallest first (0-based): smallest p with cum[p] > idx
+				int lo2 = 0, hi2 = D - 1;
+				while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (cum(mid) > idx) hi2 = mid; else lo2 = mid + 1; }
+				return lo2;
+			};
+			if (s_firstv != 0x7FFFFFFF && s_firstv > e0 + gap) ok = false;      // :86-93
+			int i_fin = cum(vmax);
+			if (i_fin >= n_ent) i_fin = n_ent - 1;                    // :106-108
+			if (n_ent > 0) {
+				const int v_fin = value_at(i_fin);
+				if (i_fin > fl && value_at(i_fin - fl) < v_fin - gap) ok = false;   // :111-113
+				if (!(i_fin > 0 && v_fin > e1 - rl)) ok = false;                   // :116-120
+			} else {
+				ok = false;
+			}
+			if (!ok) s_bad = 1;
 		}
-		if (!ok) s_bad = 1;
 	}
 	__syncthreads();
 	// ---- rule 2.  Coverage only grows with more entries, so the pair list is replayed in doubling chunks and
@@ -648,21 +698,33 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 			}
 			if (tid == 0) s_ok = 1;
 			__syncthreads();
-			if ((int) tid < nd) {
-				const int dl = d0 + (int) tid;
-				const int* row = diff + tid * stride;
-				int run = 0;
+			// one wave per delta row: chunked inclusive scan of the difference array, test on the fly
+			for (int row_i = (int) (tid >> 6); row_i < nd; row_i += MAP_THREADS / 64) {
+				const int dl = d0 + row_i;
+				const int* row = diff + row_i * stride;
+				const int lane = (int) (tid & 63);
+				int carry = 0;
 				bool ok = true;
-				for (int p = 0; p < npos; p++) {
-					run += row[p];
-					const int pos = e0 + p;
-					if (pos != e0 && (pos - 1 + clo) >= e1) break;       // the loop tests the previous mate_low (coverage.c:25)
-					int mh = pos + chi;
-					if (mh > e1) mh = e1 + 1;                             // coverage.c:36-38
-					const int j = pos + dl;
-					if (j >= mh) continue;
-					if (j < 0 || j > len + 1023) { s_bad = 1; break; }    // outside the reference's array: undefined there
-					if (run < fl) ok = false;
+				for (int p0 = 0; p0 < npos; p0 += 64) {
+					const int p = p0 + lane;
+					int v = p < npos ? row[p] : 0;
+					for (int d = 1; d < 64; d <<= 1) {
+						int u = __shfl_up(v, d);
+						if (lane >= d) v += u;
+					}
+					const int run = carry + v;
+					carry += __shfl(v, 63);
+					if (p < npos) {
+						const int pos = e0 + p;
+						const bool evaluated = pos == e0 || (pos - 1 + clo) < e1;    // the loop tests the previous mate_low (coverage.c:25)
+						int mh = pos + chi;
+						if (mh > e1) mh = e1 + 1;                                    // coverage.c:36-38
+						const int j = pos + dl;
+						if (evaluated && j < mh) {
+							if (j < 0 || j > len + 1023) s_bad = 1;                   // outside the reference's array: undefined there
+							else if (run < fl) ok = false;
+						}
+					}
 				}
 				if (!ok) s_ok = 0;
 			}
@@ -747,7 +809,7 @@ static int make_index_view(vdjx_ctx* c, ReadIndexDev* ix, int len, const char* w
 	if (len - p->rl > MAP_MAXOFF) { vdjx_set_error("%s: len=%d too long (max %d)", who, len, MAP_MAXOFF + p->rl); return VDJX_ELIMIT; }
 	ix->bases = p->d_bases;
 	ix->slots = c->d_ri_slots; ix->mask = c->ri_nslots - 1;
-	ix->rep = c->d_ri_rep; ix->start = c->d_ri_start; ix->recs = c->d_ri_recs;
+	ix->rep = c->d_ri_rep; ix->start = c->d_ri_start; ix->cnt1 = c->d_ri_cnt1; ix->recs = c->d_ri_recs;
 	ix->csr_info = c->d_rec_info; ix->pair_r2 = c->d_pair_r2;
 	ix->rl = p->rl;
 	return VDJX_OK;
@@ -805,6 +867,12 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	rc = plan_windows(c, db, ix, d_w, n, len, off, &d_order, &d_off);
 	if (rc) return rc;
 	HIP_TRY(db.alloc(&d_pairbuf, (size_t) off[n]));
+	c->stats["window_hits"] = off[n];
+	{
+		u64 mx = 0;
+		for (size_t i = 0; i < n; i++) mx = std::max<u64>(mx, off[i + 1] - off[i]);
+		c->stats["window_hits_max"] = mx;
+	}
 	// work list: deep windows are cut into slices of HIT_CHUNK hits (largest windows first)
 	std::vector<uint4> work;
 	{
@@ -835,6 +903,12 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	c->stats["window_work_items"] = work.size();
+	{
+		u64 tot = 0;
+		for (size_t i = 0; i < n; i++) tot += out_npairs[i];
+		c->stats["window_pairs"] = tot;
+	}
 	return VDJX_OK;
 }
 
@@ -885,6 +959,7 @@ extern "C" int vdjx_map_emit(vdjx_ctx* c, const char* contigs, size_t n, int len
 		HIP_TRY(hipGetLastError());
 		c->me_hoff = off;
 		c->me_key = key;
+		c->stats["map_hits"] = off[n];
 	}
 	offsets[0] = 0;
 	for (size_t i = 0; i < n; i++) offsets[i + 1] = offsets[i] + c->me_cnt[i];
