@@ -27,6 +27,7 @@
 #define HIST_THREADS 1024
 #define K3_THREADS 512
 #define K3_SLOTS 2048u              // LDS table slots per sub-pass (56 KB with u32 key_hi: 2 workgroups per CU)
+#define K3_UNR 4
 #define K3_SUB_TUPLES 3072u         // tuples per sub-pass before the first split (an overflow splits further)
 #define K3B_THREADS 256
 #define K3B_CH 1024u                // candidates per chunk
@@ -344,18 +345,30 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 		for (u32 s = 0; s < S; s++) {
 			for (u32 i = tid; i < K3_SLOTS; i += K3_THREADS) { s_khi[i] = EMPTY; s_cnt[i] = 0; s_first[i] = NONE32; }
 			__syncthreads();
-			// sweep 1: gated instances only (include_kmer, A2:240-259) -> count + first (A2:332-347)
-			for (u32 t = tid; t < n; t += K3_THREADS) {
-				const u32 iw = t_inst[base + t];
-				if (!(iw >> 31)) continue;
-				const u64 lo = t_lo[base + t];
-				const THI hi = t_hi[base + t];
-				const u64 h = vdjx_mix(lo, (u64) hi);
-				if ((u32) ((h >> 12) & (S - 1)) != s) continue;
-				int slot = lds_insert<THI>(s_klo, s_khi, lo, hi, (u32) h);
-				if (slot < 0) { s_over = 1; continue; }
-				atomicAdd(&s_cnt[slot], 1u);
-				atomicMin(&s_first[slot], iw & INST_MASK);
+			// sweep 1: gated instances only (include_kmer, A2:240-259) -> count + first (A2:332-347).
+			// K3_UNR tuples per thread are loaded before any is processed: the loop is latency-bound otherwise.
+			for (u32 t0 = 0; t0 < n; t0 += K3_UNR * K3_THREADS) {
+				u32 iw[K3_UNR];
+				u64 lo[K3_UNR];
+				THI hi[K3_UNR];
+#pragma unroll
+				for (int j = 0; j < K3_UNR; j++) {
+					const u32 t = t0 + j * K3_THREADS + tid;
+					const bool v = t < n;
+					iw[j] = v ? t_inst[base + t] : 0u;
+					lo[j] = v ? t_lo[base + t] : 0ull;
+					hi[j] = v ? t_hi[base + t] : (THI) 0;
+				}
+#pragma unroll
+				for (int j = 0; j < K3_UNR; j++) {
+					if (!(iw[j] >> 31)) continue;
+					const u64 h = vdjx_mix(lo[j], (u64) hi[j]);
+					if ((u32) ((h >> 12) & (S - 1)) != s) continue;
+					int slot = lds_insert<THI>(s_klo, s_khi, lo[j], hi[j], (u32) h);
+					if (slot < 0) { s_over = 1; continue; }
+					atomicAdd(&s_cnt[slot], 1u);
+					atomicMin(&s_first[slot], iw[j] & INST_MASK);
+				}
 			}
 			__syncthreads();
 			if (s_over) break;
@@ -376,20 +389,35 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 			}
 			__syncthreads();
 			// sweep 2: compact every instance (gated or not) of a candidate k-mer
-			for (u32 t = tid; t < n; t += K3_THREADS) {
-				const u64 lo = t_lo[base + t];
-				const THI hi = t_hi[base + t];
-				const u64 h = vdjx_mix(lo, (u64) hi);
-				bool is_c = false;
-				u32 cid = NONE32;
-				if ((u32) ((h >> 12) & (S - 1)) == s) {
-					int slot = lds_lookup<THI>(s_klo, s_khi, lo, hi, (u32) h);
-					if (slot >= 0) { cid = s_cidx[slot]; is_c = cid != NONE32; }
+			for (u32 t0 = 0; t0 < n; t0 += K3_UNR * K3_THREADS) {
+				u32 iw[K3_UNR];
+				u64 lo[K3_UNR];
+				THI hi[K3_UNR];
+				bool val[K3_UNR];
+#pragma unroll
+				for (int j = 0; j < K3_UNR; j++) {
+					const u32 t = t0 + j * K3_THREADS + tid;
+					val[j] = t < n;
+					iw[j] = val[j] ? t_inst[base + t] : 0u;
+					lo[j] = val[j] ? t_lo[base + t] : 0ull;
+					hi[j] = val[j] ? t_hi[base + t] : (THI) 0;
 				}
-				u32 p = vdjx_wave_inc(&s_nct, is_c);
-				if (is_c) {
-					ct_lcid[base + p] = cid;
-					ct_inst[base + p] = t_inst[base + t];
+#pragma unroll
+				for (int j = 0; j < K3_UNR; j++) {
+					bool is_c = false;
+					u32 cid = NONE32;
+					if (val[j]) {
+						const u64 h = vdjx_mix(lo[j], (u64) hi[j]);
+						if ((u32) ((h >> 12) & (S - 1)) == s) {
+							int slot = lds_lookup<THI>(s_klo, s_khi, lo[j], hi[j], (u32) h);
+							if (slot >= 0) { cid = s_cidx[slot]; is_c = cid != NONE32; }
+						}
+					}
+					u32 p = vdjx_wave_inc(&s_nct, is_c);
+					if (is_c) {
+						ct_lcid[base + p] = cid;
+						ct_inst[base + p] = iw[j];
+					}
 				}
 			}
 			__syncthreads();
