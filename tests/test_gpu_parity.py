@@ -297,3 +297,15 @@ def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq):
         np.testing.assert_array_equal(g.to_ids, ref.to_ids)
         np.testing.assert_array_equal(g.from_ids, ref.from_ids)
         np.testing.assert_array_equal(g.kmers, ref.kmers)
+
+
+def test_all_gated_all_distinct_overflows_the_lds_table(ctx):
+    """High-quality reads with 80 % noise: nearly every instance is gated and distinct, so buckets hold more
+    distinct k-mers than one LDS table pass takes and the sub-pass split / restart path runs."""
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(20, seed=61)
+    pool = synth.make_reads(rep, 150000, noise_frac=0.8, seed=62, clean=True)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    hg = run_both(ctx, pool, vc, jc, 35, 2, 60)
+    assert hg.pre_nodes > 6_000_000 and hg.n > 1000

@@ -28,7 +28,7 @@
 #define K3_THREADS 512
 #define K3_SLOTS 2048u              // LDS table slots per sub-pass (56 KB with u32 key_hi: 2 workgroups per CU)
 #define K3_UNR 4
-#define K3_SUB_TUPLES 3072u         // tuples per sub-pass before the first split (an overflow splits further)
+#define K3_SUB_TUPLES 16384u        // first split only for very large buckets: hot k-mers make buckets long, not wide (an overflow splits further)
 #define K3B_THREADS 256
 #define K3B_CH 1024u                // candidates per chunk
 #define K3B_A 128u                  // quality-sum rows per round
@@ -266,6 +266,20 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_tuples(const u64* __restr
 	}
 }
 
+// sub-bucket sizes inside every segment (bucket) of a partitioned tuple array: one workgroup per segment
+template <typename THI>
+__global__ __launch_bounds__(256) void k_seg_hist(const u64* __restrict__ lo, const THI* __restrict__ hi, const u32* __restrict__ seg_start,
+                                                  u32 shift, u32 sub_bits, u32* __restrict__ fine_cnt) {
+	__shared__ u32 h[PART_MAXB];
+	const u32 nbk = 1u << sub_bits;
+	for (u32 i = threadIdx.x; i < nbk; i += 256) h[i] = 0;
+	__syncthreads();
+	const u32 s0 = seg_start[blockIdx.x], s1 = seg_start[blockIdx.x + 1];
+	for (u32 t = s0 + threadIdx.x; t < s1; t += 256) atomicAdd(&h[(u32) (vdjx_mix(lo[t], (u64) hi[t]) >> shift) & (nbk - 1)], 1u);
+	__syncthreads();
+	for (u32 i = threadIdx.x; i < nbk; i += 256) fine_cnt[((size_t) blockIdx.x << sub_bits) | i] = h[i];
+}
+
 // cursors of a partition pass: cur[i] = bucket_start[i << sh]
 __global__ void k_init_cursors(const u32* __restrict__ bucket_start, u32 n, u32 sh, u32* __restrict__ cur) {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -347,27 +361,29 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 			__syncthreads();
 			// sweep 1: gated instances only (include_kmer, A2:240-259) -> count + first (A2:332-347).
 			// K3_UNR tuples per thread are loaded before any is processed: the loop is latency-bound otherwise.
+			// A bucket that fits one chunk (the common case) stays in registers for sweep 2.
+			const bool one_chunk = n <= K3_UNR * K3_THREADS;
+			u32 r_iw[K3_UNR];
+			u64 r_lo[K3_UNR];
+			THI r_hi[K3_UNR];
 			for (u32 t0 = 0; t0 < n; t0 += K3_UNR * K3_THREADS) {
-				u32 iw[K3_UNR];
-				u64 lo[K3_UNR];
-				THI hi[K3_UNR];
 #pragma unroll
 				for (int j = 0; j < K3_UNR; j++) {
 					const u32 t = t0 + j * K3_THREADS + tid;
 					const bool v = t < n;
-					iw[j] = v ? t_inst[base + t] : 0u;
-					lo[j] = v ? t_lo[base + t] : 0ull;
-					hi[j] = v ? t_hi[base + t] : (THI) 0;
+					r_iw[j] = v ? t_inst[base + t] : 0u;
+					r_lo[j] = v ? t_lo[base + t] : 0ull;
+					r_hi[j] = v ? t_hi[base + t] : (THI) 0;
 				}
 #pragma unroll
 				for (int j = 0; j < K3_UNR; j++) {
-					if (!(iw[j] >> 31)) continue;
-					const u64 h = vdjx_mix(lo[j], (u64) hi[j]);
+					if (!(r_iw[j] >> 31)) continue;
+					const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
 					if ((u32) ((h >> 12) & (S - 1)) != s) continue;
-					int slot = lds_insert<THI>(s_klo, s_khi, lo[j], hi[j], (u32) h);
+					int slot = lds_insert<THI>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
 					if (slot < 0) { s_over = 1; continue; }
 					atomicAdd(&s_cnt[slot], 1u);
-					atomicMin(&s_first[slot], iw[j] & INST_MASK);
+					atomicMin(&s_first[slot], r_iw[j] & INST_MASK);
 				}
 			}
 			__syncthreads();
@@ -390,33 +406,32 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 			__syncthreads();
 			// sweep 2: compact every instance (gated or not) of a candidate k-mer
 			for (u32 t0 = 0; t0 < n; t0 += K3_UNR * K3_THREADS) {
-				u32 iw[K3_UNR];
-				u64 lo[K3_UNR];
-				THI hi[K3_UNR];
 				bool val[K3_UNR];
 #pragma unroll
 				for (int j = 0; j < K3_UNR; j++) {
 					const u32 t = t0 + j * K3_THREADS + tid;
 					val[j] = t < n;
-					iw[j] = val[j] ? t_inst[base + t] : 0u;
-					lo[j] = val[j] ? t_lo[base + t] : 0ull;
-					hi[j] = val[j] ? t_hi[base + t] : (THI) 0;
+					if (!one_chunk) {
+						r_iw[j] = val[j] ? t_inst[base + t] : 0u;
+						r_lo[j] = val[j] ? t_lo[base + t] : 0ull;
+						r_hi[j] = val[j] ? t_hi[base + t] : (THI) 0;
+					}
 				}
 #pragma unroll
 				for (int j = 0; j < K3_UNR; j++) {
 					bool is_c = false;
 					u32 cid = NONE32;
 					if (val[j]) {
-						const u64 h = vdjx_mix(lo[j], (u64) hi[j]);
+						const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
 						if ((u32) ((h >> 12) & (S - 1)) == s) {
-							int slot = lds_lookup<THI>(s_klo, s_khi, lo[j], hi[j], (u32) h);
+							int slot = lds_lookup<THI>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
 							if (slot >= 0) { cid = s_cidx[slot]; is_c = cid != NONE32; }
 						}
 					}
 					u32 p = vdjx_wave_inc(&s_nct, is_c);
 					if (is_c) {
 						ct_lcid[base + p] = cid;
-						ct_inst[base + p] = iw[j];
+						ct_inst[base + p] = r_iw[j];
 					}
 				}
 			}
@@ -886,6 +901,37 @@ int stage_partition_fill(vdjx_ctx* c, A& db, const vdjx_pool* pool, u32 rec_base
 	return VDJX_OK;
 }
 
+// Large inputs: 2^15 buckets (the LDS histogram's limit) would hold tens of thousands of tuples each and the
+// aggregate kernel would sweep them once per sub-pass.  Split every bucket further by the next hash bits so that
+// buckets stay near 2,048 tuples whatever the pool size (one more coalesced pass over the tuples).
+template <typename THI, typename A>
+int stage_refine(vdjx_ctx* c, A& db, Tuples<THI>* t, u32 used_bits) {
+	if (t->NB == 0 || t->N / t->NB <= 4096) return VDJX_OK;
+	u32 extra = 1;
+	while (extra < 10 && ((size_t) t->N >> extra) / t->NB > 2048 && t->NB << (extra + 1) <= (1u << 22)) extra++;
+	hipStream_t st = c->stream;
+	const u32 NBf = t->NB << extra;
+	u32 *fine_cnt, *fine_start, *gcur, *o_inst;
+	u64* o_lo;
+	THI* o_hi;
+	HIP_TRY(db.alloc(&fine_cnt, NBf));
+	HIP_TRY(db.alloc(&fine_start, NBf + 1));
+	HIP_TRY(db.alloc(&gcur, NBf));
+	HIP_TRY(db.alloc(&o_lo, t->N)); HIP_TRY(db.alloc(&o_hi, t->N)); HIP_TRY(db.alloc(&o_inst, t->N));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_part_tuples<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
+	const u32 shift = 64 - used_bits - extra;
+	vdjx_prof_scope ps(c, "k_part_refine");
+	hipLaunchKernelGGL(k_seg_hist<THI>, dim3(t->NB), dim3(256), 0, st, t->lo, t->hi, t->bucket_start, shift, extra, fine_cnt);
+	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, fine_cnt, NBf, fine_start);
+	hipLaunchKernelGGL(k_init_cursors, dim3((NBf + 255) / 256), dim3(256), 0, st, fine_start, NBf, 0u, gcur);
+	hipLaunchKernelGGL(k_part_tuples<THI>, dim3(t->NB), dim3(PART_THREADS), PART_LDS_BYTES, st, t->lo, t->hi, t->inst, t->bucket_start,
+	                   0u, 1u, shift, extra, gcur, o_lo, o_hi, o_inst);
+	t->lo = o_lo; t->hi = o_hi; t->inst = o_inst;
+	t->bucket_start = fine_start;
+	t->NB = NBf;
+	return VDJX_OK;
+}
+
 // owner side: bucket the received tuples by the hash bits below the owner bits (same LDS-staged passes)
 template <typename THI, typename A>
 int stage_repartition(vdjx_ctx* c, A& db, const u64* r_lo, const THI* r_hi, const u32* r_inst, size_t n, u32 owner_bits,
@@ -939,7 +985,7 @@ int stage_repartition(vdjx_ctx* c, A& db, const u64* r_lo, const THI* r_hi, cons
 	}
 	out->NB = NBL;
 	out->N = (u32) n;
-	return VDJX_OK;
+	return stage_refine<THI>(c, db, out, owner_bits + lb);
 }
 
 // K3a + K3b
@@ -1106,6 +1152,8 @@ int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, v
 	t.bucket_start = pp.bucket_start;
 	t.NB = pp.NB;
 	rc = stage_partition_fill<THI>(c, db, pool, 0, k, pp, t.N, t.lo, t.hi, t.inst);
+	if (rc) return rc;
+	rc = stage_refine<THI>(c, db, &t, pp.nb_bits);
 	if (rc) return rc;
 	PoolView pv{pool->d_bases, pool->d_nmask, pool->d_quals, pool->qstride};
 	Survivors sv;
