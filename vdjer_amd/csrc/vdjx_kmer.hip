@@ -529,12 +529,26 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 				const u32 inst = iw & INST_MASK;
 				const u32 rec = inst / (u32) P;
 				const u32 off = inst - rec * (u32) P;
-				// first instance: the RECORD's first k qualities (A2:337-339); others: the k-mer's own (A2:354-361)
-				const uint8_t* q = quals + (size_t) rec * (size_t) qstride + (inst == l_first[lc] ? 0u : off);
+				// first instance: the RECORD's first k qualities (A2:337-339); others: the k-mer's own (A2:354-361).
+				// The record's quality row (qstride <= 64 bytes, 16-byte aligned) comes in as four 16-byte loads; the
+				// fully unrolled walk over its positions keeps the register indexing static.
+				const u32 qoff = inst == l_first[lc] ? 0u : off;
+				const uint4* qv = (const uint4*) (quals + (size_t) rec * (size_t) qstride);
+				u32 w[16];
+#pragma unroll
+				for (int v4 = 0; v4 < 4; v4++) {
+					uint4 x = make_uint4(0x21212121u, 0x21212121u, 0x21212121u, 0x21212121u);
+					if (v4 * 16 < qstride) x = qv[v4];
+					w[v4 * 4 + 0] = x.x; w[v4 * 4 + 1] = x.y; w[v4 * 4 + 2] = x.z; w[v4 * 4 + 3] = x.w;
+				}
 				u32* row = acc + (lid - l0) * K3B_KW;
-				for (int j = 0; j < k; j++) {
-					const u32 v = (uint8_t) (q[j] - 33);
-					atomicAdd(&row[j >> 1], v << (16 * (j & 1)));
+#pragma unroll
+				for (int pq = 0; pq < 64; pq++) {
+					const int j = pq - (int) qoff;
+					if (j >= 0 && j < k) {
+						const u32 v = (uint8_t) (((w[pq >> 2] >> (8 * (pq & 3))) & 0xFFu) - 33u);
+						atomicAdd(&row[j >> 1], v << (16 * (j & 1)));
+					}
 				}
 			}
 			__syncthreads();
