@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <numeric>
 #include <string.h>
+#include <stdlib.h>
+#include <stdio.h>
 
 #define NONE32 0xFFFFFFFFu
 
@@ -569,7 +571,9 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_pairs(ReadIndexDev ix, c
 // K9: coverage verdict of a window from its pair list
 __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, vdjx_cov_params cp, const u32* __restrict__ order,
                                                               const u64* __restrict__ pair_off, const u32* __restrict__ pair_buf,
-                                                              const u32* __restrict__ pair_cnt, uint8_t* __restrict__ out_valid) {
+                                                              const u32* __restrict__ pair_cnt, uint8_t* __restrict__ out_valid,
+                                                              u64* __restrict__ dbg) {
+	const long long t_begin = dbg ? clock64() : 0;
 	__shared__ u32 hf[MAP_MAXOFF + 64 + 2];         // histogram of firsts -> inclusive prefix "cum"
 	__shared__ int diff[COV_WORDS];
 	__shared__ u32 s_bad, s_ok;
@@ -674,9 +678,14 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 		for (int i = tid; i < nd * stride; i += MAP_THREADS) diff[i] = 0;
 		__syncthreads();
 		u32 done = 0, chunk = 4096;
+		const u32 tot = 2 * npairs;
+		const u64 perm_stride = (tot % 1000003u) ? 1000003ull : 1ull;      /* prime: a bijection on [0, tot) */
 		for (;;) {
 			const u32 end = done + chunk < 2 * npairs ? done + chunk : 2 * npairs;
-			for (u32 q = done + tid; q < end; q += MAP_THREADS) {
+			for (u32 q0 = done + tid; q0 < end; q0 += MAP_THREADS) {
+				// the list is roughly sorted by position (hits are enumerated offset-major): replay it in a scattered
+				// order so that every chunk samples the whole window and the early exit can fire
+				const u32 q = (u32) (((u64) q0 * perm_stride) % tot);
 				const u32 pr = pairs[q >> 1];
 				const int p1 = (int) (pr >> 16), p2 = (int) (pr & 0xFFFFu);
 				const int f = (q & 1) ? p2 : p1, sx = (q & 1) ? p1 : p2;
@@ -738,7 +747,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 		__syncthreads();
 	}
 	__syncthreads();
-	if (tid == 0) out_valid[wi] = s_bad ? 0 : 1;
+	if (tid == 0) {
+		out_valid[wi] = s_bad ? 0 : 1;
+		if (dbg) dbg[wi] = (u64) (clock64() - t_begin);
+	}
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -897,7 +909,24 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	}
 	{
 		vdjx_prof_scope ps(c, "k_window_cover");
-		hipLaunchKernelGGL(k_window_cover, dim3((u32) n), dim3(MAP_THREADS), 0, st, len, ix.rl, *p, d_order, d_off, d_pairbuf, d_np, d_valid);
+		u64* d_dbg = nullptr;
+		const char* dbgpath = getenv("VDJX_DEBUG_COVER");
+		if (dbgpath) HIP_TRY(db.alloc(&d_dbg, n));
+		hipLaunchKernelGGL(k_window_cover, dim3((u32) n), dim3(MAP_THREADS), 0, st, len, ix.rl, *p, d_order, d_off, d_pairbuf, d_np, d_valid, d_dbg);
+		if (dbgpath) {
+			HIP_TRY(hipStreamSynchronize(st));
+			std::vector<u64> dbg(n);
+			std::vector<u32> np(n);
+			std::vector<uint8_t> vv(n);
+			HIP_TRY(hipMemcpy(dbg.data(), d_dbg, n * 8, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(np.data(), d_np, n * 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(vv.data(), d_valid, n, hipMemcpyDeviceToHost));
+			FILE* f = fopen(dbgpath, "w");
+			if (f) {
+				for (size_t i = 0; i < n; i++) fprintf(f, "%zu\t%llu\t%u\t%llu\t%d\n", i, (unsigned long long) (off[i + 1] - off[i]), np[i], (unsigned long long) dbg[i], (int) vv[i]);
+				fclose(f);
+			}
+		}
 	}
 	HIP_TRY(hipMemcpyAsync(out_valid, d_valid, n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
