@@ -309,3 +309,60 @@ def test_all_gated_all_distinct_overflows_the_lds_table(ctx):
     jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
     hg = run_both(ctx, pool, vc, jc, 35, 2, 60)
     assert hg.pre_nodes > 6_000_000 and hg.n > 1000
+
+
+@pytest.mark.parametrize("rl,k,mf,mq", [(64, 35, 2, 60), (36, 25, 2, 40), (75 - 11, 50, 2, 60), (40, 40, 2, 30)])
+def test_other_read_lengths(ctx, rl, k, mf, mq):
+    """rl != 50 (records of 2*rl+1 bytes, up to the 64-base limit), including k == rl (one k-mer per record)"""
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(6, seed=71)
+    pool = synth.make_reads(rep, 6000, noise_frac=0.3, seed=72, rl=rl, err=0.004, n_rate=0.002)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    run_both(ctx, pool, vc, jc, k, mf, mq)
+
+
+def test_scorers_other_read_length_and_window_geometry(ctx):
+    """rl=36 reads, 300-base windows, shifted eval range and spans: mapper + coverage vs the oracle"""
+    from oracle import oracle
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(4, seed=81)
+    pool = synth.make_reads(rep, 20000, noise_frac=0.1, seed=82, rl=36, ins_mean=150.0)
+    ix = oracle.ReadIndex(pool)
+    p = _load_index(ctx, pool)
+    wins = []
+    for t in rep.clones:
+        for s in (0, 33, 100, 250):
+            wins.append(t[s:s + 300])
+    for ins, e0, e1, rs, ms, fl in ((150, 30, 250, 25, 30, 1), (150, 40, 200, 20, 48, 2), (120, 30, 250, 25, 30, 1)):
+        valid, npairs = ctx.window_score(wins, ins, e0=e0, e1=e1, rs=rs, ms=ms, floor=fl)
+        nvalid = 0
+        for i, w in enumerate(wins):
+            pairs, starts = ix.quick_map(w)
+            assert int(npairs[i]) == len(pairs)
+            exp = ix.coverage_is_valid(starts, len(w), ins, e0=e0, e1=e1, rs=rs, ms=ms, floor=fl)
+            assert int(valid[i]) == exp, (i, ins, e0, e1, rs, ms, fl)
+            nvalid += exp
+    offs, pairs = ctx.map_emit([w[:200] for w in wins])
+    for i, w in enumerate(wins):
+        op, _ = ix.quick_map(w[:200])
+        mine = pairs[int(offs[i]):int(offs[i + 1])]
+        assert [(int(q["pair_id"]), int(q["pos1"]), int(q["pos2"]), int(q["rec1"]), int(q["rec2"])) for q in mine] == \
+               [(int(q["pair_id"]), int(q["pos1"]), int(q["pos2"]), int(q["rec1"]), int(q["rec2"])) for q in op]
+    p.free()
+
+
+def test_scorer_argument_errors(ctx):
+    from vdjer_amd import api, synth
+    rep = synth.make_repertoire(2, seed=91)
+    pool = synth.make_reads(rep, 500, seed=92)
+    p = _load_index(ctx, pool)
+    with pytest.raises(api.VdjxError):
+        ctx.window_score(["ACGT" * 10], 175)                 # shorter than a read
+    with pytest.raises(api.VdjxError):
+        ctx.window_score(["A" * 2000], 175)                  # longer than the supported window
+    v, n = ctx.window_score(["N" * 486, "A" * 486], 175)     # nothing maps; never valid with floor 1
+    assert v.tolist() == [0, 0] and n.tolist() == [0, 0]
+    with pytest.raises(api.VdjxError):
+        ctx.root_score(["A" * 35], 35, 30) if False else ctx.kmer_build(p, 51, 3, 90)   # k > 50
+    p.free()
