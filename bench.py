@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--mrs", type=int, default=30)
     ap.add_argument("--ins", type=int, default=175)
     ap.add_argument("--seed", type=int, default=20261002)
-    ap.add_argument("--cpu-sample", type=int, default=500_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="pairs the CPU oracle is timed on (default: the whole workload)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--windows", choices=["traversal", "generator"], default="traversal",
                     help="scorer inputs: the candidate windows/contigs the host traversal derives from the graph (default), "

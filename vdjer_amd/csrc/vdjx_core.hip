@@ -203,13 +203,26 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 		if (q < 20) lq |= 1ull << i;                             // MIN_BASE_QUALITY, A2:76,252
 	}
 	const size_t g = rec0 + first + threadIdx.x;
-	bases[2 * g] = (u64) (b >> 64);
-	bases[2 * g + 1] = (u64) b;
+	((ulonglong2*) bases)[g] = make_ulonglong2((u64) (b >> 64), (u64) b);
 	nmask[g] = nm;
 	lowq[g] = lq;
-	uint8_t* qd = quals + g * (size_t) qstride;
-	for (int i = 0; i < rl; i++) qd[i] = r[1 + rl + i];
-	for (int i = rl; i < qstride; i++) qd[i] = 33;
+	// quality rows: qstride (a multiple of 16) bytes per record, written as 16-byte stores
+	const uint8_t* qs = r + 1 + rl;
+	uint4* qd = (uint4*) (quals + g * (size_t) qstride);
+	for (int v4 = 0; v4 < qstride / 16; v4++) {
+		u32 wds[4];
+#pragma unroll
+		for (int wd = 0; wd < 4; wd++) {
+			u32 x = 0;
+#pragma unroll
+			for (int bt = 0; bt < 4; bt++) {
+				const int i = v4 * 16 + wd * 4 + bt;
+				x |= (u32) (i < rl ? qs[i] : 33) << (8 * bt);
+			}
+			wds[wd] = x;
+		}
+		qd[v4] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+	}
 }
 
 static int pool_pack_device(vdjx_ctx* c, const uint8_t* d_primary, size_t n_primary,
