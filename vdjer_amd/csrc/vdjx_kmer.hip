@@ -226,7 +226,8 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_tuples(const u64* __restr
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	Tup<THI>* stage = (Tup<THI>*) smem;
 	__shared__ u32 cnt[PART_MAXB], base[PART_MAXB + 1], cur[PART_MAXB], gbase[PART_MAXB], tmp[PART_THREADS];
-	const u32 ROUND = PART_LDS_BYTES / sizeof(Tup<THI>);
+	constexpr u32 PER = PART_LDS_BYTES / sizeof(Tup<THI>) / PART_THREADS;      // tuples per thread per round, held in registers
+	constexpr u32 ROUND = PER * PART_THREADS;
 	const u32 seg = blockIdx.x / slices, sl = blockIdx.x % slices;
 	const u32 nbk = 1u << sub_bits, mask = nbk - 1;
 	const size_t s0 = seg_start[(size_t) seg << seg_shift], s1 = seg_start[((size_t) seg + 1) << seg_shift];
@@ -239,8 +240,20 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_tuples(const u64* __restr
 		const size_t te = ts + ROUND < t1 ? ts + ROUND : t1;
 		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) cnt[i] = 0;
 		__syncthreads();
-		for (size_t t = ts + threadIdx.x; t < te; t += PART_THREADS)
-			atomicAdd(&cnt[(u32) (vdjx_mix(i_lo[t], (u64) i_hi[t]) >> shift) & mask], 1u);
+		u64 r_lo[PER];
+		THI r_hi[PER];
+		u32 r_inst[PER], r_b[PER];
+#pragma unroll
+		for (u32 j = 0; j < PER; j++) {
+			const size_t t = ts + (size_t) j * PART_THREADS + threadIdx.x;
+			const bool v = t < te;
+			r_lo[j] = v ? i_lo[t] : 0ull;
+			r_hi[j] = v ? i_hi[t] : (THI) 0;
+			r_inst[j] = v ? i_inst[t] : 0u;
+			r_b[j] = v ? ((u32) (vdjx_mix(r_lo[j], (u64) r_hi[j]) >> shift) & mask) : NONE32;
+		}
+#pragma unroll
+		for (u32 j = 0; j < PER; j++) if (r_b[j] != NONE32) atomicAdd(&cnt[r_b[j]], 1u);
 		__syncthreads();
 		part_scan(cnt, base, tmp, nbk);
 		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) {
@@ -248,11 +261,12 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_tuples(const u64* __restr
 			gbase[i] = cnt[i] ? atomicAdd(&gc[i], cnt[i]) : 0u;
 		}
 		__syncthreads();
-		for (size_t t = ts + threadIdx.x; t < te; t += PART_THREADS) {
+#pragma unroll
+		for (u32 j = 0; j < PER; j++) {
+			if (r_b[j] == NONE32) continue;
 			Tup<THI> x;
-			x.lo = i_lo[t]; x.hi = i_hi[t]; x.inst = i_inst[t];
-			const u32 b = (u32) (vdjx_mix(x.lo, (u64) x.hi) >> shift) & mask;
-			stage[atomicAdd(&cur[b], 1u)] = x;
+			x.lo = r_lo[j]; x.hi = r_hi[j]; x.inst = r_inst[j];
+			stage[atomicAdd(&cur[r_b[j]], 1u)] = x;
 		}
 		__syncthreads();
 		const u32 n = base[nbk];
