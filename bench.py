@@ -211,6 +211,8 @@ def main():
         contigs_fixed = None
     my_wins = wins[rank::world]
     my_contigs = contigs_fixed[rank::world] if contigs_fixed is not None else None
+    my_wins_packed = api.Context.pack_strings(my_wins)
+    my_contigs_packed = api.Context.pack_strings(my_contigs) if my_contigs else None
 
     def gather_bytes(a):
         """all_gather of a small uint8 vector whose length differs per rank"""
@@ -238,10 +240,10 @@ def main():
         my_roots = roots[rank::world]
         ok = ctx.root_score(my_roots, args.k, args.mrs) if my_roots.shape[0] else np.zeros(0, np.uint8)
         t = lap("root_score", t)
-        valid, npairs = ctx.window_score(my_wins, args.ins)
+        valid, npairs = ctx.window_score(my_wins_packed, args.ins)
         t = lap("window_score", t)
         contigs = my_contigs if my_contigs is not None else [w[51:411] for w, v in zip(my_wins, valid) if v]
-        offs, pairs = ctx.map_emit(contigs)
+        offs, pairs = ctx.map_emit(my_contigs_packed if my_contigs_packed is not None else contigs)
         t = lap("map_emit", t)
         if world > 1:      # every rank learns every verdict (a few KB)
             ok = np.concatenate(gather_bytes(ok))

@@ -170,27 +170,29 @@ class Context:
         assert a.shape[0] == pool.n_records
         check(self.L.vdjx_read_index_build(self.h, pool.h, _p(a), _p(b), _p(c_), _p(d), n_pairs), "vdjx_read_index_build")
 
+    @staticmethod
+    def pack_strings(strings):
+        """(raw bytes, n, len) of equally long strings: pass it instead of the list to skip the per-call join/encode"""
+        n = len(strings)
+        ln = len(strings[0]) if n else 0
+        assert all(len(w) == ln for w in strings)
+        return ("".join(strings).encode(), n, ln)
+
     def window_score(self, windows, ins: int, e0: int = 52, e1: int = 411, rs: int = 35, ms: int = 48, floor: int = 1):
-        n = len(windows)
+        raw, n, ln = windows if isinstance(windows, tuple) else self.pack_strings(windows)
         if n == 0:
             return np.zeros(0, np.uint8), np.zeros(0, np.uint32)
-        ln = len(windows[0])
-        assert all(len(w) == ln for w in windows)
         cp = CovParams(e0, e1, rs, ms, ins, ins, floor)
         valid = np.zeros(n, np.uint8)
         npairs = np.zeros(n, np.uint32)
-        check(self.L.vdjx_window_score(self.h, "".join(windows).encode(), n, ln, C.byref(cp), _p(valid), _p(npairs)),
-              "vdjx_window_score")
+        check(self.L.vdjx_window_score(self.h, raw, n, ln, C.byref(cp), _p(valid), _p(npairs)), "vdjx_window_score")
         return valid, npairs
 
     def map_emit(self, contigs):
-        n = len(contigs)
+        raw, n, ln = contigs if isinstance(contigs, tuple) else self.pack_strings(contigs)
         offs = np.zeros(n + 1, np.uint64)
         if n == 0:
             return offs, np.zeros(0, PAIR_DTYPE)
-        ln = len(contigs[0])
-        assert all(len(w) == ln for w in contigs)
-        raw = "".join(contigs).encode()
         check(self.L.vdjx_map_emit(self.h, raw, n, ln, _p(offs), None), "vdjx_map_emit(count)")
         pairs = np.zeros(int(offs[n]), PAIR_DTYPE)
         check(self.L.vdjx_map_emit(self.h, raw, n, ln, _p(offs), _p(pairs)), "vdjx_map_emit")

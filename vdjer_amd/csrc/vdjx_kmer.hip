@@ -1148,15 +1148,12 @@ int stage_finish(vdjx_ctx* c, A& db, const Survivors& sv, const u32* edge_first,
 	g->has_v.resize(ns); g->has_j.resize(ns);
 	g->to_deg.resize(ns); g->from_deg.resize(ns);
 	g->to_ids.resize((size_t) ns * 4); g->from_ids.resize((size_t) ns * 4);
-	g->key_lo.resize(ns); g->key_hi.resize(ns);
 	g->kmers.resize((size_t) ns * k);
 	HIP_TRY(hipMemcpyAsync(g->first_inst.data(), no.first_inst, (size_t) ns * 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(g->gated_count.data(), no.gcnt, (size_t) ns * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(g->freq.data(), no.freq, (size_t) ns * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(g->has_v.data(), no.hv, ns, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(g->has_j.data(), no.hj, ns, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(g->key_lo.data(), no.klo, (size_t) ns * 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(g->key_hi.data(), no.khi, (size_t) ns * 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(g->kmers.data(), no.kmers, (size_t) ns * k, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(g->to_deg.data(), no.to_deg, ns, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(g->to_ids.data(), no.to_ids, (size_t) ns * 16, hipMemcpyDeviceToHost, st));

@@ -118,6 +118,54 @@ __global__ void k_seed_count(const char* __restrict__ kmers, u32 n, int k, int v
 	hit_cnt[w] = cnt;
 }
 
+// exclusive scan of cnt[n] -> pre[n+1], one 1024-thread workgroup (n up to a few million)
+__global__ __launch_bounds__(1024) void k_scan_u32(const u32* __restrict__ cnt, u32 n, u32* __restrict__ pre) {
+	__shared__ u32 part[1024];
+	const u32 per = (n + 1023) / 1024;
+	const u32 lo = threadIdx.x * per;
+	const u32 hi = lo + per < n ? lo + per : n;
+	u32 s = 0;
+	for (u32 i = lo; i < hi; i++) s += cnt[i];
+	part[threadIdx.x] = s;
+	__syncthreads();
+	for (u32 d = 1; d < 1024; d <<= 1) {
+		u32 v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+		__syncthreads();
+		part[threadIdx.x] += v;
+		__syncthreads();
+	}
+	u32 run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+	for (u32 i = lo; i < hi; i++) { pre[i] = run; run += cnt[i]; }
+	if (threadIdx.x == 1023) pre[n] = part[1023];
+}
+
+// coalesced two-level exclusive scan: per-workgroup local scan of 2048 elements + block sums
+__global__ __launch_bounds__(256) void k_scan_local(const u32* __restrict__ cnt, u32 n, u32* __restrict__ pre, u32* __restrict__ bsum) {
+	__shared__ u32 part[256];
+	const u32 base = blockIdx.x * 2048u + threadIdx.x * 8u;
+	u32 v[8], s = 0;
+#pragma unroll
+	for (int i = 0; i < 8; i++) { v[i] = base + i < n ? cnt[base + i] : 0u; s += v[i]; }
+	part[threadIdx.x] = s;
+	__syncthreads();
+	for (u32 d = 1; d < 256; d <<= 1) {
+		u32 x = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+		__syncthreads();
+		part[threadIdx.x] += x;
+		__syncthreads();
+	}
+	u32 run = part[threadIdx.x] - s;
+#pragma unroll
+	for (int i = 0; i < 8; i++) { if (base + i < n) pre[base + i] = run; run += v[i]; }
+	if (threadIdx.x == 255) bsum[blockIdx.x] = part[255];
+}
+
+__global__ void k_scan_add(u32* __restrict__ pre, u32 n, const u32* __restrict__ bpre) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) pre[i] += bpre[i / 2048u];
+	if (i == 0) pre[n] = bpre[(n + 2047u) / 2048u];
+}
+
 // one thread per (root, seed offset, hit): for every line run the (k+1) x (2k+1) DP (seq_score.c:76-116) on
 // root x line[start, start+2k), start as seq_score.c:139-146.  int8 cells, match +1 / mismatch 0 / gap -1,
 // first row and column 0; out[root] = 1 as soon as any cell >= threshold.
@@ -202,21 +250,28 @@ extern "C" int vdjx_root_score(vdjx_ctx* c, const char* kmers, size_t n, int k, 
 		vdjx_prof_scope ps(c, "k_seed_count");
 		hipLaunchKernelGGL(k_seed_count, dim3((ng + 255) / 256), dim3(256), 0, st, d_k, (u32) n, k, c->vk, c->d_seed_code, (u32) c->n_seeds, d_lo, d_cnt);
 	}
-	std::vector<u32> cnt(ng), pre(ng + 1);
-	HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt, (size_t) ng * 4, hipMemcpyDeviceToHost, st));
+	{
+		const u32 nb = (ng + 2047u) / 2048u;
+		u32 *d_bsum, *d_bpre;
+		HIP_TRY(db.alloc(&d_bsum, nb));
+		HIP_TRY(db.alloc(&d_bpre, nb + 1));
+		hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, st, d_cnt, ng, d_pre, d_bsum);
+		hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, d_bsum, nb, d_bpre);
+		hipLaunchKernelGGL(k_scan_add, dim3((ng + 255) / 256), dim3(256), 0, st, d_pre, ng, d_bpre);
+	}
+	u32 run = 0;
+	HIP_TRY(hipMemcpyAsync(&run, d_pre + ng, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
-	u64 run = 0;
-	for (u32 i = 0; i < ng; i++) { pre[i] = (u32) run; run += cnt[i]; }
-	pre[ng] = (u32) run;
-	if (run >= (1ull << 31)) { vdjx_set_error("too many seed hits in one call (%llu)", (unsigned long long) run); return VDJX_ELIMIT; }
 	c->stats["root_dp_items"] = run;
+	if (run >= (1u << 31)) { vdjx_set_error("too many seed hits in one call (%u)", run); return VDJX_ELIMIT; }
 	if (threshold <= 0) {
 		// cells of row/column 0 are 0 and are tested too (seq_score.c:103-112): any seed hit accepts
+		std::vector<u32> pre(ng + 1);
+		HIP_TRY(hipMemcpy(pre.data(), d_pre, (size_t) (ng + 1) * 4, hipMemcpyDeviceToHost));
 		for (size_t r = 0; r < n; r++) out[r] = pre[(r + 1) * stop] > pre[r * stop];
 		return VDJX_OK;
 	}
 	if (run) {
-		HIP_TRY(hipMemcpyAsync(d_pre, pre.data(), (size_t) (ng + 1) * 4, hipMemcpyHostToDevice, st));
 		vdjx_prof_scope ps(c, "k_root_dp");
 		hipLaunchKernelGGL(k_root_dp, dim3((unsigned) ((run + DP_THREADS - 1) / DP_THREADS)), dim3(DP_THREADS), 0, st, d_k, k, threshold,
 		                   d_lo, d_pre, ng, (u32) stop, (u32) run, c->d_seed_pos, c->d_vtext, c->d_line_off, (u32) c->n_lines, d_out);
