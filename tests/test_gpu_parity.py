@@ -366,3 +366,38 @@ def test_scorer_argument_errors(ctx):
     with pytest.raises(api.VdjxError):
         ctx.root_score(["A" * 35], 35, 30) if False else ctx.kmer_build(p, 51, 3, 90)   # k > 50
     p.free()
+
+
+def test_sharded_build_real_rccl_world1(ctx):
+    """The RCCL code path of the driver (async all_gather, all_to_all_single, all_reduce on device tensors) with a
+    real one-rank `nccl` process group: the most of the multi-GPU path one GPU can execute for real."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from vdjer_amd import shard, synth
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    rep = synth.make_repertoire(6, seed=43)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    pool = synth.make_reads(rep, 30000, noise_frac=0.3, seed=44, err=0.004, n_rate=0.002)
+    ref = run_both(ctx, pool, vc, jc, 35, 3, 90)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+    try:
+        p = ctx.pool_load(pool.primary, pool.secondary, 50)
+        drv = shard.ShardedHotPath(ctx, dist, dev)
+        assert drv.comm.async_ok
+        for _ in range(2):
+            g = drv.kmer_build(p, 35, 3, 90)
+            assert g.n == ref.n and g.pre_nodes == ref.pre_nodes
+            np.testing.assert_array_equal(g.first_inst, ref.first_inst)
+            np.testing.assert_array_equal(g.freq, ref.freq)
+            np.testing.assert_array_equal(g.to_ids, ref.to_ids)
+            np.testing.assert_array_equal(g.from_ids, ref.from_ids)
+        assert drv.bytes_exchanged > 0
+        p.free()
+    finally:
+        dist.destroy_process_group()

@@ -155,6 +155,7 @@ class Comm:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         backend = dist.get_backend() if hasattr(dist, "get_backend") else "native"
         self.native = backend != "gloo"
+        self.async_ok = backend == "nccl"          # real RCCL: collectives may overlap with the library's own stream
         self.on_gpu = device.type == "cuda"
         self.bytes = 0
 
@@ -246,14 +247,23 @@ class ShardedHotPath:
         stride = self.stride
         eng.begin(pool, k, mf, mq, r, G, stride)
         try:
-            # 1. replicate the packed pool (rank-major, common stride)
-            glob = []
+            # 1. replicate the packed pool (rank-major, common stride).  On RCCL the all_gathers are issued
+            #    asynchronously: they run on the communicator's stream while this rank partitions its k-mers (2.)
+            glob, pending = [], []
             for x in eng.pool_export():
                 pad = t.zeros((stride,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
                 pad[:x.shape[0]] = x
-                glob.append(cm.all_gather_cat(pad))
-            cm.sync()
-            eng.set_pool(glob)
+                if cm.async_ok:
+                    full = t.empty((G * stride,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+                    cm.sync()                     # `pad` was written on torch's stream by the library-exported copy
+                    pending.append((dist.all_gather_into_tensor(full, pad, async_op=True), pad))
+                    cm.bytes += full.numel() * full.element_size()
+                    glob.append(full)
+                else:
+                    glob.append(cm.all_gather_cat(pad))
+            if not pending:
+                cm.sync()
+            eng.set_pool(glob)        # pointers only; the first consumer is reduce() in step 4
             # 2./3. partition by owner, then the exchange step: counts, then the tuple columns
             send_counts = eng.partition_count()
             sc = t.tensor(send_counts, dtype=t.int64, device=self.dev)
@@ -266,8 +276,10 @@ class ShardedHotPath:
             ins, outs = [int(v) for v in send_counts], [int(v) for v in recv_counts]
             for s_, r_ in zip(send, recv):
                 cm.all_to_all_v(s_, ins, r_, outs)
+            for h_, _pad in pending:
+                h_.wait()
             cm.sync()
-            del send
+            del send, pending
             # 4. owners reduce and prune
             ns, ndist = eng.reduce(recv)
             meta = cm.all_gather_cat(t.tensor([[ns, ndist]], dtype=t.int64, device=self.dev)).cpu().numpy()
