@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <numeric>
 #include <string.h>
+#include <stdlib.h>
 
 #define HIST_THREADS 1024
 #define K3_THREADS 512
@@ -843,10 +844,16 @@ struct Survivors {
 
 struct Edges { u32* first = nullptr; u32* to = nullptr; };
 
+size_t tune(const char* name, size_t dflt) {      // undocumented tuning knobs for experiments (profiles/README.md)
+	const char* v = getenv(name);
+	return v && atol(v) > 0 ? (size_t) atol(v) : dflt;
+}
+
 u32 choose_nb_bits(size_t NI) {
 	// ~2048 instances per bucket, at most 2^15 buckets (128 KB LDS histogram)
+	static const size_t per = tune("VDJX_BUCKET_TUPLES", 2048);
 	u32 nb_bits = 8;
-	while (nb_bits < 15 && ((size_t) 2048 << nb_bits) < NI) nb_bits++;
+	while (nb_bits < 15 && (per << nb_bits) < NI) nb_bits++;
 	return nb_bits;
 }
 
@@ -920,7 +927,7 @@ int stage_partition_fill(vdjx_ctx* c, A& db, const vdjx_pool* pool, u32 rec_base
 	if (g.fbits) {
 		u32* gcur2;
 		HIP_TRY(db.alloc(&gcur2, pp.NB));
-		const u32 slices = 4;
+		static const u32 slices = (u32) tune("VDJX_PART_SLICES", 8);
 		vdjx_prof_scope ps(c, "k_part_tuples");
 		hipLaunchKernelGGL(k_init_cursors, dim3((pp.NB + 255) / 256), dim3(256), 0, st, pp.bucket_start, pp.NB, 0u, gcur2);
 		hipLaunchKernelGGL(k_part_tuples<THI>, dim3(NBc * slices), dim3(PART_THREADS), PART_LDS_BYTES, st, l1_lo, l1_hi, l1_inst,

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_hits(ReadIndexDev ix, co
 //    pairs (stored once in a scratch list) for every batch, prefixes, and tests.
 // ----------------------------------------------------------------------------------------------
 #define COV_WORDS 8192
-#define HIT_CHUNK 8192u          // hits per workgroup of k_window_pairs: deep windows are spread over many CUs
+#define HIT_CHUNK 65536u         // hits per workgroup of k_window_pairs: the deepest windows are split, the rest pay one preparation
 
 // K8: mapped pairs of a slice of a window's hits, appended (any order) to the window's pair list
 __global__ __launch_bounds__(MAP_THREADS) void k_window_pairs(ReadIndexDev ix, const char* __restrict__ windows, int len,
@@ -948,8 +948,9 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 		std::stable_sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
 		for (u32 wi : ord) {
 			const u32 H = (u32) (off[wi + 1] - off[wi]);
-			for (u32 h0 = 0; h0 < H || h0 == 0; h0 += HIT_CHUNK) {
-				work.push_back(make_uint4(wi, h0, std::min(H, h0 + HIT_CHUNK), 0));
+			static const u32 hit_chunk = getenv("VDJX_HIT_CHUNK") && atol(getenv("VDJX_HIT_CHUNK")) > 0 ? (u32) atol(getenv("VDJX_HIT_CHUNK")) : HIT_CHUNK;
+			for (u32 h0 = 0; h0 < H || h0 == 0; h0 += hit_chunk) {
+				work.push_back(make_uint4(wi, h0, std::min(H, h0 + hit_chunk), 0));
 				if (H == 0) break;
 			}
 		}
