@@ -604,20 +604,31 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 // ----------------------------------------------------------------------------------------------
 // K5: survivor lookup table, edges, V/J flags
 // ----------------------------------------------------------------------------------------------
-__global__ void k_surv_table(const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, u32 n, u32* __restrict__ table, u32 mask) {
+// table entry = 8-bit fingerprint of the key's hash | (survivor index + 1): a foreign key in the probed slot is almost
+// always rejected without touching the key array, and a match costs ONE 16-byte load of the interleaved key
+__global__ void k_surv_table(const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, u32 n, u32* __restrict__ table, u32 mask,
+                             ulonglong2* __restrict__ skey) {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	u32 slot = (u32) (vdjx_mix(s_lo[i], s_hi[i]) >> 20) & mask;
-	while (atomicCAS(&table[slot], 0u, i + 1) != 0u) slot = (slot + 1) & mask;
+	const u64 lo = s_lo[i], hi = s_hi[i];
+	skey[i] = make_ulonglong2(lo, hi);
+	const u64 h = vdjx_mix(lo, hi);
+	u32 slot = (u32) (h >> 20) & mask;
+	const u32 entry = ((u32) (h >> 12) << 24) | (i + 1);
+	while (atomicCAS(&table[slot], 0u, entry) != 0u) slot = (slot + 1) & mask;
 }
 
-__device__ inline int surv_lookup(const u32* __restrict__ table, u32 mask, const u64* __restrict__ s_lo,
-                                  const u64* __restrict__ s_hi, u64 lo, u64 hi) {
-	u32 slot = (u32) (vdjx_mix(lo, hi) >> 20) & mask;
+__device__ inline int surv_lookup(const u32* __restrict__ table, u32 mask, const ulonglong2* __restrict__ skey, u64 lo, u64 hi) {
+	const u64 h = vdjx_mix(lo, hi);
+	u32 slot = (u32) (h >> 20) & mask;
+	const u32 fp = (u32) (h >> 12) & 0xFFu;
 	for (;;) {
-		u32 v = table[slot];
+		const u32 v = table[slot];
 		if (!v) return -1;
-		if (s_lo[v - 1] == lo && s_hi[v - 1] == hi) return (int) (v - 1);
+		if ((v >> 24) == fp) {
+			const ulonglong2 kk = skey[(v & 0xFFFFFFu) - 1];
+			if (kk.x == lo && kk.y == hi) return (int) ((v & 0xFFFFFFu) - 1);
+		}
 		slot = (slot + 1) & mask;
 	}
 }
@@ -625,7 +636,7 @@ __device__ inline int surv_lookup(const u32* __restrict__ table, u32 mask, const
 // add_to_graph's edge bookkeeping (A2:311-318, link_nodes A2:223-237): an edge prev->curr exists when two
 // adjacent offsets of one record both survive; list order is by first sight, so keep the minimum instance.
 __global__ void k_graph_edges(const u64* __restrict__ bases, const u64* __restrict__ nmask, size_t R, u32 rec_base, int rl, int k,
-                              const u32* __restrict__ table, u32 mask, const u64* __restrict__ s_lo, const u64* __restrict__ s_hi,
+                              const u32* __restrict__ table, u32 mask, const ulonglong2* __restrict__ skey,
                               u32* __restrict__ edge_first, u32* __restrict__ edge_to) {
 	size_t r = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= R) return;
@@ -637,7 +648,7 @@ __global__ void k_graph_edges(const u64* __restrict__ bases, const u64* __restri
 		if ((v.nm >> o) & km) { prev = -1; continue; }
 		u64 khi, klo;
 		vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
-		int s = surv_lookup(table, mask, s_lo, s_hi, klo, khi);
+		int s = surv_lookup(table, mask, skey, klo, khi);
 		if (s >= 0 && prev >= 0) {
 			const u32 e = (u32) prev * 4u + (u32) (klo & 3ull);
 			const u32 inst = (u32) ((rec_base + r) * (size_t) P + (size_t) o);
@@ -1091,19 +1102,22 @@ int stage_edges(vdjx_ctx* c, A& db, const vdjx_pool* pool, u32 rec_base, int k, 
 	const u32 ns = sv.n;
 	u32 tmask = 1023;
 	while ((size_t) tmask + 1 < (size_t) ns * 2) tmask = tmask * 2 + 1;
+	if (ns >= (1u << 24) - 1) { vdjx_set_error("more than 16M surviving k-mers: not supported by the survivor table"); return VDJX_ELIMIT; }
 	u32* table;
+	ulonglong2* skey;
 	HIP_TRY(db.alloc(&table, (size_t) tmask + 1));
+	HIP_TRY(db.alloc(&skey, ns));
 	HIP_TRY(hipMemsetAsync(table, 0, ((size_t) tmask + 1) * 4, st));
 	HIP_TRY(hipMemsetAsync(edge_first, 0xFF, (size_t) ns * 16, st));
 	HIP_TRY(hipMemsetAsync(edge_to, 0xFF, (size_t) ns * 16, st));
 	{
 		vdjx_prof_scope ps(c, "k_surv_table");
-		hipLaunchKernelGGL(k_surv_table, dim3((ns + 255) / 256), dim3(256), 0, st, sv.lo, sv.hi, ns, table, tmask);
+		hipLaunchKernelGGL(k_surv_table, dim3((ns + 255) / 256), dim3(256), 0, st, sv.lo, sv.hi, ns, table, tmask, skey);
 	}
 	if (pool->n_records) {
 		vdjx_prof_scope ps(c, "k_graph_edges");
 		hipLaunchKernelGGL(k_graph_edges, dim3((unsigned) ((pool->n_records + 255) / 256)), dim3(256), 0, st, pool->d_bases, pool->d_nmask,
-		                   pool->n_records, rec_base, pool->rl, k, table, tmask, sv.lo, sv.hi, edge_first, edge_to);
+		                   pool->n_records, rec_base, pool->rl, k, table, tmask, skey, edge_first, edge_to);
 	}
 	return VDJX_OK;
 }
