@@ -633,11 +633,26 @@ __device__ inline int surv_lookup(const u32* __restrict__ table, u32 mask, const
 	}
 }
 
+// successor links of the survivor graph: link[u*4+b] = {survivor index of (key_u << 2 | b) mod 4^k or NONE, first sight}.
+// 4 hash probes per SURVIVOR, instead of one per instance: along a record, once a k-mer is a survivor the status of the
+// next offset is one 8-byte load of its link.
+__global__ void k_succ_links(const ulonglong2* __restrict__ skey, u32 n, int k, const u32* __restrict__ table, u32 mask,
+                             uint2* __restrict__ link) {
+	u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n * 4u) return;
+	const ulonglong2 kk = skey[e >> 2];
+	u128 key = (((u128) kk.y << 64) | kk.x);
+	key = (key << 2) | (u128) (e & 3u);
+	if (k < 64) key &= (((u128) 1) << (2 * k)) - 1;
+	const int s = surv_lookup(table, mask, skey, (u64) key, (u64) (key >> 64));
+	link[e] = make_uint2(s >= 0 ? (u32) s : NONE32, NONE32);
+}
+
 // add_to_graph's edge bookkeeping (A2:311-318, link_nodes A2:223-237): an edge prev->curr exists when two
 // adjacent offsets of one record both survive; list order is by first sight, so keep the minimum instance.
 __global__ void k_graph_edges(const u64* __restrict__ bases, const u64* __restrict__ nmask, size_t R, u32 rec_base, int rl, int k,
                               const u32* __restrict__ table, u32 mask, const ulonglong2* __restrict__ skey,
-                              u32* __restrict__ edge_first, u32* __restrict__ edge_to) {
+                              uint2* __restrict__ link) {
 	size_t r = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= R) return;
 	const int P = rl - k + 1;
@@ -646,20 +661,35 @@ __global__ void k_graph_edges(const u64* __restrict__ bases, const u64* __restri
 	int prev = -1;
 	for (int o = 0; o < P; o++) {
 		if ((v.nm >> o) & km) { prev = -1; continue; }
-		u64 khi, klo;
-		vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
-		int s = surv_lookup(table, mask, skey, klo, khi);
-		if (s >= 0 && prev >= 0) {
-			const u32 e = (u32) prev * 4u + (u32) (klo & 3ull);
-			const u32 inst = (u32) ((rec_base + r) * (size_t) P + (size_t) o);
-			// first sights only ever decrease: a (possibly stale) plain read that is already smaller needs no atomic
-			if (edge_first[e] > inst) {
-				atomicMin(&edge_first[e], inst);
-				edge_to[e] = (u32) s;
+		int s;
+		if (prev >= 0) {
+			// the k-mer at o is the successor of the (surviving) k-mer at o-1 by its last base
+			const int bsh = 2 * (rl - k - o);                 // last base of the k-mer at o (may sit in the high word)
+			const u32 b = (u32) (bsh < 64 ? v.blo >> bsh : v.bhi >> (bsh - 64)) & 3u;
+			const u32 e = (u32) prev * 4u + b;
+			const uint2 lk = link[e];
+			s = lk.x == NONE32 ? -1 : (int) lk.x;
+			if (s >= 0) {
+				const u32 inst = (u32) ((rec_base + r) * (size_t) P + (size_t) o);
+				// first sights only ever decrease: a (possibly stale) plain read that is already smaller needs no atomic
+				if (lk.y > inst) atomicMin(&link[e].y, inst);
 			}
+		} else {
+			u64 khi, klo;
+			vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
+			s = surv_lookup(table, mask, skey, klo, khi);
 		}
 		prev = s;
 	}
+}
+
+// links -> the two arrays the rest of the build (and the multi-GPU reduction) works on
+__global__ void k_links_split(const uint2* __restrict__ link, u32 n4, u32* __restrict__ edge_first, u32* __restrict__ edge_to) {
+	u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n4) return;
+	const uint2 lk = link[e];
+	edge_first[e] = lk.y;
+	edge_to[e] = lk.y == NONE32 ? NONE32 : lk.x;
 }
 
 // A2:288-303: has_vmer/has_jmer from the code of the node's first 16 bases
@@ -1108,17 +1138,19 @@ int stage_edges(vdjx_ctx* c, A& db, const vdjx_pool* pool, u32 rec_base, int k, 
 	HIP_TRY(db.alloc(&table, (size_t) tmask + 1));
 	HIP_TRY(db.alloc(&skey, ns));
 	HIP_TRY(hipMemsetAsync(table, 0, ((size_t) tmask + 1) * 4, st));
-	HIP_TRY(hipMemsetAsync(edge_first, 0xFF, (size_t) ns * 16, st));
-	HIP_TRY(hipMemsetAsync(edge_to, 0xFF, (size_t) ns * 16, st));
+	uint2* link;
+	HIP_TRY(db.alloc(&link, (size_t) ns * 4));
 	{
 		vdjx_prof_scope ps(c, "k_surv_table");
 		hipLaunchKernelGGL(k_surv_table, dim3((ns + 255) / 256), dim3(256), 0, st, sv.lo, sv.hi, ns, table, tmask, skey);
+		hipLaunchKernelGGL(k_succ_links, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, skey, ns, k, table, tmask, link);
 	}
 	if (pool->n_records) {
 		vdjx_prof_scope ps(c, "k_graph_edges");
 		hipLaunchKernelGGL(k_graph_edges, dim3((unsigned) ((pool->n_records + 255) / 256)), dim3(256), 0, st, pool->d_bases, pool->d_nmask,
-		                   pool->n_records, rec_base, pool->rl, k, table, tmask, skey, edge_first, edge_to);
+		                   pool->n_records, rec_base, pool->rl, k, table, tmask, skey, link);
 	}
+	hipLaunchKernelGGL(k_links_split, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, link, ns * 4, edge_first, edge_to);
 	return VDJX_OK;
 }
 
