@@ -99,8 +99,8 @@ def cpu_baseline(rep, vc, jc, wins, n_sample: int, k: int, mf: int, mq: int, ins
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=1_000_000, help="pairs per GPU")
     ap.add_argument("--clones", type=int, default=2000)
     ap.add_argument("--k", type=int, default=35)
@@ -119,6 +119,16 @@ def main():
 
     import torch
     import torch.distributed as dist
+
+    # the step hands ~25 MB of results to the host (graph arrays, mapped pairs); with glibc's default mmap threshold
+    # every such buffer is a fresh mapping (page faults + munmap per step).  Keep them on the heap instead.
+    try:
+        import ctypes
+        _libc = ctypes.CDLL(None)
+        _libc.mallopt(-3, 1 << 30)      # M_MMAP_THRESHOLD
+        _libc.mallopt(-1, 1 << 30)      # M_TRIM_THRESHOLD
+    except Exception:  # noqa: BLE001
+        pass
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -265,12 +275,16 @@ def main():
     ctx.profile(True)
     ctx.profile_reset()
     wall.clear()
+    import gc
+    gc.collect()
+    gc.disable()                       # no collector pauses inside the timed region
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     prof = ctx.profile_get()
     ctx.profile(False)
     stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_pairs", "window_work_items", "map_hits", "root_dp_items")}
