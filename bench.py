@@ -155,7 +155,7 @@ def main():
 
     rep, pool, vc, jc, wins = make_workload(args.pairs, args.clones, args.seed, rank)
     rl = pool.rl
-    ctx = api.Context(local_rank)
+    ctx = api.Context(local_rank, pinned_results=True)
     ctx.anchor_sets_load(vc, jc)
     ctx.vregion_load([rep.v_region], 15)
     d_pri = torch.from_numpy(pool.primary).to(dev)
@@ -242,13 +242,13 @@ def main():
         p = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
         t = lap("pool_pack", t)
         if engine is None:
-            g = ctx.kmer_build(p, args.k, args.mf, args.mq)
+            g = ctx.kmer_build(p, args.k, args.mf, args.mq, keep_device=True)
         else:
-            g = engine.kmer_build(p, args.k, args.mf, args.mq)
+            g = engine.kmer_build(p, args.k, args.mf, args.mq, keep_device=True)
         t = lap("kmer_build", t)
-        roots = g.kmers[g.from_deg == 0]
-        my_roots = roots[rank::world]
-        ok = ctx.root_score(my_roots, args.k, args.mrs) if my_roots.shape[0] else np.zeros(0, np.uint8)
+        # every root of the graph (nodes without predecessor), scored where the graph lives; rank r takes roots r, r+world, ...
+        root_ids, ok = ctx.root_score_graph(g, args.mrs, rank, world)
+        g.free()
         t = lap("root_score", t)
         valid, npairs = ctx.window_score(my_wins_packed, args.ins)
         t = lap("window_score", t)
@@ -259,7 +259,7 @@ def main():
             ok = np.concatenate(gather_bytes(ok))
             valid = np.concatenate(gather_bytes(valid))
             t = lap("gather_results", t)
-        state.update(nodes=g.n, pre=g.pre_nodes, roots=int(roots.shape[0]), roots_ok=int(ok.sum()), windows=len(wins),
+        state.update(nodes=g.n, pre=g.pre_nodes, roots=int(g.n_roots), roots_ok=int(ok.sum()), windows=len(wins),
                      valid=int(valid.sum()), contigs=len(contigs) if world == 1 else None, mapped_this_rank=int(pairs.shape[0]),
                      window_pairs_this_rank=int(npairs.sum()), n_contigs_rank=len(contigs), graph=g)
         p.free()

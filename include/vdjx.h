@@ -87,6 +87,13 @@ int vdjx_graph_export(const vdjx_graph* g, uint64_t* first_inst, uint32_t* gated
                       uint8_t* from_deg, uint32_t* from_ids, char* kmers);
 void vdjx_graph_free(vdjx_graph* g);
 
+/* ---- result buffers ------------------------------------------------------------------------------
+ * Every result pointer of this interface may be ordinary host memory.  Memory from vdjx_host_alloc is
+ * page-locked: copies into it run at DMA speed (the graph of 1 M pairs is ~11 MB, the mapped pairs ~11 MB).
+ * No counterpart in the reference (its tables are host memory throughout).                          */
+int vdjx_host_alloc(vdjx_ctx* ctx, size_t bytes, void** out);
+void vdjx_host_free(vdjx_ctx* ctx, void* p);
+
 /* ---- a-7: root (V-region homology) scorer ------------------------------------------------------
  * replaces: score_seq_init(k, 1000, v_region.fa) (seq_score.c:50-70) and score_seq(kmer, thr)
  * (seq_score.c:118-158) as called per root by worker_thread (A2:1103).
@@ -94,6 +101,15 @@ void vdjx_graph_free(vdjx_graph* g);
 int vdjx_vregion_load(vdjx_ctx* ctx, const char* const* lines, size_t n_lines, int vk);
 /* kmers: n*k ASCII; out[i] = 0|1 */
 int vdjx_root_score(vdjx_ctx* ctx, const char* kmers, size_t n, int k, int threshold, uint8_t* out);
+/* The same scorer over the roots of a graph that is still on the device (identify_root_nodes, A2:653-676: the nodes
+ * without predecessor), so that root k-mers never travel to the host and back.  vdjx_graph_roots = their number;
+ * roots are taken in ascending node id, this call handles the ones at positions first, first+stride, ...
+ * (vdjx_root_part of them: one call with (0,1) on one GPU, (rank,nranks) when sharded).
+ * root_ids[i] = 1-based node id, out[i] = 0|1.                                                    */
+size_t vdjx_graph_roots(const vdjx_graph* g);
+size_t vdjx_root_part(const vdjx_graph* g, uint32_t first, uint32_t stride);
+int vdjx_root_score_graph(vdjx_ctx* ctx, const vdjx_graph* g, int threshold, uint32_t first, uint32_t stride,
+                          uint32_t* root_ids, uint8_t* out);
 
 /* ---- a-8, a-9, a-10: read->contig mapper, coverage validator, SAM placements --------------------
  * replaces: add_read_info (quick_map3.c:126-149) for the index; quick_map_process_contig +

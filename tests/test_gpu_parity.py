@@ -159,6 +159,59 @@ def test_root_score_vs_oracle_multiline(ctx):
         assert got.tolist() == [s.score(q, thr) for q in qs]
 
 
+@pytest.mark.parametrize("k,thr", [(35, 30), (25, 20), (35, 0)])
+def test_root_score_graph_on_device(ctx, k, thr):
+    """roots taken from the device-resident graph == roots of the exported graph pushed through vdjx_root_score == oracle"""
+    from oracle import oracle
+    c = G.Case("noisy")
+    ctx.anchor_sets_load(c.v_codes, c.j_codes)
+    ctx.vregion_load([c.v_region], 15)
+    p = ctx.pool_load(c.pool.primary, c.pool.secondary, c.pool.rl)
+    g = ctx.kmer_build(p, k, 3 if k == 35 else 2, 90 if k == 35 else 60, keep_device=True)
+    p.free()
+    want_ids = np.flatnonzero(g.from_deg == 0) + 1
+    assert g.n_roots == want_ids.shape[0] > 0
+    ids, ok = ctx.root_score_graph(g, thr)
+    assert ids.tolist() == want_ids.tolist()
+    assert ok.tolist() == ctx.root_score(g.kmers[want_ids - 1], k, thr).tolist()
+    sc = oracle.RootScorer([c.v_region], 15)
+    assert ok.tolist() == [sc.score(g.kmer(int(i) - 1), thr) for i in ids]
+    # strided parts (what rank r of `world` ranks scores) tile the whole list
+    parts = [ctx.root_score_graph(g, thr, r, 3) for r in range(3)]
+    merged = np.zeros(g.n_roots, np.uint8)
+    for r, (pi, po) in enumerate(parts):
+        assert pi.tolist() == want_ids[r::3].tolist()
+        merged[r::3] = po
+    assert merged.tolist() == ok.tolist()
+    g.free()
+    with pytest.raises(Exception):
+        ctx.root_score_graph(g, thr)
+
+
+def test_pinned_result_buffers():
+    """results delivered into page-locked buffers (vdjx_host_alloc) are the same bytes"""
+    from vdjer_amd import api
+    c = G.Case("noisy")
+    a, b = api.Context(0), api.Context(0, pinned_results=True)
+    try:
+        out = []
+        for cx in (a, b):
+            cx.anchor_sets_load(c.v_codes, c.j_codes)
+            p = cx.pool_load(c.pool.primary, c.pool.secondary, c.pool.rl)
+            g1 = cx.kmer_build(p, 35, 3, 90)
+            snap = [np.array(x) for x in (g1.first_inst, g1.gated_count, g1.freq, g1.has_v, g1.has_j, g1.to_deg, g1.to_ids,
+                                          g1.from_deg, g1.from_ids, g1.kmers)]
+            g2 = cx.kmer_build(p, 25, 2, 60)     # reuses (pinned) or reallocates the result buffers
+            assert g2.n != g1.n
+            p.free()
+            out.append(snap)
+        for x, y in zip(*out):
+            assert np.array_equal(x, y)
+    finally:
+        a.close()
+        b.close()
+
+
 def test_anchor_probe(ctx):
     from vdjer_amd import synth
     c = G.Case("noisy")

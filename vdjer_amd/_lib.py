@@ -16,8 +16,9 @@ SYMBOLS = [
     "vdjx_pool_load", "vdjx_pool_load_device", "vdjx_pool_records", "vdjx_pool_free",
     "vdjx_anchor_sets_load", "vdjx_anchor_probe",
     "vdjx_kmer_build", "vdjx_graph_nodes", "vdjx_graph_pre_nodes", "vdjx_graph_export", "vdjx_graph_free",
-    "vdjx_vregion_load", "vdjx_root_score",
+    "vdjx_vregion_load", "vdjx_root_score", "vdjx_graph_roots", "vdjx_root_part", "vdjx_root_score_graph",
     "vdjx_read_index_build", "vdjx_window_score", "vdjx_map_emit",
+    "vdjx_host_alloc", "vdjx_host_free",
     "vdjx_stat", "vdjx_profile_enable", "vdjx_profile_reset", "vdjx_profile_count", "vdjx_profile_get",
     "vdjx_shard_begin", "vdjx_shard_free", "vdjx_shard_qstride", "vdjx_shard_key_hi_bytes", "vdjx_shard_pool_export",
     "vdjx_shard_set_pool", "vdjx_shard_partition_count", "vdjx_shard_partition_fill", "vdjx_shard_reduce",
@@ -88,6 +89,14 @@ def lib():
     L.vdjx_read_index_build.argtypes = [vp, vp, vp, vp, vp, vp, u32]
     L.vdjx_window_score.argtypes = [vp, C.c_char_p, sz, i32, C.POINTER(CovParams), vp, vp]
     L.vdjx_map_emit.argtypes = [vp, C.c_char_p, sz, i32, vp, vp]
+    L.vdjx_graph_roots.argtypes = [vp]
+    L.vdjx_graph_roots.restype = C.c_size_t
+    L.vdjx_root_part.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.vdjx_root_part.restype = C.c_size_t
+    L.vdjx_root_score_graph.argtypes = [vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
+    L.vdjx_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.vdjx_host_free.argtypes = [vp, vp]
+    L.vdjx_host_free.restype = None
     L.vdjx_stat.argtypes = [vp, C.c_char_p]
     L.vdjx_stat.restype = C.c_uint64
     L.vdjx_profile_enable.argtypes = [vp, i32]

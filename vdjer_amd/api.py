@@ -46,9 +46,23 @@ class Graph:
     from_deg: np.ndarray
     from_ids: np.ndarray
     kmers: np.ndarray        # [n, k] uint8 ASCII
+    n_roots: int = 0
+    handle: object = None    # the device-resident graph (kept only with keep_device=True); free() releases it
+    ctx: object = None
 
     def kmer(self, i: int) -> str:
         return self.kmers[i].tobytes().decode()
+
+    def free(self):
+        if self.handle is not None:
+            _lib.lib().vdjx_graph_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Pool:
@@ -70,19 +84,49 @@ class Pool:
 
 
 class Context:
-    def __init__(self, device: int = 0):
+    """pinned_results=True: result arrays (graph export, mapped pairs) are views of page-locked buffers owned by the context
+    and REUSED by the next call of the same kind — the way a C caller keeps one set of result buffers per stage."""
+
+    def __init__(self, device: int = 0, pinned_results: bool = False):
         self.L = _lib.lib()
         h = C.c_void_p()
         check(self.L.vdjx_init(device, C.byref(h)), "vdjx_init")
         self.h = h
         self.device = device
         self._pools = []
+        self.pinned_results = pinned_results
+        self._pinned = {}            # tag -> (ptr, capacity bytes)
+
+    def _result_arrays(self, tag: str, specs):
+        """specs: [(shape, dtype)] -> zero-copy numpy arrays; pinned and recycled per `tag` when pinned_results is set"""
+        if not self.pinned_results:
+            return [np.zeros(shape, dt) for shape, dt in specs]
+        sizes = [int(np.prod(shape)) * np.dtype(dt).itemsize for shape, dt in specs]
+        need = sum((b + 255) & ~255 for b in sizes) + 256
+        ptr, cap = self._pinned.get(tag, (None, 0))
+        if cap < need:
+            if ptr:
+                self.L.vdjx_host_free(self.h, ptr)
+            new = C.c_void_p()
+            cap = need + need // 4
+            check(self.L.vdjx_host_alloc(self.h, cap, C.byref(new)), "vdjx_host_alloc")
+            ptr = new.value
+            self._pinned[tag] = (ptr, cap)
+        out, at = [], ptr
+        for (shape, dt), b in zip(specs, sizes):
+            raw = (C.c_uint8 * max(b, 1)).from_address(at)
+            out.append(np.frombuffer(raw, dtype=dt, count=int(np.prod(shape))).reshape(shape))
+            at += (b + 255) & ~255
+        return out
 
     def close(self):
         for p in list(getattr(self, "_pools", [])):
             p.free()
         self._pools = []
         if getattr(self, "h", None):
+            for ptr, _ in getattr(self, "_pinned", {}).values():
+                self.L.vdjx_host_free(self.h, ptr)
+            self._pinned = {}
             self.L.vdjx_shutdown(self.h)
             self.h = None
 
@@ -128,23 +172,34 @@ class Context:
         return ov, oj
 
     # ---- a-1..a-3
-    def kmer_build(self, pool: Pool, k: int = 35, mf: int = 3, mq: int = 90, export: bool = True):
+    def kmer_build(self, pool: Pool, k: int = 35, mf: int = 3, mq: int = 90, export: bool = True, keep_device: bool = False):
         g = C.c_void_p()
         check(self.L.vdjx_kmer_build(self.h, pool.h, k, mf, mq, C.byref(g)), "vdjx_kmer_build")
+        if not export:
+            try:
+                return int(self.L.vdjx_graph_nodes(g)), int(self.L.vdjx_graph_pre_nodes(g))
+            finally:
+                self.L.vdjx_graph_free(g)
+        return self._export_graph(g, k, keep_device)
+
+    def _export_graph(self, g, k: int, keep_device: bool = False) -> Graph:
+        """copy a finished graph into host arrays; the handle is released unless keep_device (then Graph.free() does it)"""
+        keep = False
         try:
             n = int(self.L.vdjx_graph_nodes(g))
-            pre = int(self.L.vdjx_graph_pre_nodes(g))
-            if not export:
-                return n, pre
-            out = Graph(k, n, pre, np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint32),
-                        np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros((n, 4), np.uint32),
-                        np.zeros(n, np.uint8), np.zeros((n, 4), np.uint32), np.zeros((n, k), np.uint8))
+            out = Graph(k, n, int(self.L.vdjx_graph_pre_nodes(g)), *self._result_arrays("graph", [
+                ((n,), np.uint64), ((n,), np.uint32), ((n,), np.uint32), ((n,), np.uint8), ((n,), np.uint8), ((n,), np.uint8),
+                ((n, 4), np.uint32), ((n,), np.uint8), ((n, 4), np.uint32), ((n, k), np.uint8)]),
+                n_roots=int(self.L.vdjx_graph_roots(g)))
             check(self.L.vdjx_graph_export(g, _p(out.first_inst), _p(out.gated_count), _p(out.freq), _p(out.has_v),
                                            _p(out.has_j), _p(out.to_deg), _p(out.to_ids), _p(out.from_deg),
                                            _p(out.from_ids), _p(out.kmers)), "vdjx_graph_export")
+            if keep_device:
+                out.handle, out.ctx, keep = g, self, True
             return out
         finally:
-            self.L.vdjx_graph_free(g)
+            if not keep:
+                self.L.vdjx_graph_free(g)
 
     # ---- a-7
     def vregion_load(self, lines, vk: int = 15) -> None:
@@ -163,6 +218,16 @@ class Context:
         out = np.zeros(n, np.uint8)
         check(self.L.vdjx_root_score(self.h, raw, n, k, threshold, _p(out)), "vdjx_root_score")
         return out
+
+    def root_score_graph(self, graph: Graph, threshold: int, first: int = 0, stride: int = 1):
+        """scores the roots of a device-resident graph (kmer_build(..., keep_device=True)): (1-based node ids, verdicts)"""
+        if graph.handle is None:
+            raise VdjxError("root_score_graph: the graph was not kept on the device (keep_device=True)")
+        n = int(self.L.vdjx_root_part(graph.handle, first, stride))
+        ids = np.zeros(n, np.uint32)
+        out = np.zeros(n, np.uint8)
+        check(self.L.vdjx_root_score_graph(self.h, graph.handle, threshold, first, stride, _p(ids), _p(out)), "vdjx_root_score_graph")
+        return ids, out
 
     # ---- a-8..a-10
     def read_index_build(self, pool: Pool, pair_id, read_num, is_rc, reg_rank, n_pairs: int) -> None:
@@ -194,7 +259,7 @@ class Context:
         if n == 0:
             return offs, np.zeros(0, PAIR_DTYPE)
         check(self.L.vdjx_map_emit(self.h, raw, n, ln, _p(offs), None), "vdjx_map_emit(count)")
-        pairs = np.zeros(int(offs[n]), PAIR_DTYPE)
+        pairs, = self._result_arrays("pairs", [((int(offs[n]),), PAIR_DTYPE)])
         check(self.L.vdjx_map_emit(self.h, raw, n, ln, _p(offs), _p(pairs)), "vdjx_map_emit")
         return offs, pairs
 

@@ -54,9 +54,20 @@ struct vdjx_arena {
 
 struct vdjx_shard;
 
+// device blocks that outlive a call (packed pools, exported graphs): freed blocks are kept for the next call of the
+// same size class instead of going back to hipFree (which synchronises the device)
+struct vdjx_block_cache {
+	struct blk { char* p; size_t cap; };
+	std::vector<blk> free_list;
+	hipError_t acquire(size_t need, char** out, size_t* cap);
+	void release(char* p, size_t cap);
+	void drop();
+};
+
 struct vdjx_ctx {
 	int device = 0;
 	vdjx_arena arena;
+	vdjx_block_cache blocks;
 	vdjx_arena shard_arena;            // lives across the phases of one sharded build
 	vdjx_shard* live_shard = nullptr;
 	hipStream_t stream = nullptr;
@@ -105,22 +116,31 @@ struct vdjx_pool {
 	size_t n_primary = 0, n_records = 0;
 	int rl = 0;
 	int qstride = 0;
+	char* d_block = nullptr;     // one device block holds the four arrays below
+	size_t block_cap = 0;
 	u64* d_bases = nullptr;      // [R][2]  (hi, lo) of the 2*rl-bit read, first base most significant
 	u64* d_nmask = nullptr;      // [R] bit i = base i is not ACGT
 	u64* d_lowq = nullptr;       // [R] bit i = (uint8)(q-33) < 20
 	uint8_t* d_quals = nullptr;  // [R][qstride] Phred+33 characters
 };
 
+// the finished graph stays on the device until vdjx_graph_export copies it straight into the caller's arrays
 struct vdjx_graph {
+	vdjx_ctx* ctx = nullptr;
+	int device = 0;
 	int k = 0;
 	size_t n = 0, pre_nodes = 0;
-	std::vector<uint64_t> first_inst;
-	std::vector<uint32_t> gated_count, freq;
-	std::vector<uint8_t> has_v, has_j, to_deg, from_deg;
-	std::vector<uint32_t> to_ids, from_ids;
-	std::vector<u64> key_lo, key_hi;
-	std::vector<char> kmers;         // n*k ASCII
+	char* d_block = nullptr;
+	size_t block_cap = 0;
+	u64* d_first_inst = nullptr;
+	u32 *d_gcnt = nullptr, *d_freq = nullptr, *d_to_ids = nullptr, *d_from_ids = nullptr;
+	uint8_t *d_hv = nullptr, *d_hj = nullptr, *d_to_deg = nullptr, *d_from_deg = nullptr;
+	char* d_kmers = nullptr;         // n*k ASCII
+	u32* d_roots = nullptr;          // 0-based indices of the nodes without predecessor, ascending
+	size_t n_roots = 0;
 };
+
+bool vdjx_ctx_alive(const vdjx_ctx* c);   // a pool or graph may be freed after its context
 
 // scoped workspace allocations out of the context's arena
 struct vdjx_work {

@@ -4,6 +4,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
+#include <set>
 
 // ----------------------------------------------------------------------------------------------
 // errors
@@ -23,6 +25,14 @@ extern "C" const char* vdjx_version(void) { return "vdjx 0.1 (gfx950)"; }
 // ----------------------------------------------------------------------------------------------
 // context
 // ----------------------------------------------------------------------------------------------
+// ---- live contexts (pools and graphs may outlive theirs) and the block cache
+static std::mutex g_ctx_mu;
+static std::set<const vdjx_ctx*> g_ctx_live;
+bool vdjx_ctx_alive(const vdjx_ctx* c) {
+	std::lock_guard<std::mutex> lk(g_ctx_mu);
+	return g_ctx_live.count(c) != 0;
+}
+
 extern "C" int vdjx_init(int device, vdjx_ctx** out) {
 	if (!out) { vdjx_set_error("vdjx_init: out is NULL"); return VDJX_EINVAL; }
 	*out = nullptr;
@@ -34,11 +44,52 @@ extern "C" int vdjx_init(int device, vdjx_ctx** out) {
 	c->device = device;
 	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
 	if (e != hipSuccess) { delete c; vdjx_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return VDJX_EHIP; }
+	{
+		std::lock_guard<std::mutex> lk(g_ctx_mu);
+		g_ctx_live.insert(c);
+	}
 	*out = c;
 	return VDJX_OK;
 }
 
 static void free_dev(void* p) { if (p) (void) hipFree(p); }
+
+hipError_t vdjx_block_cache::acquire(size_t need, char** out, size_t* cap) {
+	need = (need + 4095) & ~(size_t) 4095;
+	int best = -1;
+	for (size_t i = 0; i < free_list.size(); i++)
+		if (free_list[i].cap >= need && free_list[i].cap <= 4 * need + (1u << 20) && (best < 0 || free_list[i].cap < free_list[best].cap)) best = (int) i;
+	if (best >= 0) {
+		*out = free_list[best].p; *cap = free_list[best].cap;
+		free_list.erase(free_list.begin() + best);
+		return hipSuccess;
+	}
+	const size_t want = need + need / 8;        // headroom: the next batch is rarely the same size to the byte
+	hipError_t e = hipMalloc(out, want);
+	if (e == hipSuccess) { *cap = want; return e; }
+	(void) hipGetLastError();
+	drop();                                     // memory pressure: give the cached blocks back and ask for the exact size
+	e = hipMalloc(out, need);
+	if (e == hipSuccess) *cap = need;
+	return e;
+}
+
+void vdjx_block_cache::release(char* p, size_t cap) {
+	if (!p) return;
+	if (free_list.size() >= 6) {                // evict the smallest
+		size_t m = 0;
+		for (size_t i = 1; i < free_list.size(); i++) if (free_list[i].cap < free_list[m].cap) m = i;
+		if (free_list[m].cap < cap) { (void) hipFree(free_list[m].p); free_list[m] = {p, cap}; }
+		else (void) hipFree(p);
+		return;
+	}
+	free_list.push_back({p, cap});
+}
+
+void vdjx_block_cache::drop() {
+	for (auto& b : free_list) (void) hipFree(b.p);
+	free_list.clear();
+}
 
 extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	if (!c) return;
@@ -51,6 +102,11 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	free_dev(c->d_rec_info); free_dev(c->me_pairs); free_dev(c->d_ri_cnt1);
 	c->arena.release();
 	c->shard_arena.release();
+	c->blocks.drop();
+	{
+		std::lock_guard<std::mutex> lk(g_ctx_mu);
+		g_ctx_live.erase(c);
+	}
 	for (auto& p : c->prof_pending) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
 	(void) hipStreamDestroy(c->stream);
 	delete c;
@@ -236,16 +292,19 @@ static int pool_pack_device(vdjx_ctx* c, const uint8_t* d_primary, size_t n_prim
 	p->ctx = c; p->device = c->device; p->n_primary = n_primary; p->n_records = R; p->rl = rl;
 	vdjx_clear_errors();
 	p->qstride = (rl + 15) / 16 * 16;
-	size_t Ra = R ? R : 1;
-	u32* d_bad = nullptr;
-	hipError_t e;
-	if ((e = hipMalloc(&p->d_bases, Ra * 16)) != hipSuccess || (e = hipMalloc(&p->d_nmask, Ra * 8)) != hipSuccess ||
-	    (e = hipMalloc(&p->d_lowq, Ra * 8)) != hipSuccess || (e = hipMalloc(&p->d_quals, Ra * (size_t) p->qstride)) != hipSuccess ||
-	    (e = hipMalloc(&d_bad, 4)) != hipSuccess) {
+	size_t Ra = (R ? R : 1);
+	Ra = (Ra + 15) & ~(size_t) 15;               // keeps every array 256-byte aligned inside the block
+	hipError_t e = c->blocks.acquire(Ra * (32 + (size_t) p->qstride) + 256, &p->d_block, &p->block_cap);
+	if (e != hipSuccess) {
 		vdjx_set_error("pool alloc: %s", hipGetErrorString(e));
 		vdjx_pool_free(p);
 		return VDJX_EHIP;
 	}
+	p->d_bases = (u64*) p->d_block;
+	p->d_nmask = (u64*) (p->d_block + Ra * 16);
+	p->d_lowq = (u64*) (p->d_block + Ra * 24);
+	p->d_quals = (uint8_t*) (p->d_block + Ra * 32);
+	u32* d_bad = (u32*) (p->d_block + Ra * (32 + (size_t) p->qstride));
 	(void) hipMemsetAsync(d_bad, 0, 4, c->stream);
 	size_t lds = (size_t) PACK_RECS * (2 * rl + 1) + 16;
 	{
@@ -261,7 +320,6 @@ static int pool_pack_device(vdjx_ctx* c, const uint8_t* d_primary, size_t n_prim
 	e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipGetLastError();
-	(void) hipFree(d_bad);
 	if (e != hipSuccess) { vdjx_set_error("pool pack: %s", hipGetErrorString(e)); vdjx_pool_free(p); return VDJX_EHIP; }
 	if (bad) {
 		// build_pre_graph prints "Initial char in input invalid" and exits (A2:383-391); we return an error
@@ -303,11 +361,31 @@ extern "C" int vdjx_pool_load(vdjx_ctx* c, const uint8_t* primary, size_t n_prim
 	return rc;
 }
 
+extern "C" int vdjx_host_alloc(vdjx_ctx* c, size_t bytes, void** out) {
+	if (!c || !out) { vdjx_set_error("vdjx_host_alloc: NULL argument"); return VDJX_EINVAL; }
+	*out = nullptr;
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+	return VDJX_OK;
+}
+
+extern "C" void vdjx_host_free(vdjx_ctx* c, void* p) {
+	if (!p) return;
+	if (c) (void) hipSetDevice(c->device);
+	(void) hipHostFree(p);
+}
+
 extern "C" size_t vdjx_pool_records(const vdjx_pool* p) { return p ? p->n_records : 0; }
 
 extern "C" void vdjx_pool_free(vdjx_pool* p) {
 	if (!p) return;
 	(void) hipSetDevice(p->device);
-	free_dev(p->d_bases); free_dev(p->d_nmask); free_dev(p->d_lowq); free_dev(p->d_quals);
+	if (p->d_block) {
+		if (vdjx_ctx_alive(p->ctx)) {
+			(void) hipStreamSynchronize(p->ctx->stream);     // nothing in flight may still read the block
+			p->ctx->blocks.release(p->d_block, p->block_cap);
+		} else
+			free_dev(p->d_block);
+	}
 	delete p;
 }

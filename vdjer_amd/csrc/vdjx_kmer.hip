@@ -787,6 +787,33 @@ struct NodeOut {
 	uint8_t* to_deg; u32* to_ids; uint8_t* from_deg; u32* from_ids;
 };
 
+// roots (identify_root_nodes, A2:653-676: nodes without predecessor) as an ascending index list
+__global__ __launch_bounds__(256) void k_root_count(const uint8_t* __restrict__ from_deg, u32 n, u32* __restrict__ block_cnt) {
+	__shared__ u32 cnt;
+	if (threadIdx.x == 0) cnt = 0;
+	__syncthreads();
+	const u32 i = blockIdx.x * 256 + threadIdx.x;
+	const bool r = i < n && from_deg[i] == 0;
+	const u64 b = __ballot(r);
+	if ((threadIdx.x & 63) == 0 && b) atomicAdd(&cnt, (u32) __popcll(b));
+	__syncthreads();
+	if (threadIdx.x == 0) block_cnt[blockIdx.x] = cnt;
+}
+
+__global__ __launch_bounds__(256) void k_root_list(const uint8_t* __restrict__ from_deg, u32 n, const u32* __restrict__ block_start,
+                                                   u32* __restrict__ roots) {
+	__shared__ u32 wave_cnt[4];
+	const u32 i = blockIdx.x * 256 + threadIdx.x;
+	const bool r = i < n && from_deg[i] == 0;
+	const u64 b = __ballot(r);
+	const u32 w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	if (lane == 0) wave_cnt[w] = (u32) __popcll(b);
+	__syncthreads();
+	u32 base = block_start[blockIdx.x];
+	for (u32 j = 0; j < w; j++) base += wave_cnt[j];
+	if (r) roots[base + (u32) __popcll(b & ((1ull << lane) - 1))] = i;
+}
+
 __global__ void k_node_rank(const u32* __restrict__ ufirst, u32 n, const u32* __restrict__ bits, const u32* __restrict__ word_pre,
                             const u32* __restrict__ block_pre, u32* __restrict__ rank) {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1161,6 +1188,8 @@ int stage_finish(vdjx_ctx* c, A& db, const Survivors& sv, const u32* edge_first,
 	const u32 ns = sv.n;
 	g->n = ns;
 	g->k = k;
+	g->ctx = c;
+	g->device = c->device;
 	if (ns == 0) return VDJX_OK;
 	uint8_t *d_hv, *d_hj;
 	HIP_TRY(db.alloc(&d_hv, ns));
@@ -1179,12 +1208,28 @@ int stage_finish(vdjx_ctx* c, A& db, const Survivors& sv, const u32* edge_first,
 	HIP_TRY(db.alloc(&rank, ns));
 	HIP_TRY(db.alloc(&in_first, (size_t) ns * 4));
 	HIP_TRY(db.alloc(&in_from, (size_t) ns * 4));
+	// the node arrays live in a block of their own: they outlive this call (vdjx_graph_export copies from there)
+	auto up = [](size_t b) { return (b + 255) & ~(size_t) 255; };
+	const size_t need = up((size_t) ns * 8) + 5 * up((size_t) ns * 4) + 4 * up(ns) + 2 * up((size_t) ns * 16) + up((size_t) ns * k);
+	{
+		hipError_t e = c->blocks.acquire(need, &g->d_block, &g->block_cap);
+		if (e != hipSuccess) { vdjx_set_error("graph alloc (%zu bytes): %s", need, hipGetErrorString(e)); return VDJX_EHIP; }
+	}
+	char* bp = g->d_block;
+	auto carve = [&](size_t b) { char* r = bp; bp += up(b); return r; };
 	NodeOut no;
-	HIP_TRY(db.alloc(&no.first_inst, ns)); HIP_TRY(db.alloc(&no.gcnt, ns)); HIP_TRY(db.alloc(&no.freq, ns));
-	HIP_TRY(db.alloc(&no.hv, ns)); HIP_TRY(db.alloc(&no.hj, ns)); HIP_TRY(db.alloc(&no.klo, ns)); HIP_TRY(db.alloc(&no.khi, ns));
-	HIP_TRY(db.alloc(&no.kmers, (size_t) ns * k));
-	HIP_TRY(db.alloc(&no.to_deg, ns)); HIP_TRY(db.alloc(&no.to_ids, (size_t) ns * 4));
-	HIP_TRY(db.alloc(&no.from_deg, ns)); HIP_TRY(db.alloc(&no.from_ids, (size_t) ns * 4));
+	no.first_inst = g->d_first_inst = (u64*) carve((size_t) ns * 8);
+	no.gcnt = g->d_gcnt = (u32*) carve((size_t) ns * 4);
+	no.freq = g->d_freq = (u32*) carve((size_t) ns * 4);
+	no.to_ids = g->d_to_ids = (u32*) carve((size_t) ns * 16);
+	no.from_ids = g->d_from_ids = (u32*) carve((size_t) ns * 16);
+	no.hv = g->d_hv = (uint8_t*) carve(ns);
+	no.hj = g->d_hj = (uint8_t*) carve(ns);
+	no.to_deg = g->d_to_deg = (uint8_t*) carve(ns);
+	no.from_deg = g->d_from_deg = (uint8_t*) carve(ns);
+	no.kmers = g->d_kmers = carve((size_t) ns * k);
+	g->d_roots = (u32*) carve((size_t) ns * 4);
+	HIP_TRY(db.alloc(&no.klo, ns)); HIP_TRY(db.alloc(&no.khi, ns));
 	HIP_TRY(hipMemsetAsync(bits, 0, (size_t) nwords * 4, st));
 	HIP_TRY(hipMemsetAsync(in_first, 0xFF, (size_t) ns * 16, st));
 	{
@@ -1197,23 +1242,21 @@ int stage_finish(vdjx_ctx* c, A& db, const Survivors& sv, const u32* edge_first,
 		hipLaunchKernelGGL(k_node_emit, dim3((ns + 255) / 256), dim3(256), 0, st, sv.lo, sv.hi, sv.gcnt, sv.ucnt, sv.ufirst, d_hv, d_hj, rank,
 		                   edge_first, edge_to, in_first, in_from, ns, k, P, no);
 	}
-	g->first_inst.resize(ns); g->gated_count.resize(ns); g->freq.resize(ns);
-	g->has_v.resize(ns); g->has_j.resize(ns);
-	g->to_deg.resize(ns); g->from_deg.resize(ns);
-	g->to_ids.resize((size_t) ns * 4); g->from_ids.resize((size_t) ns * 4);
-	g->kmers.resize((size_t) ns * k);
-	HIP_TRY(hipMemcpyAsync(g->first_inst.data(), no.first_inst, (size_t) ns * 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(g->gated_count.data(), no.gcnt, (size_t) ns * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(g->freq.data(), no.freq, (size_t) ns * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(g->has_v.data(), no.hv, ns, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(g->has_j.data(), no.hj, ns, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(g->kmers.data(), no.kmers, (size_t) ns * k, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(g->to_deg.data(), no.to_deg, ns, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(g->to_ids.data(), no.to_ids, (size_t) ns * 16, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(g->from_deg.data(), no.from_deg, ns, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(g->from_ids.data(), no.from_ids, (size_t) ns * 16, hipMemcpyDeviceToHost, st));
+	u32 n_roots = 0;
+	{
+		const u32 nrb = (ns + 255) / 256;
+		u32 *rb_cnt, *rb_start;
+		HIP_TRY(db.alloc(&rb_cnt, nrb));
+		HIP_TRY(db.alloc(&rb_start, nrb + 1));
+		vdjx_prof_scope ps(c, "k_root_list");
+		hipLaunchKernelGGL(k_root_count, dim3(nrb), dim3(256), 0, st, no.from_deg, ns, rb_cnt);
+		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, rb_cnt, nrb, rb_start);
+		hipLaunchKernelGGL(k_root_list, dim3(nrb), dim3(256), 0, st, no.from_deg, ns, rb_start, g->d_roots);
+		HIP_TRY(hipMemcpyAsync(&n_roots, rb_start + nrb, 4, hipMemcpyDeviceToHost, st));
+	}
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	g->n_roots = n_roots;
 	return VDJX_OK;
 }
 
@@ -1264,7 +1307,7 @@ extern "C" int vdjx_kmer_build(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf
 	vdjx_clear_errors();
 	vdjx_graph* g = new vdjx_graph();
 	int rc = key_hi_is_u32(k) ? kmer_build_impl<u32>(c, pool, k, mf, mq, g) : kmer_build_impl<u64>(c, pool, k, mf, mq, g);
-	if (rc != VDJX_OK) { delete g; return rc; }
+	if (rc != VDJX_OK) { vdjx_graph_free(g); return rc; }
 	*out = g;
 	return VDJX_OK;
 }
@@ -1455,30 +1498,46 @@ extern "C" int vdjx_shard_finish(vdjx_shard* s, const void* d_edge_first, const 
 	vdjx_graph* g = new vdjx_graph();
 	g->pre_nodes = (size_t) pre_nodes_total;
 	int rc = stage_finish(c, db, s->all_sv, (const u32*) d_edge_first, (const u32*) d_edge_to, NI, s->k, P, g);
-	if (rc) { delete g; return rc; }
+	if (rc) { vdjx_graph_free(g); return rc; }
 	*out = g;
 	return VDJX_OK;
 }
 
 extern "C" size_t vdjx_graph_nodes(const vdjx_graph* g) { return g ? g->n : 0; }
 extern "C" size_t vdjx_graph_pre_nodes(const vdjx_graph* g) { return g ? g->pre_nodes : 0; }
+extern "C" size_t vdjx_graph_roots(const vdjx_graph* g) { return g ? g->n_roots : 0; }
 
 extern "C" int vdjx_graph_export(const vdjx_graph* g, uint64_t* first_inst, uint32_t* gated_count, uint32_t* freq,
                                  uint8_t* has_v, uint8_t* has_j, uint8_t* to_deg, uint32_t* to_ids,
                                  uint8_t* from_deg, uint32_t* from_ids, char* kmers) {
 	if (!g) { vdjx_set_error("vdjx_graph_export: NULL graph"); return VDJX_EINVAL; }
 	const size_t n = g->n;
-	if (first_inst) memcpy(first_inst, g->first_inst.data(), n * 8);
-	if (gated_count) memcpy(gated_count, g->gated_count.data(), n * 4);
-	if (freq) memcpy(freq, g->freq.data(), n * 4);
-	if (has_v) memcpy(has_v, g->has_v.data(), n);
-	if (has_j) memcpy(has_j, g->has_j.data(), n);
-	if (to_deg) memcpy(to_deg, g->to_deg.data(), n);
-	if (from_deg) memcpy(from_deg, g->from_deg.data(), n);
-	if (to_ids) memcpy(to_ids, g->to_ids.data(), n * 16);
-	if (from_ids) memcpy(from_ids, g->from_ids.data(), n * 16);
-	if (kmers) memcpy(kmers, g->kmers.data(), n * (size_t) g->k);
+	if (n == 0) return VDJX_OK;
+	if (!g->d_block || !vdjx_ctx_alive(g->ctx)) { vdjx_set_error("vdjx_graph_export: the graph's context is gone"); return VDJX_ESTATE; }
+	HIP_TRY(hipSetDevice(g->device));
+	hipStream_t st = g->ctx->stream;
+	// straight into the caller's arrays: DMA speed when they are pinned (vdjx_host_alloc), staged by the runtime otherwise
+	if (first_inst) HIP_TRY(hipMemcpyAsync(first_inst, g->d_first_inst, n * 8, hipMemcpyDeviceToHost, st));
+	if (gated_count) HIP_TRY(hipMemcpyAsync(gated_count, g->d_gcnt, n * 4, hipMemcpyDeviceToHost, st));
+	if (freq) HIP_TRY(hipMemcpyAsync(freq, g->d_freq, n * 4, hipMemcpyDeviceToHost, st));
+	if (has_v) HIP_TRY(hipMemcpyAsync(has_v, g->d_hv, n, hipMemcpyDeviceToHost, st));
+	if (has_j) HIP_TRY(hipMemcpyAsync(has_j, g->d_hj, n, hipMemcpyDeviceToHost, st));
+	if (to_deg) HIP_TRY(hipMemcpyAsync(to_deg, g->d_to_deg, n, hipMemcpyDeviceToHost, st));
+	if (from_deg) HIP_TRY(hipMemcpyAsync(from_deg, g->d_from_deg, n, hipMemcpyDeviceToHost, st));
+	if (to_ids) HIP_TRY(hipMemcpyAsync(to_ids, g->d_to_ids, n * 16, hipMemcpyDeviceToHost, st));
+	if (from_ids) HIP_TRY(hipMemcpyAsync(from_ids, g->d_from_ids, n * 16, hipMemcpyDeviceToHost, st));
+	if (kmers) HIP_TRY(hipMemcpyAsync(kmers, g->d_kmers, n * (size_t) g->k, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
 	return VDJX_OK;
 }
 
-extern "C" void vdjx_graph_free(vdjx_graph* g) { delete g; }
+extern "C" void vdjx_graph_free(vdjx_graph* g) {
+	if (!g) return;
+	if (g->d_block) {
+		(void) hipSetDevice(g->device);
+		if (vdjx_ctx_alive(g->ctx)) g->ctx->blocks.release(g->d_block, g->block_cap);
+		else (void) hipFree(g->d_block);
+	}
+	delete g;
+}
+

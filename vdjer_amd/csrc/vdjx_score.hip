@@ -216,35 +216,17 @@ __global__ __launch_bounds__(DP_THREADS) void k_root_dp(const char* __restrict__
 	}
 }
 
-extern "C" int vdjx_root_score(vdjx_ctx* c, const char* kmers, size_t n, int k, int threshold, uint8_t* out) {
-	if (!c || (n && (!kmers || !out))) { vdjx_set_error("vdjx_root_score: NULL argument"); return VDJX_EINVAL; }
-	if (!c->d_vtext) { vdjx_set_error("vdjx_root_score: call vdjx_vregion_load first"); return VDJX_ESTATE; }
-	if (k < 1 || k > VDJX_MAX_KMER) { vdjx_set_error("k=%d outside [1,%d]", k, VDJX_MAX_KMER); return VDJX_ELIMIT; }
-	if (n == 0) return VDJX_OK;
-	for (size_t li = 0; li < c->n_lines; li++) {
-		if ((long) (c->h_line_off[li + 1] - c->h_line_off[li]) <= 2L * k) {
-			vdjx_set_error("v_region line %zu is not longer than 2k=%d (the reference reads out of bounds there)", li, 2 * k);
-			return VDJX_EINVAL;
-		}
-	}
-	memset(out, 0, n);
-	const int stop = k - c->vk;
-	if (stop <= 0 || c->n_seeds == 0) return VDJX_OK;          // no seed can hit: score_seq returns 0
-	if (n * (size_t) stop >= (1ull << 31)) { vdjx_set_error("too many roots in one call"); return VDJX_ELIMIT; }
-	HIP_TRY(hipSetDevice(c->device));
-	vdjx_clear_errors();
+// the scorer proper: d_k = n*k ASCII on the device, out = n host bytes
+static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t n, int k, int threshold, uint8_t* out) {
 	hipStream_t st = c->stream;
-	vdjx_work db(c);
-	char* d_k;
+	const int stop = k - c->vk;
 	u32 *d_lo, *d_cnt, *d_pre;
 	uint8_t* d_out;
 	const u32 ng = (u32) (n * stop);
-	HIP_TRY(db.alloc(&d_k, n * k));
 	HIP_TRY(db.alloc(&d_lo, ng));
 	HIP_TRY(db.alloc(&d_cnt, ng));
 	HIP_TRY(db.alloc(&d_pre, ng + 1));
 	HIP_TRY(db.alloc(&d_out, n));
-	HIP_TRY(hipMemcpyAsync(d_k, kmers, n * k, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemsetAsync(d_out, 0, n, st));
 	{
 		vdjx_prof_scope ps(c, "k_seed_count");
@@ -280,6 +262,75 @@ extern "C" int vdjx_root_score(vdjx_ctx* c, const char* kmers, size_t n, int k, 
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
 	return VDJX_OK;
+}
+
+static int root_score_check(vdjx_ctx* c, const char* who, size_t n, int k) {
+	if (!c->d_vtext) { vdjx_set_error("%s: call vdjx_vregion_load first", who); return VDJX_ESTATE; }
+	if (k < 1 || k > VDJX_MAX_KMER) { vdjx_set_error("k=%d outside [1,%d]", k, VDJX_MAX_KMER); return VDJX_ELIMIT; }
+	for (size_t li = 0; li < c->n_lines; li++) {
+		if ((long) (c->h_line_off[li + 1] - c->h_line_off[li]) <= 2L * k) {
+			vdjx_set_error("v_region line %zu is not longer than 2k=%d (the reference reads out of bounds there)", li, 2 * k);
+			return VDJX_EINVAL;
+		}
+	}
+	const int stop = k - c->vk;
+	if (stop > 0 && n * (size_t) stop >= (1ull << 31)) { vdjx_set_error("too many roots in one call"); return VDJX_ELIMIT; }
+	return VDJX_OK;
+}
+
+extern "C" int vdjx_root_score(vdjx_ctx* c, const char* kmers, size_t n, int k, int threshold, uint8_t* out) {
+	if (!c || (n && (!kmers || !out))) { vdjx_set_error("vdjx_root_score: NULL argument"); return VDJX_EINVAL; }
+	int rc = root_score_check(c, "vdjx_root_score", n, k);
+	if (rc) return rc;
+	if (n == 0) return VDJX_OK;
+	memset(out, 0, n);
+	if (k - c->vk <= 0 || c->n_seeds == 0) return VDJX_OK;          // no seed can hit: score_seq returns 0
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
+	vdjx_work db(c);
+	char* d_k;
+	HIP_TRY(db.alloc(&d_k, n * k));
+	HIP_TRY(hipMemcpyAsync(d_k, kmers, n * k, hipMemcpyHostToDevice, c->stream));
+	return root_score_device(c, db, d_k, n, k, threshold, out);
+}
+
+__global__ void k_root_gather(const char* __restrict__ kmers, const u32* __restrict__ roots, u32 first, u32 stride, u32 n_sel, int k,
+                              char* __restrict__ out, u32* __restrict__ ids) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_sel) return;
+	const u32 node = roots[first + (size_t) i * stride];
+	ids[i] = node + 1;
+	for (int j = 0; j < k; j++) out[(size_t) i * k + j] = kmers[(size_t) node * k + j];
+}
+
+extern "C" size_t vdjx_root_part(const vdjx_graph* g, uint32_t first, uint32_t stride) {
+	if (!g || stride == 0 || first >= g->n_roots) return 0;
+	return (g->n_roots - first + stride - 1) / stride;
+}
+
+extern "C" int vdjx_root_score_graph(vdjx_ctx* c, const vdjx_graph* g, int threshold, uint32_t first, uint32_t stride,
+                                     uint32_t* root_ids, uint8_t* out) {
+	if (!c || !g) { vdjx_set_error("vdjx_root_score_graph: NULL argument"); return VDJX_EINVAL; }
+	if (g->ctx != c) { vdjx_set_error("vdjx_root_score_graph: graph belongs to another context"); return VDJX_EINVAL; }
+	if (stride == 0) { vdjx_set_error("vdjx_root_score_graph: stride 0"); return VDJX_EINVAL; }
+	const size_t n = vdjx_root_part(g, first, stride);
+	const int k = g->k;
+	int rc = root_score_check(c, "vdjx_root_score_graph", n, k);
+	if (rc) return rc;
+	if (n == 0) return VDJX_OK;
+	if (!root_ids || !out) { vdjx_set_error("vdjx_root_score_graph: NULL result array"); return VDJX_EINVAL; }
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
+	vdjx_work db(c);
+	char* d_k;
+	u32* d_ids;
+	HIP_TRY(db.alloc(&d_k, n * k));
+	HIP_TRY(db.alloc(&d_ids, n));
+	hipLaunchKernelGGL(k_root_gather, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, c->stream, g->d_kmers, g->d_roots, first, stride, (u32) n, k, d_k, d_ids);
+	HIP_TRY(hipMemcpyAsync(root_ids, d_ids, n * 4, hipMemcpyDeviceToHost, c->stream));
+	memset(out, 0, n);
+	if (k - c->vk <= 0 || c->n_seeds == 0) { HIP_TRY(hipStreamSynchronize(c->stream)); return VDJX_OK; }
+	return root_score_device(c, db, d_k, n, k, threshold, out);
 }
 
 // ==============================================================================================

@@ -122,21 +122,10 @@ class HipShardEngine:
         check(self.L.vdjx_shard_edges(self.h, self._dp(surv_all), n, self._dp(ef), self._dp(et)), "vdjx_shard_edges")
         return ef, et
 
-    def finish(self, ef, et, pre_total):
+    def finish(self, ef, et, pre_total, keep_device: bool = False):
         g = C.c_void_p()
         check(self.L.vdjx_shard_finish(self.h, self._dp(ef), self._dp(et), pre_total, C.byref(g)), "vdjx_shard_finish")
-        try:
-            L, k = self.L, self.k
-            n = int(L.vdjx_graph_nodes(g))
-            out = Graph(k, n, int(L.vdjx_graph_pre_nodes(g)), np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint32),
-                        np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros(n, np.uint8), np.zeros((n, 4), np.uint32),
-                        np.zeros(n, np.uint8), np.zeros((n, 4), np.uint32), np.zeros((n, k), np.uint8))
-            check(L.vdjx_graph_export(g, _p(out.first_inst), _p(out.gated_count), _p(out.freq), _p(out.has_v), _p(out.has_j),
-                                      _p(out.to_deg), _p(out.to_ids), _p(out.from_deg), _p(out.from_ids), _p(out.kmers)),
-                  "vdjx_graph_export")
-            return out
-        finally:
-            L.vdjx_graph_free(g)
+        return self.ctx._export_graph(g, self.k, keep_device)
 
     def end(self):
         if self.h:
@@ -237,7 +226,7 @@ class ShardedHotPath:
     def bytes_exchanged(self):
         return self.comm.bytes
 
-    def kmer_build(self, pool, k: int = 35, mf: int = 3, mq: int = 90):
+    def kmer_build(self, pool, k: int = 35, mf: int = 3, mq: int = 90, keep_device: bool = False):
         t, dist, eng, cm = self.torch, self.dist, self.engine, self.comm
         G, r = self.world, self.rank
         if self.stride is None:
@@ -297,6 +286,6 @@ class ShardedHotPath:
                     x.bitwise_xor_(flip)
             cm.sync()
             # 6. node numbering + list order
-            return eng.finish(ef, et, pre_total)
+            return eng.finish(ef, et, pre_total, keep_device=True) if keep_device else eng.finish(ef, et, pre_total)
         finally:
             eng.end()
