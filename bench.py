@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20261002)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="pairs the CPU oracle is timed on (default: the whole workload)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-shard", action="store_true",
+                    help="N=1 only: run the k-mer build through the multi-GPU phases (one-rank RCCL group) to time its kernels; not the line of record")
     ap.add_argument("--windows", choices=["traversal", "generator"], default="traversal",
                     help="scorer inputs: the candidate windows/contigs the host traversal derives from the graph (default), "
                          "or one window per clone straight from the generator")
@@ -144,6 +146,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world == 1 and args.force_shard:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, world_size=1, rank=0)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_device:
@@ -162,7 +168,7 @@ def main():
     d_sec = torch.from_numpy(pool.secondary).to(dev)
     torch.cuda.synchronize()
 
-    if world > 1:
+    if world > 1 or args.force_shard:
         from vdjer_amd import shard
         engine = shard.ShardedHotPath(ctx, dist, dev)
         cm = engine.comm
@@ -275,6 +281,9 @@ def main():
     ctx.profile(True)
     ctx.profile_reset()
     wall.clear()
+    bytes_before = engine.bytes_exchanged if engine else 0
+    if engine:
+        engine.laps.clear()
     import gc
     gc.collect()
     gc.disable()                       # no collector pauses inside the timed region
@@ -356,9 +365,13 @@ def main():
                    "scorer_inputs": scorer_src},
         "roofline": roof, "cpu_baseline": cpu,
         "kernels_ms_per_step": {k_: round(v[0] / args.steps, 4) for k_, v in prof.items()},
-        "exchange_bytes_per_step_rank0": (engine.bytes_exchanged // (args.steps + args.warmup)) if engine else 0,
+        "exchange_bytes_per_step_rank0": ((engine.bytes_exchanged - bytes_before) // args.steps) if engine else 0,
+        "shard_wall_ms_per_step": ({k_: round(v / args.steps * 1e3, 3) for k_, v in engine.laps.items()} if engine else None),
         "wall_ms_per_step": {k_: round(v / args.steps * 1e3, 3) for k_, v in wall.items()},
-        "counts": {k_: v for k_, v in state.items() if k_ != "graph"}, "scorer_stats": stats, "parity_gate": parity,
+        "counts": {k_: v for k_, v in state.items() if k_ != "graph"}, "scorer_stats": stats,
+        "shard_stats_rank0": ({n_: ctx.stat("shard_" + n_) for n_ in ("partials_received", "open_kmers", "questions", "decided_at_merge",
+                                                                    "kept_after_answers")} if engine else None),
+        "parity_gate": parity,
     }
     print(json.dumps(out))
 

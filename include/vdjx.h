@@ -160,40 +160,55 @@ int vdjx_profile_count(vdjx_ctx* ctx);
 /* idx-th entry: kernel name, summed milliseconds, launch count */
 int vdjx_profile_get(vdjx_ctx* ctx, int idx, const char** name, double* total_ms, uint64_t* launches);
 
-/* ---- multi-GPU k-mer build: hash-prefix sharding with one exchange step ------------------
+/* ---- multi-GPU k-mer build: hash-prefix sharding, partial aggregates merged by the owner ----
  * The reference has no counterpart (its only parallelism is pthreads over roots, A2:1287-1348); these
  * phases split vdjx_kmer_build so that the caller can move the bytes between ranks (one process per GPU;
  * vdjer_amd/shard.py does it with torch.distributed over RCCL).  Record numbering is rank-major with a
  * common stride: rank r's records are [r*rec_stride, r*rec_stride + R_r).  nranks is a power of two; the
- * owner of a k-mer is given by the top log2(nranks) bits of its hash.  All pointers are device pointers
- * owned by the caller and must stay valid until vdjx_shard_free.  Call order:
- *   begin -> pool_export -> [all_gather] -> set_pool -> partition_count -> [all_to_all counts]
- *   -> partition_fill -> [all_to_all tuples] -> reduce -> survivors -> [all_gather] -> edges
- *   -> [all_reduce MIN] -> finish -> free                                                          */
+ * owner of a k-mer is given by the top log2(nranks) bits of its hash.
+ *   Every rank first aggregates ITS OWN instances per distinct k-mer (count and first instance, gated and
+ * ungated, and whether it saw two different reads: add_to_table A2:322-367 restated per rank).  These partial
+ * aggregates (24 B per distinct gated k-mer per rank, not per instance) are the one bulk exchange.  The owner
+ * merges them (counts add, firsts take the minimum, flags OR) and decides almost every k-mer on the spot;
+ * only a k-mer whose verdict needs per-read data -- no rank saw two different reads although several hold
+ * it, or its count is below the level where the quality sums cannot fail -- costs a question to the ranks
+ * that hold it and a fixed-size answer (the first record's bases, partial quality sums).
+ * All pointers are device pointers owned by the caller.  Call order (brackets = the caller's collectives):
+ *   begin -> local -> local_fill -> [all_to_all: directories, counts, partial aggregates] -> merge
+ *   -> queries -> [all_to_all: counts, questions] -> reply -> [all_to_all: answers] -> resolve
+ *   -> survivors -> [all_gather] -> edges -> [all_reduce MIN, SUM] -> finish -> free                */
 typedef struct vdjx_shard vdjx_shard;
 int vdjx_shard_begin(vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, int rank, int nranks,
                      uint64_t rec_stride, vdjx_shard** out);
 void vdjx_shard_free(vdjx_shard* s);
-int vdjx_shard_qstride(const vdjx_shard* s);       /* quality bytes per record in the packed pool */
-int vdjx_shard_key_hi_bytes(const vdjx_shard* s);  /* 4 (k <= 47) or 8: width of the key_hi tuple column */
-/* local packed pool -> caller buffers: R x 16 B bases, R x 8 B N mask, R x qstride B qualities */
-int vdjx_shard_pool_export(vdjx_shard* s, void* d_bases, void* d_nmask, void* d_quals);
-/* the replicated pool: nranks*rec_stride records each */
-int vdjx_shard_set_pool(vdjx_shard* s, const void* d_bases_all, const void* d_nmask_all, const void* d_quals_all);
-/* send_counts[nranks]: k-mer instances this rank sends to every owner */
-int vdjx_shard_partition_count(vdjx_shard* s, uint64_t* send_counts);
-/* tuple columns (u64 key_lo, u32|u64 key_hi, u32 instance|gated bit), owner-contiguous, sum(send_counts) entries */
-int vdjx_shard_partition_fill(vdjx_shard* s, void* d_lo, void* d_hi, void* d_inst);
-/* owner side: the received tuples -> this rank's survivors (a-1/a-2 for the k-mers it owns) */
-int vdjx_shard_reduce(vdjx_shard* s, const void* d_lo, const void* d_hi, const void* d_inst, uint64_t n_recv,
-                      uint64_t* n_survivors, uint64_t* n_distinct);
+/* bytes per exchanged record: kind 0 partial aggregate (24), 1 question (8), 2 answer (192) */
+size_t vdjx_shard_record_bytes(int kind);
+/* this rank's partial aggregates, grouped by owner: send_counts[nranks]; *dir_len = hash buckets per owner */
+int vdjx_shard_local(vdjx_shard* s, uint64_t* send_counts, uint32_t* dir_len);
+/* d_dir: u32 [nranks*dir_len] partial aggregates per bucket (owner-major); d_partials: sum(send_counts) records */
+int vdjx_shard_local_fill(vdjx_shard* s, void* d_dir, void* d_partials);
+/* owner: directories and partial aggregates as received (source-major) -> decided k-mers and questions;
+ * query_counts[r] = questions for rank r */
+int vdjx_shard_merge(vdjx_shard* s, const void* d_recv_dir, const void* d_recv_partials, const uint64_t* recv_counts,
+                     uint64_t* query_counts);
+/* the questions, grouped by destination rank: sum(query_counts) records */
+int vdjx_shard_queries(vdjx_shard* s, void* d_out);
+/* every rank: the questions it received (counts[o] from owner o, in that order) -> answers in the same order */
+int vdjx_shard_reply(vdjx_shard* s, const void* d_queries, const uint64_t* counts, void* d_replies);
+/* owner: the answers (grouped by answering rank, each group in question order) -> this rank's survivors
+ * (a-1/a-2 for the k-mers it owns); n_distinct = distinct gated k-mers it owns ("Pre Num nodes") */
+int vdjx_shard_resolve(vdjx_shard* s, const void* d_replies, uint64_t n_replies, uint64_t* n_survivors, uint64_t* n_distinct);
 /* n_survivors records of 32 B: {u64 key_lo, u64 key_hi, u32 gated count, u32 gated first, u32 count, u32 first} */
 int vdjx_shard_survivors(vdjx_shard* s, void* d_out);
-/* all ranks' survivors (rank order) -> local edge pass into d_edge_first/d_edge_to [ns_total*4] u32
- * (0xFFFFFFFF = no edge); the caller MIN-reduces both arrays over ranks (unsigned order) */
-int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t ns_total, void* d_edge_first, void* d_edge_to);
-/* reduced edge arrays -> the graph, identical on every rank */
-int vdjx_shard_finish(vdjx_shard* s, const void* d_edge_first, const void* d_edge_to, uint64_t pre_nodes_total, vdjx_graph** out);
+/* all ranks' survivors (rank order) -> this rank's edge pass into d_edge_first/d_edge_to [ns_total*4] u32
+ * (0xFFFFFFFF = no edge) and its share of add_to_graph's recount (A2:261-309): d_ucnt (instances of each
+ * survivor on this rank), d_ufirst (first of them, 0xFFFFFFFF = none), [ns_total] u32 each.  The caller
+ * reduces over ranks: MIN (unsigned order) for the edge arrays and d_ufirst, SUM for d_ucnt */
+int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t ns_total, void* d_edge_first, void* d_edge_to,
+                     void* d_ucnt, void* d_ufirst);
+/* reduced arrays -> the graph, identical on every rank */
+int vdjx_shard_finish(vdjx_shard* s, const void* d_edge_first, const void* d_edge_to, const void* d_ucnt, const void* d_ufirst,
+                      uint64_t pre_nodes_total, vdjx_graph** out);
 
 #ifdef __cplusplus
 }

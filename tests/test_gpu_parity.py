@@ -301,7 +301,7 @@ def test_window_score_vs_oracle_seeded(ctx):
     p.free()
 
 
-@pytest.mark.parametrize("world,k,mf,mq", [(2, 35, 3, 90), (4, 25, 2, 60), (2, 48, 2, 60)])
+@pytest.mark.parametrize("world,k,mf,mq", [(2, 35, 3, 90), (4, 25, 2, 60), (2, 48, 2, 60), (8, 35, 2, 60)])
 def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq):
     """The real multi-rank driver + the HIP phase engine with `world` ranks on this one GPU (ranks are threads,
     collectives are tensor copies: tests/fake_dist.py).  Result == single-GPU build of the union pool == oracle."""
@@ -312,14 +312,25 @@ def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq):
     rep = synth.make_repertoire(6, seed=41)
     vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
     jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
-    pools = [synth.make_reads(rep, 6000, noise_frac=0.3, seed=500 + r, err=0.004, n_rate=0.002) for r in range(world)]
+    import dataclasses
+    pools = [synth.make_reads(rep, 6000 if world < 8 else 1500, noise_frac=0.3, seed=500 + r, err=0.004, n_rate=0.002) for r in range(world)]
+    # reads present once on EVERY rank (no rank sees two different reads of their k-mers: the owner has to ask), a variant with
+    # weak qualities on rank 1 only (settles some of those flags; low quality sums), blanks elsewhere to keep the strides equal
+    shared = synth.make_reads(synth.make_repertoire(2, seed=78), 12, noise_frac=0.0, seed=10, err=0.0, n_rate=0.0).primary.copy()
+    weak = shared[:6].copy()
+    weak[:, 51:] = ord("6")
+    weak[::2, 12] = np.where(weak[::2, 12] == ord("A"), ord("C"), ord("A"))
+    blank = np.frombuffer(("0" + "N" * 50 + "I" * 50).encode(), np.uint8)
+    for r in range(world):
+        tail = weak if r == 1 else np.stack([blank] * weak.shape[0])
+        pools[r] = dataclasses.replace(pools[r], primary=np.concatenate([pools[r].primary, shared, tail]))
     cat = np.concatenate([np.concatenate([p.primary, p.secondary]) for p in pools])
     R = cat.shape[0]
     union = synth.ReadPool(50, cat, np.zeros((0, 101), np.uint8), np.zeros(R, np.uint32), np.zeros(R, np.uint8),
                            np.zeros(R, np.uint8), np.arange(R, dtype=np.uint32), 0)
     ref = run_both(ctx, union, vc, jc, k, mf, mq)           # single-GPU == oracle, and the reference result
     dist = ThreadDist(world)
-    out, errs = [None] * world, []
+    out, errs, stats = [None] * world, [], [None] * world
 
     def work(r):
         try:
@@ -329,6 +340,7 @@ def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq):
             p = c.pool_load(pools[r].primary, pools[r].secondary, 50)
             drv = shard.ShardedHotPath(c, dist, torch.device("cuda", 0))
             out[r] = drv.kmer_build(p, k, mf, mq)
+            stats[r] = {n_: c.stat("shard_" + n_) for n_ in ("partials_received", "open_kmers", "questions", "decided_at_merge", "kept_after_answers")}
             p.free()
             c.close()
         except Exception as e:  # noqa: BLE001
@@ -341,6 +353,11 @@ def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq):
     for t in th:
         t.join()
     assert not errs, errs
+    # the question round did real work, and settled open k-mers both ways
+    tot = {n_: sum(st[n_] for st in stats) for n_ in stats[0]}
+    assert tot["questions"] >= tot["open_kmers"] > 0
+    assert 0 < tot["kept_after_answers"] < tot["open_kmers"]
+    assert tot["decided_at_merge"] + tot["kept_after_answers"] == ref.n
     for g in out:
         assert g.n == ref.n and g.pre_nodes == ref.pre_nodes
         np.testing.assert_array_equal(g.first_inst, ref.first_inst)

@@ -1,5 +1,5 @@
-"""world_size-2 `gloo` run (CPU) of the multi-rank driver vdjer_amd/shard.py: the all_gather / all-to-all /
-all_reduce choreography, split arithmetic and record numbering, with the pure-Python phase engine of
+"""world_size-2 `gloo` run (CPU) of the multi-rank driver vdjer_amd/shard.py: the all-to-all / all_gather /
+all_reduce choreography (partial aggregates, questions, answers), split arithmetic and record numbering, with the pure-Python phase engine of
 tests/shard_ref_engine.py standing in for the GPU engine.  The sharded result must equal the oracle's
 single-process result on the rank-major concatenation of the shards."""
 import os
@@ -24,6 +24,24 @@ def _make(rank, n_pairs=90, seed=5):
     from vdjer_amd import synth
     rep = synth.make_repertoire(2, seed=seed)
     pool = synth.make_reads(rep, n_pairs, noise_frac=0.2, seed=100 + rank, err=0.01, n_rate=0.004)
+    # reads that exist ONCE per rank, identical on all ranks (plus one variant with weak qualities on rank 1 only): no rank sees
+    # two different reads for their k-mers, so the distinct-read flag and the quality sums are settled by the question round
+    shared = synth.make_reads(synth.make_repertoire(1, seed=77), 4, noise_frac=0.0, seed=9, err=0.0, n_rate=0.0).primary.copy()
+    if rank == 1:
+        weak = shared[:2].copy()
+        weak[:, 1 + 50:] = ord("6")                      # Phred 21: passes the gate, adds little to the sums
+        weak[0, 10] = ord("A") if weak[0, 10] != ord("A") else ord("C")
+        shared = np.concatenate([shared, weak])
+    else:                                                # same record count on every rank (the oracle's union has no stride gaps)
+        blank = np.frombuffer(("0" + "N" * 50 + "I" * 50).encode(), np.uint8)
+        shared = np.concatenate([shared, np.stack([blank, blank])])
+    import dataclasses
+    n_extra = shared.shape[0]
+    pool = dataclasses.replace(pool, primary=np.concatenate([pool.primary, shared]),
+                               pair_id=np.concatenate([pool.pair_id[:pool.primary.shape[0]], np.zeros(n_extra, np.uint32), pool.pair_id[pool.primary.shape[0]:]]),
+                               read_num=np.concatenate([pool.read_num[:pool.primary.shape[0]], np.ones(n_extra, np.uint8), pool.read_num[pool.primary.shape[0]:]]),
+                               is_rc=np.concatenate([pool.is_rc[:pool.primary.shape[0]], np.zeros(n_extra, np.uint8), pool.is_rc[pool.primary.shape[0]:]]),
+                               reg_rank=np.arange(pool.n_records + n_extra, dtype=np.uint32))
     vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
     jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
     return rep, pool, vc, jc
@@ -43,7 +61,7 @@ def _worker(rank, world, port, k, mf, mq, q):
         drv = shard.ShardedHotPath(None, dist, torch.device("cpu"), engine=RefShardEngine(vc, jc))
         g = drv.kmer_build(pool, k, mf, mq)
         q.put((rank, g.n, g.pre_nodes, g.first_inst.tolist(), g.freq.tolist(), g.gated_count.tolist(), g.has_v.tolist(),
-               g.has_j.tolist(), g.to_ids.tolist(), g.from_ids.tolist(), drv.bytes_exchanged))
+               g.has_j.tolist(), g.to_ids.tolist(), g.from_ids.tolist(), drv.bytes_exchanged, drv.engine.stats))
     finally:
         dist.destroy_process_group()
 
@@ -83,5 +101,9 @@ def test_sharded_driver_world2_gloo(k, mf, mq):
         assert r[6] == og.has_v.tolist() and r[7] == og.has_j.tolist()
         assert r[8] == og.to_ids.tolist() and r[9] == og.from_ids.tolist()
         assert r[10] > 0
+    # the question round did real work: k-mers whose flag was open after the merge (some settled either way), and low counts
+    st = [r[11] for r in res]
+    assert sum(x["open_flag"] for x in st) > 0 and sum(x["low_count"] for x in st) > 0
+    assert 0 < sum(x["flag_set_by_answers"] for x in st) < sum(x["open_flag"] for x in st)
     gc = {int(f): int(c) for f, c in zip(first, count)}
     assert sorted(res[0][5]) == sorted(gc.values())

@@ -20,8 +20,8 @@ SYMBOLS = [
     "vdjx_read_index_build", "vdjx_window_score", "vdjx_map_emit",
     "vdjx_host_alloc", "vdjx_host_free",
     "vdjx_stat", "vdjx_profile_enable", "vdjx_profile_reset", "vdjx_profile_count", "vdjx_profile_get",
-    "vdjx_shard_begin", "vdjx_shard_free", "vdjx_shard_qstride", "vdjx_shard_key_hi_bytes", "vdjx_shard_pool_export",
-    "vdjx_shard_set_pool", "vdjx_shard_partition_count", "vdjx_shard_partition_fill", "vdjx_shard_reduce",
+    "vdjx_shard_begin", "vdjx_shard_free", "vdjx_shard_record_bytes", "vdjx_shard_local", "vdjx_shard_local_fill",
+    "vdjx_shard_merge", "vdjx_shard_queries", "vdjx_shard_reply", "vdjx_shard_resolve",
     "vdjx_shard_survivors", "vdjx_shard_edges", "vdjx_shard_finish",
 ]
 

@@ -305,12 +305,12 @@ __global__ void k_init_cursors(const u32* __restrict__ bucket_start, u32 n, u32 
 // ----------------------------------------------------------------------------------------------
 // K3a: LDS hash aggregation per bucket
 // ----------------------------------------------------------------------------------------------
-template <typename THI>
+template <typename THI, u32 SLOTS = K3_SLOTS>
 __device__ inline int lds_insert(u64* s_klo, THI* s_khi, u64 lo, THI hi, u32 h) {
 	const THI EMPTY = (THI) ~(THI) 0, LOCKED = (THI) (EMPTY - 1);
-	u32 slot = h & (K3_SLOTS - 1);
+	u32 slot = h & (SLOTS - 1);
 	u32 probes = 0;
-	while (probes < K3_SLOTS) {
+	while (probes < SLOTS) {
 		THI cur = *(volatile THI*) &s_khi[slot];
 		if (cur == EMPTY) {
 			THI old = atomicCAS(&s_khi[slot], EMPTY, LOCKED);
@@ -324,21 +324,21 @@ __device__ inline int lds_insert(u64* s_klo, THI* s_khi, u64 lo, THI hi, u32 h) 
 		}
 		if (cur == LOCKED) continue;                            // another lane is writing this slot: look again
 		if (cur == hi && *(volatile u64*) &s_klo[slot] == lo) return (int) slot;
-		slot = (slot + 1) & (K3_SLOTS - 1);
+		slot = (slot + 1) & (SLOTS - 1);
 		probes++;
 	}
 	return -1;
 }
 
-template <typename THI>
+template <typename THI, u32 SLOTS = K3_SLOTS>
 __device__ inline int lds_lookup(const u64* s_klo, const THI* s_khi, u64 lo, THI hi, u32 h) {
 	const THI EMPTY = (THI) ~(THI) 0;
-	u32 slot = h & (K3_SLOTS - 1);
-	for (u32 probes = 0; probes < K3_SLOTS; probes++) {
+	u32 slot = h & (SLOTS - 1);
+	for (u32 probes = 0; probes < SLOTS; probes++) {
 		THI cur = s_khi[slot];
 		if (cur == EMPTY) return -1;
 		if (cur == hi && s_klo[slot] == lo) return (int) slot;
-		slot = (slot + 1) & (K3_SLOTS - 1);
+		slot = (slot + 1) & (SLOTS - 1);
 	}
 	return -1;
 }
@@ -602,6 +602,407 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 }
 
 // ----------------------------------------------------------------------------------------------
+// Sharded build: every rank aggregates ITS instances per distinct k-mer (LDS, per bucket), the
+// owner of the hash prefix merges the partial aggregates of all ranks, and only k-mers whose verdict needs
+// per-read data (distinct-read flag still open, count below TLOW) cost a second, tiny question/answer round.
+//   partial  = {key, local gated count + local distinct-read flag, local first gated instance}   (A.1 restated per rank);
+//              only k-mers with a gated instance travel: five in six instances of a Phred-noisy pool are ungated
+//   merged   : counts add (each capped at 32765 = MAX_FREQUENCY, A2:345-347), firsts take the minimum,
+//   flag     = OR of the local flags, or: the ranks' first records differ (asked in round 2),
+//   S_j      = first record's qualities (owner of the global first) + everybody else's own (round 2).
+//   The ungated recount of add_to_graph (A2:261-309) needs every instance of a SURVIVING k-mer, wherever it lives:
+//   each rank keeps {count, first} over all its instances per k-mer and looks the survivors up once they are known;
+//   the caller reduces those two small arrays over ranks (SUM, MIN) together with the edge arrays.
+// ----------------------------------------------------------------------------------------------
+struct Partial { u64 lo, hi; u32 mg, cg; };              // 24 bytes, what travels: gated count (bit 31 = local distinct-read flag), first gated instance
+struct LocalAll { u64 lo, hi; u32 ca, ma; };             // 24 bytes, stays on its rank: count and first over ALL instances (add_to_graph's recount)
+#define PART_FLAG 0x80000000u
+#define CNT_CAP 32765u
+#define NEED_SEQ 1u
+#define NEED_Q 2u
+#define PID_MASK 0x3FFFFFFFu
+#define REPLY_KQ 52                 // quality bytes per row (k <= 50)
+#define REPLY_BYTES 192             // pid, first instance, 16-B bases, 8-B N mask, 3 quality rows
+
+template <typename THI>
+__global__ __launch_bounds__(K3_THREADS) void k_bucket_local(const u64* __restrict__ t_lo, const THI* __restrict__ t_hi,
+                                                             const u32* __restrict__ t_inst, const u32* __restrict__ bucket_start,
+                                                             const u64* __restrict__ bases, const u64* __restrict__ nmask, u32 rec_base,
+                                                             int P, u32 tlow, Partial* __restrict__ sparse_g, u32* __restrict__ sparse_ref,
+                                                             u32* __restrict__ nd_g, LocalAll* __restrict__ sparse_a, u32* __restrict__ nd_a,
+                                                             u32* __restrict__ low_inst, u32* __restrict__ g_err) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	u64* s_klo = (u64*) smem;
+	THI* s_khi = (THI*) (s_klo + K3_SLOTS);
+	u32* s_cg = (u32*) (s_khi + K3_SLOTS);
+	u32* s_mg = s_cg + K3_SLOTS;
+	u32* s_ca = s_mg + K3_SLOTS;
+	u32* s_ma = s_ca + K3_SLOTS;
+	u32* s_loff = s_ma + K3_SLOTS;          // low-count keys: where their gated instances are listed (relative to the bucket)
+	u32* s_lfill = s_loff + K3_SLOTS;
+	uint8_t* s_fl = (uint8_t*) (s_lfill + K3_SLOTS);
+	__shared__ u32 s_n, s_ng, s_nlow, s_over;
+	const THI EMPTY = (THI) ~(THI) 0;
+	const u32 b = blockIdx.x;
+	const u32 base = bucket_start[b];
+	const u32 n = bucket_start[b + 1] - base;
+	const u32 tid = threadIdx.x;
+	if (n == 0) {
+		if (tid == 0) { nd_g[b] = 0; nd_a[b] = 0; }
+		return;
+	}
+	u32 S = 1;
+	while ((u64) S * K3_SUB_TUPLES < n) S <<= 1;
+	for (;;) {
+		if (tid == 0) { s_n = 0; s_ng = 0; s_nlow = 0; s_over = 0; }
+		for (u32 s = 0; s < S; s++) {
+			for (u32 i = tid; i < K3_SLOTS; i += K3_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE32; s_ca[i] = 0; s_ma[i] = NONE32; s_lfill[i] = 0; s_fl[i] = 0; }
+			__syncthreads();
+			const bool one_chunk = n <= K3_UNR * K3_THREADS;
+			u32 r_iw[K3_UNR];
+			u64 r_lo[K3_UNR];
+			THI r_hi[K3_UNR];
+			int r_slot[K3_UNR];
+			// sweep 1: every N-free instance: counts and firsts, gated (A2:332-347) and ungated (A2:280-309)
+			for (u32 t0 = 0; t0 < n; t0 += K3_UNR * K3_THREADS) {
+#pragma unroll
+				for (int j = 0; j < K3_UNR; j++) {
+					const u32 t = t0 + j * K3_THREADS + tid;
+					const bool v = t < n;
+					r_iw[j] = v ? t_inst[base + t] : 0u;
+					r_lo[j] = v ? t_lo[base + t] : 0ull;
+					r_hi[j] = v ? t_hi[base + t] : (THI) 0;
+					r_slot[j] = v ? -1 : -2;
+				}
+#pragma unroll
+				for (int j = 0; j < K3_UNR; j++) {
+					if (r_slot[j] == -2) continue;
+					const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
+					if ((u32) ((h >> 12) & (S - 1)) != s) continue;
+					const int slot = lds_insert<THI>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
+					if (slot < 0) { s_over = 1; continue; }
+					r_slot[j] = slot;
+					const u32 inst = r_iw[j] & INST_MASK;
+					atomicAdd(&s_ca[slot], 1u);
+					atomicMin(&s_ma[slot], inst);
+					if (r_iw[j] >> 31) { atomicAdd(&s_cg[slot], 1u); atomicMin(&s_mg[slot], inst); }
+				}
+			}
+			__syncthreads();
+			if (s_over) break;
+			// keys whose count alone cannot pass the quality test (count < TLOW) list their gated instances: the owner may ask
+			for (u32 i = tid; i < K3_SLOTS; i += K3_THREADS) {
+				const u32 cg = s_cg[i];
+				s_loff[i] = (cg && cg < tlow) ? atomicAdd(&s_nlow, cg) : NONE32;
+			}
+			__syncthreads();
+			// sweep 2: the lists, and the distinct-read flag against this rank's first gated record (compare_read, A2:142-144,349-352)
+			for (u32 t0 = 0; t0 < n; t0 += K3_UNR * K3_THREADS) {
+#pragma unroll
+				for (int j = 0; j < K3_UNR; j++) {
+					if (!one_chunk) {
+						const u32 t = t0 + j * K3_THREADS + tid;
+						const bool v = t < n;
+						r_iw[j] = v ? t_inst[base + t] : 0u;
+						r_lo[j] = v ? t_lo[base + t] : 0ull;
+						r_hi[j] = v ? t_hi[base + t] : (THI) 0;
+						r_slot[j] = -2;
+						if (v && (r_iw[j] >> 31)) {
+							const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
+							r_slot[j] = (u32) ((h >> 12) & (S - 1)) == s ? lds_lookup<THI>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h) : -1;
+						}
+					}
+				}
+#pragma unroll
+				for (int j = 0; j < K3_UNR; j++) {
+					const int slot = r_slot[j];
+					if (slot < 0 || !(r_iw[j] >> 31)) continue;
+					const u32 inst = r_iw[j] & INST_MASK;
+					if (s_loff[slot] != NONE32) low_inst[base + s_loff[slot] + atomicAdd(&s_lfill[slot], 1u)] = inst;
+					if (s_cg[slot] < 2 || *(volatile uint8_t*) &s_fl[slot]) continue;
+					const u32 rec = inst / (u32) P - rec_base;
+					const u32 frec = s_mg[slot] / (u32) P - rec_base;
+					if (rec != frec) {
+						const ulonglong2 x = ((const ulonglong2*) bases)[rec];
+						const ulonglong2 y = ((const ulonglong2*) bases)[frec];
+						if (x.x != y.x || x.y != y.y || nmask[rec] != nmask[frec]) s_fl[slot] = 1;
+					}
+				}
+			}
+			__syncthreads();
+			for (u32 i = tid; i < K3_SLOTS; i += K3_THREADS) {
+				if (s_khi[i] == EMPTY) continue;
+				const u32 idx = atomicAdd(&s_n, 1u);
+				LocalAll a;
+				a.lo = s_klo[i]; a.hi = (u64) s_khi[i];
+				a.ca = s_ca[i] > CNT_CAP ? CNT_CAP : s_ca[i];
+				a.ma = s_ma[i];
+				sparse_a[base + idx] = a;
+				if (s_cg[i]) {
+					Partial p;
+					p.lo = a.lo; p.hi = a.hi;
+					p.mg = s_mg[i];
+					p.cg = (s_cg[i] > CNT_CAP ? CNT_CAP : s_cg[i]) | (s_fl[i] ? PART_FLAG : 0u);
+					const u32 gi = atomicAdd(&s_ng, 1u);
+					sparse_g[base + gi] = p;
+					sparse_ref[base + gi] = s_loff[i] != NONE32 ? base + s_loff[i] : NONE32;
+				}
+			}
+			__syncthreads();
+		}
+		if (!s_over) break;
+		S <<= 1;
+		if (S > (1u << 20)) { if (tid == 0) atomicAdd(g_err, 1u); break; }
+		__syncthreads();
+	}
+	if (tid == 0) { nd_g[b] = s_over ? 0 : s_ng; nd_a[b] = s_over ? 0 : s_n; }
+}
+
+__global__ __launch_bounds__(256) void k_compact_partials(const Partial* __restrict__ sparse, const u32* __restrict__ sparse_ref,
+                                                          const u32* __restrict__ bucket_start, const u32* __restrict__ nd,
+                                                          const u32* __restrict__ dstart, Partial* __restrict__ dense, u32* __restrict__ dense_ref) {
+	const u32 b = blockIdx.x;
+	const u64* src = (const u64*) (sparse + bucket_start[b]);
+	u64* dst = (u64*) (dense + dstart[b]);
+	const u32 m = nd[b];
+	for (u32 i = threadIdx.x; i < m * 3; i += 256) dst[i] = src[i];
+	for (u32 i = threadIdx.x; i < m; i += 256) dense_ref[dstart[b] + i] = sparse_ref[bucket_start[b] + i];
+}
+
+// seg_cnt[s*NBo + b] (what arrived) -> seg_off (absolute offsets into the receive buffer); src_base[s] = start of source s.
+// One workgroup per source: exclusive scan of its NBo counts.
+__global__ __launch_bounds__(1024) void k_seg_offsets(const u32* __restrict__ seg_cnt, const u32* __restrict__ src_base, u32 G, u32 NBo,
+                                                      u32* __restrict__ seg_off) {
+	__shared__ u32 part[1024];
+	const u32 s = blockIdx.x;
+	const u32* cnt = seg_cnt + (size_t) s * NBo;
+	u32* off = seg_off + (size_t) s * NBo;
+	const u32 per = (NBo + 1023) / 1024;
+	const u32 lo = threadIdx.x * per;
+	const u32 hi = lo + per < NBo ? lo + per : NBo;
+	u32 sum = 0;
+	for (u32 i = lo; i < hi; i++) sum += cnt[i];
+	part[threadIdx.x] = sum;
+	__syncthreads();
+	for (u32 d = 1; d < 1024; d <<= 1) {
+		const u32 v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+		__syncthreads();
+		part[threadIdx.x] += v;
+		__syncthreads();
+	}
+	u32 run = src_base[s] + (threadIdx.x ? part[threadIdx.x - 1] : 0);
+	for (u32 i = lo; i < hi; i++) { off[i] = run; run += cnt[i]; }
+}
+
+struct PendOut { u64* lo; u64* hi; u32* cg; u32* mg; u32* need; u32* n; u32 cap; };
+
+#define MERGE_THREADS 256
+#define MERGE_SLOTS 1024u             // a bucket holds ~100 distinct gated k-mers per rank
+template <typename THI>
+__global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* __restrict__ recv, const u32* __restrict__ seg_off,
+                                                                const u32* __restrict__ seg_cnt, u32 G, u32 NBo,
+                                                                const u32* __restrict__ src_base, u32 s_mult, u32 cmin, u32 tlow,
+                                                                SurvOut so, PendOut po,
+                                                                uint2* __restrict__ queries, u32* __restrict__ g_nq,
+                                                                u64* __restrict__ g_distinct, u32* __restrict__ g_err) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	u64* s_klo = (u64*) smem;
+	THI* s_khi = (THI*) (s_klo + MERGE_SLOTS);
+	u32* s_cg = (u32*) (s_khi + MERGE_SLOTS);
+	u32* s_mg = s_cg + MERGE_SLOTS;
+	u32* s_pid = s_mg + MERGE_SLOTS;
+	u32* s_nsg = s_pid + MERGE_SLOTS;            // ranks that hold gated instances
+	uint8_t* s_fl = (uint8_t*) (s_nsg + MERGE_SLOTS);
+	__shared__ u32 s_over, s_ndist, s_total;
+	const THI EMPTY = (THI) ~(THI) 0;
+	const u32 b = blockIdx.x;
+	const u32 tid = threadIdx.x;
+	if (tid == 0) {
+		u32 tot = 0;
+		for (u32 s = 0; s < G; s++) tot += seg_cnt[(size_t) s * NBo + b];
+		s_total = tot;
+	}
+	__syncthreads();
+	const u32 total = s_total;
+	if (total == 0) return;
+	u32 S = 1;
+	while ((u64) S * (MERGE_SLOTS / 2) < total) S <<= 1;
+	S *= s_mult;
+	for (;;) {
+		if (tid == 0) { s_over = 0; s_ndist = 0; }
+		for (u32 sp = 0; sp < S; sp++) {
+			for (u32 i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE32; s_fl[i] = 0; s_nsg[i] = 0; s_pid[i] = NONE32; }
+			__syncthreads();
+			for (u32 s = 0; s < G; s++) {
+				const u32 off = seg_off[(size_t) s * NBo + b], cnt = seg_cnt[(size_t) s * NBo + b];
+				for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
+					const Partial p = recv[off + i];
+					const u64 h = vdjx_mix(p.lo, p.hi);
+					if ((u32) ((h >> 12) & (S - 1)) != sp) continue;
+					const int slot = lds_insert<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, (u32) h);
+					if (slot < 0) { s_over = 1; continue; }
+					atomicAdd(&s_cg[slot], p.cg & ~PART_FLAG);
+					atomicMin(&s_mg[slot], p.mg);
+					atomicAdd(&s_nsg[slot], 1u);
+					if (p.cg & PART_FLAG) s_fl[slot] = 1;
+				}
+			}
+			__syncthreads();
+			if (s_over) break;
+			for (u32 i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) {
+				if (s_khi[i] == EMPTY) continue;
+				const u32 cg = s_cg[i];
+				atomicAdd(&s_ndist, 1u);
+				if (cg < cmin) continue;                         // count >= max(mf, 2): A2:349-352,476
+				u32 need = 0;
+				if (!s_fl[i]) {
+					if (s_nsg[i] < 2) continue;                  // one rank holds every gated instance and saw one read only
+					need |= NEED_SEQ;
+				}
+				if (cg < tlow) need |= NEED_Q;
+				const u32 cgc = cg > CNT_CAP ? CNT_CAP : cg;
+				if (!need) {
+					const u32 pos = atomicAdd(so.n, 1u);
+					if (pos < so.cap) {
+						so.lo[pos] = s_klo[i]; so.hi[pos] = (u64) s_khi[i];
+						so.gcnt[pos] = cgc; so.gfirst[pos] = s_mg[i];
+						so.ucnt[pos] = 0; so.ufirst[pos] = NONE32;         // the recount comes later (k_surv_counts + reduce)
+					}
+				} else {
+					const u32 pid = atomicAdd(po.n, 1u);
+					if (pid < po.cap) {
+						po.lo[pid] = s_klo[i]; po.hi[pid] = (u64) s_khi[i];
+						po.cg[pid] = cg; po.mg[pid] = s_mg[i];
+						po.need[pid] = need;
+						s_pid[i] = pid | (need << 30);
+					}
+				}
+			}
+			__syncthreads();
+			// questions to every rank that holds gated instances of an open k-mer
+			for (u32 s = 0; s < G; s++) {
+				const u32 off = seg_off[(size_t) s * NBo + b], cnt = seg_cnt[(size_t) s * NBo + b];
+				for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
+					const Partial p = recv[off + i];
+					const u64 h = vdjx_mix(p.lo, p.hi);
+					if ((u32) ((h >> 12) & (S - 1)) != sp) continue;
+					const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, (u32) h);
+					if (slot < 0) continue;
+					const u32 pid = s_pid[slot];
+					if (pid == NONE32) continue;
+					const u32 q = atomicAdd(&g_nq[s], 1u);
+					queries[src_base[s] + q] = make_uint2(off + i - src_base[s], pid);
+				}
+			}
+			__syncthreads();
+		}
+		// a sub-pass that does not fit the table: earlier sub-passes have already appended their results, so the HOST
+		// resets the outputs and relaunches everything with a larger split (s_mult); rare by construction
+		if (s_over && tid == 0) atomicAdd(g_err, 1u);
+		break;
+	}
+	if (tid == 0) atomicAdd(g_distinct, (u64) s_ndist);
+}
+
+// answers of the rank that holds the instances: one wave per question
+//   [0,4) pid | need<<30   [4,8) this rank's first gated instance   [8,24) its record's bases   [24,32) its N mask
+//   [32,84) QS: sum of the own qualities of this rank's OTHER gated instances (saturating at 255: >= 214 reads as 255 anyway)
+//   [84,136) the first instance's own qualities   [136,188) its RECORD's first k qualities (A2:337-339)
+__global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ queries, u32 nq, const u32* __restrict__ owner_off, u32 G,
+                                                    const Partial* __restrict__ dense, const u32* __restrict__ dense_ref,
+                                                    const u32* __restrict__ dstart, u32 NBo, const u32* __restrict__ low_inst,
+                                                    const u64* __restrict__ bases, const u64* __restrict__ nmask,
+                                                    const uint8_t* __restrict__ quals, int qstride, u32 rec_base, int P, int k,
+                                                    uint8_t* __restrict__ replies) {
+	const u32 qi = blockIdx.x;
+	if (qi >= nq) return;
+	const u32 lane = threadIdx.x;
+	u32 o = 0;
+	while (o + 1 < G && owner_off[o + 1] <= qi) o++;
+	const uint2 q = queries[qi];
+	const u32 di = dstart[(size_t) o * NBo] + q.x;
+	const Partial p = dense[di];
+	const u32 need = q.y >> 30;
+	const u32 finst = p.mg;
+	const u32 frec = finst / (u32) P - rec_base;
+	const u32 foff = finst % (u32) P;
+	uint8_t* out = replies + (size_t) qi * REPLY_BYTES;
+	if (lane == 0) {
+		((u32*) out)[0] = q.y;
+		((u32*) out)[1] = finst;
+		const ulonglong2 b = ((const ulonglong2*) bases)[frec];
+		((u64*) out)[1] = b.x;
+		((u64*) out)[2] = b.y;
+		((u64*) out)[3] = nmask[frec];
+	}
+	if ((int) lane >= k) return;
+	u32 acc = 0;
+	const u32 ref = dense_ref[di];
+	if ((need & NEED_Q) && ref != NONE32) {          // a question about the sums only comes for a count below TLOW: the list exists
+		const u32 cg = p.cg & ~PART_FLAG;
+		for (u32 i = 0; i < cg; i++) {
+			const u32 inst = low_inst[ref + i];
+			if (inst == finst) continue;
+			const u32 rec = inst / (u32) P - rec_base, off = inst % (u32) P;
+			acc += (u32) (uint8_t) (quals[(size_t) rec * (size_t) qstride + off + lane] - 33);
+		}
+	}
+	const uint8_t* fr = quals + (size_t) frec * (size_t) qstride;
+	out[32 + lane] = (uint8_t) (acc > 255u ? 255u : acc);
+	out[32 + REPLY_KQ + lane] = (uint8_t) (fr[foff + lane] - 33);
+	out[32 + 2 * REPLY_KQ + lane] = (uint8_t) (fr[lane] - 33);
+}
+
+// owner: which answer comes from the rank of the global first instance
+__global__ void k_resolve_first(const uint8_t* __restrict__ replies, u32 nr, const u32* __restrict__ p_mg, u32* __restrict__ p_r0) {
+	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nr) return;
+	const u32* w = (const u32*) (replies + (size_t) r * REPLY_BYTES);
+	const u32 pid = w[0] & PID_MASK;
+	if (w[1] == p_mg[pid]) p_r0[pid] = r;
+}
+
+__global__ void k_resolve_add(const uint8_t* __restrict__ replies, u32 nr, const u32* __restrict__ p_r0, int k, u32* __restrict__ p_fl,
+                              u32* __restrict__ p_S) {
+	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nr) return;
+	const uint8_t* me = replies + (size_t) r * REPLY_BYTES;
+	const u32 w0 = ((const u32*) me)[0];
+	const u32 pid = w0 & PID_MASK, need = w0 >> 30;
+	const u32 r0 = p_r0[pid];
+	if (r0 == NONE32) return;                   // cannot happen: the owner of the minimum always answers
+	if ((need & NEED_SEQ) && r != r0) {
+		const u64* a = (const u64*) me;
+		const u64* b = (const u64*) (replies + (size_t) r0 * REPLY_BYTES);
+		if (a[1] != b[1] || a[2] != b[2] || a[3] != b[3]) p_fl[pid] = 1;
+	}
+	if (need & NEED_Q) {
+		const uint8_t* first = me + 32 + (r == r0 ? 2 * REPLY_KQ : REPLY_KQ);
+		for (int j = 0; j < k; j++) atomicAdd(&p_S[(size_t) pid * 64 + j], (u32) me[32 + j] + (u32) first[j]);
+	}
+}
+
+__global__ void k_resolve_keep(PendOut po, u32 np, const u32* __restrict__ p_fl, const u32* __restrict__ p_S, int k, u32 mf, u32 mqq, u32 tlow,
+                               SurvOut so) {
+	const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= np) return;
+	const u32 need = po.need[p];
+	bool keep = (need & NEED_SEQ) ? p_fl[p] != 0 : true;
+	const u32 cg = po.cg[p];
+	if (keep && cg < tlow) {
+		for (int j = 0; j < k; j++) if (p_S[(size_t) p * 64 + j] < mqq) { keep = false; break; }
+	}
+	const u32 cgc = cg > CNT_CAP ? CNT_CAP : cg;
+	if (!keep || cgc < mf) return;
+	const u32 pos = atomicAdd(so.n, 1u);
+	if (pos < so.cap) {
+		so.lo[pos] = po.lo[p]; so.hi[pos] = po.hi[p];
+		so.gcnt[pos] = cgc; so.gfirst[pos] = po.mg[p];
+		so.ucnt[pos] = 0; so.ufirst[pos] = NONE32;
+	}
+}
+
+// ----------------------------------------------------------------------------------------------
 // K5: survivor lookup table, edges, V/J flags
 // ----------------------------------------------------------------------------------------------
 // table entry = 8-bit fingerprint of the key's hash | (survivor index + 1): a foreign key in the probed slot is almost
@@ -630,6 +1031,21 @@ __device__ inline int surv_lookup(const u32* __restrict__ table, u32 mask, const
 			if (kk.x == lo && kk.y == hi) return (int) ((v & 0xFFFFFFu) - 1);
 		}
 		slot = (slot + 1) & mask;
+	}
+}
+
+// the recount of add_to_graph for the survivors (sharded build): every k-mer this rank holds looks itself up in the
+// survivor table; a key appears once per rank, so plain stores do
+__global__ __launch_bounds__(256) void k_surv_counts(const LocalAll* __restrict__ sparse_a, const u32* __restrict__ bucket_start,
+                                                     const u32* __restrict__ nd_a, const u32* __restrict__ table, u32 mask,
+                                                     const ulonglong2* __restrict__ skey, u32* __restrict__ ucnt, u32* __restrict__ ufirst) {
+	const u32 b = blockIdx.x;
+	const LocalAll* a = sparse_a + bucket_start[b];
+	const u32 n = nd_a[b];
+	for (u32 i = threadIdx.x; i < n; i += 256) {
+		const LocalAll e = a[i];
+		const int s = surv_lookup(table, mask, skey, e.lo, e.hi);
+		if (s >= 0) { ucnt[s] = e.ca; ufirst[s] = e.ma; }
 	}
 }
 
@@ -707,25 +1123,8 @@ __global__ void k_node_flags(const u64* __restrict__ s_lo, const u64* __restrict
 
 
 // ----------------------------------------------------------------------------------------------
-// multi-GPU: the owner of a hash prefix re-buckets the tuples it received from every rank
+// multi-GPU: survivor records as exchanged between owners
 // ----------------------------------------------------------------------------------------------
-template <typename THI>
-__global__ __launch_bounds__(HIST_THREADS) void k_tuple_hist(const u64* __restrict__ lo, const THI* __restrict__ hi, size_t n,
-                                                             u32 shift, u32 local_mask, size_t tpb, u32* __restrict__ block_hist) {
-	extern __shared__ u32 hist[];
-	const u32 NBL = local_mask + 1;
-	for (u32 i = threadIdx.x; i < NBL; i += HIST_THREADS) hist[i] = 0;
-	__syncthreads();
-	const size_t t0 = (size_t) blockIdx.x * tpb;
-	const size_t t1 = t0 + tpb < n ? t0 + tpb : n;
-	for (size_t t = t0 + threadIdx.x; t < t1; t += HIST_THREADS) {
-		const u64 h = vdjx_mix(lo[t], (u64) hi[t]);
-		atomicAdd(&hist[(u32) (h >> shift) & local_mask], 1u);
-	}
-	__syncthreads();
-	for (u32 i = threadIdx.x; i < NBL; i += HIST_THREADS) block_hist[(size_t) blockIdx.x * NBL + i] = hist[i];
-}
-
 struct SurvRec { u64 lo, hi; u32 gcnt, gfirst, ucnt, ufirst; };   // 32 bytes: what owners exchange
 
 __global__ void k_surv_pack(const u64* __restrict__ lo, const u64* __restrict__ hi, const u32* __restrict__ gcnt,
@@ -1008,10 +1407,12 @@ int stage_partition_fill(vdjx_ctx* c, A& db, const vdjx_pool* pool, u32 rec_base
 // aggregate kernel would sweep them once per sub-pass.  Split every bucket further by the next hash bits so that
 // buckets stay near 2,048 tuples whatever the pool size (one more coalesced pass over the tuples).
 template <typename THI, typename A>
-int stage_refine(vdjx_ctx* c, A& db, Tuples<THI>* t, u32 used_bits) {
-	if (t->NB == 0 || t->N / t->NB <= 4096) return VDJX_OK;
+int stage_refine(vdjx_ctx* c, A& db, Tuples<THI>* t, u32 used_bits, size_t decide_N = 0) {
+	// decide_N: the sharded build sizes the split from a bound every rank knows, so that all ranks cut the same buckets
+	const size_t Nd = decide_N ? decide_N : t->N;
+	if (t->NB == 0 || Nd / t->NB <= 4096) return VDJX_OK;
 	u32 extra = 1;
-	while (extra < 10 && ((size_t) t->N >> extra) / t->NB > 2048 && t->NB << (extra + 1) <= (1u << 22)) extra++;
+	while (extra < 10 && (Nd >> extra) / t->NB > 2048 && t->NB << (extra + 1) <= (1u << 22)) extra++;
 	hipStream_t st = c->stream;
 	const u32 NBf = t->NB << extra;
 	u32 *fine_cnt, *fine_start, *gcur, *o_inst;
@@ -1033,62 +1434,6 @@ int stage_refine(vdjx_ctx* c, A& db, Tuples<THI>* t, u32 used_bits) {
 	t->bucket_start = fine_start;
 	t->NB = NBf;
 	return VDJX_OK;
-}
-
-// owner side: bucket the received tuples by the hash bits below the owner bits (same LDS-staged passes)
-template <typename THI, typename A>
-int stage_repartition(vdjx_ctx* c, A& db, const u64* r_lo, const THI* r_hi, const u32* r_inst, size_t n, u32 owner_bits,
-                      Tuples<THI>* out) {
-	hipStream_t st = c->stream;
-	const u32 lb = choose_nb_bits(n);
-	const PartGeom g = part_geom(lb);
-	const u32 NBL = 1u << lb;
-	u32 nblk = (u32) std::min<size_t>(512, (n + 65535) / 65536);
-	if (nblk == 0) nblk = 1;
-	const size_t tpb = (n + nblk - 1) / nblk;
-	u32 *block_hist, *bucket_cnt, *gcur, *whole;
-	HIP_TRY(db.alloc(&block_hist, (size_t) nblk * NBL));
-	HIP_TRY(db.alloc(&bucket_cnt, NBL));
-	HIP_TRY(db.alloc(&out->bucket_start, NBL + 1));
-	HIP_TRY(db.alloc(&out->lo, n));
-	HIP_TRY(db.alloc(&out->hi, n));
-	HIP_TRY(db.alloc(&out->inst, n));
-	HIP_TRY(db.alloc(&gcur, NBL));
-	HIP_TRY(db.alloc(&whole, 2));
-	const size_t lds = (size_t) NBL * 4;
-	HIP_TRY(hipFuncSetAttribute((const void*) k_tuple_hist<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-	HIP_TRY(hipFuncSetAttribute((const void*) k_part_tuples<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
-	const u32 seg[2] = {0u, (u32) n};
-	HIP_TRY(hipMemcpyAsync(whole, seg, 8, hipMemcpyHostToDevice, st));
-	{
-		vdjx_prof_scope ps(c, "k_tuple_hist");
-		hipLaunchKernelGGL(k_tuple_hist<THI>, dim3(nblk), dim3(HIST_THREADS), lds, st, r_lo, r_hi, n, 64 - owner_bits - lb, NBL - 1, tpb, block_hist);
-		hipLaunchKernelGGL(k_hist_colscan, dim3((NBL + 255) / 256), dim3(256), 0, st, block_hist, nblk, NBL, bucket_cnt);
-		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, bucket_cnt, NBL, out->bucket_start);
-	}
-	u64* l1_lo = out->lo; THI* l1_hi = out->hi; u32* l1_inst = out->inst;
-	if (g.fbits) {
-		HIP_TRY(db.alloc(&l1_lo, n)); HIP_TRY(db.alloc(&l1_hi, n)); HIP_TRY(db.alloc(&l1_inst, n));
-	}
-	{
-		vdjx_prof_scope ps(c, "k_part_tuples");
-		const u32 NBc = 1u << g.cbits;
-		const u32 sl1 = (u32) std::min<size_t>(1024, (n + 65535) / 65536) ? (u32) std::min<size_t>(1024, (n + 65535) / 65536) : 1u;
-		// pass 1: the whole input is one segment; cursors = starts of the coarse buckets
-		hipLaunchKernelGGL(k_init_cursors, dim3((NBc + 255) / 256), dim3(256), 0, st, out->bucket_start, NBc, g.fbits, gcur);
-		hipLaunchKernelGGL(k_part_tuples<THI>, dim3(sl1), dim3(PART_THREADS), PART_LDS_BYTES, st, r_lo, r_hi, r_inst, whole, 0u, sl1,
-		                   64 - owner_bits - g.cbits, g.cbits, gcur, l1_lo, l1_hi, l1_inst);
-		if (g.fbits) {
-			u32* gcur2;
-			HIP_TRY(db.alloc(&gcur2, NBL));
-			hipLaunchKernelGGL(k_init_cursors, dim3((NBL + 255) / 256), dim3(256), 0, st, out->bucket_start, NBL, 0u, gcur2);
-			hipLaunchKernelGGL(k_part_tuples<THI>, dim3(NBc * 4), dim3(PART_THREADS), PART_LDS_BYTES, st, l1_lo, l1_hi, l1_inst,
-			                   out->bucket_start, g.fbits, 4u, 64 - owner_bits - lb, g.fbits, gcur2, out->lo, out->hi, out->inst);
-		}
-	}
-	out->NB = NBL;
-	out->N = (u32) n;
-	return stage_refine<THI>(c, db, out, owner_bits + lb);
 }
 
 // K3a + K3b
@@ -1153,8 +1498,11 @@ int stage_reduce(vdjx_ctx* c, A& db, const Tuples<THI>& t, const PoolView& pv, i
 }
 
 // K5 over the records of `pool` (numbered from rec_base); edge arrays are caller-provided [ns*4]
+struct RecountSrc { const LocalAll* all; const u32* bucket_start; const u32* nd; u32 NB; u32* ucnt; u32* ufirst; };
+
 template <typename A>
-int stage_edges(vdjx_ctx* c, A& db, const vdjx_pool* pool, u32 rec_base, int k, const Survivors& sv, u32* edge_first, u32* edge_to) {
+int stage_edges(vdjx_ctx* c, A& db, const vdjx_pool* pool, u32 rec_base, int k, const Survivors& sv, u32* edge_first, u32* edge_to,
+                const RecountSrc* rc = nullptr) {
 	hipStream_t st = c->stream;
 	const u32 ns = sv.n;
 	u32 tmask = 1023;
@@ -1178,6 +1526,12 @@ int stage_edges(vdjx_ctx* c, A& db, const vdjx_pool* pool, u32 rec_base, int k, 
 		                   pool->n_records, rec_base, pool->rl, k, table, tmask, skey, link);
 	}
 	hipLaunchKernelGGL(k_links_split, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, link, ns * 4, edge_first, edge_to);
+	if (rc) {
+		HIP_TRY(hipMemsetAsync(rc->ucnt, 0, (size_t) ns * 4, st));
+		HIP_TRY(hipMemsetAsync(rc->ufirst, 0xFF, (size_t) ns * 4, st));
+		vdjx_prof_scope ps(c, "k_surv_counts");
+		hipLaunchKernelGGL(k_surv_counts, dim3(rc->NB), dim3(256), 0, st, rc->all, rc->bucket_start, rc->nd, table, tmask, skey, rc->ucnt, rc->ufirst);
+	}
 	return VDJX_OK;
 }
 
@@ -1323,10 +1677,27 @@ struct vdjx_shard {
 	int k = 0, mf = 0, mq = 0, rank = 0, nranks = 1;
 	u32 rec_stride = 0, nb_bits = 0, owner_bits = 0;
 	bool hi64 = false;
-	PartPlan pp{};
-	u32 N_local = 0;
-	PoolView gpool{nullptr, nullptr, nullptr, 0};
+	// local phase: this rank's tuples by bucket, its partial aggregates (dense, bucket order)
+	void *t_lo = nullptr, *t_hi = nullptr;
+	u32 *t_inst = nullptr, *t_bucket_start = nullptr;
+	u32 N_local = 0, NBf = 0, NBo = 0, total_bits = 0;
+	u32 *nd = nullptr, *dstart = nullptr;          // gated partials per bucket, their dense offsets
+	Partial* dense = nullptr;
+	u32* dense_ref = nullptr;                      // per dense partial: where its gated instances are listed (count < TLOW), or NONE
+	u32* low_inst = nullptr;
+	u32 n_dense = 0;
+	LocalAll* sparse_a = nullptr;                  // {count, first} over all instances, per bucket at the bucket's tuple offset
+	u32* nd_a = nullptr;
+	// owner phase
 	Survivors local_sv, all_sv;
+	u32 sv_cap = 0;
+	u32* n_surv = nullptr;
+	PendOut po{};
+	u32 n_pend = 0;
+	uint2* queries = nullptr;
+	std::vector<u32> src_base, nq;
+	u32 *p_fl = nullptr, *p_S = nullptr, *p_r0 = nullptr;
+	u32 mqq = 0, tlow = 0;
 	int phase = 0;
 };
 
@@ -1335,7 +1706,7 @@ extern "C" int vdjx_shard_begin(vdjx_ctx* c, const vdjx_pool* pool, int k, int m
 	if (!c || !pool || !out) { vdjx_set_error("vdjx_shard_begin: NULL argument"); return VDJX_EINVAL; }
 	*out = nullptr;
 	if (c->live_shard) { vdjx_set_error("vdjx_shard_begin: a sharded build is already in flight on this context"); return VDJX_ESTATE; }
-	if (nranks < 1 || (nranks & (nranks - 1)) || nranks > 256 || rank < 0 || rank >= nranks) { vdjx_set_error("nranks must be a power of two, 0 <= rank < nranks"); return VDJX_EINVAL; }
+	if (nranks < 1 || (nranks & (nranks - 1)) || nranks > 256 || rank < 0 || rank >= nranks) { vdjx_set_error("nranks must be a power of two <= 256, 0 <= rank < nranks"); return VDJX_EINVAL; }
 	if (k < 1 || k > VDJX_MAX_KMER || k > pool->rl) { vdjx_set_error("k=%d outside [1,min(%d,rl=%d)]", k, VDJX_MAX_KMER, pool->rl); return VDJX_ELIMIT; }
 	if (rec_stride < pool->n_records) { vdjx_set_error("rec_stride %llu < local records %zu", (unsigned long long) rec_stride, pool->n_records); return VDJX_EINVAL; }
 	const size_t NI = (size_t) rec_stride * nranks * (size_t) (pool->rl - k + 1);
@@ -1345,9 +1716,12 @@ extern "C" int vdjx_shard_begin(vdjx_ctx* c, const vdjx_pool* pool, int k, int m
 	s->c = c; s->pool = pool; s->k = k; s->mf = mf; s->mq = mq; s->rank = rank; s->nranks = nranks;
 	s->rec_stride = (u32) rec_stride;
 	s->hi64 = !key_hi_is_u32(k);
-	// sender side: a coarse partition (long, coalesced runs); the owner re-buckets what it receives for LDS
 	while ((1 << s->owner_bits) < nranks) s->owner_bits++;
-	s->nb_bits = s->owner_bits + 4 > 8 ? s->owner_bits + 4 : 8;
+	// every rank cuts the SAME buckets: the geometry follows the common stride, not the local record count
+	s->nb_bits = choose_nb_bits((size_t) rec_stride * (size_t) (pool->rl - k + 1));
+	if (mq >= 255) mq = 254;                                        // A2:1514-1516
+	s->mqq = (u32) (mq < 0 ? 0 : (mq > 214 ? 214 : mq));
+	s->tlow = 1 + (s->mqq + 19) / 20;
 	c->live_shard = s;
 	*out = s;
 	return VDJX_OK;
@@ -1362,94 +1736,293 @@ extern "C" void vdjx_shard_free(vdjx_shard* s) {
 	delete s;
 }
 
-extern "C" int vdjx_shard_qstride(const vdjx_shard* s) { return s ? s->pool->qstride : 0; }
-extern "C" int vdjx_shard_key_hi_bytes(const vdjx_shard* s) { return s ? (s->hi64 ? 8 : 4) : 0; }
+/* sizes of the records the caller moves between ranks: 0 partial aggregate, 1 question, 2 answer */
+extern "C" size_t vdjx_shard_record_bytes(int kind) { return kind == 0 ? sizeof(Partial) : kind == 1 ? sizeof(uint2) : kind == 2 ? REPLY_BYTES : 0; }
 
-// copy the local packed pool (bases 16 B, N mask 8 B, qualities qstride B per record) into caller buffers
-extern "C" int vdjx_shard_pool_export(vdjx_shard* s, void* d_bases, void* d_nmask, void* d_quals) {
-	if (!s || !d_bases || !d_nmask || !d_quals) { vdjx_set_error("vdjx_shard_pool_export: NULL argument"); return VDJX_EINVAL; }
-	const vdjx_pool* p = s->pool;
-	hipStream_t st = s->c->stream;
+__global__ void k_pick_u32(const u32* __restrict__ src, u32 step, u32 n, u32* __restrict__ out) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = src[(size_t) i * step];
+}
+
+template <typename THI>
+static int shard_local_impl(vdjx_shard* s) {
+	vdjx_ctx* c = s->c;
+	hipStream_t st = c->stream;
+	PersistAlloc db(c);
+	const int P = s->pool->rl - s->k + 1;
+	const u32 rec_base = s->rec_stride * (u32) s->rank;
+	PartPlan pp;
+	Tuples<THI> t;
+	int rc = stage_partition_count(c, db, s->pool, s->k, s->nb_bits, &pp, &t.N);
+	if (rc) return rc;
+	HIP_TRY(db.alloc(&t.lo, t.N)); HIP_TRY(db.alloc(&t.hi, t.N)); HIP_TRY(db.alloc(&t.inst, t.N));
+	t.bucket_start = pp.bucket_start;
+	t.NB = pp.NB;
+	rc = stage_partition_fill<THI>(c, db, s->pool, rec_base, s->k, pp, t.N, t.lo, t.hi, t.inst);
+	if (rc) return rc;
+	rc = stage_refine<THI>(c, db, &t, pp.nb_bits, (size_t) s->rec_stride * (size_t) P);
+	if (rc) return rc;
+	s->t_lo = t.lo; s->t_hi = t.hi; s->t_inst = t.inst; s->t_bucket_start = t.bucket_start;
+	s->N_local = t.N; s->NBf = t.NB;
+	s->total_bits = 0;
+	while ((1u << s->total_bits) < t.NB) s->total_bits++;
+	s->NBo = t.NB / (u32) s->nranks;
+	Partial* sparse;
+	u32* g_err;
+	u32* sparse_ref;
+	HIP_TRY(db.alloc(&sparse, t.N));
+	HIP_TRY(db.alloc(&sparse_ref, t.N));
+	HIP_TRY(db.alloc(&s->low_inst, t.N));
+	HIP_TRY(db.alloc(&s->sparse_a, t.N));
+	HIP_TRY(db.alloc(&s->nd_a, t.NB));
+	HIP_TRY(db.alloc(&s->nd, t.NB));
+	HIP_TRY(db.alloc(&s->dstart, t.NB + 1));
+	HIP_TRY(db.alloc(&g_err, 1));
+	HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
+	const size_t lds = (size_t) K3_SLOTS * (8 + sizeof(THI) + 24 + 1);
+	HIP_TRY(hipFuncSetAttribute((const void*) k_bucket_local<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+	{
+		vdjx_prof_scope ps(c, "k_bucket_local");
+		hipLaunchKernelGGL(k_bucket_local<THI>, dim3(t.NB), dim3(K3_THREADS), lds, st, t.lo, t.hi, t.inst, t.bucket_start, s->pool->d_bases,
+		                   s->pool->d_nmask, rec_base, P, s->tlow, sparse, sparse_ref, s->nd, s->sparse_a, s->nd_a, s->low_inst, g_err);
+	}
+	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, s->nd, t.NB, s->dstart);
+	u32* d_pick;
+	const u32 G = (u32) s->nranks;
+	HIP_TRY(db.alloc(&d_pick, G + 1));
+	hipLaunchKernelGGL(k_pick_u32, dim3(1), dim3(512), 0, st, s->dstart, s->NBo, G + 1, d_pick);
+	std::vector<u32> pick(G + 1);
+	u32 err = 0;
+	HIP_TRY(hipMemcpyAsync(pick.data(), d_pick, (G + 1) * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&err, g_err, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	if (err) { vdjx_set_error("k_bucket_local: %u buckets could not be split to fit LDS", err); return VDJX_EHIP; }
+	s->src_base.assign(pick.begin(), pick.end());        // reused below as "what goes to owner o" until the merge overwrites it
+	s->n_dense = pick[G];
+	HIP_TRY(db.alloc(&s->dense, s->n_dense));
+	HIP_TRY(db.alloc(&s->dense_ref, s->n_dense));
+	{
+		vdjx_prof_scope ps(c, "k_compact_partials");
+		hipLaunchKernelGGL(k_compact_partials, dim3(t.NB), dim3(256), 0, st, sparse, sparse_ref, t.bucket_start, s->nd, s->dstart, s->dense, s->dense_ref);
+	}
+	return VDJX_OK;
+}
+
+// phase 1: this rank's partial aggregates; send_counts[o] = how many go to owner o; *dir_len = buckets per owner
+extern "C" int vdjx_shard_local(vdjx_shard* s, uint64_t* send_counts, uint32_t* dir_len) {
+	if (!s || !send_counts || !dir_len) { vdjx_set_error("vdjx_shard_local: NULL argument"); return VDJX_EINVAL; }
+	if (s->phase != 0) { vdjx_set_error("vdjx_shard_local: already called"); return VDJX_ESTATE; }
 	HIP_TRY(hipSetDevice(s->c->device));
 	vdjx_clear_errors();
-	HIP_TRY(hipMemcpyAsync(d_bases, p->d_bases, p->n_records * 16, hipMemcpyDeviceToDevice, st));
-	HIP_TRY(hipMemcpyAsync(d_nmask, p->d_nmask, p->n_records * 8, hipMemcpyDeviceToDevice, st));
-	HIP_TRY(hipMemcpyAsync(d_quals, p->d_quals, p->n_records * (size_t) p->qstride, hipMemcpyDeviceToDevice, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	return VDJX_OK;
-}
-
-// the replicated pool: arrays of nranks*rec_stride records (rank-major), caller-owned for the shard's lifetime
-extern "C" int vdjx_shard_set_pool(vdjx_shard* s, const void* d_bases_all, const void* d_nmask_all, const void* d_quals_all) {
-	if (!s || !d_bases_all || !d_nmask_all || !d_quals_all) { vdjx_set_error("vdjx_shard_set_pool: NULL argument"); return VDJX_EINVAL; }
-	s->gpool = PoolView{(const u64*) d_bases_all, (const u64*) d_nmask_all, (const uint8_t*) d_quals_all, s->pool->qstride};
-	return VDJX_OK;
-}
-
-// tuples this rank will send to every owner
-extern "C" int vdjx_shard_partition_count(vdjx_shard* s, uint64_t* send_counts) {
-	if (!s || !send_counts) { vdjx_set_error("vdjx_shard_partition_count: NULL argument"); return VDJX_EINVAL; }
-	vdjx_ctx* c = s->c;
-	HIP_TRY(hipSetDevice(c->device));
-	vdjx_clear_errors();
-	PersistAlloc db(c);
-	int rc = stage_partition_count(c, db, s->pool, s->k, s->nb_bits, &s->pp, &s->N_local);
+	int rc = s->hi64 ? shard_local_impl<u64>(s) : shard_local_impl<u32>(s);
 	if (rc) return rc;
-	std::vector<u32> starts((size_t) s->pp.NB + 1);
-	HIP_TRY(hipMemcpy(starts.data(), s->pp.bucket_start, starts.size() * 4, hipMemcpyDeviceToHost));
-	const u32 per = s->pp.NB >> s->owner_bits;
-	for (int g = 0; g < s->nranks; g++) send_counts[g] = starts[(size_t) (g + 1) * per] - starts[(size_t) g * per];
+	for (int g = 0; g < s->nranks; g++) send_counts[g] = s->src_base[g + 1] - s->src_base[g];
+	*dir_len = s->NBo;
 	s->phase = 1;
 	return VDJX_OK;
 }
 
-// write the tuples, owner-contiguous, into caller buffers of sum(send_counts) entries
-extern "C" int vdjx_shard_partition_fill(vdjx_shard* s, void* d_lo, void* d_hi, void* d_inst) {
-	if (!s || s->phase < 1) { vdjx_set_error("vdjx_shard_partition_fill: call vdjx_shard_partition_count first"); return VDJX_ESTATE; }
-	if (s->N_local && (!d_lo || !d_hi || !d_inst)) { vdjx_set_error("vdjx_shard_partition_fill: NULL buffer"); return VDJX_EINVAL; }
-	vdjx_ctx* c = s->c;
-	HIP_TRY(hipSetDevice(c->device));
+// the bytes of phase 1 into caller buffers: d_dir = partials per bucket (u32 [nranks*dir_len], owner-major),
+// d_partials = sum(send_counts) records of vdjx_shard_record_bytes(0), owner-contiguous
+extern "C" int vdjx_shard_local_fill(vdjx_shard* s, void* d_dir, void* d_partials) {
+	if (!s || s->phase < 1) { vdjx_set_error("vdjx_shard_local_fill: call vdjx_shard_local first"); return VDJX_ESTATE; }
+	if (!d_dir || (s->n_dense && !d_partials)) { vdjx_set_error("vdjx_shard_local_fill: NULL buffer"); return VDJX_EINVAL; }
+	HIP_TRY(hipSetDevice(s->c->device));
 	vdjx_clear_errors();
-	const u32 rec_base = s->rec_stride * (u32) s->rank;
-	PersistAlloc db(c);
-	int rc = s->hi64 ? stage_partition_fill<u64>(c, db, s->pool, rec_base, s->k, s->pp, s->N_local, (u64*) d_lo, (u64*) d_hi, (u32*) d_inst)
-	                 : stage_partition_fill<u32>(c, db, s->pool, rec_base, s->k, s->pp, s->N_local, (u64*) d_lo, (u32*) d_hi, (u32*) d_inst);
-	if (rc) return rc;
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	HIP_TRY(hipGetLastError());
-	s->phase = 2;
+	hipStream_t st = s->c->stream;
+	HIP_TRY(hipMemcpyAsync(d_dir, s->nd, (size_t) s->NBf * 4, hipMemcpyDeviceToDevice, st));
+	if (s->n_dense) HIP_TRY(hipMemcpyAsync(d_partials, s->dense, (size_t) s->n_dense * sizeof(Partial), hipMemcpyDeviceToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));
 	return VDJX_OK;
 }
 
 template <typename THI>
-static int shard_reduce_impl(vdjx_shard* s, const void* d_lo, const void* d_hi, const void* d_inst, uint64_t n_recv) {
+static int shard_merge_impl(vdjx_shard* s, const u32* d_recv_dir, const Partial* d_recv, const uint64_t* recv_counts, uint64_t* query_counts) {
 	vdjx_ctx* c = s->c;
+	hipStream_t st = c->stream;
 	PersistAlloc db(c);
-	Tuples<THI> t;
-	int rc = stage_repartition<THI>(c, db, (const u64*) d_lo, (const THI*) d_hi, (const u32*) d_inst, (size_t) n_recv, s->owner_bits, &t);
-	if (rc) return rc;
-	return stage_reduce<THI>(c, db, t, s->gpool, s->k, s->pool->rl - s->k + 1, s->mf, s->mq, &s->local_sv);
+	const u32 G = (u32) s->nranks, NBo = s->NBo;
+	s->src_base.assign(G + 1, 0);
+	for (u32 g = 0; g < G; g++) s->src_base[g + 1] = s->src_base[g] + (u32) recv_counts[g];
+	const u32 total = s->src_base[G];
+	u32 *d_src_base, *seg_off, *g_nq, *g_err, *n_pend;
+	u64* g_distinct;
+	HIP_TRY(db.alloc(&d_src_base, G + 1));
+	HIP_TRY(db.alloc(&seg_off, (size_t) G * NBo));
+	HIP_TRY(db.alloc(&g_nq, G));
+	HIP_TRY(db.alloc(&g_err, 1));
+	HIP_TRY(db.alloc(&n_pend, 1));
+	HIP_TRY(db.alloc(&s->n_surv, 1));
+	HIP_TRY(db.alloc(&g_distinct, 1));
+	HIP_TRY(db.alloc(&s->queries, total));
+	const u32 cap = total + 1;
+	s->sv_cap = cap;
+	Survivors& v = s->local_sv;
+	HIP_TRY(db.alloc(&v.lo, cap)); HIP_TRY(db.alloc(&v.hi, cap)); HIP_TRY(db.alloc(&v.gcnt, cap));
+	HIP_TRY(db.alloc(&v.gfirst, cap)); HIP_TRY(db.alloc(&v.ucnt, cap)); HIP_TRY(db.alloc(&v.ufirst, cap));
+	PendOut& po = s->po;
+	HIP_TRY(db.alloc(&po.lo, cap)); HIP_TRY(db.alloc(&po.hi, cap)); HIP_TRY(db.alloc(&po.cg, cap)); HIP_TRY(db.alloc(&po.mg, cap));
+	HIP_TRY(db.alloc(&po.need, cap));
+	po.n = n_pend; po.cap = cap;
+	HIP_TRY(hipMemcpyAsync(d_src_base, s->src_base.data(), (G + 1) * 4, hipMemcpyHostToDevice, st));
+	hipLaunchKernelGGL(k_seg_offsets, dim3(G), dim3(1024), 0, st, d_recv_dir, d_src_base, G, NBo, seg_off);
+	const u32 cmin = (u32) std::max(s->mf, 2);
+	const size_t lds = (size_t) MERGE_SLOTS * (8 + sizeof(THI) + 16 + 1);
+	HIP_TRY(hipFuncSetAttribute((const void*) k_bucket_merge<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+	SurvOut so{v.lo, v.hi, v.gcnt, v.gfirst, v.ucnt, v.ufirst, s->n_surv, cap};
+	s->nq.assign(G, 0);
+	u32 np = 0, ns = 0, err = 0;
+	u64 ndist = 0;
+	for (u32 s_mult = 1;; s_mult *= 4) {
+		HIP_TRY(hipMemsetAsync(g_nq, 0, (size_t) G * 4, st));
+		HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
+		HIP_TRY(hipMemsetAsync(n_pend, 0, 4, st));
+		HIP_TRY(hipMemsetAsync(s->n_surv, 0, 4, st));
+		HIP_TRY(hipMemsetAsync(g_distinct, 0, 8, st));
+		if (total) {
+			vdjx_prof_scope ps(c, "k_bucket_merge");
+			hipLaunchKernelGGL(k_bucket_merge<THI>, dim3(NBo), dim3(MERGE_THREADS), lds, st, d_recv, seg_off, d_recv_dir, G, NBo, d_src_base, s_mult, cmin,
+			                   s->tlow, so, po, s->queries, g_nq, g_distinct, g_err);
+		}
+		HIP_TRY(hipMemcpyAsync(s->nq.data(), g_nq, (size_t) G * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(&np, n_pend, 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(&ns, s->n_surv, 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(&err, g_err, 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(&ndist, g_distinct, 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(hipGetLastError());
+		if (!err) break;
+		if (s_mult >= (1u << 16)) { vdjx_set_error("k_bucket_merge: %u buckets could not be split to fit LDS", err); return VDJX_EHIP; }
+	}
+	s->n_pend = np;
+	c->stats["shard_partials_received"] = total;
+	c->stats["shard_open_kmers"] = np;
+	c->stats["shard_decided_at_merge"] = ns;
+	{
+		u64 nqs = 0;
+		for (u32 q : s->nq) nqs += q;
+		c->stats["shard_questions"] = nqs;
+	}
+	v.n = ns;                    // decided without questions; vdjx_shard_resolve appends the rest
+	v.ndist = ndist;
+	for (u32 g = 0; g < G; g++) query_counts[g] = s->nq[g];
+	HIP_TRY(db.alloc(&s->p_fl, (size_t) np));
+	HIP_TRY(db.alloc(&s->p_r0, (size_t) np));
+	HIP_TRY(db.alloc(&s->p_S, (size_t) np * 64));
+	if (np) {
+		HIP_TRY(hipMemsetAsync(s->p_fl, 0, (size_t) np * 4, st));
+		HIP_TRY(hipMemsetAsync(s->p_r0, 0xFF, (size_t) np * 4, st));
+		HIP_TRY(hipMemsetAsync(s->p_S, 0, (size_t) np * 256, st));
+	}
+	return VDJX_OK;
 }
 
-// owner side: received tuples -> this rank's survivors
-extern "C" int vdjx_shard_reduce(vdjx_shard* s, const void* d_lo, const void* d_hi, const void* d_inst, uint64_t n_recv,
-                                 uint64_t* n_survivors, uint64_t* n_distinct) {
-	if (!s || !n_survivors || !n_distinct) { vdjx_set_error("vdjx_shard_reduce: NULL argument"); return VDJX_EINVAL; }
-	if (!s->gpool.bases) { vdjx_set_error("vdjx_shard_reduce: call vdjx_shard_set_pool first"); return VDJX_ESTATE; }
-	if (n_recv >= (1ull << 31)) { vdjx_set_error("vdjx_shard_reduce: too many tuples"); return VDJX_ELIMIT; }
+// phase 2 (owner): what every rank sent for this rank's hash prefix (source-major: d_recv_dir u32 [nranks*dir_len],
+// d_recv_partials sum(recv_counts) records) -> decided k-mers + questions; query_counts[r] = questions for rank r
+extern "C" int vdjx_shard_merge(vdjx_shard* s, const void* d_recv_dir, const void* d_recv_partials, const uint64_t* recv_counts,
+                                uint64_t* query_counts) {
+	if (!s || !recv_counts || !query_counts || !d_recv_dir) { vdjx_set_error("vdjx_shard_merge: NULL argument"); return VDJX_EINVAL; }
+	if (s->phase != 1) { vdjx_set_error("vdjx_shard_merge: call vdjx_shard_local first (once)"); return VDJX_ESTATE; }
+	uint64_t tot = 0;
+	for (int g = 0; g < s->nranks; g++) tot += recv_counts[g];
+	if (tot >= (1ull << 30)) { vdjx_set_error("vdjx_shard_merge: too many partial aggregates"); return VDJX_ELIMIT; }
+	if (tot && !d_recv_partials) { vdjx_set_error("vdjx_shard_merge: NULL buffer"); return VDJX_EINVAL; }
 	HIP_TRY(hipSetDevice(s->c->device));
 	vdjx_clear_errors();
-	int rc = s->hi64 ? shard_reduce_impl<u64>(s, d_lo, d_hi, d_inst, n_recv) : shard_reduce_impl<u32>(s, d_lo, d_hi, d_inst, n_recv);
+	int rc = s->hi64 ? shard_merge_impl<u64>(s, (const u32*) d_recv_dir, (const Partial*) d_recv_partials, recv_counts, query_counts)
+	                 : shard_merge_impl<u32>(s, (const u32*) d_recv_dir, (const Partial*) d_recv_partials, recv_counts, query_counts);
 	if (rc) return rc;
-	*n_survivors = s->local_sv.n;
-	*n_distinct = s->local_sv.ndist;
+	s->phase = 2;
+	return VDJX_OK;
+}
+
+// the questions, grouped by the rank they go to (sum(query_counts) records of vdjx_shard_record_bytes(1))
+extern "C" int vdjx_shard_queries(vdjx_shard* s, void* d_out) {
+	if (!s || s->phase < 2) { vdjx_set_error("vdjx_shard_queries: call vdjx_shard_merge first"); return VDJX_ESTATE; }
+	HIP_TRY(hipSetDevice(s->c->device));
+	vdjx_clear_errors();
+	hipStream_t st = s->c->stream;
+	size_t at = 0;
+	for (int g = 0; g < s->nranks; g++) {
+		if (!s->nq[g]) continue;
+		if (!d_out) { vdjx_set_error("vdjx_shard_queries: NULL buffer"); return VDJX_EINVAL; }
+		HIP_TRY(hipMemcpyAsync((uint2*) d_out + at, s->queries + s->src_base[g], (size_t) s->nq[g] * sizeof(uint2), hipMemcpyDeviceToDevice, st));
+		at += s->nq[g];
+	}
+	HIP_TRY(hipStreamSynchronize(st));
+	return VDJX_OK;
+}
+
+// phase 3 (every rank): answer the questions of the owners; counts[o] = questions from owner o (grouped in that order);
+// d_replies = sum(counts) records of vdjx_shard_record_bytes(2), same order
+extern "C" int vdjx_shard_reply(vdjx_shard* s, const void* d_queries, const uint64_t* counts, void* d_replies) {
+	if (!s || !counts) { vdjx_set_error("vdjx_shard_reply: NULL argument"); return VDJX_EINVAL; }
+	if (s->phase < 1) { vdjx_set_error("vdjx_shard_reply: call vdjx_shard_local first"); return VDJX_ESTATE; }
+	vdjx_ctx* c = s->c;
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
+	const u32 G = (u32) s->nranks;
+	std::vector<u32> off(G + 1, 0);
+	for (u32 g = 0; g < G; g++) off[g + 1] = off[g] + (u32) counts[g];
+	const u32 nq = off[G];
+	if (!nq) return VDJX_OK;
+	if (!d_queries || !d_replies) { vdjx_set_error("vdjx_shard_reply: NULL buffer"); return VDJX_EINVAL; }
+	PersistAlloc db(c);
+	u32* d_off;
+	HIP_TRY(db.alloc(&d_off, G + 1));
+	hipStream_t st = c->stream;
+	HIP_TRY(hipMemcpyAsync(d_off, off.data(), (G + 1) * 4, hipMemcpyHostToDevice, st));
+	const vdjx_pool* p = s->pool;
+	const int P = p->rl - s->k + 1;
+	const u32 rec_base = s->rec_stride * (u32) s->rank;
+	{
+		vdjx_prof_scope ps(c, "k_shard_reply");
+		hipLaunchKernelGGL(k_shard_reply, dim3(nq), dim3(64), 0, st, (const uint2*) d_queries, nq, d_off, G, s->dense, s->dense_ref, s->dstart, s->NBo,
+		                   s->low_inst, p->d_bases, p->d_nmask, p->d_quals, p->qstride, rec_base, P, s->k, (uint8_t*) d_replies);
+	}
+	HIP_TRY(hipStreamSynchronize(st));          // `off` staging dies with this frame
+	HIP_TRY(hipGetLastError());
+	return VDJX_OK;
+}
+
+// phase 4 (owner): the answers (grouped by answering rank, in the order the questions were listed) -> this rank's survivors
+extern "C" int vdjx_shard_resolve(vdjx_shard* s, const void* d_replies, uint64_t n_replies, uint64_t* n_survivors, uint64_t* n_distinct) {
+	if (!s || !n_survivors || !n_distinct) { vdjx_set_error("vdjx_shard_resolve: NULL argument"); return VDJX_EINVAL; }
+	if (s->phase != 2) { vdjx_set_error("vdjx_shard_resolve: call vdjx_shard_merge first (once)"); return VDJX_ESTATE; }
+	uint64_t expect = 0;
+	for (u32 q : s->nq) expect += q;
+	if (n_replies != expect) { vdjx_set_error("vdjx_shard_resolve: %llu answers for %llu questions", (unsigned long long) n_replies, (unsigned long long) expect); return VDJX_EINVAL; }
+	vdjx_ctx* c = s->c;
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
+	hipStream_t st = c->stream;
+	Survivors& v = s->local_sv;
+	if (s->n_pend) {
+		if (!d_replies) { vdjx_set_error("vdjx_shard_resolve: NULL buffer"); return VDJX_EINVAL; }
+		const u32 nr = (u32) n_replies;
+		SurvOut so{v.lo, v.hi, v.gcnt, v.gfirst, v.ucnt, v.ufirst, s->n_surv, s->sv_cap};
+		vdjx_prof_scope ps(c, "k_shard_resolve");
+		hipLaunchKernelGGL(k_resolve_first, dim3((nr + 255) / 256), dim3(256), 0, st, (const uint8_t*) d_replies, nr, s->po.mg, s->p_r0);
+		hipLaunchKernelGGL(k_resolve_add, dim3((nr + 255) / 256), dim3(256), 0, st, (const uint8_t*) d_replies, nr, s->p_r0, s->k, s->p_fl, s->p_S);
+		hipLaunchKernelGGL(k_resolve_keep, dim3((s->n_pend + 255) / 256), dim3(256), 0, st, s->po, s->n_pend, s->p_fl, s->p_S, s->k,
+		                   (u32) std::max(s->mf, 0), s->mqq, s->tlow, so);
+	}
+	u32 ns = 0;
+	HIP_TRY(hipMemcpyAsync(&ns, s->n_surv, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	c->stats["shard_kept_after_answers"] = ns - v.n;
+	v.n = ns;
+	*n_survivors = ns;
+	*n_distinct = v.ndist;
 	s->phase = 3;
 	return VDJX_OK;
 }
 
 // this rank's survivors as 32-byte records {key_lo, key_hi, gated count, gated first, count, first}
 extern "C" int vdjx_shard_survivors(vdjx_shard* s, void* d_out) {
-	if (!s || s->phase < 3) { vdjx_set_error("vdjx_shard_survivors: call vdjx_shard_reduce first"); return VDJX_ESTATE; }
+	if (!s || s->phase < 3) { vdjx_set_error("vdjx_shard_survivors: call vdjx_shard_resolve first"); return VDJX_ESTATE; }
 	const Survivors& v = s->local_sv;
 	if (!v.n) return VDJX_OK;
 	if (!d_out) { vdjx_set_error("vdjx_shard_survivors: NULL buffer"); return VDJX_EINVAL; }
@@ -1462,8 +2035,10 @@ extern "C" int vdjx_shard_survivors(vdjx_shard* s, void* d_out) {
 }
 
 // every rank: all survivors (rank order) + local edge pass into caller arrays [ns_total*4] (to be MIN-reduced over ranks)
-extern "C" int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t ns_total, void* d_edge_first, void* d_edge_to) {
-	if (!s || s->phase < 3) { vdjx_set_error("vdjx_shard_edges: call vdjx_shard_reduce first"); return VDJX_ESTATE; }
+// and this rank's share of the recount: d_ucnt (to be SUMmed) and d_ufirst (to be MIN-reduced), [ns_total] each
+extern "C" int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t ns_total, void* d_edge_first, void* d_edge_to,
+                                void* d_ucnt, void* d_ufirst) {
+	if (!s || s->phase < 3) { vdjx_set_error("vdjx_shard_edges: call vdjx_shard_resolve first"); return VDJX_ESTATE; }
 	if (ns_total >= (1ull << 30)) { vdjx_set_error("vdjx_shard_edges: too many survivors"); return VDJX_ELIMIT; }
 	vdjx_ctx* c = s->c;
 	HIP_TRY(hipSetDevice(c->device));
@@ -1473,20 +2048,29 @@ extern "C" int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t 
 	a.n = (u32) ns_total;
 	s->phase = 4;
 	if (!ns_total) return VDJX_OK;
-	if (!d_surv_all || !d_edge_first || !d_edge_to) { vdjx_set_error("vdjx_shard_edges: NULL buffer"); return VDJX_EINVAL; }
+	if (!d_surv_all || !d_edge_first || !d_edge_to || !d_ucnt || !d_ufirst) { vdjx_set_error("vdjx_shard_edges: NULL buffer"); return VDJX_EINVAL; }
 	HIP_TRY(db.alloc(&a.lo, a.n)); HIP_TRY(db.alloc(&a.hi, a.n)); HIP_TRY(db.alloc(&a.gcnt, a.n));
 	HIP_TRY(db.alloc(&a.gfirst, a.n)); HIP_TRY(db.alloc(&a.ucnt, a.n)); HIP_TRY(db.alloc(&a.ufirst, a.n));
 	hipLaunchKernelGGL(k_surv_unpack, dim3((a.n + 255) / 256), dim3(256), 0, c->stream, (const SurvRec*) d_surv_all, a.n, a.lo, a.hi, a.gcnt,
 	                   a.gfirst, a.ucnt, a.ufirst);
-	int rc = stage_edges(c, db, s->pool, s->rec_stride * (u32) s->rank, s->k, a, (u32*) d_edge_first, (u32*) d_edge_to);
+	const RecountSrc rs{s->sparse_a, s->t_bucket_start, s->nd_a, s->NBf, (u32*) d_ucnt, (u32*) d_ufirst};
+	int rc = stage_edges(c, db, s->pool, s->rec_stride * (u32) s->rank, s->k, a, (u32*) d_edge_first, (u32*) d_edge_to, &rs);
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	HIP_TRY(hipGetLastError());
 	return VDJX_OK;
 }
 
-// every rank: reduced edge arrays -> the graph (identical on all ranks)
-extern "C" int vdjx_shard_finish(vdjx_shard* s, const void* d_edge_first, const void* d_edge_to, uint64_t pre_nodes_total, vdjx_graph** out) {
+__global__ void k_recount_set(const u32* __restrict__ ucnt_sum, const u32* __restrict__ ufirst_min, u32 n, u32* __restrict__ ucnt, u32* __restrict__ ufirst) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	ucnt[i] = ucnt_sum[i] > CNT_CAP ? CNT_CAP : ucnt_sum[i];         // A2:261-265
+	ufirst[i] = ufirst_min[i];
+}
+
+// every rank: reduced edge and recount arrays -> the graph (identical on all ranks)
+extern "C" int vdjx_shard_finish(vdjx_shard* s, const void* d_edge_first, const void* d_edge_to, const void* d_ucnt, const void* d_ufirst,
+                                 uint64_t pre_nodes_total, vdjx_graph** out) {
 	if (!s || !out || s->phase < 4) { vdjx_set_error("vdjx_shard_finish: call vdjx_shard_edges first"); return VDJX_ESTATE; }
 	*out = nullptr;
 	vdjx_ctx* c = s->c;
@@ -1495,9 +2079,14 @@ extern "C" int vdjx_shard_finish(vdjx_shard* s, const void* d_edge_first, const 
 	PersistAlloc db(c);
 	const int P = s->pool->rl - s->k + 1;
 	const size_t NI = (size_t) s->rec_stride * s->nranks * (size_t) P;
+	Survivors& a = s->all_sv;
+	if (a.n) {
+		if (!d_ucnt || !d_ufirst) { vdjx_set_error("vdjx_shard_finish: NULL buffer"); return VDJX_EINVAL; }
+		hipLaunchKernelGGL(k_recount_set, dim3((a.n + 255) / 256), dim3(256), 0, c->stream, (const u32*) d_ucnt, (const u32*) d_ufirst, a.n, a.ucnt, a.ufirst);
+	}
 	vdjx_graph* g = new vdjx_graph();
 	g->pre_nodes = (size_t) pre_nodes_total;
-	int rc = stage_finish(c, db, s->all_sv, (const u32*) d_edge_first, (const u32*) d_edge_to, NI, s->k, P, g);
+	int rc = stage_finish(c, db, a, (const u32*) d_edge_first, (const u32*) d_edge_to, NI, s->k, P, g);
 	if (rc) { vdjx_graph_free(g); return rc; }
 	*out = g;
 	return VDJX_OK;

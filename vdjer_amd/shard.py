@@ -1,4 +1,4 @@
-"""Multi-GPU k-mer build: hash-prefix sharding with one exchange step.
+"""Multi-GPU k-mer build: hash-prefix sharding, partial aggregates merged by the owner.
 
 One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
 tests).  Every rank holds its own slice of the read pool.  Record numbering is rank-major with a common
@@ -6,14 +6,18 @@ stride: rank r's records are [r*stride, r*stride + R_r), which is also the scan 
 union pool, so "first instance" means the same thing as in a single-process run over the concatenation.
 
 Phases (the engine does the compute, this module only moves bytes):
-  1. all_gather of the packed pool (16 B bases + 8 B N mask + qstride B qualities per record) -- the prune
-     needs the first instance's record and the low-count instances' qualities, wherever they live
-  2. every rank partitions its k-mer instances by owner = top log2(G) bits of the k-mer hash
-  3. ONE all-to-all (counts, then the three tuple columns): every instance reaches its owner
-  4. owners reduce (count / first / distinct-read flag / quality sums / ungated recount) and prune
-  5. all_gather of the survivors (32 B each), local edge pass, all_reduce(MIN) of the edge first-sight arrays
-  6. every rank numbers the nodes and orders the edge lists (identical result on all ranks)
-The serial de Bruijn traversal then runs on rank 0 (north star: host-side, not sharded).
+  1. every rank aggregates ITS instances per distinct k-mer: gated/ungated count, gated/ungated first instance,
+     "saw two different reads" (add_to_table A2:322-367 restated per rank)          -- no communication
+  2. ONE bulk all-to-all: the partial aggregates (24 B per distinct gated k-mer per rank, NOT per instance) go to the
+     owner of the k-mer = top log2(G) bits of its hash, with a per-bucket directory
+  3. the owner merges (counts add, firsts take the minimum, flags OR) and decides almost every k-mer; the few whose
+     verdict needs per-read data (flag still open although several ranks hold the k-mer; count so low that the
+     quality sums matter) cost a question (8 B) to the holders and an answer (192 B): two tiny all-to-alls
+  4. all_gather of the survivors (32 B each); local edge pass and local recount of the survivors' instances
+     (add_to_graph, A2:261-309); all_reduce MIN (edge first sights, first instances) and SUM (counts)
+  5. every rank numbers the nodes and orders the edge lists (identical result on all ranks)
+The read pool itself never leaves its rank.  The serial de Bruijn traversal then runs on rank 0 (north star:
+host-side, not sharded).
 """
 from __future__ import annotations
 
@@ -34,21 +38,23 @@ def _bind(L):
     L.vdjx_shard_begin.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(vp)]
     L.vdjx_shard_free.argtypes = [vp]
     L.vdjx_shard_free.restype = None
-    L.vdjx_shard_qstride.argtypes = [vp]
-    L.vdjx_shard_key_hi_bytes.argtypes = [vp]
-    L.vdjx_shard_pool_export.argtypes = [vp, vp, vp, vp]
-    L.vdjx_shard_set_pool.argtypes = [vp, vp, vp, vp]
-    L.vdjx_shard_partition_count.argtypes = [vp, u64p]
-    L.vdjx_shard_partition_fill.argtypes = [vp, vp, vp, vp]
-    L.vdjx_shard_reduce.argtypes = [vp, vp, vp, vp, C.c_uint64, u64p, u64p]
+    L.vdjx_shard_record_bytes.argtypes = [C.c_int]
+    L.vdjx_shard_record_bytes.restype = C.c_size_t
+    L.vdjx_shard_local.argtypes = [vp, u64p, C.POINTER(C.c_uint32)]
+    L.vdjx_shard_local_fill.argtypes = [vp, vp, vp]
+    L.vdjx_shard_merge.argtypes = [vp, vp, vp, u64p, u64p]
+    L.vdjx_shard_queries.argtypes = [vp, vp]
+    L.vdjx_shard_reply.argtypes = [vp, vp, u64p, vp]
+    L.vdjx_shard_resolve.argtypes = [vp, vp, C.c_uint64, u64p, u64p]
     L.vdjx_shard_survivors.argtypes = [vp, vp]
-    L.vdjx_shard_edges.argtypes = [vp, vp, C.c_uint64, vp, vp]
-    L.vdjx_shard_finish.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp)]
+    L.vdjx_shard_edges.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp]
+    L.vdjx_shard_finish.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(vp)]
     L._shard_bound = True
 
 
 class HipShardEngine:
-    """The phases of one sharded build on this rank's GPU (libvdjx.so, device tensors owned by torch)."""
+    """The phases of one sharded build on this rank's GPU (libvdjx.so, device tensors owned by torch).
+    Exchanged records are opaque rows of bytes: [n, vdjx_shard_record_bytes(kind)] uint8."""
 
     def __init__(self, ctx, device):
         import torch
@@ -58,53 +64,54 @@ class HipShardEngine:
         _bind(self.L)
         self.dev = device
         self.h = None
+        self.W = [int(self.L.vdjx_shard_record_bytes(i)) for i in range(3)]
 
     def begin(self, pool, k, mf, mq, rank, world, stride):
         h = C.c_void_p()
         check(self.L.vdjx_shard_begin(self.ctx.h, pool.h, k, mf, mq, rank, world, stride, C.byref(h)), "vdjx_shard_begin")
         self.h, self.pool, self.k, self.world = h, pool, k, world
-        self.hi_bytes = self.L.vdjx_shard_key_hi_bytes(h)
-        self.qstride = self.L.vdjx_shard_qstride(h)
+        self._keep = []
 
     def _dp(self, t):
         return C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
 
-    def pool_export(self):
-        t, R = self.torch, self.pool.n_records
-        out = [t.empty((R, 16), dtype=t.uint8, device=self.dev), t.empty((R, 8), dtype=t.uint8, device=self.dev),
-               t.empty((R, self.qstride), dtype=t.uint8, device=self.dev)]
-        if R:
-            check(self.L.vdjx_shard_pool_export(self.h, *[self._dp(x) for x in out]), "vdjx_shard_pool_export")
+    def _u64(self, values):
+        return (C.c_uint64 * self.world)(*[int(v) for v in values])
+
+    def local(self):
+        """-> (partials per owner [G], directory int32 [G*dir_len], partial aggregates [n, 32] uint8)"""
+        t = self.torch
+        cnt, dl = (C.c_uint64 * self.world)(), C.c_uint32()
+        check(self.L.vdjx_shard_local(self.h, cnt, C.byref(dl)), "vdjx_shard_local")
+        counts = np.array(list(cnt), dtype=np.int64)
+        d = t.empty(self.world * int(dl.value), dtype=t.int32, device=self.dev)
+        parts = t.empty((int(counts.sum()), self.W[0]), dtype=t.uint8, device=self.dev)
+        check(self.L.vdjx_shard_local_fill(self.h, self._dp(d), self._dp(parts)), "vdjx_shard_local_fill")
+        return counts, d, parts
+
+    def merge(self, recv_dir, recv_parts, recv_counts):
+        """-> questions per rank [G]"""
+        qc = (C.c_uint64 * self.world)()
+        self._keep += [recv_dir, recv_parts]
+        check(self.L.vdjx_shard_merge(self.h, self._dp(recv_dir), self._dp(recv_parts), self._u64(recv_counts), qc), "vdjx_shard_merge")
+        self._nq = np.array(list(qc), dtype=np.int64)
+        return self._nq
+
+    def queries(self):
+        t = self.torch
+        q = t.empty((int(self._nq.sum()), self.W[1]), dtype=t.uint8, device=self.dev)
+        check(self.L.vdjx_shard_queries(self.h, self._dp(q)), "vdjx_shard_queries")
+        return q
+
+    def reply(self, queries, counts):
+        t = self.torch
+        out = t.empty((queries.shape[0], self.W[2]), dtype=t.uint8, device=self.dev)
+        check(self.L.vdjx_shard_reply(self.h, self._dp(queries), self._u64(counts), self._dp(out)), "vdjx_shard_reply")
         return out
 
-    def set_pool(self, tensors):
-        self._gpool = tensors
-        check(self.L.vdjx_shard_set_pool(self.h, *[C.c_void_p(x.data_ptr()) for x in tensors]), "vdjx_shard_set_pool")
-
-    def partition_count(self):
-        cnt = (C.c_uint64 * self.world)()
-        check(self.L.vdjx_shard_partition_count(self.h, cnt), "vdjx_shard_partition_count")
-        return np.array(list(cnt), dtype=np.int64)
-
-    def partition_fill(self, n):
-        t = self.torch
-        lo = t.empty(n, dtype=t.int64, device=self.dev)
-        hi = t.empty(n, dtype=t.int64 if self.hi_bytes == 8 else t.int32, device=self.dev)
-        inst = t.empty(n, dtype=t.int32, device=self.dev)
-        check(self.L.vdjx_shard_partition_fill(self.h, self._dp(lo), self._dp(hi), self._dp(inst)), "vdjx_shard_partition_fill")
-        return [lo, hi, inst]
-
-    def recv_like(self, n):
-        t = self.torch
-        return [t.empty(n, dtype=t.int64, device=self.dev),
-                t.empty(n, dtype=t.int64 if self.hi_bytes == 8 else t.int32, device=self.dev),
-                t.empty(n, dtype=t.int32, device=self.dev)]
-
-    def reduce(self, recv):
+    def resolve(self, replies):
         ns, nd = C.c_uint64(), C.c_uint64()
-        self._recv = recv
-        check(self.L.vdjx_shard_reduce(self.h, self._dp(recv[0]), self._dp(recv[1]), self._dp(recv[2]), recv[0].numel(),
-                                       C.byref(ns), C.byref(nd)), "vdjx_shard_reduce")
+        check(self.L.vdjx_shard_resolve(self.h, self._dp(replies), replies.shape[0], C.byref(ns), C.byref(nd)), "vdjx_shard_resolve")
         return int(ns.value), int(nd.value)
 
     def survivors(self, ns):
@@ -114,24 +121,29 @@ class HipShardEngine:
         return out
 
     def edges(self, surv_all):
+        """-> (mins, ucnt): `mins` = edge first-sight | edge target | first instance of every survivor on this rank, one int32
+        tensor [9*n] to be MIN-reduced (unsigned order); ucnt int32 [n] = this rank's instances per survivor, to be SUMmed"""
         t = self.torch
         n = surv_all.shape[0]
-        ef = t.empty(n * 4, dtype=t.int32, device=self.dev)
-        et = t.empty(n * 4, dtype=t.int32, device=self.dev)
-        self._surv_all = surv_all
-        check(self.L.vdjx_shard_edges(self.h, self._dp(surv_all), n, self._dp(ef), self._dp(et)), "vdjx_shard_edges")
-        return ef, et
+        mins = t.empty(n * 9, dtype=t.int32, device=self.dev)
+        ucnt = t.empty(n, dtype=t.int32, device=self.dev)
+        self._keep.append(surv_all)
+        check(self.L.vdjx_shard_edges(self.h, self._dp(surv_all), n, self._dp(mins[:4 * n]), self._dp(mins[4 * n:8 * n]), self._dp(ucnt),
+                                      self._dp(mins[8 * n:])), "vdjx_shard_edges")
+        return mins, ucnt
 
-    def finish(self, ef, et, pre_total, keep_device: bool = False):
+    def finish(self, mins, ucnt, pre_total, keep_device: bool = False):
         g = C.c_void_p()
-        check(self.L.vdjx_shard_finish(self.h, self._dp(ef), self._dp(et), pre_total, C.byref(g)), "vdjx_shard_finish")
+        n = ucnt.shape[0]
+        check(self.L.vdjx_shard_finish(self.h, self._dp(mins[:4 * n]), self._dp(mins[4 * n:8 * n]), self._dp(ucnt), self._dp(mins[8 * n:]),
+                                       pre_total, C.byref(g)), "vdjx_shard_finish")
         return self.ctx._export_graph(g, self.k, keep_device)
 
     def end(self):
         if self.h:
             self.L.vdjx_shard_free(self.h)
             self.h = None
-        self._gpool = self._recv = self._surv_all = None
+        self._keep = []
 
 
 class Comm:
@@ -221,6 +233,7 @@ class ShardedHotPath:
             raise ValueError("the number of ranks must be a power of two (ownership = hash-prefix bits)")
         self.engine = engine if engine is not None else HipShardEngine(ctx, device)
         self.stride = None
+        self.laps = {}               # seconds per phase of kmer_build, summed over calls (host clock, diagnostic)
 
     @property
     def bytes_exchanged(self):
@@ -234,58 +247,67 @@ class ShardedHotPath:
             cm.all_reduce(s, dist.ReduceOp.MAX)
             self.stride = int(s.item())
         stride = self.stride
+        import time
+        clock = [time.perf_counter()]
+
+        def lap(name):
+            now = time.perf_counter()
+            self.laps[name] = self.laps.get(name, 0.0) + now - clock[0]
+            clock[0] = now
+
         eng.begin(pool, k, mf, mq, r, G, stride)
         try:
-            # 1. replicate the packed pool (rank-major, common stride).  On RCCL the all_gathers are issued
-            #    asynchronously: they run on the communicator's stream while this rank partitions its k-mers (2.)
-            glob, pending = [], []
-            for x in eng.pool_export():
-                pad = t.zeros((stride,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-                pad[:x.shape[0]] = x
-                if cm.async_ok:
-                    full = t.empty((G * stride,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-                    cm.sync()                     # `pad` was written on torch's stream by the library-exported copy
-                    pending.append((dist.all_gather_into_tensor(full, pad, async_op=True), pad))
-                    cm.bytes += full.numel() * full.element_size()
-                    glob.append(full)
-                else:
-                    glob.append(cm.all_gather_cat(pad))
-            if not pending:
+            def exchange(send, ins, outs):
+                recv = t.empty((int(sum(outs)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+                cm.all_to_all_v(send, [int(v) for v in ins], recv, [int(v) for v in outs])
+                return recv
+
+            def counts_of(x):            # what every peer will send me, given what I send every peer
+                got = exchange(t.tensor([int(v) for v in x], dtype=t.int64, device=self.dev), [1] * G, [1] * G)
                 cm.sync()
-            eng.set_pool(glob)        # pointers only; the first consumer is reduce() in step 4
-            # 2./3. partition by owner, then the exchange step: counts, then the tuple columns
-            send_counts = eng.partition_count()
-            sc = t.tensor(send_counts, dtype=t.int64, device=self.dev)
-            rc = t.empty_like(sc)
-            cm.all_to_all_v(sc, [1] * G, rc, [1] * G)
+                return got.cpu().numpy()
+
+            # 1. local aggregation; 2. the bulk exchange: per-bucket directory (its sums are the receive counts), then the
+            #    partial aggregates themselves
+            send_counts, sdir, sparts = eng.local()
+            lap("local")
+            dl = sdir.numel() // G
+            rdir = exchange(sdir, [dl] * G, [dl] * G)
             cm.sync()
-            recv_counts = rc.cpu().numpy()
-            send = eng.partition_fill(int(send_counts.sum()))
-            recv = eng.recv_like(int(recv_counts.sum()))
-            ins, outs = [int(v) for v in send_counts], [int(v) for v in recv_counts]
-            for s_, r_ in zip(send, recv):
-                cm.all_to_all_v(s_, ins, r_, outs)
-            for h_, _pad in pending:
-                h_.wait()
+            recv_counts = rdir.view(G, dl).sum(dim=1, dtype=t.int64).cpu().numpy()
+            rparts = exchange(sparts, send_counts, recv_counts)
             cm.sync()
-            del send, pending
-            # 4. owners reduce and prune
-            ns, ndist = eng.reduce(recv)
+            lap("exchange_partials")
+            # 3. owners merge and decide; questions and answers for the few open k-mers
+            q_out = eng.merge(rdir, rparts, recv_counts)
+            lap("merge")
+            q_in = counts_of(q_out)
+            rq = exchange(eng.queries(), q_out, q_in)
+            cm.sync()
+            answers = exchange(eng.reply(rq, q_in), q_in, q_out)
+            cm.sync()
+            lap("questions_answers")
+            ns, ndist = eng.resolve(answers)
+            del sparts, rq
+            lap("resolve")
             meta = cm.all_gather_cat(t.tensor([[ns, ndist]], dtype=t.int64, device=self.dev)).cpu().numpy()
             ns_all = [int(v) for v in meta[:, 0]]
             pre_total = int(meta[:, 1].sum())
-            # 5. survivors everywhere, local edges, MIN over ranks
+            # 4. survivors everywhere, local edges, MIN over ranks
             surv_all = cm.all_gather_var(eng.survivors(ns), ns_all)
             cm.sync()
-            ef, et = eng.edges(surv_all)
-            if ef.numel():
+            lap("gather_survivors")
+            mins, ucnt = eng.edges(surv_all)
+            lap("edges")
+            if ucnt.numel():
                 flip = -2 ** 31       # unsigned order on int32 tensors: flip the sign bit around the MIN
-                for x in (ef, et):
-                    x.bitwise_xor_(flip)
-                    cm.all_reduce(x, dist.ReduceOp.MIN)
-                    x.bitwise_xor_(flip)
+                mins.bitwise_xor_(flip)
+                cm.all_reduce(mins, dist.ReduceOp.MIN)
+                mins.bitwise_xor_(flip)
+                cm.all_reduce(ucnt, dist.ReduceOp.SUM)
             cm.sync()
-            # 6. node numbering + list order
-            return eng.finish(ef, et, pre_total, keep_device=True) if keep_device else eng.finish(ef, et, pre_total)
+            lap("reduce_edges")
+            # 5. node numbering + list order
+            return eng.finish(mins, ucnt, pre_total, keep_device=True) if keep_device else eng.finish(mins, ucnt, pre_total)
         finally:
             eng.end()
