@@ -52,14 +52,19 @@ def scorer_bytes(stats: dict, n_windows: int, n_contigs: int, k: int, rl: int = 
             "k_root_dp": 3 * k * stats.get("root_dp_items", 0)}
 
 
-def make_workload(n_pairs: int, n_clones: int, seed: int, rank: int):
+def make_workload(n_pairs: int, n_clones: int, seed: int, rank: int, world: int = 1):
+    """Rank r holds its own library: n_pairs read pairs from n_clones clones over its own germline (rank 0: exactly the
+    one-GPU workload).  N GPUs = N independent libraries processed as ONE job (one k-mer table, one graph, one traversal):
+    N x pairs, N x clones, and a ref-dir that is the union of the N germlines, so the per-GPU work stays what it is on one
+    GPU -- the definition of weak scaling (SURVEY §8d scales clones with pairs the same way: 1 M / 2,000 ... 100 M / 100,000)."""
     from vdjer_amd import synth
-    rep = synth.make_repertoire(n_clones, seed=seed)
+    libs = [synth.make_repertoire(n_clones, seed=seed + 15485863 * r) for r in range(world)]
+    rep = libs[rank]
     pool = synth.make_reads(rep, n_pairs, noise_frac=0.3, seed=seed + 7919 + 104729 * rank)
-    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
-    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
-    wins = [w for w in rep.windows() if w]
-    return rep, pool, vc, jc, wins
+    vc = np.array(sorted({synth.seq_to_int(a) for lb in libs for a in lb.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for lb in libs for a in lb.j_anchors}), dtype=np.uint32)
+    wins = [w for lb in libs for w in lb.windows() if w]
+    return rep, pool, vc, jc, wins, [lb.v_region for lb in libs]
 
 
 def cpu_baseline(rep, vc, jc, wins, n_sample: int, k: int, mf: int, mq: int, ins: int, seed: int) -> dict:
@@ -159,11 +164,11 @@ def main():
 
     from vdjer_amd import api
 
-    rep, pool, vc, jc, wins = make_workload(args.pairs, args.clones, args.seed, rank)
+    rep, pool, vc, jc, wins, v_lines = make_workload(args.pairs, args.clones, args.seed, rank, world)
     rl = pool.rl
     ctx = api.Context(local_rank, pinned_results=True)
     ctx.anchor_sets_load(vc, jc)
-    ctx.vregion_load([rep.v_region], 15)
+    ctx.vregion_load(v_lines, 15)
     d_pri = torch.from_numpy(pool.primary).to(dev)
     d_sec = torch.from_numpy(pool.secondary).to(dev)
     torch.cuda.synchronize()
@@ -361,7 +366,8 @@ def main():
         "dtype": "u8/u64 (2-bit packed bases, integer counts)", "data": "synthetic",
         "config": {"workload": f"synthetic {args.pairs} 50bp PE pairs per GPU, IGH, k={args.k} mf={args.mf} mq={args.mq} "
                                f"ins={args.ins} (BASELINE.json configs[1]; SURVEY §8d C2)",
-                   "pairs_per_gpu": args.pairs, "clones": args.clones, "noise": 0.3, "parallelism": f"hash-prefix x{world}",
+                   "pairs_per_gpu": args.pairs, "clones_per_gpu": args.clones, "noise": 0.3, "parallelism": f"hash-prefix x{world}",
+                   "multi_gpu_input": "one independent library (own germline, clones, reads) per GPU; ONE k-mer table / graph / traversal over all of them",
                    "scorer_inputs": scorer_src},
         "roofline": roof, "cpu_baseline": cpu,
         "kernels_ms_per_step": {k_: round(v[0] / args.steps, 4) for k_, v in prof.items()},

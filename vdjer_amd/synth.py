@@ -86,10 +86,14 @@ class Repertoire:
 
 
 def make_repertoire(n_clones: int, seed: int = 20261002, n_v: int = 60, n_j: int = 6,
-                    zipf_s: float = 1.1, j_codons: int = 119) -> Repertoire:
+                    zipf_s: float = 1.1, j_codons: int = 119, clone_seed: int | None = None) -> Repertoire:
+    """clone_seed: draw the clones from their own stream while the germline (and with it the ref-dir) stays the one of `seed`:
+    several libraries of different clones over one reference (bench.py gives every GPU its own library)."""
     rng = np.random.default_rng(seed)
     v_germ = [_rand_codons(rng, 99) + "TGT" for _ in range(n_v)]
     j_germ = ["TGG" + _rand_codons(rng, j_codons) for _ in range(n_j)]
+    if clone_seed is not None:
+        rng = np.random.default_rng(clone_seed)
     clones, cv, cj = [], [], []
     for _ in range(n_clones):
         g = int(rng.integers(0, n_v))
