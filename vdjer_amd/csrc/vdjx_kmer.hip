@@ -460,7 +460,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 	if (tid == 0) {
 		bucket_ncand[b] = s_over ? 0 : s_ncand;
 		bucket_nct[b] = s_over ? 0 : s_nct;
-		atomicAdd(g_distinct, (u64) s_ndist);
+		atomicAdd(&g_distinct[(b & 63u) * 16u], (u64) s_ndist);      // 64 counters on separate cache lines (summed on the host)
 	}
 }
 
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 	__shared__ u32 l_cnt[K3B_CH], l_first[K3B_CH], l_ucnt[K3B_CH], l_ufirst[K3B_CH], l_lowid[K3B_CH];
 	__shared__ uint8_t l_multi[K3B_CH], l_qok[K3B_CH];
 	__shared__ u32 acc[K3B_A * K3B_KW];
-	__shared__ u32 s_nlow;
+	__shared__ u32 s_nlow, s_base;
 	const u32 b = blockIdx.x;
 	const u32 nc = bucket_ncand[b];
 	if (nc == 0) return;
@@ -581,20 +581,28 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 			}
 			__syncthreads();
 		}
-		// prune_pre_graph (A2:467-484)
+		// prune_pre_graph (A2:467-484).  The global survivor counter is bumped once per workgroup and chunk: one address shared
+		// by every workgroup serialises in L2 (~3.5 ns per bump: 131 k survivors cost 0.45 ms when bumped one by one)
+		if (tid == 0) s_nlow = 0;
+		__syncthreads();
 		for (u32 i = tid; i < m; i += K3B_THREADS) {
 			const u32 cnt = l_cnt[i] > 32765u ? 32765u : l_cnt[i];            // A2:345-347
 			const bool keep = cnt >= mf && l_multi[i] && (l_cnt[i] >= tlow || l_qok[i]);
-			if (keep) {
-				const u32 pos = atomicAdd(so.n, 1u);
-				if (pos < so.cap) {
-					so.lo[pos] = c_lo[base + c0 + i];
-					so.hi[pos] = (u64) c_hi[base + c0 + i];
-					so.gcnt[pos] = cnt;
-					so.gfirst[pos] = l_first[i];
-					so.ucnt[pos] = l_ucnt[i] > 32765u ? 32765u : l_ucnt[i]; // A2:261-265
-					so.ufirst[pos] = l_ufirst[i];
-				}
+			l_lowid[i] = keep ? atomicAdd(&s_nlow, 1u) : NONE32;               // (reused: position among this chunk's survivors)
+		}
+		__syncthreads();
+		if (tid == 0) s_base = s_nlow ? atomicAdd(so.n, s_nlow) : 0;
+		__syncthreads();
+		for (u32 i = tid; i < m; i += K3B_THREADS) {
+			if (l_lowid[i] == NONE32) continue;
+			const u32 pos = s_base + l_lowid[i];
+			if (pos < so.cap) {
+				so.lo[pos] = c_lo[base + c0 + i];
+				so.hi[pos] = (u64) c_hi[base + c0 + i];
+				so.gcnt[pos] = l_cnt[i] > 32765u ? 32765u : l_cnt[i];
+				so.gfirst[pos] = l_first[i];
+				so.ucnt[pos] = l_ucnt[i] > 32765u ? 32765u : l_ucnt[i]; // A2:261-265
+				so.ufirst[pos] = l_ufirst[i];
 			}
 		}
 		__syncthreads();
@@ -776,7 +784,7 @@ __global__ __launch_bounds__(1024) void k_seg_offsets(const u32* __restrict__ se
 	__shared__ u32 part[1024];
 	const u32 s = blockIdx.x;
 	const u32* cnt = seg_cnt + (size_t) s * NBo;
-	u32* off = seg_off + (size_t) s * NBo;
+	u32* off = seg_off + (size_t) s * (NBo + 1);
 	const u32 per = (NBo + 1023) / 1024;
 	const u32 lo = threadIdx.x * per;
 	const u32 hi = lo + per < NBo ? lo + per : NBo;
@@ -792,6 +800,7 @@ __global__ __launch_bounds__(1024) void k_seg_offsets(const u32* __restrict__ se
 	}
 	u32 run = src_base[s] + (threadIdx.x ? part[threadIdx.x - 1] : 0);
 	for (u32 i = lo; i < hi; i++) { off[i] = run; run += cnt[i]; }
+	if (threadIdx.x == 1023) off[NBo] = src_base[s] + part[1023];
 }
 
 struct PendOut { u64* lo; u64* hi; u32* cg; u32* mg; u32* need; u32* n; u32 cap; };
@@ -800,7 +809,7 @@ struct PendOut { u64* lo; u64* hi; u32* cg; u32* mg; u32* need; u32* n; u32 cap;
 #define MERGE_SLOTS 1024u             // a bucket holds ~100 distinct gated k-mers per rank
 template <typename THI>
 __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* __restrict__ recv, const u32* __restrict__ seg_off,
-                                                                const u32* __restrict__ seg_cnt, u32 G, u32 NBo,
+                                                                u32 MG, u32 G, u32 NBo,
                                                                 const u32* __restrict__ src_base, u32 s_mult, u32 cmin, u32 tlow,
                                                                 SurvOut so, PendOut po,
                                                                 uint2* __restrict__ queries, u32* __restrict__ g_nq,
@@ -813,13 +822,14 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 	u32* s_pid = s_mg + MERGE_SLOTS;
 	u32* s_nsg = s_pid + MERGE_SLOTS;            // ranks that hold gated instances
 	uint8_t* s_fl = (uint8_t*) (s_nsg + MERGE_SLOTS);
-	__shared__ u32 s_over, s_ndist, s_total;
+	__shared__ u32 s_over, s_ndist, s_total, s_ns, s_np, s_sbase, s_pbase;
 	const THI EMPTY = (THI) ~(THI) 0;
 	const u32 b = blockIdx.x;
 	const u32 tid = threadIdx.x;
+	// one workgroup merges MG consecutive buckets (their partials are contiguous in every source's list): enough work per table
 	if (tid == 0) {
 		u32 tot = 0;
-		for (u32 s = 0; s < G; s++) tot += seg_cnt[(size_t) s * NBo + b];
+		for (u32 s = 0; s < G; s++) tot += seg_off[(size_t) s * (NBo + 1) + (b + 1) * MG] - seg_off[(size_t) s * (NBo + 1) + b * MG];
 		s_total = tot;
 	}
 	__syncthreads();
@@ -834,7 +844,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 			for (u32 i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE32; s_fl[i] = 0; s_nsg[i] = 0; s_pid[i] = NONE32; }
 			__syncthreads();
 			for (u32 s = 0; s < G; s++) {
-				const u32 off = seg_off[(size_t) s * NBo + b], cnt = seg_cnt[(size_t) s * NBo + b];
+				const u32 off = seg_off[(size_t) s * (NBo + 1) + b * MG], cnt = seg_off[(size_t) s * (NBo + 1) + (b + 1) * MG] - off;
 				for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
 					const Partial p = recv[off + i];
 					const u64 h = vdjx_mix(p.lo, p.hi);
@@ -849,49 +859,78 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 			}
 			__syncthreads();
 			if (s_over) break;
-			for (u32 i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) {
-				if (s_khi[i] == EMPTY) continue;
-				const u32 cg = s_cg[i];
-				atomicAdd(&s_ndist, 1u);
-				if (cg < cmin) continue;                         // count >= max(mf, 2): A2:349-352,476
-				u32 need = 0;
-				if (!s_fl[i]) {
-					if (s_nsg[i] < 2) continue;                  // one rank holds every gated instance and saw one read only
-					need |= NEED_SEQ;
+			// decide; the global output counters are bumped ONCE per workgroup (a few addresses shared by every workgroup
+			// serialise in L2: per-k-mer or per-wave bumps cost more than the merge itself)
+			if (tid == 0) { s_ns = 0; s_np = 0; }
+			__syncthreads();
+			for (u32 i0 = 0; i0 < MERGE_SLOTS; i0 += MERGE_THREADS) {
+				const u32 i = i0 + tid;
+				u32 need = 0, cg = 0;
+				bool live = s_khi[i] != EMPTY;
+				if (live) {
+					cg = s_cg[i];
+					atomicAdd(&s_ndist, 1u);
+					if (cg < cmin) live = false;                 // count >= max(mf, 2): A2:349-352,476
 				}
-				if (cg < tlow) need |= NEED_Q;
-				const u32 cgc = cg > CNT_CAP ? CNT_CAP : cg;
-				if (!need) {
-					const u32 pos = atomicAdd(so.n, 1u);
+				if (live && !s_fl[i]) {
+					if (s_nsg[i] < 2) live = false;              // one rank holds every gated instance and saw one read only
+					else need |= NEED_SEQ;
+				}
+				if (live && cg < tlow) need |= NEED_Q;
+				// s_pid: local index | need<<30 for open k-mers, local index | 3<<30... survivors use s_nsg as scratch
+				if (live && !need) s_nsg[i] = 0x80000000u | atomicAdd(&s_ns, 1u);
+				else s_nsg[i] = 0;
+				if (live && need) s_pid[i] = atomicAdd(&s_np, 1u) | (need << 30);
+			}
+			__syncthreads();
+			if (tid == 0) {
+				s_sbase = s_ns ? atomicAdd(so.n, s_ns) : 0;
+				s_pbase = s_np ? atomicAdd(po.n, s_np) : 0;
+			}
+			__syncthreads();
+			for (u32 i0 = 0; i0 < MERGE_SLOTS; i0 += MERGE_THREADS) {
+				const u32 i = i0 + tid;
+				if (s_nsg[i] & 0x80000000u) {
+					const u32 pos = s_sbase + (s_nsg[i] & 0x7FFFFFFFu);
 					if (pos < so.cap) {
+						const u32 cg = s_cg[i];
 						so.lo[pos] = s_klo[i]; so.hi[pos] = (u64) s_khi[i];
-						so.gcnt[pos] = cgc; so.gfirst[pos] = s_mg[i];
+						so.gcnt[pos] = cg > CNT_CAP ? CNT_CAP : cg; so.gfirst[pos] = s_mg[i];
 						so.ucnt[pos] = 0; so.ufirst[pos] = NONE32;         // the recount comes later (k_surv_counts + reduce)
 					}
-				} else {
-					const u32 pid = atomicAdd(po.n, 1u);
+				} else if (s_pid[i] != NONE32) {
+					const u32 need = s_pid[i] >> 30;
+					const u32 pid = s_pbase + (s_pid[i] & PID_MASK);
 					if (pid < po.cap) {
 						po.lo[pid] = s_klo[i]; po.hi[pid] = (u64) s_khi[i];
-						po.cg[pid] = cg; po.mg[pid] = s_mg[i];
+						po.cg[pid] = s_cg[i]; po.mg[pid] = s_mg[i];
 						po.need[pid] = need;
-						s_pid[i] = pid | (need << 30);
 					}
+					s_pid[i] = pid | (need << 30);
 				}
 			}
 			__syncthreads();
 			// questions to every rank that holds gated instances of an open k-mer
 			for (u32 s = 0; s < G; s++) {
-				const u32 off = seg_off[(size_t) s * NBo + b], cnt = seg_cnt[(size_t) s * NBo + b];
-				for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
-					const Partial p = recv[off + i];
-					const u64 h = vdjx_mix(p.lo, p.hi);
-					if ((u32) ((h >> 12) & (S - 1)) != sp) continue;
-					const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, (u32) h);
-					if (slot < 0) continue;
-					const u32 pid = s_pid[slot];
-					if (pid == NONE32) continue;
-					const u32 q = atomicAdd(&g_nq[s], 1u);
-					queries[src_base[s] + q] = make_uint2(off + i - src_base[s], pid);
+				const u32 off = seg_off[(size_t) s * (NBo + 1) + b * MG], cnt = seg_off[(size_t) s * (NBo + 1) + (b + 1) * MG] - off;
+				for (u32 i0 = 0; i0 < cnt; i0 += MERGE_THREADS) {
+					const u32 i = i0 + tid;
+					u32 pid = NONE32, li = 0;
+					if (tid == 0) s_ns = 0;
+					__syncthreads();
+					if (i < cnt) {
+						const Partial p = recv[off + i];
+						const u64 h = vdjx_mix(p.lo, p.hi);
+						if ((u32) ((h >> 12) & (S - 1)) == sp) {
+							const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, (u32) h);
+							if (slot >= 0) pid = s_pid[slot];
+						}
+					}
+					if (pid != NONE32) li = atomicAdd(&s_ns, 1u);
+					__syncthreads();
+					if (tid == 0) s_sbase = s_ns ? atomicAdd(&g_nq[s], s_ns) : 0;
+					__syncthreads();
+					if (pid != NONE32) queries[src_base[s] + s_sbase + li] = make_uint2(off + i - src_base[s], pid);
 				}
 			}
 			__syncthreads();
@@ -993,9 +1032,9 @@ __global__ void k_resolve_keep(PendOut po, u32 np, const u32* __restrict__ p_fl,
 		for (int j = 0; j < k; j++) if (p_S[(size_t) p * 64 + j] < mqq) { keep = false; break; }
 	}
 	const u32 cgc = cg > CNT_CAP ? CNT_CAP : cg;
-	if (!keep || cgc < mf) return;
-	const u32 pos = atomicAdd(so.n, 1u);
-	if (pos < so.cap) {
+	keep = keep && cgc >= mf;
+	const u32 pos = vdjx_wave_inc(so.n, keep);
+	if (keep && pos < so.cap) {
 		so.lo[pos] = po.lo[p]; so.hi[pos] = po.hi[p];
 		so.gcnt[pos] = cgc; so.gfirst[pos] = po.mg[p];
 		so.ucnt[pos] = 0; so.ufirst[pos] = NONE32;
@@ -1447,9 +1486,9 @@ int stage_reduce(vdjx_ctx* c, A& db, const Tuples<THI>& t, const PoolView& pv, i
 	HIP_TRY(db.alloc(&c_lo, N)); HIP_TRY(db.alloc(&c_hi, N)); HIP_TRY(db.alloc(&c_cnt, N)); HIP_TRY(db.alloc(&c_first, N));
 	HIP_TRY(db.alloc(&ct_lcid, N)); HIP_TRY(db.alloc(&ct_inst, N));
 	HIP_TRY(db.alloc(&bucket_ncand, NB)); HIP_TRY(db.alloc(&bucket_nct, NB));
-	HIP_TRY(db.alloc(&g_err, 1)); HIP_TRY(db.alloc(&n_surv, 1)); HIP_TRY(db.alloc(&g_distinct, 1));
+	HIP_TRY(db.alloc(&g_err, 1)); HIP_TRY(db.alloc(&n_surv, 1)); HIP_TRY(db.alloc(&g_distinct, 64 * 16));
 	HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
-	HIP_TRY(hipMemsetAsync(g_distinct, 0, 8, st));
+	HIP_TRY(hipMemsetAsync(g_distinct, 0, 64 * 16 * 8, st));
 
 	// prune thresholds.  mq is clamped as A2:1514-1516; a sum >= 214 reads as 255 (A2:356-360), so the test
 	// "S_j >= mq" is "true sum >= min(mq, 214)".  Every gated instance other than the first adds >= 20
@@ -1491,7 +1530,12 @@ int stage_reduce(vdjx_ctx* c, A& db, const Tuples<THI>& t, const PoolView& pv, i
 	}
 	u32 err = 0;
 	HIP_TRY(hipMemcpy(&err, g_err, 4, hipMemcpyDeviceToHost));
-	HIP_TRY(hipMemcpy(&sv->ndist, g_distinct, 8, hipMemcpyDeviceToHost));
+	{
+		u64 spread[64 * 16];
+		HIP_TRY(hipMemcpy(spread, g_distinct, sizeof(spread), hipMemcpyDeviceToHost));
+		sv->ndist = 0;
+		for (int i = 0; i < 64; i++) sv->ndist += spread[i * 16];
+	}
 	if (err) { vdjx_set_error("k_bucket_aggregate: %u buckets could not be split to fit LDS", err); return VDJX_EHIP; }
 	sv->n = ns;
 	return VDJX_OK;
@@ -1849,7 +1893,7 @@ static int shard_merge_impl(vdjx_shard* s, const u32* d_recv_dir, const Partial*
 	u32 *d_src_base, *seg_off, *g_nq, *g_err, *n_pend;
 	u64* g_distinct;
 	HIP_TRY(db.alloc(&d_src_base, G + 1));
-	HIP_TRY(db.alloc(&seg_off, (size_t) G * NBo));
+	HIP_TRY(db.alloc(&seg_off, (size_t) G * (NBo + 1)));
 	HIP_TRY(db.alloc(&g_nq, G));
 	HIP_TRY(db.alloc(&g_err, 1));
 	HIP_TRY(db.alloc(&n_pend, 1));
@@ -1872,6 +1916,9 @@ static int shard_merge_impl(vdjx_shard* s, const u32* d_recv_dir, const Partial*
 	HIP_TRY(hipFuncSetAttribute((const void*) k_bucket_merge<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 	SurvOut so{v.lo, v.hi, v.gcnt, v.gfirst, v.ucnt, v.ufirst, s->n_surv, cap};
 	s->nq.assign(G, 0);
+	// buckets per merge table: about MERGE_SLOTS/4 partials each (the local buckets are sized for tuples, not for distinct k-mers)
+	u32 MG = 1;
+	while (MG < NBo && (u64) total * (MG * 2) <= (u64) NBo * (MERGE_SLOTS * 3 / 8)) MG <<= 1;
 	u32 np = 0, ns = 0, err = 0;
 	u64 ndist = 0;
 	for (u32 s_mult = 1;; s_mult *= 4) {
@@ -1882,7 +1929,7 @@ static int shard_merge_impl(vdjx_shard* s, const u32* d_recv_dir, const Partial*
 		HIP_TRY(hipMemsetAsync(g_distinct, 0, 8, st));
 		if (total) {
 			vdjx_prof_scope ps(c, "k_bucket_merge");
-			hipLaunchKernelGGL(k_bucket_merge<THI>, dim3(NBo), dim3(MERGE_THREADS), lds, st, d_recv, seg_off, d_recv_dir, G, NBo, d_src_base, s_mult, cmin,
+			hipLaunchKernelGGL(k_bucket_merge<THI>, dim3(NBo / MG), dim3(MERGE_THREADS), lds, st, d_recv, seg_off, MG, G, NBo, d_src_base, s_mult, cmin,
 			                   s->tlow, so, po, s->queries, g_nq, g_distinct, g_err);
 		}
 		HIP_TRY(hipMemcpyAsync(s->nq.data(), g_nq, (size_t) G * 4, hipMemcpyDeviceToHost, st));
