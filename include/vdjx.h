@@ -87,6 +87,19 @@ int vdjx_graph_export(const vdjx_graph* g, uint64_t* first_inst, uint32_t* gated
                       uint8_t* from_deg, uint32_t* from_ids, char* kmers);
 void vdjx_graph_free(vdjx_graph* g);
 
+/* ---- f-3: the v_index / j_index generator -------------------------------------------------------
+ * replaces: process_kmers(anchors file, start, end) (seq_dist.c:49-71; its main() is commented out, :73-98) which
+ * printed "<code>\t<min base distance to any anchor>" for every 16-base code of [start, end] (inclusive) whose
+ * distance is <= MAX_DIST 5: the rows of <ref-dir>/v_index and j_index (load_kmers, vj_filter.c:56-68).
+ * anchors: seq_to_int codes of the anchor 16-mers.  Rows come in ascending code order; *n_rows = how many
+ * exist, the first min(cap, *n_rows) are written (call with cap 0 to count).                           */
+int vdjx_index_generate(vdjx_ctx* ctx, const uint32_t* anchors, size_t n_anchors, uint64_t start, uint64_t end, int max_dist,
+                        uint64_t cap, uint64_t* n_rows, uint32_t* codes, uint8_t* dists);
+/* The two membership sets of a-6 straight from the anchors, without 10^7..10^8-row files in between: exactly the sets
+ * vdjx_anchor_sets_load would hold after load_kmers(v_index, am) / load_kmers(j_index, am) on generated files
+ * (distance <= min(am, 5); code 0 never a member).                                                   */
+int vdjx_anchor_sets_from_anchors(vdjx_ctx* ctx, const uint32_t* v_anchors, size_t nv, const uint32_t* j_anchors, size_t nj, int am);
+
 /* ---- result buffers ------------------------------------------------------------------------------
  * Every result pointer of this interface may be ordinary host memory.  Memory from vdjx_host_alloc is
  * page-locked: copies into it run at DMA speed (the graph of 1 M pairs is ~11 MB, the mapped pairs ~11 MB).

@@ -81,6 +81,8 @@ def _bind(L):
     L.vdjo_sam_pair.restype = i32
     L.vdjo_sam_pair.argtypes = [vp, C.c_char_p, C.c_char_p, C.POINTER(Pair), C.c_char_p]
     L.vdjo_readidx_free.argtypes = [vp]
+    L.vdjo_index_rows.restype = sz
+    L.vdjo_index_rows.argtypes = [vp, sz, C.c_uint64, C.c_uint64, i32, vp, vp, sz]
     return L
 
 
@@ -100,6 +102,15 @@ def seq_to_int(s: str):
     ok = C.c_int(0)
     v = lib().vdjo_seq_to_int(s.encode(), C.byref(ok))
     return int(v) if ok.value else None
+
+
+def index_rows(anchors, start: int, end: int, max_dist: int = 5):
+    """process_kmers (seq_dist.c:49-71) over the codes [start, end]: (codes uint32, distances uint8), ascending"""
+    a = _c(anchors, np.uint32)
+    n = int(lib().vdjo_index_rows(_p(a), a.shape[0], start, end, max_dist, None, None, 0))
+    codes, dists = np.zeros(n, np.uint32), np.zeros(n, np.uint8)
+    lib().vdjo_index_rows(_p(a), a.shape[0], start, end, max_dist, _p(codes), _p(dists), n)
+    return codes, dists
 
 
 def inst_kmer(pool, inst: int, k: int) -> str:

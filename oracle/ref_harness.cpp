@@ -373,9 +373,18 @@ static int cmd_order(int argc, char** argv) {
 	return 0;
 }
 
+/* seqd <anchors file> <start> <end>: the index generator process_kmers (seq_dist.c:49-71) -- its own main() is commented
+ * out in the reference (seq_dist.c:73-98) and did exactly this call; rows go to stdout */
+extern void process_kmers(char* input, unsigned long start, unsigned long end);
+static int cmd_seqd(int argc, char** argv) {
+	if (argc != 5) { fprintf(stderr, "usage: vdjer_ref seqd <anchors> <start> <end>\n"); return 2; }
+	process_kmers(argv[2], strtoul(argv[3], NULL, 10), strtoul(argv[4], NULL, 10));
+	return 0;
+}
+
 int main(int argc, char** argv) {
 	if (argc < 2) {
-		fprintf(stderr, "usage: vdjer_ref run|graph|score|map|vjf|hash|order ...\n");
+		fprintf(stderr, "usage: vdjer_ref run|graph|score|map|vjf|hash|order|seqd ...\n");
 		return 2;
 	}
 	if (!strcmp(argv[1], "run")) {
@@ -389,6 +398,7 @@ int main(int argc, char** argv) {
 	if (!strcmp(argv[1], "vjf")) return cmd_vjf(argc, argv);
 	if (!strcmp(argv[1], "hash")) return cmd_hash(argc, argv);
 	if (!strcmp(argv[1], "order")) return cmd_order(argc, argv);
+	if (!strcmp(argv[1], "seqd")) return cmd_seqd(argc, argv);
 	fprintf(stderr, "unknown sub-command %s\n", argv[1]);
 	return 2;
 }

@@ -686,3 +686,37 @@ void vdjo_readidx_free(vdjo_readidx* ix) {
 	free(ix->r2_pos);
 	free(ix);
 }
+
+/* ---- f-3: the v_index / j_index generator (seq_dist.c) -------------------------------------------
+ * edit_dist (seq_dist.c:11-27): number of differing 2-bit bases of two 16-base codes.
+ * process_kmers (seq_dist.c:49-71): for every code i in [start, end] (inclusive) the minimum over the
+ * anchors; a row "i\tmin" when min <= MAX_DIST (5).  Returns the number of rows; fills at most cap. */
+static int edit_dist16(uint32_t a, uint32_t b) {
+	uint32_t v = a ^ b;
+	int d = 0;
+	while (v) {
+		if (v & 3u) d++;
+		v >>= 2;
+	}
+	return d;
+}
+
+size_t vdjo_index_rows(const uint32_t* anchors, size_t n_anchors, uint64_t start, uint64_t end, int max_dist,
+                       uint32_t* codes, uint8_t* dists, size_t cap) {
+	size_t n = 0;
+	for (uint64_t i = start; i <= end && i <= 0xFFFFFFFFull; i++) {
+		int best = 17;                                  /* SEQ_LEN + 1 */
+		for (size_t a = 0; a < n_anchors; a++) {
+			int d = edit_dist16((uint32_t) i, anchors[a]);
+			if (d < best) best = d;
+		}
+		if (best <= max_dist) {
+			if (n < cap) {
+				if (codes) codes[n] = (uint32_t) i;
+				if (dists) dists[n] = (uint8_t) best;
+			}
+			n++;
+		}
+	}
+	return n;
+}

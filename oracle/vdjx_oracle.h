@@ -87,6 +87,11 @@ int vdjo_coverage_is_valid(int rl, int contig_len, int eval_start, int eval_stop
 int vdjo_sam_pair(const vdjo_readidx* ix, const char* contig_id, const char* read_name, const vdjo_pair* p, char* buf);
 void vdjo_readidx_free(vdjo_readidx* ix);
 
+/* f-3: process_kmers (seq_dist.c:49-71): rows (code, min base distance to any anchor) for codes in [start,end]
+ * with distance <= max_dist, ascending; returns the row count, fills at most cap rows */
+size_t vdjo_index_rows(const uint32_t* anchors, size_t n_anchors, uint64_t start, uint64_t end, int max_dist,
+                       uint32_t* codes, uint8_t* dists, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

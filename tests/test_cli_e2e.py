@@ -67,3 +67,17 @@ def test_python_wiring_matches_reference(tag, tmp_path):
     assert fa.read_text() == G.text(f"{tag}.contigs.fa.gz")
     assert sam.read_text() == G.text(f"{tag}.sam.gz")
     ctx.close()
+
+
+def test_vdjx_index_cli_prints_the_reference_rows():
+    """the index generator as a command: same arguments and the same stdout bytes as the reference's process_kmers"""
+    exe = os.path.join(ROOT, "vdjer_amd", "vdjx_index")
+    assert os.path.exists(exe), "build it: make -C vdjer_amd/csrc/host"
+    _, ranges = G.index_case()
+    for s, e, codes, dists in ranges[:4] + ranges[-1:]:
+        r = subprocess.run([exe, os.path.join(G.GOLD, "index_anchors.txt"), str(s), str(e)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout == "".join(f"{c}\t{d}\n" for c, d in zip(codes.tolist(), dists.tolist()))
+    bad = subprocess.run([exe, os.path.join(G.GOLD, "index_anchors.txt")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert bad.returncode != 0 and "Usage" in bad.stderr

@@ -212,6 +212,56 @@ def test_pinned_result_buffers():
         b.close()
 
 
+def test_index_generator_vs_reference_rows(ctx):
+    """f-3: vdjx_index_generate against the rows the reference's process_kmers printed (tests/golden/index_rows.tsv.gz)"""
+    anchors, ranges = G.index_case()
+    for s, e, codes, dists in ranges:
+        c, d = ctx.index_generate(anchors, s, e)
+        assert c.tolist() == codes.tolist() and d.tolist() == dists.tolist()
+    # other radii, a range that straddles chunk borders, an empty result, more anchors than one LDS batch
+    from oracle import oracle
+    rng = np.random.default_rng(8)
+    many = rng.integers(0, 2 ** 32, 5000, dtype=np.uint64).astype(np.uint32)
+    for a, s, e, md in [(anchors, (1 << 24) - 5000, (1 << 24) + 70000, 3), (anchors, 12345678, 12345678 + 40000, 0),
+                        (anchors[:1], int(anchors[0]) - 300, int(anchors[0]) + 300, 5), (many, 3_000_000_000, 3_000_000_000 + 30000, 4),
+                        (anchors, 5, 4, 5), (anchors, 2 ** 32 - 100, 2 ** 32 + 50, 5)]:
+        c, d = ctx.index_generate(a, s, e, md)
+        oc, od = oracle.index_rows(a, s, e, md)
+        assert c.tolist() == oc.tolist() and d.tolist() == od.tolist()
+
+
+@pytest.mark.parametrize("am", [4, 5, 0, 9])
+def test_anchor_sets_from_anchors_equal_the_loaded_index(am):
+    """the Hamming-ball bitmaps == the sets the reference builds from the index files (load_kmers, vj_filter.c:56-68):
+    every row of the full-range generated index with distance <= am, for V and J separately"""
+    from vdjer_amd import api, synth
+    anchors, _ = G.index_case()
+    va, ja = anchors[:7], anchors[7:]
+    a, b = api.Context(0), api.Context(0)
+    try:
+        a.anchor_sets_from_anchors(va, ja, am)
+        sets = []
+        for x in (va, ja):
+            codes, dists = b.index_generate(x, 0, 2 ** 32 - 1, 5)
+            assert codes.shape[0] > 1_000_000 and np.all(np.diff(codes.astype(np.int64)) > 0)
+            sets.append(codes[dists <= am])
+        b.anchor_sets_load(sets[0], sets[1])
+        rng = np.random.default_rng(3)
+        probe = np.concatenate([sets[0][::max(1, sets[0].shape[0] // 20000)], sets[1][::max(1, sets[1].shape[0] // 20000)],
+                                rng.integers(0, 2 ** 32, 20000, dtype=np.uint64).astype(np.uint32),
+                                (anchors[:, None] ^ (np.uint32(3) << (2 * rng.integers(0, 16, (anchors.shape[0], 400)).astype(np.uint32)))).ravel(),
+                                np.array([0, 1, 2 ** 32 - 1], np.uint32)])
+        contig = "".join(synth.int_to_seq(int(c)) for c in probe) + "A" * 16
+        (av, aj), (bv, bj) = a.anchor_probe(contig), b.anchor_probe(contig)
+        assert np.array_equal(av, bv) and np.array_equal(aj, bj)
+        assert av[::16].sum() > 0 or am == 0
+        if am >= 0:
+            assert bool(av[::16][:1][0]) == bool(sets[0].shape[0])     # a member of the V set probes as one
+    finally:
+        a.close()
+        b.close()
+
+
 def test_anchor_probe(ctx):
     from vdjer_amd import synth
     c = G.Case("noisy")

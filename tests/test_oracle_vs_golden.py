@@ -121,3 +121,19 @@ def test_sam_text_of_final_contigs(tag):
         for q in pairs:
             out.append(ix.sam_pair(fa[i][1:], f"r{q['pair_id']}", q))
     assert "".join(out) == G.text(f"{tag}.sam.gz")
+
+
+def test_index_generator_rows():
+    """f-3: the restatement of process_kmers (seq_dist.c:49-71) against rows printed by the reference itself"""
+    anchors, ranges = G.index_case()
+    assert G.manifest()["index"]["ranges"] == len(ranges) and sum(r[2].shape[0] for r in ranges) == G.manifest()["index"]["rows"]
+    for s, e, codes, dists in ranges:
+        c, d = oracle.index_rows(anchors, s, e)
+        assert c.tolist() == codes.tolist() and d.tolist() == dists.tolist()
+    # every row is the true minimum: spot-check with the string form of the distance
+    s, e, codes, dists = ranges[2]
+    from vdjer_amd import synth
+    names = [l.strip() for l in open(G.GOLD + "/index_anchors.txt") if l.strip()]
+    for c, d in list(zip(codes.tolist(), dists.tolist()))[::97]:
+        w = synth.int_to_seq(c)
+        assert d == min(sum(x != y for x, y in zip(w, a)) for a in names)

@@ -14,7 +14,7 @@ _lib = None
 SYMBOLS = [
     "vdjx_last_error", "vdjx_version", "vdjx_init", "vdjx_shutdown", "vdjx_sync",
     "vdjx_pool_load", "vdjx_pool_load_device", "vdjx_pool_records", "vdjx_pool_free",
-    "vdjx_anchor_sets_load", "vdjx_anchor_probe",
+    "vdjx_anchor_sets_load", "vdjx_anchor_probe", "vdjx_index_generate", "vdjx_anchor_sets_from_anchors",
     "vdjx_kmer_build", "vdjx_graph_nodes", "vdjx_graph_pre_nodes", "vdjx_graph_export", "vdjx_graph_free",
     "vdjx_vregion_load", "vdjx_root_score", "vdjx_graph_roots", "vdjx_root_part", "vdjx_root_score_graph",
     "vdjx_read_index_build", "vdjx_window_score", "vdjx_map_emit",
@@ -94,6 +94,8 @@ def lib():
     L.vdjx_root_part.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.vdjx_root_part.restype = C.c_size_t
     L.vdjx_root_score_graph.argtypes = [vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
+    L.vdjx_index_generate.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), vp, vp]
+    L.vdjx_anchor_sets_from_anchors.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int]
     L.vdjx_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.vdjx_host_free.argtypes = [vp, vp]
     L.vdjx_host_free.restype = None

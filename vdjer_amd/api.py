@@ -164,6 +164,22 @@ class Context:
         j = _c(j_codes, np.uint32)
         check(self.L.vdjx_anchor_sets_load(self.h, _p(v), v.shape[0], _p(j), j.shape[0]), "vdjx_anchor_sets_load")
 
+    def anchor_sets_from_anchors(self, v_anchor_codes, j_anchor_codes, am: int = 4) -> None:
+        """the sets of anchor_sets_load, built on the device from the anchors themselves (Hamming balls of radius min(am, 5))"""
+        v, j = _c(v_anchor_codes, np.uint32), _c(j_anchor_codes, np.uint32)
+        check(self.L.vdjx_anchor_sets_from_anchors(self.h, _p(v), v.shape[0], _p(j), j.shape[0], am), "vdjx_anchor_sets_from_anchors")
+
+    def index_generate(self, anchor_codes, start: int = 0, end: int = 2 ** 32 - 1, max_dist: int = 5):
+        """rows of a v_index / j_index file (seq_dist.c:49-71) for the codes [start, end]: (codes uint32, distances uint8)"""
+        a = _c(anchor_codes, np.uint32)
+        n = C.c_uint64()
+        check(self.L.vdjx_index_generate(self.h, _p(a), a.shape[0], start, end, max_dist, 0, C.byref(n), None, None), "vdjx_index_generate(count)")
+        codes, dists = np.zeros(n.value, np.uint32), np.zeros(n.value, np.uint8)
+        if n.value:
+            check(self.L.vdjx_index_generate(self.h, _p(a), a.shape[0], start, end, max_dist, n.value, C.byref(n), _p(codes), _p(dists)),
+                  "vdjx_index_generate")
+        return codes, dists
+
     def anchor_probe(self, contig: str):
         n = max(0, len(contig) - 16)
         ov = np.zeros(n, np.uint8)

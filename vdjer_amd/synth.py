@@ -38,6 +38,11 @@ def seq_to_int(s: str) -> int:
     return val
 
 
+def int_to_seq(code: int) -> str:
+    """inverse of seq_to_int: 32-bit anchor code -> 16-mer"""
+    return "".join("ATCG"[(code >> (2 * (15 - i))) & 3] for i in range(16))
+
+
 def revcomp(s: str) -> str:
     return s[::-1].translate(str.maketrans("ACGTN", "TGCAN"))
 
