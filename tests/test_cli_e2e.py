@@ -81,3 +81,75 @@ def test_vdjx_index_cli_prints_the_reference_rows():
         assert r.stdout == "".join(f"{c}\t{d}\n" for c, d in zip(codes.tolist(), dists.tolist()))
     bad = subprocess.run([exe, os.path.join(G.GOLD, "index_anchors.txt")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert bad.returncode != 0 and "Usage" in bad.stderr
+
+
+def _bam_inputs(c, d):
+    """the e2e case as a BAM: every read unmapped (flags 77/141 + 0x10 where the stored orientation is reversed), header with the
+    IGH chromosome, records in registration order; ig_vdj.fa = the clones, so that clone reads carry V/D/J 15-mers (primary pool)
+    and noise reads do not (unmapped => secondary pool), the way extract decides (bam_read.c:346-374)"""
+    from tests import bam_model as B
+    os.makedirs(os.path.join(d, "ref"), exist_ok=True)
+    p = c.pool
+    rl = p.rl
+    allrec = np.concatenate([p.primary, p.secondary], axis=0)
+    npri = p.primary.shape[0]
+    recs, want = [], []
+    for r in np.argsort(p.reg_rank, kind="stable"):
+        if p.reg_rank[r] % 2:
+            continue
+        seq = allrec[r][1:1 + rl].tobytes().decode()
+        qual = allrec[r][1 + rl:1 + 2 * rl].tobytes().decode()
+        flag = 1 | 4 | 8 | (0x40 if p.read_num[r] == 1 else 0x80) | (0x10 if p.is_rc[r] else 0)
+        recs.append(dict(qname=f"r{p.pair_id[r]}", flag=flag, tid=-1, pos=-1, cigar=[], seq=seq, qual=qual))
+        want.append(("P" if r < npri else "S", f"r{p.pair_id[r]}", int(p.read_num[r]), int(p.is_rc[r]), seq, qual))
+    bam = os.path.join(d, "in.bam")
+    voffs = B.write_bam(bam, [("chr14", 107043718)], recs)
+    B.write_bai(bam + ".bai", 1, recs, voffs)
+    with open(os.path.join(d, "ref", "ig_vdj.fa"), "w") as f:
+        for i, t in enumerate(c.clones):
+            f.write(f">c{i}\n{t}\n")
+    return bam, want
+
+
+def test_vdjer_cli_takes_a_bam(tmp_path):
+    """--in <bam>: extraction (bamx) + the same pipeline == the reference's outputs for the same reads"""
+    from tests import bam_model as B
+    tag = "e2e_tiled"
+    exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
+    c = G.Case(tag)
+    info = G.manifest()["e2e"][tag]
+    _write_inputs(c, str(tmp_path))
+    bam, want = _bam_inputs(c, str(tmp_path))
+    got, xinfo = B.extract(bam, str(tmp_path / "ref" / "ig_vdj.fa"), "chr14:105566277-106879844", "chr14:105566277-105939754")
+    assert xinfo["read_len"] == xinfo["max_len"] == c.pool.rl
+    assert got == want                                    # same reads, same pools, same order as the pools the golden run was fed
+    cmd = [exe, "--in", "in.bam", "--chain", "IGH", "--ref-dir", "ref", "--ins", "175", "--t", "1"] + info["flags"]
+    r = subprocess.run(cmd, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert (tmp_path / "vdj_contigs.fa").read_text() == G.text(f"{tag}.contigs.fa.gz")
+    assert r.stdout == G.text(f"{tag}.sam.gz")
+    assert (tmp_path / "vdjer.dot").read_text() == G.text(f"{tag}.dot.gz")
+
+
+@pytest.mark.parametrize("tag", ["e2e_mixed", "e2e_k25"])
+def test_vdjer_cli_bam_equals_text_of_the_same_extraction(tag, tmp_path):
+    """noise reads now and then carry a V/D/J 15-mer by chance and move to the primary pool (extract's rule), so these cases are
+    compared with the text route fed with exactly what the extraction produced"""
+    from tests import bam_model as B
+    exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
+    c = G.Case(tag)
+    info = G.manifest()["e2e"][tag]
+    _write_inputs(c, str(tmp_path))
+    bam, want = _bam_inputs(c, str(tmp_path))
+    got, _ = B.extract(bam, str(tmp_path / "ref" / "ig_vdj.fa"), "chr14:105566277-106879844", "chr14:105566277-105939754")
+    assert [g[1:] for g in got] == [w[1:] for w in want] and sum(g[0] != w[0] for g, w in zip(got, want)) < 20
+    with open(tmp_path / "extracted.txt", "w") as f:
+        for pool, name, num, rev, seq, qual in got:
+            f.write(f"{pool} {name} {num} {rev} {seq} {qual}\n")
+    outs = []
+    for src in ("in.bam", "extracted.txt"):
+        cmd = [exe, "--in", src, "--chain", "IGH", "--ref-dir", "ref", "--ins", "175", "--t", "1"] + info["flags"]
+        r = subprocess.run(cmd, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append((r.stdout, (tmp_path / "vdj_contigs.fa").read_text(), (tmp_path / "vdjer.dot").read_text()))
+    assert outs[0] == outs[1] and outs[0][1].count(">") > 0

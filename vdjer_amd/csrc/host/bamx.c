@@ -1,0 +1,629 @@
+/* bamx.c -- see bamx.h.  Plain C over zlib; no GPU code. */
+#include "bamx.h"
+
+#include <limits.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+#include <zlib.h>
+
+static char g_err[512];
+const char* bamx_last_error(void) { return g_err; }
+static int fail(const char* fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return -2;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* BGZF (bgzf.c): blocks are gzip members with a 'BC' extra field holding the block size                              */
+/* ------------------------------------------------------------------------------------------------------------------ */
+struct bamx_file {
+	FILE* fp;
+	int64_t block_address;            /* file offset of the current block */
+	int block_offset, block_length;   /* position inside / size of its inflated data; 0/0 = not loaded */
+	uint8_t inflated[65536];
+	uint8_t raw[65536 + 64];
+	int n_ref;
+	char** ref_name;
+	int32_t* ref_len;
+};
+
+static int rd_u16(const uint8_t* p) { return p[0] | (p[1] << 8); }
+static uint32_t rd_u32(const uint8_t* p) { return (uint32_t) p[0] | ((uint32_t) p[1] << 8) | ((uint32_t) p[2] << 16) | ((uint32_t) p[3] << 24); }
+static uint64_t rd_u64(const uint8_t* p) { return (uint64_t) rd_u32(p) | ((uint64_t) rd_u32(p + 4) << 32); }
+
+/* bgzf_read_block (bgzf.c): 0 = ok (block_length 0 at end of file), -1 = error */
+static int read_block(bamx_file* f) {
+	const int64_t addr = ftello(f->fp);
+	uint8_t* h = f->raw;
+	size_t got = fread(h, 1, 18, f->fp);
+	if (got == 0) { f->block_length = 0; return 0; }
+	if (got != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4) || rd_u16(h + 10) != 6 || h[12] != 'B' || h[13] != 'C' || rd_u16(h + 14) != 2)
+		return fail("not a BGZF block at file offset %lld", (long long) addr), -1;
+	const int bsize = rd_u16(h + 16) + 1;
+	if (bsize < 26) return fail("BGZF block too short at %lld", (long long) addr), -1;
+	if (fread(h + 18, 1, (size_t) bsize - 18, f->fp) != (size_t) bsize - 18) return fail("truncated BGZF block at %lld", (long long) addr), -1;
+	z_stream zs;
+	memset(&zs, 0, sizeof zs);
+	zs.next_in = h + 18;
+	zs.avail_in = (uInt) (bsize - 18 - 8);
+	zs.next_out = f->inflated;
+	zs.avail_out = sizeof f->inflated;
+	if (inflateInit2(&zs, -15) != Z_OK) return fail("inflateInit2 failed"), -1;
+	const int rc = inflate(&zs, Z_FINISH);
+	inflateEnd(&zs);
+	if (rc != Z_STREAM_END) return fail("inflate failed in the block at %lld", (long long) addr), -1;
+	const int count = (int) zs.total_out;
+	if ((uint32_t) count != rd_u32(h + bsize - 4)) return fail("BGZF ISIZE mismatch at %lld", (long long) addr), -1;
+	if (f->block_length != 0) f->block_offset = 0;      /* do not reset the offset if this read follows a seek */
+	f->block_address = addr;
+	f->block_length = count;
+	return 0;
+}
+
+/* bgzf_read (bgzf.c:547-574), including the move to the next block's address when a block is used up */
+static long bz_read(bamx_file* f, void* data, size_t length) {
+	size_t done = 0;
+	uint8_t* out = (uint8_t*) data;
+	while (done < length) {
+		int avail = f->block_length - f->block_offset;
+		if (avail <= 0) {
+			if (read_block(f) != 0) return -1;
+			avail = f->block_length - f->block_offset;
+			if (avail <= 0) break;
+		}
+		const size_t take = length - done < (size_t) avail ? length - done : (size_t) avail;
+		memcpy(out, f->inflated + f->block_offset, take);
+		f->block_offset += (int) take;
+		out += take;
+		done += take;
+	}
+	if (f->block_offset == f->block_length) {
+		f->block_address = ftello(f->fp);
+		f->block_offset = f->block_length = 0;
+	}
+	return (long) done;
+}
+
+uint64_t bamx_tell(const bamx_file* f) { return ((uint64_t) f->block_address << 16) | ((uint64_t) f->block_offset & 0xFFFF); }
+
+int bamx_seek(bamx_file* f, uint64_t voff) {            /* bgzf_seek (bgzf.c:847-866) */
+	if (fseeko(f->fp, (off_t) (voff >> 16), SEEK_SET) != 0) return fail("seek failed");
+	f->block_length = 0;
+	f->block_address = (int64_t) (voff >> 16);
+	f->block_offset = (int) (voff & 0xFFFF);
+	return 0;
+}
+
+int bamx_is_bam(const char* path) {
+	FILE* fp = fopen(path, "rb");
+	if (!fp) return -1;
+	unsigned char m[2] = {0, 0};
+	const size_t n = fread(m, 1, 2, fp);
+	fclose(fp);
+	return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* BAM header and records (sam.c: bam_hdr_read, bam_read1)                                                             */
+/* ------------------------------------------------------------------------------------------------------------------ */
+bamx_file* bamx_open(const char* path) {
+	bamx_file* f = (bamx_file*) calloc(1, sizeof *f);
+	if (!f) return NULL;
+	f->fp = fopen(path, "rb");
+	if (!f->fp) { fail("cannot open %s", path); free(f); return NULL; }
+	uint8_t b[8];
+	if (bz_read(f, b, 4) != 4 || memcmp(b, "BAM\1", 4)) { fail("%s: no BAM magic", path); bamx_close(f); return NULL; }
+	if (bz_read(f, b, 4) != 4) { fail("%s: truncated header", path); bamx_close(f); return NULL; }
+	uint32_t l_text = rd_u32(b);
+	while (l_text) {                                       /* the SAM text is not needed */
+		uint8_t skip[4096];
+		const size_t take = l_text < sizeof skip ? l_text : sizeof skip;
+		if (bz_read(f, skip, take) != (long) take) { fail("%s: truncated header text", path); bamx_close(f); return NULL; }
+		l_text -= (uint32_t) take;
+	}
+	if (bz_read(f, b, 4) != 4) { fail("%s: truncated header", path); bamx_close(f); return NULL; }
+	f->n_ref = (int) rd_u32(b);
+	f->ref_name = (char**) calloc((size_t) f->n_ref + 1, sizeof(char*));
+	f->ref_len = (int32_t*) calloc((size_t) f->n_ref + 1, 4);
+	for (int i = 0; i < f->n_ref; i++) {
+		if (bz_read(f, b, 4) != 4) { fail("%s: truncated reference list", path); bamx_close(f); return NULL; }
+		const uint32_t ln = rd_u32(b);
+		f->ref_name[i] = (char*) calloc((size_t) ln + 1, 1);
+		if (bz_read(f, f->ref_name[i], ln) != (long) ln || bz_read(f, b, 4) != 4) { fail("%s: truncated reference list", path); bamx_close(f); return NULL; }
+		f->ref_len[i] = (int32_t) rd_u32(b);
+	}
+	return f;
+}
+
+void bamx_close(bamx_file* f) {
+	if (!f) return;
+	if (f->fp) fclose(f->fp);
+	for (int i = 0; i < f->n_ref; i++) free(f->ref_name ? f->ref_name[i] : NULL);
+	free(f->ref_name);
+	free(f->ref_len);
+	free(f);
+}
+
+int bamx_n_ref(const bamx_file* f) { return f->n_ref; }
+const char* bamx_ref_name(const bamx_file* f, int tid) { return tid >= 0 && tid < f->n_ref ? f->ref_name[tid] : NULL; }
+
+static int name2id(const bamx_file* f, const char* name) {   /* bam_name2id: exact match */
+	for (int i = 0; i < f->n_ref; i++) if (!strcmp(f->ref_name[i], name)) return i;
+	return -1;
+}
+
+int bamx_read1(bamx_file* f, bamx_rec* r) {
+	uint8_t b[36];
+	r->voff = bamx_tell(f);
+	long got = bz_read(f, b, 4);
+	if (got == 0) return -1;                                 /* normal end of file */
+	if (got != 4) return got < 0 ? -3 : fail("truncated record");
+	const uint32_t block_len = rd_u32(b);
+	if (block_len < 32) return fail("record shorter than its fixed part");
+	if (bz_read(f, b, 32) != 32) return fail("truncated record");
+	r->tid = (int32_t) rd_u32(b);
+	r->pos = (int32_t) rd_u32(b + 4);
+	const uint32_t x = rd_u32(b + 8), y = rd_u32(b + 12);
+	r->bin = (uint16_t) (x >> 16);
+	r->mapq = (uint8_t) ((x >> 8) & 0xFF);
+	const int l_qname = (int) (x & 0xFF);
+	r->flag = (uint16_t) (y >> 16);
+	r->n_cigar = (int32_t) (y & 0xFFFF);
+	r->l_qseq = (int32_t) rd_u32(b + 16);
+	const size_t rest = block_len - 32;
+	static uint8_t* data = NULL;
+	static size_t cap = 0;
+	if (rest + 1 > cap) { cap = rest + 1024; data = (uint8_t*) realloc(data, cap); }
+	if (bz_read(f, data, rest) != (long) rest) return fail("truncated record");
+	if (r->l_qseq < 0 || r->l_qseq > 1023) return fail("read of %d bases: longer than this reader takes", r->l_qseq);
+	const size_t need = (size_t) l_qname + (size_t) r->n_cigar * 4 + (size_t) (r->l_qseq + 1) / 2 + (size_t) r->l_qseq;
+	if (need > rest || l_qname < 1) return fail("record fields exceed the record");
+	memcpy(r->qname, data, (size_t) l_qname);
+	r->qname[l_qname] = 0;
+	const uint8_t* cig = data + l_qname;
+	int32_t rlen = 0;
+	for (int i = 0; i < r->n_cigar; i++) {
+		const uint32_t c = rd_u32(cig + 4 * i);
+		const uint32_t op = c & 0xF;
+		if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += (int32_t) (c >> 4);    /* M D N = X consume the reference */
+	}
+	r->end = r->pos + (r->n_cigar ? rlen : 1);               /* bam_readrec, sam.c:458-467 */
+	const uint8_t* sq = cig + (size_t) r->n_cigar * 4;
+	const uint8_t* ql = sq + (size_t) (r->l_qseq + 1) / 2;
+	for (int i = 0; i < r->l_qseq; i++) {
+		r->seq[i] = "=ACMGRSVTWYHKDBN"[(sq[i >> 1] >> ((~i & 1) << 2)) & 0xF];
+		r->qual[i] = (char) (ql[i] + 33);
+	}
+	r->seq[r->l_qseq] = 0;
+	r->qual[r->l_qseq] = 0;
+	return (int) block_len;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* BAI (hts.c:1159-1210) and the region iterator (hts.c:1372-1487, 1539-1580); min_shift 14, 5 levels                  */
+/* ------------------------------------------------------------------------------------------------------------------ */
+typedef struct { uint64_t u, v; } chunk_t;
+typedef struct { uint32_t bin; int n; chunk_t* list; uint64_t loff; } bin_t;
+typedef struct { int n_bin; bin_t* bins; int n_intv; uint64_t* ioff; } refidx_t;
+struct bamx_index { int n_ref; refidx_t* ref; };
+#define BAI_N_LVLS 5
+#define BAI_MIN_SHIFT 14
+#define BAI_N_BINS 37449u                     /* ((1 << 18) - 1) / 7 */
+
+static int bin_first(int l) { return ((1 << ((l << 1) + l)) - 1) / 7; }
+static int bin_parent(int b) { return (b - 1) >> 3; }
+static int bin_bot(int bin) {                 /* hts_bin_bot */
+	int l = 0, b;
+	for (b = bin; b; ++l, b = bin_parent(b)) {}
+	return (bin - bin_first(l)) << ((BAI_N_LVLS - l) * 3);
+}
+
+static const bin_t* find_bin(const refidx_t* r, uint32_t bin) {
+	for (int i = 0; i < r->n_bin; i++) if (r->bins[i].bin == bin) return &r->bins[i];
+	return NULL;
+}
+
+bamx_index* bamx_index_load(const char* bam_path) {
+	char fn[4200];
+	snprintf(fn, sizeof fn, "%s.bai", bam_path);
+	FILE* fp = fopen(fn, "rb");
+	if (!fp) { fail("cannot open %s", fn); return NULL; }
+	uint8_t b[16];
+	if (fread(b, 1, 8, fp) != 8 || memcmp(b, "BAI\1", 4)) { fail("%s: no BAI magic", fn); fclose(fp); return NULL; }
+	bamx_index* ix = (bamx_index*) calloc(1, sizeof *ix);
+	ix->n_ref = (int) rd_u32(b + 4);
+	ix->ref = (refidx_t*) calloc((size_t) ix->n_ref + 1, sizeof(refidx_t));
+	for (int i = 0; i < ix->n_ref; i++) {
+		refidx_t* r = &ix->ref[i];
+		if (fread(b, 1, 4, fp) != 4) goto bad;
+		r->n_bin = (int) rd_u32(b);
+		r->bins = (bin_t*) calloc((size_t) r->n_bin + 1, sizeof(bin_t));
+		for (int j = 0; j < r->n_bin; j++) {
+			if (fread(b, 1, 8, fp) != 8) goto bad;
+			r->bins[j].bin = rd_u32(b);
+			r->bins[j].n = (int) rd_u32(b + 4);
+			r->bins[j].list = (chunk_t*) calloc((size_t) r->bins[j].n + 1, sizeof(chunk_t));
+			for (int k = 0; k < r->bins[j].n; k++) {
+				if (fread(b, 1, 16, fp) != 16) goto bad;
+				r->bins[j].list[k].u = rd_u64(b);
+				r->bins[j].list[k].v = rd_u64(b + 8);
+			}
+		}
+		if (fread(b, 1, 4, fp) != 4) goto bad;
+		r->n_intv = (int) rd_u32(b);
+		r->ioff = (uint64_t*) calloc((size_t) r->n_intv + 1, 8);
+		for (int j = 0; j < r->n_intv; j++) {
+			if (fread(b, 1, 8, fp) != 8) goto bad;
+			r->ioff[j] = rd_u64(b);
+		}
+		for (int j = 1; j < r->n_intv; j++) if (r->ioff[j] == 0) r->ioff[j] = r->ioff[j - 1];     /* "fill missing values" */
+		for (int j = 0; j < r->n_bin; j++) {                                                          /* update_loff */
+			bin_t* p = &r->bins[j];
+			if (p->bin < BAI_N_BINS + 0u) {
+				const int bot = bin_bot((int) p->bin);
+				p->loff = bot < r->n_intv ? r->ioff[bot] : 0;
+			} else
+				p->loff = 0;
+		}
+	}
+	fclose(fp);
+	return ix;
+bad:
+	fail("%s: truncated index", fn);
+	fclose(fp);
+	bamx_index_free(ix);
+	return NULL;
+}
+
+void bamx_index_free(bamx_index* ix) {
+	if (!ix) return;
+	for (int i = 0; i < ix->n_ref; i++) {
+		for (int j = 0; j < ix->ref[i].n_bin; j++) free(ix->ref[i].bins[j].list);
+		free(ix->ref[i].bins);
+		free(ix->ref[i].ioff);
+	}
+	free(ix->ref);
+	free(ix);
+}
+
+/* hts_parse_reg (hts.c:1490-1519): returns the offset where the name ends */
+static size_t parse_reg(const char* s, int* beg, int* end) {
+	int i, k, l, name_end;
+	*beg = *end = -1;
+	name_end = l = (int) strlen(s);
+	for (i = l - 1; i >= 0; --i) if (s[i] == ':') break;
+	if (i >= 0) name_end = i;
+	if (name_end < l) {
+		int n_hyphen = 0;
+		for (i = name_end + 1; i < l; ++i) {
+			if (s[i] == '-') ++n_hyphen;
+			else if (!isdigit((unsigned char) s[i]) && s[i] != ',') break;
+		}
+		if (i < l || n_hyphen > 1) name_end = l;
+	}
+	if (name_end < l) {
+		char tmp[64];
+		for (i = name_end + 1, k = 0; i < l && k < 62; ++i) if (s[i] != ',') tmp[k++] = s[i];
+		tmp[k] = 0;
+		char* q;
+		if ((*beg = (int) strtol(tmp, &q, 10) - 1) < 0) *beg = 0;
+		*end = *q ? (int) strtol(q + 1, &q, 10) : INT_MAX;
+		if (*beg > *end) name_end = l;
+	}
+	if (name_end == l) { *beg = 0; *end = INT_MAX; }
+	return (size_t) name_end;
+}
+
+static int cmp_chunk(const void* a, const void* b) {
+	const chunk_t* x = (const chunk_t*) a;
+	const chunk_t* y = (const chunk_t*) b;
+	if (x->u != y->u) return x->u < y->u ? -1 : 1;
+	return x->v < y->v ? -1 : x->v > y->v;
+}
+
+long bamx_query(bamx_file* f, const bamx_index* ix, const char* region, void (*cb)(const bamx_rec*, void*), void* ud) {
+	int beg, end;
+	const size_t ne = parse_reg(region, &beg, &end);
+	char name[512];
+	if (ne >= sizeof name) return fail("region name too long");
+	memcpy(name, region, ne);
+	name[ne] = 0;
+	int tid = name2id(f, name);
+	if (tid < 0) tid = name2id(f, region);
+	if (tid < 0) return fail("region %s: the reference name is not in the BAM header (the reference crashes here: NULL iterator)", region);
+	/* hts_itr_query */
+	if (beg < 0) beg = 0;
+	if (end < beg || tid >= ix->n_ref) return fail("region %s: no index for that reference (NULL iterator in the reference)", region);
+	const refidx_t* r = &ix->ref[tid];
+	int bin = bin_first(BAI_N_LVLS) + (beg >> BAI_MIN_SHIFT);
+	const bin_t* hit = NULL;
+	do {
+		hit = find_bin(r, (uint32_t) bin);
+		if (hit) break;
+		const int first = (bin_parent(bin) << 3) + 1;
+		if (bin > first) --bin;
+		else bin = bin_parent(bin);
+	} while (bin);
+	if (bin == 0) hit = find_bin(r, 0);
+	const uint64_t min_off = hit ? hit->loff : 0;
+	/* reg2bins + collect chunks */
+	size_t cap = 64, n_off = 0;
+	chunk_t* off = (chunk_t*) malloc(cap * sizeof(chunk_t));
+	if (beg < end) {
+		int64_t e = end;
+		int s = BAI_MIN_SHIFT + (BAI_N_LVLS << 1) + BAI_N_LVLS;
+		if (e >= 1LL << s) e = 1LL << s;
+		--e;
+		for (int l = 0, t = 0; l <= BAI_N_LVLS; s -= 3, t += 1 << ((l << 1) + l), ++l) {
+			const int b0 = t + (int) (beg >> s), e0 = t + (int) (e >> s);
+			for (int bi = b0; bi <= e0; bi++) {
+				const bin_t* p = find_bin(r, (uint32_t) bi);
+				if (!p) continue;
+				for (int j = 0; j < p->n; j++)
+					if (p->list[j].v > min_off) {
+						if (n_off == cap) { cap *= 2; off = (chunk_t*) realloc(off, cap * sizeof(chunk_t)); }
+						off[n_off++] = p->list[j];
+					}
+			}
+		}
+	}
+	long n_ret = 0;
+	if (n_off) {
+		qsort(off, n_off, sizeof(chunk_t), cmp_chunk);
+		size_t l = 0;
+		for (size_t i = 1; i < n_off; ++i) if (off[l].v < off[i].v) off[++l] = off[i];      /* completely contained blocks */
+		n_off = l + 1;
+		for (size_t i = 1; i < n_off; ++i) if (off[i - 1].v >= off[i].u) off[i - 1].v = off[i].u;   /* overlaps */
+		l = 0;
+		for (size_t i = 1; i < n_off; ++i) {                                                  /* adjacent blocks */
+			if (off[l].v >> 16 == off[i].u >> 16) off[l].v = off[i].v;
+			else off[++l] = off[i];
+		}
+		n_off = l + 1;
+		/* hts_itr_next, repeated until it returns < 0 */
+		static bamx_rec rec;
+		long i_chunk = -1;
+		uint64_t curr_off = 0;
+		for (;;) {
+			if (curr_off == 0 || curr_off >= off[i_chunk].v) {
+				if (i_chunk == (long) n_off - 1) break;
+				if (i_chunk < 0 || off[i_chunk].v != off[i_chunk + 1].u) {
+					if (bamx_seek(f, off[i_chunk + 1].u)) { free(off); return -2; }
+					curr_off = bamx_tell(f);
+				}
+				++i_chunk;
+			}
+			const int rc = bamx_read1(f, &rec);
+			if (rc < -1) { free(off); return rc; }
+			if (rc < 0) break;
+			curr_off = bamx_tell(f);
+			if (rec.tid != tid || rec.pos >= end) break;
+			if (rec.end > beg && end > rec.pos) { n_ret++; if (cb) cb(&rec, ud); }
+		}
+	}
+	free(off);
+	return n_ret;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* string sets (the dense_hash_sets of extract: membership only, iteration order never matters)                        */
+/* ------------------------------------------------------------------------------------------------------------------ */
+typedef struct { const char** slot; size_t cap, n; size_t keylen; /* 0 = NUL-terminated strings */ } sset;
+static uint64_t hash_bytes(const char* s, size_t n) {
+	uint64_t h = 1469598103934665603ull;
+	for (size_t i = 0; i < n; i++) { h ^= (unsigned char) s[i]; h *= 1099511628211ull; }
+	return h;
+}
+static void sset_init(sset* t, size_t keylen) { t->cap = 1024; t->n = 0; t->keylen = keylen; t->slot = (const char**) calloc(t->cap, sizeof(char*)); }
+static void sset_free(sset* t) { free(t->slot); t->slot = NULL; }
+static size_t sset_len(const sset* t, const char* s) { return t->keylen ? t->keylen : strlen(s); }
+static const char* sset_get(const sset* t, const char* s) {
+	const size_t n = sset_len(t, s);
+	for (size_t i = hash_bytes(s, n) & (t->cap - 1);; i = (i + 1) & (t->cap - 1)) {
+		const char* c = t->slot[i];
+		if (!c) return NULL;
+		if (t->keylen ? !memcmp(c, s, n) : !strcmp(c, s)) return c;
+	}
+}
+static void sset_put(sset* t, const char* stored) {       /* the caller made sure it is absent */
+	if ((t->n + 1) * 2 > t->cap) {
+		const char** old = t->slot;
+		const size_t oc = t->cap;
+		t->cap *= 2;
+		t->slot = (const char**) calloc(t->cap, sizeof(char*));
+		for (size_t i = 0; i < oc; i++)
+			if (old[i]) {
+				size_t j = hash_bytes(old[i], sset_len(t, old[i])) & (t->cap - 1);
+				while (t->slot[j]) j = (j + 1) & (t->cap - 1);
+				t->slot[j] = old[i];
+			}
+		free(old);
+	}
+	size_t j = hash_bytes(stored, sset_len(t, stored)) & (t->cap - 1);
+	while (t->slot[j]) j = (j + 1) & (t->cap - 1);
+	t->slot[j] = stored;
+	t->n++;
+}
+
+/* append-only storage for names, 15-mers, sequences */
+typedef struct blk { struct blk* next; size_t used, cap; char data[]; } blk;
+static char* arena_alloc(blk** head, size_t n) {
+	if (!*head || (*head)->used + n > (*head)->cap) {
+		const size_t cap = n > (1u << 22) ? n : (1u << 22);
+		blk* b = (blk*) malloc(sizeof(blk) + cap);
+		b->next = *head; b->used = 0; b->cap = cap;
+		*head = b;
+	}
+	char* p = (*head)->data + (*head)->used;
+	(*head)->used += n;
+	return p;
+}
+static const char* arena_str(blk** head, const char* s) {
+	const size_t n = strlen(s) + 1;
+	char* p = arena_alloc(head, n);
+	memcpy(p, s, n);
+	return p;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* extract (bam_read.c:294-446)                                                                                        */
+/* ------------------------------------------------------------------------------------------------------------------ */
+#define EXTRACT_KMER_SIZE 15
+
+static char complement(char c) {              /* bam_read.c:115-129 */
+	switch (c) { case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C'; default: return c; }
+}
+
+/* load_kmers (bam_read.c:180-204): 15-mers of every fgets chunk of ig_vdj.fa that is not a header, both strands; the chunk
+ * loses its last character ("Remove newline") and the loop stops one k-mer short (i < strlen - 15) */
+static int load_vdj_kmers(const char* path, sset* set, blk** arena) {
+	FILE* fp = fopen(path, "r");
+	if (!fp) return fail("Could not open file: [%s]", path);     /* the reference prints this and then crashes in fgets */
+	char buf[1024], rcb[1024];
+	while (fgets(buf, sizeof buf, fp)) {
+		if (buf[0] == '>' || strlen(buf) < EXTRACT_KMER_SIZE) continue;
+		buf[strlen(buf) - 1] = 0;
+		const size_t n = strlen(buf);
+		for (size_t i = 0; i < n; i++) rcb[i] = complement(buf[n - 1 - i]);
+		rcb[n] = 0;
+		if (n < EXTRACT_KMER_SIZE) continue;                       /* (size_t underflow in the reference: nothing sensible to add) */
+		for (size_t i = 0; i + EXTRACT_KMER_SIZE < n; i++) {
+			const char* two[2] = {buf + i, rcb + i};
+			for (int j = 0; j < 2; j++)
+				if (!sset_get(set, two[j])) {
+					char* p = arena_alloc(arena, EXTRACT_KMER_SIZE + 1);
+					memcpy(p, two[j], EXTRACT_KMER_SIZE);
+					p[EXTRACT_KMER_SIZE] = 0;
+					sset_put(set, p);
+				}
+		}
+	}
+	fclose(fp);
+	return 0;
+}
+
+typedef struct { sset* set; blk** arena; } name_ud;
+static void add_name_cb(const bamx_rec* r, void* ud) {
+	name_ud* u = (name_ud*) ud;
+	if (!sset_get(u->set, r->qname)) sset_put(u->set, arena_str(u->arena, r->qname));
+}
+
+static void push_read(bamx_reads* out, size_t* cap, char pool, const char* name, int read_num, const bamx_rec* r, blk** arena) {
+	if (out->n == *cap) { *cap = *cap ? *cap * 2 : 4096; out->v = (bamx_read*) realloc(out->v, *cap * sizeof(bamx_read)); }
+	bamx_read* x = &out->v[out->n++];
+	const size_t L = (size_t) out->read_len;
+	x->pool = pool; x->name = name; x->read_num = read_num; x->is_rev = (r->flag & 16) != 0;
+	x->seq = arena_alloc(arena, L + 1);
+	x->qual = arena_alloc(arena, L + 1);
+	memset(x->seq, 0, L + 1);
+	memset(x->qual, 0, L + 1);
+	strncpy(x->seq, r->seq, L);                                    /* bam_read.c:220,223 */
+	strncpy(x->qual, r->qual, L);
+}
+
+int bamx_extract(const char* bam_path, const char* vdj_fasta, const char* v_region, const char* c_region, bamx_reads* out) {
+	memset(out, 0, sizeof *out);
+	blk* arena = NULL;
+	static bamx_rec rec;
+	int rc = 0;
+	/* get_read_length (bam_read.c:264-292): its own pass over the whole file (and it loads the index too) */
+	{
+		bamx_file* f = bamx_open(bam_path);
+		if (!f) return -2;
+		bamx_index* ix0 = bamx_index_load(bam_path);
+		if (!ix0) { bamx_close(f); return -2; }
+		bamx_index_free(ix0);
+		out->max_len = -1;
+		while ((rc = bamx_read1(f, &rec)) >= 0) if (rec.l_qseq > out->max_len) out->max_len = rec.l_qseq;
+		bamx_close(f);
+		if (rc < -1) return rc;
+		if (out->max_len <= 0) return fail("Error retrieving read length from: %s", bam_path);
+	}
+	sset kmers, primary, secondary;
+	sset_init(&kmers, EXTRACT_KMER_SIZE);
+	sset_init(&primary, 0);
+	sset_init(&secondary, 0);
+	bamx_file* f = NULL;
+	bamx_index* ix = NULL;
+	if ((rc = load_vdj_kmers(vdj_fasta, &kmers, &arena)) != 0) goto done;
+	f = bamx_open(bam_path);
+	if (!f) { rc = -2; goto done; }
+	ix = bamx_index_load(bam_path);
+	if (!ix) { rc = -2; goto done; }
+	/* names of the reads overlapping the variable region, then the constant region (bam_read.c:316-342) */
+	{
+		name_ud u1 = {&primary, &arena}, u2 = {&secondary, &arena};
+		if (bamx_query(f, ix, v_region, add_name_cb, &u1) < 0) { rc = -2; goto done; }
+		fprintf(stderr, "primary_reads size1: [%d]\n", (int) primary.n);
+		if (bamx_query(f, ix, c_region, add_name_cb, &u2) < 0) { rc = -2; goto done; }
+		fprintf(stderr, "secondary_reads size1: [%d]\n", (int) secondary.n);
+	}
+	/* "Process unmapped reads" (bam_read.c:346-374): sequential from WHEREVER the iterators left the file */
+	while ((rc = bamx_read1(f, &rec)) >= 0) {
+		if (out->read_len == 0) out->read_len = rec.l_qseq;
+		const size_t L = strlen(rec.seq);
+		if (L < EXTRACT_KMER_SIZE) continue;                        /* (size_t underflow in the reference) */
+		for (size_t i = 0; i + EXTRACT_KMER_SIZE < L; i++) {
+			if (sset_get(&kmers, rec.seq + i)) {
+				if (!sset_get(&primary, rec.qname)) sset_put(&primary, arena_str(&arena, rec.qname));
+			} else if ((rec.flag & 4) && !sset_get(&secondary, rec.qname))
+				sset_put(&secondary, arena_str(&arena, rec.qname));
+		}
+	}
+	if (rc < -1) goto done;
+	rc = 0;
+	bamx_close(f);
+	f = NULL;
+	out->n_primary_names = primary.n;
+	out->n_secondary_names = secondary.n;
+	/* second pass from the beginning (bam_read.c:399-432): first 0x40 and first 0x80 record of every kept name */
+	{
+		sset p1, p2, s1, s2;
+		sset_init(&p1, 0); sset_init(&p2, 0); sset_init(&s1, 0); sset_init(&s2, 0);
+		size_t cap = 0;
+		f = bamx_open(bam_path);
+		if (!f) { rc = -2; }
+		else {
+			bamx_index* ix2 = bamx_index_load(bam_path);          /* bam_open loads it again and fails without it */
+			if (!ix2) rc = -2;
+			bamx_index_free(ix2);
+		}
+		while (!rc && (rc = bamx_read1(f, &rec)) >= 0) {
+			rc = 0;
+			if (rec.flag & 0x900) continue;
+			const char* nm;
+			if ((nm = sset_get(&primary, rec.qname)) != NULL) {
+				if ((rec.flag & 0x40) && !sset_get(&p1, nm)) { push_read(out, &cap, 'P', nm, 1, &rec, &arena); sset_put(&p1, nm); }
+				else if ((rec.flag & 0x80) && !sset_get(&p2, nm)) { push_read(out, &cap, 'P', nm, 2, &rec, &arena); sset_put(&p2, nm); }
+			} else if ((nm = sset_get(&secondary, rec.qname)) != NULL) {
+				if ((rec.flag & 0x40) && !sset_get(&s1, nm)) { push_read(out, &cap, 'S', nm, 1, &rec, &arena); sset_put(&s1, nm); }
+				else if ((rec.flag & 0x80) && !sset_get(&s2, nm)) { push_read(out, &cap, 'S', nm, 2, &rec, &arena); sset_put(&s2, nm); }
+			}
+		}
+		if (rc == -1) rc = 0;
+		fprintf(stderr, "primary_output1: [%d] primary_output2: [%d] secondary_output1: [%d] secondary_output2: [%d]\n", (int) p1.n, (int) p2.n,
+		        (int) s1.n, (int) s2.n);
+		sset_free(&p1); sset_free(&p2); sset_free(&s1); sset_free(&s2);
+	}
+done:
+	if (f) bamx_close(f);
+	bamx_index_free(ix);
+	sset_free(&kmers); sset_free(&primary); sset_free(&secondary);
+	out->arena = arena;
+	if (rc) bamx_free(out);
+	return rc;
+}
+
+void bamx_free(bamx_reads* r) {
+	if (!r) return;
+	blk* b = (blk*) r->arena;
+	while (b) { blk* n = b->next; free(b); b = n; }
+	free(r->v);
+	memset(r, 0, sizeof *r);
+}

@@ -1,0 +1,76 @@
+/* bamx -- BAM/BGZF/BAI reading and V'DJer's read extraction in plain C over zlib.
+ *
+ * Replaces, for the `vdjer --in <bam>` path: get_read_length (bam_read.c:264-292) and extract (bam_read.c:294-446)
+ * together with the parts of htslib 1.2.1 they reach: bgzf_read/seek/tell (bgzf.c:547-574, 847-866), bam_hdr_read,
+ * bam_read1, the BAI loader (hts.c:1159-1210, update_loff :857-887), hts_itr_query / hts_itr_next (hts.c:1372-1487,
+ * 1539-1580) and hts_parse_reg (hts.c:1490-1519).  The reference side of this row cannot be compiled here (htslib needs
+ * its own build system and a generated header), so the extraction order rules below are a restatement checked against an
+ * independent model (tests/bam_model.py); the decoding is checked on BAM/BAI files written by real samtools.
+ */
+#ifndef VDJX_BAMX_H
+#define VDJX_BAMX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* one extracted read, in the order add_to_buffer is called (bam_read.c:404-428): the forward record; the caller derives the
+ * reverse-complement record exactly as add_to_buffer does */
+typedef struct {
+	char pool;            /* 'P' primary_buf, 'S' secondary_buf */
+	const char* name;     /* read name (owned by the bamx_reads) */
+	int read_num;         /* 1 | 2 */
+	int is_rev;           /* bam_is_rev */
+	char* seq;            /* read_len characters of "=ACMGRSVTWYHKDBN" (NUL padded if the record is shorter: strncpy, :220) */
+	char* qual;           /* read_len characters, Phred+33 */
+} bamx_read;
+
+typedef struct {
+	bamx_read* v;
+	size_t n;
+	int read_len;         /* extract's: l_qseq of the first record its sequential pass sees (bam_read.c:353-355) */
+	int max_len;          /* get_read_length: the longest l_qseq of the file (bam_read.c:264-292) */
+	size_t n_primary_names, n_secondary_names;
+	void* arena;          /* private */
+} bamx_reads;
+
+const char* bamx_last_error(void);
+/* 1 if the file starts with a gzip member (what sam_open takes for BAM), 0 if not, <0 if unreadable */
+int bamx_is_bam(const char* path);
+/* the whole extraction; v_region / c_region are samtools region strings ("chr14:105566277-106879844").  0 on success */
+int bamx_extract(const char* bam_path, const char* vdj_fasta, const char* v_region, const char* c_region, bamx_reads* out);
+void bamx_free(bamx_reads* r);
+
+/* ---- lower level, exposed for the tests -------------------------------------------------------------------------- */
+typedef struct bamx_file bamx_file;
+typedef struct bamx_index bamx_index;
+typedef struct {
+	int32_t tid, pos, l_qseq, n_cigar, end;   /* end = pos + reference length of the CIGAR, or pos + 1 (sam.c:458-467) */
+	uint16_t flag, bin;
+	uint8_t mapq;
+	char qname[256];
+	char seq[1024];                           /* "=ACMGRSVTWYHKDBN" letters (reads longer than 1023 are an error here) */
+	char qual[1024];                          /* Phred+33 */
+	uint64_t voff;                            /* virtual offset of the record's first byte */
+} bamx_rec;
+
+bamx_file* bamx_open(const char* path);
+void bamx_close(bamx_file* f);
+int bamx_n_ref(const bamx_file* f);
+const char* bamx_ref_name(const bamx_file* f, int tid);
+int bamx_read1(bamx_file* f, bamx_rec* r);              /* >= 0 record read, -1 end of file, < -1 error */
+uint64_t bamx_tell(const bamx_file* f);                  /* bgzf_tell */
+int bamx_seek(bamx_file* f, uint64_t voff);
+bamx_index* bamx_index_load(const char* bam_path);       /* <bam_path>.bai */
+void bamx_index_free(bamx_index* ix);
+/* sam_itr_querys + the loop `while (sam_itr_next(...) >= 0)`: calls cb for every record the iterator returns; leaves the
+ * file where the iterator left it.  Returns the number of records, or < 0 on error (unknown reference: the reference
+ * dereferences a NULL iterator there) */
+long bamx_query(bamx_file* f, const bamx_index* ix, const char* region, void (*cb)(const bamx_rec*, void*), void* ud);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -21,17 +21,19 @@
 #include "../../../include/vdjx.h"
 #include "sph.h"
 #include "vdjh.h"
+#include "bamx.h"
 
 typedef struct {
 	vdjh_params hp;
 	const char* in;
-	char v_anchors[4096], j_anchors[4096], source_sim_file[4096];
+	char v_anchors[4096], j_anchors[4096], source_sim_file[4096], vdj_fasta[4096];
+	char v_region[64], c_region[64];       /* set_chain_info, params.c:8-35 (hg38 coordinates); --vr / --cr override */
 	int anchor_mismatches, threads;
 	int have_chain, have_ref;
 } cli;
 
 static void usage(void) {
-	fprintf(stderr, "vdjer \n\t--in <extracted reads (text; see vdjer_main.c)>\n\t--chain <IGH|IGK|IGL>\n\t--ref-dir </path/to/vdjer/ref/dir>\n"
+	fprintf(stderr, "vdjer \n\t--in <input BAM (with .bai), or the extracted reads as text (see vdjer_main.c)>\n\t--chain <IGH|IGK|IGL>\n\t--ref-dir </path/to/vdjer/ref/dir>\n"
 	                "\t--mf <min node frequency (default: 3)>\n\t--mq <min base quality (default: 90)>\n\t--mcs <min contig score (default: -5)\n"
 	                "\t--t <threads (default: 1)\n\t--am <anchor mismatches (default: 4)\n\t--miw/--maw <min/max window between conserved amino acids>\n"
 	                "\t--jc <conserved J amino acid (W|F)\n\t--ws <window span (default: 486)\n\t--jext <J extension (default: 162)\n"
@@ -55,11 +57,19 @@ static int parse(int argc, char** argv, cli* c) {
 		if (i + 1 >= argc) { fprintf(stderr, "Missing value for param: %s\n", a); usage(); return -1; }
 		const char* v = argv[i + 1];
 		if (!strcmp(a, "--in")) c->in = v;
-		else if (!strcmp(a, "--chain")) { if (vdjh_set_chain(&c->hp, v)) { fprintf(stderr, "%s\n", vdjh_last_error()); return -1; } c->have_chain = 1; }
+		else if (!strcmp(a, "--chain")) {
+			if (vdjh_set_chain(&c->hp, v)) { fprintf(stderr, "%s\n", vdjh_last_error()); return -1; }
+			c->have_chain = 1;
+			const char* vr = !strcmp(v, "IGH") ? "chr14:105566277-106879844" : !strcmp(v, "IGL") ? "chr22:22026076-22922913" : "chr2:89851758-90235368";
+			const char* cr = !strcmp(v, "IGH") ? "chr14:105566277-105939754" : !strcmp(v, "IGL") ? "chr22:22895375-22922913" : "chr2:88857361-88857683";
+			snprintf(c->v_region, sizeof c->v_region, "%s", vr);
+			snprintf(c->c_region, sizeof c->c_region, "%s", cr);
+		}
 		else if (!strcmp(a, "--ref-dir")) {
 			snprintf(c->v_anchors, sizeof c->v_anchors, "%s/v_index", v);
 			snprintf(c->j_anchors, sizeof c->j_anchors, "%s/j_index", v);
 			snprintf(c->source_sim_file, sizeof c->source_sim_file, "%s/v_region.fa", v);
+			snprintf(c->vdj_fasta, sizeof c->vdj_fasta, "%s/ig_vdj.fa", v);
 			c->have_ref = 1;
 		}
 		else if (!strcmp(a, "--mf")) c->hp.min_node_freq = atoi(v);
@@ -74,7 +84,9 @@ static int parse(int argc, char** argv, cli* c) {
 		else if (!strcmp(a, "--jc")) c->hp.j_conserved = v[0];
 		else if (!strcmp(a, "--ws")) c->hp.window_span = atoi(v);
 		else if (!strcmp(a, "-jext")) c->hp.j_extension = atoi(v);        /* sic: params.c:262 */
-		else if (!strcmp(a, "--vdjf") || !strcmp(a, "--vr") || !strcmp(a, "--cr")) { /* extraction-only settings */ }
+		else if (!strcmp(a, "--vdjf")) snprintf(c->vdj_fasta, sizeof c->vdj_fasta, "%s", v);
+		else if (!strcmp(a, "--vr")) snprintf(c->v_region, sizeof c->v_region, "%s", v);
+		else if (!strcmp(a, "--cr")) snprintf(c->c_region, sizeof c->c_region, "%s", v);
 		else if (!strcmp(a, "--ins")) c->hp.insert_len = atoi(v);
 		else if (!strcmp(a, "--rf")) c->hp.read_filter_floor = atoi(v);
 		else if (!strcmp(a, "--k")) c->hp.k = atoi(v);
@@ -125,29 +137,13 @@ typedef struct {
 
 static char comp(char c) { switch (c) { case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C'; default: return c; } }
 
-static int load_reads(const char* path, reads_t* r) {
-	FILE* fp = fopen(path, "r");
-	if (!fp) { fprintf(stderr, "cannot open %s\n", path); return -1; }
-	unsigned char magic[4] = {0};
-	if (fread(magic, 1, 4, fp) == 4 && ((magic[0] == 0x1f && magic[1] == 0x8b) || !memcmp(magic, "BAM\1", 4))) {
-		fprintf(stderr, "%s looks like a BAM/BGZF file: BAM extraction is not part of this build (SURVEY 8f-2); "
-		                "pass the extracted reads as text (see vdjer_main.c)\n", path);
-		fclose(fp);
-		return -1;
-	}
-	rewind(fp);
-	char pool[8], name[512];
-	static char seq[1024], qual[1024];
-	int rn, rev;
+/* one extracted read before it becomes two pool records */
+typedef struct { char pool; const char* name; int rn, rev; const char* seq; const char* qual; } read_in;
+
+/* add_to_buffer (bam_read.c:206-244) for every read, in order: forward record, reverse-complement record, both registered */
+static int build_reads(const read_in* in, size_t n, int rl, reads_t* r) {
 	size_t np = 0, ns = 0;
-	int rl = -1;
-	while (fscanf(fp, "%7s %511s %d %d %1023s %1023s", pool, name, &rn, &rev, seq, qual) == 6) {   /* get_read_length: the maximum */
-		int l = (int) strlen(seq);
-		if (l > rl) rl = l;
-		if (pool[0] == 'P') np++; else ns++;
-	}
-	if (rl <= 0) { fprintf(stderr, "Error retrieving read length from: %s\n", path); fclose(fp); return -1; }
-	rewind(fp);
+	for (size_t i = 0; i < n; i++) { if (in[i].pool == 'P') np++; else ns++; }
 	memset(r, 0, sizeof *r);
 	r->rl = rl;
 	const size_t rec = 2 * (size_t) rl + 1;
@@ -165,8 +161,9 @@ static int load_reads(const char* path, reads_t* r) {
 	sph_init(&ids, 0, 0);
 	size_t ip = 0, is = 0;
 	uint32_t reg = 0;
-	while (fscanf(fp, "%7s %511s %d %d %1023s %1023s", pool, name, &rn, &rev, seq, qual) == 6) {
-		if ((int) strlen(seq) != rl || (int) strlen(qual) != rl) { fprintf(stderr, "read %s: length != %d\n", name, rl); fclose(fp); return -1; }
+	for (size_t q = 0; q < n; q++) {
+		const char *name = in[q].name, *seq = in[q].seq, *qual = in[q].qual;
+		if ((int) strlen(seq) != rl || (int) strlen(qual) != rl) { fprintf(stderr, "read %s: length != %d\n", name, rl); sph_free(&ids); return -1; }
 		size_t b = sph_find(&ids, name);
 		uint32_t pid;
 		if (b == (size_t) -1) {
@@ -176,7 +173,7 @@ static int load_reads(const char* path, reads_t* r) {
 		} else {
 			pid = (uint32_t) (uintptr_t) ids.b[b].val - 1;
 		}
-		const int isp = pool[0] == 'P';
+		const int isp = in[q].pool == 'P';
 		uint8_t* base = isp ? r->primary + ip * rec : r->secondary + is * rec;
 		const size_t g = isp ? ip : r->n_primary + is;
 		base[0] = '0';
@@ -189,15 +186,64 @@ static int load_reads(const char* path, reads_t* r) {
 		}
 		for (int j = 0; j < 2; j++) {
 			r->pair_id[g + j] = pid;
-			r->read_num[g + j] = (uint8_t) rn;
-			r->is_rc[g + j] = (uint8_t) (j ? !rev : (rev != 0));     /* add_read_info(..., bam_is_rev) then (!bam_is_rev) */
+			r->read_num[g + j] = (uint8_t) in[q].rn;
+			r->is_rc[g + j] = (uint8_t) (j ? !in[q].rev : (in[q].rev != 0));     /* add_read_info(..., bam_is_rev) then (!bam_is_rev) */
 			r->reg_rank[g + j] = reg++;
 		}
 		if (isp) ip += 2; else is += 2;
 	}
-	fclose(fp);
 	sph_free(&ids);
 	return 0;
+}
+
+/* --in <bam>: get_read_length + extract (bam_read.c:264-446) through bamx */
+static int load_bam(const cli* c, reads_t* r) {
+	if (!c->vdj_fasta[0] || !c->v_region[0] || !c->c_region[0]) { fprintf(stderr, "BAM input needs --chain/--ref-dir (or --vdjf, --vr, --cr)\n"); return -1; }
+	bamx_reads br;
+	if (bamx_extract(c->in, c->vdj_fasta, c->v_region, c->c_region, &br)) { fprintf(stderr, "%s\n", bamx_last_error()); return -1; }
+	if (br.read_len != br.max_len) {
+		fprintf(stderr, "reads of different lengths (%d and %d): the reference lays its pools out with one length\n", br.read_len, br.max_len);
+		bamx_free(&br);
+		return -1;
+	}
+	read_in* in = (read_in*) calloc(br.n + 1, sizeof(read_in));
+	for (size_t i = 0; i < br.n; i++) {
+		const bamx_read* x = &br.v[i];
+		in[i].pool = x->pool; in[i].name = x->name; in[i].rn = x->read_num; in[i].rev = x->is_rev; in[i].seq = x->seq; in[i].qual = x->qual;
+	}
+	const int rc = build_reads(in, br.n, br.max_len, r);
+	free(in);
+	bamx_free(&br);
+	return rc;
+}
+
+static int load_reads(const cli* c, reads_t* r) {
+	const char* path = c->in;
+	const int isbam = bamx_is_bam(path);
+	if (isbam < 0) { fprintf(stderr, "cannot open %s\n", path); return -1; }
+	if (isbam) return load_bam(c, r);
+	FILE* fp = fopen(path, "r");
+	if (!fp) { fprintf(stderr, "cannot open %s\n", path); return -1; }
+	char pool[8], name[512];
+	static char seq[1024], qual[1024];
+	int rn, rev;
+	size_t n = 0, cap = 1024;
+	int rl = -1;
+	read_in* in = (read_in*) calloc(cap, sizeof(read_in));
+	while (fscanf(fp, "%7s %511s %d %d %1023s %1023s", pool, name, &rn, &rev, seq, qual) == 6) {
+		const int l = (int) strlen(seq);
+		if (l > rl) rl = l;                                   /* get_read_length: the maximum */
+		if (n == cap) { cap *= 2; in = (read_in*) realloc(in, cap * sizeof(read_in)); }
+		in[n].pool = pool[0] == 'P' ? 'P' : 'S';
+		in[n].name = strdup(name); in[n].rn = rn; in[n].rev = rev; in[n].seq = strdup(seq); in[n].qual = strdup(qual);
+		n++;
+	}
+	fclose(fp);
+	if (rl <= 0) { fprintf(stderr, "Error retrieving read length from: %s\n", path); return -1; }
+	const int rc = build_reads(in, n, rl, r);
+	for (size_t i = 0; i < n; i++) { free((char*) in[i].name); free((char*) in[i].seq); free((char*) in[i].qual); }
+	free(in);
+	return rc;
 }
 
 /* load_kmers, vj_filter.c:56-68 */
@@ -315,7 +361,7 @@ int main(int argc, char** argv) {
 	cli c;
 	if (parse(argc, argv, &c)) return 255;                  /* the reference exits with -1 */
 	reads_t rd;
-	if (load_reads(c.in, &rd)) return 255;
+	if (load_reads(&c, &rd)) return 255;
 	c.hp.read_length = rd.rl;
 	fprintf(stderr, "read length:\t%d\n", rd.rl);
 
