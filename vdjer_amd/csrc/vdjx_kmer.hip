@@ -29,7 +29,8 @@
 #define K3_THREADS 512
 #define K3_SLOTS 2048u              // LDS table slots per sub-pass (56 KB with u32 key_hi: 2 workgroups per CU)
 #define K3_UNR 4
-#define K3_SUB_TUPLES 16384u        // first split only for very large buckets: hot k-mers make buckets long, not wide (an overflow splits further)
+#define K3_SUB_TUPLES g_sub_tuples  // first split only for very large buckets: hot k-mers make buckets long, not wide (an overflow splits further)
+__device__ u32 g_sub_tuples = 262144u;
 #define K3B_THREADS 256
 #define K3B_CH 1024u                // candidates per chunk
 #define K3B_A 128u                  // quality-sum rows per round
@@ -293,6 +294,24 @@ __global__ __launch_bounds__(256) void k_seg_hist(const u64* __restrict__ lo, co
 	for (u32 t = s0 + threadIdx.x; t < s1; t += 256) atomicAdd(&h[(u32) (vdjx_mix(lo[t], (u64) hi[t]) >> shift) & (nbk - 1)], 1u);
 	__syncthreads();
 	for (u32 i = threadIdx.x; i < nbk; i += 256) fine_cnt[((size_t) blockIdx.x << sub_bits) | i] = h[i];
+}
+
+// the same over long segments (the coarse buckets of pass 1): `slices` workgroups per segment, LDS counts added to the global ones
+template <typename THI>
+__global__ __launch_bounds__(512) void k_seg_hist_sliced(const u64* __restrict__ lo, const THI* __restrict__ hi, const u32* __restrict__ seg_start,
+                                                         u32 seg_shift, u32 slices, u32 shift, u32 sub_bits, u32* __restrict__ fine_cnt) {
+	__shared__ u32 h[PART_MAXB];
+	const u32 nbk = 1u << sub_bits;
+	for (u32 i = threadIdx.x; i < nbk; i += 512) h[i] = 0;
+	__syncthreads();
+	const u32 seg = blockIdx.x / slices, sl = blockIdx.x % slices;
+	const size_t s0 = seg_start[(size_t) seg << seg_shift], s1 = seg_start[((size_t) seg + 1) << seg_shift];
+	const size_t per = (s1 - s0 + slices - 1) / slices;
+	const size_t t0 = s0 + (size_t) sl * per;
+	const size_t t1 = t0 + per < s1 ? t0 + per : s1;
+	for (size_t t = t0 + threadIdx.x; t < t1; t += 512) atomicAdd(&h[(u32) (vdjx_mix(lo[t], (u64) hi[t]) >> shift) & (nbk - 1)], 1u);
+	__syncthreads();
+	for (u32 i = threadIdx.x; i < nbk; i += 512) if (h[i]) atomicAdd(&fine_cnt[((size_t) seg << sub_bits) | i], h[i]);
 }
 
 // cursors of a partition pass: cur[i] = bucket_start[i << sh]
@@ -1405,73 +1424,77 @@ inline PartGeom part_geom(u32 nb_bits) {
 	return g;
 }
 
-// K2c from the records of `pool` into caller-chosen arrays (bucket starts from stage_partition_count)
+// how many hash bits beyond the histogram's 2^15 buckets: buckets stay near `target` tuples whatever the pool size
+// (`Nd` = the tuple count the decision is made on: the sharded build passes a bound every rank knows, so that all ranks cut the
+// same buckets)
+u32 choose_extra_bits(size_t Nd, u32 NB) {
+	static const size_t target = tune("VDJX_REFINE_TUPLES", 2048);
+	if (NB == 0 || Nd / NB <= 2 * target) return 0;
+	u32 extra = 1;
+	while (extra < 5 && (Nd >> extra) / NB > target) extra++;
+	return extra;
+}
+
+// K2c: the records of `pool` -> tuples grouped by the top (nb_bits + extra) hash bits, in two LDS-staged passes.
+//   extra == 0: bucket starts come from the histogram (stage_partition_count): 256 coarse x 2^(nb_bits-8) fine.
+//   extra  > 0 (large pools): the histogram only resolves 2^15 buckets (LDS), so pass 1 cuts 2^(T-10) coarse buckets whose starts
+//   it does know, a counting pass over them yields the 2^10 sub-bucket sizes each, and pass 2 cuts those: 2^T buckets after two
+//   partition passes and one read-only pass (a third partition pass cost 13 ms per 10 M pairs).
 template <typename THI, typename A>
-int stage_partition_fill(vdjx_ctx* c, A& db, const vdjx_pool* pool, u32 rec_base, int k, const PartPlan& pp, u32 N,
-                         u64* t_lo, THI* t_hi, u32* t_inst) {
+int stage_partition_fill(vdjx_ctx* c, A& db, const vdjx_pool* pool, u32 rec_base, int k, const PartPlan& pp, u32 N, u32 extra,
+                         Tuples<THI>* out) {
 	hipStream_t st = c->stream;
-	const PartGeom g = part_geom(pp.nb_bits);
 	const size_t R = pool->n_records;
-	const u32 NBc = 1u << g.cbits;
+	if (pp.nb_bits < 15) extra = 0;                    // the histogram itself resolves the buckets below its LDS limit
+	const u32 T = pp.nb_bits + extra;
+	PartGeom g = part_geom(pp.nb_bits);
+	if (extra) { g.cbits = T - 10; g.fbits = 10; }
+	const u32 NBc = 1u << g.cbits, NBt = 1u << T;
 	u32* gcur;
 	HIP_TRY(db.alloc(&gcur, NBc));
+	HIP_TRY(db.alloc(&out->lo, N)); HIP_TRY(db.alloc(&out->hi, N)); HIP_TRY(db.alloc(&out->inst, N));
 	HIP_TRY(hipFuncSetAttribute((const void*) k_part_records<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
 	HIP_TRY(hipFuncSetAttribute((const void*) k_part_tuples<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
 	u32 nblk = (u32) std::min<size_t>(1024, (R + 2047) / 2048);
 	if (nblk == 0) nblk = 1;
 	const size_t rpb = (R + nblk - 1) / nblk;
-	u64* l1_lo = t_lo; THI* l1_hi = t_hi; u32* l1_inst = t_inst;
+	u64* l1_lo = out->lo; THI* l1_hi = out->hi; u32* l1_inst = out->inst;
 	if (g.fbits) {
 		HIP_TRY(db.alloc(&l1_lo, N)); HIP_TRY(db.alloc(&l1_hi, N)); HIP_TRY(db.alloc(&l1_inst, N));
 	}
+	const u32 cshift = pp.nb_bits - g.cbits;          // coarse bucket i starts at bucket_start[i << cshift]
 	{
 		vdjx_prof_scope ps(c, "k_part_records");
-		hipLaunchKernelGGL(k_init_cursors, dim3((NBc + 255) / 256), dim3(256), 0, st, pp.bucket_start, NBc, g.fbits, gcur);
+		hipLaunchKernelGGL(k_init_cursors, dim3((NBc + 255) / 256), dim3(256), 0, st, pp.bucket_start, NBc, cshift, gcur);
 		hipLaunchKernelGGL(k_part_records<THI>, dim3(nblk), dim3(PART_THREADS), PART_LDS_BYTES, st, pool->d_bases, pool->d_nmask,
 		                   pool->d_lowq, R, rec_base, pool->rl, k, 64 - g.cbits, NBc, rpb, gcur, l1_lo, l1_hi, l1_inst);
 	}
-	if (g.fbits) {
-		u32* gcur2;
-		HIP_TRY(db.alloc(&gcur2, pp.NB));
-		static const u32 slices = (u32) tune("VDJX_PART_SLICES", 8);
-		vdjx_prof_scope ps(c, "k_part_tuples");
-		hipLaunchKernelGGL(k_init_cursors, dim3((pp.NB + 255) / 256), dim3(256), 0, st, pp.bucket_start, pp.NB, 0u, gcur2);
-		hipLaunchKernelGGL(k_part_tuples<THI>, dim3(NBc * slices), dim3(PART_THREADS), PART_LDS_BYTES, st, l1_lo, l1_hi, l1_inst,
-		                   pp.bucket_start, g.fbits, slices, 64 - pp.nb_bits, g.fbits, gcur2, t_lo, t_hi, t_inst);
+	out->bucket_start = pp.bucket_start;
+	out->NB = pp.NB;
+	out->N = N;
+	if (!g.fbits) return VDJX_OK;
+	static const u32 slices = (u32) tune("VDJX_PART_SLICES", 8);
+	const u32* fine_start = pp.bucket_start;
+	if (extra) {
+		u32 *fine_cnt, *fs;
+		HIP_TRY(db.alloc(&fine_cnt, NBt));
+		HIP_TRY(db.alloc(&fs, NBt + 1));
+		HIP_TRY(hipMemsetAsync(fine_cnt, 0, (size_t) NBt * 4, st));
+		vdjx_prof_scope ps(c, "k_seg_hist");
+		hipLaunchKernelGGL(k_seg_hist_sliced<THI>, dim3(NBc * slices), dim3(512), 0, st, l1_lo, l1_hi, pp.bucket_start, cshift, slices, 64 - T, g.fbits, fine_cnt);
+		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, fine_cnt, NBt, fs);
+		fine_start = fs;
+		out->bucket_start = fs;
+		out->NB = NBt;
 	}
-	return VDJX_OK;
-}
-
-// Large inputs: 2^15 buckets (the LDS histogram's limit) would hold tens of thousands of tuples each and the
-// aggregate kernel would sweep them once per sub-pass.  Split every bucket further by the next hash bits so that
-// buckets stay near 2,048 tuples whatever the pool size (one more coalesced pass over the tuples).
-template <typename THI, typename A>
-int stage_refine(vdjx_ctx* c, A& db, Tuples<THI>* t, u32 used_bits, size_t decide_N = 0) {
-	// decide_N: the sharded build sizes the split from a bound every rank knows, so that all ranks cut the same buckets
-	const size_t Nd = decide_N ? decide_N : t->N;
-	if (t->NB == 0 || Nd / t->NB <= 4096) return VDJX_OK;
-	u32 extra = 1;
-	while (extra < 10 && (Nd >> extra) / t->NB > 2048 && t->NB << (extra + 1) <= (1u << 22)) extra++;
-	hipStream_t st = c->stream;
-	const u32 NBf = t->NB << extra;
-	u32 *fine_cnt, *fine_start, *gcur, *o_inst;
-	u64* o_lo;
-	THI* o_hi;
-	HIP_TRY(db.alloc(&fine_cnt, NBf));
-	HIP_TRY(db.alloc(&fine_start, NBf + 1));
-	HIP_TRY(db.alloc(&gcur, NBf));
-	HIP_TRY(db.alloc(&o_lo, t->N)); HIP_TRY(db.alloc(&o_hi, t->N)); HIP_TRY(db.alloc(&o_inst, t->N));
-	HIP_TRY(hipFuncSetAttribute((const void*) k_part_tuples<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
-	const u32 shift = 64 - used_bits - extra;
-	vdjx_prof_scope ps(c, "k_part_refine");
-	hipLaunchKernelGGL(k_seg_hist<THI>, dim3(t->NB), dim3(256), 0, st, t->lo, t->hi, t->bucket_start, shift, extra, fine_cnt);
-	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, fine_cnt, NBf, fine_start);
-	hipLaunchKernelGGL(k_init_cursors, dim3((NBf + 255) / 256), dim3(256), 0, st, fine_start, NBf, 0u, gcur);
-	hipLaunchKernelGGL(k_part_tuples<THI>, dim3(t->NB), dim3(PART_THREADS), PART_LDS_BYTES, st, t->lo, t->hi, t->inst, t->bucket_start,
-	                   0u, 1u, shift, extra, gcur, o_lo, o_hi, o_inst);
-	t->lo = o_lo; t->hi = o_hi; t->inst = o_inst;
-	t->bucket_start = fine_start;
-	t->NB = NBf;
+	u32* gcur2;
+	HIP_TRY(db.alloc(&gcur2, NBt));
+	{
+		vdjx_prof_scope ps(c, "k_part_tuples");
+		hipLaunchKernelGGL(k_init_cursors, dim3((NBt + 255) / 256), dim3(256), 0, st, fine_start, NBt, 0u, gcur2);
+		hipLaunchKernelGGL(k_part_tuples<THI>, dim3(NBc * slices), dim3(PART_THREADS), PART_LDS_BYTES, st, l1_lo, l1_hi, l1_inst,
+		                   pp.bucket_start, cshift, slices, 64 - T, g.fbits, gcur2, out->lo, out->hi, out->inst);
+	}
 	return VDJX_OK;
 }
 
@@ -1480,6 +1503,10 @@ template <typename THI, typename A>
 int stage_reduce(vdjx_ctx* c, A& db, const Tuples<THI>& t, const PoolView& pv, int k, int P, int mf, int mq, Survivors* sv) {
 	hipStream_t st = c->stream;
 	const u32 NB = t.NB, N = t.N;
+	{
+		static const u32 sub = (u32) tune("VDJX_SUB_TUPLES", 262144);
+		HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sub_tuples), &sub, 4, 0, hipMemcpyHostToDevice, st));
+	}
 	u64 *c_lo, *g_distinct;
 	THI* c_hi;
 	u32 *c_cnt, *c_first, *ct_lcid, *ct_inst, *bucket_ncand, *bucket_nct, *g_err, *n_surv;
@@ -1667,12 +1694,7 @@ int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, v
 	Tuples<THI> t;
 	int rc = stage_partition_count(c, db, pool, k, choose_nb_bits(NI), &pp, &t.N);
 	if (rc) return rc;
-	HIP_TRY(db.alloc(&t.lo, t.N)); HIP_TRY(db.alloc(&t.hi, t.N)); HIP_TRY(db.alloc(&t.inst, t.N));
-	t.bucket_start = pp.bucket_start;
-	t.NB = pp.NB;
-	rc = stage_partition_fill<THI>(c, db, pool, 0, k, pp, t.N, t.lo, t.hi, t.inst);
-	if (rc) return rc;
-	rc = stage_refine<THI>(c, db, &t, pp.nb_bits);
+	rc = stage_partition_fill<THI>(c, db, pool, 0, k, pp, t.N, choose_extra_bits(t.N, pp.NB), &t);
 	if (rc) return rc;
 	PoolView pv{pool->d_bases, pool->d_nmask, pool->d_quals, pool->qstride};
 	Survivors sv;
@@ -1799,12 +1821,7 @@ static int shard_local_impl(vdjx_shard* s) {
 	Tuples<THI> t;
 	int rc = stage_partition_count(c, db, s->pool, s->k, s->nb_bits, &pp, &t.N);
 	if (rc) return rc;
-	HIP_TRY(db.alloc(&t.lo, t.N)); HIP_TRY(db.alloc(&t.hi, t.N)); HIP_TRY(db.alloc(&t.inst, t.N));
-	t.bucket_start = pp.bucket_start;
-	t.NB = pp.NB;
-	rc = stage_partition_fill<THI>(c, db, s->pool, rec_base, s->k, pp, t.N, t.lo, t.hi, t.inst);
-	if (rc) return rc;
-	rc = stage_refine<THI>(c, db, &t, pp.nb_bits, (size_t) s->rec_stride * (size_t) P);
+	rc = stage_partition_fill<THI>(c, db, s->pool, rec_base, s->k, pp, t.N, choose_extra_bits((size_t) s->rec_stride * (size_t) P, pp.NB), &t);
 	if (rc) return rc;
 	s->t_lo = t.lo; s->t_hi = t.hi; s->t_inst = t.inst; s->t_bucket_start = t.bucket_start;
 	s->N_local = t.N; s->NBf = t.NB;
