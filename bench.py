@@ -301,7 +301,7 @@ def main():
     gc.enable()
     prof = ctx.profile_get()
     ctx.profile(False)
-    stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_pairs", "window_work_items", "map_hits", "root_dp_items")}
+    stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_hits_distinct", "window_pairs", "window_work_items", "map_hits", "root_dp_items")}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         cm.all_reduce(tt, dist.ReduceOp.MAX)

@@ -101,6 +101,8 @@ struct vdjx_ctx {
 	uint8_t* d_is_rc = nullptr;
 	u32* d_pair_r2 = nullptr;         // pair -> its two read-2 records in registration order (or ~0u)
 	uint4* d_rec_info = nullptr;      // record -> {pair id, class of read-2 record A, class of B, flags}
+	u32* d_ri_dstart = nullptr;       // class -> first of its DISTINCT read-1 infos (window scoring counts, it does not name pairs)
+	uint4* d_ri_dinfo = nullptr;      // {how many read-1 members share it, class of read-2 record A, class of B, flags}
 	// cached result of the last vdjx_map_emit count call (the write call of the two-call protocol reuses it)
 	uint64_t me_key = 0;
 	void* me_pairs = nullptr;         // vdjx_pair[me_cap], per-contig regions at me_hoff

@@ -462,6 +462,38 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 	std::vector<uint4> csr_info(recs.size());
 	for (size_t i = 0; i < (size_t) start[ncls]; i++) csr_info[i] = info[recs[i]];
 	HIP_TRY(hipMalloc(&c->d_rec_info, csr_info.size() * sizeof(uint4)));
+	// window scoring only counts mapped pairs per (pos1, pos2): read-1 members of a class whose mates fall into the same two
+	// classes with the same orientation flags behave identically there, so they are folded into one weighted entry (deep clones
+	// hold thousands of identical read pairs; the SAM emission still walks the individual members)
+	std::vector<u32> dstart(ncls + 1, 0);
+	std::vector<uint4> dinfo;
+	dinfo.reserve(csr_info.size() / 2 + 1);
+	{
+		std::vector<uint4> tmp;
+		for (u32 i = 0; i < ncls; i++) {
+			tmp.assign(csr_info.begin() + start[i], csr_info.begin() + start[i] + cnt1[i]);
+			std::sort(tmp.begin(), tmp.end(), [](const uint4& a, const uint4& b) {
+				if (a.y != b.y) return a.y < b.y;
+				if (a.z != b.z) return a.z < b.z;
+				return a.w < b.w;
+			});
+			for (size_t j = 0; j < tmp.size();) {
+				size_t e = j + 1;
+				while (e < tmp.size() && tmp[e].y == tmp[j].y && tmp[e].z == tmp[j].z && tmp[e].w == tmp[j].w) e++;
+				dinfo.push_back(make_uint4((u32) (e - j), tmp[j].y, tmp[j].z, tmp[j].w));
+				j = e;
+			}
+			dstart[i + 1] = (u32) dinfo.size();
+		}
+	}
+	if (dinfo.empty()) dinfo.push_back(make_uint4(0, 0, 0, 0));
+	free_set(c->d_ri_dstart); free_set(c->d_ri_dinfo);
+	HIP_TRY(hipMalloc(&c->d_ri_dstart, dstart.size() * 4));
+	HIP_TRY(hipMalloc(&c->d_ri_dinfo, dinfo.size() * sizeof(uint4)));
+	HIP_TRY(hipMemcpy(c->d_ri_dstart, dstart.data(), dstart.size() * 4, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(c->d_ri_dinfo, dinfo.data(), dinfo.size() * sizeof(uint4), hipMemcpyHostToDevice));
+	c->stats["read_index_r1_members"] = (u64) std::accumulate(cnt1.begin(), cnt1.end(), (u64) 0);
+	c->stats["read_index_r1_distinct"] = dstart[ncls];
 	HIP_TRY(hipMemcpy(c->d_ri_slots, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
 	if (ncls) HIP_TRY(hipMemcpy(c->d_ri_rep, rep.data(), (size_t) ncls * 4, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(c->d_ri_start, start.data(), start.size() * 4, hipMemcpyHostToDevice));
@@ -492,6 +524,7 @@ struct ReadIndexDev {
 	const u32* slots; u32 mask;
 	const u32* rep; const u32* start; const u32* cnt1; const u32* recs;
 	const uint4* csr_info; const u32* pair_r2;    // csr_info[i] = record info of recs[i]: one coalesced 16-byte load per hit
+	const u32* dstart; const uint4* dinfo;        // distinct read-1 infos per class with multiplicities (window scoring)
 	int rl;
 };
 
@@ -502,15 +535,18 @@ struct MapLds {
 	u32 wt_key[WT_SLOTS];                           // class id + 1
 	u32 wt_last[WT_SLOTS];                          // last offset + 1 with that class
 	u32 scan[MAP_THREADS];
+	u32 inst_total;                                 // weighted mode: read-1 instances behind the distinct hits
 };
 
 // classify every offset o in [0, len-rl) (quick_map3.c:200: the last offset is never looked at), build the
 // class -> last offset table, prefix the class sizes.  Returns the hit count H (uniform).
-__device__ inline u32 map_prepare(MapLds& L, const ReadIndexDev& ix, const char* __restrict__ w, int len) {
+// `weighted`: hits enumerate the DISTINCT read-1 infos of a class (ix.dstart/dinfo) instead of its members
+__device__ inline u32 map_prepare(MapLds& L, const ReadIndexDev& ix, const char* __restrict__ w, int len, bool weighted = false) {
 	const int rl = ix.rl;
 	const int noff = len - rl;
 	const u32 tid = threadIdx.x;
 	for (u32 i = tid; i < WT_SLOTS; i += MAP_THREADS) { L.wt_key[i] = 0; L.wt_last[i] = 0; }
+	if (tid == 0) L.inst_total = 0;
 	__syncthreads();
 	for (int o = tid; o < noff; o += MAP_THREADS) {
 		u128 b = 0;
@@ -534,8 +570,14 @@ __device__ inline u32 map_prepare(MapLds& L, const ReadIndexDev& ix, const char*
 			}
 		}
 		if (cls != NONE32) {
-			cs = ix.start[cls];
-			sz = ix.cnt1[cls];                      // read-1 members come first
+			if (weighted) {
+				cs = ix.dstart[cls];
+				sz = ix.dstart[cls + 1] - cs;
+				atomicAdd(&L.inst_total, ix.cnt1[cls]);
+			} else {
+				cs = ix.start[cls];
+				sz = ix.cnt1[cls];                  // read-1 members come first
+			}
 			// class -> last offset ("read2[id] = m_info": the last writer wins, quick_map3.c:214)
 			u32 slot = (cls * 2654435761u) & (WT_SLOTS - 1);
 			for (;;) {
@@ -587,13 +629,14 @@ __device__ inline u32 map_last_occurrence(const MapLds& L, u32 cls) {
 
 struct Hit {
 	bool pair;          // a mapped pair (quick_map3.c:223-245)
-	u32 pair_id, rec1;
+	u32 pair_id, rec1;  // (weighted mode: pair_id = how many identical read pairs the entry stands for)
 	int which;          // 0: read-2 record A won, 1: B
 	int pos1, pos2, insert;
 	uint8_t rc1, rc2;
 };
 
 // hit h (reference order: offset-major, registration order inside a class) -> mapped pair or not
+template <bool WEIGHTED = false>
 __device__ inline Hit map_eval_hit(const MapLds& L, const ReadIndexDev& ix, int noff, u32 h) {
 	Hit r;
 	r.pair = false;
@@ -604,7 +647,7 @@ __device__ inline Hit map_eval_hit(const MapLds& L, const ReadIndexDev& ix, int 
 	}
 	const int o = lo;
 	const u32 ci = L.cstart[o] + (h - L.hpre[o]);
-	const uint4 info = ix.csr_info[ci];
+	const uint4 info = WEIGHTED ? ix.dinfo[ci] : ix.csr_info[ci];
 	if (!(info.w & RI_R1)) return r;                // read-2 instances only feed the read2 map
 	// read2[id]: among the pair's read-2 records the one written last = largest offset, then latest registration
 	const u32 la = map_last_occurrence(L, info.y), lb = map_last_occurrence(L, info.z);
@@ -619,18 +662,18 @@ __device__ inline Hit map_eval_hit(const MapLds& L, const ReadIndexDev& ix, int 
 	const int insert = (int) (short) ((d < 0 ? -d : d) + ix.rl);
 	if (insert < 50 || insert > 400) return r;      // MIN_INSERT / MAX_INSERT, quick_map3.c:23-24
 	r.pair = true;
-	r.pair_id = info.x; r.rec1 = ix.recs[ci]; r.which = which;
+	r.pair_id = info.x; r.rec1 = WEIGHTED ? 0u : ix.recs[ci]; r.which = which;
 	r.pos1 = pos1; r.pos2 = pos2; r.insert = insert; r.rc1 = rc1; r.rc2 = rc2;
 	return r;
 }
 
 // hits per window/contig: sizes the pair scratch and orders the work largest-first
 __global__ __launch_bounds__(MAP_THREADS) void k_window_hits(ReadIndexDev ix, const char* __restrict__ windows, u32 n, int len,
-                                                             u32* __restrict__ out_hits) {
+                                                             bool weighted, u32* __restrict__ out_hits, u32* __restrict__ out_inst) {
 	__shared__ MapLds L;
 	for (u32 wi = blockIdx.x; wi < n; wi += gridDim.x) {
-		const u32 H = map_prepare(L, ix, windows + (size_t) wi * len, len);
-		if (threadIdx.x == 0) out_hits[wi] = H;
+		const u32 H = map_prepare(L, ix, windows + (size_t) wi * len, len, weighted);
+		if (threadIdx.x == 0) { out_hits[wi] = H; if (out_inst) out_inst[wi] = weighted ? L.inst_total : H; }
 		__syncthreads();
 	}
 }
@@ -652,31 +695,38 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_hits(ReadIndexDev ix, co
 #define COV_WORDS 8192
 #define HIT_CHUNK 65536u         // hits per workgroup of k_window_pairs: the deepest windows are split, the rest pay one preparation
 
-// K8: mapped pairs of a slice of a window's hits, appended (any order) to the window's pair list
+// K8: mapped pairs of a slice of a window's (distinct) hits, appended (any order) to the window's list as
+// (multiplicity << 32 | pos1 << 16 | pos2); pair_np = mapped pairs counted with multiplicity
 __global__ __launch_bounds__(MAP_THREADS) void k_window_pairs(ReadIndexDev ix, const char* __restrict__ windows, int len,
                                                               const uint4* __restrict__ work /* {window, h0, h1, -} */,
-                                                              const u64* __restrict__ pair_off, u32* __restrict__ pair_buf,
-                                                              u32* __restrict__ pair_cnt) {
+                                                              const u64* __restrict__ pair_off, u64* __restrict__ pair_buf,
+                                                              u32* __restrict__ pair_cnt, u32* __restrict__ pair_np) {
 	__shared__ MapLds L;
 	const uint4 wk = work[blockIdx.x];
 	const u32 wi = wk.x;
 	const int noff = len - ix.rl;
-	const u32 H = map_prepare(L, ix, windows + (size_t) wi * len, len);
+	const u32 H = map_prepare(L, ix, windows + (size_t) wi * len, len, true);
 	const u32 h1 = wk.z < H ? wk.z : H;
-	u32* pairs = pair_buf + pair_off[wi];
+	u64* pairs = pair_buf + pair_off[wi];
+	u32 mine = 0;
 	for (u32 h0 = wk.y; h0 < h1; h0 += MAP_THREADS) {
 		const u32 h = h0 + threadIdx.x;
 		Hit r;
 		r.pair = false;
-		if (h < h1) r = map_eval_hit(L, ix, noff, h);
+		if (h < h1) r = map_eval_hit<true>(L, ix, noff, h);
 		const u32 slot = vdjx_wave_inc(&pair_cnt[wi], r.pair);
-		if (r.pair) pairs[slot] = ((u32) r.pos1 << 16) | (u32) r.pos2;
+		if (r.pair) {
+			pairs[slot] = ((u64) r.pair_id << 32) | ((u32) r.pos1 << 16) | (u32) r.pos2;
+			mine += r.pair_id;
+		}
 	}
+	for (int d = 32; d; d >>= 1) mine += __shfl_down(mine, d);
+	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&pair_np[wi], mine);
 }
 
 // K9: coverage verdict of a window from its pair list
 __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, vdjx_cov_params cp, const u32* __restrict__ order,
-                                                              const u64* __restrict__ pair_off, const u32* __restrict__ pair_buf,
+                                                              const u64* __restrict__ pair_off, const u64* __restrict__ pair_buf,
                                                               const u32* __restrict__ pair_cnt, uint8_t* __restrict__ out_valid,
                                                               u64* __restrict__ dbg) {
 	const long long t_begin = dbg ? clock64() : 0;
@@ -694,7 +744,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 	const int stride = npos + 1;
 	const int DB = COV_WORDS / stride;               // deltas per batch (host guarantees >= 1)
 	const u32 wi = order[blockIdx.x];
-	const u32* pairs = pair_buf + pair_off[wi];
+	const u64* pairs = pair_buf + pair_off[wi];      // (multiplicity << 32 | pos1 << 16 | pos2): identical read pairs come once
 	const u32 npairs = pair_cnt[wi];
 	if (fl == 0) { if (tid == 0) out_valid[wi] = 1; return; }
 	// histogram of the start entries' first values: one private copy per wave in `diff` (deep windows put
@@ -708,9 +758,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 	__syncthreads();
 	u32* myh = priv ? hp + wv * (u32) (D + 1) : hf;
 	for (u32 q = tid; q < npairs; q += MAP_THREADS) {
-		const u32 pr = pairs[q];
-		atomicAdd(&myh[pr >> 16], 1u);
-		atomicAdd(&myh[pr & 0xFFFFu], 1u);
+		const u64 pe = pairs[q];
+		const u32 pr = (u32) pe, mult = (u32) (pe >> 32);
+		atomicAdd(&myh[pr >> 16], mult);
+		atomicAdd(&myh[pr & 0xFFFFu], mult);
 	}
 	__syncthreads();
 	if (priv) {
@@ -792,7 +843,9 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 				// the list is roughly sorted by position (hits are enumerated offset-major): replay it in a scattered
 				// order so that every chunk samples the whole window and the early exit can fire
 				const u32 q = (u32) (((u64) q0 * perm_stride) % tot);
-				const u32 pr = pairs[q >> 1];
+				const u64 pe = pairs[q >> 1];
+				const u32 pr = (u32) pe;
+				const int mult = (int) (pe >> 32);
 				const int p1 = (int) (pr >> 16), p2 = (int) (pr & 0xFFFFu);
 				const int f = (q & 1) ? p2 : p1, sx = (q & 1) ? p1 : p2;
 				// deltas of this batch with |f - (sx - delta)| < rl
@@ -806,8 +859,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 					if (lo < e0) lo = e0;
 					if (hi > e1) hi = e1;
 					if (lo < hi) {
-						atomicAdd(&diff[(dl - d0) * stride + (lo - e0)], 1);
-						atomicAdd(&diff[(dl - d0) * stride + (hi - e0)], -1);
+						atomicAdd(&diff[(dl - d0) * stride + (lo - e0)], mult);
+						atomicAdd(&diff[(dl - d0) * stride + (hi - e0)], -mult);
 					}
 				}
 			}
@@ -929,24 +982,29 @@ static int make_index_view(vdjx_ctx* c, ReadIndexDev* ix, int len, const char* w
 	ix->slots = c->d_ri_slots; ix->mask = c->ri_nslots - 1;
 	ix->rep = c->d_ri_rep; ix->start = c->d_ri_start; ix->cnt1 = c->d_ri_cnt1; ix->recs = c->d_ri_recs;
 	ix->csr_info = c->d_rec_info; ix->pair_r2 = c->d_pair_r2;
+	ix->dstart = c->d_ri_dstart; ix->dinfo = c->d_ri_dinfo;
 	ix->rl = p->rl;
 	return VDJX_OK;
 }
 
 // hits per string, exclusive offsets, and the largest-first processing order
-static int plan_windows(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, const char* d_w, size_t n, int len,
-                        std::vector<u64>& off, u32** d_order, u64** d_off) {
+static int plan_windows(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, const char* d_w, size_t n, int len, bool weighted,
+                        std::vector<u64>& off, u32** d_order, u64** d_off, u64* inst_total = nullptr, u64* inst_max = nullptr) {
 	hipStream_t st = c->stream;
-	u32* d_hits;
+	u32 *d_hits, *d_inst;
 	HIP_TRY(db.alloc(&d_hits, n));
+	HIP_TRY(db.alloc(&d_inst, n));
 	{
 		vdjx_prof_scope ps(c, "k_window_hits");
-		hipLaunchKernelGGL(k_window_hits, dim3((u32) std::min<size_t>(n, 4096)), dim3(MAP_THREADS), 0, st, ix, d_w, (u32) n, len, d_hits);
+		hipLaunchKernelGGL(k_window_hits, dim3((u32) std::min<size_t>(n, 4096)), dim3(MAP_THREADS), 0, st, ix, d_w, (u32) n, len, weighted, d_hits, d_inst);
 	}
-	std::vector<u32> hits(n), order(n);
+	std::vector<u32> hits(n), order(n), inst(n);
 	HIP_TRY(hipMemcpyAsync(hits.data(), d_hits, n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(inst.data(), d_inst, n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	if (inst_total) { *inst_total = 0; for (u32 v : inst) *inst_total += v; }
+	if (inst_max) { *inst_max = 0; for (u32 v : inst) *inst_max = std::max<u64>(*inst_max, v); }
 	off.assign(n + 1, 0);
 	for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + hits[i];
 	std::iota(order.begin(), order.end(), 0u);
@@ -974,23 +1032,22 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	hipStream_t st = c->stream;
 	vdjx_work db(c);
 	char* d_w;
-	u32 *d_np, *d_order, *d_pairbuf;
-	u64* d_off;
+	u32 *d_np, *d_order, *d_cnt;
+	u64 *d_off, *d_pairbuf;
 	uint8_t* d_valid;
 	HIP_TRY(db.alloc(&d_w, n * len));
 	HIP_TRY(db.alloc(&d_np, n));
 	HIP_TRY(db.alloc(&d_valid, n));
 	HIP_TRY(hipMemcpyAsync(d_w, windows, n * len, hipMemcpyHostToDevice, st));
 	std::vector<u64> off;
-	rc = plan_windows(c, db, ix, d_w, n, len, off, &d_order, &d_off);
+	u64 inst_total = 0, inst_max = 0;
+	rc = plan_windows(c, db, ix, d_w, n, len, true, off, &d_order, &d_off, &inst_total, &inst_max);
 	if (rc) return rc;
 	HIP_TRY(db.alloc(&d_pairbuf, (size_t) off[n]));
-	c->stats["window_hits"] = off[n];
-	{
-		u64 mx = 0;
-		for (size_t i = 0; i < n; i++) mx = std::max<u64>(mx, off[i + 1] - off[i]);
-		c->stats["window_hits_max"] = mx;
-	}
+	HIP_TRY(db.alloc(&d_cnt, n));
+	c->stats["window_hits"] = inst_total;                 // read-1 instances matched (what the reference enumerates one by one)
+	c->stats["window_hits_max"] = inst_max;
+	c->stats["window_hits_distinct"] = off[n];             // weighted entries actually evaluated
 	// work list: deep windows are cut into slices of HIT_CHUNK hits (largest windows first)
 	std::vector<uint4> work;
 	{
@@ -1010,16 +1067,17 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	HIP_TRY(db.alloc(&d_work, work.size()));
 	HIP_TRY(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(uint4), hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemsetAsync(d_np, 0, n * 4, st));
+	HIP_TRY(hipMemsetAsync(d_cnt, 0, n * 4, st));
 	{
 		vdjx_prof_scope ps(c, "k_window_pairs");
-		hipLaunchKernelGGL(k_window_pairs, dim3((u32) work.size()), dim3(MAP_THREADS), 0, st, ix, d_w, len, d_work, d_off, d_pairbuf, d_np);
+		hipLaunchKernelGGL(k_window_pairs, dim3((u32) work.size()), dim3(MAP_THREADS), 0, st, ix, d_w, len, d_work, d_off, d_pairbuf, d_cnt, d_np);
 	}
 	{
 		vdjx_prof_scope ps(c, "k_window_cover");
 		u64* d_dbg = nullptr;
 		const char* dbgpath = getenv("VDJX_DEBUG_COVER");
 		if (dbgpath) HIP_TRY(db.alloc(&d_dbg, n));
-		hipLaunchKernelGGL(k_window_cover, dim3((u32) n), dim3(MAP_THREADS), 0, st, len, ix.rl, *p, d_order, d_off, d_pairbuf, d_np, d_valid, d_dbg);
+		hipLaunchKernelGGL(k_window_cover, dim3((u32) n), dim3(MAP_THREADS), 0, st, len, ix.rl, *p, d_order, d_off, d_pairbuf, d_cnt, d_valid, d_dbg);
 		if (dbgpath) {
 			HIP_TRY(hipStreamSynchronize(st));
 			std::vector<u64> dbg(n);
@@ -1076,7 +1134,7 @@ extern "C" int vdjx_map_emit(vdjx_ctx* c, const char* contigs, size_t n, int len
 		HIP_TRY(db.alloc(&d_counts, n));
 		HIP_TRY(hipMemcpyAsync(d_c, contigs, n * len, hipMemcpyHostToDevice, st));
 		std::vector<u64> off;
-		rc = plan_windows(c, db, ix, d_c, n, len, off, &d_order, &d_off);
+		rc = plan_windows(c, db, ix, d_c, n, len, false, off, &d_order, &d_off);
 		if (rc) return rc;
 		if (off[n] > c->me_cap) {
 			free_set(c->me_pairs);
