@@ -35,6 +35,7 @@ __device__ u32 g_sub_tuples = 262144u;
 #define K3B_CH 1024u                // candidates per chunk
 #define K3B_A 128u                  // quality-sum rows per round
 #define K3B_KW 25u                  // u32 words per row (2 x u16 sums each), k <= 50
+#define K3B_Q 1536u                 // remembered low-count instances per chunk (more: the quality rounds rescan the bucket)
 #define NONE32 0xFFFFFFFFu
 #define INST_MASK 0x7FFFFFFFu
 
@@ -502,7 +503,8 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 	__shared__ u32 l_cnt[K3B_CH], l_first[K3B_CH], l_ucnt[K3B_CH], l_ufirst[K3B_CH], l_lowid[K3B_CH];
 	__shared__ uint8_t l_multi[K3B_CH], l_qok[K3B_CH];
 	__shared__ u32 acc[K3B_A * K3B_KW];
-	__shared__ u32 s_nlow, s_base;
+	__shared__ u32 s_nlow, s_base, s_nq;
+	__shared__ u32 q_lc[K3B_Q], q_inst[K3B_Q];      // gated instances of the low-count candidates of this chunk
 	const u32 b = blockIdx.x;
 	const u32 nc = bucket_ncand[b];
 	if (nc == 0) return;
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 	const u32 KW = (u32) (k + 1) / 2;
 	for (u32 c0 = 0; c0 < nc; c0 += K3B_CH) {
 		const u32 m = nc - c0 < K3B_CH ? nc - c0 : K3B_CH;
-		if (tid == 0) s_nlow = 0;
+		if (tid == 0) { s_nlow = 0; s_nq = 0; }
 		__syncthreads();
 		for (u32 i = tid; i < m; i += K3B_THREADS) {
 			const u32 cnt = c_cnt[base + c0 + i];
@@ -526,23 +528,38 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 		}
 		__syncthreads();
 		// sweep A: ungated recount + first sight (add_to_graph, A2:280-309) and the distinct-read flag (A2:349-352)
-		for (u32 t = tid; t < nt; t += K3B_THREADS) {
-			u32 lc = ct_lcid[base + t];
-			if (lc < c0 || lc >= c0 + m) continue;
-			lc -= c0;
-			const u32 iw = ct_inst[base + t];
-			const u32 inst = iw & INST_MASK;
-			atomicAdd(&l_ucnt[lc], 1u);
-			atomicMin(&l_ufirst[lc], inst);
-			if ((iw >> 31) && !*(volatile uint8_t*) &l_multi[lc]) {
-				const u32 rec = inst / (u32) P;
-				const u32 frec = l_first[lc] / (u32) P;
-				if (rec != frec) {
-					const ulonglong2 x = ((const ulonglong2*) bases)[rec];
-					const ulonglong2 y = ((const ulonglong2*) bases)[frec];
-					// compare_read (A2:142-144) on the rl-base sequences; an 'N' is coded 0 in `bases`, so the N masks
-					// take part in the comparison
-					if (x.x != y.x || x.y != y.y || nmask[rec] != nmask[frec]) l_multi[lc] = 1;
+		// (four tuples per thread are in flight before any is used: the sweep is latency-bound otherwise)
+		for (u32 t0 = 0; t0 < nt; t0 += 4 * K3B_THREADS) {
+			u32 r_lc[4], r_iw[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const u32 t = t0 + j * K3B_THREADS + tid;
+				r_lc[j] = t < nt ? ct_lcid[base + t] : NONE32;
+				r_iw[j] = t < nt ? ct_inst[base + t] : 0u;
+			}
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				u32 lc = r_lc[j];
+				if (lc < c0 || lc >= c0 + m) continue;         // (NONE32 fails the second test)
+				lc -= c0;
+				const u32 iw = r_iw[j];
+				const u32 inst = iw & INST_MASK;
+				atomicAdd(&l_ucnt[lc], 1u);
+				atomicMin(&l_ufirst[lc], inst);
+				if ((iw >> 31) && l_lowid[lc] != NONE32) {      // its qualities will be needed: remember it (few such instances)
+					const u32 qi = atomicAdd(&s_nq, 1u);
+					if (qi < K3B_Q) { q_lc[qi] = lc; q_inst[qi] = inst; }
+				}
+				if ((iw >> 31) && !*(volatile uint8_t*) &l_multi[lc]) {
+					const u32 rec = inst / (u32) P;
+					const u32 frec = l_first[lc] / (u32) P;
+					if (rec != frec) {
+						const ulonglong2 x = ((const ulonglong2*) bases)[rec];
+						const ulonglong2 y = ((const ulonglong2*) bases)[frec];
+						// compare_read (A2:142-144) on the rl-base sequences; an 'N' is coded 0 in `bases`, so the N masks
+						// take part in the comparison
+						if (x.x != y.x || x.y != y.y || nmask[rec] != nmask[frec]) l_multi[lc] = 1;
+					}
 				}
 			}
 		}
@@ -552,14 +569,20 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 		for (u32 l0 = 0; l0 < nlow; l0 += K3B_A) {
 			for (u32 i = tid; i < K3B_A * K3B_KW; i += K3B_THREADS) acc[i] = 0;
 			__syncthreads();
-			for (u32 t = tid; t < nt; t += K3B_THREADS) {
-				u32 lc = ct_lcid[base + t];
-				if (lc < c0 || lc >= c0 + m) continue;
-				lc -= c0;
-				const u32 iw = ct_inst[base + t];
-				if (!(iw >> 31)) continue;
+			const bool listed = s_nq <= K3B_Q;
+			const u32 nscan = listed ? s_nq : nt;
+			for (u32 t = tid; t < nscan; t += K3B_THREADS) {
+				u32 lc, iw;
+				if (listed) { lc = q_lc[t]; iw = q_inst[t] | 0x80000000u; }
+				else {
+					lc = ct_lcid[base + t];
+					if (lc < c0 || lc >= c0 + m) continue;
+					lc -= c0;
+					iw = ct_inst[base + t];
+					if (!(iw >> 31)) continue;
+				}
 				const u32 lid = l_lowid[lc];
-				if (lid < l0 || lid >= l0 + K3B_A) continue;
+				if (lid == NONE32 || lid < l0 || lid >= l0 + K3B_A) continue;
 				const u32 inst = iw & INST_MASK;
 				const u32 rec = inst / (u32) P;
 				const u32 off = inst - rec * (u32) P;
