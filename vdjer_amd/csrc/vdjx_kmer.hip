@@ -7,11 +7,11 @@
 // recount) is done bucket-locally in LDS.  All of it is integer/byte work bounded by HBM traffic; no
 // MFMA applies.
 //
-//   K2a k_kmer_hist        per-workgroup LDS histogram of bucket sizes over a slice of the pool
-//   K2b k_hist_colscan /   exclusive offsets per (workgroup, bucket)  -> deterministic placement,
-//       k_bucket_scan      no global atomics
+//   K2a k_kmer_hist        per-workgroup LDS histogram of bucket sizes over a slice of the pool, added to the global counts
+//   K2b k_bucket_scan      exclusive bucket starts
 //   K2c k_part_records /   LDS-staged counting sort per round: tuples {key_lo, key_hi, inst|gated} written as
-//       k_part_tuples      coalesced bucket runs (256 coarse buckets, then 128 fine ones inside each)
+//       k_part_tuples      coalesced bucket runs (256 coarse buckets, then 128 fine ones inside each; large pools:
+//                          2^(T-10) coarse, a counting pass, 1024 fine); positions inside a bucket from cursor bumps
 //   K3a k_bucket_aggregate LDS open-addressing table per bucket: gated count + first instance per
 //                          distinct k-mer; keys with count >= max(mf,2) become candidates, their
 //                          tuples are compacted in place (noise singletons die here)
@@ -61,7 +61,7 @@ __device__ inline RecView load_rec(const u64* __restrict__ bases, const u64* __r
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(HIST_THREADS) void k_kmer_hist(const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                             size_t R, int rl, int k, u32 nb_bits, size_t rpb,
-                                                            u32* __restrict__ block_hist) {   // bucket sizes do not depend on the record numbering
+                                                            u32* __restrict__ bucket_cnt) {   // bucket sizes do not depend on the record numbering
 	extern __shared__ u32 hist[];
 	const u32 NB = 1u << nb_bits;
 	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) hist[i] = 0;
@@ -81,20 +81,9 @@ __global__ __launch_bounds__(HIST_THREADS) void k_kmer_hist(const u64* __restric
 		}
 	}
 	__syncthreads();
-	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) block_hist[(size_t) blockIdx.x * NB + i] = hist[i];
-}
-
-// K2b: per bucket, exclusive running sum over workgroups (column scan; coalesced across buckets)
-__global__ void k_hist_colscan(u32* __restrict__ block_hist, u32 nblk, u32 NB, u32* __restrict__ bucket_cnt) {
-	u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-	if (b >= NB) return;
-	u32 run = 0;
-	for (u32 i = 0; i < nblk; i++) {
-		u32 v = block_hist[(size_t) i * NB + b];
-		block_hist[(size_t) i * NB + b] = run;
-		run += v;
-	}
-	bucket_cnt[b] = run;
+	// only bucket totals are needed (positions inside a bucket come from cursor bumps in the partition passes): the
+	// workgroups add their LDS counts to the global ones, a few hundred adds per address spread over 2^15 addresses
+	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) if (hist[i]) atomicAdd(&bucket_cnt[i], hist[i]);
 }
 
 // exclusive scan of bucket_cnt[NB] -> bucket_start[NB+1], one 1024-thread workgroup
@@ -1417,19 +1406,19 @@ int stage_partition_count(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, u32 
 	pp->nblk = (u32) std::min<size_t>(512, (R + 4095) / 4096);
 	if (pp->nblk == 0) pp->nblk = 1;
 	pp->rpb = (R + pp->nblk - 1) / pp->nblk;
-	HIP_TRY(db.alloc(&pp->block_hist, (size_t) pp->nblk * pp->NB));
+	pp->block_hist = nullptr;
 	HIP_TRY(db.alloc(&pp->bucket_cnt, pp->NB));
+	HIP_TRY(hipMemsetAsync(pp->bucket_cnt, 0, (size_t) pp->NB * 4, st));
 	HIP_TRY(db.alloc(&pp->bucket_start, pp->NB + 1));
 	const size_t lds_hist = (size_t) pp->NB * 4;
 	HIP_TRY(hipFuncSetAttribute((const void*) k_kmer_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_hist));
 	{
 		vdjx_prof_scope ps(c, "k_kmer_hist");
 		hipLaunchKernelGGL(k_kmer_hist, dim3(pp->nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, R, pool->rl, k,
-		                   nb_bits, pp->rpb, pp->block_hist);
+		                   nb_bits, pp->rpb, pp->bucket_cnt);
 	}
 	{
 		vdjx_prof_scope ps(c, "k_hist_scan");
-		hipLaunchKernelGGL(k_hist_colscan, dim3((pp->NB + 255) / 256), dim3(256), 0, st, pp->block_hist, pp->nblk, pp->NB, pp->bucket_cnt);
 		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, pp->bucket_cnt, pp->NB, pp->bucket_start);
 	}
 	HIP_TRY(hipMemcpyAsync(N_out, pp->bucket_start + pp->NB, 4, hipMemcpyDeviceToHost, st));
