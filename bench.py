@@ -348,7 +348,9 @@ def main():
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tf):     # PMC pass of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), see profiles/README.md
-            tk = json.load(open(tf)).get("kernels", {})
+            tj = json.load(open(tf))
+            same = tj.get("pairs_per_gpu", 1_000_000) == args.pairs and args.windows == "traversal" and args.k == 35 and world == 1
+            tk = tj.get("kernels", {}) if same else {}        # counters were collected on the default workload only
             for name, v in tk.items():
                 if name.split("<")[0] == dom[0]:
                     traffic = v["hbm_bytes"]

@@ -41,7 +41,7 @@ def main():
     traffic = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of `bench.py --no-cpu --parity-sample 0`; KB per launch "
                        "(median over the workload's launches); hbm_bytes = (2*FETCH + WRITE)*1024 (gfx950: FETCH_SIZE counts half the "
                        "streamed read bytes; calibrated on k_pool_pack: 283 MB read -> FETCH 138,130 KB, 269 MB written -> WRITE 262,507 KB)",
-               "kernels": {}}
+               "pairs_per_gpu": pairs, "kernels": {}}
     for k_ in f:
         fv, wv = sorted(f[k_]), sorted(w.get(k_, [0]))
         fk, wk = fv[len(fv) // 2], wv[len(wv) // 2]
