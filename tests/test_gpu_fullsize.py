@@ -87,3 +87,63 @@ def test_pool_duplication_property_2M_pairs():
         assert g2.freq[j] == min(2 * int(g1.freq[i]), 32765)
         assert g2.gated_count[j] == min(2 * int(g1.gated_count[i]), 32765)
     ctx.close()
+
+
+_KNOB_CASE = r'''
+import sys
+sys.path.insert(0, %r)
+from tests.test_gpu_fullsize import _full_compare
+from vdjer_amd import api, shard, synth
+import numpy as np
+g = _full_compare(120000, 300, int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))
+# the same pool through the sharded phases (their local aggregation uses the same partition code), two ranks as threads
+import threading, torch
+from tests.fake_dist import ThreadDist
+rep = synth.make_repertoire(300, seed=20261002)
+pool = synth.make_reads(rep, 120000, noise_frac=0.3, seed=20261002 + 7919)
+vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+half = pool.primary.shape[0] // 2
+dist, out, errs = ThreadDist(2), [None, None], []
+def work(r):
+    try:
+        dist.set_rank(r)
+        c = api.Context(0)
+        c.anchor_sets_load(vc, jc)
+        pri = pool.primary[:half] if r == 0 else np.concatenate([pool.primary[half:], pool.secondary])
+        if r == 0:
+            pad = np.tile(np.frombuffer(("0" + "N" * 50 + "I" * 50).encode(), np.uint8), (pool.n_records - 2 * half, 1))
+            pri = np.concatenate([pri, pad])            # equal strides: the union scan order stays the single-pool order
+        p = c.pool_load(pri, np.zeros((0, 101), np.uint8), 50)
+        out[r] = shard.ShardedHotPath(c, dist, torch.device("cuda", 0)).kmer_build(p, int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))
+        p.free(); c.close()
+    except Exception as e:
+        errs.append(e); dist.barrier.abort()
+th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+[t.start() for t in th]; [t.join() for t in th]
+assert not errs, errs
+for s in out:
+    assert s.n == g.n and s.pre_nodes == g.pre_nodes
+    np.testing.assert_array_equal(s.freq, g.freq); np.testing.assert_array_equal(s.gated_count, g.gated_count)
+    np.testing.assert_array_equal(s.to_ids, g.to_ids); np.testing.assert_array_equal(s.from_ids, g.from_ids)
+    np.testing.assert_array_equal(s.kmers, g.kmers)
+print("KNOB_CASE_OK", g.n, g.pre_nodes)
+'''
+
+
+@pytest.mark.parametrize("k,mf,mq,env", [
+    (35, 3, 90, {"VDJX_BUCKET_TUPLES": "16", "VDJX_REFINE_TUPLES": "16"}),                          # 2^20 buckets: counting pass + 1024-way pass 2
+    (25, 2, 60, {"VDJX_BUCKET_TUPLES": "64", "VDJX_REFINE_TUPLES": "200", "VDJX_SUB_TUPLES": "64"}),    # 2^17 buckets, long buckets split up front
+    (35, 3, 90, {"VDJX_BUCKET_TUPLES": "100000", "VDJX_SUB_TUPLES": "1000000000"}),                  # few huge buckets: table overflow -> sub-passes
+])
+def test_large_pool_code_paths_on_a_small_pool(k, mf, mq, env):
+    """The paths 10 M-pair pools take (more than 2^15 buckets, long-bucket handling) forced on 120 k pairs through the tuning
+    knobs, in a fresh process (the knobs are read once): full comparison with the oracle, single GPU and two sharded ranks."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _KNOB_CASE % root, str(k), str(mf), str(mq)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=1200)
+    assert r.returncode == 0 and "KNOB_CASE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
