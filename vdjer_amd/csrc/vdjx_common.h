@@ -108,6 +108,8 @@ struct vdjx_ctx {
 	void* me_pairs = nullptr;         // vdjx_pair[me_cap], per-contig regions at me_hoff
 	size_t me_cap = 0;
 	std::vector<u64> me_hoff, me_cnt;
+	std::vector<uint4> me_work;       // slices of the mapping: {contig, first hit, end hit, -}
+	std::vector<u32> me_scnt;         // pairs found per slice
 	u32 n_pairs = 0, n_classes = 0;
 	std::map<std::string, uint64_t> stats;
 };

@@ -913,63 +913,62 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 }
 
 // ----------------------------------------------------------------------------------------------
-// K10: mapped pairs of a contig in the reference's order, written to a per-contig region of `pairs`
+// K10: mapped pairs of a contig in the reference's order.  A contig's hits are cut into slices (one workgroup each): a slice
+// writes its pairs, in hit order, at the start of its own region (region offset = hit offset: pairs <= hits) and reports how
+// many; the gather below lays the slices end to end, which is the reference's order (offset-major, registration order inside
+// a class).  One workgroup per contig left half the GPU idle and walked ~20 k hits sequentially.
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MAP_THREADS) void k_map_emit(ReadIndexDev ix, const char* __restrict__ contigs, u32 n, int len,
-                                                          const u32* __restrict__ order, const u64* __restrict__ region_off,
-                                                          vdjx_pair* __restrict__ pairs, u64* __restrict__ counts) {
+#define MAP_SLICE 4096u
+__global__ __launch_bounds__(MAP_THREADS) void k_map_emit(ReadIndexDev ix, const char* __restrict__ contigs, int len,
+                                                          const uint4* __restrict__ work, const u64* __restrict__ region_off,
+                                                          vdjx_pair* __restrict__ pairs, u32* __restrict__ slice_cnt) {
 	__shared__ MapLds L;
 	__shared__ u32 s_base;
 	const u32 tid = threadIdx.x;
 	const int noff = len - ix.rl;
-	for (u32 bi = blockIdx.x; bi < n; bi += gridDim.x) {
-		const u32 ci = order[bi];
-		const char* w = contigs + (size_t) ci * len;
-		vdjx_pair* out = pairs + region_off[ci];
-		const u32 H = map_prepare(L, ix, w, len);
-		if (tid == 0) s_base = 0;
+	const uint4 wk = work[blockIdx.x];
+	const u32 ci = wk.x;
+	vdjx_pair* out = pairs + region_off[ci] + wk.y;
+	const u32 H = map_prepare(L, ix, contigs + (size_t) ci * len, len);
+	const u32 h1 = wk.z < H ? wk.z : H;
+	if (tid == 0) s_base = 0;
+	__syncthreads();
+	for (u32 h0 = wk.y; h0 < h1; h0 += MAP_THREADS) {
+		const u32 h = h0 + tid;
+		Hit r;
+		r.pair = false;
+		if (h < h1) r = map_eval_hit(L, ix, noff, h);
+		// ordered compaction: inclusive scan of the flags (wave ballots + one LDS word per wave)
+		const u64 m = __ballot(r.pair);
+		const u32 lane = tid & 63, wv = tid >> 6;
+		const u32 before = __popcll(m & ((1ull << lane) - 1ull));
+		if (lane == 0) L.scan[wv] = (u32) __popcll(m);
 		__syncthreads();
-		for (u32 h0 = 0; h0 < H; h0 += MAP_THREADS) {
-			const u32 h = h0 + tid;
-			Hit r;
-			r.pair = false;
-			if (h < H) r = map_eval_hit(L, ix, noff, h);
-			// ordered compaction: inclusive scan of the flags (wave ballots + one LDS word per wave)
-			const u64 m = __ballot(r.pair);
-			const u32 lane = tid & 63, wv = tid >> 6;
-			const u32 before = __popcll(m & ((1ull << lane) - 1ull));
-			if (lane == 0) L.scan[wv] = (u32) __popcll(m);
-			__syncthreads();
-			u32 wbase = 0, total = 0;
-			for (u32 i = 0; i < MAP_THREADS / 64; i++) {
-				const u32 v = L.scan[i];
-				if (i < wv) wbase += v;
-				total += v;
-			}
-			const u32 base = s_base;
-			if (r.pair) {
-				vdjx_pair* o = out + base + wbase + before;
-				o->pair_id = r.pair_id; o->rec1 = r.rec1; o->rec2 = ix.pair_r2[2 * (size_t) r.pair_id + r.which];
-				o->pos1 = (int16_t) r.pos1; o->pos2 = (int16_t) r.pos2; o->insert = (int16_t) r.insert;
-				o->rc1 = r.rc1; o->rc2 = r.rc2;
-			}
-			__syncthreads();
-			if (tid == 0) s_base = base + total;
-			__syncthreads();
+		u32 wbase = 0, total = 0;
+		for (u32 i = 0; i < MAP_THREADS / 64; i++) {
+			const u32 v = L.scan[i];
+			if (i < wv) wbase += v;
+			total += v;
 		}
-		if (tid == 0) counts[ci] = s_base;
+		const u32 base = s_base;
+		if (r.pair) {
+			vdjx_pair* o = out + base + wbase + before;
+			o->pair_id = r.pair_id; o->rec1 = r.rec1; o->rec2 = ix.pair_r2[2 * (size_t) r.pair_id + r.which];
+			o->pos1 = (int16_t) r.pos1; o->pos2 = (int16_t) r.pos2; o->insert = (int16_t) r.insert;
+			o->rc1 = r.rc1; o->rc2 = r.rc2;
+		}
+		__syncthreads();
+		if (tid == 0) s_base = base + total;
 		__syncthreads();
 	}
+	if (tid == 0) slice_cnt[blockIdx.x] = s_base;
 }
 
-// gather the per-contig regions into the dense caller layout
-__global__ void k_gather_pairs(const vdjx_pair* __restrict__ src, const u64* __restrict__ region_off, const u64* __restrict__ dst_off,
-                               u32 n, vdjx_pair* __restrict__ dst) {
-	const u32 ci = blockIdx.x;
-	if (ci >= n) return;
-	const u64 cnt = dst_off[ci + 1] - dst_off[ci];
-	const uint32_t* s = (const uint32_t*) (src + region_off[ci]);
-	uint32_t* d = (uint32_t*) (dst + dst_off[ci]);
+// lay the slices end to end in the caller's dense layout: move[i] = {source element, destination element, count} (u64 x 3)
+__global__ void k_gather_pairs(const vdjx_pair* __restrict__ src, const u64* __restrict__ move, vdjx_pair* __restrict__ dst) {
+	const u64 so = move[3 * (size_t) blockIdx.x], dof = move[3 * (size_t) blockIdx.x + 1], cnt = move[3 * (size_t) blockIdx.x + 2];
+	const uint32_t* s = (const uint32_t*) (src + so);
+	uint32_t* d = (uint32_t*) (dst + dof);
 	for (u64 i = threadIdx.x; i < cnt * (sizeof(vdjx_pair) / 4); i += blockDim.x) d[i] = s[i];
 }
 
@@ -1142,15 +1141,30 @@ extern "C" int vdjx_map_emit(vdjx_ctx* c, const char* contigs, size_t n, int len
 			HIP_TRY(hipMalloc(&c->me_pairs, (size_t) off[n] * sizeof(vdjx_pair)));
 			c->me_cap = (size_t) off[n];
 		}
-		{
-			vdjx_prof_scope ps(c, "k_map_emit");
-			hipLaunchKernelGGL(k_map_emit, dim3((u32) n), dim3(MAP_THREADS), 0, st, ix, d_c, (u32) n, len, d_order, d_off,
-			                   (vdjx_pair*) c->me_pairs, d_counts);
+		// slices of MAP_SLICE hits, contig after contig
+		c->me_work.clear();
+		for (size_t ci = 0; ci < n; ci++) {
+			const u32 H = (u32) (off[ci + 1] - off[ci]);
+			for (u32 h0 = 0; h0 < H; h0 += MAP_SLICE) c->me_work.push_back(make_uint4((u32) ci, h0, std::min(H, h0 + MAP_SLICE), 0));
 		}
-		c->me_cnt.resize(n);
-		HIP_TRY(hipMemcpyAsync(c->me_cnt.data(), d_counts, n * 8, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
-		HIP_TRY(hipGetLastError());
+		const size_t nsl = c->me_work.size();
+		c->me_scnt.assign(nsl, 0);
+		c->me_cnt.assign(n, 0);
+		if (nsl) {
+			uint4* d_work;
+			u32* d_scnt;
+			HIP_TRY(db.alloc(&d_work, nsl));
+			HIP_TRY(db.alloc(&d_scnt, nsl));
+			HIP_TRY(hipMemcpyAsync(d_work, c->me_work.data(), nsl * sizeof(uint4), hipMemcpyHostToDevice, st));
+			{
+				vdjx_prof_scope ps(c, "k_map_emit");
+				hipLaunchKernelGGL(k_map_emit, dim3((u32) nsl), dim3(MAP_THREADS), 0, st, ix, d_c, len, d_work, d_off, (vdjx_pair*) c->me_pairs, d_scnt);
+			}
+			HIP_TRY(hipMemcpyAsync(c->me_scnt.data(), d_scnt, nsl * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			HIP_TRY(hipGetLastError());
+			for (size_t i = 0; i < nsl; i++) c->me_cnt[c->me_work[i].x] += c->me_scnt[i];
+		}
 		c->me_hoff = off;
 		c->me_key = key;
 		c->stats["map_hits"] = off[n];
@@ -1161,15 +1175,25 @@ extern "C" int vdjx_map_emit(vdjx_ctx* c, const char* contigs, size_t n, int len
 	const u64 total = offsets[n];
 	if (total) {
 		vdjx_pair* d_dense;
-		u64 *d_roff, *d_doff;
-		HIP_TRY(db.alloc(&d_dense, (size_t) total));
-		HIP_TRY(db.alloc(&d_roff, n + 1));
-		HIP_TRY(db.alloc(&d_doff, n + 1));
-		HIP_TRY(hipMemcpyAsync(d_roff, c->me_hoff.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
-		HIP_TRY(hipMemcpyAsync(d_doff, offsets, (n + 1) * 8, hipMemcpyHostToDevice, st));
+		u64* d_move;
+		const size_t nsl = c->me_work.size();
+		std::vector<u64> move(3 * nsl + 3);
 		{
+			u64 at = 0;
+			for (size_t i = 0; i < nsl; i++) {
+				const uint4 wk = c->me_work[i];
+				move[3 * i] = c->me_hoff[wk.x] + wk.y;
+				move[3 * i + 1] = at;
+				move[3 * i + 2] = c->me_scnt[i];
+				at += c->me_scnt[i];
+			}
+		}
+		HIP_TRY(db.alloc(&d_dense, (size_t) total));
+		HIP_TRY(db.alloc(&d_move, move.size()));
+		HIP_TRY(hipMemcpyAsync(d_move, move.data(), move.size() * 8, hipMemcpyHostToDevice, st));
+		if (nsl) {
 			vdjx_prof_scope ps(c, "k_gather_pairs");
-			hipLaunchKernelGGL(k_gather_pairs, dim3((u32) n), dim3(256), 0, st, (const vdjx_pair*) c->me_pairs, d_roff, d_doff, (u32) n, d_dense);
+			hipLaunchKernelGGL(k_gather_pairs, dim3((u32) nsl), dim3(256), 0, st, (const vdjx_pair*) c->me_pairs, d_move, d_dense);
 		}
 		HIP_TRY(hipMemcpyAsync(pairs, d_dense, (size_t) total * sizeof(vdjx_pair), hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
