@@ -253,19 +253,22 @@ def main():
         p = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
         t = lap("pool_pack", t)
         if engine is None:
-            g = ctx.kmer_build(p, args.k, args.mf, args.mq, keep_device=True)
+            g = ctx.kmer_build(p, args.k, args.mf, args.mq, async_export=True)
         else:
-            g = engine.kmer_build(p, args.k, args.mf, args.mq, keep_device=True)
+            g = engine.kmer_build(p, args.k, args.mf, args.mq, async_export=True)
         t = lap("kmer_build", t)
-        # every root of the graph (nodes without predecessor), scored where the graph lives; rank r takes roots r, r+world, ...
+        # every root of the graph (nodes without predecessor), scored where the graph lives while its copy for the host traversal
+        # is still crossing PCIe; rank r takes roots r, r+world, ...
         root_ids, ok = ctx.root_score_graph(g, args.mrs, rank, world)
-        g.free()
         t = lap("root_score", t)
         valid, npairs = ctx.window_score(my_wins_packed, args.ins)
         t = lap("window_score", t)
         contigs = my_contigs if my_contigs is not None else [w[51:411] for w, v in zip(my_wins, valid) if v]
         offs, pairs = ctx.map_emit(my_contigs_packed if my_contigs_packed is not None else contigs)
         t = lap("map_emit", t)
+        g.wait()                     # the graph arrays are on the host
+        g.free()
+        t = lap("graph_copy_wait", t)
         if world > 1:      # every rank learns every verdict (a few KB)
             ok = np.concatenate(gather_bytes(ok))
             valid = np.concatenate(gather_bytes(valid))

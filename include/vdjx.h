@@ -85,6 +85,12 @@ size_t vdjx_graph_pre_nodes(const vdjx_graph* g);
 int vdjx_graph_export(const vdjx_graph* g, uint64_t* first_inst, uint32_t* gated_count, uint32_t* freq,
                       uint8_t* has_v, uint8_t* has_j, uint8_t* to_deg, uint32_t* to_ids,
                       uint8_t* from_deg, uint32_t* from_ids, char* kmers);
+/* the same copies started on a second stream: they run beside whatever is done next with the context (e.g. vdjx_root_score_graph
+ * on the device-resident graph); the arrays are valid after vdjx_graph_export_end.  Pinned arrays (vdjx_host_alloc) make it a DMA. */
+int vdjx_graph_export_begin(const vdjx_graph* g, uint64_t* first_inst, uint32_t* gated_count, uint32_t* freq,
+                            uint8_t* has_v, uint8_t* has_j, uint8_t* to_deg, uint32_t* to_ids,
+                            uint8_t* from_deg, uint32_t* from_ids, char* kmers);
+int vdjx_graph_export_end(const vdjx_graph* g);
 void vdjx_graph_free(vdjx_graph* g);
 
 /* ---- f-3: the v_index / j_index generator -------------------------------------------------------

@@ -262,6 +262,32 @@ def test_anchor_sets_from_anchors_equal_the_loaded_index(am):
         b.close()
 
 
+def test_async_graph_export():
+    """vdjx_graph_export_begin/_end: same bytes as the blocking export, with work on the context in between"""
+    from vdjer_amd import api
+    c = G.Case("noisy")
+    cx = api.Context(0, pinned_results=True)
+    try:
+        cx.anchor_sets_load(c.v_codes, c.j_codes)
+        cx.vregion_load([c.v_region], 15)
+        p = cx.pool_load(c.pool.primary, c.pool.secondary, c.pool.rl)
+        ref = cx.kmer_build(p, 35, 3, 90)
+        want = [np.array(x) for x in (ref.first_inst, ref.gated_count, ref.freq, ref.has_v, ref.has_j, ref.to_deg, ref.to_ids, ref.from_deg,
+                                      ref.from_ids, ref.kmers)]
+        for _ in range(3):
+            g = cx.kmer_build(p, 35, 3, 90, async_export=True)
+            ids, ok = cx.root_score_graph(g, 30)             # device work while the copy is in flight
+            g.wait()
+            got = (g.first_inst, g.gated_count, g.freq, g.has_v, g.has_j, g.to_deg, g.to_ids, g.from_deg, g.from_ids, g.kmers)
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b)
+            assert ids.shape[0] == g.n_roots == int((ref.from_deg == 0).sum())
+            g.free()
+        p.free()
+    finally:
+        cx.close()
+
+
 def test_anchor_probe(ctx):
     from vdjer_amd import synth
     c = G.Case("noisy")

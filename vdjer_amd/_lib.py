@@ -15,7 +15,7 @@ SYMBOLS = [
     "vdjx_last_error", "vdjx_version", "vdjx_init", "vdjx_shutdown", "vdjx_sync",
     "vdjx_pool_load", "vdjx_pool_load_device", "vdjx_pool_records", "vdjx_pool_free",
     "vdjx_anchor_sets_load", "vdjx_anchor_probe", "vdjx_index_generate", "vdjx_anchor_sets_from_anchors",
-    "vdjx_kmer_build", "vdjx_graph_nodes", "vdjx_graph_pre_nodes", "vdjx_graph_export", "vdjx_graph_free",
+    "vdjx_kmer_build", "vdjx_graph_nodes", "vdjx_graph_pre_nodes", "vdjx_graph_export", "vdjx_graph_export_begin", "vdjx_graph_export_end", "vdjx_graph_free",
     "vdjx_vregion_load", "vdjx_root_score", "vdjx_graph_roots", "vdjx_root_part", "vdjx_root_score_graph",
     "vdjx_read_index_build", "vdjx_window_score", "vdjx_map_emit",
     "vdjx_host_alloc", "vdjx_host_free",
@@ -82,6 +82,8 @@ def lib():
     L.vdjx_graph_pre_nodes.argtypes = [vp]
     L.vdjx_graph_pre_nodes.restype = sz
     L.vdjx_graph_export.argtypes = [vp] + [vp] * 10
+    L.vdjx_graph_export_begin.argtypes = [vp] + [vp] * 10
+    L.vdjx_graph_export_end.argtypes = [vp]
     L.vdjx_graph_free.argtypes = [vp]
     L.vdjx_graph_free.restype = None
     L.vdjx_vregion_load.argtypes = [vp, C.POINTER(C.c_char_p), sz, i32]

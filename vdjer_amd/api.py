@@ -53,8 +53,15 @@ class Graph:
     def kmer(self, i: int) -> str:
         return self.kmers[i].tobytes().decode()
 
+    def wait(self):
+        """after kmer_build(..., async_export=True): the host arrays are valid once this returns"""
+        if self.handle is not None and getattr(self, "_pending", False):
+            check(_lib.lib().vdjx_graph_export_end(self.handle), "vdjx_graph_export_end")
+            self._pending = False
+
     def free(self):
         if self.handle is not None:
+            self.wait()
             _lib.lib().vdjx_graph_free(self.handle)
             self.handle = None
 
@@ -188,7 +195,10 @@ class Context:
         return ov, oj
 
     # ---- a-1..a-3
-    def kmer_build(self, pool: Pool, k: int = 35, mf: int = 3, mq: int = 90, export: bool = True, keep_device: bool = False):
+    def kmer_build(self, pool: Pool, k: int = 35, mf: int = 3, mq: int = 90, export: bool = True, keep_device: bool = False,
+                   async_export: bool = False):
+        """async_export (implies keep_device): the copy of the graph into the host arrays runs on a second stream beside whatever
+        is done next with the context; call Graph.wait() before reading the arrays"""
         g = C.c_void_p()
         check(self.L.vdjx_kmer_build(self.h, pool.h, k, mf, mq, C.byref(g)), "vdjx_kmer_build")
         if not export:
@@ -196,9 +206,9 @@ class Context:
                 return int(self.L.vdjx_graph_nodes(g)), int(self.L.vdjx_graph_pre_nodes(g))
             finally:
                 self.L.vdjx_graph_free(g)
-        return self._export_graph(g, k, keep_device)
+        return self._export_graph(g, k, keep_device or async_export, async_export)
 
-    def _export_graph(self, g, k: int, keep_device: bool = False) -> Graph:
+    def _export_graph(self, g, k: int, keep_device: bool = False, async_export: bool = False) -> Graph:
         """copy a finished graph into host arrays; the handle is released unless keep_device (then Graph.free() does it)"""
         keep = False
         try:
@@ -207,11 +217,12 @@ class Context:
                 ((n,), np.uint64), ((n,), np.uint32), ((n,), np.uint32), ((n,), np.uint8), ((n,), np.uint8), ((n,), np.uint8),
                 ((n, 4), np.uint32), ((n,), np.uint8), ((n, 4), np.uint32), ((n, k), np.uint8)]),
                 n_roots=int(self.L.vdjx_graph_roots(g)))
-            check(self.L.vdjx_graph_export(g, _p(out.first_inst), _p(out.gated_count), _p(out.freq), _p(out.has_v),
-                                           _p(out.has_j), _p(out.to_deg), _p(out.to_ids), _p(out.from_deg),
-                                           _p(out.from_ids), _p(out.kmers)), "vdjx_graph_export")
+            fn = self.L.vdjx_graph_export_begin if async_export else self.L.vdjx_graph_export
+            check(fn(g, _p(out.first_inst), _p(out.gated_count), _p(out.freq), _p(out.has_v), _p(out.has_j), _p(out.to_deg),
+                     _p(out.to_ids), _p(out.from_deg), _p(out.from_ids), _p(out.kmers)), "vdjx_graph_export")
             if keep_device:
                 out.handle, out.ctx, keep = g, self, True
+                out._pending = async_export
             return out
         finally:
             if not keep:

@@ -71,6 +71,7 @@ struct vdjx_ctx {
 	vdjx_arena shard_arena;            // lives across the phases of one sharded build
 	vdjx_shard* live_shard = nullptr;
 	hipStream_t stream = nullptr;
+	hipStream_t copy_stream = nullptr;   // result copies that may run beside the next kernels (vdjx_graph_export_begin)
 	bool profiling = false;
 	std::vector<std::string> prof_names;                 // insertion order
 	std::map<std::string, vdjx_prof_entry> prof;

@@ -43,6 +43,7 @@ extern "C" int vdjx_init(int device, vdjx_ctx** out) {
 	vdjx_ctx* c = new vdjx_ctx();
 	c->device = device;
 	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
 	if (e != hipSuccess) { delete c; vdjx_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return VDJX_EHIP; }
 	{
 		std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -108,6 +109,8 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 		g_ctx_live.erase(c);
 	}
 	for (auto& p : c->prof_pending) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
+	(void) hipStreamSynchronize(c->copy_stream);
+	(void) hipStreamDestroy(c->copy_stream);
 	(void) hipStreamDestroy(c->stream);
 	delete c;
 }

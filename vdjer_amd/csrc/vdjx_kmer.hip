@@ -2172,15 +2172,9 @@ extern "C" size_t vdjx_graph_nodes(const vdjx_graph* g) { return g ? g->n : 0; }
 extern "C" size_t vdjx_graph_pre_nodes(const vdjx_graph* g) { return g ? g->pre_nodes : 0; }
 extern "C" size_t vdjx_graph_roots(const vdjx_graph* g) { return g ? g->n_roots : 0; }
 
-extern "C" int vdjx_graph_export(const vdjx_graph* g, uint64_t* first_inst, uint32_t* gated_count, uint32_t* freq,
-                                 uint8_t* has_v, uint8_t* has_j, uint8_t* to_deg, uint32_t* to_ids,
-                                 uint8_t* from_deg, uint32_t* from_ids, char* kmers) {
-	if (!g) { vdjx_set_error("vdjx_graph_export: NULL graph"); return VDJX_EINVAL; }
+static int graph_export_on(const vdjx_graph* g, hipStream_t st, uint64_t* first_inst, uint32_t* gated_count, uint32_t* freq, uint8_t* has_v,
+                           uint8_t* has_j, uint8_t* to_deg, uint32_t* to_ids, uint8_t* from_deg, uint32_t* from_ids, char* kmers) {
 	const size_t n = g->n;
-	if (n == 0) return VDJX_OK;
-	if (!g->d_block || !vdjx_ctx_alive(g->ctx)) { vdjx_set_error("vdjx_graph_export: the graph's context is gone"); return VDJX_ESTATE; }
-	HIP_TRY(hipSetDevice(g->device));
-	hipStream_t st = g->ctx->stream;
 	// straight into the caller's arrays: DMA speed when they are pinned (vdjx_host_alloc), staged by the runtime otherwise
 	if (first_inst) HIP_TRY(hipMemcpyAsync(first_inst, g->d_first_inst, n * 8, hipMemcpyDeviceToHost, st));
 	if (gated_count) HIP_TRY(hipMemcpyAsync(gated_count, g->d_gcnt, n * 4, hipMemcpyDeviceToHost, st));
@@ -2192,7 +2186,40 @@ extern "C" int vdjx_graph_export(const vdjx_graph* g, uint64_t* first_inst, uint
 	if (to_ids) HIP_TRY(hipMemcpyAsync(to_ids, g->d_to_ids, n * 16, hipMemcpyDeviceToHost, st));
 	if (from_ids) HIP_TRY(hipMemcpyAsync(from_ids, g->d_from_ids, n * 16, hipMemcpyDeviceToHost, st));
 	if (kmers) HIP_TRY(hipMemcpyAsync(kmers, g->d_kmers, n * (size_t) g->k, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
+	return VDJX_OK;
+}
+
+extern "C" int vdjx_graph_export(const vdjx_graph* g, uint64_t* first_inst, uint32_t* gated_count, uint32_t* freq,
+                                 uint8_t* has_v, uint8_t* has_j, uint8_t* to_deg, uint32_t* to_ids,
+                                 uint8_t* from_deg, uint32_t* from_ids, char* kmers) {
+	if (!g) { vdjx_set_error("vdjx_graph_export: NULL graph"); return VDJX_EINVAL; }
+	if (g->n == 0) return VDJX_OK;
+	if (!g->d_block || !vdjx_ctx_alive(g->ctx)) { vdjx_set_error("vdjx_graph_export: the graph's context is gone"); return VDJX_ESTATE; }
+	HIP_TRY(hipSetDevice(g->device));
+	int rc = graph_export_on(g, g->ctx->stream, first_inst, gated_count, freq, has_v, has_j, to_deg, to_ids, from_deg, from_ids, kmers);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+	return VDJX_OK;
+}
+
+// the same copies on the context's copy stream: they run beside whatever the caller does next with the context (the root
+// scorer works on the device-resident graph while its host copy is still in flight); vdjx_graph_export_end waits for them
+extern "C" int vdjx_graph_export_begin(const vdjx_graph* g, uint64_t* first_inst, uint32_t* gated_count, uint32_t* freq,
+                                       uint8_t* has_v, uint8_t* has_j, uint8_t* to_deg, uint32_t* to_ids,
+                                       uint8_t* from_deg, uint32_t* from_ids, char* kmers) {
+	if (!g) { vdjx_set_error("vdjx_graph_export_begin: NULL graph"); return VDJX_EINVAL; }
+	if (g->n == 0) return VDJX_OK;
+	if (!g->d_block || !vdjx_ctx_alive(g->ctx)) { vdjx_set_error("vdjx_graph_export_begin: the graph's context is gone"); return VDJX_ESTATE; }
+	HIP_TRY(hipSetDevice(g->device));
+	// the build that made `g` has synchronised the main stream before it returned: the arrays are final
+	return graph_export_on(g, g->ctx->copy_stream, first_inst, gated_count, freq, has_v, has_j, to_deg, to_ids, from_deg, from_ids, kmers);
+}
+
+extern "C" int vdjx_graph_export_end(const vdjx_graph* g) {
+	if (!g) { vdjx_set_error("vdjx_graph_export_end: NULL graph"); return VDJX_EINVAL; }
+	if (!vdjx_ctx_alive(g->ctx)) { vdjx_set_error("vdjx_graph_export_end: the graph's context is gone"); return VDJX_ESTATE; }
+	HIP_TRY(hipSetDevice(g->device));
+	HIP_TRY(hipStreamSynchronize(g->ctx->copy_stream));
 	return VDJX_OK;
 }
 
@@ -2200,7 +2227,10 @@ extern "C" void vdjx_graph_free(vdjx_graph* g) {
 	if (!g) return;
 	if (g->d_block) {
 		(void) hipSetDevice(g->device);
-		if (vdjx_ctx_alive(g->ctx)) g->ctx->blocks.release(g->d_block, g->block_cap);
+		if (vdjx_ctx_alive(g->ctx)) {
+			(void) hipStreamSynchronize(g->ctx->copy_stream);      // an export that was begun and never ended
+			g->ctx->blocks.release(g->d_block, g->block_cap);
+		}
 		else (void) hipFree(g->d_block);
 	}
 	delete g;

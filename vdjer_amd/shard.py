@@ -132,12 +132,12 @@ class HipShardEngine:
                                       self._dp(mins[8 * n:])), "vdjx_shard_edges")
         return mins, ucnt
 
-    def finish(self, mins, ucnt, pre_total, keep_device: bool = False):
+    def finish(self, mins, ucnt, pre_total, keep_device: bool = False, async_export: bool = False):
         g = C.c_void_p()
         n = ucnt.shape[0]
         check(self.L.vdjx_shard_finish(self.h, self._dp(mins[:4 * n]), self._dp(mins[4 * n:8 * n]), self._dp(ucnt), self._dp(mins[8 * n:]),
                                        pre_total, C.byref(g)), "vdjx_shard_finish")
-        return self.ctx._export_graph(g, self.k, keep_device)
+        return self.ctx._export_graph(g, self.k, keep_device or async_export, async_export)
 
     def end(self):
         if self.h:
@@ -239,7 +239,7 @@ class ShardedHotPath:
     def bytes_exchanged(self):
         return self.comm.bytes
 
-    def kmer_build(self, pool, k: int = 35, mf: int = 3, mq: int = 90, keep_device: bool = False):
+    def kmer_build(self, pool, k: int = 35, mf: int = 3, mq: int = 90, keep_device: bool = False, async_export: bool = False):
         t, dist, eng, cm = self.torch, self.dist, self.engine, self.comm
         G, r = self.world, self.rank
         if self.stride is None:
@@ -308,6 +308,8 @@ class ShardedHotPath:
             cm.sync()
             lap("reduce_edges")
             # 5. node numbering + list order
+            if async_export:
+                return eng.finish(mins, ucnt, pre_total, async_export=True)
             return eng.finish(mins, ucnt, pre_total, keep_device=True) if keep_device else eng.finish(mins, ucnt, pre_total)
         finally:
             eng.end()
