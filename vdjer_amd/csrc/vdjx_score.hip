@@ -175,8 +175,10 @@ __global__ __launch_bounds__(DP_THREADS) void k_root_dp(const char* __restrict__
                                                         u32 n_groups, u32 stop, u32 total, const u32* __restrict__ seed_pos,
                                                         const char* __restrict__ vtext, const u32* __restrict__ line_off, u32 n_lines,
                                                         uint8_t* __restrict__ out) {
-	__shared__ signed char col[(VDJX_MAX_KMER + 1) * DP_THREADS];
-	__shared__ char qs[VDJX_MAX_KMER * DP_THREADS];
+	// The DP column and the root live in REGISTERS (the row loop is fully unrolled to the longest k, guarded by the uniform
+	// r <= k): a cell is a handful of integer ops instead of a round trip through LDS per cell (the kernel is a dependent chain
+	// per thread and far too small to hide LDS latency by occupancy).  Only the reference segment sits in LDS, one read per column.
+	__shared__ char refc[2 * VDJX_MAX_KMER * DP_THREADS];
 	const u32 tid = threadIdx.x;
 	const u32 w = blockIdx.x * DP_THREADS + tid;
 	if (w >= total) return;
@@ -190,28 +192,37 @@ __global__ __launch_bounds__(DP_THREADS) void k_root_dp(const char* __restrict__
 	const u32 root = g / stop;
 	if (out[root]) return;
 	const int pos = (int) seed_pos[hit_lo[g] + (w - hit_pre[g])];
-	for (int r = 0; r < k; r++) qs[r * DP_THREADS + tid] = kmers[(size_t) root * k + r];
+	char q[VDJX_MAX_KMER];
+#pragma unroll
+	for (int r = 0; r < VDJX_MAX_KMER; r++) q[r] = r < k ? kmers[(size_t) root * k + r] : (char) 0;
 	for (u32 li = 0; li < n_lines; li++) {
 		const int len = (int) (line_off[li + 1] - line_off[li]);
 		int start = pos - k;
 		if (start < 0) start = 0;
 		if (start >= len - 2 * k) start = len - 2 * k - 1;
 		const char* ref = vtext + line_off[li] + start;
-		for (int r = 0; r <= k; r++) col[r * DP_THREADS + tid] = 0;
+		for (int cidx = 0; cidx < 2 * k; cidx++) refc[cidx * DP_THREADS + tid] = ref[cidx];
+		int col[VDJX_MAX_KMER + 1];
+#pragma unroll
+		for (int r = 0; r <= VDJX_MAX_KMER; r++) col[r] = 0;
 		for (int cidx = 1; cidx <= 2 * k; cidx++) {
-			const char rc = ref[cidx - 1];
-			int diag = 0, up = 0;
-			for (int r = 1; r <= k; r++) {
-				const int left = col[r * DP_THREADS + tid];
-				int v = left - 1;
-				v = v > up - 1 ? v : up - 1;
-				const int d = diag + (qs[(r - 1) * DP_THREADS + tid] == rc ? 1 : 0);
-				v = v > d ? v : d;
-				diag = left;
-				up = v;
-				col[r * DP_THREADS + tid] = (signed char) v;
-				if (v >= threshold) { out[root] = 1; return; }
+			const char rc = refc[(cidx - 1) * DP_THREADS + tid];
+			int diag = 0, up = 0, best = 0;
+#pragma unroll
+			for (int r = 1; r <= VDJX_MAX_KMER; r++) {
+				if (r <= k) {
+					const int left = col[r];
+					int v = left - 1;
+					v = v > up - 1 ? v : up - 1;
+					const int d = diag + (q[r - 1] == rc ? 1 : 0);
+					v = v > d ? v : d;
+					diag = left;
+					up = v;
+					col[r] = v;                                 // (0 <= v <= k: the reference's int8 cells never wrap)
+					best = best > v ? best : v;
+				}
 			}
+			if (best >= threshold) { out[root] = 1; return; }   // any cell of the matrix at or above the threshold accepts (seq_score.c:103-112)
 		}
 	}
 }
