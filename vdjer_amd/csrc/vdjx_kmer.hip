@@ -27,7 +27,8 @@
 
 #define HIST_THREADS 1024
 #define K3_THREADS 512
-#define K3_SLOTS 2048u              // LDS table slots per sub-pass (56 KB with u32 key_hi: 2 workgroups per CU)
+#define K3_SLOTS 1024u              // LDS table slots per sub-pass of k_bucket_aggregate (28 KB with u32 key_hi): ~100 distinct gated k-mers per bucket
+#define LOCAL_SLOTS 2048u           // k_bucket_local keeps every distinct k-mer of the bucket, gated or not (~600)
 #define K3_UNR 4
 #define K3_SUB_TUPLES g_sub_tuples  // first split only for very large buckets: hot k-mers make buckets long, not wide (an overflow splits further)
 __device__ u32 g_sub_tuples = 262144u;
@@ -672,14 +673,14 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_local(const u64* __restri
                                                              u32* __restrict__ low_inst, u32* __restrict__ g_err) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	u64* s_klo = (u64*) smem;
-	THI* s_khi = (THI*) (s_klo + K3_SLOTS);
-	u32* s_cg = (u32*) (s_khi + K3_SLOTS);
-	u32* s_mg = s_cg + K3_SLOTS;
-	u32* s_ca = s_mg + K3_SLOTS;
-	u32* s_ma = s_ca + K3_SLOTS;
-	u32* s_loff = s_ma + K3_SLOTS;          // low-count keys: where their gated instances are listed (relative to the bucket)
-	u32* s_lfill = s_loff + K3_SLOTS;
-	uint8_t* s_fl = (uint8_t*) (s_lfill + K3_SLOTS);
+	THI* s_khi = (THI*) (s_klo + LOCAL_SLOTS);
+	u32* s_cg = (u32*) (s_khi + LOCAL_SLOTS);
+	u32* s_mg = s_cg + LOCAL_SLOTS;
+	u32* s_ca = s_mg + LOCAL_SLOTS;
+	u32* s_ma = s_ca + LOCAL_SLOTS;
+	u32* s_loff = s_ma + LOCAL_SLOTS;          // low-count keys: where their gated instances are listed (relative to the bucket)
+	u32* s_lfill = s_loff + LOCAL_SLOTS;
+	uint8_t* s_fl = (uint8_t*) (s_lfill + LOCAL_SLOTS);
 	__shared__ u32 s_n, s_ng, s_nlow, s_over;
 	const THI EMPTY = (THI) ~(THI) 0;
 	const u32 b = blockIdx.x;
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_local(const u64* __restri
 	for (;;) {
 		if (tid == 0) { s_n = 0; s_ng = 0; s_nlow = 0; s_over = 0; }
 		for (u32 s = 0; s < S; s++) {
-			for (u32 i = tid; i < K3_SLOTS; i += K3_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE32; s_ca[i] = 0; s_ma[i] = NONE32; s_lfill[i] = 0; s_fl[i] = 0; }
+			for (u32 i = tid; i < LOCAL_SLOTS; i += K3_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE32; s_ca[i] = 0; s_ma[i] = NONE32; s_lfill[i] = 0; s_fl[i] = 0; }
 			__syncthreads();
 			const bool one_chunk = n <= K3_UNR * K3_THREADS;
 			u32 r_iw[K3_UNR];
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_local(const u64* __restri
 					if (r_slot[j] == -2) continue;
 					const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
 					if ((u32) ((h >> 12) & (S - 1)) != s) continue;
-					const int slot = lds_insert<THI>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
+					const int slot = lds_insert<THI, LOCAL_SLOTS>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
 					if (slot < 0) { s_over = 1; continue; }
 					r_slot[j] = slot;
 					const u32 inst = r_iw[j] & INST_MASK;
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_local(const u64* __restri
 			__syncthreads();
 			if (s_over) break;
 			// keys whose count alone cannot pass the quality test (count < TLOW) list their gated instances: the owner may ask
-			for (u32 i = tid; i < K3_SLOTS; i += K3_THREADS) {
+			for (u32 i = tid; i < LOCAL_SLOTS; i += K3_THREADS) {
 				const u32 cg = s_cg[i];
 				s_loff[i] = (cg && cg < tlow) ? atomicAdd(&s_nlow, cg) : NONE32;
 			}
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_local(const u64* __restri
 						r_slot[j] = -2;
 						if (v && (r_iw[j] >> 31)) {
 							const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
-							r_slot[j] = (u32) ((h >> 12) & (S - 1)) == s ? lds_lookup<THI>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h) : -1;
+							r_slot[j] = (u32) ((h >> 12) & (S - 1)) == s ? lds_lookup<THI, LOCAL_SLOTS>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h) : -1;
 						}
 					}
 				}
@@ -769,7 +770,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_local(const u64* __restri
 				}
 			}
 			__syncthreads();
-			for (u32 i = tid; i < K3_SLOTS; i += K3_THREADS) {
+			for (u32 i = tid; i < LOCAL_SLOTS; i += K3_THREADS) {
 				if (s_khi[i] == EMPTY) continue;
 				const u32 idx = atomicAdd(&s_n, 1u);
 				LocalAll a;
@@ -1852,7 +1853,7 @@ static int shard_local_impl(vdjx_shard* s) {
 	HIP_TRY(db.alloc(&s->dstart, t.NB + 1));
 	HIP_TRY(db.alloc(&g_err, 1));
 	HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
-	const size_t lds = (size_t) K3_SLOTS * (8 + sizeof(THI) + 24 + 1);
+	const size_t lds = (size_t) LOCAL_SLOTS * (8 + sizeof(THI) + 24 + 1);
 	HIP_TRY(hipFuncSetAttribute((const void*) k_bucket_local<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 	{
 		vdjx_prof_scope ps(c, "k_bucket_local");
