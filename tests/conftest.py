@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """a fresh checkout has no native libraries (they are built artefacts, not history): build what is missing once"""
+    need = [os.path.join(ROOT, "vdjer_amd", "libvdjx.so"), os.path.join(ROOT, "vdjer_amd", "libvdjhost.so"),
+            os.path.join(ROOT, "vdjer_amd", "vdjer"), os.path.join(ROOT, "oracle", "liboracle.so")]
+    if all(os.path.exists(p) for p in need):
+        return
+    import subprocess
+    for d, target in ((os.path.join("vdjer_amd", "csrc"), None), (os.path.join("vdjer_amd", "csrc", "host"), None), ("oracle", "liboracle.so")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, d)] + ([target] if target else []))
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     from oracle import oracle
