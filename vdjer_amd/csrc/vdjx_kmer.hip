@@ -121,7 +121,7 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(const u32* __restrict__ bu
 // one coarse bucket (a few MB, cache resident) at a time.  Placement inside a bucket is arbitrary
 // (per-round global cursor bump): every per-k-mer reduction downstream is order-free.
 // ----------------------------------------------------------------------------------------------
-#define PART_THREADS 512
+#define PART_THREADS 1024
 #define PART_LDS_BYTES 131072
 #define PART_MAXB 1024
 
