@@ -158,6 +158,10 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records(const u64* __rest
 	const u32 ROUND = PART_LDS_BYTES / sizeof(Tup<THI>);
 	const int P = rl - k + 1;
 	const u32 RR = ROUND / (u32) P;                                  // records per round
+	// a round holds fewer records than the workgroup has threads (8,192 tuples = 512 records at P = 16): T threads share a
+	// record, each taking a contiguous part of its offsets
+	const u32 T = RR * 4 <= PART_THREADS ? 4u : (RR * 2 <= PART_THREADS ? 2u : 1u);
+	const int off_a = (int) ((threadIdx.x % T) * (u32) P / T), off_b = (int) ((threadIdx.x % T + 1) * (u32) P / T);
 	const u64 km = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
 	const u32 mask = nbk - 1;
 	const size_t r0 = (size_t) blockIdx.x * rpb;
@@ -166,9 +170,9 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records(const u64* __rest
 		const size_t re = rs + RR < r1 ? rs + RR : r1;
 		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) cnt[i] = 0;
 		__syncthreads();
-		for (size_t r = rs + threadIdx.x; r < re; r += PART_THREADS) {
+		for (size_t r = rs + threadIdx.x / T; r < re; r += PART_THREADS / T) {
 			RecView v = load_rec(bases, nmask, nullptr, r);
-			for (int o = 0; o < P; o++) {
+			for (int o = off_a; o < off_b; o++) {
 				if ((v.nm >> o) & km) continue;
 				u64 khi, klo;
 				vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
@@ -182,9 +186,9 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records(const u64* __rest
 			gbase[i] = cnt[i] ? atomicAdd(&gcur[i], cnt[i]) : 0u;
 		}
 		__syncthreads();
-		for (size_t r = rs + threadIdx.x; r < re; r += PART_THREADS) {
+		for (size_t r = rs + threadIdx.x / T; r < re; r += PART_THREADS / T) {
 			RecView v = load_rec(bases, nmask, lowq, r);
-			for (int o = 0; o < P; o++) {
+			for (int o = off_a; o < off_b; o++) {
 				if ((v.nm >> o) & km) continue;
 				u64 khi, klo;
 				vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
