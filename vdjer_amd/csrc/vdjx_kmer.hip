@@ -362,6 +362,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
                                                                  const u32* __restrict__ t_inst, const u32* __restrict__ bucket_start,
                                                                  u32 cmin, u64* __restrict__ c_lo, THI* __restrict__ c_hi,
                                                                  u32* __restrict__ c_cnt, u32* __restrict__ c_first,
+                                                                 u32* __restrict__ c_ucnt, u32* __restrict__ c_ufirst,
                                                                  u32* __restrict__ ct_lcid, u32* __restrict__ ct_inst,
                                                                  u32* __restrict__ bucket_ncand, u32* __restrict__ bucket_nct,
                                                                  u64* __restrict__ g_distinct, u32* __restrict__ g_err) {
@@ -371,6 +372,8 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 	u32* s_cnt = (u32*) (s_khi + K3_SLOTS);
 	u32* s_first = s_cnt + K3_SLOTS;
 	u32* s_cidx = s_first + K3_SLOTS;
+	u32* s_ucnt = s_cidx + K3_SLOTS;           // every instance of the k-mer, gated or not (add_to_graph's recount, A2:261-309)
+	u32* s_ufirst = s_ucnt + K3_SLOTS;
 	__shared__ u32 s_ncand, s_nct, s_over, s_ndist;
 	const THI EMPTY = (THI) ~(THI) 0;
 	const u32 b = blockIdx.x;
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 	for (;;) {
 		if (tid == 0) { s_ncand = 0; s_nct = 0; s_over = 0; s_ndist = 0; }
 		for (u32 s = 0; s < S; s++) {
-			for (u32 i = tid; i < K3_SLOTS; i += K3_THREADS) { s_khi[i] = EMPTY; s_cnt[i] = 0; s_first[i] = NONE32; }
+			for (u32 i = tid; i < K3_SLOTS; i += K3_THREADS) { s_khi[i] = EMPTY; s_cnt[i] = 0; s_first[i] = NONE32; s_ucnt[i] = 0; s_ufirst[i] = NONE32; }
 			__syncthreads();
 			// sweep 1: gated instances only (include_kmer, A2:240-259) -> count + first (A2:332-347).
 			// K3_UNR tuples per thread are loaded before any is processed: the loop is latency-bound otherwise.
@@ -433,7 +436,8 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 				s_cidx[i] = cid;
 			}
 			__syncthreads();
-			// sweep 2: compact every instance (gated or not) of a candidate k-mer
+			// sweep 2: every instance of a candidate k-mer is recounted here (ungated ones need nothing else); the GATED ones are
+			// compacted for the finalize kernel (distinct-read flag, quality sums): a sixth of the instances of a Phred-noisy pool
 			for (u32 t0 = 0; t0 < n; t0 += K3_UNR * K3_THREADS) {
 				bool val[K3_UNR];
 #pragma unroll
@@ -454,7 +458,14 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 						const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
 						if ((u32) ((h >> 12) & (S - 1)) == s) {
 							int slot = lds_lookup<THI>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
-							if (slot >= 0) { cid = s_cidx[slot]; is_c = cid != NONE32; }
+							if (slot >= 0) {
+								cid = s_cidx[slot];
+								if (cid != NONE32) {
+									atomicAdd(&s_ucnt[slot], 1u);
+									atomicMin(&s_ufirst[slot], r_iw[j] & INST_MASK);
+									is_c = (r_iw[j] >> 31) != 0;
+								}
+							}
 						}
 					}
 					u32 p = vdjx_wave_inc(&s_nct, is_c);
@@ -463,6 +474,11 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 						ct_inst[base + p] = r_iw[j];
 					}
 				}
+			}
+			__syncthreads();
+			for (u32 i = tid; i < K3_SLOTS; i += K3_THREADS) {
+				const u32 cid = s_cidx[i];
+				if (cid != NONE32) { c_ucnt[base + cid] = s_ucnt[i]; c_ufirst[base + cid] = s_ufirst[i]; }
 			}
 			__syncthreads();
 		}
@@ -489,7 +505,8 @@ template <typename THI>
 __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __restrict__ bucket_start, const u32* __restrict__ bucket_ncand,
                                                                  const u32* __restrict__ bucket_nct, const u64* __restrict__ c_lo,
                                                                  const THI* __restrict__ c_hi, const u32* __restrict__ c_cnt,
-                                                                 const u32* __restrict__ c_first, const u32* __restrict__ ct_lcid,
+                                                                 const u32* __restrict__ c_first, const u32* __restrict__ c_ucnt,
+                                                                 const u32* __restrict__ c_ufirst, const u32* __restrict__ ct_lcid,
                                                                  const u32* __restrict__ ct_inst, const u64* __restrict__ bases,
                                                                  const u64* __restrict__ nmask,
                                                                  const uint8_t* __restrict__ quals, int qstride, int k, int P,
@@ -514,14 +531,14 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 			const u32 cnt = c_cnt[base + c0 + i];
 			l_cnt[i] = cnt;
 			l_first[i] = c_first[base + c0 + i];
-			l_ucnt[i] = 0;
-			l_ufirst[i] = NONE32;
+			l_ucnt[i] = c_ucnt[base + c0 + i];           // recounted by k_bucket_aggregate (every instance, gated or not)
+			l_ufirst[i] = c_ufirst[base + c0 + i];
 			l_multi[i] = 0;
 			l_qok[i] = 0;
 			l_lowid[i] = cnt < tlow ? atomicAdd(&s_nlow, 1u) : NONE32;
 		}
 		__syncthreads();
-		// sweep A: ungated recount + first sight (add_to_graph, A2:280-309) and the distinct-read flag (A2:349-352)
+		// sweep A over the candidates' GATED instances: the distinct-read flag (A2:349-352), and who needs quality sums
 		// (four tuples per thread are in flight before any is used: the sweep is latency-bound otherwise)
 		for (u32 t0 = 0; t0 < nt; t0 += 4 * K3B_THREADS) {
 			u32 r_lc[4], r_iw[4];
@@ -538,8 +555,6 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 				lc -= c0;
 				const u32 iw = r_iw[j];
 				const u32 inst = iw & INST_MASK;
-				atomicAdd(&l_ucnt[lc], 1u);
-				atomicMin(&l_ufirst[lc], inst);
 				if ((iw >> 31) && l_lowid[lc] != NONE32) {      // its qualities will be needed: remember it (few such instances)
 					const u32 qi = atomicAdd(&s_nq, 1u);
 					if (qi < K3B_Q) { q_lc[qi] = lc; q_inst[qi] = inst; }
@@ -1526,8 +1541,9 @@ int stage_reduce(vdjx_ctx* c, A& db, const Tuples<THI>& t, const PoolView& pv, i
 	}
 	u64 *c_lo, *g_distinct;
 	THI* c_hi;
-	u32 *c_cnt, *c_first, *ct_lcid, *ct_inst, *bucket_ncand, *bucket_nct, *g_err, *n_surv;
+	u32 *c_cnt, *c_first, *c_ucnt, *c_ufirst, *ct_lcid, *ct_inst, *bucket_ncand, *bucket_nct, *g_err, *n_surv;
 	HIP_TRY(db.alloc(&c_lo, N)); HIP_TRY(db.alloc(&c_hi, N)); HIP_TRY(db.alloc(&c_cnt, N)); HIP_TRY(db.alloc(&c_first, N));
+	HIP_TRY(db.alloc(&c_ucnt, N)); HIP_TRY(db.alloc(&c_ufirst, N));
 	HIP_TRY(db.alloc(&ct_lcid, N)); HIP_TRY(db.alloc(&ct_inst, N));
 	HIP_TRY(db.alloc(&bucket_ncand, NB)); HIP_TRY(db.alloc(&bucket_nct, NB));
 	HIP_TRY(db.alloc(&g_err, 1)); HIP_TRY(db.alloc(&n_surv, 1)); HIP_TRY(db.alloc(&g_distinct, 64 * 16));
@@ -1544,12 +1560,12 @@ int stage_reduce(vdjx_ctx* c, A& db, const Tuples<THI>& t, const PoolView& pv, i
 	const u32 cmin = (u32) std::max(mf, 2);
 	const u32 mfu = (u32) std::max(mf, 0);
 
-	const size_t lds_agg = (size_t) K3_SLOTS * (8 + sizeof(THI) + 12);
+	const size_t lds_agg = (size_t) K3_SLOTS * (8 + sizeof(THI) + 20);
 	HIP_TRY(hipFuncSetAttribute((const void*) k_bucket_aggregate<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_agg));
 	{
 		vdjx_prof_scope ps(c, "k_bucket_aggregate");
 		hipLaunchKernelGGL(k_bucket_aggregate<THI>, dim3(NB), dim3(K3_THREADS), lds_agg, st, t.lo, t.hi, t.inst, t.bucket_start, cmin,
-		                   c_lo, c_hi, c_cnt, c_first, ct_lcid, ct_inst, bucket_ncand, bucket_nct, g_distinct, g_err);
+		                   c_lo, c_hi, c_cnt, c_first, c_ucnt, c_ufirst, ct_lcid, ct_inst, bucket_ncand, bucket_nct, g_distinct, g_err);
 	}
 	// survivors: capacity grows on demand (rerun of the cheap finalize pass)
 	u32 cap = (u32) std::min<size_t>((size_t) N / 2 + 1024, (size_t) 1 << 22);
@@ -1563,7 +1579,7 @@ int stage_reduce(vdjx_ctx* c, A& db, const Tuples<THI>& t, const PoolView& pv, i
 		{
 			vdjx_prof_scope ps(c, "k_bucket_finalize");
 			hipLaunchKernelGGL(k_bucket_finalize<THI>, dim3(NB), dim3(K3B_THREADS), 0, st, t.bucket_start, bucket_ncand, bucket_nct,
-			                   c_lo, c_hi, c_cnt, c_first, ct_lcid, ct_inst, pv.bases, pv.nmask, pv.quals, pv.qstride, k, P, mfu, mqq, tlow, so);
+			                   c_lo, c_hi, c_cnt, c_first, c_ucnt, c_ufirst, ct_lcid, ct_inst, pv.bases, pv.nmask, pv.quals, pv.qstride, k, P, mfu, mqq, tlow, so);
 		}
 		HIP_TRY(hipMemcpyAsync(&ns, n_surv, 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
