@@ -189,6 +189,25 @@ __host__ __device__ inline void vdjx_kmer_at(u64 bhi, u64 blo, int rl, int k, in
 	klo = (u64) v;
 }
 
+// cnt[idx] += 1 and mn[idx] = min(mn[idx], val) on LDS arrays for the lanes with `active`.  Hot k-mers put most lanes of a wave on
+// ONE address: the lanes that share the first active lane's index are combined into one add and one min; the others go one by one.
+__device__ inline void vdjx_lds_count_min(u32* cnt, u32* mn, u32 idx, u32 val, bool active) {
+	const u64 act = __ballot(active);
+	if (act) {
+		const int leader = __ffsll((long long) act) - 1;
+		const u32 lidx = __shfl(idx, leader);
+		const bool same = active && idx == lidx;
+		const u64 m = __ballot(same);
+		if (__popcll(m) >= 16) {
+			u32 mv = same ? val : 0xFFFFFFFFu;
+			for (int d = 32; d; d >>= 1) { const u32 o = __shfl_xor(mv, d); mv = o < mv ? o : mv; }
+			if (__lane_id() == leader) { atomicAdd(&cnt[lidx], (u32) __popcll(m)); atomicMin(&mn[lidx], mv); }
+			active = active && !same;
+		}
+	}
+	if (active) { atomicAdd(&cnt[idx], 1u); atomicMin(&mn[idx], val); }
+}
+
 __device__ inline u32 vdjx_wave_inc(u32* ctr, bool pred) {
 	// wave-aggregated counter increment (LDS or global); returns this lane's slot, undefined if !pred
 	u64 m = __ballot(pred);

@@ -452,22 +452,21 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 				}
 #pragma unroll
 				for (int j = 0; j < K3_UNR; j++) {
-					bool is_c = false;
+					bool is_c = false, cand = false;
 					u32 cid = NONE32;
+					int slot = -1;
 					if (val[j]) {
 						const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
 						if ((u32) ((h >> 12) & (S - 1)) == s) {
-							int slot = lds_lookup<THI>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
+							slot = lds_lookup<THI>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
 							if (slot >= 0) {
 								cid = s_cidx[slot];
-								if (cid != NONE32) {
-									atomicAdd(&s_ucnt[slot], 1u);
-									atomicMin(&s_ufirst[slot], r_iw[j] & INST_MASK);
-									is_c = (r_iw[j] >> 31) != 0;
-								}
+								cand = cid != NONE32;
+								is_c = cand && (r_iw[j] >> 31) != 0;
 							}
 						}
 					}
+					vdjx_lds_count_min(s_ucnt, s_ufirst, cand ? (u32) slot : 0u, r_iw[j] & INST_MASK, cand);
 					u32 p = vdjx_wave_inc(&s_nct, is_c);
 					if (is_c) {
 						ct_lcid[base + p] = cid;
@@ -735,16 +734,17 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_local(const u64* __restri
 				}
 #pragma unroll
 				for (int j = 0; j < K3_UNR; j++) {
-					if (r_slot[j] == -2) continue;
-					const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
-					if ((u32) ((h >> 12) & (S - 1)) != s) continue;
-					const int slot = lds_insert<THI, LOCAL_SLOTS>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
-					if (slot < 0) { s_over = 1; continue; }
-					r_slot[j] = slot;
+					int slot = -1;
+					if (r_slot[j] != -2) {
+						const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
+						if ((u32) ((h >> 12) & (S - 1)) == s) {
+							slot = lds_insert<THI, LOCAL_SLOTS>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
+							if (slot < 0) s_over = 1; else r_slot[j] = slot;
+						}
+					}
 					const u32 inst = r_iw[j] & INST_MASK;
-					atomicAdd(&s_ca[slot], 1u);
-					atomicMin(&s_ma[slot], inst);
-					if (r_iw[j] >> 31) { atomicAdd(&s_cg[slot], 1u); atomicMin(&s_mg[slot], inst); }
+					vdjx_lds_count_min(s_ca, s_ma, slot >= 0 ? (u32) slot : 0u, inst, slot >= 0);
+					vdjx_lds_count_min(s_cg, s_mg, slot >= 0 ? (u32) slot : 0u, inst, slot >= 0 && (r_iw[j] >> 31));
 				}
 			}
 			__syncthreads();
