@@ -277,21 +277,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_tuples(const u64* __restr
 	}
 }
 
-// sub-bucket sizes inside every segment (bucket) of a partitioned tuple array: one workgroup per segment
-template <typename THI>
-__global__ __launch_bounds__(256) void k_seg_hist(const u64* __restrict__ lo, const THI* __restrict__ hi, const u32* __restrict__ seg_start,
-                                                  u32 shift, u32 sub_bits, u32* __restrict__ fine_cnt) {
-	__shared__ u32 h[PART_MAXB];
-	const u32 nbk = 1u << sub_bits;
-	for (u32 i = threadIdx.x; i < nbk; i += 256) h[i] = 0;
-	__syncthreads();
-	const u32 s0 = seg_start[blockIdx.x], s1 = seg_start[blockIdx.x + 1];
-	for (u32 t = s0 + threadIdx.x; t < s1; t += 256) atomicAdd(&h[(u32) (vdjx_mix(lo[t], (u64) hi[t]) >> shift) & (nbk - 1)], 1u);
-	__syncthreads();
-	for (u32 i = threadIdx.x; i < nbk; i += 256) fine_cnt[((size_t) blockIdx.x << sub_bits) | i] = h[i];
-}
-
-// the same over long segments (the coarse buckets of pass 1): `slices` workgroups per segment, LDS counts added to the global ones
+// sub-bucket sizes inside the segments (the coarse buckets of pass 1) of a partitioned tuple array:: `slices` workgroups per segment, LDS counts added to the global ones
 template <typename THI>
 __global__ __launch_bounds__(512) void k_seg_hist_sliced(const u64* __restrict__ lo, const THI* __restrict__ hi, const u32* __restrict__ seg_start,
                                                          u32 seg_shift, u32 slices, u32 shift, u32 sub_bits, u32* __restrict__ fine_cnt) {
@@ -1414,7 +1400,7 @@ u32 choose_nb_bits(size_t NI) {
 	return nb_bits;
 }
 
-struct PartPlan { u32 nb_bits, NB, nblk; size_t rpb; u32* block_hist; u32* bucket_cnt; u32* bucket_start; };
+struct PartPlan { u32 nb_bits, NB, nblk; size_t rpb; u32* bucket_cnt; u32* bucket_start; };
 
 // K2a + K2b over the records of `pool`: bucket sizes and per-workgroup offsets
 template <typename A>
@@ -1426,7 +1412,6 @@ int stage_partition_count(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, u32 
 	pp->nblk = (u32) std::min<size_t>(512, (R + 4095) / 4096);
 	if (pp->nblk == 0) pp->nblk = 1;
 	pp->rpb = (R + pp->nblk - 1) / pp->nblk;
-	pp->block_hist = nullptr;
 	HIP_TRY(db.alloc(&pp->bucket_cnt, pp->NB));
 	HIP_TRY(hipMemsetAsync(pp->bucket_cnt, 0, (size_t) pp->NB * 4, st));
 	HIP_TRY(db.alloc(&pp->bucket_start, pp->NB + 1));
