@@ -277,7 +277,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_tuples(const u64* __restr
 	}
 }
 
-// sub-bucket sizes inside the segments (the coarse buckets of pass 1) of a partitioned tuple array:: `slices` workgroups per segment, LDS counts added to the global ones
+// sub-bucket sizes inside the segments (the coarse buckets of pass 1) of a partitioned tuple array: `slices` workgroups per segment, LDS counts added to the global ones
 template <typename THI>
 __global__ __launch_bounds__(512) void k_seg_hist_sliced(const u64* __restrict__ lo, const THI* __restrict__ hi, const u32* __restrict__ seg_start,
                                                          u32 seg_shift, u32 slices, u32 shift, u32 sub_bits, u32* __restrict__ fine_cnt) {
