@@ -1426,9 +1426,9 @@ int stage_partition_count(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, u32 
 		vdjx_prof_scope ps(c, "k_hist_scan");
 		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, pp->bucket_cnt, pp->NB, pp->bucket_start);
 	}
-	HIP_TRY(hipMemcpyAsync(N_out, pp->bucket_start + pp->NB, 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	HIP_TRY(hipGetLastError());
+	// the exact tuple count (instances without an 'N') stays on the device (bucket_start[NB]); the host sizes everything by the
+	// bound records x offsets and saves a round trip
+	*N_out = (u32) (R * (size_t) (pool->rl - k + 1));
 	return VDJX_OK;
 }
 
