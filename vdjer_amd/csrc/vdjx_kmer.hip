@@ -384,6 +384,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 			u32 r_iw[K3_UNR];
 			u64 r_lo[K3_UNR];
 			THI r_hi[K3_UNR];
+			int r_slot[K3_UNR];                    // one-chunk buckets: the slot a gated tuple was inserted at serves sweep 2 as well
 			for (u32 t0 = 0; t0 < n; t0 += K3_UNR * K3_THREADS) {
 #pragma unroll
 				for (int j = 0; j < K3_UNR; j++) {
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 					r_iw[j] = v ? t_inst[base + t] : 0u;
 					r_lo[j] = v ? t_lo[base + t] : 0ull;
 					r_hi[j] = v ? t_hi[base + t] : (THI) 0;
+					r_slot[j] = -1;
 				}
 #pragma unroll
 				for (int j = 0; j < K3_UNR; j++) {
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 					if ((u32) ((h >> 12) & (S - 1)) != s) continue;
 					int slot = lds_insert<THI>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
 					if (slot < 0) { s_over = 1; continue; }
+					r_slot[j] = slot;
 					atomicAdd(&s_cnt[slot], 1u);
 					atomicMin(&s_first[slot], r_iw[j] & INST_MASK);
 				}
@@ -442,9 +445,12 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __re
 					u32 cid = NONE32;
 					int slot = -1;
 					if (val[j]) {
-						const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
-						if ((u32) ((h >> 12) & (S - 1)) == s) {
-							slot = lds_lookup<THI>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
+						if (one_chunk && S == 1 && (r_iw[j] >> 31)) slot = r_slot[j];          // gated: inserted in sweep 1
+						else {
+							const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
+							if ((u32) ((h >> 12) & (S - 1)) == s) slot = lds_lookup<THI>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
+						}
+						{
 							if (slot >= 0) {
 								cid = s_cidx[slot];
 								cand = cid != NONE32;
