@@ -29,7 +29,7 @@
 #define K3_THREADS 512
 #define K3_SLOTS 1024u              // LDS table slots per sub-pass of k_bucket_aggregate (28 KB with u32 key_hi): ~100 distinct gated k-mers per bucket
 #define LOCAL_SLOTS 2048u           // k_bucket_local keeps every distinct k-mer of the bucket, gated or not (~600)
-#define K3_UNR 4
+#define K3_UNR 8
 #define K3_SUB_TUPLES g_sub_tuples  // first split only for very large buckets: hot k-mers make buckets long, not wide (an overflow splits further)
 __device__ u32 g_sub_tuples = 262144u;
 #define K3B_THREADS 256
@@ -1398,9 +1398,12 @@ size_t tune(const char* name, size_t dflt) {      // undocumented tuning knobs f
 	return v && atol(v) > 0 ? (size_t) atol(v) : dflt;
 }
 
-u32 choose_nb_bits(size_t NI) {
-	// ~2048 instances per bucket, at most 2^15 buckets (128 KB LDS histogram)
-	static const size_t per = tune("VDJX_BUCKET_TUPLES", 2048);
+u32 choose_nb_bits(size_t NI, size_t per_bucket = 0) {
+	// ~4096 instances per bucket (one register-resident chunk of the reduce kernels: 512 threads x K3_UNR; fewer, larger buckets
+	// halve the per-workgroup overheads of the reduce kernels: finalize 0.41 -> 0.24 ms at 1 M pairs), at most 2^15 buckets
+	// (128 KB LDS histogram).  The sharded build keeps 2048: its local table holds every distinct k-mer of a bucket.
+	static const size_t dflt = tune("VDJX_BUCKET_TUPLES", 4096);
+	const size_t per = per_bucket ? per_bucket : dflt;
 	u32 nb_bits = 8;
 	while (nb_bits < 15 && (per << nb_bits) < NI) nb_bits++;
 	return nb_bits;
@@ -1450,8 +1453,9 @@ inline PartGeom part_geom(u32 nb_bits) {
 // how many hash bits beyond the histogram's 2^15 buckets: buckets stay near `target` tuples whatever the pool size
 // (`Nd` = the tuple count the decision is made on: the sharded build passes a bound every rank knows, so that all ranks cut the
 // same buckets)
-u32 choose_extra_bits(size_t Nd, u32 NB) {
-	static const size_t target = tune("VDJX_REFINE_TUPLES", 2048);
+u32 choose_extra_bits(size_t Nd, u32 NB, size_t per_bucket = 0) {
+	static const size_t dflt = tune("VDJX_REFINE_TUPLES", 4096);
+	const size_t target = per_bucket ? per_bucket : dflt;
 	if (NB == 0 || Nd / NB <= 2 * target) return 0;
 	u32 extra = 1;
 	while (extra < 5 && (Nd >> extra) / NB > target) extra++;
@@ -1808,7 +1812,7 @@ extern "C" int vdjx_shard_begin(vdjx_ctx* c, const vdjx_pool* pool, int k, int m
 	s->hi64 = !key_hi_is_u32(k);
 	while ((1 << s->owner_bits) < nranks) s->owner_bits++;
 	// every rank cuts the SAME buckets: the geometry follows the common stride, not the local record count
-	s->nb_bits = choose_nb_bits((size_t) rec_stride * (size_t) (pool->rl - k + 1));
+	s->nb_bits = choose_nb_bits((size_t) rec_stride * (size_t) (pool->rl - k + 1), 2048);
 	if (mq >= 255) mq = 254;                                        // A2:1514-1516
 	s->mqq = (u32) (mq < 0 ? 0 : (mq > 214 ? 214 : mq));
 	s->tlow = 1 + (s->mqq + 19) / 20;
@@ -1845,7 +1849,7 @@ static int shard_local_impl(vdjx_shard* s) {
 	Tuples<THI> t;
 	int rc = stage_partition_count(c, db, s->pool, s->k, s->nb_bits, &pp, &t.N);
 	if (rc) return rc;
-	rc = stage_partition_fill<THI>(c, db, s->pool, rec_base, s->k, pp, t.N, choose_extra_bits((size_t) s->rec_stride * (size_t) P, pp.NB), &t);
+	rc = stage_partition_fill<THI>(c, db, s->pool, rec_base, s->k, pp, t.N, choose_extra_bits((size_t) s->rec_stride * (size_t) P, pp.NB, 2048), &t);
 	if (rc) return rc;
 	s->t_lo = t.lo; s->t_hi = t.hi; s->t_inst = t.inst; s->t_bucket_start = t.bucket_start;
 	s->N_local = t.N; s->NBf = t.NB;
