@@ -502,7 +502,7 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
                                                                  const u64* __restrict__ nmask,
                                                                  const uint8_t* __restrict__ quals, int qstride, int k, int P,
                                                                  u32 mf, u32 mqq, u32 tlow, SurvOut so) {
-	__shared__ u32 l_cnt[K3B_CH], l_first[K3B_CH], l_ucnt[K3B_CH], l_ufirst[K3B_CH], l_lowid[K3B_CH];
+	__shared__ u32 l_first[K3B_CH], l_lowid[K3B_CH];      // (counts are read from the candidate arrays where needed: 35 KB of LDS, four workgroups per CU)
 	__shared__ uint8_t l_multi[K3B_CH], l_qok[K3B_CH];
 	__shared__ u32 acc[K3B_A * K3B_KW];
 	__shared__ u32 s_nlow, s_base, s_nq;
@@ -520,10 +520,7 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 		__syncthreads();
 		for (u32 i = tid; i < m; i += K3B_THREADS) {
 			const u32 cnt = c_cnt[base + c0 + i];
-			l_cnt[i] = cnt;
 			l_first[i] = c_first[base + c0 + i];
-			l_ucnt[i] = c_ucnt[base + c0 + i];           // recounted by k_bucket_aggregate (every instance, gated or not)
-			l_ufirst[i] = c_ufirst[base + c0 + i];
 			l_multi[i] = 0;
 			l_qok[i] = 0;
 			l_lowid[i] = cnt < tlow ? atomicAdd(&s_nlow, 1u) : NONE32;
@@ -628,8 +625,9 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 		if (tid == 0) s_nlow = 0;
 		__syncthreads();
 		for (u32 i = tid; i < m; i += K3B_THREADS) {
-			const u32 cnt = l_cnt[i] > 32765u ? 32765u : l_cnt[i];            // A2:345-347
-			const bool keep = cnt >= mf && l_multi[i] && (l_cnt[i] >= tlow || l_qok[i]);
+			const u32 craw = c_cnt[base + c0 + i];
+			const u32 cnt = craw > 32765u ? 32765u : craw;                     // A2:345-347
+			const bool keep = cnt >= mf && l_multi[i] && (craw >= tlow || l_qok[i]);
 			l_lowid[i] = keep ? atomicAdd(&s_nlow, 1u) : NONE32;               // (reused: position among this chunk's survivors)
 		}
 		__syncthreads();
@@ -641,10 +639,11 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 			if (pos < so.cap) {
 				so.lo[pos] = c_lo[base + c0 + i];
 				so.hi[pos] = (u64) c_hi[base + c0 + i];
-				so.gcnt[pos] = l_cnt[i] > 32765u ? 32765u : l_cnt[i];
+				const u32 craw = c_cnt[base + c0 + i], uraw = c_ucnt[base + c0 + i];   // (recounted by k_bucket_aggregate: every instance, gated or not)
+				so.gcnt[pos] = craw > 32765u ? 32765u : craw;
 				so.gfirst[pos] = l_first[i];
-				so.ucnt[pos] = l_ucnt[i] > 32765u ? 32765u : l_ucnt[i]; // A2:261-265
-				so.ufirst[pos] = l_ufirst[i];
+				so.ucnt[pos] = uraw > 32765u ? 32765u : uraw;           // A2:261-265
+				so.ufirst[pos] = c_ufirst[base + c0 + i];
 			}
 		}
 		__syncthreads();
