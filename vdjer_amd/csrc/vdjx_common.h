@@ -189,18 +189,30 @@ __host__ __device__ inline void vdjx_kmer_at(u64 bhi, u64 blo, int rl, int k, in
 	klo = (u64) v;
 }
 
+// wave-wide unsigned minimum through DPP row shifts and broadcasts (gfx9 family): no LDS traffic, unlike __shfl_xor
+// (ds_bpermute); every lane gets the result
+__device__ inline u32 vdjx_wave_min(u32 v) {
+	u32 t;
+	t = (u32) __builtin_amdgcn_update_dpp((int) 0xFFFFFFFF, (int) v, 0x111, 0xf, 0xf, false); v = t < v ? t : v;   // row_shr:1
+	t = (u32) __builtin_amdgcn_update_dpp((int) 0xFFFFFFFF, (int) v, 0x112, 0xf, 0xf, false); v = t < v ? t : v;   // row_shr:2
+	t = (u32) __builtin_amdgcn_update_dpp((int) 0xFFFFFFFF, (int) v, 0x114, 0xf, 0xf, false); v = t < v ? t : v;   // row_shr:4
+	t = (u32) __builtin_amdgcn_update_dpp((int) 0xFFFFFFFF, (int) v, 0x118, 0xf, 0xf, false); v = t < v ? t : v;   // row_shr:8: lane 15 of a row = row minimum
+	t = (u32) __builtin_amdgcn_update_dpp((int) 0xFFFFFFFF, (int) v, 0x142, 0xa, 0xf, false); v = t < v ? t : v;   // row_bcast:15 -> rows 1, 3
+	t = (u32) __builtin_amdgcn_update_dpp((int) 0xFFFFFFFF, (int) v, 0x143, 0xc, 0xf, false); v = t < v ? t : v;   // row_bcast:31 -> rows 2, 3
+	return (u32) __builtin_amdgcn_readlane((int) v, 63);
+}
+
 // cnt[idx] += 1 and mn[idx] = min(mn[idx], val) on LDS arrays for the lanes with `active`.  Hot k-mers put most lanes of a wave on
 // ONE address: the lanes that share the first active lane's index are combined into one add and one min; the others go one by one.
 __device__ inline void vdjx_lds_count_min(u32* cnt, u32* mn, u32 idx, u32 val, bool active) {
 	const u64 act = __ballot(active);
 	if (act) {
 		const int leader = __ffsll((long long) act) - 1;
-		const u32 lidx = __shfl(idx, leader);
+		const u32 lidx = (u32) __builtin_amdgcn_readlane((int) idx, leader);
 		const bool same = active && idx == lidx;
 		const u64 m = __ballot(same);
 		if (__popcll(m) >= 16) {
-			u32 mv = same ? val : 0xFFFFFFFFu;
-			for (int d = 32; d; d >>= 1) { const u32 o = __shfl_xor(mv, d); mv = o < mv ? o : mv; }
+			const u32 mv = vdjx_wave_min(same ? val : 0xFFFFFFFFu);
 			if (__lane_id() == leader) { atomicAdd(&cnt[lidx], (u32) __popcll(m)); atomicMin(&mn[lidx], mv); }
 			active = active && !same;
 		}
@@ -210,16 +222,12 @@ __device__ inline void vdjx_lds_count_min(u32* cnt, u32* mn, u32 idx, u32 val, b
 
 __device__ inline u32 vdjx_wave_inc(u32* ctr, bool pred) {
 	// wave-aggregated counter increment (LDS or global); returns this lane's slot, undefined if !pred
-	u64 m = __ballot(pred);
-	u32 res = 0;
-	if (pred) {
-		int lane = __lane_id();
-		u32 rank = __popcll(m & ((1ull << lane) - 1ull));
-		int leader = __ffsll((long long) m) - 1;
-		u32 base = 0;
-		if (lane == leader) base = atomicAdd(ctr, (u32) __popcll(m));
-		base = __shfl(base, leader);
-		res = base + rank;
-	}
-	return res;
+	const u64 m = __ballot(pred);
+	if (!m) return 0;                                      // (wave-uniform)
+	const int lane = __lane_id();
+	const int leader = __ffsll((long long) m) - 1;
+	u32 base = 0;
+	if (lane == leader) base = atomicAdd(ctr, (u32) __popcll(m));
+	base = (u32) __builtin_amdgcn_readlane((int) base, leader);     // (v_readlane: no LDS round trip, unlike __shfl)
+	return base + (u32) __popcll(m & ((1ull << lane) - 1ull));
 }
