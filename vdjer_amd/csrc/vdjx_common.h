@@ -202,6 +202,18 @@ __device__ inline u32 vdjx_wave_min(u32 v) {
 	return (u32) __builtin_amdgcn_readlane((int) v, 63);
 }
 
+// wave-wide inclusive prefix sum through DPP (row shifts inside the rows of 16 lanes, then the two row broadcasts): all 64 lanes
+// must be active
+__device__ inline int vdjx_wave_scan_add(int v) {
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+	return v;
+}
+
 // cnt[idx] += 1 and mn[idx] = min(mn[idx], val) on LDS arrays for the lanes with `active`.  Hot k-mers put most lanes of a wave on
 // ONE address: the lanes that share the first active lane's index are combined into one add and one min; the others go one by one.
 __device__ inline void vdjx_lds_count_min(u32* cnt, u32* mn, u32 idx, u32 val, bool active) {

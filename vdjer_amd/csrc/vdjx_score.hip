@@ -613,11 +613,7 @@ __device__ inline u32 map_prepare(MapLds& L, const ReadIndexDev& ix, const char*
 		const int b2 = a + per < noff ? a + per : noff;
 		u32 sum = 0;
 		for (int o = a; o < b2; o++) sum += L.hpre[o];
-		u32 incl = sum;
-		for (int d = 1; d < 64; d <<= 1) {
-			u32 v = __shfl_up(incl, d);
-			if ((int) tid >= d) incl += v;
-		}
+		const u32 incl = (u32) vdjx_wave_scan_add((int) sum);
 		u32 run = incl - sum;
 		for (int o = a; o < b2; o++) { const u32 sz = L.hpre[o]; L.hpre[o] = run; run += sz; }
 		if (tid == 63) L.hpre[noff] = incl;
@@ -731,7 +727,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_pairs(ReadIndexDev ix, c
 			mine += r.pair_id;
 		}
 	}
-	for (int d = 32; d; d >>= 1) mine += __shfl_down(mine, d);
+	mine = (u32) __builtin_amdgcn_readlane(vdjx_wave_scan_add((int) mine), 63);
 	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&pair_np[wi], mine);
 }
 
@@ -792,11 +788,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 		const int b0 = a0 + per < D ? a0 + per : D;
 		u32 sum = 0;
 		for (int q = a0; q < b0; q++) sum += hf[q];
-		u32 incl = sum;
-		for (int d = 1; d < 64; d <<= 1) {
-			u32 v = __shfl_up(incl, d);
-			if ((int) tid >= d) incl += v;
-		}
+		const u32 incl = (u32) vdjx_wave_scan_add((int) sum);
 		u32 run = incl - sum;
 		for (int q = a0; q < b0; q++) { run += hf[q]; hf[q] = run; }
 	}
@@ -886,13 +878,9 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 				bool ok = true;
 				for (int p0 = 0; p0 < npos; p0 += 64) {
 					const int p = p0 + lane;
-					int v = p < npos ? row[p] : 0;
-					for (int d = 1; d < 64; d <<= 1) {
-						int u = __shfl_up(v, d);
-						if (lane >= d) v += u;
-					}
+					const int v = vdjx_wave_scan_add(p < npos ? row[p] : 0);
 					const int run = carry + v;
-					carry += __shfl(v, 63);
+					carry += __builtin_amdgcn_readlane(v, 63);
 					if (p < npos) {
 						const int pos = e0 + p;
 						const bool evaluated = pos == e0 || (pos - 1 + clo) < e1;    // the loop tests the previous mate_low (coverage.c:25)
