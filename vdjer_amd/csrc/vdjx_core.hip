@@ -248,18 +248,14 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 	u128 b = 0;
 	u64 nm = 0, lq = 0;
 	for (int i = 0; i < rl; i++) {
-		uint8_t ch = r[1 + i];
-		u32 code;
-		switch (ch) {                       // seq_to_kmer.c:6-29: A0 T1 C2 G3
-		case 'A': code = 0; break;
-		case 'T': code = 1; break;
-		case 'C': code = 2; break;
-		case 'G': code = 3; break;
-		default: code = 0; nm |= 1ull << i; break;
-		}
-		b = (b << 2) | code;
-		uint8_t q = (uint8_t) (r[1 + rl + i] - 33);             // phred33(), A2:150-152
-		if (q < 20) lq |= 1ull << i;                             // MIN_BASE_QUALITY, A2:76,252
+		const u32 ch = r[1 + i];
+		// seq_to_kmer.c:6-29: A0 T1 C2 G3.  Branch-free: bits 1-2 of the ASCII code tell A(00) C(01) T(10) G(11) apart
+		const u32 code = (0xD8u >> (((ch >> 1) & 3u) * 2u)) & 3u;           // 00->0, 01->2, 10->1, 11->3
+		const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+		nm |= (u64) (!acgt) << i;
+		b = (b << 2) | (acgt ? code : 0u);
+		const u32 q = (u32) (uint8_t) (r[1 + rl + i] - 33);                  // phred33(), A2:150-152
+		lq |= (u64) (q < 20u) << i;                                          // MIN_BASE_QUALITY, A2:76,252
 	}
 	const size_t g = rec0 + first + threadIdx.x;
 	((ulonglong2*) bases)[g] = make_ulonglong2((u64) (b >> 64), (u64) b);
