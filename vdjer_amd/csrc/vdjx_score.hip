@@ -24,14 +24,11 @@ template <typename T> void free_set(T*& p) { if (p) (void) hipFree(p); p = nullp
 // ==============================================================================================
 // a-7 root scorer
 // ==============================================================================================
+// seq_to_kmer.c:6-29: A0 T1 C2 G3, anything else -1.  Branch-free: bits 1-2 of the ASCII code tell A(00) C(01) T(10) G(11) apart
 __host__ __device__ inline int base_code(char ch) {
-	switch (ch) {
-	case 'A': return 0;
-	case 'T': return 1;
-	case 'C': return 2;
-	case 'G': return 3;
-	default: return -1;
-	}
+	const unsigned c = (unsigned char) ch;
+	const int code = (int) ((0xD8u >> (((c >> 1) & 3u) * 2u)) & 3u);
+	return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? code : -1;
 }
 
 extern "C" int vdjx_vregion_load(vdjx_ctx* c, const char* const* lines, size_t n_lines, int vk) {
