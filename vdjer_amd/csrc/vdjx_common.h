@@ -190,7 +190,7 @@ __host__ __device__ inline void vdjx_kmer_at(u64 bhi, u64 blo, int rl, int k, in
 }
 
 // wave-wide unsigned minimum through DPP row shifts and broadcasts (gfx9 family): no LDS traffic, unlike __shfl_xor
-// (ds_bpermute); every lane gets the result
+// (ds_bpermute); every lane gets the result.  All 64 lanes must be active (the result is read from lane 63).
 __device__ inline u32 vdjx_wave_min(u32 v) {
 	u32 t;
 	t = (u32) __builtin_amdgcn_update_dpp((int) 0xFFFFFFFF, (int) v, 0x111, 0xf, 0xf, false); v = t < v ? t : v;   // row_shr:1
