@@ -286,7 +286,7 @@ def main():
 
     for i in range(args.warmup):
         step(first=(i == 0))
-    ctx.profile(True)
+    ctx.profile(os.environ.get("VDJX_BENCH_NO_EVENTS") != "1")      # (diagnostic switch: what the per-kernel HIP events cost)
     ctx.profile_reset()
     wall.clear()
     bytes_before = engine.bytes_exchanged if engine else 0

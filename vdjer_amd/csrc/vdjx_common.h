@@ -77,6 +77,7 @@ struct vdjx_ctx {
 	std::map<std::string, vdjx_prof_entry> prof;
 	struct pending_ev { std::string name; hipEvent_t a, b; };
 	std::vector<pending_ev> prof_pending;
+	std::vector<hipEvent_t> ev_free;                     // events are recycled: creating two per launch costs as much as recording them
 	// a-6 anchor bitmaps (2^32 bits each)
 	u32* d_vbits = nullptr;
 	u32* d_jbits = nullptr;

@@ -109,6 +109,7 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 		g_ctx_live.erase(c);
 	}
 	for (auto& p : c->prof_pending) { (void) hipEventDestroy(p.a); (void) hipEventDestroy(p.b); }
+	for (auto& e : c->ev_free) (void) hipEventDestroy(e);
 	(void) hipStreamSynchronize(c->copy_stream);
 	(void) hipStreamDestroy(c->copy_stream);
 	(void) hipStreamDestroy(c->stream);
@@ -158,7 +159,11 @@ extern "C" int vdjx_sync(vdjx_ctx* c) {
 // ----------------------------------------------------------------------------------------------
 vdjx_prof_scope::vdjx_prof_scope(vdjx_ctx* ctx, const char* nm) : c(ctx), name(nm) {
 	if (!c->profiling) return;
-	if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+	auto take = [&](hipEvent_t* e) {
+		if (!c->ev_free.empty()) { *e = c->ev_free.back(); c->ev_free.pop_back(); return true; }
+		return hipEventCreate(e) == hipSuccess;
+	};
+	if (!take(&a) || !take(&b)) { a = b = nullptr; return; }
 	(void) hipEventRecord(a, c->stream);
 }
 
@@ -177,8 +182,8 @@ void vdjx_prof_collect(vdjx_ctx* c) {
 			e.ms += ms;
 			e.launches++;
 		}
-		(void) hipEventDestroy(p.a);
-		(void) hipEventDestroy(p.b);
+		c->ev_free.push_back(p.a);
+		c->ev_free.push_back(p.b);
 	}
 	c->prof_pending.clear();
 }

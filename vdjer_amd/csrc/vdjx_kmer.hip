@@ -1712,6 +1712,7 @@ int stage_finish(vdjx_ctx* c, A& db, const Survivors& sv, const u32* edge_first,
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
 	g->n_roots = n_roots;
+	vdjx_prof_collect(c);              // the stream is idle: every recorded event is complete, its pair goes back to the pool
 	return VDJX_OK;
 }
 

@@ -269,6 +269,7 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 	HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	vdjx_prof_collect(c);
 	return VDJX_OK;
 }
 
@@ -1092,6 +1093,7 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	vdjx_prof_collect(c);
 	c->stats["window_work_items"] = work.size();
 	{
 		u64 tot = 0;
@@ -1194,6 +1196,7 @@ extern "C" int vdjx_map_emit(vdjx_ctx* c, const char* contigs, size_t n, int len
 		HIP_TRY(hipMemcpyAsync(pairs, d_dense, (size_t) total * sizeof(vdjx_pair), hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
 		HIP_TRY(hipGetLastError());
+		vdjx_prof_collect(c);
 	}
 	c->me_key = 0;           // one counting call serves one writing call
 	return VDJX_OK;
