@@ -76,8 +76,7 @@ def write_bam(path: str, refs, records, block: int = BLOCK):
         s = len(stream)
         stream += encode_record(r)
         spans.append((s, len(stream)))
-    blocks, addr = [], []                       # compressed blocks, file address of each
-    at = 0
+    addr = []                                   # file address of every compressed block
     out = bytearray()
     for o in range(0, len(stream), block):
         addr.append(len(out))

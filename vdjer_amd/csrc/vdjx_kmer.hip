@@ -883,7 +883,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 	u32 S = 1;
 	while ((u64) S * (MERGE_SLOTS / 2) < total) S <<= 1;
 	S *= s_mult;
-	for (;;) {
+	{
 		if (tid == 0) { s_over = 0; s_ndist = 0; }
 		for (u32 sp = 0; sp < S; sp++) {
 			for (u32 i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE32; s_fl[i] = 0; s_nsg[i] = 0; s_pid[i] = NONE32; }
@@ -983,7 +983,6 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 		// a sub-pass that does not fit the table: earlier sub-passes have already appended their results, so the HOST
 		// resets the outputs and relaunches everything with a larger split (s_mult); rare by construction
 		if (s_over && tid == 0) atomicAdd(g_err, 1u);
-		break;
 	}
 	if (tid == 0) atomicAdd(g_distinct, (u64) s_ndist);
 }
