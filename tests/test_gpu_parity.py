@@ -377,6 +377,36 @@ def test_window_score_vs_oracle_seeded(ctx):
     p.free()
 
 
+def test_deep_windows_many_slices_and_multiplicities(ctx):
+    """One clone at very high depth with clean reads: tens of thousands of hits per window/contig (several MAP_SLICE slices of
+    k_map_emit, HIT_CHUNK slices of k_window_pairs) and large multiplicities in the weighted window entries.
+    Pairs, their order, counts and verdicts against the oracle."""
+    from oracle import oracle
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(2, seed=321)
+    pool = synth.tile_reads(rep, [0, 1], ins=175, copies=500, step=2)          # every second start, 500 identical pairs each
+    ix = oracle.ReadIndex(pool)
+    p = _load_index(ctx, pool)
+    wins = [w for w in rep.windows() if w] + [t[30:516] for t in rep.clones]
+    valid, npairs = ctx.window_score(wins, 175)
+    assert ctx.stat("window_hits") > 10 * ctx.stat("window_hits_distinct") > 0          # multiplicities at work
+    assert ctx.stat("window_hits_max") > 65536                                          # more than one slice of hits
+    for i, w in enumerate(wins):
+        pairs, starts = ix.quick_map(w)
+        assert int(npairs[i]) == len(pairs) > 10000, (i, int(npairs[i]), len(pairs))
+        assert int(valid[i]) == ix.coverage_is_valid(starts, len(w), 175)
+    contigs = [w[51:411] for w in wins]
+    offs, got = ctx.map_emit(contigs)
+    assert ctx.stat("map_hits") > 8 * 4096                                              # several slices per contig
+    for j, c in enumerate(contigs):
+        pairs, _ = ix.quick_map(c)
+        mine = got[int(offs[j]):int(offs[j + 1])]
+        assert mine.shape[0] == len(pairs) > 4096
+        for fld in ("pair_id", "rec1", "rec2", "pos1", "pos2", "insert", "rc1", "rc2"):
+            assert np.array_equal(mine[fld].astype(np.int64), pairs[fld].astype(np.int64)), (j, fld)
+    p.free()
+
+
 @pytest.mark.parametrize("world,k,mf,mq", [(2, 35, 3, 90), (4, 25, 2, 60), (2, 48, 2, 60), (8, 35, 2, 60)])
 def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq):
     """The real multi-rank driver + the HIP phase engine with `world` ranks on this one GPU (ranks are threads,
