@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- M paired-reads/s through the hot path (k-mer build + contig scoring), IgH, 50 bp PE.
+"""bench.py -- M paired-reads/s through the hot path (k-mer build + contig scoring), IgH 50 bp PE.
 
 One "step" = one pass of the hot path over one batch of synthetic reads already resident in HBM as the
 reference's ASCII pool records:
     pool_pack -> k-mer table + prune + graph (a-1..a-3, a-5/a-6) -> root scorer over every root of that
-    graph (a-7) -> window mapper + coverage test over the repertoire's candidate windows (a-8, a-9)
-    -> mapped-pair emission for the accepted contigs (a-10)
-Workload = BASELINE.json configs[1]: 1 M synthetic pairs (2,000 clones, Zipf 1.1, 30 % noise,
-k=35 mf=3 mq=90, --ins 175) per GPU.  With N GPUs every rank holds its own 1 M-pair shard of an N M-pair pool
-and the k-mer instances are exchanged by hash prefix (vdjer_amd/shard.py): weak scaling.
+    graph (a-7) -> window mapper + coverage test over the candidate windows the host traversal derives from
+    this pool's graph (a-8, a-9) -> mapped-pair emission for the final contigs (a-10)
+Default workload = BASELINE.json configs[2], the configuration the north-star target is quoted on: 10 M
+synthetic pairs (20,000 clones, Zipf 1.1, 30 % noise, k=35 mf=3 mq=90, --ins 175) on one GPU.
+`--pairs 1000000` is configs[1]; `--pairs 10000000 --k 25 --mf 2 --mq 60 --mrs 20` is configs[3].
+With N GPUs every rank holds its own pool of that size and the k-mer partial aggregates are exchanged by
+hash prefix (vdjer_amd/shard.py): weak scaling.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel of the step (HIP events on the
-library's stream) against HBM peak; `cpu_baseline` times the CPU oracle (a C port of the reference's
-algorithm, oracle/vdjx_oracle.c, -O2, 1 thread) on a bounded sample of the same workload.
+library's stream) against HBM peak; `cpu_baseline` times the REFERENCE ITSELF (oracle/_ref/vdjer_ref, the
+reference's own sources compiled -O0 as it ships, --t <host cores>) on a bounded sample of the same
+generator, or -- where that binary is absent -- the C port (oracle/vdjx_oracle.c).  Neither is ever part
+of the measured path.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -28,17 +34,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "vdjer_ref")
 
 
 def algorithmic_bytes_per_pair(k: int, rl: int = 50) -> dict:
-    """SURVEY §8d.  P = 4*(rl-k+1) instances per pair; per kernel:
-    scatter: packed input once (126 B) + one 16-B key per instance written;   aggregate: every key read once;
-    graph pass: packed input once more + one 16-B probe per instance."""
+    """SURVEY §8d.  P = 4*(rl-k+1) instances per pair; compulsory input of a pair = 2 reads x (packed bases + qualities).
+    Per kernel: what its JOB requires per pair, not what the implementation moves:
+      pack: the ASCII records in;  hist: the packed input once;  partition pass 1: packed input + one 16-B key per instance
+      out;  pass 2: every key in and out;  aggregate / local: every key in;  finalize: every key in (upper bound);
+      edges: packed input once more + one 16-B probe per instance."""
     P = 4 * (rl - k + 1)
     inp = 2 * ((rl + 3) // 4 + rl)
     return {"P": P, "input": inp, "total": inp + 32 * P + inp + 16 * P,
             "k_pool_pack": 4 * (2 * rl + 1), "k_kmer_hist": inp, "k_part_records": inp + 16 * P, "k_part_tuples": 32 * P,
-            "k_bucket_aggregate": 16 * P, "k_bucket_finalize": 16 * P, "k_graph_edges": inp + 16 * P}
+            "k_seg_hist": 16 * P, "k_bucket_aggregate": 16 * P, "k_bucket_local": 16 * P, "k_bucket_finalize": 16 * P,
+            "k_graph_edges": inp + 16 * P,
+            # super-k-mer build (round 2): same jobs, same algorithmic bytes -- the 16-B-per-instance figure is the
+            # SURVEY's compulsory key traffic whatever the representation moved
+            "k_skm_scan": inp + 16 * P, "k_skm_part": 32 * P, "k_skm_aggregate": 16 * P}
 
 
 def scorer_bytes(stats: dict, n_windows: int, n_contigs: int, k: int, rl: int = 50, wlen: int = 486, clen: int = 360) -> dict:
@@ -52,37 +65,102 @@ def scorer_bytes(stats: dict, n_windows: int, n_contigs: int, k: int, rl: int = 
             "k_root_dp": 3 * k * stats.get("root_dp_items", 0)}
 
 
-def make_workload(n_pairs: int, n_clones: int, seed: int, rank: int, world: int = 1):
+def workload_label(pairs: int, k: int, mf: int, mq: int, mrs: int, ins: int, world: int) -> str:
+    if world > 1:
+        tag = f"weak scaling of BASELINE.json configs[2]-sized pools over {world} GPUs (configs[4] is {world}x12.5 M)" if pairs >= 10_000_000 else "custom"
+    elif pairs == 10_000_000 and (k, mf, mq) == (35, 3, 90):
+        tag = "BASELINE.json configs[2]; SURVEY §8d C3"
+    elif pairs == 10_000_000 and (k, mf, mq) == (25, 2, 60):
+        tag = "BASELINE.json configs[3]; SURVEY §8d C4" + (" with --mrs 20" if mrs == 20 else "")
+    elif pairs == 1_000_000 and (k, mf, mq) == (35, 3, 90):
+        tag = "BASELINE.json configs[1]; SURVEY §8d C2"
+    else:
+        tag = "custom size"
+    return f"synthetic {pairs} 50bp PE pairs per GPU, IGH, k={k} mf={mf} mq={mq} mrs={mrs} ins={ins} ({tag})"
+
+
+def make_workload(n_pairs: int, n_clones: int, seed: int, rank: int, world: int, device: str):
     """Rank r holds its own library: n_pairs read pairs from n_clones clones over its own germline (rank 0: exactly the
     one-GPU workload).  N GPUs = N independent libraries processed as ONE job (one k-mer table, one graph, one traversal):
     N x pairs, N x clones, and a ref-dir that is the union of the N germlines, so the per-GPU work stays what it is on one
-    GPU -- the definition of weak scaling (SURVEY §8d scales clones with pairs the same way: 1 M / 2,000 ... 100 M / 100,000)."""
+    GPU -- the definition of weak scaling (SURVEY §8d scales clones with pairs the same way: 1 M / 2,000 ... 100 M / 100,000).
+    The pool is generated in HBM by the counter-based generator (bit-identical to its CPU evaluation)."""
     from vdjer_amd import synth
     libs = [synth.make_repertoire(n_clones, seed=seed + 15485863 * r) for r in range(world)]
     rep = libs[rank]
-    pool = synth.make_reads(rep, n_pairs, noise_frac=0.3, seed=seed + 7919 + 104729 * rank)
+    pool = synth.make_reads_cb(rep, n_pairs, noise_frac=0.3, seed=seed + 104729 * rank, device=device)
     vc = np.array(sorted({synth.seq_to_int(a) for lb in libs for a in lb.v_anchors}), dtype=np.uint32)
     jc = np.array(sorted({synth.seq_to_int(a) for lb in libs for a in lb.j_anchors}), dtype=np.uint32)
-    wins = [w for lb in libs for w in lb.windows() if w]
-    return rep, pool, vc, jc, wins, [lb.v_region for lb in libs]
+    return rep, pool, vc, jc, [lb.v_region for lb in libs]
 
 
-def cpu_baseline(rep, vc, jc, wins, n_sample: int, k: int, mf: int, mq: int, ins: int, seed: int) -> dict:
-    """The same step on the CPU oracle (test infrastructure used here only as the timed baseline)."""
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N=1 only; bounded samples of the same generator)
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_reference(n_sample: int, seed: int, k: int, mf: int, mq: int, mrs: int, ins: int, threads: int) -> dict | None:
+    """The reference itself: its own sources compiled where they lie (oracle/Makefile, -O0 exactly like the reference's
+    Makefile:8), whole `assemble` (A2:1350-1507) with --t <threads>, on a pool of n_sample pairs of the same generator
+    (clones scaled 1 per 500 pairs like configs[1..4]).  Timed from the PRE_PRE_GRAPH1 marker (the pools are extracted,
+    A2:1388) to FINIS (A2:1473): k-mer table, prune, graph, traversal with the root / window scorers inside, SAM mapping."""
+    if not os.path.exists(REF_BIN):
+        return None
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(max(4, n_sample // 500), seed=seed)
+    pool = synth.make_reads_cb(rep, n_sample, noise_frac=0.3, seed=seed + 13)
+    with tempfile.TemporaryDirectory() as td:
+        pool.write_reads_file(os.path.join(td, "reads.txt"))
+        synth.write_ref_dir(rep, os.path.join(td, "ref"))
+        cmd = [REF_BIN, "run", "--in", "reads.txt", "--chain", "IGH", "--ref-dir", "ref", "--ins", str(ins), "--t", str(threads),
+               "--k", str(k), "--mf", str(mf), "--mq", str(mq), "--mrs", str(mrs)]
+        marks = {}
+        with open(os.path.join(td, "sam.out"), "wb") as so:
+            pr = subprocess.Popen(cmd, cwd=td, stdout=so, stderr=subprocess.PIPE, text=True, errors="replace")
+            for line in pr.stderr:
+                if line.startswith("ELAPSED_SECS\t"):
+                    marks.setdefault(line.split("\t")[1], time.perf_counter())
+            pr.wait()                 # (the exit status is meaningless: the reference's main falls off its end, SURVEY §0-2)
+        n_contigs = sum(1 for l in open(os.path.join(td, "vdj_contigs.fa")) if l.startswith(">")) if os.path.exists(os.path.join(td, "vdj_contigs.fa")) else -1
+    if "PRE_PRE_GRAPH1" not in marks or "FINIS" not in marks:
+        return None
+
+    def span(a, b):
+        return round(marks[b] - marks[a], 2) if a in marks and b in marks else None
+    secs = marks["FINIS"] - marks["PRE_PRE_GRAPH1"]
+    return {"value": n_sample / secs / 1e6, "unit": "M paired-reads/s", "cores": threads, "kind": "reference",
+            "sample": f"{n_sample} pairs / {len(rep.clones)} clones of the same generator through oracle/_ref/vdjer_ref "
+                      f"(the reference's own sources, g++ -O0 as it ships; -O1+ crashes on its missing returns, SURVEY §0-2), --t {threads}: "
+                      f"k-mer table {span('PRE_PRE_GRAPH1', 'POST_PRE_GRAPH1')}s (1 thread by construction, A2:1388-1390), prune "
+                      f"{span('POST_PRE_GRAPH1', 'POST_PRUNE_PRE_GRAPH1')}s, graph {span('POST_PRUNE_PRE_GRAPH1', 'POST_BUILD_GRAPH2')}s, "
+                      f"traversal + root/window scorers on {threads} threads {span('POST_BUILD_GRAPH2', 'THREADS_DONE')}s, SAM mapping "
+                      f"{span('THREADS_DONE', 'PRE_CLEANUP')}s; {n_contigs} contigs; includes the host traversal, which `value` does not "
+                      f"(see host_side)",
+            "seconds": round(secs, 2)}
+
+
+def cpu_port(n_sample: int, seed: int, k: int, mf: int, mq: int, mrs: int, ins: int, opt0: bool) -> dict:
+    """The C port of the reference's algorithm (oracle/vdjx_oracle.c; test infrastructure, used here only as a timed baseline)
+    on the same sample: k-mer table + prune + graph, every root scored, one window per clone mapped + validated, the valid
+    ones mapped again for the SAM records.  1 thread."""
     from oracle import oracle
     from vdjer_amd import synth
-    pool = synth.make_reads(rep, n_sample, noise_frac=0.3, seed=seed + 13)
+    L = oracle.lib(opt0=True) if opt0 else oracle.lib()
+    rep = synth.make_repertoire(max(4, n_sample // 500), seed=seed)
+    pool = synth.make_reads_cb(rep, n_sample, noise_frac=0.3, seed=seed + 13)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    wins = [w for w in rep.windows() if w]
     t0 = time.perf_counter()
-    tb = oracle.KmerTable(pool, k)
+    tb = oracle.KmerTable(pool, k, L=L)
     tb.prune(mf, mq)
     g = oracle.Graph(tb, vc, jc)
     t1 = time.perf_counter()
-    sc = oracle.RootScorer([rep.v_region], 15)
+    sc = oracle.RootScorer([rep.v_region], 15, L=L)
     roots = [oracle.inst_kmer(pool, int(g.first[i]), k) for i in np.flatnonzero(g.from_deg == 0)]
-    n_ok = sum(sc.score(r, 30) for r in roots)
+    t1b = time.perf_counter()
+    n_ok = sum(sc.score(r, mrs) for r in roots)
     t2 = time.perf_counter()
-    ix = oracle.ReadIndex(pool)
-    t3 = time.perf_counter()           # index build is part of extraction in the reference: not timed
+    ix = oracle.ReadIndex(pool, L=L)
+    t3 = time.perf_counter()           # the index belongs to extraction in the reference (bam_read.c:228,243): not timed
     nvalid = 0
     contigs = []
     for w in wins:
@@ -93,41 +171,60 @@ def cpu_baseline(rep, vc, jc, wins, n_sample: int, k: int, mf: int, mq: int, ins
     for c in contigs:
         ix.quick_map(c)
     t4 = time.perf_counter()
-    secs = (t1 - t0) + (t2 - t1) + (t4 - t3)
+    secs = (t1 - t0) + (t2 - t1b) + (t4 - t3)
     return {"value": n_sample / secs / 1e6, "unit": "M paired-reads/s", "cores": 1, "kind": "port",
-            "sample": f"{n_sample} pairs of the same generator: kmer+prune+graph {t1 - t0:.2f}s, {len(roots)} roots "
-                      f"({n_ok} accepted) {t2 - t1:.2f}s, {len(wins)} windows ({nvalid} valid) + SAM mapping {t4 - t3:.2f}s; "
-                      "oracle/vdjx_oracle.c -O2, 1 thread (the reference's k-mer build is single-threaded, A2:1388-1408)",
-            "seconds": secs}
+            "sample": f"{n_sample} pairs / {len(rep.clones)} clones: kmer+prune+graph {t1 - t0:.2f}s, {len(roots)} roots ({n_ok} accepted) "
+                      f"{t2 - t1b:.2f}s, {len(wins)} windows ({nvalid} valid) + SAM mapping {t4 - t3:.2f}s; oracle/vdjx_oracle.c "
+                      f"{'-O0' if opt0 else '-O2'}, 1 thread, no traversal",
+            "seconds": round(secs, 2)}
+
+
+def load_traffic(args, world: int, kernel: str):
+    """PMC-measured HBM bytes per launch of `kernel` from the committed rocprofv3 pass of the same command
+    (profiles/r02_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections, see profiles/README.md)."""
+    tf = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if not os.path.exists(tf):
+        return None
+    tj = json.load(open(tf))
+    same = (tj.get("pairs_per_gpu") == args.pairs and tj.get("k") == args.k and tj.get("windows", "traversal") == args.windows and world == 1)
+    if not same:
+        return None
+    for name, v in tj.get("kernels", {}).items():
+        if name.split("<")[0] == kernel:
+            return v["hbm_bytes"]
+    return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=1_000_000, help="pairs per GPU")
-    ap.add_argument("--clones", type=int, default=2000)
+    ap.add_argument("--pairs", type=int, default=10_000_000, help="pairs per GPU")
+    ap.add_argument("--clones", type=int, default=0, help="clones per GPU (default: pairs / 500)")
     ap.add_argument("--k", type=int, default=35)
     ap.add_argument("--mf", type=int, default=3)
     ap.add_argument("--mq", type=int, default=90)
     ap.add_argument("--mrs", type=int, default=30)
     ap.add_argument("--ins", type=int, default=175)
     ap.add_argument("--seed", type=int, default=20261002)
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="pairs the CPU oracle is timed on (default: the whole workload)")
+    ap.add_argument("--cpu-sample", type=int, default=400_000, help="pairs the reference is timed on")
+    ap.add_argument("--cpu-port-sample", type=int, default=200_000, help="pairs the C port is timed on (-O2 and -O0 legs)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--force-shard", action="store_true",
                     help="N=1 only: run the k-mer build through the multi-GPU phases (one-rank RCCL group) to time its kernels; not the line of record")
     ap.add_argument("--windows", choices=["traversal", "generator"], default="traversal",
                     help="scorer inputs: the candidate windows/contigs the host traversal derives from the graph (default), "
                          "or one window per clone straight from the generator")
-    ap.add_argument("--parity-sample", type=int, default=20000, help="records of the 1 %% parity gate (SURVEY §8d)")
+    ap.add_argument("--parity-sample", type=int, default=20000, help="pairs of the parity gate (SURVEY §8d)")
     args = ap.parse_args()
+    if args.clones <= 0:
+        args.clones = max(4, args.pairs // 500)
 
     import torch
     import torch.distributed as dist
 
-    # the step hands ~25 MB of results to the host (graph arrays, mapped pairs); with glibc's default mmap threshold
+    # the step hands tens of MB of results to the host (graph arrays, mapped pairs); with glibc's default mmap threshold
     # every such buffer is a fresh mapping (page faults + munmap per step).  Keep them on the heap instead.
     try:
         import ctypes
@@ -164,14 +261,15 @@ def main():
 
     from vdjer_amd import api
 
-    rep, pool, vc, jc, wins, v_lines = make_workload(args.pairs, args.clones, args.seed, rank, world)
+    t_gen = time.perf_counter()
+    rep, pool, vc, jc, v_lines = make_workload(args.pairs, args.clones, args.seed, rank, world, f"cuda:{local_rank}")
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
     rl = pool.rl
     ctx = api.Context(local_rank, pinned_results=True)
     ctx.anchor_sets_load(vc, jc)
     ctx.vregion_load(v_lines, 15)
-    d_pri = torch.from_numpy(pool.primary).to(dev)
-    d_sec = torch.from_numpy(pool.secondary).to(dev)
-    torch.cuda.synchronize()
+    d_pri, d_sec = pool.primary, pool.secondary
 
     if world > 1 or args.force_shard:
         from vdjer_amd import shard
@@ -181,9 +279,11 @@ def main():
         engine = cm = None
 
     state = {}
+    host_side = {"pool_generate_s": round(t_gen, 2)}
     # the read index belongs to extraction in the reference (add_read_info is called from extract, bam_read.c:228,243):
     # built once, outside the timed region, over a pool handle that stays alive.  With several GPUs every rank
     # holds the index of the WHOLE pool (replicate the index, shard the windows: no communication).
+    t_ix = time.perf_counter()
     if world == 1:
         p_index = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
         ctx.read_index_build(p_index, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
@@ -202,11 +302,11 @@ def main():
         p_index = ctx.pool_load_device(0, 0, allrec.data_ptr(), allrec.shape[0], rl)
         ctx.read_index_build(p_index, g_pair, g_rnum, g_rc, g_rank, args.pairs * world)
         del allrec, mine
+    host_side["read_index_build_s"] = round(time.perf_counter() - t_ix, 2)
     scorer_src = "one window per clone from the generator"
     if args.windows == "traversal":
         # the windows the reference would hand to quick_map/coverage for THIS pool: run the serial host stage once,
         # outside the timed region, and keep what it asked the scorers (identical on every rank)
-        import tempfile
         from vdjer_amd import host
         p0 = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
         g0 = engine.kmer_build(p0, args.k, args.mf, args.mq) if engine else ctx.kmer_build(p0, args.k, args.mf, args.mq)
@@ -225,10 +325,16 @@ def main():
             fa = open(os.path.join(td, "c.fa")).read().split("\n")
         wins = asked
         contigs_fixed = [fa[i] for i in range(1, len(fa), 2)]
-        scorer_src = (f"host traversal of this pool's graph ({t_tr:.1f}s serial, untimed): {st_tr['n_contig_candidates']} contig candidates "
-                      f"-> {len(wins)} distinct windows, {len(contigs_fixed)} final contigs")
+        host_side["traversal_s"] = round(t_tr, 2)
+        scorer_src = (f"host traversal of this pool's graph ({t_tr:.1f}s serial incl. its scorer calls, untimed): {st_tr['n_contig_candidates']} contig "
+                      f"candidates -> {len(wins)} distinct windows, {len(contigs_fixed)} final contigs")
         del g0
     else:
+        libs_w = [w for w in rep.windows() if w]
+        if world > 1:
+            from vdjer_amd import synth
+            libs_w = [w for r in range(world) for w in synth.make_repertoire(args.clones, seed=args.seed + 15485863 * r).windows() if w]
+        wins = libs_w
         contigs_fixed = None
     my_wins = wins[rank::world]
     my_contigs = contigs_fixed[rank::world] if contigs_fixed is not None else None
@@ -248,7 +354,7 @@ def main():
         wall[name] = wall.get(name, 0.0) + (time.perf_counter() - t)
         return time.perf_counter()
 
-    def step(first: bool = False):
+    def step():
         t = time.perf_counter()
         p = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
         t = lap("pool_pack", t)
@@ -284,8 +390,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(first=(i == 0))
+    for _ in range(args.warmup):
+        step()
     ctx.profile(os.environ.get("VDJX_BENCH_NO_EVENTS") != "1")      # (diagnostic switch: what the per-kernel HIP events cost)
     ctx.profile_reset()
     wall.clear()
@@ -310,13 +416,13 @@ def main():
         cm.all_reduce(tt, dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- parity gate inside the benchmark: a record sample re-checked against the oracle
+    # ---- parity gate inside the benchmark: a sample of the same generator re-checked against the oracle
     parity = None
     if rank == 0 and args.parity_sample > 0 and world == 1:
         from oracle import oracle
         from vdjer_amd import synth
         n_s = min(args.parity_sample, args.pairs)
-        sp = synth.make_reads(rep, n_s, noise_frac=0.3, seed=args.seed + 99)
+        sp = synth.make_reads_cb(rep, n_s, noise_frac=0.3, seed=args.seed + 99)
         pp = ctx.pool_load(sp.primary, sp.secondary, rl)
         hg = ctx.kmer_build(pp, args.k, args.mf, args.mq)
         pp.free()
@@ -341,44 +447,47 @@ def main():
         avg_ms = dom[1][0] / max(1, dom[1][1])
         launches_per_step = dom[1][1] / args.steps
         sb = scorer_bytes(stats, len(my_wins), state.get("n_contigs_rank", 0), args.k, rl)
+        per_pair = None
         if dom[0] in sb:
             bytes_per_launch = sb[dom[0]] / max(1.0, launches_per_step)
-            per_pair = None
-        else:
-            per_pair = ab.get(dom[0], ab["total"])
+        elif dom[0] in ab:
+            per_pair = ab[dom[0]]
             bytes_per_launch = per_pair * args.pairs / max(1.0, launches_per_step)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tf):     # PMC pass of the same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE), see profiles/README.md
-            tj = json.load(open(tf))
-            same = tj.get("pairs_per_gpu", 1_000_000) == args.pairs and args.windows == "traversal" and args.k == 35 and world == 1
-            tk = tj.get("kernels", {}) if same else {}        # counters were collected on the default workload only
-            for name, v in tk.items():
-                if name.split("<")[0] == dom[0]:
-                    traffic = v["hbm_bytes"]
-        roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
-                "algorithmic_bytes_per_launch": int(bytes_per_launch), "algorithmic_bytes_per_pair": per_pair,
+        else:
+            bytes_per_launch = None          # a kernel without a stated job size is not priced (never the whole path's bytes)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if bytes_per_launch else None
+        roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": load_traffic(args, world, dom[0]),
+                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch) if bytes_per_launch else None,
+                "algorithmic_bytes_per_pair": per_pair,
                 "hot_path_frac": round(ab["total"] * args.pairs / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
     cpu = None
+    cpu_port_legs = None
     if not args.no_cpu and world == 1:
-        cpu = cpu_baseline(rep, vc, jc, wins, min(args.cpu_sample, args.pairs), args.k, args.mf, args.mq, args.ins, args.seed)
+        ncores = min(os.cpu_count() or 1, 100)          # `thread_info threads[100]`, A2:1285
+        cpu = cpu_reference(min(args.cpu_sample, args.pairs), args.seed, args.k, args.mf, args.mq, args.mrs, args.ins, ncores)
+        cpu_port_legs = [cpu_port(min(args.cpu_port_sample, args.pairs), args.seed, args.k, args.mf, args.mq, args.mrs, args.ins, o0)
+                         for o0 in (False, True)]
+        if cpu is None:           # no compiled reference on this box: the -O2 port is the stated baseline
+            cpu = cpu_port_legs[0]
+    kern_ms = {k_: round(v[0] / args.steps, 4) for k_, v in prof.items()}
     out = {
         "metric": "M paired-reads/sec (k-mer build + contig score), IgH 50bp PE", "value": round(value, 4),
         "unit": "M paired-reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8/u64 (2-bit packed bases, integer counts)", "data": "synthetic",
-        "config": {"workload": f"synthetic {args.pairs} 50bp PE pairs per GPU, IGH, k={args.k} mf={args.mf} mq={args.mq} "
-                               f"ins={args.ins} (BASELINE.json configs[1]; SURVEY §8d C2)",
+        "config": {"workload": workload_label(args.pairs, args.k, args.mf, args.mq, args.mrs, args.ins, world),
                    "pairs_per_gpu": args.pairs, "clones_per_gpu": args.clones, "noise": 0.3, "parallelism": f"hash-prefix x{world}",
                    "multi_gpu_input": "one independent library (own germline, clones, reads) per GPU; ONE k-mer table / graph / traversal over all of them",
                    "scorer_inputs": scorer_src},
-        "roofline": roof, "cpu_baseline": cpu,
-        "kernels_ms_per_step": {k_: round(v[0] / args.steps, 4) for k_, v in prof.items()},
+        "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_port_legs": cpu_port_legs,
+        "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
+        "kernels_ms_per_step": kern_ms, "kernels_sum_ms_per_step": round(sum(kern_ms.values()), 3),
+        "device_busy_frac": round(sum(kern_ms.values()) / ms_step, 4) if ms_step else None,
         "exchange_bytes_per_step_rank0": ((engine.bytes_exchanged - bytes_before) // args.steps) if engine else 0,
         "shard_wall_ms_per_step": ({k_: round(v / args.steps * 1e3, 3) for k_, v in engine.laps.items()} if engine else None),
         "wall_ms_per_step": {k_: round(v / args.steps * 1e3, 3) for k_, v in wall.items()},
+        "host_side": host_side,
         "counts": {k_: v for k_, v in state.items() if k_ != "graph"}, "scorer_stats": stats,
         "shard_stats_rank0": ({n_: ctx.stat("shard_" + n_) for n_ in ("partials_received", "open_kmers", "questions", "decided_at_merge",
                                                                     "kept_after_answers")} if engine else None),

@@ -325,3 +325,163 @@ def tile_reads(rep: Repertoire, clone_ids, ins: int = 175, copies: int = 3, rl: 
     within = np.tile(np.arange(4, dtype=np.uint32), R // 4)
     return ReadPool(rl, primary, secondary, pair_id, (1 + within // 2).astype(np.uint8), (within & 1).astype(np.uint8),
                     (pair_id * 4 + within).astype(np.uint32), n)
+
+
+# ----------------------------------------------------------------------------------------------
+# Counter-based generator (BASELINE-sized workloads).
+#
+# make_reads() above draws from one sequential numpy stream: 15 s per million pairs on one core, and only on the
+# host.  The 10 M-pair configurations are generated by the function below instead: every random decision is a
+# 64-bit hash of (seed, pair index, slot), evaluated with integer tensor arithmetic only, so the SAME pool comes
+# out of torch on the CPU (build container: oracle digests, CPU baseline sample) and on the GPU (bench.py and the
+# full-size parity tests generate 10 M pairs in HBM in well under a second).  Same read model as make_reads
+# (SURVEY §8d): Zipf clone choice, insert ~ 175 +- 10 clipped to [120, 240], 50 % orientation swap, 0.2 %
+# substitutions, Phred {40: 85 %, 30: 10 %, 12: 5 %}, 0.1 % N, `noise_frac` uniform random pairs in the secondary pool.
+# ----------------------------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+def _s64(x: int) -> int:
+    """two's-complement int64 view of a 64-bit constant"""
+    x &= _M64
+    return x - (1 << 64) if x >> 63 else x
+
+
+_SM_A, _SM_B, _GOLD = _s64(0xBF58476D1CE4E5B9), _s64(0x94D049BB133111EB), _s64(0x9E3779B97F4A7C15)
+
+
+def _lsr(x, s: int):
+    """logical right shift of int64 tensors"""
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def _sm64(x):
+    """splitmix64 finalizer on int64 tensors (wrapping multiplication)"""
+    x = (x ^ _lsr(x, 30)) * _SM_A
+    x = (x ^ _lsr(x, 27)) * _SM_B
+    return x ^ _lsr(x, 31)
+
+
+def _sm64_py(x: int) -> int:
+    """the same on Python integers (tests pin the tensor arithmetic against it)"""
+    x &= _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+@dataclass
+class DeviceReadPool:
+    """make_reads_cb(..., device=cuda): the pools stay in HBM (torch uint8 tensors [R, 2*rl+1]); the per-record read
+    info is small and lives on the host like ReadPool's."""
+    rl: int
+    primary: object
+    secondary: object
+    pair_id: np.ndarray
+    read_num: np.ndarray
+    is_rc: np.ndarray
+    reg_rank: np.ndarray
+    n_pairs: int
+
+    @property
+    def n_records(self) -> int:
+        return int(self.primary.shape[0] + self.secondary.shape[0])
+
+    def to_host(self) -> ReadPool:
+        return ReadPool(self.rl, self.primary.cpu().numpy(), self.secondary.cpu().numpy(), self.pair_id, self.read_num,
+                        self.is_rc, self.reg_rank, self.n_pairs)
+
+
+def make_reads_cb(rep: Repertoire, n_pairs: int, noise_frac: float = 0.3, rl: int = 50, seed: int = 20261002,
+                  device: str = "cpu", chunk: int | None = None, pair0: int = 0):
+    """Counter-based pool of pairs [pair0, pair0 + n_pairs) of the stream `seed`: ReadPool (device='cpu') or
+    DeviceReadPool.  Bit-identical on every device; a sub-range equals the same pairs of a larger call."""
+    import torch
+    dev = torch.device(device)
+    on_gpu = dev.type == "cuda"
+    if chunk is None:
+        chunk = (1 << 20) if on_gpu else (1 << 17)
+    C = len(rep.clones)
+    lens_np = np.array([len(t) for t in rep.clones], dtype=np.int64)
+    lmax = int(lens_np.max())
+    T = np.zeros((C, lmax), dtype=np.uint8)
+    for i, t in enumerate(rep.clones):
+        T[i, :len(t)] = np.frombuffer(t.encode(), dtype=np.uint8)
+    lut = np.zeros(256, np.uint8)
+    for ch, v in _IDX.items():
+        lut[ord(ch)] = v
+    Tflat = torch.from_numpy(lut[T].reshape(-1)).to(dev)
+    lens = torch.from_numpy(lens_np).to(dev)
+    cdf = np.cumsum(rep.weights)
+    cdf_i = np.minimum(np.floor(cdf * float(1 << 53)), float((1 << 53) - 1)).astype(np.int64)
+    cdf_i[-1] = (1 << 53) - 1
+    cdf_t = torch.from_numpy(cdf_i).to(dev)
+    acgt = torch.from_numpy(ACGT.copy()).to(dev)
+    comp = torch.tensor([3, 2, 1, 0], dtype=torch.uint8, device=dev)
+    qchars = torch.tensor([40 + 33, 30 + 33, 12 + 33], dtype=torch.uint8, device=dev)
+    noise_thr = int(round(noise_frac * 65536))
+    seedc = _s64(_sm64_py(seed * 0x9E3779B97F4A7C15 + 0x1234567))
+    rec_len = 2 * rl + 1
+    slot = (torch.arange(2, device=dev, dtype=torch.int64)[:, None] * 64 + torch.arange(rl, device=dev, dtype=torch.int64)[None, :] + 8)
+    slot = (slot * _GOLD)[None, :, :]                                   # [1, 2, rl]
+    ar = torch.arange(rl, device=dev, dtype=torch.int64)
+    pri_parts, sec_parts, noise_parts = [], [], []
+    for c0 in range(0, n_pairs, chunk):
+        m = min(chunk, n_pairs - c0)
+        p = torch.arange(pair0 + c0, pair0 + c0 + m, device=dev, dtype=torch.int64)
+        hp = _sm64(p * _GOLD + seedc)
+        noise = (hp & 0xFFFF) < noise_thr
+        swap = (_lsr(hp, 16) & 1) == 1
+        h2, h3, h4 = _sm64(hp + _GOLD), _sm64(hp + _s64(2 * 0x9E3779B97F4A7C15)), _sm64(hp + _s64(3 * 0x9E3779B97F4A7C15))
+        clone = torch.clamp(torch.searchsorted(cdf_t, _lsr(h2, 11), right=True), max=C - 1)
+        s4 = (h3 & 0xFFFF) + (_lsr(h3, 16) & 0xFFFF) + (_lsr(h3, 32) & 0xFFFF) + (_lsr(h3, 48) & 0xFFFF)
+        # sum of four uniforms: sd = 65536 * sqrt(4/12); scaled to sd 10 around 175 with integer arithmetic
+        ins = 175 + torch.div((s4 - 131070) * 17321 + 32768 * 1000, 65536 * 1000, rounding_mode="floor")
+        ins = torch.minimum(torch.clamp(ins, 120, 240), lens[clone])
+        start = _lsr(_lsr(h4, 32) * (lens[clone] - ins + 1), 32)
+        hb = _sm64(hp[:, None, None] + slot)                           # [m, 2, rl]
+        base = (hb & 3).to(torch.uint8)                                # noise pairs: uniform bases
+        gb = clone * lmax + start
+        f1 = Tflat[gb[:, None] + ar[None, :]]
+        f2 = comp[Tflat[(gb + ins - rl)[:, None] + (rl - 1 - ar)[None, :]].long()]
+        ca = torch.where(swap[:, None], f2, f1)
+        cb = torch.where(swap[:, None], f1, f2)
+        cl = torch.stack([ca, cb], dim=1)                              # [m, 2, rl]
+        err = (_lsr(hb, 26) & 0x1FF) == 0                              # 1/512 = 0.195 %
+        sub = (((_lsr(hb, 35) & 0xFFFF) * 3) >> 16).to(torch.uint8) + 1
+        cl = torch.where(err, (cl + sub) & 3, cl)
+        base = torch.where(noise[:, None, None], base, cl)
+        a = acgt[base.long()]
+        a = torch.where((_lsr(hb, 16) & 0x3FF) == 0, torch.full_like(a, ord("N")), a)       # 1/1024 = 0.098 %
+        qu = _lsr(hb, 8) & 0xFF
+        q = qchars[((qu >= 218).to(torch.int64) + (qu >= 243).to(torch.int64))]             # 85.2 / 9.8 / 5.1 %
+        recs = torch.empty((m, 4, rec_len), dtype=torch.uint8, device=dev)
+        recs[:, :, 0] = ord("0")
+        ca_ = torch.full((256,), 0, dtype=torch.uint8, device=dev)
+        ca_[:] = torch.arange(256, device=dev, dtype=torch.uint8)
+        for x, y in (("A", "T"), ("T", "A"), ("C", "G"), ("G", "C")):
+            ca_[ord(x)] = ord(y)
+        for mate in (0, 1):
+            recs[:, 2 * mate, 1:1 + rl] = a[:, mate]
+            recs[:, 2 * mate, 1 + rl:] = q[:, mate]
+            recs[:, 2 * mate + 1, 1:1 + rl] = ca_[a[:, mate].flip(1).long()]
+            recs[:, 2 * mate + 1, 1 + rl:] = q[:, mate].flip(1)
+        pri_parts.append(recs[~noise].reshape(-1, rec_len))
+        sec_parts.append(recs[noise].reshape(-1, rec_len))
+        noise_parts.append(noise.cpu().numpy())
+        del hb, base, cl, a, q, qu, recs, f1, f2, ca, cb, err, sub
+    z = torch.zeros((0, rec_len), dtype=torch.uint8, device=dev)
+    primary = torch.cat(pri_parts) if pri_parts else z
+    secondary = torch.cat(sec_parts) if sec_parts else z
+    del pri_parts, sec_parts
+    is_noise = np.concatenate(noise_parts) if noise_parts else np.zeros(0, bool)
+    pair_idx = np.arange(n_pairs, dtype=np.uint32)
+    pair_id = np.concatenate([np.repeat(pair_idx[~is_noise], 4), np.repeat(pair_idx[is_noise], 4)])
+    R = pair_id.shape[0]
+    within = np.tile(np.arange(4, dtype=np.uint32), R // 4)
+    read_num = (1 + within // 2).astype(np.uint8)
+    is_rc = (within & 1).astype(np.uint8)
+    reg_rank = (pair_id.astype(np.uint64) * 4 + within).astype(np.uint32)
+    if on_gpu:
+        return DeviceReadPool(rl, primary, secondary, pair_id, read_num, is_rc, reg_rank, n_pairs)
+    return ReadPool(rl, primary.numpy(), secondary.numpy(), pair_id, read_num, is_rc, reg_rank, n_pairs)
