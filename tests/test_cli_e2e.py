@@ -24,16 +24,22 @@ def _write_inputs(c, d):
     open(os.path.join(d, "ref", "ig_vdj.fa"), "w").write(">x\nACGT\n")
 
 
-@pytest.mark.parametrize("tag", ["e2e_tiled", "e2e_mixed", "e2e_k25"])
+@pytest.mark.parametrize("tag", ["e2e_tiled", "e2e_mixed", "e2e_k25", "e2e_igk", "e2e_igl"])
 def test_vdjer_cli_matches_reference(tag, tmp_path):
+    """e2e_igk / e2e_igl: --chain IGK / IGL (set_chain_info, params.c:20-31: J residue F, CDR3 window 0-60)"""
     exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
     assert os.path.exists(exe), "build it: make -C vdjer_amd/csrc/host"
     c = G.Case(tag)
-    info = G.manifest()["e2e"][tag]
+    m = G.manifest()
+    info = m["e2e"][tag] if tag in m["e2e"] else m["e2e_chains"][tag]
     _write_inputs(c, str(tmp_path))
-    cmd = [exe, "--in", "reads.txt", "--chain", "IGH", "--ref-dir", "ref", "--ins", "175", "--t", "1"] + info["flags"]
+    cmd = [exe, "--in", "reads.txt", "--chain", info.get("chain", "IGH"), "--ref-dir", "ref", "--ins", "175", "--t", "1"] + info["flags"]
     r = subprocess.run(cmd, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
+    # the ELAPSED_SECS stage log carries the reference's marker names in the reference's order (status.c:22-32, A2:1387-1473)
+    import json
+    marks = [l.split("\t")[1] for l in r.stderr.splitlines() if l.startswith("ELAPSED_SECS\t")]
+    assert marks == json.load(open(os.path.join(G.GOLD, "stage_markers.json")))["markers"]
     assert (tmp_path / "vdj_contigs.fa").read_text() == G.text(f"{tag}.contigs.fa.gz")
     assert r.stdout == G.text(f"{tag}.sam.gz")
     assert (tmp_path / "vdjer.dot").read_text() == G.text(f"{tag}.dot.gz")

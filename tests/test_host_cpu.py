@@ -106,13 +106,19 @@ def _oracle_hooks(pool, v_region, p):
     return root_score, window_score, sam_body
 
 
-@pytest.mark.parametrize("tag", ["e2e_tiled", "e2e_mixed", "e2e_k25"])
+def _e2e_info(tag):
+    m = G.manifest()
+    return m["e2e"][tag] if tag in m["e2e"] else m["e2e_chains"][tag]
+
+
+@pytest.mark.parametrize("tag", ["e2e_tiled", "e2e_mixed", "e2e_k25", "e2e_igk", "e2e_igl"])
 def test_host_stage_end_to_end_vs_reference(tag, tmp_path):
-    """graph (from the oracle) -> host stage -> vdj_contigs.fa, SAM and vdjer.dot byte-identical to the reference's"""
+    """graph (from the oracle) -> host stage -> vdj_contigs.fa, SAM and vdjer.dot byte-identical to the reference's
+    (e2e_igk / e2e_igl: the light-chain presets of set_chain_info, params.c:20-31)"""
     c = G.Case(tag)
-    info = G.manifest()["e2e"][tag]
+    info = _e2e_info(tag)
     fl = G.flags_to_params(info["flags"])
-    p = host.make_params("IGH", ins=175, k=fl["k"], mf=fl["mf"], mq=fl["mq"], mcs=fl["mcs"], mrs=fl["mrs"], rl=c.pool.rl)
+    p = host.make_params(info.get("chain", "IGH"), ins=175, k=fl["k"], mf=fl["mf"], mq=fl["mq"], mcs=fl["mcs"], mrs=fl["mrs"], rl=c.pool.rl)
     t = oracle.KmerTable(c.pool, fl["k"])
     t.prune(fl["mf"], fl["mq"])
     og = oracle.Graph(t, c.v_codes, c.j_codes)
@@ -120,8 +126,13 @@ def test_host_stage_end_to_end_vs_reference(tag, tmp_path):
                   og.from_deg, og.from_ids,
                   np.frombuffer("".join(oracle.inst_kmer(c.pool, int(f), fl["k"]) for f in og.first).encode(), np.uint8).reshape(og.n, fl["k"]))
     fa, dot, sam = tmp_path / "c.fa", tmp_path / "g.dot", tmp_path / "o.sam"
-    st = host.assemble(p, g, *_oracle_hooks(c.pool, c.v_region, p), c.v_codes, c.j_codes, str(fa), str(dot), str(sam))
+    marks = []
+    st = host.assemble(p, g, *_oracle_hooks(c.pool, c.v_region, p), c.v_codes, c.j_codes, str(fa), str(dot), str(sam), status=marks.append)
     assert st["n_roots"] == info["roots"]
+    # the stage markers assemble() prints between the graph build and FINIS, in the reference's order (A2:1417-1464)
+    import json
+    ref = json.load(open(os.path.join(G.GOLD, "stage_markers.json")))["markers"]
+    assert marks == ref[ref.index("POST_GRAPH_BLOCK"):ref.index("FINIS")]
     assert fa.read_text() == G.text(f"{tag}.contigs.fa.gz")
     assert dot.read_text() == G.text(f"{tag}.dot.gz")
     assert sam.read_text() == G.text(f"{tag}.sam.gz")

@@ -6,10 +6,12 @@
  *         --jc --ws -jext --rf --vk --mrs --rs --ms --e0 --e1 --wo --vf --jf --rms]
  * writes ./vdj_contigs.fa and ./vdjer.dot, SAM on stdout, log on stderr; exit 0 on success.
  *
- * --in: BAM extraction (bam_read.c, htslib) is the next row of the scope table and is not part of
- * this build; --in takes the extracted read pool as text, one read per line in extraction order:
+ * --in: a BAM with its .bai (extraction as bam_read.c:264-446, restated over zlib in bamx.c), or -- recognised by its
+ * content -- the extracted read pool as text, one read per line in extraction order:
  *     <pool:P|S> <name> <read_num:1|2> <is_rev:0|1> <SEQ> <QUAL>
  * from which the pool records (as-is + reverse complement, bam_read.c:206-244) are rebuilt.
+ * stderr carries the reference's ELAPSED_SECS stage markers (status.c:22-32) in the reference's order; the k-mer table, prune and
+ * graph build are ONE device call here, so the markers between PRE_PRE_GRAPH1 and POST_BUILD_GRAPH2 follow it back to back.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -353,6 +355,8 @@ static int h_sam_body(void* ud, const char* const* ids, const char* contigs, siz
 	return 0;
 }
 
+static void h_status(void* ud, const char* desc) { (void) ud; status(desc); }
+
 #define VX(call) do { if ((call) != 0) { fprintf(stderr, "%s: %s\n", #call, vdjx_last_error()); return 1; } } while (0)
 
 int main(int argc, char** argv) {
@@ -387,9 +391,15 @@ int main(int argc, char** argv) {
 
 	fprintf(stderr, "Assembling...\n");
 	vdjx_graph* gg = NULL;
+	status("PRE_PRE_GRAPH1");                  /* A2:1387 */
 	VX(vdjx_kmer_build(gx, px, c.hp.k, c.hp.min_node_freq, c.hp.min_base_quality, &gg));
 	const size_t n = vdjx_graph_nodes(gg);
-	fprintf(stderr, "Pre Num nodes: %zu\npre nodes after pruning: %zu\nNum nodes: %zu\n", vdjx_graph_pre_nodes(gg), n, n);
+	status("PRE_PRE_GRAPH2");                  /* A2:1389-1409: one device call made the table, the prune and the graph */
+	status("POST_PRE_GRAPH1");
+	fprintf(stderr, "Pre Num nodes: %zu\npre nodes after pruning: %zu\n", vdjx_graph_pre_nodes(gg), n);
+	status("POST_PRUNE_PRE_GRAPH1");
+	status("POST_BUILD_GRAPH1");
+	fprintf(stderr, "Num nodes: %zu\n", n);
 	status("POST_BUILD_GRAPH2");
 	vdjh_graph hg;
 	memset(&hg, 0, sizeof hg);
@@ -403,7 +413,7 @@ int main(int argc, char** argv) {
 	hg.kmers = kmers; hg.freq = freq; hg.has_v = hv; hg.has_j = hj; hg.to_deg = td; hg.to_ids = ti; hg.from_deg = fd; hg.from_ids = fi;
 
 	hook_ud ud = {gx, &rd, &c.hp};
-	vdjh_hooks hk = {&ud, h_root_score, h_window_score, h_sam_body, vc, nv, jc, nj};
+	vdjh_hooks hk = {&ud, h_root_score, h_window_score, h_sam_body, vc, nv, jc, nj, h_status};
 	vdjh_stats st;
 	if (vdjh_assemble(&c.hp, &hg, &hk, "vdj_contigs.fa", "vdjer.dot", stdout, &st)) {
 		fprintf(stderr, "%s\n", vdjh_last_error());

@@ -475,8 +475,12 @@ int vdjh_assemble(const vdjh_params* p, const vdjh_graph* g, const vdjh_hooks* h
 	}
 	for (size_t i = 0; i < nroots / 2; i++) { hnode* t = roots[i]; roots[i] = roots[nroots - 1 - i]; roots[nroots - 1 - i] = t; }
 	st->n_roots = nroots;
+#define STAGE(name) do { if (h->status) h->status(h->ud, name); } while (0)
+	STAGE("POST_GRAPH_BLOCK");                 /* A2:1417 */
+	STAGE("POST_ROOT_TRACEBACK");              /* A2:1431 (traceback_roots is commented out in the reference) */
 
 	condense_graph(&G);
+	STAGE("POST_CONDENSE_GRAPH");              /* A2:1437 */
 	if (dot_path && dump_graph(&G, dot_path)) { graph_free(&G); free(roots); return -1; }
 
 	/* score_seq for every root (A2:1103), batched: a pure function of the k-mer */
@@ -491,6 +495,8 @@ int vdjh_assemble(const vdjh_params* p, const vdjh_graph* g, const vdjh_hooks* h
 	uint8_t* valid = NULL;
 	char* wbuf = NULL;
 	if (nroots && h->root_score(h->ud, rk, nroots, p->k, p->min_source_homology_score, accepted_root)) { set_err("root scorer failed"); goto done; }
+	/* process_roots prints STATUS_UPDATE when the first root is dispatched (`ts` starts at 0, A2:1301,1335) and then every 300 s */
+	if (nroots) STAGE("STATUS_UPDATE");
 
 	/* worker_thread/build_contigs per accepted root, in dispatch order (A2:1305-1318, 1093-1131) */
 	for (size_t i = 0; i < nroots; i++) {
@@ -521,6 +527,7 @@ int vdjh_assemble(const vdjh_params* p, const vdjh_graph* g, const vdjh_hooks* h
 		}
 	}
 
+	STAGE("THREADS_DONE");                     /* A2:1452 */
 	/* output_windows (A2:872-914): overlap removal with erase-during-iteration, then the FASTA in table order */
 	for (size_t b1 = sph_next(&acc, 0); b1 < acc.nbuckets; b1 = sph_next(&acc, b1 + 1)) {
 		const char* w1 = acc.b[b1].key;
@@ -569,6 +576,7 @@ int vdjh_assemble(const vdjh_params* p, const vdjh_graph* g, const vdjh_hooks* h
 		free(contigs);
 		if (ok) goto done;
 	}
+	STAGE("PRE_CLEANUP");                      /* A2:1461 */
 	rc = 0;
 done:
 	for (size_t i = 0; i < w.win.n; i++) { free(w.win.v[i]); free(w.cdr3.v[i]); }
@@ -577,5 +585,7 @@ done:
 	sph_free(&acc);
 	free(valid); free(wbuf); free(rk); free(accepted_root); free(roots);
 	graph_free(&G);
+	if (rc == 0) STAGE("POST_CLEANUP");        /* A2:1464 (`delete nodes`) */
+#undef STAGE
 	return rc;
 }

@@ -65,6 +65,10 @@ typedef struct {
 	/* sorted anchor codes (vj_filter.c:56-78) */
 	const uint32_t* v_codes; size_t nv;
 	const uint32_t* j_codes; size_t nj;
+	/* print_status (status.c:22-32) at the reference's stage boundaries inside assemble(): POST_GRAPH_BLOCK,
+	 * POST_ROOT_TRACEBACK, POST_CONDENSE_GRAPH, STATUS_UPDATE, THREADS_DONE, PRE_CLEANUP, POST_CLEANUP
+	 * (A2:1417-1464, 1336).  May be NULL. */
+	void (*status)(void* ud, const char* desc);
 } vdjh_hooks;
 
 typedef struct {

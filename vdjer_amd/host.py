@@ -41,11 +41,12 @@ ROOT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_
 WIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 SAM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 VJF_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_char_p)
+STATUS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
 
 
 class Hooks(C.Structure):
     _fields_ = [("ud", C.c_void_p), ("root_score", ROOT_FN), ("window_score", WIN_FN), ("sam_body", SAM_FN),
-                ("v_codes", C.c_void_p), ("nv", C.c_size_t), ("j_codes", C.c_void_p), ("nj", C.c_size_t)]
+                ("v_codes", C.c_void_p), ("nv", C.c_size_t), ("j_codes", C.c_void_p), ("nj", C.c_size_t), ("status", STATUS_FN)]
 
 
 class Stats(C.Structure):
@@ -133,7 +134,7 @@ def node_order(g) -> np.ndarray:
     return out
 
 
-def _hooks(root_score, window_score, sam_body, v_codes, j_codes):
+def _hooks(root_score, window_score, sam_body, v_codes, j_codes, status=None):
     vc = np.ascontiguousarray(np.sort(np.asarray(v_codes, dtype=np.uint32)))
     jc = np.ascontiguousarray(np.sort(np.asarray(j_codes, dtype=np.uint32)))
     errs = []
@@ -170,7 +171,11 @@ def _hooks(root_score, window_score, sam_body, v_codes, j_codes):
 
     fr, fw, fs = ROOT_FN(c_root), WIN_FN(c_win), SAM_FN(c_sam)
     h = Hooks(None, fr, fw, fs, vc.ctypes.data, vc.shape[0], jc.ctypes.data, jc.shape[0])
-    return h, (vc, jc, fr, fw, fs), errs
+    fst = None
+    if status is not None:
+        fst = STATUS_FN(lambda ud, desc: status(desc.decode()))
+        h.status = fst
+    return h, (vc, jc, fr, fw, fs, fst), errs
 
 
 def vjf_search(p: Params, contig: str, v_codes, j_codes):
@@ -182,11 +187,12 @@ def vjf_search(p: Params, contig: str, v_codes, j_codes):
     return out
 
 
-def assemble(p: Params, g, root_score, window_score, sam_body, v_codes, j_codes, fasta_path=None, dot_path=None, sam_path=None):
+def assemble(p: Params, g, root_score, window_score, sam_body, v_codes, j_codes, fasta_path=None, dot_path=None, sam_path=None,
+             status=None):
     """root_score(kmers[n,k] uint8, k, thr) -> 0/1 array; window_score(list of str) -> 0/1 array;
-    sam_body(ids, contigs) -> str (the SAM records after the header)."""
+    sam_body(ids, contigs) -> str (the SAM records after the header); status(name): the reference's stage markers."""
     s, keep = _graph_struct(g)
-    h, keep2, errs = _hooks(root_score, window_score, sam_body, v_codes, j_codes)
+    h, keep2, errs = _hooks(root_score, window_score, sam_body, v_codes, j_codes, status)
     st = Stats()
     fp = _libc.fopen(sam_path.encode(), b"w") if sam_path else None
     try:

@@ -64,6 +64,7 @@ class Repertoire:
     # derived
     v_anchors: list = field(default_factory=list)
     j_anchors: list = field(default_factory=list)
+    j_codon: str = "TGG"    # conserved J residue: W (IGH) or F (IGK/IGL: TTC), params.c:8-35
 
     @property
     def v_region(self) -> str:
@@ -82,21 +83,27 @@ class Repertoire:
         out = []
         for t in self.clones:
             c = 297
-            w = t.find("TGG", c + 3)
-            # the designed Trp codon is the in-frame one that starts the J tail
+            w = t.find(self.j_codon, c + 3)
+            # the designed Trp (Phe) codon is the in-frame one that starts the J tail
             while (w - c) % 3 != 0 or t[w + 8:w + 24] not in self.j_anchors:
-                w = t.find("TGG", w + 1)
+                w = t.find(self.j_codon, w + 1)
             out.append(t[c:w + 3])
         return out
 
 
 def make_repertoire(n_clones: int, seed: int = 20261002, n_v: int = 60, n_j: int = 6,
-                    zipf_s: float = 1.1, j_codons: int = 119, clone_seed: int | None = None) -> Repertoire:
+                    zipf_s: float = 1.1, j_codons: int = 119, clone_seed: int | None = None, chain: str = "IGH") -> Repertoire:
     """clone_seed: draw the clones from their own stream while the germline (and with it the ref-dir) stays the one of `seed`:
-    several libraries of different clones over one reference (bench.py gives every GPU its own library)."""
+    several libraries of different clones over one reference (bench.py gives every GPU its own library).
+    chain IGK / IGL: the J segment starts with the conserved Phe codon and the CDR3 is short enough for the light-chain
+    window (J residue F, CDR3 of 0-60 nt: set_chain_info, params.c:20-31)."""
+    if chain not in ("IGH", "IGK", "IGL"):
+        raise ValueError(chain)
+    j_codon = "TGG" if chain == "IGH" else "TTC"
+    core_lo, core_hi = (8, 21) if chain == "IGH" else (7, 18)      # light chains: CDR3 of 27-57 nt (window start >= 0 needs >= 27)
     rng = np.random.default_rng(seed)
     v_germ = [_rand_codons(rng, 99) + "TGT" for _ in range(n_v)]
-    j_germ = ["TGG" + _rand_codons(rng, j_codons) for _ in range(n_j)]
+    j_germ = [j_codon + _rand_codons(rng, j_codons) for _ in range(n_j)]
     if clone_seed is not None:
         rng = np.random.default_rng(clone_seed)
     clones, cv, cj = [], [], []
@@ -118,14 +125,14 @@ def make_repertoire(n_clones: int, seed: int = 20261002, n_v: int = 60, n_j: int
                     continue
                 v[pos] = nb
                 break
-        core = _rand_codons(rng, int(rng.integers(8, 21)))
+        core = _rand_codons(rng, int(rng.integers(core_lo, core_hi)))
         clones.append("".join(v) + core + j_germ[h])
         cv.append(g)
         cj.append(h)
     ranks = np.arange(1, n_clones + 1, dtype=np.float64)
     w = 1.0 / ranks ** zipf_s
     w /= w.sum()
-    rep = Repertoire(v_germ, j_germ, clones, cv, cj, w, seed)
+    rep = Repertoire(v_germ, j_germ, clones, cv, cj, w, seed, j_codon=j_codon)
     rep.v_anchors = [v[277:293] for v in v_germ]
     rep.j_anchors = [j[8:24] for j in j_germ]
     return rep
