@@ -289,14 +289,16 @@ def test_async_graph_export():
 
 
 def test_anchor_probe(ctx):
-    from vdjer_amd import synth
+    """seq_to_int + matches_vmer/jmer per contig offset (vj_filter.c:221-238) against the oracle's seq_to_int (pinned on the
+    reference's known answers, tests/test_oracle_vs_golden.py) and the golden code sets"""
+    from oracle import oracle
     c = G.Case("noisy")
     ctx.anchor_sets_load(c.v_codes, c.j_codes)
     vs, js = set(c.v_codes.tolist()), set(c.j_codes.tolist())
     for t in c.clones:
         ov, oj = ctx.anchor_probe(t)
-        exp_v = [int(synth.seq_to_int(t[i:i + 16]) in vs) for i in range(len(t) - 16)]
-        exp_j = [int(synth.seq_to_int(t[i:i + 16]) in js) for i in range(len(t) - 16)]
+        exp_v = [int(oracle.seq_to_int(t[i:i + 16]) in vs) for i in range(len(t) - 16)]
+        exp_j = [int(oracle.seq_to_int(t[i:i + 16]) in js) for i in range(len(t) - 16)]
         assert ov.tolist() == exp_v and oj.tolist() == exp_j
         assert sum(exp_v) >= 1 and sum(exp_j) >= 1
 

@@ -103,6 +103,7 @@ class Context:
         self._pools = []
         self.pinned_results = pinned_results
         self._pinned = {}            # tag -> (ptr, capacity bytes)
+        self._retired = []           # outgrown pinned buffers, freed with the context
 
     def _result_arrays(self, tag: str, specs):
         """specs: [(shape, dtype)] -> zero-copy numpy arrays; pinned and recycled per `tag` when pinned_results is set"""
@@ -113,7 +114,9 @@ class Context:
         ptr, cap = self._pinned.get(tag, (None, 0))
         if cap < need:
             if ptr:
-                self.L.vdjx_host_free(self.h, ptr)
+                # arrays of an earlier result may still be views of the old buffer (and an asynchronous export may still be
+                # writing into it): it is retired, not freed, until the context closes
+                self._retired.append(ptr)
             new = C.c_void_p()
             cap = need + need // 4
             check(self.L.vdjx_host_alloc(self.h, cap, C.byref(new)), "vdjx_host_alloc")
@@ -133,7 +136,9 @@ class Context:
         if getattr(self, "h", None):
             for ptr, _ in getattr(self, "_pinned", {}).values():
                 self.L.vdjx_host_free(self.h, ptr)
-            self._pinned = {}
+            for ptr in getattr(self, "_retired", []):
+                self.L.vdjx_host_free(self.h, ptr)
+            self._pinned, self._retired = {}, []
             self.L.vdjx_shutdown(self.h)
             self.h = None
 

@@ -298,6 +298,12 @@ __global__ __launch_bounds__(512) void k_seg_hist_sliced(const u64* __restrict__
 	for (u32 i = threadIdx.x; i < nbk; i += 512) if (h[i]) atomicAdd(&fine_cnt[((size_t) seg << sub_bits) | i], h[i]);
 }
 
+// out[i] = src[i*step]
+__global__ void k_pick_u32(const u32* __restrict__ src, u32 step, u32 n, u32* __restrict__ out) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = src[(size_t) i * step];
+}
+
 // cursors of a partition pass: cur[i] = bucket_start[i << sh]
 __global__ void k_init_cursors(const u32* __restrict__ bucket_start, u32 n, u32 sh, u32* __restrict__ cur) {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -651,6 +657,432 @@ __global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __re
 		}
 		__syncthreads();
 	}
+}
+
+// ==============================================================================================
+// Round-2 build: only the GATED instances travel (Phase A), the recount of add_to_graph comes from the edge pass (Phase B).
+//
+// Whether a k-mer survives (A2:467-484) depends on its gated instances only (add_to_table is never called for the others,
+// A2:240-259, 398-403): about one instance in six of a Phred-noisy pool (0.95^35).  The ungated ones matter for exactly two
+// numbers of a SURVIVING k-mer -- add_to_graph's frequency and first sight (A2:261-309) -- and those are counted where the
+// edge pass finds the survivors anyway.  So the partition moves 16-byte {key, instance} records of the gated instances only
+// (AoS: one global_load_dwordx4 per lane), and one kernel per bucket does table + prune (the former aggregate + finalize pair,
+// without their candidate arrays in global memory).
+// Instance ids are 38 bits: record << 6 | offset (the layout of vdjx_graph_export's first_inst), records < 2^32.
+// ==============================================================================================
+#define INST_BITS 38
+#define INST_MASK64 ((1ull << INST_BITS) - 1ull)
+#define NONE64 0xFFFFFFFFFFFFFFFFull
+
+struct Tup16 {                  // k <= 45: the key's high part (2k-64 <= 26 bits) shares a word with the instance id
+	u64 lo, x;
+	typedef u32 hi_t;
+	__device__ inline u64 hi() const { return x >> INST_BITS; }
+	__device__ inline u64 inst() const { return x & INST_MASK64; }
+	__device__ static inline Tup16 make(u64 lo, u64 hi, u64 inst) { Tup16 t; t.lo = lo; t.x = (hi << INST_BITS) | inst; return t; }
+	__device__ static inline Tup16 load(const Tup16* p) { const ulonglong2 v = *(const ulonglong2*) p; Tup16 t; t.lo = v.x; t.x = v.y; return t; }
+	__device__ static inline void store(Tup16* p, const Tup16& t) { *(ulonglong2*) p = make_ulonglong2(t.lo, t.x); }
+};
+struct Tup24 {                  // k 46..50
+	u64 lo, h, i;
+	typedef u64 hi_t;
+	__device__ inline u64 hi() const { return h; }
+	__device__ inline u64 inst() const { return i; }
+	__device__ static inline Tup24 make(u64 lo, u64 hi, u64 inst) { Tup24 t; t.lo = lo; t.h = hi; t.i = inst; return t; }
+	__device__ static inline Tup24 load(const Tup24* p) { return *p; }
+	__device__ static inline void store(Tup24* p, const Tup24& t) { *p = t; }
+};
+
+// K2a': bucket sizes over the gated instances (include_kmer, A2:240-259: no 'N', every Phred >= 20)
+__global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restrict__ bases, const u64* __restrict__ nmask,
+                                                             const u64* __restrict__ lowq, size_t R, int rl, int k, u32 nb_bits,
+                                                             size_t rpb, u32* __restrict__ bucket_cnt) {
+	extern __shared__ u32 hist[];
+	const u32 NB = 1u << nb_bits;
+	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) hist[i] = 0;
+	__syncthreads();
+	const size_t r0 = (size_t) blockIdx.x * rpb;
+	const size_t r1 = r0 + rpb < R ? r0 + rpb : R;
+	const int P = rl - k + 1;
+	const u64 km = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+	for (size_t r = r0 + threadIdx.x; r < r1; r += HIST_THREADS) {
+		const RecView v = load_rec(bases, nmask, lowq, r);
+		const u64 bad = v.nm | v.lq;
+		for (int o = 0; o < P; o++) {
+			if ((bad >> o) & km) continue;
+			u64 khi, klo;
+			vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
+			atomicAdd(&hist[(u32) (vdjx_mix(klo, khi) >> (64 - nb_bits))], 1u);
+		}
+	}
+	__syncthreads();
+	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) if (hist[i]) atomicAdd(&bucket_cnt[i], hist[i]);
+}
+
+// K2c' pass 1: records -> gated tuples, LDS-staged counting sort into `nbk` coarse buckets (see K2c above)
+template <typename TUP>
+__global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __restrict__ bases, const u64* __restrict__ nmask,
+                                                                 const u64* __restrict__ lowq, size_t R, u64 rec_base, int rl, int k,
+                                                                 u32 shift, u32 nbk, size_t rpb, u32* __restrict__ gcur,
+                                                                 TUP* __restrict__ out) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	TUP* stage = (TUP*) smem;
+	__shared__ u32 cnt[PART_MAXB], base[PART_MAXB + 1], cur[PART_MAXB], gbase[PART_MAXB], tmp[PART_THREADS];
+	const u32 ROUND = PART_LDS_BYTES / sizeof(TUP);
+	const int P = rl - k + 1;
+	const u32 RR = ROUND / (u32) P;                                  // records per round (every instance could be gated)
+	const u32 T = RR * 4 <= PART_THREADS ? 4u : (RR * 2 <= PART_THREADS ? 2u : 1u);
+	const int off_a = (int) ((threadIdx.x % T) * (u32) P / T), off_b = (int) ((threadIdx.x % T + 1) * (u32) P / T);
+	const u64 km = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+	const u32 mask = nbk - 1;
+	const size_t r0 = (size_t) blockIdx.x * rpb;
+	const size_t r1 = r0 + rpb < R ? r0 + rpb : R;
+	for (size_t rs = r0; rs < r1; rs += RR) {
+		const size_t re = rs + RR < r1 ? rs + RR : r1;
+		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) cnt[i] = 0;
+		__syncthreads();
+		for (size_t r = rs + threadIdx.x / T; r < re; r += PART_THREADS / T) {
+			const RecView v = load_rec(bases, nmask, lowq, r);
+			const u64 bad = v.nm | v.lq;
+			for (int o = off_a; o < off_b; o++) {
+				if ((bad >> o) & km) continue;
+				u64 khi, klo;
+				vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
+				atomicAdd(&cnt[(u32) (vdjx_mix(klo, khi) >> shift) & mask], 1u);
+			}
+		}
+		__syncthreads();
+		part_scan(cnt, base, tmp, nbk);
+		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) {
+			cur[i] = base[i];
+			gbase[i] = cnt[i] ? atomicAdd(&gcur[i], cnt[i]) : 0u;
+		}
+		__syncthreads();
+		for (size_t r = rs + threadIdx.x / T; r < re; r += PART_THREADS / T) {
+			const RecView v = load_rec(bases, nmask, lowq, r);
+			const u64 bad = v.nm | v.lq;
+			for (int o = off_a; o < off_b; o++) {
+				if ((bad >> o) & km) continue;
+				u64 khi, klo;
+				vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
+				const u32 b = (u32) (vdjx_mix(klo, khi) >> shift) & mask;
+				stage[atomicAdd(&cur[b], 1u)] = TUP::make(klo, khi, ((rec_base + (u64) r) << 6) | (u64) o);
+			}
+		}
+		__syncthreads();
+		const u32 n = base[nbk];
+		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
+			const TUP t = stage[i];
+			const u32 b = (u32) (vdjx_mix(t.lo, t.hi()) >> shift) & mask;
+			TUP::store(&out[gbase[b] + (i - base[b])], t);
+		}
+		__syncthreads();
+	}
+}
+
+// pass 2 (see k_part_tuples)
+template <typename TUP>
+__global__ __launch_bounds__(PART_THREADS) void k_part_tuples_g(const TUP* __restrict__ in, const u32* __restrict__ seg_start,
+                                                                u32 seg_shift, u32 slices, u32 shift, u32 sub_bits,
+                                                                u32* __restrict__ gcur, TUP* __restrict__ out) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	TUP* stage = (TUP*) smem;
+	__shared__ u32 cnt[PART_MAXB], base[PART_MAXB + 1], cur[PART_MAXB], gbase[PART_MAXB], tmp[PART_THREADS];
+	constexpr u32 PER = PART_LDS_BYTES / sizeof(TUP) / PART_THREADS;
+	constexpr u32 ROUND = PER * PART_THREADS;
+	const u32 seg = blockIdx.x / slices, sl = blockIdx.x % slices;
+	const u32 nbk = 1u << sub_bits, mask = nbk - 1;
+	const size_t s0 = seg_start[(size_t) seg << seg_shift], s1 = seg_start[((size_t) seg + 1) << seg_shift];
+	const size_t per = (s1 - s0 + slices - 1) / slices;
+	const size_t t0 = s0 + (size_t) sl * per;
+	const size_t t1 = t0 + per < s1 ? t0 + per : s1;
+	u32* gc = gcur + ((size_t) seg << sub_bits);
+	for (size_t ts = t0; ts < t1; ts += ROUND) {
+		const size_t te = ts + ROUND < t1 ? ts + ROUND : t1;
+		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) cnt[i] = 0;
+		__syncthreads();
+		TUP r_t[PER];
+		u32 r_b[PER];
+#pragma unroll
+		for (u32 j = 0; j < PER; j++) {
+			const size_t t = ts + (size_t) j * PART_THREADS + threadIdx.x;
+			r_b[j] = NONE32;
+			if (t < te) {
+				r_t[j] = TUP::load(&in[t]);
+				r_b[j] = (u32) (vdjx_mix(r_t[j].lo, r_t[j].hi()) >> shift) & mask;
+			}
+		}
+#pragma unroll
+		for (u32 j = 0; j < PER; j++) if (r_b[j] != NONE32) atomicAdd(&cnt[r_b[j]], 1u);
+		__syncthreads();
+		part_scan(cnt, base, tmp, nbk);
+		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) {
+			cur[i] = base[i];
+			gbase[i] = cnt[i] ? atomicAdd(&gc[i], cnt[i]) : 0u;
+		}
+		__syncthreads();
+#pragma unroll
+		for (u32 j = 0; j < PER; j++) if (r_b[j] != NONE32) stage[atomicAdd(&cur[r_b[j]], 1u)] = r_t[j];
+		__syncthreads();
+		const u32 n = base[nbk];
+		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
+			const TUP x = stage[i];
+			const u32 b = (u32) (vdjx_mix(x.lo, x.hi()) >> shift) & mask;
+			TUP::store(&out[gbase[b] + (i - base[b])], x);
+		}
+		__syncthreads();
+	}
+}
+
+template <typename TUP>
+__global__ __launch_bounds__(512) void k_seg_hist_g(const TUP* __restrict__ in, const u32* __restrict__ seg_start, u32 seg_shift, u32 slices,
+                                                    u32 shift, u32 sub_bits, u32* __restrict__ fine_cnt) {
+	__shared__ u32 h[PART_MAXB];
+	const u32 nbk = 1u << sub_bits;
+	for (u32 i = threadIdx.x; i < nbk; i += 512) h[i] = 0;
+	__syncthreads();
+	const u32 seg = blockIdx.x / slices, sl = blockIdx.x % slices;
+	const size_t s0 = seg_start[(size_t) seg << seg_shift], s1 = seg_start[((size_t) seg + 1) << seg_shift];
+	const size_t per = (s1 - s0 + slices - 1) / slices;
+	const size_t t0 = s0 + (size_t) sl * per;
+	const size_t t1 = t0 + per < s1 ? t0 + per : s1;
+	for (size_t t = t0 + threadIdx.x; t < t1; t += 512) {
+		const TUP x = TUP::load(&in[t]);
+		atomicAdd(&h[(u32) (vdjx_mix(x.lo, x.hi()) >> shift) & (nbk - 1)], 1u);
+	}
+	__syncthreads();
+	for (u32 i = threadIdx.x; i < nbk; i += 512) if (h[i]) atomicAdd(&fine_cnt[((size_t) seg << sub_bits) | i], h[i]);
+}
+
+// ----------------------------------------------------------------------------------------------
+// K3': table + prune of one bucket in one kernel (add_to_table A2:322-367, prune_pre_graph A2:467-484).
+//   sweep 1: LDS table over the bucket's (gated) tuples: count + first instance per distinct k-mer
+//   candidates: count >= max(mf, 2)
+//   sweep 2 (tuples still in registers when the bucket is one chunk): distinct-read flag (compare_read, A2:142-144, 349-352: the
+//            instance's record against the first instance's record, N masks included: two 16-byte gathers, skipped once the
+//            flag is set) and the list of the instances whose qualities will be needed
+//   quality sums only for candidates with count < TLOW (see k_bucket_finalize), then the survivors are appended
+// ----------------------------------------------------------------------------------------------
+#define RD_THREADS 512
+#define RD_UNR 8
+#define RD_SLOTS 1024u
+#define RD_Q 1024u                  // remembered instances of low-count candidates (more: the quality rounds rescan the bucket)
+#define RD_A 64u                    // quality-sum rows per round
+#define ST_CAND 1u
+#define ST_MULTI 2u
+#define ST_QOK 4u
+
+struct SurvOutG { u64* lo; u64* hi; u32* gcnt; u64* gfirst; u32* n; u32 cap; };
+
+template <typename TUP>
+__global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
+                                                             const u64* __restrict__ bases, const u64* __restrict__ nmask,
+                                                             const uint8_t* __restrict__ quals, int qstride, int k, u64 rec_base,
+                                                             u32 mf, u32 cmin, u32 mqq, u32 tlow, SurvOutG so,
+                                                             u64* __restrict__ g_distinct, u32* __restrict__ g_err) {
+	typedef typename TUP::hi_t THI;
+	__shared__ u64 s_klo[RD_SLOTS];
+	__shared__ THI s_khi[RD_SLOTS];
+	__shared__ u64 s_first[RD_SLOTS];
+	__shared__ u32 s_cnt[RD_SLOTS], s_state[RD_SLOTS], s_lowid[RD_SLOTS];
+	__shared__ u32 acc[RD_A * K3B_KW];
+	__shared__ u32 q_slot[RD_Q];
+	__shared__ u64 q_inst[RD_Q];
+	__shared__ u32 s_over, s_ndist, s_nlow, s_nq, s_nsurv, s_base;
+	const THI EMPTY = (THI) ~(THI) 0;
+	const u32 b = blockIdx.x;
+	const u32 base = bucket_start[b];
+	const u32 n = bucket_start[b + 1] - base;
+	const u32 tid = threadIdx.x;
+	if (n == 0) return;
+	const TUP* T = tup + base;
+	const u32 KW = (u32) (k + 1) / 2;
+	u32 S = 1;
+	while ((u64) S * K3_SUB_TUPLES < n) S <<= 1;
+	u32 ndist_total = 0;
+	// A bucket whose distinct k-mers do not fit the table is done in S hash-selected sub-passes.  Survivors leave per sub-pass,
+	// so a split must be known to fit BEFORE its first real sub-pass: S = 1 is simply tried (its overflow shows before anything
+	// is emitted); any S > 1 is verified first by a keys-only dry run of all its sub-passes.
+	bool verify = S > 1;
+	for (;;) {
+		if (tid == 0) { s_over = 0; s_ndist = 0; }
+		__syncthreads();
+		for (u32 s = 0; s < S; s++) {
+			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) { s_khi[i] = EMPTY; s_cnt[i] = 0; s_first[i] = NONE64; s_state[i] = 0; s_lowid[i] = NONE32; }
+			if (tid == 0) { s_nlow = 0; s_nq = 0; s_nsurv = 0; }
+			__syncthreads();
+			const bool one_chunk = n <= RD_UNR * RD_THREADS;
+			TUP r_t[RD_UNR];
+			int r_slot[RD_UNR];
+			// ---- sweep 1
+			for (u32 t0 = 0; t0 < n; t0 += RD_UNR * RD_THREADS) {
+#pragma unroll
+				for (int j = 0; j < RD_UNR; j++) {
+					const u32 t = t0 + j * RD_THREADS + tid;
+					r_slot[j] = -2;
+					if (t < n) { r_t[j] = TUP::load(&T[t]); r_slot[j] = -1; }
+				}
+#pragma unroll
+				for (int j = 0; j < RD_UNR; j++) {
+					if (r_slot[j] == -2) continue;
+					const u64 h = vdjx_mix(r_t[j].lo, r_t[j].hi());
+					if (S > 1 && (u32) ((h >> 12) & (S - 1)) != s) continue;
+					const int slot = lds_insert<THI, RD_SLOTS>(s_klo, s_khi, r_t[j].lo, (THI) r_t[j].hi(), (u32) h);
+					if (slot < 0) { s_over = 1; continue; }
+					r_slot[j] = slot;
+					if (!verify) {
+						atomicAdd(&s_cnt[slot], 1u);
+						atomicMin((unsigned long long*) &s_first[slot], (unsigned long long) r_t[j].inst());
+					}
+				}
+			}
+			__syncthreads();
+			if (s_over || verify) { if (s_over) break; continue; }
+			// ---- candidates (a k-mer seen once can never have two distinct reads, A2:349-352, 476)
+			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
+				if (s_khi[i] == EMPTY) continue;
+				atomicAdd(&s_ndist, 1u);
+				const u32 c = s_cnt[i];
+				if (c >= cmin) {
+					s_state[i] = ST_CAND;
+					if (c < tlow) s_lowid[i] = atomicAdd(&s_nlow, 1u);
+				}
+			}
+			__syncthreads();
+			// ---- sweep 2
+			for (u32 t0 = 0; t0 < n; t0 += RD_UNR * RD_THREADS) {
+#pragma unroll
+				for (int j = 0; j < RD_UNR; j++) {
+					if (!one_chunk) {
+						const u32 t = t0 + j * RD_THREADS + tid;
+						r_slot[j] = -2;
+						if (t < n) {
+							r_t[j] = TUP::load(&T[t]);
+							const u64 h = vdjx_mix(r_t[j].lo, r_t[j].hi());
+							r_slot[j] = (S > 1 && (u32) ((h >> 12) & (S - 1)) != s) ? -1
+							            : lds_lookup<THI, RD_SLOTS>(s_klo, s_khi, r_t[j].lo, (THI) r_t[j].hi(), (u32) h);
+						}
+					}
+				}
+#pragma unroll
+				for (int j = 0; j < RD_UNR; j++) {
+					const int slot = r_slot[j];
+					if (slot < 0) continue;
+					const u32 st = *(volatile u32*) &s_state[slot];
+					if (!(st & ST_CAND)) continue;
+					const u64 inst = r_t[j].inst();
+					if (s_lowid[slot] != NONE32) {
+						const u32 qi = atomicAdd(&s_nq, 1u);
+						if (qi < RD_Q) { q_slot[qi] = (u32) slot; q_inst[qi] = inst; }
+					}
+					if (!(st & ST_MULTI)) {
+						const u64 rec = (inst >> 6) - rec_base, frec = (s_first[slot] >> 6) - rec_base;
+						if (rec != frec) {
+							const ulonglong2 x = ((const ulonglong2*) bases)[rec];
+							const ulonglong2 y = ((const ulonglong2*) bases)[frec];
+							if (x.x != y.x || x.y != y.y || nmask[rec] != nmask[frec]) atomicOr(&s_state[slot], ST_MULTI);
+						}
+					}
+				}
+			}
+			__syncthreads();
+			// ---- quality sums of the low-count candidates: first instance = the RECORD's first k qualities (A2:337-339), the
+			// others their own (A2:354-361); a sum >= 214 reads as 255 (A2:356-360): the test is sum >= min(mq, 214)
+			const u32 nlow = s_nlow;
+			const bool listed = s_nq <= RD_Q;
+			for (u32 l0 = 0; l0 < nlow; l0 += RD_A) {
+				for (u32 i = tid; i < RD_A * K3B_KW; i += RD_THREADS) acc[i] = 0;
+				__syncthreads();
+				const u32 nscan = listed ? s_nq : n;
+				for (u32 t = tid; t < nscan; t += RD_THREADS) {
+					u32 slot;
+					u64 inst;
+					if (listed) { slot = q_slot[t]; inst = q_inst[t]; }
+					else {
+						const TUP x = TUP::load(&T[t]);
+						const u64 h = vdjx_mix(x.lo, x.hi());
+						if (S > 1 && (u32) ((h >> 12) & (S - 1)) != s) continue;
+						const int sl = lds_lookup<THI, RD_SLOTS>(s_klo, s_khi, x.lo, (THI) x.hi(), (u32) h);
+						if (sl < 0) continue;
+						slot = (u32) sl; inst = x.inst();
+					}
+					const u32 lid = s_lowid[slot];
+					if (lid == NONE32 || lid < l0 || lid >= l0 + RD_A) continue;
+					const u64 rec = (inst >> 6) - rec_base;
+					const u32 off = (u32) (inst & 63u);
+					const u32 qoff = inst == s_first[slot] ? 0u : off;
+					const uint4* qv = (const uint4*) (quals + (size_t) rec * (size_t) qstride);
+					u32 w[16];
+#pragma unroll
+					for (int v4 = 0; v4 < 4; v4++) {
+						uint4 x = make_uint4(0x21212121u, 0x21212121u, 0x21212121u, 0x21212121u);
+						if (v4 * 16 < qstride) x = qv[v4];
+						w[v4 * 4 + 0] = x.x; w[v4 * 4 + 1] = x.y; w[v4 * 4 + 2] = x.z; w[v4 * 4 + 3] = x.w;
+					}
+					u32* row = acc + (lid - l0) * K3B_KW;
+#pragma unroll
+					for (int pq = 0; pq < 64; pq++) {
+						const int j = pq - (int) qoff;
+						if (j >= 0 && j < k) {
+							const u32 v = (uint8_t) (((w[pq >> 2] >> (8 * (pq & 3))) & 0xFFu) - 33u);
+							atomicAdd(&row[j >> 1], v << (16 * (j & 1)));
+						}
+					}
+				}
+				__syncthreads();
+				for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
+					const u32 lid = s_lowid[i];
+					if (lid == NONE32 || lid < l0 || lid >= l0 + RD_A) continue;
+					const u32* row = acc + (lid - l0) * K3B_KW;
+					bool ok = true;
+					for (u32 w2 = 0; w2 < KW; w2++) {
+						const u32 v = row[w2];
+						if ((v & 0xFFFFu) < mqq) ok = false;
+						if (2 * w2 + 1 < (u32) k && (v >> 16) < mqq) ok = false;
+					}
+					if (ok) s_state[i] |= ST_QOK;
+				}
+				__syncthreads();
+			}
+			// ---- prune_pre_graph (A2:467-484); the global survivor counter is bumped once per workgroup and sub-pass
+			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
+				const u32 st = s_state[i];
+				bool keep = false;
+				if (st & ST_CAND) {
+					const u32 craw = s_cnt[i];
+					const u32 c = craw > 32765u ? 32765u : craw;                  // A2:345-347
+					keep = c >= mf && (st & ST_MULTI) && (craw >= tlow || (st & ST_QOK));
+				}
+				s_lowid[i] = keep ? atomicAdd(&s_nsurv, 1u) : NONE32;            // (reused: position among this sub-pass's survivors)
+			}
+			__syncthreads();
+			if (tid == 0) s_base = s_nsurv ? atomicAdd(so.n, s_nsurv) : 0;
+			__syncthreads();
+			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
+				if (s_lowid[i] == NONE32) continue;
+				const u32 pos = s_base + s_lowid[i];
+				if (pos < so.cap) {
+					so.lo[pos] = s_klo[i];
+					so.hi[pos] = (u64) s_khi[i];
+					so.gcnt[pos] = s_cnt[i] > 32765u ? 32765u : s_cnt[i];
+					so.gfirst[pos] = s_first[i];
+				}
+			}
+			__syncthreads();
+		}
+		__syncthreads();
+		if (s_over) {
+			if (S >= (1u << 20)) { if (tid == 0) atomicAdd(g_err, 1u); break; }
+			S <<= 1;
+			verify = true;
+			__syncthreads();
+			continue;
+		}
+		if (verify) { verify = false; __syncthreads(); continue; }       // the split fits: now for real
+		ndist_total = s_ndist;
+		break;
+	}
+	if (tid == 0) atomicAdd(&g_distinct[(b & 63u) * 16u], (u64) ndist_total);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1205,6 +1637,313 @@ __global__ void k_node_flags(const u64* __restrict__ s_lo, const u64* __restrict
 }
 
 
+// ==============================================================================================
+// Phase B: add_to_graph's bookkeeping (A2:261-320) for the survivors, bucket-local like everything else.
+//
+// The walk over the records (one thread per record, as k_graph_edges) finds the surviving k-mer of every instance: a hash
+// lookup where a run of survivors starts, one 4-byte successor link per further offset.  Instead of updating per-node
+// counters with global atomics (640 M random memory-side atomics at 10 M pairs), every surviving instance becomes an 8-byte
+// item {survivor index, instance id, first base of the surviving predecessor k-mer if the previous offset survived too};
+// items are partitioned by survivor index (LDS-staged, like the tuples) and one workgroup per range of survivors counts
+// them in LDS arrays indexed directly by (index - range start): node frequency, first sight (= creation order), and the
+// first sight of every in-edge (v, first base of u) -- the edge u -> v under the name of its head.
+//   item = survivor (26 bits) << 38 | has_prev << 37 | pred base << 35 | local record (29 bits) << 6 | offset
+// ==============================================================================================
+#define IT_INST_BITS 35
+#define IT_INST_MASK ((1ull << IT_INST_BITS) - 1ull)
+#define IT_SURV_SHIFT 38
+#define IT_HOLE 0xFFFFFFFFFFFFFFFFull
+#define WALK_THREADS 256
+
+struct SurvTable { const u32* table; u32 mask; u32 idx_bits; const ulonglong2* skey; };
+
+// table entry = fingerprint of the key's hash (32 - idx_bits bits) << idx_bits | (survivor index + 1)
+__global__ void k_surv_table2(const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, u32 n, u32* __restrict__ table, u32 mask,
+                              u32 idx_bits, ulonglong2* __restrict__ skey) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const u64 lo = s_lo[i], hi = s_hi[i];
+	skey[i] = make_ulonglong2(lo, hi);
+	const u64 h = vdjx_mix(lo, hi);
+	u32 slot = (u32) (h >> 20) & mask;
+	const u32 entry = idx_bits < 32 ? ((((u32) h) >> idx_bits) << idx_bits) | (i + 1) : (i + 1);
+	while (atomicCAS(&table[slot], 0u, entry) != 0u) slot = (slot + 1) & mask;
+}
+
+__device__ inline int surv_lookup2(const SurvTable& t, u64 lo, u64 hi) {
+	const u64 h = vdjx_mix(lo, hi);
+	u32 slot = (u32) (h >> 20) & t.mask;
+	const u32 imask = t.idx_bits < 32 ? (1u << t.idx_bits) - 1u : 0xFFFFFFFFu;
+	const u32 fp = t.idx_bits < 32 ? (((u32) h) >> t.idx_bits) : 0u;
+	for (;;) {
+		const u32 v = t.table[slot];
+		if (!v) return -1;
+		if (t.idx_bits >= 32 || (v >> t.idx_bits) == fp) {
+			const ulonglong2 kk = t.skey[(v & imask) - 1];
+			if (kk.x == lo && kk.y == hi) return (int) ((v & imask) - 1);
+		}
+		slot = (slot + 1) & t.mask;
+	}
+}
+
+// succ[u*4+b] = survivor index of (key_u << 2 | b) mod 4^k, or NONE32
+__global__ void k_succ_links2(SurvTable t, u32 n, int k, u32* __restrict__ succ) {
+	const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n * 4u) return;
+	const ulonglong2 kk = t.skey[e >> 2];
+	u128 key = (((u128) kk.y << 64) | kk.x);
+	key = (key << 2) | (u128) (e & 3u);
+	if (k < 64) key &= (((u128) 1) << (2 * k)) - 1;
+	const int s = surv_lookup2(t, (u64) key, (u64) (key >> 64));
+	succ[e] = s >= 0 ? (u32) s : NONE32;
+}
+
+// the walk: every wave appends its items to blocks of `blk_items` slots it reserves from the global cursor (unused slots of a
+// block are filled with IT_HOLE); item counts per survivor range go to range_cnt
+__global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restrict__ bases, const u64* __restrict__ nmask, size_t R, int rl, int k,
+                                                             SurvTable t, const u32* __restrict__ succ, u32 range_shift, u32 n_ranges,
+                                                             u64* __restrict__ raw, u64 raw_cap, u32 blk_items,
+                                                             unsigned long long* __restrict__ g_cursor,
+                                                             u32* __restrict__ range_cnt, u32* __restrict__ g_err) {
+	extern __shared__ u32 hist[];                 // [n_ranges]
+	for (u32 i = threadIdx.x; i < n_ranges; i += WALK_THREADS) hist[i] = 0;
+	__syncthreads();
+	const int P = rl - k + 1;
+	const u64 km = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+	const size_t per = ((R + gridDim.x - 1) / gridDim.x + WALK_THREADS - 1) / WALK_THREADS * WALK_THREADS;
+	const size_t r0 = (size_t) blockIdx.x * per;
+	const size_t r1 = r0 + per < R ? r0 + per : R;
+	const int lane = __lane_id();
+	u64 blk = 0;                                  // this wave's block (wave-uniform), valid once have_blk
+	u32 fill = blk_items;
+	bool have_blk = false, dead = false;
+	for (size_t rb = r0; rb < r1; rb += WALK_THREADS) {
+		const size_t r = rb + threadIdx.x;
+		const bool live = r < r1;
+		RecView v;
+		v.bhi = v.blo = 0; v.nm = ~0ull; v.lq = 0;
+		if (live) v = load_rec(bases, nmask, nullptr, r);
+		int prev = -1;
+		for (int o = 0; o < P; o++) {                                 // (uniform trip count: the compaction below is wave-wide)
+			int s = -1;
+			u32 pa = 0;
+			if (live && !((v.nm >> o) & km)) {
+				if (prev >= 0) {
+					const int bsh = 2 * (rl - k - o);                     // last base of the k-mer at o
+					const u32 bb = (u32) (bsh < 64 ? v.blo >> bsh : v.bhi >> (bsh - 64)) & 3u;
+					const u32 nx = succ[(u32) prev * 4u + bb];
+					s = nx == NONE32 ? -1 : (int) nx;
+					const int fsh = 2 * (rl - o);                          // first base of the k-mer at o-1 (the predecessor)
+					pa = (u32) (fsh < 64 ? v.blo >> fsh : v.bhi >> (fsh - 64)) & 3u;
+				} else {
+					u64 khi, klo;
+					vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
+					s = surv_lookup2(t, klo, khi);
+				}
+			}
+			const bool has_prev = prev >= 0 && s >= 0;
+			prev = s;
+			const u64 m = __ballot(s >= 0);
+			if (!m) continue;
+			const u32 cnt = (u32) __popcll(m);
+			if (fill + cnt > blk_items) {                             // (wave-uniform)
+				if (have_blk) for (u32 i = fill + (u32) lane; i < blk_items; i += 64) raw[blk + i] = IT_HOLE;
+				unsigned long long nb = 0;
+				if (lane == 0) nb = atomicAdd(g_cursor, (unsigned long long) blk_items);
+				nb = ((unsigned long long) (u32) __builtin_amdgcn_readlane((int) (nb >> 32), 0) << 32) | (u32) __builtin_amdgcn_readlane((int) nb, 0);
+				if (nb + blk_items > raw_cap) { if (lane == 0 && !dead) atomicAdd(g_err, 1u); dead = true; have_blk = false; }
+				else { blk = nb; have_blk = true; }
+				fill = 0;
+			}
+			if (s >= 0 && !dead) {
+				const u64 item = ((u64) (u32) s << IT_SURV_SHIFT) | ((u64) has_prev << 37) | ((u64) pa << 35) | ((u64) r << 6) | (u64) o;
+				raw[blk + fill + (u32) __popcll(m & ((1ull << lane) - 1ull))] = item;
+				atomicAdd(&hist[(u32) s >> range_shift], 1u);
+			}
+			fill += cnt;
+		}
+	}
+	if (have_blk) for (u32 i = fill + (u32) lane; i < blk_items; i += 64) raw[blk + i] = IT_HOLE;
+	__syncthreads();
+	for (u32 i = threadIdx.x; i < n_ranges; i += WALK_THREADS) if (hist[i]) atomicAdd(&range_cnt[i], hist[i]);
+}
+
+// items -> items grouped by survivor range (see k_part_tuples); holes are dropped.  `n_raw` is read from the device cursor.
+__global__ __launch_bounds__(PART_THREADS) void k_part_items(const u64* __restrict__ in, const unsigned long long* __restrict__ n_raw,
+                                                             u32 range_shift, u32 nbk, u32* __restrict__ gcur, u64* __restrict__ out) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	u64* stage = (u64*) smem;
+	__shared__ u32 cnt[PART_MAXB], base[PART_MAXB + 1], cur[PART_MAXB], gbase[PART_MAXB], tmp[PART_THREADS];
+	constexpr u32 PER = PART_LDS_BYTES / 8 / PART_THREADS;          // 16 items per thread per round
+	constexpr u32 ROUND = PER * PART_THREADS;
+	const size_t N = (size_t) *n_raw;
+	const size_t per = ((N + gridDim.x - 1) / gridDim.x + ROUND - 1) / ROUND * ROUND;
+	const size_t t0 = (size_t) blockIdx.x * per;
+	const size_t t1 = t0 + per < N ? t0 + per : N;
+	for (size_t ts = t0; ts < t1; ts += ROUND) {
+		const size_t te = ts + ROUND < t1 ? ts + ROUND : t1;
+		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) cnt[i] = 0;
+		__syncthreads();
+		u64 r_it[PER];
+#pragma unroll
+		for (u32 j = 0; j < PER; j += 2) {                            // 16-byte loads
+			const size_t t = ts + ((size_t) (j / 2) * PART_THREADS + threadIdx.x) * 2;
+			r_it[j] = IT_HOLE; r_it[j + 1] = IT_HOLE;
+			if (t + 1 < te) { const ulonglong2 v = *(const ulonglong2*) &in[t]; r_it[j] = v.x; r_it[j + 1] = v.y; }
+			else if (t < te) r_it[j] = in[t];
+		}
+#pragma unroll
+		for (u32 j = 0; j < PER; j++) if (r_it[j] != IT_HOLE) atomicAdd(&cnt[(u32) (r_it[j] >> IT_SURV_SHIFT) >> range_shift], 1u);
+		__syncthreads();
+		part_scan(cnt, base, tmp, nbk);
+		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) {
+			cur[i] = base[i];
+			gbase[i] = cnt[i] ? atomicAdd(&gcur[i], cnt[i]) : 0u;
+		}
+		__syncthreads();
+#pragma unroll
+		for (u32 j = 0; j < PER; j++) if (r_it[j] != IT_HOLE) stage[atomicAdd(&cur[(u32) (r_it[j] >> IT_SURV_SHIFT) >> range_shift], 1u)] = r_it[j];
+		__syncthreads();
+		const u32 n = base[nbk];
+		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
+			const u64 x = stage[i];
+			const u32 b = (u32) (x >> IT_SURV_SHIFT) >> range_shift;
+			out[gbase[b] + (i - base[b])] = x;
+		}
+		__syncthreads();
+	}
+}
+
+// second level (more than 1024 survivor ranges): segment `seg` of the level-1 output is split over `slices` workgroups and cut
+// into 2^sub_bits ranges
+__global__ __launch_bounds__(PART_THREADS) void k_part_items2(const u64* __restrict__ in, const u32* __restrict__ seg_start, u32 seg_shift, u32 slices,
+                                                              u32 range_shift, u32 sub_bits, u32* __restrict__ gcur, u64* __restrict__ out) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	u64* stage = (u64*) smem;
+	__shared__ u32 cnt[PART_MAXB], base[PART_MAXB + 1], cur[PART_MAXB], gbase[PART_MAXB], tmp[PART_THREADS];
+	constexpr u32 PER = PART_LDS_BYTES / 8 / PART_THREADS;
+	constexpr u32 ROUND = PER * PART_THREADS;
+	const u32 seg = blockIdx.x / slices, sl = blockIdx.x % slices;
+	const u32 nbk = 1u << sub_bits, mask = nbk - 1;
+	const size_t s0 = seg_start[(size_t) seg << seg_shift], s1 = seg_start[((size_t) seg + 1) << seg_shift];
+	const size_t per = (s1 - s0 + slices - 1) / slices;
+	const size_t t0 = s0 + (size_t) sl * per;
+	const size_t t1 = t0 + per < s1 ? t0 + per : s1;
+	u32* gc = gcur + ((size_t) seg << sub_bits);
+	for (size_t ts = t0; ts < t1; ts += ROUND) {
+		const size_t te = ts + ROUND < t1 ? ts + ROUND : t1;
+		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) cnt[i] = 0;
+		__syncthreads();
+		u64 r_it[PER];
+		u32 r_b[PER];
+#pragma unroll
+		for (u32 j = 0; j < PER; j++) {
+			const size_t t = ts + (size_t) j * PART_THREADS + threadIdx.x;
+			r_b[j] = NONE32;
+			if (t < te) { r_it[j] = in[t]; r_b[j] = ((u32) (r_it[j] >> IT_SURV_SHIFT) >> range_shift) & mask; }
+		}
+#pragma unroll
+		for (u32 j = 0; j < PER; j++) if (r_b[j] != NONE32) atomicAdd(&cnt[r_b[j]], 1u);
+		__syncthreads();
+		part_scan(cnt, base, tmp, nbk);
+		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) {
+			cur[i] = base[i];
+			gbase[i] = cnt[i] ? atomicAdd(&gc[i], cnt[i]) : 0u;
+		}
+		__syncthreads();
+#pragma unroll
+		for (u32 j = 0; j < PER; j++) if (r_b[j] != NONE32) stage[atomicAdd(&cur[r_b[j]], 1u)] = r_it[j];
+		__syncthreads();
+		const u32 n = base[nbk];
+		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
+			const u64 x = stage[i];
+			const u32 b = ((u32) (x >> IT_SURV_SHIFT) >> range_shift) & mask;
+			out[gbase[b] + (i - base[b])] = x;
+		}
+		__syncthreads();
+	}
+}
+
+// one workgroup per range of 2^range_shift survivors: frequency, first sight, in-edge first sights (LDS arrays, direct index).
+// Lanes of a wave that hit the same survivor (hot nodes) are combined before they touch LDS.
+#define RC_THREADS 512
+template <u32 SB>
+__global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ items, const u32* __restrict__ range_start, u32 ns, u64 rec_base,
+                                                        u32* __restrict__ ucnt, u64* __restrict__ ufirst, u64* __restrict__ in_first) {
+	__shared__ u32 c[SB];
+	__shared__ u64 f[SB];
+	__shared__ u64 ef[SB * 4];
+	const u32 b = blockIdx.x;
+	for (u32 i = threadIdx.x; i < SB; i += RC_THREADS) { c[i] = 0; f[i] = NONE64; }
+	for (u32 i = threadIdx.x; i < SB * 4; i += RC_THREADS) ef[i] = NONE64;
+	__syncthreads();
+	const u32 i0 = range_start[b], i1 = range_start[b + 1];
+	const u32 s0 = b * SB;
+	for (u32 i = i0 + threadIdx.x; i < ((i1 - i0 + RC_THREADS - 1) / RC_THREADS) * RC_THREADS + i0; i += RC_THREADS) {
+		const bool live = i < i1;
+		const u64 x = live ? items[i] : 0ull;
+		const u32 sl = live ? (u32) (x >> IT_SURV_SHIFT) - s0 : 0u;
+		const u64 inst = x & IT_INST_MASK;
+		// the lanes that share the first live lane's survivor are folded into one add and one min when they are many
+		bool mine = live;
+		const u64 act = __ballot(live);
+		if (act) {
+			const int leader = __ffsll((long long) act) - 1;
+			const u32 lsl = (u32) __builtin_amdgcn_readlane((int) sl, leader);
+			const bool same = live && sl == lsl;
+			const u64 m = __ballot(same);
+			if (__popcll(m) >= 8) {
+				// 35-bit minimum in two steps: low words among the lanes holding the minimal high word
+				const u32 hi_min = vdjx_wave_min(same ? (u32) (inst >> 32) : 0xFFFFFFFFu);
+				const u32 lo_min = vdjx_wave_min(same && (u32) (inst >> 32) == hi_min ? (u32) inst : 0xFFFFFFFFu);
+				if (__lane_id() == leader) {
+					atomicAdd(&c[lsl], (u32) __popcll(m));
+					atomicMin((unsigned long long*) &f[lsl], ((unsigned long long) hi_min << 32) | lo_min);
+				}
+				mine = live && !same;
+			}
+		}
+		if (mine) { atomicAdd(&c[sl], 1u); atomicMin((unsigned long long*) &f[sl], (unsigned long long) inst); }
+		if (live && ((x >> 37) & 1ull)) {
+			unsigned long long* e = (unsigned long long*) &ef[sl * 4 + (u32) ((x >> 35) & 3ull)];
+			if (*(volatile unsigned long long*) e > inst) atomicMin(e, (unsigned long long) inst);     // first sights only ever decrease
+		}
+	}
+	__syncthreads();
+	const u64 add = rec_base << 6;
+	for (u32 i = threadIdx.x; i < SB; i += RC_THREADS) {
+		const u32 sidx = s0 + i;
+		if (sidx >= ns) break;
+		ucnt[sidx] = c[i];
+		ufirst[sidx] = f[i] == NONE64 ? NONE64 : f[i] + add;
+	}
+	for (u32 i = threadIdx.x; i < SB * 4; i += RC_THREADS) {
+		const u32 sidx = s0 + (i >> 2);
+		if (sidx >= ns) break;
+		in_first[(size_t) s0 * 4 + i] = ef[i] == NONE64 ? NONE64 : ef[i] + add;
+	}
+}
+
+// in-edge slots (v, first base of u) -> the predecessor u, and the out-edge slot (u, last base of v) of the same edge
+__global__ void k_edges_from_in(SurvTable t, u32 n, int k, const u64* __restrict__ in_first, u32* __restrict__ in_from,
+                                u64* __restrict__ edge_first, u32* __restrict__ edge_to) {
+	const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n * 4u) return;
+	const u64 fs = in_first[e];
+	if (fs == NONE64) { in_from[e] = NONE32; return; }
+	const u32 v = e >> 2, a = e & 3u;
+	const ulonglong2 kk = t.skey[v];
+	const u128 kv = ((u128) kk.y << 64) | kk.x;
+	const u128 ku = (kv >> 2) | ((u128) a << (2 * (k - 1)));
+	const int u = surv_lookup2(t, (u64) ku, (u64) (ku >> 64));
+	in_from[e] = u >= 0 ? (u32) u : NONE32;        // (always found: the walk saw it survive)
+	if (u >= 0) {
+		const u32 oe = (u32) u * 4u + ((u32) kk.x & 3u);
+		edge_first[oe] = fs;
+		edge_to[oe] = v;
+	}
+}
+
 // ----------------------------------------------------------------------------------------------
 // multi-GPU: survivor records as exchanged between owners
 // ----------------------------------------------------------------------------------------------
@@ -1268,6 +2007,25 @@ struct NodeOut {
 	u64* first_inst; u32* gcnt; u32* freq; uint8_t* hv; uint8_t* hj; u64* klo; u64* khi; char* kmers;
 	uint8_t* to_deg; u32* to_ids; uint8_t* from_deg; u32* from_ids;
 };
+
+// round 2: first sights are 38-bit instance ids (record << 6 | offset); the bitmap runs over the compact index record*P + offset
+__device__ inline u64 inst_compact(u64 inst, u32 P) { return (inst >> 6) * (u64) P + (inst & 63ull); }
+
+__global__ void k_mark_first2(const u64* __restrict__ ufirst, u32 n, u32 P, u32* __restrict__ bits) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const u64 c = inst_compact(ufirst[i], P);
+	atomicOr(&bits[c >> 5], 1u << (u32) (c & 31));
+}
+
+__global__ void k_node_rank2(const u64* __restrict__ ufirst, u32 n, u32 P, const u32* __restrict__ bits, const u32* __restrict__ word_pre,
+                             const u32* __restrict__ block_pre, u32* __restrict__ rank) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const u64 c = inst_compact(ufirst[i], P);
+	const u64 w = c >> 5;
+	rank[i] = block_pre[w / POPC_WORDS] + word_pre[w] + __popc(bits[w] & ((1u << (u32) (c & 31)) - 1u));
+}
 
 // roots (identify_root_nodes, A2:653-676: nodes without predecessor) as an ascending index list
 __global__ __launch_bounds__(256) void k_root_count(const uint8_t* __restrict__ from_deg, u32 n, u32* __restrict__ block_cnt) {
@@ -1359,6 +2117,48 @@ __global__ void k_node_emit(const u64* __restrict__ s_lo, const u64* __restrict_
 	sort4_desc(f, id);
 	deg = 0;
 	for (int e = 0; e < 4; e++) { o.from_ids[(size_t) r * 4 + e] = f[e] != NONE32 ? id[e] : 0; deg += f[e] != NONE32; }
+	o.from_deg[r] = (uint8_t) deg;
+}
+
+__device__ inline void sort4_desc64(u64 (&f)[4], u32 (&id)[4]) {
+	// newest first sight first (prepend-on-first-sight lists, A2:223-237); absent entries (NONE64) go last
+#define CSW(a, b) { const bool sw = kk[a] < kk[b]; if (sw) { u64 t = kk[a]; kk[a] = kk[b]; kk[b] = t; u32 u = id[a]; id[a] = id[b]; id[b] = u; } }
+	u64 kk[4];
+	for (int i = 0; i < 4; i++) kk[i] = f[i] == NONE64 ? 0ull : f[i] + 1;
+	CSW(0, 1) CSW(2, 3) CSW(0, 2) CSW(1, 3) CSW(1, 2)
+	for (int i = 0; i < 4; i++) f[i] = kk[i] ? kk[i] - 1 : NONE64;
+#undef CSW
+}
+
+__global__ void k_node_emit2(const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, const u32* __restrict__ s_gcnt,
+                             const u32* __restrict__ s_ucnt, const u64* __restrict__ s_ufirst, const uint8_t* __restrict__ hv,
+                             const uint8_t* __restrict__ hj, const u32* __restrict__ rank, const u64* __restrict__ edge_first,
+                             const u32* __restrict__ edge_to, const u64* __restrict__ in_first, const u32* __restrict__ in_from,
+                             u32 n, int k, NodeOut o) {
+	const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= n) return;
+	const u32 r = rank[s];
+	o.first_inst[r] = s_ufirst[s];
+	o.gcnt[r] = s_gcnt[s];
+	o.freq[r] = s_ucnt[s] > 32765u ? 32765u : s_ucnt[s];            // A2:261-265
+	o.hv[r] = hv[s];
+	o.hj[r] = hj[s];
+	const u128 key = ((u128) s_hi[s] << 64) | s_lo[s];
+	for (int j = 0; j < k; j++) {
+		const u32 b = (u32) (key >> (2 * (k - 1 - j))) & 3u;
+		o.kmers[(size_t) r * k + j] = b == 0 ? 'A' : (b == 1 ? 'T' : (b == 2 ? 'C' : 'G'));
+	}
+	u64 f[4];
+	u32 id[4];
+	for (int e = 0; e < 4; e++) { f[e] = edge_first[(size_t) s * 4 + e]; id[e] = f[e] != NONE64 ? rank[edge_to[(size_t) s * 4 + e]] + 1 : 0; }
+	sort4_desc64(f, id);
+	u32 deg = 0;
+	for (int e = 0; e < 4; e++) { o.to_ids[(size_t) r * 4 + e] = f[e] != NONE64 ? id[e] : 0; deg += f[e] != NONE64; }
+	o.to_deg[r] = (uint8_t) deg;
+	for (int e = 0; e < 4; e++) { f[e] = in_first[(size_t) s * 4 + e]; id[e] = f[e] != NONE64 ? rank[in_from[(size_t) s * 4 + e]] + 1 : 0; }
+	sort4_desc64(f, id);
+	deg = 0;
+	for (int e = 0; e < 4; e++) { o.from_ids[(size_t) r * 4 + e] = f[e] != NONE64 ? id[e] : 0; deg += f[e] != NONE64; }
 	o.from_deg[r] = (uint8_t) deg;
 }
 
@@ -1715,6 +2515,362 @@ int stage_finish(vdjx_ctx* c, A& db, const Survivors& sv, const u32* edge_first,
 	return VDJX_OK;
 }
 
+// ==============================================================================================
+// round-2 host driver
+// ==============================================================================================
+template <typename TUP> struct GTuples {
+	TUP* t = nullptr;
+	u32* bucket_start = nullptr;      // [NB+1]
+	u32 NB = 0, N = 0;
+};
+
+struct SurvivorsG {
+	u64 *lo = nullptr, *hi = nullptr, *gfirst = nullptr, *ufirst = nullptr;
+	u32 *gcnt = nullptr, *ucnt = nullptr;
+	u32 n = 0;
+	u64 ndist = 0;
+};
+
+inline u32 ceil_log2_u64(u64 x) { u32 b = 0; while ((1ull << b) < x) b++; return b; }
+
+// Phase A, partition: the gated instances of `pool` as tuples grouped by the top T bits of the k-mer hash (T chosen from their
+// number: ~4096 per bucket).  One host read (the tuple count) sizes everything that follows.
+template <typename TUP, typename A>
+int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k, size_t per_bucket, u64 geometry_instances, GTuples<TUP>* out) {
+	hipStream_t st = c->stream;
+	const size_t R = pool->n_records;
+	const int P = pool->rl - k + 1;
+	const u64 NI = geometry_instances ? geometry_instances : (u64) R * (u64) P;
+	static const size_t dflt = tune("VDJX_BUCKET_TUPLES", 4096);
+	const size_t per = per_bucket ? per_bucket : dflt;
+	// histogram resolution: every bucket count the build could choose is a prefix of it (<= 2^15: 128 KB of LDS)
+	u32 HB = ceil_log2_u64((NI + per - 1) / per);
+	HB = std::max(8u, std::min(15u, HB));
+	const u32 NBH = 1u << HB;
+	u32 nblk = (u32) std::min<size_t>(512, (R + 4095) / 4096);
+	if (nblk == 0) nblk = 1;
+	size_t rpb = (R + nblk - 1) / nblk;
+	u32 *hcnt, *hstart;
+	HIP_TRY(db.alloc(&hcnt, NBH));
+	HIP_TRY(db.alloc(&hstart, NBH + 1));
+	HIP_TRY(hipMemsetAsync(hcnt, 0, (size_t) NBH * 4, st));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_gated_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NBH * 4)));
+	{
+		vdjx_prof_scope ps(c, "k_gated_hist");
+		hipLaunchKernelGGL(k_gated_hist, dim3(nblk), dim3(HIST_THREADS), (size_t) NBH * 4, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, pool->rl, k, HB, rpb, hcnt);
+	}
+	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, hcnt, NBH, hstart);
+	u32 N = 0;
+	HIP_TRY(hipMemcpyAsync(&N, hstart + NBH, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	out->N = N;
+	// bucket bits from the actual number of gated instances; in the sharded build every rank must cut the same buckets, so there
+	// the geometry follows the common bound `geometry_instances` instead
+	const u64 Ng = geometry_instances ? geometry_instances : (u64) N;
+	static const size_t refine = tune("VDJX_REFINE_TUPLES", 4096);
+	u32 T = 8;
+	while (T < HB && ((u64) per << T) < Ng) T++;
+	u32 extra = 0;
+	if (T == HB && HB == 15 && Ng / NBH > 2 * (per_bucket ? per_bucket : refine)) {
+		extra = 1;
+		while (extra < 5 && (Ng >> extra) / NBH > (per_bucket ? per_bucket : refine)) extra++;
+	}
+	const u32 Tt = T + extra;
+	const u32 NBt = 1u << Tt;
+	HIP_TRY(db.alloc(&out->t, (size_t) N + 1));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_part_records_g<TUP>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_part_tuples_g<TUP>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
+	// pass geometry: <= 1024 buckets in one pass; otherwise 256 coarse x the rest (large pools: 2^(Tt-10) coarse x 1024)
+	u32 cbits = Tt, fbits = 0;
+	if (Tt > 10) { cbits = extra ? Tt - 10 : 8; fbits = Tt - cbits; }
+	const u32 NBc = 1u << cbits;
+	u32 nblk2 = (u32) std::min<size_t>(1024, (R + 2047) / 2048);
+	if (nblk2 == 0) nblk2 = 1;
+	rpb = (R + nblk2 - 1) / nblk2;
+	u32* gcur;
+	HIP_TRY(db.alloc(&gcur, NBc));
+	TUP* l1 = out->t;
+	if (fbits) HIP_TRY(db.alloc(&l1, (size_t) N + 1));
+	{
+		vdjx_prof_scope ps(c, "k_part_records");
+		hipLaunchKernelGGL(k_init_cursors, dim3((NBc + 255) / 256), dim3(256), 0, st, hstart, NBc, HB - cbits, gcur);
+		hipLaunchKernelGGL(k_part_records_g<TUP>, dim3(nblk2), dim3(PART_THREADS), PART_LDS_BYTES, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, rec_base,
+		                   pool->rl, k, 64 - cbits, NBc, rpb, gcur, l1);
+	}
+	u32* tstart;                                   // starts of the final buckets
+	HIP_TRY(db.alloc(&tstart, NBt + 1));
+	out->NB = NBt;
+	out->bucket_start = tstart;
+	static const u32 slices = (u32) tune("VDJX_PART_SLICES", 8);
+	if (extra) {
+		u32* fine_cnt;
+		HIP_TRY(db.alloc(&fine_cnt, NBt));
+		HIP_TRY(hipMemsetAsync(fine_cnt, 0, (size_t) NBt * 4, st));
+		vdjx_prof_scope ps(c, "k_seg_hist");
+		hipLaunchKernelGGL(k_seg_hist_g<TUP>, dim3(NBc * slices), dim3(512), 0, st, l1, hstart, HB - cbits, slices, 64 - Tt, fbits, fine_cnt);
+		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, fine_cnt, NBt, tstart);
+	} else {
+		hipLaunchKernelGGL(k_pick_u32, dim3((NBt + 1 + 255) / 256), dim3(256), 0, st, hstart, 1u << (HB - Tt), NBt + 1, tstart);
+	}
+	if (fbits) {
+		u32* gcur2;
+		HIP_TRY(db.alloc(&gcur2, NBt));
+		vdjx_prof_scope ps(c, "k_part_tuples");
+		hipLaunchKernelGGL(k_init_cursors, dim3((NBt + 255) / 256), dim3(256), 0, st, tstart, NBt, 0u, gcur2);
+		hipLaunchKernelGGL(k_part_tuples_g<TUP>, dim3(NBc * slices), dim3(PART_THREADS), PART_LDS_BYTES, st, l1, hstart, HB - cbits, slices, 64 - Tt, fbits,
+		                   gcur2, out->t);
+	}
+	return VDJX_OK;
+}
+
+// Phase A, table + prune per bucket
+template <typename TUP, typename A>
+int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView& pv, u64 rec_base, int k, int mf, int mq, SurvivorsG* sv) {
+	hipStream_t st = c->stream;
+	{
+		static const u32 sub = (u32) tune("VDJX_SUB_TUPLES", 262144);
+		HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sub_tuples), &sub, 4, 0, hipMemcpyHostToDevice, st));
+	}
+	if (mq >= 255) mq = 254;                                        // A2:1514-1516
+	const u32 mqq = (u32) (mq < 0 ? 0 : (mq > 214 ? 214 : mq));      // a sum >= 214 reads as 255 (A2:356-360)
+	const u32 tlow = 1 + (mqq + 19) / 20;                           // see k_bucket_finalize
+	const u32 cmin = (u32) std::max(mf, 2);
+	const u32 mfu = (u32) std::max(mf, 0);
+	const u32 cap = t.N / 2 + 16;                                   // a survivor has at least two gated instances
+	u32 *g_err, *n_surv;
+	u64* g_distinct;
+	HIP_TRY(db.alloc(&sv->lo, cap)); HIP_TRY(db.alloc(&sv->hi, cap)); HIP_TRY(db.alloc(&sv->gcnt, cap)); HIP_TRY(db.alloc(&sv->gfirst, cap));
+	HIP_TRY(db.alloc(&g_err, 1)); HIP_TRY(db.alloc(&n_surv, 1)); HIP_TRY(db.alloc(&g_distinct, 64 * 16));
+	HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
+	HIP_TRY(hipMemsetAsync(n_surv, 0, 4, st));
+	HIP_TRY(hipMemsetAsync(g_distinct, 0, 64 * 16 * 8, st));
+	SurvOutG so{sv->lo, sv->hi, sv->gcnt, sv->gfirst, n_surv, cap};
+	if (t.N) {
+		vdjx_prof_scope ps(c, "k_gated_reduce");
+		hipLaunchKernelGGL(k_gated_reduce<TUP>, dim3(t.NB), dim3(RD_THREADS), 0, st, t.t, t.bucket_start, pv.bases, pv.nmask, pv.quals, pv.qstride, k, rec_base,
+		                   mfu, cmin, mqq, tlow, so, g_distinct, g_err);
+	}
+	u32 ns = 0, err = 0;
+	u64 spread[64 * 16];
+	HIP_TRY(hipMemcpyAsync(&ns, n_surv, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&err, g_err, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(spread, g_distinct, sizeof(spread), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	if (err) { vdjx_set_error("k_gated_reduce: %u buckets could not be split to fit LDS", err); return VDJX_EHIP; }
+	if (ns > cap) { vdjx_set_error("survivor capacity logic failed (%u > %u)", ns, cap); return VDJX_EHIP; }
+	sv->ndist = 0;
+	for (int i = 0; i < 64; i++) sv->ndist += spread[i * 16];
+	sv->n = ns;
+	return VDJX_OK;
+}
+
+// Phase B over the records of `pool` (local numbering; rec_base is added to the first sights): node frequency and first sight,
+// in-edge first sights and, derived from them, both edge directions.  Output arrays are caller-provided:
+//   ucnt u32 [ns] (raw count), ufirst u64 [ns], in_first u64 [ns*4], in_from u32 [ns*4], edge_first u64 [ns*4], edge_to u32 [ns*4]
+struct RecountOut { u32* ucnt; u64* ufirst; u64* in_first; u32* in_from; u64* edge_first; u32* edge_to; };
+
+template <typename A>
+int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k, const u64* s_lo, const u64* s_hi, u32 ns, const RecountOut& ro,
+                  bool derive_edges) {
+	hipStream_t st = c->stream;
+	const size_t R = pool->n_records;
+	const int P = pool->rl - k + 1;
+	if (ns >= (1u << 26)) { vdjx_set_error("more than 2^26 surviving k-mers: not supported by the recount items"); return VDJX_ELIMIT; }
+	if (R >= (1ull << 29)) { vdjx_set_error("more than 2^29 records on one GPU: not supported by the recount items"); return VDJX_ELIMIT; }
+	u32 tmask = 1023;
+	while ((size_t) tmask + 1 < (size_t) ns * 2) tmask = tmask * 2 + 1;
+	const u32 idx_bits = std::max(1u, ceil_log2_u64((u64) ns + 1));
+	u32 *table, *succ;
+	ulonglong2* skey;
+	HIP_TRY(db.alloc(&table, (size_t) tmask + 1));
+	HIP_TRY(db.alloc(&skey, ns));
+	HIP_TRY(db.alloc(&succ, (size_t) ns * 4));
+	HIP_TRY(hipMemsetAsync(table, 0, ((size_t) tmask + 1) * 4, st));
+	SurvTable tb{table, tmask, idx_bits, skey};
+	{
+		vdjx_prof_scope ps(c, "k_surv_table");
+		hipLaunchKernelGGL(k_surv_table2, dim3((ns + 255) / 256), dim3(256), 0, st, s_lo, s_hi, ns, table, tmask, idx_bits, skey);
+		hipLaunchKernelGGL(k_succ_links2, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, tb, ns, k, succ);
+	}
+	// survivor ranges of 1024 (one recount workgroup each); more than 1024 ranges take a second partition level
+	const u32 range_shift = 10;
+	const u32 n_ranges = (ns + 1023) / 1024;
+	u32 l2bits = 0;
+	while (((n_ranges + (1u << l2bits) - 1) >> l2bits) > PART_MAXB) l2bits++;
+	const u32 n_coarse = (n_ranges + (1u << l2bits) - 1) >> l2bits;
+	const u32 n_ranges_p = n_coarse << l2bits;                      // padded: every coarse segment has 2^l2bits ranges
+	// raw item blocks
+	u32 nblk = (u32) std::min<size_t>(2048, (R + WALK_THREADS * 8 - 1) / (WALK_THREADS * 8));
+	if (nblk == 0) nblk = 1;
+	const size_t nwaves = (size_t) nblk * (WALK_THREADS / 64);
+	const size_t NI = R * (size_t) P;
+	u32 blk_items = 4096;
+	while (blk_items > 256 && nwaves * blk_items > NI / 2 + 65536) blk_items >>= 1;
+	const u64 raw_cap = (u64) NI + (u64) NI / (blk_items / 64) + nwaves * (u64) blk_items + blk_items;
+	u64 *raw, *items;
+	unsigned long long* g_cursor;
+	u32 *range_cnt, *range_start, *g_err, *gcur;
+	HIP_TRY(db.alloc(&raw, (size_t) raw_cap));
+	HIP_TRY(db.alloc(&g_cursor, 1));
+	HIP_TRY(db.alloc(&range_cnt, n_ranges_p));
+	HIP_TRY(db.alloc(&range_start, n_ranges_p + 1));
+	HIP_TRY(db.alloc(&g_err, 1));
+	HIP_TRY(hipMemsetAsync(g_cursor, 0, 8, st));
+	HIP_TRY(hipMemsetAsync(range_cnt, 0, (size_t) n_ranges_p * 4, st));
+	HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
+	const size_t lds_walk = (size_t) n_ranges_p * 4;
+	if (lds_walk > 64 * 1024) { vdjx_set_error("too many survivor ranges for the walk histogram"); return VDJX_ELIMIT; }
+	HIP_TRY(hipFuncSetAttribute((const void*) k_walk_items, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_walk));
+	if (R) {
+		vdjx_prof_scope ps(c, "k_walk_items");
+		hipLaunchKernelGGL(k_walk_items, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, k, tb, succ, range_shift,
+		                   n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err);
+	}
+	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, range_cnt, n_ranges_p, range_start);
+	// the partitioned items: at most one per instance
+	HIP_TRY(db.alloc(&items, NI + 1));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_part_items, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
+	HIP_TRY(db.alloc(&gcur, n_ranges_p));
+	{
+		vdjx_prof_scope ps(c, "k_part_items");
+		u32 npb = (u32) std::min<size_t>(1024, (NI + 65535) / 65536);
+		if (npb == 0) npb = 1;
+		if (!l2bits) {
+			hipLaunchKernelGGL(k_init_cursors, dim3((n_ranges_p + 255) / 256), dim3(256), 0, st, range_start, n_ranges_p, 0u, gcur);
+			hipLaunchKernelGGL(k_part_items, dim3(npb), dim3(PART_THREADS), PART_LDS_BYTES, st, raw, g_cursor, range_shift, n_ranges_p, gcur, items);
+		} else {
+			// level 1 into `n_coarse` segments (written over a second buffer), level 2 inside each segment
+			u64* l1;
+			u32* gcur1;
+			HIP_TRY(db.alloc(&l1, NI + 1));
+			HIP_TRY(db.alloc(&gcur1, n_coarse));
+			HIP_TRY(hipFuncSetAttribute((const void*) k_part_items2, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
+			hipLaunchKernelGGL(k_init_cursors, dim3((n_coarse + 255) / 256), dim3(256), 0, st, range_start, n_coarse, l2bits, gcur1);
+			hipLaunchKernelGGL(k_part_items, dim3(npb), dim3(PART_THREADS), PART_LDS_BYTES, st, raw, g_cursor, range_shift + l2bits, n_coarse, gcur1, l1);
+			hipLaunchKernelGGL(k_init_cursors, dim3((n_ranges_p + 255) / 256), dim3(256), 0, st, range_start, n_ranges_p, 0u, gcur);
+			hipLaunchKernelGGL(k_part_items2, dim3(n_coarse * 8), dim3(PART_THREADS), PART_LDS_BYTES, st, l1, range_start, l2bits, 8u, range_shift, l2bits, gcur, items);
+		}
+	}
+	{
+		vdjx_prof_scope ps(c, "k_recount");
+		hipLaunchKernelGGL(k_recount<1024>, dim3(n_ranges), dim3(RC_THREADS), 0, st, items, range_start, ns, rec_base, ro.ucnt, ro.ufirst, ro.in_first);
+	}
+	if (derive_edges) {
+		HIP_TRY(hipMemsetAsync(ro.edge_first, 0xFF, (size_t) ns * 32, st));
+		hipLaunchKernelGGL(k_edges_from_in, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, tb, ns, k, ro.in_first, ro.in_from, ro.edge_first, ro.edge_to);
+	}
+	u32 err = 0;
+	HIP_TRY(hipMemcpyAsync(&err, g_err, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	if (err) { vdjx_set_error("k_walk_items: item buffer too small (%u waves stopped)", err); return VDJX_EHIP; }
+	return VDJX_OK;
+}
+
+// K6 for the round-2 arrays
+template <typename A>
+int stage_finish2(vdjx_ctx* c, A& db, const SurvivorsG& sv, const RecountOut& ro, u64 n_records_total, int k, int P, vdjx_graph* g) {
+	hipStream_t st = c->stream;
+	const u32 ns = sv.n;
+	g->n = ns;
+	g->k = k;
+	g->ctx = c;
+	g->device = c->device;
+	if (ns == 0) return VDJX_OK;
+	uint8_t *d_hv, *d_hj;
+	HIP_TRY(db.alloc(&d_hv, ns));
+	HIP_TRY(db.alloc(&d_hj, ns));
+	{
+		vdjx_prof_scope ps(c, "k_node_flags");
+		hipLaunchKernelGGL(k_node_flags, dim3((ns + 255) / 256), dim3(256), 0, st, sv.lo, sv.hi, ns, k, c->d_vbits, c->d_jbits, d_hv, d_hj);
+	}
+	const u64 NIc = n_records_total * (u64) P;
+	const u64 nwords64 = (NIc + 31) / 32;
+	if (nwords64 >= (1ull << 32)) { vdjx_set_error("instance space too large for the creation-order bitmap"); return VDJX_ELIMIT; }
+	const u32 nwords = (u32) nwords64;
+	const u32 npb = (nwords + POPC_WORDS - 1) / POPC_WORDS;
+	u32 *bits, *word_pre, *block_sum, *block_pre, *rank;
+	HIP_TRY(db.alloc(&bits, nwords));
+	HIP_TRY(db.alloc(&word_pre, nwords));
+	HIP_TRY(db.alloc(&block_sum, npb));
+	HIP_TRY(db.alloc(&block_pre, npb + 1));
+	HIP_TRY(db.alloc(&rank, ns));
+	auto up = [](size_t b) { return (b + 255) & ~(size_t) 255; };
+	const size_t need = up((size_t) ns * 8) + 5 * up((size_t) ns * 4) + 4 * up(ns) + 2 * up((size_t) ns * 16) + up((size_t) ns * k);
+	{
+		hipError_t e = c->blocks.acquire(need, &g->d_block, &g->block_cap);
+		if (e != hipSuccess) { vdjx_set_error("graph alloc (%zu bytes): %s", need, hipGetErrorString(e)); return VDJX_EHIP; }
+	}
+	char* bp = g->d_block;
+	auto carve = [&](size_t b) { char* r = bp; bp += up(b); return r; };
+	NodeOut no;
+	no.klo = no.khi = nullptr;
+	no.first_inst = g->d_first_inst = (u64*) carve((size_t) ns * 8);
+	no.gcnt = g->d_gcnt = (u32*) carve((size_t) ns * 4);
+	no.freq = g->d_freq = (u32*) carve((size_t) ns * 4);
+	no.to_ids = g->d_to_ids = (u32*) carve((size_t) ns * 16);
+	no.from_ids = g->d_from_ids = (u32*) carve((size_t) ns * 16);
+	no.hv = g->d_hv = (uint8_t*) carve(ns);
+	no.hj = g->d_hj = (uint8_t*) carve(ns);
+	no.to_deg = g->d_to_deg = (uint8_t*) carve(ns);
+	no.from_deg = g->d_from_deg = (uint8_t*) carve(ns);
+	no.kmers = g->d_kmers = carve((size_t) ns * k);
+	g->d_roots = (u32*) carve((size_t) ns * 4);
+	HIP_TRY(hipMemsetAsync(bits, 0, (size_t) nwords * 4, st));
+	{
+		vdjx_prof_scope ps(c, "k_node_order");
+		hipLaunchKernelGGL(k_mark_first2, dim3((ns + 255) / 256), dim3(256), 0, st, sv.ufirst, ns, (u32) P, bits);
+		hipLaunchKernelGGL(k_popc_blocks, dim3(npb), dim3(256), 0, st, bits, nwords, word_pre, block_sum);
+		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, block_sum, npb, block_pre);
+		hipLaunchKernelGGL(k_node_rank2, dim3((ns + 255) / 256), dim3(256), 0, st, sv.ufirst, ns, (u32) P, bits, word_pre, block_pre, rank);
+		hipLaunchKernelGGL(k_node_emit2, dim3((ns + 255) / 256), dim3(256), 0, st, sv.lo, sv.hi, sv.gcnt, sv.ucnt, sv.ufirst, d_hv, d_hj, rank,
+		                   ro.edge_first, ro.edge_to, ro.in_first, ro.in_from, ns, k, no);
+	}
+	u32 n_roots = 0;
+	{
+		const u32 nrb = (ns + 255) / 256;
+		u32 *rb_cnt, *rb_start;
+		HIP_TRY(db.alloc(&rb_cnt, nrb));
+		HIP_TRY(db.alloc(&rb_start, nrb + 1));
+		vdjx_prof_scope ps(c, "k_root_list");
+		hipLaunchKernelGGL(k_root_count, dim3(nrb), dim3(256), 0, st, no.from_deg, ns, rb_cnt);
+		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, rb_cnt, nrb, rb_start);
+		hipLaunchKernelGGL(k_root_list, dim3(nrb), dim3(256), 0, st, no.from_deg, ns, rb_start, g->d_roots);
+		HIP_TRY(hipMemcpyAsync(&n_roots, rb_start + nrb, 4, hipMemcpyDeviceToHost, st));
+	}
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	g->n_roots = n_roots;
+	vdjx_prof_collect(c);
+	return VDJX_OK;
+}
+
+template <typename TUP>
+int kmer_build_impl2(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, vdjx_graph* g) {
+	const int P = pool->rl - k + 1;
+	vdjx_work db(c);
+	GTuples<TUP> t;
+	int rc = stage_gated_partition<TUP>(c, db, pool, 0, k, 0, 0, &t);
+	if (rc) return rc;
+	PoolView pv{pool->d_bases, pool->d_nmask, pool->d_quals, pool->qstride};
+	SurvivorsG sv;
+	rc = stage_gated_reduce<TUP>(c, db, t, pv, 0, k, mf, mq, &sv);
+	if (rc) return rc;
+	g->pre_nodes = (size_t) sv.ndist;
+	RecountOut ro{};
+	if (sv.n) {
+		HIP_TRY(db.alloc(&sv.ucnt, sv.n)); HIP_TRY(db.alloc(&sv.ufirst, sv.n));
+		HIP_TRY(db.alloc(&ro.in_first, (size_t) sv.n * 4)); HIP_TRY(db.alloc(&ro.in_from, (size_t) sv.n * 4));
+		HIP_TRY(db.alloc(&ro.edge_first, (size_t) sv.n * 4)); HIP_TRY(db.alloc(&ro.edge_to, (size_t) sv.n * 4));
+		ro.ucnt = sv.ucnt; ro.ufirst = sv.ufirst;
+		rc = stage_recount(c, db, pool, 0, k, sv.lo, sv.hi, sv.n, ro, true);
+		if (rc) return rc;
+	}
+	return stage_finish2(c, db, sv, ro, pool->n_records, k, P, g);
+}
+
 template <typename THI>
 int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, vdjx_graph* g) {
 	const int P = pool->rl - k + 1;
@@ -1750,13 +2906,18 @@ extern "C" int vdjx_kmer_build(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf
 	*out = nullptr;
 	if (pool->ctx != c) { vdjx_set_error("vdjx_kmer_build: pool belongs to another context"); return VDJX_EINVAL; }
 	if (k < 1 || k > VDJX_MAX_KMER || k > pool->rl) { vdjx_set_error("k=%d outside [1,min(%d,rl=%d)]", k, VDJX_MAX_KMER, pool->rl); return VDJX_ELIMIT; }
-	const size_t NI = pool->n_records * (size_t) (pool->rl - k + 1);
-	if (NI >= (1ull << 31)) { vdjx_set_error("records*offsets = %zu >= 2^31: shard the pool over more GPUs", NI); return VDJX_ELIMIT; }
 	if (k > 16 && !c->anchors_loaded) { vdjx_set_error("vdjx_kmer_build: call vdjx_anchor_sets_load first (k > 16)"); return VDJX_ESTATE; }
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_clear_errors();
 	vdjx_graph* g = new vdjx_graph();
-	int rc = key_hi_is_u32(k) ? kmer_build_impl<u32>(c, pool, k, mf, mq, g) : kmer_build_impl<u64>(c, pool, k, mf, mq, g);
+	int rc;
+	static const bool legacy = getenv("VDJX_LEGACY_BUILD") != nullptr;          // the round-1 build (every instance travels), for A/B runs
+	if (legacy) {
+		const size_t NI = pool->n_records * (size_t) (pool->rl - k + 1);
+		if (NI >= (1ull << 31)) { delete g; vdjx_set_error("records*offsets = %zu >= 2^31", NI); return VDJX_ELIMIT; }
+		rc = key_hi_is_u32(k) ? kmer_build_impl<u32>(c, pool, k, mf, mq, g) : kmer_build_impl<u64>(c, pool, k, mf, mq, g);
+	} else
+		rc = k <= 45 ? kmer_build_impl2<Tup16>(c, pool, k, mf, mq, g) : kmer_build_impl2<Tup24>(c, pool, k, mf, mq, g);
 	if (rc != VDJX_OK) { vdjx_graph_free(g); return rc; }
 	*out = g;
 	return VDJX_OK;
@@ -1835,10 +2996,6 @@ extern "C" void vdjx_shard_free(vdjx_shard* s) {
 /* sizes of the records the caller moves between ranks: 0 partial aggregate, 1 question, 2 answer */
 extern "C" size_t vdjx_shard_record_bytes(int kind) { return kind == 0 ? sizeof(Partial) : kind == 1 ? sizeof(uint2) : kind == 2 ? REPLY_BYTES : 0; }
 
-__global__ void k_pick_u32(const u32* __restrict__ src, u32 step, u32 n, u32* __restrict__ out) {
-	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) out[i] = src[(size_t) i * step];
-}
 
 template <typename THI>
 static int shard_local_impl(vdjx_shard* s) {
