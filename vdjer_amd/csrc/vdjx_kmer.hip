@@ -865,12 +865,13 @@ __global__ __launch_bounds__(512) void k_seg_hist_g(const TUP* __restrict__ in, 
 // ----------------------------------------------------------------------------------------------
 #define RD_THREADS 512
 #define RD_UNR 8
-#define RD_SLOTS 1024u
-#define RD_Q 1024u                  // remembered instances of low-count candidates (more: the quality rounds rescan the bucket)
+#define RD_SLOTS 2048u               // ~1,000 distinct gated k-mers per bucket of ~3,000 tuples (most are read once): half full
+#define RD_Q 512u                  // remembered instances of low-count candidates (more: the quality rounds rescan the bucket)
 #define RD_A 64u                    // quality-sum rows per round
 #define ST_CAND 1u
 #define ST_MULTI 2u
 #define ST_QOK 4u
+#define NONE16 0xFFFFu
 
 struct SurvOutG { u64* lo; u64* hi; u32* gcnt; u64* gfirst; u32* n; u32 cap; };
 
@@ -884,7 +885,8 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 	__shared__ u64 s_klo[RD_SLOTS];
 	__shared__ THI s_khi[RD_SLOTS];
 	__shared__ u64 s_first[RD_SLOTS];
-	__shared__ u32 s_cnt[RD_SLOTS], s_state[RD_SLOTS], s_lowid[RD_SLOTS];
+	__shared__ u32 s_cnt[RD_SLOTS], s_state[RD_SLOTS];        // s_state: ST_* flags in the top bits, low-count row / survivor position below
+	__shared__ unsigned short s_lowid[RD_SLOTS];
 	__shared__ u32 acc[RD_A * K3B_KW];
 	__shared__ u32 q_slot[RD_Q];
 	__shared__ u64 q_inst[RD_Q];
@@ -908,7 +910,7 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 		if (tid == 0) { s_over = 0; s_ndist = 0; }
 		__syncthreads();
 		for (u32 s = 0; s < S; s++) {
-			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) { s_khi[i] = EMPTY; s_cnt[i] = 0; s_first[i] = NONE64; s_state[i] = 0; s_lowid[i] = NONE32; }
+			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) { s_khi[i] = EMPTY; s_cnt[i] = 0; s_first[i] = NONE64; s_state[i] = 0; s_lowid[i] = NONE16; }
 			if (tid == 0) { s_nlow = 0; s_nq = 0; s_nsurv = 0; }
 			__syncthreads();
 			const bool one_chunk = n <= RD_UNR * RD_THREADS;
@@ -945,7 +947,7 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 				const u32 c = s_cnt[i];
 				if (c >= cmin) {
 					s_state[i] = ST_CAND;
-					if (c < tlow) s_lowid[i] = atomicAdd(&s_nlow, 1u);
+					if (c < tlow) s_lowid[i] = (unsigned short) atomicAdd(&s_nlow, 1u);
 				}
 			}
 			__syncthreads();
@@ -971,7 +973,7 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 					const u32 st = *(volatile u32*) &s_state[slot];
 					if (!(st & ST_CAND)) continue;
 					const u64 inst = r_t[j].inst();
-					if (s_lowid[slot] != NONE32) {
+					if (s_lowid[slot] != NONE16) {
 						const u32 qi = atomicAdd(&s_nq, 1u);
 						if (qi < RD_Q) { q_slot[qi] = (u32) slot; q_inst[qi] = inst; }
 					}
@@ -1007,7 +1009,7 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 						slot = (u32) sl; inst = x.inst();
 					}
 					const u32 lid = s_lowid[slot];
-					if (lid == NONE32 || lid < l0 || lid >= l0 + RD_A) continue;
+					if (lid == NONE16 || lid < l0 || lid >= l0 + RD_A) continue;
 					const u64 rec = (inst >> 6) - rec_base;
 					const u32 off = (u32) (inst & 63u);
 					const u32 qoff = inst == s_first[slot] ? 0u : off;
@@ -1032,7 +1034,7 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 				__syncthreads();
 				for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
 					const u32 lid = s_lowid[i];
-					if (lid == NONE32 || lid < l0 || lid >= l0 + RD_A) continue;
+					if (lid == NONE16 || lid < l0 || lid >= l0 + RD_A) continue;
 					const u32* row = acc + (lid - l0) * K3B_KW;
 					bool ok = true;
 					for (u32 w2 = 0; w2 < KW; w2++) {
@@ -1053,13 +1055,13 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 					const u32 c = craw > 32765u ? 32765u : craw;                  // A2:345-347
 					keep = c >= mf && (st & ST_MULTI) && (craw >= tlow || (st & ST_QOK));
 				}
-				s_lowid[i] = keep ? atomicAdd(&s_nsurv, 1u) : NONE32;            // (reused: position among this sub-pass's survivors)
+				s_lowid[i] = keep ? (unsigned short) atomicAdd(&s_nsurv, 1u) : NONE16;            // (reused: position among this sub-pass's survivors)
 			}
 			__syncthreads();
 			if (tid == 0) s_base = s_nsurv ? atomicAdd(so.n, s_nsurv) : 0;
 			__syncthreads();
 			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
-				if (s_lowid[i] == NONE32) continue;
+				if (s_lowid[i] == NONE16) continue;
 				const u32 pos = s_base + s_lowid[i];
 				if (pos < so.cap) {
 					so.lo[pos] = s_klo[i];
@@ -1867,24 +1869,33 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_items2(const u64* __restr
 // one workgroup per range of 2^range_shift survivors: frequency, first sight, in-edge first sights (LDS arrays, direct index).
 // Lanes of a wave that hit the same survivor (hot nodes) are combined before they touch LDS.
 #define RC_THREADS 512
-template <u32 SB>
+template <typename IT> struct RcNone;
+template <> struct RcNone<u32> { static constexpr u32 v = 0xFFFFFFFFu; };
+template <> struct RcNone<u64> { static constexpr u64 v = 0xFFFFFFFFFFFFFFFFull; };
+__device__ inline void rc_min(u32* p, u32 v) { atomicMin(p, v); }
+__device__ inline void rc_min(u64* p, u64 v) { atomicMin((unsigned long long*) p, (unsigned long long) v); }
+
+// IT = u32 while the local instance ids fit 32 bits (up to 2^26 records on this GPU): 24 bytes of LDS per survivor instead of 44
+template <u32 SB, typename IT>
 __global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ items, const u32* __restrict__ range_start, u32 ns, u64 rec_base,
                                                         u32* __restrict__ ucnt, u64* __restrict__ ufirst, u64* __restrict__ in_first) {
 	__shared__ u32 c[SB];
-	__shared__ u64 f[SB];
-	__shared__ u64 ef[SB * 4];
+	__shared__ IT f[SB];
+	__shared__ IT ef[SB * 4];
+	constexpr IT NONE = RcNone<IT>::v;
 	const u32 b = blockIdx.x;
-	for (u32 i = threadIdx.x; i < SB; i += RC_THREADS) { c[i] = 0; f[i] = NONE64; }
-	for (u32 i = threadIdx.x; i < SB * 4; i += RC_THREADS) ef[i] = NONE64;
+	for (u32 i = threadIdx.x; i < SB; i += RC_THREADS) { c[i] = 0; f[i] = NONE; }
+	for (u32 i = threadIdx.x; i < SB * 4; i += RC_THREADS) ef[i] = NONE;
 	__syncthreads();
 	const u32 i0 = range_start[b], i1 = range_start[b + 1];
 	const u32 s0 = b * SB;
-	for (u32 i = i0 + threadIdx.x; i < ((i1 - i0 + RC_THREADS - 1) / RC_THREADS) * RC_THREADS + i0; i += RC_THREADS) {
+	const u32 iend = i0 + (i1 - i0 + RC_THREADS - 1) / RC_THREADS * RC_THREADS;       // whole waves stay together (ballots, DPP)
+	for (u32 i = i0 + threadIdx.x; i < iend; i += RC_THREADS) {
 		const bool live = i < i1;
 		const u64 x = live ? items[i] : 0ull;
 		const u32 sl = live ? (u32) (x >> IT_SURV_SHIFT) - s0 : 0u;
 		const u64 inst = x & IT_INST_MASK;
-		// the lanes that share the first live lane's survivor are folded into one add and one min when they are many
+		// the lanes that share the first live lane's survivor are folded into one add and one min when they are many (hot nodes)
 		bool mine = live;
 		const u64 act = __ballot(live);
 		if (act) {
@@ -1893,20 +1904,20 @@ __global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ 
 			const bool same = live && sl == lsl;
 			const u64 m = __ballot(same);
 			if (__popcll(m) >= 8) {
-				// 35-bit minimum in two steps: low words among the lanes holding the minimal high word
+				// minimum of the (up to 35-bit) ids in two steps: low words among the lanes holding the minimal high word
 				const u32 hi_min = vdjx_wave_min(same ? (u32) (inst >> 32) : 0xFFFFFFFFu);
 				const u32 lo_min = vdjx_wave_min(same && (u32) (inst >> 32) == hi_min ? (u32) inst : 0xFFFFFFFFu);
 				if (__lane_id() == leader) {
 					atomicAdd(&c[lsl], (u32) __popcll(m));
-					atomicMin((unsigned long long*) &f[lsl], ((unsigned long long) hi_min << 32) | lo_min);
+					rc_min(&f[lsl], (IT) (((u64) hi_min << 32) | lo_min));
 				}
 				mine = live && !same;
 			}
 		}
-		if (mine) { atomicAdd(&c[sl], 1u); atomicMin((unsigned long long*) &f[sl], (unsigned long long) inst); }
+		if (mine) { atomicAdd(&c[sl], 1u); rc_min(&f[sl], (IT) inst); }
 		if (live && ((x >> 37) & 1ull)) {
-			unsigned long long* e = (unsigned long long*) &ef[sl * 4 + (u32) ((x >> 35) & 3ull)];
-			if (*(volatile unsigned long long*) e > inst) atomicMin(e, (unsigned long long) inst);     // first sights only ever decrease
+			IT* e = &ef[sl * 4 + (u32) ((x >> 35) & 3ull)];
+			if (*(volatile IT*) e > (IT) inst) rc_min(e, (IT) inst);                      // first sights only ever decrease
 		}
 	}
 	__syncthreads();
@@ -1915,12 +1926,12 @@ __global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ 
 		const u32 sidx = s0 + i;
 		if (sidx >= ns) break;
 		ucnt[sidx] = c[i];
-		ufirst[sidx] = f[i] == NONE64 ? NONE64 : f[i] + add;
+		ufirst[sidx] = f[i] == NONE ? NONE64 : (u64) f[i] + add;
 	}
 	for (u32 i = threadIdx.x; i < SB * 4; i += RC_THREADS) {
 		const u32 sidx = s0 + (i >> 2);
 		if (sidx >= ns) break;
-		in_first[(size_t) s0 * 4 + i] = ef[i] == NONE64 ? NONE64 : ef[i] + add;
+		in_first[(size_t) s0 * 4 + i] = ef[i] == NONE ? NONE64 : (u64) ef[i] + add;
 	}
 }
 
@@ -2541,7 +2552,7 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 	const size_t R = pool->n_records;
 	const int P = pool->rl - k + 1;
 	const u64 NI = geometry_instances ? geometry_instances : (u64) R * (u64) P;
-	static const size_t dflt = tune("VDJX_BUCKET_TUPLES", 4096);
+	static const size_t dflt = tune("VDJX_GATED_BUCKET", 3072);     // gated tuples per bucket: about a third are distinct k-mers (RD_SLOTS)
 	const size_t per = per_bucket ? per_bucket : dflt;
 	// histogram resolution: every bucket count the build could choose is a prefix of it (<= 2^15: 128 KB of LDS)
 	u32 HB = ceil_log2_u64((NI + per - 1) / per);
@@ -2694,9 +2705,15 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		hipLaunchKernelGGL(k_surv_table2, dim3((ns + 255) / 256), dim3(256), 0, st, s_lo, s_hi, ns, table, tmask, idx_bits, skey);
 		hipLaunchKernelGGL(k_succ_links2, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, tb, ns, k, succ);
 	}
-	// survivor ranges of 1024 (one recount workgroup each); more than 1024 ranges take a second partition level
-	const u32 range_shift = 10;
-	const u32 n_ranges = (ns + 1023) / 1024;
+	// survivor ranges (one recount workgroup each, LDS arrays indexed by index - range start): the smallest range size that keeps
+	// the ranges <= 1024 (one partition pass); beyond the largest size a second partition level
+	static const bool force_wide = tune("VDJX_RC_WIDE", 0) != 0;                    // (test knobs: the paths of very large pools on small ones)
+	static const u32 cap_shift = (u32) tune("VDJX_RC_MAX_SHIFT", 12);
+	const bool narrow = R <= (1ull << 26) && !force_wide;           // local instance ids fit 32 bits
+	const u32 max_shift = std::max(8u, std::min(narrow ? 12u : 11u, cap_shift));
+	u32 range_shift = 8;
+	while (range_shift < max_shift && ((ns + (1u << range_shift) - 1) >> range_shift) > PART_MAXB) range_shift++;
+	const u32 n_ranges = (ns + (1u << range_shift) - 1) >> range_shift;
 	u32 l2bits = 0;
 	while (((n_ranges + (1u << l2bits) - 1) >> l2bits) > PART_MAXB) l2bits++;
 	const u32 n_coarse = (n_ranges + (1u << l2bits) - 1) >> l2bits;
@@ -2755,7 +2772,24 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	}
 	{
 		vdjx_prof_scope ps(c, "k_recount");
-		hipLaunchKernelGGL(k_recount<1024>, dim3(n_ranges), dim3(RC_THREADS), 0, st, items, range_start, ns, rec_base, ro.ucnt, ro.ufirst, ro.in_first);
+#define RC_LAUNCH(SB, IT) hipLaunchKernelGGL((k_recount<SB, IT>), dim3(n_ranges), dim3(RC_THREADS), 0, st, items, range_start, ns, rec_base, ro.ucnt, ro.ufirst, ro.in_first)
+		if (narrow) {
+			switch (range_shift) {
+				case 8: RC_LAUNCH(256, u32); break;
+				case 9: RC_LAUNCH(512, u32); break;
+				case 10: RC_LAUNCH(1024, u32); break;
+				case 11: RC_LAUNCH(2048, u32); break;
+				default: RC_LAUNCH(4096, u32); break;
+			}
+		} else {
+			switch (range_shift) {
+				case 8: RC_LAUNCH(256, u64); break;
+				case 9: RC_LAUNCH(512, u64); break;
+				case 10: RC_LAUNCH(1024, u64); break;
+				default: RC_LAUNCH(2048, u64); break;
+			}
+		}
+#undef RC_LAUNCH
 	}
 	if (derive_edges) {
 		HIP_TRY(hipMemsetAsync(ro.edge_first, 0xFF, (size_t) ns * 32, st));
