@@ -165,6 +165,10 @@ typedef struct {
 /* Mapped pairs of each contig in the reference's output order.  Two-call protocol: first call with
  * pairs == NULL fills offsets[n+1]; second call with pairs sized offsets[n]. */
 int vdjx_map_emit(vdjx_ctx* ctx, const char* contigs, size_t n, int len, uint64_t* offsets, vdjx_pair* pairs);
+/* The writing call with the transfer to the host left running on the context's copy stream (page-locked `pairs`, vdjx_host_alloc,
+ * make it a DMA beside the next kernels); the array is valid after vdjx_map_emit_end. */
+int vdjx_map_emit_begin(vdjx_ctx* ctx, const char* contigs, size_t n, int len, uint64_t* offsets, vdjx_pair* pairs);
+int vdjx_map_emit_end(vdjx_ctx* ctx);
 
 /* counters of the most recent scorer calls, by name: "window_hits" (read instances matched by the last
  * vdjx_window_score call, summed over windows), "window_hits_max", "window_pairs", "window_work_items",

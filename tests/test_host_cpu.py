@@ -111,14 +111,16 @@ def _e2e_info(tag):
     return m["e2e"][tag] if tag in m["e2e"] else m["e2e_chains"][tag]
 
 
+@pytest.mark.parametrize("threads", [1, 5])
 @pytest.mark.parametrize("tag", ["e2e_tiled", "e2e_mixed", "e2e_k25", "e2e_igk", "e2e_igl"])
-def test_host_stage_end_to_end_vs_reference(tag, tmp_path):
+def test_host_stage_end_to_end_vs_reference(tag, threads, tmp_path):
     """graph (from the oracle) -> host stage -> vdj_contigs.fa, SAM and vdjer.dot byte-identical to the reference's
     (e2e_igk / e2e_igl: the light-chain presets of set_chain_info, params.c:20-31)"""
     c = G.Case(tag)
     info = _e2e_info(tag)
     fl = G.flags_to_params(info["flags"])
-    p = host.make_params(info.get("chain", "IGH"), ins=175, k=fl["k"], mf=fl["mf"], mq=fl["mq"], mcs=fl["mcs"], mrs=fl["mrs"], rl=c.pool.rl)
+    # --t: the roots are enumerated by `threads` workers and merged in dispatch order: same bytes whatever the thread count
+    p = host.make_params(info.get("chain", "IGH"), ins=175, t=threads, k=fl["k"], mf=fl["mf"], mq=fl["mq"], mcs=fl["mcs"], mrs=fl["mrs"], rl=c.pool.rl)
     t = oracle.KmerTable(c.pool, fl["k"])
     t.prune(fl["mf"], fl["mq"])
     og = oracle.Graph(t, c.v_codes, c.j_codes)

@@ -275,6 +275,22 @@ class Context:
         assert all(len(w) == ln for w in strings)
         return ("".join(strings).encode(), n, ln)
 
+    def pin_strings(self, strings, tag: str):
+        """pack_strings into a page-locked buffer owned by the context (one per `tag`): the scorers' input then crosses PCIe as a
+        DMA instead of being staged by the runtime (a C caller builds its windows in vdjx_host_alloc memory to the same effect)"""
+        raw, n, ln = self.pack_strings(strings)
+        need = max(len(raw), 1)
+        ptr, cap = self._pinned.get("in:" + tag, (None, 0))
+        if cap < need:
+            if ptr:
+                self._retired.append(ptr)
+            new = C.c_void_p()
+            check(self.L.vdjx_host_alloc(self.h, need, C.byref(new)), "vdjx_host_alloc")
+            ptr, cap = new.value, need
+            self._pinned["in:" + tag] = (ptr, cap)
+        C.memmove(ptr, raw, len(raw))
+        return (C.cast(ptr, C.c_char_p), n, ln)
+
     def window_score(self, windows, ins: int, e0: int = 52, e1: int = 411, rs: int = 35, ms: int = 48, floor: int = 1):
         raw, n, ln = windows if isinstance(windows, tuple) else self.pack_strings(windows)
         if n == 0:
@@ -285,15 +301,28 @@ class Context:
         check(self.L.vdjx_window_score(self.h, raw, n, ln, C.byref(cp), _p(valid), _p(npairs)), "vdjx_window_score")
         return valid, npairs
 
-    def map_emit(self, contigs):
+    def map_emit(self, contigs, async_copy: bool = False):
+        """async_copy: the pairs travel to the host on the copy stream while the caller goes on (two alternating pinned result
+        buffers); they are valid after map_emit_wait(), which the next map_emit call also performs"""
         raw, n, ln = contigs if isinstance(contigs, tuple) else self.pack_strings(contigs)
         offs = np.zeros(n + 1, np.uint64)
         if n == 0:
             return offs, np.zeros(0, PAIR_DTYPE)
+        self.map_emit_wait()
         check(self.L.vdjx_map_emit(self.h, raw, n, ln, _p(offs), None), "vdjx_map_emit(count)")
-        pairs, = self._result_arrays("pairs", [((int(offs[n]),), PAIR_DTYPE)])
-        check(self.L.vdjx_map_emit(self.h, raw, n, ln, _p(offs), _p(pairs)), "vdjx_map_emit")
+        self._pairs_flip = 1 - getattr(self, "_pairs_flip", 0)
+        pairs, = self._result_arrays(f"pairs{self._pairs_flip}" if async_copy else "pairs", [((int(offs[n]),), PAIR_DTYPE)])
+        if async_copy:
+            check(self.L.vdjx_map_emit_begin(self.h, raw, n, ln, _p(offs), _p(pairs)), "vdjx_map_emit_begin")
+            self._pairs_pending = True
+        else:
+            check(self.L.vdjx_map_emit(self.h, raw, n, ln, _p(offs), _p(pairs)), "vdjx_map_emit")
         return offs, pairs
+
+    def map_emit_wait(self):
+        if getattr(self, "_pairs_pending", False):
+            check(self.L.vdjx_map_emit_end(self.h), "vdjx_map_emit_end")
+            self._pairs_pending = False
 
     def stat(self, name: str) -> int:
         return int(self.L.vdjx_stat(self.h, name.encode()))

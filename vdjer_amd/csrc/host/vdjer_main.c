@@ -367,6 +367,7 @@ int main(int argc, char** argv) {
 	reads_t rd;
 	if (load_reads(&c, &rd)) return 255;
 	c.hp.read_length = rd.rl;
+	c.hp.threads = c.threads;
 	fprintf(stderr, "read length:\t%d\n", rd.rl);
 
 	uint32_t *vc = NULL, *jc = NULL;

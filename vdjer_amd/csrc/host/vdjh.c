@@ -1,6 +1,7 @@
 /* vdjh.c -- see vdjh.h.  Serial host part of the pipeline, restated from the reference. */
 #define _GNU_SOURCE
 #include "vdjh.h"
+#include <pthread.h>
 #include "sph.h"
 
 #include <math.h>
@@ -31,6 +32,7 @@ void vdjh_default_params(vdjh_params* p) {
 	p->window_span = 486; p->j_extension = 162; p->read_filter_floor = 1; p->vregion_kmer_size = 15;
 	p->min_source_homology_score = 30; p->filter_read_span = 35; p->filter_mate_span = 48;
 	p->eval_start = 52; p->eval_stop = 411; p->window_overlap_check_size = 320;
+	p->threads = 1;               /* params.c:69 */
 }
 
 /* params.c:8-35 (the loci are only used by the BAM extraction, which is not part of this library) */
@@ -452,6 +454,87 @@ static int build_contigs(const vdjh_params* p, const vdjh_hooks* h, hnode* root,
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* roots in parallel (process_roots, A2:1287-1348), merged in dispatch order                   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+	const vdjh_params* p;
+	const vdjh_hooks* h;
+	hnode** roots;
+	const uint8_t* accepted;
+	size_t nroots;
+	wincoll* per_root;            /* [nroots]: windows of root i in encounter order, distinct within the root */
+	volatile long next;           /* next root to take */
+	volatile int failed;
+	int progress;                 /* VDJH_PROGRESS=1: the reference's per-100-roots progress lines, every 1000 roots */
+} trav_job;
+
+static void wincoll_free(wincoll* w) {
+	for (size_t i = 0; i < w->win.n; i++) { free(w->win.v[i]); free(w->cdr3.v[i]); }
+	free(w->win.v); free(w->cdr3.v);
+	sph_free(&w->seen);
+	memset(w, 0, sizeof *w);
+}
+
+static void* trav_worker(void* arg) {
+	trav_job* j = (trav_job*) arg;
+	for (;;) {
+		const long i = __sync_fetch_and_add(&j->next, 1);
+		if (i >= (long) j->nroots || j->failed) break;
+		if (!j->accepted[i]) continue;
+		wincoll* w = &j->per_root[i];
+		sph_init(&w->seen, 0, 0);
+		if (build_contigs(j->p, j->h, j->roots[i], w)) { j->failed = 1; break; }
+		if (j->progress && (i % 1000) == 0) fprintf(stderr, "Processed %ld root nodes\n", i);       /* A2:1327-1331 */
+		sph_free(&w->seen);                        /* membership inside the root is no longer needed */
+		memset(&w->seen, 0, sizeof w->seen);
+	}
+	return NULL;
+}
+
+static int traverse_roots(const vdjh_params* p, const vdjh_hooks* h, hnode** roots, const uint8_t* accepted, size_t nroots, wincoll* out) {
+	int nthreads = p->threads > 0 ? p->threads : 1;
+	if (nthreads > 256) nthreads = 256;
+	if (nthreads == 1) {
+		for (size_t i = 0; i < nroots; i++) {
+			if (!accepted[i]) continue;
+			if (build_contigs(p, h, roots[i], out)) return -1;
+		}
+		return 0;
+	}
+	trav_job job;
+	memset(&job, 0, sizeof job);
+	job.p = p; job.h = h; job.roots = roots; job.accepted = accepted; job.nroots = nroots;
+	job.progress = getenv("VDJH_PROGRESS") != NULL;
+	job.per_root = (wincoll*) calloc(nroots + 1, sizeof(wincoll));
+	pthread_t* th = (pthread_t*) calloc((size_t) nthreads, sizeof(pthread_t));
+	int started = 0;
+	for (int t = 0; t < nthreads; t++) {
+		if (pthread_create(&th[t], NULL, trav_worker, &job)) break;
+		started++;
+	}
+	if (started == 0) trav_worker(&job);
+	for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+	free(th);
+	int rc = job.failed ? -1 : 0;
+	if (rc) set_err("contig enumeration failed in a worker thread (too many paths/contigs from one root, A2:1115-1119)");
+	for (size_t i = 0; i < nroots && rc == 0; i++) {
+		wincoll* w = &job.per_root[i];
+		out->n_candidates += w->n_candidates;
+		for (size_t q = 0; q < w->win.n; q++) {
+			if (sph_find(&out->seen, w->win.v[q]) != (size_t) -1) continue;
+			sph_set_insert(&out->seen, w->win.v[q], NULL);
+			sv_push(&out->win, w->win.v[q]);            /* ownership moves to the merged list */
+			sv_push(&out->cdr3, w->cdr3.v[q]);
+			w->win.v[q] = NULL;
+			w->cdr3.v[q] = NULL;
+		}
+	}
+	for (size_t i = 0; i < nroots; i++) wincoll_free(&job.per_root[i]);
+	free(job.per_root);
+	return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* the whole host stage                                                                        */
 /* ------------------------------------------------------------------------------------------ */
 int vdjh_assemble(const vdjh_params* p, const vdjh_graph* g, const vdjh_hooks* h,
@@ -498,11 +581,14 @@ int vdjh_assemble(const vdjh_params* p, const vdjh_graph* g, const vdjh_hooks* h
 	/* process_roots prints STATUS_UPDATE when the first root is dispatched (`ts` starts at 0, A2:1301,1335) and then every 300 s */
 	if (nroots) STAGE("STATUS_UPDATE");
 
-	/* worker_thread/build_contigs per accepted root, in dispatch order (A2:1305-1318, 1093-1131) */
-	for (size_t i = 0; i < nroots; i++) {
-		if (!accepted_root[i]) continue;
-		st->n_roots_accepted++;
-		if (build_contigs(p, h, roots[i], &w)) goto done;
+	/* worker_thread/build_contigs per accepted root (A2:1305-1318, 1093-1131).  The reference hands roots to --t threads and
+	 * its output then depends on their timing; here every root collects its windows on its own (any thread) and the lists are
+	 * merged in dispatch order, which is exactly what one thread produces: a window counts where it is met first. */
+	{
+		size_t nacc = 0;
+		for (size_t i = 0; i < nroots; i++) if (accepted_root[i]) nacc++;
+		st->n_roots_accepted = nacc;
+		if (traverse_roots(p, h, roots, accepted_root, nroots, &w)) goto done;
 	}
 	st->n_contig_candidates = w.n_candidates;
 

@@ -38,6 +38,7 @@ typedef struct {
 	int insert_len;        /* --ins */
 	int vregion_kmer_size; /* --vk */
 	int read_length;
+	int threads;                  /* --t (A2:1287-1348: worker threads over the roots); results do not depend on it */
 } vdjh_params;
 
 void vdjh_default_params(vdjh_params* p);          /* params.c:53-73 */

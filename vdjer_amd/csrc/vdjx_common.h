@@ -72,6 +72,7 @@ struct vdjx_ctx {
 	vdjx_shard* live_shard = nullptr;
 	hipStream_t stream = nullptr;
 	hipStream_t copy_stream = nullptr;   // result copies that may run beside the next kernels (vdjx_graph_export_begin)
+	hipStream_t pairs_stream = nullptr;  // the mapped pairs' copy (vdjx_map_emit_begin): a stream of its own, so that waiting for one result is not waiting for the other
 	bool profiling = false;
 	std::vector<std::string> prof_names;                 // insertion order
 	std::map<std::string, vdjx_prof_entry> prof;
@@ -109,6 +110,8 @@ struct vdjx_ctx {
 	uint64_t me_key = 0;
 	void* me_pairs = nullptr;         // vdjx_pair[me_cap], per-contig regions at me_hoff
 	size_t me_cap = 0;
+	void* me_dense = nullptr;         // the pairs laid end to end for the copy to the host (kept: the copy may be asynchronous)
+	size_t me_dense_cap = 0;
 	std::vector<u64> me_hoff, me_cnt;
 	std::vector<uint4> me_work;       // slices of the mapping: {contig, first hit, end hit, -}
 	std::vector<u32> me_scnt;         // pairs found per slice

@@ -700,33 +700,99 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_hits(ReadIndexDev ix, co
 #define COV_WORDS 8192
 #define HIT_CHUNK 65536u         // hits per workgroup of k_window_pairs: the deepest windows are split, the rest pay one preparation
 
-// K8: mapped pairs of a slice of a window's (distinct) hits, appended (any order) to the window's list as
-// (multiplicity << 32 | pos1 << 16 | pos2); pair_np = mapped pairs counted with multiplicity
+// one (weighted) entry of the class at offset o -> mapped pair or not (quick_map3.c:223-245)
+__device__ inline bool map_eval_entry(const MapLds& L, int rl, int o, const uint4 info, u32& pos2_out) {
+	if (!(info.w & RI_R1)) return false;
+	const u32 la = map_last_occurrence(L, info.y), lb = map_last_occurrence(L, info.z);
+	if (!la && !lb) return false;
+	const int which = (lb && lb >= la) ? 1 : 0;
+	const u32 best = which ? lb : la;
+	const u32 rc1 = (info.w & RI_RC) ? 1u : 0u;
+	const u32 rc2 = (info.w & (which ? RI_RCB : RI_RCA)) ? 1u : 0u;
+	if (rc1 == rc2) return false;                  // quick_map3.c:227
+	const int d = (o + 1) - (int) best;
+	const int insert = (int) (short) ((d < 0 ? -d : d) + rl);
+	if (insert < 50 || insert > 400) return false; // MIN_INSERT / MAX_INSERT, quick_map3.c:23-24
+	pos2_out = best;
+	return true;
+}
+
+// K8: mapped pairs of a slice [h0, h1) of a window's (distinct) hits, appended (any order) to the window's list as
+// (multiplicity << 32 | pos1 << 16 | pos2); pair_np = mapped pairs counted with multiplicity.
+// The waves of the workgroup take the offsets of the slice one at a time (LDS ticket): the entries of an offset's read class
+// are consecutive, so a wave streams them with coalesced 16-byte loads and no search; pairs (a few per cent of the entries) are
+// staged per wave in LDS and leave with one global cursor bump per 128.
+#define WP_STAGE 128
 __global__ __launch_bounds__(MAP_THREADS) void k_window_pairs(ReadIndexDev ix, const char* __restrict__ windows, int len,
                                                               const uint4* __restrict__ work /* {window, h0, h1, -} */,
                                                               const u64* __restrict__ pair_off, u64* __restrict__ pair_buf,
                                                               u32* __restrict__ pair_cnt, u32* __restrict__ pair_np) {
 	__shared__ MapLds L;
+	__shared__ u64 stg[MAP_THREADS / 64][WP_STAGE];
+	__shared__ int s_next, s_ohi;
 	const uint4 wk = work[blockIdx.x];
 	const u32 wi = wk.x;
 	const int noff = len - ix.rl;
 	const u32 H = map_prepare(L, ix, windows + (size_t) wi * len, len, true);
-	const u32 h1 = wk.z < H ? wk.z : H;
+	const u32 h0 = wk.y, h1 = wk.z < H ? wk.z : H;
+	if (h0 >= h1) return;
+	if (threadIdx.x == 0) {
+		int lo = 0, hi = noff;                          // last offset with hpre[o] <= h0
+		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.hpre[mid] <= h0) lo = mid; else hi = mid; }
+		s_next = lo;
+		lo = 0; hi = noff;                              // last offset with hpre[o] < h1
+		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.hpre[mid] < h1) lo = mid; else hi = mid; }
+		s_ohi = lo;
+	}
+	__syncthreads();
+	const int ohi = s_ohi;
+	const int lane = __lane_id();
+	u64* mystg = stg[threadIdx.x >> 6];
 	u64* pairs = pair_buf + pair_off[wi];
-	u32 mine = 0;
-	for (u32 h0 = wk.y; h0 < h1; h0 += MAP_THREADS) {
-		const u32 h = h0 + threadIdx.x;
-		Hit r;
-		r.pair = false;
-		if (h < h1) r = map_eval_hit<true>(L, ix, noff, h);
-		const u32 slot = vdjx_wave_inc(&pair_cnt[wi], r.pair);
-		if (r.pair) {
-			pairs[slot] = ((u64) r.pair_id << 32) | ((u32) r.pos1 << 16) | (u32) r.pos2;
-			mine += r.pair_id;
+	u32 fill = 0, mine = 0;
+	for (;;) {
+		int o = 0;
+		if (lane == 0) o = atomicAdd(&s_next, 1);
+		o = __builtin_amdgcn_readlane(o, 0);
+		if (o > ohi) break;
+		const u32 a = L.hpre[o], bnd = L.hpre[o + 1];
+		if (a == bnd) continue;
+		const u32 e0 = (h0 > a ? h0 : a) - a, e1 = (h1 < bnd ? h1 : bnd) - a;
+		const u32 cs = L.cstart[o];
+		for (u32 eb = e0; eb < e1; eb += 64) {
+			const u32 e = eb + (u32) lane;
+			bool pr = false;
+			u32 pos2 = 0, mult = 0;
+			if (e < e1) {
+				const uint4 info = ix.dinfo[cs + e];
+				pr = map_eval_entry(L, ix.rl, o, info, pos2);
+				mult = info.x;
+			}
+			const u64 m = __ballot(pr);
+			if (!m) continue;
+			const u32 cnt = (u32) __popcll(m);
+			if (fill + cnt > WP_STAGE) {                   // (wave-uniform) flush
+				u32 base = 0;
+				if (lane == 0) base = atomicAdd(&pair_cnt[wi], fill);
+				base = (u32) __builtin_amdgcn_readlane((int) base, 0);
+				for (u32 i = (u32) lane; i < fill; i += 64) pairs[base + i] = mystg[i];
+				fill = 0;
+			}
+			if (pr) {
+				mystg[fill + (u32) __popcll(m & ((1ull << lane) - 1ull))] = ((u64) mult << 32) | ((u32) (o + 1) << 16) | pos2;
+				mine += mult;
+			}
+			fill += cnt;
 		}
 	}
+	if (fill) {
+		u32 base = 0;
+		if (lane == 0) base = atomicAdd(&pair_cnt[wi], fill);
+		base = (u32) __builtin_amdgcn_readlane((int) base, 0);
+		for (u32 i = (u32) lane; i < fill; i += 64) pairs[base + i] = mystg[i];
+	}
 	mine = (u32) __builtin_amdgcn_readlane(vdjx_wave_scan_add((int) mine), 63);
-	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&pair_np[wi], mine);
+	if (lane == 0 && mine) atomicAdd(&pair_np[wi], mine);
 }
 
 // K9: coverage verdict of a window from its pair list
@@ -1103,12 +1169,18 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	return VDJX_OK;
 }
 
+// identity of a contig batch between the counting and the writing call of vdjx_map_emit: FNV-1a over its head, its tail and a
+// sparse sample in between (hashing every byte of a few MB twice per call cost more than the mapping kernel)
 static uint64_t fnv1a(const char* p, size_t n, uint64_t h) {
-	for (size_t i = 0; i < n; i++) { h ^= (unsigned char) p[i]; h *= 0x100000001b3ull; }
+	auto eat = [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) { h ^= (unsigned char) p[i]; h *= 0x100000001b3ull; } };
+	if (n <= 4096) { eat(0, n); return h; }
+	eat(0, 1024);
+	for (size_t i = 1024; i + 8 <= n - 1024; i += 509) eat(i, i + 8);
+	eat(n - 1024, n);
 	return h;
 }
 
-extern "C" int vdjx_map_emit(vdjx_ctx* c, const char* contigs, size_t n, int len, uint64_t* offsets, vdjx_pair* pairs) {
+static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, uint64_t* offsets, vdjx_pair* pairs, bool async) {
 	if (!c || !offsets || (n && !contigs)) { vdjx_set_error("vdjx_map_emit: NULL argument"); return VDJX_EINVAL; }
 	if (n == 0) { offsets[0] = 0; return VDJX_OK; }
 	if (n >= (1ull << 31)) { vdjx_set_error("vdjx_map_emit: too many contigs"); return VDJX_ELIMIT; }
@@ -1172,9 +1244,17 @@ extern "C" int vdjx_map_emit(vdjx_ctx* c, const char* contigs, size_t n, int len
 	if (!pairs) return VDJX_OK;
 	const u64 total = offsets[n];
 	if (total) {
-		vdjx_pair* d_dense;
 		u64* d_move;
 		const size_t nsl = c->me_work.size();
+		// the dense copy outlives this call when the transfer to the host is asynchronous: a buffer of its own, not the arena
+		HIP_TRY(hipStreamSynchronize(c->pairs_stream));          // an earlier asynchronous copy may still be reading the buffer
+		if (total > c->me_dense_cap) {
+			free_set(c->me_dense);
+			c->me_dense_cap = 0;
+			HIP_TRY(hipMalloc(&c->me_dense, (size_t) (total + total / 4) * sizeof(vdjx_pair)));
+			c->me_dense_cap = (size_t) (total + total / 4);
+		}
+		vdjx_pair* d_dense = (vdjx_pair*) c->me_dense;
 		std::vector<u64> move(3 * nsl + 3);
 		{
 			u64 at = 0;
@@ -1186,18 +1266,40 @@ extern "C" int vdjx_map_emit(vdjx_ctx* c, const char* contigs, size_t n, int len
 				at += c->me_scnt[i];
 			}
 		}
-		HIP_TRY(db.alloc(&d_dense, (size_t) total));
 		HIP_TRY(db.alloc(&d_move, move.size()));
 		HIP_TRY(hipMemcpyAsync(d_move, move.data(), move.size() * 8, hipMemcpyHostToDevice, st));
 		if (nsl) {
 			vdjx_prof_scope ps(c, "k_gather_pairs");
 			hipLaunchKernelGGL(k_gather_pairs, dim3((u32) nsl), dim3(256), 0, st, (const vdjx_pair*) c->me_pairs, d_move, d_dense);
 		}
-		HIP_TRY(hipMemcpyAsync(pairs, d_dense, (size_t) total * sizeof(vdjx_pair), hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
-		HIP_TRY(hipGetLastError());
+		if (async) {
+			// the pairs cross PCIe on the copy stream beside whatever the caller does next (vdjx_map_emit_end waits for them)
+			HIP_TRY(hipStreamSynchronize(st));
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipMemcpyAsync(pairs, d_dense, (size_t) total * sizeof(vdjx_pair), hipMemcpyDeviceToHost, c->pairs_stream));
+		} else {
+			HIP_TRY(hipMemcpyAsync(pairs, d_dense, (size_t) total * sizeof(vdjx_pair), hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			HIP_TRY(hipGetLastError());
+		}
 		vdjx_prof_collect(c);
 	}
 	c->me_key = 0;           // one counting call serves one writing call
+	return VDJX_OK;
+}
+
+extern "C" int vdjx_map_emit(vdjx_ctx* c, const char* contigs, size_t n, int len, uint64_t* offsets, vdjx_pair* pairs) {
+	return map_emit_impl(c, contigs, n, len, offsets, pairs, false);
+}
+
+extern "C" int vdjx_map_emit_begin(vdjx_ctx* c, const char* contigs, size_t n, int len, uint64_t* offsets, vdjx_pair* pairs) {
+	if (!pairs) { vdjx_set_error("vdjx_map_emit_begin: pairs is NULL (count with vdjx_map_emit first)"); return VDJX_EINVAL; }
+	return map_emit_impl(c, contigs, n, len, offsets, pairs, true);
+}
+
+extern "C" int vdjx_map_emit_end(vdjx_ctx* c) {
+	if (!c) { vdjx_set_error("vdjx_map_emit_end: ctx is NULL"); return VDJX_EINVAL; }
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipStreamSynchronize(c->pairs_stream));
 	return VDJX_OK;
 }

@@ -28,7 +28,7 @@ class Params(C.Structure):
                 ("j_extension", C.c_int), ("read_filter_floor", C.c_int), ("min_source_homology_score", C.c_int),
                 ("filter_read_span", C.c_int), ("filter_mate_span", C.c_int), ("eval_start", C.c_int), ("eval_stop", C.c_int),
                 ("window_overlap_check_size", C.c_int), ("insert_len", C.c_int), ("vregion_kmer_size", C.c_int),
-                ("read_length", C.c_int)]
+                ("read_length", C.c_int), ("threads", C.c_int)]
 
 
 class GraphS(C.Structure):
@@ -110,7 +110,7 @@ def make_params(chain: str = "IGH", **kw) -> Params:
     names = {"k": "k", "mf": "min_node_freq", "mq": "min_base_quality", "mcs": "min_contig_score", "miw": "vj_min_win",
              "maw": "vj_max_win", "ws": "window_span", "jext": "j_extension", "rf": "read_filter_floor",
              "mrs": "min_source_homology_score", "rs": "filter_read_span", "ms": "filter_mate_span", "e0": "eval_start",
-             "e1": "eval_stop", "wo": "window_overlap_check_size", "ins": "insert_len", "vk": "vregion_kmer_size", "rl": "read_length"}
+             "e1": "eval_stop", "wo": "window_overlap_check_size", "ins": "insert_len", "vk": "vregion_kmer_size", "rl": "read_length", "t": "threads"}
     for k_, v in kw.items():
         setattr(p, names[k_], v)
     if p.min_base_quality >= 255:
