@@ -719,32 +719,35 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) if (hist[i]) atomicAdd(&bucket_cnt[i], hist[i]);
 }
 
-// K2c' pass 1: records -> gated tuples, LDS-staged counting sort into `nbk` coarse buckets (see K2c above)
+// K2c' pass 1: records -> gated tuples, LDS-staged counting sort into `nbk` coarse buckets (see K2c above).
+// A round takes `rr0` records (the host sizes it from the gated fraction the histogram measured, so that the stage fills: with one
+// instance in six gated, rounds sized for the worst case spend their time in barriers); a round whose tuples do not fit is
+// simply retried with half the records.
 template <typename TUP>
 __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                                  const u64* __restrict__ lowq, size_t R, u64 rec_base, int rl, int k,
-                                                                 u32 shift, u32 nbk, size_t rpb, u32* __restrict__ gcur,
+                                                                 u32 shift, u32 nbk, size_t rpb, u32 rr0, u32* __restrict__ gcur,
                                                                  TUP* __restrict__ out) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	TUP* stage = (TUP*) smem;
 	__shared__ u32 cnt[PART_MAXB], base[PART_MAXB + 1], cur[PART_MAXB], gbase[PART_MAXB], tmp[PART_THREADS];
 	const u32 ROUND = PART_LDS_BYTES / sizeof(TUP);
 	const int P = rl - k + 1;
-	const u32 RR = ROUND / (u32) P;                                  // records per round (every instance could be gated)
-	const u32 T = RR * 4 <= PART_THREADS ? 4u : (RR * 2 <= PART_THREADS ? 2u : 1u);
-	const int off_a = (int) ((threadIdx.x % T) * (u32) P / T), off_b = (int) ((threadIdx.x % T + 1) * (u32) P / T);
+	const u32 rr_min = ROUND / (u32) P;                              // always fits
+	u32 rr = rr0 > rr_min ? rr0 : rr_min;
 	const u64 km = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
 	const u32 mask = nbk - 1;
 	const size_t r0 = (size_t) blockIdx.x * rpb;
 	const size_t r1 = r0 + rpb < R ? r0 + rpb : R;
-	for (size_t rs = r0; rs < r1; rs += RR) {
-		const size_t re = rs + RR < r1 ? rs + RR : r1;
+	size_t rs = r0;
+	while (rs < r1) {
+		const size_t re = rs + rr < r1 ? rs + rr : r1;
 		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) cnt[i] = 0;
 		__syncthreads();
-		for (size_t r = rs + threadIdx.x / T; r < re; r += PART_THREADS / T) {
+		for (size_t r = rs + threadIdx.x; r < re; r += PART_THREADS) {
 			const RecView v = load_rec(bases, nmask, lowq, r);
 			const u64 bad = v.nm | v.lq;
-			for (int o = off_a; o < off_b; o++) {
+			for (int o = 0; o < P; o++) {
 				if ((bad >> o) & km) continue;
 				u64 khi, klo;
 				vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
@@ -753,15 +756,20 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 		}
 		__syncthreads();
 		part_scan(cnt, base, tmp, nbk);
+		if (base[nbk] > ROUND) {                                      // (uniform) too many gated instances for the stage
+			rr = rr / 2 > rr_min ? rr / 2 : rr_min;
+			__syncthreads();
+			continue;
+		}
 		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) {
 			cur[i] = base[i];
 			gbase[i] = cnt[i] ? atomicAdd(&gcur[i], cnt[i]) : 0u;
 		}
 		__syncthreads();
-		for (size_t r = rs + threadIdx.x / T; r < re; r += PART_THREADS / T) {
+		for (size_t r = rs + threadIdx.x; r < re; r += PART_THREADS) {
 			const RecView v = load_rec(bases, nmask, lowq, r);
 			const u64 bad = v.nm | v.lq;
-			for (int o = off_a; o < off_b; o++) {
+			for (int o = 0; o < P; o++) {
 				if ((bad >> o) & km) continue;
 				u64 khi, klo;
 				vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
@@ -777,6 +785,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 			TUP::store(&out[gbase[b] + (i - base[b])], t);
 		}
 		__syncthreads();
+		rs = re;
 	}
 }
 
@@ -1657,20 +1666,28 @@ __global__ void k_node_flags(const u64* __restrict__ s_lo, const u64* __restrict
 #define IT_HOLE 0xFFFFFFFFFFFFFFFFull
 #define WALK_THREADS 256
 
-struct SurvTable { const u32* table; u32 mask; u32 idx_bits; const ulonglong2* skey; };
+struct SurvTable { const u32* table; u32 mask; u32 idx_bits; const ulonglong2* skey; const u32* bloom; u32 bloom_mask; };      // bloom: one bit per survivor hash, 16 bits of filter per survivor: L2-resident (2 MB at 10 M pairs)
 
 // table entry = fingerprint of the key's hash (32 - idx_bits bits) << idx_bits | (survivor index + 1)
 __global__ void k_surv_table2(const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, u32 n, u32* __restrict__ table, u32 mask,
-                              u32 idx_bits, ulonglong2* __restrict__ skey) {
+                              u32 idx_bits, ulonglong2* __restrict__ skey, u32* __restrict__ bloom, u32 bloom_mask) {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const u64 lo = s_lo[i], hi = s_hi[i];
 	skey[i] = make_ulonglong2(lo, hi);
 	const u64 h = vdjx_mix(lo, hi);
+	{
+		const u32 bit = (u32) (h >> 40) & bloom_mask;
+		atomicOr(&bloom[bit >> 5], 1u << (bit & 31));
+	}
 	u32 slot = (u32) (h >> 20) & mask;
 	const u32 entry = idx_bits < 32 ? ((((u32) h) >> idx_bits) << idx_bits) | (i + 1) : (i + 1);
 	while (atomicCAS(&table[slot], 0u, entry) != 0u) slot = (slot + 1) & mask;
 }
+
+// lookup of a k-mer that most likely does NOT survive (the start of a run in the walk): the filter answers "no" for 15 in 16 of
+// those without leaving the L2 (the table and the keys, 24 MB at 10 M pairs, are random line fills over the fabric)
+__device__ inline int surv_lookup2f(const SurvTable& t, u64 lo, u64 hi);
 
 __device__ inline int surv_lookup2(const SurvTable& t, u64 lo, u64 hi) {
 	const u64 h = vdjx_mix(lo, hi);
@@ -1688,22 +1705,37 @@ __device__ inline int surv_lookup2(const SurvTable& t, u64 lo, u64 hi) {
 	}
 }
 
-// succ[u*4+b] = survivor index of (key_u << 2 | b) mod 4^k, or NONE32
-__global__ void k_succ_links2(SurvTable t, u32 n, int k, u32* __restrict__ succ) {
-	const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
-	if (e >= n * 4u) return;
-	const ulonglong2 kk = t.skey[e >> 2];
-	u128 key = (((u128) kk.y << 64) | kk.x);
-	key = (key << 2) | (u128) (e & 3u);
-	if (k < 64) key &= (((u128) 1) << (2 * k)) - 1;
-	const int s = surv_lookup2(t, (u64) key, (u64) (key >> 64));
-	succ[e] = s >= 0 ? (u32) s : NONE32;
+__device__ inline int surv_lookup2f(const SurvTable& t, u64 lo, u64 hi) {
+	const u64 h = vdjx_mix(lo, hi);
+	const u32 bit = (u32) (h >> 40) & t.bloom_mask;
+	if (!((t.bloom[bit >> 5] >> (bit & 31)) & 1u)) return -1;
+	return surv_lookup2(t, lo, hi);
+}
+
+// succ[u*4+b] = survivor index of (key_u << 2 | b) mod 4^k, or NONE32.  Nine nodes in ten have exactly one surviving successor:
+// succ1[u] = successor << 3 | its last base << 1 | 1 holds it in 4 bytes (0 = no successor at all, 2 = several: look into succ[]),
+// a quarter of the footprint the walk touches at random (the 16 bytes per node of succ[] miss the XCD's 4 MB L2 at 10 M pairs).
+__global__ void k_succ_links2(SurvTable t, u32 n, int k, u32* __restrict__ succ, u32* __restrict__ succ1) {
+	const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+	if (u >= n) return;
+	const ulonglong2 kk = t.skey[u];
+	const u128 base = (((u128) kk.y << 64) | kk.x) << 2;
+	const u128 km = k < 64 ? (((u128) 1) << (2 * k)) - 1 : ~(u128) 0;
+	u32 nv = 0, one = 0;
+	for (u32 b = 0; b < 4; b++) {
+		const u128 key = (base | (u128) b) & km;
+		const int s = surv_lookup2(t, (u64) key, (u64) (key >> 64));
+		succ[u * 4 + b] = s >= 0 ? (u32) s : NONE32;
+		if (s >= 0) { nv++; one = ((u32) s << 3) | (b << 1) | 1u; }
+	}
+	succ1[u] = nv == 0 ? 0u : (nv == 1 ? one : 2u);
 }
 
 // the walk: every wave appends its items to blocks of `blk_items` slots it reserves from the global cursor (unused slots of a
 // block are filled with IT_HOLE); item counts per survivor range go to range_cnt
 __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restrict__ bases, const u64* __restrict__ nmask, size_t R, int rl, int k,
-                                                             SurvTable t, const u32* __restrict__ succ, u32 range_shift, u32 n_ranges,
+                                                             SurvTable t, const u32* __restrict__ succ, const u32* __restrict__ succ1,
+                                                             u32 range_shift, u32 n_ranges,
                                                              u64* __restrict__ raw, u64 raw_cap, u32 blk_items,
                                                              unsigned long long* __restrict__ g_cursor,
                                                              u32* __restrict__ range_cnt, u32* __restrict__ g_err) {
@@ -1733,14 +1765,15 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				if (prev >= 0) {
 					const int bsh = 2 * (rl - k - o);                     // last base of the k-mer at o
 					const u32 bb = (u32) (bsh < 64 ? v.blo >> bsh : v.bhi >> (bsh - 64)) & 3u;
-					const u32 nx = succ[(u32) prev * 4u + bb];
-					s = nx == NONE32 ? -1 : (int) nx;
+					const u32 s1 = succ1[prev];
+					if (s1 & 1u) s = ((s1 >> 1) & 3u) == bb ? (int) (s1 >> 3) : -1;
+					else if (s1 == 2u) { const u32 nx = succ[(u32) prev * 4u + bb]; s = nx == NONE32 ? -1 : (int) nx; }
 					const int fsh = 2 * (rl - o);                          // first base of the k-mer at o-1 (the predecessor)
 					pa = (u32) (fsh < 64 ? v.blo >> fsh : v.bhi >> (fsh - 64)) & 3u;
 				} else {
 					u64 khi, klo;
 					vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
-					s = surv_lookup2(t, klo, khi);
+					s = surv_lookup2f(t, klo, khi);
 				}
 			}
 			const bool has_prev = prev >= 0 && s >= 0;
@@ -1869,6 +1902,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_items2(const u64* __restr
 // one workgroup per range of 2^range_shift survivors: frequency, first sight, in-edge first sights (LDS arrays, direct index).
 // Lanes of a wave that hit the same survivor (hot nodes) are combined before they touch LDS.
 #define RC_THREADS 512
+#define RC_UNR 4
 template <typename IT> struct RcNone;
 template <> struct RcNone<u32> { static constexpr u32 v = 0xFFFFFFFFu; };
 template <> struct RcNone<u64> { static constexpr u64 v = 0xFFFFFFFFFFFFFFFFull; };
@@ -1889,35 +1923,43 @@ __global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ 
 	__syncthreads();
 	const u32 i0 = range_start[b], i1 = range_start[b + 1];
 	const u32 s0 = b * SB;
-	const u32 iend = i0 + (i1 - i0 + RC_THREADS - 1) / RC_THREADS * RC_THREADS;       // whole waves stay together (ballots, DPP)
-	for (u32 i = i0 + threadIdx.x; i < iend; i += RC_THREADS) {
-		const bool live = i < i1;
-		const u64 x = live ? items[i] : 0ull;
-		const u32 sl = live ? (u32) (x >> IT_SURV_SHIFT) - s0 : 0u;
-		const u64 inst = x & IT_INST_MASK;
-		// the lanes that share the first live lane's survivor are folded into one add and one min when they are many (hot nodes)
-		bool mine = live;
-		const u64 act = __ballot(live);
-		if (act) {
-			const int leader = __ffsll((long long) act) - 1;
-			const u32 lsl = (u32) __builtin_amdgcn_readlane((int) sl, leader);
-			const bool same = live && sl == lsl;
-			const u64 m = __ballot(same);
-			if (__popcll(m) >= 8) {
-				// minimum of the (up to 35-bit) ids in two steps: low words among the lanes holding the minimal high word
-				const u32 hi_min = vdjx_wave_min(same ? (u32) (inst >> 32) : 0xFFFFFFFFu);
-				const u32 lo_min = vdjx_wave_min(same && (u32) (inst >> 32) == hi_min ? (u32) inst : 0xFFFFFFFFu);
-				if (__lane_id() == leader) {
-					atomicAdd(&c[lsl], (u32) __popcll(m));
-					rc_min(&f[lsl], (IT) (((u64) hi_min << 32) | lo_min));
+	// whole waves stay together (ballots, DPP); RC_UNR items per lane are loaded before the first is used (the loop is bound by the
+	// latency of the item loads, not by their bytes)
+	const u32 iend = i0 + (i1 - i0 + RC_THREADS * RC_UNR - 1) / (RC_THREADS * RC_UNR) * (RC_THREADS * RC_UNR);
+	for (u32 ib = i0 + threadIdx.x; ib < iend; ib += RC_THREADS * RC_UNR) {
+		u64 xs[RC_UNR];
+#pragma unroll
+		for (int u = 0; u < RC_UNR; u++) { const u32 i = ib + (u32) u * RC_THREADS; xs[u] = i < i1 ? items[i] : IT_HOLE; }
+#pragma unroll
+		for (int u = 0; u < RC_UNR; u++) {
+			const u64 x = xs[u];
+			const bool live = x != IT_HOLE;
+			const u32 sl = live ? (u32) (x >> IT_SURV_SHIFT) - s0 : 0u;
+			const u64 inst = x & IT_INST_MASK;
+			// the lanes that share the first live lane's survivor are folded into one add and one min when they are many (hot nodes)
+			bool mine = live;
+			const u64 act = __ballot(live);
+			if (act) {
+				const int leader = __ffsll((long long) act) - 1;
+				const u32 lsl = (u32) __builtin_amdgcn_readlane((int) sl, leader);
+				const bool same = live && sl == lsl;
+				const u64 m = __ballot(same);
+				if (__popcll(m) >= 8) {
+					// minimum of the (up to 35-bit) ids in two steps: low words among the lanes holding the minimal high word
+					const u32 hi_min = vdjx_wave_min(same ? (u32) (inst >> 32) : 0xFFFFFFFFu);
+					const u32 lo_min = vdjx_wave_min(same && (u32) (inst >> 32) == hi_min ? (u32) inst : 0xFFFFFFFFu);
+					if (__lane_id() == leader) {
+						atomicAdd(&c[lsl], (u32) __popcll(m));
+						rc_min(&f[lsl], (IT) (((u64) hi_min << 32) | lo_min));
+					}
+					mine = live && !same;
 				}
-				mine = live && !same;
 			}
-		}
-		if (mine) { atomicAdd(&c[sl], 1u); rc_min(&f[sl], (IT) inst); }
-		if (live && ((x >> 37) & 1ull)) {
-			IT* e = &ef[sl * 4 + (u32) ((x >> 35) & 3ull)];
-			if (*(volatile IT*) e > (IT) inst) rc_min(e, (IT) inst);                      // first sights only ever decrease
+			if (mine) { atomicAdd(&c[sl], 1u); rc_min(&f[sl], (IT) inst); }
+			if (live && ((x >> 37) & 1ull)) {
+				IT* e = &ef[sl * 4 + (u32) ((x >> 35) & 3ull)];
+				if (*(volatile IT*) e > (IT) inst) rc_min(e, (IT) inst);                  // first sights only ever decrease
+			}
 		}
 	}
 	__syncthreads();
@@ -2606,8 +2648,13 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 	{
 		vdjx_prof_scope ps(c, "k_part_records");
 		hipLaunchKernelGGL(k_init_cursors, dim3((NBc + 255) / 256), dim3(256), 0, st, hstart, NBc, HB - cbits, gcur);
+		// records per round: three quarters of the stage at the measured gated fraction, in whole sweeps of the workgroup
+		const u64 NIl = (u64) R * (u64) P;
+		const u32 stage_tuples = PART_LDS_BYTES / (u32) sizeof(TUP);
+		u64 rr = N ? (u64) stage_tuples * 3 / 4 * NIl / ((u64) N * (u64) P) : 1u << 16;
+		rr = std::max<u64>(PART_THREADS, std::min<u64>(rr / PART_THREADS * PART_THREADS, 1u << 16));
 		hipLaunchKernelGGL(k_part_records_g<TUP>, dim3(nblk2), dim3(PART_THREADS), PART_LDS_BYTES, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, rec_base,
-		                   pool->rl, k, 64 - cbits, NBc, rpb, gcur, l1);
+		                   pool->rl, k, 64 - cbits, NBc, rpb, (u32) rr, gcur, l1);
 	}
 	u32* tstart;                                   // starts of the final buckets
 	HIP_TRY(db.alloc(&tstart, NBt + 1));
@@ -2693,17 +2740,22 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	u32 tmask = 1023;
 	while ((size_t) tmask + 1 < (size_t) ns * 2) tmask = tmask * 2 + 1;
 	const u32 idx_bits = std::max(1u, ceil_log2_u64((u64) ns + 1));
-	u32 *table, *succ;
+	u32 *table, *succ, *succ1, *bloom;
 	ulonglong2* skey;
+	u32 bloom_bits = 1u << 16;
+	while (bloom_bits < (1u << 30) && (size_t) bloom_bits < (size_t) ns * 16) bloom_bits <<= 1;
+	HIP_TRY(db.alloc(&bloom, bloom_bits / 32));
+	HIP_TRY(hipMemsetAsync(bloom, 0, bloom_bits / 8, st));
 	HIP_TRY(db.alloc(&table, (size_t) tmask + 1));
 	HIP_TRY(db.alloc(&skey, ns));
 	HIP_TRY(db.alloc(&succ, (size_t) ns * 4));
+	HIP_TRY(db.alloc(&succ1, ns));
 	HIP_TRY(hipMemsetAsync(table, 0, ((size_t) tmask + 1) * 4, st));
-	SurvTable tb{table, tmask, idx_bits, skey};
+	SurvTable tb{table, tmask, idx_bits, skey, bloom, bloom_bits - 1};
 	{
 		vdjx_prof_scope ps(c, "k_surv_table");
-		hipLaunchKernelGGL(k_surv_table2, dim3((ns + 255) / 256), dim3(256), 0, st, s_lo, s_hi, ns, table, tmask, idx_bits, skey);
-		hipLaunchKernelGGL(k_succ_links2, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, tb, ns, k, succ);
+		hipLaunchKernelGGL(k_surv_table2, dim3((ns + 255) / 256), dim3(256), 0, st, s_lo, s_hi, ns, table, tmask, idx_bits, skey, bloom, bloom_bits - 1);
+		hipLaunchKernelGGL(k_succ_links2, dim3((ns + 255) / 256), dim3(256), 0, st, tb, ns, k, succ, succ1);
 	}
 	// survivor ranges (one recount workgroup each, LDS arrays indexed by index - range start): the smallest range size that keeps
 	// the ranges <= 1024 (one partition pass); beyond the largest size a second partition level
@@ -2742,7 +2794,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	HIP_TRY(hipFuncSetAttribute((const void*) k_walk_items, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_walk));
 	if (R) {
 		vdjx_prof_scope ps(c, "k_walk_items");
-		hipLaunchKernelGGL(k_walk_items, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, k, tb, succ, range_shift,
+		hipLaunchKernelGGL(k_walk_items, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, k, tb, succ, succ1, range_shift,
 		                   n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err);
 	}
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, range_cnt, n_ranges_p, range_start);

@@ -527,6 +527,8 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 #define MAP_THREADS 512
 #define MAP_MAXOFF 1024          // window/contig length - rl  <= MAP_MAXOFF
 #define WT_SLOTS 2048            // LDS table: read class -> last offset of the window where it occurs
+#define MAP_PRESENT_LOG2 15
+#define MAP_PRESENT_WORDS (1u << (MAP_PRESENT_LOG2 - 5))
 
 struct ReadIndexDev {
 	const u64* bases;
@@ -544,8 +546,12 @@ struct MapLds {
 	u32 wt_key[WT_SLOTS];                           // class id + 1
 	u32 wt_last[WT_SLOTS];                          // last offset + 1 with that class
 	u32 scan[MAP_THREADS];
+	u32 present[MAP_PRESENT_WORDS];                 // one bit per hashed class id seen in the window: "is this mate class here at all?" is one LDS
+	                                                // word for the 98 % of the hits whose mate lies elsewhere (a V gene is shared by many clones)
 	u32 inst_total;                                 // weighted mode: read-1 instances behind the distinct hits
 };
+
+__device__ inline u32 map_present_bit(u32 cls) { return (cls * 2654435761u) >> (32 - MAP_PRESENT_LOG2); }
 
 // classify every offset o in [0, len-rl) (quick_map3.c:200: the last offset is never looked at), build the
 // class -> last offset table, prefix the class sizes.  Returns the hit count H (uniform).
@@ -555,6 +561,7 @@ __device__ inline u32 map_prepare(MapLds& L, const ReadIndexDev& ix, const char*
 	const int noff = len - rl;
 	const u32 tid = threadIdx.x;
 	for (u32 i = tid; i < WT_SLOTS; i += MAP_THREADS) { L.wt_key[i] = 0; L.wt_last[i] = 0; }
+	for (u32 i = tid; i < MAP_PRESENT_WORDS; i += MAP_THREADS) L.present[i] = 0;
 	if (tid == 0) L.inst_total = 0;
 	__syncthreads();
 	for (int o = tid; o < noff; o += MAP_THREADS) {
@@ -586,6 +593,10 @@ __device__ inline u32 map_prepare(MapLds& L, const ReadIndexDev& ix, const char*
 			} else {
 				cs = ix.start[cls];
 				sz = ix.cnt1[cls];                  // read-1 members come first
+			}
+			{
+				const u32 pb = map_present_bit(cls);
+				atomicOr(&L.present[pb >> 5], 1u << (pb & 31));
 			}
 			// class -> last offset ("read2[id] = m_info": the last writer wins, quick_map3.c:214)
 			u32 slot = (cls * 2654435761u) & (WT_SLOTS - 1);
@@ -655,7 +666,10 @@ __device__ inline Hit map_eval_hit(const MapLds& L, const ReadIndexDev& ix, int 
 	const uint4 info = WEIGHTED ? ix.dinfo[ci] : ix.csr_info[ci];
 	if (!(info.w & RI_R1)) return r;                // read-2 instances only feed the read2 map
 	// read2[id]: among the pair's read-2 records the one written last = largest offset, then latest registration
-	const u32 la = map_last_occurrence(L, info.y), lb = map_last_occurrence(L, info.z);
+	const u32 ba = map_present_bit(info.y), bb = map_present_bit(info.z);
+	const bool pa = (L.present[ba >> 5] >> (ba & 31)) & 1u, pb = (L.present[bb >> 5] >> (bb & 31)) & 1u;
+	if (!pa && !pb) return r;
+	const u32 la = pa ? map_last_occurrence(L, info.y) : 0u, lb = pb ? map_last_occurrence(L, info.z) : 0u;
 	if (!la && !lb) return r;
 	const int which = (lb && lb >= la) ? 1 : 0;
 	const u32 best = which ? lb : la;
@@ -703,7 +717,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_hits(ReadIndexDev ix, co
 // one (weighted) entry of the class at offset o -> mapped pair or not (quick_map3.c:223-245)
 __device__ inline bool map_eval_entry(const MapLds& L, int rl, int o, const uint4 info, u32& pos2_out) {
 	if (!(info.w & RI_R1)) return false;
-	const u32 la = map_last_occurrence(L, info.y), lb = map_last_occurrence(L, info.z);
+	const u32 ba = map_present_bit(info.y), bb = map_present_bit(info.z);
+	const bool pa = (L.present[ba >> 5] >> (ba & 31)) & 1u, pb = (L.present[bb >> 5] >> (bb & 31)) & 1u;
+	if (!pa && !pb) return false;
+	const u32 la = pa ? map_last_occurrence(L, info.y) : 0u, lb = pb ? map_last_occurrence(L, info.z) : 0u;
 	if (!la && !lb) return false;
 	const int which = (lb && lb >= la) ? 1 : 0;
 	const u32 best = which ? lb : la;
@@ -722,7 +739,8 @@ __device__ inline bool map_eval_entry(const MapLds& L, int rl, int o, const uint
 // The waves of the workgroup take the offsets of the slice one at a time (LDS ticket): the entries of an offset's read class
 // are consecutive, so a wave streams them with coalesced 16-byte loads and no search; pairs (a few per cent of the entries) are
 // staged per wave in LDS and leave with one global cursor bump per 128.
-#define WP_STAGE 128
+#define WP_STAGE 64
+#define WP_UNR 4
 __global__ __launch_bounds__(MAP_THREADS) void k_window_pairs(ReadIndexDev ix, const char* __restrict__ windows, int len,
                                                               const uint4* __restrict__ work /* {window, h0, h1, -} */,
                                                               const u64* __restrict__ pair_off, u64* __restrict__ pair_buf,
@@ -759,30 +777,35 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_pairs(ReadIndexDev ix, c
 		if (a == bnd) continue;
 		const u32 e0 = (h0 > a ? h0 : a) - a, e1 = (h1 < bnd ? h1 : bnd) - a;
 		const u32 cs = L.cstart[o];
-		for (u32 eb = e0; eb < e1; eb += 64) {
-			const u32 e = eb + (u32) lane;
-			bool pr = false;
-			u32 pos2 = 0, mult = 0;
-			if (e < e1) {
-				const uint4 info = ix.dinfo[cs + e];
-				pr = map_eval_entry(L, ix.rl, o, info, pos2);
-				mult = info.x;
+		// four 16-byte loads are in flight per lane before the first is used: the loop is bound by their latency, not their bytes
+		for (u32 eb = e0; eb < e1; eb += 64 * WP_UNR) {
+			uint4 info[WP_UNR];
+#pragma unroll
+			for (int u = 0; u < WP_UNR; u++) {
+				const u32 e = eb + (u32) (u * 64 + lane);
+				info[u] = e < e1 ? ix.dinfo[cs + e] : make_uint4(0, 0, 0, 0);        // (flags 0: not a read-1 entry)
 			}
-			const u64 m = __ballot(pr);
-			if (!m) continue;
-			const u32 cnt = (u32) __popcll(m);
-			if (fill + cnt > WP_STAGE) {                   // (wave-uniform) flush
-				u32 base = 0;
-				if (lane == 0) base = atomicAdd(&pair_cnt[wi], fill);
-				base = (u32) __builtin_amdgcn_readlane((int) base, 0);
-				for (u32 i = (u32) lane; i < fill; i += 64) pairs[base + i] = mystg[i];
-				fill = 0;
+#pragma unroll
+			for (int u = 0; u < WP_UNR; u++) {
+				if (eb + (u32) (u * 64) >= e1) break;                                // (wave-uniform)
+				u32 pos2 = 0;
+				const bool pr = map_eval_entry(L, ix.rl, o, info[u], pos2);
+				const u64 m = __ballot(pr);
+				if (!m) continue;
+				const u32 cnt = (u32) __popcll(m);
+				if (fill + cnt > WP_STAGE) {                   // (wave-uniform) flush
+					u32 base = 0;
+					if (lane == 0) base = atomicAdd(&pair_cnt[wi], fill);
+					base = (u32) __builtin_amdgcn_readlane((int) base, 0);
+					for (u32 i = (u32) lane; i < fill; i += 64) pairs[base + i] = mystg[i];
+					fill = 0;
+				}
+				if (pr) {
+					mystg[fill + (u32) __popcll(m & ((1ull << lane) - 1ull))] = ((u64) info[u].x << 32) | ((u32) (o + 1) << 16) | pos2;
+					mine += info[u].x;
+				}
+				fill += cnt;
 			}
-			if (pr) {
-				mystg[fill + (u32) __popcll(m & ((1ull << lane) - 1ull))] = ((u64) mult << 32) | ((u32) (o + 1) << 16) | pos2;
-				mine += mult;
-			}
-			fill += cnt;
 		}
 	}
 	if (fill) {
