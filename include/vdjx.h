@@ -24,7 +24,7 @@ extern "C" {
 #define VDJX_OK 0
 #define VDJX_EINVAL (-1)   /* bad argument */
 #define VDJX_EHIP (-2)     /* HIP runtime error */
-#define VDJX_ELIMIT (-3)   /* input exceeds a documented limit (rl <= 64, k <= 50, records*offsets < 2^31) */
+#define VDJX_ELIMIT (-3)   /* input exceeds a documented limit (rl <= 64, k <= 50, 2^32 records in all, 2^29 per GPU, 2^26 surviving k-mers) */
 #define VDJX_ESTATE (-4)   /* call order violated (e.g. scorer used before its index was loaded) */
 
 #define VDJX_MAX_READ_LEN 64
@@ -186,16 +186,20 @@ int vdjx_profile_get(vdjx_ctx* ctx, int idx, const char** name, double* total_ms
 /* ---- multi-GPU k-mer build: hash-prefix sharding, partial aggregates merged by the owner ----
  * The reference has no counterpart (its only parallelism is pthreads over roots, A2:1287-1348); these
  * phases split vdjx_kmer_build so that the caller can move the bytes between ranks (one process per GPU;
- * vdjer_amd/shard.py does it with torch.distributed over RCCL).  Record numbering is rank-major with a
- * common stride: rank r's records are [r*rec_stride, r*rec_stride + R_r).  nranks is a power of two; the
- * owner of a k-mer is given by the top log2(nranks) bits of its hash.
- *   Every rank first aggregates ITS OWN instances per distinct k-mer (count and first instance, gated and
- * ungated, and whether it saw two different reads: add_to_table A2:322-367 restated per rank).  These partial
- * aggregates (24 B per distinct gated k-mer per rank, not per instance) are the one bulk exchange.  The owner
- * merges them (counts add, firsts take the minimum, flags OR) and decides almost every k-mer on the spot;
- * only a k-mer whose verdict needs per-read data -- no rank saw two different reads although several hold
- * it, or its count is below the level where the quality sums cannot fail -- costs a question to the ranks
- * that hold it and a fixed-size answer (the first record's bases, partial quality sums).
+ * vdjer_amd/shard.py does it with torch.distributed over RCCL, vdjer_amd/csrc/host/vdjx_mgpu.c with RCCL
+ * directly).  Record numbering is rank-major with a common stride: rank r's records are
+ * [r*rec_stride, r*rec_stride + R_r); instance ids are global, record << 6 | offset, so nranks * rec_stride
+ * must stay below 2^32 records.  nranks is a power of two; the owner of a k-mer is given by the top
+ * log2(nranks) bits of its hash.
+ *   Every rank first aggregates ITS OWN gated instances per distinct k-mer (count, first instance, whether it
+ * saw two different reads: add_to_table A2:322-367 restated per rank).  These partial aggregates (32 B per
+ * distinct gated k-mer per rank, not per instance) are the one bulk exchange.  The owner merges them (counts
+ * add, firsts take the minimum, flags OR) and decides almost every k-mer on the spot; only a k-mer whose
+ * verdict needs per-read data -- no rank saw two different reads although several hold it, or its count is
+ * below the level where the quality sums cannot fail -- costs a question to the ranks that hold it and a
+ * fixed-size answer (the first record's bases, partial quality sums).  add_to_graph's bookkeeping (node
+ * frequency, first sights of nodes and edges, A2:261-320) is computed by every rank over its own records for
+ * ALL survivors and reduced: SUM for the counts, MIN for the first sights.
  * All pointers are device pointers owned by the caller.  Call order (brackets = the caller's collectives):
  *   begin -> local -> local_fill -> [all_to_all: directories, counts, partial aggregates] -> merge
  *   -> queries -> [all_to_all: counts, questions] -> reply -> [all_to_all: answers] -> resolve
@@ -204,7 +208,7 @@ typedef struct vdjx_shard vdjx_shard;
 int vdjx_shard_begin(vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, int rank, int nranks,
                      uint64_t rec_stride, vdjx_shard** out);
 void vdjx_shard_free(vdjx_shard* s);
-/* bytes per exchanged record: kind 0 partial aggregate (24), 1 question (8), 2 answer (192) */
+/* bytes per exchanged record: kind 0 partial aggregate (32), 1 question (8), 2 answer (200), 3 survivor (32) */
 size_t vdjx_shard_record_bytes(int kind);
 /* this rank's partial aggregates, grouped by owner: send_counts[nranks]; *dir_len = hash buckets per owner */
 int vdjx_shard_local(vdjx_shard* s, uint64_t* send_counts, uint32_t* dir_len);
@@ -221,16 +225,16 @@ int vdjx_shard_reply(vdjx_shard* s, const void* d_queries, const uint64_t* count
 /* owner: the answers (grouped by answering rank, each group in question order) -> this rank's survivors
  * (a-1/a-2 for the k-mers it owns); n_distinct = distinct gated k-mers it owns ("Pre Num nodes") */
 int vdjx_shard_resolve(vdjx_shard* s, const void* d_replies, uint64_t n_replies, uint64_t* n_survivors, uint64_t* n_distinct);
-/* n_survivors records of 32 B: {u64 key_lo, u64 key_hi, u32 gated count, u32 gated first, u32 count, u32 first} */
+/* n_survivors records of 32 B: {u64 key_lo, u64 key_hi, u32 gated count, u32 -, u64 first gated instance} */
 int vdjx_shard_survivors(vdjx_shard* s, void* d_out);
-/* all ranks' survivors (rank order) -> this rank's edge pass into d_edge_first/d_edge_to [ns_total*4] u32
- * (0xFFFFFFFF = no edge) and its share of add_to_graph's recount (A2:261-309): d_ucnt (instances of each
- * survivor on this rank), d_ufirst (first of them, 0xFFFFFFFF = none), [ns_total] u32 each.  The caller
- * reduces over ranks: MIN (unsigned order) for the edge arrays and d_ufirst, SUM for d_ucnt */
-int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t ns_total, void* d_edge_first, void* d_edge_to,
-                     void* d_ucnt, void* d_ufirst);
+/* all ranks' survivors (rank order) -> this rank's share of add_to_graph (A2:261-320) over ITS records:
+ * d_in_first u64 [ns_total*4]: first sight (global instance id, all-ones = none) of the edge into survivor v whose tail
+ * k-mer starts with base a, at [v*4+a]; d_ufirst u64 [ns_total]: first sight of the node; d_ucnt u32 [ns_total]:
+ * its instances on this rank.  The caller reduces over ranks: MIN (unsigned order) for d_in_first and d_ufirst,
+ * SUM for d_ucnt */
+int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t ns_total, void* d_in_first, void* d_ucnt, void* d_ufirst);
 /* reduced arrays -> the graph, identical on every rank */
-int vdjx_shard_finish(vdjx_shard* s, const void* d_edge_first, const void* d_edge_to, const void* d_ucnt, const void* d_ufirst,
+int vdjx_shard_finish(vdjx_shard* s, const void* d_in_first, const void* d_ucnt, const void* d_ufirst,
                       uint64_t pre_nodes_total, vdjx_graph** out);
 
 #ifdef __cplusplus

@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 SEED = 20261002
 N_PAIRS, N_CLONES = 10_000_000, 20_000
 WINDOW_STEP = 10          # every 10th clone's generator window: 2,000 deep windows
-CASES = [("k35", 35, 3, 90, 30), ("k25", 25, 2, 60, 20)]     # configs[2]; configs[3] (--mrs 20: SURVEY §0-6)
+CASES = [("k35", 35, 3, 90, 30), ("k25", 25, 2, 60, 20),     # configs[2]; configs[3] (--mrs 20: SURVEY §0-6)
+         ("k35_mq60", 35, 3, 60, 30)]                        # reference point of the 40 M-pair (4x duplicated pool) property test
 
 
 def sha(a) -> str:
@@ -53,12 +54,17 @@ def main():
     ap.add_argument("--pairs", type=int, default=N_PAIRS)
     ap.add_argument("--clones", type=int, default=N_CLONES)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "fullsize_digests.json"))
+    ap.add_argument("--only", default="", help="comma-separated case names to (re)compute and merge into the existing file; no window pass")
     args = ap.parse_args()
     N_PAIRS, N_CLONES = args.pairs, args.clones
     from oracle import oracle
     from vdjer_amd import synth
     out = {"seed": SEED, "n_pairs": N_PAIRS, "n_clones": N_CLONES, "noise": 0.3, "generator": "synth.make_reads_cb",
            "window_step": WINDOW_STEP, "cases": {}}
+    only = [x for x in args.only.split(",") if x]
+    if only:
+        out = json.load(open(args.out))
+        assert (out["n_pairs"], out["n_clones"], out["seed"]) == (N_PAIRS, N_CLONES, SEED)
     t0 = time.time()
     rep = synth.make_repertoire(N_CLONES, seed=SEED)
     pool = synth.make_reads_cb(rep, N_PAIRS, noise_frac=0.3, seed=SEED)
@@ -68,6 +74,8 @@ def main():
     vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
     jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
     for name, k, mf, mq, mrs in CASES:
+        if only and name not in only:
+            continue
         t0 = time.time()
         tb = oracle.KmerTable(pool, k)
         pre = tb.size()
@@ -82,6 +90,11 @@ def main():
         out["cases"][name] = d
         print(f"{name}: pre={pre} nodes={g.n} roots={roots.shape[0]} ok={int(ok.sum())} ({time.time() - t0:.0f}s)", flush=True)
         del tb, g
+    if only:
+        with open(args.out, "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+            f.write("\n")
+        return
     # window scorer (a-8, a-9) on deep windows of the same pool
     t0 = time.time()
     wins = [w for w in rep.windows()[::WINDOW_STEP] if w]

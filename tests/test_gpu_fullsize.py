@@ -125,6 +125,37 @@ def test_config2_10M_pairs_window_scorer_vs_oracle_digests():
     assert sha(valid.astype(np.uint8)) == dg["windows"]["valid"]
 
 
+def test_40M_pairs_one_gpu_beyond_2_31_instances():
+    """One GPU, 40 M pairs (160 M records, 2.56 G k-mer instances: past the 2^31 the round-1 instance ids could hold; BASELINE
+    configs[4] gives every GPU 12.5 M pairs of a 100 M-pair pool): the 10 M-pair pool four times over.  With mf raised four-fold
+    and mq = 60 (a k-mer of >= 3 gated instances of this generator always reaches it) the copies change nothing but the counts:
+    same k-mers, same first sights, same edges as the oracle's graph of the single pool (digest case k35_mq60), every count x 4."""
+    import torch
+    from vdjer_amd import api
+    st = _fullsize_state()
+    d, sha, pool = st["dg"]["cases"]["k35_mq60"], st["sha"], st["pool"]
+    ctx = st["ctx"]
+    allrec = torch.cat([pool.primary, pool.secondary])
+    big = torch.cat([allrec] * 4)
+    del allrec
+    torch.cuda.synchronize()
+    empty = torch.zeros((0, big.shape[1]), dtype=torch.uint8, device=big.device)
+    p4 = ctx.pool_load_device(big.data_ptr(), big.shape[0], 0, 0, pool.rl)
+    assert p4.n_records * 16 > 2 ** 31
+    g = ctx.kmer_build(p4, d["k"], 4 * d["mf"], d["mq"])
+    p4.free()
+    del big, empty
+    torch.cuda.empty_cache()
+    assert (g.n, g.pre_nodes) == (d["nodes"], d["pre_nodes"])
+    # primary records come before secondary ones in the single pool and in every copy: same scan order inside the first copy
+    for f in ("first_inst", "has_v", "has_j", "to_ids", "from_ids"):
+        assert sha(getattr(g, f)) == d[f], f
+    g1 = ctx.kmer_build(st["p"], d["k"], d["mf"], d["mq"])
+    assert sha(g1.freq) == d["freq"]
+    np.testing.assert_array_equal(g.freq, np.minimum(4 * g1.freq.astype(np.int64), 32765).astype(np.uint32))
+    np.testing.assert_array_equal(g.gated_count, np.minimum(4 * g1.gated_count.astype(np.int64), 32765).astype(np.uint32))
+
+
 def test_fullsize_release():
     """frees the 10 M-pair pool (4 GB of ASCII + the packed pool) before the remaining tests"""
     if _FS:
@@ -205,9 +236,11 @@ print("KNOB_CASE_OK", g.n, g.pre_nodes)
 
 
 @pytest.mark.parametrize("k,mf,mq,env", [
-    (35, 3, 90, {"VDJX_BUCKET_TUPLES": "16", "VDJX_REFINE_TUPLES": "16"}),                          # 2^20 buckets: counting pass + 1024-way pass 2
-    (25, 2, 60, {"VDJX_BUCKET_TUPLES": "64", "VDJX_REFINE_TUPLES": "200", "VDJX_SUB_TUPLES": "64"}),    # 2^17 buckets, long buckets split up front
-    (35, 3, 90, {"VDJX_BUCKET_TUPLES": "100000", "VDJX_SUB_TUPLES": "1000000000"}),                  # few huge buckets: table overflow -> sub-passes
+    (35, 3, 90, {"VDJX_GATED_BUCKET": "4", "VDJX_REFINE_TUPLES": "4"}),                             # > 2^15 buckets: counting pass + 1024-way pass 2
+    (25, 2, 60, {"VDJX_GATED_BUCKET": "16", "VDJX_REFINE_TUPLES": "50", "VDJX_SUB_TUPLES": "64"}),     # long buckets split up front (verified dry run)
+    (35, 3, 90, {"VDJX_GATED_BUCKET": "100000", "VDJX_SUB_TUPLES": "1000000000"}),                   # few huge buckets: table overflow -> sub-passes
+    (35, 3, 90, {"VDJX_RC_MAX_RANGES": "4", "VDJX_RC_MAX_SHIFT": "9", "VDJX_RC_WIDE": "1"}),         # recount: two partition levels, 64-bit ids
+    (25, 2, 60, {"VDJX_RC_MAX_RANGES": "8", "VDJX_RC_MAX_SHIFT": "12"}),                             # recount: 4096-survivor ranges
 ])
 def test_large_pool_code_paths_on_a_small_pool(k, mf, mq, env):
     """The paths 10 M-pair pools take (more than 2^15 buckets, long-bucket handling) forced on 120 k pairs through the tuning

@@ -409,10 +409,13 @@ def test_deep_windows_many_slices_and_multiplicities(ctx):
     p.free()
 
 
-@pytest.mark.parametrize("world,k,mf,mq", [(2, 35, 3, 90), (4, 25, 2, 60), (2, 48, 2, 60), (8, 35, 2, 60)])
-def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq):
+@pytest.mark.parametrize("world,k,mf,mq,stride", [(2, 35, 3, 90, None), (4, 25, 2, 60, None), (2, 48, 2, 60, None), (8, 35, 2, 60, None),
+                                                  (2, 35, 3, 90, 1 << 30), (4, 25, 2, 60, (1 << 30) - 12345)])
+def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq, stride):
     """The real multi-rank driver + the HIP phase engine with `world` ranks on this one GPU (ranks are threads,
-    collectives are tensor copies: tests/fake_dist.py).  Result == single-GPU build of the union pool == oracle."""
+    collectives are tensor copies: tests/fake_dist.py).  Result == single-GPU build of the union pool == oracle.
+    stride: the ranks' records numbered 2^30 apart, so that global instance ids (record << 6 | offset) run past 2^32 as they
+    do for BASELINE configs[4] (400 M records): same graph, first instances shifted by the rank's base"""
     import threading
     import torch
     from tests.fake_dist import ThreadDist
@@ -446,7 +449,7 @@ def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq):
             c = api.Context(0)
             c.anchor_sets_load(vc, jc)
             p = c.pool_load(pools[r].primary, pools[r].secondary, 50)
-            drv = shard.ShardedHotPath(c, dist, torch.device("cuda", 0))
+            drv = shard.ShardedHotPath(c, dist, torch.device("cuda", 0), stride=stride)
             out[r] = drv.kmer_build(p, k, mf, mq)
             stats[r] = {n_: c.stat("shard_" + n_) for n_ in ("partials_received", "open_kmers", "questions", "decided_at_merge", "kept_after_answers")}
             p.free()
@@ -466,9 +469,16 @@ def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq):
     assert tot["questions"] >= tot["open_kmers"] > 0
     assert 0 < tot["kept_after_answers"] < tot["open_kmers"]
     assert tot["decided_at_merge"] + tot["kept_after_answers"] == ref.n
+    exp_first = ref.first_inst
+    if stride is not None:          # union record rank*R_r + i is global record rank*stride + i
+        per = pools[0].n_records
+        assert all(p_.n_records == per for p_ in pools)
+        rec = ref.first_inst >> np.uint64(6)
+        exp_first = (((rec // np.uint64(per)) * np.uint64(stride) + rec % np.uint64(per)) << np.uint64(6)) | (ref.first_inst & np.uint64(63))
+        assert int(exp_first.max()) >= 1 << 32
     for g in out:
         assert g.n == ref.n and g.pre_nodes == ref.pre_nodes
-        np.testing.assert_array_equal(g.first_inst, ref.first_inst)
+        np.testing.assert_array_equal(g.first_inst, exp_first)
         np.testing.assert_array_equal(g.freq, ref.freq)
         np.testing.assert_array_equal(g.gated_count, ref.gated_count)
         np.testing.assert_array_equal(g.has_v, ref.has_v)

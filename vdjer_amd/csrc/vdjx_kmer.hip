@@ -57,36 +57,6 @@ __device__ inline RecView load_rec(const u64* __restrict__ bases, const u64* __r
 	return v;
 }
 
-// ----------------------------------------------------------------------------------------------
-// K2a
-// ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(HIST_THREADS) void k_kmer_hist(const u64* __restrict__ bases, const u64* __restrict__ nmask,
-                                                            size_t R, int rl, int k, u32 nb_bits, size_t rpb,
-                                                            u32* __restrict__ bucket_cnt) {   // bucket sizes do not depend on the record numbering
-	extern __shared__ u32 hist[];
-	const u32 NB = 1u << nb_bits;
-	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) hist[i] = 0;
-	__syncthreads();
-	const size_t r0 = (size_t) blockIdx.x * rpb;
-	const size_t r1 = r0 + rpb < R ? r0 + rpb : R;
-	const int P = rl - k + 1;
-	const u64 km = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
-	for (size_t r = r0 + threadIdx.x; r < r1; r += HIST_THREADS) {
-		RecView v = load_rec(bases, nmask, nullptr, r);
-		for (int o = 0; o < P; o++) {
-			if ((v.nm >> o) & km) continue;                     // k-mer holds an 'N' (A2:246)
-			u64 khi, klo;
-			vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
-			u64 h = vdjx_mix(klo, khi);
-			atomicAdd(&hist[(u32) (h >> (64 - nb_bits))], 1u);
-		}
-	}
-	__syncthreads();
-	// only bucket totals are needed (positions inside a bucket come from cursor bumps in the partition passes): the
-	// workgroups add their LDS counts to the global ones, a few hundred adds per address spread over 2^15 addresses
-	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) if (hist[i]) atomicAdd(&bucket_cnt[i], hist[i]);
-}
-
 // exclusive scan of bucket_cnt[NB] -> bucket_start[NB+1], one 1024-thread workgroup
 __global__ __launch_bounds__(1024) void k_bucket_scan(const u32* __restrict__ bucket_cnt, u32 NB, u32* __restrict__ bucket_start) {
 	__shared__ u32 part[1024];
@@ -125,8 +95,6 @@ __global__ __launch_bounds__(1024) void k_bucket_scan(const u32* __restrict__ bu
 #define PART_LDS_BYTES 131072
 #define PART_MAXB 1024
 
-template <typename THI> struct Tup { u64 lo; THI hi; u32 inst; };
-
 // exclusive scan of cnt[0..n) (n <= 1024) into base[0..n], base[n] = total; all PART_THREADS threads call it.
 // Two counts per thread, DPP prefix sums inside the waves, one wave for the wave totals: three barriers instead of twenty.
 __device__ inline void part_scan(const u32* cnt, u32* base, u32* tmp, u32 n) {
@@ -147,155 +115,6 @@ __device__ inline void part_scan(const u32* cnt, u32* base, u32* tmp, u32 n) {
 	if (2 * t + 1 < n) base[2 * t + 1] = excl + a;
 	if (t == 0) base[n] = tmp[PART_THREADS / 64];
 	__syncthreads();
-}
-
-// records -> tuples, one pass over `nbk` buckets selected by (hash >> shift) & (nbk-1)
-template <typename THI>
-__global__ __launch_bounds__(PART_THREADS) void k_part_records(const u64* __restrict__ bases, const u64* __restrict__ nmask,
-                                                               const u64* __restrict__ lowq, size_t R, u32 rec_base, int rl, int k,
-                                                               u32 shift, u32 nbk, size_t rpb, u32* __restrict__ gcur,
-                                                               u64* __restrict__ o_lo, THI* __restrict__ o_hi, u32* __restrict__ o_inst) {
-	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	Tup<THI>* stage = (Tup<THI>*) smem;
-	__shared__ u32 cnt[PART_MAXB], base[PART_MAXB + 1], cur[PART_MAXB], gbase[PART_MAXB], tmp[PART_THREADS];
-	const u32 ROUND = PART_LDS_BYTES / sizeof(Tup<THI>);
-	const int P = rl - k + 1;
-	const u32 RR = ROUND / (u32) P;                                  // records per round
-	// a round holds fewer records than the workgroup has threads (8,192 tuples = 512 records at P = 16): T threads share a
-	// record, each taking a contiguous part of its offsets
-	const u32 T = RR * 4 <= PART_THREADS ? 4u : (RR * 2 <= PART_THREADS ? 2u : 1u);
-	const int off_a = (int) ((threadIdx.x % T) * (u32) P / T), off_b = (int) ((threadIdx.x % T + 1) * (u32) P / T);
-	const u64 km = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
-	const u32 mask = nbk - 1;
-	const size_t r0 = (size_t) blockIdx.x * rpb;
-	const size_t r1 = r0 + rpb < R ? r0 + rpb : R;
-	for (size_t rs = r0; rs < r1; rs += RR) {
-		const size_t re = rs + RR < r1 ? rs + RR : r1;
-		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) cnt[i] = 0;
-		__syncthreads();
-		for (size_t r = rs + threadIdx.x / T; r < re; r += PART_THREADS / T) {
-			RecView v = load_rec(bases, nmask, nullptr, r);
-			for (int o = off_a; o < off_b; o++) {
-				if ((v.nm >> o) & km) continue;
-				u64 khi, klo;
-				vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
-				atomicAdd(&cnt[(u32) (vdjx_mix(klo, khi) >> shift) & mask], 1u);
-			}
-		}
-		__syncthreads();
-		part_scan(cnt, base, tmp, nbk);
-		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) {
-			cur[i] = base[i];
-			gbase[i] = cnt[i] ? atomicAdd(&gcur[i], cnt[i]) : 0u;
-		}
-		__syncthreads();
-		for (size_t r = rs + threadIdx.x / T; r < re; r += PART_THREADS / T) {
-			RecView v = load_rec(bases, nmask, lowq, r);
-			for (int o = off_a; o < off_b; o++) {
-				if ((v.nm >> o) & km) continue;
-				u64 khi, klo;
-				vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
-				const u32 b = (u32) (vdjx_mix(klo, khi) >> shift) & mask;
-				const u32 pos = atomicAdd(&cur[b], 1u);
-				const u32 gated = ((v.lq >> o) & km) ? 0u : 0x80000000u;       // all k Phred >= 20 (A2:252)
-				Tup<THI> t;
-				t.lo = klo; t.hi = (THI) khi; t.inst = gated | (u32) ((rec_base + r) * (size_t) P + (size_t) o);
-				stage[pos] = t;
-			}
-		}
-		__syncthreads();
-		const u32 n = base[nbk];
-		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
-			const Tup<THI> t = stage[i];
-			const u32 b = (u32) (vdjx_mix(t.lo, (u64) t.hi) >> shift) & mask;
-			const u32 g = gbase[b] + (i - base[b]);
-			o_lo[g] = t.lo; o_hi[g] = t.hi; o_inst[g] = t.inst;
-		}
-		__syncthreads();
-	}
-}
-
-// tuples -> tuples: segment s of the input ([seg_start[s << seg_shift], seg_start[(s+1) << seg_shift])) is split over
-// `slices` workgroups; bucket = (s << sub_bits) | ((hash >> shift) & (2^sub_bits - 1)); gcur indexed by bucket
-template <typename THI>
-__global__ __launch_bounds__(PART_THREADS) void k_part_tuples(const u64* __restrict__ i_lo, const THI* __restrict__ i_hi,
-                                                              const u32* __restrict__ i_inst, const u32* __restrict__ seg_start,
-                                                              u32 seg_shift, u32 slices, u32 shift, u32 sub_bits,
-                                                              u32* __restrict__ gcur, u64* __restrict__ o_lo, THI* __restrict__ o_hi,
-                                                              u32* __restrict__ o_inst) {
-	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	Tup<THI>* stage = (Tup<THI>*) smem;
-	__shared__ u32 cnt[PART_MAXB], base[PART_MAXB + 1], cur[PART_MAXB], gbase[PART_MAXB], tmp[PART_THREADS];
-	constexpr u32 PER = PART_LDS_BYTES / sizeof(Tup<THI>) / PART_THREADS;      // tuples per thread per round, held in registers
-	constexpr u32 ROUND = PER * PART_THREADS;
-	const u32 seg = blockIdx.x / slices, sl = blockIdx.x % slices;
-	const u32 nbk = 1u << sub_bits, mask = nbk - 1;
-	const size_t s0 = seg_start[(size_t) seg << seg_shift], s1 = seg_start[((size_t) seg + 1) << seg_shift];
-	const size_t len = s1 - s0;
-	const size_t per = (len + slices - 1) / slices;
-	const size_t t0 = s0 + (size_t) sl * per;
-	const size_t t1 = t0 + per < s1 ? t0 + per : s1;
-	u32* gc = gcur + ((size_t) seg << sub_bits);
-	for (size_t ts = t0; ts < t1; ts += ROUND) {
-		const size_t te = ts + ROUND < t1 ? ts + ROUND : t1;
-		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) cnt[i] = 0;
-		__syncthreads();
-		u64 r_lo[PER];
-		THI r_hi[PER];
-		u32 r_inst[PER], r_b[PER];
-#pragma unroll
-		for (u32 j = 0; j < PER; j++) {
-			const size_t t = ts + (size_t) j * PART_THREADS + threadIdx.x;
-			const bool v = t < te;
-			r_lo[j] = v ? i_lo[t] : 0ull;
-			r_hi[j] = v ? i_hi[t] : (THI) 0;
-			r_inst[j] = v ? i_inst[t] : 0u;
-			r_b[j] = v ? ((u32) (vdjx_mix(r_lo[j], (u64) r_hi[j]) >> shift) & mask) : NONE32;
-		}
-#pragma unroll
-		for (u32 j = 0; j < PER; j++) if (r_b[j] != NONE32) atomicAdd(&cnt[r_b[j]], 1u);
-		__syncthreads();
-		part_scan(cnt, base, tmp, nbk);
-		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) {
-			cur[i] = base[i];
-			gbase[i] = cnt[i] ? atomicAdd(&gc[i], cnt[i]) : 0u;
-		}
-		__syncthreads();
-#pragma unroll
-		for (u32 j = 0; j < PER; j++) {
-			if (r_b[j] == NONE32) continue;
-			Tup<THI> x;
-			x.lo = r_lo[j]; x.hi = r_hi[j]; x.inst = r_inst[j];
-			stage[atomicAdd(&cur[r_b[j]], 1u)] = x;
-		}
-		__syncthreads();
-		const u32 n = base[nbk];
-		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
-			const Tup<THI> x = stage[i];
-			const u32 b = (u32) (vdjx_mix(x.lo, (u64) x.hi) >> shift) & mask;
-			const u32 g = gbase[b] + (i - base[b]);
-			o_lo[g] = x.lo; o_hi[g] = x.hi; o_inst[g] = x.inst;
-		}
-		__syncthreads();
-	}
-}
-
-// sub-bucket sizes inside the segments (the coarse buckets of pass 1) of a partitioned tuple array: `slices` workgroups per segment, LDS counts added to the global ones
-template <typename THI>
-__global__ __launch_bounds__(512) void k_seg_hist_sliced(const u64* __restrict__ lo, const THI* __restrict__ hi, const u32* __restrict__ seg_start,
-                                                         u32 seg_shift, u32 slices, u32 shift, u32 sub_bits, u32* __restrict__ fine_cnt) {
-	__shared__ u32 h[PART_MAXB];
-	const u32 nbk = 1u << sub_bits;
-	for (u32 i = threadIdx.x; i < nbk; i += 512) h[i] = 0;
-	__syncthreads();
-	const u32 seg = blockIdx.x / slices, sl = blockIdx.x % slices;
-	const size_t s0 = seg_start[(size_t) seg << seg_shift], s1 = seg_start[((size_t) seg + 1) << seg_shift];
-	const size_t per = (s1 - s0 + slices - 1) / slices;
-	const size_t t0 = s0 + (size_t) sl * per;
-	const size_t t1 = t0 + per < s1 ? t0 + per : s1;
-	for (size_t t = t0 + threadIdx.x; t < t1; t += 512) atomicAdd(&h[(u32) (vdjx_mix(lo[t], (u64) hi[t]) >> shift) & (nbk - 1)], 1u);
-	__syncthreads();
-	for (u32 i = threadIdx.x; i < nbk; i += 512) if (h[i]) atomicAdd(&fine_cnt[((size_t) seg << sub_bits) | i], h[i]);
 }
 
 // out[i] = src[i*step]
@@ -350,313 +169,6 @@ __device__ inline int lds_lookup(const u64* s_klo, const THI* s_khi, u64 lo, THI
 		slot = (slot + 1) & (SLOTS - 1);
 	}
 	return -1;
-}
-
-template <typename THI>
-__global__ __launch_bounds__(K3_THREADS) void k_bucket_aggregate(const u64* __restrict__ t_lo, const THI* __restrict__ t_hi,
-                                                                 const u32* __restrict__ t_inst, const u32* __restrict__ bucket_start,
-                                                                 u32 cmin, u64* __restrict__ c_lo, THI* __restrict__ c_hi,
-                                                                 u32* __restrict__ c_cnt, u32* __restrict__ c_first,
-                                                                 u32* __restrict__ c_ucnt, u32* __restrict__ c_ufirst,
-                                                                 u32* __restrict__ ct_lcid, u32* __restrict__ ct_inst,
-                                                                 u32* __restrict__ bucket_ncand, u32* __restrict__ bucket_nct,
-                                                                 u64* __restrict__ g_distinct, u32* __restrict__ g_err) {
-	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	u64* s_klo = (u64*) smem;
-	THI* s_khi = (THI*) (s_klo + K3_SLOTS);
-	u32* s_cnt = (u32*) (s_khi + K3_SLOTS);
-	u32* s_first = s_cnt + K3_SLOTS;
-	u32* s_cidx = s_first + K3_SLOTS;
-	u32* s_ucnt = s_cidx + K3_SLOTS;           // every instance of the k-mer, gated or not (add_to_graph's recount, A2:261-309)
-	u32* s_ufirst = s_ucnt + K3_SLOTS;
-	__shared__ u32 s_ncand, s_nct, s_over, s_ndist;
-	const THI EMPTY = (THI) ~(THI) 0;
-	const u32 b = blockIdx.x;
-	const u32 base = bucket_start[b];
-	const u32 n = bucket_start[b + 1] - base;
-	const u32 tid = threadIdx.x;
-	if (n == 0) {
-		if (tid == 0) { bucket_ncand[b] = 0; bucket_nct[b] = 0; }
-		return;
-	}
-	u32 S = 1;
-	while ((u64) S * K3_SUB_TUPLES < n) S <<= 1;
-	for (;;) {
-		if (tid == 0) { s_ncand = 0; s_nct = 0; s_over = 0; s_ndist = 0; }
-		for (u32 s = 0; s < S; s++) {
-			for (u32 i = tid; i < K3_SLOTS; i += K3_THREADS) { s_khi[i] = EMPTY; s_cnt[i] = 0; s_first[i] = NONE32; s_ucnt[i] = 0; s_ufirst[i] = NONE32; }
-			__syncthreads();
-			// sweep 1: gated instances only (include_kmer, A2:240-259) -> count + first (A2:332-347).
-			// K3_UNR tuples per thread are loaded before any is processed: the loop is latency-bound otherwise.
-			// A bucket that fits one chunk (the common case) stays in registers for sweep 2.
-			const bool one_chunk = n <= K3_UNR * K3_THREADS;
-			u32 r_iw[K3_UNR];
-			u64 r_lo[K3_UNR];
-			THI r_hi[K3_UNR];
-			int r_slot[K3_UNR];                    // one-chunk buckets: the slot a gated tuple was inserted at serves sweep 2 as well
-			for (u32 t0 = 0; t0 < n; t0 += K3_UNR * K3_THREADS) {
-#pragma unroll
-				for (int j = 0; j < K3_UNR; j++) {
-					const u32 t = t0 + j * K3_THREADS + tid;
-					const bool v = t < n;
-					r_iw[j] = v ? t_inst[base + t] : 0u;
-					r_lo[j] = v ? t_lo[base + t] : 0ull;
-					r_hi[j] = v ? t_hi[base + t] : (THI) 0;
-					r_slot[j] = -1;
-				}
-#pragma unroll
-				for (int j = 0; j < K3_UNR; j++) {
-					if (!(r_iw[j] >> 31)) continue;
-					const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
-					if ((u32) ((h >> 12) & (S - 1)) != s) continue;
-					int slot = lds_insert<THI>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
-					if (slot < 0) { s_over = 1; continue; }
-					r_slot[j] = slot;
-					atomicAdd(&s_cnt[slot], 1u);
-					atomicMin(&s_first[slot], r_iw[j] & INST_MASK);
-				}
-			}
-			__syncthreads();
-			if (s_over) break;
-			// candidates: count >= max(mf, 2) (a k-mer seen once can never have two distinct reads, A2:349-352,476)
-			for (u32 i = tid; i < K3_SLOTS; i += K3_THREADS) {
-				u32 cid = NONE32;
-				if (s_khi[i] != EMPTY) {
-					atomicAdd(&s_ndist, 1u);
-					if (s_cnt[i] >= cmin) {
-						cid = atomicAdd(&s_ncand, 1u);
-						c_lo[base + cid] = s_klo[i];
-						c_hi[base + cid] = s_khi[i];
-						c_cnt[base + cid] = s_cnt[i];
-						c_first[base + cid] = s_first[i];
-					}
-				}
-				s_cidx[i] = cid;
-			}
-			__syncthreads();
-			// sweep 2: every instance of a candidate k-mer is recounted here (ungated ones need nothing else); the GATED ones are
-			// compacted for the finalize kernel (distinct-read flag, quality sums): a sixth of the instances of a Phred-noisy pool
-			for (u32 t0 = 0; t0 < n; t0 += K3_UNR * K3_THREADS) {
-				bool val[K3_UNR];
-#pragma unroll
-				for (int j = 0; j < K3_UNR; j++) {
-					const u32 t = t0 + j * K3_THREADS + tid;
-					val[j] = t < n;
-					if (!one_chunk) {
-						r_iw[j] = val[j] ? t_inst[base + t] : 0u;
-						r_lo[j] = val[j] ? t_lo[base + t] : 0ull;
-						r_hi[j] = val[j] ? t_hi[base + t] : (THI) 0;
-					}
-				}
-#pragma unroll
-				for (int j = 0; j < K3_UNR; j++) {
-					bool is_c = false, cand = false;
-					u32 cid = NONE32;
-					int slot = -1;
-					if (val[j]) {
-						if (one_chunk && S == 1 && (r_iw[j] >> 31)) slot = r_slot[j];          // gated: inserted in sweep 1
-						else {
-							const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
-							if ((u32) ((h >> 12) & (S - 1)) == s) slot = lds_lookup<THI>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
-						}
-						{
-							if (slot >= 0) {
-								cid = s_cidx[slot];
-								cand = cid != NONE32;
-								is_c = cand && (r_iw[j] >> 31) != 0;
-							}
-						}
-					}
-					vdjx_lds_count_min(s_ucnt, s_ufirst, cand ? (u32) slot : 0u, r_iw[j] & INST_MASK, cand);
-					u32 p = vdjx_wave_inc(&s_nct, is_c);
-					if (is_c) {
-						ct_lcid[base + p] = cid;
-						ct_inst[base + p] = r_iw[j];
-					}
-				}
-			}
-			__syncthreads();
-			for (u32 i = tid; i < K3_SLOTS; i += K3_THREADS) {
-				const u32 cid = s_cidx[i];
-				if (cid != NONE32) { c_ucnt[base + cid] = s_ucnt[i]; c_ufirst[base + cid] = s_ufirst[i]; }
-			}
-			__syncthreads();
-		}
-		if (!s_over) break;
-		S <<= 1;
-		if (S > (1u << 20)) { if (tid == 0) atomicAdd(g_err, 1u); break; }
-		__syncthreads();
-	}
-	if (tid == 0) {
-		bucket_ncand[b] = s_over ? 0 : s_ncand;
-		bucket_nct[b] = s_over ? 0 : s_nct;
-		atomicAdd(&g_distinct[(b & 63u) * 16u], (u64) s_ndist);      // 64 counters on separate cache lines (summed on the host)
-	}
-}
-
-// ----------------------------------------------------------------------------------------------
-// K3b: finalize candidates of a bucket
-// ----------------------------------------------------------------------------------------------
-struct SurvOut {
-	u64* lo; u64* hi; u32* gcnt; u32* gfirst; u32* ucnt; u32* ufirst; u32* n; u32 cap;
-};
-
-template <typename THI>
-__global__ __launch_bounds__(K3B_THREADS) void k_bucket_finalize(const u32* __restrict__ bucket_start, const u32* __restrict__ bucket_ncand,
-                                                                 const u32* __restrict__ bucket_nct, const u64* __restrict__ c_lo,
-                                                                 const THI* __restrict__ c_hi, const u32* __restrict__ c_cnt,
-                                                                 const u32* __restrict__ c_first, const u32* __restrict__ c_ucnt,
-                                                                 const u32* __restrict__ c_ufirst, const u32* __restrict__ ct_lcid,
-                                                                 const u32* __restrict__ ct_inst, const u64* __restrict__ bases,
-                                                                 const u64* __restrict__ nmask,
-                                                                 const uint8_t* __restrict__ quals, int qstride, int k, int P,
-                                                                 u32 mf, u32 mqq, u32 tlow, SurvOut so) {
-	__shared__ u32 l_first[K3B_CH], l_lowid[K3B_CH];      // (counts are read from the candidate arrays where needed: 35 KB of LDS, four workgroups per CU)
-	__shared__ uint8_t l_multi[K3B_CH], l_qok[K3B_CH];
-	__shared__ u32 acc[K3B_A * K3B_KW];
-	__shared__ u32 s_nlow, s_base, s_nq;
-	__shared__ u32 q_lc[K3B_Q], q_inst[K3B_Q];      // gated instances of the low-count candidates of this chunk
-	const u32 b = blockIdx.x;
-	const u32 nc = bucket_ncand[b];
-	if (nc == 0) return;
-	const u32 base = bucket_start[b];
-	const u32 nt = bucket_nct[b];
-	const u32 tid = threadIdx.x;
-	const u32 KW = (u32) (k + 1) / 2;
-	for (u32 c0 = 0; c0 < nc; c0 += K3B_CH) {
-		const u32 m = nc - c0 < K3B_CH ? nc - c0 : K3B_CH;
-		if (tid == 0) { s_nlow = 0; s_nq = 0; }
-		__syncthreads();
-		for (u32 i = tid; i < m; i += K3B_THREADS) {
-			const u32 cnt = c_cnt[base + c0 + i];
-			l_first[i] = c_first[base + c0 + i];
-			l_multi[i] = 0;
-			l_qok[i] = 0;
-			l_lowid[i] = cnt < tlow ? atomicAdd(&s_nlow, 1u) : NONE32;
-		}
-		__syncthreads();
-		// sweep A over the candidates' GATED instances: the distinct-read flag (A2:349-352), and who needs quality sums
-		// (four tuples per thread are in flight before any is used: the sweep is latency-bound otherwise)
-		for (u32 t0 = 0; t0 < nt; t0 += 4 * K3B_THREADS) {
-			u32 r_lc[4], r_iw[4];
-#pragma unroll
-			for (int j = 0; j < 4; j++) {
-				const u32 t = t0 + j * K3B_THREADS + tid;
-				r_lc[j] = t < nt ? ct_lcid[base + t] : NONE32;
-				r_iw[j] = t < nt ? ct_inst[base + t] : 0u;
-			}
-#pragma unroll
-			for (int j = 0; j < 4; j++) {
-				u32 lc = r_lc[j];
-				if (lc < c0 || lc >= c0 + m) continue;         // (NONE32 fails the second test)
-				lc -= c0;
-				const u32 iw = r_iw[j];
-				const u32 inst = iw & INST_MASK;
-				if ((iw >> 31) && l_lowid[lc] != NONE32) {      // its qualities will be needed: remember it (few such instances)
-					const u32 qi = atomicAdd(&s_nq, 1u);
-					if (qi < K3B_Q) { q_lc[qi] = lc; q_inst[qi] = inst; }
-				}
-				if ((iw >> 31) && !*(volatile uint8_t*) &l_multi[lc]) {
-					const u32 rec = inst / (u32) P;
-					const u32 frec = l_first[lc] / (u32) P;
-					if (rec != frec) {
-						const ulonglong2 x = ((const ulonglong2*) bases)[rec];
-						const ulonglong2 y = ((const ulonglong2*) bases)[frec];
-						// compare_read (A2:142-144) on the rl-base sequences; an 'N' is coded 0 in `bases`, so the N masks
-						// take part in the comparison
-						if (x.x != y.x || x.y != y.y || nmask[rec] != nmask[frec]) l_multi[lc] = 1;
-					}
-				}
-			}
-		}
-		__syncthreads();
-		// quality sums, only for keys whose count cannot pass on its own (see TLOW in vdjx_kmer_build)
-		const u32 nlow = s_nlow;
-		for (u32 l0 = 0; l0 < nlow; l0 += K3B_A) {
-			for (u32 i = tid; i < K3B_A * K3B_KW; i += K3B_THREADS) acc[i] = 0;
-			__syncthreads();
-			const bool listed = s_nq <= K3B_Q;
-			const u32 nscan = listed ? s_nq : nt;
-			for (u32 t = tid; t < nscan; t += K3B_THREADS) {
-				u32 lc, iw;
-				if (listed) { lc = q_lc[t]; iw = q_inst[t] | 0x80000000u; }
-				else {
-					lc = ct_lcid[base + t];
-					if (lc < c0 || lc >= c0 + m) continue;
-					lc -= c0;
-					iw = ct_inst[base + t];
-					if (!(iw >> 31)) continue;
-				}
-				const u32 lid = l_lowid[lc];
-				if (lid == NONE32 || lid < l0 || lid >= l0 + K3B_A) continue;
-				const u32 inst = iw & INST_MASK;
-				const u32 rec = inst / (u32) P;
-				const u32 off = inst - rec * (u32) P;
-				// first instance: the RECORD's first k qualities (A2:337-339); others: the k-mer's own (A2:354-361).
-				// The record's quality row (qstride <= 64 bytes, 16-byte aligned) comes in as four 16-byte loads; the
-				// fully unrolled walk over its positions keeps the register indexing static.
-				const u32 qoff = inst == l_first[lc] ? 0u : off;
-				const uint4* qv = (const uint4*) (quals + (size_t) rec * (size_t) qstride);
-				u32 w[16];
-#pragma unroll
-				for (int v4 = 0; v4 < 4; v4++) {
-					uint4 x = make_uint4(0x21212121u, 0x21212121u, 0x21212121u, 0x21212121u);
-					if (v4 * 16 < qstride) x = qv[v4];
-					w[v4 * 4 + 0] = x.x; w[v4 * 4 + 1] = x.y; w[v4 * 4 + 2] = x.z; w[v4 * 4 + 3] = x.w;
-				}
-				u32* row = acc + (lid - l0) * K3B_KW;
-#pragma unroll
-				for (int pq = 0; pq < 64; pq++) {
-					const int j = pq - (int) qoff;
-					if (j >= 0 && j < k) {
-						const u32 v = (uint8_t) (((w[pq >> 2] >> (8 * (pq & 3))) & 0xFFu) - 33u);
-						atomicAdd(&row[j >> 1], v << (16 * (j & 1)));
-					}
-				}
-			}
-			__syncthreads();
-			for (u32 i = tid; i < m; i += K3B_THREADS) {
-				const u32 lid = l_lowid[i];
-				if (lid < l0 || lid >= l0 + K3B_A) continue;
-				const u32* row = acc + (lid - l0) * K3B_KW;
-				uint8_t ok = 1;
-				for (u32 w = 0; w < KW; w++) {
-					const u32 v = row[w];
-					if ((v & 0xFFFFu) < mqq) ok = 0;
-					if (2 * w + 1 < (u32) k && (v >> 16) < mqq) ok = 0;
-				}
-				l_qok[i] = ok;
-			}
-			__syncthreads();
-		}
-		// prune_pre_graph (A2:467-484).  The global survivor counter is bumped once per workgroup and chunk: one address shared
-		// by every workgroup serialises in L2 (~3.5 ns per bump: 131 k survivors cost 0.45 ms when bumped one by one)
-		if (tid == 0) s_nlow = 0;
-		__syncthreads();
-		for (u32 i = tid; i < m; i += K3B_THREADS) {
-			const u32 craw = c_cnt[base + c0 + i];
-			const u32 cnt = craw > 32765u ? 32765u : craw;                     // A2:345-347
-			const bool keep = cnt >= mf && l_multi[i] && (craw >= tlow || l_qok[i]);
-			l_lowid[i] = keep ? atomicAdd(&s_nlow, 1u) : NONE32;               // (reused: position among this chunk's survivors)
-		}
-		__syncthreads();
-		if (tid == 0) s_base = s_nlow ? atomicAdd(so.n, s_nlow) : 0;
-		__syncthreads();
-		for (u32 i = tid; i < m; i += K3B_THREADS) {
-			if (l_lowid[i] == NONE32) continue;
-			const u32 pos = s_base + l_lowid[i];
-			if (pos < so.cap) {
-				so.lo[pos] = c_lo[base + c0 + i];
-				so.hi[pos] = (u64) c_hi[base + c0 + i];
-				const u32 craw = c_cnt[base + c0 + i], uraw = c_ucnt[base + c0 + i];   // (recounted by k_bucket_aggregate: every instance, gated or not)
-				so.gcnt[pos] = craw > 32765u ? 32765u : craw;
-				so.gfirst[pos] = l_first[i];
-				so.ucnt[pos] = uraw > 32765u ? 32765u : uraw;           // A2:261-265
-				so.ufirst[pos] = c_ufirst[base + c0 + i];
-			}
-		}
-		__syncthreads();
-	}
 }
 
 // ==============================================================================================
@@ -1109,115 +621,94 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 //   each rank keeps {count, first} over all its instances per k-mer and looks the survivors up once they are known;
 //   the caller reduces those two small arrays over ranks (SUM, MIN) together with the edge arrays.
 // ----------------------------------------------------------------------------------------------
-struct Partial { u64 lo, hi; u32 mg, cg; };              // 24 bytes, what travels: gated count (bit 31 = local distinct-read flag), first gated instance
-struct LocalAll { u64 lo, hi; u32 ca, ma; };             // 24 bytes, stays on its rank: count and first over ALL instances (add_to_graph's recount)
+struct Partial { u64 lo, hi; u32 cg, pad; u64 fg; };     // 32 bytes, what travels: gated count (bit 31 = local distinct-read flag), first gated instance
 #define PART_FLAG 0x80000000u
 #define CNT_CAP 32765u
 #define NEED_SEQ 1u
 #define NEED_Q 2u
 #define PID_MASK 0x3FFFFFFFu
 #define REPLY_KQ 52                 // quality bytes per row (k <= 50)
-#define REPLY_BYTES 192             // pid, first instance, 16-B bases, 8-B N mask, 3 quality rows
+#define REPLY_BYTES 200             // pid | need, first instance (u64), 16-B bases, 8-B N mask, 3 quality rows
 
-template <typename THI>
-__global__ __launch_bounds__(K3_THREADS) void k_bucket_local(const u64* __restrict__ t_lo, const THI* __restrict__ t_hi,
-                                                             const u32* __restrict__ t_inst, const u32* __restrict__ bucket_start,
-                                                             const u64* __restrict__ bases, const u64* __restrict__ nmask, u32 rec_base,
-                                                             int P, u32 tlow, Partial* __restrict__ sparse_g, u32* __restrict__ sparse_ref,
-                                                             u32* __restrict__ nd_g, LocalAll* __restrict__ sparse_a, u32* __restrict__ nd_a,
-                                                             u32* __restrict__ low_inst, u32* __restrict__ g_err) {
-	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	u64* s_klo = (u64*) smem;
-	THI* s_khi = (THI*) (s_klo + LOCAL_SLOTS);
-	u32* s_cg = (u32*) (s_khi + LOCAL_SLOTS);
-	u32* s_mg = s_cg + LOCAL_SLOTS;
-	u32* s_ca = s_mg + LOCAL_SLOTS;
-	u32* s_ma = s_ca + LOCAL_SLOTS;
-	u32* s_loff = s_ma + LOCAL_SLOTS;          // low-count keys: where their gated instances are listed (relative to the bucket)
-	u32* s_lfill = s_loff + LOCAL_SLOTS;
-	uint8_t* s_fl = (uint8_t*) (s_lfill + LOCAL_SLOTS);
-	__shared__ u32 s_n, s_ng, s_nlow, s_over;
+// this rank's partial aggregates of one bucket of its gated tuples (see k_gated_reduce for the table): count, first instance,
+// "saw two different reads" against its own first record; k-mers whose count is below TLOW also list their instances
+template <typename TUP>
+__global__ __launch_bounds__(K3_THREADS) void k_gated_local(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
+                                                            const u64* __restrict__ bases, const u64* __restrict__ nmask, u64 rec_base,
+                                                            u32 tlow, Partial* __restrict__ sparse_g, u32* __restrict__ sparse_ref,
+                                                            u32* __restrict__ nd_g, u64* __restrict__ low_inst, u32* __restrict__ g_err) {
+	typedef typename TUP::hi_t THI;
+	__shared__ u64 s_klo[LOCAL_SLOTS];
+	__shared__ THI s_khi[LOCAL_SLOTS];
+	__shared__ u64 s_mg[LOCAL_SLOTS];
+	__shared__ u32 s_cg[LOCAL_SLOTS], s_loff[LOCAL_SLOTS], s_lfill[LOCAL_SLOTS], s_fl[LOCAL_SLOTS];
+	__shared__ u32 s_ng, s_nlow, s_over;
 	const THI EMPTY = (THI) ~(THI) 0;
 	const u32 b = blockIdx.x;
 	const u32 base = bucket_start[b];
 	const u32 n = bucket_start[b + 1] - base;
 	const u32 tid = threadIdx.x;
-	if (n == 0) {
-		if (tid == 0) { nd_g[b] = 0; nd_a[b] = 0; }
-		return;
-	}
+	if (n == 0) { if (tid == 0) nd_g[b] = 0; return; }
+	const TUP* T = tup + base;
 	u32 S = 1;
 	while ((u64) S * K3_SUB_TUPLES < n) S <<= 1;
 	for (;;) {
-		if (tid == 0) { s_n = 0; s_ng = 0; s_nlow = 0; s_over = 0; }
+		if (tid == 0) { s_ng = 0; s_nlow = 0; s_over = 0; }
 		for (u32 s = 0; s < S; s++) {
-			for (u32 i = tid; i < LOCAL_SLOTS; i += K3_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE32; s_ca[i] = 0; s_ma[i] = NONE32; s_lfill[i] = 0; s_fl[i] = 0; }
+			for (u32 i = tid; i < LOCAL_SLOTS; i += K3_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE64; s_lfill[i] = 0; s_fl[i] = 0; }
 			__syncthreads();
 			const bool one_chunk = n <= K3_UNR * K3_THREADS;
-			u32 r_iw[K3_UNR];
-			u64 r_lo[K3_UNR];
-			THI r_hi[K3_UNR];
+			TUP r_t[K3_UNR];
 			int r_slot[K3_UNR];
-			// sweep 1: every N-free instance: counts and firsts, gated (A2:332-347) and ungated (A2:280-309)
 			for (u32 t0 = 0; t0 < n; t0 += K3_UNR * K3_THREADS) {
 #pragma unroll
 				for (int j = 0; j < K3_UNR; j++) {
 					const u32 t = t0 + j * K3_THREADS + tid;
-					const bool v = t < n;
-					r_iw[j] = v ? t_inst[base + t] : 0u;
-					r_lo[j] = v ? t_lo[base + t] : 0ull;
-					r_hi[j] = v ? t_hi[base + t] : (THI) 0;
-					r_slot[j] = v ? -1 : -2;
+					r_slot[j] = -2;
+					if (t < n) { r_t[j] = TUP::load(&T[t]); r_slot[j] = -1; }
 				}
 #pragma unroll
 				for (int j = 0; j < K3_UNR; j++) {
-					int slot = -1;
-					if (r_slot[j] != -2) {
-						const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
-						if ((u32) ((h >> 12) & (S - 1)) == s) {
-							slot = lds_insert<THI, LOCAL_SLOTS>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h);
-							if (slot < 0) s_over = 1; else r_slot[j] = slot;
-						}
-					}
-					const u32 inst = r_iw[j] & INST_MASK;
-					vdjx_lds_count_min(s_ca, s_ma, slot >= 0 ? (u32) slot : 0u, inst, slot >= 0);
-					vdjx_lds_count_min(s_cg, s_mg, slot >= 0 ? (u32) slot : 0u, inst, slot >= 0 && (r_iw[j] >> 31));
+					if (r_slot[j] == -2) continue;
+					const u64 h = vdjx_mix(r_t[j].lo, r_t[j].hi());
+					if (S > 1 && (u32) ((h >> 12) & (S - 1)) != s) continue;
+					const int slot = lds_insert<THI, LOCAL_SLOTS>(s_klo, s_khi, r_t[j].lo, (THI) r_t[j].hi(), (u32) h);
+					if (slot < 0) { s_over = 1; continue; }
+					r_slot[j] = slot;
+					atomicAdd(&s_cg[slot], 1u);
+					atomicMin((unsigned long long*) &s_mg[slot], (unsigned long long) r_t[j].inst());
 				}
 			}
 			__syncthreads();
 			if (s_over) break;
-			// keys whose count alone cannot pass the quality test (count < TLOW) list their gated instances: the owner may ask
+			// keys whose count alone cannot pass the quality test (count < TLOW) list their instances: the owner may ask
 			for (u32 i = tid; i < LOCAL_SLOTS; i += K3_THREADS) {
 				const u32 cg = s_cg[i];
 				s_loff[i] = (cg && cg < tlow) ? atomicAdd(&s_nlow, cg) : NONE32;
 			}
 			__syncthreads();
-			// sweep 2: the lists, and the distinct-read flag against this rank's first gated record (compare_read, A2:142-144,349-352)
+			// sweep 2: the lists, and the distinct-read flag against this rank's first record (compare_read, A2:142-144, 349-352)
 			for (u32 t0 = 0; t0 < n; t0 += K3_UNR * K3_THREADS) {
 #pragma unroll
 				for (int j = 0; j < K3_UNR; j++) {
 					if (!one_chunk) {
 						const u32 t = t0 + j * K3_THREADS + tid;
-						const bool v = t < n;
-						r_iw[j] = v ? t_inst[base + t] : 0u;
-						r_lo[j] = v ? t_lo[base + t] : 0ull;
-						r_hi[j] = v ? t_hi[base + t] : (THI) 0;
 						r_slot[j] = -2;
-						if (v && (r_iw[j] >> 31)) {
-							const u64 h = vdjx_mix(r_lo[j], (u64) r_hi[j]);
-							r_slot[j] = (u32) ((h >> 12) & (S - 1)) == s ? lds_lookup<THI, LOCAL_SLOTS>(s_klo, s_khi, r_lo[j], r_hi[j], (u32) h) : -1;
+						if (t < n) {
+							r_t[j] = TUP::load(&T[t]);
+							const u64 h = vdjx_mix(r_t[j].lo, r_t[j].hi());
+							r_slot[j] = (S > 1 && (u32) ((h >> 12) & (S - 1)) != s) ? -1 : lds_lookup<THI, LOCAL_SLOTS>(s_klo, s_khi, r_t[j].lo, (THI) r_t[j].hi(), (u32) h);
 						}
 					}
 				}
 #pragma unroll
 				for (int j = 0; j < K3_UNR; j++) {
 					const int slot = r_slot[j];
-					if (slot < 0 || !(r_iw[j] >> 31)) continue;
-					const u32 inst = r_iw[j] & INST_MASK;
+					if (slot < 0) continue;
+					const u64 inst = r_t[j].inst();
 					if (s_loff[slot] != NONE32) low_inst[base + s_loff[slot] + atomicAdd(&s_lfill[slot], 1u)] = inst;
-					if (s_cg[slot] < 2 || *(volatile uint8_t*) &s_fl[slot]) continue;
-					const u32 rec = inst / (u32) P - rec_base;
-					const u32 frec = s_mg[slot] / (u32) P - rec_base;
+					if (s_cg[slot] < 2 || *(volatile u32*) &s_fl[slot]) continue;
+					const u64 rec = (inst >> 6) - rec_base, frec = (s_mg[slot] >> 6) - rec_base;
 					if (rec != frec) {
 						const ulonglong2 x = ((const ulonglong2*) bases)[rec];
 						const ulonglong2 y = ((const ulonglong2*) bases)[frec];
@@ -1228,30 +719,24 @@ __global__ __launch_bounds__(K3_THREADS) void k_bucket_local(const u64* __restri
 			__syncthreads();
 			for (u32 i = tid; i < LOCAL_SLOTS; i += K3_THREADS) {
 				if (s_khi[i] == EMPTY) continue;
-				const u32 idx = atomicAdd(&s_n, 1u);
-				LocalAll a;
-				a.lo = s_klo[i]; a.hi = (u64) s_khi[i];
-				a.ca = s_ca[i] > CNT_CAP ? CNT_CAP : s_ca[i];
-				a.ma = s_ma[i];
-				sparse_a[base + idx] = a;
-				if (s_cg[i]) {
-					Partial p;
-					p.lo = a.lo; p.hi = a.hi;
-					p.mg = s_mg[i];
-					p.cg = (s_cg[i] > CNT_CAP ? CNT_CAP : s_cg[i]) | (s_fl[i] ? PART_FLAG : 0u);
-					const u32 gi = atomicAdd(&s_ng, 1u);
-					sparse_g[base + gi] = p;
-					sparse_ref[base + gi] = s_loff[i] != NONE32 ? base + s_loff[i] : NONE32;
-				}
+				Partial p;
+				p.lo = s_klo[i]; p.hi = (u64) s_khi[i];
+				p.fg = s_mg[i];
+				p.cg = (s_cg[i] > CNT_CAP ? CNT_CAP : s_cg[i]) | (s_fl[i] ? PART_FLAG : 0u);
+				p.pad = 0;
+				const u32 gi = atomicAdd(&s_ng, 1u);
+				sparse_g[base + gi] = p;
+				sparse_ref[base + gi] = s_loff[i] != NONE32 ? base + s_loff[i] : NONE32;
 			}
 			__syncthreads();
 		}
 		if (!s_over) break;
+		// (nothing leaves the bucket before all its sub-passes are done: the counters restart with the finer split)
 		S <<= 1;
 		if (S > (1u << 20)) { if (tid == 0) atomicAdd(g_err, 1u); break; }
 		__syncthreads();
 	}
-	if (tid == 0) { nd_g[b] = s_over ? 0 : s_ng; nd_a[b] = s_over ? 0 : s_n; }
+	if (tid == 0) nd_g[b] = s_over ? 0 : s_ng;
 }
 
 __global__ __launch_bounds__(256) void k_compact_partials(const Partial* __restrict__ sparse, const u32* __restrict__ sparse_ref,
@@ -1261,7 +746,7 @@ __global__ __launch_bounds__(256) void k_compact_partials(const Partial* __restr
 	const u64* src = (const u64*) (sparse + bucket_start[b]);
 	u64* dst = (u64*) (dense + dstart[b]);
 	const u32 m = nd[b];
-	for (u32 i = threadIdx.x; i < m * 3; i += 256) dst[i] = src[i];
+	for (u32 i = threadIdx.x; i < m * 4; i += 256) dst[i] = src[i];
 	for (u32 i = threadIdx.x; i < m; i += 256) dense_ref[dstart[b] + i] = sparse_ref[bucket_start[b] + i];
 }
 
@@ -1291,25 +776,21 @@ __global__ __launch_bounds__(1024) void k_seg_offsets(const u32* __restrict__ se
 	if (threadIdx.x == 1023) off[NBo] = src_base[s] + part[1023];
 }
 
-struct PendOut { u64* lo; u64* hi; u32* cg; u32* mg; u32* need; u32* n; u32 cap; };
+struct PendOut { u64* lo; u64* hi; u32* cg; u64* mg; u32* need; u32* n; u32 cap; };
 
 #define MERGE_THREADS 256
-#define MERGE_SLOTS 1024u             // a bucket holds ~100 distinct gated k-mers per rank
+#define MERGE_SLOTS 1024u             // a bucket holds a few hundred distinct gated k-mers per rank
 template <typename THI>
 __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* __restrict__ recv, const u32* __restrict__ seg_off,
                                                                 u32 MG, u32 G, u32 NBo,
                                                                 const u32* __restrict__ src_base, u32 s_mult, u32 cmin, u32 tlow,
-                                                                SurvOut so, PendOut po,
+                                                                SurvOutG so, PendOut po,
                                                                 uint2* __restrict__ queries, u32* __restrict__ g_nq,
                                                                 u64* __restrict__ g_distinct, u32* __restrict__ g_err) {
-	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	u64* s_klo = (u64*) smem;
-	THI* s_khi = (THI*) (s_klo + MERGE_SLOTS);
-	u32* s_cg = (u32*) (s_khi + MERGE_SLOTS);
-	u32* s_mg = s_cg + MERGE_SLOTS;
-	u32* s_pid = s_mg + MERGE_SLOTS;
-	u32* s_nsg = s_pid + MERGE_SLOTS;            // ranks that hold gated instances
-	uint8_t* s_fl = (uint8_t*) (s_nsg + MERGE_SLOTS);
+	__shared__ u64 s_klo[MERGE_SLOTS];
+	__shared__ THI s_khi[MERGE_SLOTS];
+	__shared__ u64 s_mg[MERGE_SLOTS];
+	__shared__ u32 s_cg[MERGE_SLOTS], s_pid[MERGE_SLOTS], s_nsg[MERGE_SLOTS], s_fl[MERGE_SLOTS];
 	__shared__ u32 s_over, s_ndist, s_total, s_ns, s_np, s_sbase, s_pbase;
 	const THI EMPTY = (THI) ~(THI) 0;
 	const u32 b = blockIdx.x;
@@ -1329,7 +810,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 	{
 		if (tid == 0) { s_over = 0; s_ndist = 0; }
 		for (u32 sp = 0; sp < S; sp++) {
-			for (u32 i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE32; s_fl[i] = 0; s_nsg[i] = 0; s_pid[i] = NONE32; }
+			for (u32 i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE64; s_fl[i] = 0; s_nsg[i] = 0; s_pid[i] = NONE32; }
 			__syncthreads();
 			for (u32 s = 0; s < G; s++) {
 				const u32 off = seg_off[(size_t) s * (NBo + 1) + b * MG], cnt = seg_off[(size_t) s * (NBo + 1) + (b + 1) * MG] - off;
@@ -1340,7 +821,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 					const int slot = lds_insert<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, (u32) h);
 					if (slot < 0) { s_over = 1; continue; }
 					atomicAdd(&s_cg[slot], p.cg & ~PART_FLAG);
-					atomicMin(&s_mg[slot], p.mg);
+					atomicMin((unsigned long long*) &s_mg[slot], (unsigned long long) p.fg);
 					atomicAdd(&s_nsg[slot], 1u);
 					if (p.cg & PART_FLAG) s_fl[slot] = 1;
 				}
@@ -1365,7 +846,6 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 					else need |= NEED_SEQ;
 				}
 				if (live && cg < tlow) need |= NEED_Q;
-				// s_pid: local index | need<<30 for open k-mers, local index | 3<<30... survivors use s_nsg as scratch
 				if (live && !need) s_nsg[i] = 0x80000000u | atomicAdd(&s_ns, 1u);
 				else s_nsg[i] = 0;
 				if (live && need) s_pid[i] = atomicAdd(&s_np, 1u) | (need << 30);
@@ -1384,7 +864,6 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 						const u32 cg = s_cg[i];
 						so.lo[pos] = s_klo[i]; so.hi[pos] = (u64) s_khi[i];
 						so.gcnt[pos] = cg > CNT_CAP ? CNT_CAP : cg; so.gfirst[pos] = s_mg[i];
-						so.ucnt[pos] = 0; so.ufirst[pos] = NONE32;         // the recount comes later (k_surv_counts + reduce)
 					}
 				} else if (s_pid[i] != NONE32) {
 					const u32 need = s_pid[i] >> 30;
@@ -1431,14 +910,15 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 }
 
 // answers of the rank that holds the instances: one wave per question
-//   [0,4) pid | need<<30   [4,8) this rank's first gated instance   [8,24) its record's bases   [24,32) its N mask
-//   [32,84) QS: sum of the own qualities of this rank's OTHER gated instances (saturating at 255: >= 214 reads as 255 anyway)
-//   [84,136) the first instance's own qualities   [136,188) its RECORD's first k qualities (A2:337-339)
+//   [0,4) pid | need<<30   [8,16) this rank's first gated instance   [16,32) its record's bases   [32,40) its N mask
+//   [40,92) QS: sum of the own qualities of this rank's OTHER gated instances (saturating at 255: >= 214 reads as 255 anyway)
+//   [92,144) the first instance's own qualities   [144,196) its RECORD's first k qualities (A2:337-339)
+#define REPLY_Q0 40
 __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ queries, u32 nq, const u32* __restrict__ owner_off, u32 G,
                                                     const Partial* __restrict__ dense, const u32* __restrict__ dense_ref,
-                                                    const u32* __restrict__ dstart, u32 NBo, const u32* __restrict__ low_inst,
+                                                    const u32* __restrict__ dstart, u32 NBo, const u64* __restrict__ low_inst,
                                                     const u64* __restrict__ bases, const u64* __restrict__ nmask,
-                                                    const uint8_t* __restrict__ quals, int qstride, u32 rec_base, int P, int k,
+                                                    const uint8_t* __restrict__ quals, int qstride, u64 rec_base, int k,
                                                     uint8_t* __restrict__ replies) {
 	const u32 qi = blockIdx.x;
 	if (qi >= nq) return;
@@ -1449,17 +929,18 @@ __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ qu
 	const u32 di = dstart[(size_t) o * NBo] + q.x;
 	const Partial p = dense[di];
 	const u32 need = q.y >> 30;
-	const u32 finst = p.mg;
-	const u32 frec = finst / (u32) P - rec_base;
-	const u32 foff = finst % (u32) P;
+	const u64 finst = p.fg;
+	const u64 frec = (finst >> 6) - rec_base;
+	const u32 foff = (u32) (finst & 63u);
 	uint8_t* out = replies + (size_t) qi * REPLY_BYTES;
 	if (lane == 0) {
 		((u32*) out)[0] = q.y;
-		((u32*) out)[1] = finst;
-		const ulonglong2 b = ((const ulonglong2*) bases)[frec];
-		((u64*) out)[1] = b.x;
-		((u64*) out)[2] = b.y;
-		((u64*) out)[3] = nmask[frec];
+		((u32*) out)[1] = 0;
+		((u64*) out)[1] = finst;
+		const ulonglong2 bb = ((const ulonglong2*) bases)[frec];
+		((u64*) out)[2] = bb.x;
+		((u64*) out)[3] = bb.y;
+		((u64*) out)[4] = nmask[frec];
 	}
 	if ((int) lane >= k) return;
 	u32 acc = 0;
@@ -1467,25 +948,26 @@ __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ qu
 	if ((need & NEED_Q) && ref != NONE32) {          // a question about the sums only comes for a count below TLOW: the list exists
 		const u32 cg = p.cg & ~PART_FLAG;
 		for (u32 i = 0; i < cg; i++) {
-			const u32 inst = low_inst[ref + i];
+			const u64 inst = low_inst[ref + i];
 			if (inst == finst) continue;
-			const u32 rec = inst / (u32) P - rec_base, off = inst % (u32) P;
+			const u64 rec = (inst >> 6) - rec_base;
+			const u32 off = (u32) (inst & 63u);
 			acc += (u32) (uint8_t) (quals[(size_t) rec * (size_t) qstride + off + lane] - 33);
 		}
 	}
 	const uint8_t* fr = quals + (size_t) frec * (size_t) qstride;
-	out[32 + lane] = (uint8_t) (acc > 255u ? 255u : acc);
-	out[32 + REPLY_KQ + lane] = (uint8_t) (fr[foff + lane] - 33);
-	out[32 + 2 * REPLY_KQ + lane] = (uint8_t) (fr[lane] - 33);
+	out[REPLY_Q0 + lane] = (uint8_t) (acc > 255u ? 255u : acc);
+	out[REPLY_Q0 + REPLY_KQ + lane] = (uint8_t) (fr[foff + lane] - 33);
+	out[REPLY_Q0 + 2 * REPLY_KQ + lane] = (uint8_t) (fr[lane] - 33);
 }
 
 // owner: which answer comes from the rank of the global first instance
-__global__ void k_resolve_first(const uint8_t* __restrict__ replies, u32 nr, const u32* __restrict__ p_mg, u32* __restrict__ p_r0) {
+__global__ void k_resolve_first(const uint8_t* __restrict__ replies, u32 nr, const u64* __restrict__ p_mg, u32* __restrict__ p_r0) {
 	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= nr) return;
-	const u32* w = (const u32*) (replies + (size_t) r * REPLY_BYTES);
-	const u32 pid = w[0] & PID_MASK;
-	if (w[1] == p_mg[pid]) p_r0[pid] = r;
+	const uint8_t* me = replies + (size_t) r * REPLY_BYTES;
+	const u32 pid = ((const u32*) me)[0] & PID_MASK;
+	if (((const u64*) me)[1] == p_mg[pid]) p_r0[pid] = r;
 }
 
 __global__ void k_resolve_add(const uint8_t* __restrict__ replies, u32 nr, const u32* __restrict__ p_r0, int k, u32* __restrict__ p_fl,
@@ -1500,16 +982,16 @@ __global__ void k_resolve_add(const uint8_t* __restrict__ replies, u32 nr, const
 	if ((need & NEED_SEQ) && r != r0) {
 		const u64* a = (const u64*) me;
 		const u64* b = (const u64*) (replies + (size_t) r0 * REPLY_BYTES);
-		if (a[1] != b[1] || a[2] != b[2] || a[3] != b[3]) p_fl[pid] = 1;
+		if (a[2] != b[2] || a[3] != b[3] || a[4] != b[4]) p_fl[pid] = 1;
 	}
 	if (need & NEED_Q) {
-		const uint8_t* first = me + 32 + (r == r0 ? 2 * REPLY_KQ : REPLY_KQ);
-		for (int j = 0; j < k; j++) atomicAdd(&p_S[(size_t) pid * 64 + j], (u32) me[32 + j] + (u32) first[j]);
+		const uint8_t* first = me + REPLY_Q0 + (r == r0 ? 2 * REPLY_KQ : REPLY_KQ);
+		for (int j = 0; j < k; j++) atomicAdd(&p_S[(size_t) pid * 64 + j], (u32) me[REPLY_Q0 + j] + (u32) first[j]);
 	}
 }
 
 __global__ void k_resolve_keep(PendOut po, u32 np, const u32* __restrict__ p_fl, const u32* __restrict__ p_S, int k, u32 mf, u32 mqq, u32 tlow,
-                               SurvOut so) {
+                               SurvOutG so) {
 	const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
 	if (p >= np) return;
 	const u32 need = po.need[p];
@@ -1524,116 +1006,12 @@ __global__ void k_resolve_keep(PendOut po, u32 np, const u32* __restrict__ p_fl,
 	if (keep && pos < so.cap) {
 		so.lo[pos] = po.lo[p]; so.hi[pos] = po.hi[p];
 		so.gcnt[pos] = cgc; so.gfirst[pos] = po.mg[p];
-		so.ucnt[pos] = 0; so.ufirst[pos] = NONE32;
 	}
 }
 
 // ----------------------------------------------------------------------------------------------
-// K5: survivor lookup table, edges, V/J flags
+// V/J flags of the nodes
 // ----------------------------------------------------------------------------------------------
-// table entry = 8-bit fingerprint of the key's hash | (survivor index + 1): a foreign key in the probed slot is almost
-// always rejected without touching the key array, and a match costs ONE 16-byte load of the interleaved key
-__global__ void k_surv_table(const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, u32 n, u32* __restrict__ table, u32 mask,
-                             ulonglong2* __restrict__ skey) {
-	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const u64 lo = s_lo[i], hi = s_hi[i];
-	skey[i] = make_ulonglong2(lo, hi);
-	const u64 h = vdjx_mix(lo, hi);
-	u32 slot = (u32) (h >> 20) & mask;
-	const u32 entry = ((u32) (h >> 12) << 24) | (i + 1);
-	while (atomicCAS(&table[slot], 0u, entry) != 0u) slot = (slot + 1) & mask;
-}
-
-__device__ inline int surv_lookup(const u32* __restrict__ table, u32 mask, const ulonglong2* __restrict__ skey, u64 lo, u64 hi) {
-	const u64 h = vdjx_mix(lo, hi);
-	u32 slot = (u32) (h >> 20) & mask;
-	const u32 fp = (u32) (h >> 12) & 0xFFu;
-	for (;;) {
-		const u32 v = table[slot];
-		if (!v) return -1;
-		if ((v >> 24) == fp) {
-			const ulonglong2 kk = skey[(v & 0xFFFFFFu) - 1];
-			if (kk.x == lo && kk.y == hi) return (int) ((v & 0xFFFFFFu) - 1);
-		}
-		slot = (slot + 1) & mask;
-	}
-}
-
-// the recount of add_to_graph for the survivors (sharded build): every k-mer this rank holds looks itself up in the
-// survivor table; a key appears once per rank, so plain stores do
-__global__ __launch_bounds__(256) void k_surv_counts(const LocalAll* __restrict__ sparse_a, const u32* __restrict__ bucket_start,
-                                                     const u32* __restrict__ nd_a, const u32* __restrict__ table, u32 mask,
-                                                     const ulonglong2* __restrict__ skey, u32* __restrict__ ucnt, u32* __restrict__ ufirst) {
-	const u32 b = blockIdx.x;
-	const LocalAll* a = sparse_a + bucket_start[b];
-	const u32 n = nd_a[b];
-	for (u32 i = threadIdx.x; i < n; i += 256) {
-		const LocalAll e = a[i];
-		const int s = surv_lookup(table, mask, skey, e.lo, e.hi);
-		if (s >= 0) { ucnt[s] = e.ca; ufirst[s] = e.ma; }
-	}
-}
-
-// successor links of the survivor graph: link[u*4+b] = {survivor index of (key_u << 2 | b) mod 4^k or NONE, first sight}.
-// 4 hash probes per SURVIVOR, instead of one per instance: along a record, once a k-mer is a survivor the status of the
-// next offset is one 8-byte load of its link.
-__global__ void k_succ_links(const ulonglong2* __restrict__ skey, u32 n, int k, const u32* __restrict__ table, u32 mask,
-                             uint2* __restrict__ link) {
-	u32 e = blockIdx.x * blockDim.x + threadIdx.x;
-	if (e >= n * 4u) return;
-	const ulonglong2 kk = skey[e >> 2];
-	u128 key = (((u128) kk.y << 64) | kk.x);
-	key = (key << 2) | (u128) (e & 3u);
-	if (k < 64) key &= (((u128) 1) << (2 * k)) - 1;
-	const int s = surv_lookup(table, mask, skey, (u64) key, (u64) (key >> 64));
-	link[e] = make_uint2(s >= 0 ? (u32) s : NONE32, NONE32);
-}
-
-// add_to_graph's edge bookkeeping (A2:311-318, link_nodes A2:223-237): an edge prev->curr exists when two
-// adjacent offsets of one record both survive; list order is by first sight, so keep the minimum instance.
-__global__ void k_graph_edges(const u64* __restrict__ bases, const u64* __restrict__ nmask, size_t R, u32 rec_base, int rl, int k,
-                              const u32* __restrict__ table, u32 mask, const ulonglong2* __restrict__ skey,
-                              uint2* __restrict__ link) {
-	size_t r = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= R) return;
-	const int P = rl - k + 1;
-	const u64 km = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
-	RecView v = load_rec(bases, nmask, nullptr, r);
-	int prev = -1;
-	for (int o = 0; o < P; o++) {
-		if ((v.nm >> o) & km) { prev = -1; continue; }
-		int s;
-		if (prev >= 0) {
-			// the k-mer at o is the successor of the (surviving) k-mer at o-1 by its last base
-			const int bsh = 2 * (rl - k - o);                 // last base of the k-mer at o (may sit in the high word)
-			const u32 b = (u32) (bsh < 64 ? v.blo >> bsh : v.bhi >> (bsh - 64)) & 3u;
-			const u32 e = (u32) prev * 4u + b;
-			const uint2 lk = link[e];
-			s = lk.x == NONE32 ? -1 : (int) lk.x;
-			if (s >= 0) {
-				const u32 inst = (u32) ((rec_base + r) * (size_t) P + (size_t) o);
-				// first sights only ever decrease: a (possibly stale) plain read that is already smaller needs no atomic
-				if (lk.y > inst) atomicMin(&link[e].y, inst);
-			}
-		} else {
-			u64 khi, klo;
-			vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
-			s = surv_lookup(table, mask, skey, klo, khi);
-		}
-		prev = s;
-	}
-}
-
-// links -> the two arrays the rest of the build (and the multi-GPU reduction) works on
-__global__ void k_links_split(const uint2* __restrict__ link, u32 n4, u32* __restrict__ edge_first, u32* __restrict__ edge_to) {
-	u32 e = blockIdx.x * blockDim.x + threadIdx.x;
-	if (e >= n4) return;
-	const uint2 lk = link[e];
-	edge_first[e] = lk.y;
-	edge_to[e] = lk.y == NONE32 ? NONE32 : lk.x;
-}
-
 // A2:288-303: has_vmer/has_jmer from the code of the node's first 16 bases
 __global__ void k_node_flags(const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, u32 n, int k,
                              const u32* __restrict__ vbits, const u32* __restrict__ jbits,
@@ -2000,23 +1378,22 @@ __global__ void k_edges_from_in(SurvTable t, u32 n, int k, const u64* __restrict
 // ----------------------------------------------------------------------------------------------
 // multi-GPU: survivor records as exchanged between owners
 // ----------------------------------------------------------------------------------------------
-struct SurvRec { u64 lo, hi; u32 gcnt, gfirst, ucnt, ufirst; };   // 32 bytes: what owners exchange
+struct SurvRec { u64 lo, hi; u32 gcnt, pad; u64 gfirst; };   // 32 bytes: what owners exchange
 
 __global__ void k_surv_pack(const u64* __restrict__ lo, const u64* __restrict__ hi, const u32* __restrict__ gcnt,
-                            const u32* __restrict__ gfirst, const u32* __restrict__ ucnt, const u32* __restrict__ ufirst, u32 n,
-                            SurvRec* __restrict__ out) {
+                            const u64* __restrict__ gfirst, u32 n, SurvRec* __restrict__ out) {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	SurvRec r{lo[i], hi[i], gcnt[i], gfirst[i], ucnt[i], ufirst[i]};
+	SurvRec r{lo[i], hi[i], gcnt[i], 0u, gfirst[i]};
 	out[i] = r;
 }
 
 __global__ void k_surv_unpack(const SurvRec* __restrict__ in, u32 n, u64* __restrict__ lo, u64* __restrict__ hi, u32* __restrict__ gcnt,
-                              u32* __restrict__ gfirst, u32* __restrict__ ucnt, u32* __restrict__ ufirst) {
+                              u64* __restrict__ gfirst) {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const SurvRec r = in[i];
-	lo[i] = r.lo; hi[i] = r.hi; gcnt[i] = r.gcnt; gfirst[i] = r.gfirst; ucnt[i] = r.ucnt; ufirst[i] = r.ufirst;
+	lo[i] = r.lo; hi[i] = r.hi; gcnt[i] = r.gcnt; gfirst[i] = r.gfirst;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -2026,11 +1403,6 @@ __global__ void k_surv_unpack(const SurvRec* __restrict__ in, u32 n, u64* __rest
 // space and a popcount prefix (no sort).  toNodes/fromNodes are prepend-on-first-sight lists
 // (link_nodes, A2:223-237) of at most 4 entries: a 4-element sort by first sight, newest first.
 // ----------------------------------------------------------------------------------------------
-__global__ void k_mark_first(const u32* __restrict__ ufirst, u32 n, u32* __restrict__ bits) {
-	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) atomicOr(&bits[ufirst[i] >> 5], 1u << (ufirst[i] & 31));
-}
-
 #define POPC_WORDS 4096u
 __global__ __launch_bounds__(256) void k_popc_blocks(const u32* __restrict__ bits, u32 nwords, u32* __restrict__ word_pre,
                                                      u32* __restrict__ block_sum) {
@@ -2107,72 +1479,6 @@ __global__ __launch_bounds__(256) void k_root_list(const uint8_t* __restrict__ f
 	if (r) roots[base + (u32) __popcll(b & ((1ull << lane) - 1))] = i;
 }
 
-__global__ void k_node_rank(const u32* __restrict__ ufirst, u32 n, const u32* __restrict__ bits, const u32* __restrict__ word_pre,
-                            const u32* __restrict__ block_pre, u32* __restrict__ rank) {
-	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const u32 f = ufirst[i], w = f >> 5;
-	rank[i] = block_pre[w / POPC_WORDS] + word_pre[w] + __popc(bits[w] & ((1u << (f & 31)) - 1u));
-}
-
-// in-edges: (u -> v) lands in slot (v, first base of u); a k-mer has at most 4 predecessors
-__global__ void k_in_edges(const u32* __restrict__ edge_first, const u32* __restrict__ edge_to, const u64* __restrict__ s_lo,
-                           const u64* __restrict__ s_hi, u32 n, int k, u32* __restrict__ in_first, u32* __restrict__ in_from) {
-	u32 e = blockIdx.x * blockDim.x + threadIdx.x;
-	if (e >= n * 4u) return;
-	const u32 ef = edge_first[e];
-	if (ef == NONE32) return;
-	const u32 u = e >> 2, v = edge_to[e];
-	const u128 key = ((u128) s_hi[u] << 64) | s_lo[u];
-	const u32 a = (u32) (key >> (2 * (k - 1))) & 3u;
-	in_first[v * 4 + a] = ef;
-	in_from[v * 4 + a] = u;
-}
-
-__device__ inline void sort4_desc(u32 (&f)[4], u32 (&id)[4]) {
-	// entries with f == NONE32 are absent: give them the smallest key
-#define CSWAP(a, b) { const bool sw = key[a] < key[b]; if (sw) { u64 t = key[a]; key[a] = key[b]; key[b] = t; } }
-	u64 key[4];
-	for (int i = 0; i < 4; i++) key[i] = f[i] == NONE32 ? 0ull : (((u64) f[i] + 1) << 32) | id[i];
-	CSWAP(0, 1) CSWAP(2, 3) CSWAP(0, 2) CSWAP(1, 3) CSWAP(1, 2)
-	for (int i = 0; i < 4; i++) { f[i] = key[i] ? (u32) (key[i] >> 32) - 1 : NONE32; id[i] = (u32) key[i]; }
-#undef CSWAP
-}
-
-__global__ void k_node_emit(const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, const u32* __restrict__ s_gcnt,
-                            const u32* __restrict__ s_ucnt, const u32* __restrict__ s_ufirst, const uint8_t* __restrict__ hv,
-                            const uint8_t* __restrict__ hj, const u32* __restrict__ rank, const u32* __restrict__ edge_first,
-                            const u32* __restrict__ edge_to, const u32* __restrict__ in_first, const u32* __restrict__ in_from,
-                            u32 n, int k, int P, NodeOut o) {
-	u32 s = blockIdx.x * blockDim.x + threadIdx.x;
-	if (s >= n) return;
-	const u32 r = rank[s];
-	const u32 inst = s_ufirst[s];
-	o.first_inst[r] = (u64) (inst / (u32) P) * 64 + (inst % (u32) P);
-	o.gcnt[r] = s_gcnt[s];
-	o.freq[r] = s_ucnt[s];
-	o.hv[r] = hv[s];
-	o.hj[r] = hj[s];
-	o.klo[r] = s_lo[s];
-	o.khi[r] = s_hi[s];
-	const u128 key = ((u128) s_hi[s] << 64) | s_lo[s];
-	for (int j = 0; j < k; j++) {
-		const u32 b = (u32) (key >> (2 * (k - 1 - j))) & 3u;
-		o.kmers[(size_t) r * k + j] = b == 0 ? 'A' : (b == 1 ? 'T' : (b == 2 ? 'C' : 'G'));
-	}
-	u32 f[4], id[4];
-	for (int e = 0; e < 4; e++) { f[e] = edge_first[s * 4 + e]; id[e] = f[e] != NONE32 ? rank[edge_to[s * 4 + e]] + 1 : 0; }
-	sort4_desc(f, id);
-	u32 deg = 0;
-	for (int e = 0; e < 4; e++) { o.to_ids[(size_t) r * 4 + e] = f[e] != NONE32 ? id[e] : 0; deg += f[e] != NONE32; }
-	o.to_deg[r] = (uint8_t) deg;
-	for (int e = 0; e < 4; e++) { f[e] = in_first[s * 4 + e]; id[e] = f[e] != NONE32 ? rank[in_from[s * 4 + e]] + 1 : 0; }
-	sort4_desc(f, id);
-	deg = 0;
-	for (int e = 0; e < 4; e++) { o.from_ids[(size_t) r * 4 + e] = f[e] != NONE32 ? id[e] : 0; deg += f[e] != NONE32; }
-	o.from_deg[r] = (uint8_t) deg;
-}
-
 __device__ inline void sort4_desc64(u64 (&f)[4], u32 (&id)[4]) {
 	// newest first sight first (prepend-on-first-sight lists, A2:223-237); absent entries (NONE64) go last
 #define CSW(a, b) { const bool sw = kk[a] < kk[b]; if (sw) { u64 t = kk[a]; kk[a] = kk[b]; kk[b] = t; u32 u = id[a]; id[a] = id[b]; id[b] = u; } }
@@ -2230,342 +1536,11 @@ struct PersistAlloc {
 	}
 };
 
-template <typename THI> struct Tuples {
-	u64* lo = nullptr; THI* hi = nullptr; u32* inst = nullptr;
-	u32* bucket_start = nullptr;      // [NB+1]
-	u32 NB = 0, N = 0;
-};
-
 struct PoolView { const u64* bases; const u64* nmask; const uint8_t* quals; int qstride; };
-
-struct Survivors {
-	u64 *lo = nullptr, *hi = nullptr;
-	u32 *gcnt = nullptr, *gfirst = nullptr, *ucnt = nullptr, *ufirst = nullptr;
-	u32 n = 0;
-	u64 ndist = 0;
-};
-
-struct Edges { u32* first = nullptr; u32* to = nullptr; };
 
 size_t tune(const char* name, size_t dflt) {      // undocumented tuning knobs for experiments (profiles/README.md)
 	const char* v = getenv(name);
 	return v && atol(v) > 0 ? (size_t) atol(v) : dflt;
-}
-
-u32 choose_nb_bits(size_t NI, size_t per_bucket = 0) {
-	// ~4096 instances per bucket (one register-resident chunk of the reduce kernels: 512 threads x K3_UNR; fewer, larger buckets
-	// halve the per-workgroup overheads of the reduce kernels: finalize 0.41 -> 0.24 ms at 1 M pairs), at most 2^15 buckets
-	// (128 KB LDS histogram).  The sharded build keeps 2048: its local table holds every distinct k-mer of a bucket.
-	static const size_t dflt = tune("VDJX_BUCKET_TUPLES", 4096);
-	const size_t per = per_bucket ? per_bucket : dflt;
-	u32 nb_bits = 8;
-	while (nb_bits < 15 && (per << nb_bits) < NI) nb_bits++;
-	return nb_bits;
-}
-
-struct PartPlan { u32 nb_bits, NB, nblk; size_t rpb; u32* bucket_cnt; u32* bucket_start; };
-
-// K2a + K2b over the records of `pool`: bucket sizes and per-workgroup offsets
-template <typename A>
-int stage_partition_count(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, u32 nb_bits, PartPlan* pp, u32* N_out) {
-	hipStream_t st = c->stream;
-	const size_t R = pool->n_records;
-	pp->nb_bits = nb_bits;
-	pp->NB = 1u << nb_bits;
-	pp->nblk = (u32) std::min<size_t>(512, (R + 4095) / 4096);
-	if (pp->nblk == 0) pp->nblk = 1;
-	pp->rpb = (R + pp->nblk - 1) / pp->nblk;
-	HIP_TRY(db.alloc(&pp->bucket_cnt, pp->NB));
-	HIP_TRY(hipMemsetAsync(pp->bucket_cnt, 0, (size_t) pp->NB * 4, st));
-	HIP_TRY(db.alloc(&pp->bucket_start, pp->NB + 1));
-	const size_t lds_hist = (size_t) pp->NB * 4;
-	HIP_TRY(hipFuncSetAttribute((const void*) k_kmer_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_hist));
-	{
-		vdjx_prof_scope ps(c, "k_kmer_hist");
-		hipLaunchKernelGGL(k_kmer_hist, dim3(pp->nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, R, pool->rl, k,
-		                   nb_bits, pp->rpb, pp->bucket_cnt);
-	}
-	{
-		vdjx_prof_scope ps(c, "k_hist_scan");
-		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, pp->bucket_cnt, pp->NB, pp->bucket_start);
-	}
-	// the exact tuple count (instances without an 'N') stays on the device (bucket_start[NB]); the host sizes everything by the
-	// bound records x offsets and saves a round trip
-	*N_out = (u32) (R * (size_t) (pool->rl - k + 1));
-	return VDJX_OK;
-}
-
-// one- or two-pass LDS-staged partition of a tuple source into 2^nb_bits buckets whose starts are known
-// (bucket_start[NB+1]); `tmp_*` are scratch arrays of N tuples (two-pass only)
-struct PartGeom { u32 nb_bits, cbits, fbits; };
-inline PartGeom part_geom(u32 nb_bits) {
-	PartGeom g{nb_bits, nb_bits, 0};
-	if (nb_bits > 10) { g.cbits = 8; g.fbits = nb_bits - 8; }
-	return g;
-}
-
-// how many hash bits beyond the histogram's 2^15 buckets: buckets stay near `target` tuples whatever the pool size
-// (`Nd` = the tuple count the decision is made on: the sharded build passes a bound every rank knows, so that all ranks cut the
-// same buckets)
-u32 choose_extra_bits(size_t Nd, u32 NB, size_t per_bucket = 0) {
-	static const size_t dflt = tune("VDJX_REFINE_TUPLES", 4096);
-	const size_t target = per_bucket ? per_bucket : dflt;
-	if (NB == 0 || Nd / NB <= 2 * target) return 0;
-	u32 extra = 1;
-	while (extra < 5 && (Nd >> extra) / NB > target) extra++;
-	return extra;
-}
-
-// K2c: the records of `pool` -> tuples grouped by the top (nb_bits + extra) hash bits, in two LDS-staged passes.
-//   extra == 0: bucket starts come from the histogram (stage_partition_count): 256 coarse x 2^(nb_bits-8) fine.
-//   extra  > 0 (large pools): the histogram only resolves 2^15 buckets (LDS), so pass 1 cuts 2^(T-10) coarse buckets whose starts
-//   it does know, a counting pass over them yields the 2^10 sub-bucket sizes each, and pass 2 cuts those: 2^T buckets after two
-//   partition passes and one read-only pass (a third partition pass cost 13 ms per 10 M pairs).
-template <typename THI, typename A>
-int stage_partition_fill(vdjx_ctx* c, A& db, const vdjx_pool* pool, u32 rec_base, int k, const PartPlan& pp, u32 N, u32 extra,
-                         Tuples<THI>* out) {
-	hipStream_t st = c->stream;
-	const size_t R = pool->n_records;
-	if (pp.nb_bits < 15) extra = 0;                    // the histogram itself resolves the buckets below its LDS limit
-	const u32 T = pp.nb_bits + extra;
-	PartGeom g = part_geom(pp.nb_bits);
-	if (extra) { g.cbits = T - 10; g.fbits = 10; }
-	const u32 NBc = 1u << g.cbits, NBt = 1u << T;
-	u32* gcur;
-	HIP_TRY(db.alloc(&gcur, NBc));
-	HIP_TRY(db.alloc(&out->lo, N)); HIP_TRY(db.alloc(&out->hi, N)); HIP_TRY(db.alloc(&out->inst, N));
-	HIP_TRY(hipFuncSetAttribute((const void*) k_part_records<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
-	HIP_TRY(hipFuncSetAttribute((const void*) k_part_tuples<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
-	u32 nblk = (u32) std::min<size_t>(1024, (R + 2047) / 2048);
-	if (nblk == 0) nblk = 1;
-	const size_t rpb = (R + nblk - 1) / nblk;
-	u64* l1_lo = out->lo; THI* l1_hi = out->hi; u32* l1_inst = out->inst;
-	if (g.fbits) {
-		HIP_TRY(db.alloc(&l1_lo, N)); HIP_TRY(db.alloc(&l1_hi, N)); HIP_TRY(db.alloc(&l1_inst, N));
-	}
-	const u32 cshift = pp.nb_bits - g.cbits;          // coarse bucket i starts at bucket_start[i << cshift]
-	{
-		vdjx_prof_scope ps(c, "k_part_records");
-		hipLaunchKernelGGL(k_init_cursors, dim3((NBc + 255) / 256), dim3(256), 0, st, pp.bucket_start, NBc, cshift, gcur);
-		hipLaunchKernelGGL(k_part_records<THI>, dim3(nblk), dim3(PART_THREADS), PART_LDS_BYTES, st, pool->d_bases, pool->d_nmask,
-		                   pool->d_lowq, R, rec_base, pool->rl, k, 64 - g.cbits, NBc, rpb, gcur, l1_lo, l1_hi, l1_inst);
-	}
-	out->bucket_start = pp.bucket_start;
-	out->NB = pp.NB;
-	out->N = N;
-	if (!g.fbits) return VDJX_OK;
-	static const u32 slices = (u32) tune("VDJX_PART_SLICES", 8);
-	const u32* fine_start = pp.bucket_start;
-	if (extra) {
-		u32 *fine_cnt, *fs;
-		HIP_TRY(db.alloc(&fine_cnt, NBt));
-		HIP_TRY(db.alloc(&fs, NBt + 1));
-		HIP_TRY(hipMemsetAsync(fine_cnt, 0, (size_t) NBt * 4, st));
-		vdjx_prof_scope ps(c, "k_seg_hist");
-		hipLaunchKernelGGL(k_seg_hist_sliced<THI>, dim3(NBc * slices), dim3(512), 0, st, l1_lo, l1_hi, pp.bucket_start, cshift, slices, 64 - T, g.fbits, fine_cnt);
-		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, fine_cnt, NBt, fs);
-		fine_start = fs;
-		out->bucket_start = fs;
-		out->NB = NBt;
-	}
-	u32* gcur2;
-	HIP_TRY(db.alloc(&gcur2, NBt));
-	{
-		vdjx_prof_scope ps(c, "k_part_tuples");
-		hipLaunchKernelGGL(k_init_cursors, dim3((NBt + 255) / 256), dim3(256), 0, st, fine_start, NBt, 0u, gcur2);
-		hipLaunchKernelGGL(k_part_tuples<THI>, dim3(NBc * slices), dim3(PART_THREADS), PART_LDS_BYTES, st, l1_lo, l1_hi, l1_inst,
-		                   pp.bucket_start, cshift, slices, 64 - T, g.fbits, gcur2, out->lo, out->hi, out->inst);
-	}
-	return VDJX_OK;
-}
-
-// K3a + K3b
-template <typename THI, typename A>
-int stage_reduce(vdjx_ctx* c, A& db, const Tuples<THI>& t, const PoolView& pv, int k, int P, int mf, int mq, Survivors* sv) {
-	hipStream_t st = c->stream;
-	const u32 NB = t.NB, N = t.N;
-	{
-		static const u32 sub = (u32) tune("VDJX_SUB_TUPLES", 262144);
-		HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sub_tuples), &sub, 4, 0, hipMemcpyHostToDevice, st));
-	}
-	u64 *c_lo, *g_distinct;
-	THI* c_hi;
-	u32 *c_cnt, *c_first, *c_ucnt, *c_ufirst, *ct_lcid, *ct_inst, *bucket_ncand, *bucket_nct, *g_err, *n_surv;
-	HIP_TRY(db.alloc(&c_lo, N)); HIP_TRY(db.alloc(&c_hi, N)); HIP_TRY(db.alloc(&c_cnt, N)); HIP_TRY(db.alloc(&c_first, N));
-	HIP_TRY(db.alloc(&c_ucnt, N)); HIP_TRY(db.alloc(&c_ufirst, N));
-	HIP_TRY(db.alloc(&ct_lcid, N)); HIP_TRY(db.alloc(&ct_inst, N));
-	HIP_TRY(db.alloc(&bucket_ncand, NB)); HIP_TRY(db.alloc(&bucket_nct, NB));
-	HIP_TRY(db.alloc(&g_err, 1)); HIP_TRY(db.alloc(&n_surv, 1)); HIP_TRY(db.alloc(&g_distinct, 64 * 16));
-	HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
-	HIP_TRY(hipMemsetAsync(g_distinct, 0, 64 * 16 * 8, st));
-
-	// prune thresholds.  mq is clamped as A2:1514-1516; a sum >= 214 reads as 255 (A2:356-360), so the test
-	// "S_j >= mq" is "true sum >= min(mq, 214)".  Every gated instance other than the first adds >= 20
-	// (MIN_BASE_QUALITY) to every S_j, so a key with count >= TLOW = 1 + ceil(mqq/20) passes the quality test
-	// whatever its qualities are: only keys with count < TLOW need their sums computed.
-	if (mq >= 255) mq = 254;
-	const u32 mqq = (u32) (mq < 0 ? 0 : (mq > 214 ? 214 : mq));
-	const u32 tlow = 1 + (mqq + 19) / 20;
-	const u32 cmin = (u32) std::max(mf, 2);
-	const u32 mfu = (u32) std::max(mf, 0);
-
-	const size_t lds_agg = (size_t) K3_SLOTS * (8 + sizeof(THI) + 20);
-	HIP_TRY(hipFuncSetAttribute((const void*) k_bucket_aggregate<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_agg));
-	{
-		vdjx_prof_scope ps(c, "k_bucket_aggregate");
-		hipLaunchKernelGGL(k_bucket_aggregate<THI>, dim3(NB), dim3(K3_THREADS), lds_agg, st, t.lo, t.hi, t.inst, t.bucket_start, cmin,
-		                   c_lo, c_hi, c_cnt, c_first, c_ucnt, c_ufirst, ct_lcid, ct_inst, bucket_ncand, bucket_nct, g_distinct, g_err);
-	}
-	// survivors: capacity grows on demand (rerun of the cheap finalize pass)
-	u32 cap = (u32) std::min<size_t>((size_t) N / 2 + 1024, (size_t) 1 << 22);
-	u32 ns = 0;
-	for (int attempt = 0; attempt < 2; attempt++) {
-		HIP_TRY(db.alloc(&sv->lo, cap)); HIP_TRY(db.alloc(&sv->hi, cap));
-		HIP_TRY(db.alloc(&sv->gcnt, cap)); HIP_TRY(db.alloc(&sv->gfirst, cap));
-		HIP_TRY(db.alloc(&sv->ucnt, cap)); HIP_TRY(db.alloc(&sv->ufirst, cap));
-		HIP_TRY(hipMemsetAsync(n_surv, 0, 4, st));
-		SurvOut so{sv->lo, sv->hi, sv->gcnt, sv->gfirst, sv->ucnt, sv->ufirst, n_surv, cap};
-		{
-			vdjx_prof_scope ps(c, "k_bucket_finalize");
-			hipLaunchKernelGGL(k_bucket_finalize<THI>, dim3(NB), dim3(K3B_THREADS), 0, st, t.bucket_start, bucket_ncand, bucket_nct,
-			                   c_lo, c_hi, c_cnt, c_first, c_ucnt, c_ufirst, ct_lcid, ct_inst, pv.bases, pv.nmask, pv.quals, pv.qstride, k, P, mfu, mqq, tlow, so);
-		}
-		HIP_TRY(hipMemcpyAsync(&ns, n_surv, 4, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
-		HIP_TRY(hipGetLastError());
-		if (ns <= cap) break;
-		cap = ns;
-		if (attempt == 1) { vdjx_set_error("survivor capacity logic failed"); return VDJX_EHIP; }
-	}
-	u32 err = 0;
-	HIP_TRY(hipMemcpy(&err, g_err, 4, hipMemcpyDeviceToHost));
-	{
-		u64 spread[64 * 16];
-		HIP_TRY(hipMemcpy(spread, g_distinct, sizeof(spread), hipMemcpyDeviceToHost));
-		sv->ndist = 0;
-		for (int i = 0; i < 64; i++) sv->ndist += spread[i * 16];
-	}
-	if (err) { vdjx_set_error("k_bucket_aggregate: %u buckets could not be split to fit LDS", err); return VDJX_EHIP; }
-	sv->n = ns;
-	return VDJX_OK;
-}
-
-// K5 over the records of `pool` (numbered from rec_base); edge arrays are caller-provided [ns*4]
-struct RecountSrc { const LocalAll* all; const u32* bucket_start; const u32* nd; u32 NB; u32* ucnt; u32* ufirst; };
-
-template <typename A>
-int stage_edges(vdjx_ctx* c, A& db, const vdjx_pool* pool, u32 rec_base, int k, const Survivors& sv, u32* edge_first, u32* edge_to,
-                const RecountSrc* rc = nullptr) {
-	hipStream_t st = c->stream;
-	const u32 ns = sv.n;
-	u32 tmask = 1023;
-	while ((size_t) tmask + 1 < (size_t) ns * 2) tmask = tmask * 2 + 1;
-	if (ns >= (1u << 24) - 1) { vdjx_set_error("more than 16M surviving k-mers: not supported by the survivor table"); return VDJX_ELIMIT; }
-	u32* table;
-	ulonglong2* skey;
-	HIP_TRY(db.alloc(&table, (size_t) tmask + 1));
-	HIP_TRY(db.alloc(&skey, ns));
-	HIP_TRY(hipMemsetAsync(table, 0, ((size_t) tmask + 1) * 4, st));
-	uint2* link;
-	HIP_TRY(db.alloc(&link, (size_t) ns * 4));
-	{
-		vdjx_prof_scope ps(c, "k_surv_table");
-		hipLaunchKernelGGL(k_surv_table, dim3((ns + 255) / 256), dim3(256), 0, st, sv.lo, sv.hi, ns, table, tmask, skey);
-		hipLaunchKernelGGL(k_succ_links, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, skey, ns, k, table, tmask, link);
-	}
-	if (pool->n_records) {
-		vdjx_prof_scope ps(c, "k_graph_edges");
-		hipLaunchKernelGGL(k_graph_edges, dim3((unsigned) ((pool->n_records + 255) / 256)), dim3(256), 0, st, pool->d_bases, pool->d_nmask,
-		                   pool->n_records, rec_base, pool->rl, k, table, tmask, skey, link);
-	}
-	hipLaunchKernelGGL(k_links_split, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, link, ns * 4, edge_first, edge_to);
-	if (rc) {
-		HIP_TRY(hipMemsetAsync(rc->ucnt, 0, (size_t) ns * 4, st));
-		HIP_TRY(hipMemsetAsync(rc->ufirst, 0xFF, (size_t) ns * 4, st));
-		vdjx_prof_scope ps(c, "k_surv_counts");
-		hipLaunchKernelGGL(k_surv_counts, dim3(rc->NB), dim3(256), 0, st, rc->all, rc->bucket_start, rc->nd, table, tmask, skey, rc->ucnt, rc->ufirst);
-	}
-	return VDJX_OK;
-}
-
-// K6: flags, node ids, ordered lists, k-mer text; the host only copies
-template <typename A>
-int stage_finish(vdjx_ctx* c, A& db, const Survivors& sv, const u32* edge_first, const u32* edge_to, size_t NI, int k, int P, vdjx_graph* g) {
-	hipStream_t st = c->stream;
-	const u32 ns = sv.n;
-	g->n = ns;
-	g->k = k;
-	g->ctx = c;
-	g->device = c->device;
-	if (ns == 0) return VDJX_OK;
-	uint8_t *d_hv, *d_hj;
-	HIP_TRY(db.alloc(&d_hv, ns));
-	HIP_TRY(db.alloc(&d_hj, ns));
-	{
-		vdjx_prof_scope ps(c, "k_node_flags");
-		hipLaunchKernelGGL(k_node_flags, dim3((ns + 255) / 256), dim3(256), 0, st, sv.lo, sv.hi, ns, k, c->d_vbits, c->d_jbits, d_hv, d_hj);
-	}
-	const u32 nwords = (u32) ((NI + 31) / 32);
-	const u32 npb = (nwords + POPC_WORDS - 1) / POPC_WORDS;
-	u32 *bits, *word_pre, *block_sum, *block_pre, *rank, *in_first, *in_from;
-	HIP_TRY(db.alloc(&bits, nwords));
-	HIP_TRY(db.alloc(&word_pre, nwords));
-	HIP_TRY(db.alloc(&block_sum, npb));
-	HIP_TRY(db.alloc(&block_pre, npb + 1));
-	HIP_TRY(db.alloc(&rank, ns));
-	HIP_TRY(db.alloc(&in_first, (size_t) ns * 4));
-	HIP_TRY(db.alloc(&in_from, (size_t) ns * 4));
-	// the node arrays live in a block of their own: they outlive this call (vdjx_graph_export copies from there)
-	auto up = [](size_t b) { return (b + 255) & ~(size_t) 255; };
-	const size_t need = up((size_t) ns * 8) + 5 * up((size_t) ns * 4) + 4 * up(ns) + 2 * up((size_t) ns * 16) + up((size_t) ns * k);
-	{
-		hipError_t e = c->blocks.acquire(need, &g->d_block, &g->block_cap);
-		if (e != hipSuccess) { vdjx_set_error("graph alloc (%zu bytes): %s", need, hipGetErrorString(e)); return VDJX_EHIP; }
-	}
-	char* bp = g->d_block;
-	auto carve = [&](size_t b) { char* r = bp; bp += up(b); return r; };
-	NodeOut no;
-	no.first_inst = g->d_first_inst = (u64*) carve((size_t) ns * 8);
-	no.gcnt = g->d_gcnt = (u32*) carve((size_t) ns * 4);
-	no.freq = g->d_freq = (u32*) carve((size_t) ns * 4);
-	no.to_ids = g->d_to_ids = (u32*) carve((size_t) ns * 16);
-	no.from_ids = g->d_from_ids = (u32*) carve((size_t) ns * 16);
-	no.hv = g->d_hv = (uint8_t*) carve(ns);
-	no.hj = g->d_hj = (uint8_t*) carve(ns);
-	no.to_deg = g->d_to_deg = (uint8_t*) carve(ns);
-	no.from_deg = g->d_from_deg = (uint8_t*) carve(ns);
-	no.kmers = g->d_kmers = carve((size_t) ns * k);
-	g->d_roots = (u32*) carve((size_t) ns * 4);
-	HIP_TRY(db.alloc(&no.klo, ns)); HIP_TRY(db.alloc(&no.khi, ns));
-	HIP_TRY(hipMemsetAsync(bits, 0, (size_t) nwords * 4, st));
-	HIP_TRY(hipMemsetAsync(in_first, 0xFF, (size_t) ns * 16, st));
-	{
-		vdjx_prof_scope ps(c, "k_node_order");
-		hipLaunchKernelGGL(k_mark_first, dim3((ns + 255) / 256), dim3(256), 0, st, sv.ufirst, ns, bits);
-		hipLaunchKernelGGL(k_popc_blocks, dim3(npb), dim3(256), 0, st, bits, nwords, word_pre, block_sum);
-		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, block_sum, npb, block_pre);
-		hipLaunchKernelGGL(k_node_rank, dim3((ns + 255) / 256), dim3(256), 0, st, sv.ufirst, ns, bits, word_pre, block_pre, rank);
-		hipLaunchKernelGGL(k_in_edges, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, edge_first, edge_to, sv.lo, sv.hi, ns, k, in_first, in_from);
-		hipLaunchKernelGGL(k_node_emit, dim3((ns + 255) / 256), dim3(256), 0, st, sv.lo, sv.hi, sv.gcnt, sv.ucnt, sv.ufirst, d_hv, d_hj, rank,
-		                   edge_first, edge_to, in_first, in_from, ns, k, P, no);
-	}
-	u32 n_roots = 0;
-	{
-		const u32 nrb = (ns + 255) / 256;
-		u32 *rb_cnt, *rb_start;
-		HIP_TRY(db.alloc(&rb_cnt, nrb));
-		HIP_TRY(db.alloc(&rb_start, nrb + 1));
-		vdjx_prof_scope ps(c, "k_root_list");
-		hipLaunchKernelGGL(k_root_count, dim3(nrb), dim3(256), 0, st, no.from_deg, ns, rb_cnt);
-		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, rb_cnt, nrb, rb_start);
-		hipLaunchKernelGGL(k_root_list, dim3(nrb), dim3(256), 0, st, no.from_deg, ns, rb_start, g->d_roots);
-		HIP_TRY(hipMemcpyAsync(&n_roots, rb_start + nrb, 4, hipMemcpyDeviceToHost, st));
-	}
-	HIP_TRY(hipStreamSynchronize(st));
-	HIP_TRY(hipGetLastError());
-	g->n_roots = n_roots;
-	vdjx_prof_collect(c);              // the stream is idle: every recorded event is complete, its pair goes back to the pool
-	return VDJX_OK;
 }
 
 // ==============================================================================================
@@ -2731,12 +1706,13 @@ struct RecountOut { u32* ucnt; u64* ufirst; u64* in_first; u32* in_from; u64* ed
 
 template <typename A>
 int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k, const u64* s_lo, const u64* s_hi, u32 ns, const RecountOut& ro,
-                  bool derive_edges) {
+                  bool derive_edges, SurvTable* table_out = nullptr) {
 	hipStream_t st = c->stream;
 	const size_t R = pool->n_records;
 	const int P = pool->rl - k + 1;
 	if (ns >= (1u << 26)) { vdjx_set_error("more than 2^26 surviving k-mers: not supported by the recount items"); return VDJX_ELIMIT; }
 	if (R >= (1ull << 29)) { vdjx_set_error("more than 2^29 records on one GPU: not supported by the recount items"); return VDJX_ELIMIT; }
+	if ((u64) R * (u64) P >= (1ull << 32)) { vdjx_set_error("records*offsets = %llu >= 2^32 on one GPU: shard the pool over more GPUs", (unsigned long long) ((u64) R * (u64) P)); return VDJX_ELIMIT; }
 	u32 tmask = 1023;
 	while ((size_t) tmask + 1 < (size_t) ns * 2) tmask = tmask * 2 + 1;
 	const u32 idx_bits = std::max(1u, ceil_log2_u64((u64) ns + 1));
@@ -2752,6 +1728,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	HIP_TRY(db.alloc(&succ1, ns));
 	HIP_TRY(hipMemsetAsync(table, 0, ((size_t) tmask + 1) * 4, st));
 	SurvTable tb{table, tmask, idx_bits, skey, bloom, bloom_bits - 1};
+	if (table_out) *table_out = tb;
 	{
 		vdjx_prof_scope ps(c, "k_surv_table");
 		hipLaunchKernelGGL(k_surv_table2, dim3((ns + 255) / 256), dim3(256), 0, st, s_lo, s_hi, ns, table, tmask, idx_bits, skey, bloom, bloom_bits - 1);
@@ -2762,12 +1739,13 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	static const bool force_wide = tune("VDJX_RC_WIDE", 0) != 0;                    // (test knobs: the paths of very large pools on small ones)
 	static const u32 cap_shift = (u32) tune("VDJX_RC_MAX_SHIFT", 12);
 	const bool narrow = R <= (1ull << 26) && !force_wide;           // local instance ids fit 32 bits
+	static const u32 max_ranges = (u32) std::min<size_t>(PART_MAXB, std::max<size_t>(2, tune("VDJX_RC_MAX_RANGES", PART_MAXB)));
 	const u32 max_shift = std::max(8u, std::min(narrow ? 12u : 11u, cap_shift));
 	u32 range_shift = 8;
-	while (range_shift < max_shift && ((ns + (1u << range_shift) - 1) >> range_shift) > PART_MAXB) range_shift++;
+	while (range_shift < max_shift && ((ns + (1u << range_shift) - 1) >> range_shift) > max_ranges) range_shift++;
 	const u32 n_ranges = (ns + (1u << range_shift) - 1) >> range_shift;
 	u32 l2bits = 0;
-	while (((n_ranges + (1u << l2bits) - 1) >> l2bits) > PART_MAXB) l2bits++;
+	while (((n_ranges + (1u << l2bits) - 1) >> l2bits) > max_ranges) l2bits++;
 	const u32 n_coarse = (n_ranges + (1u << l2bits) - 1) >> l2bits;
 	const u32 n_ranges_p = n_coarse << l2bits;                      // padded: every coarse segment has 2^l2bits ranges
 	// raw item blocks
@@ -2957,35 +1935,7 @@ int kmer_build_impl2(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, 
 	return stage_finish2(c, db, sv, ro, pool->n_records, k, P, g);
 }
 
-template <typename THI>
-int kmer_build_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, vdjx_graph* g) {
-	const int P = pool->rl - k + 1;
-	const size_t NI = pool->n_records * (size_t) P;
-	vdjx_work db(c);
-	PartPlan pp;
-	Tuples<THI> t;
-	int rc = stage_partition_count(c, db, pool, k, choose_nb_bits(NI), &pp, &t.N);
-	if (rc) return rc;
-	rc = stage_partition_fill<THI>(c, db, pool, 0, k, pp, t.N, choose_extra_bits(t.N, pp.NB), &t);
-	if (rc) return rc;
-	PoolView pv{pool->d_bases, pool->d_nmask, pool->d_quals, pool->qstride};
-	Survivors sv;
-	rc = stage_reduce<THI>(c, db, t, pv, k, P, mf, mq, &sv);
-	if (rc) return rc;
-	g->pre_nodes = (size_t) sv.ndist;
-	Edges e;
-	if (sv.n) {
-		HIP_TRY(db.alloc(&e.first, (size_t) sv.n * 4));
-		HIP_TRY(db.alloc(&e.to, (size_t) sv.n * 4));
-		rc = stage_edges(c, db, pool, 0, k, sv, e.first, e.to);
-		if (rc) return rc;
-	}
-	return stage_finish(c, db, sv, e.first, e.to, NI, k, P, g);
-}
-
 }  // namespace
-
-static bool key_hi_is_u32(int k) { return 2 * k - 64 <= 30; }
 
 extern "C" int vdjx_kmer_build(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, vdjx_graph** out) {
 	if (!c || !pool || !out) { vdjx_set_error("vdjx_kmer_build: NULL argument"); return VDJX_EINVAL; }
@@ -2996,14 +1946,7 @@ extern "C" int vdjx_kmer_build(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_clear_errors();
 	vdjx_graph* g = new vdjx_graph();
-	int rc;
-	static const bool legacy = getenv("VDJX_LEGACY_BUILD") != nullptr;          // the round-1 build (every instance travels), for A/B runs
-	if (legacy) {
-		const size_t NI = pool->n_records * (size_t) (pool->rl - k + 1);
-		if (NI >= (1ull << 31)) { delete g; vdjx_set_error("records*offsets = %zu >= 2^31", NI); return VDJX_ELIMIT; }
-		rc = key_hi_is_u32(k) ? kmer_build_impl<u32>(c, pool, k, mf, mq, g) : kmer_build_impl<u64>(c, pool, k, mf, mq, g);
-	} else
-		rc = k <= 45 ? kmer_build_impl2<Tup16>(c, pool, k, mf, mq, g) : kmer_build_impl2<Tup24>(c, pool, k, mf, mq, g);
+	const int rc = k <= 45 ? kmer_build_impl2<Tup16>(c, pool, k, mf, mq, g) : kmer_build_impl2<Tup24>(c, pool, k, mf, mq, g);
 	if (rc != VDJX_OK) { vdjx_graph_free(g); return rc; }
 	*out = g;
 	return VDJX_OK;
@@ -3011,28 +1954,26 @@ extern "C" int vdjx_kmer_build(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf
 
 // ==============================================================================================
 // Sharded build: one process per GPU; the caller moves the bytes between ranks
-// (torch.distributed over RCCL in vdjer_amd/shard.py).  Record numbering: rank r's records are
-// [r*rec_stride, r*rec_stride + R_r); k-mer ownership = top log2(nranks) bits of the bucket index.
+// (torch.distributed over RCCL in vdjer_amd/shard.py, RCCL directly in the C host).  Record numbering: rank r's
+// records are [r*rec_stride, r*rec_stride + R_r); k-mer ownership = top log2(nranks) bits of the bucket index.
+// Instance ids are global and 38 bits wide (record << 6 | offset): nranks * rec_stride < 2^32 records.
 // ==============================================================================================
 struct vdjx_shard {
 	vdjx_ctx* c = nullptr;
 	const vdjx_pool* pool = nullptr;
 	int k = 0, mf = 0, mq = 0, rank = 0, nranks = 1;
-	u32 rec_stride = 0, nb_bits = 0, owner_bits = 0;
-	bool hi64 = false;
-	// local phase: this rank's tuples by bucket, its partial aggregates (dense, bucket order)
-	void *t_lo = nullptr, *t_hi = nullptr;
-	u32 *t_inst = nullptr, *t_bucket_start = nullptr;
-	u32 N_local = 0, NBf = 0, NBo = 0, total_bits = 0;
-	u32 *nd = nullptr, *dstart = nullptr;          // gated partials per bucket, their dense offsets
+	u64 rec_stride = 0;
+	u32 owner_bits = 0;
+	bool wide = false;                              // Tup24 (k > 45)
+	// local phase: this rank's gated tuples by bucket, its partial aggregates (dense, bucket order)
+	u32 NBf = 0, NBo = 0;
+	u32 *nd = nullptr, *dstart = nullptr;          // partials per bucket, their dense offsets
 	Partial* dense = nullptr;
-	u32* dense_ref = nullptr;                      // per dense partial: where its gated instances are listed (count < TLOW), or NONE
-	u32* low_inst = nullptr;
+	u32* dense_ref = nullptr;                      // per dense partial: where its instances are listed (count < TLOW), or NONE
+	u64* low_inst = nullptr;
 	u32 n_dense = 0;
-	LocalAll* sparse_a = nullptr;                  // {count, first} over all instances, per bucket at the bucket's tuple offset
-	u32* nd_a = nullptr;
 	// owner phase
-	Survivors local_sv, all_sv;
+	SurvivorsG local_sv, all_sv;
 	u32 sv_cap = 0;
 	u32* n_surv = nullptr;
 	PendOut po{};
@@ -3041,6 +1982,7 @@ struct vdjx_shard {
 	std::vector<u32> src_base, nq;
 	u32 *p_fl = nullptr, *p_S = nullptr, *p_r0 = nullptr;
 	u32 mqq = 0, tlow = 0;
+	SurvTable tb{};                                // survivor table of the recount (kept for the edge derivation in finish)
 	int phase = 0;
 };
 
@@ -3052,16 +1994,13 @@ extern "C" int vdjx_shard_begin(vdjx_ctx* c, const vdjx_pool* pool, int k, int m
 	if (nranks < 1 || (nranks & (nranks - 1)) || nranks > 256 || rank < 0 || rank >= nranks) { vdjx_set_error("nranks must be a power of two <= 256, 0 <= rank < nranks"); return VDJX_EINVAL; }
 	if (k < 1 || k > VDJX_MAX_KMER || k > pool->rl) { vdjx_set_error("k=%d outside [1,min(%d,rl=%d)]", k, VDJX_MAX_KMER, pool->rl); return VDJX_ELIMIT; }
 	if (rec_stride < pool->n_records) { vdjx_set_error("rec_stride %llu < local records %zu", (unsigned long long) rec_stride, pool->n_records); return VDJX_EINVAL; }
-	const size_t NI = (size_t) rec_stride * nranks * (size_t) (pool->rl - k + 1);
-	if (NI >= (1ull << 31)) { vdjx_set_error("global records*offsets = %zu >= 2^31", NI); return VDJX_ELIMIT; }
+	if (rec_stride * (uint64_t) nranks >= (1ull << 32)) { vdjx_set_error("global record count %llu >= 2^32", (unsigned long long) (rec_stride * nranks)); return VDJX_ELIMIT; }
 	if (k > 16 && !c->anchors_loaded) { vdjx_set_error("vdjx_shard_begin: call vdjx_anchor_sets_load first (k > 16)"); return VDJX_ESTATE; }
 	vdjx_shard* s = new vdjx_shard();
 	s->c = c; s->pool = pool; s->k = k; s->mf = mf; s->mq = mq; s->rank = rank; s->nranks = nranks;
-	s->rec_stride = (u32) rec_stride;
-	s->hi64 = !key_hi_is_u32(k);
+	s->rec_stride = rec_stride;
+	s->wide = k > 45;
 	while ((1 << s->owner_bits) < nranks) s->owner_bits++;
-	// every rank cuts the SAME buckets: the geometry follows the common stride, not the local record count
-	s->nb_bits = choose_nb_bits((size_t) rec_stride * (size_t) (pool->rl - k + 1), 2048);
 	if (mq >= 255) mq = 254;                                        // A2:1514-1516
 	s->mqq = (u32) (mq < 0 ? 0 : (mq > 214 ? 214 : mq));
 	s->tlow = 1 + (s->mqq + 19) / 20;
@@ -3079,46 +2018,45 @@ extern "C" void vdjx_shard_free(vdjx_shard* s) {
 	delete s;
 }
 
-/* sizes of the records the caller moves between ranks: 0 partial aggregate, 1 question, 2 answer */
-extern "C" size_t vdjx_shard_record_bytes(int kind) { return kind == 0 ? sizeof(Partial) : kind == 1 ? sizeof(uint2) : kind == 2 ? REPLY_BYTES : 0; }
+/* sizes of the records the caller moves between ranks: 0 partial aggregate, 1 question, 2 answer, 3 survivor */
+extern "C" size_t vdjx_shard_record_bytes(int kind) {
+	return kind == 0 ? sizeof(Partial) : kind == 1 ? sizeof(uint2) : kind == 2 ? REPLY_BYTES : kind == 3 ? sizeof(SurvRec) : 0;
+}
 
-
-template <typename THI>
+template <typename TUP>
 static int shard_local_impl(vdjx_shard* s) {
 	vdjx_ctx* c = s->c;
 	hipStream_t st = c->stream;
 	PersistAlloc db(c);
 	const int P = s->pool->rl - s->k + 1;
-	const u32 rec_base = s->rec_stride * (u32) s->rank;
-	PartPlan pp;
-	Tuples<THI> t;
-	int rc = stage_partition_count(c, db, s->pool, s->k, s->nb_bits, &pp, &t.N);
+	const u64 rec_base = s->rec_stride * (u64) s->rank;
+	// every rank cuts the SAME buckets: the geometry follows a bound all ranks know (a quarter of the stride's instances:
+	// the gated fraction of real pools lies between a sixth and a half), not the local count
+	GTuples<TUP> t;
+	const u64 geom = std::max<u64>(1, s->rec_stride * (u64) P / 4);
+	int rc = stage_gated_partition<TUP>(c, db, s->pool, rec_base, s->k, 0, geom, &t);
 	if (rc) return rc;
-	rc = stage_partition_fill<THI>(c, db, s->pool, rec_base, s->k, pp, t.N, choose_extra_bits((size_t) s->rec_stride * (size_t) P, pp.NB, 2048), &t);
-	if (rc) return rc;
-	s->t_lo = t.lo; s->t_hi = t.hi; s->t_inst = t.inst; s->t_bucket_start = t.bucket_start;
-	s->N_local = t.N; s->NBf = t.NB;
-	s->total_bits = 0;
-	while ((1u << s->total_bits) < t.NB) s->total_bits++;
+	if (t.NB < (u32) s->nranks) { vdjx_set_error("vdjx_shard_local: fewer buckets (%u) than ranks", t.NB); return VDJX_ELIMIT; }
+	s->NBf = t.NB;
 	s->NBo = t.NB / (u32) s->nranks;
 	Partial* sparse;
-	u32* g_err;
-	u32* sparse_ref;
-	HIP_TRY(db.alloc(&sparse, t.N));
-	HIP_TRY(db.alloc(&sparse_ref, t.N));
-	HIP_TRY(db.alloc(&s->low_inst, t.N));
-	HIP_TRY(db.alloc(&s->sparse_a, t.N));
-	HIP_TRY(db.alloc(&s->nd_a, t.NB));
+	u32 *g_err, *sparse_ref;
+	const size_t cap = (size_t) t.N + 1;
+	HIP_TRY(db.alloc(&sparse, cap));
+	HIP_TRY(db.alloc(&sparse_ref, cap));
+	HIP_TRY(db.alloc(&s->low_inst, cap));
 	HIP_TRY(db.alloc(&s->nd, t.NB));
 	HIP_TRY(db.alloc(&s->dstart, t.NB + 1));
 	HIP_TRY(db.alloc(&g_err, 1));
 	HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
-	const size_t lds = (size_t) LOCAL_SLOTS * (8 + sizeof(THI) + 24 + 1);
-	HIP_TRY(hipFuncSetAttribute((const void*) k_bucket_local<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 	{
-		vdjx_prof_scope ps(c, "k_bucket_local");
-		hipLaunchKernelGGL(k_bucket_local<THI>, dim3(t.NB), dim3(K3_THREADS), lds, st, t.lo, t.hi, t.inst, t.bucket_start, s->pool->d_bases,
-		                   s->pool->d_nmask, rec_base, P, s->tlow, sparse, sparse_ref, s->nd, s->sparse_a, s->nd_a, s->low_inst, g_err);
+		static const u32 sub = (u32) tune("VDJX_SUB_TUPLES", 262144);
+		HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sub_tuples), &sub, 4, 0, hipMemcpyHostToDevice, st));
+	}
+	{
+		vdjx_prof_scope ps(c, "k_gated_local");
+		hipLaunchKernelGGL(k_gated_local<TUP>, dim3(t.NB), dim3(K3_THREADS), 0, st, t.t, t.bucket_start, s->pool->d_bases, s->pool->d_nmask, rec_base,
+		                   s->tlow, sparse, sparse_ref, s->nd, s->low_inst, g_err);
 	}
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, s->nd, t.NB, s->dstart);
 	u32* d_pick;
@@ -3131,11 +2069,11 @@ static int shard_local_impl(vdjx_shard* s) {
 	HIP_TRY(hipMemcpyAsync(&err, g_err, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
-	if (err) { vdjx_set_error("k_bucket_local: %u buckets could not be split to fit LDS", err); return VDJX_EHIP; }
+	if (err) { vdjx_set_error("k_gated_local: %u buckets could not be split to fit LDS", err); return VDJX_EHIP; }
 	s->src_base.assign(pick.begin(), pick.end());        // reused below as "what goes to owner o" until the merge overwrites it
 	s->n_dense = pick[G];
-	HIP_TRY(db.alloc(&s->dense, s->n_dense));
-	HIP_TRY(db.alloc(&s->dense_ref, s->n_dense));
+	HIP_TRY(db.alloc(&s->dense, (size_t) s->n_dense + 1));
+	HIP_TRY(db.alloc(&s->dense_ref, (size_t) s->n_dense + 1));
 	{
 		vdjx_prof_scope ps(c, "k_compact_partials");
 		hipLaunchKernelGGL(k_compact_partials, dim3(t.NB), dim3(256), 0, st, sparse, sparse_ref, t.bucket_start, s->nd, s->dstart, s->dense, s->dense_ref);
@@ -3149,7 +2087,7 @@ extern "C" int vdjx_shard_local(vdjx_shard* s, uint64_t* send_counts, uint32_t* 
 	if (s->phase != 0) { vdjx_set_error("vdjx_shard_local: already called"); return VDJX_ESTATE; }
 	HIP_TRY(hipSetDevice(s->c->device));
 	vdjx_clear_errors();
-	int rc = s->hi64 ? shard_local_impl<u64>(s) : shard_local_impl<u32>(s);
+	int rc = s->wide ? shard_local_impl<Tup24>(s) : shard_local_impl<Tup16>(s);
 	if (rc) return rc;
 	for (int g = 0; g < s->nranks; g++) send_counts[g] = s->src_base[g + 1] - s->src_base[g];
 	*dir_len = s->NBo;
@@ -3189,12 +2127,11 @@ static int shard_merge_impl(vdjx_shard* s, const u32* d_recv_dir, const Partial*
 	HIP_TRY(db.alloc(&n_pend, 1));
 	HIP_TRY(db.alloc(&s->n_surv, 1));
 	HIP_TRY(db.alloc(&g_distinct, 1));
-	HIP_TRY(db.alloc(&s->queries, total));
+	HIP_TRY(db.alloc(&s->queries, (size_t) total + 1));
 	const u32 cap = total + 1;
 	s->sv_cap = cap;
-	Survivors& v = s->local_sv;
-	HIP_TRY(db.alloc(&v.lo, cap)); HIP_TRY(db.alloc(&v.hi, cap)); HIP_TRY(db.alloc(&v.gcnt, cap));
-	HIP_TRY(db.alloc(&v.gfirst, cap)); HIP_TRY(db.alloc(&v.ucnt, cap)); HIP_TRY(db.alloc(&v.ufirst, cap));
+	SurvivorsG& v = s->local_sv;
+	HIP_TRY(db.alloc(&v.lo, cap)); HIP_TRY(db.alloc(&v.hi, cap)); HIP_TRY(db.alloc(&v.gcnt, cap)); HIP_TRY(db.alloc(&v.gfirst, cap));
 	PendOut& po = s->po;
 	HIP_TRY(db.alloc(&po.lo, cap)); HIP_TRY(db.alloc(&po.hi, cap)); HIP_TRY(db.alloc(&po.cg, cap)); HIP_TRY(db.alloc(&po.mg, cap));
 	HIP_TRY(db.alloc(&po.need, cap));
@@ -3202,11 +2139,9 @@ static int shard_merge_impl(vdjx_shard* s, const u32* d_recv_dir, const Partial*
 	HIP_TRY(hipMemcpyAsync(d_src_base, s->src_base.data(), (G + 1) * 4, hipMemcpyHostToDevice, st));
 	hipLaunchKernelGGL(k_seg_offsets, dim3(G), dim3(1024), 0, st, d_recv_dir, d_src_base, G, NBo, seg_off);
 	const u32 cmin = (u32) std::max(s->mf, 2);
-	const size_t lds = (size_t) MERGE_SLOTS * (8 + sizeof(THI) + 16 + 1);
-	HIP_TRY(hipFuncSetAttribute((const void*) k_bucket_merge<THI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-	SurvOut so{v.lo, v.hi, v.gcnt, v.gfirst, v.ucnt, v.ufirst, s->n_surv, cap};
+	SurvOutG so{v.lo, v.hi, v.gcnt, v.gfirst, s->n_surv, cap};
 	s->nq.assign(G, 0);
-	// buckets per merge table: about MERGE_SLOTS/4 partials each (the local buckets are sized for tuples, not for distinct k-mers)
+	// buckets per merge table: about MERGE_SLOTS*3/8 partials each (the local buckets are sized for tuples, not for distinct k-mers)
 	u32 MG = 1;
 	while (MG < NBo && (u64) total * (MG * 2) <= (u64) NBo * (MERGE_SLOTS * 3 / 8)) MG <<= 1;
 	u32 np = 0, ns = 0, err = 0;
@@ -3219,7 +2154,7 @@ static int shard_merge_impl(vdjx_shard* s, const u32* d_recv_dir, const Partial*
 		HIP_TRY(hipMemsetAsync(g_distinct, 0, 8, st));
 		if (total) {
 			vdjx_prof_scope ps(c, "k_bucket_merge");
-			hipLaunchKernelGGL(k_bucket_merge<THI>, dim3(NBo / MG), dim3(MERGE_THREADS), lds, st, d_recv, seg_off, MG, G, NBo, d_src_base, s_mult, cmin,
+			hipLaunchKernelGGL(k_bucket_merge<THI>, dim3(NBo / MG), dim3(MERGE_THREADS), 0, st, d_recv, seg_off, MG, G, NBo, d_src_base, s_mult, cmin,
 			                   s->tlow, so, po, s->queries, g_nq, g_distinct, g_err);
 		}
 		HIP_TRY(hipMemcpyAsync(s->nq.data(), g_nq, (size_t) G * 4, hipMemcpyDeviceToHost, st));
@@ -3244,9 +2179,9 @@ static int shard_merge_impl(vdjx_shard* s, const u32* d_recv_dir, const Partial*
 	v.n = ns;                    // decided without questions; vdjx_shard_resolve appends the rest
 	v.ndist = ndist;
 	for (u32 g = 0; g < G; g++) query_counts[g] = s->nq[g];
-	HIP_TRY(db.alloc(&s->p_fl, (size_t) np));
-	HIP_TRY(db.alloc(&s->p_r0, (size_t) np));
-	HIP_TRY(db.alloc(&s->p_S, (size_t) np * 64));
+	HIP_TRY(db.alloc(&s->p_fl, (size_t) np + 1));
+	HIP_TRY(db.alloc(&s->p_r0, (size_t) np + 1));
+	HIP_TRY(db.alloc(&s->p_S, (size_t) np * 64 + 1));
 	if (np) {
 		HIP_TRY(hipMemsetAsync(s->p_fl, 0, (size_t) np * 4, st));
 		HIP_TRY(hipMemsetAsync(s->p_r0, 0xFF, (size_t) np * 4, st));
@@ -3263,11 +2198,11 @@ extern "C" int vdjx_shard_merge(vdjx_shard* s, const void* d_recv_dir, const voi
 	if (s->phase != 1) { vdjx_set_error("vdjx_shard_merge: call vdjx_shard_local first (once)"); return VDJX_ESTATE; }
 	uint64_t tot = 0;
 	for (int g = 0; g < s->nranks; g++) tot += recv_counts[g];
-	if (tot >= (1ull << 30)) { vdjx_set_error("vdjx_shard_merge: too many partial aggregates"); return VDJX_ELIMIT; }
+	if (tot >= (1ull << 30)) { vdjx_set_error("vdjx_shard_merge: too many partial aggregates for one owner (%llu): use more ranks", (unsigned long long) tot); return VDJX_ELIMIT; }
 	if (tot && !d_recv_partials) { vdjx_set_error("vdjx_shard_merge: NULL buffer"); return VDJX_EINVAL; }
 	HIP_TRY(hipSetDevice(s->c->device));
 	vdjx_clear_errors();
-	int rc = s->hi64 ? shard_merge_impl<u64>(s, (const u32*) d_recv_dir, (const Partial*) d_recv_partials, recv_counts, query_counts)
+	int rc = s->wide ? shard_merge_impl<u64>(s, (const u32*) d_recv_dir, (const Partial*) d_recv_partials, recv_counts, query_counts)
 	                 : shard_merge_impl<u32>(s, (const u32*) d_recv_dir, (const Partial*) d_recv_partials, recv_counts, query_counts);
 	if (rc) return rc;
 	s->phase = 2;
@@ -3311,12 +2246,10 @@ extern "C" int vdjx_shard_reply(vdjx_shard* s, const void* d_queries, const uint
 	hipStream_t st = c->stream;
 	HIP_TRY(hipMemcpyAsync(d_off, off.data(), (G + 1) * 4, hipMemcpyHostToDevice, st));
 	const vdjx_pool* p = s->pool;
-	const int P = p->rl - s->k + 1;
-	const u32 rec_base = s->rec_stride * (u32) s->rank;
 	{
 		vdjx_prof_scope ps(c, "k_shard_reply");
 		hipLaunchKernelGGL(k_shard_reply, dim3(nq), dim3(64), 0, st, (const uint2*) d_queries, nq, d_off, G, s->dense, s->dense_ref, s->dstart, s->NBo,
-		                   s->low_inst, p->d_bases, p->d_nmask, p->d_quals, p->qstride, rec_base, P, s->k, (uint8_t*) d_replies);
+		                   s->low_inst, p->d_bases, p->d_nmask, p->d_quals, p->qstride, s->rec_stride * (u64) s->rank, s->k, (uint8_t*) d_replies);
 	}
 	HIP_TRY(hipStreamSynchronize(st));          // `off` staging dies with this frame
 	HIP_TRY(hipGetLastError());
@@ -3334,11 +2267,11 @@ extern "C" int vdjx_shard_resolve(vdjx_shard* s, const void* d_replies, uint64_t
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_clear_errors();
 	hipStream_t st = c->stream;
-	Survivors& v = s->local_sv;
+	SurvivorsG& v = s->local_sv;
 	if (s->n_pend) {
 		if (!d_replies) { vdjx_set_error("vdjx_shard_resolve: NULL buffer"); return VDJX_EINVAL; }
 		const u32 nr = (u32) n_replies;
-		SurvOut so{v.lo, v.hi, v.gcnt, v.gfirst, v.ucnt, v.ufirst, s->n_surv, s->sv_cap};
+		SurvOutG so{v.lo, v.hi, v.gcnt, v.gfirst, s->n_surv, s->sv_cap};
 		vdjx_prof_scope ps(c, "k_shard_resolve");
 		hipLaunchKernelGGL(k_resolve_first, dim3((nr + 255) / 256), dim3(256), 0, st, (const uint8_t*) d_replies, nr, s->po.mg, s->p_r0);
 		hipLaunchKernelGGL(k_resolve_add, dim3((nr + 255) / 256), dim3(256), 0, st, (const uint8_t*) d_replies, nr, s->p_r0, s->k, s->p_fl, s->p_S);
@@ -3357,56 +2290,44 @@ extern "C" int vdjx_shard_resolve(vdjx_shard* s, const void* d_replies, uint64_t
 	return VDJX_OK;
 }
 
-// this rank's survivors as 32-byte records {key_lo, key_hi, gated count, gated first, count, first}
+// this rank's survivors as 32-byte records {key_lo, key_hi, gated count, -, gated first (u64)}
 extern "C" int vdjx_shard_survivors(vdjx_shard* s, void* d_out) {
 	if (!s || s->phase < 3) { vdjx_set_error("vdjx_shard_survivors: call vdjx_shard_resolve first"); return VDJX_ESTATE; }
-	const Survivors& v = s->local_sv;
+	const SurvivorsG& v = s->local_sv;
 	if (!v.n) return VDJX_OK;
 	if (!d_out) { vdjx_set_error("vdjx_shard_survivors: NULL buffer"); return VDJX_EINVAL; }
 	HIP_TRY(hipSetDevice(s->c->device));
 	vdjx_clear_errors();
-	hipLaunchKernelGGL(k_surv_pack, dim3((v.n + 255) / 256), dim3(256), 0, s->c->stream, v.lo, v.hi, v.gcnt, v.gfirst, v.ucnt, v.ufirst, v.n, (SurvRec*) d_out);
+	hipLaunchKernelGGL(k_surv_pack, dim3((v.n + 255) / 256), dim3(256), 0, s->c->stream, v.lo, v.hi, v.gcnt, v.gfirst, v.n, (SurvRec*) d_out);
 	HIP_TRY(hipStreamSynchronize(s->c->stream));
 	HIP_TRY(hipGetLastError());
 	return VDJX_OK;
 }
 
-// every rank: all survivors (rank order) + local edge pass into caller arrays [ns_total*4] (to be MIN-reduced over ranks)
-// and this rank's share of the recount: d_ucnt (to be SUMmed) and d_ufirst (to be MIN-reduced), [ns_total] each
-extern "C" int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t ns_total, void* d_edge_first, void* d_edge_to,
-                                void* d_ucnt, void* d_ufirst) {
+// every rank: all survivors (rank order) -> this rank's share of add_to_graph's bookkeeping over ITS records (A2:261-320):
+// d_in_first u64 [ns_total*4] (first sight of the in-edge (v, first base of u), global instance id, all-ones = none),
+// d_ufirst u64 [ns_total] (first sight of the node), d_ucnt u32 [ns_total] (instances); the caller reduces over ranks:
+// MIN (unsigned order) for d_in_first and d_ufirst, SUM for d_ucnt
+extern "C" int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t ns_total, void* d_in_first, void* d_ucnt, void* d_ufirst) {
 	if (!s || s->phase < 3) { vdjx_set_error("vdjx_shard_edges: call vdjx_shard_resolve first"); return VDJX_ESTATE; }
-	if (ns_total >= (1ull << 30)) { vdjx_set_error("vdjx_shard_edges: too many survivors"); return VDJX_ELIMIT; }
+	if (ns_total >= (1ull << 26)) { vdjx_set_error("vdjx_shard_edges: too many survivors"); return VDJX_ELIMIT; }
 	vdjx_ctx* c = s->c;
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_clear_errors();
 	PersistAlloc db(c);
-	Survivors& a = s->all_sv;
+	SurvivorsG& a = s->all_sv;
 	a.n = (u32) ns_total;
 	s->phase = 4;
 	if (!ns_total) return VDJX_OK;
-	if (!d_surv_all || !d_edge_first || !d_edge_to || !d_ucnt || !d_ufirst) { vdjx_set_error("vdjx_shard_edges: NULL buffer"); return VDJX_EINVAL; }
-	HIP_TRY(db.alloc(&a.lo, a.n)); HIP_TRY(db.alloc(&a.hi, a.n)); HIP_TRY(db.alloc(&a.gcnt, a.n));
-	HIP_TRY(db.alloc(&a.gfirst, a.n)); HIP_TRY(db.alloc(&a.ucnt, a.n)); HIP_TRY(db.alloc(&a.ufirst, a.n));
-	hipLaunchKernelGGL(k_surv_unpack, dim3((a.n + 255) / 256), dim3(256), 0, c->stream, (const SurvRec*) d_surv_all, a.n, a.lo, a.hi, a.gcnt,
-	                   a.gfirst, a.ucnt, a.ufirst);
-	const RecountSrc rs{s->sparse_a, s->t_bucket_start, s->nd_a, s->NBf, (u32*) d_ucnt, (u32*) d_ufirst};
-	int rc = stage_edges(c, db, s->pool, s->rec_stride * (u32) s->rank, s->k, a, (u32*) d_edge_first, (u32*) d_edge_to, &rs);
-	if (rc) return rc;
-	HIP_TRY(hipStreamSynchronize(c->stream));
-	HIP_TRY(hipGetLastError());
-	return VDJX_OK;
+	if (!d_surv_all || !d_in_first || !d_ucnt || !d_ufirst) { vdjx_set_error("vdjx_shard_edges: NULL buffer"); return VDJX_EINVAL; }
+	HIP_TRY(db.alloc(&a.lo, a.n)); HIP_TRY(db.alloc(&a.hi, a.n)); HIP_TRY(db.alloc(&a.gcnt, a.n)); HIP_TRY(db.alloc(&a.gfirst, a.n));
+	hipLaunchKernelGGL(k_surv_unpack, dim3((a.n + 255) / 256), dim3(256), 0, c->stream, (const SurvRec*) d_surv_all, a.n, a.lo, a.hi, a.gcnt, a.gfirst);
+	RecountOut ro{(u32*) d_ucnt, (u64*) d_ufirst, (u64*) d_in_first, nullptr, nullptr, nullptr};
+	return stage_recount(c, db, s->pool, s->rec_stride * (u64) s->rank, s->k, a.lo, a.hi, a.n, ro, false, &s->tb);
 }
 
-__global__ void k_recount_set(const u32* __restrict__ ucnt_sum, const u32* __restrict__ ufirst_min, u32 n, u32* __restrict__ ucnt, u32* __restrict__ ufirst) {
-	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	ucnt[i] = ucnt_sum[i] > CNT_CAP ? CNT_CAP : ucnt_sum[i];         // A2:261-265
-	ufirst[i] = ufirst_min[i];
-}
-
-// every rank: reduced edge and recount arrays -> the graph (identical on all ranks)
-extern "C" int vdjx_shard_finish(vdjx_shard* s, const void* d_edge_first, const void* d_edge_to, const void* d_ucnt, const void* d_ufirst,
+// every rank: the reduced arrays -> the graph (identical on all ranks)
+extern "C" int vdjx_shard_finish(vdjx_shard* s, const void* d_in_first, const void* d_ucnt, const void* d_ufirst,
                                  uint64_t pre_nodes_total, vdjx_graph** out) {
 	if (!s || !out || s->phase < 4) { vdjx_set_error("vdjx_shard_finish: call vdjx_shard_edges first"); return VDJX_ESTATE; }
 	*out = nullptr;
@@ -3415,15 +2336,22 @@ extern "C" int vdjx_shard_finish(vdjx_shard* s, const void* d_edge_first, const 
 	vdjx_clear_errors();
 	PersistAlloc db(c);
 	const int P = s->pool->rl - s->k + 1;
-	const size_t NI = (size_t) s->rec_stride * s->nranks * (size_t) P;
-	Survivors& a = s->all_sv;
+	SurvivorsG& a = s->all_sv;
+	RecountOut ro{};
 	if (a.n) {
-		if (!d_ucnt || !d_ufirst) { vdjx_set_error("vdjx_shard_finish: NULL buffer"); return VDJX_EINVAL; }
-		hipLaunchKernelGGL(k_recount_set, dim3((a.n + 255) / 256), dim3(256), 0, c->stream, (const u32*) d_ucnt, (const u32*) d_ufirst, a.n, a.ucnt, a.ufirst);
+		if (!d_ucnt || !d_ufirst || !d_in_first) { vdjx_set_error("vdjx_shard_finish: NULL buffer"); return VDJX_EINVAL; }
+		a.ucnt = (u32*) d_ucnt;
+		a.ufirst = (u64*) d_ufirst;
+		ro.ucnt = a.ucnt; ro.ufirst = a.ufirst; ro.in_first = (u64*) d_in_first;
+		HIP_TRY(db.alloc(&ro.in_from, (size_t) a.n * 4));
+		HIP_TRY(db.alloc(&ro.edge_first, (size_t) a.n * 4));
+		HIP_TRY(db.alloc(&ro.edge_to, (size_t) a.n * 4));
+		HIP_TRY(hipMemsetAsync(ro.edge_first, 0xFF, (size_t) a.n * 32, c->stream));
+		hipLaunchKernelGGL(k_edges_from_in, dim3((a.n * 4 + 255) / 256), dim3(256), 0, c->stream, s->tb, a.n, s->k, ro.in_first, ro.in_from, ro.edge_first, ro.edge_to);
 	}
 	vdjx_graph* g = new vdjx_graph();
 	g->pre_nodes = (size_t) pre_nodes_total;
-	int rc = stage_finish(c, db, a, (const u32*) d_edge_first, (const u32*) d_edge_to, NI, s->k, P, g);
+	int rc = stage_finish2(c, db, a, ro, s->rec_stride * (u64) s->nranks, s->k, P, g);
 	if (rc) { vdjx_graph_free(g); return rc; }
 	*out = g;
 	return VDJX_OK;

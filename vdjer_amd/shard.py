@@ -6,15 +6,16 @@ stride: rank r's records are [r*stride, r*stride + R_r), which is also the scan 
 union pool, so "first instance" means the same thing as in a single-process run over the concatenation.
 
 Phases (the engine does the compute, this module only moves bytes):
-  1. every rank aggregates ITS instances per distinct k-mer: gated/ungated count, gated/ungated first instance,
-     "saw two different reads" (add_to_table A2:322-367 restated per rank)          -- no communication
-  2. ONE bulk all-to-all: the partial aggregates (24 B per distinct gated k-mer per rank, NOT per instance) go to the
+  1. every rank aggregates ITS gated instances per distinct k-mer: count, first instance, "saw two different reads"
+     (add_to_table A2:322-367 restated per rank)                                     -- no communication
+  2. ONE bulk all-to-all: the partial aggregates (32 B per distinct gated k-mer per rank, NOT per instance) go to the
      owner of the k-mer = top log2(G) bits of its hash, with a per-bucket directory
   3. the owner merges (counts add, firsts take the minimum, flags OR) and decides almost every k-mer; the few whose
      verdict needs per-read data (flag still open although several ranks hold the k-mer; count so low that the
-     quality sums matter) cost a question (8 B) to the holders and an answer (192 B): two tiny all-to-alls
-  4. all_gather of the survivors (32 B each); local edge pass and local recount of the survivors' instances
-     (add_to_graph, A2:261-309); all_reduce MIN (edge first sights, first instances) and SUM (counts)
+     quality sums matter) cost a question (8 B) to the holders and an answer (200 B): two tiny all-to-alls
+  4. all_gather of the survivors (32 B each); every rank walks ITS records for add_to_graph's bookkeeping of all
+     survivors (A2:261-320: node frequency, first sights of nodes and in-edges); all_reduce MIN (first sights, 64-bit
+     instance ids) and SUM (counts)
   5. every rank numbers the nodes and orders the edge lists (identical result on all ranks)
 The read pool itself never leaves its rank.  The serial de Bruijn traversal then runs on rank 0 (north star:
 host-side, not sharded).
@@ -47,8 +48,8 @@ def _bind(L):
     L.vdjx_shard_reply.argtypes = [vp, vp, u64p, vp]
     L.vdjx_shard_resolve.argtypes = [vp, vp, C.c_uint64, u64p, u64p]
     L.vdjx_shard_survivors.argtypes = [vp, vp]
-    L.vdjx_shard_edges.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp]
-    L.vdjx_shard_finish.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(vp)]
+    L.vdjx_shard_edges.argtypes = [vp, vp, C.c_uint64, vp, vp, vp]
+    L.vdjx_shard_finish.argtypes = [vp, vp, vp, vp, C.c_uint64, C.POINTER(vp)]
     L._shard_bound = True
 
 
@@ -121,22 +122,23 @@ class HipShardEngine:
         return out
 
     def edges(self, surv_all):
-        """-> (mins, ucnt): `mins` = edge first-sight | edge target | first instance of every survivor on this rank, one int32
-        tensor [9*n] to be MIN-reduced (unsigned order); ucnt int32 [n] = this rank's instances per survivor, to be SUMmed"""
+        """-> (mins, ucnt): `mins` = first sight of every in-edge slot [4n] | first sight of every survivor [n] on this rank, one
+        int64 tensor (global instance ids, all-ones = none) to be MIN-reduced in unsigned order; ucnt int32 [n] = this rank's
+        instances per survivor, to be SUMmed"""
         t = self.torch
         n = surv_all.shape[0]
-        mins = t.empty(n * 9, dtype=t.int32, device=self.dev)
+        mins = t.empty(n * 5, dtype=t.int64, device=self.dev)
         ucnt = t.empty(n, dtype=t.int32, device=self.dev)
-        self._keep.append(surv_all)
-        check(self.L.vdjx_shard_edges(self.h, self._dp(surv_all), n, self._dp(mins[:4 * n]), self._dp(mins[4 * n:8 * n]), self._dp(ucnt),
-                                      self._dp(mins[8 * n:])), "vdjx_shard_edges")
+        self._keep += [surv_all, mins, ucnt]
+        check(self.L.vdjx_shard_edges(self.h, self._dp(surv_all), n, self._dp(mins[:4 * n]), self._dp(ucnt), self._dp(mins[4 * n:])),
+              "vdjx_shard_edges")
         return mins, ucnt
 
     def finish(self, mins, ucnt, pre_total, keep_device: bool = False, async_export: bool = False):
         g = C.c_void_p()
         n = ucnt.shape[0]
-        check(self.L.vdjx_shard_finish(self.h, self._dp(mins[:4 * n]), self._dp(mins[4 * n:8 * n]), self._dp(ucnt), self._dp(mins[8 * n:]),
-                                       pre_total, C.byref(g)), "vdjx_shard_finish")
+        check(self.L.vdjx_shard_finish(self.h, self._dp(mins[:4 * n]), self._dp(ucnt), self._dp(mins[4 * n:]), pre_total, C.byref(g)),
+              "vdjx_shard_finish")
         return self.ctx._export_graph(g, self.k, keep_device or async_export, async_export)
 
     def end(self):
@@ -224,7 +226,8 @@ class Comm:
 class ShardedHotPath:
     """Drives one sharded k-mer build over a torch.distributed process group."""
 
-    def __init__(self, ctx, dist, device, engine=None):
+    def __init__(self, ctx, dist, device, engine=None, stride=None):
+        """stride: records per rank in the global numbering (default: the largest local pool, agreed by all_reduce)"""
         import torch
         self.torch, self.dist, self.dev = torch, dist, device
         self.comm = Comm(dist, device)
@@ -232,7 +235,7 @@ class ShardedHotPath:
         if self.world & (self.world - 1):
             raise ValueError("the number of ranks must be a power of two (ownership = hash-prefix bits)")
         self.engine = engine if engine is not None else HipShardEngine(ctx, device)
-        self.stride = None
+        self.stride = stride
         self.laps = {}               # seconds per phase of kmer_build, summed over calls (host clock, diagnostic)
 
     @property
@@ -300,7 +303,7 @@ class ShardedHotPath:
             mins, ucnt = eng.edges(surv_all)
             lap("edges")
             if ucnt.numel():
-                flip = -2 ** 31       # unsigned order on int32 tensors: flip the sign bit around the MIN
+                flip = -2 ** 63       # unsigned order on int64 tensors: flip the sign bit around the MIN (all-ones = none stays largest)
                 mins.bitwise_xor_(flip)
                 cm.all_reduce(mins, dist.ReduceOp.MIN)
                 mins.bitwise_xor_(flip)
