@@ -213,13 +213,24 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--force-shard", action="store_true",
                     help="N=1 only: run the k-mer build through the multi-GPU phases (one-rank RCCL group) to time its kernels; not the line of record")
-    ap.add_argument("--windows", choices=["traversal", "generator"], default="traversal",
-                    help="scorer inputs: the candidate windows/contigs the host traversal derives from the graph (default), "
-                         "or one window per clone straight from the generator")
+    ap.add_argument("--windows", choices=["auto", "traversal", "generator"], default="auto",
+                    help="scorer inputs: the candidate windows/contigs the host traversal derives from the graph, or one window per "
+                         "clone straight from the generator.  auto = traversal up to 1.5 M pairs in all, generator above: the "
+                         "reference's contig enumeration (A2:939-1061, no path cap below 5e8 per root) explodes on this repertoire "
+                         "(60 V germlines shared by thousands of clones): 21 k contig candidates at 1 M pairs, 699 k at 2 M, and at "
+                         "10 M pairs it does not finish in an hour on 8 cores (DESIGN.md §5)")
     ap.add_argument("--parity-sample", type=int, default=20000, help="pairs of the parity gate (SURVEY §8d)")
     args = ap.parse_args()
     if args.clones <= 0:
         args.clones = max(4, args.pairs // 500)
+    if args.windows == "auto":
+        args.windows = "traversal" if args.pairs * args.gpus <= 1_500_000 else "generator"
+
+    # ONE JSON line on stdout: libraries that print banners to the process's stdout (RCCL does at its first collective) are sent to
+    # stderr; the line itself goes to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -284,26 +295,18 @@ def main():
     # built once, outside the timed region, over a pool handle that stays alive.  With several GPUs every rank
     # holds the index of the WHOLE pool (replicate the index, shard the windows: no communication).
     t_ix = time.perf_counter()
-    if world == 1:
-        p_index = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
-        ctx.read_index_build(p_index, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
-    else:
-        mine = torch.cat([d_pri, d_sec], dim=0)
-        allrec = cm.all_gather_cat(mine)
-
-        def gather_np(a, scale):
-            x = torch.from_numpy(a.astype(np.int64) + rank * scale).to(dev)
-            return cm.all_gather_cat(x).cpu().numpy()
-        g_pair = gather_np(pool.pair_id, args.pairs).astype(np.uint32)
-        g_rank = gather_np(pool.reg_rank, 4 * args.pairs).astype(np.uint32)
-        g_rnum = gather_np(pool.read_num, 0).astype(np.uint8)
-        g_rc = gather_np(pool.is_rc, 0).astype(np.uint8)
-        torch.cuda.synchronize()
-        p_index = ctx.pool_load_device(0, 0, allrec.data_ptr(), allrec.shape[0], rl)
-        ctx.read_index_build(p_index, g_pair, g_rnum, g_rc, g_rank, args.pairs * world)
-        del allrec, mine
+    # every rank indexes ITS pairs only (the pool is split by pair: both mates of a pair on one rank); windows are mapped by
+    # every rank against its own reads and the pair lists meet on the window's owner (vdjer_amd/shard.py:window_score)
+    p_index = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
+    ctx.read_index_build(p_index, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+    scorer = None
+    if engine is not None:
+        from vdjer_amd import shard as _shard
+        scorer = _shard.HipScorerEngine(ctx, dev, rl)
     host_side["read_index_build_s"] = round(time.perf_counter() - t_ix, 2)
-    scorer_src = "one window per clone from the generator"
+    scorer_src = ("one 486-nt window per clone from the generator (the window the reference derives for that clone's transcript) and, as contigs, the "
+                  "[51,411) slices of the windows the coverage test accepts; the host traversal is not run at this size: its contig "
+                  "enumeration explodes combinatorially on this repertoire (see --windows)")
     if args.windows == "traversal":
         # the windows the reference would hand to quick_map/coverage for THIS pool: run the serial host stage once,
         # outside the timed region, and keep what it asked the scorers (identical on every rank)
@@ -313,6 +316,9 @@ def main():
         p0.free()
         prm = host.make_params("IGH", ins=args.ins, k=args.k, mf=args.mf, mq=args.mq, mrs=args.mrs, rl=rl)
         rs_fn, ws_fn, _ = host.gpu_hooks(ctx, None, None, prm)
+        if engine is not None:          # the scorer of the sharded job (every rank runs the traversal: identical results)
+            def ws_fn(w, _ins=args.ins):          # noqa: F811
+                return engine.window_score(scorer, w, _ins)[0]
         asked = []
 
         def ws_capture(w):
@@ -336,8 +342,10 @@ def main():
             libs_w = [w for r in range(world) for w in synth.make_repertoire(args.clones, seed=args.seed + 15485863 * r).windows() if w]
         wins = libs_w
         contigs_fixed = None
-    my_wins = wins[rank::world]
-    my_contigs = contigs_fixed[rank::world] if contigs_fixed is not None else None
+    # one GPU: all windows / contigs.  Several GPUs: every rank maps ALL of them against its own reads (the k-mer instances and
+    # the reads are sharded, not the windows)
+    my_wins = wins
+    my_contigs = contigs_fixed
     my_wins_packed = ctx.pin_strings(my_wins, "windows")
     my_contigs_packed = ctx.pin_strings(my_contigs, "contigs") if my_contigs else None
 
@@ -367,7 +375,10 @@ def main():
         # is still crossing PCIe; rank r takes roots r, r+world, ...
         root_ids, ok = ctx.root_score_graph(g, args.mrs, rank, world)
         t = lap("root_score", t)
-        valid, npairs = ctx.window_score(my_wins_packed, args.ins)
+        if engine is None:
+            valid, npairs = ctx.window_score(my_wins_packed, args.ins)
+        else:
+            valid, npairs = engine.window_score(scorer, my_wins_packed, args.ins)
         t = lap("window_score", t)
         contigs = my_contigs if my_contigs is not None else [w[51:411] for w, v in zip(my_wins, valid) if v]
         # the mapped pairs (20 B each) cross PCIe on the copy stream while the next step's kernels run; they are waited for before
@@ -377,9 +388,8 @@ def main():
         g.wait()                     # the graph arrays are on the host
         g.free()
         t = lap("graph_copy_wait", t)
-        if world > 1:      # every rank learns every verdict (a few KB)
+        if world > 1:      # every rank learns every root verdict (a few KB); the window verdicts already are global
             ok = np.concatenate(gather_bytes(ok))
-            valid = np.concatenate(gather_bytes(valid))
             t = lap("gather_results", t)
         state.update(nodes=g.n, pre=g.pre_nodes, roots=int(g.n_roots), roots_ok=int(ok.sum()), windows=len(wins),
                      valid=int(valid.sum()), contigs=len(contigs) if world == 1 else None, mapped_this_rank=int(pairs.shape[0]),
@@ -496,7 +506,8 @@ def main():
                                                                     "kept_after_answers")} if engine else None),
         "parity_gate": parity,
     }
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

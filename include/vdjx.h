@@ -155,6 +155,20 @@ typedef struct {
 int vdjx_window_score(vdjx_ctx* ctx, const char* windows, size_t n, int len, const vdjx_cov_params* p,
                       uint8_t* out_valid, uint32_t* out_npairs);
 
+/* The two halves of vdjx_window_score, for a read index that holds only this rank's share of the pairs (multi-GPU: the pool is
+ * split BY PAIR, both mates of a pair on one rank).  Every rank maps every window against its own reads:
+ *   vdjx_window_pairs        out_entries[i] = entries of window i's pair list (identical read pairs are one entry with a
+ *                            multiplicity), out_npairs[i] = mapped pairs (quick_map3.c:223-245); the lists stay on the device
+ *   vdjx_window_pairs_fetch  the lists of the m named windows laid end to end (8 bytes per entry) into d_out: what travels
+ *                            to the ranks that own those windows
+ * and the owner of a window tests the union of what all ranks found (coverage_is_valid only counts entries, coverage.c:64-130):
+ *   vdjx_window_cover        d_lists = the lists as received: source after source, inside a source window after window;
+ *                            counts[s*n + w] = entries of window w from source s                                       */
+int vdjx_window_pairs(vdjx_ctx* ctx, const char* windows, size_t n, int len, uint32_t* out_entries, uint32_t* out_npairs);
+int vdjx_window_pairs_fetch(vdjx_ctx* ctx, const uint32_t* window_ids, size_t m, void* d_out);
+int vdjx_window_cover(vdjx_ctx* ctx, size_t n, int len, int rl, const vdjx_cov_params* p, const void* d_lists, size_t nsrc,
+                      const uint32_t* counts, uint8_t* out_valid);
+
 typedef struct {
 	uint32_t pair_id;
 	uint32_t rec1, rec2;       /* pool record (scan order) that matched for read 1 / read 2 */

@@ -244,3 +244,46 @@ class RefShardEngine:
 
     def end(self):
         pass
+
+
+class RefScorerEngine:
+    """CPU stand-in for vdjer_amd.shard.HipScorerEngine over the oracle's read index of THIS rank's pool -- TEST INFRASTRUCTURE."""
+
+    def __init__(self, pool):
+        from oracle import oracle
+        self.ix = oracle.ReadIndex(pool)
+        self.rl = pool.rl
+
+    def window_pairs(self, windows):
+        self._ln = len(windows[0]) if windows else 0
+        self.lists = []
+        for w in windows:
+            pairs, _ = self.ix.quick_map(w)
+            self.lists.append(np.array([(1 << 32) | (int(q["pos1"]) << 16) | int(q["pos2"]) for q in pairs], dtype=np.int64))
+        ent = np.array([x.shape[0] for x in self.lists], np.uint32)
+        return ent, ent.copy()
+
+    def window_fetch(self, window_ids, total):
+        parts = [self.lists[int(i)] for i in window_ids]
+        return torch.from_numpy(np.concatenate(parts) if parts else np.zeros(0, np.int64))
+
+    def window_cover(self, n, lists, nsrc, counts, ins, **cov):
+        a = lists.numpy()
+        counts = np.asarray(counts).reshape(nsrc, n)
+        per = [[] for _ in range(n)]
+        at = 0
+        for s in range(nsrc):
+            for w in range(n):
+                c = int(counts[s, w])
+                per[w].append(a[at:at + c])
+                at += c
+        out = np.zeros(n, np.uint8)
+        for w in range(n):
+            x = np.concatenate(per[w]) if per[w] else np.zeros(0, np.int64)
+            st = []
+            for e in x:
+                m, p1, p2 = int(e) >> 32, (int(e) >> 16) & 0xFFFF, int(e) & 0xFFFF
+                st += [(p1, p2), (p2, p1)] * m
+            st = np.array(sorted(st), dtype=np.int32).reshape(-1, 2)
+            out[w] = self.ix.coverage_is_valid(st, self._ln, ins, **cov)
+        return out

@@ -45,6 +45,25 @@ def test_vdjer_cli_matches_reference(tag, tmp_path):
     assert (tmp_path / "vdjer.dot").read_text() == G.text(f"{tag}.dot.gz")
 
 
+@pytest.mark.parametrize("tag", ["e2e_mixed", "e2e_k25"])
+def test_vdjer_cli_sharded_build_one_rank_rccl(tag, tmp_path):
+    """`vdjer --gpus N` drives the sharded k-mer build from C over RCCL (vdjer_amd/csrc/host/vdjx_mgpu.c).  The box has one GPU:
+    VDJX_FORCE_MGPU=1 sends --gpus 1 through the same code (a real one-rank communicator, every exchange a send to itself);
+    the outputs must still be the reference's bytes."""
+    exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
+    c = G.Case(tag)
+    info = G.manifest()["e2e"][tag]
+    _write_inputs(c, str(tmp_path))
+    cmd = [exe, "--in", "reads.txt", "--chain", "IGH", "--ref-dir", "ref", "--ins", "175", "--t", "2", "--gpus", "1"] + info["flags"]
+    env = dict(os.environ, VDJX_FORCE_MGPU="1")
+    r = subprocess.run(cmd, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "k-mer table sharded over 1 GPUs" in r.stderr
+    assert (tmp_path / "vdj_contigs.fa").read_text() == G.text(f"{tag}.contigs.fa.gz")
+    assert r.stdout == G.text(f"{tag}.sam.gz")
+    assert (tmp_path / "vdjer.dot").read_text() == G.text(f"{tag}.dot.gz")
+
+
 def test_cli_rejects_bad_input(tmp_path):
     exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
     r = subprocess.run([exe, "--in", "nope", "--chain", "IGH", "--ref-dir", ".", "--ins", "175"], cwd=tmp_path,

@@ -475,7 +475,7 @@ def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq, stride):
         assert all(p_.n_records == per for p_ in pools)
         rec = ref.first_inst >> np.uint64(6)
         exp_first = (((rec // np.uint64(per)) * np.uint64(stride) + rec % np.uint64(per)) << np.uint64(6)) | (ref.first_inst & np.uint64(63))
-        assert int(exp_first.max()) >= 1 << 32
+        assert (stride * (world - 1)) << 6 >= 1 << 32          # the later ranks' instance ids do not fit 32 bits
     for g in out:
         assert g.n == ref.n and g.pre_nodes == ref.pre_nodes
         np.testing.assert_array_equal(g.first_inst, exp_first)
@@ -589,3 +589,52 @@ def test_sharded_build_real_rccl_world1(ctx):
         p.free()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_window_scorer_ranks_as_threads(ctx, world):
+    """The window scorer over a pool sharded BY PAIR (vdjer_amd/shard.py:window_score + the HIP halves vdjx_window_pairs / _fetch /
+    vdjx_window_cover), `world` ranks as threads on this GPU: verdicts and pair counts equal the single-GPU scorer over the whole
+    pool, which equals the oracle."""
+    import threading
+    import torch
+    from oracle import oracle
+    from tests.fake_dist import ThreadDist
+    from tests.test_shard_gloo import _pair_share, _scorer_case
+    from vdjer_amd import api, shard
+    pool, wins = _scorer_case()
+    p = ctx.pool_load(pool.primary, pool.secondary, pool.rl)
+    ctx.read_index_build(p, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+    valid1, np1 = ctx.window_score(wins, 175)
+    ix = oracle.ReadIndex(pool)
+    for i, w in enumerate(wins):
+        pairs, starts = ix.quick_map(w)
+        assert int(np1[i]) == len(pairs) and int(valid1[i]) == ix.coverage_is_valid(starts, len(w), 175)
+    assert 0 < int(valid1.sum()) < len(wins)
+    dist, out, errs = ThreadDist(world), [None] * world, []
+
+    def work(r):
+        try:
+            dist.set_rank(r)
+            c = api.Context(0)
+            mine = _pair_share(pool, r, world)
+            pr = c.pool_load(mine.primary, mine.secondary, mine.rl)
+            c.read_index_build(pr, mine.pair_id, mine.read_num, mine.is_rc, mine.reg_rank, mine.n_pairs)
+            drv = shard.ShardedHotPath(c, dist, torch.device("cuda", 0))
+            out[r] = drv.window_score(shard.HipScorerEngine(c, torch.device("cuda", 0), mine.rl), wins, 175)
+            pr.free()
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            dist.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for valid, npairs in out:
+        np.testing.assert_array_equal(valid, valid1)
+        np.testing.assert_array_equal(npairs, np1)
+    p.free()

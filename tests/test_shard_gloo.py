@@ -107,3 +107,74 @@ def test_sharded_driver_world2_gloo(k, mf, mq):
     assert 0 < sum(x["flag_set_by_answers"] for x in st) < sum(x["open_flag"] for x in st)
     gc = {int(f): int(c) for f, c in zip(first, count)}
     assert sorted(res[0][5]) == sorted(gc.values())
+
+
+def _score_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from tests.shard_ref_engine import RefScorerEngine
+    from vdjer_amd import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pool, wins = _scorer_case()
+        mine = _pair_share(pool, rank, world)
+        drv = shard.ShardedHotPath(None, dist, torch.device("cpu"), engine=object())
+        valid, npairs = drv.window_score(RefScorerEngine(mine), wins, 175)
+        q.put((rank, valid.tolist(), npairs.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _scorer_case():
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(3, seed=11)
+    pool = synth.tile_reads(rep, [0, 1], copies=2)
+    noisy = synth.make_reads(rep, 400, noise_frac=0.1, seed=3)
+    import dataclasses
+    # dense tiling of two clones (valid windows) + a thin random sample of all three (invalid ones)
+    pool = dataclasses.replace(pool, primary=np.concatenate([pool.primary, noisy.primary, noisy.secondary]),
+                               pair_id=np.concatenate([pool.pair_id, noisy.pair_id + pool.n_pairs]),
+                               read_num=np.concatenate([pool.read_num, noisy.read_num]), is_rc=np.concatenate([pool.is_rc, noisy.is_rc]),
+                               reg_rank=np.arange(pool.n_records + noisy.n_records, dtype=np.uint32), n_pairs=pool.n_pairs + noisy.n_pairs)
+    wins = [w for w in rep.windows() if w]
+    return pool, wins + [w[::-1] for w in wins[:1]]
+
+
+def _pair_share(pool, rank, world):
+    """the records of the pairs p with p % world == rank, in pool order (both mates of a pair stay together)"""
+    from vdjer_amd import synth
+    sel = np.flatnonzero(pool.pair_id % world == rank)
+    allrec = np.concatenate([pool.primary, pool.secondary])
+    return synth.ReadPool(pool.rl, allrec[sel], np.zeros((0, allrec.shape[1]), np.uint8), pool.pair_id[sel], pool.read_num[sel], pool.is_rc[sel],
+                          np.arange(sel.shape[0], dtype=np.uint32), pool.n_pairs)
+
+
+def test_sharded_window_scorer_world2_gloo():
+    """every rank maps all windows against ITS pairs, the lists meet on the window's owner: same verdicts and pair counts as the
+    oracle over the whole pool"""
+    import torch.multiprocessing as mp
+    from oracle import oracle
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_score_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pool, wins = _scorer_case()
+    ix = oracle.ReadIndex(pool)
+    exp_valid, exp_np = [], []
+    for w in wins:
+        pairs, starts = ix.quick_map(w)
+        exp_np.append(len(pairs))
+        exp_valid.append(ix.coverage_is_valid(starts, len(w), 175))
+    assert sum(exp_valid) >= 1 and sum(exp_valid) < len(wins)
+    for r in res:
+        assert r[1] == exp_valid and r[2] == exp_np

@@ -301,6 +301,30 @@ class Context:
         check(self.L.vdjx_window_score(self.h, raw, n, ln, C.byref(cp), _p(valid), _p(npairs)), "vdjx_window_score")
         return valid, npairs
 
+    # ---- the halves of window_score for a pool sharded by pair over several GPUs (vdjer_amd/shard.py drives them)
+    def window_pairs(self, windows):
+        """-> (entries per window's pair list, mapped pairs per window); the lists stay on the device for window_pairs_fetch"""
+        raw, n, ln = windows if isinstance(windows, tuple) else self.pack_strings(windows)
+        ent, npairs = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        if n:
+            check(self.L.vdjx_window_pairs(self.h, raw, n, ln, _p(ent), _p(npairs)), "vdjx_window_pairs")
+        return ent, npairs
+
+    def window_pairs_fetch(self, window_ids, d_out: int):
+        ids = _c(window_ids, np.uint32)
+        check(self.L.vdjx_window_pairs_fetch(self.h, _p(ids), ids.shape[0], C.c_void_p(d_out)), "vdjx_window_pairs_fetch")
+
+    def window_cover(self, n: int, ln: int, rl: int, d_lists: int, nsrc: int, counts, ins: int, e0: int = 52, e1: int = 411, rs: int = 35,
+                     ms: int = 48, floor: int = 1) -> np.ndarray:
+        """counts [nsrc, n] (source-major) entries per source and window; d_lists: device pointer to the lists in that order"""
+        cnt = _c(counts, np.uint32).reshape(-1)
+        assert cnt.shape[0] == nsrc * n
+        cp = CovParams(e0, e1, rs, ms, ins, ins, floor)
+        valid = np.zeros(n, np.uint8)
+        if n:
+            check(self.L.vdjx_window_cover(self.h, n, ln, rl, C.byref(cp), C.c_void_p(d_lists), nsrc, _p(cnt), _p(valid)), "vdjx_window_cover")
+        return valid
+
     def map_emit(self, contigs, async_copy: bool = False):
         """async_copy: the pairs travel to the host on the copy stream while the caller goes on (two alternating pinned result
         buffers); they are valid after map_emit_wait(), which the next map_emit call also performs"""

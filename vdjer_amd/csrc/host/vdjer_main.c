@@ -24,6 +24,9 @@
 #include "sph.h"
 #include "vdjh.h"
 #include "bamx.h"
+#include "vdjx_mgpu.h"
+#include <sys/wait.h>
+#include <unistd.h>
 
 typedef struct {
 	vdjh_params hp;
@@ -31,6 +34,7 @@ typedef struct {
 	char v_anchors[4096], j_anchors[4096], source_sim_file[4096], vdj_fasta[4096];
 	char v_region[64], c_region[64];       /* set_chain_info, params.c:8-35 (hg38 coordinates); --vr / --cr override */
 	int anchor_mismatches, threads;
+	int gpus;                              /* --gpus N (not in the reference): the k-mer build sharded over N GPUs of this node */
 	int have_chain, have_ref;
 } cli;
 
@@ -42,7 +46,8 @@ static void usage(void) {
 	                "\t--ins <expected / median insert length>\n\t--rf <read filter floor (default: 1)\n\t--k <kmer size (default: 35)>\n"
 	                "\t--vk <vregion kmer size (default: 15)>\n\t--mrs <min source node homology score (default: 30)\n"
 	                "\t--rs <read span distance (default: 35)>\n\t--ms <mate span distance (default: 48)>\n"
-	                "\t--e0/--e1 <start/stop position for contig filtering (default: 52/411)>\n\t--wo <window overlap check size>\n");
+	                "\t--e0/--e1 <start/stop position for contig filtering (default: 52/411)>\n\t--wo <window overlap check size>\n"
+	                "\t--gpus <GPUs of this node to shard the k-mer table over (power of two, default: 1)>\n");
 }
 
 static int file_exists(const char* f) { struct stat b; return stat(f, &b) == 0; }
@@ -53,6 +58,7 @@ static int parse(int argc, char** argv, cli* c) {
 	vdjh_default_params(&c->hp);
 	c->anchor_mismatches = 4;
 	c->threads = 1;
+	c->gpus = 1;
 	for (int i = 1; i < argc; i += 2) {
 		const char* a = argv[i];
 		if (!strcmp(a, "--help")) { usage(); exit(0); }
@@ -78,6 +84,7 @@ static int parse(int argc, char** argv, cli* c) {
 		else if (!strcmp(a, "--mq")) c->hp.min_base_quality = atoi(v);
 		else if (!strcmp(a, "--mcs")) c->hp.min_contig_score = (float) atof(v);
 		else if (!strcmp(a, "--t")) c->threads = atoi(v);
+		else if (!strcmp(a, "--gpus")) c->gpus = atoi(v);
 		else if (!strcmp(a, "--vf")) snprintf(c->v_anchors, sizeof c->v_anchors, "%s", v);
 		else if (!strcmp(a, "--jf")) snprintf(c->j_anchors, sizeof c->j_anchors, "%s", v);
 		else if (!strcmp(a, "--am")) c->anchor_mismatches = atoi(v);
@@ -118,7 +125,9 @@ static int parse(int argc, char** argv, cli* c) {
 }
 
 static time_t t_start, t_prev;
+static int g_rank;                             /* --gpus N: only rank 0 writes the stage log */
 static void status(const char* desc) {         /* status.c:22-32 without the /proc dumps */
+	if (g_rank) return;
 	time_t now = time(NULL);
 	fprintf(stderr, "ELAPSED_SECS\t%s\t%ld\t%ld\n", desc, (long) (now - t_start), (long) (now - t_prev));
 	t_prev = now;
@@ -359,11 +368,35 @@ static void h_status(void* ud, const char* desc) { (void) ud; status(desc); }
 
 #define VX(call) do { if ((call) != 0) { fprintf(stderr, "%s: %s\n", #call, vdjx_last_error()); return 1; } } while (0)
 
+/* records [a, b) of the scan order (primary pool, then secondary) as one contiguous block */
+static uint8_t* slice_records(const reads_t* r, size_t a, size_t b) {
+	const size_t rec = 2 * (size_t) r->rl + 1;
+	uint8_t* out = (uint8_t*) malloc((b > a ? b - a : 1) * rec);
+	for (size_t i = a; i < b; i++)
+		memcpy(out + (i - a) * rec, i < r->n_primary ? r->primary + i * rec : r->secondary + (i - r->n_primary) * rec, rec);
+	return out;
+}
+
 int main(int argc, char** argv) {
 	t_start = t_prev = time(NULL);
-	status("START");
 	cli c;
 	if (parse(argc, argv, &c)) return 255;                  /* the reference exits with -1 */
+	/* --gpus N: one process per GPU.  The parent is rank 0 and does everything a single-GPU run does; ranks 1..N-1 are forked
+	 * BEFORE anything touches a GPU, take part in the sharded k-mer build with their slice of the pool, and leave. */
+	int rank = 0;
+	int id_pipe[256][2];
+	pid_t kids[256];
+	if (c.gpus < 1 || c.gpus > 256 || (c.gpus & (c.gpus - 1))) { fprintf(stderr, "--gpus must be a power of two in [1,256]\n"); return 255; }
+	for (int r = 1; r < c.gpus; r++) {
+		if (pipe(id_pipe[r])) { perror("pipe"); return 255; }
+		fflush(stdout); fflush(stderr);
+		const pid_t pid = fork();
+		if (pid < 0) { perror("fork"); return 255; }
+		if (pid == 0) { rank = r; g_rank = r; close(id_pipe[r][1]); break; }
+		kids[r] = pid;
+		close(id_pipe[r][0]);
+	}
+	if (rank == 0) status("START");
 	reads_t rd;
 	if (load_reads(&c, &rd)) return 255;
 	c.hp.read_length = rd.rl;
@@ -380,20 +413,57 @@ int main(int argc, char** argv) {
 	if (load_vregion(c.source_sim_file, &vlines, &nvl)) return 255;
 
 	vdjx_ctx* gx = NULL;
-	VX(vdjx_init(0, &gx));
+	VX(vdjx_init(rank, &gx));                               /* rank r drives GPU r */
+	vdjx_mgpu* mg = NULL;
+	const int use_mgpu = c.gpus > 1 || getenv("VDJX_FORCE_MGPU") != NULL;      /* (the variable: a one-rank RCCL run of the same code path) */
+	if (use_mgpu) {
+		unsigned char id[VDJX_MGPU_ID_BYTES];
+		if (rank == 0) {
+			if (vdjx_mgpu_unique_id(id)) { fprintf(stderr, "%s\n", vdjx_mgpu_last_error()); return 1; }
+			for (int r = 1; r < c.gpus; r++) { if (write(id_pipe[r][1], id, sizeof id) != (ssize_t) sizeof id) { perror("write"); return 1; } close(id_pipe[r][1]); }
+		} else {
+			if (read(id_pipe[rank][0], id, sizeof id) != (ssize_t) sizeof id) { fprintf(stderr, "rank %d: no RCCL id from rank 0\n", rank); return 1; }
+			close(id_pipe[rank][0]);
+		}
+		if (vdjx_mgpu_init(rank, c.gpus, rank, id, &mg)) { fprintf(stderr, "rank %d: %s\n", rank, vdjx_mgpu_last_error()); return 1; }
+	}
 	VX(vdjx_anchor_sets_load(gx, vc, nv, jc, nj));
 	VX(vdjx_vregion_load(gx, (const char* const*) vlines, nvl, c.hp.vregion_kmer_size));
 	status("POST_VJF_INIT");
 
 	vdjx_pool* px = NULL;
-	VX(vdjx_pool_load(gx, rd.primary, rd.n_primary, rd.secondary, rd.n_secondary, rd.rl, &px));
-	VX(vdjx_read_index_build(gx, px, rd.pair_id, rd.read_num, rd.is_rc, rd.reg_rank, rd.n_pairs));
-	status("POST_READ_EXTRACT");
-
-	fprintf(stderr, "Assembling...\n");
+	if (rank == 0) {                            /* the read index (and with it the scorers) lives on rank 0's GPU: the whole pool */
+		VX(vdjx_pool_load(gx, rd.primary, rd.n_primary, rd.secondary, rd.n_secondary, rd.rl, &px));
+		VX(vdjx_read_index_build(gx, px, rd.pair_id, rd.read_num, rd.is_rc, rd.reg_rank, rd.n_pairs));
+		status("POST_READ_EXTRACT");
+		fprintf(stderr, "Assembling...\n");
+	}
 	vdjx_graph* gg = NULL;
-	status("PRE_PRE_GRAPH1");                  /* A2:1387 */
-	VX(vdjx_kmer_build(gx, px, c.hp.k, c.hp.min_node_freq, c.hp.min_base_quality, &gg));
+	if (rank == 0) status("PRE_PRE_GRAPH1");   /* A2:1387 */
+	if (!use_mgpu) {
+		VX(vdjx_kmer_build(gx, px, c.hp.k, c.hp.min_node_freq, c.hp.min_base_quality, &gg));
+	} else {
+		/* rank r holds records [r*S, (r+1)*S) of the scan order: the rank-major numbering of the sharded build IS the scan order */
+		const size_t Rt = rd.n_primary + rd.n_secondary;
+		const size_t S = (Rt + (size_t) c.gpus - 1) / (size_t) c.gpus;
+		const size_t a = (size_t) rank * S < Rt ? (size_t) rank * S : Rt, b = a + S < Rt ? a + S : Rt;
+		uint8_t* mine = slice_records(&rd, a, b);
+		vdjx_pool* ps = NULL;
+		VX(vdjx_pool_load(gx, mine, b - a, NULL, 0, rd.rl, &ps));
+		free(mine);
+		if (vdjx_mgpu_kmer_build(mg, gx, ps, c.hp.k, c.hp.min_node_freq, c.hp.min_base_quality, S ? S : 1, &gg)) {
+			fprintf(stderr, "rank %d: %s\n", rank, vdjx_mgpu_last_error());
+			return 1;
+		}
+		vdjx_pool_free(ps);
+		if (rank == 0) fprintf(stderr, "k-mer table sharded over %d GPUs: %llu bytes sent by rank 0\n", c.gpus, (unsigned long long) vdjx_mgpu_bytes_sent(mg));
+		vdjx_mgpu_free(mg);
+		if (rank != 0) {                        /* the graph is identical on every rank; the serial traversal runs on rank 0 */
+			vdjx_graph_free(gg);
+			vdjx_shutdown(gx);
+			return 0;
+		}
+	}
 	const size_t n = vdjx_graph_nodes(gg);
 	status("PRE_PRE_GRAPH2");                  /* A2:1389-1409: one device call made the table, the prune and the graph */
 	status("POST_PRE_GRAPH1");
@@ -422,6 +492,10 @@ int main(int argc, char** argv) {
 	}
 	fprintf(stderr, "num root nodes: %zu\nProcessed roots: %zu\ncontig_candidates: %zu\nwindows scored: %zu valid: %zu\ncontigs: %zu\n",
 	        st.n_roots, st.n_roots_accepted, st.n_contig_candidates, st.n_windows_scored, st.n_windows_valid, st.n_contigs_out);
+	for (int r = 1; r < c.gpus; r++) {
+		int st_ = 0;
+		if (waitpid(kids[r], &st_, 0) < 0 || !WIFEXITED(st_) || WEXITSTATUS(st_) != 0) { fprintf(stderr, "rank %d failed\n", r); return 1; }
+	}
 	status("FINIS");
 	fflush(stdout);
 	vdjx_graph_free(gg);

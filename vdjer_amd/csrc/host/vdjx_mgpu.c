@@ -1,0 +1,207 @@
+/*
+ * vdjx_mgpu.c -- the sharded k-mer build driven from C over RCCL (one process per GPU, xGMI): what `vdjer --gpus N` runs.
+ *
+ * The reference has no counterpart (its only parallelism is pthreads over roots, A2:1287-1348).  This is the C twin of
+ * vdjer_amd/shard.py: the compute is the vdjx_shard_* phases of libvdjx (include/vdjx.h), this file only moves their bytes
+ * between ranks.  Every exchange is ONE grouped set of ncclSend/ncclRecv (each peer on its own xGMI link):
+ *   directories (their sums ARE the receive counts) -> partial aggregates -> questions -> answers -> survivors (all-gather-v)
+ * followed by two all-reduces of the per-survivor arrays (MIN over unsigned 64-bit first sights, SUM over the counts).
+ */
+#include "vdjx_mgpu.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+struct vdjx_mgpu {
+	int rank, nranks, device;
+	ncclComm_t comm;
+	hipStream_t stream;
+	uint64_t bytes_sent;
+};
+
+static __thread char g_err[512];
+static void set_err(const char* fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+}
+const char* vdjx_mgpu_last_error(void) { return g_err; }
+
+#define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err("%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); rc = -2; goto done; } } while (0)
+#define NCCLC(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { set_err("%s: %s (%s:%d)", #x, ncclGetErrorString(r_), __FILE__, __LINE__); rc = -5; goto done; } } while (0)
+#define VX(x) do { int r_ = (x); if (r_ != 0) { set_err("%s: %s", #x, vdjx_last_error()); rc = r_; goto done; } } while (0)
+
+int vdjx_mgpu_unique_id(void* out128) {
+	ncclUniqueId id;
+	if (sizeof id > VDJX_MGPU_ID_BYTES) { set_err("ncclUniqueId is %zu bytes", sizeof id); return -1; }
+	ncclResult_t r = ncclGetUniqueId(&id);
+	if (r != ncclSuccess) { set_err("ncclGetUniqueId: %s", ncclGetErrorString(r)); return -5; }
+	memset(out128, 0, VDJX_MGPU_ID_BYTES);
+	memcpy(out128, &id, sizeof id);
+	return 0;
+}
+
+int vdjx_mgpu_init(int rank, int nranks, int device, const void* unique_id, vdjx_mgpu** out) {
+	int rc = 0;
+	*out = NULL;
+	vdjx_mgpu* m = (vdjx_mgpu*) calloc(1, sizeof *m);
+	m->rank = rank; m->nranks = nranks; m->device = device;
+	ncclUniqueId id;
+	memcpy(&id, unique_id, sizeof id);
+	HIPC(hipSetDevice(device));
+	HIPC(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+	{
+		/* RCCL prints a version banner on the process's stdout when the communicator comes up; stdout is the SAM stream: the banner
+		 * goes to stderr */
+		fflush(stdout);
+		const int saved = dup(1);
+		if (saved >= 0) (void) dup2(2, 1);
+		const ncclResult_t r_ = ncclCommInitRank(&m->comm, nranks, id, rank);
+		fflush(stdout);
+		if (saved >= 0) { (void) dup2(saved, 1); close(saved); }
+		if (r_ != ncclSuccess) { set_err("ncclCommInitRank: %s", ncclGetErrorString(r_)); rc = -5; goto done; }
+	}
+	*out = m;
+	return 0;
+done:
+	free(m);
+	return rc;
+}
+
+void vdjx_mgpu_free(vdjx_mgpu* m) {
+	if (!m) return;
+	(void) hipSetDevice(m->device);
+	if (m->comm) (void) ncclCommDestroy(m->comm);
+	if (m->stream) (void) hipStreamDestroy(m->stream);
+	free(m);
+}
+
+uint64_t vdjx_mgpu_bytes_sent(const vdjx_mgpu* m) { return m ? m->bytes_sent : 0; }
+
+/* all-to-all-v of byte rows: send[r] rows of `row` bytes to rank r (contiguous, rank order), recv likewise */
+static int a2av(vdjx_mgpu* m, const void* d_send, const uint64_t* send_rows, void* d_recv, const uint64_t* recv_rows, size_t row) {
+	int rc = 0;
+	size_t so = 0, ro = 0;
+	NCCLC(ncclGroupStart());
+	for (int r = 0; r < m->nranks; r++) {
+		if (send_rows[r]) NCCLC(ncclSend((const char*) d_send + so, send_rows[r] * row, ncclChar, r, m->comm, m->stream));
+		if (recv_rows[r]) NCCLC(ncclRecv((char*) d_recv + ro, recv_rows[r] * row, ncclChar, r, m->comm, m->stream));
+		so += send_rows[r] * row;
+		ro += recv_rows[r] * row;
+		if (r != m->rank) m->bytes_sent += send_rows[r] * row;
+	}
+	NCCLC(ncclGroupEnd());
+	HIPC(hipStreamSynchronize(m->stream));
+done:
+	return rc;
+}
+
+static uint64_t sum64(const uint64_t* v, int n) { uint64_t s = 0; for (int i = 0; i < n; i++) s += v[i]; return s; }
+
+int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, uint64_t rec_stride, vdjx_graph** out) {
+	int rc = 0;
+	const int G = m->nranks, me = m->rank;
+	vdjx_shard* sh = NULL;
+	void *d_sdir = NULL, *d_rdir = NULL, *d_sparts = NULL, *d_rparts = NULL, *d_q = NULL, *d_rq = NULL, *d_ans = NULL, *d_rans = NULL;
+	void *d_meta = NULL, *d_surv = NULL, *d_surv_all = NULL, *d_mins = NULL, *d_ucnt = NULL;
+	uint32_t* h_rdir = NULL;
+	uint64_t *send_counts = (uint64_t*) calloc((size_t) G, 8), *recv_counts = (uint64_t*) calloc((size_t) G, 8), *q_out = (uint64_t*) calloc((size_t) G, 8),
+	         *q_in = (uint64_t*) calloc((size_t) G, 8), *eq = (uint64_t*) calloc((size_t) G, 8), *meta = (uint64_t*) calloc((size_t) G * (size_t) (G + 2), 8);
+	*out = NULL;
+	const size_t W0 = vdjx_shard_record_bytes(0), W1 = vdjx_shard_record_bytes(1), W2 = vdjx_shard_record_bytes(2), W3 = vdjx_shard_record_bytes(3);
+	HIPC(hipSetDevice(m->device));
+	VX(vdjx_shard_begin(ctx, pool, k, mf, mq, me, G, rec_stride, &sh));
+	/* 1. local aggregation; 2. the bulk exchange: per-bucket directories (their sums are the receive counts), then the partials */
+	uint32_t dl = 0;
+	VX(vdjx_shard_local(sh, send_counts, &dl));
+	const size_t ndir = (size_t) G * dl;
+	HIPC(hipMalloc(&d_sdir, ndir * 4 + 16));
+	HIPC(hipMalloc(&d_rdir, ndir * 4 + 16));
+	HIPC(hipMalloc(&d_sparts, sum64(send_counts, G) * W0 + 16));
+	VX(vdjx_shard_local_fill(sh, d_sdir, d_sparts));
+	for (int r = 0; r < G; r++) eq[r] = dl;
+	if ((rc = a2av(m, d_sdir, eq, d_rdir, eq, 4))) goto done;
+	h_rdir = (uint32_t*) malloc(ndir * 4 + 4);
+	HIPC(hipMemcpy(h_rdir, d_rdir, ndir * 4, hipMemcpyDeviceToHost));
+	for (int r = 0; r < G; r++) {
+		uint64_t s = 0;
+		for (uint32_t i = 0; i < dl; i++) s += h_rdir[(size_t) r * dl + i];
+		recv_counts[r] = s;
+	}
+	HIPC(hipMalloc(&d_rparts, sum64(recv_counts, G) * W0 + 16));
+	if ((rc = a2av(m, d_sparts, send_counts, d_rparts, recv_counts, W0))) goto done;
+	/* 3. owners merge and decide; questions and answers for the few open k-mers */
+	VX(vdjx_shard_merge(sh, d_rdir, d_rparts, recv_counts, q_out));
+	/* everybody learns everybody's question counts, survivor count and distinct count in one small all-gather */
+	HIPC(hipMalloc(&d_meta, (size_t) G * (size_t) (G + 2) * 8 + 16));
+	{
+		uint64_t* mine = meta + (size_t) me * (G + 2);
+		memcpy(mine, q_out, (size_t) G * 8);
+		mine[G] = mine[G + 1] = 0;
+		HIPC(hipMemcpy((char*) d_meta + (size_t) me * (G + 2) * 8, mine, (size_t) (G + 2) * 8, hipMemcpyHostToDevice));
+		NCCLC(ncclAllGather((char*) d_meta + (size_t) me * (G + 2) * 8, d_meta, (size_t) (G + 2), ncclUint64, m->comm, m->stream));
+		HIPC(hipStreamSynchronize(m->stream));
+		HIPC(hipMemcpy(meta, d_meta, (size_t) G * (G + 2) * 8, hipMemcpyDeviceToHost));
+		for (int r = 0; r < G; r++) q_in[r] = meta[(size_t) r * (G + 2) + me];
+	}
+	HIPC(hipMalloc(&d_q, sum64(q_out, G) * W1 + 16));
+	HIPC(hipMalloc(&d_rq, sum64(q_in, G) * W1 + 16));
+	HIPC(hipMalloc(&d_ans, sum64(q_in, G) * W2 + 16));
+	HIPC(hipMalloc(&d_rans, sum64(q_out, G) * W2 + 16));
+	VX(vdjx_shard_queries(sh, d_q));
+	if ((rc = a2av(m, d_q, q_out, d_rq, q_in, W1))) goto done;
+	VX(vdjx_shard_reply(sh, d_rq, q_in, d_ans));
+	if ((rc = a2av(m, d_ans, q_in, d_rans, q_out, W2))) goto done;
+	uint64_t ns = 0, ndist = 0;
+	VX(vdjx_shard_resolve(sh, d_rans, sum64(q_out, G), &ns, &ndist));
+	/* 4. survivors everywhere (all-gather-v as sends and receives), every rank's share of add_to_graph, MIN / SUM over ranks */
+	{
+		uint64_t mine[2] = {ns, ndist};
+		HIPC(hipMemcpy((char*) d_meta + (size_t) me * 16, mine, 16, hipMemcpyHostToDevice));
+		NCCLC(ncclAllGather((char*) d_meta + (size_t) me * 16, d_meta, 2, ncclUint64, m->comm, m->stream));
+		HIPC(hipStreamSynchronize(m->stream));
+		HIPC(hipMemcpy(meta, d_meta, (size_t) G * 16, hipMemcpyDeviceToHost));
+	}
+	uint64_t ns_total = 0, pre_total = 0;
+	for (int r = 0; r < G; r++) { recv_counts[r] = meta[2 * r]; ns_total += meta[2 * r]; pre_total += meta[2 * r + 1]; send_counts[r] = ns; }
+	HIPC(hipMalloc(&d_surv, ns * W3 + 16));
+	HIPC(hipMalloc(&d_surv_all, ns_total * W3 + 16));
+	VX(vdjx_shard_survivors(sh, d_surv));
+	{
+		size_t ro = 0;
+		NCCLC(ncclGroupStart());
+		for (int r = 0; r < G; r++) {
+			if (ns) NCCLC(ncclSend(d_surv, ns * W3, ncclChar, r, m->comm, m->stream));
+			if (recv_counts[r]) NCCLC(ncclRecv((char*) d_surv_all + ro, recv_counts[r] * W3, ncclChar, r, m->comm, m->stream));
+			ro += recv_counts[r] * W3;
+			if (r != me) m->bytes_sent += ns * W3;
+		}
+		NCCLC(ncclGroupEnd());
+		HIPC(hipStreamSynchronize(m->stream));
+	}
+	HIPC(hipMalloc(&d_mins, ns_total * 5 * 8 + 16));          /* in-edge first sights [4n] | node first sights [n] */
+	HIPC(hipMalloc(&d_ucnt, ns_total * 4 + 16));
+	VX(vdjx_shard_edges(sh, d_surv_all, ns_total, d_mins, d_ucnt, (char*) d_mins + ns_total * 32));
+	if (ns_total) {
+		NCCLC(ncclAllReduce(d_mins, d_mins, ns_total * 5, ncclUint64, ncclMin, m->comm, m->stream));       /* all-ones = none stays largest */
+		NCCLC(ncclAllReduce(d_ucnt, d_ucnt, ns_total, ncclUint32, ncclSum, m->comm, m->stream));
+		HIPC(hipStreamSynchronize(m->stream));
+		m->bytes_sent += (uint64_t) (G > 1) * ns_total * 44;
+	}
+	/* 5. node numbering + list order: identical on every rank */
+	VX(vdjx_shard_finish(sh, d_mins, d_ucnt, (char*) d_mins + ns_total * 32, pre_total, out));
+done:
+	if (sh) vdjx_shard_free(sh);
+	(void) hipFree(d_sdir); (void) hipFree(d_rdir); (void) hipFree(d_sparts); (void) hipFree(d_rparts); (void) hipFree(d_q); (void) hipFree(d_rq);
+	(void) hipFree(d_ans); (void) hipFree(d_rans); (void) hipFree(d_meta); (void) hipFree(d_surv); (void) hipFree(d_surv_all); (void) hipFree(d_mins);
+	(void) hipFree(d_ucnt);
+	free(h_rdir); free(send_counts); free(recv_counts); free(q_out); free(q_in); free(eq); free(meta);
+	return rc;
+}

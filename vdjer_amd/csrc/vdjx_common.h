@@ -110,6 +110,11 @@ struct vdjx_ctx {
 	uint64_t me_key = 0;
 	void* me_pairs = nullptr;         // vdjx_pair[me_cap], per-contig regions at me_hoff
 	size_t me_cap = 0;
+	// the (weighted) mapped-pair lists of the last window batch: (multiplicity << 32 | pos1 << 16 | pos2), window i at wp_off[i]
+	void* wp_buf = nullptr;
+	size_t wp_cap = 0, wp_n = 0;
+	std::vector<u64> wp_off;
+	std::vector<u32> wp_cnt;
 	void* me_dense = nullptr;         // the pairs laid end to end for the copy to the host (kept: the copy may be asynchronous)
 	size_t me_dense_cap = 0;
 	std::vector<u64> me_hoff, me_cnt;

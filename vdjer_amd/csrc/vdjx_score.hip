@@ -1102,33 +1102,40 @@ static int plan_windows(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, cons
 	return VDJX_OK;
 }
 
-extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int len, const vdjx_cov_params* p,
-                                 uint8_t* out_valid, uint32_t* out_npairs) {
-	if (!c || !p || (n && (!windows || !out_valid || !out_npairs))) { vdjx_set_error("vdjx_window_score: NULL argument"); return VDJX_EINVAL; }
-	if (n == 0) return VDJX_OK;
-	ReadIndexDev ix;
-	int rc = make_index_view(c, &ix, len, "vdjx_window_score");
-	if (rc) return rc;
-	if (p->eval_start < 1 || p->eval_stop <= p->eval_start) { vdjx_set_error("vdjx_window_score: bad eval range"); return VDJX_EINVAL; }
-	if (p->eval_stop - p->eval_start + 1 > COV_WORDS) { vdjx_set_error("vdjx_window_score: eval range too long"); return VDJX_ELIMIT; }
-	if (n >= (1ull << 31)) { vdjx_set_error("vdjx_window_score: too many windows"); return VDJX_ELIMIT; }
-	HIP_TRY(hipSetDevice(c->device));
-	vdjx_clear_errors();
+// u64 lists laid end to end: move[i] = {source element, destination element, count}
+__global__ void k_gather_u64(const u64* __restrict__ src, const u64* __restrict__ move, u64* __restrict__ dst) {
+	const u64 so = move[3 * (size_t) blockIdx.x], dof = move[3 * (size_t) blockIdx.x + 1], cnt = move[3 * (size_t) blockIdx.x + 2];
+	for (u64 i = threadIdx.x; i < cnt; i += blockDim.x) dst[dof + i] = src[so + i];
+}
+
+static int cov_params_check(const vdjx_cov_params* p, const char* who) {
+	if (p->eval_start < 1 || p->eval_stop <= p->eval_start) { vdjx_set_error("%s: bad eval range", who); return VDJX_EINVAL; }
+	if (p->eval_stop - p->eval_start + 1 > COV_WORDS) { vdjx_set_error("%s: eval range too long", who); return VDJX_ELIMIT; }
+	return VDJX_OK;
+}
+
+// K8 over n windows: the (weighted) mapped-pair list of every window in the context's pair buffer (c->wp_*); the list of window i
+// is wp_buf[wp_off[i] .. + wp_cnt[i])
+static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, const char* windows, size_t n, int len, u32** d_np_out,
+                            u32** d_cnt_out, u64** d_off_out, u32** d_order_out) {
 	hipStream_t st = c->stream;
-	vdjx_work db(c);
 	char* d_w;
 	u32 *d_np, *d_order, *d_cnt;
-	u64 *d_off, *d_pairbuf;
-	uint8_t* d_valid;
+	u64* d_off;
 	HIP_TRY(db.alloc(&d_w, n * len));
 	HIP_TRY(db.alloc(&d_np, n));
-	HIP_TRY(db.alloc(&d_valid, n));
 	HIP_TRY(hipMemcpyAsync(d_w, windows, n * len, hipMemcpyHostToDevice, st));
-	std::vector<u64> off;
+	std::vector<u64>& off = c->wp_off;
 	u64 inst_total = 0, inst_max = 0;
-	rc = plan_windows(c, db, ix, d_w, n, len, true, off, &d_order, &d_off, &inst_total, &inst_max);
+	int rc = plan_windows(c, db, ix, d_w, n, len, true, off, &d_order, &d_off, &inst_total, &inst_max);
 	if (rc) return rc;
-	HIP_TRY(db.alloc(&d_pairbuf, (size_t) off[n]));
+	if ((size_t) off[n] + 1 > c->wp_cap) {
+		free_set(c->wp_buf);
+		c->wp_cap = 0;
+		const size_t want = (size_t) off[n] + (size_t) off[n] / 4 + 1024;
+		HIP_TRY(hipMalloc(&c->wp_buf, want * 8));
+		c->wp_cap = want;
+	}
 	HIP_TRY(db.alloc(&d_cnt, n));
 	c->stats["window_hits"] = inst_total;                 // read-1 instances matched (what the reference enumerates one by one)
 	c->stats["window_hits_max"] = inst_max;
@@ -1139,9 +1146,9 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 		std::vector<u32> ord(n);
 		std::iota(ord.begin(), ord.end(), 0u);
 		std::stable_sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+		static const u32 hit_chunk = getenv("VDJX_HIT_CHUNK") && atol(getenv("VDJX_HIT_CHUNK")) > 0 ? (u32) atol(getenv("VDJX_HIT_CHUNK")) : HIT_CHUNK;
 		for (u32 wi : ord) {
 			const u32 H = (u32) (off[wi + 1] - off[wi]);
-			static const u32 hit_chunk = getenv("VDJX_HIT_CHUNK") && atol(getenv("VDJX_HIT_CHUNK")) > 0 ? (u32) atol(getenv("VDJX_HIT_CHUNK")) : HIT_CHUNK;
 			for (u32 h0 = 0; h0 < H || h0 == 0; h0 += hit_chunk) {
 				work.push_back(make_uint4(wi, h0, std::min(H, h0 + hit_chunk), 0));
 				if (H == 0) break;
@@ -1155,40 +1162,166 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	HIP_TRY(hipMemsetAsync(d_cnt, 0, n * 4, st));
 	{
 		vdjx_prof_scope ps(c, "k_window_pairs");
-		hipLaunchKernelGGL(k_window_pairs, dim3((u32) work.size()), dim3(MAP_THREADS), 0, st, ix, d_w, len, d_work, d_off, d_pairbuf, d_cnt, d_np);
+		hipLaunchKernelGGL(k_window_pairs, dim3((u32) work.size()), dim3(MAP_THREADS), 0, st, ix, d_w, len, d_work, d_off, (u64*) c->wp_buf, d_cnt, d_np);
 	}
+	HIP_TRY(hipStreamSynchronize(st));       // `work` staging dies with this frame
+	c->stats["window_work_items"] = work.size();
+	*d_np_out = d_np; *d_cnt_out = d_cnt; *d_off_out = d_off; *d_order_out = d_order;
+	return VDJX_OK;
+}
+
+extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int len, const vdjx_cov_params* p,
+                                 uint8_t* out_valid, uint32_t* out_npairs) {
+	if (!c || !p || (n && (!windows || !out_valid || !out_npairs))) { vdjx_set_error("vdjx_window_score: NULL argument"); return VDJX_EINVAL; }
+	if (n == 0) return VDJX_OK;
+	ReadIndexDev ix;
+	int rc = make_index_view(c, &ix, len, "vdjx_window_score");
+	if (rc) return rc;
+	if ((rc = cov_params_check(p, "vdjx_window_score"))) return rc;
+	if (n >= (1ull << 31)) { vdjx_set_error("vdjx_window_score: too many windows"); return VDJX_ELIMIT; }
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
+	hipStream_t st = c->stream;
+	vdjx_work db(c);
+	u32 *d_np, *d_order, *d_cnt;
+	u64* d_off;
+	uint8_t* d_valid;
+	HIP_TRY(db.alloc(&d_valid, n));
+	rc = window_pairs_run(c, db, ix, windows, n, len, &d_np, &d_cnt, &d_off, &d_order);
+	if (rc) return rc;
+	c->wp_n = 0;                                              // (the lists are not offered to vdjx_window_pairs_fetch)
 	{
 		vdjx_prof_scope ps(c, "k_window_cover");
-		u64* d_dbg = nullptr;
-		const char* dbgpath = getenv("VDJX_DEBUG_COVER");
-		if (dbgpath) HIP_TRY(db.alloc(&d_dbg, n));
-		hipLaunchKernelGGL(k_window_cover, dim3((u32) n), dim3(MAP_THREADS), 0, st, len, ix.rl, *p, d_order, d_off, d_pairbuf, d_cnt, d_valid, d_dbg);
-		if (dbgpath) {
-			HIP_TRY(hipStreamSynchronize(st));
-			std::vector<u64> dbg(n);
-			std::vector<u32> np(n);
-			std::vector<uint8_t> vv(n);
-			HIP_TRY(hipMemcpy(dbg.data(), d_dbg, n * 8, hipMemcpyDeviceToHost));
-			HIP_TRY(hipMemcpy(np.data(), d_np, n * 4, hipMemcpyDeviceToHost));
-			HIP_TRY(hipMemcpy(vv.data(), d_valid, n, hipMemcpyDeviceToHost));
-			FILE* f = fopen(dbgpath, "w");
-			if (f) {
-				for (size_t i = 0; i < n; i++) fprintf(f, "%zu\t%llu\t%u\t%llu\t%d\n", i, (unsigned long long) (off[i + 1] - off[i]), np[i], (unsigned long long) dbg[i], (int) vv[i]);
-				fclose(f);
-			}
-		}
+		hipLaunchKernelGGL(k_window_cover, dim3((u32) n), dim3(MAP_THREADS), 0, st, len, ix.rl, *p, d_order, d_off, (const u64*) c->wp_buf, d_cnt, d_valid, (u64*) nullptr);
 	}
 	HIP_TRY(hipMemcpyAsync(out_valid, d_valid, n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
 	vdjx_prof_collect(c);
-	c->stats["window_work_items"] = work.size();
 	{
 		u64 tot = 0;
 		for (size_t i = 0; i < n; i++) tot += out_npairs[i];
 		c->stats["window_pairs"] = tot;
 	}
+	return VDJX_OK;
+}
+
+// ---- the two halves of vdjx_window_score for a pool sharded BY PAIR over several GPUs: every rank maps every window against its
+// own reads (a mapped pair needs both mates in one index, so the mates of a pair must live on the same rank), the lists of a
+// window meet on the rank that owns the window, which runs the coverage test on their union (the validator only counts entries)
+extern "C" int vdjx_window_pairs(vdjx_ctx* c, const char* windows, size_t n, int len, uint32_t* out_entries, uint32_t* out_npairs) {
+	if (!c || (n && (!windows || !out_entries || !out_npairs))) { vdjx_set_error("vdjx_window_pairs: NULL argument"); return VDJX_EINVAL; }
+	if (c) c->wp_n = 0;
+	if (n == 0) return VDJX_OK;
+	ReadIndexDev ix;
+	int rc = make_index_view(c, &ix, len, "vdjx_window_pairs");
+	if (rc) return rc;
+	if (n >= (1ull << 31)) { vdjx_set_error("vdjx_window_pairs: too many windows"); return VDJX_ELIMIT; }
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
+	hipStream_t st = c->stream;
+	vdjx_work db(c);
+	u32 *d_np, *d_order, *d_cnt;
+	u64* d_off;
+	rc = window_pairs_run(c, db, ix, windows, n, len, &d_np, &d_cnt, &d_off, &d_order);
+	if (rc) return rc;
+	c->wp_cnt.resize(n);
+	HIP_TRY(hipMemcpyAsync(c->wp_cnt.data(), d_cnt, n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	vdjx_prof_collect(c);
+	memcpy(out_entries, c->wp_cnt.data(), n * 4);
+	c->wp_n = n;
+	return VDJX_OK;
+}
+
+extern "C" int vdjx_window_pairs_fetch(vdjx_ctx* c, const uint32_t* window_ids, size_t m, void* d_out) {
+	if (!c || (m && !window_ids)) { vdjx_set_error("vdjx_window_pairs_fetch: NULL argument"); return VDJX_EINVAL; }
+	if (!c->wp_n) { vdjx_set_error("vdjx_window_pairs_fetch: call vdjx_window_pairs first"); return VDJX_ESTATE; }
+	if (m == 0) return VDJX_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
+	hipStream_t st = c->stream;
+	vdjx_work db(c);
+	std::vector<u64> move(3 * m);
+	u64 at = 0;
+	for (size_t i = 0; i < m; i++) {
+		const u32 w = window_ids[i];
+		if (w >= c->wp_n) { vdjx_set_error("vdjx_window_pairs_fetch: window %u of %zu", w, c->wp_n); return VDJX_EINVAL; }
+		move[3 * i] = c->wp_off[w]; move[3 * i + 1] = at; move[3 * i + 2] = c->wp_cnt[w];
+		at += c->wp_cnt[w];
+	}
+	if (at && !d_out) { vdjx_set_error("vdjx_window_pairs_fetch: NULL buffer"); return VDJX_EINVAL; }
+	if (at) {
+		u64* d_move;
+		HIP_TRY(db.alloc(&d_move, move.size()));
+		HIP_TRY(hipMemcpyAsync(d_move, move.data(), move.size() * 8, hipMemcpyHostToDevice, st));
+		hipLaunchKernelGGL(k_gather_u64, dim3((u32) m), dim3(256), 0, st, (const u64*) c->wp_buf, d_move, (u64*) d_out);
+	}
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	return VDJX_OK;
+}
+
+extern "C" int vdjx_window_cover(vdjx_ctx* c, size_t n, int len, int rl, const vdjx_cov_params* p, const void* d_lists, size_t nsrc,
+                                 const uint32_t* counts, uint8_t* out_valid) {
+	if (!c || !p || (n && (!counts || !out_valid))) { vdjx_set_error("vdjx_window_cover: NULL argument"); return VDJX_EINVAL; }
+	if (n == 0) return VDJX_OK;
+	if (nsrc == 0 || len <= rl || len - rl > MAP_MAXOFF || rl < 1) { vdjx_set_error("vdjx_window_cover: bad geometry"); return VDJX_EINVAL; }
+	int rc = cov_params_check(p, "vdjx_window_cover");
+	if (rc) return rc;
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
+	hipStream_t st = c->stream;
+	vdjx_work db(c);
+	// source-major lists -> one list per window
+	std::vector<u64> off(n + 1, 0), move(3 * n * nsrc);
+	std::vector<u32> cnt(n), order(n);
+	for (size_t w = 0; w < n; w++) {
+		u64 t = 0;
+		for (size_t s = 0; s < nsrc; s++) t += counts[s * n + w];
+		if (t >= (1ull << 32)) { vdjx_set_error("vdjx_window_cover: window %zu has too many pairs", w); return VDJX_ELIMIT; }
+		cnt[w] = (u32) t;
+		off[w + 1] = off[w] + t;
+	}
+	{
+		u64 src_at = 0;
+		std::vector<u64> fill(off.begin(), off.end() - 1);
+		for (size_t s = 0; s < nsrc; s++)
+			for (size_t w = 0; w < n; w++) {
+				const size_t i = s * n + w;
+				move[3 * i] = src_at; move[3 * i + 1] = fill[w]; move[3 * i + 2] = counts[i];
+				src_at += counts[i];
+				fill[w] += counts[i];
+			}
+	}
+	if (off[n] && !d_lists) { vdjx_set_error("vdjx_window_cover: NULL lists"); return VDJX_EINVAL; }
+	std::iota(order.begin(), order.end(), 0u);
+	std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return cnt[a] > cnt[b]; });
+	u64 *d_move, *d_merged, *d_off;
+	u32 *d_cnt, *d_order;
+	uint8_t* d_valid;
+	HIP_TRY(db.alloc(&d_move, move.size()));
+	HIP_TRY(db.alloc(&d_merged, (size_t) off[n] + 1));
+	HIP_TRY(db.alloc(&d_off, n + 1));
+	HIP_TRY(db.alloc(&d_cnt, n));
+	HIP_TRY(db.alloc(&d_order, n));
+	HIP_TRY(db.alloc(&d_valid, n));
+	HIP_TRY(hipMemcpyAsync(d_move, move.data(), move.size() * 8, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d_off, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d_cnt, cnt.data(), n * 4, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d_order, order.data(), n * 4, hipMemcpyHostToDevice, st));
+	if (off[n]) hipLaunchKernelGGL(k_gather_u64, dim3((u32) (n * nsrc)), dim3(256), 0, st, (const u64*) d_lists, d_move, d_merged);
+	{
+		vdjx_prof_scope ps(c, "k_window_cover");
+		hipLaunchKernelGGL(k_window_cover, dim3((u32) n), dim3(MAP_THREADS), 0, st, len, rl, *p, d_order, d_off, (const u64*) d_merged, d_cnt, d_valid, (u64*) nullptr);
+	}
+	HIP_TRY(hipMemcpyAsync(out_valid, d_valid, n, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	vdjx_prof_collect(c);
 	return VDJX_OK;
 }
 

@@ -148,6 +148,29 @@ class HipShardEngine:
         self._keep = []
 
 
+class HipScorerEngine:
+    """The halves of the window scorer on this rank's GPU (vdjx_window_pairs / _fetch / vdjx_window_cover): this rank's read index
+    holds only ITS pairs (both mates of a pair on one rank)."""
+
+    def __init__(self, ctx, device, rl: int):
+        import torch
+        self.torch, self.ctx, self.dev, self.rl = torch, ctx, device, rl
+
+    def window_pairs(self, windows):
+        """windows: list of equally long strings, or Context.pack_strings / pin_strings output"""
+        self._ln = windows[2] if isinstance(windows, tuple) else (len(windows[0]) if windows else 0)
+        return self.ctx.window_pairs(windows)
+
+    def window_fetch(self, window_ids, total: int):
+        t = self.torch
+        out = t.empty(max(total, 1), dtype=t.int64, device=self.dev)
+        self.ctx.window_pairs_fetch(window_ids, out.data_ptr())
+        return out[:total]
+
+    def window_cover(self, n: int, lists, nsrc: int, counts, ins: int, **cov):
+        return self.ctx.window_cover(n, self._ln, self.rl, lists.data_ptr() if lists.numel() else 0, nsrc, counts, ins, **cov)
+
+
 class Comm:
     """The four collectives the sharded path needs, on RCCL ("nccl") natively and on "gloo" through host copies
     (gloo has no all_to_all_single / all_gather_into_tensor; used by the CPU tests and single-device dry runs)."""
@@ -241,6 +264,38 @@ class ShardedHotPath:
     @property
     def bytes_exchanged(self):
         return self.comm.bytes
+
+    def window_score(self, scorer, windows, ins: int, **cov):
+        """quick_map_process_contig + coverage_is_valid (A2:841-847) over a pool sharded BY PAIR: every rank maps ALL windows
+        against its own reads (`scorer`: HipScorerEngine or a stand-in), window w's pair lists meet on rank w % G (one
+        all-to-all of 8-byte entries: identical read pairs travel once, with a multiplicity), which tests their union.
+        Every rank passes the same windows and gets (valid[n], npairs[n])."""
+        t, dist, cm = self.torch, self.dist, self.comm
+        G, r = self.world, self.rank
+        n = windows[1] if isinstance(windows, tuple) else len(windows)
+        if n == 0:
+            return np.zeros(0, np.uint8), np.zeros(0, np.uint32)
+        ent, npairs = scorer.window_pairs(windows)
+        own = [np.arange(o, n, G) for o in range(G)]
+        all_ent = cm.all_gather_cat(t.from_numpy(ent.astype(np.int64)).to(self.dev).view(1, n)).cpu().numpy()      # [G, n]
+        send_ids = np.concatenate(own).astype(np.uint32)
+        send_counts = [int(ent[own[o]].sum()) for o in range(G)]
+        counts = all_ent[:, own[r]]                                         # what every source holds for MY windows
+        recv_counts = [int(v) for v in counts.sum(axis=1)]
+        send = scorer.window_fetch(send_ids, int(sum(send_counts)))
+        recv = t.empty(int(sum(recv_counts)), dtype=t.int64, device=send.device)
+        cm.all_to_all_v(send, send_counts, recv, recv_counts)
+        cm.sync()
+        valid_mine = scorer.window_cover(len(own[r]), recv, G, counts, ins, **cov)
+        tot = t.from_numpy(npairs.astype(np.int64)).to(self.dev)
+        cm.all_reduce(tot, dist.ReduceOp.SUM)
+        parts = cm.all_gather_var(t.from_numpy(np.ascontiguousarray(valid_mine)).to(self.dev), [len(own[o]) for o in range(G)]).cpu().numpy()
+        valid = np.zeros(n, np.uint8)
+        at = 0
+        for o in range(G):
+            valid[own[o]] = parts[at:at + len(own[o])]
+            at += len(own[o])
+        return valid, tot.cpu().numpy().astype(np.uint32)
 
     def kmer_build(self, pool, k: int = 35, mf: int = 3, mq: int = 90, keep_device: bool = False, async_export: bool = False):
         t, dist, eng, cm = self.torch, self.dist, self.engine, self.comm
