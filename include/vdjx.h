@@ -51,6 +51,18 @@ int vdjx_sync(vdjx_ctx* ctx);
  * mask, quality bytes).  Bases other than ACGT are treated as 'N'.  The caller keeps the ASCII. */
 int vdjx_pool_load(vdjx_ctx* ctx, const uint8_t* primary, size_t n_primary,
                    const uint8_t* secondary, size_t n_secondary, int rl, vdjx_pool** out);
+/* The same pools given as the reads only, n records of 2*rl+1 bytes as add_to_buffer writes the FIRST of each read's two
+ * records (bam_read.c:219-230); the reverse-complement record it writes next (bam_read.c:231-243: complemented bases in reverse
+ * order, reversed qualities) is derived on the device: record 2i is read i, record 2i+1 its reverse complement, half the bytes
+ * cross PCIe.  The resulting pool is identical to vdjx_pool_load's on the full buffers. */
+int vdjx_pool_load_forward(vdjx_ctx* ctx, const uint8_t* primary_reads, size_t n_primary_reads,
+                           const uint8_t* secondary_reads, size_t n_secondary_reads, int rl, vdjx_pool** out);
+/* vdjx_pool_load_forward without waiting: upload and packing run on the context's copy stream beside whatever the main stream is
+ * computing on another pool (page-locked buffers, vdjx_host_alloc, make the upload a DMA); the pool may be used after vdjx_pool_wait,
+ * which also reports a malformed pool. */
+int vdjx_pool_load_forward_begin(vdjx_ctx* ctx, const uint8_t* primary_reads, size_t n_primary_reads,
+                                 const uint8_t* secondary_reads, size_t n_secondary_reads, int rl, vdjx_pool** out);
+int vdjx_pool_wait(vdjx_pool* pool);
 /* same, ASCII pools already resident in device memory (16-byte aligned) */
 int vdjx_pool_load_device(vdjx_ctx* ctx, const uint8_t* d_primary, size_t n_primary,
                           const uint8_t* d_secondary, size_t n_secondary, int rl, vdjx_pool** out);

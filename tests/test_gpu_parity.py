@@ -638,3 +638,29 @@ def test_sharded_window_scorer_ranks_as_threads(ctx, world):
         np.testing.assert_array_equal(valid, valid1)
         np.testing.assert_array_equal(npairs, np1)
     p.free()
+
+
+def test_pool_load_forward_derives_the_reverse_complement_records(ctx):
+    """vdjx_pool_load_forward: the reads as extracted only; the device derives every read's reverse-complement record
+    (add_to_buffer, bam_read.c:231-243).  Same packed pool as the full buffers: same graph, same mapped pairs."""
+    c = G.Case("e2e_mixed")
+    ctx.anchor_sets_load(c.v_codes, c.j_codes)
+    pool = c.pool
+    full = ctx.pool_load(pool.primary, pool.secondary, pool.rl)
+    g1 = ctx.kmer_build(full, 35, 3, 90)
+    fwd = ctx.pool_load_forward(pool.primary[0::2], pool.secondary[0::2], pool.rl)
+    assert fwd.n_records == full.n_records
+    g2 = ctx.kmer_build(fwd, 35, 3, 90)
+    for f in ("first_inst", "freq", "gated_count", "has_v", "has_j", "to_ids", "from_ids", "kmers"):
+        np.testing.assert_array_equal(getattr(g1, f), getattr(g2, f))
+    assert g1.pre_nodes == g2.pre_nodes and g1.n > 100
+    contigs = [l for l in G.text("e2e_mixed.contigs.fa.gz").split("\n") if l and not l.startswith(">")]
+    res = []
+    for p in (full, fwd):
+        ctx.read_index_build(p, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+        offs, pairs = ctx.map_emit(contigs)
+        res.append((offs.copy(), pairs.copy()))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    assert res[0][1].tobytes() == res[1][1].tobytes() and res[0][1].shape[0] > 100
+    full.free()
+    fwd.free()

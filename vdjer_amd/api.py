@@ -76,6 +76,10 @@ class Pool:
     def __init__(self, ctx: "Context", handle, rl: int, n_records: int):
         self.ctx, self.h, self.rl, self.n_records = ctx, handle, rl, n_records
 
+    def wait(self):
+        """after pool_load_forward(..., wait=False): the pool is loaded (and well-formed) once this returns"""
+        check(_lib.lib().vdjx_pool_wait(self.h), "vdjx_pool_wait")
+
     def free(self):
         if self.h:
             _lib.lib().vdjx_pool_free(self.h)
@@ -158,6 +162,23 @@ class Context:
         h = C.c_void_p()
         check(self.L.vdjx_pool_load(self.h, _p(pri), pri.shape[0], _p(sec), sec.shape[0], rl, C.byref(h)), "vdjx_pool_load")
         p = Pool(self, h, rl, pri.shape[0] + sec.shape[0])
+        self._pools.append(p)
+        return p
+
+    def pool_load_forward(self, primary_reads, secondary_reads, rl: int, n_primary: int = None, n_secondary: int = None,
+                          wait: bool = True) -> Pool:
+        """the reads as extracted only ([n, 2*rl+1] uint8 arrays or raw host addresses with counts): every read's reverse-complement
+        record is derived on the device (record 2i = read i, 2i+1 = its reverse complement)"""
+        if isinstance(primary_reads, int):
+            pp, ps, npri, nsec = C.c_void_p(primary_reads), C.c_void_p(secondary_reads), n_primary, n_secondary
+        else:
+            pri = _c(primary_reads, np.uint8).reshape(-1, 2 * rl + 1)
+            sec = _c(secondary_reads, np.uint8).reshape(-1, 2 * rl + 1)
+            pp, ps, npri, nsec = _p(pri), _p(sec), pri.shape[0], sec.shape[0]
+        h = C.c_void_p()
+        fn = self.L.vdjx_pool_load_forward if wait else self.L.vdjx_pool_load_forward_begin      # wait=False: Pool.wait() before use
+        check(fn(self.h, pp, npri, ps, nsec, rl, C.byref(h)), "vdjx_pool_load_forward")
+        p = Pool(self, h, rl, 2 * (npri + nsec))
         self._pools.append(p)
         return p
 

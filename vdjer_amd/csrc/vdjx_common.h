@@ -73,6 +73,8 @@ struct vdjx_ctx {
 	hipStream_t stream = nullptr;
 	hipStream_t copy_stream = nullptr;   // result copies that may run beside the next kernels (vdjx_graph_export_begin)
 	hipStream_t pairs_stream = nullptr;  // the mapped pairs' copy (vdjx_map_emit_begin): a stream of its own, so that waiting for one result is not waiting for the other
+	void* d_stage[2] = {nullptr, nullptr};          // vdjx_pool_load: upload staging (two chunks in flight)
+	hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_packed[2] = {nullptr, nullptr};
 	bool profiling = false;
 	std::vector<std::string> prof_names;                 // insertion order
 	std::map<std::string, vdjx_prof_entry> prof;
@@ -136,6 +138,7 @@ struct vdjx_pool {
 	u64* d_nmask = nullptr;      // [R] bit i = base i is not ACGT
 	u64* d_lowq = nullptr;       // [R] bit i = (uint8)(q-33) < 20
 	uint8_t* d_quals = nullptr;  // [R][qstride] Phred+33 characters
+	u32* pending_bad = nullptr;  // vdjx_pool_load_forward_begin: the load is still running on the copy stream (vdjx_pool_wait)
 };
 
 // the finished graph stays on the device until vdjx_graph_export copies it straight into the caller's arrays

@@ -102,6 +102,7 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	free_dev(c->d_ri_slots); free_dev(c->d_ri_rep); free_dev(c->d_ri_start); free_dev(c->d_ri_recs);
 	free_dev(c->d_pair_id); free_dev(c->d_read_num); free_dev(c->d_is_rc); free_dev(c->d_pair_r2);
 	free_dev(c->d_rec_info); free_dev(c->me_pairs); free_dev(c->me_dense); free_dev(c->wp_buf); free_dev(c->d_ri_cnt1); free_dev(c->d_ri_dstart); free_dev(c->d_ri_dinfo);
+	for (int i = 0; i < 2; i++) { free_dev(c->d_stage[i]); if (c->ev_copied[i]) (void) hipEventDestroy(c->ev_copied[i]); if (c->ev_packed[i]) (void) hipEventDestroy(c->ev_packed[i]); }
 	c->arena.release();
 	c->shard_arena.release();
 	c->blocks.drop();
@@ -234,6 +235,49 @@ extern "C" int vdjx_profile_get(vdjx_ctx* c, int idx, const char** name, double*
 // ----------------------------------------------------------------------------------------------
 #define PACK_RECS 256
 
+// one ASCII record in LDS -> the packed record g.  REV: the reverse-complement record add_to_buffer writes after every read
+// (bam_read.c:232-243: bases complemented in reverse order, qualities reversed) derived on the chip instead of crossing PCIe
+template <bool REV>
+__device__ inline void pack_one(const uint8_t* r, int rl, size_t g, u64* __restrict__ bases, u64* __restrict__ nmask, u64* __restrict__ lowq,
+                                uint8_t* __restrict__ quals, int qstride) {
+	u128 b = 0;
+	u64 nm = 0, lq = 0;
+	for (int i = 0; i < rl; i++) {
+		const int si = REV ? rl - 1 - i : i;
+		const u32 ch = r[1 + si];
+		// seq_to_kmer.c:6-29: A0 T1 C2 G3.  Branch-free: bits 1-2 of the ASCII code tell A(00) C(01) T(10) G(11) apart
+		u32 code = (0xD8u >> (((ch >> 1) & 3u) * 2u)) & 3u;                  // 00->0, 01->2, 10->1, 11->3
+		if (REV) code ^= 1u;                                                // complement: A<->T (0<->1), C<->G (2<->3)
+		const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+		nm |= (u64) (!acgt) << i;
+		b = (b << 2) | (acgt ? code : 0u);
+		const u32 q = (u32) (uint8_t) (r[1 + rl + si] - 33);                 // phred33(), A2:150-152
+		lq |= (u64) (q < 20u) << i;                                          // MIN_BASE_QUALITY, A2:76,252
+	}
+	((ulonglong2*) bases)[g] = make_ulonglong2((u64) (b >> 64), (u64) b);
+	nmask[g] = nm;
+	lowq[g] = lq;
+	// quality rows: qstride (a multiple of 16) bytes per record, written as 16-byte stores
+	const uint8_t* qs = r + 1 + rl;
+	uint4* qd = (uint4*) (quals + g * (size_t) qstride);
+	for (int v4 = 0; v4 < qstride / 16; v4++) {
+		u32 wds[4];
+#pragma unroll
+		for (int wd = 0; wd < 4; wd++) {
+			u32 x = 0;
+#pragma unroll
+			for (int bt = 0; bt < 4; bt++) {
+				const int i = v4 * 16 + wd * 4 + bt;
+				x |= (u32) (i < rl ? qs[REV ? rl - 1 - i : i] : 33) << (8 * bt);
+			}
+			wds[wd] = x;
+		}
+		qd[v4] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+	}
+}
+
+// FWD: `ascii` holds the reads as extracted only; packed records 2i (as is) and 2i+1 (reverse complement) come out of read i
+template <bool FWD>
 __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restrict__ ascii, size_t n_rec, int rl, size_t rec0,
                                                          u64* __restrict__ bases, u64* __restrict__ nmask,
                                                          u64* __restrict__ lowq, uint8_t* __restrict__ quals, int qstride,
@@ -252,46 +296,17 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 	if (threadIdx.x >= nhere) return;
 	const uint8_t* r = lds + (size_t) threadIdx.x * reclen;
 	if (r[0] != '0') atomicAdd(bad_strand, 1u);   // A2:383-391; the reference only ever writes '0' (bam_read.c:219,231)
-	u128 b = 0;
-	u64 nm = 0, lq = 0;
-	for (int i = 0; i < rl; i++) {
-		const u32 ch = r[1 + i];
-		// seq_to_kmer.c:6-29: A0 T1 C2 G3.  Branch-free: bits 1-2 of the ASCII code tell A(00) C(01) T(10) G(11) apart
-		const u32 code = (0xD8u >> (((ch >> 1) & 3u) * 2u)) & 3u;           // 00->0, 01->2, 10->1, 11->3
-		const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
-		nm |= (u64) (!acgt) << i;
-		b = (b << 2) | (acgt ? code : 0u);
-		const u32 q = (u32) (uint8_t) (r[1 + rl + i] - 33);                  // phred33(), A2:150-152
-		lq |= (u64) (q < 20u) << i;                                          // MIN_BASE_QUALITY, A2:76,252
-	}
-	const size_t g = rec0 + first + threadIdx.x;
-	((ulonglong2*) bases)[g] = make_ulonglong2((u64) (b >> 64), (u64) b);
-	nmask[g] = nm;
-	lowq[g] = lq;
-	// quality rows: qstride (a multiple of 16) bytes per record, written as 16-byte stores
-	const uint8_t* qs = r + 1 + rl;
-	uint4* qd = (uint4*) (quals + g * (size_t) qstride);
-	for (int v4 = 0; v4 < qstride / 16; v4++) {
-		u32 wds[4];
-#pragma unroll
-		for (int wd = 0; wd < 4; wd++) {
-			u32 x = 0;
-#pragma unroll
-			for (int bt = 0; bt < 4; bt++) {
-				const int i = v4 * 16 + wd * 4 + bt;
-				x |= (u32) (i < rl ? qs[i] : 33) << (8 * bt);
-			}
-			wds[wd] = x;
-		}
-		qd[v4] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
-	}
+	if (FWD) {
+		const size_t g = rec0 + 2 * (first + threadIdx.x);
+		pack_one<false>(r, rl, g, bases, nmask, lowq, quals, qstride);
+		pack_one<true>(r, rl, g + 1, bases, nmask, lowq, quals, qstride);
+	} else
+		pack_one<false>(r, rl, rec0 + first + threadIdx.x, bases, nmask, lowq, quals, qstride);
 }
 
-static int pool_pack_device(vdjx_ctx* c, const uint8_t* d_primary, size_t n_primary,
-                            const uint8_t* d_secondary, size_t n_secondary, int rl, vdjx_pool** out) {
+static int pool_alloc(vdjx_ctx* c, size_t R, size_t n_primary, int rl, vdjx_pool** out, u32** d_bad) {
 	*out = nullptr;
 	if (rl < 1 || rl > VDJX_MAX_READ_LEN) { vdjx_set_error("read length %d outside [1,%d]", rl, VDJX_MAX_READ_LEN); return VDJX_ELIMIT; }
-	size_t R = n_primary + n_secondary;
 	if (R >= (1ull << 31)) { vdjx_set_error("too many records for one GPU: %zu", R); return VDJX_ELIMIT; }
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_pool* p = new vdjx_pool();
@@ -310,20 +325,23 @@ static int pool_pack_device(vdjx_ctx* c, const uint8_t* d_primary, size_t n_prim
 	p->d_nmask = (u64*) (p->d_block + Ra * 16);
 	p->d_lowq = (u64*) (p->d_block + Ra * 24);
 	p->d_quals = (uint8_t*) (p->d_block + Ra * 32);
-	u32* d_bad = (u32*) (p->d_block + Ra * (32 + (size_t) p->qstride));
-	(void) hipMemsetAsync(d_bad, 0, 4, c->stream);
-	size_t lds = (size_t) PACK_RECS * (2 * rl + 1) + 16;
-	{
-		vdjx_prof_scope ps(c, "k_pool_pack");
-		if (n_primary)
-			hipLaunchKernelGGL(k_pool_pack, dim3((unsigned) ((n_primary + PACK_RECS - 1) / PACK_RECS)), dim3(PACK_RECS), lds, c->stream,
-			                   d_primary, n_primary, rl, (size_t) 0, p->d_bases, p->d_nmask, p->d_lowq, p->d_quals, p->qstride, d_bad);
-		if (n_secondary)
-			hipLaunchKernelGGL(k_pool_pack, dim3((unsigned) ((n_secondary + PACK_RECS - 1) / PACK_RECS)), dim3(PACK_RECS), lds, c->stream,
-			                   d_secondary, n_secondary, rl, n_primary, p->d_bases, p->d_nmask, p->d_lowq, p->d_quals, p->qstride, d_bad);
-	}
+	*d_bad = (u32*) (p->d_block + Ra * (32 + (size_t) p->qstride));
+	(void) hipMemset(*d_bad, 0, 4);                  // (synchronous: the packing may run on either stream)
+	*out = p;
+	return VDJX_OK;
+}
+
+static void pack_launch(vdjx_ctx* c, hipStream_t st, vdjx_pool* p, const uint8_t* d_ascii, size_t n, size_t rec0, bool fwd, u32* d_bad) {
+	if (!n) return;
+	const size_t lds = (size_t) PACK_RECS * (2 * p->rl + 1) + 16;
+	const dim3 grid((unsigned) ((n + PACK_RECS - 1) / PACK_RECS));
+	if (fwd) hipLaunchKernelGGL(k_pool_pack<true>, grid, dim3(PACK_RECS), lds, st, d_ascii, n, p->rl, rec0, p->d_bases, p->d_nmask, p->d_lowq, p->d_quals, p->qstride, d_bad);
+	else hipLaunchKernelGGL(k_pool_pack<false>, grid, dim3(PACK_RECS), lds, st, d_ascii, n, p->rl, rec0, p->d_bases, p->d_nmask, p->d_lowq, p->d_quals, p->qstride, d_bad);
+}
+
+static int pool_finish(vdjx_ctx* c, vdjx_pool* p, u32* d_bad, vdjx_pool** out) {
 	u32 bad = 0;
-	e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream);
+	hipError_t e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipGetLastError();
 	if (e != hipSuccess) { vdjx_set_error("pool pack: %s", hipGetErrorString(e)); vdjx_pool_free(p); return VDJX_EHIP; }
@@ -337,6 +355,21 @@ static int pool_pack_device(vdjx_ctx* c, const uint8_t* d_primary, size_t n_prim
 	return VDJX_OK;
 }
 
+static int pool_pack_device(vdjx_ctx* c, const uint8_t* d_primary, size_t n_primary,
+                            const uint8_t* d_secondary, size_t n_secondary, int rl, vdjx_pool** out) {
+	vdjx_pool* p;
+	u32* d_bad;
+	int rc = pool_alloc(c, n_primary + n_secondary, n_primary, rl, &p, &d_bad);
+	if (rc) return rc;
+	*out = nullptr;
+	{
+		vdjx_prof_scope ps(c, "k_pool_pack");
+		pack_launch(c, c->stream, p, d_primary, n_primary, 0, false, d_bad);
+		pack_launch(c, c->stream, p, d_secondary, n_secondary, n_primary, false, d_bad);
+	}
+	return pool_finish(c, p, d_bad, out);
+}
+
 extern "C" int vdjx_pool_load_device(vdjx_ctx* c, const uint8_t* d_primary, size_t n_primary,
                                      const uint8_t* d_secondary, size_t n_secondary, int rl, vdjx_pool** out) {
 	if (!c || !out) { vdjx_set_error("vdjx_pool_load_device: NULL argument"); return VDJX_EINVAL; }
@@ -345,26 +378,97 @@ extern "C" int vdjx_pool_load_device(vdjx_ctx* c, const uint8_t* d_primary, size
 	return pool_pack_device(c, d_primary, n_primary, d_secondary, n_secondary, rl, out);
 }
 
-extern "C" int vdjx_pool_load(vdjx_ctx* c, const uint8_t* primary, size_t n_primary,
-                              const uint8_t* secondary, size_t n_secondary, int rl, vdjx_pool** out) {
+// Host pools cross PCIe in chunks on the copy stream into two staging buffers while the previous chunk is packed on the main
+// stream: with page-locked pools (vdjx_host_alloc) the upload is a DMA that the packing hides behind.
+#define LOAD_CHUNK_RECS (256u * 1024u)          // a multiple of PACK_RECS: chunk starts stay 16-byte aligned in the staging buffer
+static int pool_load_host(vdjx_ctx* c, const uint8_t* primary, size_t n_primary, const uint8_t* secondary, size_t n_secondary, int rl, bool fwd,
+                          vdjx_pool** out, bool async = false) {
 	if (!c || !out) { vdjx_set_error("vdjx_pool_load: NULL argument"); return VDJX_EINVAL; }
 	if ((n_primary && !primary) || (n_secondary && !secondary)) { vdjx_set_error("vdjx_pool_load: NULL pool"); return VDJX_EINVAL; }
-	if (rl < 1 || rl > VDJX_MAX_READ_LEN) { vdjx_set_error("read length %d outside [1,%d]", rl, VDJX_MAX_READ_LEN); return VDJX_ELIMIT; }
-	HIP_TRY(hipSetDevice(c->device));
-	size_t reclen = 2 * (size_t) rl + 1;
-	uint8_t *dp = nullptr, *ds = nullptr;
-	if (n_primary) {
-		HIP_TRY(hipMalloc(&dp, n_primary * reclen + 16));
-		HIP_TRY(hipMemcpyAsync(dp, primary, n_primary * reclen, hipMemcpyHostToDevice, c->stream));
+	const size_t mul = fwd ? 2 : 1;
+	vdjx_pool* p;
+	u32* d_bad;
+	int rc = pool_alloc(c, mul * (n_primary + n_secondary), mul * n_primary, rl, &p, &d_bad);
+	if (rc) return rc;
+	*out = nullptr;
+	const size_t reclen = 2 * (size_t) rl + 1;
+	const size_t stage_bytes = (size_t) LOAD_CHUNK_RECS * reclen + 16;
+	if (!c->d_stage[0]) {
+		for (int i = 0; i < 2; i++) {
+			hipError_t e = hipMalloc(&c->d_stage[i], stage_bytes);
+			if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming);
+			if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_packed[i], hipEventDisableTiming);
+			if (e != hipSuccess) { vdjx_set_error("pool staging: %s", hipGetErrorString(e)); vdjx_pool_free(p); return VDJX_EHIP; }
+		}
 	}
-	if (n_secondary) {
-		HIP_TRY(hipMalloc(&ds, n_secondary * reclen + 16));
-		HIP_TRY(hipMemcpyAsync(ds, secondary, n_secondary * reclen, hipMemcpyHostToDevice, c->stream));
+	if (async) {
+		// the whole load on the copy stream (chunk after chunk: copy, pack), so that the main stream keeps computing on another pool;
+		// vdjx_pool_wait joins it
+		for (int which = 0; which < 2; which++) {
+			const uint8_t* src = which ? secondary : primary;
+			const size_t n = which ? n_secondary : n_primary;
+			const size_t rec0 = which ? mul * n_primary : 0;
+			int turn = 0;
+			for (size_t at = 0; at < n; at += LOAD_CHUNK_RECS, turn ^= 1) {
+				const size_t m = n - at < LOAD_CHUNK_RECS ? n - at : LOAD_CHUNK_RECS;
+				const hipError_t e = hipMemcpyAsync(c->d_stage[turn], src + at * reclen, m * reclen, hipMemcpyHostToDevice, c->copy_stream);
+				if (e != hipSuccess) { vdjx_set_error("pool upload: %s", hipGetErrorString(e)); (void) hipStreamSynchronize(c->copy_stream); vdjx_pool_free(p); return VDJX_EHIP; }
+				pack_launch(c, c->copy_stream, p, (const uint8_t*) c->d_stage[turn], m, rec0 + mul * at, fwd, d_bad);
+			}
+		}
+		p->pending_bad = d_bad;
+		*out = p;
+		return VDJX_OK;
 	}
-	int rc = pool_pack_device(c, dp, n_primary, ds, n_secondary, rl, out);
-	free_dev(dp);
-	free_dev(ds);
-	return rc;
+	int turn = 0;
+	bool used[2] = {false, false};
+	vdjx_prof_scope ps(c, "k_pool_pack");
+	for (int which = 0; which < 2; which++) {
+		const uint8_t* src = which ? secondary : primary;
+		const size_t n = which ? n_secondary : n_primary;
+		const size_t rec0 = which ? mul * n_primary : 0;
+		for (size_t at = 0; at < n; at += LOAD_CHUNK_RECS, turn ^= 1) {
+			const size_t m = n - at < LOAD_CHUNK_RECS ? n - at : LOAD_CHUNK_RECS;
+			hipError_t e = hipSuccess;
+			if (used[turn]) e = hipStreamWaitEvent(c->copy_stream, c->ev_packed[turn], 0);           // the buffer's previous chunk is packed
+			if (e == hipSuccess) e = hipMemcpyAsync(c->d_stage[turn], src + at * reclen, m * reclen, hipMemcpyHostToDevice, c->copy_stream);
+			if (e == hipSuccess) e = hipEventRecord(c->ev_copied[turn], c->copy_stream);
+			if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_copied[turn], 0);
+			if (e != hipSuccess) { vdjx_set_error("pool upload: %s", hipGetErrorString(e)); (void) hipStreamSynchronize(c->copy_stream); vdjx_pool_free(p); return VDJX_EHIP; }
+			pack_launch(c, c->stream, p, (const uint8_t*) c->d_stage[turn], m, rec0 + mul * at, fwd, d_bad);
+			(void) hipEventRecord(c->ev_packed[turn], c->stream);
+			used[turn] = true;
+		}
+	}
+	return pool_finish(c, p, d_bad, out);
+}
+
+extern "C" int vdjx_pool_load(vdjx_ctx* c, const uint8_t* primary, size_t n_primary,
+                              const uint8_t* secondary, size_t n_secondary, int rl, vdjx_pool** out) {
+	return pool_load_host(c, primary, n_primary, secondary, n_secondary, rl, false, out);
+}
+
+extern "C" int vdjx_pool_load_forward(vdjx_ctx* c, const uint8_t* primary_reads, size_t n_primary_reads,
+                                      const uint8_t* secondary_reads, size_t n_secondary_reads, int rl, vdjx_pool** out) {
+	return pool_load_host(c, primary_reads, n_primary_reads, secondary_reads, n_secondary_reads, rl, true, out);
+}
+
+extern "C" int vdjx_pool_load_forward_begin(vdjx_ctx* c, const uint8_t* primary_reads, size_t n_primary_reads,
+                                            const uint8_t* secondary_reads, size_t n_secondary_reads, int rl, vdjx_pool** out) {
+	return pool_load_host(c, primary_reads, n_primary_reads, secondary_reads, n_secondary_reads, rl, true, out, true);
+}
+
+extern "C" int vdjx_pool_wait(vdjx_pool* p) {
+	if (!p) { vdjx_set_error("vdjx_pool_wait: NULL pool"); return VDJX_EINVAL; }
+	if (!p->pending_bad) return VDJX_OK;
+	if (!vdjx_ctx_alive(p->ctx)) { vdjx_set_error("vdjx_pool_wait: the pool's context is gone"); return VDJX_ESTATE; }
+	HIP_TRY(hipSetDevice(p->device));
+	u32 bad = 0;
+	HIP_TRY(hipMemcpyAsync(&bad, p->pending_bad, 4, hipMemcpyDeviceToHost, p->ctx->copy_stream));
+	HIP_TRY(hipStreamSynchronize(p->ctx->copy_stream));
+	p->pending_bad = nullptr;
+	if (bad) { vdjx_set_error("pool: %u records do not start with the '0' strand byte", bad); return VDJX_EINVAL; }
+	return VDJX_OK;
 }
 
 extern "C" int vdjx_host_alloc(vdjx_ctx* c, size_t bytes, void** out) {
@@ -389,6 +493,7 @@ extern "C" void vdjx_pool_free(vdjx_pool* p) {
 	if (p->d_block) {
 		if (vdjx_ctx_alive(p->ctx)) {
 			(void) hipStreamSynchronize(p->ctx->stream);     // nothing in flight may still read the block
+			if (p->pending_bad) (void) hipStreamSynchronize(p->ctx->copy_stream);
 			p->ctx->blocks.release(p->d_block, p->block_cap);
 		} else
 			free_dev(p->d_block);

@@ -1072,9 +1072,22 @@ static int make_index_view(vdjx_ctx* c, ReadIndexDev* ix, int len, const char* w
 	return VDJX_OK;
 }
 
+// largest-first processing order without a comparison sort: by descending bit length of the size (64 counting buckets; inside a
+// bucket sizes differ by less than 2x, which is all the tail of a launch cares about).  A stable_sort of 20,000 windows through
+// an index indirection cost more host time than the coverage kernel ran.
+static void order_by_size_desc(const std::vector<u64>& off, size_t n, std::vector<u32>& order) {
+	order.resize(n);
+	u32 cnt[66] = {0};
+	auto key = [&](size_t i) { const u64 sz = off[i + 1] - off[i]; return sz ? 64u - (u32) __builtin_clzll(sz) : 0u; };     // 0..64
+	for (size_t i = 0; i < n; i++) cnt[64 - key(i) + 1]++;
+	for (int b = 0; b < 65; b++) cnt[b + 1] += cnt[b];
+	for (size_t i = 0; i < n; i++) order[cnt[64 - key(i)]++] = (u32) i;
+}
+
 // hits per string, exclusive offsets, and the largest-first processing order
 static int plan_windows(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, const char* d_w, size_t n, int len, bool weighted,
-                        std::vector<u64>& off, u32** d_order, u64** d_off, u64* inst_total = nullptr, u64* inst_max = nullptr) {
+                        std::vector<u64>& off, u32** d_order, u64** d_off, u64* inst_total = nullptr, u64* inst_max = nullptr,
+                        std::vector<u32>* order_out = nullptr) {
 	hipStream_t st = c->stream;
 	u32 *d_hits, *d_inst;
 	HIP_TRY(db.alloc(&d_hits, n));
@@ -1092,8 +1105,8 @@ static int plan_windows(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, cons
 	if (inst_max) { *inst_max = 0; for (u32 v : inst) *inst_max = std::max<u64>(*inst_max, v); }
 	off.assign(n + 1, 0);
 	for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + hits[i];
-	std::iota(order.begin(), order.end(), 0u);
-	std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return hits[a] > hits[b]; });
+	order_by_size_desc(off, n, order);
+	if (order_out) *order_out = order;
 	HIP_TRY(db.alloc(d_order, n));
 	HIP_TRY(db.alloc(d_off, n + 1));
 	HIP_TRY(hipMemcpyAsync(*d_order, order.data(), n * 4, hipMemcpyHostToDevice, st));
@@ -1127,7 +1140,8 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 	HIP_TRY(hipMemcpyAsync(d_w, windows, n * len, hipMemcpyHostToDevice, st));
 	std::vector<u64>& off = c->wp_off;
 	u64 inst_total = 0, inst_max = 0;
-	int rc = plan_windows(c, db, ix, d_w, n, len, true, off, &d_order, &d_off, &inst_total, &inst_max);
+	std::vector<u32> ord;
+	int rc = plan_windows(c, db, ix, d_w, n, len, true, off, &d_order, &d_off, &inst_total, &inst_max, &ord);
 	if (rc) return rc;
 	if ((size_t) off[n] + 1 > c->wp_cap) {
 		free_set(c->wp_buf);
@@ -1143,9 +1157,6 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 	// work list: deep windows are cut into slices of HIT_CHUNK hits (largest windows first)
 	std::vector<uint4> work;
 	{
-		std::vector<u32> ord(n);
-		std::iota(ord.begin(), ord.end(), 0u);
-		std::stable_sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
 		static const u32 hit_chunk = getenv("VDJX_HIT_CHUNK") && atol(getenv("VDJX_HIT_CHUNK")) > 0 ? (u32) atol(getenv("VDJX_HIT_CHUNK")) : HIT_CHUNK;
 		for (u32 wi : ord) {
 			const u32 H = (u32) (off[wi + 1] - off[wi]);
@@ -1298,8 +1309,7 @@ extern "C" int vdjx_window_cover(vdjx_ctx* c, size_t n, int len, int rl, const v
 			}
 	}
 	if (off[n] && !d_lists) { vdjx_set_error("vdjx_window_cover: NULL lists"); return VDJX_EINVAL; }
-	std::iota(order.begin(), order.end(), 0u);
-	std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return cnt[a] > cnt[b]; });
+	order_by_size_desc(off, n, order);
 	u64 *d_move, *d_merged, *d_off;
 	u32 *d_cnt, *d_order;
 	uint8_t* d_valid;
