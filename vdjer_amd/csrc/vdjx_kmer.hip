@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
                                                              u32 range_shift, u32 n_ranges,
                                                              u64* __restrict__ raw, u64 raw_cap, u32 blk_items,
                                                              unsigned long long* __restrict__ g_cursor,
-                                                             u32* __restrict__ range_cnt, u32* __restrict__ g_err) {
+                                                             u32* __restrict__ range_cnt, u32* __restrict__ g_err, u32 dbg) {
 	extern __shared__ u32 hist[];                 // [n_ranges]
 	for (u32 i = threadIdx.x; i < n_ranges; i += WALK_THREADS) hist[i] = 0;
 	__syncthreads();
@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				if (prev >= 0) {
 					const int bsh = 2 * (rl - k - o);                     // last base of the k-mer at o
 					const u32 bb = (u32) (bsh < 64 ? v.blo >> bsh : v.bhi >> (bsh - 64)) & 3u;
-					const u32 s1 = succ1[prev];
+					const u32 s1 = (dbg & 4u) ? ((u32) (prev + 1) << 3) | (bb << 1) | 1u : succ1[prev];       // (dbg: ablation runs, see stage_recount)
 					if (s1 & 1u) s = ((s1 >> 1) & 3u) == bb ? (int) (s1 >> 3) : -1;
 					else if (s1 == 2u) { const u32 nx = succ[(u32) prev * 4u + bb]; s = nx == NONE32 ? -1 : (int) nx; }
 					const int fsh = 2 * (rl - o);                          // first base of the k-mer at o-1 (the predecessor)
@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				} else {
 					u64 khi, klo;
 					vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
-					s = surv_lookup2f(t, klo, khi);
+					s = (dbg & 8u) ? ((klo & 3u) ? (int) ((u32) vdjx_mix(klo, khi) % 1000000u) : -1) : surv_lookup2f(t, klo, khi);
 				}
 			}
 			const bool has_prev = prev >= 0 && s >= 0;
@@ -1170,8 +1170,8 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 			}
 			if (s >= 0 && !dead) {
 				const u64 item = ((u64) (u32) s << IT_SURV_SHIFT) | ((u64) has_prev << 37) | ((u64) pa << 35) | ((u64) r << 6) | (u64) o;
-				raw[blk + fill + (u32) __popcll(m & ((1ull << lane) - 1ull))] = item;
-				atomicAdd(&hist[(u32) s >> range_shift], 1u);
+				if (!(dbg & 1u)) raw[blk + fill + (u32) __popcll(m & ((1ull << lane) - 1ull))] = item;
+				if (!(dbg & 2u)) atomicAdd(&hist[(u32) s >> range_shift], 1u);
 			}
 			fill += cnt;
 		}
@@ -1770,10 +1770,28 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	const size_t lds_walk = (size_t) n_ranges_p * 4;
 	if (lds_walk > 64 * 1024) { vdjx_set_error("too many survivor ranges for the walk histogram"); return VDJX_ELIMIT; }
 	HIP_TRY(hipFuncSetAttribute((const void*) k_walk_items, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_walk));
+	// VDJX_WALK_DBG (profiles/walkdbg.sh): an ABLATED copy of the walk runs first into scratch outputs, timed as k_walk_dbg; the real
+	// one follows untouched.  Bits: 1 no item stores, 2 no range histogram, 4 successor = index + 1 without the load, 8 no
+	// filter / table / key loads at run starts.  Measured at 10 M pairs: 7.5 ms whole, 7.0 / 7.5 / 4.6 / 3.4 ms, 2.0 ms with all four.
+	static const u32 walk_dbg = (u32) tune("VDJX_WALK_DBG", 0);
+	if (R && walk_dbg) {
+		u64* raw2;
+		unsigned long long* cur2;
+		u32* cnt2;
+		HIP_TRY(db.alloc(&raw2, (size_t) raw_cap));
+		HIP_TRY(db.alloc(&cur2, 1));
+		HIP_TRY(db.alloc(&cnt2, n_ranges_p));
+		HIP_TRY(hipMemsetAsync(cur2, 0, 8, st));
+		HIP_TRY(hipMemsetAsync(cnt2, 0, (size_t) n_ranges_p * 4, st));
+		vdjx_prof_scope ps(c, "k_walk_dbg");
+		hipLaunchKernelGGL(k_walk_items, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, k, tb, succ, succ1, range_shift,
+		                   n_ranges_p, raw2, raw_cap, blk_items, cur2, cnt2, g_err, walk_dbg);
+		HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
+	}
 	if (R) {
 		vdjx_prof_scope ps(c, "k_walk_items");
 		hipLaunchKernelGGL(k_walk_items, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, k, tb, succ, succ1, range_shift,
-		                   n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err);
+		                   n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err, 0u);
 	}
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, range_cnt, n_ranges_p, range_start);
 	// the partitioned items: at most one per instance
