@@ -2,6 +2,7 @@
 Decoding is pinned on files written by real samtools (tests/golden/bam, from the reference tree's samtools-1.2/test/mpileup);
 the extraction order rules are checked against the independent model of tests/bam_model.py (the reference side of this row
 cannot be compiled here: parity of the rules is a restatement, not a pinned oracle)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -183,3 +184,41 @@ def test_errors(tmp_path):
     with pytest.raises(RuntimeError, match="cannot open"):
         B.extract(bam, fa, "chr7:1-10", "chr7:1-10")
     assert B.lib().bamx_is_bam(bam.encode()) == 1 and B.lib().bamx_is_bam(fa.encode()) == 0
+
+
+def _raw_bam(path, stream: bytes):
+    with open(path, "wb") as f:
+        f.write(B.bgzf_block(stream) + B.bgzf_block(b""))
+
+
+def test_corrupt_sizes_fail_cleanly(tmp_path):
+    """sizes taken from the file are bounded before they reach an allocator (a hostile or damaged BAM / BAI must not crash the
+    reader): absurd reference count, reference-name length, record length, and index bin count"""
+    import struct
+    L = B.lib()
+    text = b"@HD\tVN:1.4\n"
+    head = b"BAM\1" + struct.pack("<I", len(text)) + text
+    cases = {
+        "refs": head + struct.pack("<I", 0xFFFFFFF0),
+        "name": head + struct.pack("<I", 1) + struct.pack("<I", 0x7FFFFFFF) + b"chr1\0",
+    }
+    for tag, stream in cases.items():
+        p = str(tmp_path / f"{tag}.bam")
+        _raw_bam(p, stream)
+        assert not L.bamx_open(p.encode()), tag
+        assert L.bamx_last_error()
+    # a record that claims 3 GB
+    good = head + struct.pack("<I", 1) + struct.pack("<I", 5) + b"chr1\0" + struct.pack("<I", 1000)
+    p = str(tmp_path / "rec.bam")
+    _raw_bam(p, good + struct.pack("<I", 0xC0000000) + b"\0" * 64)
+    f = L.bamx_open(p.encode())
+    assert f
+    r = B.Rec()
+    assert L.bamx_read1(f, C.byref(r)) < -1 and b"sane" in L.bamx_last_error()
+    L.bamx_close(f)
+    # an index that claims 2^31 bins
+    pb = str(tmp_path / "x.bam")
+    with open(pb + ".bai", "wb") as fh:
+        fh.write(b"BAI\1" + struct.pack("<I", 1) + struct.pack("<I", 0x7FFFFFFF))
+    assert not L.bamx_index_load(pb.encode())
+    assert b"cannot open" not in L.bamx_last_error()

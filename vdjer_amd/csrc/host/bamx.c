@@ -31,7 +31,16 @@ struct bamx_file {
 	int n_ref;
 	char** ref_name;
 	int32_t* ref_len;
+	uint8_t* rec_data;                /* variable part of the record being read (per file: the reader is re-entrant) */
+	size_t rec_cap;
 };
+
+/* sizes taken from a file are bounded before they reach an allocator: a corrupt or hostile BAM fails cleanly */
+#define BAMX_MAX_REFS (1 << 24)
+#define BAMX_MAX_NAME (1 << 16)
+#define BAMX_MAX_RECORD (1u << 26)          /* 64 MB: far beyond any short-read record */
+#define BAMX_MAX_BINS (1 << 22)
+#define BAMX_MAX_CHUNKS (1 << 26)
 
 static int rd_u16(const uint8_t* p) { return p[0] | (p[1] << 8); }
 static uint32_t rd_u32(const uint8_t* p) { return (uint32_t) p[0] | ((uint32_t) p[1] << 8) | ((uint32_t) p[2] << 16) | ((uint32_t) p[3] << 24); }
@@ -128,13 +137,20 @@ bamx_file* bamx_open(const char* path) {
 		l_text -= (uint32_t) take;
 	}
 	if (bz_read(f, b, 4) != 4) { fail("%s: truncated header", path); bamx_close(f); return NULL; }
-	f->n_ref = (int) rd_u32(b);
-	f->ref_name = (char**) calloc((size_t) f->n_ref + 1, sizeof(char*));
-	f->ref_len = (int32_t*) calloc((size_t) f->n_ref + 1, 4);
+	{
+		const uint32_t nr = rd_u32(b);
+		if (nr > BAMX_MAX_REFS) { fail("%s: %u reference sequences: not a sane BAM header", path, nr); bamx_close(f); return NULL; }
+		f->ref_name = (char**) calloc((size_t) nr + 1, sizeof(char*));
+		f->ref_len = (int32_t*) calloc((size_t) nr + 1, 4);
+		if (!f->ref_name || !f->ref_len) { fail("%s: out of memory for %u reference names", path, nr); bamx_close(f); return NULL; }
+		f->n_ref = (int) nr;
+	}
 	for (int i = 0; i < f->n_ref; i++) {
 		if (bz_read(f, b, 4) != 4) { fail("%s: truncated reference list", path); bamx_close(f); return NULL; }
 		const uint32_t ln = rd_u32(b);
+		if (ln > BAMX_MAX_NAME) { fail("%s: reference name of %u bytes", path, ln); bamx_close(f); return NULL; }
 		f->ref_name[i] = (char*) calloc((size_t) ln + 1, 1);
+		if (!f->ref_name[i]) { fail("%s: out of memory", path); bamx_close(f); return NULL; }
 		if (bz_read(f, f->ref_name[i], ln) != (long) ln || bz_read(f, b, 4) != 4) { fail("%s: truncated reference list", path); bamx_close(f); return NULL; }
 		f->ref_len[i] = (int32_t) rd_u32(b);
 	}
@@ -147,6 +163,7 @@ void bamx_close(bamx_file* f) {
 	for (int i = 0; i < f->n_ref; i++) free(f->ref_name ? f->ref_name[i] : NULL);
 	free(f->ref_name);
 	free(f->ref_len);
+	free(f->rec_data);
 	free(f);
 }
 
@@ -176,10 +193,15 @@ int bamx_read1(bamx_file* f, bamx_rec* r) {
 	r->flag = (uint16_t) (y >> 16);
 	r->n_cigar = (int32_t) (y & 0xFFFF);
 	r->l_qseq = (int32_t) rd_u32(b + 16);
+	if (block_len > BAMX_MAX_RECORD) return fail("record of %u bytes: not a sane BAM record", block_len);
 	const size_t rest = block_len - 32;
-	static uint8_t* data = NULL;
-	static size_t cap = 0;
-	if (rest + 1 > cap) { cap = rest + 1024; data = (uint8_t*) realloc(data, cap); }
+	if (rest + 1 > f->rec_cap) {
+		uint8_t* nd = (uint8_t*) realloc(f->rec_data, rest + 1024);
+		if (!nd) return fail("out of memory for a record of %u bytes", block_len);
+		f->rec_data = nd;
+		f->rec_cap = rest + 1024;
+	}
+	uint8_t* data = f->rec_data;
 	if (bz_read(f, data, rest) != (long) rest) return fail("truncated record");
 	if (r->l_qseq < 0 || r->l_qseq > 1023) return fail("read of %d bases: longer than this reader takes", r->l_qseq);
 	const size_t need = (size_t) l_qname + (size_t) r->n_cigar * 4 + (size_t) (r->l_qseq + 1) / 2 + (size_t) r->l_qseq;
@@ -237,18 +259,25 @@ bamx_index* bamx_index_load(const char* bam_path) {
 	uint8_t b[16];
 	if (fread(b, 1, 8, fp) != 8 || memcmp(b, "BAI\1", 4)) { fail("%s: no BAI magic", fn); fclose(fp); return NULL; }
 	bamx_index* ix = (bamx_index*) calloc(1, sizeof *ix);
+	if (!ix) { fclose(fp); fail("%s: out of memory", fn); return NULL; }
+	if (rd_u32(b + 4) > BAMX_MAX_REFS) { fail("%s: %u references: not a sane index", fn, rd_u32(b + 4)); fclose(fp); free(ix); return NULL; }
 	ix->n_ref = (int) rd_u32(b + 4);
 	ix->ref = (refidx_t*) calloc((size_t) ix->n_ref + 1, sizeof(refidx_t));
+	if (!ix->ref) { fail("%s: out of memory", fn); fclose(fp); free(ix); return NULL; }
 	for (int i = 0; i < ix->n_ref; i++) {
 		refidx_t* r = &ix->ref[i];
 		if (fread(b, 1, 4, fp) != 4) goto bad;
+		if (rd_u32(b) > BAMX_MAX_BINS) goto bad;
 		r->n_bin = (int) rd_u32(b);
 		r->bins = (bin_t*) calloc((size_t) r->n_bin + 1, sizeof(bin_t));
+		if (!r->bins) { r->n_bin = 0; goto bad; }
 		for (int j = 0; j < r->n_bin; j++) {
 			if (fread(b, 1, 8, fp) != 8) goto bad;
 			r->bins[j].bin = rd_u32(b);
+			if (rd_u32(b + 4) > BAMX_MAX_CHUNKS) goto bad;
 			r->bins[j].n = (int) rd_u32(b + 4);
 			r->bins[j].list = (chunk_t*) calloc((size_t) r->bins[j].n + 1, sizeof(chunk_t));
+			if (!r->bins[j].list) { r->bins[j].n = 0; goto bad; }
 			for (int k = 0; k < r->bins[j].n; k++) {
 				if (fread(b, 1, 16, fp) != 16) goto bad;
 				r->bins[j].list[k].u = rd_u64(b);
@@ -256,8 +285,10 @@ bamx_index* bamx_index_load(const char* bam_path) {
 			}
 		}
 		if (fread(b, 1, 4, fp) != 4) goto bad;
+		if (rd_u32(b) > BAMX_MAX_CHUNKS) goto bad;
 		r->n_intv = (int) rd_u32(b);
 		r->ioff = (uint64_t*) calloc((size_t) r->n_intv + 1, 8);
+		if (!r->ioff) { r->n_intv = 0; goto bad; }
 		for (int j = 0; j < r->n_intv; j++) {
 			if (fread(b, 1, 8, fp) != 8) goto bad;
 			r->ioff[j] = rd_u64(b);

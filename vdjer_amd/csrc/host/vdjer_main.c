@@ -434,6 +434,9 @@ int main(int argc, char** argv) {
 	vdjx_pool* px = NULL;
 	if (rank == 0) {                            /* the read index (and with it the scorers) lives on rank 0's GPU: the whole pool */
 		VX(vdjx_pool_load(gx, rd.primary, rd.n_primary, rd.secondary, rd.n_secondary, rd.rl, &px));
+		if (vdjx_stat(gx, "pool_other_bases"))
+			fprintf(stderr, "warning: %llu bases other than ACGTN in the reads are treated as N (the reference would carry them inside k-mers)\n",
+			        (unsigned long long) vdjx_stat(gx, "pool_other_bases"));
 		VX(vdjx_read_index_build(gx, px, rd.pair_id, rd.read_num, rd.is_rc, rd.reg_rank, rd.n_pairs));
 		status("POST_READ_EXTRACT");
 		fprintf(stderr, "Assembling...\n");

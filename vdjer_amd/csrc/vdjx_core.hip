@@ -238,10 +238,11 @@ extern "C" int vdjx_profile_get(vdjx_ctx* c, int idx, const char** name, double*
 // one ASCII record in LDS -> the packed record g.  REV: the reverse-complement record add_to_buffer writes after every read
 // (bam_read.c:232-243: bases complemented in reverse order, qualities reversed) derived on the chip instead of crossing PCIe
 template <bool REV>
-__device__ inline void pack_one(const uint8_t* r, int rl, size_t g, u64* __restrict__ bases, u64* __restrict__ nmask, u64* __restrict__ lowq,
-                                uint8_t* __restrict__ quals, int qstride) {
+__device__ inline u32 pack_one(const uint8_t* r, int rl, size_t g, u64* __restrict__ bases, u64* __restrict__ nmask, u64* __restrict__ lowq,
+                               uint8_t* __restrict__ quals, int qstride) {
 	u128 b = 0;
 	u64 nm = 0, lq = 0;
+	u32 other = 0;                       // bases that are neither ACGT nor N (the BAM alphabet "=ACMGRSVTWYHKDBN", bam_read.c:52)
 	for (int i = 0; i < rl; i++) {
 		const int si = REV ? rl - 1 - i : i;
 		const u32 ch = r[1 + si];
@@ -249,6 +250,7 @@ __device__ inline void pack_one(const uint8_t* r, int rl, size_t g, u64* __restr
 		u32 code = (0xD8u >> (((ch >> 1) & 3u) * 2u)) & 3u;                  // 00->0, 01->2, 10->1, 11->3
 		if (REV) code ^= 1u;                                                // complement: A<->T (0<->1), C<->G (2<->3)
 		const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+		other += (!acgt && ch != 'N') ? 1u : 0u;
 		nm |= (u64) (!acgt) << i;
 		b = (b << 2) | (acgt ? code : 0u);
 		const u32 q = (u32) (uint8_t) (r[1 + rl + si] - 33);                 // phred33(), A2:150-152
@@ -274,6 +276,7 @@ __device__ inline void pack_one(const uint8_t* r, int rl, size_t g, u64* __restr
 		}
 		qd[v4] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
 	}
+	return other;
 }
 
 // FWD: `ascii` holds the reads as extracted only; packed records 2i (as is) and 2i+1 (reverse complement) come out of read i
@@ -296,12 +299,14 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 	if (threadIdx.x >= nhere) return;
 	const uint8_t* r = lds + (size_t) threadIdx.x * reclen;
 	if (r[0] != '0') atomicAdd(bad_strand, 1u);   // A2:383-391; the reference only ever writes '0' (bam_read.c:219,231)
+	u32 other;
 	if (FWD) {
 		const size_t g = rec0 + 2 * (first + threadIdx.x);
-		pack_one<false>(r, rl, g, bases, nmask, lowq, quals, qstride);
-		pack_one<true>(r, rl, g + 1, bases, nmask, lowq, quals, qstride);
+		other = 2 * pack_one<false>(r, rl, g, bases, nmask, lowq, quals, qstride);
+		(void) pack_one<true>(r, rl, g + 1, bases, nmask, lowq, quals, qstride);
 	} else
-		pack_one<false>(r, rl, rec0 + first + threadIdx.x, bases, nmask, lowq, quals, qstride);
+		other = pack_one<false>(r, rl, rec0 + first + threadIdx.x, bases, nmask, lowq, quals, qstride);
+	if (other) atomicAdd(bad_strand + 1, other);     // (rare: reported through vdjx_stat("pool_other_bases"))
 }
 
 static int pool_alloc(vdjx_ctx* c, size_t R, size_t n_primary, int rl, vdjx_pool** out, u32** d_bad) {
@@ -326,7 +331,7 @@ static int pool_alloc(vdjx_ctx* c, size_t R, size_t n_primary, int rl, vdjx_pool
 	p->d_lowq = (u64*) (p->d_block + Ra * 24);
 	p->d_quals = (uint8_t*) (p->d_block + Ra * 32);
 	*d_bad = (u32*) (p->d_block + Ra * (32 + (size_t) p->qstride));
-	(void) hipMemset(*d_bad, 0, 4);                  // (synchronous: the packing may run on either stream)
+	(void) hipMemset(*d_bad, 0, 8);                  // (synchronous: the packing may run on either stream); [0] bad strand bytes, [1] other bases
 	*out = p;
 	return VDJX_OK;
 }
@@ -340,11 +345,15 @@ static void pack_launch(vdjx_ctx* c, hipStream_t st, vdjx_pool* p, const uint8_t
 }
 
 static int pool_finish(vdjx_ctx* c, vdjx_pool* p, u32* d_bad, vdjx_pool** out) {
-	u32 bad = 0;
-	hipError_t e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream);
+	u32 both[2] = {0, 0};
+	hipError_t e = hipMemcpyAsync(both, d_bad, 8, hipMemcpyDeviceToHost, c->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipGetLastError();
 	if (e != hipSuccess) { vdjx_set_error("pool pack: %s", hipGetErrorString(e)); vdjx_pool_free(p); return VDJX_EHIP; }
+	const u32 bad = both[0];
+	// IUPAC codes other than N are packed as N (the reference keeps them inside its k-mer strings and exits in seq_to_int,
+	// seq_to_kmer.c:22-24, as soon as one reaches a node): the count lets a caller see the deviation
+	c->stats["pool_other_bases"] = both[1];
 	if (bad) {
 		// build_pre_graph prints "Initial char in input invalid" and exits (A2:383-391); we return an error
 		vdjx_set_error("pool: %u records do not start with the '0' strand byte", bad);
