@@ -664,3 +664,25 @@ def test_pool_load_forward_derives_the_reverse_complement_records(ctx):
     assert res[0][1].tobytes() == res[1][1].tobytes() and res[0][1].shape[0] > 100
     full.free()
     fwd.free()
+
+
+def test_iupac_bases_are_counted_and_read_as_N(ctx):
+    """bases other than ACGTN (the BAM alphabet has them, bam_read.c:52) are packed as N: k-mers over them are dropped like the
+    reference drops k-mers over N, and the count is visible (vdjx_stat "pool_other_bases")"""
+    c = G.Case("noisy")
+    ctx.anchor_sets_load(c.v_codes, c.j_codes)
+    pri = c.pool.primary.copy()
+    as_n = pri.copy()
+    rows = np.arange(0, pri.shape[0], 7)
+    pri[rows, 20] = ord("R")
+    as_n[rows, 20] = ord("N")
+    p1 = ctx.pool_load(pri, c.pool.secondary, c.pool.rl)
+    assert ctx.stat("pool_other_bases") == rows.shape[0]
+    g1 = ctx.kmer_build(p1, 35, 3, 90)
+    p2 = ctx.pool_load(as_n, c.pool.secondary, c.pool.rl)
+    assert ctx.stat("pool_other_bases") == 0
+    g2 = ctx.kmer_build(p2, 35, 3, 90)
+    for f in ("first_inst", "freq", "gated_count", "to_ids", "from_ids", "kmers"):
+        np.testing.assert_array_equal(getattr(g1, f), getattr(g2, f))
+    p1.free()
+    p2.free()
