@@ -39,26 +39,25 @@ REF_BIN = os.path.join(ROOT, "oracle", "_ref", "vdjer_ref")
 
 def algorithmic_bytes_per_pair(k: int, rl: int = 50) -> dict:
     """SURVEY §8d.  P = 4*(rl-k+1) instances per pair; compulsory input of a pair = 2 reads x (packed bases + qualities).
-    Per kernel: what its JOB requires per pair, not what the implementation moves:
+    Per kernel: what its JOB requires per pair in the SURVEY's accounting, not what the implementation moves
+    (the round-2 build moves far less than 16 B per instance through the partition: only gated instances travel):
       pack: the ASCII records in;  hist: the packed input once;  partition pass 1: packed input + one 16-B key per instance
-      out;  pass 2: every key in and out;  aggregate / local: every key in;  finalize: every key in (upper bound);
-      edges: packed input once more + one 16-B probe per instance."""
+      out;  pass 2: every key in and out;  table + prune: every key in;
+      walk (the graph pass): packed input once more + one 16-B survivor probe per instance."""
     P = 4 * (rl - k + 1)
     inp = 2 * ((rl + 3) // 4 + rl)
     return {"P": P, "input": inp, "total": inp + 32 * P + inp + 16 * P,
-            "k_pool_pack": 4 * (2 * rl + 1), "k_kmer_hist": inp, "k_part_records": inp + 16 * P, "k_part_tuples": 32 * P,
-            "k_seg_hist": 16 * P, "k_bucket_aggregate": 16 * P, "k_bucket_local": 16 * P, "k_bucket_finalize": 16 * P,
-            "k_graph_edges": inp + 16 * P,
-            # super-k-mer build (round 2): same jobs, same algorithmic bytes -- the 16-B-per-instance figure is the
-            # SURVEY's compulsory key traffic whatever the representation moved
-            "k_skm_scan": inp + 16 * P, "k_skm_part": 32 * P, "k_skm_aggregate": 16 * P}
+            "k_pool_pack": 4 * (2 * rl + 1), "k_gated_hist": inp, "k_part_records": inp + 16 * P, "k_part_tuples": 32 * P,
+            "k_seg_hist": 16 * P, "k_gated_reduce": 16 * P, "k_gated_local": 16 * P, "k_walk_items": inp + 16 * P}
 
 
 def scorer_bytes(stats: dict, n_windows: int, n_contigs: int, k: int, rl: int = 50, wlen: int = 486, clen: int = 360) -> dict:
     """SURVEY §8d, scorers (not proportional to pairs): per window (len-rl) probes x 32 B + 8 B per matched read
     instance; 8 B per emitted start entry; per contig (len-rl) probes x 32 B + 8 B per instance + one 20-B pair
     record out; per (root, seed hit) k + 2k bytes."""
-    return {"k_window_hits": n_windows * (wlen - rl) * 32,
+    return {"k_part_items": 16 * stats.get("recount_items", 0),          # every surviving instance's 8-byte item in and out
+            "k_recount": 8 * stats.get("recount_items", 0),
+            "k_window_hits": n_windows * (wlen - rl) * 32,
             "k_window_pairs": n_windows * (wlen - rl) * 32 + 8 * stats.get("window_hits", 0),
             "k_window_cover": 8 * 2 * stats.get("window_pairs", 0),
             "k_map_emit": n_contigs * (clen - rl) * 32 + 8 * stats.get("map_hits", 0),
@@ -198,7 +197,7 @@ def load_traffic(args, world: int, kernel: str):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=10_000_000, help="pairs per GPU")
     ap.add_argument("--clones", type=int, default=0, help="clones per GPU (default: pairs / 500)")
@@ -467,7 +466,7 @@ def main():
             nxt.wait()
             nxt.free()
         del host_fwd["pri"], host_fwd["sec"]
-    stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_hits_distinct", "window_pairs", "window_work_items", "map_hits", "root_dp_items")}
+    stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_hits_distinct", "window_pairs", "window_work_items", "map_hits", "root_dp_items", "recount_items")}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         cm.all_reduce(tt, dist.ReduceOp.MAX)

@@ -1843,11 +1843,13 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		HIP_TRY(hipMemsetAsync(ro.edge_first, 0xFF, (size_t) ns * 32, st));
 		hipLaunchKernelGGL(k_edges_from_in, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, tb, ns, k, ro.in_first, ro.in_from, ro.edge_first, ro.edge_to);
 	}
-	u32 err = 0;
+	u32 err = 0, n_items = 0;
 	HIP_TRY(hipMemcpyAsync(&err, g_err, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&n_items, range_start + n_ranges_p, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
 	if (err) { vdjx_set_error("k_walk_items: item buffer too small (%u waves stopped)", err); return VDJX_EHIP; }
+	c->stats["recount_items"] = n_items;            // surviving k-mer instances of this pool
 	return VDJX_OK;
 }
 
