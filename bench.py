@@ -37,18 +37,22 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "vdjer_ref")
 
 
-def algorithmic_bytes_per_pair(k: int, rl: int = 50) -> dict:
-    """SURVEY §8d.  P = 4*(rl-k+1) instances per pair; compulsory input of a pair = 2 reads x (packed bases + qualities).
-    Per kernel: what its JOB requires per pair in the SURVEY's accounting, not what the implementation moves
-    (the round-2 build moves far less than 16 B per instance through the partition: only gated instances travel):
-      pack: the ASCII records in;  hist: the packed input once;  partition pass 1: packed input + one 16-B key per instance
-      out;  pass 2: every key in and out;  table + prune: every key in;
-      walk (the graph pass): packed input once more + one 16-B survivor probe per instance."""
+def algorithmic_bytes_per_pair(k: int, rl: int = 50, gated_per_pair: float | None = None) -> dict:
+    """SURVEY §8d.  P = 4*(rl-k+1) instances per pair; compulsory input of a pair = 2 reads x (packed bases + qualities);
+    "every gated instance must reach its owner bucket once as a 16-B packed key, written once and read once"; the graph pass
+    re-reads the packed input and probes the survivors with one 16-B key per instance.
+    `total` is the SURVEY's per-pair figure for the whole k-mer build (it takes every instance as gated: 3,324 B at k=35) and
+    prices the whole path (hot_path_frac).  Per kernel the job is priced with the MEASURED number of gated instances per pair
+    (vdjx_stat "gated_instances": one instance in six of this generator's pools), because that is what the kernels move:
+      pack: the ASCII records in;  hist: the packed input once;  partition pass 1: packed input + one 16-B key per gated
+      instance out;  pass 2: every such key in and out;  table + prune: every key in;
+      walk (the graph pass): packed input once more + one 16-B survivor probe per instance (gated or not)."""
     P = 4 * (rl - k + 1)
     inp = 2 * ((rl + 3) // 4 + rl)
-    return {"P": P, "input": inp, "total": inp + 32 * P + inp + 16 * P,
-            "k_pool_pack": 4 * (2 * rl + 1), "k_gated_hist": inp, "k_part_records": inp + 16 * P, "k_part_tuples": 32 * P,
-            "k_seg_hist": 16 * P, "k_gated_reduce": 16 * P, "k_gated_local": 16 * P, "k_walk_items": inp + 16 * P}
+    g = P if gated_per_pair is None else gated_per_pair
+    return {"P": P, "input": inp, "total": inp + 32 * P + inp + 16 * P, "gated_per_pair": g,
+            "k_pool_pack": 4 * (2 * rl + 1), "k_gated_hist": inp, "k_part_records": inp + 16 * g, "k_part_tuples": 32 * g,
+            "k_seg_hist": 16 * g, "k_gated_reduce": 16 * g, "k_gated_local": 16 * g, "k_walk_items": inp + 16 * P}
 
 
 def scorer_bytes(stats: dict, n_windows: int, n_contigs: int, k: int, rl: int = 50, wlen: int = 486, clen: int = 360) -> dict:
@@ -466,7 +470,7 @@ def main():
             nxt.wait()
             nxt.free()
         del host_fwd["pri"], host_fwd["sec"]
-    stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_hits_distinct", "window_pairs", "window_work_items", "map_hits", "root_dp_items", "recount_items")}
+    stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_hits_distinct", "window_pairs", "window_work_items", "map_hits", "root_dp_items", "recount_items", "gated_instances")}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         cm.all_reduce(tt, dist.ReduceOp.MAX)
@@ -495,7 +499,7 @@ def main():
     ms_step = dt / args.steps * 1e3
     total_pairs = args.pairs * world
     value = total_pairs * args.steps / dt / 1e6
-    ab = algorithmic_bytes_per_pair(args.k, rl)
+    ab = algorithmic_bytes_per_pair(args.k, rl, stats.get("gated_instances", 0) / args.pairs if stats.get("gated_instances") else None)
     # dominant kernel of the step by summed device time
     dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else (None, (0.0, 0))
     roof = None

@@ -1593,6 +1593,7 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
 	out->N = N;
+	c->stats["gated_instances"] = N;                // k-mer instances that pass include_kmer (A2:240-259) in this pool
 	// bucket bits from the actual number of gated instances; in the sharded build every rank must cut the same buckets, so there
 	// the geometry follows the common bound `geometry_instances` instead
 	const u64 Ng = geometry_instances ? geometry_instances : (u64) N;
