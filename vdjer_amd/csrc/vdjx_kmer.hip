@@ -1029,14 +1029,19 @@ __global__ void k_node_flags(const u64* __restrict__ s_lo, const u64* __restrict
 // ==============================================================================================
 // Phase B: add_to_graph's bookkeeping (A2:261-320) for the survivors, bucket-local like everything else.
 //
-// The walk over the records (one thread per record, as k_graph_edges) finds the surviving k-mer of every instance: a hash
-// lookup where a run of survivors starts, one 4-byte successor link per further offset.  Instead of updating per-node
-// counters with global atomics (640 M random memory-side atomics at 10 M pairs), every surviving instance becomes an 8-byte
-// item {survivor index, instance id, first base of the surviving predecessor k-mer if the previous offset survived too};
-// items are partitioned by survivor index (LDS-staged, like the tuples) and one workgroup per range of survivors counts
-// them in LDS arrays indexed directly by (index - range start): node frequency, first sight (= creation order), and the
-// first sight of every in-edge (v, first base of u) -- the edge u -> v under the name of its head.
-//   item = survivor (26 bits) << 38 | has_prev << 37 | pred base << 35 | local record (29 bits) << 6 | offset
+// Nine survivors in ten have exactly one surviving successor, and a read follows such a chain for all of its offsets.  The
+// survivors are therefore renumbered in CHAIN ORDER first (list ranking over the single-successor links): along a chain the
+// successor of survivor p is p + 1, and what the walk over the records needs to know about 16 consecutive survivors (is p + 1
+// the successor, with which last base) fits one 64-bit word.  A record then costs one hash lookup where a run of survivors
+// starts and one word per 16 survivors it runs through -- not a link load per offset -- and a whole run inside a block of 16
+// becomes ONE 8-byte item {first survivor, length, instance id of its first k-mer, first base of the surviving predecessor
+// k-mer if the offset before the run survived too}, not one item per instance.
+// Items are partitioned by survivor range (LDS-staged, like the tuples) and one workgroup per range counts them in LDS:
+// node frequency, first sight (= creation order), and the first sight of every in-edge (v, first base of u) -- the edge
+// u -> v under the name of its head.  Blocks of 16 are spread over the ranges by a multiplicative permutation: a deep clone's
+// chain would otherwise put all of its instances into one or two workgroups.
+//   item = (length - 1) << (38 + pb) | survivor (pb bits) << 38 | has_prev << 37 | pred base << 35 | local record (29 bits) << 6 | offset
+//   pb = 26 - lb, lb = min(4, 26 - ceil(log2(survivors))): runs are cut at 2^lb instances when the survivors need the bits
 // ==============================================================================================
 #define IT_INST_BITS 35
 #define IT_INST_MASK ((1ull << IT_INST_BITS) - 1ull)
@@ -1045,6 +1050,19 @@ __global__ void k_node_flags(const u64* __restrict__ s_lo, const u64* __restrict
 #define WALK_THREADS 256
 
 struct SurvTable { const u32* table; u32 mask; u32 idx_bits; const ulonglong2* skey; const u32* bloom; u32 bloom_mask; };      // bloom: one bit per survivor hash, 16 bits of filter per survivor: L2-resident (2 MB at 10 M pairs)
+
+// item layout and the block permutation (host: make_item_fmt)
+struct ItemFmt {
+	u32 pmask;       // survivor field
+	u32 len_shift;   // 38 + pb
+	u32 maxlen;      // 2^lb
+	u32 mul, inv;    // scattered block = (block * mul) & bmask, block = (scattered * inv) & bmask
+	u32 bmask;       // 2^t - 1 >= number of blocks - 1
+	u32 ns;          // survivors
+};
+__device__ inline u32 it_surv(const ItemFmt& f, u64 x) { return (u32) (x >> IT_SURV_SHIFT) & f.pmask; }
+__device__ inline u32 it_len(const ItemFmt& f, u64 x) { return f.maxlen > 1 ? (u32) (x >> f.len_shift) + 1u : 1u; }
+__device__ inline u32 it_scat(const ItemFmt& f, u32 p) { return ((((p >> 4) * f.mul) & f.bmask) << 4) | (p & 15u); }    // position in the scattered index space
 
 // table entry = fingerprint of the key's hash (32 - idx_bits bits) << idx_bits | (survivor index + 1)
 __global__ void k_surv_table2(const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, u32 n, u32* __restrict__ table, u32 mask,
@@ -1090,29 +1108,171 @@ __device__ inline int surv_lookup2f(const SurvTable& t, u64 lo, u64 hi) {
 	return surv_lookup2(t, lo, hi);
 }
 
-// succ[u*4+b] = survivor index of (key_u << 2 | b) mod 4^k, or NONE32.  Nine nodes in ten have exactly one surviving successor:
-// succ1[u] = successor << 3 | its last base << 1 | 1 holds it in 4 bytes (0 = no successor at all, 2 = several: look into succ[]),
-// a quarter of the footprint the walk touches at random (the 16 bytes per node of succ[] miss the XCD's 4 MB L2 at 10 M pairs).
-__global__ void k_succ_links2(SurvTable t, u32 n, int k, u32* __restrict__ succ, u32* __restrict__ succ1) {
+// ---- chain order ------------------------------------------------------------------------------
+// succ[u*4+b] = survivor index of (key_u << 2 | b) mod 4^k, or NONE32 (arrival numbering).  Every node with a successor proposes
+// itself as the chain predecessor of its HEAVIEST successor (gated count; in a deep clone every k-mer also has surviving error
+// branches, the clone's own path is the heavy one), and a node takes its heaviest proposer (atomicMax over count << 32 | ~index:
+// the same on every rank): the chains are a heavy-path decomposition of the graph.
+__global__ void k_succ_links2(SurvTable t, u32 n, int k, const u32* __restrict__ gcnt, u32* __restrict__ succ, unsigned long long* __restrict__ pred) {
 	const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
 	if (u >= n) return;
 	const ulonglong2 kk = t.skey[u];
 	const u128 base = (((u128) kk.y << 64) | kk.x) << 2;
 	const u128 km = k < 64 ? (((u128) 1) << (2 * k)) - 1 : ~(u128) 0;
-	u32 nv = 0, one = 0;
+	u32 best = NONE32, best_g = 0;
 	for (u32 b = 0; b < 4; b++) {
 		const u128 key = (base | (u128) b) & km;
 		const int s = surv_lookup2(t, (u64) key, (u64) (key >> 64));
 		succ[u * 4 + b] = s >= 0 ? (u32) s : NONE32;
-		if (s >= 0) { nv++; one = ((u32) s << 3) | (b << 1) | 1u; }
+		if (s >= 0 && (u32) s != u) {
+			const u32 g = gcnt[s];
+			if (best == NONE32 || g > best_g) { best = (u32) s; best_g = g; }
+		}
 	}
-	succ1[u] = nv == 0 ? 0u : (nv == 1 ? one : 2u);
+	if (best != NONE32) atomicMax(&pred[best], ((unsigned long long) gcnt[u] << 32) | (unsigned long long) (0xFFFFFFFFu - u));
 }
 
-// the walk: every wave appends its items to blocks of `blk_items` slots it reserves from the global cursor (unused slots of a
-// block are filled with IT_HOLE); item counts per survivor range go to range_cnt
+// list ranking by pointer jumping, in place: pd[v] = ancestor << 32 | distance to it (ancestor NONE32: v is a head).  Every entry
+// is a true statement at all times, so concurrent updates are harmless.  A node is resolved when its ancestor is a head.  With
+// CHAIN_JUMPS jumps per node a launch multiplies the resolved distance by at least CHAIN_JUMPS + 1 (all other nodes standing still)
+// and normally by 2^CHAIN_JUMPS; launches after the one that found nothing to do return at once.
+#define CHAIN_JUMPS 15
+__global__ void k_chain_init(const unsigned long long* __restrict__ pred, u32 n, u64* __restrict__ pd) {
+	const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= n) return;
+	const unsigned long long x = pred[v];            // 0: nobody proposed
+	pd[v] = x == 0ull ? ((u64) NONE32 << 32) : ((u64) (0xFFFFFFFFu - (u32) x) << 32) | 1ull;
+}
+
+__global__ void k_chain_jump(u64* __restrict__ pd, u32 n, const u32* __restrict__ open_prev, u32* __restrict__ open_now) {
+	if (open_prev && *open_prev == 0) return;          // (every node resolved by an earlier launch)
+	const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+	bool open = false;
+	if (v < n) {
+		u64 x = __atomic_load_n(&pd[v], __ATOMIC_RELAXED);
+		for (int it = 0; it < CHAIN_JUMPS; it++) {
+			const u32 p = (u32) (x >> 32);
+			if (p == NONE32) break;
+			const u64 y = __atomic_load_n(&pd[p], __ATOMIC_RELAXED);
+			const u32 pp = (u32) (y >> 32);
+			if (pp == NONE32) break;                      // p is the head
+			x = ((u64) pp << 32) | (u64) ((u32) x + (u32) y);
+			__atomic_store_n(&pd[v], x, __ATOMIC_RELAXED);
+			open = true;
+		}
+	}
+	if (__ballot(open) && __lane_id() == 0) atomicAdd(open_now, 1u);
+}
+
+// chain lengths at the heads.  Nodes still unresolved after all launches sit on pure cycles (tandem repeats): nothing resolved
+// depends on them, each becomes a chain of its own.
+__device__ inline void chain_of(const u64* pd, u32 v, u32& head, u32& dist) {
+	const u64 x = pd[v];
+	const u32 p = (u32) (x >> 32);
+	head = v; dist = 0;
+	if (p == NONE32) return;
+	if ((u32) (pd[p] >> 32) != NONE32) return;             // unresolved
+	head = p; dist = (u32) x;
+}
+__global__ void k_chain_len(const u64* __restrict__ pd, u32 n, u32* __restrict__ len) {
+	const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= n) return;
+	u32 h, d;
+	chain_of(pd, v, h, d);
+	atomicAdd(&len[h], 1u);
+}
+
+// exclusive scan of a[0..n) in three launches: block sums (SCAN_BLOCK per workgroup), their scan (k_bucket_scan), the blocks again
+#define SCAN_BLOCK 4096u
+__global__ __launch_bounds__(256) void k_scan_sums(const u32* __restrict__ a, u32 n, u32* __restrict__ sums) {
+	__shared__ u32 part[4];
+	const u32 b0 = blockIdx.x * SCAN_BLOCK;
+	u32 s = 0;
+	for (u32 i = threadIdx.x; i < SCAN_BLOCK; i += 256) s += b0 + i < n ? a[b0 + i] : 0u;
+	s = (u32) vdjx_wave_scan_add((int) s);
+	if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(256) void k_scan_apply(const u32* __restrict__ a, u32 n, const u32* __restrict__ sum_start, u32* __restrict__ out) {
+	__shared__ u32 part[5];
+	const u32 b0 = blockIdx.x * SCAN_BLOCK + threadIdx.x * 16;
+	u32 loc[16];
+	u32 s = 0;
+	for (int i = 0; i < 16; i++) { loc[i] = s; s += b0 + i < n ? a[b0 + i] : 0u; }
+	const u32 incl = (u32) vdjx_wave_scan_add((int) s);
+	if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = incl;
+	__syncthreads();
+	u32 base = sum_start[blockIdx.x] + incl - s;
+	for (u32 w = 0; w < (threadIdx.x >> 6); w++) base += part[w];
+	for (int i = 0; i < 16; i++) if (b0 + i < n) out[b0 + i] = base + loc[i];
+}
+
+// the new index of every survivor, and the arrays in the new order
+__global__ void k_chain_place(const u64* __restrict__ pd, const u32* __restrict__ off, u32 n, u32* __restrict__ newidx) {
+	const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= n) return;
+	u32 h, d;
+	chain_of(pd, v, h, d);
+	newidx[v] = off[h] + d;
+}
+__global__ void k_chain_permute(const u32* __restrict__ newidx, u32 n, const u64* __restrict__ lo, const u64* __restrict__ hi, const u32* __restrict__ gcnt,
+                                const u64* __restrict__ gfirst, const u32* __restrict__ succ, u64* __restrict__ lo2, u64* __restrict__ hi2,
+                                u32* __restrict__ gcnt2, u64* __restrict__ gfirst2, ulonglong2* __restrict__ skey2, u32* __restrict__ succ2) {
+	const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= n) return;
+	const u32 q = newidx[v];
+	const u64 l = lo[v], h = hi[v];
+	lo2[q] = l; hi2[q] = h; gcnt2[q] = gcnt[v]; gfirst2[q] = gfirst[v];
+	skey2[q] = make_ulonglong2(l, h);
+	const uint4 s = *(const uint4*) &succ[(size_t) v * 4];
+	uint4 r;
+	r.x = s.x == NONE32 ? NONE32 : newidx[s.x];
+	r.y = s.y == NONE32 ? NONE32 : newidx[s.y];
+	r.z = s.z == NONE32 ? NONE32 : newidx[s.z];
+	r.w = s.w == NONE32 ? NONE32 : newidx[s.w];
+	*(uint4*) &succ2[(size_t) q * 4] = r;
+}
+__global__ void k_table_remap(u32* __restrict__ table, u32 slots, u32 idx_bits, const u32* __restrict__ newidx) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= slots) return;
+	const u32 v = table[i];
+	if (!v) return;
+	const u32 imask = idx_bits < 32 ? (1u << idx_bits) - 1u : 0xFFFFFFFFu;
+	table[i] = (v & ~imask) | (newidx[(v & imask) - 1] + 1u);
+}
+
+// per block of 16 survivors (new numbering): 4 bits per survivor p in linw -- bit 0: p + 1 is a successor, bits 1-2 its last base,
+// bit 3: there are other successors (look into succ[]) -- and 2 bits per survivor in fbw, the first base of its k-mer (the name
+// of the in-edge p -> p + 1 at its head)
+__global__ void k_chain_words(const u32* __restrict__ succ, const ulonglong2* __restrict__ skey, u32 n, int k, u64* __restrict__ linw, u32* __restrict__ fbw) {
+	const u32 p = blockIdx.x * blockDim.x + threadIdx.x;      // (blockDim multiple of 64, n padded by the caller's grid: whole blocks of 16 lanes)
+	u32 code = 0, fb = 0;
+	if (p < n) {
+		const uint4 s = *(const uint4*) &succ[(size_t) p * 4];
+		const u32 sv[4] = {s.x, s.y, s.z, s.w};
+		u32 others = 0;
+		for (u32 b = 0; b < 4; b++) if (sv[b] != NONE32) { if (sv[b] == p + 1) code |= 1u | (b << 1); else others = 1; }
+		code |= others << 3;
+		const ulonglong2 kk = skey[p];
+		const int sh = 2 * (k - 1);
+		fb = (u32) (sh < 64 ? kk.x >> sh : kk.y >> (sh - 64)) & 3u;
+	}
+	// 16 lanes -> one word each (DPP-free: LDS-free butterfly through shuffles of the row)
+	u64 w = (u64) code << (4 * (p & 15u));
+	u32 f = fb << (2 * (p & 15u));
+	for (int d = 1; d < 16; d <<= 1) {
+		w |= ((u64) (u32) __shfl_xor((int) (w >> 32), d) << 32) | (u32) __shfl_xor((int) (u32) w, d);
+		f |= (u32) __shfl_xor((int) f, d);
+	}
+	if ((p & 15u) == 0 && p < n) { linw[p >> 4] = w; fbw[p >> 4] = f; }
+}
+
+// ---- the walk ---------------------------------------------------------------------------------
+// every wave appends its items to blocks of `blk_items` slots it reserves from the global cursor (unused slots of a block are
+// filled with IT_HOLE); item counts per survivor range go to range_cnt
 __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restrict__ bases, const u64* __restrict__ nmask, size_t R, int rl, int k,
-                                                             SurvTable t, const u32* __restrict__ succ, const u32* __restrict__ succ1,
+                                                             SurvTable t, const u32* __restrict__ succ, const u64* __restrict__ linw, ItemFmt f,
                                                              u32 range_shift, u32 n_ranges,
                                                              u64* __restrict__ raw, u64 raw_cap, u32 blk_items,
                                                              unsigned long long* __restrict__ g_cursor,
@@ -1136,27 +1296,36 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 		v.bhi = v.blo = 0; v.nm = ~0ull; v.lq = 0;
 		if (live) v = load_rec(bases, nmask, nullptr, r);
 		int prev = -1;
-		for (int o = 0; o < P; o++) {                                 // (uniform trip count: the compaction below is wave-wide)
+		u64 w = 0;                                  // linw of prev's block
+		u32 run_p = 0, run_o = 0, run_len = 0, run_in = 0;            // the open run (run_len 0: none); run_in = has_prev << 2 | pred base
+		for (int o = 0; o <= P; o++) {                                // (uniform trip count: the compaction below is wave-wide; step P closes the last run)
 			int s = -1;
-			u32 pa = 0;
-			if (live && !((v.nm >> o) & km)) {
+			u32 in = 0;
+			if (o < P && live && !((v.nm >> o) & km)) {
 				if (prev >= 0) {
 					const int bsh = 2 * (rl - k - o);                     // last base of the k-mer at o
 					const u32 bb = (u32) (bsh < 64 ? v.blo >> bsh : v.bhi >> (bsh - 64)) & 3u;
-					const u32 s1 = (dbg & 4u) ? ((u32) (prev + 1) << 3) | (bb << 1) | 1u : succ1[prev];       // (dbg: ablation runs, see stage_recount)
-					if (s1 & 1u) s = ((s1 >> 1) & 3u) == bb ? (int) (s1 >> 3) : -1;
-					else if (s1 == 2u) { const u32 nx = succ[(u32) prev * 4u + bb]; s = nx == NONE32 ? -1 : (int) nx; }
+					const u32 code = (u32) (w >> (4 * ((u32) prev & 15u))) & 15u;
+					if ((code & 1u) && ((code >> 1) & 3u) == bb) s = prev + 1;
+					else if (code & 8u) { const u32 nx = succ[(u32) prev * 4u + bb]; s = nx == NONE32 ? -1 : (int) nx; }
 					const int fsh = 2 * (rl - o);                          // first base of the k-mer at o-1 (the predecessor)
-					pa = (u32) (fsh < 64 ? v.blo >> fsh : v.bhi >> (fsh - 64)) & 3u;
+					in = 4u | ((u32) (fsh < 64 ? v.blo >> fsh : v.bhi >> (fsh - 64)) & 3u);
 				} else {
 					u64 khi, klo;
 					vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
-					s = (dbg & 8u) ? ((klo & 3u) ? (int) ((u32) vdjx_mix(klo, khi) % 1000000u) : -1) : surv_lookup2f(t, klo, khi);
+					s = (dbg & 8u) ? ((klo & 3u) ? (int) ((u32) vdjx_mix(klo, khi) % f.ns) : -1) : surv_lookup2f(t, klo, khi);
 				}
 			}
-			const bool has_prev = prev >= 0 && s >= 0;
+			const bool cont = run_len && s == (int) (run_p + run_len) && ((u32) s & 15u) && run_len < f.maxlen;
+			const bool close = run_len && !cont;
+			u64 item = IT_HOLE;
+			if (close) item = (f.maxlen > 1 ? (u64) (run_len - 1) << f.len_shift : 0ull) | ((u64) run_p << IT_SURV_SHIFT) | ((u64) run_in << 35) | ((u64) r << 6) | (u64) run_o;
+			if (cont) run_len++;
+			else if (s >= 0) { run_p = (u32) s; run_o = (u32) o; run_len = 1; run_in = in; }
+			else run_len = 0;
+			if (s >= 0 && (prev < 0 || ((u32) s >> 4) != ((u32) prev >> 4))) w = linw[(u32) s >> 4];
 			prev = s;
-			const u64 m = __ballot(s >= 0);
+			const u64 m = __ballot(close);
 			if (!m) continue;
 			const u32 cnt = (u32) __popcll(m);
 			if (fill + cnt > blk_items) {                             // (wave-uniform)
@@ -1168,10 +1337,9 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				else { blk = nb; have_blk = true; }
 				fill = 0;
 			}
-			if (s >= 0 && !dead) {
-				const u64 item = ((u64) (u32) s << IT_SURV_SHIFT) | ((u64) has_prev << 37) | ((u64) pa << 35) | ((u64) r << 6) | (u64) o;
+			if (close && !dead) {
 				if (!(dbg & 1u)) raw[blk + fill + (u32) __popcll(m & ((1ull << lane) - 1ull))] = item;
-				if (!(dbg & 2u)) atomicAdd(&hist[(u32) s >> range_shift], 1u);
+				if (!(dbg & 2u)) atomicAdd(&hist[it_scat(f, it_surv(f, item)) >> range_shift], 1u);
 			}
 			fill += cnt;
 		}
@@ -1182,7 +1350,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 }
 
 // items -> items grouped by survivor range (see k_part_tuples); holes are dropped.  `n_raw` is read from the device cursor.
-__global__ __launch_bounds__(PART_THREADS) void k_part_items(const u64* __restrict__ in, const unsigned long long* __restrict__ n_raw,
+__global__ __launch_bounds__(PART_THREADS) void k_part_items(const u64* __restrict__ in, const unsigned long long* __restrict__ n_raw, ItemFmt f,
                                                              u32 range_shift, u32 nbk, u32* __restrict__ gcur, u64* __restrict__ out) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	u64* stage = (u64*) smem;
@@ -1198,6 +1366,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_items(const u64* __restri
 		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) cnt[i] = 0;
 		__syncthreads();
 		u64 r_it[PER];
+		u32 r_b[PER];
 #pragma unroll
 		for (u32 j = 0; j < PER; j += 2) {                            // 16-byte loads
 			const size_t t = ts + ((size_t) (j / 2) * PART_THREADS + threadIdx.x) * 2;
@@ -1206,7 +1375,10 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_items(const u64* __restri
 			else if (t < te) r_it[j] = in[t];
 		}
 #pragma unroll
-		for (u32 j = 0; j < PER; j++) if (r_it[j] != IT_HOLE) atomicAdd(&cnt[(u32) (r_it[j] >> IT_SURV_SHIFT) >> range_shift], 1u);
+		for (u32 j = 0; j < PER; j++) {
+			r_b[j] = NONE32;
+			if (r_it[j] != IT_HOLE) { r_b[j] = it_scat(f, it_surv(f, r_it[j])) >> range_shift; atomicAdd(&cnt[r_b[j]], 1u); }
+		}
 		__syncthreads();
 		part_scan(cnt, base, tmp, nbk);
 		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) {
@@ -1215,12 +1387,12 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_items(const u64* __restri
 		}
 		__syncthreads();
 #pragma unroll
-		for (u32 j = 0; j < PER; j++) if (r_it[j] != IT_HOLE) stage[atomicAdd(&cur[(u32) (r_it[j] >> IT_SURV_SHIFT) >> range_shift], 1u)] = r_it[j];
+		for (u32 j = 0; j < PER; j++) if (r_b[j] != NONE32) stage[atomicAdd(&cur[r_b[j]], 1u)] = r_it[j];
 		__syncthreads();
 		const u32 n = base[nbk];
 		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
 			const u64 x = stage[i];
-			const u32 b = (u32) (x >> IT_SURV_SHIFT) >> range_shift;
+			const u32 b = it_scat(f, it_surv(f, x)) >> range_shift;
 			out[gbase[b] + (i - base[b])] = x;
 		}
 		__syncthreads();
@@ -1229,7 +1401,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_items(const u64* __restri
 
 // second level (more than 1024 survivor ranges): segment `seg` of the level-1 output is split over `slices` workgroups and cut
 // into 2^sub_bits ranges
-__global__ __launch_bounds__(PART_THREADS) void k_part_items2(const u64* __restrict__ in, const u32* __restrict__ seg_start, u32 seg_shift, u32 slices,
+__global__ __launch_bounds__(PART_THREADS) void k_part_items2(const u64* __restrict__ in, const u32* __restrict__ seg_start, u32 seg_shift, u32 slices, ItemFmt f,
                                                               u32 range_shift, u32 sub_bits, u32* __restrict__ gcur, u64* __restrict__ out) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	u64* stage = (u64*) smem;
@@ -1253,7 +1425,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_items2(const u64* __restr
 		for (u32 j = 0; j < PER; j++) {
 			const size_t t = ts + (size_t) j * PART_THREADS + threadIdx.x;
 			r_b[j] = NONE32;
-			if (t < te) { r_it[j] = in[t]; r_b[j] = ((u32) (r_it[j] >> IT_SURV_SHIFT) >> range_shift) & mask; }
+			if (t < te) { r_it[j] = in[t]; r_b[j] = (it_scat(f, it_surv(f, r_it[j])) >> range_shift) & mask; }
 		}
 #pragma unroll
 		for (u32 j = 0; j < PER; j++) if (r_b[j] != NONE32) atomicAdd(&cnt[r_b[j]], 1u);
@@ -1270,15 +1442,23 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_items2(const u64* __restr
 		const u32 n = base[nbk];
 		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
 			const u64 x = stage[i];
-			const u32 b = ((u32) (x >> IT_SURV_SHIFT) >> range_shift) & mask;
+			const u32 b = (it_scat(f, it_surv(f, x)) >> range_shift) & mask;
 			out[gbase[b] + (i - base[b])] = x;
 		}
 		__syncthreads();
 	}
 }
 
-// one workgroup per range of 2^range_shift survivors: frequency, first sight, in-edge first sights (LDS arrays, direct index).
-// Lanes of a wave that hit the same survivor (hot nodes) are combined before they touch LDS.
+// ---- the recount ------------------------------------------------------------------------------
+// One workgroup per range of SB scattered positions (SB/16 blocks of survivors).  A run [a, e] inside a block (positions in the
+// block) with first instance I gives element x the instance I + (x - a): the run is folded into ONE counter and ONE minimum of
+// v = I + 15 - a, by its shape --
+//   a == 0: prefix slot e        e == 15: suffix slot a        otherwise its elements one by one into the singles slots
+// (a read crosses a block boundary once: its two pieces are a suffix and a prefix run; interior runs come from reads with errors
+// and from chain ends) -- and the survivors' values are put together at the end:
+//   count(x) = sum prefix[e >= x] + sum suffix[a <= x] + single[x],   first(x) = min of the same slots - 15 + x,
+//   in-edge (x, first base of x - 1) = min over prefix[e >= x], suffix[a <= x - 1] - 15 + x   (and the singles' own in-edges)
+// Lanes of a wave that hit the same slot (deep clones) are combined before they touch LDS.
 #define RC_THREADS 512
 #define RC_UNR 4
 template <typename IT> struct RcNone;
@@ -1287,20 +1467,32 @@ template <> struct RcNone<u64> { static constexpr u64 v = 0xFFFFFFFFFFFFFFFFull;
 __device__ inline void rc_min(u32* p, u32 v) { atomicMin(p, v); }
 __device__ inline void rc_min(u64* p, u64 v) { atomicMin((unsigned long long*) p, (unsigned long long) v); }
 
-// IT = u32 while the local instance ids fit 32 bits (up to 2^26 records on this GPU): 24 bytes of LDS per survivor instead of 44
+// slots of block bl: [bl*45 + e] prefix by e (0..15), [+15 + a] suffix by a (1..15), [+30 + x] singles by x (1..14)
+#define RC_SLOTS 45u
+// IT = u32 while the local instance ids fit 32 bits (fewer than 2^26 records on this GPU): 38.5 bytes of LDS per survivor instead of 66
 template <u32 SB, typename IT>
-__global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ items, const u32* __restrict__ range_start, u32 ns, u64 rec_base,
-                                                        u32* __restrict__ ucnt, u64* __restrict__ ufirst, u64* __restrict__ in_first) {
-	__shared__ u32 c[SB];
-	__shared__ IT f[SB];
+__global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ items, const u32* __restrict__ range_start, ItemFmt f, u32 ns, u64 rec_base,
+                                                        const u32* __restrict__ fbw, u32* __restrict__ ucnt, u64* __restrict__ ufirst, u64* __restrict__ in_first,
+                                                        unsigned long long* __restrict__ n_inst) {
+	__shared__ u32 c[SB / 16 * RC_SLOTS];
+	__shared__ IT mv[SB / 16 * RC_SLOTS];
 	__shared__ IT ef[SB * 4];
+	__shared__ u32 fbl[SB / 16];
+	__shared__ unsigned long long tot;
 	constexpr IT NONE = RcNone<IT>::v;
 	const u32 b = blockIdx.x;
-	for (u32 i = threadIdx.x; i < SB; i += RC_THREADS) { c[i] = 0; f[i] = NONE; }
+	const u32 s0 = b * SB;
+	const u32 nb = (ns + 15u) >> 4;
+	for (u32 i = threadIdx.x; i < SB / 16 * RC_SLOTS; i += RC_THREADS) { c[i] = 0; mv[i] = NONE; }
 	for (u32 i = threadIdx.x; i < SB * 4; i += RC_THREADS) ef[i] = NONE;
+	for (u32 i = threadIdx.x; i < SB / 16; i += RC_THREADS) {
+		const u32 sb = (s0 >> 4) + i;
+		const u32 blk = (sb * f.inv) & f.bmask;
+		fbl[i] = sb <= f.bmask && blk < nb ? fbw[blk] : 0u;
+	}
+	if (threadIdx.x == 0) tot = 0;
 	__syncthreads();
 	const u32 i0 = range_start[b], i1 = range_start[b + 1];
-	const u32 s0 = b * SB;
 	// whole waves stay together (ballots, DPP); RC_UNR items per lane are loaded before the first is used (the loop is bound by the
 	// latency of the item loads, not by their bytes)
 	const u32 iend = i0 + (i1 - i0 + RC_THREADS * RC_UNR - 1) / (RC_THREADS * RC_UNR) * (RC_THREADS * RC_UNR);
@@ -1312,47 +1504,82 @@ __global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ 
 		for (int u = 0; u < RC_UNR; u++) {
 			const u64 x = xs[u];
 			const bool live = x != IT_HOLE;
-			const u32 sl = live ? (u32) (x >> IT_SURV_SHIFT) - s0 : 0u;
+			const u32 p = it_surv(f, x);
+			const u32 len = live ? it_len(f, x) : 0u;
+			const u32 sl = live ? it_scat(f, p) - s0 : 0u;             // local position of the run's first survivor
+			const u32 a = sl & 15u, e = a + len - 1u;
 			const u64 inst = x & IT_INST_MASK;
-			// the lanes that share the first live lane's survivor are folded into one add and one min when they are many (hot nodes)
-			bool mine = live;
-			const u64 act = __ballot(live);
+			const bool shaped = live && (a == 0u || e == 15u);
+			const u32 slot = (sl >> 4) * RC_SLOTS + (a == 0u ? e : 15u + a);
+			const IT val = (IT) (inst + 15u - a);
+			// the lanes that share the first shaped lane's slot are folded into one add and one min when they are many (deep clones)
+			bool mine = shaped;
+			const u64 act = __ballot(shaped);
 			if (act) {
 				const int leader = __ffsll((long long) act) - 1;
-				const u32 lsl = (u32) __builtin_amdgcn_readlane((int) sl, leader);
-				const bool same = live && sl == lsl;
+				const u32 lslot = (u32) __builtin_amdgcn_readlane((int) slot, leader);
+				const bool same = shaped && slot == lslot;
 				const u64 m = __ballot(same);
 				if (__popcll(m) >= 8) {
-					// minimum of the (up to 35-bit) ids in two steps: low words among the lanes holding the minimal high word
-					const u32 hi_min = vdjx_wave_min(same ? (u32) (inst >> 32) : 0xFFFFFFFFu);
-					const u32 lo_min = vdjx_wave_min(same && (u32) (inst >> 32) == hi_min ? (u32) inst : 0xFFFFFFFFu);
+					// minimum of the (up to 35-bit) values in two steps: low words among the lanes holding the minimal high word
+					const u64 v64 = inst + 15u - a;
+					const u32 hi_min = vdjx_wave_min(same ? (u32) (v64 >> 32) : 0xFFFFFFFFu);
+					const u32 lo_min = vdjx_wave_min(same && (u32) (v64 >> 32) == hi_min ? (u32) v64 : 0xFFFFFFFFu);
 					if (__lane_id() == leader) {
-						atomicAdd(&c[lsl], (u32) __popcll(m));
-						rc_min(&f[lsl], (IT) (((u64) hi_min << 32) | lo_min));
+						atomicAdd(&c[lslot], (u32) __popcll(m));
+						rc_min(&mv[lslot], (IT) (((u64) hi_min << 32) | lo_min));
 					}
-					mine = live && !same;
+					mine = shaped && !same;
 				}
 			}
-			if (mine) { atomicAdd(&c[sl], 1u); rc_min(&f[sl], (IT) inst); }
+			if (mine) { atomicAdd(&c[slot], 1u); rc_min(&mv[slot], val); }
+			if (live && !shaped) {                                       // an interior run: element by element, with its own in-edges
+				const u32 fw = fbl[sl >> 4];
+				const u32 s1 = (sl >> 4) * RC_SLOTS + 30u;
+				for (u32 j = 0; j < len; j++) {
+					atomicAdd(&c[s1 + a + j], 1u);
+					rc_min(&mv[s1 + a + j], (IT) (inst + j + 15u - (a + j)));
+					if (j) {
+						IT* ep = &ef[(sl + j) * 4 + ((fw >> (2 * (a + j - 1))) & 3u)];
+						if (*(volatile IT*) ep > (IT) (inst + j)) rc_min(ep, (IT) (inst + j));
+					}
+				}
+			}
 			if (live && ((x >> 37) & 1ull)) {
-				IT* e = &ef[sl * 4 + (u32) ((x >> 35) & 3ull)];
-				if (*(volatile IT*) e > (IT) inst) rc_min(e, (IT) inst);                  // first sights only ever decrease
+				IT* ep = &ef[sl * 4 + (u32) ((x >> 35) & 3ull)];
+				if (*(volatile IT*) ep > (IT) inst) rc_min(ep, (IT) inst);                  // first sights only ever decrease
 			}
 		}
 	}
 	__syncthreads();
 	const u64 add = rec_base << 6;
+	u32 my_cnt = 0;
 	for (u32 i = threadIdx.x; i < SB; i += RC_THREADS) {
-		const u32 sidx = s0 + i;
-		if (sidx >= ns) break;
-		ucnt[sidx] = c[i];
-		ufirst[sidx] = f[i] == NONE ? NONE64 : (u64) f[i] + add;
+		const u32 sb = (s0 + i) >> 4;
+		const u32 blk = (sb * f.inv) & f.bmask;
+		const u32 x = i & 15u, p = (blk << 4) | x;
+		if (sb > f.bmask || blk >= nb || p >= ns) continue;
+		const u32 sbase = (i >> 4) * RC_SLOTS;
+		const bool inner = x >= 1u && x <= 14u;
+		u32 cc = inner ? c[sbase + 30 + x] : 0u;
+		IT mm = inner ? mv[sbase + 30 + x] : NONE;             // every run that holds x
+		IT me = NONE;                                          // every shaped run that holds x - 1 and x
+		for (u32 e = x; e < 16; e++) { cc += c[sbase + e]; const IT t = mv[sbase + e]; mm = t < mm ? t : mm; if (x) me = t < me ? t : me; }
+		for (u32 a = 1; a <= x; a++) { cc += c[sbase + 15 + a]; const IT t = mv[sbase + 15 + a]; mm = t < mm ? t : mm; if (a < x) me = t < me ? t : me; }
+		my_cnt += cc;
+		ucnt[p] = cc;
+		ufirst[p] = mm == NONE ? NONE64 : (u64) mm - 15u + x + add;
+		IT e4[4] = {ef[i * 4], ef[i * 4 + 1], ef[i * 4 + 2], ef[i * 4 + 3]};
+		if (x && me != NONE) {
+			const u32 pa = (fbl[i >> 4] >> (2 * (x - 1))) & 3u;
+			const IT t = (IT) (me - 15u + x);
+			if (t < e4[pa]) e4[pa] = t;
+		}
+		for (u32 q = 0; q < 4; q++) in_first[(size_t) p * 4 + q] = e4[q] == NONE ? NONE64 : (u64) e4[q] + add;
 	}
-	for (u32 i = threadIdx.x; i < SB * 4; i += RC_THREADS) {
-		const u32 sidx = s0 + (i >> 2);
-		if (sidx >= ns) break;
-		in_first[(size_t) s0 * 4 + i] = ef[i] == NONE ? NONE64 : (u64) ef[i] + add;
-	}
+	if (my_cnt) atomicAdd(&tot, (unsigned long long) my_cnt);
+	__syncthreads();
+	if (threadIdx.x == 0 && tot) atomicAdd(n_inst, tot);
 }
 
 // in-edge slots (v, first base of u) -> the predecessor u, and the out-edge slot (u, last base of v) of the same edge
@@ -1706,45 +1933,93 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 struct RecountOut { u32* ucnt; u64* ufirst; u64* in_first; u32* in_from; u64* edge_first; u32* edge_to; };
 
 template <typename A>
-int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k, const u64* s_lo, const u64* s_hi, u32 ns, const RecountOut& ro,
+int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k, SurvivorsG& sv, const RecountOut& ro,
                   bool derive_edges, SurvTable* table_out = nullptr) {
 	hipStream_t st = c->stream;
 	const size_t R = pool->n_records;
 	const int P = pool->rl - k + 1;
+	const u32 ns = sv.n;
 	if (ns >= (1u << 26)) { vdjx_set_error("more than 2^26 surviving k-mers: not supported by the recount items"); return VDJX_ELIMIT; }
 	if (R >= (1ull << 29)) { vdjx_set_error("more than 2^29 records on one GPU: not supported by the recount items"); return VDJX_ELIMIT; }
 	if ((u64) R * (u64) P >= (1ull << 32)) { vdjx_set_error("records*offsets = %llu >= 2^32 on one GPU: shard the pool over more GPUs", (unsigned long long) ((u64) R * (u64) P)); return VDJX_ELIMIT; }
 	u32 tmask = 1023;
 	while ((size_t) tmask + 1 < (size_t) ns * 2) tmask = tmask * 2 + 1;
 	const u32 idx_bits = std::max(1u, ceil_log2_u64((u64) ns + 1));
-	u32 *table, *succ, *succ1, *bloom;
-	ulonglong2* skey;
+	unsigned long long* pred;
+	u32 *table, *succ0, *succ, *bloom, *clen, *coff, *csum, *csum_start, *newidx, *jump_open, *fbw, *gcnt2;
+	u64 *pd, *lo2, *hi2, *gfirst2, *linw;
+	ulonglong2 *skey0, *skey;
 	u32 bloom_bits = 1u << 16;
 	while (bloom_bits < (1u << 30) && (size_t) bloom_bits < (size_t) ns * 16) bloom_bits <<= 1;
+	const u32 nb16 = (ns + 15u) >> 4;
+	const u32 n_scan = (ns + SCAN_BLOCK - 1) / SCAN_BLOCK;
+	const u32 n_jump = (ceil_log2_u64((u64) ns + 1) + 3) / 4 + 1;      // launches that resolve every chain of up to `ns` nodes (16x each at least)
 	HIP_TRY(db.alloc(&bloom, bloom_bits / 32));
 	HIP_TRY(hipMemsetAsync(bloom, 0, bloom_bits / 8, st));
 	HIP_TRY(db.alloc(&table, (size_t) tmask + 1));
-	HIP_TRY(db.alloc(&skey, ns));
-	HIP_TRY(db.alloc(&succ, (size_t) ns * 4));
-	HIP_TRY(db.alloc(&succ1, ns));
+	HIP_TRY(db.alloc(&skey0, ns)); HIP_TRY(db.alloc(&skey, ns));
+	HIP_TRY(db.alloc(&succ0, (size_t) ns * 4)); HIP_TRY(db.alloc(&succ, (size_t) ns * 4));
+	HIP_TRY(db.alloc(&pred, ns)); HIP_TRY(db.alloc(&pd, ns)); HIP_TRY(db.alloc(&clen, ns)); HIP_TRY(db.alloc(&coff, ns));
+	HIP_TRY(db.alloc(&csum, n_scan)); HIP_TRY(db.alloc(&csum_start, n_scan + 1)); HIP_TRY(db.alloc(&newidx, ns));
+	HIP_TRY(db.alloc(&jump_open, n_jump + 1));
+	HIP_TRY(db.alloc(&lo2, ns)); HIP_TRY(db.alloc(&hi2, ns)); HIP_TRY(db.alloc(&gcnt2, ns)); HIP_TRY(db.alloc(&gfirst2, ns));
+	HIP_TRY(db.alloc(&linw, nb16)); HIP_TRY(db.alloc(&fbw, nb16));
 	HIP_TRY(hipMemsetAsync(table, 0, ((size_t) tmask + 1) * 4, st));
-	SurvTable tb{table, tmask, idx_bits, skey, bloom, bloom_bits - 1};
+	HIP_TRY(hipMemsetAsync(pred, 0, (size_t) ns * 8, st));
+	HIP_TRY(hipMemsetAsync(clen, 0, (size_t) ns * 4, st));
+	HIP_TRY(hipMemsetAsync(jump_open, 0, (size_t) (n_jump + 1) * 4, st));
+	const SurvTable tb0{table, tmask, idx_bits, skey0, bloom, bloom_bits - 1};      // arrival numbering
+	const SurvTable tb{table, tmask, idx_bits, skey, bloom, bloom_bits - 1};        // chain order (after k_table_remap)
 	if (table_out) *table_out = tb;
+	const dim3 gs((ns + 255) / 256), bs(256);
 	{
 		vdjx_prof_scope ps(c, "k_surv_table");
-		hipLaunchKernelGGL(k_surv_table2, dim3((ns + 255) / 256), dim3(256), 0, st, s_lo, s_hi, ns, table, tmask, idx_bits, skey, bloom, bloom_bits - 1);
-		hipLaunchKernelGGL(k_succ_links2, dim3((ns + 255) / 256), dim3(256), 0, st, tb, ns, k, succ, succ1);
+		hipLaunchKernelGGL(k_surv_table2, gs, bs, 0, st, sv.lo, sv.hi, ns, table, tmask, idx_bits, skey0, bloom, bloom_bits - 1);
+		hipLaunchKernelGGL(k_succ_links2, gs, bs, 0, st, tb0, ns, k, sv.gcnt, succ0, pred);
 	}
-	// survivor ranges (one recount workgroup each, LDS arrays indexed by index - range start): the smallest range size that keeps
-	// the ranges <= 1024 (one partition pass); beyond the largest size a second partition level
+	{
+		// chain order: the survivors, their table entries and their successor lists renumbered
+		vdjx_prof_scope ps(c, "k_chain_order");
+		hipLaunchKernelGGL(k_chain_init, gs, bs, 0, st, pred, ns, pd);
+		for (u32 j = 0; j < n_jump; j++) hipLaunchKernelGGL(k_chain_jump, gs, bs, 0, st, pd, ns, j ? jump_open + j - 1 : (const u32*) nullptr, jump_open + j);
+		hipLaunchKernelGGL(k_chain_len, gs, bs, 0, st, pd, ns, clen);
+		hipLaunchKernelGGL(k_scan_sums, dim3(n_scan), dim3(256), 0, st, clen, ns, csum);
+		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, csum, n_scan, csum_start);
+		hipLaunchKernelGGL(k_scan_apply, dim3(n_scan), dim3(256), 0, st, clen, ns, csum_start, coff);
+		hipLaunchKernelGGL(k_chain_place, gs, bs, 0, st, pd, coff, ns, newidx);
+		hipLaunchKernelGGL(k_chain_permute, gs, bs, 0, st, newidx, ns, sv.lo, sv.hi, sv.gcnt, sv.gfirst, succ0, lo2, hi2, gcnt2, gfirst2, skey, succ);
+		hipLaunchKernelGGL(k_table_remap, dim3(tmask / 256 + 1), bs, 0, st, table, tmask + 1, idx_bits, newidx);
+		hipLaunchKernelGGL(k_chain_words, gs, bs, 0, st, succ, skey, ns, k, linw, fbw);
+	}
+	sv.lo = lo2; sv.hi = hi2; sv.gcnt = gcnt2; sv.gfirst = gfirst2;
+	// item layout and the permutation of the blocks of 16 over the ranges
+	ItemFmt f;
+	{
+		const u32 sb = ceil_log2_u64(ns);
+		const u32 lb = std::min(4u, 26u - sb);
+		const u32 pb = 26u - lb;
+		f.pmask = (1u << pb) - 1u;
+		f.len_shift = IT_SURV_SHIFT + pb;
+		f.maxlen = 1u << lb;
+		const u32 t = ceil_log2_u64(nb16);
+		f.bmask = (1u << t) - 1u;
+		f.mul = t ? ((0x9E3779B9u >> (32 - t)) | 1u) : 1u;
+		u32 x = f.mul;
+		for (int i = 0; i < 5; i++) x *= 2u - f.mul * x;                // inverse mod 2^32 (Newton), then mod 2^t
+		f.inv = x & f.bmask;
+		f.ns = ns;
+	}
+	const u32 nsp = (f.bmask + 1u) << 4;                               // scattered index space
+	// ranges of the scattered space (one recount workgroup each, LDS arrays indexed by position - range start): the smallest range
+	// size that keeps the ranges <= 1024 (one partition pass); beyond the largest size a second partition level
 	static const bool force_wide = tune("VDJX_RC_WIDE", 0) != 0;                    // (test knobs: the paths of very large pools on small ones)
 	static const u32 cap_shift = (u32) tune("VDJX_RC_MAX_SHIFT", 12);
-	const bool narrow = R <= (1ull << 26) && !force_wide;           // local instance ids fit 32 bits
+	const bool narrow = R < (1ull << 26) && !force_wide;            // local instance ids (+15) fit 32 bits
 	static const u32 max_ranges = (u32) std::min<size_t>(PART_MAXB, std::max<size_t>(2, tune("VDJX_RC_MAX_RANGES", PART_MAXB)));
-	const u32 max_shift = std::max(8u, std::min(narrow ? 12u : 11u, cap_shift));
+	const u32 max_shift = std::max(8u, std::min(narrow ? 11u : 10u, cap_shift));
 	u32 range_shift = 8;
-	while (range_shift < max_shift && ((ns + (1u << range_shift) - 1) >> range_shift) > max_ranges) range_shift++;
-	const u32 n_ranges = (ns + (1u << range_shift) - 1) >> range_shift;
+	while (range_shift < max_shift && (nsp >> range_shift) > max_ranges) range_shift++;
+	const u32 n_ranges = std::max(1u, nsp >> range_shift);
 	u32 l2bits = 0;
 	while (((n_ranges + (1u << l2bits) - 1) >> l2bits) > max_ranges) l2bits++;
 	const u32 n_coarse = (n_ranges + (1u << l2bits) - 1) >> l2bits;
@@ -1758,22 +2033,22 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	while (blk_items > 256 && nwaves * blk_items > NI / 2 + 65536) blk_items >>= 1;
 	const u64 raw_cap = (u64) NI + (u64) NI / (blk_items / 64) + nwaves * (u64) blk_items + blk_items;
 	u64 *raw, *items;
-	unsigned long long* g_cursor;
+	unsigned long long *g_cursor, *n_inst;
 	u32 *range_cnt, *range_start, *g_err, *gcur;
 	HIP_TRY(db.alloc(&raw, (size_t) raw_cap));
-	HIP_TRY(db.alloc(&g_cursor, 1));
+	HIP_TRY(db.alloc(&g_cursor, 2));
+	n_inst = g_cursor + 1;
 	HIP_TRY(db.alloc(&range_cnt, n_ranges_p));
 	HIP_TRY(db.alloc(&range_start, n_ranges_p + 1));
 	HIP_TRY(db.alloc(&g_err, 1));
-	HIP_TRY(hipMemsetAsync(g_cursor, 0, 8, st));
+	HIP_TRY(hipMemsetAsync(g_cursor, 0, 16, st));
 	HIP_TRY(hipMemsetAsync(range_cnt, 0, (size_t) n_ranges_p * 4, st));
 	HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
 	const size_t lds_walk = (size_t) n_ranges_p * 4;
 	if (lds_walk > 64 * 1024) { vdjx_set_error("too many survivor ranges for the walk histogram"); return VDJX_ELIMIT; }
 	HIP_TRY(hipFuncSetAttribute((const void*) k_walk_items, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_walk));
 	// VDJX_WALK_DBG (profiles/walkdbg.sh): an ABLATED copy of the walk runs first into scratch outputs, timed as k_walk_dbg; the real
-	// one follows untouched.  Bits: 1 no item stores, 2 no range histogram, 4 successor = index + 1 without the load, 8 no
-	// filter / table / key loads at run starts.  Measured at 10 M pairs: 7.5 ms whole, 7.0 / 7.5 / 4.6 / 3.4 ms, 2.0 ms with all four.
+	// one follows untouched.  Bits: 1 no item stores, 2 no range histogram, 8 no filter / table / key loads at run starts.
 	static const u32 walk_dbg = (u32) tune("VDJX_WALK_DBG", 0);
 	if (R && walk_dbg) {
 		u64* raw2;
@@ -1785,13 +2060,13 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		HIP_TRY(hipMemsetAsync(cur2, 0, 8, st));
 		HIP_TRY(hipMemsetAsync(cnt2, 0, (size_t) n_ranges_p * 4, st));
 		vdjx_prof_scope ps(c, "k_walk_dbg");
-		hipLaunchKernelGGL(k_walk_items, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, k, tb, succ, succ1, range_shift,
+		hipLaunchKernelGGL(k_walk_items, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, k, tb, succ, linw, f, range_shift,
 		                   n_ranges_p, raw2, raw_cap, blk_items, cur2, cnt2, g_err, walk_dbg);
 		HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
 	}
 	if (R) {
 		vdjx_prof_scope ps(c, "k_walk_items");
-		hipLaunchKernelGGL(k_walk_items, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, k, tb, succ, succ1, range_shift,
+		hipLaunchKernelGGL(k_walk_items, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, k, tb, succ, linw, f, range_shift,
 		                   n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err, 0u);
 	}
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, range_cnt, n_ranges_p, range_start);
@@ -1801,11 +2076,11 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	HIP_TRY(db.alloc(&gcur, n_ranges_p));
 	{
 		vdjx_prof_scope ps(c, "k_part_items");
-		u32 npb = (u32) std::min<size_t>(1024, (NI + 65535) / 65536);
+		u32 npb = (u32) std::min<size_t>(1024, (NI / 4 + 65535) / 65536);
 		if (npb == 0) npb = 1;
 		if (!l2bits) {
 			hipLaunchKernelGGL(k_init_cursors, dim3((n_ranges_p + 255) / 256), dim3(256), 0, st, range_start, n_ranges_p, 0u, gcur);
-			hipLaunchKernelGGL(k_part_items, dim3(npb), dim3(PART_THREADS), PART_LDS_BYTES, st, raw, g_cursor, range_shift, n_ranges_p, gcur, items);
+			hipLaunchKernelGGL(k_part_items, dim3(npb), dim3(PART_THREADS), PART_LDS_BYTES, st, raw, g_cursor, f, range_shift, n_ranges_p, gcur, items);
 		} else {
 			// level 1 into `n_coarse` segments (written over a second buffer), level 2 inside each segment
 			u64* l1;
@@ -1814,28 +2089,26 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 			HIP_TRY(db.alloc(&gcur1, n_coarse));
 			HIP_TRY(hipFuncSetAttribute((const void*) k_part_items2, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
 			hipLaunchKernelGGL(k_init_cursors, dim3((n_coarse + 255) / 256), dim3(256), 0, st, range_start, n_coarse, l2bits, gcur1);
-			hipLaunchKernelGGL(k_part_items, dim3(npb), dim3(PART_THREADS), PART_LDS_BYTES, st, raw, g_cursor, range_shift + l2bits, n_coarse, gcur1, l1);
+			hipLaunchKernelGGL(k_part_items, dim3(npb), dim3(PART_THREADS), PART_LDS_BYTES, st, raw, g_cursor, f, range_shift + l2bits, n_coarse, gcur1, l1);
 			hipLaunchKernelGGL(k_init_cursors, dim3((n_ranges_p + 255) / 256), dim3(256), 0, st, range_start, n_ranges_p, 0u, gcur);
-			hipLaunchKernelGGL(k_part_items2, dim3(n_coarse * 8), dim3(PART_THREADS), PART_LDS_BYTES, st, l1, range_start, l2bits, 8u, range_shift, l2bits, gcur, items);
+			hipLaunchKernelGGL(k_part_items2, dim3(n_coarse * 8), dim3(PART_THREADS), PART_LDS_BYTES, st, l1, range_start, l2bits, 8u, f, range_shift, l2bits, gcur, items);
 		}
 	}
 	{
 		vdjx_prof_scope ps(c, "k_recount");
-#define RC_LAUNCH(SB, IT) hipLaunchKernelGGL((k_recount<SB, IT>), dim3(n_ranges), dim3(RC_THREADS), 0, st, items, range_start, ns, rec_base, ro.ucnt, ro.ufirst, ro.in_first)
+#define RC_LAUNCH(SB, IT) hipLaunchKernelGGL((k_recount<SB, IT>), dim3(n_ranges), dim3(RC_THREADS), 0, st, items, range_start, f, ns, rec_base, fbw, ro.ucnt, ro.ufirst, ro.in_first, n_inst)
 		if (narrow) {
 			switch (range_shift) {
 				case 8: RC_LAUNCH(256, u32); break;
 				case 9: RC_LAUNCH(512, u32); break;
 				case 10: RC_LAUNCH(1024, u32); break;
-				case 11: RC_LAUNCH(2048, u32); break;
-				default: RC_LAUNCH(4096, u32); break;
+				default: RC_LAUNCH(2048, u32); break;
 			}
 		} else {
 			switch (range_shift) {
 				case 8: RC_LAUNCH(256, u64); break;
 				case 9: RC_LAUNCH(512, u64); break;
-				case 10: RC_LAUNCH(1024, u64); break;
-				default: RC_LAUNCH(2048, u64); break;
+				default: RC_LAUNCH(1024, u64); break;
 			}
 		}
 #undef RC_LAUNCH
@@ -1845,12 +2118,15 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		hipLaunchKernelGGL(k_edges_from_in, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, tb, ns, k, ro.in_first, ro.in_from, ro.edge_first, ro.edge_to);
 	}
 	u32 err = 0, n_items = 0;
+	unsigned long long inst = 0;
 	HIP_TRY(hipMemcpyAsync(&err, g_err, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&n_items, range_start + n_ranges_p, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&inst, n_inst, 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
 	if (err) { vdjx_set_error("k_walk_items: item buffer too small (%u waves stopped)", err); return VDJX_EHIP; }
-	c->stats["recount_items"] = n_items;            // surviving k-mer instances of this pool
+	c->stats["recount_items"] = n_items;            // runs of surviving k-mer instances of this pool (8 bytes each)
+	c->stats["recount_instances"] = inst;           // the instances themselves
 	return VDJX_OK;
 }
 
@@ -1950,7 +2226,7 @@ int kmer_build_impl2(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, 
 		HIP_TRY(db.alloc(&ro.in_first, (size_t) sv.n * 4)); HIP_TRY(db.alloc(&ro.in_from, (size_t) sv.n * 4));
 		HIP_TRY(db.alloc(&ro.edge_first, (size_t) sv.n * 4)); HIP_TRY(db.alloc(&ro.edge_to, (size_t) sv.n * 4));
 		ro.ucnt = sv.ucnt; ro.ufirst = sv.ufirst;
-		rc = stage_recount(c, db, pool, 0, k, sv.lo, sv.hi, sv.n, ro, true);
+		rc = stage_recount(c, db, pool, 0, k, sv, ro, true);
 		if (rc) return rc;
 	}
 	return stage_finish2(c, db, sv, ro, pool->n_records, k, P, g);
@@ -2344,7 +2620,7 @@ extern "C" int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t 
 	HIP_TRY(db.alloc(&a.lo, a.n)); HIP_TRY(db.alloc(&a.hi, a.n)); HIP_TRY(db.alloc(&a.gcnt, a.n)); HIP_TRY(db.alloc(&a.gfirst, a.n));
 	hipLaunchKernelGGL(k_surv_unpack, dim3((a.n + 255) / 256), dim3(256), 0, c->stream, (const SurvRec*) d_surv_all, a.n, a.lo, a.hi, a.gcnt, a.gfirst);
 	RecountOut ro{(u32*) d_ucnt, (u64*) d_ufirst, (u64*) d_in_first, nullptr, nullptr, nullptr};
-	return stage_recount(c, db, s->pool, s->rec_stride * (u64) s->rank, s->k, a.lo, a.hi, a.n, ro, false, &s->tb);
+	return stage_recount(c, db, s->pool, s->rec_stride * (u64) s->rank, s->k, a, ro, false, &s->tb);
 }
 
 // every rank: the reduced arrays -> the graph (identical on all ranks)
