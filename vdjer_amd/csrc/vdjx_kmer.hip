@@ -1242,35 +1242,44 @@ __global__ void k_table_remap(u32* __restrict__ table, u32 slots, u32 idx_bits, 
 	table[i] = (v & ~imask) | (newidx[(v & imask) - 1] + 1u);
 }
 
-// per block of 16 survivors (new numbering): 4 bits per survivor p in linw -- bit 0: p + 1 is a successor, bits 1-2 its last base,
-// bit 3: there are other successors (look into succ[]) -- and 2 bits per survivor in fbw, the first base of its k-mer (the name
-// of the in-edge p -> p + 1 at its head)
+// per block of 16 survivors (new numbering), survivor j of the block: linw bit 15-j: p + 1 is a successor; bit 31-j: there are
+// other successors (look into succ[]); bits 32 + 2*(15-j): the last base of p + 1 -- first survivor most significant, like the
+// bases of a packed read -- and 2 bits per survivor in fbw, the first base of its k-mer (the name of the in-edge p -> p + 1 at its head)
 __global__ void k_chain_words(const u32* __restrict__ succ, const ulonglong2* __restrict__ skey, u32 n, int k, u64* __restrict__ linw, u32* __restrict__ fbw) {
-	const u32 p = blockIdx.x * blockDim.x + threadIdx.x;      // (blockDim multiple of 64, n padded by the caller's grid: whole blocks of 16 lanes)
-	u32 code = 0, fb = 0;
+	const u32 p = blockIdx.x * blockDim.x + threadIdx.x;      // (whole blocks of 16 lanes: nobody returns before the shuffles)
+	const u32 j = p & 15u;
+	u64 w = 0;
+	u32 fb = 0;
 	if (p < n) {
 		const uint4 s = *(const uint4*) &succ[(size_t) p * 4];
 		const u32 sv[4] = {s.x, s.y, s.z, s.w};
-		u32 others = 0;
-		for (u32 b = 0; b < 4; b++) if (sv[b] != NONE32) { if (sv[b] == p + 1) code |= 1u | (b << 1); else others = 1; }
-		code |= others << 3;
+		for (u32 b = 0; b < 4; b++) if (sv[b] != NONE32) {
+			if (sv[b] == p + 1) w |= (1ull << (15u - j)) | ((u64) b << (32u + 2u * (15u - j)));
+			else w |= 1ull << (31u - j);
+		}
 		const ulonglong2 kk = skey[p];
 		const int sh = 2 * (k - 1);
 		fb = (u32) (sh < 64 ? kk.x >> sh : kk.y >> (sh - 64)) & 3u;
 	}
-	// 16 lanes -> one word each (DPP-free: LDS-free butterfly through shuffles of the row)
-	u64 w = (u64) code << (4 * (p & 15u));
-	u32 f = fb << (2 * (p & 15u));
+	u32 fw = fb << (2 * j);
 	for (int d = 1; d < 16; d <<= 1) {
 		w |= ((u64) (u32) __shfl_xor((int) (w >> 32), d) << 32) | (u32) __shfl_xor((int) (u32) w, d);
-		f |= (u32) __shfl_xor((int) f, d);
+		fw |= (u32) __shfl_xor((int) fw, d);
 	}
-	if ((p & 15u) == 0 && p < n) { linw[p >> 4] = w; fbw[p >> 4] = f; }
+	if (j == 0 && p < n) { linw[p >> 4] = w; fbw[p >> 4] = fw; }
 }
 
 // ---- the walk ---------------------------------------------------------------------------------
-// every wave appends its items to blocks of `blk_items` slots it reserves from the global cursor (unused slots of a block are
-// filled with IT_HOLE); item counts per survivor range go to range_cnt
+// One lane per record, in rounds.  A round of a lane starts at an offset whose k-mer is a known survivor s -- from a table lookup
+// (the first valid offset of the record; after a gap, the next offset the k-mer filter lets through: the filter bits of all
+// remaining offsets are fetched at once, as independent loads) or from the successor list of the node the previous round ended on
+// -- and follows the chain s, s + 1, ... as far as the read agrees with it: the chain's 16 next bases and link bits (two words of
+// linw) against the read's 16 next bases and valid offsets, one XOR and three count-leading-zeros, no loop over the offsets.  The
+// run goes out as one item per block of 16 it touches.  Reads of a clone take one round; a sequencing error, a branch or an N adds
+// one.  All lanes of a wave do their lookups of a round together, so the wave waits for memory a few times per record, not at
+// every offset.
+// Every wave appends its items to blocks of `blk_items` slots it reserves from the global cursor (unused slots of a block are
+// filled with IT_HOLE); item counts per survivor range go to range_cnt.
 __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restrict__ bases, const u64* __restrict__ nmask, size_t R, int rl, int k,
                                                              SurvTable t, const u32* __restrict__ succ, const u64* __restrict__ linw, ItemFmt f,
                                                              u32 range_shift, u32 n_ranges,
@@ -1281,7 +1290,6 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 	for (u32 i = threadIdx.x; i < n_ranges; i += WALK_THREADS) hist[i] = 0;
 	__syncthreads();
 	const int P = rl - k + 1;
-	const u64 km = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
 	const size_t per = ((R + gridDim.x - 1) / gridDim.x + WALK_THREADS - 1) / WALK_THREADS * WALK_THREADS;
 	const size_t r0 = (size_t) blockIdx.x * per;
 	const size_t r1 = r0 + per < R ? r0 + per : R;
@@ -1295,53 +1303,128 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 		RecView v;
 		v.bhi = v.blo = 0; v.nm = ~0ull; v.lq = 0;
 		if (live) v = load_rec(bases, nmask, nullptr, r);
-		int prev = -1;
-		u64 w = 0;                                  // linw of prev's block
-		u32 run_p = 0, run_o = 0, run_len = 0, run_in = 0;            // the open run (run_len 0: none); run_in = has_prev << 2 | pred base
-		for (int o = 0; o <= P; o++) {                                // (uniform trip count: the compaction below is wave-wide; step P closes the last run)
-			int s = -1;
-			u32 in = 0;
-			if (o < P && live && !((v.nm >> o) & km)) {
-				if (prev >= 0) {
-					const int bsh = 2 * (rl - k - o);                     // last base of the k-mer at o
-					const u32 bb = (u32) (bsh < 64 ? v.blo >> bsh : v.bhi >> (bsh - 64)) & 3u;
-					const u32 code = (u32) (w >> (4 * ((u32) prev & 15u))) & 15u;
-					if ((code & 1u) && ((code >> 1) & 3u) == bb) s = prev + 1;
-					else if (code & 8u) { const u32 nx = succ[(u32) prev * 4u + bb]; s = nx == NONE32 ? -1 : (int) nx; }
-					const int fsh = 2 * (rl - o);                          // first base of the k-mer at o-1 (the predecessor)
-					in = 4u | ((u32) (fsh < 64 ? v.blo >> fsh : v.bhi >> (fsh - 64)) & 3u);
-				} else {
+		// V: the offsets whose k bases are all valid (bit o of nm = base o is N or masked)
+		u64 inv = v.nm;
+		{
+			int cur = 1;
+			while (cur * 2 <= k) { inv |= inv >> cur; cur *= 2; }
+			inv |= inv >> (k - cur);
+		}
+		const u64 V = live ? ~inv & ((1ull << P) - 1ull) : 0ull;
+		const u128 b128 = ((u128) v.bhi << 64) | v.blo;          // base i at bits 2*(rl-1-i)
+		int o = V ? __builtin_ctzll(V) : P;                      // the offset this lane works on; P: done
+		int s = -1;                                              // its survivor, if known
+		u32 in = 0;                                              // has_prev << 2 | first base of the predecessor k-mer
+		bool first = true, have_c = false;
+		u64 C = 0;                                               // valid offsets the k-mer filter lets through (once have_c)
+		while (__ballot(o < P)) {
+			// ---- lookups ----
+			const bool need = o < P && s < 0;
+			if (__ballot(need && !first && !have_c)) {           // (wave-uniform) filter bits of all remaining offsets, 4 loads in flight
+				const bool mine = need && !first && !have_c;
+				for (int ob = 0; ob < P; ob += 4) {
+					u32 wv[4], bt[4];
+#pragma unroll
+					for (int j = 0; j < 4; j++) {
+						const int oo = ob + j;
+						wv[j] = 0; bt[j] = 0;
+						if (mine && oo >= o && oo < P && ((V >> oo) & 1ull)) {
+							u64 khi, klo;
+							vdjx_kmer_at(v.bhi, v.blo, rl, k, oo, khi, klo);
+							const u32 bit = (u32) (vdjx_mix(klo, khi) >> 40) & t.bloom_mask;
+							bt[j] = bit & 31u;
+							wv[j] = (dbg & 8u) ? 0xFFFFFFFFu : t.bloom[bit >> 5];
+						}
+					}
+#pragma unroll
+					for (int j = 0; j < 4; j++) if ((wv[j] >> bt[j]) & 1u) C |= 1ull << (ob + j);
+				}
+				if (mine) have_c = true;
+			}
+			if (need) {
+				bool filtered = false;
+				if (!first) {
+					const u64 cm = C & ~((1ull << o) - 1ull);
+					o = cm ? __builtin_ctzll(cm) : P;
+					filtered = true;
+				}
+				first = false;
+				if (o < P) {
 					u64 khi, klo;
 					vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
-					s = (dbg & 8u) ? ((klo & 3u) ? (int) ((u32) vdjx_mix(klo, khi) % f.ns) : -1) : surv_lookup2f(t, klo, khi);
+					if (dbg & 8u) s = (klo & 3u) ? (int) ((u32) vdjx_mix(klo, khi) % f.ns) : -1;
+					else s = filtered ? surv_lookup2(t, klo, khi) : surv_lookup2f(t, klo, khi);
+					in = 0;
+					if (s < 0) o++;
 				}
 			}
-			const bool cont = run_len && s == (int) (run_p + run_len) && ((u32) s & 15u) && run_len < f.maxlen;
-			const bool close = run_len && !cont;
-			u64 item = IT_HOLE;
-			if (close) item = (f.maxlen > 1 ? (u64) (run_len - 1) << f.len_shift : 0ull) | ((u64) run_p << IT_SURV_SHIFT) | ((u64) run_in << 35) | ((u64) r << 6) | (u64) run_o;
-			if (cont) run_len++;
-			else if (s >= 0) { run_p = (u32) s; run_o = (u32) o; run_len = 1; run_in = in; }
-			else run_len = 0;
-			if (s >= 0 && (prev < 0 || ((u32) s >> 4) != ((u32) prev >> 4))) w = linw[(u32) s >> 4];
-			prev = s;
-			const u64 m = __ballot(close);
-			if (!m) continue;
-			const u32 cnt = (u32) __popcll(m);
-			if (fill + cnt > blk_items) {                             // (wave-uniform)
-				if (have_blk) for (u32 i = fill + (u32) lane; i < blk_items; i += 64) raw[blk + i] = IT_HOLE;
-				unsigned long long nb = 0;
-				if (lane == 0) nb = atomicAdd(g_cursor, (unsigned long long) blk_items);
-				nb = ((unsigned long long) (u32) __builtin_amdgcn_readlane((int) (nb >> 32), 0) << 32) | (u32) __builtin_amdgcn_readlane((int) nb, 0);
-				if (nb + blk_items > raw_cap) { if (lane == 0 && !dead) atomicAdd(g_err, 1u); dead = true; have_blk = false; }
-				else { blk = nb; have_blk = true; }
-				fill = 0;
+			// ---- the chain from s ----
+			const bool act = o < P && s >= 0;
+			u32 rem = 0, pp = 0, po = 0;
+			if (act) {
+				const u32 a = (u32) s & 15u;
+				const u64 w0 = linw[(u32) s >> 4], w1 = linw[((u32) s >> 4) + 1];
+				// windows over the 16 nodes s .. s+15, node s+j at bit 15-j (links, others) / bits 2*(15-j) (bases)
+				const u32 lw = (((((u32) w0 & 0xFFFFu) << 16) | ((u32) w1 & 0xFFFFu)) << a) >> 16;
+				const u32 ow = ((((u32) w0 & 0xFFFF0000u) | ((u32) w1 >> 16)) << a) >> 16;
+				const u32 bw = (u32) (((((w0 >> 32) << 32) | (w1 >> 32)) << (2 * a)) >> 32);
+				const int sh = 2 * (rl - 16 - (o + k));             // the read's bases o+k .. o+k+15 in the same layout
+				const u32 rw = sh >= 0 ? (u32) (b128 >> sh) : (sh > -32 ? (u32) b128 << (-sh) : 0u);
+				const u32 x = bw ^ rw;
+				const u32 nl = ~lw & 0xFFFFu;
+				const u32 m_base = x ? (u32) __builtin_clz(x) >> 1 : 16u;
+				const u32 m_lin = nl ? (u32) __builtin_clz(nl) - 16u : 16u;
+				const u64 nv = ~(V >> (o + 1));                     // (bits at and above P are invalid: never all ones)
+				const u32 m_valid = (u32) __builtin_ctzll(nv);
+				u32 steps = m_base < m_lin ? m_base : m_lin;
+				steps = steps < m_valid ? steps : m_valid;
+				const bool capped = steps >= 16u;                     // (reads with more than 17 offsets) the chain goes on: next round from s + 16
+				if (capped) steps = 15u;
+				rem = steps + 1u; pp = (u32) s; po = (u32) o;
+				// where the next round starts
+				const int o2 = o + (int) rem;
+				int s2 = -1;
+				if (o2 < P && ((V >> o2) & 1ull)) {
+					if (capped) s2 = s + 16;
+					else if ((ow >> (15u - steps)) & 1u) {                     // the last node has successors off the chain
+						const u32 bb = (u32) (b128 >> (2 * (rl - k - o2))) & 3u;
+						const u32 nx = succ[((u32) s + steps) * 4u + bb];
+						s2 = nx == NONE32 ? -1 : (int) nx;
+					}
+				}
+				o = s2 >= 0 || o2 >= P ? o2 : o2 + 1;                  // nothing survives at o2: the search goes on behind it
+				s = s2;
 			}
-			if (close && !dead) {
-				if (!(dbg & 1u)) raw[blk + fill + (u32) __popcll(m & ((1ull << lane) - 1ull))] = item;
-				if (!(dbg & 2u)) atomicAdd(&hist[it_scat(f, it_surv(f, item)) >> range_shift], 1u);
+			// ---- the run, one item per block of 16 (and per 2^lb nodes) ----
+			u32 pin = in;
+			if (act) in = s >= 0 ? (4u | ((u32) (b128 >> (2 * (rl - o))) & 3u)) : 0u;      // (next round: first base of the k-mer at o - 1)
+			while (__ballot(rem > 0)) {
+				const bool close = rem > 0;
+				u32 len = 16u - (pp & 15u);
+				len = len < rem ? len : rem;
+				len = len < f.maxlen ? len : f.maxlen;
+				const u64 item = (f.maxlen > 1 ? (u64) (len - 1) << f.len_shift : 0ull) | ((u64) pp << IT_SURV_SHIFT) | ((u64) pin << 35) | ((u64) r << 6) | (u64) po;
+				const u64 m = __ballot(close);
+				const u32 cnt = (u32) __popcll(m);
+				if (fill + cnt > blk_items) {                             // (wave-uniform)
+					if (have_blk) for (u32 i = fill + (u32) lane; i < blk_items; i += 64) raw[blk + i] = IT_HOLE;
+					unsigned long long nb = 0;
+					if (lane == 0) nb = atomicAdd(g_cursor, (unsigned long long) blk_items);
+					nb = ((unsigned long long) (u32) __builtin_amdgcn_readlane((int) (nb >> 32), 0) << 32) | (u32) __builtin_amdgcn_readlane((int) nb, 0);
+					if (nb + blk_items > raw_cap) { if (lane == 0 && !dead) atomicAdd(g_err, 1u); dead = true; have_blk = false; }
+					else { blk = nb; have_blk = true; }
+					fill = 0;
+				}
+				if (close && !dead) {
+					if (!(dbg & 1u)) raw[blk + fill + (u32) __popcll(m & ((1ull << lane) - 1ull))] = item;
+					if (!(dbg & 2u)) atomicAdd(&hist[it_scat(f, pp) >> range_shift], 1u);
+				}
+				fill += cnt;
+				if (close) {
+					rem -= len; pp += len; po += len;
+					pin = 4u | ((u32) (b128 >> (2 * (rl - po))) & 3u);        // the next piece's predecessor is the node before it
+				}
 			}
-			fill += cnt;
 		}
 	}
 	if (have_blk) for (u32 i = fill + (u32) lane; i < blk_items; i += 64) raw[blk + i] = IT_HOLE;
@@ -1963,7 +2046,8 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	HIP_TRY(db.alloc(&csum, n_scan)); HIP_TRY(db.alloc(&csum_start, n_scan + 1)); HIP_TRY(db.alloc(&newidx, ns));
 	HIP_TRY(db.alloc(&jump_open, n_jump + 1));
 	HIP_TRY(db.alloc(&lo2, ns)); HIP_TRY(db.alloc(&hi2, ns)); HIP_TRY(db.alloc(&gcnt2, ns)); HIP_TRY(db.alloc(&gfirst2, ns));
-	HIP_TRY(db.alloc(&linw, nb16)); HIP_TRY(db.alloc(&fbw, nb16));
+	HIP_TRY(db.alloc(&linw, (size_t) nb16 + 1)); HIP_TRY(db.alloc(&fbw, nb16));
+	HIP_TRY(hipMemsetAsync(linw + nb16, 0, 8, st));        // (the walk reads the word behind a run's first block)
 	HIP_TRY(hipMemsetAsync(table, 0, ((size_t) tmask + 1) * 4, st));
 	HIP_TRY(hipMemsetAsync(pred, 0, (size_t) ns * 8, st));
 	HIP_TRY(hipMemsetAsync(clen, 0, (size_t) ns * 4, st));
