@@ -1049,9 +1049,14 @@ __global__ void k_node_flags(const u64* __restrict__ s_lo, const u64* __restrict
 #define IT_HOLE 0xFFFFFFFFFFFFFFFFull
 #define WALK_THREADS 256
 
-struct SurvTable { const u32* table; u32 mask; u32 idx_bits; const ulonglong2* skey; const u32* bloom; u32 bloom_mask; };      // bloom: one bit per survivor hash, 16 bits of filter per survivor: L2-resident (2 MB at 10 M pairs)
+// the survivor table: open addressing over 16-byte slots {key_lo, key_hi | (survivor index + 1) << 36} (k <= 50: the key's high
+// part has at most 36 bits), all zero = empty -- a lookup is ONE random line fill; skey[] (keys by index) serves the per-survivor
+// kernels.  bloom: one bit per survivor hash, 16 bits of filter per survivor: L2-resident (2 MB at 10 M pairs)
+#define SLOT_HI_BITS 36
+#define SLOT_HI_MASK ((1ull << SLOT_HI_BITS) - 1ull)
+struct SurvTable { const ulonglong2* slots; u32 mask; const ulonglong2* skey; const u32* bloom; u32 bloom_mask; };
 
-// item layout and the block permutation (host: make_item_fmt)
+// item layout and the block permutation (host: stage_recount)
 struct ItemFmt {
 	u32 pmask;       // survivor field
 	u32 len_shift;   // 38 + pb
@@ -1064,9 +1069,8 @@ __device__ inline u32 it_surv(const ItemFmt& f, u64 x) { return (u32) (x >> IT_S
 __device__ inline u32 it_len(const ItemFmt& f, u64 x) { return f.maxlen > 1 ? (u32) (x >> f.len_shift) + 1u : 1u; }
 __device__ inline u32 it_scat(const ItemFmt& f, u32 p) { return ((((p >> 4) * f.mul) & f.bmask) << 4) | (p & 15u); }    // position in the scattered index space
 
-// table entry = fingerprint of the key's hash (32 - idx_bits bits) << idx_bits | (survivor index + 1)
-__global__ void k_surv_table2(const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, u32 n, u32* __restrict__ table, u32 mask,
-                              u32 idx_bits, ulonglong2* __restrict__ skey, u32* __restrict__ bloom, u32 bloom_mask) {
+__global__ void k_surv_table2(const u64* __restrict__ s_lo, const u64* __restrict__ s_hi, u32 n, ulonglong2* __restrict__ slots, u32 mask,
+                              ulonglong2* __restrict__ skey, u32* __restrict__ bloom, u32 bloom_mask) {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const u64 lo = s_lo[i], hi = s_hi[i];
@@ -1077,26 +1081,21 @@ __global__ void k_surv_table2(const u64* __restrict__ s_lo, const u64* __restric
 		atomicOr(&bloom[bit >> 5], 1u << (bit & 31));
 	}
 	u32 slot = (u32) (h >> 20) & mask;
-	const u32 entry = idx_bits < 32 ? ((((u32) h) >> idx_bits) << idx_bits) | (i + 1) : (i + 1);
-	while (atomicCAS(&table[slot], 0u, entry) != 0u) slot = (slot + 1) & mask;
+	const unsigned long long entry = hi | ((unsigned long long) (i + 1) << SLOT_HI_BITS);
+	while (atomicCAS((unsigned long long*) &slots[slot].y, 0ull, entry) != 0ull) slot = (slot + 1) & mask;
+	slots[slot].x = lo;                                     // (read by later launches only)
 }
 
 // lookup of a k-mer that most likely does NOT survive (the start of a run in the walk): the filter answers "no" for 15 in 16 of
-// those without leaving the L2 (the table and the keys, 24 MB at 10 M pairs, are random line fills over the fabric)
+// those without leaving the L2 (the table, 32-64 MB at 10 M pairs, is a random line fill over the fabric)
 __device__ inline int surv_lookup2f(const SurvTable& t, u64 lo, u64 hi);
 
 __device__ inline int surv_lookup2(const SurvTable& t, u64 lo, u64 hi) {
-	const u64 h = vdjx_mix(lo, hi);
-	u32 slot = (u32) (h >> 20) & t.mask;
-	const u32 imask = t.idx_bits < 32 ? (1u << t.idx_bits) - 1u : 0xFFFFFFFFu;
-	const u32 fp = t.idx_bits < 32 ? (((u32) h) >> t.idx_bits) : 0u;
+	u32 slot = (u32) (vdjx_mix(lo, hi) >> 20) & t.mask;
 	for (;;) {
-		const u32 v = t.table[slot];
-		if (!v) return -1;
-		if (t.idx_bits >= 32 || (v >> t.idx_bits) == fp) {
-			const ulonglong2 kk = t.skey[(v & imask) - 1];
-			if (kk.x == lo && kk.y == hi) return (int) ((v & imask) - 1);
-		}
+		const ulonglong2 v = t.slots[slot];
+		if (!v.y) return -1;
+		if (v.x == lo && (v.y & SLOT_HI_MASK) == hi) return (int) (v.y >> SLOT_HI_BITS) - 1;
 		slot = (slot + 1) & t.mask;
 	}
 }
@@ -1233,13 +1232,12 @@ __global__ void k_chain_permute(const u32* __restrict__ newidx, u32 n, const u64
 	r.w = s.w == NONE32 ? NONE32 : newidx[s.w];
 	*(uint4*) &succ2[(size_t) q * 4] = r;
 }
-__global__ void k_table_remap(u32* __restrict__ table, u32 slots, u32 idx_bits, const u32* __restrict__ newidx) {
+__global__ void k_table_remap(ulonglong2* __restrict__ slots, u32 n_slots, const u32* __restrict__ newidx) {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= slots) return;
-	const u32 v = table[i];
-	if (!v) return;
-	const u32 imask = idx_bits < 32 ? (1u << idx_bits) - 1u : 0xFFFFFFFFu;
-	table[i] = (v & ~imask) | (newidx[(v & imask) - 1] + 1u);
+	if (i >= n_slots) return;
+	const u64 y = slots[i].y;
+	if (!y) return;
+	slots[i].y = (y & SLOT_HI_MASK) | ((u64) (newidx[(u32) (y >> SLOT_HI_BITS) - 1] + 1u) << SLOT_HI_BITS);
 }
 
 // per block of 16 survivors (new numbering), survivor j of the block: linw bit 15-j: p + 1 is a successor; bit 31-j: there are
@@ -2027,9 +2025,9 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	if ((u64) R * (u64) P >= (1ull << 32)) { vdjx_set_error("records*offsets = %llu >= 2^32 on one GPU: shard the pool over more GPUs", (unsigned long long) ((u64) R * (u64) P)); return VDJX_ELIMIT; }
 	u32 tmask = 1023;
 	while ((size_t) tmask + 1 < (size_t) ns * 2) tmask = tmask * 2 + 1;
-	const u32 idx_bits = std::max(1u, ceil_log2_u64((u64) ns + 1));
 	unsigned long long* pred;
-	u32 *table, *succ0, *succ, *bloom, *clen, *coff, *csum, *csum_start, *newidx, *jump_open, *fbw, *gcnt2;
+	ulonglong2* table;
+	u32 *succ0, *succ, *bloom, *clen, *coff, *csum, *csum_start, *newidx, *jump_open, *fbw, *gcnt2;
 	u64 *pd, *lo2, *hi2, *gfirst2, *linw;
 	ulonglong2 *skey0, *skey;
 	u32 bloom_bits = 1u << 16;
@@ -2048,17 +2046,17 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	HIP_TRY(db.alloc(&lo2, ns)); HIP_TRY(db.alloc(&hi2, ns)); HIP_TRY(db.alloc(&gcnt2, ns)); HIP_TRY(db.alloc(&gfirst2, ns));
 	HIP_TRY(db.alloc(&linw, (size_t) nb16 + 1)); HIP_TRY(db.alloc(&fbw, nb16));
 	HIP_TRY(hipMemsetAsync(linw + nb16, 0, 8, st));        // (the walk reads the word behind a run's first block)
-	HIP_TRY(hipMemsetAsync(table, 0, ((size_t) tmask + 1) * 4, st));
+	HIP_TRY(hipMemsetAsync(table, 0, ((size_t) tmask + 1) * 16, st));
 	HIP_TRY(hipMemsetAsync(pred, 0, (size_t) ns * 8, st));
 	HIP_TRY(hipMemsetAsync(clen, 0, (size_t) ns * 4, st));
 	HIP_TRY(hipMemsetAsync(jump_open, 0, (size_t) (n_jump + 1) * 4, st));
-	const SurvTable tb0{table, tmask, idx_bits, skey0, bloom, bloom_bits - 1};      // arrival numbering
-	const SurvTable tb{table, tmask, idx_bits, skey, bloom, bloom_bits - 1};        // chain order (after k_table_remap)
+	const SurvTable tb0{table, tmask, skey0, bloom, bloom_bits - 1};      // arrival numbering
+	const SurvTable tb{table, tmask, skey, bloom, bloom_bits - 1};        // chain order (after k_table_remap)
 	if (table_out) *table_out = tb;
 	const dim3 gs((ns + 255) / 256), bs(256);
 	{
 		vdjx_prof_scope ps(c, "k_surv_table");
-		hipLaunchKernelGGL(k_surv_table2, gs, bs, 0, st, sv.lo, sv.hi, ns, table, tmask, idx_bits, skey0, bloom, bloom_bits - 1);
+		hipLaunchKernelGGL(k_surv_table2, gs, bs, 0, st, sv.lo, sv.hi, ns, table, tmask, skey0, bloom, bloom_bits - 1);
 		hipLaunchKernelGGL(k_succ_links2, gs, bs, 0, st, tb0, ns, k, sv.gcnt, succ0, pred);
 	}
 	{
@@ -2072,7 +2070,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		hipLaunchKernelGGL(k_scan_apply, dim3(n_scan), dim3(256), 0, st, clen, ns, csum_start, coff);
 		hipLaunchKernelGGL(k_chain_place, gs, bs, 0, st, pd, coff, ns, newidx);
 		hipLaunchKernelGGL(k_chain_permute, gs, bs, 0, st, newidx, ns, sv.lo, sv.hi, sv.gcnt, sv.gfirst, succ0, lo2, hi2, gcnt2, gfirst2, skey, succ);
-		hipLaunchKernelGGL(k_table_remap, dim3(tmask / 256 + 1), bs, 0, st, table, tmask + 1, idx_bits, newidx);
+		hipLaunchKernelGGL(k_table_remap, dim3(tmask / 256 + 1), bs, 0, st, table, tmask + 1, newidx);
 		hipLaunchKernelGGL(k_chain_words, gs, bs, 0, st, succ, skey, ns, k, linw, fbw);
 	}
 	sv.lo = lo2; sv.hi = hi2; sv.gcnt = gcnt2; sv.gfirst = gfirst2;
