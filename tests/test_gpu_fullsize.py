@@ -240,7 +240,9 @@ print("KNOB_CASE_OK", g.n, g.pre_nodes)
     (25, 2, 60, {"VDJX_GATED_BUCKET": "16", "VDJX_REFINE_TUPLES": "50", "VDJX_SUB_TUPLES": "64"}),     # long buckets split up front (verified dry run)
     (35, 3, 90, {"VDJX_GATED_BUCKET": "100000", "VDJX_SUB_TUPLES": "1000000000"}),                   # few huge buckets: table overflow -> sub-passes
     (35, 3, 90, {"VDJX_RC_MAX_RANGES": "4", "VDJX_RC_MAX_SHIFT": "9", "VDJX_RC_WIDE": "1"}),         # recount: two partition levels, 64-bit ids
-    (25, 2, 60, {"VDJX_RC_MAX_RANGES": "8", "VDJX_RC_MAX_SHIFT": "12"}),                             # recount: 4096-survivor ranges
+    (25, 2, 60, {"VDJX_RC_MAX_RANGES": "8", "VDJX_RC_MAX_SHIFT": "12"}),                             # recount: the largest ranges
+    (35, 3, 90, {"VDJX_RC_LEN_BITS": "0"}),                                                          # > 2^25 survivors: one item per instance
+    (25, 2, 60, {"VDJX_RC_LEN_BITS": "2", "VDJX_RC_WIDE": "1", "VDJX_RC_MAX_SHIFT": "8"}),           # > 2^23 survivors: runs of at most 4, 64-bit ids, 256-position ranges
 ])
 def test_large_pool_code_paths_on_a_small_pool(k, mf, mq, env):
     """The paths 10 M-pair pools take (more than 2^15 buckets, long-bucket handling) forced on 120 k pairs through the tuning

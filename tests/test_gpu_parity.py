@@ -117,6 +117,30 @@ def test_kmer_build_edge_cases(ctx):
         ctx.pool_load(np.full((2, 131), ord("0"), np.uint8), np.zeros((0, 131), np.uint8), 65)   # rl > 64
 
 
+def test_tandem_repeats_and_homopolymers(ctx):
+    """k-mers that are their own successor (poly-A) or lie on a short cycle ((AC)n, (ACG)n, (ACGTT)n): the chain order of the
+    survivors must leave cycles alone (no head to rank from), and reads that go round a cycle follow it through the successor lists."""
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(3, seed=15)
+    pool = synth.make_reads(rep, 3000, noise_frac=0.2, seed=16)
+    rng = np.random.default_rng(3)
+    units = ["A", "AC", "ACG", "ACGTT", "T", "GGC"]
+    rows = np.arange(0, pool.primary.shape[0], 9)
+    for i, r in enumerate(rows):
+        u = units[i % len(units)]
+        ph = int(rng.integers(0, len(u)))
+        tail = 25 if i % 11 == 0 else 10                  # every read leaves the repeat (distinct reads, A2:150-170), a few half way
+        seq = (u * 60)[ph:ph + 50 - tail] + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, tail))
+        pool.primary[r, 1:51] = np.frombuffer(seq.encode(), np.uint8)
+        pool.primary[r, 51:101] = ord("I")
+    vc = np.array([synth.seq_to_int(a) for a in rep.v_anchors], dtype=np.uint32)
+    jc = np.array([synth.seq_to_int(a) for a in rep.j_anchors], dtype=np.uint32)
+    for k, mf, mq in ((35, 2, 60), (25, 3, 90), (50, 2, 60)):
+        hg = run_both(ctx, pool, vc, jc, k, mf, mq)
+        kmers = {hg.kmer(i) for i in range(hg.n)}
+        assert k > 40 or ("A" * k in kmers and ("AC" * k)[:k] in kmers and ("ACG" * k)[:k] in kmers)
+
+
 def test_hot_kmer_skew(ctx):
     """One clone at extreme depth: a handful of k-mers with tens of thousands of instances in one bucket."""
     from vdjer_amd import synth

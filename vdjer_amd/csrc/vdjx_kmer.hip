@@ -2078,7 +2078,8 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	ItemFmt f;
 	{
 		const u32 sb = ceil_log2_u64(ns);
-		const u32 lb = std::min(4u, 26u - sb);
+		static const u32 force_lb = (u32) tune("VDJX_RC_LEN_BITS", 4);      // (test knob: the shorter runs of pools with more than 2^22 survivors)
+		const u32 lb = std::min(std::min(4u, 26u - sb), force_lb);
 		const u32 pb = 26u - lb;
 		f.pmask = (1u << pb) - 1u;
 		f.len_shift = IT_SURV_SHIFT + pb;
