@@ -351,6 +351,7 @@ def main():
     my_wins = wins
     my_contigs = contigs_fixed
     my_wins_packed = ctx.pin_strings(my_wins, "windows")
+    my_wins_rows = np.frombuffer("".join(my_wins).encode(), np.uint8).reshape(len(my_wins), -1) if my_wins else np.zeros((0, 486), np.uint8)
     my_contigs_packed = ctx.pin_strings(my_contigs, "contigs") if my_contigs else None
 
     def gather_bytes(a):
@@ -395,10 +396,15 @@ def main():
         else:
             valid, npairs = engine.window_score(scorer, my_wins_packed, args.ins)
         t = lap("window_score", t)
-        contigs = my_contigs if my_contigs is not None else [w[51:411] for w, v in zip(my_wins, valid) if v]
+        # generator windows: the contigs are the [51,411) slices of the windows the coverage test accepts (page-locked, like the windows)
+        if my_contigs is not None:
+            cpk = my_contigs_packed if my_contigs_packed is not None else (b"", 0, 0)
+        else:
+            cpk = ctx.pin_array(my_wins_rows[valid.astype(bool), 51:411], "contigs")
+        n_contigs = cpk[1]
         # the mapped pairs (20 B each) cross PCIe on the copy stream while the next step's kernels run; they are waited for before
         # the next map_emit reuses the stream (and after the last step, inside the timed region)
-        offs, pairs = ctx.map_emit(my_contigs_packed if my_contigs_packed is not None else contigs, async_copy=True)
+        offs, pairs = ctx.map_emit(cpk, async_copy=True)
         t = lap("map_emit", t)
         g.wait()                     # the graph arrays are on the host
         g.free()
@@ -407,8 +413,8 @@ def main():
             ok = np.concatenate(gather_bytes(ok))
             t = lap("gather_results", t)
         state.update(nodes=g.n, pre=g.pre_nodes, roots=int(g.n_roots), roots_ok=int(ok.sum()), windows=len(wins),
-                     valid=int(valid.sum()), contigs=len(contigs) if world == 1 else None, mapped_this_rank=int(pairs.shape[0]),
-                     window_pairs_this_rank=int(npairs.sum()), n_contigs_rank=len(contigs), graph=g)
+                     valid=int(valid.sum()), contigs=n_contigs if world == 1 else None, mapped_this_rank=int(pairs.shape[0]),
+                     window_pairs_this_rank=int(npairs.sum()), n_contigs_rank=n_contigs, graph=g)
         p.free()
 
     def barrier():
@@ -470,6 +476,12 @@ def main():
             nxt.wait()
             nxt.free()
         del host_fwd["pri"], host_fwd["sec"]
+    laps = None
+    if os.environ.get("VDJX_LAPS"):          # (diagnostic: host-side microseconds per step inside the scorer calls, vdjx_common.h vdjx_laps)
+        names = ("plan_hits_wait", "plan_order_upload", "wp_upload", "wp_plan", "wp_worklist", "wp_work_upload", "wp_kernel_wait", "ws_cover_wait",
+                 "ws_prof_collect", "me_key", "me_plan", "me_worklist", "me_work_upload", "me_kernel_wait", "me_second_call", "me_prev_copy_wait",
+                 "me_move_list", "me_move_upload", "me_gather_wait", "me_copy_issue")
+        laps = {n_: round(ctx.stat("us_" + n_) / (args.warmup + args.steps), 1) for n_ in names}
     stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_hits_distinct", "window_pairs", "window_work_items", "map_hits", "root_dp_items", "recount_items", "gated_instances")}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -549,7 +561,7 @@ def main():
         "shard_wall_ms_per_step": ({k_: round(v / args.steps * 1e3, 3) for k_, v in engine.laps.items()} if engine else None),
         "wall_ms_per_step": {k_: round(v / args.steps * 1e3, 3) for k_, v in wall.items()},
         "host_side": host_side,
-        "counts": {k_: v for k_, v in state.items() if k_ != "graph"}, "scorer_stats": stats,
+        "counts": {k_: v for k_, v in state.items() if k_ != "graph"}, "scorer_stats": stats, **({"host_laps_us_per_step": laps} if laps else {}),
         "shard_stats_rank0": ({n_: ctx.stat("shard_" + n_) for n_ in ("partials_received", "open_kmers", "questions", "decided_at_merge",
                                                                     "kept_after_answers")} if engine else None),
         "parity_gate": parity,

@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the scorers split only windows of more than 512 K distinct hits over several workgroups; the test pools stay far below, so the tests
+# run with the split at 128 hits (test_deep_windows_many_slices_and_multiplicities asserts that it happens).  Read once per process.
+os.environ.setdefault("VDJX_HIT_CHUNK", "128")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

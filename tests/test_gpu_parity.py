@@ -416,7 +416,8 @@ def test_deep_windows_many_slices_and_multiplicities(ctx):
     wins = [w for w in rep.windows() if w] + [t[30:516] for t in rep.clones]
     valid, npairs = ctx.window_score(wins, 175)
     assert ctx.stat("window_hits") > 10 * ctx.stat("window_hits_distinct") > 0          # multiplicities at work
-    assert ctx.stat("window_hits_max") > 65536                                          # more than one slice of hits
+    assert ctx.stat("window_hits_max") > 65536                                          # more than one slice of hits ...
+    assert ctx.stat("window_work_items") > len(wins)                                    # ... and the split happened (conftest: VDJX_HIT_CHUNK)
     for i, w in enumerate(wins):
         pairs, starts = ix.quick_map(w)
         assert int(npairs[i]) == len(pairs) > 10000, (i, int(npairs[i]), len(pairs))

@@ -312,6 +312,22 @@ class Context:
         C.memmove(ptr, raw, len(raw))
         return (C.cast(ptr, C.c_char_p), n, ln)
 
+    def pin_array(self, rows: np.ndarray, tag: str):
+        """pin_strings for strings that already are the rows of a C-contiguous uint8 matrix (no join / encode)"""
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        n, ln = rows.shape
+        need = max(rows.nbytes, 1)
+        ptr, cap = self._pinned.get("in:" + tag, (None, 0))
+        if cap < need:
+            if ptr:
+                self._retired.append(ptr)
+            new = C.c_void_p()
+            check(self.L.vdjx_host_alloc(self.h, need + need // 4, C.byref(new)), "vdjx_host_alloc")
+            ptr, cap = new.value, need + need // 4
+            self._pinned["in:" + tag] = (ptr, cap)
+        C.memmove(ptr, rows.ctypes.data, rows.nbytes)
+        return (C.cast(ptr, C.c_char_p), n, ln)
+
     def window_score(self, windows, ins: int, e0: int = 52, e1: int = 411, rs: int = 35, ms: int = 48, floor: int = 1):
         raw, n, ln = windows if isinstance(windows, tuple) else self.pack_strings(windows)
         if n == 0:

@@ -6,6 +6,7 @@
 #include <stddef.h>
 #include <string>
 #include <vector>
+#include <chrono>
 #include <map>
 
 #include "../../include/vdjx.h"
@@ -119,9 +120,11 @@ struct vdjx_ctx {
 	std::vector<u32> wp_cnt;
 	void* me_dense = nullptr;         // the pairs laid end to end for the copy to the host (kept: the copy may be asynchronous)
 	size_t me_dense_cap = 0;
-	std::vector<u64> me_hoff, me_cnt;
-	std::vector<uint4> me_work;       // slices of the mapping: {contig, first hit, end hit, -}
-	std::vector<u32> me_scnt;         // pairs found per slice
+	std::vector<u64> me_cnt;          // pairs per contig
+	void* me_book = nullptr;          // device bookkeeping between the counting and the writing call (vdjx_score.hip map_emit_impl)
+	size_t me_book_cap = 0, me_nsl = 0;
+	u32 me_slice_hits = 0;
+	hipEvent_t ev_gathered = nullptr;
 	u32 n_pairs = 0, n_classes = 0;
 	std::map<std::string, uint64_t> stats;
 };
@@ -179,6 +182,20 @@ struct vdjx_prof_scope {
 	~vdjx_prof_scope();
 };
 void vdjx_prof_collect(vdjx_ctx* ctx);
+
+// host-side laps (VDJX_LAPS=1): microseconds between two marks of a call, summed into vdjx_stat("us_<name>")
+struct vdjx_laps {
+	vdjx_ctx* c;
+	bool on;
+	std::chrono::steady_clock::time_point t;
+	explicit vdjx_laps(vdjx_ctx* ctx) : c(ctx) { static const bool e = getenv("VDJX_LAPS") != nullptr; on = e; if (on) t = std::chrono::steady_clock::now(); }
+	void mark(const char* name) {
+		if (!on) return;
+		const auto n = std::chrono::steady_clock::now();
+		c->stats[std::string("us_") + name] += (uint64_t) std::chrono::duration_cast<std::chrono::microseconds>(n - t).count();
+		t = n;
+	}
+};
 
 // ----------------------------------------------------------------------------------------------
 // device helpers

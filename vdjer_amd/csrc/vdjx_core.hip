@@ -45,6 +45,7 @@ extern "C" int vdjx_init(int device, vdjx_ctx** out) {
 	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->pairs_stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming);
 	if (e != hipSuccess) { delete c; vdjx_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return VDJX_EHIP; }
 	{
 		std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -101,7 +102,7 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	free_dev(c->d_vtext); free_dev(c->d_line_off); free_dev(c->d_seed_code); free_dev(c->d_seed_pos);
 	free_dev(c->d_ri_slots); free_dev(c->d_ri_rep); free_dev(c->d_ri_start); free_dev(c->d_ri_recs);
 	free_dev(c->d_pair_id); free_dev(c->d_read_num); free_dev(c->d_is_rc); free_dev(c->d_pair_r2);
-	free_dev(c->d_rec_info); free_dev(c->me_pairs); free_dev(c->me_dense); free_dev(c->wp_buf); free_dev(c->d_ri_cnt1); free_dev(c->d_ri_dstart); free_dev(c->d_ri_dinfo);
+	free_dev(c->d_rec_info); free_dev(c->me_pairs); free_dev(c->me_dense); free_dev(c->me_book); free_dev(c->wp_buf); free_dev(c->d_ri_cnt1); free_dev(c->d_ri_dstart); free_dev(c->d_ri_dinfo);
 	for (int i = 0; i < 2; i++) { free_dev(c->d_stage[i]); if (c->ev_copied[i]) (void) hipEventDestroy(c->ev_copied[i]); if (c->ev_packed[i]) (void) hipEventDestroy(c->ev_packed[i]); }
 	c->arena.release();
 	c->shard_arena.release();
@@ -115,6 +116,7 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	(void) hipStreamSynchronize(c->copy_stream);
 	(void) hipStreamDestroy(c->copy_stream);
 	if (c->pairs_stream) { (void) hipStreamSynchronize(c->pairs_stream); (void) hipStreamDestroy(c->pairs_stream); }
+	if (c->ev_gathered) (void) hipEventDestroy(c->ev_gathered);
 	(void) hipStreamDestroy(c->stream);
 	delete c;
 }

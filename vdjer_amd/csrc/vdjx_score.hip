@@ -712,7 +712,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_hits(ReadIndexDev ix, co
 //    pairs (stored once in a scratch list) for every batch, prefixes, and tests.
 // ----------------------------------------------------------------------------------------------
 #define COV_WORDS 8192
-#define HIT_CHUNK 65536u         // hits per workgroup of k_window_pairs: the deepest windows are split, the rest pay one preparation
+#define HIT_CHUNK 524288u        // hits per workgroup of k_window_pairs: only the very deepest windows are split (every piece pays one
+                                 // preparation of the window; measured at 10 M pairs: 65536 -> 5.2 ms, 262144 and above -> 3.5 ms)
 
 // one (weighted) entry of the class at offset o -> mapped pair or not (quick_map3.c:223-245)
 __device__ inline bool map_eval_entry(const MapLds& L, int rl, int o, const uint4 info, u32& pos2_out) {
@@ -1004,22 +1005,34 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 // many; the gather below lays the slices end to end, which is the reference's order (offset-major, registration order inside
 // a class).  One workgroup per contig left half the GPU idle and walked ~20 k hits sequentially.
 // ----------------------------------------------------------------------------------------------
-#define MAP_SLICE 4096u
-__global__ __launch_bounds__(MAP_THREADS) void k_map_emit(ReadIndexDev ix, const char* __restrict__ contigs, int len,
-                                                          const uint4* __restrict__ work, const u64* __restrict__ region_off,
+#define MAP_SLICE 4096u          // hits per slice at least ...
+#define MAP_SLICE_MAX 32768u     // ... and at most (map_emit_impl)
+// slice b belongs to the contig ci with slice_start[ci] <= b < slice_start[ci + 1] (the slices are never listed: a binary search
+// over the contigs' slice prefix replaces the work list the host used to build and upload)
+__device__ inline u32 slice_contig(const u32* __restrict__ slice_start, u32 n, u32 b) {
+	u32 lo = 0, hi = n;
+	while (hi - lo > 1) {
+		const u32 mid = (lo + hi) >> 1;
+		if (slice_start[mid] <= b) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+
+__global__ __launch_bounds__(MAP_THREADS) void k_map_emit(ReadIndexDev ix, const char* __restrict__ contigs, u32 n, int len, u32 slice_hits,
+                                                          const u32* __restrict__ slice_start, const u64* __restrict__ region_off,
                                                           vdjx_pair* __restrict__ pairs, u32* __restrict__ slice_cnt) {
 	__shared__ MapLds L;
 	__shared__ u32 s_base;
 	const u32 tid = threadIdx.x;
 	const int noff = len - ix.rl;
-	const uint4 wk = work[blockIdx.x];
-	const u32 ci = wk.x;
-	vdjx_pair* out = pairs + region_off[ci] + wk.y;
+	const u32 ci = slice_contig(slice_start, n, blockIdx.x);
+	const u32 w0 = (blockIdx.x - slice_start[ci]) * slice_hits;
+	vdjx_pair* out = pairs + region_off[ci] + w0;
 	const u32 H = map_prepare(L, ix, contigs + (size_t) ci * len, len);
-	const u32 h1 = wk.z < H ? wk.z : H;
+	const u32 h1 = w0 + slice_hits < H ? w0 + slice_hits : H;
 	if (tid == 0) s_base = 0;
 	__syncthreads();
-	for (u32 h0 = wk.y; h0 < h1; h0 += MAP_THREADS) {
+	for (u32 h0 = w0; h0 < h1; h0 += MAP_THREADS) {
 		const u32 h = h0 + tid;
 		Hit r;
 		r.pair = false;
@@ -1050,9 +1063,37 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_emit(ReadIndexDev ix, const
 	if (tid == 0) slice_cnt[blockIdx.x] = s_base;
 }
 
-// lay the slices end to end in the caller's dense layout: move[i] = {source element, destination element, count} (u64 x 3)
-__global__ void k_gather_pairs(const vdjx_pair* __restrict__ src, const u64* __restrict__ move, vdjx_pair* __restrict__ dst) {
-	const u64 so = move[3 * (size_t) blockIdx.x], dof = move[3 * (size_t) blockIdx.x + 1], cnt = move[3 * (size_t) blockIdx.x + 2];
+// exclusive u64 prefix of the slice counts (one workgroup) and, from it, the pairs of every contig
+__global__ __launch_bounds__(1024) void k_slice_scan(const u32* __restrict__ cnt, u32 n, u64* __restrict__ pre) {
+	__shared__ u64 part[1024];
+	const u32 per = (n + 1023) / 1024;
+	const u32 lo = threadIdx.x * per;
+	const u32 hi = lo + per < n ? lo + per : n;
+	u64 s = 0;
+	for (u32 i = lo; i < hi; i++) s += cnt[i];
+	part[threadIdx.x] = s;
+	__syncthreads();
+	for (u32 d = 1; d < 1024; d <<= 1) {
+		const u64 v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+		__syncthreads();
+		part[threadIdx.x] += v;
+		__syncthreads();
+	}
+	u64 run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+	for (u32 i = lo; i < hi; i++) { pre[i] = run; run += cnt[i]; }
+	if (threadIdx.x == 1023) pre[n] = part[1023];
+}
+__global__ void k_contig_counts(const u64* __restrict__ slice_pre, const u32* __restrict__ slice_start, u32 n, u64* __restrict__ out) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = slice_pre[slice_start[i + 1]] - slice_pre[slice_start[i]];
+}
+
+// lay the slices end to end in the caller's dense layout
+__global__ void k_gather_pairs(const vdjx_pair* __restrict__ src, u32 n, u32 slice_hits, const u32* __restrict__ slice_start,
+                               const u64* __restrict__ region_off, const u64* __restrict__ slice_pre, vdjx_pair* __restrict__ dst) {
+	const u32 ci = slice_contig(slice_start, n, blockIdx.x);
+	const u64 so = region_off[ci] + (u64) (blockIdx.x - slice_start[ci]) * slice_hits;
+	const u64 dof = slice_pre[blockIdx.x], cnt = slice_pre[blockIdx.x + 1] - dof;
 	const uint32_t* s = (const uint32_t*) (src + so);
 	uint32_t* d = (uint32_t*) (dst + dof);
 	for (u64 i = threadIdx.x; i < cnt * (sizeof(vdjx_pair) / 4); i += blockDim.x) d[i] = s[i];
@@ -1089,6 +1130,7 @@ static int plan_windows(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, cons
                         std::vector<u64>& off, u32** d_order, u64** d_off, u64* inst_total = nullptr, u64* inst_max = nullptr,
                         std::vector<u32>* order_out = nullptr) {
 	hipStream_t st = c->stream;
+	vdjx_laps lp(c);
 	u32 *d_hits, *d_inst;
 	HIP_TRY(db.alloc(&d_hits, n));
 	HIP_TRY(db.alloc(&d_inst, n));
@@ -1101,6 +1143,7 @@ static int plan_windows(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, cons
 	HIP_TRY(hipMemcpyAsync(inst.data(), d_inst, n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	lp.mark("plan_hits_wait");
 	if (inst_total) { *inst_total = 0; for (u32 v : inst) *inst_total += v; }
 	if (inst_max) { *inst_max = 0; for (u32 v : inst) *inst_max = std::max<u64>(*inst_max, v); }
 	off.assign(n + 1, 0);
@@ -1112,6 +1155,7 @@ static int plan_windows(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, cons
 	HIP_TRY(hipMemcpyAsync(*d_order, order.data(), n * 4, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(*d_off, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipStreamSynchronize(st));       // `order`/`off` staging buffers die with this frame
+	lp.mark("plan_order_upload");
 	return VDJX_OK;
 }
 
@@ -1135,14 +1179,17 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 	char* d_w;
 	u32 *d_np, *d_order, *d_cnt;
 	u64* d_off;
+	vdjx_laps lp(c);
 	HIP_TRY(db.alloc(&d_w, n * len));
 	HIP_TRY(db.alloc(&d_np, n));
 	HIP_TRY(hipMemcpyAsync(d_w, windows, n * len, hipMemcpyHostToDevice, st));
+	lp.mark("wp_upload");
 	std::vector<u64>& off = c->wp_off;
 	u64 inst_total = 0, inst_max = 0;
 	std::vector<u32> ord;
 	int rc = plan_windows(c, db, ix, d_w, n, len, true, off, &d_order, &d_off, &inst_total, &inst_max, &ord);
 	if (rc) return rc;
+	lp.mark("wp_plan");
 	if ((size_t) off[n] + 1 > c->wp_cap) {
 		free_set(c->wp_buf);
 		c->wp_cap = 0;
@@ -1167,8 +1214,10 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 		}
 	}
 	uint4* d_work;
+	lp.mark("wp_worklist");
 	HIP_TRY(db.alloc(&d_work, work.size()));
 	HIP_TRY(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(uint4), hipMemcpyHostToDevice, st));
+	lp.mark("wp_work_upload");
 	HIP_TRY(hipMemsetAsync(d_np, 0, n * 4, st));
 	HIP_TRY(hipMemsetAsync(d_cnt, 0, n * 4, st));
 	{
@@ -1176,6 +1225,7 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 		hipLaunchKernelGGL(k_window_pairs, dim3((u32) work.size()), dim3(MAP_THREADS), 0, st, ix, d_w, len, d_work, d_off, (u64*) c->wp_buf, d_cnt, d_np);
 	}
 	HIP_TRY(hipStreamSynchronize(st));       // `work` staging dies with this frame
+	lp.mark("wp_kernel_wait");
 	c->stats["window_work_items"] = work.size();
 	*d_np_out = d_np; *d_cnt_out = d_cnt; *d_off_out = d_off; *d_order_out = d_order;
 	return VDJX_OK;
@@ -1207,9 +1257,12 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	}
 	HIP_TRY(hipMemcpyAsync(out_valid, d_valid, n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
+	vdjx_laps lp(c);
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	lp.mark("ws_cover_wait");
 	vdjx_prof_collect(c);
+	lp.mark("ws_prof_collect");
 	{
 		u64 tot = 0;
 		for (size_t i = 0; i < n; i++) tot += out_npairs[i];
@@ -1357,51 +1410,75 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 	vdjx_clear_errors();
 	hipStream_t st = c->stream;
 	vdjx_work db(c);
-	// the mapping runs once: the counting call keeps its pairs on the device for the writing call
+	vdjx_laps lp(c);
+	// the mapping runs once: the counting call keeps its pairs (and the slice bookkeeping) on the device for the writing call
 	uint64_t key = fnv1a(contigs, n * (size_t) len, 0xcbf29ce484222325ull ^ (uint64_t) n * 1315423911ull ^ (uint64_t) len);
 	if (!key) key = 1;
+	lp.mark("me_key");
+	static const u32 slice_env = getenv("VDJX_MAP_SLICE") && atol(getenv("VDJX_MAP_SLICE")) > 0 ? (u32) atol(getenv("VDJX_MAP_SLICE")) : 0u;
 	if (c->me_key != key || c->me_cnt.size() != n) {
 		c->me_key = 0;
 		char* d_c;
 		u32* d_order;
-		u64 *d_off, *d_counts;
+		u64* d_off;
 		HIP_TRY(db.alloc(&d_c, n * len));
-		HIP_TRY(db.alloc(&d_counts, n));
 		HIP_TRY(hipMemcpyAsync(d_c, contigs, n * len, hipMemcpyHostToDevice, st));
 		std::vector<u64> off;
 		rc = plan_windows(c, db, ix, d_c, n, len, false, off, &d_order, &d_off);
 		if (rc) return rc;
+		lp.mark("me_plan");
 		if (off[n] > c->me_cap) {
 			free_set(c->me_pairs);
 			c->me_cap = 0;
 			HIP_TRY(hipMalloc(&c->me_pairs, (size_t) off[n] * sizeof(vdjx_pair)));
 			c->me_cap = (size_t) off[n];
 		}
-		// slices of MAP_SLICE hits, contig after contig
-		c->me_work.clear();
-		for (size_t ci = 0; ci < n; ci++) {
-			const u32 H = (u32) (off[ci + 1] - off[ci]);
-			for (u32 h0 = 0; h0 < H; h0 += MAP_SLICE) c->me_work.push_back(make_uint4((u32) ci, h0, std::min(H, h0 + MAP_SLICE), 0));
+		// slices of `slice_hits` hits, contig after contig: only their prefix over the contigs goes to the device.  Every slice pays
+		// one preparation of its contig (a few hundred index probes): as long as the slices are, while ~8 k of them remain
+		u32 slice_hits = slice_env;
+		if (!slice_hits) {
+			slice_hits = MAP_SLICE;
+			while (slice_hits < MAP_SLICE_MAX && off[n] / (slice_hits * 2) >= 8192) slice_hits *= 2;
 		}
-		const size_t nsl = c->me_work.size();
-		c->me_scnt.assign(nsl, 0);
+		c->me_slice_hits = slice_hits;
+		std::vector<u32> sstart(n + 1, 0);
+		for (size_t ci = 0; ci < n; ci++) {
+			const u64 sl = (off[ci + 1] - off[ci] + slice_hits - 1) / slice_hits;
+			if (sstart[ci] + sl >= (1ull << 31)) { vdjx_set_error("vdjx_map_emit: too many hit slices"); return VDJX_ELIMIT; }
+			sstart[ci + 1] = sstart[ci] + (u32) sl;
+		}
+		const size_t nsl = sstart[n];
+		// persistent bookkeeping: slice prefix of the contigs, hit offsets of the contigs, pairs per slice and their prefix
+		const size_t need = (n + 1) * 4 + 8 + (n + 1) * 8 + nsl * 4 + 8 + (nsl + 1) * 8 + n * 8 + 64;
+		if (need > c->me_book_cap) {
+			free_set(c->me_book);
+			c->me_book_cap = 0;
+			HIP_TRY(hipMalloc(&c->me_book, need + need / 4));
+			c->me_book_cap = need + need / 4;
+		}
+		uint8_t* bk = (uint8_t*) c->me_book;
+		u64* b_off = (u64*) bk;                      bk += (n + 1) * 8;
+		u64* b_pre = (u64*) bk;                      bk += (nsl + 1) * 8;
+		u64* b_cnt = (u64*) bk;                      bk += n * 8;
+		u32* b_sstart = (u32*) bk;                   bk += ((n + 1) * 4 + 7) / 8 * 8;
+		u32* b_scnt = (u32*) bk;
+		c->me_nsl = nsl;
 		c->me_cnt.assign(n, 0);
+		HIP_TRY(hipMemcpyAsync(b_sstart, sstart.data(), (n + 1) * 4, hipMemcpyHostToDevice, st));
+		HIP_TRY(hipMemcpyAsync(b_off, d_off, (n + 1) * 8, hipMemcpyDeviceToDevice, st));
+		lp.mark("me_worklist");
 		if (nsl) {
-			uint4* d_work;
-			u32* d_scnt;
-			HIP_TRY(db.alloc(&d_work, nsl));
-			HIP_TRY(db.alloc(&d_scnt, nsl));
-			HIP_TRY(hipMemcpyAsync(d_work, c->me_work.data(), nsl * sizeof(uint4), hipMemcpyHostToDevice, st));
 			{
 				vdjx_prof_scope ps(c, "k_map_emit");
-				hipLaunchKernelGGL(k_map_emit, dim3((u32) nsl), dim3(MAP_THREADS), 0, st, ix, d_c, len, d_work, d_off, (vdjx_pair*) c->me_pairs, d_scnt);
+				hipLaunchKernelGGL(k_map_emit, dim3((u32) nsl), dim3(MAP_THREADS), 0, st, ix, d_c, (u32) n, len, slice_hits, b_sstart, b_off, (vdjx_pair*) c->me_pairs, b_scnt);
 			}
-			HIP_TRY(hipMemcpyAsync(c->me_scnt.data(), d_scnt, nsl * 4, hipMemcpyDeviceToHost, st));
-			HIP_TRY(hipStreamSynchronize(st));
-			HIP_TRY(hipGetLastError());
-			for (size_t i = 0; i < nsl; i++) c->me_cnt[c->me_work[i].x] += c->me_scnt[i];
+			hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, st, b_scnt, (u32) nsl, b_pre);
+			hipLaunchKernelGGL(k_contig_counts, dim3((u32) (n + 255) / 256), dim3(256), 0, st, b_pre, b_sstart, (u32) n, b_cnt);
+			HIP_TRY(hipMemcpyAsync(c->me_cnt.data(), b_cnt, n * 8, hipMemcpyDeviceToHost, st));
 		}
-		c->me_hoff = off;
+		HIP_TRY(hipStreamSynchronize(st));           // (also: `sstart` staging dies with this frame)
+		HIP_TRY(hipGetLastError());
+		lp.mark("me_kernel_wait");
 		c->me_key = key;
 		c->stats["map_hits"] = off[n];
 	}
@@ -1410,10 +1487,17 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 	if (!pairs) return VDJX_OK;
 	const u64 total = offsets[n];
 	if (total) {
-		u64* d_move;
-		const size_t nsl = c->me_work.size();
+		const size_t nsl = c->me_nsl;
+		const u32 slice_hits = c->me_slice_hits;
+		uint8_t* bk = (uint8_t*) c->me_book;
+		const u64* b_off = (const u64*) bk;          bk += (n + 1) * 8;
+		const u64* b_pre = (const u64*) bk;          bk += (nsl + 1) * 8;
+		bk += n * 8;
+		const u32* b_sstart = (const u32*) bk;
 		// the dense copy outlives this call when the transfer to the host is asynchronous: a buffer of its own, not the arena
+		lp.mark("me_second_call");
 		HIP_TRY(hipStreamSynchronize(c->pairs_stream));          // an earlier asynchronous copy may still be reading the buffer
+		lp.mark("me_prev_copy_wait");
 		if (total > c->me_dense_cap) {
 			free_set(c->me_dense);
 			c->me_dense_cap = 0;
@@ -1421,34 +1505,23 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 			c->me_dense_cap = (size_t) (total + total / 4);
 		}
 		vdjx_pair* d_dense = (vdjx_pair*) c->me_dense;
-		std::vector<u64> move(3 * nsl + 3);
-		{
-			u64 at = 0;
-			for (size_t i = 0; i < nsl; i++) {
-				const uint4 wk = c->me_work[i];
-				move[3 * i] = c->me_hoff[wk.x] + wk.y;
-				move[3 * i + 1] = at;
-				move[3 * i + 2] = c->me_scnt[i];
-				at += c->me_scnt[i];
-			}
-		}
-		HIP_TRY(db.alloc(&d_move, move.size()));
-		HIP_TRY(hipMemcpyAsync(d_move, move.data(), move.size() * 8, hipMemcpyHostToDevice, st));
 		if (nsl) {
 			vdjx_prof_scope ps(c, "k_gather_pairs");
-			hipLaunchKernelGGL(k_gather_pairs, dim3((u32) nsl), dim3(256), 0, st, (const vdjx_pair*) c->me_pairs, d_move, d_dense);
+			hipLaunchKernelGGL(k_gather_pairs, dim3((u32) nsl), dim3(256), 0, st, (const vdjx_pair*) c->me_pairs, (u32) n, slice_hits, b_sstart, b_off, b_pre, d_dense);
 		}
 		if (async) {
-			// the pairs cross PCIe on the copy stream beside whatever the caller does next (vdjx_map_emit_end waits for them)
-			HIP_TRY(hipStreamSynchronize(st));
-			HIP_TRY(hipGetLastError());
+			// the pairs cross PCIe on the copy stream beside whatever the caller does next (vdjx_map_emit_end waits for them); the
+			// copy stream waits for the gather through an event, the host does not
+			HIP_TRY(hipEventRecord(c->ev_gathered, st));
+			HIP_TRY(hipStreamWaitEvent(c->pairs_stream, c->ev_gathered, 0));
 			HIP_TRY(hipMemcpyAsync(pairs, d_dense, (size_t) total * sizeof(vdjx_pair), hipMemcpyDeviceToHost, c->pairs_stream));
+			lp.mark("me_copy_issue");
 		} else {
 			HIP_TRY(hipMemcpyAsync(pairs, d_dense, (size_t) total * sizeof(vdjx_pair), hipMemcpyDeviceToHost, st));
 			HIP_TRY(hipStreamSynchronize(st));
 			HIP_TRY(hipGetLastError());
+			vdjx_prof_collect(c);          // (asynchronous: the gather's timing is collected by the next call that waits for the stream)
 		}
-		vdjx_prof_collect(c);
 	}
 	c->me_key = 0;           // one counting call serves one writing call
 	return VDJX_OK;
