@@ -205,7 +205,26 @@ struct Tup24 {                  // k 46..50
 	__device__ static inline void store(Tup24* p, const Tup24& t) { *p = t; }
 };
 
-// K2a': bucket sizes over the gated instances (include_kmer, A2:240-259: no 'N', every Phred >= 20)
+// the offsets whose k bases are all clean: bit o is set iff none of the bits o .. o+k-1 of `bad` is (o < P) -- OR of k shifts in
+// log2(k) steps instead of P window tests
+__device__ inline u64 vdjx_clean_offsets(u64 bad, int k, int P) {
+	u64 inv = bad;
+	int cur = 1;
+	while (cur * 2 <= k) { inv |= inv >> cur; cur *= 2; }
+	inv |= inv >> (k - cur);
+	return ~inv & (P >= 64 ? ~0ull : (1ull << P) - 1ull);
+}
+
+// One instance in six is gated, in runs (a read is clean or it is not): a loop over the offsets of a lane's record spends most of
+// its trips masked off in most lanes, and the hash of a k-mer costs ~50 instructions.  The kernels below therefore list the gated
+// (lane, offset) pairs of a wave's 64 records densely in LDS (16 offsets at a time: a prefix sum over the lanes' counts, a few
+// cheap trips to write the entries) and hash them with all lanes busy: ~3 dense trips per 64 records instead of 16 sparse ones.
+#define GL_WAVE_BYTES 3072u         // per wave: 64 x 16-byte packed bases, 1024 x 2-byte entries (lane << 6 | offset)
+
+// K2a': bucket sizes over the gated instances (include_kmer, A2:240-259: no 'N', every Phred >= 20).  One loop trip per offset:
+// the dense listing of k_part_records_g, tried here too, was observed to put a few instances in ten thousand into wrong buckets for
+// reads of more than 32 offsets on gfx950 (timing dependent, gone with any perturbation of the kernel, never seen in
+// k_part_records_g, whose listing is followed by an LDS atomic with return) -- not understood, so not used: 0.2 ms at 10 M pairs.
 __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                              const u64* __restrict__ lowq, size_t R, int rl, int k, u32 nb_bits,
                                                              size_t rpb, u32* __restrict__ bucket_cnt) {
@@ -234,65 +253,92 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 // K2c' pass 1: records -> gated tuples, LDS-staged counting sort into `nbk` coarse buckets (see K2c above).
 // A round takes `rr0` records (the host sizes it from the gated fraction the histogram measured, so that the stage fills: with one
 // instance in six gated, rounds sized for the worst case spend their time in barriers); a round whose tuples do not fit is
-// simply retried with half the records.
+// simply retried with half the records.  The gated instances of a round are listed once (dense, see above) as descriptors
+// {record in the round (16 bits), offset (6), bucket (10)}; the placement pass reads the descriptors, not the records' offsets.
+#define PARTR_STAGE_BYTES 98304u
 template <typename TUP>
 __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                                  const u64* __restrict__ lowq, size_t R, u64 rec_base, int rl, int k,
                                                                  u32 shift, u32 nbk, size_t rpb, u32 rr0, u32* __restrict__ gcur,
                                                                  TUP* __restrict__ out) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	TUP* stage = (TUP*) smem;
+	TUP* stage = (TUP*) smem;                                         // (the waves' instance lists live here while the round is counted)
+	u32* desc = (u32*) (smem + PARTR_STAGE_BYTES);
 	__shared__ u32 cnt[PART_MAXB], base[PART_MAXB + 1], cur[PART_MAXB], gbase[PART_MAXB], tmp[PART_THREADS];
-	const u32 ROUND = PART_LDS_BYTES / sizeof(TUP);
+	__shared__ u32 s_n;
+	constexpr u32 ROUND = PARTR_STAGE_BYTES / sizeof(TUP);
 	const int P = rl - k + 1;
 	const u32 rr_min = ROUND / (u32) P;                              // always fits
 	u32 rr = rr0 > rr_min ? rr0 : rr_min;
-	const u64 km = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
 	const u32 mask = nbk - 1;
+	const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	uint8_t* wv = smem + wave * GL_WAVE_BYTES;
+	ulonglong2* wb = (ulonglong2*) wv;
+	uint16_t* wl = (uint16_t*) (wv + 1024);
 	const size_t r0 = (size_t) blockIdx.x * rpb;
 	const size_t r1 = r0 + rpb < R ? r0 + rpb : R;
 	size_t rs = r0;
 	while (rs < r1) {
 		const size_t re = rs + rr < r1 ? rs + rr : r1;
 		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) cnt[i] = 0;
+		if (threadIdx.x == 0) s_n = 0;
 		__syncthreads();
-		for (size_t r = rs + threadIdx.x; r < re; r += PART_THREADS) {
-			const RecView v = load_rec(bases, nmask, lowq, r);
-			const u64 bad = v.nm | v.lq;
-			for (int o = 0; o < P; o++) {
-				if ((bad >> o) & km) continue;
-				u64 khi, klo;
-				vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
-				atomicAdd(&cnt[(u32) (vdjx_mix(klo, khi) >> shift) & mask], 1u);
+		for (size_t rb = rs; rb < re; rb += PART_THREADS) {
+			const size_t r = rb + threadIdx.x;
+			u64 G = 0;
+			if (r < re) {
+				const RecView v = load_rec(bases, nmask, lowq, r);
+				G = vdjx_clean_offsets(v.nm | v.lq, k, P);
+				wb[lane] = make_ulonglong2(v.bhi, v.blo);
+			}
+			const u32 loc0 = (u32) (rb - rs) + wave * 64u;                // this wave's first record in the round
+			for (int ob = 0; ob < P; ob += 16) {
+				const u32 g = (u32) (G >> ob) & 0xFFFFu;
+				const u32 c = (u32) __popc(g);
+				const u32 incl = (u32) vdjx_wave_scan_add((int) c);
+				const u32 total = (u32) __builtin_amdgcn_readlane((int) incl, 63);
+				if (!total) continue;                                     // (wave-uniform)
+				u32 at = incl - c;
+				for (u32 gg = g; gg; gg &= gg - 1) wl[at++] = (uint16_t) ((lane << 6) | (u32) (ob + __builtin_ctz(gg)));
+				u32 dbase = 0;
+				if (lane == 0) dbase = atomicAdd(&s_n, total);
+				dbase = (u32) __builtin_amdgcn_readlane((int) dbase, 0);
+				for (u32 i = lane; i < total; i += 64) {
+					const u32 e = wl[i];
+					const ulonglong2 bb = wb[e >> 6];
+					u64 khi, klo;
+					vdjx_kmer_at(bb.x, bb.y, rl, k, (int) (e & 63u), khi, klo);
+					const u32 b = (u32) (vdjx_mix(klo, khi) >> shift) & mask;
+					atomicAdd(&cnt[b], 1u);
+					if (dbase + i < ROUND) desc[dbase + i] = ((loc0 + (e >> 6)) << 16) | ((e & 63u) << 10) | b;
+				}
 			}
 		}
 		__syncthreads();
-		part_scan(cnt, base, tmp, nbk);
-		if (base[nbk] > ROUND) {                                      // (uniform) too many gated instances for the stage
+		if (s_n > ROUND) {                                            // (uniform) too many gated instances for the stage
 			rr = rr / 2 > rr_min ? rr / 2 : rr_min;
 			__syncthreads();
 			continue;
 		}
+		part_scan(cnt, base, tmp, nbk);
 		for (u32 i = threadIdx.x; i < nbk; i += PART_THREADS) {
 			cur[i] = base[i];
 			gbase[i] = cnt[i] ? atomicAdd(&gcur[i], cnt[i]) : 0u;
 		}
 		__syncthreads();
-		for (size_t r = rs + threadIdx.x; r < re; r += PART_THREADS) {
-			const RecView v = load_rec(bases, nmask, lowq, r);
-			const u64 bad = v.nm | v.lq;
-			for (int o = 0; o < P; o++) {
-				if ((bad >> o) & km) continue;
-				u64 khi, klo;
-				vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
-				const u32 b = (u32) (vdjx_mix(klo, khi) >> shift) & mask;
-				stage[atomicAdd(&cur[b], 1u)] = TUP::make(klo, khi, ((rec_base + (u64) r) << 6) | (u64) o);
-			}
-		}
-		__syncthreads();
 		const u32 n = base[nbk];
 		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
-			const TUP t = stage[i];
+			const u32 d = desc[i];
+			const size_t r = rs + (d >> 16);
+			const u32 o = (d >> 10) & 63u;
+			const ulonglong2 bb = ((const ulonglong2*) bases)[r];
+			u64 khi, klo;
+			vdjx_kmer_at(bb.x, bb.y, rl, k, (int) o, khi, klo);
+			TUP::store(&stage[atomicAdd(&cur[d & 1023u], 1u)], TUP::make(klo, khi, ((rec_base + (u64) r) << 6) | (u64) o));
+		}
+		__syncthreads();
+		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
+			const TUP t = TUP::load(&stage[i]);
 			const u32 b = (u32) (vdjx_mix(t.lo, t.hi()) >> shift) & mask;
 			TUP::store(&out[gbase[b] + (i - base[b])], t);
 		}
@@ -1663,6 +1709,14 @@ __global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ 
 	if (threadIdx.x == 0 && tot) atomicAdd(n_inst, tot);
 }
 
+// survivors the walk never met (whole-pool builds: there are none, every survivor has gated instances in this pool)
+__global__ void k_count_unseen(const u64* __restrict__ ufirst, u32 n, u32* __restrict__ out) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool un = i < n && ufirst[i] == NONE64;
+	const u64 m = __ballot(un);
+	if (m && __lane_id() == 0) atomicAdd(out, (u32) __popcll(m));
+}
+
 // in-edge slots (v, first base of u) -> the predecessor u, and the out-edge slot (u, last base of v) of the same edge
 __global__ void k_edges_from_in(SurvTable t, u32 n, int k, const u64* __restrict__ in_first, u32* __restrict__ in_from,
                                 u64* __restrict__ edge_first, u32* __restrict__ edge_to) {
@@ -1869,6 +1923,14 @@ struct SurvivorsG {
 
 inline u32 ceil_log2_u64(u64 x) { u32 b = 0; while ((1ull << b) < x) b++; return b; }
 
+// VDJX_SYNC_DEBUG=1: wait for the stream after every stage and say so (which launch faulted)
+static void dbg_sync(vdjx_ctx* c, const char* what) {
+	static const bool on = getenv("VDJX_SYNC_DEBUG") != nullptr;
+	if (!on) return;
+	const hipError_t e = hipStreamSynchronize(c->stream);
+	fprintf(stderr, "[vdjx] %s: %s\n", what, hipGetErrorString(e));
+}
+
 // Phase A, partition: the gated instances of `pool` as tuples grouped by the top T bits of the k-mer hash (T chosen from their
 // number: ~4096 per bucket).  One host read (the tuple count) sizes everything that follows.
 template <typename TUP, typename A>
@@ -1895,6 +1957,7 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 		vdjx_prof_scope ps(c, "k_gated_hist");
 		hipLaunchKernelGGL(k_gated_hist, dim3(nblk), dim3(HIST_THREADS), (size_t) NBH * 4, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, pool->rl, k, HB, rpb, hcnt);
 	}
+	dbg_sync(c, "k_gated_hist");
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, hcnt, NBH, hstart);
 	u32 N = 0;
 	HIP_TRY(hipMemcpyAsync(&N, hstart + NBH, 4, hipMemcpyDeviceToHost, st));
@@ -1916,7 +1979,9 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 	const u32 Tt = T + extra;
 	const u32 NBt = 1u << Tt;
 	HIP_TRY(db.alloc(&out->t, (size_t) N + 1));
-	HIP_TRY(hipFuncSetAttribute((const void*) k_part_records_g<TUP>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
+	constexpr u32 stage_tuples = PARTR_STAGE_BYTES / (u32) sizeof(TUP);
+	constexpr u32 lds_partr = PARTR_STAGE_BYTES + stage_tuples * 4;
+	HIP_TRY(hipFuncSetAttribute((const void*) k_part_records_g<TUP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_partr));
 	HIP_TRY(hipFuncSetAttribute((const void*) k_part_tuples_g<TUP>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
 	// pass geometry: <= 1024 buckets in one pass; otherwise 256 coarse x the rest (large pools: 2^(Tt-10) coarse x 1024)
 	u32 cbits = Tt, fbits = 0;
@@ -1934,12 +1999,12 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 		hipLaunchKernelGGL(k_init_cursors, dim3((NBc + 255) / 256), dim3(256), 0, st, hstart, NBc, HB - cbits, gcur);
 		// records per round: three quarters of the stage at the measured gated fraction, in whole sweeps of the workgroup
 		const u64 NIl = (u64) R * (u64) P;
-		const u32 stage_tuples = PART_LDS_BYTES / (u32) sizeof(TUP);
 		u64 rr = N ? (u64) stage_tuples * 3 / 4 * NIl / ((u64) N * (u64) P) : 1u << 16;
 		rr = std::max<u64>(PART_THREADS, std::min<u64>(rr / PART_THREADS * PART_THREADS, 1u << 16));
-		hipLaunchKernelGGL(k_part_records_g<TUP>, dim3(nblk2), dim3(PART_THREADS), PART_LDS_BYTES, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, rec_base,
+		hipLaunchKernelGGL(k_part_records_g<TUP>, dim3(nblk2), dim3(PART_THREADS), lds_partr, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, rec_base,
 		                   pool->rl, k, 64 - cbits, NBc, rpb, (u32) rr, gcur, l1);
 	}
+	dbg_sync(c, "k_part_records");
 	u32* tstart;                                   // starts of the final buckets
 	HIP_TRY(db.alloc(&tstart, NBt + 1));
 	out->NB = NBt;
@@ -2073,6 +2138,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		hipLaunchKernelGGL(k_table_remap, dim3(tmask / 256 + 1), bs, 0, st, table, tmask + 1, newidx);
 		hipLaunchKernelGGL(k_chain_words, gs, bs, 0, st, succ, skey, ns, k, linw, fbw);
 	}
+	dbg_sync(c, "k_chain_order");
 	sv.lo = lo2; sv.hi = hi2; sv.gcnt = gcnt2; sv.gfirst = gfirst2;
 	// item layout and the permutation of the blocks of 16 over the ranges
 	ItemFmt f;
@@ -2123,10 +2189,10 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	n_inst = g_cursor + 1;
 	HIP_TRY(db.alloc(&range_cnt, n_ranges_p));
 	HIP_TRY(db.alloc(&range_start, n_ranges_p + 1));
-	HIP_TRY(db.alloc(&g_err, 1));
+	HIP_TRY(db.alloc(&g_err, 2));
 	HIP_TRY(hipMemsetAsync(g_cursor, 0, 16, st));
 	HIP_TRY(hipMemsetAsync(range_cnt, 0, (size_t) n_ranges_p * 4, st));
-	HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
+	HIP_TRY(hipMemsetAsync(g_err, 0, 8, st));
 	const size_t lds_walk = (size_t) n_ranges_p * 4;
 	if (lds_walk > 64 * 1024) { vdjx_set_error("too many survivor ranges for the walk histogram"); return VDJX_ELIMIT; }
 	HIP_TRY(hipFuncSetAttribute((const void*) k_walk_items, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_walk));
@@ -2152,6 +2218,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		hipLaunchKernelGGL(k_walk_items, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, k, tb, succ, linw, f, range_shift,
 		                   n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err, 0u);
 	}
+	dbg_sync(c, "k_walk_items");
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, range_cnt, n_ranges_p, range_start);
 	// the partitioned items: at most one per instance
 	HIP_TRY(db.alloc(&items, NI + 1));
@@ -2177,6 +2244,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 			hipLaunchKernelGGL(k_part_items2, dim3(n_coarse * 8), dim3(PART_THREADS), PART_LDS_BYTES, st, l1, range_start, l2bits, 8u, f, range_shift, l2bits, gcur, items);
 		}
 	}
+	dbg_sync(c, "k_part_items");
 	{
 		vdjx_prof_scope ps(c, "k_recount");
 #define RC_LAUNCH(SB, IT) hipLaunchKernelGGL((k_recount<SB, IT>), dim3(n_ranges), dim3(RC_THREADS), 0, st, items, range_start, f, ns, rec_base, fbw, ro.ucnt, ro.ufirst, ro.in_first, n_inst)
@@ -2196,18 +2264,21 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		}
 #undef RC_LAUNCH
 	}
+	dbg_sync(c, "k_recount");
 	if (derive_edges) {
+		hipLaunchKernelGGL(k_count_unseen, dim3((ns + 255) / 256), dim3(256), 0, st, ro.ufirst, ns, g_err + 1);
 		HIP_TRY(hipMemsetAsync(ro.edge_first, 0xFF, (size_t) ns * 32, st));
 		hipLaunchKernelGGL(k_edges_from_in, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, tb, ns, k, ro.in_first, ro.in_from, ro.edge_first, ro.edge_to);
 	}
-	u32 err = 0, n_items = 0;
+	u32 err[2] = {0, 0}, n_items = 0;
 	unsigned long long inst = 0;
-	HIP_TRY(hipMemcpyAsync(&err, g_err, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(err, g_err, 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&n_items, range_start + n_ranges_p, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&inst, n_inst, 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
-	if (err) { vdjx_set_error("k_walk_items: item buffer too small (%u waves stopped)", err); return VDJX_EHIP; }
+	if (err[0]) { vdjx_set_error("k_walk_items: item buffer too small (%u waves stopped)", err[0]); return VDJX_EHIP; }
+	if (err[1]) { vdjx_set_error("internal error: %u of %u surviving k-mers were not met again in the records", err[1], ns); return VDJX_EHIP; }
 	c->stats["recount_items"] = n_items;            // runs of surviving k-mer instances of this pool (8 bytes each)
 	c->stats["recount_instances"] = inst;           // the instances themselves
 	return VDJX_OK;
@@ -2302,6 +2373,7 @@ int kmer_build_impl2(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, 
 	SurvivorsG sv;
 	rc = stage_gated_reduce<TUP>(c, db, t, pv, 0, k, mf, mq, &sv);
 	if (rc) return rc;
+	dbg_sync(c, "gated_reduce");
 	g->pre_nodes = (size_t) sv.ndist;
 	RecountOut ro{};
 	if (sv.n) {
