@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 					u64 khi, klo;
 					vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
 					if (dbg & 8u) s = (klo & 3u) ? (int) ((u32) vdjx_mix(klo, khi) % f.ns) : -1;
-					else s = filtered ? surv_lookup2(t, klo, khi) : surv_lookup2f(t, klo, khi);
+					else s = (filtered || (dbg & 16u)) ? surv_lookup2(t, klo, khi) : surv_lookup2f(t, klo, khi);
 					in = 0;
 					if (s < 0) o++;
 				}
@@ -2174,7 +2174,8 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	const u32 n_coarse = (n_ranges + (1u << l2bits) - 1) >> l2bits;
 	const u32 n_ranges_p = n_coarse << l2bits;                      // padded: every coarse segment has 2^l2bits ranges
 	// raw item blocks
-	u32 nblk = (u32) std::min<size_t>(2048, (R + WALK_THREADS * 8 - 1) / (WALK_THREADS * 8));
+	static const size_t walk_blocks = tune("VDJX_WALK_BLOCKS", 4096);
+	u32 nblk = (u32) std::min<size_t>(walk_blocks, (R + WALK_THREADS * 8 - 1) / (WALK_THREADS * 8));
 	if (nblk == 0) nblk = 1;
 	const size_t nwaves = (size_t) nblk * (WALK_THREADS / 64);
 	const size_t NI = R * (size_t) P;
@@ -2216,7 +2217,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	if (R) {
 		vdjx_prof_scope ps(c, "k_walk_items");
 		hipLaunchKernelGGL(k_walk_items, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, k, tb, succ, linw, f, range_shift,
-		                   n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err, 0u);
+		                   n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err, (u32) tune("VDJX_WALK_FLAGS", 0));
 	}
 	dbg_sync(c, "k_walk_items");
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, range_cnt, n_ranges_p, range_start);
