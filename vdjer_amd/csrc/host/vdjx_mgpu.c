@@ -86,20 +86,41 @@ void vdjx_mgpu_free(vdjx_mgpu* m) {
 uint64_t vdjx_mgpu_bytes_sent(const vdjx_mgpu* m) { return m ? m->bytes_sent : 0; }
 
 /* all-to-all-v of byte rows: send[r] rows of `row` bytes to rank r (contiguous, rank order), recv likewise */
+/* RCCL moved the second half of a 1.09 GB transfer wrongly on this stack (ROCm 7.0.2 / RCCL 2.26.6: a rank sending 34 M partials to
+ * itself through all_to_all_single, bytes beyond 2^29 differ, silently): no single transfer is larger than A2A_CHUNK here, and what a
+ * rank sends to itself is a device copy. */
+#define A2A_CHUNK ((size_t) 128 << 20)
 static int a2av(vdjx_mgpu* m, const void* d_send, const uint64_t* send_rows, void* d_recv, const uint64_t* recv_rows, size_t row) {
 	int rc = 0;
-	size_t so = 0, ro = 0;
-	NCCLC(ncclGroupStart());
-	for (int r = 0; r < m->nranks; r++) {
-		if (send_rows[r]) NCCLC(ncclSend((const char*) d_send + so, send_rows[r] * row, ncclChar, r, m->comm, m->stream));
-		if (recv_rows[r]) NCCLC(ncclRecv((char*) d_recv + ro, recv_rows[r] * row, ncclChar, r, m->comm, m->stream));
-		so += send_rows[r] * row;
-		ro += recv_rows[r] * row;
-		if (r != m->rank) m->bytes_sent += send_rows[r] * row;
+	const int G = m->nranks, me = m->rank;
+	size_t* so = (size_t*) calloc((size_t) G + 1, sizeof(size_t));
+	size_t* ro = (size_t*) calloc((size_t) G + 1, sizeof(size_t));
+	size_t rounds = 0;
+	if (!so || !ro) { rc = VDJX_EHIP; goto done; }
+	for (int r = 0; r < G; r++) {
+		so[r + 1] = so[r] + (size_t) send_rows[r] * row;
+		ro[r + 1] = ro[r] + (size_t) recv_rows[r] * row;
+		if (r != me) {
+			const size_t a = ((size_t) send_rows[r] * row + A2A_CHUNK - 1) / A2A_CHUNK, b = ((size_t) recv_rows[r] * row + A2A_CHUNK - 1) / A2A_CHUNK;
+			if (a > rounds) rounds = a;
+			if (b > rounds) rounds = b;
+			m->bytes_sent += send_rows[r] * row;
+		}
 	}
-	NCCLC(ncclGroupEnd());
+	if (send_rows[me]) HIPC(hipMemcpyAsync((char*) d_recv + ro[me], (const char*) d_send + so[me], (size_t) send_rows[me] * row, hipMemcpyDeviceToDevice, m->stream));
+	for (size_t rd = 0; rd < rounds; rd++) {
+		NCCLC(ncclGroupStart());
+		for (int r = 0; r < G; r++) {
+			if (r == me) continue;
+			const size_t sb = (size_t) send_rows[r] * row, rb = (size_t) recv_rows[r] * row, a = rd * A2A_CHUNK;
+			if (a < sb) NCCLC(ncclSend((const char*) d_send + so[r] + a, sb - a < A2A_CHUNK ? sb - a : A2A_CHUNK, ncclChar, r, m->comm, m->stream));
+			if (a < rb) NCCLC(ncclRecv((char*) d_recv + ro[r] + a, rb - a < A2A_CHUNK ? rb - a : A2A_CHUNK, ncclChar, r, m->comm, m->stream));
+		}
+		NCCLC(ncclGroupEnd());
+	}
 	HIPC(hipStreamSynchronize(m->stream));
 done:
+	free(so); free(ro);
 	return rc;
 }
 
@@ -175,23 +196,47 @@ int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int
 	HIPC(hipMalloc(&d_surv_all, ns_total * W3 + 16));
 	VX(vdjx_shard_survivors(sh, d_surv));
 	{
-		size_t ro = 0;
-		NCCLC(ncclGroupStart());
+		/* every rank's survivors to every rank, in pieces of at most A2A_CHUNK (see a2av); the own ones by a device copy */
+		size_t ro = 0, rounds = 0;
 		for (int r = 0; r < G; r++) {
-			if (ns) NCCLC(ncclSend(d_surv, ns * W3, ncclChar, r, m->comm, m->stream));
-			if (recv_counts[r]) NCCLC(ncclRecv((char*) d_surv_all + ro, recv_counts[r] * W3, ncclChar, r, m->comm, m->stream));
-			ro += recv_counts[r] * W3;
-			if (r != me) m->bytes_sent += ns * W3;
+			const size_t a = ((size_t) recv_counts[r] * W3 + A2A_CHUNK - 1) / A2A_CHUNK;
+			if (r != me && a > rounds) rounds = a;
 		}
-		NCCLC(ncclGroupEnd());
+		{
+			const size_t a = ((size_t) ns * W3 + A2A_CHUNK - 1) / A2A_CHUNK;
+			if (G > 1 && a > rounds) rounds = a;
+		}
+		for (int r = 0; r < me; r++) ro += recv_counts[r] * W3;
+		if (ns) HIPC(hipMemcpyAsync((char*) d_surv_all + ro, d_surv, ns * W3, hipMemcpyDeviceToDevice, m->stream));
+		for (size_t rd = 0; rd < rounds; rd++) {
+			const size_t a = rd * A2A_CHUNK;
+			ro = 0;
+			NCCLC(ncclGroupStart());
+			for (int r = 0; r < G; r++) {
+				const size_t sb = (size_t) ns * W3, rb = (size_t) recv_counts[r] * W3;
+				if (r != me) {
+					if (a < sb) NCCLC(ncclSend((const char*) d_surv + a, sb - a < A2A_CHUNK ? sb - a : A2A_CHUNK, ncclChar, r, m->comm, m->stream));
+					if (a < rb) NCCLC(ncclRecv((char*) d_surv_all + ro + a, rb - a < A2A_CHUNK ? rb - a : A2A_CHUNK, ncclChar, r, m->comm, m->stream));
+				}
+				ro += rb;
+			}
+			NCCLC(ncclGroupEnd());
+		}
+		for (int r = 0; r < G; r++) if (r != me) m->bytes_sent += ns * W3;
 		HIPC(hipStreamSynchronize(m->stream));
 	}
 	HIPC(hipMalloc(&d_mins, ns_total * 5 * 8 + 16));          /* in-edge first sights [4n] | node first sights [n] */
 	HIPC(hipMalloc(&d_ucnt, ns_total * 4 + 16));
 	VX(vdjx_shard_edges(sh, d_surv_all, ns_total, d_mins, d_ucnt, (char*) d_mins + ns_total * 32));
 	if (ns_total) {
-		NCCLC(ncclAllReduce(d_mins, d_mins, ns_total * 5, ncclUint64, ncclMin, m->comm, m->stream));       /* all-ones = none stays largest */
-		NCCLC(ncclAllReduce(d_ucnt, d_ucnt, ns_total, ncclUint32, ncclSum, m->comm, m->stream));
+		for (size_t a = 0; a < ns_total * 5; a += A2A_CHUNK / 8) {                                       /* all-ones = none stays largest */
+			const size_t n = ns_total * 5 - a < A2A_CHUNK / 8 ? ns_total * 5 - a : A2A_CHUNK / 8;
+			NCCLC(ncclAllReduce((char*) d_mins + a * 8, (char*) d_mins + a * 8, n, ncclUint64, ncclMin, m->comm, m->stream));
+		}
+		for (size_t a = 0; a < ns_total; a += A2A_CHUNK / 4) {
+			const size_t n = ns_total - a < A2A_CHUNK / 4 ? ns_total - a : A2A_CHUNK / 4;
+			NCCLC(ncclAllReduce((char*) d_ucnt + a * 4, (char*) d_ucnt + a * 4, n, ncclUint32, ncclSum, m->comm, m->stream));
+		}
 		HIPC(hipStreamSynchronize(m->stream));
 		m->bytes_sent += (uint64_t) (G > 1) * ns_total * 44;
 	}
