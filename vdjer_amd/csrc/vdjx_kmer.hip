@@ -824,8 +824,8 @@ __global__ __launch_bounds__(1024) void k_seg_offsets(const u32* __restrict__ se
 
 struct PendOut { u64* lo; u64* hi; u32* cg; u64* mg; u32* need; u32* n; u32 cap; };
 
-#define MERGE_THREADS 256
-#define MERGE_SLOTS 1024u             // a bucket holds a few hundred distinct gated k-mers per rank
+#define MERGE_THREADS 512
+#define MERGE_SLOTS 2048u             // a bucket holds ~1,000 distinct gated k-mers of all ranks together at 3,000 tuples per bucket
 template <typename THI>
 __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* __restrict__ recv, const u32* __restrict__ seg_off,
                                                                 u32 MG, u32 G, u32 NBo,
@@ -926,25 +926,33 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 			// questions to every rank that holds gated instances of an open k-mer
 			for (u32 s = 0; s < G; s++) {
 				const u32 off = seg_off[(size_t) s * (NBo + 1) + b * MG], cnt = seg_off[(size_t) s * (NBo + 1) + (b + 1) * MG] - off;
-				for (u32 i0 = 0; i0 < cnt; i0 += MERGE_THREADS) {
-					const u32 i = i0 + tid;
-					u32 pid = NONE32, li = 0;
-					if (tid == 0) s_ns = 0;
-					__syncthreads();
-					if (i < cnt) {
+				// count this source's questions, reserve their places with ONE bump of the source's counter, then write them
+				if (tid == 0) s_ns = 0;
+				__syncthreads();
+				u32 mine = 0;
+				for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
+					const Partial p = recv[off + i];
+					const u64 h = vdjx_mix(p.lo, p.hi);
+					if ((u32) ((h >> 12) & (S - 1)) != sp) continue;
+					const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, (u32) h);
+					if (slot >= 0 && s_pid[slot] != NONE32) mine++;
+				}
+				if (mine) atomicAdd(&s_ns, mine);
+				__syncthreads();
+				if (tid == 0) { s_sbase = s_ns ? atomicAdd(&g_nq[s], s_ns) : 0; s_np = 0; }
+				__syncthreads();
+				if (s_ns) {
+					for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
 						const Partial p = recv[off + i];
 						const u64 h = vdjx_mix(p.lo, p.hi);
-						if ((u32) ((h >> 12) & (S - 1)) == sp) {
-							const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, (u32) h);
-							if (slot >= 0) pid = s_pid[slot];
-						}
+						if ((u32) ((h >> 12) & (S - 1)) != sp) continue;
+						const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, (u32) h);
+						if (slot < 0) continue;
+						const u32 pid = s_pid[slot];
+						if (pid != NONE32) queries[src_base[s] + s_sbase + atomicAdd(&s_np, 1u)] = make_uint2(off + i - src_base[s], pid);
 					}
-					if (pid != NONE32) li = atomicAdd(&s_ns, 1u);
-					__syncthreads();
-					if (tid == 0) s_sbase = s_ns ? atomicAdd(&g_nq[s], s_ns) : 0;
-					__syncthreads();
-					if (pid != NONE32) queries[src_base[s] + s_sbase + li] = make_uint2(off + i - src_base[s], pid);
 				}
+				__syncthreads();
 			}
 			__syncthreads();
 		}
@@ -1016,23 +1024,26 @@ __global__ void k_resolve_first(const uint8_t* __restrict__ replies, u32 nr, con
 	if (((const u64*) me)[1] == p_mg[pid]) p_r0[pid] = r;
 }
 
-__global__ void k_resolve_add(const uint8_t* __restrict__ replies, u32 nr, const u32* __restrict__ p_r0, int k, u32* __restrict__ p_fl,
-                              u32* __restrict__ p_S) {
-	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per answer: lane j adds the answer's j-th quality sum (64 consecutive words per wave instead of k scattered atomics of
+// one thread)
+__global__ __launch_bounds__(256) void k_resolve_add(const uint8_t* __restrict__ replies, u32 nr, const u32* __restrict__ p_r0, int k, u32* __restrict__ p_fl,
+                                                     u32* __restrict__ p_S) {
+	const u32 r = blockIdx.x * 4u + (threadIdx.x >> 6);
+	const u32 lane = threadIdx.x & 63u;
 	if (r >= nr) return;
 	const uint8_t* me = replies + (size_t) r * REPLY_BYTES;
 	const u32 w0 = ((const u32*) me)[0];
 	const u32 pid = w0 & PID_MASK, need = w0 >> 30;
 	const u32 r0 = p_r0[pid];
 	if (r0 == NONE32) return;                   // cannot happen: the owner of the minimum always answers
-	if ((need & NEED_SEQ) && r != r0) {
+	if ((need & NEED_SEQ) && r != r0 && lane == 0) {
 		const u64* a = (const u64*) me;
 		const u64* b = (const u64*) (replies + (size_t) r0 * REPLY_BYTES);
 		if (a[2] != b[2] || a[3] != b[3] || a[4] != b[4]) p_fl[pid] = 1;
 	}
-	if (need & NEED_Q) {
+	if ((need & NEED_Q) && (int) lane < k) {
 		const uint8_t* first = me + REPLY_Q0 + (r == r0 ? 2 * REPLY_KQ : REPLY_KQ);
-		for (int j = 0; j < k; j++) atomicAdd(&p_S[(size_t) pid * 64 + j], (u32) me[REPLY_Q0 + j] + (u32) first[j]);
+		atomicAdd(&p_S[(size_t) pid * 64 + lane], (u32) me[REPLY_Q0 + lane] + (u32) first[lane]);
 	}
 }
 
@@ -2727,7 +2738,7 @@ extern "C" int vdjx_shard_resolve(vdjx_shard* s, const void* d_replies, uint64_t
 		SurvOutG so{v.lo, v.hi, v.gcnt, v.gfirst, s->n_surv, s->sv_cap};
 		vdjx_prof_scope ps(c, "k_shard_resolve");
 		hipLaunchKernelGGL(k_resolve_first, dim3((nr + 255) / 256), dim3(256), 0, st, (const uint8_t*) d_replies, nr, s->po.mg, s->p_r0);
-		hipLaunchKernelGGL(k_resolve_add, dim3((nr + 255) / 256), dim3(256), 0, st, (const uint8_t*) d_replies, nr, s->p_r0, s->k, s->p_fl, s->p_S);
+		hipLaunchKernelGGL(k_resolve_add, dim3((nr + 3) / 4), dim3(256), 0, st, (const uint8_t*) d_replies, nr, s->p_r0, s->k, s->p_fl, s->p_S);
 		hipLaunchKernelGGL(k_resolve_keep, dim3((s->n_pend + 255) / 256), dim3(256), 0, st, s->po, s->n_pend, s->p_fl, s->p_S, s->k,
 		                   (u32) std::max(s->mf, 0), s->mqq, s->tlow, so);
 	}
