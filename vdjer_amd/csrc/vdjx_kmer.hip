@@ -1597,7 +1597,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_items2(const u64* __restr
 //   count(x) = sum prefix[e >= x] + sum suffix[a <= x] + single[x],   first(x) = min of the same slots - 15 + x,
 //   in-edge (x, first base of x - 1) = min over prefix[e >= x], suffix[a <= x - 1] - 15 + x   (and the singles' own in-edges)
 // Lanes of a wave that hit the same slot (deep clones) are combined before they touch LDS.
-#define RC_THREADS 512
+#define RC_THREADS 1024
 #define RC_UNR 4
 template <typename IT> struct RcNone;
 template <> struct RcNone<u32> { static constexpr u32 v = 0xFFFFFFFFu; };
