@@ -218,6 +218,32 @@ __host__ __device__ inline void vdjx_kmer_at(u64 bhi, u64 blo, int rl, int k, in
 	klo = (u64) v;
 }
 
+// the same for an offset that differs from lane to lane, written without a single per-lane select: the 128-bit shift by a VGPR
+// amount compiles to v_cmp (mask into an SGPR pair) + v_cndmask, and with shift amounts on both sides of 64 in one wave the
+// k-mers of a few lanes in ten thousand came out wrong on gfx950 (ROCm 7.0.2), depending on timing -- reads of more than 32
+// offsets only, because only there 2*(rl-k-o) reaches 64.  Masks and double shifts instead.
+__device__ inline void vdjx_kmer_at_lane(u64 bhi, u64 blo, int rl, int k, int o, u64& khi, u64& klo) {
+	const u32 sh = (u32) (2 * (rl - k - o));               // 0 .. 126
+	const u64 big = 0ull - (u64) (sh >> 6);                 // all ones: shift by 64 or more
+	const u64 x_lo = (bhi & big) | (blo & ~big), x_hi = bhi & ~big;
+	const u32 s = sh & 63u;
+	u64 lo = (x_lo >> s) | ((x_hi << 1) << (63u - s));
+	u64 hi = x_hi >> s;
+	if (k < 32) { lo &= (1ull << (2 * k)) - 1ull; hi = 0; }          // (k is uniform: scalar branches)
+	else if (k < 64) hi &= (1ull << (2 * k - 64)) - 1ull;
+	khi = hi;
+	klo = lo;
+}
+
+// 32 bits of the packed read from bit `pos` (0 .. 127) up, and one base, for positions that differ from lane to lane (see above)
+__device__ inline u32 vdjx_bits_at_lane(u64 bhi, u64 blo, u32 pos) {
+	const u64 big = 0ull - (u64) (pos >> 6);
+	const u64 x_lo = (bhi & big) | (blo & ~big), x_hi = bhi & ~big;
+	const u32 s = pos & 63u;
+	return (u32) ((x_lo >> s) | ((x_hi << 1) << (63u - s)));
+}
+__device__ inline u32 vdjx_base_at_lane(u64 bhi, u64 blo, int rl, int i) { return vdjx_bits_at_lane(bhi, blo, (u32) (2 * (rl - 1 - i))) & 3u; }
+
 // wave-wide unsigned minimum through DPP row shifts and broadcasts (gfx9 family): no LDS traffic, unlike __shfl_xor
 // (ds_bpermute); every lane gets the result.  All 64 lanes must be active (the result is read from lane 63).
 __device__ inline u32 vdjx_wave_min(u32 v) {

@@ -25,7 +25,7 @@
 #include <string.h>
 #include <stdlib.h>
 
-#define HIST_THREADS 1024
+#define HIST_THREADS 512
 #define K3_THREADS 512
 #define K3_SLOTS 1024u              // LDS table slots per sub-pass of k_bucket_aggregate (28 KB with u32 key_hi): ~100 distinct gated k-mers per bucket
 #define LOCAL_SLOTS 2048u           // k_bucket_local keeps every distinct k-mer of the bucket, gated or not (~600)
@@ -219,31 +219,48 @@ __device__ inline u64 vdjx_clean_offsets(u64 bad, int k, int P) {
 // its trips masked off in most lanes, and the hash of a k-mer costs ~50 instructions.  The kernels below therefore list the gated
 // (lane, offset) pairs of a wave's 64 records densely in LDS (16 offsets at a time: a prefix sum over the lanes' counts, a few
 // cheap trips to write the entries) and hash them with all lanes busy: ~3 dense trips per 64 records instead of 16 sparse ones.
+// The offset of a listed instance differs from lane to lane: the k-mer is cut out with vdjx_kmer_at_lane (vdjx_common.h: the plain
+// 128-bit shift by a per-lane amount gave wrong k-mers on gfx950 when the amounts of a wave lay on both sides of 64).
 #define GL_WAVE_BYTES 3072u         // per wave: 64 x 16-byte packed bases, 1024 x 2-byte entries (lane << 6 | offset)
 
-// K2a': bucket sizes over the gated instances (include_kmer, A2:240-259: no 'N', every Phred >= 20).  One loop trip per offset:
-// the dense listing of k_part_records_g, tried here too, was observed to put a few instances in ten thousand into wrong buckets for
-// reads of more than 32 offsets on gfx950 (timing dependent, gone with any perturbation of the kernel, never seen in
-// k_part_records_g, whose listing is followed by an LDS atomic with return) -- not understood, so not used: 0.2 ms at 10 M pairs.
+// K2a': bucket sizes over the gated instances (include_kmer, A2:240-259: no 'N', every Phred >= 20), listed densely per wave
 __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                              const u64* __restrict__ lowq, size_t R, int rl, int k, u32 nb_bits,
                                                              size_t rpb, u32* __restrict__ bucket_cnt) {
-	extern __shared__ u32 hist[];
+	extern __shared__ __attribute__((aligned(16))) u32 hist[];       // [NB], then GL_WAVE_BYTES per wave
 	const u32 NB = 1u << nb_bits;
 	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) hist[i] = 0;
 	__syncthreads();
+	uint8_t* wv = (uint8_t*) (hist + NB) + (threadIdx.x >> 6) * GL_WAVE_BYTES;
+	ulonglong2* wb = (ulonglong2*) wv;
+	uint16_t* wl = (uint16_t*) (wv + 1024);
+	const u32 lane = threadIdx.x & 63u;
 	const size_t r0 = (size_t) blockIdx.x * rpb;
 	const size_t r1 = r0 + rpb < R ? r0 + rpb : R;
 	const int P = rl - k + 1;
-	const u64 km = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
-	for (size_t r = r0 + threadIdx.x; r < r1; r += HIST_THREADS) {
-		const RecView v = load_rec(bases, nmask, lowq, r);
-		const u64 bad = v.nm | v.lq;
-		for (int o = 0; o < P; o++) {
-			if ((bad >> o) & km) continue;
-			u64 khi, klo;
-			vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
-			atomicAdd(&hist[(u32) (vdjx_mix(klo, khi) >> (64 - nb_bits))], 1u);
+	for (size_t rb = r0; rb < r1; rb += HIST_THREADS) {
+		const size_t r = rb + threadIdx.x;
+		u64 G = 0;
+		if (r < r1) {
+			const RecView v = load_rec(bases, nmask, lowq, r);
+			G = vdjx_clean_offsets(v.nm | v.lq, k, P);
+			wb[lane] = make_ulonglong2(v.bhi, v.blo);
+		}
+		for (int ob = 0; ob < P; ob += 16) {
+			const u32 g = (u32) (G >> ob) & 0xFFFFu;
+			const u32 c = (u32) __popc(g);
+			const u32 incl = (u32) vdjx_wave_scan_add((int) c);
+			const u32 total = (u32) __builtin_amdgcn_readlane((int) incl, 63);
+			if (!total) continue;                                     // (wave-uniform)
+			u32 at = incl - c;
+			for (u32 gg = g; gg; gg &= gg - 1) wl[at++] = (uint16_t) ((lane << 6) | (u32) (ob + __builtin_ctz(gg)));
+			for (u32 i = lane; i < total; i += 64) {
+				const u32 e = wl[i];
+				const ulonglong2 bb = wb[e >> 6];
+				u64 khi, klo;
+				vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) (e & 63u), khi, klo);
+				atomicAdd(&hist[(u32) (vdjx_mix(klo, khi) >> (64 - nb_bits))], 1u);
+			}
 		}
 	}
 	__syncthreads();
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 					const u32 e = wl[i];
 					const ulonglong2 bb = wb[e >> 6];
 					u64 khi, klo;
-					vdjx_kmer_at(bb.x, bb.y, rl, k, (int) (e & 63u), khi, klo);
+					vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) (e & 63u), khi, klo);
 					const u32 b = (u32) (vdjx_mix(klo, khi) >> shift) & mask;
 					atomicAdd(&cnt[b], 1u);
 					if (dbase + i < ROUND) desc[dbase + i] = ((loc0 + (e >> 6)) << 16) | ((e & 63u) << 10) | b;
@@ -333,7 +350,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 			const u32 o = (d >> 10) & 63u;
 			const ulonglong2 bb = ((const ulonglong2*) bases)[r];
 			u64 khi, klo;
-			vdjx_kmer_at(bb.x, bb.y, rl, k, (int) o, khi, klo);
+			vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) o, khi, klo);
 			TUP::store(&stage[atomicAdd(&cur[d & 1023u], 1u)], TUP::make(klo, khi, ((rec_base + (u64) r) << 6) | (u64) o));
 		}
 		__syncthreads();
@@ -1366,7 +1383,6 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 			inv |= inv >> (k - cur);
 		}
 		const u64 V = live ? ~inv & ((1ull << P) - 1ull) : 0ull;
-		const u128 b128 = ((u128) v.bhi << 64) | v.blo;          // base i at bits 2*(rl-1-i)
 		int o = V ? __builtin_ctzll(V) : P;                      // the offset this lane works on; P: done
 		int s = -1;                                              // its survivor, if known
 		u32 in = 0;                                              // has_prev << 2 | first base of the predecessor k-mer
@@ -1406,7 +1422,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				first = false;
 				if (o < P) {
 					u64 khi, klo;
-					vdjx_kmer_at(v.bhi, v.blo, rl, k, o, khi, klo);
+					vdjx_kmer_at_lane(v.bhi, v.blo, rl, k, o, khi, klo);
 					if (dbg & 8u) s = (klo & 3u) ? (int) ((u32) vdjx_mix(klo, khi) % f.ns) : -1;
 					else s = (filtered || (dbg & 16u)) ? surv_lookup2(t, klo, khi) : surv_lookup2f(t, klo, khi);
 					in = 0;
@@ -1424,7 +1440,10 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				const u32 ow = ((((u32) w0 & 0xFFFF0000u) | ((u32) w1 >> 16)) << a) >> 16;
 				const u32 bw = (u32) (((((w0 >> 32) << 32) | (w1 >> 32)) << (2 * a)) >> 32);
 				const int sh = 2 * (rl - 16 - (o + k));             // the read's bases o+k .. o+k+15 in the same layout
-				const u32 rw = sh >= 0 ? (u32) (b128 >> sh) : (sh > -32 ? (u32) b128 << (-sh) : 0u);
+				// (per-lane positions: no 128-bit shift by a VGPR amount, see vdjx_kmer_at_lane)
+				const u32 rw_dn = vdjx_bits_at_lane(v.bhi, v.blo, (u32) (sh > 0 ? sh : 0));
+				const u32 up = (u32) (sh < 0 ? -sh : 0);
+				const u32 rw = (rw_dn << (up & 31u)) & (0u - (u32) (up < 32u));
 				const u32 x = bw ^ rw;
 				const u32 nl = ~lw & 0xFFFFu;
 				const u32 m_base = x ? (u32) __builtin_clz(x) >> 1 : 16u;
@@ -1442,7 +1461,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				if (o2 < P && ((V >> o2) & 1ull)) {
 					if (capped) s2 = s + 16;
 					else if ((ow >> (15u - steps)) & 1u) {                     // the last node has successors off the chain
-						const u32 bb = (u32) (b128 >> (2 * (rl - k - o2))) & 3u;
+						const u32 bb = vdjx_base_at_lane(v.bhi, v.blo, rl, o2 + k - 1);
 						const u32 nx = succ[((u32) s + steps) * 4u + bb];
 						s2 = nx == NONE32 ? -1 : (int) nx;
 					}
@@ -1452,7 +1471,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 			}
 			// ---- the run, one item per block of 16 (and per 2^lb nodes) ----
 			u32 pin = in;
-			if (act) in = s >= 0 ? (4u | ((u32) (b128 >> (2 * (rl - o))) & 3u)) : 0u;      // (next round: first base of the k-mer at o - 1)
+			if (act) in = s >= 0 ? (4u | vdjx_base_at_lane(v.bhi, v.blo, rl, o - 1)) : 0u;      // (next round: first base of the k-mer at o - 1)
 			while (__ballot(rem > 0)) {
 				const bool close = rem > 0;
 				u32 len = 16u - (pp & 15u);
@@ -1477,7 +1496,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				fill += cnt;
 				if (close) {
 					rem -= len; pp += len; po += len;
-					pin = 4u | ((u32) (b128 >> (2 * (rl - po))) & 3u);        // the next piece's predecessor is the node before it
+					pin = 4u | vdjx_base_at_lane(v.bhi, v.blo, rl, (int) po - 1);        // the next piece's predecessor is the node before it
 				}
 			}
 		}
@@ -1963,10 +1982,11 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 	HIP_TRY(db.alloc(&hcnt, NBH));
 	HIP_TRY(db.alloc(&hstart, NBH + 1));
 	HIP_TRY(hipMemsetAsync(hcnt, 0, (size_t) NBH * 4, st));
-	HIP_TRY(hipFuncSetAttribute((const void*) k_gated_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NBH * 4)));
+	const size_t lds_hist = (size_t) NBH * 4 + (HIST_THREADS / 64) * GL_WAVE_BYTES;
+	HIP_TRY(hipFuncSetAttribute((const void*) k_gated_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_hist));
 	{
 		vdjx_prof_scope ps(c, "k_gated_hist");
-		hipLaunchKernelGGL(k_gated_hist, dim3(nblk), dim3(HIST_THREADS), (size_t) NBH * 4, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, pool->rl, k, HB, rpb, hcnt);
+		hipLaunchKernelGGL(k_gated_hist, dim3(nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, pool->rl, k, HB, rpb, hcnt);
 	}
 	dbg_sync(c, "k_gated_hist");
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, hcnt, NBH, hstart);
@@ -2150,6 +2170,23 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		hipLaunchKernelGGL(k_chain_words, gs, bs, 0, st, succ, skey, ns, k, linw, fbw);
 	}
 	dbg_sync(c, "k_chain_order");
+	if (getenv("VDJX_SYNC_DEBUG")) {              // the new numbering is a permutation, and every key finds itself
+		std::vector<u32> ni(ns), seen(ns, 0);
+		(void) hipMemcpy(ni.data(), newidx, (size_t) ns * 4, hipMemcpyDeviceToHost);
+		u32 dup = 0, oob = 0;
+		for (u32 i = 0; i < ns; i++) { if (ni[i] >= ns) oob++; else if (seen[ni[i]]++) dup++; }
+		std::vector<u64> pdh(ns);
+		std::vector<unsigned long long> prh(ns);
+		(void) hipMemcpy(pdh.data(), pd, (size_t) ns * 8, hipMemcpyDeviceToHost);
+		(void) hipMemcpy(prh.data(), pred, (size_t) ns * 8, hipMemcpyDeviceToHost);
+		u32 unresolved = 0;
+		for (u32 i = 0; i < ns; i++) { const u32 p0 = (u32) (pdh[i] >> 32); if (p0 != NONE32 && (u32) (pdh[p0] >> 32) != NONE32) unresolved++; }
+		fprintf(stderr, "[vdjx] chain order: %u survivors, %u duplicate new indices, %u out of range, %u unresolved (cycles), %u jump launches\n", ns, dup, oob, unresolved, n_jump);
+		for (u32 i = 0, shown = 0; i < ns && shown < 6; i++) if (ni[i] < ns && seen[ni[i]] > 1) {
+			fprintf(stderr, "[vdjx]   old %u -> new %u: pd = (%u, %u), pred word %llx\n", i, ni[i], (u32) (pdh[i] >> 32), (u32) pdh[i], prh[i]);
+			shown++;
+		}
+	}
 	sv.lo = lo2; sv.hi = hi2; sv.gcnt = gcnt2; sv.gfirst = gfirst2;
 	// item layout and the permutation of the blocks of 16 over the ranges
 	ItemFmt f;
@@ -2290,7 +2327,27 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
 	if (err[0]) { vdjx_set_error("k_walk_items: item buffer too small (%u waves stopped)", err[0]); return VDJX_EHIP; }
-	if (err[1]) { vdjx_set_error("internal error: %u of %u surviving k-mers were not met again in the records", err[1], ns); return VDJX_EHIP; }
+	if (err[1]) {
+		if (getenv("VDJX_SYNC_DEBUG")) {          // name the k-mers
+			std::vector<u64> uf(ns), lo(ns), hi(ns), gf(ns);
+			std::vector<u32> gc(ns);
+			(void) hipMemcpy(uf.data(), ro.ufirst, (size_t) ns * 8, hipMemcpyDeviceToHost);
+			(void) hipMemcpy(lo.data(), sv.lo, (size_t) ns * 8, hipMemcpyDeviceToHost);
+			(void) hipMemcpy(hi.data(), sv.hi, (size_t) ns * 8, hipMemcpyDeviceToHost);
+			(void) hipMemcpy(gf.data(), sv.gfirst, (size_t) ns * 8, hipMemcpyDeviceToHost);
+			(void) hipMemcpy(gc.data(), sv.gcnt, (size_t) ns * 4, hipMemcpyDeviceToHost);
+			for (u32 i = 0, shown = 0; i < ns && shown < 8; i++) if (uf[i] == NONE64) {
+				char txt[65];
+				for (int j = 0; j < k; j++) { const int sh = 2 * (k - 1 - j); const u32 c2 = (u32) (sh < 64 ? lo[i] >> sh : hi[i] >> (sh - 64)) & 3u; txt[j] = "ATCG"[c2]; }
+				txt[k] = 0;
+				fprintf(stderr, "[vdjx] unseen survivor %u: %s gated count %u first gated instance record %llu offset %llu\n", i, txt, gc[i],
+				        (unsigned long long) (gf[i] >> 6), (unsigned long long) (gf[i] & 63));
+				shown++;
+			}
+		}
+		vdjx_set_error("internal error: %u of %u surviving k-mers were not met again in the records", err[1], ns);
+		return VDJX_EHIP;
+	}
 	c->stats["recount_items"] = n_items;            // runs of surviving k-mer instances of this pool (8 bytes each)
 	c->stats["recount_instances"] = inst;           // the instances themselves
 	return VDJX_OK;
