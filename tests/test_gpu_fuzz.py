@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+_SCALE = int(os.environ.get("VDJX_FUZZ_SCALE", "1"))          # more configurations per run (and other seeds: VDJX_FUZZ_SEED)
+_SEED = int(os.environ.get("VDJX_FUZZ_SEED", "0"))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -38,8 +40,8 @@ def ctx():
 def test_kmer_build_random_configurations_vs_oracle(ctx, mode, seed, n):
     from vdjer_amd import synth
     import test_gpu_parity as T
-    rng = np.random.default_rng(seed)
-    for it in range(n):
+    rng = np.random.default_rng(seed + _SEED)
+    for it in range(n * _SCALE):
         c = _draw(rng, mode)
         rep = synth.make_repertoire(c["clones"], seed=c["seed"])
         pool = synth.make_reads(rep, c["pairs"], noise_frac=c["noise"], seed=c["seed"] + 1, rl=c["rl"], err=c["err"], n_rate=c["n_rate"])
@@ -55,3 +57,120 @@ def test_kmer_build_random_configurations_vs_oracle(ctx, mode, seed, n):
             T.run_both(ctx, pool, vc, jc, c["k"], c["mf"], c["mq"])
         except Exception as e:
             raise AssertionError(f"configuration {it} of ({mode}, seed {seed}): {c}") from e
+
+
+@pytest.mark.parametrize("seed,n", [(201, 12)])
+def test_scorers_random_configurations_vs_oracle(ctx, seed, n):
+    """a-8 / a-9 / a-10 with random read length, window length, insert size, evaluation range, spans and floor, window starts all
+    over the transcripts (and reverse complements, and windows nothing maps to), contig slices of random length: mapped pairs in the
+    reference's order, counts and verdicts against the oracle."""
+    from oracle import oracle
+    from vdjer_amd import synth
+    import test_gpu_parity as T
+    rng = np.random.default_rng(seed + _SEED)
+    for it in range(n * _SCALE):
+        rl = int(rng.choice([36, 50, 50, 64]))
+        wlen = int(rng.integers(rl + 120, 640))
+        ins = int(rng.integers(120, 260))
+        rep = synth.make_repertoire(int(rng.integers(1, 8)), seed=int(rng.integers(0, 1 << 30)))
+        pool = synth.make_reads(rep, int(rng.integers(500, 9000)), noise_frac=float(rng.choice([0.0, 0.2])), seed=int(rng.integers(0, 1 << 30)),
+                                rl=rl, ins_mean=float(ins), err=float(rng.choice([0.0, 0.004])))
+        ix = oracle.ReadIndex(pool)
+        p = T._load_index(ctx, pool)
+        wins = []
+        for t in rep.clones:
+            for _ in range(4):
+                st = int(rng.integers(0, max(1, len(t) - wlen)))
+                w = t[st:st + wlen]
+                if len(w) == wlen:
+                    wins.append(w if rng.random() < 0.8 else synth.revcomp(w))
+        wins.append("".join("ACGT"[int(x)] for x in rng.integers(0, 4, wlen)))
+        e0 = int(rng.integers(1, wlen // 3))
+        e1 = int(rng.integers(e0 + 20, wlen - rl))
+        rs, ms, fl = int(rng.integers(10, rl)), int(rng.integers(10, 80)), int(rng.integers(0, 4))
+        cfg = dict(it=it, rl=rl, wlen=wlen, ins=ins, e0=e0, e1=e1, rs=rs, ms=ms, fl=fl, n_wins=len(wins))
+        valid, npairs = ctx.window_score(wins, ins, e0=e0, e1=e1, rs=rs, ms=ms, floor=fl)
+        for i, w in enumerate(wins):
+            pairs, starts = ix.quick_map(w)
+            assert int(npairs[i]) == len(pairs), (cfg, i)
+            exp = 1 if fl == 0 else ix.coverage_is_valid(starts, len(w), ins, e0=e0, e1=e1, rs=rs, ms=ms, floor=fl)
+            assert int(valid[i]) == exp, (cfg, i)
+        clen = int(rng.integers(rl + 20, wlen))
+        c0 = int(rng.integers(0, wlen - clen + 1))
+        contigs = [w[c0:c0 + clen] for w in wins]
+        offs, got = ctx.map_emit(contigs)
+        for j, c in enumerate(contigs):
+            pairs, _ = ix.quick_map(c)
+            mine = got[int(offs[j]):int(offs[j + 1])]
+            assert mine.shape[0] == len(pairs), (cfg, j)
+            for fld in ("pair_id", "rec1", "rec2", "pos1", "pos2", "insert", "rc1", "rc2"):
+                assert np.array_equal(mine[fld].astype(np.int64), pairs[fld].astype(np.int64)), (cfg, j, fld)
+        p.free()
+
+
+@pytest.mark.parametrize("seed,n", [(301, 10)])
+def test_sharded_build_random_configurations_vs_single_gpu(ctx, seed, n):
+    """The sharded driver with 2 or 4 ranks as threads on this GPU (tests/fake_dist.py) on random configurations (including reads of
+    more than 32 offsets, duplicated records, k up to 50): the graph of every rank == the single-GPU build of the union pool (which
+    run_both also checks against the oracle)."""
+    import threading
+    import torch
+    from fake_dist import ThreadDist
+    from vdjer_amd import api, shard, synth
+    import test_gpu_parity as T
+    rng = np.random.default_rng(seed + _SEED)
+    for it in range(n * _SCALE):
+        c = _draw(rng, "any" if it % 2 else "gt32")
+        world = int(rng.choice([2, 4]))
+        rl = c["rl"]
+        rep = synth.make_repertoire(c["clones"], seed=c["seed"])
+        per = max(200, c["pairs"] // world)
+        pools = [synth.make_reads(rep, per, noise_frac=c["noise"], seed=c["seed"] + 1 + r, rl=rl, err=c["err"], n_rate=c["n_rate"]) for r in range(world)]
+        if c["dup"]:                        # rank 1 holds rank 0's reads again: k-mers whose reads differ only across ranks
+            m = min(pools[0].primary.shape[0], pools[1].primary.shape[0]) // 2
+            pools[1].primary[:m] = pools[0].primary[:m]
+        vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+        jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+        nrec = [p_.primary.shape[0] + p_.secondary.shape[0] for p_ in pools]
+        stride = max(nrec)
+        blank = np.frombuffer(("0" + "N" * rl + "I" * rl).encode(), np.uint8)
+        parts = []
+        for r, p_ in enumerate(pools):      # the union in global numbering: rank r's records start at r * stride
+            rows = np.concatenate([p_.primary, p_.secondary])
+            pad = np.stack([blank] * (stride - rows.shape[0])) if stride > rows.shape[0] else np.zeros((0, 2 * rl + 1), np.uint8)
+            parts += [rows, pad]
+        cat = np.concatenate(parts)
+        R = cat.shape[0]
+        union = synth.ReadPool(rl, cat, np.zeros((0, 2 * rl + 1), np.uint8), np.zeros(R, np.uint32), np.zeros(R, np.uint8),
+                               np.zeros(R, np.uint8), np.arange(R, dtype=np.uint32), 0)
+        cfg = dict(c, world=world, it=it)
+        try:
+            ref = T.run_both(ctx, union, vc, jc, c["k"], c["mf"], c["mq"])
+        except Exception as e:
+            raise AssertionError(f"single-GPU build of the union: {cfg}") from e
+        dist = ThreadDist(world)
+        out, errs = [None] * world, []
+
+        def work(r):
+            try:
+                dist.set_rank(r)
+                cx = api.Context(0)
+                cx.anchor_sets_load(vc, jc)
+                p = cx.pool_load(pools[r].primary, pools[r].secondary, rl)
+                out[r] = shard.ShardedHotPath(cx, dist, torch.device("cuda", 0), stride=stride).kmer_build(p, c["k"], c["mf"], c["mq"])
+                p.free()
+                cx.close()
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+                dist.barrier.abort()
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, (cfg, errs)
+        for g in out:
+            assert (g.n, g.pre_nodes) == (ref.n, ref.pre_nodes), cfg
+            for f in ("first_inst", "freq", "gated_count", "has_v", "has_j", "to_ids", "from_ids", "kmers"):
+                assert np.array_equal(getattr(g, f), getattr(ref, f)), (cfg, f)
