@@ -174,3 +174,57 @@ def test_sharded_build_random_configurations_vs_single_gpu(ctx, seed, n):
             assert (g.n, g.pre_nodes) == (ref.n, ref.pre_nodes), cfg
             for f in ("first_inst", "freq", "gated_count", "has_v", "has_j", "to_ids", "from_ids", "kmers"):
                 assert np.array_equal(getattr(g, f), getattr(ref, f)), (cfg, f)
+
+
+REF_BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "vdjer_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/vdjer_ref (the reference's own sources, compiled by oracle/Makefile) is not built")
+@pytest.mark.parametrize("seed,n", [(401, 5)])
+def test_cli_end_to_end_random_pools_vs_the_compiled_reference(seed, n, tmp_path):
+    """The whole command line against THE REFERENCE ITSELF (oracle/_ref/vdjer_ref: its own sources compiled where they lie, exactly
+    how the goldens were made, tests/golden/make_golden.py) on pools drawn here: tiled clones (they pass the coverage test) or noisy
+    reads, k / mf / mq / mrs at random.  vdj_contigs.fa, the SAM on stdout and vdjer.dot byte for byte.  A run of the reference
+    counts when it scored every root (its root threads race otherwise, as in make_golden.py)."""
+    import re
+    import subprocess
+    from vdjer_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "vdjer_amd", "vdjer")
+    rng = np.random.default_rng(seed + _SEED)
+    with_contigs = 0
+    for it in range(n * _SCALE):
+        n_clones = int(rng.integers(2, 7))
+        rep = synth.make_repertoire(n_clones, seed=int(rng.integers(0, 1 << 30)))
+        if rng.random() < 0.5:
+            pool = synth.tile_reads(rep, list(range(int(rng.integers(1, n_clones + 1)))), copies=int(rng.integers(2, 5)))
+        else:
+            pool = synth.make_reads(rep, int(rng.integers(3000, 9000)), noise_frac=float(rng.choice([0.1, 0.3])), seed=int(rng.integers(0, 1 << 30)))
+        k = int(rng.choice([25, 31, 35]))
+        flags = ["--k", str(k), "--mf", str(int(rng.integers(2, 4))), "--mq", str(int(rng.choice([60, 90]))), "--mrs", str(int(rng.choice([20, 30])))]
+        cfg = dict(it=it, clones=n_clones, pairs=pool.n_pairs, flags=flags)
+        outs = {}
+        for who, binary in (("ref", [REF_BIN, "run"]), ("hip", [exe])):
+            d = tmp_path / f"{it}_{who}"
+            d.mkdir()
+            pool.write_reads_file(str(d / "reads.txt"))
+            synth.write_ref_dir(rep, str(d / "ref"))
+            cmd = binary + ["--in", "reads.txt", "--chain", "IGH", "--ref-dir", "ref", "--ins", "175", "--t", "1"] + flags
+            for attempt in range(8):
+                r = subprocess.run(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                err = r.stderr.decode(errors="replace")
+                if who == "hip":
+                    assert r.returncode == 0, (cfg, err[-2000:])
+                    break
+                m1, m2 = re.search(r"num root nodes: (\d+)", err), re.search(r"HARNESS_ROOTS_SCORED\t(\d+)", err)
+                if m1 and m2 and m1.group(1) == m2.group(1):
+                    break
+            else:
+                pytest.skip(f"the reference never scored all its roots: {cfg}")
+            outs[who] = ((d / "vdj_contigs.fa").read_bytes() if (d / "vdj_contigs.fa").exists() else b"", r.stdout,
+                         (d / "vdjer.dot").read_bytes() if (d / "vdjer.dot").exists() else b"")
+        assert outs["hip"][0] == outs["ref"][0], (cfg, "vdj_contigs.fa differs")
+        assert outs["hip"][1] == outs["ref"][1], (cfg, "SAM differs")
+        assert outs["hip"][2] == outs["ref"][2], (cfg, "vdjer.dot differs")
+        with_contigs += 1 if outs["ref"][0].count(b">") else 0
+    assert with_contigs >= 1          # at least one configuration assembled contigs
