@@ -195,21 +195,22 @@ def test_cli_end_to_end_random_pools_vs_the_compiled_reference(seed, n, tmp_path
     with_contigs = 0
     for it in range(n * _SCALE):
         n_clones = int(rng.integers(2, 7))
-        rep = synth.make_repertoire(n_clones, seed=int(rng.integers(0, 1 << 30)))
+        chain = str(rng.choice(["IGH", "IGH", "IGK", "IGL"]))
+        rep = synth.make_repertoire(n_clones, seed=int(rng.integers(0, 1 << 30)), chain=chain)
         if rng.random() < 0.5:
             pool = synth.tile_reads(rep, list(range(int(rng.integers(1, n_clones + 1)))), copies=int(rng.integers(2, 5)))
         else:
             pool = synth.make_reads(rep, int(rng.integers(3000, 9000)), noise_frac=float(rng.choice([0.1, 0.3])), seed=int(rng.integers(0, 1 << 30)))
         k = int(rng.choice([25, 31, 35]))
         flags = ["--k", str(k), "--mf", str(int(rng.integers(2, 4))), "--mq", str(int(rng.choice([60, 90]))), "--mrs", str(int(rng.choice([20, 30])))]
-        cfg = dict(it=it, clones=n_clones, pairs=pool.n_pairs, flags=flags)
+        cfg = dict(it=it, chain=chain, clones=n_clones, pairs=pool.n_pairs, flags=flags)
         outs = {}
         for who, binary in (("ref", [REF_BIN, "run"]), ("hip", [exe])):
             d = tmp_path / f"{it}_{who}"
             d.mkdir()
             pool.write_reads_file(str(d / "reads.txt"))
             synth.write_ref_dir(rep, str(d / "ref"))
-            cmd = binary + ["--in", "reads.txt", "--chain", "IGH", "--ref-dir", "ref", "--ins", "175", "--t", "1"] + flags
+            cmd = binary + ["--in", "reads.txt", "--chain", chain, "--ref-dir", "ref", "--ins", "175", "--t", "1"] + flags
             for attempt in range(8):
                 r = subprocess.run(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
                 err = r.stderr.decode(errors="replace")
