@@ -244,6 +244,22 @@ __device__ inline u32 vdjx_bits_at_lane(u64 bhi, u64 blo, u32 pos) {
 }
 __device__ inline u32 vdjx_base_at_lane(u64 bhi, u64 blo, int rl, int i) { return vdjx_bits_at_lane(bhi, blo, (u32) (2 * (rl - 1 - i))) & 3u; }
 
+// Is the 2k-bit k-mer (hi:lo) equal to itself d bases further on, i.e. K[i] == K[i+d] for all i < k-d (0 < d < k)?  Two gated
+// instances of one k-mer at offsets d apart in reads with identical sequences force that period on the k-mer, so a k-mer WITHOUT it
+// proves the two reads different (compare_read, A2:142-144) without fetching them.  d differs from lane to lane: masks and double
+// shifts only (see vdjx_kmer_at_lane).
+__device__ inline bool vdjx_kmer_has_period(u64 hi, u64 lo, int k, u32 d) {
+	const u32 sh = 2u * d;                                   // 2 .. 98
+	const u64 big = 0ull - (u64) (sh >> 6);
+	const u64 x_lo = (hi & big) | (lo & ~big), x_hi = hi & ~big;
+	const u32 s = sh & 63u;
+	const u64 s_lo = (x_lo >> s) | ((x_hi << 1) << (63u - s)), s_hi = x_hi >> s;
+	const u32 bits = 2u * ((u32) k - d);                      // 2 .. 98: the low bits that must agree
+	const u32 bl = bits < 64u ? bits : 64u, bh = bits > 64u ? bits - 64u : 0u;
+	const u64 m_lo = ~0ull >> (64u - bl), m_hi = (1ull << bh) - 1ull;
+	return (((s_lo ^ lo) & m_lo) | ((s_hi ^ hi) & m_hi)) == 0ull;
+}
+
 // wave-wide unsigned minimum through DPP row shifts and broadcasts (gfx9 family): no LDS traffic, unlike __shfl_xor
 // (ds_bpermute); every lane gets the result.  All 64 lanes must be active (the result is read from lane 63).
 __device__ inline u32 vdjx_wave_min(u32 v) {

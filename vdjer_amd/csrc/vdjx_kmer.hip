@@ -562,11 +562,19 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 						if (qi < RD_Q) { q_slot[qi] = (u32) slot; q_inst[qi] = inst; }
 					}
 					if (!(st & ST_MULTI)) {
-						const u64 rec = (inst >> 6) - rec_base, frec = (s_first[slot] >> 6) - rec_base;
+						const u64 fi = s_first[slot];
+						const u64 rec = (inst >> 6) - rec_base, frec = (fi >> 6) - rec_base;
 						if (rec != frec) {
-							const ulonglong2 x = ((const ulonglong2*) bases)[rec];
-							const ulonglong2 y = ((const ulonglong2*) bases)[frec];
-							if (x.x != y.x || x.y != y.y || nmask[rec] != nmask[frec]) atomicOr(&s_state[slot], ST_MULTI);
+							// two instances d offsets apart in identical reads would give the k-mer the period d: a k-mer without it settles
+							// the question without fetching the two records (most instances: a k-mer sits at a different offset in every read)
+							const u32 o1 = (u32) (inst & 63u), o0 = (u32) (fi & 63u);
+							const u32 d = o1 > o0 ? o1 - o0 : o0 - o1;
+							if (d && d < (u32) k && !vdjx_kmer_has_period(r_t[j].hi(), r_t[j].lo, k, d)) atomicOr(&s_state[slot], ST_MULTI);
+							else {
+								const ulonglong2 x = ((const ulonglong2*) bases)[rec];
+								const ulonglong2 y = ((const ulonglong2*) bases)[frec];
+								if (x.x != y.x || x.y != y.y || nmask[rec] != nmask[frec]) atomicOr(&s_state[slot], ST_MULTI);
+							}
 						}
 					}
 				}
@@ -697,7 +705,7 @@ struct Partial { u64 lo, hi; u32 cg, pad; u64 fg; };     // 32 bytes, what trave
 // "saw two different reads" against its own first record; k-mers whose count is below TLOW also list their instances
 template <typename TUP>
 __global__ __launch_bounds__(K3_THREADS) void k_gated_local(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
-                                                            const u64* __restrict__ bases, const u64* __restrict__ nmask, u64 rec_base,
+                                                            const u64* __restrict__ bases, const u64* __restrict__ nmask, u64 rec_base, int k,
                                                             u32 tlow, Partial* __restrict__ sparse_g, u32* __restrict__ sparse_ref,
                                                             u32* __restrict__ nd_g, u64* __restrict__ low_inst, u32* __restrict__ g_err) {
 	typedef typename TUP::hi_t THI;
@@ -771,11 +779,17 @@ __global__ __launch_bounds__(K3_THREADS) void k_gated_local(const TUP* __restric
 					const u64 inst = r_t[j].inst();
 					if (s_loff[slot] != NONE32) low_inst[base + s_loff[slot] + atomicAdd(&s_lfill[slot], 1u)] = inst;
 					if (s_cg[slot] < 2 || *(volatile u32*) &s_fl[slot]) continue;
-					const u64 rec = (inst >> 6) - rec_base, frec = (s_mg[slot] >> 6) - rec_base;
+					const u64 fi = s_mg[slot];
+					const u64 rec = (inst >> 6) - rec_base, frec = (fi >> 6) - rec_base;
 					if (rec != frec) {
-						const ulonglong2 x = ((const ulonglong2*) bases)[rec];
-						const ulonglong2 y = ((const ulonglong2*) bases)[frec];
-						if (x.x != y.x || x.y != y.y || nmask[rec] != nmask[frec]) s_fl[slot] = 1;
+						const u32 o1 = (u32) (inst & 63u), o0 = (u32) (fi & 63u);             // (see k_gated_reduce)
+						const u32 d = o1 > o0 ? o1 - o0 : o0 - o1;
+						if (d && d < (u32) k && !vdjx_kmer_has_period(r_t[j].hi(), r_t[j].lo, k, d)) s_fl[slot] = 1;
+						else {
+							const ulonglong2 x = ((const ulonglong2*) bases)[rec];
+							const ulonglong2 y = ((const ulonglong2*) bases)[frec];
+							if (x.x != y.x || x.y != y.y || nmask[rec] != nmask[frec]) s_fl[slot] = 1;
+						}
 					}
 				}
 			}
@@ -2577,7 +2591,7 @@ static int shard_local_impl(vdjx_shard* s) {
 	{
 		vdjx_prof_scope ps(c, "k_gated_local");
 		hipLaunchKernelGGL(k_gated_local<TUP>, dim3(t.NB), dim3(K3_THREADS), 0, st, t.t, t.bucket_start, s->pool->d_bases, s->pool->d_nmask, rec_base,
-		                   s->tlow, sparse, sparse_ref, s->nd, s->low_inst, g_err);
+		                   s->k, s->tlow, sparse, sparse_ref, s->nd, s->low_inst, g_err);
 	}
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, s->nd, t.NB, s->dstart);
 	u32* d_pick;
