@@ -303,6 +303,27 @@ __device__ inline void vdjx_lds_count_min(u32* cnt, u32* mn, u32 idx, u32 val, b
 	if (active) { atomicAdd(&cnt[idx], 1u); atomicMin(&mn[idx], val); }
 }
 
+// the same for a 64-bit minimum of values below 2^63 (instance ids).  The loop of the caller must be wave-uniform (ballots, DPP).
+__device__ inline void vdjx_lds_count_min64(u32* cnt, u64* mn, u32 idx, u64 val, bool active) {
+	const u64 act = __ballot(active);
+	if (act) {
+		const int leader = __ffsll((long long) act) - 1;
+		const u32 lidx = (u32) __builtin_amdgcn_readlane((int) idx, leader);
+		const bool same = active && idx == lidx;
+		const u64 m = __ballot(same);
+		if (__popcll(m) >= 8) {
+			const u32 hi_min = vdjx_wave_min(same ? (u32) (val >> 32) : 0xFFFFFFFFu);
+			const u32 lo_min = vdjx_wave_min(same && (u32) (val >> 32) == hi_min ? (u32) val : 0xFFFFFFFFu);
+			if (__lane_id() == leader) {
+				atomicAdd(&cnt[lidx], (u32) __popcll(m));
+				atomicMin((unsigned long long*) &mn[lidx], ((unsigned long long) hi_min << 32) | lo_min);
+			}
+			active = active && !same;
+		}
+	}
+	if (active) { atomicAdd(&cnt[idx], 1u); atomicMin((unsigned long long*) &mn[idx], (unsigned long long) val); }
+}
+
 __device__ inline u32 vdjx_wave_inc(u32* ctr, bool pred) {
 	// wave-aggregated counter increment (LDS or global); returns this lane's slot, undefined if !pred
 	const u64 m = __ballot(pred);

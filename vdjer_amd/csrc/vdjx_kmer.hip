@@ -510,16 +510,18 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 				}
 #pragma unroll
 				for (int j = 0; j < RD_UNR; j++) {
-					if (r_slot[j] == -2) continue;
-					const u64 h = vdjx_mix(r_t[j].lo, r_t[j].hi());
-					if (S > 1 && (u32) ((h >> 12) & (S - 1)) != s) continue;
-					const int slot = lds_insert<THI, RD_SLOTS>(s_klo, s_khi, r_t[j].lo, (THI) r_t[j].hi(), (u32) h);
-					if (slot < 0) { s_over = 1; continue; }
-					r_slot[j] = slot;
-					if (!verify) {
-						atomicAdd(&s_cnt[slot], 1u);
-						atomicMin((unsigned long long*) &s_first[slot], (unsigned long long) r_t[j].inst());
+					// (no lane leaves the body early: the count / first update folds the lanes of a wave that hit one slot -- a deep
+					// clone's k-mer holds most tuples of its bucket, and same-address LDS atomics go one at a time)
+					int slot = -1;
+					if (r_slot[j] != -2) {
+						const u64 h = vdjx_mix(r_t[j].lo, r_t[j].hi());
+						if (!(S > 1 && (u32) ((h >> 12) & (S - 1)) != s)) {
+							slot = lds_insert<THI, RD_SLOTS>(s_klo, s_khi, r_t[j].lo, (THI) r_t[j].hi(), (u32) h);
+							if (slot < 0) s_over = 1;
+							else r_slot[j] = slot;
+						}
 					}
+					vdjx_lds_count_min64(s_cnt, s_first, (u32) (slot < 0 ? 0 : slot), r_t[j].inst(), slot >= 0 && !verify);
 				}
 			}
 			__syncthreads();
@@ -740,14 +742,16 @@ __global__ __launch_bounds__(K3_THREADS) void k_gated_local(const TUP* __restric
 				}
 #pragma unroll
 				for (int j = 0; j < K3_UNR; j++) {
-					if (r_slot[j] == -2) continue;
-					const u64 h = vdjx_mix(r_t[j].lo, r_t[j].hi());
-					if (S > 1 && (u32) ((h >> 12) & (S - 1)) != s) continue;
-					const int slot = lds_insert<THI, LOCAL_SLOTS>(s_klo, s_khi, r_t[j].lo, (THI) r_t[j].hi(), (u32) h);
-					if (slot < 0) { s_over = 1; continue; }
-					r_slot[j] = slot;
-					atomicAdd(&s_cg[slot], 1u);
-					atomicMin((unsigned long long*) &s_mg[slot], (unsigned long long) r_t[j].inst());
+					int slot = -1;                                                // (see k_gated_reduce: nobody leaves early, same-slot lanes are folded)
+					if (r_slot[j] != -2) {
+						const u64 h = vdjx_mix(r_t[j].lo, r_t[j].hi());
+						if (!(S > 1 && (u32) ((h >> 12) & (S - 1)) != s)) {
+							slot = lds_insert<THI, LOCAL_SLOTS>(s_klo, s_khi, r_t[j].lo, (THI) r_t[j].hi(), (u32) h);
+							if (slot < 0) s_over = 1;
+							else r_slot[j] = slot;
+						}
+					}
+					vdjx_lds_count_min64(s_cg, s_mg, (u32) (slot < 0 ? 0 : slot), r_t[j].inst(), slot >= 0);
 				}
 			}
 			__syncthreads();
