@@ -178,3 +178,54 @@ def test_sharded_window_scorer_world2_gloo():
     assert sum(exp_valid) >= 1 and sum(exp_valid) < len(wins)
     for r in res:
         assert r[1] == exp_valid and r[2] == exp_np
+
+
+def _chunk_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from vdjer_amd import shard
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cm = shard.Comm(dist, torch.device("cpu"))
+        cm.native = True                      # the code path of the RCCL runs (P2P pieces, chunked reductions), on CPU tensors over gloo
+        cm.CHUNK_BYTES = 96                   # 3 rows of 32 bytes per transfer: many rounds, ragged tails, peers with different numbers of rounds
+        rng = np.random.default_rng(1234)
+        counts = rng.integers(0, 23, (world, world))          # counts[a][b]: rows a sends to b (the same matrix on every rank)
+        counts[0, world - 1] = 0                              # an empty pair
+        send = torch.cat([torch.full((int(counts[rank, b]), 4), 1000 * rank + b, dtype=torch.int64) +
+                          torch.arange(int(counts[rank, b]), dtype=torch.int64).view(-1, 1) * 7 for b in range(world)])
+        recv = torch.empty((int(counts[:, rank].sum()), 4), dtype=torch.int64)
+        cm.all_to_all_v(send, [int(v) for v in counts[rank]], recv, [int(v) for v in counts[:, rank]])
+        exp = torch.cat([torch.full((int(counts[a, rank]), 4), 1000 * a + rank, dtype=torch.int64) +
+                         torch.arange(int(counts[a, rank]), dtype=torch.int64).view(-1, 1) * 7 for a in range(world)])
+        ok = bool(torch.equal(recv, exp))
+        # chunked all_reduce (MIN on the sign-flipped ids, SUM) and all_gather over more rows than one transfer holds
+        x = torch.arange(100, dtype=torch.int64) * (rank + 1)
+        cm.all_reduce(x, dist.ReduceOp.SUM)
+        ok = ok and bool(torch.equal(x, torch.arange(100, dtype=torch.int64) * sum(range(1, world + 1))))
+        y = torch.arange(40, dtype=torch.int64).view(10, 4) + 100 * rank
+        g = cm.all_gather_cat(y)
+        ok = ok and bool(torch.equal(g, torch.cat([torch.arange(40, dtype=torch.int64).view(10, 4) + 100 * a for a in range(world)])))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_in_pieces_over_gloo(world):
+    """shard.Comm cuts every transfer into pieces of CHUNK_BYTES (RCCL delivered the second half of a 1.09 GB transfer wrongly):
+    the piecewise send/receive rounds, with uneven and empty pairs, and the piecewise reductions and gathers, on CPU tensors."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_chunk_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]
