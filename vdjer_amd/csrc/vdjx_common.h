@@ -121,6 +121,8 @@ struct vdjx_ctx {
 	void* me_dense = nullptr;         // the pairs laid end to end for the copy to the host (kept: the copy may be asynchronous)
 	size_t me_dense_cap = 0;
 	std::vector<u64> me_cnt;          // pairs per contig
+	void* h_plan = nullptr;           // page-locked scratch of plan_windows (hit counts down, order and offsets up: DMA, no staging copies)
+	size_t h_plan_cap = 0;
 	void* me_book = nullptr;          // device bookkeeping between the counting and the writing call (vdjx_score.hip map_emit_impl)
 	size_t me_book_cap = 0, me_nsl = 0;
 	u32 me_slice_hits = 0;

@@ -117,6 +117,7 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	(void) hipStreamDestroy(c->copy_stream);
 	if (c->pairs_stream) { (void) hipStreamSynchronize(c->pairs_stream); (void) hipStreamDestroy(c->pairs_stream); }
 	if (c->ev_gathered) (void) hipEventDestroy(c->ev_gathered);
+	if (c->h_plan) (void) hipHostFree(c->h_plan);
 	(void) hipStreamDestroy(c->stream);
 	delete c;
 }

@@ -1138,23 +1138,37 @@ static int plan_windows(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, cons
 		vdjx_prof_scope ps(c, "k_window_hits");
 		hipLaunchKernelGGL(k_window_hits, dim3((u32) std::min<size_t>(n, 4096)), dim3(MAP_THREADS), 0, st, ix, d_w, (u32) n, len, weighted, d_hits, d_inst);
 	}
-	std::vector<u32> hits(n), order(n), inst(n);
-	HIP_TRY(hipMemcpyAsync(hits.data(), d_hits, n * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(inst.data(), d_inst, n * 4, hipMemcpyDeviceToHost, st));
+	// hit counts down, order and offsets up through ONE page-locked scratch buffer (pageable vectors cost a staging copy each way)
+	const size_t need = n * 4 * 3 + (n + 1) * 8 + 64;
+	if (need > c->h_plan_cap) {
+		if (c->h_plan) (void) hipHostFree(c->h_plan);
+		c->h_plan = nullptr; c->h_plan_cap = 0;
+		HIP_TRY(hipHostMalloc(&c->h_plan, need + need / 2, hipHostMallocDefault));
+		c->h_plan_cap = need + need / 2;
+	}
+	u64* h_off = (u64*) c->h_plan;
+	u32* hits = (u32*) (h_off + n + 1);
+	u32* inst = hits + n;
+	u32* h_order = inst + n;
+	HIP_TRY(hipMemcpyAsync(hits, d_hits, n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(inst, d_inst, n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
 	lp.mark("plan_hits_wait");
-	if (inst_total) { *inst_total = 0; for (u32 v : inst) *inst_total += v; }
-	if (inst_max) { *inst_max = 0; for (u32 v : inst) *inst_max = std::max<u64>(*inst_max, v); }
+	if (inst_total) { *inst_total = 0; for (size_t i = 0; i < n; i++) *inst_total += inst[i]; }
+	if (inst_max) { *inst_max = 0; for (size_t i = 0; i < n; i++) *inst_max = std::max<u64>(*inst_max, inst[i]); }
 	off.assign(n + 1, 0);
 	for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + hits[i];
+	std::vector<u32> order;
 	order_by_size_desc(off, n, order);
 	if (order_out) *order_out = order;
+	memcpy(h_order, order.data(), n * 4);
+	memcpy(h_off, off.data(), (n + 1) * 8);
 	HIP_TRY(db.alloc(d_order, n));
 	HIP_TRY(db.alloc(d_off, n + 1));
-	HIP_TRY(hipMemcpyAsync(*d_order, order.data(), n * 4, hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(*d_off, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
-	HIP_TRY(hipStreamSynchronize(st));       // `order`/`off` staging buffers die with this frame
+	HIP_TRY(hipMemcpyAsync(*d_order, h_order, n * 4, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(*d_off, h_off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+	// (no wait: the scratch is rewritten by the next plan only, and every caller waits for the stream before it returns)
 	lp.mark("plan_order_upload");
 	return VDJX_OK;
 }
