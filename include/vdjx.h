@@ -151,6 +151,9 @@ int vdjx_root_score_graph(vdjx_ctx* ctx, const vdjx_graph* g, int threshold, uin
  * registration rank (order of the add_read_info calls).                                           */
 int vdjx_read_index_build(vdjx_ctx* ctx, const vdjx_pool* pool, const uint32_t* pair_id,
                           const uint8_t* read_num, const uint8_t* is_rc, const uint32_t* reg_rank, uint32_t n_pairs);
+/* the same with the four per-record arrays already in device memory (e.g. written there by the extraction side) */
+int vdjx_read_index_build_device(vdjx_ctx* ctx, const vdjx_pool* pool, const uint32_t* d_pair_id,
+                                 const uint8_t* d_read_num, const uint8_t* d_is_rc, const uint32_t* d_reg_rank, uint32_t n_pairs);
 
 typedef struct {
 	int eval_start;    /* --e0 */

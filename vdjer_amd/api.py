@@ -288,6 +288,11 @@ class Context:
         assert a.shape[0] == pool.n_records
         check(self.L.vdjx_read_index_build(self.h, pool.h, _p(a), _p(b), _p(c_), _p(d), n_pairs), "vdjx_read_index_build")
 
+    def read_index_build_device(self, pool: Pool, d_pair_id: int, d_read_num: int, d_is_rc: int, d_reg_rank: int, n_pairs: int) -> None:
+        """the per-record arrays as raw device pointers (uint32, uint8, uint8, uint32; one entry per pool record)"""
+        check(self.L.vdjx_read_index_build_device(self.h, pool.h, C.c_void_p(d_pair_id), C.c_void_p(d_read_num), C.c_void_p(d_is_rc),
+                                                  C.c_void_p(d_reg_rank), n_pairs), "vdjx_read_index_build_device")
+
     @staticmethod
     def pack_strings(strings):
         """(raw bytes, n, len) of equally long strings: pass it instead of the list to skip the per-call join/encode"""

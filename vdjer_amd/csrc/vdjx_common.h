@@ -17,6 +17,12 @@ typedef unsigned __int128 u128;
 
 #define VDJX_WAVE 64
 
+// flags of a read-index entry (csr_info / dinfo .w, vdjx_rindex.hip)
+#define RI_R1 1u        // the record is a read-1 instance
+#define RI_RC 2u        // its is_rc flag
+#define RI_RCA 4u       // is_rc of the pair's read-2 record A (registered first)
+#define RI_RCB 8u       // is_rc of the pair's read-2 record B (registered last)
+
 // ----------------------------------------------------------------------------------------------
 // error plumbing
 // ----------------------------------------------------------------------------------------------
@@ -100,11 +106,8 @@ struct vdjx_ctx {
 	u32 ri_nslots = 0;
 	u32* d_ri_rep = nullptr;          // class -> representative record
 	u32* d_ri_start = nullptr;        // class -> CSR start [ncls+1]
-	u32* d_ri_cnt1 = nullptr;         // class -> number of read-1 members (stored first)
-	u32* d_ri_recs = nullptr;         // CSR: records in registration order
-	u32* d_pair_id = nullptr;
-	uint8_t* d_read_num = nullptr;
-	uint8_t* d_is_rc = nullptr;
+	u32* d_ri_cnt1 = nullptr;         // class -> number of read-1 members (the CSR lists those only)
+	u32* d_ri_recs = nullptr;         // CSR: read-1 records in registration order
 	u32* d_pair_r2 = nullptr;         // pair -> its two read-2 records in registration order (or ~0u)
 	uint4* d_rec_info = nullptr;      // record -> {pair id, class of read-2 record A, class of B, flags}
 	u32* d_ri_dstart = nullptr;       // class -> first of its DISTINCT read-1 infos (window scoring counts, it does not name pairs)

@@ -1,7 +1,7 @@
 // vdjx_score.hip -- the batched scorers (SURVEY §8a rows a-7 ... a-10).
 //
 //   K7  k_seed_count / k_root_dp      root (V-region homology) scorer         seq_score.c:92-156
-//   K8  k_ri_insert + host CSR        read index                              quick_map3.c:126-149
+//   K8  (vdjx_rindex.hip)             read index                              quick_map3.c:126-149
 //       k_window_pairs / k_window_cover  read->window mapper + coverage test  quick_map3.c:188-266, coverage.c:10-130
 //   K10 k_map_emit                    mapped pairs of final contigs in order  quick_map3.c:152-181, 311-340
 //
@@ -342,184 +342,7 @@ extern "C" int vdjx_root_score_graph(vdjx_ctx* c, const vdjx_graph* g, int thres
 	return root_score_device(c, db, d_k, n, k, threshold, out);
 }
 
-// ==============================================================================================
-// a-8 read index
-// ==============================================================================================
-// Exact-match index: read sequence -> records.  Device part: open-addressing table whose slots name
-// a representative record (the key bytes live in the immutable packed pool, so claiming a slot is
-// one 32-bit CAS).  Records holding an 'N' are left out: contigs are ACGT-only and can never match them.
-__global__ void k_ri_insert(const u64* __restrict__ bases, const u64* __restrict__ nmask, u32 R,
-                            u32* __restrict__ slots, u32 mask, u32* __restrict__ rec_slot) {
-	u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= R) return;
-	if (nmask[r]) { rec_slot[r] = NONE32; return; }
-	const ulonglong2 b = ((const ulonglong2*) bases)[r];
-	u32 slot = (u32) (vdjx_mix(b.y, b.x) >> 17) & mask;
-	for (;;) {
-		u32 cur = slots[slot];
-		if (cur == 0) {
-			cur = atomicCAS(&slots[slot], 0u, r + 1);
-			if (cur == 0) break;
-		}
-		const ulonglong2 o = ((const ulonglong2*) bases)[cur - 1];
-		if (o.x == b.x && o.y == b.y) break;
-		slot = (slot + 1) & mask;
-	}
-	rec_slot[r] = slot;
-}
-
-#define RI_R1 1u        // rec_info.w: the record is a read-1 instance
-#define RI_RC 2u        //             its is_rc flag
-#define RI_RCA 4u       //             is_rc of the pair's read-2 record A (registered first)
-#define RI_RCB 8u       //             is_rc of the pair's read-2 record B (registered last)
-
-extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const uint32_t* pair_id,
-                                     const uint8_t* read_num, const uint8_t* is_rc, const uint32_t* reg_rank, uint32_t n_pairs) {
-	if (!c || !pool || !pair_id || !read_num || !is_rc || !reg_rank) { vdjx_set_error("vdjx_read_index_build: NULL argument"); return VDJX_EINVAL; }
-	if (pool->ctx != c) { vdjx_set_error("vdjx_read_index_build: pool belongs to another context"); return VDJX_EINVAL; }
-	HIP_TRY(hipSetDevice(c->device));
-	vdjx_clear_errors();
-	hipStream_t st = c->stream;
-	const u32 R = (u32) pool->n_records;
-	free_set(c->d_ri_slots); free_set(c->d_ri_rep); free_set(c->d_ri_start); free_set(c->d_ri_recs);
-	free_set(c->d_pair_id); free_set(c->d_read_num); free_set(c->d_is_rc); free_set(c->d_pair_r2); free_set(c->d_rec_info);
-	c->ri_pool = nullptr;
-	c->me_key = 0;
-	for (u32 r = 0; r < R; r++) {
-		if (pair_id[r] >= n_pairs) { vdjx_set_error("pair_id[%u]=%u >= n_pairs=%u", r, pair_id[r], n_pairs); return VDJX_EINVAL; }
-	}
-	u32 mask = 1023;
-	while ((size_t) mask + 1 < (size_t) R * 2) mask = mask * 2 + 1;
-	vdjx_work db(c);
-	u32* d_rec_slot;
-	HIP_TRY(hipMalloc(&c->d_ri_slots, ((size_t) mask + 1) * 4));
-	HIP_TRY(db.alloc(&d_rec_slot, R));
-	HIP_TRY(hipMemsetAsync(c->d_ri_slots, 0, ((size_t) mask + 1) * 4, st));
-	if (R) {
-		vdjx_prof_scope ps(c, "k_ri_insert");
-		hipLaunchKernelGGL(k_ri_insert, dim3((R + 255) / 256), dim3(256), 0, st, pool->d_bases, pool->d_nmask, R, c->d_ri_slots, mask, d_rec_slot);
-	}
-	std::vector<u32> rec_slot(R);
-	HIP_TRY(hipMemcpyAsync(rec_slot.data(), d_rec_slot, (size_t) R * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
-	HIP_TRY(hipGetLastError());
-	// host: classes in first-registration order, members in registration order (add_read_info, quick_map3.c:126-149)
-	std::vector<u32> order(R);
-	std::iota(order.begin(), order.end(), 0u);
-	std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return reg_rank[a] < reg_rank[b]; });
-	std::vector<u32> slot_cls((size_t) mask + 1, NONE32), cls_cnt, rep;
-	std::vector<u32> rec_cls(R, NONE32);
-	for (u32 i = 0; i < R; i++) {
-		const u32 r = order[i];
-		const u32 s = rec_slot[r];
-		if (s == NONE32) continue;
-		if (slot_cls[s] == NONE32) { slot_cls[s] = (u32) cls_cnt.size(); cls_cnt.push_back(0); rep.push_back(r); }
-		rec_cls[r] = slot_cls[s];
-		cls_cnt[slot_cls[s]]++;
-	}
-	const u32 ncls = (u32) cls_cnt.size();
-	std::vector<u32> start(ncls + 1, 0), recs;
-	for (u32 i = 0; i < ncls; i++) start[i + 1] = start[i] + cls_cnt[i];
-	recs.resize(start[ncls] ? start[ncls] : 1);
-	// members of a class: read-1 instances first, each group in registration order.  Only read-1 instances are
-	// enumerated as hits (quick_map3.c:211-215: read-2 instances only feed the read2 map, which the class -> last
-	// offset table replaces), so a class's hit count is its read-1 count.
-	std::vector<u32> cnt1(ncls + 1, 0);
-	for (u32 r = 0; r < R; r++) if (rec_cls[r] != NONE32 && read_num[r] == 1) cnt1[rec_cls[r]]++;
-	std::vector<u32> fill1(start.begin(), start.end() - 1), fill2(ncls);
-	for (u32 i = 0; i < ncls; i++) fill2[i] = start[i] + cnt1[i];
-	for (u32 i = 0; i < R; i++) {
-		const u32 r = order[i];
-		if (rec_cls[r] == NONE32) continue;
-		if (read_num[r] == 1) recs[fill1[rec_cls[r]]++] = r; else recs[fill2[rec_cls[r]]++] = r;
-	}
-	std::vector<u32> slots((size_t) mask + 1, 0);
-	for (size_t s = 0; s <= mask; s++) if (slot_cls[s] != NONE32) slots[s] = slot_cls[s] + 1;
-	// read-2 records of every pair in registration order (at most two: as-is and reverse complement, bam_read.c:206-244)
-	std::vector<u32> pr2((size_t) n_pairs * 2 + 2, NONE32);
-	for (u32 i = 0; i < R; i++) {
-		const u32 r = order[i];
-		if (read_num[r] == 1) continue;
-		const u32 p = pair_id[r];
-		if (pr2[2 * (size_t) p] == NONE32) pr2[2 * (size_t) p] = r;
-		else if (pr2[2 * (size_t) p + 1] == NONE32) pr2[2 * (size_t) p + 1] = r;
-		else { vdjx_set_error("pair %u has more than two read-2 records (read names must be unique per pair)", p); return VDJX_EINVAL; }
-	}
-	// per record: everything a hit needs in one 16-byte load
-	std::vector<uint4> info(R ? R : 1);
-	for (u32 r = 0; r < R; r++) {
-		const u32 p = pair_id[r];
-		const u32 ra = pr2[2 * (size_t) p], rb = pr2[2 * (size_t) p + 1];
-		uint4 v;
-		v.x = p;
-		v.y = ra != NONE32 ? rec_cls[ra] : NONE32;
-		v.z = rb != NONE32 ? rec_cls[rb] : NONE32;
-		v.w = (read_num[r] == 1 ? RI_R1 : 0u) | (is_rc[r] ? RI_RC : 0u) | (ra != NONE32 && is_rc[ra] ? RI_RCA : 0u) |
-		      (rb != NONE32 && is_rc[rb] ? RI_RCB : 0u);
-		info[r] = v;
-	}
-	free_set(c->d_ri_cnt1);
-	HIP_TRY(hipMalloc(&c->d_ri_cnt1, ((size_t) ncls + 1) * 4));
-	HIP_TRY(hipMemcpy(c->d_ri_cnt1, cnt1.data(), ((size_t) ncls + 1) * 4, hipMemcpyHostToDevice));
-	HIP_TRY(hipMalloc(&c->d_ri_rep, ((size_t) ncls + 1) * 4));
-	HIP_TRY(hipMalloc(&c->d_ri_start, ((size_t) ncls + 1) * 4));
-	HIP_TRY(hipMalloc(&c->d_ri_recs, recs.size() * 4));
-	HIP_TRY(hipMalloc(&c->d_pair_id, ((size_t) R + 1) * 4));
-	HIP_TRY(hipMalloc(&c->d_read_num, (size_t) R + 1));
-	HIP_TRY(hipMalloc(&c->d_is_rc, (size_t) R + 1));
-	HIP_TRY(hipMalloc(&c->d_pair_r2, pr2.size() * 4));
-	std::vector<uint4> csr_info(recs.size());
-	for (size_t i = 0; i < (size_t) start[ncls]; i++) csr_info[i] = info[recs[i]];
-	HIP_TRY(hipMalloc(&c->d_rec_info, csr_info.size() * sizeof(uint4)));
-	// window scoring only counts mapped pairs per (pos1, pos2): read-1 members of a class whose mates fall into the same two
-	// classes with the same orientation flags behave identically there, so they are folded into one weighted entry (deep clones
-	// hold thousands of identical read pairs; the SAM emission still walks the individual members)
-	std::vector<u32> dstart(ncls + 1, 0);
-	std::vector<uint4> dinfo;
-	dinfo.reserve(csr_info.size() / 2 + 1);
-	{
-		std::vector<uint4> tmp;
-		for (u32 i = 0; i < ncls; i++) {
-			tmp.assign(csr_info.begin() + start[i], csr_info.begin() + start[i] + cnt1[i]);
-			std::sort(tmp.begin(), tmp.end(), [](const uint4& a, const uint4& b) {
-				if (a.y != b.y) return a.y < b.y;
-				if (a.z != b.z) return a.z < b.z;
-				return a.w < b.w;
-			});
-			for (size_t j = 0; j < tmp.size();) {
-				size_t e = j + 1;
-				while (e < tmp.size() && tmp[e].y == tmp[j].y && tmp[e].z == tmp[j].z && tmp[e].w == tmp[j].w) e++;
-				dinfo.push_back(make_uint4((u32) (e - j), tmp[j].y, tmp[j].z, tmp[j].w));
-				j = e;
-			}
-			dstart[i + 1] = (u32) dinfo.size();
-		}
-	}
-	if (dinfo.empty()) dinfo.push_back(make_uint4(0, 0, 0, 0));
-	free_set(c->d_ri_dstart); free_set(c->d_ri_dinfo);
-	HIP_TRY(hipMalloc(&c->d_ri_dstart, dstart.size() * 4));
-	HIP_TRY(hipMalloc(&c->d_ri_dinfo, dinfo.size() * sizeof(uint4)));
-	HIP_TRY(hipMemcpy(c->d_ri_dstart, dstart.data(), dstart.size() * 4, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(c->d_ri_dinfo, dinfo.data(), dinfo.size() * sizeof(uint4), hipMemcpyHostToDevice));
-	c->stats["read_index_r1_members"] = (u64) std::accumulate(cnt1.begin(), cnt1.end(), (u64) 0);
-	c->stats["read_index_r1_distinct"] = dstart[ncls];
-	HIP_TRY(hipMemcpy(c->d_ri_slots, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
-	if (ncls) HIP_TRY(hipMemcpy(c->d_ri_rep, rep.data(), (size_t) ncls * 4, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(c->d_ri_start, start.data(), start.size() * 4, hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(c->d_ri_recs, recs.data(), recs.size() * 4, hipMemcpyHostToDevice));
-	if (R) {
-		HIP_TRY(hipMemcpy(c->d_pair_id, pair_id, (size_t) R * 4, hipMemcpyHostToDevice));
-		HIP_TRY(hipMemcpy(c->d_read_num, read_num, R, hipMemcpyHostToDevice));
-		HIP_TRY(hipMemcpy(c->d_is_rc, is_rc, R, hipMemcpyHostToDevice));
-	}
-	HIP_TRY(hipMemcpy(c->d_rec_info, csr_info.data(), csr_info.size() * sizeof(uint4), hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(c->d_pair_r2, pr2.data(), pr2.size() * 4, hipMemcpyHostToDevice));
-	c->ri_nslots = mask + 1;
-	c->n_pairs = n_pairs;
-	c->n_classes = ncls;
-	c->ri_pool = pool;
-	return VDJX_OK;
-}
+// (a-8 read index: vdjx_rindex.hip)
 
 // ==============================================================================================
 // a-8/a-9/a-10 mapper core shared by k_window_hits, k_window_pairs and k_map_emit
