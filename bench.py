@@ -426,7 +426,8 @@ def main():
             t = lap("gather_results", t)
         state.update(nodes=g.n, pre=g.pre_nodes, roots=int(g.n_roots), roots_ok=int(ok.sum()), windows=len(wins),
                      valid=int(valid.sum()), contigs=n_contigs if world == 1 else None, mapped_this_rank=int(pairs.shape[0]),
-                     window_pairs_this_rank=int(npairs.sum()), n_contigs_rank=n_contigs, graph=g)
+                     window_pairs_this_rank=int(npairs.sum()), n_contigs_rank=n_contigs, graph=g,
+                     last=dict(root_ids=root_ids, ok=ok, valid=valid, npairs=npairs, offs=offs, pairs=pairs))
         p.free()
 
     def barrier():
@@ -456,6 +457,42 @@ def main():
     gc.enable()
     prof = ctx.profile_get()
     ctx.profile(False)
+    # ---- parity gate inside the benchmark.  (1) What the LAST TIMED STEP produced -- graph, root verdicts, every
+    # window's verdict and pair count, the mapped-pair stream -- against the oracle's digests of this very workload
+    # (tests/golden/fullsize_digests.json, made by tests/golden/make_fullsize_digests.py on the same counter-based pool), when the
+    # flags name that workload; (2) a small sample of the same generator re-checked against the oracle itself.
+    timed_check = None
+    dg_path = os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")
+    if rank == 0 and world == 1 and not args.force_shard and os.path.exists(dg_path):
+        import hashlib
+        dg = json.load(open(dg_path))
+        case = {(35, 3, 90, 30): "k35", (25, 2, 60, 20): "k25", (35, 3, 60, 30): "k35_mq60"}.get((args.k, args.mf, args.mq, args.mrs))
+        if (dg["n_pairs"], dg["n_clones"], dg["seed"]) == (args.pairs, args.clones, args.seed) and case in dg["cases"]:
+            def sha(a):
+                return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+            d, g, last = dg["cases"][case], state["graph"], state["last"]
+            bad = []
+            if (g.pre_nodes, g.n) != (d["pre_nodes"], d["nodes"]):
+                bad.append("node counts")
+            for f in ("first_inst", "freq", "has_v", "has_j", "to_ids", "from_ids"):
+                if sha(getattr(g, f)) != d[f]:
+                    bad.append("graph." + f)
+            if sha(last["root_ids"].astype(np.uint32)) != d["root_ids"] or sha(last["ok"].astype(np.uint8)) != d["root_verdicts"]:
+                bad.append("root verdicts")
+            checked = ["graph", "roots"]
+            bs = dg.get("bench_scorers")
+            if bs and args.windows == "generator" and args.ins == bs["ins"] and len(wins) == bs["n_windows"]:
+                if sha(last["valid"].astype(np.uint8)) != bs["valid"] or sha(last["npairs"].astype(np.uint32)) != bs["npairs"]:
+                    bad.append("window verdicts / pair counts")
+                per_contig = np.diff(last["offs"].astype(np.uint64))
+                if int(last["pairs"].shape[0]) != bs["pairs_total"] or sha(per_contig.astype(np.uint64)) != bs["pairs_per_contig"]:
+                    bad.append("mapped pairs per contig")
+                if sha(last["pairs"]) != bs["pairs"]:
+                    bad.append("mapped-pair stream")
+                checked += ["windows(all)", "mapped pairs(all)"]
+            timed_check = {"case": case, "checked": checked, "ok": not bad, "differs": bad}
+            if bad:
+                raise SystemExit(f"parity gate failed: the timed step's {bad} differ from the oracle digests")
     # ---- the same step fed from the HOST (never `value`): the reads as extracted (one 101-byte record per read; the reverse
     # complement records are derived on the chip) in page-locked memory, uploaded in chunks beside the packing
     e2e = None
@@ -500,7 +537,8 @@ def main():
         cm.all_reduce(tt, dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- parity gate inside the benchmark: a sample of the same generator re-checked against the oracle
+    # ---- parity gate, part 2 (part 1, the timed step's own outputs, ran right after the timed loop): a small sample of the same
+    # generator re-checked against the oracle itself
     parity = None
     if rank == 0 and args.parity_sample > 0 and world == 1:
         from oracle import oracle
@@ -590,10 +628,10 @@ def main():
         "shard_wall_ms_per_step": ({k_: round(v / args.steps * 1e3, 3) for k_, v in engine.laps.items()} if engine else None),
         "wall_ms_per_step": {k_: round(v / args.steps * 1e3, 3) for k_, v in wall.items()},
         "host_side": host_side,
-        "counts": {k_: v for k_, v in state.items() if k_ != "graph"}, "scorer_stats": stats, **({"host_laps_us_per_step": laps} if laps else {}),
+        "counts": {k_: v for k_, v in state.items() if k_ not in ("graph", "last")}, "scorer_stats": stats, **({"host_laps_us_per_step": laps} if laps else {}),
         "shard_stats_rank0": ({n_: ctx.stat("shard_" + n_) for n_ in ("partials_received", "open_kmers", "questions", "decided_at_merge",
                                                                     "kept_after_answers")} if engine else None),
-        "parity_gate": parity,
+        "parity_gate": parity, "parity_gate_timed_step": timed_check,
     }
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(out) + "\n").encode())

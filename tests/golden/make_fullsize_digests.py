@@ -47,6 +47,52 @@ def _score_window(w):
     return int(_IX.coverage_is_valid(starts, len(w), 175)), len(pairs)
 
 
+def _score_and_map(w):
+    """bench.py's scorer workload for one generator window: verdict, mapped pairs, and -- for an accepted window -- the mapped
+    pairs of its [51,411) slice in the reference's output order (quick_map3.c:152-181), as the bytes of the vdjx_pair array"""
+    pairs, starts = _IX.quick_map(w)
+    v = int(_IX.coverage_is_valid(starts, len(w), 175))
+    cp = _IX.quick_map(w[51:411])[0].tobytes() if v else None
+    return v, len(pairs), cp
+
+
+def scorers_all(args):
+    """--scorers-all: every generator window of the bench workload (one per clone) and the mapped-pair stream of the accepted
+    ones -> "bench_scorers" of the existing digest file.  ~15 min on 8 cores."""
+    global _IX
+    from oracle import oracle
+    from vdjer_amd import synth
+    out = json.load(open(args.out))
+    assert (out["n_pairs"], out["n_clones"], out["seed"]) == (N_PAIRS, N_CLONES, SEED)
+    t0 = time.time()
+    rep = synth.make_repertoire(N_CLONES, seed=SEED)
+    pool = synth.make_reads_cb(rep, N_PAIRS, noise_frac=0.3, seed=SEED)
+    assert sha(pool.primary[:100000]) == out["pool"]["primary_head_sha"]
+    wins = [w for w in rep.windows() if w]
+    _IX = oracle.ReadIndex(pool)
+    print(f"pool + read index ({time.time() - t0:.0f}s), {len(wins)} windows", flush=True)
+    h = hashlib.sha256()
+    valid, npairs, per_contig = [], [], []
+    with mp.get_context("fork").Pool(8) as pl:
+        for i, (v, n, cp) in enumerate(pl.imap(_score_and_map, wins, chunksize=8)):
+            valid.append(v)
+            npairs.append(n)
+            if v:
+                h.update(cp)
+                per_contig.append(len(cp) // oracle.PAIR_DTYPE.itemsize)
+            if i % 2000 == 0:
+                print(f"  window {i} ({time.time() - t0:.0f}s)", flush=True)
+    valid, npairs, per_contig = np.array(valid, np.uint8), np.array(npairs, np.uint32), np.array(per_contig, np.uint64)
+    out["bench_scorers"] = {"n_windows": len(wins), "ins": 175, "valid": sha(valid), "npairs": sha(npairs), "n_valid": int(valid.sum()),
+                            "npairs_sum": int(npairs.astype(np.int64).sum()), "contigs": int(valid.sum()),
+                            "contig_rule": "the [51,411) slice of every accepted window, in window order",
+                            "pairs_total": int(per_contig.sum()), "pairs_per_contig": sha(per_contig), "pairs": h.hexdigest()}
+    print(out["bench_scorers"], f"({time.time() - t0:.0f}s)", flush=True)
+    with open(args.out, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+        f.write("\n")
+
+
 def main():
     global _IX, N_PAIRS, N_CLONES
     import argparse
@@ -55,8 +101,11 @@ def main():
     ap.add_argument("--clones", type=int, default=N_CLONES)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "fullsize_digests.json"))
     ap.add_argument("--only", default="", help="comma-separated case names to (re)compute and merge into the existing file; no window pass")
+    ap.add_argument("--scorers-all", action="store_true", help="only (re)compute bench_scorers: all windows + the mapped-pair stream")
     args = ap.parse_args()
     N_PAIRS, N_CLONES = args.pairs, args.clones
+    if args.scorers_all:
+        return scorers_all(args)
     from oracle import oracle
     from vdjer_amd import synth
     out = {"seed": SEED, "n_pairs": N_PAIRS, "n_clones": N_CLONES, "noise": 0.3, "generator": "synth.make_reads_cb",

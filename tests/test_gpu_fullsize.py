@@ -157,6 +157,46 @@ def test_config2_10M_pairs_window_scorer_vs_oracle_digests():
     assert sha(valid.astype(np.uint8)) == dg["windows"]["valid"]
 
 
+_PROD_SCORER_CASE = r'''
+import hashlib, json, os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from vdjer_amd import api, synth
+assert "VDJX_HIT_CHUNK" not in os.environ and "VDJX_MAP_SLICE" not in os.environ
+dg = json.load(open(os.path.join(%r, "tests", "golden", "fullsize_digests.json")))
+bs = dg["bench_scorers"]
+sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+rep = synth.make_repertoire(dg["n_clones"], seed=dg["seed"])
+pool = synth.make_reads_cb(rep, dg["n_pairs"], noise_frac=dg["noise"], seed=dg["seed"], device="cuda:0")
+ctx = api.Context(0)
+p = ctx.pool_load_device(pool.primary.data_ptr(), pool.primary.shape[0], pool.secondary.data_ptr(), pool.secondary.shape[0], pool.rl)
+ctx.read_index_build(p, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+wins = [w for w in rep.windows() if w]
+assert len(wins) == bs["n_windows"]
+valid, npairs = ctx.window_score(wins, bs["ins"])
+assert ctx.stat("window_work_items") > len(wins), "no window was cut into slices: the production split was not exercised"
+assert (int(valid.sum()), int(npairs.astype(np.int64).sum())) == (bs["n_valid"], bs["npairs_sum"])
+assert sha(valid.astype(np.uint8)) == bs["valid"] and sha(npairs.astype(np.uint32)) == bs["npairs"]
+contigs = [w[51:411] for w, v in zip(wins, valid) if v]
+offs, pairs = ctx.map_emit(contigs)
+assert int(pairs.shape[0]) == bs["pairs_total"] and sha(np.diff(offs.astype(np.uint64)).astype(np.uint64)) == bs["pairs_per_contig"]
+assert sha(pairs) == bs["pairs"], "mapped-pair stream differs from the oracle"
+print("PROD_SCORER_OK", len(wins), int(valid.sum()), int(pairs.shape[0]))
+'''
+
+
+def test_config2_10M_pairs_scorers_production_slicing_vs_oracle_digests():
+    """The scorers exactly as bench.py times them -- shipped VDJX_HIT_CHUNK / slice sizes (the suite otherwise runs with 128-hit
+    pieces, tests/conftest.py), all 20,000 generator windows, the mapped pairs of the 3,846 accepted ones -- against the oracle's
+    digests (`bench_scorers`, tests/golden/make_fullsize_digests.py --scorers-all).  Fresh process: the knobs are read once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k_: v for k_, v in os.environ.items() if k_ not in ("VDJX_HIT_CHUNK", "VDJX_MAP_SLICE")}
+    r = subprocess.run([sys.executable, "-c", _PROD_SCORER_CASE % (root, root)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert r.returncode == 0 and "PROD_SCORER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
 def test_40M_pairs_one_gpu_beyond_2_31_instances():
     """One GPU, 40 M pairs (160 M records, 2.56 G k-mer instances: past the 2^31 the round-1 instance ids could hold; BASELINE
     configs[4] gives every GPU 12.5 M pairs of a 100 M-pair pool): the 10 M-pair pool four times over.  With mf raised four-fold

@@ -459,6 +459,27 @@ __global__ __launch_bounds__(512) void k_seg_hist_g(const TUP* __restrict__ in, 
 
 struct SurvOutG { u64* lo; u64* hi; u32* gcnt; u64* gfirst; u32* n; u32 cap; };
 
+// one gated instance's k qualities added to its k-mer's row of packed u16 sums (A2:337-339, 354-361): the qualities from position
+// qoff of the record's row on (qoff = 0 for the first instance: the RECORD's first k qualities, the load-bearing bug)
+__device__ inline void rd_add_qualities(u32* row, const uint8_t* __restrict__ qrow, int qstride, u32 qoff, int k) {
+	const uint4* qv = (const uint4*) qrow;
+	u32 w[16];
+#pragma unroll
+	for (int v4 = 0; v4 < 4; v4++) {
+		uint4 x = make_uint4(0x21212121u, 0x21212121u, 0x21212121u, 0x21212121u);
+		if (v4 * 16 < qstride) x = qv[v4];
+		w[v4 * 4 + 0] = x.x; w[v4 * 4 + 1] = x.y; w[v4 * 4 + 2] = x.z; w[v4 * 4 + 3] = x.w;
+	}
+#pragma unroll
+	for (int pq = 0; pq < 64; pq++) {
+		const int j = pq - (int) qoff;
+		if (j >= 0 && j < k) {
+			const u32 v = (uint8_t) (((w[pq >> 2] >> (8 * (pq & 3))) & 0xFFu) - 33u);
+			atomicAdd(&row[j >> 1], v << (16 * (j & 1)));
+		}
+	}
+}
+
 template <typename TUP>
 __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
                                                              const u64* __restrict__ bases, const u64* __restrict__ nmask,
@@ -537,7 +558,18 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 				}
 			}
 			__syncthreads();
-			// ---- sweep 2
+			// the low-count candidates' quality rows fit one round (nearly always): every instance adds its qualities where the
+			// sweep meets it, no list and no second pass
+			const u32 nlow = s_nlow;
+			const bool direct = nlow <= RD_A;
+			if (direct) for (u32 i = tid; i < nlow * K3B_KW; i += RD_THREADS) acc[i] = 0;
+			__syncthreads();
+			// ---- sweep 2, per chunk: (a) what settles without a fetch -- a k-mer that sits at two different offsets of two reads and
+			// lacks the period of that distance proves the reads different (compare_read, A2:142-144, 349-352) -- and the quality rows;
+			// (b) after a barrier, only for k-mers that are still open: this instance's record against the first instance's (two
+			// 16-byte gathers).  Deep clones hold hundreds of instances per k-mer, many at the first instance's own offset
+			// (duplicate reads): asked one by one in a single pass they all fetched, although a neighbour's instance at another
+			// offset settles the k-mer for free.
 			for (u32 t0 = 0; t0 < n; t0 += RD_UNR * RD_THREADS) {
 #pragma unroll
 				for (int j = 0; j < RD_UNR; j++) {
@@ -552,6 +584,7 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 						}
 					}
 				}
+				u32 pend = 0;
 #pragma unroll
 				for (int j = 0; j < RD_UNR; j++) {
 					const int slot = r_slot[j];
@@ -559,34 +592,43 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 					const u32 st = *(volatile u32*) &s_state[slot];
 					if (!(st & ST_CAND)) continue;
 					const u64 inst = r_t[j].inst();
-					if (s_lowid[slot] != NONE16) {
-						const u32 qi = atomicAdd(&s_nq, 1u);
-						if (qi < RD_Q) { q_slot[qi] = (u32) slot; q_inst[qi] = inst; }
-					}
-					if (!(st & ST_MULTI)) {
-						const u64 fi = s_first[slot];
-						const u64 rec = (inst >> 6) - rec_base, frec = (fi >> 6) - rec_base;
-						if (rec != frec) {
-							// two instances d offsets apart in identical reads would give the k-mer the period d: a k-mer without it settles
-							// the question without fetching the two records (most instances: a k-mer sits at a different offset in every read)
-							const u32 o1 = (u32) (inst & 63u), o0 = (u32) (fi & 63u);
-							const u32 d = o1 > o0 ? o1 - o0 : o0 - o1;
-							if (d && d < (u32) k && !vdjx_kmer_has_period(r_t[j].hi(), r_t[j].lo, k, d)) atomicOr(&s_state[slot], ST_MULTI);
-							else {
-								const ulonglong2 x = ((const ulonglong2*) bases)[rec];
-								const ulonglong2 y = ((const ulonglong2*) bases)[frec];
-								if (x.x != y.x || x.y != y.y || nmask[rec] != nmask[frec]) atomicOr(&s_state[slot], ST_MULTI);
-							}
+					const u64 fi = s_first[slot];
+					const u32 lid = s_lowid[slot];
+					if (lid != NONE16) {
+						if (direct) {
+							const u64 rec = (inst >> 6) - rec_base;
+							rd_add_qualities(acc + lid * K3B_KW, quals + (size_t) rec * (size_t) qstride, qstride, inst == fi ? 0u : (u32) (inst & 63u), k);
+						} else {
+							const u32 qi = atomicAdd(&s_nq, 1u);
+							if (qi < RD_Q) { q_slot[qi] = (u32) slot; q_inst[qi] = inst; }
 						}
 					}
+					if (!(st & ST_MULTI) && (inst >> 6) != (fi >> 6)) {
+						const u32 o1 = (u32) (inst & 63u), o0 = (u32) (fi & 63u);
+						const u32 d = o1 > o0 ? o1 - o0 : o0 - o1;
+						if (d && d < (u32) k && !vdjx_kmer_has_period(r_t[j].hi(), r_t[j].lo, k, d)) atomicOr(&s_state[slot], ST_MULTI);
+						else pend |= 1u << j;
+					}
 				}
+				__syncthreads();
+#pragma unroll
+				for (int j = 0; j < RD_UNR; j++) {
+					if (!((pend >> j) & 1u)) continue;
+					const int slot = r_slot[j];
+					if (*(volatile u32*) &s_state[slot] & ST_MULTI) continue;
+					const u64 rec = (r_t[j].inst() >> 6) - rec_base, frec = (s_first[slot] >> 6) - rec_base;
+					const ulonglong2 x = ((const ulonglong2*) bases)[rec];
+					const ulonglong2 y = ((const ulonglong2*) bases)[frec];
+					if (x.x != y.x || x.y != y.y || nmask[rec] != nmask[frec]) atomicOr(&s_state[slot], ST_MULTI);
+				}
+				if (!one_chunk) __syncthreads();             // (the next chunk reuses the registers only; the barrier keeps the chunks' phases apart)
 			}
 			__syncthreads();
 			// ---- quality sums of the low-count candidates: first instance = the RECORD's first k qualities (A2:337-339), the
 			// others their own (A2:354-361); a sum >= 214 reads as 255 (A2:356-360): the test is sum >= min(mq, 214)
-			const u32 nlow = s_nlow;
 			const bool listed = s_nq <= RD_Q;
 			for (u32 l0 = 0; l0 < nlow; l0 += RD_A) {
+				if (!direct) {
 				for (u32 i = tid; i < RD_A * K3B_KW; i += RD_THREADS) acc[i] = 0;
 				__syncthreads();
 				const u32 nscan = listed ? s_nq : n;
@@ -605,27 +647,10 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 					const u32 lid = s_lowid[slot];
 					if (lid == NONE16 || lid < l0 || lid >= l0 + RD_A) continue;
 					const u64 rec = (inst >> 6) - rec_base;
-					const u32 off = (u32) (inst & 63u);
-					const u32 qoff = inst == s_first[slot] ? 0u : off;
-					const uint4* qv = (const uint4*) (quals + (size_t) rec * (size_t) qstride);
-					u32 w[16];
-#pragma unroll
-					for (int v4 = 0; v4 < 4; v4++) {
-						uint4 x = make_uint4(0x21212121u, 0x21212121u, 0x21212121u, 0x21212121u);
-						if (v4 * 16 < qstride) x = qv[v4];
-						w[v4 * 4 + 0] = x.x; w[v4 * 4 + 1] = x.y; w[v4 * 4 + 2] = x.z; w[v4 * 4 + 3] = x.w;
-					}
-					u32* row = acc + (lid - l0) * K3B_KW;
-#pragma unroll
-					for (int pq = 0; pq < 64; pq++) {
-						const int j = pq - (int) qoff;
-						if (j >= 0 && j < k) {
-							const u32 v = (uint8_t) (((w[pq >> 2] >> (8 * (pq & 3))) & 0xFFu) - 33u);
-							atomicAdd(&row[j >> 1], v << (16 * (j & 1)));
-						}
-					}
+					rd_add_qualities(acc + (lid - l0) * K3B_KW, quals + (size_t) rec * (size_t) qstride, qstride, inst == s_first[slot] ? 0u : (u32) (inst & 63u), k);
 				}
 				__syncthreads();
+				}
 				for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
 					const u32 lid = s_lowid[i];
 					if (lid == NONE16 || lid < l0 || lid >= l0 + RD_A) continue;
