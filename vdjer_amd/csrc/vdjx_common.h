@@ -22,6 +22,12 @@ typedef unsigned __int128 u128;
 #define RI_RC 2u        // its is_rc flag
 #define RI_RCA 4u       // is_rc of the pair's read-2 record A (registered first)
 #define RI_RCB 8u       // is_rc of the pair's read-2 record B (registered last)
+// an 8-byte entry: class of the pair's read-2 record A (26 bits, all ones = none) | class of B (26) | flags (4) | multiplicity (8)
+#define RI_ENT_NONE 0x3FFFFFFu
+#define RI_ENT_MAXCNT 255u
+__host__ __device__ inline unsigned long long ri_entry(unsigned y, unsigned z, unsigned fl, unsigned cnt) {
+	return (unsigned long long) y | ((unsigned long long) z << 26) | ((unsigned long long) fl << 52) | ((unsigned long long) cnt << 56);
+}
 
 // ----------------------------------------------------------------------------------------------
 // error plumbing
@@ -102,18 +108,19 @@ struct vdjx_ctx {
 	std::vector<u32> h_line_off;
 	// a-8 read index
 	const vdjx_pool* ri_pool = nullptr;
-	u32* d_ri_slots = nullptr;        // hash slot -> class id + 1
-	u32 ri_nslots = 0;
-	u32* d_ri_rep = nullptr;          // class -> representative record
+	void* d_ri_tab = nullptr;         // 32-byte slots {read sequence, class + 1}
+	u32 ri_tab_mask = 0;
 	u32* d_ri_start = nullptr;        // class -> CSR start [ncls+1]
 	u32* d_ri_cnt1 = nullptr;         // class -> number of read-1 members (the CSR lists those only)
 	u32* d_ri_recs = nullptr;         // CSR: read-1 records in registration order
+	u64* d_ri_csr8 = nullptr;         // CSR: the member's 8-byte entry (ri_entry)
+	u32* d_ri_csr_pair = nullptr;     // CSR: the member's pair id
 	u32* d_pair_r2 = nullptr;         // pair -> its two read-2 records in registration order (or ~0u)
-	uint4* d_rec_info = nullptr;      // record -> {pair id, class of read-2 record A, class of B, flags}
-	u32* d_ri_dstart = nullptr;       // class -> first of its DISTINCT read-1 infos (window scoring counts, it does not name pairs)
-	uint4* d_ri_dinfo = nullptr;      // {how many read-1 members share it, class of read-2 record A, class of B, flags}
+	u32* d_ri_dstart = nullptr;       // class -> first of its DISTINCT read-1 entries (window scoring counts, it does not name pairs)
+	u64* d_ri_d8 = nullptr;           // those entries, with multiplicities
 	// cached result of the last vdjx_map_emit count call (the write call of the two-call protocol reuses it)
 	uint64_t me_key = 0;
+	const void* me_src = nullptr;     // the batch the cached mapping belongs to
 	void* me_pairs = nullptr;         // vdjx_pair[me_cap], per-contig regions at me_hoff
 	size_t me_cap = 0;
 	// the (weighted) mapped-pair lists of the last window batch: (multiplicity << 32 | pos1 << 16 | pos2), window i at wp_off[i]
@@ -124,7 +131,7 @@ struct vdjx_ctx {
 	void* me_dense = nullptr;         // the pairs laid end to end for the copy to the host (kept: the copy may be asynchronous)
 	size_t me_dense_cap = 0;
 	std::vector<u64> me_cnt;          // pairs per contig
-	void* h_plan = nullptr;           // page-locked scratch of plan_windows (hit counts down, order and offsets up: DMA, no staging copies)
+	void* h_plan = nullptr;           // page-locked scratch: the plan's totals come down here (vdjx_score.hip classify_and_plan)
 	size_t h_plan_cap = 0;
 	void* me_book = nullptr;          // device bookkeeping between the counting and the writing call (vdjx_score.hip map_emit_impl)
 	size_t me_book_cap = 0, me_nsl = 0;

@@ -481,7 +481,7 @@ __device__ inline void rd_add_qualities(u32* row, const uint8_t* __restrict__ qr
 }
 
 template <typename TUP>
-__global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
+__global__ __launch_bounds__(RD_THREADS, 4) void k_gated_reduce(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
                                                              const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                              const uint8_t* __restrict__ quals, int qstride, int k, u64 rec_base,
                                                              u32 mf, u32 cmin, u32 mqq, u32 tlow, SurvOutG so,
@@ -558,12 +558,6 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 				}
 			}
 			__syncthreads();
-			// the low-count candidates' quality rows fit one round (nearly always): every instance adds its qualities where the
-			// sweep meets it, no list and no second pass
-			const u32 nlow = s_nlow;
-			const bool direct = nlow <= RD_A;
-			if (direct) for (u32 i = tid; i < nlow * K3B_KW; i += RD_THREADS) acc[i] = 0;
-			__syncthreads();
 			// ---- sweep 2, per chunk: (a) what settles without a fetch -- a k-mer that sits at two different offsets of two reads and
 			// lacks the period of that distance proves the reads different (compare_read, A2:142-144, 349-352) -- and the quality rows;
 			// (b) after a barrier, only for k-mers that are still open: this instance's record against the first instance's (two
@@ -595,13 +589,10 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 					const u64 fi = s_first[slot];
 					const u32 lid = s_lowid[slot];
 					if (lid != NONE16) {
-						if (direct) {
-							const u64 rec = (inst >> 6) - rec_base;
-							rd_add_qualities(acc + lid * K3B_KW, quals + (size_t) rec * (size_t) qstride, qstride, inst == fi ? 0u : (u32) (inst & 63u), k);
-						} else {
-							const u32 qi = atomicAdd(&s_nq, 1u);
-							if (qi < RD_Q) { q_slot[qi] = (u32) slot; q_inst[qi] = inst; }
-						}
+						// (listed and summed afterwards by dense lanes: adding the row here, inside the sparse sweep, made every wave walk
+						// the 64-position loop for its one or two low-count instances: 2.4 -> 5.9 ms)
+						const u32 qi = atomicAdd(&s_nq, 1u);
+						if (qi < RD_Q) { q_slot[qi] = (u32) slot; q_inst[qi] = inst; }
 					}
 					if (!(st & ST_MULTI) && (inst >> 6) != (fi >> 6)) {
 						const u32 o1 = (u32) (inst & 63u), o0 = (u32) (fi & 63u);
@@ -626,9 +617,9 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 			__syncthreads();
 			// ---- quality sums of the low-count candidates: first instance = the RECORD's first k qualities (A2:337-339), the
 			// others their own (A2:354-361); a sum >= 214 reads as 255 (A2:356-360): the test is sum >= min(mq, 214)
+			const u32 nlow = s_nlow;
 			const bool listed = s_nq <= RD_Q;
 			for (u32 l0 = 0; l0 < nlow; l0 += RD_A) {
-				if (!direct) {
 				for (u32 i = tid; i < RD_A * K3B_KW; i += RD_THREADS) acc[i] = 0;
 				__syncthreads();
 				const u32 nscan = listed ? s_nq : n;
@@ -650,7 +641,6 @@ __global__ __launch_bounds__(RD_THREADS) void k_gated_reduce(const TUP* __restri
 					rd_add_qualities(acc + (lid - l0) * K3B_KW, quals + (size_t) rec * (size_t) qstride, qstride, inst == s_first[slot] ? 0u : (u32) (inst & 63u), k);
 				}
 				__syncthreads();
-				}
 				for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
 					const u32 lid = s_lowid[i];
 					if (lid == NONE16 || lid < l0 || lid >= l0 + RD_A) continue;

@@ -2,13 +2,15 @@
 //
 // replaces add_read_info (quick_map3.c:126-149): a map "read sequence -> its instances in registration order", filled once per
 // record by extract (bam_read.c:228,243).  What the mapper kernels (vdjx_score.hip) read:
-//   slots[]          open-addressing table over the packed reads: slot -> read class + 1 (a class = one distinct read sequence)
-//   rep[cls]         a record holding the class's sequence (the key bytes live in the packed pool)
+//   tab[]            open-addressing table over the distinct read sequences (classes), 32-byte slots {sequence, class + 1}: a
+//                    lookup is ONE line fill (the build's own table names records and is dropped)
 //   start[cls]       CSR of the class's READ-1 members in registration order (read-2 instances only ever feed the "read2" map,
 //                    quick_map3.c:211-215, which the kernels replace by a class -> last offset table: they are not listed)
-//   recs[i], csr_info[i]  record and {pair id, class of the pair's read-2 record A, of B, flags} of CSR entry i
+//   recs[i], csr_pair[i], csr8[i]  record, pair id and the 8-byte entry of CSR member i
 //   pair_r2[2p..]    the pair's read-2 records in registration order (at most two: as-is and reverse complement, bam_read.c:206-244)
-//   dstart/dinfo     per class its DISTINCT read-1 infos with multiplicities (window scoring counts pairs, it does not name them)
+//   dstart/d8        per class its DISTINCT read-1 entries with multiplicities (window scoring counts pairs, it does not name them)
+// An entry is 8 bytes: class of the pair's read-2 record A (26 bits) | class of B (26) | flags (4) | multiplicity (8); the mapper
+// kernels stream billions of them per step, so their size is the kernels' time.
 // Everything is counting, scanning and two key sorts (class-major: registration order inside a class for the CSR, a hash of the
 // info for the folding); no host pass over the records.  Round 2 did this on the host: 3.8 s at 10 M pairs.
 #include "vdjx_common.h"
@@ -166,36 +168,31 @@ __global__ void k_ri_members(const u32* __restrict__ rec_cls, const uint8_t* __r
 	}
 }
 
-// everything a hit needs in one 16-byte load, in CSR order; and the key of the folding sort: class << 32 | hash of the info
+// what a hit needs in one 8-byte load, in CSR order; and the key of the folding sort: class << 32 | hash of the entry
 __global__ void k_ri_info(const u64* __restrict__ keys_sorted, const u32* __restrict__ recs, u32 n1, const u32* __restrict__ pair_id,
                           const uint8_t* __restrict__ is_rc, const u32* __restrict__ rec_cls, const u32* __restrict__ pair_r2,
-                          uint4* __restrict__ csr_info, u64* __restrict__ keys2, u32* __restrict__ vals2) {
+                          u64* __restrict__ csr8, u32* __restrict__ csr_pair, u64* __restrict__ keys2, u32* __restrict__ vals2) {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n1) return;
 	const u32 r = recs[i];
 	const u32 p = pair_id[r];
 	const u32 ra = pair_r2[2 * (size_t) p], rb = pair_r2[2 * (size_t) p + 1];
-	uint4 v;
-	v.x = p;
-	v.y = ra != NONE32 ? rec_cls[ra] : NONE32;
-	v.z = rb != NONE32 ? rec_cls[rb] : NONE32;
-	v.w = RI_R1 | (is_rc[r] ? RI_RC : 0u) | (ra != NONE32 && is_rc[ra] ? RI_RCA : 0u) | (rb != NONE32 && is_rc[rb] ? RI_RCB : 0u);
-	csr_info[i] = v;
-	const u32 h = (u32) (vdjx_mix(((u64) v.z << 32) | v.y, v.w) >> 32);
-	keys2[i] = (keys_sorted[i] & 0xFFFFFFFF00000000ull) | h;
+	const u32 ca = ra != NONE32 ? rec_cls[ra] : NONE32, cb = rb != NONE32 ? rec_cls[rb] : NONE32;
+	const u32 fl = (is_rc[r] ? RI_RC : 0u) | (ra != NONE32 && is_rc[ra] ? RI_RCA : 0u) | (rb != NONE32 && is_rc[rb] ? RI_RCB : 0u);
+	const u64 e = ri_entry(ca == NONE32 ? RI_ENT_NONE : ca, cb == NONE32 ? RI_ENT_NONE : cb, fl, 1u);
+	csr8[i] = e;
+	csr_pair[i] = p;
+	keys2[i] = (keys_sorted[i] & 0xFFFFFFFF00000000ull) | (u32) (vdjx_mix(e, 0) >> 32);
 	vals2[i] = i;
 }
 
-// sorted by (class, hash): an entry opens a new weighted entry when its class or its info differs from its predecessor's (a hash
-// collision between different infos of a class only splits a group in two: the multiplicities still add up to the members)
-__global__ void k_ri_heads(const u64* __restrict__ keys2, const u32* __restrict__ vals2, u32 n1, const uint4* __restrict__ csr_info, u32* __restrict__ head) {
+// sorted by (class, hash): a member opens a new weighted entry when its class or its entry differs from its predecessor's (a hash
+// collision between different entries of a class only splits a group in two: the multiplicities still add up to the members)
+__global__ void k_ri_heads(const u64* __restrict__ keys2, const u32* __restrict__ vals2, u32 n1, const u64* __restrict__ csr8, u32* __restrict__ head) {
 	const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= n1) return;
 	u32 h = 1;
-	if (j && (keys2[j] >> 32) == (keys2[j - 1] >> 32)) {
-		const uint4 a = csr_info[vals2[j]], b = csr_info[vals2[j - 1]];
-		h = (a.y != b.y || a.z != b.z || a.w != b.w) ? 1u : 0u;
-	}
+	if (j && (keys2[j] >> 32) == (keys2[j - 1] >> 32)) h = csr8[vals2[j]] != csr8[vals2[j - 1]] ? 1u : 0u;
 	head[j] = h;
 }
 __global__ void k_ri_head_pos(const u32* __restrict__ head, const u32* __restrict__ hpre, u32 n1, u32* __restrict__ hpos) {
@@ -203,17 +200,39 @@ __global__ void k_ri_head_pos(const u32* __restrict__ head, const u32* __restric
 	if (j < n1 && head[j]) hpos[hpre[j]] = j;
 	if (j == 0) hpos[hpre[n1]] = n1;
 }
-__global__ void k_ri_dinfo(const u32* __restrict__ hpos, u32 nd, const u32* __restrict__ vals2, const uint4* __restrict__ csr_info, uint4* __restrict__ dinfo) {
+// a group of m identical members becomes ceil(m / 255) entries (the multiplicity field has 8 bits)
+__global__ void k_ri_group_size(const u32* __restrict__ hpos, u32 ng, u32* __restrict__ ne) {
 	const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
-	if (d >= nd) return;
-	const u32 j = hpos[d];
-	const uint4 v = csr_info[vals2[j]];
-	dinfo[d] = make_uint4(hpos[d + 1] - j, v.y, v.z, v.w);
+	if (d < ng) ne[d] = (hpos[d + 1] - hpos[d] + RI_ENT_MAXCNT - 1) / RI_ENT_MAXCNT;
+	if (d == ng) ne[d] = 0;
 }
-// the folding sort is class-major like the CSR: the weighted entries of a class start where its CSR segment starts
-__global__ void k_ri_dstart(const u32* __restrict__ start, u32 ncls, const u32* __restrict__ hpre, u32* __restrict__ dstart) {
+__global__ void k_ri_d8(const u32* __restrict__ hpos, const u32* __restrict__ epre, u32 ng, const u32* __restrict__ vals2, const u64* __restrict__ csr8,
+                        u64* __restrict__ d8) {
+	const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+	if (d >= ng) return;
+	const u32 j = hpos[d];
+	u32 m = hpos[d + 1] - j;
+	const u64 e = csr8[vals2[j]] & ((1ull << 56) - 1ull);
+	for (u32 at = epre[d]; m; at++) {
+		const u32 c = m < RI_ENT_MAXCNT ? m : RI_ENT_MAXCNT;
+		d8[at] = e | ((u64) c << 56);
+		m -= c;
+	}
+}
+// the folding sort is class-major like the CSR: the weighted entries of a class start with the group its CSR segment starts with
+__global__ void k_ri_dstart(const u32* __restrict__ start, u32 ncls, const u32* __restrict__ hpre, const u32* __restrict__ epre, u32* __restrict__ dstart) {
 	const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c <= ncls) dstart[c] = hpre[start[c]];
+	if (c <= ncls) dstart[c] = epre[hpre[start[c]]];
+}
+
+// the lookup table the mapper reads: one 32-byte slot per class {sequence, class + 1}
+__global__ void k_ri_tab(const u32* __restrict__ rep, u32 ncls, const u64* __restrict__ bases, uint4* __restrict__ tab, u32 mask) {
+	const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= ncls) return;
+	const ulonglong2 b = ((const ulonglong2*) bases)[rep[c]];
+	u32 slot = (u32) (vdjx_mix(b.y, b.x) >> 17) & mask;
+	while (atomicCAS(&tab[2 * (size_t) slot + 1].x, 0u, c + 1) != 0u) slot = (slot + 1) & mask;
+	tab[2 * (size_t) slot] = make_uint4((u32) b.x, (u32) (b.x >> 32), (u32) b.y, (u32) (b.y >> 32));
 }
 
 int sort_pairs(vdjx_work& db, hipStream_t st, u64* k_in, u64* k_out, u32* v_in, u32* v_out, u32 n, unsigned end_bit) {
@@ -238,37 +257,48 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	const dim3 gR(R / 256 + 1), b256(256);
 	u32 *d_rec_slot, *d_rec_cls, *d_err, *d_n1;
 	unsigned long long* d_r2key;
-	HIP_TRY(hipMalloc(&c->d_ri_slots, (size_t) nslots * 4));
+	u32* d_slots;                                 // the build's own table: slot -> a record of the class, then -> class + 1
+	HIP_TRY(db.alloc(&d_slots, (size_t) nslots));
 	HIP_TRY(db.alloc(&d_rec_slot, (size_t) R + 1));
 	HIP_TRY(db.alloc(&d_rec_cls, (size_t) R + 1));
 	HIP_TRY(db.alloc(&d_err, 4));
 	d_n1 = d_err + 2;
 	HIP_TRY(db.alloc(&d_r2key, (size_t) n_pairs * 2 + 2));
-	HIP_TRY(hipMemsetAsync(c->d_ri_slots, 0, (size_t) nslots * 4, st));
+	HIP_TRY(hipMemsetAsync(d_slots, 0, (size_t) nslots * 4, st));
 	HIP_TRY(hipMemsetAsync(d_err, 0, 16, st));
 	HIP_TRY(hipMemsetAsync(d_r2key, 0xFF, ((size_t) n_pairs * 2 + 2) * 8, st));
 	{
 		vdjx_prof_scope ps(c, "k_ri_insert");
-		hipLaunchKernelGGL(k_ri_insert, gR, b256, 0, st, pool->d_bases, pool->d_nmask, R, c->d_ri_slots, mask, d_rec_slot);
+		hipLaunchKernelGGL(k_ri_insert, gR, b256, 0, st, pool->d_bases, pool->d_nmask, R, d_slots, mask, d_rec_slot);
 	}
 	// classes
 	const u32 nsb = (nslots + RS_BLOCK - 1) / RS_BLOCK;
 	u32 *d_bcnt, *d_bpre;
 	HIP_TRY(db.alloc(&d_bcnt, nsb + 1));
 	HIP_TRY(db.alloc(&d_bpre, nsb + 1));
-	hipLaunchKernelGGL(k_ri_occ, dim3(nsb), b256, 0, st, c->d_ri_slots, nslots, d_bcnt);
+	hipLaunchKernelGGL(k_ri_occ, dim3(nsb), b256, 0, st, d_slots, nslots, d_bcnt);
 	hipLaunchKernelGGL(k_rs_top, dim3(1), dim3(1024), 0, st, d_bcnt, nsb, d_bpre);
 	u32 ncls = 0;
 	HIP_TRY(hipMemcpyAsync(&ncls, d_bpre + nsb, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMalloc(&c->d_ri_rep, ((size_t) ncls + 1) * 4));
+	if (ncls >= RI_ENT_NONE) { vdjx_set_error("vdjx_read_index_build: %u distinct read sequences on one GPU (limit 2^26 - 1): shard the pool by pair", ncls); return VDJX_ELIMIT; }
+	u32 tmask = 1023;
+	while ((size_t) tmask + 1 < (size_t) ncls * 2) tmask = tmask * 2 + 1;
+	u32* d_rep;
+	HIP_TRY(db.alloc(&d_rep, (size_t) ncls + 1));
+	HIP_TRY(hipMalloc(&c->d_ri_tab, ((size_t) tmask + 1) * 32));
 	HIP_TRY(hipMalloc(&c->d_ri_start, ((size_t) ncls + 2) * 4));
 	HIP_TRY(hipMalloc(&c->d_ri_cnt1, ((size_t) ncls + 2) * 4));
 	HIP_TRY(hipMalloc(&c->d_ri_dstart, ((size_t) ncls + 2) * 4));
 	HIP_TRY(hipMalloc(&c->d_pair_r2, ((size_t) n_pairs * 2 + 2) * 4));
 	HIP_TRY(hipMemsetAsync(c->d_ri_cnt1, 0, ((size_t) ncls + 2) * 4, st));
-	hipLaunchKernelGGL(k_ri_number, dim3(nsb), b256, 0, st, c->d_ri_slots, nslots, d_bpre, c->d_ri_rep);
+	HIP_TRY(hipMemsetAsync(c->d_ri_tab, 0, ((size_t) tmask + 1) * 32, st));
+	hipLaunchKernelGGL(k_ri_number, dim3(nsb), b256, 0, st, d_slots, nslots, d_bpre, d_rep);
+	{
+		vdjx_prof_scope ps(c, "k_ri_tab");
+		hipLaunchKernelGGL(k_ri_tab, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, (uint4*) c->d_ri_tab, tmask);
+	}
 	// records: class, read-2 records of the pairs; read-1 members
 	u64 *d_keys, *d_keys_s;
 	u32 *d_vals, *d_vals_s;
@@ -278,7 +308,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(db.alloc(&d_vals_s, (size_t) R + 1));
 	{
 		vdjx_prof_scope ps(c, "k_ri_records");
-		hipLaunchKernelGGL(k_ri_records, gR, b256, 0, st, d_rec_slot, c->d_ri_slots, R, d_pair, d_rnum, d_reg, n_pairs, d_rec_cls, d_r2key, d_err);
+		hipLaunchKernelGGL(k_ri_records, gR, b256, 0, st, d_rec_slot, d_slots, R, d_pair, d_rnum, d_reg, n_pairs, d_rec_cls, d_r2key, d_err);
 		hipLaunchKernelGGL(k_ri_r2, dim3((unsigned) (((size_t) n_pairs * 2 + 2) / 256 + 1)), b256, 0, st, d_r2key, (size_t) n_pairs * 2 + 2, c->d_pair_r2);
 		hipLaunchKernelGGL(k_ri_members, gR, b256, 0, st, d_rec_cls, d_rnum, d_reg, R, c->d_ri_cnt1, d_keys, d_vals, d_n1);
 	}
@@ -293,7 +323,8 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	const u32 n1 = h_err[2];
 	// CSR order = (class, registration rank)
 	HIP_TRY(hipMalloc(&c->d_ri_recs, ((size_t) n1 + 1) * 4));
-	HIP_TRY(hipMalloc(&c->d_rec_info, ((size_t) n1 + 1) * sizeof(uint4)));
+	HIP_TRY(hipMalloc(&c->d_ri_csr8, ((size_t) n1 + 1) * 8));
+	HIP_TRY(hipMalloc(&c->d_ri_csr_pair, ((size_t) n1 + 1) * 4));
 	u32 nd = 0;
 	if (n1) {
 		{
@@ -304,28 +335,37 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 		HIP_TRY(hipMemcpyAsync(c->d_ri_recs, d_vals_s, (size_t) n1 * 4, hipMemcpyDeviceToDevice, st));
 		const dim3 g1(n1 / 256 + 1);
 		// (the unsorted key/value buffers are free again: they take the folding sort's input)
-		hipLaunchKernelGGL(k_ri_info, g1, b256, 0, st, d_keys_s, c->d_ri_recs, n1, d_pair, d_rc, d_rec_cls, c->d_pair_r2, c->d_rec_info, d_keys, d_vals);
+		hipLaunchKernelGGL(k_ri_info, g1, b256, 0, st, d_keys_s, c->d_ri_recs, n1, d_pair, d_rc, d_rec_cls, c->d_pair_r2, c->d_ri_csr8, c->d_ri_csr_pair, d_keys, d_vals);
 		{
 			vdjx_prof_scope ps(c, "ri_sort_infos");
 			rc = sort_pairs(db, st, d_keys, d_keys_s, d_vals, d_vals_s, n1, 32u + bits_for(ncls));
 			if (rc) return rc;
 		}
-		u32 *d_head, *d_hpre, *d_hpos;
+		u32 *d_head, *d_hpre, *d_hpos, *d_ne, *d_epre;
 		HIP_TRY(db.alloc(&d_head, (size_t) n1 + 1));
 		HIP_TRY(db.alloc(&d_hpre, (size_t) n1 + 2));
 		HIP_TRY(db.alloc(&d_hpos, (size_t) n1 + 2));
-		hipLaunchKernelGGL(k_ri_heads, g1, b256, 0, st, d_keys_s, d_vals_s, n1, c->d_rec_info, d_head);
+		HIP_TRY(db.alloc(&d_ne, (size_t) n1 + 2));
+		HIP_TRY(db.alloc(&d_epre, (size_t) n1 + 3));
+		hipLaunchKernelGGL(k_ri_heads, g1, b256, 0, st, d_keys_s, d_vals_s, n1, c->d_ri_csr8, d_head);
 		rc = scan_u32(db, st, d_head, n1, d_hpre);
 		if (rc) return rc;
-		HIP_TRY(hipMemcpyAsync(&nd, d_hpre + n1, 4, hipMemcpyDeviceToHost, st));
+		u32 ng = 0;
+		HIP_TRY(hipMemcpyAsync(&ng, d_hpre + n1, 4, hipMemcpyDeviceToHost, st));
 		hipLaunchKernelGGL(k_ri_head_pos, g1, b256, 0, st, d_head, d_hpre, n1, d_hpos);
-		hipLaunchKernelGGL(k_ri_dstart, dim3(ncls / 256 + 1), b256, 0, st, c->d_ri_start, ncls, d_hpre, c->d_ri_dstart);
 		HIP_TRY(hipStreamSynchronize(st));
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMalloc(&c->d_ri_dinfo, ((size_t) nd + 1) * sizeof(uint4)));
-		hipLaunchKernelGGL(k_ri_dinfo, dim3(nd / 256 + 1), b256, 0, st, d_hpos, nd, d_vals_s, c->d_rec_info, c->d_ri_dinfo);
+		hipLaunchKernelGGL(k_ri_group_size, dim3(ng / 256 + 1), b256, 0, st, d_hpos, ng, d_ne);
+		rc = scan_u32(db, st, d_ne, ng + 1, d_epre);          // (ne[ng] = 0: epre[ng] = epre[ng + 1] = entries)
+		if (rc) return rc;
+		HIP_TRY(hipMemcpyAsync(&nd, d_epre + ng, 4, hipMemcpyDeviceToHost, st));
+		hipLaunchKernelGGL(k_ri_dstart, dim3(ncls / 256 + 1), b256, 0, st, c->d_ri_start, ncls, d_hpre, d_epre, c->d_ri_dstart);
+		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMalloc(&c->d_ri_d8, ((size_t) nd + 1) * 8));
+		hipLaunchKernelGGL(k_ri_d8, dim3(ng / 256 + 1), b256, 0, st, d_hpos, d_epre, ng, d_vals_s, c->d_ri_csr8, c->d_ri_d8);
 	} else {
-		HIP_TRY(hipMalloc(&c->d_ri_dinfo, sizeof(uint4)));
+		HIP_TRY(hipMalloc(&c->d_ri_d8, 8));
 		HIP_TRY(hipMemsetAsync(c->d_ri_dstart, 0, ((size_t) ncls + 2) * 4, st));
 	}
 	HIP_TRY(hipStreamSynchronize(st));
@@ -334,7 +374,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	c->stats["read_index_r1_members"] = n1;
 	c->stats["read_index_r1_distinct"] = nd;
 	c->stats["read_index_classes"] = ncls;
-	c->ri_nslots = nslots;
+	c->ri_tab_mask = tmask;
 	c->n_pairs = n_pairs;
 	c->n_classes = ncls;
 	c->ri_pool = pool;
@@ -342,8 +382,8 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 }
 
 void drop_index(vdjx_ctx* c) {
-	free_set(c->d_ri_slots); free_set(c->d_ri_rep); free_set(c->d_ri_start); free_set(c->d_ri_recs); free_set(c->d_ri_cnt1);
-	free_set(c->d_pair_r2); free_set(c->d_rec_info); free_set(c->d_ri_dstart); free_set(c->d_ri_dinfo);
+	free_set(c->d_ri_tab); free_set(c->d_ri_start); free_set(c->d_ri_recs); free_set(c->d_ri_cnt1);
+	free_set(c->d_pair_r2); free_set(c->d_ri_csr8); free_set(c->d_ri_csr_pair); free_set(c->d_ri_dstart); free_set(c->d_ri_d8);
 	c->ri_pool = nullptr;
 	c->me_key = 0;
 }

@@ -2,7 +2,7 @@
 //
 //   K7  k_seed_count / k_root_dp      root (V-region homology) scorer         seq_score.c:92-156
 //   K8  (vdjx_rindex.hip)             read index                              quick_map3.c:126-149
-//       k_window_pairs / k_window_cover  read->window mapper + coverage test  quick_map3.c:188-266, coverage.c:10-130
+//       k_map_classify / k_plan / k_window_pairs / k_window_cover  read->window mapper + coverage test  quick_map3.c:188-266, coverage.c:10-130
 //   K10 k_map_emit                    mapped pairs of final contigs in order  quick_map3.c:152-181, 311-340
 //
 // None of this is a dense contraction: the DP is a max-plus recurrence on int8 cells, the mapper is
@@ -345,7 +345,7 @@ extern "C" int vdjx_root_score_graph(vdjx_ctx* c, const vdjx_graph* g, int thres
 // (a-8 read index: vdjx_rindex.hip)
 
 // ==============================================================================================
-// a-8/a-9/a-10 mapper core shared by k_window_hits, k_window_pairs and k_map_emit
+// a-8/a-9/a-10 mapper core shared by k_window_pairs and k_map_emit
 // ==============================================================================================
 #define MAP_THREADS 512
 #define MAP_MAXOFF 1024          // window/contig length - rl  <= MAP_MAXOFF
@@ -353,75 +353,100 @@ extern "C" int vdjx_root_score_graph(vdjx_ctx* c, const vdjx_graph* g, int thres
 #define MAP_PRESENT_LOG2 15
 #define MAP_PRESENT_WORDS (1u << (MAP_PRESENT_LOG2 - 5))
 
-struct ReadIndexDev {
-	const u64* bases;
-	const u32* slots; u32 mask;
-	const u32* rep; const u32* start; const u32* cnt1; const u32* recs;
-	const uint4* csr_info; const u32* pair_r2;    // csr_info[i] = record info of recs[i]: one coalesced 16-byte load per hit
-	const u32* dstart; const uint4* dinfo;        // distinct read-1 infos per class with multiplicities (window scoring)
+struct ReadIndexDev {                             // vdjx_rindex.hip
+	const uint4* tab; u32 mask;                   // two uint4 per slot: the read sequence {lo, hi}, then {class + 1, -, -, -}
+	const u32* start; const u32* cnt1; const u32* recs;
+	const u64* csr8; const u32* csr_pair; const u32* pair_r2;     // per CSR member: 8-byte entry, pair id; per pair: its read-2 records
+	const u32* dstart; const u64* d8;             // distinct read-1 entries per class with multiplicities (window scoring)
 	int rl;
 };
+__device__ inline u32 ent_a(u64 e) { return (u32) e & RI_ENT_NONE; }
+__device__ inline u32 ent_b(u64 e) { return (u32) (e >> 26) & RI_ENT_NONE; }
+__device__ inline u32 ent_flags(u64 e) { return (u32) (e >> 52) & 15u; }
+__device__ inline u32 ent_count(u64 e) { return (u32) (e >> 56); }
 
 struct MapLds {
 	u32 cls[MAP_MAXOFF];                            // read class at the offset or NONE32
-	u32 cstart[MAP_MAXOFF];                         // CSR start of that class
+	u32 cstart[MAP_MAXOFF];                         // first entry of that class
 	u32 hpre[MAP_MAXOFF + 1];                       // prefix of class sizes (hits enumerate in reference order)
 	u32 wt_key[WT_SLOTS];                           // class id + 1
 	u32 wt_last[WT_SLOTS];                          // last offset + 1 with that class
 	u32 scan[MAP_THREADS];
 	u32 present[MAP_PRESENT_WORDS];                 // one bit per hashed class id seen in the window: "is this mate class here at all?" is one LDS
 	                                                // word for the 98 % of the hits whose mate lies elsewhere (a V gene is shared by many clones)
-	u32 inst_total;                                 // weighted mode: read-1 instances behind the distinct hits
 };
 
 __device__ inline u32 map_present_bit(u32 cls) { return (cls * 2654435761u) >> (32 - MAP_PRESENT_LOG2); }
 
-// classify every offset o in [0, len-rl) (quick_map3.c:200: the last offset is never looked at), build the
-// class -> last offset table, prefix the class sizes.  Returns the hit count H (uniform).
-// `weighted`: hits enumerate the DISTINCT read-1 infos of a class (ix.dstart/dinfo) instead of its members
-__device__ inline u32 map_prepare(MapLds& L, const ReadIndexDev& ix, const char* __restrict__ w, int len, bool weighted = false) {
-	const int rl = ix.rl;
-	const int noff = len - rl;
+// ---- classification: every offset o in [0, len-rl) of every string (quick_map3.c:200: the last offset is never looked at) -> its
+// read class, the class's entries and how many (weighted: the DISTINCT read-1 entries, else the read-1 members), kept in HBM
+// (16 bytes per offset) for the kernels that evaluate the hits: a string is looked up in the index ONCE per call.
+// One workgroup per string (looping), one thread per offset; the string is staged in LDS.
+__global__ __launch_bounds__(MAP_THREADS) void k_map_classify(ReadIndexDev ix, const char* __restrict__ strings, u32 n, int len, bool weighted,
+                                                              uint4* __restrict__ prep, u32* __restrict__ out_hits, u32* __restrict__ out_inst) {
+	__shared__ char txt[MAP_MAXOFF + 64 + 16];
+	__shared__ u32 s_h[MAP_THREADS / 64], s_i[MAP_THREADS / 64];
+	const int rl = ix.rl, noff = len - rl;
+	const u32 tid = threadIdx.x;
+	for (u32 wi = blockIdx.x; wi < n; wi += gridDim.x) {
+		const char* w = strings + (size_t) wi * len;
+		for (int i = tid; i < len; i += MAP_THREADS) txt[i] = w[i];
+		__syncthreads();
+		u32 hs = 0, is = 0;
+		for (int o = tid; o < noff; o += MAP_THREADS) {
+			u128 b = 0;
+			bool ok = true;
+			for (int j = 0; j < rl; j++) {
+				const int cde = base_code(txt[o + j]);
+				if (cde < 0) ok = false;
+				b = (b << 2) | (u32) (cde & 3);
+			}
+			const u64 hi = (u64) (b >> 64), lo = (u64) b;
+			u32 cls = NONE32, cs = 0, sz = 0, inst = 0;
+			if (ok) {
+				u32 slot = (u32) (vdjx_mix(lo, hi) >> 17) & ix.mask;
+				for (;;) {
+					const uint4 key = ix.tab[2 * (size_t) slot], val = ix.tab[2 * (size_t) slot + 1];
+					if (!val.x) break;
+					if ((((u64) key.y << 32) | key.x) == hi && (((u64) key.w << 32) | key.z) == lo) { cls = val.x - 1; break; }
+					slot = (slot + 1) & ix.mask;
+				}
+			}
+			if (cls != NONE32) {
+				inst = ix.cnt1[cls];
+				if (weighted) { cs = ix.dstart[cls]; sz = ix.dstart[cls + 1] - cs; }
+				else { cs = ix.start[cls]; sz = inst; }
+			}
+			prep[(size_t) wi * noff + o] = make_uint4(cls, cs, sz, inst);
+			hs += sz; is += inst;
+		}
+		hs = (u32) __builtin_amdgcn_readlane(vdjx_wave_scan_add((int) hs), 63);
+		is = (u32) __builtin_amdgcn_readlane(vdjx_wave_scan_add((int) is), 63);
+		if ((tid & 63u) == 0) { s_h[tid >> 6] = hs; s_i[tid >> 6] = is; }
+		__syncthreads();
+		if (tid == 0) {
+			u32 a = 0, b2 = 0;
+			for (u32 v = 0; v < MAP_THREADS / 64; v++) { a += s_h[v]; b2 += s_i[v]; }
+			out_hits[wi] = a;
+			out_inst[wi] = b2;
+		}
+		__syncthreads();
+	}
+}
+
+// the classified offsets of one string -> the workgroup's LDS image: class / first entry / prefix of sizes per offset, the class ->
+// last offset table ("read2[id] = m_info": the last writer wins, quick_map3.c:214) and the presence bits.  Returns the hit count.
+__device__ inline u32 map_load_prep(MapLds& L, const uint4* __restrict__ prow, int noff) {
 	const u32 tid = threadIdx.x;
 	for (u32 i = tid; i < WT_SLOTS; i += MAP_THREADS) { L.wt_key[i] = 0; L.wt_last[i] = 0; }
 	for (u32 i = tid; i < MAP_PRESENT_WORDS; i += MAP_THREADS) L.present[i] = 0;
-	if (tid == 0) L.inst_total = 0;
 	__syncthreads();
 	for (int o = tid; o < noff; o += MAP_THREADS) {
-		u128 b = 0;
-		bool ok = true;
-		for (int j = 0; j < rl; j++) {
-			int cde = base_code(w[o + j]);
-			if (cde < 0) ok = false;
-			b = (b << 2) | (u32) (cde & 3);
-		}
-		const u64 hi = (u64) (b >> 64), lo = (u64) b;
-		u32 cls = NONE32, cs = 0, sz = 0;
-		if (ok) {
-			u32 slot = (u32) (vdjx_mix(lo, hi) >> 17) & ix.mask;
-			for (;;) {
-				const u32 v = ix.slots[slot];
-				if (!v) break;
-				const u32 rr = ix.rep[v - 1];
-				const ulonglong2 k = ((const ulonglong2*) ix.bases)[rr];
-				if (k.x == hi && k.y == lo) { cls = v - 1; break; }
-				slot = (slot + 1) & ix.mask;
-			}
-		}
+		const uint4 p = prow[o];
+		const u32 cls = p.x;
 		if (cls != NONE32) {
-			if (weighted) {
-				cs = ix.dstart[cls];
-				sz = ix.dstart[cls + 1] - cs;
-				atomicAdd(&L.inst_total, ix.cnt1[cls]);
-			} else {
-				cs = ix.start[cls];
-				sz = ix.cnt1[cls];                  // read-1 members come first
-			}
-			{
-				const u32 pb = map_present_bit(cls);
-				atomicOr(&L.present[pb >> 5], 1u << (pb & 31));
-			}
-			// class -> last offset ("read2[id] = m_info": the last writer wins, quick_map3.c:214)
+			const u32 pb = map_present_bit(cls);
+			atomicOr(&L.present[pb >> 5], 1u << (pb & 31));
 			u32 slot = (cls * 2654435761u) & (WT_SLOTS - 1);
 			for (;;) {
 				u32 cur = L.wt_key[slot];
@@ -434,11 +459,11 @@ __device__ inline u32 map_prepare(MapLds& L, const ReadIndexDev& ix, const char*
 			}
 		}
 		L.cls[o] = cls;
-		L.cstart[o] = cs;
-		L.hpre[o] = sz;
+		L.cstart[o] = p.y;
+		L.hpre[o] = p.z;
 	}
 	__syncthreads();
-	// exclusive prefix of the class sizes: wave 0, 16 consecutive offsets per lane
+	// exclusive prefix of the class sizes: wave 0, consecutive offsets per lane
 	if (tid < 64) {
 		const int per = (noff + 63) / 64;
 		const int a = (int) tid * per;
@@ -456,7 +481,6 @@ __device__ inline u32 map_prepare(MapLds& L, const ReadIndexDev& ix, const char*
 
 // last offset+1 at which a read of class `cls` occurs in the window, or 0
 __device__ inline u32 map_last_occurrence(const MapLds& L, u32 cls) {
-	if (cls == NONE32) return 0;
 	u32 slot = (cls * 2654435761u) & (WT_SLOTS - 1);
 	for (;;) {
 		const u32 cur = L.wt_key[slot];
@@ -466,57 +490,133 @@ __device__ inline u32 map_last_occurrence(const MapLds& L, u32 cls) {
 	}
 }
 
-struct Hit {
-	bool pair;          // a mapped pair (quick_map3.c:223-245)
-	u32 pair_id, rec1;  // (weighted mode: pair_id = how many identical read pairs the entry stands for)
-	int which;          // 0: read-2 record A won, 1: B
-	int pos1, pos2, insert;
-	uint8_t rc1, rc2;
-};
-
-// hit h (reference order: offset-major, registration order inside a class) -> mapped pair or not
-template <bool WEIGHTED = false>
-__device__ inline Hit map_eval_hit(const MapLds& L, const ReadIndexDev& ix, int noff, u32 h) {
-	Hit r;
-	r.pair = false;
-	int lo = 0, hi = noff;                          // offset holding hit h: last o with hpre[o] <= h
-	while (hi - lo > 1) {
-		int mid = (lo + hi) >> 1;
-		if (L.hpre[mid] <= h) lo = mid; else hi = mid;
-	}
-	const int o = lo;
-	const u32 ci = L.cstart[o] + (h - L.hpre[o]);
-	const uint4 info = WEIGHTED ? ix.dinfo[ci] : ix.csr_info[ci];
-	if (!(info.w & RI_R1)) return r;                // read-2 instances only feed the read2 map
-	// read2[id]: among the pair's read-2 records the one written last = largest offset, then latest registration
-	const u32 ba = map_present_bit(info.y), bb = map_present_bit(info.z);
-	const bool pa = (L.present[ba >> 5] >> (ba & 31)) & 1u, pb = (L.present[bb >> 5] >> (bb & 31)) & 1u;
-	if (!pa && !pb) return r;
-	const u32 la = pa ? map_last_occurrence(L, info.y) : 0u, lb = pb ? map_last_occurrence(L, info.z) : 0u;
-	if (!la && !lb) return r;
-	const int which = (lb && lb >= la) ? 1 : 0;
+// one entry of the class at offset o -> mapped pair or not (quick_map3.c:223-245).  read2[id]: among the pair's read-2 records the
+// one written last = largest offset, then latest registration (B)
+__device__ inline bool map_eval_entry(const MapLds& L, int rl, int o, const u64 e, u32& pos2_out, u32& which_out) {
+	const u32 ca = ent_a(e), cb = ent_b(e);
+	const u32 ba = map_present_bit(ca), bb = map_present_bit(cb);
+	const bool pa = ca != RI_ENT_NONE && ((L.present[ba >> 5] >> (ba & 31)) & 1u), pb = cb != RI_ENT_NONE && ((L.present[bb >> 5] >> (bb & 31)) & 1u);
+	if (!pa && !pb) return false;
+	const u32 la = pa ? map_last_occurrence(L, ca) : 0u, lb = pb ? map_last_occurrence(L, cb) : 0u;
+	if (!la && !lb) return false;
+	const u32 which = (lb && lb >= la) ? 1u : 0u;
 	const u32 best = which ? lb : la;
-	const uint8_t rc1 = (info.w & RI_RC) ? 1 : 0;
-	const uint8_t rc2 = (info.w & (which ? RI_RCB : RI_RCA)) ? 1 : 0;
-	if (rc1 == rc2) return r;                       // quick_map3.c:227
-	const int pos1 = o + 1, pos2 = (int) best;
-	const int d = pos1 - pos2;
-	const int insert = (int) (short) ((d < 0 ? -d : d) + ix.rl);
-	if (insert < 50 || insert > 400) return r;      // MIN_INSERT / MAX_INSERT, quick_map3.c:23-24
-	r.pair = true;
-	r.pair_id = info.x; r.rec1 = WEIGHTED ? 0u : ix.recs[ci]; r.which = which;
-	r.pos1 = pos1; r.pos2 = pos2; r.insert = insert; r.rc1 = rc1; r.rc2 = rc2;
-	return r;
+	const u32 fl = ent_flags(e);
+	const u32 rc1 = (fl & RI_RC) ? 1u : 0u;
+	const u32 rc2 = (fl & (which ? RI_RCB : RI_RCA)) ? 1u : 0u;
+	if (rc1 == rc2) return false;                  // quick_map3.c:227
+	const int d = (o + 1) - (int) best;
+	const int insert = (int) (short) ((d < 0 ? -d : d) + rl);
+	if (insert < 50 || insert > 400) return false; // MIN_INSERT / MAX_INSERT, quick_map3.c:23-24
+	pos2_out = best;
+	which_out = which;
+	return true;
 }
 
-// hits per window/contig: sizes the pair scratch and orders the work largest-first
-__global__ __launch_bounds__(MAP_THREADS) void k_window_hits(ReadIndexDev ix, const char* __restrict__ windows, u32 n, int len,
-                                                             bool weighted, u32* __restrict__ out_hits, u32* __restrict__ out_inst) {
-	__shared__ MapLds L;
-	for (u32 wi = blockIdx.x; wi < n; wi += gridDim.x) {
-		const u32 H = map_prepare(L, ix, windows + (size_t) wi * len, len, weighted);
-		if (threadIdx.x == 0) { out_hits[wi] = H; if (out_inst) out_inst[wi] = weighted ? L.inst_total : H; }
+// ----------------------------------------------------------------------------------------------
+// planning on the device: offsets of the strings' hit lists, processing order (largest first), work items
+// ----------------------------------------------------------------------------------------------
+// entry b of a prefix array belongs to the position j with start[j] <= b < start[j + 1]
+__device__ inline u32 slice_contig(const u32* __restrict__ slice_start, u32 n, u32 b) {
+	u32 lo = 0, hi = n;
+	while (hi - lo > 1) {
+		const u32 mid = (lo + hi) >> 1;
+		if (slice_start[mid] <= b) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+
+#define MAP_SLICE 4096u          // hits per slice of k_map_emit at least ...
+#define MAP_SLICE_MAX 32768u     // ... and at most: as long as ~8 k slices remain (every slice loads its contig's image once)
+struct PlanOut { u64 total_hits, inst_total; u32 inst_max, chunk, nwork, pad; };
+
+__device__ inline u32 plan_block_scan(u32 v, u32* tmp, u32& total) {       // exclusive prefix over the 1024 threads (all call it)
+	const u32 incl = (u32) vdjx_wave_scan_add((int) v);
+	__syncthreads();
+	if ((threadIdx.x & 63u) == 63u) tmp[threadIdx.x >> 6] = incl;
+	__syncthreads();
+	u32 base = 0, tot = 0;
+	for (u32 w = 0; w < 16; w++) { const u32 x = tmp[w]; if (w < (threadIdx.x >> 6)) base += x; tot += x; }
+	total = tot;
+	return base + incl - v;
+}
+
+// One workgroup: off[i] = hits before string i (u64), order[] = strings by descending bit length of their hit count (sorted) or as
+// they come, wstart[j] = work items before position j of that order, where string i has ceil(hits / chunk) of them (at least one if
+// min_one).  chunk_fixed == 0: the slice length of k_map_emit, chosen from the total.  A stable_sort of 20,000 windows on the host,
+// the list of their slices and three transfers cost more than the coverage kernel ran.
+__global__ __launch_bounds__(1024) void k_plan(const u32* __restrict__ hits, const u32* __restrict__ inst, u32 n, u32 chunk_fixed, int sorted, int min_one,
+                                               u64* __restrict__ off, u32* __restrict__ order, u32* __restrict__ wstart, PlanOut* __restrict__ out) {
+	__shared__ u64 part[1024];
+	__shared__ u32 tmp[16];
+	__shared__ u64 s_inst;
+	__shared__ u32 s_imax, s_chunk;
+	const u32 tid = threadIdx.x;
+	const u32 per = (n + 1023) / 1024;
+	const u32 lo = tid * per < n ? tid * per : n;
+	const u32 hi = lo + per < n ? lo + per : n;
+	if (tid == 0) { s_inst = 0; s_imax = 0; }
+	u64 s = 0, is = 0;
+	u32 im = 0;
+	for (u32 i = lo; i < hi; i++) { s += hits[i]; const u32 x = inst[i]; is += x; im = im > x ? im : x; }
+	part[tid] = s;
+	__syncthreads();
+	for (u32 d = 1; d < 1024; d <<= 1) {
+		const u64 v = tid >= d ? part[tid - d] : 0;
 		__syncthreads();
+		part[tid] += v;
+		__syncthreads();
+	}
+	const u64 total = part[1023];
+	u64 run = part[tid] - s;
+	for (u32 i = lo; i < hi; i++) { off[i] = run; run += hits[i]; }
+	if (is) atomicAdd((unsigned long long*) &s_inst, (unsigned long long) is);
+	if (im) atomicMax(&s_imax, im);
+	if (tid == 0) {
+		off[n] = total;
+		u32 chunk = chunk_fixed;
+		if (!chunk) {
+			chunk = MAP_SLICE;
+			while (chunk < MAP_SLICE_MAX && total / ((u64) chunk * 2) >= 8192) chunk *= 2;
+		}
+		s_chunk = chunk;
+	}
+	__syncthreads();
+	const u32 chunk = s_chunk;
+	// order: one block scan per bit length, longest first (stable inside a bucket: deterministic)
+	if (sorted) {
+		u32 base = 0;
+		for (int bl = 32; bl >= 0; bl--) {
+			u32 c = 0;
+			for (u32 i = lo; i < hi; i++) { const u32 h = hits[i]; c += (h ? 32 - __clz(h) : 0) == bl; }
+			u32 tot;
+			u32 at = base + plan_block_scan(c, tmp, tot);
+			if (c) for (u32 i = lo; i < hi; i++) { const u32 h = hits[i]; if ((h ? 32 - __clz(h) : 0) == bl) order[at++] = i; }
+			base += tot;
+		}
+		__threadfence_block();
+		__syncthreads();
+	} else
+		for (u32 i = lo; i < hi; i++) order[i] = i;
+	__syncthreads();
+	// work items by position
+	u32 wc = 0;
+	for (u32 j = lo; j < hi; j++) {
+		const u32 h = hits[sorted ? order[j] : j];
+		const u32 it = (h + chunk - 1) / chunk;
+		wc += (min_one && !it) ? 1u : it;
+	}
+	u32 wtot;
+	u32 wrun = plan_block_scan(wc, tmp, wtot);
+	for (u32 j = lo; j < hi; j++) {
+		const u32 h = hits[sorted ? order[j] : j];
+		const u32 it = (h + chunk - 1) / chunk;
+		wstart[j] = wrun;
+		wrun += (min_one && !it) ? 1u : it;
+	}
+	if (tid == 0) {
+		wstart[n] = wtot;
+		out->total_hits = total; out->inst_total = s_inst; out->inst_max = s_imax; out->chunk = chunk; out->nwork = wtot; out->pad = 0;
 	}
 }
 
@@ -535,109 +635,184 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_hits(ReadIndexDev ix, co
 //    pairs (stored once in a scratch list) for every batch, prefixes, and tests.
 // ----------------------------------------------------------------------------------------------
 #define COV_WORDS 8192
-#define HIT_CHUNK 524288u        // hits per workgroup of k_window_pairs: only the very deepest windows are split (every piece pays one
-                                 // preparation of the window; measured at 10 M pairs: 65536 -> 5.2 ms, 262144 and above -> 3.5 ms)
+#define HIT_CHUNK 524288u        // hits per workgroup of k_window_pairs: only the very deepest windows are split (every piece loads the
+                                 // window's image once; measured at 10 M pairs: 65536 -> 5.2 ms, 262144 and above -> 3.5 ms)
 
-// one (weighted) entry of the class at offset o -> mapped pair or not (quick_map3.c:223-245)
-__device__ inline bool map_eval_entry(const MapLds& L, int rl, int o, const uint4 info, u32& pos2_out) {
-	if (!(info.w & RI_R1)) return false;
-	const u32 ba = map_present_bit(info.y), bb = map_present_bit(info.z);
-	const bool pa = (L.present[ba >> 5] >> (ba & 31)) & 1u, pb = (L.present[bb >> 5] >> (bb & 31)) & 1u;
-	if (!pa && !pb) return false;
-	const u32 la = pa ? map_last_occurrence(L, info.y) : 0u, lb = pb ? map_last_occurrence(L, info.z) : 0u;
-	if (!la && !lb) return false;
-	const int which = (lb && lb >= la) ? 1 : 0;
-	const u32 best = which ? lb : la;
-	const u32 rc1 = (info.w & RI_RC) ? 1u : 0u;
-	const u32 rc2 = (info.w & (which ? RI_RCB : RI_RCA)) ? 1u : 0u;
-	if (rc1 == rc2) return false;                  // quick_map3.c:227
-	const int d = (o + 1) - (int) best;
-	const int insert = (int) (short) ((d < 0 ? -d : d) + rl);
-	if (insert < 50 || insert > 400) return false; // MIN_INSERT / MAX_INSERT, quick_map3.c:23-24
-	pos2_out = best;
-	return true;
+// K8: mapped pairs of a slice of a window's (distinct) hits, appended (any order) to the window's list as
+// (multiplicity << 32 | pos1 << 16 | pos2); pair_np = mapped pairs counted with multiplicity.  Work item b is slice b - wstart[j] of
+// the window at position j of the processing order (binary search over the prefix: the slices are never listed).
+// The waves of the workgroup take the offsets of the slice one at a time (LDS ticket): the entries of an offset's read class
+// are consecutive, so a wave streams them with coalesced 8-byte loads and no search; pairs (a few per cent of the entries) are
+// staged per wave in LDS and leave with one global cursor bump per 64.
+#define WP_K 16                  // rows of 64 consecutive hits per wave and round: 16 loads in flight per lane
+#define WP_Q 128                 // per-wave queue of the entries that passed the presence test
+// the LDS image without the arrays only k_map_emit needs
+struct MapLdsW {
+	u32 cstart[MAP_MAXOFF];
+	u32 hpre[MAP_MAXOFF + 1];
+	u32 wt_key[WT_SLOTS];
+	u32 wt_last[WT_SLOTS];
+	u32 present[MAP_PRESENT_WORDS];
+};
+__device__ inline u32 mapw_last_occurrence(const MapLdsW& L, u32 cls) {
+	u32 slot = (cls * 2654435761u) & (WT_SLOTS - 1);
+	for (;;) {
+		const u32 cur = L.wt_key[slot];
+		if (cur == 0) return 0;
+		if (cur == cls + 1) return L.wt_last[slot];
+		slot = (slot + 1) & (WT_SLOTS - 1);
+	}
 }
 
-// K8: mapped pairs of a slice [h0, h1) of a window's (distinct) hits, appended (any order) to the window's list as
-// (multiplicity << 32 | pos1 << 16 | pos2); pair_np = mapped pairs counted with multiplicity.
-// The waves of the workgroup take the offsets of the slice one at a time (LDS ticket): the entries of an offset's read class
-// are consecutive, so a wave streams them with coalesced 16-byte loads and no search; pairs (a few per cent of the entries) are
-// staged per wave in LDS and leave with one global cursor bump per 128.
-#define WP_STAGE 64
-#define WP_UNR 4
-__global__ __launch_bounds__(MAP_THREADS) void k_window_pairs(ReadIndexDev ix, const char* __restrict__ windows, int len,
-                                                              const uint4* __restrict__ work /* {window, h0, h1, -} */,
+__global__ __launch_bounds__(MAP_THREADS) void k_window_pairs(ReadIndexDev ix, const uint4* __restrict__ prep, u32 n, int len, u32 chunk,
+                                                              const u32* __restrict__ order, const u32* __restrict__ wstart,
                                                               const u64* __restrict__ pair_off, u64* __restrict__ pair_buf,
                                                               u32* __restrict__ pair_cnt, u32* __restrict__ pair_np) {
-	__shared__ MapLds L;
-	__shared__ u64 stg[MAP_THREADS / 64][WP_STAGE];
-	__shared__ int s_next, s_ohi;
-	const uint4 wk = work[blockIdx.x];
-	const u32 wi = wk.x;
+	__shared__ MapLdsW L;
+	__shared__ u64 q_ent[MAP_THREADS / 64][WP_Q];
+	__shared__ unsigned short q_off[MAP_THREADS / 64][WP_Q];
+	__shared__ u32 s_next;
+	const u32 j = slice_contig(wstart, n, blockIdx.x);
+	const u32 wi = order[j];
 	const int noff = len - ix.rl;
-	const u32 H = map_prepare(L, ix, windows + (size_t) wi * len, len, true);
-	const u32 h0 = wk.y, h1 = wk.z < H ? wk.z : H;
-	if (h0 >= h1) return;
-	if (threadIdx.x == 0) {
-		int lo = 0, hi = noff;                          // last offset with hpre[o] <= h0
-		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.hpre[mid] <= h0) lo = mid; else hi = mid; }
-		s_next = lo;
-		lo = 0; hi = noff;                              // last offset with hpre[o] < h1
-		while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.hpre[mid] < h1) lo = mid; else hi = mid; }
-		s_ohi = lo;
-	}
+	const u32 tid = threadIdx.x;
+	// ---- the window's image (map_load_prep without the arrays this kernel does not read)
+	for (u32 i = tid; i < WT_SLOTS; i += MAP_THREADS) { L.wt_key[i] = 0; L.wt_last[i] = 0; }
+	for (u32 i = tid; i < MAP_PRESENT_WORDS; i += MAP_THREADS) L.present[i] = 0;
+	if (tid == 0) s_next = (blockIdx.x - wstart[j]) * chunk;
 	__syncthreads();
-	const int ohi = s_ohi;
-	const int lane = __lane_id();
-	u64* mystg = stg[threadIdx.x >> 6];
-	u64* pairs = pair_buf + pair_off[wi];
-	u32 fill = 0, mine = 0;
-	for (;;) {
-		int o = 0;
-		if (lane == 0) o = atomicAdd(&s_next, 1);
-		o = __builtin_amdgcn_readlane(o, 0);
-		if (o > ohi) break;
-		const u32 a = L.hpre[o], bnd = L.hpre[o + 1];
-		if (a == bnd) continue;
-		const u32 e0 = (h0 > a ? h0 : a) - a, e1 = (h1 < bnd ? h1 : bnd) - a;
-		const u32 cs = L.cstart[o];
-		// four 16-byte loads are in flight per lane before the first is used: the loop is bound by their latency, not their bytes
-		for (u32 eb = e0; eb < e1; eb += 64 * WP_UNR) {
-			uint4 info[WP_UNR];
-#pragma unroll
-			for (int u = 0; u < WP_UNR; u++) {
-				const u32 e = eb + (u32) (u * 64 + lane);
-				info[u] = e < e1 ? ix.dinfo[cs + e] : make_uint4(0, 0, 0, 0);        // (flags 0: not a read-1 entry)
-			}
-#pragma unroll
-			for (int u = 0; u < WP_UNR; u++) {
-				if (eb + (u32) (u * 64) >= e1) break;                                // (wave-uniform)
-				u32 pos2 = 0;
-				const bool pr = map_eval_entry(L, ix.rl, o, info[u], pos2);
-				const u64 m = __ballot(pr);
-				if (!m) continue;
-				const u32 cnt = (u32) __popcll(m);
-				if (fill + cnt > WP_STAGE) {                   // (wave-uniform) flush
-					u32 base = 0;
-					if (lane == 0) base = atomicAdd(&pair_cnt[wi], fill);
-					base = (u32) __builtin_amdgcn_readlane((int) base, 0);
-					for (u32 i = (u32) lane; i < fill; i += 64) pairs[base + i] = mystg[i];
-					fill = 0;
+	{
+		const uint4* prow = prep + (size_t) wi * noff;
+		for (int o = tid; o < noff; o += MAP_THREADS) {
+			const uint4 p = prow[o];
+			const u32 cls = p.x;
+			if (cls != NONE32) {
+				const u32 pb = map_present_bit(cls);
+				atomicOr(&L.present[pb >> 5], 1u << (pb & 31));
+				u32 slot = (cls * 2654435761u) & (WT_SLOTS - 1);
+				for (;;) {
+					u32 cur = L.wt_key[slot];
+					if (cur == 0) {
+						cur = atomicCAS(&L.wt_key[slot], 0u, cls + 1);
+						if (cur == 0) cur = cls + 1;
+					}
+					if (cur == cls + 1) { atomicMax(&L.wt_last[slot], (u32) o + 1); break; }
+					slot = (slot + 1) & (WT_SLOTS - 1);
 				}
-				if (pr) {
-					mystg[fill + (u32) __popcll(m & ((1ull << lane) - 1ull))] = ((u64) info[u].x << 32) | ((u32) (o + 1) << 16) | pos2;
-					mine += info[u].x;
-				}
-				fill += cnt;
 			}
+			L.cstart[o] = p.y;
+			L.hpre[o] = p.z;
 		}
 	}
-	if (fill) {
-		u32 base = 0;
-		if (lane == 0) base = atomicAdd(&pair_cnt[wi], fill);
-		base = (u32) __builtin_amdgcn_readlane((int) base, 0);
-		for (u32 i = (u32) lane; i < fill; i += 64) pairs[base + i] = mystg[i];
+	__syncthreads();
+	if (tid < 64) {
+		const int per = (noff + 63) / 64;
+		const int a = (int) tid * per;
+		const int b2 = a + per < noff ? a + per : noff;
+		u32 sum = 0;
+		for (int o = a; o < b2; o++) sum += L.hpre[o];
+		const u32 incl = (u32) vdjx_wave_scan_add((int) sum);
+		u32 run = incl - sum;
+		for (int o = a; o < b2; o++) { const u32 sz = L.hpre[o]; L.hpre[o] = run; run += sz; }
+		if (tid == 63) L.hpre[noff] = incl;
 	}
+	__syncthreads();
+	const u32 H = L.hpre[noff];
+	const u32 h0 = (blockIdx.x - wstart[j]) * chunk, h1 = h0 + chunk < H ? h0 + chunk : H;
+	if (h0 >= h1) return;
+	const int lane = __lane_id();
+	const u32 wv = tid >> 6;
+	u64* pairs = pair_buf + pair_off[wi];
+	u32 qn = 0, mine = 0;                               // (qn: wave-uniform)
+	// the queued entries, 64 at a time with every lane busy: the full test (quick_map3.c:223-245) and the pairs out
+	auto drain = [&]() {
+		for (u32 q0 = 0; q0 < qn; q0 += 64) {
+			const u32 qi = q0 + (u32) lane;
+			bool pr = false;
+			u64 e = 0;
+			u32 pos2 = 0, o = 0;
+			if (qi < qn) {
+				e = q_ent[wv][qi]; o = q_off[wv][qi];
+				const u32 ca = ent_a(e), cb = ent_b(e);
+				const u32 la = ca != RI_ENT_NONE ? mapw_last_occurrence(L, ca) : 0u, lb = cb != RI_ENT_NONE ? mapw_last_occurrence(L, cb) : 0u;
+				if (la | lb) {
+					const u32 which = (lb && lb >= la) ? 1u : 0u;
+					const u32 best = which ? lb : la;
+					const u32 fl = ent_flags(e);
+					const u32 rc1 = (fl & RI_RC) ? 1u : 0u, rc2 = (fl & (which ? RI_RCB : RI_RCA)) ? 1u : 0u;
+					const int d = (int) (o + 1) - (int) best;
+					const int insert = (int) (short) ((d < 0 ? -d : d) + ix.rl);
+					pr = rc1 != rc2 && insert >= 50 && insert <= 400;          // quick_map3.c:227, 23-24
+					pos2 = best;
+				}
+			}
+			const u64 m = __ballot(pr);
+			if (m) {
+				u32 base = 0;
+				if (lane == 0) base = atomicAdd(&pair_cnt[wi], (u32) __popcll(m));
+				base = (u32) __builtin_amdgcn_readlane((int) base, 0);
+				if (pr) {
+					const u32 mult = ent_count(e);
+					pairs[base + (u32) __popcll(m & ((1ull << lane) - 1ull))] = ((u64) mult << 32) | ((o + 1) << 16) | pos2;
+					mine += mult;
+				}
+			}
+		}
+		qn = 0;
+	};
+	// The hits of the slice are one flat sequence (offset-major); a wave takes WP_K rows of 64 consecutive hits per round: WP_K
+	// loads in flight per lane whatever the class sizes (a round per OFFSET waited for memory 436 times per window).  98 % of the
+	// entries fail the presence test "is either mate class in the window at all?" (a V gene is shared by hundreds of clones): that
+	// test is all the sparse sweep does, straight-line; the few that pass are queued and finished 64 at a time (the rest of the
+	// test inline ran for one or two lanes of nearly every row: the kernel was bound by instruction issue).
+	for (;;) {
+		u32 hb = 0;
+		if (lane == 0) hb = atomicAdd(&s_next, 64u * WP_K);
+		hb = (u32) __builtin_amdgcn_readlane((int) hb, 0);
+		if (hb >= h1) break;
+		// the offset of every row's first hit: lanes 0 .. WP_K-1 search, one row each
+		int orow = 0;
+		{
+			const u32 hr = hb + (u32) lane * 64u;
+			if (lane < WP_K && hr < h1) {
+				int lo = 0, hi = noff;                      // last offset with hpre[o] <= hr
+				while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.hpre[mid] <= hr) lo = mid; else hi = mid; }
+				orow = lo;
+			}
+		}
+		u64 ent[WP_K];
+		u32 oo[WP_K / 2];                               // the hits' offsets, two per register
+#pragma unroll
+		for (int u = 0; u < WP_K; u++) {
+			const u32 h = hb + (u32) (u * 64 + lane);
+			int o = __builtin_amdgcn_readlane(orow, u);
+			u64 e = ~0ull;
+			if (h < h1) {
+				while (h >= L.hpre[o + 1]) o++;                 // (few steps: a row of 64 hits spans few classes; empty ones are skipped)
+				e = ix.d8[L.cstart[o] + (h - L.hpre[o])];
+			}
+			ent[u] = e;
+			if (u & 1) oo[u >> 1] |= (u32) o << 16; else oo[u >> 1] = (u32) o;
+		}
+#pragma unroll
+		for (int u = 0; u < WP_K; u++) {
+			if (hb + (u32) (u * 64) >= h1) break;                                // (wave-uniform)
+			// (a "none" class hashes to some bit like any other: a false positive the full test sorts out)
+			const u32 ba = map_present_bit(ent_a(ent[u])), bb = map_present_bit(ent_b(ent[u]));
+			const u32 wa = L.present[ba >> 5], wb = L.present[bb >> 5];
+			const bool pass = (((wa >> (ba & 31)) | (wb >> (bb & 31))) & 1u) && hb + (u32) (u * 64 + lane) < h1;
+			const u64 m = __ballot(pass);
+			if (!m) continue;
+			if (pass) {
+				const u32 at = qn + (u32) __popcll(m & ((1ull << lane) - 1ull));
+				q_ent[wv][at] = ent[u];
+				q_off[wv][at] = (unsigned short) ((oo[u >> 1] >> (16 * (u & 1))) & 0xFFFFu);
+			}
+			qn += (u32) __popcll(m);
+			if (qn > WP_Q - 64) drain();
+		}
+	}
+	drain();
 	mine = (u32) __builtin_amdgcn_readlane(vdjx_wave_scan_add((int) mine), 63);
 	if (lane == 0 && mine) atomicAdd(&pair_np[wi], mine);
 }
@@ -828,62 +1003,84 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 // many; the gather below lays the slices end to end, which is the reference's order (offset-major, registration order inside
 // a class).  One workgroup per contig left half the GPU idle and walked ~20 k hits sequentially.
 // ----------------------------------------------------------------------------------------------
-#define MAP_SLICE 4096u          // hits per slice at least ...
-#define MAP_SLICE_MAX 32768u     // ... and at most (map_emit_impl)
-// slice b belongs to the contig ci with slice_start[ci] <= b < slice_start[ci + 1] (the slices are never listed: a binary search
-// over the contigs' slice prefix replaces the work list the host used to build and upload)
-__device__ inline u32 slice_contig(const u32* __restrict__ slice_start, u32 n, u32 b) {
-	u32 lo = 0, hi = n;
-	while (hi - lo > 1) {
-		const u32 mid = (lo + hi) >> 1;
-		if (slice_start[mid] <= b) lo = mid; else hi = mid;
-	}
-	return lo;
-}
-
-__global__ __launch_bounds__(MAP_THREADS) void k_map_emit(ReadIndexDev ix, const char* __restrict__ contigs, u32 n, int len, u32 slice_hits,
+#define ME_K 8                    // rows of MAP_THREADS consecutive hits per round: 8 loads in flight per thread, one ordered compaction per round
+__global__ __launch_bounds__(MAP_THREADS) void k_map_emit(ReadIndexDev ix, const uint4* __restrict__ prep, u32 n, int len, u32 slice_hits,
                                                           const u32* __restrict__ slice_start, const u64* __restrict__ region_off,
                                                           vdjx_pair* __restrict__ pairs, u32* __restrict__ slice_cnt) {
 	__shared__ MapLds L;
-	__shared__ u32 s_base;
-	const u32 tid = threadIdx.x;
+	__shared__ u32 s_rows[ME_K][MAP_THREADS / 64];          // pairs per row and wave
+	const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
 	const int noff = len - ix.rl;
 	const u32 ci = slice_contig(slice_start, n, blockIdx.x);
 	const u32 w0 = (blockIdx.x - slice_start[ci]) * slice_hits;
 	vdjx_pair* out = pairs + region_off[ci] + w0;
-	const u32 H = map_prepare(L, ix, contigs + (size_t) ci * len, len);
+	const u32 H = map_load_prep(L, prep + (size_t) ci * noff, noff);
 	const u32 h1 = w0 + slice_hits < H ? w0 + slice_hits : H;
-	if (tid == 0) s_base = 0;
-	__syncthreads();
-	for (u32 h0 = w0; h0 < h1; h0 += MAP_THREADS) {
-		const u32 h = h0 + tid;
-		Hit r;
-		r.pair = false;
-		if (h < h1) r = map_eval_hit(L, ix, noff, h);
-		// ordered compaction: inclusive scan of the flags (wave ballots + one LDS word per wave)
-		const u64 m = __ballot(r.pair);
-		const u32 lane = tid & 63, wv = tid >> 6;
-		const u32 before = __popcll(m & ((1ull << lane) - 1ull));
-		if (lane == 0) L.scan[wv] = (u32) __popcll(m);
-		__syncthreads();
-		u32 wbase = 0, total = 0;
-		for (u32 i = 0; i < MAP_THREADS / 64; i++) {
-			const u32 v = L.scan[i];
-			if (i < wv) wbase += v;
-			total += v;
+	u32 done = 0;                                           // pairs written so far (uniform)
+	// thread-per-hit with ONE load in flight and three barriers per 512 hits was bound by memory latency; a round now covers ME_K rows
+	// of 512 consecutive hits: ME_K loads in flight per thread, then one ordered compaction (row-major = hit order) for all of them
+	for (u32 hb = w0; hb < h1; hb += MAP_THREADS * ME_K) {
+		// the offset of the first hit of this wave's piece of every row: lanes 0 .. ME_K-1 search
+		int orow = 0;
+		{
+			const u32 hr = hb + lane * MAP_THREADS + wv * 64u;
+			if (lane < ME_K && hr < h1) {
+				int lo = 0, hi = noff;                      // last o with hpre[o] <= hr
+				while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.hpre[mid] <= hr) lo = mid; else hi = mid; }
+				orow = lo;
+			}
 		}
-		const u32 base = s_base;
-		if (r.pair) {
-			vdjx_pair* o = out + base + wbase + before;
-			o->pair_id = r.pair_id; o->rec1 = r.rec1; o->rec2 = ix.pair_r2[2 * (size_t) r.pair_id + r.which];
-			o->pos1 = (int16_t) r.pos1; o->pos2 = (int16_t) r.pos2; o->insert = (int16_t) r.insert;
-			o->rc1 = r.rc1; o->rc2 = r.rc2;
+		u64 ent[ME_K];
+		u32 cix[ME_K], oo[ME_K / 2];
+#pragma unroll
+		for (int u = 0; u < ME_K; u++) {
+			const u32 h = hb + (u32) u * MAP_THREADS + tid;
+			int o = __builtin_amdgcn_readlane(orow, u);
+			u64 e = ~0ull;
+			u32 ci2 = 0;
+			if (h < h1) {
+				while (h >= L.hpre[o + 1]) o++;
+				ci2 = L.cstart[o] + (h - L.hpre[o]);
+				e = ix.csr8[ci2];
+			}
+			ent[u] = e; cix[u] = ci2;
+			if (u & 1) oo[u >> 1] |= (u32) o << 16; else oo[u >> 1] = (u32) o;
+		}
+		u32 prm = 0, whm = 0, pos2s[ME_K], before[ME_K];
+#pragma unroll
+		for (int u = 0; u < ME_K; u++) {
+			const int o = (int) ((oo[u >> 1] >> (16 * (u & 1))) & 0xFFFFu);
+			u32 pos2 = 0, which = 0;
+			const bool pr = map_eval_entry(L, ix.rl, o, ent[u], pos2, which);
+			const u64 m = __ballot(pr);
+			prm |= (pr ? 1u : 0u) << u; whm |= which << u;
+			pos2s[u] = pos2;
+			before[u] = (u32) __popcll(m & ((1ull << lane) - 1ull));
+			if (lane == 0) s_rows[u][wv] = (u32) __popcll(m);
 		}
 		__syncthreads();
-		if (tid == 0) s_base = base + total;
+		u32 run = done;
+#pragma unroll
+		for (int u = 0; u < ME_K; u++) {
+			u32 wbase = 0, total = 0;
+			for (u32 i = 0; i < MAP_THREADS / 64; i++) { const u32 v = s_rows[u][i]; if (i < wv) wbase += v; total += v; }
+			if ((prm >> u) & 1u) {
+				const int o = (int) ((oo[u >> 1] >> (16 * (u & 1))) & 0xFFFFu);
+				const u32 which = (whm >> u) & 1u, ci2 = cix[u];
+				const u32 pid = ix.csr_pair[ci2];
+				const u32 fl = ent_flags(ent[u]);
+				const int d = (o + 1) - (int) pos2s[u];
+				vdjx_pair* q = out + run + wbase + before[u];
+				q->pair_id = pid; q->rec1 = ix.recs[ci2]; q->rec2 = ix.pair_r2[2 * (size_t) pid + which];
+				q->pos1 = (int16_t) (o + 1); q->pos2 = (int16_t) pos2s[u]; q->insert = (int16_t) ((d < 0 ? -d : d) + ix.rl);
+				q->rc1 = (fl & RI_RC) ? 1 : 0; q->rc2 = (fl & (which ? RI_RCB : RI_RCA)) ? 1 : 0;
+			}
+			run += total;
+		}
+		done = run;
 		__syncthreads();
 	}
-	if (tid == 0) slice_cnt[blockIdx.x] = s_base;
+	if (tid == 0) slice_cnt[blockIdx.x] = done;
 }
 
 // exclusive u64 prefix of the slice counts (one workgroup) and, from it, the pairs of every contig
@@ -927,18 +1124,16 @@ static int make_index_view(vdjx_ctx* c, ReadIndexDev* ix, int len, const char* w
 	const vdjx_pool* p = c->ri_pool;
 	if (len <= p->rl) { vdjx_set_error("%s: len=%d must exceed the read length %d", who, len, p->rl); return VDJX_EINVAL; }
 	if (len - p->rl > MAP_MAXOFF) { vdjx_set_error("%s: len=%d too long (max %d)", who, len, MAP_MAXOFF + p->rl); return VDJX_ELIMIT; }
-	ix->bases = p->d_bases;
-	ix->slots = c->d_ri_slots; ix->mask = c->ri_nslots - 1;
-	ix->rep = c->d_ri_rep; ix->start = c->d_ri_start; ix->cnt1 = c->d_ri_cnt1; ix->recs = c->d_ri_recs;
-	ix->csr_info = c->d_rec_info; ix->pair_r2 = c->d_pair_r2;
-	ix->dstart = c->d_ri_dstart; ix->dinfo = c->d_ri_dinfo;
+	ix->tab = (const uint4*) c->d_ri_tab; ix->mask = c->ri_tab_mask;
+	ix->start = c->d_ri_start; ix->cnt1 = c->d_ri_cnt1; ix->recs = c->d_ri_recs;
+	ix->csr8 = c->d_ri_csr8; ix->csr_pair = c->d_ri_csr_pair; ix->pair_r2 = c->d_pair_r2;
+	ix->dstart = c->d_ri_dstart; ix->d8 = c->d_ri_d8;
 	ix->rl = p->rl;
 	return VDJX_OK;
 }
 
-// largest-first processing order without a comparison sort: by descending bit length of the size (64 counting buckets; inside a
-// bucket sizes differ by less than 2x, which is all the tail of a launch cares about).  A stable_sort of 20,000 windows through
-// an index indirection cost more host time than the coverage kernel ran.
+// largest-first processing order without a comparison sort: by descending bit length of the size (host version: vdjx_window_cover,
+// whose list sizes arrive as host numbers)
 static void order_by_size_desc(const std::vector<u64>& off, size_t n, std::vector<u32>& order) {
 	order.resize(n);
 	u32 cnt[66] = {0};
@@ -948,51 +1143,47 @@ static void order_by_size_desc(const std::vector<u64>& off, size_t n, std::vecto
 	for (size_t i = 0; i < n; i++) order[cnt[64 - key(i)]++] = (u32) i;
 }
 
-// hits per string, exclusive offsets, and the largest-first processing order
-static int plan_windows(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, const char* d_w, size_t n, int len, bool weighted,
-                        std::vector<u64>& off, u32** d_order, u64** d_off, u64* inst_total = nullptr, u64* inst_max = nullptr,
-                        std::vector<u32>* order_out = nullptr) {
+// the strings on the device, classified (k_map_classify) and planned (k_plan); the plan's totals come back through the context's
+// page-locked scratch: the one host wait of a scorer call before its result
+struct MapPlan {
+	uint4* d_prep = nullptr;
+	u64* d_off = nullptr;
+	u32 *d_order = nullptr, *d_wstart = nullptr;
+	PlanOut tot{};
+};
+static int classify_and_plan(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, const char* strings, size_t n, int len, bool weighted,
+                             u32 chunk_fixed, MapPlan* mp) {
 	hipStream_t st = c->stream;
 	vdjx_laps lp(c);
+	const int noff = len - ix.rl;
+	char* d_s;
 	u32 *d_hits, *d_inst;
+	PlanOut* d_tot;
+	HIP_TRY(db.alloc(&d_s, n * len));
+	HIP_TRY(db.alloc(&mp->d_prep, n * (size_t) noff));
 	HIP_TRY(db.alloc(&d_hits, n));
 	HIP_TRY(db.alloc(&d_inst, n));
+	HIP_TRY(db.alloc(&mp->d_off, n + 1));
+	HIP_TRY(db.alloc(&mp->d_order, n));
+	HIP_TRY(db.alloc(&mp->d_wstart, n + 1));
+	HIP_TRY(db.alloc(&d_tot, 1));
+	HIP_TRY(hipMemcpyAsync(d_s, strings, n * len, hipMemcpyHostToDevice, st));
 	{
-		vdjx_prof_scope ps(c, "k_window_hits");
-		hipLaunchKernelGGL(k_window_hits, dim3((u32) std::min<size_t>(n, 4096)), dim3(MAP_THREADS), 0, st, ix, d_w, (u32) n, len, weighted, d_hits, d_inst);
+		vdjx_prof_scope ps(c, "k_map_classify");
+		hipLaunchKernelGGL(k_map_classify, dim3((u32) std::min<size_t>(n, 8192)), dim3(MAP_THREADS), 0, st, ix, d_s, (u32) n, len, weighted, mp->d_prep, d_hits, d_inst);
 	}
-	// hit counts down, order and offsets up through ONE page-locked scratch buffer (pageable vectors cost a staging copy each way)
-	const size_t need = n * 4 * 3 + (n + 1) * 8 + 64;
-	if (need > c->h_plan_cap) {
-		if (c->h_plan) (void) hipHostFree(c->h_plan);
-		c->h_plan = nullptr; c->h_plan_cap = 0;
-		HIP_TRY(hipHostMalloc(&c->h_plan, need + need / 2, hipHostMallocDefault));
-		c->h_plan_cap = need + need / 2;
+	hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, d_hits, d_inst, (u32) n, chunk_fixed, weighted ? 1 : 0, weighted ? 1 : 0, mp->d_off, mp->d_order, mp->d_wstart, d_tot);
+	if (!c->h_plan) {
+		HIP_TRY(hipHostMalloc(&c->h_plan, 256, hipHostMallocDefault));
+		c->h_plan_cap = 256;
 	}
-	u64* h_off = (u64*) c->h_plan;
-	u32* hits = (u32*) (h_off + n + 1);
-	u32* inst = hits + n;
-	u32* h_order = inst + n;
-	HIP_TRY(hipMemcpyAsync(hits, d_hits, n * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(inst, d_inst, n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(c->h_plan, d_tot, sizeof(PlanOut), hipMemcpyDeviceToHost, st));
+	lp.mark("plan_issue");
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
-	lp.mark("plan_hits_wait");
-	if (inst_total) { *inst_total = 0; for (size_t i = 0; i < n; i++) *inst_total += inst[i]; }
-	if (inst_max) { *inst_max = 0; for (size_t i = 0; i < n; i++) *inst_max = std::max<u64>(*inst_max, inst[i]); }
-	off.assign(n + 1, 0);
-	for (size_t i = 0; i < n; i++) off[i + 1] = off[i] + hits[i];
-	std::vector<u32> order;
-	order_by_size_desc(off, n, order);
-	if (order_out) *order_out = order;
-	memcpy(h_order, order.data(), n * 4);
-	memcpy(h_off, off.data(), (n + 1) * 8);
-	HIP_TRY(db.alloc(d_order, n));
-	HIP_TRY(db.alloc(d_off, n + 1));
-	HIP_TRY(hipMemcpyAsync(*d_order, h_order, n * 4, hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(*d_off, h_off, (n + 1) * 8, hipMemcpyHostToDevice, st));
-	// (no wait: the scratch is rewritten by the next plan only, and every caller waits for the stream before it returns)
-	lp.mark("plan_order_upload");
+	lp.mark("plan_wait");
+	mp->tot = *(const PlanOut*) c->h_plan;
+	if (mp->tot.total_hits >= (1ull << 40)) { vdjx_set_error("too many hits in one scorer call (%llu)", (unsigned long long) mp->tot.total_hits); return VDJX_ELIMIT; }
 	return VDJX_OK;
 }
 
@@ -1008,63 +1199,37 @@ static int cov_params_check(const vdjx_cov_params* p, const char* who) {
 	return VDJX_OK;
 }
 
-// K8 over n windows: the (weighted) mapped-pair list of every window in the context's pair buffer (c->wp_*); the list of window i
-// is wp_buf[wp_off[i] .. + wp_cnt[i])
+// K8 over n windows: the (weighted) mapped-pair list of every window in the context's pair buffer; the list of window i
+// is wp_buf[d_off[i] .. + d_cnt[i])
 static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, const char* windows, size_t n, int len, u32** d_np_out,
-                            u32** d_cnt_out, u64** d_off_out, u32** d_order_out) {
+                            u32** d_cnt_out, MapPlan* mp) {
 	hipStream_t st = c->stream;
-	char* d_w;
-	u32 *d_np, *d_order, *d_cnt;
-	u64* d_off;
-	vdjx_laps lp(c);
-	HIP_TRY(db.alloc(&d_w, n * len));
-	HIP_TRY(db.alloc(&d_np, n));
-	HIP_TRY(hipMemcpyAsync(d_w, windows, n * len, hipMemcpyHostToDevice, st));
-	lp.mark("wp_upload");
-	std::vector<u64>& off = c->wp_off;
-	u64 inst_total = 0, inst_max = 0;
-	std::vector<u32> ord;
-	int rc = plan_windows(c, db, ix, d_w, n, len, true, off, &d_order, &d_off, &inst_total, &inst_max, &ord);
+	u32 *d_np, *d_cnt;
+	static const u32 hit_chunk = getenv("VDJX_HIT_CHUNK") && atol(getenv("VDJX_HIT_CHUNK")) > 0 ? (u32) atol(getenv("VDJX_HIT_CHUNK")) : HIT_CHUNK;
+	int rc = classify_and_plan(c, db, ix, windows, n, len, true, hit_chunk, mp);
 	if (rc) return rc;
-	lp.mark("wp_plan");
-	if ((size_t) off[n] + 1 > c->wp_cap) {
+	const u64 total = mp->tot.total_hits;
+	if ((size_t) total + 1 > c->wp_cap) {
 		free_set(c->wp_buf);
 		c->wp_cap = 0;
-		const size_t want = (size_t) off[n] + (size_t) off[n] / 4 + 1024;
+		const size_t want = (size_t) total + (size_t) total / 4 + 1024;
 		HIP_TRY(hipMalloc(&c->wp_buf, want * 8));
 		c->wp_cap = want;
 	}
+	HIP_TRY(db.alloc(&d_np, n));
 	HIP_TRY(db.alloc(&d_cnt, n));
-	c->stats["window_hits"] = inst_total;                 // read-1 instances matched (what the reference enumerates one by one)
-	c->stats["window_hits_max"] = inst_max;
-	c->stats["window_hits_distinct"] = off[n];             // weighted entries actually evaluated
-	// work list: deep windows are cut into slices of HIT_CHUNK hits (largest windows first)
-	std::vector<uint4> work;
-	{
-		static const u32 hit_chunk = getenv("VDJX_HIT_CHUNK") && atol(getenv("VDJX_HIT_CHUNK")) > 0 ? (u32) atol(getenv("VDJX_HIT_CHUNK")) : HIT_CHUNK;
-		for (u32 wi : ord) {
-			const u32 H = (u32) (off[wi + 1] - off[wi]);
-			for (u32 h0 = 0; h0 < H || h0 == 0; h0 += hit_chunk) {
-				work.push_back(make_uint4(wi, h0, std::min(H, h0 + hit_chunk), 0));
-				if (H == 0) break;
-			}
-		}
-	}
-	uint4* d_work;
-	lp.mark("wp_worklist");
-	HIP_TRY(db.alloc(&d_work, work.size()));
-	HIP_TRY(hipMemcpyAsync(d_work, work.data(), work.size() * sizeof(uint4), hipMemcpyHostToDevice, st));
-	lp.mark("wp_work_upload");
+	c->stats["window_hits"] = mp->tot.inst_total;          // read-1 instances matched (what the reference enumerates one by one)
+	c->stats["window_hits_max"] = mp->tot.inst_max;
+	c->stats["window_hits_distinct"] = total;              // weighted entries actually evaluated
+	c->stats["window_work_items"] = mp->tot.nwork;
 	HIP_TRY(hipMemsetAsync(d_np, 0, n * 4, st));
 	HIP_TRY(hipMemsetAsync(d_cnt, 0, n * 4, st));
-	{
+	if (mp->tot.nwork) {
 		vdjx_prof_scope ps(c, "k_window_pairs");
-		hipLaunchKernelGGL(k_window_pairs, dim3((u32) work.size()), dim3(MAP_THREADS), 0, st, ix, d_w, len, d_work, d_off, (u64*) c->wp_buf, d_cnt, d_np);
+		hipLaunchKernelGGL(k_window_pairs, dim3(mp->tot.nwork), dim3(MAP_THREADS), 0, st, ix, mp->d_prep, (u32) n, len, mp->tot.chunk, mp->d_order, mp->d_wstart,
+		                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np);
 	}
-	HIP_TRY(hipStreamSynchronize(st));       // `work` staging dies with this frame
-	lp.mark("wp_kernel_wait");
-	c->stats["window_work_items"] = work.size();
-	*d_np_out = d_np; *d_cnt_out = d_cnt; *d_off_out = d_off; *d_order_out = d_order;
+	*d_np_out = d_np; *d_cnt_out = d_cnt;
 	return VDJX_OK;
 }
 
@@ -1081,16 +1246,16 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	vdjx_clear_errors();
 	hipStream_t st = c->stream;
 	vdjx_work db(c);
-	u32 *d_np, *d_order, *d_cnt;
-	u64* d_off;
+	u32 *d_np, *d_cnt;
 	uint8_t* d_valid;
+	MapPlan mp;
 	HIP_TRY(db.alloc(&d_valid, n));
-	rc = window_pairs_run(c, db, ix, windows, n, len, &d_np, &d_cnt, &d_off, &d_order);
+	rc = window_pairs_run(c, db, ix, windows, n, len, &d_np, &d_cnt, &mp);
 	if (rc) return rc;
 	c->wp_n = 0;                                              // (the lists are not offered to vdjx_window_pairs_fetch)
 	{
 		vdjx_prof_scope ps(c, "k_window_cover");
-		hipLaunchKernelGGL(k_window_cover, dim3((u32) n), dim3(MAP_THREADS), 0, st, len, ix.rl, *p, d_order, d_off, (const u64*) c->wp_buf, d_cnt, d_valid, (u64*) nullptr);
+		hipLaunchKernelGGL(k_window_cover, dim3((u32) n), dim3(MAP_THREADS), 0, st, len, ix.rl, *p, mp.d_order, mp.d_off, (const u64*) c->wp_buf, d_cnt, d_valid, (u64*) nullptr);
 	}
 	HIP_TRY(hipMemcpyAsync(out_valid, d_valid, n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
@@ -1099,7 +1264,6 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	HIP_TRY(hipGetLastError());
 	lp.mark("ws_cover_wait");
 	vdjx_prof_collect(c);
-	lp.mark("ws_prof_collect");
 	{
 		u64 tot = 0;
 		for (size_t i = 0; i < n; i++) tot += out_npairs[i];
@@ -1123,12 +1287,14 @@ extern "C" int vdjx_window_pairs(vdjx_ctx* c, const char* windows, size_t n, int
 	vdjx_clear_errors();
 	hipStream_t st = c->stream;
 	vdjx_work db(c);
-	u32 *d_np, *d_order, *d_cnt;
-	u64* d_off;
-	rc = window_pairs_run(c, db, ix, windows, n, len, &d_np, &d_cnt, &d_off, &d_order);
+	u32 *d_np, *d_cnt;
+	MapPlan mp;
+	rc = window_pairs_run(c, db, ix, windows, n, len, &d_np, &d_cnt, &mp);
 	if (rc) return rc;
 	c->wp_cnt.resize(n);
+	c->wp_off.resize(n + 1);
 	HIP_TRY(hipMemcpyAsync(c->wp_cnt.data(), d_cnt, n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(c->wp_off.data(), mp.d_off, (n + 1) * 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
@@ -1226,7 +1392,8 @@ extern "C" int vdjx_window_cover(vdjx_ctx* c, size_t n, int len, int rl, const v
 }
 
 // identity of a contig batch between the counting and the writing call of vdjx_map_emit: FNV-1a over its head, its tail and a
-// sparse sample in between (hashing every byte of a few MB twice per call cost more than the mapping kernel)
+// sparse sample in between (hashing every byte of a few MB twice per call cost more than the mapping kernel).  Only a guard: the
+// counting call always maps afresh, and a writing call that does not follow the counting call of the same batch maps again.
 static uint64_t fnv1a(const char* p, size_t n, uint64_t h) {
 	auto eat = [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) { h ^= (unsigned char) p[i]; h *= 0x100000001b3ull; } };
 	if (n <= 4096) { eat(0, n); return h; }
@@ -1253,39 +1420,24 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 	if (!key) key = 1;
 	lp.mark("me_key");
 	static const u32 slice_env = getenv("VDJX_MAP_SLICE") && atol(getenv("VDJX_MAP_SLICE")) > 0 ? (u32) atol(getenv("VDJX_MAP_SLICE")) : 0u;
-	if (c->me_key != key || c->me_cnt.size() != n) {
+	if (!pairs) c->me_key = 0;               // a counting call never reuses an earlier mapping
+	if (c->me_key != key || c->me_cnt.size() != n || c->me_src != (const void*) contigs) {
 		c->me_key = 0;
-		char* d_c;
-		u32* d_order;
-		u64* d_off;
-		HIP_TRY(db.alloc(&d_c, n * len));
-		HIP_TRY(hipMemcpyAsync(d_c, contigs, n * len, hipMemcpyHostToDevice, st));
-		std::vector<u64> off;
-		rc = plan_windows(c, db, ix, d_c, n, len, false, off, &d_order, &d_off);
+		MapPlan mp;
+		rc = classify_and_plan(c, db, ix, contigs, n, len, false, slice_env, &mp);
 		if (rc) return rc;
 		lp.mark("me_plan");
-		if (off[n] > c->me_cap) {
+		const u64 total_hits = mp.tot.total_hits;
+		if (total_hits > c->me_cap) {
 			free_set(c->me_pairs);
 			c->me_cap = 0;
-			HIP_TRY(hipMalloc(&c->me_pairs, (size_t) off[n] * sizeof(vdjx_pair)));
-			c->me_cap = (size_t) off[n];
+			HIP_TRY(hipMalloc(&c->me_pairs, (size_t) total_hits * sizeof(vdjx_pair)));
+			c->me_cap = (size_t) total_hits;
 		}
-		// slices of `slice_hits` hits, contig after contig: only their prefix over the contigs goes to the device.  Every slice pays
-		// one preparation of its contig (a few hundred index probes): as long as the slices are, while ~8 k of them remain
-		u32 slice_hits = slice_env;
-		if (!slice_hits) {
-			slice_hits = MAP_SLICE;
-			while (slice_hits < MAP_SLICE_MAX && off[n] / (slice_hits * 2) >= 8192) slice_hits *= 2;
-		}
+		const u32 slice_hits = mp.tot.chunk;
+		const size_t nsl = mp.tot.nwork;
 		c->me_slice_hits = slice_hits;
-		std::vector<u32> sstart(n + 1, 0);
-		for (size_t ci = 0; ci < n; ci++) {
-			const u64 sl = (off[ci + 1] - off[ci] + slice_hits - 1) / slice_hits;
-			if (sstart[ci] + sl >= (1ull << 31)) { vdjx_set_error("vdjx_map_emit: too many hit slices"); return VDJX_ELIMIT; }
-			sstart[ci + 1] = sstart[ci] + (u32) sl;
-		}
-		const size_t nsl = sstart[n];
-		// persistent bookkeeping: slice prefix of the contigs, hit offsets of the contigs, pairs per slice and their prefix
+		// persistent bookkeeping: hit offsets of the contigs, pairs per slice and their prefix, pairs per contig, slice prefix of the contigs
 		const size_t need = (n + 1) * 4 + 8 + (n + 1) * 8 + nsl * 4 + 8 + (nsl + 1) * 8 + n * 8 + 64;
 		if (need > c->me_book_cap) {
 			free_set(c->me_book);
@@ -1301,23 +1453,23 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 		u32* b_scnt = (u32*) bk;
 		c->me_nsl = nsl;
 		c->me_cnt.assign(n, 0);
-		HIP_TRY(hipMemcpyAsync(b_sstart, sstart.data(), (n + 1) * 4, hipMemcpyHostToDevice, st));
-		HIP_TRY(hipMemcpyAsync(b_off, d_off, (n + 1) * 8, hipMemcpyDeviceToDevice, st));
-		lp.mark("me_worklist");
+		HIP_TRY(hipMemcpyAsync(b_sstart, mp.d_wstart, (n + 1) * 4, hipMemcpyDeviceToDevice, st));
+		HIP_TRY(hipMemcpyAsync(b_off, mp.d_off, (n + 1) * 8, hipMemcpyDeviceToDevice, st));
 		if (nsl) {
 			{
 				vdjx_prof_scope ps(c, "k_map_emit");
-				hipLaunchKernelGGL(k_map_emit, dim3((u32) nsl), dim3(MAP_THREADS), 0, st, ix, d_c, (u32) n, len, slice_hits, b_sstart, b_off, (vdjx_pair*) c->me_pairs, b_scnt);
+				hipLaunchKernelGGL(k_map_emit, dim3((u32) nsl), dim3(MAP_THREADS), 0, st, ix, mp.d_prep, (u32) n, len, slice_hits, b_sstart, b_off, (vdjx_pair*) c->me_pairs, b_scnt);
 			}
 			hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, st, b_scnt, (u32) nsl, b_pre);
 			hipLaunchKernelGGL(k_contig_counts, dim3((u32) (n + 255) / 256), dim3(256), 0, st, b_pre, b_sstart, (u32) n, b_cnt);
 			HIP_TRY(hipMemcpyAsync(c->me_cnt.data(), b_cnt, n * 8, hipMemcpyDeviceToHost, st));
 		}
-		HIP_TRY(hipStreamSynchronize(st));           // (also: `sstart` staging dies with this frame)
+		HIP_TRY(hipStreamSynchronize(st));
 		HIP_TRY(hipGetLastError());
 		lp.mark("me_kernel_wait");
 		c->me_key = key;
-		c->stats["map_hits"] = off[n];
+		c->me_src = (const void*) contigs;
+		c->stats["map_hits"] = total_hits;
 	}
 	offsets[0] = 0;
 	for (size_t i = 0; i < n; i++) offsets[i + 1] = offsets[i] + c->me_cnt[i];
