@@ -527,9 +527,7 @@ def main():
         del host_fwd["pri"], host_fwd["sec"]
     laps = None
     if os.environ.get("VDJX_LAPS"):          # (diagnostic: host-side microseconds per step inside the scorer calls, vdjx_common.h vdjx_laps)
-        names = ("plan_hits_wait", "plan_order_upload", "wp_upload", "wp_plan", "wp_worklist", "wp_work_upload", "wp_kernel_wait", "ws_cover_wait",
-                 "ws_prof_collect", "me_key", "me_plan", "me_worklist", "me_work_upload", "me_kernel_wait", "me_second_call", "me_prev_copy_wait",
-                 "me_move_list", "me_move_upload", "me_gather_wait", "me_copy_issue")
+        names = ("plan_issue", "plan_wait", "ws_cover_wait", "me_key", "me_plan", "me_kernel_wait", "me_second_call", "me_prev_copy_wait", "me_copy_issue")
         laps = {n_: round(ctx.stat("us_" + n_) / (args.warmup + args.steps), 1) for n_ in names}
     stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_hits_distinct", "window_pairs", "window_work_items", "map_hits", "root_dp_items", "recount_items", "recount_instances", "gated_instances")}
     if world > 1:

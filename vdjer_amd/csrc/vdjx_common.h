@@ -121,7 +121,8 @@ struct vdjx_ctx {
 	// cached result of the last vdjx_map_emit count call (the write call of the two-call protocol reuses it)
 	uint64_t me_key = 0;
 	const void* me_src = nullptr;     // the batch the cached mapping belongs to
-	void* me_pairs = nullptr;         // vdjx_pair[me_cap], per-contig regions at me_hoff
+	void* me_pairs = nullptr;         // vdjx_pair[me_cap], per-contig regions at the contigs' hit offsets
+	void* me_hit = nullptr;           // u32[me_cap]: the hit (inside its slice) every stored pair belongs to
 	size_t me_cap = 0;
 	// the (weighted) mapped-pair lists of the last window batch: (multiplicity << 32 | pos1 << 16 | pos2), window i at wp_off[i]
 	void* wp_buf = nullptr;

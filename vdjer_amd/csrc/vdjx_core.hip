@@ -102,7 +102,7 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	free_dev(c->d_vtext); free_dev(c->d_line_off); free_dev(c->d_seed_code); free_dev(c->d_seed_pos);
 	free_dev(c->d_ri_tab); free_dev(c->d_ri_start); free_dev(c->d_ri_recs); free_dev(c->d_ri_csr8); free_dev(c->d_ri_csr_pair);
 	free_dev(c->d_pair_r2);
-	free_dev(c->me_pairs); free_dev(c->me_dense); free_dev(c->me_book); free_dev(c->wp_buf); free_dev(c->d_ri_cnt1); free_dev(c->d_ri_dstart); free_dev(c->d_ri_d8);
+	free_dev(c->me_pairs); free_dev(c->me_hit); free_dev(c->me_dense); free_dev(c->me_book); free_dev(c->wp_buf); free_dev(c->d_ri_cnt1); free_dev(c->d_ri_dstart); free_dev(c->d_ri_d8);
 	for (int i = 0; i < 2; i++) { free_dev(c->d_stage[i]); if (c->ev_copied[i]) (void) hipEventDestroy(c->ev_copied[i]); if (c->ev_packed[i]) (void) hipEventDestroy(c->ev_packed[i]); }
 	c->arena.release();
 	c->shard_arena.release();
@@ -233,56 +233,49 @@ extern "C" int vdjx_profile_get(vdjx_ctx* c, int idx, const char** name, double*
 // ----------------------------------------------------------------------------------------------
 // K1 pool_pack: ASCII records -> 2-bit bases + masks + quality bytes
 //   replaces the record parsing of A2:380-394 (layout written by bam_read.c:206-244)
-//   One 256-thread workgroup stages 256 records (<= 33 KB) through LDS with 16-byte coalesced
-//   loads; thread t then packs record t.  HBM-bound: reads 2*rl+1 B, writes 32 B + qstride per record.
+//   One 256-thread workgroup stages 256 records through LDS with 16-byte coalesced loads; thread t then packs record t
+//   FOUR CHARACTERS AT A TIME: aligned 32-bit LDS words funnelled to the record's own alignment (v_alignbyte), the four base
+//   codes / not-ACGT flags / Phred<20 flags of a word by byte-parallel arithmetic, the quality bytes handed back through LDS so
+//   that the quality rows leave as whole 16-byte lanes on consecutive addresses.  (One thread walking its record byte by byte --
+//   170 one-byte LDS reads per record -- ran at 0.24 of the HBM rate.)  HBM-bound: reads 2*rl+1 B, writes 32 B + qstride per record.
 // ----------------------------------------------------------------------------------------------
 #define PACK_RECS 256
+#define SW_H 0x80808080u
+// bit 7 of every byte of x that is zero
+__device__ inline u32 sw_zero_bytes(u32 x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & SW_H; }
+// bits 7, 15, 23, 31 -> bits 0..3
+__device__ inline u32 sw_gather4(u32 m) { m >>= 7; return (m | (m >> 7) | (m >> 14) | (m >> 21)) & 0xFu; }
 
-// one ASCII record in LDS -> the packed record g.  REV: the reverse-complement record add_to_buffer writes after every read
-// (bam_read.c:232-243: bases complemented in reverse order, qualities reversed) derived on the chip instead of crossing PCIe
-template <bool REV>
-__device__ inline u32 pack_one(const uint8_t* r, int rl, size_t g, u64* __restrict__ bases, u64* __restrict__ nmask, u64* __restrict__ lowq,
-                               uint8_t* __restrict__ quals, int qstride) {
-	u128 b = 0;
-	u64 nm = 0, lq = 0;
-	u32 other = 0;                       // bases that are neither ACGT nor N (the BAM alphabet "=ACMGRSVTWYHKDBN", bam_read.c:52)
-	for (int i = 0; i < rl; i++) {
-		const int si = REV ? rl - 1 - i : i;
-		const u32 ch = r[1 + si];
-		// seq_to_kmer.c:6-29: A0 T1 C2 G3.  Branch-free: bits 1-2 of the ASCII code tell A(00) C(01) T(10) G(11) apart
-		u32 code = (0xD8u >> (((ch >> 1) & 3u) * 2u)) & 3u;                  // 00->0, 01->2, 10->1, 11->3
-		if (REV) code ^= 1u;                                                // complement: A<->T (0<->1), C<->G (2<->3)
-		const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
-		other += (!acgt && ch != 'N') ? 1u : 0u;
-		nm |= (u64) (!acgt) << i;
-		b = (b << 2) | (acgt ? code : 0u);
-		const u32 q = (u32) (uint8_t) (r[1 + rl + si] - 33);                 // phred33(), A2:150-152
-		lq |= (u64) (q < 20u) << i;                                          // MIN_BASE_QUALITY, A2:76,252
-	}
-	((ulonglong2*) bases)[g] = make_ulonglong2((u64) (b >> 64), (u64) b);
-	nmask[g] = nm;
-	lowq[g] = lq;
-	// quality rows: qstride (a multiple of 16) bytes per record, written as 16-byte stores
-	const uint8_t* qs = r + 1 + rl;
-	uint4* qd = (uint4*) (quals + g * (size_t) qstride);
-	for (int v4 = 0; v4 < qstride / 16; v4++) {
-		u32 wds[4];
-#pragma unroll
-		for (int wd = 0; wd < 4; wd++) {
-			u32 x = 0;
-#pragma unroll
-			for (int bt = 0; bt < 4; bt++) {
-				const int i = v4 * 16 + wd * 4 + bt;
-				x |= (u32) (i < rl ? qs[REV ? rl - 1 - i : i] : 33) << (8 * bt);
-			}
-			wds[wd] = x;
-		}
-		qd[v4] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
-	}
-	return other;
+// four bases (byte 0 first): codes as 8 bits, first base most significant (seq_to_kmer.c:6-29: A0 T1 C2 G3; anything else 0), and
+// the flags "not ACGT" / "neither ACGT nor N" (bit 7 per byte)
+__device__ inline u32 sw_base_codes(u32 w, u32& not_acgt, u32& other) {
+	const u32 acgt = sw_zero_bytes(w ^ 0x41414141u) | sw_zero_bytes(w ^ 0x43434343u) | sw_zero_bytes(w ^ 0x47474747u) | sw_zero_bytes(w ^ 0x54545454u);
+	not_acgt = ~acgt & SW_H;
+	other = not_acgt & ~sw_zero_bytes(w ^ 0x4E4E4E4Eu);
+	const u32 x = (w >> 1) & 0x03030303u;                               // bits 1-2 of the ASCII code: A0 C1 T2 G3
+	u32 code = ((x & 0x01010101u) << 1) | ((x >> 1) & 0x01010101u);     // swap C and T
+	code &= (acgt >> 7) * 3u;
+	return (code * 0x40100401u) >> 24;                                  // byte i's two bits -> bits 7-2i, 6-2i
+}
+// four quality characters: bit 7 per byte where (uint8)(q - 33) < 20 (phred33, A2:150-152; MIN_BASE_QUALITY, A2:76,252)
+__device__ inline u32 sw_low_quality(u32 w) {
+	const u32 z = ((w | SW_H) - 0x21212121u) ^ ((w ^ ~0x21212121u) & SW_H);     // byte-wise w - 33
+	return ~(((z & 0x7F7F7F7Fu) + 0x6C6C6C6Cu) | z) & SW_H;
+}
+// every bit of x between zeros: bit i -> bit 2i
+__device__ inline u64 sw_spread32(u32 v) {
+	u64 x = v;
+	x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+	x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+	x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+	x = (x | (x << 2)) & 0x3333333333333333ull;
+	x = (x | (x << 1)) & 0x5555555555555555ull;
+	return x;
 }
 
-// FWD: `ascii` holds the reads as extracted only; packed records 2i (as is) and 2i+1 (reverse complement) come out of read i
+// FWD: `ascii` holds the reads as extracted only; packed records 2i (as is) and 2i+1 (the reverse complement add_to_buffer writes
+// after every read, bam_read.c:232-243: bases complemented in reverse order, qualities reversed) come out of read i, the second one
+// from the PACKED first one (bit reversal, no second pass over the characters)
 template <bool FWD>
 __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restrict__ ascii, size_t n_rec, int rl, size_t rec0,
                                                          u64* __restrict__ bases, u64* __restrict__ nmask,
@@ -290,26 +283,131 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
                                                          u32* __restrict__ bad_strand) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const int reclen = 2 * rl + 1;
+	const u32 tid = threadIdx.x;
 	const size_t first = (size_t) blockIdx.x * PACK_RECS;
-	const size_t nhere = n_rec - first < PACK_RECS ? n_rec - first : PACK_RECS;
-	const size_t bytes = nhere * (size_t) reclen;
+	const u32 nhere = (u32) (n_rec - first < PACK_RECS ? n_rec - first : PACK_RECS);
+	const size_t bytes = (size_t) nhere * (size_t) reclen;
 	const uint8_t* src = ascii + first * (size_t) reclen;       // 16-byte aligned: 256*reclen is a multiple of 16
 	const size_t nvec = bytes / 16;
-	for (size_t v = threadIdx.x; v < nvec; v += PACK_RECS)
-		((uint4*) lds)[v] = ((const uint4*) src)[v];
-	for (size_t b = nvec * 16 + threadIdx.x; b < bytes; b += PACK_RECS) lds[b] = src[b];
+	for (size_t v = tid; v < nvec; v += PACK_RECS) ((uint4*) lds)[v] = ((const uint4*) src)[v];
+	for (size_t b = nvec * 16 + tid; b < bytes; b += PACK_RECS) lds[b] = src[b];
+	const u32 in_words = ((u32) PACK_RECS * (u32) reclen + 3u) / 4u + 4u;
+	const u32* inw = (const u32*) lds;
+	const u32 QW = (u32) qstride / 4u, OS = QW + 1u;              // quality row in LDS: an odd stride keeps the banks apart
+	u32* orow = (u32*) lds + ((in_words + 3u) & ~3u);
 	__syncthreads();
-	if (threadIdx.x >= nhere) return;
-	const uint8_t* r = lds + (size_t) threadIdx.x * reclen;
-	if (r[0] != '0') atomicAdd(bad_strand, 1u);   // A2:383-391; the reference only ever writes '0' (bam_read.c:219,231)
-	u32 other;
-	if (FWD) {
-		const size_t g = rec0 + 2 * (first + threadIdx.x);
-		other = 2 * pack_one<false>(r, rl, g, bases, nmask, lowq, quals, qstride);
-		(void) pack_one<true>(r, rl, g + 1, bases, nmask, lowq, quals, qstride);
-	} else
-		other = pack_one<false>(r, rl, rec0 + first + threadIdx.x, bases, nmask, lowq, quals, qstride);
-	if (other) atomicAdd(bad_strand + 1, other);     // (rare: reported through vdjx_stat("pool_other_bases"))
+	if (tid < nhere) {
+		const u32 start = tid * (u32) reclen;
+		if (lds[start] != '0') atomicAdd(bad_strand, 1u);   // A2:383-391; the reference only ever writes '0' (bam_read.c:219,231)
+		const u32 nw = ((u32) rl + 3u) / 4u;
+		// every LDS word of the record is asked for before the first is used (unrolled to the longest record, uniform guards): the
+		// loop with one read per trip waited for LDS twenty-six times per record
+		constexpr int NWMAX = (VDJX_MAX_READ_LEN + 3) / 4;
+		u32 rb[NWMAX + 1], rq[NWMAX + 1];
+		const u32 sb = start + 1u, sq = start + 1u + (u32) rl;
+#pragma unroll
+		for (int j = 0; j <= NWMAX; j++) {
+			rb[j] = (u32) j <= nw ? inw[(sb >> 2) + j] : 0u;
+			rq[j] = (u32) j <= nw ? inw[(sq >> 2) + j] : 0u;
+		}
+		// ---- bases
+		u64 bhi = 0, blo = 0, nm = 0, lq = 0;
+		u32 oth = 0;
+		u32* my = orow + tid * OS;
+		u32 qrow[NWMAX];                                  // (!FWD: the quality row stays in registers)
+#pragma unroll
+		for (int j = 0; j < NWMAX; j++) qrow[j] = 0x21212121u;
+#pragma unroll
+		for (int j = 0; j < NWMAX; j++) {
+			if ((u32) j < nw) {
+				const u32 valid = (u32) rl - 4u * j < 4u ? (u32) rl - 4u * j : 4u;
+				const u32 vm = valid < 4u ? (1u << (8u * valid)) - 1u : 0xFFFFFFFFu;
+				u32 w = __builtin_amdgcn_alignbyte(rb[j + 1], rb[j], sb & 3u);
+				w = (w & vm) | (0x41414141u & ~vm);
+				u32 na, ot;
+				const u32 c8 = sw_base_codes(w, na, ot) >> (8u - 2u * valid);
+				bhi = (bhi << (2u * valid)) | (blo >> (64u - 2u * valid));
+				blo = (blo << (2u * valid)) | c8;
+				nm |= (u64) sw_gather4(na) << (4u * j);
+				oth += (u32) __popc(ot);
+				// ---- qualities
+				u32 q = __builtin_amdgcn_alignbyte(rq[j + 1], rq[j], sq & 3u);
+				q = (q & vm) | (0x21212121u & ~vm);
+				lq |= (u64) (sw_gather4(sw_low_quality(q)) & ((1u << valid) - 1u)) << (4u * j);
+				if (FWD) my[j] = q; else qrow[j] = q;
+			}
+		}
+		if (FWD) for (u32 j = nw; j < QW; j++) my[j] = 0x21212121u;
+		const size_t g = FWD ? rec0 + 2 * (first + tid) : rec0 + first + tid;
+		((ulonglong2*) bases)[g] = make_ulonglong2(bhi, blo);
+		nmask[g] = nm;
+		lowq[g] = lq;
+		if (!FWD) {
+			// the row straight from the registers: four 16-byte stores per record (the staging through LDS of the FWD variant costs
+			// 17 KB per workgroup, i.e. half the workgroups per CU and half the bytes in flight)
+			uint4* qd = (uint4*) (quals + g * (size_t) qstride);
+#pragma unroll
+			for (int v = 0; v < NWMAX / 4; v++) if (v < qstride / 16) qd[v] = make_uint4(qrow[4 * v], qrow[4 * v + 1], qrow[4 * v + 2], qrow[4 * v + 3]);
+		}
+		if (FWD) {
+			// the reverse complement from the packed read: groups of two bits in reverse order, complemented (A0 <-> T1, C2 <-> G3: bit 0 of
+			// the code), not-ACGT bases at code 0; the two masks reversed
+			u64 rh = __brevll(blo), rlo = __brevll(bhi);
+			rh = ((rh >> 1) & 0x5555555555555555ull) | ((rh & 0x5555555555555555ull) << 1);
+			rlo = ((rlo >> 1) & 0x5555555555555555ull) | ((rlo & 0x5555555555555555ull) << 1);
+			const u32 s = 128u - 2u * (u32) rl;                       // 0 .. 126 (uniform)
+			if (s >= 64u) { rlo = rh >> (s - 64u); rh = 0; }
+			else if (s) { rlo = (rlo >> s) | (rh << (64u - s)); rh >>= s; }
+			const u32 nb = 2u * (u32) rl;
+			const u64 m_lo = nb >= 64u ? ~0ull : (1ull << nb) - 1ull, m_hi = nb > 64u ? (nb >= 128u ? ~0ull : (1ull << (nb - 64u)) - 1ull) : 0ull;
+			rlo ^= 0x5555555555555555ull & m_lo;
+			rh ^= 0x5555555555555555ull & m_hi;
+			if (nm) {                                                 // (rare) base i of this record sits at the bits 2(rl-1-i): N of the read at i' = rl-1-i
+				const u64 p_lo = sw_spread32((u32) nm), p_hi = sw_spread32((u32) (nm >> 32));
+				rlo &= ~(p_lo | (p_lo << 1));
+				rh &= ~(p_hi | (p_hi << 1));
+			}
+			((ulonglong2*) bases)[g + 1] = make_ulonglong2(rh, rlo);
+			nmask[g + 1] = __brevll(nm) >> (64u - (u32) rl);
+			lowq[g + 1] = __brevll(lq) >> (64u - (u32) rl);
+			oth *= 2u;
+		}
+		if (oth) atomicAdd(bad_strand + 1, oth);     // (rare: reported through vdjx_stat("pool_other_bases"))
+	}
+	if (!FWD) return;
+	__syncthreads();
+	// ---- quality rows out: 16 bytes per lane, consecutive lanes on consecutive addresses
+	const u32 rows = FWD ? 2u * nhere : nhere;
+	const u32 V = QW / 4u;                                                // 16-byte pieces per row
+	uint4* qd = (uint4*) (quals + (FWD ? rec0 + 2 * first : rec0 + first) * (size_t) qstride);
+	for (u32 idx = tid; idx < rows * V; idx += PACK_RECS) {
+		const u32 row = idx / V, v = idx - row * V;
+		const u32* my = orow + (FWD ? row >> 1 : row) * OS;
+		u32 x[4];
+		if (!FWD || !(row & 1u)) {
+#pragma unroll
+			for (int q = 0; q < 4; q++) x[q] = my[4u * v + q];
+		} else {
+			// reversed qualities: byte i of the row = byte rl-1-i of the read's row
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const int i0 = (int) (16u * v + 4u * q);                     // output bytes i0 .. i0+3 <- input bytes rl-1-i0 .. rl-4-i0
+				const int top = rl - 1 - i0;                                 // input position of output byte i0 (may be negative: padding)
+				u32 w = 0x21212121u;
+				if (top >= 0) {
+					const int lo = top - 3;                                  // lowest input byte needed (may be negative)
+					const u32 wl = lo >= 0 ? my[lo >> 2] : 0u, wh = my[top >> 2];
+					u32 asc;                                                 // input bytes lo .. lo+3 in ascending order
+					if (lo >= 0) asc = __builtin_amdgcn_alignbyte(wh, wl, (u32) lo & 3u);
+					else asc = wh << (8u * (u32) (-lo));                     // (top < 3: bytes below position 0 do not exist)
+					w = __builtin_bswap32(asc);
+					if (lo < 0) { const u32 keep = (1u << (8u * (u32) (top + 1))) - 1u; w = (w & keep) | (0x21212121u & ~keep); }
+				}
+				x[q] = w;
+			}
+		}
+		qd[idx] = make_uint4(x[0], x[1], x[2], x[3]);
+	}
 }
 
 static int pool_alloc(vdjx_ctx* c, size_t R, size_t n_primary, int rl, vdjx_pool** out, u32** d_bad) {
@@ -341,7 +439,8 @@ static int pool_alloc(vdjx_ctx* c, size_t R, size_t n_primary, int rl, vdjx_pool
 
 static void pack_launch(vdjx_ctx* c, hipStream_t st, vdjx_pool* p, const uint8_t* d_ascii, size_t n, size_t rec0, bool fwd, u32* d_bad) {
 	if (!n) return;
-	const size_t lds = (size_t) PACK_RECS * (2 * p->rl + 1) + 16;
+	const size_t in_words = ((size_t) PACK_RECS * (2 * p->rl + 1) + 3) / 4 + 4;
+	const size_t lds = (((in_words + 3) & ~(size_t) 3) + (fwd ? (size_t) PACK_RECS * (p->qstride / 4 + 1) : 0)) * 4 + 16;
 	const dim3 grid((unsigned) ((n + PACK_RECS - 1) / PACK_RECS));
 	if (fwd) hipLaunchKernelGGL(k_pool_pack<true>, grid, dim3(PACK_RECS), lds, st, d_ascii, n, p->rl, rec0, p->d_bases, p->d_nmask, p->d_lowq, p->d_quals, p->qstride, d_bad);
 	else hipLaunchKernelGGL(k_pool_pack<false>, grid, dim3(PACK_RECS), lds, st, d_ascii, n, p->rl, rec0, p->d_bases, p->d_nmask, p->d_lowq, p->d_quals, p->qstride, d_bad);

@@ -365,18 +365,19 @@ __device__ inline u32 ent_b(u64 e) { return (u32) (e >> 26) & RI_ENT_NONE; }
 __device__ inline u32 ent_flags(u64 e) { return (u32) (e >> 52) & 15u; }
 __device__ inline u32 ent_count(u64 e) { return (u32) (e >> 56); }
 
-struct MapLds {
-	u32 cls[MAP_MAXOFF];                            // read class at the offset or NONE32
-	u32 cstart[MAP_MAXOFF];                         // first entry of that class
-	u32 hpre[MAP_MAXOFF + 1];                       // prefix of class sizes (hits enumerate in reference order)
-	u32 wt_key[WT_SLOTS];                           // class id + 1
-	u32 wt_last[WT_SLOTS];                          // last offset + 1 with that class
-	u32 scan[MAP_THREADS];
-	u32 present[MAP_PRESENT_WORDS];                 // one bit per hashed class id seen in the window: "is this mate class here at all?" is one LDS
-	                                                // word for the 98 % of the hits whose mate lies elsewhere (a V gene is shared by many clones)
+// the image of one classified string in LDS, sized for at most NOFF offsets (512: windows of 486 and contigs of 360 bases at any read
+// length; 1024: the limit of the interface)
+template <int NOFF> struct MapImg {
+	u32 cstart[NOFF];                               // first entry of the class at the offset
+	u32 hpre[NOFF + 1];                             // prefix of class sizes (hits enumerate in reference order)
+	u32 wt_key[2 * NOFF];                           // class id + 1 -> ...
+	u32 wt_last[2 * NOFF];                          // ... last offset + 1 with that class
+	u32 present[MAP_PRESENT_WORDS];                 // one bit per (low bits of the) class id seen in the string: "is this mate class here at all?" is one
+	                                                // LDS word for the 98 % of the hits whose mate lies elsewhere (a V gene is shared by many clones)
 };
 
-__device__ inline u32 map_present_bit(u32 cls) { return (cls * 2654435761u) >> (32 - MAP_PRESENT_LOG2); }
+// class ids are ranks in the order of a hash table's slots: their low bits are as good as a hash (and cost no multiplication)
+__device__ inline u32 map_present_bit(u32 cls) { return cls & ((1u << MAP_PRESENT_LOG2) - 1u); }
 
 // ---- classification: every offset o in [0, len-rl) of every string (quick_map3.c:200: the last offset is never looked at) -> its
 // read class, the class's entries and how many (weighted: the DISTINCT read-1 entries, else the read-1 members), kept in HBM
@@ -434,11 +435,12 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_classify(ReadIndexDev ix, c
 	}
 }
 
-// the classified offsets of one string -> the workgroup's LDS image: class / first entry / prefix of sizes per offset, the class ->
-// last offset table ("read2[id] = m_info": the last writer wins, quick_map3.c:214) and the presence bits.  Returns the hit count.
-__device__ inline u32 map_load_prep(MapLds& L, const uint4* __restrict__ prow, int noff) {
+// the classified offsets of one string -> the workgroup's LDS image: first entry / prefix of sizes per offset, the class -> last offset
+// table ("read2[id] = m_info": the last writer wins, quick_map3.c:214) and the presence bits.  Returns the hit count.
+template <int NOFF>
+__device__ inline u32 map_load_prep(MapImg<NOFF>& L, const uint4* __restrict__ prow, int noff) {
 	const u32 tid = threadIdx.x;
-	for (u32 i = tid; i < WT_SLOTS; i += MAP_THREADS) { L.wt_key[i] = 0; L.wt_last[i] = 0; }
+	for (u32 i = tid; i < 2 * NOFF; i += MAP_THREADS) { L.wt_key[i] = 0; L.wt_last[i] = 0; }
 	for (u32 i = tid; i < MAP_PRESENT_WORDS; i += MAP_THREADS) L.present[i] = 0;
 	__syncthreads();
 	for (int o = tid; o < noff; o += MAP_THREADS) {
@@ -447,7 +449,7 @@ __device__ inline u32 map_load_prep(MapLds& L, const uint4* __restrict__ prow, i
 		if (cls != NONE32) {
 			const u32 pb = map_present_bit(cls);
 			atomicOr(&L.present[pb >> 5], 1u << (pb & 31));
-			u32 slot = (cls * 2654435761u) & (WT_SLOTS - 1);
+			u32 slot = cls & (2 * NOFF - 1);
 			for (;;) {
 				u32 cur = L.wt_key[slot];
 				if (cur == 0) {
@@ -455,10 +457,9 @@ __device__ inline u32 map_load_prep(MapLds& L, const uint4* __restrict__ prow, i
 					if (cur == 0) cur = cls + 1;
 				}
 				if (cur == cls + 1) { atomicMax(&L.wt_last[slot], (u32) o + 1); break; }
-				slot = (slot + 1) & (WT_SLOTS - 1);
+				slot = (slot + 1) & (2 * NOFF - 1);
 			}
 		}
-		L.cls[o] = cls;
 		L.cstart[o] = p.y;
 		L.hpre[o] = p.z;
 	}
@@ -479,26 +480,32 @@ __device__ inline u32 map_load_prep(MapLds& L, const uint4* __restrict__ prow, i
 	return L.hpre[noff];
 }
 
-// last offset+1 at which a read of class `cls` occurs in the window, or 0
-__device__ inline u32 map_last_occurrence(const MapLds& L, u32 cls) {
-	u32 slot = (cls * 2654435761u) & (WT_SLOTS - 1);
+// last offset+1 at which a read of class `cls` occurs in the string, or 0
+template <int NOFF>
+__device__ inline u32 map_last_occurrence(const MapImg<NOFF>& L, u32 cls) {
+	u32 slot = cls & (2 * NOFF - 1);
 	for (;;) {
 		const u32 cur = L.wt_key[slot];
 		if (cur == 0) return 0;
 		if (cur == cls + 1) return L.wt_last[slot];
-		slot = (slot + 1) & (WT_SLOTS - 1);
+		slot = (slot + 1) & (2 * NOFF - 1);
 	}
 }
 
-// one entry of the class at offset o -> mapped pair or not (quick_map3.c:223-245).  read2[id]: among the pair's read-2 records the
-// one written last = largest offset, then latest registration (B)
-__device__ inline bool map_eval_entry(const MapLds& L, int rl, int o, const u64 e, u32& pos2_out, u32& which_out) {
+// the cheap half of the test of an entry: is either mate class in the string at all?  (A "none" class tests some bit like any other:
+// a false positive the full test sorts out.)
+template <int NOFF>
+__device__ inline bool map_entry_present(const MapImg<NOFF>& L, const u64 e) {
+	const u32 ba = map_present_bit(ent_a(e)), bb = map_present_bit(ent_b(e));
+	return ((L.present[ba >> 5] >> (ba & 31)) | (L.present[bb >> 5] >> (bb & 31))) & 1u;
+}
+// the full test: the entry of the class at offset o -> mapped pair or not (quick_map3.c:223-245).  read2[id]: among the pair's read-2
+// records the one written last = largest offset, then latest registration (B)
+template <int NOFF>
+__device__ inline bool map_eval_entry(const MapImg<NOFF>& L, int rl, int o, const u64 e, u32& pos2_out, u32& which_out) {
 	const u32 ca = ent_a(e), cb = ent_b(e);
-	const u32 ba = map_present_bit(ca), bb = map_present_bit(cb);
-	const bool pa = ca != RI_ENT_NONE && ((L.present[ba >> 5] >> (ba & 31)) & 1u), pb = cb != RI_ENT_NONE && ((L.present[bb >> 5] >> (bb & 31)) & 1u);
-	if (!pa && !pb) return false;
-	const u32 la = pa ? map_last_occurrence(L, ca) : 0u, lb = pb ? map_last_occurrence(L, cb) : 0u;
-	if (!la && !lb) return false;
+	const u32 la = ca != RI_ENT_NONE ? map_last_occurrence(L, ca) : 0u, lb = cb != RI_ENT_NONE ? map_last_occurrence(L, cb) : 0u;
+	if (!(la | lb)) return false;
 	const u32 which = (lb && lb >= la) ? 1u : 0u;
 	const u32 best = which ? lb : la;
 	const u32 fl = ent_flags(e);
@@ -512,6 +519,22 @@ __device__ inline bool map_eval_entry(const MapLds& L, int rl, int o, const u64 
 	which_out = which;
 	return true;
 }
+
+// a lane's walk through the flat hit sequence: hits are visited in increasing order, so the offset only moves forward and the class
+// bounds stay in registers until a hit leaves the class
+struct HitCursor {
+	int o; u32 lo, hi, cs;
+	template <int NOFF> __device__ inline void start(const MapImg<NOFF>& L, int o0) { o = o0; lo = L.hpre[o]; hi = L.hpre[o + 1]; cs = L.cstart[o]; }
+	// h >= hpre[o] on entry (o is a lower bound); -> index of hit h's entry
+	template <int NOFF> __device__ inline u32 seek(const MapImg<NOFF>& L, u32 h, int o_min) {
+		if (o_min > o) { o = o_min; hi = L.hpre[o + 1]; if (h < hi) { lo = L.hpre[o]; cs = L.cstart[o]; } }
+		if (h >= hi) {
+			do { o++; hi = L.hpre[o + 1]; } while (h >= hi);              // (few steps: 64 hits span few classes; empty ones are skipped)
+			lo = L.hpre[o]; cs = L.cstart[o];
+		}
+		return cs + (h - lo);
+	}
+};
 
 // ----------------------------------------------------------------------------------------------
 // planning on the device: offsets of the strings' hit lists, processing order (largest first), work items
@@ -644,31 +667,15 @@ __global__ __launch_bounds__(1024) void k_plan(const u32* __restrict__ hits, con
 // The waves of the workgroup take the offsets of the slice one at a time (LDS ticket): the entries of an offset's read class
 // are consecutive, so a wave streams them with coalesced 8-byte loads and no search; pairs (a few per cent of the entries) are
 // staged per wave in LDS and leave with one global cursor bump per 64.
-#define WP_K 16                  // rows of 64 consecutive hits per wave and round: 16 loads in flight per lane
+#define WP_K 16                  // rows of 64 consecutive hits per wave and round: 16 loads in flight per lane, in 64 registers (8 waves per SIMD:
+                                 // with 96 registers and 5 waves the same kernel ran 1.7x longer)
 #define WP_Q 128                 // per-wave queue of the entries that passed the presence test
-// the LDS image without the arrays only k_map_emit needs
-struct MapLdsW {
-	u32 cstart[MAP_MAXOFF];
-	u32 hpre[MAP_MAXOFF + 1];
-	u32 wt_key[WT_SLOTS];
-	u32 wt_last[WT_SLOTS];
-	u32 present[MAP_PRESENT_WORDS];
-};
-__device__ inline u32 mapw_last_occurrence(const MapLdsW& L, u32 cls) {
-	u32 slot = (cls * 2654435761u) & (WT_SLOTS - 1);
-	for (;;) {
-		const u32 cur = L.wt_key[slot];
-		if (cur == 0) return 0;
-		if (cur == cls + 1) return L.wt_last[slot];
-		slot = (slot + 1) & (WT_SLOTS - 1);
-	}
-}
-
-__global__ __launch_bounds__(MAP_THREADS) void k_window_pairs(ReadIndexDev ix, const uint4* __restrict__ prep, u32 n, int len, u32 chunk,
+template <int NOFF>
+__global__ __launch_bounds__(MAP_THREADS, 8) void k_window_pairs(ReadIndexDev ix, const uint4* __restrict__ prep, u32 n, int len, u32 chunk,
                                                               const u32* __restrict__ order, const u32* __restrict__ wstart,
                                                               const u64* __restrict__ pair_off, u64* __restrict__ pair_buf,
                                                               u32* __restrict__ pair_cnt, u32* __restrict__ pair_np) {
-	__shared__ MapLdsW L;
+	__shared__ MapImg<NOFF> L;
 	__shared__ u64 q_ent[MAP_THREADS / 64][WP_Q];
 	__shared__ unsigned short q_off[MAP_THREADS / 64][WP_Q];
 	__shared__ u32 s_next;
@@ -676,75 +683,25 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_pairs(ReadIndexDev ix, c
 	const u32 wi = order[j];
 	const int noff = len - ix.rl;
 	const u32 tid = threadIdx.x;
-	// ---- the window's image (map_load_prep without the arrays this kernel does not read)
-	for (u32 i = tid; i < WT_SLOTS; i += MAP_THREADS) { L.wt_key[i] = 0; L.wt_last[i] = 0; }
-	for (u32 i = tid; i < MAP_PRESENT_WORDS; i += MAP_THREADS) L.present[i] = 0;
-	if (tid == 0) s_next = (blockIdx.x - wstart[j]) * chunk;
-	__syncthreads();
-	{
-		const uint4* prow = prep + (size_t) wi * noff;
-		for (int o = tid; o < noff; o += MAP_THREADS) {
-			const uint4 p = prow[o];
-			const u32 cls = p.x;
-			if (cls != NONE32) {
-				const u32 pb = map_present_bit(cls);
-				atomicOr(&L.present[pb >> 5], 1u << (pb & 31));
-				u32 slot = (cls * 2654435761u) & (WT_SLOTS - 1);
-				for (;;) {
-					u32 cur = L.wt_key[slot];
-					if (cur == 0) {
-						cur = atomicCAS(&L.wt_key[slot], 0u, cls + 1);
-						if (cur == 0) cur = cls + 1;
-					}
-					if (cur == cls + 1) { atomicMax(&L.wt_last[slot], (u32) o + 1); break; }
-					slot = (slot + 1) & (WT_SLOTS - 1);
-				}
-			}
-			L.cstart[o] = p.y;
-			L.hpre[o] = p.z;
-		}
-	}
-	__syncthreads();
-	if (tid < 64) {
-		const int per = (noff + 63) / 64;
-		const int a = (int) tid * per;
-		const int b2 = a + per < noff ? a + per : noff;
-		u32 sum = 0;
-		for (int o = a; o < b2; o++) sum += L.hpre[o];
-		const u32 incl = (u32) vdjx_wave_scan_add((int) sum);
-		u32 run = incl - sum;
-		for (int o = a; o < b2; o++) { const u32 sz = L.hpre[o]; L.hpre[o] = run; run += sz; }
-		if (tid == 63) L.hpre[noff] = incl;
-	}
-	__syncthreads();
-	const u32 H = L.hpre[noff];
-	const u32 h0 = (blockIdx.x - wstart[j]) * chunk, h1 = h0 + chunk < H ? h0 + chunk : H;
+	const u32 h0 = (blockIdx.x - wstart[j]) * chunk;
+	if (tid == 0) s_next = h0;
+	const u32 H = map_load_prep(L, prep + (size_t) wi * noff, noff);
+	const u32 h1 = h0 + chunk < H ? h0 + chunk : H;
 	if (h0 >= h1) return;
 	const int lane = __lane_id();
 	const u32 wv = tid >> 6;
 	u64* pairs = pair_buf + pair_off[wi];
 	u32 qn = 0, mine = 0;                               // (qn: wave-uniform)
-	// the queued entries, 64 at a time with every lane busy: the full test (quick_map3.c:223-245) and the pairs out
+	// the queued entries, 64 at a time with every lane busy: the full test and the pairs out
 	auto drain = [&]() {
 		for (u32 q0 = 0; q0 < qn; q0 += 64) {
 			const u32 qi = q0 + (u32) lane;
 			bool pr = false;
 			u64 e = 0;
-			u32 pos2 = 0, o = 0;
+			u32 pos2 = 0, which = 0, o = 0;
 			if (qi < qn) {
 				e = q_ent[wv][qi]; o = q_off[wv][qi];
-				const u32 ca = ent_a(e), cb = ent_b(e);
-				const u32 la = ca != RI_ENT_NONE ? mapw_last_occurrence(L, ca) : 0u, lb = cb != RI_ENT_NONE ? mapw_last_occurrence(L, cb) : 0u;
-				if (la | lb) {
-					const u32 which = (lb && lb >= la) ? 1u : 0u;
-					const u32 best = which ? lb : la;
-					const u32 fl = ent_flags(e);
-					const u32 rc1 = (fl & RI_RC) ? 1u : 0u, rc2 = (fl & (which ? RI_RCB : RI_RCA)) ? 1u : 0u;
-					const int d = (int) (o + 1) - (int) best;
-					const int insert = (int) (short) ((d < 0 ? -d : d) + ix.rl);
-					pr = rc1 != rc2 && insert >= 50 && insert <= 400;          // quick_map3.c:227, 23-24
-					pos2 = best;
-				}
+				pr = map_eval_entry(L, ix.rl, (int) o, e, pos2, which);
 			}
 			const u64 m = __ballot(pr);
 			if (m) {
@@ -797,10 +754,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_pairs(ReadIndexDev ix, c
 #pragma unroll
 		for (int u = 0; u < WP_K; u++) {
 			if (hb + (u32) (u * 64) >= h1) break;                                // (wave-uniform)
-			// (a "none" class hashes to some bit like any other: a false positive the full test sorts out)
-			const u32 ba = map_present_bit(ent_a(ent[u])), bb = map_present_bit(ent_b(ent[u]));
-			const u32 wa = L.present[ba >> 5], wb = L.present[bb >> 5];
-			const bool pass = (((wa >> (ba & 31)) | (wb >> (bb & 31))) & 1u) && hb + (u32) (u * 64 + lane) < h1;
+			const bool pass = map_entry_present(L, ent[u]) && hb + (u32) (u * 64 + lane) < h1;
 			const u64 m = __ballot(pass);
 			if (!m) continue;
 			if (pass) {
@@ -1003,84 +957,116 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 // many; the gather below lays the slices end to end, which is the reference's order (offset-major, registration order inside
 // a class).  One workgroup per contig left half the GPU idle and walked ~20 k hits sequentially.
 // ----------------------------------------------------------------------------------------------
-#define ME_K 8                    // rows of MAP_THREADS consecutive hits per round: 8 loads in flight per thread, one ordered compaction per round
-__global__ __launch_bounds__(MAP_THREADS) void k_map_emit(ReadIndexDev ix, const uint4* __restrict__ prep, u32 n, int len, u32 slice_hits,
+#define ME_K 8                    // rows of 64 consecutive hits per wave and round
+#define ME_Q 128
+// A slice writes its mapped pairs at the start of its own region (region offset = hit offset: pairs <= hits) in ANY order, each with
+// the number of its hit, and marks the hit in the slice's bitmap; k_gather_pairs puts every pair at the rank of its hit among the
+// marked ones -- the reference's order (offset-major, registration order inside a class) comes out of the hit numbering, not out
+// of the order of evaluation.  The sweep is the one of k_window_pairs: presence test over the flat hits, dense queue for the full
+// test.
+template <int NOFF>
+__global__ __launch_bounds__(MAP_THREADS, 6) void k_map_emit(ReadIndexDev ix, const uint4* __restrict__ prep, u32 n, int len, u32 slice_hits,
                                                           const u32* __restrict__ slice_start, const u64* __restrict__ region_off,
-                                                          vdjx_pair* __restrict__ pairs, u32* __restrict__ slice_cnt) {
-	__shared__ MapLds L;
-	__shared__ u32 s_rows[ME_K][MAP_THREADS / 64];          // pairs per row and wave
-	const u32 tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+                                                          vdjx_pair* __restrict__ pairs, u32* __restrict__ pair_hit, u32* __restrict__ slice_bits,
+                                                          u32* __restrict__ slice_cnt) {
+	__shared__ MapImg<NOFF> L;
+	__shared__ u64 q_ent[MAP_THREADS / 64][ME_Q];
+	__shared__ u32 q_hit[MAP_THREADS / 64][ME_Q];
+	__shared__ unsigned short q_off[MAP_THREADS / 64][ME_Q];
+	__shared__ u32 bits[MAP_SLICE_MAX / 32];
+	__shared__ u32 s_next, s_cnt;
+	const u32 tid = threadIdx.x, wv = tid >> 6;
+	const int lane = __lane_id();
 	const int noff = len - ix.rl;
 	const u32 ci = slice_contig(slice_start, n, blockIdx.x);
 	const u32 w0 = (blockIdx.x - slice_start[ci]) * slice_hits;
 	vdjx_pair* out = pairs + region_off[ci] + w0;
+	u32* out_hit = pair_hit + region_off[ci] + w0;
+	const u32 nwords = (slice_hits + 31) / 32;
+	for (u32 i = tid; i < nwords; i += MAP_THREADS) bits[i] = 0;
+	if (tid == 0) { s_next = w0; s_cnt = 0; }
 	const u32 H = map_load_prep(L, prep + (size_t) ci * noff, noff);
 	const u32 h1 = w0 + slice_hits < H ? w0 + slice_hits : H;
-	u32 done = 0;                                           // pairs written so far (uniform)
-	// thread-per-hit with ONE load in flight and three barriers per 512 hits was bound by memory latency; a round now covers ME_K rows
-	// of 512 consecutive hits: ME_K loads in flight per thread, then one ordered compaction (row-major = hit order) for all of them
-	for (u32 hb = w0; hb < h1; hb += MAP_THREADS * ME_K) {
-		// the offset of the first hit of this wave's piece of every row: lanes 0 .. ME_K-1 search
+	u32 qn = 0;
+	auto drain = [&]() {
+		for (u32 q0 = 0; q0 < qn; q0 += 64) {
+			const u32 qi = q0 + (u32) lane;
+			bool pr = false;
+			u64 e = 0;
+			u32 o = 0, h = 0, pos2 = 0, which = 0;
+			if (qi < qn) {
+				e = q_ent[wv][qi]; o = q_off[wv][qi]; h = q_hit[wv][qi];
+				pr = map_eval_entry(L, ix.rl, (int) o, e, pos2, which);
+			}
+			const u64 m = __ballot(pr);
+			if (!m) continue;
+			u32 base = 0;
+			if (lane == 0) base = atomicAdd(&s_cnt, (u32) __popcll(m));
+			base = (u32) __builtin_amdgcn_readlane((int) base, 0);
+			if (pr) {
+				const u32 at = base + (u32) __popcll(m & ((1ull << lane) - 1ull));
+				const u32 ci2 = L.cstart[o] + (h - L.hpre[o]);
+				const u32 pid = ix.csr_pair[ci2];
+				const u32 fl = ent_flags(e);
+				const int d = (int) (o + 1) - (int) pos2;
+				vdjx_pair* q = out + at;
+				q->pair_id = pid; q->rec1 = ix.recs[ci2]; q->rec2 = ix.pair_r2[2 * (size_t) pid + which];
+				q->pos1 = (int16_t) (o + 1); q->pos2 = (int16_t) pos2; q->insert = (int16_t) ((d < 0 ? -d : d) + ix.rl);
+				q->rc1 = (fl & RI_RC) ? 1 : 0; q->rc2 = (fl & (which ? RI_RCB : RI_RCA)) ? 1 : 0;
+				out_hit[at] = h - w0;
+				atomicOr(&bits[(h - w0) >> 5], 1u << ((h - w0) & 31));
+			}
+		}
+		qn = 0;
+	};
+	if (w0 < h1) for (;;) {
+		u32 hb = 0;
+		if (lane == 0) hb = atomicAdd(&s_next, 64u * ME_K);
+		hb = (u32) __builtin_amdgcn_readlane((int) hb, 0);
+		if (hb >= h1) break;
 		int orow = 0;
 		{
-			const u32 hr = hb + lane * MAP_THREADS + wv * 64u;
+			const u32 hr = hb + (u32) lane * 64u;
 			if (lane < ME_K && hr < h1) {
-				int lo = 0, hi = noff;                      // last o with hpre[o] <= hr
+				int lo = 0, hi = noff;                      // last offset with hpre[o] <= hr
 				while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.hpre[mid] <= hr) lo = mid; else hi = mid; }
 				orow = lo;
 			}
 		}
 		u64 ent[ME_K];
-		u32 cix[ME_K], oo[ME_K / 2];
+		u32 oo[ME_K / 2];
+		HitCursor cu;
+		cu.start(L, __builtin_amdgcn_readlane(orow, 0));
 #pragma unroll
 		for (int u = 0; u < ME_K; u++) {
-			const u32 h = hb + (u32) u * MAP_THREADS + tid;
-			int o = __builtin_amdgcn_readlane(orow, u);
+			const u32 h = hb + (u32) (u * 64 + lane);
 			u64 e = ~0ull;
-			u32 ci2 = 0;
-			if (h < h1) {
-				while (h >= L.hpre[o + 1]) o++;
-				ci2 = L.cstart[o] + (h - L.hpre[o]);
-				e = ix.csr8[ci2];
-			}
-			ent[u] = e; cix[u] = ci2;
-			if (u & 1) oo[u >> 1] |= (u32) o << 16; else oo[u >> 1] = (u32) o;
+			if (h < h1) e = ix.csr8[cu.seek(L, h, __builtin_amdgcn_readlane(orow, u))];
+			ent[u] = e;
+			if (u & 1) oo[u >> 1] |= (u32) cu.o << 16; else oo[u >> 1] = (u32) cu.o;
 		}
-		u32 prm = 0, whm = 0, pos2s[ME_K], before[ME_K];
 #pragma unroll
 		for (int u = 0; u < ME_K; u++) {
-			const int o = (int) ((oo[u >> 1] >> (16 * (u & 1))) & 0xFFFFu);
-			u32 pos2 = 0, which = 0;
-			const bool pr = map_eval_entry(L, ix.rl, o, ent[u], pos2, which);
-			const u64 m = __ballot(pr);
-			prm |= (pr ? 1u : 0u) << u; whm |= which << u;
-			pos2s[u] = pos2;
-			before[u] = (u32) __popcll(m & ((1ull << lane) - 1ull));
-			if (lane == 0) s_rows[u][wv] = (u32) __popcll(m);
-		}
-		__syncthreads();
-		u32 run = done;
-#pragma unroll
-		for (int u = 0; u < ME_K; u++) {
-			u32 wbase = 0, total = 0;
-			for (u32 i = 0; i < MAP_THREADS / 64; i++) { const u32 v = s_rows[u][i]; if (i < wv) wbase += v; total += v; }
-			if ((prm >> u) & 1u) {
-				const int o = (int) ((oo[u >> 1] >> (16 * (u & 1))) & 0xFFFFu);
-				const u32 which = (whm >> u) & 1u, ci2 = cix[u];
-				const u32 pid = ix.csr_pair[ci2];
-				const u32 fl = ent_flags(ent[u]);
-				const int d = (o + 1) - (int) pos2s[u];
-				vdjx_pair* q = out + run + wbase + before[u];
-				q->pair_id = pid; q->rec1 = ix.recs[ci2]; q->rec2 = ix.pair_r2[2 * (size_t) pid + which];
-				q->pos1 = (int16_t) (o + 1); q->pos2 = (int16_t) pos2s[u]; q->insert = (int16_t) ((d < 0 ? -d : d) + ix.rl);
-				q->rc1 = (fl & RI_RC) ? 1 : 0; q->rc2 = (fl & (which ? RI_RCB : RI_RCA)) ? 1 : 0;
+			if (hb + (u32) (u * 64) >= h1) break;                                // (wave-uniform)
+			const u32 h = hb + (u32) (u * 64 + lane);
+			const bool pass = map_entry_present(L, ent[u]) && h < h1;
+			const u64 m = __ballot(pass);
+			if (!m) continue;
+			if (pass) {
+				const u32 at = qn + (u32) __popcll(m & ((1ull << lane) - 1ull));
+				q_ent[wv][at] = ent[u];
+				q_hit[wv][at] = h;
+				q_off[wv][at] = (unsigned short) ((oo[u >> 1] >> (16 * (u & 1))) & 0xFFFFu);
 			}
-			run += total;
+			qn += (u32) __popcll(m);
+			if (qn > ME_Q - 64) drain();
 		}
-		done = run;
-		__syncthreads();
 	}
-	if (tid == 0) slice_cnt[blockIdx.x] = done;
+	drain();
+	__syncthreads();
+	u32* gb = slice_bits + (size_t) blockIdx.x * nwords;
+	for (u32 i = tid; i < nwords; i += MAP_THREADS) gb[i] = bits[i];
+	if (tid == 0) slice_cnt[blockIdx.x] = s_cnt;
 }
 
 // exclusive u64 prefix of the slice counts (one workgroup) and, from it, the pairs of every contig
@@ -1108,15 +1094,42 @@ __global__ void k_contig_counts(const u64* __restrict__ slice_pre, const u32* __
 	if (i < n) out[i] = slice_pre[slice_start[i + 1]] - slice_pre[slice_start[i]];
 }
 
-// lay the slices end to end in the caller's dense layout
-__global__ void k_gather_pairs(const vdjx_pair* __restrict__ src, u32 n, u32 slice_hits, const u32* __restrict__ slice_start,
-                               const u64* __restrict__ region_off, const u64* __restrict__ slice_pre, vdjx_pair* __restrict__ dst) {
+// every pair of a slice to the rank of its hit among the slice's mapped hits, slice after slice, in the caller's dense layout: hit order
+// = the reference's order
+__global__ __launch_bounds__(256) void k_gather_pairs(const vdjx_pair* __restrict__ src, const u32* __restrict__ pair_hit, u32 n, u32 slice_hits,
+                                                      const u32* __restrict__ slice_start, const u64* __restrict__ region_off,
+                                                      const u32* __restrict__ slice_bits, const u64* __restrict__ slice_pre, vdjx_pair* __restrict__ dst) {
+	__shared__ u32 wpre[MAP_SLICE_MAX / 32 + 1], wbit[MAP_SLICE_MAX / 32];
+	__shared__ u32 part[4];
+	const u64 dof = slice_pre[blockIdx.x];
+	const u32 cnt = (u32) (slice_pre[blockIdx.x + 1] - dof);
+	if (!cnt) return;
 	const u32 ci = slice_contig(slice_start, n, blockIdx.x);
 	const u64 so = region_off[ci] + (u64) (blockIdx.x - slice_start[ci]) * slice_hits;
-	const u64 dof = slice_pre[blockIdx.x], cnt = slice_pre[blockIdx.x + 1] - dof;
-	const uint32_t* s = (const uint32_t*) (src + so);
-	uint32_t* d = (uint32_t*) (dst + dof);
-	for (u64 i = threadIdx.x; i < cnt * (sizeof(vdjx_pair) / 4); i += blockDim.x) d[i] = s[i];
+	const u32 nwords = (slice_hits + 31) / 32;
+	const u32* gb = slice_bits + (size_t) blockIdx.x * nwords;
+	// exclusive prefix of the words' popcounts (nwords <= 1024: four words per thread)
+	const u32 per = (nwords + 255) / 256;
+	const u32 lo = threadIdx.x * per < nwords ? threadIdx.x * per : nwords, hi = lo + per < nwords ? lo + per : nwords;
+	u32 sum = 0;
+	for (u32 i = lo; i < hi; i++) { const u32 w = gb[i]; wbit[i] = w; sum += __popc(w); }
+	const u32 incl = (u32) vdjx_wave_scan_add((int) sum);
+	if ((threadIdx.x & 63u) == 63u) part[threadIdx.x >> 6] = incl;
+	__syncthreads();
+	u32 run = incl - sum;
+	for (u32 w = 0; w < (threadIdx.x >> 6); w++) run += part[w];
+	for (u32 i = lo; i < hi; i++) { wpre[i] = run; run += __popc(wbit[i]); }
+	__syncthreads();
+	constexpr u32 PW = sizeof(vdjx_pair) / 4;
+	const uint32_t* s4 = (const uint32_t*) (src + so);
+	uint32_t* d4 = (uint32_t*) (dst + dof);
+	// dword q of pair i: consecutive threads read consecutive dwords (the slice's pairs are contiguous)
+	for (u32 t = threadIdx.x; t < cnt * PW; t += 256) {
+		const u32 i = t / PW, q = t - i * PW;
+		const u32 h = pair_hit[so + i];
+		const u32 rank = wpre[h >> 5] + (u32) __popc(wbit[h >> 5] & ((1u << (h & 31)) - 1u));
+		d4[(size_t) rank * PW + q] = s4[t];
+	}
 }
 
 static int make_index_view(vdjx_ctx* c, ReadIndexDev* ix, int len, const char* who) {
@@ -1172,7 +1185,10 @@ static int classify_and_plan(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix,
 		vdjx_prof_scope ps(c, "k_map_classify");
 		hipLaunchKernelGGL(k_map_classify, dim3((u32) std::min<size_t>(n, 8192)), dim3(MAP_THREADS), 0, st, ix, d_s, (u32) n, len, weighted, mp->d_prep, d_hits, d_inst);
 	}
-	hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, d_hits, d_inst, (u32) n, chunk_fixed, weighted ? 1 : 0, weighted ? 1 : 0, mp->d_off, mp->d_order, mp->d_wstart, d_tot);
+	{
+		vdjx_prof_scope ps(c, "k_plan");
+		hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, d_hits, d_inst, (u32) n, chunk_fixed, weighted ? 1 : 0, weighted ? 1 : 0, mp->d_off, mp->d_order, mp->d_wstart, d_tot);
+	}
 	if (!c->h_plan) {
 		HIP_TRY(hipHostMalloc(&c->h_plan, 256, hipHostMallocDefault));
 		c->h_plan_cap = 256;
@@ -1226,8 +1242,12 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 	HIP_TRY(hipMemsetAsync(d_cnt, 0, n * 4, st));
 	if (mp->tot.nwork) {
 		vdjx_prof_scope ps(c, "k_window_pairs");
-		hipLaunchKernelGGL(k_window_pairs, dim3(mp->tot.nwork), dim3(MAP_THREADS), 0, st, ix, mp->d_prep, (u32) n, len, mp->tot.chunk, mp->d_order, mp->d_wstart,
-		                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np);
+		if (len - ix.rl <= 512)
+			hipLaunchKernelGGL(k_window_pairs<512>, dim3(mp->tot.nwork), dim3(MAP_THREADS), 0, st, ix, mp->d_prep, (u32) n, len, mp->tot.chunk, mp->d_order, mp->d_wstart,
+			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np);
+		else
+			hipLaunchKernelGGL(k_window_pairs<MAP_MAXOFF>, dim3(mp->tot.nwork), dim3(MAP_THREADS), 0, st, ix, mp->d_prep, (u32) n, len, mp->tot.chunk, mp->d_order, mp->d_wstart,
+			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np);
 	}
 	*d_np_out = d_np; *d_cnt_out = d_cnt;
 	return VDJX_OK;
@@ -1419,7 +1439,7 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 	uint64_t key = fnv1a(contigs, n * (size_t) len, 0xcbf29ce484222325ull ^ (uint64_t) n * 1315423911ull ^ (uint64_t) len);
 	if (!key) key = 1;
 	lp.mark("me_key");
-	static const u32 slice_env = getenv("VDJX_MAP_SLICE") && atol(getenv("VDJX_MAP_SLICE")) > 0 ? (u32) atol(getenv("VDJX_MAP_SLICE")) : 0u;
+	static const u32 slice_env = getenv("VDJX_MAP_SLICE") && atol(getenv("VDJX_MAP_SLICE")) > 0 ? (u32) std::min<long>(atol(getenv("VDJX_MAP_SLICE")), (long) MAP_SLICE_MAX) : 0u;
 	if (!pairs) c->me_key = 0;               // a counting call never reuses an earlier mapping
 	if (c->me_key != key || c->me_cnt.size() != n || c->me_src != (const void*) contigs) {
 		c->me_key = 0;
@@ -1430,15 +1450,19 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 		const u64 total_hits = mp.tot.total_hits;
 		if (total_hits > c->me_cap) {
 			free_set(c->me_pairs);
+			free_set(c->me_hit);
 			c->me_cap = 0;
 			HIP_TRY(hipMalloc(&c->me_pairs, (size_t) total_hits * sizeof(vdjx_pair)));
+			HIP_TRY(hipMalloc(&c->me_hit, (size_t) total_hits * 4 + 4));
 			c->me_cap = (size_t) total_hits;
 		}
 		const u32 slice_hits = mp.tot.chunk;
 		const size_t nsl = mp.tot.nwork;
 		c->me_slice_hits = slice_hits;
-		// persistent bookkeeping: hit offsets of the contigs, pairs per slice and their prefix, pairs per contig, slice prefix of the contigs
-		const size_t need = (n + 1) * 4 + 8 + (n + 1) * 8 + nsl * 4 + 8 + (nsl + 1) * 8 + n * 8 + 64;
+		// persistent bookkeeping: hit offsets of the contigs, pairs per slice and their prefix, pairs per contig, slice prefix of the
+		// contigs, the slices' bitmaps of mapped hits
+		const size_t nwords = ((size_t) slice_hits + 31) / 32;
+		const size_t need = (n + 1) * 4 + 8 + (n + 1) * 8 + nsl * 4 + 8 + (nsl + 1) * 8 + n * 8 + nsl * nwords * 4 + 64;
 		if (need > c->me_book_cap) {
 			free_set(c->me_book);
 			c->me_book_cap = 0;
@@ -1450,7 +1474,8 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 		u64* b_pre = (u64*) bk;                      bk += (nsl + 1) * 8;
 		u64* b_cnt = (u64*) bk;                      bk += n * 8;
 		u32* b_sstart = (u32*) bk;                   bk += ((n + 1) * 4 + 7) / 8 * 8;
-		u32* b_scnt = (u32*) bk;
+		u32* b_scnt = (u32*) bk;                     bk += (nsl * 4 + 7) / 8 * 8;
+		u32* b_bits = (u32*) bk;
 		c->me_nsl = nsl;
 		c->me_cnt.assign(n, 0);
 		HIP_TRY(hipMemcpyAsync(b_sstart, mp.d_wstart, (n + 1) * 4, hipMemcpyDeviceToDevice, st));
@@ -1458,7 +1483,10 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 		if (nsl) {
 			{
 				vdjx_prof_scope ps(c, "k_map_emit");
-				hipLaunchKernelGGL(k_map_emit, dim3((u32) nsl), dim3(MAP_THREADS), 0, st, ix, mp.d_prep, (u32) n, len, slice_hits, b_sstart, b_off, (vdjx_pair*) c->me_pairs, b_scnt);
+				if (len - ix.rl <= 512)
+					hipLaunchKernelGGL(k_map_emit<512>, dim3((u32) nsl), dim3(MAP_THREADS), 0, st, ix, mp.d_prep, (u32) n, len, slice_hits, b_sstart, b_off, (vdjx_pair*) c->me_pairs, (u32*) c->me_hit, b_bits, b_scnt);
+				else
+					hipLaunchKernelGGL(k_map_emit<MAP_MAXOFF>, dim3((u32) nsl), dim3(MAP_THREADS), 0, st, ix, mp.d_prep, (u32) n, len, slice_hits, b_sstart, b_off, (vdjx_pair*) c->me_pairs, (u32*) c->me_hit, b_bits, b_scnt);
 			}
 			hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, st, b_scnt, (u32) nsl, b_pre);
 			hipLaunchKernelGGL(k_contig_counts, dim3((u32) (n + 255) / 256), dim3(256), 0, st, b_pre, b_sstart, (u32) n, b_cnt);
@@ -1482,7 +1510,9 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 		const u64* b_off = (const u64*) bk;          bk += (n + 1) * 8;
 		const u64* b_pre = (const u64*) bk;          bk += (nsl + 1) * 8;
 		bk += n * 8;
-		const u32* b_sstart = (const u32*) bk;
+		const u32* b_sstart = (const u32*) bk;       bk += ((n + 1) * 4 + 7) / 8 * 8;
+		bk += (nsl * 4 + 7) / 8 * 8;
+		const u32* b_bits = (const u32*) bk;
 		// the dense copy outlives this call when the transfer to the host is asynchronous: a buffer of its own, not the arena
 		lp.mark("me_second_call");
 		HIP_TRY(hipStreamSynchronize(c->pairs_stream));          // an earlier asynchronous copy may still be reading the buffer
@@ -1496,7 +1526,7 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 		vdjx_pair* d_dense = (vdjx_pair*) c->me_dense;
 		if (nsl) {
 			vdjx_prof_scope ps(c, "k_gather_pairs");
-			hipLaunchKernelGGL(k_gather_pairs, dim3((u32) nsl), dim3(256), 0, st, (const vdjx_pair*) c->me_pairs, (u32) n, slice_hits, b_sstart, b_off, b_pre, d_dense);
+			hipLaunchKernelGGL(k_gather_pairs, dim3((u32) nsl), dim3(256), 0, st, (const vdjx_pair*) c->me_pairs, (const u32*) c->me_hit, (u32) n, slice_hits, b_sstart, b_off, b_bits, b_pre, d_dense);
 		}
 		if (async) {
 			// the pairs cross PCIe on the copy stream beside whatever the caller does next (vdjx_map_emit_end waits for them); the
