@@ -63,7 +63,9 @@ int vdjx_pool_load_forward(vdjx_ctx* ctx, const uint8_t* primary_reads, size_t n
 int vdjx_pool_load_forward_begin(vdjx_ctx* ctx, const uint8_t* primary_reads, size_t n_primary_reads,
                                  const uint8_t* secondary_reads, size_t n_secondary_reads, int rl, vdjx_pool** out);
 int vdjx_pool_wait(vdjx_pool* pool);
-/* same, ASCII pools already resident in device memory (16-byte aligned) */
+/* same, ASCII pools already resident in device memory (16-byte aligned).  The two buffers must stay valid and unchanged until
+ * vdjx_pool_free: bases and masks are packed, but the quality characters are NOT copied -- the few k-mers whose quality sums
+ * matter (count below 1 + ceil(mq/20), A2:454-465) read them from the records where they lie (a third of the packing's bytes). */
 int vdjx_pool_load_device(vdjx_ctx* ctx, const uint8_t* d_primary, size_t n_primary,
                           const uint8_t* d_secondary, size_t n_secondary, int rl, vdjx_pool** out);
 size_t vdjx_pool_records(const vdjx_pool* pool);

@@ -153,7 +153,9 @@ struct vdjx_pool {
 	u64* d_bases = nullptr;      // [R][2]  (hi, lo) of the 2*rl-bit read, first base most significant
 	u64* d_nmask = nullptr;      // [R] bit i = base i is not ACGT
 	u64* d_lowq = nullptr;       // [R] bit i = (uint8)(q-33) < 20
-	uint8_t* d_quals = nullptr;  // [R][qstride] Phred+33 characters
+	const uint8_t* d_quals = nullptr;   // quality rows (Phred+33 characters), `qstride` bytes apart: packed [R][qstride] inside d_block, or -- for a pool
+	const uint8_t* d_quals2 = nullptr;  // loaded from ASCII records that stay resident in device memory (vdjx_pool_load_device) -- the records' own
+	size_t q_split = ~(size_t) 0;       // quality characters, never copied: records below q_split in d_quals (primary), the others in d_quals2
 	u32* pending_bad = nullptr;  // vdjx_pool_load_forward_begin: the load is still running on the copy stream (vdjx_pool_wait)
 };
 
@@ -213,6 +215,11 @@ struct vdjx_laps {
 // ----------------------------------------------------------------------------------------------
 // device helpers
 // ----------------------------------------------------------------------------------------------
+// where the quality characters of a record are (see vdjx_pool::d_quals)
+struct vdjx_qrows {
+	const uint8_t* a; const uint8_t* b; size_t split; int stride;
+	__host__ __device__ inline const uint8_t* row(size_t rec) const { return rec < split ? a + rec * (size_t) stride : b + (rec - split) * (size_t) stride; }
+};
 __host__ __device__ inline u64 vdjx_mix(u64 lo, u64 hi) {
 	u64 x = lo ^ (hi * 0x9E3779B97F4A7C15ull) ^ 0x2545F4914F6CDD1Dull;
 	x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;

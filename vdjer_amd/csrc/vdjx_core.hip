@@ -276,7 +276,8 @@ __device__ inline u64 sw_spread32(u32 v) {
 // FWD: `ascii` holds the reads as extracted only; packed records 2i (as is) and 2i+1 (the reverse complement add_to_buffer writes
 // after every read, bam_read.c:232-243: bases complemented in reverse order, qualities reversed) come out of read i, the second one
 // from the PACKED first one (bit reversal, no second pass over the characters)
-template <bool FWD>
+// WQ: the quality rows are written (false: they are read from the resident ASCII records later, nothing to copy)
+template <bool FWD, bool WQ>
 __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restrict__ ascii, size_t n_rec, int rl, size_t rec0,
                                                          u64* __restrict__ bases, u64* __restrict__ nmask,
                                                          u64* __restrict__ lowq, uint8_t* __restrict__ quals, int qstride,
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 				u32 q = __builtin_amdgcn_alignbyte(rq[j + 1], rq[j], sq & 3u);
 				q = (q & vm) | (0x21212121u & ~vm);
 				lq |= (u64) (sw_gather4(sw_low_quality(q)) & ((1u << valid) - 1u)) << (4u * j);
-				if (FWD) my[j] = q; else qrow[j] = q;
+				if (FWD) my[j] = q; else if (WQ) qrow[j] = q;
 			}
 		}
 		if (FWD) for (u32 j = nw; j < QW; j++) my[j] = 0x21212121u;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 		((ulonglong2*) bases)[g] = make_ulonglong2(bhi, blo);
 		nmask[g] = nm;
 		lowq[g] = lq;
-		if (!FWD) {
+		if (!FWD && WQ) {
 			// the row straight from the registers: four 16-byte stores per record (the staging through LDS of the FWD variant costs
 			// 17 KB per workgroup, i.e. half the workgroups per CU and half the bytes in flight)
 			uint4* qd = (uint4*) (quals + g * (size_t) qstride);
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 	}
 }
 
-static int pool_alloc(vdjx_ctx* c, size_t R, size_t n_primary, int rl, vdjx_pool** out, u32** d_bad) {
+static int pool_alloc(vdjx_ctx* c, size_t R, size_t n_primary, int rl, vdjx_pool** out, u32** d_bad, bool external_quals = false) {
 	*out = nullptr;
 	if (rl < 1 || rl > VDJX_MAX_READ_LEN) { vdjx_set_error("read length %d outside [1,%d]", rl, VDJX_MAX_READ_LEN); return VDJX_ELIMIT; }
 	if (R >= (1ull << 31)) { vdjx_set_error("too many records for one GPU: %zu", R); return VDJX_ELIMIT; }
@@ -421,7 +422,8 @@ static int pool_alloc(vdjx_ctx* c, size_t R, size_t n_primary, int rl, vdjx_pool
 	p->qstride = (rl + 15) / 16 * 16;
 	size_t Ra = (R ? R : 1);
 	Ra = (Ra + 15) & ~(size_t) 15;               // keeps every array 256-byte aligned inside the block
-	hipError_t e = c->blocks.acquire(Ra * (32 + (size_t) p->qstride) + 256, &p->d_block, &p->block_cap);
+	const size_t qbytes = external_quals ? 0 : (size_t) p->qstride;
+	hipError_t e = c->blocks.acquire(Ra * (32 + qbytes) + 256, &p->d_block, &p->block_cap);
 	if (e != hipSuccess) {
 		vdjx_set_error("pool alloc: %s", hipGetErrorString(e));
 		vdjx_pool_free(p);
@@ -430,20 +432,22 @@ static int pool_alloc(vdjx_ctx* c, size_t R, size_t n_primary, int rl, vdjx_pool
 	p->d_bases = (u64*) p->d_block;
 	p->d_nmask = (u64*) (p->d_block + Ra * 16);
 	p->d_lowq = (u64*) (p->d_block + Ra * 24);
-	p->d_quals = (uint8_t*) (p->d_block + Ra * 32);
-	*d_bad = (u32*) (p->d_block + Ra * (32 + (size_t) p->qstride));
+	p->d_quals = p->d_quals2 = (const uint8_t*) (p->d_block + Ra * 32);
+	*d_bad = (u32*) (p->d_block + Ra * (32 + qbytes));
 	(void) hipMemset(*d_bad, 0, 8);                  // (synchronous: the packing may run on either stream); [0] bad strand bytes, [1] other bases
 	*out = p;
 	return VDJX_OK;
 }
 
-static void pack_launch(vdjx_ctx* c, hipStream_t st, vdjx_pool* p, const uint8_t* d_ascii, size_t n, size_t rec0, bool fwd, u32* d_bad) {
+static void pack_launch(vdjx_ctx* c, hipStream_t st, vdjx_pool* p, const uint8_t* d_ascii, size_t n, size_t rec0, bool fwd, u32* d_bad, bool write_quals = true) {
 	if (!n) return;
 	const size_t in_words = ((size_t) PACK_RECS * (2 * p->rl + 1) + 3) / 4 + 4;
 	const size_t lds = (((in_words + 3) & ~(size_t) 3) + (fwd ? (size_t) PACK_RECS * (p->qstride / 4 + 1) : 0)) * 4 + 16;
 	const dim3 grid((unsigned) ((n + PACK_RECS - 1) / PACK_RECS));
-	if (fwd) hipLaunchKernelGGL(k_pool_pack<true>, grid, dim3(PACK_RECS), lds, st, d_ascii, n, p->rl, rec0, p->d_bases, p->d_nmask, p->d_lowq, p->d_quals, p->qstride, d_bad);
-	else hipLaunchKernelGGL(k_pool_pack<false>, grid, dim3(PACK_RECS), lds, st, d_ascii, n, p->rl, rec0, p->d_bases, p->d_nmask, p->d_lowq, p->d_quals, p->qstride, d_bad);
+	uint8_t* q = (uint8_t*) p->d_block + (((p->n_records ? p->n_records : 1) + 15) & ~(size_t) 15) * 32;        // (the packed rows, when there are any)
+	if (fwd) hipLaunchKernelGGL((k_pool_pack<true, true>), grid, dim3(PACK_RECS), lds, st, d_ascii, n, p->rl, rec0, p->d_bases, p->d_nmask, p->d_lowq, q, p->qstride, d_bad);
+	else if (write_quals) hipLaunchKernelGGL((k_pool_pack<false, true>), grid, dim3(PACK_RECS), lds, st, d_ascii, n, p->rl, rec0, p->d_bases, p->d_nmask, p->d_lowq, q, p->qstride, d_bad);
+	else hipLaunchKernelGGL((k_pool_pack<false, false>), grid, dim3(PACK_RECS), lds, st, d_ascii, n, p->rl, rec0, p->d_bases, p->d_nmask, p->d_lowq, q, p->qstride, d_bad);
 }
 
 static int pool_finish(vdjx_ctx* c, vdjx_pool* p, u32* d_bad, vdjx_pool** out) {
@@ -470,13 +474,18 @@ static int pool_pack_device(vdjx_ctx* c, const uint8_t* d_primary, size_t n_prim
                             const uint8_t* d_secondary, size_t n_secondary, int rl, vdjx_pool** out) {
 	vdjx_pool* p;
 	u32* d_bad;
-	int rc = pool_alloc(c, n_primary + n_secondary, n_primary, rl, &p, &d_bad);
+	// the quality characters stay where they are: the records are resident, and only the few low-count k-mers ever look at a row
+	int rc = pool_alloc(c, n_primary + n_secondary, n_primary, rl, &p, &d_bad, true);
 	if (rc) return rc;
 	*out = nullptr;
+	p->qstride = 2 * rl + 1;
+	p->d_quals = d_primary + 1 + rl;
+	p->d_quals2 = d_secondary + 1 + rl;
+	p->q_split = n_primary;
 	{
 		vdjx_prof_scope ps(c, "k_pool_pack");
-		pack_launch(c, c->stream, p, d_primary, n_primary, 0, false, d_bad);
-		pack_launch(c, c->stream, p, d_secondary, n_secondary, n_primary, false, d_bad);
+		pack_launch(c, c->stream, p, d_primary, n_primary, 0, false, d_bad, false);
+		pack_launch(c, c->stream, p, d_secondary, n_secondary, n_primary, false, d_bad, false);
 	}
 	return pool_finish(c, p, d_bad, out);
 }

@@ -461,15 +461,17 @@ struct SurvOutG { u64* lo; u64* hi; u32* gcnt; u64* gfirst; u32* n; u32 cap; };
 
 // one gated instance's k qualities added to its k-mer's row of packed u16 sums (A2:337-339, 354-361): the qualities from position
 // qoff of the record's row on (qoff = 0 for the first instance: the RECORD's first k qualities, the load-bearing bug)
-__device__ inline void rd_add_qualities(u32* row, const uint8_t* __restrict__ qrow, int qstride, u32 qoff, int k) {
-	const uint4* qv = (const uint4*) qrow;
-	u32 w[16];
+__device__ inline void rd_add_qualities(u32* row, const uint8_t* __restrict__ qrow, int rl, u32 qoff, int k) {
+	// the row may start at any byte (quality characters inside resident ASCII records): aligned words, funnelled; a word is only
+	// fetched if it holds a character of the row (never past the end of the caller's buffer)
+	const u32 sh = (u32) ((uintptr_t) qrow & 3u);
+	const u32* qw = (const u32*) (qrow - sh);
+	const u32 need = (sh + (u32) rl + 3u) / 4u;                       // words holding the row
+	u32 d[17], w[16];
 #pragma unroll
-	for (int v4 = 0; v4 < 4; v4++) {
-		uint4 x = make_uint4(0x21212121u, 0x21212121u, 0x21212121u, 0x21212121u);
-		if (v4 * 16 < qstride) x = qv[v4];
-		w[v4 * 4 + 0] = x.x; w[v4 * 4 + 1] = x.y; w[v4 * 4 + 2] = x.z; w[v4 * 4 + 3] = x.w;
-	}
+	for (int i = 0; i < 17; i++) d[i] = (u32) i < need ? qw[i] : 0x21212121u;
+#pragma unroll
+	for (int i = 0; i < 16; i++) w[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
 #pragma unroll
 	for (int pq = 0; pq < 64; pq++) {
 		const int j = pq - (int) qoff;
@@ -483,7 +485,7 @@ __device__ inline void rd_add_qualities(u32* row, const uint8_t* __restrict__ qr
 template <typename TUP>
 __global__ __launch_bounds__(RD_THREADS, 4) void k_gated_reduce(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
                                                              const u64* __restrict__ bases, const u64* __restrict__ nmask,
-                                                             const uint8_t* __restrict__ quals, int qstride, int k, u64 rec_base,
+                                                             vdjx_qrows quals, int rl, int k, u64 rec_base,
                                                              u32 mf, u32 cmin, u32 mqq, u32 tlow, SurvOutG so,
                                                              u64* __restrict__ g_distinct, u32* __restrict__ g_err) {
 	typedef typename TUP::hi_t THI;
@@ -638,7 +640,7 @@ __global__ __launch_bounds__(RD_THREADS, 4) void k_gated_reduce(const TUP* __res
 					const u32 lid = s_lowid[slot];
 					if (lid == NONE16 || lid < l0 || lid >= l0 + RD_A) continue;
 					const u64 rec = (inst >> 6) - rec_base;
-					rd_add_qualities(acc + (lid - l0) * K3B_KW, quals + (size_t) rec * (size_t) qstride, qstride, inst == s_first[slot] ? 0u : (u32) (inst & 63u), k);
+					rd_add_qualities(acc + (lid - l0) * K3B_KW, quals.row(rec), rl, inst == s_first[slot] ? 0u : (u32) (inst & 63u), k);
 				}
 				__syncthreads();
 				for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
@@ -1022,7 +1024,7 @@ __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ qu
                                                     const Partial* __restrict__ dense, const u32* __restrict__ dense_ref,
                                                     const u32* __restrict__ dstart, u32 NBo, const u64* __restrict__ low_inst,
                                                     const u64* __restrict__ bases, const u64* __restrict__ nmask,
-                                                    const uint8_t* __restrict__ quals, int qstride, u64 rec_base, int k,
+                                                    vdjx_qrows quals, u64 rec_base, int k,
                                                     uint8_t* __restrict__ replies) {
 	const u32 qi = blockIdx.x;
 	if (qi >= nq) return;
@@ -1056,10 +1058,10 @@ __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ qu
 			if (inst == finst) continue;
 			const u64 rec = (inst >> 6) - rec_base;
 			const u32 off = (u32) (inst & 63u);
-			acc += (u32) (uint8_t) (quals[(size_t) rec * (size_t) qstride + off + lane] - 33);
+			acc += (u32) (uint8_t) (quals.row(rec)[off + lane] - 33);
 		}
 	}
-	const uint8_t* fr = quals + (size_t) frec * (size_t) qstride;
+	const uint8_t* fr = quals.row(frec);
 	out[REPLY_Q0 + lane] = (uint8_t) (acc > 255u ? 255u : acc);
 	out[REPLY_Q0 + REPLY_KQ + lane] = (uint8_t) (fr[foff + lane] - 33);
 	out[REPLY_Q0 + 2 * REPLY_KQ + lane] = (uint8_t) (fr[lane] - 33);
@@ -1961,7 +1963,7 @@ struct PersistAlloc {
 	}
 };
 
-struct PoolView { const u64* bases; const u64* nmask; const uint8_t* quals; int qstride; };
+struct PoolView { const u64* bases; const u64* nmask; vdjx_qrows quals; int rl; };
 
 size_t tune(const char* name, size_t dflt) {      // undocumented tuning knobs for experiments (profiles/README.md)
 	const char* v = getenv(name);
@@ -2119,7 +2121,7 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 	SurvOutG so{sv->lo, sv->hi, sv->gcnt, sv->gfirst, n_surv, cap};
 	if (t.N) {
 		vdjx_prof_scope ps(c, "k_gated_reduce");
-		hipLaunchKernelGGL(k_gated_reduce<TUP>, dim3(t.NB), dim3(RD_THREADS), 0, st, t.t, t.bucket_start, pv.bases, pv.nmask, pv.quals, pv.qstride, k, rec_base,
+		hipLaunchKernelGGL(k_gated_reduce<TUP>, dim3(t.NB), dim3(RD_THREADS), 0, st, t.t, t.bucket_start, pv.bases, pv.nmask, pv.quals, pv.rl, k, rec_base,
 		                   mfu, cmin, mqq, tlow, so, g_distinct, g_err);
 	}
 	u32 ns = 0, err = 0;
@@ -2471,7 +2473,7 @@ int kmer_build_impl2(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, 
 	GTuples<TUP> t;
 	int rc = stage_gated_partition<TUP>(c, db, pool, 0, k, 0, 0, &t);
 	if (rc) return rc;
-	PoolView pv{pool->d_bases, pool->d_nmask, pool->d_quals, pool->qstride};
+	PoolView pv{pool->d_bases, pool->d_nmask, vdjx_qrows{pool->d_quals, pool->d_quals2, pool->q_split, pool->qstride}, pool->rl};
 	SurvivorsG sv;
 	rc = stage_gated_reduce<TUP>(c, db, t, pv, 0, k, mf, mq, &sv);
 	if (rc) return rc;
@@ -2803,7 +2805,7 @@ extern "C" int vdjx_shard_reply(vdjx_shard* s, const void* d_queries, const uint
 	{
 		vdjx_prof_scope ps(c, "k_shard_reply");
 		hipLaunchKernelGGL(k_shard_reply, dim3(nq), dim3(64), 0, st, (const uint2*) d_queries, nq, d_off, G, s->dense, s->dense_ref, s->dstart, s->NBo,
-		                   s->low_inst, p->d_bases, p->d_nmask, p->d_quals, p->qstride, s->rec_stride * (u64) s->rank, s->k, (uint8_t*) d_replies);
+		                   s->low_inst, p->d_bases, p->d_nmask, vdjx_qrows{p->d_quals, p->d_quals2, p->q_split, p->qstride}, s->rec_stride * (u64) s->rank, s->k, (uint8_t*) d_replies);
 	}
 	HIP_TRY(hipStreamSynchronize(st));          // `off` staging dies with this frame
 	HIP_TRY(hipGetLastError());
