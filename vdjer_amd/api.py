@@ -75,15 +75,20 @@ class Graph:
 class Pool:
     def __init__(self, ctx: "Context", handle, rl: int, n_records: int):
         self.ctx, self.h, self.rl, self.n_records = ctx, handle, rl, n_records
+        self._src = None           # host buffers an asynchronous load still reads
 
     def wait(self):
         """after pool_load_forward(..., wait=False): the pool is loaded (and well-formed) once this returns"""
-        check(_lib.lib().vdjx_pool_wait(self.h), "vdjx_pool_wait")
+        try:
+            check(_lib.lib().vdjx_pool_wait(self.h), "vdjx_pool_wait")
+        finally:
+            self._src = None
 
     def free(self):
         if self.h:
-            _lib.lib().vdjx_pool_free(self.h)
+            _lib.lib().vdjx_pool_free(self.h)      # (waits for a load that is still running)
             self.h = None
+            self._src = None
             if self in getattr(self.ctx, "_pools", []):
                 self.ctx._pools.remove(self)
 
@@ -179,6 +184,10 @@ class Context:
         fn = self.L.vdjx_pool_load_forward if wait else self.L.vdjx_pool_load_forward_begin      # wait=False: Pool.wait() before use
         check(fn(self.h, pp, npri, ps, nsec, rl, C.byref(h)), "vdjx_pool_load_forward")
         p = Pool(self, h, rl, 2 * (npri + nsec))
+        if not wait and not isinstance(primary_reads, int):
+            # the upload is still reading these buffers (they may be contiguous COPIES made above): the pool keeps them alive
+            # until Pool.wait() / free()
+            p._src = (pri, sec)
         self._pools.append(p)
         return p
 

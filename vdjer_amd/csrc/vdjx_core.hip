@@ -583,10 +583,12 @@ extern "C" int vdjx_pool_wait(vdjx_pool* p) {
 	if (!p->pending_bad) return VDJX_OK;
 	if (!vdjx_ctx_alive(p->ctx)) { vdjx_set_error("vdjx_pool_wait: the pool's context is gone"); return VDJX_ESTATE; }
 	HIP_TRY(hipSetDevice(p->device));
-	u32 bad = 0;
-	HIP_TRY(hipMemcpyAsync(&bad, p->pending_bad, 4, hipMemcpyDeviceToHost, p->ctx->copy_stream));
+	u32 both[2] = {0, 0};
+	HIP_TRY(hipMemcpyAsync(both, p->pending_bad, 8, hipMemcpyDeviceToHost, p->ctx->copy_stream));
 	HIP_TRY(hipStreamSynchronize(p->ctx->copy_stream));
 	p->pending_bad = nullptr;
+	const u32 bad = both[0];
+	p->ctx->stats["pool_other_bases"] = both[1];      // IUPAC codes packed as N (see pool_finish)
 	if (bad) { vdjx_set_error("pool: %u records do not start with the '0' strand byte", bad); return VDJX_EINVAL; }
 	return VDJX_OK;
 }
