@@ -24,10 +24,11 @@ extern "C" {
 #define VDJX_OK 0
 #define VDJX_EINVAL (-1)   /* bad argument */
 #define VDJX_EHIP (-2)     /* HIP runtime error */
-#define VDJX_ELIMIT (-3)   /* input exceeds a documented limit (rl <= 64, k <= 50, 2^32 records in all, 2^29 per GPU, 2^26 surviving k-mers) */
+#define VDJX_ELIMIT (-3)   /* input exceeds a documented limit (rl <= 160, k <= 50, 2^32 records in all (2^30 with reads of more than 64 bases), 2^29 per GPU, 2^26 surviving k-mers) */
 #define VDJX_ESTATE (-4)   /* call order violated (e.g. scorer used before its index was loaded) */
 
-#define VDJX_MAX_READ_LEN 64
+#define VDJX_MAX_READ_LEN 160   /* the reference takes up to 255 (bam_read.c:208 `char seq[256]`); reads of up to 64 bases run on the short-read kernels */
+#define VDJX_SHORT_READ_LEN 64
 #define VDJX_MAX_KMER 50    /* A2:70 MAX_KMER_LEN */
 
 typedef struct vdjx_ctx vdjx_ctx;
@@ -89,7 +90,8 @@ size_t vdjx_graph_nodes(const vdjx_graph* g);
 /* distinct gated k-mers before the prune ("Pre Num nodes", A2:407) */
 size_t vdjx_graph_pre_nodes(const vdjx_graph* g);
 /* Node i (0-based; reference node id = i+1, A2:188,200), in creation order:
- *   first_inst  record*64+offset of the first (ungated) occurrence, records counted over primary then secondary
+ *   first_inst  record << 6 | offset of the first (ungated) occurrence, records counted over primary then secondary
+ *               (pools of reads longer than 64 bases: record << 8 | offset)
  *   gated_count frequency of the pre_node (A2:130,345-347), saturated at 32765
  *   freq        node frequency (A2:119,261-265), saturated at 32765
  *   has_v/has_j A2:288-303

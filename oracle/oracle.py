@@ -114,8 +114,10 @@ def index_rows(anchors, start: int, end: int, max_dist: int = 5):
 
 
 def inst_kmer(pool, inst: int, k: int) -> str:
-    """ASCII k-mer of an instance index (record*64+offset) over primary-then-secondary records."""
-    rec, off = inst >> 6, inst & 63
+    """ASCII k-mer of an instance index (record << 6 | offset; reads of more than 64 bases: record << 8 | offset) over
+    primary-then-secondary records."""
+    ob = 8 if pool.rl > 64 else 6
+    rec, off = inst >> ob, inst & ((1 << ob) - 1)
     npri = pool.primary.shape[0]
     row = pool.primary[rec] if rec < npri else pool.secondary[rec - npri]
     return row[1 + off:1 + off + k].tobytes().decode()

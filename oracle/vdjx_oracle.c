@@ -131,7 +131,7 @@ static void add_to_table(vdjo_table* t, const char* seq, const char* qual, uint6
 			}
 			e->key = kmer;
 			e->first_read = seq;
-			e->first_inst = rec_index * 64 + (uint64_t) i;
+			e->first_inst = (rec_index << (rl > 64 ? 8 : 6)) + (uint64_t) i;      /* record << 6 | offset; reads of more than 64 bases: record << 8 | offset */
 			e->frequency = 1;
 			e->multi = 0;
 			/* A2:337-339: the record's FIRST k qualities, not the k-mer's (shadowed loop index) */
@@ -296,7 +296,7 @@ static void add_to_graph(vdjo_graph* g, const vdjo_table* pruned, const char* se
 			gnode* nd = &g->nodes[g->n++];
 			memset(nd, 0, sizeof *nd);
 			nd->kmer = kmer;
-			nd->first_inst = rec_index * 64 + (uint64_t) i;
+			nd->first_inst = (rec_index << (rl > 64 ? 8 : 6)) + (uint64_t) i;
 			nd->frequency = 1;
 			if (k > SEQ_LEN) {
 				int ok;

@@ -114,7 +114,7 @@ def test_kmer_build_edge_cases(ctx):
     with pytest.raises(api.VdjxError):
         ctx.pool_load(bad, pool.secondary, 50)
     with pytest.raises(api.VdjxError):
-        ctx.pool_load(np.full((2, 131), ord("0"), np.uint8), np.zeros((0, 131), np.uint8), 65)   # rl > 64
+        ctx.pool_load(np.full((2, 323), ord("0"), np.uint8), np.zeros((0, 323), np.uint8), 161)   # rl > 160
 
 
 def test_tandem_repeats_and_homopolymers(ctx):
@@ -524,15 +524,55 @@ def test_all_gated_all_distinct_overflows_the_lds_table(ctx):
     assert hg.pre_nodes > 6_000_000 and hg.n > 1000
 
 
-@pytest.mark.parametrize("rl,k,mf,mq", [(64, 35, 2, 60), (36, 25, 2, 40), (75 - 11, 50, 2, 60), (40, 40, 2, 30)])
+@pytest.mark.parametrize("rl,k,mf,mq", [(64, 35, 2, 60), (36, 25, 2, 40), (75 - 11, 50, 2, 60), (40, 40, 2, 30),
+                                        (65, 35, 2, 60), (75, 35, 3, 90), (100, 35, 3, 90), (100, 25, 2, 60), (151, 35, 3, 90), (151, 50, 2, 60),
+                                        (160, 21, 2, 40), (96, 50, 2, 60), (128, 35, 2, 60), (129, 35, 2, 230), (150, 150 - 100, 1, 20)])
 def test_other_read_lengths(ctx, rl, k, mf, mq):
-    """rl != 50 (records of 2*rl+1 bytes, up to the 64-base limit), including k == rl (one k-mer per record)"""
+    """rl != 50 (records of 2*rl+1 bytes): the short-read kernels up to 64 bases, including k == rl (one k-mer per record), and
+    the long-read record format (words, vdjx_pool) up to the 160-base limit -- 75 / 100 / 151 bp libraries; the oracle and the
+    reference take them as they are (bam_read.c:208)"""
     from vdjer_amd import synth
     rep = synth.make_repertoire(6, seed=71)
     pool = synth.make_reads(rep, 6000, noise_frac=0.3, seed=72, rl=rl, err=0.004, n_rate=0.002)
     vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
     jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
     run_both(ctx, pool, vc, jc, k, mf, mq)
+
+
+@pytest.mark.parametrize("rl", [75, 100, 151])
+def test_long_reads_forward_load_and_scorers(ctx, rl):
+    """reads of more than 64 bases through the rest of the path: the forward-only load (reverse-complement records derived on the
+    device) equals the full load, and the read index / window mapper / coverage test / mapped pairs equal the oracle's"""
+    from oracle import oracle
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(4, seed=91)
+    pool = synth.make_reads(rep, 12000, noise_frac=0.2, seed=92, rl=rl, ins_mean=max(175.0, rl + 40.0), err=0.003, n_rate=0.001)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    ctx.anchor_sets_load(vc, jc)
+    p1 = ctx.pool_load(pool.primary, pool.secondary, rl)
+    g1 = ctx.kmer_build(p1, 35, 3, 90)
+    p2 = ctx.pool_load_forward(pool.primary[0::2], pool.secondary[0::2], rl)
+    g2 = ctx.kmer_build(p2, 35, 3, 90)
+    for f in ("first_inst", "freq", "gated_count", "to_ids", "from_ids", "kmers"):
+        np.testing.assert_array_equal(getattr(g1, f), getattr(g2, f))
+    p2.free()
+    ix = oracle.ReadIndex(pool)
+    ctx.read_index_build(p1, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+    wins = [w for w in rep.windows() if w] + [t[s:s + 486] for t in rep.clones for s in (0, 40, 117)]
+    ins = int(max(175, rl + 40))
+    valid, npairs = ctx.window_score(wins, ins)
+    for i, w in enumerate(wins):
+        pairs, starts = ix.quick_map(w)
+        assert int(npairs[i]) == len(pairs), (i, rl)
+        assert int(valid[i]) == ix.coverage_is_valid(starts, len(w), ins), (i, rl)
+    contigs = [w[51:411] for w in wins]
+    offs, pairs = ctx.map_emit(contigs)
+    for i, cg in enumerate(contigs):
+        op, _ = ix.quick_map(cg)
+        mine = pairs[int(offs[i]):int(offs[i + 1])]
+        assert mine.tobytes() == op.tobytes(), (i, rl)
+    p1.free()
 
 
 def test_scorers_other_read_length_and_window_geometry(ctx):

@@ -87,6 +87,7 @@ struct vdjx_ctx {
 	hipStream_t copy_stream = nullptr;   // result copies that may run beside the next kernels (vdjx_graph_export_begin)
 	hipStream_t pairs_stream = nullptr;  // the mapped pairs' copy (vdjx_map_emit_begin): a stream of its own, so that waiting for one result is not waiting for the other
 	void* d_stage[2] = {nullptr, nullptr};          // vdjx_pool_load: upload staging (two chunks in flight)
+	size_t stage_cap = 0;
 	hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_packed[2] = {nullptr, nullptr};
 	bool profiling = false;
 	std::vector<std::string> prof_names;                 // insertion order
@@ -142,17 +143,24 @@ struct vdjx_ctx {
 	std::map<std::string, uint64_t> stats;
 };
 
+// Two record formats.  Reads of up to 64 bases (W = 2, M = 1, ob = 6): the read as ONE 2*rl-bit integer in two words (hi, lo), first base
+// most significant, right-aligned -- a k-mer is one 128-bit shift + mask.  Longer reads (up to VDJX_MAX_READ_LEN; W = 5, M = 3,
+// ob = 8): W words, LEFT-aligned, base i in bits 63-2(i%32), 62-2(i%32) of word i/32; masks of M words, bit i%64 of word i/64.
+// Instance ids are record << ob | offset.
+#define VDJX_LONG_W 5
+#define VDJX_LONG_M 3
 struct vdjx_pool {
 	vdjx_ctx* ctx = nullptr;
 	int device = 0;              // copy: a pool may be freed after its context
 	size_t n_primary = 0, n_records = 0;
 	int rl = 0;
 	int qstride = 0;
+	int W = 2, M = 1, ob = 6;    // words per read, words per mask, offset bits of an instance id
 	char* d_block = nullptr;     // one device block holds the four arrays below
 	size_t block_cap = 0;
-	u64* d_bases = nullptr;      // [R][2]  (hi, lo) of the 2*rl-bit read, first base most significant
-	u64* d_nmask = nullptr;      // [R] bit i = base i is not ACGT
-	u64* d_lowq = nullptr;       // [R] bit i = (uint8)(q-33) < 20
+	u64* d_bases = nullptr;      // [R][W]
+	u64* d_nmask = nullptr;      // [R][M] bit i = base i is not ACGT
+	u64* d_lowq = nullptr;       // [R][M] bit i = (uint8)(q-33) < 20
 	const uint8_t* d_quals = nullptr;   // quality rows (Phred+33 characters), `qstride` bytes apart: packed [R][qstride] inside d_block, or -- for a pool
 	const uint8_t* d_quals2 = nullptr;  // loaded from ASCII records that stay resident in device memory (vdjx_pool_load_device) -- the records' own
 	size_t q_split = ~(size_t) 0;       // quality characters, never copied: records below q_split in d_quals (primary), the others in d_quals2
@@ -228,6 +236,16 @@ __host__ __device__ inline u64 vdjx_mix(u64 lo, u64 hi) {
 	return x;
 }
 
+// hash of a read of W words (the read index: vdjx_rindex.hip, k_map_classify)
+template <int W>
+__device__ inline u64 ri_hash(const u64* __restrict__ w) {
+	if (W == 2) return vdjx_mix(w[1], w[0]);
+	u64 h = vdjx_mix(w[1], w[0]);
+#pragma unroll
+	for (int i = 2; i < W; i += 2) h = vdjx_mix(h ^ w[i], i + 1 < W ? w[i + 1] : 0ull);
+	return h;
+}
+
 // k-mer at offset o of a packed read (first base most significant), as a 2k-bit integer
 __host__ __device__ inline void vdjx_kmer_at(u64 bhi, u64 blo, int rl, int k, int o, u64& khi, u64& klo) {
 	u128 b = ((u128) bhi << 64) | blo;
@@ -253,6 +271,63 @@ __device__ inline void vdjx_kmer_at_lane(u64 bhi, u64 blo, int rl, int k, int o,
 	else if (k < 64) hi &= (1ull << (2 * k - 64)) - 1ull;
 	khi = hi;
 	klo = lo;
+}
+
+// ---- long reads (left-aligned words; see vdjx_pool) ----
+// k-mer at offset o of a read given as words w[0 .. W) followed by at least two readable words (their content never reaches the
+// result): the 128 bits from bit 2o of the stream, then the top 2k of them.  o may differ from lane to lane: 64-bit shifts only.
+__device__ inline void vdjx_kmer_at_words(const u64* __restrict__ w, int k, int o, u64& khi, u64& klo) {
+	const int wi = o >> 5;
+	const u32 s = 2u * ((u32) o & 31u);                     // 0 .. 62
+	const u64 x0 = w[wi], x1 = w[wi + 1], x2 = w[wi + 2];
+	const u64 hi = (x0 << s) | ((x1 >> 1) >> (63u - s));
+	const u64 lo = (x1 << s) | ((x2 >> 1) >> (63u - s));
+	const u32 r = 128u - 2u * (u32) k;                       // uniform; k <= 50: r >= 28
+	if (r >= 64u) { klo = hi >> (r - 64u); khi = 0; }
+	else { klo = (lo >> r) | (hi << (64u - r)); khi = hi >> r; }
+}
+// 32 bits = the 16 bases from base index bi on (zeros past the words), first base most significant
+__device__ inline u32 vdjx_bases16_words(const u64* __restrict__ w, int bi) {
+	const int wi = bi >> 5;
+	const u32 s = 2u * ((u32) bi & 31u);
+	const u64 hi = (w[wi] << s) | ((w[wi + 1] >> 1) >> (63u - s));
+	return (u32) (hi >> 32);
+}
+__device__ inline u32 vdjx_base_words(const u64* __restrict__ w, int i) { return (u32) (w[i >> 5] >> (62u - 2u * ((u32) i & 31u))) & 3u; }
+
+// masks of up to three words (bit i%64 of word i/64), by value
+struct vdjx_mask3 {
+	u64 w0, w1, w2;
+	__host__ __device__ inline u64 word(int i) const { return i == 0 ? w0 : (i == 1 ? w1 : (i == 2 ? w2 : 0ull)); }
+	__device__ inline bool test(int i) const { return (word(i >> 6) >> (i & 63)) & 1ull; }
+	__device__ inline void set(int i) { const u64 b = 1ull << (i & 63); if ((i >> 6) == 0) w0 |= b; else if ((i >> 6) == 1) w1 |= b; else w2 |= b; }
+	__device__ inline bool any() const { return (w0 | w1 | w2) != 0ull; }
+	// 64 bits from bit `from` on
+	__device__ inline u64 slice(int from) const {
+		const int i = from >> 6;
+		const u32 s = (u32) from & 63u;
+		return (word(i) >> s) | ((word(i + 1) << 1) << (63u - s));
+	}
+	// first set bit at or above `from`, or `none`
+	__device__ inline int next(int from, int none) const {
+		for (int i = from >> 6; i < 3; i++) {
+			u64 x = word(i);
+			if (i == (from >> 6)) x &= ~0ull << (from & 63);
+			if (x) return 64 * i + __builtin_ctzll(x);
+		}
+		return none;
+	}
+};
+// the 16 offsets base_o .. base_o+15 (base_o a multiple of 16) whose k bases are all clean: bit j set iff none of the bits
+// base_o+j .. base_o+j+k-1 of `bad` is, and base_o+j < P
+__device__ inline u32 vdjx_clean16(const vdjx_mask3& bad, int base_o, int k, int P) {
+	u64 lo = bad.slice(base_o), hi = bad.slice(base_o + 64);
+	int cur = 1;
+	while (cur * 2 <= k) { lo |= (lo >> cur) | (hi << (64 - cur)); hi |= hi >> cur; cur *= 2; }     // (cur <= 32)
+	const int rest = k - cur;                                                                       // 0 .. 31
+	if (rest) lo |= (lo >> rest) | (hi << (64 - rest));
+	const int left = P - base_o;
+	return ~(u32) lo & 0xFFFFu & (left >= 16 ? 0xFFFFu : (left > 0 ? (1u << left) - 1u : 0u));
 }
 
 // 32 bits of the packed read from bit `pos` (0 .. 127) up, and one base, for positions that differ from lane to lane (see above)

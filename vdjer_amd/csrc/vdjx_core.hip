@@ -303,7 +303,7 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 		const u32 nw = ((u32) rl + 3u) / 4u;
 		// every LDS word of the record is asked for before the first is used (unrolled to the longest record, uniform guards): the
 		// loop with one read per trip waited for LDS twenty-six times per record
-		constexpr int NWMAX = (VDJX_MAX_READ_LEN + 3) / 4;
+		constexpr int NWMAX = (VDJX_SHORT_READ_LEN + 3) / 4;
 		u32 rb[NWMAX + 1], rq[NWMAX + 1];
 		const u32 sb = start + 1u, sq = start + 1u + (u32) rl;
 #pragma unroll
@@ -411,6 +411,54 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 	}
 }
 
+// reads of more than 64 bases (left-aligned words, vdjx_pool): one thread per record, character by character from the LDS-staged
+// records -- the plain form of the packing; long reads are the rare case and take the simple kernel
+#define PACKL_RECS 128
+template <bool FWD, bool WQ>
+__global__ __launch_bounds__(PACKL_RECS) void k_pool_pack_long(const uint8_t* __restrict__ ascii, size_t n_rec, int rl, size_t rec0, int W, int M,
+                                                                u64* __restrict__ bases, u64* __restrict__ nmask, u64* __restrict__ lowq,
+                                                                uint8_t* __restrict__ quals, int qstride, u32* __restrict__ bad_strand) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const int reclen = 2 * rl + 1;
+	const u32 tid = threadIdx.x;
+	const size_t first = (size_t) blockIdx.x * PACKL_RECS;
+	const u32 nhere = (u32) (n_rec - first < PACKL_RECS ? n_rec - first : PACKL_RECS);
+	const size_t bytes = (size_t) nhere * (size_t) reclen;
+	const uint8_t* src = ascii + first * (size_t) reclen;       // 16-byte aligned: 128*reclen is a multiple of 16
+	const size_t nvec = bytes / 16;
+	for (size_t v = tid; v < nvec; v += PACKL_RECS) ((uint4*) lds)[v] = ((const uint4*) src)[v];
+	for (size_t b = nvec * 16 + tid; b < bytes; b += PACKL_RECS) lds[b] = src[b];
+	__syncthreads();
+	if (tid >= nhere) return;
+	const uint8_t* r = lds + (size_t) tid * reclen;
+	if (r[0] != '0') atomicAdd(bad_strand, 1u);
+	u32 other = 0;
+	for (int rev = 0; rev < (FWD ? 2 : 1); rev++) {
+		const size_t g = FWD ? rec0 + 2 * (first + tid) + (size_t) rev : rec0 + first + tid;
+		u64 acc = 0, nm = 0, lq = 0;
+		for (int i = 0; i < rl; i++) {
+			const int si = rev ? rl - 1 - i : i;
+			const u32 ch = r[1 + si];
+			u32 code = (0xD8u >> (((ch >> 1) & 3u) * 2u)) & 3u;                  // seq_to_kmer.c:6-29: A0 T1 C2 G3
+			if (rev) code ^= 1u;                                                // complement: A<->T, C<->G
+			const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+			other += (!acgt && ch != 'N') ? 1u : 0u;
+			acc = (acc << 2) | (acgt ? code : 0u);
+			nm |= (u64) (!acgt) << (i & 63);
+			lq |= (u64) ((u32) (uint8_t) (r[1 + rl + si] - 33) < 20u) << (i & 63);
+			if ((i & 31) == 31 || i == rl - 1) { bases[g * (size_t) W + (i >> 5)] = acc << (2 * (31 - (i & 31))); acc = 0; }
+			if ((i & 63) == 63 || i == rl - 1) { nmask[g * (size_t) M + (i >> 6)] = nm; lowq[g * (size_t) M + (i >> 6)] = lq; nm = 0; lq = 0; }
+		}
+		for (int w = (rl + 31) / 32; w < W; w++) bases[g * (size_t) W + w] = 0;
+		for (int w = (rl + 63) / 64; w < M; w++) { nmask[g * (size_t) M + w] = 0; lowq[g * (size_t) M + w] = 0; }
+		if (WQ) {
+			uint8_t* q = quals + g * (size_t) qstride;
+			for (int i = 0; i < qstride; i++) q[i] = i < rl ? r[1 + rl + (rev ? rl - 1 - i : i)] : (uint8_t) 33;
+		}
+	}
+	if (other) atomicAdd(bad_strand + 1, other);
+}
+
 static int pool_alloc(vdjx_ctx* c, size_t R, size_t n_primary, int rl, vdjx_pool** out, u32** d_bad, bool external_quals = false) {
 	*out = nullptr;
 	if (rl < 1 || rl > VDJX_MAX_READ_LEN) { vdjx_set_error("read length %d outside [1,%d]", rl, VDJX_MAX_READ_LEN); return VDJX_ELIMIT; }
@@ -418,22 +466,25 @@ static int pool_alloc(vdjx_ctx* c, size_t R, size_t n_primary, int rl, vdjx_pool
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_pool* p = new vdjx_pool();
 	p->ctx = c; p->device = c->device; p->n_primary = n_primary; p->n_records = R; p->rl = rl;
+	if (rl > VDJX_SHORT_READ_LEN) { p->W = VDJX_LONG_W; p->M = VDJX_LONG_M; p->ob = 8; }
 	vdjx_clear_errors();
 	p->qstride = (rl + 15) / 16 * 16;
 	size_t Ra = (R ? R : 1);
 	Ra = (Ra + 15) & ~(size_t) 15;               // keeps every array 256-byte aligned inside the block
 	const size_t qbytes = external_quals ? 0 : (size_t) p->qstride;
-	hipError_t e = c->blocks.acquire(Ra * (32 + qbytes) + 256, &p->d_block, &p->block_cap);
+	const size_t wb = (size_t) p->W * 8, mb = (size_t) p->M * 8;
+	// (+64: the long-read kernels read up to two words past a record's bases)
+	hipError_t e = c->blocks.acquire(Ra * (wb + 2 * mb + qbytes) + 256 + 64, &p->d_block, &p->block_cap);
 	if (e != hipSuccess) {
 		vdjx_set_error("pool alloc: %s", hipGetErrorString(e));
 		vdjx_pool_free(p);
 		return VDJX_EHIP;
 	}
-	p->d_bases = (u64*) p->d_block;
-	p->d_nmask = (u64*) (p->d_block + Ra * 16);
-	p->d_lowq = (u64*) (p->d_block + Ra * 24);
-	p->d_quals = p->d_quals2 = (const uint8_t*) (p->d_block + Ra * 32);
-	*d_bad = (u32*) (p->d_block + Ra * (32 + qbytes));
+	p->d_nmask = (u64*) p->d_block;
+	p->d_lowq = (u64*) (p->d_block + Ra * mb);
+	p->d_quals = p->d_quals2 = (const uint8_t*) (p->d_block + Ra * 2 * mb);
+	*d_bad = (u32*) (p->d_block + Ra * (2 * mb + qbytes));
+	p->d_bases = (u64*) (p->d_block + Ra * (2 * mb + qbytes) + 256);
 	(void) hipMemset(*d_bad, 0, 8);                  // (synchronous: the packing may run on either stream); [0] bad strand bytes, [1] other bases
 	*out = p;
 	return VDJX_OK;
@@ -441,10 +492,18 @@ static int pool_alloc(vdjx_ctx* c, size_t R, size_t n_primary, int rl, vdjx_pool
 
 static void pack_launch(vdjx_ctx* c, hipStream_t st, vdjx_pool* p, const uint8_t* d_ascii, size_t n, size_t rec0, bool fwd, u32* d_bad, bool write_quals = true) {
 	if (!n) return;
+	uint8_t* q = (uint8_t*) p->d_quals;        // (the packed rows, when there are any)
+	if (p->W > 2) {
+		const size_t lds = (size_t) PACKL_RECS * (2 * p->rl + 1) + 16;
+		const dim3 grid((unsigned) ((n + PACKL_RECS - 1) / PACKL_RECS));
+#define PL(F, Q) hipLaunchKernelGGL((k_pool_pack_long<F, Q>), grid, dim3(PACKL_RECS), lds, st, d_ascii, n, p->rl, rec0, p->W, p->M, p->d_bases, p->d_nmask, p->d_lowq, q, p->qstride, d_bad)
+		if (fwd) PL(true, true); else if (write_quals) PL(false, true); else PL(false, false);
+#undef PL
+		return;
+	}
 	const size_t in_words = ((size_t) PACK_RECS * (2 * p->rl + 1) + 3) / 4 + 4;
 	const size_t lds = (((in_words + 3) & ~(size_t) 3) + (fwd ? (size_t) PACK_RECS * (p->qstride / 4 + 1) : 0)) * 4 + 16;
 	const dim3 grid((unsigned) ((n + PACK_RECS - 1) / PACK_RECS));
-	uint8_t* q = (uint8_t*) p->d_block + (((p->n_records ? p->n_records : 1) + 15) & ~(size_t) 15) * 32;        // (the packed rows, when there are any)
 	if (fwd) hipLaunchKernelGGL((k_pool_pack<true, true>), grid, dim3(PACK_RECS), lds, st, d_ascii, n, p->rl, rec0, p->d_bases, p->d_nmask, p->d_lowq, q, p->qstride, d_bad);
 	else if (write_quals) hipLaunchKernelGGL((k_pool_pack<false, true>), grid, dim3(PACK_RECS), lds, st, d_ascii, n, p->rl, rec0, p->d_bases, p->d_nmask, p->d_lowq, q, p->qstride, d_bad);
 	else hipLaunchKernelGGL((k_pool_pack<false, false>), grid, dim3(PACK_RECS), lds, st, d_ascii, n, p->rl, rec0, p->d_bases, p->d_nmask, p->d_lowq, q, p->qstride, d_bad);
@@ -513,13 +572,18 @@ static int pool_load_host(vdjx_ctx* c, const uint8_t* primary, size_t n_primary,
 	*out = nullptr;
 	const size_t reclen = 2 * (size_t) rl + 1;
 	const size_t stage_bytes = (size_t) LOAD_CHUNK_RECS * reclen + 16;
-	if (!c->d_stage[0]) {
+	if (stage_bytes > c->stage_cap) {              // (sized for the longest records seen so far)
+		(void) hipStreamSynchronize(c->copy_stream);
+		(void) hipStreamSynchronize(c->stream);
 		for (int i = 0; i < 2; i++) {
+			if (c->d_stage[i]) (void) hipFree(c->d_stage[i]);
+			c->d_stage[i] = nullptr;
 			hipError_t e = hipMalloc(&c->d_stage[i], stage_bytes);
-			if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming);
-			if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_packed[i], hipEventDisableTiming);
-			if (e != hipSuccess) { vdjx_set_error("pool staging: %s", hipGetErrorString(e)); vdjx_pool_free(p); return VDJX_EHIP; }
+			if (e == hipSuccess && !c->ev_copied[i]) e = hipEventCreateWithFlags(&c->ev_copied[i], hipEventDisableTiming);
+			if (e == hipSuccess && !c->ev_packed[i]) e = hipEventCreateWithFlags(&c->ev_packed[i], hipEventDisableTiming);
+			if (e != hipSuccess) { c->stage_cap = 0; vdjx_set_error("pool staging: %s", hipGetErrorString(e)); vdjx_pool_free(p); return VDJX_EHIP; }
 		}
+		c->stage_cap = stage_bytes;
 	}
 	if (async) {
 		// the whole load on the copy stream (chunk after chunk: copy, pack), so that the main stream keeps computing on another pool;

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <numeric>
+#include <type_traits>
 #include <string.h>
 #include <stdlib.h>
 
@@ -223,7 +224,25 @@ __device__ inline u64 vdjx_clean_offsets(u64 bad, int k, int P) {
 // 128-bit shift by a per-lane amount gave wrong k-mers on gfx950 when the amounts of a wave lay on both sides of 64).
 #define GL_WAVE_BYTES 3072u         // per wave: 64 x 16-byte packed bases, 1024 x 2-byte entries (lane << 6 | offset)
 
+// long reads (W words per read, vdjx_pool): a lane's record in LDS is W + 2 words (two zero words behind it: the k-mer extraction
+// reads three words from the k-mer's first), entries are lane << 8 | offset
+#define GL_ROW_LONG (VDJX_LONG_W + 2)
+#define GL_WAVE_BYTES_LONG (64u * GL_ROW_LONG * 8u + 2048u)
+__device__ inline vdjx_mask3 load_bad3(const u64* __restrict__ nmask, const u64* __restrict__ lowq, size_t r) {
+	vdjx_mask3 b;
+	b.w0 = nmask[r * VDJX_LONG_M] | (lowq ? lowq[r * VDJX_LONG_M] : 0ull);
+	b.w1 = nmask[r * VDJX_LONG_M + 1] | (lowq ? lowq[r * VDJX_LONG_M + 1] : 0ull);
+	b.w2 = nmask[r * VDJX_LONG_M + 2] | (lowq ? lowq[r * VDJX_LONG_M + 2] : 0ull);
+	return b;
+}
+__device__ inline void stage_row_long(u64* row, const u64* __restrict__ bases, size_t r) {
+#pragma unroll
+	for (int w = 0; w < VDJX_LONG_W; w++) row[w] = bases[r * VDJX_LONG_W + w];
+	row[VDJX_LONG_W] = 0; row[VDJX_LONG_W + 1] = 0;
+}
+
 // K2a': bucket sizes over the gated instances (include_kmer, A2:240-259: no 'N', every Phred >= 20), listed densely per wave
+template <bool LONG>
 __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                              const u64* __restrict__ lowq, size_t R, int rl, int k, u32 nb_bits,
                                                              size_t rpb, u32* __restrict__ bucket_cnt) {
@@ -231,9 +250,10 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 	const u32 NB = 1u << nb_bits;
 	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) hist[i] = 0;
 	__syncthreads();
-	uint8_t* wv = (uint8_t*) (hist + NB) + (threadIdx.x >> 6) * GL_WAVE_BYTES;
+	uint8_t* wv = (uint8_t*) (hist + NB) + (threadIdx.x >> 6) * (LONG ? GL_WAVE_BYTES_LONG : GL_WAVE_BYTES);
 	ulonglong2* wb = (ulonglong2*) wv;
-	uint16_t* wl = (uint16_t*) (wv + 1024);
+	u64* wrow = (u64*) wv;
+	uint16_t* wl = (uint16_t*) (wv + (LONG ? 64u * GL_ROW_LONG * 8u : 1024u));
 	const u32 lane = threadIdx.x & 63u;
 	const size_t r0 = (size_t) blockIdx.x * rpb;
 	const size_t r1 = r0 + rpb < R ? r0 + rpb : R;
@@ -241,24 +261,31 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 	for (size_t rb = r0; rb < r1; rb += HIST_THREADS) {
 		const size_t r = rb + threadIdx.x;
 		u64 G = 0;
+		vdjx_mask3 bad{~0ull, ~0ull, ~0ull};
 		if (r < r1) {
-			const RecView v = load_rec(bases, nmask, lowq, r);
-			G = vdjx_clean_offsets(v.nm | v.lq, k, P);
-			wb[lane] = make_ulonglong2(v.bhi, v.blo);
+			if (LONG) { bad = load_bad3(nmask, lowq, r); stage_row_long(wrow + lane * GL_ROW_LONG, bases, r); }
+			else {
+				const RecView v = load_rec(bases, nmask, lowq, r);
+				G = vdjx_clean_offsets(v.nm | v.lq, k, P);
+				wb[lane] = make_ulonglong2(v.bhi, v.blo);
+			}
 		}
 		for (int ob = 0; ob < P; ob += 16) {
-			const u32 g = (u32) (G >> ob) & 0xFFFFu;
+			const u32 g = LONG ? vdjx_clean16(bad, ob, k, P) : (u32) (G >> ob) & 0xFFFFu;
 			const u32 c = (u32) __popc(g);
 			const u32 incl = (u32) vdjx_wave_scan_add((int) c);
 			const u32 total = (u32) __builtin_amdgcn_readlane((int) incl, 63);
 			if (!total) continue;                                     // (wave-uniform)
 			u32 at = incl - c;
-			for (u32 gg = g; gg; gg &= gg - 1) wl[at++] = (uint16_t) ((lane << 6) | (u32) (ob + __builtin_ctz(gg)));
+			for (u32 gg = g; gg; gg &= gg - 1) wl[at++] = (uint16_t) ((lane << (LONG ? 8 : 6)) | (u32) (ob + __builtin_ctz(gg)));
 			for (u32 i = lane; i < total; i += 64) {
 				const u32 e = wl[i];
-				const ulonglong2 bb = wb[e >> 6];
 				u64 khi, klo;
-				vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) (e & 63u), khi, klo);
+				if (LONG) vdjx_kmer_at_words(wrow + (e >> 8) * GL_ROW_LONG, k, (int) (e & 255u), khi, klo);
+				else {
+					const ulonglong2 bb = wb[e >> 6];
+					vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) (e & 63u), khi, klo);
+				}
 				atomicAdd(&hist[(u32) (vdjx_mix(klo, khi) >> (64 - nb_bits))], 1u);
 			}
 		}
@@ -273,7 +300,7 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 // simply retried with half the records.  The gated instances of a round are listed once (dense, see above) as descriptors
 // {record in the round (16 bits), offset (6), bucket (10)}; the placement pass reads the descriptors, not the records' offsets.
 #define PARTR_STAGE_BYTES 98304u
-template <typename TUP>
+template <typename TUP, bool LONG>
 __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                                  const u64* __restrict__ lowq, size_t R, u64 rec_base, int rl, int k,
                                                                  u32 shift, u32 nbk, size_t rpb, u32 rr0, u32* __restrict__ gcur,
@@ -284,14 +311,16 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 	__shared__ u32 cnt[PART_MAXB], base[PART_MAXB + 1], cur[PART_MAXB], gbase[PART_MAXB], tmp[PART_THREADS];
 	__shared__ u32 s_n;
 	constexpr u32 ROUND = PARTR_STAGE_BYTES / sizeof(TUP);
+	constexpr int OB = LONG ? 8 : 6;                                  // offset bits (descriptor: record in the round << (OB + 10) | offset << 10 | bucket)
 	const int P = rl - k + 1;
 	const u32 rr_min = ROUND / (u32) P;                              // always fits
 	u32 rr = rr0 > rr_min ? rr0 : rr_min;
 	const u32 mask = nbk - 1;
 	const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	uint8_t* wv = smem + wave * GL_WAVE_BYTES;
+	uint8_t* wv = smem + wave * (LONG ? GL_WAVE_BYTES_LONG : GL_WAVE_BYTES);
 	ulonglong2* wb = (ulonglong2*) wv;
-	uint16_t* wl = (uint16_t*) (wv + 1024);
+	u64* wrow = (u64*) wv;
+	uint16_t* wl = (uint16_t*) (wv + (LONG ? 64u * GL_ROW_LONG * 8u : 1024u));
 	const size_t r0 = (size_t) blockIdx.x * rpb;
 	const size_t r1 = r0 + rpb < R ? r0 + rpb : R;
 	size_t rs = r0;
@@ -303,31 +332,38 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 		for (size_t rb = rs; rb < re; rb += PART_THREADS) {
 			const size_t r = rb + threadIdx.x;
 			u64 G = 0;
+			vdjx_mask3 bad{~0ull, ~0ull, ~0ull};
 			if (r < re) {
-				const RecView v = load_rec(bases, nmask, lowq, r);
-				G = vdjx_clean_offsets(v.nm | v.lq, k, P);
-				wb[lane] = make_ulonglong2(v.bhi, v.blo);
+				if (LONG) { bad = load_bad3(nmask, lowq, r); stage_row_long(wrow + lane * GL_ROW_LONG, bases, r); }
+				else {
+					const RecView v = load_rec(bases, nmask, lowq, r);
+					G = vdjx_clean_offsets(v.nm | v.lq, k, P);
+					wb[lane] = make_ulonglong2(v.bhi, v.blo);
+				}
 			}
 			const u32 loc0 = (u32) (rb - rs) + wave * 64u;                // this wave's first record in the round
 			for (int ob = 0; ob < P; ob += 16) {
-				const u32 g = (u32) (G >> ob) & 0xFFFFu;
+				const u32 g = LONG ? vdjx_clean16(bad, ob, k, P) : (u32) (G >> ob) & 0xFFFFu;
 				const u32 c = (u32) __popc(g);
 				const u32 incl = (u32) vdjx_wave_scan_add((int) c);
 				const u32 total = (u32) __builtin_amdgcn_readlane((int) incl, 63);
 				if (!total) continue;                                     // (wave-uniform)
 				u32 at = incl - c;
-				for (u32 gg = g; gg; gg &= gg - 1) wl[at++] = (uint16_t) ((lane << 6) | (u32) (ob + __builtin_ctz(gg)));
+				for (u32 gg = g; gg; gg &= gg - 1) wl[at++] = (uint16_t) ((lane << OB) | (u32) (ob + __builtin_ctz(gg)));
 				u32 dbase = 0;
 				if (lane == 0) dbase = atomicAdd(&s_n, total);
 				dbase = (u32) __builtin_amdgcn_readlane((int) dbase, 0);
 				for (u32 i = lane; i < total; i += 64) {
 					const u32 e = wl[i];
-					const ulonglong2 bb = wb[e >> 6];
 					u64 khi, klo;
-					vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) (e & 63u), khi, klo);
+					if (LONG) vdjx_kmer_at_words(wrow + (e >> 8) * GL_ROW_LONG, k, (int) (e & 255u), khi, klo);
+					else {
+						const ulonglong2 bb = wb[e >> 6];
+						vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) (e & 63u), khi, klo);
+					}
 					const u32 b = (u32) (vdjx_mix(klo, khi) >> shift) & mask;
 					atomicAdd(&cnt[b], 1u);
-					if (dbase + i < ROUND) desc[dbase + i] = ((loc0 + (e >> 6)) << 16) | ((e & 63u) << 10) | b;
+					if (dbase + i < ROUND) desc[dbase + i] = ((loc0 + (e >> OB)) << (OB + 10)) | ((e & ((1u << OB) - 1u)) << 10) | b;
 				}
 			}
 		}
@@ -346,12 +382,15 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 		const u32 n = base[nbk];
 		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
 			const u32 d = desc[i];
-			const size_t r = rs + (d >> 16);
-			const u32 o = (d >> 10) & 63u;
-			const ulonglong2 bb = ((const ulonglong2*) bases)[r];
+			const size_t r = rs + (d >> (OB + 10));
+			const u32 o = (d >> 10) & ((1u << OB) - 1u);
 			u64 khi, klo;
-			vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) o, khi, klo);
-			TUP::store(&stage[atomicAdd(&cur[d & 1023u], 1u)], TUP::make(klo, khi, ((rec_base + (u64) r) << 6) | (u64) o));
+			if (LONG) vdjx_kmer_at_words(bases + r * VDJX_LONG_W, k, (int) o, khi, klo);      // (two words past the last record are readable: pool_alloc)
+			else {
+				const ulonglong2 bb = ((const ulonglong2*) bases)[r];
+				vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) o, khi, klo);
+			}
+			TUP::store(&stage[atomicAdd(&cur[d & 1023u], 1u)], TUP::make(klo, khi, ((rec_base + (u64) r) << OB) | (u64) o));
 		}
 		__syncthreads();
 		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
@@ -461,7 +500,26 @@ struct SurvOutG { u64* lo; u64* hi; u32* gcnt; u64* gfirst; u32* n; u32 cap; };
 
 // one gated instance's k qualities added to its k-mer's row of packed u16 sums (A2:337-339, 354-361): the qualities from position
 // qoff of the record's row on (qoff = 0 for the first instance: the RECORD's first k qualities, the load-bearing bug)
+// compare_read (A2:142-144): the two records' sequences, not-ACGT masks included
+__device__ inline bool reads_equal(const u64* __restrict__ bases, const u64* __restrict__ nmask, int rl, u64 a, u64 b) {
+	if (rl <= VDJX_SHORT_READ_LEN) {
+		const ulonglong2 x = ((const ulonglong2*) bases)[a];
+		const ulonglong2 y = ((const ulonglong2*) bases)[b];
+		return x.x == y.x && x.y == y.y && nmask[a] == nmask[b];
+	}
+	u64 d = 0;
+#pragma unroll
+	for (int w = 0; w < VDJX_LONG_W; w++) d |= bases[a * VDJX_LONG_W + w] ^ bases[b * VDJX_LONG_W + w];
+#pragma unroll
+	for (int w = 0; w < VDJX_LONG_M; w++) d |= nmask[a * VDJX_LONG_M + w] ^ nmask[b * VDJX_LONG_M + w];
+	return d == 0;
+}
+
 __device__ inline void rd_add_qualities(u32* row, const uint8_t* __restrict__ qrow, int rl, u32 qoff, int k) {
+	if (rl > VDJX_SHORT_READ_LEN) {                            // long reads: the plain form (rows of up to 160 characters; a rare path)
+		for (int j = 0; j < k; j++) atomicAdd(&row[j >> 1], (u32) (uint8_t) (qrow[qoff + (u32) j] - 33u) << (16 * (j & 1)));
+		return;
+	}
 	// the row may start at any byte (quality characters inside resident ASCII records): aligned words, funnelled; a word is only
 	// fetched if it holds a character of the row (never past the end of the caller's buffer)
 	const u32 sh = (u32) ((uintptr_t) qrow & 3u);
@@ -485,7 +543,7 @@ __device__ inline void rd_add_qualities(u32* row, const uint8_t* __restrict__ qr
 template <typename TUP>
 __global__ __launch_bounds__(RD_THREADS, 4) void k_gated_reduce(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
                                                              const u64* __restrict__ bases, const u64* __restrict__ nmask,
-                                                             vdjx_qrows quals, int rl, int k, u64 rec_base,
+                                                             vdjx_qrows quals, int rl, int ob, int k, u64 rec_base,
                                                              u32 mf, u32 cmin, u32 mqq, u32 tlow, SurvOutG so,
                                                              u64* __restrict__ g_distinct, u32* __restrict__ g_err) {
 	typedef typename TUP::hi_t THI;
@@ -596,8 +654,9 @@ __global__ __launch_bounds__(RD_THREADS, 4) void k_gated_reduce(const TUP* __res
 						const u32 qi = atomicAdd(&s_nq, 1u);
 						if (qi < RD_Q) { q_slot[qi] = (u32) slot; q_inst[qi] = inst; }
 					}
-					if (!(st & ST_MULTI) && (inst >> 6) != (fi >> 6)) {
-						const u32 o1 = (u32) (inst & 63u), o0 = (u32) (fi & 63u);
+					if (!(st & ST_MULTI) && (inst >> ob) != (fi >> ob)) {
+						const u32 om = (1u << ob) - 1u;
+						const u32 o1 = (u32) inst & om, o0 = (u32) fi & om;
 						const u32 d = o1 > o0 ? o1 - o0 : o0 - o1;
 						if (d && d < (u32) k && !vdjx_kmer_has_period(r_t[j].hi(), r_t[j].lo, k, d)) atomicOr(&s_state[slot], ST_MULTI);
 						else pend |= 1u << j;
@@ -609,10 +668,8 @@ __global__ __launch_bounds__(RD_THREADS, 4) void k_gated_reduce(const TUP* __res
 					if (!((pend >> j) & 1u)) continue;
 					const int slot = r_slot[j];
 					if (*(volatile u32*) &s_state[slot] & ST_MULTI) continue;
-					const u64 rec = (r_t[j].inst() >> 6) - rec_base, frec = (s_first[slot] >> 6) - rec_base;
-					const ulonglong2 x = ((const ulonglong2*) bases)[rec];
-					const ulonglong2 y = ((const ulonglong2*) bases)[frec];
-					if (x.x != y.x || x.y != y.y || nmask[rec] != nmask[frec]) atomicOr(&s_state[slot], ST_MULTI);
+					const u64 rec = (r_t[j].inst() >> ob) - rec_base, frec = (s_first[slot] >> ob) - rec_base;
+					if (!reads_equal(bases, nmask, rl, rec, frec)) atomicOr(&s_state[slot], ST_MULTI);
 				}
 				if (!one_chunk) __syncthreads();             // (the next chunk reuses the registers only; the barrier keeps the chunks' phases apart)
 			}
@@ -639,8 +696,8 @@ __global__ __launch_bounds__(RD_THREADS, 4) void k_gated_reduce(const TUP* __res
 					}
 					const u32 lid = s_lowid[slot];
 					if (lid == NONE16 || lid < l0 || lid >= l0 + RD_A) continue;
-					const u64 rec = (inst >> 6) - rec_base;
-					rd_add_qualities(acc + (lid - l0) * K3B_KW, quals.row(rec), rl, inst == s_first[slot] ? 0u : (u32) (inst & 63u), k);
+					const u64 rec = (inst >> ob) - rec_base;
+					rd_add_qualities(acc + (lid - l0) * K3B_KW, quals.row(rec), rl, inst == s_first[slot] ? 0u : (u32) inst & ((1u << ob) - 1u), k);
 				}
 				__syncthreads();
 				for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
@@ -1387,15 +1444,48 @@ __global__ void k_chain_words(const u32* __restrict__ succ, const ulonglong2* __
 // every offset.
 // Every wave appends its items to blocks of `blk_items` slots it reserves from the global cursor (unused slots of a block are
 // filled with IT_HOLE); item counts per survivor range go to range_cnt.
-__global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restrict__ bases, const u64* __restrict__ nmask, size_t R, int rl, int k,
+// the two record formats behind one face (vdjx_pool): what the walk asks of a record, and the masks over its offsets
+struct WalkRecS {                       // reads of up to 64 bases: two registers
+	u64 bhi, blo; int rl;
+	__device__ inline void kmer_u(int k, int o, u64& hi, u64& lo) const { vdjx_kmer_at(bhi, blo, rl, k, o, hi, lo); }          // o uniform
+	__device__ inline void kmer_l(int k, int o, u64& hi, u64& lo) const { vdjx_kmer_at_lane(bhi, blo, rl, k, o, hi, lo); }     // o per lane
+	__device__ inline u32 bases16(int bi) const {                // bases bi .. bi+15, first most significant, zeros past the read
+		const int sh = 2 * (rl - 16 - bi);
+		const u32 rw_dn = vdjx_bits_at_lane(bhi, blo, (u32) (sh > 0 ? sh : 0));
+		const u32 up = (u32) (sh < 0 ? -sh : 0);
+		return (rw_dn << (up & 31u)) & (0u - (u32) (up < 32u));
+	}
+	__device__ inline u32 base(int i) const { return vdjx_base_at_lane(bhi, blo, rl, i); }
+};
+struct WalkRecL {                       // longer reads: a row of words in LDS
+	const u64* row;
+	__device__ inline void kmer_u(int k, int o, u64& hi, u64& lo) const { vdjx_kmer_at_words(row, k, o, hi, lo); }
+	__device__ inline void kmer_l(int k, int o, u64& hi, u64& lo) const { vdjx_kmer_at_words(row, k, o, hi, lo); }
+	__device__ inline u32 bases16(int bi) const { return vdjx_bases16_words(row, bi); }
+	__device__ inline u32 base(int i) const { return vdjx_base_words(row, i); }
+};
+__device__ inline bool wm_test(u64 m, int i) { return (m >> i) & 1ull; }
+__device__ inline bool wm_test(const vdjx_mask3& m, int i) { return m.test(i); }
+__device__ inline void wm_set(u64& m, int i) { m |= 1ull << i; }
+__device__ inline void wm_set(vdjx_mask3& m, int i) { m.set(i); }
+__device__ inline int wm_next(u64 m, int from, int none) { const u64 x = from < 64 ? m & (~0ull << from) : 0ull; return x ? __builtin_ctzll(x) : none; }
+__device__ inline int wm_next(const vdjx_mask3& m, int from, int none) { return m.next(from, none); }
+__device__ inline u32 wm_slice32(u64 m, int from) { return from < 64 ? (u32) (m >> from) : 0u; }
+__device__ inline u32 wm_slice32(const vdjx_mask3& m, int from) { return (u32) m.slice(from); }
+
+template <bool LONG>
+__global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restrict__ bases, const u64* __restrict__ nmask, size_t R, int rl, int ob_bits, int k,
                                                              SurvTable t, const u32* __restrict__ succ, const u64* __restrict__ linw, ItemFmt f,
                                                              u32 range_shift, u32 n_ranges,
                                                              u64* __restrict__ raw, u64 raw_cap, u32 blk_items,
                                                              unsigned long long* __restrict__ g_cursor,
                                                              u32* __restrict__ range_cnt, u32* __restrict__ g_err, u32 dbg) {
-	extern __shared__ u32 hist[];                 // [n_ranges]
+	extern __shared__ u32 hist[];                 // [n_ranges] (+ LONG: one row of GL_ROW_LONG words per thread)
+	typedef typename std::conditional<LONG, vdjx_mask3, u64>::type MaskT;
+	typedef typename std::conditional<LONG, WalkRecL, WalkRecS>::type RecT;
 	for (u32 i = threadIdx.x; i < n_ranges; i += WALK_THREADS) hist[i] = 0;
 	__syncthreads();
+	u64* myrow = (u64*) (hist + ((n_ranges + 1u) & ~1u)) + threadIdx.x * GL_ROW_LONG;
 	const int P = rl - k + 1;
 	const size_t per = ((R + gridDim.x - 1) / gridDim.x + WALK_THREADS - 1) / WALK_THREADS * WALK_THREADS;
 	const size_t r0 = (size_t) blockIdx.x * per;
@@ -1407,22 +1497,36 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 	for (size_t rb = r0; rb < r1; rb += WALK_THREADS) {
 		const size_t r = rb + threadIdx.x;
 		const bool live = r < r1;
-		RecView v;
-		v.bhi = v.blo = 0; v.nm = ~0ull; v.lq = 0;
-		if (live) v = load_rec(bases, nmask, nullptr, r);
-		// V: the offsets whose k bases are all valid (bit o of nm = base o is N or masked)
-		u64 inv = v.nm;
-		{
-			int cur = 1;
-			while (cur * 2 <= k) { inv |= inv >> cur; cur *= 2; }
-			inv |= inv >> (k - cur);
+		RecT v;
+		MaskT V{};                                    // the offsets whose k bases are all valid (bit o of nm = base o is N or masked)
+		if constexpr (LONG) {
+			v.row = myrow;
+			if (live) {
+				stage_row_long(myrow, bases, r);
+				const vdjx_mask3 nm = load_bad3(nmask, nullptr, r);
+				for (int o16 = 0; o16 < P; o16 += 16) {
+					const u64 g = (u64) vdjx_clean16(nm, o16, k, P) << (o16 & 63);
+					if ((o16 >> 6) == 0) V.w0 |= g; else if ((o16 >> 6) == 1) V.w1 |= g; else V.w2 |= g;
+				}
+			} else
+				for (int w = 0; w < GL_ROW_LONG; w++) myrow[w] = 0;
+		} else {
+			v.bhi = v.blo = 0; v.rl = rl;
+			if (live) {
+				const RecView rv = load_rec(bases, nmask, nullptr, r);
+				v.bhi = rv.bhi; v.blo = rv.blo;
+				u64 inv = rv.nm;
+				int cur = 1;
+				while (cur * 2 <= k) { inv |= inv >> cur; cur *= 2; }
+				inv |= inv >> (k - cur);
+				V = ~inv & (P >= 64 ? ~0ull : (1ull << P) - 1ull);
+			}
 		}
-		const u64 V = live ? ~inv & ((1ull << P) - 1ull) : 0ull;
-		int o = V ? __builtin_ctzll(V) : P;                      // the offset this lane works on; P: done
+		int o = wm_next(V, 0, P);                               // the offset this lane works on; P: done
 		int s = -1;                                              // its survivor, if known
 		u32 in = 0;                                              // has_prev << 2 | first base of the predecessor k-mer
 		bool first = true, have_c = false;
-		u64 C = 0;                                               // valid offsets the k-mer filter lets through (once have_c)
+		MaskT C{};                                               // valid offsets the k-mer filter lets through (once have_c)
 		while (__ballot(o < P)) {
 			// ---- lookups ----
 			const bool need = o < P && s < 0;
@@ -1434,30 +1538,29 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 					for (int j = 0; j < 4; j++) {
 						const int oo = ob + j;
 						wv[j] = 0; bt[j] = 0;
-						if (mine && oo >= o && oo < P && ((V >> oo) & 1ull)) {
+						if (mine && oo >= o && oo < P && wm_test(V, oo)) {
 							u64 khi, klo;
-							vdjx_kmer_at(v.bhi, v.blo, rl, k, oo, khi, klo);
+							v.kmer_u(k, oo, khi, klo);
 							const u32 bit = (u32) (vdjx_mix(klo, khi) >> 40) & t.bloom_mask;
 							bt[j] = bit & 31u;
 							wv[j] = (dbg & 8u) ? 0xFFFFFFFFu : t.bloom[bit >> 5];
 						}
 					}
 #pragma unroll
-					for (int j = 0; j < 4; j++) if ((wv[j] >> bt[j]) & 1u) C |= 1ull << (ob + j);
+					for (int j = 0; j < 4; j++) if ((wv[j] >> bt[j]) & 1u) wm_set(C, ob + j);
 				}
 				if (mine) have_c = true;
 			}
 			if (need) {
 				bool filtered = false;
 				if (!first) {
-					const u64 cm = C & ~((1ull << o) - 1ull);
-					o = cm ? __builtin_ctzll(cm) : P;
+					o = wm_next(C, o, P);
 					filtered = true;
 				}
 				first = false;
 				if (o < P) {
 					u64 khi, klo;
-					vdjx_kmer_at_lane(v.bhi, v.blo, rl, k, o, khi, klo);
+					v.kmer_l(k, o, khi, klo);
 					if (dbg & 8u) s = (klo & 3u) ? (int) ((u32) vdjx_mix(klo, khi) % f.ns) : -1;
 					else s = (filtered || (dbg & 16u)) ? surv_lookup2(t, klo, khi) : surv_lookup2f(t, klo, khi);
 					in = 0;
@@ -1474,17 +1577,13 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				const u32 lw = (((((u32) w0 & 0xFFFFu) << 16) | ((u32) w1 & 0xFFFFu)) << a) >> 16;
 				const u32 ow = ((((u32) w0 & 0xFFFF0000u) | ((u32) w1 >> 16)) << a) >> 16;
 				const u32 bw = (u32) (((((w0 >> 32) << 32) | (w1 >> 32)) << (2 * a)) >> 32);
-				const int sh = 2 * (rl - 16 - (o + k));             // the read's bases o+k .. o+k+15 in the same layout
-				// (per-lane positions: no 128-bit shift by a VGPR amount, see vdjx_kmer_at_lane)
-				const u32 rw_dn = vdjx_bits_at_lane(v.bhi, v.blo, (u32) (sh > 0 ? sh : 0));
-				const u32 up = (u32) (sh < 0 ? -sh : 0);
-				const u32 rw = (rw_dn << (up & 31u)) & (0u - (u32) (up < 32u));
+				const u32 rw = v.bases16(o + k);                   // the read's bases o+k .. o+k+15 in the same layout
 				const u32 x = bw ^ rw;
 				const u32 nl = ~lw & 0xFFFFu;
 				const u32 m_base = x ? (u32) __builtin_clz(x) >> 1 : 16u;
 				const u32 m_lin = nl ? (u32) __builtin_clz(nl) - 16u : 16u;
-				const u64 nv = ~(V >> (o + 1));                     // (bits at and above P are invalid: never all ones)
-				const u32 m_valid = (u32) __builtin_ctzll(nv);
+				const u32 nv = ~wm_slice32(V, o + 1);                // (17 offsets matter; bits at and above P are invalid)
+				const u32 m_valid = nv ? (u32) __builtin_ctz(nv) : 32u;
 				u32 steps = m_base < m_lin ? m_base : m_lin;
 				steps = steps < m_valid ? steps : m_valid;
 				const bool capped = steps >= 16u;                     // (reads with more than 17 offsets) the chain goes on: next round from s + 16
@@ -1493,10 +1592,10 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				// where the next round starts
 				const int o2 = o + (int) rem;
 				int s2 = -1;
-				if (o2 < P && ((V >> o2) & 1ull)) {
+				if (o2 < P && wm_test(V, o2)) {
 					if (capped) s2 = s + 16;
 					else if ((ow >> (15u - steps)) & 1u) {                     // the last node has successors off the chain
-						const u32 bb = vdjx_base_at_lane(v.bhi, v.blo, rl, o2 + k - 1);
+						const u32 bb = v.base(o2 + k - 1);
 						const u32 nx = succ[((u32) s + steps) * 4u + bb];
 						s2 = nx == NONE32 ? -1 : (int) nx;
 					}
@@ -1506,13 +1605,13 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 			}
 			// ---- the run, one item per block of 16 (and per 2^lb nodes) ----
 			u32 pin = in;
-			if (act) in = s >= 0 ? (4u | vdjx_base_at_lane(v.bhi, v.blo, rl, o - 1)) : 0u;      // (next round: first base of the k-mer at o - 1)
+			if (act) in = s >= 0 ? (4u | v.base(o - 1)) : 0u;      // (next round: first base of the k-mer at o - 1)
 			while (__ballot(rem > 0)) {
 				const bool close = rem > 0;
 				u32 len = 16u - (pp & 15u);
 				len = len < rem ? len : rem;
 				len = len < f.maxlen ? len : f.maxlen;
-				const u64 item = (f.maxlen > 1 ? (u64) (len - 1) << f.len_shift : 0ull) | ((u64) pp << IT_SURV_SHIFT) | ((u64) pin << 35) | ((u64) r << 6) | (u64) po;
+				const u64 item = (f.maxlen > 1 ? (u64) (len - 1) << f.len_shift : 0ull) | ((u64) pp << IT_SURV_SHIFT) | ((u64) pin << 35) | ((u64) r << ob_bits) | (u64) po;
 				const u64 m = __ballot(close);
 				const u32 cnt = (u32) __popcll(m);
 				if (fill + cnt > blk_items) {                             // (wave-uniform)
@@ -1531,7 +1630,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				fill += cnt;
 				if (close) {
 					rem -= len; pp += len; po += len;
-					pin = 4u | vdjx_base_at_lane(v.bhi, v.blo, rl, (int) po - 1);        // the next piece's predecessor is the node before it
+					pin = 4u | v.base((int) po - 1);        // the next piece's predecessor is the node before it
 				}
 			}
 		}
@@ -1663,7 +1762,7 @@ __device__ inline void rc_min(u64* p, u64 v) { atomicMin((unsigned long long*) p
 #define RC_SLOTS 45u
 // IT = u32 while the local instance ids fit 32 bits (fewer than 2^26 records on this GPU): 38.5 bytes of LDS per survivor instead of 66
 template <u32 SB, typename IT>
-__global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ items, const u32* __restrict__ range_start, ItemFmt f, u32 ns, u64 rec_base,
+__global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ items, const u32* __restrict__ range_start, ItemFmt f, u32 ns, u64 rec_base, int ob,
                                                         const u32* __restrict__ fbw, u32* __restrict__ ucnt, u64* __restrict__ ufirst, u64* __restrict__ in_first,
                                                         unsigned long long* __restrict__ n_inst) {
 	__shared__ u32 c[SB / 16 * RC_SLOTS];
@@ -1744,7 +1843,7 @@ __global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ 
 		}
 	}
 	__syncthreads();
-	const u64 add = rec_base << 6;
+	const u64 add = rec_base << ob;
 	u32 my_cnt = 0;
 	for (u32 i = threadIdx.x; i < SB; i += RC_THREADS) {
 		const u32 sb = (s0 + i) >> 4;
@@ -1861,20 +1960,20 @@ struct NodeOut {
 };
 
 // round 2: first sights are 38-bit instance ids (record << 6 | offset); the bitmap runs over the compact index record*P + offset
-__device__ inline u64 inst_compact(u64 inst, u32 P) { return (inst >> 6) * (u64) P + (inst & 63ull); }
+__device__ inline u64 inst_compact(u64 inst, u32 P, int ob) { return (inst >> ob) * (u64) P + (inst & ((1ull << ob) - 1ull)); }
 
-__global__ void k_mark_first2(const u64* __restrict__ ufirst, u32 n, u32 P, u32* __restrict__ bits) {
+__global__ void k_mark_first2(const u64* __restrict__ ufirst, u32 n, u32 P, int ob, u32* __restrict__ bits) {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	const u64 c = inst_compact(ufirst[i], P);
+	const u64 c = inst_compact(ufirst[i], P, ob);
 	atomicOr(&bits[c >> 5], 1u << (u32) (c & 31));
 }
 
-__global__ void k_node_rank2(const u64* __restrict__ ufirst, u32 n, u32 P, const u32* __restrict__ bits, const u32* __restrict__ word_pre,
+__global__ void k_node_rank2(const u64* __restrict__ ufirst, u32 n, u32 P, int ob, const u32* __restrict__ bits, const u32* __restrict__ word_pre,
                              const u32* __restrict__ block_pre, u32* __restrict__ rank) {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	const u64 c = inst_compact(ufirst[i], P);
+	const u64 c = inst_compact(ufirst[i], P, ob);
 	const u64 w = c >> 5;
 	rank[i] = block_pre[w / POPC_WORDS] + word_pre[w] + __popc(bits[w] & ((1u << (u32) (c & 31)) - 1u));
 }
@@ -1963,7 +2062,7 @@ struct PersistAlloc {
 	}
 };
 
-struct PoolView { const u64* bases; const u64* nmask; vdjx_qrows quals; int rl; };
+struct PoolView { const u64* bases; const u64* nmask; vdjx_qrows quals; int rl; int ob; };
 
 size_t tune(const char* name, size_t dflt) {      // undocumented tuning knobs for experiments (profiles/README.md)
 	const char* v = getenv(name);
@@ -2017,11 +2116,14 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 	HIP_TRY(db.alloc(&hcnt, NBH));
 	HIP_TRY(db.alloc(&hstart, NBH + 1));
 	HIP_TRY(hipMemsetAsync(hcnt, 0, (size_t) NBH * 4, st));
-	const size_t lds_hist = (size_t) NBH * 4 + (HIST_THREADS / 64) * GL_WAVE_BYTES;
-	HIP_TRY(hipFuncSetAttribute((const void*) k_gated_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_hist));
+	const bool lng = pool->W > 2;
+	const size_t lds_hist = (size_t) NBH * 4 + (HIST_THREADS / 64) * (lng ? GL_WAVE_BYTES_LONG : GL_WAVE_BYTES);
+	HIP_TRY(hipFuncSetAttribute((const void*) k_gated_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_hist));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_gated_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_hist));
 	{
 		vdjx_prof_scope ps(c, "k_gated_hist");
-		hipLaunchKernelGGL(k_gated_hist, dim3(nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, pool->rl, k, HB, rpb, hcnt);
+		if (lng) hipLaunchKernelGGL(k_gated_hist<true>, dim3(nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, pool->rl, k, HB, rpb, hcnt);
+		else hipLaunchKernelGGL(k_gated_hist<false>, dim3(nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, pool->rl, k, HB, rpb, hcnt);
 	}
 	dbg_sync(c, "k_gated_hist");
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, hcnt, NBH, hstart);
@@ -2047,7 +2149,8 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 	HIP_TRY(db.alloc(&out->t, (size_t) N + 1));
 	constexpr u32 stage_tuples = PARTR_STAGE_BYTES / (u32) sizeof(TUP);
 	constexpr u32 lds_partr = PARTR_STAGE_BYTES + stage_tuples * 4;
-	HIP_TRY(hipFuncSetAttribute((const void*) k_part_records_g<TUP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_partr));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_part_records_g<TUP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_partr));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_part_records_g<TUP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_partr));
 	HIP_TRY(hipFuncSetAttribute((const void*) k_part_tuples_g<TUP>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
 	// pass geometry: <= 1024 buckets in one pass; otherwise 256 coarse x the rest (large pools: 2^(Tt-10) coarse x 1024)
 	u32 cbits = Tt, fbits = 0;
@@ -2066,9 +2169,11 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 		// records per round: three quarters of the stage at the measured gated fraction, in whole sweeps of the workgroup
 		const u64 NIl = (u64) R * (u64) P;
 		u64 rr = N ? (u64) stage_tuples * 3 / 4 * NIl / ((u64) N * (u64) P) : 1u << 16;
-		rr = std::max<u64>(PART_THREADS, std::min<u64>(rr / PART_THREADS * PART_THREADS, 1u << 16));
-		hipLaunchKernelGGL(k_part_records_g<TUP>, dim3(nblk2), dim3(PART_THREADS), lds_partr, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, rec_base,
-		                   pool->rl, k, 64 - cbits, NBc, rpb, (u32) rr, gcur, l1);
+		rr = std::max<u64>(PART_THREADS, std::min<u64>(rr / PART_THREADS * PART_THREADS, lng ? 1u << 14 : 1u << 16));      // (the descriptor's record field)
+		if (lng) hipLaunchKernelGGL((k_part_records_g<TUP, true>), dim3(nblk2), dim3(PART_THREADS), lds_partr, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, rec_base,
+		                            pool->rl, k, 64 - cbits, NBc, rpb, (u32) rr, gcur, l1);
+		else hipLaunchKernelGGL((k_part_records_g<TUP, false>), dim3(nblk2), dim3(PART_THREADS), lds_partr, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, rec_base,
+		                        pool->rl, k, 64 - cbits, NBc, rpb, (u32) rr, gcur, l1);
 	}
 	dbg_sync(c, "k_part_records");
 	u32* tstart;                                   // starts of the final buckets
@@ -2121,7 +2226,7 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 	SurvOutG so{sv->lo, sv->hi, sv->gcnt, sv->gfirst, n_surv, cap};
 	if (t.N) {
 		vdjx_prof_scope ps(c, "k_gated_reduce");
-		hipLaunchKernelGGL(k_gated_reduce<TUP>, dim3(t.NB), dim3(RD_THREADS), 0, st, t.t, t.bucket_start, pv.bases, pv.nmask, pv.quals, pv.rl, k, rec_base,
+		hipLaunchKernelGGL(k_gated_reduce<TUP>, dim3(t.NB), dim3(RD_THREADS), 0, st, t.t, t.bucket_start, pv.bases, pv.nmask, pv.quals, pv.rl, pv.ob, k, rec_base,
 		                   mfu, cmin, mqq, tlow, so, g_distinct, g_err);
 	}
 	u32 ns = 0, err = 0;
@@ -2246,7 +2351,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	// size that keeps the ranges <= 1024 (one partition pass); beyond the largest size a second partition level
 	static const bool force_wide = tune("VDJX_RC_WIDE", 0) != 0;                    // (test knobs: the paths of very large pools on small ones)
 	static const u32 cap_shift = (u32) tune("VDJX_RC_MAX_SHIFT", 12);
-	const bool narrow = R < (1ull << 26) && !force_wide;            // local instance ids (+15) fit 32 bits
+	const bool narrow = R < (1ull << (32 - pool->ob)) && !force_wide;            // local instance ids (+15) fit 32 bits
 	static const u32 max_ranges = (u32) std::min<size_t>(PART_MAXB, std::max<size_t>(2, tune("VDJX_RC_MAX_RANGES", PART_MAXB)));
 	const u32 max_shift = std::max(8u, std::min(narrow ? 11u : 10u, cap_shift));
 	u32 range_shift = 8;
@@ -2277,9 +2382,12 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	HIP_TRY(hipMemsetAsync(g_cursor, 0, 16, st));
 	HIP_TRY(hipMemsetAsync(range_cnt, 0, (size_t) n_ranges_p * 4, st));
 	HIP_TRY(hipMemsetAsync(g_err, 0, 8, st));
-	const size_t lds_walk = (size_t) n_ranges_p * 4;
-	if (lds_walk > 64 * 1024) { vdjx_set_error("too many survivor ranges for the walk histogram"); return VDJX_ELIMIT; }
-	HIP_TRY(hipFuncSetAttribute((const void*) k_walk_items, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_walk));
+	const bool lng = pool->W > 2;
+	if (lng && R >= (1ull << 27)) { vdjx_set_error("more than 2^27 records of long reads on one GPU: not supported by the recount items"); return VDJX_ELIMIT; }
+	const size_t lds_walk = (((size_t) n_ranges_p + 1) & ~(size_t) 1) * 4 + (lng ? (size_t) WALK_THREADS * GL_ROW_LONG * 8 : 0);
+	if ((size_t) n_ranges_p * 4 > 64 * 1024) { vdjx_set_error("too many survivor ranges for the walk histogram"); return VDJX_ELIMIT; }
+	HIP_TRY(hipFuncSetAttribute((const void*) k_walk_items<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_walk));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_walk_items<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_walk));
 	// VDJX_WALK_DBG (profiles/walkdbg.sh): an ABLATED copy of the walk runs first into scratch outputs, timed as k_walk_dbg; the real
 	// one follows untouched.  Bits: 1 no item stores, 2 no range histogram, 8 no filter / table / key loads at run starts.
 	static const u32 walk_dbg = (u32) tune("VDJX_WALK_DBG", 0);
@@ -2293,14 +2401,18 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		HIP_TRY(hipMemsetAsync(cur2, 0, 8, st));
 		HIP_TRY(hipMemsetAsync(cnt2, 0, (size_t) n_ranges_p * 4, st));
 		vdjx_prof_scope ps(c, "k_walk_dbg");
-		hipLaunchKernelGGL(k_walk_items, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, k, tb, succ, linw, f, range_shift,
-		                   n_ranges_p, raw2, raw_cap, blk_items, cur2, cnt2, g_err, walk_dbg);
+		if (lng) hipLaunchKernelGGL(k_walk_items<true>, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, pool->ob, k, tb, succ, linw, f, range_shift,
+		                            n_ranges_p, raw2, raw_cap, blk_items, cur2, cnt2, g_err, walk_dbg);
+		else hipLaunchKernelGGL(k_walk_items<false>, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, pool->ob, k, tb, succ, linw, f, range_shift,
+		                        n_ranges_p, raw2, raw_cap, blk_items, cur2, cnt2, g_err, walk_dbg);
 		HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
 	}
 	if (R) {
 		vdjx_prof_scope ps(c, "k_walk_items");
-		hipLaunchKernelGGL(k_walk_items, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, k, tb, succ, linw, f, range_shift,
-		                   n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err, (u32) tune("VDJX_WALK_FLAGS", 0));
+		if (lng) hipLaunchKernelGGL(k_walk_items<true>, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, pool->ob, k, tb, succ, linw, f, range_shift,
+		                            n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err, (u32) tune("VDJX_WALK_FLAGS", 0));
+		else hipLaunchKernelGGL(k_walk_items<false>, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, pool->ob, k, tb, succ, linw, f, range_shift,
+		                        n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err, (u32) tune("VDJX_WALK_FLAGS", 0));
 	}
 	dbg_sync(c, "k_walk_items");
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, range_cnt, n_ranges_p, range_start);
@@ -2331,7 +2443,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	dbg_sync(c, "k_part_items");
 	{
 		vdjx_prof_scope ps(c, "k_recount");
-#define RC_LAUNCH(SB, IT) hipLaunchKernelGGL((k_recount<SB, IT>), dim3(n_ranges), dim3(RC_THREADS), 0, st, items, range_start, f, ns, rec_base, fbw, ro.ucnt, ro.ufirst, ro.in_first, n_inst)
+#define RC_LAUNCH(SB, IT) hipLaunchKernelGGL((k_recount<SB, IT>), dim3(n_ranges), dim3(RC_THREADS), 0, st, items, range_start, f, ns, rec_base, pool->ob, fbw, ro.ucnt, ro.ufirst, ro.in_first, n_inst)
 		if (narrow) {
 			switch (range_shift) {
 				case 8: RC_LAUNCH(256, u32); break;
@@ -2390,7 +2502,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 
 // K6 for the round-2 arrays
 template <typename A>
-int stage_finish2(vdjx_ctx* c, A& db, const SurvivorsG& sv, const RecountOut& ro, u64 n_records_total, int k, int P, vdjx_graph* g) {
+int stage_finish2(vdjx_ctx* c, A& db, const SurvivorsG& sv, const RecountOut& ro, u64 n_records_total, int k, int P, int ob, vdjx_graph* g) {
 	hipStream_t st = c->stream;
 	const u32 ns = sv.n;
 	g->n = ns;
@@ -2440,10 +2552,10 @@ int stage_finish2(vdjx_ctx* c, A& db, const SurvivorsG& sv, const RecountOut& ro
 	HIP_TRY(hipMemsetAsync(bits, 0, (size_t) nwords * 4, st));
 	{
 		vdjx_prof_scope ps(c, "k_node_order");
-		hipLaunchKernelGGL(k_mark_first2, dim3((ns + 255) / 256), dim3(256), 0, st, sv.ufirst, ns, (u32) P, bits);
+		hipLaunchKernelGGL(k_mark_first2, dim3((ns + 255) / 256), dim3(256), 0, st, sv.ufirst, ns, (u32) P, ob, bits);
 		hipLaunchKernelGGL(k_popc_blocks, dim3(npb), dim3(256), 0, st, bits, nwords, word_pre, block_sum);
 		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, block_sum, npb, block_pre);
-		hipLaunchKernelGGL(k_node_rank2, dim3((ns + 255) / 256), dim3(256), 0, st, sv.ufirst, ns, (u32) P, bits, word_pre, block_pre, rank);
+		hipLaunchKernelGGL(k_node_rank2, dim3((ns + 255) / 256), dim3(256), 0, st, sv.ufirst, ns, (u32) P, ob, bits, word_pre, block_pre, rank);
 		hipLaunchKernelGGL(k_node_emit2, dim3((ns + 255) / 256), dim3(256), 0, st, sv.lo, sv.hi, sv.gcnt, sv.ucnt, sv.ufirst, d_hv, d_hj, rank,
 		                   ro.edge_first, ro.edge_to, ro.in_first, ro.in_from, ns, k, no);
 	}
@@ -2473,7 +2585,7 @@ int kmer_build_impl2(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, 
 	GTuples<TUP> t;
 	int rc = stage_gated_partition<TUP>(c, db, pool, 0, k, 0, 0, &t);
 	if (rc) return rc;
-	PoolView pv{pool->d_bases, pool->d_nmask, vdjx_qrows{pool->d_quals, pool->d_quals2, pool->q_split, pool->qstride}, pool->rl};
+	PoolView pv{pool->d_bases, pool->d_nmask, vdjx_qrows{pool->d_quals, pool->d_quals2, pool->q_split, pool->qstride}, pool->rl, pool->ob};
 	SurvivorsG sv;
 	rc = stage_gated_reduce<TUP>(c, db, t, pv, 0, k, mf, mq, &sv);
 	if (rc) return rc;
@@ -2488,7 +2600,7 @@ int kmer_build_impl2(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, 
 		rc = stage_recount(c, db, pool, 0, k, sv, ro, true);
 		if (rc) return rc;
 	}
-	return stage_finish2(c, db, sv, ro, pool->n_records, k, P, g);
+	return stage_finish2(c, db, sv, ro, pool->n_records, k, P, pool->ob, g);
 }
 
 }  // namespace
@@ -2552,6 +2664,7 @@ extern "C" int vdjx_shard_begin(vdjx_ctx* c, const vdjx_pool* pool, int k, int m
 	if (rec_stride < pool->n_records) { vdjx_set_error("rec_stride %llu < local records %zu", (unsigned long long) rec_stride, pool->n_records); return VDJX_EINVAL; }
 	if (rec_stride * (uint64_t) nranks >= (1ull << 32)) { vdjx_set_error("global record count %llu >= 2^32", (unsigned long long) (rec_stride * nranks)); return VDJX_ELIMIT; }
 	if (k > 16 && !c->anchors_loaded) { vdjx_set_error("vdjx_shard_begin: call vdjx_anchor_sets_load first (k > 16)"); return VDJX_ESTATE; }
+	if (pool->W > 2) { vdjx_set_error("vdjx_shard_begin: the sharded build takes reads of up to %d bases (this pool: %d)", VDJX_SHORT_READ_LEN, pool->rl); return VDJX_ELIMIT; }
 	vdjx_shard* s = new vdjx_shard();
 	s->c = c; s->pool = pool; s->k = k; s->mf = mf; s->mq = mq; s->rank = rank; s->nranks = nranks;
 	s->rec_stride = rec_stride;
@@ -2907,7 +3020,7 @@ extern "C" int vdjx_shard_finish(vdjx_shard* s, const void* d_in_first, const vo
 	}
 	vdjx_graph* g = new vdjx_graph();
 	g->pre_nodes = (size_t) pre_nodes_total;
-	int rc = stage_finish2(c, db, a, ro, s->rec_stride * (u64) s->nranks, s->k, P, g);
+	int rc = stage_finish2(c, db, a, ro, s->rec_stride * (u64) s->nranks, s->k, P, s->pool->ob, g);
 	if (rc) { vdjx_graph_free(g); return rc; }
 	*out = g;
 	return VDJX_OK;

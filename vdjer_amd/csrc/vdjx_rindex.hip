@@ -76,22 +76,30 @@ int scan_u32(vdjx_work& db, hipStream_t st, const u32* d_cnt, u32 n, u32* d_pre)
 
 // ---- the table ------------------------------------------------------------------------------------------------------------------
 // slots name a representative record (claiming a slot is one 32-bit CAS).  Records holding an 'N' are left out: contigs are
-// ACGT-only and can never match them.
+// ACGT-only and can never match them.  W words per read (vdjx_pool: 2, or 5 for reads of more than 64 bases), M per mask.
+template <int W, int M>
 __global__ void k_ri_insert(const u64* __restrict__ bases, const u64* __restrict__ nmask, u32 R,
                             u32* __restrict__ slots, u32 mask, u32* __restrict__ rec_slot) {
 	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= R) return;
-	if (nmask[r]) { rec_slot[r] = NONE32; return; }
-	const ulonglong2 b = ((const ulonglong2*) bases)[r];
-	u32 slot = (u32) (vdjx_mix(b.y, b.x) >> 17) & mask;
+	u64 nm = 0;
+#pragma unroll
+	for (int i = 0; i < M; i++) nm |= nmask[(size_t) r * M + i];
+	if (nm) { rec_slot[r] = NONE32; return; }
+	u64 b[W];
+#pragma unroll
+	for (int i = 0; i < W; i++) b[i] = bases[(size_t) r * W + i];
+	u32 slot = (u32) (ri_hash<W>(b) >> 17) & mask;
 	for (;;) {
 		u32 cur = slots[slot];
 		if (cur == 0) {
 			cur = atomicCAS(&slots[slot], 0u, r + 1);
 			if (cur == 0) break;
 		}
-		const ulonglong2 o = ((const ulonglong2*) bases)[cur - 1];
-		if (o.x == b.x && o.y == b.y) break;
+		u64 d = 0;
+#pragma unroll
+		for (int i = 0; i < W; i++) d |= bases[(size_t) (cur - 1) * W + i] ^ b[i];
+		if (!d) break;
 		slot = (slot + 1) & mask;
 	}
 	rec_slot[r] = slot;
@@ -225,14 +233,20 @@ __global__ void k_ri_dstart(const u32* __restrict__ start, u32 ncls, const u32* 
 	if (c <= ncls) dstart[c] = epre[hpre[start[c]]];
 }
 
-// the lookup table the mapper reads: one 32-byte slot per class {sequence, class + 1}
-__global__ void k_ri_tab(const u32* __restrict__ rep, u32 ncls, const u64* __restrict__ bases, uint4* __restrict__ tab, u32 mask) {
+// the lookup table the mapper reads: one slot per class {sequence (W words), class + 1}: W + 1 words rounded up to an even number
+// (32 bytes; 48 for reads of more than 64 bases)
+template <int W>
+__global__ void k_ri_tab(const u32* __restrict__ rep, u32 ncls, const u64* __restrict__ bases, u64* __restrict__ tab, u32 mask) {
+	constexpr int SW = (W + 2) & ~1;
 	const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= ncls) return;
-	const ulonglong2 b = ((const ulonglong2*) bases)[rep[c]];
-	u32 slot = (u32) (vdjx_mix(b.y, b.x) >> 17) & mask;
-	while (atomicCAS(&tab[2 * (size_t) slot + 1].x, 0u, c + 1) != 0u) slot = (slot + 1) & mask;
-	tab[2 * (size_t) slot] = make_uint4((u32) b.x, (u32) (b.x >> 32), (u32) b.y, (u32) (b.y >> 32));
+	u64 b[W];
+#pragma unroll
+	for (int i = 0; i < W; i++) b[i] = bases[(size_t) rep[c] * W + i];
+	u32 slot = (u32) (ri_hash<W>(b) >> 17) & mask;
+	while (atomicCAS((u32*) &tab[(size_t) slot * SW + W], 0u, c + 1) != 0u) slot = (slot + 1) & mask;
+#pragma unroll
+	for (int i = 0; i < W; i++) tab[(size_t) slot * SW + i] = b[i];
 }
 
 int sort_pairs(vdjx_work& db, hipStream_t st, u64* k_in, u64* k_out, u32* v_in, u32* v_out, u32 n, unsigned end_bit) {
@@ -269,7 +283,8 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(hipMemsetAsync(d_r2key, 0xFF, ((size_t) n_pairs * 2 + 2) * 8, st));
 	{
 		vdjx_prof_scope ps(c, "k_ri_insert");
-		hipLaunchKernelGGL(k_ri_insert, gR, b256, 0, st, pool->d_bases, pool->d_nmask, R, d_slots, mask, d_rec_slot);
+		if (pool->W == 2) hipLaunchKernelGGL((k_ri_insert<2, 1>), gR, b256, 0, st, pool->d_bases, pool->d_nmask, R, d_slots, mask, d_rec_slot);
+		else hipLaunchKernelGGL((k_ri_insert<VDJX_LONG_W, VDJX_LONG_M>), gR, b256, 0, st, pool->d_bases, pool->d_nmask, R, d_slots, mask, d_rec_slot);
 	}
 	// classes
 	const u32 nsb = (nslots + RS_BLOCK - 1) / RS_BLOCK;
@@ -287,17 +302,19 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	while ((size_t) tmask + 1 < (size_t) ncls * 2) tmask = tmask * 2 + 1;
 	u32* d_rep;
 	HIP_TRY(db.alloc(&d_rep, (size_t) ncls + 1));
-	HIP_TRY(hipMalloc(&c->d_ri_tab, ((size_t) tmask + 1) * 32));
+	const size_t slot_bytes = (size_t) ((pool->W + 2) & ~1) * 8;
+	HIP_TRY(hipMalloc(&c->d_ri_tab, ((size_t) tmask + 1) * slot_bytes));
 	HIP_TRY(hipMalloc(&c->d_ri_start, ((size_t) ncls + 2) * 4));
 	HIP_TRY(hipMalloc(&c->d_ri_cnt1, ((size_t) ncls + 2) * 4));
 	HIP_TRY(hipMalloc(&c->d_ri_dstart, ((size_t) ncls + 2) * 4));
 	HIP_TRY(hipMalloc(&c->d_pair_r2, ((size_t) n_pairs * 2 + 2) * 4));
 	HIP_TRY(hipMemsetAsync(c->d_ri_cnt1, 0, ((size_t) ncls + 2) * 4, st));
-	HIP_TRY(hipMemsetAsync(c->d_ri_tab, 0, ((size_t) tmask + 1) * 32, st));
+	HIP_TRY(hipMemsetAsync(c->d_ri_tab, 0, ((size_t) tmask + 1) * slot_bytes, st));
 	hipLaunchKernelGGL(k_ri_number, dim3(nsb), b256, 0, st, d_slots, nslots, d_bpre, d_rep);
 	{
 		vdjx_prof_scope ps(c, "k_ri_tab");
-		hipLaunchKernelGGL(k_ri_tab, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, (uint4*) c->d_ri_tab, tmask);
+		if (pool->W == 2) hipLaunchKernelGGL(k_ri_tab<2>, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, (u64*) c->d_ri_tab, tmask);
+		else hipLaunchKernelGGL(k_ri_tab<VDJX_LONG_W>, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, (u64*) c->d_ri_tab, tmask);
 	}
 	// records: class, read-2 records of the pairs; read-1 members
 	u64 *d_keys, *d_keys_s;

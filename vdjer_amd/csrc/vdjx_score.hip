@@ -354,7 +354,7 @@ extern "C" int vdjx_root_score_graph(vdjx_ctx* c, const vdjx_graph* g, int thres
 #define MAP_PRESENT_WORDS (1u << (MAP_PRESENT_LOG2 - 5))
 
 struct ReadIndexDev {                             // vdjx_rindex.hip
-	const uint4* tab; u32 mask;                   // two uint4 per slot: the read sequence {lo, hi}, then {class + 1, -, -, -}
+	const u64* tab; u32 mask;                     // per slot: the read sequence (W words), then class + 1; W + 1 words rounded up to even
 	const u32* start; const u32* cnt1; const u32* recs;
 	const u64* csr8; const u32* csr_pair; const u32* pair_r2;     // per CSR member: 8-byte entry, pair id; per pair: its read-2 records
 	const u32* dstart; const u64* d8;             // distinct read-1 entries per class with multiplicities (window scoring)
@@ -383,10 +383,12 @@ __device__ inline u32 map_present_bit(u32 cls) { return cls & ((1u << MAP_PRESEN
 // read class, the class's entries and how many (weighted: the DISTINCT read-1 entries, else the read-1 members), kept in HBM
 // (16 bytes per offset) for the kernels that evaluate the hits: a string is looked up in the index ONCE per call.
 // One workgroup per string (looping), one thread per offset; the string is staged in LDS.
+template <int W>
 __global__ __launch_bounds__(MAP_THREADS) void k_map_classify(ReadIndexDev ix, const char* __restrict__ strings, u32 n, int len, bool weighted,
                                                               uint4* __restrict__ prep, u32* __restrict__ out_hits, u32* __restrict__ out_inst) {
-	__shared__ char txt[MAP_MAXOFF + 64 + 16];
+	__shared__ char txt[MAP_MAXOFF + VDJX_MAX_READ_LEN + 16];
 	__shared__ u32 s_h[MAP_THREADS / 64], s_i[MAP_THREADS / 64];
+	constexpr int SW = (W + 2) & ~1;
 	const int rl = ix.rl, noff = len - rl;
 	const u32 tid = threadIdx.x;
 	for (u32 wi = blockIdx.x; wi < n; wi += gridDim.x) {
@@ -395,21 +397,40 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_classify(ReadIndexDev ix, c
 		__syncthreads();
 		u32 hs = 0, is = 0;
 		for (int o = tid; o < noff; o += MAP_THREADS) {
-			u128 b = 0;
+			// the read-length string at the offset in the pool's record format (vdjx_pool)
+			u64 key[W];
 			bool ok = true;
-			for (int j = 0; j < rl; j++) {
-				const int cde = base_code(txt[o + j]);
-				if (cde < 0) ok = false;
-				b = (b << 2) | (u32) (cde & 3);
+			if (W == 2) {
+				u128 b = 0;
+				for (int j = 0; j < rl; j++) {
+					const int cde = base_code(txt[o + j]);
+					if (cde < 0) ok = false;
+					b = (b << 2) | (u32) (cde & 3);
+				}
+				key[0] = (u64) (b >> 64); key[1] = (u64) b;
+			} else {
+#pragma unroll
+				for (int q = 0; q < W; q++) {
+					u64 x = 0;
+					for (int j = 32 * q; j < 32 * q + 32; j++) {
+						int cde = 0;
+						if (j < rl) { cde = base_code(txt[o + j]); if (cde < 0) ok = false; }
+						x = (x << 2) | (u32) (cde & 3);
+					}
+					key[q] = x;
+				}
 			}
-			const u64 hi = (u64) (b >> 64), lo = (u64) b;
 			u32 cls = NONE32, cs = 0, sz = 0, inst = 0;
 			if (ok) {
-				u32 slot = (u32) (vdjx_mix(lo, hi) >> 17) & ix.mask;
+				u32 slot = (u32) (ri_hash<W>(key) >> 17) & ix.mask;
 				for (;;) {
-					const uint4 key = ix.tab[2 * (size_t) slot], val = ix.tab[2 * (size_t) slot + 1];
-					if (!val.x) break;
-					if ((((u64) key.y << 32) | key.x) == hi && (((u64) key.w << 32) | key.z) == lo) { cls = val.x - 1; break; }
+					const u64* sl = ix.tab + (size_t) slot * SW;
+					const u32 c1 = (u32) sl[W];
+					if (!c1) break;
+					u64 d = 0;
+#pragma unroll
+					for (int q = 0; q < W; q++) d |= sl[q] ^ key[q];
+					if (!d) { cls = c1 - 1; break; }
 					slot = (slot + 1) & ix.mask;
 				}
 			}
@@ -1137,7 +1158,7 @@ static int make_index_view(vdjx_ctx* c, ReadIndexDev* ix, int len, const char* w
 	const vdjx_pool* p = c->ri_pool;
 	if (len <= p->rl) { vdjx_set_error("%s: len=%d must exceed the read length %d", who, len, p->rl); return VDJX_EINVAL; }
 	if (len - p->rl > MAP_MAXOFF) { vdjx_set_error("%s: len=%d too long (max %d)", who, len, MAP_MAXOFF + p->rl); return VDJX_ELIMIT; }
-	ix->tab = (const uint4*) c->d_ri_tab; ix->mask = c->ri_tab_mask;
+	ix->tab = (const u64*) c->d_ri_tab; ix->mask = c->ri_tab_mask;
 	ix->start = c->d_ri_start; ix->cnt1 = c->d_ri_cnt1; ix->recs = c->d_ri_recs;
 	ix->csr8 = c->d_ri_csr8; ix->csr_pair = c->d_ri_csr_pair; ix->pair_r2 = c->d_pair_r2;
 	ix->dstart = c->d_ri_dstart; ix->d8 = c->d_ri_d8;
@@ -1183,7 +1204,8 @@ static int classify_and_plan(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix,
 	HIP_TRY(hipMemcpyAsync(d_s, strings, n * len, hipMemcpyHostToDevice, st));
 	{
 		vdjx_prof_scope ps(c, "k_map_classify");
-		hipLaunchKernelGGL(k_map_classify, dim3((u32) std::min<size_t>(n, 8192)), dim3(MAP_THREADS), 0, st, ix, d_s, (u32) n, len, weighted, mp->d_prep, d_hits, d_inst);
+		if (c->ri_pool->W == 2) hipLaunchKernelGGL(k_map_classify<2>, dim3((u32) std::min<size_t>(n, 8192)), dim3(MAP_THREADS), 0, st, ix, d_s, (u32) n, len, weighted, mp->d_prep, d_hits, d_inst);
+		else hipLaunchKernelGGL(k_map_classify<VDJX_LONG_W>, dim3((u32) std::min<size_t>(n, 8192)), dim3(MAP_THREADS), 0, st, ix, d_s, (u32) n, len, weighted, mp->d_prep, d_hits, d_inst);
 	}
 	{
 		vdjx_prof_scope ps(c, "k_plan");

@@ -243,7 +243,7 @@ def make_reads(rep: Repertoire, n_pairs: int, noise_frac: float = 0.3, rl: int =
         if ci.size:
             clone = np.searchsorted(cdf, rng.random(ci.size), side="right").astype(np.int64)
             clone = np.minimum(clone, C - 1)
-            ins = np.clip(np.rint(rng.normal(ins_mean, ins_sd, ci.size)), ins_lo, ins_hi).astype(np.int64)
+            ins = np.clip(np.rint(rng.normal(ins_mean, ins_sd, ci.size)), max(ins_lo, rl), max(ins_hi, rl)).astype(np.int64)      # (a fragment holds a whole read)
             ins = np.minimum(ins, lens[clone])
             start = (rng.random(ci.size) * (lens[clone] - ins + 1)).astype(np.int64)
             base = clone * lmax + start
@@ -429,7 +429,8 @@ def make_reads_cb(rep: Repertoire, n_pairs: int, noise_frac: float = 0.3, rl: in
     noise_thr = int(round(noise_frac * 65536))
     seedc = _s64(_sm64_py(seed * 0x9E3779B97F4A7C15 + 0x1234567))
     rec_len = 2 * rl + 1
-    slot = (torch.arange(2, device=dev, dtype=torch.int64)[:, None] * 64 + torch.arange(rl, device=dev, dtype=torch.int64)[None, :] + 8)
+    mate_stride = 64 if rl <= 56 else 256              # (slots of the two mates must not meet; 64 is what the committed digests were made with)
+    slot = (torch.arange(2, device=dev, dtype=torch.int64)[:, None] * mate_stride + torch.arange(rl, device=dev, dtype=torch.int64)[None, :] + 8)
     slot = (slot * _GOLD)[None, :, :]                                   # [1, 2, rl]
     ar = torch.arange(rl, device=dev, dtype=torch.int64)
     pri_parts, sec_parts, noise_parts = [], [], []
@@ -444,7 +445,7 @@ def make_reads_cb(rep: Repertoire, n_pairs: int, noise_frac: float = 0.3, rl: in
         s4 = (h3 & 0xFFFF) + (_lsr(h3, 16) & 0xFFFF) + (_lsr(h3, 32) & 0xFFFF) + (_lsr(h3, 48) & 0xFFFF)
         # sum of four uniforms: sd = 65536 * sqrt(4/12); scaled to sd 10 around 175 with integer arithmetic
         ins = 175 + torch.div((s4 - 131070) * 17321 + 32768 * 1000, 65536 * 1000, rounding_mode="floor")
-        ins = torch.minimum(torch.clamp(ins, 120, 240), lens[clone])
+        ins = torch.minimum(torch.clamp(ins, max(120, rl), max(240, rl)), lens[clone])
         start = _lsr(_lsr(h4, 32) * (lens[clone] - ins + 1), 32)
         hb = _sm64(hp[:, None, None] + slot)                           # [m, 2, rl]
         base = (hb & 3).to(torch.uint8)                                # noise pairs: uniform bases
