@@ -24,16 +24,17 @@ def _write_inputs(c, d):
     open(os.path.join(d, "ref", "ig_vdj.fa"), "w").write(">x\nACGT\n")
 
 
-@pytest.mark.parametrize("tag", ["e2e_tiled", "e2e_mixed", "e2e_k25", "e2e_igk", "e2e_igl"])
+@pytest.mark.parametrize("tag", ["e2e_tiled", "e2e_mixed", "e2e_k25", "e2e_igk", "e2e_igl", "e2e_rl100", "e2e_rl151"])
 def test_vdjer_cli_matches_reference(tag, tmp_path):
-    """e2e_igk / e2e_igl: --chain IGK / IGL (set_chain_info, params.c:20-31: J residue F, CDR3 window 0-60)"""
+    """e2e_igk / e2e_igl: --chain IGK / IGL (set_chain_info, params.c:20-31: J residue F, CDR3 window 0-60); e2e_rl100 / e2e_rl151: 2x100 and
+    2x151 bp libraries (the long-read record format), goldens from the compiled reference (tests/golden/make_golden_longreads.py)"""
     exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
     assert os.path.exists(exe), "build it: make -C vdjer_amd/csrc/host"
     c = G.Case(tag)
     m = G.manifest()
     info = m["e2e"][tag] if tag in m["e2e"] else m["e2e_chains"][tag]
     _write_inputs(c, str(tmp_path))
-    cmd = [exe, "--in", "reads.txt", "--chain", info.get("chain", "IGH"), "--ref-dir", "ref", "--ins", "175", "--t", "1"] + info["flags"]
+    cmd = [exe, "--in", "reads.txt", "--chain", info.get("chain", "IGH"), "--ref-dir", "ref", "--ins", str(info.get("ins", 175)), "--t", "1"] + info["flags"]
     r = subprocess.run(cmd, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     # the ELAPSED_SECS stage log carries the reference's marker names in the reference's order (status.c:22-32, A2:1387-1473)
