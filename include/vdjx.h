@@ -203,6 +203,19 @@ int vdjx_map_emit(vdjx_ctx* ctx, const char* contigs, size_t n, int len, uint64_
 int vdjx_map_emit_begin(vdjx_ctx* ctx, const char* contigs, size_t n, int len, uint64_t* offsets, vdjx_pair* pairs);
 int vdjx_map_emit_end(vdjx_ctx* ctx);
 
+/* The SAM records themselves, formatted on the device.
+ * replaces: output_mapping (quick_map3.c:152-181) as called through quick_map_process_contig_file (:311-340): per mapped pair the two
+ * lines "%s\t%d\t%s\t%d\t255\t%dM\t=\t%d\t%d\t%s\t%s\n" (:168) -- read name without its leading '@', flag, contig id, position, read
+ * length, mate position, insert, then the stored sequence and qualities of the record that matched -- contig after contig, in the order
+ * of vdjx_map_emit.  (The header lines, output_header :274-309, are the caller's: they need only the contig ids.)
+ *   vdjx_sam_names_load  the read names by pair id (the pair_id of vdjx_read_index_build): names[name_off[p] .. name_off[p+1])
+ *   vdjx_sam_text        contig ids likewise (ids[id_off[c] .. id_off[c+1])); *out_text points at *out_bytes bytes (NUL after them) in a
+ *                        page-locked buffer owned by the context, valid until the next vdjx_sam_text call
+ * Bases that are not ACGT come out as N (they are stored as N: see vdjx_pool_load).                                                   */
+int vdjx_sam_names_load(vdjx_ctx* ctx, const char* names, const uint64_t* name_off, uint32_t n_pairs);
+int vdjx_sam_text(vdjx_ctx* ctx, const char* contigs, size_t n, int len, const char* ids, const uint32_t* id_off,
+                  const char** out_text, uint64_t* out_bytes);
+
 /* counters of the most recent scorer calls, by name: "window_hits" (read instances matched by the last
  * vdjx_window_score call, summed over windows), "window_hits_max", "window_pairs", "window_work_items",
  * "map_hits", "root_dp_items".  Unknown names return 0.  Used by bench.py to price the scorers' algorithmic bytes. */

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def _draw(rng, mode):
-    rl = int(rng.choice([36, 40, 50, 50, 50, 64]))
+    rl = int(rng.integers(65, 161)) if mode == "long" else int(rng.choice([36, 40, 50, 50, 50, 64]))      # long: the word-per-32-bases record format
     k = int(rng.integers(8, min(50, rl) + 1))
     if mode == "gt32" and rl - k + 1 <= 32:
         k = max(8, rl - 32 - int(rng.integers(0, 8)))
@@ -36,7 +36,7 @@ def ctx():
     c.close()
 
 
-@pytest.mark.parametrize("mode,seed,n", [("gt32", 101, 40), ("le32", 102, 40), ("any", 103, 40)])
+@pytest.mark.parametrize("mode,seed,n", [("gt32", 101, 40), ("le32", 102, 40), ("any", 103, 40), ("long", 104, 30)])
 def test_kmer_build_random_configurations_vs_oracle(ctx, mode, seed, n):
     from vdjer_amd import synth
     import test_gpu_parity as T

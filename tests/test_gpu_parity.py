@@ -361,9 +361,10 @@ def test_window_score_and_map_vs_reference_dump(ctx, tag):
     p.free()
 
 
-@pytest.mark.parametrize("tag", ["e2e_tiled", "e2e_mixed", "e2e_k25"])
+@pytest.mark.parametrize("tag", ["e2e_tiled", "e2e_mixed", "e2e_k25", "e2e_rl100"])
 def test_sam_of_reference_contigs(ctx, tag):
-    """a-10: map the reference's own final contigs and reproduce its SAM body byte for byte."""
+    """a-10: map the reference's own final contigs and reproduce its SAM body byte for byte -- from the pairs (host formatting) and
+    with the text formatted on the device (vdjx_sam_text; names with a leading '@' lose it, quick_map3.c:160-163)."""
     from vdjer_amd import api
     c = G.Case(tag)
     p = _load_index(ctx, c.pool)
@@ -374,6 +375,9 @@ def test_sam_of_reference_contigs(ctx, tag):
     body = api.sam_text((c.pool.primary, c.pool.secondary), c.pool.names(), ids, offs, pairs, c.pool.rl)
     head = "@HD\tVN:1.4\tSO:unsorted\n" + "".join(f"@SQ\tSN:{i}\tLN:{len(s)}\n" for i, s in zip(ids, seqs))
     assert head + body == G.text(f"{tag}.sam.gz")
+    ctx.sam_names_load(["@" + nm if i % 3 == 0 else nm for i, nm in enumerate(c.pool.names())])
+    assert head + ctx.sam_text_device(seqs, ids).decode() == G.text(f"{tag}.sam.gz")
+    assert ctx.sam_text_device(seqs[:1], ids[:1]).decode() == body[:len(ctx.sam_text_device(seqs[:1], ids[:1]))]
     p.free()
 
 

@@ -399,6 +399,23 @@ class Context:
             check(self.L.vdjx_map_emit_end(self.h), "vdjx_map_emit_end")
             self._pairs_pending = False
 
+    def sam_names_load(self, names) -> None:
+        """read names by pair id (list of str) for sam_text_device"""
+        enc = [s_.encode() for s_ in names]
+        off = np.zeros(len(enc) + 1, np.uint64)
+        off[1:] = np.cumsum([len(e) for e in enc])
+        check(self.L.vdjx_sam_names_load(self.h, b"".join(enc), _p(off), len(enc)), "vdjx_sam_names_load")
+
+    def sam_text_device(self, contigs, contig_ids) -> bytes:
+        """the SAM records of output_mapping (quick_map3.c:152-181) for these contigs, formatted on the device"""
+        raw, n, ln = contigs if isinstance(contigs, tuple) else self.pack_strings(contigs)
+        enc = [s_.encode() for s_ in contig_ids]
+        off = np.zeros(n + 1, np.uint32)
+        off[1:] = np.cumsum([len(e) for e in enc])
+        txt, nb = C.c_char_p(), C.c_uint64()
+        check(self.L.vdjx_sam_text(self.h, raw, n, ln, b"".join(enc), _p(off), C.byref(txt), C.byref(nb)), "vdjx_sam_text")
+        return C.string_at(txt, nb.value)
+
     def stat(self, name: str) -> int:
         return int(self.L.vdjx_stat(self.h, name.encode()))
 

@@ -328,10 +328,26 @@ static const uint8_t* rec_ptr(const reads_t* r, uint32_t rec) {
 	return rec < r->n_primary ? r->primary + rec * sz : r->secondary + (rec - r->n_primary) * sz;
 }
 
-/* output_mapping, quick_map3.c:152-181 */
+/* output_mapping, quick_map3.c:152-181: mapped and formatted on the device (vdjx_sam_text); VDJX_SAM_HOST=1 formats the pairs of
+ * vdjx_map_emit here instead (the same bytes; kept as the cross-check of the formatting kernel) */
 static int h_sam_body(void* ud, const char* const* ids, const char* contigs, size_t n, int len, FILE* out) {
 	hook_ud* u = (hook_ud*) ud;
 	const reads_t* r = u->r;
+	if (!getenv("VDJX_SAM_HOST")) {
+		uint32_t* id_off = (uint32_t*) calloc(n + 1, 4);
+		size_t tot = 0;
+		for (size_t c = 0; c < n; c++) { tot += strlen(ids[c]); id_off[c + 1] = (uint32_t) tot; }
+		char* cat = (char*) malloc(tot + 1);
+		for (size_t c = 0; c < n; c++) memcpy(cat + id_off[c], ids[c], id_off[c + 1] - id_off[c]);
+		const char* text = NULL;
+		uint64_t nb = 0;
+		int rc = vdjx_sam_text(u->gx, contigs, n, len, cat, id_off, &text, &nb);
+		free(cat);
+		free(id_off);
+		if (rc) { fprintf(stderr, "vdjx_sam_text: %s\n", vdjx_last_error()); return rc; }
+		if (nb && fwrite(text, 1, (size_t) nb, out) != (size_t) nb) { fprintf(stderr, "short write of the SAM records\n"); return -1; }
+		return 0;
+	}
 	uint64_t* offs = (uint64_t*) calloc(n + 1, 8);
 	int rc = vdjx_map_emit(u->gx, contigs, n, len, offs, NULL);
 	vdjx_pair* pairs = NULL;
@@ -438,6 +454,16 @@ int main(int argc, char** argv) {
 			fprintf(stderr, "warning: %llu bases other than ACGTN in the reads are treated as N (the reference would carry them inside k-mers)\n",
 			        (unsigned long long) vdjx_stat(gx, "pool_other_bases"));
 		VX(vdjx_read_index_build(gx, px, rd.pair_id, rd.read_num, rd.is_rc, rd.reg_rank, rd.n_pairs));
+		{	/* the read names by pair id, for the SAM records formatted on the device */
+			uint64_t* noff = (uint64_t*) calloc((size_t) rd.n_pairs + 1, 8);
+			for (uint32_t i = 0; i < rd.n_pairs; i++) noff[i + 1] = noff[i] + strlen(rd.names[i]);
+			char* cat = (char*) malloc((size_t) noff[rd.n_pairs] + 1);
+			for (uint32_t i = 0; i < rd.n_pairs; i++) memcpy(cat + noff[i], rd.names[i], (size_t) (noff[i + 1] - noff[i]));
+			const int rcn = vdjx_sam_names_load(gx, cat, noff, rd.n_pairs);
+			free(cat);
+			free(noff);
+			if (rcn) { fprintf(stderr, "vdjx_sam_names_load: %s\n", vdjx_last_error()); return 1; }
+		}
 		status("POST_READ_EXTRACT");
 		fprintf(stderr, "Assembling...\n");
 	}

@@ -139,6 +139,13 @@ struct vdjx_ctx {
 	size_t me_book_cap = 0, me_nsl = 0;
 	u32 me_slice_hits = 0;
 	hipEvent_t ev_gathered = nullptr;
+	// SAM text (vdjx_sam_text): read names by pair id on the device, the text buffers
+	char* d_sam_names = nullptr;
+	u64* d_sam_noff = nullptr;
+	u32 sam_pairs = 0;
+	void* d_sam_text = nullptr;
+	void* h_sam_text = nullptr;
+	size_t sam_text_cap = 0;
 	u32 n_pairs = 0, n_classes = 0;
 	std::map<std::string, uint64_t> stats;
 };

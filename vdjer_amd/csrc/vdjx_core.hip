@@ -118,6 +118,8 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	if (c->pairs_stream) { (void) hipStreamSynchronize(c->pairs_stream); (void) hipStreamDestroy(c->pairs_stream); }
 	if (c->ev_gathered) (void) hipEventDestroy(c->ev_gathered);
 	if (c->h_plan) (void) hipHostFree(c->h_plan);
+	if (c->h_sam_text) (void) hipHostFree(c->h_sam_text);
+	free_dev(c->d_sam_text); free_dev(c->d_sam_names); free_dev(c->d_sam_noff);
 	(void) hipStreamDestroy(c->stream);
 	delete c;
 }

@@ -1445,7 +1445,7 @@ static uint64_t fnv1a(const char* p, size_t n, uint64_t h) {
 	return h;
 }
 
-static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, uint64_t* offsets, vdjx_pair* pairs, bool async) {
+static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, uint64_t* offsets, vdjx_pair* pairs, bool async, bool device_only = false) {
 	if (!c || !offsets || (n && !contigs)) { vdjx_set_error("vdjx_map_emit: NULL argument"); return VDJX_EINVAL; }
 	if (n == 0) { offsets[0] = 0; return VDJX_OK; }
 	if (n >= (1ull << 31)) { vdjx_set_error("vdjx_map_emit: too many contigs"); return VDJX_ELIMIT; }
@@ -1550,7 +1550,9 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 			vdjx_prof_scope ps(c, "k_gather_pairs");
 			hipLaunchKernelGGL(k_gather_pairs, dim3((u32) nsl), dim3(256), 0, st, (const vdjx_pair*) c->me_pairs, (const u32*) c->me_hit, (u32) n, slice_hits, b_sstart, b_off, b_bits, b_pre, d_dense);
 		}
-		if (async) {
+		if (device_only) {
+			// (vdjx_sam_text: the pairs stay in c->me_dense, the stream is not waited for)
+		} else if (async) {
 			// the pairs cross PCIe on the copy stream beside whatever the caller does next (vdjx_map_emit_end waits for them); the
 			// copy stream waits for the gather through an event, the host does not
 			HIP_TRY(hipEventRecord(c->ev_gathered, st));
@@ -1581,5 +1583,189 @@ extern "C" int vdjx_map_emit_end(vdjx_ctx* c) {
 	if (!c) { vdjx_set_error("vdjx_map_emit_end: ctx is NULL"); return VDJX_EINVAL; }
 	HIP_TRY(hipSetDevice(c->device));
 	HIP_TRY(hipStreamSynchronize(c->pairs_stream));
+	return VDJX_OK;
+}
+
+// ==============================================================================================
+// a-10, the text: SAM records of the mapped pairs, formatted on the device
+//   replaces output_mapping (quick_map3.c:152-181): per pair two lines
+//     "%s\t%d\t%s\t%d\t255\t%dM\t=\t%d\t%d\t%s\t%s\n"  name (leading '@' dropped), flag, contig id, pos, read length, mate pos, insert, seq, qual
+//   with the stored sequence and qualities of the record that matched (the pool's record: not-ACGT bases read as N, like everywhere here)
+// ==============================================================================================
+__device__ inline u32 dec_digits(u32 v) { return v < 10u ? 1u : v < 100u ? 2u : v < 1000u ? 3u : v < 10000u ? 4u : v < 100000u ? 5u : v < 1000000u ? 6u : 10u; }
+__device__ inline u32 put_dec(char* dst, u32 v) {
+	const u32 n = dec_digits(v);
+	for (u32 i = n; i-- > 0;) { dst[i] = (char) ('0' + v % 10u); v /= 10u; }
+	return n;
+}
+struct SamSrc {
+	const vdjx_pair* pairs; const u64* offs; u32 n_contigs;        // pairs of contig c: [offs[c], offs[c+1])
+	const char* ids; const u32* id_off;                            // contig ids, concatenated
+	const char* names; const u64* name_off;                        // read names by pair id, concatenated
+	const u64* bases; const u64* nmask; vdjx_qrows quals; int rl, W, M;
+};
+__device__ inline u32 sam_contig_of(const SamSrc& s, u64 i) {
+	u32 lo = 0, hi = s.n_contigs;
+	while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s.offs[mid] <= i) lo = mid; else hi = mid; }
+	return lo;
+}
+__device__ inline u32 sam_name(const SamSrc& s, u32 pid, const char*& nm) {
+	const u64 a = s.name_off[pid], b = s.name_off[pid + 1];
+	nm = s.names + a;
+	u32 n = (u32) (b - a);
+	if (n && nm[0] == '@') { nm++; n--; }
+	return n;
+}
+__global__ void k_sam_len(SamSrc s, u64 total, u32* __restrict__ len) {
+	const u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= total) return;
+	const vdjx_pair q = s.pairs[i];
+	const u32 c = sam_contig_of(s, i);
+	const char* nm;
+	const u32 nl = sam_name(s, q.pair_id, nm), cl = s.id_off[c + 1] - s.id_off[c];
+	const u32 f1 = 1u | 2u | (q.rc1 ? 0x10u : 0x20u) | 0x40u, f2 = 1u | 2u | (q.rc2 ? 0x10u : 0x20u) | 0x80u;
+	const u32 per = nl + cl + dec_digits((u32) q.pos1) + dec_digits((u32) q.pos2) + dec_digits((u32) s.rl) + dec_digits((u32) q.insert) + 2u * (u32) s.rl + 16u;
+	len[i] = 2u * per + dec_digits(f1) + dec_digits(f2);
+}
+__device__ inline char sam_base(const SamSrc& s, u32 rec, int i) {
+	if (s.W == 2) {
+		if ((s.nmask[rec] >> i) & 1ull) return 'N';
+		const ulonglong2 b = ((const ulonglong2*) s.bases)[rec];
+		const int sh = 2 * (s.rl - 1 - i);
+		const u32 cde = (u32) (sh < 64 ? b.y >> sh : b.x >> (sh - 64)) & 3u;
+		return "ATCG"[cde];
+	}
+	if ((s.nmask[(size_t) rec * s.M + (i >> 6)] >> (i & 63)) & 1ull) return 'N';
+	return "ATCG"[(u32) (s.bases[(size_t) rec * s.W + (i >> 5)] >> (62 - 2 * (i & 31))) & 3u];
+}
+// one wave per pair
+__global__ __launch_bounds__(256) void k_sam_write(SamSrc s, u64 total, const u64* __restrict__ at, char* __restrict__ text) {
+	__shared__ char hdr[4][2][64];
+	const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const u64 i = (u64) blockIdx.x * 4u + wv;
+	if (i >= total) return;
+	const vdjx_pair q = s.pairs[i];
+	const u32 c = sam_contig_of(s, i);
+	const char* nm;
+	const u32 nl = sam_name(s, q.pair_id, nm);
+	const char* cid = s.ids + s.id_off[c];
+	const u32 cl = s.id_off[c + 1] - s.id_off[c];
+	char* dst = text + at[i];
+	for (int line = 0; line < 2; line++) {
+		const u32 flag = 1u | 2u | ((line ? q.rc2 : q.rc1) ? 0x10u : 0x20u) | (line ? 0x80u : 0x40u);
+		const u32 pos = (u32) (line ? q.pos2 : q.pos1), mpos = (u32) (line ? q.pos1 : q.pos2), rec = line ? q.rec2 : q.rec1;
+		char* ha = hdr[wv][0];          // "\t<flag>\t"
+		char* hb = hdr[wv][1];          // "\t<pos>\t255\t<rl>M\t=\t<mate pos>\t<insert>\t"
+		u32 la = 0, lb = 0;
+		if (lane == 0) {
+			ha[la++] = '\t'; la += put_dec(ha + la, flag); ha[la++] = '\t';
+			hb[lb++] = '\t'; lb += put_dec(hb + lb, pos);
+			hb[lb++] = '\t'; hb[lb++] = '2'; hb[lb++] = '5'; hb[lb++] = '5'; hb[lb++] = '\t';
+			lb += put_dec(hb + lb, (u32) s.rl); hb[lb++] = 'M'; hb[lb++] = '\t'; hb[lb++] = '='; hb[lb++] = '\t';
+			lb += put_dec(hb + lb, mpos); hb[lb++] = '\t';
+			lb += put_dec(hb + lb, (u32) q.insert); hb[lb++] = '\t';
+		}
+		la = (u32) __builtin_amdgcn_readlane((int) la, 0);
+		lb = (u32) __builtin_amdgcn_readlane((int) lb, 0);
+		for (u32 j = lane; j < nl; j += 64) dst[j] = nm[j];
+		dst += nl;
+		if (lane < la) dst[lane] = ha[lane];
+		dst += la;
+		for (u32 j = lane; j < cl; j += 64) dst[j] = cid[j];
+		dst += cl;
+		if (lane < lb) dst[lane] = hb[lane];
+		dst += lb;
+		for (int j = (int) lane; j < s.rl; j += 64) dst[j] = sam_base(s, rec, j);
+		dst += s.rl;
+		if (lane == 0) dst[0] = '\t';
+		dst += 1;
+		const uint8_t* qr = s.quals.row(rec);
+		for (int j = (int) lane; j < s.rl; j += 64) dst[j] = (char) qr[j];
+		dst += s.rl;
+		if (lane == 0) dst[0] = '\n';
+		dst += 1;
+	}
+}
+
+// read names by pair id for vdjx_sam_text: name_off[n_pairs + 1] into `names`
+extern "C" int vdjx_sam_names_load(vdjx_ctx* c, const char* names, const uint64_t* name_off, uint32_t n_pairs) {
+	if (!c || !name_off || (n_pairs && !names)) { vdjx_set_error("vdjx_sam_names_load: NULL argument"); return VDJX_EINVAL; }
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	free_set(c->d_sam_names); free_set(c->d_sam_noff);
+	c->sam_pairs = 0;
+	for (uint32_t i = 0; i < n_pairs; i++) if (name_off[i + 1] < name_off[i]) { vdjx_set_error("vdjx_sam_names_load: offsets must not decrease"); return VDJX_EINVAL; }
+	const size_t nb = (size_t) name_off[n_pairs];
+	HIP_TRY(hipMalloc(&c->d_sam_names, nb + 16));
+	HIP_TRY(hipMalloc(&c->d_sam_noff, ((size_t) n_pairs + 1) * 8));
+	if (nb) HIP_TRY(hipMemcpy(c->d_sam_names, names, nb, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(c->d_sam_noff, name_off, ((size_t) n_pairs + 1) * 8, hipMemcpyHostToDevice));
+	c->sam_pairs = n_pairs;
+	return VDJX_OK;
+}
+
+extern "C" int vdjx_sam_text(vdjx_ctx* c, const char* contigs, size_t n, int len, const char* ids, const uint32_t* id_off,
+                             const char** out_text, uint64_t* out_bytes) {
+	if (!c || !out_text || !out_bytes || (n && (!contigs || !ids || !id_off))) { vdjx_set_error("vdjx_sam_text: NULL argument"); return VDJX_EINVAL; }
+	*out_text = ""; *out_bytes = 0;
+	if (n == 0) return VDJX_OK;
+	if (!c->d_sam_noff) { vdjx_set_error("vdjx_sam_text: call vdjx_sam_names_load first"); return VDJX_ESTATE; }
+	if (!c->ri_pool) { vdjx_set_error("vdjx_sam_text: call vdjx_read_index_build first"); return VDJX_ESTATE; }
+	if (c->sam_pairs < c->n_pairs) { vdjx_set_error("vdjx_sam_text: %u names for %u pairs", c->sam_pairs, c->n_pairs); return VDJX_EINVAL; }
+	std::vector<uint64_t> offs(n + 1);
+	int rc = map_emit_impl(c, contigs, n, len, offs.data(), nullptr, false);
+	if (rc) return rc;
+	const u64 total = offs[n];
+	if (!total) return VDJX_OK;
+	rc = map_emit_impl(c, contigs, n, len, offs.data(), (vdjx_pair*) 1, false, true);         // -> c->me_dense, on the stream
+	if (rc) return rc;
+	HIP_TRY(hipSetDevice(c->device));
+	hipStream_t st = c->stream;
+	vdjx_work db(c);
+	const vdjx_pool* p = c->ri_pool;
+	u64 *d_offs, *d_at;
+	u32 *d_idoff, *d_len;
+	char* d_ids;
+	const size_t idb = id_off[n];
+	HIP_TRY(db.alloc(&d_offs, n + 1));
+	HIP_TRY(db.alloc(&d_idoff, n + 1));
+	HIP_TRY(db.alloc(&d_ids, idb + 16));
+	HIP_TRY(db.alloc(&d_len, (size_t) total + 1));
+	HIP_TRY(db.alloc(&d_at, (size_t) total + 2));
+	HIP_TRY(hipMemcpyAsync(d_offs, offs.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d_idoff, id_off, (n + 1) * 4, hipMemcpyHostToDevice, st));
+	if (idb) HIP_TRY(hipMemcpyAsync(d_ids, ids, idb, hipMemcpyHostToDevice, st));
+	SamSrc s{(const vdjx_pair*) c->me_dense, d_offs, (u32) n, d_ids, d_idoff, c->d_sam_names, c->d_sam_noff, p->d_bases, p->d_nmask,
+	         vdjx_qrows{p->d_quals, p->d_quals2, p->q_split, p->qstride}, p->rl, p->W, p->M};
+	if (total >= (1ull << 32)) { vdjx_set_error("vdjx_sam_text: too many pairs in one call"); return VDJX_ELIMIT; }
+	u64 nbytes = 0;
+	{
+		vdjx_prof_scope ps(c, "k_sam_text");
+		hipLaunchKernelGGL(k_sam_len, dim3((u32) ((total + 255) / 256)), dim3(256), 0, st, s, total, d_len);
+		hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, st, d_len, (u32) total, d_at);
+		HIP_TRY(hipMemcpyAsync(&nbytes, d_at + total, 8, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(hipGetLastError());
+		if (nbytes + 1 > c->sam_text_cap) {
+			if (c->h_sam_text) (void) hipHostFree(c->h_sam_text);
+			free_set(c->d_sam_text);
+			c->h_sam_text = nullptr; c->sam_text_cap = 0;
+			const size_t want = (size_t) nbytes + (size_t) nbytes / 8 + 4096;
+			HIP_TRY(hipMalloc(&c->d_sam_text, want));
+			HIP_TRY(hipHostMalloc(&c->h_sam_text, want, hipHostMallocDefault));
+			c->sam_text_cap = want;
+		}
+		hipLaunchKernelGGL(k_sam_write, dim3((u32) ((total + 3) / 4)), dim3(256), 0, st, s, total, d_at, (char*) c->d_sam_text);
+	}
+	HIP_TRY(hipMemcpyAsync(c->h_sam_text, c->d_sam_text, (size_t) nbytes, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	vdjx_prof_collect(c);
+	((char*) c->h_sam_text)[nbytes] = 0;
+	*out_text = (const char*) c->h_sam_text;
+	*out_bytes = nbytes;
+	c->stats["sam_pairs"] = total;
+	c->stats["sam_bytes"] = nbytes;
 	return VDJX_OK;
 }
