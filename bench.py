@@ -116,21 +116,53 @@ def cpu_reference(n_sample: int, seed: int, k: int, mf: int, mq: int, mrs: int, 
         synth.write_ref_dir(rep, os.path.join(td, "ref"))
         cmd = [REF_BIN, "run", "--in", "reads.txt", "--chain", "IGH", "--ref-dir", "ref", "--ins", str(ins), "--t", str(threads),
                "--k", str(k), "--mf", str(mf), "--mq", str(mq), "--mrs", str(mrs)]
-        marks = {}
-        with open(os.path.join(td, "sam.out"), "wb") as so:
-            pr = subprocess.Popen(cmd, cwd=td, stdout=so, stderr=subprocess.PIPE, text=True, errors="replace")
-            for line in pr.stderr:
-                if line.startswith("ELAPSED_SECS\t"):
-                    marks.setdefault(line.split("\t")[1], time.perf_counter())
-            pr.wait()                 # (the exit status is meaningless: the reference's main falls off its end)
+        def timed_run(argv, cwd, sam_name):
+            mk = {}
+            t_start = time.perf_counter()
+            with open(os.path.join(cwd, sam_name), "wb") as so:
+                pr = subprocess.Popen(argv, cwd=cwd, stdout=so, stderr=subprocess.PIPE, text=True, errors="replace")
+                for line in pr.stderr:
+                    if line.startswith("ELAPSED_SECS\t"):
+                        mk.setdefault(line.split("\t")[1], time.perf_counter())
+                pr.wait()             # (the reference's exit status is meaningless: its main falls off its end)
+            return mk, t_start, time.perf_counter(), pr.returncode
+        marks, _, _, _ = timed_run(cmd, td, "sam.out")
         n_contigs = sum(1 for l in open(os.path.join(td, "vdj_contigs.fa")) if l.startswith(">")) if os.path.exists(os.path.join(td, "vdj_contigs.fa")) else -1
+        # ---- the whole command line of THIS build on the same file, same flags (one GPU): the first number that covers the read
+        # index, the serial host traversal and the text output as well
+        exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
+        cli = None
+        if os.path.exists(exe):
+            d2 = os.path.join(td, "hip")
+            os.makedirs(d2)
+            os.symlink(os.path.join(td, "reads.txt"), os.path.join(d2, "reads.txt"))
+            os.symlink(os.path.join(td, "ref"), os.path.join(d2, "ref"))
+            mk2, t0c, t1c, rc2 = timed_run([exe] + cmd[2:], d2, "sam.out")
+            same = None
+            try:
+                same = (open(os.path.join(d2, "vdj_contigs.fa"), "rb").read() == open(os.path.join(td, "vdj_contigs.fa"), "rb").read()
+                        and open(os.path.join(d2, "sam.out"), "rb").read() == open(os.path.join(td, "sam.out"), "rb").read())
+            except OSError:
+                pass
+
+            def sp(m, a, b):
+                return round(m[b] - m[a], 3) if a in m and b in m else None
+            stages = (("kmer_table", "PRE_PRE_GRAPH1", "POST_PRE_GRAPH1"), ("prune", "POST_PRE_GRAPH1", "POST_PRUNE_PRE_GRAPH1"),
+                      ("graph", "POST_PRUNE_PRE_GRAPH1", "POST_BUILD_GRAPH2"), ("traversal_and_scorers", "POST_BUILD_GRAPH2", "THREADS_DONE"),
+                      ("output_and_sam", "THREADS_DONE", "PRE_CLEANUP"), ("assemble_total", "PRE_PRE_GRAPH1", "FINIS"))
+            cli = {"pairs": n_sample, "exit_code": rc2, "wall_s_process": round(t1c - t0c, 3),
+                   "stages_s": {n_: sp(mk2, a, b) for n_, a, b in stages}, "reference_stages_s": {n_: sp(marks, a, b) for n_, a, b in stages},
+                   "outputs_identical_to_reference": same,
+                   "note": "vdjer_amd/vdjer (C host over libvdjx, one GPU) and oracle/_ref/vdjer_ref on the same extracted-reads file and ref-dir, "
+                           "timed by their ELAPSED_SECS stage markers as they arrive; process wall time includes reading the file, loading the "
+                           "pool, building the read index and the GPU start-up"}
     if "PRE_PRE_GRAPH1" not in marks or "FINIS" not in marks:
         return None
 
     def span(a, b):
         return round(marks[b] - marks[a], 2) if a in marks and b in marks else None
     secs = marks["FINIS"] - marks["PRE_PRE_GRAPH1"]
-    return {"value": n_sample / secs / 1e6, "unit": "M paired-reads/s", "cores": threads, "kind": "reference",
+    return {"value": n_sample / secs / 1e6, "unit": "M paired-reads/s", "cores": threads, "kind": "reference", "cli_end_to_end": cli,
             "sample": f"{n_sample} pairs / {len(rep.clones)} clones of the same generator through oracle/_ref/vdjer_ref "
                       f"(the reference's own sources, g++ -O0 as it ships; -O1+ crashes on its missing returns, SURVEY §0-2), --t {threads}: "
                       f"k-mer table {span('PRE_PRE_GRAPH1', 'POST_PRE_GRAPH1')}s (1 thread by construction, A2:1388-1390), prune "
@@ -607,6 +639,7 @@ def main():
                          for o0 in (False, True)]
         if cpu is None:           # no compiled reference on this box: the -O2 port is the stated baseline
             cpu = cpu_port_legs[0]
+    cli_e2e = cpu.pop("cli_end_to_end", None) if cpu else None
     kern_ms = {k_: round(v[0] / args.steps, 4) for k_, v in prof.items()}
     out = {
         "metric": "M paired-reads/sec (k-mer build + contig score), IgH 50bp PE", "value": round(value, 4),
@@ -619,7 +652,7 @@ def main():
                    "scorer_inputs": scorer_src},
         "roofline": roof, "roofline_by_kernel": by_kernel, "cpu_baseline": cpu, "cpu_baseline_port_legs": cpu_port_legs,
         "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
-        "value_end_to_end": e2e,
+        "value_end_to_end": e2e, "cli_end_to_end": cli_e2e,
         "kernels_ms_per_step": kern_ms, "kernels_sum_ms_per_step": round(sum(kern_ms.values()), 3),
         "device_busy_frac": round(sum(kern_ms.values()) / ms_step, 4) if ms_step else None,
         "exchange_bytes_per_step_rank0": ((engine.bytes_exchanged - bytes_before) // args.steps) if engine else 0,
