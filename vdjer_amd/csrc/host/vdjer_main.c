@@ -25,7 +25,10 @@
 #include "vdjh.h"
 #include "bamx.h"
 #include "vdjx_mgpu.h"
+#include <errno.h>
 #include <sys/wait.h>
+#include <sys/prctl.h>
+#include <signal.h>
 #include <unistd.h>
 
 typedef struct {
@@ -228,11 +231,67 @@ static int load_bam(const cli* c, reads_t* r) {
 	return rc;
 }
 
-static int load_reads(const cli* c, reads_t* r) {
+/* A rank other than 0 of `--gpus N` only ever uses ITS records [rank*S, (rank+1)*S) of the scan order (primary pool, then secondary;
+ * two records per read): the text file is read twice -- once to count the reads of the two pools, once to keep the rank's own --
+ * instead of every process holding the whole pool (40 GB each at 100 M pairs).  The slice comes back as the primary pool of `r`
+ * (n_primary records, nothing else filled in); *stride = S. */
+static int load_slice_text(const char* path, int rank, int nranks, reads_t* r, size_t* stride) {
+	FILE* fp = fopen(path, "r");
+	if (!fp) { fprintf(stderr, "cannot open %s\n", path); return -1; }
+	char pool[8], name[512];
+	static char seq[1024], qual[1024];
+	int rn, rev, rl = -1;
+	size_t np = 0, ns = 0;
+	while (fscanf(fp, "%7s %511s %d %d %1023s %1023s", pool, name, &rn, &rev, seq, qual) == 6) {
+		const int l = (int) strlen(seq);
+		if (l > rl) rl = l;
+		if (pool[0] == 'P') np++; else ns++;
+	}
+	if (rl <= 0) { fclose(fp); fprintf(stderr, "Error retrieving read length from: %s\n", path); return -1; }
+	const size_t Rt = 2 * (np + ns), S = (Rt + (size_t) nranks - 1) / (size_t) nranks;
+	const size_t a = (size_t) rank * S < Rt ? (size_t) rank * S : Rt, b = a + S < Rt ? a + S : Rt;
+	const size_t rec = 2 * (size_t) rl + 1;
+	memset(r, 0, sizeof *r);
+	r->rl = rl;
+	r->n_primary = b - a;
+	r->primary = (uint8_t*) calloc((b - a) * rec + 1, 1);
+	*stride = S;
+	rewind(fp);
+	size_t ip = 0, is = 0;
+	int bad = 0;
+	while (fscanf(fp, "%7s %511s %d %d %1023s %1023s", pool, name, &rn, &rev, seq, qual) == 6) {
+		const int isp = pool[0] == 'P';
+		const size_t g = isp ? ip : 2 * np + is;              /* scan index of the read's first record */
+		if (isp) ip += 2; else is += 2;
+		if (g + 2 <= a || g >= b) continue;
+		if ((int) strlen(seq) != rl || (int) strlen(qual) != rl) { fprintf(stderr, "read %s: length != %d\n", name, rl); bad = 1; break; }
+		for (int j = 0; j < 2; j++) {
+			if (g + (size_t) j < a || g + (size_t) j >= b) continue;
+			uint8_t* base = r->primary + (g + (size_t) j - a) * rec;
+			base[0] = '0';
+			for (int i = 0; i < rl; i++) {
+				base[1 + i] = (uint8_t) (j ? comp(seq[rl - 1 - i]) : seq[i]);
+				base[1 + rl + i] = (uint8_t) (j ? qual[rl - 1 - i] : qual[i]);
+			}
+		}
+	}
+	fclose(fp);
+	return bad ? -1 : 0;
+}
+
+static int load_reads(const cli* c, reads_t* r, int rank, int nranks) {
 	const char* path = c->in;
 	const int isbam = bamx_is_bam(path);
 	if (isbam < 0) { fprintf(stderr, "cannot open %s\n", path); return -1; }
-	if (isbam) return load_bam(c, r);
+	if (isbam) return load_bam(c, r);                        /* (every rank extracts: the BAM passes are not sliced) */
+	if (rank > 0 && nranks > 1) {
+		size_t S = 0;
+		const int rc = load_slice_text(path, rank, nranks, r, &S);
+		r->n_pairs = 0;
+		r->n_secondary = S;                                   /* (smuggled to main: the slice's stride; a slice has no secondary pool) */
+		r->secondary = NULL;
+		return rc;
+	}
 	FILE* fp = fopen(path, "r");
 	if (!fp) { fprintf(stderr, "cannot open %s\n", path); return -1; }
 	char pool[8], name[512];
@@ -393,31 +452,91 @@ static uint8_t* slice_records(const reads_t* r, size_t a, size_t b) {
 	return out;
 }
 
+/* ---- `--gpus N`: the other ranks are child processes.  A rank that fails must never leave the others waiting inside a collective
+ * (RCCL has no timeout of its own): a child dies with its parent (PR_SET_PDEATHSIG), the parent takes every child down when it
+ * leaves for whatever reason (atexit), and a child that ends badly ends the whole run at once (SIGCHLD) instead of hanging it. */
+static pid_t g_kids[256];
+static volatile sig_atomic_t g_kid_state[256];      /* 0 running, 1 ended well, 2 reaped after being killed */
+static int g_nkids = 0;
+
+static void kill_kids(void) {
+	for (int r = 1; r <= g_nkids; r++) if (g_kid_state[r] == 0) (void) kill(g_kids[r], SIGTERM);
+	for (int r = 1; r <= g_nkids; r++) if (g_kid_state[r] == 0) { int st_; (void) waitpid(g_kids[r], &st_, 0); g_kid_state[r] = 2; }
+}
+
+static void on_sigchld(int sig) {
+	(void) sig;
+	for (int r = 1; r <= g_nkids; r++) {
+		if (g_kid_state[r] != 0) continue;
+		int st_ = 0;
+		const pid_t p = waitpid(g_kids[r], &st_, WNOHANG);
+		if (p != g_kids[r]) continue;
+		if (WIFEXITED(st_) && WEXITSTATUS(st_) == 0) { g_kid_state[r] = 1; continue; }
+		g_kid_state[r] = 2;
+		static const char msg[] = "vdjer: a GPU rank failed; stopping the others\n";
+		(void) !write(2, msg, sizeof msg - 1);
+		for (int q = 1; q <= g_nkids; q++) if (g_kid_state[q] == 0) (void) kill(g_kids[q], SIGKILL);
+		for (int q = 1; q <= g_nkids; q++) if (g_kid_state[q] == 0) { int s2; (void) waitpid(g_kids[q], &s2, 0); }      /* (no zombies left to whoever inherits them) */
+		_exit(1);
+	}
+}
+
 int main(int argc, char** argv) {
 	t_start = t_prev = time(NULL);
 	cli c;
 	if (parse(argc, argv, &c)) return 255;                  /* the reference exits with -1 */
 	/* --gpus N: one process per GPU.  The parent is rank 0 and does everything a single-GPU run does; ranks 1..N-1 are forked
 	 * BEFORE anything touches a GPU, take part in the sharded k-mer build with their slice of the pool, and leave. */
+	if (getenv("VDJX_DUMP_SLICE")) {            /* (test hook, no GPU: "rank,nranks" -> that rank's records of the text input on stdout) */
+		int rk = 0, nr = 1;
+		reads_t sl;
+		size_t S = 0;
+		if (sscanf(getenv("VDJX_DUMP_SLICE"), "%d,%d", &rk, &nr) != 2 || load_slice_text(c.in, rk, nr, &sl, &S)) return 255;
+		fprintf(stderr, "slice\t%d\t%d\trl\t%d\trecords\t%zu\tstride\t%zu\n", rk, nr, sl.rl, sl.n_primary, S);
+		fwrite(sl.primary, 2 * (size_t) sl.rl + 1, sl.n_primary, stdout);
+		return 0;
+	}
 	int rank = 0;
 	int id_pipe[256][2];
-	pid_t kids[256];
 	if (c.gpus < 1 || c.gpus > 256 || (c.gpus & (c.gpus - 1))) { fprintf(stderr, "--gpus must be a power of two in [1,256]\n"); return 255; }
+	if (c.gpus > 1) {
+		struct sigaction sa;
+		memset(&sa, 0, sizeof sa);
+		sa.sa_handler = on_sigchld;
+		sa.sa_flags = SA_RESTART | SA_NOCLDSTOP;
+		sigaction(SIGCHLD, &sa, NULL);
+		atexit(kill_kids);
+	}
+	const pid_t parent = getpid();
+	sigset_t chld, before;
+	sigemptyset(&chld);
+	sigaddset(&chld, SIGCHLD);
+	sigprocmask(SIG_BLOCK, &chld, &before);       /* (no rank's end is handled before every rank is on the list) */
 	for (int r = 1; r < c.gpus; r++) {
 		if (pipe(id_pipe[r])) { perror("pipe"); return 255; }
 		fflush(stdout); fflush(stderr);
 		const pid_t pid = fork();
 		if (pid < 0) { perror("fork"); return 255; }
-		if (pid == 0) { rank = r; g_rank = r; close(id_pipe[r][1]); break; }
-		kids[r] = pid;
+		if (pid == 0) {
+			rank = r; g_rank = r; g_nkids = 0;
+			signal(SIGCHLD, SIG_DFL);
+			sigprocmask(SIG_SETMASK, &before, NULL);
+			(void) prctl(PR_SET_PDEATHSIG, SIGKILL);
+			if (getppid() != parent) _exit(1);             /* (the parent was gone before the request took effect) */
+			close(id_pipe[r][1]);
+			break;
+		}
+		g_kids[r] = pid;
+		g_nkids = r;
 		close(id_pipe[r][0]);
 	}
+	if (rank == 0) sigprocmask(SIG_SETMASK, &before, NULL);
 	if (rank == 0) status("START");
 	reads_t rd;
-	if (load_reads(&c, &rd)) return 255;
+	if (load_reads(&c, &rd, rank, c.gpus)) return 255;
 	c.hp.read_length = rd.rl;
 	c.hp.threads = c.threads;
-	fprintf(stderr, "read length:\t%d\n", rd.rl);
+	if (rank == 0) fprintf(stderr, "read length:\t%d\n", rd.rl);
 
 	uint32_t *vc = NULL, *jc = NULL;
 	size_t nv = 0, nj = 0;
@@ -473,13 +592,14 @@ int main(int argc, char** argv) {
 		VX(vdjx_kmer_build(gx, px, c.hp.k, c.hp.min_node_freq, c.hp.min_base_quality, &gg));
 	} else {
 		/* rank r holds records [r*S, (r+1)*S) of the scan order: the rank-major numbering of the sharded build IS the scan order */
+		const int sliced = rank > 0 && rd.secondary == NULL && rd.n_pairs == 0;      /* load_slice_text: the pool IS the slice */
 		const size_t Rt = rd.n_primary + rd.n_secondary;
-		const size_t S = (Rt + (size_t) c.gpus - 1) / (size_t) c.gpus;
+		const size_t S = sliced ? rd.n_secondary : (Rt + (size_t) c.gpus - 1) / (size_t) c.gpus;
 		const size_t a = (size_t) rank * S < Rt ? (size_t) rank * S : Rt, b = a + S < Rt ? a + S : Rt;
-		uint8_t* mine = slice_records(&rd, a, b);
+		uint8_t* mine = sliced ? rd.primary : slice_records(&rd, a, b);
 		vdjx_pool* ps = NULL;
-		VX(vdjx_pool_load(gx, mine, b - a, NULL, 0, rd.rl, &ps));
-		free(mine);
+		VX(vdjx_pool_load(gx, mine, sliced ? rd.n_primary : b - a, NULL, 0, rd.rl, &ps));
+		if (!sliced) free(mine);
 		if (vdjx_mgpu_kmer_build(mg, gx, ps, c.hp.k, c.hp.min_node_freq, c.hp.min_base_quality, S ? S : 1, &gg)) {
 			fprintf(stderr, "rank %d: %s\n", rank, vdjx_mgpu_last_error());
 			return 1;
@@ -521,9 +641,14 @@ int main(int argc, char** argv) {
 	}
 	fprintf(stderr, "num root nodes: %zu\nProcessed roots: %zu\ncontig_candidates: %zu\nwindows scored: %zu valid: %zu\ncontigs: %zu\n",
 	        st.n_roots, st.n_roots_accepted, st.n_contig_candidates, st.n_windows_scored, st.n_windows_valid, st.n_contigs_out);
-	for (int r = 1; r < c.gpus; r++) {
-		int st_ = 0;
-		if (waitpid(kids[r], &st_, 0) < 0 || !WIFEXITED(st_) || WEXITSTATUS(st_) != 0) { fprintf(stderr, "rank %d failed\n", r); return 1; }
+	for (int r = 1; r < c.gpus; r++) {                    /* (normally all ended, well, long ago: on_sigchld has their status) */
+		while (g_kid_state[r] == 0) {
+			int st_ = 0;
+			const pid_t p = waitpid(g_kids[r], &st_, 0);
+			if (p == g_kids[r]) g_kid_state[r] = (WIFEXITED(st_) && WEXITSTATUS(st_) == 0) ? 1 : 2;
+			else if (p < 0 && errno != EINTR) break;          /* reaped by the handler meanwhile */
+		}
+		if (g_kid_state[r] != 1) { fprintf(stderr, "rank %d failed\n", r); return 1; }
 	}
 	status("FINIS");
 	fflush(stdout);

@@ -8,6 +8,7 @@
  * followed by two all-reduces of the per-survivor arrays (MIN over unsigned 64-bit first sights, SUM over the counts).
  */
 #include "vdjx_mgpu.h"
+#include "vdjx_a2a_plan.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -93,34 +94,25 @@ uint64_t vdjx_mgpu_bytes_sent(const vdjx_mgpu* m) { return m ? m->bytes_sent : 0
 static int a2av(vdjx_mgpu* m, const void* d_send, const uint64_t* send_rows, void* d_recv, const uint64_t* recv_rows, size_t row) {
 	int rc = 0;
 	const int G = m->nranks, me = m->rank;
-	size_t* so = (size_t*) calloc((size_t) G + 1, sizeof(size_t));
-	size_t* ro = (size_t*) calloc((size_t) G + 1, sizeof(size_t));
-	size_t rounds = 0;
-	if (!so || !ro) { rc = VDJX_EHIP; goto done; }
-	for (int r = 0; r < G; r++) {
-		so[r + 1] = so[r] + (size_t) send_rows[r] * row;
-		ro[r + 1] = ro[r] + (size_t) recv_rows[r] * row;
-		if (r != me) {
-			const size_t a = ((size_t) send_rows[r] * row + A2A_CHUNK - 1) / A2A_CHUNK, b = ((size_t) recv_rows[r] * row + A2A_CHUNK - 1) / A2A_CHUNK;
-			if (a > rounds) rounds = a;
-			if (b > rounds) rounds = b;
-			m->bytes_sent += send_rows[r] * row;
-		}
-	}
-	if (send_rows[me]) HIPC(hipMemcpyAsync((char*) d_recv + ro[me], (const char*) d_send + so[me], (size_t) send_rows[me] * row, hipMemcpyDeviceToDevice, m->stream));
-	for (size_t rd = 0; rd < rounds; rd++) {
+	uint64_t self[3] = {0, 0, 0};
+	const size_t nst = vdjx_a2a_plan(G, me, send_rows, recv_rows, row, A2A_CHUNK, NULL, 0, self);         /* (the offsets: vdjx_a2a_plan.c, tested on the CPU) */
+	vdjx_a2a_step* st = (vdjx_a2a_step*) calloc(nst + 1, sizeof *st);
+	if (!st) { rc = VDJX_EHIP; goto done; }
+	(void) vdjx_a2a_plan(G, me, send_rows, recv_rows, row, A2A_CHUNK, st, nst, self);
+	for (int r = 0; r < G; r++) if (r != me) m->bytes_sent += send_rows[r] * row;
+	if (self[2]) HIPC(hipMemcpyAsync((char*) d_recv + self[1], (const char*) d_send + self[0], (size_t) self[2], hipMemcpyDeviceToDevice, m->stream));
+	for (size_t i = 0; i < nst;) {
+		const uint32_t round = st[i].round;
 		NCCLC(ncclGroupStart());
-		for (int r = 0; r < G; r++) {
-			if (r == me) continue;
-			const size_t sb = (size_t) send_rows[r] * row, rb = (size_t) recv_rows[r] * row, a = rd * A2A_CHUNK;
-			if (a < sb) NCCLC(ncclSend((const char*) d_send + so[r] + a, sb - a < A2A_CHUNK ? sb - a : A2A_CHUNK, ncclChar, r, m->comm, m->stream));
-			if (a < rb) NCCLC(ncclRecv((char*) d_recv + ro[r] + a, rb - a < A2A_CHUNK ? rb - a : A2A_CHUNK, ncclChar, r, m->comm, m->stream));
+		for (; i < nst && st[i].round == round; i++) {
+			if (st[i].send_len) NCCLC(ncclSend((const char*) d_send + st[i].send_off, (size_t) st[i].send_len, ncclChar, st[i].peer, m->comm, m->stream));
+			if (st[i].recv_len) NCCLC(ncclRecv((char*) d_recv + st[i].recv_off, (size_t) st[i].recv_len, ncclChar, st[i].peer, m->comm, m->stream));
 		}
 		NCCLC(ncclGroupEnd());
 	}
 	HIPC(hipStreamSynchronize(m->stream));
 done:
-	free(so); free(ro);
+	free(st);
 	return rc;
 }
 
