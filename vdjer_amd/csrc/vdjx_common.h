@@ -86,6 +86,8 @@ struct vdjx_ctx {
 	hipStream_t stream = nullptr;
 	hipStream_t copy_stream = nullptr;   // result copies that may run beside the next kernels (vdjx_graph_export_begin)
 	hipStream_t pairs_stream = nullptr;  // the mapped pairs' copy (vdjx_map_emit_begin): a stream of its own, so that waiting for one result is not waiting for the other
+	void* h_pin = nullptr;                          // 16 KB of page-locked memory: where the small numbers a call waits for come down (a copy into
+	                                                // pageable memory goes through a staging buffer of the runtime: tens of microseconds per read)
 	void* d_stage[2] = {nullptr, nullptr};          // vdjx_pool_load: upload staging (two chunks in flight)
 	size_t stage_cap = 0;
 	hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_packed[2] = {nullptr, nullptr};

@@ -46,6 +46,7 @@ extern "C" int vdjx_init(int device, vdjx_ctx** out) {
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->pairs_stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipHostMalloc(&c->h_pin, 16384, hipHostMallocDefault);
 	if (e != hipSuccess) { delete c; vdjx_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return VDJX_EHIP; }
 	{
 		std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -118,6 +119,7 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	if (c->pairs_stream) { (void) hipStreamSynchronize(c->pairs_stream); (void) hipStreamDestroy(c->pairs_stream); }
 	if (c->ev_gathered) (void) hipEventDestroy(c->ev_gathered);
 	if (c->h_plan) (void) hipHostFree(c->h_plan);
+	if (c->h_pin) (void) hipHostFree(c->h_pin);
 	if (c->h_sam_text) (void) hipHostFree(c->h_sam_text);
 	free_dev(c->d_sam_text); free_dev(c->d_sam_names); free_dev(c->d_sam_noff);
 	(void) hipStreamDestroy(c->stream);
@@ -512,7 +514,8 @@ static void pack_launch(vdjx_ctx* c, hipStream_t st, vdjx_pool* p, const uint8_t
 }
 
 static int pool_finish(vdjx_ctx* c, vdjx_pool* p, u32* d_bad, vdjx_pool** out) {
-	u32 both[2] = {0, 0};
+	u32* both = (u32*) c->h_pin;
+	both[0] = both[1] = 0;
 	hipError_t e = hipMemcpyAsync(both, d_bad, 8, hipMemcpyDeviceToHost, c->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipGetLastError();

@@ -1965,6 +1965,7 @@ __device__ inline u64 inst_compact(u64 inst, u32 P, int ob) { return (inst >> ob
 __global__ void k_mark_first2(const u64* __restrict__ ufirst, u32 n, u32 P, int ob, u32* __restrict__ bits) {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
+	if (ufirst[i] == NONE64) return;                  // (an unseen survivor: the build fails, nothing may be written out of bounds first)
 	const u64 c = inst_compact(ufirst[i], P, ob);
 	atomicOr(&bits[c >> 5], 1u << (u32) (c & 31));
 }
@@ -1973,6 +1974,7 @@ __global__ void k_node_rank2(const u64* __restrict__ ufirst, u32 n, u32 P, int o
                              const u32* __restrict__ block_pre, u32* __restrict__ rank) {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
+	if (ufirst[i] == NONE64) { rank[i] = i; return; }
 	const u64 c = inst_compact(ufirst[i], P, ob);
 	const u64 w = c >> 5;
 	rank[i] = block_pre[w / POPC_WORDS] + word_pre[w] + __popc(bits[w] & ((1u << (u32) (c & 31)) - 1u));
@@ -2127,10 +2129,10 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 	}
 	dbg_sync(c, "k_gated_hist");
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, hcnt, NBH, hstart);
-	u32 N = 0;
-	HIP_TRY(hipMemcpyAsync(&N, hstart + NBH, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(c->h_pin, hstart + NBH, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	const u32 N = *(const u32*) c->h_pin;
 	out->N = N;
 	c->stats["gated_instances"] = N;                // k-mer instances that pass include_kmer (A2:240-259) in this pool
 	// bucket bits from the actual number of gated instances; in the sharded build every rank must cut the same buckets, so there
@@ -2229,13 +2231,14 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 		hipLaunchKernelGGL(k_gated_reduce<TUP>, dim3(t.NB), dim3(RD_THREADS), 0, st, t.t, t.bucket_start, pv.bases, pv.nmask, pv.quals, pv.rl, pv.ob, k, rec_base,
 		                   mfu, cmin, mqq, tlow, so, g_distinct, g_err);
 	}
-	u32 ns = 0, err = 0;
-	u64 spread[64 * 16];
-	HIP_TRY(hipMemcpyAsync(&ns, n_surv, 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(&err, g_err, 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(spread, g_distinct, sizeof(spread), hipMemcpyDeviceToHost, st));
+	u64* spread = (u64*) c->h_pin;                    // [64 * 16], then ns, err
+	u32* tail = (u32*) (spread + 64 * 16);
+	HIP_TRY(hipMemcpyAsync(&tail[0], n_surv, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&tail[1], g_err, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(spread, g_distinct, 64 * 16 * 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	const u32 ns = tail[0], err = tail[1];
 	if (err) { vdjx_set_error("k_gated_reduce: %u buckets could not be split to fit LDS", err); return VDJX_EHIP; }
 	if (ns > cap) { vdjx_set_error("survivor capacity logic failed (%u > %u)", ns, cap); return VDJX_EHIP; }
 	sv->ndist = 0;
@@ -2248,10 +2251,19 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 // in-edge first sights and, derived from them, both edge directions.  Output arrays are caller-provided:
 //   ucnt u32 [ns] (raw count), ufirst u64 [ns], in_first u64 [ns*4], in_from u32 [ns*4], edge_first u64 [ns*4], edge_to u32 [ns*4]
 struct RecountOut { u32* ucnt; u64* ufirst; u64* in_first; u32* in_from; u64* edge_first; u32* edge_to; };
+// what stage_recount leaves on the device for a caller that waits later (one host wait less per build): read back by recount_status_read
+struct RecountStatus { const u32* g_err = nullptr; const u32* n_items = nullptr; const unsigned long long* n_inst = nullptr; u32 ns = 0; };
+static int recount_status_check(vdjx_ctx* c, const u32* hp, u32 ns) {          // hp: err[2], n_items, -, inst (u64)
+	if (hp[0]) { vdjx_set_error("k_walk_items: item buffer too small (%u waves stopped)", hp[0]); return VDJX_EHIP; }
+	if (hp[1]) { vdjx_set_error("internal error: %u of %u surviving k-mers were not met again in the records (VDJX_SYNC_DEBUG=1 names them)", hp[1], ns); return VDJX_EHIP; }
+	c->stats["recount_items"] = hp[2];                                    // runs of surviving k-mer instances of this pool (8 bytes each)
+	c->stats["recount_instances"] = *(const unsigned long long*) (hp + 4);          // the instances themselves
+	return VDJX_OK;
+}
 
 template <typename A>
 int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k, SurvivorsG& sv, const RecountOut& ro,
-                  bool derive_edges, SurvTable* table_out = nullptr) {
+                  bool derive_edges, SurvTable* table_out = nullptr, RecountStatus* defer = nullptr) {
 	hipStream_t st = c->stream;
 	const size_t R = pool->n_records;
 	const int P = pool->rl - k + 1;
@@ -2466,13 +2478,19 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		HIP_TRY(hipMemsetAsync(ro.edge_first, 0xFF, (size_t) ns * 32, st));
 		hipLaunchKernelGGL(k_edges_from_in, dim3((ns * 4 + 255) / 256), dim3(256), 0, st, tb, ns, k, ro.in_first, ro.in_from, ro.edge_first, ro.edge_to);
 	}
-	u32 err[2] = {0, 0}, n_items = 0;
-	unsigned long long inst = 0;
-	HIP_TRY(hipMemcpyAsync(err, g_err, 8, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(&n_items, range_start + n_ranges_p, 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(&inst, n_inst, 8, hipMemcpyDeviceToHost, st));
+	if (defer && !getenv("VDJX_SYNC_DEBUG")) {         // the caller reads the status when it waits anyway
+		defer->g_err = g_err; defer->n_items = range_start + n_ranges_p; defer->n_inst = n_inst; defer->ns = ns;
+		return VDJX_OK;
+	}
+	if (defer) defer->g_err = nullptr;
+	u32* hp = (u32*) c->h_pin;                        // err[2], n_items, -, inst (u64)
+	HIP_TRY(hipMemcpyAsync(hp, g_err, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(hp + 2, range_start + n_ranges_p, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(hp + 4, n_inst, 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	const u32 err[2] = {hp[0], hp[1]}, n_items = hp[2];
+	const unsigned long long inst = *(const unsigned long long*) (hp + 4);
 	if (err[0]) { vdjx_set_error("k_walk_items: item buffer too small (%u waves stopped)", err[0]); return VDJX_EHIP; }
 	if (err[1]) {
 		if (getenv("VDJX_SYNC_DEBUG")) {          // name the k-mers
@@ -2569,10 +2587,11 @@ int stage_finish2(vdjx_ctx* c, A& db, const SurvivorsG& sv, const RecountOut& ro
 		hipLaunchKernelGGL(k_root_count, dim3(nrb), dim3(256), 0, st, no.from_deg, ns, rb_cnt);
 		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, rb_cnt, nrb, rb_start);
 		hipLaunchKernelGGL(k_root_list, dim3(nrb), dim3(256), 0, st, no.from_deg, ns, rb_start, g->d_roots);
-		HIP_TRY(hipMemcpyAsync(&n_roots, rb_start + nrb, 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(c->h_pin, rb_start + nrb, 4, hipMemcpyDeviceToHost, st));
 	}
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	n_roots = *(const u32*) c->h_pin;
 	g->n_roots = n_roots;
 	vdjx_prof_collect(c);
 	return VDJX_OK;
@@ -2597,8 +2616,18 @@ int kmer_build_impl2(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, 
 		HIP_TRY(db.alloc(&ro.in_first, (size_t) sv.n * 4)); HIP_TRY(db.alloc(&ro.in_from, (size_t) sv.n * 4));
 		HIP_TRY(db.alloc(&ro.edge_first, (size_t) sv.n * 4)); HIP_TRY(db.alloc(&ro.edge_to, (size_t) sv.n * 4));
 		ro.ucnt = sv.ucnt; ro.ufirst = sv.ufirst;
-		rc = stage_recount(c, db, pool, 0, k, sv, ro, true);
+		RecountStatus rs;
+		rc = stage_recount(c, db, pool, 0, k, sv, ro, true, nullptr, &rs);
 		if (rc) return rc;
+		u32* hp = (u32*) c->h_pin + 1024;              // (behind what stage_finish2 reads back)
+		if (rs.g_err) {
+			HIP_TRY(hipMemcpyAsync(hp, rs.g_err, 8, hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipMemcpyAsync(hp + 2, rs.n_items, 4, hipMemcpyDeviceToHost, c->stream));
+			HIP_TRY(hipMemcpyAsync(hp + 4, rs.n_inst, 8, hipMemcpyDeviceToHost, c->stream));
+		}
+		rc = stage_finish2(c, db, sv, ro, pool->n_records, k, P, pool->ob, g);          // (waits for the stream)
+		if (rc) return rc;
+		return rs.g_err ? recount_status_check(c, hp, rs.ns) : VDJX_OK;
 	}
 	return stage_finish2(c, db, sv, ro, pool->n_records, k, P, pool->ob, g);
 }

@@ -249,9 +249,9 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 		hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, d_bsum, nb, d_bpre);
 		hipLaunchKernelGGL(k_scan_add, dim3((ng + 255) / 256), dim3(256), 0, st, d_pre, ng, d_bpre);
 	}
-	u32 run = 0;
-	HIP_TRY(hipMemcpyAsync(&run, d_pre + ng, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(c->h_pin, d_pre + ng, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
+	const u32 run = *(const u32*) c->h_pin;
 	c->stats["root_dp_items"] = run;
 	if (run >= (1u << 31)) { vdjx_set_error("too many seed hits in one call (%u)", run); return VDJX_ELIMIT; }
 	if (threshold <= 0) {
