@@ -45,27 +45,33 @@ def algorithmic_bytes_per_pair(k: int, rl: int = 50, gated_per_pair: float | Non
     `total` is the SURVEY's per-pair figure for the whole k-mer build (it takes every instance as gated: 3,324 B at k=35) and
     prices the whole path (hot_path_frac).  Per kernel the job is priced with the MEASURED number of gated instances per pair
     (vdjx_stat "gated_instances": one instance in six of this generator's pools), because that is what the kernels move:
-      pack: the ASCII records in;  hist: the packed input once;  partition pass 1: packed input + one 16-B key per gated
+      pack: the four ASCII records of the pair in, their packed bases and masks out (32 B each; the quality characters stay in
+      the resident records);  hist: the packed input once;  partition pass 1: packed input + one 16-B key per gated
       instance out;  pass 2: every such key in and out;  table + prune: every key in;
       walk (the graph pass): packed input once more + one 16-B survivor probe per instance (gated or not)."""
     P = 4 * (rl - k + 1)
     inp = 2 * ((rl + 3) // 4 + rl)
     g = P if gated_per_pair is None else gated_per_pair
     return {"P": P, "input": inp, "total": inp + 32 * P + inp + 16 * P, "gated_per_pair": g,
-            "k_pool_pack": 4 * (2 * rl + 1), "k_gated_hist": inp, "k_part_records": inp + 16 * g, "k_part_tuples": 32 * g,
+            "k_pool_pack": 4 * (2 * rl + 1) + 4 * 32, "k_gated_hist": inp, "k_part_records": inp + 16 * g, "k_part_tuples": 32 * g,
             "k_seg_hist": 16 * g, "k_gated_reduce": 16 * g, "k_gated_local": 16 * g, "k_walk_items": inp + 16 * P}
 
 
 def scorer_bytes(stats: dict, n_windows: int, n_contigs: int, k: int, rl: int = 50, wlen: int = 486, clen: int = 360) -> dict:
-    """SURVEY §8d, scorers (not proportional to pairs): per window (len-rl) probes x 32 B + 8 B per matched read
-    instance; 8 B per emitted start entry; per contig (len-rl) probes x 32 B + 8 B per instance + one 20-B pair
-    record out; per (root, seed hit) k + 2k bytes."""
-    return {"k_part_items": 16 * stats.get("recount_items", 0),          # every surviving instance's 8-byte item in and out
+    """The scorers' jobs (not proportional to pairs), priced on what each kernel must read and write in THIS design:
+    classification: (len-rl) offsets per string x (one 32-B index slot in + one 16-B image entry out);
+    window mapper: the image (16 B per offset) + one 8-B index entry per DISTINCT read-1 entry of the classes met (identical read
+    pairs are one weighted entry; SURVEY 8d's "8 B per matched read instance" prices the reference's per-instance walk, 2.5 times
+    as many) + 8 B per list entry out;  coverage: the list in twice;  pair emission: image + 8 B per hit + 24 B per mapped pair out,
+    the gather 24 B in and 20 B out per pair;  root DP: k + 2k bytes per (root, seed hit)."""
+    nw, nc = n_windows * (wlen - rl), n_contigs * (clen - rl)
+    return {"k_part_items": 16 * stats.get("recount_items", 0),          # every run item (8 bytes) in and out
             "k_recount": 8 * stats.get("recount_items", 0),
-            "k_window_hits": n_windows * (wlen - rl) * 32,
-            "k_window_pairs": n_windows * (wlen - rl) * 32 + 8 * stats.get("window_hits", 0),
-            "k_window_cover": 8 * 2 * stats.get("window_pairs", 0),
-            "k_map_emit": n_contigs * (clen - rl) * 32 + 8 * stats.get("map_hits", 0),
+            "k_map_classify": (nw + nc) * 48,
+            "k_window_pairs": nw * 16 + 8 * stats.get("window_hits_distinct", 0) + 8 * stats.get("window_pairs_entries", 0),
+            "k_window_cover": 8 * 2 * stats.get("window_pairs_entries", stats.get("window_pairs", 0)),
+            "k_map_emit": nc * 16 + 8 * stats.get("map_hits", 0) + 24 * stats.get("mapped_pairs", 0),
+            "k_gather_pairs": 44 * stats.get("mapped_pairs", 0),
             "k_root_dp": 3 * k * stats.get("root_dp_items", 0)}
 
 
@@ -216,12 +222,14 @@ def cpu_port(n_sample: int, seed: int, k: int, mf: int, mq: int, mrs: int, ins: 
 
 
 def load_traffic(args, world: int, kernel: str):
-    """PMC-measured HBM bytes per launch of `kernel` from the committed rocprofv3 pass of the same command
-    (profiles/r02_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections, see profiles/README.md)."""
-    tf = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if not os.path.exists(tf):
+    """PMC-measured HBM bytes per launch of `kernel` from the newest committed rocprofv3 pass of the same command
+    (profiles/rNN_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections, see profiles/README.md; the
+    file names the commit it was taken at)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+    if not files:
         return None
-    tj = json.load(open(tf))
+    tj = json.load(open(files[-1]))
     same = (tj.get("pairs_per_gpu") == args.pairs and tj.get("k") == args.k and tj.get("windows", "traversal") == args.windows and world == 1)
     if not same:
         return None
@@ -229,6 +237,15 @@ def load_traffic(args, world: int, kernel: str):
         if name.split("<")[0] == kernel:
             return v["hbm_bytes"]
     return None
+
+
+def traffic_source() -> dict | None:
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+    if not files:
+        return None
+    tj = json.load(open(files[-1]))
+    return {"file": os.path.relpath(files[-1], ROOT), "commit": tj.get("commit"), "note": "PMC passes are separate runs of the same command (profiles/prof_step.sh)"}
 
 
 def main():
@@ -562,6 +579,8 @@ def main():
         names = ("plan_issue", "plan_wait", "ws_cover_wait", "me_key", "me_plan", "me_kernel_wait", "me_second_call", "me_prev_copy_wait", "me_copy_issue")
         laps = {n_: round(ctx.stat("us_" + n_) / (args.warmup + args.steps), 1) for n_ in names}
     stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_hits_distinct", "window_pairs", "window_work_items", "map_hits", "root_dp_items", "recount_items", "recount_instances", "gated_instances")}
+    stats["mapped_pairs"] = int(state["last"]["pairs"].shape[0]) if state.get("last") else 0
+    stats["window_pairs_entries"] = ctx.stat("window_pairs_entries")
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         cm.all_reduce(tt, dist.ReduceOp.MAX)
@@ -625,10 +644,16 @@ def main():
     roof = None
     if dom[0]:
         pr = by_kernel[dom[0]]
+        longest = max(prof.items(), key=lambda kv: kv[1][0] / max(1, kv[1][1]))
+        lk = by_kernel.get(longest[0], {})
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": pr["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pr["frac"],
-                "traffic": pr["traffic"], "avg_launch_ms": pr["avg_launch_ms"], "algorithmic_bytes_per_launch": pr["algorithmic_bytes_per_launch"],
+                "traffic": pr["traffic"], "traffic_source": traffic_source(), "avg_launch_ms": pr["avg_launch_ms"],
+                "algorithmic_bytes_per_launch": pr["algorithmic_bytes_per_launch"],
                 "algorithmic_bytes_per_pair": pr["algorithmic_bytes_per_pair"],
                 "rule": "longest kernel of the k-mer build (the HBM-streaming kernels); all priced kernels in roofline_by_kernel",
+                "longest_kernel_overall": {"kernel": longest[0], "avg_launch_ms": round(longest[1][0] / max(1, longest[1][1]), 4),
+                                           "frac": lk.get("frac"), "achieved": lk.get("achieved"), "traffic": lk.get("traffic"),
+                                           "hbm_streaming": lk.get("hbm_streaming")},
                 "hot_path_frac": round(ab["total"] * args.pairs / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
     cpu = None
     cpu_port_legs = None

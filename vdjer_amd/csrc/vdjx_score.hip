@@ -1301,15 +1301,18 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	}
 	HIP_TRY(hipMemcpyAsync(out_valid, d_valid, n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
+	c->wp_cnt.resize(n);
+	HIP_TRY(hipMemcpyAsync(c->wp_cnt.data(), d_cnt, n * 4, hipMemcpyDeviceToHost, st));
 	vdjx_laps lp(c);
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
 	lp.mark("ws_cover_wait");
 	vdjx_prof_collect(c);
 	{
-		u64 tot = 0;
-		for (size_t i = 0; i < n; i++) tot += out_npairs[i];
-		c->stats["window_pairs"] = tot;
+		u64 tot = 0, ent = 0;
+		for (size_t i = 0; i < n; i++) { tot += out_npairs[i]; ent += c->wp_cnt[i]; }
+		c->stats["window_pairs"] = tot;                    // mapped pairs (with multiplicity)
+		c->stats["window_pairs_entries"] = ent;            // entries of the weighted lists
 	}
 	return VDJX_OK;
 }
