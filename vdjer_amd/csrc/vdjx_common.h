@@ -265,10 +265,20 @@ __host__ __device__ inline void vdjx_kmer_at(u64 bhi, u64 blo, int rl, int k, in
 	klo = (u64) v;
 }
 
-// the same for an offset that differs from lane to lane, written without a single per-lane select: the 128-bit shift by a VGPR
-// amount compiles to v_cmp (mask into an SGPR pair) + v_cndmask, and with shift amounts on both sides of 64 in one wave the
-// k-mers of a few lanes in ten thousand came out wrong on gfx950 (ROCm 7.0.2), depending on timing -- reads of more than 32
-// offsets only, because only there 2*(rl-k-o) reaches 64.  Masks and double shifts instead.
+// LDS written by one lane of a wave and read by another without a workgroup barrier (the dense listings): the hardware keeps a
+// wave's LDS operations in order, this keeps the COMPILER from moving or caching them across the hand-over
+__device__ inline void vdjx_wave_lds_fence() {
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+// the same for an offset that differs from lane to lane, written with masks and double shifts only.  Round 2 blamed the plain
+// 128-bit shift by a per-lane amount (v_cmp into an SGPR pair + v_cndmask) for a few wrong k-mers in ten thousand when a wave's
+// amounts lay on both sides of 64 (reads of more than 32 offsets).  The standalone reproducer (tests/test_gpu_platform.py) does NOT
+// show it: 5 x 4 M random shifts, 0 mismatches on this stack -- so that diagnosis stands unconfirmed, and the likelier cause is the
+// dense listing it was found in handing LDS data from lane to lane without telling the compiler (vdjx_wave_lds_fence, added in
+// round 3).  This form is kept: it is what the randomised differential tests (tests/test_gpu_fuzz.py) have been green with, and it
+// costs nothing over the shift.
 __device__ inline void vdjx_kmer_at_lane(u64 bhi, u64 blo, int rl, int k, int o, u64& khi, u64& klo) {
 	const u32 sh = (u32) (2 * (rl - k - o));               // 0 .. 126
 	const u64 big = 0ull - (u64) (sh >> 6);                 // all ones: shift by 64 or more

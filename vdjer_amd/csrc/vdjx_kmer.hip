@@ -278,6 +278,7 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 			if (!total) continue;                                     // (wave-uniform)
 			u32 at = incl - c;
 			for (u32 gg = g; gg; gg &= gg - 1) wl[at++] = (uint16_t) ((lane << (LONG ? 8 : 6)) | (u32) (ob + __builtin_ctz(gg)));
+			vdjx_wave_lds_fence();                                    // the list and the records are read by OTHER lanes of the wave
 			for (u32 i = lane; i < total; i += 64) {
 				const u32 e = wl[i];
 				u64 khi, klo;
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 				}
 				atomicAdd(&hist[(u32) (vdjx_mix(klo, khi) >> (64 - nb_bits))], 1u);
 			}
+			vdjx_wave_lds_fence();                                    // ... before the next 16 offsets overwrite the list
 		}
 	}
 	__syncthreads();
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 				if (!total) continue;                                     // (wave-uniform)
 				u32 at = incl - c;
 				for (u32 gg = g; gg; gg &= gg - 1) wl[at++] = (uint16_t) ((lane << OB) | (u32) (ob + __builtin_ctz(gg)));
+				vdjx_wave_lds_fence();                                    // (see k_gated_hist)
 				u32 dbase = 0;
 				if (lane == 0) dbase = atomicAdd(&s_n, total);
 				dbase = (u32) __builtin_amdgcn_readlane((int) dbase, 0);
@@ -365,6 +368,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 					atomicAdd(&cnt[b], 1u);
 					if (dbase + i < ROUND) desc[dbase + i] = ((loc0 + (e >> OB)) << (OB + 10)) | ((e & ((1u << OB) - 1u)) << 10) | b;
 				}
+				vdjx_wave_lds_fence();
 			}
 		}
 		__syncthreads();

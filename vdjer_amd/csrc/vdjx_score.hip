@@ -627,17 +627,17 @@ __global__ __launch_bounds__(1024) void k_plan(const u32* __restrict__ hits, con
 	}
 	__syncthreads();
 	const u32 chunk = s_chunk;
-	// order: one block scan per bit length, longest first (stable inside a bucket: deterministic)
+	// order: by descending bit length of the hit count (33 buckets; inside a bucket any order serves: the order only decides which
+	// workgroup starts first, never a result)
 	if (sorted) {
-		u32 base = 0;
-		for (int bl = 32; bl >= 0; bl--) {
-			u32 c = 0;
-			for (u32 i = lo; i < hi; i++) { const u32 h = hits[i]; c += (h ? 32 - __clz(h) : 0) == bl; }
-			u32 tot;
-			u32 at = base + plan_block_scan(c, tmp, tot);
-			if (c) for (u32 i = lo; i < hi; i++) { const u32 h = hits[i]; if ((h ? 32 - __clz(h) : 0) == bl) order[at++] = i; }
-			base += tot;
-		}
+		__shared__ u32 bcnt[33], bcur[33];
+		if (tid < 33) bcnt[tid] = 0;
+		__syncthreads();
+		for (u32 i = lo; i < hi; i++) { const u32 h = hits[i]; atomicAdd(&bcnt[32 - (h ? 32 - __clz(h) : 0)], 1u); }
+		__syncthreads();
+		if (tid == 0) { u32 run = 0; for (int b = 0; b < 33; b++) { bcur[b] = run; run += bcnt[b]; } }
+		__syncthreads();
+		for (u32 i = lo; i < hi; i++) { const u32 h = hits[i]; order[atomicAdd(&bcur[32 - (h ? 32 - __clz(h) : 0)], 1u)] = i; }
 		__threadfence_block();
 		__syncthreads();
 	} else
@@ -715,6 +715,7 @@ __global__ __launch_bounds__(MAP_THREADS, 8) void k_window_pairs(ReadIndexDev ix
 	u32 qn = 0, mine = 0;                               // (qn: wave-uniform)
 	// the queued entries, 64 at a time with every lane busy: the full test and the pairs out
 	auto drain = [&]() {
+		vdjx_wave_lds_fence();                          // (the queue was written by other lanes of the wave)
 		for (u32 q0 = 0; q0 < qn; q0 += 64) {
 			const u32 qi = q0 + (u32) lane;
 			bool pr = false;
@@ -736,6 +737,7 @@ __global__ __launch_bounds__(MAP_THREADS, 8) void k_window_pairs(ReadIndexDev ix
 				}
 			}
 		}
+		vdjx_wave_lds_fence();
 		qn = 0;
 	};
 	// The hits of the slice are one flat sequence (offset-major); a wave takes WP_K rows of 64 consecutive hits per round: WP_K
@@ -1010,6 +1012,7 @@ __global__ __launch_bounds__(MAP_THREADS, 6) void k_map_emit(ReadIndexDev ix, co
 	const u32 h1 = w0 + slice_hits < H ? w0 + slice_hits : H;
 	u32 qn = 0;
 	auto drain = [&]() {
+		vdjx_wave_lds_fence();                          // (the queue was written by other lanes of the wave)
 		for (u32 q0 = 0; q0 < qn; q0 += 64) {
 			const u32 qi = q0 + (u32) lane;
 			bool pr = false;
@@ -1038,6 +1041,7 @@ __global__ __launch_bounds__(MAP_THREADS, 6) void k_map_emit(ReadIndexDev ix, co
 				atomicOr(&bits[(h - w0) >> 5], 1u << ((h - w0) & 31));
 			}
 		}
+		vdjx_wave_lds_fence();
 		qn = 0;
 	};
 	if (w0 < h1) for (;;) {
