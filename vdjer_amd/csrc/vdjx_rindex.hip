@@ -2,8 +2,9 @@
 //
 // replaces add_read_info (quick_map3.c:126-149): a map "read sequence -> its instances in registration order", filled once per
 // record by extract (bam_read.c:228,243).  What the mapper kernels (vdjx_score.hip) read:
-//   tab[]            open-addressing table over the distinct read sequences (classes), 32-byte slots {sequence, class + 1}: a
-//                    lookup is ONE line fill (the build's own table names records and is dropped)
+//   tab[]            open-addressing table over the distinct read sequences (classes), 48-byte slots {sequence, class + 1, members,
+//                    CSR start, first weighted entry, weighted entries}: everything the classification of a window offset needs
+//                    in one probe (the build's own table names records and is dropped)
 //   start[cls]       CSR of the class's READ-1 members in registration order (read-2 instances only ever feed the "read2" map,
 //                    quick_map3.c:211-215, which the kernels replace by a class -> last offset table: they are not listed)
 //   recs[i], csr_pair[i], csr8[i]  record, pair id and the 8-byte entry of CSR member i
@@ -233,11 +234,12 @@ __global__ void k_ri_dstart(const u32* __restrict__ start, u32 ncls, const u32* 
 	if (c <= ncls) dstart[c] = epre[hpre[start[c]]];
 }
 
-// the lookup table the mapper reads: one slot per class {sequence (W words), class + 1}: W + 1 words rounded up to an even number
-// (32 bytes; 48 for reads of more than 64 bases)
+// the lookup table the mapper reads: one slot per class = the sequence (W words), then {class + 1 | read-1 members << 32}, {CSR start |
+// first weighted entry << 32}, {weighted entries}: W + 3 words rounded up to an even number (48 bytes; 64 for reads of more than 64 bases)
 template <int W>
-__global__ void k_ri_tab(const u32* __restrict__ rep, u32 ncls, const u64* __restrict__ bases, u64* __restrict__ tab, u32 mask) {
-	constexpr int SW = (W + 2) & ~1;
+__global__ void k_ri_tab(const u32* __restrict__ rep, u32 ncls, const u64* __restrict__ bases, const u32* __restrict__ cnt1, const u32* __restrict__ start,
+                         const u32* __restrict__ dstart, u64* __restrict__ tab, u32 mask) {
+	constexpr int SW = VDJX_RI_SLOT_WORDS(W);
 	const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= ncls) return;
 	u64 b[W];
@@ -245,8 +247,12 @@ __global__ void k_ri_tab(const u32* __restrict__ rep, u32 ncls, const u64* __res
 	for (int i = 0; i < W; i++) b[i] = bases[(size_t) rep[c] * W + i];
 	u32 slot = (u32) (ri_hash<W>(b) >> 17) & mask;
 	while (atomicCAS((u32*) &tab[(size_t) slot * SW + W], 0u, c + 1) != 0u) slot = (slot + 1) & mask;
+	u64* sl = tab + (size_t) slot * SW;
 #pragma unroll
-	for (int i = 0; i < W; i++) tab[(size_t) slot * SW + i] = b[i];
+	for (int i = 0; i < W; i++) sl[i] = b[i];
+	((u32*) &sl[W])[1] = cnt1[c];                         // (the low half was claimed by the CAS)
+	sl[W + 1] = (u64) start[c] | ((u64) dstart[c] << 32);
+	sl[W + 2] = (u64) (dstart[c + 1] - dstart[c]);
 }
 
 int sort_pairs(vdjx_work& db, hipStream_t st, u64* k_in, u64* k_out, u32* v_in, u32* v_out, u32 n, unsigned end_bit) {
@@ -302,7 +308,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	while ((size_t) tmask + 1 < (size_t) ncls * 2) tmask = tmask * 2 + 1;
 	u32* d_rep;
 	HIP_TRY(db.alloc(&d_rep, (size_t) ncls + 1));
-	const size_t slot_bytes = (size_t) ((pool->W + 2) & ~1) * 8;
+	const size_t slot_bytes = (size_t) (pool->W == 2 ? VDJX_RI_SLOT_WORDS(2) : VDJX_RI_SLOT_WORDS(VDJX_LONG_W)) * 8;
 	HIP_TRY(hipMalloc(&c->d_ri_tab, ((size_t) tmask + 1) * slot_bytes));
 	HIP_TRY(hipMalloc(&c->d_ri_start, ((size_t) ncls + 2) * 4));
 	HIP_TRY(hipMalloc(&c->d_ri_cnt1, ((size_t) ncls + 2) * 4));
@@ -311,11 +317,6 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(hipMemsetAsync(c->d_ri_cnt1, 0, ((size_t) ncls + 2) * 4, st));
 	HIP_TRY(hipMemsetAsync(c->d_ri_tab, 0, ((size_t) tmask + 1) * slot_bytes, st));
 	hipLaunchKernelGGL(k_ri_number, dim3(nsb), b256, 0, st, d_slots, nslots, d_bpre, d_rep);
-	{
-		vdjx_prof_scope ps(c, "k_ri_tab");
-		if (pool->W == 2) hipLaunchKernelGGL(k_ri_tab<2>, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, (u64*) c->d_ri_tab, tmask);
-		else hipLaunchKernelGGL(k_ri_tab<VDJX_LONG_W>, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, (u64*) c->d_ri_tab, tmask);
-	}
 	// records: class, read-2 records of the pairs; read-1 members
 	u64 *d_keys, *d_keys_s;
 	u32 *d_vals, *d_vals_s;
@@ -384,6 +385,11 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	} else {
 		HIP_TRY(hipMalloc(&c->d_ri_d8, 8));
 		HIP_TRY(hipMemsetAsync(c->d_ri_dstart, 0, ((size_t) ncls + 2) * 4, st));
+	}
+	{	// the mapper's table, now that the classes' sizes and starts are known
+		vdjx_prof_scope ps(c, "k_ri_tab");
+		if (pool->W == 2) hipLaunchKernelGGL(k_ri_tab<2>, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, c->d_ri_cnt1, c->d_ri_start, c->d_ri_dstart, (u64*) c->d_ri_tab, tmask);
+		else hipLaunchKernelGGL(k_ri_tab<VDJX_LONG_W>, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, c->d_ri_cnt1, c->d_ri_start, c->d_ri_dstart, (u64*) c->d_ri_tab, tmask);
 	}
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());

@@ -354,7 +354,7 @@ extern "C" int vdjx_root_score_graph(vdjx_ctx* c, const vdjx_graph* g, int thres
 #define MAP_PRESENT_WORDS (1u << (MAP_PRESENT_LOG2 - 5))
 
 struct ReadIndexDev {                             // vdjx_rindex.hip
-	const u64* tab; u32 mask;                     // per slot: the read sequence (W words), then class + 1; W + 1 words rounded up to even
+	const u64* tab; u32 mask;                     // per slot: the read sequence (W words), then the class's data (k_ri_tab, vdjx_rindex.hip)
 	const u32* start; const u32* cnt1; const u32* recs;
 	const u64* csr8; const u32* csr_pair; const u32* pair_r2;     // per CSR member: 8-byte entry, pair id; per pair: its read-2 records
 	const u32* dstart; const u64* d8;             // distinct read-1 entries per class with multiplicities (window scoring)
@@ -386,38 +386,56 @@ __device__ inline u32 map_present_bit(u32 cls) { return cls & ((1u << MAP_PRESEN
 template <int W>
 __global__ __launch_bounds__(MAP_THREADS) void k_map_classify(ReadIndexDev ix, const char* __restrict__ strings, u32 n, int len, bool weighted,
                                                               uint4* __restrict__ prep, u32* __restrict__ out_hits, u32* __restrict__ out_inst) {
-	__shared__ char txt[MAP_MAXOFF + VDJX_MAX_READ_LEN + 16];
+	constexpr int TXT = MAP_MAXOFF + VDJX_MAX_READ_LEN;
+	__shared__ u64 wimg[TXT / 32 + 8];                      // the string as 2-bit codes, 32 bases per word, first base most significant
+	__shared__ u64 bimg[TXT / 64 + 4];                      // bit i: character i is not ACGT
 	__shared__ u32 s_h[MAP_THREADS / 64], s_i[MAP_THREADS / 64];
-	constexpr int SW = (W + 2) & ~1;
+	constexpr int SW = VDJX_RI_SLOT_WORDS(W);
 	const int rl = ix.rl, noff = len - rl;
 	const u32 tid = threadIdx.x;
 	for (u32 wi = blockIdx.x; wi < n; wi += gridDim.x) {
 		const char* w = strings + (size_t) wi * len;
-		for (int i = tid; i < len; i += MAP_THREADS) txt[i] = w[i];
+		for (u32 i = tid; i < TXT / 32 + 8; i += MAP_THREADS) wimg[i] = 0;
+		for (u32 i = tid; i < TXT / 64 + 4; i += MAP_THREADS) bimg[i] = 0;
+		__syncthreads();
+		// every character once: its code into the word image (a per-offset loop over rl characters did this 436 times over)
+		for (int i = tid; i < len; i += MAP_THREADS) {
+			const int cde = base_code(w[i]);
+			if (cde < 0) atomicOr((unsigned long long*) &bimg[i >> 6], 1ull << (i & 63));
+			else if (cde) atomicOr((unsigned long long*) &wimg[i >> 5], (unsigned long long) cde << (62 - 2 * (i & 31)));
+		}
 		__syncthreads();
 		u32 hs = 0, is = 0;
 		for (int o = tid; o < noff; o += MAP_THREADS) {
-			// the read-length string at the offset in the pool's record format (vdjx_pool)
-			u64 key[W];
+			// any character of [o, o + rl) that is not ACGT?
 			bool ok = true;
-			if (W == 2) {
-				u128 b = 0;
-				for (int j = 0; j < rl; j++) {
-					const int cde = base_code(txt[o + j]);
-					if (cde < 0) ok = false;
-					b = (b << 2) | (u32) (cde & 3);
-				}
-				key[0] = (u64) (b >> 64); key[1] = (u64) b;
-			} else {
+			for (int a = 0; a < rl; a += 64) {
+				const int i = (o + a) >> 6;
+				const u32 sh = (u32) (o + a) & 63u;
+				u64 m = (bimg[i] >> sh) | ((bimg[i + 1] << 1) << (63u - sh));
+				if (rl - a < 64) m &= (1ull << (rl - a)) - 1ull;
+				if (m) ok = false;
+			}
+			// the read-length string at the offset in the pool's record format (vdjx_pool): the words from base o on
+			u64 key[W];
+			{
+				const int wi0 = o >> 5;
+				const u32 s2 = 2u * ((u32) o & 31u);
+				if (W == 2) {                       // right-aligned 2*rl-bit integer in (hi, lo)
+					const u64 x0 = wimg[wi0], x1 = wimg[wi0 + 1], x2 = wimg[wi0 + 2];
+					const u64 hi = (x0 << s2) | ((x1 >> 1) >> (63u - s2)), lo = (x1 << s2) | ((x2 >> 1) >> (63u - s2));
+					const u32 r = 128u - 2u * (u32) rl;                  // 0 .. 126 (uniform)
+					if (r >= 64u) { key[1] = hi >> (r - 64u); key[0] = 0; }
+					else if (r) { key[1] = (lo >> r) | (hi << (64u - r)); key[0] = hi >> r; }
+					else { key[1] = lo; key[0] = hi; }
+				} else {                            // W words, left-aligned, nothing behind base rl
 #pragma unroll
-				for (int q = 0; q < W; q++) {
-					u64 x = 0;
-					for (int j = 32 * q; j < 32 * q + 32; j++) {
-						int cde = 0;
-						if (j < rl) { cde = base_code(txt[o + j]); if (cde < 0) ok = false; }
-						x = (x << 2) | (u32) (cde & 3);
+					for (int q = 0; q < W; q++) {
+						u64 x = (wimg[wi0 + q] << s2) | ((wimg[wi0 + q + 1] >> 1) >> (63u - s2));
+						const int left = 2 * rl - 64 * q;                // bits of this word that belong to the read
+						if (left <= 0) x = 0; else if (left < 64) x &= ~0ull << (64 - left);
+						key[q] = x;
 					}
-					key[q] = x;
 				}
 			}
 			u32 cls = NONE32, cs = 0, sz = 0, inst = 0;
@@ -425,19 +443,20 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_classify(ReadIndexDev ix, c
 				u32 slot = (u32) (ri_hash<W>(key) >> 17) & ix.mask;
 				for (;;) {
 					const u64* sl = ix.tab + (size_t) slot * SW;
-					const u32 c1 = (u32) sl[W];
-					if (!c1) break;
+					const u64 cw = sl[W];
+					if (!(u32) cw) break;
 					u64 d = 0;
 #pragma unroll
 					for (int q = 0; q < W; q++) d |= sl[q] ^ key[q];
-					if (!d) { cls = c1 - 1; break; }
+					if (!d) {
+						const u64 a = sl[W + 1];
+						cls = (u32) cw - 1; inst = (u32) (cw >> 32);
+						if (weighted) { cs = (u32) (a >> 32); sz = (u32) sl[W + 2]; }
+						else { cs = (u32) a; sz = inst; }
+						break;
+					}
 					slot = (slot + 1) & ix.mask;
 				}
-			}
-			if (cls != NONE32) {
-				inst = ix.cnt1[cls];
-				if (weighted) { cs = ix.dstart[cls]; sz = ix.dstart[cls + 1] - cs; }
-				else { cs = ix.start[cls]; sz = inst; }
 			}
 			prep[(size_t) wi * noff + o] = make_uint4(cls, cs, sz, inst);
 			hs += sz; is += inst;
