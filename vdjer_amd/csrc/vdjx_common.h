@@ -401,6 +401,13 @@ __device__ inline int vdjx_wave_scan_add(int v) {
 	return v;
 }
 
+// A read / write of a word other lanes are changing (LDS tables): a relaxed atomic access of workgroup scope.  NOT `volatile`: the
+// address-space inference of the compiler leaves volatile accesses alone, so a volatile access through a pointer that went through
+// a function parameter stays a FLAT one with system-scope cache bits -- flat_load_dword ... sc0 sc1 and a wait on both the vector
+// memory and the LDS counter, instead of one ds_read (round 3: 50 of them in k_gated_reduce's sweeps).
+template <typename T> __device__ inline T vdjx_peek(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <typename T> __device__ inline void vdjx_poke(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 // cnt[idx] += 1 and mn[idx] = min(mn[idx], val) on LDS arrays for the lanes with `active`.  Hot k-mers put most lanes of a wave on
 // ONE address: the lanes that share the first active lane's index are combined into one add and one min; the others go one by one.
 __device__ inline void vdjx_lds_count_min(u32* cnt, u32* mn, u32 idx, u32 val, bool active) {

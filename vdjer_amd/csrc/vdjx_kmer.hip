@@ -140,19 +140,19 @@ __device__ inline int lds_insert(u64* s_klo, THI* s_khi, u64 lo, THI hi, u32 h) 
 	u32 slot = h & (SLOTS - 1);
 	u32 probes = 0;
 	while (probes < SLOTS) {
-		THI cur = *(volatile THI*) &s_khi[slot];
+		THI cur = vdjx_peek(&s_khi[slot]);
 		if (cur == EMPTY) {
 			THI old = atomicCAS(&s_khi[slot], EMPTY, LOCKED);
 			if (old == EMPTY) {
-				*(volatile u64*) &s_klo[slot] = lo;
+				vdjx_poke(&s_klo[slot], lo);
 				__threadfence_block();
-				*(volatile THI*) &s_khi[slot] = hi;             // publish
+				vdjx_poke(&s_khi[slot], hi);                    // publish
 				return (int) slot;
 			}
 			cur = old;
 		}
 		if (cur == LOCKED) continue;                            // another lane is writing this slot: look again
-		if (cur == hi && *(volatile u64*) &s_klo[slot] == lo) return (int) slot;
+		if (cur == hi && vdjx_peek(&s_klo[slot]) == lo) return (int) slot;
 		slot = (slot + 1) & (SLOTS - 1);
 		probes++;
 	}
@@ -483,27 +483,40 @@ __global__ __launch_bounds__(512) void k_seg_hist_g(const TUP* __restrict__ in, 
 
 // ----------------------------------------------------------------------------------------------
 // K3': table + prune of one bucket in one kernel (add_to_table A2:322-367, prune_pre_graph A2:467-484).
-//   sweep 1: LDS table over the bucket's (gated) tuples: count + first instance per distinct k-mer
+//   sweep 1: LDS table over the bucket's (gated) tuples: count + first instance per distinct k-mer.  The distinct-read flag
+//            (compare_read, A2:142-144, 349-352: "some instance's read differs from the first instance's") is the same as "two of
+//            its reads differ", so ANY earlier instance proves it: a k-mer that sits at two different offsets of two records
+//            and lacks the period of that distance cannot come from equal reads -- tested against whatever instance the table
+//            holds at that moment, without a fetch.  A tuple that finds its k-mer proven and already TLOW instances deep is
+//            SETTLED: nothing about it can matter any more (the count only grows; qualities are summed for counts below
+//            TLOW only).  In a deep clone that is nearly every tuple.  The others are listed (tuple index, slot) in LDS.
 //   candidates: count >= max(mf, 2)
-//   sweep 2 (tuples still in registers when the bucket is one chunk): distinct-read flag (compare_read, A2:142-144, 349-352: the
-//            instance's record against the first instance's record, N masks included: two 16-byte gathers, skipped once the
-//            flag is set) and the list of the instances whose qualities will be needed
-//   quality sums only for candidates with count < TLOW (see k_bucket_finalize), then the survivors are appended
+//   sweep 2, over the listed tuples only, all lanes busy: the exact rule for candidates still open (this instance's record
+//            against the first instance's, N masks included: two 16-byte gathers) and the instances of the low-count candidates
+//   quality sums: one WAVE per low-count candidate, one lane per position of the k-mer, a byte per instance and lane
+//   then the survivors are appended
+// (Round 2 kept the tuples in registers across both sweeps and visited every one twice; buckets of more than 4,096 tuples -- half
+//  of all tuples of a Zipf repertoire sit in them -- read, hashed and looked theirs up again.  profiles/README.md, round 3.)
 // ----------------------------------------------------------------------------------------------
-#define RD_THREADS 512
-#define RD_UNR 8
-#define RD_SLOTS 2048u               // ~1,000 distinct gated k-mers per bucket of ~3,000 tuples (most are read once): half full
-#define RD_Q 512u                  // remembered instances of low-count candidates (more: the quality rounds rescan the bucket)
-#define RD_A 64u                    // quality-sum rows per round
+#ifndef RD_THREADS                  // measured at 10 M pairs (threads / tuples per lane in flight / waves per SIMD): 512/8/4 1.90 ms, 1024/4/8 1.77,
+#define RD_THREADS 768              // 1024/2/8 1.72, 768/4/6 1.63: two workgroups per CU (LDS), six waves per SIMD at 80 registers
+#define RD_UNR 4
+#define RD_WAVES 6
+#endif
+#define RD_SLOTS 2048u               // ~1,000 distinct gated k-mers per bucket (most are read once): half full
+#define RD_SLOT_BITS 11
+#define RD_PQ 4096u                 // listed tuples (more: sweep 2 rescans the bucket)
+#define RD_LI 512u                  // remembered instances of low-count candidates per round
+#define RD_LROWS 128u               // low-count candidates per round
+#define RD_MAXLOW 11u               // instances of a low-count candidate: fewer than TLOW <= 1 + (214 + 19) / 20
 #define ST_CAND 1u
 #define ST_MULTI 2u
 #define ST_QOK 4u
-#define NONE16 0xFFFFu
+#define ST_ID_SHIFT 8               // s_state: flags below, low-count row / survivor position above
+#define ST_NOID 0xFFFFFFu
 
 struct SurvOutG { u64* lo; u64* hi; u32* gcnt; u64* gfirst; u32* n; u32 cap; };
 
-// one gated instance's k qualities added to its k-mer's row of packed u16 sums (A2:337-339, 354-361): the qualities from position
-// qoff of the record's row on (qoff = 0 for the first instance: the RECORD's first k qualities, the load-bearing bug)
 // compare_read (A2:142-144): the two records' sequences, not-ACGT masks included
 __device__ inline bool reads_equal(const u64* __restrict__ bases, const u64* __restrict__ nmask, int rl, u64 a, u64 b) {
 	if (rl <= VDJX_SHORT_READ_LEN) {
@@ -519,47 +532,57 @@ __device__ inline bool reads_equal(const u64* __restrict__ bases, const u64* __r
 	return d == 0;
 }
 
-__device__ inline void rd_add_qualities(u32* row, const uint8_t* __restrict__ qrow, int rl, u32 qoff, int k) {
-	if (rl > VDJX_SHORT_READ_LEN) {                            // long reads: the plain form (rows of up to 160 characters; a rare path)
-		for (int j = 0; j < k; j++) atomicAdd(&row[j >> 1], (u32) (uint8_t) (qrow[qoff + (u32) j] - 33u) << (16 * (j & 1)));
-		return;
-	}
-	// the row may start at any byte (quality characters inside resident ASCII records): aligned words, funnelled; a word is only
-	// fetched if it holds a character of the row (never past the end of the caller's buffer)
-	const u32 sh = (u32) ((uintptr_t) qrow & 3u);
-	const u32* qw = (const u32*) (qrow - sh);
-	const u32 need = (sh + (u32) rl + 3u) / 4u;                       // words holding the row
-	u32 d[17], w[16];
-#pragma unroll
-	for (int i = 0; i < 17; i++) d[i] = (u32) i < need ? qw[i] : 0x21212121u;
-#pragma unroll
-	for (int i = 0; i < 16; i++) w[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
-#pragma unroll
-	for (int pq = 0; pq < 64; pq++) {
-		const int j = pq - (int) qoff;
-		if (j >= 0 && j < k) {
-			const u32 v = (uint8_t) (((w[pq >> 2] >> (8 * (pq & 3))) & 0xFFu) - 33u);
-			atomicAdd(&row[j >> 1], v << (16 * (j & 1)));
+// the table's own hash: the bucket has used up the leading bits of vdjx_mix, and inside a bucket 11 bits of ANY decent mix of the key
+// do (three 32-bit multiplications instead of the nine of vdjx_mix: the multiplier runs at a quarter of the ALU rate)
+__device__ inline u32 rd_hash(u64 lo, u64 hi) {
+	u32 x = (u32) lo ^ ((u32) (lo >> 32) * 0x9E3779B1u) ^ (((u32) hi ^ (u32) (hi >> 32) * 0x27D4EB2Fu) * 0x85EBCA6Bu);
+	x ^= x >> 15; x *= 0xC2B2AE35u; x ^= x >> 13;
+	return x;
+}
+
+// cnt[idx] += 1, mn[idx] = min(mn[idx], val) for the lanes with `active`, and how many instances the slot had counted before this
+// lane's (lanes of a wave that share the first active lane's slot are folded into one add and one min: vdjx_lds_count_min64)
+__device__ inline u32 rd_count_min(u32* cnt, u64* mn, u32 idx, u64 val, bool active) {
+	u32 c0 = 0;
+	const u64 act = __ballot(active);
+	if (act) {
+		const int leader = __ffsll((long long) act) - 1;
+		const u32 lidx = (u32) __builtin_amdgcn_readlane((int) idx, leader);
+		const bool same = active && idx == lidx;
+		const u64 m = __ballot(same);
+		if (__popcll(m) >= 8) {
+			const u32 hi_min = vdjx_wave_min(same ? (u32) (val >> 32) : 0xFFFFFFFFu);
+			const u32 lo_min = vdjx_wave_min(same && (u32) (val >> 32) == hi_min ? (u32) val : 0xFFFFFFFFu);
+			u32 old = 0;
+			if (__lane_id() == leader) {
+				old = atomicAdd(&cnt[lidx], (u32) __popcll(m));
+				atomicMin((unsigned long long*) &mn[lidx], ((unsigned long long) hi_min << 32) | lo_min);
+			}
+			old = (u32) __builtin_amdgcn_readlane((int) old, leader);
+			if (same) c0 = old + (u32) __popcll(m & ((1ull << __lane_id()) - 1ull));
+			active = active && !same;
 		}
 	}
+	if (active) { c0 = atomicAdd(&cnt[idx], 1u); atomicMin((unsigned long long*) &mn[idx], (unsigned long long) val); }
+	return c0;
 }
 
 template <typename TUP>
-__global__ __launch_bounds__(RD_THREADS, 4) void k_gated_reduce(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
+__global__ __launch_bounds__(RD_THREADS, RD_WAVES) void k_gated_reduce(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
                                                              const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                              vdjx_qrows quals, int rl, int ob, int k, u64 rec_base,
                                                              u32 mf, u32 cmin, u32 mqq, u32 tlow, SurvOutG so,
-                                                             u64* __restrict__ g_distinct, u32* __restrict__ g_err) {
+                                                             u64* __restrict__ g_distinct, u32* __restrict__ g_err, u32 dbg) {
 	typedef typename TUP::hi_t THI;
 	__shared__ u64 s_klo[RD_SLOTS];
 	__shared__ THI s_khi[RD_SLOTS];
 	__shared__ u64 s_first[RD_SLOTS];
-	__shared__ u32 s_cnt[RD_SLOTS], s_state[RD_SLOTS];        // s_state: ST_* flags in the top bits, low-count row / survivor position below
-	__shared__ unsigned short s_lowid[RD_SLOTS];
-	__shared__ u32 acc[RD_A * K3B_KW];
-	__shared__ u32 q_slot[RD_Q];
-	__shared__ u64 q_inst[RD_Q];
-	__shared__ u32 s_over, s_ndist, s_nlow, s_nq, s_nsurv, s_base;
+	__shared__ u32 s_cnt[RD_SLOTS], s_state[RD_SLOTS];
+	__shared__ u32 pq[RD_PQ];                                   // tuple index << RD_SLOT_BITS | slot
+	__shared__ u64 low_inst[RD_LI];
+	__shared__ u32 low_n[RD_LROWS];
+	__shared__ unsigned short low_slot[RD_LROWS];
+	__shared__ u32 s_over, s_ndist, s_nlow, s_npq, s_nsurv, s_base;
 	const THI EMPTY = (THI) ~(THI) 0;
 	const u32 b = blockIdx.x;
 	const u32 base = bucket_start[b];
@@ -567,7 +590,9 @@ __global__ __launch_bounds__(RD_THREADS, 4) void k_gated_reduce(const TUP* __res
 	const u32 tid = threadIdx.x;
 	if (n == 0) return;
 	const TUP* T = tup + base;
-	const u32 KW = (u32) (k + 1) / 2;
+	const u32 om = (1u << ob) - 1u;
+	const u32 per_low = tlow > 1 ? (tlow - 1 < RD_MAXLOW ? tlow - 1 : RD_MAXLOW) : 1;       // a low-count candidate has fewer than tlow instances
+	const u32 lrows = RD_LI / per_low < RD_LROWS ? RD_LI / per_low : RD_LROWS;
 	u32 S = 1;
 	while ((u64) S * K3_SUB_TUPLES < n) S <<= 1;
 	u32 ndist_total = 0;
@@ -579,145 +604,129 @@ __global__ __launch_bounds__(RD_THREADS, 4) void k_gated_reduce(const TUP* __res
 		if (tid == 0) { s_over = 0; s_ndist = 0; }
 		__syncthreads();
 		for (u32 s = 0; s < S; s++) {
-			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) { s_khi[i] = EMPTY; s_cnt[i] = 0; s_first[i] = NONE64; s_state[i] = 0; s_lowid[i] = NONE16; }
-			if (tid == 0) { s_nlow = 0; s_nq = 0; s_nsurv = 0; }
+			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) { s_khi[i] = EMPTY; s_cnt[i] = 0; s_first[i] = NONE64; s_state[i] = 0; }
+			if (tid == 0) { s_nlow = 0; s_npq = n >> (32 - RD_SLOT_BITS) ? RD_PQ + 1 : 0; s_nsurv = 0; }     // (an index that does not fit an entry: rescan)
 			__syncthreads();
-			const bool one_chunk = n <= RD_UNR * RD_THREADS;
-			TUP r_t[RD_UNR];
-			int r_slot[RD_UNR];
 			// ---- sweep 1
 			for (u32 t0 = 0; t0 < n; t0 += RD_UNR * RD_THREADS) {
+				TUP r_t[RD_UNR];
 #pragma unroll
 				for (int j = 0; j < RD_UNR; j++) {
 					const u32 t = t0 + j * RD_THREADS + tid;
-					r_slot[j] = -2;
-					if (t < n) { r_t[j] = TUP::load(&T[t]); r_slot[j] = -1; }
+					if (t < n) r_t[j] = TUP::load(&T[t]);
 				}
 #pragma unroll
 				for (int j = 0; j < RD_UNR; j++) {
 					// (no lane leaves the body early: the count / first update folds the lanes of a wave that hit one slot -- a deep
 					// clone's k-mer holds most tuples of its bucket, and same-address LDS atomics go one at a time)
+					const u32 t = t0 + j * RD_THREADS + tid;
 					int slot = -1;
-					if (r_slot[j] != -2) {
-						const u64 h = vdjx_mix(r_t[j].lo, r_t[j].hi());
-						if (!(S > 1 && (u32) ((h >> 12) & (S - 1)) != s)) {
-							slot = lds_insert<THI, RD_SLOTS>(s_klo, s_khi, r_t[j].lo, (THI) r_t[j].hi(), (u32) h);
+					if (t < n) {
+						const u32 h = rd_hash(r_t[j].lo, r_t[j].hi());
+						if (!(S > 1 && ((h >> 12) & (S - 1)) != s)) {
+							slot = lds_insert<THI, RD_SLOTS>(s_klo, s_khi, r_t[j].lo, (THI) r_t[j].hi(), h);
 							if (slot < 0) s_over = 1;
-							else r_slot[j] = slot;
 						}
 					}
-					vdjx_lds_count_min64(s_cnt, s_first, (u32) (slot < 0 ? 0 : slot), r_t[j].inst(), slot >= 0 && !verify);
+					const bool live = slot >= 0 && !verify;
+					const u64 inst = r_t[j].inst();
+					const u32 c0 = rd_count_min(s_cnt, s_first, (u32) (live ? slot : 0), inst, live);
+					bool list = false;
+					if (live) {
+						u32 st = vdjx_peek(&s_state[slot]);
+						if (!(st & ST_MULTI)) {
+							const u64 f = vdjx_peek(&s_first[slot]);                 // (some instance of this k-mer, at least this wave's earliest)
+							if (f != NONE64 && (f >> ob) != (inst >> ob)) {
+								const u32 o1 = (u32) inst & om, o0 = (u32) f & om;
+								const u32 d = o1 > o0 ? o1 - o0 : o0 - o1;
+								if (d && d < (u32) k && !vdjx_kmer_has_period(r_t[j].hi(), r_t[j].lo, k, d)) { atomicOr(&s_state[slot], ST_MULTI); st |= ST_MULTI; }
+							}
+						}
+						list = !((st & ST_MULTI) && c0 + 1 >= tlow);
+					}
+					const u32 qi = vdjx_wave_inc(&s_npq, list);
+					if (list && qi < RD_PQ) pq[qi] = (t << RD_SLOT_BITS) | (u32) slot;
 				}
 			}
 			__syncthreads();
 			if (s_over || verify) { if (s_over) break; continue; }
+			if (dbg == 1) return;
 			// ---- candidates (a k-mer seen once can never have two distinct reads, A2:349-352, 476)
 			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
 				if (s_khi[i] == EMPTY) continue;
 				atomicAdd(&s_ndist, 1u);
 				const u32 c = s_cnt[i];
-				if (c >= cmin) {
-					s_state[i] = ST_CAND;
-					if (c < tlow) s_lowid[i] = (unsigned short) atomicAdd(&s_nlow, 1u);
-				}
+				if (c >= cmin) s_state[i] = (s_state[i] & ST_MULTI) | ST_CAND | ((c < tlow ? atomicAdd(&s_nlow, 1u) : ST_NOID) << ST_ID_SHIFT);
 			}
 			__syncthreads();
-			// ---- sweep 2, per chunk: (a) what settles without a fetch -- a k-mer that sits at two different offsets of two reads and
-			// lacks the period of that distance proves the reads different (compare_read, A2:142-144, 349-352) -- and the quality rows;
-			// (b) after a barrier, only for k-mers that are still open: this instance's record against the first instance's (two
-			// 16-byte gathers).  Deep clones hold hundreds of instances per k-mer, many at the first instance's own offset
-			// (duplicate reads): asked one by one in a single pass they all fetched, although a neighbour's instance at another
-			// offset settles the k-mer for free.
-			for (u32 t0 = 0; t0 < n; t0 += RD_UNR * RD_THREADS) {
-#pragma unroll
-				for (int j = 0; j < RD_UNR; j++) {
-					if (!one_chunk) {
-						const u32 t = t0 + j * RD_THREADS + tid;
-						r_slot[j] = -2;
-						if (t < n) {
-							r_t[j] = TUP::load(&T[t]);
-							const u64 h = vdjx_mix(r_t[j].lo, r_t[j].hi());
-							r_slot[j] = (S > 1 && (u32) ((h >> 12) & (S - 1)) != s) ? -1
-							            : lds_lookup<THI, RD_SLOTS>(s_klo, s_khi, r_t[j].lo, (THI) r_t[j].hi(), (u32) h);
-						}
+			// ---- sweep 2 over the listed tuples (or, if the list ran over, over the bucket): per round of low-count candidates their
+			// instances; in the first round the exact distinct-read rule for the candidates still open.  Then the quality sums of the
+			// round: first instance = the RECORD's first k qualities (A2:337-339, the load-bearing bug), the others their own
+			// (A2:354-361); a sum >= 214 reads as 255 (A2:356-360): the test is sum >= min(mq, 214)
+			const u32 nlow = s_nlow;
+			const bool listed = s_npq <= RD_PQ;
+			const u32 nscan = listed ? s_npq : n;
+			for (u32 l0 = 0; l0 == 0 || l0 < nlow; l0 += lrows) {
+				for (u32 i = tid; i < RD_LROWS; i += RD_THREADS) low_n[i] = 0;
+				__syncthreads();
+				for (u32 e = tid; e < nscan; e += RD_THREADS) {
+					u32 slot, t;
+					TUP x;
+					if (listed) {
+						slot = pq[e] & (RD_SLOTS - 1); t = pq[e] >> RD_SLOT_BITS;
+						if (!(vdjx_peek(&s_state[slot]) & ST_CAND)) continue;
+						x = TUP::load(&T[t]);
+					} else {
+						x = TUP::load(&T[e]);
+						const u32 h = rd_hash(x.lo, x.hi());
+						if (S > 1 && ((h >> 12) & (S - 1)) != s) continue;
+						const int sl = lds_lookup<THI, RD_SLOTS>(s_klo, s_khi, x.lo, (THI) x.hi(), h);
+						if (sl < 0) continue;
+						slot = (u32) sl;
 					}
-				}
-				u32 pend = 0;
-#pragma unroll
-				for (int j = 0; j < RD_UNR; j++) {
-					const int slot = r_slot[j];
-					if (slot < 0) continue;
-					const u32 st = *(volatile u32*) &s_state[slot];
+					const u32 st = vdjx_peek(&s_state[slot]);
 					if (!(st & ST_CAND)) continue;
-					const u64 inst = r_t[j].inst();
-					const u64 fi = s_first[slot];
-					const u32 lid = s_lowid[slot];
-					if (lid != NONE16) {
-						// (listed and summed afterwards by dense lanes: adding the row here, inside the sparse sweep, made every wave walk
-						// the 64-position loop for its one or two low-count instances: 2.4 -> 5.9 ms)
-						const u32 qi = atomicAdd(&s_nq, 1u);
-						if (qi < RD_Q) { q_slot[qi] = (u32) slot; q_inst[qi] = inst; }
+					const u64 inst = x.inst(), fi = s_first[slot];
+					const u32 lid = st >> ST_ID_SHIFT;
+					if (lid != ST_NOID && lid >= l0 && lid < l0 + lrows) {
+						const u32 pos = atomicAdd(&low_n[lid - l0], 1u);
+						if (pos < per_low) low_inst[(lid - l0) * per_low + pos] = inst;
+						low_slot[lid - l0] = (unsigned short) slot;
 					}
-					if (!(st & ST_MULTI) && (inst >> ob) != (fi >> ob)) {
-						const u32 om = (1u << ob) - 1u;
+					if (l0 == 0 && !(st & ST_MULTI) && (inst >> ob) != (fi >> ob)) {
 						const u32 o1 = (u32) inst & om, o0 = (u32) fi & om;
 						const u32 d = o1 > o0 ? o1 - o0 : o0 - o1;
-						if (d && d < (u32) k && !vdjx_kmer_has_period(r_t[j].hi(), r_t[j].lo, k, d)) atomicOr(&s_state[slot], ST_MULTI);
-						else pend |= 1u << j;
+						if ((d && d < (u32) k && !vdjx_kmer_has_period(x.hi(), x.lo, k, d))
+						    || !reads_equal(bases, nmask, rl, (inst >> ob) - rec_base, (fi >> ob) - rec_base)) atomicOr(&s_state[slot], ST_MULTI);
 					}
 				}
 				__syncthreads();
+				if (dbg == 4) return;
+				const u32 rows = nlow - l0 < lrows ? nlow - l0 : lrows;
+				const u32 lane = tid & 63u;
+				for (u32 r = tid >> 6; r < (nlow ? rows : 0u); r += RD_THREADS / 64) {
+					const u32 slot = low_slot[r], cnt = low_n[r];
+					const u64 fi = s_first[slot];
+					// (every instance's byte asked for before the first is added: the rows lie anywhere in the pool)
+					u32 qv[RD_MAXLOW];
 #pragma unroll
-				for (int j = 0; j < RD_UNR; j++) {
-					if (!((pend >> j) & 1u)) continue;
-					const int slot = r_slot[j];
-					if (*(volatile u32*) &s_state[slot] & ST_MULTI) continue;
-					const u64 rec = (r_t[j].inst() >> ob) - rec_base, frec = (s_first[slot] >> ob) - rec_base;
-					if (!reads_equal(bases, nmask, rl, rec, frec)) atomicOr(&s_state[slot], ST_MULTI);
-				}
-				if (!one_chunk) __syncthreads();             // (the next chunk reuses the registers only; the barrier keeps the chunks' phases apart)
-			}
-			__syncthreads();
-			// ---- quality sums of the low-count candidates: first instance = the RECORD's first k qualities (A2:337-339), the
-			// others their own (A2:354-361); a sum >= 214 reads as 255 (A2:356-360): the test is sum >= min(mq, 214)
-			const u32 nlow = s_nlow;
-			const bool listed = s_nq <= RD_Q;
-			for (u32 l0 = 0; l0 < nlow; l0 += RD_A) {
-				for (u32 i = tid; i < RD_A * K3B_KW; i += RD_THREADS) acc[i] = 0;
-				__syncthreads();
-				const u32 nscan = listed ? s_nq : n;
-				for (u32 t = tid; t < nscan; t += RD_THREADS) {
-					u32 slot;
-					u64 inst;
-					if (listed) { slot = q_slot[t]; inst = q_inst[t]; }
-					else {
-						const TUP x = TUP::load(&T[t]);
-						const u64 h = vdjx_mix(x.lo, x.hi());
-						if (S > 1 && (u32) ((h >> 12) & (S - 1)) != s) continue;
-						const int sl = lds_lookup<THI, RD_SLOTS>(s_klo, s_khi, x.lo, (THI) x.hi(), (u32) h);
-						if (sl < 0) continue;
-						slot = (u32) sl; inst = x.inst();
+					for (u32 i = 0; i < RD_MAXLOW; i++) {
+						qv[i] = 33u;
+						if (i < cnt && i < per_low) {
+							const u64 inst = low_inst[r * per_low + i];
+							const uint8_t* q = quals.row((inst >> ob) - rec_base) + (inst == fi ? 0u : (u32) inst & om);
+							if (lane < (u32) k) qv[i] = q[lane];
+						}
 					}
-					const u32 lid = s_lowid[slot];
-					if (lid == NONE16 || lid < l0 || lid >= l0 + RD_A) continue;
-					const u64 rec = (inst >> ob) - rec_base;
-					rd_add_qualities(acc + (lid - l0) * K3B_KW, quals.row(rec), rl, inst == s_first[slot] ? 0u : (u32) inst & ((1u << ob) - 1u), k);
-				}
-				__syncthreads();
-				for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
-					const u32 lid = s_lowid[i];
-					if (lid == NONE16 || lid < l0 || lid >= l0 + RD_A) continue;
-					const u32* row = acc + (lid - l0) * K3B_KW;
-					bool ok = true;
-					for (u32 w2 = 0; w2 < KW; w2++) {
-						const u32 v = row[w2];
-						if ((v & 0xFFFFu) < mqq) ok = false;
-						if (2 * w2 + 1 < (u32) k && (v >> 16) < mqq) ok = false;
-					}
-					if (ok) s_state[i] |= ST_QOK;
+					u32 sum = 0;
+#pragma unroll
+					for (u32 i = 0; i < RD_MAXLOW; i++) sum += (u32) (uint8_t) (qv[i] - 33u);
+					const bool lowq = lane < (u32) k && sum < mqq;
+					if (!__ballot(lowq) && lane == 0) atomicOr(&s_state[slot], ST_QOK);
 				}
 				__syncthreads();
 			}
+			if (dbg == 5) return;
 			// ---- prune_pre_graph (A2:467-484); the global survivor counter is bumped once per workgroup and sub-pass
 			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
 				const u32 st = s_state[i];
@@ -727,14 +736,14 @@ __global__ __launch_bounds__(RD_THREADS, 4) void k_gated_reduce(const TUP* __res
 					const u32 c = craw > 32765u ? 32765u : craw;                  // A2:345-347
 					keep = c >= mf && (st & ST_MULTI) && (craw >= tlow || (st & ST_QOK));
 				}
-				s_lowid[i] = keep ? (unsigned short) atomicAdd(&s_nsurv, 1u) : NONE16;            // (reused: position among this sub-pass's survivors)
+				s_state[i] = keep ? atomicAdd(&s_nsurv, 1u) : NONE32;                  // (reused: position among this sub-pass's survivors)
 			}
 			__syncthreads();
 			if (tid == 0) s_base = s_nsurv ? atomicAdd(so.n, s_nsurv) : 0;
 			__syncthreads();
 			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
-				if (s_lowid[i] == NONE16) continue;
-				const u32 pos = s_base + s_lowid[i];
+				if (s_state[i] == NONE32) continue;
+				const u32 pos = s_base + s_state[i];
 				if (pos < so.cap) {
 					so.lo[pos] = s_klo[i];
 					so.hi[pos] = (u64) s_khi[i];
@@ -860,7 +869,7 @@ __global__ __launch_bounds__(K3_THREADS) void k_gated_local(const TUP* __restric
 					if (slot < 0) continue;
 					const u64 inst = r_t[j].inst();
 					if (s_loff[slot] != NONE32) low_inst[base + s_loff[slot] + atomicAdd(&s_lfill[slot], 1u)] = inst;
-					if (s_cg[slot] < 2 || *(volatile u32*) &s_fl[slot]) continue;
+					if (s_cg[slot] < 2 || vdjx_peek(&s_fl[slot])) continue;
 					const u64 fi = s_mg[slot];
 					const u64 rec = (inst >> 6) - rec_base, frec = (fi >> 6) - rec_base;
 					if (rec != frec) {
@@ -1836,13 +1845,13 @@ __global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ 
 					rc_min(&mv[s1 + a + j], (IT) (inst + j + 15u - (a + j)));
 					if (j) {
 						IT* ep = &ef[(sl + j) * 4 + ((fw >> (2 * (a + j - 1))) & 3u)];
-						if (*(volatile IT*) ep > (IT) (inst + j)) rc_min(ep, (IT) (inst + j));
+						if (vdjx_peek(ep) > (IT) (inst + j)) rc_min(ep, (IT) (inst + j));
 					}
 				}
 			}
 			if (live && ((x >> 37) & 1ull)) {
 				IT* ep = &ef[sl * 4 + (u32) ((x >> 35) & 3ull)];
-				if (*(volatile IT*) ep > (IT) inst) rc_min(ep, (IT) inst);                  // first sights only ever decrease
+				if (vdjx_peek(ep) > (IT) inst) rc_min(ep, (IT) inst);                  // first sights only ever decrease
 			}
 		}
 	}
@@ -2230,10 +2239,11 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 	HIP_TRY(hipMemsetAsync(n_surv, 0, 4, st));
 	HIP_TRY(hipMemsetAsync(g_distinct, 0, 64 * 16 * 8, st));
 	SurvOutG so{sv->lo, sv->hi, sv->gcnt, sv->gfirst, n_surv, cap};
+	static const u32 rd_dbg = (u32) tune("VDJX_RD_DBG", 0);        // profiles/reducedbg.py: the kernel stops after a phase
 	if (t.N) {
 		vdjx_prof_scope ps(c, "k_gated_reduce");
 		hipLaunchKernelGGL(k_gated_reduce<TUP>, dim3(t.NB), dim3(RD_THREADS), 0, st, t.t, t.bucket_start, pv.bases, pv.nmask, pv.quals, pv.rl, pv.ob, k, rec_base,
-		                   mfu, cmin, mqq, tlow, so, g_distinct, g_err);
+		                   mfu, cmin, mqq, tlow, so, g_distinct, g_err, rd_dbg);
 	}
 	u64* spread = (u64*) c->h_pin;                    // [64 * 16], then ns, err
 	u32* tail = (u32*) (spread + 64 * 16);
