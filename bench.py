@@ -554,7 +554,7 @@ def main():
                     bad.append("mapped-pair stream")
                 checked += ["windows(all)", "mapped pairs(all)"]
             timed_check = {"case": case, "checked": checked, "ok": not bad, "differs": bad}
-            if bad:
+            if bad and not os.environ.get("VDJX_BENCH_ABLATION"):     # (kernel ablations under profiles/: wrong results on purpose; the line says ok: false)
                 raise SystemExit(f"parity gate failed: the timed step's {bad} differ from the oracle digests")
     # ---- the same step fed from the HOST (never `value`): the reads as extracted (one 101-byte record per read; the reverse
     # complement records are derived on the chip) in page-locked memory, uploaded in chunks beside the packing
@@ -595,6 +595,8 @@ def main():
     stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_hits_distinct", "window_pairs", "window_work_items", "map_hits", "root_dp_items", "recount_items", "recount_instances", "gated_instances")}
     stats["mapped_pairs"] = int(state["last"]["pairs"].shape[0]) if state.get("last") else 0
     stats["window_pairs_entries"] = ctx.stat("window_pairs_entries")
+    for n_ in ("group_hits_distinct", "group_overflows", "group_classes", "group_queued"):      # k_group_pairs: what the groups of windows shared
+        stats[n_] = ctx.stat(n_)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         cm.all_reduce(tt, dist.ReduceOp.MAX)

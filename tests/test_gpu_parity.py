@@ -755,3 +755,21 @@ def test_iupac_bases_are_counted_and_read_as_N(ctx):
         np.testing.assert_array_equal(getattr(g1, f), getattr(g2, f))
     p1.free()
     p2.free()
+
+
+def test_window_scorer_without_grouping_in_a_fresh_process():
+    """k_group_pairs takes groups of windows that share read classes; windows it leaves (unrelated ones, long ones) and every
+    window under VDJX_WINDOW_GROUP=0 go through k_window_pairs with its slices of deep windows.  The knob is read once per
+    process: the window-scorer tests of this file and of the randomised suite run again with grouping off."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.environ.get("VDJX_WINDOW_GROUP") == "0":
+        pytest.skip("already the ungrouped run")
+    env = dict(os.environ, VDJX_WINDOW_GROUP="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_fuzz.py"),
+                        "-m", "gpu", "-x", "-q", "-k", "window or scorers or deep_windows"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -389,6 +389,13 @@ __device__ inline u32 vdjx_wave_min(u32 v) {
 	return (u32) __builtin_amdgcn_readlane((int) v, 63);
 }
 
+// wave-wide maximum of a 64-bit value, in every lane (all 64 lanes active)
+__device__ inline u64 vdjx_wave_max64(u64 v) {
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) { const u64 t = (u64) __shfl_xor((unsigned long long) v, d, 64); v = t > v ? t : v; }
+	return v;
+}
+
 // wave-wide inclusive prefix sum through DPP (row shifts inside the rows of 16 lanes, then the two row broadcasts): all 64 lanes
 // must be active
 __device__ inline int vdjx_wave_scan_add(int v) {

@@ -419,6 +419,11 @@ int check_args(vdjx_ctx* c, const vdjx_pool* pool, const void* a, const void* b,
 }
 }  // namespace
 
+// (the scorers sort their strings with the same helper: vdjx_score.hip)
+int vdjx_sort_pairs(vdjx_work& db, hipStream_t st, u64* k_in, u64* k_out, u32* v_in, u32* v_out, u32 n, unsigned end_bit) {
+	return sort_pairs(db, st, k_in, k_out, v_in, v_out, n, end_bit);
+}
+
 extern "C" int vdjx_read_index_build_device(vdjx_ctx* c, const vdjx_pool* pool, const uint32_t* d_pair_id, const uint8_t* d_read_num,
                                             const uint8_t* d_is_rc, const uint32_t* d_reg_rank, uint32_t n_pairs) {
 	int rc = check_args(c, pool, d_pair_id, d_read_num, d_is_rc, d_reg_rank, "vdjx_read_index_build_device");

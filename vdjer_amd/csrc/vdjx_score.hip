@@ -385,11 +385,13 @@ __device__ inline u32 map_present_bit(u32 cls) { return cls & ((1u << MAP_PRESEN
 // One workgroup per string (looping), one thread per offset; the string is staged in LDS.
 template <int W>
 __global__ __launch_bounds__(MAP_THREADS) void k_map_classify(ReadIndexDev ix, const char* __restrict__ strings, u32 n, int len, bool weighted,
-                                                              uint4* __restrict__ prep, u32* __restrict__ out_hits, u32* __restrict__ out_inst) {
+                                                              uint4* __restrict__ prep, u32* __restrict__ out_hits, u32* __restrict__ out_inst,
+                                                              u64* __restrict__ out_gkey, u32* __restrict__ out_gidx) {
 	constexpr int TXT = MAP_MAXOFF + VDJX_MAX_READ_LEN;
 	__shared__ u64 wimg[TXT / 32 + 8];                      // the string as 2-bit codes, 32 bases per word, first base most significant
 	__shared__ u64 bimg[TXT / 64 + 4];                      // bit i: character i is not ACGT
 	__shared__ u32 s_h[MAP_THREADS / 64], s_i[MAP_THREADS / 64];
+	__shared__ u64 s_b1[MAP_THREADS / 64], s_b2[MAP_THREADS / 64];
 	constexpr int SW = VDJX_RI_SLOT_WORDS(W);
 	const int rl = ix.rl, noff = len - rl;
 	const u32 tid = threadIdx.x;
@@ -406,6 +408,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_classify(ReadIndexDev ix, c
 		}
 		__syncthreads();
 		u32 hs = 0, is = 0;
+		u64 b1 = 0, b2 = 0;                                    // deepest class of the string's first / second half: entries << 26 | ~class
 		for (int o = tid; o < noff; o += MAP_THREADS) {
 			// any character of [o, o + rl) that is not ACGT?
 			bool ok = true;
@@ -460,16 +463,31 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_classify(ReadIndexDev ix, c
 			}
 			prep[(size_t) wi * noff + o] = make_uint4(cls, cs, sz, inst);
 			hs += sz; is += inst;
+			if (sz) {
+				const u64 v = ((u64) sz << 26) | (u64) (RI_ENT_NONE - cls);
+				if (2 * o < noff) b1 = v > b1 ? v : b1; else b2 = v > b2 ? v : b2;
+			}
 		}
+		b1 = vdjx_wave_max64(b1); b2 = vdjx_wave_max64(b2);
 		hs = (u32) __builtin_amdgcn_readlane(vdjx_wave_scan_add((int) hs), 63);
 		is = (u32) __builtin_amdgcn_readlane(vdjx_wave_scan_add((int) is), 63);
-		if ((tid & 63u) == 0) { s_h[tid >> 6] = hs; s_i[tid >> 6] = is; }
+		if ((tid & 63u) == 0) { s_h[tid >> 6] = hs; s_i[tid >> 6] = is; s_b1[tid >> 6] = b1; s_b2[tid >> 6] = b2; }
 		__syncthreads();
 		if (tid == 0) {
-			u32 a = 0, b2 = 0;
-			for (u32 v = 0; v < MAP_THREADS / 64; v++) { a += s_h[v]; b2 += s_i[v]; }
+			u32 a = 0, bb = 0;
+			u64 m1 = 0, m2 = 0;
+			for (u32 v = 0; v < MAP_THREADS / 64; v++) { a += s_h[v]; bb += s_i[v]; m1 = s_b1[v] > m1 ? s_b1[v] : m1; m2 = s_b2[v] > m2 ? s_b2[v] : m2; }
 			out_hits[wi] = a;
-			out_inst[wi] = b2;
+			out_inst[wi] = bb;
+			if (out_gkey) {
+				// strings that share their deepest classes (the reads of a V gene, of a J gene: hundreds of clones) are neighbours under
+				// this key, the deepest ones first: 6 bits of depth, 16 bits of a hash of the two classes (k_group_pairs)
+				const u64 deep = (m1 > m2 ? m1 : m2) >> 26;
+				const u32 depth = deep ? 64u - (u32) __builtin_clzll(deep) : 0u;            // 0 .. 32
+				const u32 c1 = (u32) m1 & RI_ENT_NONE, c2 = (u32) m2 & RI_ENT_NONE;
+				out_gkey[wi] = ((u64) (63u - depth) << 16) | (vdjx_mix(c1, c2) >> 48);
+				out_gidx[wi] = wi;
+			}
 		}
 		__syncthreads();
 	}
@@ -593,13 +611,13 @@ __device__ inline u32 slice_contig(const u32* __restrict__ slice_start, u32 n, u
 #define MAP_SLICE_MAX 32768u     // ... and at most: as long as ~8 k slices remain (every slice loads its contig's image once)
 struct PlanOut { u64 total_hits, inst_total; u32 inst_max, chunk, nwork, pad; };
 
-__device__ inline u32 plan_block_scan(u32 v, u32* tmp, u32& total) {       // exclusive prefix over the 1024 threads (all call it)
+__device__ inline u32 plan_block_scan(u32 v, u32* tmp, u32& total) {       // exclusive prefix over the threads of the workgroup (all call it; at most 1024)
 	const u32 incl = (u32) vdjx_wave_scan_add((int) v);
 	__syncthreads();
 	if ((threadIdx.x & 63u) == 63u) tmp[threadIdx.x >> 6] = incl;
 	__syncthreads();
 	u32 base = 0, tot = 0;
-	for (u32 w = 0; w < 16; w++) { const u32 x = tmp[w]; if (w < (threadIdx.x >> 6)) base += x; tot += x; }
+	for (u32 w = 0; w < blockDim.x / 64; w++) { const u32 x = tmp[w]; if (w < (threadIdx.x >> 6)) base += x; tot += x; }
 	total = tot;
 	return base + incl - v;
 }
@@ -714,13 +732,14 @@ template <int NOFF>
 __global__ __launch_bounds__(MAP_THREADS, 8) void k_window_pairs(ReadIndexDev ix, const uint4* __restrict__ prep, u32 n, int len, u32 chunk,
                                                               const u32* __restrict__ order, const u32* __restrict__ wstart,
                                                               const u64* __restrict__ pair_off, u64* __restrict__ pair_buf,
-                                                              u32* __restrict__ pair_cnt, u32* __restrict__ pair_np) {
+                                                              u32* __restrict__ pair_cnt, u32* __restrict__ pair_np, const u32* __restrict__ done) {
 	__shared__ MapImg<NOFF> L;
 	__shared__ u64 q_ent[MAP_THREADS / 64][WP_Q];
 	__shared__ unsigned short q_off[MAP_THREADS / 64][WP_Q];
 	__shared__ u32 s_next;
 	const u32 j = slice_contig(wstart, n, blockIdx.x);
 	const u32 wi = order[j];
+	if (done && done[wi]) return;                       // (k_group_pairs)
 	const int noff = len - ix.rl;
 	const u32 tid = threadIdx.x;
 	const u32 h0 = (blockIdx.x - wstart[j]) * chunk;
@@ -811,6 +830,268 @@ __global__ __launch_bounds__(MAP_THREADS, 8) void k_window_pairs(ReadIndexDev ix
 	drain();
 	mine = (u32) __builtin_amdgcn_readlane(vdjx_wave_scan_add((int) mine), 63);
 	if (lane == 0 && mine) atomicAdd(&pair_np[wi], mine);
+}
+
+// K8 for GP_G strings at a time ("class-major": VERDICT r2 item 4).  A V gene is shared by hundreds of clones and a J gene by thousands:
+// the windows of such clones consist of the same read classes but for the CDR3 and a few mutations, and k_window_pairs streams the
+// same entry lists -- the deep ones -- once per window: 1.85 G entries at 10 M pairs, a kernel bound by instruction issue.  Here
+// a workgroup takes GP_G windows that are neighbours under k_map_classify's key, numbers their DISTINCT classes, streams every
+// class's entries ONCE against the union of the windows' presence bits, and only the entries that pass (a few per cent) are
+// taken to the windows that hold their class: the occurrences (window, offset) of every class are listed by window, so "the
+// last offset of mate class A in window w" is a walk over A's list in step with the walk over the entry's own.  Pair lists are
+// appended through LDS counters (a group is never split), any order (k_window_cover only counts).
+// A group whose distinct classes do not fit (unrelated windows) is left alone: k_window_pairs, launched after this kernel,
+// does every window that is not marked done.
+#define GP_G 8
+#ifndef GP_THREADS
+#define GP_THREADS 1024
+#define GP_WAVES 8
+#define GP_K 8                     // (16 rows per round spill 21 registers at 64: 1.94 ms against 1.47)
+#define GP_Q 96
+#endif
+#define GP_TS 4096u                 // class table slots
+#define GP_DMAX 2048u               // distinct classes of a group
+#define GP_NOFF 512
+#define GP_OCC (GP_G * GP_NOFF)
+#define GP_PRESENT_LOG2 16
+struct GroupImg {
+	u32 key[GP_TS];                                 // class + 1 -> ...
+	unsigned short didx[GP_TS];                     // ... its number in the group
+	u32 hpre[GP_DMAX + 1];                          // per numbered class: prefix of the entry counts (the flat hit sequence) ...
+	u32 cstart[GP_DMAX];                            // ... and its first entry
+	unsigned short occ_start[GP_DMAX + 2];          // its occurrences: occ[occ_start[d] .. occ_start[d + 1]), by window
+	unsigned short wmask[GP_DMAX];                  // bit w: window w holds the class; bit 15: some window holds it at more than one offset
+	unsigned short occ[GP_OCC];                     // window slot << 10 | offset
+	u32 present[1u << (GP_PRESENT_LOG2 - 5)];
+};
+__device__ inline int gp_lookup(const GroupImg& L, u32 cls) {
+	u32 slot = cls & (GP_TS - 1);
+	for (;;) {
+		const u32 cur = L.key[slot];
+		if (cur == 0) return -1;
+		if (cur == cls + 1) return (int) L.didx[slot];
+		slot = (slot + 1) & (GP_TS - 1);
+	}
+}
+__device__ inline bool gp_entry_present(const GroupImg& L, const u64 e) {
+	const u32 ba = ent_a(e) & ((1u << GP_PRESENT_LOG2) - 1u), bb = ent_b(e) & ((1u << GP_PRESENT_LOG2) - 1u);
+	return ((L.present[ba >> 5] >> (ba & 31)) | (L.present[bb >> 5] >> (bb & 31))) & 1u;
+}
+
+__global__ __launch_bounds__(GP_THREADS, GP_WAVES) void k_group_pairs(ReadIndexDev ix, const uint4* __restrict__ prep, const u32* __restrict__ hits, u32 n, int len,
+                                                              const u32* __restrict__ gorder, const u64* __restrict__ pair_off, u64* __restrict__ pair_buf,
+                                                              u32* __restrict__ pair_cnt, u32* __restrict__ pair_np, u32* __restrict__ done, unsigned long long* __restrict__ gstat, u32 dbg) {
+	__shared__ GroupImg L;
+	__shared__ u64 q_ent[GP_THREADS / 64][GP_Q];
+	__shared__ unsigned short q_d[GP_THREADS / 64][GP_Q];
+	__shared__ u64 s_pbase[GP_G];
+	__shared__ u32 s_w[GP_G], s_pcnt[GP_G], s_np[GP_G], s_tmp[GP_THREADS / 64];
+	__shared__ u32 s_nd, s_next, s_over;
+	const int noff = len - ix.rl;
+	const u32 tid = threadIdx.x;
+	const int lane = __lane_id();
+	const u32 wv = tid >> 6;
+	if (tid < GP_G) {
+		const u32 idx = blockIdx.x * GP_G + tid;
+		const u32 wi = idx < n ? gorder[idx] : NONE32;
+		s_w[tid] = wi;
+		s_pbase[tid] = wi != NONE32 ? pair_off[wi] : 0ull;
+		s_pcnt[tid] = 0; s_np[tid] = 0;
+	}
+	if (tid == 0) { s_nd = 0; s_next = 0; s_over = 0; }
+	for (u32 i = tid; i < GP_TS; i += GP_THREADS) L.key[i] = 0;
+	for (u32 i = tid; i < (1u << (GP_PRESENT_LOG2 - 5)); i += GP_THREADS) L.present[i] = 0;
+	__syncthreads();
+	if (tid == 0) {                                       // (the flat hit sequence is indexed with 32 bits)
+		u64 tot = 0;
+		for (int w = 0; w < GP_G; w++) if (s_w[w] != NONE32) tot += hits[s_w[w]];
+		if (tot >> 32) s_over = 1;
+	}
+	const u32 items = (u32) GP_G * (u32) noff;
+	// ---- the distinct classes of the group, numbered as they come
+	for (u32 it = tid; it < items; it += GP_THREADS) {
+		const u32 w = it / (u32) noff, o = it - w * (u32) noff;
+		if (s_w[w] == NONE32) continue;
+		const uint4 p = prep[(size_t) s_w[w] * noff + o];
+		const u32 cls = p.x;
+		if (cls == NONE32) continue;
+		const u32 pb = cls & ((1u << GP_PRESENT_LOG2) - 1u);
+		atomicOr(&L.present[pb >> 5], 1u << (pb & 31));
+		u32 slot = cls & (GP_TS - 1);
+		for (u32 probes = 0;; probes++) {
+			u32 cur = L.key[slot];
+			if (cur == 0) {
+				cur = atomicCAS(&L.key[slot], 0u, cls + 1);
+				if (cur == 0) {
+					const u32 d = atomicAdd(&s_nd, 1u);
+					if (d < GP_DMAX) { L.didx[slot] = (unsigned short) d; L.cstart[d] = p.y; L.hpre[d] = p.z; }
+					else s_over = 1;
+					break;
+				}
+			}
+			if (cur == cls + 1) break;
+			slot = (slot + 1) & (GP_TS - 1);
+			if (probes >= GP_TS) { s_over = 1; break; }
+		}
+	}
+	__syncthreads();
+	if (s_over) { if (tid == 0) atomicAdd(&gstat[1], 1ull); return; }       // (k_window_pairs takes these windows)
+	const u32 nd = s_nd;
+	u32* ocnt = (u32*) &q_ent[0][0];                      // (the queues are idle while the image is built)
+	for (u32 i = tid; i < nd; i += GP_THREADS) ocnt[i] = 0;
+	__syncthreads();
+	for (u32 it = tid; it < items; it += GP_THREADS) {
+		const u32 w = it / (u32) noff, o = it - w * (u32) noff;
+		if (s_w[w] == NONE32) continue;
+		const u32 cls = prep[(size_t) s_w[w] * noff + o].x;
+		if (cls != NONE32) atomicAdd(&ocnt[gp_lookup(L, cls)], 1u);
+	}
+	__syncthreads();
+	{	// both prefixes: GP_DMAX / GP_THREADS consecutive numbered classes per thread
+		constexpr u32 PER = GP_DMAX / GP_THREADS;
+		u32 hv[PER], cv[PER], hs = 0, cs = 0;
+#pragma unroll
+		for (u32 j = 0; j < PER; j++) {
+			const u32 a = PER * tid + j;
+			hv[j] = a < nd ? L.hpre[a] : 0u; cv[j] = a < nd ? ocnt[a] : 0u;
+			hs += hv[j]; cs += cv[j];
+		}
+		u32 htot, ctot;
+		u32 hx = plan_block_scan(hs, s_tmp, htot);
+		u32 cx = plan_block_scan(cs, s_tmp, ctot);
+		__syncthreads();
+#pragma unroll
+		for (u32 j = 0; j < PER; j++) {
+			const u32 a = PER * tid + j;
+			if (a <= nd) { L.hpre[a] = hx; L.occ_start[a] = (unsigned short) cx; }
+			if (a < nd) ocnt[a] = 0;
+			hx += hv[j]; cx += cv[j];
+		}
+		if (tid == 0 && nd == GP_DMAX) { L.hpre[nd] = htot; L.occ_start[nd] = (unsigned short) ctot; }
+	}
+	__syncthreads();
+	for (int w = 0; w < GP_G; w++) {                      // window by window: a class's occurrences lie in runs by window
+		if (s_w[w] != NONE32)
+			for (int o = (int) tid; o < noff; o += GP_THREADS) {
+				const u32 cls = prep[(size_t) s_w[w] * noff + o].x;
+				if (cls == NONE32) continue;
+				const int d = gp_lookup(L, cls);
+				L.occ[L.occ_start[d] + (atomicAdd(&ocnt[d], 1u) & 0xFFFFu)] = (unsigned short) ((u32) w << 10 | (u32) o);
+				if (atomicOr(&ocnt[d], 0x10000u << w) & (0x10000u << w)) atomicOr(&ocnt[d], 0x80000000u);      // (twice in this window)
+			}
+		__syncthreads();
+	}
+	for (u32 i = tid; i < nd; i += GP_THREADS) L.wmask[i] = (unsigned short) (ocnt[i] >> 16);
+	__syncthreads();
+	const u32 H = dbg == 2 ? 0u : L.hpre[nd];
+	if (tid == 0) { atomicAdd(&gstat[0], (unsigned long long) H); atomicAdd(&gstat[2], (unsigned long long) nd); }
+	u32 qn = 0, nq = 0;                                     // (wave-uniform)
+	// the queued entries, one per lane: the windows that hold the entry's class, each with its own last offsets of the mate classes
+	auto drain = [&]() {
+		vdjx_wave_lds_fence();
+		for (u32 q0 = 0; q0 < (dbg == 1 ? 0u : qn); q0 += 64) {
+			const u32 qi = q0 + (u32) lane;
+			if (qi >= qn) continue;
+			const u64 e = q_ent[wv][qi];
+			const u32 d = q_d[wv][qi];
+			const u32 ca = ent_a(e), cb = ent_b(e);
+			u32 as = 0, ae = 0, bs = 0, be = 0;
+			int xa = -1, xb = -1;
+			if (ca != RI_ENT_NONE) { xa = gp_lookup(L, ca); if (xa >= 0) { as = L.occ_start[xa]; ae = L.occ_start[xa + 1]; } }
+			if (cb != RI_ENT_NONE) { xb = gp_lookup(L, cb); if (xb >= 0) { bs = L.occ_start[xb]; be = L.occ_start[xb + 1]; } }
+			if (as == ae && bs == be) continue;
+			const u32 fl = ent_flags(e), mult = ent_count(e);
+			const u32 rc1 = (fl & RI_RC) ? 1u : 0u;
+			const u32 mc = L.wmask[d], ma = as < ae ? (u32) L.wmask[xa] : 0u, mb = bs < be ? (u32) L.wmask[xb] : 0u;
+			const u32 cs = L.occ_start[d];
+			auto emit = [&](u32 w, u32 o, u32 la, u32 lb) {               // (quick_map3.c:223-245, as map_eval_entry)
+				const u32 which = (lb && lb >= la) ? 1u : 0u;
+				const u32 best = which ? lb : la;
+				const u32 rc2 = (fl & (which ? RI_RCB : RI_RCA)) ? 1u : 0u;
+				if (rc1 == rc2) return;
+				const int dd = (int) (o + 1) - (int) best;
+				const int insert = (int) (short) ((dd < 0 ? -dd : dd) + ix.rl);
+				if (insert < 50 || insert > 400) return;
+				const u32 pos = atomicAdd(&s_pcnt[w], 1u);
+				pair_buf[s_pbase[w] + pos] = ((u64) mult << 32) | ((o + 1) << 16) | best;
+				atomicAdd(&s_np[w], mult);
+			};
+			if (!((mc | ma | mb) & 0x8000u)) {
+				// every class at most once per window: the occurrence in window w is the popcount(mask below w)-th of its list
+				for (u32 m = mc & (ma | mb); m; m &= m - 1) {
+					const u32 w = (u32) __ffs((int) m) - 1u, below = (1u << w) - 1u;
+					const u32 o = (u32) L.occ[cs + (u32) __popc(mc & below)] & 1023u;
+					const u32 la = (ma >> w) & 1u ? ((u32) L.occ[as + (u32) __popc(ma & below)] & 1023u) + 1u : 0u;
+					const u32 lb = (mb >> w) & 1u ? ((u32) L.occ[bs + (u32) __popc(mb & below)] & 1023u) + 1u : 0u;
+					emit(w, o, la, lb);
+				}
+				continue;
+			}
+			// a class repeats inside a window: the lists are walked in step (runs by window)
+			u32 i = cs;
+			const u32 ce = L.occ_start[d + 1];
+			while (i < ce) {
+				const u32 w = (u32) L.occ[i] >> 10;
+				u32 la = 0, lb = 0;
+				while (as < ae && ((u32) L.occ[as] >> 10) < w) as++;
+				while (as < ae && ((u32) L.occ[as] >> 10) == w) { const u32 x = ((u32) L.occ[as] & 1023u) + 1u; la = x > la ? x : la; as++; }
+				while (bs < be && ((u32) L.occ[bs] >> 10) < w) bs++;
+				while (bs < be && ((u32) L.occ[bs] >> 10) == w) { const u32 x = ((u32) L.occ[bs] & 1023u) + 1u; lb = x > lb ? x : lb; bs++; }
+				for (; i < ce && ((u32) L.occ[i] >> 10) == w; i++)
+					if (la | lb) emit(w, (u32) L.occ[i] & 1023u, la, lb);
+			}
+		}
+		vdjx_wave_lds_fence();
+		qn = 0;
+	};
+	// the sweep of k_window_pairs over the classes of the group instead of the offsets of a window
+	for (;;) {
+		u32 hb = 0;
+		if (lane == 0) hb = atomicAdd(&s_next, 64u * GP_K);
+		hb = (u32) __builtin_amdgcn_readlane((int) hb, 0);
+		if (hb >= H) break;
+		int drow = 0;
+		{
+			const u32 hr = hb + (u32) lane * 64u;
+			if (lane < GP_K && hr < H) {
+				int lo = 0, hi = (int) nd;                  // last class with hpre[d] <= hr
+				while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.hpre[mid] <= hr) lo = mid; else hi = mid; }
+				drow = lo;
+			}
+		}
+		u64 ent[GP_K];
+		u32 dd[GP_K / 2];
+#pragma unroll
+		for (int u = 0; u < GP_K; u++) {
+			const u32 h = hb + (u32) (u * 64 + lane);
+			int d = __builtin_amdgcn_readlane(drow, u);
+			u64 e = ~0ull;
+			if (h < H) {
+				while (h >= L.hpre[d + 1]) d++;
+				e = ix.d8[L.cstart[d] + (h - L.hpre[d])];
+			}
+			ent[u] = e;
+			if (u & 1) dd[u >> 1] |= (u32) d << 16; else dd[u >> 1] = (u32) d;
+		}
+#pragma unroll
+		for (int u = 0; u < GP_K; u++) {
+			if (hb + (u32) (u * 64) >= H) break;                                 // (wave-uniform)
+			const bool pass = gp_entry_present(L, ent[u]) && hb + (u32) (u * 64 + lane) < H;
+			const u64 m = __ballot(pass);
+			if (!m) continue;
+			if (pass) {
+				const u32 at = qn + (u32) __popcll(m & ((1ull << lane) - 1ull));
+				q_ent[wv][at] = ent[u];
+				q_d[wv][at] = (unsigned short) ((dd[u >> 1] >> (16 * (u & 1))) & 0xFFFFu);
+			}
+			qn += (u32) __popcll(m); nq += (u32) __popcll(m);
+			if (qn > GP_Q - 64) drain();
+		}
+	}
+	drain();
+	if (lane == 0 && nq) atomicAdd(&gstat[3], (unsigned long long) nq);
+	__syncthreads();
+	if (tid < GP_G && s_w[tid] != NONE32) { pair_cnt[s_w[tid]] = s_pcnt[tid]; pair_np[s_w[tid]] = s_np[tid]; done[s_w[tid]] = 1u; }
 }
 
 // K9: coverage verdict of a window from its pair list
@@ -1206,10 +1487,13 @@ struct MapPlan {
 	uint4* d_prep = nullptr;
 	u64* d_off = nullptr;
 	u32 *d_order = nullptr, *d_wstart = nullptr;
+	u32 *d_hits = nullptr, *d_gorder = nullptr;       // hits per string; the strings in k_group_pairs' order (if asked for)
+	bool gstat = false;
 	PlanOut tot{};
 };
+int vdjx_sort_pairs(vdjx_work& db, hipStream_t st, u64* k_in, u64* k_out, u32* v_in, u32* v_out, u32 n, unsigned end_bit);     // vdjx_rindex.hip
 static int classify_and_plan(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, const char* strings, size_t n, int len, bool weighted,
-                             u32 chunk_fixed, MapPlan* mp) {
+                             u32 chunk_fixed, MapPlan* mp, bool grouped = false) {
 	hipStream_t st = c->stream;
 	vdjx_laps lp(c);
 	const int noff = len - ix.rl;
@@ -1224,15 +1508,29 @@ static int classify_and_plan(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix,
 	HIP_TRY(db.alloc(&mp->d_order, n));
 	HIP_TRY(db.alloc(&mp->d_wstart, n + 1));
 	HIP_TRY(db.alloc(&d_tot, 1));
+	u64 *d_gkey = nullptr, *d_gkey2 = nullptr;
+	u32* d_gidx = nullptr;
+	if (grouped) {
+		HIP_TRY(db.alloc(&d_gkey, n));
+		HIP_TRY(db.alloc(&d_gkey2, n));
+		HIP_TRY(db.alloc(&d_gidx, n));
+		HIP_TRY(db.alloc(&mp->d_gorder, n));
+	}
+	mp->d_hits = d_hits;
 	HIP_TRY(hipMemcpyAsync(d_s, strings, n * len, hipMemcpyHostToDevice, st));
 	{
 		vdjx_prof_scope ps(c, "k_map_classify");
-		if (c->ri_pool->W == 2) hipLaunchKernelGGL(k_map_classify<2>, dim3((u32) std::min<size_t>(n, 8192)), dim3(MAP_THREADS), 0, st, ix, d_s, (u32) n, len, weighted, mp->d_prep, d_hits, d_inst);
-		else hipLaunchKernelGGL(k_map_classify<VDJX_LONG_W>, dim3((u32) std::min<size_t>(n, 8192)), dim3(MAP_THREADS), 0, st, ix, d_s, (u32) n, len, weighted, mp->d_prep, d_hits, d_inst);
+		if (c->ri_pool->W == 2) hipLaunchKernelGGL(k_map_classify<2>, dim3((u32) std::min<size_t>(n, 8192)), dim3(MAP_THREADS), 0, st, ix, d_s, (u32) n, len, weighted, mp->d_prep, d_hits, d_inst, d_gkey, d_gidx);
+		else hipLaunchKernelGGL(k_map_classify<VDJX_LONG_W>, dim3((u32) std::min<size_t>(n, 8192)), dim3(MAP_THREADS), 0, st, ix, d_s, (u32) n, len, weighted, mp->d_prep, d_hits, d_inst, d_gkey, d_gidx);
 	}
 	{
 		vdjx_prof_scope ps(c, "k_plan");
 		hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, d_hits, d_inst, (u32) n, chunk_fixed, weighted ? 1 : 0, weighted ? 1 : 0, mp->d_off, mp->d_order, mp->d_wstart, d_tot);
+	}
+	if (grouped) {
+		vdjx_prof_scope ps(c, "group_sort");
+		const int rc = vdjx_sort_pairs(db, st, d_gkey, d_gkey2, d_gidx, mp->d_gorder, (u32) n, 22);
+		if (rc) return rc;
 	}
 	if (!c->h_plan) {
 		HIP_TRY(hipHostMalloc(&c->h_plan, 256, hipHostMallocDefault));
@@ -1267,7 +1565,11 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 	hipStream_t st = c->stream;
 	u32 *d_np, *d_cnt;
 	static const u32 hit_chunk = getenv("VDJX_HIT_CHUNK") && atol(getenv("VDJX_HIT_CHUNK")) > 0 ? (u32) atol(getenv("VDJX_HIT_CHUNK")) : HIT_CHUNK;
-	int rc = classify_and_plan(c, db, ix, windows, n, len, true, hit_chunk, mp);
+	// VDJX_WINDOW_GROUP=0: every window on its own (k_window_pairs only)
+	static const u32 gp_dbg = getenv("VDJX_GP_DBG") ? (u32) atol(getenv("VDJX_GP_DBG")) : 0u;      // ablation (profiles/): 1 no full tests, 2 images only
+	static const bool group_on = !(getenv("VDJX_WINDOW_GROUP") && atol(getenv("VDJX_WINDOW_GROUP")) == 0);
+	const bool grouped = group_on && len - ix.rl <= GP_NOFF;
+	int rc = classify_and_plan(c, db, ix, windows, n, len, true, hit_chunk, mp, grouped);
 	if (rc) return rc;
 	const u64 total = mp->tot.total_hits;
 	if ((size_t) total + 1 > c->wp_cap) {
@@ -1285,15 +1587,28 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 	c->stats["window_work_items"] = mp->tot.nwork;
 	HIP_TRY(hipMemsetAsync(d_np, 0, n * 4, st));
 	HIP_TRY(hipMemsetAsync(d_cnt, 0, n * 4, st));
+	u32* d_done = nullptr;
+	unsigned long long* d_gstat = nullptr;
+	if (grouped) {
+		HIP_TRY(db.alloc(&d_done, n));
+		HIP_TRY(hipMemsetAsync(d_done, 0, n * 4, st));
+		HIP_TRY(db.alloc(&d_gstat, 4));
+		HIP_TRY(hipMemsetAsync(d_gstat, 0, 32, st));
+		vdjx_prof_scope ps(c, "k_group_pairs");
+		hipLaunchKernelGGL(k_group_pairs, dim3((u32) ((n + GP_G - 1) / GP_G)), dim3(GP_THREADS), 0, st, ix, mp->d_prep, mp->d_hits, (u32) n, len, mp->d_gorder,
+		                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done, d_gstat, gp_dbg);
+	}
 	if (mp->tot.nwork) {
 		vdjx_prof_scope ps(c, "k_window_pairs");
 		if (len - ix.rl <= 512)
 			hipLaunchKernelGGL(k_window_pairs<512>, dim3(mp->tot.nwork), dim3(MAP_THREADS), 0, st, ix, mp->d_prep, (u32) n, len, mp->tot.chunk, mp->d_order, mp->d_wstart,
-			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np);
+			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done);
 		else
 			hipLaunchKernelGGL(k_window_pairs<MAP_MAXOFF>, dim3(mp->tot.nwork), dim3(MAP_THREADS), 0, st, ix, mp->d_prep, (u32) n, len, mp->tot.chunk, mp->d_order, mp->d_wstart,
-			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np);
+			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done);
 	}
+	if (d_gstat) HIP_TRY(hipMemcpyAsync((char*) c->h_plan + 128, d_gstat, 32, hipMemcpyDeviceToHost, st));        // (read after the caller's wait)
+	mp->gstat = d_gstat != nullptr;
 	*d_np_out = d_np; *d_cnt_out = d_cnt;
 	return VDJX_OK;
 }
@@ -1331,6 +1646,13 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	HIP_TRY(hipGetLastError());
 	lp.mark("ws_cover_wait");
 	vdjx_prof_collect(c);
+	if (mp.gstat) {
+		const unsigned long long* g = (const unsigned long long*) ((const char*) c->h_plan + 128);
+		c->stats["group_hits_distinct"] = g[0];                // entries streamed by k_group_pairs (each class of a group once)
+		c->stats["group_overflows"] = g[1];                    // groups left to k_window_pairs
+		c->stats["group_classes"] = g[2];
+		c->stats["group_queued"] = g[3];                       // entries that passed the presence test of their group
+	}
 	{
 		u64 tot = 0, ent = 0;
 		for (size_t i = 0; i < n; i++) { tot += out_npairs[i]; ent += c->wp_cnt[i]; }
