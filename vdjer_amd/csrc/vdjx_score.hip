@@ -843,17 +843,18 @@ __global__ __launch_bounds__(MAP_THREADS, 8) void k_window_pairs(ReadIndexDev ix
 // A group whose distinct classes do not fit (unrelated windows) is left alone: k_window_pairs, launched after this kernel,
 // does every window that is not marked done.
 #define GP_G 8
-#ifndef GP_THREADS
-#define GP_THREADS 1024
-#define GP_WAVES 8
-#define GP_K 8                     // (16 rows per round spill 21 registers at 64: 1.94 ms against 1.47)
-#define GP_Q 96
+#ifndef GP_THREADS                  // measured at 10 M pairs (threads / waves per SIMD / rows per round): 1024/8/16 1.94 ms (21 registers spilled), 1024/8/8 1.47,
+#define GP_THREADS 768              // 512/4/16 1.51, 768/6/8 1.25, 768/6/12 1.21: two workgroups per CU (LDS), 70 registers
+#define GP_WAVES 6
+#define GP_K 12
+#define GP_Q 128                   // the queue of a wave: drained in full rows of 64 (GP_Q - 64 entries wait at most)
 #endif
 #define GP_TS 4096u                 // class table slots
 #define GP_DMAX 2048u               // distinct classes of a group
 #define GP_NOFF 512
 #define GP_OCC (GP_G * GP_NOFF)
 #define GP_PRESENT_LOG2 16
+static_assert(GP_Q >= 128, "a drain of full rows must find one");
 struct GroupImg {
 	u32 key[GP_TS];                                 // class + 1 -> ...
 	unsigned short didx[GP_TS];                     // ... its number in the group
@@ -948,7 +949,7 @@ __global__ __launch_bounds__(GP_THREADS, GP_WAVES) void k_group_pairs(ReadIndexD
 	}
 	__syncthreads();
 	{	// both prefixes: GP_DMAX / GP_THREADS consecutive numbered classes per thread
-		constexpr u32 PER = GP_DMAX / GP_THREADS;
+		constexpr u32 PER = (GP_DMAX + GP_THREADS) / GP_THREADS;      // (covers index nd <= GP_DMAX as well)
 		u32 hv[PER], cv[PER], hs = 0, cs = 0;
 #pragma unroll
 		for (u32 j = 0; j < PER; j++) {
@@ -967,7 +968,6 @@ __global__ __launch_bounds__(GP_THREADS, GP_WAVES) void k_group_pairs(ReadIndexD
 			if (a < nd) ocnt[a] = 0;
 			hx += hv[j]; cx += cv[j];
 		}
-		if (tid == 0 && nd == GP_DMAX) { L.hpre[nd] = htot; L.occ_start[nd] = (unsigned short) ctot; }
 	}
 	__syncthreads();
 	for (int w = 0; w < GP_G; w++) {                      // window by window: a class's occurrences lie in runs by window
@@ -987,9 +987,10 @@ __global__ __launch_bounds__(GP_THREADS, GP_WAVES) void k_group_pairs(ReadIndexD
 	if (tid == 0) { atomicAdd(&gstat[0], (unsigned long long) H); atomicAdd(&gstat[2], (unsigned long long) nd); }
 	u32 qn = 0, nq = 0;                                     // (wave-uniform)
 	// the queued entries, one per lane: the windows that hold the entry's class, each with its own last offsets of the mate classes
-	auto drain = [&]() {
+	auto drain = [&](bool all) {
 		vdjx_wave_lds_fence();
-		for (u32 q0 = 0; q0 < (dbg == 1 ? 0u : qn); q0 += 64) {
+		const u32 upto = all ? qn : qn & ~63u;                  // (full rows of 64 only, until the last call: every lane busy)
+		for (u32 q0 = 0; q0 < (dbg == 1 ? 0u : upto); q0 += 64) {
 			const u32 qi = q0 + (u32) lane;
 			if (qi >= qn) continue;
 			const u64 e = q_ent[wv][qi];
@@ -1041,8 +1042,14 @@ __global__ __launch_bounds__(GP_THREADS, GP_WAVES) void k_group_pairs(ReadIndexD
 					if (la | lb) emit(w, (u32) L.occ[i] & 1023u, la, lb);
 			}
 		}
+		// what is left moves to the front
+		const u32 rem = qn - upto;
+		u64 me = 0; unsigned short md = 0;
+		if ((u32) lane < rem) { me = q_ent[wv][upto + (u32) lane]; md = q_d[wv][upto + (u32) lane]; }
 		vdjx_wave_lds_fence();
-		qn = 0;
+		if ((u32) lane < rem && upto) { q_ent[wv][lane] = me; q_d[wv][lane] = md; }
+		vdjx_wave_lds_fence();
+		qn = rem;
 	};
 	// the sweep of k_window_pairs over the classes of the group instead of the offsets of a window
 	for (;;) {
@@ -1085,10 +1092,10 @@ __global__ __launch_bounds__(GP_THREADS, GP_WAVES) void k_group_pairs(ReadIndexD
 				q_d[wv][at] = (unsigned short) ((dd[u >> 1] >> (16 * (u & 1))) & 0xFFFFu);
 			}
 			qn += (u32) __popcll(m); nq += (u32) __popcll(m);
-			if (qn > GP_Q - 64) drain();
+			if (qn > GP_Q - 64) drain(false);
 		}
 	}
-	drain();
+	drain(true);
 	if (lane == 0 && nq) atomicAdd(&gstat[3], (unsigned long long) nq);
 	__syncthreads();
 	if (tid < GP_G && s_w[tid] != NONE32) { pair_cnt[s_w[tid]] = s_pcnt[tid]; pair_np[s_w[tid]] = s_np[tid]; done[s_w[tid]] = 1u; }
