@@ -68,7 +68,11 @@ def scorer_bytes(stats: dict, n_windows: int, n_contigs: int, k: int, rl: int = 
     return {"k_part_items": 16 * stats.get("recount_items", 0),          # every run item (8 bytes) in and out
             "k_recount": 8 * stats.get("recount_items", 0),
             "k_map_classify": (nw + nc) * 48,
-            "k_window_pairs": nw * 16 + 8 * stats.get("window_hits_distinct", 0) + 8 * stats.get("window_pairs_entries", 0),
+            # the grouped mapper reads every image three times (numbering, counting, listing the occurrences), one 8-B entry per
+            # DISTINCT entry of a GROUP's classes (a class shared by the group's windows is streamed once), and writes the lists;
+            # k_window_pairs only looks at the flags of the windows the groups have done (none are left on this workload)
+            "k_group_pairs": 3 * nw * 16 + 8 * stats.get("group_hits_distinct", 0) + 8 * stats.get("window_pairs_entries", 0),
+            "k_window_pairs": (nw * 16 + 8 * stats.get("window_hits_distinct", 0) + 8 * stats.get("window_pairs_entries", 0)) if not stats.get("group_hits_distinct") else n_windows * 8,
             "k_window_cover": 8 * 2 * stats.get("window_pairs_entries", stats.get("window_pairs", 0)),
             "k_map_emit": nc * 16 + 8 * stats.get("map_hits", 0) + 24 * stats.get("mapped_pairs", 0),
             "k_gather_pairs": 44 * stats.get("mapped_pairs", 0),

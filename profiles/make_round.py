@@ -34,8 +34,8 @@ def main():
     ab = bench.algorithmic_bytes_per_pair(k, 50, gi / pairs if gi else None)
     sb = bench.scorer_bytes(st, b["counts"]["windows"], b["counts"]["n_contigs_rank"], k)
     launches = {"k_pool_pack": 2, "k_map_classify": 2, "k_plan": 2}
-    print("| kernel | ms/step (HIP events) | rocprofv3 avg ms/launch | alg. bytes/step | achieved GB/s | frac of 8 TB/s | fabric traffic/step (PMC) | traffic / alg. | L2 hit | wave-cycles waiting | LDS conflict |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    print("| kernel | ms/step (HIP events) | rocprofv3 avg ms/launch | alg. bytes/step | achieved GB/s | frac of 8 TB/s | fabric traffic/step (PMC) | traffic / alg. | L2 hit | wave-cycles waiting | LDS conflict | VALU issue share |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
     for name, ms in sorted(b["kernels_ms_per_step"].items(), key=lambda kv: -kv[1]):
         v = pm.get(alias.get(name, name), {})
         algb = ab[name] * pairs if name in ab and name not in ("P", "input", "total", "gated_per_pair") else sb.get(name)
@@ -44,9 +44,9 @@ def main():
         if algb and t:
             ach = algb / (ms * 1e-3) / 1e9
             print(f"| {name} | {ms:.3f} | {v.get('avg_ns', 0) / 1e6:.3f} | {algb / 1e6:.0f} MB | {ach:.0f} | {ach / 8000:.3f} | {t / 1e6:.0f} MB | {t / algb:.2f} | "
-                  f"{v.get('l2_hit')} | {v.get('SQ_WAIT_ANY_frac')} | {v.get('lds_conflict_frac')} |")
+                  f"{v.get('l2_hit')} | {v.get('SQ_WAIT_ANY_frac')} | {v.get('lds_conflict_frac')} | {v.get('valu_issue_frac_at_2.4GHz')} |")
         else:
-            print(f"| {name} | {ms:.3f} | {v.get('avg_ns', 0) / 1e6:.3f} | - | - | - | {(t or 0) / 1e6:.0f} MB | - | {v.get('l2_hit')} | {v.get('SQ_WAIT_ANY_frac')} | {v.get('lds_conflict_frac')} |")
+            print(f"| {name} | {ms:.3f} | {v.get('avg_ns', 0) / 1e6:.3f} | - | - | - | {(t or 0) / 1e6:.0f} MB | - | {v.get('l2_hit')} | {v.get('SQ_WAIT_ANY_frac')} | {v.get('lds_conflict_frac')} | {v.get('valu_issue_frac_at_2.4GHz')} |")
 
 
 if __name__ == "__main__":

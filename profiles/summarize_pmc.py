@@ -22,7 +22,7 @@ def med(v):
 def main():
     out = sys.argv[1]
     res = collections.defaultdict(dict)
-    for grp in ("fetch", "write", "sq", "tcc"):
+    for grp in ("fetch", "write", "sq", "tcc", "inst"):
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         for f in glob.glob(os.path.join(out, grp, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
@@ -47,6 +47,10 @@ def main():
         if d.get("SQ_LDS_IDX_ACTIVE"):
             d["lds_conflict_frac"] = round(d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"], 4)
         d.update(stats.get(k, {}))
+        if d.get("SQ_INSTS_VALU") and d.get("avg_ns"):
+            # a wave's vector instruction occupies its SIMD for 4 cycles (64 lanes over 16): the share of the launch during which the
+            # 1024 SIMDs of the chip would be issuing them at 2.4 GHz -- the ALU-side roofline of integer kernels like these
+            d["valu_issue_frac_at_2.4GHz"] = round(d["SQ_INSTS_VALU"] * 4 / (1024 * 2.4 * d["avg_ns"]), 3)
     json.dump({"kernels": res}, sys.stdout, indent=1, sort_keys=True)
 
 
