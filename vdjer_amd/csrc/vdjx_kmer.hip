@@ -1506,10 +1506,23 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 	const int lane = __lane_id();
 	u64 blk = 0;                                  // this wave's block (wave-uniform), valid once have_blk
 	u32 fill = blk_items;
+#ifdef WALK_STATS                       // (build with -DWALK_STATS, run with VDJX_WALK_DBG=32: what a wave's trips are spent on; the counters cost scalar registers)
+	u32 st_rows = 0, st_rounds = 0, st_filter = 0, st_lookup = 0, st_items = 0, st_chain = 0;
+#define WST(x) x
+#else
+#define WST(x)
+#endif
 	bool have_blk = false, dead = false;
-	for (size_t rb = r0; rb < r1; rb += WALK_THREADS) {
-		const size_t r = rb + threadIdx.x;
-		const bool live = r < r1;
+	// Records that leave their chain (an error, a branch, noise: four in ten) need the k-mer filter: 16 k-mers cut out and hashed, half
+	// of this kernel's instructions -- issued for the whole wave when ONE lane asks.  A lane of a fresh row therefore only goes as
+	// far as its first lookup and the chains carry it; where it would ask the filter, the record is set aside (record, offset) in
+	// the wave's queue, and the queued records are walked 64 at a time, every lane with the same need.  (VDJX_WALK_DBG=32 with
+	// -DWALK_STATS counted, per row of 64 records: 4.6 rounds, the filter in 1.3 of them; profiles/README.md, round 3.)
+	__shared__ u64 dq[WALK_THREADS / 64][128];
+	const u32 wq = threadIdx.x >> 6;
+	u32 qn = 0;                                   // (wave-uniform)
+	auto walk_row = [&](auto fresh_tag, const size_t r, const bool live, const int o_from) {
+		constexpr bool FRESH = decltype(fresh_tag)::value;
 		RecT v;
 		MaskT V{};                                    // the offsets whose k bases are all valid (bit o of nm = base o is N or masked)
 		if constexpr (LONG) {
@@ -1535,15 +1548,27 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				V = ~inv & (P >= 64 ? ~0ull : (1ull << P) - 1ull);
 			}
 		}
-		int o = wm_next(V, 0, P);                               // the offset this lane works on; P: done
+		int o = wm_next(V, o_from, P);                          // the offset this lane works on; P: done
 		int s = -1;                                              // its survivor, if known
 		u32 in = 0;                                              // has_prev << 2 | first base of the predecessor k-mer
-		bool first = true, have_c = false;
+		bool first = FRESH, have_c = false;
 		MaskT C{};                                               // valid offsets the k-mer filter lets through (once have_c)
+		WST(st_rows++;)
 		while (__ballot(o < P)) {
+			WST(st_rounds++;)
 			// ---- lookups ----
-			const bool need = o < P && s < 0;
-			if (__ballot(need && !first && !have_c)) {           // (wave-uniform) filter bits of all remaining offsets, 4 loads in flight
+			bool need = o < P && s < 0;
+			if (FRESH) {
+				const bool later = need && !first;
+				const u64 lm = __ballot(later);
+				if (lm) {
+					if (later) { dq[wq][qn + (u32) __popcll(lm & ((1ull << lane) - 1ull))] = ((u64) r << 8) | (u64) (u32) o; o = P; need = false; }
+					qn += (u32) __popcll(lm);
+				}
+			}
+			WST(if (__ballot(need)) st_lookup++;)
+			if (!FRESH && __ballot(need && !first && !have_c)) {
+				WST(st_filter++;)      // (wave-uniform) filter bits of all remaining offsets, 4 loads in flight
 				const bool mine = need && !first && !have_c;
 				for (int ob = 0; ob < P; ob += 4) {
 					u32 wv[4], bt[4];
@@ -1582,6 +1607,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 			}
 			// ---- the chain from s ----
 			const bool act = o < P && s >= 0;
+			WST(if (__ballot(act)) st_chain++;)
 			u32 rem = 0, pp = 0, po = 0;
 			if (act) {
 				const u32 a = (u32) s & 15u;
@@ -1620,6 +1646,7 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 			u32 pin = in;
 			if (act) in = s >= 0 ? (4u | v.base(o - 1)) : 0u;      // (next round: first base of the k-mer at o - 1)
 			while (__ballot(rem > 0)) {
+				WST(st_items++;)
 				const bool close = rem > 0;
 				u32 len = 16u - (pp & 15u);
 				len = len < rem ? len : rem;
@@ -1647,8 +1674,28 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				}
 			}
 		}
+	};
+	auto walk_queued = [&](u32 take) {                // the last `take` <= 64 queued records, one per lane
+		vdjx_wave_lds_fence();
+		const bool live = (u32) lane < take;
+		const u64 e = live ? dq[wq][qn - take + (u32) lane] : 0ull;
+		vdjx_wave_lds_fence();
+		qn -= take;
+		walk_row(std::false_type{}, (size_t) (e >> 8), live, (int) (e & 255u));
+	};
+	for (size_t rb = r0; rb < r1; rb += WALK_THREADS) {
+		const size_t r = rb + threadIdx.x;
+		walk_row(std::true_type{}, r, r < r1, 0);
+		while (qn >= 64) walk_queued(64);
 	}
+	if (qn) walk_queued(qn);
 	if (have_blk) for (u32 i = fill + (u32) lane; i < blk_items; i += 64) raw[blk + i] = IT_HOLE;
+#ifdef WALK_STATS
+	if ((dbg & 32u) && lane == 0) {
+		atomicAdd(&g_cursor[1], (unsigned long long) st_rows); atomicAdd(&g_cursor[2], (unsigned long long) st_rounds); atomicAdd(&g_cursor[3], (unsigned long long) st_filter);
+		atomicAdd(&g_cursor[4], (unsigned long long) st_lookup); atomicAdd(&g_cursor[5], (unsigned long long) st_chain); atomicAdd(&g_cursor[6], (unsigned long long) st_items);
+	}
+#endif
 	__syncthreads();
 	for (u32 i = threadIdx.x; i < n_ranges; i += WALK_THREADS) if (hist[i]) atomicAdd(&range_cnt[i], hist[i]);
 }
@@ -2388,7 +2435,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	const u32 n_coarse = (n_ranges + (1u << l2bits) - 1) >> l2bits;
 	const u32 n_ranges_p = n_coarse << l2bits;                      // padded: every coarse segment has 2^l2bits ranges
 	// raw item blocks
-	static const size_t walk_blocks = tune("VDJX_WALK_BLOCKS", 4096);
+	static const size_t walk_blocks = tune("VDJX_WALK_BLOCKS", 7168);      // (seven waves per SIMD are resident: 28 blocks per CU = one resident set x 4; measured 4096 2.45 ms, 7168 2.32, 16384 2.52)
 	u32 nblk = (u32) std::min<size_t>(walk_blocks, (R + WALK_THREADS * 8 - 1) / (WALK_THREADS * 8));
 	if (nblk == 0) nblk = 1;
 	const size_t nwaves = (size_t) nblk * (WALK_THREADS / 64);
@@ -2422,9 +2469,9 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		unsigned long long* cur2;
 		u32* cnt2;
 		HIP_TRY(db.alloc(&raw2, (size_t) raw_cap));
-		HIP_TRY(db.alloc(&cur2, 1));
+		HIP_TRY(db.alloc(&cur2, 8));
 		HIP_TRY(db.alloc(&cnt2, n_ranges_p));
-		HIP_TRY(hipMemsetAsync(cur2, 0, 8, st));
+		HIP_TRY(hipMemsetAsync(cur2, 0, 64, st));
 		HIP_TRY(hipMemsetAsync(cnt2, 0, (size_t) n_ranges_p * 4, st));
 		vdjx_prof_scope ps(c, "k_walk_dbg");
 		if (lng) hipLaunchKernelGGL(k_walk_items<true>, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, pool->ob, k, tb, succ, linw, f, range_shift,
@@ -2432,6 +2479,13 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		else hipLaunchKernelGGL(k_walk_items<false>, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, pool->ob, k, tb, succ, linw, f, range_shift,
 		                        n_ranges_p, raw2, raw_cap, blk_items, cur2, cnt2, g_err, walk_dbg);
 		HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
+		if (walk_dbg & 32u) {                      // per wave: rows of 64 records, rounds, and the rounds that ran each part
+			unsigned long long hs[8];
+			HIP_TRY(hipMemcpyAsync(hs, cur2, 64, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			const char* nm[] = {"", "rows", "rounds", "filter", "lookup", "chain", "item_trips"};
+			for (int i = 1; i < 7; i++) c->stats[std::string("walk_dbg_") + nm[i]] = hs[i];
+		}
 	}
 	if (R) {
 		vdjx_prof_scope ps(c, "k_walk_items");
