@@ -773,3 +773,58 @@ def test_window_scorer_without_grouping_in_a_fresh_process():
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_grouped_window_mapper_edge_cases(ctx):
+    """k_group_pairs takes eight windows at a time: identical windows in one group (every class shared), a single window, a
+    group that is not full, windows nothing maps to, windows in which a read class repeats (tandem repeats: the slow walk of the
+    occurrence lists), unrelated random windows (more distinct classes than a group's table: left to k_window_pairs) and
+    windows longer than the grouped kernel takes -- pair counts and verdicts against the oracle, and the statistics say which
+    kernel did the work."""
+    from oracle import oracle
+    from vdjer_amd import synth
+    rng = np.random.default_rng(77)
+    rep = synth.make_repertoire(9, seed=4321)
+    # a clone with a tandem repeat inside its window: reads of the repeat unit recur at several offsets of the same window
+    unit = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 25))
+    rep_clone = rep.clones[0][:150] + unit * 8 + rep.clones[0][350:]
+    rep2 = synth.Repertoire(rep.v_germ, rep.j_germ, rep.clones + [rep_clone], rep.clone_v + [0], rep.clone_j + [0], np.full(10, 0.1), 99, j_codon=rep.j_codon)
+    both = synth.tile_reads(rep2, range(10), ins=175, copies=2, step=2)
+    ix = oracle.ReadIndex(both)
+    p = _load_index(ctx, both)
+    base = [w for w in rep.windows() if w]
+    rand = ["".join("ACGT"[int(x)] for x in rng.integers(0, 4, 486)) for _ in range(16)]
+    cases = {
+        "one": base[:1],
+        "same8": [base[0]] * 8,
+        "nine": (base * 3)[:9],
+        "repeat": [rep_clone[100:586], rep_clone[120:606], base[0], rep_clone[100:586]],
+        "nothing": rand[:5],
+        "mixed": base + rand + [rep_clone[100:586]] + [t[s:s + 486] for t in rep.clones for s in (3, 21)],
+    }
+    for name, wins in cases.items():
+        valid, npairs = ctx.window_score(wins, 175)
+        for i, w in enumerate(wins):
+            pairs, starts = ix.quick_map(w)
+            assert int(npairs[i]) == len(pairs), (name, i)
+            assert int(valid[i]) == ix.coverage_is_valid(starts, len(w), 175), (name, i)
+        if name == "same8":
+            assert ctx.stat("group_overflows") == 0 and ctx.stat("group_classes") <= 436         # eight windows, one set of classes
+    # eight windows of eight different clones, every offset of each one a read class of its own: 3,000 distinct classes do not fit a
+    # group's table (2,048), the group is left to k_window_pairs
+    for name, wins in (("eight_clones", [t[20:506] for t in rep.clones[:8]]),
+                       ("shifted", [t[s:s + 486] for s in (0, 5, 11, 17, 23, 29, 37, 41) for t in rep.clones])):
+        valid, npairs = ctx.window_score(wins, 175)
+        if name == "eight_clones":
+            assert ctx.stat("group_overflows") == 1
+        for i, w in enumerate(wins):
+            pairs, starts = ix.quick_map(w)
+            assert int(npairs[i]) == len(pairs), (name, i)
+            assert int(valid[i]) == ix.coverage_is_valid(starts, len(w), 175), (name, i)
+    # longer than the grouped kernel takes (more than 512 offsets): k_window_pairs alone
+    long_w = [t[:600] for t in rep.clones]
+    valid, npairs = ctx.window_score(long_w, 175, e1=500)
+    for i, w in enumerate(long_w):
+        pairs, starts = ix.quick_map(w)
+        assert int(npairs[i]) == len(pairs), ("long", i)
+    p.free()
