@@ -29,6 +29,6 @@ for it in range(4):
     torch.cuda.synchronize()
     del g, p
 pr = ctx.profile_get()
-print("dbg", sys.argv[1], {k: round(v[0] / max(v[1], 1), 3) for k, v in pr.items() if "reduce" in k or "part" in k})
+print("dbg", sys.argv[1], {k: round(v[0] / max(v[1], 1), 3) for k, v in pr.items() if "reduce" in k or "part" in k or "walk" in k or "recount" in k})
 if os.environ.get("VDJX_WALK_DBG"):
     print("walk:", {n: ctx.stat("walk_dbg_" + n) for n in ("rows", "rounds", "filter", "lookup", "chain", "item_trips")}, {k: round(v[0] / max(v[1], 1), 3) for k, v in pr.items() if "walk" in k})
