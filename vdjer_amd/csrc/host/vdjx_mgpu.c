@@ -19,11 +19,16 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+enum { WS_SDIR, WS_RDIR, WS_SPARTS, WS_RPARTS, WS_META, WS_Q, WS_RQ, WS_ANS, WS_RANS, WS_SURV, WS_SURV_ALL, WS_MINS, WS_UCNT, WS_SLOTS };
 struct vdjx_mgpu {
 	int rank, nranks, device;
 	ncclComm_t comm;
 	hipStream_t stream;
 	uint64_t bytes_sent;
+	/* the build's exchange buffers: one per purpose, kept by the handle and only replaced when a build needs more (a process that
+	 * builds again -- a second chain, the next sample -- allocates nothing) */
+	void* ws[WS_SLOTS];
+	size_t ws_cap[WS_SLOTS];
 };
 
 static __thread char g_err[512];
@@ -35,9 +40,24 @@ static void set_err(const char* fmt, ...) {
 }
 const char* vdjx_mgpu_last_error(void) { return g_err; }
 
+/* buffer `slot` of at least `bytes` bytes (contents undefined) */
+static int ws_get(vdjx_mgpu* m, int slot, size_t bytes, void** out) {
+	if (bytes > m->ws_cap[slot]) {
+		if (m->ws[slot]) (void) hipFree(m->ws[slot]);
+		m->ws[slot] = NULL; m->ws_cap[slot] = 0;
+		const size_t want = bytes + bytes / 8 + 256;
+		const hipError_t e = hipMalloc(&m->ws[slot], want);
+		if (e != hipSuccess) { set_err("hipMalloc of %zu bytes (exchange buffer %d): %s", want, slot, hipGetErrorString(e)); return VDJX_EHIP; }
+		m->ws_cap[slot] = want;
+	}
+	*out = m->ws[slot];
+	return 0;
+}
+
 #define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err("%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); rc = -2; goto done; } } while (0)
 #define NCCLC(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { set_err("%s: %s (%s:%d)", #x, ncclGetErrorString(r_), __FILE__, __LINE__); rc = -5; goto done; } } while (0)
 #define VX(x) do { int r_ = (x); if (r_ != 0) { set_err("%s: %s", #x, vdjx_last_error()); rc = r_; goto done; } } while (0)
+#define WSG(slot, bytes, out) do { void* p_ = NULL; const int r_ = ws_get(m, slot, (size_t) (bytes), &p_); if (r_) { rc = r_; goto done; } *(out) = p_; } while (0)
 
 int vdjx_mgpu_unique_id(void* out128) {
 	ncclUniqueId id;
@@ -81,6 +101,7 @@ void vdjx_mgpu_free(vdjx_mgpu* m) {
 	(void) hipSetDevice(m->device);
 	if (m->comm) (void) ncclCommDestroy(m->comm);
 	if (m->stream) (void) hipStreamDestroy(m->stream);
+	for (int i = 0; i < WS_SLOTS; i++) if (m->ws[i]) (void) hipFree(m->ws[i]);
 	free(m);
 }
 
@@ -135,9 +156,9 @@ int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int
 	uint32_t dl = 0;
 	VX(vdjx_shard_local(sh, send_counts, &dl));
 	const size_t ndir = (size_t) G * dl;
-	HIPC(hipMalloc(&d_sdir, ndir * 4 + 16));
-	HIPC(hipMalloc(&d_rdir, ndir * 4 + 16));
-	HIPC(hipMalloc(&d_sparts, sum64(send_counts, G) * W0 + 16));
+	WSG(WS_SDIR, ndir * 4 + 16, &d_sdir);
+	WSG(WS_RDIR, ndir * 4 + 16, &d_rdir);
+	WSG(WS_SPARTS, sum64(send_counts, G) * W0 + 16, &d_sparts);
 	VX(vdjx_shard_local_fill(sh, d_sdir, d_sparts));
 	for (int r = 0; r < G; r++) eq[r] = dl;
 	if ((rc = a2av(m, d_sdir, eq, d_rdir, eq, 4))) goto done;
@@ -148,12 +169,12 @@ int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int
 		for (uint32_t i = 0; i < dl; i++) s += h_rdir[(size_t) r * dl + i];
 		recv_counts[r] = s;
 	}
-	HIPC(hipMalloc(&d_rparts, sum64(recv_counts, G) * W0 + 16));
+	WSG(WS_RPARTS, sum64(recv_counts, G) * W0 + 16, &d_rparts);
 	if ((rc = a2av(m, d_sparts, send_counts, d_rparts, recv_counts, W0))) goto done;
 	/* 3. owners merge and decide; questions and answers for the few open k-mers */
 	VX(vdjx_shard_merge(sh, d_rdir, d_rparts, recv_counts, q_out));
 	/* everybody learns everybody's question counts, survivor count and distinct count in one small all-gather */
-	HIPC(hipMalloc(&d_meta, (size_t) G * (size_t) (G + 2) * 8 + 16));
+	WSG(WS_META, (size_t) G * (size_t) (G + 2) * 8 + 16, &d_meta);
 	{
 		uint64_t* mine = meta + (size_t) me * (G + 2);
 		memcpy(mine, q_out, (size_t) G * 8);
@@ -164,10 +185,10 @@ int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int
 		HIPC(hipMemcpy(meta, d_meta, (size_t) G * (G + 2) * 8, hipMemcpyDeviceToHost));
 		for (int r = 0; r < G; r++) q_in[r] = meta[(size_t) r * (G + 2) + me];
 	}
-	HIPC(hipMalloc(&d_q, sum64(q_out, G) * W1 + 16));
-	HIPC(hipMalloc(&d_rq, sum64(q_in, G) * W1 + 16));
-	HIPC(hipMalloc(&d_ans, sum64(q_in, G) * W2 + 16));
-	HIPC(hipMalloc(&d_rans, sum64(q_out, G) * W2 + 16));
+	WSG(WS_Q, sum64(q_out, G) * W1 + 16, &d_q);
+	WSG(WS_RQ, sum64(q_in, G) * W1 + 16, &d_rq);
+	WSG(WS_ANS, sum64(q_in, G) * W2 + 16, &d_ans);
+	WSG(WS_RANS, sum64(q_out, G) * W2 + 16, &d_rans);
 	VX(vdjx_shard_queries(sh, d_q));
 	if ((rc = a2av(m, d_q, q_out, d_rq, q_in, W1))) goto done;
 	VX(vdjx_shard_reply(sh, d_rq, q_in, d_ans));
@@ -184,8 +205,8 @@ int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int
 	}
 	uint64_t ns_total = 0, pre_total = 0;
 	for (int r = 0; r < G; r++) { recv_counts[r] = meta[2 * r]; ns_total += meta[2 * r]; pre_total += meta[2 * r + 1]; send_counts[r] = ns; }
-	HIPC(hipMalloc(&d_surv, ns * W3 + 16));
-	HIPC(hipMalloc(&d_surv_all, ns_total * W3 + 16));
+	WSG(WS_SURV, ns * W3 + 16, &d_surv);
+	WSG(WS_SURV_ALL, ns_total * W3 + 16, &d_surv_all);
 	VX(vdjx_shard_survivors(sh, d_surv));
 	{
 		/* every rank's survivors to every rank, in pieces of at most A2A_CHUNK (see a2av); the own ones by a device copy */
@@ -217,8 +238,8 @@ int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int
 		for (int r = 0; r < G; r++) if (r != me) m->bytes_sent += ns * W3;
 		HIPC(hipStreamSynchronize(m->stream));
 	}
-	HIPC(hipMalloc(&d_mins, ns_total * 5 * 8 + 16));          /* in-edge first sights [4n] | node first sights [n] */
-	HIPC(hipMalloc(&d_ucnt, ns_total * 4 + 16));
+	WSG(WS_MINS, ns_total * 5 * 8 + 16, &d_mins);          /* in-edge first sights [4n] | node first sights [n] */
+	WSG(WS_UCNT, ns_total * 4 + 16, &d_ucnt);
 	VX(vdjx_shard_edges(sh, d_surv_all, ns_total, d_mins, d_ucnt, (char*) d_mins + ns_total * 32));
 	if (ns_total) {
 		for (size_t a = 0; a < ns_total * 5; a += A2A_CHUNK / 8) {                                       /* all-ones = none stays largest */
@@ -236,9 +257,6 @@ int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int
 	VX(vdjx_shard_finish(sh, d_mins, d_ucnt, (char*) d_mins + ns_total * 32, pre_total, out));
 done:
 	if (sh) vdjx_shard_free(sh);
-	(void) hipFree(d_sdir); (void) hipFree(d_rdir); (void) hipFree(d_sparts); (void) hipFree(d_rparts); (void) hipFree(d_q); (void) hipFree(d_rq);
-	(void) hipFree(d_ans); (void) hipFree(d_rans); (void) hipFree(d_meta); (void) hipFree(d_surv); (void) hipFree(d_surv_all); (void) hipFree(d_mins);
-	(void) hipFree(d_ucnt);
 	free(h_rdir); free(send_counts); free(recv_counts); free(q_out); free(q_in); free(eq); free(meta);
 	return rc;
 }
