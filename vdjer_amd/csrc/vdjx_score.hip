@@ -725,6 +725,12 @@ __global__ __launch_bounds__(1024) void k_plan(const u32* __restrict__ hits, con
 //    pairs (stored once in a scratch list) for every batch, prefixes, and tests.
 // ----------------------------------------------------------------------------------------------
 #define COV_WORDS 8192
+#ifndef COVER_CHUNK0
+#define COVER_CHUNK0 512u               // first replayed chunk of rule 2 (then doubling): a few hundred scattered entries cover a valid window (4096: 0.82 ms, 512: 0.77)
+#endif
+#ifndef COVER_RULE2
+#define COVER_RULE2 true             // (ablation: -DCOVER_RULE2=false)
+#endif
 #define HIT_CHUNK 524288u        // hits per workgroup of k_window_pairs: only the very deepest windows are split (every piece loads the
                                  // window's image once; measured at 10 M pairs: 65536 -> 5.2 ms, 262144 and above -> 3.5 ms)
 
@@ -1212,11 +1218,11 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 	__syncthreads();
 	// ---- rule 2.  Coverage only grows with more entries, so the pair list is replayed in doubling chunks and
 	// a batch of deltas is done as soon as every tested (pos, delta) already reaches the floor.
-	for (int d0 = clo; d0 < chi && !s_bad; d0 += DB) {
+	for (int d0 = clo; d0 < chi && !s_bad && COVER_RULE2; d0 += DB) {
 		const int nd = chi - d0 < DB ? chi - d0 : DB;
 		for (int i = tid; i < nd * stride; i += MAP_THREADS) diff[i] = 0;
 		__syncthreads();
-		u32 done = 0, chunk = 4096;
+		u32 done = 0, chunk = COVER_CHUNK0;
 		const u32 tot = 2 * npairs;
 		const u64 perm_stride = (tot % 1000003u) ? 1000003ull : 1ull;      /* prime: a bijection on [0, tot) */
 		for (;;) {
