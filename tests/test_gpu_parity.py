@@ -783,6 +783,8 @@ def test_grouped_window_mapper_edge_cases(ctx):
     kernel did the work."""
     from oracle import oracle
     from vdjer_amd import synth
+    import os
+    grouping = os.environ.get("VDJX_WINDOW_GROUP") != "0"        # (this test runs again with grouping off: test_window_scorer_without_grouping_...)
     rng = np.random.default_rng(77)
     rep = synth.make_repertoire(9, seed=4321)
     # a clone with a tandem repeat inside its window: reads of the repeat unit recur at several offsets of the same window
@@ -808,14 +810,14 @@ def test_grouped_window_mapper_edge_cases(ctx):
             pairs, starts = ix.quick_map(w)
             assert int(npairs[i]) == len(pairs), (name, i)
             assert int(valid[i]) == ix.coverage_is_valid(starts, len(w), 175), (name, i)
-        if name == "same8":
+        if name == "same8" and grouping:
             assert ctx.stat("group_overflows") == 0 and ctx.stat("group_classes") <= 436         # eight windows, one set of classes
     # eight windows of eight different clones, every offset of each one a read class of its own: 3,000 distinct classes do not fit a
     # group's table (2,048), the group is left to k_window_pairs
     for name, wins in (("eight_clones", [t[20:506] for t in rep.clones[:8]]),
                        ("shifted", [t[s:s + 486] for s in (0, 5, 11, 17, 23, 29, 37, 41) for t in rep.clones])):
         valid, npairs = ctx.window_score(wins, 175)
-        if name == "eight_clones":
+        if name == "eight_clones" and grouping:
             assert ctx.stat("group_overflows") == 1
         for i, w in enumerate(wins):
             pairs, starts = ix.quick_map(w)
