@@ -587,22 +587,6 @@ __device__ inline bool map_eval_entry(const MapImg<NOFF>& L, int rl, int o, cons
 	return true;
 }
 
-// a lane's walk through the flat hit sequence: hits are visited in increasing order, so the offset only moves forward and the class
-// bounds stay in registers until a hit leaves the class
-struct HitCursor {
-	int o; u32 lo, hi, cs;
-	template <int NOFF> __device__ inline void start(const MapImg<NOFF>& L, int o0) { o = o0; lo = L.hpre[o]; hi = L.hpre[o + 1]; cs = L.cstart[o]; }
-	// h >= hpre[o] on entry (o is a lower bound); -> index of hit h's entry
-	template <int NOFF> __device__ inline u32 seek(const MapImg<NOFF>& L, u32 h, int o_min) {
-		if (o_min > o) { o = o_min; hi = L.hpre[o + 1]; if (h < hi) { lo = L.hpre[o]; cs = L.cstart[o]; } }
-		if (h >= hi) {
-			do { o++; hi = L.hpre[o + 1]; } while (h >= hi);              // (few steps: 64 hits span few classes; empty ones are skipped)
-			lo = L.hpre[o]; cs = L.cstart[o];
-		}
-		return cs + (h - lo);
-	}
-};
-
 // ----------------------------------------------------------------------------------------------
 // planning on the device: offsets of the strings' hit lists, processing order (largest first), work items
 // ----------------------------------------------------------------------------------------------
@@ -1302,7 +1286,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 // many; the gather below lays the slices end to end, which is the reference's order (offset-major, registration order inside
 // a class).  One workgroup per contig left half the GPU idle and walked ~20 k hits sequentially.
 // ----------------------------------------------------------------------------------------------
-#define ME_K 8                    // rows of 64 consecutive hits per wave and round
+#ifndef ME_K
+#define ME_K 8                    // rows of 64 consecutive hits per wave and round (10: 0.77 ms, 12: 0.82 with 5 spilled registers, 16: 1.30)
+#define ME_WAVES 8
+#endif
 #define ME_Q 128
 // A slice writes its mapped pairs at the start of its own region (region offset = hit offset: pairs <= hits) in ANY order, each with
 // the number of its hit, and marks the hit in the slice's bitmap; k_gather_pairs puts every pair at the rank of its hit among the
@@ -1310,7 +1297,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 // of the order of evaluation.  The sweep is the one of k_window_pairs: presence test over the flat hits, dense queue for the full
 // test.
 template <int NOFF>
-__global__ __launch_bounds__(MAP_THREADS, 6) void k_map_emit(ReadIndexDev ix, const uint4* __restrict__ prep, u32 n, int len, u32 slice_hits,
+__global__ __launch_bounds__(MAP_THREADS, ME_WAVES) void k_map_emit(ReadIndexDev ix, const uint4* __restrict__ prep, u32 n, int len, u32 slice_hits,
                                                           const u32* __restrict__ slice_start, const u64* __restrict__ region_off,
                                                           vdjx_pair* __restrict__ pairs, u32* __restrict__ pair_hit, u32* __restrict__ slice_bits,
                                                           u32* __restrict__ slice_cnt) {
@@ -1382,15 +1369,17 @@ __global__ __launch_bounds__(MAP_THREADS, 6) void k_map_emit(ReadIndexDev ix, co
 		}
 		u64 ent[ME_K];
 		u32 oo[ME_K / 2];
-		HitCursor cu;
-		cu.start(L, __builtin_amdgcn_readlane(orow, 0));
 #pragma unroll
 		for (int u = 0; u < ME_K; u++) {
 			const u32 h = hb + (u32) (u * 64 + lane);
+			int o = __builtin_amdgcn_readlane(orow, u);
 			u64 e = ~0ull;
-			if (h < h1) e = ix.csr8[cu.seek(L, h, __builtin_amdgcn_readlane(orow, u))];
+			if (h < h1) {
+				while (h >= L.hpre[o + 1]) o++;                 // (few steps: a row of 64 hits spans few classes; empty ones are skipped)
+				e = ix.csr8[L.cstart[o] + (h - L.hpre[o])];
+			}
 			ent[u] = e;
-			if (u & 1) oo[u >> 1] |= (u32) cu.o << 16; else oo[u >> 1] = (u32) cu.o;
+			if (u & 1) oo[u >> 1] |= (u32) o << 16; else oo[u >> 1] = (u32) o;
 		}
 #pragma unroll
 		for (int u = 0; u < ME_K; u++) {
