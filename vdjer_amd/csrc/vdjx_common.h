@@ -22,8 +22,8 @@ typedef unsigned __int128 u128;
 #define RI_RC 2u        // its is_rc flag
 #define RI_RCA 4u       // is_rc of the pair's read-2 record A (registered first)
 #define RI_RCB 8u       // is_rc of the pair's read-2 record B (registered last)
-// words per slot of the read index's lookup table: the read (W words) + three words of class data, rounded up to even
-#define VDJX_RI_SLOT_WORDS(W) (((W) + 4) & ~1)
+// words per slot of the read index's lookup table: the read (W words) + three words of class data
+#define VDJX_RI_SLOT_WORDS(W) 8     // (64 bytes: W <= 5 words of key + 3 of class data; a 48-byte slot lay across two 64-byte lines half of the time)
 // an 8-byte entry: class of the pair's read-2 record A (26 bits, all ones = none) | class of B (26) | flags (4) | multiplicity (8)
 #define RI_ENT_NONE 0x3FFFFFFu
 #define RI_ENT_MAXCNT 255u

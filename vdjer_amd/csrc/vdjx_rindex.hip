@@ -2,7 +2,7 @@
 //
 // replaces add_read_info (quick_map3.c:126-149): a map "read sequence -> its instances in registration order", filled once per
 // record by extract (bam_read.c:228,243).  What the mapper kernels (vdjx_score.hip) read:
-//   tab[]            open-addressing table over the distinct read sequences (classes), 48-byte slots {sequence, class + 1, members,
+//   tab[]            open-addressing table over the distinct read sequences (classes), 64-byte slots {sequence, class + 1, members,
 //                    CSR start, first weighted entry, weighted entries}: everything the classification of a window offset needs
 //                    in one probe (the build's own table names records and is dropped)
 //   start[cls]       CSR of the class's READ-1 members in registration order (read-2 instances only ever feed the "read2" map,
@@ -235,7 +235,7 @@ __global__ void k_ri_dstart(const u32* __restrict__ start, u32 ncls, const u32* 
 }
 
 // the lookup table the mapper reads: one slot per class = the sequence (W words), then {class + 1 | read-1 members << 32}, {CSR start |
-// first weighted entry << 32}, {weighted entries}: W + 3 words rounded up to an even number (48 bytes; 64 for reads of more than 64 bases)
+// first weighted entry << 32}, {weighted entries}: W + 3 words in a 64-byte slot (one line per probe)
 template <int W>
 __global__ void k_ri_tab(const u32* __restrict__ rep, u32 ncls, const u64* __restrict__ bases, const u32* __restrict__ cnt1, const u32* __restrict__ start,
                          const u32* __restrict__ dstart, u64* __restrict__ tab, u32 mask) {
