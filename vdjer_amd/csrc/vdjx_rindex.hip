@@ -419,6 +419,12 @@ int check_args(vdjx_ctx* c, const vdjx_pool* pool, const void* a, const void* b,
 }
 }  // namespace
 
+// the same sort for a caller with its own allocator (vdjx_kmer.hip: node numbering): tmp == nullptr asks for the scratch size
+int vdjx_sort_pairs_raw(void* tmp, size_t* tmp_bytes, hipStream_t st, u64* k_in, u64* k_out, u32* v_in, u32* v_out, u32 n, unsigned end_bit) {
+	HIP_TRY(rocprim::radix_sort_pairs(tmp, *tmp_bytes, k_in, k_out, v_in, v_out, (size_t) n, 0u, end_bit, st));
+	return VDJX_OK;
+}
+
 // (the scorers sort their strings with the same helper: vdjx_score.hip)
 int vdjx_sort_pairs(vdjx_work& db, hipStream_t st, u64* k_in, u64* k_out, u32* v_in, u32* v_out, u32 n, unsigned end_bit) {
 	return sort_pairs(db, st, k_in, k_out, v_in, v_out, n, end_bit);
