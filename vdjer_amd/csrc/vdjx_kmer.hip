@@ -568,7 +568,7 @@ __device__ inline u32 rd_count_min(u32* cnt, u64* mn, u32 idx, u64 val, bool act
 }
 
 template <typename TUP>
-__global__ __launch_bounds__(RD_THREADS, RD_WAVES) void k_gated_reduce(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
+__global__ __launch_bounds__(RD_THREADS, sizeof(TUP) == 16 ? RD_WAVES : RD_WAVES / 2) void k_gated_reduce(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
                                                              const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                              vdjx_qrows quals, int rl, int ob, int k, u64 rec_base,
                                                              u32 mf, u32 cmin, u32 mqq, u32 tlow, SurvOutG so,
