@@ -311,6 +311,8 @@ print("KNOB_CASE_OK", g.n, g.pre_nodes)
     (35, 3, 90, {"VDJX_GATED_BUCKET": "4", "VDJX_REFINE_TUPLES": "4"}),                             # > 2^15 buckets: counting pass + 1024-way pass 2
     (25, 2, 60, {"VDJX_GATED_BUCKET": "16", "VDJX_REFINE_TUPLES": "50", "VDJX_SUB_TUPLES": "64"}),     # long buckets split up front (verified dry run)
     (35, 3, 90, {"VDJX_GATED_BUCKET": "100000", "VDJX_SUB_TUPLES": "1000000000"}),                   # few huge buckets: table overflow -> sub-passes
+    (35, 3, 90, {"VDJX_RD_DBG": "9"}),                                                               # table + prune: the list of unsettled tuples "ran over": second sweep by rescan
+    (25, 2, 60, {"VDJX_RD_DBG": "9", "VDJX_GATED_BUCKET": "100000", "VDJX_SUB_TUPLES": "1000000000"}),   # ... inside hash-selected sub-passes
     (35, 3, 90, {"VDJX_RC_MAX_RANGES": "4", "VDJX_RC_MAX_SHIFT": "9", "VDJX_RC_WIDE": "1"}),         # recount: two partition levels, 64-bit ids
     (25, 2, 60, {"VDJX_RC_MAX_RANGES": "8", "VDJX_RC_MAX_SHIFT": "12"}),                             # recount: the largest ranges
     (35, 3, 90, {"VDJX_RC_LEN_BITS": "0"}),                                                          # > 2^25 survivors: one item per instance

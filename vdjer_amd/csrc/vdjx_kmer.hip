@@ -605,7 +605,7 @@ __global__ __launch_bounds__(RD_THREADS, sizeof(TUP) == 16 ? RD_WAVES : RD_WAVES
 		__syncthreads();
 		for (u32 s = 0; s < S; s++) {
 			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) { s_khi[i] = EMPTY; s_cnt[i] = 0; s_first[i] = NONE64; s_state[i] = 0; }
-			if (tid == 0) { s_nlow = 0; s_npq = n >> (32 - RD_SLOT_BITS) ? RD_PQ + 1 : 0; s_nsurv = 0; }     // (an index that does not fit an entry: rescan)
+			if (tid == 0) { s_nlow = 0; s_npq = (n >> (32 - RD_SLOT_BITS) || dbg == 9) ? RD_PQ + 1 : 0; s_nsurv = 0; }     // (an index that does not fit an entry: rescan; VDJX_RD_DBG=9: the tests' way into the rescan)
 			__syncthreads();
 			// ---- sweep 1
 			for (u32 t0 = 0; t0 < n; t0 += RD_UNR * RD_THREADS) {
