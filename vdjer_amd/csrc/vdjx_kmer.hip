@@ -790,10 +790,17 @@ struct Partial { u64 lo, hi; u32 cg, pad; u64 fg; };     // 32 bytes, what trave
 #define REPLY_KQ 52                 // quality bytes per row (k <= 50)
 #define REPLY_BYTES 200             // pid | need, first instance (u64), 16-B bases, 8-B N mask, 3 quality rows
 
-// this rank's partial aggregates of one bucket of its gated tuples (see k_gated_reduce for the table): count, first instance,
-// "saw two different reads" against its own first record; k-mers whose count is below TLOW also list their instances
+// this rank's partial aggregates of one bucket of its gated tuples: count, first instance, "saw two different reads" (any two:
+// the owner ORs the ranks' flags and compares their first records); k-mers whose count is below TLOW also list their instances.
+// The sweeps are k_gated_reduce's: settled tuples (k-mer proven, TLOW instances deep) are done after the first, the others are
+// listed and visited by a second, dense one (a list that runs over: rescan).  A low-count k-mer's fill counter sits in the upper
+// half of its count word (the count is below TLOW <= 12).
+#define LG_THREADS 768
+#define LG_UNR 4
+#define LG_FLAG 0x80000000u
+#define LG_NOLIST 0x7FFFFFFFu
 template <typename TUP>
-__global__ __launch_bounds__(K3_THREADS) void k_gated_local(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
+__global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated_local(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
                                                             const u64* __restrict__ bases, const u64* __restrict__ nmask, u64 rec_base, int k,
                                                             u32 tlow, Partial* __restrict__ sparse_g, u32* __restrict__ sparse_ref,
                                                             u32* __restrict__ nd_g, u64* __restrict__ low_inst, u32* __restrict__ g_err) {
@@ -801,8 +808,10 @@ __global__ __launch_bounds__(K3_THREADS) void k_gated_local(const TUP* __restric
 	__shared__ u64 s_klo[LOCAL_SLOTS];
 	__shared__ THI s_khi[LOCAL_SLOTS];
 	__shared__ u64 s_mg[LOCAL_SLOTS];
-	__shared__ u32 s_cg[LOCAL_SLOTS], s_loff[LOCAL_SLOTS], s_lfill[LOCAL_SLOTS], s_fl[LOCAL_SLOTS];
-	__shared__ u32 s_ng, s_nlow, s_over;
+	__shared__ u32 s_cg[LOCAL_SLOTS], s_st[LOCAL_SLOTS];        // s_st: LG_FLAG | offset of the k-mer's instance list in the bucket (LG_NOLIST: none)
+	__shared__ u32 pq[RD_PQ];
+	__shared__ u32 s_ng, s_nlow, s_over, s_npq;
+	static_assert(LOCAL_SLOTS == (1u << RD_SLOT_BITS), "list entries carry the slot in RD_SLOT_BITS bits");
 	const THI EMPTY = (THI) ~(THI) 0;
 	const u32 b = blockIdx.x;
 	const u32 base = bucket_start[b];
@@ -815,86 +824,111 @@ __global__ __launch_bounds__(K3_THREADS) void k_gated_local(const TUP* __restric
 	for (;;) {
 		if (tid == 0) { s_ng = 0; s_nlow = 0; s_over = 0; }
 		for (u32 s = 0; s < S; s++) {
-			for (u32 i = tid; i < LOCAL_SLOTS; i += K3_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE64; s_lfill[i] = 0; s_fl[i] = 0; }
+			for (u32 i = tid; i < LOCAL_SLOTS; i += LG_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE64; s_st[i] = 0; }
+			if (tid == 0) s_npq = n >> (32 - RD_SLOT_BITS) ? RD_PQ + 1 : 0;
 			__syncthreads();
-			const bool one_chunk = n <= K3_UNR * K3_THREADS;
-			TUP r_t[K3_UNR];
-			int r_slot[K3_UNR];
-			for (u32 t0 = 0; t0 < n; t0 += K3_UNR * K3_THREADS) {
+			// ---- sweep 1 (k_gated_reduce)
+			for (u32 t0 = 0; t0 < n; t0 += LG_UNR * LG_THREADS) {
+				TUP r_t[LG_UNR];
 #pragma unroll
-				for (int j = 0; j < K3_UNR; j++) {
-					const u32 t = t0 + j * K3_THREADS + tid;
-					r_slot[j] = -2;
-					if (t < n) { r_t[j] = TUP::load(&T[t]); r_slot[j] = -1; }
+				for (int j = 0; j < LG_UNR; j++) {
+					const u32 t = t0 + j * LG_THREADS + tid;
+					if (t < n) r_t[j] = TUP::load(&T[t]);
 				}
 #pragma unroll
-				for (int j = 0; j < K3_UNR; j++) {
-					int slot = -1;                                                // (see k_gated_reduce: nobody leaves early, same-slot lanes are folded)
-					if (r_slot[j] != -2) {
-						const u64 h = vdjx_mix(r_t[j].lo, r_t[j].hi());
-						if (!(S > 1 && (u32) ((h >> 12) & (S - 1)) != s)) {
-							slot = lds_insert<THI, LOCAL_SLOTS>(s_klo, s_khi, r_t[j].lo, (THI) r_t[j].hi(), (u32) h);
+				for (int j = 0; j < LG_UNR; j++) {
+					const u32 t = t0 + j * LG_THREADS + tid;
+					int slot = -1;
+					if (t < n) {
+						const u32 h = rd_hash(r_t[j].lo, r_t[j].hi());
+						if (!(S > 1 && ((h >> 12) & (S - 1)) != s)) {
+							slot = lds_insert<THI, LOCAL_SLOTS>(s_klo, s_khi, r_t[j].lo, (THI) r_t[j].hi(), h);
 							if (slot < 0) s_over = 1;
-							else r_slot[j] = slot;
 						}
 					}
-					vdjx_lds_count_min64(s_cg, s_mg, (u32) (slot < 0 ? 0 : slot), r_t[j].inst(), slot >= 0);
+					const bool live = slot >= 0;
+					const u64 inst = r_t[j].inst();
+					const u32 c0 = rd_count_min(s_cg, s_mg, (u32) (live ? slot : 0), inst, live);
+					bool list = false;
+					if (live) {
+						u32 st = vdjx_peek(&s_st[slot]);
+						if (!(st & LG_FLAG)) {
+							const u64 f = vdjx_peek(&s_mg[slot]);
+							if (f != NONE64 && (f >> 6) != (inst >> 6)) {
+								const u32 o1 = (u32) inst & 63u, o0 = (u32) f & 63u;
+								const u32 d = o1 > o0 ? o1 - o0 : o0 - o1;
+								if (d && d < (u32) k && !vdjx_kmer_has_period(r_t[j].hi(), r_t[j].lo, k, d)) { atomicOr(&s_st[slot], LG_FLAG); st |= LG_FLAG; }
+							}
+						}
+						list = !((st & LG_FLAG) && c0 + 1 >= tlow);
+					}
+					const u32 qi = vdjx_wave_inc(&s_npq, list);
+					if (list && qi < RD_PQ) pq[qi] = (t << RD_SLOT_BITS) | (u32) slot;
 				}
 			}
 			__syncthreads();
 			if (s_over) break;
 			// keys whose count alone cannot pass the quality test (count < TLOW) list their instances: the owner may ask
-			for (u32 i = tid; i < LOCAL_SLOTS; i += K3_THREADS) {
+			for (u32 i = tid; i < LOCAL_SLOTS; i += LG_THREADS) {
 				const u32 cg = s_cg[i];
-				s_loff[i] = (cg && cg < tlow) ? atomicAdd(&s_nlow, cg) : NONE32;
+				s_st[i] = (s_st[i] & LG_FLAG) | ((cg && cg < tlow) ? atomicAdd(&s_nlow, cg) : LG_NOLIST);
 			}
 			__syncthreads();
-			// sweep 2: the lists, and the distinct-read flag against this rank's first record (compare_read, A2:142-144, 349-352)
-			for (u32 t0 = 0; t0 < n; t0 += K3_UNR * K3_THREADS) {
-#pragma unroll
-				for (int j = 0; j < K3_UNR; j++) {
-					if (!one_chunk) {
-						const u32 t = t0 + j * K3_THREADS + tid;
-						r_slot[j] = -2;
-						if (t < n) {
-							r_t[j] = TUP::load(&T[t]);
-							const u64 h = vdjx_mix(r_t[j].lo, r_t[j].hi());
-							r_slot[j] = (S > 1 && (u32) ((h >> 12) & (S - 1)) != s) ? -1 : lds_lookup<THI, LOCAL_SLOTS>(s_klo, s_khi, r_t[j].lo, (THI) r_t[j].hi(), (u32) h);
-						}
-					}
+			// ---- sweep 2 over the listed tuples (or the bucket): the lists, and the exact distinct-read rule for keys still open
+			const bool listed = s_npq <= RD_PQ;
+			const u32 nscan = listed ? s_npq : n;
+			for (u32 e = tid; e < nscan; e += LG_THREADS) {
+				u32 slot;
+				TUP x;
+				if (listed) {
+					slot = pq[e] & (LOCAL_SLOTS - 1);
+					const u32 st0 = vdjx_peek(&s_st[slot]);
+					if ((st0 & LG_NOLIST) == LG_NOLIST && (st0 & LG_FLAG)) continue;       // (neither a list nor an open flag)
+					x = TUP::load(&T[pq[e] >> RD_SLOT_BITS]);
+				} else {
+					x = TUP::load(&T[e]);
+					const u32 h = rd_hash(x.lo, x.hi());
+					if (S > 1 && ((h >> 12) & (S - 1)) != s) continue;
+					const int sl = lds_lookup<THI, LOCAL_SLOTS>(s_klo, s_khi, x.lo, (THI) x.hi(), h);
+					if (sl < 0) continue;
+					slot = (u32) sl;
 				}
-#pragma unroll
-				for (int j = 0; j < K3_UNR; j++) {
-					const int slot = r_slot[j];
-					if (slot < 0) continue;
-					const u64 inst = r_t[j].inst();
-					if (s_loff[slot] != NONE32) low_inst[base + s_loff[slot] + atomicAdd(&s_lfill[slot], 1u)] = inst;
-					if (s_cg[slot] < 2 || vdjx_peek(&s_fl[slot])) continue;
-					const u64 fi = s_mg[slot];
-					const u64 rec = (inst >> 6) - rec_base, frec = (fi >> 6) - rec_base;
-					if (rec != frec) {
-						const u32 o1 = (u32) (inst & 63u), o0 = (u32) (fi & 63u);             // (see k_gated_reduce)
-						const u32 d = o1 > o0 ? o1 - o0 : o0 - o1;
-						if (d && d < (u32) k && !vdjx_kmer_has_period(r_t[j].hi(), r_t[j].lo, k, d)) s_fl[slot] = 1;
-						else {
-							const ulonglong2 x = ((const ulonglong2*) bases)[rec];
-							const ulonglong2 y = ((const ulonglong2*) bases)[frec];
-							if (x.x != y.x || x.y != y.y || nmask[rec] != nmask[frec]) s_fl[slot] = 1;
-						}
+				const u32 st = vdjx_peek(&s_st[slot]);
+				const u32 loff = st & LG_NOLIST;
+				const u64 inst = x.inst();
+				u32 cg = vdjx_peek(&s_cg[slot]);
+				if (loff != LG_NOLIST) {
+					cg &= 0xFFFFu;
+					low_inst[base + loff + (atomicAdd(&s_cg[slot], 0x10000u) >> 16)] = inst;
+				}
+				if (cg < 2 || (st & LG_FLAG)) continue;
+				const u64 fi = s_mg[slot];
+				const u64 rec = (inst >> 6) - rec_base, frec = (fi >> 6) - rec_base;
+				if (rec != frec) {
+					const u32 o1 = (u32) (inst & 63u), o0 = (u32) (fi & 63u);
+					const u32 d = o1 > o0 ? o1 - o0 : o0 - o1;
+					if (d && d < (u32) k && !vdjx_kmer_has_period(x.hi(), x.lo, k, d)) atomicOr(&s_st[slot], LG_FLAG);
+					else {
+						const ulonglong2 xa = ((const ulonglong2*) bases)[rec];
+						const ulonglong2 ya = ((const ulonglong2*) bases)[frec];
+						if (xa.x != ya.x || xa.y != ya.y || nmask[rec] != nmask[frec]) atomicOr(&s_st[slot], LG_FLAG);
 					}
 				}
 			}
 			__syncthreads();
-			for (u32 i = tid; i < LOCAL_SLOTS; i += K3_THREADS) {
+			for (u32 i = tid; i < LOCAL_SLOTS; i += LG_THREADS) {
 				if (s_khi[i] == EMPTY) continue;
+				const u32 st = s_st[i];
+				const u32 loff = st & LG_NOLIST;
+				const u32 cg = loff != LG_NOLIST ? s_cg[i] & 0xFFFFu : s_cg[i];
 				Partial p;
 				p.lo = s_klo[i]; p.hi = (u64) s_khi[i];
 				p.fg = s_mg[i];
-				p.cg = (s_cg[i] > CNT_CAP ? CNT_CAP : s_cg[i]) | (s_fl[i] ? PART_FLAG : 0u);
+				p.cg = (cg > CNT_CAP ? CNT_CAP : cg) | ((st & LG_FLAG) ? PART_FLAG : 0u);
 				p.pad = 0;
 				const u32 gi = atomicAdd(&s_ng, 1u);
 				sparse_g[base + gi] = p;
-				sparse_ref[base + gi] = s_loff[i] != NONE32 ? base + s_loff[i] : NONE32;
+				sparse_ref[base + gi] = loff != LG_NOLIST ? base + loff : NONE32;
 			}
 			__syncthreads();
 		}
@@ -2794,7 +2828,7 @@ static int shard_local_impl(vdjx_shard* s) {
 	}
 	{
 		vdjx_prof_scope ps(c, "k_gated_local");
-		hipLaunchKernelGGL(k_gated_local<TUP>, dim3(t.NB), dim3(K3_THREADS), 0, st, t.t, t.bucket_start, s->pool->d_bases, s->pool->d_nmask, rec_base,
+		hipLaunchKernelGGL(k_gated_local<TUP>, dim3(t.NB), dim3(LG_THREADS), 0, st, t.t, t.bucket_start, s->pool->d_bases, s->pool->d_nmask, rec_base,
 		                   s->k, s->tlow, sparse, sparse_ref, s->nd, s->low_inst, g_err);
 	}
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, s->nd, t.NB, s->dstart);
