@@ -994,6 +994,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 	__shared__ u64 s_mg[MERGE_SLOTS];
 	__shared__ u32 s_cg[MERGE_SLOTS], s_pid[MERGE_SLOTS], s_nsg[MERGE_SLOTS], s_fl[MERGE_SLOTS];
 	__shared__ u32 s_over, s_ndist, s_total, s_ns, s_np, s_sbase, s_pbase;
+	__shared__ u32 s_pend[MERGE_SLOTS / 32];               // bit h & (MERGE_SLOTS - 1): a k-mer with that home slot has a question open
 	const THI EMPTY = (THI) ~(THI) 0;
 	const u32 b = blockIdx.x;
 	const u32 tid = threadIdx.x;
@@ -1018,9 +1019,9 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 				const u32 off = seg_off[(size_t) s * (NBo + 1) + b * MG], cnt = seg_off[(size_t) s * (NBo + 1) + (b + 1) * MG] - off;
 				for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
 					const Partial p = recv[off + i];
-					const u64 h = vdjx_mix(p.lo, p.hi);
-					if ((u32) ((h >> 12) & (S - 1)) != sp) continue;
-					const int slot = lds_insert<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, (u32) h);
+					const u32 h = rd_hash(p.lo, p.hi);
+					if (((h >> 12) & (S - 1)) != sp) continue;
+					const int slot = lds_insert<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, h);
 					if (slot < 0) { s_over = 1; continue; }
 					atomicAdd(&s_cg[slot], p.cg & ~PART_FLAG);
 					atomicMin((unsigned long long*) &s_mg[slot], (unsigned long long) p.fg);
@@ -1033,6 +1034,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 			// decide; the global output counters are bumped ONCE per workgroup (a few addresses shared by every workgroup
 			// serialise in L2: per-k-mer or per-wave bumps cost more than the merge itself)
 			if (tid == 0) { s_ns = 0; s_np = 0; }
+			for (u32 i = tid; i < MERGE_SLOTS / 32; i += MERGE_THREADS) s_pend[i] = 0;
 			__syncthreads();
 			for (u32 i0 = 0; i0 < MERGE_SLOTS; i0 += MERGE_THREADS) {
 				const u32 i = i0 + tid;
@@ -1050,7 +1052,11 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 				if (live && cg < tlow) need |= NEED_Q;
 				if (live && !need) s_nsg[i] = 0x80000000u | atomicAdd(&s_ns, 1u);
 				else s_nsg[i] = 0;
-				if (live && need) s_pid[i] = atomicAdd(&s_np, 1u) | (need << 30);
+				if (live && need) {
+					s_pid[i] = atomicAdd(&s_np, 1u) | (need << 30);
+					const u32 hm = rd_hash(s_klo[i], (u64) s_khi[i]) & (MERGE_SLOTS - 1);
+					atomicOr(&s_pend[hm >> 5], 1u << (hm & 31));
+				}
 			}
 			__syncthreads();
 			if (tid == 0) {
@@ -1088,9 +1094,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 				u32 mine = 0;
 				for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
 					const Partial p = recv[off + i];
-					const u64 h = vdjx_mix(p.lo, p.hi);
-					if ((u32) ((h >> 12) & (S - 1)) != sp) continue;
-					const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, (u32) h);
+					const u32 h = rd_hash(p.lo, p.hi);
+					if (((h >> 12) & (S - 1)) != sp) continue;
+					if (!((s_pend[(h & (MERGE_SLOTS - 1)) >> 5] >> (h & 31)) & 1u)) continue;       // (few k-mers have a question open: most partials stop here)
+					const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, h);
 					if (slot >= 0 && s_pid[slot] != NONE32) mine++;
 				}
 				if (mine) atomicAdd(&s_ns, mine);
@@ -1100,9 +1107,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 				if (s_ns) {
 					for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
 						const Partial p = recv[off + i];
-						const u64 h = vdjx_mix(p.lo, p.hi);
-						if ((u32) ((h >> 12) & (S - 1)) != sp) continue;
-						const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, (u32) h);
+						const u32 h = rd_hash(p.lo, p.hi);
+						if (((h >> 12) & (S - 1)) != sp) continue;
+						if (!((s_pend[(h & (MERGE_SLOTS - 1)) >> 5] >> (h & 31)) & 1u)) continue;
+						const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, h);
 						if (slot < 0) continue;
 						const u32 pid = s_pid[slot];
 						if (pid != NONE32) queries[src_base[s] + s_sbase + atomicAdd(&s_np, 1u)] = make_uint2(off + i - src_base[s], pid);
