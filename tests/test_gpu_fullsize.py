@@ -185,14 +185,17 @@ print("PROD_SCORER_OK", len(wins), int(valid.sum()), int(pairs.shape[0]))
 '''
 
 
-def test_config2_10M_pairs_scorers_production_slicing_vs_oracle_digests():
+@pytest.mark.parametrize("grouped", ["1", "0"])
+def test_config2_10M_pairs_scorers_production_slicing_vs_oracle_digests(grouped):
     """The scorers exactly as bench.py times them -- shipped VDJX_HIT_CHUNK / slice sizes (the suite otherwise runs with 128-hit
     pieces, tests/conftest.py), all 20,000 generator windows, the mapped pairs of the 3,846 accepted ones -- against the oracle's
-    digests (`bench_scorers`, tests/golden/make_fullsize_digests.py --scorers-all).  Fresh process: the knobs are read once."""
+    digests (`bench_scorers`, tests/golden/make_fullsize_digests.py --scorers-all).  Fresh process: the knobs are read once.
+    Once with the windows mapped in groups of eight (k_group_pairs, the shipped way), once one by one (k_window_pairs alone)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = {k_: v for k_, v in os.environ.items() if k_ not in ("VDJX_HIT_CHUNK", "VDJX_MAP_SLICE")}
+    e["VDJX_WINDOW_GROUP"] = grouped
     r = subprocess.run([sys.executable, "-c", _PROD_SCORER_CASE % (root, root)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
     assert r.returncode == 0 and "PROD_SCORER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
