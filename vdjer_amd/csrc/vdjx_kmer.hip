@@ -2213,7 +2213,10 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 	u32 T = 8;
 	while (T < HB && ((u64) per << T) < Ng) T++;
 	u32 extra = 0;
-	if (T == HB && HB == 15 && Ng / NBH > 2 * (per_bucket ? per_bucket : refine)) {
+	// (beyond the histogram's 2^15 buckets the tuples of a bucket are cut again, BEFORE a bucket's distinct k-mers -- a third of its
+	// tuples -- come near the 2,048 slots of the reduce kernel's table: at 6,100 tuples per bucket (20 M pairs) every bucket overflowed
+	// its table after probing it to the brim, 52 ms instead of 3)
+	if (T == HB && HB == 15 && Ng / NBH > (per_bucket ? per_bucket : refine)) {
 		extra = 1;
 		while (extra < 5 && (Ng >> extra) / NBH > (per_bucket ? per_bucket : refine)) extra++;
 	}
