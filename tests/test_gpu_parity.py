@@ -830,3 +830,19 @@ def test_grouped_window_mapper_edge_cases(ctx):
         pairs, starts = ix.quick_map(w)
         assert int(npairs[i]) == len(pairs), ("long", i)
     p.free()
+
+
+@pytest.mark.parametrize("rl,n_pairs", [(100, 200_000), (151, 120_000)])
+def test_long_reads_at_the_histogram_cap(ctx, rl, n_pairs):
+    """Enough long reads for the gated histogram to want its full resolution: the long-read kernels stage 5.6 KB of records per
+    wave beside it, and 2^15 counters did not fit (every build beyond about a million pairs of 2 x 100 bp failed with "invalid
+    argument"; the pools of test_other_read_lengths are too small to get there).  2^14 counters and a second cut of the buckets
+    now: graph against the oracle."""
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(n_pairs // 500, seed=171)
+    pool = synth.make_reads_cb(rep, n_pairs, noise_frac=0.3, rl=rl, seed=172)
+    assert pool.n_records * (rl - 35 + 1) // 3072 > (1 << 14)            # the histogram is capped
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    hg = run_both(ctx, pool, vc, jc, 35, 3, 90)
+    assert hg.n > 10_000

@@ -2178,9 +2178,12 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 	const u64 NI = geometry_instances ? geometry_instances : (u64) R * (u64) P;
 	static const size_t dflt = tune("VDJX_GATED_BUCKET", 3072);     // gated tuples per bucket: about a third are distinct k-mers (RD_SLOTS)
 	const size_t per = per_bucket ? per_bucket : dflt;
-	// histogram resolution: every bucket count the build could choose is a prefix of it (<= 2^15: 128 KB of LDS)
+	// histogram resolution: every bucket count the build could choose is a prefix of it (<= 2^15: 128 KB of LDS; 2^14 for long reads,
+	// whose waves stage 5.6 KB of records each beside the histogram: 2^15 asked for 173 KB and every build of more than ~1 M pairs of
+	// 2 x 100 bp failed -- the parity tests' pools were too small to get there; profiles/longreads.py now runs them at size)
+	const u32 hb_max = pool->W > 2 ? 14u : 15u;
 	u32 HB = ceil_log2_u64((NI + per - 1) / per);
-	HB = std::max(8u, std::min(15u, HB));
+	HB = std::max(8u, std::min(hb_max, HB));
 	const u32 NBH = 1u << HB;
 	u32 nblk = (u32) std::min<size_t>(512, (R + 4095) / 4096);
 	if (nblk == 0) nblk = 1;
@@ -2216,7 +2219,7 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 	// (beyond the histogram's 2^15 buckets the tuples of a bucket are cut again, BEFORE a bucket's distinct k-mers -- a third of its
 	// tuples -- come near the 2,048 slots of the reduce kernel's table: at 6,100 tuples per bucket (20 M pairs) every bucket overflowed
 	// its table after probing it to the brim, 52 ms instead of 3)
-	if (T == HB && HB == 15 && Ng / NBH > (per_bucket ? per_bucket : refine)) {
+	if (T == HB && HB == hb_max && Ng / NBH > (per_bucket ? per_bucket : refine)) {
 		extra = 1;
 		while (extra < 5 && (Ng >> extra) / NBH > (per_bucket ? per_bucket : refine)) extra++;
 	}
