@@ -31,6 +31,19 @@ for it in range(4):
     del g, p
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 3
+# the scorers on the same pool (no oracle here: does it run at size, and how fast)
+p = ctx.pool_load_device(pool.primary.data_ptr(), pool.primary.shape[0], pool.secondary.data_ptr(), pool.secondary.shape[0], pool.rl)
+ctx.read_index_build(p, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+wins = [w for w in rep.windows() if w]
+ins = max(175, rl + 40)
+torch.cuda.synchronize()
+t1 = time.perf_counter()
+valid, npairs = ctx.window_score(wins, ins)
+contigs = [w[51:411] for w, v in zip(wins, valid) if v]
+offs, mapped = ctx.map_emit(contigs) if contigs else (np.zeros(1, np.uint64), np.zeros(0))
+torch.cuda.synchronize()
+t_sc = time.perf_counter() - t1
+print(f"scorers: {len(wins)} windows, {int(valid.sum())} valid, {int(npairs.astype(np.int64).sum())} window pairs, {len(mapped)} mapped pairs, {t_sc * 1e3:.1f} ms")
 pr = ctx.profile_get()
 print(f"rl {rl}, {pairs} pairs, k {k}: {dt * 1e3:.2f} ms per load + build = {pairs / dt / 1e6:.1f} M pairs/s, {n} nodes")
 print({k_: round(v[0] / max(v[1], 1), 3) for k_, v in pr.items()})
