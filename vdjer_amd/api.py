@@ -414,7 +414,9 @@ class Context:
         off[1:] = np.cumsum([len(e) for e in enc])
         txt, nb = C.c_char_p(), C.c_uint64()
         check(self.L.vdjx_sam_text(self.h, raw, n, ln, b"".join(enc), _p(off), C.byref(txt), C.byref(nb)), "vdjx_sam_text")
-        return C.string_at(txt, nb.value)
+        # (C.string_at takes a C int: the text of 10 M pairs is 3 GB)
+        addr = C.cast(txt, C.c_void_p).value
+        return bytes((C.c_char * nb.value).from_address(addr)) if nb.value else b""
 
     def stat(self, name: str) -> int:
         return int(self.L.vdjx_stat(self.h, name.encode()))
