@@ -731,11 +731,13 @@ template <int NOFF>
 __global__ __launch_bounds__(MAP_THREADS, 8) void k_window_pairs(ReadIndexDev ix, const uint4* __restrict__ prep, u32 n, int len, u32 chunk,
                                                               const u32* __restrict__ order, const u32* __restrict__ wstart,
                                                               const u64* __restrict__ pair_off, u64* __restrict__ pair_buf,
-                                                              u32* __restrict__ pair_cnt, u32* __restrict__ pair_np, const u32* __restrict__ done) {
+                                                              u32* __restrict__ pair_cnt, u32* __restrict__ pair_np, const u32* __restrict__ done,
+                                                              const unsigned long long* __restrict__ groups_left) {
 	__shared__ MapImg<NOFF> L;
 	__shared__ u64 q_ent[MAP_THREADS / 64][WP_Q];
 	__shared__ unsigned short q_off[MAP_THREADS / 64][WP_Q];
 	__shared__ u32 s_next;
+	if (groups_left && *groups_left == 0) return;       // (k_group_pairs did every window: one cached word instead of a search per workgroup)
 	const u32 j = slice_contig(wstart, n, blockIdx.x);
 	const u32 wi = order[j];
 	if (done && done[wi]) return;                       // (k_group_pairs)
@@ -1613,10 +1615,10 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 		vdjx_prof_scope ps(c, "k_window_pairs");
 		if (len - ix.rl <= 512)
 			hipLaunchKernelGGL(k_window_pairs<512>, dim3(mp->tot.nwork), dim3(MAP_THREADS), 0, st, ix, mp->d_prep, (u32) n, len, mp->tot.chunk, mp->d_order, mp->d_wstart,
-			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done);
+			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done, d_gstat ? d_gstat + 1 : nullptr);
 		else
 			hipLaunchKernelGGL(k_window_pairs<MAP_MAXOFF>, dim3(mp->tot.nwork), dim3(MAP_THREADS), 0, st, ix, mp->d_prep, (u32) n, len, mp->tot.chunk, mp->d_order, mp->d_wstart,
-			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done);
+			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done, d_gstat ? d_gstat + 1 : nullptr);
 	}
 	if (d_gstat) HIP_TRY(hipMemcpyAsync((char*) c->h_plan + 128, d_gstat, 32, hipMemcpyDeviceToHost, st));        // (read after the caller's wait)
 	mp->gstat = d_gstat != nullptr;
