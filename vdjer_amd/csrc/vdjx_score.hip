@@ -1290,7 +1290,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 // ----------------------------------------------------------------------------------------------
 #ifndef ME_K
 #define ME_K 8                    // rows of 64 consecutive hits per wave and round (10: 0.77 ms, 12: 0.82 with 5 spilled registers, 16: 1.30)
-#define ME_WAVES 8
+#define ME_WAVES 6
 #endif
 #define ME_Q 128
 // A slice writes its mapped pairs at the start of its own region (region offset = hit offset: pairs <= hits) in ANY order, each with
