@@ -139,6 +139,8 @@ struct vdjx_ctx {
 	std::vector<u64> me_cnt;          // pairs per contig
 	void* h_plan = nullptr;           // page-locked scratch: the plan's totals come down here (vdjx_score.hip classify_and_plan)
 	size_t h_plan_cap = 0;
+	void* h_res = nullptr;            // page-locked, grows: small per-call results come down here in one go (a copy into the caller's pageable
+	size_t h_res_cap = 0;             // arrays blocks the host per copy) and are handed over after the call's one wait
 	void* me_book = nullptr;          // device bookkeeping between the counting and the writing call (vdjx_score.hip map_emit_impl)
 	size_t me_book_cap = 0, me_nsl = 0;
 	u32 me_slice_hits = 0;

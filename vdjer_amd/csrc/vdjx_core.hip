@@ -119,6 +119,7 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	if (c->pairs_stream) { (void) hipStreamSynchronize(c->pairs_stream); (void) hipStreamDestroy(c->pairs_stream); }
 	if (c->ev_gathered) (void) hipEventDestroy(c->ev_gathered);
 	if (c->h_plan) (void) hipHostFree(c->h_plan);
+	if (c->h_res) (void) hipHostFree(c->h_res);
 	if (c->h_pin) (void) hipHostFree(c->h_pin);
 	if (c->h_sam_text) (void) hipHostFree(c->h_sam_text);
 	free_dev(c->d_sam_text); free_dev(c->d_sam_names); free_dev(c->d_sam_noff);

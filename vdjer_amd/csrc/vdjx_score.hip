@@ -1650,14 +1650,27 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 		vdjx_prof_scope ps(c, "k_window_cover");
 		hipLaunchKernelGGL(k_window_cover, dim3((u32) n), dim3(MAP_THREADS), 0, st, len, ix.rl, *p, mp.d_order, mp.d_off, (const u64*) c->wp_buf, d_cnt, d_valid, (u64*) nullptr);
 	}
-	HIP_TRY(hipMemcpyAsync(out_valid, d_valid, n, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
-	c->wp_cnt.resize(n);
-	HIP_TRY(hipMemcpyAsync(c->wp_cnt.data(), d_cnt, n * 4, hipMemcpyDeviceToHost, st));
+	// verdicts, pair counts and list lengths through the context's page-locked buffer: three asynchronous copies and one wait
+	const size_t nres = ((n + 15) & ~(size_t) 15) + 8 * n;
+	if (nres > c->h_res_cap) {
+		if (c->h_res) (void) hipHostFree(c->h_res);
+		c->h_res = nullptr; c->h_res_cap = 0;
+		HIP_TRY(hipHostMalloc(&c->h_res, nres + nres / 4, hipHostMallocDefault));
+		c->h_res_cap = nres + nres / 4;
+	}
+	uint8_t* hr_valid = (uint8_t*) c->h_res;
+	u32* hr_np = (u32*) (hr_valid + ((n + 15) & ~(size_t) 15));
+	u32* hr_cnt = hr_np + n;
+	HIP_TRY(hipMemcpyAsync(hr_valid, d_valid, n, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(hr_np, d_np, n * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(hr_cnt, d_cnt, n * 4, hipMemcpyDeviceToHost, st));
 	vdjx_laps lp(c);
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
 	lp.mark("ws_cover_wait");
+	memcpy(out_valid, hr_valid, n);
+	memcpy(out_npairs, hr_np, n * 4);
+	c->wp_cnt.assign(hr_cnt, hr_cnt + n);
 	vdjx_prof_collect(c);
 	if (mp.gstat) {
 		const unsigned long long* g = (const unsigned long long*) ((const char*) c->h_plan + 128);
