@@ -113,7 +113,7 @@ struct vdjx_ctx {
 	std::vector<u32> h_line_off;
 	// a-8 read index
 	const vdjx_pool* ri_pool = nullptr;
-	void* d_ri_tab = nullptr;         // 32-byte slots {read sequence, class + 1}
+	void* d_ri_tab = nullptr;         // 64-byte slots {read sequence, class + 1 | members, CSR start | first weighted entry, weighted entries} (k_ri_tab)
 	u32 ri_tab_mask = 0;
 	u32* d_ri_start = nullptr;        // class -> CSR start [ncls+1]
 	u32* d_ri_cnt1 = nullptr;         // class -> number of read-1 members (the CSR lists those only)
