@@ -72,7 +72,12 @@ def test_scorers_random_configurations_vs_oracle(ctx, seed, n):
         rl = int(rng.choice([36, 50, 50, 64]))
         wlen = int(rng.integers(rl + 120, 640))
         ins = int(rng.integers(120, 260))
-        rep = synth.make_repertoire(int(rng.integers(1, 8)), seed=int(rng.integers(0, 1 << 30)))
+        # every other configuration: many clones over two V and one J gene (windows of different clones share most of their read
+        # classes, the grouped window mapper's case); else a few unrelated clones
+        if it % 2:
+            rep = synth.make_repertoire(int(rng.integers(6, 20)), seed=int(rng.integers(0, 1 << 30)), n_v=2, n_j=1)
+        else:
+            rep = synth.make_repertoire(int(rng.integers(1, 8)), seed=int(rng.integers(0, 1 << 30)))
         pool = synth.make_reads(rep, int(rng.integers(500, 9000)), noise_frac=float(rng.choice([0.0, 0.2])), seed=int(rng.integers(0, 1 << 30)),
                                 rl=rl, ins_mean=float(ins), err=float(rng.choice([0.0, 0.004])))
         ix = oracle.ReadIndex(pool)
