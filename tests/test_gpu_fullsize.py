@@ -332,3 +332,33 @@ def test_large_pool_code_paths_on_a_small_pool(k, mf, mq, env):
     r = subprocess.run([sys.executable, "-c", _KNOB_CASE % root, str(k), str(mf), str(mq)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=1200)
     assert r.returncode == 0 and "KNOB_CASE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_20M_pairs_buckets_are_cut_before_the_table_fills():
+    """20 M pairs on one GPU: 200 M gated tuples want 2^16 buckets, the histogram has 2^15.  Round 3 found the second cut of the
+    buckets starting only at 8,192 tuples per bucket: at 6,100 every bucket's 2,080 distinct k-mers probed the reduce kernel's
+    2,048-slot table to the brim, overflowed and started over in sub-passes -- same graph, 52 ms instead of 3.  No oracle at this
+    size: the test pins the path (the second-cut kernel runs) and the order of magnitude of the kernel's time."""
+    import torch
+    from vdjer_amd import api, synth
+    torch.cuda.empty_cache()
+    rep = synth.make_repertoire(40_000, seed=20261002)
+    pool = synth.make_reads_cb(rep, 20_000_000, noise_frac=0.3, seed=20261002 + 7, device="cuda:0")
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    ctx = api.Context(0)
+    ctx.anchor_sets_load(vc, jc)
+    ctx.profile(True)
+    p = ctx.pool_load_device(pool.primary.data_ptr(), pool.primary.shape[0], pool.secondary.data_ptr(), pool.secondary.shape[0], pool.rl)
+    g = ctx.kmer_build(p, 35, 3, 90)
+    ctx.profile_reset()
+    g2 = ctx.kmer_build(p, 35, 3, 90)
+    pr = ctx.profile_get()
+    assert g.n == g2.n and g.n > 1_500_000
+    assert "k_seg_hist" in pr, sorted(pr)                                  # the buckets were cut a second time
+    ms = pr["k_gated_reduce"][0] / max(pr["k_gated_reduce"][1], 1)
+    assert ms < 15.0, f"k_gated_reduce took {ms:.1f} ms at 20 M pairs"
+    p.free()
+    ctx.close()
+    del pool
+    torch.cuda.empty_cache()
