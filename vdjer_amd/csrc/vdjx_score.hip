@@ -855,6 +855,9 @@ __global__ __launch_bounds__(MAP_THREADS, 8) void k_window_pairs(ReadIndexDev ix
 #define GP_NOFF 512
 #define GP_OCC (GP_G * GP_NOFF)
 #define GP_PRESENT_LOG2 16
+#ifndef GP_XCD_TILE
+#define GP_XCD_TILE 1                // (0: groups to workgroups as they come: 1.22-1.27 ms against 1.19-1.20; the same for k_map_emit's slices: no difference)
+#endif
 static_assert(GP_Q >= 128, "a drain of full rows must find one");
 struct GroupImg {
 	u32 key[GP_TS];                                 // class + 1 -> ...
@@ -893,8 +896,12 @@ __global__ __launch_bounds__(GP_THREADS, GP_WAVES) void k_group_pairs(ReadIndexD
 	const u32 tid = threadIdx.x;
 	const int lane = __lane_id();
 	const u32 wv = tid >> 6;
+	// workgroups go to the XCDs round-robin (workgroup b to XCD b % 8, each with its own L2): inside every tile of 64 workgroups an XCD
+	// gets 8 groups that are neighbours under the key -- they stream the same deep classes at the same time
+	u32 gblk = blockIdx.x;
+	if (GP_XCD_TILE && (gblk | 63u) < gridDim.x) gblk = (gblk & ~63u) | ((gblk & 7u) << 3) | ((gblk >> 3) & 7u);
 	if (tid < GP_G) {
-		const u32 idx = blockIdx.x * GP_G + tid;
+		const u32 idx = gblk * GP_G + tid;
 		const u32 wi = idx < n ? gorder[idx] : NONE32;
 		s_w[tid] = wi;
 		s_pbase[tid] = wi != NONE32 ? pair_off[wi] : 0ull;
