@@ -885,7 +885,9 @@ __device__ inline bool gp_entry_present(const GroupImg& L, const u64 e) {
 
 __global__ __launch_bounds__(GP_THREADS, GP_WAVES) void k_group_pairs(ReadIndexDev ix, const uint4* __restrict__ prep, const u32* __restrict__ hits, u32 n, int len,
                                                               const u32* __restrict__ gorder, const u64* __restrict__ pair_off, u64* __restrict__ pair_buf,
-                                                              u32* __restrict__ pair_cnt, u32* __restrict__ pair_np, u32* __restrict__ done, unsigned long long* __restrict__ gstat, u32 dbg) {
+                                                              u32* __restrict__ pair_cnt, u32* __restrict__ pair_np, u32* __restrict__ done, unsigned long long* __restrict__ gstat, u32 dbg,
+                                                              u64 cap) {
+	if (pair_off[n] + 1 > cap) return;                  // (launched before the host knew the lists' total size: they do not fit, it will come again)
 	__shared__ GroupImg L;
 	__shared__ u64 q_ent[GP_THREADS / 64][GP_Q];
 	__shared__ unsigned short q_d[GP_THREADS / 64][GP_Q];
@@ -1512,8 +1514,19 @@ struct MapPlan {
 	PlanOut tot{};
 };
 int vdjx_sort_pairs(vdjx_work& db, hipStream_t st, u64* k_in, u64* k_out, u32* v_in, u32* v_out, u32 n, unsigned end_bit);     // vdjx_rindex.hip
+// the plan's totals once they have come down: the host waits for the EVENT behind their copy, not for the stream (work launched behind
+// the plan keeps the device busy meanwhile)
+static int plan_finish(vdjx_ctx* c, MapPlan* mp) {
+	vdjx_laps lp(c);
+	HIP_TRY(hipEventSynchronize(c->ev_plan));
+	HIP_TRY(hipGetLastError());
+	lp.mark("plan_wait");
+	mp->tot = *(const PlanOut*) c->h_plan;
+	if (mp->tot.total_hits >= (1ull << 40)) { vdjx_set_error("too many hits in one scorer call (%llu)", (unsigned long long) mp->tot.total_hits); return VDJX_ELIMIT; }
+	return VDJX_OK;
+}
 static int classify_and_plan(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, const char* strings, size_t n, int len, bool weighted,
-                             u32 chunk_fixed, MapPlan* mp, bool grouped = false) {
+                             u32 chunk_fixed, MapPlan* mp, bool grouped = false, bool wait = true) {
 	hipStream_t st = c->stream;
 	vdjx_laps lp(c);
 	const int noff = len - ix.rl;
@@ -1557,13 +1570,9 @@ static int classify_and_plan(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix,
 		c->h_plan_cap = 256;
 	}
 	HIP_TRY(hipMemcpyAsync(c->h_plan, d_tot, sizeof(PlanOut), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipEventRecord(c->ev_plan, st));
 	lp.mark("plan_issue");
-	HIP_TRY(hipStreamSynchronize(st));
-	HIP_TRY(hipGetLastError());
-	lp.mark("plan_wait");
-	mp->tot = *(const PlanOut*) c->h_plan;
-	if (mp->tot.total_hits >= (1ull << 40)) { vdjx_set_error("too many hits in one scorer call (%llu)", (unsigned long long) mp->tot.total_hits); return VDJX_ELIMIT; }
-	return VDJX_OK;
+	return wait ? plan_finish(c, mp) : VDJX_OK;
 }
 
 // u64 lists laid end to end: move[i] = {source element, destination element, count}
@@ -1589,35 +1598,48 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 	static const u32 gp_dbg = getenv("VDJX_GP_DBG") ? (u32) atol(getenv("VDJX_GP_DBG")) : 0u;      // ablation (profiles/): 1 no full tests, 2 images only
 	static const bool group_on = !(getenv("VDJX_WINDOW_GROUP") && atol(getenv("VDJX_WINDOW_GROUP")) == 0);
 	const bool grouped = group_on && len - ix.rl <= GP_NOFF;
-	int rc = classify_and_plan(c, db, ix, windows, n, len, true, hit_chunk, mp, grouped);
+	// With a pair buffer from an earlier call the groups are mapped BEFORE the host knows the plan's totals (the kernel returns at once
+	// if the lists would not fit): the host's wait for the totals and its next launches hide behind that kernel.
+	int rc = classify_and_plan(c, db, ix, windows, n, len, true, hit_chunk, mp, grouped, false);
 	if (rc) return rc;
+	HIP_TRY(db.alloc(&d_np, n));
+	HIP_TRY(db.alloc(&d_cnt, n));
+	u32* d_done = nullptr;
+	unsigned long long* d_gstat = nullptr;
+	if (grouped) {
+		HIP_TRY(db.alloc(&d_done, n));
+		HIP_TRY(db.alloc(&d_gstat, 4));
+	}
+	auto map_groups = [&]() -> int {
+		HIP_TRY(hipMemsetAsync(d_np, 0, n * 4, st));
+		HIP_TRY(hipMemsetAsync(d_cnt, 0, n * 4, st));
+		if (!grouped) return VDJX_OK;
+		HIP_TRY(hipMemsetAsync(d_done, 0, n * 4, st));
+		HIP_TRY(hipMemsetAsync(d_gstat, 0, 32, st));
+		vdjx_prof_scope ps(c, "k_group_pairs");
+		hipLaunchKernelGGL(k_group_pairs, dim3((u32) ((n + GP_G - 1) / GP_G)), dim3(GP_THREADS), 0, st, ix, mp->d_prep, mp->d_hits, (u32) n, len, mp->d_gorder,
+		                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done, d_gstat, gp_dbg, (u64) c->wp_cap);
+		return VDJX_OK;
+	};
+	const bool early = grouped && c->wp_cap > 0;
+	if (early && (rc = map_groups())) return rc;
+	if ((rc = plan_finish(c, mp))) return rc;
 	const u64 total = mp->tot.total_hits;
+	bool again = !early;
 	if ((size_t) total + 1 > c->wp_cap) {
+		HIP_TRY(hipStreamSynchronize(st));                  // (the early launch, if any, has returned without a write: wait before the buffer goes)
 		free_set(c->wp_buf);
 		c->wp_cap = 0;
 		const size_t want = (size_t) total + (size_t) total / 4 + 1024;
 		HIP_TRY(hipMalloc(&c->wp_buf, want * 8));
 		c->wp_cap = want;
+		again = true;
 	}
-	HIP_TRY(db.alloc(&d_np, n));
-	HIP_TRY(db.alloc(&d_cnt, n));
+	if (again && (rc = map_groups())) return rc;
 	c->stats["window_hits"] = mp->tot.inst_total;          // read-1 instances matched (what the reference enumerates one by one)
 	c->stats["window_hits_max"] = mp->tot.inst_max;
 	c->stats["window_hits_distinct"] = total;              // weighted entries actually evaluated
 	c->stats["window_work_items"] = mp->tot.nwork;
-	HIP_TRY(hipMemsetAsync(d_np, 0, n * 4, st));
-	HIP_TRY(hipMemsetAsync(d_cnt, 0, n * 4, st));
-	u32* d_done = nullptr;
-	unsigned long long* d_gstat = nullptr;
-	if (grouped) {
-		HIP_TRY(db.alloc(&d_done, n));
-		HIP_TRY(hipMemsetAsync(d_done, 0, n * 4, st));
-		HIP_TRY(db.alloc(&d_gstat, 4));
-		HIP_TRY(hipMemsetAsync(d_gstat, 0, 32, st));
-		vdjx_prof_scope ps(c, "k_group_pairs");
-		hipLaunchKernelGGL(k_group_pairs, dim3((u32) ((n + GP_G - 1) / GP_G)), dim3(GP_THREADS), 0, st, ix, mp->d_prep, mp->d_hits, (u32) n, len, mp->d_gorder,
-		                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done, d_gstat, gp_dbg);
-	}
 	if (mp->tot.nwork) {
 		vdjx_prof_scope ps(c, "k_window_pairs");
 		if (len - ix.rl <= 512)
