@@ -235,8 +235,8 @@ int vdjx_profile_get(vdjx_ctx* ctx, int idx, const char** name, double* total_ms
  * vdjer_amd/shard.py does it with torch.distributed over RCCL, vdjer_amd/csrc/host/vdjx_mgpu.c with RCCL
  * directly).  Record numbering is rank-major with a common stride: rank r's records are
  * [r*rec_stride, r*rec_stride + R_r); instance ids are global, record << 6 | offset, so nranks * rec_stride
- * must stay below 2^32 records.  nranks is a power of two; the owner of a k-mer is given by the top
- * log2(nranks) bits of its hash.
+ * must stay below 2^32 records.  Any 1 <= nranks <= 256; the owner of a k-mer is its hash bucket divided by
+ * the buckets per owner (*dir_len of vdjx_shard_local: the quotient of the bucket count by nranks, rounded up).
  *   Every rank first aggregates ITS OWN gated instances per distinct k-mer (count, first instance, whether it
  * saw two different reads: add_to_table A2:322-367 restated per rank).  These partial aggregates (32 B per
  * distinct gated k-mer per rank, not per instance) are the one bulk exchange.  The owner merges them (counts

@@ -26,11 +26,10 @@ class RefShardEngine:
         self.rank, self.world, self.stride = rank, world, stride
         self.rl = pool.rl
         self.P = self.rl - k + 1
-        self.obits = world.bit_length() - 1
         self.recs = np.concatenate([pool.primary, pool.secondary], axis=0)
 
     def _owner(self, key: bytes) -> int:
-        return (zlib.crc32(key) >> (32 - self.obits)) if self.obits else 0
+        return (zlib.crc32(key) * self.world) >> 32                 # any number of ranks
 
     def _instances(self):
         rl, k = self.rl, self.k

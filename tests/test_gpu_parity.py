@@ -439,7 +439,8 @@ def test_deep_windows_many_slices_and_multiplicities(ctx):
 
 
 @pytest.mark.parametrize("world,k,mf,mq,stride", [(2, 35, 3, 90, None), (4, 25, 2, 60, None), (2, 48, 2, 60, None), (8, 35, 2, 60, None),
-                                                  (2, 35, 3, 90, 1 << 30), (4, 25, 2, 60, (1 << 30) - 12345)])
+                                                  (2, 35, 3, 90, 1 << 30), (4, 25, 2, 60, (1 << 30) - 12345),
+                                                  (3, 35, 3, 90, None), (6, 25, 2, 60, None), (5, 35, 2, 60, (1 << 29) + 77)])
 def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq, stride):
     """The real multi-rank driver + the HIP phase engine with `world` ranks on this one GPU (ranks are threads,
     collectives are tensor copies: tests/fake_dist.py).  Result == single-GPU build of the union pool == oracle.

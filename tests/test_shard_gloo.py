@@ -66,12 +66,11 @@ def _worker(rank, world, port, k, mf, mq, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,mf,mq", [(35, 2, 60), (25, 2, 40)])
-def test_sharded_driver_world2_gloo(k, mf, mq):
+@pytest.mark.parametrize("world,k,mf,mq", [(2, 35, 2, 60), (2, 25, 2, 40), (3, 35, 2, 60)])
+def test_sharded_driver_gloo(world, k, mf, mq):
     import torch.multiprocessing as mp
     from oracle import oracle
     from vdjer_amd import synth
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -50,7 +50,7 @@ static void usage(void) {
 	                "\t--vk <vregion kmer size (default: 15)>\n\t--mrs <min source node homology score (default: 30)\n"
 	                "\t--rs <read span distance (default: 35)>\n\t--ms <mate span distance (default: 48)>\n"
 	                "\t--e0/--e1 <start/stop position for contig filtering (default: 52/411)>\n\t--wo <window overlap check size>\n"
-	                "\t--gpus <GPUs of this node to shard the k-mer table over (power of two, default: 1)>\n");
+	                "\t--gpus <GPUs of this node to shard the k-mer table over (default: 1)>\n");
 }
 
 static int file_exists(const char* f) { struct stat b; return stat(f, &b) == 0; }
@@ -498,7 +498,7 @@ int main(int argc, char** argv) {
 	}
 	int rank = 0;
 	int id_pipe[256][2];
-	if (c.gpus < 1 || c.gpus > 256 || (c.gpus & (c.gpus - 1))) { fprintf(stderr, "--gpus must be a power of two in [1,256]\n"); return 255; }
+	if (c.gpus < 1 || c.gpus > 256) { fprintf(stderr, "--gpus must be in [1,256]\n"); return 255; }
 	if (c.gpus > 1) {
 		struct sigaction sa;
 		memset(&sa, 0, sizeof sa);

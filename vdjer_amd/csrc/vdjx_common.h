@@ -145,6 +145,7 @@ struct vdjx_ctx {
 	size_t me_book_cap = 0, me_nsl = 0;
 	u32 me_slice_hits = 0;
 	hipEvent_t ev_gathered = nullptr;
+	uint32_t root_dp_hint = 0;        // work items of the last root scoring (+ a margin): the next call's DP is launched for that many ahead of its own count
 	hipEvent_t ev_plan = nullptr;     // the scorers' plan totals have come down (the host waits for this, not for the stream)
 	// SAM text (vdjx_sam_text): read names by pair id on the device, the text buffers
 	char* d_sam_names = nullptr;

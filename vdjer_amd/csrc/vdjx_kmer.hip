@@ -2741,7 +2741,8 @@ extern "C" int vdjx_kmer_build(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf
 // ==============================================================================================
 // Sharded build: one process per GPU; the caller moves the bytes between ranks
 // (torch.distributed over RCCL in vdjer_amd/shard.py, RCCL directly in the C host).  Record numbering: rank r's
-// records are [r*rec_stride, r*rec_stride + R_r); k-mer ownership = top log2(nranks) bits of the bucket index.
+// records are [r*rec_stride, r*rec_stride + R_r); k-mer ownership = bucket index / buckets per owner (any number of ranks: the
+// buckets per owner are the quotient rounded up, to a multiple of 16 when it is not exact; the last owner has the fewest).
 // Instance ids are global and 38 bits wide (record << 6 | offset): nranks * rec_stride < 2^32 records.
 // ==============================================================================================
 struct vdjx_shard {
@@ -2749,7 +2750,6 @@ struct vdjx_shard {
 	const vdjx_pool* pool = nullptr;
 	int k = 0, mf = 0, mq = 0, rank = 0, nranks = 1;
 	u64 rec_stride = 0;
-	u32 owner_bits = 0;
 	bool wide = false;                              // Tup24 (k > 45)
 	// local phase: this rank's gated tuples by bucket, its partial aggregates (dense, bucket order)
 	u32 NBf = 0, NBo = 0;
@@ -2777,7 +2777,7 @@ extern "C" int vdjx_shard_begin(vdjx_ctx* c, const vdjx_pool* pool, int k, int m
 	if (!c || !pool || !out) { vdjx_set_error("vdjx_shard_begin: NULL argument"); return VDJX_EINVAL; }
 	*out = nullptr;
 	if (c->live_shard) { vdjx_set_error("vdjx_shard_begin: a sharded build is already in flight on this context"); return VDJX_ESTATE; }
-	if (nranks < 1 || (nranks & (nranks - 1)) || nranks > 256 || rank < 0 || rank >= nranks) { vdjx_set_error("nranks must be a power of two <= 256, 0 <= rank < nranks"); return VDJX_EINVAL; }
+	if (nranks < 1 || nranks > 256 || rank < 0 || rank >= nranks) { vdjx_set_error("1 <= nranks <= 256, 0 <= rank < nranks"); return VDJX_EINVAL; }
 	if (k < 1 || k > VDJX_MAX_KMER || k > pool->rl) { vdjx_set_error("k=%d outside [1,min(%d,rl=%d)]", k, VDJX_MAX_KMER, pool->rl); return VDJX_ELIMIT; }
 	if (rec_stride < pool->n_records) { vdjx_set_error("rec_stride %llu < local records %zu", (unsigned long long) rec_stride, pool->n_records); return VDJX_EINVAL; }
 	if (rec_stride * (uint64_t) nranks >= (1ull << 32)) { vdjx_set_error("global record count %llu >= 2^32", (unsigned long long) (rec_stride * nranks)); return VDJX_ELIMIT; }
@@ -2787,7 +2787,6 @@ extern "C" int vdjx_shard_begin(vdjx_ctx* c, const vdjx_pool* pool, int k, int m
 	s->c = c; s->pool = pool; s->k = k; s->mf = mf; s->mq = mq; s->rank = rank; s->nranks = nranks;
 	s->rec_stride = rec_stride;
 	s->wide = k > 45;
-	while ((1 << s->owner_bits) < nranks) s->owner_bits++;
 	if (mq >= 255) mq = 254;                                        // A2:1514-1516
 	s->mqq = (u32) (mq < 0 ? 0 : (mq > 214 ? 214 : mq));
 	s->tlow = 1 + (s->mqq + 19) / 20;
@@ -2824,18 +2823,21 @@ static int shard_local_impl(vdjx_shard* s) {
 	int rc = stage_gated_partition<TUP>(c, db, s->pool, rec_base, s->k, 0, geom, &t);
 	if (rc) return rc;
 	if (t.NB < (u32) s->nranks) { vdjx_set_error("vdjx_shard_local: fewer buckets (%u) than ranks", t.NB); return VDJX_ELIMIT; }
-	s->NBf = t.NB;
+	// buckets per owner; the directory every rank sends has nranks * NBo entries (the ones past the last bucket are empty)
 	s->NBo = t.NB / (u32) s->nranks;
+	if (s->NBo * (u32) s->nranks != t.NB) s->NBo = (s->NBo + 1 + 15) & ~15u;
+	s->NBf = s->NBo * (u32) s->nranks;
 	Partial* sparse;
 	u32 *g_err, *sparse_ref;
 	const size_t cap = (size_t) t.N + 1;
 	HIP_TRY(db.alloc(&sparse, cap));
 	HIP_TRY(db.alloc(&sparse_ref, cap));
 	HIP_TRY(db.alloc(&s->low_inst, cap));
-	HIP_TRY(db.alloc(&s->nd, t.NB));
-	HIP_TRY(db.alloc(&s->dstart, t.NB + 1));
+	HIP_TRY(db.alloc(&s->nd, s->NBf));
+	HIP_TRY(db.alloc(&s->dstart, s->NBf + 1));
 	HIP_TRY(db.alloc(&g_err, 1));
 	HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
+	if (s->NBf > t.NB) HIP_TRY(hipMemsetAsync(s->nd + t.NB, 0, (size_t) (s->NBf - t.NB) * 4, st));
 	{
 		static const u32 sub = (u32) tune("VDJX_SUB_TUPLES", 262144);
 		HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sub_tuples), &sub, 4, 0, hipMemcpyHostToDevice, st));
@@ -2845,7 +2847,7 @@ static int shard_local_impl(vdjx_shard* s) {
 		hipLaunchKernelGGL(k_gated_local<TUP>, dim3(t.NB), dim3(LG_THREADS), 0, st, t.t, t.bucket_start, s->pool->d_bases, s->pool->d_nmask, rec_base,
 		                   s->k, s->tlow, sparse, sparse_ref, s->nd, s->low_inst, g_err);
 	}
-	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, s->nd, t.NB, s->dstart);
+	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, s->nd, s->NBf, s->dstart);
 	u32* d_pick;
 	const u32 G = (u32) s->nranks;
 	HIP_TRY(db.alloc(&d_pick, G + 1));
@@ -2930,7 +2932,7 @@ static int shard_merge_impl(vdjx_shard* s, const u32* d_recv_dir, const Partial*
 	s->nq.assign(G, 0);
 	// buckets per merge table: about MERGE_SLOTS*3/8 partials each (the local buckets are sized for tuples, not for distinct k-mers)
 	u32 MG = 1;
-	while (MG < NBo && (u64) total * (MG * 2) <= (u64) NBo * (MERGE_SLOTS * 3 / 8)) MG <<= 1;
+	while (MG < NBo && NBo % (MG * 2) == 0 && (u64) total * (MG * 2) <= (u64) NBo * (MERGE_SLOTS * 3 / 8)) MG <<= 1;
 	u32 np = 0, ns = 0, err = 0;
 	u64 ndist = 0;
 	for (u32 s_mult = 1;; s_mult *= 4) {

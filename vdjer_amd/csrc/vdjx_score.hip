@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_scan_add(u32* __restrict__ pre, u32 n, 
 #define DP_THREADS 128
 __global__ __launch_bounds__(DP_THREADS) void k_root_dp(const char* __restrict__ kmers, int k, int threshold,
                                                         const u32* __restrict__ hit_lo, const u32* __restrict__ hit_pre,
-                                                        u32 n_groups, u32 stop, u32 total, const u32* __restrict__ seed_pos,
+                                                        u32 n_groups, u32 stop, u32 base, const u32* __restrict__ seed_pos,
                                                         const char* __restrict__ vtext, const u32* __restrict__ line_off, u32 n_lines,
                                                         uint8_t* __restrict__ out) {
 	// The DP column and the root live in REGISTERS (the row loop is fully unrolled to the longest k, guarded by the uniform
@@ -186,8 +186,8 @@ __global__ __launch_bounds__(DP_THREADS) void k_root_dp(const char* __restrict__
 	// per thread and far too small to hide LDS latency by occupancy).  Only the reference segment sits in LDS, one read per column.
 	__shared__ char refc[2 * VDJX_MAX_KMER * DP_THREADS];
 	const u32 tid = threadIdx.x;
-	const u32 w = blockIdx.x * DP_THREADS + tid;
-	if (w >= total) return;
+	const u32 w = base + blockIdx.x * DP_THREADS + tid;      // (the number of work items is read on the device: the kernel may be launched before the host has it)
+	if (w >= hit_pre[n_groups]) return;
 	// group = (root, seed offset) holding work item w: last group with hit_pre[g] <= w
 	u32 lo = 0, hi = n_groups;
 	while (hi - lo > 1) {
@@ -258,9 +258,21 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 		hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, d_bsum, nb, d_bpre);
 		hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, st, d_pre, ng, d_bpre);
 	}
+	// the DP is launched for as many items as the last call had before the host knows this call's number (the host then waits for
+	// the number's event only, and adds a launch for what is beyond the guess)
+	u32 ahead = 0;
+	if (threshold > 0 && c->root_dp_hint) {
+		ahead = c->root_dp_hint;
+		vdjx_prof_scope ps(c, "k_root_dp");
+		hipLaunchKernelGGL(k_root_dp, dim3((unsigned) ((ahead + DP_THREADS - 1) / DP_THREADS)), dim3(DP_THREADS), 0, st, d_k, k, threshold,
+		                   d_lo, d_pre, ng, (u32) stop, 0u, c->d_seed_pos, c->d_vtext, c->d_line_off, (u32) c->n_lines, d_out);
+		ahead = (ahead + DP_THREADS - 1) / DP_THREADS * DP_THREADS;
+	}
 	HIP_TRY(hipMemcpyAsync(c->h_pin, d_pre + ng, 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipEventRecord(c->ev_plan, st));
+	HIP_TRY(hipEventSynchronize(c->ev_plan));
 	const u32 run = *(const u32*) c->h_pin;
+	c->root_dp_hint = run + run / 4 + 1024;
 	c->stats["root_dp_items"] = run;
 	if (run >= (1u << 31)) { vdjx_set_error("too many seed hits in one call (%u)", run); return VDJX_ELIMIT; }
 	if (threshold <= 0) {
@@ -270,10 +282,10 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 		for (size_t r = 0; r < n; r++) out[r] = pre[(r + 1) * stop] > pre[r * stop];
 		return VDJX_OK;
 	}
-	if (run) {
+	if (run > ahead) {
 		vdjx_prof_scope ps(c, "k_root_dp");
-		hipLaunchKernelGGL(k_root_dp, dim3((unsigned) ((run + DP_THREADS - 1) / DP_THREADS)), dim3(DP_THREADS), 0, st, d_k, k, threshold,
-		                   d_lo, d_pre, ng, (u32) stop, (u32) run, c->d_seed_pos, c->d_vtext, c->d_line_off, (u32) c->n_lines, d_out);
+		hipLaunchKernelGGL(k_root_dp, dim3((unsigned) ((run - ahead + DP_THREADS - 1) / DP_THREADS)), dim3(DP_THREADS), 0, st, d_k, k, threshold,
+		                   d_lo, d_pre, ng, (u32) stop, ahead, c->d_seed_pos, c->d_vtext, c->d_line_off, (u32) c->n_lines, d_out);
 	}
 	HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));

@@ -9,7 +9,7 @@ Phases (the engine does the compute, this module only moves bytes):
   1. every rank aggregates ITS gated instances per distinct k-mer: count, first instance, "saw two different reads"
      (add_to_table A2:322-367 restated per rank)                                     -- no communication
   2. ONE bulk all-to-all: the partial aggregates (32 B per distinct gated k-mer per rank, NOT per instance) go to the
-     owner of the k-mer = top log2(G) bits of its hash, with a per-bucket directory
+     owner of the k-mer = its hash bucket / buckets per owner (any number of ranks), with a per-bucket directory
   3. the owner merges (counts add, firsts take the minimum, flags OR) and decides almost every k-mer; the few whose
      verdict needs per-read data (flag still open although several ranks hold the k-mer; count so low that the
      quality sums matter) cost a question (8 B) to the holders and an answer (200 B): two tiny all-to-alls
@@ -308,8 +308,6 @@ class ShardedHotPath:
         self.torch, self.dist, self.dev = torch, dist, device
         self.comm = Comm(dist, device)
         self.rank, self.world = self.comm.rank, self.comm.world
-        if self.world & (self.world - 1):
-            raise ValueError("the number of ranks must be a power of two (ownership = hash-prefix bits)")
         self.engine = engine if engine is not None else HipShardEngine(ctx, device)
         self.stride = stride
         self.laps = {}               # seconds per phase of kmer_build, summed over calls (host clock, diagnostic)
