@@ -342,6 +342,23 @@ class Context:
         C.memmove(ptr, rows.ctypes.data, rows.nbytes)
         return (C.cast(ptr, C.c_char_p), n, ln)
 
+    def pin_rows_take(self, rows: np.ndarray, idx: np.ndarray, tag: str):
+        """pin_array(rows[idx]) without the intermediate array: the chosen rows are gathered straight into the page-locked buffer"""
+        n, ln = int(idx.shape[0]), int(rows.shape[1])
+        need = max(n * ln, 1)
+        ptr, cap = self._pinned.get("in:" + tag, (None, 0))
+        if cap < need:
+            if ptr:
+                self._retired.append(ptr)
+            new = C.c_void_p()
+            check(self.L.vdjx_host_alloc(self.h, need + need // 4, C.byref(new)), "vdjx_host_alloc")
+            ptr, cap = new.value, need + need // 4
+            self._pinned["in:" + tag] = (ptr, cap)
+        if n:
+            out = np.ctypeslib.as_array((C.c_uint8 * (n * ln)).from_address(ptr)).reshape(n, ln)
+            np.take(rows, idx, axis=0, out=out)
+        return (C.cast(ptr, C.c_char_p), n, ln)
+
     def window_score(self, windows, ins: int, e0: int = 52, e1: int = 411, rs: int = 35, ms: int = 48, floor: int = 1):
         raw, n, ln = windows if isinstance(windows, tuple) else self.pack_strings(windows)
         if n == 0:

@@ -219,7 +219,7 @@ struct vdjx_prof_scope {
 	vdjx_prof_scope(vdjx_ctx* ctx, const char* nm);
 	~vdjx_prof_scope();
 };
-void vdjx_prof_collect(vdjx_ctx* ctx);
+void vdjx_prof_collect(vdjx_ctx* ctx, bool force = true);
 
 // host-side laps (VDJX_LAPS=1): microseconds between two marks of a call, summed into vdjx_stat("us_<name>")
 struct vdjx_laps {

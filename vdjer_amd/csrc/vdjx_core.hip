@@ -186,7 +186,10 @@ vdjx_prof_scope::~vdjx_prof_scope() {
 	c->prof_pending.push_back({name, a, b});
 }
 
-void vdjx_prof_collect(vdjx_ctx* c) {
+// `force` = false (the end of a compute call): the events are read when somebody asks for the numbers, not here -- reading forty
+// events costs the host 0.1 ms during which the device has nothing to do; a bound on the pending list keeps the event pool small
+void vdjx_prof_collect(vdjx_ctx* c, bool force) {
+	if (!force && c->prof_pending.size() < 16384) return;
 	for (auto& p : c->prof_pending) {
 		float ms = 0;
 		if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {

@@ -2682,7 +2682,7 @@ int stage_finish2(vdjx_ctx* c, A& db, const SurvivorsG& sv, const RecountOut& ro
 	HIP_TRY(hipGetLastError());
 	n_roots = *(const u32*) c->h_pin;
 	g->n_roots = n_roots;
-	vdjx_prof_collect(c);
+	vdjx_prof_collect(c, false);
 	return VDJX_OK;
 }
 

@@ -393,7 +393,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	}
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
-	vdjx_prof_collect(c);
+	vdjx_prof_collect(c, false);
 	c->stats["read_index_r1_members"] = n1;
 	c->stats["read_index_r1_distinct"] = nd;
 	c->stats["read_index_classes"] = ncls;

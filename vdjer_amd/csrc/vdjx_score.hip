@@ -258,8 +258,10 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 		hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, st, d_bsum, nb, d_bpre);
 		hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, st, d_pre, ng, d_bpre);
 	}
-	// the DP is launched for as many items as the last call had before the host knows this call's number (the host then waits for
-	// the number's event only, and adds a launch for what is beyond the guess)
+	// the DP is launched for as many items as the last call had before the host knows this call's number (its copy is queued first:
+	// the host waits for that event only, and adds a launch for what is beyond the guess)
+	HIP_TRY(hipMemcpyAsync(c->h_pin, d_pre + ng, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipEventRecord(c->ev_plan, st));
 	u32 ahead = 0;
 	if (threshold > 0 && c->root_dp_hint) {
 		ahead = c->root_dp_hint;
@@ -268,8 +270,6 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 		                   d_lo, d_pre, ng, (u32) stop, 0u, c->d_seed_pos, c->d_vtext, c->d_line_off, (u32) c->n_lines, d_out);
 		ahead = (ahead + DP_THREADS - 1) / DP_THREADS * DP_THREADS;
 	}
-	HIP_TRY(hipMemcpyAsync(c->h_pin, d_pre + ng, 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipEventRecord(c->ev_plan, st));
 	HIP_TRY(hipEventSynchronize(c->ev_plan));
 	const u32 run = *(const u32*) c->h_pin;
 	c->root_dp_hint = run + run / 4 + 1024;
@@ -290,7 +290,7 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 	HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
-	vdjx_prof_collect(c);
+	vdjx_prof_collect(c, false);
 	return VDJX_OK;
 }
 
@@ -1712,7 +1712,7 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 	memcpy(out_valid, hr_valid, n);
 	memcpy(out_npairs, hr_np, n * 4);
 	c->wp_cnt.assign(hr_cnt, hr_cnt + n);
-	vdjx_prof_collect(c);
+	vdjx_prof_collect(c, false);
 	if (mp.gstat) {
 		const unsigned long long* g = (const unsigned long long*) ((const char*) c->h_plan + 128);
 		c->stats["group_hits_distinct"] = g[0];                // entries streamed by k_group_pairs (each class of a group once)
@@ -1755,7 +1755,7 @@ extern "C" int vdjx_window_pairs(vdjx_ctx* c, const char* windows, size_t n, int
 	HIP_TRY(hipMemcpyAsync(out_npairs, d_np, n * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
-	vdjx_prof_collect(c);
+	vdjx_prof_collect(c, false);
 	memcpy(out_entries, c->wp_cnt.data(), n * 4);
 	c->wp_n = n;
 	return VDJX_OK;
@@ -1844,7 +1844,7 @@ extern "C" int vdjx_window_cover(vdjx_ctx* c, size_t n, int len, int rl, const v
 	HIP_TRY(hipMemcpyAsync(out_valid, d_valid, n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
-	vdjx_prof_collect(c);
+	vdjx_prof_collect(c, false);
 	return VDJX_OK;
 }
 
@@ -1978,7 +1978,7 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 			HIP_TRY(hipMemcpyAsync(pairs, d_dense, (size_t) total * sizeof(vdjx_pair), hipMemcpyDeviceToHost, st));
 			HIP_TRY(hipStreamSynchronize(st));
 			HIP_TRY(hipGetLastError());
-			vdjx_prof_collect(c);          // (asynchronous: the gather's timing is collected by the next call that waits for the stream)
+			vdjx_prof_collect(c, false);          // (asynchronous: the gather's timing is collected by the next call that waits for the stream)
 		}
 	}
 	c->me_key = 0;           // one counting call serves one writing call
@@ -2176,7 +2176,7 @@ extern "C" int vdjx_sam_text(vdjx_ctx* c, const char* contigs, size_t n, int len
 	HIP_TRY(hipMemcpyAsync(c->h_sam_text, c->d_sam_text, (size_t) nbytes, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
-	vdjx_prof_collect(c);
+	vdjx_prof_collect(c, false);
 	((char*) c->h_sam_text)[nbytes] = 0;
 	*out_text = (const char*) c->h_sam_text;
 	*out_bytes = nbytes;
