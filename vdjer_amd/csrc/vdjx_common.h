@@ -136,6 +136,7 @@ struct vdjx_ctx {
 	std::vector<u32> wp_cnt;
 	void* me_dense = nullptr;         // the pairs laid end to end for the copy to the host (kept: the copy may be asynchronous)
 	size_t me_dense_cap = 0;
+	size_t me_gathered_cap = 0;       // capacity the counting call's gather (launched ahead of the total) ran against; 0: it did not run
 	std::vector<u64> me_cnt;          // pairs per contig
 	void* h_plan = nullptr;           // page-locked scratch: the plan's totals come down here (vdjx_score.hip classify_and_plan)
 	size_t h_plan_cap = 0;
@@ -145,6 +146,9 @@ struct vdjx_ctx {
 	size_t me_book_cap = 0, me_nsl = 0;
 	u32 me_slice_hits = 0;
 	hipEvent_t ev_gathered = nullptr;
+	hipStream_t up_stream = nullptr;        // the scorers' strings on their way up, in pieces (classify_and_plan)
+	hipEvent_t ev_up[5] = {};
+	hipEvent_t ev_pairs_copied = nullptr;   // the last asynchronous copy of mapped pairs to the host has left me_dense
 	uint32_t root_dp_hint = 0;        // work items of the last root scoring (+ a margin): the next call's DP is launched for that many ahead of its own count
 	hipEvent_t ev_plan = nullptr;     // the scorers' plan totals have come down (the host waits for this, not for the stream)
 	// SAM text (vdjx_sam_text): read names by pair id on the device, the text buffers

@@ -46,6 +46,9 @@ extern "C" int vdjx_init(int device, vdjx_ctx** out) {
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->pairs_stream, hipStreamNonBlocking);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking);
+	for (auto& ev : c->ev_up) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pairs_copied, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipHostMalloc(&c->h_pin, 16384, hipHostMallocDefault);
 	if (e != hipSuccess) { delete c; vdjx_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return VDJX_EHIP; }
@@ -119,6 +122,9 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	(void) hipStreamDestroy(c->copy_stream);
 	if (c->pairs_stream) { (void) hipStreamSynchronize(c->pairs_stream); (void) hipStreamDestroy(c->pairs_stream); }
 	if (c->ev_gathered) (void) hipEventDestroy(c->ev_gathered);
+	if (c->up_stream) { (void) hipStreamSynchronize(c->up_stream); (void) hipStreamDestroy(c->up_stream); }
+	for (auto& ev : c->ev_up) if (ev) (void) hipEventDestroy(ev);
+	if (c->ev_pairs_copied) (void) hipEventDestroy(c->ev_pairs_copied);
 	if (c->ev_plan) (void) hipEventDestroy(c->ev_plan);
 	if (c->h_plan) (void) hipHostFree(c->h_plan);
 	if (c->h_res) (void) hipHostFree(c->h_res);

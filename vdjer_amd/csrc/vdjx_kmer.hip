@@ -2298,10 +2298,10 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 	u32 *g_err, *n_surv;
 	u64* g_distinct;
 	HIP_TRY(db.alloc(&sv->lo, cap)); HIP_TRY(db.alloc(&sv->hi, cap)); HIP_TRY(db.alloc(&sv->gcnt, cap)); HIP_TRY(db.alloc(&sv->gfirst, cap));
-	HIP_TRY(db.alloc(&g_err, 1)); HIP_TRY(db.alloc(&n_surv, 1)); HIP_TRY(db.alloc(&g_distinct, 64 * 16));
-	HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
-	HIP_TRY(hipMemsetAsync(n_surv, 0, 4, st));
-	HIP_TRY(hipMemsetAsync(g_distinct, 0, 64 * 16 * 8, st));
+	HIP_TRY(db.alloc(&g_distinct, 64 * 16 + 1));                     // one cleared block: the counters of distinct k-mers | error word, survivors
+	g_err = (u32*) (g_distinct + 64 * 16);
+	n_surv = g_err + 1;
+	HIP_TRY(hipMemsetAsync(g_distinct, 0, (64 * 16 + 1) * 8, st));
 	SurvOutG so{sv->lo, sv->hi, sv->gcnt, sv->gfirst, n_surv, cap};
 	static const u32 rd_dbg = (u32) tune("VDJX_RD_DBG", 0);        // profiles/reducedbg.py: the kernel stops after a phase
 	if (t.N) {
@@ -2361,21 +2361,28 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	const u32 nb16 = (ns + 15u) >> 4;
 	const u32 n_scan = (ns + SCAN_BLOCK - 1) / SCAN_BLOCK;
 	const u32 n_jump = (ceil_log2_u64((u64) ns + 1) + 3) / 4 + 1;      // launches that resolve every chain of up to `ns` nodes (16x each at least)
-	HIP_TRY(db.alloc(&bloom, bloom_bits / 32));
-	HIP_TRY(hipMemsetAsync(bloom, 0, bloom_bits / 8, st));
-	HIP_TRY(db.alloc(&table, (size_t) tmask + 1));
+	// what has to start as zeros lies in one block, cleared by one launch (six small clears cost the stream their turn-arounds)
+	{
+		auto up = [](size_t b) { return (b + 255) & ~(size_t) 255; };
+		const size_t b_bloom = up(bloom_bits / 8), b_table = up(((size_t) tmask + 1) * 16), b_pred = up((size_t) ns * 8), b_clen = up((size_t) ns * 4),
+		             b_jump = up((size_t) (n_jump + 1) * 4), b_linw = up(((size_t) nb16 + 1) * 8);     // (linw: the walk reads the word behind a run's first block)
+		uint8_t* z;
+		const size_t zb = b_bloom + b_table + b_pred + b_clen + b_jump + b_linw;
+		HIP_TRY(db.alloc(&z, zb));
+		HIP_TRY(hipMemsetAsync(z, 0, zb, st));
+		table = (ulonglong2*) z; z += b_table;
+		bloom = (u32*) z; z += b_bloom;
+		pred = (unsigned long long*) z; z += b_pred;
+		clen = (u32*) z; z += b_clen;
+		jump_open = (u32*) z; z += b_jump;
+		linw = (u64*) z;
+	}
 	HIP_TRY(db.alloc(&skey0, ns)); HIP_TRY(db.alloc(&skey, ns));
 	HIP_TRY(db.alloc(&succ0, (size_t) ns * 4)); HIP_TRY(db.alloc(&succ, (size_t) ns * 4));
-	HIP_TRY(db.alloc(&pred, ns)); HIP_TRY(db.alloc(&pd, ns)); HIP_TRY(db.alloc(&clen, ns)); HIP_TRY(db.alloc(&coff, ns));
+	HIP_TRY(db.alloc(&pd, ns)); HIP_TRY(db.alloc(&coff, ns));
 	HIP_TRY(db.alloc(&csum, n_scan)); HIP_TRY(db.alloc(&csum_start, n_scan + 1)); HIP_TRY(db.alloc(&newidx, ns));
-	HIP_TRY(db.alloc(&jump_open, n_jump + 1));
 	HIP_TRY(db.alloc(&lo2, ns)); HIP_TRY(db.alloc(&hi2, ns)); HIP_TRY(db.alloc(&gcnt2, ns)); HIP_TRY(db.alloc(&gfirst2, ns));
-	HIP_TRY(db.alloc(&linw, (size_t) nb16 + 1)); HIP_TRY(db.alloc(&fbw, nb16));
-	HIP_TRY(hipMemsetAsync(linw + nb16, 0, 8, st));        // (the walk reads the word behind a run's first block)
-	HIP_TRY(hipMemsetAsync(table, 0, ((size_t) tmask + 1) * 16, st));
-	HIP_TRY(hipMemsetAsync(pred, 0, (size_t) ns * 8, st));
-	HIP_TRY(hipMemsetAsync(clen, 0, (size_t) ns * 4, st));
-	HIP_TRY(hipMemsetAsync(jump_open, 0, (size_t) (n_jump + 1) * 4, st));
+	HIP_TRY(db.alloc(&fbw, nb16));
 	const SurvTable tb0{table, tmask, skey0, bloom, bloom_bits - 1};      // arrival numbering
 	const SurvTable tb{table, tmask, skey, bloom, bloom_bits - 1};        // chain order (after k_table_remap)
 	if (table_out) *table_out = tb;
@@ -2464,14 +2471,12 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	unsigned long long *g_cursor, *n_inst;
 	u32 *range_cnt, *range_start, *g_err, *gcur;
 	HIP_TRY(db.alloc(&raw, (size_t) raw_cap));
-	HIP_TRY(db.alloc(&g_cursor, 2));
+	HIP_TRY(db.alloc(&g_cursor, 4 + ((size_t) n_ranges_p + 1) / 2));      // one cleared block: cursor, instance count | error words | range counts
 	n_inst = g_cursor + 1;
-	HIP_TRY(db.alloc(&range_cnt, n_ranges_p));
+	g_err = (u32*) (g_cursor + 2);
+	range_cnt = (u32*) (g_cursor + 4);
 	HIP_TRY(db.alloc(&range_start, n_ranges_p + 1));
-	HIP_TRY(db.alloc(&g_err, 2));
-	HIP_TRY(hipMemsetAsync(g_cursor, 0, 16, st));
-	HIP_TRY(hipMemsetAsync(range_cnt, 0, (size_t) n_ranges_p * 4, st));
-	HIP_TRY(hipMemsetAsync(g_err, 0, 8, st));
+	HIP_TRY(hipMemsetAsync(g_cursor, 0, 32 + (size_t) n_ranges_p * 4, st));
 	const bool lng = pool->W > 2;
 	if (lng && R >= (1ull << 27)) { vdjx_set_error("more than 2^27 records of long reads on one GPU: not supported by the recount items"); return VDJX_ELIMIT; }
 	const size_t lds_walk = (((size_t) n_ranges_p + 1) & ~(size_t) 1) * 4 + (lng ? (size_t) WALK_THREADS * GL_ROW_LONG * 8 : 0);

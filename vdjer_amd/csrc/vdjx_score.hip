@@ -407,7 +407,7 @@ __device__ inline u32 map_present_bit(u32 cls) { return cls & ((1u << MAP_PRESEN
 template <int W>
 __global__ __launch_bounds__(MAP_THREADS) void k_map_classify(ReadIndexDev ix, const char* __restrict__ strings, u32 n, int len, bool weighted,
                                                               uint4* __restrict__ prep, u32* __restrict__ out_hits, u32* __restrict__ out_inst,
-                                                              u64* __restrict__ out_gkey, u32* __restrict__ out_gidx) {
+                                                              u64* __restrict__ out_gkey, u32* __restrict__ out_gidx, u32 w0) {
 	constexpr int TXT = MAP_MAXOFF + VDJX_MAX_READ_LEN;
 	__shared__ u64 wimg[TXT / 32 + 8];                      // the string as 2-bit codes, 32 bases per word, first base most significant
 	__shared__ u64 bimg[TXT / 64 + 4];                      // bit i: character i is not ACGT
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_classify(ReadIndexDev ix, c
 	constexpr int SW = VDJX_RI_SLOT_WORDS(W);
 	const int rl = ix.rl, noff = len - rl;
 	const u32 tid = threadIdx.x;
-	for (u32 wi = blockIdx.x; wi < n; wi += gridDim.x) {
+	for (u32 wi = w0 + blockIdx.x; wi < n; wi += gridDim.x) {         // strings [w0, n)
 		const char* w = strings + (size_t) wi * len;
 		for (u32 i = tid; i < TXT / 32 + 8; i += MAP_THREADS) wimg[i] = 0;
 		for (u32 i = tid; i < TXT / 64 + 4; i += MAP_THREADS) bimg[i] = 0;
@@ -1457,9 +1457,10 @@ __global__ void k_contig_counts(const u64* __restrict__ slice_pre, const u32* __
 // = the reference's order
 __global__ __launch_bounds__(256) void k_gather_pairs(const vdjx_pair* __restrict__ src, const u32* __restrict__ pair_hit, u32 n, u32 slice_hits,
                                                       const u32* __restrict__ slice_start, const u64* __restrict__ region_off,
-                                                      const u32* __restrict__ slice_bits, const u64* __restrict__ slice_pre, vdjx_pair* __restrict__ dst) {
+                                                      const u32* __restrict__ slice_bits, const u64* __restrict__ slice_pre, vdjx_pair* __restrict__ dst, u64 cap) {
 	__shared__ u32 wpre[MAP_SLICE_MAX / 32 + 1], wbit[MAP_SLICE_MAX / 32];
 	__shared__ u32 part[4];
+	if (slice_pre[gridDim.x] > cap) return;          // (launched before the host knew the total: the buffer is the last call's)
 	const u64 dof = slice_pre[blockIdx.x];
 	const u32 cnt = (u32) (slice_pre[blockIdx.x + 1] - dof);
 	if (!cnt) return;
@@ -1562,11 +1563,25 @@ static int classify_and_plan(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix,
 		HIP_TRY(db.alloc(&mp->d_gorder, n));
 	}
 	mp->d_hits = d_hits;
-	HIP_TRY(hipMemcpyAsync(d_s, strings, n * len, hipMemcpyHostToDevice, st));
-	{
+	// the strings cross PCIe in pieces on a stream of their own, each piece classified as soon as it is there (8.7 MB of windows: 0.18 ms
+	// of which the first quarter is waited for)
+	const u32 pieces = n * (size_t) len >= (2u << 20) ? 4u : 1u;
+	if (pieces > 1) {
+		HIP_TRY(hipEventRecord(c->ev_up[0], st));                  // (the arena's last users are on `st`)
+		HIP_TRY(hipStreamWaitEvent(c->up_stream, c->ev_up[0], 0));
+	}
+	for (u32 pc = 0; pc < pieces; pc++) {
+		const size_t a = n * (size_t) pc / pieces, b = n * (size_t) (pc + 1) / pieces;
+		if (pieces > 1) {
+			HIP_TRY(hipMemcpyAsync(d_s + a * len, strings + a * len, (b - a) * len, hipMemcpyHostToDevice, c->up_stream));
+			HIP_TRY(hipEventRecord(c->ev_up[1 + pc], c->up_stream));
+			HIP_TRY(hipStreamWaitEvent(st, c->ev_up[1 + pc], 0));
+		} else
+			HIP_TRY(hipMemcpyAsync(d_s, strings, n * len, hipMemcpyHostToDevice, st));
 		vdjx_prof_scope ps(c, "k_map_classify");
-		if (c->ri_pool->W == 2) hipLaunchKernelGGL(k_map_classify<2>, dim3((u32) std::min<size_t>(n, 8192)), dim3(MAP_THREADS), 0, st, ix, d_s, (u32) n, len, weighted, mp->d_prep, d_hits, d_inst, d_gkey, d_gidx);
-		else hipLaunchKernelGGL(k_map_classify<VDJX_LONG_W>, dim3((u32) std::min<size_t>(n, 8192)), dim3(MAP_THREADS), 0, st, ix, d_s, (u32) n, len, weighted, mp->d_prep, d_hits, d_inst, d_gkey, d_gidx);
+		const dim3 grid((u32) std::min<size_t>(b - a, 8192));
+		if (c->ri_pool->W == 2) hipLaunchKernelGGL(k_map_classify<2>, grid, dim3(MAP_THREADS), 0, st, ix, d_s, (u32) b, len, weighted, mp->d_prep, d_hits, d_inst, d_gkey, d_gidx, (u32) a);
+		else hipLaunchKernelGGL(k_map_classify<VDJX_LONG_W>, grid, dim3(MAP_THREADS), 0, st, ix, d_s, (u32) b, len, weighted, mp->d_prep, d_hits, d_inst, d_gkey, d_gidx, (u32) a);
 	}
 	{
 		vdjx_prof_scope ps(c, "k_plan");
@@ -1928,8 +1943,20 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 			hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, st, b_scnt, (u32) nsl, b_pre);
 			hipLaunchKernelGGL(k_contig_counts, dim3((u32) (n + 255) / 256), dim3(256), 0, st, b_pre, b_sstart, (u32) n, b_cnt);
 			HIP_TRY(hipMemcpyAsync(c->me_cnt.data(), b_cnt, n * 8, hipMemcpyDeviceToHost, st));
-		}
-		HIP_TRY(hipStreamSynchronize(st));
+			HIP_TRY(hipEventRecord(c->ev_plan, st));
+			// the pairs are laid end to end while the host still waits for their number: into the buffer of the last call if it is
+			// large enough (the kernel looks), again by the writing call if it was not
+			c->me_gathered_cap = 0;
+			if (c->me_dense_cap) {
+				HIP_TRY(hipStreamWaitEvent(st, c->ev_pairs_copied, 0));      // an earlier asynchronous copy may still be reading the buffer
+				vdjx_prof_scope ps(c, "k_gather_pairs");
+				hipLaunchKernelGGL(k_gather_pairs, dim3((u32) nsl), dim3(256), 0, st, (const vdjx_pair*) c->me_pairs, (const u32*) c->me_hit, (u32) n, slice_hits, b_sstart, b_off, b_bits, b_pre,
+				                   (vdjx_pair*) c->me_dense, (u64) c->me_dense_cap);
+				c->me_gathered_cap = c->me_dense_cap;
+			}
+			HIP_TRY(hipEventSynchronize(c->ev_plan));
+		} else
+			HIP_TRY(hipStreamSynchronize(st));
 		HIP_TRY(hipGetLastError());
 		lp.mark("me_kernel_wait");
 		c->me_key = key;
@@ -1954,16 +1981,20 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 		lp.mark("me_second_call");
 		HIP_TRY(hipStreamSynchronize(c->pairs_stream));          // an earlier asynchronous copy may still be reading the buffer
 		lp.mark("me_prev_copy_wait");
+		const bool gathered = total <= c->me_gathered_cap;
+		c->me_gathered_cap = 0;
 		if (total > c->me_dense_cap) {
+			HIP_TRY(hipStreamSynchronize(st));           // (a gather launched ahead that found the buffer too small may still be queued)
 			free_set(c->me_dense);
 			c->me_dense_cap = 0;
 			HIP_TRY(hipMalloc(&c->me_dense, (size_t) (total + total / 4) * sizeof(vdjx_pair)));
 			c->me_dense_cap = (size_t) (total + total / 4);
 		}
 		vdjx_pair* d_dense = (vdjx_pair*) c->me_dense;
-		if (nsl) {
+		if (nsl && !gathered) {
 			vdjx_prof_scope ps(c, "k_gather_pairs");
-			hipLaunchKernelGGL(k_gather_pairs, dim3((u32) nsl), dim3(256), 0, st, (const vdjx_pair*) c->me_pairs, (const u32*) c->me_hit, (u32) n, slice_hits, b_sstart, b_off, b_bits, b_pre, d_dense);
+			hipLaunchKernelGGL(k_gather_pairs, dim3((u32) nsl), dim3(256), 0, st, (const vdjx_pair*) c->me_pairs, (const u32*) c->me_hit, (u32) n, slice_hits, b_sstart, b_off, b_bits, b_pre, d_dense,
+			                   (u64) c->me_dense_cap);
 		}
 		if (device_only) {
 			// (vdjx_sam_text: the pairs stay in c->me_dense, the stream is not waited for)
@@ -1973,6 +2004,7 @@ static int map_emit_impl(vdjx_ctx* c, const char* contigs, size_t n, int len, ui
 			HIP_TRY(hipEventRecord(c->ev_gathered, st));
 			HIP_TRY(hipStreamWaitEvent(c->pairs_stream, c->ev_gathered, 0));
 			HIP_TRY(hipMemcpyAsync(pairs, d_dense, (size_t) total * sizeof(vdjx_pair), hipMemcpyDeviceToHost, c->pairs_stream));
+			HIP_TRY(hipEventRecord(c->ev_pairs_copied, c->pairs_stream));
 			lp.mark("me_copy_issue");
 		} else {
 			HIP_TRY(hipMemcpyAsync(pairs, d_dense, (size_t) total * sizeof(vdjx_pair), hipMemcpyDeviceToHost, st));
