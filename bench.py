@@ -431,7 +431,6 @@ def main():
     my_contigs = contigs_fixed
     my_wins_packed = ctx.pin_strings(my_wins, "windows")
     my_wins_rows = np.frombuffer("".join(my_wins).encode(), np.uint8).reshape(len(my_wins), -1) if my_wins else np.zeros((0, 486), np.uint8)
-    my_contig_rows = np.ascontiguousarray(my_wins_rows[:, 51:411])      # what a valid window hands to the SAM mapping (A2:841-847)
     my_contigs_packed = ctx.pin_strings(my_contigs, "contigs") if my_contigs else None
 
     def gather_bytes(a):
@@ -480,7 +479,7 @@ def main():
         if my_contigs is not None:
             cpk = my_contigs_packed if my_contigs_packed is not None else (b"", 0, 0)
         else:
-            cpk = ctx.pin_rows_take(my_contig_rows, np.flatnonzero(valid), "contigs")
+            cpk = ctx.pin_rows_take(my_wins_rows, np.flatnonzero(valid), "contigs", 51, 360)
         n_contigs = cpk[1]
         # the mapped pairs (20 B each) cross PCIe on the copy stream while the next step's kernels run; they are waited for before
         # the next map_emit reuses the stream (and after the last step, inside the timed region)

@@ -128,6 +128,9 @@ int vdjx_anchor_sets_from_anchors(vdjx_ctx* ctx, const uint32_t* v_anchors, size
  * No counterpart in the reference (its tables are host memory throughout).                          */
 int vdjx_host_alloc(vdjx_ctx* ctx, size_t bytes, void** out);
 void vdjx_host_free(vdjx_ctx* ctx, void* p);
+/* dst row i = bytes [first, first + len) of src row idx[i] (rows `stride` bytes apart): the contigs of the accepted windows, laid
+ * end to end for vdjx_map_emit (output_windows hands the [51,411) slice of a window that passed coverage on, A2:841-847,872-914). */
+int vdjx_host_take_rows(void* dst, const void* src, size_t stride, size_t first, size_t len, const uint32_t* idx, size_t n);
 
 /* ---- a-7: root (V-region homology) scorer ------------------------------------------------------
  * replaces: score_seq_init(k, 1000, v_region.fa) (seq_score.c:50-70) and score_seq(kmer, thr)

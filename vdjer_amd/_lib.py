@@ -18,7 +18,7 @@ SYMBOLS = [
     "vdjx_kmer_build", "vdjx_graph_nodes", "vdjx_graph_pre_nodes", "vdjx_graph_export", "vdjx_graph_export_begin", "vdjx_graph_export_end", "vdjx_graph_free",
     "vdjx_vregion_load", "vdjx_root_score", "vdjx_graph_roots", "vdjx_root_part", "vdjx_root_score_graph",
     "vdjx_read_index_build", "vdjx_read_index_build_device", "vdjx_window_score", "vdjx_window_pairs", "vdjx_window_pairs_fetch", "vdjx_window_cover", "vdjx_map_emit", "vdjx_map_emit_begin", "vdjx_map_emit_end", "vdjx_sam_names_load", "vdjx_sam_text",
-    "vdjx_host_alloc", "vdjx_host_free",
+    "vdjx_host_alloc", "vdjx_host_free", "vdjx_host_take_rows",
     "vdjx_stat", "vdjx_profile_enable", "vdjx_profile_reset", "vdjx_profile_count", "vdjx_profile_get",
     "vdjx_shard_begin", "vdjx_shard_free", "vdjx_shard_record_bytes", "vdjx_shard_local", "vdjx_shard_local_fill",
     "vdjx_shard_merge", "vdjx_shard_queries", "vdjx_shard_reply", "vdjx_shard_resolve",
@@ -112,6 +112,7 @@ def lib():
     L.vdjx_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.vdjx_host_free.argtypes = [vp, vp]
     L.vdjx_host_free.restype = None
+    L.vdjx_host_take_rows.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp, C.c_size_t]
     L.vdjx_stat.argtypes = [vp, C.c_char_p]
     L.vdjx_stat.restype = C.c_uint64
     L.vdjx_profile_enable.argtypes = [vp, i32]

@@ -342,9 +342,13 @@ class Context:
         C.memmove(ptr, rows.ctypes.data, rows.nbytes)
         return (C.cast(ptr, C.c_char_p), n, ln)
 
-    def pin_rows_take(self, rows: np.ndarray, idx: np.ndarray, tag: str):
-        """pin_array(rows[idx]) without the intermediate array: the chosen rows are gathered straight into the page-locked buffer"""
-        n, ln = int(idx.shape[0]), int(rows.shape[1])
+    def pin_rows_take(self, rows: np.ndarray, idx: np.ndarray, tag: str, first: int = 0, length: int | None = None):
+        """pin_array(rows[idx, first:first + length]) without intermediate arrays: the chosen rows' slices are copied straight into
+        the page-locked buffer (vdjx_host_take_rows)"""
+        assert rows.dtype == np.uint8 and rows.ndim == 2 and rows.flags.c_contiguous
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        n = int(idx.shape[0])
+        ln = int(rows.shape[1]) - first if length is None else int(length)
         need = max(n * ln, 1)
         ptr, cap = self._pinned.get("in:" + tag, (None, 0))
         if cap < need:
@@ -354,9 +358,9 @@ class Context:
             check(self.L.vdjx_host_alloc(self.h, need + need // 4, C.byref(new)), "vdjx_host_alloc")
             ptr, cap = new.value, need + need // 4
             self._pinned["in:" + tag] = (ptr, cap)
-        if n:
-            out = np.ctypeslib.as_array((C.c_uint8 * (n * ln)).from_address(ptr)).reshape(n, ln)
-            np.take(rows, idx, axis=0, out=out)
+        if n and int(idx.max()) >= rows.shape[0]:
+            raise IndexError("pin_rows_take: row index out of range")
+        check(self.L.vdjx_host_take_rows(ptr, rows.ctypes.data, rows.shape[1], first, ln, idx.ctypes.data, n), "vdjx_host_take_rows")
         return (C.cast(ptr, C.c_char_p), n, ln)
 
     def window_score(self, windows, ins: int, e0: int = 52, e1: int = 411, rs: int = 35, ms: int = 48, floor: int = 1):

@@ -694,6 +694,13 @@ extern "C" void vdjx_host_free(vdjx_ctx* c, void* p) {
 	(void) hipHostFree(p);
 }
 
+extern "C" int vdjx_host_take_rows(void* dst, const void* src, size_t stride, size_t first, size_t len, const uint32_t* idx, size_t n) {
+	if (n && (!dst || !src || !idx)) { vdjx_set_error("vdjx_host_take_rows: NULL argument"); return VDJX_EINVAL; }
+	if (first + len > stride) { vdjx_set_error("vdjx_host_take_rows: [first, first + len) leaves the row"); return VDJX_EINVAL; }
+	for (size_t i = 0; i < n; i++) memcpy((char*) dst + i * len, (const char*) src + (size_t) idx[i] * stride + first, len);
+	return VDJX_OK;
+}
+
 extern "C" size_t vdjx_pool_records(const vdjx_pool* p) { return p ? p->n_records : 0; }
 
 extern "C" void vdjx_pool_free(vdjx_pool* p) {
