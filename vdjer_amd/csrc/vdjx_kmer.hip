@@ -1845,13 +1845,16 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_items2(const u64* __restr
 
 // ---- the recount ------------------------------------------------------------------------------
 // One workgroup per range of SB scattered positions (SB/16 blocks of survivors).  A run [a, e] inside a block (positions in the
-// block) with first instance I gives element x the instance I + (x - a): the run is folded into ONE counter and ONE minimum of
-// v = I + 15 - a, by its shape --
-//   a == 0: prefix slot e        e == 15: suffix slot a        otherwise its elements one by one into the singles slots
-// (a read crosses a block boundary once: its two pieces are a suffix and a prefix run; interior runs come from reads with errors
-// and from chain ends) -- and the survivors' values are put together at the end:
-//   count(x) = sum prefix[e >= x] + sum suffix[a <= x] + single[x],   first(x) = min of the same slots - 15 + x,
-//   in-edge (x, first base of x - 1) = min over prefix[e >= x], suffix[a <= x - 1] - 15 + x   (and the singles' own in-edges)
+// block) with first instance I gives element x the instance I + (x - a).  No run is walked element by element:
+//   counts    every run adds 1 to the block's counter e and takes 1 from counter a - 1 (a > 0): count(x) = sum of the counters >= x
+//   minima    of v = I + 15 - a (first(x) = v - 15 + x), by the run's shape: a == 0 -> prefix slot e, e == 15 -> suffix slot a, and an
+//             interior run (a read with an error, a chain end) -> TWO window slots of width w = 2^floor(log2 length), the windows
+//             [a, a + w) and (e - w, e]: they cover the run, lie inside it and overlap, so every neighbouring pair (x - 1, x) of the
+//             run is inside one of them -- which is what the in-edge (x - 1 -> x) needs
+// and the survivors' values are put together at the end:
+//   first(x) = min over the slots whose run holds x, - 15 + x;   in-edge (x, first base of x - 1) = the same over the slots holding
+//   x - 1 and x (and the runs' own in-edges at their heads, `ef`)
+// (Round 3: the interior runs used to be walked -- one lane's 14 trips for the whole wave: 0.77 -> see profiles/README.md.)
 // Lanes of a wave that hit the same slot (deep clones) are combined before they touch LDS.
 #define RC_THREADS 1024
 #define RC_UNR 4
@@ -1861,15 +1864,18 @@ template <> struct RcNone<u64> { static constexpr u64 v = 0xFFFFFFFFFFFFFFFFull;
 __device__ inline void rc_min(u32* p, u32 v) { atomicMin(p, v); }
 __device__ inline void rc_min(u64* p, u64 v) { atomicMin((unsigned long long*) p, (unsigned long long) v); }
 
-// slots of block bl: [bl*45 + e] prefix by e (0..15), [+15 + a] suffix by a (1..15), [+30 + x] singles by x (1..14)
-#define RC_SLOTS 45u
-// IT = u32 while the local instance ids fit 32 bits (fewer than 2^26 records on this GPU): 38.5 bytes of LDS per survivor instead of 66
+// slots of block bl: counters [bl*16 + e]; minima [bl*76 + ...]: prefix by e (0..15), [+15 + a] suffix by a (1..15), [+31 + window]
+#define RC_CS 16u
+#define RC_MS 76u
+// window of width 2^k starting at s (1 <= s, s + 2^k - 1 <= 14): 14 + 13 + 11 + 7 = 45 slots
+__device__ inline u32 rc_win(u32 k, u32 s) { return 31u + ((0x261B0E00u >> (8u * k)) & 0xFFu) + s - 1u; }
+// IT = u32 while the local instance ids fit 32 bits (fewer than 2^26 records on this GPU)
 template <u32 SB, typename IT>
 __global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ items, const u32* __restrict__ range_start, ItemFmt f, u32 ns, u64 rec_base, int ob,
                                                         const u32* __restrict__ fbw, u32* __restrict__ ucnt, u64* __restrict__ ufirst, u64* __restrict__ in_first,
                                                         unsigned long long* __restrict__ n_inst) {
-	__shared__ u32 c[SB / 16 * RC_SLOTS];
-	__shared__ IT mv[SB / 16 * RC_SLOTS];
+	__shared__ u32 c[SB / 16 * RC_CS];
+	__shared__ IT mv[SB / 16 * RC_MS];
 	__shared__ IT ef[SB * 4];
 	__shared__ u32 fbl[SB / 16];
 	__shared__ unsigned long long tot;
@@ -1877,7 +1883,8 @@ __global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ 
 	const u32 b = blockIdx.x;
 	const u32 s0 = b * SB;
 	const u32 nb = (ns + 15u) >> 4;
-	for (u32 i = threadIdx.x; i < SB / 16 * RC_SLOTS; i += RC_THREADS) { c[i] = 0; mv[i] = NONE; }
+	for (u32 i = threadIdx.x; i < SB / 16 * RC_CS; i += RC_THREADS) c[i] = 0;
+	for (u32 i = threadIdx.x; i < SB / 16 * RC_MS; i += RC_THREADS) mv[i] = NONE;
 	for (u32 i = threadIdx.x; i < SB * 4; i += RC_THREADS) ef[i] = NONE;
 	for (u32 i = threadIdx.x; i < SB / 16; i += RC_THREADS) {
 		const u32 sb = (s0 >> 4) + i;
@@ -1899,12 +1906,13 @@ __global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ 
 			const u64 x = xs[u];
 			const bool live = x != IT_HOLE;
 			const u32 p = it_surv(f, x);
-			const u32 len = live ? it_len(f, x) : 0u;
+			const u32 len = live ? it_len(f, x) : 1u;
 			const u32 sl = live ? it_scat(f, p) - s0 : 0u;             // local position of the run's first survivor
 			const u32 a = sl & 15u, e = a + len - 1u;
 			const u64 inst = x & IT_INST_MASK;
 			const bool shaped = live && (a == 0u || e == 15u);
-			const u32 slot = (sl >> 4) * RC_SLOTS + (a == 0u ? e : 15u + a);
+			const u32 cb = (sl >> 4) * RC_CS, mb = (sl >> 4) * RC_MS;
+			const u32 slot = mb + (a == 0u ? e : 15u + a);
 			const IT val = (IT) (inst + 15u - a);
 			// the lanes that share the first shaped lane's slot are folded into one add and one min when they are many (deep clones)
 			bool mine = shaped;
@@ -1919,25 +1927,24 @@ __global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ 
 					const u64 v64 = inst + 15u - a;
 					const u32 hi_min = vdjx_wave_min(same ? (u32) (v64 >> 32) : 0xFFFFFFFFu);
 					const u32 lo_min = vdjx_wave_min(same && (u32) (v64 >> 32) == hi_min ? (u32) v64 : 0xFFFFFFFFu);
-					if (__lane_id() == leader) {
-						atomicAdd(&c[lslot], (u32) __popcll(m));
+					if (__lane_id() == leader) {                          // (the lanes of one slot share a and e)
+						const u32 n = (u32) __popcll(m);
+						atomicAdd(&c[cb + e], n);
+						if (a) atomicAdd(&c[cb + a - 1u], 0u - n);
 						rc_min(&mv[lslot], (IT) (((u64) hi_min << 32) | lo_min));
 					}
 					mine = shaped && !same;
 				}
 			}
-			if (mine) { atomicAdd(&c[slot], 1u); rc_min(&mv[slot], val); }
-			if (live && !shaped) {                                       // an interior run: element by element, with its own in-edges
-				const u32 fw = fbl[sl >> 4];
-				const u32 s1 = (sl >> 4) * RC_SLOTS + 30u;
-				for (u32 j = 0; j < len; j++) {
-					atomicAdd(&c[s1 + a + j], 1u);
-					rc_min(&mv[s1 + a + j], (IT) (inst + j + 15u - (a + j)));
-					if (j) {
-						IT* ep = &ef[(sl + j) * 4 + ((fw >> (2 * (a + j - 1))) & 3u)];
-						if (vdjx_peek(ep) > (IT) (inst + j)) rc_min(ep, (IT) (inst + j));
-					}
-				}
+			if (live && (mine || !shaped)) {
+				atomicAdd(&c[cb + e], 1u);
+				if (a) atomicAdd(&c[cb + a - 1u], 0xFFFFFFFFu);
+			}
+			if (mine) rc_min(&mv[slot], val);
+			if (live && !shaped) {                                       // an interior run: two windows of width 2^k <= its length
+				const u32 k = 31u - (u32) __builtin_clz(len), w = 1u << k;
+				rc_min(&mv[mb + rc_win(k, a)], val);
+				if (len != w) rc_min(&mv[mb + rc_win(k, e + 1u - w)], val);
 			}
 			if (live && ((x >> 37) & 1ull)) {
 				IT* ep = &ef[sl * 4 + (u32) ((x >> 35) & 3ull)];
@@ -1953,13 +1960,18 @@ __global__ __launch_bounds__(RC_THREADS) void k_recount(const u64* __restrict__ 
 		const u32 blk = (sb * f.inv) & f.bmask;
 		const u32 x = i & 15u, p = (blk << 4) | x;
 		if (sb > f.bmask || blk >= nb || p >= ns) continue;
-		const u32 sbase = (i >> 4) * RC_SLOTS;
-		const bool inner = x >= 1u && x <= 14u;
-		u32 cc = inner ? c[sbase + 30 + x] : 0u;
-		IT mm = inner ? mv[sbase + 30 + x] : NONE;             // every run that holds x
-		IT me = NONE;                                          // every shaped run that holds x - 1 and x
-		for (u32 e = x; e < 16; e++) { cc += c[sbase + e]; const IT t = mv[sbase + e]; mm = t < mm ? t : mm; if (x) me = t < me ? t : me; }
-		for (u32 a = 1; a <= x; a++) { cc += c[sbase + 15 + a]; const IT t = mv[sbase + 15 + a]; mm = t < mm ? t : mm; if (a < x) me = t < me ? t : me; }
+		const u32 cbase = (i >> 4) * RC_CS, mbase = (i >> 4) * RC_MS;
+		u32 cc = 0;
+		IT mm = NONE;                                          // every run that holds x
+		IT me = NONE;                                          // every run that holds x - 1 and x
+		for (u32 e = x; e < 16; e++) { cc += c[cbase + e]; const IT t = mv[mbase + e]; mm = t < mm ? t : mm; if (x) me = t < me ? t : me; }
+		for (u32 a = 1; a <= x; a++) { const IT t = mv[mbase + 15 + a]; mm = t < mm ? t : mm; if (a < x) me = t < me ? t : me; }
+#pragma unroll
+		for (u32 k = 0; k < 4; k++) {                          // windows [s, s + w): 1 <= s, s + w - 1 <= 14
+			const u32 w = 1u << k;
+			const u32 lo = x >= w ? x - w + 1u : 1u, hi = x < 15u - w ? x : 15u - w;
+			for (u32 s = lo ? lo : 1u; s <= hi; s++) { const IT t = mv[mbase + rc_win(k, s)]; mm = t < mm ? t : mm; if (s < x) me = t < me ? t : me; }
+		}
 		my_cnt += cc;
 		ucnt[p] = cc;
 		ufirst[p] = mm == NONE ? NONE64 : (u64) mm - 15u + x + add;
