@@ -1864,9 +1864,10 @@ template <> struct RcNone<u64> { static constexpr u64 v = 0xFFFFFFFFFFFFFFFFull;
 __device__ inline void rc_min(u32* p, u32 v) { atomicMin(p, v); }
 __device__ inline void rc_min(u64* p, u64 v) { atomicMin((unsigned long long*) p, (unsigned long long) v); }
 
-// slots of block bl: counters [bl*16 + e]; minima [bl*76 + ...]: prefix by e (0..15), [+15 + a] suffix by a (1..15), [+31 + window]
-#define RC_CS 16u
-#define RC_MS 76u
+// slots of block bl: counters [bl*17 + e]; minima [bl*77 + ...]: prefix by e (0..15), [+15 + a] suffix by a (1..15), [+31 + window]
+// (16 counters and 76 minima per block; the odd strides keep the blocks' counter 15 -- where every suffix run counts -- on different banks)
+#define RC_CS 17u
+#define RC_MS 77u
 // window of width 2^k starting at s (1 <= s, s + 2^k - 1 <= 14): 14 + 13 + 11 + 7 = 45 slots
 __device__ inline u32 rc_win(u32 k, u32 s) { return 31u + ((0x261B0E00u >> (8u * k)) & 0xFFu) + s - 1u; }
 // IT = u32 while the local instance ids fit 32 bits (fewer than 2^26 records on this GPU)
