@@ -847,3 +847,46 @@ def test_long_reads_at_the_histogram_cap(ctx, rl, n_pairs):
     jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
     hg = run_both(ctx, pool, vc, jc, 35, 3, 90)
     assert hg.n > 10_000
+
+
+def test_calls_that_grow_and_shrink(ctx):
+    """The root DP is launched for the LAST call's item count and the mapped pairs are gathered into the LAST call's buffer before the
+    host knows this call's numbers: a small call, a much larger one (the guess is short: a second launch / a new buffer), the small one
+    again (the guess is long), each against the oracle; and the contigs picked out of window rows in page-locked memory."""
+    from oracle import oracle
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(6, seed=77)
+    lines = [rep.v_region]
+    s = oracle.RootScorer(lines, 15)
+    ctx.vregion_load(lines, 15)
+    rng = np.random.default_rng(8)
+    qs = []
+    for _ in range(2000):
+        st = int(rng.integers(0, len(rep.v_region) - 35))
+        q = list(rep.v_region[st:st + 35])
+        for _m in range(int(rng.integers(0, 6))):
+            q[int(rng.integers(0, 35))] = "ACGT"[int(rng.integers(0, 4))]
+        qs.append("".join(q))
+    exp = [s.score(q, 30) for q in qs]
+    for sel in (slice(0, 3), slice(0, 2000), slice(5, 9), slice(0, 700), slice(0, 0), slice(0, 2000)):
+        assert ctx.root_score(qs[sel], 35, 30).tolist() == exp[sel]
+        if qs[sel]:
+            assert ctx.stat("root_dp_items") > 0
+    pool = synth.tile_reads(rep, list(range(6)), ins=175, copies=6, step=3)
+    ix = oracle.ReadIndex(pool)
+    p = _load_index(ctx, pool)
+    wins = [w for w in rep.windows() if w]
+    rows = np.frombuffer("".join(wins).encode(), np.uint8).reshape(len(wins), -1)
+    contigs = [w[51:411] for w in wins]
+    want = [ix.quick_map(c)[0] for c in contigs]
+    for idx in ([0], list(range(len(contigs))), [2, 1], [], list(range(len(contigs))), [1]):
+        packed = ctx.pin_rows_take(rows, np.array(idx, dtype=np.int64), "contigs_test", 51, 360)
+        assert packed[1] == len(idx) and packed[2] == 360
+        offs, got = ctx.map_emit(packed)
+        assert int(offs[-1]) == sum(len(want[j]) for j in idx)
+        for n_, j in enumerate(idx):
+            mine = got[int(offs[n_]):int(offs[n_ + 1])]
+            assert mine.shape[0] == len(want[j]) > 0
+            for fld in ("pair_id", "rec1", "rec2", "pos1", "pos2", "insert", "rc1", "rc2"):
+                assert np.array_equal(mine[fld].astype(np.int64), want[j][fld].astype(np.int64)), (idx, j, fld)
+    p.free()
