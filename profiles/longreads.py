@@ -16,7 +16,7 @@ rep = synth.make_repertoire(max(4, pairs // 500), seed=20261002)
 pool = synth.make_reads_cb(rep, pairs, noise_frac=0.3, rl=rl, seed=20261002 + 7, device="cuda:0")
 vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
 jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
-ctx = api.Context(0)
+ctx = api.Context(0, pinned_results=True)
 ctx.anchor_sets_load(vc, jc)
 ctx.profile(True)
 import time  # noqa: E402
