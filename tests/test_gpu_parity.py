@@ -890,3 +890,38 @@ def test_calls_that_grow_and_shrink(ctx):
             for fld in ("pair_id", "rec1", "rec2", "pos1", "pos2", "insert", "rc1", "rc2"):
                 assert np.array_equal(mine[fld].astype(np.int64), want[j][fld].astype(np.int64)), (idx, j, fld)
     p.free()
+
+
+@pytest.mark.parametrize("rl", [65, 75, 100, 130, 151, 160])
+def test_long_reads_resident_records(ctx, rl):
+    """vdjx_pool_load_device on reads of more than 64 bases (records resident on the device, packed four characters at a time) gives
+    the pool of vdjx_pool_load (character by character) on the same records -- N, other letters, low qualities and every tail
+    length included: same graph, same count of other bases"""
+    import torch
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(3, seed=191 + rl)
+    pool = synth.make_reads(rep, 9000, noise_frac=0.2, seed=192 + rl, rl=rl, ins_mean=max(175.0, rl + 40.0), err=0.003, n_rate=0.002)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    ctx.anchor_sets_load(vc, jc)
+    pri, sec = pool.primary.copy(), pool.secondary.copy()
+    rng = np.random.default_rng(rl)
+    for a in (pri, sec):                                     # letters the BAM alphabet has besides ACGTN, at every column of the read
+        rows = rng.integers(0, a.shape[0], 300)
+        a[rows, 1 + rng.integers(0, rl, 300)] = np.frombuffer(b"RYKMSWacgtn.", np.uint8)[rng.integers(0, 12, 300)]
+        rows = rng.integers(0, a.shape[0], 600)
+        a[rows, 1 + rl + rng.integers(0, rl, 600)] = rng.integers(33, 54, 600).astype(np.uint8)      # Phred 0..20 around the gate
+    p1 = ctx.pool_load(pri, sec, rl)
+    other = ctx.stat("pool_other_bases")
+    assert other > 0
+    g1 = ctx.kmer_build(p1, 35, 3, 90)
+    # (device records must be 16-byte aligned and stay alive while the pool reads their quality characters)
+    d_pri, d_sec = torch.from_numpy(pri).cuda(), torch.from_numpy(sec).cuda()
+    p2 = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
+    assert ctx.stat("pool_other_bases") == other
+    g2 = ctx.kmer_build(p2, 35, 3, 90)
+    assert g1.n == g2.n > 100 and g1.pre_nodes == g2.pre_nodes
+    for f in ("first_inst", "freq", "gated_count", "has_v", "has_j", "to_ids", "from_ids", "kmers"):
+        np.testing.assert_array_equal(getattr(g1, f), getattr(g2, f))
+    p1.free()
+    p2.free()
