@@ -3,6 +3,8 @@
   (2) the CPU oracle (oracle/vdjx_oracle.c) on seeded inputs.
 Everything is integer / byte / index work: comparisons are bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -399,6 +401,10 @@ def test_window_score_vs_oracle_seeded(ctx):
             wins.append(t[s:s + 486])
     for ins, rs, ms, fl in ((175, 35, 48, 1), (160, 30, 60, 2), (175, 35, 48, 0), (230, 35, 48, 1)):
         valid, npairs = ctx.window_score(wins, ins, rs=rs, ms=ms, floor=fl)
+        if os.environ.get("VDJX_WP_BUDGET_MB") == "1":           # (the fresh-process run below: the windows go in slices)
+            assert ctx.stat("window_slices") > 1
+        else:
+            assert ctx.stat("window_slices") == 1
         for i, w in enumerate(wins):
             pairs, starts = ix.quick_map(w)
             assert int(npairs[i]) == len(pairs)
@@ -770,7 +776,24 @@ def test_window_scorer_without_grouping_in_a_fresh_process():
         pytest.skip("already the ungrouped run")
     env = dict(os.environ, VDJX_WINDOW_GROUP="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_fuzz.py"),
-                        "-m", "gpu", "-x", "-q", "-k", "window or scorers or deep_windows"],
+                        "-m", "gpu", "-x", "-q", "-k", "(window or scorers or deep_windows) and not in_slices"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+def test_window_scorer_in_slices_in_a_fresh_process():
+    """The pair lists of a vdjx_window_score call are sized by its windows' hits; what does not fit the device is done in slices of
+    windows (400 k windows over 10 M pairs would ask for 600 GB).  VDJX_WP_BUDGET_MB=1 (read once per process) puts the scorer tests'
+    small calls through the slices: same verdicts, same pair counts."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.environ.get("VDJX_WP_BUDGET_MB"):
+        pytest.skip("already the sliced run")
+    env = dict(os.environ, VDJX_WP_BUDGET_MB="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_fuzz.py"),
+                        "-m", "gpu", "-x", "-q", "-k", "(window_score or scorers or deep_windows or grouped_window) and not fresh_process"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout

@@ -1616,8 +1616,10 @@ static int cov_params_check(const vdjx_cov_params* p, const char* who) {
 
 // K8 over n windows: the (weighted) mapped-pair list of every window in the context's pair buffer; the list of window i
 // is wp_buf[d_off[i] .. + d_cnt[i])
+// budget (bytes, 0: none): pair lists that would need more are not built -- *need = their bytes, nothing else done (the caller takes
+// fewer windows at a time)
 static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, const char* windows, size_t n, int len, u32** d_np_out,
-                            u32** d_cnt_out, MapPlan* mp) {
+                            u32** d_cnt_out, MapPlan* mp, u64 budget = 0, u64* need = nullptr) {
 	hipStream_t st = c->stream;
 	u32 *d_np, *d_cnt;
 	static const u32 hit_chunk = getenv("VDJX_HIT_CHUNK") && atol(getenv("VDJX_HIT_CHUNK")) > 0 ? (u32) atol(getenv("VDJX_HIT_CHUNK")) : HIT_CHUNK;
@@ -1653,6 +1655,12 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 	if ((rc = plan_finish(c, mp))) return rc;
 	const u64 total = mp->tot.total_hits;
 	bool again = !early;
+	if (need) *need = 0;
+	if ((size_t) total + 1 > c->wp_cap && budget && n > 1 && (total + total / 4 + 1024) * 8 > budget) {
+		HIP_TRY(hipStreamSynchronize(st));                  // (the early launch has returned without a write)
+		*need = (total + total / 4 + 1024) * 8;
+		return VDJX_OK;
+	}
 	if ((size_t) total + 1 > c->wp_cap) {
 		HIP_TRY(hipStreamSynchronize(st));                  // (the early launch, if any, has returned without a write: wait before the buffer goes)
 		free_set(c->wp_buf);
@@ -1682,25 +1690,17 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 	return VDJX_OK;
 }
 
-extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int len, const vdjx_cov_params* p,
-                                 uint8_t* out_valid, uint32_t* out_npairs) {
-	if (!c || !p || (n && (!windows || !out_valid || !out_npairs))) { vdjx_set_error("vdjx_window_score: NULL argument"); return VDJX_EINVAL; }
-	if (n == 0) return VDJX_OK;
-	ReadIndexDev ix;
-	int rc = make_index_view(c, &ix, len, "vdjx_window_score");
-	if (rc) return rc;
-	if ((rc = cov_params_check(p, "vdjx_window_score"))) return rc;
-	if (n >= (1ull << 31)) { vdjx_set_error("vdjx_window_score: too many windows"); return VDJX_ELIMIT; }
-	HIP_TRY(hipSetDevice(c->device));
-	vdjx_clear_errors();
+// one slice of windows; *need != 0 on return: its pair lists do not fit the budget, nothing was written
+static int window_score_slice(vdjx_ctx* c, const ReadIndexDev& ix, const char* windows, size_t n, int len, const vdjx_cov_params* p,
+                              uint8_t* out_valid, uint32_t* out_npairs, u64 budget, u64* need) {
 	hipStream_t st = c->stream;
 	vdjx_work db(c);
 	u32 *d_np, *d_cnt;
 	uint8_t* d_valid;
 	MapPlan mp;
 	HIP_TRY(db.alloc(&d_valid, n));
-	rc = window_pairs_run(c, db, ix, windows, n, len, &d_np, &d_cnt, &mp);
-	if (rc) return rc;
+	int rc = window_pairs_run(c, db, ix, windows, n, len, &d_np, &d_cnt, &mp, budget, need);
+	if (rc || *need) return rc;
 	c->wp_n = 0;                                              // (the lists are not offered to vdjx_window_pairs_fetch)
 	{
 		vdjx_prof_scope ps(c, "k_window_cover");
@@ -1741,6 +1741,54 @@ extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int
 		c->stats["window_pairs"] = tot;                    // mapped pairs (with multiplicity)
 		c->stats["window_pairs_entries"] = ent;            // entries of the weighted lists
 	}
+	return VDJX_OK;
+}
+
+extern "C" int vdjx_window_score(vdjx_ctx* c, const char* windows, size_t n, int len, const vdjx_cov_params* p,
+                                 uint8_t* out_valid, uint32_t* out_npairs) {
+	if (!c || !p || (n && (!windows || !out_valid || !out_npairs))) { vdjx_set_error("vdjx_window_score: NULL argument"); return VDJX_EINVAL; }
+	if (n == 0) return VDJX_OK;
+	ReadIndexDev ix;
+	int rc = make_index_view(c, &ix, len, "vdjx_window_score");
+	if (rc) return rc;
+	if ((rc = cov_params_check(p, "vdjx_window_score"))) return rc;
+	if (n >= (1ull << 31)) { vdjx_set_error("vdjx_window_score: too many windows"); return VDJX_ELIMIT; }
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
+	// The pair lists of a call are sized by its windows' hits (8 bytes each; reads of a shared V germline hit every window that has
+	// it: the sum grows with windows x pool).  What does not fit the device is done in slices of windows, every slice like a call of
+	// its own (400 k windows over 10 M pairs ask for 600 GB at once).  VDJX_WP_BUDGET_MB: the tests' way into the slices.
+	static const u64 budget_env = getenv("VDJX_WP_BUDGET_MB") && atol(getenv("VDJX_WP_BUDGET_MB")) > 0 ? (u64) atol(getenv("VDJX_WP_BUDGET_MB")) << 20 : 0;
+	u64 budget = budget_env;
+	if (!budget) {
+		size_t fr = 0, tt = 0;
+		HIP_TRY(hipMemGetInfo(&fr, &tt));
+		budget = ((u64) fr + (u64) c->wp_cap * 8) / 10 * 8;            // (the buffer in hand is given back before a larger one is asked for)
+	}
+	static const char* const summed[] = {"window_hits", "window_hits_distinct", "window_work_items", "group_hits_distinct", "group_overflows", "group_classes",
+	                                     "group_queued", "window_pairs", "window_pairs_entries"};
+	std::map<std::string, uint64_t> acc;
+	u64 hits_max = 0, slices = 0;
+	size_t at = 0, step = n;
+	while (at < n) {
+		const size_t m = std::min(step, n - at);
+		u64 need = 0;
+		rc = window_score_slice(c, ix, windows + at * (size_t) len, m, len, p, out_valid + at, out_npairs + at, budget, &need);
+		if (rc) return rc;
+		if (need) {                                          // fewer windows: in proportion, with a margin
+			step = std::max<size_t>(1, std::min<size_t>(m - 1, (size_t) ((double) m * (double) budget / (double) need * 0.8)));
+			continue;
+		}
+		for (const char* k_ : summed) acc[k_] += c->stats[k_];
+		hits_max = std::max<u64>(hits_max, c->stats["window_hits_max"]);
+		slices++;
+		at += m;
+	}
+	if (slices > 1) {
+		for (const char* k_ : summed) c->stats[k_] = acc[k_];
+		c->stats["window_hits_max"] = hits_max;
+	}
+	c->stats["window_slices"] = slices;
 	return VDJX_OK;
 }
 
