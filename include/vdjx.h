@@ -173,7 +173,8 @@ typedef struct {
 } vdjx_cov_params;
 
 /* windows: n strings of `len` chars, stride `len`.  out_valid[i] = coverage_is_valid(...),
- * out_npairs[i] = mapped pairs. */
+ * out_npairs[i] = mapped pairs.  Any n: the windows' pair lists (8 bytes per distinct hit) are built in device memory, and a call
+ * whose lists would not fit takes its windows in slices (vdjx_stat "window_slices"); one window's lists have to fit. */
 int vdjx_window_score(vdjx_ctx* ctx, const char* windows, size_t n, int len, const vdjx_cov_params* p,
                       uint8_t* out_valid, uint32_t* out_npairs);
 
