@@ -631,8 +631,17 @@ __device__ inline u32 plan_block_scan(u32 v, u32* tmp, u32& total) {       // ex
 // they come, wstart[j] = work items before position j of that order, where string i has ceil(hits / chunk) of them (at least one if
 // min_one).  chunk_fixed == 0: the slice length of k_map_emit, chosen from the total.  A stable_sort of 20,000 windows on the host,
 // the list of their slices and three transfers cost more than the coverage kernel ran.
-__global__ __launch_bounds__(1024) void k_plan(const u32* __restrict__ hits, const u32* __restrict__ inst, u32 n, u32 chunk_fixed, int sorted, int min_one,
-                                               u64* __restrict__ off, u32* __restrict__ order, u32* __restrict__ wstart, PlanOut* __restrict__ out) {
+// (One workgroup; every thread owns a run of consecutive strings and walks it five times.  `staged`: the hit counts are first copied
+// into dynamic LDS with consecutive lanes on consecutive addresses -- read from global memory a thread's run was a chain of line
+// fills per pass: 105 us for 20,000 windows.)
+__global__ __launch_bounds__(1024) void k_plan(const u32* __restrict__ hits_g, const u32* __restrict__ inst, u32 n, u32 chunk_fixed, int sorted, int min_one,
+                                               u64* __restrict__ off, u32* __restrict__ order, u32* __restrict__ wstart, PlanOut* __restrict__ out, int staged) {
+	extern __shared__ u32 hits_l[];
+	if (staged) {
+		for (u32 i = threadIdx.x; i < n; i += 1024) hits_l[i] = hits_g[i];
+		__syncthreads();
+	}
+	const u32* hits = staged ? hits_l : hits_g;
 	__shared__ u64 part[1024];
 	__shared__ u32 tmp[16];
 	__shared__ u64 s_inst;
@@ -644,7 +653,8 @@ __global__ __launch_bounds__(1024) void k_plan(const u32* __restrict__ hits, con
 	if (tid == 0) { s_inst = 0; s_imax = 0; }
 	u64 s = 0, is = 0;
 	u32 im = 0;
-	for (u32 i = lo; i < hi; i++) { s += hits[i]; const u32 x = inst[i]; is += x; im = im > x ? im : x; }
+	for (u32 i = lo; i < hi; i++) s += hits[i];
+	for (u32 i = tid; i < n; i += 1024) { const u32 x = inst[i]; is += x; im = im > x ? im : x; }      // (sum and maximum: any order)
 	part[tid] = s;
 	__syncthreads();
 	for (u32 d = 1; d < 1024; d <<= 1) {
@@ -1585,7 +1595,10 @@ static int classify_and_plan(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix,
 	}
 	{
 		vdjx_prof_scope ps(c, "k_plan");
-		hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, st, d_hits, d_inst, (u32) n, chunk_fixed, weighted ? 1 : 0, weighted ? 1 : 0, mp->d_off, mp->d_order, mp->d_wstart, d_tot);
+		const bool staged = n * 4 <= 96 * 1024;
+		if (staged) HIP_TRY(hipFuncSetAttribute((const void*) k_plan, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+		hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), staged ? n * 4 : 0, st, d_hits, d_inst, (u32) n, chunk_fixed, weighted ? 1 : 0, weighted ? 1 : 0, mp->d_off, mp->d_order, mp->d_wstart, d_tot,
+		                   staged ? 1 : 0);
 	}
 	if (grouped) {
 		vdjx_prof_scope ps(c, "group_sort");
