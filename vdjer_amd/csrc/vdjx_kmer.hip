@@ -1579,9 +1579,11 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 	// the wave's queue, and the queued records are walked 64 at a time, every lane with the same need.  (VDJX_WALK_DBG=32 with
 	// -DWALK_STATS counted, per row of 64 records: 4.6 rounds, the filter in 1.3 of them; profiles/README.md, round 3.)
 	__shared__ u64 dq[WALK_THREADS / 64][128];
+	__shared__ ulonglong2 dq_b[LONG ? 1 : WALK_THREADS / 64][LONG ? 1 : 128];      // (short reads: the record travels with its queue entry --
+	__shared__ u64 dq_v[LONG ? 1 : WALK_THREADS / 64][LONG ? 1 : 128];             //  read again from the pool it is two random line fills per lane)
 	const u32 wq = threadIdx.x >> 6;
 	u32 qn = 0;                                   // (wave-uniform)
-	auto walk_row = [&](auto fresh_tag, const size_t r, const bool live, const int o_from) {
+	auto walk_row = [&](auto fresh_tag, const size_t r, const bool live, const int o_from, const ulonglong2 qb, const u64 qv) {
 		constexpr bool FRESH = decltype(fresh_tag)::value;
 		RecT v;
 		MaskT V{};                                    // the offsets whose k bases are all valid (bit o of nm = base o is N or masked)
@@ -1598,7 +1600,8 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				for (int w = 0; w < GL_ROW_LONG; w++) myrow[w] = 0;
 		} else {
 			v.bhi = v.blo = 0; v.rl = rl;
-			if (live) {
+			if (!FRESH) { if (live) { v.bhi = qb.x; v.blo = qb.y; V = qv; } }
+			else if (live) {
 				const RecView rv = load_rec(bases, nmask, nullptr, r);
 				v.bhi = rv.bhi; v.blo = rv.blo;
 				u64 inv = rv.nm;
@@ -1622,7 +1625,12 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				const bool later = need && !first;
 				const u64 lm = __ballot(later);
 				if (lm) {
-					if (later) { dq[wq][qn + (u32) __popcll(lm & ((1ull << lane) - 1ull))] = ((u64) r << 8) | (u64) (u32) o; o = P; need = false; }
+					if (later) {
+						const u32 qi = qn + (u32) __popcll(lm & ((1ull << lane) - 1ull));
+						dq[wq][qi] = ((u64) r << 8) | (u64) (u32) o;
+						if constexpr (!LONG) { dq_b[wq][qi] = make_ulonglong2(v.bhi, v.blo); dq_v[wq][qi] = V; }
+						o = P; need = false;
+					}
 					qn += (u32) __popcll(lm);
 				}
 			}
@@ -1739,13 +1747,16 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 		vdjx_wave_lds_fence();
 		const bool live = (u32) lane < take;
 		const u64 e = live ? dq[wq][qn - take + (u32) lane] : 0ull;
+		ulonglong2 qb = make_ulonglong2(0ull, 0ull);
+		u64 qv = 0;
+		if constexpr (!LONG) if (live) { qb = dq_b[wq][qn - take + (u32) lane]; qv = dq_v[wq][qn - take + (u32) lane]; }
 		vdjx_wave_lds_fence();
 		qn -= take;
-		walk_row(std::false_type{}, (size_t) (e >> 8), live, (int) (e & 255u));
+		walk_row(std::false_type{}, (size_t) (e >> 8), live, (int) (e & 255u), qb, qv);
 	};
 	for (size_t rb = r0; rb < r1; rb += WALK_THREADS) {
 		const size_t r = rb + threadIdx.x;
-		walk_row(std::true_type{}, r, r < r1, 0);
+		walk_row(std::true_type{}, r, r < r1, 0, make_ulonglong2(0ull, 0ull), 0ull);
 		while (qn >= 64) walk_queued(64);
 	}
 	if (qn) walk_queued(qn);
