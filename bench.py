@@ -375,18 +375,26 @@ def main():
     ri_dev = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank)]
     torch.cuda.synchronize()
     ix_times = []
+
+    def build_index():
+        ctx.read_index_build_device(p_index, ri_dev[0].data_ptr(), ri_dev[1].data_ptr(), ri_dev[2].data_ptr(), ri_dev[3].data_ptr(), pool.n_pairs)
+    build_index()                       # (first call: allocations)
+    ctx.profile(True)
+    ctx.profile_reset()
     for _ in range(3):
         t_ix = time.perf_counter()
-        ctx.read_index_build_device(p_index, ri_dev[0].data_ptr(), ri_dev[1].data_ptr(), ri_dev[2].data_ptr(), ri_dev[3].data_ptr(), pool.n_pairs)
+        build_index()
         ix_times.append(time.perf_counter() - t_ix)
-    del ri_dev
+    ri_prof = ctx.profile_get()
+    ctx.profile(False)
+    ctx.profile_reset()
     scorer = None
     if engine is not None:
         from vdjer_amd import shard as _shard
         scorer = _shard.HipScorerEngine(ctx, dev, rl)
     host_side["read_index_build_s"] = round(min(ix_times), 4)
-    host_side["read_index_build_first_call_s"] = round(ix_times[0], 4)
-    host_side["read_index"] = {n_: ctx.stat("read_index_" + n_) for n_ in ("classes", "r1_members", "r1_distinct")}
+    host_side["read_index"] = {n_: ctx.stat("read_index_" + n_) for n_ in ("classes", "r1_members", "r1_distinct", "rank_order")}
+    host_side["read_index_kernels_ms"] = {k_: round(v[0] / 3, 4) for k_, v in ri_prof.items()}
     scorer_src = ("one 486-nt window per clone from the generator (the window the reference derives for that clone's transcript) and, as contigs, the "
                   "[51,411) slices of the windows the coverage test accepts; the host traversal is not run at this size: its contig "
                   "enumeration explodes combinatorially on this repertoire (see --windows)")
@@ -503,7 +511,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    first_step_ms = None
+    if args.warmup:
+        torch.cuda.synchronize()
+        t_first = time.perf_counter()
+        step()
+        ctx.map_emit_wait()
+        torch.cuda.synchronize()
+        first_step_ms = (time.perf_counter() - t_first) * 1e3
+    for _ in range(max(0, args.warmup - 1)):
         step()
     ctx.profile(os.environ.get("VDJX_BENCH_NO_EVENTS") != "1")      # (diagnostic switch: what the per-kernel HIP events cost)
     ctx.profile_reset()
@@ -592,6 +608,25 @@ def main():
             nxt.wait()
             nxt.free()
         del host_fwd["pri"], host_fwd["sec"]
+    # ---- the same step with the read index of its pool built inside it (row a-8's index, quick_map3.c:126-149: the reference
+    # builds it during extraction, bam_read.c:228,243, once per pool -- like a command line that sees every pool once)
+    with_index = None
+    if world == 1 and not args.force_shard:
+        n_wi = max(2, min(args.steps, 10))
+        wall_keep = dict(wall)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_wi):
+            build_index()
+            step()
+        ctx.map_emit_wait()
+        barrier()
+        dtw = time.perf_counter() - t1
+        with_index = {"value": round(args.pairs * n_wi / dtw / 1e6, 4), "unit": "M paired-reads/s", "ms_per_step": round(dtw / n_wi * 1e3, 3), "steps": n_wi,
+                      "note": "vdjx_read_index_build_device (per-record arrays resident in HBM like the pools) + the step of `value`, every step"}
+        wall.clear()
+        wall.update(wall_keep)
+    del ri_dev
     laps = None
     if os.environ.get("VDJX_LAPS"):          # (diagnostic: host-side microseconds per step inside the scorer calls, vdjx_common.h vdjx_laps)
         names = ("plan_issue", "plan_wait", "ws_cover_wait", "me_key", "me_plan", "me_kernel_wait", "me_second_call", "me_prev_copy_wait", "me_copy_issue")
@@ -660,6 +695,24 @@ def main():
         if pr:
             pr["hbm_streaming"] = name in build_kernels
             by_kernel[name] = pr
+    # the read index's kernels (one build per pool, outside `value`; inside `value_with_read_index`): bytes this design must move
+    ri = host_side.get("read_index", {})
+    R_ix, n1_ix, ncls_ix, nd_ix = 4 * args.pairs, ri.get("r1_members", 0), ri.get("classes", 0), ri.get("r1_distinct", 0)
+    ri_bytes = {"k_ri_insert": R_ix * 28 + 2 * R_ix * 4,            # packed read + mask in, a 4-byte slot claimed, record -> slot out
+                "k_ri_number": 2 * 2 * R_ix * 4 * 2,                  # the build's table (2 R slots) read twice, written once
+                "k_ri_records": R_ix * (4 + 4 + 4 + 1 + 1 + 4 + 4) + 2 * args.pairs * 12,
+                "k_ri_members": R_ix * (4 + 1 + 4) + n1_ix * (4 + 8 + 8 + 8 + 4 + 4 + 4 + 8),
+                "ri_sort_members": n1_ix * (2 * 12 + 3 * 2 * 8 + 8 + 24),       # merge of the two runs, three 8-bit passes over 8-byte keys, the gather
+                "k_ri_fold": n1_ix * 8 + nd_ix * 8 + ncls_ix * 12,
+                "k_ri_tab": ncls_ix * (4 + 16 + 12 + 64)}
+    for name, (tot_ms, launches) in ri_prof.items():
+        if name in ri_bytes and tot_ms > 0:
+            avg = tot_ms / 3
+            by_kernel[name] = {"avg_launch_ms": round(avg, 4), "launches_per_step": "one per index build (3 timed builds)", "algorithmic_bytes_per_launch": int(ri_bytes[name]),
+                               "algorithmic_bytes_per_pair": round(ri_bytes[name] / args.pairs, 1), "achieved": round(ri_bytes[name] / (avg * 1e-3) / 1e9, 2),
+                               "frac": round(ri_bytes[name] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": load_traffic(args, world, name), "hbm_streaming": False}
+    for v_ in by_kernel.values():       # what the counters say the kernel moved, against the same peak (null without a PMC pass of this workload)
+        v_["frac_on_traffic"] = round(v_["traffic"] / (v_["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if v_.get("traffic") and v_["avg_launch_ms"] else None
     dom = max(((n_, v_) for n_, v_ in prof.items() if n_ in build_kernels and n_ in by_kernel), key=lambda kv: kv[1][0], default=(None, (0.0, 0)))
     roof = None
     if dom[0]:
@@ -674,7 +727,13 @@ def main():
                 "longest_kernel_overall": {"kernel": longest[0], "avg_launch_ms": round(longest[1][0] / max(1, longest[1][1]), 4),
                                            "frac": lk.get("frac"), "achieved": lk.get("achieved"), "traffic": lk.get("traffic"),
                                            "hbm_streaming": lk.get("hbm_streaming")},
-                "hot_path_frac": round(ab["total"] * args.pairs / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                "frac_on_traffic": pr.get("frac_on_traffic"),
+                "frac_note": "`frac` prices SURVEY 8d's algorithmic bytes (for the walk: a 16-B probe per instance, most of which this design answers from two "
+                             "chain words in cache, so its PMC traffic is BELOW that figure); `frac_on_traffic` = PMC bytes / time / peak is what the kernel "
+                             "really moves per second",
+                "hot_path_frac": round(ab["total"] * args.pairs / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                # SURVEY 8d's per-pair figure takes EVERY instance as gated (3,324 B at k=35); with the gated instances this run measured
+                "hot_path_frac_gated": round((2 * ab["input"] + 32 * ab["gated_per_pair"] + 16 * ab["P"]) * args.pairs / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
     cpu = None
     cpu_port_legs = None
     if not args.no_cpu and world == 1:
@@ -697,7 +756,8 @@ def main():
                    "scorer_inputs": scorer_src},
         "roofline": roof, "roofline_by_kernel": by_kernel, "cpu_baseline": cpu, "cpu_baseline_port_legs": cpu_port_legs,
         "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
-        "value_end_to_end": e2e, "cli_end_to_end": cli_e2e,
+        "value_end_to_end": e2e, "value_with_read_index": with_index, "first_step_ms": round(first_step_ms, 3) if first_step_ms else None,
+        "cli_end_to_end": cli_e2e,
         "kernels_ms_per_step": kern_ms, "kernels_sum_ms_per_step": round(sum(kern_ms.values()), 3),
         "device_busy_frac": round(sum(kern_ms.values()) / ms_step, 4) if ms_step else None,
         "exchange_bytes_per_step_rank0": ((engine.bytes_exchanged - bytes_before) // args.steps) if engine else 0,

@@ -948,3 +948,40 @@ def test_long_reads_resident_records(ctx, rl):
         np.testing.assert_array_equal(getattr(g1, f), getattr(g2, f))
     p1.free()
     p2.free()
+
+
+def test_pool_load_device_holds_the_buffers_it_points_into():
+    """vdjx_pool_load_device does not copy the quality characters (include/vdjx.h): the Python wrapper keeps the tensors it is
+    given alive until Pool.free(), so a caller that drops its own references -- and then lets torch's caching allocator hand the
+    block to somebody else -- still gets the reference's quality sums (api.py pool_load_device).  mq 230 makes every
+    low-count k-mer's verdict depend on those sums (A2:454-465)."""
+    import gc
+
+    import torch
+    from oracle import oracle
+    from vdjer_amd import api, synth
+    rep = synth.make_repertoire(3, seed=5)
+    pool = synth.make_reads(rep, 3000, noise_frac=0.3, seed=9)
+    ctx = api.Context(0)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    ctx.anchor_sets_load(vc, jc)
+    d_pri, d_sec = torch.from_numpy(pool.primary).cuda(), torch.from_numpy(pool.secondary).cuda()
+    p = ctx.pool_load_device(d_pri, d_secondary=d_sec)
+    assert p.rl == pool.rl and p.n_records == pool.primary.shape[0] + pool.secondary.shape[0]
+    del d_pri, d_sec
+    gc.collect()
+    junk = [torch.full((pool.primary.shape[0], 2 * pool.rl + 1), 33, dtype=torch.uint8, device="cuda") for _ in range(4)]      # would land in the freed blocks
+    torch.cuda.synchronize()
+    g = ctx.kmer_build(p, 35, 2, 230)
+    t = oracle.KmerTable(pool, 35)
+    t.prune(2, 230)
+    og = oracle.Graph(t, vc, jc)
+    assert g.n == og.n > 0
+    np.testing.assert_array_equal(g.first_inst, og.first)
+    np.testing.assert_array_equal(g.freq, og.freq)
+    assert p._src is not None
+    p.free()
+    assert p._src is None
+    del junk
+    ctx.close()

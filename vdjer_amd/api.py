@@ -191,12 +191,33 @@ class Context:
         self._pools.append(p)
         return p
 
-    def pool_load_device(self, d_primary: int, n_primary: int, d_secondary: int, n_secondary: int, rl: int) -> Pool:
-        """ASCII pools already resident in device memory (raw device pointers, 16-byte aligned)."""
+    def pool_load_device(self, d_primary, n_primary: int = None, d_secondary=None, n_secondary: int = None, rl: int = None, keepalive=None) -> Pool:
+        """ASCII pools already resident in device memory (16-byte aligned).
+
+        LIFETIME (include/vdjx.h, vdjx_pool_load_device): bases and masks are packed, but the quality characters are NOT copied --
+        the pool keeps pointers into the two buffers, which must stay valid and unchanged until Pool.free().  Pass the buffers as
+        torch tensors ([records, 2*rl+1] uint8, contiguous) and the Pool holds references to them until it is freed; with raw
+        device pointers (ints) the caller answers for the lifetime, or hands the owning objects over in `keepalive`.  A buffer
+        that is released or overwritten while the pool lives gives silently wrong quality sums and SAM qualities."""
+        owners = [keepalive] if keepalive is not None else []
+
+        def as_ptr(x, n):
+            if hasattr(x, "data_ptr"):
+                if not x.is_contiguous():
+                    raise VdjxError("vdjx_pool_load_device: the buffer must be contiguous")
+                owners.append(x)
+                return x.data_ptr(), (int(x.shape[0]) if n is None else n), (int(x.shape[1] - 1) // 2 if x.dim() == 2 else None)
+            return (int(x) if x is not None else 0), (n or 0), None
+        pp, np_, rl_p = as_ptr(d_primary, n_primary)
+        ps, ns_, rl_s = as_ptr(d_secondary, n_secondary)
+        if rl is None:
+            rl = rl_p if rl_p is not None else rl_s
+        if rl is None:
+            raise VdjxError("vdjx_pool_load_device: rl is needed with raw pointers")
         h = C.c_void_p()
-        check(self.L.vdjx_pool_load_device(self.h, C.c_void_p(d_primary), n_primary, C.c_void_p(d_secondary), n_secondary,
-                                           rl, C.byref(h)), "vdjx_pool_load_device")
-        p = Pool(self, h, rl, n_primary + n_secondary)
+        check(self.L.vdjx_pool_load_device(self.h, C.c_void_p(pp), np_, C.c_void_p(ps), ns_, rl, C.byref(h)), "vdjx_pool_load_device")
+        p = Pool(self, h, rl, np_ + ns_)
+        p._src = owners or None      # dropped in Pool.free()
         self._pools.append(p)
         return p
 

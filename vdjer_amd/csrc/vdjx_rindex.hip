@@ -18,6 +18,7 @@
 
 #include <string.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_merge.hpp>
 
 #define NONE32 0xFFFFFFFFu
 #define NONE64 0xFFFFFFFFFFFFFFFFull
@@ -139,106 +140,220 @@ __global__ __launch_bounds__(256) void k_ri_number(u32* __restrict__ slots, u32 
 // ---- per record ---------------------------------------------------------------------------------------------------------------------
 #define RI_ERR_PAIR 0      // err[0]: records whose pair id is out of range
 #define RI_ERR_R2 1        // err[1]: pairs with more than two read-2 records
-// record -> class; the pair's read-2 records in registration order: the two smallest (reg_rank << 32 | record) of the pair, kept
-// by a chain of two atomic minima (what loses at the first slot moves on to the second; a third arrival is an error)
-__global__ void k_ri_records(const u32* __restrict__ rec_slot, const u32* __restrict__ slots, u32 R, const u32* __restrict__ pair_id,
-                             const uint8_t* __restrict__ read_num, const u32* __restrict__ reg_rank, u32 n_pairs,
-                             u32* __restrict__ rec_cls, unsigned long long* __restrict__ r2key, u32* __restrict__ err) {
-	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= R) return;
-	const u32 s = rec_slot[r];
-	rec_cls[r] = s == NONE32 ? NONE32 : slots[s] - 1;
-	const u32 p = pair_id[r];
-	if (p >= n_pairs) { atomicAdd(&err[RI_ERR_PAIR], 1u); return; }
-	if (read_num[r] == 1) return;
-	const unsigned long long v = ((unsigned long long) reg_rank[r] << 32) | r;
-	const unsigned long long old = atomicMin(&r2key[2 * (size_t) p], v);
-	const unsigned long long y = old > v ? old : v;                  // what does not stay in the first slot
-	if (y == NONE64) return;
-	const unsigned long long z = atomicMin(&r2key[2 * (size_t) p + 1], y);
-	if (z != NONE64) atomicAdd(&err[RI_ERR_R2], 1u);
+#define RI_ERR_ORDER 2     // err[2]: a record registered before its predecessor inside a pool (the members need a sort by rank)
+#define RI_ERR_RUNS 3      // err[3]: the secondary pool's first record registered before the primary pool's last (a merge of the two runs)
+#define RI_RB 2048u        // records per workgroup of the record passes: 8 per thread, all of a thread's loads in flight together
+#define RI_RCBIT 0x80000000u
+// record -> class (| is_rc in the top bit: what the entry of a pair needs of its mates in ONE load); the pair's read-2 records in
+// registration order: the two smallest (reg_rank << 32 | record) of the pair, kept by a chain of two atomic minima (what loses at the
+// first slot moves on to the second; a third arrival is an error); read-1 members per workgroup (their compaction follows)
+__global__ __launch_bounds__(256) void k_ri_records(const u32* __restrict__ rec_slot, const u32* __restrict__ slots, u32 R, u32 n_primary,
+                                                    const u32* __restrict__ pair_id, const uint8_t* __restrict__ read_num, const uint8_t* __restrict__ is_rc,
+                                                    const u32* __restrict__ reg_rank, u32 n_pairs, u32* __restrict__ rec_cls,
+                                                    unsigned long long* __restrict__ r2key, u32* __restrict__ err, u32* __restrict__ bcnt) {
+	__shared__ u32 part[4];
+	const u32 base = blockIdx.x * RI_RB + threadIdx.x;
+	u32 s[8], p[8], reg[8], regp[8];
+	uint8_t rn[8], rc[8];
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		const u32 r = base + (u32) i * 256u;
+		const bool in = r < R;
+		s[i] = in ? rec_slot[r] : NONE32;
+		p[i] = in ? pair_id[r] : 0u;
+		rn[i] = in ? read_num[r] : (uint8_t) 0;
+		rc[i] = in ? is_rc[r] : (uint8_t) 0;
+		reg[i] = in ? reg_rank[r] : 0u;
+		regp[i] = in && r ? reg_rank[r - 1] : 0u;
+	}
+	u32 cls[8];
+#pragma unroll
+	for (int i = 0; i < 8; i++) cls[i] = s[i] == NONE32 ? RI_ENT_NONE : slots[s[i]] - 1u;
+	u32 mine = 0;
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		const u32 r = base + (u32) i * 256u;
+		if (r >= R) continue;
+		rec_cls[r] = cls[i] | (rc[i] ? RI_RCBIT : 0u);
+		if (r && reg[i] < regp[i]) atomicAdd(&err[r == n_primary ? RI_ERR_RUNS : RI_ERR_ORDER], 1u);
+		if (p[i] >= n_pairs) { atomicAdd(&err[RI_ERR_PAIR], 1u); continue; }
+		if (rn[i] == 1) { mine += cls[i] != RI_ENT_NONE; continue; }
+		const unsigned long long v = ((unsigned long long) reg[i] << 32) | r;
+		const unsigned long long old = atomicMin(&r2key[2 * (size_t) p[i]], v);
+		const unsigned long long y = old > v ? old : v;                  // what does not stay in the first slot
+		if (y == NONE64) continue;
+		const unsigned long long z = atomicMin(&r2key[2 * (size_t) p[i] + 1], y);
+		if (z != NONE64) atomicAdd(&err[RI_ERR_R2], 1u);
+	}
+	const u32 incl = (u32) vdjx_wave_scan_add((int) mine);
+	if ((threadIdx.x & 63u) == 63u) part[threadIdx.x >> 6] = incl;
+	__syncthreads();
+	if (threadIdx.x == 0) bcnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 __global__ void k_ri_r2(const unsigned long long* __restrict__ r2key, size_t n, u32* __restrict__ pair_r2) {
 	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) pair_r2[i] = r2key[i] == NONE64 ? NONE32 : (u32) r2key[i];
 }
 
-// the read-1 members of the classes: how many per class, and (class << 32 | registration rank, record) for the sort
-__global__ void k_ri_members(const u32* __restrict__ rec_cls, const uint8_t* __restrict__ read_num, const u32* __restrict__ reg_rank, u32 R,
-                             u32* __restrict__ cnt1, u64* __restrict__ keys, u32* __restrict__ vals, u32* __restrict__ n1) {
-	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-	const u32 cls = r < R ? rec_cls[r] : NONE32;
-	const bool mem = cls != NONE32 && read_num[r] == 1;
-	const u32 pos = vdjx_wave_inc(n1, mem);
-	if (mem) {
+// the read-1 members of the classes, compacted IN RECORD ORDER (a workgroup's members start at bpre[workgroup]: no global counter):
+// per member its record, pair, registration rank, the 8-byte entry a hit needs (the classes and orientations of the pair's read-2
+// records) and the sort key class << 32 | member; members per class
+__global__ __launch_bounds__(256) void k_ri_members(const u32* __restrict__ rec_cls, const uint8_t* __restrict__ read_num, const u32* __restrict__ reg_rank,
+                                                    const u32* __restrict__ pair_id, const u32* __restrict__ pair_r2, u32 R, u32 n_pairs,
+                                                    const u32* __restrict__ bpre, u32* __restrict__ cnt1, u64* __restrict__ mkey, u32* __restrict__ m_reg,
+                                                    u32* __restrict__ m_rec, u32* __restrict__ m_pair, u64* __restrict__ m_ent) {
+	__shared__ u32 wcnt[8][4];
+	const u32 base = blockIdx.x * RI_RB + threadIdx.x;
+	const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	u32 cr[8], p[8];
+	u64 bal[8];
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		const u32 r = base + (u32) i * 256u;
+		const bool in = r < R;
+		cr[i] = in ? rec_cls[r] : RI_ENT_NONE;
+		p[i] = in ? pair_id[r] : NONE32;
+		const bool mem = in && (cr[i] & RI_ENT_NONE) != RI_ENT_NONE && read_num[r] == 1 && p[i] < n_pairs;
+		if (!mem) p[i] = NONE32;
+		bal[i] = __ballot(mem);
+		if (lane == 0) wcnt[i][wv] = (u32) __popcll(bal[i]);
+	}
+	__syncthreads();
+	u32 run = bpre[blockIdx.x];
+	uint2 r2[8];
+#pragma unroll
+	for (int i = 0; i < 8; i++) r2[i] = p[i] != NONE32 ? *(const uint2*) &pair_r2[2 * (size_t) p[i]] : make_uint2(NONE32, NONE32);
+	u32 ca[8], cb[8];
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		ca[i] = r2[i].x != NONE32 ? rec_cls[r2[i].x] : RI_ENT_NONE;
+		cb[i] = r2[i].y != NONE32 ? rec_cls[r2[i].y] : RI_ENT_NONE;
+	}
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		u32 at = run;
+		for (u32 w = 0; w < wv; w++) at += wcnt[i][w];
+		run += wcnt[i][0] + wcnt[i][1] + wcnt[i][2] + wcnt[i][3];
+		if (p[i] == NONE32) continue;
+		const u32 r = base + (u32) i * 256u;
+		const u32 pos = at + (u32) __popcll(bal[i] & ((1ull << lane) - 1ull));
+		const u32 cls = cr[i] & RI_ENT_NONE;
+		const u32 fl = (cr[i] & RI_RCBIT ? RI_RC : 0u) | (ca[i] != RI_ENT_NONE && (ca[i] & RI_RCBIT) ? RI_RCA : 0u) | (cb[i] != RI_ENT_NONE && (cb[i] & RI_RCBIT) ? RI_RCB : 0u);
 		atomicAdd(&cnt1[cls], 1u);
-		keys[pos] = ((u64) cls << 32) | reg_rank[r];
-		vals[pos] = r;
+		mkey[pos] = ((u64) cls << 32) | pos;
+		m_reg[pos] = reg_rank[r];
+		m_rec[pos] = r;
+		m_pair[pos] = p[i];
+		m_ent[pos] = ri_entry(ca[i] & RI_ENT_NONE, cb[i] & RI_ENT_NONE, fl, 1u);
 	}
 }
+// first member that is a record of the secondary pool (the members are in record order)
+__global__ void k_ri_split(const u32* __restrict__ m_rec, u32 n1, u32 n_primary, u32* __restrict__ out) {
+	u32 lo = 0, hi = n1;
+	while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (m_rec[mid] < n_primary) lo = mid + 1; else hi = mid; }
+	*out = lo;
+}
 
-// what a hit needs in one 8-byte load, in CSR order; and the key of the folding sort: class << 32 | hash of the entry
-__global__ void k_ri_info(const u64* __restrict__ keys_sorted, const u32* __restrict__ recs, u32 n1, const u32* __restrict__ pair_id,
-                          const uint8_t* __restrict__ is_rc, const u32* __restrict__ rec_cls, const u32* __restrict__ pair_r2,
-                          u64* __restrict__ csr8, u32* __restrict__ csr_pair, u64* __restrict__ keys2, u32* __restrict__ vals2) {
+// CSR order = (class, registration rank): the sorted key names the member
+__global__ void k_ri_csr(const u64* __restrict__ mkey_sorted, u32 n1, const u32* __restrict__ m_rec, const u32* __restrict__ m_pair, const u64* __restrict__ m_ent,
+                         u32* __restrict__ recs, u32* __restrict__ csr_pair, u64* __restrict__ csr8) {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n1) return;
-	const u32 r = recs[i];
-	const u32 p = pair_id[r];
-	const u32 ra = pair_r2[2 * (size_t) p], rb = pair_r2[2 * (size_t) p + 1];
-	const u32 ca = ra != NONE32 ? rec_cls[ra] : NONE32, cb = rb != NONE32 ? rec_cls[rb] : NONE32;
-	const u32 fl = (is_rc[r] ? RI_RC : 0u) | (ra != NONE32 && is_rc[ra] ? RI_RCA : 0u) | (rb != NONE32 && is_rc[rb] ? RI_RCB : 0u);
-	const u64 e = ri_entry(ca == NONE32 ? RI_ENT_NONE : ca, cb == NONE32 ? RI_ENT_NONE : cb, fl, 1u);
-	csr8[i] = e;
-	csr_pair[i] = p;
-	keys2[i] = (keys_sorted[i] & 0xFFFFFFFF00000000ull) | (u32) (vdjx_mix(e, 0) >> 32);
-	vals2[i] = i;
+	const u32 m = (u32) mkey_sorted[i];
+	recs[i] = m_rec[m];
+	csr_pair[i] = m_pair[m];
+	csr8[i] = m_ent[m];
 }
 
-// sorted by (class, hash): a member opens a new weighted entry when its class or its entry differs from its predecessor's (a hash
-// collision between different entries of a class only splits a group in two: the multiplicities still add up to the members)
-__global__ void k_ri_heads(const u64* __restrict__ keys2, const u32* __restrict__ vals2, u32 n1, const u64* __restrict__ csr8, u32* __restrict__ head) {
-	const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= n1) return;
-	u32 h = 1;
-	if (j && (keys2[j] >> 32) == (keys2[j - 1] >> 32)) h = csr8[vals2[j]] != csr8[vals2[j - 1]] ? 1u : 0u;
-	head[j] = h;
-}
-__global__ void k_ri_head_pos(const u32* __restrict__ head, const u32* __restrict__ hpre, u32 n1, u32* __restrict__ hpos) {
-	const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-	if (j < n1 && head[j]) hpos[hpre[j]] = j;
-	if (j == 0) hpos[hpre[n1]] = n1;
-}
-// a group of m identical members becomes ceil(m / 255) entries (the multiplicity field has 8 bits)
-__global__ void k_ri_group_size(const u32* __restrict__ hpos, u32 ng, u32* __restrict__ ne) {
-	const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
-	if (d < ng) ne[d] = (hpos[d + 1] - hpos[d] + RI_ENT_MAXCNT - 1) / RI_ENT_MAXCNT;
-	if (d == ng) ne[d] = 0;
-}
-__global__ void k_ri_d8(const u32* __restrict__ hpos, const u32* __restrict__ epre, u32 ng, const u32* __restrict__ vals2, const u64* __restrict__ csr8,
-                        u64* __restrict__ d8) {
-	const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
-	if (d >= ng) return;
-	const u32 j = hpos[d];
-	u32 m = hpos[d + 1] - j;
-	const u64 e = csr8[vals2[j]] & ((1ull << 56) - 1ull);
-	for (u32 at = epre[d]; m; at++) {
-		const u32 c = m < RI_ENT_MAXCNT ? m : RI_ENT_MAXCNT;
-		d8[at] = e | ((u64) c << 56);
-		m -= c;
+// ---- the weighted entries: identical read-1 entries of a class folded into one with a multiplicity ------------------------------------
+// (window scoring counts pairs, it does not name them.)  Class c's entries go to d8[start[c] ...): the region of its CSR members,
+// of which they use the first dcnt[c] -- no scan, no second pass; ANY grouping whose multiplicities add up to the members is a
+// valid result, which is what the overflow paths rely on.  A thread folds a class of up to RI_FOLD_SMALL members by comparing them
+// all; the larger ones (reads of deep clones: hundreds of members, tens of distinct entries) are left to the waves of the workgroup,
+// one class at a time, through a table in LDS.
+#define RI_FOLD_SMALL 8u
+#define RI_FOLD_SLOTS 512u            // per wave; a class with more distinct entries than 3/4 of it writes the rest unfolded
+__global__ __launch_bounds__(256) void k_ri_fold(const u32* __restrict__ start, const u32* __restrict__ cnt1, u32 ncls, const u64* __restrict__ csr8,
+                                                 u64* __restrict__ d8, u32* __restrict__ dcnt, unsigned long long* __restrict__ n_entries) {
+	__shared__ u32 big[256];
+	__shared__ u32 nbig, total;
+	__shared__ unsigned long long tkey[4][RI_FOLD_SLOTS];
+	__shared__ u32 tcnt[4][RI_FOLD_SLOTS];
+	if (threadIdx.x == 0) { nbig = 0; total = 0; }
+	__syncthreads();
+	const u32 c = blockIdx.x * 256u + threadIdx.x;
+	u32 made = 0;
+	if (c < ncls) {
+		const u32 m = cnt1[c], s = start[c];
+		if (m > RI_FOLD_SMALL) big[atomicAdd(&nbig, 1u)] = c;
+		else if (m) {
+			u64 e[RI_FOLD_SMALL];
+			u32 n[RI_FOLD_SMALL];
+#pragma unroll
+			for (u32 i = 0; i < RI_FOLD_SMALL; i++) { e[i] = i < m ? csr8[s + i] & ((1ull << 56) - 1ull) : 0ull; n[i] = i < m ? 1u : 0u; }
+#pragma unroll
+			for (u32 i = 1; i < RI_FOLD_SMALL; i++)
+#pragma unroll
+				for (u32 j = 0; j < i; j++) if (n[i] && n[j] && e[i] == e[j]) { n[j] += n[i]; n[i] = 0; }
+#pragma unroll
+			for (u32 i = 0; i < RI_FOLD_SMALL; i++) if (n[i]) d8[s + made++] = e[i] | ((u64) n[i] << 56);
+			dcnt[c] = made;
+		} else dcnt[c] = 0;
 	}
-}
-// the folding sort is class-major like the CSR: the weighted entries of a class start with the group its CSR segment starts with
-__global__ void k_ri_dstart(const u32* __restrict__ start, u32 ncls, const u32* __restrict__ hpre, const u32* __restrict__ epre, u32* __restrict__ dstart) {
-	const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c <= ncls) dstart[c] = epre[hpre[start[c]]];
+	__syncthreads();
+	const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	unsigned long long* tk = tkey[wv];
+	u32* tc = tcnt[wv];
+	for (u32 b = wv; b < nbig; b += 4) {
+		const u32 cc = big[b], m = cnt1[cc], s = start[cc];
+		for (u32 i = lane; i < RI_FOLD_SLOTS; i += 64) { tk[i] = NONE64; tc[i] = 0; }
+		vdjx_wave_lds_fence();
+		u32 out = 0, distinct = 0;            // (wave-uniform)
+		for (u32 at = 0; at < m; at += 64) {
+			const bool have = at + lane < m;
+			const u64 e = have ? csr8[s + at + lane] & ((1ull << 56) - 1ull) : 0ull;
+			bool direct = have && distinct > RI_FOLD_SLOTS * 3 / 4;      // the table is full enough: this row leaves unfolded
+			bool fresh = false;
+			if (have && !direct) {
+				u32 slot = (u32) (vdjx_mix(e, 0) >> 40) & (RI_FOLD_SLOTS - 1u);
+				for (;;) {
+					unsigned long long cur = vdjx_peek(&tk[slot]);
+					if (cur == NONE64) { cur = atomicCAS(&tk[slot], NONE64, (unsigned long long) e); if (cur == NONE64) { fresh = true; break; } }
+					if (cur == (unsigned long long) e) break;
+					slot = (slot + 1) & (RI_FOLD_SLOTS - 1u);
+				}
+				atomicAdd(&tc[slot], 1u);
+			}
+			distinct += (u32) __popcll(__ballot(fresh));
+			const u64 dm = __ballot(direct);
+			if (direct) d8[s + out + (u32) __popcll(dm & ((1ull << lane) - 1ull))] = e | (1ull << 56);
+			out += (u32) __popcll(dm);
+		}
+		vdjx_wave_lds_fence();
+		for (u32 i = 0; i < RI_FOLD_SLOTS; i += 64) {
+			const u32 n = tc[i + lane];
+			const u32 pieces = (n + RI_ENT_MAXCNT - 1) / RI_ENT_MAXCNT;      // the multiplicity field has 8 bits
+			const u32 incl = (u32) vdjx_wave_scan_add((int) pieces);
+			u32 o = s + out + incl - pieces, left = n;
+			const u64 e = (u64) tk[i + lane];
+			while (left) { const u32 q = left < RI_ENT_MAXCNT ? left : RI_ENT_MAXCNT; d8[o++] = e | ((u64) q << 56); left -= q; }
+			out += (u32) __builtin_amdgcn_readlane((int) incl, 63);
+		}
+		if (lane == 0) { dcnt[cc] = out; atomicAdd(&total, out); }
+		vdjx_wave_lds_fence();
+	}
+	// entries in all (a statistic)
+	const u32 incl = (u32) vdjx_wave_scan_add((int) made);
+	if (lane == 63 && incl) atomicAdd(&total, incl);
+	__syncthreads();
+	if (threadIdx.x == 0 && total) atomicAdd(n_entries, (unsigned long long) total);
 }
 
 // the lookup table the mapper reads: one slot per class = the sequence (W words), then {class + 1 | read-1 members << 32}, {CSR start |
 // first weighted entry << 32}, {weighted entries}: W + 3 words in a 64-byte slot (one line per probe)
 template <int W>
 __global__ void k_ri_tab(const u32* __restrict__ rep, u32 ncls, const u64* __restrict__ bases, const u32* __restrict__ cnt1, const u32* __restrict__ start,
-                         const u32* __restrict__ dstart, u64* __restrict__ tab, u32 mask) {
+                         const u32* __restrict__ dcnt, u64* __restrict__ tab, u32 mask) {
 	constexpr int SW = VDJX_RI_SLOT_WORDS(W);
 	const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= ncls) return;
@@ -251,8 +366,8 @@ __global__ void k_ri_tab(const u32* __restrict__ rep, u32 ncls, const u64* __res
 #pragma unroll
 	for (int i = 0; i < W; i++) sl[i] = b[i];
 	((u32*) &sl[W])[1] = cnt1[c];                         // (the low half was claimed by the CAS)
-	sl[W + 1] = (u64) start[c] | ((u64) dstart[c] << 32);
-	sl[W + 2] = (u64) (dstart[c + 1] - dstart[c]);
+	sl[W + 1] = (u64) start[c] | ((u64) start[c] << 32);  // (the weighted entries of a class lie where its CSR members do: k_ri_fold)
+	sl[W + 2] = (u64) dcnt[c];
 }
 
 int sort_pairs(vdjx_work& db, hipStream_t st, u64* k_in, u64* k_out, u32* v_in, u32* v_out, u32 n, unsigned end_bit) {
@@ -270,22 +385,24 @@ inline unsigned bits_for(u64 x) { unsigned b = 1; while (b < 64 && (1ull << b) <
 int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, const u32* d_pair, const uint8_t* d_rnum, const uint8_t* d_rc,
                          const u32* d_reg, u32 n_pairs) {
 	hipStream_t st = c->stream;
+	if (pool->n_records > ((size_t) 1 << 29)) { vdjx_set_error("vdjx_read_index_build: %zu records on one GPU (limit 2^29): shard the pool by pair", pool->n_records); return VDJX_ELIMIT; }
 	const u32 R = (u32) pool->n_records;
 	u32 mask = 1023;
 	while ((size_t) mask + 1 < (size_t) R * 2) mask = mask * 2 + 1;
-	const u32 nslots = mask + 1;
-	const dim3 gR(R / 256 + 1), b256(256);
-	u32 *d_rec_slot, *d_rec_cls, *d_err, *d_n1;
-	unsigned long long* d_r2key;
+	const size_t nslots = (size_t) mask + 1;
+	const dim3 gR(R / 256 + 1), gB((R + RI_RB - 1) / RI_RB + 1), b256(256);
+	u32 *d_rec_slot, *d_rec_cls, *d_err, *d_split;
+	unsigned long long *d_r2key, *d_nent;
 	u32* d_slots;                                 // the build's own table: slot -> a record of the class, then -> class + 1
-	HIP_TRY(db.alloc(&d_slots, (size_t) nslots));
+	HIP_TRY(db.alloc(&d_slots, nslots));
 	HIP_TRY(db.alloc(&d_rec_slot, (size_t) R + 1));
 	HIP_TRY(db.alloc(&d_rec_cls, (size_t) R + 1));
-	HIP_TRY(db.alloc(&d_err, 4));
-	d_n1 = d_err + 2;
+	HIP_TRY(db.alloc(&d_err, 8));
+	d_split = d_err + 4;
+	d_nent = (unsigned long long*) (d_err + 6);
 	HIP_TRY(db.alloc(&d_r2key, (size_t) n_pairs * 2 + 2));
-	HIP_TRY(hipMemsetAsync(d_slots, 0, (size_t) nslots * 4, st));
-	HIP_TRY(hipMemsetAsync(d_err, 0, 16, st));
+	HIP_TRY(hipMemsetAsync(d_slots, 0, nslots * 4, st));
+	HIP_TRY(hipMemsetAsync(d_err, 0, 32, st));
 	HIP_TRY(hipMemsetAsync(d_r2key, 0xFF, ((size_t) n_pairs * 2 + 2) * 8, st));
 	{
 		vdjx_prof_scope ps(c, "k_ri_insert");
@@ -293,12 +410,15 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 		else hipLaunchKernelGGL((k_ri_insert<VDJX_LONG_W, VDJX_LONG_M>), gR, b256, 0, st, pool->d_bases, pool->d_nmask, R, d_slots, mask, d_rec_slot);
 	}
 	// classes
-	const u32 nsb = (nslots + RS_BLOCK - 1) / RS_BLOCK;
+	const u32 nsb = (u32) ((nslots + RS_BLOCK - 1) / RS_BLOCK);
 	u32 *d_bcnt, *d_bpre;
 	HIP_TRY(db.alloc(&d_bcnt, nsb + 1));
 	HIP_TRY(db.alloc(&d_bpre, nsb + 1));
-	hipLaunchKernelGGL(k_ri_occ, dim3(nsb), b256, 0, st, d_slots, nslots, d_bcnt);
-	hipLaunchKernelGGL(k_rs_top, dim3(1), dim3(1024), 0, st, d_bcnt, nsb, d_bpre);
+	{
+		vdjx_prof_scope ps(c, "k_ri_number");
+		hipLaunchKernelGGL(k_ri_occ, dim3(nsb), b256, 0, st, d_slots, (u32) nslots, d_bcnt);
+		hipLaunchKernelGGL(k_rs_top, dim3(1), dim3(1024), 0, st, d_bcnt, nsb, d_bpre);
+	}
 	u32 ncls = 0;
 	HIP_TRY(hipMemcpyAsync(&ncls, d_bpre + nsb, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
@@ -312,80 +432,93 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(hipMalloc(&c->d_ri_tab, ((size_t) tmask + 1) * slot_bytes));
 	HIP_TRY(hipMalloc(&c->d_ri_start, ((size_t) ncls + 2) * 4));
 	HIP_TRY(hipMalloc(&c->d_ri_cnt1, ((size_t) ncls + 2) * 4));
-	HIP_TRY(hipMalloc(&c->d_ri_dstart, ((size_t) ncls + 2) * 4));
+	HIP_TRY(hipMalloc(&c->d_ri_dstart, ((size_t) ncls + 2) * 4));          // (weighted entries per class: k_ri_fold's dcnt)
 	HIP_TRY(hipMalloc(&c->d_pair_r2, ((size_t) n_pairs * 2 + 2) * 4));
 	HIP_TRY(hipMemsetAsync(c->d_ri_cnt1, 0, ((size_t) ncls + 2) * 4, st));
 	HIP_TRY(hipMemsetAsync(c->d_ri_tab, 0, ((size_t) tmask + 1) * slot_bytes, st));
-	hipLaunchKernelGGL(k_ri_number, dim3(nsb), b256, 0, st, d_slots, nslots, d_bpre, d_rep);
-	// records: class, read-2 records of the pairs; read-1 members
-	u64 *d_keys, *d_keys_s;
-	u32 *d_vals, *d_vals_s;
-	HIP_TRY(db.alloc(&d_keys, (size_t) R + 1));
-	HIP_TRY(db.alloc(&d_keys_s, (size_t) R + 1));
-	HIP_TRY(db.alloc(&d_vals, (size_t) R + 1));
-	HIP_TRY(db.alloc(&d_vals_s, (size_t) R + 1));
+	{
+		vdjx_prof_scope ps(c, "k_ri_number");
+		hipLaunchKernelGGL(k_ri_number, dim3(nsb), b256, 0, st, d_slots, (u32) nslots, d_bpre, d_rep);
+	}
+	// records: class, read-2 records of the pairs; the read-1 members in record order
+	const u32 nrb = (R + RI_RB - 1) / RI_RB;
+	u32 *d_rbcnt, *d_rbpre;
+	HIP_TRY(db.alloc(&d_rbcnt, nrb + 1));
+	HIP_TRY(db.alloc(&d_rbpre, nrb + 2));
 	{
 		vdjx_prof_scope ps(c, "k_ri_records");
-		hipLaunchKernelGGL(k_ri_records, gR, b256, 0, st, d_rec_slot, d_slots, R, d_pair, d_rnum, d_reg, n_pairs, d_rec_cls, d_r2key, d_err);
+		if (nrb) hipLaunchKernelGGL(k_ri_records, dim3(nrb), b256, 0, st, d_rec_slot, d_slots, R, (u32) pool->n_primary, d_pair, d_rnum, d_rc, d_reg, n_pairs, d_rec_cls, d_r2key, d_err, d_rbcnt);
 		hipLaunchKernelGGL(k_ri_r2, dim3((unsigned) (((size_t) n_pairs * 2 + 2) / 256 + 1)), b256, 0, st, d_r2key, (size_t) n_pairs * 2 + 2, c->d_pair_r2);
-		hipLaunchKernelGGL(k_ri_members, gR, b256, 0, st, d_rec_cls, d_rnum, d_reg, R, c->d_ri_cnt1, d_keys, d_vals, d_n1);
+		hipLaunchKernelGGL(k_rs_top, dim3(1), dim3(1024), 0, st, d_rbcnt, nrb, d_rbpre);
 	}
-	int rc = scan_u32(db, st, c->d_ri_cnt1, ncls + 1, c->d_ri_start);         // (cnt1[ncls] = 0: start[ncls] = start[ncls + 1] = members)
-	if (rc) return rc;
-	u32 h_err[4] = {0, 0, 0, 0};
+	u32 h_err[4] = {0, 0, 0, 0}, n1 = 0;
 	HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&n1, d_rbpre + nrb, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
 	if (h_err[RI_ERR_PAIR]) { vdjx_set_error("vdjx_read_index_build: %u records with a pair id >= n_pairs=%u", h_err[RI_ERR_PAIR], n_pairs); return VDJX_EINVAL; }
 	if (h_err[RI_ERR_R2]) { vdjx_set_error("a pair has more than two read-2 records (read names must be unique per pair)"); return VDJX_EINVAL; }
-	const u32 n1 = h_err[2];
+	u64 *d_mkey, *d_mkey2, *d_ment;
+	u32 *d_mreg, *d_mreg2, *d_mrec, *d_mpair;
+	HIP_TRY(db.alloc(&d_mkey, (size_t) n1 + 1));
+	HIP_TRY(db.alloc(&d_mkey2, (size_t) n1 + 1));
+	HIP_TRY(db.alloc(&d_ment, (size_t) n1 + 1));
+	HIP_TRY(db.alloc(&d_mreg, (size_t) n1 + 1));
+	HIP_TRY(db.alloc(&d_mreg2, (size_t) n1 + 1));
+	HIP_TRY(db.alloc(&d_mrec, (size_t) n1 + 1));
+	HIP_TRY(db.alloc(&d_mpair, (size_t) n1 + 1));
+	{
+		vdjx_prof_scope ps(c, "k_ri_members");
+		if (nrb) hipLaunchKernelGGL(k_ri_members, dim3(nrb), b256, 0, st, d_rec_cls, d_rnum, d_reg, d_pair, c->d_pair_r2, R, n_pairs, d_rbpre, c->d_ri_cnt1, d_mkey, d_mreg, d_mrec, d_mpair, d_ment);
+	}
+	int rc = scan_u32(db, st, c->d_ri_cnt1, ncls + 1, c->d_ri_start);         // (cnt1[ncls] = 0: start[ncls] = start[ncls + 1] = members)
+	if (rc) return rc;
 	// CSR order = (class, registration rank)
 	HIP_TRY(hipMalloc(&c->d_ri_recs, ((size_t) n1 + 1) * 4));
 	HIP_TRY(hipMalloc(&c->d_ri_csr8, ((size_t) n1 + 1) * 8));
 	HIP_TRY(hipMalloc(&c->d_ri_csr_pair, ((size_t) n1 + 1) * 4));
-	u32 nd = 0;
+	HIP_TRY(hipMalloc(&c->d_ri_d8, ((size_t) n1 + 1) * 8));
+	unsigned long long nd = 0;
 	if (n1) {
-		{
-			vdjx_prof_scope ps(c, "ri_sort_members");
-			rc = sort_pairs(db, st, d_keys, d_keys_s, d_vals, d_vals_s, n1, 32u + bits_for(ncls));
-			if (rc) return rc;
+		vdjx_prof_scope ps(c, "ri_sort_members");
+		// the members are in record order; inside a pool that IS registration order (add_to_buffer registers what it appends,
+		// bam_read.c:206-244), so by rank they are two sorted runs (primary, secondary): a merge.  A caller whose ranks do not
+		// follow its records gets a sort by rank instead.  Then a STABLE sort by class alone (the key's upper half; the member
+		// rides in the lower one): three 8-bit passes over 8-byte keys instead of seven over key + value.
+		u64* by_rank = d_mkey;
+		if (h_err[RI_ERR_ORDER]) {
+			size_t tb = 0;
+			const unsigned rb = 32;
+			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, d_mreg, d_mreg2, d_mkey, d_mkey2, (size_t) n1, 0u, rb, st));
+			char* tmp;
+			HIP_TRY(db.alloc(&tmp, tb + 256));
+			HIP_TRY(rocprim::radix_sort_pairs((void*) tmp, tb, d_mreg, d_mreg2, d_mkey, d_mkey2, (size_t) n1, 0u, rb, st));
+			by_rank = d_mkey2;
+		} else if (h_err[RI_ERR_RUNS]) {
+			u32 n1p = 0;
+			hipLaunchKernelGGL(k_ri_split, dim3(1), dim3(1), 0, st, d_mrec, n1, (u32) pool->n_primary, d_split);
+			HIP_TRY(hipMemcpyAsync(&n1p, d_split, 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			size_t tb = 0;
+			HIP_TRY(rocprim::merge(nullptr, tb, d_mreg, d_mreg + n1p, d_mreg2, d_mkey, d_mkey + n1p, d_mkey2, (size_t) n1p, (size_t) (n1 - n1p), rocprim::less<u32>(), st));
+			char* tmp;
+			HIP_TRY(db.alloc(&tmp, tb + 256));
+			HIP_TRY(rocprim::merge((void*) tmp, tb, d_mreg, d_mreg + n1p, d_mreg2, d_mkey, d_mkey + n1p, d_mkey2, (size_t) n1p, (size_t) (n1 - n1p), rocprim::less<u32>(), st));
+			by_rank = d_mkey2;
 		}
-		HIP_TRY(hipMemcpyAsync(c->d_ri_recs, d_vals_s, (size_t) n1 * 4, hipMemcpyDeviceToDevice, st));
-		const dim3 g1(n1 / 256 + 1);
-		// (the unsorted key/value buffers are free again: they take the folding sort's input)
-		hipLaunchKernelGGL(k_ri_info, g1, b256, 0, st, d_keys_s, c->d_ri_recs, n1, d_pair, d_rc, d_rec_cls, c->d_pair_r2, c->d_ri_csr8, c->d_ri_csr_pair, d_keys, d_vals);
-		{
-			vdjx_prof_scope ps(c, "ri_sort_infos");
-			rc = sort_pairs(db, st, d_keys, d_keys_s, d_vals, d_vals_s, n1, 32u + bits_for(ncls));
-			if (rc) return rc;
-		}
-		u32 *d_head, *d_hpre, *d_hpos, *d_ne, *d_epre;
-		HIP_TRY(db.alloc(&d_head, (size_t) n1 + 1));
-		HIP_TRY(db.alloc(&d_hpre, (size_t) n1 + 2));
-		HIP_TRY(db.alloc(&d_hpos, (size_t) n1 + 2));
-		HIP_TRY(db.alloc(&d_ne, (size_t) n1 + 2));
-		HIP_TRY(db.alloc(&d_epre, (size_t) n1 + 3));
-		hipLaunchKernelGGL(k_ri_heads, g1, b256, 0, st, d_keys_s, d_vals_s, n1, c->d_ri_csr8, d_head);
-		rc = scan_u32(db, st, d_head, n1, d_hpre);
-		if (rc) return rc;
-		u32 ng = 0;
-		HIP_TRY(hipMemcpyAsync(&ng, d_hpre + n1, 4, hipMemcpyDeviceToHost, st));
-		hipLaunchKernelGGL(k_ri_head_pos, g1, b256, 0, st, d_head, d_hpre, n1, d_hpos);
-		HIP_TRY(hipStreamSynchronize(st));
-		HIP_TRY(hipGetLastError());
-		hipLaunchKernelGGL(k_ri_group_size, dim3(ng / 256 + 1), b256, 0, st, d_hpos, ng, d_ne);
-		rc = scan_u32(db, st, d_ne, ng + 1, d_epre);          // (ne[ng] = 0: epre[ng] = epre[ng + 1] = entries)
-		if (rc) return rc;
-		HIP_TRY(hipMemcpyAsync(&nd, d_epre + ng, 4, hipMemcpyDeviceToHost, st));
-		hipLaunchKernelGGL(k_ri_dstart, dim3(ncls / 256 + 1), b256, 0, st, c->d_ri_start, ncls, d_hpre, d_epre, c->d_ri_dstart);
-		HIP_TRY(hipStreamSynchronize(st));
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMalloc(&c->d_ri_d8, ((size_t) nd + 1) * 8));
-		hipLaunchKernelGGL(k_ri_d8, dim3(ng / 256 + 1), b256, 0, st, d_hpos, d_epre, ng, d_vals_s, c->d_ri_csr8, c->d_ri_d8);
-	} else {
-		HIP_TRY(hipMalloc(&c->d_ri_d8, 8));
-		HIP_TRY(hipMemsetAsync(c->d_ri_dstart, 0, ((size_t) ncls + 2) * 4, st));
+		u64* by_class = by_rank == d_mkey ? d_mkey2 : d_mkey;
+		size_t tb = 0;
+		HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, by_rank, by_class, (size_t) n1, 32u, 32u + bits_for(ncls), st));
+		char* tmp;
+		HIP_TRY(db.alloc(&tmp, tb + 256));
+		HIP_TRY(rocprim::radix_sort_keys((void*) tmp, tb, by_rank, by_class, (size_t) n1, 32u, 32u + bits_for(ncls), st));
+		hipLaunchKernelGGL(k_ri_csr, dim3(n1 / 256 + 1), b256, 0, st, by_class, n1, d_mrec, d_mpair, d_ment, c->d_ri_recs, c->d_ri_csr_pair, c->d_ri_csr8);
 	}
+	{
+		vdjx_prof_scope ps(c, "k_ri_fold");
+		hipLaunchKernelGGL(k_ri_fold, dim3(ncls / 256 + 1), b256, 0, st, c->d_ri_start, c->d_ri_cnt1, ncls, c->d_ri_csr8, c->d_ri_d8, c->d_ri_dstart, d_nent);
+	}
+	HIP_TRY(hipMemcpyAsync(&nd, d_nent, 8, hipMemcpyDeviceToHost, st));
 	{	// the mapper's table, now that the classes' sizes and starts are known
 		vdjx_prof_scope ps(c, "k_ri_tab");
 		if (pool->W == 2) hipLaunchKernelGGL(k_ri_tab<2>, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, c->d_ri_cnt1, c->d_ri_start, c->d_ri_dstart, (u64*) c->d_ri_tab, tmask);
@@ -397,6 +530,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	c->stats["read_index_r1_members"] = n1;
 	c->stats["read_index_r1_distinct"] = nd;
 	c->stats["read_index_classes"] = ncls;
+	c->stats["read_index_rank_order"] = h_err[RI_ERR_ORDER] ? 2 : (h_err[RI_ERR_RUNS] ? 1 : 0);      // 0 as recorded, 1 merge of the two pools' runs, 2 sort by rank
 	c->ri_tab_mask = tmask;
 	c->n_pairs = n_pairs;
 	c->n_classes = ncls;
