@@ -24,7 +24,8 @@ extern "C" {
 #define VDJX_OK 0
 #define VDJX_EINVAL (-1)   /* bad argument */
 #define VDJX_EHIP (-2)     /* HIP runtime error */
-#define VDJX_ELIMIT (-3)   /* input exceeds a documented limit (rl <= 160, k <= 50, 2^32 records in all (2^30 with reads of more than 64 bases), 2^29 per GPU, 2^26 surviving k-mers) */
+#define VDJX_ELIMIT (-3)   /* input exceeds a documented limit: rl <= 160, k <= 50; 2^32 records in all (2^30 with reads of more than 64 bases); per GPU
+                            * 2^29 records (2^27 with reads of more than 64 bases), 2^26 surviving k-mers, 2^26 - 1 distinct read sequences in the read index */
 #define VDJX_ESTATE (-4)   /* call order violated (e.g. scorer used before its index was loaded) */
 
 #define VDJX_MAX_READ_LEN 160   /* the reference takes up to 255 (bam_read.c:208 `char seq[256]`); reads of up to 64 bases run on the short-read kernels */

@@ -459,13 +459,23 @@ static pid_t g_kids[256];
 static volatile sig_atomic_t g_kid_state[256];      /* 0 running, 1 ended well, 2 reaped after being killed */
 static int g_nkids = 0;
 
+static volatile sig_atomic_t g_leaving = 0;       /* the parent is taking the ranks down itself: their end is not a failure to report */
+
 static void kill_kids(void) {
+	/* a deliberate teardown (rank 0 failed on its own, or is done): no SIGCHLD handler run from here on, so the exit status the
+	 * caller chose survives and nobody blames a GPU rank for a host-side error */
+	sigset_t chld;
+	sigemptyset(&chld);
+	sigaddset(&chld, SIGCHLD);
+	sigprocmask(SIG_BLOCK, &chld, NULL);
+	g_leaving = 1;
 	for (int r = 1; r <= g_nkids; r++) if (g_kid_state[r] == 0) (void) kill(g_kids[r], SIGTERM);
 	for (int r = 1; r <= g_nkids; r++) if (g_kid_state[r] == 0) { int st_; (void) waitpid(g_kids[r], &st_, 0); g_kid_state[r] = 2; }
 }
 
 static void on_sigchld(int sig) {
 	(void) sig;
+	if (g_leaving) return;
 	for (int r = 1; r <= g_nkids; r++) {
 		if (g_kid_state[r] != 0) continue;
 		int st_ = 0;

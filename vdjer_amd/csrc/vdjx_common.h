@@ -422,6 +422,9 @@ __device__ inline int vdjx_wave_scan_add(int v) {
 // memory and the LDS counter, instead of one ds_read (round 3: 50 of them in k_gated_reduce's sweeps).
 template <typename T> __device__ inline T vdjx_peek(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 template <typename T> __device__ inline void vdjx_poke(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// a value that publishes data written before it / the read that such data is reached through (claim-and-publish slots in LDS)
+template <typename T> __device__ inline T vdjx_peek_acquire(const T* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <typename T> __device__ inline void vdjx_poke_release(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // cnt[idx] += 1 and mn[idx] = min(mn[idx], val) on LDS arrays for the lanes with `active`.  Hot k-mers put most lanes of a wave on
 // ONE address: the lanes that share the first active lane's index are combined into one add and one min; the others go one by one.

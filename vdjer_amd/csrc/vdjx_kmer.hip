@@ -157,16 +157,18 @@ __device__ inline int lds_insert(u64* s_klo, THI* s_khi, u64 lo, THI hi, u32 h) 
 	u32 slot = h & (SLOTS - 1);
 	u32 probes = 0;
 	while (probes < SLOTS) {
-		THI cur = vdjx_peek(&s_khi[slot]);
+		// the claimant writes klo, then PUBLISHES khi with release order; a reader that sees a published khi (acquire) therefore
+		// sees that klo -- relaxed accesses to two addresses may be reordered by the compiler (on LDS the orders cost no instruction)
+		THI cur = vdjx_peek_acquire(&s_khi[slot]);
 		if (cur == EMPTY) {
 			THI old = atomicCAS(&s_khi[slot], EMPTY, LOCKED);
 			if (old == EMPTY) {
 				vdjx_poke(&s_klo[slot], lo);
-				__threadfence_block();
-				vdjx_poke(&s_khi[slot], hi);                    // publish
+				vdjx_poke_release(&s_khi[slot], hi);            // publish
 				return (int) slot;
 			}
 			cur = old;
+			if (cur != LOCKED) cur = vdjx_peek_acquire(&s_khi[slot]);      // (the CAS's own load carries no order)
 		}
 		if (cur == LOCKED) continue;                            // another lane is writing this slot: look again
 		if (cur == hi && vdjx_peek(&s_klo[slot]) == lo) return (int) slot;

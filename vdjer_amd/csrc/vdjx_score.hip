@@ -2173,6 +2173,7 @@ __global__ __launch_bounds__(256) void k_sam_write(SamSrc s, u64 total, const u6
 			lb += put_dec(hb + lb, mpos); hb[lb++] = '\t';
 			lb += put_dec(hb + lb, (u32) q.insert); hb[lb++] = '\t';
 		}
+		vdjx_wave_lds_fence();         // lane 0's header bytes are read by the other lanes of the wave
 		la = (u32) __builtin_amdgcn_readlane((int) la, 0);
 		lb = (u32) __builtin_amdgcn_readlane((int) lb, 0);
 		for (u32 j = lane; j < nl; j += 64) dst[j] = nm[j];
@@ -2192,6 +2193,7 @@ __global__ __launch_bounds__(256) void k_sam_write(SamSrc s, u64 total, const u6
 		dst += s.rl;
 		if (lane == 0) dst[0] = '\n';
 		dst += 1;
+		vdjx_wave_lds_fence();         // the next line rewrites the header buffers
 	}
 }
 
