@@ -272,9 +272,27 @@ __global__ void k_ri_csr(const u64* __restrict__ mkey_sorted, u32 n1, const u32*
 // all; the larger ones (reads of deep clones: hundreds of members, tens of distinct entries) are left to the waves of the workgroup,
 // one class at a time, through a table in LDS.
 #define RI_FOLD_SMALL 8u
-#define RI_FOLD_SLOTS 512u            // per wave; a class with more distinct entries than 3/4 of it writes the rest unfolded
+#define RI_FOLD_WAVE 256u             // up to here a wave folds the class through its own LDS table (it cannot fill: 512 slots)
+#define RI_FOLD_SLOTS 512u
+#define RI_FOLD_BIG_SLOTS 8192u       // beyond, a workgroup per class (k_ri_fold_big); a class with more distinct entries than 3/4 of this
+#define RI_FOLD_BIG_THREADS 512u      // writes the rest unfolded
+__device__ inline u32 ri_fold_slot(u64 e, u32 slots) { return (u32) (vdjx_mix(e, 0) >> 40) & (slots - 1u); }
+// insert e into an LDS table of (key, count); returns true if this lane made the key
+__device__ inline bool ri_fold_insert(unsigned long long* tk, u32* tc, u32 slots, u64 e) {
+	u32 slot = ri_fold_slot(e, slots);
+	bool fresh = false;
+	for (;;) {
+		unsigned long long cur = vdjx_peek(&tk[slot]);
+		if (cur == NONE64) { cur = atomicCAS(&tk[slot], NONE64, (unsigned long long) e); if (cur == NONE64) { fresh = true; break; } }
+		if (cur == (unsigned long long) e) break;
+		slot = (slot + 1) & (slots - 1u);
+	}
+	atomicAdd(&tc[slot], 1u);
+	return fresh;
+}
 __global__ __launch_bounds__(256) void k_ri_fold(const u32* __restrict__ start, const u32* __restrict__ cnt1, u32 ncls, const u64* __restrict__ csr8,
-                                                 u64* __restrict__ d8, u32* __restrict__ dcnt, unsigned long long* __restrict__ n_entries) {
+                                                 u64* __restrict__ d8, u32* __restrict__ dcnt, unsigned long long* __restrict__ n_entries,
+                                                 u32* __restrict__ giant, u32* __restrict__ n_giant) {
 	__shared__ u32 big[256];
 	__shared__ u32 nbig, total;
 	__shared__ unsigned long long tkey[4][RI_FOLD_SLOTS];
@@ -285,7 +303,8 @@ __global__ __launch_bounds__(256) void k_ri_fold(const u32* __restrict__ start, 
 	u32 made = 0;
 	if (c < ncls) {
 		const u32 m = cnt1[c], s = start[c];
-		if (m > RI_FOLD_SMALL) big[atomicAdd(&nbig, 1u)] = c;
+		if (m > RI_FOLD_WAVE) giant[atomicAdd(n_giant, 1u)] = c;
+		else if (m > RI_FOLD_SMALL) big[atomicAdd(&nbig, 1u)] = c;
 		else if (m) {
 			u64 e[RI_FOLD_SMALL];
 			u32 n[RI_FOLD_SMALL];
@@ -308,30 +327,12 @@ __global__ __launch_bounds__(256) void k_ri_fold(const u32* __restrict__ start, 
 		const u32 cc = big[b], m = cnt1[cc], s = start[cc];
 		for (u32 i = lane; i < RI_FOLD_SLOTS; i += 64) { tk[i] = NONE64; tc[i] = 0; }
 		vdjx_wave_lds_fence();
-		u32 out = 0, distinct = 0;            // (wave-uniform)
-		for (u32 at = 0; at < m; at += 64) {
-			const bool have = at + lane < m;
-			const u64 e = have ? csr8[s + at + lane] & ((1ull << 56) - 1ull) : 0ull;
-			bool direct = have && distinct > RI_FOLD_SLOTS * 3 / 4;      // the table is full enough: this row leaves unfolded
-			bool fresh = false;
-			if (have && !direct) {
-				u32 slot = (u32) (vdjx_mix(e, 0) >> 40) & (RI_FOLD_SLOTS - 1u);
-				for (;;) {
-					unsigned long long cur = vdjx_peek(&tk[slot]);
-					if (cur == NONE64) { cur = atomicCAS(&tk[slot], NONE64, (unsigned long long) e); if (cur == NONE64) { fresh = true; break; } }
-					if (cur == (unsigned long long) e) break;
-					slot = (slot + 1) & (RI_FOLD_SLOTS - 1u);
-				}
-				atomicAdd(&tc[slot], 1u);
-			}
-			distinct += (u32) __popcll(__ballot(fresh));
-			const u64 dm = __ballot(direct);
-			if (direct) d8[s + out + (u32) __popcll(dm & ((1ull << lane) - 1ull))] = e | (1ull << 56);
-			out += (u32) __popcll(dm);
-		}
+		for (u32 at = 0; at < m; at += 64)
+			if (at + lane < m) (void) ri_fold_insert(tk, tc, RI_FOLD_SLOTS, csr8[s + at + lane] & ((1ull << 56) - 1ull));
 		vdjx_wave_lds_fence();
+		u32 out = 0;
 		for (u32 i = 0; i < RI_FOLD_SLOTS; i += 64) {
-			const u32 n = tc[i + lane];
+			const u32 n = tc[i + lane];                                    // (n <= 256: one entry, or two)
 			const u32 pieces = (n + RI_ENT_MAXCNT - 1) / RI_ENT_MAXCNT;      // the multiplicity field has 8 bits
 			const u32 incl = (u32) vdjx_wave_scan_add((int) pieces);
 			u32 o = s + out + incl - pieces, left = n;
@@ -347,6 +348,54 @@ __global__ __launch_bounds__(256) void k_ri_fold(const u32* __restrict__ start, 
 	if (lane == 63 && incl) atomicAdd(&total, incl);
 	__syncthreads();
 	if (threadIdx.x == 0 && total) atomicAdd(n_entries, (unsigned long long) total);
+}
+// the classes of more than RI_FOLD_WAVE members (the reads of the deepest clones: thousands of members, hundreds of distinct
+// entries), a workgroup at a time; their number stays on the device (the workgroups take them in turns)
+__global__ __launch_bounds__(RI_FOLD_BIG_THREADS) void k_ri_fold_big(const u32* __restrict__ giant, const u32* __restrict__ n_giant, const u32* __restrict__ start,
+                                                                     const u32* __restrict__ cnt1, const u64* __restrict__ csr8, u64* __restrict__ d8,
+                                                                     u32* __restrict__ dcnt, unsigned long long* __restrict__ n_entries) {
+	__shared__ unsigned long long tk[RI_FOLD_BIG_SLOTS];
+	__shared__ u32 tc[RI_FOLD_BIG_SLOTS];
+	__shared__ u32 s_distinct, s_out;
+	const u32 lane = threadIdx.x & 63u;
+	for (u32 b = blockIdx.x; b < *n_giant; b += gridDim.x) {
+	const u32 cc = giant[b], m = cnt1[cc], s = start[cc];
+	__syncthreads();
+	for (u32 i = threadIdx.x; i < RI_FOLD_BIG_SLOTS; i += RI_FOLD_BIG_THREADS) { tk[i] = NONE64; tc[i] = 0; }
+	if (threadIdx.x == 0) { s_distinct = 0; s_out = 0; }
+	__syncthreads();
+	for (u32 at = 0; at < m; at += RI_FOLD_BIG_THREADS) {
+		const bool full = s_distinct > RI_FOLD_BIG_SLOTS * 3 / 4;          // (the same for the whole workgroup: read between two barriers)
+		__syncthreads();
+		const bool have = at + threadIdx.x < m;
+		const u64 e = have ? csr8[s + at + threadIdx.x] & ((1ull << 56) - 1ull) : 0ull;
+		if (!full) {
+			const bool fresh = have && ri_fold_insert(tk, tc, RI_FOLD_BIG_SLOTS, e);
+			const u64 fm = __ballot(fresh);
+			if (lane == 0 && fm) atomicAdd(&s_distinct, (u32) __popcll(fm));
+		} else {                                                            // the table is full enough: this row leaves unfolded
+			const u64 dm = __ballot(have);
+			u32 base = 0;
+			if (lane == 0 && dm) base = atomicAdd(&s_out, (u32) __popcll(dm));
+			base = (u32) __builtin_amdgcn_readlane((int) base, 0);
+			if (have) d8[s + base + (u32) __popcll(dm & ((1ull << lane) - 1ull))] = e | (1ull << 56);
+		}
+		__syncthreads();
+	}
+	for (u32 i = 0; i < RI_FOLD_BIG_SLOTS; i += RI_FOLD_BIG_THREADS) {
+		u32 left = tc[i + threadIdx.x];
+		const u32 pieces = (left + RI_ENT_MAXCNT - 1) / RI_ENT_MAXCNT;
+		const u32 incl = (u32) vdjx_wave_scan_add((int) pieces);
+		u32 base = 0;
+		if (lane == 63 && incl) base = atomicAdd(&s_out, incl);
+		base = (u32) __builtin_amdgcn_readlane((int) base, 63);
+		u32 o = s + base + incl - pieces;
+		const u64 e = (u64) tk[i + threadIdx.x];
+		while (left) { const u32 q = left < RI_ENT_MAXCNT ? left : RI_ENT_MAXCNT; d8[o++] = e | ((u64) q << 56); left -= q; }
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) { dcnt[cc] = s_out; atomicAdd(n_entries, (unsigned long long) s_out); }
+	}
 }
 
 // the lookup table the mapper reads: one slot per class = the sequence (W words), then {class + 1 | read-1 members << 32}, {CSR start |
@@ -516,7 +565,11 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	}
 	{
 		vdjx_prof_scope ps(c, "k_ri_fold");
-		hipLaunchKernelGGL(k_ri_fold, dim3(ncls / 256 + 1), b256, 0, st, c->d_ri_start, c->d_ri_cnt1, ncls, c->d_ri_csr8, c->d_ri_d8, c->d_ri_dstart, d_nent);
+		const u32 max_giant = n1 / (RI_FOLD_WAVE + 1) + 1;
+		u32* d_giant;
+		HIP_TRY(db.alloc(&d_giant, (size_t) max_giant + 1));
+		hipLaunchKernelGGL(k_ri_fold, dim3(ncls / 256 + 1), b256, 0, st, c->d_ri_start, c->d_ri_cnt1, ncls, c->d_ri_csr8, c->d_ri_d8, c->d_ri_dstart, d_nent, d_giant, d_split + 1);
+		hipLaunchKernelGGL(k_ri_fold_big, dim3(max_giant < 2048u ? max_giant : 2048u), dim3(RI_FOLD_BIG_THREADS), 0, st, d_giant, d_split + 1, c->d_ri_start, c->d_ri_cnt1, c->d_ri_csr8, c->d_ri_d8, c->d_ri_dstart, d_nent);
 	}
 	HIP_TRY(hipMemcpyAsync(&nd, d_nent, 8, hipMemcpyDeviceToHost, st));
 	{	// the mapper's table, now that the classes' sizes and starts are known
