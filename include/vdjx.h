@@ -221,6 +221,26 @@ int vdjx_sam_names_load(vdjx_ctx* ctx, const char* names, const uint64_t* name_o
 int vdjx_sam_text(vdjx_ctx* ctx, const char* contigs, size_t n, int len, const char* ids, const uint32_t* id_off,
                   const char** out_text, uint64_t* out_bytes);
 
+/* ---- the same records for a pool that is sharded BY PAIR over several GPUs (row e; no counterpart in the reference) -----------------
+ * Every rank formats the records of ITS pairs and leaves them on its device; the caller brings the ranks' results to one rank, which
+ * lays them out in the order output_mapping would have written them (quick_map3.c:152-181 called per contig from :311-340; inside a
+ * contig the order of quick_map_process_contig's lists, :199-245: offsets ascending, the instances of a read in registration order).
+ *   vdjx_sam_blocks   maps `contigs` against this context's read index; per mapped pair ("block") the two SAM lines, their byte
+ *                     count (u32) and a 64-bit key (contig << 44 | read-1 position << 32 | registration rank of the read-1 record;
+ *                     d_reg_rank: the rank of every record of the index's pool, GLOBAL over all shards).  The three arrays stay on the
+ *                     device, owned by the context, valid until the next vdjx_sam_blocks / vdjx_sam_text call.  Fewer than 2^20 contigs
+ *                     of fewer than 4096 bases per call.
+ *   vdjx_sam_merge    d_keys / d_lens / d_text = the blocks of all sources, source after source (every source's text the concatenation of
+ *                     its blocks in its own order); *out_text = the n_bytes of text in ascending key order, in a page-locked buffer owned
+ *                     by the context, valid until the next vdjx_sam_merge call.                                                   */
+int vdjx_sam_blocks(vdjx_ctx* ctx, const char* contigs, size_t n, int len, const char* ids, const uint32_t* id_off, const uint32_t* d_reg_rank,
+                    uint64_t* n_blocks, uint64_t* n_bytes, const void** d_keys, const void** d_lens, const void** d_text);
+int vdjx_sam_merge(vdjx_ctx* ctx, uint64_t n_blocks, uint64_t n_bytes, const void* d_keys, const void* d_lens, const void* d_text,
+                   const char** out_text, uint64_t* out_bytes);
+/* rows of `row` bytes on the device: row d_pos[i] of d_dst = row i of d_src.  (The records of a pool sharded by pair on their way to
+ * the ranks that hold their slice of the scan order for the k-mer build, A2:1388-1390: every record arrives with its place.) */
+int vdjx_rows_scatter(vdjx_ctx* ctx, void* d_dst, const void* d_src, const uint32_t* d_pos, size_t n, size_t row);
+
 /* counters of the most recent scorer calls, by name: "window_hits" (read instances matched by the last
  * vdjx_window_score call, summed over windows), "window_hits_max", "window_pairs", "window_work_items",
  * "map_hits", "root_dp_items".  Unknown names return 0.  Used by bench.py to price the scorers' algorithmic bytes. */

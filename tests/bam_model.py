@@ -138,12 +138,13 @@ class Rec(C.Structure):
 
 
 class Read(C.Structure):
-    _fields_ = [("pool", C.c_char), ("name", C.c_char_p), ("read_num", C.c_int), ("is_rev", C.c_int), ("seq", C.c_char_p), ("qual", C.c_char_p)]
+    _fields_ = [("pool", C.c_char), ("name", C.c_char_p), ("read_num", C.c_int), ("is_rev", C.c_int), ("seq", C.c_char_p), ("qual", C.c_char_p),
+                ("seq_no", C.c_uint64), ("pool_no", C.c_uint64)]
 
 
 class Reads(C.Structure):
     _fields_ = [("v", C.POINTER(Read)), ("n", C.c_size_t), ("read_len", C.c_int), ("max_len", C.c_int), ("n_primary_names", C.c_size_t),
-                ("n_secondary_names", C.c_size_t), ("arena", C.c_void_p)]
+                ("n_secondary_names", C.c_size_t), ("n_primary_reads", C.c_uint64), ("n_secondary_reads", C.c_uint64), ("arena", C.c_void_p)]
 
 
 _L = None

@@ -65,6 +65,89 @@ def test_vdjer_cli_sharded_build_one_rank_rccl(tag, tmp_path):
     assert (tmp_path / "vdjer.dot").read_text() == G.text(f"{tag}.dot.gz")
 
 
+def _shares(stderr):
+    out = {}
+    for l in stderr.splitlines():
+        f = l.split("\t")
+        if f[0] == "share" and f[1] == "rank":
+            out[int(f[2])] = dict(records=int(f[4]), total=int(f[6]), pairs=int(f[8]), host_pool_bytes=int(f[10]), maxrss_kb=int(f[12]))
+    return out
+
+
+@pytest.mark.parametrize("tag,gpus,sam_pairs", [("e2e_mixed", 2, None), ("e2e_mixed", 3, "40"), ("e2e_k25", 2, None), ("e2e_igk", 3, None), ("e2e_igl", 2, None),
+                                                ("e2e_tiled", 4, None), ("e2e_rl100", 2, None), ("e2e_rl151", 3, "1000")])
+def test_vdjer_cli_gpus_n_ranks_share_one_device(tag, gpus, sam_pairs, tmp_path):
+    """`vdjer --gpus N` end to end from C: N processes, every rank keeps 1/N of the pool (by pair), the ranks deal the k-mer build's
+    slices of the scan order out to each other, build the graph together, and ranks 1..N-1 then serve rank 0's scorer calls (window
+    scorer sharded like vdjer_amd/shard.py, SAM records formatted per rank and merged by key on rank 0) while it runs the serial
+    traversal.  The box has ONE GPU and RCCL refuses two ranks on a device, so VDJX_MGPU_ONE_DEVICE=1 puts every rank on device 0
+    and moves the bytes through host sockets (vdjx_comm.c "host" transport: the same driver code, another wire).  Reference bytes
+    out (reads of 50, 100 and 151 bases; IGH, IGK, IGL), whatever N; VDJX_MGPU_SAM_PAIRS cuts the SAM body into several runs."""
+    exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
+    c = G.Case(tag)
+    m = G.manifest()
+    info = m["e2e"][tag] if tag in m["e2e"] else m["e2e_chains"][tag]
+    _write_inputs(c, str(tmp_path))
+    cmd = [exe, "--in", "reads.txt", "--chain", info.get("chain", "IGH"), "--ref-dir", "ref", "--ins", str(info.get("ins", 175)), "--t", "2", "--gpus", str(gpus)] + info["flags"]
+    env = dict(os.environ, VDJX_MGPU_ONE_DEVICE="1", VDJX_REPORT_SHARE="1", VDJX_MGPU_TIMEOUT_S="120")
+    if sam_pairs:
+        env["VDJX_MGPU_SAM_PAIRS"] = sam_pairs
+    r = subprocess.run(cmd, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert f"k-mer table sharded over {gpus} GPUs (host)" in r.stderr
+    assert (tmp_path / "vdj_contigs.fa").read_text() == G.text(f"{tag}.contigs.fa.gz")
+    assert r.stdout == G.text(f"{tag}.sam.gz")
+    assert (tmp_path / "vdjer.dot").read_text() == G.text(f"{tag}.dot.gz")
+    sh = _shares(r.stderr)
+    R = c.pool.primary.shape[0] + c.pool.secondary.shape[0]
+    assert sorted(sh) == list(range(gpus)) and all(v["total"] == R for v in sh.values())
+    assert sum(v["records"] for v in sh.values()) == R and sum(v["pairs"] for v in sh.values()) == c.pool.n_pairs
+    assert max(v["records"] for v in sh.values()) <= 1.35 * R / gpus + 64         # a rank's host pool is its share: about 1/N
+
+
+def test_vdjer_cli_gpus_n_takes_a_bam(tmp_path):
+    """--in <bam> --gpus 2: every rank runs the extraction's passes and keeps its share (bamx_extract_filtered); same bytes as one GPU"""
+    exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
+    tag = "e2e_tiled"
+    c = G.Case(tag)
+    info = G.manifest()["e2e"][tag]
+    _write_inputs(c, str(tmp_path))
+    _bam_inputs(c, str(tmp_path))
+    cmd = [exe, "--in", "in.bam", "--chain", "IGH", "--ref-dir", "ref", "--ins", "175", "--t", "1", "--gpus", "2"] + info["flags"]
+    r = subprocess.run(cmd, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900,
+                       env=dict(os.environ, VDJX_MGPU_ONE_DEVICE="1", VDJX_MGPU_TIMEOUT_S="120"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert (tmp_path / "vdj_contigs.fa").read_text() == G.text(f"{tag}.contigs.fa.gz")
+    assert r.stdout == G.text(f"{tag}.sam.gz")
+    assert (tmp_path / "vdjer.dot").read_text() == G.text(f"{tag}.dot.gz")
+
+
+def test_vdjer_cli_gpus_n_host_share_scales_down(tmp_path):
+    """peak host memory of a rank: a pool of 60,000 pairs (24 MB of records) through --gpus 1 (whole pool in one process) and
+    --gpus 4: every rank of the latter holds about a quarter of the records, and its peak resident set stays below the one-GPU
+    run's by most of the difference (the runtime's own footprint is the same)"""
+    from vdjer_amd import synth
+    exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
+    rep = synth.make_repertoire(40, seed=77)
+    pool = synth.make_reads(rep, 60000, noise_frac=0.3, seed=78)
+    pool.write_reads_file(os.path.join(tmp_path, "reads.txt"))
+    synth.write_ref_dir(rep, os.path.join(tmp_path, "ref"))
+    outs, rss = [], []
+    for gpus in (1, 4):
+        d = tmp_path / f"g{gpus}"
+        d.mkdir()
+        cmd = [exe, "--in", "../reads.txt", "--chain", "IGH", "--ref-dir", "../ref", "--ins", "175", "--t", "2", "--gpus", str(gpus)]
+        r = subprocess.run(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900,
+                           env=dict(os.environ, VDJX_MGPU_ONE_DEVICE="1", VDJX_REPORT_SHARE="1", VDJX_MGPU_TIMEOUT_S="300"))
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append((r.stdout, (d / "vdj_contigs.fa").read_text(), (d / "vdjer.dot").read_text()))
+        rss.append(_shares(r.stderr))
+    assert outs[0] == outs[1] and outs[0][1].count(">") > 0
+    R = rss[0][0]["total"]
+    assert rss[0][0]["records"] == R and all(0.8 * R / 4 < v["records"] < 1.2 * R / 4 for v in rss[1].values())
+    print("maxrss_kb one GPU:", rss[0][0]["maxrss_kb"], "four ranks:", [v["maxrss_kb"] for v in rss[1].values()])
+
+
 def test_cli_rejects_bad_input(tmp_path):
     exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
     r = subprocess.run([exe, "--in", "nope", "--chain", "IGH", "--ref-dir", ".", "--ins", "175"], cwd=tmp_path,

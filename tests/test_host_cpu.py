@@ -207,23 +207,79 @@ def _tiny_cli_inputs(d, n_pairs=300, rl=50):
     return pool
 
 
-def test_ranks_read_only_their_slice_of_the_text_input(tmp_path):
-    """rank r of `vdjer --gpus N` keeps records [r*S, (r+1)*S) of the scan order (two passes over the file, load_slice_text): the
-    slices of all ranks laid end to end are the whole pool, primary records before secondary ones"""
+def _dump_share(exe, cwd, rk, nr, inp="reads.txt"):
     import subprocess
+    r = subprocess.run([exe, "--in", inp, "--chain", "IGH", "--ref-dir", "ref", "--ins", "175"], cwd=cwd,
+                       env=dict(os.environ, VDJX_DUMP_SHARE=f"{rk},{nr}"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    lines = r.stderr.decode().splitlines()
+    head = next(l for l in lines if l.startswith("share\t")).split("\t")
+    recs = [l.split("\t")[1:] for l in lines if l.startswith("rec\t")]
+    return {"rl": int(head[4]), "records": int(head[6]), "total": int(head[8]), "pairs": int(head[10]), "recs": recs, "bytes": r.stdout}
+
+
+def test_ranks_keep_their_share_of_the_pool_by_pair(tmp_path):
+    """rank r of `vdjer --gpus N` keeps the pairs whose read name hashes to it -- both mates, all four records -- and knows every
+    record's place in the scan order of the WHOLE pool (primary pool, then secondary: A2:1388-1390) and its registration rank over the
+    whole pool (the order of the add_read_info calls, bam_read.c:228,243).  The shares of all ranks, each record put back at its
+    place, are the pool the one-GPU run loads; a share is in ascending scan order; no pair is split."""
     exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
     if not os.path.exists(exe):
         pytest.skip("vdjer is not built")
     pool = _tiny_cli_inputs(str(tmp_path))
-    whole = np.concatenate([pool.primary, pool.secondary]).tobytes()
-    for nr in (2, 4):
-        got = b""
+    whole = np.concatenate([pool.primary, pool.secondary])
+    R, rec = whole.shape
+    one = _dump_share(exe, tmp_path, 0, 1)
+    assert one["records"] == one["total"] == R and one["bytes"] == whole.tobytes()
+    reg_one = {int(x[0]): int(x[1]) for x in one["recs"]}
+    for nr in (2, 3, 4):
+        got = np.zeros_like(whole)
+        seen = np.zeros(R, bool)
+        owner = {}
+        sizes = []
         for rk in range(nr):
-            r = subprocess.run([exe, "--in", "reads.txt", "--chain", "IGH", "--ref-dir", "ref", "--ins", "175"], cwd=tmp_path,
-                               env=dict(os.environ, VDJX_DUMP_SLICE=f"{rk},{nr}"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
-            assert r.returncode == 0, r.stderr[-500:]
-            got += r.stdout
-        assert got == whole
+            sh = _dump_share(exe, tmp_path, rk, nr)
+            assert sh["total"] == R and sh["rl"] == pool.rl and len(sh["recs"]) == sh["records"]
+            rows = np.frombuffer(sh["bytes"], np.uint8).reshape(-1, rec)
+            scan = np.array([int(x[0]) for x in sh["recs"]])
+            assert np.all(np.diff(scan) > 0)                         # ascending: what goes to a rank's slice is one run of the share
+            assert not seen[scan].any()
+            seen[scan] = True
+            got[scan] = rows
+            for x in sh["recs"]:
+                assert reg_one[int(x[0])] == int(x[1])               # the registration rank is the whole pool's, not the share's
+                assert owner.setdefault(x[5], rk) == rk              # a read name lives on one rank
+            assert len({x[5] for x in sh["recs"]}) == sh["pairs"]
+            sizes.append(sh["records"])
+        assert seen.all() and np.array_equal(got, whole)
+        assert max(sizes) < 1.5 * R / nr + 40                        # shares are about 1/N of the pool
+
+
+def test_ranks_keep_their_share_of_a_bam(tmp_path):
+    """the same through the BAM route (bamx_extract_filtered): every rank runs the extraction's passes and stores only its share"""
+    exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
+    if not os.path.exists(exe):
+        pytest.skip("vdjer is not built")
+    from tests import golden_util as G
+    from tests.test_cli_e2e import _bam_inputs, _write_inputs
+    c = G.Case("e2e_mixed")
+    _write_inputs(c, str(tmp_path))
+    _bam_inputs(c, str(tmp_path))
+    one = _dump_share(exe, tmp_path, 0, 1, "in.bam")
+    R = one["total"]
+    rec = 2 * one["rl"] + 1
+    assert one["records"] == R > 0
+    whole = np.frombuffer(one["bytes"], np.uint8).reshape(R, rec)
+    reg_one = {int(x[0]): int(x[1]) for x in one["recs"]}
+    got = np.zeros_like(whole)
+    n = 0
+    for rk in range(3):
+        sh = _dump_share(exe, tmp_path, rk, 3, "in.bam")
+        scan = np.array([int(x[0]) for x in sh["recs"]], dtype=np.int64)
+        assert np.all(np.diff(scan) > 0) and all(reg_one[int(x[0])] == int(x[1]) for x in sh["recs"])
+        got[scan] = np.frombuffer(sh["bytes"], np.uint8).reshape(-1, rec)
+        n += sh["records"]
+    assert n == R and np.array_equal(got, whole)
 
 
 def test_multi_gpu_cli_fails_fast_and_leaves_no_rank_behind(tmp_path):

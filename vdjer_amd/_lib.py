@@ -17,7 +17,7 @@ SYMBOLS = [
     "vdjx_anchor_sets_load", "vdjx_anchor_probe", "vdjx_index_generate", "vdjx_anchor_sets_from_anchors",
     "vdjx_kmer_build", "vdjx_graph_nodes", "vdjx_graph_pre_nodes", "vdjx_graph_export", "vdjx_graph_export_begin", "vdjx_graph_export_end", "vdjx_graph_free",
     "vdjx_vregion_load", "vdjx_root_score", "vdjx_graph_roots", "vdjx_root_part", "vdjx_root_score_graph",
-    "vdjx_read_index_build", "vdjx_read_index_build_device", "vdjx_window_score", "vdjx_window_pairs", "vdjx_window_pairs_fetch", "vdjx_window_cover", "vdjx_map_emit", "vdjx_map_emit_begin", "vdjx_map_emit_end", "vdjx_sam_names_load", "vdjx_sam_text",
+    "vdjx_read_index_build", "vdjx_read_index_build_device", "vdjx_window_score", "vdjx_window_pairs", "vdjx_window_pairs_fetch", "vdjx_window_cover", "vdjx_map_emit", "vdjx_map_emit_begin", "vdjx_map_emit_end", "vdjx_sam_names_load", "vdjx_sam_text", "vdjx_sam_blocks", "vdjx_sam_merge", "vdjx_rows_scatter",
     "vdjx_host_alloc", "vdjx_host_free", "vdjx_host_take_rows",
     "vdjx_stat", "vdjx_profile_enable", "vdjx_profile_reset", "vdjx_profile_count", "vdjx_profile_get",
     "vdjx_shard_begin", "vdjx_shard_free", "vdjx_shard_record_bytes", "vdjx_shard_local", "vdjx_shard_local_fill",

@@ -545,11 +545,16 @@ static void add_name_cb(const bamx_rec* r, void* ud) {
 	if (!sset_get(u->set, r->qname)) sset_put(u->set, arena_str(u->arena, r->qname));
 }
 
-static void push_read(bamx_reads* out, size_t* cap, char pool, const char* name, int read_num, const bamx_rec* r, blk** arena) {
+typedef struct { int (*keep)(void* ud, const char* name); void* ud; } keep_fn;
+static void push_read(bamx_reads* out, size_t* cap, char pool, const char* name, int read_num, const bamx_rec* r, blk** arena, const keep_fn* kf) {
+	const uint64_t seq_no = out->n_primary_reads + out->n_secondary_reads;
+	const uint64_t pool_no = pool == 'P' ? out->n_primary_reads++ : out->n_secondary_reads++;
+	if (kf->keep && !kf->keep(kf->ud, name)) return;
 	if (out->n == *cap) { *cap = *cap ? *cap * 2 : 4096; out->v = (bamx_read*) realloc(out->v, *cap * sizeof(bamx_read)); }
 	bamx_read* x = &out->v[out->n++];
 	const size_t L = (size_t) out->read_len;
 	x->pool = pool; x->name = name; x->read_num = read_num; x->is_rev = (r->flag & 16) != 0;
+	x->seq_no = seq_no; x->pool_no = pool_no;
 	x->seq = arena_alloc(arena, L + 1);
 	x->qual = arena_alloc(arena, L + 1);
 	memset(x->seq, 0, L + 1);
@@ -559,6 +564,12 @@ static void push_read(bamx_reads* out, size_t* cap, char pool, const char* name,
 }
 
 int bamx_extract(const char* bam_path, const char* vdj_fasta, const char* v_region, const char* c_region, bamx_reads* out) {
+	return bamx_extract_filtered(bam_path, vdj_fasta, v_region, c_region, NULL, NULL, out);
+}
+
+int bamx_extract_filtered(const char* bam_path, const char* vdj_fasta, const char* v_region, const char* c_region,
+                          int (*keep)(void* ud, const char* name), void* ud, bamx_reads* out) {
+	const keep_fn kf = {keep, ud};
 	memset(out, 0, sizeof *out);
 	blk* arena = NULL;
 	static bamx_rec rec;
@@ -630,11 +641,11 @@ int bamx_extract(const char* bam_path, const char* vdj_fasta, const char* v_regi
 			if (rec.flag & 0x900) continue;
 			const char* nm;
 			if ((nm = sset_get(&primary, rec.qname)) != NULL) {
-				if ((rec.flag & 0x40) && !sset_get(&p1, nm)) { push_read(out, &cap, 'P', nm, 1, &rec, &arena); sset_put(&p1, nm); }
-				else if ((rec.flag & 0x80) && !sset_get(&p2, nm)) { push_read(out, &cap, 'P', nm, 2, &rec, &arena); sset_put(&p2, nm); }
+				if ((rec.flag & 0x40) && !sset_get(&p1, nm)) { push_read(out, &cap, 'P', nm, 1, &rec, &arena, &kf); sset_put(&p1, nm); }
+				else if ((rec.flag & 0x80) && !sset_get(&p2, nm)) { push_read(out, &cap, 'P', nm, 2, &rec, &arena, &kf); sset_put(&p2, nm); }
 			} else if ((nm = sset_get(&secondary, rec.qname)) != NULL) {
-				if ((rec.flag & 0x40) && !sset_get(&s1, nm)) { push_read(out, &cap, 'S', nm, 1, &rec, &arena); sset_put(&s1, nm); }
-				else if ((rec.flag & 0x80) && !sset_get(&s2, nm)) { push_read(out, &cap, 'S', nm, 2, &rec, &arena); sset_put(&s2, nm); }
+				if ((rec.flag & 0x40) && !sset_get(&s1, nm)) { push_read(out, &cap, 'S', nm, 1, &rec, &arena, &kf); sset_put(&s1, nm); }
+				else if ((rec.flag & 0x80) && !sset_get(&s2, nm)) { push_read(out, &cap, 'S', nm, 2, &rec, &arena, &kf); sset_put(&s2, nm); }
 			}
 		}
 		if (rc == -1) rc = 0;

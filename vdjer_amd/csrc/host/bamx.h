@@ -25,6 +25,8 @@ typedef struct {
 	int is_rev;           /* bam_is_rev */
 	char* seq;            /* read_len characters of "=ACMGRSVTWYHKDBN" (NUL padded if the record is shorter: strncpy, :220) */
 	char* qual;           /* read_len characters, Phred+33 */
+	uint64_t seq_no;      /* its place among ALL reads the extraction emits (kept or not): add_read_info is called for read q as calls 2q, 2q+1 */
+	uint64_t pool_no;     /* its place among the reads of its pool: records 2*pool_no, 2*pool_no+1 of primary_buf / secondary_buf */
 } bamx_read;
 
 typedef struct {
@@ -33,6 +35,7 @@ typedef struct {
 	int read_len;         /* extract's: l_qseq of the first record its sequential pass sees (bam_read.c:353-355) */
 	int max_len;          /* get_read_length: the longest l_qseq of the file (bam_read.c:264-292) */
 	size_t n_primary_names, n_secondary_names;
+	uint64_t n_primary_reads, n_secondary_reads;   /* reads emitted into either pool, kept by the caller's filter or not */
 	void* arena;          /* private */
 } bamx_reads;
 
@@ -41,6 +44,10 @@ const char* bamx_last_error(void);
 int bamx_is_bam(const char* path);
 /* the whole extraction; v_region / c_region are samtools region strings ("chr14:105566277-106879844").  0 on success */
 int bamx_extract(const char* bam_path, const char* vdj_fasta, const char* v_region, const char* c_region, bamx_reads* out);
+/* the same passes, but only the reads `keep` says yes to are stored (all are counted and numbered): one rank of `vdjer --gpus N` keeps
+ * the pairs it owns, 1/N of the pool, instead of every rank holding all of it.  keep == NULL keeps everything. */
+int bamx_extract_filtered(const char* bam_path, const char* vdj_fasta, const char* v_region, const char* c_region,
+                          int (*keep)(void* ud, const char* name), void* ud, bamx_reads* out);
 void bamx_free(bamx_reads* r);
 
 /* ---- lower level, exposed for the tests -------------------------------------------------------------------------- */

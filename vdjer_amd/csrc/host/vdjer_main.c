@@ -27,6 +27,7 @@
 #include "vdjx_mgpu.h"
 #include <errno.h>
 #include <sys/wait.h>
+#include <sys/resource.h>
 #include <sys/prctl.h>
 #include <signal.h>
 #include <unistd.h>
@@ -139,70 +140,122 @@ static void status(const char* desc) {         /* status.c:22-32 without the /pr
 /* ------------------------------------------------------------------------------------------ */
 /* inputs                                                                                      */
 /* ------------------------------------------------------------------------------------------ */
+/* What one process holds of the read pool.  One GPU: all of it, the two pools as the reference lays them out (bam_read.c:376-379).
+ * `--gpus N`: the process's SHARE -- the pairs whose read name hashes to its rank, both mates, all four records -- as ONE block
+ * (`primary`: its primary-pool records followed by its secondary-pool ones, each group in extraction order), with every record's place
+ * in the scan order of the whole pool and its registration rank over the whole pool beside it. */
 typedef struct {
 	int rl;
 	uint8_t *primary, *secondary;
-	size_t n_primary, n_secondary;
-	uint32_t *pair_id, *reg_rank;       /* scan order: primary records then secondary */
+	size_t n_primary, n_secondary;      /* records */
+	uint32_t *pair_id, *reg_rank;       /* per record of this process, block order */
+	uint32_t* scan_index;               /* `--gpus N`: place in the whole pool's scan order (primary pool, then secondary) */
 	uint8_t *read_num, *is_rc;
-	char** names;
+	char** names;                       /* by pair id (the process's own numbering) */
 	uint32_t n_pairs;
+	uint64_t total_records;             /* of the whole pool */
 } reads_t;
 
 static char comp(char c) { switch (c) { case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C'; default: return c; } }
 
 /* one extracted read before it becomes two pool records */
-typedef struct { char pool; const char* name; int rn, rev; const char* seq; const char* qual; } read_in;
+typedef struct {
+	char pool; char* name; int rn, rev; char* seq; char* qual;
+	uint64_t seq_no, pool_no;           /* among all reads of the extraction / among the reads of its pool (kept by this process or not) */
+} read_in;
+typedef struct {
+	read_in* v; size_t n, cap;
+	uint64_t np, ns;                    /* reads of the primary / secondary pool, kept or not */
+	int max_len;
+	int rank, nranks;
+} collector;
 
-/* add_to_buffer (bam_read.c:206-244) for every read, in order: forward record, reverse-complement record, both registered */
-static int build_reads(const read_in* in, size_t n, int rl, reads_t* r) {
+static uint64_t name_hash(const char* s) {
+	uint64_t h = 1469598103934665603ull;
+	for (; *s; s++) { h ^= (unsigned char) *s; h *= 1099511628211ull; }
+	h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+	return h;
+}
+/* `--gpus N`: which rank owns the pair of this name */
+static int owner_of(const char* name, int nranks) { return nranks > 1 ? (int) (name_hash(name) % (uint64_t) nranks) : 0; }
+static int keep_name(void* ud, const char* name) { const collector* c = (const collector*) ud; return owner_of(name, c->nranks) == c->rank; }
+
+static int collect(collector* c, char pool, const char* name, int rn, int rev, const char* seq, const char* qual) {
+	const uint64_t seq_no = c->np + c->ns, pool_no = pool == 'P' ? c->np++ : c->ns++;
+	const int l = (int) strlen(seq);
+	if (l > c->max_len) c->max_len = l;                       /* get_read_length: the maximum (bam_read.c:264-292) */
+	if (owner_of(name, c->nranks) != c->rank) return 0;
+	if (c->n == c->cap) {
+		c->cap = c->cap ? c->cap * 2 : 4096;
+		c->v = (read_in*) realloc(c->v, c->cap * sizeof(read_in));
+		if (!c->v) return -1;
+	}
+	read_in* x = &c->v[c->n++];
+	x->pool = pool; x->rn = rn; x->rev = rev; x->seq_no = seq_no; x->pool_no = pool_no;
+	x->name = strdup(name); x->seq = strdup(seq); x->qual = strdup(qual);
+	return x->name && x->seq && x->qual ? 0 : -1;
+}
+static void collector_free(collector* c) {
+	for (size_t i = 0; i < c->n; i++) { free(c->v[i].name); free(c->v[i].seq); free(c->v[i].qual); }
+	free(c->v);
+	memset(c, 0, sizeof *c);
+}
+
+/* add_to_buffer (bam_read.c:206-244) for every collected read: forward record, reverse-complement record, both registered.
+ * One GPU: two pools, pair ids in extraction order.  A share: one block, primary-pool reads first. */
+static int build_reads(const collector* c, reads_t* r) {
+	const int rl = c->max_len, multi = c->nranks > 1;
 	size_t np = 0, ns = 0;
-	for (size_t i = 0; i < n; i++) { if (in[i].pool == 'P') np++; else ns++; }
+	for (size_t i = 0; i < c->n; i++) { if (c->v[i].pool == 'P') np++; else ns++; }
 	memset(r, 0, sizeof *r);
 	r->rl = rl;
+	r->total_records = 2 * (c->np + c->ns);
+	if (r->total_records >= (1ull << 32)) { fprintf(stderr, "more than 2^32 pool records\n"); return -1; }
 	const size_t rec = 2 * (size_t) rl + 1;
-	r->n_primary = 2 * np;
-	r->n_secondary = 2 * ns;
-	const size_t R = r->n_primary + r->n_secondary;
+	const size_t R = 2 * (np + ns);
+	r->n_primary = multi ? R : 2 * np;
+	r->n_secondary = multi ? 0 : 2 * ns;
 	r->primary = (uint8_t*) calloc(r->n_primary * rec + 1, 1);
-	r->secondary = (uint8_t*) calloc(r->n_secondary * rec + 1, 1);
+	r->secondary = multi ? NULL : (uint8_t*) calloc(r->n_secondary * rec + 1, 1);
 	r->pair_id = (uint32_t*) calloc(R + 1, 4);
 	r->reg_rank = (uint32_t*) calloc(R + 1, 4);
+	r->scan_index = (uint32_t*) calloc(R + 1, 4);
 	r->read_num = (uint8_t*) calloc(R + 1, 1);
 	r->is_rc = (uint8_t*) calloc(R + 1, 1);
 	r->names = (char**) calloc(np + ns + 1, sizeof(char*));
+	if (!r->primary || (!multi && !r->secondary) || !r->pair_id || !r->reg_rank || !r->scan_index || !r->read_num || !r->is_rc || !r->names) { fprintf(stderr, "out of memory\n"); return -1; }
 	sph_table ids;                       /* read name -> pair id */
 	sph_init(&ids, 0, 0);
 	size_t ip = 0, is = 0;
-	uint32_t reg = 0;
-	for (size_t q = 0; q < n; q++) {
-		const char *name = in[q].name, *seq = in[q].seq, *qual = in[q].qual;
-		if ((int) strlen(seq) != rl || (int) strlen(qual) != rl) { fprintf(stderr, "read %s: length != %d\n", name, rl); sph_free(&ids); return -1; }
-		size_t b = sph_find(&ids, name);
+	for (size_t q = 0; q < c->n; q++) {
+		const read_in* in = &c->v[q];
+		if ((int) strlen(in->seq) != rl || (int) strlen(in->qual) != rl) { fprintf(stderr, "read %s: length != %d\n", in->name, rl); sph_free(&ids); return -1; }
+		size_t b = sph_find(&ids, in->name);
 		uint32_t pid;
 		if (b == (size_t) -1) {
 			pid = r->n_pairs++;
-			r->names[pid] = strdup(name);
+			r->names[pid] = strdup(in->name);
 			sph_map_put(&ids, r->names[pid], (void*) (uintptr_t) (pid + 1), NULL);
 		} else {
 			pid = (uint32_t) (uintptr_t) ids.b[b].val - 1;
 		}
-		const int isp = in[q].pool == 'P';
-		uint8_t* base = isp ? r->primary + ip * rec : r->secondary + is * rec;
-		const size_t g = isp ? ip : r->n_primary + is;
+		const int isp = in->pool == 'P';
+		const size_t g = isp ? ip : 2 * np + is;                /* first record of the read in this process's block order */
+		uint8_t* base = multi || isp ? r->primary + g * rec : r->secondary + is * rec;
 		base[0] = '0';
-		memcpy(base + 1, seq, (size_t) rl);
-		memcpy(base + 1 + rl, qual, (size_t) rl);
+		memcpy(base + 1, in->seq, (size_t) rl);
+		memcpy(base + 1 + rl, in->qual, (size_t) rl);
 		base[rec] = '0';
 		for (int i = 0; i < rl; i++) {
-			base[rec + 1 + i] = (uint8_t) comp(seq[rl - 1 - i]);
-			base[rec + 1 + rl + i] = (uint8_t) qual[rl - 1 - i];
+			base[rec + 1 + i] = (uint8_t) comp(in->seq[rl - 1 - i]);
+			base[rec + 1 + rl + i] = (uint8_t) in->qual[rl - 1 - i];
 		}
 		for (int j = 0; j < 2; j++) {
 			r->pair_id[g + j] = pid;
-			r->read_num[g + j] = (uint8_t) in[q].rn;
-			r->is_rc[g + j] = (uint8_t) (j ? !in[q].rev : (in[q].rev != 0));     /* add_read_info(..., bam_is_rev) then (!bam_is_rev) */
-			r->reg_rank[g + j] = reg++;
+			r->read_num[g + j] = (uint8_t) in->rn;
+			r->is_rc[g + j] = (uint8_t) (j ? !in->rev : (in->rev != 0));     /* add_read_info(..., bam_is_rev) then (!bam_is_rev) */
+			r->reg_rank[g + j] = (uint32_t) (2 * in->seq_no + (uint64_t) j);
+			r->scan_index[g + j] = (uint32_t) ((isp ? 0 : 2 * c->np) + 2 * in->pool_no + (uint64_t) j);
 		}
 		if (isp) ip += 2; else is += 2;
 	}
@@ -210,109 +263,86 @@ static int build_reads(const read_in* in, size_t n, int rl, reads_t* r) {
 	return 0;
 }
 
-/* --in <bam>: get_read_length + extract (bam_read.c:264-446) through bamx */
-static int load_bam(const cli* c, reads_t* r) {
+/* --in <bam>: get_read_length + extract (bam_read.c:264-446) through bamx; a rank of `--gpus N` runs the same passes and keeps its share */
+static int load_bam(const cli* c, collector* col) {
 	if (!c->vdj_fasta[0] || !c->v_region[0] || !c->c_region[0]) { fprintf(stderr, "BAM input needs --chain/--ref-dir (or --vdjf, --vr, --cr)\n"); return -1; }
 	bamx_reads br;
-	if (bamx_extract(c->in, c->vdj_fasta, c->v_region, c->c_region, &br)) { fprintf(stderr, "%s\n", bamx_last_error()); return -1; }
+	if (bamx_extract_filtered(c->in, c->vdj_fasta, c->v_region, c->c_region, col->nranks > 1 ? keep_name : NULL, col, &br)) { fprintf(stderr, "%s\n", bamx_last_error()); return -1; }
 	if (br.read_len != br.max_len) {
 		fprintf(stderr, "reads of different lengths (%d and %d): the reference lays its pools out with one length\n", br.read_len, br.max_len);
 		bamx_free(&br);
 		return -1;
 	}
-	read_in* in = (read_in*) calloc(br.n + 1, sizeof(read_in));
+	col->v = (read_in*) calloc(br.n + 1, sizeof(read_in));
+	col->cap = br.n + 1;
 	for (size_t i = 0; i < br.n; i++) {
 		const bamx_read* x = &br.v[i];
-		in[i].pool = x->pool; in[i].name = x->name; in[i].rn = x->read_num; in[i].rev = x->is_rev; in[i].seq = x->seq; in[i].qual = x->qual;
+		read_in* o = &col->v[col->n++];
+		o->pool = x->pool; o->rn = x->read_num; o->rev = x->is_rev; o->seq_no = x->seq_no; o->pool_no = x->pool_no;
+		o->name = strdup(x->name);
+		o->seq = (char*) calloc((size_t) br.max_len + 1, 1);
+		o->qual = (char*) calloc((size_t) br.max_len + 1, 1);
+		memcpy(o->seq, x->seq, (size_t) br.read_len);
+		memcpy(o->qual, x->qual, (size_t) br.read_len);
 	}
-	const int rc = build_reads(in, br.n, br.max_len, r);
-	free(in);
+	col->np = br.n_primary_reads; col->ns = br.n_secondary_reads;
+	col->max_len = br.max_len;
 	bamx_free(&br);
+	return 0;
+}
+
+/* whitespace-separated tokens of a file, a megabyte at a time (the text route's lines are six of them) */
+typedef struct { FILE* fp; char* buf; size_t len, at; int eof; } tok_reader;
+static int next_token(tok_reader* t, char* out, size_t cap) {
+	size_t n = 0;
+	for (;;) {
+		if (t->at == t->len) {
+			if (t->eof) break;
+			t->len = fread(t->buf, 1, 1u << 20, t->fp);
+			t->at = 0;
+			if (t->len == 0) { t->eof = 1; break; }
+		}
+		const char ch = t->buf[t->at];
+		const int ws = ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r' || ch == '\f' || ch == '\v';
+		if (ws) { t->at++; if (n) break; continue; }
+		if (n + 1 < cap) out[n++] = ch;
+		else { t->at++; continue; }            /* (fscanf's %511s stops there and leaves the rest as the next token; such lines are malformed either way) */
+		t->at++;
+	}
+	out[n] = 0;
+	return n > 0;
+}
+
+/* the extracted read pool as text (see the head of this file): every process reads the whole file once and keeps its share */
+static int load_text(const char* path, collector* col) {
+	tok_reader t = {fopen(path, "r"), (char*) malloc(1u << 20), 0, 0, 0};
+	if (!t.fp || !t.buf) { fprintf(stderr, "cannot open %s\n", path); if (t.fp) fclose(t.fp); free(t.buf); return -1; }
+	char pool[8], name[512], rn[16], rev[16];
+	static char seq[1024], qual[1024];
+	int rc = 0;
+	while (next_token(&t, pool, sizeof pool)) {
+		if (!next_token(&t, name, sizeof name) || !next_token(&t, rn, sizeof rn) || !next_token(&t, rev, sizeof rev) || !next_token(&t, seq, sizeof seq)
+		    || !next_token(&t, qual, sizeof qual)) break;
+		char* e1; char* e2;
+		const long a = strtol(rn, &e1, 10), b = strtol(rev, &e2, 10);
+		if (*e1 || *e2) break;                                        /* (fscanf's %d would have stopped here) */
+		if ((rc = collect(col, pool[0] == 'P' ? 'P' : 'S', name, (int) a, (int) b, seq, qual)) != 0) { fprintf(stderr, "out of memory\n"); break; }
+	}
+	fclose(t.fp);
+	free(t.buf);
 	return rc;
 }
 
-/* A rank other than 0 of `--gpus N` only ever uses ITS records [rank*S, (rank+1)*S) of the scan order (primary pool, then secondary;
- * two records per read): the text file is read twice -- once to count the reads of the two pools, once to keep the rank's own --
- * instead of every process holding the whole pool (40 GB each at 100 M pairs).  The slice comes back as the primary pool of `r`
- * (n_primary records, nothing else filled in); *stride = S. */
-static int load_slice_text(const char* path, int rank, int nranks, reads_t* r, size_t* stride) {
-	FILE* fp = fopen(path, "r");
-	if (!fp) { fprintf(stderr, "cannot open %s\n", path); return -1; }
-	char pool[8], name[512];
-	static char seq[1024], qual[1024];
-	int rn, rev, rl = -1;
-	size_t np = 0, ns = 0;
-	while (fscanf(fp, "%7s %511s %d %d %1023s %1023s", pool, name, &rn, &rev, seq, qual) == 6) {
-		const int l = (int) strlen(seq);
-		if (l > rl) rl = l;
-		if (pool[0] == 'P') np++; else ns++;
-	}
-	if (rl <= 0) { fclose(fp); fprintf(stderr, "Error retrieving read length from: %s\n", path); return -1; }
-	const size_t Rt = 2 * (np + ns), S = (Rt + (size_t) nranks - 1) / (size_t) nranks;
-	const size_t a = (size_t) rank * S < Rt ? (size_t) rank * S : Rt, b = a + S < Rt ? a + S : Rt;
-	const size_t rec = 2 * (size_t) rl + 1;
-	memset(r, 0, sizeof *r);
-	r->rl = rl;
-	r->n_primary = b - a;
-	r->primary = (uint8_t*) calloc((b - a) * rec + 1, 1);
-	*stride = S;
-	rewind(fp);
-	size_t ip = 0, is = 0;
-	int bad = 0;
-	while (fscanf(fp, "%7s %511s %d %d %1023s %1023s", pool, name, &rn, &rev, seq, qual) == 6) {
-		const int isp = pool[0] == 'P';
-		const size_t g = isp ? ip : 2 * np + is;              /* scan index of the read's first record */
-		if (isp) ip += 2; else is += 2;
-		if (g + 2 <= a || g >= b) continue;
-		if ((int) strlen(seq) != rl || (int) strlen(qual) != rl) { fprintf(stderr, "read %s: length != %d\n", name, rl); bad = 1; break; }
-		for (int j = 0; j < 2; j++) {
-			if (g + (size_t) j < a || g + (size_t) j >= b) continue;
-			uint8_t* base = r->primary + (g + (size_t) j - a) * rec;
-			base[0] = '0';
-			for (int i = 0; i < rl; i++) {
-				base[1 + i] = (uint8_t) (j ? comp(seq[rl - 1 - i]) : seq[i]);
-				base[1 + rl + i] = (uint8_t) (j ? qual[rl - 1 - i] : qual[i]);
-			}
-		}
-	}
-	fclose(fp);
-	return bad ? -1 : 0;
-}
-
 static int load_reads(const cli* c, reads_t* r, int rank, int nranks) {
-	const char* path = c->in;
-	const int isbam = bamx_is_bam(path);
-	if (isbam < 0) { fprintf(stderr, "cannot open %s\n", path); return -1; }
-	if (isbam) return load_bam(c, r);                        /* (every rank extracts: the BAM passes are not sliced) */
-	if (rank > 0 && nranks > 1) {
-		size_t S = 0;
-		const int rc = load_slice_text(path, rank, nranks, r, &S);
-		r->n_pairs = 0;
-		r->n_secondary = S;                                   /* (smuggled to main: the slice's stride; a slice has no secondary pool) */
-		r->secondary = NULL;
-		return rc;
-	}
-	FILE* fp = fopen(path, "r");
-	if (!fp) { fprintf(stderr, "cannot open %s\n", path); return -1; }
-	char pool[8], name[512];
-	static char seq[1024], qual[1024];
-	int rn, rev;
-	size_t n = 0, cap = 1024;
-	int rl = -1;
-	read_in* in = (read_in*) calloc(cap, sizeof(read_in));
-	while (fscanf(fp, "%7s %511s %d %d %1023s %1023s", pool, name, &rn, &rev, seq, qual) == 6) {
-		const int l = (int) strlen(seq);
-		if (l > rl) rl = l;                                   /* get_read_length: the maximum */
-		if (n == cap) { cap *= 2; in = (read_in*) realloc(in, cap * sizeof(read_in)); }
-		in[n].pool = pool[0] == 'P' ? 'P' : 'S';
-		in[n].name = strdup(name); in[n].rn = rn; in[n].rev = rev; in[n].seq = strdup(seq); in[n].qual = strdup(qual);
-		n++;
-	}
-	fclose(fp);
-	if (rl <= 0) { fprintf(stderr, "Error retrieving read length from: %s\n", path); return -1; }
-	const int rc = build_reads(in, n, rl, r);
-	for (size_t i = 0; i < n; i++) { free((char*) in[i].name); free((char*) in[i].seq); free((char*) in[i].qual); }
-	free(in);
+	const int isbam = bamx_is_bam(c->in);
+	if (isbam < 0) { fprintf(stderr, "cannot open %s\n", c->in); return -1; }
+	collector col;
+	memset(&col, 0, sizeof col);
+	col.rank = rank; col.nranks = nranks; col.max_len = -1;
+	int rc = isbam ? load_bam(c, &col) : load_text(c->in, &col);
+	if (!rc && col.max_len <= 0) { fprintf(stderr, "Error retrieving read length from: %s\n", c->in); rc = -1; }
+	if (!rc) rc = build_reads(&col, r);
+	collector_free(&col);
 	return rc;
 }
 
@@ -362,7 +392,7 @@ static int load_vregion(const char* path, char*** lines, size_t* n) {
 /* ------------------------------------------------------------------------------------------ */
 /* hooks onto libvdjx                                                                          */
 /* ------------------------------------------------------------------------------------------ */
-typedef struct { vdjx_ctx* gx; const reads_t* r; const vdjh_params* p; } hook_ud;
+typedef struct { vdjx_ctx* gx; const reads_t* r; const vdjh_params* p; vdjx_mgpu* mg; } hook_ud;
 
 static int h_root_score(void* ud, const char* kmers, size_t n, int k, int thr, uint8_t* out) {
 	hook_ud* u = (hook_ud*) ud;
@@ -375,6 +405,11 @@ static int h_window_score(void* ud, const char* windows, size_t n, int len, uint
 	hook_ud* u = (hook_ud*) ud;
 	const vdjh_params* p = u->p;
 	vdjx_cov_params cp = {p->eval_start, p->eval_stop, p->filter_read_span, p->filter_mate_span, p->insert_len, p->insert_len, p->read_filter_floor};
+	if (u->mg) {                              /* `--gpus N`: every rank maps the windows against its share of the pool */
+		const int rcm = vdjx_mgpu_window_score(u->mg, u->gx, windows, n, len, &cp, valid);
+		if (rcm) fprintf(stderr, "vdjx_mgpu_window_score: %s\n", vdjx_mgpu_last_error());
+		return rcm;
+	}
 	uint32_t* np = (uint32_t*) malloc((n + 1) * 4);
 	int rc = vdjx_window_score(u->gx, windows, n, len, &cp, valid, np);
 	if (rc) fprintf(stderr, "vdjx_window_score: %s\n", vdjx_last_error());
@@ -392,7 +427,7 @@ static const uint8_t* rec_ptr(const reads_t* r, uint32_t rec) {
 static int h_sam_body(void* ud, const char* const* ids, const char* contigs, size_t n, int len, FILE* out) {
 	hook_ud* u = (hook_ud*) ud;
 	const reads_t* r = u->r;
-	if (!getenv("VDJX_SAM_HOST")) {
+	if (u->mg || !getenv("VDJX_SAM_HOST")) {
 		uint32_t* id_off = (uint32_t*) calloc(n + 1, 4);
 		size_t tot = 0;
 		for (size_t c = 0; c < n; c++) { tot += strlen(ids[c]); id_off[c + 1] = (uint32_t) tot; }
@@ -400,10 +435,10 @@ static int h_sam_body(void* ud, const char* const* ids, const char* contigs, siz
 		for (size_t c = 0; c < n; c++) memcpy(cat + id_off[c], ids[c], id_off[c + 1] - id_off[c]);
 		const char* text = NULL;
 		uint64_t nb = 0;
-		int rc = vdjx_sam_text(u->gx, contigs, n, len, cat, id_off, &text, &nb);
+		int rc = u->mg ? vdjx_mgpu_sam_body(u->mg, u->gx, contigs, n, len, cat, id_off, &text, &nb) : vdjx_sam_text(u->gx, contigs, n, len, cat, id_off, &text, &nb);
 		free(cat);
 		free(id_off);
-		if (rc) { fprintf(stderr, "vdjx_sam_text: %s\n", vdjx_last_error()); return rc; }
+		if (rc) { fprintf(stderr, "%s: %s\n", u->mg ? "vdjx_mgpu_sam_body" : "vdjx_sam_text", u->mg ? vdjx_mgpu_last_error() : vdjx_last_error()); return rc; }
 		if (nb && fwrite(text, 1, (size_t) nb, out) != (size_t) nb) { fprintf(stderr, "short write of the SAM records\n"); return -1; }
 		return 0;
 	}
@@ -442,15 +477,6 @@ static int h_sam_body(void* ud, const char* const* ids, const char* contigs, siz
 static void h_status(void* ud, const char* desc) { (void) ud; status(desc); }
 
 #define VX(call) do { if ((call) != 0) { fprintf(stderr, "%s: %s\n", #call, vdjx_last_error()); return 1; } } while (0)
-
-/* records [a, b) of the scan order (primary pool, then secondary) as one contiguous block */
-static uint8_t* slice_records(const reads_t* r, size_t a, size_t b) {
-	const size_t rec = 2 * (size_t) r->rl + 1;
-	uint8_t* out = (uint8_t*) malloc((b > a ? b - a : 1) * rec);
-	for (size_t i = a; i < b; i++)
-		memcpy(out + (i - a) * rec, i < r->n_primary ? r->primary + i * rec : r->secondary + (i - r->n_primary) * rec, rec);
-	return out;
-}
 
 /* ---- `--gpus N`: the other ranks are child processes.  A rank that fails must never leave the others waiting inside a collective
  * (RCCL has no timeout of its own): a child dies with its parent (PR_SET_PDEATHSIG), the parent takes every child down when it
@@ -491,25 +517,44 @@ static void on_sigchld(int sig) {
 	}
 }
 
+static void report_share(int rank, const reads_t* rd) {
+	if (!getenv("VDJX_REPORT_SHARE")) return;
+	struct rusage ru;
+	getrusage(RUSAGE_SELF, &ru);
+	fprintf(stderr, "share\trank\t%d\trecords\t%zu\tof\t%llu\tpairs\t%u\thost_pool_bytes\t%zu\tmaxrss_kb\t%ld\n", rank, rd->n_primary + rd->n_secondary,
+	        (unsigned long long) rd->total_records, rd->n_pairs, (rd->n_primary + rd->n_secondary) * (2 * (size_t) rd->rl + 1), ru.ru_maxrss);
+}
+
 int main(int argc, char** argv) {
 	t_start = t_prev = time(NULL);
 	cli c;
 	if (parse(argc, argv, &c)) return 255;                  /* the reference exits with -1 */
-	/* --gpus N: one process per GPU.  The parent is rank 0 and does everything a single-GPU run does; ranks 1..N-1 are forked
-	 * BEFORE anything touches a GPU, take part in the sharded k-mer build with their slice of the pool, and leave. */
-	if (getenv("VDJX_DUMP_SLICE")) {            /* (test hook, no GPU: "rank,nranks" -> that rank's records of the text input on stdout) */
+	/* --gpus N: one process per GPU.  The parent is rank 0; ranks 1..N-1 are forked BEFORE anything touches a GPU.  Every rank reads
+	 * the input and keeps ITS share of the pool (the pairs whose name hashes to it), the ranks deal the k-mer build's slices out to
+	 * each other on the devices, build the graph together, and the others then serve rank 0's scorer calls (vdjx_mgpu.h) while it
+	 * runs the serial traversal. */
+	if (getenv("VDJX_DUMP_SHARE")) {            /* (test hook, no GPU: "rank,nranks" -> that rank's share: its records on stdout, their places on stderr) */
 		int rk = 0, nr = 1;
-		reads_t sl;
-		size_t S = 0;
-		if (sscanf(getenv("VDJX_DUMP_SLICE"), "%d,%d", &rk, &nr) != 2 || load_slice_text(c.in, rk, nr, &sl, &S)) return 255;
-		fprintf(stderr, "slice\t%d\t%d\trl\t%d\trecords\t%zu\tstride\t%zu\n", rk, nr, sl.rl, sl.n_primary, S);
-		fwrite(sl.primary, 2 * (size_t) sl.rl + 1, sl.n_primary, stdout);
+		reads_t sh;
+		if (sscanf(getenv("VDJX_DUMP_SHARE"), "%d,%d", &rk, &nr) != 2 || nr < 1 || rk < 0 || rk >= nr || load_reads(&c, &sh, rk, nr)) return 255;
+		const size_t R = sh.n_primary + sh.n_secondary;
+		fprintf(stderr, "share\t%d\t%d\trl\t%d\trecords\t%zu\ttotal\t%llu\tpairs\t%u\n", rk, nr, sh.rl, R, (unsigned long long) sh.total_records, sh.n_pairs);
+		for (size_t i = 0; i < R; i++) fprintf(stderr, "rec\t%u\t%u\t%u\t%d\t%d\t%s\n", sh.scan_index[i], sh.reg_rank[i], sh.pair_id[i], sh.read_num[i], sh.is_rc[i], sh.names[sh.pair_id[i]]);
+		fwrite(sh.primary, 2 * (size_t) sh.rl + 1, sh.n_primary, stdout);
+		if (sh.n_secondary) fwrite(sh.secondary, 2 * (size_t) sh.rl + 1, sh.n_secondary, stdout);
 		return 0;
 	}
 	int rank = 0;
-	int id_pipe[256][2];
 	if (c.gpus < 1 || c.gpus > 256) { fprintf(stderr, "--gpus must be in [1,256]\n"); return 255; }
+	const int use_mgpu = c.gpus > 1 || getenv("VDJX_FORCE_MGPU") != NULL;      /* (the variable: a one-rank run of the same code path) */
+	/* ranks that share ONE device (the multi-rank tests on a one-GPU box; RCCL refuses two ranks on a device): bytes move through the
+	 * host.  Otherwise rank r drives GPU r and the bytes move by RCCL over xGMI. */
+	const int one_device = getenv("VDJX_MGPU_ONE_DEVICE") != NULL;
+	const char* transport = one_device ? "host" : (getenv("VDJX_MGPU_TRANSPORT") ? getenv("VDJX_MGPU_TRANSPORT") : "rccl");
+	int* fds = NULL;
 	if (c.gpus > 1) {
+		fds = (int*) malloc((size_t) c.gpus * (size_t) c.gpus * sizeof(int));
+		if (vdjx_comm_sockets(c.gpus, !strcmp(transport, "host"), fds)) { fprintf(stderr, "%s\n", vdjx_comm_last_error()); return 255; }
 		struct sigaction sa;
 		memset(&sa, 0, sizeof sa);
 		sa.sa_handler = on_sigchld;
@@ -523,7 +568,6 @@ int main(int argc, char** argv) {
 	sigaddset(&chld, SIGCHLD);
 	sigprocmask(SIG_BLOCK, &chld, &before);       /* (no rank's end is handled before every rank is on the list) */
 	for (int r = 1; r < c.gpus; r++) {
-		if (pipe(id_pipe[r])) { perror("pipe"); return 255; }
 		fflush(stdout); fflush(stderr);
 		const pid_t pid = fork();
 		if (pid < 0) { perror("fork"); return 255; }
@@ -533,17 +577,16 @@ int main(int argc, char** argv) {
 			sigprocmask(SIG_SETMASK, &before, NULL);
 			(void) prctl(PR_SET_PDEATHSIG, SIGKILL);
 			if (getppid() != parent) _exit(1);             /* (the parent was gone before the request took effect) */
-			close(id_pipe[r][1]);
 			break;
 		}
 		g_kids[r] = pid;
 		g_nkids = r;
-		close(id_pipe[r][0]);
 	}
+	if (fds) vdjx_comm_sockets_keep(c.gpus, rank, fds);
 	if (rank == 0) sigprocmask(SIG_SETMASK, &before, NULL);
 	if (rank == 0) status("START");
 	reads_t rd;
-	if (load_reads(&c, &rd, rank, c.gpus)) return 255;
+	if (load_reads(&c, &rd, rank, use_mgpu ? c.gpus : 1)) return 255;
 	c.hp.read_length = rd.rl;
 	c.hp.threads = c.threads;
 	if (rank == 0) fprintf(stderr, "read length:\t%d\n", rd.rl);
@@ -557,70 +600,70 @@ int main(int argc, char** argv) {
 	size_t nvl = 0;
 	if (load_vregion(c.source_sim_file, &vlines, &nvl)) return 255;
 
+	const int device = one_device ? 0 : rank;              /* rank r drives GPU r */
 	vdjx_ctx* gx = NULL;
-	VX(vdjx_init(rank, &gx));                               /* rank r drives GPU r */
+	VX(vdjx_init(device, &gx));
 	vdjx_mgpu* mg = NULL;
-	const int use_mgpu = c.gpus > 1 || getenv("VDJX_FORCE_MGPU") != NULL;      /* (the variable: a one-rank RCCL run of the same code path) */
 	if (use_mgpu) {
-		unsigned char id[VDJX_MGPU_ID_BYTES];
-		if (rank == 0) {
-			if (vdjx_mgpu_unique_id(id)) { fprintf(stderr, "%s\n", vdjx_mgpu_last_error()); return 1; }
-			for (int r = 1; r < c.gpus; r++) { if (write(id_pipe[r][1], id, sizeof id) != (ssize_t) sizeof id) { perror("write"); return 1; } close(id_pipe[r][1]); }
-		} else {
-			if (read(id_pipe[rank][0], id, sizeof id) != (ssize_t) sizeof id) { fprintf(stderr, "rank %d: no RCCL id from rank 0\n", rank); return 1; }
-			close(id_pipe[rank][0]);
+		unsigned char id[VDJX_COMM_ID_BYTES];
+		memset(id, 0, sizeof id);
+		if (!strcmp(transport, "rccl")) {
+			if (rank == 0) {
+				if (vdjx_comm_unique_id(id)) { fprintf(stderr, "%s\n", vdjx_comm_last_error()); return 1; }
+				for (int r = 1; r < c.gpus; r++) if (write(fds[r], id, sizeof id) != (ssize_t) sizeof id) { perror("write"); return 1; }
+			} else if (read(fds[0], id, sizeof id) != (ssize_t) sizeof id) { fprintf(stderr, "rank %d: no RCCL id from rank 0\n", rank); return 1; }
 		}
-		if (vdjx_mgpu_init(rank, c.gpus, rank, id, &mg)) { fprintf(stderr, "rank %d: %s\n", rank, vdjx_mgpu_last_error()); return 1; }
+		vdjx_comm* cm = NULL;
+		if (vdjx_comm_init(transport, rank, c.gpus, device, fds ? fds + (size_t) rank * (size_t) c.gpus : NULL, id, &cm)) { fprintf(stderr, "rank %d: %s\n", rank, vdjx_comm_last_error()); return 1; }
+		if (vdjx_mgpu_init(cm, device, &mg)) { fprintf(stderr, "rank %d: %s\n", rank, vdjx_mgpu_last_error()); return 1; }
 	}
 	VX(vdjx_anchor_sets_load(gx, vc, nv, jc, nj));
 	VX(vdjx_vregion_load(gx, (const char* const*) vlines, nvl, c.hp.vregion_kmer_size));
 	status("POST_VJF_INIT");
 
 	vdjx_pool* px = NULL;
-	if (rank == 0) {                            /* the read index (and with it the scorers) lives on rank 0's GPU: the whole pool */
+	if (!use_mgpu) {
 		VX(vdjx_pool_load(gx, rd.primary, rd.n_primary, rd.secondary, rd.n_secondary, rd.rl, &px));
-		if (vdjx_stat(gx, "pool_other_bases"))
-			fprintf(stderr, "warning: %llu bases other than ACGTN in the reads are treated as N (the reference would carry them inside k-mers)\n",
-			        (unsigned long long) vdjx_stat(gx, "pool_other_bases"));
 		VX(vdjx_read_index_build(gx, px, rd.pair_id, rd.read_num, rd.is_rc, rd.reg_rank, rd.n_pairs));
-		{	/* the read names by pair id, for the SAM records formatted on the device */
-			uint64_t* noff = (uint64_t*) calloc((size_t) rd.n_pairs + 1, 8);
-			for (uint32_t i = 0; i < rd.n_pairs; i++) noff[i + 1] = noff[i] + strlen(rd.names[i]);
-			char* cat = (char*) malloc((size_t) noff[rd.n_pairs] + 1);
-			for (uint32_t i = 0; i < rd.n_pairs; i++) memcpy(cat + noff[i], rd.names[i], (size_t) (noff[i + 1] - noff[i]));
-			const int rcn = vdjx_sam_names_load(gx, cat, noff, rd.n_pairs);
-			free(cat);
-			free(noff);
-			if (rcn) { fprintf(stderr, "vdjx_sam_names_load: %s\n", vdjx_last_error()); return 1; }
-		}
-		status("POST_READ_EXTRACT");
-		fprintf(stderr, "Assembling...\n");
+	} else if (vdjx_mgpu_load(mg, gx, rd.primary, rd.n_primary, rd.rl, rd.scan_index, rd.pair_id, rd.read_num, rd.is_rc, rd.reg_rank, rd.n_pairs, rd.total_records)) {
+		fprintf(stderr, "%s\n", vdjx_mgpu_last_error());
+		return 1;
 	}
+	if (vdjx_stat(gx, "pool_other_bases"))
+		fprintf(stderr, "warning: %llu bases other than ACGTN in the reads%s are treated as N (the reference would carry them inside k-mers)\n",
+		        (unsigned long long) vdjx_stat(gx, "pool_other_bases"), use_mgpu ? " of this rank" : "");
+	{	/* the read names by pair id, for the SAM records formatted on the device */
+		uint64_t* noff = (uint64_t*) calloc((size_t) rd.n_pairs + 1, 8);
+		for (uint32_t i = 0; i < rd.n_pairs; i++) noff[i + 1] = noff[i] + strlen(rd.names[i]);
+		char* cat = (char*) malloc((size_t) noff[rd.n_pairs] + 1);
+		for (uint32_t i = 0; i < rd.n_pairs; i++) memcpy(cat + noff[i], rd.names[i], (size_t) (noff[i + 1] - noff[i]));
+		const int rcn = vdjx_sam_names_load(gx, cat, noff, rd.n_pairs);
+		free(cat);
+		free(noff);
+		if (rcn) { fprintf(stderr, "vdjx_sam_names_load: %s\n", vdjx_last_error()); return 1; }
+	}
+	report_share(rank, &rd);
+	if (use_mgpu) {                              /* the records live on the device now (the share's quality characters included) */
+		free(rd.primary); rd.primary = NULL;
+		free(rd.pair_id); free(rd.reg_rank); free(rd.scan_index); free(rd.read_num); free(rd.is_rc);
+		rd.pair_id = rd.reg_rank = rd.scan_index = NULL; rd.read_num = rd.is_rc = NULL;
+	}
+	status("POST_READ_EXTRACT");
+	if (rank == 0) fprintf(stderr, "Assembling...\n");
 	vdjx_graph* gg = NULL;
-	if (rank == 0) status("PRE_PRE_GRAPH1");   /* A2:1387 */
+	status("PRE_PRE_GRAPH1");                  /* A2:1387 */
 	if (!use_mgpu) {
 		VX(vdjx_kmer_build(gx, px, c.hp.k, c.hp.min_node_freq, c.hp.min_base_quality, &gg));
 	} else {
-		/* rank r holds records [r*S, (r+1)*S) of the scan order: the rank-major numbering of the sharded build IS the scan order */
-		const int sliced = rank > 0 && rd.secondary == NULL && rd.n_pairs == 0;      /* load_slice_text: the pool IS the slice */
-		const size_t Rt = rd.n_primary + rd.n_secondary;
-		const size_t S = sliced ? rd.n_secondary : (Rt + (size_t) c.gpus - 1) / (size_t) c.gpus;
-		const size_t a = (size_t) rank * S < Rt ? (size_t) rank * S : Rt, b = a + S < Rt ? a + S : Rt;
-		uint8_t* mine = sliced ? rd.primary : slice_records(&rd, a, b);
-		vdjx_pool* ps = NULL;
-		VX(vdjx_pool_load(gx, mine, sliced ? rd.n_primary : b - a, NULL, 0, rd.rl, &ps));
-		if (!sliced) free(mine);
-		if (vdjx_mgpu_kmer_build(mg, gx, ps, c.hp.k, c.hp.min_node_freq, c.hp.min_base_quality, S ? S : 1, &gg)) {
-			fprintf(stderr, "rank %d: %s\n", rank, vdjx_mgpu_last_error());
-			return 1;
-		}
-		vdjx_pool_free(ps);
-		if (rank == 0) fprintf(stderr, "k-mer table sharded over %d GPUs: %llu bytes sent by rank 0\n", c.gpus, (unsigned long long) vdjx_mgpu_bytes_sent(mg));
-		vdjx_mgpu_free(mg);
-		if (rank != 0) {                        /* the graph is identical on every rank; the serial traversal runs on rank 0 */
+		if (vdjx_mgpu_kmer_build(mg, gx, c.hp.k, c.hp.min_node_freq, c.hp.min_base_quality, &gg)) { fprintf(stderr, "%s\n", vdjx_mgpu_last_error()); return 1; }
+		if (rank == 0) fprintf(stderr, "k-mer table sharded over %d GPUs (%s): %llu bytes sent by rank 0 so far\n", c.gpus, transport, (unsigned long long) vdjx_mgpu_bytes_sent(mg));
+		if (rank != 0) {                        /* the graph is identical on every rank; the serial traversal runs on rank 0, which calls on the others' scorers */
 			vdjx_graph_free(gg);
+			const int rcs = vdjx_mgpu_serve(mg, gx);
+			if (rcs) fprintf(stderr, "%s\n", vdjx_mgpu_last_error());
+			vdjx_mgpu_free(mg);
 			vdjx_shutdown(gx);
-			return 0;
+			return rcs ? 1 : 0;
 		}
 	}
 	const size_t n = vdjx_graph_nodes(gg);
@@ -642,7 +685,7 @@ int main(int argc, char** argv) {
 	VX(vdjx_graph_export(gg, NULL, NULL, freq, hv, hj, td, ti, fd, fi, kmers));
 	hg.kmers = kmers; hg.freq = freq; hg.has_v = hv; hg.has_j = hj; hg.to_deg = td; hg.to_ids = ti; hg.from_deg = fd; hg.from_ids = fi;
 
-	hook_ud ud = {gx, &rd, &c.hp};
+	hook_ud ud = {gx, &rd, &c.hp, mg};
 	vdjh_hooks hk = {&ud, h_root_score, h_window_score, h_sam_body, vc, nv, jc, nj, h_status};
 	vdjh_stats st;
 	if (vdjh_assemble(&c.hp, &hg, &hk, "vdj_contigs.fa", "vdjer.dot", stdout, &st)) {
@@ -651,7 +694,11 @@ int main(int argc, char** argv) {
 	}
 	fprintf(stderr, "num root nodes: %zu\nProcessed roots: %zu\ncontig_candidates: %zu\nwindows scored: %zu valid: %zu\ncontigs: %zu\n",
 	        st.n_roots, st.n_roots_accepted, st.n_contig_candidates, st.n_windows_scored, st.n_windows_valid, st.n_contigs_out);
-	for (int r = 1; r < c.gpus; r++) {                    /* (normally all ended, well, long ago: on_sigchld has their status) */
+	if (mg) {
+		fprintf(stderr, "%llu bytes sent by rank 0 in all\n", (unsigned long long) vdjx_mgpu_bytes_sent(mg));
+		if (vdjx_mgpu_finish(mg)) { fprintf(stderr, "%s\n", vdjx_mgpu_last_error()); return 1; }
+	}
+	for (int r = 1; r < c.gpus; r++) {                    /* the ranks have been released: they end, well */
 		while (g_kid_state[r] == 0) {
 			int st_ = 0;
 			const pid_t p = waitpid(g_kids[r], &st_, 0);
@@ -663,6 +710,7 @@ int main(int argc, char** argv) {
 	status("FINIS");
 	fflush(stdout);
 	vdjx_graph_free(gg);
+	if (mg) vdjx_mgpu_free(mg);
 	vdjx_pool_free(px);
 	vdjx_shutdown(gx);
 	return 0;

@@ -232,7 +232,7 @@ static int stage_host(char** buf, size_t* cap, size_t need) {
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* bulk                                                                                                                */
 /* ------------------------------------------------------------------------------------------------------------------ */
-static uint64_t sum64(const uint64_t* v, int n) { uint64_t s = 0; for (int i = 0; i < n; i++) s += v[i]; return s; }
+
 
 /* the "host" transport's exchange of host buffers: in step t a rank sends to me+t and receives from me-t */
 static int host_a2a(vdjx_comm* c, const char* hs, const uint64_t* sb, const uint64_t* so, char* hr, const uint64_t* rb, const uint64_t* ro) {

@@ -1,14 +1,12 @@
 /*
- * vdjx_mgpu.c -- the sharded k-mer build driven from C over RCCL (one process per GPU, xGMI): what `vdjer --gpus N` runs.
+ * vdjx_mgpu.c -- see vdjx_mgpu.h: the sharded hot path driven from C (what `vdjer --gpus N` runs).
  *
- * The reference has no counterpart (its only parallelism is pthreads over roots, A2:1287-1348).  This is the C twin of
- * vdjer_amd/shard.py: the compute is the vdjx_shard_* phases of libvdjx (include/vdjx.h), this file only moves their bytes
- * between ranks.  Every exchange is ONE grouped set of ncclSend/ncclRecv (each peer on its own xGMI link):
- *   directories (their sums ARE the receive counts) -> partial aggregates -> questions -> answers -> survivors (all-gather-v)
- * followed by two all-reduces of the per-survivor arrays (MIN over unsigned 64-bit first sights, SUM over the counts).
+ * The compute is libvdjx's (include/vdjx.h: vdjx_shard_* for the k-mer build, vdjx_window_pairs / _fetch / vdjx_window_cover for the
+ * window scorer, vdjx_sam_blocks / vdjx_sam_merge for the SAM records); this file only decides who sends what to whom and moves it
+ * through vdjx_comm.  It is the C twin of vdjer_amd/shard.py (the test and bench driver over torch.distributed).
  */
+#define _GNU_SOURCE
 #include "vdjx_mgpu.h"
-#include "vdjx_a2a_plan.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -17,26 +15,31 @@
 #include <unistd.h>
 
 #include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
 
-enum { WS_SDIR, WS_RDIR, WS_SPARTS, WS_RPARTS, WS_META, WS_Q, WS_RQ, WS_ANS, WS_RANS, WS_SURV, WS_SURV_ALL, WS_MINS, WS_UCNT, WS_SLOTS };
+enum { WS_SDIR, WS_RDIR, WS_SPARTS, WS_RPARTS, WS_Q, WS_RQ, WS_ANS, WS_RANS, WS_SURV, WS_SURV_ALL, WS_MINS, WS_UCNT, WS_A, WS_B, WS_C, WS_D, WS_SLOTS };
+enum { CMD_QUIT = 1, CMD_WINDOWS = 2, CMD_SAM = 3 };
+
 struct vdjx_mgpu {
 	int rank, nranks, device;
-	ncclComm_t comm;
-	hipStream_t stream;
-	uint64_t bytes_sent;
-	/* the build's exchange buffers: one per purpose, kept by the handle and only replaced when a build needs more (a process that
-	 * builds again -- a second chain, the next sample -- allocates nothing) */
+	vdjx_comm* cm;
+	/* exchange buffers: one per purpose, kept by the handle and only replaced when a call needs more (a process that builds again -- a
+	 * second chain, the next sample -- allocates nothing) */
 	void* ws[WS_SLOTS];
 	size_t ws_cap[WS_SLOTS];
+	/* the rank's share of the pool (ASCII records; the packed pool reads its quality characters here) and its slice of the scan order */
+	void *d_share, *d_slice, *d_reg;
+	vdjx_pool *share_pool, *slice_pool;
+	uint64_t stride;
+	int rl;
 };
 
-static __thread char g_err[512];
-static void set_err(const char* fmt, ...) {
+static __thread char g_err[640];
+static int fail(int rc, const char* fmt, ...) {
 	va_list ap;
 	va_start(ap, fmt);
 	vsnprintf(g_err, sizeof g_err, fmt, ap);
 	va_end(ap);
+	return rc;
 }
 const char* vdjx_mgpu_last_error(void) { return g_err; }
 
@@ -47,104 +50,120 @@ static int ws_get(vdjx_mgpu* m, int slot, size_t bytes, void** out) {
 		m->ws[slot] = NULL; m->ws_cap[slot] = 0;
 		const size_t want = bytes + bytes / 8 + 256;
 		const hipError_t e = hipMalloc(&m->ws[slot], want);
-		if (e != hipSuccess) { set_err("hipMalloc of %zu bytes (exchange buffer %d): %s", want, slot, hipGetErrorString(e)); return VDJX_EHIP; }
+		if (e != hipSuccess) return fail(VDJX_EHIP, "hipMalloc of %zu bytes (exchange buffer %d): %s", want, slot, hipGetErrorString(e));
 		m->ws_cap[slot] = want;
 	}
 	*out = m->ws[slot];
 	return 0;
 }
 
-#define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err("%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); rc = -2; goto done; } } while (0)
-#define NCCLC(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { set_err("%s: %s (%s:%d)", #x, ncclGetErrorString(r_), __FILE__, __LINE__); rc = -5; goto done; } } while (0)
-#define VX(x) do { int r_ = (x); if (r_ != 0) { set_err("%s: %s", #x, vdjx_last_error()); rc = r_; goto done; } } while (0)
+#define HIPC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = fail(VDJX_EHIP, "%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); goto done; } } while (0)
+#define VX(x) do { int r_ = (x); if (r_ != 0) { rc = fail(r_, "rank %d: %s: %s", m->rank, #x, vdjx_last_error()); goto done; } } while (0)
+#define CX(x) do { int r_ = (x); if (r_ != 0) { rc = fail(r_, "rank %d: %s: %s", m->rank, #x, vdjx_comm_last_error()); goto done; } } while (0)
 #define WSG(slot, bytes, out) do { void* p_ = NULL; const int r_ = ws_get(m, slot, (size_t) (bytes), &p_); if (r_) { rc = r_; goto done; } *(out) = p_; } while (0)
 
-int vdjx_mgpu_unique_id(void* out128) {
-	ncclUniqueId id;
-	if (sizeof id > VDJX_MGPU_ID_BYTES) { set_err("ncclUniqueId is %zu bytes", sizeof id); return -1; }
-	ncclResult_t r = ncclGetUniqueId(&id);
-	if (r != ncclSuccess) { set_err("ncclGetUniqueId: %s", ncclGetErrorString(r)); return -5; }
-	memset(out128, 0, VDJX_MGPU_ID_BYTES);
-	memcpy(out128, &id, sizeof id);
+int vdjx_mgpu_init(vdjx_comm* cm, int device, vdjx_mgpu** out) {
+	*out = NULL;
+	if (!cm) return fail(VDJX_EINVAL, "vdjx_mgpu_init: no communicator");
+	vdjx_mgpu* m = (vdjx_mgpu*) calloc(1, sizeof *m);
+	if (!m) return fail(VDJX_EINVAL, "out of memory");
+	m->cm = cm; m->rank = vdjx_comm_rank(cm); m->nranks = vdjx_comm_size(cm); m->device = device;
+	*out = m;
 	return 0;
 }
 
-int vdjx_mgpu_init(int rank, int nranks, int device, const void* unique_id, vdjx_mgpu** out) {
-	int rc = 0;
-	*out = NULL;
-	vdjx_mgpu* m = (vdjx_mgpu*) calloc(1, sizeof *m);
-	m->rank = rank; m->nranks = nranks; m->device = device;
-	ncclUniqueId id;
-	memcpy(&id, unique_id, sizeof id);
-	HIPC(hipSetDevice(device));
-	HIPC(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
-	{
-		/* RCCL prints a version banner on the process's stdout when the communicator comes up; stdout is the SAM stream: the banner
-		 * goes to stderr */
-		fflush(stdout);
-		const int saved = dup(1);
-		if (saved >= 0) (void) dup2(2, 1);
-		const ncclResult_t r_ = ncclCommInitRank(&m->comm, nranks, id, rank);
-		fflush(stdout);
-		if (saved >= 0) { (void) dup2(saved, 1); close(saved); }
-		if (r_ != ncclSuccess) { set_err("ncclCommInitRank: %s", ncclGetErrorString(r_)); rc = -5; goto done; }
-	}
-	*out = m;
-	return 0;
-done:
-	free(m);
-	return rc;
+static void drop_slice(vdjx_mgpu* m) {
+	if (m->slice_pool) vdjx_pool_free(m->slice_pool);
+	m->slice_pool = NULL;
+	if (m->d_slice) (void) hipFree(m->d_slice);
+	m->d_slice = NULL;
 }
 
 void vdjx_mgpu_free(vdjx_mgpu* m) {
 	if (!m) return;
 	(void) hipSetDevice(m->device);
-	if (m->comm) (void) ncclCommDestroy(m->comm);
-	if (m->stream) (void) hipStreamDestroy(m->stream);
+	drop_slice(m);
+	if (m->share_pool) vdjx_pool_free(m->share_pool);
+	if (m->d_share) (void) hipFree(m->d_share);
+	if (m->d_reg) (void) hipFree(m->d_reg);
 	for (int i = 0; i < WS_SLOTS; i++) if (m->ws[i]) (void) hipFree(m->ws[i]);
+	vdjx_comm_free(m->cm);
 	free(m);
 }
 
-uint64_t vdjx_mgpu_bytes_sent(const vdjx_mgpu* m) { return m ? m->bytes_sent : 0; }
-
-/* all-to-all-v of byte rows: send[r] rows of `row` bytes to rank r (contiguous, rank order), recv likewise */
-/* RCCL moved the second half of a 1.09 GB transfer wrongly on this stack (ROCm 7.0.2 / RCCL 2.26.6: a rank sending 34 M partials to
- * itself through all_to_all_single, bytes beyond 2^29 differ, silently): no single transfer is larger than A2A_CHUNK here, and what a
- * rank sends to itself is a device copy. */
-#define A2A_CHUNK ((size_t) 128 << 20)
-static int a2av(vdjx_mgpu* m, const void* d_send, const uint64_t* send_rows, void* d_recv, const uint64_t* recv_rows, size_t row) {
-	int rc = 0;
-	const int G = m->nranks, me = m->rank;
-	uint64_t self[3] = {0, 0, 0};
-	const size_t nst = vdjx_a2a_plan(G, me, send_rows, recv_rows, row, A2A_CHUNK, NULL, 0, self);         /* (the offsets: vdjx_a2a_plan.c, tested on the CPU) */
-	vdjx_a2a_step* st = (vdjx_a2a_step*) calloc(nst + 1, sizeof *st);
-	if (!st) { rc = VDJX_EHIP; goto done; }
-	(void) vdjx_a2a_plan(G, me, send_rows, recv_rows, row, A2A_CHUNK, st, nst, self);
-	for (int r = 0; r < G; r++) if (r != me) m->bytes_sent += send_rows[r] * row;
-	if (self[2]) HIPC(hipMemcpyAsync((char*) d_recv + self[1], (const char*) d_send + self[0], (size_t) self[2], hipMemcpyDeviceToDevice, m->stream));
-	for (size_t i = 0; i < nst;) {
-		const uint32_t round = st[i].round;
-		NCCLC(ncclGroupStart());
-		for (; i < nst && st[i].round == round; i++) {
-			if (st[i].send_len) NCCLC(ncclSend((const char*) d_send + st[i].send_off, (size_t) st[i].send_len, ncclChar, st[i].peer, m->comm, m->stream));
-			if (st[i].recv_len) NCCLC(ncclRecv((char*) d_recv + st[i].recv_off, (size_t) st[i].recv_len, ncclChar, st[i].peer, m->comm, m->stream));
-		}
-		NCCLC(ncclGroupEnd());
-	}
-	HIPC(hipStreamSynchronize(m->stream));
-done:
-	free(st);
-	return rc;
-}
+uint64_t vdjx_mgpu_bytes_sent(const vdjx_mgpu* m) { return m ? vdjx_comm_bytes_sent(m->cm) : 0; }
 
 static uint64_t sum64(const uint64_t* v, int n) { uint64_t s = 0; for (int i = 0; i < n; i++) s += v[i]; return s; }
 
-int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, uint64_t rec_stride, vdjx_graph** out) {
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* the share, its read index, and the slices of the scan order                                                         */
+/* ------------------------------------------------------------------------------------------------------------------ */
+int vdjx_mgpu_load(vdjx_mgpu* m, vdjx_ctx* ctx, const uint8_t* records, size_t n_records, int rl, const uint32_t* scan_index, const uint32_t* pair_id,
+                   const uint8_t* read_num, const uint8_t* is_rc, const uint32_t* reg_rank, uint32_t n_pairs, uint64_t total_records) {
+	int rc = 0;
+	const int G = m->nranks, me = m->rank;
+	const size_t rec = 2 * (size_t) rl + 1;
+	uint64_t *send_rows = (uint64_t*) calloc((size_t) G, 8), *recv_rows = (uint64_t*) calloc((size_t) G, 8), *all_rows = (uint64_t*) calloc((size_t) G * (size_t) G, 8);
+	uint32_t* pos = (uint32_t*) malloc((n_records + 1) * 4);
+	void *d_rows = NULL, *d_pos_s = NULL, *d_pos_r = NULL;
+	if (!send_rows || !recv_rows || !all_rows || !pos) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; }
+	if (rl < 1 || rl > VDJX_MAX_READ_LEN) { rc = fail(VDJX_ELIMIT, "read length %d outside [1,%d]", rl, VDJX_MAX_READ_LEN); goto done; }
+	if (total_records >= (1ull << 32) - (uint64_t) G) { rc = fail(VDJX_ELIMIT, "%llu records in all: at most 2^32", (unsigned long long) total_records); goto done; }
+	HIPC(hipSetDevice(m->device));
+	drop_slice(m);
+	if (m->share_pool) { vdjx_pool_free(m->share_pool); m->share_pool = NULL; }
+	if (m->d_share) { (void) hipFree(m->d_share); m->d_share = NULL; }
+	if (m->d_reg) { (void) hipFree(m->d_reg); m->d_reg = NULL; }
+	m->rl = rl;
+	/* the share on the device: the packed pool of the scorers (it keeps reading the quality characters from these records) */
+	HIPC(hipMalloc(&m->d_share, n_records * rec + 16));
+	HIPC(hipMalloc(&m->d_reg, (n_records + 1) * 4));
+	if (n_records) {
+		HIPC(hipMemcpy(m->d_share, records, n_records * rec, hipMemcpyHostToDevice));
+		HIPC(hipMemcpy(m->d_reg, reg_rank, n_records * 4, hipMemcpyHostToDevice));
+	}
+	VX(vdjx_pool_load_device(ctx, (const uint8_t*) m->d_share, n_records, NULL, 0, rl, &m->share_pool));
+	VX(vdjx_read_index_build(ctx, m->share_pool, pair_id, read_num, is_rc, reg_rank, n_pairs));
+	/* the slices: record g of the scan order belongs to rank g / S, at place g % S.  The share is in ascending scan order, so what goes
+	 * to a rank is one run of it. */
+	const uint64_t S = total_records ? (total_records + (uint64_t) G - 1) / (uint64_t) G : 1;
+	m->stride = S;
+	for (size_t i = 0; i < n_records; i++) {
+		const uint64_t g = scan_index[i];
+		if (g >= total_records || (i && scan_index[i - 1] >= g)) { rc = fail(VDJX_EINVAL, "rank %d: scan positions of the share must ascend below %llu (record %zu: %llu)", me, (unsigned long long) total_records, i, (unsigned long long) g); goto done; }
+		send_rows[g / S]++;
+		pos[i] = (uint32_t) (g % S);
+	}
+	CX(vdjx_comm_allgather_host(m->cm, send_rows, (size_t) G * 8, all_rows));
+	for (int s = 0; s < G; s++) recv_rows[s] = all_rows[(size_t) s * G + me];
+	const uint64_t n_slice = sum64(recv_rows, G);
+	{
+		const uint64_t a = (uint64_t) me * S < total_records ? (uint64_t) me * S : total_records, b = a + S < total_records ? a + S : total_records;
+		if (n_slice != b - a) { rc = fail(VDJX_EINVAL, "rank %d: %llu records arrive for a slice of %llu (the shares do not cover the pool once)", me, (unsigned long long) n_slice, (unsigned long long) (b - a)); goto done; }
+	}
+	WSG(WS_A, n_slice * rec + 16, &d_rows);
+	WSG(WS_B, (n_records + 1) * 4, &d_pos_s);
+	WSG(WS_C, (n_slice + 1) * 4, &d_pos_r);
+	if (n_records) HIPC(hipMemcpy(d_pos_s, pos, n_records * 4, hipMemcpyHostToDevice));
+	CX(vdjx_comm_a2av(m->cm, m->d_share, send_rows, d_rows, recv_rows, rec));
+	CX(vdjx_comm_a2av(m->cm, d_pos_s, send_rows, d_pos_r, recv_rows, 4));
+	HIPC(hipMalloc(&m->d_slice, n_slice * rec + 16));
+	VX(vdjx_rows_scatter(ctx, m->d_slice, d_rows, (const uint32_t*) d_pos_r, (size_t) n_slice, rec));
+	VX(vdjx_pool_load_device(ctx, (const uint8_t*) m->d_slice, (size_t) n_slice, NULL, 0, rl, &m->slice_pool));
+done:
+	free(send_rows); free(recv_rows); free(all_rows); free(pos);
+	return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* the k-mer build                                                                                                     */
+/* ------------------------------------------------------------------------------------------------------------------ */
+int vdjx_mgpu_kmer_build_pool(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, uint64_t rec_stride, vdjx_graph** out) {
 	int rc = 0;
 	const int G = m->nranks, me = m->rank;
 	vdjx_shard* sh = NULL;
 	void *d_sdir = NULL, *d_rdir = NULL, *d_sparts = NULL, *d_rparts = NULL, *d_q = NULL, *d_rq = NULL, *d_ans = NULL, *d_rans = NULL;
-	void *d_meta = NULL, *d_surv = NULL, *d_surv_all = NULL, *d_mins = NULL, *d_ucnt = NULL;
+	void *d_surv = NULL, *d_surv_all = NULL, *d_mins = NULL, *d_ucnt = NULL;
 	uint32_t* h_rdir = NULL;
 	uint64_t *send_counts = (uint64_t*) calloc((size_t) G, 8), *recv_counts = (uint64_t*) calloc((size_t) G, 8), *q_out = (uint64_t*) calloc((size_t) G, 8),
 	         *q_in = (uint64_t*) calloc((size_t) G, 8), *eq = (uint64_t*) calloc((size_t) G, 8), *meta = (uint64_t*) calloc((size_t) G * (size_t) (G + 2), 8);
@@ -161,102 +180,269 @@ int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int
 	WSG(WS_SPARTS, sum64(send_counts, G) * W0 + 16, &d_sparts);
 	VX(vdjx_shard_local_fill(sh, d_sdir, d_sparts));
 	for (int r = 0; r < G; r++) eq[r] = dl;
-	if ((rc = a2av(m, d_sdir, eq, d_rdir, eq, 4))) goto done;
-	h_rdir = (uint32_t*) malloc(ndir * 4 + 4);
-	HIPC(hipMemcpy(h_rdir, d_rdir, ndir * 4, hipMemcpyDeviceToHost));
-	for (int r = 0; r < G; r++) {
-		uint64_t s = 0;
-		for (uint32_t i = 0; i < dl; i++) s += h_rdir[(size_t) r * dl + i];
-		recv_counts[r] = s;
-	}
+	/* what every rank will send this one: the counts travel as control traffic beside the directories (no device round trip in between) */
+	CX(vdjx_comm_allgather_host(m->cm, send_counts, (size_t) G * 8, meta));
+	for (int r = 0; r < G; r++) recv_counts[r] = meta[(size_t) r * G + me];
+	CX(vdjx_comm_a2av(m->cm, d_sdir, eq, d_rdir, eq, 4));
 	WSG(WS_RPARTS, sum64(recv_counts, G) * W0 + 16, &d_rparts);
-	if ((rc = a2av(m, d_sparts, send_counts, d_rparts, recv_counts, W0))) goto done;
+	CX(vdjx_comm_a2av(m->cm, d_sparts, send_counts, d_rparts, recv_counts, W0));
 	/* 3. owners merge and decide; questions and answers for the few open k-mers */
 	VX(vdjx_shard_merge(sh, d_rdir, d_rparts, recv_counts, q_out));
-	/* everybody learns everybody's question counts, survivor count and distinct count in one small all-gather */
-	WSG(WS_META, (size_t) G * (size_t) (G + 2) * 8 + 16, &d_meta);
-	{
-		uint64_t* mine = meta + (size_t) me * (G + 2);
-		memcpy(mine, q_out, (size_t) G * 8);
-		mine[G] = mine[G + 1] = 0;
-		HIPC(hipMemcpy((char*) d_meta + (size_t) me * (G + 2) * 8, mine, (size_t) (G + 2) * 8, hipMemcpyHostToDevice));
-		NCCLC(ncclAllGather((char*) d_meta + (size_t) me * (G + 2) * 8, d_meta, (size_t) (G + 2), ncclUint64, m->comm, m->stream));
-		HIPC(hipStreamSynchronize(m->stream));
-		HIPC(hipMemcpy(meta, d_meta, (size_t) G * (G + 2) * 8, hipMemcpyDeviceToHost));
-		for (int r = 0; r < G; r++) q_in[r] = meta[(size_t) r * (G + 2) + me];
-	}
+	CX(vdjx_comm_allgather_host(m->cm, q_out, (size_t) G * 8, meta));
+	for (int r = 0; r < G; r++) q_in[r] = meta[(size_t) r * G + me];
 	WSG(WS_Q, sum64(q_out, G) * W1 + 16, &d_q);
 	WSG(WS_RQ, sum64(q_in, G) * W1 + 16, &d_rq);
 	WSG(WS_ANS, sum64(q_in, G) * W2 + 16, &d_ans);
 	WSG(WS_RANS, sum64(q_out, G) * W2 + 16, &d_rans);
 	VX(vdjx_shard_queries(sh, d_q));
-	if ((rc = a2av(m, d_q, q_out, d_rq, q_in, W1))) goto done;
+	CX(vdjx_comm_a2av(m->cm, d_q, q_out, d_rq, q_in, W1));
 	VX(vdjx_shard_reply(sh, d_rq, q_in, d_ans));
-	if ((rc = a2av(m, d_ans, q_in, d_rans, q_out, W2))) goto done;
+	CX(vdjx_comm_a2av(m->cm, d_ans, q_in, d_rans, q_out, W2));
 	uint64_t ns = 0, ndist = 0;
 	VX(vdjx_shard_resolve(sh, d_rans, sum64(q_out, G), &ns, &ndist));
-	/* 4. survivors everywhere (all-gather-v as sends and receives), every rank's share of add_to_graph, MIN / SUM over ranks */
+	/* 4. survivors everywhere, every rank's share of add_to_graph, MIN / SUM over ranks */
 	{
 		uint64_t mine[2] = {ns, ndist};
-		HIPC(hipMemcpy((char*) d_meta + (size_t) me * 16, mine, 16, hipMemcpyHostToDevice));
-		NCCLC(ncclAllGather((char*) d_meta + (size_t) me * 16, d_meta, 2, ncclUint64, m->comm, m->stream));
-		HIPC(hipStreamSynchronize(m->stream));
-		HIPC(hipMemcpy(meta, d_meta, (size_t) G * 16, hipMemcpyDeviceToHost));
+		CX(vdjx_comm_allgather_host(m->cm, mine, 16, meta));
 	}
 	uint64_t ns_total = 0, pre_total = 0;
-	for (int r = 0; r < G; r++) { recv_counts[r] = meta[2 * r]; ns_total += meta[2 * r]; pre_total += meta[2 * r + 1]; send_counts[r] = ns; }
+	for (int r = 0; r < G; r++) { recv_counts[r] = meta[2 * r]; ns_total += meta[2 * r]; pre_total += meta[2 * r + 1]; }
 	WSG(WS_SURV, ns * W3 + 16, &d_surv);
 	WSG(WS_SURV_ALL, ns_total * W3 + 16, &d_surv_all);
 	VX(vdjx_shard_survivors(sh, d_surv));
-	{
-		/* every rank's survivors to every rank, in pieces of at most A2A_CHUNK (see a2av); the own ones by a device copy */
-		size_t ro = 0, rounds = 0;
-		for (int r = 0; r < G; r++) {
-			const size_t a = ((size_t) recv_counts[r] * W3 + A2A_CHUNK - 1) / A2A_CHUNK;
-			if (r != me && a > rounds) rounds = a;
-		}
-		{
-			const size_t a = ((size_t) ns * W3 + A2A_CHUNK - 1) / A2A_CHUNK;
-			if (G > 1 && a > rounds) rounds = a;
-		}
-		for (int r = 0; r < me; r++) ro += recv_counts[r] * W3;
-		if (ns) HIPC(hipMemcpyAsync((char*) d_surv_all + ro, d_surv, ns * W3, hipMemcpyDeviceToDevice, m->stream));
-		for (size_t rd = 0; rd < rounds; rd++) {
-			const size_t a = rd * A2A_CHUNK;
-			ro = 0;
-			NCCLC(ncclGroupStart());
-			for (int r = 0; r < G; r++) {
-				const size_t sb = (size_t) ns * W3, rb = (size_t) recv_counts[r] * W3;
-				if (r != me) {
-					if (a < sb) NCCLC(ncclSend((const char*) d_surv + a, sb - a < A2A_CHUNK ? sb - a : A2A_CHUNK, ncclChar, r, m->comm, m->stream));
-					if (a < rb) NCCLC(ncclRecv((char*) d_surv_all + ro + a, rb - a < A2A_CHUNK ? rb - a : A2A_CHUNK, ncclChar, r, m->comm, m->stream));
-				}
-				ro += rb;
-			}
-			NCCLC(ncclGroupEnd());
-		}
-		for (int r = 0; r < G; r++) if (r != me) m->bytes_sent += ns * W3;
-		HIPC(hipStreamSynchronize(m->stream));
-	}
+	CX(vdjx_comm_allgatherv(m->cm, d_surv, d_surv_all, recv_counts, W3));
 	WSG(WS_MINS, ns_total * 5 * 8 + 16, &d_mins);          /* in-edge first sights [4n] | node first sights [n] */
 	WSG(WS_UCNT, ns_total * 4 + 16, &d_ucnt);
 	VX(vdjx_shard_edges(sh, d_surv_all, ns_total, d_mins, d_ucnt, (char*) d_mins + ns_total * 32));
-	if (ns_total) {
-		for (size_t a = 0; a < ns_total * 5; a += A2A_CHUNK / 8) {                                       /* all-ones = none stays largest */
-			const size_t n = ns_total * 5 - a < A2A_CHUNK / 8 ? ns_total * 5 - a : A2A_CHUNK / 8;
-			NCCLC(ncclAllReduce((char*) d_mins + a * 8, (char*) d_mins + a * 8, n, ncclUint64, ncclMin, m->comm, m->stream));
-		}
-		for (size_t a = 0; a < ns_total; a += A2A_CHUNK / 4) {
-			const size_t n = ns_total - a < A2A_CHUNK / 4 ? ns_total - a : A2A_CHUNK / 4;
-			NCCLC(ncclAllReduce((char*) d_ucnt + a * 4, (char*) d_ucnt + a * 4, n, ncclUint32, ncclSum, m->comm, m->stream));
-		}
-		HIPC(hipStreamSynchronize(m->stream));
-		m->bytes_sent += (uint64_t) (G > 1) * ns_total * 44;
-	}
+	CX(vdjx_comm_allreduce_min_u64(m->cm, d_mins, (size_t) ns_total * 5));                         /* all-ones = none stays largest */
+	CX(vdjx_comm_allreduce_sum_u32(m->cm, d_ucnt, (size_t) ns_total));
 	/* 5. node numbering + list order: identical on every rank */
 	VX(vdjx_shard_finish(sh, d_mins, d_ucnt, (char*) d_mins + ns_total * 32, pre_total, out));
 done:
 	if (sh) vdjx_shard_free(sh);
 	free(h_rdir); free(send_counts); free(recv_counts); free(q_out); free(q_in); free(eq); free(meta);
+	return rc;
+}
+
+int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, int k, int mf, int mq, vdjx_graph** out) {
+	if (!m->slice_pool) return fail(VDJX_ESTATE, "vdjx_mgpu_kmer_build: call vdjx_mgpu_load first");
+	const int rc = vdjx_mgpu_kmer_build_pool(m, ctx, m->slice_pool, k, mf, mq, m->stride, out);
+	(void) hipSetDevice(m->device);
+	drop_slice(m);
+	return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* the window scorer (every rank, the same windows)                                                                    */
+/* ------------------------------------------------------------------------------------------------------------------ */
+static int do_window_score(vdjx_mgpu* m, vdjx_ctx* ctx, const char* windows, size_t n, int len, const vdjx_cov_params* p, uint8_t* out_valid) {
+	int rc = 0;
+	const int G = m->nranks, me = m->rank;
+	const size_t nmax = (n + (size_t) G - 1) / (size_t) G, n_mine = n > (size_t) me ? (n - (size_t) me + (size_t) G - 1) / (size_t) G : 0;
+	uint32_t *ent = (uint32_t*) calloc(n + 1, 4), *npairs = (uint32_t*) calloc(n + 1, 4), *all_ent = (uint32_t*) calloc((size_t) G * n + 1, 4);
+	uint32_t *send_ids = (uint32_t*) calloc(n + 1, 4), *counts = (uint32_t*) calloc((size_t) G * n_mine + 1, 4);
+	uint64_t *send_counts = (uint64_t*) calloc((size_t) G, 8), *recv_counts = (uint64_t*) calloc((size_t) G, 8);
+	uint8_t *mine = (uint8_t*) calloc(nmax + 1, 1), *all_valid = (uint8_t*) calloc((size_t) G * nmax + 1, 1);
+	void *d_send = NULL, *d_recv = NULL;
+	if (!ent || !npairs || !all_ent || !send_ids || !counts || !send_counts || !recv_counts || !mine || !all_valid) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; }
+	if (!n) goto done;
+	HIPC(hipSetDevice(m->device));
+	VX(vdjx_window_pairs(ctx, windows, n, len, ent, npairs));
+	CX(vdjx_comm_allgather_host(m->cm, ent, n * 4, all_ent));
+	{
+		size_t at = 0;
+		for (int o = 0; o < G; o++)
+			for (size_t w = (size_t) o; w < n; w += (size_t) G) { send_ids[at++] = (uint32_t) w; send_counts[o] += ent[w]; }
+	}
+	for (int s = 0; s < G; s++)
+		for (size_t j = 0; j < n_mine; j++) {
+			const uint32_t v = all_ent[(size_t) s * n + (size_t) me + j * (size_t) G];
+			counts[(size_t) s * n_mine + j] = v;
+			recv_counts[s] += v;
+		}
+	WSG(WS_A, sum64(send_counts, G) * 8 + 16, &d_send);
+	WSG(WS_B, sum64(recv_counts, G) * 8 + 16, &d_recv);
+	VX(vdjx_window_pairs_fetch(ctx, send_ids, n, d_send));
+	CX(vdjx_comm_a2av(m->cm, d_send, send_counts, d_recv, recv_counts, 8));
+	if (n_mine) VX(vdjx_window_cover(ctx, n_mine, len, m->rl, p, d_recv, (size_t) G, counts, mine));
+	CX(vdjx_comm_allgather_host(m->cm, mine, nmax, all_valid));
+	for (int o = 0; o < G; o++)
+		for (size_t w = (size_t) o, j = 0; w < n; w += (size_t) G, j++) out_valid[w] = all_valid[(size_t) o * nmax + j];
+done:
+	free(ent); free(npairs); free(all_ent); free(send_ids); free(counts); free(send_counts); free(recv_counts); free(mine); free(all_valid);
+	return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* the SAM records (every rank, the same contigs; the text arrives on rank 0)                                          */
+/* ------------------------------------------------------------------------------------------------------------------ */
+typedef int (*sam_sink)(void* ud, const char* text, uint64_t bytes);
+
+static int do_sam(vdjx_mgpu* m, vdjx_ctx* ctx, const char* contigs, size_t n, int len, const char* ids, const uint32_t* id_off, sam_sink sink, void* ud) {
+	int rc = 0;
+	const int G = m->nranks, me = m->rank;
+	uint64_t *offs = (uint64_t*) calloc(n + 2, 8), *cnt = (uint64_t*) calloc(n + 1, 8), *all_cnt = (uint64_t*) calloc((size_t) G * n + 1, 8);
+	uint64_t *meta = (uint64_t*) calloc((size_t) G * 2 + 2, 8), *send_rows = (uint64_t*) calloc((size_t) G, 8), *recv_rows = (uint64_t*) calloc((size_t) G, 8);
+	uint32_t* sub_off = (uint32_t*) calloc(n + 2, 4);
+	if (!offs || !cnt || !all_cnt || !meta || !send_rows || !recv_rows || !sub_off) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; }
+	if (!n) goto done;
+	HIPC(hipSetDevice(m->device));
+	/* pairs per contig over all ranks: the contigs are taken in runs of at most `budget` pairs, so that the text of one run (a few
+	 * hundred bytes per pair, on every rank and all of it on rank 0) stays a few GB whatever the pool */
+	VX(vdjx_map_emit(ctx, contigs, n, len, offs, NULL));
+	for (size_t i = 0; i < n; i++) cnt[i] = offs[i + 1] - offs[i];
+	CX(vdjx_comm_allgather_host(m->cm, cnt, n * 8, all_cnt));
+	for (size_t i = 0; i < n; i++) { uint64_t s = 0; for (int r = 0; r < G; r++) s += all_cnt[(size_t) r * n + i]; cnt[i] = s; }
+	uint64_t budget = 8u << 20;
+	if (getenv("VDJX_MGPU_SAM_PAIRS") && atoll(getenv("VDJX_MGPU_SAM_PAIRS")) > 0) budget = (uint64_t) atoll(getenv("VDJX_MGPU_SAM_PAIRS"));
+	for (size_t a = 0; a < n;) {
+		size_t b = a;
+		uint64_t in_run = 0;
+		while (b < n && b - a < (1u << 19) && (b == a || in_run + cnt[b] <= budget)) in_run += cnt[b++];
+		for (size_t i = a; i <= b; i++) sub_off[i - a] = id_off[i] - id_off[a];
+		uint64_t nb = 0, nbytes = 0;
+		const void *dk = NULL, *dl = NULL, *dt = NULL;
+		VX(vdjx_sam_blocks(ctx, contigs + a * (size_t) len, b - a, len, ids + id_off[a], sub_off, (const uint32_t*) m->d_reg, &nb, &nbytes, &dk, &dl, &dt));
+		uint64_t mine[2] = {nb, nbytes};
+		CX(vdjx_comm_allgather_host(m->cm, mine, 16, meta));
+		uint64_t NB = 0, NBY = 0;
+		for (int r = 0; r < G; r++) { NB += meta[2 * r]; NBY += meta[2 * r + 1]; }
+		void *d_keys = NULL, *d_lens = NULL, *d_text = NULL;
+		if (me == 0) {
+			WSG(WS_A, NB * 8 + 16, &d_keys);
+			WSG(WS_B, NB * 4 + 16, &d_lens);
+			WSG(WS_C, NBY + 16, &d_text);
+		}
+		memset(send_rows, 0, (size_t) G * 8);
+		memset(recv_rows, 0, (size_t) G * 8);
+		send_rows[0] = nb;
+		if (me == 0) for (int r = 0; r < G; r++) recv_rows[r] = meta[2 * r];
+		CX(vdjx_comm_a2av(m->cm, dk, send_rows, d_keys, recv_rows, 8));
+		CX(vdjx_comm_a2av(m->cm, dl, send_rows, d_lens, recv_rows, 4));
+		send_rows[0] = nbytes;
+		if (me == 0) for (int r = 0; r < G; r++) recv_rows[r] = meta[2 * r + 1];
+		CX(vdjx_comm_a2av(m->cm, dt, send_rows, d_text, recv_rows, 1));
+		if (me == 0 && NB) {
+			const char* text = NULL;
+			uint64_t tb = 0;
+			VX(vdjx_sam_merge(ctx, NB, NBY, d_keys, d_lens, d_text, &text, &tb));
+			if (sink && (rc = sink(ud, text, tb)) != 0) { rc = fail(rc, "the SAM sink failed"); goto done; }
+		}
+		a = b;
+	}
+done:
+	free(offs); free(cnt); free(all_cnt); free(meta); free(send_rows); free(recv_rows); free(sub_off);
+	return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* rank 0's calls and the other ranks' service loop                                                                    */
+/* ------------------------------------------------------------------------------------------------------------------ */
+int vdjx_mgpu_window_score(vdjx_mgpu* m, vdjx_ctx* ctx, const char* windows, size_t n, int len, const vdjx_cov_params* p, uint8_t* out_valid) {
+	int rc = 0;
+	if (m->rank != 0) return fail(VDJX_ESTATE, "vdjx_mgpu_window_score is rank 0's call");
+	if (!n) return 0;
+	if (m->nranks > 1) {
+		const uint64_t cmd[4] = {CMD_WINDOWS, n, (uint64_t) len, 0};
+		vdjx_cov_params pc = *p;
+		CX(vdjx_comm_command_send(m->cm, cmd));
+		CX(vdjx_comm_bcast_host(m->cm, &pc, sizeof pc));
+		CX(vdjx_comm_bcast_host(m->cm, (void*) windows, n * (size_t) len));
+	}
+	rc = do_window_score(m, ctx, windows, n, len, p, out_valid);
+done:
+	return rc;
+}
+
+typedef struct { const char* text; uint64_t bytes; char* own; uint64_t cap; } sam_acc;
+static int acc_sink(void* ud, const char* text, uint64_t bytes) {
+	sam_acc* a = (sam_acc*) ud;
+	if (!a->own && !a->text) { a->text = text; a->bytes = bytes; return 0; }       /* one run: the context's buffer is handed on as it is */
+	if (!a->own) {
+		a->cap = (a->bytes + bytes) * 2 + 4096;
+		a->own = (char*) malloc((size_t) a->cap);
+		if (!a->own) return VDJX_EINVAL;
+		memcpy(a->own, a->text, (size_t) a->bytes);
+	} else if (a->bytes + bytes + 1 > a->cap) {
+		a->cap = (a->bytes + bytes) * 2 + 4096;
+		char* q = (char*) realloc(a->own, (size_t) a->cap);
+		if (!q) return VDJX_EINVAL;
+		a->own = q;
+	}
+	memcpy(a->own + a->bytes, text, (size_t) bytes);
+	a->bytes += bytes;
+	a->text = a->own;
+	return 0;
+}
+
+static __thread char* g_sam_own;       /* the text of a call that took several runs (freed by the next call) */
+
+int vdjx_mgpu_sam_body(vdjx_mgpu* m, vdjx_ctx* ctx, const char* contigs, size_t n, int len, const char* ids, const uint32_t* id_off,
+                       const char** out_text, uint64_t* out_bytes) {
+	int rc = 0;
+	*out_text = ""; *out_bytes = 0;
+	if (m->rank != 0) return fail(VDJX_ESTATE, "vdjx_mgpu_sam_body is rank 0's call");
+	if (!n) return 0;
+	free(g_sam_own);
+	g_sam_own = NULL;
+	if (m->nranks > 1) {
+		const uint64_t cmd[4] = {CMD_SAM, n, (uint64_t) len, id_off[n]};
+		CX(vdjx_comm_command_send(m->cm, cmd));
+		CX(vdjx_comm_bcast_host(m->cm, (void*) contigs, n * (size_t) len));
+		CX(vdjx_comm_bcast_host(m->cm, (void*) id_off, (n + 1) * 4));
+		CX(vdjx_comm_bcast_host(m->cm, (void*) ids, id_off[n]));
+	}
+	sam_acc acc = {NULL, 0, NULL, 0};
+	rc = do_sam(m, ctx, contigs, n, len, ids, id_off, acc_sink, &acc);
+	if (rc) { free(acc.own); return rc; }
+	g_sam_own = acc.own;
+	if (acc.text) { *out_text = acc.text; *out_bytes = acc.bytes; }
+done:
+	return rc;
+}
+
+int vdjx_mgpu_finish(vdjx_mgpu* m) {
+	if (m->rank != 0 || m->nranks == 1) return 0;
+	const uint64_t cmd[4] = {CMD_QUIT, 0, 0, 0};
+	const int rc = vdjx_comm_command_send(m->cm, cmd);
+	return rc ? fail(rc, "%s", vdjx_comm_last_error()) : 0;
+}
+
+int vdjx_mgpu_serve(vdjx_mgpu* m, vdjx_ctx* ctx) {
+	int rc = 0;
+	char *a = NULL, *b = NULL;
+	uint32_t* off = NULL;
+	uint8_t* valid = NULL;
+	if (m->rank == 0) return fail(VDJX_ESTATE, "rank 0 does not serve");
+	for (;;) {
+		uint64_t cmd[4];
+		const int w = vdjx_comm_command_wait(m->cm, cmd);
+		if (w) { rc = fail(w < 0 ? w : -5, "rank %d: rank 0 is gone", m->rank); goto done; }
+		free(a); free(b); free(off); free(valid);
+		a = b = NULL; off = NULL; valid = NULL;
+		if (cmd[0] == CMD_QUIT) break;
+		const size_t n = (size_t) cmd[1];
+		const int len = (int) cmd[2];
+		if (cmd[0] == CMD_WINDOWS) {
+			vdjx_cov_params pc;
+			a = (char*) malloc(n * (size_t) len + 1);
+			valid = (uint8_t*) malloc(n + 1);
+			if (!a || !valid) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; }
+			CX(vdjx_comm_bcast_host(m->cm, &pc, sizeof pc));
+			CX(vdjx_comm_bcast_host(m->cm, a, n * (size_t) len));
+			if ((rc = do_window_score(m, ctx, a, n, len, &pc, valid))) goto done;
+		} else if (cmd[0] == CMD_SAM) {
+			a = (char*) malloc(n * (size_t) len + 1);
+			off = (uint32_t*) malloc((n + 1) * 4);
+			b = (char*) malloc((size_t) cmd[3] + 1);
+			if (!a || !off || !b) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; }
+			CX(vdjx_comm_bcast_host(m->cm, a, n * (size_t) len));
+			CX(vdjx_comm_bcast_host(m->cm, off, (n + 1) * 4));
+			CX(vdjx_comm_bcast_host(m->cm, b, (size_t) cmd[3]));
+			if ((rc = do_sam(m, ctx, a, n, len, b, off, NULL, NULL))) goto done;
+		} else { rc = fail(VDJX_EINVAL, "rank %d: unknown command %llu", m->rank, (unsigned long long) cmd[0]); goto done; }
+	}
+done:
+	free(a); free(b); free(off); free(valid);
 	return rc;
 }

@@ -123,6 +123,7 @@ struct vdjx_ctx {
 	u32* d_pair_r2 = nullptr;         // pair -> its two read-2 records in registration order (or ~0u)
 	u32* d_ri_dstart = nullptr;       // class -> first of its DISTINCT read-1 entries (window scoring counts, it does not name pairs)
 	u64* d_ri_d8 = nullptr;           // those entries, with multiplicities
+	size_t ri_cap[9] = {};            // bytes behind the nine arrays above (kept from build to build, vdjx_rindex.hip ri_keep)
 	// cached result of the last vdjx_map_emit count call (the write call of the two-call protocol reuses it)
 	uint64_t me_key = 0;
 	const void* me_src = nullptr;     // the batch the cached mapping belongs to
@@ -158,6 +159,10 @@ struct vdjx_ctx {
 	void* d_sam_text = nullptr;
 	void* h_sam_text = nullptr;
 	size_t sam_text_cap = 0;
+	void *d_sam_keys = nullptr, *d_sam_lens = nullptr;      // vdjx_sam_blocks: per mapped pair its ordering key and the bytes of its two lines
+	size_t sam_blk_cap = 0;
+	void* h_sam_merge = nullptr;      // vdjx_sam_merge: the merged text (page-locked)
+	size_t sam_merge_cap = 0;
 	u32 n_pairs = 0, n_classes = 0;
 	std::map<std::string, uint64_t> stats;
 };

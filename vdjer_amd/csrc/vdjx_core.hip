@@ -107,6 +107,8 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	free_dev(c->d_vtext); free_dev(c->d_line_off); free_dev(c->d_seed_code); free_dev(c->d_seed_pos);
 	free_dev(c->d_ri_tab); free_dev(c->d_ri_start); free_dev(c->d_ri_recs); free_dev(c->d_ri_csr8); free_dev(c->d_ri_csr_pair);
 	free_dev(c->d_pair_r2);
+	free_dev(c->d_sam_keys); free_dev(c->d_sam_lens);
+	if (c->h_sam_merge) (void) hipHostFree(c->h_sam_merge);
 	free_dev(c->me_pairs); free_dev(c->me_hit); free_dev(c->me_dense); free_dev(c->me_book); free_dev(c->wp_buf); free_dev(c->d_ri_cnt1); free_dev(c->d_ri_dstart); free_dev(c->d_ri_d8);
 	for (int i = 0; i < 2; i++) { free_dev(c->d_stage[i]); if (c->ev_copied[i]) (void) hipEventDestroy(c->ev_copied[i]); if (c->ev_packed[i]) (void) hipEventDestroy(c->ev_packed[i]); }
 	c->arena.release();

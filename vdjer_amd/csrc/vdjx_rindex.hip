@@ -25,6 +25,16 @@
 
 namespace {
 template <typename T> void free_set(T*& p) { if (p) (void) hipFree(p); p = nullptr; }
+// *p holds at least `bytes` bytes (contents undefined): kept if large enough, replaced (with a margin) if not
+template <typename T> hipError_t ri_keep(T** p, size_t* cap, size_t bytes) {
+	if (*p && *cap >= bytes) return hipSuccess;
+	if (*p) (void) hipFree(*p);
+	*p = nullptr; *cap = 0;
+	const size_t want = bytes + bytes / 8 + 256;
+	const hipError_t e = hipMalloc((void**) p, want);
+	if (e == hipSuccess) *cap = want;
+	return e;
+}
 
 // ---- exclusive scan of u32 counts (n up to 2^31): out[0..n], out[n] = total -------------------------------------------------
 #define RS_BLOCK 2048u
@@ -140,14 +150,14 @@ __global__ __launch_bounds__(256) void k_ri_number(u32* __restrict__ slots, u32 
 // ---- per record ---------------------------------------------------------------------------------------------------------------------
 #define RI_ERR_PAIR 0      // err[0]: records whose pair id is out of range
 #define RI_ERR_R2 1        // err[1]: pairs with more than two read-2 records
-#define RI_ERR_ORDER 2     // err[2]: a record registered before its predecessor inside a pool (the members need a sort by rank)
-#define RI_ERR_RUNS 3      // err[3]: the secondary pool's first record registered before the primary pool's last (a merge of the two runs)
+#define RI_ERR_ORDER 2     // err[2]: records registered before their predecessor: none -- the records are in registration order; one -- two runs
+#define RI_ERR_RUNS 3      // err[3]: ... that meet at this record (a merge); more -- the members are sorted by rank
 #define RI_RB 2048u        // records per workgroup of the record passes: 8 per thread, all of a thread's loads in flight together
 #define RI_RCBIT 0x80000000u
 // record -> class (| is_rc in the top bit: what the entry of a pair needs of its mates in ONE load); the pair's read-2 records in
 // registration order: the two smallest (reg_rank << 32 | record) of the pair, kept by a chain of two atomic minima (what loses at the
 // first slot moves on to the second; a third arrival is an error); read-1 members per workgroup (their compaction follows)
-__global__ __launch_bounds__(256) void k_ri_records(const u32* __restrict__ rec_slot, const u32* __restrict__ slots, u32 R, u32 n_primary,
+__global__ __launch_bounds__(256) void k_ri_records(const u32* __restrict__ rec_slot, const u32* __restrict__ slots, u32 R,
                                                     const u32* __restrict__ pair_id, const uint8_t* __restrict__ read_num, const uint8_t* __restrict__ is_rc,
                                                     const u32* __restrict__ reg_rank, u32 n_pairs, u32* __restrict__ rec_cls,
                                                     unsigned long long* __restrict__ r2key, u32* __restrict__ err, u32* __restrict__ bcnt) {
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(256) void k_ri_records(const u32* __restrict__ rec_
 		const u32 r = base + (u32) i * 256u;
 		if (r >= R) continue;
 		rec_cls[r] = cls[i] | (rc[i] ? RI_RCBIT : 0u);
-		if (r && reg[i] < regp[i]) atomicAdd(&err[r == n_primary ? RI_ERR_RUNS : RI_ERR_ORDER], 1u);
+		if (r && reg[i] < regp[i]) { atomicAdd(&err[RI_ERR_ORDER], 1u); atomicMax(&err[RI_ERR_RUNS], r); }
 		if (p[i] >= n_pairs) { atomicAdd(&err[RI_ERR_PAIR], 1u); continue; }
 		if (rn[i] == 1) { mine += cls[i] != RI_ENT_NONE; continue; }
 		const unsigned long long v = ((unsigned long long) reg[i] << 32) | r;
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(256) void k_ri_members(const u32* __restrict__ rec_
 		m_ent[pos] = ri_entry(ca[i] & RI_ENT_NONE, cb[i] & RI_ENT_NONE, fl, 1u);
 	}
 }
-// first member that is a record of the secondary pool (the members are in record order)
+// first member that is a record of the second run (the members are in record order)
 __global__ void k_ri_split(const u32* __restrict__ m_rec, u32 n1, u32 n_primary, u32* __restrict__ out) {
 	u32 lo = 0, hi = n1;
 	while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (m_rec[mid] < n_primary) lo = mid + 1; else hi = mid; }
@@ -437,7 +447,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	if (pool->n_records > ((size_t) 1 << 29)) { vdjx_set_error("vdjx_read_index_build: %zu records on one GPU (limit 2^29): shard the pool by pair", pool->n_records); return VDJX_ELIMIT; }
 	const u32 R = (u32) pool->n_records;
 	u32 mask = 1023;
-	while ((size_t) mask + 1 < (size_t) R * 2) mask = mask * 2 + 1;
+	while ((size_t) mask + 1 < (size_t) R + R / 2) mask = mask * 2 + 1;          // (at worst -- every record a class of its own -- a third of the slots stays free)
 	const size_t nslots = (size_t) mask + 1;
 	const dim3 gR(R / 256 + 1), gB((R + RI_RB - 1) / RI_RB + 1), b256(256);
 	u32 *d_rec_slot, *d_rec_cls, *d_err, *d_split;
@@ -478,11 +488,13 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	u32* d_rep;
 	HIP_TRY(db.alloc(&d_rep, (size_t) ncls + 1));
 	const size_t slot_bytes = (size_t) (pool->W == 2 ? VDJX_RI_SLOT_WORDS(2) : VDJX_RI_SLOT_WORDS(VDJX_LONG_W)) * 8;
-	HIP_TRY(hipMalloc(&c->d_ri_tab, ((size_t) tmask + 1) * slot_bytes));
-	HIP_TRY(hipMalloc(&c->d_ri_start, ((size_t) ncls + 2) * 4));
-	HIP_TRY(hipMalloc(&c->d_ri_cnt1, ((size_t) ncls + 2) * 4));
-	HIP_TRY(hipMalloc(&c->d_ri_dstart, ((size_t) ncls + 2) * 4));          // (weighted entries per class: k_ri_fold's dcnt)
-	HIP_TRY(hipMalloc(&c->d_pair_r2, ((size_t) n_pairs * 2 + 2) * 4));
+	// the index's arrays are kept from build to build and only replaced when one needs more (hipMalloc / hipFree of gigabytes per pool
+	// cost more than the kernels that fill them)
+	HIP_TRY(ri_keep(&c->d_ri_tab, &c->ri_cap[0], ((size_t) tmask + 1) * slot_bytes));
+	HIP_TRY(ri_keep(&c->d_ri_start, &c->ri_cap[1], ((size_t) ncls + 2) * 4));
+	HIP_TRY(ri_keep(&c->d_ri_cnt1, &c->ri_cap[2], ((size_t) ncls + 2) * 4));
+	HIP_TRY(ri_keep(&c->d_ri_dstart, &c->ri_cap[3], ((size_t) ncls + 2) * 4));          // (weighted entries per class: k_ri_fold's dcnt)
+	HIP_TRY(ri_keep(&c->d_pair_r2, &c->ri_cap[4], ((size_t) n_pairs * 2 + 2) * 4));
 	HIP_TRY(hipMemsetAsync(c->d_ri_cnt1, 0, ((size_t) ncls + 2) * 4, st));
 	HIP_TRY(hipMemsetAsync(c->d_ri_tab, 0, ((size_t) tmask + 1) * slot_bytes, st));
 	{
@@ -496,7 +508,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(db.alloc(&d_rbpre, nrb + 2));
 	{
 		vdjx_prof_scope ps(c, "k_ri_records");
-		if (nrb) hipLaunchKernelGGL(k_ri_records, dim3(nrb), b256, 0, st, d_rec_slot, d_slots, R, (u32) pool->n_primary, d_pair, d_rnum, d_rc, d_reg, n_pairs, d_rec_cls, d_r2key, d_err, d_rbcnt);
+		if (nrb) hipLaunchKernelGGL(k_ri_records, dim3(nrb), b256, 0, st, d_rec_slot, d_slots, R, d_pair, d_rnum, d_rc, d_reg, n_pairs, d_rec_cls, d_r2key, d_err, d_rbcnt);
 		hipLaunchKernelGGL(k_ri_r2, dim3((unsigned) (((size_t) n_pairs * 2 + 2) / 256 + 1)), b256, 0, st, d_r2key, (size_t) n_pairs * 2 + 2, c->d_pair_r2);
 		hipLaunchKernelGGL(k_rs_top, dim3(1), dim3(1024), 0, st, d_rbcnt, nrb, d_rbpre);
 	}
@@ -523,10 +535,10 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	int rc = scan_u32(db, st, c->d_ri_cnt1, ncls + 1, c->d_ri_start);         // (cnt1[ncls] = 0: start[ncls] = start[ncls + 1] = members)
 	if (rc) return rc;
 	// CSR order = (class, registration rank)
-	HIP_TRY(hipMalloc(&c->d_ri_recs, ((size_t) n1 + 1) * 4));
-	HIP_TRY(hipMalloc(&c->d_ri_csr8, ((size_t) n1 + 1) * 8));
-	HIP_TRY(hipMalloc(&c->d_ri_csr_pair, ((size_t) n1 + 1) * 4));
-	HIP_TRY(hipMalloc(&c->d_ri_d8, ((size_t) n1 + 1) * 8));
+	HIP_TRY(ri_keep(&c->d_ri_recs, &c->ri_cap[5], ((size_t) n1 + 1) * 4));
+	HIP_TRY(ri_keep(&c->d_ri_csr8, &c->ri_cap[6], ((size_t) n1 + 1) * 8));
+	HIP_TRY(ri_keep(&c->d_ri_csr_pair, &c->ri_cap[7], ((size_t) n1 + 1) * 4));
+	HIP_TRY(ri_keep(&c->d_ri_d8, &c->ri_cap[8], ((size_t) n1 + 1) * 8));
 	unsigned long long nd = 0;
 	if (n1) {
 		vdjx_prof_scope ps(c, "ri_sort_members");
@@ -535,7 +547,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 		// follow its records gets a sort by rank instead.  Then a STABLE sort by class alone (the key's upper half; the member
 		// rides in the lower one): three 8-bit passes over 8-byte keys instead of seven over key + value.
 		u64* by_rank = d_mkey;
-		if (h_err[RI_ERR_ORDER]) {
+		if (h_err[RI_ERR_ORDER] > 1) {
 			size_t tb = 0;
 			const unsigned rb = 32;
 			HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, d_mreg, d_mreg2, d_mkey, d_mkey2, (size_t) n1, 0u, rb, st));
@@ -543,9 +555,9 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 			HIP_TRY(db.alloc(&tmp, tb + 256));
 			HIP_TRY(rocprim::radix_sort_pairs((void*) tmp, tb, d_mreg, d_mreg2, d_mkey, d_mkey2, (size_t) n1, 0u, rb, st));
 			by_rank = d_mkey2;
-		} else if (h_err[RI_ERR_RUNS]) {
+		} else if (h_err[RI_ERR_ORDER] == 1) {
 			u32 n1p = 0;
-			hipLaunchKernelGGL(k_ri_split, dim3(1), dim3(1), 0, st, d_mrec, n1, (u32) pool->n_primary, d_split);
+			hipLaunchKernelGGL(k_ri_split, dim3(1), dim3(1), 0, st, d_mrec, n1, h_err[RI_ERR_RUNS], d_split);
 			HIP_TRY(hipMemcpyAsync(&n1p, d_split, 4, hipMemcpyDeviceToHost, st));
 			HIP_TRY(hipStreamSynchronize(st));
 			size_t tb = 0;
@@ -583,7 +595,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	c->stats["read_index_r1_members"] = n1;
 	c->stats["read_index_r1_distinct"] = nd;
 	c->stats["read_index_classes"] = ncls;
-	c->stats["read_index_rank_order"] = h_err[RI_ERR_ORDER] ? 2 : (h_err[RI_ERR_RUNS] ? 1 : 0);      // 0 as recorded, 1 merge of the two pools' runs, 2 sort by rank
+	c->stats["read_index_rank_order"] = h_err[RI_ERR_ORDER] > 1 ? 2 : h_err[RI_ERR_ORDER];      // 0 as recorded, 1 merge of the two pools' runs, 2 sort by rank
 	c->ri_tab_mask = tmask;
 	c->n_pairs = n_pairs;
 	c->n_classes = ncls;
@@ -591,9 +603,8 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	return VDJX_OK;
 }
 
+// the index is gone (its arrays stay for the next build: ri_keep)
 void drop_index(vdjx_ctx* c) {
-	free_set(c->d_ri_tab); free_set(c->d_ri_start); free_set(c->d_ri_recs); free_set(c->d_ri_cnt1);
-	free_set(c->d_pair_r2); free_set(c->d_ri_csr8); free_set(c->d_ri_csr_pair); free_set(c->d_ri_dstart); free_set(c->d_ri_d8);
 	c->ri_pool = nullptr;
 	c->me_key = 0;
 }

@@ -2215,11 +2215,22 @@ extern "C" int vdjx_sam_names_load(vdjx_ctx* c, const char* names, const uint64_
 	return VDJX_OK;
 }
 
-extern "C" int vdjx_sam_text(vdjx_ctx* c, const char* contigs, size_t n, int len, const char* ids, const uint32_t* id_off,
-                             const char** out_text, uint64_t* out_bytes) {
-	if (!c || !out_text || !out_bytes || (n && (!contigs || !ids || !id_off))) { vdjx_set_error("vdjx_sam_text: NULL argument"); return VDJX_EINVAL; }
-	*out_text = ""; *out_bytes = 0;
-	if (n == 0) return VDJX_OK;
+// per mapped pair the key that orders the SAM records of a pool sharded by pair (vdjx_sam_blocks): contig, then read-1 position,
+// then the registration rank of the read-1 record -- the order quick_map_process_contig walks its lists in (quick_map3.c:199-245:
+// offsets ascending, the instances of a read sequence in registration order)
+#define SAM_KEY_POS_BITS 12
+#define SAM_KEY_CONTIG_BITS 20
+__global__ void k_sam_keys(SamSrc s, u64 total, const u32* __restrict__ reg_rank, u64* __restrict__ keys) {
+	const u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= total) return;
+	const vdjx_pair q = s.pairs[i];
+	keys[i] = ((u64) sam_contig_of(s, i) << (32 + SAM_KEY_POS_BITS)) | ((u64) (u32) q.pos1 << 32) | reg_rank[q.rec1];
+}
+
+// the SAM text of the mapped pairs of `contigs` in c->d_sam_text (device), the bytes of every pair's two lines in *d_len_out (arena of `db`)
+static int sam_text_device(vdjx_ctx* c, vdjx_work& db, const char* contigs, size_t n, int len, const char* ids, const uint32_t* id_off, SamSrc* src, u64* total_out,
+                           u64* nbytes_out, u32** d_len_out) {
+	*total_out = 0; *nbytes_out = 0; *d_len_out = nullptr;
 	if (!c->d_sam_noff) { vdjx_set_error("vdjx_sam_text: call vdjx_sam_names_load first"); return VDJX_ESTATE; }
 	if (!c->ri_pool) { vdjx_set_error("vdjx_sam_text: call vdjx_read_index_build first"); return VDJX_ESTATE; }
 	if (c->sam_pairs < c->n_pairs) { vdjx_set_error("vdjx_sam_text: %u names for %u pairs", c->sam_pairs, c->n_pairs); return VDJX_EINVAL; }
@@ -2232,7 +2243,6 @@ extern "C" int vdjx_sam_text(vdjx_ctx* c, const char* contigs, size_t n, int len
 	if (rc) return rc;
 	HIP_TRY(hipSetDevice(c->device));
 	hipStream_t st = c->stream;
-	vdjx_work db(c);
 	const vdjx_pool* p = c->ri_pool;
 	u64 *d_offs, *d_at;
 	u32 *d_idoff, *d_len;
@@ -2255,7 +2265,7 @@ extern "C" int vdjx_sam_text(vdjx_ctx* c, const char* contigs, size_t n, int len
 		hipLaunchKernelGGL(k_sam_len, dim3((u32) ((total + 255) / 256)), dim3(256), 0, st, s, total, d_len);
 		hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, st, d_len, (u32) total, d_at);
 		HIP_TRY(hipMemcpyAsync(&nbytes, d_at + total, 8, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(hipStreamSynchronize(st));           // (also: `offs` and the ids have left the host)
 		HIP_TRY(hipGetLastError());
 		if (nbytes + 1 > c->sam_text_cap) {
 			if (c->h_sam_text) (void) hipHostFree(c->h_sam_text);
@@ -2268,6 +2278,24 @@ extern "C" int vdjx_sam_text(vdjx_ctx* c, const char* contigs, size_t n, int len
 		}
 		hipLaunchKernelGGL(k_sam_write, dim3((u32) ((total + 3) / 4)), dim3(256), 0, st, s, total, d_at, (char*) c->d_sam_text);
 	}
+	*src = s; *total_out = total; *nbytes_out = nbytes; *d_len_out = d_len;
+	c->stats["sam_pairs"] = total;
+	c->stats["sam_bytes"] = nbytes;
+	return VDJX_OK;
+}
+
+extern "C" int vdjx_sam_text(vdjx_ctx* c, const char* contigs, size_t n, int len, const char* ids, const uint32_t* id_off,
+                             const char** out_text, uint64_t* out_bytes) {
+	if (!c || !out_text || !out_bytes || (n && (!contigs || !ids || !id_off))) { vdjx_set_error("vdjx_sam_text: NULL argument"); return VDJX_EINVAL; }
+	*out_text = ""; *out_bytes = 0;
+	if (n == 0) return VDJX_OK;
+	vdjx_work db(c);
+	SamSrc s;
+	u64 total = 0, nbytes = 0;
+	u32* d_len;
+	int rc = sam_text_device(c, db, contigs, n, len, ids, id_off, &s, &total, &nbytes, &d_len);
+	if (rc || !total) return rc;
+	hipStream_t st = c->stream;
 	HIP_TRY(hipMemcpyAsync(c->h_sam_text, c->d_sam_text, (size_t) nbytes, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
@@ -2275,7 +2303,131 @@ extern "C" int vdjx_sam_text(vdjx_ctx* c, const char* contigs, size_t n, int len
 	((char*) c->h_sam_text)[nbytes] = 0;
 	*out_text = (const char*) c->h_sam_text;
 	*out_bytes = nbytes;
-	c->stats["sam_pairs"] = total;
-	c->stats["sam_bytes"] = nbytes;
+	return VDJX_OK;
+}
+
+// ==============================================================================================
+// the SAM records of a pool that is sharded BY PAIR over several GPUs (no counterpart in the reference): every rank formats the
+// records of ITS pairs (vdjx_sam_blocks: text, bytes per pair, an ordering key per pair -- all left on the device), the caller
+// brings them to one rank, which lays them out in the reference's order (vdjx_sam_merge: one sort of the keys, one copy)
+// ==============================================================================================
+extern "C" int vdjx_sam_blocks(vdjx_ctx* c, const char* contigs, size_t n, int len, const char* ids, const uint32_t* id_off, const uint32_t* d_reg_rank,
+                               uint64_t* n_blocks, uint64_t* n_bytes, const void** d_keys, const void** d_lens, const void** d_text) {
+	if (!c || !n_blocks || !n_bytes || !d_keys || !d_lens || !d_text || (n && (!contigs || !ids || !id_off || !d_reg_rank))) { vdjx_set_error("vdjx_sam_blocks: NULL argument"); return VDJX_EINVAL; }
+	*n_blocks = 0; *n_bytes = 0; *d_keys = nullptr; *d_lens = nullptr; *d_text = nullptr;
+	if (n == 0) return VDJX_OK;
+	if (n >= (1ull << SAM_KEY_CONTIG_BITS) || len >= (1 << SAM_KEY_POS_BITS)) { vdjx_set_error("vdjx_sam_blocks: at most 2^%d contigs of fewer than %d bases per call", SAM_KEY_CONTIG_BITS, 1 << SAM_KEY_POS_BITS); return VDJX_ELIMIT; }
+	vdjx_work db(c);
+	SamSrc s;
+	u64 total = 0, nbytes = 0;
+	u32* d_len;
+	int rc = sam_text_device(c, db, contigs, n, len, ids, id_off, &s, &total, &nbytes, &d_len);
+	if (rc || !total) return rc;
+	hipStream_t st = c->stream;
+	if (total > c->sam_blk_cap) {
+		free_set(c->d_sam_keys); free_set(c->d_sam_lens);
+		c->sam_blk_cap = 0;
+		HIP_TRY(hipMalloc(&c->d_sam_keys, (size_t) (total + total / 8 + 64) * 8));
+		HIP_TRY(hipMalloc(&c->d_sam_lens, (size_t) (total + total / 8 + 64) * 4));
+		c->sam_blk_cap = (size_t) (total + total / 8 + 64);
+	}
+	hipLaunchKernelGGL(k_sam_keys, dim3((u32) ((total + 255) / 256)), dim3(256), 0, st, s, total, d_reg_rank, (u64*) c->d_sam_keys);
+	HIP_TRY(hipMemcpyAsync(c->d_sam_lens, d_len, (size_t) total * 4, hipMemcpyDeviceToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	vdjx_prof_collect(c, false);
+	*n_blocks = total; *n_bytes = nbytes;
+	*d_keys = c->d_sam_keys; *d_lens = c->d_sam_lens; *d_text = c->d_sam_text;
+	return VDJX_OK;
+}
+
+__global__ void k_iota_u32(u32* __restrict__ v, u32 n) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) v[i] = i;
+}
+__global__ void k_take_u32(const u32* __restrict__ src, const u32* __restrict__ idx, u32 n, u32* __restrict__ dst) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) dst[i] = src[idx[i]];
+}
+// one wave per block of text: bytes [from[idx[j]], + len) of `src` to `at[j]` of `dst`
+__global__ __launch_bounds__(256) void k_sam_move(const char* __restrict__ src, const u64* __restrict__ from, const u32* __restrict__ lens, const u32* __restrict__ idx,
+                                                  const u64* __restrict__ at, u32 n, char* __restrict__ dst) {
+	const u32 j = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (j >= n) return;
+	const u32 b = idx[j], l = lens[b];
+	const char* sp = src + from[b];
+	char* dp = dst + at[j];
+	for (u32 i = lane; i < l; i += 64) dp[i] = sp[i];
+}
+
+extern "C" int vdjx_sam_merge(vdjx_ctx* c, uint64_t n_blocks, uint64_t n_bytes, const void* d_keys, const void* d_lens, const void* d_text,
+                              const char** out_text, uint64_t* out_bytes) {
+	if (!c || !out_text || !out_bytes) { vdjx_set_error("vdjx_sam_merge: NULL argument"); return VDJX_EINVAL; }
+	*out_text = ""; *out_bytes = 0;
+	if (!n_blocks) return VDJX_OK;
+	if (!d_keys || !d_lens || !d_text) { vdjx_set_error("vdjx_sam_merge: NULL buffer"); return VDJX_EINVAL; }
+	if (n_blocks >= (1ull << 32)) { vdjx_set_error("vdjx_sam_merge: too many pairs in one call"); return VDJX_ELIMIT; }
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
+	hipStream_t st = c->stream;
+	vdjx_work db(c);
+	const u32 nb = (u32) n_blocks;
+	u64 *d_from, *d_at, *d_k2, *d_kin;
+	u32 *d_idx, *d_idx2, *d_l2;
+	char* d_out;
+	HIP_TRY(db.alloc(&d_from, (size_t) nb + 2));
+	HIP_TRY(db.alloc(&d_at, (size_t) nb + 2));
+	HIP_TRY(db.alloc(&d_kin, (size_t) nb + 1));
+	HIP_TRY(db.alloc(&d_k2, (size_t) nb + 1));
+	HIP_TRY(db.alloc(&d_idx, (size_t) nb + 1));
+	HIP_TRY(db.alloc(&d_idx2, (size_t) nb + 1));
+	HIP_TRY(db.alloc(&d_l2, (size_t) nb + 1));
+	HIP_TRY(db.alloc(&d_out, (size_t) n_bytes + 16));
+	// where every block starts in the text as it came (source after source, every source's blocks in its own order: one running sum)
+	hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, st, (const u32*) d_lens, nb, d_from);
+	HIP_TRY(hipMemcpyAsync(d_kin, d_keys, (size_t) nb * 8, hipMemcpyDeviceToDevice, st));       // (the sort may use its input as scratch)
+	hipLaunchKernelGGL(k_iota_u32, dim3(nb / 256 + 1), dim3(256), 0, st, d_idx, nb);
+	int rc = vdjx_sort_pairs(db, st, d_kin, d_k2, d_idx, d_idx2, nb, 64u);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_take_u32, dim3(nb / 256 + 1), dim3(256), 0, st, (const u32*) d_lens, d_idx2, nb, d_l2);
+	hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, st, d_l2, nb, d_at);
+	u64 tot_in = 0, tot_out = 0;
+	HIP_TRY(hipMemcpyAsync(&tot_in, d_from + nb, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&tot_out, d_at + nb, 8, hipMemcpyDeviceToHost, st));
+	hipLaunchKernelGGL(k_sam_move, dim3((nb + 3) / 4), dim3(256), 0, st, (const char*) d_text, d_from, (const u32*) d_lens, d_idx2, d_at, nb, d_out);
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	if (tot_in != n_bytes || tot_out != n_bytes) { vdjx_set_error("vdjx_sam_merge: the blocks' lengths add up to %llu bytes, the text has %llu", (unsigned long long) tot_in, (unsigned long long) n_bytes); return VDJX_EINVAL; }
+	if (n_bytes + 1 > c->sam_merge_cap) {
+		if (c->h_sam_merge) (void) hipHostFree(c->h_sam_merge);
+		c->h_sam_merge = nullptr; c->sam_merge_cap = 0;
+		const size_t want = (size_t) n_bytes + (size_t) n_bytes / 8 + 4096;
+		HIP_TRY(hipHostMalloc(&c->h_sam_merge, want, hipHostMallocDefault));
+		c->sam_merge_cap = want;
+	}
+	HIP_TRY(hipMemcpyAsync(c->h_sam_merge, d_out, (size_t) n_bytes, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	((char*) c->h_sam_merge)[n_bytes] = 0;
+	*out_text = (const char*) c->h_sam_merge;
+	*out_bytes = n_bytes;
+	return VDJX_OK;
+}
+
+// rows of `row` bytes: row pos[i] of dst = row i of src (the records a rank receives for its slice of the scan order, each with its place)
+__global__ __launch_bounds__(256) void k_rows_scatter(char* __restrict__ dst, const char* __restrict__ src, const u32* __restrict__ pos, u64 n, u32 row) {
+	const u64 i = (u64) blockIdx.x * 4u + (threadIdx.x >> 6);
+	if (i >= n) return;
+	const char* sp = src + i * row;
+	char* dp = dst + (u64) pos[i] * row;
+	for (u32 b = threadIdx.x & 63u; b < row; b += 64) dp[b] = sp[b];
+}
+extern "C" int vdjx_rows_scatter(vdjx_ctx* c, void* d_dst, const void* d_src, const uint32_t* d_pos, size_t n, size_t row) {
+	if (!c || (n && (!d_dst || !d_src || !d_pos)) || row == 0 || row >= (1u << 20)) { vdjx_set_error("vdjx_rows_scatter: bad argument"); return VDJX_EINVAL; }
+	if (!n) return VDJX_OK;
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
+	hipLaunchKernelGGL(k_rows_scatter, dim3((u32) ((n + 3) / 4)), dim3(256), 0, c->stream, (char*) d_dst, (const char*) d_src, d_pos, (u64) n, (u32) row);
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipGetLastError());
 	return VDJX_OK;
 }
