@@ -260,7 +260,7 @@ int vdjx_profile_get(vdjx_ctx* ctx, int idx, const char** name, double* total_ms
  * vdjer_amd/shard.py does it with torch.distributed over RCCL, vdjer_amd/csrc/host/vdjx_mgpu.c with RCCL
  * directly).  Record numbering is rank-major with a common stride: rank r's records are
  * [r*rec_stride, r*rec_stride + R_r); instance ids are global, record << 6 | offset, so nranks * rec_stride
- * must stay below 2^32 records.  Any 1 <= nranks <= 256; the owner of a k-mer is its hash bucket divided by
+ * must stay below 2^32 records (record << 8 | offset and 2^30 records with reads of more than 64 bases).  Any 1 <= nranks <= 256; the owner of a k-mer is its hash bucket divided by
  * the buckets per owner (*dir_len of vdjx_shard_local: the quotient of the bucket count by nranks, rounded up).
  *   Every rank first aggregates ITS OWN gated instances per distinct k-mer (count, first instance, whether it
  * saw two different reads: add_to_table A2:322-367 restated per rank).  These partial aggregates (32 B per
@@ -279,7 +279,7 @@ typedef struct vdjx_shard vdjx_shard;
 int vdjx_shard_begin(vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, int rank, int nranks,
                      uint64_t rec_stride, vdjx_shard** out);
 void vdjx_shard_free(vdjx_shard* s);
-/* bytes per exchanged record: kind 0 partial aggregate (32), 1 question (8), 2 answer (200), 3 survivor (32) */
+/* bytes per exchanged record: kind 0 partial aggregate (32), 1 question (8), 2 answer (240), 3 survivor (32) */
 size_t vdjx_shard_record_bytes(int kind);
 /* this rank's partial aggregates, grouped by owner: send_counts[nranks]; *dir_len = hash buckets per owner */
 int vdjx_shard_local(vdjx_shard* s, uint64_t* send_counts, uint32_t* dir_len);

@@ -444,10 +444,11 @@ def test_deep_windows_many_slices_and_multiplicities(ctx):
     p.free()
 
 
-@pytest.mark.parametrize("world,k,mf,mq,stride", [(2, 35, 3, 90, None), (4, 25, 2, 60, None), (2, 48, 2, 60, None), (8, 35, 2, 60, None),
-                                                  (2, 35, 3, 90, 1 << 30), (4, 25, 2, 60, (1 << 30) - 12345),
-                                                  (3, 35, 3, 90, None), (6, 25, 2, 60, None), (5, 35, 2, 60, (1 << 29) + 77)])
-def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq, stride):
+@pytest.mark.parametrize("world,k,mf,mq,stride,rl", [(2, 35, 3, 90, None, 50), (4, 25, 2, 60, None, 50), (2, 48, 2, 60, None, 50), (8, 35, 2, 60, None, 50),
+                                                     (2, 35, 3, 90, 1 << 30, 50), (4, 25, 2, 60, (1 << 30) - 12345, 50),
+                                                     (3, 35, 3, 90, None, 50), (6, 25, 2, 60, None, 50), (5, 35, 2, 60, (1 << 29) + 77, 50),
+                                                     (2, 35, 3, 90, None, 100), (3, 25, 2, 60, (1 << 28) + 5, 151), (4, 50, 2, 60, None, 75)])
+def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq, stride, rl):
     """The real multi-rank driver + the HIP phase engine with `world` ranks on this one GPU (ranks are threads,
     collectives are tensor copies: tests/fake_dist.py).  Result == single-GPU build of the union pool == oracle.
     stride: the ranks' records numbered 2^30 apart, so that global instance ids (record << 6 | offset) run past 2^32 as they
@@ -460,20 +461,21 @@ def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq, stride):
     vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
     jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
     import dataclasses
-    pools = [synth.make_reads(rep, 6000 if world < 8 else 1500, noise_frac=0.3, seed=500 + r, err=0.004, n_rate=0.002) for r in range(world)]
+    ob = 6 if rl <= 64 else 8                                # instance ids: record << 6 | offset, or << 8 with reads of more than 64 bases (the long-read record format)
+    pools = [synth.make_reads(rep, 6000 if world < 8 else 1500, noise_frac=0.3, seed=500 + r, err=0.004, n_rate=0.002, rl=rl) for r in range(world)]
     # reads present once on EVERY rank (no rank sees two different reads of their k-mers: the owner has to ask), a variant with
     # weak qualities on rank 1 only (settles some of those flags; low quality sums), blanks elsewhere to keep the strides equal
-    shared = synth.make_reads(synth.make_repertoire(2, seed=78), 12, noise_frac=0.0, seed=10, err=0.0, n_rate=0.0).primary.copy()
+    shared = synth.make_reads(synth.make_repertoire(2, seed=78), 12, noise_frac=0.0, seed=10, err=0.0, n_rate=0.0, rl=rl).primary.copy()
     weak = shared[:6].copy()
-    weak[:, 51:] = ord("6")
+    weak[:, 1 + rl:] = ord("6")
     weak[::2, 12] = np.where(weak[::2, 12] == ord("A"), ord("C"), ord("A"))
-    blank = np.frombuffer(("0" + "N" * 50 + "I" * 50).encode(), np.uint8)
+    blank = np.frombuffer(("0" + "N" * rl + "I" * rl).encode(), np.uint8)
     for r in range(world):
         tail = weak if r == 1 else np.stack([blank] * weak.shape[0])
         pools[r] = dataclasses.replace(pools[r], primary=np.concatenate([pools[r].primary, shared, tail]))
     cat = np.concatenate([np.concatenate([p.primary, p.secondary]) for p in pools])
     R = cat.shape[0]
-    union = synth.ReadPool(50, cat, np.zeros((0, 101), np.uint8), np.zeros(R, np.uint32), np.zeros(R, np.uint8),
+    union = synth.ReadPool(rl, cat, np.zeros((0, 2 * rl + 1), np.uint8), np.zeros(R, np.uint32), np.zeros(R, np.uint8),
                            np.zeros(R, np.uint8), np.arange(R, dtype=np.uint32), 0)
     ref = run_both(ctx, union, vc, jc, k, mf, mq)           # single-GPU == oracle, and the reference result
     dist = ThreadDist(world)
@@ -484,7 +486,7 @@ def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq, stride):
             dist.set_rank(r)
             c = api.Context(0)
             c.anchor_sets_load(vc, jc)
-            p = c.pool_load(pools[r].primary, pools[r].secondary, 50)
+            p = c.pool_load(pools[r].primary, pools[r].secondary, rl)
             drv = shard.ShardedHotPath(c, dist, torch.device("cuda", 0), stride=stride)
             out[r] = drv.kmer_build(p, k, mf, mq)
             stats[r] = {n_: c.stat("shard_" + n_) for n_ in ("partials_received", "open_kmers", "questions", "decided_at_merge", "kept_after_answers")}
@@ -509,9 +511,9 @@ def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq, stride):
     if stride is not None:          # union record rank*R_r + i is global record rank*stride + i
         per = pools[0].n_records
         assert all(p_.n_records == per for p_ in pools)
-        rec = ref.first_inst >> np.uint64(6)
-        exp_first = (((rec // np.uint64(per)) * np.uint64(stride) + rec % np.uint64(per)) << np.uint64(6)) | (ref.first_inst & np.uint64(63))
-        assert (stride * (world - 1)) << 6 >= 1 << 32          # the later ranks' instance ids do not fit 32 bits
+        rec = ref.first_inst >> np.uint64(ob)
+        exp_first = (((rec // np.uint64(per)) * np.uint64(stride) + rec % np.uint64(per)) << np.uint64(ob)) | (ref.first_inst & np.uint64((1 << ob) - 1))
+        assert (stride * (world - 1)) << ob >= 1 << 32         # the later ranks' instance ids do not fit 32 bits
     for g in out:
         assert g.n == ref.n and g.pre_nodes == ref.pre_nodes
         np.testing.assert_array_equal(g.first_inst, exp_first)

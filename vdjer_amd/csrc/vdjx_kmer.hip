@@ -807,7 +807,7 @@ struct Partial { u64 lo, hi; u32 cg, pad; u64 fg; };     // 32 bytes, what trave
 #define NEED_Q 2u
 #define PID_MASK 0x3FFFFFFFu
 #define REPLY_KQ 52                 // quality bytes per row (k <= 50)
-#define REPLY_BYTES 200             // pid | need, first instance (u64), 16-B bases, 8-B N mask, 3 quality rows
+#define REPLY_BYTES 240             // pid | need, first instance (u64), the record's bases and N mask (8 words: 2 + 1 or 5 + 3), 3 quality rows
 
 // this rank's partial aggregates of one bucket of its gated tuples: count, first instance, "saw two different reads" (any two:
 // the owner ORs the ranks' flags and compares their first records); k-mers whose count is below TLOW also list their instances.
@@ -820,7 +820,7 @@ struct Partial { u64 lo, hi; u32 cg, pad; u64 fg; };     // 32 bytes, what trave
 #define LG_NOLIST 0x7FFFFFFFu
 template <typename TUP>
 __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated_local(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
-                                                            const u64* __restrict__ bases, const u64* __restrict__ nmask, u64 rec_base, int k,
+                                                            const u64* __restrict__ bases, const u64* __restrict__ nmask, u64 rec_base, int k, int rl, int ob,
                                                             u32 tlow, Partial* __restrict__ sparse_g, u32* __restrict__ sparse_ref,
                                                             u32* __restrict__ nd_g, u64* __restrict__ low_inst, u32* __restrict__ g_err) {
 	typedef typename TUP::hi_t THI;
@@ -836,6 +836,7 @@ __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated
 	const u32 base = bucket_start[b];
 	const u32 n = bucket_start[b + 1] - base;
 	const u32 tid = threadIdx.x;
+	const u32 om = (1u << ob) - 1u;
 	if (n == 0) { if (tid == 0) nd_g[b] = 0; return; }
 	const TUP* T = tup + base;
 	u32 S = 1;
@@ -873,8 +874,8 @@ __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated
 						u32 st = vdjx_peek(&s_st[slot]);
 						if (!(st & LG_FLAG)) {
 							const u64 f = vdjx_peek(&s_mg[slot]);
-							if (f != NONE64 && (f >> 6) != (inst >> 6)) {
-								const u32 o1 = (u32) inst & 63u, o0 = (u32) f & 63u;
+							if (f != NONE64 && (f >> ob) != (inst >> ob)) {
+								const u32 o1 = (u32) inst & om, o0 = (u32) f & om;
 								const u32 d = o1 > o0 ? o1 - o0 : o0 - o1;
 								if (d && d < (u32) k && !vdjx_kmer_has_period(r_t[j].hi(), r_t[j].lo, k, d)) { atomicOr(&s_st[slot], LG_FLAG); st |= LG_FLAG; }
 							}
@@ -922,16 +923,12 @@ __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated
 				}
 				if (cg < 2 || (st & LG_FLAG)) continue;
 				const u64 fi = s_mg[slot];
-				const u64 rec = (inst >> 6) - rec_base, frec = (fi >> 6) - rec_base;
+				const u64 rec = (inst >> ob) - rec_base, frec = (fi >> ob) - rec_base;
 				if (rec != frec) {
-					const u32 o1 = (u32) (inst & 63u), o0 = (u32) (fi & 63u);
+					const u32 o1 = (u32) inst & om, o0 = (u32) fi & om;
 					const u32 d = o1 > o0 ? o1 - o0 : o0 - o1;
 					if (d && d < (u32) k && !vdjx_kmer_has_period(x.hi(), x.lo, k, d)) atomicOr(&s_st[slot], LG_FLAG);
-					else {
-						const ulonglong2 xa = ((const ulonglong2*) bases)[rec];
-						const ulonglong2 ya = ((const ulonglong2*) bases)[frec];
-						if (xa.x != ya.x || xa.y != ya.y || nmask[rec] != nmask[frec]) atomicOr(&s_st[slot], LG_FLAG);
-					}
+					else if (!reads_equal(bases, nmask, rl, rec, frec)) atomicOr(&s_st[slot], LG_FLAG);
 				}
 			}
 			__syncthreads();
@@ -1147,15 +1144,16 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 }
 
 // answers of the rank that holds the instances: one wave per question
-//   [0,4) pid | need<<30   [8,16) this rank's first gated instance   [16,32) its record's bases   [32,40) its N mask
-//   [40,92) QS: sum of the own qualities of this rank's OTHER gated instances (saturating at 255: >= 214 reads as 255 anyway)
-//   [92,144) the first instance's own qualities   [144,196) its RECORD's first k qualities (A2:337-339)
-#define REPLY_Q0 40
+//   [0,4) pid | need<<30   [8,16) this rank's first gated instance   [16,80) its record's bases, then its N mask (2 + 1 words, or 5 + 3
+//   for reads of more than 64 bases; the rest zero)
+//   [80,132) QS: sum of the own qualities of this rank's OTHER gated instances (saturating at 255: >= 214 reads as 255 anyway)
+//   [132,184) the first instance's own qualities   [184,236) its RECORD's first k qualities (A2:337-339)
+#define REPLY_Q0 80
 __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ queries, u32 nq, const u32* __restrict__ owner_off, u32 G,
                                                     const Partial* __restrict__ dense, const u32* __restrict__ dense_ref,
                                                     const u32* __restrict__ dstart, u32 NBo, const u64* __restrict__ low_inst,
                                                     const u64* __restrict__ bases, const u64* __restrict__ nmask,
-                                                    vdjx_qrows quals, u64 rec_base, int k,
+                                                    vdjx_qrows quals, u64 rec_base, int k, int rl, int ob,
                                                     uint8_t* __restrict__ replies) {
 	const u32 qi = blockIdx.x;
 	if (qi >= nq) return;
@@ -1167,17 +1165,18 @@ __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ qu
 	const Partial p = dense[di];
 	const u32 need = q.y >> 30;
 	const u64 finst = p.fg;
-	const u64 frec = (finst >> 6) - rec_base;
-	const u32 foff = (u32) (finst & 63u);
+	const u32 om = (1u << ob) - 1u;
+	const u64 frec = (finst >> ob) - rec_base;
+	const u32 foff = (u32) finst & om;
 	uint8_t* out = replies + (size_t) qi * REPLY_BYTES;
 	if (lane == 0) {
 		((u32*) out)[0] = q.y;
 		((u32*) out)[1] = 0;
 		((u64*) out)[1] = finst;
-		const ulonglong2 bb = ((const ulonglong2*) bases)[frec];
-		((u64*) out)[2] = bb.x;
-		((u64*) out)[3] = bb.y;
-		((u64*) out)[4] = nmask[frec];
+	}
+	if (lane < 8) {
+		const int W = rl <= VDJX_SHORT_READ_LEN ? 2 : VDJX_LONG_W, M = rl <= VDJX_SHORT_READ_LEN ? 1 : VDJX_LONG_M;
+		((u64*) out)[2 + lane] = (int) lane < W ? bases[frec * W + lane] : ((int) lane < W + M ? nmask[frec * M + (lane - W)] : 0ull);
 	}
 	if ((int) lane >= k) return;
 	u32 acc = 0;
@@ -1187,8 +1186,8 @@ __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ qu
 		for (u32 i = 0; i < cg; i++) {
 			const u64 inst = low_inst[ref + i];
 			if (inst == finst) continue;
-			const u64 rec = (inst >> 6) - rec_base;
-			const u32 off = (u32) (inst & 63u);
+			const u64 rec = (inst >> ob) - rec_base;
+			const u32 off = (u32) inst & om;
 			acc += (u32) (uint8_t) (quals.row(rec)[off + lane] - 33);
 		}
 	}
@@ -1222,7 +1221,10 @@ __global__ __launch_bounds__(256) void k_resolve_add(const uint8_t* __restrict__
 	if ((need & NEED_SEQ) && r != r0 && lane == 0) {
 		const u64* a = (const u64*) me;
 		const u64* b = (const u64*) (replies + (size_t) r0 * REPLY_BYTES);
-		if (a[2] != b[2] || a[3] != b[3] || a[4] != b[4]) p_fl[pid] = 1;
+		u64 d = 0;
+#pragma unroll
+		for (int w = 2; w < 10; w++) d |= a[w] ^ b[w];
+		if (d) p_fl[pid] = 1;
 	}
 	if ((need & NEED_Q) && (int) lane < k) {
 		const uint8_t* first = me + REPLY_Q0 + (r == r0 ? 2 * REPLY_KQ : REPLY_KQ);
@@ -2795,7 +2797,8 @@ extern "C" int vdjx_kmer_build(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf
 // (torch.distributed over RCCL in vdjer_amd/shard.py, RCCL directly in the C host).  Record numbering: rank r's
 // records are [r*rec_stride, r*rec_stride + R_r); k-mer ownership = bucket index / buckets per owner (any number of ranks: the
 // buckets per owner are the quotient rounded up, to a multiple of 16 when it is not exact; the last owner has the fewest).
-// Instance ids are global and 38 bits wide (record << 6 | offset): nranks * rec_stride < 2^32 records.
+// Instance ids are global and 38 bits wide (record << 6 | offset; record << 8 | offset for reads of more than 64 bases):
+// nranks * rec_stride < 2^32 (2^30) records.
 // ==============================================================================================
 struct vdjx_shard {
 	vdjx_ctx* c = nullptr;
@@ -2832,9 +2835,9 @@ extern "C" int vdjx_shard_begin(vdjx_ctx* c, const vdjx_pool* pool, int k, int m
 	if (nranks < 1 || nranks > 256 || rank < 0 || rank >= nranks) { vdjx_set_error("1 <= nranks <= 256, 0 <= rank < nranks"); return VDJX_EINVAL; }
 	if (k < 1 || k > VDJX_MAX_KMER || k > pool->rl) { vdjx_set_error("k=%d outside [1,min(%d,rl=%d)]", k, VDJX_MAX_KMER, pool->rl); return VDJX_ELIMIT; }
 	if (rec_stride < pool->n_records) { vdjx_set_error("rec_stride %llu < local records %zu", (unsigned long long) rec_stride, pool->n_records); return VDJX_EINVAL; }
-	if (rec_stride * (uint64_t) nranks >= (1ull << 32)) { vdjx_set_error("global record count %llu >= 2^32", (unsigned long long) (rec_stride * nranks)); return VDJX_ELIMIT; }
+	if (rec_stride * (uint64_t) nranks >= (1ull << (INST_BITS - pool->ob))) { vdjx_set_error("global record count %llu >= 2^%d (instance ids are record << %d | offset in %d bits)", (unsigned long long) (rec_stride * nranks), INST_BITS - pool->ob, pool->ob, INST_BITS); return VDJX_ELIMIT; }
 	if (k > 16 && !c->anchors_loaded) { vdjx_set_error("vdjx_shard_begin: call vdjx_anchor_sets_load first (k > 16)"); return VDJX_ESTATE; }
-	if (pool->W > 2) { vdjx_set_error("vdjx_shard_begin: the sharded build takes reads of up to %d bases (this pool: %d)", VDJX_SHORT_READ_LEN, pool->rl); return VDJX_ELIMIT; }
+	if (pool->W > 2 && pool->n_records >= (1ull << 27)) { vdjx_set_error("more than 2^27 records of long reads on one GPU: not supported by the recount items"); return VDJX_ELIMIT; }
 	vdjx_shard* s = new vdjx_shard();
 	s->c = c; s->pool = pool; s->k = k; s->mf = mf; s->mq = mq; s->rank = rank; s->nranks = nranks;
 	s->rec_stride = rec_stride;
@@ -2897,7 +2900,7 @@ static int shard_local_impl(vdjx_shard* s) {
 	{
 		vdjx_prof_scope ps(c, "k_gated_local");
 		hipLaunchKernelGGL(k_gated_local<TUP>, dim3(t.NB), dim3(LG_THREADS), 0, st, t.t, t.bucket_start, s->pool->d_bases, s->pool->d_nmask, rec_base,
-		                   s->k, s->tlow, sparse, sparse_ref, s->nd, s->low_inst, g_err);
+		                   s->k, s->pool->rl, s->pool->ob, s->tlow, sparse, sparse_ref, s->nd, s->low_inst, g_err);
 	}
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, s->nd, s->NBf, s->dstart);
 	u32* d_pick;
@@ -3090,7 +3093,7 @@ extern "C" int vdjx_shard_reply(vdjx_shard* s, const void* d_queries, const uint
 	{
 		vdjx_prof_scope ps(c, "k_shard_reply");
 		hipLaunchKernelGGL(k_shard_reply, dim3(nq), dim3(64), 0, st, (const uint2*) d_queries, nq, d_off, G, s->dense, s->dense_ref, s->dstart, s->NBo,
-		                   s->low_inst, p->d_bases, p->d_nmask, vdjx_qrows{p->d_quals, p->d_quals2, p->q_split, p->qstride}, s->rec_stride * (u64) s->rank, s->k, (uint8_t*) d_replies);
+		                   s->low_inst, p->d_bases, p->d_nmask, vdjx_qrows{p->d_quals, p->d_quals2, p->q_split, p->qstride}, s->rec_stride * (u64) s->rank, s->k, p->rl, p->ob, (uint8_t*) d_replies);
 	}
 	HIP_TRY(hipStreamSynchronize(st));          // `off` staging dies with this frame
 	HIP_TRY(hipGetLastError());
