@@ -168,6 +168,7 @@ typedef struct {
 	uint64_t np, ns;                    /* reads of the primary / secondary pool, kept or not */
 	int max_len;
 	int rank, nranks;
+	int one_block;                      /* lay the records out as a share (one block), whatever nranks: the `--gpus N` code path */
 } collector;
 
 static uint64_t name_hash(const char* s) {
@@ -204,7 +205,7 @@ static void collector_free(collector* c) {
 /* add_to_buffer (bam_read.c:206-244) for every collected read: forward record, reverse-complement record, both registered.
  * One GPU: two pools, pair ids in extraction order.  A share: one block, primary-pool reads first. */
 static int build_reads(const collector* c, reads_t* r) {
-	const int rl = c->max_len, multi = c->nranks > 1;
+	const int rl = c->max_len, multi = c->one_block;
 	size_t np = 0, ns = 0;
 	for (size_t i = 0; i < c->n; i++) { if (c->v[i].pool == 'P') np++; else ns++; }
 	memset(r, 0, sizeof *r);
@@ -333,12 +334,12 @@ static int load_text(const char* path, collector* col) {
 	return rc;
 }
 
-static int load_reads(const cli* c, reads_t* r, int rank, int nranks) {
+static int load_reads(const cli* c, reads_t* r, int rank, int nranks, int as_share) {
 	const int isbam = bamx_is_bam(c->in);
 	if (isbam < 0) { fprintf(stderr, "cannot open %s\n", c->in); return -1; }
 	collector col;
 	memset(&col, 0, sizeof col);
-	col.rank = rank; col.nranks = nranks; col.max_len = -1;
+	col.rank = rank; col.nranks = nranks; col.max_len = -1; col.one_block = as_share;
 	int rc = isbam ? load_bam(c, &col) : load_text(c->in, &col);
 	if (!rc && col.max_len <= 0) { fprintf(stderr, "Error retrieving read length from: %s\n", c->in); rc = -1; }
 	if (!rc) rc = build_reads(&col, r);
@@ -536,7 +537,7 @@ int main(int argc, char** argv) {
 	if (getenv("VDJX_DUMP_SHARE")) {            /* (test hook, no GPU: "rank,nranks" -> that rank's share: its records on stdout, their places on stderr) */
 		int rk = 0, nr = 1;
 		reads_t sh;
-		if (sscanf(getenv("VDJX_DUMP_SHARE"), "%d,%d", &rk, &nr) != 2 || nr < 1 || rk < 0 || rk >= nr || load_reads(&c, &sh, rk, nr)) return 255;
+		if (sscanf(getenv("VDJX_DUMP_SHARE"), "%d,%d", &rk, &nr) != 2 || nr < 1 || rk < 0 || rk >= nr || load_reads(&c, &sh, rk, nr, nr > 1)) return 255;
 		const size_t R = sh.n_primary + sh.n_secondary;
 		fprintf(stderr, "share\t%d\t%d\trl\t%d\trecords\t%zu\ttotal\t%llu\tpairs\t%u\n", rk, nr, sh.rl, R, (unsigned long long) sh.total_records, sh.n_pairs);
 		for (size_t i = 0; i < R; i++) fprintf(stderr, "rec\t%u\t%u\t%u\t%d\t%d\t%s\n", sh.scan_index[i], sh.reg_rank[i], sh.pair_id[i], sh.read_num[i], sh.is_rc[i], sh.names[sh.pair_id[i]]);
@@ -586,7 +587,7 @@ int main(int argc, char** argv) {
 	if (rank == 0) sigprocmask(SIG_SETMASK, &before, NULL);
 	if (rank == 0) status("START");
 	reads_t rd;
-	if (load_reads(&c, &rd, rank, use_mgpu ? c.gpus : 1)) return 255;
+	if (load_reads(&c, &rd, rank, c.gpus, use_mgpu)) return 255;
 	c.hp.read_length = rd.rl;
 	c.hp.threads = c.threads;
 	if (rank == 0) fprintf(stderr, "read length:\t%d\n", rd.rl);
