@@ -272,7 +272,7 @@ int vdjx_profile_get(vdjx_ctx* ctx, int idx, const char** name, double* total_ms
  * frequency, first sights of nodes and edges, A2:261-320) is computed by every rank over its own records for
  * ALL survivors and reduced: SUM for the counts, MIN for the first sights.
  * All pointers are device pointers owned by the caller.  Call order (brackets = the caller's collectives):
- *   begin -> local -> local_fill -> [all_to_all: directories, counts, partial aggregates] -> merge
+ *   begin -> (count -> [all_reduce MAX] -> geometry ->) local -> local_fill -> [all_to_all: directories, counts, partial aggregates] -> merge
  *   -> queries -> [all_to_all: counts, questions] -> reply -> [all_to_all: answers] -> resolve
  *   -> survivors -> [all_gather] -> edges -> [all_reduce MIN, SUM] -> finish -> free                */
 typedef struct vdjx_shard vdjx_shard;
@@ -281,9 +281,16 @@ int vdjx_shard_begin(vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq
 void vdjx_shard_free(vdjx_shard* s);
 /* bytes per exchanged record: kind 0 partial aggregate (32), 1 question (8), 2 answer (240), 3 survivor (32) */
 size_t vdjx_shard_record_bytes(int kind);
+/* optional, before vdjx_shard_local: this rank's gated k-mer instances (A2:240-259); the ranks compare them [all_reduce MAX] and pass
+ * the largest to vdjx_shard_geometry, so that every rank cuts the hash buckets the one-GPU build would cut for the largest rank.
+ * Without it the bucket count follows a bound from rec_stride (more, smaller buckets: a partition level more at 10 M pairs per rank). */
+int vdjx_shard_count(vdjx_shard* s, uint64_t* gated_instances);
+int vdjx_shard_geometry(vdjx_shard* s, uint64_t agreed_instances);
 /* this rank's partial aggregates, grouped by owner: send_counts[nranks]; *dir_len = hash buckets per owner */
 int vdjx_shard_local(vdjx_shard* s, uint64_t* send_counts, uint32_t* dir_len);
-/* d_dir: u32 [nranks*dir_len] partial aggregates per bucket (owner-major); d_partials: sum(send_counts) records */
+/* d_dir: u32 [nranks*dir_len] partial aggregates per bucket (owner-major); d_partials: sum(send_counts) records, 16-byte aligned.
+ * The aggregates are laid end to end IN d_partials, which must stay valid and unchanged until vdjx_shard_reply has returned (the
+ * answers to the owners' questions are looked up in it: no second copy of a gigabyte per rank). */
 int vdjx_shard_local_fill(vdjx_shard* s, void* d_dir, void* d_partials);
 /* owner: directories and partial aggregates as received (source-major) -> decided k-mers and questions;
  * query_counts[r] = questions for rank r */

@@ -171,6 +171,14 @@ int vdjx_mgpu_kmer_build_pool(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool
 	const size_t W0 = vdjx_shard_record_bytes(0), W1 = vdjx_shard_record_bytes(1), W2 = vdjx_shard_record_bytes(2), W3 = vdjx_shard_record_bytes(3);
 	HIPC(hipSetDevice(m->device));
 	VX(vdjx_shard_begin(ctx, pool, k, mf, mq, me, G, rec_stride, &sh));
+	/* 0. the ranks agree on the bucket geometry: the largest number of gated instances any of them holds */
+	{
+		uint64_t mine = 0, most = 0;
+		VX(vdjx_shard_count(sh, &mine));
+		CX(vdjx_comm_allgather_host(m->cm, &mine, 8, meta));
+		for (int r = 0; r < G; r++) if (meta[r] > most) most = meta[r];
+		VX(vdjx_shard_geometry(sh, most));
+	}
 	/* 1. local aggregation; 2. the bulk exchange: per-bucket directories (their sums are the receive counts), then the partials */
 	uint32_t dl = 0;
 	VX(vdjx_shard_local(sh, send_counts, &dl));

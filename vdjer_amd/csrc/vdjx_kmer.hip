@@ -1011,7 +1011,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 	__shared__ u32 s_cg[MERGE_SLOTS], s_pid[MERGE_SLOTS], s_nsg[MERGE_SLOTS], s_fl[MERGE_SLOTS];
 	__shared__ u32 s_over, s_ndist, s_total, s_ns, s_np, s_sbase, s_pbase;
 	__shared__ u32 s_pend[MERGE_SLOTS / 32];               // bit h & (MERGE_SLOTS - 1): a k-mer with that home slot has a question open
-	const THI EMPTY = (THI) ~(THI) 0;
+	__shared__ u32 s_list[MERGE_SLOTS], s_nocc;            // the slots in use: what is done per k-mer walks these, not the whole table (a third of it)
+	const THI EMPTY = (THI) ~(THI) 0, LOCKED = (THI) (EMPTY - 1);
 	const u32 b = blockIdx.x;
 	const u32 tid = threadIdx.x;
 	// one workgroup merges MG consecutive buckets (their partials are contiguous in every source's list): enough work per table
@@ -1029,7 +1030,9 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 	{
 		if (tid == 0) { s_over = 0; s_ndist = 0; }
 		for (u32 sp = 0; sp < S; sp++) {
-			for (u32 i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE64; s_fl[i] = 0; s_nsg[i] = 0; s_pid[i] = NONE32; }
+			// (only the keys are cleared: the lane that claims a slot sets the slot's other words before it publishes the key)
+			for (u32 i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) s_khi[i] = EMPTY;
+			if (tid == 0) s_nocc = 0;
 			__syncthreads();
 			for (u32 s = 0; s < G; s++) {
 				const u32 off = seg_off[(size_t) s * (NBo + 1) + b * MG], cnt = seg_off[(size_t) s * (NBo + 1) + (b + 1) * MG] - off;
@@ -1037,7 +1040,31 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 					const Partial p = recv[off + i];
 					const u32 h = rd_hash(p.lo, p.hi);
 					if (((h >> 12) & (S - 1)) != sp) continue;
-					const int slot = lds_insert<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, h);
+					// lds_insert, with the claimed slot's words set up under the claim
+					int slot = -1;
+					{
+						const THI hi = (THI) p.hi;
+						u32 sl = h & (MERGE_SLOTS - 1);
+						for (u32 probes = 0; probes < MERGE_SLOTS;) {
+							THI cur = vdjx_peek_acquire(&s_khi[sl]);
+							if (cur == EMPTY) {
+								const THI old = atomicCAS(&s_khi[sl], EMPTY, LOCKED);
+								if (old == EMPTY) {
+									s_klo[sl] = p.lo; s_cg[sl] = 0; s_mg[sl] = NONE64; s_fl[sl] = 0; s_nsg[sl] = 0; s_pid[sl] = NONE32;
+									s_list[atomicAdd(&s_nocc, 1u)] = sl;
+									vdjx_poke_release(&s_khi[sl], hi);
+									slot = (int) sl;
+									break;
+								}
+								cur = old;
+								if (cur != LOCKED) cur = vdjx_peek_acquire(&s_khi[sl]);
+							}
+							if (cur == LOCKED) continue;
+							if (cur == hi && vdjx_peek(&s_klo[sl]) == p.lo) { slot = (int) sl; break; }
+							sl = (sl + 1) & (MERGE_SLOTS - 1);
+							probes++;
+						}
+					}
 					if (slot < 0) { s_over = 1; continue; }
 					atomicAdd(&s_cg[slot], p.cg & ~PART_FLAG);
 					atomicMin((unsigned long long*) &s_mg[slot], (unsigned long long) p.fg);
@@ -1047,20 +1074,18 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 			}
 			__syncthreads();
 			if (s_over) break;
+			const u32 nocc = s_nocc;
 			// decide; the global output counters are bumped ONCE per workgroup (a few addresses shared by every workgroup
 			// serialise in L2: per-k-mer or per-wave bumps cost more than the merge itself)
 			if (tid == 0) { s_ns = 0; s_np = 0; }
 			for (u32 i = tid; i < MERGE_SLOTS / 32; i += MERGE_THREADS) s_pend[i] = 0;
 			__syncthreads();
-			for (u32 i0 = 0; i0 < MERGE_SLOTS; i0 += MERGE_THREADS) {
-				const u32 i = i0 + tid;
-				u32 need = 0, cg = 0;
-				bool live = s_khi[i] != EMPTY;
-				if (live) {
-					cg = s_cg[i];
-					atomicAdd(&s_ndist, 1u);
-					if (cg < cmin) live = false;                 // count >= max(mf, 2): A2:349-352,476
-				}
+			if (tid == 0) s_ndist += nocc;
+			for (u32 e = tid; e < nocc; e += MERGE_THREADS) {
+				const u32 i = s_list[e];
+				u32 need = 0;
+				const u32 cg = s_cg[i];
+				bool live = cg >= cmin;                          // count >= max(mf, 2): A2:349-352,476
 				if (live && !s_fl[i]) {
 					if (s_nsg[i] < 2) live = false;              // one rank holds every gated instance and saw one read only
 					else need |= NEED_SEQ;
@@ -1080,8 +1105,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 				s_pbase = s_np ? atomicAdd(po.n, s_np) : 0;
 			}
 			__syncthreads();
-			for (u32 i0 = 0; i0 < MERGE_SLOTS; i0 += MERGE_THREADS) {
-				const u32 i = i0 + tid;
+			for (u32 e = tid; e < nocc; e += MERGE_THREADS) {
+				const u32 i = s_list[e];
 				if (s_nsg[i] & 0x80000000u) {
 					const u32 pos = s_sbase + (s_nsg[i] & 0x7FFFFFFFu);
 					if (pos < so.cap) {
@@ -2215,8 +2240,10 @@ static void dbg_sync(vdjx_ctx* c, const char* what) {
 
 // Phase A, partition: the gated instances of `pool` as tuples grouped by the top T bits of the k-mer hash (T chosen from their
 // number: ~4096 per bucket).  One host read (the tuple count) sizes everything that follows.
-template <typename TUP, typename A>
-int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k, size_t per_bucket, u64 geometry_instances, GTuples<TUP>* out) {
+// the histogram of the gated instances over the hash buckets, and their number (one host wait): what the cut below starts from
+struct GatedHist { u32 HB = 0, NBH = 0, N = 0; u32* hstart = nullptr; };
+template <typename A>
+int stage_gated_hist(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, size_t per_bucket, u64 geometry_instances, GatedHist* gh) {
 	hipStream_t st = c->stream;
 	const size_t R = pool->n_records;
 	const int P = pool->rl - k + 1;
@@ -2252,10 +2279,27 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
 	const u32 N = *(const u32*) c->h_pin;
-	out->N = N;
 	c->stats["gated_instances"] = N;                // k-mer instances that pass include_kmer (A2:240-259) in this pool
-	// bucket bits from the actual number of gated instances; in the sharded build every rank must cut the same buckets, so there
-	// the geometry follows the common bound `geometry_instances` instead
+	gh->HB = HB; gh->NBH = NBH; gh->N = N; gh->hstart = hstart;
+	return VDJX_OK;
+}
+
+// the cut: the gated instances as tuples, by bucket.  Bucket bits from the actual number of gated instances; in the sharded build every
+// rank must cut the same buckets, so there the geometry follows a number all ranks agree on (`geometry_instances`: the largest count
+// of any rank when they have compared them, a bound from the stride when they have not)
+template <typename TUP, typename A>
+int stage_gated_cut(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k, size_t per_bucket, u64 geometry_instances, const GatedHist& gh, GTuples<TUP>* out) {
+	hipStream_t st = c->stream;
+	const size_t R = pool->n_records;
+	const int P = pool->rl - k + 1;
+	static const size_t dflt = tune("VDJX_GATED_BUCKET", 3072);
+	const size_t per = per_bucket ? per_bucket : dflt;
+	const u32 hb_max = pool->W > 2 ? 14u : 15u;
+	const bool lng = pool->W > 2;
+	const u32 HB = gh.HB, NBH = gh.NBH, N = gh.N;
+	u32* hstart = gh.hstart;
+	size_t rpb;
+	out->N = N;
 	const u64 Ng = geometry_instances ? geometry_instances : (u64) N;
 	static const size_t refine = tune("VDJX_REFINE_TUPLES", 4096);
 	u32 T = 8;
@@ -2324,6 +2368,14 @@ int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_bas
 		                   gcur2, out->t);
 	}
 	return VDJX_OK;
+}
+
+template <typename TUP, typename A>
+int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k, size_t per_bucket, u64 geometry_instances, GTuples<TUP>* out) {
+	GatedHist gh;
+	int rc = stage_gated_hist(c, db, pool, k, per_bucket, geometry_instances, &gh);
+	if (rc) return rc;
+	return stage_gated_cut<TUP>(c, db, pool, rec_base, k, per_bucket, geometry_instances, gh, out);
 }
 
 // Phase A, table + prune per bucket
@@ -2825,6 +2877,15 @@ struct vdjx_shard {
 	u32 mqq = 0, tlow = 0;
 	SurvTable tb{};                                // survivor table of the recount (kept for the edge derivation in finish)
 	int phase = 0;
+	// vdjx_shard_count: the histogram of this rank's gated instances, kept for vdjx_shard_local; the number the ranks agreed on
+	bool have_hist = false;
+	GatedHist gh;
+	u64 agreed = 0;
+	// vdjx_shard_local -> vdjx_shard_local_fill: the partial aggregates by bucket before they are laid end to end
+	Partial* sparse = nullptr;
+	u32* sparse_ref = nullptr;
+	const u32* tuple_bucket_start = nullptr;
+	u32 NBt = 0;
 };
 
 extern "C" int vdjx_shard_begin(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, int rank, int nranks,
@@ -2864,18 +2925,27 @@ extern "C" size_t vdjx_shard_record_bytes(int kind) {
 	return kind == 0 ? sizeof(Partial) : kind == 1 ? sizeof(uint2) : kind == 2 ? REPLY_BYTES : kind == 3 ? sizeof(SurvRec) : 0;
 }
 
+// every rank cuts the SAME buckets.  Without vdjx_shard_count the geometry follows a bound all ranks know (a quarter of the stride's
+// instances: the gated fraction of real pools lies between a sixth and a half), not the local count
+static u64 shard_geometry_bound(const vdjx_shard* s) {
+	const int P = s->pool->rl - s->k + 1;
+	return std::max<u64>(1, s->rec_stride * (u64) P / 4);
+}
+
 template <typename TUP>
 static int shard_local_impl(vdjx_shard* s) {
 	vdjx_ctx* c = s->c;
 	hipStream_t st = c->stream;
 	PersistAlloc db(c);
-	const int P = s->pool->rl - s->k + 1;
 	const u64 rec_base = s->rec_stride * (u64) s->rank;
-	// every rank cuts the SAME buckets: the geometry follows a bound all ranks know (a quarter of the stride's instances:
-	// the gated fraction of real pools lies between a sixth and a half), not the local count
 	GTuples<TUP> t;
-	const u64 geom = std::max<u64>(1, s->rec_stride * (u64) P / 4);
-	int rc = stage_gated_partition<TUP>(c, db, s->pool, rec_base, s->k, 0, geom, &t);
+	int rc = VDJX_OK;
+	if (!s->have_hist) rc = stage_gated_hist(c, db, s->pool, s->k, 0, shard_geometry_bound(s), &s->gh);
+	if (rc) return rc;
+	s->have_hist = true;
+	// (the ranks' largest count if they compared them, vdjx_shard_count + vdjx_shard_geometry: buckets of the size the one-GPU build
+	// cuts -- at 10 M pairs per rank half as many as the bound asks for, and one partition level less)
+	rc = stage_gated_cut<TUP>(c, db, s->pool, rec_base, s->k, 0, s->agreed ? s->agreed : shard_geometry_bound(s), s->gh, &t);
 	if (rc) return rc;
 	if (t.NB < (u32) s->nranks) { vdjx_set_error("vdjx_shard_local: fewer buckets (%u) than ranks", t.NB); return VDJX_ELIMIT; }
 	// buckets per owner; the directory every rank sends has nranks * NBo entries (the ones past the last bucket are empty)
@@ -2916,12 +2986,10 @@ static int shard_local_impl(vdjx_shard* s) {
 	if (err) { vdjx_set_error("k_gated_local: %u buckets could not be split to fit LDS", err); return VDJX_EHIP; }
 	s->src_base.assign(pick.begin(), pick.end());        // reused below as "what goes to owner o" until the merge overwrites it
 	s->n_dense = pick[G];
-	HIP_TRY(db.alloc(&s->dense, (size_t) s->n_dense + 1));
 	HIP_TRY(db.alloc(&s->dense_ref, (size_t) s->n_dense + 1));
-	{
-		vdjx_prof_scope ps(c, "k_compact_partials");
-		hipLaunchKernelGGL(k_compact_partials, dim3(t.NB), dim3(256), 0, st, sparse, sparse_ref, t.bucket_start, s->nd, s->dstart, s->dense, s->dense_ref);
-	}
+	// (the aggregates are laid end to end by vdjx_shard_local_fill, straight into the caller's send buffer)
+	s->sparse = sparse; s->sparse_ref = sparse_ref; s->tuple_bucket_start = t.bucket_start; s->NBt = t.NB;
+	s->dense = nullptr;
 	return VDJX_OK;
 }
 
@@ -2944,12 +3012,44 @@ extern "C" int vdjx_shard_local(vdjx_shard* s, uint64_t* send_counts, uint32_t* 
 extern "C" int vdjx_shard_local_fill(vdjx_shard* s, void* d_dir, void* d_partials) {
 	if (!s || s->phase < 1) { vdjx_set_error("vdjx_shard_local_fill: call vdjx_shard_local first"); return VDJX_ESTATE; }
 	if (!d_dir || (s->n_dense && !d_partials)) { vdjx_set_error("vdjx_shard_local_fill: NULL buffer"); return VDJX_EINVAL; }
+	if (((uintptr_t) d_partials & 15u) != 0) { vdjx_set_error("vdjx_shard_local_fill: d_partials must be 16-byte aligned"); return VDJX_EINVAL; }
 	HIP_TRY(hipSetDevice(s->c->device));
 	vdjx_clear_errors();
 	hipStream_t st = s->c->stream;
 	HIP_TRY(hipMemcpyAsync(d_dir, s->nd, (size_t) s->NBf * 4, hipMemcpyDeviceToDevice, st));
-	if (s->n_dense) HIP_TRY(hipMemcpyAsync(d_partials, s->dense, (size_t) s->n_dense * sizeof(Partial), hipMemcpyDeviceToDevice, st));
+	if (s->n_dense) {
+		// the aggregates of every bucket end to end, in the caller's buffer -- which from here on IS this rank's list of them: the
+		// answers to the owners' questions are looked up in it (vdjx_shard_reply)
+		vdjx_prof_scope ps(s->c, "k_compact_partials");
+		hipLaunchKernelGGL(k_compact_partials, dim3(s->NBt), dim3(256), 0, st, s->sparse, s->sparse_ref, s->tuple_bucket_start, s->nd, s->dstart, (Partial*) d_partials, s->dense_ref);
+	}
+	s->dense = (Partial*) d_partials;
 	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipGetLastError());
+	return VDJX_OK;
+}
+
+// this rank's gated instances (one pass over its records); the ranks compare these numbers (MAX) and hand the largest to
+// vdjx_shard_geometry, so that all cut the buckets the one-GPU build would cut for the largest rank.  Optional.
+extern "C" int vdjx_shard_count(vdjx_shard* s, uint64_t* gated_instances) {
+	if (!s || !gated_instances) { vdjx_set_error("vdjx_shard_count: NULL argument"); return VDJX_EINVAL; }
+	if (s->phase != 0) { vdjx_set_error("vdjx_shard_count: call it before vdjx_shard_local"); return VDJX_ESTATE; }
+	HIP_TRY(hipSetDevice(s->c->device));
+	vdjx_clear_errors();
+	if (!s->have_hist) {
+		PersistAlloc db(s->c);
+		const int rc = stage_gated_hist(s->c, db, s->pool, s->k, 0, shard_geometry_bound(s), &s->gh);
+		if (rc) return rc;
+		s->have_hist = true;
+	}
+	*gated_instances = s->gh.N;
+	return VDJX_OK;
+}
+extern "C" int vdjx_shard_geometry(vdjx_shard* s, uint64_t agreed_instances) {
+	if (!s) { vdjx_set_error("vdjx_shard_geometry: NULL argument"); return VDJX_EINVAL; }
+	if (s->phase != 0) { vdjx_set_error("vdjx_shard_geometry: call it before vdjx_shard_local"); return VDJX_ESTATE; }
+	if (agreed_instances < s->gh.N) { vdjx_set_error("vdjx_shard_geometry: %llu is less than this rank's own %u gated instances", (unsigned long long) agreed_instances, s->gh.N); return VDJX_EINVAL; }
+	s->agreed = agreed_instances ? agreed_instances : 1;
 	return VDJX_OK;
 }
 
@@ -3074,7 +3174,7 @@ extern "C" int vdjx_shard_queries(vdjx_shard* s, void* d_out) {
 // d_replies = sum(counts) records of vdjx_shard_record_bytes(2), same order
 extern "C" int vdjx_shard_reply(vdjx_shard* s, const void* d_queries, const uint64_t* counts, void* d_replies) {
 	if (!s || !counts) { vdjx_set_error("vdjx_shard_reply: NULL argument"); return VDJX_EINVAL; }
-	if (s->phase < 1) { vdjx_set_error("vdjx_shard_reply: call vdjx_shard_local first"); return VDJX_ESTATE; }
+	if (s->phase < 1 || (s->n_dense && !s->dense)) { vdjx_set_error("vdjx_shard_reply: call vdjx_shard_local and vdjx_shard_local_fill first"); return VDJX_ESTATE; }
 	vdjx_ctx* c = s->c;
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_clear_errors();

@@ -41,6 +41,8 @@ def _bind(L):
     L.vdjx_shard_free.restype = None
     L.vdjx_shard_record_bytes.argtypes = [C.c_int]
     L.vdjx_shard_record_bytes.restype = C.c_size_t
+    L.vdjx_shard_count.argtypes = [vp, u64p]
+    L.vdjx_shard_geometry.argtypes = [vp, C.c_uint64]
     L.vdjx_shard_local.argtypes = [vp, u64p, C.POINTER(C.c_uint32)]
     L.vdjx_shard_local_fill.argtypes = [vp, vp, vp]
     L.vdjx_shard_merge.argtypes = [vp, vp, vp, u64p, u64p]
@@ -79,8 +81,18 @@ class HipShardEngine:
     def _u64(self, values):
         return (C.c_uint64 * self.world)(*[int(v) for v in values])
 
+    def count(self) -> int:
+        """this rank's gated k-mer instances (the ranks agree on the largest: geometry())"""
+        n = C.c_uint64()
+        check(self.L.vdjx_shard_count(self.h, C.byref(n)), "vdjx_shard_count")
+        return int(n.value)
+
+    def geometry(self, agreed: int) -> None:
+        check(self.L.vdjx_shard_geometry(self.h, int(agreed)), "vdjx_shard_geometry")
+
     def local(self):
-        """-> (partials per owner [G], directory int32 [G*dir_len], partial aggregates [n, 32] uint8)"""
+        """-> (partials per owner [G], directory int32 [G*dir_len], partial aggregates [n, 32] uint8; the engine keeps reading the
+        aggregates from that tensor until reply() has returned)"""
         t = self.torch
         cnt, dl = (C.c_uint64 * self.world)(), C.c_uint32()
         check(self.L.vdjx_shard_local(self.h, cnt, C.byref(dl)), "vdjx_shard_local")
@@ -88,6 +100,7 @@ class HipShardEngine:
         d = t.empty(self.world * int(dl.value), dtype=t.int32, device=self.dev)
         parts = t.empty((int(counts.sum()), self.W[0]), dtype=t.uint8, device=self.dev)
         check(self.L.vdjx_shard_local_fill(self.h, self._dp(d), self._dp(parts)), "vdjx_shard_local_fill")
+        self._keep.append(parts)
         return counts, d, parts
 
     def merge(self, recv_dir, recv_parts, recv_counts):
@@ -376,6 +389,13 @@ class ShardedHotPath:
                 cm.sync()
                 return got.cpu().numpy()
 
+            # 0. the ranks agree on the bucket geometry: the largest number of gated instances any of them holds
+            if hasattr(eng, "count"):
+                nmax = t.tensor([eng.count()], dtype=t.int64, device=self.dev)
+                if G > 1:
+                    cm.all_reduce(nmax, dist.ReduceOp.MAX)
+                eng.geometry(int(nmax.item()))
+                lap("count")
             # 1. local aggregation; 2. the bulk exchange: per-bucket directory (its sums are the receive counts), then the
             #    partial aggregates themselves
             send_counts, sdir, sparts = eng.local()
