@@ -1011,8 +1011,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 	__shared__ u32 s_cg[MERGE_SLOTS], s_pid[MERGE_SLOTS], s_nsg[MERGE_SLOTS], s_fl[MERGE_SLOTS];
 	__shared__ u32 s_over, s_ndist, s_total, s_ns, s_np, s_sbase, s_pbase;
 	__shared__ u32 s_pend[MERGE_SLOTS / 32];               // bit h & (MERGE_SLOTS - 1): a k-mer with that home slot has a question open
-	__shared__ u32 s_list[MERGE_SLOTS], s_nocc;            // the slots in use: what is done per k-mer walks these, not the whole table (a third of it)
-	const THI EMPTY = (THI) ~(THI) 0, LOCKED = (THI) (EMPTY - 1);
+	const THI EMPTY = (THI) ~(THI) 0;
 	const u32 b = blockIdx.x;
 	const u32 tid = threadIdx.x;
 	// one workgroup merges MG consecutive buckets (their partials are contiguous in every source's list): enough work per table
@@ -1025,14 +1024,12 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 	const u32 total = s_total;
 	if (total == 0) return;
 	u32 S = 1;
-	while ((u64) S * (MERGE_SLOTS / 2) < total) S <<= 1;
+	while ((u64) S * (MERGE_SLOTS * 3 / 4) < total) S <<= 1;      // (a sub-pass's k-mers cannot outnumber its partials: the table never fills)
 	S *= s_mult;
 	{
 		if (tid == 0) { s_over = 0; s_ndist = 0; }
 		for (u32 sp = 0; sp < S; sp++) {
-			// (only the keys are cleared: the lane that claims a slot sets the slot's other words before it publishes the key)
-			for (u32 i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) s_khi[i] = EMPTY;
-			if (tid == 0) s_nocc = 0;
+			for (u32 i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE64; s_fl[i] = 0; s_nsg[i] = 0; s_pid[i] = NONE32; }
 			__syncthreads();
 			for (u32 s = 0; s < G; s++) {
 				const u32 off = seg_off[(size_t) s * (NBo + 1) + b * MG], cnt = seg_off[(size_t) s * (NBo + 1) + (b + 1) * MG] - off;
@@ -1040,31 +1037,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 					const Partial p = recv[off + i];
 					const u32 h = rd_hash(p.lo, p.hi);
 					if (((h >> 12) & (S - 1)) != sp) continue;
-					// lds_insert, with the claimed slot's words set up under the claim
-					int slot = -1;
-					{
-						const THI hi = (THI) p.hi;
-						u32 sl = h & (MERGE_SLOTS - 1);
-						for (u32 probes = 0; probes < MERGE_SLOTS;) {
-							THI cur = vdjx_peek_acquire(&s_khi[sl]);
-							if (cur == EMPTY) {
-								const THI old = atomicCAS(&s_khi[sl], EMPTY, LOCKED);
-								if (old == EMPTY) {
-									s_klo[sl] = p.lo; s_cg[sl] = 0; s_mg[sl] = NONE64; s_fl[sl] = 0; s_nsg[sl] = 0; s_pid[sl] = NONE32;
-									s_list[atomicAdd(&s_nocc, 1u)] = sl;
-									vdjx_poke_release(&s_khi[sl], hi);
-									slot = (int) sl;
-									break;
-								}
-								cur = old;
-								if (cur != LOCKED) cur = vdjx_peek_acquire(&s_khi[sl]);
-							}
-							if (cur == LOCKED) continue;
-							if (cur == hi && vdjx_peek(&s_klo[sl]) == p.lo) { slot = (int) sl; break; }
-							sl = (sl + 1) & (MERGE_SLOTS - 1);
-							probes++;
-						}
-					}
+					const int slot = lds_insert<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, h);
 					if (slot < 0) { s_over = 1; continue; }
 					atomicAdd(&s_cg[slot], p.cg & ~PART_FLAG);
 					atomicMin((unsigned long long*) &s_mg[slot], (unsigned long long) p.fg);
@@ -1074,18 +1047,20 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 			}
 			__syncthreads();
 			if (s_over) break;
-			const u32 nocc = s_nocc;
 			// decide; the global output counters are bumped ONCE per workgroup (a few addresses shared by every workgroup
 			// serialise in L2: per-k-mer or per-wave bumps cost more than the merge itself)
 			if (tid == 0) { s_ns = 0; s_np = 0; }
 			for (u32 i = tid; i < MERGE_SLOTS / 32; i += MERGE_THREADS) s_pend[i] = 0;
 			__syncthreads();
-			if (tid == 0) s_ndist += nocc;
-			for (u32 e = tid; e < nocc; e += MERGE_THREADS) {
-				const u32 i = s_list[e];
-				u32 need = 0;
-				const u32 cg = s_cg[i];
-				bool live = cg >= cmin;                          // count >= max(mf, 2): A2:349-352,476
+			for (u32 i0 = 0; i0 < MERGE_SLOTS; i0 += MERGE_THREADS) {
+				const u32 i = i0 + tid;
+				u32 need = 0, cg = 0;
+				bool live = s_khi[i] != EMPTY;
+				if (live) {
+					cg = s_cg[i];
+					atomicAdd(&s_ndist, 1u);
+					if (cg < cmin) live = false;                 // count >= max(mf, 2): A2:349-352,476
+				}
 				if (live && !s_fl[i]) {
 					if (s_nsg[i] < 2) live = false;              // one rank holds every gated instance and saw one read only
 					else need |= NEED_SEQ;
@@ -1105,8 +1080,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 				s_pbase = s_np ? atomicAdd(po.n, s_np) : 0;
 			}
 			__syncthreads();
-			for (u32 e = tid; e < nocc; e += MERGE_THREADS) {
-				const u32 i = s_list[e];
+			for (u32 i0 = 0; i0 < MERGE_SLOTS; i0 += MERGE_THREADS) {
+				const u32 i = i0 + tid;
 				if (s_nsg[i] & 0x80000000u) {
 					const u32 pos = s_sbase + (s_nsg[i] & 0x7FFFFFFFu);
 					if (pos < so.cap) {

@@ -23,6 +23,7 @@ host-side, not sharded).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -380,6 +381,8 @@ class ShardedHotPath:
         eng.begin(pool, k, mf, mq, r, G, stride)
         try:
             def exchange(send, ins, outs):
+                if G == 1:            # nothing to move: what a rank keeps for itself is its send buffer (with peers, a 1/G-th of it is copied)
+                    return send
                 recv = t.empty((int(sum(outs)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
                 cm.all_to_all_v(send, [int(v) for v in ins], recv, [int(v) for v in outs])
                 return recv
@@ -390,7 +393,7 @@ class ShardedHotPath:
                 return got.cpu().numpy()
 
             # 0. the ranks agree on the bucket geometry: the largest number of gated instances any of them holds
-            if hasattr(eng, "count"):
+            if hasattr(eng, "count") and not os.environ.get("VDJX_SHARD_NO_AGREE"):      # (the variable: the stride's bound instead, for comparison)
                 nmax = t.tensor([eng.count()], dtype=t.int64, device=self.dev)
                 if G > 1:
                     cm.all_reduce(nmax, dist.ReduceOp.MAX)
