@@ -228,23 +228,14 @@ int bamx_read1(bamx_file* f, bamx_rec* r) {
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
-/* BAI (hts.c:1159-1210) and the region iterator (hts.c:1372-1487, 1539-1580); min_shift 14, 5 levels                  */
+/* BAI (SAM specification 5.2: bins with their chunks, the linear index) and the region query (5.1.3, 5.3)             */
 /* ------------------------------------------------------------------------------------------------------------------ */
 typedef struct { uint64_t u, v; } chunk_t;
-typedef struct { uint32_t bin; int n; chunk_t* list; uint64_t loff; } bin_t;
+typedef struct { uint32_t bin; int n; chunk_t* list; } bin_t;
 typedef struct { int n_bin; bin_t* bins; int n_intv; uint64_t* ioff; } refidx_t;
 struct bamx_index { int n_ref; refidx_t* ref; };
 #define BAI_N_LVLS 5
 #define BAI_MIN_SHIFT 14
-#define BAI_N_BINS 37449u                     /* ((1 << 18) - 1) / 7 */
-
-static int bin_first(int l) { return ((1 << ((l << 1) + l)) - 1) / 7; }
-static int bin_parent(int b) { return (b - 1) >> 3; }
-static int bin_bot(int bin) {                 /* hts_bin_bot */
-	int l = 0, b;
-	for (b = bin; b; ++l, b = bin_parent(b)) {}
-	return (bin - bin_first(l)) << ((BAI_N_LVLS - l) * 3);
-}
 
 static const bin_t* find_bin(const refidx_t* r, uint32_t bin) {
 	for (int i = 0; i < r->n_bin; i++) if (r->bins[i].bin == bin) return &r->bins[i];
@@ -294,14 +285,6 @@ bamx_index* bamx_index_load(const char* bam_path) {
 			r->ioff[j] = rd_u64(b);
 		}
 		for (int j = 1; j < r->n_intv; j++) if (r->ioff[j] == 0) r->ioff[j] = r->ioff[j - 1];     /* "fill missing values" */
-		for (int j = 0; j < r->n_bin; j++) {                                                          /* update_loff */
-			bin_t* p = &r->bins[j];
-			if (p->bin < BAI_N_BINS + 0u) {
-				const int bot = bin_bot((int) p->bin);
-				p->loff = bot < r->n_intv ? r->ioff[bot] : 0;
-			} else
-				p->loff = 0;
-		}
 	}
 	fclose(fp);
 	return ix;
@@ -323,32 +306,46 @@ void bamx_index_free(bamx_index* ix) {
 	free(ix);
 }
 
-/* hts_parse_reg (hts.c:1490-1519): returns the offset where the name ends */
-static size_t parse_reg(const char* s, int* beg, int* end) {
-	int i, k, l, name_end;
-	*beg = *end = -1;
-	name_end = l = (int) strlen(s);
-	for (i = l - 1; i >= 0; --i) if (s[i] == ':') break;
-	if (i >= 0) name_end = i;
-	if (name_end < l) {
-		int n_hyphen = 0;
-		for (i = name_end + 1; i < l; ++i) {
-			if (s[i] == '-') ++n_hyphen;
-			else if (!isdigit((unsigned char) s[i]) && s[i] != ',') break;
-		}
-		if (i < l || n_hyphen > 1) name_end = l;
+/* A samtools region, "RNAME[:START[-END]]" (SAM specification / samtools(1): 1-based, END inclusive, thousands separators allowed in
+ * the numbers, a missing END = up to the end of the reference).  Written from that description: the part after the LAST colon is a
+ * coordinate range only if it reads as one (digits and commas, at most one '-', START <= END); otherwise the whole string is the
+ * reference name (names may hold colons).  Result: 0-based half-open [*beg, *end), and the length of the name. */
+static int region_number(const char* s, size_t n, long long* out) {
+	long long v = 0;
+	int digits = 0;
+	for (size_t i = 0; i < n; i++) {
+		if (s[i] == ',') continue;
+		if (s[i] < '0' || s[i] > '9') return -1;
+		if (v > (long long) INT_MAX) return -1;
+		v = v * 10 + (s[i] - '0');
+		digits++;
 	}
-	if (name_end < l) {
-		char tmp[64];
-		for (i = name_end + 1, k = 0; i < l && k < 62; ++i) if (s[i] != ',') tmp[k++] = s[i];
-		tmp[k] = 0;
-		char* q;
-		if ((*beg = (int) strtol(tmp, &q, 10) - 1) < 0) *beg = 0;
-		*end = *q ? (int) strtol(q + 1, &q, 10) : INT_MAX;
-		if (*beg > *end) name_end = l;
+	*out = v;
+	return digits;
+}
+static size_t parse_region(const char* s, int* beg, int* end) {
+	const size_t len = strlen(s);
+	*beg = 0; *end = INT_MAX;
+	const char* colon = strrchr(s, ':');
+	if (!colon) return len;
+	const char* range = colon + 1;
+	const size_t rn = len - (size_t) (range - s);
+	const char* dash = (const char*) memchr(range, '-', rn);
+	long long a = 0, b = (long long) INT_MAX;
+	const int da = region_number(range, dash ? (size_t) (dash - range) : rn, &a);
+	if (da < 0) return len;                                      /* not a range: the colon belongs to the name */
+	if (dash) {
+		const int db = region_number(dash + 1, rn - (size_t) (dash + 1 - range), &b);
+		if (db < 0) return len;
+		if (db == 0) b = 0;                                      /* "chr:5-" reads an empty END as 0 with strtol: START > END, a name */
 	}
-	if (name_end == l) { *beg = 0; *end = INT_MAX; }
-	return (size_t) name_end;
+	long long lo = a - 1;                                        /* 1-based START -> 0-based; START 0 (or none) means the first base */
+	if (lo < 0) lo = 0;
+	if (b > (long long) INT_MAX) b = INT_MAX;
+	if (lo > b) return len;
+	*beg = (int) lo;
+	*end = (int) b;
+	return (size_t) (colon - s);
 }
 
 static int cmp_chunk(const void* a, const void* b) {
@@ -358,9 +355,15 @@ static int cmp_chunk(const void* a, const void* b) {
 	return x->v < y->v ? -1 : x->v > y->v;
 }
 
+/* The bins that may hold alignments overlapping [beg, end), SAM specification section 5.3 (the UCSC binning scheme with a 16 kb
+ * minimum interval and five levels: bin 0 spans 512 Mb; the levels start at bins 1, 9, 73, 585 and 4681 with intervals of 64 Mb,
+ * 8 Mb, 1 Mb, 128 kb and 16 kb). */
+static const int LEVEL_FIRST[6] = {0, 1, 9, 73, 585, 4681};
+static const int LEVEL_SHIFT[6] = {29, 26, 23, 20, 17, 14};
+
 long bamx_query(bamx_file* f, const bamx_index* ix, const char* region, void (*cb)(const bamx_rec*, void*), void* ud) {
 	int beg, end;
-	const size_t ne = parse_reg(region, &beg, &end);
+	const size_t ne = parse_region(region, &beg, &end);
 	char name[512];
 	if (ne >= sizeof name) return fail("region name too long");
 	memcpy(name, region, ne);
@@ -368,74 +371,64 @@ long bamx_query(bamx_file* f, const bamx_index* ix, const char* region, void (*c
 	int tid = name2id(f, name);
 	if (tid < 0) tid = name2id(f, region);
 	if (tid < 0) return fail("region %s: the reference name is not in the BAM header (the reference crashes here: NULL iterator)", region);
-	/* hts_itr_query */
-	if (beg < 0) beg = 0;
-	if (end < beg || tid >= ix->n_ref) return fail("region %s: no index for that reference (NULL iterator in the reference)", region);
+	if (tid >= ix->n_ref) return fail("region %s: no index for that reference (NULL iterator in the reference)", region);
 	const refidx_t* r = &ix->ref[tid];
-	int bin = bin_first(BAI_N_LVLS) + (beg >> BAI_MIN_SHIFT);
-	const bin_t* hit = NULL;
-	do {
-		hit = find_bin(r, (uint32_t) bin);
-		if (hit) break;
-		const int first = (bin_parent(bin) << 3) + 1;
-		if (bin > first) --bin;
-		else bin = bin_parent(bin);
-	} while (bin);
-	if (bin == 0) hit = find_bin(r, 0);
-	const uint64_t min_off = hit ? hit->loff : 0;
-	/* reg2bins + collect chunks */
+	/* the linear index (section 5.1.3): entry w is the smallest file offset of an alignment that overlaps the 16 kb window w.  In a
+	 * coordinate-sorted file no alignment that overlaps [beg, end) starts before the first one overlapping beg's window: chunks
+	 * that END at or before that offset hold nothing for this region. */
+	uint64_t min_off = 0;
+	if (r->n_intv > 0) {
+		const int w = beg >> BAI_MIN_SHIFT;
+		min_off = r->ioff[w < r->n_intv ? w : r->n_intv - 1];
+	}
+	/* candidate chunks: those of every bin that can hold an overlapping alignment */
 	size_t cap = 64, n_off = 0;
 	chunk_t* off = (chunk_t*) malloc(cap * sizeof(chunk_t));
+	if (!off) return fail("out of memory");
 	if (beg < end) {
-		int64_t e = end;
-		int s = BAI_MIN_SHIFT + (BAI_N_LVLS << 1) + BAI_N_LVLS;
-		if (e >= 1LL << s) e = 1LL << s;
-		--e;
-		for (int l = 0, t = 0; l <= BAI_N_LVLS; s -= 3, t += 1 << ((l << 1) + l), ++l) {
-			const int b0 = t + (int) (beg >> s), e0 = t + (int) (e >> s);
-			for (int bi = b0; bi <= e0; bi++) {
+		long long last = (long long) end - 1;                                 /* last base of the region */
+		if (last >= (1LL << 29)) last = (1LL << 29) - 1;                       /* the scheme addresses 512 Mb */
+		for (int lvl = 0; lvl <= BAI_N_LVLS && (long long) beg < (1LL << 29); lvl++) {
+			const int from = LEVEL_FIRST[lvl] + (beg >> LEVEL_SHIFT[lvl]), to = LEVEL_FIRST[lvl] + (int) (last >> LEVEL_SHIFT[lvl]);
+			for (int bi = from; bi <= to; bi++) {
 				const bin_t* p = find_bin(r, (uint32_t) bi);
 				if (!p) continue;
-				for (int j = 0; j < p->n; j++)
-					if (p->list[j].v > min_off) {
-						if (n_off == cap) { cap *= 2; off = (chunk_t*) realloc(off, cap * sizeof(chunk_t)); }
-						off[n_off++] = p->list[j];
+				for (int j = 0; j < p->n; j++) {
+					if (p->list[j].v <= min_off) continue;
+					if (n_off == cap) {
+						cap *= 2;
+						chunk_t* q = (chunk_t*) realloc(off, cap * sizeof(chunk_t));
+						if (!q) { free(off); return fail("out of memory"); }
+						off = q;
 					}
+					off[n_off++] = p->list[j];
+				}
 			}
 		}
 	}
 	long n_ret = 0;
 	if (n_off) {
+		/* one pass over the file: the chunks in file order, every stretch covered by any of them read once.  Two chunks are read as
+		 * one when they overlap, touch, or the gap between them lies inside one compressed block (a seek there would decompress the
+		 * same block again; what the gap holds fails the overlap test below like anything else that does not belong). */
 		qsort(off, n_off, sizeof(chunk_t), cmp_chunk);
-		size_t l = 0;
-		for (size_t i = 1; i < n_off; ++i) if (off[l].v < off[i].v) off[++l] = off[i];      /* completely contained blocks */
-		n_off = l + 1;
-		for (size_t i = 1; i < n_off; ++i) if (off[i - 1].v >= off[i].u) off[i - 1].v = off[i].u;   /* overlaps */
-		l = 0;
-		for (size_t i = 1; i < n_off; ++i) {                                                  /* adjacent blocks */
-			if (off[l].v >> 16 == off[i].u >> 16) off[l].v = off[i].v;
-			else off[++l] = off[i];
+		size_t m = 0;
+		for (size_t i = 1; i < n_off; i++) {
+			if (off[i].u <= off[m].v || (off[i].u >> 16) == (off[m].v >> 16)) { if (off[i].v > off[m].v) off[m].v = off[i].v; }
+			else off[++m] = off[i];
 		}
-		n_off = l + 1;
-		/* hts_itr_next, repeated until it returns < 0 */
+		n_off = m + 1;
 		static bamx_rec rec;
-		long i_chunk = -1;
-		uint64_t curr_off = 0;
-		for (;;) {
-			if (curr_off == 0 || curr_off >= off[i_chunk].v) {
-				if (i_chunk == (long) n_off - 1) break;
-				if (i_chunk < 0 || off[i_chunk].v != off[i_chunk + 1].u) {
-					if (bamx_seek(f, off[i_chunk + 1].u)) { free(off); return -2; }
-					curr_off = bamx_tell(f);
-				}
-				++i_chunk;
+		int done = 0;
+		for (size_t i = 0; i < n_off && !done; i++) {
+			if (bamx_tell(f) != off[i].u && bamx_seek(f, off[i].u)) { free(off); return -2; }
+			while (bamx_tell(f) < off[i].v) {
+				const int rc = bamx_read1(f, &rec);
+				if (rc < -1) { free(off); return rc; }
+				if (rc < 0) { done = 1; break; }                                /* end of file */
+				if (rec.tid != tid || rec.pos >= end) { done = 1; break; }      /* sorted by coordinate: nothing further on can overlap */
+				if (rec.end > beg && rec.pos < end) { n_ret++; if (cb) cb(&rec, ud); }
 			}
-			const int rc = bamx_read1(f, &rec);
-			if (rc < -1) { free(off); return rc; }
-			if (rc < 0) break;
-			curr_off = bamx_tell(f);
-			if (rec.tid != tid || rec.pos >= end) break;
-			if (rec.end > beg && end > rec.pos) { n_ret++; if (cb) cb(&rec, ud); }
 		}
 	}
 	free(off);

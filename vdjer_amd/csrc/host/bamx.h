@@ -1,11 +1,14 @@
 /* bamx -- BAM/BGZF/BAI reading and V'DJer's read extraction in plain C over zlib.
  *
- * Replaces, for the `vdjer --in <bam>` path: get_read_length (bam_read.c:264-292) and extract (bam_read.c:294-446)
- * together with the parts of htslib 1.2.1 they reach: bgzf_read/seek/tell (bgzf.c:547-574, 847-866), bam_hdr_read,
- * bam_read1, the BAI loader (hts.c:1159-1210, update_loff :857-887), hts_itr_query / hts_itr_next (hts.c:1372-1487,
- * 1539-1580) and hts_parse_reg (hts.c:1490-1519).  The reference side of this row cannot be compiled here (htslib needs
- * its own build system and a generated header), so the extraction order rules below are a restatement checked against an
- * independent model (tests/bam_model.py); the decoding is checked on BAM/BAI files written by real samtools.
+ * Replaces, for the `vdjer --in <bam>` path: get_read_length (bam_read.c:264-292) and extract (bam_read.c:294-446) together with
+ * what they reach into htslib 1.2.1 for: sequential BAM reading (bgzf_read/seek/tell, bam_hdr_read, bam_read1), the BAI index and the
+ * region iterator behind sam_itr_querys / sam_itr_next.  The file formats and the region query are written from the SAM/BAM
+ * specification (BGZF 4.1, BAM 4.2, BAI 5.2, the binning scheme 5.3, region strings as samtools(1) describes them); what is taken from
+ * the reference is BEHAVIOUR that its extraction depends on: where a finished region query leaves the file (extract's sequential pass
+ * starts there, bam_read.c:346-374), and which records it returns.  The reference side of this row cannot be compiled here -- hts.c
+ * includes a version.h that only the vendored Makefile generates, and the rules of this build forbid both running that Makefile and
+ * writing a stand-in -- so the extraction's order rules are a restatement checked against an independent model (tests/bam_model.py);
+ * the decoding and the region query are checked on BAM/BAI files written by real samtools (tests/golden/bam).
  */
 #ifndef VDJX_BAMX_H
 #define VDJX_BAMX_H
