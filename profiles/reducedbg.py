@@ -5,6 +5,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["VDJX_RD_DBG"] = sys.argv[1]
+# the phase switches live in the ablation build only (make -C vdjer_amd/csrc ablate)
+os.environ.setdefault("VDJX_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vdjer_amd", "libvdjx_ablate.so"))
 import torch  # noqa: E402
 
 import bench  # noqa: E402

@@ -7,8 +7,9 @@
 # filter of all 16 offsets probed up front as independent loads (-> 9.3 ms: 640 M probes instead of 250 M), and a first chain-order
 # renumbering over the SINGLE-successor links (8.5 ms: in deep clones every k-mer has surviving error branches, so those chains
 # are one or two nodes long where the instances are).  The heavy-path chains + run items of r02e are what that evidence led to.
+# (the switches live in the ablation build only: make -C vdjer_amd/csrc ablate)
 for d in 1 2 8 11; do
-  VDJX_WALK_DBG=$d timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu --parity-sample 0 --no-e2e 2>/dev/null | python3 -c "
+  VDJX_LIB_PATH=vdjer_amd/libvdjx_ablate.so VDJX_BENCH_ABLATION=1 VDJX_WALK_DBG=$d timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu --parity-sample 0 --no-e2e 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernels_ms_per_step']; print('dbg', $d, 'walk_dbg', k.get('k_walk_dbg'), 'walk', k.get('k_walk_items'))"
 done

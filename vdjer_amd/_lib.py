@@ -7,7 +7,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvdjx.so")
+# VDJX_LIB_PATH: another build of the same library (profiles/: the -DVDJX_ABLATE build, `make -C vdjer_amd/csrc ablate`)
+LIB_PATH = os.environ.get("VDJX_LIB_PATH") or os.path.join(_HERE, "libvdjx.so")
 _lib = None
 
 # every symbol include/vdjx.h declares

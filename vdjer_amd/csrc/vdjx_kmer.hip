@@ -591,7 +591,14 @@ __global__ __launch_bounds__(RD_THREADS, sizeof(TUP) == 16 ? RD_WAVES : RD_WAVES
                                                              const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                              vdjx_qrows quals, int rl, int ob, int k, u64 rec_base,
                                                              u32 mf, u32 cmin, u32 mqq, u32 tlow, SurvOutG so,
-                                                             u64* __restrict__ g_distinct, u32* __restrict__ g_err, u32 dbg) {
+                                                             u64* __restrict__ g_distinct, u32* __restrict__ g_err, u32 dbg_in) {
+	// the kernel's phase-by-phase ablation (profiles/reducedbg.py) exists only in the -DVDJX_ABLATE build (make -C vdjer_amd/csrc ablate);
+	// the shipped kernel keeps one switch, 9 = take the rescan path (the tests' way into a fallback real pools rarely reach)
+#ifdef VDJX_ABLATE
+	const u32 dbg = dbg_in;
+#else
+	const u32 dbg = dbg_in == 9u ? 9u : 0u;
+#endif
 	typedef typename TUP::hi_t THI;
 	__shared__ u64 s_klo[RD_SLOTS];
 	__shared__ THI s_khi[RD_SLOTS];
@@ -1556,7 +1563,15 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
                                                              u32 range_shift, u32 n_ranges,
                                                              u64* __restrict__ raw, u64 raw_cap, u32 blk_items,
                                                              unsigned long long* __restrict__ g_cursor,
-                                                             u32* __restrict__ range_cnt, u32* __restrict__ g_err, u32 dbg) {
+                                                             u32* __restrict__ range_cnt, u32* __restrict__ g_err, u32 dbg_in) {
+	// the ablation switches of profiles/walkdbg.sh (filter off, lookups faked, outputs dropped, per-wave statistics) exist only in the
+	// -DVDJX_ABLATE build: the shipped walk has none of those branches
+#ifdef VDJX_ABLATE
+	const u32 dbg = dbg_in;
+#else
+	(void) dbg_in;
+	constexpr u32 dbg = 0u;
+#endif
 	extern __shared__ u32 hist[];                 // [n_ranges] (+ LONG: one row of GL_ROW_LONG words per thread)
 	typedef typename std::conditional<LONG, vdjx_mask3, u64>::type MaskT;
 	typedef typename std::conditional<LONG, WalkRecL, WalkRecS>::type RecT;
@@ -2560,8 +2575,12 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	HIP_TRY(hipFuncSetAttribute((const void*) k_walk_items<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_walk));
 	// VDJX_WALK_DBG (profiles/walkdbg.sh): an ABLATED copy of the walk runs first into scratch outputs, timed as k_walk_dbg; the real
 	// one follows untouched.  Bits: 1 no item stores, 2 no range histogram, 8 no filter / table / key loads at run starts.
+#ifdef VDJX_ABLATE
 	static const u32 walk_dbg = (u32) tune("VDJX_WALK_DBG", 0);
-	if (R && walk_dbg) {
+#else
+	constexpr u32 walk_dbg = 0;
+#endif
+	if (R && walk_dbg != 0u) {
 		u64* raw2;
 		unsigned long long* cur2;
 		u32* cnt2;
