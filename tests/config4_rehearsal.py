@@ -7,11 +7,14 @@ vdjer_amd/shard.py and the real HIP phases, collectives as tensor copies), each 
 (50 M records) of a 100 M-pair library, global instance ids record << 6 | offset running up to 2.56e10 (past 2^32 from the
 second rank on), 8 x 1.3 GB of partial aggregates exchanged -- and the three chain presets (set_chain_info, params.c:13-30) one
 after the other in the SAME process and contexts (arenas and exchange buffers reused, a new repertoire / ref-dir / pool each).
-Checked: every rank ends with the same graph, and it is the graph the one-GPU build makes of the union pool (400 M records in
-one context: itself pinned to the oracle at 10 M and 40 M pairs by the tests around it).  Prints one JSON line per chain with
-the phases' wall times and the bytes a rank exchanged.
+Checked: every rank ends with the same graph; and that graph is
+  - at 8 x 8 M pairs (the most one context takes: records x offsets < 2^32) the graph the ONE-GPU build makes of the union pool
+    (itself pinned to the oracle at 10 M and 40 M pairs by the tests around this one),
+  - at the full 8 x 12.5 M (the union does not fit one context) the graph 4 ranks of 25 M pairs each make of the same union
+    (another partition of the same scan order: any dependence on where the slices are cut shows).
+Prints one JSON line per chain with the phases' wall times and the bytes a rank exchanged.
 
-usage: config4_rehearsal.py [pairs_per_rank=12500000] [ranks=8]
+usage: config4_rehearsal.py [pairs_per_rank=12500000] [ranks=8] [chains=IGH,IGK,IGL]
 """
 import hashlib
 import json
@@ -35,87 +38,135 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+FIELDS = ("first_inst", "freq", "gated_count", "has_v", "has_j", "to_ids", "from_ids")
+
+
+def sharded_build(ctxs, dist, dev, pools, stride, vc, jc, k, mf, mq, keep_graph=False):
+    """one sharded k-mer build with len(pools) ranks as threads; -> (digests of rank 0's graph [+ the graph], phase laps of rank 0, bytes per rank)"""
+    world = len(pools)
+    out, errs, laps, moved = [None] * world, [], [None] * world, [0] * world
+
+    def work(r):
+        try:
+            dist.set_rank(r)
+            c = ctxs[r]
+            c.anchor_sets_load(vc, jc)
+            p = c.pool_load_device(pools[r][0], d_secondary=pools[r][1])
+            drv = shard.ShardedHotPath(c, dist, dev, stride=stride)
+            g = drv.kmer_build(p, k, mf, mq)
+            out[r] = {f: sha(getattr(g, f)) for f in FIELDS}
+            out[r]["n"], out[r]["pre"] = g.n, g.pre_nodes
+            if r == 0:
+                out[r]["largest_instance_id"] = int(g.first_inst.max()) if g.n else 0
+                if keep_graph:
+                    out[r]["graph"] = g
+            laps[r] = dict(drv.laps)
+            moved[r] = drv.bytes_exchanged
+            p.free()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+            dist.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    if errs:
+        raise RuntimeError("; ".join(errs[:2]))
+    strip = lambda d: {k_: v for k_, v in d.items() if k_ not in ("graph", "largest_instance_id")}      # noqa: E731
+    for r in range(1, world):
+        assert strip(out[r]) == strip(out[0]), f"rank {r}'s graph differs from rank 0's"
+    return out[0], laps[0], moved
+
+
 def main():
     per = int(sys.argv[1]) if len(sys.argv) > 1 else 12_500_000
     world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    chains = sys.argv[3].split(",") if len(sys.argv) > 3 else ["IGH", "IGK", "IGL"]
     k, mf, mq = 35, 3, 90
+    P = 50 - k + 1
     dev = torch.device("cuda", 0)
     free, total = torch.cuda.mem_get_info()
-    need = world * per * 2200 + per * world * 1500                       # (measured: ~2.2 KB per pair and rank in flight, ~1.5 KB per pair for the union build)
+    need = int(os.environ.get("VDJX_REHEARSAL_NEED_GIB", "0")) << 30 or world * per * 2000           # (measured: see the lines printed)
     if free < need:
         print(json.dumps({"skipped": f"needs about {need >> 30} GiB of device memory, {free >> 30} GiB free"}))
         return 0
+    # one GPU holds records x offsets < 2^32 (include/vdjx.h): the union pool of the full configuration (400 M records x 16) does not
+    # fit one context, 8 x 8 M pairs does.  Where it fits, the sharded graph is compared with the one-GPU build of the union pool;
+    # where it does not, with a second sharded build of the same union by HALF as many ranks holding twice as much each.
+    union_fits = per * world * 4 * P < (1 << 32) and per * world * 4 <= (1 << 29)
     ctxs = [api.Context(0) for _ in range(world)]
-    dist = ThreadDist(world)
     t_all = time.perf_counter()
-    for ci, chain in enumerate(("IGH", "IGK", "IGL")):
+    for ci, chain in enumerate(chains):
         t0 = time.perf_counter()
         rep = synth.make_repertoire(max(4, per * world // 1000), seed=20261002 + 7 * ci, chain=chain)
         vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
         jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
-        pools = [synth.make_reads_cb(rep, per, noise_frac=0.3, seed=20261002 + 1000 * ci, device="cuda:0", pair0=r * per) for r in range(world)]
+        # two ranks' pools lie in one block (the pool of one rank of the half-world cross-check: the same scan order)
+        blocks, pools = [], []
+        for j in range(0, world, 2):
+            two = [synth.make_reads_cb(rep, per, noise_frac=0.3, seed=20261002 + 1000 * ci, device="cuda:0", pair0=r * per) for r in (j, j + 1) if r < world]
+            blk = torch.cat([x for p_ in two for x in (p_.primary, p_.secondary)])
+            at = 0
+            for p_ in two:                 # (a rank's primary and secondary records as one block: the same scan order, and a 16-byte aligned base)
+                n_ = p_.primary.shape[0] + p_.secondary.shape[0]
+                assert (at * blk.shape[1]) % 16 == 0
+                pools.append((blk[at:at + n_], None))
+                at += n_
+            blocks.append(blk)
+            del two
         torch.cuda.synchronize()
         t_gen = time.perf_counter() - t0
-        stride = pools[0].primary.shape[0] + pools[0].secondary.shape[0]
-        assert all(p.primary.shape[0] + p.secondary.shape[0] == stride for p in pools)
-        assert (stride * (world - 1)) << 6 >= 1 << 32 or per < 12_500_000
-        out, errs, laps, moved = [None] * world, [], [None] * world, [0] * world
-
-        def work(r):
-            try:
-                dist.set_rank(r)
-                c = ctxs[r]
-                c.anchor_sets_load(vc, jc)
-                p = c.pool_load_device(pools[r].primary, d_secondary=pools[r].secondary)
-                drv = shard.ShardedHotPath(c, dist, dev, stride=stride)
-                g = drv.kmer_build(p, k, mf, mq)
-                out[r] = {f: sha(getattr(g, f)) for f in ("first_inst", "freq", "gated_count", "has_v", "has_j", "to_ids", "from_ids")}
-                out[r]["n"], out[r]["pre"] = g.n, g.pre_nodes
-                if r == 0:
-                    out[r]["graph"] = g
-                laps[r] = dict(drv.laps)
-                moved[r] = drv.bytes_exchanged
-                p.free()
-            except Exception as e:  # noqa: BLE001
-                errs.append(repr(e))
-                dist.barrier.abort()
-
+        stride = pools[0][0].shape[0]
+        assert all(p_[0].shape[0] == stride for p_ in pools)
         t1 = time.perf_counter()
-        th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        torch.cuda.synchronize()
+        d8, laps, moved = sharded_build(ctxs, ThreadDist(world), dev, pools, stride, vc, jc, k, mf, mq, keep_graph=union_fits)
         t_shard = time.perf_counter() - t1
-        if errs:
-            print(json.dumps({"chain": chain, "error": errs[:2]}))
-            return 1
-        for r in range(1, world):
-            assert {k_: v for k_, v in out[r].items() if k_ != "graph"} == {k_: v for k_, v in out[0].items() if k_ != "graph"}, f"rank {r} differs from rank 0"
-        gs = out[0]["graph"]
-        # the union pool in ONE context: rank-major concatenation = the sharded build's scan order
-        t2 = time.perf_counter()
-        cat = torch.cat([x for p in pools for x in (p.primary, p.secondary)])
-        del pools
-        c0 = ctxs[0]
-        pu = c0.pool_load_device(cat)
-        gu = c0.kmer_build(pu, k, mf, mq)
-        torch.cuda.synchronize()
-        t_union = time.perf_counter() - t2
-        same = gu.n == gs.n and gu.pre_nodes == gs.pre_nodes and all(np.array_equal(getattr(gu, f), getattr(gs, f)) for f in
-                                                                      ("first_inst", "freq", "gated_count", "has_v", "has_j", "to_ids", "from_ids"))
-        line = {"chain": chain, "ranks": world, "pairs_per_rank": per, "records": stride * world, "largest_instance_id": int(gs.first_inst.max()) if gs.n else 0,
-                "nodes": int(gs.n), "pre_nodes": int(gs.pre_nodes), "sharded_equals_union": bool(same),
-                "seconds": {"generate": round(t_gen, 2), "sharded_build_all_ranks_on_one_device": round(t_shard, 2), "union_build_one_context": round(t_union, 2)},
-                "phase_wall_ms_rank0": {k_: round(v * 1e3, 2) for k_, v in laps[0].items()},
-                "bytes_exchanged_per_rank": moved, "shard_stats_rank0": {n_: ctxs[0].stat("shard_" + n_) for n_ in ("partials_received", "open_kmers", "questions", "decided_at_merge", "kept_after_answers")}}
+        line = {"chain": chain, "ranks": world, "pairs_per_rank": per, "records": stride * world, "largest_instance_id": d8["largest_instance_id"],
+                "instance_ids_pass_2_32": d8["largest_instance_id"] >= 1 << 32, "nodes": int(d8["n"]), "pre_nodes": int(d8["pre"]), "all_ranks_agree": True,
+                "seconds": {"generate": round(t_gen, 2), "sharded_build_all_ranks_on_one_device": round(t_shard, 2)},
+                "phase_wall_ms_rank0": {k_: round(v * 1e3, 2) for k_, v in laps.items()}, "bytes_exchanged_per_rank": moved,
+                "shard_stats_rank0": {n_: ctxs[0].stat("shard_" + n_) for n_ in ("partials_received", "open_kmers", "questions", "decided_at_merge", "kept_after_answers")}}
+        same = True
+        if union_fits:
+            # the union pool in ONE context: rank-major concatenation = the sharded build's scan order
+            t2 = time.perf_counter()
+            cat = torch.cat(blocks)
+            torch.cuda.synchronize()           # (torch's stream made it; the library reads it on its own)
+            del pools, blocks
+            pu = ctxs[0].pool_load_device(cat)
+            gu = ctxs[0].kmer_build(pu, k, mf, mq)
+            gs = d8["graph"]
+            same = gu.n == gs.n and gu.pre_nodes == gs.pre_nodes and all(np.array_equal(getattr(gu, f), getattr(gs, f)) for f in FIELDS)
+            line["sharded_equals_one_gpu_build_of_the_union_pool"] = bool(same)
+            line["seconds"]["union_build_one_context"] = round(time.perf_counter() - t2, 2)
+            pu.free()
+            del cat, gu, gs
+        elif ci == len(chains) - 1 and world % 2 == 0:
+            # last chain: the same union through world/2 ranks of twice the size (the other contexts are closed first: their arenas go back)
+            for c in ctxs[world // 2:]:
+                c.close()
+            del ctxs[world // 2:]
+            del pools
+            t2 = time.perf_counter()
+            d4, laps4, _ = sharded_build(ctxs, ThreadDist(world // 2), dev, [(b, None) for b in blocks], 2 * stride, vc, jc, k, mf, mq)
+            strip = lambda d: {k_: v for k_, v in d.items() if k_ not in ("graph", "largest_instance_id")}      # noqa: E731
+            same = strip(d4) == strip(d8)
+            line[f"equals_the_build_by_{world // 2}_ranks_of_twice_the_size"] = bool(same)
+            line["seconds"]["half_world_build"] = round(time.perf_counter() - t2, 2)
+            line["phase_wall_ms_rank0_half_world"] = {k_: round(v * 1e3, 2) for k_, v in laps4.items()}
+            del blocks
+        else:
+            del pools, blocks
+        line["device_free_GiB_after"] = round(torch.cuda.mem_get_info()[0] / 2 ** 30, 1)
         print(json.dumps(line), flush=True)
-        pu.free()
-        del cat, gu, gs, out
+        del d8
         if not same:
             return 1
-    print(json.dumps({"done": True, "seconds": round(time.perf_counter() - t_all, 1), "peak_device_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
+    print(json.dumps({"done": True, "seconds": round(time.perf_counter() - t_all, 1), "device_total_GiB": round(total / 2 ** 30, 1), "device_free_GiB_at_start": round(free / 2 ** 30, 1),
+                      "torch_peak_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
     return 0
 
 

@@ -65,6 +65,12 @@ struct vdjx_arena {
 	void* alloc(size_t bytes);       // 256-byte aligned; nullptr (and the error set) on failure
 	void reset();                    // forget all allocations; coalesces multiple chunks into one
 	void release();
+	// stack discipline inside one call sequence: everything allocated after mark() is given up by release_to(mark) -- the space is
+	// taken again by the next alloc, and chunks the arena had to ADD since the mark go back to the device (a first build's
+	// temporaries do not stay resident through its later phases).  Nothing on the stream may still use what is released.
+	struct mark_t { size_t chunks, used; };
+	mark_t mark() const { return {chunks.size(), used}; }
+	void release_to(mark_t m);
 };
 
 struct vdjx_shard;
@@ -218,6 +224,8 @@ struct vdjx_work {
 		*out = (T*) c->arena.alloc((n ? n : 1) * sizeof(T));
 		return *out ? hipSuccess : hipErrorOutOfMemory;
 	}
+	vdjx_arena::mark_t mark() const { return c->arena.mark(); }
+	void release_to(vdjx_arena::mark_t m) { c->arena.release_to(m); }
 };
 
 // profiling: bracket a launch with events on the context's stream

@@ -163,6 +163,12 @@ void vdjx_arena::reset() {
 	used = 0;
 }
 
+void vdjx_arena::release_to(mark_t m) {
+	if (m.chunks > chunks.size()) return;
+	while (chunks.size() > m.chunks) { (void) hipFree(chunks.back().p); chunks.pop_back(); }
+	used = chunks.empty() ? 0 : m.used;
+}
+
 void vdjx_arena::release() {
 	for (auto& ch : chunks) (void) hipFree(ch.p);
 	chunks.clear();

@@ -2193,6 +2193,8 @@ struct PersistAlloc {
 		*out = (T*) c->shard_arena.alloc((n ? n : 1) * sizeof(T));
 		return *out ? hipSuccess : hipErrorOutOfMemory;
 	}
+	vdjx_arena::mark_t mark() const { return c->shard_arena.mark(); }
+	void release_to(vdjx_arena::mark_t m) { c->shard_arena.release_to(m); }
 };
 
 struct PoolView { const u64* bases; const u64* nmask; vdjx_qrows quals; int rl; int ob; };
@@ -2560,6 +2562,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	u64 *raw, *items;
 	unsigned long long *g_cursor, *n_inst;
 	u32 *range_cnt, *range_start, *g_err, *gcur;
+	const vdjx_arena::mark_t tmp_mark = db.mark();          // what follows (items and their bookkeeping: the large part) is dead when the recount is done
 	HIP_TRY(db.alloc(&raw, (size_t) raw_cap));
 	HIP_TRY(db.alloc(&g_cursor, 4 + ((size_t) n_ranges_p + 1) / 2));      // one cleared block: cursor, instance count | error words | range counts
 	n_inst = g_cursor + 1;
@@ -2700,6 +2703,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	}
 	c->stats["recount_items"] = n_items;            // runs of surviving k-mer instances of this pool (8 bytes each)
 	c->stats["recount_instances"] = inst;           // the instances themselves
+	db.release_to(tmp_mark);                        // (the stream has been waited for: nothing reads the items any more)
 	return VDJX_OK;
 }
 
@@ -2878,6 +2882,7 @@ struct vdjx_shard {
 	// vdjx_shard_local -> vdjx_shard_local_fill: the partial aggregates by bucket before they are laid end to end
 	Partial* sparse = nullptr;
 	u32* sparse_ref = nullptr;
+	vdjx_arena::mark_t fill_mark{0, 0};
 	const u32* tuple_bucket_start = nullptr;
 	u32 NBt = 0;
 };
@@ -2939,6 +2944,21 @@ static int shard_local_impl(vdjx_shard* s) {
 	s->have_hist = true;
 	// (the ranks' largest count if they compared them, vdjx_shard_count + vdjx_shard_geometry: buckets of the size the one-GPU build
 	// cuts -- at 10 M pairs per rank half as many as the bound asks for, and one partition level less)
+	// what lives until the answers are out first; then the aggregates by bucket (until vdjx_shard_local_fill has laid them end to end);
+	// then the tuples (until this function returns): the arena gives the later ones up again in that order
+	const size_t cap = (size_t) s->gh.N + 1;
+	const size_t nb_max = ((size_t) 1 << 20) + 16 * (size_t) s->nranks + 2;          // (stage_gated_cut: at most 2^(15+5) buckets; the directory's padding)
+	Partial* sparse;
+	u32 *g_err, *sparse_ref;
+	HIP_TRY(db.alloc(&s->low_inst, cap));
+	HIP_TRY(db.alloc(&s->dense_ref, cap));
+	HIP_TRY(db.alloc(&s->nd, nb_max));
+	HIP_TRY(db.alloc(&s->dstart, nb_max + 1));
+	HIP_TRY(db.alloc(&g_err, 1));
+	s->fill_mark = db.mark();
+	HIP_TRY(db.alloc(&sparse, cap));
+	HIP_TRY(db.alloc(&sparse_ref, cap));
+	const vdjx_arena::mark_t tuple_mark = db.mark();
 	rc = stage_gated_cut<TUP>(c, db, s->pool, rec_base, s->k, 0, s->agreed ? s->agreed : shard_geometry_bound(s), s->gh, &t);
 	if (rc) return rc;
 	if (t.NB < (u32) s->nranks) { vdjx_set_error("vdjx_shard_local: fewer buckets (%u) than ranks", t.NB); return VDJX_ELIMIT; }
@@ -2946,15 +2966,7 @@ static int shard_local_impl(vdjx_shard* s) {
 	s->NBo = t.NB / (u32) s->nranks;
 	if (s->NBo * (u32) s->nranks != t.NB) s->NBo = (s->NBo + 1 + 15) & ~15u;
 	s->NBf = s->NBo * (u32) s->nranks;
-	Partial* sparse;
-	u32 *g_err, *sparse_ref;
-	const size_t cap = (size_t) t.N + 1;
-	HIP_TRY(db.alloc(&sparse, cap));
-	HIP_TRY(db.alloc(&sparse_ref, cap));
-	HIP_TRY(db.alloc(&s->low_inst, cap));
-	HIP_TRY(db.alloc(&s->nd, s->NBf));
-	HIP_TRY(db.alloc(&s->dstart, s->NBf + 1));
-	HIP_TRY(db.alloc(&g_err, 1));
+	if ((size_t) s->NBf + 1 > nb_max) { vdjx_set_error("vdjx_shard_local: %u buckets", s->NBf); return VDJX_ELIMIT; }
 	HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
 	if (s->NBf > t.NB) HIP_TRY(hipMemsetAsync(s->nd + t.NB, 0, (size_t) (s->NBf - t.NB) * 4, st));
 	{
@@ -2980,10 +2992,19 @@ static int shard_local_impl(vdjx_shard* s) {
 	if (err) { vdjx_set_error("k_gated_local: %u buckets could not be split to fit LDS", err); return VDJX_EHIP; }
 	s->src_base.assign(pick.begin(), pick.end());        // reused below as "what goes to owner o" until the merge overwrites it
 	s->n_dense = pick[G];
-	HIP_TRY(db.alloc(&s->dense_ref, (size_t) s->n_dense + 1));
 	// (the aggregates are laid end to end by vdjx_shard_local_fill, straight into the caller's send buffer)
-	s->sparse = sparse; s->sparse_ref = sparse_ref; s->tuple_bucket_start = t.bucket_start; s->NBt = t.NB;
+	s->sparse = sparse; s->sparse_ref = sparse_ref; s->NBt = t.NB;
 	s->dense = nullptr;
+	// the tuples are done with; the bucket starts the compaction needs move below them first
+	{
+		std::vector<u32> bs((size_t) t.NB + 1);
+		HIP_TRY(hipMemcpy(bs.data(), t.bucket_start, ((size_t) t.NB + 1) * 4, hipMemcpyDeviceToHost));
+		db.release_to(tuple_mark);
+		u32* keep;
+		HIP_TRY(db.alloc(&keep, (size_t) t.NB + 1));
+		HIP_TRY(hipMemcpy(keep, bs.data(), ((size_t) t.NB + 1) * 4, hipMemcpyHostToDevice));
+		s->tuple_bucket_start = keep;
+	}
 	return VDJX_OK;
 }
 
@@ -3020,6 +3041,11 @@ extern "C" int vdjx_shard_local_fill(vdjx_shard* s, void* d_dir, void* d_partial
 	s->dense = (Partial*) d_partials;
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	if (s->sparse) {                                   // the aggregates by bucket have been laid end to end: their space goes back
+		PersistAlloc db(s->c);
+		db.release_to(s->fill_mark);
+		s->sparse = nullptr; s->sparse_ref = nullptr; s->tuple_bucket_start = nullptr;
+	}
 	return VDJX_OK;
 }
 
