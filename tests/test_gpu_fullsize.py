@@ -362,3 +362,29 @@ def test_20M_pairs_buckets_are_cut_before_the_table_fills():
     ctx.close()
     del pool
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("per,chains,check", [(8_000_000, "IGH", "sharded_equals_one_gpu_build_of_the_union_pool"),
+                                              (12_500_000, "IGH,IGK,IGL", "equals_the_build_by_4_ranks_of_twice_the_size")])
+def test_config4_geometry_rehearsed_on_one_gpu(per, chains, check):
+    """BASELINE.json configs[4] (100 M pairs hash-prefix sharded over 8 GPUs, IGH + IGK + IGL back to back) has never met an 8-GPU
+    node; tests/config4_rehearsal.py runs its GEOMETRY here: 8 ranks as threads with their own contexts, 12.5 M pairs each, one
+    process for the three chain presets, instance ids past 2^32, 1.8 GB of exchange per rank.  At 8 x 8 M pairs the sharded graph is
+    compared with the ONE-GPU build of the union pool (the most one context takes: records x offsets < 2^32), at the full size with the
+    build of the same union by 4 ranks of 25 M pairs.  Fresh process (the 8 contexts hold ~160 GB of workspace between them)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "config4_rehearsal.py"), str(per), "8", chains], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.stdout[-3000:], r.stderr[-3000:])
+    if "skipped" in lines[0]:
+        pytest.skip(lines[0]["skipped"])
+    per_chain = [l for l in lines if "chain" in l]
+    assert [l["chain"] for l in per_chain] == chains.split(",") and lines[-1].get("done")
+    for l in per_chain:
+        assert l["all_ranks_agree"] and l["instance_ids_pass_2_32"] and l["nodes"] > 1_000_000 and l["records"] == per * 32
+        assert min(l["bytes_exchanged_per_rank"]) > 1_000_000_000
+        print(json.dumps({k_: l[k_] for k_ in ("chain", "records", "nodes", "pre_nodes", "seconds", "phase_wall_ms_rank0", "bytes_exchanged_per_rank")}))
+    assert per_chain[-1][check] is True

@@ -2615,8 +2615,18 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	}
 	dbg_sync(c, "k_walk_items");
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, range_cnt, n_ranges_p, range_start);
-	// the partitioned items: at most one per instance
-	HIP_TRY(db.alloc(&items, NI + 1));
+	// the partitioned items: at most one per instance.  A build that waits for this stage anyway (the sharded one: `defer` is null)
+	// asks how many the walk made and sizes the two partition buffers by that (a tenth of the bound: 12 GB less per rank at 12.5 M
+	// pairs); the one-GPU build does not stop for it.
+	size_t items_cap = NI + 1;
+	if (!defer) {
+		u32* hp = (u32*) c->h_pin;
+		HIP_TRY(hipMemcpyAsync(hp, range_start + n_ranges_p, 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(hipGetLastError());
+		items_cap = (size_t) hp[0] + 1;
+	}
+	HIP_TRY(db.alloc(&items, items_cap));
 	HIP_TRY(hipFuncSetAttribute((const void*) k_part_items, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
 	HIP_TRY(db.alloc(&gcur, n_ranges_p));
 	{
@@ -2630,7 +2640,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 			// level 1 into `n_coarse` segments (written over a second buffer), level 2 inside each segment
 			u64* l1;
 			u32* gcur1;
-			HIP_TRY(db.alloc(&l1, NI + 1));
+			HIP_TRY(db.alloc(&l1, items_cap));
 			HIP_TRY(db.alloc(&gcur1, n_coarse));
 			HIP_TRY(hipFuncSetAttribute((const void*) k_part_items2, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
 			hipLaunchKernelGGL(k_init_cursors, dim3((n_coarse + 255) / 256), dim3(256), 0, st, range_start, n_coarse, l2bits, gcur1);
