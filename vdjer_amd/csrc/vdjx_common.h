@@ -61,15 +61,18 @@ struct vdjx_prof_entry {
 struct vdjx_arena {
 	struct chunk { char* p; size_t cap; };
 	std::vector<chunk> chunks;
-	size_t used = 0;                 // bytes used in the last chunk
+	size_t cur = 0;                  // the chunk allocations come out of
+	size_t used = 0;                 // bytes used in chunk `cur`
 	void* alloc(size_t bytes);       // 256-byte aligned; nullptr (and the error set) on failure
 	void reset();                    // forget all allocations; coalesces multiple chunks into one
 	void release();
-	// stack discipline inside one call sequence: everything allocated after mark() is given up by release_to(mark) -- the space is
-	// taken again by the next alloc, and chunks the arena had to ADD since the mark go back to the device (a first build's
-	// temporaries do not stay resident through its later phases).  Nothing on the stream may still use what is released.
-	struct mark_t { size_t chunks, used; };
-	mark_t mark() const { return {chunks.size(), used}; }
+	// stack discipline inside one call sequence: everything allocated after mark() is given up by release_to(mark) and its space is
+	// taken again by the next allocations (a build's early temporaries do not add to its later phases' footprint).  The chunks stay
+	// with the arena -- giving them back to the device and asking again every call costs more than the kernels in between -- so that
+	// reset() still sizes the one coalesced chunk by what a whole build held at its peak.  Nothing on the stream may still use what
+	// is released.
+	struct mark_t { size_t cur, used; };
+	mark_t mark() const { return {cur, used}; }
 	void release_to(mark_t m);
 };
 

@@ -139,17 +139,22 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 
 void* vdjx_arena::alloc(size_t bytes) {
 	bytes = (bytes + 255) & ~(size_t) 255;
-	if (chunks.empty() || used + bytes > chunks.back().cap) {
-		size_t cap = bytes > ((size_t) 64 << 20) ? bytes : ((size_t) 64 << 20);
-		char* p = nullptr;
-		hipError_t e = hipMalloc(&p, cap);
-		if (e != hipSuccess) { vdjx_set_error("workspace alloc of %zu bytes: %s", cap, hipGetErrorString(e)); return nullptr; }
-		chunks.push_back({p, cap});
-		used = 0;
+	if (!chunks.empty() && used + bytes <= chunks[cur].cap) {
+		void* r = chunks[cur].p + used;
+		used += bytes;
+		return r;
 	}
-	void* r = chunks.back().p + used;
-	used += bytes;
-	return r;
+	// a later chunk the arena already has (after release_to), else a new one
+	for (size_t i = chunks.empty() ? 0 : cur + 1; i < chunks.size(); i++)
+		if (bytes <= chunks[i].cap) { cur = i; used = bytes; return chunks[i].p; }
+	size_t cap = bytes > ((size_t) 64 << 20) ? bytes : ((size_t) 64 << 20);
+	char* p = nullptr;
+	hipError_t e = hipMalloc(&p, cap);
+	if (e != hipSuccess) { vdjx_set_error("workspace alloc of %zu bytes: %s", cap, hipGetErrorString(e)); return nullptr; }
+	chunks.push_back({p, cap});
+	cur = chunks.size() - 1;
+	used = bytes;
+	return p;
 }
 
 void vdjx_arena::reset() {
@@ -160,18 +165,20 @@ void vdjx_arena::reset() {
 		char* p = nullptr;
 		if (hipMalloc(&p, total) == hipSuccess) chunks.push_back({p, total});
 	}
+	cur = 0;
 	used = 0;
 }
 
 void vdjx_arena::release_to(mark_t m) {
-	if (m.chunks > chunks.size()) return;
-	while (chunks.size() > m.chunks) { (void) hipFree(chunks.back().p); chunks.pop_back(); }
-	used = chunks.empty() ? 0 : m.used;
+	if (chunks.empty() || m.cur >= chunks.size()) { cur = 0; used = 0; return; }
+	cur = m.cur;
+	used = m.used;
 }
 
 void vdjx_arena::release() {
 	for (auto& ch : chunks) (void) hipFree(ch.p);
 	chunks.clear();
+	cur = 0;
 	used = 0;
 }
 
