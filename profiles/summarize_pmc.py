@@ -11,7 +11,7 @@ import sys
 
 
 def short(name):
-    return name.replace("void ", "").split("(")[0].split("<")[0]
+    return name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
 
 
 def med(v):

@@ -136,6 +136,13 @@ def main():
             cat = torch.cat(blocks)
             torch.cuda.synchronize()           # (torch's stream made it; the library reads it on its own)
             del pools, blocks
+            # (the ranks' contexts keep their workspaces between builds -- 8 x ~17 GB here; the one-GPU build of 64 M pairs wants
+            # ~150 GB of its own: it gets a fresh context, the ranks' ones are closed.  This invocation has no further chain.)
+            assert ci == len(chains) - 1, "the union check closes the ranks' contexts: last chain only"
+            for c in ctxs:
+                c.close()
+            ctxs[:] = [api.Context(0)]
+            ctxs[0].anchor_sets_load(vc, jc)
             pu = ctxs[0].pool_load_device(cat)
             gu = ctxs[0].kmer_build(pu, k, mf, mq)
             gs = d8["graph"]
