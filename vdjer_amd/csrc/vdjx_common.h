@@ -23,7 +23,8 @@ typedef unsigned __int128 u128;
 #define RI_RCA 4u       // is_rc of the pair's read-2 record A (registered first)
 #define RI_RCB 8u       // is_rc of the pair's read-2 record B (registered last)
 // words per slot of the read index's lookup table: the read (W words) + three words of class data
-#define VDJX_RI_SLOT_WORDS(W) 8     // (64 bytes: W <= 5 words of key + 3 of class data; a 48-byte slot lay across two 64-byte lines half of the time)
+#define VDJX_RI_SLOT_WORDS(W) ((W) == 2 ? 4 : 8)     // the read (W words) + {class + 1 | members << 32} + {CSR start | weighted entries << 32}: 32 bytes
+                                                     // for reads of up to 64 bases (two slots per 64-byte line, a 1 GB table at 10 M pairs), 64 for longer ones
 // an 8-byte entry: class of the pair's read-2 record A (26 bits, all ones = none) | class of B (26) | flags (4) | multiplicity (8)
 #define RI_ENT_NONE 0x3FFFFFFu
 #define RI_ENT_MAXCNT 255u
@@ -122,7 +123,7 @@ struct vdjx_ctx {
 	std::vector<u32> h_line_off;
 	// a-8 read index
 	const vdjx_pool* ri_pool = nullptr;
-	void* d_ri_tab = nullptr;         // 64-byte slots {read sequence, class + 1 | members, CSR start | first weighted entry, weighted entries} (k_ri_tab)
+	void* d_ri_tab = nullptr;         // slots {read sequence, class + 1 | members, CSR start | weighted entries} (k_ri_tab; VDJX_RI_SLOT_WORDS)
 	u32 ri_tab_mask = 0;
 	u32* d_ri_start = nullptr;        // class -> CSR start [ncls+1]
 	u32* d_ri_cnt1 = nullptr;         // class -> number of read-1 members (the CSR lists those only)

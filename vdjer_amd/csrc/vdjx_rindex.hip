@@ -409,7 +409,7 @@ __global__ __launch_bounds__(RI_FOLD_BIG_THREADS) void k_ri_fold_big(const u32* 
 }
 
 // the lookup table the mapper reads: one slot per class = the sequence (W words), then {class + 1 | read-1 members << 32}, {CSR start |
-// first weighted entry << 32}, {weighted entries}: W + 3 words in a 64-byte slot (one line per probe)
+// weighted entries << 32}: W + 2 words (32-byte slots for reads of up to 64 bases, 64-byte ones beyond: a probe is one line either way)
 template <int W>
 __global__ void k_ri_tab(const u32* __restrict__ rep, u32 ncls, const u64* __restrict__ bases, const u32* __restrict__ cnt1, const u32* __restrict__ start,
                          const u32* __restrict__ dcnt, u64* __restrict__ tab, u32 mask) {
@@ -425,8 +425,7 @@ __global__ void k_ri_tab(const u32* __restrict__ rep, u32 ncls, const u64* __res
 #pragma unroll
 	for (int i = 0; i < W; i++) sl[i] = b[i];
 	((u32*) &sl[W])[1] = cnt1[c];                         // (the low half was claimed by the CAS)
-	sl[W + 1] = (u64) start[c] | ((u64) start[c] << 32);  // (the weighted entries of a class lie where its CSR members do: k_ri_fold)
-	sl[W + 2] = (u64) dcnt[c];
+	sl[W + 1] = (u64) start[c] | ((u64) dcnt[c] << 32);   // (the weighted entries of a class lie where its CSR members do: k_ri_fold)
 }
 
 int sort_pairs(vdjx_work& db, hipStream_t st, u64* k_in, u64* k_out, u32* v_in, u32* v_out, u32 n, unsigned end_bit) {

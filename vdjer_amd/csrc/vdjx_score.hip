@@ -475,8 +475,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_classify(ReadIndexDev ix, c
 					if (!d) {
 						const u64 a = sl[W + 1];
 						cls = (u32) cw - 1; inst = (u32) (cw >> 32);
-						if (weighted) { cs = (u32) (a >> 32); sz = (u32) sl[W + 2]; }
-						else { cs = (u32) a; sz = inst; }
+						cs = (u32) a;                                  // (the weighted entries lie where the class's CSR members do)
+						sz = weighted ? (u32) (a >> 32) : inst;
 						break;
 					}
 					slot = (slot + 1) & ix.mask;
