@@ -608,14 +608,26 @@ int main(int argc, char** argv) {
 	if (use_mgpu) {
 		unsigned char id[VDJX_COMM_ID_BYTES];
 		memset(id, 0, sizeof id);
-		if (!strcmp(transport, "rccl")) {
-			if (rank == 0) {
-				if (vdjx_comm_unique_id(id)) { fprintf(stderr, "%s\n", vdjx_comm_last_error()); return 1; }
-				for (int r = 1; r < c.gpus; r++) if (write(fds[r], id, sizeof id) != (ssize_t) sizeof id) { perror("write"); return 1; }
-			} else if (read(fds[0], id, sizeof id) != (ssize_t) sizeof id) { fprintf(stderr, "rank %d: no RCCL id from rank 0\n", rank); return 1; }
+		/* the communicator's bootstrap id: made by rank 0 (RCCL only; zeros otherwise), handed to every rank over its control socket --
+		 * whatever the transport, so that the hand-over itself runs in the one-device tests too */
+		const int* my_fds = fds ? fds + (size_t) rank * (size_t) c.gpus : NULL;
+		if (rank == 0) {
+			if (!strcmp(transport, "rccl") && vdjx_comm_unique_id(id)) { fprintf(stderr, "%s\n", vdjx_comm_last_error()); return 1; }
+			for (int r = 1; r < c.gpus; r++)
+				for (size_t at = 0; at < sizeof id;) {
+					const ssize_t k = write(my_fds[r], id + at, sizeof id - at);
+					if (k <= 0) { if (k < 0 && errno == EINTR) continue; perror("write"); return 1; }
+					at += (size_t) k;
+				}
+		} else {
+			for (size_t at = 0; at < sizeof id;) {
+				const ssize_t k = read(my_fds[0], id + at, sizeof id - at);
+				if (k <= 0) { if (k < 0 && errno == EINTR) continue; fprintf(stderr, "rank %d: no communicator id from rank 0\n", rank); return 1; }
+				at += (size_t) k;
+			}
 		}
 		vdjx_comm* cm = NULL;
-		if (vdjx_comm_init(transport, rank, c.gpus, device, fds ? fds + (size_t) rank * (size_t) c.gpus : NULL, id, &cm)) { fprintf(stderr, "rank %d: %s\n", rank, vdjx_comm_last_error()); return 1; }
+		if (vdjx_comm_init(transport, rank, c.gpus, device, my_fds, id, &cm)) { fprintf(stderr, "rank %d: %s\n", rank, vdjx_comm_last_error()); return 1; }
 		if (vdjx_mgpu_init(cm, device, &mg)) { fprintf(stderr, "rank %d: %s\n", rank, vdjx_mgpu_last_error()); return 1; }
 	}
 	VX(vdjx_anchor_sets_load(gx, vc, nv, jc, nj));
