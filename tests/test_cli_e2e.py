@@ -123,13 +123,14 @@ def test_vdjer_cli_gpus_n_takes_a_bam(tmp_path):
 
 
 def test_vdjer_cli_gpus_n_host_share_scales_down(tmp_path):
-    """peak host memory of a rank: a pool of 60,000 pairs (24 MB of records) through --gpus 1 (whole pool in one process) and
-    --gpus 4: every rank of the latter holds about a quarter of the records, and its peak resident set stays below the one-GPU
-    run's by most of the difference (the runtime's own footprint is the same)"""
+    """peak host memory of a rank: a pool of 300,000 pairs (121 MB of records; the one-GPU process also holds the reads it parsed
+    until the records are laid out) through --gpus 1 (whole pool in one process) and --gpus 4: every rank of the latter holds about
+    a quarter of the records, and its peak resident set -- most of which is the HIP / RCCL runtime's own 1.2 GB, the same in both --
+    lies below the one-GPU run's by most of what the other three quarters weigh"""
     from vdjer_amd import synth
     exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
-    rep = synth.make_repertoire(40, seed=77)
-    pool = synth.make_reads(rep, 60000, noise_frac=0.3, seed=78)
+    rep = synth.make_repertoire(200, seed=77)
+    pool = synth.make_reads(rep, 300000, noise_frac=0.3, seed=78)
     pool.write_reads_file(os.path.join(tmp_path, "reads.txt"))
     synth.write_ref_dir(rep, os.path.join(tmp_path, "ref"))
     outs, rss = [], []
@@ -137,15 +138,18 @@ def test_vdjer_cli_gpus_n_host_share_scales_down(tmp_path):
         d = tmp_path / f"g{gpus}"
         d.mkdir()
         cmd = [exe, "--in", "../reads.txt", "--chain", "IGH", "--ref-dir", "../ref", "--ins", "175", "--t", "2", "--gpus", str(gpus)]
-        r = subprocess.run(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900,
+        r = subprocess.run(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200,
                            env=dict(os.environ, VDJX_MGPU_ONE_DEVICE="1", VDJX_REPORT_SHARE="1", VDJX_MGPU_TIMEOUT_S="300"))
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append((r.stdout, (d / "vdj_contigs.fa").read_text(), (d / "vdjer.dot").read_text()))
         rss.append(_shares(r.stderr))
     assert outs[0] == outs[1] and outs[0][1].count(">") > 0
     R = rss[0][0]["total"]
-    assert rss[0][0]["records"] == R and all(0.8 * R / 4 < v["records"] < 1.2 * R / 4 for v in rss[1].values())
-    print("maxrss_kb one GPU:", rss[0][0]["maxrss_kb"], "four ranks:", [v["maxrss_kb"] for v in rss[1].values()])
+    assert rss[0][0]["records"] == R and all(0.9 * R / 4 < v["records"] < 1.1 * R / 4 for v in rss[1].values())
+    one, four = rss[0][0]["maxrss_kb"], [v["maxrss_kb"] for v in rss[1].values()]
+    pool_kb = rss[0][0]["host_pool_bytes"] // 1024
+    print("records", R, "host pool KB", pool_kb, "maxrss_kb one GPU:", one, "four ranks:", four)
+    assert max(four) < one - pool_kb // 2                # three quarters of the pool (and of the parsed reads) are not in a rank's memory
 
 
 def test_cli_rejects_bad_input(tmp_path):
