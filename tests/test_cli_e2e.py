@@ -122,6 +122,27 @@ def test_vdjer_cli_gpus_n_takes_a_bam(tmp_path):
     assert (tmp_path / "vdjer.dot").read_text() == G.text(f"{tag}.dot.gz")
 
 
+@pytest.mark.parametrize("n_pairs,gpus", [(7, 4), (40, 3), (1, 2)])
+def test_vdjer_cli_gpus_n_with_nearly_empty_shares(n_pairs, gpus, tmp_path):
+    """more ranks than a handful of pairs can feed: some shares (and slices) are empty or hold one pair; the run must still end well
+    and say what the one-GPU run says"""
+    from vdjer_amd import synth
+    exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
+    rep = synth.make_repertoire(2, seed=3)
+    pool = synth.make_reads(rep, n_pairs, noise_frac=0.3, seed=4, clean=True)
+    pool.write_reads_file(os.path.join(tmp_path, "reads.txt"))
+    synth.write_ref_dir(rep, os.path.join(tmp_path, "ref"))
+    outs = []
+    for g in (1, gpus):
+        d = tmp_path / f"g{g}"
+        d.mkdir()
+        r = subprocess.run([exe, "--in", "../reads.txt", "--chain", "IGH", "--ref-dir", "../ref", "--ins", "175", "--mf", "1", "--gpus", str(g)], cwd=d,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=dict(os.environ, VDJX_MGPU_ONE_DEVICE="1", VDJX_MGPU_TIMEOUT_S="120"))
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append((r.stdout, (d / "vdj_contigs.fa").read_text(), (d / "vdjer.dot").read_text()))
+    assert outs[0] == outs[1]
+
+
 def test_vdjer_cli_gpus_n_host_share_scales_down(tmp_path):
     """peak host memory of a rank: a pool of 300,000 pairs (121 MB of records; the one-GPU process also holds the reads it parsed
     until the records are laid out) through --gpus 1 (whole pool in one process) and --gpus 4: every rank of the latter holds about
