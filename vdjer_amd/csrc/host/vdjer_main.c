@@ -132,6 +132,13 @@ static time_t t_start, t_prev;
 static int g_rank;                             /* --gpus N: only rank 0 writes the stage log */
 static void status(const char* desc) {         /* status.c:22-32 without the /proc dumps */
 	if (g_rank) return;
+	if (getenv("VDJX_TIMES")) {                 /* (diagnostic: milliseconds since the process started, beside the reference's whole seconds) */
+		static struct timespec t0;
+		struct timespec t;
+		clock_gettime(CLOCK_MONOTONIC, &t);
+		if (!t0.tv_sec) t0 = t;
+		fprintf(stderr, "VDJX_TIMES\t%s\t%.1f\n", desc, (t.tv_sec - t0.tv_sec) * 1e3 + (t.tv_nsec - t0.tv_nsec) / 1e6);
+	}
 	time_t now = time(NULL);
 	fprintf(stderr, "ELAPSED_SECS\t%s\t%ld\t%ld\n", desc, (long) (now - t_start), (long) (now - t_prev));
 	t_prev = now;
@@ -603,7 +610,9 @@ int main(int argc, char** argv) {
 
 	const int device = one_device ? 0 : rank;              /* rank r drives GPU r */
 	vdjx_ctx* gx = NULL;
+	if (getenv("VDJX_TIMES")) status("(inputs read)");
 	VX(vdjx_init(device, &gx));
+	if (getenv("VDJX_TIMES")) status("(vdjx_init done)");
 	vdjx_mgpu* mg = NULL;
 	if (use_mgpu) {
 		unsigned char id[VDJX_COMM_ID_BYTES];
