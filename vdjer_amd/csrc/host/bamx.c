@@ -567,18 +567,17 @@ int bamx_extract_filtered(const char* bam_path, const char* vdj_fasta, const cha
 	blk* arena = NULL;
 	static bamx_rec rec;
 	int rc = 0;
-	/* get_read_length (bam_read.c:264-292): its own pass over the whole file (and it loads the index too) */
+	/* get_read_length (bam_read.c:264-292) is a pass of its own over the whole file in the reference (and it loads the index too): the
+	 * longest l_qseq of the file.  extract's last pass reads every record anyway: the maximum is taken there, one decompression of the
+	 * whole file less.  (What get_read_length would have stopped on -- a file or an index that cannot be opened -- still stops here.) */
 	{
 		bamx_file* f = bamx_open(bam_path);
 		if (!f) return -2;
 		bamx_index* ix0 = bamx_index_load(bam_path);
-		if (!ix0) { bamx_close(f); return -2; }
+		bamx_close(f);
+		if (!ix0) return -2;
 		bamx_index_free(ix0);
 		out->max_len = -1;
-		while ((rc = bamx_read1(f, &rec)) >= 0) if (rec.l_qseq > out->max_len) out->max_len = rec.l_qseq;
-		bamx_close(f);
-		if (rc < -1) return rc;
-		if (out->max_len <= 0) return fail("Error retrieving read length from: %s", bam_path);
 	}
 	sset kmers, primary, secondary;
 	sset_init(&kmers, EXTRACT_KMER_SIZE);
@@ -631,6 +630,7 @@ int bamx_extract_filtered(const char* bam_path, const char* vdj_fasta, const cha
 		}
 		while (!rc && (rc = bamx_read1(f, &rec)) >= 0) {
 			rc = 0;
+			if (rec.l_qseq > out->max_len) out->max_len = rec.l_qseq;          /* (get_read_length) */
 			if (rec.flag & 0x900) continue;
 			const char* nm;
 			if ((nm = sset_get(&primary, rec.qname)) != NULL) {
@@ -642,6 +642,7 @@ int bamx_extract_filtered(const char* bam_path, const char* vdj_fasta, const cha
 			}
 		}
 		if (rc == -1) rc = 0;
+		if (!rc && out->max_len <= 0) rc = fail("Error retrieving read length from: %s", bam_path);
 		fprintf(stderr, "primary_output1: [%d] primary_output2: [%d] secondary_output1: [%d] secondary_output2: [%d]\n", (int) p1.n, (int) p2.n,
 		        (int) s1.n, (int) s2.n);
 		sset_free(&p1); sset_free(&p2); sset_free(&s1); sset_free(&s2);

@@ -170,13 +170,31 @@ typedef struct {
 	char pool; char* name; int rn, rev; char* seq; char* qual;
 	uint64_t seq_no, pool_no;           /* among all reads of the extraction / among the reads of its pool (kept by this process or not) */
 } read_in;
+typedef struct str_blk { struct str_blk* next; size_t used, cap; char data[]; } str_blk;
 typedef struct {
 	read_in* v; size_t n, cap;
 	uint64_t np, ns;                    /* reads of the primary / secondary pool, kept or not */
 	int max_len;
 	int rank, nranks;
 	int one_block;                      /* lay the records out as a share (one block), whatever nranks: the `--gpus N` code path */
+	str_blk* strs;                      /* names, sequences and qualities of the kept reads: appended to megabyte blocks (a malloc per field cost
+	                                     * more than reading it) */
 } collector;
+
+static char* col_str(collector* c, const char* s, size_t n) {
+	if (!c->strs || c->strs->used + n + 1 > c->strs->cap) {
+		const size_t cap = n + 1 > ((size_t) 4 << 20) ? n + 1 : ((size_t) 4 << 20);
+		str_blk* b = (str_blk*) malloc(sizeof(str_blk) + cap);
+		if (!b) return NULL;
+		b->next = c->strs; b->used = 0; b->cap = cap;
+		c->strs = b;
+	}
+	char* p = c->strs->data + c->strs->used;
+	memcpy(p, s, n);
+	p[n] = 0;
+	c->strs->used += n + 1;
+	return p;
+}
 
 static uint64_t name_hash(const char* s) {
 	uint64_t h = 1469598103934665603ull;
@@ -188,9 +206,10 @@ static uint64_t name_hash(const char* s) {
 static int owner_of(const char* name, int nranks) { return nranks > 1 ? (int) (name_hash(name) % (uint64_t) nranks) : 0; }
 static int keep_name(void* ud, const char* name) { const collector* c = (const collector*) ud; return owner_of(name, c->nranks) == c->rank; }
 
-static int collect(collector* c, char pool, const char* name, int rn, int rev, const char* seq, const char* qual) {
+/* (name must be NUL-terminated at name[ln]) */
+static int collect_n(collector* c, char pool, const char* name, size_t ln, int rn, int rev, const char* seq, size_t ls, const char* qual, size_t lq) {
 	const uint64_t seq_no = c->np + c->ns, pool_no = pool == 'P' ? c->np++ : c->ns++;
-	const int l = (int) strlen(seq);
+	const int l = (int) ls;
 	if (l > c->max_len) c->max_len = l;                       /* get_read_length: the maximum (bam_read.c:264-292) */
 	if (owner_of(name, c->nranks) != c->rank) return 0;
 	if (c->n == c->cap) {
@@ -200,11 +219,11 @@ static int collect(collector* c, char pool, const char* name, int rn, int rev, c
 	}
 	read_in* x = &c->v[c->n++];
 	x->pool = pool; x->rn = rn; x->rev = rev; x->seq_no = seq_no; x->pool_no = pool_no;
-	x->name = strdup(name); x->seq = strdup(seq); x->qual = strdup(qual);
+	x->name = col_str(c, name, ln); x->seq = col_str(c, seq, ls); x->qual = col_str(c, qual, lq);
 	return x->name && x->seq && x->qual ? 0 : -1;
 }
 static void collector_free(collector* c) {
-	for (size_t i = 0; i < c->n; i++) { free(c->v[i].name); free(c->v[i].seq); free(c->v[i].qual); }
+	for (str_blk* b = c->strs; b;) { str_blk* nx = b->next; free(b); b = nx; }
 	free(c->v);
 	memset(c, 0, sizeof *c);
 }
@@ -287,11 +306,9 @@ static int load_bam(const cli* c, collector* col) {
 		const bamx_read* x = &br.v[i];
 		read_in* o = &col->v[col->n++];
 		o->pool = x->pool; o->rn = x->read_num; o->rev = x->is_rev; o->seq_no = x->seq_no; o->pool_no = x->pool_no;
-		o->name = strdup(x->name);
-		o->seq = (char*) calloc((size_t) br.max_len + 1, 1);
-		o->qual = (char*) calloc((size_t) br.max_len + 1, 1);
-		memcpy(o->seq, x->seq, (size_t) br.read_len);
-		memcpy(o->qual, x->qual, (size_t) br.read_len);
+		o->name = col_str(col, x->name, strlen(x->name));
+		o->seq = col_str(col, x->seq, (size_t) br.read_len);         /* (read_len characters, NUL padded by the extraction if the record was shorter) */
+		o->qual = col_str(col, x->qual, (size_t) br.read_len);
 	}
 	col->np = br.n_primary_reads; col->ns = br.n_secondary_reads;
 	col->max_len = br.max_len;
@@ -299,45 +316,58 @@ static int load_bam(const cli* c, collector* col) {
 	return 0;
 }
 
-/* whitespace-separated tokens of a file, a megabyte at a time (the text route's lines are six of them) */
-typedef struct { FILE* fp; char* buf; size_t len, at; int eof; } tok_reader;
-static int next_token(tok_reader* t, char* out, size_t cap) {
-	size_t n = 0;
-	for (;;) {
-		if (t->at == t->len) {
-			if (t->eof) break;
-			t->len = fread(t->buf, 1, 1u << 20, t->fp);
-			t->at = 0;
-			if (t->len == 0) { t->eof = 1; break; }
-		}
-		const char ch = t->buf[t->at];
-		const int ws = ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r' || ch == '\f' || ch == '\v';
-		if (ws) { t->at++; if (n) break; continue; }
-		if (n + 1 < cap) out[n++] = ch;
-		else { t->at++; continue; }            /* (fscanf's %511s stops there and leaves the rest as the next token; such lines are malformed either way) */
-		t->at++;
-	}
-	out[n] = 0;
-	return n > 0;
-}
-
-/* the extracted read pool as text (see the head of this file): every process reads the whole file once and keeps its share */
+/* the extracted read pool as text (see the head of this file): every process reads the whole file once and keeps its share.
+ * Six whitespace-separated fields per read (fscanf's "%s %s %d %d %s %s": any run of blanks or newlines separates), a few MB at a time. */
+static int is_ws(char ch) { return ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r' || ch == '\f' || ch == '\v'; }
 static int load_text(const char* path, collector* col) {
-	tok_reader t = {fopen(path, "r"), (char*) malloc(1u << 20), 0, 0, 0};
-	if (!t.fp || !t.buf) { fprintf(stderr, "cannot open %s\n", path); if (t.fp) fclose(t.fp); free(t.buf); return -1; }
-	char pool[8], name[512], rn[16], rev[16];
-	static char seq[1024], qual[1024];
-	int rc = 0;
-	while (next_token(&t, pool, sizeof pool)) {
-		if (!next_token(&t, name, sizeof name) || !next_token(&t, rn, sizeof rn) || !next_token(&t, rev, sizeof rev) || !next_token(&t, seq, sizeof seq)
-		    || !next_token(&t, qual, sizeof qual)) break;
-		char* e1; char* e2;
-		const long a = strtol(rn, &e1, 10), b = strtol(rev, &e2, 10);
-		if (*e1 || *e2) break;                                        /* (fscanf's %d would have stopped here) */
-		if ((rc = collect(col, pool[0] == 'P' ? 'P' : 'S', name, (int) a, (int) b, seq, qual)) != 0) { fprintf(stderr, "out of memory\n"); break; }
+	FILE* fp = fopen(path, "r");
+	const size_t CH = (size_t) 8 << 20;
+	char* buf = (char*) malloc(CH + 1);
+	if (!fp || !buf) { fprintf(stderr, "cannot open %s\n", path); if (fp) fclose(fp); free(buf); return -1; }
+	size_t have = 0;
+	int rc = 0, eof = 0, stop = 0;
+	while (!stop && !rc) {
+		if (!eof) {
+			const size_t got = fread(buf + have, 1, CH - have, fp);
+			have += got;
+			if (got == 0) eof = 1;
+		}
+		buf[have] = 0;
+		/* whole reads only: up to the last whitespace that ends a sixth field (at the end of the file: everything) */
+		size_t at = 0;
+		for (;;) {
+			char* f[6];
+			size_t fl[6];
+			size_t p = at;
+			int k = 0;
+			for (; k < 6; k++) {
+				while (p < have && is_ws(buf[p])) p++;
+				if (p >= have) break;
+				const size_t a0 = p;
+				while (p < have && !is_ws(buf[p])) p++;
+				if (p >= have && !eof) break;                       /* (the field may go on in the next piece) */
+				f[k] = buf + a0; fl[k] = p - a0;
+			}
+			if (k < 6) { if (eof) stop = 1; break; }
+			/* numbers as fscanf's %d reads them; a malformed line ends the input there, like the reference's format string would */
+			char *e1, *e2;
+			const char c2 = f[2][fl[2]], c3 = f[3][fl[3]];
+			f[2][fl[2]] = 0; f[3][fl[3]] = 0;
+			const long rn = strtol(f[2], &e1, 10), rv = strtol(f[3], &e2, 10);
+			const int bad = *e1 || *e2 || fl[0] > 7 || fl[1] > 511 || fl[4] > 1023 || fl[5] > 1023;
+			f[2][fl[2]] = c2; f[3][fl[3]] = c3;
+			if (bad) { stop = 1; break; }
+			f[1][fl[1]] = 0;                                        /* (the separator after the name: the name is hashed as a C string) */
+			if ((rc = collect_n(col, f[0][0] == 'P' ? 'P' : 'S', f[1], fl[1], (int) rn, (int) rv, f[4], fl[4], f[5], fl[5])) != 0) { fprintf(stderr, "out of memory\n"); break; }
+			at = p;
+		}
+		if (eof) break;
+		memmove(buf, buf + at, have - at);
+		have -= at;
+		if (have == CH) { fprintf(stderr, "%s: a read of more than %zu bytes\n", path, CH); rc = -1; }
 	}
-	fclose(t.fp);
-	free(t.buf);
+	fclose(fp);
+	free(buf);
 	return rc;
 }
 
