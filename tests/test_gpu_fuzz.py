@@ -190,7 +190,8 @@ def test_cli_end_to_end_random_pools_vs_the_compiled_reference(seed, n, tmp_path
     """The whole command line against THE REFERENCE ITSELF (oracle/_ref/vdjer_ref: its own sources compiled where they lie, exactly
     how the goldens were made, tests/golden/make_golden.py) on pools drawn here: tiled clones (they pass the coverage test) or noisy
     reads, k / mf / mq / mrs at random.  vdj_contigs.fa, the SAM on stdout and vdjer.dot byte for byte.  A run of the reference
-    counts when it scored every root (its root threads race otherwise, as in make_golden.py)."""
+    counts when it scored every root (its root threads race otherwise, as in make_golden.py).  Every pool also goes through
+    `vdjer --gpus N` (N = 2..4 process-ranks on the one device): the sharded path from C against the reference's bytes."""
     import re
     import subprocess
     from vdjer_amd import synth
@@ -210,17 +211,19 @@ def test_cli_end_to_end_random_pools_vs_the_compiled_reference(seed, n, tmp_path
         flags = ["--k", str(k), "--mf", str(int(rng.integers(2, 4))), "--mq", str(int(rng.choice([60, 90]))), "--mrs", str(int(rng.choice([20, 30])))]
         cfg = dict(it=it, chain=chain, clones=n_clones, pairs=pool.n_pairs, flags=flags)
         outs = {}
-        for who, binary in (("ref", [REF_BIN, "run"]), ("hip", [exe])):
+        gpus = int(rng.integers(2, 5))          # the same pool through `vdjer --gpus N` as well (N process-ranks sharing the one device: host transport)
+        for who, binary in (("ref", [REF_BIN, "run"]), ("hip", [exe]), ("hipN", [exe])):
             d = tmp_path / f"{it}_{who}"
             d.mkdir()
             pool.write_reads_file(str(d / "reads.txt"))
             synth.write_ref_dir(rep, str(d / "ref"))
-            cmd = binary + ["--in", "reads.txt", "--chain", chain, "--ref-dir", "ref", "--ins", "175", "--t", "1"] + flags
+            cmd = binary + ["--in", "reads.txt", "--chain", chain, "--ref-dir", "ref", "--ins", "175", "--t", "1"] + flags + (["--gpus", str(gpus)] if who == "hipN" else [])
             for attempt in range(8):
-                r = subprocess.run(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                r = subprocess.run(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                                   env=dict(os.environ, VDJX_MGPU_ONE_DEVICE="1", VDJX_MGPU_TIMEOUT_S="120") if who == "hipN" else None)
                 err = r.stderr.decode(errors="replace")
-                if who == "hip":
-                    assert r.returncode == 0, (cfg, err[-2000:])
+                if who != "ref":
+                    assert r.returncode == 0, (cfg, who, gpus, err[-2000:])
                     break
                 m1, m2 = re.search(r"num root nodes: (\d+)", err), re.search(r"HARNESS_ROOTS_SCORED\t(\d+)", err)
                 if m1 and m2 and m1.group(1) == m2.group(1):
@@ -232,5 +235,6 @@ def test_cli_end_to_end_random_pools_vs_the_compiled_reference(seed, n, tmp_path
         assert outs["hip"][0] == outs["ref"][0], (cfg, "vdj_contigs.fa differs")
         assert outs["hip"][1] == outs["ref"][1], (cfg, "SAM differs")
         assert outs["hip"][2] == outs["ref"][2], (cfg, "vdjer.dot differs")
+        assert outs["hipN"] == outs["ref"], (cfg, f"--gpus {gpus} differs from the reference")
         with_contigs += 1 if outs["ref"][0].count(b">") else 0
     assert with_contigs >= 1          # at least one configuration assembled contigs
