@@ -89,7 +89,7 @@ def main():
     P = 50 - k + 1
     dev = torch.device("cuda", 0)
     free, total = torch.cuda.mem_get_info()
-    need = int(os.environ.get("VDJX_REHEARSAL_NEED_GIB", "0")) << 30 or world * per * 2000           # (measured: see the lines printed)
+    need = int(os.environ.get("VDJX_REHEARSAL_NEED_GIB", "0")) << 30 or world * per * 2300           # (measured: ~170 GB of workspace at 8 x 12.5 M pairs, 79 GB of pools in flight)
     if free < need:
         print(json.dumps({"skipped": f"needs about {need >> 30} GiB of device memory, {free >> 30} GiB free"}))
         return 0

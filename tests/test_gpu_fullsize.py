@@ -372,9 +372,24 @@ def test_config4_geometry_rehearsed_on_one_gpu(per, chains, check):
     process for the three chain presets, instance ids past 2^32, 1.8 GB of exchange per rank.  At 8 x 8 M pairs the sharded graph is
     compared with the ONE-GPU build of the union pool (the most one context takes: records x offsets < 2^32), at the full size with the
     build of the same union by 4 ranks of 25 M pairs.  Fresh process (the 8 contexts hold ~160 GB of workspace between them)."""
+    import gc
     import json
     import subprocess
     import sys
+    # what this process still holds on the device (the 10 M / 40 M-pair tests' context keeps its workspace: tens of GB) goes back first
+    if _FS:
+        try:
+            _FS["p"].free()
+            _FS["ctx"].close()
+        except Exception:  # noqa: BLE001
+            pass
+        _FS.clear()
+    gc.collect()
+    try:
+        import torch
+        torch.cuda.empty_cache()
+    except Exception:  # noqa: BLE001
+        pass
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "config4_rehearsal.py"), str(per), "8", chains], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
