@@ -172,15 +172,21 @@ def lib():
         L.bamx_extract.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Reads)]
         L.bamx_free.argtypes = [C.POINTER(Reads)]
         L.bamx_is_bam.argtypes = [C.c_char_p]
+        L.bamx_threads.argtypes = [C.c_int]
+        L.bamx_threads.restype = None
+        L.bamx_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.bamx_seek.argtypes = [C.c_void_p, C.c_uint64]
         _L = L
     return _L
 
 
-def read_all(path: str):
-    """[(dict of the decoded fields)] for every record, plus the reference names"""
+def read_all(path: str, threads: int = 1):
+    """[(dict of the decoded fields)] for every record, plus the reference names (threads > 1: through the read-ahead)"""
     L = lib()
     f = L.bamx_open(path.encode())
     assert f, L.bamx_last_error()
+    if threads > 1:
+        assert L.bamx_set_threads(f, threads) == 0, L.bamx_last_error()
     refs = [L.bamx_ref_name(f, i).decode() for i in range(L.bamx_n_ref(f))]
     out, r = [], Rec()
     while True:
@@ -215,8 +221,9 @@ def query(path: str, region: str):
     return got, tell
 
 
-def extract(bam: str, vdj_fasta: str, v_region: str, c_region: str):
+def extract(bam: str, vdj_fasta: str, v_region: str, c_region: str, threads: int = 1):
     L = lib()
+    L.bamx_threads(threads)
     rs = Reads()
     rc = L.bamx_extract(bam.encode(), vdj_fasta.encode(), v_region.encode(), c_region.encode(), C.byref(rs))
     if rc:
@@ -225,6 +232,7 @@ def extract(bam: str, vdj_fasta: str, v_region: str, c_region: str):
            for i in range(rs.n)]
     info = dict(read_len=rs.read_len, max_len=rs.max_len, n_primary_names=rs.n_primary_names, n_secondary_names=rs.n_secondary_names)
     L.bamx_free(C.byref(rs))
+    L.bamx_threads(1)
     return out, info
 
 

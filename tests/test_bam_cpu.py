@@ -88,6 +88,8 @@ def test_writer_reader_round_trip(tmp_path, block):
     bam, _fa, voffs = _case(tmp_path, recs, ">x\nACGT\n", refs, block)
     names, got = B.read_all(bam)
     assert names == [r[0] for r in refs] and len(got) == len(recs)
+    for th in (2, 5):             # the same records, offsets included, with the blocks inflated ahead by other threads
+        assert B.read_all(bam, threads=th) == (names, got)
     for g, r, (u, v) in zip(got, recs, voffs):
         assert (g["qname"], g["flag"], g["tid"], g["pos"], g["seq"], g["qual"]) == (r["qname"], r["flag"], r["tid"], r["pos"], r["seq"], r["qual"])
         assert g["voff"] == u and g["tell"] == v and g["end"] == B.rec_end(r)
@@ -147,6 +149,7 @@ def test_extraction_rules_against_the_model(tmp_path, seed, n_other, n_v, n_c, n
     assert info == winfo
     assert got == want
     assert len(got) > 0
+    assert B.extract(bam, fa, VR, CR, threads=4) == (got, info)          # (`vdjer --t 4`: blocks inflated ahead of the parser in the sequential passes)
     pools = {p for p, *_ in got}
     assert "P" in pools or n_v + n_other == 0
     # the sequential pass starts where the iterators stopped: reads that lie before that point and outside both loci are not

@@ -246,8 +246,10 @@ def _bam_inputs(c, d):
     return bam, want
 
 
-def test_vdjer_cli_takes_a_bam(tmp_path):
-    """--in <bam>: extraction (bamx) + the same pipeline == the reference's outputs for the same reads"""
+@pytest.mark.parametrize("threads", ["1", "4"])
+def test_vdjer_cli_takes_a_bam(threads, tmp_path):
+    """--in <bam>: extraction (bamx) + the same pipeline == the reference's outputs for the same reads (--t 4: the BAM's blocks are
+    inflated ahead of the parser by other threads, the roots enumerated on four)"""
     from tests import bam_model as B
     tag = "e2e_tiled"
     exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
@@ -258,7 +260,7 @@ def test_vdjer_cli_takes_a_bam(tmp_path):
     got, xinfo = B.extract(bam, str(tmp_path / "ref" / "ig_vdj.fa"), "chr14:105566277-106879844", "chr14:105566277-105939754")
     assert xinfo["read_len"] == xinfo["max_len"] == c.pool.rl
     assert got == want                                    # same reads, same pools, same order as the pools the golden run was fed
-    cmd = [exe, "--in", "in.bam", "--chain", "IGH", "--ref-dir", "ref", "--ins", "175", "--t", "1"] + info["flags"]
+    cmd = [exe, "--in", "in.bam", "--chain", "IGH", "--ref-dir", "ref", "--ins", "175", "--t", threads] + info["flags"]
     r = subprocess.run(cmd, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert (tmp_path / "vdj_contigs.fa").read_text() == G.text(f"{tag}.contigs.fa.gz")

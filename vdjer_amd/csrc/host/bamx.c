@@ -8,6 +8,7 @@
 #include <string.h>
 #include <ctype.h>
 #include <zlib.h>
+#include <pthread.h>
 
 static char g_err[512];
 const char* bamx_last_error(void) { return g_err; }
@@ -22,10 +23,36 @@ static int fail(const char* fmt, ...) {
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* BGZF (bgzf.c): blocks are gzip members with a 'BC' extra field holding the block size                              */
 /* ------------------------------------------------------------------------------------------------------------------ */
+/* Read-ahead for the SEQUENTIAL passes of extract (bamx_set_threads): BGZF blocks are independent deflate streams, so while the
+ * consumer parses records the blocks behind it are already being inflated -- one thread reads raw blocks into a ring in file order,
+ * the others inflate them, the consumer takes them in order.  (The reference inflates on the thread that parses, one block at a time:
+ * with the assembly down to milliseconds the four passes over the BAM are what a run waits for.)  A seek empties the ring. */
+#define RA_SLOTS 128
+typedef struct {
+	int64_t addr;                     /* file offset of the block */
+	int bsize, count;                 /* compressed size; inflated size, or -1: error */
+	int state;                        /* 0 free, 1 raw, 2 being inflated, 3 inflated */
+	uint8_t raw[65536 + 64], out[65536];
+} ra_slot;
+typedef struct {
+	pthread_t reader, *workers;
+	int n_workers, started;
+	pthread_mutex_t mu;
+	pthread_cond_t cv;
+	ra_slot* ring;
+	uint64_t head, tail, next_job;    /* consumer takes ring[head % RA_SLOTS]; the reader fills [tail]; workers inflate [next_job] */
+	int eof, stop, err;               /* the reader saw the end of the file / shutdown / a malformed block */
+	char errmsg[160];
+	FILE* fp;
+} readahead;
+
 struct bamx_file {
 	FILE* fp;
 	int64_t block_address;            /* file offset of the current block */
 	int block_offset, block_length;   /* position inside / size of its inflated data; 0/0 = not loaded */
+	int64_t next_address;             /* file offset behind the current block (what ftello says without read-ahead) */
+	readahead* ra;
+	char path[4096];
 	uint8_t inflated[65536];
 	uint8_t raw[65536 + 64];
 	int n_ref;
@@ -46,8 +73,144 @@ static int rd_u16(const uint8_t* p) { return p[0] | (p[1] << 8); }
 static uint32_t rd_u32(const uint8_t* p) { return (uint32_t) p[0] | ((uint32_t) p[1] << 8) | ((uint32_t) p[2] << 16) | ((uint32_t) p[3] << 24); }
 static uint64_t rd_u64(const uint8_t* p) { return (uint64_t) rd_u32(p) | ((uint64_t) rd_u32(p + 4) << 32); }
 
+/* inflate one raw block (18-byte header checked by the caller): the inflated size, or -1 */
+static int inflate_block(const uint8_t* h, int bsize, uint8_t* out) {
+	z_stream zs;
+	memset(&zs, 0, sizeof zs);
+	zs.next_in = (Bytef*) (h + 18);
+	zs.avail_in = (uInt) (bsize - 18 - 8);
+	zs.next_out = out;
+	zs.avail_out = 65536;
+	if (inflateInit2(&zs, -15) != Z_OK) return -1;
+	const int rc = inflate(&zs, Z_FINISH);
+	inflateEnd(&zs);
+	if (rc != Z_STREAM_END) return -1;
+	if ((uint32_t) zs.total_out != rd_u32(h + bsize - 4)) return -1;
+	return (int) zs.total_out;
+}
+
+static void* ra_reader(void* arg) {
+	readahead* ra = (readahead*) arg;
+	for (;;) {
+		pthread_mutex_lock(&ra->mu);
+		while (!ra->stop && ra->tail - ra->head >= RA_SLOTS) pthread_cond_wait(&ra->cv, &ra->mu);
+		if (ra->stop) { pthread_mutex_unlock(&ra->mu); return NULL; }
+		ra_slot* sl = &ra->ring[ra->tail % RA_SLOTS];
+		pthread_mutex_unlock(&ra->mu);
+		/* (the slot is free and only this thread fills slots: no lock while reading the file) */
+		const int64_t addr = ftello(ra->fp);
+		uint8_t* h = sl->raw;
+		const size_t got = fread(h, 1, 18, ra->fp);
+		int bad = 0, end = 0, bsize = 0;
+		if (got == 0) end = 1;
+		else if (got != 18 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4) || rd_u16(h + 10) != 6 || h[12] != 'B' || h[13] != 'C' || rd_u16(h + 14) != 2) bad = 1;
+		else {
+			bsize = rd_u16(h + 16) + 1;
+			if (bsize < 26 || fread(h + 18, 1, (size_t) bsize - 18, ra->fp) != (size_t) bsize - 18) bad = 1;
+		}
+		pthread_mutex_lock(&ra->mu);
+		if (bad) { ra->err = 1; snprintf(ra->errmsg, sizeof ra->errmsg, "not a BGZF block (or a truncated one) at file offset %lld", (long long) addr); }
+		if (bad || end) { ra->eof = 1; pthread_cond_broadcast(&ra->cv); pthread_mutex_unlock(&ra->mu); return NULL; }
+		sl->addr = addr; sl->bsize = bsize; sl->state = 1;
+		ra->tail++;
+		pthread_cond_broadcast(&ra->cv);
+		pthread_mutex_unlock(&ra->mu);
+	}
+}
+
+static void* ra_worker(void* arg) {
+	readahead* ra = (readahead*) arg;
+	for (;;) {
+		pthread_mutex_lock(&ra->mu);
+		while (!ra->stop && !(ra->next_job < ra->tail) && !ra->eof) pthread_cond_wait(&ra->cv, &ra->mu);
+		if (ra->stop || !(ra->next_job < ra->tail)) {                   /* shutdown, or the file is read and every block taken */
+			const int done = ra->stop || ra->eof;
+			pthread_mutex_unlock(&ra->mu);
+			if (done) return NULL;
+			continue;
+		}
+		ra_slot* sl = &ra->ring[ra->next_job++ % RA_SLOTS];
+		sl->state = 2;
+		pthread_mutex_unlock(&ra->mu);
+		const int count = inflate_block(sl->raw, sl->bsize, sl->out);
+		pthread_mutex_lock(&ra->mu);
+		sl->count = count;
+		sl->state = 3;
+		pthread_cond_broadcast(&ra->cv);
+		pthread_mutex_unlock(&ra->mu);
+	}
+}
+
+static void ra_stop(bamx_file* f) {
+	readahead* ra = f->ra;
+	if (!ra) return;
+	if (ra->started) {
+		pthread_mutex_lock(&ra->mu);
+		ra->stop = 1;
+		pthread_cond_broadcast(&ra->cv);
+		pthread_mutex_unlock(&ra->mu);
+		pthread_join(ra->reader, NULL);
+		for (int i = 0; i < ra->n_workers; i++) pthread_join(ra->workers[i], NULL);
+	}
+	if (ra->fp) fclose(ra->fp);
+	pthread_mutex_destroy(&ra->mu);
+	pthread_cond_destroy(&ra->cv);
+	free(ra->workers);
+	free(ra->ring);
+	free(ra);
+	f->ra = NULL;
+}
+
+/* (re)start the read-ahead at file offset `from`, with `n` inflating threads */
+static int ra_start(bamx_file* f, int64_t from, int n) {
+	ra_stop(f);
+	readahead* ra = (readahead*) calloc(1, sizeof *ra);
+	if (!ra) return fail("out of memory");
+	ra->ring = (ra_slot*) calloc(RA_SLOTS, sizeof(ra_slot));
+	ra->workers = (pthread_t*) calloc((size_t) n, sizeof(pthread_t));
+	ra->fp = fopen(f->path, "rb");
+	pthread_mutex_init(&ra->mu, NULL);
+	pthread_cond_init(&ra->cv, NULL);
+	f->ra = ra;
+	if (!ra->ring || !ra->workers || !ra->fp || fseeko(ra->fp, (off_t) from, SEEK_SET) != 0) { ra_stop(f); return fail("cannot start the read-ahead on %s", f->path); }
+	ra->n_workers = n;
+	if (pthread_create(&ra->reader, NULL, ra_reader, ra) != 0) { ra_stop(f); return fail("pthread_create failed"); }
+	ra->started = 1;
+	for (int i = 0; i < n; i++)
+		if (pthread_create(&ra->workers[i], NULL, ra_worker, ra) != 0) { ra->n_workers = i; ra_stop(f); return fail("pthread_create failed"); }
+	return 0;
+}
+
 /* bgzf_read_block (bgzf.c): 0 = ok (block_length 0 at end of file), -1 = error */
 static int read_block(bamx_file* f) {
+	if (f->ra) {
+		readahead* ra = f->ra;
+		pthread_mutex_lock(&ra->mu);
+		while (!(ra->head < ra->tail && ra->ring[ra->head % RA_SLOTS].state == 3) && !(ra->eof && ra->head == ra->tail)) pthread_cond_wait(&ra->cv, &ra->mu);
+		if (ra->head == ra->tail) {                       /* the end of the file (or of what could be read of it) */
+			const int err = ra->err;
+			char msg[160];
+			memcpy(msg, ra->errmsg, sizeof msg);
+			pthread_mutex_unlock(&ra->mu);
+			if (err) return fail("%s", msg), -1;
+			f->block_length = 0;
+			return 0;
+		}
+		ra_slot* sl = &ra->ring[ra->head % RA_SLOTS];
+		pthread_mutex_unlock(&ra->mu);
+		if (sl->count < 0) return fail("inflate failed in the block at %lld", (long long) sl->addr), -1;
+		memcpy(f->inflated, sl->out, (size_t) sl->count);
+		if (f->block_length != 0) f->block_offset = 0;
+		f->block_address = sl->addr;
+		f->block_length = sl->count;
+		f->next_address = sl->addr + sl->bsize;
+		pthread_mutex_lock(&ra->mu);
+		sl->state = 0;
+		ra->head++;
+		pthread_cond_broadcast(&ra->cv);
+		pthread_mutex_unlock(&ra->mu);
+		return 0;
+	}
 	const int64_t addr = ftello(f->fp);
 	uint8_t* h = f->raw;
 	size_t got = fread(h, 1, 18, f->fp);
@@ -57,21 +220,12 @@ static int read_block(bamx_file* f) {
 	const int bsize = rd_u16(h + 16) + 1;
 	if (bsize < 26) return fail("BGZF block too short at %lld", (long long) addr), -1;
 	if (fread(h + 18, 1, (size_t) bsize - 18, f->fp) != (size_t) bsize - 18) return fail("truncated BGZF block at %lld", (long long) addr), -1;
-	z_stream zs;
-	memset(&zs, 0, sizeof zs);
-	zs.next_in = h + 18;
-	zs.avail_in = (uInt) (bsize - 18 - 8);
-	zs.next_out = f->inflated;
-	zs.avail_out = sizeof f->inflated;
-	if (inflateInit2(&zs, -15) != Z_OK) return fail("inflateInit2 failed"), -1;
-	const int rc = inflate(&zs, Z_FINISH);
-	inflateEnd(&zs);
-	if (rc != Z_STREAM_END) return fail("inflate failed in the block at %lld", (long long) addr), -1;
-	const int count = (int) zs.total_out;
-	if ((uint32_t) count != rd_u32(h + bsize - 4)) return fail("BGZF ISIZE mismatch at %lld", (long long) addr), -1;
+	const int count = inflate_block(h, bsize, f->inflated);
+	if (count < 0) return fail("inflate failed (or ISIZE mismatch) in the block at %lld", (long long) addr), -1;
 	if (f->block_length != 0) f->block_offset = 0;      /* do not reset the offset if this read follows a seek */
 	f->block_address = addr;
 	f->block_length = count;
+	f->next_address = addr + bsize;
 	return 0;
 }
 
@@ -93,7 +247,7 @@ static long bz_read(bamx_file* f, void* data, size_t length) {
 		done += take;
 	}
 	if (f->block_offset == f->block_length) {
-		f->block_address = ftello(f->fp);
+		f->block_address = f->next_address;             /* (= ftello(fp) of the plain reader: the next block's address) */
 		f->block_offset = f->block_length = 0;
 	}
 	return (long) done;
@@ -101,8 +255,24 @@ static long bz_read(bamx_file* f, void* data, size_t length) {
 
 uint64_t bamx_tell(const bamx_file* f) { return ((uint64_t) f->block_address << 16) | ((uint64_t) f->block_offset & 0xFFFF); }
 
+int bamx_set_threads(bamx_file* f, int n) {
+	if (n <= 1) { if (f->ra) { const int64_t at = f->next_address; ra_stop(f); if (fseeko(f->fp, (off_t) at, SEEK_SET) != 0) return fail("seek failed"); } return 0; }
+	/* what lies behind the block the reader holds (or the position it was sent to) is what the read-ahead starts with */
+	const int64_t from = f->block_length ? f->next_address : f->block_address;
+	return ra_start(f, from, n);
+}
+
 int bamx_seek(bamx_file* f, uint64_t voff) {            /* bgzf_seek (bgzf.c:847-866) */
+	if (f->ra) {                                       /* (the blocks read ahead are of no use at the new place) */
+		const int n = f->ra->n_workers;
+		f->block_length = 0;
+		f->block_address = (int64_t) (voff >> 16);
+		f->block_offset = (int) (voff & 0xFFFF);
+		f->next_address = f->block_address;
+		return ra_start(f, f->block_address, n);
+	}
 	if (fseeko(f->fp, (off_t) (voff >> 16), SEEK_SET) != 0) return fail("seek failed");
+	f->next_address = (int64_t) (voff >> 16);
 	f->block_length = 0;
 	f->block_address = (int64_t) (voff >> 16);
 	f->block_offset = (int) (voff & 0xFFFF);
@@ -126,6 +296,7 @@ bamx_file* bamx_open(const char* path) {
 	if (!f) return NULL;
 	f->fp = fopen(path, "rb");
 	if (!f->fp) { fail("cannot open %s", path); free(f); return NULL; }
+	snprintf(f->path, sizeof f->path, "%s", path);
 	uint8_t b[8];
 	if (bz_read(f, b, 4) != 4 || memcmp(b, "BAM\1", 4)) { fail("%s: no BAM magic", path); bamx_close(f); return NULL; }
 	if (bz_read(f, b, 4) != 4) { fail("%s: truncated header", path); bamx_close(f); return NULL; }
@@ -159,6 +330,7 @@ bamx_file* bamx_open(const char* path) {
 
 void bamx_close(bamx_file* f) {
 	if (!f) return;
+	ra_stop(f);
 	if (f->fp) fclose(f->fp);
 	for (int i = 0; i < f->n_ref; i++) free(f->ref_name ? f->ref_name[i] : NULL);
 	free(f->ref_name);
@@ -498,15 +670,52 @@ static const char* arena_str(blk** head, const char* s) {
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* extract (bam_read.c:294-446)                                                                                        */
 /* ------------------------------------------------------------------------------------------------------------------ */
-#define EXTRACT_KMER_SIZE 15
-
 static char complement(char c) {              /* bam_read.c:115-129 */
 	switch (c) { case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C'; default: return c; }
 }
 
 /* load_kmers (bam_read.c:180-204): 15-mers of every fgets chunk of ig_vdj.fa that is not a header, both strands; the chunk
  * loses its last character ("Remove newline") and the loop stops one k-mer short (i < strlen - 15) */
-static int load_vdj_kmers(const char* path, sset* set, blk** arena) {
+#define EXTRACT_KMER_SIZE 15
+/* The 15-mers of ig_vdj.fa that consist of A, C, G, T only (all of them, in practice) also go into a table of their 30-bit codes: the
+ * screen of extract's sequential pass asks 35 times per read whether a 15-mer of the read is one of them -- a rolling code and one probe
+ * of a table that stays in cache instead of hashing 15 characters and comparing strings (the reference's dense_hash_set of char*). */
+typedef struct { uint32_t* slot; size_t cap, n; } cset;          /* slot: code + 1, 0 = empty */
+static int base2(char c) { switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; } }
+static void cset_init(cset* t) { t->cap = 1 << 12; t->n = 0; t->slot = (uint32_t*) calloc(t->cap, 4); }
+static void cset_free(cset* t) { free(t->slot); t->slot = NULL; }
+static inline size_t cset_home(const cset* t, uint32_t code) { return ((size_t) code * 0x9E3779B1u >> 7) & (t->cap - 1); }
+static inline int cset_has(const cset* t, uint32_t code) {
+	for (size_t i = cset_home(t, code);; i = (i + 1) & (t->cap - 1)) {
+		const uint32_t c = t->slot[i];
+		if (!c) return 0;
+		if (c == code + 1) return 1;
+	}
+}
+static void cset_put(cset* t, uint32_t code) {
+	if (cset_has(t, code)) return;
+	if ((t->n + 1) * 4 > t->cap) {
+		uint32_t* old = t->slot;
+		const size_t oc = t->cap;
+		t->cap *= 2;
+		t->slot = (uint32_t*) calloc(t->cap, 4);
+		for (size_t i = 0; i < oc; i++)
+			if (old[i]) { size_t j = cset_home(t, old[i] - 1); while (t->slot[j]) j = (j + 1) & (t->cap - 1); t->slot[j] = old[i]; }
+		free(old);
+	}
+	size_t j = cset_home(t, code);
+	while (t->slot[j]) j = (j + 1) & (t->cap - 1);
+	t->slot[j] = code + 1;
+	t->n++;
+}
+/* the code of the 15 characters at s, or -1 if one of them is not A, C, G or T */
+static long code15(const char* s) {
+	uint32_t c = 0;
+	for (int i = 0; i < EXTRACT_KMER_SIZE; i++) { const int b = base2(s[i]); if (b < 0) return -1; c = (c << 2) | (uint32_t) b; }
+	return (long) c;
+}
+
+static int load_vdj_kmers(const char* path, sset* set, cset* codes, size_t* n_other, blk** arena) {
 	FILE* fp = fopen(path, "r");
 	if (!fp) return fail("Could not open file: [%s]", path);     /* the reference prints this and then crashes in fgets */
 	char buf[1024], rcb[1024];
@@ -519,13 +728,17 @@ static int load_vdj_kmers(const char* path, sset* set, blk** arena) {
 		if (n < EXTRACT_KMER_SIZE) continue;                       /* (size_t underflow in the reference: nothing sensible to add) */
 		for (size_t i = 0; i + EXTRACT_KMER_SIZE < n; i++) {
 			const char* two[2] = {buf + i, rcb + i};
-			for (int j = 0; j < 2; j++)
-				if (!sset_get(set, two[j])) {
+			for (int j = 0; j < 2; j++) {
+				const long cd = code15(two[j]);
+				if (cd >= 0) { cset_put(codes, (uint32_t) cd); continue; }
+				if (!sset_get(set, two[j])) {                      /* (a 15-mer with another letter in it: kept as text) */
 					char* p = arena_alloc(arena, EXTRACT_KMER_SIZE + 1);
 					memcpy(p, two[j], EXTRACT_KMER_SIZE);
 					p[EXTRACT_KMER_SIZE] = 0;
 					sset_put(set, p);
+					(*n_other)++;
 				}
+			}
 		}
 	}
 	fclose(fp);
@@ -556,6 +769,9 @@ static void push_read(bamx_reads* out, size_t* cap, char pool, const char* name,
 	strncpy(x->qual, r->qual, L);
 }
 
+static int g_threads = 1;
+void bamx_threads(int n) { g_threads = n < 1 ? 1 : (n > 64 ? 64 : n); }
+
 int bamx_extract(const char* bam_path, const char* vdj_fasta, const char* v_region, const char* c_region, bamx_reads* out) {
 	return bamx_extract_filtered(bam_path, vdj_fasta, v_region, c_region, NULL, NULL, out);
 }
@@ -580,12 +796,15 @@ int bamx_extract_filtered(const char* bam_path, const char* vdj_fasta, const cha
 		out->max_len = -1;
 	}
 	sset kmers, primary, secondary;
+	cset codes;
+	size_t n_other_kmers = 0;
 	sset_init(&kmers, EXTRACT_KMER_SIZE);
+	cset_init(&codes);
 	sset_init(&primary, 0);
 	sset_init(&secondary, 0);
 	bamx_file* f = NULL;
 	bamx_index* ix = NULL;
-	if ((rc = load_vdj_kmers(vdj_fasta, &kmers, &arena)) != 0) goto done;
+	if ((rc = load_vdj_kmers(vdj_fasta, &kmers, &codes, &n_other_kmers, &arena)) != 0) goto done;
 	f = bamx_open(bam_path);
 	if (!f) { rc = -2; goto done; }
 	ix = bamx_index_load(bam_path);
@@ -599,16 +818,35 @@ int bamx_extract_filtered(const char* bam_path, const char* vdj_fasta, const cha
 		fprintf(stderr, "secondary_reads size1: [%d]\n", (int) secondary.n);
 	}
 	/* "Process unmapped reads" (bam_read.c:346-374): sequential from WHEREVER the iterators left the file */
+	if (g_threads > 1 && bamx_set_threads(f, g_threads)) { rc = -2; goto done; }
 	while ((rc = bamx_read1(f, &rec)) >= 0) {
 		if (out->read_len == 0) out->read_len = rec.l_qseq;
 		const size_t L = strlen(rec.seq);
 		if (L < EXTRACT_KMER_SIZE) continue;                        /* (size_t underflow in the reference) */
-		for (size_t i = 0; i + EXTRACT_KMER_SIZE < L; i++) {
-			if (sset_get(&kmers, rec.seq + i)) {
-				if (!sset_get(&primary, rec.qname)) sset_put(&primary, arena_str(&arena, rec.qname));
-			} else if ((rec.flag & 4) && !sset_get(&secondary, rec.qname))
-				sset_put(&secondary, arena_str(&arena, rec.qname));
+		/* the reference's loop (bam_read.c:358-372) asks at every position: is this 15-mer a V/D/J one?  yes -> the name into the
+		 * primary set (if absent); no, and the read is unmapped -> into the secondary set (if absent).  What it leaves behind depends
+		 * on two facts only -- some position hit, some position missed -- so they are found with a rolling 2-bit code (a window with
+		 * another letter in it is looked up as text, in the few 15-mers of ig_vdj.fa that hold one) and the sets are touched once. */
+		int any_hit = 0, any_miss = 0;
+		{
+			const int want_miss = (rec.flag & 4) != 0;
+			uint32_t code = 0;
+			int run = 0;                                                /* consecutive A/C/G/T characters ending at the current one */
+			const size_t last = L - EXTRACT_KMER_SIZE;                  /* positions 0 .. last-1 are looked at (i + 15 < L) */
+			for (size_t j = 0; j + 1 < L && !(any_hit && (any_miss || !want_miss)); j++) {
+				const int b = base2(rec.seq[j]);
+				if (b < 0) run = 0; else { code = ((code << 2) | (uint32_t) b) & 0x3FFFFFFFu; run++; }
+				if (j + 1 < EXTRACT_KMER_SIZE) continue;
+				const size_t i = j + 1 - EXTRACT_KMER_SIZE;             /* the window [i, i + 15) ends at j */
+				if (i >= last) break;
+				int hit;
+				if (run >= EXTRACT_KMER_SIZE) hit = cset_has(&codes, code);
+				else hit = n_other_kmers ? sset_get(&kmers, rec.seq + i) != NULL : 0;
+				if (hit) any_hit = 1; else any_miss = 1;
+			}
 		}
+		if (any_hit && !sset_get(&primary, rec.qname)) sset_put(&primary, arena_str(&arena, rec.qname));
+		if (any_miss && (rec.flag & 4) && !sset_get(&secondary, rec.qname)) sset_put(&secondary, arena_str(&arena, rec.qname));
 	}
 	if (rc < -1) goto done;
 	rc = 0;
@@ -627,6 +865,7 @@ int bamx_extract_filtered(const char* bam_path, const char* vdj_fasta, const cha
 			bamx_index* ix2 = bamx_index_load(bam_path);          /* bam_open loads it again and fails without it */
 			if (!ix2) rc = -2;
 			bamx_index_free(ix2);
+			if (!rc && g_threads > 1 && bamx_set_threads(f, g_threads)) rc = -2;
 		}
 		while (!rc && (rc = bamx_read1(f, &rec)) >= 0) {
 			rc = 0;
@@ -650,7 +889,7 @@ int bamx_extract_filtered(const char* bam_path, const char* vdj_fasta, const cha
 done:
 	if (f) bamx_close(f);
 	bamx_index_free(ix);
-	sset_free(&kmers); sset_free(&primary); sset_free(&secondary);
+	sset_free(&kmers); cset_free(&codes); sset_free(&primary); sset_free(&secondary);
 	out->arena = arena;
 	if (rc) bamx_free(out);
 	return rc;

@@ -52,6 +52,9 @@ int bamx_extract(const char* bam_path, const char* vdj_fasta, const char* v_regi
 int bamx_extract_filtered(const char* bam_path, const char* vdj_fasta, const char* v_region, const char* c_region,
                           int (*keep)(void* ud, const char* name), void* ud, bamx_reads* out);
 void bamx_free(bamx_reads* r);
+/* threads that inflate BGZF blocks ahead of the parser in extract's sequential passes (1: none, the parser inflates as the reference's
+ * does; `vdjer --t N` passes N).  The records and their order do not depend on it. */
+void bamx_threads(int n);
 
 /* ---- lower level, exposed for the tests -------------------------------------------------------------------------- */
 typedef struct bamx_file bamx_file;
@@ -73,6 +76,7 @@ const char* bamx_ref_name(const bamx_file* f, int tid);
 int bamx_read1(bamx_file* f, bamx_rec* r);              /* >= 0 record read, -1 end of file, < -1 error */
 uint64_t bamx_tell(const bamx_file* f);                  /* bgzf_tell */
 int bamx_seek(bamx_file* f, uint64_t voff);
+int bamx_set_threads(bamx_file* f, int n);               /* read-ahead from the reader's position on with n inflating threads (<= 1: off) */
 bamx_index* bamx_index_load(const char* bam_path);       /* <bam_path>.bai */
 void bamx_index_free(bamx_index* ix);
 /* sam_itr_querys + the loop `while (sam_itr_next(...) >= 0)`: calls cb for every record the iterator returns; leaves the

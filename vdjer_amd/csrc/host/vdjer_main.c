@@ -294,6 +294,7 @@ static int build_reads(const collector* c, reads_t* r) {
 static int load_bam(const cli* c, collector* col) {
 	if (!c->vdj_fasta[0] || !c->v_region[0] || !c->c_region[0]) { fprintf(stderr, "BAM input needs --chain/--ref-dir (or --vdjf, --vr, --cr)\n"); return -1; }
 	bamx_reads br;
+	bamx_threads(c->threads);                              /* (--t: blocks are inflated ahead of the parser in the sequential passes) */
 	if (bamx_extract_filtered(c->in, c->vdj_fasta, c->v_region, c->c_region, col->nranks > 1 ? keep_name : NULL, col, &br)) { fprintf(stderr, "%s\n", bamx_last_error()); return -1; }
 	if (br.read_len != br.max_len) {
 		fprintf(stderr, "reads of different lengths (%d and %d): the reference lays its pools out with one length\n", br.read_len, br.max_len);
