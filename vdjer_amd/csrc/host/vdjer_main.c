@@ -158,12 +158,15 @@ typedef struct {
 	uint32_t *pair_id, *reg_rank;       /* per record of this process, block order */
 	uint32_t* scan_index;               /* `--gpus N`: place in the whole pool's scan order (primary pool, then secondary) */
 	uint8_t *read_num, *is_rc;
-	char** names;                       /* by pair id (the process's own numbering) */
+	char** names;                       /* by pair id (the process's own numbering); the characters live in `name_blocks` */
+	void* name_blocks;
 	uint32_t n_pairs;
 	uint64_t total_records;             /* of the whole pool */
 } reads_t;
 
 static char comp(char c) { switch (c) { case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C'; default: return c; } }
+static uint8_t comp_lut[256];
+static void comp_init(void) { if (!comp_lut['A']) for (int i = 0; i < 256; i++) comp_lut[i] = (uint8_t) comp((char) i); }
 
 /* one extracted read before it becomes two pool records */
 typedef struct {
@@ -177,24 +180,26 @@ typedef struct {
 	int max_len;
 	int rank, nranks;
 	int one_block;                      /* lay the records out as a share (one block), whatever nranks: the `--gpus N` code path */
-	str_blk* strs;                      /* names, sequences and qualities of the kept reads: appended to megabyte blocks (a malloc per field cost
-	                                     * more than reading it) */
+	str_blk *strs, *name_strs;          /* sequences and qualities / names of the kept reads: appended to megabyte blocks (a malloc per field
+	                                     * cost more than reading it); the names' blocks go on to the pool, which points into them */
 } collector;
 
-static char* col_str(collector* c, const char* s, size_t n) {
-	if (!c->strs || c->strs->used + n + 1 > c->strs->cap) {
+static char* blk_str(str_blk** head, const char* s, size_t n) {
+	if (!*head || (*head)->used + n + 1 > (*head)->cap) {
 		const size_t cap = n + 1 > ((size_t) 4 << 20) ? n + 1 : ((size_t) 4 << 20);
 		str_blk* b = (str_blk*) malloc(sizeof(str_blk) + cap);
 		if (!b) return NULL;
-		b->next = c->strs; b->used = 0; b->cap = cap;
-		c->strs = b;
+		b->next = *head; b->used = 0; b->cap = cap;
+		*head = b;
 	}
-	char* p = c->strs->data + c->strs->used;
+	char* p = (*head)->data + (*head)->used;
 	memcpy(p, s, n);
 	p[n] = 0;
-	c->strs->used += n + 1;
+	(*head)->used += n + 1;
 	return p;
 }
+static char* col_str(collector* c, const char* s, size_t n) { return blk_str(&c->strs, s, n); }
+static char* col_name(collector* c, const char* s, size_t n) { return blk_str(&c->name_strs, s, n); }
 
 static uint64_t name_hash(const char* s) {
 	uint64_t h = 1469598103934665603ull;
@@ -219,11 +224,12 @@ static int collect_n(collector* c, char pool, const char* name, size_t ln, int r
 	}
 	read_in* x = &c->v[c->n++];
 	x->pool = pool; x->rn = rn; x->rev = rev; x->seq_no = seq_no; x->pool_no = pool_no;
-	x->name = col_str(c, name, ln); x->seq = col_str(c, seq, ls); x->qual = col_str(c, qual, lq);
+	x->name = col_name(c, name, ln); x->seq = col_str(c, seq, ls); x->qual = col_str(c, qual, lq);
 	return x->name && x->seq && x->qual ? 0 : -1;
 }
 static void collector_free(collector* c) {
 	for (str_blk* b = c->strs; b;) { str_blk* nx = b->next; free(b); b = nx; }
+	for (str_blk* b = c->name_strs; b;) { str_blk* nx = b->next; free(b); b = nx; }
 	free(c->v);
 	memset(c, 0, sizeof *c);
 }
@@ -253,6 +259,7 @@ static int build_reads(const collector* c, reads_t* r) {
 	if (!r->primary || (!multi && !r->secondary) || !r->pair_id || !r->reg_rank || !r->scan_index || !r->read_num || !r->is_rc || !r->names) { fprintf(stderr, "out of memory\n"); return -1; }
 	sph_table ids;                       /* read name -> pair id */
 	sph_init(&ids, 0, 0);
+	comp_init();
 	size_t ip = 0, is = 0;
 	for (size_t q = 0; q < c->n; q++) {
 		const read_in* in = &c->v[q];
@@ -261,7 +268,7 @@ static int build_reads(const collector* c, reads_t* r) {
 		uint32_t pid;
 		if (b == (size_t) -1) {
 			pid = r->n_pairs++;
-			r->names[pid] = strdup(in->name);
+			r->names[pid] = in->name;                          /* (in the collector's string blocks, which this pool takes over) */
 			sph_map_put(&ids, r->names[pid], (void*) (uintptr_t) (pid + 1), NULL);
 		} else {
 			pid = (uint32_t) (uintptr_t) ids.b[b].val - 1;
@@ -274,7 +281,7 @@ static int build_reads(const collector* c, reads_t* r) {
 		memcpy(base + 1 + rl, in->qual, (size_t) rl);
 		base[rec] = '0';
 		for (int i = 0; i < rl; i++) {
-			base[rec + 1 + i] = (uint8_t) comp(in->seq[rl - 1 - i]);
+			base[rec + 1 + i] = comp_lut[(uint8_t) in->seq[rl - 1 - i]];
 			base[rec + 1 + rl + i] = (uint8_t) in->qual[rl - 1 - i];
 		}
 		for (int j = 0; j < 2; j++) {
@@ -307,7 +314,7 @@ static int load_bam(const cli* c, collector* col) {
 		const bamx_read* x = &br.v[i];
 		read_in* o = &col->v[col->n++];
 		o->pool = x->pool; o->rn = x->read_num; o->rev = x->is_rev; o->seq_no = x->seq_no; o->pool_no = x->pool_no;
-		o->name = col_str(col, x->name, strlen(x->name));
+		o->name = col_name(col, x->name, strlen(x->name));
 		o->seq = col_str(col, x->seq, (size_t) br.read_len);         /* (read_len characters, NUL padded by the extraction if the record was shorter) */
 		o->qual = col_str(col, x->qual, (size_t) br.read_len);
 	}
@@ -381,6 +388,7 @@ static int load_reads(const cli* c, reads_t* r, int rank, int nranks, int as_sha
 	int rc = isbam ? load_bam(c, &col) : load_text(c->in, &col);
 	if (!rc && col.max_len <= 0) { fprintf(stderr, "Error retrieving read length from: %s\n", c->in); rc = -1; }
 	if (!rc) rc = build_reads(&col, r);
+	if (!rc) { r->name_blocks = col.name_strs; col.name_strs = NULL; }      /* (the names point into them) */
 	collector_free(&col);
 	return rc;
 }
