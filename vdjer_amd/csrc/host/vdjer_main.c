@@ -763,7 +763,10 @@ int main(int argc, char** argv) {
 		while (g_kid_state[r] == 0) {
 			int st_ = 0;
 			const pid_t p = waitpid(g_kids[r], &st_, 0);
-			if (p == g_kids[r]) g_kid_state[r] = (WIFEXITED(st_) && WEXITSTATUS(st_) == 0) ? 1 : 2;
+			if (p == g_kids[r]) {
+				g_kid_state[r] = (WIFEXITED(st_) && WEXITSTATUS(st_) == 0) ? 1 : 2;
+				if (g_kid_state[r] == 2) fprintf(stderr, "rank %d ended with %s %d\n", r, WIFSIGNALED(st_) ? "signal" : "status", WIFSIGNALED(st_) ? WTERMSIG(st_) : WEXITSTATUS(st_));
+			}
 			else if (p < 0 && errno != EINTR) break;          /* reaped by the handler meanwhile */
 		}
 		if (g_kid_state[r] != 1) { fprintf(stderr, "rank %d failed\n", r); return 1; }
