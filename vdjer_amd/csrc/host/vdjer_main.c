@@ -767,7 +767,13 @@ int main(int argc, char** argv) {
 				g_kid_state[r] = (WIFEXITED(st_) && WEXITSTATUS(st_) == 0) ? 1 : 2;
 				if (g_kid_state[r] == 2) fprintf(stderr, "rank %d ended with %s %d\n", r, WIFSIGNALED(st_) ? "signal" : "status", WIFSIGNALED(st_) ? WTERMSIG(st_) : WEXITSTATUS(st_));
 			}
-			else if (p < 0 && errno != EINTR) break;          /* reaped by the handler meanwhile */
+			else if (p < 0 && errno != EINTR) {
+				/* reaped by the SIGCHLD handler -- which may be running on ANOTHER thread of this process (the GPU runtime has some,
+				 * and a signal goes to any thread that does not block it): between its waitpid and its note of the outcome this
+				 * thread can get here.  Its note comes within microseconds; a rank it found to have failed ends the process there. */
+				for (int spin = 0; spin < 5000 && g_kid_state[r] == 0; spin++) usleep(1000);
+				break;
+			}
 		}
 		if (g_kid_state[r] != 1) { fprintf(stderr, "rank %d failed\n", r); return 1; }
 	}
