@@ -126,6 +126,8 @@ int vdjx_anchor_sets_from_anchors(vdjx_ctx* ctx, const uint32_t* v_anchors, size
 /* ---- result buffers ------------------------------------------------------------------------------
  * Every result pointer of this interface may be ordinary host memory.  Memory from vdjx_host_alloc is
  * page-locked: copies into it run at DMA speed (the graph of 1 M pairs is ~11 MB, the mapped pairs ~11 MB).
+ * Windows / contigs handed to the scorers in such memory are not copied at all: the classifying kernel reads them where they lie
+ * (each character once, over PCIe), and they must stay unchanged until the call returns -- as for any argument.
  * No counterpart in the reference (its tables are host memory throughout).                          */
 int vdjx_host_alloc(vdjx_ctx* ctx, size_t bytes, void** out);
 void vdjx_host_free(vdjx_ctx* ctx, void* p);

@@ -1,0 +1,8 @@
+# quick look: parity of the k-mer build + the default line's kernel times (gpurun -- 'bash profiles/quick.sh [bench args]')
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
+python bench.py --no-cpu --steps 30 "$@" 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(d['value'], d['ms_per_step'], d['device_busy_frac'], d['parity_gate'], (d['parity_gate_timed_step'] or {}).get('ok'))
+print({k:round(v,3) for k,v in d['kernels_ms_per_step'].items()})
+"

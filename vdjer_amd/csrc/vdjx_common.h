@@ -8,6 +8,8 @@
 #include <vector>
 #include <chrono>
 #include <map>
+#include <mutex>
+#include <utility>
 
 #include "../../include/vdjx.h"
 
@@ -134,6 +136,8 @@ struct vdjx_ctx {
 	u32* d_ri_dstart = nullptr;       // class -> first of its DISTINCT read-1 entries (window scoring counts, it does not name pairs)
 	u64* d_ri_d8 = nullptr;           // those entries, with multiplicities
 	size_t ri_cap[9] = {};            // bytes behind the nine arrays above (kept from build to build, vdjx_rindex.hip ri_keep)
+	std::vector<std::pair<const char*, size_t>> host_blocks;     // vdjx_host_alloc's page-locked blocks (the scorers read strings that lie in one of them in place)
+	std::mutex host_blocks_mu;
 	// cached result of the last vdjx_map_emit count call (the write call of the two-call protocol reuses it)
 	uint64_t me_key = 0;
 	const void* me_src = nullptr;     // the batch the cached mapping belongs to
@@ -218,6 +222,7 @@ struct vdjx_graph {
 };
 
 bool vdjx_ctx_alive(const vdjx_ctx* c);   // a pool or graph may be freed after its context
+bool vdjx_host_block_holds(vdjx_ctx* c, const void* p, size_t bytes);   // [p, p + bytes) inside a block of vdjx_host_alloc (vdjx_core.hip)
 
 // scoped workspace allocations out of the context's arena
 struct vdjx_work {
@@ -270,6 +275,25 @@ __host__ __device__ inline u64 vdjx_mix(u64 lo, u64 hi) {
 	x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
 	x ^= x >> 32;
 	return x;
+}
+
+// the partition's hash of a k-mer: only where a k-mer's tuples MEET depends on it (its bucket; in the sharded build its owner), no
+// result does.  Every gated instance is hashed five times on its way into its bucket (histogram, both placements of both partition
+// passes) and the multiplier runs at a quarter of the ALU rate: four 32-bit multiplications here against the twelve the three 64-bit
+// products of vdjx_mix compile to.  32 result bits on top of the word (the buckets use at most 20); every input bit flips every one
+// of them with probability 0.49-0.51 (profiles/micro/bucket_hash.py), bucket occupancies of real k-mer sets as Poisson as vdjx_mix's.
+__host__ __device__ inline u64 vdjx_bucket_mix(u64 lo, u64 hi) {
+	u32 c = (u32) hi ^ ((u32) (hi >> 32) << 26);            // (2k - 64 <= 36 bits)
+	u32 h = (c ^ (c >> 15)) * 0x9E3779B1u;
+	h ^= h >> 15;
+	h = (h ^ (u32) lo) * 0x85EBCA6Bu;
+	h ^= h >> 13;
+	const u32 b = (u32) (lo >> 32);
+	h = (h ^ b ^ (b >> 16)) * 0xC2B2AE35u;
+	h ^= h >> 16;
+	h *= 0x27D4EB2Fu;
+	h ^= h >> 15;
+	return (u64) h << 32;
 }
 
 // hash of a read of W words (the read index: vdjx_rindex.hip, k_map_classify)

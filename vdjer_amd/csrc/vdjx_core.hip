@@ -735,13 +735,30 @@ extern "C" int vdjx_host_alloc(vdjx_ctx* c, size_t bytes, void** out) {
 	*out = nullptr;
 	HIP_TRY(hipSetDevice(c->device));
 	HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+	{
+		std::lock_guard<std::mutex> g(c->host_blocks_mu);
+		c->host_blocks.emplace_back((const char*) *out, bytes ? bytes : 1);
+	}
 	return VDJX_OK;
 }
 
 extern "C" void vdjx_host_free(vdjx_ctx* c, void* p) {
 	if (!p) return;
-	if (c) (void) hipSetDevice(c->device);
+	if (c) {
+		(void) hipSetDevice(c->device);
+		std::lock_guard<std::mutex> g(c->host_blocks_mu);
+		for (size_t i = 0; i < c->host_blocks.size(); i++)
+			if (c->host_blocks[i].first == (const char*) p) { c->host_blocks.erase(c->host_blocks.begin() + (long) i); break; }
+	}
 	(void) hipHostFree(p);
+}
+
+// [p, p + bytes) inside one of the context's own page-locked blocks?  (hipHostMalloc'ed memory has one address on both sides)
+bool vdjx_host_block_holds(vdjx_ctx* c, const void* p, size_t bytes) {
+	std::lock_guard<std::mutex> g(c->host_blocks_mu);
+	for (const auto& b : c->host_blocks)
+		if ((const char*) p >= b.first && (const char*) p + bytes <= b.first + b.second) return true;
+	return false;
 }
 
 extern "C" int vdjx_host_take_rows(void* dst, const void* src, size_t stride, size_t first, size_t len, const uint32_t* idx, size_t n) {

@@ -264,7 +264,13 @@ __device__ inline void stage_row_long(u64* row, const u64* __restrict__ bases, s
 template <bool LONG>
 __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                              const u64* __restrict__ lowq, size_t R, int rl, int k, u32 nb_bits,
-                                                             size_t rpb, u32* __restrict__ bucket_cnt) {
+                                                             size_t rpb, u32* __restrict__ bucket_cnt, u32 dbg_in) {
+#ifdef VDJX_ABLATE                  // profiles/histdbg.py: 1 = loads and gate masks only, 2 = + the listing, 3 = + k-mers and hashes, 4 = all but the flush
+	const u32 dbg = dbg_in;
+#else
+	const u32 dbg = 0u;
+#endif
+	u32 sink = 0;
 	extern __shared__ __attribute__((aligned(16))) u32 hist[];       // [NB], then GL_WAVE_BYTES per wave
 	const u32 NB = 1u << nb_bits;
 	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) hist[i] = 0;
@@ -294,10 +300,12 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 			const u32 c = (u32) __popc(g);
 			const u32 incl = (u32) vdjx_wave_scan_add((int) c);
 			const u32 total = (u32) __builtin_amdgcn_readlane((int) incl, 63);
+			if (dbg == 1) { sink += incl; continue; }
 			if (!total) continue;                                     // (wave-uniform)
 			u32 at = incl - c;
 			for (u32 gg = g; gg; gg &= gg - 1) wl[at++] = (uint16_t) ((lane << (LONG ? 8 : 6)) | (u32) (ob + __builtin_ctz(gg)));
 			vdjx_wave_lds_fence();                                    // the list and the records are read by OTHER lanes of the wave
+			if (dbg == 2) { sink += wl[lane]; vdjx_wave_lds_fence(); continue; }
 			for (u32 i = lane; i < total; i += 64) {
 				const u32 e = wl[i];
 				u64 khi, klo;
@@ -306,12 +314,14 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 					const ulonglong2 bb = wb[e >> 6];
 					vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) (e & 63u), khi, klo);
 				}
-				atomicAdd(&hist[(u32) (vdjx_mix(klo, khi) >> (64 - nb_bits))], 1u);
+				if (dbg == 3) { sink += (u32) (vdjx_bucket_mix(klo, khi) >> (64 - nb_bits)); continue; }
+				atomicAdd(&hist[(u32) (vdjx_bucket_mix(klo, khi) >> (64 - nb_bits))], 1u);
 			}
 			vdjx_wave_lds_fence();                                    // ... before the next 16 offsets overwrite the list
 		}
 	}
 	__syncthreads();
+	if (dbg) { if (sink == 0x12345u) bucket_cnt[0] = sink; return; }
 	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) if (hist[i]) atomicAdd(&bucket_cnt[i], hist[i]);
 }
 
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 						const ulonglong2 bb = wb[e >> 6];
 						vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) (e & 63u), khi, klo);
 					}
-					const u32 b = (u32) (vdjx_mix(klo, khi) >> shift) & mask;
+					const u32 b = (u32) (vdjx_bucket_mix(klo, khi) >> shift) & mask;
 					atomicAdd(&cnt[b], 1u);
 					if (dbase + i < ROUND) desc[dbase + i] = ((loc0 + (e >> OB)) << (OB + 10)) | ((e & ((1u << OB) - 1u)) << 10) | b;
 				}
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 		__syncthreads();
 		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
 			const TUP t = TUP::load(&stage[i]);
-			const u32 b = (u32) (vdjx_mix(t.lo, t.hi()) >> shift) & mask;
+			const u32 b = (u32) (vdjx_bucket_mix(t.lo, t.hi()) >> shift) & mask;
 			TUP::store(&out[gbase[b] + (i - base[b])], t);
 		}
 		__syncthreads();
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_tuples_g(const TUP* __res
 			r_b[j] = NONE32;
 			if (t < te) {
 				r_t[j] = TUP::load(&in[t]);
-				r_b[j] = (u32) (vdjx_mix(r_t[j].lo, r_t[j].hi()) >> shift) & mask;
+				r_b[j] = (u32) (vdjx_bucket_mix(r_t[j].lo, r_t[j].hi()) >> shift) & mask;
 			}
 		}
 #pragma unroll
@@ -473,7 +483,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_tuples_g(const TUP* __res
 		const u32 n = base[nbk];
 		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
 			const TUP x = stage[i];
-			const u32 b = (u32) (vdjx_mix(x.lo, x.hi()) >> shift) & mask;
+			const u32 b = (u32) (vdjx_bucket_mix(x.lo, x.hi()) >> shift) & mask;
 			TUP::store(&out[gbase[b] + (i - base[b])], x);
 		}
 		__syncthreads();
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(512) void k_seg_hist_g(const TUP* __restrict__ in, 
 	const size_t t1 = t0 + per < s1 ? t0 + per : s1;
 	for (size_t t = t0 + threadIdx.x; t < t1; t += 512) {
 		const TUP x = TUP::load(&in[t]);
-		atomicAdd(&h[(u32) (vdjx_mix(x.lo, x.hi()) >> shift) & (nbk - 1)], 1u);
+		atomicAdd(&h[(u32) (vdjx_bucket_mix(x.lo, x.hi()) >> shift) & (nbk - 1)], 1u);
 	}
 	__syncthreads();
 	for (u32 i = threadIdx.x; i < nbk; i += 512) if (h[i]) atomicAdd(&fine_cnt[((size_t) seg << sub_bits) | i], h[i]);
@@ -2249,7 +2259,9 @@ int stage_gated_hist(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, size_t pe
 	u32 HB = ceil_log2_u64((NI + per - 1) / per);
 	HB = std::max(8u, std::min(hb_max, HB));
 	const u32 NBH = 1u << HB;
-	u32 nblk = (u32) std::min<size_t>(512, (R + 4095) / 4096);
+	static const u32 hist_dbg = (u32) tune("VDJX_HIST_DBG", 0);      // (ablation build only: profiles/histdbg.py)
+	static const size_t hist_blocks = tune("VDJX_HIST_BLOCKS", 512);
+	u32 nblk = (u32) std::min<size_t>(hist_blocks, (R + 4095) / 4096);
 	if (nblk == 0) nblk = 1;
 	size_t rpb = (R + nblk - 1) / nblk;
 	u32 *hcnt, *hstart;
@@ -2262,14 +2274,17 @@ int stage_gated_hist(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, size_t pe
 	HIP_TRY(hipFuncSetAttribute((const void*) k_gated_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_hist));
 	{
 		vdjx_prof_scope ps(c, "k_gated_hist");
-		if (lng) hipLaunchKernelGGL(k_gated_hist<true>, dim3(nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, pool->rl, k, HB, rpb, hcnt);
-		else hipLaunchKernelGGL(k_gated_hist<false>, dim3(nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, pool->rl, k, HB, rpb, hcnt);
+		if (lng) hipLaunchKernelGGL(k_gated_hist<true>, dim3(nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, pool->rl, k, HB, rpb, hcnt, hist_dbg);
+		else hipLaunchKernelGGL(k_gated_hist<false>, dim3(nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, pool->rl, k, HB, rpb, hcnt, hist_dbg);
 	}
 	dbg_sync(c, "k_gated_hist");
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, hcnt, NBH, hstart);
 	HIP_TRY(hipMemcpyAsync(c->h_pin, hstart + NBH, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+#ifdef VDJX_ABLATE
+	if (hist_dbg) return VDJX_ESTATE;             // (a cut histogram sizes nothing: the build stops here, profiles/histdbg.py reads the kernel's time)
+#endif
 	const u32 N = *(const u32*) c->h_pin;
 	c->stats["gated_instances"] = N;                // k-mer instances that pass include_kmer (A2:240-259) in this pool
 	gh->HB = HB; gh->NBH = NBH; gh->N = N; gh->hstart = hstart;

@@ -1575,7 +1575,13 @@ static int classify_and_plan(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix,
 	mp->d_hits = d_hits;
 	// the strings cross PCIe in pieces on a stream of their own, each piece classified as soon as it is there (8.7 MB of windows: 0.18 ms
 	// of which the first quarter is waited for)
-	const u32 pieces = n * (size_t) len >= (2u << 20) ? 4u : 1u;
+	// ... unless they lie in page-locked host memory of the context's own (vdjx_host_alloc): then the
+	// kernel reads them where they are -- every character is read exactly once, 64 consecutive bytes per wave, and the other workgroups
+	// of a CU classify while one waits for its string; no copy, no pieces, nothing for the stream to wait for
+	static const bool zero_copy = !(getenv("VDJX_STRINGS_IN_PLACE") && atoi(getenv("VDJX_STRINGS_IN_PLACE")) == 0);
+	const char* d_src = nullptr;
+	if (zero_copy && vdjx_host_block_holds(c, strings, n * (size_t) len)) d_src = strings;      // (asking the runtime about a foreign pointer costs more than the copy saves)
+	const u32 pieces = d_src ? 1u : n * (size_t) len >= (2u << 20) ? 4u : 1u;
 	if (pieces > 1) {
 		HIP_TRY(hipEventRecord(c->ev_up[0], st));                  // (the arena's last users are on `st`)
 		HIP_TRY(hipStreamWaitEvent(c->up_stream, c->ev_up[0], 0));
@@ -1586,10 +1592,11 @@ static int classify_and_plan(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix,
 			HIP_TRY(hipMemcpyAsync(d_s + a * len, strings + a * len, (b - a) * len, hipMemcpyHostToDevice, c->up_stream));
 			HIP_TRY(hipEventRecord(c->ev_up[1 + pc], c->up_stream));
 			HIP_TRY(hipStreamWaitEvent(st, c->ev_up[1 + pc], 0));
-		} else
+		} else if (!d_src)
 			HIP_TRY(hipMemcpyAsync(d_s, strings, n * len, hipMemcpyHostToDevice, st));
 		vdjx_prof_scope ps(c, "k_map_classify");
 		const dim3 grid((u32) std::min<size_t>(b - a, 8192));
+		if (d_src) d_s = const_cast<char*>(d_src);
 		if (c->ri_pool->W == 2) hipLaunchKernelGGL(k_map_classify<2>, grid, dim3(MAP_THREADS), 0, st, ix, d_s, (u32) b, len, weighted, mp->d_prep, d_hits, d_inst, d_gkey, d_gidx, (u32) a);
 		else hipLaunchKernelGGL(k_map_classify<VDJX_LONG_W>, grid, dim3(MAP_THREADS), 0, st, ix, d_s, (u32) b, len, weighted, mp->d_prep, d_hits, d_inst, d_gkey, d_gidx, (u32) a);
 	}
