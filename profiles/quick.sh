@@ -6,3 +6,6 @@ d=json.loads(sys.stdin.read())
 print(d['value'], d['ms_per_step'], d['device_busy_frac'], d['parity_gate'], (d['parity_gate_timed_step'] or {}).get('ok'))
 print({k:round(v,3) for k,v in d['kernels_ms_per_step'].items()})
 "
+python bench.py --no-cpu --pairs 1000000 --steps 100 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('1M', d['value'], d['ms_per_step'], d['device_busy_frac'], {k:round(v,3) for k,v in d['kernels_ms_per_step'].items() if v>0.05})"

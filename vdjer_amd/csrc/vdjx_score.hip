@@ -737,6 +737,9 @@ __global__ __launch_bounds__(1024) void k_plan(const u32* __restrict__ hits_g, c
 #ifndef COVER_RULE2
 #define COVER_RULE2 true             // (ablation: -DCOVER_RULE2=false)
 #endif
+#ifndef COVER_BITS
+#define COVER_BITS true              // (-DCOVER_BITS=false: floor 1 through the difference arrays too)
+#endif
 #define HIT_CHUNK 524288u        // hits per workgroup of k_window_pairs: only the very deepest windows are split (every piece loads the
                                  // window's image once; measured at 10 M pairs: 65536 -> 5.2 ms, 262144 and above -> 3.5 ms)
 
@@ -1166,11 +1169,22 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 	if (tid == 0) { s_bad = 0; s_ok = 0; }
 	__syncthreads();
 	u32* myh = priv ? hp + wv * (u32) (D + 1) : hf;
-	for (u32 q = tid; q < npairs; q += MAP_THREADS) {
-		const u64 pe = pairs[q];
+	// (the list is roughly offset-major: the 64 consecutive entries of a wave mostly start at ONE position -- 64 adds to one LDS word go
+	// one at a time -- so the lanes that share the first lane's position are summed in registers and added once)
+	for (u32 q0 = 0; q0 < npairs; q0 += MAP_THREADS) {
+		const u32 q = q0 + tid;
+		const bool have = q < npairs;
+		const u64 pe = have ? pairs[q] : 0ull;
 		const u32 pr = (u32) pe, mult = (u32) (pe >> 32);
-		atomicAdd(&myh[pr >> 16], mult);
-		atomicAdd(&myh[pr & 0xFFFFu], mult);
+		const u32 first_pos = (u32) __builtin_amdgcn_readfirstlane((int) (pr >> 16));     // (a wave's missing lanes are its last)
+		const bool same = have && (pr >> 16) == first_pos;
+		if (__popcll(__ballot(same)) >= 8) {
+			const u32 sum = (u32) __builtin_amdgcn_readlane(vdjx_wave_scan_add((int) (same ? mult : 0u)), 63);
+			if ((tid & 63u) == 0) atomicAdd(&myh[first_pos], sum);
+			if (have && !same) atomicAdd(&myh[pr >> 16], mult);
+		} else if (have)
+			atomicAdd(&myh[pr >> 16], mult);
+		if (have) atomicAdd(&myh[pr & 0xFFFFu], mult);
 	}
 	__syncthreads();
 	if (priv) {
@@ -1235,7 +1249,73 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 	__syncthreads();
 	// ---- rule 2.  Coverage only grows with more entries, so the pair list is replayed in doubling chunks and
 	// a batch of deltas is done as soon as every tested (pos, delta) already reaches the floor.
-	for (int d0 = clo; d0 < chi && !s_bad && COVER_RULE2; d0 += DB) {
+	// Floor 1 (the reference's default, params.c:64) asks whether every tested (position, delta) is covered AT ALL -- one bit each -- and
+	// that needs no pass over (entry, position, delta): an entry (read at f, mate at s) is ONE bit of a grid, row f, column s - f; the
+	// mate sees position pos + delta iff s lies in (pos + delta - rl, pos + delta], the read sees pos iff f lies in (pos - rl, pos].  So
+	//   covered(pos, delta)  =  OR over t = pos - f in [0, rl)  of  "row pos - t has a bit in columns [t + i, t + i + rl)",  i = delta - clo,
+	// i.e. with every row smeared over rl columns once (log2(rl) shifts): the word of deltas of a position is the OR of rl shifted
+	// row words.  Cost per window: one LDS atomic per entry, then (positions + rl) x a few words -- whatever the depth.  (The
+	// difference arrays below pay two LDS atomics per entry AND delta plus a scan per delta, in batches of 22 deltas, and replay the
+	// list in growing chunks until the window is covered: 0.36 ms for ONE window of 15,000 entries, the tail of the whole kernel.)
+	const int nd_all = chi - clo;
+	const int fmin = e0 - rl + 1 > 0 ? e0 - rl + 1 : 0;            // rows: reads at fmin .. e1 - 1
+	const int nrows = e1 - fmin;
+	const int nbits = nd_all + 2 * rl;                             // columns: s - f - (clo - rl + 1) in [0, nd_all + 2 rl - 2)
+	const int nwb = (nbits + 63) >> 6;
+	const bool by_bits = fl == 1 && nd_all >= 1 && nd_all <= 64 && nrows >= 1 && nrows * nwb * 2 <= COV_WORDS && COVER_RULE2 && COVER_BITS;
+	if (by_bits && !s_bad) {
+		u64* grid = (u64*) diff;
+		const int dmin = clo - rl + 1;
+		for (int i = tid; i < nrows * nwb; i += MAP_THREADS) grid[i] = 0;
+		__syncthreads();
+		for (u32 q = tid; q < 2 * npairs; q += MAP_THREADS) {
+			const u32 pr = (u32) pairs[q >> 1];
+			const int p1 = (int) (pr >> 16), p2 = (int) (pr & 0xFFFFu);
+			const int f = (q & 1) ? p2 : p1, sx = (q & 1) ? p1 : p2;
+			const int y = sx - f - dmin;
+			if (f < fmin || f >= e1 || y < 0 || y >= nbits) continue;
+			u64* w = &grid[(f - fmin) * nwb + (y >> 6)];
+			const u64 bit = 1ull << (y & 63);
+			if (!(vdjx_peek(w) & bit)) atomicOr((unsigned long long*) w, (unsigned long long) bit);
+		}
+		__syncthreads();
+		// smear: bit z of a row <- OR of its bits z .. z + rl - 1 (a thread per row, words in ascending order: a word only reads itself
+		// and the words above it)
+		for (int r = tid; r < nrows; r += MAP_THREADS) {
+			u64* row = grid + r * nwb;
+			auto or_shifted = [&](int sh) {
+				const int ws = sh >> 6, bs = sh & 63;
+				for (int j = 0; j + ws < nwb; j++) {
+					const u64 lo = row[j + ws], hi = j + ws + 1 < nwb ? row[j + ws + 1] : 0ull;
+					row[j] |= bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
+				}
+			};
+			int cur = 1;
+			while (cur * 2 <= rl) { or_shifted(cur); cur *= 2; }
+			if (rl > cur) or_shifted(rl - cur);
+		}
+		__syncthreads();
+		for (int p = tid; p < npos; p += MAP_THREADS) {
+			const int pos = e0 + p;
+			const bool evaluated = pos == e0 || (pos - 1 + clo) < e1;    // the loop tests the previous mate_low (coverage.c:25)
+			int mh = pos + chi;
+			if (mh > e1) mh = e1 + 1;                                    // coverage.c:36-38
+			const int nreq = (mh - pos < chi ? mh - pos : chi) - clo;    // deltas clo .. clo + nreq - 1 are tested at pos
+			if (!evaluated || nreq <= 0) continue;
+			if (pos + clo < 0 || pos + clo + nreq - 1 > len + 1023) { s_bad = 1; continue; }      // outside the reference's array: undefined there
+			const u64 req = nreq >= 64 ? ~0ull : (1ull << nreq) - 1ull;
+			u64 acc = 0;
+			for (int t = 0; t < rl && pos - t >= fmin; t++) {
+				const u64* row = grid + (pos - t - fmin) * nwb;
+				const int ws = t >> 6, bs = t & 63;
+				const u64 lo = row[ws], hi = ws + 1 < nwb ? row[ws + 1] : 0ull;
+				acc |= bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
+			}
+			if ((acc & req) != req) s_bad = 1;
+		}
+		__syncthreads();
+	}
+	for (int d0 = clo; d0 < chi && !s_bad && COVER_RULE2 && !by_bits; d0 += DB) {
 		const int nd = chi - d0 < DB ? chi - d0 : DB;
 		for (int i = tid; i < nd * stride; i += MAP_THREADS) diff[i] = 0;
 		__syncthreads();
@@ -1724,7 +1804,32 @@ static int window_score_slice(vdjx_ctx* c, const ReadIndexDev& ix, const char* w
 	c->wp_n = 0;                                              // (the lists are not offered to vdjx_window_pairs_fetch)
 	{
 		vdjx_prof_scope ps(c, "k_window_cover");
-		hipLaunchKernelGGL(k_window_cover, dim3((u32) n), dim3(MAP_THREADS), 0, st, len, ix.rl, *p, mp.d_order, mp.d_off, (const u64*) c->wp_buf, d_cnt, d_valid, (u64*) nullptr);
+		u64* d_clk = nullptr;
+		static const bool cover_clocks = getenv("VDJX_COVER_CLOCKS") != nullptr;       // profiling aid: the slowest windows of the call to stderr
+		if (cover_clocks) HIP_TRY(db.alloc(&d_clk, n));
+		hipLaunchKernelGGL(k_window_cover, dim3((u32) n), dim3(MAP_THREADS), 0, st, len, ix.rl, *p, mp.d_order, mp.d_off, (const u64*) c->wp_buf, d_cnt, d_valid, d_clk);
+		if (cover_clocks) {
+			std::vector<u64> clk(n);
+			std::vector<u32> cnt(n), ord(n);
+			std::vector<uint8_t> val(n);
+			HIP_TRY(hipStreamSynchronize(st));
+			HIP_TRY(hipMemcpy(clk.data(), d_clk, n * 8, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(cnt.data(), d_cnt, n * 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(ord.data(), mp.d_order, n * 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(val.data(), d_valid, n, hipMemcpyDeviceToHost));
+			std::vector<u32> by(n);
+			for (size_t i = 0; i < n; i++) by[i] = (u32) i;
+			std::sort(by.begin(), by.end(), [&](u32 a, u32 b) { return clk[a] > clk[b]; });
+			u64 sum = 0;
+			for (size_t i = 0; i < n; i++) sum += clk[i];
+			fprintf(stderr, "cover clocks: %zu windows, sum %llu, slowest:", n, (unsigned long long) sum);
+			for (size_t i = 0; i < n && i < 8; i++) {
+				size_t at = 0;
+				while (at < n && ord[at] != by[i]) at++;
+				fprintf(stderr, " [w%u blk%zu entries %u valid %d clk %llu]", by[i], at, cnt[by[i]], (int) val[by[i]], (unsigned long long) clk[by[i]]);
+			}
+			fprintf(stderr, "\n");
+		}
 	}
 	// verdicts, pair counts and list lengths through the context's page-locked buffer: three asynchronous copies and one wait
 	const size_t nres = ((n + 15) & ~(size_t) 15) + 8 * n;
