@@ -270,11 +270,20 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 		                   d_lo, d_pre, ng, (u32) stop, 0u, c->d_seed_pos, c->d_vtext, c->d_line_off, (u32) c->n_lines, d_out);
 		ahead = (ahead + DP_THREADS - 1) / DP_THREADS * DP_THREADS;
 	}
+	// (the verdicts follow the guessed launch at once: when the guess covered the call -- every call but the first of a size -- the host
+	// wakes up once, with the verdicts there, instead of once for the number and again for the verdicts)
+	if (ahead) HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipEventSynchronize(c->ev_plan));
 	const u32 run = *(const u32*) c->h_pin;
 	c->root_dp_hint = run + run / 4 + 1024;
 	c->stats["root_dp_items"] = run;
 	if (run >= (1u << 31)) { vdjx_set_error("too many seed hits in one call (%u)", run); return VDJX_ELIMIT; }
+	if (ahead && threshold > 0 && run <= ahead) {
+		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(hipGetLastError());
+		vdjx_prof_collect(c, false);
+		return VDJX_OK;
+	}
 	if (threshold <= 0) {
 		// cells of row/column 0 are 0 and are tested too (seq_score.c:103-112): any seed hit accepts
 		std::vector<u32> pre(ng + 1);

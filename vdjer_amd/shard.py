@@ -341,6 +341,10 @@ class ShardedHotPath:
         if n == 0:
             return np.zeros(0, np.uint8), np.zeros(0, np.uint32)
         ent, npairs = scorer.window_pairs(windows)
+        if G == 1:               # (one rank: its lists are the union already; nothing to gather, move or reduce)
+            ids = np.arange(n, dtype=np.uint32)
+            lists = scorer.window_fetch(ids, int(ent.sum()))
+            return scorer.window_cover(n, lists, 1, ent.astype(np.int64).reshape(1, n), ins, **cov), npairs.astype(np.uint32)
         own = [np.arange(o, n, G) for o in range(G)]
         all_ent = cm.all_gather_cat(t.from_numpy(ent.astype(np.int64)).to(self.dev).view(1, n)).cpu().numpy()      # [G, n]
         send_ids = np.concatenate(own).astype(np.uint32)
@@ -388,6 +392,8 @@ class ShardedHotPath:
                 return recv
 
             def counts_of(x):            # what every peer will send me, given what I send every peer
+                if G == 1:
+                    return np.asarray([int(v) for v in x], dtype=np.int64)
                 got = exchange(t.tensor([int(v) for v in x], dtype=t.int64, device=self.dev), [1] * G, [1] * G)
                 cm.sync()
                 return got.cpu().numpy()
@@ -422,22 +428,24 @@ class ShardedHotPath:
             ns, ndist = eng.resolve(answers)
             del sparts, rq
             lap("resolve")
-            meta = cm.all_gather_cat(t.tensor([[ns, ndist]], dtype=t.int64, device=self.dev)).cpu().numpy()
+            meta = np.asarray([[ns, ndist]], dtype=np.int64) if G == 1 else cm.all_gather_cat(t.tensor([[ns, ndist]], dtype=t.int64, device=self.dev)).cpu().numpy()
             ns_all = [int(v) for v in meta[:, 0]]
             pre_total = int(meta[:, 1].sum())
             # 4. survivors everywhere, local edges, MIN over ranks
-            surv_all = cm.all_gather_var(eng.survivors(ns), ns_all)
-            cm.sync()
+            surv_all = eng.survivors(ns) if G == 1 else cm.all_gather_var(eng.survivors(ns), ns_all)
+            if G > 1:
+                cm.sync()
             lap("gather_survivors")
             mins, ucnt = eng.edges(surv_all)
             lap("edges")
-            if ucnt.numel():
+            if ucnt.numel() and G > 1:
                 flip = -2 ** 63       # unsigned order on int64 tensors: flip the sign bit around the MIN (all-ones = none stays largest)
                 mins.bitwise_xor_(flip)
                 cm.all_reduce(mins, dist.ReduceOp.MIN)
                 mins.bitwise_xor_(flip)
                 cm.all_reduce(ucnt, dist.ReduceOp.SUM)
-            cm.sync()
+            if G > 1:
+                cm.sync()
             lap("reduce_edges")
             # 5. node numbering + list order
             if async_export:
