@@ -511,7 +511,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    first_step_ms = None
+    first_step_ms, first_step_phases = None, None
     if args.warmup:
         torch.cuda.synchronize()
         t_first = time.perf_counter()
@@ -519,6 +519,7 @@ def main():
         ctx.map_emit_wait()
         torch.cuda.synchronize()
         first_step_ms = (time.perf_counter() - t_first) * 1e3
+        first_step_phases = {k_: round(v * 1e3, 3) for k_, v in wall.items()}     # where the first call of a process spends it: workspaces, page-locked result buffers
     for _ in range(max(0, args.warmup - 1)):
         step()
     ctx.profile(os.environ.get("VDJX_BENCH_NO_EVENTS") != "1")      # (diagnostic switch: what the per-kernel HIP events cost)
@@ -756,7 +757,7 @@ def main():
                    "scorer_inputs": scorer_src},
         "roofline": roof, "roofline_by_kernel": by_kernel, "cpu_baseline": cpu, "cpu_baseline_port_legs": cpu_port_legs,
         "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
-        "value_end_to_end": e2e, "value_with_read_index": with_index, "first_step_ms": round(first_step_ms, 3) if first_step_ms else None,
+        "value_end_to_end": e2e, "value_with_read_index": with_index, "first_step_ms": round(first_step_ms, 3) if first_step_ms else None, "first_step_phases_ms": first_step_phases,
         "cli_end_to_end": cli_e2e,
         "kernels_ms_per_step": kern_ms, "kernels_sum_ms_per_step": round(sum(kern_ms.values()), 3),
         "device_busy_frac": round(sum(kern_ms.values()) / ms_step, 4) if ms_step else None,

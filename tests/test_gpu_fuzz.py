@@ -113,6 +113,53 @@ def test_scorers_random_configurations_vs_oracle(ctx, seed, n):
         p.free()
 
 
+@pytest.mark.parametrize("seed,n", [(251, 20)])
+def test_coverage_floor_one_random_configurations_vs_oracle(ctx, seed, n):
+    """a-9 at the reference's default floor (params.c:64), the bit-grid form of k_window_cover (and, where the mate span passes 64
+    deltas, its fall-back to the difference arrays): random read length incl. 75 / 100 / 151 bases, window length, insert size,
+    evaluation range and spans over deep pools, so that valid AND invalid windows occur; verdicts and pair counts vs the oracle's
+    coverage_is_valid (coverage.c:10-130)."""
+    from oracle import oracle
+    from vdjer_amd import synth
+    import test_gpu_parity as T
+    rng = np.random.default_rng(seed + _SEED)
+    seen = {0: 0, 1: 0}
+    for it in range(n * _SCALE):
+        rl = int(rng.choice([36, 50, 50, 75, 100, 151]))
+        wlen = int(rng.integers(rl + 160, rl + 520))
+        ins = int(rng.integers(rl + 60, rl + 220))
+        rep = synth.make_repertoire(int(rng.integers(1, 5)), seed=int(rng.integers(0, 1 << 30)))
+        pool = synth.make_reads(rep, int(rng.choice([300, 600, 1200, 2500, 6000])), noise_frac=0.0, seed=int(rng.integers(0, 1 << 30)), rl=rl, ins_mean=float(ins),
+                                err=float(rng.choice([0.0, 0.002])))
+        ix = oracle.ReadIndex(pool)
+        p = T._load_index(ctx, pool)
+        wins = []
+        for t in rep.clones:
+            for _ in range(6):
+                st = int(rng.integers(0, max(1, len(t) - wlen)))
+                w = t[st:st + wlen]
+                if len(w) == wlen:
+                    wins.append(w if rng.random() < 0.8 else synth.revcomp(w))
+        if not wins:
+            p.free()
+            continue
+        # evaluation ranges from a few positions to most of the window; mate spans on both sides of the 64 deltas one word holds
+        e0 = int(rng.integers(1, max(2, wlen // 2)))
+        e1 = int(rng.integers(e0 + 5, max(e0 + 6, wlen - rl // 2)))
+        rs = int(rng.integers(10, rl))
+        ms = int(rng.choice([10, 30, 48, 48, 63, 64, 65, 90]))
+        cfg = dict(it=it, rl=rl, wlen=wlen, ins=ins, e0=e0, e1=e1, rs=rs, ms=ms, n_wins=len(wins))
+        valid, npairs = ctx.window_score(wins, ins, e0=e0, e1=e1, rs=rs, ms=ms, floor=1)
+        for i, w in enumerate(wins):
+            pairs, starts = ix.quick_map(w)
+            assert int(npairs[i]) == len(pairs), (cfg, i)
+            exp = ix.coverage_is_valid(starts, len(w), ins, e0=e0, e1=e1, rs=rs, ms=ms, floor=1)
+            assert int(valid[i]) == exp, (cfg, i)
+            seen[int(exp)] += 1
+        p.free()
+    assert seen[0] and seen[1], seen          # (both verdicts occurred)
+
+
 @pytest.mark.parametrize("seed,n", [(301, 10)])
 def test_sharded_build_random_configurations_vs_single_gpu(ctx, seed, n):
     """The sharded driver with 2 or 4 ranks as threads on this GPU (tests/fake_dist.py) on random configurations (including reads of
