@@ -284,7 +284,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-fed (PCIe-inclusive) variant of the step")
     ap.add_argument("--force-shard", action="store_true",
-                    help="N=1 only: run the k-mer build through the multi-GPU phases (one-rank RCCL group) to time its kernels; not the line of record")
+                    help="N=1 only: run the k-mer build and the window scorer through the multi-GPU phases (kernels and host logic of the sharded path; a lone rank "
+                         "skips the collectives that would hand it its own data back -- VDJX_SHARD_SELF_COLLECTIVES=1 keeps them, over a one-rank RCCL group); "
+                         "not the line of record")
     ap.add_argument("--windows", choices=["auto", "traversal", "generator"], default="auto",
                     help="scorer inputs: the candidate windows/contigs the host traversal derives from the graph, or one window per "
                          "clone straight from the generator.  auto = traversal up to 1.5 M pairs in all, generator above: the "

@@ -634,9 +634,10 @@ def test_scorer_argument_errors(ctx):
     p.free()
 
 
-def test_sharded_build_real_rccl_world1(ctx):
+def test_sharded_build_real_rccl_world1(ctx, monkeypatch):
     """The RCCL code path of the driver (async all_gather, all_to_all_single, all_reduce on device tensors) with a
     real one-rank `nccl` process group: the most of the multi-GPU path one GPU can execute for real."""
+    monkeypatch.setenv("VDJX_SHARD_SELF_COLLECTIVES", "1")      # (a lone rank would skip the collectives: here they are the point)
     import socket
     import torch
     import torch.distributed as dist

@@ -62,21 +62,32 @@ struct vdjx_prof_entry {
 // hipMalloc/hipFree cost milliseconds each and hipFree synchronises the device; the hot path allocates ~25
 // buffers per call, so they come out of this arena instead.
 struct vdjx_arena {
+	// ONE growing range of device addresses (hipMemAddressReserve), backed piece by piece as the calls need it (hipMemCreate +
+	// hipMemMap at the end of what is mapped): allocation is a bump of `used`, a call that needs more than any before adds pieces
+	// behind the others, nothing is ever moved, traded or re-sized, and what a context holds is the PEAK of its calls -- not the sum
+	// of chunk lists that different call sequences left behind.  (Round 4: the arena used to be a list of hipMalloc'ed chunks traded
+	// for one chunk of their total after every call; that one large hipMalloc -- 38 GB -- took 0.3 ms on some runs and 1.0-2.4 s
+	// on others: the "first step" of bench.py at k = 25.  Keeping the chunks instead grew 8 contexts on one device out of memory
+	// over three chains of the configs[4] rehearsal.)  Where the runtime has no virtual memory management the chunk list remains.
+	char* base = nullptr;            // the reserved range (nullptr: chunk mode)
+	size_t reserved = 0, mapped = 0; // bytes of the range / backed so far
+	std::vector<std::pair<void*, size_t>> pieces;     // allocation handles (hipMemGenericAllocationHandle_t) and sizes, in address order
+	size_t gran = 0;
+	int mode = 0;                    // 0 undecided, 1 one range, 2 chunks
 	struct chunk { char* p; size_t cap; };
 	std::vector<chunk> chunks;
-	size_t cur = 0;                  // the chunk allocations come out of
-	size_t used = 0;                 // bytes used in chunk `cur`
+	size_t cur = 0;                  // chunk mode: the chunk allocations come out of
+	size_t used = 0;                 // bytes used (of the range; of chunk `cur`)
 	void* alloc(size_t bytes);       // 256-byte aligned; nullptr (and the error set) on failure
-	void reset();                    // forget all allocations; coalesces multiple chunks into one
-	void release();
+	void reset();                    // forget all allocations (the memory stays)
+	void release(bool for_good = false);     // give the memory back (for_good: the address range too)
 	// stack discipline inside one call sequence: everything allocated after mark() is given up by release_to(mark) and its space is
-	// taken again by the next allocations (a build's early temporaries do not add to its later phases' footprint).  The chunks stay
-	// with the arena -- giving them back to the device and asking again every call costs more than the kernels in between -- so that
-	// reset() still sizes the one coalesced chunk by what a whole build held at its peak.  Nothing on the stream may still use what
-	// is released.
+	// taken again by the next allocations (a build's early temporaries do not add to its later phases' footprint).  Nothing on the
+	// stream may still use what is released.
 	struct mark_t { size_t cur, used; };
 	mark_t mark() const { return {cur, used}; }
 	void release_to(mark_t m);
+	bool grow(size_t upto);
 };
 
 struct vdjx_shard;

@@ -111,8 +111,8 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	if (c->h_sam_merge) (void) hipHostFree(c->h_sam_merge);
 	free_dev(c->me_pairs); free_dev(c->me_hit); free_dev(c->me_dense); free_dev(c->me_book); free_dev(c->wp_buf); free_dev(c->d_ri_cnt1); free_dev(c->d_ri_dstart); free_dev(c->d_ri_d8);
 	for (int i = 0; i < 2; i++) { free_dev(c->d_stage[i]); if (c->ev_copied[i]) (void) hipEventDestroy(c->ev_copied[i]); if (c->ev_packed[i]) (void) hipEventDestroy(c->ev_packed[i]); }
-	c->arena.release();
-	c->shard_arena.release();
+	c->arena.release(true);
+	c->shard_arena.release(true);
 	c->blocks.drop();
 	{
 		std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -137,19 +137,87 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	delete c;
 }
 
+static bool arena_trace() { static const bool t = getenv("VDJX_ARENA_TRACE") != nullptr; return t; }     // diagnostic: every growth of a workspace
+
+// back the range up to `upto` bytes: pieces of at most 4 GB (a single 38 GB allocation is what took seconds)
+bool vdjx_arena::grow(size_t upto) {
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return false;
+	hipMemAllocationProp prop = {};
+	prop.type = hipMemAllocationTypePinned;
+	prop.location.type = hipMemLocationTypeDevice;
+	prop.location.id = dev;
+	hipMemAccessDesc acc = {};
+	acc.location = prop.location;
+	acc.flags = hipMemAccessFlagsProtReadWrite;
+	// (equal pieces, each at a multiple of its size: hipMemSetAccess refused a 3,953 MB piece mapped behind one of 256 MB, "invalid argument")
+	const size_t piece = (size_t) 1 << 30;
+	while (mapped < upto) {
+		const size_t want = piece;
+		if (mapped + want > reserved) { vdjx_set_error("workspace: the reserved address range (%zu GB) is used up", reserved >> 30); return false; }
+		const auto t0 = std::chrono::steady_clock::now();
+		hipMemGenericAllocationHandle_t h;
+		const char* step = "hipMemCreate";
+		hipError_t e = hipMemCreate(&h, want, &prop, 0);
+		if (e == hipSuccess) {
+			step = "hipMemMap";
+			e = hipMemMap(base + mapped, want, 0, h, 0);
+			if (e == hipSuccess) { step = "hipMemSetAccess"; e = hipMemSetAccess(base + mapped, want, &acc, 1); if (e != hipSuccess) (void) hipMemUnmap(base + mapped, want); }
+			if (e != hipSuccess) (void) hipMemRelease(h);
+		}
+		if (e != hipSuccess && arena_trace()) fprintf(stderr, "[vdjx] workspace: %s of %zu MB at %zu MB failed: %s\n", step, want >> 20, mapped >> 20, hipGetErrorString(e));
+		if (e != hipSuccess) { vdjx_set_error("workspace: %zu MB more (behind %zu MB): %s", want >> 20, mapped >> 20, hipGetErrorString(e)); (void) hipGetLastError(); return false; }
+		pieces.emplace_back((void*) h, want);
+		mapped += want;
+		if (arena_trace()) fprintf(stderr, "[vdjx] workspace grows by %zu MB to %zu MB: %.3f ms\n", want >> 20, mapped >> 20,
+		                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+	}
+	return true;
+}
+
 void* vdjx_arena::alloc(size_t bytes) {
 	bytes = (bytes + 255) & ~(size_t) 255;
+	if (mode == 0) {
+		// one range, if the runtime manages virtual memory on this device (VDJX_ARENA_CHUNKS=1: the chunk list, for comparison)
+		mode = 2;
+		int dev = 0, vmm = 0;
+		static const bool force_chunks = getenv("VDJX_ARENA_CHUNKS") != nullptr;
+		if (!force_chunks && hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, dev) == hipSuccess && vmm) {
+			hipMemAllocationProp prop = {};
+			prop.type = hipMemAllocationTypePinned;
+			prop.location.type = hipMemLocationTypeDevice;
+			prop.location.id = dev;
+			size_t total = 0, fr = 0, g = 0;
+			if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && g && hipMemGetInfo(&fr, &total) == hipSuccess) {
+				const size_t gb = (size_t) 1 << 30;
+				const size_t want = (total + gb - 1) / gb * gb;            // (addresses, not memory: as much as the device has)
+				void* r = nullptr;
+				if (hipMemAddressReserve(&r, want, gb, nullptr, 0) == hipSuccess && r) { base = (char*) r; reserved = want; gran = g; mode = 1; }
+			}
+		}
+		(void) hipGetLastError();
+		if (arena_trace()) fprintf(stderr, "[vdjx] workspace: %s\n", mode == 1 ? "one reserved address range, backed as needed" : "list of chunks");
+	}
+	if (mode == 1) {
+		if (used + bytes > mapped && !grow(used + bytes)) return nullptr;
+		void* r = base + used;
+		used += bytes;
+		return r;
+	}
 	if (!chunks.empty() && used + bytes <= chunks[cur].cap) {
 		void* r = chunks[cur].p + used;
 		used += bytes;
 		return r;
 	}
-	// a later chunk the arena already has (after release_to), else a new one
+	// a later chunk the arena already has (after release_to / reset), else a new one
 	for (size_t i = chunks.empty() ? 0 : cur + 1; i < chunks.size(); i++)
 		if (bytes <= chunks[i].cap) { cur = i; used = bytes; return chunks[i].p; }
 	size_t cap = bytes > ((size_t) 64 << 20) ? bytes : ((size_t) 64 << 20);
 	char* p = nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
 	hipError_t e = hipMalloc(&p, cap);
+	if (arena_trace()) fprintf(stderr, "[vdjx] workspace grows by %zu MB (chunk %zu): hipMalloc %.3f ms\n", cap >> 20, chunks.size(),
+	                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 	if (e != hipSuccess) { vdjx_set_error("workspace alloc of %zu bytes: %s", cap, hipGetErrorString(e)); return nullptr; }
 	chunks.push_back({p, cap});
 	cur = chunks.size() - 1;
@@ -158,24 +226,31 @@ void* vdjx_arena::alloc(size_t bytes) {
 }
 
 void vdjx_arena::reset() {
-	if (chunks.size() > 1) {
-		size_t total = 0;
-		for (auto& ch : chunks) { total += ch.cap; (void) hipFree(ch.p); }
-		chunks.clear();
-		char* p = nullptr;
-		if (hipMalloc(&p, total) == hipSuccess) chunks.push_back({p, total});
-	}
 	cur = 0;
 	used = 0;
 }
 
 void vdjx_arena::release_to(mark_t m) {
+	if (mode == 1) { used = m.used <= used ? m.used : used; return; }
 	if (chunks.empty() || m.cur >= chunks.size()) { cur = 0; used = 0; return; }
 	cur = m.cur;
 	used = m.used;
 }
 
-void vdjx_arena::release() {
+void vdjx_arena::release(bool for_good) {
+	if (mode == 1) {
+		size_t at = 0;
+		for (auto& pc : pieces) {
+			(void) hipMemUnmap(base + at, pc.second);
+			(void) hipMemRelease((hipMemGenericAllocationHandle_t) pc.first);
+			at += pc.second;
+		}
+		pieces.clear();
+		mapped = 0;
+		used = 0;
+		if (for_good) { (void) hipMemAddressFree(base, reserved); base = nullptr; reserved = 0; mode = 0; }      // (else the range stays reserved: the arena may be used again)
+		return;
+	}
 	for (auto& ch : chunks) (void) hipFree(ch.p);
 	chunks.clear();
 	cur = 0;

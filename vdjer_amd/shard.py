@@ -341,7 +341,7 @@ class ShardedHotPath:
         if n == 0:
             return np.zeros(0, np.uint8), np.zeros(0, np.uint32)
         ent, npairs = scorer.window_pairs(windows)
-        if G == 1:               # (one rank: its lists are the union already; nothing to gather, move or reduce)
+        if G == 1 and not os.environ.get("VDJX_SHARD_SELF_COLLECTIVES"):               # (one rank: its lists are the union already; nothing to gather, move or reduce)
             ids = np.arange(n, dtype=np.uint32)
             lists = scorer.window_fetch(ids, int(ent.sum()))
             return scorer.window_cover(n, lists, 1, ent.astype(np.int64).reshape(1, n), ins, **cov), npairs.astype(np.uint32)
@@ -374,6 +374,7 @@ class ShardedHotPath:
             cm.all_reduce(s, dist.ReduceOp.MAX)
             self.stride = int(s.item())
         stride = self.stride
+        alone = G == 1 and not os.environ.get("VDJX_SHARD_SELF_COLLECTIVES")      # (the variable: a lone rank calls the collectives all the same -- the one-rank RCCL test)
         import time
         clock = [time.perf_counter()]
 
@@ -385,14 +386,14 @@ class ShardedHotPath:
         eng.begin(pool, k, mf, mq, r, G, stride)
         try:
             def exchange(send, ins, outs):
-                if G == 1:            # nothing to move: what a rank keeps for itself is its send buffer (with peers, a 1/G-th of it is copied)
+                if alone:             # nothing to move: what a rank keeps for itself is its send buffer (with peers, a 1/G-th of it is copied)
                     return send
                 recv = t.empty((int(sum(outs)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
                 cm.all_to_all_v(send, [int(v) for v in ins], recv, [int(v) for v in outs])
                 return recv
 
             def counts_of(x):            # what every peer will send me, given what I send every peer
-                if G == 1:
+                if alone:
                     return np.asarray([int(v) for v in x], dtype=np.int64)
                 got = exchange(t.tensor([int(v) for v in x], dtype=t.int64, device=self.dev), [1] * G, [1] * G)
                 cm.sync()
@@ -428,23 +429,23 @@ class ShardedHotPath:
             ns, ndist = eng.resolve(answers)
             del sparts, rq
             lap("resolve")
-            meta = np.asarray([[ns, ndist]], dtype=np.int64) if G == 1 else cm.all_gather_cat(t.tensor([[ns, ndist]], dtype=t.int64, device=self.dev)).cpu().numpy()
+            meta = np.asarray([[ns, ndist]], dtype=np.int64) if alone else cm.all_gather_cat(t.tensor([[ns, ndist]], dtype=t.int64, device=self.dev)).cpu().numpy()
             ns_all = [int(v) for v in meta[:, 0]]
             pre_total = int(meta[:, 1].sum())
             # 4. survivors everywhere, local edges, MIN over ranks
-            surv_all = eng.survivors(ns) if G == 1 else cm.all_gather_var(eng.survivors(ns), ns_all)
-            if G > 1:
+            surv_all = eng.survivors(ns) if alone else cm.all_gather_var(eng.survivors(ns), ns_all)
+            if not alone:
                 cm.sync()
             lap("gather_survivors")
             mins, ucnt = eng.edges(surv_all)
             lap("edges")
-            if ucnt.numel() and G > 1:
+            if ucnt.numel() and not alone:
                 flip = -2 ** 63       # unsigned order on int64 tensors: flip the sign bit around the MIN (all-ones = none stays largest)
                 mins.bitwise_xor_(flip)
                 cm.all_reduce(mins, dist.ReduceOp.MIN)
                 mins.bitwise_xor_(flip)
                 cm.all_reduce(ucnt, dist.ReduceOp.SUM)
-            if G > 1:
+            if not alone:
                 cm.sync()
             lap("reduce_edges")
             # 5. node numbering + list order
