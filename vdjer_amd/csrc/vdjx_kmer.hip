@@ -2568,6 +2568,10 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	// raw item blocks
 	static const size_t walk_blocks = tune("VDJX_WALK_BLOCKS", 7168);      // (seven waves per SIMD are resident: 28 blocks per CU = one resident set x 4; measured 4096 2.45 ms, 7168 2.32, 16384 2.52)
 	u32 nblk = (u32) std::min<size_t>(walk_blocks, (R + WALK_THREADS * 8 - 1) / (WALK_THREADS * 8));
+	// (1,536 blocks are resident at once -- six waves per SIMD --: a pool that asks for a few more pays a second, nearly empty round with
+	// the latency of a full one.  1 M pairs, 1,953 blocks asked: 0.41 ms; 1,500: 0.36; 1,700: 0.40.  3 M pairs: 3,000 0.77, 5,000 0.81)
+	static const u32 walk_resident = (u32) tune("VDJX_WALK_RESIDENT", 1536);
+	if (walk_resident && nblk > walk_resident && nblk < walk_blocks) nblk = nblk / walk_resident * walk_resident;
 	if (nblk == 0) nblk = 1;
 	const size_t nwaves = (size_t) nblk * (WALK_THREADS / 64);
 	const size_t NI = R * (size_t) P;
