@@ -209,7 +209,8 @@ struct vdjx_pool {
 	size_t block_cap = 0;
 	u64* d_bases = nullptr;      // [R][W]
 	u64* d_nmask = nullptr;      // [R][M] bit i = base i is not ACGT
-	u64* d_lowq = nullptr;       // [R][M] bit i = (uint8)(q-33) < 20
+	u64* d_lowq = nullptr;       // [R][M] the GATE mask: bit i = base i is not ACGT or (uint8)(q-33) < 20 (include_kmer, A2:240-259, needs nothing else: the
+	                             // gating kernels read this word and not d_nmask)
 	const uint8_t* d_quals = nullptr;   // quality rows (Phred+33 characters), `qstride` bytes apart: packed [R][qstride] inside d_block, or -- for a pool
 	const uint8_t* d_quals2 = nullptr;  // loaded from ASCII records that stay resident in device memory (vdjx_pool_load_device) -- the records' own
 	size_t q_split = ~(size_t) 0;       // quality characters, never copied: records below q_split in d_quals (primary), the others in d_quals2

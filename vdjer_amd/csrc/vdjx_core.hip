@@ -452,7 +452,7 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 		const size_t g = FWD ? rec0 + 2 * (first + tid) : rec0 + first + tid;
 		((ulonglong2*) bases)[g] = make_ulonglong2(bhi, blo);
 		nmask[g] = nm;
-		lowq[g] = lq;
+		lowq[g] = lq | nm;                                            // (see vdjx_pool::d_lowq: the gate mask)
 		if (!FWD && WQ) {
 			// the row straight from the registers: four 16-byte stores per record (the staging through LDS of the FWD variant costs
 			// 17 KB per workgroup, i.e. half the workgroups per CU and half the bytes in flight)
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 			}
 			((ulonglong2*) bases)[g + 1] = make_ulonglong2(rh, rlo);
 			nmask[g + 1] = __brevll(nm) >> (64u - (u32) rl);
-			lowq[g + 1] = __brevll(lq) >> (64u - (u32) rl);
+			lowq[g + 1] = __brevll(lq | nm) >> (64u - (u32) rl);
 			oth *= 2u;
 		}
 		if (oth) atomicAdd(bad_strand + 1, oth);     // (rare: reported through vdjx_stat("pool_other_bases"))
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(PACKL_RECS) void k_pool_pack_long(const uint8_t* __
 			lq |= (u64) (sw_gather4(sw_low_quality(q)) & ((1u << valid) - 1u)) << ((4 * j) & 63);
 			other += (u32) __popc(ot);
 			if ((j & 7) == 7 || j == ngroups - 1) { bases[g * (size_t) W + (j >> 3)] = acc << (64 - 8 * ((j & 7) + 1)); acc = 0; }
-			if ((j & 15) == 15 || j == ngroups - 1) { nmask[g * (size_t) M + (j >> 4)] = nm; lowq[g * (size_t) M + (j >> 4)] = lq; nm = 0; lq = 0; }
+			if ((j & 15) == 15 || j == ngroups - 1) { nmask[g * (size_t) M + (j >> 4)] = nm; lowq[g * (size_t) M + (j >> 4)] = lq | nm; nm = 0; lq = 0; }
 		}
 		for (int w = (rl + 31) / 32; w < W; w++) bases[g * (size_t) W + w] = 0;
 		for (int w = (rl + 63) / 64; w < M; w++) { nmask[g * (size_t) M + w] = 0; lowq[g * (size_t) M + w] = 0; }
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(PACKL_RECS) void k_pool_pack_long(const uint8_t* __
 			nm |= (u64) (!acgt) << (i & 63);
 			lq |= (u64) ((u32) (uint8_t) (r[1 + rl + si] - 33) < 20u) << (i & 63);
 			if ((i & 31) == 31 || i == rl - 1) { bases[g * (size_t) W + (i >> 5)] = acc << (2 * (31 - (i & 31))); acc = 0; }
-			if ((i & 63) == 63 || i == rl - 1) { nmask[g * (size_t) M + (i >> 6)] = nm; lowq[g * (size_t) M + (i >> 6)] = lq; nm = 0; lq = 0; }
+			if ((i & 63) == 63 || i == rl - 1) { nmask[g * (size_t) M + (i >> 6)] = nm; lowq[g * (size_t) M + (i >> 6)] = lq | nm; nm = 0; lq = 0; }
 		}
 		for (int w = (rl + 31) / 32; w < W; w++) bases[g * (size_t) W + w] = 0;
 		for (int w = (rl + 63) / 64; w < M; w++) { nmask[g * (size_t) M + w] = 0; lowq[g * (size_t) M + w] = 0; }

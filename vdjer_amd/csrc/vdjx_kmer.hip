@@ -247,6 +247,20 @@ __device__ inline u64 vdjx_clean_offsets(u64 bad, int k, int P) {
 // reads three words from the k-mer's first), entries are lane << 8 | offset
 #define GL_ROW_LONG (VDJX_LONG_W + 2)
 #define GL_WAVE_BYTES_LONG (64u * GL_ROW_LONG * 8u + 2048u)
+// the gating kernels' view of a short record: bases and the gate mask (vdjx_pool::d_lowq = not-ACGT | Phred < 20): 24 bytes, not 32
+struct GateView { u64 bhi, blo, bad; };
+__device__ inline GateView load_gate(const u64* __restrict__ bases, const u64* __restrict__ gate, size_t r) {
+	GateView v;
+	const ulonglong2 b = ((const ulonglong2*) bases)[r];
+	v.bhi = b.x; v.blo = b.y;
+	v.bad = gate[r];
+	return v;
+}
+__device__ inline vdjx_mask3 load_gate3(const u64* __restrict__ gate, size_t r) {
+	vdjx_mask3 b;
+	b.w0 = gate[r * VDJX_LONG_M]; b.w1 = gate[r * VDJX_LONG_M + 1]; b.w2 = gate[r * VDJX_LONG_M + 2];
+	return b;
+}
 __device__ inline vdjx_mask3 load_bad3(const u64* __restrict__ nmask, const u64* __restrict__ lowq, size_t r) {
 	vdjx_mask3 b;
 	b.w0 = nmask[r * VDJX_LONG_M] | (lowq ? lowq[r * VDJX_LONG_M] : 0ull);
@@ -288,10 +302,10 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 		u64 G = 0;
 		vdjx_mask3 bad{~0ull, ~0ull, ~0ull};
 		if (r < r1) {
-			if (LONG) { bad = load_bad3(nmask, lowq, r); stage_row_long(wrow + lane * GL_ROW_LONG, bases, r); }
+			if (LONG) { bad = load_gate3(lowq, r); stage_row_long(wrow + lane * GL_ROW_LONG, bases, r); }
 			else {
-				const RecView v = load_rec(bases, nmask, lowq, r);
-				G = vdjx_clean_offsets(v.nm | v.lq, k, P);
+				const GateView v = load_gate(bases, lowq, r);
+				G = vdjx_clean_offsets(v.bad, k, P);
 				wb[lane] = make_ulonglong2(v.bhi, v.blo);
 			}
 		}
@@ -365,10 +379,10 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 			u64 G = 0;
 			vdjx_mask3 bad{~0ull, ~0ull, ~0ull};
 			if (r < re) {
-				if (LONG) { bad = load_bad3(nmask, lowq, r); stage_row_long(wrow + lane * GL_ROW_LONG, bases, r); }
+				if (LONG) { bad = load_gate3(lowq, r); stage_row_long(wrow + lane * GL_ROW_LONG, bases, r); }
 				else {
-					const RecView v = load_rec(bases, nmask, lowq, r);
-					G = vdjx_clean_offsets(v.nm | v.lq, k, P);
+					const GateView v = load_gate(bases, lowq, r);
+					G = vdjx_clean_offsets(v.bad, k, P);
 					wb[lane] = make_ulonglong2(v.bhi, v.blo);
 				}
 			}
