@@ -1178,22 +1178,11 @@ __global__ __launch_bounds__(MAP_THREADS) void k_window_cover(int len, int rl, v
 	if (tid == 0) { s_bad = 0; s_ok = 0; }
 	__syncthreads();
 	u32* myh = priv ? hp + wv * (u32) (D + 1) : hf;
-	// (the list is roughly offset-major: the 64 consecutive entries of a wave mostly start at ONE position -- 64 adds to one LDS word go
-	// one at a time -- so the lanes that share the first lane's position are summed in registers and added once)
-	for (u32 q0 = 0; q0 < npairs; q0 += MAP_THREADS) {
-		const u32 q = q0 + tid;
-		const bool have = q < npairs;
-		const u64 pe = have ? pairs[q] : 0ull;
+	for (u32 q = tid; q < npairs; q += MAP_THREADS) {
+		const u64 pe = pairs[q];
 		const u32 pr = (u32) pe, mult = (u32) (pe >> 32);
-		const u32 first_pos = (u32) __builtin_amdgcn_readfirstlane((int) (pr >> 16));     // (a wave's missing lanes are its last)
-		const bool same = have && (pr >> 16) == first_pos;
-		if (__popcll(__ballot(same)) >= 8) {
-			const u32 sum = (u32) __builtin_amdgcn_readlane(vdjx_wave_scan_add((int) (same ? mult : 0u)), 63);
-			if ((tid & 63u) == 0) atomicAdd(&myh[first_pos], sum);
-			if (have && !same) atomicAdd(&myh[pr >> 16], mult);
-		} else if (have)
-			atomicAdd(&myh[pr >> 16], mult);
-		if (have) atomicAdd(&myh[pr & 0xFFFFu], mult);
+		atomicAdd(&myh[pr >> 16], mult);
+		atomicAdd(&myh[pr & 0xFFFFu], mult);
 	}
 	__syncthreads();
 	if (priv) {
