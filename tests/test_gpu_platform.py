@@ -132,3 +132,52 @@ def test_unchunked_1088MB_all_to_all_single_one_rank():
     finally:
         if mine:
             dist.destroy_process_group()
+
+
+_ARENA_SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from vdjer_amd import api, synth
+rep = synth.make_repertoire(6, seed=5)
+vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+ctx = api.Context(0)
+ctx.anchor_sets_load(vc, jc)
+out = []
+for pairs, k in ((3000, 35), (40000, 25), (3000, 35), (20000, 35)):     # calls of different sizes through one workspace
+    pool = synth.make_reads(rep, pairs, noise_frac=0.3, seed=7 + pairs)
+    p = ctx.pool_load(pool.primary, pool.secondary, pool.rl)
+    g = ctx.kmer_build(p, k, 3, 90)
+    out.append(hashlib.sha256(b"".join(np.ascontiguousarray(getattr(g, f)).tobytes() for f in ("first_inst", "freq", "to_ids", "from_ids"))).hexdigest())
+    ctx.read_index_build(p, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+    w = [t[:486] for t in rep.clones if len(t) >= 486][:4]
+    if w:
+        v, n = ctx.window_score(w, 175)
+        out.append(str(v.tolist()) + str(n.tolist()))
+    p.free()
+print("DIGEST", hashlib.sha256("|".join(out).encode()).hexdigest())
+"""
+
+
+@pytest.mark.gpu
+def test_workspace_as_one_mapped_range_and_as_chunk_list_agree():
+    """The workspace arena is one reserved address range backed piece by piece (hipMemAddressReserve / hipMemCreate / hipMemMap);
+    where the runtime has no virtual memory management it falls back to a list of hipMalloc'ed chunks (VDJX_ARENA_CHUNKS=1 forces
+    that).  Builds and scorer calls of different sizes through ONE context give the same results either way."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode in ("range", "chunks"):
+        env = dict(os.environ)
+        env.pop("VDJX_ARENA_CHUNKS", None)
+        if mode == "chunks":
+            env["VDJX_ARENA_CHUNKS"] = "1"
+        env["VDJX_ARENA_TRACE"] = "1"
+        r = subprocess.run([os.sys.executable, "-c", _ARENA_SCRIPT % root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")]
+        assert line, r.stdout[-500:]
+        got[mode] = line[0]
+        said = "one reserved address range" if mode == "range" else "list of chunks"
+        assert said in r.stderr, r.stderr[-1500:]
+    assert got["range"] == got["chunks"]
