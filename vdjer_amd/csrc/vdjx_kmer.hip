@@ -610,12 +610,33 @@ __device__ inline u32 rd_count_min(u32* cnt, u64* mn, u32 idx, u64 val, bool act
 	return c0;
 }
 
+// the buckets in descending order of their size class (bit length of the tuple count): the reduce kernel's workgroups differ in
+// length by a factor of sixty, and the longest should not be among the last to start.  One workgroup: counts per class, the
+// classes' places, then every bucket to a place of its class (any order inside a class).
+__global__ __launch_bounds__(1024) void k_bucket_order(const u32* __restrict__ bucket_start, u32 NB, u32* __restrict__ order) {
+	__shared__ u32 cls_cnt[33], cls_at[33];
+	if (threadIdx.x < 33) cls_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	for (u32 b = threadIdx.x; b < NB; b += 1024) {
+		const u32 n = bucket_start[b + 1] - bucket_start[b];
+		atomicAdd(&cls_cnt[n ? 32u - (u32) __builtin_clz(n) : 0u], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) { u32 at = 0; for (int cl = 32; cl >= 0; cl--) { cls_at[cl] = at; at += cls_cnt[cl]; } }
+	__syncthreads();
+	for (u32 b = threadIdx.x; b < NB; b += 1024) {
+		const u32 n = bucket_start[b + 1] - bucket_start[b];
+		order[atomicAdd(&cls_at[n ? 32u - (u32) __builtin_clz(n) : 0u], 1u)] = b;
+	}
+}
+
 template <typename TUP>
 __global__ __launch_bounds__(RD_THREADS, sizeof(TUP) == 16 ? RD_WAVES : RD_WAVES / 2) void k_gated_reduce(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
                                                              const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                              vdjx_qrows quals, int rl, int ob, int k, u64 rec_base,
                                                              u32 mf, u32 cmin, u32 mqq, u32 tlow, SurvOutG so,
-                                                             u64* __restrict__ g_distinct, u32* __restrict__ g_err, u32 dbg_in) {
+                                                             u64* __restrict__ g_distinct, u32* __restrict__ g_err, u32 dbg_in,
+                                                             const u32* __restrict__ order) {
 	// the kernel's phase-by-phase ablation (profiles/reducedbg.py) exists only in the -DVDJX_ABLATE build (make -C vdjer_amd/csrc ablate);
 	// the shipped kernel keeps one switch, 9 = take the rescan path (the tests' way into a fallback real pools rarely reach)
 #ifdef VDJX_ABLATE
@@ -634,7 +655,7 @@ __global__ __launch_bounds__(RD_THREADS, sizeof(TUP) == 16 ? RD_WAVES : RD_WAVES
 	__shared__ unsigned short low_slot[RD_LROWS];
 	__shared__ u32 s_over, s_ndist, s_nlow, s_npq, s_nsurv, s_base;
 	const THI EMPTY = (THI) ~(THI) 0;
-	const u32 b = blockIdx.x;
+	const u32 b = order ? order[blockIdx.x] : blockIdx.x;
 	const u32 base = bucket_start[b];
 	const u32 n = bucket_start[b + 1] - base;
 	const u32 tid = threadIdx.x;
@@ -2424,8 +2445,14 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 	static const u32 rd_dbg = (u32) tune("VDJX_RD_DBG", 0);        // profiles/reducedbg.py: the kernel stops after a phase
 	if (t.N) {
 		vdjx_prof_scope ps(c, "k_gated_reduce");
+		static const bool by_size = tune("VDJX_RD_ORDER", 1) == 1;
+		u32* order = nullptr;
+		if (by_size && t.NB >= 1024) {
+			HIP_TRY(db.alloc(&order, t.NB));
+			hipLaunchKernelGGL(k_bucket_order, dim3(1), dim3(1024), 0, st, t.bucket_start, t.NB, order);
+		}
 		hipLaunchKernelGGL(k_gated_reduce<TUP>, dim3(t.NB), dim3(RD_THREADS), 0, st, t.t, t.bucket_start, pv.bases, pv.nmask, pv.quals, pv.rl, pv.ob, k, rec_base,
-		                   mfu, cmin, mqq, tlow, so, g_distinct, g_err, rd_dbg);
+		                   mfu, cmin, mqq, tlow, so, g_distinct, g_err, rd_dbg, (const u32*) order);
 	}
 	u64* spread = (u64*) c->h_pin;                    // [64 * 16], then ns, err
 	u32* tail = (u32*) (spread + 64 * 16);
