@@ -874,7 +874,8 @@ template <typename TUP>
 __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated_local(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
                                                             const u64* __restrict__ bases, const u64* __restrict__ nmask, u64 rec_base, int k, int rl, int ob,
                                                             u32 tlow, Partial* __restrict__ sparse_g, u32* __restrict__ sparse_ref,
-                                                            u32* __restrict__ nd_g, u64* __restrict__ low_inst, u32* __restrict__ g_err) {
+                                                            u32* __restrict__ nd_g, u64* __restrict__ low_inst, u32* __restrict__ g_err,
+                                                            const u32* __restrict__ order) {
 	typedef typename TUP::hi_t THI;
 	__shared__ u64 s_klo[LOCAL_SLOTS];
 	__shared__ THI s_khi[LOCAL_SLOTS];
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated
 	__shared__ u32 s_ng, s_nlow, s_over, s_npq;
 	static_assert(LOCAL_SLOTS == (1u << RD_SLOT_BITS), "list entries carry the slot in RD_SLOT_BITS bits");
 	const THI EMPTY = (THI) ~(THI) 0;
-	const u32 b = blockIdx.x;
+	const u32 b = order ? order[blockIdx.x] : blockIdx.x;      // (largest buckets first: k_bucket_order)
 	const u32 base = bucket_start[b];
 	const u32 n = bucket_start[b + 1] - base;
 	const u32 tid = threadIdx.x;
@@ -3045,8 +3046,14 @@ static int shard_local_impl(vdjx_shard* s) {
 	}
 	{
 		vdjx_prof_scope ps(c, "k_gated_local");
+		static const bool by_size = tune("VDJX_RD_ORDER", 1) == 1;
+		u32* order = nullptr;
+		if (by_size && t.NB >= 1024) {
+			HIP_TRY(db.alloc(&order, t.NB));
+			hipLaunchKernelGGL(k_bucket_order, dim3(1), dim3(1024), 0, st, t.bucket_start, t.NB, order);
+		}
 		hipLaunchKernelGGL(k_gated_local<TUP>, dim3(t.NB), dim3(LG_THREADS), 0, st, t.t, t.bucket_start, s->pool->d_bases, s->pool->d_nmask, rec_base,
-		                   s->k, s->pool->rl, s->pool->ob, s->tlow, sparse, sparse_ref, s->nd, s->low_inst, g_err);
+		                   s->k, s->pool->rl, s->pool->ob, s->tlow, sparse, sparse_ref, s->nd, s->low_inst, g_err, (const u32*) order);
 	}
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, s->nd, s->NBf, s->dstart);
 	u32* d_pick;
