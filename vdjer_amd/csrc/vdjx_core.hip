@@ -400,7 +400,8 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 	const size_t bytes = (size_t) nhere * (size_t) reclen;
 	const uint8_t* src = ascii + first * (size_t) reclen;       // 16-byte aligned: 256*reclen is a multiple of 16
 	const size_t nvec = bytes / 16;
-	for (size_t v = tid; v < nvec; v += PACK_RECS) ((uint4*) lds)[v] = ((const uint4*) src)[v];
+	typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+	for (size_t v = tid; v < nvec; v += PACK_RECS) ((u32x4_t*) lds)[v] = __builtin_nontemporal_load(&((const u32x4_t*) src)[v]);      // (read once: not kept in the caches)
 	for (size_t b = nvec * 16 + tid; b < bytes; b += PACK_RECS) lds[b] = src[b];
 	const u32 in_words = ((u32) PACK_RECS * (u32) reclen + 3u) / 4u + 4u;
 	const u32* inw = (const u32*) lds;
