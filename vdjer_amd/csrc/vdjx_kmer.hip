@@ -2802,9 +2802,11 @@ int stage_finish2(vdjx_ctx* c, A& db, const SurvivorsG& sv, const RecountOut& ro
 	HIP_TRY(db.alloc(&rk_idx, ns));
 	HIP_TRY(db.alloc(&rk_idx2, ns));
 	HIP_TRY(db.alloc(&rank, ns));
-	unsigned rk_bits = 1;                             // instance ids are below n_records_total << ob; one bit more keeps NONE64 apart
-	while (rk_bits < 63 && (1ull << rk_bits) <= ((n_records_total << ob) | 1ull)) rk_bits++;
-	rk_bits = rk_bits + 1 > 64 ? 64 : rk_bits + 1;
+	// instance ids are below n_records_total << ob = at most 2^rk_bits - 1; NONE64 (an unseen survivor: the build fails anyway), cut to
+	// rk_bits bits, is 2^rk_bits - 1 and still sorts behind every id.  (One bit more "to keep NONE64 apart" made 33 bits and a fifth
+	// pass of the sort at 10 M pairs.)
+	unsigned rk_bits = 1;
+	while (rk_bits < 64 && (1ull << rk_bits) <= ((n_records_total << ob) | 1ull)) rk_bits++;
 	auto up = [](size_t b) { return (b + 255) & ~(size_t) 255; };
 	const size_t need = up((size_t) ns * 8) + 5 * up((size_t) ns * 4) + 4 * up(ns) + 2 * up((size_t) ns * 16) + up((size_t) ns * k);
 	{
