@@ -637,7 +637,7 @@ def main():
     stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_hits_distinct", "window_pairs", "window_work_items", "map_hits", "root_dp_items", "recount_items", "recount_instances", "gated_instances")}
     stats["mapped_pairs"] = int(state["last"]["pairs"].shape[0]) if state.get("last") else 0
     stats["window_pairs_entries"] = ctx.stat("window_pairs_entries")
-    for n_ in ("group_hits_distinct", "group_overflows", "group_classes", "group_queued"):      # k_group_pairs: what the groups of windows shared
+    for n_ in ("group_hits_distinct", "group_overflows", "group_classes", "group_queued", "group_clocks_sum", "group_clocks_max"):      # k_group_pairs: what the groups of windows shared
         stats[n_] = ctx.stat(n_)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)

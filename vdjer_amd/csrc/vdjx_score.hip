@@ -936,6 +936,7 @@ __global__ __launch_bounds__(GP_THREADS, GP_WAVES) void k_group_pairs(ReadIndexD
                                                               u32* __restrict__ pair_cnt, u32* __restrict__ pair_np, u32* __restrict__ done, unsigned long long* __restrict__ gstat, u32 dbg,
                                                               u64 cap) {
 	if (pair_off[n] + 1 > cap) return;                  // (launched before the host knew the lists' total size: they do not fit, it will come again)
+	const long long t_begin = clock64();
 	__shared__ GroupImg L;
 	__shared__ u64 q_ent[GP_THREADS / 64][GP_Q];
 	__shared__ unsigned short q_d[GP_THREADS / 64][GP_Q];
@@ -1158,6 +1159,11 @@ __global__ __launch_bounds__(GP_THREADS, GP_WAVES) void k_group_pairs(ReadIndexD
 	if (lane == 0 && nq) atomicAdd(&gstat[3], (unsigned long long) nq);
 	__syncthreads();
 	if (tid < GP_G && s_w[tid] != NONE32) { pair_cnt[s_w[tid]] = s_pcnt[tid]; pair_np[s_w[tid]] = s_np[tid]; done[s_w[tid]] = 1u; }
+	if (tid == 0) {                                       // (statistics: is the kernel its work or its longest workgroup?  vdjx_stat "group_clocks_*")
+		const unsigned long long dt = (unsigned long long) (clock64() - t_begin);
+		atomicAdd(&gstat[4], dt);
+		atomicMax(&gstat[5], dt);
+	}
 }
 
 // K9: coverage verdict of a window from its pair list
@@ -1750,14 +1756,14 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 	unsigned long long* d_gstat = nullptr;
 	if (grouped) {
 		HIP_TRY(db.alloc(&d_done, n));
-		HIP_TRY(db.alloc(&d_gstat, 4));
+		HIP_TRY(db.alloc(&d_gstat, 8));
 	}
 	auto map_groups = [&]() -> int {
 		HIP_TRY(hipMemsetAsync(d_np, 0, n * 4, st));
 		HIP_TRY(hipMemsetAsync(d_cnt, 0, n * 4, st));
 		if (!grouped) return VDJX_OK;
 		HIP_TRY(hipMemsetAsync(d_done, 0, n * 4, st));
-		HIP_TRY(hipMemsetAsync(d_gstat, 0, 32, st));
+		HIP_TRY(hipMemsetAsync(d_gstat, 0, 64, st));
 		vdjx_prof_scope ps(c, "k_group_pairs");
 		hipLaunchKernelGGL(k_group_pairs, dim3((u32) ((n + GP_G - 1) / GP_G)), dim3(GP_THREADS), 0, st, ix, mp->d_prep, mp->d_hits, (u32) n, len, mp->d_gorder,
 		                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done, d_gstat, gp_dbg, (u64) c->wp_cap);
@@ -1797,7 +1803,7 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 			hipLaunchKernelGGL(k_window_pairs<MAP_MAXOFF>, dim3(mp->tot.nwork), dim3(MAP_THREADS), 0, st, ix, mp->d_prep, (u32) n, len, mp->tot.chunk, mp->d_order, mp->d_wstart,
 			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done, d_gstat ? d_gstat + 1 : nullptr);
 	}
-	if (d_gstat) HIP_TRY(hipMemcpyAsync((char*) c->h_plan + 128, d_gstat, 32, hipMemcpyDeviceToHost, st));        // (read after the caller's wait)
+	if (d_gstat) HIP_TRY(hipMemcpyAsync((char*) c->h_plan + 128, d_gstat, 64, hipMemcpyDeviceToHost, st));        // (read after the caller's wait)
 	mp->gstat = d_gstat != nullptr;
 	*d_np_out = d_np; *d_cnt_out = d_cnt;
 	return VDJX_OK;
@@ -1872,6 +1878,8 @@ static int window_score_slice(vdjx_ctx* c, const ReadIndexDev& ix, const char* w
 		c->stats["group_overflows"] = g[1];                    // groups left to k_window_pairs
 		c->stats["group_classes"] = g[2];
 		c->stats["group_queued"] = g[3];                       // entries that passed the presence test of their group
+		c->stats["group_clocks_sum"] = g[4];                   // shader clocks over all workgroups of k_group_pairs ...
+		c->stats["group_clocks_max"] = g[5];                   // ... and of the longest one
 	}
 	{
 		u64 tot = 0, ent = 0;
