@@ -233,6 +233,70 @@ __global__ __launch_bounds__(DP_THREADS) void k_root_dp(const char* __restrict__
 	}
 }
 
+// The same DP, ONE WAVE per work item, for calls with few items (a small pool: a few thousand, every thread of k_root_dp then walks
+// its 2,450 cells alone on a SIMD -- 0.11 ms, the longest kernel of a 100 k-pair step).  Lane r - 1 owns row r and the cells are
+// taken by anti-diagonals: at step t lane r computes cell (r, t - r) from its own last value (left), its upper neighbour's last
+// value (up) and that neighbour's value before (diag); the reference characters move down the lanes one per step the same way.
+// k + 2k steps of a dozen instructions instead of k x 2k cells of half a dozen.
+#define DPW_THREADS 256
+__global__ __launch_bounds__(DPW_THREADS) void k_root_dp_wave(const char* __restrict__ kmers, int k, int threshold,
+                                                             const u32* __restrict__ hit_lo, const u32* __restrict__ hit_pre,
+                                                             u32 n_groups, u32 stop, u32 base, const u32* __restrict__ seed_pos,
+                                                             const char* __restrict__ vtext, const u32* __restrict__ line_off, u32 n_lines,
+                                                             uint8_t* __restrict__ out) {
+	const int lane = __lane_id();
+	const u32 w = base + blockIdx.x * (DPW_THREADS / 64) + (threadIdx.x >> 6);      // (wave-uniform)
+	if (w >= hit_pre[n_groups]) return;
+	u32 lo = 0, hi = n_groups;                               // last group with hit_pre[g] <= w: 64 probes a step (three dependent loads for
+	while (hi - lo > 1) {                                    // 34 k groups where a binary search takes fifteen)
+		const u32 step = (hi - lo + 63u) / 64u;
+		const u32 idx = lo + (u32) lane * step;
+		const bool le = idx < hi && hit_pre[idx] <= w;         // (monotone: true for lanes 0 .. j)
+		const u32 j = (u32) __popcll(__ballot(le)) - 1u;        // (lane 0 probes `lo`, which holds)
+		lo += j * step;
+		hi = lo + step < hi ? lo + step : hi;
+	}
+	const u32 g = lo;
+	const u32 root = g / stop;
+	if (out[root]) return;
+	const int pos = (int) seed_pos[hit_lo[g] + (w - hit_pre[g])];
+	const int r = lane + 1;                                   // this lane's row (1 .. k; the others idle)
+	const char qc = r <= k ? kmers[(size_t) root * k + (r - 1)] : (char) 0;
+	for (u32 li = 0; li < n_lines; li++) {
+		const int len = (int) (line_off[li + 1] - line_off[li]);
+		int start = pos - k;
+		if (start < 0) start = 0;
+		if (start >= len - 2 * k) start = len - 2 * k - 1;
+		const char* ref = vtext + line_off[li] + start;
+		const int refA = lane < 2 * k ? (int) ref[lane] : 0, refB = 64 + lane < 2 * k ? (int) ref[64 + lane] : 0;      // the 2k reference characters, one or two per lane
+		int cur = 0, up_prev = 0, best = 0;                   // this row's last cell; the upper row's cell of the step before (= this step's diagonal)
+		int rc = 0;                                           // the reference character of this lane's current column
+		for (int t = 2; t <= 3 * k; t++) {                    // cell (r, c = t - r): c runs 1 .. 2k for every row r <= k
+			// (one DPP move each -- wave_shr:1, lane 0 gets 0 -- instead of a trip through the LDS crossbar: the two are this loop's whole dependency chain)
+			const int up = __builtin_amdgcn_update_dpp(0, cur, 0x138, 0xf, 0xf, false);      // lane r - 2 holds row r - 1: its cell (r - 1, c) of the last step
+			const int rc_up = __builtin_amdgcn_update_dpp(0, rc, 0x138, 0xf, 0xf, false);
+			const int c = t - r;
+			const int ci = t - 2;                             // (uniform) row 1's column - 1
+			const int rc_new = ci < 2 * k ? (ci < 64 ? __builtin_amdgcn_readlane(refA, ci) : __builtin_amdgcn_readlane(refB, ci - 64)) : 0;
+			rc = lane == 0 ? rc_new : rc_up;
+			const int upv = lane == 0 ? 0 : up;               // (row 0 is zero)
+			const int diag = lane == 0 ? 0 : up_prev;
+			if (r <= k && c >= 1 && c <= 2 * k) {
+				const int left = c == 1 ? 0 : cur;            // (column 0 is zero)
+				const int dg = c == 1 ? 0 : diag;
+				int v = left - 1;
+				v = v > upv - 1 ? v : upv - 1;
+				const int d = dg + ((int) qc == rc ? 1 : 0);
+				v = v > d ? v : d;
+				cur = v;
+				best = best > v ? best : v;
+			}
+			up_prev = up;
+		}
+		if (__ballot(best >= threshold)) { if (lane == 0) out[root] = 1; return; }      // any cell at or above the threshold accepts (seq_score.c:103-112)
+	}
+}
+
 // the scorer proper: d_k = n*k ASCII on the device, out = n host bytes
 static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t n, int k, int threshold, uint8_t* out) {
 	hipStream_t st = c->stream;
@@ -262,14 +326,22 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 	// the host waits for that event only, and adds a launch for what is beyond the guess)
 	HIP_TRY(hipMemcpyAsync(c->h_pin, d_pre + ng, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipEventRecord(c->ev_plan, st));
-	u32 ahead = 0;
-	if (threshold > 0 && c->root_dp_hint) {
-		ahead = c->root_dp_hint;
+	// few items: a wave each (k_root_dp_wave); many: a thread each
+	static const u32 dp_wave_max = getenv("VDJX_DP_WAVE_MAX") ? (u32) atol(getenv("VDJX_DP_WAVE_MAX")) : 65536u;
+	auto launch_dp = [&](u32 first, u32 count) -> u32 {        // -> items covered from `first` on (whole workgroups)
 		vdjx_prof_scope ps(c, "k_root_dp");
-		hipLaunchKernelGGL(k_root_dp, dim3((unsigned) ((ahead + DP_THREADS - 1) / DP_THREADS)), dim3(DP_THREADS), 0, st, d_k, k, threshold,
-		                   d_lo, d_pre, ng, (u32) stop, 0u, c->d_seed_pos, c->d_vtext, c->d_line_off, (u32) c->n_lines, d_out);
-		ahead = (ahead + DP_THREADS - 1) / DP_THREADS * DP_THREADS;
-	}
+		if (count <= dp_wave_max && k <= 64) {
+			const u32 per = DPW_THREADS / 64;
+			hipLaunchKernelGGL(k_root_dp_wave, dim3((count + per - 1) / per), dim3(DPW_THREADS), 0, st, d_k, k, threshold,
+			                   d_lo, d_pre, ng, (u32) stop, first, c->d_seed_pos, c->d_vtext, c->d_line_off, (u32) c->n_lines, d_out);
+			return (count + per - 1) / per * per;
+		}
+		hipLaunchKernelGGL(k_root_dp, dim3((unsigned) ((count + DP_THREADS - 1) / DP_THREADS)), dim3(DP_THREADS), 0, st, d_k, k, threshold,
+		                   d_lo, d_pre, ng, (u32) stop, first, c->d_seed_pos, c->d_vtext, c->d_line_off, (u32) c->n_lines, d_out);
+		return (count + DP_THREADS - 1) / DP_THREADS * DP_THREADS;
+	};
+	u32 ahead = 0;
+	if (threshold > 0 && c->root_dp_hint) ahead = launch_dp(0u, c->root_dp_hint);
 	// (the verdicts follow the guessed launch at once: when the guess covered the call -- every call but the first of a size -- the host
 	// wakes up once, with the verdicts there, instead of once for the number and again for the verdicts)
 	if (ahead) HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, st));
@@ -291,11 +363,7 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 		for (size_t r = 0; r < n; r++) out[r] = pre[(r + 1) * stop] > pre[r * stop];
 		return VDJX_OK;
 	}
-	if (run > ahead) {
-		vdjx_prof_scope ps(c, "k_root_dp");
-		hipLaunchKernelGGL(k_root_dp, dim3((unsigned) ((run - ahead + DP_THREADS - 1) / DP_THREADS)), dim3(DP_THREADS), 0, st, d_k, k, threshold,
-		                   d_lo, d_pre, ng, (u32) stop, ahead, c->d_seed_pos, c->d_vtext, c->d_line_off, (u32) c->n_lines, d_out);
-	}
+	if (run > ahead) (void) launch_dp(ahead, run - ahead);
 	HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
