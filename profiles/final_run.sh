@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-bash profiles/prof_step.sh r04g > gpurun_out/prof_r04g.log 2>&1; tail -2 gpurun_out/prof_r04g.log
+bash profiles/prof_step.sh r04h > gpurun_out/prof_r04h.log 2>&1; tail -2 gpurun_out/prof_r04h.log
 mkdir -p gpurun_out/r04m
 python bench.py > gpurun_out/r04m/default.json 2> gpurun_out/r04m/default.err
 python bench.py --pairs 1000000 --steps 200 > gpurun_out/r04m/1M.json 2> gpurun_out/r04m/1M.err
