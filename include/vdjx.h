@@ -280,6 +280,13 @@ int vdjx_profile_get(vdjx_ctx* ctx, int idx, const char** name, double* total_ms
 typedef struct vdjx_shard vdjx_shard;
 int vdjx_shard_begin(vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, int rank, int nranks,
                      uint64_t rec_stride, vdjx_shard** out);
+/* The same build over a SHARE of the pool (the way `vdjer --gpus N` deals the reads: by pair, both mates on one rank): record i of
+ * `pool` is record d_scan_index[i] of the scan order of the whole pool (primary then secondary, A2:1388-1390; total_records records
+ * over all ranks).  The positions ascend -- a share keeps the pool's order -- and every position belongs to exactly one rank.  The
+ * kernels work on local record numbers; a first instance is translated through d_scan_index where it leaves the rank, so no record
+ * ever moves between ranks.  d_scan_index is a device pointer that must stay valid until vdjx_shard_free. */
+int vdjx_shard_begin_share(vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, int rank, int nranks,
+                           const uint32_t* d_scan_index, uint64_t total_records, vdjx_shard** out);
 void vdjx_shard_free(vdjx_shard* s);
 /* bytes per exchanged record: kind 0 partial aggregate (32), 1 question (8), 2 answer (240), 3 survivor (32) */
 size_t vdjx_shard_record_bytes(int kind);

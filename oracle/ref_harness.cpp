@@ -25,7 +25,12 @@
 #include <stdint.h>
 #include <assert.h>
 
+#include <stdio.h>
+#include <stdlib.h>
+#include <pthread.h>
 static long vdjx_roots_scored = 0;
+static FILE* vdjx_root_log = NULL;                 /* VDJX_REF_ROOT_LOG=<file>: "<root k-mer>\t<verdict>" per consumed root */
+static pthread_mutex_t vdjx_root_log_mutex = PTHREAD_MUTEX_INITIALIZER;
 extern "C" int vdjx_hook_score_seq(const char* seq, int threshold);
 /* count every root consumed by worker_thread (A2:1103) to detect the lost-root race */
 #define score_seq(a, b) vdjx_hook_score_seq(a, b)
@@ -37,7 +42,14 @@ extern "C" int vdjx_hook_score_seq(const char* seq, int threshold);
 int score_seq(const char* seq, int threshold); /* the real one, seq_score.c:158 */
 extern "C" int vdjx_hook_score_seq(const char* seq, int threshold) {
 	__sync_fetch_and_add(&vdjx_roots_scored, 1);
-	return score_seq(seq, threshold);
+	int verdict = score_seq(seq, threshold);
+	if (vdjx_root_log) {        /* which roots a run consumed and what the (racy, at --t > 1: seq_score.c:14) scorer said of each */
+		pthread_mutex_lock(&vdjx_root_log_mutex);
+		fwrite(seq, 1, kmer_size, vdjx_root_log);
+		fprintf(vdjx_root_log, "\t%d\n", verdict);
+		pthread_mutex_unlock(&vdjx_root_log_mutex);
+	}
+	return verdict;
 }
 
 /* quick_map3.c */
@@ -118,7 +130,10 @@ void extract(char* reads_file, char* vdj_fasta, char* v_region, char* c_region,
 
 static void print_n(FILE* f, const char* s, int n) { for (int i = 0; i < n; i++) fputc(s[i], f); }
 
-static void at_exit_report() { fprintf(stderr, "HARNESS_ROOTS_SCORED\t%ld\n", vdjx_roots_scored); }
+static void at_exit_report() {
+	fprintf(stderr, "HARNESS_ROOTS_SCORED\t%ld\n", vdjx_roots_scored);
+	if (vdjx_root_log) fclose(vdjx_root_log);
+}
 
 typedef dense_hash_map<const char*, pre_node, my_hash, eqstr> pre_map_t;
 typedef dense_hash_map<const char*, struct node*, my_hash, eqstr> node_map_t;
@@ -389,6 +404,7 @@ int main(int argc, char** argv) {
 	}
 	if (!strcmp(argv[1], "run")) {
 		atexit(at_exit_report);
+		if (getenv("VDJX_REF_ROOT_LOG")) vdjx_root_log = fopen(getenv("VDJX_REF_ROOT_LOG"), "w");
 		/* the reference's own main(): params -> read length -> scorer init -> extract -> assemble */
 		return vdjer_reference_main(argc - 1, argv + 1);
 	}

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Mid-scale end-to-end goldens: digests of what the compiled reference (oracle/_ref/vdjer_ref, --t 1) writes for pools of
+hundreds of thousands of pairs -- tens of contigs, thousands of roots, hundreds of candidate windows, several growth steps of
+the order-defining sparsehash tables (A2:775-914, vj_filter.c:209-309) -- where tests/golden/e2e_* stop at 9 k pairs.
+
+Runs ONLY in the build container (needs `make -C oracle ref`).  The inputs are not stored: they regenerate from the counter-based
+generator (vdjer_amd/synth.py: make_repertoire + make_reads_cb, bit-identical on CPU and GPU), so a case is its generator
+parameters, its flags and the SHA-256 / sizes of vdj_contigs.fa, the SAM on stdout, vdjer.dot and the per-root verdict log.
+
+Complete-run rule (as make_golden.py): the reference loses its last root(s) to a wake-up race even at --t 1; a run
+counts only if the harness saw as many roots scored as the reference reported, and the case is accepted only when at least two
+complete runs exist and ALL complete runs agree byte for byte.
+
+    python tests/golden/make_golden_midscale.py [case ...]      # -> tests/golden/midscale.json
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from vdjer_amd import synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "vdjer_ref")
+OUT = os.path.join(HERE, "midscale.json")
+
+# name -> generator + flags.  mid_400k is the sample bench.py times the reference on (cpu_baseline / cli_end_to_end);
+# mid_cfg1 is BASELINE.json configs[1] whole (1 M pairs, 2,000 clones); mid_k25 is the sensitive mode of configs[3] at a size the
+# reference's serial traversal still finishes.
+CASES = {
+    "mid_400k": dict(pairs=400_000, clones=800, seed=20261002, noise=0.3, chain="IGH", ins=175,
+                     flags=["--k", "35", "--mf", "3", "--mq", "90", "--mrs", "30"]),
+    "mid_cfg1": dict(pairs=1_000_000, clones=2000, seed=20261002, noise=0.3, chain="IGH", ins=175,
+                     flags=["--k", "35", "--mf", "3", "--mq", "90", "--mrs", "30"]),
+    "mid_k25": dict(pairs=200_000, clones=400, seed=20261002, noise=0.3, chain="IGH", ins=175,
+                    flags=["--k", "25", "--mf", "2", "--mq", "60", "--mcs", "-5.5", "--mrs", "20"]),
+}
+
+
+def write_inputs(case: dict, d: str):
+    """The files a case's command line reads (also used by the tests, which is why it lives beside the digests)."""
+    rep = synth.make_repertoire(case["clones"], seed=case["seed"])
+    pool = synth.make_reads_cb(rep, case["pairs"], noise_frac=case["noise"], seed=case["seed"] + 13)
+    pool.write_reads_file(os.path.join(d, "reads.txt"))
+    synth.write_ref_dir(rep, os.path.join(d, "ref"))
+    return rep, pool
+
+
+def argv_of(case: dict, threads: int = 1):
+    return ["--in", "reads.txt", "--chain", case["chain"], "--ref-dir", "ref", "--ins", str(case["ins"]), "--t", str(threads)] + case["flags"]
+
+
+def digest(path: str) -> dict:
+    h, n, lines = hashlib.sha256(), 0, 0
+    with open(path, "rb") as f:
+        while True:
+            b = f.read(1 << 22)
+            if not b:
+                break
+            h.update(b)
+            n += len(b)
+            lines += b.count(b"\n")
+    return {"sha256": h.hexdigest(), "bytes": n, "lines": lines}
+
+
+def one_case(name: str, case: dict, attempts: int = 8, parallel: int = 4) -> dict:
+    work = tempfile.mkdtemp(prefix=f"vdjx_{name}_")
+    t0 = time.time()
+    write_inputs(case, work)
+    print(f"{name}: inputs in {time.time() - t0:.0f}s", flush=True)
+    complete, tried = [], 0
+    while tried < attempts and len(complete) < 2:
+        procs = []
+        for _ in range(min(parallel, attempts - tried)):
+            wd = os.path.join(work, f"run{tried}")
+            os.makedirs(wd)
+            os.symlink(os.path.join(work, "reads.txt"), os.path.join(wd, "reads.txt"))
+            os.symlink(os.path.join(work, "ref"), os.path.join(wd, "ref"))
+            pr = subprocess.Popen([REF, "run"] + argv_of(case), cwd=wd, stdout=open(os.path.join(wd, "out.sam"), "wb"),
+                                  stderr=open(os.path.join(wd, "err.txt"), "wb"), env=dict(os.environ, VDJX_REF_ROOT_LOG="roots.log"))
+            procs.append((wd, pr))
+            tried += 1
+        for wd, pr in procs:
+            pr.wait()
+            err = open(os.path.join(wd, "err.txt"), errors="replace").read()
+            m1, m2 = re.search(r"num root nodes: (\d+)", err), re.search(r"HARNESS_ROOTS_SCORED\t(\d+)", err)
+            if not (m1 and m2 and "FINIS" in err):
+                print(f"{name}: a run did not finish: {err[-300:]}", flush=True)
+                continue
+            ok = int(m1.group(1)) == int(m2.group(1))
+            print(f"{name}: run {os.path.basename(wd)} scored {m2.group(1)} of {m1.group(1)} roots{'' if ok else ' (incomplete: dropped)'}  [{time.time() - t0:.0f}s]", flush=True)
+            if ok:
+                complete.append((wd, int(m1.group(1))))
+    assert len(complete) >= 2, f"{name}: fewer than two complete runs in {tried} attempts"
+    dg = [{f: digest(os.path.join(wd, f)) for f in ("vdj_contigs.fa", "out.sam", "vdjer.dot", "roots.log")} for wd, _ in complete]
+    assert all(d == dg[0] for d in dg), f"{name}: complete runs disagree"
+    wd, nroots = complete[0]
+    log = [l.split("\t") for l in open(os.path.join(wd, "roots.log")).read().splitlines()]
+    fa = open(os.path.join(wd, "vdj_contigs.fa")).read()
+    res = dict(case)
+    res.update(roots=nroots, roots_accepted=sum(int(v) for _, v in log), contigs=fa.count(">"), complete_runs=len(complete), runs=tried,
+               fasta=dg[0]["vdj_contigs.fa"], sam=dg[0]["out.sam"], dot=dg[0]["vdjer.dot"], root_log=dg[0]["roots.log"],
+               root_log_format="<root k-mer>\\t<score_seq verdict>\\n per root in dispatch order (A2:1305-1318 at --t 1)",
+               reference_wall_s=round((time.time() - t0) / max(1, (tried + parallel - 1) // parallel)))
+    subprocess.run(["rm", "-rf", work])
+    return res
+
+
+def main():
+    assert os.path.exists(REF), "build the reference first: make -C oracle ref"
+    names = sys.argv[1:] or list(CASES)
+    out = json.load(open(OUT)) if os.path.exists(OUT) else {"cases": {}}
+    out["note"] = ("digests of complete --t 1 runs of the compiled reference; inputs regenerate from vdjer_amd/synth.py "
+                   "(make_golden_midscale.write_inputs)")
+    for n in names:
+        out["cases"][n] = one_case(n, CASES[n])
+        json.dump(out, open(OUT, "w"), indent=1, sort_keys=True)
+        print(json.dumps(out["cases"][n]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

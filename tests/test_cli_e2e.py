@@ -105,6 +105,33 @@ def test_vdjer_cli_gpus_n_ranks_share_one_device(tag, gpus, sam_pairs, tmp_path)
     assert max(v["records"] for v in sh.values()) <= 1.35 * R / gpus + 64         # a rank's host pool is its share: about 1/N
 
 
+@pytest.mark.parametrize("name,gpus", [("mid_400k", 1), ("mid_400k", 3), ("mid_k25", 1), ("mid_k25", 2), ("mid_cfg1", 1), ("mid_cfg1", 4)])
+def test_vdjer_cli_midscale_vs_reference_digests(name, gpus, tmp_path):
+    """End to end at MID scale (tests/golden/midscale.json: complete --t 1 runs of the compiled reference on 200 k - 1 M pairs, hundreds
+    to thousands of clones: thousands of roots, hundreds of candidate windows, tens of contigs, 10^5-10^6 SAM lines; mid_cfg1 is
+    BASELINE.json configs[1] whole): `vdjer` and `vdjer --gpus N` (N process-ranks on the box's one device, the pool dealt by pair,
+    no record moving between ranks) write the reference's vdj_contigs.fa, SAM and vdjer.dot byte for byte, and score every root as it
+    does.  Inputs regenerate from the counter-based generator."""
+    from tests import midscale_util as M
+    cases = M.cases()
+    if name not in cases:
+        pytest.skip(f"{name}: no digest in tests/golden/midscale.json (the reference did not finish it in the build container)")
+    case = cases[name]
+    exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
+    M.gen.write_inputs(case, str(tmp_path))
+    cmd = [exe] + M.gen.argv_of(case, threads=4) + (["--gpus", str(gpus)] if gpus > 1 else [])
+    env = dict(os.environ, VDJH_ROOT_LOG="roots.log", VDJX_MGPU_ONE_DEVICE="1", VDJX_MGPU_TIMEOUT_S="300")
+    with open(tmp_path / "out.sam", "wb") as so:
+        r = subprocess.run(cmd, cwd=tmp_path, stdout=so, stderr=subprocess.PIPE, text=True, timeout=1800, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    if gpus > 1:
+        assert f"k-mer table sharded over {gpus} GPUs (host)" in r.stderr
+    assert M.digest_file(str(tmp_path / "roots.log")) == case["root_log"]
+    assert M.digest_file(str(tmp_path / "vdj_contigs.fa")) == case["fasta"]
+    assert M.digest_file(str(tmp_path / "vdjer.dot")) == case["dot"]
+    assert M.digest_file(str(tmp_path / "out.sam")) == case["sam"]
+
+
 def test_vdjer_cli_gpus_n_takes_a_bam(tmp_path):
     """--in <bam> --gpus 2: every rank runs the extraction's passes and keeps its share (bamx_extract_filtered); same bytes as one GPU"""
     exe = os.path.join(ROOT, "vdjer_amd", "vdjer")

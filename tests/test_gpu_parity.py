@@ -525,6 +525,66 @@ def test_sharded_build_ranks_as_threads(ctx, world, k, mf, mq, stride, rl):
         np.testing.assert_array_equal(g.kmers, ref.kmers)
 
 
+@pytest.mark.parametrize("world,k,mf,mq,rl,base", [(2, 35, 3, 90, 50, 0), (3, 25, 2, 60, 50, 0), (4, 35, 2, 60, 50, (1 << 31) + 12345), (8, 35, 2, 60, 50, 0),
+                                                   (3, 35, 3, 90, 100, 0), (2, 50, 2, 60, 151, (1 << 29) + 7), (5, 48, 2, 60, 50, 0)])
+def test_sharded_build_over_shares_by_pair(ctx, world, k, mf, mq, rl, base):
+    """vdjx_shard_begin_share: every rank holds a SHARE of the pool dealt by pair (both mates, all four records of a pair on one rank --
+    what `vdjer --gpus N` keeps), its records at scattered places of the scan order, and builds over local record numbers; first
+    instances go through the share's scan positions where they leave the rank.  No record moves.  Result == the one-GPU build of
+    the whole pool == oracle.  base: the pool's records sit at scan positions base + i of a larger pool (positions and instance
+    ids beyond 2^32 >> 6, as at BASELINE configs[4])."""
+    import threading
+    import torch
+    from tests.fake_dist import ThreadDist
+    from vdjer_amd import api, shard, synth
+    rep = synth.make_repertoire(6, seed=43)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    ob = 6 if rl <= 64 else 8
+    pool = synth.make_reads(rep, 9000 if world < 8 else 12000, noise_frac=0.3, seed=611, err=0.004, n_rate=0.002, rl=rl)
+    ref = run_both(ctx, pool, vc, jc, k, mf, mq)
+    npri, R = pool.primary.shape[0], pool.n_records
+    cat = np.concatenate([pool.primary, pool.secondary])
+    owner = ((pool.pair_id.astype(np.uint64) * np.uint64(2654435761)) >> np.uint64(9)) % np.uint64(world)
+    dist = ThreadDist(world)
+    out, errs = [None] * world, []
+
+    def work(r):
+        try:
+            dist.set_rank(r)
+            c = api.Context(0)
+            c.anchor_sets_load(vc, jc)
+            mine = np.flatnonzero(owner == r)                              # ascending scan positions
+            p = c.pool_load(np.ascontiguousarray(cat[mine[mine < npri]]), np.ascontiguousarray(cat[mine[mine >= npri]]), rl)
+            scan = torch.from_numpy((mine.astype(np.uint64) + np.uint64(base)).astype(np.uint32).view(np.int32)).to("cuda:0")
+            drv = shard.ShardedHotPath(c, dist, torch.device("cuda", 0))
+            out[r] = drv.kmer_build(p, k, mf, mq, scan_index=scan, total_records=base + R)
+            p.free()
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            dist.barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    exp_first = ref.first_inst + (np.uint64(base) << np.uint64(ob))
+    if base:
+        assert int(exp_first.max()) >= 1 << 32
+    for g in out:
+        assert g.n == ref.n and g.pre_nodes == ref.pre_nodes
+        np.testing.assert_array_equal(g.first_inst, exp_first)
+        np.testing.assert_array_equal(g.freq, ref.freq)
+        np.testing.assert_array_equal(g.gated_count, ref.gated_count)
+        np.testing.assert_array_equal(g.has_v, ref.has_v)
+        np.testing.assert_array_equal(g.to_ids, ref.to_ids)
+        np.testing.assert_array_equal(g.from_ids, ref.from_ids)
+        np.testing.assert_array_equal(g.kmers, ref.kmers)
+
+
 def test_all_gated_all_distinct_overflows_the_lds_table(ctx):
     """High-quality reads with 80 % noise: nearly every instance is gated and distinct, so buckets hold more
     distinct k-mers than one LDS table pass takes and the sub-pass split / restart path runs."""

@@ -141,6 +141,38 @@ def test_host_stage_end_to_end_vs_reference(tag, threads, tmp_path):
     assert st["n_contigs_out"] == info["contigs"]
 
 
+def test_host_stage_midscale_vs_reference_digests(tmp_path):
+    """The serial host stage at MID scale -- 400,000 pairs / 800 clones: 4,381 roots, 989 contig candidates, 319 candidate windows,
+    55 contigs, the order-defining tables grown several times (A2:775-914 overlap removal with erase-during-iteration, vjf_windows_temp
+    A2:806, print_windows vj_filter.c:209-309) -- behind the oracle's graph and scorers: FASTA, SAM, vdjer.dot and the per-root verdict
+    log byte-identical (by digest) to complete --t 1 runs of the compiled reference (tests/golden/midscale.json)."""
+    from tests import midscale_util as M
+    from vdjer_amd import synth
+    case = M.cases()["mid_400k"]
+    rep = synth.make_repertoire(case["clones"], seed=case["seed"])
+    pool = synth.make_reads_cb(rep, case["pairs"], noise_frac=case["noise"], seed=case["seed"] + 13)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    fl = G.flags_to_params(case["flags"])
+    t = oracle.KmerTable(pool, fl["k"])
+    t.prune(fl["mf"], fl["mq"])
+    og = oracle.Graph(t, vc, jc)
+    g = api.Graph(fl["k"], og.n, 0, og.first, np.zeros(og.n, np.uint32), og.freq, og.has_v, og.has_j, og.to_deg, og.to_ids, og.from_deg, og.from_ids,
+                  np.frombuffer("".join(oracle.inst_kmer(pool, int(f), fl["k"]) for f in og.first).encode(), np.uint8).reshape(og.n, fl["k"]))
+    p = host.make_params(case["chain"], ins=case["ins"], t=4, k=fl["k"], mf=fl["mf"], mq=fl["mq"], mcs=fl["mcs"], mrs=fl["mrs"], rl=pool.rl)
+    fa, dot, sam, rlog = tmp_path / "c.fa", tmp_path / "g.dot", tmp_path / "o.sam", tmp_path / "roots.log"
+    os.environ["VDJH_ROOT_LOG"] = str(rlog)
+    try:
+        st = host.assemble(p, g, *_oracle_hooks(pool, rep.v_region, p), vc, jc, str(fa), str(dot), str(sam))
+    finally:
+        del os.environ["VDJH_ROOT_LOG"]
+    assert (st["n_roots"], st["n_roots_accepted"], st["n_contigs_out"]) == (case["roots"], case["roots_accepted"], case["contigs"])
+    assert M.digest_file(str(rlog)) == case["root_log"]
+    assert M.digest_file(str(fa)) == case["fasta"]
+    assert M.digest_file(str(dot)) == case["dot"]
+    assert M.digest_file(str(sam)) == case["sam"]
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

@@ -578,6 +578,13 @@ int vdjh_assemble(const vdjh_params* p, const vdjh_graph* g, const vdjh_hooks* h
 	uint8_t* valid = NULL;
 	char* wbuf = NULL;
 	if (nroots && h->root_score(h->ud, rk, nroots, p->k, p->min_source_homology_score, accepted_root)) { set_err("root scorer failed"); goto done; }
+	if (getenv("VDJH_ROOT_LOG")) {       /* (diagnostic: "<root k-mer>\t<verdict>" in dispatch order; bench.py sets it beside the reference's own log) */
+		FILE* rl = fopen(getenv("VDJH_ROOT_LOG"), "w");
+		if (rl) {
+			for (size_t i = 0; i < nroots; i++) { fwrite(rk + i * (size_t) p->k, 1, (size_t) p->k, rl); fprintf(rl, "\t%d\n", (int) accepted_root[i]); }
+			fclose(rl);
+		}
+	}
 	/* process_roots prints STATUS_UPDATE when the first root is dispatched (`ts` starts at 0, A2:1301,1335) and then every 300 s */
 	if (nroots) STAGE("STATUS_UPDATE");
 

@@ -26,10 +26,10 @@ struct vdjx_mgpu {
 	 * second chain, the next sample -- allocates nothing) */
 	void* ws[WS_SLOTS];
 	size_t ws_cap[WS_SLOTS];
-	/* the rank's share of the pool (ASCII records; the packed pool reads its quality characters here) and its slice of the scan order */
-	void *d_share, *d_slice, *d_reg;
-	vdjx_pool *share_pool, *slice_pool;
-	uint64_t stride;
+	/* the rank's share of the pool (ASCII records; the packed pool reads its quality characters here), the registration ranks and the scan positions of its records */
+	void *d_share, *d_reg, *d_scan;
+	vdjx_pool* share_pool;
+	uint64_t total_records;
 	int rl;
 };
 
@@ -72,20 +72,13 @@ int vdjx_mgpu_init(vdjx_comm* cm, int device, vdjx_mgpu** out) {
 	return 0;
 }
 
-static void drop_slice(vdjx_mgpu* m) {
-	if (m->slice_pool) vdjx_pool_free(m->slice_pool);
-	m->slice_pool = NULL;
-	if (m->d_slice) (void) hipFree(m->d_slice);
-	m->d_slice = NULL;
-}
-
 void vdjx_mgpu_free(vdjx_mgpu* m) {
 	if (!m) return;
 	(void) hipSetDevice(m->device);
-	drop_slice(m);
 	if (m->share_pool) vdjx_pool_free(m->share_pool);
 	if (m->d_share) (void) hipFree(m->d_share);
 	if (m->d_reg) (void) hipFree(m->d_reg);
+	if (m->d_scan) (void) hipFree(m->d_scan);
 	for (int i = 0; i < WS_SLOTS; i++) if (m->ws[i]) (void) hipFree(m->ws[i]);
 	vdjx_comm_free(m->cm);
 	free(m);
@@ -96,69 +89,57 @@ uint64_t vdjx_mgpu_bytes_sent(const vdjx_mgpu* m) { return m ? vdjx_comm_bytes_s
 static uint64_t sum64(const uint64_t* v, int n) { uint64_t s = 0; for (int i = 0; i < n; i++) s += v[i]; return s; }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
-/* the share, its read index, and the slices of the scan order                                                         */
+/* the share and its read index                                                                                        */
 /* ------------------------------------------------------------------------------------------------------------------ */
 int vdjx_mgpu_load(vdjx_mgpu* m, vdjx_ctx* ctx, const uint8_t* records, size_t n_records, int rl, const uint32_t* scan_index, const uint32_t* pair_id,
                    const uint8_t* read_num, const uint8_t* is_rc, const uint32_t* reg_rank, uint32_t n_pairs, uint64_t total_records) {
 	int rc = 0;
 	const int G = m->nranks, me = m->rank;
 	const size_t rec = 2 * (size_t) rl + 1;
-	uint64_t *send_rows = (uint64_t*) calloc((size_t) G, 8), *recv_rows = (uint64_t*) calloc((size_t) G, 8), *all_rows = (uint64_t*) calloc((size_t) G * (size_t) G, 8);
-	uint32_t* pos = (uint32_t*) malloc((n_records + 1) * 4);
-	void *d_rows = NULL, *d_pos_s = NULL, *d_pos_r = NULL;
-	if (!send_rows || !recv_rows || !all_rows || !pos) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; }
+	uint64_t* all_rows = (uint64_t*) calloc((size_t) G, 8);
+	if (!all_rows) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; }
 	if (rl < 1 || rl > VDJX_MAX_READ_LEN) { rc = fail(VDJX_ELIMIT, "read length %d outside [1,%d]", rl, VDJX_MAX_READ_LEN); goto done; }
 	if (total_records >= (1ull << 32) - (uint64_t) G) { rc = fail(VDJX_ELIMIT, "%llu records in all: at most 2^32", (unsigned long long) total_records); goto done; }
 	HIPC(hipSetDevice(m->device));
-	drop_slice(m);
 	if (m->share_pool) { vdjx_pool_free(m->share_pool); m->share_pool = NULL; }
 	if (m->d_share) { (void) hipFree(m->d_share); m->d_share = NULL; }
 	if (m->d_reg) { (void) hipFree(m->d_reg); m->d_reg = NULL; }
+	if (m->d_scan) { (void) hipFree(m->d_scan); m->d_scan = NULL; }
 	m->rl = rl;
-	/* the share on the device: the packed pool of the scorers (it keeps reading the quality characters from these records) */
-	HIPC(hipMalloc(&m->d_share, n_records * rec + 16));
-	HIPC(hipMalloc(&m->d_reg, (n_records + 1) * 4));
-	if (n_records) {
-		HIPC(hipMemcpy(m->d_share, records, n_records * rec, hipMemcpyHostToDevice));
-		HIPC(hipMemcpy(m->d_reg, reg_rank, n_records * 4, hipMemcpyHostToDevice));
-	}
-	VX(vdjx_pool_load_device(ctx, (const uint8_t*) m->d_share, n_records, NULL, 0, rl, &m->share_pool));
-	VX(vdjx_read_index_build(ctx, m->share_pool, pair_id, read_num, is_rc, reg_rank, n_pairs));
-	/* the slices: record g of the scan order belongs to rank g / S, at place g % S.  The share is in ascending scan order, so what goes
-	 * to a rank is one run of it. */
-	const uint64_t S = total_records ? (total_records + (uint64_t) G - 1) / (uint64_t) G : 1;
-	m->stride = S;
+	m->total_records = total_records;
+	/* the share on the device: the packed pool of the k-mer build AND of the scorers (it keeps reading the quality characters from these
+	 * records).  Round 4 dealt the ASCII records out again into slices of the scan order (one all-to-all of 101-byte records: 5 GB per
+	 * rank at configs[4], 2.8 times the partial aggregates the build exchanges); the build now takes the share as it is and translates
+	 * a first instance through scan_index where it leaves the rank (vdjx_shard_begin_share): no record moves between ranks. */
 	for (size_t i = 0; i < n_records; i++) {
 		const uint64_t g = scan_index[i];
 		if (g >= total_records || (i && scan_index[i - 1] >= g)) { rc = fail(VDJX_EINVAL, "rank %d: scan positions of the share must ascend below %llu (record %zu: %llu)", me, (unsigned long long) total_records, i, (unsigned long long) g); goto done; }
-		send_rows[g / S]++;
-		pos[i] = (uint32_t) (g % S);
 	}
-	CX(vdjx_comm_allgather_host(m->cm, send_rows, (size_t) G * 8, all_rows));
-	for (int s = 0; s < G; s++) recv_rows[s] = all_rows[(size_t) s * G + me];
-	const uint64_t n_slice = sum64(recv_rows, G);
 	{
-		const uint64_t a = (uint64_t) me * S < total_records ? (uint64_t) me * S : total_records, b = a + S < total_records ? a + S : total_records;
-		if (n_slice != b - a) { rc = fail(VDJX_EINVAL, "rank %d: %llu records arrive for a slice of %llu (the shares do not cover the pool once)", me, (unsigned long long) n_slice, (unsigned long long) (b - a)); goto done; }
+		uint64_t mine = n_records, sum = 0;
+		CX(vdjx_comm_allgather_host(m->cm, &mine, 8, all_rows));
+		for (int r = 0; r < G; r++) sum += all_rows[r];
+		if (sum != total_records) { rc = fail(VDJX_EINVAL, "rank %d: the shares hold %llu records, the pool %llu (the shares do not cover the pool once)", me, (unsigned long long) sum, (unsigned long long) total_records); goto done; }
 	}
-	WSG(WS_A, n_slice * rec + 16, &d_rows);
-	WSG(WS_B, (n_records + 1) * 4, &d_pos_s);
-	WSG(WS_C, (n_slice + 1) * 4, &d_pos_r);
-	if (n_records) HIPC(hipMemcpy(d_pos_s, pos, n_records * 4, hipMemcpyHostToDevice));
-	CX(vdjx_comm_a2av(m->cm, m->d_share, send_rows, d_rows, recv_rows, rec));
-	CX(vdjx_comm_a2av(m->cm, d_pos_s, send_rows, d_pos_r, recv_rows, 4));
-	HIPC(hipMalloc(&m->d_slice, n_slice * rec + 16));
-	VX(vdjx_rows_scatter(ctx, m->d_slice, d_rows, (const uint32_t*) d_pos_r, (size_t) n_slice, rec));
-	VX(vdjx_pool_load_device(ctx, (const uint8_t*) m->d_slice, (size_t) n_slice, NULL, 0, rl, &m->slice_pool));
+	HIPC(hipMalloc(&m->d_share, n_records * rec + 16));
+	HIPC(hipMalloc(&m->d_reg, (n_records + 1) * 4));
+	HIPC(hipMalloc(&m->d_scan, (n_records + 1) * 4));
+	if (n_records) {
+		HIPC(hipMemcpy(m->d_share, records, n_records * rec, hipMemcpyHostToDevice));
+		HIPC(hipMemcpy(m->d_reg, reg_rank, n_records * 4, hipMemcpyHostToDevice));
+		HIPC(hipMemcpy(m->d_scan, scan_index, n_records * 4, hipMemcpyHostToDevice));
+	}
+	VX(vdjx_pool_load_device(ctx, (const uint8_t*) m->d_share, n_records, NULL, 0, rl, &m->share_pool));
+	VX(vdjx_read_index_build(ctx, m->share_pool, pair_id, read_num, is_rc, reg_rank, n_pairs));
 done:
-	free(send_rows); free(recv_rows); free(all_rows); free(pos);
+	free(all_rows);
 	return rc;
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* the k-mer build                                                                                                     */
 /* ------------------------------------------------------------------------------------------------------------------ */
-int vdjx_mgpu_kmer_build_pool(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, uint64_t rec_stride, vdjx_graph** out) {
+static int kmer_build_any(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, uint64_t rec_stride, const uint32_t* d_scan, uint64_t total_records, vdjx_graph** out) {
 	int rc = 0;
 	const int G = m->nranks, me = m->rank;
 	vdjx_shard* sh = NULL;
@@ -168,9 +149,11 @@ int vdjx_mgpu_kmer_build_pool(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool
 	uint64_t *send_counts = (uint64_t*) calloc((size_t) G, 8), *recv_counts = (uint64_t*) calloc((size_t) G, 8), *q_out = (uint64_t*) calloc((size_t) G, 8),
 	         *q_in = (uint64_t*) calloc((size_t) G, 8), *eq = (uint64_t*) calloc((size_t) G, 8), *meta = (uint64_t*) calloc((size_t) G * (size_t) (G + 2), 8);
 	*out = NULL;
+	if (!send_counts || !recv_counts || !q_out || !q_in || !eq || !meta) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; }
 	const size_t W0 = vdjx_shard_record_bytes(0), W1 = vdjx_shard_record_bytes(1), W2 = vdjx_shard_record_bytes(2), W3 = vdjx_shard_record_bytes(3);
 	HIPC(hipSetDevice(m->device));
-	VX(vdjx_shard_begin(ctx, pool, k, mf, mq, me, G, rec_stride, &sh));
+	if (d_scan) VX(vdjx_shard_begin_share(ctx, pool, k, mf, mq, me, G, d_scan, total_records, &sh));
+	else VX(vdjx_shard_begin(ctx, pool, k, mf, mq, me, G, rec_stride, &sh));
 	/* 0. the ranks agree on the bucket geometry: the largest number of gated instances any of them holds */
 	{
 		uint64_t mine = 0, most = 0;
@@ -232,12 +215,13 @@ done:
 	return rc;
 }
 
+int vdjx_mgpu_kmer_build_pool(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, uint64_t rec_stride, vdjx_graph** out) {
+	return kmer_build_any(m, ctx, pool, k, mf, mq, rec_stride, NULL, 0, out);
+}
+
 int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, int k, int mf, int mq, vdjx_graph** out) {
-	if (!m->slice_pool) return fail(VDJX_ESTATE, "vdjx_mgpu_kmer_build: call vdjx_mgpu_load first");
-	const int rc = vdjx_mgpu_kmer_build_pool(m, ctx, m->slice_pool, k, mf, mq, m->stride, out);
-	(void) hipSetDevice(m->device);
-	drop_slice(m);
-	return rc;
+	if (!m->share_pool) return fail(VDJX_ESTATE, "vdjx_mgpu_kmer_build: call vdjx_mgpu_load first");
+	return kmer_build_any(m, ctx, m->share_pool, k, mf, mq, 0, (const uint32_t*) m->d_scan, m->total_records, out);
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */

@@ -38,10 +38,11 @@ uint64_t vdjx_mgpu_bytes_sent(const vdjx_mgpu* m);
  *   pair_id      the share's own numbering of the read names (0 .. n_pairs-1), read_num 1|2, is_rc (add_read_info, quick_map3.c:126-149)
  *   reg_rank     the order of the add_read_info calls over the WHOLE pool (global)
  * total_records = records of the whole pool (the same on every rank).  Collective.  Afterwards the context holds the read index of the
- * share (with vdjx_sam_names_load left to the caller) and the handle the rank's slice for vdjx_mgpu_kmer_build. */
+ * share (with vdjx_sam_names_load left to the caller) and the handle the share's packed pool and scan positions for vdjx_mgpu_kmer_build.
+ * No record moves between ranks (round 4 dealt the ASCII pool out again into slices of the scan order: 5 GB per rank at configs[4]). */
 int vdjx_mgpu_load(vdjx_mgpu* m, vdjx_ctx* ctx, const uint8_t* records, size_t n_records, int rl, const uint32_t* scan_index, const uint32_t* pair_id,
                    const uint8_t* read_num, const uint8_t* is_rc, const uint32_t* reg_rank, uint32_t n_pairs, uint64_t total_records);
-/* collective: the sharded k-mer build (vdjx_shard_*) over the slices; the same graph on every rank.  The slices are released. */
+/* collective: the sharded k-mer build (vdjx_shard_begin_share ...) over the shares; the same graph on every rank. */
 int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, int k, int mf, int mq, vdjx_graph** out);
 /* the same over pools the caller made itself (every rank passes its slice: records [rank*rec_stride, ...) of the scan order) */
 int vdjx_mgpu_kmer_build_pool(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, uint64_t rec_stride, vdjx_graph** out);

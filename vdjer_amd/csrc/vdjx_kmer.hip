@@ -1012,12 +1012,17 @@ __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated
 
 __global__ __launch_bounds__(256) void k_compact_partials(const Partial* __restrict__ sparse, const u32* __restrict__ sparse_ref,
                                                           const u32* __restrict__ bucket_start, const u32* __restrict__ nd,
-                                                          const u32* __restrict__ dstart, Partial* __restrict__ dense, u32* __restrict__ dense_ref) {
+                                                          const u32* __restrict__ dstart, Partial* __restrict__ dense, u32* __restrict__ dense_ref,
+                                                          const u32* __restrict__ scan, int ob) {
 	const u32 b = blockIdx.x;
 	const u64* src = (const u64*) (sparse + bucket_start[b]);
 	u64* dst = (u64*) (dense + dstart[b]);
 	const u32 m = nd[b];
-	for (u32 i = threadIdx.x; i < m * 4; i += 256) dst[i] = src[i];
+	for (u32 i = threadIdx.x; i < m * 4; i += 256) {
+		u64 v = src[i];
+		if (scan && (i & 3u) == 3u) v = ((u64) scan[v >> ob] << ob) | (v & ((1ull << ob) - 1ull));      // (share mode: the first instance leaves as a scan position)
+		dst[i] = v;
+	}
 	for (u32 i = threadIdx.x; i < m; i += 256) dense_ref[dstart[b] + i] = sparse_ref[bucket_start[b] + i];
 }
 
@@ -1206,7 +1211,7 @@ __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ qu
                                                     const Partial* __restrict__ dense, const u32* __restrict__ dense_ref,
                                                     const u32* __restrict__ dstart, u32 NBo, const u64* __restrict__ low_inst,
                                                     const u64* __restrict__ bases, const u64* __restrict__ nmask,
-                                                    vdjx_qrows quals, u64 rec_base, int k, int rl, int ob,
+                                                    vdjx_qrows quals, u64 rec_base, const u32* __restrict__ scan, u32 n_local, int k, int rl, int ob,
                                                     uint8_t* __restrict__ replies) {
 	const u32 qi = blockIdx.x;
 	if (qi >= nq) return;
@@ -1219,8 +1224,15 @@ __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ qu
 	const u32 need = q.y >> 30;
 	const u64 finst = p.fg;
 	const u32 om = (1u << ob) - 1u;
-	const u64 frec = (finst >> ob) - rec_base;
+	u64 frec = (finst >> ob) - rec_base;
 	const u32 foff = (u32) finst & om;
+	if (scan) {        // share mode: the aggregate carries a scan position; the local record is where the share holds it (the share ascends)
+		const u32 g = (u32) (finst >> ob);
+		u32 lo = 0, hi = n_local;
+		while (lo + 1 < hi) { const u32 mid = lo + ((hi - lo) >> 1); if (scan[mid] <= g) lo = mid; else hi = mid; }
+		frec = lo;
+	}
+	const u64 finst_local = (frec << ob) | foff;
 	uint8_t* out = replies + (size_t) qi * REPLY_BYTES;
 	if (lane == 0) {
 		((u32*) out)[0] = q.y;
@@ -1238,7 +1250,7 @@ __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ qu
 		const u32 cg = p.cg & ~PART_FLAG;
 		for (u32 i = 0; i < cg; i++) {
 			const u64 inst = low_inst[ref + i];
-			if (inst == finst) continue;
+			if (inst == (scan ? finst_local : finst)) continue;
 			const u64 rec = (inst >> ob) - rec_base;
 			const u32 off = (u32) inst & om;
 			acc += (u32) (uint8_t) (quals.row(rec)[off + lane] - 33);
@@ -1302,6 +1314,15 @@ __global__ void k_resolve_keep(PendOut po, u32 np, const u32* __restrict__ p_fl,
 		so.lo[pos] = po.lo[p]; so.hi[pos] = po.hi[p];
 		so.gcnt[pos] = cgc; so.gfirst[pos] = po.mg[p];
 	}
+}
+
+// share mode of the sharded build: local first sights (record << ob | offset, all-ones = none) -> the same with the record's scan position
+__global__ void k_first_to_scan(u64* __restrict__ a, size_t na, u64* __restrict__ b, size_t nb, const u32* __restrict__ scan, int ob) {
+	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= na + nb) return;
+	u64* p = i < na ? a + i : b + (i - na);
+	const u64 v = *p;
+	if (v != NONE64) *p = ((u64) scan[v >> ob] << ob) | (v & ((1ull << ob) - 1ull));
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -2928,6 +2949,13 @@ struct vdjx_shard {
 	const vdjx_pool* pool = nullptr;
 	int k = 0, mf = 0, mq = 0, rank = 0, nranks = 1;
 	u64 rec_stride = 0;
+	// share mode (vdjx_shard_begin_share): the rank's records are a SHARE of the pool in ascending scan order, record i at scan
+	// position scan[i]; the kernels work on local record numbers (an ascending renumbering keeps every "first") and what leaves
+	// the rank -- a partial aggregate's first instance, the first sights of nodes and in-edges -- goes through scan[] on its way out
+	const u32* scan = nullptr;
+	u64 total_records = 0;
+	u64 rec_base() const { return scan ? 0 : rec_stride * (u64) rank; }
+	u64 records_in_all() const { return scan ? total_records : rec_stride * (u64) nranks; }
 	bool wide = false;                              // Tup24 (k > 45)
 	// local phase: this rank's gated tuples by bucket, its partial aggregates (dense, bucket order)
 	u32 NBf = 0, NBo = 0;
@@ -2960,20 +2988,27 @@ struct vdjx_shard {
 	u32 NBt = 0;
 };
 
-extern "C" int vdjx_shard_begin(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, int rank, int nranks,
-                                uint64_t rec_stride, vdjx_shard** out) {
+static int shard_begin_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, int rank, int nranks,
+                            uint64_t rec_stride, const uint32_t* d_scan, uint64_t total_records, vdjx_shard** out) {
 	if (!c || !pool || !out) { vdjx_set_error("vdjx_shard_begin: NULL argument"); return VDJX_EINVAL; }
 	*out = nullptr;
 	if (c->live_shard) { vdjx_set_error("vdjx_shard_begin: a sharded build is already in flight on this context"); return VDJX_ESTATE; }
 	if (nranks < 1 || nranks > 256 || rank < 0 || rank >= nranks) { vdjx_set_error("1 <= nranks <= 256, 0 <= rank < nranks"); return VDJX_EINVAL; }
 	if (k < 1 || k > VDJX_MAX_KMER || k > pool->rl) { vdjx_set_error("k=%d outside [1,min(%d,rl=%d)]", k, VDJX_MAX_KMER, pool->rl); return VDJX_ELIMIT; }
-	if (rec_stride < pool->n_records) { vdjx_set_error("rec_stride %llu < local records %zu", (unsigned long long) rec_stride, pool->n_records); return VDJX_EINVAL; }
-	if (rec_stride * (uint64_t) nranks >= (1ull << (INST_BITS - pool->ob))) { vdjx_set_error("global record count %llu >= 2^%d (instance ids are record << %d | offset in %d bits)", (unsigned long long) (rec_stride * nranks), INST_BITS - pool->ob, pool->ob, INST_BITS); return VDJX_ELIMIT; }
+	if (d_scan) {
+		if (total_records < pool->n_records) { vdjx_set_error("total_records %llu < local records %zu", (unsigned long long) total_records, pool->n_records); return VDJX_EINVAL; }
+		if (total_records >= (1ull << 32) || total_records >= (1ull << (INST_BITS - pool->ob))) { vdjx_set_error("global record count %llu: scan positions are 32 bits and instance ids record << %d | offset in %d bits", (unsigned long long) total_records, pool->ob, INST_BITS); return VDJX_ELIMIT; }
+		rec_stride = (total_records + (uint64_t) nranks - 1) / (uint64_t) nranks;        // (only the geometry bound of a build without vdjx_shard_count reads it)
+	} else {
+		if (rec_stride < pool->n_records) { vdjx_set_error("rec_stride %llu < local records %zu", (unsigned long long) rec_stride, pool->n_records); return VDJX_EINVAL; }
+		if (rec_stride * (uint64_t) nranks >= (1ull << (INST_BITS - pool->ob))) { vdjx_set_error("global record count %llu >= 2^%d (instance ids are record << %d | offset in %d bits)", (unsigned long long) (rec_stride * nranks), INST_BITS - pool->ob, pool->ob, INST_BITS); return VDJX_ELIMIT; }
+	}
 	if (k > 16 && !c->anchors_loaded) { vdjx_set_error("vdjx_shard_begin: call vdjx_anchor_sets_load first (k > 16)"); return VDJX_ESTATE; }
 	if (pool->W > 2 && pool->n_records >= (1ull << 27)) { vdjx_set_error("more than 2^27 records of long reads on one GPU: not supported by the recount items"); return VDJX_ELIMIT; }
 	vdjx_shard* s = new vdjx_shard();
 	s->c = c; s->pool = pool; s->k = k; s->mf = mf; s->mq = mq; s->rank = rank; s->nranks = nranks;
 	s->rec_stride = rec_stride;
+	s->scan = d_scan; s->total_records = total_records;
 	s->wide = k > 45;
 	if (mq >= 255) mq = 254;                                        // A2:1514-1516
 	s->mqq = (u32) (mq < 0 ? 0 : (mq > 214 ? 214 : mq));
@@ -2981,6 +3016,21 @@ extern "C" int vdjx_shard_begin(vdjx_ctx* c, const vdjx_pool* pool, int k, int m
 	c->live_shard = s;
 	*out = s;
 	return VDJX_OK;
+}
+
+extern "C" int vdjx_shard_begin(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, int rank, int nranks,
+                                uint64_t rec_stride, vdjx_shard** out) {
+	return shard_begin_impl(c, pool, k, mf, mq, rank, nranks, rec_stride, nullptr, 0, out);
+}
+
+// the same build over a SHARE of the pool: record i of `pool` is record d_scan_index[i] of the scan order (A2:1388-1390) of a pool
+// of total_records records; the positions ascend (a share keeps the pool's order) and no two ranks hold the same one.  The array
+// lives on the device and must stay valid until vdjx_shard_free.
+extern "C" int vdjx_shard_begin_share(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, int rank, int nranks,
+                                      const uint32_t* d_scan_index, uint64_t total_records, vdjx_shard** out) {
+	if (pool && pool->n_records && !d_scan_index) { vdjx_set_error("vdjx_shard_begin_share: NULL scan index"); return VDJX_EINVAL; }
+	static const uint32_t none = 0;
+	return shard_begin_impl(c, pool, k, mf, mq, rank, nranks, 0, d_scan_index ? d_scan_index : &none, total_records, out);
 }
 
 extern "C" void vdjx_shard_free(vdjx_shard* s) {
@@ -3009,7 +3059,7 @@ static int shard_local_impl(vdjx_shard* s) {
 	vdjx_ctx* c = s->c;
 	hipStream_t st = c->stream;
 	PersistAlloc db(c);
-	const u64 rec_base = s->rec_stride * (u64) s->rank;
+	const u64 rec_base = s->rec_base();
 	GTuples<TUP> t;
 	int rc = VDJX_OK;
 	if (!s->have_hist) rc = stage_gated_hist(c, db, s->pool, s->k, 0, shard_geometry_bound(s), &s->gh);
@@ -3115,7 +3165,7 @@ extern "C" int vdjx_shard_local_fill(vdjx_shard* s, void* d_dir, void* d_partial
 		// the aggregates of every bucket end to end, in the caller's buffer -- which from here on IS this rank's list of them: the
 		// answers to the owners' questions are looked up in it (vdjx_shard_reply)
 		vdjx_prof_scope ps(s->c, "k_compact_partials");
-		hipLaunchKernelGGL(k_compact_partials, dim3(s->NBt), dim3(256), 0, st, s->sparse, s->sparse_ref, s->tuple_bucket_start, s->nd, s->dstart, (Partial*) d_partials, s->dense_ref);
+		hipLaunchKernelGGL(k_compact_partials, dim3(s->NBt), dim3(256), 0, st, s->sparse, s->sparse_ref, s->tuple_bucket_start, s->nd, s->dstart, (Partial*) d_partials, s->dense_ref, s->scan, s->pool->ob);
 	}
 	s->dense = (Partial*) d_partials;
 	HIP_TRY(hipStreamSynchronize(st));
@@ -3292,7 +3342,7 @@ extern "C" int vdjx_shard_reply(vdjx_shard* s, const void* d_queries, const uint
 	{
 		vdjx_prof_scope ps(c, "k_shard_reply");
 		hipLaunchKernelGGL(k_shard_reply, dim3(nq), dim3(64), 0, st, (const uint2*) d_queries, nq, d_off, G, s->dense, s->dense_ref, s->dstart, s->NBo,
-		                   s->low_inst, p->d_bases, p->d_nmask, vdjx_qrows{p->d_quals, p->d_quals2, p->q_split, p->qstride}, s->rec_stride * (u64) s->rank, s->k, p->rl, p->ob, (uint8_t*) d_replies);
+		                   s->low_inst, p->d_bases, p->d_nmask, vdjx_qrows{p->d_quals, p->d_quals2, p->q_split, p->qstride}, s->rec_base(), s->scan, (u32) p->n_records, s->k, p->rl, p->ob, (uint8_t*) d_replies);
 	}
 	HIP_TRY(hipStreamSynchronize(st));          // `off` staging dies with this frame
 	HIP_TRY(hipGetLastError());
@@ -3366,7 +3416,13 @@ extern "C" int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t 
 	HIP_TRY(db.alloc(&a.lo, a.n)); HIP_TRY(db.alloc(&a.hi, a.n)); HIP_TRY(db.alloc(&a.gcnt, a.n)); HIP_TRY(db.alloc(&a.gfirst, a.n));
 	hipLaunchKernelGGL(k_surv_unpack, dim3((a.n + 255) / 256), dim3(256), 0, c->stream, (const SurvRec*) d_surv_all, a.n, a.lo, a.hi, a.gcnt, a.gfirst);
 	RecountOut ro{(u32*) d_ucnt, (u64*) d_ufirst, (u64*) d_in_first, nullptr, nullptr, nullptr};
-	return stage_recount(c, db, s->pool, s->rec_stride * (u64) s->rank, s->k, a, ro, false, &s->tb);
+	const int rc = stage_recount(c, db, s->pool, s->rec_base(), s->k, a, ro, false, &s->tb);
+	if (rc || !s->scan) return rc;
+	// share mode: the first sights are local instance ids; on their way to the reduction over ranks they become scan positions
+	hipLaunchKernelGGL(k_first_to_scan, dim3((a.n * 5 + 255) / 256), dim3(256), 0, c->stream, (u64*) d_in_first, (size_t) a.n * 4, (u64*) d_ufirst, (size_t) a.n, s->scan, s->pool->ob);
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipGetLastError());
+	return VDJX_OK;
 }
 
 // every rank: the reduced arrays -> the graph (identical on all ranks)
@@ -3394,7 +3450,7 @@ extern "C" int vdjx_shard_finish(vdjx_shard* s, const void* d_in_first, const vo
 	}
 	vdjx_graph* g = new vdjx_graph();
 	g->pre_nodes = (size_t) pre_nodes_total;
-	int rc = stage_finish2(c, db, a, ro, s->rec_stride * (u64) s->nranks, s->k, P, s->pool->ob, g);
+	int rc = stage_finish2(c, db, a, ro, s->records_in_all(), s->k, P, s->pool->ob, g);
 	if (rc) { vdjx_graph_free(g); return rc; }
 	*out = g;
 	return VDJX_OK;

@@ -38,6 +38,7 @@ def _bind(L):
         return
     vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
     L.vdjx_shard_begin.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(vp)]
+    L.vdjx_shard_begin_share.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_uint64, C.POINTER(vp)]
     L.vdjx_shard_free.argtypes = [vp]
     L.vdjx_shard_free.restype = None
     L.vdjx_shard_record_bytes.argtypes = [C.c_int]
@@ -70,11 +71,18 @@ class HipShardEngine:
         self.h = None
         self.W = [int(self.L.vdjx_shard_record_bytes(i)) for i in range(3)]
 
-    def begin(self, pool, k, mf, mq, rank, world, stride):
+    def begin(self, pool, k, mf, mq, rank, world, stride, scan_index=None, total_records=0):
+        """scan_index (device int32/uint32 tensor [pool.n_records], ascending): the pool is a SHARE of a pool of total_records records
+        and record i sits at scan position scan_index[i] (vdjx_shard_begin_share); None: rank r holds records [r*stride, ...)"""
         h = C.c_void_p()
-        check(self.L.vdjx_shard_begin(self.ctx.h, pool.h, k, mf, mq, rank, world, stride, C.byref(h)), "vdjx_shard_begin")
-        self.h, self.pool, self.k, self.world = h, pool, k, world
         self._keep = []
+        if scan_index is not None:
+            self._keep.append(scan_index)
+            check(self.L.vdjx_shard_begin_share(self.ctx.h, pool.h, k, mf, mq, rank, world, self._dp(scan_index), int(total_records), C.byref(h)),
+                  "vdjx_shard_begin_share")
+        else:
+            check(self.L.vdjx_shard_begin(self.ctx.h, pool.h, k, mf, mq, rank, world, stride, C.byref(h)), "vdjx_shard_begin")
+        self.h, self.pool, self.k, self.world = h, pool, k, world
 
     def _dp(self, t):
         return C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
@@ -366,10 +374,13 @@ class ShardedHotPath:
             at += len(own[o])
         return valid, tot.cpu().numpy().astype(np.uint32)
 
-    def kmer_build(self, pool, k: int = 35, mf: int = 3, mq: int = 90, keep_device: bool = False, async_export: bool = False):
+    def kmer_build(self, pool, k: int = 35, mf: int = 3, mq: int = 90, keep_device: bool = False, async_export: bool = False,
+                   scan_index=None, total_records: int = 0):
+        """scan_index / total_records: the pool is this rank's SHARE of the whole pool (by pair, any dealing that keeps the scan order),
+        record i at scan position scan_index[i]; without them rank r holds the r-th slice of the scan order"""
         t, dist, eng, cm = self.torch, self.dist, self.engine, self.comm
         G, r = self.world, self.rank
-        if self.stride is None:
+        if scan_index is None and self.stride is None:
             s = t.tensor([pool.n_records], dtype=t.int64, device=self.dev)
             cm.all_reduce(s, dist.ReduceOp.MAX)
             self.stride = int(s.item())
@@ -383,7 +394,10 @@ class ShardedHotPath:
             self.laps[name] = self.laps.get(name, 0.0) + now - clock[0]
             clock[0] = now
 
-        eng.begin(pool, k, mf, mq, r, G, stride)
+        if scan_index is not None:
+            eng.begin(pool, k, mf, mq, r, G, 0, scan_index=scan_index, total_records=total_records)
+        else:
+            eng.begin(pool, k, mf, mq, r, G, stride)
         try:
             def exchange(send, ins, outs):
                 if alone:             # nothing to move: what a rank keeps for itself is its send buffer (with peers, a 1/G-th of it is copied)
