@@ -79,7 +79,12 @@ def scorer_bytes(stats: dict, n_windows: int, n_contigs: int, k: int, rl: int = 
             "k_root_dp": 3 * k * stats.get("root_dp_items", 0)}
 
 
-def workload_label(pairs: int, k: int, mf: int, mq: int, mrs: int, ins: int, world: int) -> str:
+def workload_label(pairs: int, k: int, mf: int, mq: int, mrs: int, ins: int, world: int, chains=("IGH",)) -> str:
+    if len(chains) > 1:
+        return (f"BASELINE.json configs[4]{'' if (pairs, world) == (12_500_000, 8) else ' geometry'}: {pairs} synthetic 50bp PE pairs per GPU x {world} GPU(s) = "
+                f"{pairs * world} pairs per chain, hash-prefix sharded (pool dealt by pair, one bulk all-to-all of partial aggregates), "
+                f"{' -> '.join(chains)} back to back in one process (set_chain_info params.c:13-30: own repertoire, ref-dir, anchors and pool per chain; "
+                f"anchor sets, V region, pool packing and read index inside every step), k={k} mf={mf} mq={mq} mrs={mrs} ins={ins}; SURVEY §8d C5")
     if world > 1:
         tag = f"weak scaling of BASELINE.json configs[2]-sized pools over {world} GPUs (configs[4] is {world}x12.5 M)" if pairs >= 10_000_000 else "custom"
     elif pairs == 10_000_000 and (k, mf, mq) == (35, 3, 90):
@@ -93,16 +98,16 @@ def workload_label(pairs: int, k: int, mf: int, mq: int, mrs: int, ins: int, wor
     return f"synthetic {pairs} 50bp PE pairs per GPU, IGH, k={k} mf={mf} mq={mq} mrs={mrs} ins={ins} ({tag})"
 
 
-def make_workload(n_pairs: int, n_clones: int, seed: int, rank: int, world: int, device: str):
+def make_workload(n_pairs: int, n_clones: int, seed: int, rank: int, world: int, device: str, chain: str = "IGH", ci: int = 0):
     """Rank r holds its own library: n_pairs read pairs from n_clones clones over its own germline (rank 0: exactly the
     one-GPU workload).  N GPUs = N independent libraries processed as ONE job (one k-mer table, one graph, one traversal):
     N x pairs, N x clones, and a ref-dir that is the union of the N germlines, so the per-GPU work stays what it is on one
     GPU -- the definition of weak scaling (SURVEY §8d scales clones with pairs the same way: 1 M / 2,000 ... 100 M / 100,000).
     The pool is generated in HBM by the counter-based generator (bit-identical to its CPU evaluation)."""
     from vdjer_amd import synth
-    libs = [synth.make_repertoire(n_clones, seed=seed + 15485863 * r) for r in range(world)]
+    libs = [synth.make_repertoire(n_clones, seed=seed + 15485863 * r + 7 * ci, chain=chain) for r in range(world)]
     rep = libs[rank]
-    pool = synth.make_reads_cb(rep, n_pairs, noise_frac=0.3, seed=seed + 104729 * rank, device=device)
+    pool = synth.make_reads_cb(rep, n_pairs, noise_frac=0.3, seed=seed + 104729 * rank + 1000 * ci, device=device)
     vc = np.array(sorted({synth.seq_to_int(a) for lb in libs for a in lb.v_anchors}), dtype=np.uint32)
     jc = np.array(sorted({synth.seq_to_int(a) for lb in libs for a in lb.j_anchors}), dtype=np.uint32)
     return rep, pool, vc, jc, [lb.v_region for lb in libs]
@@ -126,21 +131,38 @@ def cpu_reference(n_sample: int, seed: int, k: int, mf: int, mq: int, mrs: int, 
         synth.write_ref_dir(rep, os.path.join(td, "ref"))
         cmd = [REF_BIN, "run", "--in", "reads.txt", "--chain", "IGH", "--ref-dir", "ref", "--ins", str(ins), "--t", str(threads),
                "--k", str(k), "--mf", str(mf), "--mq", str(mq), "--mrs", str(mrs)]
-        def timed_run(argv, cwd, sam_name):
+        def timed_run(argv, cwd, sam_name, env=None):
             mk = {}
             t_start = time.perf_counter()
             with open(os.path.join(cwd, sam_name), "wb") as so:
-                pr = subprocess.Popen(argv, cwd=cwd, stdout=so, stderr=subprocess.PIPE, text=True, errors="replace")
+                pr = subprocess.Popen(argv, cwd=cwd, stdout=so, stderr=subprocess.PIPE, text=True, errors="replace", env=env)
                 for line in pr.stderr:
                     if line.startswith("ELAPSED_SECS\t"):
                         mk.setdefault(line.split("\t")[1], time.perf_counter())
+                    elif line.startswith("VDJX_TIMES\t"):          # (this build's own milliseconds beside the reference's whole seconds)
+                        f_ = line.rstrip("\n").split("\t")
+                        mk.setdefault("_ms", {}).setdefault(f_[1], float(f_[2]))
                     elif line.startswith("num root nodes:"):
                         mk["_roots"] = int(line.split(":")[1])
                     elif line.startswith("HARNESS_ROOTS_SCORED"):
                         mk["_scored"] = int(line.split("\t")[1])
                 pr.wait()             # (the reference's exit status is meaningless: its main falls off its end)
             return mk, t_start, time.perf_counter(), pr.returncode
-        marks, _, _, _ = timed_run(cmd, td, "sam.out")
+
+        def digests(d, sam_name):
+            from tests import midscale_util as M
+            out = {}
+            for key, fn in (("fasta", "vdj_contigs.fa"), ("sam", sam_name), ("dot", "vdjer.dot"), ("root_log", "roots.log")):
+                out[key] = M.digest_file(os.path.join(d, fn)) if os.path.exists(os.path.join(d, fn)) else None
+            return out
+
+        def root_log(path):
+            try:
+                return dict(l.rstrip("\n").split("\t") for l in open(path))
+            except OSError:
+                return {}
+        # the timed run: --t <threads>, the harness logging what score_seq said of every root it consumed (one fwrite per root)
+        marks, _, _, _ = timed_run(cmd, td, "sam.out", dict(os.environ, VDJX_REF_ROOT_LOG="roots.log"))
         ref_complete = marks.get("_roots") is not None and marks.get("_roots") == marks.get("_scored")
         n_contigs = sum(1 for l in open(os.path.join(td, "vdj_contigs.fa")) if l.startswith(">")) if os.path.exists(os.path.join(td, "vdj_contigs.fa")) else -1
         # ---- the whole command line of THIS build on the same file, same flags (one GPU): the first number that covers the read
@@ -152,34 +174,86 @@ def cpu_reference(n_sample: int, seed: int, k: int, mf: int, mq: int, mrs: int, 
             os.makedirs(d2)
             os.symlink(os.path.join(td, "reads.txt"), os.path.join(d2, "reads.txt"))
             os.symlink(os.path.join(td, "ref"), os.path.join(d2, "ref"))
-            mk2, t0c, t1c, rc2 = timed_run([exe] + cmd[2:], d2, "sam.out")
-            same = same_set = None
+            mk2, t0c, t1c, rc2 = timed_run([exe] + cmd[2:], d2, "sam.out", dict(os.environ, VDJH_ROOT_LOG="roots.log", VDJX_TIMES="1"))
+            mine = digests(d2, "sam.out")
+            # ---- (1) byte for byte against the reference at --t 1 (its race-free order): the committed digests of complete
+            # --t 1 runs when this sample IS a committed mid-scale golden (tests/golden/midscale.json), a live --t 1 run otherwise
+            t1 = {"source": None, "identical": None}
+            try:
+                from tests import midscale_util as M
+                gold = next((c for c in M.cases().values() if (c["pairs"], c["clones"], c["seed"], c["noise"], c["chain"], c["ins"]) ==
+                             (n_sample, len(rep.clones), seed, 0.3, "IGH", ins) and c["flags"] == cmd[cmd.index("--k"):]), None)
+            except Exception:  # noqa: BLE001
+                gold = None
+            if gold is not None:
+                t1 = {"source": "tests/golden/midscale.json: digests of complete --t 1 runs of the compiled reference on this very sample "
+                                f"({gold['complete_runs']} runs, all identical; tests/golden/make_golden_midscale.py)",
+                      "identical": all(mine[f_] == gold[f_] for f_ in ("fasta", "sam", "dot")), "root_verdicts_identical": mine["root_log"] == gold["root_log"],
+                      "differs": [f_ for f_ in ("fasta", "sam", "dot", "root_log") if mine[f_] != gold[f_]]}
+            elif os.environ.get("VDJX_BENCH_REF_T1", "1") != "0":
+                for attempt in range(2):          # (the reference loses its last roots to a wake-up race even at --t 1: a run counts only when it scored them all)
+                    d1 = os.path.join(td, f"t1_{attempt}")
+                    os.makedirs(d1)
+                    os.symlink(os.path.join(td, "reads.txt"), os.path.join(d1, "reads.txt"))
+                    os.symlink(os.path.join(td, "ref"), os.path.join(d1, "ref"))
+                    c1 = list(cmd)
+                    c1[c1.index("--t") + 1] = "1"
+                    mk1, _, _, _ = timed_run(c1, d1, "sam.out", dict(os.environ, VDJX_REF_ROOT_LOG="roots.log"))
+                    if mk1.get("_roots") is not None and mk1.get("_roots") == mk1.get("_scored"):
+                        theirs = digests(d1, "sam.out")
+                        t1 = {"source": f"a complete --t 1 run of oracle/_ref/vdjer_ref beside this one (attempt {attempt + 1})",
+                              "identical": all(mine[f_] == theirs[f_] for f_ in ("fasta", "sam", "dot")), "root_verdicts_identical": mine["root_log"] == theirs["root_log"],
+                              "differs": [f_ for f_ in ("fasta", "sam", "dot", "root_log") if mine[f_] != theirs[f_]]}
+                        break
+                    t1["source"] = "two --t 1 runs of the reference both lost roots to its wake-up race (SURVEY §0-3): nothing to compare with"
+            # ---- (2) the timed --t N run of the reference against that: at --t > 1 its workers share ONE scoring matrix (seq_score.c:14,
+            # written by every worker, seq_score.c:93-98), so root verdicts flip with thread timing, and its windows enter the
+            # order-defining tables in thread-timing order: its contig set, order and numbering are not a function of the input
+            same_set = None
             try:
                 fa_a, fa_b = open(os.path.join(d2, "vdj_contigs.fa"), "rb").read(), open(os.path.join(td, "vdj_contigs.fa"), "rb").read()
-                same = fa_a == fa_b and open(os.path.join(d2, "sam.out"), "rb").read() == open(os.path.join(td, "sam.out"), "rb").read()
                 same_set = sorted(fa_a.split(b"\n")[1::2]) == sorted(fa_b.split(b"\n")[1::2])       # the contigs, whatever their order and numbering
+                only_ref = sorted(set(fa_b.split(b"\n")[1::2]) - set(fa_a.split(b"\n")[1::2]))
+                only_here = sorted(set(fa_a.split(b"\n")[1::2]) - set(fa_b.split(b"\n")[1::2]))
             except OSError:
-                pass
+                only_ref = only_here = []
+            la, lb = root_log(os.path.join(d2, "roots.log")), root_log(os.path.join(td, "roots.log"))
+            flips = sorted(k_ for k_ in lb if k_ in la and la[k_] != lb[k_])
+            tn = {"threads": threads, "scored_all_roots": ref_complete, "roots": marks.get("_roots"), "roots_scored": marks.get("_scored"),
+                  "same_contig_set": same_set, "contigs_only_in_reference_run": len(only_ref), "contigs_only_here": len(only_here),
+                  "root_verdicts_differing_from_t1": len(flips), "roots_accepted_here_and_at_t1": sum(1 for v_ in la.values() if v_ == "1"),
+                  "roots_accepted_by_this_reference_run": sum(1 for v_ in lb.values() if v_ == "1"),
+                  "flipped_roots_sample": [f"{k_} t1={la[k_]} t{threads}={lb[k_]}" for k_ in flips[:6]],
+                  "why": "seq_score_matrix is one global scratch written by every worker (seq_score.c:14,93-98): at --t > 1 a root's DP is "
+                         "overwritten mid-way by its neighbours' and score_seq accepts roots the serial run rejects (or the reverse); every such "
+                         "root is listed by k-mer.  The extra accepted roots can add contigs, and the accepted windows' insertion order -- thread "
+                         "timing -- decides which of two overlapping windows A2:875-898 erases.  This build emits the --t 1 bytes whatever --t."}
 
             def sp(m, a, b):
                 return round(m[b] - m[a], 3) if a in m and b in m else None
             stages = (("kmer_table", "PRE_PRE_GRAPH1", "POST_PRE_GRAPH1"), ("prune", "POST_PRE_GRAPH1", "POST_PRUNE_PRE_GRAPH1"),
                       ("graph", "POST_PRUNE_PRE_GRAPH1", "POST_BUILD_GRAPH2"), ("traversal_and_scorers", "POST_BUILD_GRAPH2", "THREADS_DONE"),
                       ("output_and_sam", "THREADS_DONE", "PRE_CLEANUP"), ("assemble_total", "PRE_PRE_GRAPH1", "FINIS"))
-            cli = {"pairs": n_sample, "exit_code": rc2, "wall_s_process": round(t1c - t0c, 3),
+            ms = mk2.get("_ms", {})
+
+            def seg(a, b):
+                return round(ms[b] - ms[a], 1) if a in ms and b in ms else None
+            breakdown = {"process_start_to_first_marker": round((mk2["START"] - t0c) * 1e3, 1) if "START" in mk2 else None,
+                         "input_read_and_parsed (the HIP runtime starting beside it on a thread)": seg("START", "(inputs read)"),
+                         "wait_for_hip_init": seg("(inputs read)", "(vdjx_init done)"),
+                         "anchor_sets_and_v_region": seg("(vdjx_init done)", "POST_VJF_INIT"),
+                         "pool_load": seg("POST_VJF_INIT", "(pool loaded)"), "read_index": seg("(pool loaded)", "(read index built)"),
+                         "read_names_to_device": seg("(read index built)", "POST_READ_EXTRACT"),
+                         "kmer_build": seg("PRE_PRE_GRAPH1", "POST_BUILD_GRAPH2"), "traversal_and_scorers": seg("POST_BUILD_GRAPH2", "THREADS_DONE"),
+                         "overlap_removal_fasta_sam": seg("THREADS_DONE", "PRE_CLEANUP"), "teardown": seg("PRE_CLEANUP", "FINIS"),
+                         "finis_to_process_end": round((t1c - mk2["FINIS"]) * 1e3, 1) if "FINIS" in mk2 else None}
+            cli = {"pairs": n_sample, "exit_code": rc2, "wall_s_process": round(t1c - t0c, 3), "cli_process_breakdown_ms": breakdown,
                    "stages_s": {n_: sp(mk2, a, b) for n_, a, b in stages}, "reference_stages_s": {n_: sp(marks, a, b) for n_, a, b in stages},
-                   "reference_scored_all_roots": ref_complete,
-                   "outputs_identical_to_reference": same if ref_complete else None,
-                   "same_contig_set_as_reference": same_set if ref_complete else None,
-                   "order_note": "with --t > 1 the reference inserts its windows in thread-timing order, which its hash tables' iteration order (and "
-                                 "with it contig order and numbering) depends on; this build emits the --t 1 order whatever --t",
-                   "outputs_note": None if ref_complete else ("the reference run lost roots to its thread race at --t > 1 (SURVEY §0-3: "
-                                                              f"{marks.get('_scored')} of {marks.get('_roots')} scored): its outputs are incomplete, "
-                                                              "so they are not compared here; tests/test_gpu_fuzz.py compares the two command lines "
-                                                              "byte for byte on complete --t 1 runs"),
+                   "outputs_identical_to_reference": t1["identical"], "reference_t1": t1, "reference_tN": tn,
                    "note": "vdjer_amd/vdjer (C host over libvdjx, one GPU) and oracle/_ref/vdjer_ref on the same extracted-reads file and ref-dir, "
                            "timed by their ELAPSED_SECS stage markers as they arrive; process wall time includes reading the file, loading the "
-                           "pool, building the read index and the GPU start-up"}
+                           "pool, building the read index and the GPU start-up.  outputs_identical_to_reference: vdj_contigs.fa, SAM and "
+                           "vdjer.dot byte for byte against the reference at --t 1"}
     if "PRE_PRE_GRAPH1" not in marks or "FINIS" not in marks:
         return None
 
@@ -271,7 +345,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=10_000_000, help="pairs per GPU")
+    ap.add_argument("--pairs", type=int, default=None, help="pairs per GPU (default 10 M; 12.5 M with --config4)")
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE.json configs[4]: 12.5 M pairs per GPU, IGH -> IGK -> IGL back to back in one process (a step = the three chains: anchor sets, "
+                         "V region, pool packing, read index, sharded k-mer build over the pool dealt by pair, scorers -- per chain).  The default with --gpus 8")
+    ap.add_argument("--no-config4", action="store_true", help="--gpus 8 as weak scaling of configs[2]-sized IGH pools, like --gpus 2 / 4")
+    ap.add_argument("--chains", default=None, help="comma-separated chain presets of a --config4 step (default IGH,IGK,IGL)")
     ap.add_argument("--clones", type=int, default=0, help="clones per GPU (default: pairs / 500)")
     ap.add_argument("--k", type=int, default=35)
     ap.add_argument("--mf", type=int, default=3)
@@ -295,6 +374,15 @@ def main():
                          "10 M pairs it does not finish in an hour on 8 cores (DESIGN.md §5)")
     ap.add_argument("--parity-sample", type=int, default=20000, help="pairs of the parity gate (SURVEY §8d)")
     args = ap.parse_args()
+    if args.gpus == 8 and not args.no_config4:
+        args.config4 = True
+    chains = tuple((args.chains or "IGH,IGK,IGL").split(",")) if args.config4 else ("IGH",)
+    if args.pairs is None:
+        args.pairs = 12_500_000 if args.config4 else 10_000_000
+    if args.config4:
+        args.force_shard = True          # configs[4] runs only through the sharded path (one rank: the same phases, nothing to exchange)
+        args.no_e2e = True
+        args.windows = "generator"
     if args.clones <= 0:
         args.clones = max(4, args.pairs // 500)
     if args.windows == "auto":
@@ -347,7 +435,13 @@ def main():
     from vdjer_amd import api
 
     t_gen = time.perf_counter()
-    rep, pool, vc, jc, v_lines = make_workload(args.pairs, args.clones, args.seed, rank, world, f"cuda:{local_rank}")
+    # W: the chains of one step.  One entry (IGH) but for --config4, where a step is IGH -> IGK -> IGL back to back: a repertoire,
+    # ref-dir (anchor sets, V region), pool and candidate windows per chain, all resident before the timed region
+    W = []
+    for ci_, chain_ in enumerate(chains):
+        rep_, pool_, vc_, jc_, vl_ = make_workload(args.pairs, args.clones, args.seed, rank, world, f"cuda:{local_rank}", chain_, ci_)
+        W.append({"chain": chain_, "ci": ci_, "rep": rep_, "pool": pool_, "vc": vc_, "jc": jc_, "v_lines": vl_, "d_pri": pool_.primary, "d_sec": pool_.secondary})
+    rep, pool, vc, jc, v_lines = (W[0][n_] for n_ in ("rep", "pool", "vc", "jc", "v_lines"))
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
     rl = pool.rl
@@ -374,7 +468,26 @@ def main():
     p_index = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
     # the per-record read info {pair, read_num, is_rc, registration rank} resident in HBM like the pools; the index itself is
     # built on the device (vdjx_rindex.hip): timed here, reported beside `value` (row a-8's index, quick_map3.c:126-149)
-    ri_dev = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank)]
+    for w_ in W:
+        w_["ri_dev"] = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (w_["pool"].pair_id, w_["pool"].read_num, w_["pool"].is_rc, w_["pool"].reg_rank)]
+    ri_dev = W[0]["ri_dev"]
+    if args.config4 and world > 1:
+        # the pool dealt BY PAIR over the ranks (what `vdjer --gpus N` keeps): the four records of local pair j of rank r sit at scan
+        # positions ((j * world) + r) * 4 ... of the primary part (then the secondary part) of the whole pool -- interleaved with every
+        # other rank's.  The build works on local record numbers and translates first instances on their way out (vdjx_shard_begin_share)
+        for w_ in W:
+            npri_, nsec_ = int(w_["d_pri"].shape[0]), int(w_["d_sec"].shape[0])
+            mx = torch.tensor([npri_, nsec_], dtype=torch.int64, device=dev)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            mp_, ms_ = int(mx[0].item()), int(mx[1].item())
+            i_ = torch.arange(npri_, dtype=torch.int64, device=dev)
+            j_ = torch.arange(nsec_, dtype=torch.int64, device=dev)
+            pos = torch.cat([((i_ // 4) * world + rank) * 4 + i_ % 4, world * mp_ + ((j_ // 4) * world + rank) * 4 + j_ % 4])
+            w_["total"] = world * (mp_ + ms_)
+            if w_["total"] >= 1 << 32:
+                raise SystemExit("scan positions beyond 2^32")
+            w_["scan"] = (pos & 0xFFFFFFFF).to(torch.int64).numpy(force=True).astype(np.uint32).view(np.int32)
+            w_["scan"] = torch.from_numpy(w_["scan"]).to(dev)
     torch.cuda.synchronize()
     ix_times = []
 
@@ -429,18 +542,24 @@ def main():
                       f"candidates -> {len(wins)} distinct windows, {len(contigs_fixed)} final contigs")
         del g0
     else:
-        libs_w = [w for w in rep.windows() if w]
-        if world > 1:
-            from vdjer_amd import synth
-            libs_w = [w for r in range(world) for w in synth.make_repertoire(args.clones, seed=args.seed + 15485863 * r).windows() if w]
-        wins = libs_w
+        for w_ in W:
+            libs_w = [w for w in w_["rep"].windows() if w]
+            if world > 1:
+                from vdjer_amd import synth
+                libs_w = [w for r in range(world) for w in synth.make_repertoire(args.clones, seed=args.seed + 15485863 * r + 7 * w_["ci"], chain=w_["chain"]).windows() if w]
+            w_["wins"] = libs_w
+        wins = W[0]["wins"]
         contigs_fixed = None
     # one GPU: all windows / contigs.  Several GPUs: every rank maps ALL of them against its own reads (the k-mer instances and
     # the reads are sharded, not the windows)
     my_wins = wins
     my_contigs = contigs_fixed
-    my_wins_packed = ctx.pin_strings(my_wins, "windows")
-    my_wins_rows = np.frombuffer("".join(my_wins).encode(), np.uint8).reshape(len(my_wins), -1) if my_wins else np.zeros((0, 486), np.uint8)
+    W[0].setdefault("wins", wins)
+    for w_ in W:
+        tg = "" if w_["ci"] == 0 else str(w_["ci"])
+        w_["wins_packed"] = ctx.pin_strings(w_["wins"], "windows" + tg)
+        w_["wins_rows"] = np.frombuffer("".join(w_["wins"]).encode(), np.uint8).reshape(len(w_["wins"]), -1) if w_["wins"] else np.zeros((0, 486), np.uint8)
+    my_wins_packed, my_wins_rows = W[0]["wins_packed"], W[0]["wins_rows"]
     my_contigs_packed = ctx.pin_strings(my_contigs, "contigs") if my_contigs else None
 
     def gather_bytes(a):
@@ -459,7 +578,17 @@ def main():
     host_fwd = {}
 
     def step(from_host: bool = False):
+        for w_ in W:
+            step_chain(w_, from_host)
+
+    def step_chain(w_, from_host: bool = False):
         t = time.perf_counter()
+        tg = "" if w_["ci"] == 0 else str(w_["ci"])
+        d_pri, d_sec = w_["d_pri"], w_["d_sec"]
+        if args.config4:           # a new chain: its ref-dir's anchor sets (two 2^32-bit bitmaps) and V region go up with it
+            ctx.anchor_sets_load(w_["vc"], w_["jc"])
+            ctx.vregion_load(w_["v_lines"], 15)
+            t = lap("chain_ref_dir", t)
         if from_host:      # end-to-end variant: the reads start in page-locked HOST memory (forward records only) and cross PCIe;
             # the NEXT step's pool is uploaded and packed on the copy stream while this step computes (two pools in flight)
             def upload():
@@ -471,8 +600,14 @@ def main():
         else:
             p = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
         t = lap("pool_pack", t)
+        if args.config4:           # every chain's pool is seen once: its read index (quick_map3.c:126-149) is part of the step
+            rd_ = w_["ri_dev"]
+            ctx.read_index_build_device(p, rd_[0].data_ptr(), rd_[1].data_ptr(), rd_[2].data_ptr(), rd_[3].data_ptr(), w_["pool"].n_pairs)
+            t = lap("read_index", t)
         if engine is None:
             g = ctx.kmer_build(p, args.k, args.mf, args.mq, async_export=True)
+        elif w_.get("scan") is not None:
+            g = engine.kmer_build(p, args.k, args.mf, args.mq, async_export=True, scan_index=w_["scan"], total_records=w_["total"])
         else:
             g = engine.kmer_build(p, args.k, args.mf, args.mq, async_export=True)
         t = lap("kmer_build", t)
@@ -481,15 +616,15 @@ def main():
         root_ids, ok = ctx.root_score_graph(g, args.mrs, rank, world)
         t = lap("root_score", t)
         if engine is None:
-            valid, npairs = ctx.window_score(my_wins_packed, args.ins)
+            valid, npairs = ctx.window_score(w_["wins_packed"], args.ins)
         else:
-            valid, npairs = engine.window_score(scorer, my_wins_packed, args.ins)
+            valid, npairs = engine.window_score(scorer, w_["wins_packed"], args.ins)
         t = lap("window_score", t)
         # generator windows: the contigs are the [51,411) slices of the windows the coverage test accepts (page-locked, like the windows)
         if my_contigs is not None:
             cpk = my_contigs_packed if my_contigs_packed is not None else (b"", 0, 0)
         else:
-            cpk = ctx.pin_rows_take(my_wins_rows, np.flatnonzero(valid), "contigs", 51, 360)
+            cpk = ctx.pin_rows_take(w_["wins_rows"], np.flatnonzero(valid), "contigs" + tg, 51, 360)
         n_contigs = cpk[1]
         # the mapped pairs (20 B each) cross PCIe on the copy stream while the next step's kernels run; they are waited for before
         # the next map_emit reuses the stream (and after the last step, inside the timed region)
@@ -501,10 +636,13 @@ def main():
         if world > 1:      # every rank learns every root verdict (a few KB); the window verdicts already are global
             ok = np.concatenate(gather_bytes(ok))
             t = lap("gather_results", t)
-        state.update(nodes=g.n, pre=g.pre_nodes, roots=int(g.n_roots), roots_ok=int(ok.sum()), windows=len(wins),
-                     valid=int(valid.sum()), contigs=n_contigs if world == 1 else None, mapped_this_rank=int(pairs.shape[0]),
-                     window_pairs_this_rank=int(npairs.sum()), n_contigs_rank=n_contigs, graph=g,
-                     last=dict(root_ids=root_ids, ok=ok, valid=valid, npairs=npairs, offs=offs, pairs=pairs))
+        per_chain = dict(nodes=g.n, pre=g.pre_nodes, roots=int(g.n_roots), roots_ok=int(ok.sum()), windows=len(w_["wins"]),
+                         valid=int(valid.sum()), contigs=n_contigs if world == 1 else None, mapped_this_rank=int(pairs.shape[0]),
+                         window_pairs_this_rank=int(npairs.sum()), n_contigs_rank=n_contigs)
+        state.setdefault("per_chain", {})[w_["chain"]] = per_chain
+        if w_["ci"] == 0:
+            state.update(per_chain)
+            state.update(graph=g, last=dict(root_ids=root_ids, ok=ok, valid=valid, npairs=npairs, offs=offs, pairs=pairs))
         p.free()
 
     def barrier():
@@ -652,6 +790,7 @@ def main():
         from vdjer_amd import synth
         n_s = min(args.parity_sample, args.pairs)
         sp = synth.make_reads_cb(rep, n_s, noise_frac=0.3, seed=args.seed + 99)
+        ctx.anchor_sets_load(vc, jc)          # (a --config4 step leaves its last chain's sets behind)
         pp = ctx.pool_load(sp.primary, sp.secondary, rl)
         hg = ctx.kmer_build(pp, args.k, args.mf, args.mq)
         pp.free()
@@ -666,9 +805,9 @@ def main():
     if rank != 0:
         return
     ms_step = dt / args.steps * 1e3
-    total_pairs = args.pairs * world
+    total_pairs = args.pairs * world * len(W)          # (a --config4 step takes its chains' pools one after the other)
     value = total_pairs * args.steps / dt / 1e6
-    ab = algorithmic_bytes_per_pair(args.k, rl, stats.get("gated_instances", 0) / args.pairs if stats.get("gated_instances") else None)
+    ab = algorithmic_bytes_per_pair(args.k, rl, stats.get("gated_instances", 0) / args.pairs if stats.get("gated_instances") else None)      # (the last build's count: one chain's pool)
     # `roofline`: the dominant kernel among the HBM-streaming ones, i.e. the longest kernel of the k-mer build.  The scorer kernels
     # are priced in `roofline_by_kernel` too, but k_window_pairs / k_window_cover work on cache-resident inputs (every read class is
     # looked at by many windows: PMC fabric traffic is a third of SURVEY 8d's per-instance bytes), so an HBM fraction says nothing
@@ -682,9 +821,9 @@ def main():
         per_step = launches / args.steps
         per_pair = ab.get(name) if name in ab and name not in ("P", "input", "total", "gated_per_pair") else None
         if name in sb:
-            bpl = sb[name] / max(1.0, per_step)
+            bpl = sb[name] * len(W) / max(1.0, per_step)
         elif per_pair is not None:
-            bpl = per_pair * args.pairs / max(1.0, per_step)
+            bpl = per_pair * args.pairs * len(W) / max(1.0, per_step)
         else:
             return None                      # a kernel without a stated job size is not priced (never the whole path's bytes)
         ach = bpl / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None
@@ -734,9 +873,9 @@ def main():
                 "frac_note": "`frac` prices SURVEY 8d's algorithmic bytes (for the walk: a 16-B probe per instance, most of which this design answers from two "
                              "chain words in cache, so its PMC traffic is BELOW that figure); `frac_on_traffic` = PMC bytes / time / peak is what the kernel "
                              "really moves per second",
-                "hot_path_frac": round(ab["total"] * args.pairs / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "hot_path_frac": round(ab["total"] * args.pairs * len(W) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 # SURVEY 8d's per-pair figure takes EVERY instance as gated (3,324 B at k=35); with the gated instances this run measured
-                "hot_path_frac_gated": round((2 * ab["input"] + 32 * ab["gated_per_pair"] + 16 * ab["P"]) * args.pairs / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                "hot_path_frac_gated": round((2 * ab["input"] + 32 * ab["gated_per_pair"] + 16 * ab["P"]) * args.pairs * len(W) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
     cpu = None
     cpu_port_legs = None
     if not args.no_cpu and world == 1:
@@ -753,7 +892,7 @@ def main():
         "unit": "M paired-reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8/u64 (2-bit packed bases, integer counts)", "data": "synthetic",
-        "config": {"workload": workload_label(args.pairs, args.k, args.mf, args.mq, args.mrs, args.ins, world),
+        "config": {"workload": workload_label(args.pairs, args.k, args.mf, args.mq, args.mrs, args.ins, world, chains), "chains": list(chains),
                    "pairs_per_gpu": args.pairs, "clones_per_gpu": args.clones, "noise": 0.3, "parallelism": f"hash-prefix x{world}",
                    "multi_gpu_input": "one independent library (own germline, clones, reads) per GPU; ONE k-mer table / graph / traversal over all of them",
                    "scorer_inputs": scorer_src},

@@ -30,6 +30,7 @@
 #include <sys/resource.h>
 #include <sys/prctl.h>
 #include <signal.h>
+#include <pthread.h>
 #include <unistd.h>
 
 typedef struct {
@@ -126,6 +127,14 @@ static int parse(int argc, char** argv, cli* c) {
 	if (!ok) { usage(); return -1; }
 	if (c->hp.min_base_quality >= 255) c->hp.min_base_quality = 254;      /* A2:1514-1516 */
 	return 0;
+}
+
+typedef struct { int device; vdjx_ctx* gx; int rc; char err[512]; } init_job;
+static void* init_thread(void* p) {
+	init_job* j = (init_job*) p;
+	j->rc = vdjx_init(j->device, &j->gx);
+	if (j->rc) snprintf(j->err, sizeof j->err, "%s", vdjx_last_error());      /* (the message is the calling thread's) */
+	return NULL;
 }
 
 static time_t t_start, t_prev;
@@ -632,6 +641,15 @@ int main(int argc, char** argv) {
 	if (fds) vdjx_comm_sockets_keep(c.gpus, rank, fds);
 	if (rank == 0) sigprocmask(SIG_SETMASK, &before, NULL);
 	if (rank == 0) status("START");
+	/* the GPU context starts on a thread of its own while this one reads the input: bringing up the HIP runtime takes a few hundred
+	 * milliseconds, about what parsing a few hundred thousand pairs takes.  (After the forks: no rank touches a GPU before it is a
+	 * process of its own, and nothing is ever exec'ed from here.) */
+	const int device = one_device ? 0 : rank;              /* rank r drives GPU r */
+	init_job ij;
+	memset(&ij, 0, sizeof ij);
+	ij.device = device;
+	pthread_t init_th;
+	const int init_threaded = getenv("VDJX_INIT_SERIAL") == NULL && pthread_create(&init_th, NULL, init_thread, &ij) == 0;
 	reads_t rd;
 	if (load_reads(&c, &rd, rank, c.gpus, use_mgpu)) return 255;
 	c.hp.read_length = rd.rl;
@@ -647,10 +665,12 @@ int main(int argc, char** argv) {
 	size_t nvl = 0;
 	if (load_vregion(c.source_sim_file, &vlines, &nvl)) return 255;
 
-	const int device = one_device ? 0 : rank;              /* rank r drives GPU r */
 	vdjx_ctx* gx = NULL;
 	if (getenv("VDJX_TIMES")) status("(inputs read)");
-	VX(vdjx_init(device, &gx));
+	if (init_threaded) pthread_join(init_th, NULL);
+	else init_thread(&ij);
+	if (ij.rc) { fprintf(stderr, "vdjx_init: %s\n", ij.err); return 1; }
+	gx = ij.gx;
 	if (getenv("VDJX_TIMES")) status("(vdjx_init done)");
 	vdjx_mgpu* mg = NULL;
 	if (use_mgpu) {
@@ -685,7 +705,9 @@ int main(int argc, char** argv) {
 	vdjx_pool* px = NULL;
 	if (!use_mgpu) {
 		VX(vdjx_pool_load(gx, rd.primary, rd.n_primary, rd.secondary, rd.n_secondary, rd.rl, &px));
+		if (getenv("VDJX_TIMES")) status("(pool loaded)");
 		VX(vdjx_read_index_build(gx, px, rd.pair_id, rd.read_num, rd.is_rc, rd.reg_rank, rd.n_pairs));
+		if (getenv("VDJX_TIMES")) status("(read index built)");
 	} else if (vdjx_mgpu_load(mg, gx, rd.primary, rd.n_primary, rd.rl, rd.scan_index, rd.pair_id, rd.read_num, rd.is_rc, rd.reg_rank, rd.n_pairs, rd.total_records)) {
 		fprintf(stderr, "%s\n", vdjx_mgpu_last_error());
 		return 1;

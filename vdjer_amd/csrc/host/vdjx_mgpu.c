@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <hip/hip_runtime_api.h>
@@ -31,7 +32,39 @@ struct vdjx_mgpu {
 	vdjx_pool* share_pool;
 	uint64_t total_records;
 	int rl;
+	/* VDJX_TIMES: wall milliseconds per phase on this rank (a rank waits inside a collective for the slowest: what the phases cost
+	 * the job), printed by rank 0 when it releases the others */
+	int timing;
+	int n_laps;
+	struct { const char* name; double ms; uint64_t calls; uint64_t bytes; } laps[48];
+	struct timespec lap_t;
+	uint64_t lap_bytes;
 };
+
+static void lap_start(vdjx_mgpu* m) {
+	if (!m->timing) return;
+	clock_gettime(CLOCK_MONOTONIC, &m->lap_t);
+	m->lap_bytes = vdjx_comm_bytes_sent(m->cm);
+}
+static void lap(vdjx_mgpu* m, const char* name) {
+	if (!m->timing) return;
+	struct timespec t;
+	clock_gettime(CLOCK_MONOTONIC, &t);
+	const double ms = (t.tv_sec - m->lap_t.tv_sec) * 1e3 + (t.tv_nsec - m->lap_t.tv_nsec) / 1e6;
+	const uint64_t by = vdjx_comm_bytes_sent(m->cm);
+	int i = 0;
+	while (i < m->n_laps && strcmp(m->laps[i].name, name)) i++;
+	if (i == m->n_laps && m->n_laps < 48) { m->laps[i].name = name; m->laps[i].ms = 0; m->laps[i].calls = 0; m->laps[i].bytes = 0; m->n_laps++; }
+	if (i < m->n_laps) { m->laps[i].ms += ms; m->laps[i].calls++; m->laps[i].bytes += by - m->lap_bytes; }
+	m->lap_t = t;
+	m->lap_bytes = by;
+}
+void vdjx_mgpu_print_times(const vdjx_mgpu* m, FILE* f) {
+	if (!m || !m->timing) return;
+	for (int i = 0; i < m->n_laps; i++)
+		fprintf(f, "VDJX_MGPU_PHASE\trank\t%d\t%s\tms\t%.2f\tcalls\t%llu\tbytes_sent\t%llu\n", m->rank, m->laps[i].name, m->laps[i].ms,
+		        (unsigned long long) m->laps[i].calls, (unsigned long long) m->laps[i].bytes);
+}
 
 static __thread char g_err[640];
 static int fail(int rc, const char* fmt, ...) {
@@ -68,6 +101,7 @@ int vdjx_mgpu_init(vdjx_comm* cm, int device, vdjx_mgpu** out) {
 	vdjx_mgpu* m = (vdjx_mgpu*) calloc(1, sizeof *m);
 	if (!m) return fail(VDJX_EINVAL, "out of memory");
 	m->cm = cm; m->rank = vdjx_comm_rank(cm); m->nranks = vdjx_comm_size(cm); m->device = device;
+	m->timing = getenv("VDJX_TIMES") != NULL;
 	*out = m;
 	return 0;
 }
@@ -107,6 +141,7 @@ int vdjx_mgpu_load(vdjx_mgpu* m, vdjx_ctx* ctx, const uint8_t* records, size_t n
 	if (m->d_scan) { (void) hipFree(m->d_scan); m->d_scan = NULL; }
 	m->rl = rl;
 	m->total_records = total_records;
+	lap_start(m);
 	/* the share on the device: the packed pool of the k-mer build AND of the scorers (it keeps reading the quality characters from these
 	 * records).  Round 4 dealt the ASCII records out again into slices of the scan order (one all-to-all of 101-byte records: 5 GB per
 	 * rank at configs[4], 2.8 times the partial aggregates the build exchanges); the build now takes the share as it is and translates
@@ -129,8 +164,11 @@ int vdjx_mgpu_load(vdjx_mgpu* m, vdjx_ctx* ctx, const uint8_t* records, size_t n
 		HIPC(hipMemcpy(m->d_reg, reg_rank, n_records * 4, hipMemcpyHostToDevice));
 		HIPC(hipMemcpy(m->d_scan, scan_index, n_records * 4, hipMemcpyHostToDevice));
 	}
+	lap(m, "load: check + upload of the share");
 	VX(vdjx_pool_load_device(ctx, (const uint8_t*) m->d_share, n_records, NULL, 0, rl, &m->share_pool));
+	lap(m, "load: pack");
 	VX(vdjx_read_index_build(ctx, m->share_pool, pair_id, read_num, is_rc, reg_rank, n_pairs));
+	lap(m, "load: read index of the share");
 done:
 	free(all_rows);
 	return rc;
@@ -152,6 +190,7 @@ static int kmer_build_any(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, in
 	if (!send_counts || !recv_counts || !q_out || !q_in || !eq || !meta) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; }
 	const size_t W0 = vdjx_shard_record_bytes(0), W1 = vdjx_shard_record_bytes(1), W2 = vdjx_shard_record_bytes(2), W3 = vdjx_shard_record_bytes(3);
 	HIPC(hipSetDevice(m->device));
+	lap_start(m);
 	if (d_scan) VX(vdjx_shard_begin_share(ctx, pool, k, mf, mq, me, G, d_scan, total_records, &sh));
 	else VX(vdjx_shard_begin(ctx, pool, k, mf, mq, me, G, rec_stride, &sh));
 	/* 0. the ranks agree on the bucket geometry: the largest number of gated instances any of them holds */
@@ -162,6 +201,7 @@ static int kmer_build_any(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, in
 		for (int r = 0; r < G; r++) if (meta[r] > most) most = meta[r];
 		VX(vdjx_shard_geometry(sh, most));
 	}
+	lap(m, "build: count + agree on the geometry");
 	/* 1. local aggregation; 2. the bulk exchange: per-bucket directories (their sums are the receive counts), then the partials */
 	uint32_t dl = 0;
 	VX(vdjx_shard_local(sh, send_counts, &dl));
@@ -170,6 +210,7 @@ static int kmer_build_any(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, in
 	WSG(WS_RDIR, ndir * 4 + 16, &d_rdir);
 	WSG(WS_SPARTS, sum64(send_counts, G) * W0 + 16, &d_sparts);
 	VX(vdjx_shard_local_fill(sh, d_sdir, d_sparts));
+	lap(m, "build: local aggregation");
 	for (int r = 0; r < G; r++) eq[r] = dl;
 	/* what every rank will send this one: the counts travel as control traffic beside the directories (no device round trip in between) */
 	CX(vdjx_comm_allgather_host(m->cm, send_counts, (size_t) G * 8, meta));
@@ -177,8 +218,10 @@ static int kmer_build_any(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, in
 	CX(vdjx_comm_a2av(m->cm, d_sdir, eq, d_rdir, eq, 4));
 	WSG(WS_RPARTS, sum64(recv_counts, G) * W0 + 16, &d_rparts);
 	CX(vdjx_comm_a2av(m->cm, d_sparts, send_counts, d_rparts, recv_counts, W0));
+	lap(m, "build: exchange of the partial aggregates");
 	/* 3. owners merge and decide; questions and answers for the few open k-mers */
 	VX(vdjx_shard_merge(sh, d_rdir, d_rparts, recv_counts, q_out));
+	lap(m, "build: owner merge");
 	CX(vdjx_comm_allgather_host(m->cm, q_out, (size_t) G * 8, meta));
 	for (int r = 0; r < G; r++) q_in[r] = meta[(size_t) r * G + me];
 	WSG(WS_Q, sum64(q_out, G) * W1 + 16, &d_q);
@@ -190,7 +233,9 @@ static int kmer_build_any(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, in
 	VX(vdjx_shard_reply(sh, d_rq, q_in, d_ans));
 	CX(vdjx_comm_a2av(m->cm, d_ans, q_in, d_rans, q_out, W2));
 	uint64_t ns = 0, ndist = 0;
+	lap(m, "build: questions and answers");
 	VX(vdjx_shard_resolve(sh, d_rans, sum64(q_out, G), &ns, &ndist));
+	lap(m, "build: resolve");
 	/* 4. survivors everywhere, every rank's share of add_to_graph, MIN / SUM over ranks */
 	{
 		uint64_t mine[2] = {ns, ndist};
@@ -202,13 +247,17 @@ static int kmer_build_any(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, in
 	WSG(WS_SURV_ALL, ns_total * W3 + 16, &d_surv_all);
 	VX(vdjx_shard_survivors(sh, d_surv));
 	CX(vdjx_comm_allgatherv(m->cm, d_surv, d_surv_all, recv_counts, W3));
+	lap(m, "build: gather of the survivors");
 	WSG(WS_MINS, ns_total * 5 * 8 + 16, &d_mins);          /* in-edge first sights [4n] | node first sights [n] */
 	WSG(WS_UCNT, ns_total * 4 + 16, &d_ucnt);
 	VX(vdjx_shard_edges(sh, d_surv_all, ns_total, d_mins, d_ucnt, (char*) d_mins + ns_total * 32));
+	lap(m, "build: graph pass over the share");
 	CX(vdjx_comm_allreduce_min_u64(m->cm, d_mins, (size_t) ns_total * 5));                         /* all-ones = none stays largest */
 	CX(vdjx_comm_allreduce_sum_u32(m->cm, d_ucnt, (size_t) ns_total));
+	lap(m, "build: reduction of first sights and counts");
 	/* 5. node numbering + list order: identical on every rank */
 	VX(vdjx_shard_finish(sh, d_mins, d_ucnt, (char*) d_mins + ns_total * 32, pre_total, out));
+	lap(m, "build: node numbering");
 done:
 	if (sh) vdjx_shard_free(sh);
 	free(h_rdir); free(send_counts); free(recv_counts); free(q_out); free(q_in); free(eq); free(meta);
@@ -239,7 +288,9 @@ static int do_window_score(vdjx_mgpu* m, vdjx_ctx* ctx, const char* windows, siz
 	if (!ent || !npairs || !all_ent || !send_ids || !counts || !send_counts || !recv_counts || !mine || !all_valid) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; }
 	if (!n) goto done;
 	HIPC(hipSetDevice(m->device));
+	lap_start(m);
 	VX(vdjx_window_pairs(ctx, windows, n, len, ent, npairs));
+	lap(m, "windows: pair lists against the share");
 	CX(vdjx_comm_allgather_host(m->cm, ent, n * 4, all_ent));
 	{
 		size_t at = 0;
@@ -256,8 +307,11 @@ static int do_window_score(vdjx_mgpu* m, vdjx_ctx* ctx, const char* windows, siz
 	WSG(WS_B, sum64(recv_counts, G) * 8 + 16, &d_recv);
 	VX(vdjx_window_pairs_fetch(ctx, send_ids, n, d_send));
 	CX(vdjx_comm_a2av(m->cm, d_send, send_counts, d_recv, recv_counts, 8));
+	lap(m, "windows: exchange of the pair lists");
 	if (n_mine) VX(vdjx_window_cover(ctx, n_mine, len, m->rl, p, d_recv, (size_t) G, counts, mine));
+	lap(m, "windows: coverage test of the own windows");
 	CX(vdjx_comm_allgather_host(m->cm, mine, nmax, all_valid));
+	lap(m, "windows: gather of the verdicts");
 	for (int o = 0; o < G; o++)
 		for (size_t w = (size_t) o, j = 0; w < n; w += (size_t) G, j++) out_valid[w] = all_valid[(size_t) o * nmax + j];
 done:
@@ -279,12 +333,14 @@ static int do_sam(vdjx_mgpu* m, vdjx_ctx* ctx, const char* contigs, size_t n, in
 	if (!offs || !cnt || !all_cnt || !meta || !send_rows || !recv_rows || !sub_off) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; }
 	if (!n) goto done;
 	HIPC(hipSetDevice(m->device));
+	lap_start(m);
 	/* pairs per contig over all ranks: the contigs are taken in runs of at most `budget` pairs, so that the text of one run (a few
 	 * hundred bytes per pair, on every rank and all of it on rank 0) stays a few GB whatever the pool */
 	VX(vdjx_map_emit(ctx, contigs, n, len, offs, NULL));
 	for (size_t i = 0; i < n; i++) cnt[i] = offs[i + 1] - offs[i];
 	CX(vdjx_comm_allgather_host(m->cm, cnt, n * 8, all_cnt));
 	for (size_t i = 0; i < n; i++) { uint64_t s = 0; for (int r = 0; r < G; r++) s += all_cnt[(size_t) r * n + i]; cnt[i] = s; }
+	lap(m, "sam: counting pass");
 	uint64_t budget = 8u << 20;
 	if (getenv("VDJX_MGPU_SAM_PAIRS") && atoll(getenv("VDJX_MGPU_SAM_PAIRS")) > 0) budget = (uint64_t) atoll(getenv("VDJX_MGPU_SAM_PAIRS"));
 	for (size_t a = 0; a < n;) {
@@ -296,6 +352,7 @@ static int do_sam(vdjx_mgpu* m, vdjx_ctx* ctx, const char* contigs, size_t n, in
 		const void *dk = NULL, *dl = NULL, *dt = NULL;
 		VX(vdjx_sam_blocks(ctx, contigs + a * (size_t) len, b - a, len, ids + id_off[a], sub_off, (const uint32_t*) m->d_reg, &nb, &nbytes, &dk, &dl, &dt));
 		uint64_t mine[2] = {nb, nbytes};
+		lap(m, "sam: records of the own pairs");
 		CX(vdjx_comm_allgather_host(m->cm, mine, 16, meta));
 		uint64_t NB = 0, NBY = 0;
 		for (int r = 0; r < G; r++) { NB += meta[2 * r]; NBY += meta[2 * r + 1]; }
@@ -314,11 +371,13 @@ static int do_sam(vdjx_mgpu* m, vdjx_ctx* ctx, const char* contigs, size_t n, in
 		send_rows[0] = nbytes;
 		if (me == 0) for (int r = 0; r < G; r++) recv_rows[r] = meta[2 * r + 1];
 		CX(vdjx_comm_a2av(m->cm, dt, send_rows, d_text, recv_rows, 1));
+		lap(m, "sam: blocks to rank 0");
 		if (me == 0 && NB) {
 			const char* text = NULL;
 			uint64_t tb = 0;
 			VX(vdjx_sam_merge(ctx, NB, NBY, d_keys, d_lens, d_text, &text, &tb));
 			if (sink && (rc = sink(ud, text, tb)) != 0) { rc = fail(rc, "the SAM sink failed"); goto done; }
+			lap(m, "sam: merge by key on rank 0");
 		}
 		a = b;
 	}
@@ -394,8 +453,10 @@ done:
 }
 
 int vdjx_mgpu_finish(vdjx_mgpu* m) {
+	if (m->rank == 0 && m->nranks == 1) vdjx_mgpu_print_times(m, stderr);
 	if (m->rank != 0 || m->nranks == 1) return 0;
 	const uint64_t cmd[4] = {CMD_QUIT, 0, 0, 0};
+	vdjx_mgpu_print_times(m, stderr);
 	const int rc = vdjx_comm_command_send(m->cm, cmd);
 	return rc ? fail(rc, "%s", vdjx_comm_last_error()) : 0;
 }

@@ -16,6 +16,7 @@
 #define VDJX_MGPU_H
 
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../../include/vdjx.h"
 #include "vdjx_comm.h"
@@ -31,6 +32,8 @@ int vdjx_mgpu_init(vdjx_comm* cm, int device, vdjx_mgpu** out);
 void vdjx_mgpu_free(vdjx_mgpu* m);
 const char* vdjx_mgpu_last_error(void);
 uint64_t vdjx_mgpu_bytes_sent(const vdjx_mgpu* m);
+/* VDJX_TIMES set: this rank's wall milliseconds and bytes sent per phase, one VDJX_MGPU_PHASE line each (rank 0 prints them in vdjx_mgpu_finish) */
+void vdjx_mgpu_print_times(const vdjx_mgpu* m, FILE* f);
 
 /* This rank's share of the pool, as the extraction wrote it (bam_read.c:206-244): records of 2*rl+1 bytes, its primary-pool records
  * followed by its secondary-pool ones, in extraction order; per record
