@@ -44,6 +44,16 @@ int vdjx_init(int device, vdjx_ctx** out);
 void vdjx_shutdown(vdjx_ctx* ctx);
 /* blocks until all work queued on the context's stream is done */
 int vdjx_sync(vdjx_ctx* ctx);
+/* gives the workspaces' device memory back (they hold the PEAK of the calls so far: tens of GB after a k-mer build of 10 M pairs) and with
+ * them the scorers' grow-only result buffers (pair lists of the last window batch, mapped pairs and SAM records of the last contigs); the
+ * next call maps again what it needs.  For a process that builds once and then serves scorer calls (a rank of `vdjer --gpus N`).  Not
+ * between the two calls of a two-call protocol (vdjx_map_emit count / write, vdjx_window_pairs / _fetch), not during a sharded build. */
+int vdjx_trim(vdjx_ctx* ctx);
+/* drops the context's read index and frees its arrays (kept from build to build otherwise); the scorers need a new index afterwards */
+int vdjx_read_index_drop(vdjx_ctx* ctx);
+/* `bytes` bytes from one device buffer to another (synchronous): for drivers that move library-owned device results (vdjx_sam_blocks)
+ * into exchange buffers of their own */
+int vdjx_device_copy(vdjx_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 
 /* ---- a-0: read pool -------------------------------------------------------------------------
  * replaces: the two NUL-terminated ASCII pools handed to assemble() (A2:1350-1358, 1545-1554),

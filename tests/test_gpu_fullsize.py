@@ -391,7 +391,10 @@ def test_config4_geometry_rehearsed_on_one_gpu(per, chains, check):
     except Exception:  # noqa: BLE001
         pass
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "config4_rehearsal.py"), str(per), "8", chains], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    # the full geometry also runs the rest of the path on the shares (round 5): read index per rank, the sharded window scorer over 20,000
+    # windows, the SAM records of 400 contigs formatted per rank and merged on rank 0 -- 8 ranks == 4 ranks of twice the size, every chain
+    mode = "score" if per == 12_500_000 else "build"
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "config4_rehearsal.py"), str(per), "8", chains, mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=3000)
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and lines, (r.stdout[-3000:], r.stderr[-3000:])
     if "skipped" in lines[0]:
@@ -400,6 +403,10 @@ def test_config4_geometry_rehearsed_on_one_gpu(per, chains, check):
     assert [l["chain"] for l in per_chain] == chains.split(",") and lines[-1].get("done")
     for l in per_chain:
         assert l["all_ranks_agree"] and l["instance_ids_pass_2_32"] and l["nodes"] > 1_000_000 and l["records"] == per * 32
-        assert min(l["bytes_exchanged_per_rank"]) > 1_000_000_000
-        print(json.dumps({k_: l[k_] for k_ in ("chain", "records", "nodes", "pre_nodes", "seconds", "phase_wall_ms_rank0", "bytes_exchanged_per_rank")}))
+        moved = [m["build"] if isinstance(m, dict) else m for m in l["bytes_exchanged_per_rank"]]
+        assert min(moved) > 1_000_000_000
+        if mode == "score":
+            assert l["scorers_equal_those_of_half_as_many_ranks"] is True and l["equals_the_build_by_4_ranks_of_twice_the_size"] is True
+            assert l["scorers"]["windows"] >= 20_000 and l["scorers"]["windows_valid"] > 0 and l["scorers"]["sam_lines"] > 10_000
+        print(json.dumps({k_: l[k_] for k_ in ("chain", "records", "nodes", "pre_nodes", "seconds", "phase_wall_ms_rank0", "bytes_exchanged_per_rank", "scorers") if k_ in l}))
     assert per_chain[-1][check] is True

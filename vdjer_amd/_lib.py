@@ -13,7 +13,7 @@ _lib = None
 
 # every symbol include/vdjx.h declares
 SYMBOLS = [
-    "vdjx_last_error", "vdjx_version", "vdjx_init", "vdjx_shutdown", "vdjx_sync",
+    "vdjx_last_error", "vdjx_version", "vdjx_init", "vdjx_shutdown", "vdjx_sync", "vdjx_trim", "vdjx_read_index_drop", "vdjx_device_copy",
     "vdjx_pool_load", "vdjx_pool_load_forward", "vdjx_pool_load_forward_begin", "vdjx_pool_wait", "vdjx_pool_load_device", "vdjx_pool_records", "vdjx_pool_free",
     "vdjx_anchor_sets_load", "vdjx_anchor_probe", "vdjx_index_generate", "vdjx_anchor_sets_from_anchors",
     "vdjx_kmer_build", "vdjx_graph_nodes", "vdjx_graph_pre_nodes", "vdjx_graph_export", "vdjx_graph_export_begin", "vdjx_graph_export_end", "vdjx_graph_free",
@@ -103,6 +103,11 @@ def lib():
     L.vdjx_map_emit_end.argtypes = [vp]
     L.vdjx_sam_names_load.argtypes = [vp, C.c_char_p, vp, u32]
     L.vdjx_sam_text.argtypes = [vp, C.c_char_p, sz, i32, C.c_char_p, vp, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
+    L.vdjx_sam_blocks.argtypes = [vp, C.c_char_p, sz, i32, C.c_char_p, vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.vdjx_sam_merge.argtypes = [vp, C.c_uint64, C.c_uint64, vp, vp, vp, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]
+    L.vdjx_trim.argtypes = [vp]
+    L.vdjx_read_index_drop.argtypes = [vp]
+    L.vdjx_device_copy.argtypes = [vp, vp, vp, C.c_size_t]
     L.vdjx_graph_roots.argtypes = [vp]
     L.vdjx_graph_roots.restype = C.c_size_t
     L.vdjx_root_part.argtypes = [vp, C.c_uint32, C.c_uint32]

@@ -170,6 +170,16 @@ class Context:
     def sync(self):
         check(self.L.vdjx_sync(self.h), "vdjx_sync")
 
+    def device_copy(self, d_dst: int, d_src: int, nbytes: int) -> None:
+        check(self.L.vdjx_device_copy(self.h, C.c_void_p(d_dst), C.c_void_p(d_src), nbytes), "vdjx_device_copy")
+
+    def read_index_drop(self):
+        check(self.L.vdjx_read_index_drop(self.h), "vdjx_read_index_drop")
+
+    def trim(self):
+        """hand the workspaces' device memory back (vdjx_trim): a context keeps the peak of its calls otherwise"""
+        check(self.L.vdjx_trim(self.h), "vdjx_trim")
+
     # ---- a-0
     def pool_load(self, primary: np.ndarray, secondary: np.ndarray, rl: int) -> Pool:
         pri = _c(primary, np.uint8).reshape(-1, 2 * rl + 1)
@@ -313,7 +323,10 @@ class Context:
         return out
 
     def root_score_graph(self, graph: Graph, threshold: int, first: int = 0, stride: int = 1):
-        """scores the roots of a device-resident graph (kmer_build(..., keep_device=True)): (1-based node ids, verdicts)"""
+        """scores the roots of a device-resident graph (kmer_build(..., keep_device=True)): (1-based node ids, verdicts).
+        On a context made with pinned_results=True the two arrays are views of ONE recycled page-locked buffer (like every pinned
+        result of this class): they are valid until the next root_score_graph call of the context -- a second call of the same size
+        returns the very same arrays with new contents.  Copy them (np.array(x)) to hold two results at once."""
         if graph.handle is None:
             raise VdjxError("root_score_graph: the graph was not kept on the device (keep_device=True)")
         n = int(self.L.vdjx_root_part(graph.handle, first, stride))
@@ -456,6 +469,38 @@ class Context:
         off = np.zeros(len(enc) + 1, np.uint64)
         off[1:] = np.cumsum([len(e) for e in enc])
         check(self.L.vdjx_sam_names_load(self.h, b"".join(enc), _p(off), len(enc)), "vdjx_sam_names_load")
+
+    def sam_names_load_raw(self, cat: np.ndarray, off: np.ndarray) -> None:
+        """the same from the names laid end to end (uint8) and their offsets (uint64 [n_pairs + 1]): no Python string per pair"""
+        cat = np.ascontiguousarray(cat, np.uint8)
+        off = np.ascontiguousarray(off, np.uint64)
+        check(self.L.vdjx_sam_names_load(self.h, C.cast(cat.ctypes.data, C.c_char_p), _p(off), off.shape[0] - 1), "vdjx_sam_names_load")
+
+    @staticmethod
+    def _ids(contig_ids, n):
+        enc = [s_.encode() for s_ in contig_ids]
+        off = np.zeros(n + 1, np.uint32)
+        off[1:] = np.cumsum([len(e) for e in enc])
+        return b"".join(enc), off
+
+    def sam_blocks(self, contigs, contig_ids, d_reg_rank: int):
+        """vdjx_sam_blocks: the SAM records of THIS context's pairs for these contigs (a pool sharded by pair), left on the device:
+        -> (blocks, bytes, d_keys, d_lens, d_text) -- device pointers owned by the context, valid until the next sam_blocks / sam_text.
+        d_reg_rank: device pointer, the GLOBAL registration rank of every record of the index's pool."""
+        raw, n, ln = contigs if isinstance(contigs, tuple) else self.pack_strings(contigs)
+        ids, off = self._ids(contig_ids, n)
+        nb, nby = C.c_uint64(), C.c_uint64()
+        dk, dl, dt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(self.L.vdjx_sam_blocks(self.h, raw, n, ln, ids, _p(off), C.c_void_p(d_reg_rank), C.byref(nb), C.byref(nby), C.byref(dk), C.byref(dl), C.byref(dt)),
+              "vdjx_sam_blocks")
+        return int(nb.value), int(nby.value), dk.value or 0, dl.value or 0, dt.value or 0
+
+    def sam_merge(self, n_blocks: int, n_bytes: int, d_keys: int, d_lens: int, d_text: int) -> bytes:
+        """vdjx_sam_merge: the blocks of all sources (source after source) laid out in ascending key order = the reference's order"""
+        txt, nb = C.c_char_p(), C.c_uint64()
+        check(self.L.vdjx_sam_merge(self.h, n_blocks, n_bytes, C.c_void_p(d_keys), C.c_void_p(d_lens), C.c_void_p(d_text), C.byref(txt), C.byref(nb)), "vdjx_sam_merge")
+        addr = C.cast(txt, C.c_void_p).value
+        return bytes((C.c_char * nb.value).from_address(addr)) if nb.value else b""
 
     def sam_text_device(self, contigs, contig_ids) -> bytes:
         """the SAM records of output_mapping (quick_map3.c:152-181) for these contigs, formatted on the device"""

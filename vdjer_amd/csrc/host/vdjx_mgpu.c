@@ -270,7 +270,13 @@ int vdjx_mgpu_kmer_build_pool(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool
 
 int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, int k, int mf, int mq, vdjx_graph** out) {
 	if (!m->share_pool) return fail(VDJX_ESTATE, "vdjx_mgpu_kmer_build: call vdjx_mgpu_load first");
-	return kmer_build_any(m, ctx, m->share_pool, k, mf, mq, 0, (const uint32_t*) m->d_scan, m->total_records, out);
+	const int rc = kmer_build_any(m, ctx, m->share_pool, k, mf, mq, 0, (const uint32_t*) m->d_scan, m->total_records, out);
+	/* a rank builds once and then serves scorer calls: what only the build needed goes back to the device -- its exchange buffers here,
+	 * the library's workspaces (the peak of the build: tens of GB per rank at configs[4]) through vdjx_trim */
+	(void) hipSetDevice(m->device);
+	for (int i = WS_SDIR; i <= WS_UCNT; i++) if (m->ws[i]) { (void) hipFree(m->ws[i]); m->ws[i] = NULL; m->ws_cap[i] = 0; }
+	if (rc == 0 && vdjx_trim(ctx) != 0) return fail(VDJX_EHIP, "rank %d: vdjx_trim: %s", m->rank, vdjx_last_error());
+	return rc;
 }
 
 /* ------------------------------------------------------------------------------------------------------------------ */

@@ -137,6 +137,67 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	delete c;
 }
 
+// Hands the workspaces' memory back to the device: the arenas hold the PEAK of the calls so far (tens of GB after a k-mer build),
+// which a process that builds once and then serves scorer calls -- a rank of `vdjer --gpus N` -- has no further use for.  The address
+// ranges stay reserved; a later call maps what it needs again (0.02 ms a piece).
+extern "C" int vdjx_trim(vdjx_ctx* c) {
+	if (!c) { vdjx_set_error("vdjx_trim: ctx is NULL"); return VDJX_EINVAL; }
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipStreamSynchronize(c->copy_stream));
+	if (c->pairs_stream) HIP_TRY(hipStreamSynchronize(c->pairs_stream));
+	c->arena.release(false);
+	if (!c->live_shard) c->shard_arena.release(false);
+	c->blocks.drop();
+	// the scorers' result buffers (grow-only between calls: the pair lists of the last window batch, the mapped pairs and the SAM
+	// records of the last contigs): results the caller has taken; the next call allocates what it needs
+	auto drop = [](void*& p, size_t& cap) { if (p) (void) hipFree(p); p = nullptr; cap = 0; };
+	drop(c->wp_buf, c->wp_cap);
+	c->wp_n = 0;
+	drop(c->me_pairs, c->me_cap);
+	if (c->me_hit) { (void) hipFree(c->me_hit); c->me_hit = nullptr; }
+	drop(c->me_dense, c->me_dense_cap);
+	c->me_gathered_cap = 0;
+	drop(c->me_book, c->me_book_cap);
+	if (c->d_sam_text) { (void) hipFree(c->d_sam_text); c->d_sam_text = nullptr; }
+	if (c->h_sam_text) { (void) hipHostFree(c->h_sam_text); c->h_sam_text = nullptr; }
+	c->sam_text_cap = 0;
+	if (c->d_sam_keys) { (void) hipFree(c->d_sam_keys); c->d_sam_keys = nullptr; }
+	if (c->d_sam_lens) { (void) hipFree(c->d_sam_lens); c->d_sam_lens = nullptr; }
+	c->sam_blk_cap = 0;
+	c->me_key = 0;          // (the cached counting call of vdjx_map_emit pointed into the workspace)
+	c->me_src = nullptr;
+	return VDJX_OK;
+}
+
+// The read index of the context is dropped and its arrays (kept from build to build otherwise: 2-5 GB at 10 M pairs) go back to the
+// device.  The scorers need a new vdjx_read_index_build afterwards.
+extern "C" int vdjx_read_index_drop(vdjx_ctx* c) {
+	if (!c) { vdjx_set_error("vdjx_read_index_drop: ctx is NULL"); return VDJX_EINVAL; }
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	free_dev(c->d_ri_tab); free_dev(c->d_ri_start); free_dev(c->d_ri_cnt1); free_dev(c->d_ri_dstart); free_dev(c->d_pair_r2);
+	free_dev(c->d_ri_recs); free_dev(c->d_ri_csr8); free_dev(c->d_ri_csr_pair); free_dev(c->d_ri_d8);
+	c->d_ri_tab = nullptr; c->d_ri_start = nullptr; c->d_ri_cnt1 = nullptr; c->d_ri_dstart = nullptr; c->d_pair_r2 = nullptr;
+	c->d_ri_recs = nullptr; c->d_ri_csr8 = nullptr; c->d_ri_csr_pair = nullptr; c->d_ri_d8 = nullptr;
+	for (auto& cap : c->ri_cap) cap = 0;
+	c->ri_pool = nullptr;
+	c->me_key = 0;
+	return VDJX_OK;
+}
+
+// bytes from one device buffer to another on the context's stream (test and bench drivers move library-owned results into buffers
+// of their own with it; the C host calls the runtime directly)
+extern "C" int vdjx_device_copy(vdjx_ctx* c, void* d_dst, const void* d_src, size_t bytes) {
+	if (!c) { vdjx_set_error("vdjx_device_copy: ctx is NULL"); return VDJX_EINVAL; }
+	if (!bytes) return VDJX_OK;
+	if (!d_dst || !d_src) { vdjx_set_error("vdjx_device_copy: NULL buffer"); return VDJX_EINVAL; }
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	return VDJX_OK;
+}
+
 static bool arena_trace() { static const bool t = getenv("VDJX_ARENA_TRACE") != nullptr; return t; }     // diagnostic: every growth of a workspace
 
 // back the range up to `upto` bytes: pieces of at most 4 GB (a single 38 GB allocation is what took seconds)

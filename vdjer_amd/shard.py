@@ -374,6 +374,38 @@ class ShardedHotPath:
             at += len(own[o])
         return valid, tot.cpu().numpy().astype(np.uint32)
 
+    def sam_body(self, ctx, contigs, contig_ids, d_reg_rank: int):
+        """output_mapping (quick_map3.c:152-181) over a pool sharded BY PAIR: every rank formats the SAM records of ITS pairs for these
+        contigs on its device (vdjx_sam_blocks: text, bytes per pair, a 64-bit key contig << 44 | read-1 position << 32 | global
+        registration rank), the blocks travel to rank 0 (three all-to-alls with one receiver) and vdjx_sam_merge lays them out in key
+        order = the order quick_map_process_contig walks its lists in.  -> the text on rank 0 (b"" elsewhere).  The driver of
+        vdjx_mgpu.c:do_sam in Python (one run: the caller bounds the contigs)."""
+        t, cm = self.torch, self.comm
+        G, r = self.world, self.rank
+        nb, nby, dk, dl, dt = ctx.sam_blocks(contigs, contig_ids, d_reg_rank)
+        keys = t.empty(max(nb, 1), dtype=t.int64, device=self.dev)
+        lens = t.empty(max(nb, 1), dtype=t.int32, device=self.dev)
+        text = t.empty(max(nby, 1), dtype=t.uint8, device=self.dev)
+        ctx.device_copy(keys.data_ptr(), dk, nb * 8)
+        ctx.device_copy(lens.data_ptr(), dl, nb * 4)
+        ctx.device_copy(text.data_ptr(), dt, nby)
+        if G == 1:
+            return ctx.sam_merge(nb, nby, keys.data_ptr(), lens.data_ptr(), text.data_ptr())
+        meta = cm.all_gather_cat(t.tensor([[nb, nby]], dtype=t.int64, device=self.dev)).cpu().numpy()
+        NB, NBY = int(meta[:, 0].sum()), int(meta[:, 1].sum())
+        to0 = lambda n_: [int(n_)] + [0] * (G - 1)            # noqa: E731
+        from0 = lambda col: [int(v) for v in meta[:, col]] if r == 0 else [0] * G      # noqa: E731
+        rk = t.empty(NB if r == 0 else 0, dtype=t.int64, device=self.dev)
+        rl_ = t.empty(NB if r == 0 else 0, dtype=t.int32, device=self.dev)
+        rt = t.empty(NBY if r == 0 else 0, dtype=t.uint8, device=self.dev)
+        cm.all_to_all_v(keys[:nb], to0(nb), rk, from0(0))
+        cm.all_to_all_v(lens[:nb], to0(nb), rl_, from0(0))
+        cm.all_to_all_v(text[:nby], to0(nby), rt, from0(1))
+        cm.sync()
+        if r != 0 or NB == 0:
+            return b""
+        return ctx.sam_merge(NB, NBY, rk.data_ptr(), rl_.data_ptr(), rt.data_ptr())
+
     def kmer_build(self, pool, k: int = 35, mf: int = 3, mq: int = 90, keep_device: bool = False, async_export: bool = False,
                    scan_index=None, total_records: int = 0):
         """scan_index / total_records: the pool is this rank's SHARE of the whole pool (by pair, any dealing that keeps the scan order),
