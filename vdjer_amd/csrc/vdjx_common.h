@@ -205,6 +205,8 @@ struct vdjx_pool {
 	int rl = 0;
 	int qstride = 0;
 	int W = 2, M = 1, ob = 6;    // words per read, words per mask, offset bits of an instance id
+	bool sym = false;            // every record 2i+1 is the reverse complement of record 2i with mirrored masks (checked by the packing, or made by it):
+	                             // phase A of the k-mer build then moves half the tuples (vdjx_kmer.hip, SYM)
 	char* d_block = nullptr;     // one device block holds the four arrays below
 	size_t block_cap = 0;
 	u64* d_bases = nullptr;      // [R][W]
@@ -420,6 +422,32 @@ __device__ inline u32 vdjx_bits_at_lane(u64 bhi, u64 blo, u32 pos) {
 	return (u32) ((x_lo >> s) | ((x_hi << 1) << (63u - s)));
 }
 __device__ inline u32 vdjx_base_at_lane(u64 bhi, u64 blo, int rl, int i) { return vdjx_bits_at_lane(bhi, blo, (u32) (2 * (rl - 1 - i))) & 3u; }
+
+// reverse complement of a packed k-mer (2k bits, right-aligned, first base most significant; A0 T1 C2 G3: the complement is bit 0
+// of every code): the 2-bit groups in reverse order, complemented.  k is uniform.
+__device__ inline void vdjx_kmer_rc(u64 hi, u64 lo, int k, u64& rhi, u64& rlo) {
+	u64 a = __brevll(lo), b = __brevll(hi);            // 128-bit bit reversal: (b:a) -> new (hi:lo) = (a:b)
+	a = ((a >> 1) & 0x5555555555555555ull) | ((a & 0x5555555555555555ull) << 1);      // the two bits of every group back in order
+	b = ((b >> 1) & 0x5555555555555555ull) | ((b & 0x5555555555555555ull) << 1);
+	const u32 s = 128u - 2u * (u32) k;                  // the reversed k-mer sits in the TOP 2k bits of (a:b): down by s (28 .. 126)
+	u64 h, l;
+	if (s >= 64u) { l = s == 64u ? a : a >> (s - 64u); h = 0; }
+	else { l = (b >> s) | (a << (64u - s)); h = a >> s; }
+	const u32 nb = 2u * (u32) k;
+	const u64 m_lo = nb >= 64u ? ~0ull : (1ull << nb) - 1ull, m_hi = nb > 64u ? (1ull << (nb - 64u)) - 1ull : 0ull;
+	rlo = l ^ (0x5555555555555555ull & m_lo);
+	rhi = h ^ (0x5555555555555555ull & m_hi);
+}
+
+// ---- pools whose odd records are the reverse complements of the records before them (what add_to_buffer writes, bam_read.c:206-244:
+// vdjx_pool::sym).  The gated instances of record 2i+1 mirror those of record 2i: k-mer X at offset o there is rc(X) at offset
+// rl-k-o here.  Of the two tuples the pair of instances would make, phase A of the k-mer build keeps the one whose key is the smaller
+// of X and rc(X) (k odd: they differ) -- half the tuples -- and restores the other side where the verdicts are made.
+// the mirror of an instance id (record << ob | offset): the same bases read from the other record of the couple
+__device__ inline u64 vdjx_inst_mirror(u64 inst, int ob, int rl, int k) {
+	const u64 om = (1ull << ob) - 1ull;
+	return (((inst >> ob) ^ 1ull) << ob) | ((u64) (rl - k) - (inst & om));
+}
 
 // Is the 2k-bit k-mer (hi:lo) equal to itself d bases further on, i.e. K[i] == K[i+d] for all i < k-d (0 < d < k)?  Two gated
 // instances of one k-mer at offsets d apart in reads with identical sequences force that period on the k-mer, so a k-mer WITHOUT it

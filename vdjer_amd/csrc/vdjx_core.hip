@@ -444,6 +444,32 @@ __device__ inline u64 sw_spread32(u32 v) {
 	return x;
 }
 
+// the reverse complement of a packed short read (rl <= 64): groups of two bits in reverse order, complemented (A0 <-> T1, C2 <-> G3: bit 0
+// of the code), not-ACGT bases at code 0; the masks reversed
+__device__ inline void pack_rc(u64 bhi, u64 blo, u64 nm, u64 gate, int rl, u64& rh, u64& rlo, u64& rnm, u64& rgate) {
+	rh = __brevll(blo); rlo = __brevll(bhi);
+	rh = ((rh >> 1) & 0x5555555555555555ull) | ((rh & 0x5555555555555555ull) << 1);
+	rlo = ((rlo >> 1) & 0x5555555555555555ull) | ((rlo & 0x5555555555555555ull) << 1);
+	const u32 s = 128u - 2u * (u32) rl;                       // 0 .. 126 (uniform)
+	if (s >= 64u) { rlo = rh >> (s - 64u); rh = 0; }
+	else if (s) { rlo = (rlo >> s) | (rh << (64u - s)); rh >>= s; }
+	const u32 nb = 2u * (u32) rl;
+	const u64 m_lo = nb >= 64u ? ~0ull : (1ull << nb) - 1ull, m_hi = nb > 64u ? (nb >= 128u ? ~0ull : (1ull << (nb - 64u)) - 1ull) : 0ull;
+	rlo ^= 0x5555555555555555ull & m_lo;
+	rh ^= 0x5555555555555555ull & m_hi;
+	if (nm) {                                                 // (rare) base i of this record sits at the bits 2(rl-1-i): N of the read at i' = rl-1-i
+		const u64 p_lo = sw_spread32((u32) nm), p_hi = sw_spread32((u32) (nm >> 32));
+		rlo &= ~(p_lo | (p_lo << 1));
+		rh &= ~(p_hi | (p_hi << 1));
+	}
+	rnm = __brevll(nm) >> (64u - (u32) rl);
+	rgate = __brevll(gate) >> (64u - (u32) rl);
+}
+__device__ inline u64 shfl_down1_u64(u64 v) {
+	const u32 lo = (u32) __shfl_down((int) (u32) v, 1), hi = (u32) __shfl_down((int) (u32) (v >> 32), 1);
+	return ((u64) hi << 32) | lo;
+}
+
 // FWD: `ascii` holds the reads as extracted only; packed records 2i (as is) and 2i+1 (the reverse complement add_to_buffer writes
 // after every read, bam_read.c:232-243: bases complemented in reverse order, qualities reversed) come out of read i, the second one
 // from the PACKED first one (bit reversal, no second pass over the characters)
@@ -469,6 +495,7 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 	const u32 QW = (u32) qstride / 4u, OS = QW + 1u;              // quality row in LDS: an odd stride keeps the banks apart
 	u32* orow = (u32*) lds + ((in_words + 3u) & ~3u);
 	__syncthreads();
+	u64 s_bhi = 0, s_blo = 0, s_nm = 0, s_gate = 0;          // (this thread's packed record, for the symmetry check behind the branch)
 	if (tid < nhere) {
 		const u32 start = tid * (u32) reclen;
 		if (lds[start] != '0') atomicAdd(bad_strand, 1u);   // A2:383-391; the reference only ever writes '0' (bam_read.c:219,231)
@@ -523,31 +550,30 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 			for (int v = 0; v < NWMAX / 4; v++) if (v < qstride / 16) qd[v] = make_uint4(qrow[4 * v], qrow[4 * v + 1], qrow[4 * v + 2], qrow[4 * v + 3]);
 		}
 		if (FWD) {
-			// the reverse complement from the packed read: groups of two bits in reverse order, complemented (A0 <-> T1, C2 <-> G3: bit 0 of
-			// the code), not-ACGT bases at code 0; the two masks reversed
-			u64 rh = __brevll(blo), rlo = __brevll(bhi);
-			rh = ((rh >> 1) & 0x5555555555555555ull) | ((rh & 0x5555555555555555ull) << 1);
-			rlo = ((rlo >> 1) & 0x5555555555555555ull) | ((rlo & 0x5555555555555555ull) << 1);
-			const u32 s = 128u - 2u * (u32) rl;                       // 0 .. 126 (uniform)
-			if (s >= 64u) { rlo = rh >> (s - 64u); rh = 0; }
-			else if (s) { rlo = (rlo >> s) | (rh << (64u - s)); rh >>= s; }
-			const u32 nb = 2u * (u32) rl;
-			const u64 m_lo = nb >= 64u ? ~0ull : (1ull << nb) - 1ull, m_hi = nb > 64u ? (nb >= 128u ? ~0ull : (1ull << (nb - 64u)) - 1ull) : 0ull;
-			rlo ^= 0x5555555555555555ull & m_lo;
-			rh ^= 0x5555555555555555ull & m_hi;
-			if (nm) {                                                 // (rare) base i of this record sits at the bits 2(rl-1-i): N of the read at i' = rl-1-i
-				const u64 p_lo = sw_spread32((u32) nm), p_hi = sw_spread32((u32) (nm >> 32));
-				rlo &= ~(p_lo | (p_lo << 1));
-				rh &= ~(p_hi | (p_hi << 1));
-			}
+			// the reverse complement from the packed read (pack_rc)
+			u64 rh, rlo, rnm, rgate;
+			pack_rc(bhi, blo, nm, lq | nm, rl, rh, rlo, rnm, rgate);
 			((ulonglong2*) bases)[g + 1] = make_ulonglong2(rh, rlo);
-			nmask[g + 1] = __brevll(nm) >> (64u - (u32) rl);
-			lowq[g + 1] = __brevll(lq | nm) >> (64u - (u32) rl);
+			nmask[g + 1] = rnm;
+			lowq[g + 1] = rgate;
 			oth *= 2u;
 		}
 		if (oth) atomicAdd(bad_strand + 1, oth);     // (rare: reported through vdjx_stat("pool_other_bases"))
+		s_bhi = bhi; s_blo = blo; s_nm = nm; s_gate = lq | nm;
 	}
-	if (!FWD) return;
+	if (!FWD) {
+		// is every odd record the reverse complement of the record before it, masks mirrored (vdjx_pool::sym: what add_to_buffer writes,
+		// bam_read.c:206-244)?  The even lane holds record 2i and takes record 2i+1's packed words from its neighbour.  bad_strand[2]
+		// counts the couples that are not (and the records without a partner).
+		u64 rh, rlo, rnm, rgate;
+		pack_rc(s_bhi, s_blo, s_nm, s_gate, rl, rh, rlo, rnm, rgate);
+		const u64 p_hi = shfl_down1_u64(s_bhi), p_lo = shfl_down1_u64(s_blo), p_nm = shfl_down1_u64(s_nm), p_gate = shfl_down1_u64(s_gate);
+		if (tid < nhere && !(tid & 1u)) {
+			const bool ok = ((rec0 + first) & 1) == 0 && tid + 1u < nhere && rh == p_hi && rlo == p_lo && rnm == p_nm && rgate == p_gate;
+			if (!ok) atomicAdd(bad_strand + 2, 1u);
+		}
+		return;
+	}
 	__syncthreads();
 	// ---- quality rows out: 16 bytes per lane, consecutive lanes on consecutive addresses
 	const u32 rows = FWD ? 2u * nhere : nhere;
@@ -692,7 +718,7 @@ static int pool_alloc(vdjx_ctx* c, hipStream_t pack_stream, size_t R, size_t n_p
 	// every stream of the device: a step's first call waited for the previous step's mapped pairs to finish their 4 ms trip over
 	// PCIe on the copy stream -- 1.3 ms per step at 10 M pairs, found in the HIP API trace as one 2.6 ms hipMemset every other step.)
 	{
-		const hipError_t em = hipMemsetAsync(*d_bad, 0, 8, pack_stream);
+		const hipError_t em = hipMemsetAsync(*d_bad, 0, 16, pack_stream);
 		if (em != hipSuccess) { vdjx_set_error("pool alloc: %s", hipGetErrorString(em)); vdjx_pool_free(p); return VDJX_EHIP; }
 	}
 	*out = p;
@@ -718,10 +744,12 @@ static void pack_launch(vdjx_ctx* c, hipStream_t st, vdjx_pool* p, const uint8_t
 	else hipLaunchKernelGGL((k_pool_pack<false, false>), grid, dim3(PACK_RECS), lds, st, d_ascii, n, p->rl, rec0, p->d_bases, p->d_nmask, p->d_lowq, q, p->qstride, d_bad);
 }
 
-static int pool_finish(vdjx_ctx* c, vdjx_pool* p, u32* d_bad, vdjx_pool** out) {
+static bool sym_wanted() { static const bool on = getenv("VDJX_NO_SYM") == nullptr; return on; }
+
+static int pool_finish(vdjx_ctx* c, vdjx_pool* p, u32* d_bad, vdjx_pool** out, bool fwd = false) {
 	u32* both = (u32*) c->h_pin;
-	both[0] = both[1] = 0;
-	hipError_t e = hipMemcpyAsync(both, d_bad, 8, hipMemcpyDeviceToHost, c->stream);
+	both[0] = both[1] = both[2] = 0;
+	hipError_t e = hipMemcpyAsync(both, d_bad, 12, hipMemcpyDeviceToHost, c->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e == hipSuccess) e = hipGetLastError();
 	if (e != hipSuccess) { vdjx_set_error("pool pack: %s", hipGetErrorString(e)); vdjx_pool_free(p); return VDJX_EHIP; }
@@ -729,6 +757,9 @@ static int pool_finish(vdjx_ctx* c, vdjx_pool* p, u32* d_bad, vdjx_pool** out) {
 	// IUPAC codes other than N are packed as N (the reference keeps them inside its k-mer strings and exits in seq_to_int,
 	// seq_to_kmer.c:22-24, as soon as one reaches a node): the count lets a caller see the deviation
 	c->stats["pool_other_bases"] = both[1];
+	// couples (record, its reverse complement): made by the forward load, verified by the packing otherwise (short reads)
+	p->sym = sym_wanted() && p->W == 2 && p->n_records % 2 == 0 && p->n_primary % 2 == 0 && (fwd || both[2] == 0);
+	c->stats["pool_symmetric"] = p->sym ? 1 : 0;
 	if (bad) {
 		// build_pre_graph prints "Initial char in input invalid" and exits (A2:383-391); we return an error
 		vdjx_set_error("pool: %u records do not start with the '0' strand byte", bad);
@@ -834,7 +865,7 @@ static int pool_load_host(vdjx_ctx* c, const uint8_t* primary, size_t n_primary,
 			used[turn] = true;
 		}
 	}
-	return pool_finish(c, p, d_bad, out);
+	return pool_finish(c, p, d_bad, out, fwd);
 }
 
 extern "C" int vdjx_pool_load(vdjx_ctx* c, const uint8_t* primary, size_t n_primary,
@@ -863,6 +894,8 @@ extern "C" int vdjx_pool_wait(vdjx_pool* p) {
 	p->pending_bad = nullptr;
 	const u32 bad = both[0];
 	p->ctx->stats["pool_other_bases"] = both[1];      // IUPAC codes packed as N (see pool_finish)
+	p->sym = sym_wanted() && p->W == 2 && p->n_records % 2 == 0 && p->n_primary % 2 == 0;      // (vdjx_pool_load_forward_begin: the couples are made by the packing)
+	p->ctx->stats["pool_symmetric"] = p->sym ? 1 : 0;
 	if (bad) { vdjx_set_error("pool: %u records do not start with the '0' strand byte", bad); return VDJX_EINVAL; }
 	return VDJX_OK;
 }

@@ -242,6 +242,7 @@ __device__ inline u64 vdjx_clean_offsets(u64 bad, int k, int P) {
 // The offset of a listed instance differs from lane to lane: the k-mer is cut out with vdjx_kmer_at_lane (vdjx_common.h: the plain
 // 128-bit shift by a per-lane amount gave wrong k-mers on gfx950 when the amounts of a wave lay on both sides of 64).
 #define GL_WAVE_BYTES 3072u         // per wave: 64 x 16-byte packed bases, 1024 x 2-byte entries (lane << 6 | offset)
+#define GL_WAVE_BYTES_SYM 4096u     // SYM: 64 x 2 x 16 bytes (a lane's record and its reverse-complement record), then the entries
 
 // long reads (W words per read, vdjx_pool): a lane's record in LDS is W + 2 words (two zero words behind it: the k-mer extraction
 // reads three words from the k-mer's first), entries are lane << 8 | offset
@@ -275,7 +276,22 @@ __device__ inline void stage_row_long(u64* row, const u64* __restrict__ bases, s
 }
 
 // K2a': bucket sizes over the gated instances (include_kmer, A2:240-259: no 'N', every Phred >= 20), listed densely per wave
-template <bool LONG>
+// the canonical side of a couple's instance (vdjx_pool::sym): k-mer X at offset o of record 2i is rc(X) at offset rl-k-o of record
+// 2i+1 -- which the pool holds packed, so rc(X) is cut out like X; the smaller of the two is the key (k odd: they differ)
+__device__ inline bool sym_canonical(const ulonglong2 f, const ulonglong2 r, int rl, int k, int o, u64& khi, u64& klo) {
+	u64 xh, xl, yh, yl;
+	vdjx_kmer_at_lane(f.x, f.y, rl, k, o, xh, xl);
+	vdjx_kmer_at_lane(r.x, r.y, rl, k, rl - k - o, yh, yl);
+	const bool flip = yh < xh || (yh == xh && yl < xl);
+	khi = flip ? yh : xh;
+	klo = flip ? yl : xl;
+	return flip;
+}
+
+// SYM (short reads, k odd, vdjx_pool::sym): a thread takes a COUPLE of records (2q, 2q+1; R counts couples) and lists the gated
+// offsets of the first; every listed instance stands for itself and its mirror in the second record, and is counted -- and later
+// moved -- once, under the smaller of the two k-mers
+template <bool LONG, bool SYM = false>
 __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                              const u64* __restrict__ lowq, size_t R, int rl, int k, u32 nb_bits,
                                                              size_t rpb, u32* __restrict__ bucket_cnt, u32 dbg_in) {
@@ -289,10 +305,11 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 	const u32 NB = 1u << nb_bits;
 	for (u32 i = threadIdx.x; i < NB; i += HIST_THREADS) hist[i] = 0;
 	__syncthreads();
-	uint8_t* wv = (uint8_t*) (hist + NB) + (threadIdx.x >> 6) * (LONG ? GL_WAVE_BYTES_LONG : GL_WAVE_BYTES);
+	static_assert(!(LONG && SYM), "SYM is the short-read form");
+	uint8_t* wv = (uint8_t*) (hist + NB) + (threadIdx.x >> 6) * (LONG ? GL_WAVE_BYTES_LONG : SYM ? GL_WAVE_BYTES_SYM : GL_WAVE_BYTES);
 	ulonglong2* wb = (ulonglong2*) wv;
 	u64* wrow = (u64*) wv;
-	uint16_t* wl = (uint16_t*) (wv + (LONG ? 64u * GL_ROW_LONG * 8u : 1024u));
+	uint16_t* wl = (uint16_t*) (wv + (LONG ? 64u * GL_ROW_LONG * 8u : SYM ? 2048u : 1024u));
 	const u32 lane = threadIdx.x & 63u;
 	const size_t r0 = (size_t) blockIdx.x * rpb;
 	const size_t r1 = r0 + rpb < R ? r0 + rpb : R;
@@ -303,7 +320,12 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 		vdjx_mask3 bad{~0ull, ~0ull, ~0ull};
 		if (r < r1) {
 			if (LONG) { bad = load_gate3(lowq, r); stage_row_long(wrow + lane * GL_ROW_LONG, bases, r); }
-			else {
+			else if (SYM) {
+				const GateView v = load_gate(bases, lowq, 2 * r);
+				G = vdjx_clean_offsets(v.bad, k, P);
+				wb[2 * lane] = make_ulonglong2(v.bhi, v.blo);
+				wb[2 * lane + 1] = ((const ulonglong2*) bases)[2 * r + 1];
+			} else {
 				const GateView v = load_gate(bases, lowq, r);
 				G = vdjx_clean_offsets(v.bad, k, P);
 				wb[lane] = make_ulonglong2(v.bhi, v.blo);
@@ -324,6 +346,7 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 				const u32 e = wl[i];
 				u64 khi, klo;
 				if (LONG) vdjx_kmer_at_words(wrow + (e >> 8) * GL_ROW_LONG, k, (int) (e & 255u), khi, klo);
+				else if (SYM) (void) sym_canonical(wb[2 * (e >> 6)], wb[2 * (e >> 6) + 1], rl, k, (int) (e & 63u), khi, klo);
 				else {
 					const ulonglong2 bb = wb[e >> 6];
 					vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) (e & 63u), khi, klo);
@@ -345,7 +368,7 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 // simply retried with half the records.  The gated instances of a round are listed once (dense, see above) as descriptors
 // {record in the round (16 bits), offset (6), bucket (10)}; the placement pass reads the descriptors, not the records' offsets.
 #define PARTR_STAGE_BYTES 98304u
-template <typename TUP, bool LONG>
+template <typename TUP, bool LONG, bool SYM = false>
 __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                                  const u64* __restrict__ lowq, size_t R, u64 rec_base, int rl, int k,
                                                                  u32 shift, u32 nbk, size_t rpb, u32 rr0, u32* __restrict__ gcur,
@@ -362,11 +385,12 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 	u32 rr = rr0 > rr_min ? rr0 : rr_min;
 	const u32 mask = nbk - 1;
 	const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-	uint8_t* wv = smem + wave * (LONG ? GL_WAVE_BYTES_LONG : GL_WAVE_BYTES);
+	static_assert(!(LONG && SYM), "SYM is the short-read form");
+	uint8_t* wv = smem + wave * (LONG ? GL_WAVE_BYTES_LONG : SYM ? GL_WAVE_BYTES_SYM : GL_WAVE_BYTES);
 	ulonglong2* wb = (ulonglong2*) wv;
 	u64* wrow = (u64*) wv;
-	uint16_t* wl = (uint16_t*) (wv + (LONG ? 64u * GL_ROW_LONG * 8u : 1024u));
-	const size_t r0 = (size_t) blockIdx.x * rpb;
+	uint16_t* wl = (uint16_t*) (wv + (LONG ? 64u * GL_ROW_LONG * 8u : SYM ? 2048u : 1024u));
+	const size_t r0 = (size_t) blockIdx.x * rpb;            // (SYM: R, rpb, rr and the descriptors count COUPLES of records)
 	const size_t r1 = r0 + rpb < R ? r0 + rpb : R;
 	size_t rs = r0;
 	while (rs < r1) {
@@ -380,7 +404,12 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 			vdjx_mask3 bad{~0ull, ~0ull, ~0ull};
 			if (r < re) {
 				if (LONG) { bad = load_gate3(lowq, r); stage_row_long(wrow + lane * GL_ROW_LONG, bases, r); }
-				else {
+				else if (SYM) {
+					const GateView v = load_gate(bases, lowq, 2 * r);
+					G = vdjx_clean_offsets(v.bad, k, P);
+					wb[2 * lane] = make_ulonglong2(v.bhi, v.blo);
+					wb[2 * lane + 1] = ((const ulonglong2*) bases)[2 * r + 1];
+				} else {
 					const GateView v = load_gate(bases, lowq, r);
 					G = vdjx_clean_offsets(v.bad, k, P);
 					wb[lane] = make_ulonglong2(v.bhi, v.blo);
@@ -403,6 +432,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 					const u32 e = wl[i];
 					u64 khi, klo;
 					if (LONG) vdjx_kmer_at_words(wrow + (e >> 8) * GL_ROW_LONG, k, (int) (e & 255u), khi, klo);
+					else if (SYM) (void) sym_canonical(wb[2 * (e >> 6)], wb[2 * (e >> 6) + 1], rl, k, (int) (e & 63u), khi, klo);
 					else {
 						const ulonglong2 bb = wb[e >> 6];
 						vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) (e & 63u), khi, klo);
@@ -432,12 +462,17 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 			const size_t r = rs + (d >> (OB + 10));
 			const u32 o = (d >> 10) & ((1u << OB) - 1u);
 			u64 khi, klo;
+			u64 inst = ((rec_base + (u64) r) << OB) | (u64) o;
 			if (LONG) vdjx_kmer_at_words(bases + r * VDJX_LONG_W, k, (int) o, khi, klo);      // (two words past the last record are readable: pool_alloc)
-			else {
+			else if (SYM) {
+				// the tuple of the canonical side: this instance, or its mirror in the couple's second record
+				const bool flip = sym_canonical(((const ulonglong2*) bases)[2 * r], ((const ulonglong2*) bases)[2 * r + 1], rl, k, (int) o, khi, klo);
+				inst = flip ? ((rec_base + 2 * (u64) r + 1) << OB) | (u64) (rl - k - (int) o) : ((rec_base + 2 * (u64) r) << OB) | (u64) o;
+			} else {
 				const ulonglong2 bb = ((const ulonglong2*) bases)[r];
 				vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) o, khi, klo);
 			}
-			TUP::store(&stage[atomicAdd(&cur[d & 1023u], 1u)], TUP::make(klo, khi, ((rec_base + (u64) r) << OB) | (u64) o));
+			TUP::store(&stage[atomicAdd(&cur[d & 1023u], 1u)], TUP::make(klo, khi, inst));
 		}
 		__syncthreads();
 		for (u32 i = threadIdx.x; i < n; i += PART_THREADS) {
@@ -555,6 +590,7 @@ __global__ __launch_bounds__(512) void k_seg_hist_g(const TUP* __restrict__ in, 
 #define ST_CAND 1u
 #define ST_MULTI 2u
 #define ST_QOK 4u
+#define ST_QOK_R 8u                 // SYM: the quality test of the reverse-complement k-mer
 #define ST_ID_SHIFT 8               // s_state: flags below, low-count row / survivor position above
 #define ST_NOID 0xFFFFFFu
 
@@ -630,7 +666,12 @@ __global__ __launch_bounds__(1024) void k_bucket_order(const u32* __restrict__ b
 	}
 }
 
-template <typename TUP>
+// SYM (vdjx_pool::sym, k odd): the tuples are the canonical half of the instances -- a k-mer C and, implied, its reverse complement R
+// with the mirrored instances (vdjx_inst_mirror).  One table entry stands for both: same count, same distinct-read verdict (two reads
+// differ iff their reverse complements do); the quality sums differ only through the first instance's quirk (A2:337-339), so the
+// low-count candidates are summed once per side; up to two survivors leave per entry.  (The first instance handed on for R is A
+// gated instance of R, the first one only for low counts: nothing reads it after the prune.)
+template <typename TUP, bool SYM = false>
 __global__ __launch_bounds__(RD_THREADS, sizeof(TUP) == 16 ? RD_WAVES : RD_WAVES / 2) void k_gated_reduce(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
                                                              const u64* __restrict__ bases, const u64* __restrict__ nmask,
                                                              vdjx_qrows quals, int rl, int ob, int k, u64 rec_base,
@@ -725,7 +766,7 @@ __global__ __launch_bounds__(RD_THREADS, sizeof(TUP) == 16 ? RD_WAVES : RD_WAVES
 			// ---- candidates (a k-mer seen once can never have two distinct reads, A2:349-352, 476)
 			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
 				if (s_khi[i] == EMPTY) continue;
-				atomicAdd(&s_ndist, 1u);
+				atomicAdd(&s_ndist, SYM ? 2u : 1u);
 				const u32 c = s_cnt[i];
 				if (c >= cmin) s_state[i] = (s_state[i] & ST_MULTI) | ST_CAND | ((c < tlow ? atomicAdd(&s_nlow, 1u) : ST_NOID) << ST_ID_SHIFT);
 			}
@@ -794,6 +835,27 @@ __global__ __launch_bounds__(RD_THREADS, sizeof(TUP) == 16 ? RD_WAVES : RD_WAVES
 					for (u32 i = 0; i < RD_MAXLOW; i++) sum += (u32) (uint8_t) (qv[i] - 33u);
 					const bool lowq = lane < (u32) k && sum < mqq;
 					if (!__ballot(lowq) && lane == 0) atomicOr(&s_state[slot], ST_QOK);
+					if (SYM) {
+						// the reverse-complement k-mer: the mirrored instances, the first of THEM with its record's first k qualities
+						u64 fr = NONE64;
+#pragma unroll
+						for (u32 i = 0; i < RD_MAXLOW; i++)
+							if (i < cnt && i < per_low) { const u64 m = vdjx_inst_mirror(low_inst[r * per_low + i], ob, rl, k); fr = m < fr ? m : fr; }
+#pragma unroll
+						for (u32 i = 0; i < RD_MAXLOW; i++) {
+							qv[i] = 33u;
+							if (i < cnt && i < per_low) {
+								const u64 inst = vdjx_inst_mirror(low_inst[r * per_low + i], ob, rl, k);
+								const uint8_t* q = quals.row((inst >> ob) - rec_base) + (inst == fr ? 0u : (u32) inst & om);
+								if (lane < (u32) k) qv[i] = q[lane];
+							}
+						}
+						u32 sum_r = 0;
+#pragma unroll
+						for (u32 i = 0; i < RD_MAXLOW; i++) sum_r += (u32) (uint8_t) (qv[i] - 33u);
+						const bool lowq_r = lane < (u32) k && sum_r < mqq;
+						if (!__ballot(lowq_r) && lane == 0) atomicOr(&s_state[slot], ST_QOK_R);
+					}
 				}
 				__syncthreads();
 			}
@@ -801,25 +863,40 @@ __global__ __launch_bounds__(RD_THREADS, sizeof(TUP) == 16 ? RD_WAVES : RD_WAVES
 			// ---- prune_pre_graph (A2:467-484); the global survivor counter is bumped once per workgroup and sub-pass
 			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
 				const u32 st = s_state[i];
-				bool keep = false;
+				bool keep = false, keep_r = false;
 				if (st & ST_CAND) {
 					const u32 craw = s_cnt[i];
 					const u32 c = craw > 32765u ? 32765u : craw;                  // A2:345-347
 					keep = c >= mf && (st & ST_MULTI) && (craw >= tlow || (st & ST_QOK));
+					if (SYM) keep_r = c >= mf && (st & ST_MULTI) && (craw >= tlow || (st & ST_QOK_R));
 				}
-				s_state[i] = keep ? atomicAdd(&s_nsurv, 1u) : NONE32;                  // (reused: position among this sub-pass's survivors)
+				// (reused: position among this sub-pass's survivors; SYM: << 2 | which of the two sides leave)
+				if (SYM) s_state[i] = (keep || keep_r) ? (atomicAdd(&s_nsurv, (u32) keep + (u32) keep_r) << 2) | (u32) keep | ((u32) keep_r << 1) : NONE32;
+				else s_state[i] = keep ? atomicAdd(&s_nsurv, 1u) : NONE32;
 			}
 			__syncthreads();
 			if (tid == 0) s_base = s_nsurv ? atomicAdd(so.n, s_nsurv) : 0;
 			__syncthreads();
 			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
 				if (s_state[i] == NONE32) continue;
-				const u32 pos = s_base + s_state[i];
-				if (pos < so.cap) {
+				u32 pos = s_base + (SYM ? s_state[i] >> 2 : s_state[i]);
+				const u32 cgo = s_cnt[i] > 32765u ? 32765u : s_cnt[i];
+				if ((!SYM || (s_state[i] & 1u)) && pos < so.cap) {
 					so.lo[pos] = s_klo[i];
 					so.hi[pos] = (u64) s_khi[i];
-					so.gcnt[pos] = s_cnt[i] > 32765u ? 32765u : s_cnt[i];
+					so.gcnt[pos] = cgo;
 					so.gfirst[pos] = s_first[i];
+				}
+				if (SYM && (s_state[i] & 2u)) {
+					pos += s_state[i] & 1u;
+					if (pos < so.cap) {
+						u64 rh, rlo;
+						vdjx_kmer_rc((u64) s_khi[i], s_klo[i], k, rh, rlo);
+						so.lo[pos] = rlo;
+						so.hi[pos] = rh;
+						so.gcnt[pos] = cgo;
+						so.gfirst[pos] = vdjx_inst_mirror(s_first[i], ob, rl, k);
+					}
 				}
 			}
 			__syncthreads();
@@ -852,7 +929,8 @@ __global__ __launch_bounds__(RD_THREADS, sizeof(TUP) == 16 ? RD_WAVES : RD_WAVES
 //   each rank keeps {count, first} over all its instances per k-mer and looks the survivors up once they are known;
 //   the caller reduces those two small arrays over ranks (SUM, MIN) together with the edge arrays.
 // ----------------------------------------------------------------------------------------------
-struct Partial { u64 lo, hi; u32 cg, pad; u64 fg; };     // 32 bytes, what travels: gated count (bit 31 = local distinct-read flag), first gated instance
+struct Partial { u64 lo, hi; u32 cg, h; u64 fg; };     // 32 bytes, what travels: gated count (bit 31 = local distinct-read flag), the key's table hash (rd_hash: the owner's merge
+                                                       // looks every partial up three times and need not hash it again), first gated instance
 #define PART_FLAG 0x80000000u
 #define CNT_CAP 32765u
 #define NEED_SEQ 1u
@@ -994,7 +1072,7 @@ __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated
 				p.lo = s_klo[i]; p.hi = (u64) s_khi[i];
 				p.fg = s_mg[i];
 				p.cg = (cg > CNT_CAP ? CNT_CAP : cg) | ((st & LG_FLAG) ? PART_FLAG : 0u);
-				p.pad = 0;
+				p.h = rd_hash(p.lo, p.hi);
 				const u32 gi = atomicAdd(&s_ng, 1u);
 				sparse_g[base + gi] = p;
 				sparse_ref[base + gi] = loff != LG_NOLIST ? base + loff : NONE32;
@@ -1093,7 +1171,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 				const u32 off = seg_off[(size_t) s * (NBo + 1) + b * MG], cnt = seg_off[(size_t) s * (NBo + 1) + (b + 1) * MG] - off;
 				for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
 					const Partial p = recv[off + i];
-					const u32 h = rd_hash(p.lo, p.hi);
+					const u32 h = p.h;
 					if (((h >> 12) & (S - 1)) != sp) continue;
 					const int slot = lds_insert<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, h);
 					if (slot < 0) { s_over = 1; continue; }
@@ -1168,7 +1246,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 				u32 mine = 0;
 				for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
 					const Partial p = recv[off + i];
-					const u32 h = rd_hash(p.lo, p.hi);
+					const u32 h = p.h;
 					if (((h >> 12) & (S - 1)) != sp) continue;
 					if (!((s_pend[(h & (MERGE_SLOTS - 1)) >> 5] >> (h & 31)) & 1u)) continue;       // (few k-mers have a question open: most partials stop here)
 					const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, h);
@@ -1181,7 +1259,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 				if (s_ns) {
 					for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
 						const Partial p = recv[off + i];
-						const u32 h = rd_hash(p.lo, p.hi);
+						const u32 h = p.h;
 						if (((h >> 12) & (S - 1)) != sp) continue;
 						if (!((s_pend[(h & (MERGE_SLOTS - 1)) >> 5] >> (h & 31)) & 1u)) continue;
 						const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, h);
@@ -2300,11 +2378,17 @@ static void dbg_sync(vdjx_ctx* c, const char* what) {
 // Phase A, partition: the gated instances of `pool` as tuples grouped by the top T bits of the k-mer hash (T chosen from their
 // number: ~4096 per bucket).  One host read (the tuple count) sizes everything that follows.
 // the histogram of the gated instances over the hash buckets, and their number (one host wait): what the cut below starts from
-struct GatedHist { u32 HB = 0, NBH = 0, N = 0; u32* hstart = nullptr; };
+struct GatedHist { u32 HB = 0, NBH = 0, N = 0; u32* hstart = nullptr; bool sym = false; };
+// sym: the pool's records come in couples (record, its reverse complement: vdjx_pool::sym) and k is odd: the kernels walk the couples
+// and move one tuple per pair of mirrored instances (k_gated_hist SYM)
+static bool build_sym(const vdjx_pool* pool, int k) {
+	static const bool on = getenv("VDJX_NO_SYM") == nullptr;
+	return on && pool->sym && pool->W == 2 && (k & 1) && pool->n_records % 2 == 0;
+}
 template <typename A>
-int stage_gated_hist(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, size_t per_bucket, u64 geometry_instances, GatedHist* gh) {
+int stage_gated_hist(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, size_t per_bucket, u64 geometry_instances, GatedHist* gh, bool sym = false) {
 	hipStream_t st = c->stream;
-	const size_t R = pool->n_records;
+	const size_t R = sym ? pool->n_records / 2 : pool->n_records;           // (sym: couples)
 	const int P = pool->rl - k + 1;
 	const u64 NI = geometry_instances ? geometry_instances : (u64) R * (u64) P;
 	static const size_t dflt = tune("VDJX_GATED_BUCKET", 3072);     // gated tuples per bucket: about a third are distinct k-mers (RD_SLOTS)
@@ -2312,7 +2396,7 @@ int stage_gated_hist(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, size_t pe
 	// histogram resolution: every bucket count the build could choose is a prefix of it (<= 2^15: 128 KB of LDS; 2^14 for long reads,
 	// whose waves stage 5.6 KB of records each beside the histogram: 2^15 asked for 173 KB and every build of more than ~1 M pairs of
 	// 2 x 100 bp failed -- the parity tests' pools were too small to get there; profiles/longreads.py now runs them at size)
-	const u32 hb_max = pool->W > 2 ? 14u : 15u;
+	const u32 hb_max = pool->W > 2 || sym ? 14u : 15u;                      // (sym: the waves stage two records per lane)
 	u32 HB = ceil_log2_u64((NI + per - 1) / per);
 	HB = std::max(8u, std::min(hb_max, HB));
 	const u32 NBH = 1u << HB;
@@ -2326,12 +2410,14 @@ int stage_gated_hist(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, size_t pe
 	HIP_TRY(db.alloc(&hstart, NBH + 1));
 	HIP_TRY(hipMemsetAsync(hcnt, 0, (size_t) NBH * 4, st));
 	const bool lng = pool->W > 2;
-	const size_t lds_hist = (size_t) NBH * 4 + (HIST_THREADS / 64) * (lng ? GL_WAVE_BYTES_LONG : GL_WAVE_BYTES);
+	const size_t lds_hist = (size_t) NBH * 4 + (HIST_THREADS / 64) * (lng ? GL_WAVE_BYTES_LONG : sym ? GL_WAVE_BYTES_SYM : GL_WAVE_BYTES);
 	HIP_TRY(hipFuncSetAttribute((const void*) k_gated_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_hist));
 	HIP_TRY(hipFuncSetAttribute((const void*) k_gated_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_hist));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_gated_hist<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_hist));
 	{
 		vdjx_prof_scope ps(c, "k_gated_hist");
 		if (lng) hipLaunchKernelGGL(k_gated_hist<true>, dim3(nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, pool->rl, k, HB, rpb, hcnt, hist_dbg);
+		else if (sym) hipLaunchKernelGGL((k_gated_hist<false, true>), dim3(nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, pool->rl, k, HB, rpb, hcnt, hist_dbg);
 		else hipLaunchKernelGGL(k_gated_hist<false>, dim3(nblk), dim3(HIST_THREADS), lds_hist, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, pool->rl, k, HB, rpb, hcnt, hist_dbg);
 	}
 	dbg_sync(c, "k_gated_hist");
@@ -2343,8 +2429,8 @@ int stage_gated_hist(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, size_t pe
 	if (hist_dbg) return VDJX_ESTATE;             // (a cut histogram sizes nothing: the build stops here, profiles/histdbg.py reads the kernel's time)
 #endif
 	const u32 N = *(const u32*) c->h_pin;
-	c->stats["gated_instances"] = N;                // k-mer instances that pass include_kmer (A2:240-259) in this pool
-	gh->HB = HB; gh->NBH = NBH; gh->N = N; gh->hstart = hstart;
+	c->stats["gated_instances"] = sym ? 2ull * N : N;      // k-mer instances that pass include_kmer (A2:240-259) in this pool (sym: a tuple stands for two)
+	gh->HB = HB; gh->NBH = NBH; gh->N = N; gh->hstart = hstart; gh->sym = sym;
 	return VDJX_OK;
 }
 
@@ -2354,11 +2440,12 @@ int stage_gated_hist(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, size_t pe
 template <typename TUP, typename A>
 int stage_gated_cut(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k, size_t per_bucket, u64 geometry_instances, const GatedHist& gh, GTuples<TUP>* out) {
 	hipStream_t st = c->stream;
-	const size_t R = pool->n_records;
+	const bool sym = gh.sym;
+	const size_t R = sym ? pool->n_records / 2 : pool->n_records;           // (sym: couples, stage_gated_hist)
 	const int P = pool->rl - k + 1;
 	static const size_t dflt = tune("VDJX_GATED_BUCKET", 3072);
 	const size_t per = per_bucket ? per_bucket : dflt;
-	const u32 hb_max = pool->W > 2 ? 14u : 15u;
+	const u32 hb_max = pool->W > 2 || sym ? 14u : 15u;
 	const bool lng = pool->W > 2;
 	const u32 HB = gh.HB, NBH = gh.NBH, N = gh.N;
 	u32* hstart = gh.hstart;
@@ -2383,6 +2470,7 @@ int stage_gated_cut(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int
 	constexpr u32 lds_partr = PARTR_STAGE_BYTES + stage_tuples * 4;
 	HIP_TRY(hipFuncSetAttribute((const void*) k_part_records_g<TUP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_partr));
 	HIP_TRY(hipFuncSetAttribute((const void*) k_part_records_g<TUP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_partr));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_part_records_g<TUP, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_partr));
 	HIP_TRY(hipFuncSetAttribute((const void*) k_part_tuples_g<TUP>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_LDS_BYTES));
 	// pass geometry: <= 1024 buckets in one pass; otherwise 256 coarse x the rest (large pools: 2^(Tt-10) coarse x 1024)
 	u32 cbits = Tt, fbits = 0;
@@ -2404,6 +2492,8 @@ int stage_gated_cut(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int
 		rr = std::max<u64>(PART_THREADS, std::min<u64>(rr / PART_THREADS * PART_THREADS, lng ? 1u << 14 : 1u << 16));      // (the descriptor's record field)
 		if (lng) hipLaunchKernelGGL((k_part_records_g<TUP, true>), dim3(nblk2), dim3(PART_THREADS), lds_partr, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, rec_base,
 		                            pool->rl, k, 64 - cbits, NBc, rpb, (u32) rr, gcur, l1);
+		else if (sym) hipLaunchKernelGGL((k_part_records_g<TUP, false, true>), dim3(nblk2), dim3(PART_THREADS), lds_partr, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, rec_base,
+		                                 pool->rl, k, 64 - cbits, NBc, rpb, (u32) rr, gcur, l1);
 		else hipLaunchKernelGGL((k_part_records_g<TUP, false>), dim3(nblk2), dim3(PART_THREADS), lds_partr, st, pool->d_bases, pool->d_nmask, pool->d_lowq, R, rec_base,
 		                        pool->rl, k, 64 - cbits, NBc, rpb, (u32) rr, gcur, l1);
 	}
@@ -2435,16 +2525,16 @@ int stage_gated_cut(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int
 }
 
 template <typename TUP, typename A>
-int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k, size_t per_bucket, u64 geometry_instances, GTuples<TUP>* out) {
+int stage_gated_partition(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k, size_t per_bucket, u64 geometry_instances, GTuples<TUP>* out, bool sym = false) {
 	GatedHist gh;
-	int rc = stage_gated_hist(c, db, pool, k, per_bucket, geometry_instances, &gh);
+	int rc = stage_gated_hist(c, db, pool, k, per_bucket, geometry_instances, &gh, sym);
 	if (rc) return rc;
 	return stage_gated_cut<TUP>(c, db, pool, rec_base, k, per_bucket, geometry_instances, gh, out);
 }
 
 // Phase A, table + prune per bucket
 template <typename TUP, typename A>
-int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView& pv, u64 rec_base, int k, int mf, int mq, SurvivorsG* sv) {
+int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView& pv, u64 rec_base, int k, int mf, int mq, SurvivorsG* sv, bool sym = false) {
 	hipStream_t st = c->stream;
 	{
 		static const u32 sub = (u32) tune("VDJX_SUB_TUPLES", 262144);
@@ -2455,7 +2545,7 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 	const u32 tlow = 1 + (mqq + 19) / 20;                           // see k_bucket_finalize
 	const u32 cmin = (u32) std::max(mf, 2);
 	const u32 mfu = (u32) std::max(mf, 0);
-	const u32 cap = t.N / 2 + 16;                                   // a survivor has at least two gated instances
+	const u32 cap = (sym ? t.N : t.N / 2) + 16;                     // a survivor has at least two gated instances (sym: two survivors per two tuples)
 	u32 *g_err, *n_surv;
 	u64* g_distinct;
 	HIP_TRY(db.alloc(&sv->lo, cap)); HIP_TRY(db.alloc(&sv->hi, cap)); HIP_TRY(db.alloc(&sv->gcnt, cap)); HIP_TRY(db.alloc(&sv->gfirst, cap));
@@ -2473,8 +2563,10 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 			HIP_TRY(db.alloc(&order, t.NB));
 			hipLaunchKernelGGL(k_bucket_order, dim3(1), dim3(1024), 0, st, t.bucket_start, t.NB, order);
 		}
-		hipLaunchKernelGGL(k_gated_reduce<TUP>, dim3(t.NB), dim3(RD_THREADS), 0, st, t.t, t.bucket_start, pv.bases, pv.nmask, pv.quals, pv.rl, pv.ob, k, rec_base,
-		                   mfu, cmin, mqq, tlow, so, g_distinct, g_err, rd_dbg, (const u32*) order);
+		if (sym) hipLaunchKernelGGL((k_gated_reduce<TUP, true>), dim3(t.NB), dim3(RD_THREADS), 0, st, t.t, t.bucket_start, pv.bases, pv.nmask, pv.quals, pv.rl, pv.ob, k, rec_base,
+		                            mfu, cmin, mqq, tlow, so, g_distinct, g_err, rd_dbg, (const u32*) order);
+		else hipLaunchKernelGGL(k_gated_reduce<TUP>, dim3(t.NB), dim3(RD_THREADS), 0, st, t.t, t.bucket_start, pv.bases, pv.nmask, pv.quals, pv.rl, pv.ob, k, rec_base,
+		                        mfu, cmin, mqq, tlow, so, g_distinct, g_err, rd_dbg, (const u32*) order);
 	}
 	u64* spread = (u64*) c->h_pin;                    // [64 * 16], then ns, err
 	u32* tail = (u32*) (spread + 64 * 16);
@@ -2889,11 +2981,13 @@ int kmer_build_impl2(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, 
 	const int P = pool->rl - k + 1;
 	vdjx_work db(c);
 	GTuples<TUP> t;
-	int rc = stage_gated_partition<TUP>(c, db, pool, 0, k, 0, 0, &t);
+	const bool sym = build_sym(pool, k);
+	c->stats["kmer_build_sym"] = sym ? 1 : 0;
+	int rc = stage_gated_partition<TUP>(c, db, pool, 0, k, 0, 0, &t, sym);
 	if (rc) return rc;
 	PoolView pv{pool->d_bases, pool->d_nmask, vdjx_qrows{pool->d_quals, pool->d_quals2, pool->q_split, pool->qstride}, pool->rl, pool->ob};
 	SurvivorsG sv;
-	rc = stage_gated_reduce<TUP>(c, db, t, pv, 0, k, mf, mq, &sv);
+	rc = stage_gated_reduce<TUP>(c, db, t, pv, 0, k, mf, mq, &sv, sym);
 	if (rc) return rc;
 	dbg_sync(c, "gated_reduce");
 	g->pre_nodes = (size_t) sv.ndist;
