@@ -284,7 +284,7 @@ int vdjx_profile_get(vdjx_ctx* ctx, int idx, const char** name, double* total_ms
  * frequency, first sights of nodes and edges, A2:261-320) is computed by every rank over its own records for
  * ALL survivors and reduced: SUM for the counts, MIN for the first sights.
  * All pointers are device pointers owned by the caller.  Call order (brackets = the caller's collectives):
- *   begin -> (count -> [all_reduce MAX] -> geometry ->) local -> local_fill -> [all_to_all: directories, counts, partial aggregates] -> merge
+ *   begin -> (count, symmetric -> [all_reduce MAX, MIN] -> geometry2 ->) local -> local_fill -> [all_to_all: directories, counts, partial aggregates] -> merge
  *   -> queries -> [all_to_all: counts, questions] -> reply -> [all_to_all: answers] -> resolve
  *   -> survivors -> [all_gather] -> edges -> [all_reduce MIN, SUM] -> finish -> free                */
 typedef struct vdjx_shard vdjx_shard;
@@ -305,6 +305,14 @@ size_t vdjx_shard_record_bytes(int kind);
  * Without it the bucket count follows a bound from rec_stride (more, smaller buckets: a partition level more at 10 M pairs per rank). */
 int vdjx_shard_count(vdjx_shard* s, uint64_t* gated_instances);
 int vdjx_shard_geometry(vdjx_shard* s, uint64_t agreed_instances);
+/* A pool as add_to_buffer writes it (bam_read.c:206-244) is made of couples: every read followed by its reverse complement with reversed
+ * qualities.  The gated k-mer instances of the second record mirror those of the first, so the local phase can move ONE tuple per pair
+ * of mirrored instances -- under the smaller of the k-mer and its reverse complement (k odd) -- and hand both aggregates to the same
+ * owner.  That changes which bucket a k-mer falls into, so ALL ranks must do it or none: vdjx_shard_symmetric says whether this rank
+ * could (its pool passed the packing's check, k is odd, reads of up to 64 bases); the caller ANDs the ranks' answers [all_reduce MIN]
+ * and passes the result to vdjx_shard_geometry2 beside the agreed instance count.  (vdjx_shard_geometry = all_symmetric 0.) */
+int vdjx_shard_symmetric(const vdjx_shard* s);
+int vdjx_shard_geometry2(vdjx_shard* s, uint64_t agreed_instances, int all_symmetric);
 /* this rank's partial aggregates, grouped by owner: send_counts[nranks]; *dir_len = hash buckets per owner */
 int vdjx_shard_local(vdjx_shard* s, uint64_t* send_counts, uint32_t* dir_len);
 /* d_dir: u32 [nranks*dir_len] partial aggregates per bucket (owner-major); d_partials: sum(send_counts) records, 16-byte aligned.

@@ -195,11 +195,15 @@ static int kmer_build_any(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, in
 	else VX(vdjx_shard_begin(ctx, pool, k, mf, mq, me, G, rec_stride, &sh));
 	/* 0. the ranks agree on the bucket geometry: the largest number of gated instances any of them holds */
 	{
-		uint64_t mine = 0, most = 0;
-		VX(vdjx_shard_count(sh, &mine));
-		CX(vdjx_comm_allgather_host(m->cm, &mine, 8, meta));
-		for (int r = 0; r < G; r++) if (meta[r] > most) most = meta[r];
-		VX(vdjx_shard_geometry(sh, most));
+		/* ... and on whether every rank's pool is made of couples (record, reverse complement): then all cut their buckets by the smaller of a
+		 * k-mer and its reverse complement and move half the tuples (vdjx_shard_symmetric) */
+		uint64_t mine[2] = {0, 0}, most = 0;
+		int all_sym = 1;
+		VX(vdjx_shard_count(sh, &mine[0]));
+		mine[1] = (uint64_t) vdjx_shard_symmetric(sh);
+		CX(vdjx_comm_allgather_host(m->cm, mine, 16, meta));
+		for (int r = 0; r < G; r++) { if (meta[2 * r] > most) most = meta[2 * r]; if (!meta[2 * r + 1]) all_sym = 0; }
+		VX(vdjx_shard_geometry2(sh, most, all_sym));
 	}
 	lap(m, "build: count + agree on the geometry");
 	/* 1. local aggregation; 2. the bulk exchange: per-bucket directories (their sums are the receive counts), then the partials */

@@ -242,7 +242,8 @@ __device__ inline u64 vdjx_clean_offsets(u64 bad, int k, int P) {
 // The offset of a listed instance differs from lane to lane: the k-mer is cut out with vdjx_kmer_at_lane (vdjx_common.h: the plain
 // 128-bit shift by a per-lane amount gave wrong k-mers on gfx950 when the amounts of a wave lay on both sides of 64).
 #define GL_WAVE_BYTES 3072u         // per wave: 64 x 16-byte packed bases, 1024 x 2-byte entries (lane << 6 | offset)
-#define GL_WAVE_BYTES_SYM 4096u     // SYM: 64 x 2 x 16 bytes (a lane's record and its reverse-complement record), then the entries
+#define GL_WAVE_BYTES_SYM 3072u     // SYM: 64 x 2 x 16 bytes (a lane's record and its reverse-complement record), then 512 entries: 8 offsets at a
+                                    // time instead of 16, so that the histogram keeps its 2^15 counters beside the eight waves' staging
 
 // long reads (W words per read, vdjx_pool): a lane's record in LDS is W + 2 words (two zero words behind it: the k-mer extraction
 // reads three words from the k-mer's first), entries are lane << 8 | offset
@@ -331,8 +332,9 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 				wb[lane] = make_ulonglong2(v.bhi, v.blo);
 			}
 		}
-		for (int ob = 0; ob < P; ob += 16) {
-			const u32 g = LONG ? vdjx_clean16(bad, ob, k, P) : (u32) (G >> ob) & 0xFFFFu;
+		constexpr int LSTEP = SYM ? 8 : 16;                                 // offsets listed per trip (the list's room: GL_WAVE_BYTES*)
+		for (int ob = 0; ob < P; ob += LSTEP) {
+			const u32 g = LONG ? vdjx_clean16(bad, ob, k, P) : (u32) (G >> ob) & (SYM ? 0xFFu : 0xFFFFu);
 			const u32 c = (u32) __popc(g);
 			const u32 incl = (u32) vdjx_wave_scan_add((int) c);
 			const u32 total = (u32) __builtin_amdgcn_readlane((int) incl, 63);
@@ -416,8 +418,9 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 				}
 			}
 			const u32 loc0 = (u32) (rb - rs) + wave * 64u;                // this wave's first record in the round
-			for (int ob = 0; ob < P; ob += 16) {
-				const u32 g = LONG ? vdjx_clean16(bad, ob, k, P) : (u32) (G >> ob) & 0xFFFFu;
+			constexpr int LSTEP = SYM ? 8 : 16;
+			for (int ob = 0; ob < P; ob += LSTEP) {
+				const u32 g = LONG ? vdjx_clean16(bad, ob, k, P) : (u32) (G >> ob) & (SYM ? 0xFFu : 0xFFFFu);
 				const u32 c = (u32) __popc(g);
 				const u32 incl = (u32) vdjx_wave_scan_add((int) c);
 				const u32 total = (u32) __builtin_amdgcn_readlane((int) incl, 63);
@@ -948,13 +951,19 @@ struct Partial { u64 lo, hi; u32 cg, h; u64 fg; };     // 32 bytes, what travels
 #define LG_UNR 4
 #define LG_FLAG 0x80000000u
 #define LG_NOLIST 0x7FFFFFFFu
-template <typename TUP>
+#define REF_MIRROR 0x80000000u       // sparse_ref / dense_ref: the listed instances are those of the reverse complement: mirror them (SYM)
+// SYM (see k_gated_reduce): the tuples are the canonical half; a table entry leaves as TWO partial aggregates, the k-mer's and its
+// reverse complement's (same count and flag, the mirrored first instance: exact where it can matter, i.e. below TLOW instances),
+// side by side in THIS bucket -- all ranks cut the buckets by the canonical k-mer, so both reach the same owner and the same
+// merge table, where they are two keys like any others.  A bucket of n tuples makes up to 2n aggregates: its region starts at 2 x base.
+template <typename TUP, bool SYM = false>
 __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated_local(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
                                                             const u64* __restrict__ bases, const u64* __restrict__ nmask, u64 rec_base, int k, int rl, int ob,
                                                             u32 tlow, Partial* __restrict__ sparse_g, u32* __restrict__ sparse_ref,
                                                             u32* __restrict__ nd_g, u64* __restrict__ low_inst, u32* __restrict__ g_err,
                                                             const u32* __restrict__ order) {
 	typedef typename TUP::hi_t THI;
+	const size_t obase = SYM ? 2 * (size_t) bucket_start[order ? order[blockIdx.x] : blockIdx.x] : (size_t) bucket_start[order ? order[blockIdx.x] : blockIdx.x];
 	__shared__ u64 s_klo[LOCAL_SLOTS];
 	__shared__ THI s_khi[LOCAL_SLOTS];
 	__shared__ u64 s_mg[LOCAL_SLOTS];
@@ -1073,9 +1082,22 @@ __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated
 				p.fg = s_mg[i];
 				p.cg = (cg > CNT_CAP ? CNT_CAP : cg) | ((st & LG_FLAG) ? PART_FLAG : 0u);
 				p.h = rd_hash(p.lo, p.hi);
-				const u32 gi = atomicAdd(&s_ng, 1u);
-				sparse_g[base + gi] = p;
-				sparse_ref[base + gi] = loff != LG_NOLIST ? base + loff : NONE32;
+				const u32 gi = atomicAdd(&s_ng, SYM ? 2u : 1u);
+				sparse_g[obase + gi] = p;
+				sparse_ref[obase + gi] = loff != LG_NOLIST ? base + loff : NONE32;
+				if (SYM) {
+					// the reverse complement's aggregate: the mirrored instances; its first one exactly where the owner may ask for it
+					u64 fr = vdjx_inst_mirror(p.fg, ob, rl, k);
+					if (loff != LG_NOLIST)
+						for (u32 j = 0; j < cg; j++) { const u64 m = vdjx_inst_mirror(low_inst[base + loff + j], ob, rl, k); fr = m < fr ? m : fr; }
+					Partial q;
+					vdjx_kmer_rc(p.hi, p.lo, k, q.hi, q.lo);
+					q.fg = fr;
+					q.cg = p.cg;
+					q.h = rd_hash(q.lo, q.hi);
+					sparse_g[obase + gi + 1] = q;
+					sparse_ref[obase + gi + 1] = loff != LG_NOLIST ? (base + loff) | REF_MIRROR : NONE32;
+				}
 			}
 			__syncthreads();
 		}
@@ -1091,9 +1113,9 @@ __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated
 __global__ __launch_bounds__(256) void k_compact_partials(const Partial* __restrict__ sparse, const u32* __restrict__ sparse_ref,
                                                           const u32* __restrict__ bucket_start, const u32* __restrict__ nd,
                                                           const u32* __restrict__ dstart, Partial* __restrict__ dense, u32* __restrict__ dense_ref,
-                                                          const u32* __restrict__ scan, int ob) {
+                                                          const u32* __restrict__ scan, int ob, u32 mul) {
 	const u32 b = blockIdx.x;
-	const u64* src = (const u64*) (sparse + bucket_start[b]);
+	const u64* src = (const u64*) (sparse + (size_t) mul * bucket_start[b]);        // (mul = 2: k_gated_local SYM)
 	u64* dst = (u64*) (dense + dstart[b]);
 	const u32 m = nd[b];
 	for (u32 i = threadIdx.x; i < m * 4; i += 256) {
@@ -1101,7 +1123,7 @@ __global__ __launch_bounds__(256) void k_compact_partials(const Partial* __restr
 		if (scan && (i & 3u) == 3u) v = ((u64) scan[v >> ob] << ob) | (v & ((1ull << ob) - 1ull));      // (share mode: the first instance leaves as a scan position)
 		dst[i] = v;
 	}
-	for (u32 i = threadIdx.x; i < m; i += 256) dense_ref[dstart[b] + i] = sparse_ref[bucket_start[b] + i];
+	for (u32 i = threadIdx.x; i < m; i += 256) dense_ref[dstart[b] + i] = sparse_ref[(size_t) mul * bucket_start[b] + i];
 }
 
 // seg_cnt[s*NBo + b] (what arrived) -> seg_off (absolute offsets into the receive buffer); src_base[s] = start of source s.
@@ -1323,11 +1345,13 @@ __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ qu
 	}
 	if ((int) lane >= k) return;
 	u32 acc = 0;
-	const u32 ref = dense_ref[di];
+	const u32 ref0 = dense_ref[di];
+	const bool mirror = ref0 != NONE32 && (ref0 & REF_MIRROR);       // (the aggregate of a reverse complement: k_gated_local SYM lists the other side's instances)
+	const u32 ref = ref0 == NONE32 ? NONE32 : ref0 & ~REF_MIRROR;
 	if ((need & NEED_Q) && ref != NONE32) {          // a question about the sums only comes for a count below TLOW: the list exists
 		const u32 cg = p.cg & ~PART_FLAG;
 		for (u32 i = 0; i < cg; i++) {
-			const u64 inst = low_inst[ref + i];
+			const u64 inst = mirror ? vdjx_inst_mirror(low_inst[ref + i], ob, rl, k) : low_inst[ref + i];
 			if (inst == (scan ? finst_local : finst)) continue;
 			const u64 rec = (inst >> ob) - rec_base;
 			const u32 off = (u32) inst & om;
@@ -2396,7 +2420,7 @@ int stage_gated_hist(vdjx_ctx* c, A& db, const vdjx_pool* pool, int k, size_t pe
 	// histogram resolution: every bucket count the build could choose is a prefix of it (<= 2^15: 128 KB of LDS; 2^14 for long reads,
 	// whose waves stage 5.6 KB of records each beside the histogram: 2^15 asked for 173 KB and every build of more than ~1 M pairs of
 	// 2 x 100 bp failed -- the parity tests' pools were too small to get there; profiles/longreads.py now runs them at size)
-	const u32 hb_max = pool->W > 2 || sym ? 14u : 15u;                      // (sym: the waves stage two records per lane)
+	const u32 hb_max = pool->W > 2 ? 14u : 15u;
 	u32 HB = ceil_log2_u64((NI + per - 1) / per);
 	HB = std::max(8u, std::min(hb_max, HB));
 	const u32 NBH = 1u << HB;
@@ -2445,7 +2469,7 @@ int stage_gated_cut(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int
 	const int P = pool->rl - k + 1;
 	static const size_t dflt = tune("VDJX_GATED_BUCKET", 3072);
 	const size_t per = per_bucket ? per_bucket : dflt;
-	const u32 hb_max = pool->W > 2 || sym ? 14u : 15u;
+	const u32 hb_max = pool->W > 2 ? 14u : 15u;
 	const bool lng = pool->W > 2;
 	const u32 HB = gh.HB, NBH = gh.NBH, N = gh.N;
 	u32* hstart = gh.hstart;
@@ -2459,9 +2483,10 @@ int stage_gated_cut(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int
 	// (beyond the histogram's 2^15 buckets the tuples of a bucket are cut again, BEFORE a bucket's distinct k-mers -- a third of its
 	// tuples -- come near the 2,048 slots of the reduce kernel's table: at 6,100 tuples per bucket (20 M pairs) every bucket overflowed
 	// its table after probing it to the brim, 52 ms instead of 3)
-	if (T == HB && HB == hb_max && Ng / NBH > (per_bucket ? per_bucket : refine)) {
+	const size_t refine_at = per_bucket ? std::max<size_t>(per_bucket, refine / 2) : refine;
+	if (T == HB && HB == hb_max && Ng / NBH > refine_at) {
 		extra = 1;
-		while (extra < 5 && (Ng >> extra) / NBH > (per_bucket ? per_bucket : refine)) extra++;
+		while (extra < 5 && (Ng >> extra) / NBH > refine_at) extra++;
 	}
 	const u32 Tt = T + extra;
 	const u32 NBt = 1u << Tt;
@@ -3050,6 +3075,10 @@ struct vdjx_shard {
 	u64 total_records = 0;
 	u64 rec_base() const { return scan ? 0 : rec_stride * (u64) rank; }
 	u64 records_in_all() const { return scan ? total_records : rec_stride * (u64) nranks; }
+	// this rank's records are couples (record, its reverse complement) and k is odd: the local phase can move one tuple per pair of
+	// mirrored instances (k_gated_local SYM) -- IF every rank does (the buckets are then cut by the canonical k-mer): the ranks tell each
+	// other (vdjx_shard_symmetric) and the caller passes the verdict on (vdjx_shard_geometry2)
+	bool sym_capable = false, sym = false;
 	bool wide = false;                              // Tup24 (k > 45)
 	// local phase: this rank's gated tuples by bucket, its partial aggregates (dense, bucket order)
 	u32 NBf = 0, NBo = 0;
@@ -3103,6 +3132,7 @@ static int shard_begin_impl(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, i
 	s->c = c; s->pool = pool; s->k = k; s->mf = mf; s->mq = mq; s->rank = rank; s->nranks = nranks;
 	s->rec_stride = rec_stride;
 	s->scan = d_scan; s->total_records = total_records;
+	s->sym_capable = build_sym(pool, k) && s->rec_base() % 2 == 0;
 	s->wide = k > 45;
 	if (mq >= 255) mq = 254;                                        // A2:1514-1516
 	s->mqq = (u32) (mq < 0 ? 0 : (mq > 214 ? 214 : mq));
@@ -3156,7 +3186,10 @@ static int shard_local_impl(vdjx_shard* s) {
 	const u64 rec_base = s->rec_base();
 	GTuples<TUP> t;
 	int rc = VDJX_OK;
-	if (!s->have_hist) rc = stage_gated_hist(c, db, s->pool, s->k, 0, shard_geometry_bound(s), &s->gh);
+	if (s->have_hist && s->gh.sym != s->sym) s->have_hist = false;          // (counted before the ranks had compared their pools: once more, the other way)
+	// (SYM: a table entry leaves as two aggregates, so the owner's merge table sees twice what the local one held: buckets of half the tuples)
+	const size_t per_b = s->sym ? tune("VDJX_GATED_BUCKET", 3072) / 2 : 0;
+	if (!s->have_hist) rc = stage_gated_hist(c, db, s->pool, s->k, per_b, shard_geometry_bound(s) / (s->sym ? 2 : 1), &s->gh, s->sym);
 	if (rc) return rc;
 	s->have_hist = true;
 	// (the ranks' largest count if they compared them, vdjx_shard_count + vdjx_shard_geometry: buckets of the size the one-GPU build
@@ -3168,15 +3201,15 @@ static int shard_local_impl(vdjx_shard* s) {
 	Partial* sparse;
 	u32 *g_err, *sparse_ref;
 	HIP_TRY(db.alloc(&s->low_inst, cap));
-	HIP_TRY(db.alloc(&s->dense_ref, cap));
+	HIP_TRY(db.alloc(&s->dense_ref, (s->sym ? 2 : 1) * cap));
 	HIP_TRY(db.alloc(&s->nd, nb_max));
 	HIP_TRY(db.alloc(&s->dstart, nb_max + 1));
 	HIP_TRY(db.alloc(&g_err, 1));
 	s->fill_mark = db.mark();
-	HIP_TRY(db.alloc(&sparse, cap));
-	HIP_TRY(db.alloc(&sparse_ref, cap));
+	HIP_TRY(db.alloc(&sparse, (s->sym ? 2 : 1) * cap));              // (SYM: two aggregates per table entry)
+	HIP_TRY(db.alloc(&sparse_ref, (s->sym ? 2 : 1) * cap));
 	const vdjx_arena::mark_t tuple_mark = db.mark();
-	rc = stage_gated_cut<TUP>(c, db, s->pool, rec_base, s->k, 0, s->agreed ? s->agreed : shard_geometry_bound(s), s->gh, &t);
+	rc = stage_gated_cut<TUP>(c, db, s->pool, rec_base, s->k, per_b, (s->agreed ? s->agreed : shard_geometry_bound(s)) / (s->sym ? 2 : 1), s->gh, &t);
 	if (rc) return rc;
 	if (t.NB < (u32) s->nranks) { vdjx_set_error("vdjx_shard_local: fewer buckets (%u) than ranks", t.NB); return VDJX_ELIMIT; }
 	// buckets per owner; the directory every rank sends has nranks * NBo entries (the ones past the last bucket are empty)
@@ -3198,8 +3231,10 @@ static int shard_local_impl(vdjx_shard* s) {
 			HIP_TRY(db.alloc(&order, t.NB));
 			hipLaunchKernelGGL(k_bucket_order, dim3(1), dim3(1024), 0, st, t.bucket_start, t.NB, order);
 		}
-		hipLaunchKernelGGL(k_gated_local<TUP>, dim3(t.NB), dim3(LG_THREADS), 0, st, t.t, t.bucket_start, s->pool->d_bases, s->pool->d_nmask, rec_base,
-		                   s->k, s->pool->rl, s->pool->ob, s->tlow, sparse, sparse_ref, s->nd, s->low_inst, g_err, (const u32*) order);
+		if (s->sym) hipLaunchKernelGGL((k_gated_local<TUP, true>), dim3(t.NB), dim3(LG_THREADS), 0, st, t.t, t.bucket_start, s->pool->d_bases, s->pool->d_nmask, rec_base,
+		                               s->k, s->pool->rl, s->pool->ob, s->tlow, sparse, sparse_ref, s->nd, s->low_inst, g_err, (const u32*) order);
+		else hipLaunchKernelGGL(k_gated_local<TUP>, dim3(t.NB), dim3(LG_THREADS), 0, st, t.t, t.bucket_start, s->pool->d_bases, s->pool->d_nmask, rec_base,
+		                        s->k, s->pool->rl, s->pool->ob, s->tlow, sparse, sparse_ref, s->nd, s->low_inst, g_err, (const u32*) order);
 	}
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, s->nd, s->NBf, s->dstart);
 	u32* d_pick;
@@ -3259,7 +3294,7 @@ extern "C" int vdjx_shard_local_fill(vdjx_shard* s, void* d_dir, void* d_partial
 		// the aggregates of every bucket end to end, in the caller's buffer -- which from here on IS this rank's list of them: the
 		// answers to the owners' questions are looked up in it (vdjx_shard_reply)
 		vdjx_prof_scope ps(s->c, "k_compact_partials");
-		hipLaunchKernelGGL(k_compact_partials, dim3(s->NBt), dim3(256), 0, st, s->sparse, s->sparse_ref, s->tuple_bucket_start, s->nd, s->dstart, (Partial*) d_partials, s->dense_ref, s->scan, s->pool->ob);
+		hipLaunchKernelGGL(k_compact_partials, dim3(s->NBt), dim3(256), 0, st, s->sparse, s->sparse_ref, s->tuple_bucket_start, s->nd, s->dstart, (Partial*) d_partials, s->dense_ref, s->scan, s->pool->ob, s->sym ? 2u : 1u);
 	}
 	s->dense = (Partial*) d_partials;
 	HIP_TRY(hipStreamSynchronize(st));
@@ -3280,18 +3315,31 @@ extern "C" int vdjx_shard_count(vdjx_shard* s, uint64_t* gated_instances) {
 	HIP_TRY(hipSetDevice(s->c->device));
 	vdjx_clear_errors();
 	if (!s->have_hist) {
+		// (counted the way this rank would like to build: over couples if its pool is made of them; vdjx_shard_geometry2 has the last word)
 		PersistAlloc db(s->c);
-		const int rc = stage_gated_hist(s->c, db, s->pool, s->k, 0, shard_geometry_bound(s), &s->gh);
+		const int rc = stage_gated_hist(s->c, db, s->pool, s->k, s->sym_capable ? tune("VDJX_GATED_BUCKET", 3072) / 2 : 0, shard_geometry_bound(s) / (s->sym_capable ? 2 : 1), &s->gh, s->sym_capable);
 		if (rc) return rc;
 		s->have_hist = true;
 	}
-	*gated_instances = s->gh.N;
+	*gated_instances = (u64) s->gh.N * (s->gh.sym ? 2 : 1);
+	return VDJX_OK;
+}
+// 1: this rank's pool is made of couples (record, its reverse complement) and k is odd -- its local phase could move half the tuples.
+// Only if ALL ranks can (the buckets are then cut by the smaller of a k-mer and its reverse complement): the caller ANDs the ranks'
+// answers and hands the result to vdjx_shard_geometry2.
+extern "C" int vdjx_shard_symmetric(const vdjx_shard* s) { return s && s->sym_capable ? 1 : 0; }
+extern "C" int vdjx_shard_geometry2(vdjx_shard* s, uint64_t agreed_instances, int all_symmetric) {
+	if (!s) { vdjx_set_error("vdjx_shard_geometry2: NULL argument"); return VDJX_EINVAL; }
+	if (all_symmetric && !s->sym_capable) { vdjx_set_error("vdjx_shard_geometry2: this rank's pool is not made of couples"); return VDJX_EINVAL; }
+	const int rc = vdjx_shard_geometry(s, agreed_instances);
+	if (rc) return rc;
+	s->sym = all_symmetric != 0;
 	return VDJX_OK;
 }
 extern "C" int vdjx_shard_geometry(vdjx_shard* s, uint64_t agreed_instances) {
 	if (!s) { vdjx_set_error("vdjx_shard_geometry: NULL argument"); return VDJX_EINVAL; }
 	if (s->phase != 0) { vdjx_set_error("vdjx_shard_geometry: call it before vdjx_shard_local"); return VDJX_ESTATE; }
-	if (agreed_instances < s->gh.N) { vdjx_set_error("vdjx_shard_geometry: %llu is less than this rank's own %u gated instances", (unsigned long long) agreed_instances, s->gh.N); return VDJX_EINVAL; }
+	if (agreed_instances < (u64) s->gh.N * (s->gh.sym ? 2 : 1)) { vdjx_set_error("vdjx_shard_geometry: %llu is less than this rank's own %llu gated instances", (unsigned long long) agreed_instances, (unsigned long long) s->gh.N * (s->gh.sym ? 2 : 1)); return VDJX_EINVAL; }
 	s->agreed = agreed_instances ? agreed_instances : 1;
 	return VDJX_OK;
 }

@@ -45,6 +45,8 @@ def _bind(L):
     L.vdjx_shard_record_bytes.restype = C.c_size_t
     L.vdjx_shard_count.argtypes = [vp, u64p]
     L.vdjx_shard_geometry.argtypes = [vp, C.c_uint64]
+    L.vdjx_shard_symmetric.argtypes = [vp]
+    L.vdjx_shard_geometry2.argtypes = [vp, C.c_uint64, C.c_int]
     L.vdjx_shard_local.argtypes = [vp, u64p, C.POINTER(C.c_uint32)]
     L.vdjx_shard_local_fill.argtypes = [vp, vp, vp]
     L.vdjx_shard_merge.argtypes = [vp, vp, vp, u64p, u64p]
@@ -96,8 +98,12 @@ class HipShardEngine:
         check(self.L.vdjx_shard_count(self.h, C.byref(n)), "vdjx_shard_count")
         return int(n.value)
 
-    def geometry(self, agreed: int) -> None:
-        check(self.L.vdjx_shard_geometry(self.h, int(agreed)), "vdjx_shard_geometry")
+    def symmetric(self) -> int:
+        """1: this rank's pool is made of couples (record, its reverse complement) and k is odd: its local phase could move half the tuples"""
+        return int(self.L.vdjx_shard_symmetric(self.h))
+
+    def geometry(self, agreed: int, all_symmetric: int = 0) -> None:
+        check(self.L.vdjx_shard_geometry2(self.h, int(agreed), int(all_symmetric)), "vdjx_shard_geometry2")
 
     def local(self):
         """-> (partials per owner [G], directory int32 [G*dir_len], partial aggregates [n, 32] uint8; the engine keeps reading the
@@ -447,10 +453,16 @@ class ShardedHotPath:
 
             # 0. the ranks agree on the bucket geometry: the largest number of gated instances any of them holds
             if hasattr(eng, "count") and not os.environ.get("VDJX_SHARD_NO_AGREE"):      # (the variable: the stride's bound instead, for comparison)
-                nmax = t.tensor([eng.count()], dtype=t.int64, device=self.dev)
+                # (one reduction for both: the largest count, and -- as the largest of the negated flags -- whether EVERY rank's pool is made
+                # of couples, in which case all cut their buckets by the smaller of a k-mer and its reverse complement)
+                sym = eng.symmetric() if hasattr(eng, "symmetric") else 0
+                nmax = t.tensor([eng.count(), 1 - sym], dtype=t.int64, device=self.dev)
                 if G > 1:
                     cm.all_reduce(nmax, dist.ReduceOp.MAX)
-                eng.geometry(int(nmax.item()))
+                if hasattr(eng, "symmetric"):
+                    eng.geometry(int(nmax[0].item()), 1 - int(nmax[1].item()))
+                else:
+                    eng.geometry(int(nmax[0].item()))
                 lap("count")
             # 1. local aggregation; 2. the bulk exchange: per-bucket directory (its sums are the receive counts), then the
             #    partial aggregates themselves
