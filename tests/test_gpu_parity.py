@@ -66,6 +66,9 @@ def test_kmer_build_vs_reference_dump(ctx, case, tag):
     # the goldens' pools are couples (record, reverse complement) as add_to_buffer writes them (bam_read.c:206-244) and k is odd: the build
     # took the form that moves one tuple per pair of mirrored instances (vdjx_pool::sym)
     assert ctx.stat("pool_symmetric") == 1 and ctx.stat("kmer_build_sym") == (p["k"] & 1)
+    # ... and phase B walked the couples' first records only, the survivor set closed under reverse complement and the chains mirror
+    # images of each other (k_walk_items SYM); the fallback -- every record -- was not needed
+    assert ctx.stat("kmer_build_sym_walk") == (p["k"] & 1) and ctx.stat("kmer_build_sym_walk_retries") == 0
     assert hg.pre_nodes == info["pre"]
     nodes = G.rows(f"{tag}.nodes.tsv.gz")
     assert hg.n == len(nodes) == info["nodes"]

@@ -597,7 +597,13 @@ __global__ __launch_bounds__(512) void k_seg_hist_g(const TUP* __restrict__ in, 
 #define ST_ID_SHIFT 8               // s_state: flags below, low-count row / survivor position above
 #define ST_NOID 0xFFFFFFu
 
-struct SurvOutG { u64* lo; u64* hi; u32* gcnt; u64* gfirst; u32* n; u32 cap; };
+struct SurvOutG { u64* lo; u64* hi; u32* gcnt; u64* gfirst; u32* n; u32 cap; u32* n_real; };
+// SYM: the survivor set is handed on CLOSED under reverse complement -- a k-mer whose own quality test failed while its reverse
+// complement's passed (the first instance's quirk, A2:337-339, is not mirror-symmetric) goes along as a SHADOW (this bit of its gated
+// count): phase B walks the couples' first records only and needs both sides to mirror a run; shadows get no node, and edges that
+// touch one are dropped where the nodes are written (k_node_emit2) -- what the reference, which never saw them survive, has.
+#define GC_SHADOW 0x80000000u
+#define GC_MASK 0x7FFFFFFFu
 
 // compare_read (A2:142-144): the two records' sequences, not-ACGT masks included
 __device__ inline bool reads_equal(const u64* __restrict__ bases, const u64* __restrict__ nmask, int rl, u64 a, u64 b) {
@@ -697,7 +703,7 @@ __global__ __launch_bounds__(RD_THREADS, sizeof(TUP) == 16 ? RD_WAVES : RD_WAVES
 	__shared__ u64 low_inst[RD_LI];
 	__shared__ u32 low_n[RD_LROWS];
 	__shared__ unsigned short low_slot[RD_LROWS];
-	__shared__ u32 s_over, s_ndist, s_nlow, s_npq, s_nsurv, s_base;
+	__shared__ u32 s_over, s_ndist, s_nlow, s_npq, s_nsurv, s_base, s_nreal;
 	const THI EMPTY = (THI) ~(THI) 0;
 	const u32 b = order ? order[blockIdx.x] : blockIdx.x;
 	const u32 base = bucket_start[b];
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(RD_THREADS, sizeof(TUP) == 16 ? RD_WAVES : RD_WAVES
 		__syncthreads();
 		for (u32 s = 0; s < S; s++) {
 			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) { s_khi[i] = EMPTY; s_cnt[i] = 0; s_first[i] = NONE64; s_state[i] = 0; }
-			if (tid == 0) { s_nlow = 0; s_npq = (n >> (32 - RD_SLOT_BITS) || dbg == 9) ? RD_PQ + 1 : 0; s_nsurv = 0; }     // (an index that does not fit an entry: rescan; VDJX_RD_DBG=9: the tests' way into the rescan)
+			if (tid == 0) { s_nlow = 0; s_npq = (n >> (32 - RD_SLOT_BITS) || dbg == 9) ? RD_PQ + 1 : 0; s_nsurv = 0; s_nreal = 0; }     // (an index that does not fit an entry: rescan; VDJX_RD_DBG=9: the tests' way into the rescan)
 			__syncthreads();
 			// ---- sweep 1
 			for (u32 t0 = 0; t0 < n; t0 += RD_UNR * RD_THREADS) {
@@ -873,31 +879,33 @@ __global__ __launch_bounds__(RD_THREADS, sizeof(TUP) == 16 ? RD_WAVES : RD_WAVES
 					keep = c >= mf && (st & ST_MULTI) && (craw >= tlow || (st & ST_QOK));
 					if (SYM) keep_r = c >= mf && (st & ST_MULTI) && (craw >= tlow || (st & ST_QOK_R));
 				}
-				// (reused: position among this sub-pass's survivors; SYM: << 2 | which of the two sides leave)
-				if (SYM) s_state[i] = (keep || keep_r) ? (atomicAdd(&s_nsurv, (u32) keep + (u32) keep_r) << 2) | (u32) keep | ((u32) keep_r << 1) : NONE32;
-				else s_state[i] = keep ? atomicAdd(&s_nsurv, 1u) : NONE32;
+				// (reused: position among this sub-pass's survivors; SYM: both sides leave, << 2 | which of them are real)
+				if (SYM) {
+					s_state[i] = (keep || keep_r) ? (atomicAdd(&s_nsurv, 2u) << 2) | (u32) keep | ((u32) keep_r << 1) : NONE32;
+					if (keep || keep_r) atomicAdd(&s_nreal, (u32) keep + (u32) keep_r);
+				} else s_state[i] = keep ? atomicAdd(&s_nsurv, 1u) : NONE32;
 			}
 			__syncthreads();
-			if (tid == 0) s_base = s_nsurv ? atomicAdd(so.n, s_nsurv) : 0;
+			if (tid == 0) { s_base = s_nsurv ? atomicAdd(so.n, s_nsurv) : 0; if (SYM && s_nreal) atomicAdd(so.n_real, s_nreal); }
 			__syncthreads();
 			for (u32 i = tid; i < RD_SLOTS; i += RD_THREADS) {
 				if (s_state[i] == NONE32) continue;
 				u32 pos = s_base + (SYM ? s_state[i] >> 2 : s_state[i]);
 				const u32 cgo = s_cnt[i] > 32765u ? 32765u : s_cnt[i];
-				if ((!SYM || (s_state[i] & 1u)) && pos < so.cap) {
+				if (pos < so.cap) {
 					so.lo[pos] = s_klo[i];
 					so.hi[pos] = (u64) s_khi[i];
-					so.gcnt[pos] = cgo;
+					so.gcnt[pos] = cgo | (SYM && !(s_state[i] & 1u) ? GC_SHADOW : 0u);
 					so.gfirst[pos] = s_first[i];
 				}
-				if (SYM && (s_state[i] & 2u)) {
-					pos += s_state[i] & 1u;
+				if (SYM) {
+					pos += 1u;
 					if (pos < so.cap) {
 						u64 rh, rlo;
 						vdjx_kmer_rc((u64) s_khi[i], s_klo[i], k, rh, rlo);
 						so.lo[pos] = rlo;
 						so.hi[pos] = rh;
-						so.gcnt[pos] = cgo;
+						so.gcnt[pos] = cgo | (!(s_state[i] & 2u) ? GC_SHADOW : 0u);
 						so.gfirst[pos] = vdjx_inst_mirror(s_first[i], ob, rl, k);
 					}
 				}
@@ -1527,27 +1535,36 @@ __device__ inline int surv_lookup2f(const SurvTable& t, u64 lo, u64 hi) {
 }
 
 // ---- chain order ------------------------------------------------------------------------------
-// succ[u*4+b] = survivor index of (key_u << 2 | b) mod 4^k, or NONE32 (arrival numbering).  Every node with a successor proposes
-// itself as the chain predecessor of its HEAVIEST successor (gated count; in a deep clone every k-mer also has surviving error
-// branches, the clone's own path is the heavy one), and a node takes its heaviest proposer (atomicMax over count << 32 | ~index:
-// the same on every rank): the chains are a heavy-path decomposition of the graph.
-__global__ void k_succ_links2(SurvTable t, u32 n, int k, const u32* __restrict__ gcnt, u32* __restrict__ succ, unsigned long long* __restrict__ pred) {
+// succ[u*4+b] = survivor index of (key_u << 2 | b) mod 4^k, or NONE32 (arrival numbering).  The chains are a heavy-path decomposition
+// of the graph: u -> v is a chain link iff v is u's HEAVIEST successor (gated count; in a deep clone every k-mer also has surviving
+// error branches, the clone's own path is the heavy one) AND u is v's heaviest predecessor.  Ties: the successor with the larger last
+// base, the predecessor with the larger COMPLEMENT of its first base -- the rule is then its own mirror image (the successors of a
+// k-mer are the reverse complements of its reverse complement's predecessors, last base <-> complement of the first), so over a
+// survivor set that is closed under reverse complement the chains come in mirrored pairs: rc(u -> v) = rc(v) -> rc(u) is a link too,
+// which is what lets the walk derive a couple's second record from its first (k_walk_items SYM).
+// pred[v] = max over the predecessors u of (count << 32 | complement of u's first base << 30 | u); bestsucc[u].
+__global__ void k_succ_links2(SurvTable t, u32 n, int k, const u32* __restrict__ gcnt, u32* __restrict__ succ, unsigned long long* __restrict__ pred,
+                              u32* __restrict__ bestsucc) {
 	const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
 	if (u >= n) return;
 	const ulonglong2 kk = t.skey[u];
 	const u128 base = (((u128) kk.y << 64) | kk.x) << 2;
 	const u128 km = k < 64 ? (((u128) 1) << (2 * k)) - 1 : ~(u128) 0;
+	const int sh = 2 * (k - 1);
+	const u32 fb = (u32) (sh < 64 ? kk.x >> sh : kk.y >> (sh - 64)) & 3u;
+	const unsigned long long mine = ((unsigned long long) (gcnt[u] & GC_MASK) << 32) | ((unsigned long long) (fb ^ 1u) << 30) | (unsigned long long) u;
 	u32 best = NONE32, best_g = 0;
 	for (u32 b = 0; b < 4; b++) {
 		const u128 key = (base | (u128) b) & km;
 		const int s = surv_lookup2(t, (u64) key, (u64) (key >> 64));
 		succ[u * 4 + b] = s >= 0 ? (u32) s : NONE32;
 		if (s >= 0 && (u32) s != u) {
-			const u32 g = gcnt[s];
-			if (best == NONE32 || g > best_g) { best = (u32) s; best_g = g; }
+			const u32 g = gcnt[s] & GC_MASK;
+			if (best == NONE32 || g >= best_g) { best = (u32) s; best_g = g; }
+			atomicMax(&pred[s], mine);
 		}
 	}
-	if (best != NONE32) atomicMax(&pred[best], ((unsigned long long) gcnt[u] << 32) | (unsigned long long) (0xFFFFFFFFu - u));
+	bestsucc[u] = best;
 }
 
 // list ranking by pointer jumping, in place: pd[v] = ancestor << 32 | distance to it (ancestor NONE32: v is a head).  Every entry
@@ -1555,11 +1572,34 @@ __global__ void k_succ_links2(SurvTable t, u32 n, int k, const u32* __restrict__
 // CHAIN_JUMPS jumps per node a launch multiplies the resolved distance by at least CHAIN_JUMPS + 1 (all other nodes standing still)
 // and normally by 2^CHAIN_JUMPS; launches after the one that found nothing to do return at once.
 #define CHAIN_JUMPS 31                  // (measured at 1.05 M survivors, the whole chain order: 3 jumps per launch 0.82 ms, 7 0.59, 15 0.52, 31 / 63 / 255 0.48)
-__global__ void k_chain_init(const unsigned long long* __restrict__ pred, u32 n, u64* __restrict__ pd) {
+__global__ void k_chain_init(const unsigned long long* __restrict__ pred, const u32* __restrict__ bestsucc, u32 n, u64* __restrict__ pd) {
 	const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= n) return;
-	const unsigned long long x = pred[v];            // 0: nobody proposed
-	pd[v] = x == 0ull ? ((u64) NONE32 << 32) : ((u64) (0xFFFFFFFFu - (u32) x) << 32) | 1ull;
+	const unsigned long long x = pred[v];            // 0: no predecessor
+	const u32 u = (u32) x & 0x3FFFFFFFu;             // the heaviest one
+	pd[v] = x != 0ull && bestsucc[u] == v ? ((u64) u << 32) | 1ull : ((u64) NONE32 << 32);
+}
+
+// SYM: partner[p] = the survivor that is p's reverse complement (chain order).  The set is closed (GC_SHADOW) and the chains are
+// mirrored pairs: along a link p -> p + 1 the partners run backwards, partner[p + 1] = partner[p] - 1.  Anything else is counted
+// in bad[0] (the build then walks every record: kmer_build_impl2).
+__global__ void k_partner(SurvTable t, u32 n, int k, u32* __restrict__ partner) {
+	const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n) return;
+	const ulonglong2 kk = t.skey[p];
+	u64 rh, rlo;
+	vdjx_kmer_rc(kk.y, kk.x, k, rh, rlo);
+	const int q = surv_lookup2(t, rlo, rh);
+	partner[p] = q >= 0 ? (u32) q : NONE32;
+}
+__global__ void k_partner_check(const u32* __restrict__ partner, const u64* __restrict__ linw, u32 n, u32* __restrict__ bad) {
+	const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n) return;
+	bool wrong = partner[p] == NONE32;
+	const bool linked = (linw[p >> 4] >> (15u - (p & 15u))) & 1ull;
+	if (!wrong && linked && (p + 1 >= n || partner[p + 1] != partner[p] - 1u)) wrong = true;
+	const u64 m = __ballot(wrong);
+	if (m && __lane_id() == 0) atomicAdd(bad, (u32) __popcll(m));
 }
 
 __global__ void k_chain_jump(u64* __restrict__ pd, u32 n, const u32* __restrict__ open_prev, u32* __restrict__ open_now) {
@@ -1726,13 +1766,19 @@ __device__ inline int wm_next(const vdjx_mask3& m, int from, int none) { return 
 __device__ inline u32 wm_slice32(u64 m, int from) { return from < 64 ? (u32) (m >> from) : 0u; }
 __device__ inline u32 wm_slice32(const vdjx_mask3& m, int from) { return (u32) m.slice(from); }
 
-template <bool LONG>
+// SYM (vdjx_pool::sym, a survivor set closed under reverse complement, mirrored chains: k_succ_links2): only the FIRST record of every
+// couple is walked (R counts couples); a run of survivors pp .. pp + L - 1 at the offsets po .. of record 2q is, read backwards, the run
+// partner[pp] - (L - 1) .. partner[pp] at the offsets rl - k - (po + L - 1) .. of record 2q + 1, whose predecessor there is the mirror of
+// the node that FOLLOWS the run here.  Both runs leave as items; the table lookups -- what this kernel waits for -- are made once.
+template <bool LONG, bool SYM = false>
 __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restrict__ bases, const u64* __restrict__ nmask, size_t R, int rl, int ob_bits, int k,
                                                              SurvTable t, const u32* __restrict__ succ, const u64* __restrict__ linw, ItemFmt f,
                                                              u32 range_shift, u32 n_ranges,
                                                              u64* __restrict__ raw, u64 raw_cap, u32 blk_items,
                                                              unsigned long long* __restrict__ g_cursor,
-                                                             u32* __restrict__ range_cnt, u32* __restrict__ g_err, u32 dbg_in) {
+                                                             u32* __restrict__ range_cnt, u32* __restrict__ g_err, u32 dbg_in,
+                                                             const u32* __restrict__ partner) {
+	static_assert(!(LONG && SYM), "SYM is the short-read form");
 	// the ablation switches of profiles/walkdbg.sh (filter off, lookups faked, outputs dropped, per-wave statistics) exist only in the
 	// -DVDJX_ABLATE build: the shipped walk has none of those branches
 #ifdef VDJX_ABLATE
@@ -1899,35 +1945,59 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 				s = s2;
 			}
 			// ---- the run, one item per block of 16 (and per 2^lb nodes) ----
-			u32 pin = in;
+			const u32 pin0 = in;
 			if (act) in = s >= 0 ? (4u | v.base(o - 1)) : 0u;      // (next round: first base of the k-mer at o - 1)
-			while (__ballot(rem > 0)) {
-				WST(st_items++;)
-				const bool close = rem > 0;
-				u32 len = 16u - (pp & 15u);
-				len = len < rem ? len : rem;
-				len = len < f.maxlen ? len : f.maxlen;
-				const u64 item = (f.maxlen > 1 ? (u64) (len - 1) << f.len_shift : 0ull) | ((u64) pp << IT_SURV_SHIFT) | ((u64) pin << 35) | ((u64) r << ob_bits) | (u64) po;
-				const u64 m = __ballot(close);
-				const u32 cnt = (u32) __popcll(m);
-				if (fill + cnt > blk_items) {                             // (wave-uniform)
-					if (have_blk) for (u32 i = fill + (u32) lane; i < blk_items; i += 64) raw[blk + i] = IT_HOLE;
-					unsigned long long nb = 0;
-					if (lane == 0) nb = atomicAdd(g_cursor, (unsigned long long) blk_items);
-					nb = ((unsigned long long) (u32) __builtin_amdgcn_readlane((int) (nb >> 32), 0) << 32) | (u32) __builtin_amdgcn_readlane((int) nb, 0);
-					if (nb + blk_items > raw_cap) { if (lane == 0 && !dead) atomicAdd(g_err, 1u); dead = true; have_blk = false; }
-					else { blk = nb; have_blk = true; }
-					fill = 0;
+			// SYM: the partner of the run's first node, asked for before the run's own items are written
+			const u32 run_len = rem, run_pp = pp, run_po = po;
+			u32 q_last = 0;
+			if (SYM && act) q_last = partner[run_pp];
+			auto emit = [&](auto mir_tag, u32 rem_, u32 pp_, u32 po_, u32 pin_, const size_t rec_) {
+				constexpr bool MIR = decltype(mir_tag)::value;
+				while (__ballot(rem_ > 0)) {
+					WST(st_items++;)
+					const bool close = rem_ > 0;
+					u32 len = 16u - (pp_ & 15u);
+					len = len < rem_ ? len : rem_;
+					len = len < f.maxlen ? len : f.maxlen;
+					const u64 item = (f.maxlen > 1 ? (u64) (len - 1) << f.len_shift : 0ull) | ((u64) pp_ << IT_SURV_SHIFT) | ((u64) pin_ << 35) | ((u64) rec_ << ob_bits) | (u64) po_;
+					const u64 m = __ballot(close);
+					const u32 cnt = (u32) __popcll(m);
+					if (fill + cnt > blk_items) {                             // (wave-uniform)
+						if (have_blk) for (u32 i = fill + (u32) lane; i < blk_items; i += 64) raw[blk + i] = IT_HOLE;
+						unsigned long long nb = 0;
+						if (lane == 0) nb = atomicAdd(g_cursor, (unsigned long long) blk_items);
+						nb = ((unsigned long long) (u32) __builtin_amdgcn_readlane((int) (nb >> 32), 0) << 32) | (u32) __builtin_amdgcn_readlane((int) nb, 0);
+						if (nb + blk_items > raw_cap) { if (lane == 0 && !dead) atomicAdd(g_err, 1u); dead = true; have_blk = false; }
+						else { blk = nb; have_blk = true; }
+						fill = 0;
+					}
+					if (close && !dead) {
+						if (!(dbg & 1u)) raw[blk + fill + (u32) __popcll(m & ((1ull << lane) - 1ull))] = item;
+						if (!(dbg & 2u)) atomicAdd(&hist[it_scat(f, pp_) >> range_shift], 1u);
+					}
+					fill += cnt;
+					if (close) {
+						rem_ -= len; pp_ += len; po_ += len;
+						// the next piece's predecessor is the node before it: here the base at po - 1; in the mirrored record the base at
+						// po' - 1 there, i.e. the complement of this record's base rl - po'
+						pin_ = 4u | (MIR ? (v.base(rl - (int) po_) ^ 1u) : v.base((int) po_ - 1));
+					}
 				}
-				if (close && !dead) {
-					if (!(dbg & 1u)) raw[blk + fill + (u32) __popcll(m & ((1ull << lane) - 1ull))] = item;
-					if (!(dbg & 2u)) atomicAdd(&hist[it_scat(f, pp) >> range_shift], 1u);
+			};
+			emit(std::false_type{}, rem, pp, po, pin0, r);
+			if constexpr (SYM) {
+				// the same run in the couple's second record (see above): it ends where this one starts; its predecessor is the mirror of
+				// this run's successor (known now: s), named by the complement of that k-mer's last base
+				u32 mrem = 0, mpp = 0, mpo = 0, mpin = 0;
+				if (act) {
+					if (q_last == NONE32 || q_last + 1u < run_len) { if (!dead) atomicAdd(g_err + 2, 1u); }      // (cannot happen: the set is closed, the chains mirrored)
+					else {
+						mrem = run_len; mpp = q_last - (run_len - 1u);
+						mpo = (u32) (rl - k) - (run_po + run_len - 1u);
+						mpin = s >= 0 ? (4u | (v.base(rl - (int) mpo) ^ 1u)) : 0u;
+					}
 				}
-				fill += cnt;
-				if (close) {
-					rem -= len; pp += len; po += len;
-					pin = 4u | v.base((int) po - 1);        // the next piece's predecessor is the node before it
-				}
+				emit(std::true_type{}, mrem, mpp, mpo, mpin, r + 1);
 			}
 		}
 	};
@@ -1943,8 +2013,8 @@ __global__ __launch_bounds__(WALK_THREADS) void k_walk_items(const u64* __restri
 		walk_row(std::false_type{}, (size_t) (e >> 8), live, (int) (e & 255u), qb, qv);
 	};
 	for (size_t rb = r0; rb < r1; rb += WALK_THREADS) {
-		const size_t r = rb + threadIdx.x;
-		walk_row(std::true_type{}, r, r < r1, 0, make_ulonglong2(0ull, 0ull), 0ull);
+		const size_t r = rb + threadIdx.x;                   // (SYM: a couple; its first record is 2r)
+		walk_row(std::true_type{}, SYM ? 2 * r : r, r < r1, 0, make_ulonglong2(0ull, 0ull), 0ull);
 		while (qn >= 64) walk_queued(64);
 	}
 	if (qn) walk_queued(qn);
@@ -2269,9 +2339,9 @@ struct NodeOut {
 // node numbering by first sight = the survivors sorted by their first instance (a bitmap over the whole instance space with a
 // popcount prefix did this without a sort: 80 MB cleared, marked, counted and prefixed for one million set bits, 0.24 ms at 10 M
 // pairs, and growing with the pool, not with the graph)
-__global__ void k_rank_keys(const u64* __restrict__ ufirst, u32 n, u64* __restrict__ key, u32* __restrict__ idx) {
+__global__ void k_rank_keys(const u64* __restrict__ ufirst, const u32* __restrict__ gcnt, u32 n, u64* __restrict__ key, u32* __restrict__ idx) {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) { key[i] = ufirst[i]; idx[i] = i; }
+	if (i < n) { key[i] = (gcnt[i] & GC_SHADOW) ? NONE64 : ufirst[i]; idx[i] = i; }      // (shadows sort behind every node: they get none)
 }
 __global__ void k_rank_scatter(const u64* __restrict__ key, const u32* __restrict__ idx, u32 n, u32* __restrict__ rank) {
 	const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2324,6 +2394,7 @@ __global__ void k_node_emit2(const u64* __restrict__ s_lo, const u64* __restrict
                              u32 n, int k, NodeOut o) {
 	const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= n) return;
+	if (s_gcnt[s] & GC_SHADOW) return;                       // a k-mer that went along for its reverse complement's sake only (GC_SHADOW)
 	const u32 r = rank[s];
 	o.first_inst[r] = s_ufirst[s];
 	o.gcnt[r] = s_gcnt[s];
@@ -2337,12 +2408,21 @@ __global__ void k_node_emit2(const u64* __restrict__ s_lo, const u64* __restrict
 	}
 	u64 f[4];
 	u32 id[4];
-	for (int e = 0; e < 4; e++) { f[e] = edge_first[(size_t) s * 4 + e]; id[e] = f[e] != NONE64 ? rank[edge_to[(size_t) s * 4 + e]] + 1 : 0; }
+	// (an edge to or from a shadow does not exist: the reference never saw that k-mer survive, A2:316-318)
+	for (int e = 0; e < 4; e++) {
+		f[e] = edge_first[(size_t) s * 4 + e];
+		if (f[e] != NONE64 && (s_gcnt[edge_to[(size_t) s * 4 + e]] & GC_SHADOW)) f[e] = NONE64;
+		id[e] = f[e] != NONE64 ? rank[edge_to[(size_t) s * 4 + e]] + 1 : 0;
+	}
 	sort4_desc64(f, id);
 	u32 deg = 0;
 	for (int e = 0; e < 4; e++) { o.to_ids[(size_t) r * 4 + e] = f[e] != NONE64 ? id[e] : 0; deg += f[e] != NONE64; }
 	o.to_deg[r] = (uint8_t) deg;
-	for (int e = 0; e < 4; e++) { f[e] = in_first[(size_t) s * 4 + e]; id[e] = f[e] != NONE64 ? rank[in_from[(size_t) s * 4 + e]] + 1 : 0; }
+	for (int e = 0; e < 4; e++) {
+		f[e] = in_first[(size_t) s * 4 + e];
+		if (f[e] != NONE64 && (in_from[(size_t) s * 4 + e] == NONE32 || (s_gcnt[in_from[(size_t) s * 4 + e]] & GC_SHADOW))) f[e] = NONE64;
+		id[e] = f[e] != NONE64 ? rank[in_from[(size_t) s * 4 + e]] + 1 : 0;
+	}
 	sort4_desc64(f, id);
 	deg = 0;
 	for (int e = 0; e < 4; e++) { o.from_ids[(size_t) r * 4 + e] = f[e] != NONE64 ? id[e] : 0; deg += f[e] != NONE64; }
@@ -2385,7 +2465,7 @@ template <typename TUP> struct GTuples {
 struct SurvivorsG {
 	u64 *lo = nullptr, *hi = nullptr, *gfirst = nullptr, *ufirst = nullptr;
 	u32 *gcnt = nullptr, *ucnt = nullptr;
-	u32 n = 0;
+	u32 n = 0, n_real = 0;
 	u64 ndist = 0;
 };
 
@@ -2577,8 +2657,11 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 	HIP_TRY(db.alloc(&g_distinct, 64 * 16 + 1));                     // one cleared block: the counters of distinct k-mers | error word, survivors
 	g_err = (u32*) (g_distinct + 64 * 16);
 	n_surv = g_err + 1;
+	u32* n_real;
+	HIP_TRY(db.alloc(&n_real, 2));
+	HIP_TRY(hipMemsetAsync(n_real, 0, 8, st));
 	HIP_TRY(hipMemsetAsync(g_distinct, 0, (64 * 16 + 1) * 8, st));
-	SurvOutG so{sv->lo, sv->hi, sv->gcnt, sv->gfirst, n_surv, cap};
+	SurvOutG so{sv->lo, sv->hi, sv->gcnt, sv->gfirst, n_surv, cap, n_real};
 	static const u32 rd_dbg = (u32) tune("VDJX_RD_DBG", 0);        // profiles/reducedbg.py: the kernel stops after a phase
 	if (t.N) {
 		vdjx_prof_scope ps(c, "k_gated_reduce");
@@ -2597,6 +2680,7 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 	u32* tail = (u32*) (spread + 64 * 16);
 	HIP_TRY(hipMemcpyAsync(&tail[0], n_surv, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&tail[1], g_err, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(&tail[2], n_real, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(spread, g_distinct, 64 * 16 * 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
@@ -2606,6 +2690,7 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 	sv->ndist = 0;
 	for (int i = 0; i < 64; i++) sv->ndist += spread[i * 16];
 	sv->n = ns;
+	sv->n_real = sym ? tail[2] : ns;             // (sym: the set is closed under reverse complement; the rest are shadows, GC_SHADOW)
 	return VDJX_OK;
 }
 
@@ -2615,7 +2700,9 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 struct RecountOut { u32* ucnt; u64* ufirst; u64* in_first; u32* in_from; u64* edge_first; u32* edge_to; };
 // what stage_recount leaves on the device for a caller that waits later (one host wait less per build): read back by recount_status_read
 struct RecountStatus { const u32* g_err = nullptr; const u32* n_items = nullptr; const unsigned long long* n_inst = nullptr; u32 ns = 0; };
-static int recount_status_check(vdjx_ctx* c, const u32* hp, u32 ns) {          // hp: err[2], n_items, -, inst (u64)
+#define VDJX_ESYMWALK (-1000)          // (internal) the mirrored walk met a survivor set or chains that are not mirror images: walk every record instead
+static int recount_status_check(vdjx_ctx* c, const u32* hp, u32 ns) {          // hp: err[2], n_items, -, inst (u64), sym violations [2]
+	if (hp[6] || hp[7]) { vdjx_set_error("the mirrored walk found %u + %u places where the chains are not mirror images", hp[6], hp[7]); return VDJX_ESYMWALK; }
 	if (hp[0]) { vdjx_set_error("k_walk_items: item buffer too small (%u waves stopped)", hp[0]); return VDJX_EHIP; }
 	if (hp[1]) { vdjx_set_error("internal error: %u of %u surviving k-mers were not met again in the records (VDJX_SYNC_DEBUG=1 names them)", hp[1], ns); return VDJX_EHIP; }
 	c->stats["recount_items"] = hp[2];                                    // runs of surviving k-mer instances of this pool (8 bytes each)
@@ -2625,7 +2712,7 @@ static int recount_status_check(vdjx_ctx* c, const u32* hp, u32 ns) {          /
 
 template <typename A>
 int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k, SurvivorsG& sv, const RecountOut& ro,
-                  bool derive_edges, SurvTable* table_out = nullptr, RecountStatus* defer = nullptr) {
+                  bool derive_edges, SurvTable* table_out = nullptr, RecountStatus* defer = nullptr, bool sym_walk = false) {
 	hipStream_t st = c->stream;
 	const size_t R = pool->n_records;
 	const int P = pool->rl - k + 1;
@@ -2637,7 +2724,7 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	while ((size_t) tmask + 1 < (size_t) ns * 2) tmask = tmask * 2 + 1;
 	unsigned long long* pred;
 	ulonglong2* table;
-	u32 *succ0, *succ, *bloom, *clen, *coff, *csum, *csum_start, *newidx, *jump_open, *fbw, *gcnt2;
+	u32 *succ0, *succ, *bloom, *clen, *coff, *csum, *csum_start, *newidx, *jump_open, *fbw, *gcnt2, *bestsucc, *partner = nullptr;
 	u64 *pd, *lo2, *hi2, *gfirst2, *linw;
 	ulonglong2 *skey0, *skey;
 	u32 bloom_bits = 1u << 16;
@@ -2667,6 +2754,8 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	HIP_TRY(db.alloc(&csum, n_scan)); HIP_TRY(db.alloc(&csum_start, n_scan + 1)); HIP_TRY(db.alloc(&newidx, ns));
 	HIP_TRY(db.alloc(&lo2, ns)); HIP_TRY(db.alloc(&hi2, ns)); HIP_TRY(db.alloc(&gcnt2, ns)); HIP_TRY(db.alloc(&gfirst2, ns));
 	HIP_TRY(db.alloc(&fbw, nb16));
+	HIP_TRY(db.alloc(&bestsucc, ns));
+	if (sym_walk) HIP_TRY(db.alloc(&partner, ns));
 	const SurvTable tb0{table, tmask, skey0, bloom, bloom_bits - 1};      // arrival numbering
 	const SurvTable tb{table, tmask, skey, bloom, bloom_bits - 1};        // chain order (after k_table_remap)
 	if (table_out) *table_out = tb;
@@ -2674,12 +2763,12 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	{
 		vdjx_prof_scope ps(c, "k_surv_table");
 		hipLaunchKernelGGL(k_surv_table2, gs, bs, 0, st, sv.lo, sv.hi, ns, table, tmask, skey0, bloom, bloom_bits - 1);
-		hipLaunchKernelGGL(k_succ_links2, gs, bs, 0, st, tb0, ns, k, sv.gcnt, succ0, pred);
+		hipLaunchKernelGGL(k_succ_links2, gs, bs, 0, st, tb0, ns, k, sv.gcnt, succ0, pred, bestsucc);
 	}
 	{
 		// chain order: the survivors, their table entries and their successor lists renumbered
 		vdjx_prof_scope ps(c, "k_chain_order");
-		hipLaunchKernelGGL(k_chain_init, gs, bs, 0, st, pred, ns, pd);
+		hipLaunchKernelGGL(k_chain_init, gs, bs, 0, st, pred, bestsucc, ns, pd);
 		for (u32 j = 0; j < n_jump; j++) hipLaunchKernelGGL(k_chain_jump, gs, bs, 0, st, pd, ns, j ? jump_open + j - 1 : (const u32*) nullptr, jump_open + j);
 		hipLaunchKernelGGL(k_chain_len, gs, bs, 0, st, pd, ns, clen);
 		hipLaunchKernelGGL(k_scan_sums, dim3(n_scan), dim3(256), 0, st, clen, ns, csum);
@@ -2747,7 +2836,8 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	const u32 n_ranges_p = n_coarse << l2bits;                      // padded: every coarse segment has 2^l2bits ranges
 	// raw item blocks
 	static const size_t walk_blocks = tune("VDJX_WALK_BLOCKS", 7168);      // (seven waves per SIMD are resident: 28 blocks per CU = one resident set x 4; measured 4096 2.45 ms, 7168 2.32, 16384 2.52)
-	u32 nblk = (u32) std::min<size_t>(walk_blocks, (R + WALK_THREADS * 8 - 1) / (WALK_THREADS * 8));
+	const size_t Rw = sym_walk ? R / 2 : R;                          // what the walk's lanes take: records, or couples of them
+	u32 nblk = (u32) std::min<size_t>(walk_blocks, (Rw + WALK_THREADS * 8 - 1) / (WALK_THREADS * 8));
 	// (1,536 blocks are resident at once -- six waves per SIMD --: a pool that asks for a few more pays a second, nearly empty round with
 	// the latency of a full one.  1 M pairs, 1,953 blocks asked: 0.41 ms; 1,500: 0.36; 1,700: 0.40.  3 M pairs: 3,000 0.77, 5,000 0.81)
 	static const u32 walk_resident = (u32) tune("VDJX_WALK_RESIDENT", 1536);
@@ -2769,12 +2859,18 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	range_cnt = (u32*) (g_cursor + 4);
 	HIP_TRY(db.alloc(&range_start, n_ranges_p + 1));
 	HIP_TRY(hipMemsetAsync(g_cursor, 0, 32 + (size_t) n_ranges_p * 4, st));
+	if (sym_walk) {          // the survivors' reverse complements, and whether the chains are mirror images (g_err[3]: read with the other status words)
+		vdjx_prof_scope ps(c, "k_chain_order");
+		hipLaunchKernelGGL(k_partner, gs, bs, 0, st, tb, ns, k, partner);
+		hipLaunchKernelGGL(k_partner_check, gs, bs, 0, st, partner, linw, ns, g_err + 3);
+	}
 	const bool lng = pool->W > 2;
 	if (lng && R >= (1ull << 27)) { vdjx_set_error("more than 2^27 records of long reads on one GPU: not supported by the recount items"); return VDJX_ELIMIT; }
 	const size_t lds_walk = (((size_t) n_ranges_p + 1) & ~(size_t) 1) * 4 + (lng ? (size_t) WALK_THREADS * GL_ROW_LONG * 8 : 0);
 	if ((size_t) n_ranges_p * 4 > 64 * 1024) { vdjx_set_error("too many survivor ranges for the walk histogram"); return VDJX_ELIMIT; }
 	HIP_TRY(hipFuncSetAttribute((const void*) k_walk_items<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_walk));
 	HIP_TRY(hipFuncSetAttribute((const void*) k_walk_items<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_walk));
+	HIP_TRY(hipFuncSetAttribute((const void*) k_walk_items<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_walk));
 	// VDJX_WALK_DBG (profiles/walkdbg.sh): an ABLATED copy of the walk runs first into scratch outputs, timed as k_walk_dbg; the real
 	// one follows untouched.  Bits: 1 no item stores, 2 no range histogram, 8 no filter / table / key loads at run starts.
 #ifdef VDJX_ABLATE
@@ -2793,9 +2889,9 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		HIP_TRY(hipMemsetAsync(cnt2, 0, (size_t) n_ranges_p * 4, st));
 		vdjx_prof_scope ps(c, "k_walk_dbg");
 		if (lng) hipLaunchKernelGGL(k_walk_items<true>, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, pool->ob, k, tb, succ, linw, f, range_shift,
-		                            n_ranges_p, raw2, raw_cap, blk_items, cur2, cnt2, g_err, walk_dbg);
+		                            n_ranges_p, raw2, raw_cap, blk_items, cur2, cnt2, g_err, walk_dbg, (const u32*) nullptr);
 		else hipLaunchKernelGGL(k_walk_items<false>, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, pool->ob, k, tb, succ, linw, f, range_shift,
-		                        n_ranges_p, raw2, raw_cap, blk_items, cur2, cnt2, g_err, walk_dbg);
+		                        n_ranges_p, raw2, raw_cap, blk_items, cur2, cnt2, g_err, walk_dbg, (const u32*) nullptr);
 		HIP_TRY(hipMemsetAsync(g_err, 0, 4, st));
 		if (walk_dbg & 32u) {                      // per wave: rows of 64 records, rounds, and the rounds that ran each part
 			unsigned long long hs[8];
@@ -2808,9 +2904,11 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	if (R) {
 		vdjx_prof_scope ps(c, "k_walk_items");
 		if (lng) hipLaunchKernelGGL(k_walk_items<true>, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, pool->ob, k, tb, succ, linw, f, range_shift,
-		                            n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err, (u32) tune("VDJX_WALK_FLAGS", 0));
+		                            n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err, (u32) tune("VDJX_WALK_FLAGS", 0), (const u32*) nullptr);
+		else if (sym_walk) hipLaunchKernelGGL((k_walk_items<false, true>), dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R / 2, pool->rl, pool->ob, k, tb, succ, linw, f, range_shift,
+		                                      n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err, (u32) tune("VDJX_WALK_FLAGS", 0), (const u32*) partner);
 		else hipLaunchKernelGGL(k_walk_items<false>, dim3(nblk), dim3(WALK_THREADS), lds_walk, st, pool->d_bases, pool->d_nmask, R, pool->rl, pool->ob, k, tb, succ, linw, f, range_shift,
-		                        n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err, (u32) tune("VDJX_WALK_FLAGS", 0));
+		                        n_ranges_p, raw, raw_cap, blk_items, g_cursor, range_cnt, g_err, (u32) tune("VDJX_WALK_FLAGS", 0), (const u32*) nullptr);
 	}
 	dbg_sync(c, "k_walk_items");
 	hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, range_cnt, n_ranges_p, range_start);
@@ -2880,12 +2978,14 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		return VDJX_OK;
 	}
 	if (defer) defer->g_err = nullptr;
-	u32* hp = (u32*) c->h_pin;                        // err[2], n_items, -, inst (u64)
+	u32* hp = (u32*) c->h_pin;                        // err[2], n_items, -, inst (u64), mirrored walk's complaints [2]
 	HIP_TRY(hipMemcpyAsync(hp, g_err, 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(hp + 2, range_start + n_ranges_p, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(hp + 4, n_inst, 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(hp + 6, g_err + 2, 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	if (hp[6] || hp[7]) { vdjx_set_error("the mirrored walk found %u + %u places where the chains are not mirror images", hp[6], hp[7]); return VDJX_ESYMWALK; }
 	const u32 err[2] = {hp[0], hp[1]}, n_items = hp[2];
 	const unsigned long long inst = *(const unsigned long long*) (hp + 4);
 	if (err[0]) { vdjx_set_error("k_walk_items: item buffer too small (%u waves stopped)", err[0]); return VDJX_EHIP; }
@@ -2921,7 +3021,8 @@ template <typename A>
 int stage_finish2(vdjx_ctx* c, A& db, const SurvivorsG& sv, const RecountOut& ro, u64 n_records_total, int k, int P, int ob, vdjx_graph* g) {
 	hipStream_t st = c->stream;
 	const u32 ns = sv.n;
-	g->n = ns;
+	const u32 nr = sv.n_real <= ns ? sv.n_real : ns;          // the nodes: the survivors that are not shadows (GC_SHADOW; they sort last)
+	g->n = nr;
 	g->k = k;
 	g->ctx = c;
 	g->device = c->device;
@@ -2968,7 +3069,7 @@ int stage_finish2(vdjx_ctx* c, A& db, const SurvivorsG& sv, const RecountOut& ro
 	g->d_roots = (u32*) carve((size_t) ns * 4);
 	{
 		vdjx_prof_scope ps(c, "k_node_order");
-		hipLaunchKernelGGL(k_rank_keys, dim3((ns + 255) / 256), dim3(256), 0, st, sv.ufirst, ns, rk_key, rk_idx);
+		hipLaunchKernelGGL(k_rank_keys, dim3((ns + 255) / 256), dim3(256), 0, st, sv.ufirst, sv.gcnt, ns, rk_key, rk_idx);
 		{
 			size_t tb = 0;
 			int rc_ = vdjx_sort_pairs_raw(nullptr, &tb, st, rk_key, rk_key2, rk_idx, rk_idx2, ns, rk_bits);
@@ -2983,14 +3084,14 @@ int stage_finish2(vdjx_ctx* c, A& db, const SurvivorsG& sv, const RecountOut& ro
 	}
 	u32 n_roots = 0;
 	{
-		const u32 nrb = (ns + 255) / 256;
+		const u32 nrb = (nr + 255) / 256;
 		u32 *rb_cnt, *rb_start;
-		HIP_TRY(db.alloc(&rb_cnt, nrb));
+		HIP_TRY(db.alloc(&rb_cnt, nrb + 1));
 		HIP_TRY(db.alloc(&rb_start, nrb + 1));
 		vdjx_prof_scope ps(c, "k_root_list");
-		hipLaunchKernelGGL(k_root_count, dim3(nrb), dim3(256), 0, st, no.from_deg, ns, rb_cnt);
+		if (nrb) hipLaunchKernelGGL(k_root_count, dim3(nrb), dim3(256), 0, st, no.from_deg, nr, rb_cnt);
 		hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, rb_cnt, nrb, rb_start);
-		hipLaunchKernelGGL(k_root_list, dim3(nrb), dim3(256), 0, st, no.from_deg, ns, rb_start, g->d_roots);
+		if (nrb) hipLaunchKernelGGL(k_root_list, dim3(nrb), dim3(256), 0, st, no.from_deg, nr, rb_start, g->d_roots);
 		HIP_TRY(hipMemcpyAsync(c->h_pin, rb_start + nrb, 4, hipMemcpyDeviceToHost, st));
 	}
 	HIP_TRY(hipStreamSynchronize(st));
@@ -3022,18 +3123,33 @@ int kmer_build_impl2(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, 
 		HIP_TRY(db.alloc(&ro.in_first, (size_t) sv.n * 4)); HIP_TRY(db.alloc(&ro.in_from, (size_t) sv.n * 4));
 		HIP_TRY(db.alloc(&ro.edge_first, (size_t) sv.n * 4)); HIP_TRY(db.alloc(&ro.edge_to, (size_t) sv.n * 4));
 		ro.ucnt = sv.ucnt; ro.ufirst = sv.ufirst;
-		RecountStatus rs;
-		rc = stage_recount(c, db, pool, 0, k, sv, ro, true, nullptr, &rs);
-		if (rc) return rc;
-		u32* hp = (u32*) c->h_pin + 1024;              // (behind what stage_finish2 reads back)
-		if (rs.g_err) {
-			HIP_TRY(hipMemcpyAsync(hp, rs.g_err, 8, hipMemcpyDeviceToHost, c->stream));
-			HIP_TRY(hipMemcpyAsync(hp + 2, rs.n_items, 4, hipMemcpyDeviceToHost, c->stream));
-			HIP_TRY(hipMemcpyAsync(hp + 4, rs.n_inst, 8, hipMemcpyDeviceToHost, c->stream));
+		// phase B: over the couples' first records when the survivor set came out of phase A closed under reverse complement (sym); should
+		// the chains turn out not to be mirror images after all (they are, by construction: k_succ_links2) the walk is done again over
+		// every record -- a survivor set with shadows is as good an input to that one
+		static const bool sym_walk_on = getenv("VDJX_NO_SYM_WALK") == nullptr;
+		for (int attempt = 0; attempt < 2; attempt++) {
+			const bool sym_walk = sym && sym_walk_on && attempt == 0;
+			c->stats["kmer_build_sym_walk"] = sym_walk ? 1 : 0;
+			RecountStatus rs;
+			rc = stage_recount(c, db, pool, 0, k, sv, ro, true, nullptr, &rs, sym_walk);
+			if (rc == VDJX_ESYMWALK && sym_walk) { c->stats["kmer_build_sym_walk_retries"] += 1; continue; }      // (VDJX_SYNC_DEBUG: the stage read its own status)
+			if (rc) return rc;
+			u32* hp = (u32*) c->h_pin + 1024;              // (behind what stage_finish2 reads back)
+			hp[6] = hp[7] = 0;
+			if (rs.g_err) {
+				HIP_TRY(hipMemcpyAsync(hp, rs.g_err, 8, hipMemcpyDeviceToHost, c->stream));
+				HIP_TRY(hipMemcpyAsync(hp + 2, rs.n_items, 4, hipMemcpyDeviceToHost, c->stream));
+				HIP_TRY(hipMemcpyAsync(hp + 4, rs.n_inst, 8, hipMemcpyDeviceToHost, c->stream));
+				HIP_TRY(hipMemcpyAsync(hp + 6, rs.g_err + 2, 8, hipMemcpyDeviceToHost, c->stream));
+			}
+			rc = stage_finish2(c, db, sv, ro, pool->n_records, k, P, pool->ob, g);          // (waits for the stream)
+			if (rc) return rc;
+			rc = rs.g_err ? recount_status_check(c, hp, rs.ns) : VDJX_OK;
+			if (rc != VDJX_ESYMWALK || !sym_walk) return rc == VDJX_ESYMWALK ? VDJX_EHIP : rc;
+			c->stats["kmer_build_sym_walk_retries"] += 1;
+			if (g->d_block) { c->blocks.release(g->d_block, g->block_cap); g->d_block = nullptr; g->block_cap = 0; }
 		}
-		rc = stage_finish2(c, db, sv, ro, pool->n_records, k, P, pool->ob, g);          // (waits for the stream)
-		if (rc) return rc;
-		return rs.g_err ? recount_status_check(c, hp, rs.ns) : VDJX_OK;
+		return VDJX_EHIP;
 	}
 	return stage_finish2(c, db, sv, ro, pool->n_records, k, P, pool->ob, g);
 }
@@ -3374,7 +3490,7 @@ static int shard_merge_impl(vdjx_shard* s, const u32* d_recv_dir, const Partial*
 	HIP_TRY(hipMemcpyAsync(d_src_base, s->src_base.data(), (G + 1) * 4, hipMemcpyHostToDevice, st));
 	hipLaunchKernelGGL(k_seg_offsets, dim3(G), dim3(1024), 0, st, d_recv_dir, d_src_base, G, NBo, seg_off);
 	const u32 cmin = (u32) std::max(s->mf, 2);
-	SurvOutG so{v.lo, v.hi, v.gcnt, v.gfirst, s->n_surv, cap};
+	SurvOutG so{v.lo, v.hi, v.gcnt, v.gfirst, s->n_surv, cap, nullptr};
 	s->nq.assign(G, 0);
 	// buckets per merge table: about MERGE_SLOTS*3/8 partials each (the local buckets are sized for tuples, not for distinct k-mers)
 	u32 MG = 1;
@@ -3506,7 +3622,7 @@ extern "C" int vdjx_shard_resolve(vdjx_shard* s, const void* d_replies, uint64_t
 	if (s->n_pend) {
 		if (!d_replies) { vdjx_set_error("vdjx_shard_resolve: NULL buffer"); return VDJX_EINVAL; }
 		const u32 nr = (u32) n_replies;
-		SurvOutG so{v.lo, v.hi, v.gcnt, v.gfirst, s->n_surv, s->sv_cap};
+		SurvOutG so{v.lo, v.hi, v.gcnt, v.gfirst, s->n_surv, s->sv_cap, nullptr};
 		vdjx_prof_scope ps(c, "k_shard_resolve");
 		hipLaunchKernelGGL(k_resolve_first, dim3((nr + 255) / 256), dim3(256), 0, st, (const uint8_t*) d_replies, nr, s->po.mg, s->p_r0);
 		hipLaunchKernelGGL(k_resolve_add, dim3((nr + 3) / 4), dim3(256), 0, st, (const uint8_t*) d_replies, nr, s->p_r0, s->k, s->p_fl, s->p_S);
@@ -3552,6 +3668,7 @@ extern "C" int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t 
 	PersistAlloc db(c);
 	SurvivorsG& a = s->all_sv;
 	a.n = (u32) ns_total;
+	a.n_real = a.n;
 	s->phase = 4;
 	if (!ns_total) return VDJX_OK;
 	if (!d_surv_all || !d_in_first || !d_ucnt || !d_ufirst) { vdjx_set_error("vdjx_shard_edges: NULL buffer"); return VDJX_EINVAL; }
