@@ -772,7 +772,8 @@ def main():
     if os.environ.get("VDJX_LAPS"):          # (diagnostic: host-side microseconds per step inside the scorer calls, vdjx_common.h vdjx_laps)
         names = ("plan_issue", "plan_wait", "ws_cover_wait", "me_key", "me_plan", "me_kernel_wait", "me_second_call", "me_prev_copy_wait", "me_copy_issue")
         laps = {n_: round(ctx.stat("us_" + n_) / (args.warmup + args.steps), 1) for n_ in names}
-    stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_hits_distinct", "window_pairs", "window_work_items", "map_hits", "root_dp_items", "recount_items", "recount_instances", "gated_instances")}
+    stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_hits_distinct", "window_pairs", "window_work_items", "map_hits", "root_dp_items", "recount_items", "recount_instances", "gated_instances",
+                                             "pool_symmetric", "kmer_build_sym", "kmer_build_sym_walk", "kmer_build_sym_walk_retries", "kmer_build_shadows")}
     stats["mapped_pairs"] = int(state["last"]["pairs"].shape[0]) if state.get("last") else 0
     stats["window_pairs_entries"] = ctx.stat("window_pairs_entries")
     for n_ in ("group_hits_distinct", "group_overflows", "group_classes", "group_queued", "group_clocks_sum", "group_clocks_max"):      # k_group_pairs: what the groups of windows shared

@@ -110,6 +110,10 @@ def test_config2_and_3_10M_pairs_vs_oracle_digests(case):
     ids, ok = ctx.root_score_graph(g, d["mrs"])
     assert ids.shape[0] == d["n_roots"] and sha(ids.astype(np.uint32)) == d["root_ids"]
     assert int(ok.sum()) == d["roots_ok"] and sha(ok.astype(np.uint8)) == d["root_verdicts"]
+    # the pool is made of couples (record, reverse complement) and k is odd: both phases took the form that exploits it, and the mirrored
+    # walk never had to be done again over every record
+    assert ctx.stat("kmer_build_sym") == 1 and ctx.stat("kmer_build_sym_walk") == 1 and ctx.stat("kmer_build_sym_walk_retries") == 0
+    assert ctx.stat("kmer_build_shadows") > 0          # k-mers whose own quality test failed and whose reverse complement's passed: no nodes
     g.free()
 
 
@@ -217,7 +221,14 @@ def test_40M_pairs_one_gpu_beyond_2_31_instances():
     empty = torch.zeros((0, big.shape[1]), dtype=torch.uint8, device=big.device)
     p4 = ctx.pool_load_device(big.data_ptr(), big.shape[0], 0, 0, pool.rl)
     assert p4.n_records * 16 > 2 ** 31
+    ctx.profile(True)
+    ctx.profile_reset()
     g = ctx.kmer_build(p4, d["k"], 4 * d["mf"], d["mq"])
+    pr = ctx.profile_get()
+    ctx.profile(False)
+    # 400 M gated instances = 200 M tuples (the pool is made of couples: one tuple per pair of mirrored instances): more than 4,096 per
+    # bucket of the histogram's 2^15, so the buckets were cut a second time before the reduce kernel's table could fill
+    assert ctx.stat("kmer_build_sym") == 1 and ctx.stat("kmer_build_sym_walk") == 1 and "k_seg_hist" in pr, sorted(pr)
     p4.free()
     del big, empty
     torch.cuda.empty_cache()
@@ -355,7 +366,11 @@ def test_20M_pairs_buckets_are_cut_before_the_table_fills():
     g2 = ctx.kmer_build(p, 35, 3, 90)
     pr = ctx.profile_get()
     assert g.n == g2.n and g.n > 1_500_000
-    assert "k_seg_hist" in pr, sorted(pr)                                  # the buckets were cut a second time
+    # the buckets are cut a second time exactly when the 2^15 the histogram has would hold more than 4,096 tuples each.  (Round 5: a pool
+    # made of couples moves half the tuples -- 100 M at 20 M pairs --, so THIS pool no longer needs the second cut; the 40 M-pair test
+    # above pins it)
+    tuples = ctx.stat("gated_instances") // (2 if ctx.stat("kmer_build_sym") else 1)
+    assert ("k_seg_hist" in pr) == (tuples // 32768 > 4096), (sorted(pr), tuples)
     ms = pr["k_gated_reduce"][0] / max(pr["k_gated_reduce"][1], 1)
     assert ms < 15.0, f"k_gated_reduce took {ms:.1f} ms at 20 M pairs"
     p.free()

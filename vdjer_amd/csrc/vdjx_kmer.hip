@@ -242,8 +242,7 @@ __device__ inline u64 vdjx_clean_offsets(u64 bad, int k, int P) {
 // The offset of a listed instance differs from lane to lane: the k-mer is cut out with vdjx_kmer_at_lane (vdjx_common.h: the plain
 // 128-bit shift by a per-lane amount gave wrong k-mers on gfx950 when the amounts of a wave lay on both sides of 64).
 #define GL_WAVE_BYTES 3072u         // per wave: 64 x 16-byte packed bases, 1024 x 2-byte entries (lane << 6 | offset)
-#define GL_WAVE_BYTES_SYM 3072u     // SYM: 64 x 2 x 16 bytes (a lane's record and its reverse-complement record), then 512 entries: 8 offsets at a
-                                    // time instead of 16, so that the histogram keeps its 2^15 counters beside the eight waves' staging
+#define GL_WAVE_BYTES_SYM GL_WAVE_BYTES
 
 // long reads (W words per read, vdjx_pool): a lane's record in LDS is W + 2 words (two zero words behind it: the k-mer extraction
 // reads three words from the k-mer's first), entries are lane << 8 | offset
@@ -278,11 +277,11 @@ __device__ inline void stage_row_long(u64* row, const u64* __restrict__ bases, s
 
 // K2a': bucket sizes over the gated instances (include_kmer, A2:240-259: no 'N', every Phred >= 20), listed densely per wave
 // the canonical side of a couple's instance (vdjx_pool::sym): k-mer X at offset o of record 2i is rc(X) at offset rl-k-o of record
-// 2i+1 -- which the pool holds packed, so rc(X) is cut out like X; the smaller of the two is the key (k odd: they differ)
-__device__ inline bool sym_canonical(const ulonglong2 f, const ulonglong2 r, int rl, int k, int o, u64& khi, u64& klo) {
+// 2i+1; the smaller of the two is the key (k odd: they differ)
+__device__ inline bool sym_canonical(const ulonglong2 f, int rl, int k, int o, u64& khi, u64& klo) {
 	u64 xh, xl, yh, yl;
 	vdjx_kmer_at_lane(f.x, f.y, rl, k, o, xh, xl);
-	vdjx_kmer_at_lane(r.x, r.y, rl, k, rl - k - o, yh, yl);
+	vdjx_kmer_rc(xh, xl, k, yh, yl);             // (what the couple's second record holds at offset rl - k - o: computed, not fetched -- 16 bytes per couple less to read)
 	const bool flip = yh < xh || (yh == xh && yl < xl);
 	khi = flip ? yh : xh;
 	klo = flip ? yl : xl;
@@ -310,7 +309,7 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 	uint8_t* wv = (uint8_t*) (hist + NB) + (threadIdx.x >> 6) * (LONG ? GL_WAVE_BYTES_LONG : SYM ? GL_WAVE_BYTES_SYM : GL_WAVE_BYTES);
 	ulonglong2* wb = (ulonglong2*) wv;
 	u64* wrow = (u64*) wv;
-	uint16_t* wl = (uint16_t*) (wv + (LONG ? 64u * GL_ROW_LONG * 8u : SYM ? 2048u : 1024u));
+	uint16_t* wl = (uint16_t*) (wv + (LONG ? 64u * GL_ROW_LONG * 8u : 1024u));
 	const u32 lane = threadIdx.x & 63u;
 	const size_t r0 = (size_t) blockIdx.x * rpb;
 	const size_t r1 = r0 + rpb < R ? r0 + rpb : R;
@@ -321,20 +320,15 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 		vdjx_mask3 bad{~0ull, ~0ull, ~0ull};
 		if (r < r1) {
 			if (LONG) { bad = load_gate3(lowq, r); stage_row_long(wrow + lane * GL_ROW_LONG, bases, r); }
-			else if (SYM) {
-				const GateView v = load_gate(bases, lowq, 2 * r);
-				G = vdjx_clean_offsets(v.bad, k, P);
-				wb[2 * lane] = make_ulonglong2(v.bhi, v.blo);
-				wb[2 * lane + 1] = ((const ulonglong2*) bases)[2 * r + 1];
-			} else {
-				const GateView v = load_gate(bases, lowq, r);
+			else {
+				const GateView v = load_gate(bases, lowq, SYM ? 2 * r : r);
 				G = vdjx_clean_offsets(v.bad, k, P);
 				wb[lane] = make_ulonglong2(v.bhi, v.blo);
 			}
 		}
-		constexpr int LSTEP = SYM ? 8 : 16;                                 // offsets listed per trip (the list's room: GL_WAVE_BYTES*)
+		constexpr int LSTEP = 16;                                           // offsets listed per trip (the list's room: GL_WAVE_BYTES)
 		for (int ob = 0; ob < P; ob += LSTEP) {
-			const u32 g = LONG ? vdjx_clean16(bad, ob, k, P) : (u32) (G >> ob) & (SYM ? 0xFFu : 0xFFFFu);
+			const u32 g = LONG ? vdjx_clean16(bad, ob, k, P) : (u32) (G >> ob) & 0xFFFFu;
 			const u32 c = (u32) __popc(g);
 			const u32 incl = (u32) vdjx_wave_scan_add((int) c);
 			const u32 total = (u32) __builtin_amdgcn_readlane((int) incl, 63);
@@ -348,7 +342,7 @@ __global__ __launch_bounds__(HIST_THREADS) void k_gated_hist(const u64* __restri
 				const u32 e = wl[i];
 				u64 khi, klo;
 				if (LONG) vdjx_kmer_at_words(wrow + (e >> 8) * GL_ROW_LONG, k, (int) (e & 255u), khi, klo);
-				else if (SYM) (void) sym_canonical(wb[2 * (e >> 6)], wb[2 * (e >> 6) + 1], rl, k, (int) (e & 63u), khi, klo);
+				else if (SYM) (void) sym_canonical(wb[e >> 6], rl, k, (int) (e & 63u), khi, klo);
 				else {
 					const ulonglong2 bb = wb[e >> 6];
 					vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) (e & 63u), khi, klo);
@@ -391,7 +385,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 	uint8_t* wv = smem + wave * (LONG ? GL_WAVE_BYTES_LONG : SYM ? GL_WAVE_BYTES_SYM : GL_WAVE_BYTES);
 	ulonglong2* wb = (ulonglong2*) wv;
 	u64* wrow = (u64*) wv;
-	uint16_t* wl = (uint16_t*) (wv + (LONG ? 64u * GL_ROW_LONG * 8u : SYM ? 2048u : 1024u));
+	uint16_t* wl = (uint16_t*) (wv + (LONG ? 64u * GL_ROW_LONG * 8u : 1024u));
 	const size_t r0 = (size_t) blockIdx.x * rpb;            // (SYM: R, rpb, rr and the descriptors count COUPLES of records)
 	const size_t r1 = r0 + rpb < R ? r0 + rpb : R;
 	size_t rs = r0;
@@ -406,21 +400,16 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 			vdjx_mask3 bad{~0ull, ~0ull, ~0ull};
 			if (r < re) {
 				if (LONG) { bad = load_gate3(lowq, r); stage_row_long(wrow + lane * GL_ROW_LONG, bases, r); }
-				else if (SYM) {
-					const GateView v = load_gate(bases, lowq, 2 * r);
-					G = vdjx_clean_offsets(v.bad, k, P);
-					wb[2 * lane] = make_ulonglong2(v.bhi, v.blo);
-					wb[2 * lane + 1] = ((const ulonglong2*) bases)[2 * r + 1];
-				} else {
-					const GateView v = load_gate(bases, lowq, r);
+				else {
+					const GateView v = load_gate(bases, lowq, SYM ? 2 * r : r);
 					G = vdjx_clean_offsets(v.bad, k, P);
 					wb[lane] = make_ulonglong2(v.bhi, v.blo);
 				}
 			}
 			const u32 loc0 = (u32) (rb - rs) + wave * 64u;                // this wave's first record in the round
-			constexpr int LSTEP = SYM ? 8 : 16;
+			constexpr int LSTEP = 16;
 			for (int ob = 0; ob < P; ob += LSTEP) {
-				const u32 g = LONG ? vdjx_clean16(bad, ob, k, P) : (u32) (G >> ob) & (SYM ? 0xFFu : 0xFFFFu);
+				const u32 g = LONG ? vdjx_clean16(bad, ob, k, P) : (u32) (G >> ob) & 0xFFFFu;
 				const u32 c = (u32) __popc(g);
 				const u32 incl = (u32) vdjx_wave_scan_add((int) c);
 				const u32 total = (u32) __builtin_amdgcn_readlane((int) incl, 63);
@@ -435,7 +424,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 					const u32 e = wl[i];
 					u64 khi, klo;
 					if (LONG) vdjx_kmer_at_words(wrow + (e >> 8) * GL_ROW_LONG, k, (int) (e & 255u), khi, klo);
-					else if (SYM) (void) sym_canonical(wb[2 * (e >> 6)], wb[2 * (e >> 6) + 1], rl, k, (int) (e & 63u), khi, klo);
+					else if (SYM) (void) sym_canonical(wb[e >> 6], rl, k, (int) (e & 63u), khi, klo);
 					else {
 						const ulonglong2 bb = wb[e >> 6];
 						vdjx_kmer_at_lane(bb.x, bb.y, rl, k, (int) (e & 63u), khi, klo);
@@ -469,7 +458,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_part_records_g(const u64* __re
 			if (LONG) vdjx_kmer_at_words(bases + r * VDJX_LONG_W, k, (int) o, khi, klo);      // (two words past the last record are readable: pool_alloc)
 			else if (SYM) {
 				// the tuple of the canonical side: this instance, or its mirror in the couple's second record
-				const bool flip = sym_canonical(((const ulonglong2*) bases)[2 * r], ((const ulonglong2*) bases)[2 * r + 1], rl, k, (int) o, khi, klo);
+				const bool flip = sym_canonical(((const ulonglong2*) bases)[2 * r], rl, k, (int) o, khi, klo);
 				inst = flip ? ((rec_base + 2 * (u64) r + 1) << OB) | (u64) (rl - k - (int) o) : ((rec_base + 2 * (u64) r) << OB) | (u64) o;
 			} else {
 				const ulonglong2 bb = ((const ulonglong2*) bases)[r];
@@ -1702,7 +1691,11 @@ __global__ void k_table_remap(ulonglong2* __restrict__ slots, u32 n_slots, const
 // per block of 16 survivors (new numbering), survivor j of the block: linw bit 15-j: p + 1 is a successor; bit 31-j: there are
 // other successors (look into succ[]); bits 32 + 2*(15-j): the last base of p + 1 -- first survivor most significant, like the
 // bases of a packed read -- and 2 bits per survivor in fbw, the first base of its k-mer (the name of the in-edge p -> p + 1 at its head)
-__global__ void k_chain_words(const u32* __restrict__ succ, const ulonglong2* __restrict__ skey, u32 n, int k, u64* __restrict__ linw, u32* __restrict__ fbw) {
+// partner (SYM walk, else null): p + 1 counts as "the successor along the chain" only if the step is a mirror image too, partner[p + 1]
+// == partner[p] - 1 -- true of every chain link (k_succ_links2), but p + 1 may also be the head of the NEXT chain that happens to be a
+// successor of p: the walk may run on across such a seam, its mirror image may not.
+__global__ void k_chain_words(const u32* __restrict__ succ, const ulonglong2* __restrict__ skey, u32 n, int k, u64* __restrict__ linw, u32* __restrict__ fbw,
+                              const u32* __restrict__ partner) {
 	const u32 p = blockIdx.x * blockDim.x + threadIdx.x;      // (whole blocks of 16 lanes: nobody returns before the shuffles)
 	const u32 j = p & 15u;
 	u64 w = 0;
@@ -1710,8 +1703,9 @@ __global__ void k_chain_words(const u32* __restrict__ succ, const ulonglong2* __
 	if (p < n) {
 		const uint4 s = *(const uint4*) &succ[(size_t) p * 4];
 		const u32 sv[4] = {s.x, s.y, s.z, s.w};
+		const bool mirrored = !partner || (p + 1 < n && partner[p] != NONE32 && partner[p + 1] == partner[p] - 1u);
 		for (u32 b = 0; b < 4; b++) if (sv[b] != NONE32) {
-			if (sv[b] == p + 1) w |= (1ull << (15u - j)) | ((u64) b << (32u + 2u * (15u - j)));
+			if (sv[b] == p + 1 && mirrored) w |= (1ull << (15u - j)) | ((u64) b << (32u + 2u * (15u - j)));
 			else w |= 1ull << (31u - j);
 		}
 		const ulonglong2 kk = skey[p];
@@ -2691,6 +2685,7 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 	for (int i = 0; i < 64; i++) sv->ndist += spread[i * 16];
 	sv->n = ns;
 	sv->n_real = sym ? tail[2] : ns;             // (sym: the set is closed under reverse complement; the rest are shadows, GC_SHADOW)
+	c->stats["kmer_build_shadows"] = ns - sv->n_real;
 	return VDJX_OK;
 }
 
@@ -2777,7 +2772,8 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 		hipLaunchKernelGGL(k_chain_place, gs, bs, 0, st, pd, coff, ns, newidx);
 		hipLaunchKernelGGL(k_chain_permute, gs, bs, 0, st, newidx, ns, sv.lo, sv.hi, sv.gcnt, sv.gfirst, succ0, lo2, hi2, gcnt2, gfirst2, skey, succ);
 		hipLaunchKernelGGL(k_table_remap, dim3(tmask / 256 + 1), bs, 0, st, table, tmask + 1, newidx);
-		hipLaunchKernelGGL(k_chain_words, gs, bs, 0, st, succ, skey, ns, k, linw, fbw);
+		if (sym_walk) hipLaunchKernelGGL(k_partner, gs, bs, 0, st, tb, ns, k, partner);          // (the table answers in chain order now)
+		hipLaunchKernelGGL(k_chain_words, gs, bs, 0, st, succ, skey, ns, k, linw, fbw, (const u32*) partner);
 	}
 	dbg_sync(c, "k_chain_order");
 	if (getenv("VDJX_SYNC_DEBUG")) {              // the new numbering is a permutation, and every key finds itself
@@ -2861,7 +2857,6 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	HIP_TRY(hipMemsetAsync(g_cursor, 0, 32 + (size_t) n_ranges_p * 4, st));
 	if (sym_walk) {          // the survivors' reverse complements, and whether the chains are mirror images (g_err[3]: read with the other status words)
 		vdjx_prof_scope ps(c, "k_chain_order");
-		hipLaunchKernelGGL(k_partner, gs, bs, 0, st, tb, ns, k, partner);
 		hipLaunchKernelGGL(k_partner_check, gs, bs, 0, st, partner, linw, ns, g_err + 3);
 	}
 	const bool lng = pool->W > 2;
