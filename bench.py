@@ -22,6 +22,7 @@ of the measured path.
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import subprocess
@@ -592,6 +593,9 @@ def main():
         if from_host:      # end-to-end variant: the reads start in page-locked HOST memory (forward records only) and cross PCIe;
             # the NEXT step's pool is uploaded and packed on the copy stream while this step computes (two pools in flight)
             def upload():
+                if host_fwd.get("packed"):
+                    return ctx.pool_load_packed(host_fwd["pri"].data_ptr(), host_fwd["sec"].data_ptr(), rl, host_fwd["pri"].shape[0],
+                                                host_fwd["sec"].shape[0], wait=False)
                 return ctx.pool_load_forward(host_fwd["pri"].data_ptr(), host_fwd["sec"].data_ptr(), rl, host_fwd["pri"].shape[0],
                                              host_fwd["sec"].shape[0], wait=False)
             p = host_fwd.pop("next", None) or upload()
@@ -721,34 +725,55 @@ def main():
     # complement records are derived on the chip) in page-locked memory, uploaded in chunks beside the packing
     e2e = None
     if world == 1 and not args.no_e2e:
-        host_fwd["pri"] = torch.empty((d_pri.shape[0] // 2, d_pri.shape[1]), dtype=torch.uint8, pin_memory=True)
-        host_fwd["sec"] = torch.empty((d_sec.shape[0] // 2, d_sec.shape[1]), dtype=torch.uint8, pin_memory=True)
-        host_fwd["pri"].copy_(d_pri[0::2])
-        host_fwd["sec"].copy_(d_sec[0::2])
-        torch.cuda.synchronize()
-        n_e2e = max(2, min(args.steps, 8))
-        wall_keep = dict(wall)
-        step(True)
-        wall.clear()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(n_e2e):
+        def host_fed(packed: bool):
+            """the step of `value` fed from page-locked HOST memory: the reads as extracted (forward records only; the reverse complement
+            records are derived on the chip), as 101-byte ASCII records or in the packed host format (vdjx_pool_load_packed: 64 bytes per read)"""
+            asc = [torch.empty((d_.shape[0] // 2, d_.shape[1]), dtype=torch.uint8, pin_memory=True) for d_ in (d_pri, d_sec)]
+            asc[0].copy_(d_pri[0::2])
+            asc[1].copy_(d_sec[0::2])
+            torch.cuda.synchronize()
+            if packed:
+                S = ctx.packed_read_bytes(rl)
+                pk = [torch.empty((a_.shape[0], S), dtype=torch.uint8, pin_memory=True) for a_ in asc]
+                t_pk = time.perf_counter()
+                for a_, p_ in zip(asc, pk):
+                    api.check(ctx.L.vdjx_pack_reads(ctypes.c_void_p(a_.data_ptr()), a_.shape[0], rl, ctypes.c_void_p(p_.data_ptr())), "vdjx_pack_reads")
+                t_pk = time.perf_counter() - t_pk
+                host_fwd["pri"], host_fwd["sec"] = pk
+                del asc
+            else:
+                t_pk = None
+                host_fwd["pri"], host_fwd["sec"] = asc
+            host_fwd["packed"] = packed
+            n_e2e = max(2, min(args.steps, 8))
             step(True)
-        ctx.map_emit_wait()
-        barrier()
-        dte = time.perf_counter() - t1
-        up_bytes = (host_fwd["pri"].numel() + host_fwd["sec"].numel())
-        e2e = {"value": round(args.pairs * n_e2e / dte / 1e6, 4), "unit": "M paired-reads/s", "ms_per_step": round(dte / n_e2e * 1e3, 3), "steps": n_e2e,
-               "upload_bytes_per_step": int(up_bytes), "pool_load_ms_per_step": round(wall.get("pool_pack", 0.0) / n_e2e * 1e3, 3),
-               "note": "host (page-locked) forward reads -> results: vdjx_pool_load_forward_begin uploads the NEXT step's pool (202 B per pair, "
-                       "256 K-record chunks) and packs it on the copy stream while this step computes; everything else as in `value`"}
-        wall.clear()
+            wall.clear()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n_e2e):
+                step(True)
+            ctx.map_emit_wait()
+            barrier()
+            dte = time.perf_counter() - t1
+            up_bytes = (host_fwd["pri"].numel() + host_fwd["sec"].numel())
+            res = {"value": round(args.pairs * n_e2e / dte / 1e6, 4), "unit": "M paired-reads/s", "ms_per_step": round(dte / n_e2e * 1e3, 3), "steps": n_e2e,
+                   "upload_bytes_per_step": int(up_bytes), "upload_bytes_per_pair": round(up_bytes / args.pairs, 1), "upload_GBps": round(up_bytes / (dte / n_e2e) / 1e9, 1),
+                   "pool_load_ms_per_step": round(wall.get("pool_pack", 0.0) / n_e2e * 1e3, 3),
+                   "host_pack_s_one_core": round(t_pk, 2) if t_pk is not None else None}
+            wall.clear()
+            nxt = host_fwd.pop("next", None)
+            if nxt is not None:
+                nxt.wait()
+                nxt.free()
+            del host_fwd["pri"], host_fwd["sec"]
+            return res
+        wall_keep = dict(wall)
+        e2e = host_fed(True)
+        e2e["note"] = ("host (page-locked) forward reads in the PACKED host format (vdjx_pool_load_packed_begin: 2-bit bases + quality bytes, 64 B per "
+                       "50 bp read) -> results: the NEXT step's pool is uploaded in 256 K-read chunks and unpacked on the copy stream while this step "
+                       "computes; everything else as in `value`.  ascii_records: the same with add_to_buffer's 101-byte records (vdjx_pool_load_forward_begin)")
+        e2e["ascii_records"] = host_fed(False)
         wall.update(wall_keep)
-        nxt = host_fwd.pop("next", None)
-        if nxt is not None:
-            nxt.wait()
-            nxt.free()
-        del host_fwd["pri"], host_fwd["sec"]
     # ---- the same step with the read index of its pool built inside it (row a-8's index, quick_map3.c:126-149: the reference
     # builds it during extraction, bam_read.c:228,243, once per pool -- like a command line that sees every pool once)
     with_index = None

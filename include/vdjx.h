@@ -75,6 +75,18 @@ int vdjx_pool_load_forward(vdjx_ctx* ctx, const uint8_t* primary_reads, size_t n
 int vdjx_pool_load_forward_begin(vdjx_ctx* ctx, const uint8_t* primary_reads, size_t n_primary_reads,
                                  const uint8_t* secondary_reads, size_t n_secondary_reads, int rl, vdjx_pool** out);
 int vdjx_pool_wait(vdjx_pool* pool);
+/* The reads in a PACKED host format, for callers that can produce it (an extraction that converts BAM's 4-bit bases itself): per read
+ * vdjx_packed_read_bytes(rl) bytes -- ceil(rl/4) bytes of 2-bit bases (A0 T1 C2 G3 as seq_to_kmer.c:6-29, the first base in the top two
+ * bits of byte 0, code 0 for a base that is not ACGT), then rl quality bytes (Phred+33, bit 7 set where the base is not ACGT), zero
+ * padding to a multiple of 16: 64 bytes for a 50 bp read where add_to_buffer's record (bam_read.c:219-230) has 101 -- 128 bytes per
+ * pair over PCIe instead of 202.  Reads of up to 64 bases.  Otherwise exactly vdjx_pool_load_forward[_begin]: record 2i is read i,
+ * record 2i+1 its reverse complement with reversed qualities.  vdjx_pack_reads converts n ASCII records on the host (plain C). */
+size_t vdjx_packed_read_bytes(int rl);
+int vdjx_pack_reads(const uint8_t* ascii_reads, size_t n, int rl, uint8_t* out_packed);
+int vdjx_pool_load_packed(vdjx_ctx* ctx, const uint8_t* primary_reads, size_t n_primary_reads,
+                          const uint8_t* secondary_reads, size_t n_secondary_reads, int rl, vdjx_pool** out);
+int vdjx_pool_load_packed_begin(vdjx_ctx* ctx, const uint8_t* primary_reads, size_t n_primary_reads,
+                                const uint8_t* secondary_reads, size_t n_secondary_reads, int rl, vdjx_pool** out);
 /* same, ASCII pools already resident in device memory (16-byte aligned).  The two buffers must stay valid and unchanged until
  * vdjx_pool_free: bases and masks are packed, but the quality characters are NOT copied -- the few k-mers whose quality sums
  * matter (count below 1 + ceil(mq/20), A2:454-465) read them from the records where they lie (a third of the packing's bytes). */

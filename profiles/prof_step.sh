@@ -13,6 +13,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- p
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --output-format csv -d $OUT/sq -- python3 $ARGS > /dev/null 2> $OUT/sq.err
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc -- python3 $ARGS > /dev/null 2> $OUT/tcc.err
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --output-format csv -d $OUT/inst -- python3 $ARGS > /dev/null 2> $OUT/inst.err
+rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum TCC_EA0_RDREQ_DRAM_sum --output-format csv -d $OUT/ea -- python3 $ARGS > /dev/null 2> $OUT/ea.err
 python3 profiles/summarize_pmc.py $OUT > $OUT/summary.json
 # the raw per-dispatch tables are large: keep the per-kernel statistics and the summary
 find $OUT -name "*counter_collection.csv" -delete

@@ -1,7 +1,20 @@
 #!/usr/bin/env python3
 """Per-kernel medians of the rocprofv3 PMC passes made by profiles/prof_step.sh -> JSON on stdout.
-hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KB and on gfx950 FETCH_SIZE counts half of the
-streamed read bytes (/opt/skills/guides/MI355X_MICROARCH.md, "HBM")."""
+
+What the traffic figure is (round 5; calibrated on this stack with kernels of known byte counts, profiles/micro/ea_calib.hip ->
+profiles/r05_ea_calib/summary.json):
+  * FETCH_SIZE = 64 B x TCC_EA0_RDREQ (TCC_BUBBLE, "128-byte requests", and TCC_EA0_RDREQ_32B both read 0 on gfx950).
+  * A wide coalesced stream (16 B per lane) makes ONE request per 128 bytes: FETCH_SIZE shows HALF its bytes (4 GiB read, 2 GiB
+    counted) -- the guide's x2 (/opt/skills/guides/MI355X_MICROARCH.md, "HBM").
+  * A random 4-, 8- or 16-byte read of a table larger than the caches makes ONE request per access, 67.1-67.8 M requests for 64 Mi
+    accesses at 1.39-1.52 ms per launch whatever the width: at 64 B each that is 2.9 TB/s of random fills, at 128 B it would be
+    5.7 TB/s -- more than the same chip streams (5.2 TB/s, same run): they are 64-byte requests and FETCH_SIZE is right as it stands.
+  * So the x2 belongs to the coalesced share only.  The counters cannot tell the two kinds apart (one request either way), the
+    kernel's source can: fabric_bytes = FETCH + min(FETCH, known coalesced input bytes / 2) + WRITE, with the coalesced input of every
+    kernel stated below (STREAM_IN); fabric_bytes_max = 2 x FETCH + WRITE (round 4's figure) is the bound if everything streamed.
+  * Infinity-Cache hits cannot be separated from HBM: TCC_EA0_RDREQ_DRAM == TCC_EA0_RDREQ for every kernel, and a 64 MiB buffer
+    streamed three times in a row shows the same 524,360 requests "to DRAM" each time.  The figure is traffic between the L2s and
+    the memory side (fabric), an upper bound on HBM bytes."""
 import collections
 import csv
 import glob
@@ -19,10 +32,35 @@ def med(v):
     return v[len(v) // 2] if v else None
 
 
+def stream_in(bench_line):
+    """coalesced (16 B per lane, consecutive lanes on consecutive addresses) input bytes per launch of the kernels that stream, from the
+    counts of the run itself"""
+    if not bench_line:
+        return {}
+    b = bench_line
+    pairs = b["config"]["pairs_per_gpu"]
+    st = b.get("scorer_stats", {})
+    sym, symw = st.get("kmer_build_sym", 0), st.get("kmer_build_sym_walk", 0)
+    tuples = st.get("gated_instances", 0) / (2 if sym else 1)
+    items = st.get("recount_items", 0)
+    recs = 4 * pairs
+    gate = 24 * (recs // 2 if sym else recs)                    # bases (16) + gate mask (8) of every record a gating kernel looks at
+    return {"k_pool_pack": 101 * recs / 2,                       # (two launches per step: primary, secondary; the median launch is weighed as half)
+            "k_gated_hist": gate, "k_part_records_g": gate + 16 * tuples, "k_part_tuples_g": 16 * tuples, "k_seg_hist_g": 16 * tuples,
+            "k_gated_reduce": 16 * tuples, "k_gated_local": 16 * tuples, "k_walk_items": 24 * (recs // 2 if symw else recs),
+            "k_part_items": 8 * items, "k_recount": 8 * items, "k_compact_partials": 0, "k_bucket_merge": 0}
+
+
 def main():
     out = sys.argv[1]
+    bench_line = None
+    try:
+        bench_line = json.loads(open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001
+        pass
+    STREAM_IN = stream_in(bench_line)
     res = collections.defaultdict(dict)
-    for grp in ("fetch", "write", "sq", "tcc", "inst"):
+    for grp in ("fetch", "write", "sq", "tcc", "inst", "ea"):
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         for f in glob.glob(os.path.join(out, grp, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
@@ -37,7 +75,13 @@ def main():
             stats[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "total_ns": float(r["TotalDurationNs"])}
     for k, d in res.items():
         if "FETCH_SIZE" in d:
-            d["hbm_bytes"] = int((2 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0.0)) * 1024)
+            fetch, write = d["FETCH_SIZE"] * 1024, d.get("WRITE_SIZE", 0.0) * 1024
+            stream = STREAM_IN.get(k)
+            d["fabric_bytes_max"] = int(2 * fetch + write)              # everything taken as coalesced (round 4's figure)
+            d["stream_in_bytes"] = None if stream is None else int(stream)
+            # the x2 on the coalesced share only (see the module text); a kernel without a stated stream keeps the bound
+            d["hbm_bytes"] = int(fetch + min(fetch, stream / 2) + write) if stream is not None else int(2 * fetch + write)
+            d["traffic_rule"] = "FETCH + min(FETCH, stream_in/2) + WRITE" if stream is not None else "2*FETCH + WRITE (no stated stream: bound)"
         if d.get("TCC_HIT_sum") is not None and d.get("TCC_MISS_sum") is not None and d["TCC_HIT_sum"] + d["TCC_MISS_sum"] > 0:
             d["l2_hit"] = round(d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"]), 4)
         if d.get("SQ_WAVE_CYCLES"):

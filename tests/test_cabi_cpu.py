@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,3 +45,23 @@ def test_struct_layouts_match_header():
     from vdjer_amd import _lib
     assert ctypes.sizeof(_lib.Pair) == 20
     assert ctypes.sizeof(_lib.CovParams) == 28
+
+
+def test_pack_reads_host_format():
+    """vdjx_pack_reads (plain C, no GPU): ASCII records -> the packed host format of vdjx_pool_load_packed: ceil(rl/4) bytes of 2-bit
+    bases (A0 T1 C2 G3, seq_to_kmer.c:6-29; first base in the top bits of byte 0; code 0 where the base is not ACGT), then rl quality
+    bytes (Phred+33, bit 7 = not ACGT), zero padding to a multiple of 16"""
+    from vdjer_amd import api
+    assert [api.Context.packed_read_bytes(rl) for rl in (50, 51, 52, 64, 36)] == [64, 64, 80, 80, 48]
+    assert api.Context.packed_read_bytes(65) == 0                      # reads of more than 64 bases: vdjx_pool_load_forward
+    rl = 10
+    rec = np.frombuffer(b"0" + b"ACGTNRTTCA" + b"I5#II+IIII", np.uint8)
+    out = api.Context.pack_reads(rec, rl)
+    assert out.shape == (1, 16)
+    # A0 C2 G3 T1 | N0 R0 T1 T1 | C2 A0 -- --
+    assert out[0, :3].tolist() == [0b00101101, 0b00000101, 0b10000000]
+    q = out[0, 3:13]
+    assert (q & 0x7F).tobytes() == b"I5#II+IIII" and (q >> 7).tolist() == [0, 0, 0, 0, 1, 1, 0, 0, 0, 0]
+    assert not out[0, 13:].any()
+    with pytest.raises(Exception):
+        api.Context.pack_reads(np.frombuffer(b"1" + b"A" * 10 + b"I" * 10, np.uint8), rl)

@@ -591,6 +591,51 @@ def test_sharded_build_over_shares_by_pair(ctx, world, k, mf, mq, rl, base):
         np.testing.assert_array_equal(g.kmers, ref.kmers)
 
 
+@pytest.mark.parametrize("rl", [50, 36, 51, 52, 64])
+def test_packed_host_format_equals_the_forward_load(ctx, rl):
+    """vdjx_pool_load_packed (2-bit bases + quality bytes, 64 bytes per 50 bp read over PCIe instead of 101) makes the pool that
+    vdjx_pool_load_forward makes of the same reads' ASCII records -- and that vdjx_pool_load makes of add_to_buffer's full buffers
+    (bam_read.c:206-244): same graph (k-mers, counts, first sights, edges: bases, masks AND quality rows of both records of every
+    couple take part), same SAM text (sequences and qualities of both orientations), incl. N, other IUPAC codes and low qualities"""
+    from oracle import oracle
+    from vdjer_amd import api, synth
+    rep = synth.make_repertoire(5, seed=91)
+    pool = synth.make_reads(rep, 5000, noise_frac=0.25, seed=92, rl=rl, err=0.004, n_rate=0.004)
+    pri, sec = pool.primary.copy(), pool.secondary.copy()
+    for a in (pri, sec):                                        # a few IUPAC codes other than N (packed as N; both records of the couple)
+        for r in range(0, a.shape[0] - 1, 97 * 2):
+            a[r, 1 + 7] = ord("R")
+            a[r + 1, 1 + rl - 1 - 7] = ord("Y")
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    ctx.anchor_sets_load(vc, jc)
+    k = min(35, rl - 8) | 1
+    graphs, texts = [], []
+    names = [f"r{i}" for i in range(pool.n_pairs)]
+    wins = [w for w in rep.windows() if w]
+    for how in ("full", "forward", "packed"):
+        if how == "full":
+            p = ctx.pool_load(pri, sec, rl)
+        elif how == "forward":
+            p = ctx.pool_load_forward(pri[0::2], sec[0::2], rl)
+        else:
+            p = ctx.pool_load_packed(api.Context.pack_reads(pri[0::2], rl), api.Context.pack_reads(sec[0::2], rl), rl)
+        assert ctx.stat("pool_symmetric") == 1
+        g = ctx.kmer_build(p, k, 2, 60)
+        graphs.append(g)
+        ctx.read_index_build(p, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+        ctx.sam_names_load(names)
+        contigs = [w[51:411] for w in wins]
+        texts.append(ctx.sam_text_device(contigs, [f"c{i}" for i in range(len(contigs))]))
+        p.free()
+    assert len(texts[0]) > 10000
+    for g in graphs[1:]:
+        assert g.n == graphs[0].n > 100 and g.pre_nodes == graphs[0].pre_nodes
+        for f in ("first_inst", "freq", "gated_count", "has_v", "has_j", "to_ids", "from_ids", "kmers"):
+            np.testing.assert_array_equal(getattr(g, f), getattr(graphs[0], f), err_msg=f)
+    assert texts[1] == texts[0] and texts[2] == texts[0]
+
+
 def test_all_gated_all_distinct_overflows_the_lds_table(ctx):
     """High-quality reads with 80 % noise: nearly every instance is gated and distinct, so buckets hold more
     distinct k-mers than one LDS table pass takes and the sub-pass split / restart path runs."""

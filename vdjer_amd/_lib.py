@@ -14,7 +14,7 @@ _lib = None
 # every symbol include/vdjx.h declares
 SYMBOLS = [
     "vdjx_last_error", "vdjx_version", "vdjx_init", "vdjx_shutdown", "vdjx_sync", "vdjx_trim", "vdjx_read_index_drop", "vdjx_device_copy",
-    "vdjx_pool_load", "vdjx_pool_load_forward", "vdjx_pool_load_forward_begin", "vdjx_pool_wait", "vdjx_pool_load_device", "vdjx_pool_records", "vdjx_pool_free",
+    "vdjx_pool_load", "vdjx_pool_load_forward", "vdjx_pool_load_forward_begin", "vdjx_pool_wait", "vdjx_packed_read_bytes", "vdjx_pack_reads", "vdjx_pool_load_packed", "vdjx_pool_load_packed_begin", "vdjx_pool_load_device", "vdjx_pool_records", "vdjx_pool_free",
     "vdjx_anchor_sets_load", "vdjx_anchor_probe", "vdjx_index_generate", "vdjx_anchor_sets_from_anchors",
     "vdjx_kmer_build", "vdjx_graph_nodes", "vdjx_graph_pre_nodes", "vdjx_graph_export", "vdjx_graph_export_begin", "vdjx_graph_export_end", "vdjx_graph_free",
     "vdjx_vregion_load", "vdjx_root_score", "vdjx_graph_roots", "vdjx_root_part", "vdjx_root_score_graph",
@@ -73,6 +73,11 @@ def lib():
     L.vdjx_pool_load_device.argtypes = [vp, vp, sz, vp, sz, i32, C.POINTER(vp)]
     L.vdjx_pool_load_forward.argtypes = [vp, vp, sz, vp, sz, i32, C.POINTER(vp)]
     L.vdjx_pool_load_forward_begin.argtypes = [vp, vp, sz, vp, sz, i32, C.POINTER(vp)]
+    L.vdjx_pool_load_packed.argtypes = [vp, vp, sz, vp, sz, i32, C.POINTER(vp)]
+    L.vdjx_pool_load_packed_begin.argtypes = [vp, vp, sz, vp, sz, i32, C.POINTER(vp)]
+    L.vdjx_packed_read_bytes.argtypes = [i32]
+    L.vdjx_packed_read_bytes.restype = C.c_size_t
+    L.vdjx_pack_reads.argtypes = [vp, sz, i32, vp]
     L.vdjx_pool_wait.argtypes = [vp]
     L.vdjx_pool_records.argtypes = [vp]
     L.vdjx_pool_records.restype = sz

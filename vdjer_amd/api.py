@@ -190,6 +190,38 @@ class Context:
         self._pools.append(p)
         return p
 
+    @staticmethod
+    def packed_read_bytes(rl: int) -> int:
+        return int(_lib.lib().vdjx_packed_read_bytes(rl))
+
+    @staticmethod
+    def pack_reads(ascii_reads: np.ndarray, rl: int) -> np.ndarray:
+        """[n, 2*rl+1] ASCII records of reads ('0' + bases + qualities) -> [n, packed_read_bytes(rl)] in the packed host format
+        (vdjx_pack_reads: 2-bit bases, then the quality bytes with bit 7 = not ACGT)"""
+        a = _c(ascii_reads, np.uint8).reshape(-1, 2 * rl + 1)
+        S = Context.packed_read_bytes(rl)
+        out = np.zeros((a.shape[0], S), np.uint8)
+        check(_lib.lib().vdjx_pack_reads(_p(a), a.shape[0], rl, _p(out)), "vdjx_pack_reads")
+        return out
+
+    def pool_load_packed(self, primary_reads, secondary_reads, rl: int, n_primary: int = None, n_secondary: int = None, wait: bool = True) -> Pool:
+        """pool_load_forward for reads in the packed host format ([n, packed_read_bytes(rl)] uint8 arrays, or raw host addresses with counts)"""
+        S = self.packed_read_bytes(rl)
+        if isinstance(primary_reads, int):
+            pp, ps, npri, nsec = C.c_void_p(primary_reads), C.c_void_p(secondary_reads), n_primary, n_secondary
+        else:
+            pri = _c(primary_reads, np.uint8).reshape(-1, S)
+            sec = _c(secondary_reads, np.uint8).reshape(-1, S)
+            pp, ps, npri, nsec = _p(pri), _p(sec), pri.shape[0], sec.shape[0]
+        h = C.c_void_p()
+        fn = self.L.vdjx_pool_load_packed if wait else self.L.vdjx_pool_load_packed_begin
+        check(fn(self.h, pp, npri, ps, nsec, rl, C.byref(h)), "vdjx_pool_load_packed")
+        p = Pool(self, h, rl, 2 * (npri + nsec))
+        if not wait and not isinstance(primary_reads, int):
+            p._src = (pri, sec)
+        self._pools.append(p)
+        return p
+
     def pool_load_forward(self, primary_reads, secondary_reads, rl: int, n_primary: int = None, n_secondary: int = None,
                           wait: bool = True) -> Pool:
         """the reads as extracted only ([n, 2*rl+1] uint8 arrays or raw host addresses with counts): every read's reverse-complement

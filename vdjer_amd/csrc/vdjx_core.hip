@@ -609,6 +609,113 @@ __global__ __launch_bounds__(PACK_RECS) void k_pool_pack(const uint8_t* __restri
 	}
 }
 
+// ---- packed host format (vdjx_pool_load_packed): a read is VDJX_PACKED_BYTES(rl) bytes -- ceil(rl/4) bytes of 2-bit bases (A0 T1 C2
+// G3, seq_to_kmer.c:6-29; the first base in the top bits of byte 0, four per byte, code 0 where the base is not ACGT), then rl quality
+// bytes (Phred+33; bit 7 set = the base is not ACGT), zero-padded to a multiple of 16: 64 bytes for 50 bp where the extracted ASCII
+// record has 101.  Record 2i = the read, record 2i+1 = its reverse complement with reversed qualities (bam_read.c:231-243), exactly
+// what the forward load makes of the ASCII.  One thread per read, its bytes as 16-byte loads straight from the (device) buffer.
+__host__ __device__ inline unsigned vdjx_packed_bytes(int rl) { return (unsigned) (((rl + 3) / 4 + rl + 15) / 16 * 16); }
+template <int NV>         // 16-byte pieces per read: vdjx_packed_bytes(rl) / 16 = 1 .. 5 (4 for reads of 39 .. 51 bases)
+__global__ __launch_bounds__(PACK_RECS) void k_pool_unpack(const uint8_t* __restrict__ packed, size_t n_reads, int rl, size_t rec0,
+                                                           u64* __restrict__ bases, u64* __restrict__ nmask, u64* __restrict__ lowq,
+                                                           uint8_t* __restrict__ quals, int qstride, u32* __restrict__ bad_strand) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const u32 tid = threadIdx.x;
+	const size_t first = (size_t) blockIdx.x * PACK_RECS;
+	const u32 nhere = (u32) (n_reads - first < PACK_RECS ? n_reads - first : PACK_RECS);
+	const u32 QW = (u32) qstride / 4u, OS = QW + 1u;
+	u32* orow = (u32*) lds;
+	typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+	if (tid < nhere) {
+		u32 w[NV * 4 + 1];
+		const u32x4_t* src = (const u32x4_t*) (packed + (first + tid) * (size_t) (NV * 16));
+#pragma unroll
+		for (int v = 0; v < NV; v++) { const u32x4_t x = __builtin_nontemporal_load(&src[v]); w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w; }
+		w[NV * 4] = 0;
+		const u32 nb = ((u32) rl + 3u) / 4u;                              // base bytes
+		// bases: the bytes are the codes already, first base first: as a big-endian number of 8 nb bits, down by the 2 (4 nb - rl) unused ones
+		u64 hi = 0, lo = 0;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			const u32 be = __builtin_bswap32(w[j]);                       // bytes 4j .. 4j+3, the first most significant
+			if ((u32) (4 * j) < nb) {
+				const u32 have = nb - 4u * j < 4u ? nb - 4u * j : 4u;      // bytes of this word that are base bytes
+				const u32 val = have < 4u ? be >> (8u * (4u - have)) : be;
+				hi = (hi << (8u * have)) | (lo >> (64u - 8u * have));
+				lo = (lo << (8u * have)) | val;
+			}
+		}
+		const u32 drop = 2u * (4u * nb - (u32) rl);                      // 0, 2, 4 or 6
+		if (drop) { lo = (lo >> drop) | (hi << (64u - drop)); hi >>= drop; }
+		// qualities: rl bytes from byte nb on
+		u64 nm = 0, lq = 0;
+		u32* my = orow + tid * OS;
+		const u32 nw = ((u32) rl + 3u) / 4u;
+#pragma unroll
+		for (int j = 0; j < (VDJX_SHORT_READ_LEN + 3) / 4; j++) {
+			if ((u32) j < nw) {
+				const u32 at = nb + 4u * j;                                // byte offset of this word of qualities
+				const u32 valid = (u32) rl - 4u * j < 4u ? (u32) rl - 4u * j : 4u;
+				const u32 vm = valid < 4u ? (1u << (8u * valid)) - 1u : 0xFFFFFFFFu;
+				u32 q = __builtin_amdgcn_alignbyte(w[(at >> 2) + 1], w[at >> 2], at & 3u);
+				q = (q & vm) | (0x21212121u & ~vm);
+				nm |= (u64) (sw_gather4(q & SW_H) & ((1u << valid) - 1u)) << (4u * j);
+				q &= 0x7F7F7F7Fu;
+				lq |= (u64) (sw_gather4(sw_low_quality(q)) & ((1u << valid) - 1u)) << (4u * j);
+				my[j] = q;
+			}
+		}
+		for (u32 j = nw; j < QW; j++) my[j] = 0x21212121u;
+		if (nm) {                                                        // (rare) not-ACGT bases carry code 0, whatever the packer wrote
+			const u64 p_lo = sw_spread32((u32) __brevll(nm << (64u - (u32) rl))), p_hi = sw_spread32((u32) (__brevll(nm << (64u - (u32) rl)) >> 32));
+			lo &= ~(p_lo | (p_lo << 1));
+			hi &= ~(p_hi | (p_hi << 1));
+		}
+		const size_t g = rec0 + 2 * (first + tid);
+		((ulonglong2*) bases)[g] = make_ulonglong2(hi, lo);
+		nmask[g] = nm;
+		lowq[g] = lq | nm;
+		u64 rh, rlo, rnm, rgate;
+		pack_rc(hi, lo, nm, lq | nm, rl, rh, rlo, rnm, rgate);
+		((ulonglong2*) bases)[g + 1] = make_ulonglong2(rh, rlo);
+		nmask[g + 1] = rnm;
+		lowq[g + 1] = rgate;
+	}
+	(void) bad_strand;
+	__syncthreads();
+	// ---- quality rows out, as in k_pool_pack<FWD>: 16 bytes per lane, consecutive lanes on consecutive addresses
+	const u32 rows = 2u * nhere;
+	const u32 V = QW / 4u;
+	uint4* qd = (uint4*) (quals + (rec0 + 2 * first) * (size_t) qstride);
+	for (u32 idx = tid; idx < rows * V; idx += PACK_RECS) {
+		const u32 row = idx / V, v = idx - row * V;
+		const u32* my = orow + (row >> 1) * OS;
+		u32 x[4];
+		if (!(row & 1u)) {
+#pragma unroll
+			for (int q = 0; q < 4; q++) x[q] = my[4u * v + q];
+		} else {
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const int i0 = (int) (16u * v + 4u * q);
+				const int top = rl - 1 - i0;
+				u32 w = 0x21212121u;
+				if (top >= 0) {
+					const int lo_ = top - 3;
+					const u32 wl = lo_ >= 0 ? my[lo_ >> 2] : 0u, wh = my[top >> 2];
+					u32 asc;
+					if (lo_ >= 0) asc = __builtin_amdgcn_alignbyte(wh, wl, (u32) lo_ & 3u);
+					else asc = wh << (8u * (u32) (-lo_));
+					w = __builtin_bswap32(asc);
+					if (lo_ < 0) { const u32 keep = (1u << (8u * (u32) (top + 1))) - 1u; w = (w & keep) | (0x21212121u & ~keep); }
+				}
+				x[q] = w;
+			}
+		}
+		qd[idx] = make_uint4(x[0], x[1], x[2], x[3]);
+	}
+}
+
 // reads of more than 64 bases (left-aligned words, vdjx_pool): one thread per record, character by character from the LDS-staged
 // records -- the plain form of the packing; long reads are the rare case and take the simple kernel
 #define PACKL_RECS 128
@@ -725,9 +832,23 @@ static int pool_alloc(vdjx_ctx* c, hipStream_t pack_stream, size_t R, size_t n_p
 	return VDJX_OK;
 }
 
-static void pack_launch(vdjx_ctx* c, hipStream_t st, vdjx_pool* p, const uint8_t* d_ascii, size_t n, size_t rec0, bool fwd, u32* d_bad, bool write_quals = true) {
+static void pack_launch(vdjx_ctx* c, hipStream_t st, vdjx_pool* p, const uint8_t* d_ascii, size_t n, size_t rec0, bool fwd, u32* d_bad, bool write_quals = true, bool packed_in = false) {
 	if (!n) return;
 	uint8_t* q = (uint8_t*) p->d_quals;        // (the packed rows, when there are any)
+	if (packed_in) {                           // the packed host format (k_pool_unpack): n reads -> 2 n records
+		const size_t lds = (size_t) PACK_RECS * (p->qstride / 4 + 1) * 4 + 16;
+		const dim3 grid((unsigned) ((n + PACK_RECS - 1) / PACK_RECS));
+#define UNPACK(NV) hipLaunchKernelGGL(k_pool_unpack<NV>, grid, dim3(PACK_RECS), lds, st, d_ascii, n, p->rl, rec0, p->d_bases, p->d_nmask, p->d_lowq, q, p->qstride, d_bad)
+		switch (vdjx_packed_bytes(p->rl) / 16) {          // 16-byte pieces per read: 4 for reads of 39..51 bases
+			case 1: UNPACK(1); break;
+			case 2: UNPACK(2); break;
+			case 3: UNPACK(3); break;
+			case 4: UNPACK(4); break;
+			default: UNPACK(5); break;
+		}
+#undef UNPACK
+		return;
+	}
 	if (p->W > 2) {
 		const size_t lds = (size_t) PACKL_RECS * (2 * p->rl + 1) + 16;
 		const dim3 grid((unsigned) ((n + PACKL_RECS - 1) / PACKL_RECS));
@@ -802,17 +923,18 @@ extern "C" int vdjx_pool_load_device(vdjx_ctx* c, const uint8_t* d_primary, size
 // stream: with page-locked pools (vdjx_host_alloc) the upload is a DMA that the packing hides behind.
 #define LOAD_CHUNK_RECS (256u * 1024u)          // a multiple of PACK_RECS: chunk starts stay 16-byte aligned in the staging buffer
 static int pool_load_host(vdjx_ctx* c, const uint8_t* primary, size_t n_primary, const uint8_t* secondary, size_t n_secondary, int rl, bool fwd,
-                          vdjx_pool** out, bool async = false) {
+                          vdjx_pool** out, bool async = false, bool packed_in = false) {
 	if (!c || !out) { vdjx_set_error("vdjx_pool_load: NULL argument"); return VDJX_EINVAL; }
 	if ((n_primary && !primary) || (n_secondary && !secondary)) { vdjx_set_error("vdjx_pool_load: NULL pool"); return VDJX_EINVAL; }
+	if (packed_in && (rl < 1 || rl > VDJX_SHORT_READ_LEN)) { vdjx_set_error("vdjx_pool_load_packed: reads of up to %d bases (rl=%d): longer ones go through vdjx_pool_load_forward", VDJX_SHORT_READ_LEN, rl); return VDJX_ELIMIT; }
 	const size_t mul = fwd ? 2 : 1;
 	vdjx_pool* p;
 	u32* d_bad;
 	int rc = pool_alloc(c, async ? c->copy_stream : c->stream, mul * (n_primary + n_secondary), mul * n_primary, rl, &p, &d_bad);
 	if (rc) return rc;
 	*out = nullptr;
-	const size_t reclen = 2 * (size_t) rl + 1;
-	const size_t stage_bytes = (size_t) LOAD_CHUNK_RECS * reclen + 16;
+	const size_t reclen = packed_in ? (size_t) vdjx_packed_bytes(rl) : 2 * (size_t) rl + 1;      // bytes per input record
+	const size_t stage_bytes = (size_t) LOAD_CHUNK_RECS * (2 * (size_t) rl + 1) + 16;           // (sized for the ASCII form: the larger one)
 	if (stage_bytes > c->stage_cap) {              // (sized for the longest records seen so far)
 		(void) hipStreamSynchronize(c->copy_stream);
 		(void) hipStreamSynchronize(c->stream);
@@ -838,7 +960,7 @@ static int pool_load_host(vdjx_ctx* c, const uint8_t* primary, size_t n_primary,
 				const size_t m = n - at < LOAD_CHUNK_RECS ? n - at : LOAD_CHUNK_RECS;
 				const hipError_t e = hipMemcpyAsync(c->d_stage[turn], src + at * reclen, m * reclen, hipMemcpyHostToDevice, c->copy_stream);
 				if (e != hipSuccess) { vdjx_set_error("pool upload: %s", hipGetErrorString(e)); (void) hipStreamSynchronize(c->copy_stream); vdjx_pool_free(p); return VDJX_EHIP; }
-				pack_launch(c, c->copy_stream, p, (const uint8_t*) c->d_stage[turn], m, rec0 + mul * at, fwd, d_bad);
+				pack_launch(c, c->copy_stream, p, (const uint8_t*) c->d_stage[turn], m, rec0 + mul * at, fwd, d_bad, true, packed_in);
 			}
 		}
 		p->pending_bad = d_bad;
@@ -860,7 +982,7 @@ static int pool_load_host(vdjx_ctx* c, const uint8_t* primary, size_t n_primary,
 			if (e == hipSuccess) e = hipEventRecord(c->ev_copied[turn], c->copy_stream);
 			if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_copied[turn], 0);
 			if (e != hipSuccess) { vdjx_set_error("pool upload: %s", hipGetErrorString(e)); (void) hipStreamSynchronize(c->copy_stream); vdjx_pool_free(p); return VDJX_EHIP; }
-			pack_launch(c, c->stream, p, (const uint8_t*) c->d_stage[turn], m, rec0 + mul * at, fwd, d_bad);
+			pack_launch(c, c->stream, p, (const uint8_t*) c->d_stage[turn], m, rec0 + mul * at, fwd, d_bad, true, packed_in);
 			(void) hipEventRecord(c->ev_packed[turn], c->stream);
 			used[turn] = true;
 		}
@@ -881,6 +1003,37 @@ extern "C" int vdjx_pool_load_forward(vdjx_ctx* c, const uint8_t* primary_reads,
 extern "C" int vdjx_pool_load_forward_begin(vdjx_ctx* c, const uint8_t* primary_reads, size_t n_primary_reads,
                                             const uint8_t* secondary_reads, size_t n_secondary_reads, int rl, vdjx_pool** out) {
 	return pool_load_host(c, primary_reads, n_primary_reads, secondary_reads, n_secondary_reads, rl, true, out, true);
+}
+
+// the reads in the packed host format (k_pool_unpack): 64 bytes per 50 bp read instead of the 101 of the extracted ASCII record
+extern "C" size_t vdjx_packed_read_bytes(int rl) { return rl >= 1 && rl <= VDJX_SHORT_READ_LEN ? (size_t) vdjx_packed_bytes(rl) : 0; }
+extern "C" int vdjx_pool_load_packed(vdjx_ctx* c, const uint8_t* primary_reads, size_t n_primary_reads,
+                                     const uint8_t* secondary_reads, size_t n_secondary_reads, int rl, vdjx_pool** out) {
+	return pool_load_host(c, primary_reads, n_primary_reads, secondary_reads, n_secondary_reads, rl, true, out, false, true);
+}
+extern "C" int vdjx_pool_load_packed_begin(vdjx_ctx* c, const uint8_t* primary_reads, size_t n_primary_reads,
+                                           const uint8_t* secondary_reads, size_t n_secondary_reads, int rl, vdjx_pool** out) {
+	return pool_load_host(c, primary_reads, n_primary_reads, secondary_reads, n_secondary_reads, rl, true, out, true, true);
+}
+// host side of the format: n ASCII records of 2*rl+1 bytes ('0' + bases + Phred+33 characters, what add_to_buffer writes first for a
+// read, bam_read.c:219-230) -> n packed reads.  Plain C, no GPU: what an extraction that wants to skip the ASCII stage would do per read.
+extern "C" int vdjx_pack_reads(const uint8_t* ascii_reads, size_t n, int rl, uint8_t* out_packed) {
+	if (rl < 1 || rl > VDJX_SHORT_READ_LEN) { vdjx_set_error("vdjx_pack_reads: rl=%d outside [1,%d]", rl, VDJX_SHORT_READ_LEN); return VDJX_ELIMIT; }
+	if (n && (!ascii_reads || !out_packed)) { vdjx_set_error("vdjx_pack_reads: NULL argument"); return VDJX_EINVAL; }
+	const size_t S = vdjx_packed_bytes(rl), reclen = 2 * (size_t) rl + 1, nb = ((size_t) rl + 3) / 4;
+	for (size_t i = 0; i < n; i++) {
+		const uint8_t* r = ascii_reads + i * reclen;
+		uint8_t* o = out_packed + i * S;
+		memset(o, 0, S);
+		if (r[0] != '0') { vdjx_set_error("vdjx_pack_reads: record %zu does not start with the '0' strand byte", i); return VDJX_EINVAL; }
+		for (int j = 0; j < rl; j++) {
+			const uint8_t ch = r[1 + j];
+			const int code = ch == 'A' ? 0 : ch == 'T' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : -1;      // seq_to_kmer.c:6-29
+			if (code > 0) o[j >> 2] |= (uint8_t) (code << (2 * (3 - (j & 3))));
+			o[nb + j] = (uint8_t) ((r[1 + rl + j] & 0x7F) | (code < 0 ? 0x80 : 0));
+		}
+	}
+	return VDJX_OK;
 }
 
 extern "C" int vdjx_pool_wait(vdjx_pool* p) {
