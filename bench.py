@@ -385,7 +385,9 @@ def main():
         args.no_e2e = True
         args.windows = "generator"
     if args.clones <= 0:
-        args.clones = max(4, args.pairs // 500)
+        # clones per GPU: 1 per 500 pairs like configs[1..3] (1 M / 2,000, 10 M / 20,000); configs[4] is 100 M pairs of 100,000 clones
+        # (SURVEY §8d C5): 1 per 1,000
+        args.clones = max(4, args.pairs // (1000 if args.config4 else 500))
     if args.windows == "auto":
         args.windows = "traversal" if args.pairs * args.gpus <= 1_500_000 else "generator"
 

@@ -548,10 +548,25 @@ long bamx_query(bamx_file* f, const bamx_index* ix, const char* region, void (*c
 	/* the linear index (section 5.1.3): entry w is the smallest file offset of an alignment that overlaps the 16 kb window w.  In a
 	 * coordinate-sorted file no alignment that overlaps [beg, end) starts before the first one overlapping beg's window: chunks
 	 * that END at or before that offset hold nothing for this region. */
+	/* Which window's entry: the tightest bound would be beg's own window.  The reference's library takes a LOOSER one -- the entry of the
+	 * first window of the nearest bin THAT EXISTS at or before beg's leaf bin (the leaf itself, else its left neighbours under the same
+	 * parent, else the parent, and so on upwards) -- and which chunks are read decides where the query leaves the file, which is where
+	 * extract's sequential pass starts (bam_read.c:346-374).  The same reads come back either way; the looser bound keeps the file
+	 * position the reference's (round-4 advice: with the tight bound a region without overlapping reads in a sparse neighbourhood left
+	 * the file untouched where the reference seeks and reads). */
 	uint64_t min_off = 0;
-	if (r->n_intv > 0) {
-		const int w = beg >> BAI_MIN_SHIFT;
-		min_off = r->ioff[w < r->n_intv ? w : r->n_intv - 1];
+	if (r->n_intv > 0 && (long long) beg < (1LL << 29)) {
+		int lvl = BAI_N_LVLS;
+		int bin = LEVEL_FIRST[lvl] + (beg >> LEVEL_SHIFT[lvl]);
+		while (bin > 0 && !find_bin(r, (uint32_t) bin)) {
+			const int parent = (bin - 1) >> 3, first_child = (parent << 3) + 1;
+			if (bin > first_child) bin--;                      /* the neighbour to the left, same level */
+			else { bin = parent; lvl--; }
+		}
+		if (bin > 0 || find_bin(r, 0)) {
+			const long long w = (long long) (bin - LEVEL_FIRST[lvl]) << (LEVEL_SHIFT[lvl] - BAI_MIN_SHIFT);      /* first 16 kb window the bin covers */
+			min_off = w < r->n_intv ? r->ioff[w] : 0;
+		}
 	}
 	/* candidate chunks: those of every bin that can hold an overlapping alignment */
 	size_t cap = 64, n_off = 0;

@@ -239,6 +239,12 @@ __global__ __launch_bounds__(DP_THREADS) void k_root_dp(const char* __restrict__
 // value (up) and that neighbour's value before (diag); the reference characters move down the lanes one per step the same way.
 // k + 2k steps of a dozen instructions instead of k x 2k cells of half a dozen.
 #define DPW_THREADS 256
+// (The anti-diagonal sweep below moves cells down the lanes with DPP wave_shr:1 -- control 0x138, lane 0 keeps `old` --, a GFX9-family
+// wave-64 control: gfx90a / gfx942 / gfx950.  This library is written for gfx950 alone; the check makes a build for anything else
+// stop here instead of assembling a different shift.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "k_root_dp_wave uses the GFX9 DPP control wave_shr:1 (0x138): build with --offload-arch=gfx950"
+#endif
 __global__ __launch_bounds__(DPW_THREADS) void k_root_dp_wave(const char* __restrict__ kmers, int k, int threshold,
                                                              const u32* __restrict__ hit_lo, const u32* __restrict__ hit_pre,
                                                              u32 n_groups, u32 stop, u32 base, const u32* __restrict__ seed_pos,
