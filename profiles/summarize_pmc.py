@@ -44,10 +44,13 @@ def stream_in(bench_line):
     tuples = st.get("gated_instances", 0) / (2 if sym else 1)
     items = st.get("recount_items", 0)
     recs = 4 * pairs
-    gate = 24 * (recs // 2 if sym else recs)                    # bases (16) + gate mask (8) of every record a gating kernel looks at
-    return {"k_pool_pack": 101 * recs / 2,                       # (two launches per step: primary, secondary; the median launch is weighed as half)
+    # bases (16) + gate mask (8) of every record: the couples' forms (sym) USE every other record only, but records are 16 / 8 bytes in
+    # arrays of all records, so every 64-byte sector is still touched -- the arrays are swept whole (k_gated_hist: 482 MB counted for
+    # 480 MB used = 964 MB moved)
+    gate = 24 * recs
+    return {"k_pool_pack": 101 * recs,                           # (everything it reads is a coalesced stream; two launches per step, the cap below is FETCH itself)
             "k_gated_hist": gate, "k_part_records_g": gate + 16 * tuples, "k_part_tuples_g": 16 * tuples, "k_seg_hist_g": 16 * tuples,
-            "k_gated_reduce": 16 * tuples, "k_gated_local": 16 * tuples, "k_walk_items": 24 * (recs // 2 if symw else recs),
+            "k_gated_reduce": 16 * tuples, "k_gated_local": 16 * tuples, "k_walk_items": 24 * recs,
             "k_part_items": 8 * items, "k_recount": 8 * items, "k_compact_partials": 0, "k_bucket_merge": 0}
 
 

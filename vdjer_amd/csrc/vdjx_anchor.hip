@@ -39,20 +39,16 @@ __global__ void k_anchor_probe(const char* __restrict__ contig, int len, const u
 	out_j[i] = code ? (jbits[code >> 5] >> (code & 31)) & 1u : 0;
 }
 
-static int load_set(vdjx_ctx* c, const u32* codes, size_t n, u32** d_bits) {
+// the set's codes go up into a buffer the context keeps (no hipMalloc / hipFree -- the latter waits for the whole device -- per load: a
+// --config4 step loads a new chain's sets with every pool), behind the clearing of its bitmap on the same stream; the caller waits once
+static int load_set(vdjx_ctx* c, const u32* codes, size_t n, u32** d_bits, size_t tmp_at) {
 	const size_t words = (size_t) 1 << 27;
 	if (!*d_bits) HIP_TRY(hipMalloc(d_bits, words * 4));
 	HIP_TRY(hipMemsetAsync(*d_bits, 0, words * 4, c->stream));
 	if (n) {
-		u32* d_codes = nullptr;
-		HIP_TRY(hipMalloc(&d_codes, n * 4));
-		hipError_t e = hipMemcpyAsync(d_codes, codes, n * 4, hipMemcpyHostToDevice, c->stream);
-		if (e == hipSuccess) {
-			hipLaunchKernelGGL(k_bitmap_set, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, c->stream, d_codes, n, *d_bits);
-			e = hipStreamSynchronize(c->stream);
-		}
-		(void) hipFree(d_codes);
-		if (e != hipSuccess) { vdjx_set_error("anchor set load: %s", hipGetErrorString(e)); return VDJX_EHIP; }
+		u32* d_codes = c->d_anchor_tmp + tmp_at;
+		HIP_TRY(hipMemcpyAsync(d_codes, codes, n * 4, hipMemcpyHostToDevice, c->stream));
+		hipLaunchKernelGGL(k_bitmap_set, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, c->stream, d_codes, n, *d_bits);
 	}
 	return VDJX_OK;
 }
@@ -61,11 +57,20 @@ extern "C" int vdjx_anchor_sets_load(vdjx_ctx* c, const uint32_t* v_codes, size_
 	if (!c || (nv && !v_codes) || (nj && !j_codes)) { vdjx_set_error("vdjx_anchor_sets_load: NULL argument"); return VDJX_EINVAL; }
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_clear_errors();
-	int rc = load_set(c, v_codes, nv, &c->d_vbits);
+	const size_t need = (nv + nj + 2) * 4;
+	if (need > c->anchor_tmp_cap) {
+		HIP_TRY(hipStreamSynchronize(c->stream));
+		if (c->d_anchor_tmp) (void) hipFree(c->d_anchor_tmp);
+		c->d_anchor_tmp = nullptr; c->anchor_tmp_cap = 0;
+		HIP_TRY(hipMalloc(&c->d_anchor_tmp, need + need / 4));
+		c->anchor_tmp_cap = need + need / 4;
+	}
+	int rc = load_set(c, v_codes, nv, &c->d_vbits, 0);
 	if (rc) return rc;
-	rc = load_set(c, j_codes, nj, &c->d_jbits);
+	rc = load_set(c, j_codes, nj, &c->d_jbits, nv + 1);
 	if (rc) return rc;
-	HIP_TRY(hipStreamSynchronize(c->stream));
+	HIP_TRY(hipStreamSynchronize(c->stream));            // (the codes have left the caller's arrays)
+	HIP_TRY(hipGetLastError());
 	c->anchors_loaded = true;
 	return VDJX_OK;
 }
@@ -319,8 +324,8 @@ extern "C" int vdjx_anchor_sets_from_anchors(vdjx_ctx* c, const uint32_t* v_anch
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_clear_errors();
 	if (am < 0) {                                            // no row has a distance <= am: empty sets
-		int rc = load_set(c, nullptr, 0, &c->d_vbits);
-		if (!rc) rc = load_set(c, nullptr, 0, &c->d_jbits);
+		int rc = load_set(c, nullptr, 0, &c->d_vbits, 0);
+		if (!rc) rc = load_set(c, nullptr, 0, &c->d_jbits, 0);
 		if (rc) return rc;
 	} else {
 		const u32 thr = (u32) (am > 5 ? 5 : am);             // the index files stop at MAX_DIST 5 (seq_dist.c:9)

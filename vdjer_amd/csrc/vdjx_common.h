@@ -126,6 +126,8 @@ struct vdjx_ctx {
 	u32* d_vbits = nullptr;
 	u32* d_jbits = nullptr;
 	bool anchors_loaded = false;
+	u32* d_anchor_tmp = nullptr;      // the codes of a set on their way into its bitmap (kept: a new chain's ref-dir comes with every pool at configs[4])
+	size_t anchor_tmp_cap = 0, vtext_cap = 0, line_off_cap = 0, seed_cap = 0;      // bytes behind d_anchor_tmp / d_vtext / d_line_off / d_seed_code and d_seed_pos
 	// a-7 V-region index
 	char* d_vtext = nullptr;          // all lines concatenated
 	u32* d_line_off = nullptr;        // [n_lines+1]

@@ -103,7 +103,7 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	if (!c) return;
 	(void) hipSetDevice(c->device);
 	(void) hipStreamSynchronize(c->stream);
-	free_dev(c->d_vbits); free_dev(c->d_jbits);
+	free_dev(c->d_vbits); free_dev(c->d_jbits); free_dev(c->d_anchor_tmp);
 	free_dev(c->d_vtext); free_dev(c->d_line_off); free_dev(c->d_seed_code); free_dev(c->d_seed_pos);
 	free_dev(c->d_ri_tab); free_dev(c->d_ri_start); free_dev(c->d_ri_recs); free_dev(c->d_ri_csr8); free_dev(c->d_ri_csr_pair);
 	free_dev(c->d_pair_r2);

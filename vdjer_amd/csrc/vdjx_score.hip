@@ -36,7 +36,6 @@ extern "C" int vdjx_vregion_load(vdjx_ctx* c, const char* const* lines, size_t n
 	if (vk < 2 || vk > 16) { vdjx_set_error("vregion k-mer size %d outside [2,16]", vk); return VDJX_ELIMIT; }
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_clear_errors();
-	free_set(c->d_vtext); free_set(c->d_line_off); free_set(c->d_seed_code); free_set(c->d_seed_pos);
 	std::vector<u32> off(n_lines + 1, 0);
 	std::string text;
 	for (size_t i = 0; i < n_lines; i++) {
@@ -63,16 +62,31 @@ extern "C" int vdjx_vregion_load(vdjx_ctx* c, const char* const* lines, size_t n
 	seeds.erase(std::unique(seeds.begin(), seeds.end()), seeds.end());
 	std::vector<u32> sc(seeds.size()), sp(seeds.size());
 	for (size_t i = 0; i < seeds.size(); i++) { sc[i] = seeds[i].first; sp[i] = seeds[i].second; }
-	HIP_TRY(hipMalloc(&c->d_vtext, text.size() + 16));
-	HIP_TRY(hipMalloc(&c->d_line_off, off.size() * 4));
-	HIP_TRY(hipMalloc(&c->d_seed_code, sc.size() * 4 + 4));
-	HIP_TRY(hipMalloc(&c->d_seed_pos, sp.size() * 4 + 4));
-	HIP_TRY(hipMemcpy(c->d_vtext, text.data(), text.size(), hipMemcpyHostToDevice));
-	HIP_TRY(hipMemcpy(c->d_line_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
-	if (!sc.empty()) {
-		HIP_TRY(hipMemcpy(c->d_seed_code, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
-		HIP_TRY(hipMemcpy(c->d_seed_pos, sp.data(), sp.size() * 4, hipMemcpyHostToDevice));
+	// the four arrays are kept from load to load and only replaced when one needs more (a --config4 step loads a chain's V region with
+	// every pool: four hipFree + four hipMalloc + four waits each time were most of the call); one wait for the four copies
+	HIP_TRY(hipStreamSynchronize(c->stream));                // nothing in flight may still read the region that is replaced
+	auto keep = [](auto** p, size_t* cap, size_t bytes) -> hipError_t {
+		if (*p && *cap >= bytes) return hipSuccess;
+		if (*p) (void) hipFree(*p);
+		*p = nullptr; *cap = 0;
+		const hipError_t e = hipMalloc((void**) p, bytes + bytes / 4 + 64);
+		if (e == hipSuccess) *cap = bytes + bytes / 4 + 64;
+		return e;
+	};
+	HIP_TRY(keep(&c->d_vtext, &c->vtext_cap, text.size() + 16));
+	HIP_TRY(keep(&c->d_line_off, &c->line_off_cap, off.size() * 4));
+	{
+		size_t cap2 = c->seed_cap;
+		HIP_TRY(keep(&c->d_seed_code, &c->seed_cap, sc.size() * 4 + 4));
+		HIP_TRY(keep(&c->d_seed_pos, &cap2, sc.size() * 4 + 4));
 	}
+	HIP_TRY(hipMemcpyAsync(c->d_vtext, text.data(), text.size(), hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(hipMemcpyAsync(c->d_line_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
+	if (!sc.empty()) {
+		HIP_TRY(hipMemcpyAsync(c->d_seed_code, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(hipMemcpyAsync(c->d_seed_pos, sp.data(), sp.size() * 4, hipMemcpyHostToDevice, c->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(c->stream));                // (the vectors die with this frame)
 	c->n_lines = n_lines;
 	c->n_seeds = sc.size();
 	c->vk = vk;
