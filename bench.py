@@ -619,7 +619,9 @@ def main():
         t = lap("kmer_build", t)
         # every root of the graph (nodes without predecessor), scored where the graph lives while its copy for the host traversal
         # is still crossing PCIe; rank r takes roots r, r+world, ...
-        root_ids, ok = ctx.root_score_graph(g, args.mrs, rank, world)
+        # (queued, not waited for: the verdicts -- a few kilobytes -- are looked at after the window scorer has had the device; the windows
+        # of this bench do not depend on them)
+        root_ids, ok = ctx.root_score_graph(g, args.mrs, rank, world, wait=False)
         t = lap("root_score", t)
         if engine is None:
             valid, npairs = ctx.window_score(w_["wins_packed"], args.ins)
@@ -636,6 +638,7 @@ def main():
         # the next map_emit reuses the stream (and after the last step, inside the timed region)
         offs, pairs = ctx.map_emit(cpk, async_copy=True)
         t = lap("map_emit", t)
+        ctx.root_score_wait()        # the root verdicts are on the host
         g.wait()                     # the graph arrays are on the host
         g.free()
         t = lap("graph_copy_wait", t)

@@ -173,6 +173,13 @@ size_t vdjx_graph_roots(const vdjx_graph* g);
 size_t vdjx_root_part(const vdjx_graph* g, uint32_t first, uint32_t stride);
 int vdjx_root_score_graph(vdjx_ctx* ctx, const vdjx_graph* g, int threshold, uint32_t first, uint32_t stride,
                           uint32_t* root_ids, uint8_t* out);
+/* The same without waiting: everything is queued on the context's stream and the call returns; the two arrays (page-locked memory,
+ * vdjx_host_alloc) are valid after vdjx_root_score_graph_end.  Calls made in between run behind it on the device, so a caller with
+ * other work that does not need the verdicts (scoring windows it already has) keeps the device busy instead of waiting for a few
+ * kilobytes.  The graph stays alive until _end; one call in flight per context. */
+int vdjx_root_score_graph_begin(vdjx_ctx* ctx, const vdjx_graph* g, int threshold, uint32_t first, uint32_t stride,
+                                uint32_t* root_ids, uint8_t* out);
+int vdjx_root_score_graph_end(vdjx_ctx* ctx);
 
 /* ---- a-8, a-9, a-10: read->contig mapper, coverage validator, SAM placements --------------------
  * replaces: add_read_info (quick_map3.c:126-149) for the index; quick_map_process_contig +

@@ -9,7 +9,8 @@ f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'k_pool_pack' in r['Kernel_Name']]
-step = rows[idx[-4]:idx[-2]]                      # two pack launches per step: the last full step
+no = int(sys.argv[2]) if len(sys.argv) > 2 else None
+step = rows[idx[2 * no]:idx[2 * no + 2]] if no is not None else rows[idx[-4]:idx[-2]]      # two pack launches per step: step `no` (0-based), or the last full step
 iv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'][:44]) for r in step)
 t0, t1 = iv[0][0], max(e for _, e, _ in iv)
 busy, holes = 0, []

@@ -636,6 +636,33 @@ def test_packed_host_format_equals_the_forward_load(ctx, rl):
     assert texts[1] == texts[0] and texts[2] == texts[0]
 
 
+def test_root_scorer_begun_and_ended_equals_the_waiting_call():
+    """vdjx_root_score_graph_begin / _end (queued on the stream, other scorer calls behind it, verdicts read at the end) against
+    vdjx_root_score_graph: same ids, same verdicts -- also when the guessed item count falls short (a second, larger graph: the
+    call is then repeated the ordinary way inside _end)"""
+    from vdjer_amd import api, synth
+    c = api.Context(0, pinned_results=True)
+    rep = synth.make_repertoire(8, seed=101)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    c.anchor_sets_load(vc, jc)
+    c.vregion_load([rep.v_region], 15)
+    for n_pairs in (3000, 3000, 40000):                      # (the third graph has many more roots than the guess from the second)
+        pool = synth.make_reads(rep, n_pairs, noise_frac=0.3, seed=102 + n_pairs)
+        p = c.pool_load(pool.primary, pool.secondary, pool.rl)
+        g = c.kmer_build(p, 35, 3, 90, keep_device=True)
+        ids0, ok0 = (np.array(x) for x in c.root_score_graph(g, 30))
+        ids1, ok1 = c.root_score_graph(g, 30, wait=False)
+        wins = [w for w in rep.windows() if w]
+        c.read_index_build(p, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+        c.window_score(wins, 175)                           # (work queued behind the begun call)
+        c.root_score_wait()
+        assert ids0.shape[0] > 10 and np.array_equal(ids0, ids1) and np.array_equal(ok0, ok1) and 0 < int(ok0.sum()) < ok0.shape[0]
+        g.free()
+        p.free()
+    c.close()
+
+
 def test_all_gated_all_distinct_overflows_the_lds_table(ctx):
     """High-quality reads with 80 % noise: nearly every instance is gated and distinct, so buckets hold more
     distinct k-mers than one LDS table pass takes and the sub-pass split / restart path runs."""

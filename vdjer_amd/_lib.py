@@ -17,7 +17,7 @@ SYMBOLS = [
     "vdjx_pool_load", "vdjx_pool_load_forward", "vdjx_pool_load_forward_begin", "vdjx_pool_wait", "vdjx_packed_read_bytes", "vdjx_pack_reads", "vdjx_pool_load_packed", "vdjx_pool_load_packed_begin", "vdjx_pool_load_device", "vdjx_pool_records", "vdjx_pool_free",
     "vdjx_anchor_sets_load", "vdjx_anchor_probe", "vdjx_index_generate", "vdjx_anchor_sets_from_anchors",
     "vdjx_kmer_build", "vdjx_graph_nodes", "vdjx_graph_pre_nodes", "vdjx_graph_export", "vdjx_graph_export_begin", "vdjx_graph_export_end", "vdjx_graph_free",
-    "vdjx_vregion_load", "vdjx_root_score", "vdjx_graph_roots", "vdjx_root_part", "vdjx_root_score_graph",
+    "vdjx_vregion_load", "vdjx_root_score", "vdjx_graph_roots", "vdjx_root_part", "vdjx_root_score_graph", "vdjx_root_score_graph_begin", "vdjx_root_score_graph_end",
     "vdjx_read_index_build", "vdjx_read_index_build_device", "vdjx_window_score", "vdjx_window_pairs", "vdjx_window_pairs_fetch", "vdjx_window_cover", "vdjx_map_emit", "vdjx_map_emit_begin", "vdjx_map_emit_end", "vdjx_sam_names_load", "vdjx_sam_text", "vdjx_sam_blocks", "vdjx_sam_merge", "vdjx_rows_scatter",
     "vdjx_host_alloc", "vdjx_host_free", "vdjx_host_take_rows",
     "vdjx_stat", "vdjx_profile_enable", "vdjx_profile_reset", "vdjx_profile_count", "vdjx_profile_get",
@@ -118,6 +118,8 @@ def lib():
     L.vdjx_root_part.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.vdjx_root_part.restype = C.c_size_t
     L.vdjx_root_score_graph.argtypes = [vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
+    L.vdjx_root_score_graph_begin.argtypes = [vp, vp, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
+    L.vdjx_root_score_graph_end.argtypes = [vp]
     L.vdjx_index_generate.argtypes = [vp, vp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), vp, vp]
     L.vdjx_anchor_sets_from_anchors.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int]
     L.vdjx_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]

@@ -354,7 +354,7 @@ class Context:
         check(self.L.vdjx_root_score(self.h, raw, n, k, threshold, _p(out)), "vdjx_root_score")
         return out
 
-    def root_score_graph(self, graph: Graph, threshold: int, first: int = 0, stride: int = 1):
+    def root_score_graph(self, graph: Graph, threshold: int, first: int = 0, stride: int = 1, wait: bool = True):
         """scores the roots of a device-resident graph (kmer_build(..., keep_device=True)): (1-based node ids, verdicts).
         On a context made with pinned_results=True the two arrays are views of ONE recycled page-locked buffer (like every pinned
         result of this class): they are valid until the next root_score_graph call of the context -- a second call of the same size
@@ -363,8 +363,18 @@ class Context:
             raise VdjxError("root_score_graph: the graph was not kept on the device (keep_device=True)")
         n = int(self.L.vdjx_root_part(graph.handle, first, stride))
         ids, out = self._result_arrays("roots", [((n,), np.uint32), ((n,), np.uint8)])
+        if not wait and self.pinned_results:
+            # queued, not waited for: the arrays are valid after root_score_wait() (vdjx_root_score_graph_begin / _end)
+            check(self.L.vdjx_root_score_graph_begin(self.h, graph.handle, threshold, first, stride, _p(ids), _p(out)), "vdjx_root_score_graph_begin")
+            self._roots_pending = True
+            return ids, out
         check(self.L.vdjx_root_score_graph(self.h, graph.handle, threshold, first, stride, _p(ids), _p(out)), "vdjx_root_score_graph")
         return ids, out
+
+    def root_score_wait(self):
+        if getattr(self, "_roots_pending", False):
+            self._roots_pending = False
+            check(self.L.vdjx_root_score_graph_end(self.h), "vdjx_root_score_graph_end")
 
     # ---- a-8..a-10
     def read_index_build(self, pool: Pool, pair_id, read_num, is_rc, reg_rank, n_pairs: int) -> None:

@@ -179,6 +179,14 @@ struct vdjx_ctx {
 	hipEvent_t ev_pairs_copied = nullptr;   // the last asynchronous copy of mapped pairs to the host has left me_dense
 	uint32_t root_dp_hint = 0;        // work items of the last root scoring (+ a margin): the next call's DP is launched for that many ahead of its own count
 	hipEvent_t ev_plan = nullptr;     // the scorers' plan totals have come down (the host waits for this, not for the stream)
+	// vdjx_root_score_graph_begin .. _end: the call in flight
+	bool root_pending = false;
+	const vdjx_graph* root_pending_g = nullptr;
+	int root_pending_thr = 0;
+	uint32_t root_pending_first = 0, root_pending_stride = 1, root_pending_ahead = 0;
+	uint32_t* root_pending_ids = nullptr;
+	uint8_t* root_pending_out = nullptr;
+	hipEvent_t ev_root_done = nullptr;
 	// SAM text (vdjx_sam_text): read names by pair id on the device, the text buffers
 	char* d_sam_names = nullptr;
 	u64* d_sam_noff = nullptr;

@@ -50,6 +50,7 @@ extern "C" int vdjx_init(int device, vdjx_ctx** out) {
 	for (auto& ev : c->ev_up) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pairs_copied, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_root_done, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipHostMalloc(&c->h_pin, 16384, hipHostMallocDefault);
 	if (e != hipSuccess) { delete c; vdjx_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return VDJX_EHIP; }
 	{
@@ -128,6 +129,7 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	for (auto& ev : c->ev_up) if (ev) (void) hipEventDestroy(ev);
 	if (c->ev_pairs_copied) (void) hipEventDestroy(c->ev_pairs_copied);
 	if (c->ev_plan) (void) hipEventDestroy(c->ev_plan);
+	if (c->ev_root_done) (void) hipEventDestroy(c->ev_root_done);
 	if (c->h_plan) (void) hipHostFree(c->h_plan);
 	if (c->h_res) (void) hipHostFree(c->h_res);
 	if (c->h_pin) (void) hipHostFree(c->h_pin);

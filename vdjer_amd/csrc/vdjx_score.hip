@@ -318,8 +318,12 @@ __global__ __launch_bounds__(DPW_THREADS) void k_root_dp_wave(const char* __rest
 }
 
 // the scorer proper: d_k = n*k ASCII on the device, out = n host bytes
-static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t n, int k, int threshold, uint8_t* out) {
+// begin: queue everything, wait for nothing -- possible when the last call's item count is at hand as a guess (root_dp_hint) and the
+// threshold is positive; *begun says whether it was (else the call ran to its end as ever).  vdjx_root_score_graph_end waits, and
+// repeats the call the ordinary way should the guess have fallen short.
+static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t n, int k, int threshold, uint8_t* out, bool* begun = nullptr) {
 	hipStream_t st = c->stream;
+	if (begun) *begun = false;
 	const int stop = k - c->vk;
 	u32 *d_lo, *d_cnt, *d_pre;
 	uint8_t* d_out;
@@ -344,8 +348,9 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 	}
 	// the DP is launched for as many items as the last call had before the host knows this call's number (its copy is queued first:
 	// the host waits for that event only, and adds a launch for what is beyond the guess)
-	HIP_TRY(hipMemcpyAsync(c->h_pin, d_pre + ng, 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipEventRecord(c->ev_plan, st));
+	u32* h_run = begun ? (u32*) c->h_pin + 2048 : (u32*) c->h_pin;          // (a begun call's number waits in a place no other call writes)
+	HIP_TRY(hipMemcpyAsync(h_run, d_pre + ng, 4, hipMemcpyDeviceToHost, st));
+	if (!begun) HIP_TRY(hipEventRecord(c->ev_plan, st));
 	// few items: a wave each (k_root_dp_wave); many: a thread each
 	static const u32 dp_wave_max = getenv("VDJX_DP_WAVE_MAX") ? (u32) atol(getenv("VDJX_DP_WAVE_MAX")) : 32768u;      // (measured: 10 k items 0.043 against 0.110 ms, 25 k 0.087 / 0.111, 77 k 0.234 / 0.130, 252 k 0.74 / 0.18)
 	auto launch_dp = [&](u32 first, u32 count) -> u32 {        // -> items covered from `first` on (whole workgroups)
@@ -365,8 +370,10 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 	// (the verdicts follow the guessed launch at once: when the guess covered the call -- every call but the first of a size -- the host
 	// wakes up once, with the verdicts there, instead of once for the number and again for the verdicts)
 	if (ahead) HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, st));
+	if (begun && ahead && threshold > 0) { c->root_pending_ahead = ahead; *begun = true; return VDJX_OK; }      // (nothing waited for)
+	if (begun) HIP_TRY(hipEventRecord(c->ev_plan, st));
 	HIP_TRY(hipEventSynchronize(c->ev_plan));
-	const u32 run = *(const u32*) c->h_pin;
+	const u32 run = *h_run;
 	c->root_dp_hint = run + run / 4 + 1024;
 	c->stats["root_dp_items"] = run;
 	if (run >= (1u << 31)) { vdjx_set_error("too many seed hits in one call (%u)", run); return VDJX_ELIMIT; }
@@ -458,6 +465,56 @@ extern "C" int vdjx_root_score_graph(vdjx_ctx* c, const vdjx_graph* g, int thres
 	memset(out, 0, n);
 	if (k - c->vk <= 0 || c->n_seeds == 0) { HIP_TRY(hipStreamSynchronize(c->stream)); return VDJX_OK; }
 	return root_score_device(c, db, d_k, n, k, threshold, out);
+}
+
+// The same without waiting: kernels and result copies are queued on the context's stream and the call returns; the two arrays
+// (page-locked: vdjx_host_alloc) are valid after vdjx_root_score_graph_end.  Calls made in between run BEHIND it on the same stream
+// (they may reuse its workspace: stream order), so a caller with other work for the device -- the window scorer does not need the
+// root verdicts -- keeps it busy instead of waiting for a few kilobytes.  The graph must stay alive until _end.
+extern "C" int vdjx_root_score_graph_begin(vdjx_ctx* c, const vdjx_graph* g, int threshold, uint32_t first, uint32_t stride,
+                                           uint32_t* root_ids, uint8_t* out) {
+	if (!c || !g) { vdjx_set_error("vdjx_root_score_graph_begin: NULL argument"); return VDJX_EINVAL; }
+	if (c->root_pending) { vdjx_set_error("vdjx_root_score_graph_begin: a begun call has not been ended"); return VDJX_ESTATE; }
+	if (g->ctx != c) { vdjx_set_error("vdjx_root_score_graph_begin: graph belongs to another context"); return VDJX_EINVAL; }
+	if (stride == 0) { vdjx_set_error("vdjx_root_score_graph_begin: stride 0"); return VDJX_EINVAL; }
+	const size_t n = vdjx_root_part(g, first, stride);
+	const int k = g->k;
+	int rc = root_score_check(c, "vdjx_root_score_graph_begin", n, k);
+	if (rc) return rc;
+	if (n == 0) return VDJX_OK;
+	if (!root_ids || !out) { vdjx_set_error("vdjx_root_score_graph_begin: NULL result array"); return VDJX_EINVAL; }
+	if (k - c->vk <= 0 || c->n_seeds == 0 || threshold <= 0 || !c->root_dp_hint) return vdjx_root_score_graph(c, g, threshold, first, stride, root_ids, out);
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
+	vdjx_work db(c);
+	char* d_k;
+	u32* d_ids;
+	HIP_TRY(db.alloc(&d_k, n * k));
+	HIP_TRY(db.alloc(&d_ids, n));
+	hipLaunchKernelGGL(k_root_gather, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, c->stream, g->d_kmers, g->d_roots, first, stride, (u32) n, k, d_k, d_ids);
+	HIP_TRY(hipMemcpyAsync(root_ids, d_ids, n * 4, hipMemcpyDeviceToHost, c->stream));
+	bool begun = false;
+	rc = root_score_device(c, db, d_k, n, k, threshold, out, &begun);
+	if (rc || !begun) return rc;
+	HIP_TRY(hipEventRecord(c->ev_root_done, c->stream));
+	c->root_pending = true;
+	c->root_pending_g = g; c->root_pending_thr = threshold; c->root_pending_first = first; c->root_pending_stride = stride;
+	c->root_pending_ids = root_ids; c->root_pending_out = out;
+	return VDJX_OK;
+}
+extern "C" int vdjx_root_score_graph_end(vdjx_ctx* c) {
+	if (!c) { vdjx_set_error("vdjx_root_score_graph_end: NULL argument"); return VDJX_EINVAL; }
+	if (!c->root_pending) return VDJX_OK;
+	c->root_pending = false;
+	HIP_TRY(hipSetDevice(c->device));
+	HIP_TRY(hipEventSynchronize(c->ev_root_done));
+	HIP_TRY(hipGetLastError());
+	const u32 run = *((const u32*) c->h_pin + 2048);
+	c->root_dp_hint = run + run / 4 + 1024;
+	c->stats["root_dp_items"] = run;
+	if (run <= c->root_pending_ahead) return VDJX_OK;
+	// the guess fell short (a pool unlike the last one): the call again, the ordinary way
+	return vdjx_root_score_graph(c, c->root_pending_g, c->root_pending_thr, c->root_pending_first, c->root_pending_stride, c->root_pending_ids, c->root_pending_out);
 }
 
 // (a-8 read index: vdjx_rindex.hip)
