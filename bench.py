@@ -901,9 +901,12 @@ def main():
                                            "frac": lk.get("frac"), "achieved": lk.get("achieved"), "traffic": lk.get("traffic"),
                                            "hbm_streaming": lk.get("hbm_streaming")},
                 "frac_on_traffic": pr.get("frac_on_traffic"),
-                "frac_note": "`frac` prices SURVEY 8d's algorithmic bytes (for the walk: a 16-B probe per instance, most of which this design answers from two "
-                             "chain words in cache, so its PMC traffic is BELOW that figure); `frac_on_traffic` = PMC bytes / time / peak is what the kernel "
-                             "really moves per second",
+                "frac_note": "`frac` prices SURVEY 8d's algorithmic bytes (for the walk: the packed input of all four records of a pair and a 16-B probe per "
+                             "instance).  This design answers most probes from two chain words in cache, and since round 5 walks only the FIRST record of every "
+                             "couple (read, reverse complement) and derives the second (DESIGN 4.1): it does the modelled job on well under half the modelled "
+                             "bytes, so `frac` says how fast the model's bytes were dealt with, NOT how close the kernel runs to the HBM limit -- "
+                             "`frac_on_traffic` = fabric bytes the counters saw / time / peak does (calibrated: profiles/r05_ea_calib)",
+                "frac_half_records": round(pr["frac"] / 2, 5) if pr.get("frac") and stats.get("kmer_build_sym_walk") and dom[0] == "k_walk_items" else None,
                 "hot_path_frac": round(ab["total"] * args.pairs * len(W) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 # SURVEY 8d's per-pair figure takes EVERY instance as gated (3,324 B at k=35); with the gated instances this run measured
                 "hot_path_frac_gated": round((2 * ab["input"] + 32 * ab["gated_per_pair"] + 16 * ab["P"]) * args.pairs * len(W) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}

@@ -22,12 +22,14 @@ def main():
     alias = {"k_part_records": "k_part_records_g", "k_part_tuples": "k_part_tuples_g", "k_seg_hist": "k_seg_hist_g"}
     back = {v: k_ for k_, v in alias.items()}
     tr = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes (profiles/prof_step.sh), median per launch; "
-                  "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: both counters are in KB and on gfx950 FETCH_SIZE counts half of the streamed "
-                  "read bytes (MI355X_MICROARCH.md, HBM)",
+                  "both counters are in KB; on gfx950 FETCH_SIZE is 64 B per read request and a coalesced 16-byte-per-lane stream is one request "
+                  "per 128 B (profiles/r05_ea_calib): hbm_bytes = (FETCH + min(FETCH, stream_in/2) + WRITE)*1024 where the kernel's streamed "
+                  "input is stated (summarize_pmc.py STREAM_IN), else the bound (2*FETCH + WRITE)*1024; traffic_rule says which",
           "commit": commit, "passes": tag, "pairs_per_gpu": pairs, "k": k, "windows": "generator", "kernels": {}}
     for name, v in pm.items():
         if "hbm_bytes" in v and name.startswith("k_"):
-            tr["kernels"][back.get(name, name)] = {"hbm_bytes": v["hbm_bytes"], "fetch_kb": v.get("FETCH_SIZE"), "write_kb": v.get("WRITE_SIZE")}
+            tr["kernels"][back.get(name, name)] = {"hbm_bytes": v["hbm_bytes"], "fetch_kb": v.get("FETCH_SIZE"), "write_kb": v.get("WRITE_SIZE"),
+                                                   "traffic_rule": v.get("traffic_rule")}
     json.dump(tr, open(os.path.join(HERE, f"{rnd}_traffic.json"), "w"), indent=1, sort_keys=True)
     st = dict(b["scorer_stats"])
     gi = st.get("gated_instances")
