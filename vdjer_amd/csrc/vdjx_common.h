@@ -567,3 +567,14 @@ __device__ inline u32 vdjx_wave_inc(u32* ctr, bool pred) {
 	base = (u32) __builtin_amdgcn_readlane((int) base, leader);     // (v_readlane: no LDS round trip, unlike __shfl)
 	return base + (u32) __popcll(m & ((1ull << lane) - 1ull));
 }
+// the same with `each` places per lane
+__device__ inline u32 vdjx_wave_inc(u32* ctr, bool pred, u32 each) {
+	const u64 m = __ballot(pred);
+	if (!m) return 0;
+	const int lane = __lane_id();
+	const int leader = __ffsll((long long) m) - 1;
+	u32 base = 0;
+	if (lane == leader) base = atomicAdd(ctr, each * (u32) __popcll(m));
+	base = (u32) __builtin_amdgcn_readlane((int) base, leader);
+	return base + each * (u32) __popcll(m & ((1ull << lane) - 1ull));
+}

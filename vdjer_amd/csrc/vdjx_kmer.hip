@@ -933,11 +933,25 @@ struct Partial { u64 lo, hi; u32 cg, h; u64 fg; };     // 32 bytes, what travels
                                                        // looks every partial up three times and need not hash it again), first gated instance
 #define PART_FLAG 0x80000000u
 #define CNT_CAP 32765u
+// SYM (pools made of couples, k odd; see k_gated_reduce): ONE aggregate per pair {k-mer, its reverse complement}, under the smaller of
+// the two -- the canonical k-mer the tuples carry -- in the same 32 bytes: count and flag are the same on both sides (every gated
+// instance has its mirror image in the record next door), the first gated instances are not, and both travel:
+//   lo | hi (2k - 64 <= 36 bits) + count (15 bits) and flag in bits 48..63 | first gated instance (38 bits) + 26 bits of the table
+//   hash | the reverse complement's first gated instance
+struct PartialS { u64 lo, hic, fgh, fgr; };
+static_assert(sizeof(PartialS) == sizeof(Partial), "vdjx_shard_record_bytes(0) is one number");
+#define PS_H_BITS 26
+#define PS_MAX_SPLIT (1u << (PS_H_BITS - 12))        // the merge picks its sub-pass by hash bits 12 and up
+__device__ inline u64 ps_hi(const PartialS& p) { return p.hic & 0xFFFFFFFFFFFFull; }
+__device__ inline u32 ps_cg(const PartialS& p) { const u32 c = (u32) (p.hic >> 48); return (c & 0x7FFFu) | ((c & 0x8000u) ? PART_FLAG : 0u); }
+__device__ inline u64 ps_fg(const PartialS& p) { return p.fgh & INST_MASK64; }
+__device__ inline u32 ps_h(const PartialS& p) { return (u32) (p.fgh >> INST_BITS); }
 #define NEED_SEQ 1u
 #define NEED_Q 2u
 #define PID_MASK 0x3FFFFFFFu
 #define REPLY_KQ 52                 // quality bytes per row (k <= 50)
-#define REPLY_BYTES 240             // pid | need, first instance (u64), the record's bases and N mask (8 words: 2 + 1 or 5 + 3), 3 quality rows
+#define REPLY_BYTES 408             // pid | need, first instance (u64), the record's bases and N mask (8 words: 2 + 1 or 5 + 3), 3 quality rows;
+                                    // SYM: from byte 240 the reverse complement's first instance and ITS 3 quality rows
 
 // this rank's partial aggregates of one bucket of its gated tuples: count, first instance, "saw two different reads" (any two:
 // the owner ORs the ranks' flags and compares their first records); k-mers whose count is below TLOW also list their instances.
@@ -948,11 +962,9 @@ struct Partial { u64 lo, hi; u32 cg, h; u64 fg; };     // 32 bytes, what travels
 #define LG_UNR 4
 #define LG_FLAG 0x80000000u
 #define LG_NOLIST 0x7FFFFFFFu
-#define REF_MIRROR 0x80000000u       // sparse_ref / dense_ref: the listed instances are those of the reverse complement: mirror them (SYM)
-// SYM (see k_gated_reduce): the tuples are the canonical half; a table entry leaves as TWO partial aggregates, the k-mer's and its
-// reverse complement's (same count and flag, the mirrored first instance: exact where it can matter, i.e. below TLOW instances),
-// side by side in THIS bucket -- all ranks cut the buckets by the canonical k-mer, so both reach the same owner and the same
-// merge table, where they are two keys like any others.  A bucket of n tuples makes up to 2n aggregates: its region starts at 2 x base.
+// SYM (see k_gated_reduce): the tuples are the canonical half; a table entry leaves as ONE aggregate for the k-mer and its reverse
+// complement together (PartialS: the reverse complement's first instance is the smallest mirrored one -- exact where it can matter,
+// i.e. below TLOW instances, where the instances are listed).  All ranks cut the buckets by the canonical k-mer.
 template <typename TUP, bool SYM = false>
 __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated_local(const TUP* __restrict__ tup, const u32* __restrict__ bucket_start,
                                                             const u64* __restrict__ bases, const u64* __restrict__ nmask, u64 rec_base, int k, int rl, int ob,
@@ -960,7 +972,7 @@ __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated
                                                             u32* __restrict__ nd_g, u64* __restrict__ low_inst, u32* __restrict__ g_err,
                                                             const u32* __restrict__ order) {
 	typedef typename TUP::hi_t THI;
-	const size_t obase = SYM ? 2 * (size_t) bucket_start[order ? order[blockIdx.x] : blockIdx.x] : (size_t) bucket_start[order ? order[blockIdx.x] : blockIdx.x];
+	const size_t obase = (size_t) bucket_start[order ? order[blockIdx.x] : blockIdx.x];
 	__shared__ u64 s_klo[LOCAL_SLOTS];
 	__shared__ THI s_khi[LOCAL_SLOTS];
 	__shared__ u64 s_mg[LOCAL_SLOTS];
@@ -1079,22 +1091,20 @@ __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated
 				p.fg = s_mg[i];
 				p.cg = (cg > CNT_CAP ? CNT_CAP : cg) | ((st & LG_FLAG) ? PART_FLAG : 0u);
 				p.h = rd_hash(p.lo, p.hi);
-				const u32 gi = atomicAdd(&s_ng, SYM ? 2u : 1u);
-				sparse_g[obase + gi] = p;
+				const u32 gi = atomicAdd(&s_ng, 1u);
 				sparse_ref[obase + gi] = loff != LG_NOLIST ? base + loff : NONE32;
 				if (SYM) {
-					// the reverse complement's aggregate: the mirrored instances; its first one exactly where the owner may ask for it
+					// the reverse complement's first gated instance: the smallest mirrored one, exactly where the owner may ask about it
 					u64 fr = vdjx_inst_mirror(p.fg, ob, rl, k);
 					if (loff != LG_NOLIST)
 						for (u32 j = 0; j < cg; j++) { const u64 m = vdjx_inst_mirror(low_inst[base + loff + j], ob, rl, k); fr = m < fr ? m : fr; }
-					Partial q;
-					vdjx_kmer_rc(p.hi, p.lo, k, q.hi, q.lo);
-					q.fg = fr;
-					q.cg = p.cg;
-					q.h = rd_hash(q.lo, q.hi);
-					sparse_g[obase + gi + 1] = q;
-					sparse_ref[obase + gi + 1] = loff != LG_NOLIST ? (base + loff) | REF_MIRROR : NONE32;
-				}
+					PartialS q;
+					q.lo = p.lo;
+					q.hic = p.hi | ((u64) ((p.cg & 0x7FFFu) | ((p.cg & PART_FLAG) ? 0x8000u : 0u)) << 48);
+					q.fgh = p.fg | ((u64) (p.h & ((1u << PS_H_BITS) - 1u)) << INST_BITS);
+					q.fgr = fr;
+					((PartialS*) sparse_g)[obase + gi] = q;
+				} else sparse_g[obase + gi] = p;
 			}
 			__syncthreads();
 		}
@@ -1110,17 +1120,21 @@ __global__ __launch_bounds__(LG_THREADS, sizeof(TUP) == 16 ? 6 : 3) void k_gated
 __global__ __launch_bounds__(256) void k_compact_partials(const Partial* __restrict__ sparse, const u32* __restrict__ sparse_ref,
                                                           const u32* __restrict__ bucket_start, const u32* __restrict__ nd,
                                                           const u32* __restrict__ dstart, Partial* __restrict__ dense, u32* __restrict__ dense_ref,
-                                                          const u32* __restrict__ scan, int ob, u32 mul) {
+                                                          const u32* __restrict__ scan, int ob, bool sym) {
 	const u32 b = blockIdx.x;
-	const u64* src = (const u64*) (sparse + (size_t) mul * bucket_start[b]);        // (mul = 2: k_gated_local SYM)
+	const u64* src = (const u64*) (sparse + (size_t) bucket_start[b]);
 	u64* dst = (u64*) (dense + dstart[b]);
 	const u32 m = nd[b];
+	const u64 om = (1ull << ob) - 1ull;
 	for (u32 i = threadIdx.x; i < m * 4; i += 256) {
 		u64 v = src[i];
-		if (scan && (i & 3u) == 3u) v = ((u64) scan[v >> ob] << ob) | (v & ((1ull << ob) - 1ull));      // (share mode: the first instance leaves as a scan position)
+		if (scan) {          // share mode: the first instances leave as scan positions (PartialS: both of them, the first below its hash bits)
+			if ((i & 3u) == 3u) v = ((u64) scan[v >> ob] << ob) | (v & om);
+			else if (sym && (i & 3u) == 2u) { const u64 f = v & INST_MASK64; v = (v & ~INST_MASK64) | ((u64) scan[f >> ob] << ob) | (f & om); }
+		}
 		dst[i] = v;
 	}
-	for (u32 i = threadIdx.x; i < m; i += 256) dense_ref[dstart[b] + i] = sparse_ref[(size_t) mul * bucket_start[b] + i];
+	for (u32 i = threadIdx.x; i < m; i += 256) dense_ref[dstart[b] + i] = sparse_ref[(size_t) bucket_start[b] + i];
 }
 
 // seg_cnt[s*NBo + b] (what arrived) -> seg_off (absolute offsets into the receive buffer); src_base[s] = start of source s.
@@ -1149,21 +1163,29 @@ __global__ __launch_bounds__(1024) void k_seg_offsets(const u32* __restrict__ se
 	if (threadIdx.x == 1023) off[NBo] = src_base[s] + part[1023];
 }
 
-struct PendOut { u64* lo; u64* hi; u32* cg; u64* mg; u32* need; u32* n; u32 cap; };
+struct PendOut { u64* lo; u64* hi; u32* cg; u64* mg; u32* need; u32* n; u32 cap; u64* mgr; };      // (mgr: SYM, the reverse complement's first gated instance)
 
 #define MERGE_THREADS 512
 #define MERGE_SLOTS 2048u             // a bucket holds ~1,000 distinct gated k-mers of all ranks together at 3,000 tuples per bucket
-template <typename THI>
+// SYM: the aggregates are PartialS, one per pair of mirrored k-mers under the canonical one: one table entry decides both (count and
+// flag are the same on both sides); what is decided here leaves as two survivors side by side, what is still open as one question
+// s_st, one word per table entry with two lives.  While the aggregates arrive: sources that sent the k-mer (at most 256) | MS_FLAG per
+// source that saw two different reads.  Once decided: NONE32 nothing to do | place among this sub-pass's survivors (top two bits
+// clear) | question number | what is asked << 30 (NEED_SEQ, NEED_Q: never zero)
+#define MS_FLAG 0x10000u
+__device__ inline bool ms_open(u32 st) { return st != NONE32 && (st >> 30) != 0u; }
+template <typename THI, bool SYM = false>
 __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* __restrict__ recv, const u32* __restrict__ seg_off,
                                                                 u32 MG, u32 G, u32 NBo,
                                                                 const u32* __restrict__ src_base, u32 s_mult, u32 cmin, u32 tlow,
                                                                 SurvOutG so, PendOut po,
                                                                 uint2* __restrict__ queries, u32* __restrict__ g_nq,
-                                                                u64* __restrict__ g_distinct, u32* __restrict__ g_err) {
+                                                                u64* __restrict__ g_distinct, u32* __restrict__ g_err, int k) {
 	__shared__ u64 s_klo[MERGE_SLOTS];
 	__shared__ THI s_khi[MERGE_SLOTS];
 	__shared__ u64 s_mg[MERGE_SLOTS];
-	__shared__ u32 s_cg[MERGE_SLOTS], s_pid[MERGE_SLOTS], s_nsg[MERGE_SLOTS], s_fl[MERGE_SLOTS];
+	__shared__ u64 s_mgr[SYM ? MERGE_SLOTS : 1];
+	__shared__ u32 s_cg[MERGE_SLOTS], s_st[MERGE_SLOTS];
 	__shared__ u32 s_over, s_ndist, s_total, s_ns, s_np, s_sbase, s_pbase;
 	__shared__ u32 s_pend[MERGE_SLOTS / 32];               // bit h & (MERGE_SLOTS - 1): a k-mer with that home slot has a question open
 	const THI EMPTY = (THI) ~(THI) 0;
@@ -1181,23 +1203,31 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 	u32 S = 1;
 	while ((u64) S * (MERGE_SLOTS * 3 / 4) < total) S <<= 1;      // (a sub-pass's k-mers cannot outnumber its partials: the table never fills)
 	S *= s_mult;
+	if (SYM && S > PS_MAX_SPLIT) { if (tid == 0) atomicAdd(g_err, 1u); return; }        // (a PartialS carries PS_H_BITS bits of the hash)
+	// an aggregate's key and hash, whichever way it is packed
+	auto key_of = [&](u32 at, u64& lo, u64& hi, u32& h) {
+		if (SYM) { const PartialS q = ((const PartialS*) recv)[at]; lo = q.lo; hi = ps_hi(q); h = ps_h(q); }
+		else { const Partial q = recv[at]; lo = q.lo; hi = q.hi; h = q.h; }
+	};
 	{
 		if (tid == 0) { s_over = 0; s_ndist = 0; }
 		for (u32 sp = 0; sp < S; sp++) {
-			for (u32 i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE64; s_fl[i] = 0; s_nsg[i] = 0; s_pid[i] = NONE32; }
+			for (u32 i = tid; i < MERGE_SLOTS; i += MERGE_THREADS) { s_khi[i] = EMPTY; s_cg[i] = 0; s_mg[i] = NONE64; s_st[i] = 0; if (SYM) s_mgr[i] = NONE64; }
 			__syncthreads();
 			for (u32 s = 0; s < G; s++) {
 				const u32 off = seg_off[(size_t) s * (NBo + 1) + b * MG], cnt = seg_off[(size_t) s * (NBo + 1) + (b + 1) * MG] - off;
 				for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
-					const Partial p = recv[off + i];
-					const u32 h = p.h;
+					u64 lo, hi, fg, fgr = 0;
+					u32 h, cg;
+					if (SYM) { const PartialS q = ((const PartialS*) recv)[off + i]; lo = q.lo; hi = ps_hi(q); h = ps_h(q); cg = ps_cg(q); fg = ps_fg(q); fgr = q.fgr; }
+					else { const Partial q = recv[off + i]; lo = q.lo; hi = q.hi; h = q.h; cg = q.cg; fg = q.fg; }
 					if (((h >> 12) & (S - 1)) != sp) continue;
-					const int slot = lds_insert<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, h);
+					const int slot = lds_insert<THI, MERGE_SLOTS>(s_klo, s_khi, lo, (THI) hi, h);
 					if (slot < 0) { s_over = 1; continue; }
-					atomicAdd(&s_cg[slot], p.cg & ~PART_FLAG);
-					atomicMin((unsigned long long*) &s_mg[slot], (unsigned long long) p.fg);
-					atomicAdd(&s_nsg[slot], 1u);
-					if (p.cg & PART_FLAG) s_fl[slot] = 1;
+					atomicAdd(&s_cg[slot], cg & ~PART_FLAG);
+					atomicMin((unsigned long long*) &s_mg[slot], (unsigned long long) fg);
+					if (SYM) atomicMin((unsigned long long*) &s_mgr[slot], (unsigned long long) fgr);
+					atomicAdd(&s_st[slot], 1u | ((cg & PART_FLAG) ? MS_FLAG : 0u));          // (the flag: added once per source, at most 256 times -- it may carry into the bits above, all of which read as "set")
 				}
 			}
 			__syncthreads();
@@ -1213,18 +1243,19 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 				bool live = s_khi[i] != EMPTY;
 				if (live) {
 					cg = s_cg[i];
-					atomicAdd(&s_ndist, 1u);
+					atomicAdd(&s_ndist, SYM ? 2u : 1u);
 					if (cg < cmin) live = false;                 // count >= max(mf, 2): A2:349-352,476
 				}
-				if (live && !s_fl[i]) {
-					if (s_nsg[i] < 2) live = false;              // one rank holds every gated instance and saw one read only
+				const u32 st0 = s_st[i];
+				if (live && !(st0 >> 16)) {
+					if ((st0 & 0xFFFFu) < 2) live = false;       // one rank holds every gated instance and saw one read only
 					else need |= NEED_SEQ;
 				}
 				if (live && cg < tlow) need |= NEED_Q;
-				if (live && !need) s_nsg[i] = 0x80000000u | atomicAdd(&s_ns, 1u);
-				else s_nsg[i] = 0;
+				if (live && !need) s_st[i] = atomicAdd(&s_ns, SYM ? 2u : 1u);
+				else s_st[i] = NONE32;
 				if (live && need) {
-					s_pid[i] = atomicAdd(&s_np, 1u) | (need << 30);
+					s_st[i] = atomicAdd(&s_np, 1u) | (need << 30);
 					const u32 hm = rd_hash(s_klo[i], (u64) s_khi[i]) & (MERGE_SLOTS - 1);
 					atomicOr(&s_pend[hm >> 5], 1u << (hm & 31));
 				}
@@ -1237,22 +1268,31 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 			__syncthreads();
 			for (u32 i0 = 0; i0 < MERGE_SLOTS; i0 += MERGE_THREADS) {
 				const u32 i = i0 + tid;
-				if (s_nsg[i] & 0x80000000u) {
-					const u32 pos = s_sbase + (s_nsg[i] & 0x7FFFFFFFu);
+				const u32 st = s_st[i];
+				if (st != NONE32 && !(st >> 30)) {
+					const u32 pos = s_sbase + st;
 					if (pos < so.cap) {
 						const u32 cg = s_cg[i];
 						so.lo[pos] = s_klo[i]; so.hi[pos] = (u64) s_khi[i];
 						so.gcnt[pos] = cg > CNT_CAP ? CNT_CAP : cg; so.gfirst[pos] = s_mg[i];
 					}
-				} else if (s_pid[i] != NONE32) {
-					const u32 need = s_pid[i] >> 30;
-					const u32 pid = s_pbase + (s_pid[i] & PID_MASK);
+					if (SYM && pos + 1 < so.cap) {
+						const u32 cg = s_cg[i];
+						u64 rh, rlo;
+						vdjx_kmer_rc((u64) s_khi[i], s_klo[i], k, rh, rlo);
+						so.lo[pos + 1] = rlo; so.hi[pos + 1] = rh;
+						so.gcnt[pos + 1] = cg > CNT_CAP ? CNT_CAP : cg; so.gfirst[pos + 1] = s_mgr[i];
+					}
+				} else if (st != NONE32) {
+					const u32 need = st >> 30;
+					const u32 pid = s_pbase + (st & PID_MASK);
 					if (pid < po.cap) {
 						po.lo[pid] = s_klo[i]; po.hi[pid] = (u64) s_khi[i];
 						po.cg[pid] = s_cg[i]; po.mg[pid] = s_mg[i];
+						if (SYM) po.mgr[pid] = s_mgr[i];
 						po.need[pid] = need;
 					}
-					s_pid[i] = pid | (need << 30);
+					s_st[i] = pid | (need << 30);
 				}
 			}
 			__syncthreads();
@@ -1264,12 +1304,13 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 				__syncthreads();
 				u32 mine = 0;
 				for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
-					const Partial p = recv[off + i];
-					const u32 h = p.h;
+					u64 lo, hi;
+					u32 h;
+					key_of(off + i, lo, hi, h);
 					if (((h >> 12) & (S - 1)) != sp) continue;
 					if (!((s_pend[(h & (MERGE_SLOTS - 1)) >> 5] >> (h & 31)) & 1u)) continue;       // (few k-mers have a question open: most partials stop here)
-					const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, h);
-					if (slot >= 0 && s_pid[slot] != NONE32) mine++;
+					const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, lo, (THI) hi, h);
+					if (slot >= 0 && ms_open(s_st[slot])) mine++;
 				}
 				if (mine) atomicAdd(&s_ns, mine);
 				__syncthreads();
@@ -1277,14 +1318,15 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 				__syncthreads();
 				if (s_ns) {
 					for (u32 i = tid; i < cnt; i += MERGE_THREADS) {
-						const Partial p = recv[off + i];
-						const u32 h = p.h;
+						u64 lo, hi;
+						u32 h;
+						key_of(off + i, lo, hi, h);
 						if (((h >> 12) & (S - 1)) != sp) continue;
 						if (!((s_pend[(h & (MERGE_SLOTS - 1)) >> 5] >> (h & 31)) & 1u)) continue;
-						const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, p.lo, (THI) p.hi, h);
+						const int slot = lds_lookup<THI, MERGE_SLOTS>(s_klo, s_khi, lo, (THI) hi, h);
 						if (slot < 0) continue;
-						const u32 pid = s_pid[slot];
-						if (pid != NONE32) queries[src_base[s] + s_sbase + atomicAdd(&s_np, 1u)] = make_uint2(off + i - src_base[s], pid);
+						const u32 pid = s_st[slot];
+						if (ms_open(pid)) queries[src_base[s] + s_sbase + atomicAdd(&s_np, 1u)] = make_uint2(off + i - src_base[s], pid);
 					}
 				}
 				__syncthreads();
@@ -1303,7 +1345,11 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_bucket_merge(const Partial* _
 //   for reads of more than 64 bases; the rest zero)
 //   [80,132) QS: sum of the own qualities of this rank's OTHER gated instances (saturating at 255: >= 214 reads as 255 anyway)
 //   [132,184) the first instance's own qualities   [184,236) its RECORD's first k qualities (A2:337-339)
+//   SYM: [240,248) the first gated instance of the reverse complement, [248,404) the same three rows for it (over the mirrored instances)
 #define REPLY_Q0 80
+#define REPLY_R0 240
+#define REPLY_RQ0 248
+template <bool SYM>
 __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ queries, u32 nq, const u32* __restrict__ owner_off, u32 G,
                                                     const Partial* __restrict__ dense, const u32* __restrict__ dense_ref,
                                                     const u32* __restrict__ dstart, u32 NBo, const u64* __restrict__ low_inst,
@@ -1317,63 +1363,80 @@ __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ qu
 	while (o + 1 < G && owner_off[o + 1] <= qi) o++;
 	const uint2 q = queries[qi];
 	const u32 di = dstart[(size_t) o * NBo] + q.x;
-	const Partial p = dense[di];
+	u64 finst, finst_r = 0;
+	u32 p_cg;
+	if (SYM) { const PartialS p = ((const PartialS*) dense)[di]; finst = ps_fg(p); finst_r = p.fgr; p_cg = ps_cg(p); }
+	else { const Partial p = dense[di]; finst = p.fg; p_cg = p.cg; }
 	const u32 need = q.y >> 30;
-	const u64 finst = p.fg;
 	const u32 om = (1u << ob) - 1u;
-	u64 frec = (finst >> ob) - rec_base;
-	const u32 foff = (u32) finst & om;
-	if (scan) {        // share mode: the aggregate carries a scan position; the local record is where the share holds it (the share ascends)
-		const u32 g = (u32) (finst >> ob);
+	// share mode: the aggregate carries a scan position; the local record is where the share holds it (the share ascends)
+	auto local_rec = [&](u64 inst) -> u64 {
+		if (!scan) return (inst >> ob) - rec_base;
+		const u32 g = (u32) (inst >> ob);
 		u32 lo = 0, hi = n_local;
 		while (lo + 1 < hi) { const u32 mid = lo + ((hi - lo) >> 1); if (scan[mid] <= g) lo = mid; else hi = mid; }
-		frec = lo;
-	}
+		return lo;
+	};
+	const u64 frec = local_rec(finst);
+	const u32 foff = (u32) finst & om;
 	const u64 finst_local = (frec << ob) | foff;
+	const u64 frec_r = SYM ? local_rec(finst_r) : 0;
+	const u32 foff_r = (u32) finst_r & om;
+	const u64 finst_r_local = (frec_r << ob) | foff_r;
 	uint8_t* out = replies + (size_t) qi * REPLY_BYTES;
 	if (lane == 0) {
 		((u32*) out)[0] = q.y;
 		((u32*) out)[1] = 0;
 		((u64*) out)[1] = finst;
+		if (SYM) ((u64*) out)[REPLY_R0 / 8] = finst_r;
 	}
 	if (lane < 8) {
 		const int W = rl <= VDJX_SHORT_READ_LEN ? 2 : VDJX_LONG_W, M = rl <= VDJX_SHORT_READ_LEN ? 1 : VDJX_LONG_M;
 		((u64*) out)[2 + lane] = (int) lane < W ? bases[frec * W + lane] : ((int) lane < W + M ? nmask[frec * M + (lane - W)] : 0ull);
 	}
 	if ((int) lane >= k) return;
-	u32 acc = 0;
-	const u32 ref0 = dense_ref[di];
-	const bool mirror = ref0 != NONE32 && (ref0 & REF_MIRROR);       // (the aggregate of a reverse complement: k_gated_local SYM lists the other side's instances)
-	const u32 ref = ref0 == NONE32 ? NONE32 : ref0 & ~REF_MIRROR;
+	u32 acc = 0, acc_r = 0;
+	const u32 ref = dense_ref[di];
 	if ((need & NEED_Q) && ref != NONE32) {          // a question about the sums only comes for a count below TLOW: the list exists
-		const u32 cg = p.cg & ~PART_FLAG;
+		const u32 cg = p_cg & ~PART_FLAG;
 		for (u32 i = 0; i < cg; i++) {
-			const u64 inst = mirror ? vdjx_inst_mirror(low_inst[ref + i], ob, rl, k) : low_inst[ref + i];
-			if (inst == (scan ? finst_local : finst)) continue;
-			const u64 rec = (inst >> ob) - rec_base;
-			const u32 off = (u32) inst & om;
-			acc += (u32) (uint8_t) (quals.row(rec)[off + lane] - 33);
+			const u64 inst = low_inst[ref + i];
+			if (inst != (scan ? finst_local : finst)) acc += (u32) (uint8_t) (quals.row((inst >> ob) - rec_base)[((u32) inst & om) + lane] - 33);
+			if (SYM) {
+				const u64 m = vdjx_inst_mirror(inst, ob, rl, k);
+				if (m != (scan ? finst_r_local : finst_r)) acc_r += (u32) (uint8_t) (quals.row((m >> ob) - rec_base)[((u32) m & om) + lane] - 33);
+			}
 		}
 	}
 	const uint8_t* fr = quals.row(frec);
 	out[REPLY_Q0 + lane] = (uint8_t) (acc > 255u ? 255u : acc);
 	out[REPLY_Q0 + REPLY_KQ + lane] = (uint8_t) (fr[foff + lane] - 33);
 	out[REPLY_Q0 + 2 * REPLY_KQ + lane] = (uint8_t) (fr[lane] - 33);
+	if (SYM) {
+		const uint8_t* frr = quals.row(frec_r);
+		out[REPLY_RQ0 + lane] = (uint8_t) (acc_r > 255u ? 255u : acc_r);
+		out[REPLY_RQ0 + REPLY_KQ + lane] = (uint8_t) (frr[foff_r + lane] - 33);
+		out[REPLY_RQ0 + 2 * REPLY_KQ + lane] = (uint8_t) (frr[lane] - 33);
+	}
 }
 
 // owner: which answer comes from the rank of the global first instance
-__global__ void k_resolve_first(const uint8_t* __restrict__ replies, u32 nr, const u64* __restrict__ p_mg, u32* __restrict__ p_r0) {
+// (SYM: and which from the rank of the reverse complement's -- p_r0[np + pid])
+__global__ void k_resolve_first(const uint8_t* __restrict__ replies, u32 nr, const u64* __restrict__ p_mg, u32* __restrict__ p_r0,
+                                const u64* __restrict__ p_mgr, u32 np) {
 	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= nr) return;
 	const uint8_t* me = replies + (size_t) r * REPLY_BYTES;
 	const u32 pid = ((const u32*) me)[0] & PID_MASK;
 	if (((const u64*) me)[1] == p_mg[pid]) p_r0[pid] = r;
+	if (p_mgr && ((const u64*) me)[REPLY_R0 / 8] == p_mgr[pid]) p_r0[np + pid] = r;
 }
 
 // one wave per answer: lane j adds the answer's j-th quality sum (64 consecutive words per wave instead of k scattered atomics of
 // one thread)
+// SYM (np != 0): the sums of the reverse complement in the second half of p_S (np * 64 words on)
 __global__ __launch_bounds__(256) void k_resolve_add(const uint8_t* __restrict__ replies, u32 nr, const u32* __restrict__ p_r0, int k, u32* __restrict__ p_fl,
-                                                     u32* __restrict__ p_S) {
+                                                     u32* __restrict__ p_S, u32 np) {
 	const u32 r = blockIdx.x * 4u + (threadIdx.x >> 6);
 	const u32 lane = threadIdx.x & 63u;
 	if (r >= nr) return;
@@ -1393,25 +1456,47 @@ __global__ __launch_bounds__(256) void k_resolve_add(const uint8_t* __restrict__
 	if ((need & NEED_Q) && (int) lane < k) {
 		const uint8_t* first = me + REPLY_Q0 + (r == r0 ? 2 * REPLY_KQ : REPLY_KQ);
 		atomicAdd(&p_S[(size_t) pid * 64 + lane], (u32) me[REPLY_Q0 + lane] + (u32) first[lane]);
+		if (np) {
+			const uint8_t* first_r = me + REPLY_RQ0 + (r == p_r0[np + pid] ? 2 * REPLY_KQ : REPLY_KQ);
+			atomicAdd(&p_S[((size_t) np + pid) * 64 + lane], (u32) me[REPLY_RQ0 + lane] + (u32) first_r[lane]);
+		}
 	}
 }
 
+// SYM: an open pair {k-mer, reverse complement} has one verdict on its reads and one per side on its qualities (the first instance's
+// quirk, A2:337-339, is not mirror-symmetric); if either side stays, both leave, the other as a SHADOW (GC_SHADOW, see k_gated_reduce)
+template <bool SYM>
 __global__ void k_resolve_keep(PendOut po, u32 np, const u32* __restrict__ p_fl, const u32* __restrict__ p_S, int k, u32 mf, u32 mqq, u32 tlow,
                                SurvOutG so) {
 	const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-	if (p >= np) return;
-	const u32 need = po.need[p];
-	bool keep = (need & NEED_SEQ) ? p_fl[p] != 0 : true;
-	const u32 cg = po.cg[p];
-	if (keep && cg < tlow) {
-		for (int j = 0; j < k; j++) if (p_S[(size_t) p * 64 + j] < mqq) { keep = false; break; }
-	}
+	const bool in = p < np;
+	const u32 need = in ? po.need[p] : 0u;
+	bool keep = in && ((need & NEED_SEQ) ? p_fl[p] != 0 : true);
+	const u32 cg = in ? po.cg[p] : 0u;
 	const u32 cgc = cg > CNT_CAP ? CNT_CAP : cg;
 	keep = keep && cgc >= mf;
-	const u32 pos = vdjx_wave_inc(so.n, keep);
-	if (keep && pos < so.cap) {
+	bool keep_r = keep;
+	if (keep && cg < tlow) {
+		for (int j = 0; j < k; j++) if (p_S[(size_t) p * 64 + j] < mqq) { keep = false; break; }
+		if (SYM) for (int j = 0; j < k; j++) if (p_S[((size_t) np + p) * 64 + j] < mqq) { keep_r = false; break; }
+	}
+	if (!SYM) {
+		const u32 pos = vdjx_wave_inc(so.n, keep);
+		if (keep && pos < so.cap) {
+			so.lo[pos] = po.lo[p]; so.hi[pos] = po.hi[p];
+			so.gcnt[pos] = cgc; so.gfirst[pos] = po.mg[p];
+		}
+		return;
+	}
+	const bool any = keep || keep_r;
+	const u32 pos = vdjx_wave_inc(so.n, any, 2u);
+	if (any && pos + 1 < so.cap) {
 		so.lo[pos] = po.lo[p]; so.hi[pos] = po.hi[p];
-		so.gcnt[pos] = cgc; so.gfirst[pos] = po.mg[p];
+		so.gcnt[pos] = cgc | (keep ? 0u : GC_SHADOW); so.gfirst[pos] = po.mg[p];
+		u64 rh, rlo;
+		vdjx_kmer_rc(po.hi[p], po.lo[p], k, rh, rlo);
+		so.lo[pos + 1] = rlo; so.hi[pos + 1] = rh;
+		so.gcnt[pos + 1] = cgc | (keep_r ? 0u : GC_SHADOW); so.gfirst[pos + 1] = po.mgr[p];
 	}
 }
 
@@ -2310,12 +2395,17 @@ __global__ void k_surv_pack(const u64* __restrict__ lo, const u64* __restrict__ 
 	out[i] = r;
 }
 
+// (n_real: the survivors that are not shadows, GC_SHADOW)
 __global__ void k_surv_unpack(const SurvRec* __restrict__ in, u32 n, u64* __restrict__ lo, u64* __restrict__ hi, u32* __restrict__ gcnt,
-                              u64* __restrict__ gfirst) {
+                              u64* __restrict__ gfirst, u32* __restrict__ n_real) {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const SurvRec r = in[i];
-	lo[i] = r.lo; hi[i] = r.hi; gcnt[i] = r.gcnt; gfirst[i] = r.gfirst;
+	const bool in_range = i < n;
+	SurvRec r{0, 0, GC_SHADOW, 0, 0};
+	if (in_range) {
+		r = in[i];
+		lo[i] = r.lo; hi[i] = r.hi; gcnt[i] = r.gcnt; gfirst[i] = r.gfirst;
+	}
+	(void) vdjx_wave_inc(n_real, in_range && !(r.gcnt & GC_SHADOW));
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -3298,8 +3388,7 @@ static int shard_local_impl(vdjx_shard* s) {
 	GTuples<TUP> t;
 	int rc = VDJX_OK;
 	if (s->have_hist && s->gh.sym != s->sym) s->have_hist = false;          // (counted before the ranks had compared their pools: once more, the other way)
-	// (SYM: a table entry leaves as two aggregates, so the owner's merge table sees twice what the local one held: buckets of half the tuples)
-	const size_t per_b = s->sym ? tune("VDJX_GATED_BUCKET", 3072) / 2 : 0;
+	const size_t per_b = 0;
 	if (!s->have_hist) rc = stage_gated_hist(c, db, s->pool, s->k, per_b, shard_geometry_bound(s) / (s->sym ? 2 : 1), &s->gh, s->sym);
 	if (rc) return rc;
 	s->have_hist = true;
@@ -3312,13 +3401,13 @@ static int shard_local_impl(vdjx_shard* s) {
 	Partial* sparse;
 	u32 *g_err, *sparse_ref;
 	HIP_TRY(db.alloc(&s->low_inst, cap));
-	HIP_TRY(db.alloc(&s->dense_ref, (s->sym ? 2 : 1) * cap));
+	HIP_TRY(db.alloc(&s->dense_ref, cap));
 	HIP_TRY(db.alloc(&s->nd, nb_max));
 	HIP_TRY(db.alloc(&s->dstart, nb_max + 1));
 	HIP_TRY(db.alloc(&g_err, 1));
 	s->fill_mark = db.mark();
-	HIP_TRY(db.alloc(&sparse, (s->sym ? 2 : 1) * cap));              // (SYM: two aggregates per table entry)
-	HIP_TRY(db.alloc(&sparse_ref, (s->sym ? 2 : 1) * cap));
+	HIP_TRY(db.alloc(&sparse, cap));
+	HIP_TRY(db.alloc(&sparse_ref, cap));
 	const vdjx_arena::mark_t tuple_mark = db.mark();
 	rc = stage_gated_cut<TUP>(c, db, s->pool, rec_base, s->k, per_b, (s->agreed ? s->agreed : shard_geometry_bound(s)) / (s->sym ? 2 : 1), s->gh, &t);
 	if (rc) return rc;
@@ -3405,7 +3494,7 @@ extern "C" int vdjx_shard_local_fill(vdjx_shard* s, void* d_dir, void* d_partial
 		// the aggregates of every bucket end to end, in the caller's buffer -- which from here on IS this rank's list of them: the
 		// answers to the owners' questions are looked up in it (vdjx_shard_reply)
 		vdjx_prof_scope ps(s->c, "k_compact_partials");
-		hipLaunchKernelGGL(k_compact_partials, dim3(s->NBt), dim3(256), 0, st, s->sparse, s->sparse_ref, s->tuple_bucket_start, s->nd, s->dstart, (Partial*) d_partials, s->dense_ref, s->scan, s->pool->ob, s->sym ? 2u : 1u);
+		hipLaunchKernelGGL(k_compact_partials, dim3(s->NBt), dim3(256), 0, st, s->sparse, s->sparse_ref, s->tuple_bucket_start, s->nd, s->dstart, (Partial*) d_partials, s->dense_ref, s->scan, s->pool->ob, s->sym);
 	}
 	s->dense = (Partial*) d_partials;
 	HIP_TRY(hipStreamSynchronize(st));
@@ -3428,7 +3517,7 @@ extern "C" int vdjx_shard_count(vdjx_shard* s, uint64_t* gated_instances) {
 	if (!s->have_hist) {
 		// (counted the way this rank would like to build: over couples if its pool is made of them; vdjx_shard_geometry2 has the last word)
 		PersistAlloc db(s->c);
-		const int rc = stage_gated_hist(s->c, db, s->pool, s->k, s->sym_capable ? tune("VDJX_GATED_BUCKET", 3072) / 2 : 0, shard_geometry_bound(s) / (s->sym_capable ? 2 : 1), &s->gh, s->sym_capable);
+		const int rc = stage_gated_hist(s->c, db, s->pool, s->k, 0, shard_geometry_bound(s) / (s->sym_capable ? 2 : 1), &s->gh, s->sym_capable);
 		if (rc) return rc;
 		s->have_hist = true;
 	}
@@ -3474,13 +3563,15 @@ static int shard_merge_impl(vdjx_shard* s, const u32* d_recv_dir, const Partial*
 	HIP_TRY(db.alloc(&s->n_surv, 1));
 	HIP_TRY(db.alloc(&g_distinct, 1));
 	HIP_TRY(db.alloc(&s->queries, (size_t) total + 1));
-	const u32 cap = total + 1;
+	const u32 cap = (s->sym ? 2 : 1) * total + 2;            // (SYM: an aggregate can leave as two survivors)
 	s->sv_cap = cap;
 	SurvivorsG& v = s->local_sv;
 	HIP_TRY(db.alloc(&v.lo, cap)); HIP_TRY(db.alloc(&v.hi, cap)); HIP_TRY(db.alloc(&v.gcnt, cap)); HIP_TRY(db.alloc(&v.gfirst, cap));
 	PendOut& po = s->po;
 	HIP_TRY(db.alloc(&po.lo, cap)); HIP_TRY(db.alloc(&po.hi, cap)); HIP_TRY(db.alloc(&po.cg, cap)); HIP_TRY(db.alloc(&po.mg, cap));
 	HIP_TRY(db.alloc(&po.need, cap));
+	po.mgr = nullptr;
+	if (s->sym) HIP_TRY(db.alloc(&po.mgr, cap));
 	po.n = n_pend; po.cap = cap;
 	HIP_TRY(hipMemcpyAsync(d_src_base, s->src_base.data(), (G + 1) * 4, hipMemcpyHostToDevice, st));
 	hipLaunchKernelGGL(k_seg_offsets, dim3(G), dim3(1024), 0, st, d_recv_dir, d_src_base, G, NBo, seg_off);
@@ -3500,8 +3591,10 @@ static int shard_merge_impl(vdjx_shard* s, const u32* d_recv_dir, const Partial*
 		HIP_TRY(hipMemsetAsync(g_distinct, 0, 8, st));
 		if (total) {
 			vdjx_prof_scope ps(c, "k_bucket_merge");
-			hipLaunchKernelGGL(k_bucket_merge<THI>, dim3(NBo / MG), dim3(MERGE_THREADS), 0, st, d_recv, seg_off, MG, G, NBo, d_src_base, s_mult, cmin,
-			                   s->tlow, so, po, s->queries, g_nq, g_distinct, g_err);
+			if (s->sym) hipLaunchKernelGGL((k_bucket_merge<THI, true>), dim3(NBo / MG), dim3(MERGE_THREADS), 0, st, d_recv, seg_off, MG, G, NBo, d_src_base, s_mult, cmin,
+			                               s->tlow, so, po, s->queries, g_nq, g_distinct, g_err, s->k);
+			else hipLaunchKernelGGL(k_bucket_merge<THI>, dim3(NBo / MG), dim3(MERGE_THREADS), 0, st, d_recv, seg_off, MG, G, NBo, d_src_base, s_mult, cmin,
+			                        s->tlow, so, po, s->queries, g_nq, g_distinct, g_err, s->k);
 		}
 		HIP_TRY(hipMemcpyAsync(s->nq.data(), g_nq, (size_t) G * 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipMemcpyAsync(&np, n_pend, 4, hipMemcpyDeviceToHost, st));
@@ -3525,13 +3618,14 @@ static int shard_merge_impl(vdjx_shard* s, const u32* d_recv_dir, const Partial*
 	v.n = ns;                    // decided without questions; vdjx_shard_resolve appends the rest
 	v.ndist = ndist;
 	for (u32 g = 0; g < G; g++) query_counts[g] = s->nq[g];
+	const size_t sides = s->sym ? 2 : 1;                     // (SYM: the reverse complements' answering rank and sums behind the k-mers')
 	HIP_TRY(db.alloc(&s->p_fl, (size_t) np + 1));
-	HIP_TRY(db.alloc(&s->p_r0, (size_t) np + 1));
-	HIP_TRY(db.alloc(&s->p_S, (size_t) np * 64 + 1));
+	HIP_TRY(db.alloc(&s->p_r0, sides * np + 1));
+	HIP_TRY(db.alloc(&s->p_S, sides * np * 64 + 1));
 	if (np) {
 		HIP_TRY(hipMemsetAsync(s->p_fl, 0, (size_t) np * 4, st));
-		HIP_TRY(hipMemsetAsync(s->p_r0, 0xFF, (size_t) np * 4, st));
-		HIP_TRY(hipMemsetAsync(s->p_S, 0, (size_t) np * 256, st));
+		HIP_TRY(hipMemsetAsync(s->p_r0, 0xFF, sides * np * 4, st));
+		HIP_TRY(hipMemsetAsync(s->p_S, 0, sides * np * 256, st));
 	}
 	return VDJX_OK;
 }
@@ -3594,8 +3688,10 @@ extern "C" int vdjx_shard_reply(vdjx_shard* s, const void* d_queries, const uint
 	const vdjx_pool* p = s->pool;
 	{
 		vdjx_prof_scope ps(c, "k_shard_reply");
-		hipLaunchKernelGGL(k_shard_reply, dim3(nq), dim3(64), 0, st, (const uint2*) d_queries, nq, d_off, G, s->dense, s->dense_ref, s->dstart, s->NBo,
-		                   s->low_inst, p->d_bases, p->d_nmask, vdjx_qrows{p->d_quals, p->d_quals2, p->q_split, p->qstride}, s->rec_base(), s->scan, (u32) p->n_records, s->k, p->rl, p->ob, (uint8_t*) d_replies);
+		if (s->sym) hipLaunchKernelGGL(k_shard_reply<true>, dim3(nq), dim3(64), 0, st, (const uint2*) d_queries, nq, d_off, G, s->dense, s->dense_ref, s->dstart, s->NBo,
+		                               s->low_inst, p->d_bases, p->d_nmask, vdjx_qrows{p->d_quals, p->d_quals2, p->q_split, p->qstride}, s->rec_base(), s->scan, (u32) p->n_records, s->k, p->rl, p->ob, (uint8_t*) d_replies);
+		else hipLaunchKernelGGL(k_shard_reply<false>, dim3(nq), dim3(64), 0, st, (const uint2*) d_queries, nq, d_off, G, s->dense, s->dense_ref, s->dstart, s->NBo,
+		                        s->low_inst, p->d_bases, p->d_nmask, vdjx_qrows{p->d_quals, p->d_quals2, p->q_split, p->qstride}, s->rec_base(), s->scan, (u32) p->n_records, s->k, p->rl, p->ob, (uint8_t*) d_replies);
 	}
 	HIP_TRY(hipStreamSynchronize(st));          // `off` staging dies with this frame
 	HIP_TRY(hipGetLastError());
@@ -3619,10 +3715,12 @@ extern "C" int vdjx_shard_resolve(vdjx_shard* s, const void* d_replies, uint64_t
 		const u32 nr = (u32) n_replies;
 		SurvOutG so{v.lo, v.hi, v.gcnt, v.gfirst, s->n_surv, s->sv_cap, nullptr};
 		vdjx_prof_scope ps(c, "k_shard_resolve");
-		hipLaunchKernelGGL(k_resolve_first, dim3((nr + 255) / 256), dim3(256), 0, st, (const uint8_t*) d_replies, nr, s->po.mg, s->p_r0);
-		hipLaunchKernelGGL(k_resolve_add, dim3((nr + 3) / 4), dim3(256), 0, st, (const uint8_t*) d_replies, nr, s->p_r0, s->k, s->p_fl, s->p_S);
-		hipLaunchKernelGGL(k_resolve_keep, dim3((s->n_pend + 255) / 256), dim3(256), 0, st, s->po, s->n_pend, s->p_fl, s->p_S, s->k,
-		                   (u32) std::max(s->mf, 0), s->mqq, s->tlow, so);
+		hipLaunchKernelGGL(k_resolve_first, dim3((nr + 255) / 256), dim3(256), 0, st, (const uint8_t*) d_replies, nr, s->po.mg, s->p_r0, (const u64*) s->po.mgr, s->n_pend);
+		hipLaunchKernelGGL(k_resolve_add, dim3((nr + 3) / 4), dim3(256), 0, st, (const uint8_t*) d_replies, nr, s->p_r0, s->k, s->p_fl, s->p_S, s->sym ? s->n_pend : 0u);
+		if (s->sym) hipLaunchKernelGGL(k_resolve_keep<true>, dim3((s->n_pend + 255) / 256), dim3(256), 0, st, s->po, s->n_pend, s->p_fl, s->p_S, s->k,
+		                               (u32) std::max(s->mf, 0), s->mqq, s->tlow, so);
+		else hipLaunchKernelGGL(k_resolve_keep<false>, dim3((s->n_pend + 255) / 256), dim3(256), 0, st, s->po, s->n_pend, s->p_fl, s->p_S, s->k,
+		                        (u32) std::max(s->mf, 0), s->mqq, s->tlow, so);
 	}
 	u32 ns = 0;
 	HIP_TRY(hipMemcpyAsync(&ns, s->n_surv, 4, hipMemcpyDeviceToHost, st));
@@ -3668,10 +3766,29 @@ extern "C" int vdjx_shard_edges(vdjx_shard* s, const void* d_surv_all, uint64_t 
 	if (!ns_total) return VDJX_OK;
 	if (!d_surv_all || !d_in_first || !d_ucnt || !d_ufirst) { vdjx_set_error("vdjx_shard_edges: NULL buffer"); return VDJX_EINVAL; }
 	HIP_TRY(db.alloc(&a.lo, a.n)); HIP_TRY(db.alloc(&a.hi, a.n)); HIP_TRY(db.alloc(&a.gcnt, a.n)); HIP_TRY(db.alloc(&a.gfirst, a.n));
-	hipLaunchKernelGGL(k_surv_unpack, dim3((a.n + 255) / 256), dim3(256), 0, c->stream, (const SurvRec*) d_surv_all, a.n, a.lo, a.hi, a.gcnt, a.gfirst);
+	u32* d_nreal;
+	HIP_TRY(db.alloc(&d_nreal, 1));
+	HIP_TRY(hipMemsetAsync(d_nreal, 0, 4, c->stream));
+	hipLaunchKernelGGL(k_surv_unpack, dim3((a.n + 255) / 256), dim3(256), 0, c->stream, (const SurvRec*) d_surv_all, a.n, a.lo, a.hi, a.gcnt, a.gfirst, d_nreal);
+	u32* h_nreal = (u32*) c->h_pin + 1536;                 // (stage_recount reads its own status into the first words)
+	HIP_TRY(hipMemcpyAsync(h_nreal, d_nreal, 4, hipMemcpyDeviceToHost, c->stream));
 	RecountOut ro{(u32*) d_ucnt, (u64*) d_ufirst, (u64*) d_in_first, nullptr, nullptr, nullptr};
-	const int rc = stage_recount(c, db, s->pool, s->rec_base(), s->k, a, ro, false, &s->tb);
-	if (rc || !s->scan) return rc;
+	// the survivors of a build over couples came out of the merge closed under reverse complement (shadows included, k_resolve_keep):
+	// the walk takes the couples' first records only, as in the one-GPU build.  Should it find chains that are not mirror images (it
+	// cannot, by construction), this rank walks every record instead -- from the SAME survivor list, so that its numbering stays the
+	// one the other ranks use
+	static const bool sym_walk_on = getenv("VDJX_NO_SYM_WALK") == nullptr;
+	const bool sym_walk = s->sym && sym_walk_on;
+	c->stats["kmer_build_sym_walk"] = sym_walk ? 1 : 0;
+	const SurvivorsG a_in = a;
+	int rc = stage_recount(c, db, s->pool, s->rec_base(), s->k, a, ro, false, &s->tb, nullptr, sym_walk);
+	if (rc == VDJX_ESYMWALK && sym_walk) {
+		c->stats["kmer_build_sym_walk_retries"] += 1;
+		a = a_in;
+		rc = stage_recount(c, db, s->pool, s->rec_base(), s->k, a, ro, false, &s->tb, nullptr, false);
+	}
+	if (rc == VDJX_OK) a.n_real = *h_nreal;              // (the stage has waited for the stream)
+	if (rc || !s->scan) return rc == VDJX_ESYMWALK ? VDJX_EHIP : rc;
 	// share mode: the first sights are local instance ids; on their way to the reduction over ranks they become scan positions
 	hipLaunchKernelGGL(k_first_to_scan, dim3((a.n * 5 + 255) / 256), dim3(256), 0, c->stream, (u64*) d_in_first, (size_t) a.n * 4, (u64*) d_ufirst, (size_t) a.n, s->scan, s->pool->ob);
 	HIP_TRY(hipStreamSynchronize(c->stream));
