@@ -117,6 +117,71 @@ __global__ void k_ri_insert(const u64* __restrict__ bases, const u64* __restrict
 	rec_slot[r] = slot;
 }
 
+// ---- pools made of couples (vdjx_pool::sym: record 2i + 1 is the reverse complement of record 2i -- what add_to_buffer writes,
+// bam_read.c:206-244; reads of up to 64 bases).  A couple is inserted ONCE, under the smaller of its two sequences: half the
+// insertions into a table of half the size.  The sequence under the key gets class 2c, its reverse complement class 2c + 1 (c: the
+// key's number in slot order); a read that is its own reverse complement (even lengths) has class 2c only.
+#define RI_CS_STR 0x80000000u         // couple_slot: record 2i holds the LARGER sequence (its class is the odd one, record 2i + 1's the even one)
+#define RI_CS_PAL 0x40000000u         // ... the two are the same sequence
+#define RI_CS_SLOT 0x3FFFFFFFu
+#define RI_SLOT_PAL 0x80000000u       // slots[]: the representative record + 1 | this while the table is built (k_ri_number_sym: the key's number + 1)
+__device__ inline void ri_read_rc(u64 hi, u64 lo, int rl, u64& rhi, u64& rlo) {
+	if (rl < 64) { vdjx_kmer_rc(hi, lo, rl, rhi, rlo); return; }
+	u64 a = __brevll(lo), b = __brevll(hi);
+	a = ((a >> 1) & 0x5555555555555555ull) | ((a & 0x5555555555555555ull) << 1);
+	b = ((b >> 1) & 0x5555555555555555ull) | ((b & 0x5555555555555555ull) << 1);
+	rhi = a ^ 0x5555555555555555ull;
+	rlo = b ^ 0x5555555555555555ull;
+}
+__global__ void k_ri_insert_sym(const u64* __restrict__ bases, const u64* __restrict__ nmask, u32 R2, int rl,
+                                u32* __restrict__ slots, u32 mask, u32* __restrict__ couple_slot) {
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= R2) return;
+	if (nmask[2 * (size_t) i]) { couple_slot[i] = NONE32; return; }          // (the mask of record 2i + 1 is this one reversed)
+	const ulonglong2 f = ((const ulonglong2*) bases)[2 * (size_t) i];
+	u64 rh, rlo;
+	ri_read_rc(f.x, f.y, rl, rh, rlo);
+	const bool flip = rh < f.x || (rh == f.x && rlo < f.y);
+	const bool pal = rh == f.x && rlo == f.y;
+	u64 b[2];
+	b[0] = flip ? rh : f.x;
+	b[1] = flip ? rlo : f.y;
+	const u32 rep = 2u * i + (flip ? 1u : 0u);                                // the record that holds the key
+	u32 slot = (u32) (ri_hash<2>(b) >> 17) & mask;
+	for (;;) {
+		u32 cur = slots[slot];
+		if (cur == 0) {
+			cur = atomicCAS(&slots[slot], 0u, (rep + 1) | (pal ? RI_SLOT_PAL : 0u));
+			if (cur == 0) break;
+		}
+		const ulonglong2 o = ((const ulonglong2*) bases)[(cur & ~RI_SLOT_PAL) - 1];
+		if (o.x == b[0] && o.y == b[1]) break;
+		slot = (slot + 1) & mask;
+	}
+	couple_slot[i] = slot | (flip ? RI_CS_STR : 0u) | (pal ? RI_CS_PAL : 0u);
+}
+// the keys numbered in slot order; rep[2c], rep[2c + 1]: a record that holds class 2c's sequence, one that holds class 2c + 1's (its
+// neighbour; none for a sequence that is its own reverse complement)
+__global__ __launch_bounds__(256) void k_ri_number_sym(u32* __restrict__ slots, u32 nslots, const u32* __restrict__ bpre, u32* __restrict__ rep) {
+	__shared__ u32 part[4];
+	const u32 base = blockIdx.x * RS_BLOCK + threadIdx.x * 8u;
+	u32 v[8], s = 0;
+#pragma unroll
+	for (int i = 0; i < 8; i++) { v[i] = base + i < nslots ? slots[base + i] : 0u; s += v[i] != 0; }
+	const u32 incl = (u32) vdjx_wave_scan_add((int) s);
+	if ((threadIdx.x & 63u) == 63u) part[threadIdx.x >> 6] = incl;
+	__syncthreads();
+	u32 run = bpre[blockIdx.x] + incl - s;
+	for (u32 w = 0; w < (threadIdx.x >> 6); w++) run += part[w];
+#pragma unroll
+	for (int i = 0; i < 8; i++) if (v[i]) {
+		const u32 r = (v[i] & ~RI_SLOT_PAL) - 1u;
+		*(uint2*) &rep[2 * (size_t) run] = make_uint2(r, (v[i] & RI_SLOT_PAL) ? NONE32 : r ^ 1u);
+		slots[base + i] = run + 1;
+		run++;
+	}
+}
+
 // classes are numbered in slot order (any numbering serves: a class id is an identity, never an order)
 __global__ __launch_bounds__(256) void k_ri_occ(const u32* __restrict__ slots, u32 nslots, u32* __restrict__ bcnt) {
 	__shared__ u32 part[4];
@@ -157,6 +222,8 @@ __global__ __launch_bounds__(256) void k_ri_number(u32* __restrict__ slots, u32 
 // record -> class (| is_rc in the top bit: what the entry of a pair needs of its mates in ONE load); the pair's read-2 records in
 // registration order: the two smallest (reg_rank << 32 | record) of the pair, kept by a chain of two atomic minima (what loses at the
 // first slot moves on to the second; a third arrival is an error); read-1 members per workgroup (their compaction follows)
+// (SYM: rec_slot is per COUPLE, k_ri_insert_sym; the two records of a couple ask for the same slot)
+template <bool SYM>
 __global__ __launch_bounds__(256) void k_ri_records(const u32* __restrict__ rec_slot, const u32* __restrict__ slots, u32 R,
                                                     const u32* __restrict__ pair_id, const uint8_t* __restrict__ read_num, const uint8_t* __restrict__ is_rc,
                                                     const u32* __restrict__ reg_rank, u32 n_pairs, u32* __restrict__ rec_cls,
@@ -169,7 +236,7 @@ __global__ __launch_bounds__(256) void k_ri_records(const u32* __restrict__ rec_
 	for (int i = 0; i < 8; i++) {
 		const u32 r = base + (u32) i * 256u;
 		const bool in = r < R;
-		s[i] = in ? rec_slot[r] : NONE32;
+		s[i] = in ? rec_slot[SYM ? r >> 1 : r] : NONE32;
 		p[i] = in ? pair_id[r] : 0u;
 		rn[i] = in ? read_num[r] : (uint8_t) 0;
 		rc[i] = in ? is_rc[r] : (uint8_t) 0;
@@ -178,7 +245,13 @@ __global__ __launch_bounds__(256) void k_ri_records(const u32* __restrict__ rec_
 	}
 	u32 cls[8];
 #pragma unroll
-	for (int i = 0; i < 8; i++) cls[i] = s[i] == NONE32 ? RI_ENT_NONE : slots[s[i]] - 1u;
+	for (int i = 0; i < 8; i++) {
+		if (!SYM) { cls[i] = s[i] == NONE32 ? RI_ENT_NONE : slots[s[i]] - 1u; continue; }
+		const u32 r = base + (u32) i * 256u;
+		// the record's own side of its couple: the odd class if it holds the larger sequence
+		const u32 odd = (s[i] & RI_CS_PAL) ? 0u : ((s[i] >> 31) ^ (r & 1u));
+		cls[i] = s[i] == NONE32 ? RI_ENT_NONE : 2u * (slots[s[i] & RI_CS_SLOT] - 1u) + odd;
+	}
 	u32 mine = 0;
 #pragma unroll
 	for (int i = 0; i < 8; i++) {
@@ -278,9 +351,9 @@ __global__ void k_ri_csr(const u64* __restrict__ mkey_sorted, u32 n1, const ulon
 // ---- the weighted entries: identical read-1 entries of a class folded into one with a multiplicity ------------------------------------
 // (window scoring counts pairs, it does not name them.)  Class c's entries go to d8[start[c] ...): the region of its CSR members,
 // of which they use the first dcnt[c] -- no scan, no second pass; ANY grouping whose multiplicities add up to the members is a
-// valid result, which is what the overflow paths rely on.  A thread folds a class of up to RI_FOLD_SMALL members by comparing them
-// all; the larger ones (reads of deep clones: hundreds of members, tens of distinct entries) are left to the waves of the workgroup,
-// one class at a time, through a table in LDS.
+// valid result, which is what the overflow paths rely on.  The classes of up to RI_FOLD_SMALL members are folded by their members'
+// own threads (k_ri_fold_members); the larger ones (reads of deep clones: hundreds of members, tens of distinct entries) are left to
+// the waves of a workgroup, one class at a time, through a table in LDS.
 #define RI_FOLD_SMALL 8u
 #define RI_FOLD_WAVE 256u             // up to here a wave folds the class through its own LDS table (it cannot fill: 512 slots)
 #define RI_FOLD_SLOTS 512u
@@ -300,6 +373,48 @@ __device__ inline bool ri_fold_insert(unsigned long long* tk, u32* tc, u32 slots
 	atomicAdd(&tc[slot], 1u);
 	return fresh;
 }
+// the classes of up to RI_FOLD_SMALL members -- nearly all of them, most with one -- a thread per MEMBER in CSR order: its class's
+// entries are its neighbours' (a thread per class walked its members one dependent load after the other: 0.77 ms at 10 M pairs,
+// 92 % of the wave-cycles waiting).  A member whose entry no earlier member of the class holds writes it, with the number of members
+// that hold it, at its rank among such; the class's first member writes their number.
+__global__ __launch_bounds__(256) void k_ri_fold_members(const u64* __restrict__ by_class, u32 n1, const u32* __restrict__ start, const u32* __restrict__ cnt1,
+                                                         const u64* __restrict__ csr8, u64* __restrict__ d8, u32* __restrict__ dcnt,
+                                                         unsigned long long* __restrict__ n_entries) {
+	const u32 i = blockIdx.x * 256u + threadIdx.x;
+	u32 made = 0;
+	if (i < n1) {
+		const u32 cls = (u32) (by_class[i] >> 32);
+		const u32 s = start[cls], m = cnt1[cls];
+		if (m <= RI_FOLD_SMALL) {
+			const u32 j = i - s;
+			u64 e[RI_FOLD_SMALL];
+#pragma unroll
+			for (u32 q = 0; q < RI_FOLD_SMALL; q++) e[q] = q < m ? csr8[s + q] & ((1ull << 56) - 1ull) : 0ull;
+			u32 lead = 0;                              // bit p: member p's entry is not held by an earlier member
+#pragma unroll
+			for (u32 p_ = 0; p_ < RI_FOLD_SMALL; p_++) {
+				bool first = p_ < m;
+#pragma unroll
+				for (u32 q = 0; q < p_; q++) first = first && e[q] != e[p_];
+				lead |= (u32) first << p_;
+			}
+			if ((lead >> j) & 1u) {
+				u64 mine = 0;
+				u32 mult = 0;
+#pragma unroll
+				for (u32 q = 0; q < RI_FOLD_SMALL; q++) if (q == j) mine = e[q];
+#pragma unroll
+				for (u32 q = 0; q < RI_FOLD_SMALL; q++) mult += q < m && e[q] == mine;
+				d8[s + (u32) __popc(lead & ((1u << j) - 1u))] = mine | ((u64) mult << 56);
+				made = 1;
+			}
+			if (j == 0) dcnt[cls] = (u32) __popc(lead);
+		}
+	}
+	const u32 incl = (u32) vdjx_wave_scan_add((int) made);
+	if ((threadIdx.x & 63u) == 63u && incl) atomicAdd(n_entries, (unsigned long long) incl);
+}
+
 __global__ __launch_bounds__(256) void k_ri_fold(const u32* __restrict__ start, const u32* __restrict__ cnt1, u32 ncls, const u64* __restrict__ csr8,
                                                  u64* __restrict__ d8, u32* __restrict__ dcnt, unsigned long long* __restrict__ n_entries,
                                                  u32* __restrict__ giant, u32* __restrict__ n_giant) {
@@ -312,22 +427,10 @@ __global__ __launch_bounds__(256) void k_ri_fold(const u32* __restrict__ start, 
 	const u32 c = blockIdx.x * 256u + threadIdx.x;
 	u32 made = 0;
 	if (c < ncls) {
-		const u32 m = cnt1[c], s = start[c];
+		const u32 m = cnt1[c];
 		if (m > RI_FOLD_WAVE) giant[atomicAdd(n_giant, 1u)] = c;
 		else if (m > RI_FOLD_SMALL) big[atomicAdd(&nbig, 1u)] = c;
-		else if (m) {
-			u64 e[RI_FOLD_SMALL];
-			u32 n[RI_FOLD_SMALL];
-#pragma unroll
-			for (u32 i = 0; i < RI_FOLD_SMALL; i++) { e[i] = i < m ? csr8[s + i] & ((1ull << 56) - 1ull) : 0ull; n[i] = i < m ? 1u : 0u; }
-#pragma unroll
-			for (u32 i = 1; i < RI_FOLD_SMALL; i++)
-#pragma unroll
-				for (u32 j = 0; j < i; j++) if (n[i] && n[j] && e[i] == e[j]) { n[j] += n[i]; n[i] = 0; }
-#pragma unroll
-			for (u32 i = 0; i < RI_FOLD_SMALL; i++) if (n[i]) d8[s + made++] = e[i] | ((u64) n[i] << 56);
-			dcnt[c] = made;
-		} else dcnt[c] = 0;
+		else if (!m) dcnt[c] = 0;                  // (1 .. RI_FOLD_SMALL members: k_ri_fold_members)
 	}
 	__syncthreads();
 	const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -416,6 +519,7 @@ __global__ void k_ri_tab(const u32* __restrict__ rep, u32 ncls, const u64* __res
 	constexpr int SW = VDJX_RI_SLOT_WORDS(W);
 	const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= ncls) return;
+	if (rep[c] == NONE32) return;                          // (couples: the odd class of a read that is its own reverse complement)
 	u64 b[W];
 #pragma unroll
 	for (int i = 0; i < W; i++) b[i] = bases[(size_t) rep[c] * W + i];
@@ -445,18 +549,22 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	hipStream_t st = c->stream;
 	if (pool->n_records > ((size_t) 1 << 29)) { vdjx_set_error("vdjx_read_index_build: %zu records on one GPU (limit 2^29): shard the pool by pair", pool->n_records); return VDJX_ELIMIT; }
 	const u32 R = (u32) pool->n_records;
+	static const bool sym_on = getenv("VDJX_NO_SYM_INDEX") == nullptr;
+	const bool sym = sym_on && pool->sym && pool->W == 2 && R % 2 == 0;      // couples: k_ri_insert_sym
+	c->stats["read_index_sym"] = sym ? 1 : 0;
+	const size_t RK = sym ? R / 2 : R;                     // what the build's table holds: records, or couples
 	u32 mask = 1023;
 	// (2 R slots.  1.5 R would do for the table itself and saves 0.3 ms of clearing and scanning at 10 M pairs -- but the classes are
 	// numbered in slot order, the window mapper groups windows by a hash of their deepest classes' NUMBERS, and how evenly the deep
 	// windows fall into groups decides k_group_pairs' longest workgroup: 1.17 ms with this numbering, 1.84 ms with that one, same work)
-	while ((size_t) mask + 1 < (size_t) R * 2) mask = mask * 2 + 1;
+	while ((size_t) mask + 1 < RK * 2) mask = mask * 2 + 1;
 	const size_t nslots = (size_t) mask + 1;
-	const dim3 gR(R / 256 + 1), gB((R + RI_RB - 1) / RI_RB + 1), b256(256);
+	const dim3 gR((u32) (RK / 256 + 1)), gB((R + RI_RB - 1) / RI_RB + 1), b256(256);
 	u32 *d_rec_slot, *d_rec_cls, *d_err, *d_split;
 	unsigned long long *d_r2key, *d_nent;
 	u32* d_slots;                                 // the build's own table: slot -> a record of the class, then -> class + 1
 	HIP_TRY(db.alloc(&d_slots, nslots));
-	HIP_TRY(db.alloc(&d_rec_slot, (size_t) R + 1));
+	HIP_TRY(db.alloc(&d_rec_slot, RK + 1));
 	HIP_TRY(db.alloc(&d_rec_cls, (size_t) R + 1));
 	HIP_TRY(db.alloc(&d_err, 8));
 	d_split = d_err + 4;
@@ -467,7 +575,8 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(hipMemsetAsync(d_r2key, 0xFF, ((size_t) n_pairs * 2 + 2) * 8, st));
 	{
 		vdjx_prof_scope ps(c, "k_ri_insert");
-		if (pool->W == 2) hipLaunchKernelGGL((k_ri_insert<2, 1>), gR, b256, 0, st, pool->d_bases, pool->d_nmask, R, d_slots, mask, d_rec_slot);
+		if (sym) hipLaunchKernelGGL(k_ri_insert_sym, gR, b256, 0, st, pool->d_bases, pool->d_nmask, (u32) RK, pool->rl, d_slots, mask, d_rec_slot);
+		else if (pool->W == 2) hipLaunchKernelGGL((k_ri_insert<2, 1>), gR, b256, 0, st, pool->d_bases, pool->d_nmask, R, d_slots, mask, d_rec_slot);
 		else hipLaunchKernelGGL((k_ri_insert<VDJX_LONG_W, VDJX_LONG_M>), gR, b256, 0, st, pool->d_bases, pool->d_nmask, R, d_slots, mask, d_rec_slot);
 	}
 	// classes
@@ -484,6 +593,10 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(hipMemcpyAsync(&ncls, d_bpre + nsb, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
+	if (sym) {
+		if (ncls >= RI_ENT_NONE / 2) { vdjx_set_error("vdjx_read_index_build: %u distinct read sequences on one GPU (limit 2^26 - 1): shard the pool by pair", 2 * ncls); return VDJX_ELIMIT; }
+		ncls *= 2;                                          // a key's sequence and its reverse complement
+	}
 	if (ncls >= RI_ENT_NONE) { vdjx_set_error("vdjx_read_index_build: %u distinct read sequences on one GPU (limit 2^26 - 1): shard the pool by pair", ncls); return VDJX_ELIMIT; }
 	u32 tmask = 1023;
 	while ((size_t) tmask + 1 < (size_t) ncls * 2) tmask = tmask * 2 + 1;
@@ -501,7 +614,8 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(hipMemsetAsync(c->d_ri_tab, 0, ((size_t) tmask + 1) * slot_bytes, st));
 	{
 		vdjx_prof_scope ps(c, "k_ri_number");
-		hipLaunchKernelGGL(k_ri_number, dim3(nsb), b256, 0, st, d_slots, (u32) nslots, d_bpre, d_rep);
+		if (sym) hipLaunchKernelGGL(k_ri_number_sym, dim3(nsb), b256, 0, st, d_slots, (u32) nslots, d_bpre, d_rep);
+		else hipLaunchKernelGGL(k_ri_number, dim3(nsb), b256, 0, st, d_slots, (u32) nslots, d_bpre, d_rep);
 	}
 	// records: class, read-2 records of the pairs; the read-1 members in record order
 	const u32 nrb = (R + RI_RB - 1) / RI_RB;
@@ -510,7 +624,8 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(db.alloc(&d_rbpre, nrb + 2));
 	{
 		vdjx_prof_scope ps(c, "k_ri_records");
-		if (nrb) hipLaunchKernelGGL(k_ri_records, dim3(nrb), b256, 0, st, d_rec_slot, d_slots, R, d_pair, d_rnum, d_rc, d_reg, n_pairs, d_rec_cls, d_r2key, d_err, d_rbcnt);
+		if (nrb && sym) hipLaunchKernelGGL(k_ri_records<true>, dim3(nrb), b256, 0, st, d_rec_slot, d_slots, R, d_pair, d_rnum, d_rc, d_reg, n_pairs, d_rec_cls, d_r2key, d_err, d_rbcnt);
+		else if (nrb) hipLaunchKernelGGL(k_ri_records<false>, dim3(nrb), b256, 0, st, d_rec_slot, d_slots, R, d_pair, d_rnum, d_rc, d_reg, n_pairs, d_rec_cls, d_r2key, d_err, d_rbcnt);
 		hipLaunchKernelGGL(k_ri_r2, dim3((unsigned) (((size_t) n_pairs * 2 + 2) / 256 + 1)), b256, 0, st, d_r2key, (size_t) n_pairs * 2 + 2, c->d_pair_r2);
 		hipLaunchKernelGGL(k_rs_top, dim3(1), dim3(1024), 0, st, d_rbcnt, nrb, d_rbpre);
 	}
@@ -541,6 +656,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(ri_keep(&c->d_ri_csr_pair, &c->ri_cap[7], ((size_t) n1 + 1) * 4));
 	HIP_TRY(ri_keep(&c->d_ri_d8, &c->ri_cap[8], ((size_t) n1 + 1) * 8));
 	unsigned long long nd = 0;
+	u64* d_by_class = nullptr;
 	if (n1) {
 		vdjx_prof_scope ps(c, "ri_sort_members");
 		// the members are in record order; inside a pool that IS registration order (add_to_buffer registers what it appends,
@@ -575,12 +691,14 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 		HIP_TRY(db.alloc(&tmp, tb + 256));
 		HIP_TRY(rocprim::radix_sort_keys((void*) tmp, tb, by_rank, by_class, (size_t) n1, 32u, 32u + bits_for(ncls), st));
 		hipLaunchKernelGGL(k_ri_csr, dim3(n1 / 256 + 1), b256, 0, st, by_class, n1, d_mpack, c->d_ri_recs, c->d_ri_csr_pair, c->d_ri_csr8);
+		d_by_class = by_class;
 	}
 	{
 		vdjx_prof_scope ps(c, "k_ri_fold");
 		const u32 max_giant = n1 / (RI_FOLD_WAVE + 1) + 1;
 		u32* d_giant;
 		HIP_TRY(db.alloc(&d_giant, (size_t) max_giant + 1));
+		if (n1) hipLaunchKernelGGL(k_ri_fold_members, dim3(n1 / 256 + 1), b256, 0, st, (const u64*) d_by_class, n1, c->d_ri_start, c->d_ri_cnt1, c->d_ri_csr8, c->d_ri_d8, c->d_ri_dstart, d_nent);
 		hipLaunchKernelGGL(k_ri_fold, dim3(ncls / 256 + 1), b256, 0, st, c->d_ri_start, c->d_ri_cnt1, ncls, c->d_ri_csr8, c->d_ri_d8, c->d_ri_dstart, d_nent, d_giant, d_split + 1);
 		hipLaunchKernelGGL(k_ri_fold_big, dim3(max_giant < 2048u ? max_giant : 2048u), dim3(RI_FOLD_BIG_THREADS), 0, st, d_giant, d_split + 1, c->d_ri_start, c->d_ri_cnt1, c->d_ri_csr8, c->d_ri_d8, c->d_ri_dstart, d_nent);
 	}
