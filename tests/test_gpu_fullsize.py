@@ -419,7 +419,7 @@ def test_config4_geometry_rehearsed_on_one_gpu(per, chains, check):
     for l in per_chain:
         assert l["all_ranks_agree"] and l["instance_ids_pass_2_32"] and l["nodes"] > 1_000_000 and l["records"] == per * 32
         moved = [m["build"] if isinstance(m, dict) else m for m in l["bytes_exchanged_per_rank"]]
-        assert min(moved) > 1_000_000_000
+        assert min(moved) > 400_000_000            # (one 32-byte aggregate per pair of mirrored k-mers since round 5: 0.76 GB at 8 x 8 M pairs, 1.2 GB at 12.5 M)
         if mode == "score":
             assert l["scorers_equal_those_of_half_as_many_ranks"] is True and l["equals_the_build_by_4_ranks_of_twice_the_size"] is True
             assert l["scorers"]["windows"] >= 20_000 and l["scorers"]["windows_valid"] > 0 and l["scorers"]["sam_lines"] > 10_000
