@@ -915,18 +915,25 @@ __global__ __launch_bounds__(1024) void k_plan(const u32* __restrict__ hits_g, c
 #define WP_K 16                  // rows of 64 consecutive hits per wave and round: 16 loads in flight per lane, in 64 registers (8 waves per SIMD:
                                  // with 96 registers and 5 waves the same kernel ran 1.7x longer)
 #define WP_Q 128                 // per-wave queue of the entries that passed the presence test
+// work item -> position of its window in the processing order (what slice_contig finds by a search over wstart: with the windows of
+// the groups done, tens of thousands of k_window_pairs' workgroups are there only to find that out)
+__global__ void k_work_items(const u32* __restrict__ wstart, u32 n, u32* __restrict__ witem) {
+	const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n) return;
+	for (u32 b = wstart[j]; b < wstart[j + 1]; b++) witem[b] = j;
+}
 template <int NOFF>
 __global__ __launch_bounds__(MAP_THREADS, 8) void k_window_pairs(ReadIndexDev ix, const uint4* __restrict__ prep, u32 n, int len, u32 chunk,
                                                               const u32* __restrict__ order, const u32* __restrict__ wstart,
                                                               const u64* __restrict__ pair_off, u64* __restrict__ pair_buf,
                                                               u32* __restrict__ pair_cnt, u32* __restrict__ pair_np, const u32* __restrict__ done,
-                                                              const unsigned long long* __restrict__ groups_left) {
+                                                              const unsigned long long* __restrict__ groups_left, const u32* __restrict__ witem) {
 	__shared__ MapImg<NOFF> L;
 	__shared__ u64 q_ent[MAP_THREADS / 64][WP_Q];
 	__shared__ unsigned short q_off[MAP_THREADS / 64][WP_Q];
 	__shared__ u32 s_next;
 	if (groups_left && *groups_left == 0) return;       // (k_group_pairs did every window: one cached word instead of a search per workgroup)
-	const u32 j = slice_contig(wstart, n, blockIdx.x);
+	const u32 j = witem ? witem[blockIdx.x] : slice_contig(wstart, n, blockIdx.x);
 	const u32 wi = order[j];
 	if (done && done[wi]) return;                       // (k_group_pairs)
 	const int noff = len - ix.rl;
@@ -1896,7 +1903,11 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 	const bool grouped = group_on && len - ix.rl <= GP_NOFF;
 	// With a pair buffer from an earlier call the groups are mapped BEFORE the host knows the plan's totals (the kernel returns at once
 	// if the lists would not fit): the host's wait for the totals and its next launches hide behind that kernel.
-	int rc = classify_and_plan(c, db, ix, windows, n, len, true, hit_chunk, mp, grouped, false);
+	// (grouped: k_window_pairs only gets the windows of the few groups whose classes did not fit one image -- unrelated windows, each as
+	// deep as a window gets, and nothing else is running by then: their hits in small slices over many workgroups.  Two such groups of
+	// the bench workload: 0.135 ms in slices of 524,288 hits)
+	static const u32 left_chunk = getenv("VDJX_LEFT_CHUNK") && atol(getenv("VDJX_LEFT_CHUNK")) > 0 ? (u32) atol(getenv("VDJX_LEFT_CHUNK")) : 32768u;
+	int rc = classify_and_plan(c, db, ix, windows, n, len, true, grouped && left_chunk < hit_chunk ? left_chunk : hit_chunk, mp, grouped, false);
 	if (rc) return rc;
 	HIP_TRY(db.alloc(&d_np, n));
 	HIP_TRY(db.alloc(&d_cnt, n));
@@ -1943,13 +1954,16 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 	c->stats["window_hits_distinct"] = total;              // weighted entries actually evaluated
 	c->stats["window_work_items"] = mp->tot.nwork;
 	if (mp->tot.nwork) {
+		u32* d_witem = nullptr;
+		if (grouped) HIP_TRY(db.alloc(&d_witem, (size_t) mp->tot.nwork + 1));
 		vdjx_prof_scope ps(c, "k_window_pairs");
+		if (grouped) hipLaunchKernelGGL(k_work_items, dim3((u32) (n / 256 + 1)), dim3(256), 0, st, mp->d_wstart, (u32) n, d_witem);
 		if (len - ix.rl <= 512)
 			hipLaunchKernelGGL(k_window_pairs<512>, dim3(mp->tot.nwork), dim3(MAP_THREADS), 0, st, ix, mp->d_prep, (u32) n, len, mp->tot.chunk, mp->d_order, mp->d_wstart,
-			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done, d_gstat ? d_gstat + 1 : nullptr);
+			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done, d_gstat ? d_gstat + 1 : nullptr, (const u32*) d_witem);
 		else
 			hipLaunchKernelGGL(k_window_pairs<MAP_MAXOFF>, dim3(mp->tot.nwork), dim3(MAP_THREADS), 0, st, ix, mp->d_prep, (u32) n, len, mp->tot.chunk, mp->d_order, mp->d_wstart,
-			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done, d_gstat ? d_gstat + 1 : nullptr);
+			                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done, d_gstat ? d_gstat + 1 : nullptr, (const u32*) d_witem);
 	}
 	if (d_gstat) HIP_TRY(hipMemcpyAsync((char*) c->h_plan + 128, d_gstat, 64, hipMemcpyDeviceToHost, st));        // (read after the caller's wait)
 	mp->gstat = d_gstat != nullptr;
