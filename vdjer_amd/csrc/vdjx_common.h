@@ -140,6 +140,7 @@ struct vdjx_ctx {
 	const vdjx_pool* ri_pool = nullptr;
 	void* d_ri_tab = nullptr;         // slots {read sequence, class + 1 | members, CSR start | weighted entries} (k_ri_tab; VDJX_RI_SLOT_WORDS)
 	u32 ri_tab_mask = 0;
+	bool ri_canon = false;            // the table holds one 64-byte slot per pair {sequence, reverse complement} under the smaller of the two (k_ri_tab_canon: pools of couples)
 	u32* d_ri_start = nullptr;        // class -> CSR start [ncls+1]
 	u32* d_ri_cnt1 = nullptr;         // class -> number of read-1 members (the CSR lists those only)
 	u32* d_ri_recs = nullptr;         // CSR: read-1 records in registration order
@@ -447,6 +448,16 @@ __device__ inline void vdjx_kmer_rc(u64 hi, u64 lo, int k, u64& rhi, u64& rlo) {
 	const u64 m_lo = nb >= 64u ? ~0ull : (1ull << nb) - 1ull, m_hi = nb > 64u ? (1ull << (nb - 64u)) - 1ull : 0ull;
 	rlo = l ^ (0x5555555555555555ull & m_lo);
 	rhi = h ^ (0x5555555555555555ull & m_hi);
+}
+
+// reverse complement of a read of rl <= 64 bases (a right-aligned 2*rl-bit integer in hi:lo, vdjx_pool's short-read record)
+__device__ inline void vdjx_read_rc(u64 hi, u64 lo, int rl, u64& rhi, u64& rlo) {
+	if (rl < 64) { vdjx_kmer_rc(hi, lo, rl, rhi, rlo); return; }
+	u64 a = __brevll(lo), b = __brevll(hi);
+	a = ((a >> 1) & 0x5555555555555555ull) | ((a & 0x5555555555555555ull) << 1);
+	b = ((b >> 1) & 0x5555555555555555ull) | ((b & 0x5555555555555555ull) << 1);
+	rhi = a ^ 0x5555555555555555ull;
+	rlo = b ^ 0x5555555555555555ull;
 }
 
 // ---- pools whose odd records are the reverse complements of the records before them (what add_to_buffer writes, bam_read.c:206-244:

@@ -125,14 +125,6 @@ __global__ void k_ri_insert(const u64* __restrict__ bases, const u64* __restrict
 #define RI_CS_PAL 0x40000000u         // ... the two are the same sequence
 #define RI_CS_SLOT 0x3FFFFFFFu
 #define RI_SLOT_PAL 0x80000000u       // slots[]: the representative record + 1 | this while the table is built (k_ri_number_sym: the key's number + 1)
-__device__ inline void ri_read_rc(u64 hi, u64 lo, int rl, u64& rhi, u64& rlo) {
-	if (rl < 64) { vdjx_kmer_rc(hi, lo, rl, rhi, rlo); return; }
-	u64 a = __brevll(lo), b = __brevll(hi);
-	a = ((a >> 1) & 0x5555555555555555ull) | ((a & 0x5555555555555555ull) << 1);
-	b = ((b >> 1) & 0x5555555555555555ull) | ((b & 0x5555555555555555ull) << 1);
-	rhi = a ^ 0x5555555555555555ull;
-	rlo = b ^ 0x5555555555555555ull;
-}
 __global__ void k_ri_insert_sym(const u64* __restrict__ bases, const u64* __restrict__ nmask, u32 R2, int rl,
                                 u32* __restrict__ slots, u32 mask, u32* __restrict__ couple_slot) {
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -140,7 +132,7 @@ __global__ void k_ri_insert_sym(const u64* __restrict__ bases, const u64* __rest
 	if (nmask[2 * (size_t) i]) { couple_slot[i] = NONE32; return; }          // (the mask of record 2i + 1 is this one reversed)
 	const ulonglong2 f = ((const ulonglong2*) bases)[2 * (size_t) i];
 	u64 rh, rlo;
-	ri_read_rc(f.x, f.y, rl, rh, rlo);
+	vdjx_read_rc(f.x, f.y, rl, rh, rlo);
 	const bool flip = rh < f.x || (rh == f.x && rlo < f.y);
 	const bool pal = rh == f.x && rlo == f.y;
 	u64 b[2];
@@ -538,6 +530,25 @@ __global__ void k_ri_tab(const u32* __restrict__ rep, u32 ncls, const u64* __res
 	sl[W + 1] = (u64) start[c] | ((u64) dcnt[c] << 32);   // (the weighted entries of a class lie where its CSR members do: k_ri_fold)
 }
 
+// couples: ONE 64-byte slot per pair {sequence, reverse complement}, under the smaller of the two (what k_ri_insert_sym keyed the
+// build's own table by): {key hi, key lo, key number + 1, members of class 2c | of class 2c + 1 << 32, CSR start | weighted entries << 32
+// of class 2c, the same of class 2c + 1}.  Half the insertions of k_ri_tab into lines of their own; k_map_classify looks a string up
+// under the smaller of itself and its reverse complement and takes its side of the slot.
+__global__ void k_ri_tab_canon(const u32* __restrict__ rep, u32 ncanon, const u64* __restrict__ bases, const u32* __restrict__ cnt1, const u32* __restrict__ start,
+                               const u32* __restrict__ dcnt, u64* __restrict__ tab, u32 mask) {
+	const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= ncanon) return;
+	const ulonglong2 b = ((const ulonglong2*) bases)[rep[2 * (size_t) c]];
+	u64 key[2] = {b.x, b.y};
+	u32 slot = (u32) (ri_hash<2>(key) >> 17) & mask;
+	while (atomicCAS((u32*) &tab[(size_t) slot * 8 + 2], 0u, c + 1) != 0u) slot = (slot + 1) & mask;
+	u64* sl = tab + (size_t) slot * 8;
+	const uint2 m = *(const uint2*) &cnt1[2 * (size_t) c], st = *(const uint2*) &start[2 * (size_t) c], dc = *(const uint2*) &dcnt[2 * (size_t) c];
+	((ulonglong2*) sl)[0] = b;
+	((ulonglong2*) sl)[2] = make_ulonglong2((u64) st.x | ((u64) dc.x << 32), (u64) st.y | ((u64) dc.y << 32));
+	sl[3] = (u64) m.x | ((u64) m.y << 32);                // (word 2's low half was claimed by the CAS)
+}
+
 int sort_pairs(vdjx_work& db, hipStream_t st, u64* k_in, u64* k_out, u32* v_in, u32* v_out, u32 n, unsigned end_bit) {
 	size_t tb = 0;
 	HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, k_in, k_out, v_in, v_out, (size_t) n, 0u, end_bit, st));
@@ -605,10 +616,10 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	}
 	if (ncls >= RI_ENT_NONE) { vdjx_set_error("vdjx_read_index_build: %u distinct read sequences on one GPU (limit 2^26 - 1): shard the pool by pair", ncls); return VDJX_ELIMIT; }
 	u32 tmask = 1023;
-	while ((size_t) tmask + 1 < (size_t) ncls * 2) tmask = tmask * 2 + 1;
+	while ((size_t) tmask + 1 < (size_t) (sym ? ncls / 2 : ncls) * 2) tmask = tmask * 2 + 1;
 	u32* d_rep;
 	HIP_TRY(db.alloc(&d_rep, (size_t) ncls + 1));
-	const size_t slot_bytes = (size_t) (pool->W == 2 ? VDJX_RI_SLOT_WORDS(2) : VDJX_RI_SLOT_WORDS(VDJX_LONG_W)) * 8;
+	const size_t slot_bytes = sym ? 64 : (size_t) (pool->W == 2 ? VDJX_RI_SLOT_WORDS(2) : VDJX_RI_SLOT_WORDS(VDJX_LONG_W)) * 8;
 	// the index's arrays are kept from build to build and only replaced when one needs more (hipMalloc / hipFree of gigabytes per pool
 	// cost more than the kernels that fill them)
 	HIP_TRY(ri_keep(&c->d_ri_tab, &c->ri_cap[0], ((size_t) tmask + 1) * slot_bytes));
@@ -711,7 +722,8 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(hipMemcpyAsync(&nd, d_nent, 8, hipMemcpyDeviceToHost, st));
 	{	// the mapper's table, now that the classes' sizes and starts are known
 		vdjx_prof_scope ps(c, "k_ri_tab");
-		if (pool->W == 2) hipLaunchKernelGGL(k_ri_tab<2>, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, c->d_ri_cnt1, c->d_ri_start, c->d_ri_dstart, (u64*) c->d_ri_tab, tmask);
+		if (sym) hipLaunchKernelGGL(k_ri_tab_canon, dim3(ncls / 512 + 1), b256, 0, st, d_rep, ncls / 2, pool->d_bases, c->d_ri_cnt1, c->d_ri_start, c->d_ri_dstart, (u64*) c->d_ri_tab, tmask);
+		else if (pool->W == 2) hipLaunchKernelGGL(k_ri_tab<2>, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, c->d_ri_cnt1, c->d_ri_start, c->d_ri_dstart, (u64*) c->d_ri_tab, tmask);
 		else hipLaunchKernelGGL(k_ri_tab<VDJX_LONG_W>, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, c->d_ri_cnt1, c->d_ri_start, c->d_ri_dstart, (u64*) c->d_ri_tab, tmask);
 	}
 	HIP_TRY(hipStreamSynchronize(st));
@@ -722,6 +734,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	c->stats["read_index_classes"] = ncls;
 	c->stats["read_index_rank_order"] = h_err[RI_ERR_ORDER] > 1 ? 2 : h_err[RI_ERR_ORDER];      // 0 as recorded, 1 merge of the two pools' runs, 2 sort by rank
 	c->ri_tab_mask = tmask;
+	c->ri_canon = sym;
 	c->n_pairs = n_pairs;
 	c->n_classes = ncls;
 	c->ri_pool = pool;

@@ -534,6 +534,7 @@ struct ReadIndexDev {                             // vdjx_rindex.hip
 	const u64* csr8; const u32* csr_pair; const u32* pair_r2;     // per CSR member: 8-byte entry, pair id; per pair: its read-2 records
 	const u32* dstart; const u64* d8;             // distinct read-1 entries per class with multiplicities (window scoring)
 	int rl;
+	bool canon;                                   // the table's slots are pairs {sequence, reverse complement} (k_ri_tab_canon)
 };
 __device__ inline u32 ent_a(u64 e) { return (u32) e & RI_ENT_NONE; }
 __device__ inline u32 ent_b(u64 e) { return (u32) (e >> 26) & RI_ENT_NONE; }
@@ -621,7 +622,31 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_classify(ReadIndexDev ix, c
 				}
 			}
 			u32 cls = NONE32, cs = 0, sz = 0, inst = 0;
-			if (ok) {
+			if (ok && W == 2 && ix.canon) {
+				// pools of couples: the slot of the pair {string, reverse complement} lies under the smaller of the two; the odd class is the larger one's
+				u64 rh, rlo;
+				vdjx_read_rc(key[0], key[1], rl, rh, rlo);
+				const bool odd = rh < key[0] || (rh == key[0] && rlo < key[1]);
+				u64 ck[2];
+				ck[0] = odd ? rh : key[0];
+				ck[1] = odd ? rlo : key[1];
+				u32 slot = (u32) (ri_hash<2>(ck) >> 17) & ix.mask;
+				for (;;) {
+					const u64* sl = ix.tab + (size_t) slot * 8;
+					const ulonglong2 kk = ((const ulonglong2*) sl)[0];
+					const ulonglong2 w23 = ((const ulonglong2*) sl)[1];
+					if (!(u32) w23.x) break;
+					if (kk.x == ck[0] && kk.y == ck[1]) {
+						const u64 a = sl[odd ? 5 : 4];
+						cls = 2u * ((u32) w23.x - 1u) + (odd ? 1u : 0u);
+						inst = odd ? (u32) (w23.y >> 32) : (u32) w23.y;
+						cs = (u32) a;
+						sz = weighted ? (u32) (a >> 32) : inst;
+						break;
+					}
+					slot = (slot + 1) & ix.mask;
+				}
+			} else if (ok) {
 				u32 slot = (u32) (ri_hash<W>(key) >> 17) & ix.mask;
 				for (;;) {
 					const u64* sl = ix.tab + (size_t) slot * SW;
@@ -1766,6 +1791,7 @@ static int make_index_view(vdjx_ctx* c, ReadIndexDev* ix, int len, const char* w
 	ix->csr8 = c->d_ri_csr8; ix->csr_pair = c->d_ri_csr_pair; ix->pair_r2 = c->d_pair_r2;
 	ix->dstart = c->d_ri_dstart; ix->d8 = c->d_ri_d8;
 	ix->rl = p->rl;
+	ix->canon = c->ri_canon;
 	return VDJX_OK;
 }
 
