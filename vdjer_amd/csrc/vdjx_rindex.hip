@@ -235,6 +235,15 @@ __global__ __launch_bounds__(256) void k_ri_records(const u32* __restrict__ rec_
 		reg[i] = in ? reg_rank[r] : 0u;
 		regp[i] = in && r ? reg_rank[r - 1] : 0u;
 	}
+	unsigned long long mate[8];                            // SYM: the neighbouring record's (rank, record) if it is a read-2 record of the same pair (in range), else all-ones
+#pragma unroll
+	for (int i = 0; i < 8; i++) {
+		mate[i] = NONE64;
+		if (!SYM) continue;
+		const u32 r = base + (u32) i * 256u;
+		const u32 pp = (u32) __shfl_xor((int) p[i], 1), rp = (u32) __shfl_xor((int) reg[i], 1), np = (u32) __shfl_xor((int) rn[i], 1);
+		if ((r ^ 1u) < R && rn[i] == 2 && np == 2u && pp == p[i] && p[i] < n_pairs) mate[i] = ((unsigned long long) rp << 32) | (r ^ 1u);
+	}
 	u32 cls[8];
 #pragma unroll
 	for (int i = 0; i < 8; i++) {
@@ -254,11 +263,23 @@ __global__ __launch_bounds__(256) void k_ri_records(const u32* __restrict__ rec_
 		if (p[i] >= n_pairs) { atomicAdd(&err[RI_ERR_PAIR], 1u); continue; }
 		if (rn[i] == 1) { mine += cls[i] != RI_ENT_NONE; continue; }
 		const unsigned long long v = ((unsigned long long) reg[i] << 32) | r;
-		const unsigned long long old = atomicMin(&r2key[2 * (size_t) p[i]], v);
-		const unsigned long long y = old > v ? old : v;                  // what does not stay in the first slot
-		if (y == NONE64) continue;
-		const unsigned long long z = atomicMin(&r2key[2 * (size_t) p[i] + 1], y);
-		if (z != NONE64) atomicAdd(&err[RI_ERR_R2], 1u);
+		// one record into the pair's two places: the smaller stays in the first, what loses moves on to the second, a third arrival is an error
+		auto chain = [&](unsigned long long x) {
+			const unsigned long long old = atomicMin(&r2key[2 * (size_t) p[i]], x);
+			const unsigned long long y = old > x ? old : x;
+			if (y == NONE64) return;
+			if (atomicMin(&r2key[2 * (size_t) p[i] + 1], y) != NONE64) atomicAdd(&err[RI_ERR_R2], 1u);
+		};
+		if (SYM && mate[i] != NONE64) {
+			// couples: the read-2 records of a pair are a read and its reverse complement next to each other -- the even lane brings both,
+			// two atomics instead of four (someone else in the first place already: one by one after all)
+			if (r & 1u) continue;
+			const unsigned long long v0 = v < mate[i] ? v : mate[i], v1 = v < mate[i] ? mate[i] : v;
+			if (atomicMin(&r2key[2 * (size_t) p[i]], v0) == NONE64) { if (atomicMin(&r2key[2 * (size_t) p[i] + 1], v1) != NONE64) atomicAdd(&err[RI_ERR_R2], 1u); }
+			else { chain(v0); chain(v1); }
+			continue;
+		}
+		chain(v);
 	}
 	const u32 incl = (u32) vdjx_wave_scan_add((int) mine);
 	if ((threadIdx.x & 63u) == 63u) part[threadIdx.x >> 6] = incl;
@@ -371,12 +392,24 @@ __device__ inline bool ri_fold_insert(unsigned long long* tk, u32* tc, u32 slots
 // that hold it, at its rank among such; the class's first member writes their number.
 __global__ __launch_bounds__(256) void k_ri_fold_members(const u64* __restrict__ by_class, u32 n1, const u32* __restrict__ start, const u32* __restrict__ cnt1,
                                                          const u64* __restrict__ csr8, u64* __restrict__ d8, u32* __restrict__ dcnt,
-                                                         unsigned long long* __restrict__ n_entries) {
+                                                         unsigned long long* __restrict__ n_entries, u32* __restrict__ giant, u32* __restrict__ n_giant) {
+	// the larger classes that START among this workgroup's members (at most 256 / (RI_FOLD_SMALL + 1) + 1 of them) are folded by its waves
+	// afterwards, one class at a time through a table in LDS; those of more than RI_FOLD_WAVE members go on the list of k_ri_fold_big
+	__shared__ u32 s_big[32];
+	__shared__ u32 s_nbig, tot;
+	__shared__ unsigned long long tkey[4][RI_FOLD_SLOTS];
+	__shared__ u32 tcnt[4][RI_FOLD_SLOTS];
+	static_assert(256 / (RI_FOLD_SMALL + 1) + 1 <= 32, "s_big");
+	if (threadIdx.x == 0) { s_nbig = 0; tot = 0; }
+	__syncthreads();
 	const u32 i = blockIdx.x * 256u + threadIdx.x;
 	u32 made = 0;
+	bool is_big = false, is_giant = false;
+	u32 cls = 0;
 	if (i < n1) {
-		const u32 cls = (u32) (by_class[i] >> 32);
+		cls = (u32) (by_class[i] >> 32);
 		const u32 s = start[cls], m = cnt1[cls];
+		if (m > RI_FOLD_SMALL && i == s) { is_giant = m > RI_FOLD_WAVE; is_big = !is_giant; }
 		if (m <= RI_FOLD_SMALL) {
 			const u32 j = i - s;
 			u64 e[RI_FOLD_SMALL];
@@ -403,63 +436,43 @@ __global__ __launch_bounds__(256) void k_ri_fold_members(const u64* __restrict__
 			if (j == 0) dcnt[cls] = (u32) __popc(lead);
 		}
 	}
-	// (the statistic: one bump per workgroup -- a bump per wave was 300,000 atomics on one address, 2 ms of the kernel's 2.2)
-	__shared__ u32 tot;
-	if (threadIdx.x == 0) tot = 0;
-	__syncthreads();
+	if (is_big) s_big[atomicAdd(&s_nbig, 1u)] = cls;
+	{
+		const u32 ag = vdjx_wave_inc(n_giant, is_giant);
+		if (is_giant) giant[ag] = cls;
+	}
+	// (the statistic: one bump per workgroup -- a bump per wave was 300,000 atomics on one address, 2 ms of the kernel's 2.2; so was a
+	// global list of the larger classes)
 	const u32 incl = (u32) vdjx_wave_scan_add((int) made);
 	if ((threadIdx.x & 63u) == 63u && incl) atomicAdd(&tot, incl);
-	__syncthreads();
-	if (threadIdx.x == 0 && tot) atomicAdd(n_entries, (unsigned long long) tot);
-}
-
-__global__ __launch_bounds__(256) void k_ri_fold(const u32* __restrict__ start, const u32* __restrict__ cnt1, u32 ncls, const u64* __restrict__ csr8,
-                                                 u64* __restrict__ d8, u32* __restrict__ dcnt, unsigned long long* __restrict__ n_entries,
-                                                 u32* __restrict__ giant, u32* __restrict__ n_giant) {
-	__shared__ u32 big[256];
-	__shared__ u32 nbig, total;
-	__shared__ unsigned long long tkey[4][RI_FOLD_SLOTS];
-	__shared__ u32 tcnt[4][RI_FOLD_SLOTS];
-	if (threadIdx.x == 0) { nbig = 0; total = 0; }
-	__syncthreads();
-	const u32 c = blockIdx.x * 256u + threadIdx.x;
-	u32 made = 0;
-	if (c < ncls) {
-		const u32 m = cnt1[c];
-		if (m > RI_FOLD_WAVE) giant[atomicAdd(n_giant, 1u)] = c;
-		else if (m > RI_FOLD_SMALL) big[atomicAdd(&nbig, 1u)] = c;
-		else if (!m) dcnt[c] = 0;                  // (1 .. RI_FOLD_SMALL members: k_ri_fold_members)
-	}
 	__syncthreads();
 	const u32 wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	unsigned long long* tk = tkey[wv];
 	u32* tc = tcnt[wv];
-	for (u32 b = wv; b < nbig; b += 4) {
-		const u32 cc = big[b], m = cnt1[cc], s = start[cc];
-		for (u32 i = lane; i < RI_FOLD_SLOTS; i += 64) { tk[i] = NONE64; tc[i] = 0; }
+	for (u32 b = wv; b < s_nbig; b += 4) {
+		const u32 cc = s_big[b], m = cnt1[cc], s = start[cc];
+		for (u32 q = lane; q < RI_FOLD_SLOTS; q += 64) { tk[q] = NONE64; tc[q] = 0; }
 		vdjx_wave_lds_fence();
 		for (u32 at = 0; at < m; at += 64)
 			if (at + lane < m) (void) ri_fold_insert(tk, tc, RI_FOLD_SLOTS, csr8[s + at + lane] & ((1ull << 56) - 1ull));
 		vdjx_wave_lds_fence();
 		u32 out = 0;
-		for (u32 i = 0; i < RI_FOLD_SLOTS; i += 64) {
-			const u32 n = tc[i + lane];                                    // (n <= 256: one entry, or two)
+		for (u32 q = 0; q < RI_FOLD_SLOTS; q += 64) {
+			const u32 n = tc[q + lane];                                    // (n <= 256: one entry, or two)
 			const u32 pieces = (n + RI_ENT_MAXCNT - 1) / RI_ENT_MAXCNT;      // the multiplicity field has 8 bits
-			const u32 incl = (u32) vdjx_wave_scan_add((int) pieces);
-			u32 o = s + out + incl - pieces, left = n;
-			const u64 e = (u64) tk[i + lane];
-			while (left) { const u32 q = left < RI_ENT_MAXCNT ? left : RI_ENT_MAXCNT; d8[o++] = e | ((u64) q << 56); left -= q; }
-			out += (u32) __builtin_amdgcn_readlane((int) incl, 63);
+			const u32 inc2 = (u32) vdjx_wave_scan_add((int) pieces);
+			u32 o = s + out + inc2 - pieces, left = n;
+			const u64 e = (u64) tk[q + lane];
+			while (left) { const u32 x = left < RI_ENT_MAXCNT ? left : RI_ENT_MAXCNT; d8[o++] = e | ((u64) x << 56); left -= x; }
+			out += (u32) __builtin_amdgcn_readlane((int) inc2, 63);
 		}
-		if (lane == 0) { dcnt[cc] = out; atomicAdd(&total, out); }
+		if (lane == 0) { dcnt[cc] = out; atomicAdd(&tot, out); }
 		vdjx_wave_lds_fence();
 	}
-	// entries in all (a statistic)
-	const u32 incl = (u32) vdjx_wave_scan_add((int) made);
-	if (lane == 63 && incl) atomicAdd(&total, incl);
 	__syncthreads();
-	if (threadIdx.x == 0 && total) atomicAdd(n_entries, (unsigned long long) total);
+	if (threadIdx.x == 0 && tot) atomicAdd(n_entries, (unsigned long long) tot);
 }
+
 // the classes of more than RI_FOLD_WAVE members (the reads of the deepest clones: thousands of members, hundreds of distinct
 // entries), a workgroup at a time; their number stays on the device (the workgroups take them in turns)
 __global__ __launch_bounds__(RI_FOLD_BIG_THREADS) void k_ri_fold_big(const u32* __restrict__ giant, const u32* __restrict__ n_giant, const u32* __restrict__ start,
@@ -583,12 +596,12 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(db.alloc(&d_slots, nslots));
 	HIP_TRY(db.alloc(&d_rec_slot, RK + 1));
 	HIP_TRY(db.alloc(&d_rec_cls, (size_t) R + 1));
-	HIP_TRY(db.alloc(&d_err, 8));
+	HIP_TRY(db.alloc(&d_err, 12));                     // errors [4] | split, giants | entries (u64) | larger classes
 	d_split = d_err + 4;
 	d_nent = (unsigned long long*) (d_err + 6);
 	HIP_TRY(db.alloc(&d_r2key, (size_t) n_pairs * 2 + 2));
 	HIP_TRY(hipMemsetAsync(d_slots, 0, nslots * 4, st));
-	HIP_TRY(hipMemsetAsync(d_err, 0, 32, st));
+	HIP_TRY(hipMemsetAsync(d_err, 0, 48, st));
 	HIP_TRY(hipMemsetAsync(d_r2key, 0xFF, ((size_t) n_pairs * 2 + 2) * 8, st));
 	{
 		vdjx_prof_scope ps(c, "k_ri_insert");
@@ -715,8 +728,9 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 		const u32 max_giant = n1 / (RI_FOLD_WAVE + 1) + 1;
 		u32* d_giant;
 		HIP_TRY(db.alloc(&d_giant, (size_t) max_giant + 1));
-		if (n1) hipLaunchKernelGGL(k_ri_fold_members, dim3(n1 / 256 + 1), b256, 0, st, (const u64*) d_by_class, n1, c->d_ri_start, c->d_ri_cnt1, c->d_ri_csr8, c->d_ri_d8, c->d_ri_dstart, d_nent);
-		hipLaunchKernelGGL(k_ri_fold, dim3(ncls / 256 + 1), b256, 0, st, c->d_ri_start, c->d_ri_cnt1, ncls, c->d_ri_csr8, c->d_ri_d8, c->d_ri_dstart, d_nent, d_giant, d_split + 1);
+		HIP_TRY(hipMemsetAsync(c->d_ri_dstart, 0, ((size_t) ncls + 2) * 4, st));          // (a class without read-1 members has no entries)
+		if (n1) hipLaunchKernelGGL(k_ri_fold_members, dim3(n1 / 256 + 1), b256, 0, st, (const u64*) d_by_class, n1, c->d_ri_start, c->d_ri_cnt1, c->d_ri_csr8, c->d_ri_d8, c->d_ri_dstart, d_nent,
+		                           d_giant, d_split + 1);
 		hipLaunchKernelGGL(k_ri_fold_big, dim3(max_giant < 2048u ? max_giant : 2048u), dim3(RI_FOLD_BIG_THREADS), 0, st, d_giant, d_split + 1, c->d_ri_start, c->d_ri_cnt1, c->d_ri_csr8, c->d_ri_d8, c->d_ri_dstart, d_nent);
 	}
 	HIP_TRY(hipMemcpyAsync(&nd, d_nent, 8, hipMemcpyDeviceToHost, st));
