@@ -636,6 +636,59 @@ def test_packed_host_format_equals_the_forward_load(ctx, rl):
     assert texts[1] == texts[0] and texts[2] == texts[0]
 
 
+@pytest.mark.parametrize("rl", [50, 36, 64])
+def test_read_index_over_couples_equals_the_general_build(ctx, monkeypatch, rl):
+    """A pool made of couples (record 2i + 1 = reverse complement of record 2i) gets its read index built over the couples
+    (k_ri_insert_sym, k_ri_tab_canon: one insertion and one table slot per pair of mirrored sequences; round 5); the general build of
+    the same pool (VDJX_NO_SYM_INDEX=1) numbers the classes differently and must give the same index to its users: the same class
+    counts, the same verdicts and pair counts of every window, the same mapped pairs of every contig, the same SAM text.  Even read
+    lengths (a read can be its own reverse complement: planted) and 64 bases (the reverse complement's own code path) included."""
+    from vdjer_amd import synth
+    rep = synth.make_repertoire(6, seed=191)
+    pool = synth.make_reads(rep, 6000, noise_frac=0.25, seed=192, rl=rl, err=0.004, n_rate=0.003)
+    pri = pool.primary.copy()
+    if rl % 2 == 0:                                            # reads that are their own reverse complement, as read 1 and as read 2
+        pal = ("ACGT" * 16)[:rl // 2]
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+        pal = pal + "".join(comp[c] for c in reversed(pal))
+        for r in (0, 2, 4 * 37, 4 * 37 + 2):
+            pri[r, 1:1 + rl] = np.frombuffer(pal.encode(), dtype=np.uint8)
+            pri[r + 1, 1:1 + rl] = pri[r, 1:1 + rl]
+    names = [f"r{i}" for i in range(pool.n_pairs)]
+    wins = [w for w in rep.windows() if w]
+    wl = len(wins[0])
+    if rl % 2 == 0:
+        wins.append((pal + "ACGT" * 200)[:wl])                 # a window that holds the planted read
+    contigs = [w[51:411] for w in wins]
+    p = ctx.pool_load(pri, pool.secondary, rl)
+    assert ctx.stat("pool_symmetric") == 1
+    got = []
+    for no_sym in (False, True):
+        if no_sym:
+            monkeypatch.setenv("VDJX_NO_SYM_INDEX", "1")
+        ctx.read_index_build(p, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+        assert ctx.stat("read_index_sym") == (0 if no_sym else 1)
+        ctx.sam_names_load(names)
+        valid, npairs = ctx.window_score(wins, 175)
+        offs, pairs = ctx.map_emit(contigs)
+        text = ctx.sam_text_device(contigs, [f"c{i}" for i in range(len(contigs))])
+        st = {n: ctx.stat("read_index_" + n) for n in ("r1_members", "r1_distinct")}
+        got.append((valid.copy(), npairs.copy(), offs.copy(), pairs.copy(), text, st, ctx.stat("read_index_classes")))
+    monkeypatch.delenv("VDJX_NO_SYM_INDEX")
+    a, b = got
+    assert a[1].sum() > 1000 and len(a[4]) > 10000
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[2], b[2])
+    for f in a[3].dtype.names:
+        if f not in ("cls",):
+            np.testing.assert_array_equal(a[3][f], b[3][f], err_msg=f)
+    assert a[4] == b[4] and a[5] == b[5]
+    # (the couples' build numbers both sides of every pair: one class more than the general one per read that is its own reverse complement)
+    assert a[6] >= b[6] and a[6] - b[6] <= 8
+    p.free()
+
+
 def test_root_scorer_begun_and_ended_equals_the_waiting_call():
     """vdjx_root_score_graph_begin / _end (queued on the stream, other scorer calls behind it, verdicts read at the end) against
     vdjx_root_score_graph: same ids, same verdicts -- also when the guessed item count falls short (a second, larger graph: the

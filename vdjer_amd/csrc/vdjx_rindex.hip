@@ -579,7 +579,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	hipStream_t st = c->stream;
 	if (pool->n_records > ((size_t) 1 << 29)) { vdjx_set_error("vdjx_read_index_build: %zu records on one GPU (limit 2^29): shard the pool by pair", pool->n_records); return VDJX_ELIMIT; }
 	const u32 R = (u32) pool->n_records;
-	static const bool sym_on = getenv("VDJX_NO_SYM_INDEX") == nullptr;
+	const bool sym_on = getenv("VDJX_NO_SYM_INDEX") == nullptr;       // (read per build: the tests build one pool both ways)
 	const bool sym = sym_on && pool->sym && pool->W == 2 && R % 2 == 0;      // couples: k_ri_insert_sym
 	c->stats["read_index_sym"] = sym ? 1 : 0;
 	const size_t RK = sym ? R / 2 : R;                     // what the build's table holds: records, or couples
