@@ -38,7 +38,8 @@ typedef struct {
 	pthread_t reader, *workers;
 	int n_workers, started;
 	pthread_mutex_t mu;
-	pthread_cond_t cv;
+	pthread_cond_t cv, cv_work, cv_space;      /* cv: the parser waits for the block at the head; cv_work: the inflating threads for a raw block; cv_space: the
+	                                            * reader for a free slot (one condition for all three woke every thread at every block: eight threads were slower than four) */
 	ra_slot* ring;
 	uint64_t head, tail, next_job;    /* consumer takes ring[head % RA_SLOTS]; the reader fills [tail]; workers inflate [next_job] */
 	int eof, stop, err;               /* the reader saw the end of the file / shutdown / a malformed block */
@@ -60,6 +61,7 @@ struct bamx_file {
 	int32_t* ref_len;
 	uint8_t* rec_data;                /* variable part of the record being read (per file: the reader is re-entrant) */
 	size_t rec_cap;
+	const uint8_t *cur_sq, *cur_ql;   /* the packed bases and the qualities of the record read last (read1_fields: decoded on request) */
 };
 
 /* sizes taken from a file are bounded before they reach an allocator: a corrupt or hostile BAM fails cleanly */
@@ -93,7 +95,7 @@ static void* ra_reader(void* arg) {
 	readahead* ra = (readahead*) arg;
 	for (;;) {
 		pthread_mutex_lock(&ra->mu);
-		while (!ra->stop && ra->tail - ra->head >= RA_SLOTS) pthread_cond_wait(&ra->cv, &ra->mu);
+		while (!ra->stop && ra->tail - ra->head >= RA_SLOTS) pthread_cond_wait(&ra->cv_space, &ra->mu);
 		if (ra->stop) { pthread_mutex_unlock(&ra->mu); return NULL; }
 		ra_slot* sl = &ra->ring[ra->tail % RA_SLOTS];
 		pthread_mutex_unlock(&ra->mu);
@@ -110,10 +112,10 @@ static void* ra_reader(void* arg) {
 		}
 		pthread_mutex_lock(&ra->mu);
 		if (bad) { ra->err = 1; snprintf(ra->errmsg, sizeof ra->errmsg, "not a BGZF block (or a truncated one) at file offset %lld", (long long) addr); }
-		if (bad || end) { ra->eof = 1; pthread_cond_broadcast(&ra->cv); pthread_mutex_unlock(&ra->mu); return NULL; }
+		if (bad || end) { ra->eof = 1; pthread_cond_broadcast(&ra->cv); pthread_cond_broadcast(&ra->cv_work); pthread_mutex_unlock(&ra->mu); return NULL; }
 		sl->addr = addr; sl->bsize = bsize; sl->state = 1;
 		ra->tail++;
-		pthread_cond_broadcast(&ra->cv);
+		pthread_cond_signal(&ra->cv_work);
 		pthread_mutex_unlock(&ra->mu);
 	}
 }
@@ -122,21 +124,22 @@ static void* ra_worker(void* arg) {
 	readahead* ra = (readahead*) arg;
 	for (;;) {
 		pthread_mutex_lock(&ra->mu);
-		while (!ra->stop && !(ra->next_job < ra->tail) && !ra->eof) pthread_cond_wait(&ra->cv, &ra->mu);
+		while (!ra->stop && !(ra->next_job < ra->tail) && !ra->eof) pthread_cond_wait(&ra->cv_work, &ra->mu);
 		if (ra->stop || !(ra->next_job < ra->tail)) {                   /* shutdown, or the file is read and every block taken */
 			const int done = ra->stop || ra->eof;
 			pthread_mutex_unlock(&ra->mu);
 			if (done) return NULL;
 			continue;
 		}
-		ra_slot* sl = &ra->ring[ra->next_job++ % RA_SLOTS];
+		const uint64_t job = ra->next_job++;
+		ra_slot* sl = &ra->ring[job % RA_SLOTS];
 		sl->state = 2;
 		pthread_mutex_unlock(&ra->mu);
 		const int count = inflate_block(sl->raw, sl->bsize, sl->out);
 		pthread_mutex_lock(&ra->mu);
 		sl->count = count;
 		sl->state = 3;
-		pthread_cond_broadcast(&ra->cv);
+		if (job == ra->head) pthread_cond_signal(&ra->cv);          /* (the parser waits for the block at the head only) */
 		pthread_mutex_unlock(&ra->mu);
 	}
 }
@@ -148,6 +151,8 @@ static void ra_stop(bamx_file* f) {
 		pthread_mutex_lock(&ra->mu);
 		ra->stop = 1;
 		pthread_cond_broadcast(&ra->cv);
+		pthread_cond_broadcast(&ra->cv_work);
+		pthread_cond_broadcast(&ra->cv_space);
 		pthread_mutex_unlock(&ra->mu);
 		pthread_join(ra->reader, NULL);
 		for (int i = 0; i < ra->n_workers; i++) pthread_join(ra->workers[i], NULL);
@@ -155,15 +160,19 @@ static void ra_stop(bamx_file* f) {
 	if (ra->fp) fclose(ra->fp);
 	pthread_mutex_destroy(&ra->mu);
 	pthread_cond_destroy(&ra->cv);
+	pthread_cond_destroy(&ra->cv_work);
+	pthread_cond_destroy(&ra->cv_space);
 	free(ra->workers);
 	free(ra->ring);
 	free(ra);
 	f->ra = NULL;
 }
 
-/* (re)start the read-ahead at file offset `from`, with `n` inflating threads */
+/* (re)start the read-ahead at file offset `from` for a run of `n` threads: the parser is one of them, the others inflate (the thread
+ * that reads the raw blocks sleeps in the file system most of the time) */
 static int ra_start(bamx_file* f, int64_t from, int n) {
 	ra_stop(f);
+	n = n > 2 ? n - 1 : 1;
 	readahead* ra = (readahead*) calloc(1, sizeof *ra);
 	if (!ra) return fail("out of memory");
 	ra->ring = (ra_slot*) calloc(RA_SLOTS, sizeof(ra_slot));
@@ -171,6 +180,8 @@ static int ra_start(bamx_file* f, int64_t from, int n) {
 	ra->fp = fopen(f->path, "rb");
 	pthread_mutex_init(&ra->mu, NULL);
 	pthread_cond_init(&ra->cv, NULL);
+	pthread_cond_init(&ra->cv_work, NULL);
+	pthread_cond_init(&ra->cv_space, NULL);
 	f->ra = ra;
 	if (!ra->ring || !ra->workers || !ra->fp || fseeko(ra->fp, (off_t) from, SEEK_SET) != 0) { ra_stop(f); return fail("cannot start the read-ahead on %s", f->path); }
 	ra->n_workers = n;
@@ -207,7 +218,7 @@ static int read_block(bamx_file* f) {
 		pthread_mutex_lock(&ra->mu);
 		sl->state = 0;
 		ra->head++;
-		pthread_cond_broadcast(&ra->cv);
+		pthread_cond_signal(&ra->cv_space);
 		pthread_mutex_unlock(&ra->mu);
 		return 0;
 	}
@@ -347,7 +358,25 @@ static int name2id(const bamx_file* f, const char* name) {   /* bam_name2id: exa
 	return -1;
 }
 
+/* a record's fixed fields, name and end; its sequence and qualities stay packed in the file's buffer until rec_seq / rec_qual ask
+ * for them (extract's last pass looks at the name and the flag of every record of the file and keeps one in thousands) */
+static void rec_seq(const bamx_file* f, bamx_rec* r) {
+	const uint8_t* sq = f->cur_sq;
+	for (int i = 0; i < r->l_qseq; i++) r->seq[i] = "=ACMGRSVTWYHKDBN"[(sq[i >> 1] >> ((~i & 1) << 2)) & 0xF];
+	r->seq[r->l_qseq] = 0;
+}
+static void rec_qual(const bamx_file* f, bamx_rec* r) {
+	const uint8_t* ql = f->cur_ql;
+	for (int i = 0; i < r->l_qseq; i++) r->qual[i] = (char) (ql[i] + 33);
+	r->qual[r->l_qseq] = 0;
+}
+static int read1_fields(bamx_file* f, bamx_rec* r);
 int bamx_read1(bamx_file* f, bamx_rec* r) {
+	const int rc = read1_fields(f, r);
+	if (rc >= 0) { rec_seq(f, r); rec_qual(f, r); }
+	return rc;
+}
+static int read1_fields(bamx_file* f, bamx_rec* r) {
 	uint8_t b[36];
 	r->voff = bamx_tell(f);
 	long got = bz_read(f, b, 4);
@@ -388,14 +417,9 @@ int bamx_read1(bamx_file* f, bamx_rec* r) {
 		if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += (int32_t) (c >> 4);    /* M D N = X consume the reference */
 	}
 	r->end = r->pos + (r->n_cigar ? rlen : 1);               /* bam_readrec, sam.c:458-467 */
-	const uint8_t* sq = cig + (size_t) r->n_cigar * 4;
-	const uint8_t* ql = sq + (size_t) (r->l_qseq + 1) / 2;
-	for (int i = 0; i < r->l_qseq; i++) {
-		r->seq[i] = "=ACMGRSVTWYHKDBN"[(sq[i >> 1] >> ((~i & 1) << 2)) & 0xF];
-		r->qual[i] = (char) (ql[i] + 33);
-	}
-	r->seq[r->l_qseq] = 0;
-	r->qual[r->l_qseq] = 0;
+	f->cur_sq = cig + (size_t) r->n_cigar * 4;
+	f->cur_ql = f->cur_sq + (size_t) (r->l_qseq + 1) / 2;
+	r->seq[0] = r->qual[0] = 0;
 	return (int) block_len;
 }
 
@@ -625,40 +649,52 @@ long bamx_query(bamx_file* f, const bamx_index* ix, const char* region, void (*c
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* string sets (the dense_hash_sets of extract: membership only, iteration order never matters)                        */
 /* ------------------------------------------------------------------------------------------------------------------ */
-typedef struct { const char** slot; size_t cap, n; size_t keylen; /* 0 = NUL-terminated strings */ } sset;
+typedef struct { const char** slot; uint32_t* tag; size_t cap, n; size_t keylen; /* 0 = NUL-terminated strings */ } sset;      /* tag: the upper half of the key's hash (a probe compares it before it follows the pointer) */
 static uint64_t hash_bytes(const char* s, size_t n) {
 	uint64_t h = 1469598103934665603ull;
 	for (size_t i = 0; i < n; i++) { h ^= (unsigned char) s[i]; h *= 1099511628211ull; }
 	return h;
 }
-static void sset_init(sset* t, size_t keylen) { t->cap = 1024; t->n = 0; t->keylen = keylen; t->slot = (const char**) calloc(t->cap, sizeof(char*)); }
-static void sset_free(sset* t) { free(t->slot); t->slot = NULL; }
+static void sset_init(sset* t, size_t keylen) { t->cap = 1024; t->n = 0; t->keylen = keylen; t->slot = (const char**) calloc(t->cap, sizeof(char*)); t->tag = (uint32_t*) calloc(t->cap, 4); }
+static void sset_free(sset* t) { free(t->slot); free(t->tag); t->slot = NULL; t->tag = NULL; }
 static size_t sset_len(const sset* t, const char* s) { return t->keylen ? t->keylen : strlen(s); }
-static const char* sset_get(const sset* t, const char* s) {
-	const size_t n = sset_len(t, s);
-	for (size_t i = hash_bytes(s, n) & (t->cap - 1);; i = (i + 1) & (t->cap - 1)) {
+/* (h: hash_bytes of the key -- a name asked for in several sets is hashed once) */
+static const char* sset_get_h(const sset* t, const char* s, size_t n, uint64_t h) {
+	const uint32_t tg = (uint32_t) (h >> 32);
+	for (size_t i = h & (t->cap - 1);; i = (i + 1) & (t->cap - 1)) {
 		const char* c = t->slot[i];
 		if (!c) return NULL;
-		if (t->keylen ? !memcmp(c, s, n) : !strcmp(c, s)) return c;
+		if (t->tag[i] == tg && (t->keylen ? !memcmp(c, s, n) : !strcmp(c, s))) return c;
 	}
+}
+static const char* sset_get(const sset* t, const char* s) {
+	const size_t n = sset_len(t, s);
+	return sset_get_h(t, s, n, hash_bytes(s, n));
 }
 static void sset_put(sset* t, const char* stored) {       /* the caller made sure it is absent */
 	if ((t->n + 1) * 2 > t->cap) {
 		const char** old = t->slot;
+		uint32_t* otag = t->tag;
 		const size_t oc = t->cap;
 		t->cap *= 2;
 		t->slot = (const char**) calloc(t->cap, sizeof(char*));
+		t->tag = (uint32_t*) calloc(t->cap, 4);
 		for (size_t i = 0; i < oc; i++)
 			if (old[i]) {
-				size_t j = hash_bytes(old[i], sset_len(t, old[i])) & (t->cap - 1);
+				const uint64_t h = hash_bytes(old[i], sset_len(t, old[i]));
+				size_t j = h & (t->cap - 1);
 				while (t->slot[j]) j = (j + 1) & (t->cap - 1);
 				t->slot[j] = old[i];
+				t->tag[j] = (uint32_t) (h >> 32);
 			}
 		free(old);
+		free(otag);
 	}
-	size_t j = hash_bytes(stored, sset_len(t, stored)) & (t->cap - 1);
+	const uint64_t h = hash_bytes(stored, sset_len(t, stored));
+	size_t j = h & (t->cap - 1);
 	while (t->slot[j]) j = (j + 1) & (t->cap - 1);
 	t->slot[j] = stored;
+	t->tag[j] = (uint32_t) (h >> 32);
 	t->n++;
 }
 
@@ -834,8 +870,9 @@ int bamx_extract_filtered(const char* bam_path, const char* vdj_fasta, const cha
 	}
 	/* "Process unmapped reads" (bam_read.c:346-374): sequential from WHEREVER the iterators left the file */
 	if (g_threads > 1 && bamx_set_threads(f, g_threads)) { rc = -2; goto done; }
-	while ((rc = bamx_read1(f, &rec)) >= 0) {
+	while ((rc = read1_fields(f, &rec)) >= 0) {
 		if (out->read_len == 0) out->read_len = rec.l_qseq;
+		rec_seq(f, &rec);                                           /* (the screen reads the bases; nobody reads the qualities here) */
 		const size_t L = strlen(rec.seq);
 		if (L < EXTRACT_KMER_SIZE) continue;                        /* (size_t underflow in the reference) */
 		/* the reference's loop (bam_read.c:358-372) asks at every position: is this 15-mer a V/D/J one?  yes -> the name into the
@@ -882,17 +919,20 @@ int bamx_extract_filtered(const char* bam_path, const char* vdj_fasta, const cha
 			bamx_index_free(ix2);
 			if (!rc && g_threads > 1 && bamx_set_threads(f, g_threads)) rc = -2;
 		}
-		while (!rc && (rc = bamx_read1(f, &rec)) >= 0) {
+		while (!rc && (rc = read1_fields(f, &rec)) >= 0) {
 			rc = 0;
 			if (rec.l_qseq > out->max_len) out->max_len = rec.l_qseq;          /* (get_read_length) */
 			if (rec.flag & 0x900) continue;
+			/* every record of the file asks both sets for its name: hashed once; the text of a record is made when it is kept */
+			const size_t nl = strlen(rec.qname);
+			const uint64_t nh = hash_bytes(rec.qname, nl);
 			const char* nm;
-			if ((nm = sset_get(&primary, rec.qname)) != NULL) {
-				if ((rec.flag & 0x40) && !sset_get(&p1, nm)) { push_read(out, &cap, 'P', nm, 1, &rec, &arena, &kf); sset_put(&p1, nm); }
-				else if ((rec.flag & 0x80) && !sset_get(&p2, nm)) { push_read(out, &cap, 'P', nm, 2, &rec, &arena, &kf); sset_put(&p2, nm); }
-			} else if ((nm = sset_get(&secondary, rec.qname)) != NULL) {
-				if ((rec.flag & 0x40) && !sset_get(&s1, nm)) { push_read(out, &cap, 'S', nm, 1, &rec, &arena, &kf); sset_put(&s1, nm); }
-				else if ((rec.flag & 0x80) && !sset_get(&s2, nm)) { push_read(out, &cap, 'S', nm, 2, &rec, &arena, &kf); sset_put(&s2, nm); }
+			if ((nm = sset_get_h(&primary, rec.qname, nl, nh)) != NULL) {
+				if ((rec.flag & 0x40) && !sset_get_h(&p1, nm, nl, nh)) { rec_seq(f, &rec); rec_qual(f, &rec); push_read(out, &cap, 'P', nm, 1, &rec, &arena, &kf); sset_put(&p1, nm); }
+				else if ((rec.flag & 0x80) && !sset_get_h(&p2, nm, nl, nh)) { rec_seq(f, &rec); rec_qual(f, &rec); push_read(out, &cap, 'P', nm, 2, &rec, &arena, &kf); sset_put(&p2, nm); }
+			} else if ((nm = sset_get_h(&secondary, rec.qname, nl, nh)) != NULL) {
+				if ((rec.flag & 0x40) && !sset_get_h(&s1, nm, nl, nh)) { rec_seq(f, &rec); rec_qual(f, &rec); push_read(out, &cap, 'S', nm, 1, &rec, &arena, &kf); sset_put(&s1, nm); }
+				else if ((rec.flag & 0x80) && !sset_get_h(&s2, nm, nl, nh)) { rec_seq(f, &rec); rec_qual(f, &rec); push_read(out, &cap, 'S', nm, 2, &rec, &arena, &kf); sset_put(&s2, nm); }
 			}
 		}
 		if (rc == -1) rc = 0;
