@@ -129,6 +129,13 @@ int vdjx_graph_export(const vdjx_graph* g, uint64_t* first_inst, uint32_t* gated
 int vdjx_graph_export_begin(const vdjx_graph* g, uint64_t* first_inst, uint32_t* gated_count, uint32_t* freq,
                             uint8_t* has_v, uint8_t* has_j, uint8_t* to_deg, uint32_t* to_ids,
                             uint8_t* from_deg, uint32_t* from_ids, char* kmers);
+/* The ten arrays lie in one block on the device.  offsets[10]: where each starts in it, in the order of vdjx_graph_export's arguments
+ * (every array holds vdjx_graph_nodes entries; ids in rows of 4, k-mers in rows of k); *bytes: the bytes that hold them all.
+ * vdjx_graph_export_block copies those bytes into host_block (same layout) in ONE transfer; _begin does it on the second stream
+ * (vdjx_graph_export_end waits).  For callers that export small graphs often: ten transfers cost more in calls than in bytes. */
+int vdjx_graph_block_layout(const vdjx_graph* g, uint64_t* offsets, uint64_t* bytes);
+int vdjx_graph_export_block(const vdjx_graph* g, void* host_block);
+int vdjx_graph_export_block_begin(const vdjx_graph* g, void* host_block);
 int vdjx_graph_export_end(const vdjx_graph* g);
 void vdjx_graph_free(vdjx_graph* g);
 

@@ -16,7 +16,7 @@ SYMBOLS = [
     "vdjx_last_error", "vdjx_version", "vdjx_init", "vdjx_shutdown", "vdjx_sync", "vdjx_trim", "vdjx_read_index_drop", "vdjx_device_copy",
     "vdjx_pool_load", "vdjx_pool_load_forward", "vdjx_pool_load_forward_begin", "vdjx_pool_wait", "vdjx_packed_read_bytes", "vdjx_pack_reads", "vdjx_pool_load_packed", "vdjx_pool_load_packed_begin", "vdjx_pool_load_device", "vdjx_pool_records", "vdjx_pool_free",
     "vdjx_anchor_sets_load", "vdjx_anchor_probe", "vdjx_index_generate", "vdjx_anchor_sets_from_anchors",
-    "vdjx_kmer_build", "vdjx_graph_nodes", "vdjx_graph_pre_nodes", "vdjx_graph_export", "vdjx_graph_export_begin", "vdjx_graph_export_end", "vdjx_graph_free",
+    "vdjx_kmer_build", "vdjx_graph_nodes", "vdjx_graph_pre_nodes", "vdjx_graph_export", "vdjx_graph_export_begin", "vdjx_graph_export_end", "vdjx_graph_block_layout", "vdjx_graph_export_block", "vdjx_graph_export_block_begin", "vdjx_graph_free",
     "vdjx_vregion_load", "vdjx_root_score", "vdjx_graph_roots", "vdjx_root_part", "vdjx_root_score_graph", "vdjx_root_score_graph_begin", "vdjx_root_score_graph_end",
     "vdjx_read_index_build", "vdjx_read_index_build_device", "vdjx_window_score", "vdjx_window_pairs", "vdjx_window_pairs_fetch", "vdjx_window_cover", "vdjx_map_emit", "vdjx_map_emit_begin", "vdjx_map_emit_end", "vdjx_sam_names_load", "vdjx_sam_text", "vdjx_sam_blocks", "vdjx_sam_merge", "vdjx_rows_scatter",
     "vdjx_host_alloc", "vdjx_host_free", "vdjx_host_take_rows",
@@ -93,6 +93,9 @@ def lib():
     L.vdjx_graph_export.argtypes = [vp] + [vp] * 10
     L.vdjx_graph_export_begin.argtypes = [vp] + [vp] * 10
     L.vdjx_graph_export_end.argtypes = [vp]
+    L.vdjx_graph_block_layout.argtypes = [vp, vp, vp]
+    L.vdjx_graph_export_block.argtypes = [vp, vp]
+    L.vdjx_graph_export_block_begin.argtypes = [vp, vp]
     L.vdjx_graph_free.argtypes = [vp]
     L.vdjx_graph_free.restype = None
     L.vdjx_vregion_load.argtypes = [vp, C.POINTER(C.c_char_p), sz, i32]

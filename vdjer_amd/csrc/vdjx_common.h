@@ -126,6 +126,7 @@ struct vdjx_ctx {
 	u32* d_vbits = nullptr;
 	u32* d_jbits = nullptr;
 	bool anchors_loaded = false;
+	u32 sub_tuples_set = 0;           // the value of the device's g_sub_tuples this context has set (vdjx_kmer.hip: once, not per build)
 	u32* d_anchor_tmp = nullptr;      // the codes of a set on their way into its bitmap (kept: a new chain's ref-dir comes with every pool at configs[4])
 	size_t anchor_tmp_cap = 0, vtext_cap = 0, line_off_cap = 0, seed_cap = 0;      // bytes behind d_anchor_tmp / d_vtext / d_line_off / d_seed_code and d_seed_pos
 	// a-7 V-region index
@@ -236,6 +237,7 @@ struct vdjx_graph {
 	int device = 0;
 	int k = 0;
 	size_t n = 0, pre_nodes = 0;
+	size_t export_bytes = 0;         // the arrays of vdjx_graph_export lie in the first export_bytes bytes of d_block (vdjx_graph_block_layout)
 	char* d_block = nullptr;
 	size_t block_cap = 0;
 	u64* d_first_inst = nullptr;

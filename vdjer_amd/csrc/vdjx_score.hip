@@ -1935,20 +1935,17 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 	static const u32 left_chunk = getenv("VDJX_LEFT_CHUNK") && atol(getenv("VDJX_LEFT_CHUNK")) > 0 ? (u32) atol(getenv("VDJX_LEFT_CHUNK")) : 32768u;
 	int rc = classify_and_plan(c, db, ix, windows, n, len, true, grouped && left_chunk < hit_chunk ? left_chunk : hit_chunk, mp, grouped, false);
 	if (rc) return rc;
-	HIP_TRY(db.alloc(&d_np, n));
-	HIP_TRY(db.alloc(&d_cnt, n));
+	// (one block, cleared by one call: a fill is 5 us of a small pool's step whatever its size)
+	const size_t nq = (n + 3) & ~(size_t) 3;                  // the statistics are 64-bit words behind three arrays of n
+	u32* d_zero;
+	HIP_TRY(db.alloc(&d_zero, (grouped ? 3 : 2) * nq + (grouped ? 16 : 0)));
+	d_np = d_zero; d_cnt = d_zero + nq;
 	u32* d_done = nullptr;
 	unsigned long long* d_gstat = nullptr;
-	if (grouped) {
-		HIP_TRY(db.alloc(&d_done, n));
-		HIP_TRY(db.alloc(&d_gstat, 8));
-	}
+	if (grouped) { d_done = d_zero + 2 * nq; d_gstat = (unsigned long long*) (d_zero + 3 * nq); }
 	auto map_groups = [&]() -> int {
-		HIP_TRY(hipMemsetAsync(d_np, 0, n * 4, st));
-		HIP_TRY(hipMemsetAsync(d_cnt, 0, n * 4, st));
+		HIP_TRY(hipMemsetAsync(d_zero, 0, ((grouped ? 3 : 2) * nq + (grouped ? 16 : 0)) * 4, st));
 		if (!grouped) return VDJX_OK;
-		HIP_TRY(hipMemsetAsync(d_done, 0, n * 4, st));
-		HIP_TRY(hipMemsetAsync(d_gstat, 0, 64, st));
 		vdjx_prof_scope ps(c, "k_group_pairs");
 		hipLaunchKernelGGL(k_group_pairs, dim3((u32) ((n + GP_G - 1) / GP_G)), dim3(GP_THREADS), 0, st, ix, mp->d_prep, mp->d_hits, (u32) n, len, mp->d_gorder,
 		                   mp->d_off, (u64*) c->wp_buf, d_cnt, d_np, d_done, d_gstat, gp_dbg, (u64) c->wp_cap);
