@@ -2926,6 +2926,9 @@ int stage_recount(vdjx_ctx* c, A& db, const vdjx_pool* pool, u64 rec_base, int k
 	// the latency of a full one.  1 M pairs, 1,953 blocks asked: 0.41 ms; 1,500: 0.36; 1,700: 0.40.  3 M pairs: 3,000 0.77, 5,000 0.81)
 	static const u32 walk_resident = (u32) tune("VDJX_WALK_RESIDENT", 1536);
 	if (walk_resident && nblk > walk_resident && nblk < walk_blocks) nblk = nblk / walk_resident * walk_resident;
+	// (a pool too small to fill one resident set at eight rows of records per wave takes fewer rows per wave, down to one: 100 k pairs
+	// were 98 blocks -- a wave per SIMD on a third of the CUs, every lookup's latency in the open -- and 0.119 ms)
+	if (walk_resident && nblk < walk_resident) nblk = (u32) std::min<size_t>(walk_resident, (Rw + WALK_THREADS - 1) / WALK_THREADS);
 	if (nblk == 0) nblk = 1;
 	const size_t nwaves = (size_t) nblk * (WALK_THREADS / 64);
 	const size_t NI = R * (size_t) P;
