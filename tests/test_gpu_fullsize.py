@@ -178,7 +178,10 @@ ctx.read_index_build(p, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, 
 wins = [w for w in rep.windows() if w]
 assert len(wins) == bs["n_windows"]
 valid, npairs = ctx.window_score(wins, bs["ins"])
-assert ctx.stat("window_work_items") == len(wins)        # (at this depth no window reaches 512 K distinct hits: one workgroup each, as in bench.py)
+if os.environ.get("VDJX_WINDOW_GROUP") == "0":
+    assert ctx.stat("window_work_items") == len(wins)    # (at this depth no window reaches 512 K distinct hits: one workgroup each)
+else:
+    assert ctx.stat("window_work_items") > len(wins)     # (grouped: what the groups leave over goes in slices of 32,768 hits, as in bench.py)
 assert (int(valid.sum()), int(npairs.astype(np.int64).sum())) == (bs["n_valid"], bs["npairs_sum"])
 assert sha(valid.astype(np.uint8)) == bs["valid"] and sha(npairs.astype(np.uint32)) == bs["npairs"]
 contigs = [w[51:411] for w, v in zip(wins, valid) if v]
