@@ -368,6 +368,7 @@ __global__ void k_ri_csr(const u64* __restrict__ mkey_sorted, u32 n1, const ulon
 // own threads (k_ri_fold_members); the larger ones (reads of deep clones: hundreds of members, tens of distinct entries) are left to
 // the waves of a workgroup, one class at a time, through a table in LDS.
 #define RI_FOLD_SMALL 8u
+#define RI_FM_PER 1024u               // members per workgroup of k_ri_fold_members
 #define RI_FOLD_WAVE 256u             // up to here a wave folds the class through its own LDS table (it cannot fill: 512 slots)
 #define RI_FOLD_SLOTS 512u
 #define RI_FOLD_BIG_SLOTS 8192u       // beyond, a workgroup per class (k_ri_fold_big); a class with more distinct entries than 3/4 of this
@@ -393,17 +394,19 @@ __device__ inline bool ri_fold_insert(unsigned long long* tk, u32* tc, u32 slots
 __global__ __launch_bounds__(256) void k_ri_fold_members(const u64* __restrict__ by_class, u32 n1, const u32* __restrict__ start, const u32* __restrict__ cnt1,
                                                          const u64* __restrict__ csr8, u64* __restrict__ d8, u32* __restrict__ dcnt,
                                                          unsigned long long* __restrict__ n_entries, u32* __restrict__ giant, u32* __restrict__ n_giant) {
-	// the larger classes that START among this workgroup's members (at most 256 / (RI_FOLD_SMALL + 1) + 1 of them) are folded by its waves
-	// afterwards, one class at a time through a table in LDS; those of more than RI_FOLD_WAVE members go on the list of k_ri_fold_big
-	__shared__ u32 s_big[32];
+	// the larger classes that START among this workgroup's members (at most RI_FM_PER / (RI_FOLD_SMALL + 1) + 1 of them) are folded by its
+	// waves afterwards, one class at a time through a table in LDS; those of more than RI_FOLD_WAVE members go on the list of k_ri_fold_big.
+	// (RI_FM_PER members per workgroup, four per thread: with one per thread the kernel was 74,000 workgroups of 25 KB of LDS at 10 M pairs
+	// and their dispatch, not their work, its 0.65 ms)
+	__shared__ u32 s_big[RI_FM_PER / (RI_FOLD_SMALL + 1) + 2];
 	__shared__ u32 s_nbig, tot;
 	__shared__ unsigned long long tkey[4][RI_FOLD_SLOTS];
 	__shared__ u32 tcnt[4][RI_FOLD_SLOTS];
-	static_assert(256 / (RI_FOLD_SMALL + 1) + 1 <= 32, "s_big");
 	if (threadIdx.x == 0) { s_nbig = 0; tot = 0; }
 	__syncthreads();
-	const u32 i = blockIdx.x * 256u + threadIdx.x;
 	u32 made = 0;
+	for (u32 rep = 0; rep < RI_FM_PER / 256u; rep++) {
+	const u32 i = blockIdx.x * RI_FM_PER + rep * 256u + threadIdx.x;
 	bool is_big = false, is_giant = false;
 	u32 cls = 0;
 	if (i < n1) {
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(256) void k_ri_fold_members(const u64* __restrict__
 #pragma unroll
 				for (u32 q = 0; q < RI_FOLD_SMALL; q++) mult += q < m && e[q] == mine;
 				d8[s + (u32) __popc(lead & ((1u << j) - 1u))] = mine | ((u64) mult << 56);
-				made = 1;
+				made++;
 			}
 			if (j == 0) dcnt[cls] = (u32) __popc(lead);
 		}
@@ -440,6 +443,7 @@ __global__ __launch_bounds__(256) void k_ri_fold_members(const u64* __restrict__
 	{
 		const u32 ag = vdjx_wave_inc(n_giant, is_giant);
 		if (is_giant) giant[ag] = cls;
+	}
 	}
 	// (the statistic: one bump per workgroup -- a bump per wave was 300,000 atomics on one address, 2 ms of the kernel's 2.2; so was a
 	// global list of the larger classes)
@@ -729,7 +733,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 		u32* d_giant;
 		HIP_TRY(db.alloc(&d_giant, (size_t) max_giant + 1));
 		HIP_TRY(hipMemsetAsync(c->d_ri_dstart, 0, ((size_t) ncls + 2) * 4, st));          // (a class without read-1 members has no entries)
-		if (n1) hipLaunchKernelGGL(k_ri_fold_members, dim3(n1 / 256 + 1), b256, 0, st, (const u64*) d_by_class, n1, c->d_ri_start, c->d_ri_cnt1, c->d_ri_csr8, c->d_ri_d8, c->d_ri_dstart, d_nent,
+		if (n1) hipLaunchKernelGGL(k_ri_fold_members, dim3(n1 / RI_FM_PER + 1), b256, 0, st, (const u64*) d_by_class, n1, c->d_ri_start, c->d_ri_cnt1, c->d_ri_csr8, c->d_ri_d8, c->d_ri_dstart, d_nent,
 		                           d_giant, d_split + 1);
 		hipLaunchKernelGGL(k_ri_fold_big, dim3(max_giant < 2048u ? max_giant : 2048u), dim3(RI_FOLD_BIG_THREADS), 0, st, d_giant, d_split + 1, c->d_ri_start, c->d_ri_cnt1, c->d_ri_csr8, c->d_ri_d8, c->d_ri_dstart, d_nent);
 	}
