@@ -28,6 +28,7 @@ typedef unsigned __int128 u128;
 #define VDJX_RI_SLOT_WORDS(W) ((W) == 2 ? 4 : 8)     // the read (W words) + {class + 1 | members << 32} + {CSR start | weighted entries << 32}: 32 bytes
                                                      // for reads of up to 64 bases (two slots per 64-byte line, a 1 GB table at 10 M pairs), 64 for longer ones
 // an 8-byte entry: class of the pair's read-2 record A (26 bits, all ones = none) | class of B (26) | flags (4) | multiplicity (8)
+#define RI_TAB_EPOCH_SHIFT 25        // k_ri_tab_canon's claim word: build number << 25 | key number + 1 (keys: half of the 2^26 - 1 classes)
 #define RI_ENT_NONE 0x3FFFFFFu
 #define RI_ENT_MAXCNT 255u
 __host__ __device__ inline unsigned long long ri_entry(unsigned y, unsigned z, unsigned fl, unsigned cnt) {
@@ -141,6 +142,8 @@ struct vdjx_ctx {
 	const vdjx_pool* ri_pool = nullptr;
 	void* d_ri_tab = nullptr;         // slots {read sequence, class + 1 | members, CSR start | weighted entries} (k_ri_tab; VDJX_RI_SLOT_WORDS)
 	u32 ri_tab_mask = 0;
+	u32 ri_tab_epoch = 0;             // k_ri_tab_canon: a slot is taken iff the top 7 bits of its claim word hold the build's number (1 .. 127; 0: the table
+	                                  // has to be cleared first) -- clearing a gigabyte per build was 0.15 ms of 4.8
 	bool ri_canon = false;            // the table holds one 64-byte slot per pair {sequence, reverse complement} under the smaller of the two (k_ri_tab_canon: pools of couples)
 	u32* d_ri_start = nullptr;        // class -> CSR start [ncls+1]
 	u32* d_ri_cnt1 = nullptr;         // class -> number of read-1 members (the CSR lists those only)

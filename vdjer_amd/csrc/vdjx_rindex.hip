@@ -286,16 +286,14 @@ __global__ __launch_bounds__(256) void k_ri_records(const u32* __restrict__ rec_
 	__syncthreads();
 	if (threadIdx.x == 0) bcnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
-__global__ void k_ri_r2(const unsigned long long* __restrict__ r2key, size_t n, u32* __restrict__ pair_r2) {
-	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) pair_r2[i] = r2key[i] == NONE64 ? NONE32 : (u32) r2key[i];
-}
 
 // the read-1 members of the classes, compacted IN RECORD ORDER (a workgroup's members start at bpre[workgroup]: no global counter):
 // per member its record, pair, registration rank, the 8-byte entry a hit needs (the classes and orientations of the pair's read-2
 // records) and the sort key class << 32 | member; members per class
+// (the pair's read-2 records come straight from the two minima of k_ri_records and are written, as records, where the mapper looks
+// for them: pair_r2 -- only the pairs of members are ever looked up there)
 __global__ __launch_bounds__(256) void k_ri_members(const u32* __restrict__ rec_cls, const uint8_t* __restrict__ read_num, const u32* __restrict__ reg_rank,
-                                                    const u32* __restrict__ pair_id, const u32* __restrict__ pair_r2, u32 R, u32 n_pairs,
+                                                    const u32* __restrict__ pair_id, const unsigned long long* __restrict__ r2key, u32* __restrict__ pair_r2, u32 R, u32 n_pairs,
                                                     const u32* __restrict__ bpre, u32* __restrict__ cnt1, u64* __restrict__ mkey, u32* __restrict__ m_reg,
                                                     ulonglong2* __restrict__ m_pack) {
 	__shared__ u32 wcnt[8][4];
@@ -318,7 +316,13 @@ __global__ __launch_bounds__(256) void k_ri_members(const u32* __restrict__ rec_
 	u32 run = bpre[blockIdx.x];
 	uint2 r2[8];
 #pragma unroll
-	for (int i = 0; i < 8; i++) r2[i] = p[i] != NONE32 ? *(const uint2*) &pair_r2[2 * (size_t) p[i]] : make_uint2(NONE32, NONE32);
+	for (int i = 0; i < 8; i++) {
+		r2[i] = make_uint2(NONE32, NONE32);
+		if (p[i] == NONE32) continue;
+		const ulonglong2 kk = *(const ulonglong2*) &r2key[2 * (size_t) p[i]];
+		r2[i] = make_uint2(kk.x == NONE64 ? NONE32 : (u32) kk.x, kk.y == NONE64 ? NONE32 : (u32) kk.y);
+		*(uint2*) &pair_r2[2 * (size_t) p[i]] = r2[i];
+	}
 	u32 ca[8], cb[8];
 #pragma unroll
 	for (int i = 0; i < 8; i++) {
@@ -551,14 +555,21 @@ __global__ void k_ri_tab(const u32* __restrict__ rep, u32 ncls, const u64* __res
 // build's own table by): {key hi, key lo, key number + 1, members of class 2c | of class 2c + 1 << 32, CSR start | weighted entries << 32
 // of class 2c, the same of class 2c + 1}.  Half the insertions of k_ri_tab into lines of their own; k_map_classify looks a string up
 // under the smaller of itself and its reverse complement and takes its side of the slot.
+// The claim word of a slot is build number << 25 | key number + 1: what an earlier build of the context left in the table reads as
+// empty, so the table is cleared once per 127 builds (and when it is new), not per build.
 __global__ void k_ri_tab_canon(const u32* __restrict__ rep, u32 ncanon, const u64* __restrict__ bases, const u32* __restrict__ cnt1, const u32* __restrict__ start,
-                               const u32* __restrict__ dcnt, u64* __restrict__ tab, u32 mask) {
+                               const u32* __restrict__ dcnt, u64* __restrict__ tab, u32 mask, u32 epoch) {
 	const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= ncanon) return;
 	const ulonglong2 b = ((const ulonglong2*) bases)[rep[2 * (size_t) c]];
 	u64 key[2] = {b.x, b.y};
 	u32 slot = (u32) (ri_hash<2>(key) >> 17) & mask;
-	while (atomicCAS((u32*) &tab[(size_t) slot * 8 + 2], 0u, c + 1) != 0u) slot = (slot + 1) & mask;
+	for (;;) {
+		u32* w = (u32*) &tab[(size_t) slot * 8 + 2];
+		const u32 old = vdjx_peek(w);
+		if ((old >> RI_TAB_EPOCH_SHIFT) == epoch) { slot = (slot + 1) & mask; continue; }       // taken in this build
+		if (atomicCAS(w, old, (epoch << RI_TAB_EPOCH_SHIFT) | (c + 1)) == old) break;           // (lost the race for it: look again)
+	}
 	u64* sl = tab + (size_t) slot * 8;
 	const uint2 m = *(const uint2*) &cnt1[2 * (size_t) c], st = *(const uint2*) &start[2 * (size_t) c], dc = *(const uint2*) &dcnt[2 * (size_t) c];
 	((ulonglong2*) sl)[0] = b;
@@ -621,8 +632,10 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	{
 		vdjx_prof_scope ps(c, "k_ri_number");
 		hipLaunchKernelGGL(k_ri_occ, dim3(nsb), b256, 0, st, d_slots, (u32) nslots, d_bcnt);
-		hipLaunchKernelGGL(k_rs_top, dim3(1), dim3(1024), 0, st, d_bcnt, nsb, d_bpre);
 	}
+	// (two levels: one workgroup over the 32,768 block counts of a 10 M-pair pool's table was 56 us)
+	if (nsb > 4096) { const int rc_ = scan_u32(db, st, d_bcnt, nsb, d_bpre); if (rc_) return rc_; }
+	else hipLaunchKernelGGL(k_rs_top, dim3(1), dim3(1024), 0, st, d_bcnt, nsb, d_bpre);
 	u32 ncls = 0;
 	HIP_TRY(hipMemcpyAsync(&ncls, d_bpre + nsb, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
@@ -639,13 +652,17 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	const size_t slot_bytes = sym ? 64 : (size_t) (pool->W == 2 ? VDJX_RI_SLOT_WORDS(2) : VDJX_RI_SLOT_WORDS(VDJX_LONG_W)) * 8;
 	// the index's arrays are kept from build to build and only replaced when one needs more (hipMalloc / hipFree of gigabytes per pool
 	// cost more than the kernels that fill them)
+	const void* tab_before = c->d_ri_tab;
+	const size_t tab_cap_before = c->ri_cap[0];
 	HIP_TRY(ri_keep(&c->d_ri_tab, &c->ri_cap[0], ((size_t) tmask + 1) * slot_bytes));
+	if (c->d_ri_tab != tab_before || c->ri_cap[0] != tab_cap_before || !sym || c->ri_tab_epoch >= 127u) c->ri_tab_epoch = 0;        // a new buffer, another slot format, the numbers used up: clear
 	HIP_TRY(ri_keep(&c->d_ri_start, &c->ri_cap[1], ((size_t) ncls + 2) * 4));
 	HIP_TRY(ri_keep(&c->d_ri_cnt1, &c->ri_cap[2], ((size_t) ncls + 2) * 4));
 	HIP_TRY(ri_keep(&c->d_ri_dstart, &c->ri_cap[3], ((size_t) ncls + 2) * 4));          // (weighted entries per class: k_ri_fold's dcnt)
 	HIP_TRY(ri_keep(&c->d_pair_r2, &c->ri_cap[4], ((size_t) n_pairs * 2 + 2) * 4));
 	HIP_TRY(hipMemsetAsync(c->d_ri_cnt1, 0, ((size_t) ncls + 2) * 4, st));
-	HIP_TRY(hipMemsetAsync(c->d_ri_tab, 0, ((size_t) tmask + 1) * slot_bytes, st));
+	if (c->ri_tab_epoch == 0) HIP_TRY(hipMemsetAsync(c->d_ri_tab, 0, c->ri_cap[0], st));          // (all of it: a later build may use more of the buffer)
+	if (sym) c->ri_tab_epoch++;
 	{
 		vdjx_prof_scope ps(c, "k_ri_number");
 		if (sym) hipLaunchKernelGGL(k_ri_number_sym, dim3(nsb), b256, 0, st, d_slots, (u32) nslots, d_bpre, d_rep);
@@ -660,7 +677,6 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 		vdjx_prof_scope ps(c, "k_ri_records");
 		if (nrb && sym) hipLaunchKernelGGL(k_ri_records<true>, dim3(nrb), b256, 0, st, d_rec_slot, d_slots, R, d_pair, d_rnum, d_rc, d_reg, n_pairs, d_rec_cls, d_r2key, d_err, d_rbcnt);
 		else if (nrb) hipLaunchKernelGGL(k_ri_records<false>, dim3(nrb), b256, 0, st, d_rec_slot, d_slots, R, d_pair, d_rnum, d_rc, d_reg, n_pairs, d_rec_cls, d_r2key, d_err, d_rbcnt);
-		hipLaunchKernelGGL(k_ri_r2, dim3((unsigned) (((size_t) n_pairs * 2 + 2) / 256 + 1)), b256, 0, st, d_r2key, (size_t) n_pairs * 2 + 2, c->d_pair_r2);
 		hipLaunchKernelGGL(k_rs_top, dim3(1), dim3(1024), 0, st, d_rbcnt, nrb, d_rbpre);
 	}
 	u32 h_err[4] = {0, 0, 0, 0}, n1 = 0;
@@ -680,7 +696,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(db.alloc(&d_mreg2, (size_t) n1 + 1));
 	{
 		vdjx_prof_scope ps(c, "k_ri_members");
-		if (nrb) hipLaunchKernelGGL(k_ri_members, dim3(nrb), b256, 0, st, d_rec_cls, d_rnum, d_reg, d_pair, c->d_pair_r2, R, n_pairs, d_rbpre, c->d_ri_cnt1, d_mkey, d_mreg, d_mpack);
+		if (nrb) hipLaunchKernelGGL(k_ri_members, dim3(nrb), b256, 0, st, d_rec_cls, d_rnum, d_reg, d_pair, d_r2key, c->d_pair_r2, R, n_pairs, d_rbpre, c->d_ri_cnt1, d_mkey, d_mreg, d_mpack);
 	}
 	int rc = scan_u32(db, st, c->d_ri_cnt1, ncls + 1, c->d_ri_start);         // (cnt1[ncls] = 0: start[ncls] = start[ncls + 1] = members)
 	if (rc) return rc;
@@ -740,7 +756,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(hipMemcpyAsync(&nd, d_nent, 8, hipMemcpyDeviceToHost, st));
 	{	// the mapper's table, now that the classes' sizes and starts are known
 		vdjx_prof_scope ps(c, "k_ri_tab");
-		if (sym) hipLaunchKernelGGL(k_ri_tab_canon, dim3(ncls / 512 + 1), b256, 0, st, d_rep, ncls / 2, pool->d_bases, c->d_ri_cnt1, c->d_ri_start, c->d_ri_dstart, (u64*) c->d_ri_tab, tmask);
+		if (sym) hipLaunchKernelGGL(k_ri_tab_canon, dim3(ncls / 512 + 1), b256, 0, st, d_rep, ncls / 2, pool->d_bases, c->d_ri_cnt1, c->d_ri_start, c->d_ri_dstart, (u64*) c->d_ri_tab, tmask, c->ri_tab_epoch);
 		else if (pool->W == 2) hipLaunchKernelGGL(k_ri_tab<2>, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, c->d_ri_cnt1, c->d_ri_start, c->d_ri_dstart, (u64*) c->d_ri_tab, tmask);
 		else hipLaunchKernelGGL(k_ri_tab<VDJX_LONG_W>, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, c->d_ri_cnt1, c->d_ri_start, c->d_ri_dstart, (u64*) c->d_ri_tab, tmask);
 	}

@@ -535,6 +535,7 @@ struct ReadIndexDev {                             // vdjx_rindex.hip
 	const u32* dstart; const u64* d8;             // distinct read-1 entries per class with multiplicities (window scoring)
 	int rl;
 	bool canon;                                   // the table's slots are pairs {sequence, reverse complement} (k_ri_tab_canon)
+	u32 epoch;                                    // ... taken iff their claim word's top bits hold this number
 };
 __device__ inline u32 ent_a(u64 e) { return (u32) e & RI_ENT_NONE; }
 __device__ inline u32 ent_b(u64 e) { return (u32) (e >> 26) & RI_ENT_NONE; }
@@ -635,10 +636,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_map_classify(ReadIndexDev ix, c
 					const u64* sl = ix.tab + (size_t) slot * 8;
 					const ulonglong2 kk = ((const ulonglong2*) sl)[0];
 					const ulonglong2 w23 = ((const ulonglong2*) sl)[1];
-					if (!(u32) w23.x) break;
+					if (((u32) w23.x >> RI_TAB_EPOCH_SHIFT) != ix.epoch) break;
 					if (kk.x == ck[0] && kk.y == ck[1]) {
 						const u64 a = sl[odd ? 5 : 4];
-						cls = 2u * ((u32) w23.x - 1u) + (odd ? 1u : 0u);
+						cls = 2u * (((u32) w23.x & ((1u << RI_TAB_EPOCH_SHIFT) - 1u)) - 1u) + (odd ? 1u : 0u);
 						inst = odd ? (u32) (w23.y >> 32) : (u32) w23.y;
 						cs = (u32) a;
 						sz = weighted ? (u32) (a >> 32) : inst;
@@ -1792,6 +1793,7 @@ static int make_index_view(vdjx_ctx* c, ReadIndexDev* ix, int len, const char* w
 	ix->dstart = c->d_ri_dstart; ix->d8 = c->d_ri_d8;
 	ix->rl = p->rl;
 	ix->canon = c->ri_canon;
+	ix->epoch = c->ri_tab_epoch;
 	return VDJX_OK;
 }
 
