@@ -347,11 +347,21 @@ __global__ __launch_bounds__(256) void k_ri_members(const u32* __restrict__ rec_
 		m_pack[pos] = make_ulonglong2((u64) r | ((u64) p[i] << 32), ri_entry(ca[i] & RI_ENT_NONE, cb[i] & RI_ENT_NONE, fl, 1u));
 	}
 }
-// first member that is a record of the second run (the members are in record order)
-__global__ void k_ri_split(const ulonglong2* __restrict__ m_pack, u32 n1, u32 n_primary, u32* __restrict__ out) {
-	u32 lo = 0, hi = n1;
-	while (lo < hi) { const u32 mid = (lo + hi) >> 1; if ((u32) m_pack[mid].x < n_primary) lo = mid + 1; else hi = mid; }
-	*out = lo;
+// the read-1 members before record err[RI_ERR_RUNS] -- where the second run of registration ranks starts, if the records are two runs:
+// the members of the workgroups before that record's (bpre) + those of its own workgroup up to the record.  One workgroup, right behind
+// k_ri_records: the number reaches the host with the other counts (a search over the finished members cost a wait of its own).
+__global__ __launch_bounds__(256) void k_ri_split(const u32* __restrict__ err, const u32* __restrict__ rec_cls, const uint8_t* __restrict__ read_num,
+                                                  const u32* __restrict__ pair_id, u32 R, u32 n_pairs, const u32* __restrict__ bpre, u32* __restrict__ out) {
+	__shared__ u32 part[4];
+	const u32 rs = err[RI_ERR_RUNS] < R ? err[RI_ERR_RUNS] : R;
+	const u32 blk = rs / RI_RB;
+	u32 mine = 0;
+	for (u32 r = blk * RI_RB + threadIdx.x; r < rs; r += 256u)
+		mine += (rec_cls[r] & RI_ENT_NONE) != RI_ENT_NONE && read_num[r] == 1 && pair_id[r] < n_pairs;
+	const u32 incl = (u32) vdjx_wave_scan_add((int) mine);
+	if ((threadIdx.x & 63u) == 63u) part[threadIdx.x >> 6] = incl;
+	__syncthreads();
+	if (threadIdx.x == 0) *out = bpre[blk] + part[0] + part[1] + part[2] + part[3];
 }
 
 // CSR order = (class, registration rank): the sorted key names the member
@@ -678,8 +688,10 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 		if (nrb && sym) hipLaunchKernelGGL(k_ri_records<true>, dim3(nrb), b256, 0, st, d_rec_slot, d_slots, R, d_pair, d_rnum, d_rc, d_reg, n_pairs, d_rec_cls, d_r2key, d_err, d_rbcnt);
 		else if (nrb) hipLaunchKernelGGL(k_ri_records<false>, dim3(nrb), b256, 0, st, d_rec_slot, d_slots, R, d_pair, d_rnum, d_rc, d_reg, n_pairs, d_rec_cls, d_r2key, d_err, d_rbcnt);
 		hipLaunchKernelGGL(k_rs_top, dim3(1), dim3(1024), 0, st, d_rbcnt, nrb, d_rbpre);
+		hipLaunchKernelGGL(k_ri_split, dim3(1), b256, 0, st, d_err, d_rec_cls, d_rnum, d_pair, R, n_pairs, d_rbpre, d_split);
 	}
-	u32 h_err[4] = {0, 0, 0, 0}, n1 = 0;
+	u32 h_err[4] = {0, 0, 0, 0}, n1 = 0, n1p = 0;
+	HIP_TRY(hipMemcpyAsync(&n1p, d_split, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(h_err, d_err, 16, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&n1, d_rbpre + nrb, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
@@ -723,10 +735,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 			HIP_TRY(rocprim::radix_sort_pairs((void*) tmp, tb, d_mreg, d_mreg2, d_mkey, d_mkey2, (size_t) n1, 0u, rb, st));
 			by_rank = d_mkey2;
 		} else if (h_err[RI_ERR_ORDER] == 1) {
-			u32 n1p = 0;
-			hipLaunchKernelGGL(k_ri_split, dim3(1), dim3(1), 0, st, d_mpack, n1, h_err[RI_ERR_RUNS], d_split);
-			HIP_TRY(hipMemcpyAsync(&n1p, d_split, 4, hipMemcpyDeviceToHost, st));
-			HIP_TRY(hipStreamSynchronize(st));
+			if (n1p > n1) n1p = n1;
 			size_t tb = 0;
 			HIP_TRY(rocprim::merge(nullptr, tb, d_mreg, d_mreg + n1p, d_mreg2, d_mkey, d_mkey + n1p, d_mkey2, (size_t) n1p, (size_t) (n1 - n1p), rocprim::less<u32>(), st));
 			char* tmp;
