@@ -689,6 +689,47 @@ def test_read_index_over_couples_equals_the_general_build(ctx, monkeypatch, rl):
     p.free()
 
 
+def test_read_index_table_survives_many_builds_and_changes_of_kind(monkeypatch):
+    """The lookup table of the couples' index is not cleared per build: a slot counts as taken only if its claim word carries the build's
+    number (7 bits), and the table is cleared when the numbers are used up (every 127 builds), when the buffer is new, and when the
+    other kind of build (VDJX_NO_SYM_INDEX: 32-byte slots) has written it.  140 builds over two different pools in one context, the
+    kinds mixed: every build's window verdicts and pair counts are those of a fresh context."""
+    from vdjer_amd import api, synth
+    pools, wins, want = [], [], []
+    for seed in (311, 322):
+        rep = synth.make_repertoire(4, seed=seed)
+        pool = synth.make_reads(rep, 1500, noise_frac=0.25, seed=seed + 1, rl=50, err=0.004)
+        pools.append(pool)
+        wins.append([w for w in rep.windows() if w])
+        fresh = api.Context(0)
+        p = fresh.pool_load(pool.primary, pool.secondary, 50)
+        fresh.read_index_build(p, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+        want.append(fresh.window_score(wins[-1], 175))
+        p.free()
+        fresh.close()
+    assert sum(int(w[1].sum()) for w in want) > 500
+    ctx = api.Context(0)
+    ps = [ctx.pool_load(pool.primary, pool.secondary, 50) for pool in pools]
+    try:
+        for it in range(140):
+            which = it % 2 if it % 7 else 0
+            plain = it in (5, 60, 61, 129)                      # the other kind of build in between
+            if plain:
+                monkeypatch.setenv("VDJX_NO_SYM_INDEX", "1")
+            pool = pools[which]
+            ctx.read_index_build(ps[which], pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+            if plain:
+                monkeypatch.delenv("VDJX_NO_SYM_INDEX")
+            assert ctx.stat("read_index_sym") == (0 if plain else 1)
+            valid, npairs = ctx.window_score(wins[which], 175)
+            np.testing.assert_array_equal(valid, want[which][0], err_msg=f"build {it}")
+            np.testing.assert_array_equal(npairs, want[which][1], err_msg=f"build {it}")
+    finally:
+        for p in ps:
+            p.free()
+        ctx.close()
+
+
 def test_root_scorer_begun_and_ended_equals_the_waiting_call():
     """vdjx_root_score_graph_begin / _end (queued on the stream, other scorer calls behind it, verdicts read at the end) against
     vdjx_root_score_graph: same ids, same verdicts -- also when the guessed item count falls short (a second, larger graph: the
