@@ -341,6 +341,11 @@ def traffic_source() -> dict | None:
     return {"file": os.path.relpath(files[-1], ROOT), "commit": tj.get("commit"), "note": "PMC passes are separate runs of the same command (profiles/prof_step.sh)"}
 
 
+# the HBM-streaming kernels of the k-mer build: the roofline kernel is the longest of them
+BUILD_KERNELS = ("k_pool_pack", "k_gated_hist", "k_part_records", "k_part_tuples", "k_seg_hist", "k_gated_reduce", "k_gated_local",
+                 "k_walk_items", "k_part_items", "k_recount")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -671,7 +676,32 @@ def main():
         first_step_phases = {k_: round(v * 1e3, 3) for k_, v in wall.items()}     # where the first call of a process spends it: workspaces, page-locked result buffers
     for _ in range(max(0, args.warmup - 1)):
         step()
-    ctx.profile(os.environ.get("VDJX_BENCH_NO_EVENTS") != "1")      # (diagnostic switch: what the per-kernel HIP events cost)
+    # Every kernel bracketed by HIP events is 80 event records per step: 0.16 ms of a 10 M-pair step, 0.29 ms of a 1 M-pair one -- the
+    # instrument, not the path.  So: (1) n_prof UNTIMED steps with every kernel bracketed -> kernels_ms_per_step, roofline_by_kernel, the
+    # busy fraction, and the name of the roofline kernel (the longest HBM-streaming kernel of the build); (2) the timed region with that
+    # ONE kernel bracketed (vdjx_profile_only): roofline.achieved is measured live inside the timed region, on the stream the kernel is
+    # launched on.  VDJX_BENCH_ALL_EVENTS=1: every kernel inside the timed region, as in rounds 1-4; VDJX_BENCH_NO_EVENTS=1: none anywhere.
+    no_events = os.environ.get("VDJX_BENCH_NO_EVENTS") == "1"
+    all_events = os.environ.get("VDJX_BENCH_ALL_EVENTS") == "1"
+    prof_full, prof_ms_step, n_prof, dom_name = None, None, 0, None
+    if not no_events and not all_events:
+        n_prof = max(1, min(args.steps, 10))
+        ctx.profile(True)
+        step()                          # (the events are made on their first use: not a step to measure)
+        ctx.map_emit_wait()
+        ctx.profile_reset()
+        barrier()
+        t_p = time.perf_counter()
+        for _ in range(n_prof):
+            step()
+        ctx.map_emit_wait()
+        barrier()
+        prof_ms_step = (time.perf_counter() - t_p) / n_prof * 1e3
+        prof_full = ctx.profile_get()
+        cand = {n_: v_ for n_, v_ in prof_full.items() if n_ in BUILD_KERNELS}
+        dom_name = max(cand.items(), key=lambda kv: kv[1][0])[0] if cand else None
+        ctx.profile_only(dom_name)
+    ctx.profile(not no_events)
     ctx.profile_reset()
     wall.clear()
     bytes_before = engine.bytes_exchanged if engine else 0
@@ -688,8 +718,13 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
-    prof = ctx.profile_get()
+    prof_timed = ctx.profile_get()
     ctx.profile(False)
+    ctx.profile_only(None)
+    if prof_full is None:               # (every kernel was bracketed inside the timed region, or none at all)
+        prof, prof_steps, prof_ms_step = prof_timed, args.steps, dt / args.steps * 1e3
+    else:
+        prof, prof_steps = dict(prof_full), n_prof
     # ---- parity gate inside the benchmark.  (1) What the LAST TIMED STEP produced -- graph, root verdicts, every
     # window's verdict and pair count, the mapped-pair stream -- against the oracle's digests of this very workload
     # (tests/golden/fullsize_digests.json, made by tests/golden/make_fullsize_digests.py on the same counter-based pool), when the
@@ -844,12 +879,11 @@ def main():
     # looked at by many windows: PMC fabric traffic is a third of SURVEY 8d's per-instance bytes), so an HBM fraction says nothing
     # about them.
     sb = scorer_bytes(stats, len(my_wins), state.get("n_contigs_rank", 0), args.k, rl)
-    build_kernels = ("k_pool_pack", "k_gated_hist", "k_part_records", "k_part_tuples", "k_seg_hist", "k_gated_reduce", "k_gated_local",
-                     "k_walk_items", "k_part_items", "k_recount")
+    build_kernels = BUILD_KERNELS
 
     def price(name, tot_ms, launches):
         avg_ms = tot_ms / max(1, launches)
-        per_step = launches / args.steps
+        per_step = launches / prof_steps
         per_pair = ab.get(name) if name in ab and name not in ("P", "input", "total", "gated_per_pair") else None
         if name in sb:
             bpl = sb[name] * len(W) / max(1.0, per_step)
@@ -887,6 +921,18 @@ def main():
     for v_ in by_kernel.values():       # what the counters say the kernel moved, against the same peak (null without a PMC pass of this workload)
         v_["frac_on_traffic"] = round(v_["traffic"] / (v_["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if v_.get("traffic") and v_["avg_launch_ms"] else None
     dom = max(((n_, v_) for n_, v_ in prof.items() if n_ in build_kernels and n_ in by_kernel), key=lambda kv: kv[1][0], default=(None, (0.0, 0)))
+    if dom_name and dom_name in prof_timed and dom_name in by_kernel:
+        # the roofline kernel's own figures come from INSIDE the timed region (it alone was bracketed there); the untimed pass's are kept beside them
+        tt, tl = prof_timed[dom_name]
+        live = dict(by_kernel[dom_name])
+        scale = (by_kernel[dom_name]["avg_launch_ms"] / (tt / max(1, tl))) if tt > 0 else 1.0
+        live.update(avg_launch_ms=round(tt / max(1, tl), 4), avg_launch_ms_untimed_pass=by_kernel[dom_name]["avg_launch_ms"],
+                    achieved=round(by_kernel[dom_name]["achieved"] * scale, 2) if by_kernel[dom_name].get("achieved") else None,
+                    frac=round(by_kernel[dom_name]["frac"] * scale, 5) if by_kernel[dom_name].get("frac") else None)
+        if live.get("traffic") and live["avg_launch_ms"]:
+            live["frac_on_traffic"] = round(live["traffic"] / (live["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        by_kernel[dom_name] = live
+        dom = (dom_name, prof[dom_name])
     roof = None
     if dom[0]:
         pr = by_kernel[dom[0]]
@@ -920,7 +966,7 @@ def main():
         if cpu is None:           # no compiled reference on this box: the -O2 port is the stated baseline
             cpu = cpu_port_legs[0]
     cli_e2e = cpu.pop("cli_end_to_end", None) if cpu else None
-    kern_ms = {k_: round(v[0] / args.steps, 4) for k_, v in prof.items()}
+    kern_ms = {k_: round(v[0] / prof_steps, 4) for k_, v in prof.items()}
     out = {
         "metric": "M paired-reads/sec (k-mer build + contig score), IgH 50bp PE", "value": round(value, 4),
         "unit": "M paired-reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -935,7 +981,14 @@ def main():
         "value_end_to_end": e2e, "value_with_read_index": with_index, "first_step_ms": round(first_step_ms, 3) if first_step_ms else None, "first_step_phases_ms": first_step_phases,
         "cli_end_to_end": cli_e2e,
         "kernels_ms_per_step": kern_ms, "kernels_sum_ms_per_step": round(sum(kern_ms.values()), 3),
-        "device_busy_frac": round(sum(kern_ms.values()) / ms_step, 4) if ms_step else None,
+        "device_busy_frac": round(sum(kern_ms.values()) / prof_ms_step, 4) if prof_ms_step else None,
+        "instrumentation": ({"timed_region_events": f"{dom_name} only (the roofline kernel: roofline.avg_launch_ms / achieved / frac are measured inside the timed region)",
+                             "per_kernel_pass": f"{n_prof} untimed steps before the timed region with every kernel bracketed by HIP events: kernels_ms_per_step, "
+                                                "roofline_by_kernel, device_busy_frac (against that pass's own wall time)",
+                             "per_kernel_pass_ms_per_step": round(prof_ms_step, 3),
+                             "why": "80 event records per step are 0.16 ms of a 10 M-pair step and 0.29 ms of a 1 M-pair one; VDJX_BENCH_ALL_EVENTS=1 puts them back "
+                                    "into the timed region (rounds 1-4)"} if prof_full is not None else
+                            {"timed_region_events": "none" if no_events else "every kernel (VDJX_BENCH_ALL_EVENTS=1)"}),
         "exchange_bytes_per_step_rank0": ((engine.bytes_exchanged - bytes_before) // args.steps) if engine else 0,
         "shard_wall_ms_per_step": ({k_: round(v / args.steps * 1e3, 3) for k_, v in engine.laps.items()} if engine else None),
         "wall_ms_per_step": {k_: round(v / args.steps * 1e3, 3) for k_, v in wall.items()},

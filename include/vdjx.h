@@ -286,6 +286,9 @@ uint64_t vdjx_stat(vdjx_ctx* ctx, const char* name);
 
 /* ---- profiling hooks (HIP events on the context's stream) ---------------------------------------*/
 int vdjx_profile_enable(vdjx_ctx* ctx, int on);
+/* bracket only the launches of this scope name from now on (NULL: all again): two event records per scope and step cost a small pool's
+ * step a tenth of its time; a caller that wants one kernel's duration from inside a region it times pays for that one */
+int vdjx_profile_only(vdjx_ctx* ctx, const char* name);
 int vdjx_profile_reset(vdjx_ctx* ctx);
 /* number of distinct kernel names recorded since the last reset */
 int vdjx_profile_count(vdjx_ctx* ctx);

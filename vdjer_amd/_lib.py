@@ -20,7 +20,7 @@ SYMBOLS = [
     "vdjx_vregion_load", "vdjx_root_score", "vdjx_graph_roots", "vdjx_root_part", "vdjx_root_score_graph", "vdjx_root_score_graph_begin", "vdjx_root_score_graph_end",
     "vdjx_read_index_build", "vdjx_read_index_build_device", "vdjx_window_score", "vdjx_window_pairs", "vdjx_window_pairs_fetch", "vdjx_window_cover", "vdjx_map_emit", "vdjx_map_emit_begin", "vdjx_map_emit_end", "vdjx_sam_names_load", "vdjx_sam_text", "vdjx_sam_blocks", "vdjx_sam_merge", "vdjx_rows_scatter",
     "vdjx_host_alloc", "vdjx_host_free", "vdjx_host_take_rows",
-    "vdjx_stat", "vdjx_profile_enable", "vdjx_profile_reset", "vdjx_profile_count", "vdjx_profile_get",
+    "vdjx_stat", "vdjx_profile_enable", "vdjx_profile_only", "vdjx_profile_reset", "vdjx_profile_count", "vdjx_profile_get",
     "vdjx_shard_begin", "vdjx_shard_begin_share", "vdjx_shard_free", "vdjx_shard_record_bytes", "vdjx_shard_count", "vdjx_shard_geometry", "vdjx_shard_symmetric", "vdjx_shard_geometry2", "vdjx_shard_local", "vdjx_shard_local_fill",
     "vdjx_shard_merge", "vdjx_shard_queries", "vdjx_shard_reply", "vdjx_shard_resolve",
     "vdjx_shard_survivors", "vdjx_shard_edges", "vdjx_shard_finish",
@@ -132,6 +132,7 @@ def lib():
     L.vdjx_stat.argtypes = [vp, C.c_char_p]
     L.vdjx_stat.restype = C.c_uint64
     L.vdjx_profile_enable.argtypes = [vp, i32]
+    L.vdjx_profile_only.argtypes = [vp, C.c_char_p]
     L.vdjx_profile_reset.argtypes = [vp]
     L.vdjx_profile_count.argtypes = [vp]
     L.vdjx_profile_get.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]

@@ -583,6 +583,10 @@ class Context:
     def profile(self, on: bool = True):
         check(self.L.vdjx_profile_enable(self.h, 1 if on else 0))
 
+    def profile_only(self, name=None) -> None:
+        """bracket only the launches of this scope from now on (None: all again)"""
+        check(self.L.vdjx_profile_only(self.h, name.encode() if name else None), "vdjx_profile_only")
+
     def profile_reset(self):
         check(self.L.vdjx_profile_reset(self.h))
 

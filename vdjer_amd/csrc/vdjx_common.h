@@ -118,6 +118,7 @@ struct vdjx_ctx {
 	size_t stage_cap = 0;
 	hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_packed[2] = {nullptr, nullptr};
 	bool profiling = false;
+	std::string prof_only;            // vdjx_profile_only: the one scope name that is bracketed (empty: all)
 	std::vector<std::string> prof_names;                 // insertion order
 	std::map<std::string, vdjx_prof_entry> prof;
 	struct pending_ev { std::string name; hipEvent_t a, b; };
