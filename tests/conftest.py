@@ -11,6 +11,10 @@ if ROOT not in sys.path:
 # the scorers split only windows of more than 512 K distinct hits over several workgroups; the test pools stay far below, so the tests
 # run with the split at 128 hits (test_deep_windows_many_slices_and_multiplicities asserts that it happens).  Read once per process.
 os.environ.setdefault("VDJX_HIT_CHUNK", "128")
+# ... and windows are mapped in groups of eight (k_group_pairs) from 4,096 windows up only (below, one by one is faster): the suite's
+# pools have tens of windows, so it groups from the first one -- the tests that run the scorers "both ways" set VDJX_WINDOW_GROUP=0 for
+# the other way; bench.py and the production-slicing test run with the shipped threshold
+os.environ.setdefault("VDJX_GROUP_MIN", "1")
 
 
 def pytest_configure(config):

@@ -166,7 +166,7 @@ import hashlib, json, os, sys
 sys.path.insert(0, %r)
 import numpy as np, torch
 from vdjer_amd import api, synth
-assert "VDJX_HIT_CHUNK" not in os.environ and "VDJX_MAP_SLICE" not in os.environ
+assert "VDJX_HIT_CHUNK" not in os.environ and "VDJX_MAP_SLICE" not in os.environ and "VDJX_GROUP_MIN" not in os.environ
 dg = json.load(open(os.path.join(%r, "tests", "golden", "fullsize_digests.json")))
 bs = dg["bench_scorers"]
 sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
@@ -201,7 +201,7 @@ def test_config2_10M_pairs_scorers_production_slicing_vs_oracle_digests(grouped)
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    e = {k_: v for k_, v in os.environ.items() if k_ not in ("VDJX_HIT_CHUNK", "VDJX_MAP_SLICE")}
+    e = {k_: v for k_, v in os.environ.items() if k_ not in ("VDJX_HIT_CHUNK", "VDJX_MAP_SLICE", "VDJX_GROUP_MIN")}
     e["VDJX_WINDOW_GROUP"] = grouped
     r = subprocess.run([sys.executable, "-c", _PROD_SCORER_CASE % (root, root)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
     assert r.returncode == 0 and "PROD_SCORER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -1928,7 +1928,10 @@ static int window_pairs_run(vdjx_ctx* c, vdjx_work& db, const ReadIndexDev& ix, 
 	// VDJX_WINDOW_GROUP=0: every window on its own (k_window_pairs only)
 	static const u32 gp_dbg = getenv("VDJX_GP_DBG") ? (u32) atol(getenv("VDJX_GP_DBG")) : 0u;      // ablation (profiles/): 1 no full tests, 2 images only
 	static const bool group_on = !(getenv("VDJX_WINDOW_GROUP") && atol(getenv("VDJX_WINDOW_GROUP")) == 0);
-	const bool grouped = group_on && len - ix.rl <= GP_NOFF;
+	// (few windows are mapped one by one: a group is one workgroup for eight windows, and below a few thousand windows the groups
+	// leave most of the chip idle -- 200 windows: 0.14 ms in groups + left-overs, 0.08 one by one; 2,000: 0.29 against 0.23; 20,000: 1.1 against 3.5)
+	static const size_t group_min = getenv("VDJX_GROUP_MIN") ? (size_t) atol(getenv("VDJX_GROUP_MIN")) : 4096;
+	const bool grouped = group_on && len - ix.rl <= GP_NOFF && n >= group_min;
 	// With a pair buffer from an earlier call the groups are mapped BEFORE the host knows the plan's totals (the kernel returns at once
 	// if the lists would not fit): the host's wait for the totals and its next launches hide behind that kernel.
 	// (grouped: k_window_pairs only gets the windows of the few groups whose classes did not fit one image -- unrelated windows, each as
