@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "vdjer_ref")
 
 
-def algorithmic_bytes_per_pair(k: int, rl: int = 50, gated_per_pair: float | None = None) -> dict:
+def algorithmic_bytes_per_pair(k: int, rl: int = 50, gated_per_pair: float | None = None, sym: bool = False, sym_walk: bool = False) -> dict:
     """SURVEY §8d.  P = 4*(rl-k+1) instances per pair; compulsory input of a pair = 2 reads x (packed bases + qualities);
     "every gated instance must reach its owner bucket once as a 16-B packed key, written once and read once"; the graph pass
     re-reads the packed input and probes the survivors with one 16-B key per instance.
@@ -49,13 +49,40 @@ def algorithmic_bytes_per_pair(k: int, rl: int = 50, gated_per_pair: float | Non
       pack: the four ASCII records of the pair in, their packed bases and masks out (32 B each; the quality characters stay in
       the resident records);  hist: the packed input once;  partition pass 1: packed input + one 16-B key per gated
       instance out;  pass 2: every such key in and out;  table + prune: every key in;
-      walk (the graph pass): packed input once more + one 16-B survivor probe per instance (gated or not)."""
+      walk (the graph pass): packed input once more + one 16-B survivor probe per instance (gated or not).
+    **Units the launch processes (round 6).**  A pool made of couples (record, reverse complement: what add_to_buffer
+    writes) is built over HALF the records: phase A (`sym`) moves one tuple per pair of mirrored gated instances and scans the couples'
+    first records only; the walk (`sym_walk`) takes the first record of every couple and derives the second.  The per-kernel figures
+    below are the §8d per-unit bytes x the units THAT launch processes -- so half the model's bytes for those kernels; the figure for
+    all records is kept under `model_all_records` (what rounds 1-5 reported for the walk)."""
     P = 4 * (rl - k + 1)
     inp = 2 * ((rl + 3) // 4 + rl)
     g = P if gated_per_pair is None else gated_per_pair
-    return {"P": P, "input": inp, "total": inp + 32 * P + inp + 16 * P, "gated_per_pair": g,
-            "k_pool_pack": 4 * (2 * rl + 1) + 4 * 32, "k_gated_hist": inp, "k_part_records": inp + 16 * g, "k_part_tuples": 32 * g,
-            "k_seg_hist": 16 * g, "k_gated_reduce": 16 * g, "k_gated_local": 16 * g, "k_walk_items": inp + 16 * P}
+    fa = 0.5 if sym else 1.0             # phase A: records scanned and tuples moved
+    fw = 0.5 if sym_walk else 1.0        # the walk: records walked and instances probed
+    allrec = {"k_gated_hist": inp, "k_part_records": inp + 16 * g, "k_part_tuples": 32 * g, "k_seg_hist": 16 * g, "k_gated_reduce": 16 * g,
+              "k_gated_local": 16 * g, "k_walk_items": inp + 16 * P}
+    out = {"P": P, "input": inp, "total": inp + 32 * P + inp + 16 * P, "gated_per_pair": g, "k_pool_pack": 4 * (2 * rl + 1) + 4 * 32,
+           "model_all_records": allrec, "units_factor": {"phase_a": fa, "walk": fw}}
+    for n_, v_ in allrec.items():
+        out[n_] = v_ * (fw if n_ == "k_walk_items" else fa)
+    return out
+
+
+def survivor_bytes(ns: int, k: int, tmask_slots: int | None = None) -> dict:
+    """The composite scopes of the k-mer build that work on the SURVIVORS (ns of them; 1.05 M at 10 M pairs), priced by their member
+    kernels' array traffic per survivor (vdjx_kmer.hip stage_walk / stage_finish2) -- rounds 1-5 left them unpriced (1.05 ms of the step):
+      k_surv_table = k_surv_table2 (key 16 in; table slot 16, key copy 16, filter bit out) + k_succ_links2 (four successor probes of 16,
+                     counts 4 x 4; successor list 16, proposal 8, best successor 4 out)                                     = 156 B
+      k_chain_order = k_chain_init (12 in, 8 out) + k_chain_jump x launches (8 + 8 in, 8 out: ~3 launches do work) + k_chain_len (8, 4)
+                     + the scan (3 x 4) + k_chain_place (16) + k_chain_permute (key, counts, first, successor list: 60 in, 76 out)
+                     + k_table_remap (the table: 2 slots of 16 per survivor in and out) + k_partner (one probe 16, 4 out)
+                     + k_chain_words (successors 16, key 16 in; 12 out) + k_partner_check (4 + 8)                           = 420 B
+      k_node_order = k_rank_keys (12 in, 12 out) + the radix sort (five 8-bit passes over 8-byte keys + 4-byte values, in and out: 120)
+                     + k_rank_scatter (12, 4) + k_node_emit2 (key 16, counts 12, first 8, flags 2, rank 4, edge slots 4 x 16 in; the
+                     node: 8 + 4 + 4 + 32 + 4 + k out)                                                                      = 326 + k B
+      k_node_flags = key 16 in, two bitmap probes of 4, 2 out                                                               = 26 B"""
+    return {"k_surv_table": 156 * ns, "k_chain_order": 420 * ns, "k_node_order": (326 + k) * ns, "k_node_flags": 26 * ns}
 
 
 def scorer_bytes(stats: dict, n_windows: int, n_contigs: int, k: int, rl: int = 50, wlen: int = 486, clen: int = 360) -> dict:
@@ -243,9 +270,12 @@ def cpu_reference(n_sample: int, seed: int, k: int, mf: int, mq: int, mrs: int, 
                          "input_read_and_parsed (the HIP runtime starting beside it on a thread)": seg("START", "(inputs read)"),
                          "wait_for_hip_init": seg("(inputs read)", "(vdjx_init done)"),
                          "anchor_sets_and_v_region": seg("(vdjx_init done)", "POST_VJF_INIT"),
-                         "pool_load": seg("POST_VJF_INIT", "(pool loaded)"), "read_index": seg("(pool loaded)", "(read index built)"),
-                         "read_names_to_device": seg("(read index built)", "POST_READ_EXTRACT"),
-                         "kmer_build": seg("PRE_PRE_GRAPH1", "POST_BUILD_GRAPH2"), "traversal_and_scorers": seg("POST_BUILD_GRAPH2", "THREADS_DONE"),
+                         "pool_load": seg("POST_VJF_INIT", "(pool loaded)"), "read_index_begin": seg("(pool loaded)", "(read index begun)"),
+                         "read_names_to_device": seg("(read index begun)", "POST_READ_EXTRACT"),
+                         "kmer_build (the read index beside it)": seg("PRE_PRE_GRAPH1", "(k-mer build done)"),
+                         "read_index_waited_for_after_the_build": seg("(k-mer build done)", "(read index ended)"),
+                         "read_index_plus_kmer_build": seg("(pool loaded)", "(read index ended)"),
+                         "traversal_and_scorers": seg("POST_BUILD_GRAPH2", "THREADS_DONE"),
                          "overlap_removal_fasta_sam": seg("THREADS_DONE", "PRE_CLEANUP"), "teardown": seg("PRE_CLEANUP", "FINIS"),
                          "finis_to_process_end": round((t1c - mk2["FINIS"]) * 1e3, 1) if "FINIS" in mk2 else None}
             cli = {"pairs": n_sample, "exit_code": rc2, "wall_s_process": round(t1c - t0c, 3), "cli_process_breakdown_ms": breakdown,
@@ -314,17 +344,25 @@ def cpu_port(n_sample: int, seed: int, k: int, mf: int, mq: int, mrs: int, ins: 
             "seconds": round(secs, 2)}
 
 
-def load_traffic(args, world: int, kernel: str):
-    """PMC-measured HBM bytes per launch of `kernel` from the newest committed rocprofv3 pass of the same command
-    (profiles/rNN_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections, see profiles/README.md; the
-    file names the commit it was taken at)."""
+def _traffic_file(args, world: int):
+    """the newest committed PMC pass of THIS workload: profiles/rNN_traffic[_<variant>].json (variant: k25, shard, config4; none = the
+    default configs[2] step).  The file names the commit and the flags it was taken with."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
-    if not files:
-        return None
+    variant = "config4" if getattr(args, "config4", False) else ("shard" if args.force_shard else ("k25" if args.k == 25 else ""))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_traffic{'_' + variant if variant else ''}.json")))
+    if not files or world != 1:
+        return None, None
     tj = json.load(open(files[-1]))
-    same = (tj.get("pairs_per_gpu") == args.pairs and tj.get("k") == args.k and tj.get("windows", "traversal") == args.windows and world == 1)
-    if not same:
+    same = (tj.get("pairs_per_gpu") == args.pairs and tj.get("k") == args.k and tj.get("windows", "traversal") == args.windows
+            and tj.get("variant", "") == variant)
+    return (tj, files[-1]) if same else (None, None)
+
+
+def load_traffic(args, world: int, kernel: str):
+    """PMC-measured fabric bytes per launch of `kernel` (a composite scope: per step, summed over its member kernels) from the newest
+    committed rocprofv3 pass of the same command (separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections, profiles/README.md)"""
+    tj, _ = _traffic_file(args, world)
+    if not tj:
         return None
     for name, v in tj.get("kernels", {}).items():
         if name.split("<")[0] == kernel:
@@ -332,18 +370,28 @@ def load_traffic(args, world: int, kernel: str):
     return None
 
 
-def traffic_source() -> dict | None:
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
-    if not files:
+def step_traffic(args, world: int):
+    tj, _ = _traffic_file(args, world)
+    if not tj or not tj.get("step"):
         return None
-    tj = json.load(open(files[-1]))
-    return {"file": os.path.relpath(files[-1], ROOT), "commit": tj.get("commit"), "note": "PMC passes are separate runs of the same command (profiles/prof_step.sh)"}
+    return tj["step"]
+
+
+def traffic_source(args=None, world: int = 1) -> dict | None:
+    if args is None:
+        return None
+    tj, f = _traffic_file(args, world)
+    if not tj:
+        return None
+    return {"file": os.path.relpath(f, ROOT), "commit": tj.get("commit"), "note": "PMC passes are separate runs of the same command (profiles/prof_step.sh)"}
 
 
 # the HBM-streaming kernels of the k-mer build: the roofline kernel is the longest of them
 BUILD_KERNELS = ("k_pool_pack", "k_gated_hist", "k_part_records", "k_part_tuples", "k_seg_hist", "k_gated_reduce", "k_gated_local",
                  "k_walk_items", "k_part_items", "k_recount")
+# every scope with a stated job size (algorithmic_bytes_per_pair, scorer_bytes, survivor_bytes): the roofline kernel is the longest of THESE
+PRICED_KERNELS = BUILD_KERNELS + ("k_surv_table", "k_chain_order", "k_node_order", "k_node_flags", "k_map_classify", "k_group_pairs", "k_window_pairs",
+                                  "k_window_cover", "k_map_emit", "k_gather_pairs", "k_root_dp")
 
 
 def main():
@@ -379,6 +427,7 @@ def main():
                          "(60 V germlines shared by thousands of clones): 21 k contig candidates at 1 M pairs, 699 k at 2 M, and at "
                          "10 M pairs it does not finish in an hour on 8 cores (DESIGN.md §5)")
     ap.add_argument("--parity-sample", type=int, default=20000, help="pairs of the parity gate (SURVEY §8d)")
+    ap.add_argument("--no-index-leg", action="store_true", help="skip value_with_read_index (profiles/prof_step.sh: the process then ends with the timed steps)")
     args = ap.parse_args()
     if args.gpus == 8 and not args.no_config4:
         args.config4 = True
@@ -613,8 +662,11 @@ def main():
         t = lap("pool_pack", t)
         if args.config4:           # every chain's pool is seen once: its read index (quick_map3.c:126-149) is part of the step
             rd_ = w_["ri_dev"]
-            ctx.read_index_build_device(p, rd_[0].data_ptr(), rd_[1].data_ptr(), rd_[2].data_ptr(), rd_[3].data_ptr(), w_["pool"].n_pairs)
-            t = lap("read_index", t)
+            # begun on the library's index stream: built beside the k-mer build of the same pool (both only read the packed records), ended by
+            # the window scorer's first call (VDJX_BENCH_INDEX_SERIAL=1: waited for here, as until round 5)
+            ctx.read_index_build_device(p, rd_[0].data_ptr(), rd_[1].data_ptr(), rd_[2].data_ptr(), rd_[3].data_ptr(), w_["pool"].n_pairs,
+                                        wait=os.environ.get("VDJX_BENCH_INDEX_SERIAL") == "1")
+            t = lap("read_index_begin", t)
         if engine is None:
             g = ctx.kmer_build(p, args.k, args.mf, args.mq, async_export=True)
         elif w_.get("scan") is not None:
@@ -698,7 +750,9 @@ def main():
         barrier()
         prof_ms_step = (time.perf_counter() - t_p) / n_prof * 1e3
         prof_full = ctx.profile_get()
-        cand = {n_: v_ for n_, v_ in prof_full.items() if n_ in BUILD_KERNELS}
+        # the roofline kernel: the LONGEST scope of the whole step (per step, all its launches), whatever it is -- k-mer build, scorer or one
+        # of the composite survivor scopes (round 6; rounds 1-5 looked among the k-mer build's streaming kernels only)
+        cand = {n_: v_ for n_, v_ in prof_full.items() if n_ in PRICED_KERNELS}
         dom_name = max(cand.items(), key=lambda kv: kv[1][0])[0] if cand else None
         ctx.profile_only(dom_name)
     ctx.profile(not no_events)
@@ -817,19 +871,30 @@ def main():
     # ---- the same step with the read index of its pool built inside it (row a-8's index, quick_map3.c:126-149: the reference
     # builds it during extraction, bam_read.c:228,243, once per pool -- like a command line that sees every pool once)
     with_index = None
-    if world == 1 and not args.force_shard:
+    if world == 1 and not args.force_shard and not args.no_index_leg:
         n_wi = max(2, min(args.steps, 10))
         wall_keep = dict(wall)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(n_wi):
-            build_index()
-            step()
-        ctx.map_emit_wait()
-        barrier()
-        dtw = time.perf_counter() - t1
+
+        def index_leg(overlap: bool):
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n_wi):
+                if overlap:       # begun on the index stream; the step's k-mer build runs beside it; the step's window scorer ends it
+                    ctx.read_index_build_device(p_index, ri_dev[0].data_ptr(), ri_dev[1].data_ptr(), ri_dev[2].data_ptr(), ri_dev[3].data_ptr(), pool.n_pairs, wait=False)
+                else:
+                    build_index()
+                step()
+            ctx.map_emit_wait()
+            barrier()
+            return time.perf_counter() - t1
+        dts = index_leg(False)
+        dtw = index_leg(True)
         with_index = {"value": round(args.pairs * n_wi / dtw / 1e6, 4), "unit": "M paired-reads/s", "ms_per_step": round(dtw / n_wi * 1e3, 3), "steps": n_wi,
-                      "note": "vdjx_read_index_build_device (per-record arrays resident in HBM like the pools) + the step of `value`, every step"}
+                      "serial": {"value": round(args.pairs * n_wi / dts / 1e6, 4), "ms_per_step": round(dts / n_wi * 1e3, 3)},
+                      "note": "the step of `value` with the read index of its pool built in it, every step (per-record arrays resident in HBM like the pools): "
+                              "vdjx_read_index_build_device_begin -- the index on a stream, a workspace and a thread of its own BESIDE the k-mer build (both only read "
+                              "the packed records; quick_map3.c:126-149 vs A2:1388), ended by the window scorer's first call.  `serial`: vdjx_read_index_build_device, "
+                              "waited for, then the step (rounds 1-5)"}
         wall.clear()
         wall.update(wall_keep)
     del ri_dev
@@ -873,7 +938,9 @@ def main():
     ms_step = dt / args.steps * 1e3
     total_pairs = args.pairs * world * len(W)          # (a --config4 step takes its chains' pools one after the other)
     value = total_pairs * args.steps / dt / 1e6
-    ab = algorithmic_bytes_per_pair(args.k, rl, stats.get("gated_instances", 0) / args.pairs if stats.get("gated_instances") else None)      # (the last build's count: one chain's pool)
+    ab = algorithmic_bytes_per_pair(args.k, rl, stats.get("gated_instances", 0) / args.pairs if stats.get("gated_instances") else None,      # (the last build's count: one chain's pool)
+                                    sym=bool(stats.get("kmer_build_sym")), sym_walk=bool(stats.get("kmer_build_sym_walk")))
+    svb = survivor_bytes(int(state.get("nodes", 0)) + int(stats.get("kmer_build_shadows", 0)), args.k)
     # `roofline`: the dominant kernel among the HBM-streaming ones, i.e. the longest kernel of the k-mer build.  The scorer kernels
     # are priced in `roofline_by_kernel` too, but k_window_pairs / k_window_cover work on cache-resident inputs (every read class is
     # looked at by many windows: PMC fabric traffic is a third of SURVEY 8d's per-instance bytes), so an HBM fraction says nothing
@@ -884,23 +951,30 @@ def main():
     def price(name, tot_ms, launches):
         avg_ms = tot_ms / max(1, launches)
         per_step = launches / prof_steps
-        per_pair = ab.get(name) if name in ab and name not in ("P", "input", "total", "gated_per_pair") else None
+        per_pair = ab.get(name) if name in ab and name not in ("P", "input", "total", "gated_per_pair", "model_all_records", "units_factor") else None
         if name in sb:
             bpl = sb[name] * len(W) / max(1.0, per_step)
+        elif name in svb:
+            bpl = svb[name] * len(W) / max(1.0, per_step)
         elif per_pair is not None:
             bpl = per_pair * args.pairs * len(W) / max(1.0, per_step)
         else:
             return None                      # a kernel without a stated job size is not priced (never the whole path's bytes)
         ach = bpl / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None
-        return {"avg_launch_ms": round(avg_ms, 4), "launches_per_step": round(per_step, 2), "algorithmic_bytes_per_launch": int(bpl),
-                "algorithmic_bytes_per_pair": per_pair, "achieved": round(ach, 2) if ach else None,
-                "frac": round(ach / HBM_PEAK_GBS, 5) if ach else None, "traffic": load_traffic(args, world, name)}
+        res = {"avg_launch_ms": round(avg_ms, 4), "launches_per_step": round(per_step, 2), "algorithmic_bytes_per_launch": int(bpl),
+               "algorithmic_bytes_per_pair": per_pair, "achieved": round(ach, 2) if ach else None,
+               "frac": round(ach / HBM_PEAK_GBS, 5) if ach else None, "traffic": load_traffic(args, world, name)}
+        allrec = ab["model_all_records"].get(name)
+        if allrec is not None and per_pair and allrec != per_pair and ach:       # (a couples' form: what the same time would be on the model's bytes for ALL records)
+            res["frac_model_all_records"] = round(ach * allrec / per_pair / HBM_PEAK_GBS, 5)
+        return res
 
     by_kernel = {}
     for name, (tot_ms, launches) in prof.items():
         pr = price(name, tot_ms, launches)
         if pr:
             pr["hbm_streaming"] = name in build_kernels
+            pr["ms_per_step"] = round(tot_ms / prof_steps, 4)
             by_kernel[name] = pr
     # the read index's kernels (one build per pool, outside `value`; inside `value_with_read_index`): bytes this design must move
     ri = host_side.get("read_index", {})
@@ -920,7 +994,7 @@ def main():
                                "frac": round(ri_bytes[name] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": load_traffic(args, world, name), "hbm_streaming": False}
     for v_ in by_kernel.values():       # what the counters say the kernel moved, against the same peak (null without a PMC pass of this workload)
         v_["frac_on_traffic"] = round(v_["traffic"] / (v_["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if v_.get("traffic") and v_["avg_launch_ms"] else None
-    dom = max(((n_, v_) for n_, v_ in prof.items() if n_ in build_kernels and n_ in by_kernel), key=lambda kv: kv[1][0], default=(None, (0.0, 0)))
+    dom = max(((n_, v_) for n_, v_ in prof.items() if n_ in PRICED_KERNELS and n_ in by_kernel), key=lambda kv: kv[1][0], default=(None, (0.0, 0)))
     if dom_name and dom_name in prof_timed and dom_name in by_kernel:
         # the roofline kernel's own figures come from INSIDE the timed region (it alone was bracketed there); the untimed pass's are kept beside them
         tt, tl = prof_timed[dom_name]
@@ -929,6 +1003,8 @@ def main():
         live.update(avg_launch_ms=round(tt / max(1, tl), 4), avg_launch_ms_untimed_pass=by_kernel[dom_name]["avg_launch_ms"],
                     achieved=round(by_kernel[dom_name]["achieved"] * scale, 2) if by_kernel[dom_name].get("achieved") else None,
                     frac=round(by_kernel[dom_name]["frac"] * scale, 5) if by_kernel[dom_name].get("frac") else None)
+        if live.get("frac_model_all_records"):
+            live["frac_model_all_records"] = round(live["frac_model_all_records"] * scale, 5)
         if live.get("traffic") and live["avg_launch_ms"]:
             live["frac_on_traffic"] = round(live["traffic"] / (live["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         by_kernel[dom_name] = live
@@ -938,21 +1014,29 @@ def main():
         pr = by_kernel[dom[0]]
         longest = max(prof.items(), key=lambda kv: kv[1][0] / max(1, kv[1][1]))
         lk = by_kernel.get(longest[0], {})
+        step_tr = step_traffic(args, world)
         roof = {"bound": "hbm", "kernel": dom[0], "achieved": pr["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pr["frac"],
-                "traffic": pr["traffic"], "traffic_source": traffic_source(), "avg_launch_ms": pr["avg_launch_ms"],
+                "traffic": pr["traffic"], "traffic_source": traffic_source(args, world), "avg_launch_ms": pr["avg_launch_ms"],
                 "algorithmic_bytes_per_launch": pr["algorithmic_bytes_per_launch"],
                 "algorithmic_bytes_per_pair": pr["algorithmic_bytes_per_pair"],
-                "rule": "longest kernel of the k-mer build (the HBM-streaming kernels); all priced kernels in roofline_by_kernel",
+                "rule": "the longest scope of the whole step among all priced kernels (k-mer build, survivor scopes, scorers); `achieved` = SURVEY 8d's "
+                        "per-unit bytes x the units THIS launch processes / its average duration measured inside the timed region; all priced kernels "
+                        "in roofline_by_kernel",
+                "units": ({"records_walked_per_pair": 4 * ab["units_factor"]["walk"], "instances_probed_per_pair": ab["P"] * ab["units_factor"]["walk"],
+                           "note": "a pool of couples (read, reverse complement): the walk takes the first record of every couple and derives the second (DESIGN 4.1)"}
+                          if dom[0] == "k_walk_items" else None),
                 "longest_kernel_overall": {"kernel": longest[0], "avg_launch_ms": round(longest[1][0] / max(1, longest[1][1]), 4),
                                            "frac": lk.get("frac"), "achieved": lk.get("achieved"), "traffic": lk.get("traffic"),
                                            "hbm_streaming": lk.get("hbm_streaming")},
                 "frac_on_traffic": pr.get("frac_on_traffic"),
-                "frac_note": "`frac` prices SURVEY 8d's algorithmic bytes (for the walk: the packed input of all four records of a pair and a 16-B probe per "
-                             "instance).  This design answers most probes from two chain words in cache, and since round 5 walks only the FIRST record of every "
-                             "couple (read, reverse complement) and derives the second (DESIGN 4.1): it does the modelled job on well under half the modelled "
-                             "bytes, so `frac` says how fast the model's bytes were dealt with, NOT how close the kernel runs to the HBM limit -- "
-                             "`frac_on_traffic` = fabric bytes the counters saw / time / peak does (calibrated: profiles/r05_ea_calib)",
-                "frac_half_records": round(pr["frac"] / 2, 5) if pr.get("frac") and stats.get("kmer_build_sym_walk") and dom[0] == "k_walk_items" else None,
+                "frac_model_all_records": pr.get("frac_model_all_records"),
+                "frac_note": "`frac` = model bytes of the units the launch processes / time / peak (round 6: for a pool of couples the walk's 575 B/pair, "
+                             "not the 1,150 of all four records -- `frac_model_all_records` keeps that figure, which charged the kernel for bytes it never "
+                             "touched).  `frac_on_traffic` = fabric bytes the counters saw / time / peak (calibrated: profiles/r05_ea_calib).  Neither says "
+                             "the walk is bandwidth-bound: it waits on dependent table / chain-word probes (L2 hit 0.80, 72 % of wave-cycles waiting)",
+                # the whole step against the peak: every byte the counters saw between the L2s and the memory side, all kernels of a step
+                "step_traffic_frac": (round(step_tr["bytes_per_step"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if step_tr else None),
+                "step_traffic": step_tr,
                 "hot_path_frac": round(ab["total"] * args.pairs * len(W) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 # SURVEY 8d's per-pair figure takes EVERY instance as gated (3,324 B at k=35); with the gated instances this run measured
                 "hot_path_frac_gated": round((2 * ab["input"] + 32 * ab["gated_per_pair"] + 16 * ab["P"]) * args.pairs * len(W) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
@@ -974,6 +1058,8 @@ def main():
         "dtype": "u8/u64 (2-bit packed bases, integer counts)", "data": "synthetic",
         "config": {"workload": workload_label(args.pairs, args.k, args.mf, args.mq, args.mrs, args.ins, world, chains), "chains": list(chains),
                    "pairs_per_gpu": args.pairs, "clones_per_gpu": args.clones, "noise": 0.3, "parallelism": f"hash-prefix x{world}",
+                   "k": args.k, "mf": args.mf, "mq": args.mq, "mrs": args.mrs, "ins": args.ins, "windows": args.windows,
+                   "variant": "config4" if args.config4 else ("shard" if args.force_shard else ("k25" if args.k == 25 else "")),
                    "multi_gpu_input": "one independent library (own germline, clones, reads) per GPU; ONE k-mer table / graph / traversal over all of them",
                    "scorer_inputs": scorer_src},
         "roofline": roof, "roofline_by_kernel": by_kernel, "cpu_baseline": cpu, "cpu_baseline_port_legs": cpu_port_legs,

@@ -201,6 +201,20 @@ int vdjx_read_index_build(vdjx_ctx* ctx, const vdjx_pool* pool, const uint32_t* 
 int vdjx_read_index_build_device(vdjx_ctx* ctx, const vdjx_pool* pool, const uint32_t* d_pair_id,
                                  const uint8_t* d_read_num, const uint8_t* d_is_rc, const uint32_t* d_reg_rank, uint32_t n_pairs);
 
+/* The same two calls begun and ended: the index is built on a stream and out of a workspace of its own, by a thread of the library,
+ * BESIDE whatever the caller does next with the context -- the k-mer build of the same pool above all: both only read the packed
+ * records, and the reference orders them only by accident of its call sequence (add_read_info runs inside extract, bam_read.c:228,243,
+ * before A2:1388; nothing reads the index before the first quick_map_process_contig, A2:841).  Everything queued on the context
+ * before _begin comes first (the packing of `pool`; scorer calls that still read the index being replaced).  _end returns the
+ * build's status; the first call that needs the index (vdjx_window_score, vdjx_window_pairs, vdjx_map_emit, vdjx_sam_text ...) ends a
+ * build that was not.  _begin (host arrays): the four arrays must stay valid until _end.  One build in flight per context; `pool`
+ * may not be freed before _end (vdjx_pool_free waits for it). */
+int vdjx_read_index_build_begin(vdjx_ctx* ctx, const vdjx_pool* pool, const uint32_t* pair_id,
+                                const uint8_t* read_num, const uint8_t* is_rc, const uint32_t* reg_rank, uint32_t n_pairs);
+int vdjx_read_index_build_device_begin(vdjx_ctx* ctx, const vdjx_pool* pool, const uint32_t* d_pair_id,
+                                       const uint8_t* d_read_num, const uint8_t* d_is_rc, const uint32_t* d_reg_rank, uint32_t n_pairs);
+int vdjx_read_index_build_end(vdjx_ctx* ctx);
+
 typedef struct {
 	int eval_start;    /* --e0 */
 	int eval_stop;     /* --e1 */

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_pmc_summary.json (rocprofv3 PMC passes of `bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --parity-sample 0`, reduced by
-summarize_pmc.py) + the bench line of the same run -> profiles/<round>_traffic.json (what bench.py reports as roofline.traffic,
-stamped with the commit the passes were taken at) and the per-kernel table of profiles/README.md on stdout.
+"""profiles/<tag>_pmc_summary.json (rocprofv3 PMC passes of `bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --no-index-leg --parity-sample 0 [flags]`,
+reduced by summarize_pmc.py) + the bench line of the same run -> profiles/<round>_traffic[_<variant>].json (what bench.py reports as
+roofline.traffic / step_traffic, stamped with the commit the passes were taken at) and the per-kernel table on stdout.
+The variant (none = the default configs[2] step; k25 = configs[3]; shard = --force-shard; config4 = --config4 --gpus 1) is read from the
+bench line's config.
 
-    python profiles/make_round.py r03a r03 $(git rev-parse --short HEAD)
+    python profiles/make_round.py r06a r06 $(git rev-parse --short HEAD) > profiles/r06_table.md
 """
 import json
 import os
@@ -16,42 +18,72 @@ import bench  # noqa: E402
 
 def main():
     tag, rnd, commit = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else None)
-    pm = json.load(open(os.path.join(HERE, f"{tag}_pmc_summary.json")))["kernels"]
+    summ = json.load(open(os.path.join(HERE, f"{tag}_pmc_summary.json")))
+    pm, step = summ["kernels"], summ.get("step")
     b = json.load(open(os.path.join(HERE, f"{tag}_bench.json")))
-    pairs, k = b["config"]["pairs_per_gpu"], 35
+    cfg = b["config"]
+    pairs, k, variant = cfg["pairs_per_gpu"], cfg.get("k", 35), cfg.get("variant", "")
+    chains = len(cfg.get("chains", ["IGH"]))
     alias = {"k_part_records": "k_part_records_g", "k_part_tuples": "k_part_tuples_g", "k_seg_hist": "k_seg_hist_g"}
     back = {v: k_ for k_, v in alias.items()}
     tr = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes (profiles/prof_step.sh), median per launch; "
                   "both counters are in KB; on gfx950 FETCH_SIZE is 64 B per read request and a coalesced 16-byte-per-lane stream is one request "
                   "per 128 B (profiles/r05_ea_calib): hbm_bytes = (FETCH + min(FETCH, stream_in/2) + WRITE)*1024 where the kernel's streamed "
-                  "input is stated (summarize_pmc.py STREAM_IN), else the bound (2*FETCH + WRITE)*1024; traffic_rule says which",
-          "commit": commit, "passes": tag, "pairs_per_gpu": pairs, "k": k, "windows": "generator", "kernels": {}}
+                  "input is stated (summarize_pmc.py STREAM_IN), else the bound (2*FETCH + WRITE)*1024; traffic_rule says which.  Composite scopes "
+                  "(several launches under one HIP-event name): hbm_bytes is PER STEP, summed over the member kernels (composite_of).  `step`: every "
+                  "dispatch of a timed step, all kernels",
+          "commit": commit, "passes": tag, "pairs_per_gpu": pairs, "k": k, "windows": cfg.get("windows", "generator"), "variant": variant, "kernels": {}}
     for name, v in pm.items():
         if "hbm_bytes" in v and name.startswith("k_"):
             tr["kernels"][back.get(name, name)] = {"hbm_bytes": v["hbm_bytes"], "fetch_kb": v.get("FETCH_SIZE"), "write_kb": v.get("WRITE_SIZE"),
                                                    "traffic_rule": v.get("traffic_rule")}
-    json.dump(tr, open(os.path.join(HERE, f"{rnd}_traffic.json"), "w"), indent=1, sort_keys=True)
+        elif "hbm_bytes_per_step" in v:
+            tr["kernels"][name] = {"hbm_bytes": v["hbm_bytes_per_step"], "composite_of": v.get("composite_of"), "launches_per_step": v.get("launches_per_step"),
+                                   "traffic_rule": "sum over the member kernels, per step"}
+    if step:
+        tr["step"] = {k_: v_ for k_, v_ in step.items() if k_ != "per_kernel"}
+    json.dump(tr, open(os.path.join(HERE, f"{rnd}_traffic{'_' + variant if variant else ''}.json"), "w"), indent=1, sort_keys=True)
     st = dict(b["scorer_stats"])
     gi = st.get("gated_instances")
-    ab = bench.algorithmic_bytes_per_pair(k, 50, gi / pairs if gi else None)
+    ab = bench.algorithmic_bytes_per_pair(k, 50, gi / pairs if gi else None, sym=bool(st.get("kmer_build_sym")), sym_walk=bool(st.get("kmer_build_sym_walk")))
     sb = bench.scorer_bytes(st, b["counts"]["windows"], b["counts"]["n_contigs_rank"], k)
-    launches = {"k_pool_pack": 2, "k_map_classify": 5, "k_plan": 2}      # (classify: the windows in four pieces + the contigs, until the strings were read in place)
-    for k_, v_ in b.get("roofline_by_kernel", {}).items():               # what the run itself counted
-        if isinstance(v_.get("launches_per_step"), (int, float)) and k_ == "k_map_classify":      # (the pack's two launches are one timed scope there)
-            launches[k_] = v_["launches_per_step"]
-    print("| kernel | ms/step (HIP events) | rocprofv3 avg ms/launch | alg. bytes/step | achieved GB/s | frac of 8 TB/s | fabric traffic/step (PMC) | traffic / alg. | L2 hit | wave-cycles waiting | LDS conflict | VALU issue share |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    svb = bench.survivor_bytes(int(b["counts"].get("nodes", 0)) + int(st.get("kmer_build_shadows", 0)), k)
+    skip = ("P", "input", "total", "gated_per_pair", "model_all_records", "units_factor")
+    rbk = b.get("roofline_by_kernel", {})
+    print(f"<!-- {tag}: {cfg['workload']} -- commit {commit} -->")
+    print("| kernel | ms/step (HIP events) | rocprofv3 avg ms/launch x launches/step | model bytes/step (units launched) | achieved GB/s | frac of 8 TB/s | fabric traffic/step (PMC) | frac on traffic | traffic / model | L2 hit | wave-cycles waiting | LDS conflict | VALU issue share |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for name, ms in sorted(b["kernels_ms_per_step"].items(), key=lambda kv: -kv[1]):
         v = pm.get(alias.get(name, name), {})
-        algb = ab[name] * pairs if name in ab and name not in ("P", "input", "total", "gated_per_pair") else sb.get(name)
-        t = v.get("hbm_bytes")
-        t = t * launches.get(name, 1) if t else t
+        lps = rbk.get(name, {}).get("launches_per_step")
+        lps = lps if isinstance(lps, (int, float)) else 1
+        if "hbm_bytes_per_step" in v:            # a composite scope
+            t = v["hbm_bytes_per_step"] * 1.0
+            rp = f"{v.get('ns_per_step', 0) / 1e6:.3f} ({v.get('launches_per_step', 0):.0f} launches of {len(v.get('composite_of', []))} kernels)"
+        else:
+            t = v.get("hbm_bytes")
+            t = t * lps if t else t
+            rp = f"{v.get('avg_ns', 0) / 1e6:.3f} x {lps:g}"
+        if name in sb:
+            algb = sb[name] * chains
+        elif name in svb:
+            algb = svb[name] * chains
+        elif name in ab and name not in skip:
+            algb = ab[name] * pairs * chains
+        else:
+            algb = None
+        cols = f"{v.get('l2_hit')} | {v.get('SQ_WAIT_ANY_frac')} | {v.get('lds_conflict_frac')} | {v.get('valu_issue_frac_at_2.4GHz')}"
         if algb and t:
             ach = algb / (ms * 1e-3) / 1e9
-            print(f"| {name} | {ms:.3f} | {v.get('avg_ns', 0) / 1e6:.3f} | {algb / 1e6:.0f} MB | {ach:.0f} | {ach / 8000:.3f} | {t / 1e6:.0f} MB | {t / algb:.2f} | "
-                  f"{v.get('l2_hit')} | {v.get('SQ_WAIT_ANY_frac')} | {v.get('lds_conflict_frac')} | {v.get('valu_issue_frac_at_2.4GHz')} |")
+            print(f"| {name} | {ms:.3f} | {rp} | {algb / 1e6:.0f} MB | {ach:.0f} | {ach / 8000:.3f} | {t / 1e6:.0f} MB | {t / (ms * 1e-3) / 1e9 / 8000:.3f} | {t / algb:.2f} | {cols} |")
         else:
-            print(f"| {name} | {ms:.3f} | {v.get('avg_ns', 0) / 1e6:.3f} | - | - | - | {(t or 0) / 1e6:.0f} MB | - | {v.get('l2_hit')} | {v.get('SQ_WAIT_ANY_frac')} | {v.get('lds_conflict_frac')} | {v.get('valu_issue_frac_at_2.4GHz')} |")
+            tt = f"{t / 1e6:.0f} MB | {t / (ms * 1e-3) / 1e9 / 8000:.3f}" if t else "- | -"
+            print(f"| {name} | {ms:.3f} | {rp} | - | - | - | {tt} | - | {cols} |")
+    if step:
+        ms_step = b["ms_per_step"]
+        print(f"\nstep as a whole: {step['bytes_per_step'] / 1e9:.2f} GB of counted fabric traffic per step ({step['kernels_counted']} kernels; bound {step['bytes_per_step_max'] / 1e9:.2f} GB) "
+              f"in {ms_step:.3f} ms = {step['bytes_per_step'] / (ms_step * 1e-3) / 1e12:.2f} TB/s = {step['bytes_per_step'] / (ms_step * 1e-3) / 1e9 / 8000:.3f} of the 8 TB/s peak "
+              f"(device busy {b.get('device_busy_frac')})")
 
 
 if __name__ == "__main__":

@@ -6,7 +6,8 @@ TAG=$1; shift
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --parity-sample 0 $*"
+ARGS="bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --no-index-leg --parity-sample 0 $*"
+export PROF_STEPS=2
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/bench.json 2> $OUT/stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > /dev/null 2> $OUT/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > /dev/null 2> $OUT/write.err

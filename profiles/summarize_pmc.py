@@ -54,8 +54,34 @@ def stream_in(bench_line):
             "k_part_items": 8 * items, "k_recount": 8 * items, "k_compact_partials": 0, "k_bucket_merge": 0}
 
 
+# the composite scopes of bench.py's kernels_ms_per_step (vdjx_prof_scope names that bracket several launches) and their member kernels,
+# as rocprofv3 names them: priced per STEP (sum over the members of median bytes x calls per step)
+COMPOSITES = {
+    "k_surv_table": ("k_surv_table2", "k_succ_links2"),
+    "k_chain_order": ("k_chain_init", "k_chain_jump", "k_chain_len", "k_scan_sums", "k_scan_apply", "k_chain_place", "k_chain_permute", "k_table_remap",
+                      "k_partner", "k_chain_words", "k_partner_check"),
+    "k_node_order": ("k_rank_keys", "k_rank_scatter", "k_node_emit2"),      # (+ rocPRIM's radix sort kernels: counted in the step total, not named here)
+    "k_shard_resolve": ("k_resolve_first", "k_resolve_add", "k_resolve_keep"),
+}
+
+
+def step_span(rows, steps):
+    """rows of one counter pass in dispatch order -> those of the last `steps` steps of the process (prof_step.sh runs bench.py so that the
+    timed steps are the last thing it launches): from the first k_pool_pack launch of the steps-th step from the end on.  A step has two
+    pack launches (primary, secondary pool) unless the secondary is empty; the count per step is taken from the run itself."""
+    packs = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith("k_pool_pack") or short(r["Kernel_Name"]).startswith("k_pool_unpack")]
+    walks = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == "k_walk_items"]
+    if not packs or len(walks) < steps:
+        return []
+    chains = int(os.environ.get("PROF_CHAINS", "1"))          # (--config4: a step is three chains, each with its own packing and walk)
+    per = max(1, round(len(packs) / max(1, len(walks)))) * chains
+    first = packs[-per * steps] if len(packs) >= per * steps else packs[0]
+    return rows[first:]
+
+
 def main():
     out = sys.argv[1]
+    steps_timed = int(os.environ.get("PROF_STEPS", "2"))
     bench_line = None
     try:
         bench_line = json.loads(open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1])
@@ -63,11 +89,26 @@ def main():
         pass
     STREAM_IN = stream_in(bench_line)
     res = collections.defaultdict(dict)
+    step_tot = {}
     for grp in ("fetch", "write", "sq", "tcc", "inst", "ea"):
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         for f in glob.glob(os.path.join(out, grp, "**", "*counter_collection.csv"), recursive=True):
-            for r in csv.DictReader(open(f)):
+            rows = list(csv.DictReader(open(f)))
+            for r in rows:
                 per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if grp in ("fetch", "write") and rows:
+                # the whole step: every dispatch between the first launch of a timed step and the end of the process, all kernels (the
+                # library's, rocPRIM's, the runtime's fills), per step and per kernel name
+                key = "Dispatch_Id" if "Dispatch_Id" in rows[0] else None
+                if key:
+                    rows.sort(key=lambda r: int(r[key]))
+                span = step_span(rows, steps_timed)
+                agg = collections.defaultdict(lambda: [0.0, 0])
+                for r in span:
+                    a = agg[short(r["Kernel_Name"])]
+                    a[0] += float(r["Counter_Value"]) * 1024
+                    a[1] += 1
+                step_tot[grp] = {k_: (v_[0] / steps_timed, v_[1] / steps_timed) for k_, v_ in agg.items()}
         for k, cs in per.items():
             for c, v in cs.items():
                 res[k][c] = med(v)
@@ -98,7 +139,37 @@ def main():
             # a wave's vector instruction occupies its SIMD for 4 cycles (64 lanes over 16): the share of the launch during which the
             # 1024 SIMDs of the chip would be issuing them at 2.4 GHz -- the ALU-side roofline of integer kernels like these
             d["valu_issue_frac_at_2.4GHz"] = round(d["SQ_INSTS_VALU"] * 4 / (1024 * 2.4 * d["avg_ns"]), 3)
-    json.dump({"kernels": res}, sys.stdout, indent=1, sort_keys=True)
+    # ---- the step as a whole, and the composite scopes per step
+    step = None
+    if "fetch" in step_tot:
+        fk, wk = step_tot["fetch"], step_tot.get("write", {})
+        tot_f = tot_w = tot_cal = 0.0
+        per_kernel = {}
+        for k_ in set(fk) | set(wk):
+            f_, n_ = fk.get(k_, (0.0, 0))
+            w_ = wk.get(k_, (0.0, 0))[0]
+            stream = STREAM_IN.get(k_)
+            cal = f_ + (min(f_, stream * n_ / 2) if stream is not None else f_) + w_       # (the x2 on the stated coalesced share; no stated stream: the bound)
+            per_kernel[k_] = {"fetch_bytes_per_step": int(f_), "write_bytes_per_step": int(w_), "launches_per_step": n_, "fabric_bytes_per_step": int(cal)}
+            tot_f += f_; tot_w += w_; tot_cal += cal
+        step = {"bytes_per_step": int(tot_cal), "bytes_per_step_max": int(2 * tot_f + tot_w), "fetch_counted": int(tot_f), "write_counted": int(tot_w),
+                "kernels_counted": len(per_kernel), "steps": steps_timed,
+                "rule": "every dispatch of the last `steps` steps of the process (all kernels: the library's, rocPRIM's, fills), FETCH_SIZE / WRITE_SIZE passes; "
+                        "per kernel FETCH + min(FETCH, stated coalesced input / 2) + WRITE, kernels without a stated stream at the bound 2*FETCH + WRITE",
+                "per_kernel": per_kernel}
+        for comp, members in COMPOSITES.items():
+            got = [per_kernel[m] for m in members if m in per_kernel]
+            if got:
+                res[comp]["composite_of"] = [m for m in members if m in per_kernel]
+                res[comp]["hbm_bytes_per_step"] = int(sum(g["fabric_bytes_per_step"] for g in got))
+                res[comp]["launches_per_step"] = sum(g["launches_per_step"] for g in got)
+                ns_ = sum(res[m].get("avg_ns", 0.0) * per_kernel[m]["launches_per_step"] for m in members if m in per_kernel and m in res)
+                res[comp]["ns_per_step"] = ns_
+                for c in ("l2_hit", "SQ_WAIT_ANY_frac", "lds_conflict_frac"):      # the members' figures weighted by their time
+                    ws = [(res[m].get(c), res[m].get("avg_ns", 0.0) * per_kernel[m]["launches_per_step"]) for m in members if m in res and m in per_kernel and res[m].get(c) is not None]
+                    if ws and sum(w for _, w in ws) > 0:
+                        res[comp][c] = round(sum(v * w for v, w in ws) / sum(w for _, w in ws), 4)
+    json.dump({"kernels": res, "step": step}, sys.stdout, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

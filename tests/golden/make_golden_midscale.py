@@ -42,6 +42,10 @@ CASES = {
                      flags=["--k", "35", "--mf", "3", "--mq", "90", "--mrs", "30"]),
     "mid_k25": dict(pairs=200_000, clones=400, seed=20261002, noise=0.3, chain="IGH", ins=175,
                     flags=["--k", "25", "--mf", "2", "--mq", "60", "--mcs", "-5.5", "--mrs", "20"]),
+    # BASELINE.json configs[3] AS WRITTEN (README's sensitive mode, no --mrs: the default 30 stands): at k = 25 the root DP is bounded by
+    # 25 < 30, so no root can pass (seq_score.c:92-116, params.c:66, A2:1103): empty FASTA, header-less SAM, every verdict 0
+    "mid_k25_mrs30": dict(pairs=200_000, clones=400, seed=20261002, noise=0.3, chain="IGH", ins=175,
+                          flags=["--k", "25", "--mf", "2", "--mq", "60", "--mcs", "-5.5"]),
 }
 
 

@@ -24,8 +24,21 @@ def _write_inputs(c, d):
     open(os.path.join(d, "ref", "ig_vdj.fa"), "w").write(">x\nACGT\n")
 
 
+def _child_env(knobs: str, **extra):
+    """the environment of a `vdjer` child process.  "suite": what tests/conftest.py sets for the whole suite (the scorers' slicing at 128
+    hits, windows grouped from the first one -- so that tiny pools run the code big pools run).  "shipped": both knobs REMOVED -- the
+    thresholds a user's run has (few windows are mapped one by one, vdjx_score.hip; slices from 512 K hits): VERDICT r5 weak #2, the
+    goldens must hold for the product as it ships, not only under the suite's knobs"""
+    env = dict(os.environ, **extra)
+    if knobs == "shipped":
+        env.pop("VDJX_HIT_CHUNK", None)
+        env.pop("VDJX_GROUP_MIN", None)
+    return env
+
+
+@pytest.mark.parametrize("knobs", ["suite", "shipped"])
 @pytest.mark.parametrize("tag", ["e2e_tiled", "e2e_mixed", "e2e_k25", "e2e_igk", "e2e_igl", "e2e_rl100", "e2e_rl151"])
-def test_vdjer_cli_matches_reference(tag, tmp_path):
+def test_vdjer_cli_matches_reference(tag, knobs, tmp_path):
     """e2e_igk / e2e_igl: --chain IGK / IGL (set_chain_info, params.c:20-31: J residue F, CDR3 window 0-60); e2e_rl100 / e2e_rl151: 2x100 and
     2x151 bp libraries (the long-read record format), goldens from the compiled reference (tests/golden/make_golden_longreads.py)"""
     exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
@@ -35,7 +48,7 @@ def test_vdjer_cli_matches_reference(tag, tmp_path):
     info = m["e2e"][tag] if tag in m["e2e"] else m["e2e_chains"][tag]
     _write_inputs(c, str(tmp_path))
     cmd = [exe, "--in", "reads.txt", "--chain", info.get("chain", "IGH"), "--ref-dir", "ref", "--ins", str(info.get("ins", 175)), "--t", "1"] + info["flags"]
-    r = subprocess.run(cmd, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=_child_env(knobs))
     assert r.returncode == 0, r.stderr[-3000:]
     # the ELAPSED_SECS stage log carries the reference's marker names in the reference's order (status.c:22-32, A2:1387-1473)
     import json
@@ -105,8 +118,9 @@ def test_vdjer_cli_gpus_n_ranks_share_one_device(tag, gpus, sam_pairs, tmp_path)
     assert max(v["records"] for v in sh.values()) <= 1.35 * R / gpus + 64         # a rank's host pool is its share: about 1/N
 
 
-@pytest.mark.parametrize("name,gpus", [("mid_400k", 1), ("mid_400k", 3), ("mid_k25", 1), ("mid_k25", 2), ("mid_cfg1", 1), ("mid_cfg1", 4)])
-def test_vdjer_cli_midscale_vs_reference_digests(name, gpus, tmp_path):
+@pytest.mark.parametrize("name,gpus,knobs", [("mid_400k", 1, "suite"), ("mid_400k", 1, "shipped"), ("mid_400k", 3, "suite"), ("mid_k25", 1, "suite"), ("mid_k25", 1, "shipped"),
+                                             ("mid_k25", 2, "shipped"), ("mid_cfg1", 1, "shipped"), ("mid_cfg1", 4, "suite"), ("mid_k25_mrs30", 1, "shipped"), ("mid_k25_mrs30", 2, "suite")])
+def test_vdjer_cli_midscale_vs_reference_digests(name, gpus, knobs, tmp_path):
     """End to end at MID scale (tests/golden/midscale.json: complete --t 1 runs of the compiled reference on 200 k - 1 M pairs, hundreds
     to thousands of clones: thousands of roots, hundreds of candidate windows, tens of contigs, 10^5-10^6 SAM lines; mid_cfg1 is
     BASELINE.json configs[1] whole): `vdjer` and `vdjer --gpus N` (N process-ranks on the box's one device, the pool dealt by pair,
@@ -120,7 +134,7 @@ def test_vdjer_cli_midscale_vs_reference_digests(name, gpus, tmp_path):
     exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
     M.gen.write_inputs(case, str(tmp_path))
     cmd = [exe] + M.gen.argv_of(case, threads=4) + (["--gpus", str(gpus)] if gpus > 1 else [])
-    env = dict(os.environ, VDJH_ROOT_LOG="roots.log", VDJX_MGPU_ONE_DEVICE="1", VDJX_MGPU_TIMEOUT_S="300")
+    env = _child_env(knobs, VDJH_ROOT_LOG="roots.log", VDJX_MGPU_ONE_DEVICE="1", VDJX_MGPU_TIMEOUT_S="300")
     with open(tmp_path / "out.sam", "wb") as so:
         r = subprocess.run(cmd, cwd=tmp_path, stdout=so, stderr=subprocess.PIPE, text=True, timeout=1800, env=env)
     assert r.returncode == 0, r.stderr[-3000:]

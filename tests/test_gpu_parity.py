@@ -689,6 +689,70 @@ def test_read_index_over_couples_equals_the_general_build(ctx, monkeypatch, rl):
     p.free()
 
 
+@pytest.mark.parametrize("rl", [50, 100])
+def test_read_index_begun_beside_the_kmer_build(rl):
+    """vdjx_read_index_build[_device]_begin / _end (round 6): the index on a stream, a workspace and a thread of its own beside the k-mer
+    build of the same pool (quick_map3.c:126-149 against A2:1388: nothing orders the two before the first quick_map_process_contig).
+    Same graph as without it (vs the oracle), same window verdicts / pair counts / mapped pairs / SAM text as the waiting build;
+    ended by _end, or by the first scorer call; several rounds in one context (the index arrays are recycled); a bad pair id
+    comes back from _end as the waiting call's error, and the scorers then refuse."""
+    import torch
+    from vdjer_amd import api, synth
+    from vdjer_amd._lib import VdjxError
+    c = api.Context(0)
+    rep = synth.make_repertoire(6, seed=411)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    c.anchor_sets_load(vc, jc)
+    wins = [w for w in rep.windows() if w]
+    contigs = [w[51:411] for w in wins]
+    for it, n_pairs in enumerate((5000, 9000, 5000)):
+        pool = synth.make_reads(rep, n_pairs, noise_frac=0.25, seed=412 + it, rl=rl, err=0.004, n_rate=0.003)
+        names = [f"r{i}" for i in range(pool.n_pairs)]
+        p = c.pool_load(pool.primary, pool.secondary, rl)
+        # the waiting build: what every result is compared with
+        c.read_index_build(p, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+        c.sam_names_load(names)
+        want = (c.window_score(wins, 175), c.map_emit(contigs), c.sam_text_device(contigs, [f"c{i}" for i in range(len(contigs))]))
+        want = ([x.copy() for x in want[0]], [x.copy() for x in want[1]], want[2])
+        g0 = c.kmer_build(p, 35, 3, 90)
+        for mode in ("host_end", "device_first_scorer_call"):
+            if mode == "host_end":
+                c.read_index_build_begin(p, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+            else:
+                dv = [torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0") for a in (pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank)]
+                torch.cuda.synchronize()
+                c.read_index_build_device(p, dv[0].data_ptr(), dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(), pool.n_pairs, wait=False)
+            g = c.kmer_build(p, 35, 3, 90)                       # <- runs beside the index
+            if mode == "host_end":
+                c.read_index_wait()
+            assert g.n == g0.n and g.n > 0
+            for f in ("first_inst", "freq", "to_ids", "from_ids", "has_v", "has_j"):
+                np.testing.assert_array_equal(getattr(g, f), getattr(g0, f), err_msg=f)
+            c.sam_names_load(names)
+            valid, npairs = c.window_score(wins, 175)             # (device mode: this call ends the build)
+            np.testing.assert_array_equal(valid, want[0][0])
+            np.testing.assert_array_equal(npairs, want[0][1])
+            offs, pairs = c.map_emit(contigs)
+            np.testing.assert_array_equal(offs, want[1][0])
+            for f in pairs.dtype.names:
+                if f != "cls":
+                    np.testing.assert_array_equal(pairs[f], want[1][1][f], err_msg=f)
+            assert c.sam_text_device(contigs, [f"c{i}" for i in range(len(contigs))]) == want[2]
+            assert c.stat("read_index_classes") > 0
+        if it == 2:
+            bad = pool.pair_id.copy()
+            bad[7] = pool.n_pairs + 5
+            c.read_index_build_begin(p, bad, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+            c.kmer_build(p, 35, 3, 90, export=False)
+            with pytest.raises(VdjxError, match="pair id"):
+                c.read_index_wait()
+            with pytest.raises(VdjxError, match="read_index_build first"):
+                c.window_score(wins, 175)
+        p.free()
+    c.close()
+
+
 def test_read_index_table_survives_many_builds_and_changes_of_kind(monkeypatch):
     """The lookup table of the couples' index is not cleared per build: a slot counts as taken only if its claim word carries the build's
     number (7 bits), and the table is cleared when the numbers are used up (every 127 builds), when the buffer is new, and when the
@@ -754,6 +818,44 @@ def test_root_scorer_begun_and_ended_equals_the_waiting_call():
         assert ids0.shape[0] > 10 and np.array_equal(ids0, ids1) and np.array_equal(ok0, ok1) and 0 < int(ok0.sum()) < ok0.shape[0]
         g.free()
         p.free()
+    c.close()
+
+
+def test_kmer_build_between_root_begin_and_end_with_a_short_guess():
+    """the header allows any call between vdjx_root_score_graph_begin and _end.  A k-mer build reads 8,208
+    bytes of status into the context's page-locked scratch; the begun call's item count used to wait at byte 8,192 of it, was
+    overwritten with 0, and _end then took a short guess for complete.  Second graph much larger than the first (the guess falls
+    short), a build of a third pool in between: ids and verdicts must equal the waiting call's."""
+    from vdjer_amd import api, synth
+    c = api.Context(0, pinned_results=True)
+    rep = synth.make_repertoire(8, seed=131)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    c.anchor_sets_load(vc, jc)
+    c.vregion_load([rep.v_region], 15)
+    other = synth.make_reads(rep, 5000, noise_frac=0.3, seed=77)
+    po = c.pool_load(other.primary, other.secondary, other.rl)
+    for n_pairs in (2000, 40000):
+        pool = synth.make_reads(rep, n_pairs, noise_frac=0.3, seed=132 + n_pairs)
+        p = c.pool_load(pool.primary, pool.secondary, pool.rl)
+        g = c.kmer_build(p, 35, 3, 90, keep_device=True)
+        ids0, ok0 = (np.array(x) for x in c.root_score_graph(g, 30))
+        if n_pairs == 40000:
+            c.root_score_graph(g, 30)          # (hint := this graph's item count) ... then a SMALL graph's call shrinks it again below
+        pool_s = synth.make_reads(rep, 1500, noise_frac=0.3, seed=5)
+        ps = c.pool_load(pool_s.primary, pool_s.secondary, pool_s.rl)
+        gs = c.kmer_build(ps, 35, 3, 90, keep_device=True)
+        c.root_score_graph(gs, 30)             # the guess for the next call is now this small graph's count
+        gs.free()
+        ps.free()
+        ids1, ok1 = c.root_score_graph(g, 30, wait=False)
+        n_mid, _ = c.kmer_build(po, 35, 3, 90, export=False)          # <- the call in between
+        c.root_score_wait()
+        assert n_mid > 0 and ids0.shape[0] > 5
+        assert np.array_equal(ids0, ids1) and np.array_equal(ok0, ok1), n_pairs
+        g.free()
+        p.free()
+    po.free()
     c.close()
 
 

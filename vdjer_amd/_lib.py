@@ -18,7 +18,7 @@ SYMBOLS = [
     "vdjx_anchor_sets_load", "vdjx_anchor_probe", "vdjx_index_generate", "vdjx_anchor_sets_from_anchors",
     "vdjx_kmer_build", "vdjx_graph_nodes", "vdjx_graph_pre_nodes", "vdjx_graph_export", "vdjx_graph_export_begin", "vdjx_graph_export_end", "vdjx_graph_block_layout", "vdjx_graph_export_block", "vdjx_graph_export_block_begin", "vdjx_graph_free",
     "vdjx_vregion_load", "vdjx_root_score", "vdjx_graph_roots", "vdjx_root_part", "vdjx_root_score_graph", "vdjx_root_score_graph_begin", "vdjx_root_score_graph_end",
-    "vdjx_read_index_build", "vdjx_read_index_build_device", "vdjx_window_score", "vdjx_window_pairs", "vdjx_window_pairs_fetch", "vdjx_window_cover", "vdjx_map_emit", "vdjx_map_emit_begin", "vdjx_map_emit_end", "vdjx_sam_names_load", "vdjx_sam_text", "vdjx_sam_blocks", "vdjx_sam_merge", "vdjx_rows_scatter",
+    "vdjx_read_index_build", "vdjx_read_index_build_device", "vdjx_read_index_build_begin", "vdjx_read_index_build_device_begin", "vdjx_read_index_build_end", "vdjx_window_score", "vdjx_window_pairs", "vdjx_window_pairs_fetch", "vdjx_window_cover", "vdjx_map_emit", "vdjx_map_emit_begin", "vdjx_map_emit_end", "vdjx_sam_names_load", "vdjx_sam_text", "vdjx_sam_blocks", "vdjx_sam_merge", "vdjx_rows_scatter",
     "vdjx_host_alloc", "vdjx_host_free", "vdjx_host_take_rows",
     "vdjx_stat", "vdjx_profile_enable", "vdjx_profile_only", "vdjx_profile_reset", "vdjx_profile_count", "vdjx_profile_get",
     "vdjx_shard_begin", "vdjx_shard_begin_share", "vdjx_shard_free", "vdjx_shard_record_bytes", "vdjx_shard_count", "vdjx_shard_geometry", "vdjx_shard_symmetric", "vdjx_shard_geometry2", "vdjx_shard_local", "vdjx_shard_local_fill",
@@ -102,6 +102,9 @@ def lib():
     L.vdjx_root_score.argtypes = [vp, C.c_char_p, sz, i32, i32, vp]
     L.vdjx_read_index_build.argtypes = [vp, vp, vp, vp, vp, vp, u32]
     L.vdjx_read_index_build_device.argtypes = [vp, vp, vp, vp, vp, vp, u32]
+    L.vdjx_read_index_build_begin.argtypes = [vp, vp, vp, vp, vp, vp, u32]
+    L.vdjx_read_index_build_device_begin.argtypes = [vp, vp, vp, vp, vp, vp, u32]
+    L.vdjx_read_index_build_end.argtypes = [vp]
     L.vdjx_window_score.argtypes = [vp, C.c_char_p, sz, i32, C.POINTER(CovParams), vp, vp]
     L.vdjx_map_emit.argtypes = [vp, C.c_char_p, sz, i32, vp, vp]
     L.vdjx_window_pairs.argtypes = [vp, C.c_char_p, sz, i32, vp, vp]

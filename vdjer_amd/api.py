@@ -402,10 +402,29 @@ class Context:
         assert a.shape[0] == pool.n_records
         check(self.L.vdjx_read_index_build(self.h, pool.h, _p(a), _p(b), _p(c_), _p(d), n_pairs), "vdjx_read_index_build")
 
-    def read_index_build_device(self, pool: Pool, d_pair_id: int, d_read_num: int, d_is_rc: int, d_reg_rank: int, n_pairs: int) -> None:
-        """the per-record arrays as raw device pointers (uint32, uint8, uint8, uint32; one entry per pool record)"""
+    def read_index_build_device(self, pool: Pool, d_pair_id: int, d_read_num: int, d_is_rc: int, d_reg_rank: int, n_pairs: int, wait: bool = True) -> None:
+        """the per-record arrays as raw device pointers (uint32, uint8, uint8, uint32; one entry per pool record).
+        wait=False: begun on the index stream, beside the calls that follow (the k-mer build of the same pool); read_index_wait() --
+        or the first scorer call -- ends it (vdjx_read_index_build_device_begin / _end)"""
+        if not wait:
+            check(self.L.vdjx_read_index_build_device_begin(self.h, pool.h, C.c_void_p(d_pair_id), C.c_void_p(d_read_num), C.c_void_p(d_is_rc),
+                                                            C.c_void_p(d_reg_rank), n_pairs), "vdjx_read_index_build_device_begin")
+            return
         check(self.L.vdjx_read_index_build_device(self.h, pool.h, C.c_void_p(d_pair_id), C.c_void_p(d_read_num), C.c_void_p(d_is_rc),
                                                   C.c_void_p(d_reg_rank), n_pairs), "vdjx_read_index_build_device")
+
+    def read_index_build_begin(self, pool: Pool, pair_id, read_num, is_rc, reg_rank, n_pairs: int) -> None:
+        """host arrays, begun (vdjx_read_index_build_begin): they are kept alive here until read_index_wait()"""
+        a, b, c_, d = _c(pair_id, np.uint32), _c(read_num, np.uint8), _c(is_rc, np.uint8), _c(reg_rank, np.uint32)
+        assert a.shape[0] == pool.n_records
+        self._ri_keep = (a, b, c_, d, pool)
+        check(self.L.vdjx_read_index_build_begin(self.h, pool.h, _p(a), _p(b), _p(c_), _p(d), n_pairs), "vdjx_read_index_build_begin")
+
+    def read_index_wait(self) -> None:
+        try:
+            check(self.L.vdjx_read_index_build_end(self.h), "vdjx_read_index_build_end")
+        finally:
+            self._ri_keep = None
 
     @staticmethod
     def pack_strings(strings):

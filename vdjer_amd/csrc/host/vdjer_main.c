@@ -651,19 +651,23 @@ int main(int argc, char** argv) {
 	pthread_t init_th;
 	const int init_threaded = getenv("VDJX_INIT_SERIAL") == NULL && pthread_create(&init_th, NULL, init_thread, &ij) == 0;
 	reads_t rd;
-	if (load_reads(&c, &rd, rank, c.gpus, use_mgpu)) return 255;
+	/* an input error between here and the join below must not run exit() and its handlers while the HIP runtime is still coming up on the
+	 * other thread: wait for that thread, then leave with the documented code */
+#define BAIL(code) do { if (init_threaded) pthread_join(init_th, NULL); return (code); } while (0)
+	if (load_reads(&c, &rd, rank, c.gpus, use_mgpu)) BAIL(255);
 	c.hp.read_length = rd.rl;
 	c.hp.threads = c.threads;
 	if (rank == 0) fprintf(stderr, "read length:\t%d\n", rd.rl);
 
 	uint32_t *vc = NULL, *jc = NULL;
 	size_t nv = 0, nj = 0;
-	if (load_codes(c.v_anchors, c.anchor_mismatches, &vc, &nv) || load_codes(c.j_anchors, c.anchor_mismatches, &jc, &nj)) return 255;
+	if (load_codes(c.v_anchors, c.anchor_mismatches, &vc, &nv) || load_codes(c.j_anchors, c.anchor_mismatches, &jc, &nj)) BAIL(255);
 	qsort(vc, nv, 4, cmp_u32);
 	qsort(jc, nj, 4, cmp_u32);
 	char** vlines = NULL;
 	size_t nvl = 0;
-	if (load_vregion(c.source_sim_file, &vlines, &nvl)) return 255;
+	if (load_vregion(c.source_sim_file, &vlines, &nvl)) BAIL(255);
+#undef BAIL
 
 	vdjx_ctx* gx = NULL;
 	if (getenv("VDJX_TIMES")) status("(inputs read)");
@@ -706,8 +710,12 @@ int main(int argc, char** argv) {
 	if (!use_mgpu) {
 		VX(vdjx_pool_load(gx, rd.primary, rd.n_primary, rd.secondary, rd.n_secondary, rd.rl, &px));
 		if (getenv("VDJX_TIMES")) status("(pool loaded)");
-		VX(vdjx_read_index_build(gx, px, rd.pair_id, rd.read_num, rd.is_rc, rd.reg_rank, rd.n_pairs));
-		if (getenv("VDJX_TIMES")) status("(read index built)");
+		/* the read index (add_read_info, quick_map3.c:126-149) is begun on the library's index stream and built BESIDE the k-mer build below:
+		 * both only read the packed pool, and nothing needs the index before the traversal's first window (A2:841).  It is ended after
+		 * the build (VDJX_INDEX_SERIAL=1: built here, waited for, as until round 5) */
+		if (getenv("VDJX_INDEX_SERIAL")) VX(vdjx_read_index_build(gx, px, rd.pair_id, rd.read_num, rd.is_rc, rd.reg_rank, rd.n_pairs));
+		else VX(vdjx_read_index_build_begin(gx, px, rd.pair_id, rd.read_num, rd.is_rc, rd.reg_rank, rd.n_pairs));
+		if (getenv("VDJX_TIMES")) status(getenv("VDJX_INDEX_SERIAL") ? "(read index built)" : "(read index begun)");
 	} else if (vdjx_mgpu_load(mg, gx, rd.primary, rd.n_primary, rd.rl, rd.scan_index, rd.pair_id, rd.read_num, rd.is_rc, rd.reg_rank, rd.n_pairs, rd.total_records)) {
 		fprintf(stderr, "%s\n", vdjx_mgpu_last_error());
 		return 1;
@@ -737,6 +745,9 @@ int main(int argc, char** argv) {
 	status("PRE_PRE_GRAPH1");                  /* A2:1387 */
 	if (!use_mgpu) {
 		VX(vdjx_kmer_build(gx, px, c.hp.k, c.hp.min_node_freq, c.hp.min_base_quality, &gg));
+		if (getenv("VDJX_TIMES")) status("(k-mer build done)");
+		VX(vdjx_read_index_build_end(gx));
+		if (getenv("VDJX_TIMES")) status("(read index ended)");
 	} else {
 		if (vdjx_mgpu_kmer_build(mg, gx, c.hp.k, c.hp.min_node_freq, c.hp.min_base_quality, &gg)) { fprintf(stderr, "%s\n", vdjx_mgpu_last_error()); return 1; }
 		if (rank == 0) fprintf(stderr, "k-mer table sharded over %d GPUs (%s): %llu bytes sent by rank 0 so far\n", c.gpus, transport, (unsigned long long) vdjx_mgpu_bytes_sent(mg));

@@ -29,6 +29,7 @@ struct vdjx_mgpu {
 	size_t ws_cap[WS_SLOTS];
 	/* the rank's share of the pool (ASCII records; the packed pool reads its quality characters here), the registration ranks and the scan positions of its records */
 	void *d_share, *d_reg, *d_scan;
+	void* d_info;            /* pair ids (4 B), read numbers and is_rc flags (1 B each) of the share's records: the begun index build reads them */
 	vdjx_pool* share_pool;
 	uint64_t total_records;
 	int rl;
@@ -113,6 +114,7 @@ void vdjx_mgpu_free(vdjx_mgpu* m) {
 	if (m->d_share) (void) hipFree(m->d_share);
 	if (m->d_reg) (void) hipFree(m->d_reg);
 	if (m->d_scan) (void) hipFree(m->d_scan);
+	if (m->d_info) (void) hipFree(m->d_info);
 	for (int i = 0; i < WS_SLOTS; i++) if (m->ws[i]) (void) hipFree(m->ws[i]);
 	vdjx_comm_free(m->cm);
 	free(m);
@@ -139,6 +141,7 @@ int vdjx_mgpu_load(vdjx_mgpu* m, vdjx_ctx* ctx, const uint8_t* records, size_t n
 	if (m->d_share) { (void) hipFree(m->d_share); m->d_share = NULL; }
 	if (m->d_reg) { (void) hipFree(m->d_reg); m->d_reg = NULL; }
 	if (m->d_scan) { (void) hipFree(m->d_scan); m->d_scan = NULL; }
+	if (m->d_info) { (void) hipFree(m->d_info); m->d_info = NULL; }
 	m->rl = rl;
 	m->total_records = total_records;
 	lap_start(m);
@@ -146,20 +149,34 @@ int vdjx_mgpu_load(vdjx_mgpu* m, vdjx_ctx* ctx, const uint8_t* records, size_t n
 	 * records).  Round 4 dealt the ASCII records out again into slices of the scan order (one all-to-all of 101-byte records: 5 GB per
 	 * rank at configs[4], 2.8 times the partial aggregates the build exchanges); the build now takes the share as it is and translates
 	 * a first instance through scan_index where it leaves the rank (vdjx_shard_begin_share): no record moves between ranks. */
-	for (size_t i = 0; i < n_records; i++) {
-		const uint64_t g = scan_index[i];
-		if (g >= total_records || (i && scan_index[i - 1] >= g)) { rc = fail(VDJX_EINVAL, "rank %d: scan positions of the share must ascend below %llu (record %zu: %llu)", me, (unsigned long long) total_records, i, (unsigned long long) g); goto done; }
-	}
 	{
-		uint64_t mine = n_records, sum = 0;
-		CX(vdjx_comm_allgather_host(m->cm, &mine, 8, all_rows));
-		for (int r = 0; r < G; r++) sum += all_rows[r];
+		/* the local verdict travels WITH the record count: a rank whose share is bad must not leave the collective the others wait in
+		 *  -- every rank learns of it and all fail together */
+		uint64_t mine[2] = {n_records, 0}, sum = 0;
+		size_t bad_at = 0;
+		for (size_t i = 0; i < n_records && !mine[1]; i++) {
+			const uint64_t g = scan_index[i];
+			if (g >= total_records || (i && scan_index[i - 1] >= g)) { mine[1] = 1; bad_at = i; }
+		}
+		uint64_t* all2 = (uint64_t*) calloc((size_t) G * 2, 8);
+		if (!all2) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; }
+		const int rg = vdjx_comm_allgather_host(m->cm, mine, 16, all2);
+		int bad_rank = -1;
+		for (int r = 0; r < G && !rg; r++) { all_rows[r] = all2[2 * r]; sum += all2[2 * r]; if (all2[2 * r + 1] && bad_rank < 0) bad_rank = r; }
+		free(all2);
+		if (rg) { rc = fail(rg, "rank %d: vdjx_comm_allgather_host: %s", me, vdjx_comm_last_error()); goto done; }
+		if (mine[1]) { rc = fail(VDJX_EINVAL, "rank %d: scan positions of the share must ascend below %llu (record %zu: %llu)", me, (unsigned long long) total_records, bad_at, (unsigned long long) scan_index[bad_at]); goto done; }
+		if (bad_rank >= 0) { rc = fail(VDJX_EINVAL, "rank %d: rank %d's share is not in scan order", me, bad_rank); goto done; }
 		if (sum != total_records) { rc = fail(VDJX_EINVAL, "rank %d: the shares hold %llu records, the pool %llu (the shares do not cover the pool once)", me, (unsigned long long) sum, (unsigned long long) total_records); goto done; }
 	}
 	HIPC(hipMalloc(&m->d_share, n_records * rec + 16));
 	HIPC(hipMalloc(&m->d_reg, (n_records + 1) * 4));
 	HIPC(hipMalloc(&m->d_scan, (n_records + 1) * 4));
+	HIPC(hipMalloc(&m->d_info, (n_records + 1) * 6));
 	if (n_records) {
+		HIPC(hipMemcpy(m->d_info, pair_id, n_records * 4, hipMemcpyHostToDevice));
+		HIPC(hipMemcpy((char*) m->d_info + (n_records + 1) * 4, read_num, n_records, hipMemcpyHostToDevice));
+		HIPC(hipMemcpy((char*) m->d_info + (n_records + 1) * 5, is_rc, n_records, hipMemcpyHostToDevice));
 		HIPC(hipMemcpy(m->d_share, records, n_records * rec, hipMemcpyHostToDevice));
 		HIPC(hipMemcpy(m->d_reg, reg_rank, n_records * 4, hipMemcpyHostToDevice));
 		HIPC(hipMemcpy(m->d_scan, scan_index, n_records * 4, hipMemcpyHostToDevice));
@@ -167,8 +184,11 @@ int vdjx_mgpu_load(vdjx_mgpu* m, vdjx_ctx* ctx, const uint8_t* records, size_t n
 	lap(m, "load: check + upload of the share");
 	VX(vdjx_pool_load_device(ctx, (const uint8_t*) m->d_share, n_records, NULL, 0, rl, &m->share_pool));
 	lap(m, "load: pack");
-	VX(vdjx_read_index_build(ctx, m->share_pool, pair_id, read_num, is_rc, reg_rank, n_pairs));
-	lap(m, "load: read index of the share");
+	/* the share's read index is BEGUN here, on the library's index stream: it is built beside the sharded k-mer build (both only read the
+	 * packed share) and ended by vdjx_mgpu_kmer_build -- or by the first scorer call */
+	VX(vdjx_read_index_build_device_begin(ctx, m->share_pool, (const uint32_t*) m->d_info, (const uint8_t*) m->d_info + (n_records + 1) * 4,
+	                                      (const uint8_t*) m->d_info + (n_records + 1) * 5, (const uint32_t*) m->d_reg, n_pairs));
+	lap(m, "load: read index of the share begun");
 done:
 	free(all_rows);
 	return rc;
@@ -274,7 +294,11 @@ int vdjx_mgpu_kmer_build_pool(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool
 
 int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, int k, int mf, int mq, vdjx_graph** out) {
 	if (!m->share_pool) return fail(VDJX_ESTATE, "vdjx_mgpu_kmer_build: call vdjx_mgpu_load first");
-	const int rc = kmer_build_any(m, ctx, m->share_pool, k, mf, mq, 0, (const uint32_t*) m->d_scan, m->total_records, out);
+	int rc = kmer_build_any(m, ctx, m->share_pool, k, mf, mq, 0, (const uint32_t*) m->d_scan, m->total_records, out);
+	lap_start(m);
+	const int ri = vdjx_read_index_build_end(ctx);        /* (begun by vdjx_mgpu_load) */
+	lap(m, "read index of the share: waited for after the build");
+	if (ri && !rc) rc = fail(ri, "rank %d: vdjx_read_index_build_end: %s", m->rank, vdjx_last_error());
 	/* a rank builds once and then serves scorer calls: what only the build needed goes back to the device -- its exchange buffers here,
 	 * the library's workspaces (the peak of the build: tens of GB per rank at configs[4]) through vdjx_trim */
 	(void) hipSetDevice(m->device);

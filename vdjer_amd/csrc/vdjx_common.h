@@ -93,6 +93,15 @@ struct vdjx_arena {
 
 struct vdjx_shard;
 
+// vdjx_ctx::h_pin: 16 KB of page-locked scratch.  Every synchronous call reads its small numbers back into the first bytes (the
+// largest: stage_gated_reduce's (64 * 16 + 2) * 8 = 8,208); a call that is BEGUN and ended later (vdjx_root_score_graph_begin) keeps
+// its number in a word behind all of those, because other calls run in between (a k-mer build between begin and end
+// overwrote a word at byte 8,192)
+#define VDJX_HPIN_BYTES 16384
+#define VDJX_HPIN_SYNC_BYTES ((64 * 16 + 2) * 8)       // the largest read-back of a synchronous call (vdjx_kmer.hip stage_gated_reduce)
+#define VDJX_HPIN_ROOT_RUN 3072                        // u32 index: byte 12,288
+static_assert(VDJX_HPIN_ROOT_RUN * 4 >= VDJX_HPIN_SYNC_BYTES + 64 && VDJX_HPIN_ROOT_RUN * 4 + 4 <= VDJX_HPIN_BYTES, "h_pin layout");
+
 // device blocks that outlive a call (packed pools, exported graphs): freed blocks are kept for the next call of the
 // same size class instead of going back to hipFree (which synchronises the device)
 struct vdjx_block_cache {
@@ -108,6 +117,13 @@ struct vdjx_ctx {
 	vdjx_arena arena;
 	vdjx_block_cache blocks;
 	vdjx_arena shard_arena;            // lives across the phases of one sharded build
+	// vdjx_read_index_build[_device]_begin .. _end: the index is built by a thread of its own, on a stream of its own, out of a workspace of
+	// its own, beside the k-mer build of the same pool (both only READ the packed records; the reference registers the reads during
+	// extraction, quick_map3.c:126-149, and builds its k-mer table afterwards, A2:1388: nothing orders the two but the first scorer call)
+	hipStream_t ri_stream = nullptr;
+	hipEvent_t ev_ri_go = nullptr;
+	vdjx_arena ri_arena;
+	struct vdjx_ri_job* ri_job = nullptr;     // the build in flight (vdjx_rindex.hip); every call that looks at the index joins it first
 	vdjx_shard* live_shard = nullptr;
 	hipStream_t stream = nullptr;
 	hipStream_t copy_stream = nullptr;   // result copies that may run beside the next kernels (vdjx_graph_export_begin)
@@ -253,19 +269,22 @@ struct vdjx_graph {
 };
 
 bool vdjx_ctx_alive(const vdjx_ctx* c);   // a pool or graph may be freed after its context
+int vdjx_ri_join(vdjx_ctx* c);            // waits for a begun read-index build (vdjx_rindex.hip); its status, VDJX_OK if none is in flight
 bool vdjx_host_block_holds(vdjx_ctx* c, const void* p, size_t bytes);   // [p, p + bytes) inside a block of vdjx_host_alloc (vdjx_core.hip)
 
 // scoped workspace allocations out of the context's arena
 struct vdjx_work {
 	vdjx_ctx* c;
-	explicit vdjx_work(vdjx_ctx* ctx) : c(ctx) {}
-	~vdjx_work() { c->arena.reset(); }
+	vdjx_arena* ar;
+	explicit vdjx_work(vdjx_ctx* ctx) : c(ctx), ar(&ctx->arena) {}
+	vdjx_work(vdjx_ctx* ctx, vdjx_arena* arena) : c(ctx), ar(arena) {}      // (the begun read-index build: a workspace of its own)
+	~vdjx_work() { ar->reset(); }
 	template <typename T> hipError_t alloc(T** out, size_t n) {
-		*out = (T*) c->arena.alloc((n ? n : 1) * sizeof(T));
+		*out = (T*) ar->alloc((n ? n : 1) * sizeof(T));
 		return *out ? hipSuccess : hipErrorOutOfMemory;
 	}
-	vdjx_arena::mark_t mark() const { return c->arena.mark(); }
-	void release_to(vdjx_arena::mark_t m) { c->arena.release_to(m); }
+	vdjx_arena::mark_t mark() const { return ar->mark(); }
+	void release_to(vdjx_arena::mark_t m) { ar->release_to(m); }
 };
 
 // profiling: bracket a launch with events on the context's stream
@@ -273,7 +292,7 @@ struct vdjx_prof_scope {
 	vdjx_ctx* c;
 	const char* name;
 	hipEvent_t a = nullptr, b = nullptr;
-	vdjx_prof_scope(vdjx_ctx* ctx, const char* nm);
+	vdjx_prof_scope(vdjx_ctx* ctx, const char* nm);      // ctx == nullptr: nothing is bracketed (a launch on another stream than the context's)
 	~vdjx_prof_scope();
 };
 void vdjx_prof_collect(vdjx_ctx* ctx, bool force = true);

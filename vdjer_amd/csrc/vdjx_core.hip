@@ -51,7 +51,9 @@ extern "C" int vdjx_init(int device, vdjx_ctx** out) {
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pairs_copied, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_root_done, hipEventDisableTiming);
-	if (e == hipSuccess) e = hipHostMalloc(&c->h_pin, 16384, hipHostMallocDefault);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->ri_stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ri_go, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipHostMalloc(&c->h_pin, VDJX_HPIN_BYTES, hipHostMallocDefault);
 	if (e != hipSuccess) { delete c; vdjx_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return VDJX_EHIP; }
 	{
 		std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -103,7 +105,11 @@ void vdjx_block_cache::drop() {
 extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	if (!c) return;
 	(void) hipSetDevice(c->device);
+	(void) vdjx_ri_join(c);
 	(void) hipStreamSynchronize(c->stream);
+	if (c->ri_stream) { (void) hipStreamSynchronize(c->ri_stream); (void) hipStreamDestroy(c->ri_stream); }
+	if (c->ev_ri_go) (void) hipEventDestroy(c->ev_ri_go);
+	c->ri_arena.release(true);
 	free_dev(c->d_vbits); free_dev(c->d_jbits); free_dev(c->d_anchor_tmp);
 	free_dev(c->d_vtext); free_dev(c->d_line_off); free_dev(c->d_seed_code); free_dev(c->d_seed_pos);
 	free_dev(c->d_ri_tab); free_dev(c->d_ri_start); free_dev(c->d_ri_recs); free_dev(c->d_ri_csr8); free_dev(c->d_ri_csr_pair);
@@ -145,10 +151,12 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 extern "C" int vdjx_trim(vdjx_ctx* c) {
 	if (!c) { vdjx_set_error("vdjx_trim: ctx is NULL"); return VDJX_EINVAL; }
 	HIP_TRY(hipSetDevice(c->device));
+	(void) vdjx_ri_join(c);
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	HIP_TRY(hipStreamSynchronize(c->copy_stream));
 	if (c->pairs_stream) HIP_TRY(hipStreamSynchronize(c->pairs_stream));
 	c->arena.release(false);
+	c->ri_arena.release(false);
 	if (!c->live_shard) c->shard_arena.release(false);
 	c->blocks.drop();
 	// the scorers' result buffers (grow-only between calls: the pair lists of the last window batch, the mapped pairs and the SAM
@@ -177,6 +185,7 @@ extern "C" int vdjx_trim(vdjx_ctx* c) {
 extern "C" int vdjx_read_index_drop(vdjx_ctx* c) {
 	if (!c) { vdjx_set_error("vdjx_read_index_drop: ctx is NULL"); return VDJX_EINVAL; }
 	HIP_TRY(hipSetDevice(c->device));
+	(void) vdjx_ri_join(c);
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	free_dev(c->d_ri_tab); free_dev(c->d_ri_start); free_dev(c->d_ri_cnt1); free_dev(c->d_ri_dstart); free_dev(c->d_pair_r2);
 	free_dev(c->d_ri_recs); free_dev(c->d_ri_csr8); free_dev(c->d_ri_csr_pair); free_dev(c->d_ri_d8);
@@ -330,7 +339,7 @@ extern "C" int vdjx_sync(vdjx_ctx* c) {
 // profiling
 // ----------------------------------------------------------------------------------------------
 vdjx_prof_scope::vdjx_prof_scope(vdjx_ctx* ctx, const char* nm) : c(ctx), name(nm) {
-	if (!c->profiling) return;
+	if (!c || !c->profiling) return;
 	if (!c->prof_only.empty() && c->prof_only != nm) return;          // (vdjx_profile_only: one scope is bracketed, the others cost nothing)
 	auto take = [&](hipEvent_t* e) {
 		if (!c->ev_free.empty()) { *e = c->ev_free.back(); c->ev_free.pop_back(); return true; }
@@ -341,7 +350,7 @@ vdjx_prof_scope::vdjx_prof_scope(vdjx_ctx* ctx, const char* nm) : c(ctx), name(n
 }
 
 vdjx_prof_scope::~vdjx_prof_scope() {
-	if (!c->profiling || !a) return;
+	if (!c || !c->profiling || !a) return;
 	(void) hipEventRecord(b, c->stream);
 	c->prof_pending.push_back({name, a, b});
 }
@@ -1111,6 +1120,7 @@ extern "C" void vdjx_pool_free(vdjx_pool* p) {
 	(void) hipSetDevice(p->device);
 	if (p->d_block) {
 		if (vdjx_ctx_alive(p->ctx)) {
+			if (p->ctx->ri_job) (void) vdjx_ri_join(p->ctx);    // (a begun index build may be reading these records)
 			(void) hipStreamSynchronize(p->ctx->stream);     // nothing in flight may still read the block
 			if (p->pending_bad) (void) hipStreamSynchronize(p->ctx->copy_stream);
 			p->ctx->blocks.release(p->d_block, p->block_cap);

@@ -2763,7 +2763,8 @@ int stage_gated_reduce(vdjx_ctx* c, A& db, const GTuples<TUP>& t, const PoolView
 	}
 	u64* spread = (u64*) c->h_pin;                    // [64 * 16], then ns, err
 	u32* tail = (u32*) (spread + 64 * 16);
-	HIP_TRY(hipMemcpyAsync(spread, g_distinct, (64 * 16 + 2) * 8, hipMemcpyDeviceToHost, st));      // (one transfer: tail[] = error word, survivors, real survivors)
+	static_assert((64 * 16 + 2) * 8 == VDJX_HPIN_SYNC_BYTES, "h_pin layout (vdjx_common.h)");
+	HIP_TRY(hipMemcpyAsync(spread, g_distinct, VDJX_HPIN_SYNC_BYTES, hipMemcpyDeviceToHost, st));      // (one transfer: tail[] = error word, survivors, real survivors)
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
 	const u32 ns = tail[1], err = tail[0];

@@ -17,6 +17,7 @@
 #include "vdjx_common.h"
 
 #include <string.h>
+#include <thread>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_merge.hpp>
 
@@ -599,14 +600,15 @@ int sort_pairs(vdjx_work& db, hipStream_t st, u64* k_in, u64* k_out, u32* v_in, 
 inline unsigned bits_for(u64 x) { unsigned b = 1; while (b < 64 && (1ull << b) <= x) b++; return b; }
 
 // the build proper; the four per-record arrays are on the device
+// `st`: the context's stream (the waiting calls) or its index stream (a begun build: then nothing is bracketed for the profile --
+// `pc` is null -- and the counts go to `stats`, handed to the context when the build is joined: the caller's thread owns c->stats)
 int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, const u32* d_pair, const uint8_t* d_rnum, const uint8_t* d_rc,
-                         const u32* d_reg, u32 n_pairs) {
-	hipStream_t st = c->stream;
+                         const u32* d_reg, u32 n_pairs, hipStream_t st, vdjx_ctx* pc, std::map<std::string, uint64_t>& stats) {
 	if (pool->n_records > ((size_t) 1 << 29)) { vdjx_set_error("vdjx_read_index_build: %zu records on one GPU (limit 2^29): shard the pool by pair", pool->n_records); return VDJX_ELIMIT; }
 	const u32 R = (u32) pool->n_records;
 	const bool sym_on = getenv("VDJX_NO_SYM_INDEX") == nullptr;       // (read per build: the tests build one pool both ways)
 	const bool sym = sym_on && pool->sym && pool->W == 2 && R % 2 == 0;      // couples: k_ri_insert_sym
-	c->stats["read_index_sym"] = sym ? 1 : 0;
+	stats["read_index_sym"] = sym ? 1 : 0;
 	const size_t RK = sym ? R / 2 : R;                     // what the build's table holds: records, or couples
 	u32 mask = 1023;
 	// (2 R slots.  1.5 R would do for the table itself and saves 0.3 ms of clearing and scanning at 10 M pairs -- but the classes are
@@ -629,7 +631,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(hipMemsetAsync(d_err, 0, 48, st));
 	HIP_TRY(hipMemsetAsync(d_r2key, 0xFF, ((size_t) n_pairs * 2 + 2) * 8, st));
 	{
-		vdjx_prof_scope ps(c, "k_ri_insert");
+		vdjx_prof_scope ps(pc, "k_ri_insert");
 		if (sym) hipLaunchKernelGGL(k_ri_insert_sym, gR, b256, 0, st, pool->d_bases, pool->d_nmask, (u32) RK, pool->rl, d_slots, mask, d_rec_slot);
 		else if (pool->W == 2) hipLaunchKernelGGL((k_ri_insert<2, 1>), gR, b256, 0, st, pool->d_bases, pool->d_nmask, R, d_slots, mask, d_rec_slot);
 		else hipLaunchKernelGGL((k_ri_insert<VDJX_LONG_W, VDJX_LONG_M>), gR, b256, 0, st, pool->d_bases, pool->d_nmask, R, d_slots, mask, d_rec_slot);
@@ -640,7 +642,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(db.alloc(&d_bcnt, nsb + 1));
 	HIP_TRY(db.alloc(&d_bpre, nsb + 1));
 	{
-		vdjx_prof_scope ps(c, "k_ri_number");
+		vdjx_prof_scope ps(pc, "k_ri_number");
 		hipLaunchKernelGGL(k_ri_occ, dim3(nsb), b256, 0, st, d_slots, (u32) nslots, d_bcnt);
 	}
 	// (two levels: one workgroup over the 32,768 block counts of a 10 M-pair pool's table was 56 us)
@@ -674,7 +676,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	if (c->ri_tab_epoch == 0) HIP_TRY(hipMemsetAsync(c->d_ri_tab, 0, c->ri_cap[0], st));          // (all of it: a later build may use more of the buffer)
 	if (sym) c->ri_tab_epoch++;
 	{
-		vdjx_prof_scope ps(c, "k_ri_number");
+		vdjx_prof_scope ps(pc, "k_ri_number");
 		if (sym) hipLaunchKernelGGL(k_ri_number_sym, dim3(nsb), b256, 0, st, d_slots, (u32) nslots, d_bpre, d_rep);
 		else hipLaunchKernelGGL(k_ri_number, dim3(nsb), b256, 0, st, d_slots, (u32) nslots, d_bpre, d_rep);
 	}
@@ -684,7 +686,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(db.alloc(&d_rbcnt, nrb + 1));
 	HIP_TRY(db.alloc(&d_rbpre, nrb + 2));
 	{
-		vdjx_prof_scope ps(c, "k_ri_records");
+		vdjx_prof_scope ps(pc, "k_ri_records");
 		if (nrb && sym) hipLaunchKernelGGL(k_ri_records<true>, dim3(nrb), b256, 0, st, d_rec_slot, d_slots, R, d_pair, d_rnum, d_rc, d_reg, n_pairs, d_rec_cls, d_r2key, d_err, d_rbcnt);
 		else if (nrb) hipLaunchKernelGGL(k_ri_records<false>, dim3(nrb), b256, 0, st, d_rec_slot, d_slots, R, d_pair, d_rnum, d_rc, d_reg, n_pairs, d_rec_cls, d_r2key, d_err, d_rbcnt);
 		hipLaunchKernelGGL(k_rs_top, dim3(1), dim3(1024), 0, st, d_rbcnt, nrb, d_rbpre);
@@ -707,7 +709,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	HIP_TRY(db.alloc(&d_mreg, (size_t) n1 + 1));
 	HIP_TRY(db.alloc(&d_mreg2, (size_t) n1 + 1));
 	{
-		vdjx_prof_scope ps(c, "k_ri_members");
+		vdjx_prof_scope ps(pc, "k_ri_members");
 		if (nrb) hipLaunchKernelGGL(k_ri_members, dim3(nrb), b256, 0, st, d_rec_cls, d_rnum, d_reg, d_pair, d_r2key, c->d_pair_r2, R, n_pairs, d_rbpre, c->d_ri_cnt1, d_mkey, d_mreg, d_mpack);
 	}
 	int rc = scan_u32(db, st, c->d_ri_cnt1, ncls + 1, c->d_ri_start);         // (cnt1[ncls] = 0: start[ncls] = start[ncls + 1] = members)
@@ -720,7 +722,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	unsigned long long nd = 0;
 	u64* d_by_class = nullptr;
 	if (n1) {
-		vdjx_prof_scope ps(c, "ri_sort_members");
+		vdjx_prof_scope ps(pc, "ri_sort_members");
 		// the members are in record order; inside a pool that IS registration order (add_to_buffer registers what it appends,
 		// bam_read.c:206-244), so by rank they are two sorted runs (primary, secondary): a merge.  A caller whose ranks do not
 		// follow its records gets a sort by rank instead.  Then a STABLE sort by class alone (the key's upper half; the member
@@ -753,7 +755,7 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 		d_by_class = by_class;
 	}
 	{
-		vdjx_prof_scope ps(c, "k_ri_fold");
+		vdjx_prof_scope ps(pc, "k_ri_fold");
 		const u32 max_giant = n1 / (RI_FOLD_WAVE + 1) + 1;
 		u32* d_giant;
 		HIP_TRY(db.alloc(&d_giant, (size_t) max_giant + 1));
@@ -764,18 +766,18 @@ int read_index_build_dev(vdjx_ctx* c, vdjx_work& db, const vdjx_pool* pool, cons
 	}
 	HIP_TRY(hipMemcpyAsync(&nd, d_nent, 8, hipMemcpyDeviceToHost, st));
 	{	// the mapper's table, now that the classes' sizes and starts are known
-		vdjx_prof_scope ps(c, "k_ri_tab");
+		vdjx_prof_scope ps(pc, "k_ri_tab");
 		if (sym) hipLaunchKernelGGL(k_ri_tab_canon, dim3(ncls / 512 + 1), b256, 0, st, d_rep, ncls / 2, pool->d_bases, c->d_ri_cnt1, c->d_ri_start, c->d_ri_dstart, (u64*) c->d_ri_tab, tmask, c->ri_tab_epoch);
 		else if (pool->W == 2) hipLaunchKernelGGL(k_ri_tab<2>, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, c->d_ri_cnt1, c->d_ri_start, c->d_ri_dstart, (u64*) c->d_ri_tab, tmask);
 		else hipLaunchKernelGGL(k_ri_tab<VDJX_LONG_W>, dim3(ncls / 256 + 1), b256, 0, st, d_rep, ncls, pool->d_bases, c->d_ri_cnt1, c->d_ri_start, c->d_ri_dstart, (u64*) c->d_ri_tab, tmask);
 	}
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
-	vdjx_prof_collect(c, false);
-	c->stats["read_index_r1_members"] = n1;
-	c->stats["read_index_r1_distinct"] = nd;
-	c->stats["read_index_classes"] = ncls;
-	c->stats["read_index_rank_order"] = h_err[RI_ERR_ORDER] > 1 ? 2 : h_err[RI_ERR_ORDER];      // 0 as recorded, 1 merge of the two pools' runs, 2 sort by rank
+	if (pc) vdjx_prof_collect(pc, false);
+	stats["read_index_r1_members"] = n1;
+	stats["read_index_r1_distinct"] = nd;
+	stats["read_index_classes"] = ncls;
+	stats["read_index_rank_order"] = h_err[RI_ERR_ORDER] > 1 ? 2 : h_err[RI_ERR_ORDER];      // 0 as recorded, 1 merge of the two pools' runs, 2 sort by rank
 	c->ri_tab_mask = tmask;
 	c->ri_canon = sym;
 	c->n_pairs = n_pairs;
@@ -809,16 +811,99 @@ int vdjx_sort_pairs(vdjx_work& db, hipStream_t st, u64* k_in, u64* k_out, u32* v
 	return sort_pairs(db, st, k_in, k_out, v_in, v_out, n, end_bit);
 }
 
+// ---- a build begun and ended (the index beside the k-mer build) -----------------------------------------------------------------
+struct vdjx_ri_job {
+	std::thread th;
+	int rc = VDJX_OK;
+	std::string err;
+	std::map<std::string, uint64_t> stats;
+};
+
+int vdjx_ri_join(vdjx_ctx* c) {
+	vdjx_ri_job* j = c->ri_job;
+	if (!j) return VDJX_OK;
+	if (j->th.joinable()) j->th.join();
+	c->ri_job = nullptr;
+	for (auto& kv : j->stats) c->stats[kv.first] = kv.second;
+	const int rc = j->rc;
+	if (rc) { vdjx_set_error("%s", j->err.c_str()); drop_index(c); }
+	delete j;
+	return rc;
+}
+
+namespace {
+// host = true: the four arrays are the caller's host arrays (they go up on the index stream; they must stay valid until _end)
+int ri_begin(vdjx_ctx* c, const vdjx_pool* pool, const uint32_t* pair_id, const uint8_t* read_num, const uint8_t* is_rc, const uint32_t* reg_rank,
+             uint32_t n_pairs, bool host, const char* who) {
+	int rc = check_args(c, pool, pair_id, read_num, is_rc, reg_rank, who);
+	if (rc) return rc;
+	HIP_TRY(hipSetDevice(c->device));
+	vdjx_clear_errors();
+	rc = vdjx_ri_join(c);                               // (one build in flight per context; an unjoined one ends here)
+	if (rc) return rc;
+	drop_index(c);
+	// what the context's stream holds so far -- the packing of this pool, the last scorer kernels that read the index being replaced --
+	// comes first; nothing else orders the two streams until _end
+	HIP_TRY(hipEventRecord(c->ev_ri_go, c->stream));
+	HIP_TRY(hipStreamWaitEvent(c->ri_stream, c->ev_ri_go, 0));
+	vdjx_ri_job* j = new vdjx_ri_job();
+	c->ri_job = j;
+	const int device = c->device;
+	j->th = std::thread([=]() {
+		if (hipSetDevice(device) != hipSuccess) { j->rc = VDJX_EHIP; j->err = "vdjx_read_index_build_begin: hipSetDevice failed on the index thread"; return; }
+		vdjx_work db(c, &c->ri_arena);
+		hipStream_t st = c->ri_stream;
+		const uint32_t *d_pair = pair_id, *d_reg = reg_rank;
+		const uint8_t *d_rnum = read_num, *d_rc = is_rc;
+		int r = VDJX_OK;
+		if (host) {
+			const size_t R = pool->n_records;
+			u32 *dp = nullptr, *dr = nullptr;
+			uint8_t *dn = nullptr, *dc = nullptr;
+			if (db.alloc(&dp, R + 1) != hipSuccess || db.alloc(&dr, R + 1) != hipSuccess || db.alloc(&dn, R + 1) != hipSuccess || db.alloc(&dc, R + 1) != hipSuccess) r = VDJX_EHIP;
+			if (!r && R) {
+				hipError_t e = hipMemcpyAsync(dp, pair_id, R * 4, hipMemcpyHostToDevice, st);
+				if (e == hipSuccess) e = hipMemcpyAsync(dr, reg_rank, R * 4, hipMemcpyHostToDevice, st);
+				if (e == hipSuccess) e = hipMemcpyAsync(dn, read_num, R, hipMemcpyHostToDevice, st);
+				if (e == hipSuccess) e = hipMemcpyAsync(dc, is_rc, R, hipMemcpyHostToDevice, st);
+				if (e != hipSuccess) { vdjx_set_error("vdjx_read_index_build_begin: upload: %s", hipGetErrorString(e)); r = VDJX_EHIP; }
+			}
+			d_pair = dp; d_reg = dr; d_rnum = dn; d_rc = dc;
+		}
+		if (!r) r = read_index_build_dev(c, db, pool, d_pair, d_rnum, d_rc, d_reg, n_pairs, st, nullptr, j->stats);
+		if (r) { (void) hipStreamSynchronize(st); j->err = vdjx_last_error(); }      // (nothing of a failed build may still be running when its workspace is reset)
+		j->rc = r;
+	});
+	return VDJX_OK;
+}
+}  // namespace
+
+extern "C" int vdjx_read_index_build_device_begin(vdjx_ctx* c, const vdjx_pool* pool, const uint32_t* d_pair_id, const uint8_t* d_read_num,
+                                                  const uint8_t* d_is_rc, const uint32_t* d_reg_rank, uint32_t n_pairs) {
+	return ri_begin(c, pool, d_pair_id, d_read_num, d_is_rc, d_reg_rank, n_pairs, false, "vdjx_read_index_build_device_begin");
+}
+
+extern "C" int vdjx_read_index_build_begin(vdjx_ctx* c, const vdjx_pool* pool, const uint32_t* pair_id, const uint8_t* read_num,
+                                           const uint8_t* is_rc, const uint32_t* reg_rank, uint32_t n_pairs) {
+	return ri_begin(c, pool, pair_id, read_num, is_rc, reg_rank, n_pairs, true, "vdjx_read_index_build_begin");
+}
+
+extern "C" int vdjx_read_index_build_end(vdjx_ctx* c) {
+	if (!c) { vdjx_set_error("vdjx_read_index_build_end: ctx is NULL"); return VDJX_EINVAL; }
+	return vdjx_ri_join(c);
+}
+
 extern "C" int vdjx_read_index_build_device(vdjx_ctx* c, const vdjx_pool* pool, const uint32_t* d_pair_id, const uint8_t* d_read_num,
                                             const uint8_t* d_is_rc, const uint32_t* d_reg_rank, uint32_t n_pairs) {
 	int rc = check_args(c, pool, d_pair_id, d_read_num, d_is_rc, d_reg_rank, "vdjx_read_index_build_device");
 	if (rc) return rc;
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_clear_errors();
+	(void) vdjx_ri_join(c);
 	HIP_TRY(hipStreamSynchronize(c->stream));           // nothing in flight may still read the index that is replaced
 	drop_index(c);
 	vdjx_work db(c);
-	rc = read_index_build_dev(c, db, pool, d_pair_id, d_read_num, d_is_rc, d_reg_rank, n_pairs);
+	rc = read_index_build_dev(c, db, pool, d_pair_id, d_read_num, d_is_rc, d_reg_rank, n_pairs, c->stream, c, c->stats);
 	if (rc) drop_index(c);
 	return rc;
 }
@@ -829,6 +914,7 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 	if (rc) return rc;
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_clear_errors();
+	(void) vdjx_ri_join(c);
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	drop_index(c);
 	vdjx_work db(c);
@@ -845,7 +931,7 @@ extern "C" int vdjx_read_index_build(vdjx_ctx* c, const vdjx_pool* pool, const u
 		HIP_TRY(hipMemcpyAsync(d_rnum, read_num, R, hipMemcpyHostToDevice, c->stream));
 		HIP_TRY(hipMemcpyAsync(d_rc, is_rc, R, hipMemcpyHostToDevice, c->stream));
 	}
-	rc = read_index_build_dev(c, db, pool, d_pair, d_rnum, d_rc, d_reg, n_pairs);
+	rc = read_index_build_dev(c, db, pool, d_pair, d_rnum, d_rc, d_reg, n_pairs, c->stream, c, c->stats);
 	if (rc) drop_index(c);
 	return rc;
 }

@@ -348,7 +348,7 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 	}
 	// the DP is launched for as many items as the last call had before the host knows this call's number (its copy is queued first:
 	// the host waits for that event only, and adds a launch for what is beyond the guess)
-	u32* h_run = begun ? (u32*) c->h_pin + 2048 : (u32*) c->h_pin;          // (a begun call's number waits in a place no other call writes)
+	u32* h_run = begun ? (u32*) c->h_pin + VDJX_HPIN_ROOT_RUN : (u32*) c->h_pin;          // (a begun call's number waits in a place no other call writes: vdjx_common.h)
 	HIP_TRY(hipMemcpyAsync(h_run, d_pre + ng, 4, hipMemcpyDeviceToHost, st));
 	if (!begun) HIP_TRY(hipEventRecord(c->ev_plan, st));
 	// few items: a wave each (k_root_dp_wave); many: a thread each
@@ -509,7 +509,7 @@ extern "C" int vdjx_root_score_graph_end(vdjx_ctx* c) {
 	HIP_TRY(hipSetDevice(c->device));
 	HIP_TRY(hipEventSynchronize(c->ev_root_done));
 	HIP_TRY(hipGetLastError());
-	const u32 run = *((const u32*) c->h_pin + 2048);
+	const u32 run = *((const u32*) c->h_pin + VDJX_HPIN_ROOT_RUN);
 	c->root_dp_hint = run + run / 4 + 1024;
 	c->stats["root_dp_items"] = run;
 	if (run <= c->root_pending_ahead) return VDJX_OK;
@@ -1783,6 +1783,7 @@ __global__ __launch_bounds__(256) void k_gather_pairs(const vdjx_pair* __restric
 }
 
 static int make_index_view(vdjx_ctx* c, ReadIndexDev* ix, int len, const char* who) {
+	if (c->ri_job) { const int jr = vdjx_ri_join(c); if (jr) return jr; }      // a begun index build ends at the first call that needs the index
 	if (!c->ri_pool) { vdjx_set_error("%s: call vdjx_read_index_build first", who); return VDJX_ESTATE; }
 	const vdjx_pool* p = c->ri_pool;
 	if (len <= p->rl) { vdjx_set_error("%s: len=%d must exceed the read length %d", who, len, p->rl); return VDJX_EINVAL; }
@@ -2555,6 +2556,7 @@ static int sam_text_device(vdjx_ctx* c, vdjx_work& db, const char* contigs, size
                            u64* nbytes_out, u32** d_len_out) {
 	*total_out = 0; *nbytes_out = 0; *d_len_out = nullptr;
 	if (!c->d_sam_noff) { vdjx_set_error("vdjx_sam_text: call vdjx_sam_names_load first"); return VDJX_ESTATE; }
+	if (c->ri_job) { const int jr = vdjx_ri_join(c); if (jr) return jr; }
 	if (!c->ri_pool) { vdjx_set_error("vdjx_sam_text: call vdjx_read_index_build first"); return VDJX_ESTATE; }
 	if (c->sam_pairs < c->n_pairs) { vdjx_set_error("vdjx_sam_text: %u names for %u pairs", c->sam_pairs, c->n_pairs); return VDJX_EINVAL; }
 	std::vector<uint64_t> offs(n + 1);

@@ -92,8 +92,13 @@ class Repertoire:
 
 
 def make_repertoire(n_clones: int, seed: int = 20261002, n_v: int = 60, n_j: int = 6,
-                    zipf_s: float = 1.1, j_codons: int = 119, clone_seed: int | None = None, chain: str = "IGH") -> Repertoire:
-    """clone_seed: draw the clones from their own stream while the germline (and with it the ref-dir) stays the one of `seed`:
+                    zipf_s: float = 1.1, j_codons: int = 119, clone_seed: int | None = None, chain: str = "IGH",
+                    private_v: bool = False) -> Repertoire:
+    """private_v: every clone has a germline V of its own (n_v is ignored: n_v = n_clones, clone i over V i).  With V segments SHARED
+    by hundreds of clones (60 for all) the reference's contig enumeration (A2:939-1061) branches at every somatic mutation
+    of every clone of the segment and does not end above ~1.5 M pairs; with private segments a root's paths are its clone's transcript
+    and its surviving sequencing errors, and the serial traversal terminates at BASELINE size (10 M pairs / 20,000 clones: DESIGN 5).
+    clone_seed: draw the clones from their own stream while the germline (and with it the ref-dir) stays the one of `seed`:
     several libraries of different clones over one reference (bench.py gives every GPU its own library).
     chain IGK / IGL: the J segment starts with the conserved Phe codon and the CDR3 is short enough for the light-chain
     window (J residue F, CDR3 of 0-60 nt: set_chain_info, params.c:20-31)."""
@@ -102,13 +107,15 @@ def make_repertoire(n_clones: int, seed: int = 20261002, n_v: int = 60, n_j: int
     j_codon = "TGG" if chain == "IGH" else "TTC"
     core_lo, core_hi = (8, 21) if chain == "IGH" else (7, 18)      # light chains: CDR3 of 27-57 nt (window start >= 0 needs >= 27)
     rng = np.random.default_rng(seed)
+    if private_v:
+        n_v = n_clones
     v_germ = [_rand_codons(rng, 99) + "TGT" for _ in range(n_v)]
     j_germ = [j_codon + _rand_codons(rng, j_codons) for _ in range(n_j)]
     if clone_seed is not None:
         rng = np.random.default_rng(clone_seed)
     clones, cv, cj = [], [], []
-    for _ in range(n_clones):
-        g = int(rng.integers(0, n_v))
+    for ci_ in range(n_clones):
+        g = ci_ if private_v else int(rng.integers(0, n_v))
         h = int(rng.integers(0, n_j))
         v = list(v_germ[g])
         for _m in range(int(rng.integers(0, 7))):
