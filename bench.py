@@ -478,10 +478,6 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world == 1 and args.force_shard:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, world_size=1, rank=0)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_device:
@@ -508,11 +504,19 @@ def main():
     d_pri, d_sec = pool.primary, pool.secondary
 
     if world > 1 or args.force_shard:
-        from vdjer_amd import shard
-        engine = shard.ShardedHotPath(ctx, dist, dev)
-        cm = engine.comm
+        # ONE multi-GPU driver, the product's (round 6): csrc/host/vdjx_mgpu.c + vdjx_comm.c -- what `vdjer --gpus N` runs -- as libvdjmgpu.so
+        # through ctypes.  The ranks are the launcher's processes; they meet over sockets (vdjx_comm_rendezvous), the bulk bytes move over
+        # RCCL (or host sockets when the ranks share one device: dry runs only).  torch.distributed is left with the bench's own
+        # bookkeeping (barrier, the slowest rank's time); vdjer_amd/shard.py remains the test-side model of the protocol
+        from vdjer_amd import mgpu
+        engine = mgpu.Driver(ctx, rank, world, local_rank, "host" if one_device else "rccl")
     else:
-        engine = cm = None
+        engine = None
+
+    def all_gather_obj(x):
+        out = [None] * world
+        dist.all_gather_object(out, x)
+        return out
 
     state = {}
     host_side = {"pool_generate_s": round(t_gen, 2)}
@@ -560,10 +564,6 @@ def main():
     ri_prof = ctx.profile_get()
     ctx.profile(False)
     ctx.profile_reset()
-    scorer = None
-    if engine is not None:
-        from vdjer_amd import shard as _shard
-        scorer = _shard.HipScorerEngine(ctx, dev, rl)
     host_side["read_index_build_s"] = round(min(ix_times), 4)
     host_side["read_index"] = {n_: ctx.stat("read_index_" + n_) for n_ in ("classes", "r1_members", "r1_distinct", "rank_order")}
     host_side["read_index_kernels_ms"] = {k_: round(v[0] / 3, 4) for k_, v in ri_prof.items()}
@@ -571,29 +571,38 @@ def main():
                   "[51,411) slices of the windows the coverage test accepts; the host traversal is not run at this size: its contig "
                   "enumeration explodes combinatorially on this repertoire (see --windows)")
     if args.windows == "traversal":
-        # the windows the reference would hand to quick_map/coverage for THIS pool: run the serial host stage once,
-        # outside the timed region, and keep what it asked the scorers (identical on every rank)
+        # the windows the reference would hand to quick_map/coverage for THIS pool: run the serial host stage once, outside the timed
+        # region, and keep what it asked the scorers.  Several ranks: rank 0 runs it (as in `vdjer --gpus N`) and calls on the others'
+        # scorers, which serve until it yields; the windows and contigs it ends up with are told to everybody
         from vdjer_amd import host
         p0 = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
         g0 = engine.kmer_build(p0, args.k, args.mf, args.mq) if engine else ctx.kmer_build(p0, args.k, args.mf, args.mq)
         p0.free()
-        prm = host.make_params("IGH", ins=args.ins, k=args.k, mf=args.mf, mq=args.mq, mrs=args.mrs, rl=rl)
-        rs_fn, ws_fn, _ = host.gpu_hooks(ctx, None, None, prm)
-        if engine is not None:          # the scorer of the sharded job (every rank runs the traversal: identical results)
-            def ws_fn(w, _ins=args.ins):          # noqa: F811
-                return engine.window_score(scorer, w, _ins)[0]
-        asked = []
+        wins, contigs_fixed, t_tr, st_tr = None, None, 0.0, None
+        if rank == 0:
+            prm = host.make_params("IGH", ins=args.ins, k=args.k, mf=args.mf, mq=args.mq, mrs=args.mrs, rl=rl)
+            rs_fn, ws_fn, _ = host.gpu_hooks(ctx, None, None, prm)
+            if engine is not None:
+                def ws_fn(w, _ins=args.ins):          # noqa: F811
+                    return engine.window_score(w, _ins)[0]
+            asked = []
 
-        def ws_capture(w):
-            asked.extend(w)
-            return ws_fn(w)
-        with tempfile.TemporaryDirectory() as td:
-            t_tr = time.perf_counter()
-            st_tr = host.assemble(prm, g0, rs_fn, ws_capture, None, vc, jc, os.path.join(td, "c.fa"), None, None)
-            t_tr = time.perf_counter() - t_tr
-            fa = open(os.path.join(td, "c.fa")).read().split("\n")
-        wins = asked
-        contigs_fixed = [fa[i] for i in range(1, len(fa), 2)]
+            def ws_capture(w):
+                asked.extend(w)
+                return ws_fn(w)
+            with tempfile.TemporaryDirectory() as td:
+                t_tr = time.perf_counter()
+                st_tr = host.assemble(prm, g0, rs_fn, ws_capture, None, vc, jc, os.path.join(td, "c.fa"), None, None)
+                t_tr = time.perf_counter() - t_tr
+                fa = open(os.path.join(td, "c.fa")).read().split("\n")
+            wins = asked
+            contigs_fixed = [fa[i] for i in range(1, len(fa), 2)]
+            if engine is not None:
+                engine.yield_step()
+        elif engine is not None:
+            engine.serve_step(1)
+        if world > 1:
+            wins, contigs_fixed, t_tr, st_tr = all_gather_obj((wins, contigs_fixed, t_tr, st_tr))[0]
         host_side["traversal_s"] = round(t_tr, 2)
         scorer_src = (f"host traversal of this pool's graph ({t_tr:.1f}s serial incl. its scorer calls, untimed): {st_tr['n_contig_candidates']} contig "
                       f"candidates -> {len(wins)} distinct windows, {len(contigs_fixed)} final contigs")
@@ -620,11 +629,8 @@ def main():
     my_contigs_packed = ctx.pin_strings(my_contigs, "contigs") if my_contigs else None
 
     def gather_bytes(a):
-        """all_gather of a small uint8 vector whose length differs per rank"""
-        ns = cm.all_gather_cat(torch.tensor([a.shape[0]], dtype=torch.int64, device=dev)).cpu().numpy()
-        full = cm.all_gather_var(torch.from_numpy(np.ascontiguousarray(a)).to(dev), [int(x) for x in ns]).cpu().numpy()
-        offs = np.concatenate([[0], np.cumsum(ns)])
-        return [full[offs[i]:offs[i + 1]] for i in range(world)]
+        """all_gather of a small uint8 vector whose length differs per rank (bookkeeping of the bench, not the data path)"""
+        return [np.asarray(x) for x in all_gather_obj(np.ascontiguousarray(a))]
 
     wall = {}
 
@@ -682,8 +688,11 @@ def main():
         t = lap("root_score", t)
         if engine is None:
             valid, npairs = ctx.window_score(w_["wins_packed"], args.ins)
+        elif rank == 0:           # rank 0 calls, the others serve (vdjx_mgpu_window_score2 / vdjx_mgpu_serve_step): every rank ends up with all verdicts
+            valid, npairs = engine.window_score(w_["wins_packed"], args.ins)
+            engine.yield_step()
         else:
-            valid, npairs = engine.window_score(scorer, w_["wins_packed"], args.ins)
+            valid, npairs, _ = engine.serve_step(len(w_["wins"]))
         t = lap("window_score", t)
         # generator windows: the contigs are the [51,411) slices of the windows the coverage test accepts (page-locked, like the windows)
         if my_contigs is not None:
@@ -759,8 +768,6 @@ def main():
     ctx.profile_reset()
     wall.clear()
     bytes_before = engine.bytes_exchanged if engine else 0
-    if engine:
-        engine.laps.clear()
     import gc
     gc.collect()
     gc.disable()                       # no collector pauses inside the timed region
@@ -909,9 +916,7 @@ def main():
     for n_ in ("group_hits_distinct", "group_overflows", "group_classes", "group_queued", "group_clocks_sum", "group_clocks_max"):      # k_group_pairs: what the groups of windows shared
         stats[n_] = ctx.stat(n_)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        cm.all_reduce(tt, dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = max(all_gather_obj(dt))            # the slowest rank's time
 
     # ---- parity gate, part 2 (part 1, the timed step's own outputs, ran right after the timed loop): a small sample of the same
     # generator re-checked against the oracle itself
@@ -1076,7 +1081,8 @@ def main():
                                     "into the timed region (rounds 1-4)"} if prof_full is not None else
                             {"timed_region_events": "none" if no_events else "every kernel (VDJX_BENCH_ALL_EVENTS=1)"}),
         "exchange_bytes_per_step_rank0": ((engine.bytes_exchanged - bytes_before) // args.steps) if engine else 0,
-        "shard_wall_ms_per_step": ({k_: round(v / args.steps * 1e3, 3) for k_, v in engine.laps.items()} if engine else None),
+        "multi_gpu_driver": ("vdjer_amd/libvdjmgpu.so (csrc/host/vdjx_mgpu.c + vdjx_comm.c: the driver of `vdjer --gpus N`), transport "
+                             + ("host sockets (ranks share one device: dry run)" if one_device else "rccl")) if engine else None,
         "wall_ms_per_step": {k_: round(v / args.steps * 1e3, 3) for k_, v in wall.items()},
         "host_side": host_side,
         "counts": {k_: v for k_, v in state.items() if k_ not in ("graph", "last")}, "scorer_stats": stats, **({"host_laps_us_per_step": laps} if laps else {}),

@@ -65,3 +65,52 @@ def test_pack_reads_host_format():
     assert not out[0, 13:].any()
     with pytest.raises(Exception):
         api.Context.pack_reads(np.frombuffer(b"1" + b"A" * 10 + b"I" * 10, np.uint8), rl)
+
+
+def test_mgpu_library_exports_its_headers():
+    """libvdjmgpu.so (the multi-GPU driver of `vdjer --gpus N` as a library: bench.py --gpus N drives it through vdjer_amd/mgpu.py)
+    exports every entry point vdjx_mgpu.h and vdjx_comm.h declare"""
+    from vdjer_amd import mgpu
+    L = mgpu.lib()
+    for hdr in ("vdjx_mgpu.h", "vdjx_comm.h"):
+        txt = open(os.path.join(ROOT, "vdjer_amd", "csrc", "host", hdr)).read()
+        for s in sorted(set(re.findall(r"\b(vdjx_(?:mgpu|comm)_[a-z0-9_]+)\s*\(", txt))):
+            assert hasattr(L, s), s
+
+
+def _rdv_worker(d, me, G, mesh, q):
+    from vdjer_amd import mgpu
+    L = mgpu.lib()
+    fds = (ctypes.c_int * G)()
+    rc = L.vdjx_comm_rendezvous(d.encode(), me, G, mesh, fds)
+    row = [int(x) for x in fds]
+    got = {}
+    if rc == 0:
+        for j, fd in enumerate(row):               # every pair says hello both ways over its socket
+            if fd >= 0:
+                os.write(fd, bytes([me, j]))
+        for j, fd in enumerate(row):
+            if fd >= 0:
+                got[j] = list(os.read(fd, 2))
+    q.put((me, rc, [j for j, fd in enumerate(row) if fd >= 0], got))
+
+
+@pytest.mark.parametrize("G,mesh", [(2, 0), (3, 1), (4, 0), (5, 1)])
+def test_comm_rendezvous_of_started_ranks(G, mesh, tmp_path):
+    """vdjx_comm_rendezvous: ranks that are processes already (bench.py under torch.distributed.run) meet in a directory and get the
+    socket row vdjx_comm_sockets would have given them before a fork -- control pairs with rank 0 only (mesh 0: the RCCL transport) or
+    the full mesh (the host transport).  No GPU involved."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_rdv_worker, args=(str(tmp_path / "rdv"), r, G, mesh, q)) for r in range(G)]
+    for p in reversed(ps):                         # (the listeners start last: the callers retry until they are there)
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(G))
+    for p in ps:
+        p.join(30)
+    for me, rc, peers, got in res:
+        assert rc == 0
+        want = [j for j in range(G) if j != me and (mesh or me == 0 or j == 0)]
+        assert peers == want
+        assert got == {j: [j, me] for j in want}

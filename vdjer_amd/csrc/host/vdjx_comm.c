@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/socket.h>
+#include <sys/stat.h>
+#include <sys/un.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -75,6 +77,72 @@ int vdjx_comm_sockets(int G, int mesh, int* fds) {
 			fds[j * G + i] = sv[1];
 		}
 	return 0;
+}
+
+/* Ranks that are processes ALREADY (one per GPU, started by a launcher: torch.distributed.run under bench.py) meet in a directory all of
+ * them know: rank i listens on <dir>/r<i>.sock, every higher rank that needs the pair connects and says who it is.  Same table row as
+ * vdjx_comm_sockets would have given the rank. */
+static int connect_to(const char* path, double deadline_s) {
+	const double t_end = now_s() + deadline_s;
+	for (;;) {
+		const int fd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+		if (fd < 0) return fail(-1, "socket: %s", strerror(errno));
+		struct sockaddr_un a;
+		memset(&a, 0, sizeof a);
+		a.sun_family = AF_UNIX;
+		snprintf(a.sun_path, sizeof a.sun_path, "%s", path);
+		if (connect(fd, (struct sockaddr*) &a, sizeof a) == 0) return fd;
+		close(fd);
+		if (now_s() > t_end) return fail(E_COMM, "no rank listening on %s after %.0f s", path, deadline_s);
+		struct timespec ts = {0, 2000000};
+		nanosleep(&ts, NULL);
+	}
+}
+
+int vdjx_comm_rendezvous(const char* dir, int me, int G, int mesh, int* fds_row) {
+	for (int j = 0; j < G; j++) fds_row[j] = -1;
+	if (G <= 1) return 0;
+	if (mesh && G > VDJX_COMM_MAX_MESH) return fail(-1, "the host transport takes up to %d ranks", VDJX_COMM_MAX_MESH);
+	double deadline = 120;
+	if (getenv("VDJX_MGPU_TIMEOUT_S") && atof(getenv("VDJX_MGPU_TIMEOUT_S")) > 0) deadline = atof(getenv("VDJX_MGPU_TIMEOUT_S"));
+	(void) mkdir(dir, 0700);
+	char path[108];
+	int lfd = -1, expect = 0;
+	for (int j = me + 1; j < G; j++) if (mesh || me == 0) expect++;          /* the higher ranks that will call */
+	if (expect) {
+		if (snprintf(path, sizeof path, "%s/r%d.sock", dir, me) >= (int) sizeof path) return fail(-1, "rendezvous directory name too long");
+		(void) unlink(path);
+		lfd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+		struct sockaddr_un a;
+		memset(&a, 0, sizeof a);
+		a.sun_family = AF_UNIX;
+		snprintf(a.sun_path, sizeof a.sun_path, "%s", path);
+		if (lfd < 0 || bind(lfd, (struct sockaddr*) &a, sizeof a) || listen(lfd, G)) { const int e = errno; if (lfd >= 0) close(lfd); return fail(-1, "listen on %s: %s", path, strerror(e)); }
+	}
+	int rc = 0;
+	for (int i = 0; i < me && !rc; i++) {                                       /* call the lower ranks */
+		if (!mesh && i != 0) continue;
+		if (snprintf(path, sizeof path, "%s/r%d.sock", dir, i) >= (int) sizeof path) { rc = fail(-1, "rendezvous directory name too long"); break; }
+		const int fd = connect_to(path, deadline);
+		if (fd < 0) { rc = fd; break; }
+		const uint32_t who = (uint32_t) me;
+		if (write(fd, &who, 4) != 4) { close(fd); rc = fail(E_COMM, "rank %d: hello to rank %d failed", me, i); break; }
+		fds_row[i] = fd;
+	}
+	for (int n = 0; n < expect && !rc; n++) {
+		struct pollfd pf = {lfd, POLLIN, 0};
+		const int pr = poll(&pf, 1, (int) (deadline * 1000));
+		if (pr <= 0) { rc = fail(E_COMM, "rank %d: %d of %d higher ranks did not call within %.0f s", me, expect - n, expect, deadline); break; }
+		const int fd = accept4(lfd, NULL, NULL, SOCK_CLOEXEC);
+		uint32_t who = 0;
+		if (fd < 0 || read(fd, &who, 4) != 4 || who <= (uint32_t) me || who >= (uint32_t) G || fds_row[who] >= 0) { if (fd >= 0) close(fd); rc = fail(E_COMM, "rank %d: bad hello", me); break; }
+		fds_row[who] = fd;
+	}
+	if (lfd >= 0) { close(lfd); snprintf(path, sizeof path, "%s/r%d.sock", dir, me); (void) unlink(path); }
+	const int big = 4 << 20;
+	for (int j = 0; j < G; j++) if (fds_row[j] >= 0) { (void) setsockopt(fds_row[j], SOL_SOCKET, SO_SNDBUF, &big, sizeof big); (void) setsockopt(fds_row[j], SOL_SOCKET, SO_RCVBUF, &big, sizeof big); }
+	if (rc) for (int j = 0; j < G; j++) if (fds_row[j] >= 0) { close(fds_row[j]); fds_row[j] = -1; }
+	return rc;
 }
 
 void vdjx_comm_sockets_keep(int G, int me, int* fds) {

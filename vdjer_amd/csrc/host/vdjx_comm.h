@@ -31,6 +31,10 @@ typedef struct vdjx_comm vdjx_comm;
 /* Before the fork: fds[i*nranks + j] = the descriptor rank i talks to rank j with (-1 where there is none).  mesh = 0: only the pairs
  * with rank 0 (control; enough for the "rccl" transport); mesh = 1: every pair.  0 on success. */
 int vdjx_comm_sockets(int nranks, int mesh, int* fds);
+/* Ranks that are separate processes already (started one per GPU by a launcher: bench.py under torch.distributed.run): they meet in a
+ * directory they all know -- rank i listens on <dir>/r<i>.sock, the higher ranks call it -- and get the same row the table above would
+ * have given them (fds_row[j] = the descriptor to rank j; mesh as above).  Collective over the ranks; 0 on success. */
+int vdjx_comm_rendezvous(const char* dir, int me, int nranks, int mesh, int* fds_row);
 /* After the fork, in rank `me`: closes every descriptor that is not this rank's. */
 void vdjx_comm_sockets_keep(int nranks, int me, int* fds);
 

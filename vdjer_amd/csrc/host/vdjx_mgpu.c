@@ -18,7 +18,7 @@
 #include <hip/hip_runtime_api.h>
 
 enum { WS_SDIR, WS_RDIR, WS_SPARTS, WS_RPARTS, WS_Q, WS_RQ, WS_ANS, WS_RANS, WS_SURV, WS_SURV_ALL, WS_MINS, WS_UCNT, WS_A, WS_B, WS_C, WS_D, WS_SLOTS };
-enum { CMD_QUIT = 1, CMD_WINDOWS = 2, CMD_SAM = 3 };
+enum { CMD_QUIT = 1, CMD_WINDOWS = 2, CMD_SAM = 3, CMD_YIELD = 4 };
 
 struct vdjx_mgpu {
 	int rank, nranks, device;
@@ -292,6 +292,27 @@ int vdjx_mgpu_kmer_build_pool(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool
 	return kmer_build_any(m, ctx, pool, k, mf, mq, rec_stride, NULL, 0, out);
 }
 
+/* the same over a pool the caller packed itself that is this rank's SHARE of a pool of total_records records (by pair, any dealing that keeps the
+ * scan order): record i at scan position d_scan_index[i] (device array, ascending) -- what vdjx_mgpu_load + vdjx_mgpu_kmer_build do for records
+ * that start on the host */
+int vdjx_mgpu_kmer_build_share(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, const uint32_t* d_scan_index, uint64_t total_records, vdjx_graph** out) {
+	if (!d_scan_index) return fail(VDJX_EINVAL, "vdjx_mgpu_kmer_build_share: NULL scan index");
+	return kmer_build_any(m, ctx, pool, k, mf, mq, 0, d_scan_index, total_records, out);
+}
+
+/* the ranks' largest value of `mine` (the record stride of vdjx_mgpu_kmer_build_pool is the largest pool of any rank) */
+int vdjx_mgpu_agree_max(vdjx_mgpu* m, uint64_t mine, uint64_t* most) {
+	int rc = 0;
+	uint64_t* all = (uint64_t*) calloc((size_t) m->nranks, 8);
+	if (!all) return fail(VDJX_EINVAL, "out of memory");
+	CX(vdjx_comm_allgather_host(m->cm, &mine, 8, all));
+	*most = 0;
+	for (int r = 0; r < m->nranks; r++) if (all[r] > *most) *most = all[r];
+done:
+	free(all);
+	return rc;
+}
+
 int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, int k, int mf, int mq, vdjx_graph** out) {
 	if (!m->share_pool) return fail(VDJX_ESTATE, "vdjx_mgpu_kmer_build: call vdjx_mgpu_load first");
 	int rc = kmer_build_any(m, ctx, m->share_pool, k, mf, mq, 0, (const uint32_t*) m->d_scan, m->total_records, out);
@@ -310,7 +331,7 @@ int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, int k, int mf, int mq, vdj
 /* ------------------------------------------------------------------------------------------------------------------ */
 /* the window scorer (every rank, the same windows)                                                                    */
 /* ------------------------------------------------------------------------------------------------------------------ */
-static int do_window_score(vdjx_mgpu* m, vdjx_ctx* ctx, const char* windows, size_t n, int len, const vdjx_cov_params* p, uint8_t* out_valid) {
+static int do_window_score(vdjx_mgpu* m, vdjx_ctx* ctx, const char* windows, size_t n, int len, const vdjx_cov_params* p, uint8_t* out_valid, uint32_t* out_npairs) {
 	int rc = 0;
 	const int G = m->nranks, me = m->rank;
 	const size_t nmax = (n + (size_t) G - 1) / (size_t) G, n_mine = n > (size_t) me ? (n - (size_t) me + (size_t) G - 1) / (size_t) G : 0;
@@ -348,6 +369,14 @@ static int do_window_score(vdjx_mgpu* m, vdjx_ctx* ctx, const char* windows, siz
 	lap(m, "windows: gather of the verdicts");
 	for (int o = 0; o < G; o++)
 		for (size_t w = (size_t) o, j = 0; w < n; w += (size_t) G, j++) out_valid[w] = all_valid[(size_t) o * nmax + j];
+	if (out_npairs) {                     /* mapped pairs per window over all shares (a pair lives on one rank: the counts add) */
+		if (G == 1) memcpy(out_npairs, npairs, n * 4);
+		else {
+			CX(vdjx_comm_allgather_host(m->cm, npairs, n * 4, all_ent));
+			for (size_t w = 0; w < n; w++) { uint32_t s = 0; for (int r = 0; r < G; r++) s += all_ent[(size_t) r * n + w]; out_npairs[w] = s; }
+		}
+		lap(m, "windows: sum of the pair counts");
+	}
 done:
 	free(ent); free(npairs); free(all_ent); free(send_ids); free(counts); free(send_counts); free(recv_counts); free(mine); free(all_valid);
 	return rc;
@@ -424,19 +453,31 @@ done:
 /* rank 0's calls and the other ranks' service loop                                                                    */
 /* ------------------------------------------------------------------------------------------------------------------ */
 int vdjx_mgpu_window_score(vdjx_mgpu* m, vdjx_ctx* ctx, const char* windows, size_t n, int len, const vdjx_cov_params* p, uint8_t* out_valid) {
+	return vdjx_mgpu_window_score2(m, ctx, windows, n, len, p, out_valid, NULL);
+}
+
+int vdjx_mgpu_window_score2(vdjx_mgpu* m, vdjx_ctx* ctx, const char* windows, size_t n, int len, const vdjx_cov_params* p, uint8_t* out_valid, uint32_t* out_npairs) {
 	int rc = 0;
 	if (m->rank != 0) return fail(VDJX_ESTATE, "vdjx_mgpu_window_score is rank 0's call");
 	if (!n) return 0;
 	if (m->nranks > 1) {
-		const uint64_t cmd[4] = {CMD_WINDOWS, n, (uint64_t) len, 0};
+		const uint64_t cmd[4] = {CMD_WINDOWS, n, (uint64_t) len, out_npairs ? 1u : 0u};
 		vdjx_cov_params pc = *p;
 		CX(vdjx_comm_command_send(m->cm, cmd));
 		CX(vdjx_comm_bcast_host(m->cm, &pc, sizeof pc));
 		CX(vdjx_comm_bcast_host(m->cm, (void*) windows, n * (size_t) len));
 	}
-	rc = do_window_score(m, ctx, windows, n, len, p, out_valid);
+	rc = do_window_score(m, ctx, windows, n, len, p, out_valid, out_npairs);
 done:
 	return rc;
+}
+
+/* rank 0: the other ranks' vdjx_mgpu_serve_step returns (they stay in the job: the next step's collective calls follow) */
+int vdjx_mgpu_yield(vdjx_mgpu* m) {
+	if (m->rank != 0 || m->nranks == 1) return 0;
+	const uint64_t cmd[4] = {CMD_YIELD, 0, 0, 0};
+	const int rc = vdjx_comm_command_send(m->cm, cmd);
+	return rc ? fail(rc, "%s", vdjx_comm_last_error()) : 0;
 }
 
 typedef struct { const char* text; uint64_t bytes; char* own; uint64_t cap; } sam_acc;
@@ -495,19 +536,25 @@ int vdjx_mgpu_finish(vdjx_mgpu* m) {
 	return rc ? fail(rc, "%s", vdjx_comm_last_error()) : 0;
 }
 
-int vdjx_mgpu_serve(vdjx_mgpu* m, vdjx_ctx* ctx) {
+/* out_valid / out_npairs (cap entries, may be NULL): the verdicts and pair counts of the LAST window call served -- every rank computes
+ * them all (do_window_score), so a caller that goes on with the same step on every rank (bench.py: the pair emission of the accepted
+ * windows against the own share) has them without another exchange.  *released = 1: rank 0 quit the job; 0: it yielded. */
+static int serve_impl(vdjx_mgpu* m, vdjx_ctx* ctx, int until_yield, uint8_t* out_valid, uint32_t* out_npairs, size_t cap, size_t* n_out, int* released) {
 	int rc = 0;
 	char *a = NULL, *b = NULL;
-	uint32_t* off = NULL;
+	uint32_t *off = NULL, *np = NULL;
 	uint8_t* valid = NULL;
+	if (n_out) *n_out = 0;
+	if (released) *released = 0;
 	if (m->rank == 0) return fail(VDJX_ESTATE, "rank 0 does not serve");
 	for (;;) {
 		uint64_t cmd[4];
 		const int w = vdjx_comm_command_wait(m->cm, cmd);
 		if (w) { rc = fail(w < 0 ? w : -5, "rank %d: rank 0 is gone", m->rank); goto done; }
-		free(a); free(b); free(off); free(valid);
-		a = b = NULL; off = NULL; valid = NULL;
-		if (cmd[0] == CMD_QUIT) break;
+		free(a); free(b); free(off); free(valid); free(np);
+		a = b = NULL; off = NULL; valid = NULL; np = NULL;
+		if (cmd[0] == CMD_QUIT) { if (released) *released = 1; break; }
+		if (cmd[0] == CMD_YIELD) { if (until_yield) break; continue; }
 		const size_t n = (size_t) cmd[1];
 		const int len = (int) cmd[2];
 		if (cmd[0] == CMD_WINDOWS) {
@@ -515,9 +562,15 @@ int vdjx_mgpu_serve(vdjx_mgpu* m, vdjx_ctx* ctx) {
 			a = (char*) malloc(n * (size_t) len + 1);
 			valid = (uint8_t*) malloc(n + 1);
 			if (!a || !valid) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; }
+			if (cmd[3]) { np = (uint32_t*) malloc((n + 1) * 4); if (!np) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; } }
 			CX(vdjx_comm_bcast_host(m->cm, &pc, sizeof pc));
 			CX(vdjx_comm_bcast_host(m->cm, a, n * (size_t) len));
-			if ((rc = do_window_score(m, ctx, a, n, len, &pc, valid))) goto done;
+			if ((rc = do_window_score(m, ctx, a, n, len, &pc, valid, np))) goto done;
+			if (n_out) {
+				*n_out = n;
+				if (out_valid && n <= cap) memcpy(out_valid, valid, n);
+				if (out_npairs && np && n <= cap) memcpy(out_npairs, np, n * 4);
+			}
 		} else if (cmd[0] == CMD_SAM) {
 			a = (char*) malloc(n * (size_t) len + 1);
 			off = (uint32_t*) malloc((n + 1) * 4);
@@ -530,6 +583,12 @@ int vdjx_mgpu_serve(vdjx_mgpu* m, vdjx_ctx* ctx) {
 		} else { rc = fail(VDJX_EINVAL, "rank %d: unknown command %llu", m->rank, (unsigned long long) cmd[0]); goto done; }
 	}
 done:
-	free(a); free(b); free(off); free(valid);
+	free(a); free(b); free(off); free(valid); free(np);
 	return rc;
+}
+
+int vdjx_mgpu_serve(vdjx_mgpu* m, vdjx_ctx* ctx) { return serve_impl(m, ctx, 0, NULL, NULL, 0, NULL, NULL); }
+
+int vdjx_mgpu_serve_step(vdjx_mgpu* m, vdjx_ctx* ctx, uint8_t* out_valid, uint32_t* out_npairs, size_t cap, size_t* n_out, int* released) {
+	return serve_impl(m, ctx, 1, out_valid, out_npairs, cap, n_out, released);
 }

@@ -50,10 +50,18 @@ int vdjx_mgpu_kmer_build(vdjx_mgpu* m, vdjx_ctx* ctx, int k, int mf, int mq, vdj
 /* the same over pools the caller made itself (every rank passes its slice: records [rank*rec_stride, ...) of the scan order) */
 int vdjx_mgpu_kmer_build_pool(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, uint64_t rec_stride, vdjx_graph** out);
 
+/* the same over a pool the caller packed itself that is this rank's SHARE of a pool of total_records records: record i at scan position
+ * d_scan_index[i] (device array, ascending; it must stay valid until the call returns) */
+int vdjx_mgpu_kmer_build_share(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, const uint32_t* d_scan_index, uint64_t total_records, vdjx_graph** out);
+/* collective: the ranks' largest value of `mine` (e.g. the record stride of vdjx_mgpu_kmer_build_pool: the largest pool of any rank) */
+int vdjx_mgpu_agree_max(vdjx_mgpu* m, uint64_t mine, uint64_t* most);
+
 /* ---- rank 0 (the others are inside vdjx_mgpu_serve) ---- */
 /* quick_map_process_contig + coverage_is_valid (A2:841-847) for n windows over the sharded pool: every rank maps every window against
  * its reads, window w's pair lists meet on rank w % N, which tests their union */
 int vdjx_mgpu_window_score(vdjx_mgpu* m, vdjx_ctx* ctx, const char* windows, size_t n, int len, const vdjx_cov_params* p, uint8_t* out_valid);
+/* the same, and out_npairs[w] (may be NULL) = the mapped pairs of window w over all shares */
+int vdjx_mgpu_window_score2(vdjx_mgpu* m, vdjx_ctx* ctx, const char* windows, size_t n, int len, const vdjx_cov_params* p, uint8_t* out_valid, uint32_t* out_npairs);
 /* the SAM records of the mapped pairs of n contigs (quick_map_process_contig_file -> output_mapping, quick_map3.c:152-181, 311-340) in
  * the reference's order: every rank formats its pairs' records (vdjx_sam_blocks), rank 0 merges them (vdjx_sam_merge).  The text
  * belongs to the context (valid until the next call). */
@@ -63,6 +71,11 @@ int vdjx_mgpu_sam_body(vdjx_mgpu* m, vdjx_ctx* ctx, const char* contigs, size_t 
 int vdjx_mgpu_finish(vdjx_mgpu* m);
 /* ---- ranks other than 0: serves rank 0's calls until vdjx_mgpu_finish; 0 when released ---- */
 int vdjx_mgpu_serve(vdjx_mgpu* m, vdjx_ctx* ctx);
+/* A job of several steps (bench.py --gpus N: every step a collective build, then rank 0's scorer calls): rank 0 ends a step's scorer
+ * calls with vdjx_mgpu_yield, the others' vdjx_mgpu_serve_step returns there (*released = 0) -- or when rank 0 finishes (*released = 1).
+ * out_valid / out_npairs (cap entries each, may be NULL): verdicts and pair counts of the last window call served; *n_out its windows. */
+int vdjx_mgpu_yield(vdjx_mgpu* m);
+int vdjx_mgpu_serve_step(vdjx_mgpu* m, vdjx_ctx* ctx, uint8_t* out_valid, uint32_t* out_npairs, size_t cap, size_t* n_out, int* released);
 
 #ifdef __cplusplus
 }

@@ -270,6 +270,7 @@ struct vdjx_graph {
 
 bool vdjx_ctx_alive(const vdjx_ctx* c);   // a pool or graph may be freed after its context
 int vdjx_ri_join(vdjx_ctx* c);            // waits for a begun read-index build (vdjx_rindex.hip); its status, VDJX_OK if none is in flight
+void vdjx_ri_open_gate(vdjx_ctx* c);      // a begun build that waits for the k-mer build's graph pass may start (no-op without one)
 bool vdjx_host_block_holds(vdjx_ctx* c, const void* p, size_t bytes);   // [p, p + bytes) inside a block of vdjx_host_alloc (vdjx_core.hip)
 
 // scoped workspace allocations out of the context's arena

@@ -3203,6 +3203,7 @@ int kmer_build_impl2(vdjx_ctx* c, const vdjx_pool* pool, int k, int mf, int mq, 
 	SurvivorsG sv;
 	rc = stage_gated_reduce<TUP>(c, db, t, pv, 0, k, mf, mq, &sv, sym);
 	if (rc) return rc;
+	vdjx_ri_open_gate(c);          // phase A is done: a begun read-index build of this context runs beside the graph pass (vdjx_rindex.hip)
 	dbg_sync(c, "gated_reduce");
 	g->pre_nodes = (size_t) sv.ndist;
 	RecountOut ro{};
@@ -3480,6 +3481,7 @@ extern "C" int vdjx_shard_local(vdjx_shard* s, uint64_t* send_counts, uint32_t* 
 	vdjx_clear_errors();
 	int rc = s->wide ? shard_local_impl<Tup24>(s) : shard_local_impl<Tup16>(s);
 	if (rc) return rc;
+	vdjx_ri_open_gate(s->c);       // the local phase A is done: a begun read-index build runs beside the exchange and the graph pass
 	for (int g = 0; g < s->nranks; g++) send_counts[g] = s->src_base[g + 1] - s->src_base[g];
 	*dir_len = s->NBo;
 	s->phase = 1;

@@ -18,6 +18,7 @@
 
 #include <string.h>
 #include <thread>
+#include <condition_variable>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_merge.hpp>
 
@@ -817,11 +818,31 @@ struct vdjx_ri_job {
 	int rc = VDJX_OK;
 	std::string err;
 	std::map<std::string, uint64_t> stats;
+	// the gate: the thread launches nothing before it opens.  Measured (profiles/overlap.py, 10 M pairs): beside phase A of the k-mer build
+	// -- the streaming histogram / partition kernels, which fill the machine on their own -- both sides only stretch (k_part_records 2.5x,
+	// k_gated_hist 2.5x, k_ri_fold_big 6x: 12.3 ms of work done in 11.4); the graph pass is where the device waits on dependent probes
+	// with most of its bandwidth idle.  So the k-mer build opens the gate when its phase A is done (vdjx_ri_open_gate), and so does
+	// whoever asks for the index first
+	std::mutex mu;
+	std::condition_variable cv;
+	bool go = false;
 };
+
+void vdjx_ri_open_gate(vdjx_ctx* c) {
+	vdjx_ri_job* j = c->ri_job;
+	if (!j) return;
+	{
+		std::lock_guard<std::mutex> lk(j->mu);
+		if (j->go) return;
+		j->go = true;
+	}
+	j->cv.notify_all();
+}
 
 int vdjx_ri_join(vdjx_ctx* c) {
 	vdjx_ri_job* j = c->ri_job;
 	if (!j) return VDJX_OK;
+	vdjx_ri_open_gate(c);
 	if (j->th.joinable()) j->th.join();
 	c->ri_job = nullptr;
 	for (auto& kv : j->stats) c->stats[kv.first] = kv.second;
@@ -849,7 +870,13 @@ int ri_begin(vdjx_ctx* c, const vdjx_pool* pool, const uint32_t* pair_id, const 
 	vdjx_ri_job* j = new vdjx_ri_job();
 	c->ri_job = j;
 	const int device = c->device;
+	static const bool gated = !(getenv("VDJX_RI_GATE") && getenv("VDJX_RI_GATE")[0] == '0');      // (VDJX_RI_GATE=0: start at once, beside whatever comes)
+	j->go = !gated;
 	j->th = std::thread([=]() {
+		{
+			std::unique_lock<std::mutex> lk(j->mu);
+			j->cv.wait(lk, [&] { return j->go; });
+		}
 		if (hipSetDevice(device) != hipSuccess) { j->rc = VDJX_EHIP; j->err = "vdjx_read_index_build_begin: hipSetDevice failed on the index thread"; return; }
 		vdjx_work db(c, &c->ri_arena);
 		hipStream_t st = c->ri_stream;
