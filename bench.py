@@ -123,7 +123,61 @@ def workload_label(pairs: int, k: int, mf: int, mq: int, mrs: int, ins: int, wor
         tag = "BASELINE.json configs[1]; SURVEY §8d C2"
     else:
         tag = "custom size"
+    if REP_KW:
+        tag += ("; --repertoire private: every clone over a germline V of its own, Zipf 0.25, one clone per 4,000 pairs -- BASELINE size on a repertoire the "
+                "reference's serial traversal finishes (tests/golden/midscale.json cfg2_pv)")
     return f"synthetic {pairs} 50bp PE pairs per GPU, IGH, k={k} mf={mf} mq={mq} mrs={mrs} ins={ins} ({tag})"
+
+
+def cli_at_size(args, rep, pool) -> dict | None:
+    """--cli-at-size: this build's whole command line (vdjer_amd/vdjer) on the FULL-SIZE pool of --repertoire private -- the reads file written from
+    the very pool the bench times -- against the committed digests of the reference's complete --t 1 run on it (tests/golden/midscale.json,
+    made once in the build container by tests/golden/make_golden_midscale.py: ~25 minutes of the reference)."""
+    from tests import midscale_util as M
+    from vdjer_amd import synth
+    flags = ["--k", str(args.k), "--mf", str(args.mf), "--mq", str(args.mq), "--mrs", str(args.mrs)]
+    gold = next((c for c in M.cases().values() if c.get("private_v") and (c["pairs"], c["clones"], c["seed"], c["ins"]) == (args.pairs, args.clones, args.seed, args.ins)
+                 and c["flags"] == flags), None)
+    exe = os.path.join(ROOT, "vdjer_amd", "vdjer")
+    if gold is None or not os.path.exists(exe):
+        return {"skipped": "no committed reference digest for this workload (tests/golden/midscale.json) or vdjer not built"}
+    with tempfile.TemporaryDirectory() as td:
+        t_w = time.perf_counter()
+        (pool.to_host() if hasattr(pool, "to_host") else pool).write_reads_file(os.path.join(td, "reads.txt"))
+        synth.write_ref_dir(rep, os.path.join(td, "ref"))
+        t_w = time.perf_counter() - t_w
+        cmd = [exe, "--in", "reads.txt", "--chain", "IGH", "--ref-dir", "ref", "--ins", str(args.ins), "--t", str(min(os.cpu_count() or 1, 100))] + flags
+        t0 = time.perf_counter()
+        ms = {}
+        with open(os.path.join(td, "out.sam"), "wb") as so:
+            pr = subprocess.Popen(cmd, cwd=td, stdout=so, stderr=subprocess.PIPE, text=True, errors="replace", env=dict(os.environ, VDJH_ROOT_LOG="roots.log", VDJX_TIMES="1"))
+            tail = []
+            for line in pr.stderr:
+                if line.startswith("VDJX_TIMES\t"):
+                    f_ = line.rstrip("\n").split("\t")
+                    ms.setdefault(f_[1], float(f_[2]))
+                tail.append(line)
+                tail = tail[-12:]
+            pr.wait()
+        wall = time.perf_counter() - t0
+        mine = {key: (M.digest_file(os.path.join(td, fn)) if os.path.exists(os.path.join(td, fn)) else None)
+                for key, fn in (("fasta", "vdj_contigs.fa"), ("sam", "out.sam"), ("dot", "vdjer.dot"), ("root_log", "roots.log"))}
+
+    def seg(a, b):
+        return round(ms[b] - ms[a], 1) if a in ms and b in ms else None
+    return {"pairs": args.pairs, "clones": args.clones, "exit_code": pr.returncode, "wall_s_process": round(wall, 2), "reads_file_written_s": round(t_w, 1),
+            "contigs": (mine["fasta"] or {}).get("lines", 0) // 2, "sam_lines": (mine["sam"] or {}).get("lines"),
+            "outputs_identical_to_reference": all(mine[f_] == gold[f_] for f_ in ("fasta", "sam", "dot")), "root_verdicts_identical": mine["root_log"] == gold["root_log"],
+            "differs": [f_ for f_ in ("fasta", "sam", "dot", "root_log") if mine[f_] != gold[f_]],
+            "reference": {"contigs": gold["contigs"], "roots": gold["roots"], "roots_accepted": gold["roots_accepted"], "wall_s": gold.get("reference_wall_s"),
+                          "complete_runs": gold.get("complete_runs"), "source": "tests/golden/midscale.json (complete --t 1 runs of oracle/_ref/vdjer_ref, all identical)"},
+            "process_breakdown_ms": {"input_read_and_parsed": seg("START", "(inputs read)"), "pool_load": seg("POST_VJF_INIT", "(pool loaded)"),
+                                     "read_index_plus_kmer_build": seg("(pool loaded)", "(read index ended)"),
+                                     "traversal_and_scorers": seg("POST_BUILD_GRAPH2", "THREADS_DONE"), "overlap_removal_fasta_sam": seg("THREADS_DONE", "PRE_CLEANUP")},
+            "stderr_tail": None if pr.returncode == 0 else "".join(tail)[-1500:]}
+
+
+REP_KW = {}          # generator parameters of --repertoire private (make_repertoire keywords), set by main()
 
 
 def make_workload(n_pairs: int, n_clones: int, seed: int, rank: int, world: int, device: str, chain: str = "IGH", ci: int = 0):
@@ -133,9 +187,10 @@ def make_workload(n_pairs: int, n_clones: int, seed: int, rank: int, world: int,
     GPU -- the definition of weak scaling (SURVEY §8d scales clones with pairs the same way: 1 M / 2,000 ... 100 M / 100,000).
     The pool is generated in HBM by the counter-based generator (bit-identical to its CPU evaluation)."""
     from vdjer_amd import synth
-    libs = [synth.make_repertoire(n_clones, seed=seed + 15485863 * r + 7 * ci, chain=chain) for r in range(world)]
+    libs = [synth.make_repertoire(n_clones, seed=seed + 15485863 * r + 7 * ci, chain=chain, **REP_KW) for r in range(world)]
     rep = libs[rank]
-    pool = synth.make_reads_cb(rep, n_pairs, noise_frac=0.3, seed=seed + 104729 * rank + 1000 * ci, device=device)
+    # (--repertoire private on one GPU: the very pool of tests/golden/midscale.json's cfg2_pv -- seed + 13 -- so that its reference digests apply)
+    pool = synth.make_reads_cb(rep, n_pairs, noise_frac=0.3, seed=seed + (13 if REP_KW and world == 1 and ci == 0 else 104729 * rank + 1000 * ci), device=device)
     vc = np.array(sorted({synth.seq_to_int(a) for lb in libs for a in lb.v_anchors}), dtype=np.uint32)
     jc = np.array(sorted({synth.seq_to_int(a) for lb in libs for a in lb.j_anchors}), dtype=np.uint32)
     return rep, pool, vc, jc, [lb.v_region for lb in libs]
@@ -405,7 +460,16 @@ def main():
                          "V region, pool packing, read index, sharded k-mer build over the pool dealt by pair, scorers -- per chain).  The default with --gpus 8")
     ap.add_argument("--no-config4", action="store_true", help="--gpus 8 as weak scaling of configs[2]-sized IGH pools, like --gpus 2 / 4")
     ap.add_argument("--chains", default=None, help="comma-separated chain presets of a --config4 step (default IGH,IGK,IGL)")
-    ap.add_argument("--clones", type=int, default=0, help="clones per GPU (default: pairs / 500)")
+    ap.add_argument("--clones", type=int, default=0, help="clones per GPU (default: pairs / 500; --repertoire private: pairs / 4000)")
+    ap.add_argument("--repertoire", choices=["survey", "private"], default="survey",
+                    help="survey: SURVEY 8d's repertoire (60 germline V segments shared by all clones, Zipf 1.1) -- the reference's contig enumeration does not "
+                         "end on it above ~1.5 M pairs, so the windows come from the generator there.  private: every clone over a germline V of its own, "
+                         "abundance Zipf 0.25, one clone per 4,000 pairs (tests/golden/make_golden_midscale.py cfg2_pv): the serial traversal TERMINATES at "
+                         "10 M pairs (reference: ~25 min at --t 1, 2 k contigs), so the scorers get the windows the reference's DFS really asks for and the "
+                         "whole command line is compared with the reference's bytes at BASELINE size (--cli-at-size)")
+    ap.add_argument("--cli-at-size", action="store_true",
+                    help="--repertoire private only: run this build's `vdjer` on the full-size pool (written as a reads file) and compare vdj_contigs.fa / SAM / "
+                         "vdjer.dot / root verdicts with the committed digests of the reference's complete --t 1 run (tests/golden/midscale.json cfg2_pv)")
     ap.add_argument("--k", type=int, default=35)
     ap.add_argument("--mf", type=int, default=3)
     ap.add_argument("--mq", type=int, default=90)
@@ -438,6 +502,12 @@ def main():
         args.force_shard = True          # configs[4] runs only through the sharded path (one rank: the same phases, nothing to exchange)
         args.no_e2e = True
         args.windows = "generator"
+    if args.repertoire == "private":
+        REP_KW.update(private_v=True, zipf_s=0.25)
+        if args.clones <= 0:
+            args.clones = max(4, args.pairs // 4000)
+        if args.windows == "auto":
+            args.windows = "traversal"
     if args.clones <= 0:
         # clones per GPU: 1 per 500 pairs like configs[1..3] (1 M / 2,000, 10 M / 20,000); configs[4] is 100 M pairs of 100,000 clones
         # (SURVEY §8d C5): 1 per 1,000
@@ -612,7 +682,7 @@ def main():
             libs_w = [w for w in w_["rep"].windows() if w]
             if world > 1:
                 from vdjer_amd import synth
-                libs_w = [w for r in range(world) for w in synth.make_repertoire(args.clones, seed=args.seed + 15485863 * r + 7 * w_["ci"], chain=w_["chain"]).windows() if w]
+                libs_w = [w for r in range(world) for w in synth.make_repertoire(args.clones, seed=args.seed + 15485863 * r + 7 * w_["ci"], chain=w_["chain"], **REP_KW).windows() if w]
             w_["wins"] = libs_w
         wins = W[0]["wins"]
         contigs_fixed = None
@@ -938,6 +1008,11 @@ def main():
         if not parity:
             raise SystemExit("parity gate failed: HIP k-mer build differs from the oracle")
 
+    if engine is not None:          # the job ends the way `vdjer --gpus N` ends: rank 0 releases the others (VDJX_TIMES=1: its per-phase laps on stderr)
+        if rank == 0:
+            engine.finish()
+        else:
+            engine.serve_step(1)
     if rank != 0:
         return
     ms_step = dt / args.steps * 1e3
@@ -1055,6 +1130,7 @@ def main():
         if cpu is None:           # no compiled reference on this box: the -O2 port is the stated baseline
             cpu = cpu_port_legs[0]
     cli_e2e = cpu.pop("cli_end_to_end", None) if cpu else None
+    cli_size = cli_at_size(args, rep, pool) if (args.cli_at_size and REP_KW and world == 1) else None
     kern_ms = {k_: round(v[0] / prof_steps, 4) for k_, v in prof.items()}
     out = {
         "metric": "M paired-reads/sec (k-mer build + contig score), IgH 50bp PE", "value": round(value, 4),
@@ -1070,7 +1146,7 @@ def main():
         "roofline": roof, "roofline_by_kernel": by_kernel, "cpu_baseline": cpu, "cpu_baseline_port_legs": cpu_port_legs,
         "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
         "value_end_to_end": e2e, "value_with_read_index": with_index, "first_step_ms": round(first_step_ms, 3) if first_step_ms else None, "first_step_phases_ms": first_step_phases,
-        "cli_end_to_end": cli_e2e,
+        "cli_end_to_end": cli_e2e, "cli_at_size": cli_size,
         "kernels_ms_per_step": kern_ms, "kernels_sum_ms_per_step": round(sum(kern_ms.values()), 3),
         "device_busy_frac": round(sum(kern_ms.values()) / prof_ms_step, 4) if prof_ms_step else None,
         "instrumentation": ({"timed_region_events": f"{dom_name} only (the roofline kernel: roofline.avg_launch_ms / achieved / frac are measured inside the timed region)",

@@ -341,7 +341,8 @@ int vdjx_shard_begin(vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq
 int vdjx_shard_begin_share(vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, int rank, int nranks,
                            const uint32_t* d_scan_index, uint64_t total_records, vdjx_shard** out);
 void vdjx_shard_free(vdjx_shard* s);
-/* bytes per exchanged record: kind 0 partial aggregate (32), 1 question (8), 2 answer (240), 3 survivor (32) */
+/* bytes per exchanged record: kind 0 partial aggregate (32), 1 question (8), 2 answer (408: 240 for the k-mer -- the holder's first record,
+ * its quality rows -- and, for builds over couples, 168 more for its reverse complement's; always ask, never assume), 3 survivor (32) */
 size_t vdjx_shard_record_bytes(int kind);
 /* optional, before vdjx_shard_local: this rank's gated k-mer instances (A2:240-259); the ranks compare them [all_reduce MAX] and pass
  * the largest to vdjx_shard_geometry, so that every rank cuts the hash buckets the one-GPU build would cut for the largest rank.

@@ -33,15 +33,32 @@ def main():
                   "(several launches under one HIP-event name): hbm_bytes is PER STEP, summed over the member kernels (composite_of).  `step`: every "
                   "dispatch of a timed step, all kernels",
           "commit": commit, "passes": tag, "pairs_per_gpu": pairs, "k": k, "windows": cfg.get("windows", "generator"), "variant": variant, "kernels": {}}
-    for name, v in pm.items():
-        if "hbm_bytes" in v and name.startswith("k_"):
-            tr["kernels"][back.get(name, name)] = {"hbm_bytes": v["hbm_bytes"], "fetch_kb": v.get("FETCH_SIZE"), "write_kb": v.get("WRITE_SIZE"),
-                                                   "traffic_rule": v.get("traffic_rule")}
-        elif "hbm_bytes_per_step" in v:
-            tr["kernels"][name] = {"hbm_bytes": v["hbm_bytes_per_step"], "composite_of": v.get("composite_of"), "launches_per_step": v.get("launches_per_step"),
-                                   "traffic_rule": "sum over the member kernels, per step"}
+    rbk = b.get("roofline_by_kernel", {})
+    per_step = (step or {}).get("per_kernel", {})
+
+    def scopes_per_step(name):          # how often the HIP-event scope of that name is opened per step (k_chain_order: twice; config4: per chain)
+        v = rbk.get(name, {}).get("launches_per_step")
+        return v if isinstance(v, (int, float)) and v > 0 else 1
+
+    def step_bytes(name):               # counted fabric bytes per STEP of a scope: its kernel's (or, a composite, its member kernels') dispatches of a timed step
+        v = pm.get(alias.get(name, name), {})
+        members = v.get("composite_of") or [alias.get(name, name)]
+        got = [per_step[m_]["fabric_bytes_per_step"] for m_ in members if m_ in per_step]
+        return float(sum(got)) if got else None
+    for name in b["kernels_ms_per_step"]:
+        v = pm.get(alias.get(name, name), {})
+        sbytes = step_bytes(name)
+        if sbytes is None:
+            continue
+        tr["kernels"][name] = {"hbm_bytes": int(sbytes / scopes_per_step(name)), "hbm_bytes_per_step": int(sbytes), "scopes_per_step": scopes_per_step(name),
+                               "composite_of": v.get("composite_of"), "fetch_kb_median_launch": v.get("FETCH_SIZE"), "write_kb_median_launch": v.get("WRITE_SIZE"),
+                               "traffic_rule": v.get("traffic_rule") or "sum over the member kernels' dispatches of a timed step"}
+    for name, v in pm.items():          # (kernels outside the step's scopes -- the read index's -- keep the median launch)
+        if "hbm_bytes" in v and name.startswith("k_") and back.get(name, name) not in tr["kernels"]:
+            tr["kernels"][back.get(name, name)] = {"hbm_bytes": v["hbm_bytes"], "traffic_rule": v.get("traffic_rule")}
     if step:
         tr["step"] = {k_: v_ for k_, v_ in step.items() if k_ != "per_kernel"}
+        tr["step"]["note"] = "hbm_bytes of a scope = its dispatches' bytes of a timed step / the scope's openings per step (what bench.py divides by that scope's average duration)"
     json.dump(tr, open(os.path.join(HERE, f"{rnd}_traffic{'_' + variant if variant else ''}.json"), "w"), indent=1, sort_keys=True)
     st = dict(b["scorer_stats"])
     gi = st.get("gated_instances")
@@ -49,21 +66,17 @@ def main():
     sb = bench.scorer_bytes(st, b["counts"]["windows"], b["counts"]["n_contigs_rank"], k)
     svb = bench.survivor_bytes(int(b["counts"].get("nodes", 0)) + int(st.get("kmer_build_shadows", 0)), k)
     skip = ("P", "input", "total", "gated_per_pair", "model_all_records", "units_factor")
-    rbk = b.get("roofline_by_kernel", {})
     print(f"<!-- {tag}: {cfg['workload']} -- commit {commit} -->")
     print("| kernel | ms/step (HIP events) | rocprofv3 avg ms/launch x launches/step | model bytes/step (units launched) | achieved GB/s | frac of 8 TB/s | fabric traffic/step (PMC) | frac on traffic | traffic / model | L2 hit | wave-cycles waiting | LDS conflict | VALU issue share |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for name, ms in sorted(b["kernels_ms_per_step"].items(), key=lambda kv: -kv[1]):
         v = pm.get(alias.get(name, name), {})
-        lps = rbk.get(name, {}).get("launches_per_step")
-        lps = lps if isinstance(lps, (int, float)) else 1
+        t = step_bytes(name)
         if "hbm_bytes_per_step" in v:            # a composite scope
-            t = v["hbm_bytes_per_step"] * 1.0
             rp = f"{v.get('ns_per_step', 0) / 1e6:.3f} ({v.get('launches_per_step', 0):.0f} launches of {len(v.get('composite_of', []))} kernels)"
         else:
-            t = v.get("hbm_bytes")
-            t = t * lps if t else t
-            rp = f"{v.get('avg_ns', 0) / 1e6:.3f} x {lps:g}"
+            kl = per_step.get(alias.get(name, name), {}).get("launches_per_step", 1)
+            rp = f"{v.get('avg_ns', 0) / 1e6:.3f} x {kl:g}"
         if name in sb:
             algb = sb[name] * chains
         elif name in svb:
@@ -82,7 +95,7 @@ def main():
     if step:
         ms_step = b["ms_per_step"]
         print(f"\nstep as a whole: {step['bytes_per_step'] / 1e9:.2f} GB of counted fabric traffic per step ({step['kernels_counted']} kernels; bound {step['bytes_per_step_max'] / 1e9:.2f} GB) "
-              f"in {ms_step:.3f} ms = {step['bytes_per_step'] / (ms_step * 1e-3) / 1e12:.2f} TB/s = {step['bytes_per_step'] / (ms_step * 1e-3) / 1e9 / 8000:.3f} of the 8 TB/s peak "
+              f"in {ms_step:.3f} ms UNDER rocprofv3 (the bench line divides the same bytes by its own step time: roofline.step_traffic_frac) = {step['bytes_per_step'] / (ms_step * 1e-3) / 1e12:.2f} TB/s = {step['bytes_per_step'] / (ms_step * 1e-3) / 1e9 / 8000:.3f} of the 8 TB/s peak "
               f"(device busy {b.get('device_busy_frac')})")
 
 

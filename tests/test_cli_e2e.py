@@ -119,7 +119,8 @@ def test_vdjer_cli_gpus_n_ranks_share_one_device(tag, gpus, sam_pairs, tmp_path)
 
 
 @pytest.mark.parametrize("name,gpus,knobs", [("mid_400k", 1, "suite"), ("mid_400k", 1, "shipped"), ("mid_400k", 3, "suite"), ("mid_k25", 1, "suite"), ("mid_k25", 1, "shipped"),
-                                             ("mid_k25", 2, "shipped"), ("mid_cfg1", 1, "shipped"), ("mid_cfg1", 4, "suite"), ("mid_k25_mrs30", 1, "shipped"), ("mid_k25_mrs30", 2, "suite")])
+                                             ("mid_k25", 2, "shipped"), ("mid_cfg1", 1, "shipped"), ("mid_cfg1", 4, "suite"), ("mid_k25_mrs30", 1, "shipped"), ("mid_k25_mrs30", 2, "suite"),
+                                             ("cfg2_pv", 1, "shipped"), ("cfg2_pv", 4, "shipped")])
 def test_vdjer_cli_midscale_vs_reference_digests(name, gpus, knobs, tmp_path):
     """End to end at MID scale (tests/golden/midscale.json: complete --t 1 runs of the compiled reference on 200 k - 1 M pairs, hundreds
     to thousands of clones: thousands of roots, hundreds of candidate windows, tens of contigs, 10^5-10^6 SAM lines; mid_cfg1 is

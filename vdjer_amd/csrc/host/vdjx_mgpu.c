@@ -300,6 +300,9 @@ int vdjx_mgpu_kmer_build_share(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* poo
 	return kmer_build_any(m, ctx, pool, k, mf, mq, 0, d_scan_index, total_records, out);
 }
 
+/* the read length of the pools the scorers work on (vdjx_mgpu_load sets it; a caller that loads its own pools says so here) */
+void vdjx_mgpu_set_read_length(vdjx_mgpu* m, int rl) { if (m) m->rl = rl; }
+
 /* the ranks' largest value of `mine` (the record stride of vdjx_mgpu_kmer_build_pool is the largest pool of any rank) */
 int vdjx_mgpu_agree_max(vdjx_mgpu* m, uint64_t mine, uint64_t* most) {
 	int rc = 0;

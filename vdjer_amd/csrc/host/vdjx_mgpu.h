@@ -53,6 +53,9 @@ int vdjx_mgpu_kmer_build_pool(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool
 /* the same over a pool the caller packed itself that is this rank's SHARE of a pool of total_records records: record i at scan position
  * d_scan_index[i] (device array, ascending; it must stay valid until the call returns) */
 int vdjx_mgpu_kmer_build_share(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, int k, int mf, int mq, const uint32_t* d_scan_index, uint64_t total_records, vdjx_graph** out);
+/* the read length of the pools the scorer calls work on: set by vdjx_mgpu_load; a caller with pools of its own (vdjx_mgpu_kmer_build_pool /
+ * _share) says so before the first vdjx_mgpu_window_score */
+void vdjx_mgpu_set_read_length(vdjx_mgpu* m, int rl);
 /* collective: the ranks' largest value of `mine` (e.g. the record stride of vdjx_mgpu_kmer_build_pool: the largest pool of any rank) */
 int vdjx_mgpu_agree_max(vdjx_mgpu* m, uint64_t mine, uint64_t* most);
 

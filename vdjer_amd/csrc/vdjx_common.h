@@ -209,6 +209,11 @@ struct vdjx_ctx {
 	uint32_t* root_pending_ids = nullptr;
 	uint8_t* root_pending_out = nullptr;
 	hipEvent_t ev_root_done = nullptr;
+	// round 6: a begun root scoring runs on a stream and out of a workspace of its own -- its kernels are small (tens of thousands of roots,
+	// a wave per seed hit) and wait on dependent loads; the window scorer's kernels, which do not need the verdicts, run beside them
+	hipStream_t root_stream = nullptr;
+	hipEvent_t ev_root_go = nullptr;
+	vdjx_arena root_arena;
 	// SAM text (vdjx_sam_text): read names by pair id on the device, the text buffers
 	char* d_sam_names = nullptr;
 	u64* d_sam_noff = nullptr;
@@ -293,7 +298,8 @@ struct vdjx_prof_scope {
 	vdjx_ctx* c;
 	const char* name;
 	hipEvent_t a = nullptr, b = nullptr;
-	vdjx_prof_scope(vdjx_ctx* ctx, const char* nm);      // ctx == nullptr: nothing is bracketed (a launch on another stream than the context's)
+	hipStream_t st = nullptr;                             // the stream the launch goes to (null: the context's)
+	vdjx_prof_scope(vdjx_ctx* ctx, const char* nm, hipStream_t stream = nullptr);      // ctx == nullptr: nothing is bracketed (another THREAD's launches)
 	~vdjx_prof_scope();
 };
 void vdjx_prof_collect(vdjx_ctx* ctx, bool force = true);

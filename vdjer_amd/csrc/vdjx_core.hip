@@ -52,6 +52,8 @@ extern "C" int vdjx_init(int device, vdjx_ctx** out) {
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_root_done, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->ri_stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->root_stream, hipStreamNonBlocking);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_root_go, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ri_go, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipHostMalloc(&c->h_pin, VDJX_HPIN_BYTES, hipHostMallocDefault);
 	if (e != hipSuccess) { delete c; vdjx_set_error("hipStreamCreate: %s", hipGetErrorString(e)); return VDJX_EHIP; }
@@ -110,6 +112,9 @@ extern "C" void vdjx_shutdown(vdjx_ctx* c) {
 	if (c->ri_stream) { (void) hipStreamSynchronize(c->ri_stream); (void) hipStreamDestroy(c->ri_stream); }
 	if (c->ev_ri_go) (void) hipEventDestroy(c->ev_ri_go);
 	c->ri_arena.release(true);
+	if (c->root_stream) { (void) hipStreamSynchronize(c->root_stream); (void) hipStreamDestroy(c->root_stream); }
+	if (c->ev_root_go) (void) hipEventDestroy(c->ev_root_go);
+	c->root_arena.release(true);
 	free_dev(c->d_vbits); free_dev(c->d_jbits); free_dev(c->d_anchor_tmp);
 	free_dev(c->d_vtext); free_dev(c->d_line_off); free_dev(c->d_seed_code); free_dev(c->d_seed_pos);
 	free_dev(c->d_ri_tab); free_dev(c->d_ri_start); free_dev(c->d_ri_recs); free_dev(c->d_ri_csr8); free_dev(c->d_ri_csr_pair);
@@ -155,8 +160,10 @@ extern "C" int vdjx_trim(vdjx_ctx* c) {
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	HIP_TRY(hipStreamSynchronize(c->copy_stream));
 	if (c->pairs_stream) HIP_TRY(hipStreamSynchronize(c->pairs_stream));
+	if (c->root_stream) HIP_TRY(hipStreamSynchronize(c->root_stream));
 	c->arena.release(false);
 	c->ri_arena.release(false);
+	c->root_arena.release(false);
 	if (!c->live_shard) c->shard_arena.release(false);
 	c->blocks.drop();
 	// the scorers' result buffers (grow-only between calls: the pair lists of the last window batch, the mapped pairs and the SAM
@@ -338,20 +345,21 @@ extern "C" int vdjx_sync(vdjx_ctx* c) {
 // ----------------------------------------------------------------------------------------------
 // profiling
 // ----------------------------------------------------------------------------------------------
-vdjx_prof_scope::vdjx_prof_scope(vdjx_ctx* ctx, const char* nm) : c(ctx), name(nm) {
+vdjx_prof_scope::vdjx_prof_scope(vdjx_ctx* ctx, const char* nm, hipStream_t stream) : c(ctx), name(nm), st(stream) {
 	if (!c || !c->profiling) return;
+	if (!st) st = c->stream;
 	if (!c->prof_only.empty() && c->prof_only != nm) return;          // (vdjx_profile_only: one scope is bracketed, the others cost nothing)
 	auto take = [&](hipEvent_t* e) {
 		if (!c->ev_free.empty()) { *e = c->ev_free.back(); c->ev_free.pop_back(); return true; }
 		return hipEventCreate(e) == hipSuccess;
 	};
 	if (!take(&a) || !take(&b)) { a = b = nullptr; return; }
-	(void) hipEventRecord(a, c->stream);
+	(void) hipEventRecord(a, st);
 }
 
 vdjx_prof_scope::~vdjx_prof_scope() {
 	if (!c || !c->profiling || !a) return;
-	(void) hipEventRecord(b, c->stream);
+	(void) hipEventRecord(b, st);
 	c->prof_pending.push_back({name, a, b});
 }
 

@@ -1390,6 +1390,7 @@ __global__ __launch_bounds__(64) void k_shard_reply(const uint2* __restrict__ qu
 		((u64*) out)[1] = finst;
 		if (SYM) ((u64*) out)[REPLY_R0 / 8] = finst_r;
 	}
+	if (!SYM && lane < (REPLY_BYTES - REPLY_R0) / 4) ((u32*) (out + REPLY_R0))[lane] = 0;      // (the reverse complement's part of an answer is not used: zeros, not stale device bytes, on the wire)
 	if (lane < 8) {
 		const int W = rl <= VDJX_SHORT_READ_LEN ? 2 : VDJX_LONG_W, M = rl <= VDJX_SHORT_READ_LEN ? 1 : VDJX_LONG_M;
 		((u64*) out)[2 + lane] = (int) lane < W ? bases[frec * W + lane] : ((int) lane < W + M ? nmask[frec * M + (lane - W)] : 0ull);
@@ -3409,6 +3410,8 @@ static int shard_local_impl(vdjx_shard* s) {
 	HIP_TRY(db.alloc(&s->nd, nb_max));
 	HIP_TRY(db.alloc(&s->dstart, nb_max + 1));
 	HIP_TRY(db.alloc(&g_err, 1));
+	u32* keep_starts;                          // the tuples' bucket starts, kept below everything the fill gives up (the compaction reads them)
+	HIP_TRY(db.alloc(&keep_starts, nb_max + 1));
 	s->fill_mark = db.mark();
 	HIP_TRY(db.alloc(&sparse, cap));
 	HIP_TRY(db.alloc(&sparse_ref, cap));
@@ -3452,6 +3455,9 @@ static int shard_local_impl(vdjx_shard* s) {
 	u32 err = 0;
 	HIP_TRY(hipMemcpyAsync(pick.data(), d_pick, (G + 1) * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(&err, g_err, 4, hipMemcpyDeviceToHost, st));
+	// (the bucket starts move below the tuples on the device, in stream order, before the one wait of this phase: round 5 brought them to
+	// the host and back with two synchronous copies after it)
+	HIP_TRY(hipMemcpyAsync(keep_starts, t.bucket_start, ((size_t) t.NB + 1) * 4, hipMemcpyDeviceToDevice, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	HIP_TRY(hipGetLastError());
 	if (err) { vdjx_set_error("k_gated_local: %u buckets could not be split to fit LDS", err); return VDJX_EHIP; }
@@ -3460,16 +3466,9 @@ static int shard_local_impl(vdjx_shard* s) {
 	// (the aggregates are laid end to end by vdjx_shard_local_fill, straight into the caller's send buffer)
 	s->sparse = sparse; s->sparse_ref = sparse_ref; s->NBt = t.NB;
 	s->dense = nullptr;
-	// the tuples are done with; the bucket starts the compaction needs move below them first
-	{
-		std::vector<u32> bs((size_t) t.NB + 1);
-		HIP_TRY(hipMemcpy(bs.data(), t.bucket_start, ((size_t) t.NB + 1) * 4, hipMemcpyDeviceToHost));
-		db.release_to(tuple_mark);
-		u32* keep;
-		HIP_TRY(db.alloc(&keep, (size_t) t.NB + 1));
-		HIP_TRY(hipMemcpy(keep, bs.data(), ((size_t) t.NB + 1) * 4, hipMemcpyHostToDevice));
-		s->tuple_bucket_start = keep;
-	}
+	// the tuples are done with
+	db.release_to(tuple_mark);
+	s->tuple_bucket_start = keep_starts;
 	return VDJX_OK;
 }
 
@@ -3542,6 +3541,7 @@ extern "C" int vdjx_shard_geometry2(vdjx_shard* s, uint64_t agreed_instances, in
 	const int rc = vdjx_shard_geometry(s, agreed_instances);
 	if (rc) return rc;
 	s->sym = all_symmetric != 0;
+	s->c->stats["kmer_build_sym"] = s->sym ? 1 : 0;          // (what vdjx_kmer_build reports: the callers' byte models read it)
 	return VDJX_OK;
 }
 extern "C" int vdjx_shard_geometry(vdjx_shard* s, uint64_t agreed_instances) {
@@ -3928,6 +3928,7 @@ extern "C" void vdjx_graph_free(vdjx_graph* g) {
 		(void) hipSetDevice(g->device);
 		if (vdjx_ctx_alive(g->ctx)) {
 			(void) hipStreamSynchronize(g->ctx->copy_stream);      // an export that was begun and never ended
+			if (g->ctx->root_pending && g->ctx->root_pending_g == g && g->ctx->root_stream) (void) hipStreamSynchronize(g->ctx->root_stream);      // a root scoring begun on this graph and never ended
 			g->ctx->blocks.release(g->d_block, g->block_cap);
 		}
 		else (void) hipFree(g->d_block);

@@ -321,8 +321,8 @@ __global__ __launch_bounds__(DPW_THREADS) void k_root_dp_wave(const char* __rest
 // begin: queue everything, wait for nothing -- possible when the last call's item count is at hand as a guess (root_dp_hint) and the
 // threshold is positive; *begun says whether it was (else the call ran to its end as ever).  vdjx_root_score_graph_end waits, and
 // repeats the call the ordinary way should the guess have fallen short.
-static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t n, int k, int threshold, uint8_t* out, bool* begun = nullptr) {
-	hipStream_t st = c->stream;
+static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t n, int k, int threshold, uint8_t* out, bool* begun = nullptr, hipStream_t st = nullptr) {
+	if (!st) st = c->stream;
 	if (begun) *begun = false;
 	const int stop = k - c->vk;
 	u32 *d_lo, *d_cnt, *d_pre;
@@ -334,7 +334,7 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 	HIP_TRY(db.alloc(&d_out, n));
 	HIP_TRY(hipMemsetAsync(d_out, 0, n, st));
 	{
-		vdjx_prof_scope ps(c, "k_seed_count");
+		vdjx_prof_scope ps(c, "k_seed_count", st);
 		hipLaunchKernelGGL(k_seed_count, dim3((ng + 255) / 256), dim3(256), 0, st, d_k, (u32) n, k, c->vk, c->d_seed_code, (u32) c->n_seeds, d_lo, d_cnt);
 	}
 	{
@@ -354,7 +354,7 @@ static int root_score_device(vdjx_ctx* c, vdjx_work& db, const char* d_k, size_t
 	// few items: a wave each (k_root_dp_wave); many: a thread each
 	static const u32 dp_wave_max = getenv("VDJX_DP_WAVE_MAX") ? (u32) atol(getenv("VDJX_DP_WAVE_MAX")) : 32768u;      // (measured: 10 k items 0.043 against 0.110 ms, 25 k 0.087 / 0.111, 77 k 0.234 / 0.130, 252 k 0.74 / 0.18)
 	auto launch_dp = [&](u32 first, u32 count) -> u32 {        // -> items covered from `first` on (whole workgroups)
-		vdjx_prof_scope ps(c, "k_root_dp");
+		vdjx_prof_scope ps(c, "k_root_dp", st);
 		if (count <= dp_wave_max && k <= 64) {
 			const u32 per = DPW_THREADS / 64;
 			hipLaunchKernelGGL(k_root_dp_wave, dim3((count + per - 1) / per), dim3(DPW_THREADS), 0, st, d_k, k, threshold,
@@ -486,17 +486,28 @@ extern "C" int vdjx_root_score_graph_begin(vdjx_ctx* c, const vdjx_graph* g, int
 	if (k - c->vk <= 0 || c->n_seeds == 0 || threshold <= 0 || !c->root_dp_hint) return vdjx_root_score_graph(c, g, threshold, first, stride, root_ids, out);
 	HIP_TRY(hipSetDevice(c->device));
 	vdjx_clear_errors();
-	vdjx_work db(c);
+	// VDJX_ROOT_STREAM=1: on a stream and out of a workspace of its own, behind everything the context's stream holds so far, BESIDE what the
+	// caller queues on the context afterwards (the window scorer).  Measured at 10 M pairs (round 6): the step got SLOWER, 10.87 -> 11.10 ms --
+	// the begin call costs the host 0.25 ms instead of 0.07 (event record + cross-stream wait + a second queue to feed) and the window
+	// scorer gains 0.09 ms: the root kernels are 0.23 ms of small launches that the scorer's kernels, which fill the machine, do not
+	// run beside but around.  1 M pairs: 1.955 -> 1.964 ms.  So the default stays the context's stream (the calls in between run behind it)
+	static const bool own_stream = getenv("VDJX_ROOT_STREAM") && getenv("VDJX_ROOT_STREAM")[0] == '1';
+	hipStream_t st = own_stream ? c->root_stream : c->stream;
+	if (own_stream) {
+		HIP_TRY(hipEventRecord(c->ev_root_go, c->stream));
+		HIP_TRY(hipStreamWaitEvent(st, c->ev_root_go, 0));
+	}
+	vdjx_work db(c, own_stream ? &c->root_arena : &c->arena);      // (its own workspace: the calls in between reset and reuse the context's)
 	char* d_k;
 	u32* d_ids;
 	HIP_TRY(db.alloc(&d_k, n * k));
 	HIP_TRY(db.alloc(&d_ids, n));
-	hipLaunchKernelGGL(k_root_gather, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, c->stream, g->d_kmers, g->d_roots, first, stride, (u32) n, k, d_k, d_ids);
-	HIP_TRY(hipMemcpyAsync(root_ids, d_ids, n * 4, hipMemcpyDeviceToHost, c->stream));
+	hipLaunchKernelGGL(k_root_gather, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, g->d_kmers, g->d_roots, first, stride, (u32) n, k, d_k, d_ids);
+	HIP_TRY(hipMemcpyAsync(root_ids, d_ids, n * 4, hipMemcpyDeviceToHost, st));
 	bool begun = false;
-	rc = root_score_device(c, db, d_k, n, k, threshold, out, &begun);
+	rc = root_score_device(c, db, d_k, n, k, threshold, out, &begun, st);
 	if (rc || !begun) return rc;
-	HIP_TRY(hipEventRecord(c->ev_root_done, c->stream));
+	HIP_TRY(hipEventRecord(c->ev_root_done, st));
 	c->root_pending = true;
 	c->root_pending_g = g; c->root_pending_thr = threshold; c->root_pending_first = first; c->root_pending_stride = stride;
 	c->root_pending_ids = root_ids; c->root_pending_out = out;

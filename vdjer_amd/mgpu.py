@@ -44,6 +44,8 @@ def lib():
     L.vdjx_mgpu_bytes_sent.argtypes = [vp]
     L.vdjx_mgpu_bytes_sent.restype = u64
     L.vdjx_mgpu_agree_max.argtypes = [vp, u64, C.POINTER(u64)]
+    L.vdjx_mgpu_set_read_length.argtypes = [vp, i32]
+    L.vdjx_mgpu_set_read_length.restype = None
     L.vdjx_mgpu_kmer_build_pool.argtypes = [vp, vp, vp, i32, i32, i32, u64, C.POINTER(vp)]
     L.vdjx_mgpu_kmer_build_share.argtypes = [vp, vp, vp, i32, i32, i32, vp, u64, C.POINTER(vp)]
     L.vdjx_mgpu_window_score2.argtypes = [vp, vp, vp, sz, i32, C.POINTER(CovParams), vp, vp]
@@ -116,6 +118,7 @@ class Driver:
         """collective.  scan_index (device int32/uint32 tensor, ascending) / total_records: the pool is this rank's share of the whole pool;
         without them rank r holds the r-th slice of the scan order (stride = the largest pool of any rank, agreed once)"""
         g = C.c_void_p()
+        self.L.vdjx_mgpu_set_read_length(self.m, int(pool.rl))
         if scan_index is not None:
             _check(self.L.vdjx_mgpu_kmer_build_share(self.m, self.ctx.h, pool.h, k, mf, mq, C.c_void_p(scan_index.data_ptr()), int(total_records), C.byref(g)),
                    "vdjx_mgpu_kmer_build_share", self.L)
