@@ -124,7 +124,7 @@ def workload_label(pairs: int, k: int, mf: int, mq: int, mrs: int, ins: int, wor
     else:
         tag = "custom size"
     if REP_KW:
-        tag += ("; --repertoire private: every clone over a germline V of its own, Zipf 0.25, one clone per 4,000 pairs -- BASELINE size on a repertoire the "
+        tag += ("; --repertoire private: every clone over a germline V and J tail of its own, Zipf 0.25, one clone per 4,000 pairs -- BASELINE size on a repertoire the "
                 "reference's serial traversal finishes (tests/golden/midscale.json cfg2_pv)")
     return f"synthetic {pairs} 50bp PE pairs per GPU, IGH, k={k} mf={mf} mq={mq} mrs={mrs} ins={ins} ({tag})"
 
@@ -463,8 +463,8 @@ def main():
     ap.add_argument("--clones", type=int, default=0, help="clones per GPU (default: pairs / 500; --repertoire private: pairs / 4000)")
     ap.add_argument("--repertoire", choices=["survey", "private"], default="survey",
                     help="survey: SURVEY 8d's repertoire (60 germline V segments shared by all clones, Zipf 1.1) -- the reference's contig enumeration does not "
-                         "end on it above ~1.5 M pairs, so the windows come from the generator there.  private: every clone over a germline V of its own, "
-                         "abundance Zipf 0.25, one clone per 4,000 pairs (tests/golden/make_golden_midscale.py cfg2_pv): the serial traversal TERMINATES at "
+                         "end on it above ~1.5 M pairs, so the windows come from the generator there.  private: every clone over a germline V and a J + constant tail of its "
+                         "own, abundance Zipf 0.25, one clone per 4,000 pairs (tests/golden/make_golden_midscale.py cfg2_pv): the serial traversal TERMINATES at "
                          "10 M pairs (reference: ~25 min at --t 1, 2 k contigs), so the scorers get the windows the reference's DFS really asks for and the "
                          "whole command line is compared with the reference's bytes at BASELINE size (--cli-at-size)")
     ap.add_argument("--cli-at-size", action="store_true",
@@ -503,7 +503,7 @@ def main():
         args.no_e2e = True
         args.windows = "generator"
     if args.repertoire == "private":
-        REP_KW.update(private_v=True, zipf_s=0.25)
+        REP_KW.update(private_v=True, private_j=True, zipf_s=0.25)
         if args.clones <= 0:
             args.clones = max(4, args.pairs // 4000)
         if args.windows == "auto":

@@ -45,11 +45,13 @@ CASES = {
     # BASELINE.json configs[3] AS WRITTEN (README's sensitive mode, no --mrs: the default 30 stands): at k = 25 the root DP is bounded by
     # 25 < 30, so no root can pass (seq_score.c:92-116, params.c:66, A2:1103): empty FASTA, header-less SAM, every verdict 0
     # BASELINE.json configs[2]'s SIZE on a repertoire the reference's serial traversal finishes (VERDICT r5 missing #4): 10 M pairs, every clone
-    # with a germline V of its own (no contig enumeration across clones that share a segment, A2:939-1061) and an abundance flat enough
-    # (Zipf 0.25 over 2,500 clones: 400x mean coverage) that the sequencing errors of a clone rarely reach --mf 3: thousands of contigs,
-    # the reference's whole run ~25 min at --t 1.  SURVEY 8d's C3 repertoire (20,000 clones over 60 shared V segments, Zipf 1.1) does not
-    # end: 200 of ~55,000 accepted roots in its first three minutes of traversal, the deep clones' error branches each a window to map
-    "cfg2_pv": dict(pairs=10_000_000, clones=2500, seed=20261002, noise=0.3, chain="IGH", ins=175, private_v=True, zipf_s=0.25,
+    # with a germline V AND a J + constant tail of its own (no contig enumeration across clones that share a segment, A2:939-1061) and an
+    # abundance flat enough (Zipf 0.25 over 2,500 clones: 400x mean coverage) that the sequencing errors of a clone rarely reach --mf 3:
+    # thousands of contigs, the reference's whole run ~20 min at --t 1.  What does not end here, measured: SURVEY 8d's C3 repertoire (20,000
+    # clones over 60 shared V segments, Zipf 1.1) -- 200 of ~55,000 accepted roots in the first three minutes of traversal, the deep clones'
+    # error branches each a window to map; and private V segments over the six SHARED J + constant tails -- every clone covers its tail, so
+    # every sequencing error in a tail survives and every root enumerates ~800 candidates through it: 100,000 in two minutes
+    "cfg2_pv": dict(pairs=10_000_000, clones=2500, seed=20261002, noise=0.3, chain="IGH", ins=175, private_v=True, private_j=True, zipf_s=0.25,
                     flags=["--k", "35", "--mf", "3", "--mq", "90", "--mrs", "30"], attempts=4, parallel=2),
     "mid_k25_mrs30": dict(pairs=200_000, clones=400, seed=20261002, noise=0.3, chain="IGH", ins=175,
                           flags=["--k", "25", "--mf", "2", "--mq", "60", "--mcs", "-5.5"]),
@@ -58,7 +60,8 @@ CASES = {
 
 def make_rep(case: dict):
     """the case's repertoire (private_v / zipf_s: the second parameterisation of the generator, see cfg2_pv)"""
-    return synth.make_repertoire(case["clones"], seed=case["seed"], private_v=bool(case.get("private_v", False)), zipf_s=float(case.get("zipf_s", 1.1)))
+    return synth.make_repertoire(case["clones"], seed=case["seed"], private_v=bool(case.get("private_v", False)), private_j=bool(case.get("private_j", False)),
+                                 zipf_s=float(case.get("zipf_s", 1.1)))
 
 
 def write_inputs(case: dict, d: str):

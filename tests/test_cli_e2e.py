@@ -69,7 +69,7 @@ def test_vdjer_cli_sharded_build_one_rank_rccl(tag, tmp_path):
     info = G.manifest()["e2e"][tag]
     _write_inputs(c, str(tmp_path))
     cmd = [exe, "--in", "reads.txt", "--chain", "IGH", "--ref-dir", "ref", "--ins", "175", "--t", "2", "--gpus", "1"] + info["flags"]
-    env = dict(os.environ, VDJX_FORCE_MGPU="1")
+    env = dict(os.environ, VDJX_FORCE_MGPU="1", VDJX_MGPU_SELF_COLLECTIVES="1")      # (a lone rank would skip the exchanges: here they are the point)
     r = subprocess.run(cmd, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "k-mer table sharded over 1 GPUs" in r.stderr

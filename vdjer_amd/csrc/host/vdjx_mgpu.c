@@ -210,6 +210,8 @@ static int kmer_build_any(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, in
 	if (!send_counts || !recv_counts || !q_out || !q_in || !eq || !meta) { rc = fail(VDJX_EINVAL, "out of memory"); goto done; }
 	const size_t W0 = vdjx_shard_record_bytes(0), W1 = vdjx_shard_record_bytes(1), W2 = vdjx_shard_record_bytes(2), W3 = vdjx_shard_record_bytes(3);
 	HIPC(hipSetDevice(m->device));
+	/* a lone rank skips the exchanges that would hand it its own data back (VDJX_MGPU_SELF_COLLECTIVES=1 keeps them: the one-rank RCCL test) */
+	const int alone = G == 1 && getenv("VDJX_MGPU_SELF_COLLECTIVES") == NULL;
 	lap_start(m);
 	if (d_scan) VX(vdjx_shard_begin_share(ctx, pool, k, mf, mq, me, G, d_scan, total_records, &sh));
 	else VX(vdjx_shard_begin(ctx, pool, k, mf, mq, me, G, rec_stride, &sh));
@@ -239,9 +241,13 @@ static int kmer_build_any(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, in
 	/* what every rank will send this one: the counts travel as control traffic beside the directories (no device round trip in between) */
 	CX(vdjx_comm_allgather_host(m->cm, send_counts, (size_t) G * 8, meta));
 	for (int r = 0; r < G; r++) recv_counts[r] = meta[(size_t) r * G + me];
-	CX(vdjx_comm_a2av(m->cm, d_sdir, eq, d_rdir, eq, 4));
-	WSG(WS_RPARTS, sum64(recv_counts, G) * W0 + 16, &d_rparts);
-	CX(vdjx_comm_a2av(m->cm, d_sparts, send_counts, d_rparts, recv_counts, W0));
+	/* (a lone rank has nothing to exchange: what it would send itself IS what it received -- no device copy of its own 0.5 GB of aggregates) */
+	if (alone) { d_rdir = d_sdir; d_rparts = d_sparts; }
+	else {
+		CX(vdjx_comm_a2av(m->cm, d_sdir, eq, d_rdir, eq, 4));
+		WSG(WS_RPARTS, sum64(recv_counts, G) * W0 + 16, &d_rparts);
+		CX(vdjx_comm_a2av(m->cm, d_sparts, send_counts, d_rparts, recv_counts, W0));
+	}
 	lap(m, "build: exchange of the partial aggregates");
 	/* 3. owners merge and decide; questions and answers for the few open k-mers */
 	VX(vdjx_shard_merge(sh, d_rdir, d_rparts, recv_counts, q_out));
@@ -249,13 +255,19 @@ static int kmer_build_any(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, in
 	CX(vdjx_comm_allgather_host(m->cm, q_out, (size_t) G * 8, meta));
 	for (int r = 0; r < G; r++) q_in[r] = meta[(size_t) r * G + me];
 	WSG(WS_Q, sum64(q_out, G) * W1 + 16, &d_q);
-	WSG(WS_RQ, sum64(q_in, G) * W1 + 16, &d_rq);
 	WSG(WS_ANS, sum64(q_in, G) * W2 + 16, &d_ans);
-	WSG(WS_RANS, sum64(q_out, G) * W2 + 16, &d_rans);
 	VX(vdjx_shard_queries(sh, d_q));
-	CX(vdjx_comm_a2av(m->cm, d_q, q_out, d_rq, q_in, W1));
+	if (alone) d_rq = d_q;
+	else {
+		WSG(WS_RQ, sum64(q_in, G) * W1 + 16, &d_rq);
+		CX(vdjx_comm_a2av(m->cm, d_q, q_out, d_rq, q_in, W1));
+	}
 	VX(vdjx_shard_reply(sh, d_rq, q_in, d_ans));
-	CX(vdjx_comm_a2av(m->cm, d_ans, q_in, d_rans, q_out, W2));
+	if (alone) d_rans = d_ans;
+	else {
+		WSG(WS_RANS, sum64(q_out, G) * W2 + 16, &d_rans);
+		CX(vdjx_comm_a2av(m->cm, d_ans, q_in, d_rans, q_out, W2));
+	}
 	uint64_t ns = 0, ndist = 0;
 	lap(m, "build: questions and answers");
 	VX(vdjx_shard_resolve(sh, d_rans, sum64(q_out, G), &ns, &ndist));
@@ -268,16 +280,21 @@ static int kmer_build_any(vdjx_mgpu* m, vdjx_ctx* ctx, const vdjx_pool* pool, in
 	uint64_t ns_total = 0, pre_total = 0;
 	for (int r = 0; r < G; r++) { recv_counts[r] = meta[2 * r]; ns_total += meta[2 * r]; pre_total += meta[2 * r + 1]; }
 	WSG(WS_SURV, ns * W3 + 16, &d_surv);
-	WSG(WS_SURV_ALL, ns_total * W3 + 16, &d_surv_all);
 	VX(vdjx_shard_survivors(sh, d_surv));
-	CX(vdjx_comm_allgatherv(m->cm, d_surv, d_surv_all, recv_counts, W3));
+	if (alone) d_surv_all = d_surv;
+	else {
+		WSG(WS_SURV_ALL, ns_total * W3 + 16, &d_surv_all);
+		CX(vdjx_comm_allgatherv(m->cm, d_surv, d_surv_all, recv_counts, W3));
+	}
 	lap(m, "build: gather of the survivors");
 	WSG(WS_MINS, ns_total * 5 * 8 + 16, &d_mins);          /* in-edge first sights [4n] | node first sights [n] */
 	WSG(WS_UCNT, ns_total * 4 + 16, &d_ucnt);
 	VX(vdjx_shard_edges(sh, d_surv_all, ns_total, d_mins, d_ucnt, (char*) d_mins + ns_total * 32));
 	lap(m, "build: graph pass over the share");
-	CX(vdjx_comm_allreduce_min_u64(m->cm, d_mins, (size_t) ns_total * 5));                         /* all-ones = none stays largest */
-	CX(vdjx_comm_allreduce_sum_u32(m->cm, d_ucnt, (size_t) ns_total));
+	if (!alone) {
+		CX(vdjx_comm_allreduce_min_u64(m->cm, d_mins, (size_t) ns_total * 5));                     /* all-ones = none stays largest */
+		CX(vdjx_comm_allreduce_sum_u32(m->cm, d_ucnt, (size_t) ns_total));
+	}
 	lap(m, "build: reduction of first sights and counts");
 	/* 5. node numbering + list order: identical on every rank */
 	VX(vdjx_shard_finish(sh, d_mins, d_ucnt, (char*) d_mins + ns_total * 32, pre_total, out));
@@ -362,9 +379,12 @@ static int do_window_score(vdjx_mgpu* m, vdjx_ctx* ctx, const char* windows, siz
 			recv_counts[s] += v;
 		}
 	WSG(WS_A, sum64(send_counts, G) * 8 + 16, &d_send);
-	WSG(WS_B, sum64(recv_counts, G) * 8 + 16, &d_recv);
 	VX(vdjx_window_pairs_fetch(ctx, send_ids, n, d_send));
-	CX(vdjx_comm_a2av(m->cm, d_send, send_counts, d_recv, recv_counts, 8));
+	if (G == 1 && !getenv("VDJX_MGPU_SELF_COLLECTIVES")) d_recv = d_send;          /* (a lone rank's lists are the union already) */
+	else {
+		WSG(WS_B, sum64(recv_counts, G) * 8 + 16, &d_recv);
+		CX(vdjx_comm_a2av(m->cm, d_send, send_counts, d_recv, recv_counts, 8));
+	}
 	lap(m, "windows: exchange of the pair lists");
 	if (n_mine) VX(vdjx_window_cover(ctx, n_mine, len, m->rl, p, d_recv, (size_t) G, counts, mine));
 	lap(m, "windows: coverage test of the own windows");

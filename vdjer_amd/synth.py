@@ -81,11 +81,12 @@ class Repertoire:
 
     def cdr3s(self) -> list:
         out = []
+        ja = set(self.j_anchors)
         for t in self.clones:
             c = 297
             w = t.find(self.j_codon, c + 3)
             # the designed Trp (Phe) codon is the in-frame one that starts the J tail
-            while (w - c) % 3 != 0 or t[w + 8:w + 24] not in self.j_anchors:
+            while (w - c) % 3 != 0 or t[w + 8:w + 24] not in ja:
                 w = t.find(self.j_codon, w + 1)
             out.append(t[c:w + 3])
         return out
@@ -93,11 +94,15 @@ class Repertoire:
 
 def make_repertoire(n_clones: int, seed: int = 20261002, n_v: int = 60, n_j: int = 6,
                     zipf_s: float = 1.1, j_codons: int = 119, clone_seed: int | None = None, chain: str = "IGH",
-                    private_v: bool = False) -> Repertoire:
+                    private_v: bool = False, private_j: bool = False) -> Repertoire:
     """private_v: every clone has a germline V of its own (n_v is ignored: n_v = n_clones, clone i over V i).  With V segments SHARED
     by hundreds of clones (60 for all) the reference's contig enumeration (A2:939-1061) branches at every somatic mutation
     of every clone of the segment and does not end above ~1.5 M pairs; with private segments a root's paths are its clone's transcript
     and its surviving sequencing errors, and the serial traversal terminates at BASELINE size (10 M pairs / 20,000 clones: DESIGN 5).
+    private_j: every clone has a J + constant tail of its own too (n_j = n_clones, clone i over J i).  Shared tails -- six for all clones --
+    are covered by EVERY clone that uses them (hundreds of thousands of reads deep at 10 M pairs), so every sequencing error in them
+    survives --mf 3 and every accepted root enumerates ~800 contig candidates through them (A2:939-1061: one per error branch within
+    --mcs of the main path): 100,000 candidates in the reference's first two minutes of traversal at 10 M pairs / 2,500 clones.
     clone_seed: draw the clones from their own stream while the germline (and with it the ref-dir) stays the one of `seed`:
     several libraries of different clones over one reference (bench.py gives every GPU its own library).
     chain IGK / IGL: the J segment starts with the conserved Phe codon and the CDR3 is short enough for the light-chain
@@ -109,6 +114,8 @@ def make_repertoire(n_clones: int, seed: int = 20261002, n_v: int = 60, n_j: int
     rng = np.random.default_rng(seed)
     if private_v:
         n_v = n_clones
+    if private_j:
+        n_j = n_clones
     v_germ = [_rand_codons(rng, 99) + "TGT" for _ in range(n_v)]
     j_germ = [j_codon + _rand_codons(rng, j_codons) for _ in range(n_j)]
     if clone_seed is not None:
@@ -116,7 +123,7 @@ def make_repertoire(n_clones: int, seed: int = 20261002, n_v: int = 60, n_j: int
     clones, cv, cj = [], [], []
     for ci_ in range(n_clones):
         g = ci_ if private_v else int(rng.integers(0, n_v))
-        h = int(rng.integers(0, n_j))
+        h = ci_ if private_j else int(rng.integers(0, n_j))
         v = list(v_germ[g])
         for _m in range(int(rng.integers(0, 7))):
             # somatic point mutation outside the anchor (277..292) and the Cys codon, never making a stop
