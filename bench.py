@@ -862,7 +862,7 @@ def main():
     # flags name that workload; (2) a small sample of the same generator re-checked against the oracle itself.
     timed_check = None
     dg_path = os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")
-    if rank == 0 and world == 1 and not args.force_shard and os.path.exists(dg_path):
+    if rank == 0 and world == 1 and not args.config4 and os.path.exists(dg_path):          # (--force-shard too: the C driver's one-rank build and scorers against the same digests)
         import hashlib
         dg = json.load(open(dg_path))
         case = {(35, 3, 90, 30): "k35", (25, 2, 60, 20): "k25", (35, 3, 60, 30): "k35_mq60"}.get((args.k, args.mf, args.mq, args.mrs))

@@ -63,3 +63,19 @@ def test_bench_line_ranks_on_one_device(n):
               env={"VDJX_BENCH_ONE_DEVICE": "1"})
     _check(d, n, 2, 1)
     assert d["config"]["parallelism"].endswith(f"x{n}")
+
+
+def test_bench_line_through_the_c_driver_one_rank():
+    """--force-shard: the step through libvdjmgpu.so (vdjx_mgpu.c, the driver of `vdjer --gpus N`) with one rank; the line names the driver"""
+    d = _line([sys.executable, "bench.py", "--force-shard", "--steps", "2", "--warmup", "1", "--pairs", "200000", "--no-cpu", "--no-e2e"])
+    _check(d, 1, 2, 1)
+    assert "libvdjmgpu.so" in d["multi_gpu_driver"] and d["counts"]["nodes"] > 1000 and d["counts"]["windows"] > 0
+
+
+def test_bench_line_private_repertoire_takes_the_traversal_windows():
+    """--repertoire private: the workload on which the reference's serial traversal ends at BASELINE size (tests/golden/midscale.json cfg2_pv);
+    here small: the scorer inputs are the windows the host traversal asks for, whatever the size"""
+    d = _line([sys.executable, "bench.py", "--repertoire", "private", "--steps", "2", "--warmup", "1", "--pairs", "400000", "--no-cpu", "--no-e2e", "--no-index-leg"])
+    _check(d, 1, 2, 1)
+    assert d["config"]["windows"] == "traversal" and d["config"]["clones_per_gpu"] == 100 and "private" in d["config"]["workload"]
+    assert d["counts"]["contigs"] >= 50
