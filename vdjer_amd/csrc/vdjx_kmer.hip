@@ -3900,6 +3900,9 @@ static int graph_block_on(const vdjx_graph* g, bool copy_stream, void* host_bloc
 	if (!host_block) { vdjx_set_error("%s: NULL buffer", who); return VDJX_EINVAL; }
 	if (!g->d_block || !vdjx_ctx_alive(g->ctx)) { vdjx_set_error("%s: the graph's context is gone", who); return VDJX_ESTATE; }
 	HIP_TRY(hipSetDevice(g->device));
+	// (round 6 tried a copy kernel of its own with a small footprint -- 32 to 4,096 workgroups storing 16 bytes per lane into the page-locked
+	// block -- instead of the runtime's blit: the same 1.77 ms for the 128 MB of a 10 M-pair graph, but the step went 10.9 -> 15.3-16.8 ms:
+	// the kernels that ran beside it, k_pool_pack above all, slowed down three- to fourfold, which beside the runtime's copy they do not)
 	HIP_TRY(hipMemcpyAsync(host_block, g->d_block, g->export_bytes, hipMemcpyDeviceToHost, copy_stream ? g->ctx->copy_stream : g->ctx->stream));
 	return VDJX_OK;
 }

@@ -428,13 +428,20 @@ extern "C" int vdjx_root_score(vdjx_ctx* c, const char* kmers, size_t n, int k, 
 	return root_score_device(c, db, d_k, n, k, threshold, out);
 }
 
+// the root k-mers laid end to end for the scorer: 16 LANES per root, lane j copies the characters j, j + 16, ... of its root -- a root's k bytes
+// are a few consecutive loads and stores of a quarter wave (one thread per root was k one-byte loads and stores 35 bytes apart from lane to
+// lane).  0.011 ms at 10 M pairs by HIP events.  (rocprofv3's kernel trace shows this kernel at 1.2-1.4 ms whenever the graph's copy to
+// the host runs beside it on the copy stream -- its timestamps, not its time: profiles/README.md, round 6.)
 __global__ void k_root_gather(const char* __restrict__ kmers, const u32* __restrict__ roots, u32 first, u32 stride, u32 n_sel, int k,
                               char* __restrict__ out, u32* __restrict__ ids) {
-	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+	const u32 i = t >> 4, j0 = t & 15u;
 	if (i >= n_sel) return;
 	const u32 node = roots[first + (size_t) i * stride];
-	ids[i] = node + 1;
-	for (int j = 0; j < k; j++) out[(size_t) i * k + j] = kmers[(size_t) node * k + j];
+	if (j0 == 0) ids[i] = node + 1;
+	const char* src = kmers + (size_t) node * k;
+	char* dst = out + (size_t) i * k;
+	for (int j = (int) j0; j < k; j += 16) dst[j] = src[j];
 }
 
 extern "C" size_t vdjx_root_part(const vdjx_graph* g, uint32_t first, uint32_t stride) {
@@ -460,7 +467,7 @@ extern "C" int vdjx_root_score_graph(vdjx_ctx* c, const vdjx_graph* g, int thres
 	u32* d_ids;
 	HIP_TRY(db.alloc(&d_k, n * k));
 	HIP_TRY(db.alloc(&d_ids, n));
-	hipLaunchKernelGGL(k_root_gather, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, c->stream, g->d_kmers, g->d_roots, first, stride, (u32) n, k, d_k, d_ids);
+	hipLaunchKernelGGL(k_root_gather, dim3((unsigned) ((n * 16 + 255) / 256)), dim3(256), 0, c->stream, g->d_kmers, g->d_roots, first, stride, (u32) n, k, d_k, d_ids);
 	HIP_TRY(hipMemcpyAsync(root_ids, d_ids, n * 4, hipMemcpyDeviceToHost, c->stream));
 	memset(out, 0, n);
 	if (k - c->vk <= 0 || c->n_seeds == 0) { HIP_TRY(hipStreamSynchronize(c->stream)); return VDJX_OK; }
@@ -502,7 +509,10 @@ extern "C" int vdjx_root_score_graph_begin(vdjx_ctx* c, const vdjx_graph* g, int
 	u32* d_ids;
 	HIP_TRY(db.alloc(&d_k, n * k));
 	HIP_TRY(db.alloc(&d_ids, n));
-	hipLaunchKernelGGL(k_root_gather, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, st, g->d_kmers, g->d_roots, first, stride, (u32) n, k, d_k, d_ids);
+	{
+		vdjx_prof_scope ps(c, "k_root_gather", st);
+		hipLaunchKernelGGL(k_root_gather, dim3((unsigned) ((n * 16 + 255) / 256)), dim3(256), 0, st, g->d_kmers, g->d_roots, first, stride, (u32) n, k, d_k, d_ids);
+	}
 	HIP_TRY(hipMemcpyAsync(root_ids, d_ids, n * 4, hipMemcpyDeviceToHost, st));
 	bool begun = false;
 	rc = root_score_device(c, db, d_k, n, k, threshold, out, &begun, st);
