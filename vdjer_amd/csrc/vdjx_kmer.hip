@@ -895,7 +895,8 @@ __global__ __launch_bounds__(RD_THREADS, sizeof(TUP) == 16 ? RD_WAVES : RD_WAVES
 						so.lo[pos] = rlo;
 						so.hi[pos] = rh;
 						so.gcnt[pos] = cgo | (!(s_state[i] & 2u) ? GC_SHADOW : 0u);
-						so.gfirst[pos] = vdjx_inst_mirror(s_first[i], ob, rl, k);
+						so.gfirst[pos] = vdjx_inst_mirror(s_first[i], ob, rl, k);      // A gated instance of R, not its first: after the prune gfirst is read by
+						                                                                // ONE place, the VDJX_SYNC_DEBUG print of an unseen survivor (recount_status_check) -- a place to look, not a result
 					}
 				}
 			}
