@@ -491,6 +491,10 @@ def main():
                          "(60 V germlines shared by thousands of clones): 21 k contig candidates at 1 M pairs, 699 k at 2 M, and at "
                          "10 M pairs it does not finish in an hour on 8 cores (DESIGN.md §5)")
     ap.add_argument("--parity-sample", type=int, default=20000, help="pairs of the parity gate (SURVEY §8d)")
+    ap.add_argument("--no-two-in-flight", action="store_true",
+                    help="N=1: skip the leg that runs, after the timed region, the same steps again with TWO batches in flight -- a second context (own stream, workspaces, anchor sets) and a "
+                         "second host thread, the steps dealt alternately: what the host waits and kernel tails of one step leave idle is filled by the other "
+                         "(reported as value_two_in_flight; never `value`)")
     ap.add_argument("--no-index-leg", action="store_true", help="skip value_with_read_index (profiles/prof_step.sh: the process then ends with the timed steps)")
     args = ap.parse_args()
     if args.gpus == 8 and not args.no_config4:
@@ -974,6 +978,63 @@ def main():
                               "waited for, then the step (rounds 1-5)"}
         wall.clear()
         wall.update(wall_keep)
+    # ---- two batches in flight (never `value`): how much of the step is the device waiting for the host and for kernel tails
+    two = None
+    if world == 1 and engine is None and not args.no_two_in_flight and not args.no_index_leg:
+        import threading
+        cx2 = api.Context(local_rank, pinned_results=True)
+        cx2.anchor_sets_load(vc, jc)
+        cx2.vregion_load(v_lines, 15)
+        wp = {id(ctx): W[0]["wins_packed"], id(cx2): cx2.pin_strings(W[0]["wins"], "windows")}
+        cfix = {id(ctx): my_contigs_packed, id(cx2): (cx2.pin_strings(my_contigs, "contigs") if my_contigs else None)}
+        p_index2 = cx2.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
+        cx2.read_index_build_device(p_index2, ri_dev[0].data_ptr(), ri_dev[1].data_ptr(), ri_dev[2].data_ptr(), ri_dev[3].data_ptr(), pool.n_pairs)
+        res2 = {}
+
+        def mini_step(cx):
+            p_ = cx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
+            g_ = cx.kmer_build(p_, args.k, args.mf, args.mq, async_export=True)
+            cx.root_score_graph(g_, args.mrs, 0, 1, wait=False)
+            valid_, np_ = cx.window_score(wp[id(cx)], args.ins)
+            cpk_ = cfix[id(cx)] if my_contigs is not None else cx.pin_rows_take(W[0]["wins_rows"], np.flatnonzero(valid_), "contigs", 51, 360)
+            offs_, pairs_ = cx.map_emit(cpk_ if cpk_ is not None else (b"", 0, 0), async_copy=True)
+            cx.root_score_wait()
+            g_.wait()
+            res2[id(cx)] = (g_.n, int(valid_.sum()), int(pairs_.shape[0]))
+            g_.free()
+            p_.free()
+
+        def worker(cx, n_):
+            for _ in range(n_):
+                mini_step(cx)
+            cx.map_emit_wait()
+        for cx in (ctx, cx2):
+            mini_step(cx)           # (first calls of the second context: allocations)
+            cx.map_emit_wait()
+        n_two = max(2, args.steps // 2 * 2)
+        barrier()
+        t1 = time.perf_counter()
+        worker(ctx, n_two)
+        barrier()
+        dt_one = time.perf_counter() - t1
+        ths = [threading.Thread(target=worker, args=(cx, n_two // 2)) for cx in (ctx, cx2)]
+        barrier()
+        t1 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        barrier()
+        dt_two = time.perf_counter() - t1
+        same = res2[id(ctx)] == res2[id(cx2)] == (state["nodes"], state["valid"], state["mapped_this_rank"])
+        two = {"value": round(args.pairs * n_two / dt_two / 1e6, 4), "unit": "M paired-reads/s", "ms_per_step": round(dt_two / n_two * 1e3, 3), "steps": n_two,
+               "one_in_flight_same_loop": {"value": round(args.pairs * n_two / dt_one / 1e6, 4), "ms_per_step": round(dt_one / n_two * 1e3, 3)},
+               "results_equal_the_timed_steps": bool(same),
+               "note": "two contexts on the one device (own streams, workspaces, anchor sets, read index), two host threads, the steps dealt alternately: the "
+                       "device's idle time inside one step -- host waits for four sizes, kernel tails -- is filled by the other batch.  Not `value`: a step "
+                       "of `value` is one batch alone on the device"}
+        p_index2.free()
+        cx2.close()
     del ri_dev
     laps = None
     if os.environ.get("VDJX_LAPS"):          # (diagnostic: host-side microseconds per step inside the scorer calls, vdjx_common.h vdjx_laps)
@@ -1145,7 +1206,7 @@ def main():
                    "scorer_inputs": scorer_src},
         "roofline": roof, "roofline_by_kernel": by_kernel, "cpu_baseline": cpu, "cpu_baseline_port_legs": cpu_port_legs,
         "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
-        "value_end_to_end": e2e, "value_with_read_index": with_index, "first_step_ms": round(first_step_ms, 3) if first_step_ms else None, "first_step_phases_ms": first_step_phases,
+        "value_end_to_end": e2e, "value_with_read_index": with_index, "value_two_in_flight": two, "first_step_ms": round(first_step_ms, 3) if first_step_ms else None, "first_step_phases_ms": first_step_phases,
         "cli_end_to_end": cli_e2e, "cli_at_size": cli_size,
         "kernels_ms_per_step": kern_ms, "kernels_sum_ms_per_step": round(sum(kern_ms.values()), 3),
         "device_busy_frac": round(sum(kern_ms.values()) / prof_ms_step, 4) if prof_ms_step else None,
