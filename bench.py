@@ -1035,6 +1035,84 @@ def main():
                        "of `value` is one batch alone on the device"}
         p_index2.free()
         cx2.close()
+    if world == 1 and engine is not None and not args.no_two_in_flight and not args.no_index_leg:
+        # the same through the C driver (--force-shard / --config4 on one GPU): a second context WITH a second one-rank driver; the chains of
+        # the steps (config4: IGH, IGK, IGL, IGH, ...) dealt alternately to two host threads -- chain i + 1's packing, index and build under
+        # chain i's scorers, which is what two `vdjer --gpus N` runs side by side on the same devices would do
+        import threading
+        from vdjer_amd import mgpu as _mgpu
+        cx2 = api.Context(local_rank, pinned_results=True)
+        drv2 = _mgpu.Driver(cx2, 0, 1, local_rank, "rccl")
+        pairs_ctx = ((ctx, engine), (cx2, drv2))
+        winp = {}
+        for cx, _ in pairs_ctx:
+            cx.anchor_sets_load(vc, jc)
+            cx.vregion_load(v_lines, 15)
+            for w_ in W:
+                winp[(id(cx), w_["ci"])] = w_["wins_packed"] if cx is ctx else cx.pin_strings(w_["wins"], "windows" + ("" if w_["ci"] == 0 else str(w_["ci"])))
+        p_index2 = None
+        if not args.config4:          # (the index is outside the step: the second context needs one of its own over the same pool)
+            p_index2 = cx2.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
+            cx2.read_index_build_device(p_index2, W[0]["ri_dev"][0].data_ptr(), W[0]["ri_dev"][1].data_ptr(), W[0]["ri_dev"][2].data_ptr(), W[0]["ri_dev"][3].data_ptr(), pool.n_pairs)
+        res2 = {}
+
+        def chain_step(cx, drv, w_):
+            tg = "" if w_["ci"] == 0 else str(w_["ci"])
+            if args.config4:
+                cx.anchor_sets_load(w_["vc"], w_["jc"])
+                cx.vregion_load(w_["v_lines"], 15)
+            dp_, ds_ = w_["d_pri"], w_["d_sec"]
+            p_ = cx.pool_load_device(dp_.data_ptr(), dp_.shape[0], ds_.data_ptr(), ds_.shape[0], rl)
+            if args.config4:
+                rd_ = w_["ri_dev"]
+                cx.read_index_build_device(p_, rd_[0].data_ptr(), rd_[1].data_ptr(), rd_[2].data_ptr(), rd_[3].data_ptr(), w_["pool"].n_pairs, wait=False)
+            g_ = drv.kmer_build(p_, args.k, args.mf, args.mq, async_export=True)
+            cx.root_score_graph(g_, args.mrs, 0, 1, wait=False)
+            valid_, np_ = drv.window_score(winp[(id(cx), w_["ci"])], args.ins)
+            drv.yield_step()
+            cpk_ = cx.pin_rows_take(w_["wins_rows"], np.flatnonzero(valid_), "contigs" + tg, 51, 360) if my_contigs is None else (my_contigs_packed if cx is ctx else cfix2)
+            offs_, pairs_ = cx.map_emit(cpk_ if cpk_ is not None else (b"", 0, 0), async_copy=True)
+            cx.root_score_wait()
+            g_.wait()
+            res2[(id(cx), w_["ci"])] = (g_.n, int(valid_.sum()), int(pairs_.shape[0]))
+            g_.free()
+            p_.free()
+        cfix2 = cx2.pin_strings(my_contigs, "contigs") if my_contigs else None
+
+        def worker(cx, drv, items):
+            for w_ in items:
+                chain_step(cx, drv, w_)
+            cx.map_emit_wait()
+        for cx, drv in pairs_ctx:          # (first calls of the second context: allocations)
+            worker(cx, drv, list(W))
+        n_two = max(2, min(args.steps, 10) // 2 * 2)
+        seq = [w_ for _ in range(n_two) for w_ in W]
+        barrier()
+        t1 = time.perf_counter()
+        worker(ctx, engine, seq)
+        barrier()
+        dt_one = time.perf_counter() - t1
+        ths = [threading.Thread(target=worker, args=(cx, drv, seq[i::2])) for i, (cx, drv) in enumerate(pairs_ctx)]
+        barrier()
+        t1 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        barrier()
+        dt_two = time.perf_counter() - t1
+        pc = state.get("per_chain", {})
+        same = all(res2.get((id(cx), w_["ci"])) in (None, (pc[w_["chain"]]["nodes"], pc[w_["chain"]]["valid"], pc[w_["chain"]]["mapped_this_rank"])) for cx, _ in pairs_ctx for w_ in W)
+        tp = args.pairs * len(W) * n_two
+        two = {"value": round(tp / dt_two / 1e6, 4), "unit": "M paired-reads/s", "ms_per_step": round(dt_two / n_two * 1e3, 3), "steps": n_two,
+               "one_in_flight_same_loop": {"value": round(tp / dt_one / 1e6, 4), "ms_per_step": round(dt_one / n_two * 1e3, 3)},
+               "results_equal_the_timed_steps": bool(same),
+               "note": "two contexts on the one device, each with a one-rank driver of its own (libvdjmgpu.so), two host threads, the chains of the steps dealt "
+                       "alternately: chain i + 1's packing, read index and build run under chain i's scorers.  Not `value`"}
+        if p_index2 is not None:
+            p_index2.free()
+        drv2.close()
+        cx2.close()
     del ri_dev
     laps = None
     if os.environ.get("VDJX_LAPS"):          # (diagnostic: host-side microseconds per step inside the scorer calls, vdjx_common.h vdjx_laps)
