@@ -1004,8 +1004,12 @@ def main():
             g_.free()
             p_.free()
 
-        def worker(cx, n_):
+        pix = {id(ctx): p_index, id(cx2): p_index2}
+
+        def worker(cx, n_, with_ix=False):
             for _ in range(n_):
+                if with_ix:       # the pool's read index begun in every step, as in value_with_read_index
+                    cx.read_index_build_device(pix[id(cx)], ri_dev[0].data_ptr(), ri_dev[1].data_ptr(), ri_dev[2].data_ptr(), ri_dev[3].data_ptr(), pool.n_pairs, wait=False)
                 mini_step(cx)
             cx.map_emit_wait()
         for cx in (ctx, cx2):
@@ -1026,9 +1030,20 @@ def main():
             th.join()
         barrier()
         dt_two = time.perf_counter() - t1
+        ths = [threading.Thread(target=worker, args=(cx, n_two // 2, True)) for cx in (ctx, cx2)]
+        barrier()
+        t1 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        barrier()
+        dt_two_ix = time.perf_counter() - t1
         same = res2[id(ctx)] == res2[id(cx2)] == (state["nodes"], state["valid"], state["mapped_this_rank"])
         two = {"value": round(args.pairs * n_two / dt_two / 1e6, 4), "unit": "M paired-reads/s", "ms_per_step": round(dt_two / n_two * 1e3, 3), "steps": n_two,
                "one_in_flight_same_loop": {"value": round(args.pairs * n_two / dt_one / 1e6, 4), "ms_per_step": round(dt_one / n_two * 1e3, 3)},
+               "with_read_index": {"value": round(args.pairs * n_two / dt_two_ix / 1e6, 4), "ms_per_step": round(dt_two_ix / n_two * 1e3, 3),
+                                   "note": "the same with every pool's read index begun in its step (value_with_read_index, two in flight)"},
                "results_equal_the_timed_steps": bool(same),
                "note": "two contexts on the one device (own streams, workspaces, anchor sets, read index), two host threads, the steps dealt alternately: the "
                        "device's idle time inside one step -- host waits for four sizes, kernel tails -- is filled by the other batch.  Not `value`: a step "
