@@ -67,7 +67,16 @@ def make_rep(case: dict):
 def write_inputs(case: dict, d: str):
     """The files a case's command line reads (also used by the tests, which is why it lives beside the digests)."""
     rep = make_rep(case)
-    pool = synth.make_reads_cb(rep, case["pairs"], noise_frac=case["noise"], seed=case["seed"] + 13)
+    dev = "cpu"
+    try:                                    # (the counter-based generator makes the same bytes on either device; on the GPU box 10 M pairs take a second)
+        import torch
+        if torch.cuda.is_available():
+            dev = "cuda:0"
+    except Exception:  # noqa: BLE001
+        pass
+    pool = synth.make_reads_cb(rep, case["pairs"], noise_frac=case["noise"], seed=case["seed"] + 13, device=dev)
+    if hasattr(pool, "to_host"):
+        pool = pool.to_host()
     pool.write_reads_file(os.path.join(d, "reads.txt"))
     synth.write_ref_dir(rep, os.path.join(d, "ref"))
     return rep, pool

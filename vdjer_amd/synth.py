@@ -192,19 +192,59 @@ class ReadPool:
         return [f"r{i}" for i in range(self.n_pairs)]
 
     def write_reads_file(self, path: str) -> None:
-        """Extracted-reads text file (one read per line, registration order): the --in format of vdjer_amd/vdjer."""
+        """Extracted-reads text file (one read per line, registration order): the --in format of vdjer_amd/vdjer.
+        `P|S r<pair id> <read_num> <is_rc> <SEQ> <QUAL>` per FORWARD record (the reverse-complement record of a read is derived by the
+        reader).  Laid out with numpy, a field at a time over all lines (a Python loop over the 20 M reads of a 10 M-pair pool took two
+        minutes; round 6's BASELINE-size tests and bench.py --cli-at-size write such files)."""
         rl = self.rl
-        allrec = np.concatenate([self.primary, self.secondary], axis=0)
         npri = self.primary.shape[0]
         order = np.argsort(self.reg_rank, kind="stable")
-        with open(path, "w") as f:
-            for r in order:
-                if self.reg_rank[r] % 2:      # the rc record of a read: derived by the harness
-                    continue
-                rec = allrec[r]
-                seq = rec[1:1 + rl].tobytes().decode()
-                qual = rec[1 + rl:1 + 2 * rl].tobytes().decode()
-                f.write(f"{'P' if r < npri else 'S'} r{self.pair_id[r]} {self.read_num[r]} {self.is_rc[r]} {seq} {qual}\n")
+        order = order[self.reg_rank[order] % 2 == 0]              # forward records, in registration order
+        n = int(order.shape[0])
+        if n == 0:
+            open(path, "wb").close()
+            return
+        pid = self.pair_id[order].astype(np.int64)
+        nd = np.ones(n, np.int64)                                  # decimal digits of the pair id
+        t = 10
+        while True:
+            more = pid >= t
+            if not more.any():
+                break
+            nd += more
+            t *= 10
+        # P|S ' ' 'r' digits ' ' read_num ' ' is_rc ' ' SEQ ' ' QUAL '\n': a matrix of lines as wide as the longest, the digit field padded
+        # with zero bytes on the right, which are dropped when the lines are laid end to end
+        D = int(nd.max())
+        width = 3 + D + 1 + 1 + 1 + 1 + 1 + rl + 1 + rl + 1
+        chunk = 1_000_000
+        p10 = 10 ** np.arange(D, dtype=np.int64)
+        with open(path, "wb") as f:
+            for a in range(0, n, chunk):
+                b = min(n, a + chunk)
+                rec_idx = order[a:b]
+                in_p = rec_idx < npri
+                M = np.full((b - a, width), ord(" "), np.uint8)
+                M[:, 0] = np.where(in_p, ord("P"), ord("S"))
+                M[:, 2] = ord("r")
+                nd_, pid_ = nd[a:b], pid[a:b]
+                for j in range(D):                                 # digit j from the left (zero byte where the number has fewer)
+                    e = nd_ - 1 - j
+                    dig = (pid_ // p10[np.clip(e, 0, D - 1)]) % 10
+                    M[:, 3 + j] = np.where(e >= 0, ord("0") + dig, 0)
+                c0 = 3 + D + 1
+                M[:, c0] = ord("0") + self.read_num[rec_idx]
+                M[:, c0 + 2] = ord("0") + self.is_rc[rec_idx]
+                recs = np.empty((b - a, 2 * rl + 1), np.uint8)
+                if in_p.any():
+                    recs[in_p] = self.primary[rec_idx[in_p]]
+                if (~in_p).any():
+                    recs[~in_p] = self.secondary[rec_idx[~in_p] - npri]
+                M[:, c0 + 4:c0 + 4 + rl] = recs[:, 1:1 + rl]
+                M[:, c0 + 5 + rl:c0 + 5 + 2 * rl] = recs[:, 1 + rl:1 + 2 * rl]
+                M[:, width - 1] = ord("\n")
+                flat = M.reshape(-1)
+                f.write(flat[flat != 0].tobytes())
 
 
 _COMP = np.array([3, 2, 1, 0], dtype=np.uint8)   # over ACGT indices
