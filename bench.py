@@ -87,7 +87,7 @@ def survivor_bytes(ns: int, k: int, tmask_slots: int | None = None) -> dict:
 
 def scorer_bytes(stats: dict, n_windows: int, n_contigs: int, k: int, rl: int = 50, wlen: int = 486, clen: int = 360) -> dict:
     """The scorers' jobs (not proportional to pairs), priced on what each kernel must read and write in THIS design:
-    classification: (len-rl) offsets per string x (one 32-B index slot in + one 16-B image entry out);
+    classification: (len-rl) offsets per string x (one index slot in -- 32 B, or 64 B for an index over couples -- + one 16-B image entry out);
     window mapper: the image (16 B per offset) + one 8-B index entry per DISTINCT read-1 entry of the classes met (identical read
     pairs are one weighted entry; SURVEY 8d's "8 B per matched read instance" prices the reference's per-instance walk, 2.5 times
     as many) + 8 B per list entry out;  coverage: the list in twice;  pair emission: image + 8 B per hit + 24 B per mapped pair out,
@@ -95,7 +95,8 @@ def scorer_bytes(stats: dict, n_windows: int, n_contigs: int, k: int, rl: int = 
     nw, nc = n_windows * (wlen - rl), n_contigs * (clen - rl)
     return {"k_part_items": 16 * stats.get("recount_items", 0),          # every run item (8 bytes) in and out
             "k_recount": 8 * stats.get("recount_items", 0),
-            "k_map_classify": (nw + nc) * 48,
+            # (an index over couples keeps one 64-byte slot per pair {sequence, reverse complement}: k_ri_tab_canon; else 32-byte slots)
+            "k_map_classify": (nw + nc) * ((64 if stats.get("read_index_sym") else 32) + 16),
             # the grouped mapper reads every image three times (numbering, counting, listing the occurrences), one 8-B entry per
             # DISTINCT entry of a GROUP's classes (a class shared by the group's windows is streamed once), and writes the lists;
             # k_window_pairs only looks at the flags of the windows the groups have done (none are left on this workload)
@@ -1134,7 +1135,7 @@ def main():
         names = ("plan_issue", "plan_wait", "ws_cover_wait", "me_key", "me_plan", "me_kernel_wait", "me_second_call", "me_prev_copy_wait", "me_copy_issue")
         laps = {n_: round(ctx.stat("us_" + n_) / (args.warmup + args.steps), 1) for n_ in names}
     stats = {n_: ctx.stat(n_) for n_ in ("window_hits", "window_hits_max", "window_hits_distinct", "window_pairs", "window_work_items", "map_hits", "root_dp_items", "recount_items", "recount_instances", "gated_instances",
-                                             "pool_symmetric", "kmer_build_sym", "kmer_build_sym_walk", "kmer_build_sym_walk_retries", "kmer_build_shadows")}
+                                             "pool_symmetric", "kmer_build_sym", "kmer_build_sym_walk", "kmer_build_sym_walk_retries", "kmer_build_shadows", "read_index_sym")}
     stats["mapped_pairs"] = int(state["last"]["pairs"].shape[0]) if state.get("last") else 0
     stats["window_pairs_entries"] = ctx.stat("window_pairs_entries")
     for n_ in ("group_hits_distinct", "group_overflows", "group_classes", "group_queued", "group_clocks_sum", "group_clocks_max"):      # k_group_pairs: what the groups of windows shared
