@@ -753,6 +753,42 @@ def test_read_index_begun_beside_the_kmer_build(rl):
     c.close()
 
 
+def test_read_index_begun_many_times_every_way_it_can_end():
+    """300 begun index builds in one context over three pools: ended by _end after a k-mer build (the gate opened by the build), by _end
+    at once (the join opens the gate), by the first scorer call after a build, and by the first scorer call with no build at all --
+    no deadlock, and every time the window verdicts and pair counts of the first build of that pool"""
+    from vdjer_amd import api, synth
+    c = api.Context(0)
+    rep = synth.make_repertoire(4, seed=3)
+    vc = np.array(sorted({synth.seq_to_int(a) for a in rep.v_anchors}), dtype=np.uint32)
+    jc = np.array(sorted({synth.seq_to_int(a) for a in rep.j_anchors}), dtype=np.uint32)
+    c.anchor_sets_load(vc, jc)
+    wins = [w for w in rep.windows() if w]
+    pools = [synth.make_reads(rep, n, noise_frac=0.3, seed=10 + i) for i, n in enumerate((800, 3000, 12000))]
+    ref = {}
+    for it in range(300):
+        pool = pools[it % 3]
+        p = c.pool_load(pool.primary, pool.secondary, pool.rl)
+        c.read_index_build_begin(p, pool.pair_id, pool.read_num, pool.is_rc, pool.reg_rank, pool.n_pairs)
+        mode = it % 4
+        if mode == 0:
+            c.kmer_build(p, 35, 3, 90, export=False)
+            c.read_index_wait()
+        elif mode == 1:
+            c.read_index_wait()
+        elif mode == 2:
+            c.kmer_build(p, 35, 3, 90, export=False)
+        valid, npairs = c.window_score(wins, 175)
+        if it % 3 in ref:
+            np.testing.assert_array_equal(ref[it % 3][0], valid, err_msg=str(it))
+            np.testing.assert_array_equal(ref[it % 3][1], npairs, err_msg=str(it))
+        else:
+            ref[it % 3] = (valid.copy(), npairs.copy())
+        p.free()
+    c.close()
+    assert sum(int(r[1].sum()) for r in ref.values()) > 1000
+
+
 def test_read_index_table_survives_many_builds_and_changes_of_kind(monkeypatch):
     """The lookup table of the couples' index is not cleared per build: a slot counts as taken only if its claim word carries the build's
     number (7 bits), and the table is cleared when the numbers are used up (every 127 builds), when the buffer is new, and when the
