@@ -53,6 +53,10 @@ CASES = {
     # every sequencing error in a tail survives and every root enumerates ~800 candidates through it: 100,000 in two minutes
     "cfg2_pv": dict(pairs=10_000_000, clones=2500, seed=20261002, noise=0.3, chain="IGH", ins=175, private_v=True, private_j=True, zipf_s=0.25,
                     flags=["--k", "35", "--mf", "3", "--mq", "90", "--mrs", "30"], attempts=4, parallel=2),
+    # the same pool in the sensitive mode of BASELINE.json configs[3] (--mrs 20 so that roots can pass): --mf 2 lets a clone's
+    # sequencing errors survive (tens of error branches per clone), so the traversal enumerates and maps many more windows than cfg2_pv
+    "cfg3_pv": dict(pairs=10_000_000, clones=2500, seed=20261002, noise=0.3, chain="IGH", ins=175, private_v=True, private_j=True, zipf_s=0.25,
+                    flags=["--k", "25", "--mf", "2", "--mq", "60", "--mcs", "-5.5", "--mrs", "20"], attempts=4, parallel=2),
     "mid_k25_mrs30": dict(pairs=200_000, clones=400, seed=20261002, noise=0.3, chain="IGH", ins=175,
                           flags=["--k", "25", "--mf", "2", "--mq", "60", "--mcs", "-5.5"]),
 }
