@@ -56,7 +56,7 @@ CASES = {
     # the same pool in the sensitive mode of BASELINE.json configs[3] (--mrs 20 so that roots can pass): --mf 2 lets a clone's
     # sequencing errors survive (tens of error branches per clone), so the traversal enumerates and maps many more windows than cfg2_pv
     "cfg3_pv": dict(pairs=10_000_000, clones=2500, seed=20261002, noise=0.3, chain="IGH", ins=175, private_v=True, private_j=True, zipf_s=0.25,
-                    flags=["--k", "25", "--mf", "2", "--mq", "60", "--mcs", "-5.5", "--mrs", "20"], attempts=4, parallel=2),
+                    flags=["--k", "25", "--mf", "2", "--mq", "60", "--mcs", "-5.5", "--mrs", "20"], attempts=3, parallel=1),
     "mid_k25_mrs30": dict(pairs=200_000, clones=400, seed=20261002, noise=0.3, chain="IGH", ins=175,
                           flags=["--k", "25", "--mf", "2", "--mq", "60", "--mcs", "-5.5"]),
 }
@@ -103,52 +103,84 @@ def digest(path: str) -> dict:
     return {"sha256": h.hexdigest(), "bytes": n, "lines": lines}
 
 
-def one_case(name: str, case: dict, attempts: int = 8, parallel: int = 4) -> dict:
-    attempts, parallel = int(case.get("attempts", attempts)), int(case.get("parallel", parallel))
-    work = tempfile.mkdtemp(prefix=f"vdjx_{name}_")
-    t0 = time.time()
-    write_inputs(case, work)
-    print(f"{name}: inputs in {time.time() - t0:.0f}s", flush=True)
-    complete, tried = [], 0
-    while tried < attempts and len(complete) < 2:
-        procs = []
-        for _ in range(min(parallel, attempts - tried)):
-            wd = os.path.join(work, f"run{tried}")
-            os.makedirs(wd)
-            os.symlink(os.path.join(work, "reads.txt"), os.path.join(wd, "reads.txt"))
-            os.symlink(os.path.join(work, "ref"), os.path.join(wd, "ref"))
-            pr = subprocess.Popen([REF, "run"] + argv_of(case), cwd=wd, stdout=open(os.path.join(wd, "out.sam"), "wb"),
-                                  stderr=open(os.path.join(wd, "err.txt"), "wb"), env=dict(os.environ, VDJX_REF_ROOT_LOG="roots.log"))
-            procs.append((wd, pr))
-            tried += 1
-        for wd, pr in procs:
-            pr.wait()
-            err = open(os.path.join(wd, "err.txt"), errors="replace").read()
-            m1, m2 = re.search(r"num root nodes: (\d+)", err), re.search(r"HARNESS_ROOTS_SCORED\t(\d+)", err)
-            if not (m1 and m2 and "FINIS" in err):
-                print(f"{name}: a run did not finish: {err[-300:]}", flush=True)
-                continue
-            ok = int(m1.group(1)) == int(m2.group(1))
-            print(f"{name}: run {os.path.basename(wd)} scored {m2.group(1)} of {m1.group(1)} roots{'' if ok else ' (incomplete: dropped)'}  [{time.time() - t0:.0f}s]", flush=True)
-            if ok:
-                complete.append((wd, int(m1.group(1))))
-    assert len(complete) >= 2, f"{name}: fewer than two complete runs in {tried} attempts"
+def run_once(case: dict, work: str, wd: str):
+    """one --t 1 run of the compiled reference in wd (inputs symlinked from work); -> the process"""
+    os.makedirs(wd)
+    os.symlink(os.path.join(work, "reads.txt"), os.path.join(wd, "reads.txt"))
+    os.symlink(os.path.join(work, "ref"), os.path.join(wd, "ref"))
+    return subprocess.Popen([REF, "run"] + argv_of(case), cwd=wd, stdout=open(os.path.join(wd, "out.sam"), "wb"),
+                            stderr=open(os.path.join(wd, "err.txt"), "wb"), env=dict(os.environ, VDJX_REF_ROOT_LOG="roots.log"))
+
+
+def run_is_complete(name: str, wd: str):
+    """the complete-run rule: the reference reported as many roots as the harness saw scored -> (complete, roots), or None if it did not finish"""
+    err = open(os.path.join(wd, "err.txt"), errors="replace").read()
+    m1, m2 = re.search(r"num root nodes: (\d+)", err), re.search(r"HARNESS_ROOTS_SCORED\t(\d+)", err)
+    if not (m1 and m2 and "FINIS" in err):
+        print(f"{name}: a run did not finish: {err[-300:]}", flush=True)
+        return None
+    return int(m1.group(1)) == int(m2.group(1)), int(m1.group(1)), int(m2.group(1))
+
+
+def collect(name: str, case: dict, run_dirs, wall_s: float) -> dict:
+    """run directories of finished runs -> the case's entry: at least two complete runs, ALL complete runs byte-identical"""
+    complete = []
+    for wd in run_dirs:
+        r = run_is_complete(name, wd)
+        if r is None:
+            continue
+        ok, nroots, nscored = r
+        print(f"{name}: run {os.path.basename(wd)} scored {nscored} of {nroots} roots{'' if ok else ' (incomplete: dropped)'}", flush=True)
+        if ok:
+            complete.append((wd, nroots))
+    assert len(complete) >= 2, f"{name}: fewer than two complete runs among {len(list(run_dirs))}"
     dg = [{f: digest(os.path.join(wd, f)) for f in ("vdj_contigs.fa", "out.sam", "vdjer.dot", "roots.log")} for wd, _ in complete]
     assert all(d == dg[0] for d in dg), f"{name}: complete runs disagree"
     wd, nroots = complete[0]
     log = [l.split("\t") for l in open(os.path.join(wd, "roots.log")).read().splitlines()]
     fa = open(os.path.join(wd, "vdj_contigs.fa")).read()
     res = {k_: v_ for k_, v_ in case.items() if k_ not in ("attempts", "parallel")}
-    res.update(roots=nroots, roots_accepted=sum(int(v) for _, v in log), contigs=fa.count(">"), complete_runs=len(complete), runs=tried,
+    res.update(roots=nroots, roots_accepted=sum(int(v) for _, v in log), contigs=fa.count(">"), complete_runs=len(complete), runs=len(list(run_dirs)),
                fasta=dg[0]["vdj_contigs.fa"], sam=dg[0]["out.sam"], dot=dg[0]["vdjer.dot"], root_log=dg[0]["roots.log"],
                root_log_format="<root k-mer>\\t<score_seq verdict>\\n per root in dispatch order (A2:1305-1318 at --t 1)",
-               reference_wall_s=round((time.time() - t0) / max(1, (tried + parallel - 1) // parallel)))
+               reference_wall_s=round(wall_s))
+    return res
+
+
+def one_case(name: str, case: dict, attempts: int = 8, parallel: int = 4) -> dict:
+    attempts, parallel = int(case.get("attempts", attempts)), int(case.get("parallel", parallel))
+    work = tempfile.mkdtemp(prefix=f"vdjx_{name}_")
+    t0 = time.time()
+    write_inputs(case, work)
+    print(f"{name}: inputs in {time.time() - t0:.0f}s", flush=True)
+    dirs, tried, n_complete = [], 0, 0
+    while tried < attempts and n_complete < 2:
+        procs = []
+        for _ in range(min(parallel, attempts - tried)):
+            wd = os.path.join(work, f"run{tried}")
+            procs.append((wd, run_once(case, work, wd)))
+            tried += 1
+        for wd, pr in procs:
+            pr.wait()
+            dirs.append(wd)
+            r = run_is_complete(name, wd)
+            n_complete += bool(r and r[0])
+    res = collect(name, case, dirs, (time.time() - t0) / max(1, (tried + parallel - 1) // parallel))
     subprocess.run(["rm", "-rf", work])
     return res
 
 
 def main():
     assert os.path.exists(REF), "build the reference first: make -C oracle ref"
+    if len(sys.argv) >= 4 and sys.argv[1] == "--collect":
+        # runs started by hand, one at a time (a 10 M-pair run at k = 25 peaks at 33 GB: two at once do not fit this container's 62 GB):
+        #   make_golden_midscale.py --collect <name> <wall seconds of one run> <run dir> <run dir> ...
+        name, wall = sys.argv[2], float(sys.argv[3])
+        out = json.load(open(OUT)) if os.path.exists(OUT) else {"cases": {}}
+        out["cases"][name] = collect(name, CASES[name], sys.argv[4:], wall)
+        json.dump(out, open(OUT, "w"), indent=1, sort_keys=True)
+        print(json.dumps(out["cases"][name]), flush=True)
+        return
     names = sys.argv[1:] or list(CASES)
     out = json.load(open(OUT)) if os.path.exists(OUT) else {"cases": {}}
     out["note"] = ("digests of complete --t 1 runs of the compiled reference; inputs regenerate from vdjer_amd/synth.py "
