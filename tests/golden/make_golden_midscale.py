@@ -57,6 +57,12 @@ CASES = {
     # sequencing errors survive (tens of error branches per clone), so the traversal enumerates and maps many more windows than cfg2_pv
     "cfg3_pv": dict(pairs=10_000_000, clones=2500, seed=20261002, noise=0.3, chain="IGH", ins=175, private_v=True, private_j=True, zipf_s=0.25,
                     flags=["--k", "25", "--mf", "2", "--mq", "60", "--mcs", "-5.5", "--mrs", "20"], attempts=3, parallel=1),
+    # BASELINE.json configs[4]'s other two chains at its per-GPU size (12.5 M pairs): the light-chain presets of set_chain_info (params.c:20-31:
+    # J residue F, CDR3 window 0-60), private repertoire as above
+    "cfg4_igk_pv": dict(pairs=12_500_000, clones=3125, seed=20261002, noise=0.3, chain="IGK", ins=175, private_v=True, private_j=True, zipf_s=0.25,
+                        flags=["--k", "35", "--mf", "3", "--mq", "90", "--mrs", "30"], attempts=4, parallel=2),
+    "cfg4_igl_pv": dict(pairs=12_500_000, clones=3125, seed=20261003, noise=0.3, chain="IGL", ins=175, private_v=True, private_j=True, zipf_s=0.25,
+                        flags=["--k", "35", "--mf", "3", "--mq", "90", "--mrs", "30"], attempts=4, parallel=2),
     "mid_k25_mrs30": dict(pairs=200_000, clones=400, seed=20261002, noise=0.3, chain="IGH", ins=175,
                           flags=["--k", "25", "--mf", "2", "--mq", "60", "--mcs", "-5.5"]),
 }
@@ -65,7 +71,7 @@ CASES = {
 def make_rep(case: dict):
     """the case's repertoire (private_v / zipf_s: the second parameterisation of the generator, see cfg2_pv)"""
     return synth.make_repertoire(case["clones"], seed=case["seed"], private_v=bool(case.get("private_v", False)), private_j=bool(case.get("private_j", False)),
-                                 zipf_s=float(case.get("zipf_s", 1.1)))
+                                 zipf_s=float(case.get("zipf_s", 1.1)), chain=case.get("chain", "IGH"))
 
 
 def write_inputs(case: dict, d: str):

@@ -121,11 +121,13 @@ def test_vdjer_cli_gpus_n_ranks_share_one_device(tag, gpus, sam_pairs, tmp_path)
 @pytest.mark.parametrize("name,gpus,knobs", [("mid_400k", 1, "suite"), ("mid_400k", 1, "shipped"), ("mid_400k", 3, "suite"), ("mid_k25", 1, "suite"), ("mid_k25", 1, "shipped"),
                                              ("mid_k25", 2, "shipped"), ("mid_cfg1", 1, "shipped"), ("mid_cfg1", 4, "suite"), ("mid_k25_mrs30", 1, "shipped"), ("mid_k25_mrs30", 2, "suite"),
                                              ("cfg2_pv", 1, "shipped"), ("cfg2_pv", 4, "shipped"),
-                                             ("cfg3_pv", 1, "shipped"), ("cfg3_pv", 3, "shipped")])
+                                             ("cfg3_pv", 1, "shipped"), ("cfg3_pv", 3, "shipped"),
+                                             ("cfg4_igk_pv", 1, "shipped"), ("cfg4_igl_pv", 4, "shipped")])
 def test_vdjer_cli_midscale_vs_reference_digests(name, gpus, knobs, tmp_path):
     """cfg2_pv: BASELINE.json configs[2]'s SIZE -- 10 M pairs, 2,500 clones over private V and J segments (the repertoire on which the reference's
     serial traversal ends: 22 minutes of the reference at --t 1, 7,230 roots, 3,014 accepted, 2,172 contigs, 3.25 M SAM lines = 635 MB) -- `vdjer`
     and `vdjer --gpus 4` byte for byte (VERDICT r5 missing #4: "FASTA and SAM bit-exact" at the size the metric is quoted on).
+    cfg4_igk_pv / cfg4_igl_pv: BASELINE.json configs[4]'s other two chains (--chain IGK / IGL) at its per-GPU size, 12.5 M pairs.
     cfg3_pv: the same pool in the sensitive mode of BASELINE.json configs[3] (--k 25 --mf 2 --mq 60 --mcs -5.5, --mrs 20 so that roots can pass).
     End to end at MID scale (tests/golden/midscale.json: complete --t 1 runs of the compiled reference on 200 k - 1 M pairs, hundreds
     to thousands of clones: thousands of roots, hundreds of candidate windows, tens of contigs, 10^5-10^6 SAM lines; mid_cfg1 is
