@@ -10,7 +10,7 @@ Default workload = BASELINE.json configs[2], the configuration the north-star ta
 synthetic pairs (20,000 clones, Zipf 1.1, 30 % noise, k=35 mf=3 mq=90, --ins 175) on one GPU.
 `--pairs 1000000` is configs[1]; `--pairs 10000000 --k 25 --mf 2 --mq 60 --mrs 20` is configs[3].
 With N GPUs every rank holds its own pool of that size and the k-mer partial aggregates are exchanged by
-hash prefix (vdjer_amd/shard.py): weak scaling.
+hash prefix through the C driver of `vdjer --gpus N` (vdjer_amd/libvdjmgpu.so, vdjer_amd/mgpu.py): weak scaling.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant HBM-streaming kernel of the step (the longest
 kernel of the k-mer build; HIP events on the library's stream) against HBM peak, `roofline_by_kernel` every
@@ -600,7 +600,7 @@ def main():
     # holds the index of the WHOLE pool (replicate the index, shard the windows: no communication).
     t_ix = time.perf_counter()
     # every rank indexes ITS pairs only (the pool is split by pair: both mates of a pair on one rank); windows are mapped by
-    # every rank against its own reads and the pair lists meet on the window's owner (vdjer_amd/shard.py:window_score)
+    # every rank against its own reads and the pair lists meet on the window's owner (vdjx_mgpu.c:do_window_score)
     p_index = ctx.pool_load_device(d_pri.data_ptr(), d_pri.shape[0], d_sec.data_ptr(), d_sec.shape[0], rl)
     # the per-record read info {pair, read_num, is_rc, registration rank} resident in HBM like the pools; the index itself is
     # built on the device (vdjx_rindex.hip): timed here, reported beside `value` (row a-8's index, quick_map3.c:126-149)
